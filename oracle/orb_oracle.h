@@ -1,0 +1,37 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY.  C API of the CPU restatement (ctypes-loadable liboracle.so).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library. */
+#pragma once
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float x, y, size, angle, response; int octave, class_id; } orc_keypoint; /* cv::KeyPoint, 28 B */
+typedef struct orc_extractor orc_extractor;
+
+orc_extractor* orc_extractor_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+void orc_extractor_destroy(orc_extractor*);
+/* ORBextractor::operator() — returns monoIndex, -1 for an empty image, -2 if cap is too small */
+int orc_extract(orc_extractor*, const uint8_t* img, int w, int h, int stride, int lap0, int lap1,
+                orc_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+void orc_extractor_tables(orc_extractor*, float* scale, float* invScale, float* sigma2, float* invSigma2,
+                          int* featPerLevel, int* umax16);
+int orc_level_size(orc_extractor*, int lvl, int* w, int* h);
+int orc_level_image(orc_extractor*, int lvl, uint8_t* out_padded);
+int orc_level_blurred(orc_extractor*, int lvl, uint8_t* out);
+int orc_level_candidates(orc_extractor*, int lvl, orc_keypoint* out, int cap);
+int orc_level_keypoints(orc_extractor*, int lvl, orc_keypoint* out, int cap);
+
+void orc_resize_linear(const uint8_t* src, int sw, int sh, int sstep, uint8_t* dst, int dw, int dh, int dstep);
+void orc_gaussian7(const uint8_t* src, int w, int h, int sstep, uint8_t* dst, int dstep);
+void orc_border101(uint8_t* buf, int w, int h, int step, int border);
+int orc_fast(const uint8_t* img, int w, int h, int step, int threshold, int nms, orc_keypoint* out, int cap);
+int orc_distribute(const orc_keypoint* in, int n, int minX, int maxX, int minY, int maxY, int N,
+                   orc_keypoint* out, int cap);
+float orc_fast_atan2(float y, float x);
+float orc_cosf(float x);
+float orc_sinf(float x);
+
+#ifdef __cplusplus
+}
+#endif

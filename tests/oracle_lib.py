@@ -1,0 +1,121 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE (the checker), never the product path."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.path.join(ORACLE_DIR, "liboracle.so")
+    try:
+        _lib = C.CDLL(path)
+    except OSError:
+        build()
+        _lib = C.CDLL(path)
+    L = _lib
+    u8p, kpp, ip, fp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+    L.orc_extractor_create.restype = C.c_void_p
+    L.orc_extractor_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+    L.orc_extractor_destroy.argtypes = [C.c_void_p]
+    L.orc_extract.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, kpp, u8p, C.c_int, ip]
+    L.orc_extractor_tables.argtypes = [C.c_void_p, fp, fp, fp, fp, ip, ip]
+    L.orc_level_size.argtypes = [C.c_void_p, C.c_int, ip, ip]
+    L.orc_level_image.argtypes = [C.c_void_p, C.c_int, u8p]
+    L.orc_level_blurred.argtypes = [C.c_void_p, C.c_int, u8p]
+    L.orc_level_candidates.argtypes = [C.c_void_p, C.c_int, kpp, C.c_int]
+    L.orc_level_keypoints.argtypes = [C.c_void_p, C.c_int, kpp, C.c_int]
+    L.orc_resize_linear.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int, C.c_int, C.c_int]
+    L.orc_gaussian7.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
+    L.orc_border101.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_fast.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, kpp, C.c_int]
+    L.orc_distribute.argtypes = [kpp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, kpp, C.c_int]
+    L.orc_fast_atan2.restype = C.c_float
+    L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+    L.orc_cosf.restype = C.c_float
+    L.orc_cosf.argtypes = [C.c_float]
+    L.orc_sinf.restype = C.c_float
+    L.orc_sinf.argtypes = [C.c_float]
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleExtractor:
+    """Mirror of ORB_SLAM3::ORBextractor (include/ORBextractor.h:44-105) over the CPU restatement."""
+
+    def __init__(self, nfeatures=1200, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7):
+        self.L = lib()
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+        self.h = self.L.orc_extractor_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_extractor_destroy(self.h)
+            self.h = None
+
+    def tables(self):
+        n = self.nlevels
+        sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        fpl = np.zeros(n, np.int32)
+        umax = np.zeros(16, np.int32)
+        self.L.orc_extractor_tables(self.h, _p(sc), _p(isc), _p(s2), _p(is2), _p(fpl), _p(umax))
+        return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2, feat_per_level=fpl, umax=umax)
+
+    def __call__(self, img, lap=(0, 0)):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        cap = self.nfeatures + 16 * self.nlevels
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        mono = self.L.orc_extract(self.h, _p(img), w, h, w, lap[0], lap[1], _p(kps), _p(desc), cap, C.byref(n))
+        assert mono != -2
+        return mono, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def level_size(self, lvl):
+        w, h = C.c_int(), C.c_int()
+        self.L.orc_level_size(self.h, lvl, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def level_image(self, lvl):
+        w, h = self.level_size(lvl)
+        out = np.zeros((h + 38, w + 38), np.uint8)
+        self.L.orc_level_image(self.h, lvl, _p(out))
+        return out
+
+    def level_blurred(self, lvl):
+        w, h = self.level_size(lvl)
+        out = np.zeros((h, w), np.uint8)
+        r = self.L.orc_level_blurred(self.h, lvl, _p(out))
+        return out if r == 1 else None
+
+    def level_candidates(self, lvl):
+        n = self.L.orc_level_candidates(self.h, lvl, None, 0)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        self.L.orc_level_candidates(self.h, lvl, _p(out), n)
+        return out[:n]
+
+    def level_keypoints(self, lvl):
+        n = self.L.orc_level_keypoints(self.h, lvl, None, 0)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        self.L.orc_level_keypoints(self.h, lvl, _p(out), n)
+        return out[:n]
