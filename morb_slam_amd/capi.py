@@ -1,0 +1,77 @@
+"""ctypes binding of libmorb_hip.so (include/morb_hip.h).  There is NO CPU fallback: importing this module
+without the built library, or calling into it without a GPU, raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "libmorb_hip.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+MORB_OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_EMPTY = 0, -1, -2, -3, -4, -5
+
+
+class MorbError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmorb_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback for the product path)")
+        # torch (device memory / streams / torch.distributed plumbing) bundles its own libamdhip64.so.7; load it
+        # first so libmorb_hip.so binds to the SAME HIP runtime instead of pulling a second one into the process
+        # (two runtimes in one process leave the later one without a GPU).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(LIB_PATH)
+        vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+        L.morb_last_error.restype = C.c_char_p
+        L.morb_device_count.restype = i
+        L.morb_extractor_create.argtypes = [C.POINTER(vp), i, f, i, i, i, i]
+        L.morb_extractor_destroy.argtypes = [vp]
+        L.morb_extractor_destroy.restype = None
+        L.morb_extractor_levels.argtypes = [vp]
+        L.morb_extractor_scale_factor.argtypes = [vp]
+        L.morb_extractor_scale_factor.restype = f
+        L.morb_extractor_tables.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.morb_extractor_max_keypoints.argtypes = [vp]
+        L.morb_extract.argtypes = [vp, vp, i, i, i, i, i, vp, vp, i, C.POINTER(i)]
+        L.morb_extract_batch.argtypes = [vp, vp, i, i, i, i, sz, vp, vp, vp, i, vp, vp, vp]
+        L.morb_extractor_pyramid_level.argtypes = [vp, i, i, C.POINTER(vp), C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+        L.morb_extractor_pyramid_level_host.argtypes = [vp, i, i, vp]
+        L.morb_extractor_blurred_level_host.argtypes = [vp, i, i, vp]
+        L.morb_extractor_level_candidates_host.argtypes = [vp, i, i, vp, i, C.POINTER(i)]
+        L.morb_extractor_level_keypoints_host.argtypes = [vp, i, i, vp, i, C.POINTER(i)]
+        L.morb_extractor_set_profiling.argtypes = [vp, i]
+        L.morb_extractor_stage_ms.argtypes = [vp, vp]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise MorbError(rc, lib().morb_last_error().decode(errors="replace"))
+    return rc
+
+
+def ptr(a):
+    """Host numpy array or torch tensor (host or device) -> void*."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(a.data_ptr())

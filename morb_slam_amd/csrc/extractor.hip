@@ -1,0 +1,1003 @@
+// ORB extractor for MI355X (gfx950): batched, device-resident implementation of
+// ORB_SLAM3::ORBextractor::operator() (reference src/ORBextractor.cc:1006-1086) behind the C ABI of
+// include/morb_hip.h.  Written for CDNA4: wave64 ballots/popcounts for ordered compaction, LDS tiles for the
+// stencils, one wave per (image, level) for the order-exact quadtree, integer arithmetic bit-identical to the
+// CPU oracle (oracle/).  Built with -ffp-contract=off: the few float expressions (fastAtan2, the rBRIEF
+// rotation, pt *= scale) must round exactly like the reference's separate mul/add.
+//
+// HBM layout (level-major slabs; one batch = nimg images of one size):
+//   pyramid : for level l, image i : (h_l + 38) rows x pstride_l bytes, 19-px BORDER_REFLECT_101 pad included
+//             (= mvImagePyramid[l] with its pad, ORBextractor.cc:1088-1112); pstride_l is a multiple of 64.
+//   blur    : for level l, image i : h_l rows x bstride_l bytes (GaussianBlur 7x7 s=2 of the level, :1049-1050)
+//   cand    : per image, per FAST cell (all levels, flat cell index): cellCap packed keys + a count
+//   sel     : per image, per level: keys chosen by DistributeOctTree, in the reference's list order
+// Kernels per batch: level0 pad-copy, 7 resizes, blur, FAST(+score+NMS+cell fallback), distribute, layout,
+// describe (IC_Angle + rBRIEF + final keypoint records).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "quadtree.h"
+
+namespace morb {
+std::string& last_error() {
+  static thread_local std::string e;
+  return e;
+}
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  last_error() = buf;
+}
+}  // namespace morb
+
+using namespace morb;
+
+namespace {
+
+constexpr int kMaxLevels = 16;
+constexpr int EDGE = 19;        // EDGE_THRESHOLD  ORBextractor.cc:73
+constexpr int HALF_PATCH = 15;  // HALF_PATCH_SIZE :72
+constexpr int PATCH = 31;       // PATCH_SIZE :71
+constexpr int MINB = 16;        // minBorderX/Y = EDGE_THRESHOLD - 3 (:746-747)
+constexpr int kLdsKeys = 3072;  // distribute: key arrays live in LDS up to this many candidates per level
+
+struct LevelGeom {
+  int w, h;
+  int pstride, bstride;
+  unsigned long long pyrOff, pyrImg;    // bytes: slab offset, per-image size
+  unsigned long long blurOff, blurImg;
+  int nCols, nRows, wCell, hCell, cellBase;
+  int maxBorderX, maxBorderY;
+  int quota, nIni;
+  int nodeCap, listCap;
+  int selBase, selCap;                  // per-image offsets into sel[]
+  unsigned long long qtOff, qtImg;      // element offsets into the global key scratch
+  int blurTileBase, blurTilesX, blurTilesY;
+  int xtabOff, ytabOff;                 // offsets (entries) into the resize tables
+  float scale;                          // mvScaleFactor[l]
+  float kpSize;                         // (float)(int)(PATCH_SIZE * mvScaleFactor[l])  (:831)
+};
+
+struct ResizeTab {  // one entry per padded destination column / row
+  short s0, s1, c0, c1;  // source index (clipped), source index + 1 (clipped), fixed-point weights (2048 = 1)
+};
+
+__constant__ int c_pattern[256 * 4] = {
+#include "orb_pattern.inc"
+};
+__constant__ int c_umax[16];
+
+// ---------------------------------------------------------------------------------------------------
+// K1a: level 0 = copyMakeBorder(image, BORDER_REFLECT_101)  (ORBextractor.cc:1108)
+__device__ __forceinline__ int reflect101(int p, int len) {
+  // one reflection is enough for |pad| = 19 < len
+  if (p < 0) p = -p;
+  if (p >= len) p = 2 * (len - 1) - p;
+  return p;
+}
+
+__global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src, int w, int h, int stride,
+                                                size_t pitch, uint8_t* __restrict__ pyr, LevelGeom g) {
+  const int px = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int py = blockIdx.y;
+  const int img = blockIdx.z;
+  if (px >= g.pstride) return;
+  const uint8_t* s = src + (size_t)img * pitch + (size_t)reflect101(py - EDGE, h) * stride;
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int x = px + k - EDGE;
+    if (px + k < w + 2 * EDGE) v |= (uint32_t)s[reflect101(x, w)] << (8 * k);
+  }
+  *reinterpret_cast<uint32_t*>(pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)py * g.pstride + px) = v;
+}
+
+// K1b: level l = resize(level l-1, INTER_LINEAR) + copyMakeBorder(BORDER_REFLECT_101|ISOLATED)
+// (ORBextractor.cc:1101-1104).  Every padded pixel is computed directly from level l-1 through tables that
+// already fold the reflection, so one launch writes interior and pad.
+__global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, LevelGeom gs, LevelGeom gd,
+                                                const ResizeTab* __restrict__ xtab,
+                                                const ResizeTab* __restrict__ ytab) {
+  const int px = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int py = blockIdx.y;
+  const int img = blockIdx.z;
+  if (px >= gd.pstride) return;
+  const ResizeTab ty = ytab[py];
+  const uint8_t* sbase = pyr + gs.pyrOff + (size_t)img * gs.pyrImg + (size_t)EDGE * gs.pstride + EDGE;
+  const uint8_t* r0 = sbase + (size_t)ty.s0 * gs.pstride;
+  const uint8_t* r1 = sbase + (size_t)ty.s1 * gs.pstride;
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (px + k < gd.w + 2 * EDGE) {
+      const ResizeTab tx = xtab[px + k];
+      const int h0 = r0[tx.s0] * tx.c0 + r0[tx.s1] * tx.c1;
+      const int h1 = r1[tx.s0] * tx.c0 + r1[tx.s1] * tx.c1;
+      const int o = ((((int)ty.c0 * (h0 >> 4)) >> 16) + (((int)ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      v |= (uint32_t)(o & 0xFF) << (8 * k);
+    }
+  }
+  *reinterpret_cast<uint32_t*>(pyr + gd.pyrOff + (size_t)img * gd.pyrImg + (size_t)py * gd.pstride + px) = v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K5: GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101), OpenCV fixed-point path: 8.8 kernel
+// {18,34,48,56,48,34,18}, row pass exact, column pass rounded (+0.5) to u8.  The level's own 19-px
+// reflect-101 pad is exactly the border the blur needs, so the tile loads straight from the padded pyramid.
+constexpr int BT_W = 64, BT_H = 16;
+__global__ __launch_bounds__(256) void k_blur(const LevelGeom* __restrict__ geom, int nlevels,
+                                              const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
+  __shared__ uint8_t tin[BT_H + 6][BT_W + 8];
+  __shared__ uint16_t hrow[BT_H + 6][BT_W];
+  int l = 0;
+  while (l + 1 < nlevels && (int)blockIdx.x >= geom[l + 1].blurTileBase) ++l;
+  const LevelGeom g = geom[l];
+  const int t = blockIdx.x - g.blurTileBase;
+  const int x0 = (t % g.blurTilesX) * BT_W, y0 = (t / g.blurTilesX) * BT_H;
+  const int img = blockIdx.y;
+  const uint8_t* base = pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)EDGE * g.pstride + EDGE;
+  for (int i = threadIdx.x; i < (BT_H + 6) * (BT_W + 6); i += 256) {
+    const int r = i / (BT_W + 6), c = i % (BT_W + 6);
+    int gy = y0 + r - 3, gx = x0 + c - 3;
+    gy = gy > g.h + EDGE - 1 ? g.h + EDGE - 1 : gy;  // tile overhang: stay inside the allocation
+    gx = gx > g.w + EDGE - 1 ? g.w + EDGE - 1 : gx;
+    tin[r][c] = base[(ptrdiff_t)gy * g.pstride + gx];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (BT_H + 6) * BT_W; i += 256) {
+    const int r = i / BT_W, c = i % BT_W;
+    const uint8_t* p = &tin[r][c];
+    hrow[r][c] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
+  }
+  __syncthreads();
+  uint8_t* out = blur + g.blurOff + (size_t)img * g.blurImg;
+  for (int i = threadIdx.x; i < BT_H * BT_W; i += 256) {
+    const int r = i / BT_W, c = i % BT_W;
+    const uint32_t acc = 18u * (hrow[r][c] + hrow[r + 6][c]) + 34u * (hrow[r + 1][c] + hrow[r + 5][c]) +
+                         48u * (hrow[r + 2][c] + hrow[r + 4][c]) + 56u * hrow[r + 3][c];
+    if (x0 + c < g.w && y0 + r < g.h) out[(size_t)(y0 + r) * g.bstride + x0 + c] = (uint8_t)((acc + 32768u) >> 16);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2: per-cell FAST-9/16 + cornerScore + 3x3 NMS with the iniThFAST -> minThFAST fallback
+// (ORBextractor.cc:763-820 calling cv::FAST twice).  One workgroup per 35-px cell; the cell window
+// (wCell+6 x hCell+6) sits in LDS; survivors are written in row-major order (ordered ballot compaction) so
+// that concatenating cells in row-major cell order reproduces vToDistributeKeys.
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+// max(A, C): A = max over the 16 circular 9-arcs of min(v - p_k), C likewise for (p_k - v).  A pixel is a
+// FAST-9 corner at threshold t iff this exceeds t, and cv's cornerScore<16> equals it minus 1.
+__device__ __forceinline__ int fast_strength(const uint8_t* __restrict__ p, int pitch) {
+  const int v = p[0];
+  int d[16];
+  d[0] = v - p[3 * pitch];       d[1] = v - p[3 * pitch + 1];   d[2] = v - p[2 * pitch + 2];
+  d[3] = v - p[pitch + 3];       d[4] = v - p[3];               d[5] = v - p[-pitch + 3];
+  d[6] = v - p[-2 * pitch + 2];  d[7] = v - p[-3 * pitch + 1];  d[8] = v - p[-3 * pitch];
+  d[9] = v - p[-3 * pitch - 1];  d[10] = v - p[-2 * pitch - 2]; d[11] = v - p[-pitch - 3];
+  d[12] = v - p[-3];             d[13] = v - p[pitch - 3];      d[14] = v - p[2 * pitch - 2];
+  d[15] = v - p[3 * pitch - 1];
+  int mn3[16], mx3[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    mn3[k] = imin(imin(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+    mx3[k] = imax(imax(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+  }
+  int A = -256, B = 256;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    A = imax(A, imin(imin(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]));
+    B = imin(B, imax(imax(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]));
+  }
+  return imax(A, -B);
+}
+
+__global__ __launch_bounds__(256) void k_fast(const LevelGeom* __restrict__ geom, int nlevels,
+                                              const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
+                                              int* __restrict__ candCnt, int totalCells, int cellCap, int tilePitch,
+                                              int tileRows, int iniTh, int minTh) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  uint8_t* tile = smem;                           // [tileRows][tilePitch]
+  uint8_t* sc = smem + tileRows * tilePitch;      // [tileRows][tilePitch] strength, 0 outside the evaluated area
+  __shared__ int waveCnt[4];
+  __shared__ int sTotal;
+
+  int l = 0;
+  while (l + 1 < nlevels && (int)blockIdx.x >= geom[l + 1].cellBase) ++l;
+  const LevelGeom g = geom[l];
+  const int cell = blockIdx.x - g.cellBase;
+  const int ci = cell / g.nCols, cj = cell % g.nCols;
+  const int img = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const size_t cellSlot = (size_t)img * totalCells + blockIdx.x;
+
+  const int iniX = MINB + cj * g.wCell, iniY = MINB + ci * g.hCell;
+  int maxX = iniX + g.wCell + 6, maxY = iniY + g.hCell + 6;
+  if (iniY >= g.maxBorderY - 3 || iniX >= g.maxBorderX - 6) {  // :770, :775
+    if (tid == 0) candCnt[cellSlot] = 0;
+    return;
+  }
+  maxX = imin(maxX, g.maxBorderX);
+  maxY = imin(maxY, g.maxBorderY);
+  const int tw = maxX - iniX, th = maxY - iniY;
+  const int ew = tw - 6, eh = th - 6;  // evaluated area: x in [3, tw-3), y in [3, th-3)
+  if (ew <= 0 || eh <= 0) {
+    if (tid == 0) candCnt[cellSlot] = 0;
+    return;
+  }
+  const uint8_t* base = pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)(EDGE + iniY) * g.pstride + EDGE + iniX;
+  for (int i = tid; i < th * tw; i += 256) {
+    const int r = i / tw, c = i % tw;
+    tile[r * tilePitch + c] = base[(size_t)r * g.pstride + c];
+    sc[r * tilePitch + c] = 0;
+  }
+  __syncthreads();
+  const int nEval = ew * eh;
+  for (int i = tid; i < nEval; i += 256) {
+    const int y = i / ew + 3, x = i % ew + 3;
+    int s = fast_strength(tile + y * tilePitch + x, tilePitch);
+    sc[y * tilePitch + x] = (uint8_t)imin(imax(s, 0), 255);
+  }
+  __syncthreads();
+
+  // NMS at threshold t: corner iff S > t, score = S - 1, neighbours that are not corners score 0; keep iff
+  // score strictly greater than all 8 neighbour scores.
+  auto keepAt = [&](int i, int t) -> bool {
+    const int y = i / ew + 3, x = i % ew + 3;
+    const uint8_t* q = sc + y * tilePitch + x;
+    const int S = q[0];
+    if (S <= t) return false;
+    bool keep = true;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        if (dx == 0 && dy == 0) continue;
+        const int Sn = q[dy * tilePitch + dx];
+        const int ns = Sn > t ? Sn - 1 : 0;
+        keep = keep && (S - 1 > ns);
+      }
+    return keep;
+  };
+
+  int thr = iniTh;
+  for (int pass = 0; pass < 2; ++pass) {
+    int cnt = 0;
+    for (int i = tid; i < nEval; i += 256) cnt += keepAt(i, thr) ? 1 : 0;
+    const int tot = __syncthreads_count(cnt > 0);
+    if (tot > 0 || pass == 1) break;
+    thr = minTh;  // vKeysCell.empty() -> second cv::FAST with minThFAST (:795)
+  }
+
+  // ordered compaction, row-major over the evaluated area
+  uint32_t* out = cand + cellSlot * (size_t)cellCap;
+  int running = 0;
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int i0 = 0; i0 < nEval; i0 += 256) {
+    const int i = i0 + tid;
+    const bool k = i < nEval && keepAt(i, thr);
+    const uint64_t m = __ballot(k);
+    if (lane == 0) waveCnt[wv] = __popcll(m);
+    __syncthreads();
+    int off = running;
+    for (int q = 0; q < wv; ++q) off += waveCnt[q];
+    if (k) {
+      const int y = i / ew + 3, x = i % ew + 3;
+      const int slot = off + __popcll(m & lt);
+      if (slot < cellCap)
+        out[slot] = morbqt::make_key(x + cj * g.wCell, y + ci * g.hCell, sc[y * tilePitch + x] - 1);
+    }
+    running += waveCnt[0] + waveCnt[1] + waveCnt[2] + waveCnt[3];
+    __syncthreads();
+  }
+  if (tid == 0) candCnt[cellSlot] = imin(running, cellCap);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3: DistributeOctTree, one wave per (level, image).  See quadtree.h.
+__global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ cand,
+                                                   const int* __restrict__ candCnt, int totalCells, int cellCap,
+                                                   uint32_t* __restrict__ qtScratch, uint32_t* __restrict__ sel,
+                                                   int* __restrict__ selCnt, int selPerImg, int nlevels,
+                                                   int maxNodeCap, int maxCells) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int lvl = blockIdx.x, img = blockIdx.y, lane = threadIdx.x;
+  const LevelGeom g = geom[lvl];
+  // LDS carve-up (sizes from the largest level)
+  uint8_t* sp = smem;
+  uint64_t* vA = reinterpret_cast<uint64_t*>(sp); sp += (size_t)maxNodeCap * 8;
+  uint64_t* vB = reinterpret_cast<uint64_t*>(sp); sp += (size_t)maxNodeCap * 8;
+  morbqt::Node* nodes = reinterpret_cast<morbqt::Node*>(sp); sp += (size_t)maxNodeCap * sizeof(morbqt::Node);
+  uint32_t* ldsKeys = reinterpret_cast<uint32_t*>(sp); sp += (size_t)kLdsKeys * 4;
+  uint32_t* ldsTmp = reinterpret_cast<uint32_t*>(sp); sp += (size_t)kLdsKeys * 4;
+  int* cellOff = reinterpret_cast<int*>(sp); sp += (size_t)(maxCells + 1) * 4;
+  uint16_t* freeIds = reinterpret_cast<uint16_t*>(sp); sp += (size_t)maxNodeCap * 2;
+  uint16_t* list = reinterpret_cast<uint16_t*>(sp);
+
+  const int ncell = g.nRows * g.nCols;
+  const int* counts = candCnt + (size_t)img * totalCells + g.cellBase;
+  int running = 0;
+  for (int c0 = 0; c0 < ncell; c0 += 64) {
+    const int c = c0 + lane;
+    const int n = c < ncell ? counts[c] : 0;
+    int incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    if (c < ncell) cellOff[c] = running + incl - n;
+    running += __shfl(incl, 63, 64);
+  }
+  const int T = running;
+  if (lane == 0) cellOff[ncell] = T;
+  QT_SYNC();
+
+  uint32_t* keys;
+  uint32_t* tmp;
+  if (T <= kLdsKeys) {
+    keys = ldsKeys;
+    tmp = ldsTmp;
+  } else {
+    keys = qtScratch + g.qtOff + (size_t)img * g.qtImg;
+    tmp = keys + g.qtImg / 2;
+  }
+  const uint32_t* cbase = cand + ((size_t)img * totalCells + g.cellBase) * (size_t)cellCap;
+  for (int t = lane; t < T; t += 64) {
+    int lo = 0, hi = ncell;  // largest c with cellOff[c] <= t
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (cellOff[mid] <= t) lo = mid; else hi = mid;
+    }
+    keys[t] = cbase[(size_t)lo * cellCap + (t - cellOff[lo])];
+  }
+  QT_SYNC();
+
+  morbqt::Work w;
+  w.keys = keys; w.tmp = tmp; w.nodes = nodes; w.freeIds = freeIds; w.list = list; w.vA = vA; w.vB = vB;
+  w.nodeCap = g.nodeCap; w.listCap = g.listCap;
+  uint32_t* out = sel + (size_t)img * selPerImg + g.selBase;
+  const int n = morbqt::qt_distribute(w, (uint32_t)T, g.maxBorderX - MINB, g.maxBorderY - MINB, g.quota, out, g.selCap);
+  if (lane == 0) selCnt[img * nlevels + lvl] = n < g.selCap ? n : g.selCap;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Layout: final slot of every keypoint (operator() tail, ORBextractor.cc:1041-1085): levels in order, keypoints
+// in list order; x in [lap0, lap1] (after pt *= scale) fills from the back, the rest from the front.
+__global__ __launch_bounds__(256) void k_layout(const LevelGeom* __restrict__ geom, int nlevels,
+                                                const uint32_t* __restrict__ sel, const int* __restrict__ selCnt,
+                                                int selPerImg, const int* __restrict__ lap, int* __restrict__ slots,
+                                                int* __restrict__ nkp, int* __restrict__ mono, int cap) {
+  __shared__ int wm[4], ws[4];
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int base[kMaxLevels + 1];
+  int total = 0;
+  for (int l = 0; l < nlevels; ++l) { base[l] = total; total += selCnt[img * nlevels + l]; }
+  base[nlevels] = total;
+  const float lap0 = (float)lap[img * 2], lap1 = (float)lap[img * 2 + 1];
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  int monoRun = 0, stereoRun = 0;
+  for (int g0 = 0; g0 < total; g0 += 256) {
+    const int gi = g0 + tid;
+    const bool valid = gi < total;
+    bool isLap = false;
+    if (valid) {
+      int l = 0;
+      while (gi >= base[l + 1]) ++l;
+      const uint32_t key = sel[(size_t)img * selPerImg + geom[l].selBase + (gi - base[l])];
+      float x = (float)(morbqt::key_x(key) + MINB);
+      if (l != 0) x = x * geom[l].scale;
+      isLap = (x >= lap0) && (x <= lap1);
+    }
+    const uint64_t mS = __ballot(valid && isLap), mM = __ballot(valid && !isLap);
+    if (lane == 0) { ws[wv] = __popcll(mS); wm[wv] = __popcll(mM); }
+    __syncthreads();
+    int offS = stereoRun, offM = monoRun;
+    for (int q = 0; q < wv; ++q) { offS += ws[q]; offM += wm[q]; }
+    if (valid) {
+      const int slot = isLap ? (total - 1 - (offS + __popcll(mS & lt))) : (offM + __popcll(mM & lt));
+      slots[(size_t)img * selPerImg + gi] = slot < cap ? slot : -1;
+    }
+    stereoRun += ws[0] + ws[1] + ws[2] + ws[3];
+    monoRun += wm[0] + wm[1] + wm[2] + wm[3];
+    __syncthreads();
+  }
+  if (tid == 0) { nkp[img] = total < cap ? total : cap; mono[img] = monoRun; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Describe: IC_Angle (:75-99) + computeOrbDescriptor (:102-145) + keypoint record, one wave per keypoint.
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fastAtan2, f32 throughout
+  const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+  const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+  const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+  const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + (float)2.2204460492503131e-16);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + (float)2.2204460492503131e-16);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+// glibc 2.35 sincosf restated (same sequence as oracle/cvprims.cc; bit-equal to libm cosf/sinf on [0, 7])
+struct SinCosTab { double sign[4]; double hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3; };
+__device__ __forceinline__ double sc_poly(double x, double x2, const SinCosTab& p, int n) {
+  if ((n & 1) == 0) {
+    const double x3 = x * x2, s1 = p.s2 + x2 * p.s3, x7 = x3 * x2, s = x + x3 * p.s1;
+    return s + x7 * s1;
+  }
+  const double x4 = x2 * x2, c2 = p.c3 + x2 * p.c4, c1 = p.c0 + x2 * p.c1, x6 = x4 * x2, c = c1 + x4 * p.c2;
+  return c + x6 * c2;
+}
+__device__ __forceinline__ void sincosf_glibc(float y, float* sn, float* cs) {
+  const SinCosTab t0 = {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, 0x1p0,
+                        -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5, -0x1.6c087e89a359dp-10,
+                        0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7,
+                        -0x1.994eb3774cf24p-13};
+  const SinCosTab t1 = {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, -0x1p0,
+                        0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5, 0x1.6c087e89a359dp-10,
+                        -0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7,
+                        -0x1.994eb3774cf24p-13};
+  const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ff;
+  const uint32_t topPio4 = (__float_as_uint(0x1.921FB6p-1f) >> 20) & 0x7ff;
+  const uint32_t topTiny = (__float_as_uint(0x1p-12f) >> 20) & 0x7ff;
+  double x = (double)y;
+  if (top < topPio4) {
+    const double x2 = x * x;
+    if (top < topTiny) { *cs = 1.0f; *sn = y; return; }
+    *cs = (float)sc_poly(x, x2, t0, 1);
+    *sn = (float)sc_poly(x, x2, t0, 0);
+    return;
+  }
+  const double r = x * t0.hpi_inv;
+  const int n = ((int32_t)r + 0x800000) >> 24;
+  x = x - n * t0.hpi;
+  const double s = t0.sign[n & 3];
+  const SinCosTab& p = (n & 2) ? t1 : t0;
+  *cs = (float)sc_poly(x * s, x * x, p, n ^ 1);
+  *sn = (float)sc_poly(x * s, x * x, p, n);
+}
+
+__global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ geom, int nlevels,
+                                                  const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                                  const uint32_t* __restrict__ sel, const int* __restrict__ selCnt,
+                                                  int selPerImg, const int* __restrict__ slots,
+                                                  morb_keypoint* __restrict__ kps, uint8_t* __restrict__ desc, int cap) {
+  const int img = blockIdx.y, lane = threadIdx.x & 63;
+  const int gi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int l = 0, b = 0;
+  {
+    int acc = 0;
+    bool found = false;
+    for (int q = 0; q < nlevels; ++q) {
+      const int n = selCnt[img * nlevels + q];
+      if (!found && gi < acc + n) { l = q; b = acc; found = true; }
+      acc += n;
+    }
+    if (!found) return;
+  }
+  const LevelGeom g = geom[l];
+  const int slot = slots[(size_t)img * selPerImg + gi];
+  if (slot < 0) return;
+  const uint32_t key = sel[(size_t)img * selPerImg + g.selBase + (gi - b)];
+  const int cx = morbqt::key_x(key) + MINB, cy = morbqt::key_y(key) + MINB;
+
+  // IC_Angle on the un-blurred level: lanes 0..30 take rows v = -15..15
+  int m10 = 0, m01 = 0;
+  if (lane < 2 * HALF_PATCH + 1) {
+    const int v = lane - HALF_PATCH;
+    const int d = c_umax[v < 0 ? -v : v];
+    const uint8_t* row = pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)(EDGE + cy + v) * g.pstride + EDGE + cx;
+    int rs = 0;
+    for (int u = -d; u <= d; ++u) {
+      const int val = row[u];
+      m10 += u * val;
+      rs += val;
+    }
+    m01 = v * rs;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    m10 += __shfl_xor(m10, off, 64);
+    m01 += __shfl_xor(m01, off, 64);
+  }
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+  // rBRIEF on the blurred level: lane k evaluates tests 4k..4k+3
+  const float factorPI = (float)(3.14159265358979323846 / 180.f);
+  float a, bsin;
+  sincosf_glibc(angle * factorPI, &bsin, &a);
+  const uint8_t* center = blur + g.blurOff + (size_t)img * g.blurImg + (size_t)cy * g.bstride + cx;
+  uint32_t nib = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int* pt = &c_pattern[(lane * 4 + q) * 4];
+    const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+    const int r0 = __float2int_rn(x0 * bsin + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bsin);
+    const int r1 = __float2int_rn(x1 * bsin + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bsin);
+    const int t0 = center[(ptrdiff_t)r0 * g.bstride + c0], t1 = center[(ptrdiff_t)r1 * g.bstride + c1];
+    nib |= (uint32_t)(t0 < t1) << q;
+  }
+  const uint32_t hi = __shfl_down(nib, 1, 64);
+  if ((lane & 1) == 0) desc[((size_t)img * cap + slot) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+  if (lane == 0) {
+    morb_keypoint kp;
+    float x = (float)cx, y = (float)cy;
+    if (l != 0) { x = x * g.scale; y = y * g.scale; }
+    kp.x = x; kp.y = y; kp.size = g.kpSize; kp.angle = angle; kp.response = (float)morbqt::key_r(key);
+    kp.octave = l; kp.class_id = -1;
+    kps[(size_t)img * cap + slot] = kp;
+  }
+}
+
+}  // namespace
+
+// =====================================================================================================
+// Host side
+// =====================================================================================================
+struct morb_extractor {
+  int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0, device = 0;
+  float scaleFactor = 1.2f;
+  std::vector<float> scale, invScale, sigma2, invSigma2;
+  std::vector<int> quota;
+  int umax[16];
+
+  int W = 0, H = 0, nimgCap = 0, nimgLast = 0;
+  LevelGeom geom[kMaxLevels];
+  int totalCells = 0, cellCap = 0, tilePitch = 0, tileRows = 0, maxCells = 0, maxNodeCap = 0, maxListCap = 0;
+  int selPerImg = 0, blurTiles = 0, outCap = 0;
+  size_t pyrBytes = 0, blurBytes = 0, qtElems = 0, distSmem = 0;
+
+  hipStream_t stream = nullptr;
+  LevelGeom* d_geom = nullptr;
+  ResizeTab* d_tabs = nullptr;
+  uint8_t *d_pyr = nullptr, *d_blur = nullptr;
+  uint32_t *d_cand = nullptr, *d_qt = nullptr, *d_sel = nullptr;
+  int *d_candCnt = nullptr, *d_selCnt = nullptr, *d_slots = nullptr, *d_lap = nullptr;
+  // staging for the single-image host API
+  uint8_t* d_img = nullptr; size_t imgBytes = 0;
+  morb_keypoint* d_kps1 = nullptr; uint8_t* d_desc1 = nullptr; int *d_cnt1 = nullptr, *d_mono1 = nullptr;
+  std::vector<int> lapLast;  // host mirror of d_lap
+  bool profiling = false;
+  hipEvent_t ev[8] = {nullptr};
+  float stageMs[7] = {0};
+};
+
+namespace {
+
+static int cvRoundF(float v) { return (int)lrintf(v); }
+
+void free_buffers(morb_extractor* e) {
+  auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+  F(e->d_geom); F(e->d_tabs); F(e->d_pyr); F(e->d_blur); F(e->d_cand); F(e->d_qt); F(e->d_sel);
+  F(e->d_candCnt); F(e->d_selCnt); F(e->d_slots); F(e->d_lap);
+  e->W = e->H = e->nimgCap = 0;
+  e->lapLast.clear();
+}
+void free_staging(morb_extractor* e) {
+  auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+  F(e->d_img); F(e->d_kps1); F(e->d_desc1); F(e->d_cnt1); F(e->d_mono1);
+  e->imgBytes = 0;
+}
+
+// Build geometry + tables for (W, H) and allocate for nimg images.
+int configure(morb_extractor* e, int W, int H, int nimg) {
+  if (e->W == W && e->H == H && e->nimgCap >= nimg) return MORB_OK;
+  MORB_HIP_CHECK(hipSetDevice(e->device));
+  MORB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  free_buffers(e);
+  const int L = e->nlevels;
+  std::vector<ResizeTab> tabs;
+  size_t pyrOff = 0, blurOff = 0, qtOff = 0;
+  int cellBase = 0, selBase = 0, blurTileBase = 0;
+  e->cellCap = 0; e->tilePitch = 0; e->tileRows = 0; e->maxCells = 0; e->maxNodeCap = 0; e->maxListCap = 0;
+  for (int l = 0; l < L; ++l) {
+    LevelGeom& g = e->geom[l];
+    memset(&g, 0, sizeof g);
+    const float s = e->invScale[l];
+    g.w = cvRoundF((float)W * s);  // ORBextractor.cc:1091-1092
+    g.h = cvRoundF((float)H * s);
+    MORB_REQUIRE(g.w >= 2 * EDGE + 35 + 3 && g.h >= 2 * EDGE + 35 + 3 && g.w <= 4095 && g.h <= 4095, MORB_ERR_UNSUPPORTED,
+                 "image size unsupported: every pyramid level must be between 76 and 4095 px in each dimension");
+    g.pstride = (int)align_up((size_t)g.w + 2 * EDGE, 64);
+    g.bstride = (int)align_up((size_t)g.w, 64);
+    g.pyrOff = pyrOff; g.pyrImg = (size_t)(g.h + 2 * EDGE) * g.pstride; pyrOff += g.pyrImg * nimg;
+    g.blurOff = blurOff; g.blurImg = (size_t)g.h * g.bstride; blurOff += g.blurImg * nimg;
+    g.maxBorderX = g.w - EDGE + 3; g.maxBorderY = g.h - EDGE + 3;  // :748-749
+    const float width = (float)(g.maxBorderX - MINB), height = (float)(g.maxBorderY - MINB);
+    g.nCols = (int)(width / 35.f); g.nRows = (int)(height / 35.f);                    // :755-758
+    g.wCell = (int)std::ceil(width / g.nCols); g.hCell = (int)std::ceil(height / g.nRows);  // :760-761
+    g.cellBase = cellBase; cellBase += g.nCols * g.nRows;
+    e->maxCells = std::max(e->maxCells, g.nCols * g.nRows);
+    e->cellCap = std::max(e->cellCap, ((g.wCell + 1) / 2) * ((g.hCell + 1) / 2));
+    e->tilePitch = std::max(e->tilePitch, (int)align_up((size_t)g.wCell + 6, 4));
+    e->tileRows = std::max(e->tileRows, g.hCell + 6);
+    g.quota = e->quota[l];
+    g.nIni = (int)std::round(width / height);  // :545
+    MORB_REQUIRE(g.nIni >= 1 && g.nIni <= 4, MORB_ERR_UNSUPPORTED, "aspect ratio unsupported (need 0.5 <= w/h < 4.5)");
+    g.nodeCap = morbqt::qt_node_cap(g.quota, g.nIni);
+    g.listCap = morbqt::qt_list_cap(g.nodeCap);
+    MORB_REQUIRE(g.listCap < 65535, MORB_ERR_UNSUPPORTED, "nfeatures too large for 16-bit node lists");
+    e->maxNodeCap = std::max(e->maxNodeCap, g.nodeCap);
+    e->maxListCap = std::max(e->maxListCap, g.listCap);
+    g.selCap = std::max(g.quota + 3, 4 * g.nIni) + 1;
+    g.selBase = selBase; selBase += g.selCap;
+    g.scale = e->scale[l];
+    g.kpSize = (float)(int)(PATCH * e->scale[l]);
+    g.blurTilesX = div_up(g.w, BT_W); g.blurTilesY = div_up(g.h, BT_H);
+    g.blurTileBase = blurTileBase; blurTileBase += g.blurTilesX * g.blurTilesY;
+  }
+  // global key scratch: 2 x (cells x cellCap) per (level, image), used only when a level has > kLdsKeys candidates
+  for (int l = 0; l < L; ++l) {
+    LevelGeom& g = e->geom[l];
+    g.qtImg = 2ull * g.nCols * g.nRows * e->cellCap;
+    g.qtOff = qtOff; qtOff += g.qtImg * nimg;
+  }
+  // resize tables in padded destination coordinates (imgproc/resize.cpp coefficient set-up, see oracle)
+  for (int l = 1; l < L; ++l) {
+    LevelGeom& g = e->geom[l];
+    const LevelGeom& gs = e->geom[l - 1];
+    const int ONE = 2048;
+    auto build = [&](int dn, int sn, bool horizontal, std::vector<ResizeTab>& out) {
+      const double inv = (double)dn / sn, sc = 1. / inv;
+      std::vector<ResizeTab> interior(dn);
+      for (int d = 0; d < dn; ++d) {
+        float f = (float)((d + 0.5) * sc - 0.5);
+        int si = (int)std::floor(f);
+        f -= si;
+        if (horizontal) {
+          if (si < 0) { f = 0; si = 0; }
+          if (si >= sn - 1) { f = 0; si = sn - 1; }
+        }
+        ResizeTab t;
+        int s0 = si, s1 = si + 1;
+        s0 = s0 < 0 ? 0 : (s0 < sn ? s0 : sn - 1);
+        s1 = s1 < 0 ? 0 : (s1 < sn ? s1 : sn - 1);
+        t.s0 = (short)s0; t.s1 = (short)s1;
+        t.c0 = (short)std::min(std::max(cvRoundF((1.f - f) * ONE), -32768), 32767);
+        t.c1 = (short)std::min(std::max(cvRoundF(f * ONE), -32768), 32767);
+        interior[d] = t;
+      }
+      for (int p = 0; p < dn + 2 * EDGE; ++p) {
+        int q = p - EDGE;
+        if (q < 0) q = -q;
+        if (q >= dn) q = 2 * (dn - 1) - q;
+        out.push_back(interior[q]);
+      }
+    };
+    g.xtabOff = (int)tabs.size(); build(g.w, gs.w, true, tabs);
+    g.ytabOff = (int)tabs.size(); build(g.h, gs.h, false, tabs);
+  }
+  e->totalCells = cellBase;
+  e->selPerImg = selBase;
+  e->blurTiles = blurTileBase;
+  e->pyrBytes = pyrOff; e->blurBytes = blurOff; e->qtElems = qtOff;
+  e->outCap = selBase;
+  e->distSmem = (size_t)e->maxNodeCap * (8 + 8 + sizeof(morbqt::Node) + 2) + (size_t)kLdsKeys * 8 +
+                (size_t)(e->maxCells + 1) * 4 + (size_t)e->maxListCap * 2 + 64;
+  MORB_REQUIRE(e->distSmem <= 160 * 1024, MORB_ERR_UNSUPPORTED, "nfeatures too large for the LDS-resident quadtree");
+
+  MORB_HIP_CHECK(hipMalloc(&e->d_geom, sizeof(LevelGeom) * kMaxLevels));
+  MORB_HIP_CHECK(hipMemcpy(e->d_geom, e->geom, sizeof(LevelGeom) * kMaxLevels, hipMemcpyHostToDevice));
+  MORB_HIP_CHECK(hipMalloc(&e->d_tabs, sizeof(ResizeTab) * std::max<size_t>(tabs.size(), 1)));
+  if (!tabs.empty()) MORB_HIP_CHECK(hipMemcpy(e->d_tabs, tabs.data(), sizeof(ResizeTab) * tabs.size(), hipMemcpyHostToDevice));
+  MORB_HIP_CHECK(hipMalloc(&e->d_pyr, e->pyrBytes + 256));
+  MORB_HIP_CHECK(hipMalloc(&e->d_blur, e->blurBytes + 256));
+  MORB_HIP_CHECK(hipMalloc(&e->d_cand, sizeof(uint32_t) * (size_t)nimg * e->totalCells * e->cellCap));
+  MORB_HIP_CHECK(hipMalloc(&e->d_candCnt, sizeof(int) * (size_t)nimg * e->totalCells));
+  MORB_HIP_CHECK(hipMalloc(&e->d_qt, sizeof(uint32_t) * std::max<size_t>(e->qtElems, 1)));
+  MORB_HIP_CHECK(hipMalloc(&e->d_sel, sizeof(uint32_t) * (size_t)nimg * e->selPerImg));
+  MORB_HIP_CHECK(hipMalloc(&e->d_selCnt, sizeof(int) * (size_t)nimg * L));
+  MORB_HIP_CHECK(hipMalloc(&e->d_slots, sizeof(int) * (size_t)nimg * e->selPerImg));
+  MORB_HIP_CHECK(hipMalloc(&e->d_lap, sizeof(int) * (size_t)nimg * 2));
+  MORB_HIP_CHECK(hipMemset(e->d_selCnt, 0, sizeof(int) * (size_t)nimg * L));
+  MORB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), e->umax, sizeof(int) * 16));
+  MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_distribute),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->distSmem));
+  e->W = W; e->H = H; e->nimgCap = nimg;
+  return MORB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* morb_last_error(void) { return last_error().c_str(); }
+
+int morb_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int morb_extractor_create(morb_extractor** out, int nfeatures, float scaleFactor, int nlevels, int iniThFAST,
+                          int minThFAST, int device) {
+  MORB_REQUIRE(out, MORB_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  MORB_REQUIRE(nfeatures > 0 && nlevels >= 1 && nlevels <= kMaxLevels && scaleFactor > 1.0f, MORB_ERR_INVALID,
+               "bad extractor parameters");
+  MORB_REQUIRE(iniThFAST >= 0 && iniThFAST <= 255 && minThFAST >= 0 && minThFAST <= 255, MORB_ERR_INVALID,
+               "FAST thresholds must be in [0,255]");
+  int ndev = 0;
+  MORB_HIP_CHECK(hipGetDeviceCount(&ndev));
+  MORB_REQUIRE(device >= 0 && device < ndev, MORB_ERR_INVALID, "no such HIP device");
+  morb_extractor* e = new morb_extractor();
+  e->nfeatures = nfeatures; e->scaleFactor = scaleFactor; e->nlevels = nlevels; e->iniTh = iniThFAST;
+  e->minTh = minThFAST; e->device = device;
+  // ORBextractor.cc:413-443
+  e->scale.resize(nlevels); e->sigma2.resize(nlevels); e->invScale.resize(nlevels); e->invSigma2.resize(nlevels);
+  e->scale[0] = 1.0f; e->sigma2[0] = 1.0f;
+  for (int i = 1; i < nlevels; i++) { e->scale[i] = e->scale[i - 1] * scaleFactor; e->sigma2[i] = e->scale[i] * e->scale[i]; }
+  for (int i = 0; i < nlevels; i++) { e->invScale[i] = 1.0f / e->scale[i]; e->invSigma2[i] = 1.0f / e->sigma2[i]; }
+  e->quota.resize(nlevels);
+  float factor = 1.0f / scaleFactor;
+  float nDesired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+  int sum = 0;
+  for (int l = 0; l < nlevels - 1; l++) { e->quota[l] = cvRoundF(nDesired); sum += e->quota[l]; nDesired *= factor; }
+  e->quota[nlevels - 1] = std::max(nfeatures - sum, 0);
+  // umax (:451-463)
+  {
+    int v, v0, vmax = (int)std::floor(HALF_PATCH * std::sqrt(2.f) / 2 + 1);
+    int vmin = (int)std::ceil(HALF_PATCH * std::sqrt(2.f) / 2);
+    const double hp2 = HALF_PATCH * HALF_PATCH;
+    for (v = 0; v <= vmax; ++v) e->umax[v] = (int)lrint(std::sqrt(hp2 - v * v));
+    for (v = HALF_PATCH, v0 = 0; v >= vmin; --v) {
+      while (e->umax[v0] == e->umax[v0 + 1]) ++v0;
+      e->umax[v] = v0;
+      ++v0;
+    }
+  }
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+    set_error("cannot create a stream on device %d", device);
+    delete e;
+    return MORB_ERR_HIP;
+  }
+  for (auto& ev : e->ev) (void)hipEventCreate(&ev);
+  *out = e;
+  return MORB_OK;
+}
+
+void morb_extractor_destroy(morb_extractor* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  free_buffers(e);
+  free_staging(e);
+  for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int morb_extractor_levels(const morb_extractor* e) { return e ? e->nlevels : MORB_ERR_INVALID; }
+float morb_extractor_scale_factor(const morb_extractor* e) { return e ? e->scaleFactor : 0.f; }
+int morb_extractor_tables(const morb_extractor* e, float* sc, float* isc, float* s2, float* is2, int* fpl) {
+  MORB_REQUIRE(e, MORB_ERR_INVALID, "extractor is NULL");
+  for (int i = 0; i < e->nlevels; ++i) {
+    if (sc) sc[i] = e->scale[i];
+    if (isc) isc[i] = e->invScale[i];
+    if (s2) s2[i] = e->sigma2[i];
+    if (is2) is2[i] = e->invSigma2[i];
+    if (fpl) fpl[i] = e->quota[i];
+  }
+  return MORB_OK;
+}
+int morb_extractor_max_keypoints(const morb_extractor* e) {
+  if (!e) return MORB_ERR_INVALID;
+  int n = 0;
+  for (int l = 0; l < e->nlevels; ++l) n += std::max(e->quota[l] + 3, 16) + 1;
+  return n;
+}
+int morb_extractor_set_profiling(morb_extractor* e, int enable) {
+  MORB_REQUIRE(e, MORB_ERR_INVALID, "extractor is NULL");
+  e->profiling = enable != 0;
+  return MORB_OK;
+}
+int morb_extractor_stage_ms(const morb_extractor* e, float* ms7) {
+  MORB_REQUIRE(e && ms7, MORB_ERR_INVALID, "NULL argument");
+  for (int i = 0; i < 7; ++i) ms7[i] = e->stageMs[i];
+  return MORB_OK;
+}
+
+int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int width, int height, int stride,
+                       size_t image_pitch, const int* lap, morb_keypoint* d_kps, uint8_t* d_desc, int cap,
+                       int* d_count, int* d_mono, void* stream_) {
+  MORB_REQUIRE(e && d_images && d_kps && d_desc && d_count && d_mono, MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(nimg > 0, MORB_ERR_INVALID, "nimg must be positive");
+  if (width <= 0 || height <= 0) { set_error("empty image"); return MORB_ERR_EMPTY; }
+  MORB_REQUIRE(stride >= width && image_pitch >= (size_t)stride * height, MORB_ERR_INVALID, "bad stride/pitch");
+  MORB_REQUIRE(cap > 0, MORB_ERR_CAPACITY, "cap must be positive");
+  MORB_HIP_CHECK(hipSetDevice(e->device));
+  int rc = configure(e, width, height, nimg);
+  if (rc != MORB_OK) return rc;
+  hipStream_t st = stream_ ? (hipStream_t)stream_ : e->stream;
+  const int L = e->nlevels;
+  e->nimgLast = nimg;
+
+  {
+    std::vector<int> lapv((size_t)nimg * 2, 0);
+    if (lap) memcpy(lapv.data(), lap, sizeof(int) * nimg * 2);
+    if (lapv != e->lapLast) {  // rare: the lapping areas are per-camera constants
+      MORB_HIP_CHECK(hipStreamSynchronize(st));
+      MORB_HIP_CHECK(hipMemcpy(e->d_lap, lapv.data(), sizeof(int) * nimg * 2, hipMemcpyHostToDevice));
+      e->lapLast = lapv;
+    }
+  }
+
+  auto mark = [&](int i) { if (e->profiling) (void)hipEventRecord(e->ev[i], st); };
+  mark(0);
+  {
+    const LevelGeom& g0 = e->geom[0];
+    dim3 grid(div_up(g0.pstride / 4, 256), g0.h + 2 * EDGE, nimg);
+    hipLaunchKernelGGL(k_level0, grid, dim3(256), 0, st, d_images, width, height, stride, image_pitch, e->d_pyr, g0);
+    for (int l = 1; l < L; ++l) {
+      const LevelGeom& g = e->geom[l];
+      dim3 gr(div_up(g.pstride / 4, 256), g.h + 2 * EDGE, nimg);
+      hipLaunchKernelGGL(k_resize, gr, dim3(256), 0, st, e->d_pyr, e->geom[l - 1], g, e->d_tabs + g.xtabOff,
+                         e->d_tabs + g.ytabOff);
+    }
+  }
+  mark(1);
+  hipLaunchKernelGGL(k_blur, dim3(e->blurTiles, nimg), dim3(256), 0, st, e->d_geom, L, e->d_pyr, e->d_blur);
+  mark(2);
+  {
+    const size_t smem = 2ull * e->tileRows * e->tilePitch;
+    hipLaunchKernelGGL(k_fast, dim3(e->totalCells, nimg), dim3(256), smem, st, e->d_geom, L, e->d_pyr, e->d_cand,
+                       e->d_candCnt, e->totalCells, e->cellCap, e->tilePitch, e->tileRows, e->iniTh, e->minTh);
+  }
+  mark(3);
+  hipLaunchKernelGGL(k_distribute, dim3(L, nimg), dim3(64), e->distSmem, st, e->d_geom, e->d_cand, e->d_candCnt,
+                     e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L, e->maxNodeCap,
+                     e->maxCells);
+  mark(4);
+  hipLaunchKernelGGL(k_layout, dim3(nimg), dim3(256), 0, st, e->d_geom, L, e->d_sel, e->d_selCnt, e->selPerImg,
+                     e->d_lap, e->d_slots, d_count, d_mono, cap);
+  mark(5);
+  hipLaunchKernelGGL(k_describe, dim3(div_up(e->selPerImg, 4), nimg), dim3(256), 0, st, e->d_geom, L, e->d_pyr,
+                     e->d_blur, e->d_sel, e->d_selCnt, e->selPerImg, e->d_slots, d_kps, d_desc, cap);
+  mark(6);
+  MORB_HIP_CHECK(hipGetLastError());
+  if (e->profiling) {
+    MORB_HIP_CHECK(hipEventSynchronize(e->ev[6]));
+    for (int i = 0; i < 6; ++i) (void)hipEventElapsedTime(&e->stageMs[i], e->ev[i], e->ev[i + 1]);
+    (void)hipEventElapsedTime(&e->stageMs[6], e->ev[0], e->ev[6]);
+  }
+  return MORB_OK;
+}
+
+int morb_extract(morb_extractor* e, const uint8_t* image, int width, int height, int stride, int lap0, int lap1,
+                 morb_keypoint* kps, uint8_t* desc, int cap, int* n) {
+  MORB_REQUIRE(e && n, MORB_ERR_INVALID, "NULL argument");
+  *n = 0;
+  if (!image || width <= 0 || height <= 0) { set_error("empty image"); return MORB_ERR_EMPTY; }
+  MORB_REQUIRE(kps && desc, MORB_ERR_INVALID, "NULL output");
+  MORB_REQUIRE(stride >= width, MORB_ERR_INVALID, "bad stride");
+  MORB_HIP_CHECK(hipSetDevice(e->device));
+  const size_t bytes = (size_t)stride * height;
+  const int maxk = morb_extractor_max_keypoints(e);
+  if (e->imgBytes < bytes || !e->d_kps1) {
+    MORB_HIP_CHECK(hipStreamSynchronize(e->stream));
+    if (e->d_img) (void)hipFree(e->d_img);
+    e->d_img = nullptr;
+    MORB_HIP_CHECK(hipMalloc(&e->d_img, bytes));
+    e->imgBytes = bytes;
+    if (!e->d_kps1) {
+      MORB_HIP_CHECK(hipMalloc(&e->d_kps1, sizeof(morb_keypoint) * maxk));
+      MORB_HIP_CHECK(hipMalloc(&e->d_desc1, 32 * (size_t)maxk));
+      MORB_HIP_CHECK(hipMalloc(&e->d_cnt1, sizeof(int)));
+      MORB_HIP_CHECK(hipMalloc(&e->d_mono1, sizeof(int)));
+    }
+  }
+  int rc = configure(e, width, height, 1);
+  if (rc != MORB_OK) return rc;
+  MORB_HIP_CHECK(hipMemcpyAsync(e->d_img, image, bytes, hipMemcpyHostToDevice, e->stream));
+  int lap[2] = {lap0, lap1};
+  rc = morb_extract_batch(e, e->d_img, 1, width, height, stride, bytes, lap, e->d_kps1, e->d_desc1, maxk, e->d_cnt1,
+                          e->d_mono1, e->stream);
+  if (rc != MORB_OK) return rc;
+  int cnt = 0, mono = 0;
+  MORB_HIP_CHECK(hipMemcpyAsync(&cnt, e->d_cnt1, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  MORB_HIP_CHECK(hipMemcpyAsync(&mono, e->d_mono1, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  MORB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  *n = cnt;
+  MORB_REQUIRE(cnt <= cap, MORB_ERR_CAPACITY, "keypoint buffer too small");
+  if (cnt) {
+    MORB_HIP_CHECK(hipMemcpy(kps, e->d_kps1, sizeof(morb_keypoint) * cnt, hipMemcpyDeviceToHost));
+    MORB_HIP_CHECK(hipMemcpy(desc, e->d_desc1, 32 * (size_t)cnt, hipMemcpyDeviceToHost));
+  }
+  return mono;
+}
+
+int morb_extractor_pyramid_level(const morb_extractor* e, int img, int lvl, const uint8_t** d_ptr, int* width,
+                                 int* height, int* stride) {
+  MORB_REQUIRE(e && e->W > 0, MORB_ERR_INVALID, "no batch has been extracted yet");
+  MORB_REQUIRE(lvl >= 0 && lvl < e->nlevels && img >= 0 && img < e->nimgLast, MORB_ERR_INVALID, "bad level/image");
+  const LevelGeom& g = e->geom[lvl];
+  if (d_ptr) *d_ptr = e->d_pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)EDGE * g.pstride + EDGE;
+  if (width) *width = g.w;
+  if (height) *height = g.h;
+  if (stride) *stride = g.pstride;
+  return MORB_OK;
+}
+
+int morb_extractor_pyramid_level_host(const morb_extractor* e, int img, int lvl, uint8_t* out) {
+  const uint8_t* p; int w, h, s;
+  int rc = morb_extractor_pyramid_level(e, img, lvl, &p, &w, &h, &s);
+  if (rc != MORB_OK) return rc;
+  MORB_HIP_CHECK(hipSetDevice(e->device));
+  MORB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  MORB_HIP_CHECK(hipMemcpy2D(out, w + 2 * EDGE, p - (size_t)EDGE * s - EDGE, s, w + 2 * EDGE, h + 2 * EDGE, hipMemcpyDeviceToHost));
+  return MORB_OK;
+}
+
+int morb_extractor_blurred_level_host(const morb_extractor* e, int img, int lvl, uint8_t* out) {
+  MORB_REQUIRE(e && e->W > 0, MORB_ERR_INVALID, "no batch has been extracted yet");
+  MORB_REQUIRE(lvl >= 0 && lvl < e->nlevels && img >= 0 && img < e->nimgLast, MORB_ERR_INVALID, "bad level/image");
+  const LevelGeom& g = e->geom[lvl];
+  MORB_HIP_CHECK(hipSetDevice(e->device));
+  MORB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  MORB_HIP_CHECK(hipMemcpy2D(out, g.w, e->d_blur + g.blurOff + (size_t)img * g.blurImg, g.bstride, g.w, g.h, hipMemcpyDeviceToHost));
+  return MORB_OK;
+}
+
+int morb_extractor_level_candidates_host(const morb_extractor* e, int img, int lvl, morb_keypoint* out, int cap, int* n) {
+  MORB_REQUIRE(e && e->W > 0 && n, MORB_ERR_INVALID, "no batch has been extracted yet");
+  MORB_REQUIRE(lvl >= 0 && lvl < e->nlevels && img >= 0 && img < e->nimgLast, MORB_ERR_INVALID, "bad level/image");
+  const LevelGeom& g = e->geom[lvl];
+  const int ncell = g.nCols * g.nRows;
+  MORB_HIP_CHECK(hipSetDevice(e->device));
+  MORB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  std::vector<int> cnt(ncell);
+  std::vector<uint32_t> keys((size_t)ncell * e->cellCap);
+  MORB_HIP_CHECK(hipMemcpy(cnt.data(), e->d_candCnt + (size_t)img * e->totalCells + g.cellBase, sizeof(int) * ncell, hipMemcpyDeviceToHost));
+  MORB_HIP_CHECK(hipMemcpy(keys.data(), e->d_cand + ((size_t)img * e->totalCells + g.cellBase) * e->cellCap,
+                           sizeof(uint32_t) * keys.size(), hipMemcpyDeviceToHost));
+  int m = 0;
+  for (int c = 0; c < ncell; ++c)
+    for (int i = 0; i < cnt[c]; ++i, ++m) {
+      if (out && m < cap) {
+        const uint32_t k = keys[(size_t)c * e->cellCap + i];
+        out[m] = morb_keypoint{(float)morbqt::key_x(k), (float)morbqt::key_y(k), 7.f, -1.f, (float)morbqt::key_r(k), 0, -1};
+      }
+    }
+  *n = m;
+  return MORB_OK;
+}
+
+int morb_extractor_level_keypoints_host(const morb_extractor* e, int img, int lvl, morb_keypoint* out, int cap, int* n) {
+  MORB_REQUIRE(e && e->W > 0 && n, MORB_ERR_INVALID, "no batch has been extracted yet");
+  MORB_REQUIRE(lvl >= 0 && lvl < e->nlevels && img >= 0 && img < e->nimgLast, MORB_ERR_INVALID, "bad level/image");
+  const LevelGeom& g = e->geom[lvl];
+  MORB_HIP_CHECK(hipSetDevice(e->device));
+  MORB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  int cnt = 0;
+  MORB_HIP_CHECK(hipMemcpy(&cnt, e->d_selCnt + img * e->nlevels + lvl, sizeof(int), hipMemcpyDeviceToHost));
+  std::vector<uint32_t> keys(std::max(cnt, 1));
+  MORB_HIP_CHECK(hipMemcpy(keys.data(), e->d_sel + (size_t)img * e->selPerImg + g.selBase, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost));
+  for (int i = 0; i < cnt && i < cap && out; ++i) {
+    const uint32_t k = keys[i];
+    out[i] = morb_keypoint{(float)(morbqt::key_x(k) + MINB), (float)(morbqt::key_y(k) + MINB), g.kpSize, -1.f,
+                           (float)morbqt::key_r(k), lvl, -1};
+  }
+  *n = cnt;
+  return MORB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,436 @@
+// Order-exact restatement of ORBextractor::DistributeOctTree (reference src/ORBextractor.cc:540-738,
+// ExtractorNode::DivideNode :475-523, compareNodes :525-538) for one wave64 per (image, level).
+//
+// Design (MI355X): the reference keeps a std::list<ExtractorNode> whose nodes own std::vector<KeyPoint>;
+// here a node is a rectangle + a contiguous segment [begin, begin+count) of one packed key array, the list
+// is an array of node ids that grows towards index 0 (push_front = --head, erase = tombstone, compaction
+// between sweeps), and DivideNode is a stable in-segment 4-way partition done by the whole wave with
+// ballots + popcounts.  The control flow runs on wave-uniform values; only lane 0 stores.  The result is
+// identical to the reference including list order, the "largest first" phase and the behaviour of
+// libstdc++'s std::sort on equivalent elements (introsort emulated below).
+//
+// The same source compiles for the host (tests/ build it with g++ to check it against the oracle's
+// std::list/std::sort restatement on random inputs); the product only uses the device instantiation.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define QT_DEVICE 1
+#else
+#define QT_DEVICE 0
+#endif
+#if defined(__HIPCC__)
+#define QT_HD __host__ __device__ __forceinline__
+#else
+#define QT_HD inline
+#endif
+
+namespace morbqt {
+
+// key = x | y << 12 | response << 24, x/y relative to (minBorderX, minBorderY); position in the key array =
+// rank in vToDistributeKeys.
+QT_HD int key_x(uint32_t k) { return (int)(k & 0xFFFu); }
+QT_HD int key_y(uint32_t k) { return (int)((k >> 12) & 0xFFFu); }
+QT_HD int key_r(uint32_t k) { return (int)(k >> 24); }
+QT_HD uint32_t make_key(int x, int y, int r) { return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)r << 24); }
+
+struct Node {
+  int16_t x0, y0, x1, y1;  // UL=(x0,y0) UR=(x1,y0) BL=(x0,y1) BR=(x1,y1)
+  uint32_t begin, count;
+  uint16_t lit;     // position in the list array
+  uint16_t noMore;  // bNoMore
+};
+
+struct Work {
+  uint32_t* keys;  // [kcap]
+  uint32_t* tmp;   // [kcap]
+  Node* nodes;     // [nodeCap]
+  uint16_t* freeIds;  // [nodeCap] stack of free node ids
+  uint16_t* list;     // [listCap] node id or 0xFFFF (erased)
+  uint64_t* vA;       // [nodeCap] vSizeAndPointerToNode: count << 32 | x0 << 16 | id
+  uint64_t* vB;       // [nodeCap] vPrevSizeAndPointerToNode
+  int nodeCap, listCap;
+};
+
+QT_HD int qt_node_cap(int N, int nIni) { int a = N + 3, b = 4 * nIni; return (a > b ? a : b) + 8; }
+QT_HD int qt_list_cap(int nodeCap) { return 5 * nodeCap; }
+
+#if QT_DEVICE
+#define QT_LANE ((int)(threadIdx.x & 63))
+#define QT_LANE0 (QT_LANE == 0)
+#define QT_SYNC()                                          \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); \
+    __builtin_amdgcn_wave_barrier();                       \
+  } while (0)
+#else
+#define QT_LANE 0
+#define QT_LANE0 true
+#define QT_SYNC() \
+  do {            \
+  } while (0)
+#endif
+
+// ---- wave-cooperative primitives ---------------------------------------------------------------------
+
+// Stable partition of keys[begin, begin+count) into G (<= 4) groups given by cls(key) in group order;
+// returns the group sizes in cnt[].  All lanes call this convergently.
+template <typename Cls>
+QT_HD void qt_partition(uint32_t* keys, uint32_t* tmp, uint32_t begin, uint32_t count, Cls cls, uint32_t cnt[4]) {
+#if QT_DEVICE
+  const int lane = QT_LANE;
+  uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  for (uint32_t i = 0; i < count; i += 64) {
+    int g = -1;
+    if (i + lane < count) g = cls(keys[begin + i + lane]);
+    c0 += __popcll(__ballot(g == 0));
+    c1 += __popcll(__ballot(g == 1));
+    c2 += __popcll(__ballot(g == 2));
+    c3 += __popcll(__ballot(g == 3));
+  }
+  cnt[0] = c0; cnt[1] = c1; cnt[2] = c2; cnt[3] = c3;
+  uint32_t b0 = 0, b1 = c0, b2 = c0 + c1, b3 = c0 + c1 + c2;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (uint32_t i = 0; i < count; i += 64) {
+    int g = -1;
+    uint32_t k = 0;
+    if (i + lane < count) { k = keys[begin + i + lane]; g = cls(k); }
+    uint64_t m0 = __ballot(g == 0), m1 = __ballot(g == 1), m2 = __ballot(g == 2), m3 = __ballot(g == 3);
+    uint32_t dst = 0;
+    if (g == 0) dst = b0 + __popcll(m0 & lt);
+    if (g == 1) dst = b1 + __popcll(m1 & lt);
+    if (g == 2) dst = b2 + __popcll(m2 & lt);
+    if (g == 3) dst = b3 + __popcll(m3 & lt);
+    if (g >= 0) tmp[begin + dst] = k;
+    b0 += __popcll(m0); b1 += __popcll(m1); b2 += __popcll(m2); b3 += __popcll(m3);
+  }
+  QT_SYNC();
+  for (uint32_t i = lane; i < count; i += 64) keys[begin + i] = tmp[begin + i];
+  QT_SYNC();
+#else
+  uint32_t c[4] = {0, 0, 0, 0};
+  for (uint32_t i = 0; i < count; ++i) c[cls(keys[begin + i])]++;
+  uint32_t b[4] = {0, c[0], c[0] + c[1], c[0] + c[1] + c[2]};
+  for (uint32_t i = 0; i < count; ++i) { uint32_t k = keys[begin + i]; tmp[begin + b[cls(k)]++] = k; }
+  for (uint32_t i = 0; i < count; ++i) keys[begin + i] = tmp[begin + i];
+  for (int g = 0; g < 4; ++g) cnt[g] = c[g];
+#endif
+}
+
+// First key with the maximum response in keys[begin, begin+count)  (ORBextractor.cc:719-735).
+QT_HD uint32_t qt_best_key(const uint32_t* keys, uint32_t begin, uint32_t count) {
+#if QT_DEVICE
+  const int lane = QT_LANE;
+  // maximise (response, -position): pack response << 32 | (0xFFFFFFFF - position)
+  uint64_t best = 0;
+  for (uint32_t i = lane; i < count; i += 64) {
+    uint64_t v = ((uint64_t)key_r(keys[begin + i]) << 32) | (uint64_t)(0xFFFFFFFFu - i);
+    best = v > best ? v : best;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    uint64_t o = __shfl_xor(best, off, 64);
+    best = o > best ? o : best;
+  }
+  uint32_t pos = 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFu);
+  return keys[begin + pos];
+#else
+  uint32_t bk = keys[begin];
+  for (uint32_t i = 1; i < count; ++i)
+    if (key_r(keys[begin + i]) > key_r(bk)) bk = keys[begin + i];
+  return bk;
+#endif
+}
+
+// ---- libstdc++ std::sort(first, last, compareNodes) emulation on packed entries -------------------------
+// entry = count << 32 | x0 << 16 | id ; compareNodes(e1, e2) == ((e1 >> 16) < (e2 >> 16)).
+QT_HD bool qt_less(uint64_t a, uint64_t b) { return (a >> 16) < (b >> 16); }
+QT_HD void qt_swap(uint64_t* v, int a, int b) { uint64_t t = v[a]; v[a] = v[b]; v[b] = t; }
+
+QT_HD void qt_adjust_heap(uint64_t* v, int first, int holeIndex, int len, uint64_t value) {
+  const int topIndex = holeIndex;
+  int secondChild = holeIndex;
+  while (secondChild < (len - 1) / 2) {
+    secondChild = 2 * (secondChild + 1);
+    if (qt_less(v[first + secondChild], v[first + (secondChild - 1)])) secondChild--;
+    v[first + holeIndex] = v[first + secondChild];
+    holeIndex = secondChild;
+  }
+  if ((len & 1) == 0 && secondChild == (len - 2) / 2) {
+    secondChild = 2 * (secondChild + 1);
+    v[first + holeIndex] = v[first + (secondChild - 1)];
+    holeIndex = secondChild - 1;
+  }
+  int parent = (holeIndex - 1) / 2;  // __push_heap
+  while (holeIndex > topIndex && qt_less(v[first + parent], value)) {
+    v[first + holeIndex] = v[first + parent];
+    holeIndex = parent;
+    parent = (holeIndex - 1) / 2;
+  }
+  v[first + holeIndex] = value;
+}
+
+QT_HD void qt_heapsort(uint64_t* v, int first, int last) {  // std::__partial_sort(first, last, last)
+  const int len = last - first;
+  if (len >= 2) {  // __make_heap
+    int parent = (len - 2) / 2;
+    while (true) {
+      uint64_t value = v[first + parent];
+      qt_adjust_heap(v, first, parent, len, value);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  while (last - first > 1) {  // __sort_heap
+    --last;
+    uint64_t value = v[last];
+    v[last] = v[first];
+    qt_adjust_heap(v, first, 0, last - first, value);
+  }
+}
+
+QT_HD void qt_unguarded_linear_insert(uint64_t* v, int last) {
+  uint64_t val = v[last];
+  int next = last - 1;
+  while (qt_less(val, v[next])) { v[last] = v[next]; last = next; --next; }
+  v[last] = val;
+}
+
+QT_HD void qt_insertion_sort(uint64_t* v, int first, int last) {
+  if (first == last) return;
+  for (int i = first + 1; i != last; ++i) {
+    if (qt_less(v[i], v[first])) {
+      uint64_t val = v[i];
+      for (int k = i; k > first; --k) v[k] = v[k - 1];  // move_backward(first, i, i+1)
+      v[first] = val;
+    } else
+      qt_unguarded_linear_insert(v, i);
+  }
+}
+
+// Serial; call from ONE lane (or the host).
+QT_HD void qt_std_sort(uint64_t* v, int n) {
+  if (n <= 0) return;
+  int lg = 0;
+  for (int t = n; t > 1; t >>= 1) ++lg;  // std::__lg(n)
+  // __introsort_loop with an explicit stack of (first, last, depth) for the recursive right halves
+  int stF[64], stL[64], stD[64];
+  int sp = 0;
+  stF[0] = 0; stL[0] = n; stD[0] = lg * 2; sp = 1;
+  while (sp > 0) {
+    --sp;
+    int first = stF[sp], last = stL[sp], depth = stD[sp];
+    while (last - first > 16) {
+      if (depth == 0) { qt_heapsort(v, first, last); break; }
+      --depth;
+      // __unguarded_partition_pivot
+      int mid = first + (last - first) / 2;
+      {  // __move_median_to_first(first, first+1, mid, last-1)
+        int a = first + 1, b = mid, c = last - 1;
+        if (qt_less(v[a], v[b])) {
+          if (qt_less(v[b], v[c])) qt_swap(v, first, b);
+          else if (qt_less(v[a], v[c])) qt_swap(v, first, c);
+          else qt_swap(v, first, a);
+        } else if (qt_less(v[a], v[c])) qt_swap(v, first, a);
+        else if (qt_less(v[b], v[c])) qt_swap(v, first, c);
+        else qt_swap(v, first, b);
+      }
+      int lo = first + 1, hi = last;
+      while (true) {  // __unguarded_partition(first+1, last, pivot = first)
+        while (qt_less(v[lo], v[first])) ++lo;
+        --hi;
+        while (qt_less(v[first], v[hi])) --hi;
+        if (!(lo < hi)) break;
+        qt_swap(v, lo, hi);
+        ++lo;
+      }
+      const int cut = lo;
+      // recurse on [cut, last) first (the reference recursion order), then loop on [first, cut): the two
+      // ranges are disjoint so the order of processing does not change the result; push the right half.
+      stF[sp] = cut; stL[sp] = last; stD[sp] = depth; ++sp;
+      last = cut;
+    }
+  }
+  // __final_insertion_sort
+  if (n > 16) {
+    qt_insertion_sort(v, 0, 16);
+    for (int i = 16; i != n; ++i) qt_unguarded_linear_insert(v, i);
+  } else
+    qt_insertion_sort(v, 0, n);
+}
+
+// ---- the distribution -----------------------------------------------------------------------------
+
+struct State {
+  int head;      // list occupies [head, listCap)
+  int size;      // live nodes
+  int nFree;     // free-id stack height
+  int nA;        // entries in vA
+};
+
+QT_HD int qt_alloc(Work& w, State& s) { return w.freeIds[--s.nFree]; }
+
+// push_front of a child; returns nothing.  Wave-uniform arguments; lane 0 stores.
+QT_HD void qt_push_child(Work& w, State& s, int x0, int y0, int x1, int y1, uint32_t begin, uint32_t count,
+                         int* nToExpand) {
+  if (count == 0) return;
+  const int id = qt_alloc(w, s);
+  --s.head;
+  ++s.size;
+  if (QT_LANE0) {
+    Node nd;
+    nd.x0 = (int16_t)x0; nd.y0 = (int16_t)y0; nd.x1 = (int16_t)x1; nd.y1 = (int16_t)y1;
+    nd.begin = begin; nd.count = count; nd.lit = (uint16_t)s.head; nd.noMore = (count == 1) ? 1 : 0;
+    w.nodes[id] = nd;
+    w.list[s.head] = (uint16_t)id;
+    if (count > 1) w.vA[s.nA] = ((uint64_t)count << 32) | ((uint64_t)(uint16_t)x0 << 16) | (uint64_t)id;
+  }
+  if (count > 1) { ++s.nA; if (nToExpand) ++*nToExpand; }
+}
+
+// DivideNode + the four push_front blocks + erase of the parent (ORBextractor.cc:609-650 / :671-708).
+QT_HD void qt_split(Work& w, State& s, int id, int* nToExpand) {
+  QT_SYNC();
+  const Node nd = w.nodes[id];
+  const int halfX = (nd.x1 - nd.x0 + 1) >> 1;  // ceil((UR.x-UL.x)/2.f) for non-negative ints
+  const int halfY = (nd.y1 - nd.y0 + 1) >> 1;
+  const int mx = nd.x0 + halfX, my = nd.y0 + halfY;
+  uint32_t cnt[4];
+  qt_partition(w.keys, w.tmp, nd.begin, nd.count,
+               [mx, my](uint32_t k) -> int { return (key_x(k) < mx ? 0 : 1) + (key_y(k) < my ? 0 : 2); }, cnt);
+  // group order 0:n1 (x<mx,y<my) 1:n2 (x>=mx,y<my) 2:n3 (x<mx,y>=my) 3:n4
+  uint32_t b = nd.begin;
+  // erase(parent) happens after the pushes in the reference; ids are not reused within a split because the
+  // parent's id is released last.
+  qt_push_child(w, s, nd.x0, nd.y0, mx, my, b, cnt[0], nToExpand); b += cnt[0];
+  qt_push_child(w, s, mx, nd.y0, nd.x1, my, b, cnt[1], nToExpand); b += cnt[1];
+  qt_push_child(w, s, nd.x0, my, mx, nd.y1, b, cnt[2], nToExpand); b += cnt[2];
+  qt_push_child(w, s, mx, my, nd.x1, nd.y1, b, cnt[3], nToExpand);
+  if (QT_LANE0) {
+    w.list[nd.lit] = 0xFFFF;
+    w.freeIds[s.nFree] = (uint16_t)id;
+  }
+  ++s.nFree;
+  --s.size;
+  QT_SYNC();
+}
+
+// Move the live entries to the top of the list array (order preserved) and refresh Node::lit.
+QT_HD void qt_compact(Work& w, State& s) {
+  QT_SYNC();
+  int wp = w.listCap;
+  for (int rp = w.listCap - 1; rp >= s.head; --rp) {
+    const uint16_t id = w.list[rp];
+    if (id != 0xFFFF) {
+      --wp;
+      if (QT_LANE0) { w.list[wp] = id; w.nodes[id].lit = (uint16_t)wp; }
+    }
+  }
+  s.head = wp;
+  QT_SYNC();
+}
+
+// keys[0..nkeys) hold vToDistributeKeys in order.  Writes the selected keys (reference output order) to
+// out[] and returns their number.  width = maxX-minX, height = maxY-minY.
+QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, uint32_t* out, int outCap) {
+  // nIni = round((float)width / height); hX = (float)width / nIni   (:545-547)
+  const float ratio = (float)width / (float)height;
+  const int nIni = (int)roundf(ratio);
+  if (nIni <= 0 || nIni > 4 || nkeys == 0) return 0;
+  const float hX = (float)width / (float)nIni;
+
+  State s;
+  s.head = w.listCap;
+  s.size = 0;
+  s.nA = 0;
+  s.nFree = w.nodeCap;
+  for (int i = QT_LANE; i < w.nodeCap; i += (QT_DEVICE ? 64 : 1)) w.freeIds[i] = (uint16_t)(w.nodeCap - 1 - i);
+  QT_SYNC();
+
+  // initial nodes, pushed BACK in order i = 0..nIni-1 (:555-567); keys go to node (int)(x / hX) (:570-573);
+  // empty initial nodes are erased (:577-585).  nIni <= 4 (aspect ratio < 4.5:1) is enforced by the caller.
+  {
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    const int last = nIni - 1;
+    qt_partition(w.keys, w.tmp, 0, nkeys,
+                 [hX, last](uint32_t k) -> int { int g = (int)((float)key_x(k) / hX); return g > last ? last : g; }, cnt);
+    int live = 0;
+    for (int i = 0; i < nIni; ++i) live += cnt[i] > 0 ? 1 : 0;
+    s.head = w.listCap - live;
+    s.size = live;
+    int p = s.head;
+    uint32_t begin = 0;
+    for (int i = 0; i < nIni; ++i) {
+      if (cnt[i] > 0) {
+        const int id = qt_alloc(w, s);
+        if (QT_LANE0) {
+          Node nd;
+          nd.x0 = (int16_t)(int)(hX * (float)i);
+          nd.x1 = (int16_t)(int)(hX * (float)(i + 1));
+          nd.y0 = 0;
+          nd.y1 = (int16_t)height;
+          nd.begin = begin; nd.count = cnt[i]; nd.lit = (uint16_t)p; nd.noMore = (cnt[i] == 1) ? 1 : 0;
+          w.nodes[id] = nd;
+          w.list[p] = (uint16_t)id;
+        }
+        ++p;
+      }
+      begin += cnt[i];
+    }
+    QT_SYNC();
+  }
+
+  bool bFinish = false;
+  while (!bFinish) {
+    qt_compact(w, s);
+    const int prevSize = s.size;
+    int nToExpand = 0;
+    s.nA = 0;
+    const int oldHead = s.head;
+    for (int pos = oldHead; pos < w.listCap; ++pos) {  // children are pushed in front of oldHead: not visited
+      const uint16_t id = w.list[pos];
+      if (id == 0xFFFF) continue;
+      if (w.nodes[id].noMore) continue;
+      qt_split(w, s, id, &nToExpand);
+    }
+    if (s.size >= N || s.size == prevSize) {
+      bFinish = true;
+    } else if (s.size + nToExpand * 3 > N) {
+      while (!bFinish) {
+        const int prevSize2 = s.size;
+        // vPrev = vSize; vSize.clear(); sort(vPrev)
+        const int nPrev = s.nA;
+        QT_SYNC();
+        for (int i = QT_LANE; i < nPrev; i += (QT_DEVICE ? 64 : 1)) w.vB[i] = w.vA[i];
+        QT_SYNC();
+        s.nA = 0;
+        if (QT_LANE0) qt_std_sort(w.vB, nPrev);
+        QT_SYNC();
+        // compaction keeps ids stable (vB holds ids), only Node::lit moves
+        qt_compact(w, s);
+        for (int j = nPrev - 1; j >= 0; --j) {
+          const int id = (int)(w.vB[j] & 0xFFFF);
+          qt_split(w, s, id, nullptr);
+          if (s.size >= N) break;
+        }
+        if (s.size >= N || s.size == prevSize2) bFinish = true;
+      }
+    }
+  }
+
+  // retain the best point in each node, list order (:716-737)
+  QT_SYNC();
+  int nOut = 0;
+  for (int pos = s.head; pos < w.listCap; ++pos) {
+    const uint16_t id = w.list[pos];
+    if (id == 0xFFFF) continue;
+    const Node nd = w.nodes[id];
+    const uint32_t bk = qt_best_key(w.keys, nd.begin, nd.count);
+    if (nOut < outCap && QT_LANE0) out[nOut] = bk;
+    ++nOut;
+  }
+  QT_SYNC();
+  return nOut;
+}
+
+}  // namespace morbqt

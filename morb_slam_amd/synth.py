@@ -44,7 +44,7 @@ def make_image(w=752, h=480, seed=0, n_shapes=None, noise_sigma=2.0):
             m = (np.abs(u) <= s * 0.8) & (np.abs(v) <= s * 0.4)
             sub[m] = grey
     img += rng.normal(0, noise_sigma, size=img.shape)
-    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))
 
 
 def make_stereo_pair(w=752, h=480, seed=0, dmin=2.0, dmax=60.0):
@@ -60,7 +60,7 @@ def make_stereo_pair(w=752, h=480, seed=0, dmin=2.0, dmax=60.0):
     rows = np.arange(h)[:, None]
     L = left.astype(np.float32)
     right = L[rows, x0] * (1 - f) + L[rows, x1] * f + rng.normal(0, 1.0, size=L.shape)
-    return left, np.clip(np.rint(right), 0, 255).astype(np.uint8)
+    return left, np.ascontiguousarray(np.clip(np.rint(right), 0, 255).astype(np.uint8))
 
 
 def shift_image(img, dx, dy):
@@ -68,4 +68,4 @@ def shift_image(img, dx, dy):
     h, w = img.shape
     ys = np.clip(np.arange(h) - dy, 0, h - 1)
     xs = np.clip(np.arange(w) - dx, 0, w - 1)
-    return img[ys][:, xs]
+    return np.ascontiguousarray(img[ys][:, xs])

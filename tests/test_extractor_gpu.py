@@ -1,0 +1,120 @@
+"""GPU parity: HIP ORBextractor (through the C ABI) vs the CPU oracle, stage by stage and end to end.
+Bit-exact everywhere: pyramid bytes, blurred bytes, FAST candidates (order included), quadtree selection
+(order included), angles (f32 bits), descriptors, final keypoint records and monoIndex."""
+import numpy as np
+import pytest
+
+from morb_slam_amd.synth import make_image, make_stereo_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _extractors(nfeat, **kw):
+    from morb_slam_amd import ORBextractor
+    from oracle_lib import OracleExtractor
+    args = dict(scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7)
+    args.update(kw)
+    return ORBextractor(nfeat, args["scaleFactor"], args["nlevels"], args["iniThFAST"], args["minThFAST"]), \
+        OracleExtractor(nfeat, args["scaleFactor"], args["nlevels"], args["iniThFAST"], args["minThFAST"])
+
+
+def _compare(img, nfeat, lap=(0, 0), stages=True, **kw):
+    g, o = _extractors(nfeat, **kw)
+    mono_g, kg, dg = g(img, None, lap)
+    mono_o, ko, do = o(img, lap)
+    if stages:
+        for l in range(g.GetLevels()):
+            assert g.level_size(l) == o.level_size(l)
+            np.testing.assert_array_equal(g.pyramid_level(l), o.level_image(l), err_msg=f"pyramid level {l}")
+            co, cg = o.level_candidates(l), g.level_candidates(l)
+            assert len(co) == len(cg), f"level {l}: {len(cg)} candidates vs oracle {len(co)}"
+            for f in ("x", "y", "response"):
+                np.testing.assert_array_equal(cg[f], co[f], err_msg=f"candidates level {l} field {f}")
+            so, sg = o.level_keypoints(l), g.level_keypoints(l)
+            assert len(so) == len(sg), f"level {l}: {len(sg)} selected vs oracle {len(so)}"
+            for f in ("x", "y", "response", "octave", "size"):
+                np.testing.assert_array_equal(sg[f], so[f], err_msg=f"selected level {l} field {f}")
+            bo = o.level_blurred(l)
+            if bo is not None:
+                np.testing.assert_array_equal(g.blurred_level(l), bo, err_msg=f"blur level {l}")
+    assert mono_g == mono_o
+    assert len(kg) == len(ko)
+    assert kg.tobytes() == ko.tobytes(), "keypoint records differ"
+    np.testing.assert_array_equal(dg, do)
+    return len(kg)
+
+
+def test_vga_1200_bit_exact():
+    left, right = make_stereo_pair(752, 480, seed=1)
+    n = _compare(left, 1200)
+    assert n > 1000
+    _compare(right, 1200)
+
+
+def test_mono_lapping_reverse_fill():
+    # Frame.cc:428 passes [0,1000] for mono: every keypoint of a 752-wide image is "stereo" and the output is
+    # filled from the back; monoIndex 0
+    img = make_image(752, 480, seed=3)
+    g, o = _extractors(1000)
+    mono_g, kg, dg = g(img, None, (0, 1000))
+    mono_o, ko, do = o(img, (0, 1000))
+    assert mono_g == mono_o == 0
+    assert kg.tobytes() == ko.tobytes()
+    np.testing.assert_array_equal(dg, do)
+
+
+def test_fisheye_512_partial_lap():
+    img = make_image(512, 512, seed=5)
+    _compare(img, 1500, lap=(100, 400))
+
+
+def test_low_texture_threshold_fallback_and_short_quota():
+    # nearly flat image: most cells need the minThFAST pass and the quadtree ends short of nfeatures
+    rng = np.random.default_rng(7)
+    img = np.full((480, 752), 120, np.uint8)
+    img[100:140, 200:260] = 200
+    img[300:310, 500:700] = 30
+    img = (img.astype(np.int16) + rng.integers(-3, 4, img.shape)).clip(0, 255).astype(np.uint8)
+    n = _compare(img, 1200)
+    assert n < 1200
+
+
+def test_noise_image_many_candidates():
+    # white noise: tens of thousands of FAST candidates, exercises the global-memory key path of the quadtree
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (480, 752), dtype=np.uint8)
+    _compare(img, 1200)
+
+
+def test_other_sizes_and_params():
+    _compare(make_image(640, 480, seed=21), 500, scaleFactor=1.2, nlevels=8)
+    _compare(make_image(333, 217, seed=22), 300, nlevels=4)
+    _compare(make_image(1280, 720, seed=23), 2000, iniThFAST=15, minThFAST=5)
+
+
+def test_1080p_4000():
+    _compare(make_image(1920, 1080, seed=31), 4000)
+
+
+def test_empty_image_returns_minus_one():
+    g, _ = _extractors(1000)
+    mono, k, d = g(np.zeros((0, 0), np.uint8))
+    assert mono == -1 and len(k) == 0
+
+
+def test_batch_matches_single():
+    import torch
+    from morb_slam_amd import KP_DTYPE
+    g, o = _extractors(1200)
+    imgs = np.stack([make_image(752, 480, seed=40 + i) for i in range(6)])
+    d = torch.from_numpy(imgs).cuda()
+    kps, desc, cnt, mono = g.extract_batch(d)
+    torch.cuda.synchronize()
+    cnt = cnt.cpu().numpy(); mono = mono.cpu().numpy()
+    kps = kps.cpu().numpy(); desc = desc.cpu().numpy()
+    for i in range(len(imgs)):
+        mo, ko, do = o(imgs[i])
+        assert cnt[i] == len(ko) and mono[i] == mo
+        kg = kps[i, :cnt[i]].reshape(-1).view(KP_DTYPE)
+        assert kg.tobytes() == ko.tobytes()
+        np.testing.assert_array_equal(desc[i, :cnt[i]], do)
