@@ -84,11 +84,13 @@ int morb_extractor_level_candidates_host(const morb_extractor*, int img, int lvl
 int morb_extractor_level_keypoints_host(const morb_extractor*, int img, int lvl, morb_keypoint* out, int cap,
                                         int* n);
 
-/* Per-stage device time (ms) of the last morb_extract_batch when profiling is enabled with
- * morb_extractor_set_profiling(e, 1): stages 0..6 = pyramid, blur, fast, distribute, layout, describe, total.
+/* Per-stage device time: with profiling enabled every morb_extract_batch records HIP events on its stream at
+ * the stage boundaries (no host synchronisation in the call).  morb_extractor_stage_ms waits for the recorded
+ * calls (at most the last 64), writes the per-call AVERAGE in ms for stages 0..6 = pyramid, blur, fast,
+ * distribute, layout, describe, total, resets the window and returns the number of calls averaged.
  * Mirrors the reference's REGISTER_TIMES spans (src/Frame.cc:190-206). */
 int morb_extractor_set_profiling(morb_extractor*, int enable);
-int morb_extractor_stage_ms(const morb_extractor*, float* ms7);
+int morb_extractor_stage_ms(morb_extractor*, float* ms7);
 
 #ifdef __cplusplus
 }

@@ -576,8 +576,12 @@ struct morb_extractor {
   uint8_t* d_img = nullptr; size_t imgBytes = 0;
   morb_keypoint* d_kps1 = nullptr; uint8_t* d_desc1 = nullptr; int *d_cnt1 = nullptr, *d_mono1 = nullptr;
   std::vector<int> lapLast;  // host mirror of d_lap
+  // profiling: a ring of event sets, one per morb_extract_batch call, read back (and averaged) on demand so the
+  // timed region never synchronises with the host
   bool profiling = false;
-  hipEvent_t ev[8] = {nullptr};
+  static constexpr int kProfRing = 64;
+  std::vector<hipEvent_t> ev;  // [kProfRing][7]
+  int profCalls = 0;
   float stageMs[7] = {0};
 };
 
@@ -770,7 +774,6 @@ int morb_extractor_create(morb_extractor** out, int nfeatures, float scaleFactor
     delete e;
     return MORB_ERR_HIP;
   }
-  for (auto& ev : e->ev) (void)hipEventCreate(&ev);
   *out = e;
   return MORB_OK;
 }
@@ -782,6 +785,7 @@ void morb_extractor_destroy(morb_extractor* e) {
   free_buffers(e);
   free_staging(e);
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+  e->ev.clear();
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -807,13 +811,34 @@ int morb_extractor_max_keypoints(const morb_extractor* e) {
 }
 int morb_extractor_set_profiling(morb_extractor* e, int enable) {
   MORB_REQUIRE(e, MORB_ERR_INVALID, "extractor is NULL");
+  MORB_HIP_CHECK(hipSetDevice(e->device));
   e->profiling = enable != 0;
+  e->profCalls = 0;
+  if (e->profiling && e->ev.empty()) {
+    e->ev.resize((size_t)morb_extractor::kProfRing * 7, nullptr);
+    for (auto& ev : e->ev) MORB_HIP_CHECK(hipEventCreate(&ev));
+  }
   return MORB_OK;
 }
-int morb_extractor_stage_ms(const morb_extractor* e, float* ms7) {
+int morb_extractor_stage_ms(morb_extractor* e, float* ms7) {
   MORB_REQUIRE(e && ms7, MORB_ERR_INVALID, "NULL argument");
+  const int n = e->profCalls < morb_extractor::kProfRing ? e->profCalls : morb_extractor::kProfRing;
+  for (int i = 0; i < 7; ++i) e->stageMs[i] = 0.f;
+  for (int c = 0; c < n; ++c) {
+    hipEvent_t* ev = &e->ev[(size_t)c * 7];
+    MORB_HIP_CHECK(hipEventSynchronize(ev[6]));
+    for (int i = 0; i < 6; ++i) {
+      float ms = 0.f;
+      MORB_HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+      e->stageMs[i] += ms / n;
+    }
+    float ms = 0.f;
+    MORB_HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[6]));
+    e->stageMs[6] += ms / n;
+  }
   for (int i = 0; i < 7; ++i) ms7[i] = e->stageMs[i];
-  return MORB_OK;
+  e->profCalls = 0;
+  return n;
 }
 
 int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int width, int height, int stride,
@@ -841,7 +866,8 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
     }
   }
 
-  auto mark = [&](int i) { if (e->profiling) (void)hipEventRecord(e->ev[i], st); };
+  hipEvent_t* evs = e->profiling ? &e->ev[(size_t)(e->profCalls % morb_extractor::kProfRing) * 7] : nullptr;
+  auto mark = [&](int i) { if (evs) (void)hipEventRecord(evs[i], st); };
   mark(0);
   {
     const LevelGeom& g0 = e->geom[0];
@@ -874,11 +900,7 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
                      e->d_blur, e->d_sel, e->d_selCnt, e->selPerImg, e->d_slots, d_kps, d_desc, cap);
   mark(6);
   MORB_HIP_CHECK(hipGetLastError());
-  if (e->profiling) {
-    MORB_HIP_CHECK(hipEventSynchronize(e->ev[6]));
-    for (int i = 0; i < 6; ++i) (void)hipEventElapsedTime(&e->stageMs[i], e->ev[i], e->ev[i + 1]);
-    (void)hipEventElapsedTime(&e->stageMs[6], e->ev[0], e->ev[6]);
-  }
+  if (e->profiling) ++e->profCalls;
   return MORB_OK;
 }
 

@@ -111,5 +111,6 @@ class ORBextractor:
 
     def stage_ms(self):
         ms = np.zeros(7, np.float32)
-        check(self._L.morb_extractor_stage_ms(self._h, ptr(ms)))
+        n = check(self._L.morb_extractor_stage_ms(self._h, ptr(ms)))
+        self.last_profile_calls = n
         return dict(zip(["pyramid", "blur", "fast", "distribute", "layout", "describe", "total"], ms.tolist()))

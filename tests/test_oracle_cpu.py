@@ -1,0 +1,326 @@
+"""CPU tests (no GPU): the oracle against known answers / golden fixtures / independent definitions, the
+host instantiation of the device quadtree against the oracle, and the C-ABI surface."""
+import ctypes as C
+import hashlib
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle_lib import KP_DTYPE, OracleExtractor, _p, lib
+from morb_slam_amd.synth import make_image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+# ---- constants the reference itself pins (SURVEY §8c "golden material": tables only) ------------------
+def test_umax_and_quota_tables():
+    t = OracleExtractor(1200).tables()
+    assert t["umax"].tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    assert t["feat_per_level"].tolist() == [261, 217, 181, 151, 126, 105, 87, 72]       # C2 quotas
+    assert OracleExtractor(1000).tables()["feat_per_level"].tolist() == [217, 181, 151, 126, 105, 87, 73, 60]
+    assert OracleExtractor(1500).tables()["feat_per_level"].tolist() == [326, 271, 226, 189, 157, 131, 109, 91]
+    assert OracleExtractor(4000).tables()["feat_per_level"].tolist() == [869, 724, 603, 503, 419, 349, 291, 242]
+    sc = t["scale"]
+    assert sc[0] == 1.0 and sc[1] == np.float32(1.2) and sc[2] == np.float32(1.2) * np.float32(1.2)
+
+
+@pytest.mark.parametrize("wh,sizes", [
+    ((752, 480), [(752, 480), (627, 400), (522, 333), (435, 278), (363, 231), (302, 193), (252, 161), (210, 134)]),
+    ((512, 512), [(512, 512), (427, 427), (356, 356), (296, 296), (247, 247), (206, 206), (171, 171), (143, 143)]),
+])
+def test_level_sizes(wh, sizes):
+    o = OracleExtractor(500)
+    o(make_image(wh[0], wh[1], seed=2))
+    assert [o.level_size(l) for l in range(8)] == sizes
+
+
+# ---- OpenCV primitive restatements vs independent definitions ----------------------------------------
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+        (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def _fast_bruteforce(img, t):
+    """FAST-9/16 + score by exhaustive threshold search + strict 3x3 NMS, straight from the definition."""
+    h, w = img.shape
+    score = np.zeros((h, w), np.int32)
+
+    def is_corner(y, x, thr):
+        v = int(img[y, x])
+        ring = [int(img[y + dy, x + dx]) for dx, dy in RING]
+        for pol in (1, -1):
+            flags = [(pol * (v - q)) > thr for q in ring]
+            ff = flags + flags
+            run = 0
+            for f in ff:
+                run = run + 1 if f else 0
+                if run >= 9:
+                    return True
+        return False
+
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            if is_corner(y, x, t):
+                s = t
+                while is_corner(y, x, s + 1):
+                    s += 1
+                score[y, x] = s  # largest threshold for which it is still a corner
+    out = []
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            s = score[y, x]
+            if s == 0 and not is_corner(y, x, t):
+                continue
+            nb = score[y - 1:y + 2, x - 1:x + 2].copy()
+            nb[1, 1] = -1
+            if (s > nb).all():
+                out.append((x, y, s))
+    return out
+
+
+def test_fast_matches_definition():
+    rng = np.random.default_rng(5)
+    L = lib()
+    for trial, t in enumerate((20, 7, 7, 1)):
+        img = make_image(96, 80, seed=50 + trial)[:40, :44].copy()
+        if trial == 3:
+            img = rng.integers(0, 256, (24, 30), dtype=np.uint8)
+        h, w = img.shape
+        out = np.zeros(4096, KP_DTYPE)
+        n = L.orc_fast(_p(img), w, h, w, t, 1, _p(out), len(out))
+        got = [(int(k["x"]), int(k["y"]), int(k["response"])) for k in out[:n]]
+        assert got == _fast_bruteforce(img, t)
+        assert all(k["size"] == 7 and k["angle"] == -1 and k["class_id"] == -1 for k in out[:n])
+
+
+def test_gaussian_kernel_and_impulse():
+    L = lib()
+    k = np.array([18, 34, 48, 56, 48, 34, 18])
+    assert k.sum() == 256
+    const = np.full((20, 31), 77, np.uint8)
+    out = np.zeros_like(const)
+    L.orc_gaussian7(_p(const), 31, 20, 31, _p(out), 31)
+    assert (out == 77).all()
+    imp = np.zeros((15, 15), np.uint8)
+    imp[7, 7] = 255
+    out = np.zeros_like(imp)
+    L.orc_gaussian7(_p(imp), 15, 15, 15, _p(out), 15)
+    exp = (np.outer(k, k) * 255 + 32768) >> 16
+    np.testing.assert_array_equal(out[4:11, 4:11], exp)
+    # BORDER_REFLECT_101 at the edges == blurring the reflect-padded image
+    img = make_image(80, 76, seed=9)[:30, :40].copy()
+    out = np.zeros_like(img)
+    L.orc_gaussian7(_p(img), 40, 30, 40, _p(out), 40)
+    pad = np.pad(img.astype(np.int64), 3, mode="reflect")
+    ref = np.zeros((30, 40), np.int64)
+    for dy in range(7):
+        for dx in range(7):
+            ref += k[dy] * k[dx] * pad[dy:dy + 30, dx:dx + 40]
+    np.testing.assert_array_equal(out, (ref + 32768) >> 16)
+
+
+def test_border_reflect101():
+    L = lib()
+    w, h, b = 9, 7, 19
+    buf = np.zeros((h + 2 * b, w + 2 * b), np.uint8)
+    inner = np.arange(w * h, dtype=np.uint8).reshape(h, w)
+    buf[b:b + h, b:b + w] = inner
+    L.orc_border101(_p(buf), w, h, w + 2 * b, b)
+    np.testing.assert_array_equal(buf, np.pad(inner, b, mode="reflect"))
+
+
+def test_resize_properties():
+    L = lib()
+    src = make_image(120, 90, seed=4)
+    same = np.zeros_like(src)
+    L.orc_resize_linear(_p(src), 120, 90, 120, _p(same), 120, 90, 120)
+    np.testing.assert_array_equal(same, src)            # scale 1: fx = 0 everywhere
+    const = np.full((90, 120), 201, np.uint8)
+    dst = np.zeros((75, 100), np.uint8)
+    L.orc_resize_linear(_p(const), 120, 90, 120, _p(dst), 100, 75, 100)
+    assert (dst == 201).all()
+    # against a float bilinear (half-pixel centres): fixed point stays within 1 grey level
+    dst = np.zeros((75, 100), np.uint8)
+    L.orc_resize_linear(_p(src), 120, 90, 120, _p(dst), 100, 75, 100)
+    xs = (np.arange(100) + 0.5) * 1.2 - 0.5
+    ys = (np.arange(75) + 0.5) * 1.2 - 0.5
+    x0 = np.clip(np.floor(xs).astype(int), 0, 118); y0 = np.clip(np.floor(ys).astype(int), 0, 88)
+    fx = np.clip(xs - x0, 0, 1)[None, :]; fy = np.clip(ys - y0, 0, 1)[:, None]
+    S = src.astype(np.float64)
+    ref = (S[y0][:, x0] * (1 - fx) + S[y0][:, x0 + 1] * fx) * (1 - fy) + (S[y0 + 1][:, x0] * (1 - fx) + S[y0 + 1][:, x0 + 1] * fx) * fy
+    assert np.abs(dst.astype(np.float64) - ref).max() <= 1.0
+
+
+def test_fast_atan2_accuracy_and_quadrants():
+    L = lib()
+    rng = np.random.default_rng(3)
+    for _ in range(2000):
+        y, x = (float(v) for v in rng.integers(-200000, 200000, 2))
+        a = L.orc_fast_atan2(y, x)
+        ref = math.degrees(math.atan2(y, x)) % 360.0
+        d = abs(a - ref)
+        assert min(d, 360 - d) < 0.3
+    assert L.orc_fast_atan2(0.0, 0.0) == 0.0
+    assert L.orc_fast_atan2(0.0, 5.0) == 0.0 and L.orc_fast_atan2(5.0, 0.0) == 90.0
+
+
+def test_sincosf_restatement_equals_libm():
+    L = lib()
+    libm = C.CDLL("libm.so.6")
+    libm.cosf.restype = C.c_float; libm.cosf.argtypes = [C.c_float]
+    libm.sinf.restype = C.c_float; libm.sinf.argtypes = [C.c_float]
+    rng = np.random.default_rng(1)
+    deg = np.concatenate([rng.random(20000) * 360, np.arange(0, 361, 0.5), [1e-5, 0.013, 44.99999, 45.00001]]).astype(np.float32)
+    rad = deg * np.float32(math.pi / 180.0)
+    for r in rad.tolist():
+        assert L.orc_cosf(r) == libm.cosf(r) and L.orc_sinf(r) == libm.sinf(r)   # exhaustive run: tools/check_sincosf.c
+
+
+# ---- golden fixtures (oracle_*: regression pins, see tests/golden/make_golden.py) ------------------------
+def test_golden_small_fixture():
+    z = np.load(os.path.join(GOLD, "oracle_extract_320x240.npz"))
+    o = OracleExtractor(300, 1.2, 4, 20, 7)
+    mono, k, d = o(z["image"], (100, 200))
+    assert mono == int(z["mono"])
+    assert k.tobytes() == z["kps"].tobytes()
+    np.testing.assert_array_equal(d, z["desc"])
+    assert [len(o.level_candidates(l)) for l in range(4)] == z["cand_counts"].tolist()
+    assert [len(o.level_keypoints(l)) for l in range(4)] == z["sel_counts"].tolist()
+    np.testing.assert_array_equal(make_image(320, 240, seed=1234), z["image"])   # synth generator is stable
+
+
+def test_golden_vga_hashes():
+    exp = dict(l.split() for l in open(os.path.join(GOLD, "oracle_extract_752x480_seed1.txt")))
+    img = make_image(752, 480, seed=1)
+    assert hashlib.sha256(img.tobytes()).hexdigest() == exp["image_sha256"]
+    o = OracleExtractor(1200)
+    mono, k, d = o(img)
+    assert len(k) == int(exp["n"]) and mono == int(exp["mono"])
+    assert hashlib.sha256(k.tobytes()).hexdigest() == exp["kps_sha256"]
+    assert hashlib.sha256(d.tobytes()).hexdigest() == exp["desc_sha256"]
+    for l in range(8):
+        assert hashlib.sha256(o.level_image(l).tobytes()).hexdigest() == exp[f"level{l}_pyr_sha256"]
+
+
+def test_extract_invariants():
+    img = make_image(752, 480, seed=8)
+    o = OracleExtractor(1000)
+    mono, k, d = o(img, (0, 1000))
+    assert mono == 0 and len(k) > 900                       # mono call: reverse fill (Frame.cc:428)
+    mono2, k2, d2 = o(img, (0, 0))
+    assert mono2 == len(k2) == len(k)
+    assert k2[::-1].tobytes() == k.tobytes() and np.array_equal(d2[::-1], d)
+    assert (k2["octave"][:-1] <= k2["octave"][1:]).all()    # level-major order
+    assert ((k2["angle"] >= 0) & (k2["angle"] < 360)).all()
+    lv = k2["octave"]
+    assert (k2["size"] == np.floor(31 * o.tables()["scale"][lv])).all()
+    m, kk, dd = o(np.zeros((0, 0), np.uint8).reshape(0, 0))
+    assert m == -1                                          # empty image (ORBextractor.cc:1011)
+
+
+# ---- device quadtree (host instantiation) vs the oracle's std::list/std::sort restatement ----------------
+@pytest.fixture(scope="module")
+def qt():
+    from morb_slam_amd import build
+    return C.CDLL(build.build_test_native())
+
+
+def _killer(n):
+    """median-of-3 killer permutation (Musser): drives introsort into its heapsort fallback."""
+    k = n // 2
+    a = [0] * n
+    for i in range(k):
+        a[2 * i if False else i] = 0
+    out = [0] * n
+    for i in range(1, k + 1):
+        if i % 2 == 1:
+            out[i - 1] = i
+            out[i] = k + i
+        out[k + i - 1] = 2 * i
+    return out
+
+
+def test_introsort_emulation_matches_libstdcpp(qt):
+    rng = np.random.default_rng(0)
+    cases = []
+    for t in range(1500):
+        n = int(rng.integers(0, 700))
+        cnt = rng.integers(2, 6 if t % 2 else 40, n).astype(np.uint64)
+        x0 = rng.integers(0, 8 if t % 3 else 700, n).astype(np.uint64)
+        v = (cnt << np.uint64(32)) | (x0 << np.uint64(16)) | np.arange(n, dtype=np.uint64)
+        if t % 7 == 0: v = np.sort(v)
+        if t % 11 == 0: v = np.sort(v)[::-1].copy()
+        cases.append(v)
+    for n in (64, 256, 1000, 4096):   # heapsort fallback path
+        kk = np.array(_killer(n), np.uint64)
+        cases.append((kk << np.uint64(32)) | np.arange(n, dtype=np.uint64))
+        cases.append(((kk // np.uint64(3)) << np.uint64(32)) | np.arange(n, dtype=np.uint64))
+    for v in cases:
+        a, b = v.copy(), v.copy()
+        qt.qt_host_sort(_p(a), len(a)); qt.qt_ref_std_sort(_p(b), len(b))
+        np.testing.assert_array_equal(a, b)
+
+
+def test_quadtree_matches_oracle(qt):
+    L = lib()
+    rng = np.random.default_rng(0)
+    checked = 0
+    for t in range(250):
+        W = int(rng.integers(100, 1900)); H = int(rng.integers(80, 1100))
+        if not 1 <= round(W / H) <= 4:
+            continue
+        n = int(rng.integers(1, 5000)); N = int(rng.integers(1, 900))
+        if t % 3 == 0:
+            xs = np.clip(rng.normal(W / 2, W / 10, n), 3, W - 4).astype(int)
+            ys = np.clip(rng.normal(H / 2, H / 10, n), 3, H - 4).astype(int)
+        else:
+            xs = rng.integers(3, W - 3, n); ys = rng.integers(3, H - 3, n)
+        pos = np.unique(ys * 4096 + xs); rng.shuffle(pos)
+        xs, ys = pos % 4096, pos // 4096; n = len(pos)
+        resp = rng.integers(7, 60 if t % 2 else 255, n)
+        kin = np.zeros(n, KP_DTYPE)
+        kin["x"], kin["y"], kin["response"], kin["size"], kin["angle"], kin["class_id"] = xs, ys, resp, 7, -1, -1
+        kout = np.zeros(4 * N + 64, KP_DTYPE)
+        m = L.orc_distribute(_p(kin), n, 16, 16 + W, 16, 16 + H, N, _p(kout), len(kout))
+        keys = (xs.astype(np.uint32) | (ys.astype(np.uint32) << 12) | (resp.astype(np.uint32) << 24)).astype(np.uint32)
+        out = np.zeros(4 * N + 64, np.uint32)
+        m2 = qt.qt_host_distribute(_p(keys), n, W, H, N, _p(out), len(out))
+        assert m == m2
+        np.testing.assert_array_equal(out[:m] & 0xFFF, kout["x"][:m].astype(np.uint32))
+        np.testing.assert_array_equal((out[:m] >> 12) & 0xFFF, kout["y"][:m].astype(np.uint32))
+        np.testing.assert_array_equal(out[:m] >> 24, kout["response"][:m].astype(np.uint32))
+        checked += 1
+    assert checked > 150
+
+
+# ---- C ABI surface -------------------------------------------------------------------------------------
+def test_c_abi_exports_every_declared_symbol():
+    from morb_slam_amd import capi
+    hdr = ""
+    inc = os.path.join(ROOT, "include")
+    for f in sorted(os.listdir(inc)):
+        if f.endswith(".h"):
+            hdr += open(os.path.join(inc, f)).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(morb_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 15
+    L = C.CDLL(capi.LIB_PATH)   # loads without a GPU; no compute call is made here
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+
+
+def test_product_path_has_no_cpu_fallback():
+    """The package must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "morb_slam_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cc", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                if f == "build.py":
+                    continue  # build_oracle() only compiles the checker for the tests
+                assert "oracle_lib" not in txt and "liboracle" not in txt, f
+                assert not re.search(r'#include\s*[<"][^>"]*oracle', txt), f
+                assert not re.search(r"^\s*(from|import)\s+\S*oracle", txt, flags=re.M), f
