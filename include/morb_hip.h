@@ -92,6 +92,60 @@ int morb_extractor_level_keypoints_host(const morb_extractor*, int img, int lvl,
 int morb_extractor_set_profiling(morb_extractor*, int enable);
 int morb_extractor_stage_ms(morb_extractor*, float* ms7);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Matchers: ORBmatcher (include/ORBmatcher.h:36-129, src/ORBmatcher.cc) and the per-frame stereo matchers
+ * of Frame.cc.  The reference walks Frame/KeyFrame/MapPoint objects; the ABI takes the fields each function
+ * reads, flattened: features of image i live at [i*cap, i*cap + count[i]) of the keypoint / descriptor arrays
+ * (the layout morb_extract_batch writes).  All array arguments are DEVICE pointers; calls are asynchronous
+ * on `stream` (NULL = the matcher's own stream).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct morb_matcher morb_matcher;
+int morb_matcher_create(morb_matcher** out, int device);
+void morb_matcher_destroy(morb_matcher*);
+
+/* static int ORBmatcher::DescriptorDistance(a, b)  ORBmatcher.h:43, ORBmatcher.cc:1880-1894; n pairs of 32-byte
+ * descriptors -> n distances. */
+int morb_hamming_pairs(morb_matcher*, const uint8_t* d_a, const uint8_t* d_b, int n, int* d_out, void* stream);
+
+/* cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, matches, 2) as Frame::ComputeStereoFishEyeMatches uses
+ * it (Frame.cc:46, :1242).  Problem p: query rows [qOff[p], nq[p]) of d_query + p*qPitch*32, train rows
+ * [tOff[p], nt[p]) likewise (qOff/tOff NULL = 0: monoLeft / monoRight in the reference).  Output for query row
+ * r (relative to qOff): d_idx[(p*qPitch + r)*2 + {0,1}] = train index relative to tOff (-1 if absent),
+ * d_dist likewise; ties: lower train index first. */
+int morb_hamming_knn2_batch(morb_matcher*, int nprob, const uint8_t* d_query, const int* d_nq, int qPitch,
+                            const int* d_qOff, const uint8_t* d_train, const int* d_nt, int tPitch, const int* d_tOff,
+                            int* d_idx, int* d_dist, void* stream);
+
+/* void Frame::ComputeStereoMatches()  Frame.cc:889-1047 for nframes rectified stereo frames whose images the
+ * extractor has just processed in ONE batch with left = image 2f, right = image 2f+1 (it reads the
+ * extractor's mvImagePyramid like the reference does, Frame.cc:895,974,987).  mbf, mb as Frame::mbf / mb.
+ * Outputs mvuRight / mvDepth: d_uRight[f*cap + i], d_depth[f*cap + i] for left keypoint i (-1 = no match). */
+int morb_stereo_match_batch(morb_matcher*, const morb_extractor*, int nframes, const morb_keypoint* d_kps,
+                            const uint8_t* d_desc, const int* d_count, int cap, float mbf, float mb, float* d_uRight,
+                            float* d_depth, void* stream);
+
+/* DBoW2 TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup)
+ * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1218-1259) for every feature of nimg images: the vocabulary is
+ * a k-ary tree in arrays (node 0 = root; children of n = firstChild[n] .. firstChild[n]+k-1; firstChild < 0 =
+ * leaf; one 32-byte descriptor per node).  d_wordId = leaf node reached, d_nodeId = ancestor at level
+ * L - levelsup: the FeatureVector key that SearchByBoW / SearchForTriangulation bucket on (Frame::ComputeBoW,
+ * Frame.cc:822-827, levelsup = 4). */
+int morb_bow_transform_batch(morb_matcher*, int nimg, const uint8_t* d_desc, const int* d_count, int cap,
+                             const uint8_t* d_nodeDesc, const int* d_firstChild, int k, int L, int levelsup,
+                             int* d_wordId, int* d_nodeId, void* stream);
+
+/* int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)
+ * ORBmatcher.h:68, ORBmatcher.cc:218-395 (non-fisheye branch) for npairs (keyframe, frame) pairs drawn from a
+ * pool of nimg images: pair p matches image d_kfImg[p] (as pKF) against image d_fImg[p] (as F).
+ * d_node[i*cap + j] = FeatureVector node id of feature j (negative = not in the FeatureVector);
+ * d_hasMP[i*cap + j] != 0 <=> vpMapPointsKF[j] is non-NULL and not bad.  nnratio / checkOri = the ORBmatcher
+ * constructor arguments.  d_matchF[p*cap + j] = keyframe feature matched to frame feature j (-1 = none; the
+ * adapter maps it to vpMapPointsKF[...]); d_nmatches[p] = the return value. */
+int morb_search_by_bow_batch(morb_matcher*, int npairs, const int* d_kfImg, const int* d_fImg, int nimg,
+                             const morb_keypoint* d_kps, const uint8_t* d_desc, const int* d_node, const int* d_count,
+                             const uint8_t* d_hasMP, int cap, float nnratio, int checkOri, int* d_matchF,
+                             int* d_nmatches, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

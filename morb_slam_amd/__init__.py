@@ -3,3 +3,4 @@ local-BA hot path.  The compute lives in libmorb_hip.so (hand-written HIP for gf
 include/morb_hip.h); this package is the host-side mirror of the reference class surfaces."""
 from .capi import KP_DTYPE, MorbError  # noqa: F401
 from .extractor import ORBextractor  # noqa: F401
+from .matcher import ORBmatcher  # noqa: F401

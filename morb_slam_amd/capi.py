@@ -58,6 +58,14 @@ def lib():
         L.morb_extractor_level_keypoints_host.argtypes = [vp, i, i, vp, i, C.POINTER(i)]
         L.morb_extractor_set_profiling.argtypes = [vp, i]
         L.morb_extractor_stage_ms.argtypes = [vp, vp]
+        L.morb_matcher_create.argtypes = [C.POINTER(vp), i]
+        L.morb_matcher_destroy.argtypes = [vp]
+        L.morb_matcher_destroy.restype = None
+        L.morb_hamming_pairs.argtypes = [vp, vp, vp, i, vp, vp]
+        L.morb_hamming_knn2_batch.argtypes = [vp, i, vp, vp, i, vp, vp, vp, i, vp, vp, vp, vp]
+        L.morb_stereo_match_batch.argtypes = [vp, vp, i, vp, vp, vp, i, f, f, vp, vp, vp]
+        L.morb_bow_transform_batch.argtypes = [vp, i, vp, vp, i, vp, vp, i, i, i, vp, vp, vp]
+        L.morb_search_by_bow_batch.argtypes = [vp, i, vp, vp, i, vp, vp, vp, vp, vp, i, f, i, vp, vp, vp]
         _lib = L
     return _lib
 

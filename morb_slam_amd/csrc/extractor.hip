@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "common.h"
+#include "extractor_internal.h"
 #include "quadtree.h"
 
 namespace morb {
@@ -41,34 +42,6 @@ void set_error(const char* fmt, ...) {
 using namespace morb;
 
 namespace {
-
-constexpr int kMaxLevels = 16;
-constexpr int EDGE = 19;        // EDGE_THRESHOLD  ORBextractor.cc:73
-constexpr int HALF_PATCH = 15;  // HALF_PATCH_SIZE :72
-constexpr int PATCH = 31;       // PATCH_SIZE :71
-constexpr int MINB = 16;        // minBorderX/Y = EDGE_THRESHOLD - 3 (:746-747)
-constexpr int kLdsKeys = 3072;  // distribute: key arrays live in LDS up to this many candidates per level
-
-struct LevelGeom {
-  int w, h;
-  int pstride, bstride;
-  unsigned long long pyrOff, pyrImg;    // bytes: slab offset, per-image size
-  unsigned long long blurOff, blurImg;
-  int nCols, nRows, wCell, hCell, cellBase;
-  int maxBorderX, maxBorderY;
-  int quota, nIni;
-  int nodeCap, listCap;
-  int selBase, selCap;                  // per-image offsets into sel[]
-  unsigned long long qtOff, qtImg;      // element offsets into the global key scratch
-  int blurTileBase, blurTilesX, blurTilesY;
-  int xtabOff, ytabOff;                 // offsets (entries) into the resize tables
-  float scale;                          // mvScaleFactor[l]
-  float kpSize;                         // (float)(int)(PATCH_SIZE * mvScaleFactor[l])  (:831)
-};
-
-struct ResizeTab {  // one entry per padded destination column / row
-  short s0, s1, c0, c1;  // source index (clipped), source index + 1 (clipped), fixed-point weights (2048 = 1)
-};
 
 __constant__ int c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
@@ -553,38 +526,6 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
 // =====================================================================================================
 // Host side
 // =====================================================================================================
-struct morb_extractor {
-  int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0, device = 0;
-  float scaleFactor = 1.2f;
-  std::vector<float> scale, invScale, sigma2, invSigma2;
-  std::vector<int> quota;
-  int umax[16];
-
-  int W = 0, H = 0, nimgCap = 0, nimgLast = 0;
-  LevelGeom geom[kMaxLevels];
-  int totalCells = 0, cellCap = 0, tilePitch = 0, tileRows = 0, maxCells = 0, maxNodeCap = 0, maxListCap = 0;
-  int selPerImg = 0, blurTiles = 0, outCap = 0;
-  size_t pyrBytes = 0, blurBytes = 0, qtElems = 0, distSmem = 0;
-
-  hipStream_t stream = nullptr;
-  LevelGeom* d_geom = nullptr;
-  ResizeTab* d_tabs = nullptr;
-  uint8_t *d_pyr = nullptr, *d_blur = nullptr;
-  uint32_t *d_cand = nullptr, *d_qt = nullptr, *d_sel = nullptr;
-  int *d_candCnt = nullptr, *d_selCnt = nullptr, *d_slots = nullptr, *d_lap = nullptr;
-  // staging for the single-image host API
-  uint8_t* d_img = nullptr; size_t imgBytes = 0;
-  morb_keypoint* d_kps1 = nullptr; uint8_t* d_desc1 = nullptr; int *d_cnt1 = nullptr, *d_mono1 = nullptr;
-  std::vector<int> lapLast;  // host mirror of d_lap
-  // profiling: a ring of event sets, one per morb_extract_batch call, read back (and averaged) on demand so the
-  // timed region never synchronises with the host
-  bool profiling = false;
-  static constexpr int kProfRing = 64;
-  std::vector<hipEvent_t> ev;  // [kProfRing][7]
-  int profCalls = 0;
-  float stageMs[7] = {0};
-};
-
 namespace {
 
 static int cvRoundF(float v) { return (int)lrintf(v); }

@@ -1,0 +1,589 @@
+// Hamming matchers for MI355X (gfx950), batched over frames, behind the C ABI of include/morb_hip.h:
+//   M0  ORBmatcher::DescriptorDistance                 (reference src/ORBmatcher.cc:1880-1894)
+//   F1  Frame::ComputeStereoMatches                    (src/Frame.cc:889-1047)
+//   F2  cv::BFMatcher(NORM_HAMMING).knnMatch(k = 2)    (src/Frame.cc:46, :1242)
+//   M3  ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ..) (src/ORBmatcher.cc:218-395, non-fisheye branch)
+//   N3  DBoW2 vocabulary descent (FeatureVector node ids; Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1218-1259)
+// Every "first best wins" loop of the reference is restated as a lexicographic minimum over
+// (distance, position in the reference's iteration order), which is order-independent and therefore parallel;
+// the greedy "skip what is already matched" dependencies are kept by running them sequentially inside one
+// wave per independent unit (a BoW node, a frame).  Distances are 8 x (xor, popcount) on 32-bit words;
+// reductions are wave64 shuffles.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "extractor_internal.h"
+
+using namespace morb;
+
+namespace {
+
+constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;  // ORBmatcher.cc:35-37
+constexpr int EDGE_ = 19;
+
+struct Desc { uint32_t w[8]; };
+
+__device__ __forceinline__ Desc load_desc(const uint8_t* p) {
+  Desc d;
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 a = q[0], b = q[1];
+  d.w[0] = a.x; d.w[1] = a.y; d.w[2] = a.z; d.w[3] = a.w;
+  d.w[4] = b.x; d.w[5] = b.y; d.w[6] = b.z; d.w[7] = b.w;
+  return d;
+}
+__device__ __forceinline__ int hamming(const Desc& a, const Desc& b) {
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += __popc(a.w[i] ^ b.w[i]);
+  return s;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(v, off, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+// merge two sorted pairs (a1<=a2), (b1<=b2) of u64 keys -> the two smallest
+__device__ __forceinline__ void top2_merge(unsigned long long& a1, unsigned long long& a2, unsigned long long b1,
+                                           unsigned long long b2) {
+  const unsigned long long lo = a1 < b1 ? a1 : b1;
+  const unsigned long long hi1 = a1 < b1 ? b1 : a1;
+  const unsigned long long lo2 = a1 < b1 ? a2 : b2;
+  a1 = lo;
+  a2 = hi1 < lo2 ? hi1 : lo2;
+}
+__device__ __forceinline__ void top2_insert(unsigned long long& k1, unsigned long long& k2, unsigned long long k) {
+  if (k < k1) { k2 = k1; k1 = k; }
+  else if (k < k2) k2 = k;
+}
+__device__ __forceinline__ void wave_top2(unsigned long long& k1, unsigned long long& k2) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o1 = __shfl_xor(k1, off, 64), o2 = __shfl_xor(k2, off, 64);
+    top2_merge(k1, k2, o1, o2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// M0: element-wise DescriptorDistance
+__global__ __launch_bounds__(256) void k_hamming_pairs(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int n,
+                                                       int* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = hamming(load_desc(a + (size_t)i * 32), load_desc(b + (size_t)i * 32));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// F2: brute-force 2-nearest neighbours.  One query per lane (descriptor in registers), train descriptors
+// staged through LDS in tiles of 256 and read as wave-uniform broadcasts.
+__global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, const int* __restrict__ nqv, int qPitch,
+                                              const uint8_t* __restrict__ t, const int* __restrict__ ntv, int tPitch,
+                                              const int* __restrict__ qOffv, const int* __restrict__ tOffv,
+                                              int* __restrict__ idx, int* __restrict__ dist) {
+  __shared__ uint4 tile[256 * 2];
+  const int prob = blockIdx.y;
+  const int qOff = qOffv ? qOffv[prob] : 0, tOff = tOffv ? tOffv[prob] : 0;
+  const int nq = nqv[prob] - qOff, nt = ntv[prob] - tOff;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const uint8_t* qb = q + ((size_t)prob * qPitch + qOff) * 32;
+  const uint8_t* tb = t + ((size_t)prob * tPitch + tOff) * 32;
+  if ((int)blockIdx.x * 256 >= nq) return;
+  Desc d;
+  if (i < nq) d = load_desc(qb + (size_t)i * 32);
+  unsigned long long k1 = ~0ull, k2 = ~0ull;
+  for (int j0 = 0; j0 < nt; j0 += 256) {
+    const int j = j0 + threadIdx.x;
+    if (j < nt) {
+      const uint4* src = reinterpret_cast<const uint4*>(tb + (size_t)j * 32);
+      tile[threadIdx.x * 2] = src[0];
+      tile[threadIdx.x * 2 + 1] = src[1];
+    }
+    __syncthreads();
+    const int m = nt - j0 < 256 ? nt - j0 : 256;
+    if (i < nq) {
+      for (int jj = 0; jj < m; ++jj) {
+        const uint4 a = tile[jj * 2], b = tile[jj * 2 + 1];
+        const int s = __popc(d.w[0] ^ a.x) + __popc(d.w[1] ^ a.y) + __popc(d.w[2] ^ a.z) + __popc(d.w[3] ^ a.w) +
+                      __popc(d.w[4] ^ b.x) + __popc(d.w[5] ^ b.y) + __popc(d.w[6] ^ b.z) + __popc(d.w[7] ^ b.w);
+        top2_insert(k1, k2, ((unsigned long long)s << 32) | (unsigned)(j0 + jj));
+      }
+    }
+    __syncthreads();
+  }
+  if (i < nq) {
+    const size_t o = ((size_t)prob * qPitch + i) * 2;
+    idx[o] = k1 == ~0ull ? -1 : (int)(k1 & 0xFFFFFFFFu);
+    dist[o] = k1 == ~0ull ? -1 : (int)(k1 >> 32);
+    idx[o + 1] = k2 == ~0ull ? -1 : (int)(k2 & 0xFFFFFFFFu);
+    dist[o + 1] = k2 == ~0ull ? -1 : (int)(k2 >> 32);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// F1: ComputeStereoMatches.  Kernel A: one wave per left keypoint: row-band/octave/disparity-gated best
+// Hamming match (lexicographic (dist, iR) minimum = the reference's first-best over vRowIndices[row]), then the
+// 11x11 SAD search over 11 shifts on the un-blurred pyramid level, parabola refinement, disparity -> depth.
+// Kernel B: one workgroup per frame: median of the accepted SAD distances, 1.5*1.4*median cut.
+__global__ __launch_bounds__(256) void k_stereo_match(const LevelGeom* __restrict__ geom, const uint8_t* __restrict__ pyr,
+                                                      const morb_keypoint* __restrict__ kps,
+                                                      const uint8_t* __restrict__ desc, const int* __restrict__ count,
+                                                      int cap, const float* __restrict__ scaleF,
+                                                      const float* __restrict__ invScaleF, float mbf, float mb,
+                                                      float* __restrict__ uRight, float* __restrict__ depth,
+                                                      int* __restrict__ sadDist) {
+  const int f = blockIdx.y, lane = threadIdx.x & 63;
+  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int imgL = 2 * f, imgR = 2 * f + 1;
+  if (iL >= cap) return;
+  const size_t o = (size_t)f * cap + iL;
+  float outU = -1.0f, outD = -1.0f;
+  int outS = -1;
+  const int NL = count[imgL], NR = count[imgR];
+  if (iL < NL) {
+    const morb_keypoint kpL = kps[(size_t)imgL * cap + iL];
+    const int levelL = kpL.octave;
+    const float vL = kpL.y, uL = kpL.x;
+    const int nRows = geom[0].h;
+    const int row = (int)vL;
+    const float maxD = mbf / mb;
+    const float minU = uL - maxD, maxU = uL - 0.f;
+    const Desc dL = load_desc(desc + ((size_t)imgL * cap + iL) * 32);
+    unsigned long long best = ~0ull;
+    if (row >= 0 && row < nRows && !(maxU < 0)) {
+      for (int j0 = 0; j0 < NR; j0 += 64) {
+        const int iR = j0 + lane;
+        if (iR < NR) {
+          const morb_keypoint kpR = kps[(size_t)imgR * cap + iR];
+          const float r = 2.0f * scaleF[kpR.octave];
+          int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
+          const bool ok = row >= minr && row <= maxr && !(kpR.octave < levelL - 1 || kpR.octave > levelL + 1) &&
+                          kpR.x >= minU && kpR.x <= maxU;
+          if (ok) {
+            const int d = hamming(dL, load_desc(desc + ((size_t)imgR * cap + iR) * 32));
+            if (d < TH_HIGH) {
+              const unsigned long long k = ((unsigned long long)d << 32) | (unsigned)iR;
+              best = k < best ? k : best;
+            }
+          }
+        }
+      }
+    }
+    best = wave_min_u64(best);
+    const int bestDist = best == ~0ull ? TH_HIGH : (int)(best >> 32);
+    if (bestDist < (TH_HIGH + TH_LOW) / 2) {
+      const int bestIdxR = (int)(best & 0xFFFFFFFFu);
+      const float uR0 = kps[(size_t)imgR * cap + bestIdxR].x;
+      const float sf = invScaleF[levelL];
+      const float scaleduL = roundf(kpL.x * sf), scaledvL = roundf(kpL.y * sf), scaleduR0 = roundf(uR0 * sf);
+      const LevelGeom g = geom[levelL];
+      const float iniu = scaleduR0 + 5 - 5, endu = scaleduR0 + 5 + 5 + 1;
+      if (!(iniu < 0 || endu >= (float)g.w)) {
+        const uint8_t* L0 = pyr + g.pyrOff + (size_t)imgL * g.pyrImg + (size_t)(EDGE_ + (int)scaledvL) * g.pstride + EDGE_ + (int)scaleduL;
+        const uint8_t* R0 = pyr + g.pyrOff + (size_t)imgR * g.pyrImg + (size_t)(EDGE_ + (int)scaledvL) * g.pstride + EDGE_ + (int)scaleduR0;
+        // lanes cover the 121 patch pixels (two per lane)
+        const int p0 = lane, p1 = lane + 64;
+        const int dy0 = p0 / 11 - 5, dx0 = p0 % 11 - 5, dy1 = p1 / 11 - 5, dx1 = p1 % 11 - 5;
+        const int a0 = L0[dy0 * g.pstride + dx0];
+        const int a1 = p1 < 121 ? L0[dy1 * g.pstride + dx1] : 0;
+        float vDists[11];
+        int bestS = 0x7fffffff, bestinc = 0;
+#pragma unroll
+        for (int inc = -5; inc <= 5; ++inc) {
+          int s = abs(a0 - (int)R0[dy0 * g.pstride + dx0 + inc]);
+          if (p1 < 121) s += abs(a1 - (int)R0[dy1 * g.pstride + dx1 + inc]);
+          s = wave_sum(s);
+          const float dist = (float)s;
+          if (dist < (float)bestS) { bestS = (int)dist; bestinc = inc; }
+          vDists[inc + 5] = dist;
+        }
+        if (!(bestinc == -5 || bestinc == 5)) {
+          float dist1 = 0, dist2 = 0, dist3 = 0;
+#pragma unroll
+          for (int q = 1; q < 10; ++q)
+            if (q == bestinc + 5) { dist1 = vDists[q - 1]; dist2 = vDists[q]; dist3 = vDists[q + 1]; }
+          const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+          if (!(deltaR < -1 || deltaR > 1)) {
+            float bestuR = scaleF[levelL] * ((float)scaleduR0 + (float)bestinc + deltaR);
+            float disparity = uL - bestuR;
+            if (disparity >= 0.f && disparity < maxD) {
+              if (disparity <= 0) {
+                disparity = 0.01f;
+                bestuR = (float)((double)uL - 0.01);
+              }
+              outD = mbf / disparity;
+              outU = bestuR;
+              outS = bestS;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (lane == 0) { uRight[o] = outU; depth[o] = outD; sadDist[o] = outS; }
+}
+
+__global__ __launch_bounds__(256) void k_stereo_median(const int* __restrict__ count, int cap, float* __restrict__ uRight,
+                                                       float* __restrict__ depth, const int* __restrict__ sadDist) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int NL = count[2 * f];
+  const size_t o = (size_t)f * cap;
+  int n = 0;
+  for (int i = tid; i < NL; i += 256) n += sadDist[o + i] >= 0 ? 1 : 0;
+  __shared__ int red[4];
+  auto blockSum = [&](int v) -> int {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+  };
+  const int total = blockSum(n);
+  if (total == 0) return;
+  const int k = total / 2;  // vDistIdx[size/2].first of the ascending sort
+  int lo = 0, hi = 121 * 255;  // smallest v with #(d <= v) > k
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    int c = 0;
+    for (int i = tid; i < NL; i += 256) { const int d = sadDist[o + i]; c += (d >= 0 && d <= mid) ? 1 : 0; }
+    c = blockSum(c);
+    if (c > k) hi = mid; else lo = mid + 1;
+  }
+  const float median = (float)lo;
+  const float thDist = 1.5f * 1.4f * median;
+  for (int i = tid; i < NL; i += 256) {
+    const int d = sadDist[o + i];
+    if (d >= 0 && !((float)d < thDist)) { uRight[o + i] = -1; depth[o + i] = -1; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// N3: DBoW2 transform descent, one thread per feature.
+__global__ __launch_bounds__(256) void k_bow_transform(const uint8_t* __restrict__ feat, const int* __restrict__ count,
+                                                       int cap, const uint8_t* __restrict__ nodeDesc,
+                                                       const int* __restrict__ firstChild, int k, int L, int levelsup,
+                                                       int* __restrict__ wordId, int* __restrict__ nodeId) {
+  const int img = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cap) return;
+  const size_t o = (size_t)img * cap + i;
+  if (i >= count[img]) { wordId[o] = -1; nodeId[o] = -1; return; }
+  const Desc d = load_desc(feat + o * 32);
+  const int nid_level = L - levelsup;
+  int final_id = 0, level = 0, nid = 0;
+  do {
+    ++level;
+    const int c0 = firstChild[final_id];
+    int best = c0, bestd = hamming(d, load_desc(nodeDesc + (size_t)c0 * 32));
+    for (int c = c0 + 1; c < c0 + k; ++c) {
+      const int dd = hamming(d, load_desc(nodeDesc + (size_t)c * 32));
+      if (dd < bestd) { bestd = dd; best = c; }
+    }
+    final_id = best;
+    if (level == nid_level) nid = final_id;
+  } while (firstChild[final_id] >= 0);
+  wordId[o] = final_id;
+  nodeId[o] = nid;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// M3: SearchByBoW.  (1) per frame, sort (node, index) pairs: bitonic sort in LDS; features with node < 0 go
+// last.  (2) one wave per BoW node present in the keyframe: merge-join against the frame's sorted list,
+// then the keyframe's features of that node IN ORDER (the greedy dependency), lanes over the frame's features
+// of the node with a top-2 lexicographic reduction.  (3) per pair: rotation histogram, three maxima, filter.
+__global__ __launch_bounds__(256) void k_bow_sort(const int* __restrict__ node, const int* __restrict__ count, int cap,
+                                                  int P, unsigned long long* __restrict__ sorted) {
+  extern __shared__ unsigned long long skeys[];
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const int n = count[img];
+  for (int i = tid; i < P; i += 256) {
+    unsigned long long k = ~0ull;
+    if (i < n) {
+      const int nd = node[(size_t)img * cap + i];
+      if (nd >= 0) k = ((unsigned long long)(unsigned)nd << 32) | (unsigned)i;
+    }
+    skeys[i] = k;
+  }
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P; i += 256) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = skeys[i], b = skeys[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { skeys[i] = b; skeys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < cap; i += 256) sorted[(size_t)img * cap + i] = i < P ? skeys[i] : ~0ull;
+}
+
+__global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __restrict__ sortedKF,
+                                                   const unsigned long long* __restrict__ sortedF,
+                                                   const int* __restrict__ nKFv, const int* __restrict__ nFv, int cap,
+                                                   const uint8_t* __restrict__ descKF, const uint8_t* __restrict__ hasMP,
+                                                   const morb_keypoint* __restrict__ kpsKF,
+                                                   const uint8_t* __restrict__ descF, const morb_keypoint* __restrict__ kpsF,
+                                                   const int* __restrict__ kfImg, const int* __restrict__ fImg,
+                                                   float nnratio, int* __restrict__ matchF, int* __restrict__ binF) {
+  const int pair = blockIdx.y, lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ik = kfImg[pair], jf = fImg[pair];
+  const int nKF = nKFv[ik], nF = nFv[jf];
+  if (p >= nKF) return;
+  const unsigned long long* sk = sortedKF + (size_t)ik * cap;
+  const unsigned long long* sf = sortedF + (size_t)jf * cap;
+  const unsigned long long kp = sk[p];
+  if (kp == ~0ull) return;
+  const unsigned node = (unsigned)(kp >> 32);
+  if (p > 0 && (unsigned)(sk[p - 1] >> 32) == node) return;  // not the first feature of its node
+  // frame segment of this node: lower_bound(node << 32)
+  int lo = 0, hi = nF;
+  const unsigned long long target = (unsigned long long)node << 32;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (sf[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  const int fBeg = lo;
+  int fEnd = fBeg;
+  while (fEnd < nF && (unsigned)(sf[fEnd] >> 32) == node) ++fEnd;  // small segments (tens of features)
+  if (fEnd == fBeg) return;
+  int* mF = matchF + (size_t)pair * cap;
+  int* bF = binF + (size_t)pair * cap;
+  const float factor = 1.0f / HISTO_LENGTH;
+  for (int q = p; q < nKF; ++q) {
+    const unsigned long long kq = sk[q];
+    if (kq == ~0ull || (unsigned)(kq >> 32) != node) break;
+    const int realIdxKF = (int)(kq & 0xFFFFFFFFu);
+    if (!hasMP[(size_t)ik * cap + realIdxKF]) continue;
+    const Desc dKF = load_desc(descKF + ((size_t)ik * cap + realIdxKF) * 32);
+    unsigned long long k1 = ~0ull, k2 = ~0ull;
+    for (int s0 = fBeg; s0 < fEnd; s0 += 64) {
+      const int s = s0 + lane;
+      if (s < fEnd) {
+        const int realIdxF = (int)(sf[s] & 0xFFFFFFFFu);
+        if (mF[realIdxF] < 0) {
+          const int d = hamming(dKF, load_desc(descF + ((size_t)jf * cap + realIdxF) * 32));
+          top2_insert(k1, k2, ((unsigned long long)d << 32) | (unsigned)realIdxF);
+        }
+      }
+    }
+    wave_top2(k1, k2);
+    const int bestDist1 = k1 == ~0ull ? 256 : (int)(k1 >> 32);
+    const int bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 32);
+    if (bestDist1 <= TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {
+      const int bestIdxF = (int)(k1 & 0xFFFFFFFFu);
+      float rot = kpsKF[(size_t)ik * cap + realIdxKF].angle - kpsF[(size_t)jf * cap + bestIdxF].angle;
+      if (rot < 0.0f) rot += 360.0f;
+      int bin = (int)roundf(rot * factor);
+      if (bin == HISTO_LENGTH) bin = 0;
+      if (lane == 0) { mF[bestIdxF] = realIdxKF; bF[bestIdxF] = bin; }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+__device__ void three_maxima(const int* cnt, int L, int& ind1, int& ind2, int& ind3) {  // ORBmatcher.cc:1844-1876
+  int max1 = 0, max2 = 0, max3 = 0;
+  ind1 = ind2 = ind3 = -1;
+  for (int i = 0; i < L; i++) {
+    const int s = cnt[i];
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+__global__ __launch_bounds__(256) void k_rot_filter(const int* __restrict__ nFv, const int* __restrict__ fImg, int cap,
+                                                    int checkOri, int* __restrict__ matchF, const int* __restrict__ binF,
+                                                    int* __restrict__ nmatches) {
+  __shared__ int hist[HISTO_LENGTH];
+  __shared__ int keep[3];
+  __shared__ int total;
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int nF = nFv[fImg[pair]];
+  int* mF = matchF + (size_t)pair * cap;
+  const int* bF = binF + (size_t)pair * cap;
+  if (tid < HISTO_LENGTH) hist[tid] = 0;
+  if (tid == 0) total = 0;
+  __syncthreads();
+  for (int i = tid; i < nF; i += 256)
+    if (mF[i] >= 0) { atomicAdd(&total, 1); if (checkOri) atomicAdd(&hist[bF[i]], 1); }
+  __syncthreads();
+  if (checkOri) {
+    if (tid == 0) three_maxima(hist, HISTO_LENGTH, keep[0], keep[1], keep[2]);
+    __syncthreads();
+    for (int i = tid; i < nF; i += 256)
+      if (mF[i] >= 0) {
+        const int b = bF[i];
+        if (b != keep[0] && b != keep[1] && b != keep[2]) { mF[i] = -1; atomicSub(&total, 1); }
+      }
+    __syncthreads();
+  }
+  if (tid == 0) nmatches[pair] = total;
+}
+
+__global__ void k_fill_i32(int* p, size_t n, int v) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+// =====================================================================================================
+struct morb_matcher {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // workspace (grown on demand)
+  unsigned long long *d_sortA = nullptr, *d_sortB = nullptr;
+  int* d_bin = nullptr;
+  int* d_sad = nullptr;
+  float *d_scale = nullptr, *d_invScale = nullptr;
+  int* d_idx = nullptr;
+  size_t sortElems = 0, binElems = 0, sadElems = 0, idxElems = 0;
+};
+
+namespace {
+template <typename T>
+int grow(T*& p, size_t& have, size_t need) {
+  if (have >= need) return MORB_OK;
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  have = 0;
+  MORB_HIP_CHECK(hipMalloc(&p, sizeof(T) * need));
+  have = need;
+  return MORB_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int morb_matcher_create(morb_matcher** out, int device) {
+  MORB_REQUIRE(out, MORB_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  MORB_HIP_CHECK(hipGetDeviceCount(&ndev));
+  MORB_REQUIRE(device >= 0 && device < ndev, MORB_ERR_INVALID, "no such HIP device");
+  MORB_HIP_CHECK(hipSetDevice(device));
+  morb_matcher* m = new morb_matcher();
+  m->device = device;
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete m;
+    set_error("cannot create stream");
+    return MORB_ERR_HIP;
+  }
+  if (hipMalloc(&m->d_scale, sizeof(float) * 32) != hipSuccess || hipMalloc(&m->d_invScale, sizeof(float) * 32) != hipSuccess) {
+    set_error("hipMalloc failed");
+    delete m;
+    return MORB_ERR_HIP;
+  }
+  *out = m;
+  return MORB_OK;
+}
+
+void morb_matcher_destroy(morb_matcher* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  (void)hipStreamSynchronize(m->stream);
+  auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+  F(m->d_sortA); F(m->d_sortB); F(m->d_bin); F(m->d_sad); F(m->d_scale); F(m->d_invScale); F(m->d_idx);
+  (void)hipStreamDestroy(m->stream);
+  delete m;
+}
+
+int morb_hamming_pairs(morb_matcher* m, const uint8_t* d_a, const uint8_t* d_b, int n, int* d_out, void* stream) {
+  MORB_REQUIRE(m && d_a && d_b && d_out && n >= 0, MORB_ERR_INVALID, "bad argument");
+  MORB_HIP_CHECK(hipSetDevice(m->device));
+  hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+  if (n) hipLaunchKernelGGL(k_hamming_pairs, dim3(div_up(n, 256)), dim3(256), 0, st, d_a, d_b, n, d_out);
+  MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}
+
+int morb_hamming_knn2_batch(morb_matcher* m, int nprob, const uint8_t* d_query, const int* d_nq, int qPitch,
+                            const int* d_qOff, const uint8_t* d_train, const int* d_nt, int tPitch, const int* d_tOff,
+                            int* d_idx, int* d_dist, void* stream) {
+  MORB_REQUIRE(m && d_query && d_train && d_nq && d_nt && d_idx && d_dist, MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(nprob > 0 && qPitch > 0 && tPitch > 0, MORB_ERR_INVALID, "bad sizes");
+  MORB_HIP_CHECK(hipSetDevice(m->device));
+  hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+  hipLaunchKernelGGL(k_knn2, dim3(div_up(qPitch, 256), nprob), dim3(256), 0, st, d_query, d_nq, qPitch, d_train, d_nt,
+                     tPitch, d_qOff, d_tOff, d_idx, d_dist);
+  MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}
+
+int morb_stereo_match_batch(morb_matcher* m, const morb_extractor* e, int nframes, const morb_keypoint* d_kps,
+                            const uint8_t* d_desc, const int* d_count, int cap, float mbf, float mb, float* d_uRight,
+                            float* d_depth, void* stream) {
+  MORB_REQUIRE(m && e && d_kps && d_desc && d_count && d_uRight && d_depth, MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(nframes > 0 && cap > 0 && mb > 0.f, MORB_ERR_INVALID, "bad sizes");
+  MORB_REQUIRE(e->W > 0 && e->nimgLast >= 2 * nframes, MORB_ERR_INVALID,
+               "the extractor must have processed the 2*nframes images (left = 2f, right = 2f+1) of this batch");
+  MORB_REQUIRE(e->device == m->device, MORB_ERR_INVALID, "extractor and matcher live on different devices");
+  MORB_HIP_CHECK(hipSetDevice(m->device));
+  hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+  int rc = grow(m->d_sad, m->sadElems, (size_t)nframes * cap);
+  if (rc != MORB_OK) return rc;
+  MORB_HIP_CHECK(hipMemcpyAsync(m->d_scale, e->scale.data(), sizeof(float) * e->nlevels, hipMemcpyHostToDevice, st));
+  MORB_HIP_CHECK(hipMemcpyAsync(m->d_invScale, e->invScale.data(), sizeof(float) * e->nlevels, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_stereo_match, dim3(div_up(cap, 4), nframes), dim3(256), 0, st, e->d_geom, e->d_pyr, d_kps, d_desc,
+                     d_count, cap, m->d_scale, m->d_invScale, mbf, mb, d_uRight, d_depth, m->d_sad);
+  hipLaunchKernelGGL(k_stereo_median, dim3(nframes), dim3(256), 0, st, d_count, cap, d_uRight, d_depth, m->d_sad);
+  MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}
+
+int morb_bow_transform_batch(morb_matcher* m, int nimg, const uint8_t* d_desc, const int* d_count, int cap,
+                             const uint8_t* d_nodeDesc, const int* d_firstChild, int k, int L, int levelsup,
+                             int* d_wordId, int* d_nodeId, void* stream) {
+  MORB_REQUIRE(m && d_desc && d_count && d_nodeDesc && d_firstChild && d_wordId && d_nodeId, MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(nimg > 0 && cap > 0 && k > 0 && L > 0, MORB_ERR_INVALID, "bad sizes");
+  MORB_HIP_CHECK(hipSetDevice(m->device));
+  hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+  hipLaunchKernelGGL(k_bow_transform, dim3(div_up(cap, 256), nimg), dim3(256), 0, st, d_desc, d_count, cap, d_nodeDesc,
+                     d_firstChild, k, L, levelsup, d_wordId, d_nodeId);
+  MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}
+
+int morb_search_by_bow_batch(morb_matcher* m, int npairs, const int* d_kfImg, const int* d_fImg, int nimg,
+                             const morb_keypoint* d_kps, const uint8_t* d_desc, const int* d_node, const int* d_count,
+                             const uint8_t* d_hasMP, int cap, float nnratio, int checkOri, int* d_matchF,
+                             int* d_nmatches, void* stream) {
+  MORB_REQUIRE(m && d_kfImg && d_fImg && d_kps && d_desc && d_node && d_count && d_hasMP && d_matchF && d_nmatches,
+               MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(npairs > 0 && nimg > 0 && cap > 0, MORB_ERR_INVALID, "bad sizes");
+  int P = 1;
+  while (P < cap) P <<= 1;
+  MORB_REQUIRE((size_t)P * 8 <= 160 * 1024, MORB_ERR_UNSUPPORTED, "too many features per frame for the LDS sort");
+  MORB_HIP_CHECK(hipSetDevice(m->device));
+  hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+  int rc = grow(m->d_sortA, m->sortElems, (size_t)nimg * cap);
+  if (rc != MORB_OK) return rc;
+  rc = grow(m->d_bin, m->binElems, (size_t)npairs * cap);
+  if (rc != MORB_OK) return rc;
+  MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_sort), hipFuncAttributeMaxDynamicSharedMemorySize, P * 8));
+  hipLaunchKernelGGL(k_bow_sort, dim3(nimg), dim3(256), (size_t)P * 8, st, d_node, d_count, cap, P, m->d_sortA);
+  const size_t nm = (size_t)npairs * cap;
+  hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, d_matchF, nm, -1);
+  hipLaunchKernelGGL(k_bow_match, dim3(div_up(cap, 4), npairs), dim3(256), 0, st, m->d_sortA, m->d_sortA, d_count, d_count,
+                     cap, d_desc, d_hasMP, d_kps, d_desc, d_kps, d_kfImg, d_fImg, nnratio, d_matchF, m->d_bin);
+  hipLaunchKernelGGL(k_rot_filter, dim3(npairs), dim3(256), 0, st, d_count, d_fImg, cap, checkOri, d_matchF, m->d_bin, d_nmatches);
+  MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+"""ORBmatcher and the Frame-level stereo matchers — host-side mirror of the reference surfaces
+(include/ORBmatcher.h:36-129, Frame::ComputeStereoMatches / ComputeStereoFishEyeMatches) over the HIP kernels.
+Inputs are torch device tensors in the batched layout morb_extract_batch writes ([nimg, cap, ...])."""
+import ctypes as C
+
+import numpy as np
+
+from .capi import check, lib, ptr
+
+TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30   # ORBmatcher.cc:35-37
+
+
+class ORBmatcher:
+    TH_HIGH, TH_LOW, HISTO_LENGTH = TH_HIGH, TH_LOW, HISTO_LENGTH
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0):
+        self._L = lib()
+        self._h = C.c_void_p()
+        check(self._L.morb_matcher_create(C.byref(self._h), device))
+        self.mfNNratio, self.mbCheckOrientation, self.device = float(nnratio), bool(checkOri), device
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.morb_matcher_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @staticmethod
+    def _st(stream):
+        return None if stream is None else C.c_void_p(stream)
+
+    def DescriptorDistance(self, a, b, stream=None):
+        """static DescriptorDistance on n pairs: a, b = uint8 device tensors [n, 32] -> int32 [n]."""
+        import torch
+        n = a.shape[0]
+        out = torch.empty((n,), dtype=torch.int32, device=a.device)
+        check(self._L.morb_hamming_pairs(self._h, ptr(a), ptr(b), n, ptr(out), self._st(stream)))
+        return out
+
+    def knn2(self, query, nq, train, nt, qoff=None, toff=None, stream=None):
+        """BFMatcher(NORM_HAMMING).knnMatch(k=2), batched: query/train [nprob, pitch, 32] u8, nq/nt int32 [nprob]."""
+        import torch
+        nprob, qp = query.shape[0], query.shape[1]
+        idx = torch.full((nprob, qp, 2), -1, dtype=torch.int32, device=query.device)
+        dist = torch.full((nprob, qp, 2), -1, dtype=torch.int32, device=query.device)
+        check(self._L.morb_hamming_knn2_batch(self._h, nprob, ptr(query), ptr(nq), qp, ptr(qoff), ptr(train), ptr(nt),
+                                              train.shape[1], ptr(toff), ptr(idx), ptr(dist), self._st(stream)))
+        return idx, dist
+
+    def ComputeStereoMatches(self, extractor, kps, desc, count, mbf, mb, out=None, stream=None):
+        """Frame::ComputeStereoMatches for nframes = nimg/2 frames (left = image 2f, right = 2f+1 of the batch the
+        extractor just processed).  Returns (mvuRight, mvDepth) float32 [nframes, cap]."""
+        import torch
+        nimg, cap = kps.shape[0], kps.shape[1]
+        nf = nimg // 2
+        if out is None:
+            out = (torch.empty((nf, cap), dtype=torch.float32, device=kps.device),
+                   torch.empty((nf, cap), dtype=torch.float32, device=kps.device))
+        check(self._L.morb_stereo_match_batch(self._h, extractor._h, nf, ptr(kps), ptr(desc), ptr(count), cap,
+                                              float(mbf), float(mb), ptr(out[0]), ptr(out[1]), self._st(stream)))
+        return out
+
+    def bow_transform(self, desc, count, voc_desc, voc_first, k, L, levelsup=4, out=None, stream=None):
+        """DBoW2 transform (Frame::ComputeBoW): returns (wordId, nodeId) int32 [nimg, cap]."""
+        import torch
+        nimg, cap = desc.shape[0], desc.shape[1]
+        if out is None:
+            out = (torch.empty((nimg, cap), dtype=torch.int32, device=desc.device),
+                   torch.empty((nimg, cap), dtype=torch.int32, device=desc.device))
+        check(self._L.morb_bow_transform_batch(self._h, nimg, ptr(desc), ptr(count), cap, ptr(voc_desc), ptr(voc_first),
+                                               k, L, levelsup, ptr(out[0]), ptr(out[1]), self._st(stream)))
+        return out
+
+    def SearchByBoW(self, kf_img, f_img, kps, desc, node, count, has_mp, out=None, stream=None):
+        """SearchByBoW(pKF, F, vpMapPointMatches) for pairs (kf_img[p], f_img[p]) of images of one pool.
+        Returns (matchF int32 [npairs, cap] = keyframe feature index per frame feature or -1, nmatches int32 [npairs])."""
+        import torch
+        npairs = kf_img.shape[0]
+        nimg, cap = kps.shape[0], kps.shape[1]
+        if out is None:
+            out = (torch.empty((npairs, cap), dtype=torch.int32, device=kps.device),
+                   torch.empty((npairs,), dtype=torch.int32, device=kps.device))
+        check(self._L.morb_search_by_bow_batch(self._h, npairs, ptr(kf_img), ptr(f_img), nimg, ptr(kps), ptr(desc),
+                                               ptr(node), ptr(count), ptr(has_mp), cap, self.mfNNratio,
+                                               1 if self.mbCheckOrientation else 0, ptr(out[0]), ptr(out[1]),
+                                               self._st(stream)))
+        return out

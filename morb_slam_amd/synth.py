@@ -69,3 +69,25 @@ def shift_image(img, dx, dy):
     ys = np.clip(np.arange(h) - dy, 0, h - 1)
     xs = np.clip(np.arange(w) - dx, 0, w - 1)
     return np.ascontiguousarray(img[ys][:, xs])
+
+
+def make_vocabulary(k=10, L=6, seed=0):
+    """Synthetic DBoW2-shaped ORB vocabulary (the real ORBvoc.txt is a missing blob, SURVEY.md finding 3):
+    complete k-ary tree of depth L in level order (node 0 = root, children of n = k*n+1 .. k*n+k), each child
+    descriptor = parent descriptor with a level-dependent fraction of random bits flipped.
+    Returns (nodeDesc [nnodes, 32] u8, firstChild [nnodes] i32, -1 for leaves)."""
+    rng = np.random.default_rng(0xB0 + seed)
+    nn = (k ** (L + 1) - 1) // (k - 1)
+    desc = np.zeros((nn, 32), np.uint8)
+    first = np.full(nn, -1, np.int32)
+    desc[0] = rng.integers(0, 256, 32, dtype=np.uint8)
+    start, cnt = 0, 1
+    for lvl in range(L):
+        parents = np.arange(start, start + cnt)
+        first[parents] = k * parents + 1
+        p = 0.5 / (lvl + 1.5)
+        child_ids = (k * parents[:, None] + 1 + np.arange(k)[None, :]).reshape(-1)
+        flips = np.packbits(rng.random((len(child_ids), 256)) < p, axis=1)
+        desc[child_ids] = np.repeat(desc[parents], k, axis=0) ^ flips
+        start, cnt = start + cnt, cnt * k
+    return desc, first

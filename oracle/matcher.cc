@@ -1,0 +1,299 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product path.
+//
+// CPU restatement of the reference's matchers on flattened (POD) inputs: ORBmatcher
+// (/root/reference/src/ORBmatcher.cc) and the two per-frame stereo matchers in Frame.cc.  The reference
+// operates on Frame/KeyFrame/MapPoint objects; the C-ABI boundary flattens exactly the fields each function
+// reads, and these functions take the same flattened form so that HIP and oracle consume
+// identical bytes.  PARITY UNPINNED where OpenCV defines the arithmetic (BFMatcher tie order, cv::norm).
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <utility>
+#include <vector>
+
+#include "cvprims.h"
+#include "matcher.h"
+#include "orb_oracle.h"
+
+namespace orc {
+
+static const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;  // ORBmatcher.cc:35-37
+
+// ORBmatcher.cc:1880-1894 (SWAR popcount on 8 x int32)
+int DescriptorDistance(const uint8_t* a, const uint8_t* b) {
+  const int32_t* pa = reinterpret_cast<const int32_t*>(a);
+  const int32_t* pb = reinterpret_cast<const int32_t*>(b);
+  int dist = 0;
+  for (int i = 0; i < 8; i++, pa++, pb++) {
+    unsigned int v = *pa ^ *pb;
+    v = v - ((v >> 1) & 0x55555555);
+    v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+    dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+  }
+  return dist;
+}
+
+// ORBmatcher.cc:1844-1876
+void ComputeThreeMaxima(const std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = (int)histo[i].size();
+    if (s > max1) {
+      max3 = max2; max2 = max1; max1 = s;
+      ind3 = ind2; ind2 = ind1; ind1 = i;
+    } else if (s > max2) {
+      max3 = max2; max2 = s;
+      ind3 = ind2; ind2 = i;
+    } else if (s > max3) {
+      max3 = s; ind3 = i;
+    }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+// Frame::ComputeStereoMatches, Frame.cc:889-1047.  pyrL/pyrR: mvImagePyramid of the two extractors.
+// Guards added where the reference has UB: row indices clamped to [0, nRows), empty vDistIdx.
+void ComputeStereoMatches(int N, const KeyPoint* mvKeys, const uint8_t* mDescriptors, int Nr,
+                          const KeyPoint* mvKeysRight, const uint8_t* mDescriptorsRight, const float* mvScaleFactors,
+                          const float* mvInvScaleFactors, const std::vector<Img>& pyrL, const std::vector<Img>& pyrR,
+                          float mbf, float mb, float* mvuRight, float* mvDepth) {
+  for (int i = 0; i < N; ++i) { mvuRight[i] = -1.0f; mvDepth[i] = -1.0f; }
+  const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+  const int nRows = pyrL[0].rows;
+  std::vector<std::vector<size_t>> vRowIndices(nRows);
+  for (int iR = 0; iR < Nr; iR++) {
+    const KeyPoint& kp = mvKeysRight[iR];
+    const float kpY = kp.y;
+    const float r = 2.0f * mvScaleFactors[kp.octave];
+    const int maxr = (int)std::ceil(kpY + r);
+    const int minr = (int)std::floor(kpY - r);
+    for (int yi = std::max(minr, 0); yi <= std::min(maxr, nRows - 1); yi++) vRowIndices[yi].push_back(iR);
+  }
+  const float minZ = mb;
+  const float minD = 0;
+  const float maxD = mbf / minZ;
+  std::vector<std::pair<int, int>> vDistIdx;
+  for (int iL = 0; iL < N; iL++) {
+    const KeyPoint& kpL = mvKeys[iL];
+    const int levelL = kpL.octave;
+    const float vL = kpL.y, uL = kpL.x;
+    const int row = (int)vL;
+    if (row < 0 || row >= nRows) continue;
+    const std::vector<size_t>& vCandidates = vRowIndices[row];
+    if (vCandidates.empty()) continue;
+    const float minU = uL - maxD;
+    const float maxU = uL - minD;
+    if (maxU < 0) continue;
+    int bestDist = TH_HIGH;
+    size_t bestIdxR = 0;
+    const uint8_t* dL = mDescriptors + (size_t)iL * 32;
+    for (size_t iC = 0; iC < vCandidates.size(); iC++) {
+      const size_t iR = vCandidates[iC];
+      const KeyPoint& kpR = mvKeysRight[iR];
+      if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+      const float uR = kpR.x;
+      if (uR >= minU && uR <= maxU) {
+        const int dist = DescriptorDistance(dL, mDescriptorsRight + iR * 32);
+        if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+      }
+    }
+    if (bestDist < thOrbDist) {
+      const float uR0 = mvKeysRight[bestIdxR].x;
+      const float scaleFactor = mvInvScaleFactors[kpL.octave];
+      const float scaleduL = std::round(kpL.x * scaleFactor);
+      const float scaledvL = std::round(kpL.y * scaleFactor);
+      const float scaleduR0 = std::round(uR0 * scaleFactor);
+      const int w = 5;
+      const Img& IL = pyrL[kpL.octave];
+      const Img& IRimg = pyrR[kpL.octave];
+      int bestDistS = INT_MAX;
+      int bestincR = 0;
+      const int L = 5;
+      float vDists[2 * 5 + 1];
+      const float iniu = scaleduR0 + L - w;
+      const float endu = scaleduR0 + L + w + 1;
+      if (iniu < 0 || endu >= IRimg.cols) continue;
+      for (int incR = -L; incR <= +L; incR++) {
+        // cv::norm(IL, IR, NORM_L1) over the 11x11 patches
+        int sad = 0;
+        for (int dy = -w; dy <= w; ++dy)
+          for (int dx = -w; dx <= w; ++dx) {
+            int a = IL.at((int)scaledvL + dy, (int)scaleduL + dx);
+            int b = IRimg.at((int)scaledvL + dy, (int)scaleduR0 + incR + dx);
+            sad += std::abs(a - b);
+          }
+        float dist = (float)(double)sad;
+        if (dist < bestDistS) { bestDistS = (int)dist; bestincR = incR; }
+        vDists[L + incR] = dist;
+      }
+      if (bestincR == -L || bestincR == L) continue;
+      const float dist1 = vDists[L + bestincR - 1];
+      const float dist2 = vDists[L + bestincR];
+      const float dist3 = vDists[L + bestincR + 1];
+      const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+      if (deltaR < -1 || deltaR > 1) continue;
+      float bestuR = mvScaleFactors[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+      float disparity = (uL - bestuR);
+      if (disparity >= minD && disparity < maxD) {
+        if (disparity <= 0) {
+          disparity = 0.01;
+          bestuR = uL - 0.01;
+        }
+        mvDepth[iL] = mbf / disparity;
+        mvuRight[iL] = bestuR;
+        vDistIdx.push_back(std::pair<int, int>(bestDistS, iL));
+      }
+    }
+  }
+  if (vDistIdx.empty()) return;  // reference: UB (vDistIdx[0] on an empty vector)
+  std::sort(vDistIdx.begin(), vDistIdx.end());
+  const float median = (float)vDistIdx[vDistIdx.size() / 2].first;
+  const float thDist = 1.5f * 1.4f * median;
+  for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+    if (vDistIdx[i].first < thDist) break;
+    mvuRight[vDistIdx[i].second] = -1;
+    mvDepth[vDistIdx[i].second] = -1;
+  }
+}
+
+// cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, k=2)  (Frame.cc:46, :1242): exhaustive, ascending
+// distance, equal distances keep the lower train index first.
+void knnMatch2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* idx /*[nq][2]*/, int* dist /*[nq][2]*/) {
+  for (int i = 0; i < nq; ++i) {
+    int b0 = INT_MAX, b1 = INT_MAX, i0 = -1, i1 = -1;
+    for (int j = 0; j < nt; ++j) {
+      const int d = DescriptorDistance(q + (size_t)i * 32, t + (size_t)j * 32);
+      if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = j; }
+      else if (d < b1) { b1 = d; i1 = j; }
+    }
+    idx[2 * i] = i0; idx[2 * i + 1] = i1;
+    dist[2 * i] = i0 < 0 ? -1 : b0; dist[2 * i + 1] = i1 < 0 ? -1 : b1;
+  }
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches), ORBmatcher.cc:218-395, non-fisheye branch
+// (F.Nleft == -1).  FeatureVectors are given as one node id per feature (the DBoW2 contract: map nodeId ->
+// ascending feature indices; a negative node id = feature absent from the FeatureVector).  kfHasMP[i] != 0 <=>
+// vpMapPointsKF[i] != NULL && !isBad().  matchF[j] = KF feature index matched to frame feature j, or -1.
+int SearchByBoW(int nKF, const uint8_t* descKF, const float* angleKF, const uint8_t* kfHasMP, const int* nodeKF,
+                int nF, const uint8_t* descF, const float* angleF, const int* nodeF, float mfNNratio,
+                bool mbCheckOrientation, int* matchF) {
+  std::map<int, std::vector<unsigned>> vFeatVecKF, FFeatVec;
+  for (int i = 0; i < nKF; ++i) if (nodeKF[i] >= 0) vFeatVecKF[nodeKF[i]].push_back(i);
+  for (int i = 0; i < nF; ++i) if (nodeF[i] >= 0) FFeatVec[nodeF[i]].push_back(i);
+  for (int i = 0; i < nF; ++i) matchF[i] = -1;
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  auto KFit = vFeatVecKF.begin(), KFend = vFeatVecKF.end();
+  auto Fit = FFeatVec.begin(), Fend = FFeatVec.end();
+  while (KFit != KFend && Fit != Fend) {
+    if (KFit->first == Fit->first) {
+      const std::vector<unsigned>& vIndicesKF = KFit->second;
+      const std::vector<unsigned>& vIndicesF = Fit->second;
+      for (size_t iKF = 0; iKF < vIndicesKF.size(); iKF++) {
+        const unsigned realIdxKF = vIndicesKF[iKF];
+        if (!kfHasMP[realIdxKF]) continue;
+        const uint8_t* dKF = descKF + (size_t)realIdxKF * 32;
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        for (size_t iF = 0; iF < vIndicesF.size(); iF++) {
+          const unsigned realIdxF = vIndicesF[iF];
+          if (matchF[realIdxF] >= 0) continue;
+          const int dist = DescriptorDistance(dKF, descF + (size_t)realIdxF * 32);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+          else if (dist < bestDist2) { bestDist2 = dist; }
+        }
+        if (bestDist1 <= TH_LOW) {
+          if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+            matchF[bestIdxF] = (int)realIdxKF;
+            if (mbCheckOrientation) {
+              float rot = angleKF[realIdxKF] - angleF[bestIdxF];
+              if (rot < 0.0) rot += 360.0f;
+              int bin = (int)std::round(rot * factor);
+              if (bin == HISTO_LENGTH) bin = 0;
+              rotHist[bin].push_back(bestIdxF);
+            }
+            nmatches++;
+          }
+        }
+      }
+      KFit++;
+      Fit++;
+    } else if (KFit->first < Fit->first) {
+      KFit = vFeatVecKF.lower_bound(Fit->first);
+    } else {
+      Fit = FFeatVec.lower_bound(KFit->first);
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+        matchF[rotHist[i][j]] = -1;
+        nmatches--;
+      }
+    }
+  }
+  return nmatches;
+}
+
+// DBoW2 TemplatedVocabulary::transform(feature, word id, weight, nid, levelsup)
+// (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1218-1259): greedy descent, at each level the child with the
+// smallest Hamming distance (first minimum), nid = the ancestor at level (L - levelsup).  The tree is given as
+// a complete k-ary array: node 0 = root, children of node n are firstChild[n] .. firstChild[n]+k-1
+// (firstChild < 0 for leaves), one 32-byte descriptor per node.
+void BowTransform(const uint8_t* feat, int n, const uint8_t* nodeDesc, const int* firstChild, int k, int L, int levelsup,
+                  int* wordId, int* nodeId) {
+  const int nid_level = L - levelsup;
+  for (int f = 0; f < n; ++f) {
+    int final_id = 0, current_level = 0, nid = 0;
+    if (nid_level <= 0) nid = 0;
+    do {
+      ++current_level;
+      const int c0 = firstChild[final_id];
+      int best_d = DescriptorDistance(feat + (size_t)f * 32, nodeDesc + (size_t)c0 * 32);
+      int best = c0;
+      for (int c = c0 + 1; c < c0 + k; ++c) {
+        int d = DescriptorDistance(feat + (size_t)f * 32, nodeDesc + (size_t)c * 32);
+        if (d < best_d) { best_d = d; best = c; }
+      }
+      final_id = best;
+      if (current_level == nid_level) nid = final_id;
+    } while (firstChild[final_id] >= 0);
+    wordId[f] = final_id;
+    nodeId[f] = nid;
+  }
+}
+
+}  // namespace orc
+
+using namespace orc;
+extern "C" {
+
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b) { return DescriptorDistance(a, b); }
+
+void orc_three_maxima(const int* counts, int L, int* ind) {
+  std::vector<std::vector<int>> h(L);
+  for (int i = 0; i < L; ++i) h[i].resize(counts[i]);
+  ind[0] = ind[1] = ind[2] = -1;
+  ComputeThreeMaxima(h.data(), L, ind[0], ind[1], ind[2]);
+}
+
+void orc_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* idx, int* dist) { knnMatch2(q, nq, t, nt, idx, dist); }
+
+int orc_search_by_bow(int nKF, const uint8_t* descKF, const float* angleKF, const uint8_t* kfHasMP, const int* nodeKF,
+                      int nF, const uint8_t* descF, const float* angleF, const int* nodeF, float nnratio, int checkOri,
+                      int* matchF) {
+  return SearchByBoW(nKF, descKF, angleKF, kfHasMP, nodeKF, nF, descF, angleF, nodeF, nnratio, checkOri != 0, matchF);
+}
+
+void orc_bow_transform(const uint8_t* feat, int n, const uint8_t* nodeDesc, const int* firstChild, int k, int L,
+                       int levelsup, int* wordId, int* nodeId) {
+  BowTransform(feat, n, nodeDesc, firstChild, k, L, levelsup, wordId, nodeId);
+}
+}

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "cvprims.h"
+#include "matcher.h"
 #include "orb_oracle.h"
 
 namespace orc {
@@ -485,6 +486,16 @@ int orc_distribute(const orc_keypoint* in, int n, int minX, int maxX, int minY, 
   std::vector<KeyPoint> r = DistributeOctTree(v, minX, maxX, minY, maxY, N);
   if (out) memcpy(out, r.data(), (size_t)std::min((int)r.size(), cap) * sizeof(KeyPoint));
   return (int)r.size();
+}
+// Frame::ComputeStereoMatches on the keypoints/descriptors of two extractors that have just processed the
+// left and right image (their mvImagePyramid members are read, Frame.cc:895,974,987)
+void orc_stereo_matches(orc_extractor* left, orc_extractor* right, int N, const orc_keypoint* kpsL, const uint8_t* descL,
+                        int Nr, const orc_keypoint* kpsR, const uint8_t* descR, float mbf, float mb, float* uRight,
+                        float* depth) {
+  Extractor* l = reinterpret_cast<Extractor*>(left);
+  Extractor* r = reinterpret_cast<Extractor*>(right);
+  ComputeStereoMatches(N, (const KeyPoint*)kpsL, descL, Nr, (const KeyPoint*)kpsR, descR, l->mvScaleFactor.data(),
+                       l->mvInvScaleFactor.data(), l->mvImagePyramid, r->mvImagePyramid, mbf, mb, uRight, depth);
 }
 float orc_fast_atan2(float y, float x) { return fastAtan2(y, x); }
 float orc_cosf(float x) { return cosf_glibc(x); }

@@ -28,6 +28,17 @@ void orc_border101(uint8_t* buf, int w, int h, int step, int border);
 int orc_fast(const uint8_t* img, int w, int h, int step, int threshold, int nms, orc_keypoint* out, int cap);
 int orc_distribute(const orc_keypoint* in, int n, int minX, int maxX, int minY, int maxY, int N,
                    orc_keypoint* out, int cap);
+void orc_stereo_matches(orc_extractor* left, orc_extractor* right, int N, const orc_keypoint* kpsL, const uint8_t* descL,
+                        int Nr, const orc_keypoint* kpsR, const uint8_t* descR, float mbf, float mb, float* uRight,
+                        float* depth);
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b);
+void orc_three_maxima(const int* counts, int L, int* ind3);
+void orc_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* idx, int* dist);
+int orc_search_by_bow(int nKF, const uint8_t* descKF, const float* angleKF, const uint8_t* kfHasMP, const int* nodeKF,
+                      int nF, const uint8_t* descF, const float* angleF, const int* nodeF, float nnratio, int checkOri,
+                      int* matchF);
+void orc_bow_transform(const uint8_t* feat, int n, const uint8_t* nodeDesc, const int* firstChild, int k, int L,
+                       int levelsup, int* wordId, int* nodeId);
 float orc_fast_atan2(float y, float x);
 float orc_cosf(float x);
 float orc_sinf(float x);

@@ -45,6 +45,12 @@ def lib():
     L.orc_border101.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.orc_fast.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, kpp, C.c_int]
     L.orc_distribute.argtypes = [kpp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, kpp, C.c_int]
+    L.orc_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, kpp, u8p, C.c_int, kpp, u8p, C.c_float, C.c_float, fp, fp]
+    L.orc_descriptor_distance.argtypes = [u8p, u8p]
+    L.orc_three_maxima.argtypes = [ip, C.c_int, ip]
+    L.orc_knn2.argtypes = [u8p, C.c_int, u8p, C.c_int, ip, ip]
+    L.orc_search_by_bow.argtypes = [C.c_int, u8p, fp, u8p, ip, C.c_int, u8p, fp, ip, C.c_float, C.c_int, ip]
+    L.orc_bow_transform.argtypes = [u8p, C.c_int, u8p, ip, C.c_int, C.c_int, C.c_int, ip, ip]
     L.orc_fast_atan2.restype = C.c_float
     L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
     L.orc_cosf.restype = C.c_float
@@ -119,3 +125,41 @@ class OracleExtractor:
         out = np.zeros(max(n, 1), KP_DTYPE)
         self.L.orc_level_keypoints(self.h, lvl, _p(out), n)
         return out[:n]
+
+
+def stereo_matches(ext_l, ext_r, kl, dl, kr, dr, mbf, mb):
+    """Frame::ComputeStereoMatches over two OracleExtractors that just processed the left / right image."""
+    L = lib()
+    n = len(kl)
+    u = np.zeros(max(n, 1), np.float32); d = np.zeros(max(n, 1), np.float32)
+    kl = np.ascontiguousarray(kl); kr = np.ascontiguousarray(kr)
+    dl = np.ascontiguousarray(dl); dr = np.ascontiguousarray(dr)
+    L.orc_stereo_matches(ext_l.h, ext_r.h, n, _p(kl), _p(dl), len(kr), _p(kr), _p(dr), mbf, mb, _p(u), _p(d))
+    return u[:n], d[:n]
+
+
+def knn2(q, t):
+    L = lib()
+    q = np.ascontiguousarray(q); t = np.ascontiguousarray(t)
+    idx = np.zeros((max(len(q), 1), 2), np.int32); dist = np.zeros((max(len(q), 1), 2), np.int32)
+    L.orc_knn2(_p(q), len(q), _p(t), len(t), _p(idx), _p(dist))
+    return idx[:len(q)], dist[:len(q)]
+
+
+def search_by_bow(descKF, angleKF, hasMP, nodeKF, descF, angleF, nodeF, nnratio, checkOri):
+    L = lib()
+    a = [np.ascontiguousarray(x) for x in (descKF, angleKF.astype(np.float32), hasMP.astype(np.uint8), nodeKF.astype(np.int32),
+                                           descF, angleF.astype(np.float32), nodeF.astype(np.int32))]
+    m = np.zeros(max(len(descF), 1), np.int32)
+    n = L.orc_search_by_bow(len(descKF), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), len(descF), _p(a[4]), _p(a[5]), _p(a[6]),
+                            nnratio, 1 if checkOri else 0, _p(m))
+    return n, m[:len(descF)]
+
+
+def bow_transform(desc, voc_desc, voc_first, k, Lv, levelsup):
+    L = lib()
+    desc = np.ascontiguousarray(desc)
+    w = np.zeros(max(len(desc), 1), np.int32); nd = np.zeros(max(len(desc), 1), np.int32)
+    L.orc_bow_transform(_p(desc), len(desc), _p(np.ascontiguousarray(voc_desc)), _p(np.ascontiguousarray(voc_first)), k, Lv,
+                        levelsup, _p(w), _p(nd))
+    return w[:len(desc)], nd[:len(desc)]
