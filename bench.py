@@ -44,13 +44,15 @@ def algorithmic_bytes(w, h):
 
 
 def make_batch(nframes, seed):
-    """nframes distinct stereo pairs built from 4 seeded base pairs + integer shifts (cheap, deterministic)."""
+    """nframes stereo pairs = 4 seeded sequences of nframes/4 consecutive frames with a 3x2 px/frame global
+    shift, so frame f-1 is a real 'previous frame' of frame f except at the 4 sequence starts."""
     from morb_slam_amd.synth import make_stereo_pair, shift_image
     base = [make_stereo_pair(W, H, seed=seed * 16 + i) for i in range(4)]
     imgs = np.empty((nframes, 2, H, W), np.uint8)
+    per = max(nframes // 4, 1)
     for f in range(nframes):
-        l, r = base[f % 4]
-        dx, dy = 3 * (f // 4), 2 * (f // 4)
+        l, r = base[(f // per) % 4]
+        dx, dy = 3 * (f % per), 2 * (f % per)
         imgs[f, 0] = shift_image(l, dx, dy)
         imgs[f, 1] = shift_image(r, dx, dy)
     return imgs
