@@ -146,6 +146,57 @@ int morb_search_by_bow_batch(morb_matcher*, int npairs, const int* d_kfImg, cons
                              const uint8_t* d_hasMP, int cap, float nnratio, int checkOri, int* d_matchF,
                              int* d_nmatches, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Optimizer  (include/Optimizer.h:46-139, src/Optimizer.cc; g2o Levenberg-Marquardt semantics)
+ * Poses cross the boundary the way the reference hands them to g2o: unit quaternion (x, y, z, w) followed by
+ * the translation, 7 floats (Sophus::SE3f::unit_quaternion() / translation(), Optimizer.cc:781-783, :1046-1048).
+ * Pinhole mono (uRight < 0) and rectified-stereo (uRight >= 0) observations are supported; the KannalaBrandt8
+ * "ToBody" edges are not yet (MORB_ERR_UNSUPPORTED is never silently substituted).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct morb_optimizer morb_optimizer;
+int morb_optimizer_create(morb_optimizer** out, int device);
+void morb_optimizer_destroy(morb_optimizer*);
+
+/* static int Optimizer::PoseOptimization(Frame* pFrame)  Optimizer.h:86, Optimizer.cc:762-1051, for nframes
+ * frames at once (DEVICE pointers, frame f at offset f*cap): d_count[f] = Frame::N (NULL = cap),
+ * d_hasMP[i] != 0 <=> mvpMapPoints[i], d_obs[i] = (mvKeysUn[i].pt.x, .pt.y, mvuRight[i]),
+ * d_invSigma2[i] = mvInvLevelSigma2[octave], d_Xw[i] = MapPoint world position; fx..bf = Frame::fx, fy, cx, cy,
+ * mbf.  d_pose [nframes][7] in/out (Frame::GetPose / SetPose), d_outlier[i] = mvbOutlier[i],
+ * d_nInliers[f] = the return value (0 when fewer than 3 correspondences; the pose is then left untouched).
+ * d_stats (optional) [nframes][2] = outer LM iterations, LM trials. */
+int morb_pose_optimization_batch(morb_optimizer*, int nframes, int cap, const int* d_count, const uint8_t* d_hasMP,
+                                 const float* d_obs, const float* d_invSigma2, const float* d_Xw, float fx, float fy,
+                                 float cx, float cy, float bf, float* d_pose, uint8_t* d_outlier, int* d_nInliers,
+                                 int* d_stats, void* stream);
+
+/* static void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF,
+ * int& num_OptKF, int& num_MPs, int& num_edges)  Optimizer.h:67-69, Optimizer.cc:1053-1441, on the graph the
+ * reference assembles at :1058-1351, flattened (HOST pointers): nKF keyframes (local ones first or in any
+ * order; kfFixed[i] != 0 for lFixedCameras and the map's initial keyframe), nMP local map points, nE
+ * observations (eKF, eMP indices; eObs = (x, y, uRight); eInvSigma2).  lambdaInit100 != 0 <=>
+ * pMap->IsInertial() (:1137).  stopFlag = *pbStopFlag at entry (the graph is not optimised when set, :1355).
+ * Outputs: optimised kfPose (free keyframes) and mpPos in place, eraseFlag[e] = 1 where the reference erases the
+ * observation (:1366-1401), stats2 = {outer LM iterations, LM trials}. */
+int morb_local_bundle_adjustment(morb_optimizer*, int nKF, float* kfPose, const uint8_t* kfFixed, int nMP, float* mpPos,
+                                 int nE, const int* eKF, const int* eMP, const float* eObs, const float* eInvSigma2,
+                                 float fx, float fy, float cx, float cy, float bf, int lambdaInit100,
+                                 const int* stopFlag, uint8_t* eraseFlag, int* stats2);
+
+/* The same in three steps, so that a problem can stay resident in HBM and be solved repeatedly (benchmarks) or
+ * aborted from another thread: create (upload + CSR build), solve (device only, asynchronous on `stream`,
+ * restarts from the uploaded initial values), results (synchronises, downloads).  morb_ba_set_stop mirrors
+ * LocalMapping::InterruptBA -> mbAbortBA (LocalMapping.cc:884): the kernel polls the flag at the top of every
+ * outer iteration and every LM trial like g2o does (sparse_optimizer.cpp:376, optimization_algorithm_levenberg.cpp:149). */
+typedef struct morb_ba_problem morb_ba_problem;
+int morb_ba_problem_create(morb_optimizer*, morb_ba_problem** out, int nKF, const float* kfPose, const uint8_t* kfFixed,
+                           int nMP, const float* mpPos, int nE, const int* eKF, const int* eMP, const float* eObs,
+                           const float* eInvSigma2, float fx, float fy, float cx, float cy, float bf,
+                           int lambdaInit100);
+void morb_ba_problem_destroy(morb_ba_problem*);
+int morb_ba_set_stop(morb_ba_problem*, int stop);
+int morb_ba_solve(morb_ba_problem*, void* stream);
+int morb_ba_results(morb_ba_problem*, float* kfPose, float* mpPos, uint8_t* eraseFlag, int* stats2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,3 +4,4 @@ include/morb_hip.h); this package is the host-side mirror of the reference class
 from .capi import KP_DTYPE, MorbError  # noqa: F401
 from .extractor import ORBextractor  # noqa: F401
 from .matcher import ORBmatcher  # noqa: F401
+from .optimizer import BAProblem, Optimizer  # noqa: F401

@@ -66,6 +66,17 @@ def lib():
         L.morb_stereo_match_batch.argtypes = [vp, vp, i, vp, vp, vp, i, f, f, vp, vp, vp]
         L.morb_bow_transform_batch.argtypes = [vp, i, vp, vp, i, vp, vp, i, i, i, vp, vp, vp]
         L.morb_search_by_bow_batch.argtypes = [vp, i, vp, vp, i, vp, vp, vp, vp, vp, i, f, i, vp, vp, vp]
+        L.morb_optimizer_create.argtypes = [C.POINTER(vp), i]
+        L.morb_optimizer_destroy.argtypes = [vp]
+        L.morb_optimizer_destroy.restype = None
+        L.morb_pose_optimization_batch.argtypes = [vp, i, i, vp, vp, vp, vp, vp, f, f, f, f, f, vp, vp, vp, vp, vp]
+        L.morb_local_bundle_adjustment.argtypes = [vp, i, vp, vp, i, vp, i, vp, vp, vp, vp, f, f, f, f, f, i, vp, vp, vp]
+        L.morb_ba_problem_create.argtypes = [vp, C.POINTER(vp), i, vp, vp, i, vp, i, vp, vp, vp, vp, f, f, f, f, f, i]
+        L.morb_ba_problem_destroy.argtypes = [vp]
+        L.morb_ba_problem_destroy.restype = None
+        L.morb_ba_set_stop.argtypes = [vp, i]
+        L.morb_ba_solve.argtypes = [vp, vp]
+        L.morb_ba_results.argtypes = [vp, vp, vp, vp, vp]
         _lib = L
     return _lib
 

@@ -1,0 +1,82 @@
+"""Optimizer — host-side mirror of the reference's static Optimizer functions on the hot path
+(include/Optimizer.h:46-139): PoseOptimization and LocalBundleAdjustment, over the device-resident LM kernels."""
+import ctypes as C
+
+import numpy as np
+
+from .capi import check, lib, ptr
+
+
+class Optimizer:
+    def __init__(self, device=0):
+        self._L = lib()
+        self._h = C.c_void_p()
+        check(self._L.morb_optimizer_create(C.byref(self._h), device))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.morb_optimizer_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def PoseOptimization(self, hasMP, obs, invSigma2, Xw, pose, cam, count=None, out=None, stream=None):
+        """Batched PoseOptimization.  Device tensors: hasMP u8 [F, cap], obs f32 [F, cap, 3] (x, y, uRight),
+        invSigma2 f32 [F, cap], Xw f32 [F, cap, 3], pose f32 [F, 7] (in/out), count i32 [F] or None.
+        Returns (nInliers i32 [F], outlier u8 [F, cap], stats i32 [F, 2]); pose is updated in place."""
+        import torch
+        F, cap = hasMP.shape
+        if out is None:
+            out = (torch.empty((F,), dtype=torch.int32, device=hasMP.device),
+                   torch.zeros((F, cap), dtype=torch.uint8, device=hasMP.device),
+                   torch.empty((F, 2), dtype=torch.int32, device=hasMP.device))
+        st = None if stream is None else C.c_void_p(stream)
+        check(self._L.morb_pose_optimization_batch(self._h, F, cap, ptr(count), ptr(hasMP), ptr(obs), ptr(invSigma2), ptr(Xw),
+                                                   cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["bf"], ptr(pose),
+                                                   ptr(out[1]), ptr(out[0]), ptr(out[2]), st))
+        return out
+
+    def LocalBundleAdjustment(self, kfPose, kfFixed, mpPos, eKF, eMP, eObs, eInvSigma2, cam, inertial=False, stop=False):
+        """One-shot LocalBundleAdjustment on host numpy arrays; returns (kfPose, mpPos, eraseFlag, stats)."""
+        p = BAProblem(self, kfPose, kfFixed, mpPos, eKF, eMP, eObs, eInvSigma2, cam, inertial)
+        if stop:
+            p.set_stop(True)
+        p.solve()
+        return p.results()
+
+
+class BAProblem:
+    """A LocalBundleAdjustment graph resident in HBM (create once, solve repeatedly)."""
+
+    def __init__(self, opt, kfPose, kfFixed, mpPos, eKF, eMP, eObs, eInvSigma2, cam, inertial=False):
+        self._L = lib()
+        self._opt = opt
+        self._h = C.c_void_p()
+        a = [np.ascontiguousarray(kfPose, np.float32), np.ascontiguousarray(kfFixed, np.uint8),
+             np.ascontiguousarray(mpPos, np.float32), np.ascontiguousarray(eKF, np.int32), np.ascontiguousarray(eMP, np.int32),
+             np.ascontiguousarray(eObs, np.float32), np.ascontiguousarray(eInvSigma2, np.float32)]
+        self.nKF, self.nMP, self.nE = len(a[0]), len(a[2]), len(a[3])
+        self._init = (a[0], a[2])
+        check(self._L.morb_ba_problem_create(opt._h, C.byref(self._h), self.nKF, ptr(a[0]), ptr(a[1]), self.nMP, ptr(a[2]),
+                                             self.nE, ptr(a[3]), ptr(a[4]), ptr(a[5]), ptr(a[6]), cam["fx"], cam["fy"],
+                                             cam["cx"], cam["cy"], cam["bf"], 1 if inertial else 0))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.morb_ba_problem_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_stop(self, on):
+        check(self._L.morb_ba_set_stop(self._h, 1 if on else 0))
+
+    def solve(self, stream=None):
+        check(self._L.morb_ba_solve(self._h, None if stream is None else C.c_void_p(stream)))
+
+    def results(self):
+        kf = self._init[0].copy(); mp = self._init[1].copy()
+        erase = np.zeros(self.nE, np.uint8); stats = np.zeros(2, np.int32)
+        check(self._L.morb_ba_results(self._h, ptr(kf), ptr(mp), ptr(erase), ptr(stats)))
+        return kf, mp, erase, stats

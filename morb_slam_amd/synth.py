@@ -91,3 +91,109 @@ def make_vocabulary(k=10, L=6, seed=0):
         desc[child_ids] = np.repeat(desc[parents], k, axis=0) ^ flips
         start, cnt = start + cnt, cnt * k
     return desc, first
+
+
+# ---- synthetic geometry for the optimisers ------------------------------------------------
+EUROC_CAM = dict(fx=458.654, fy=457.296, cx=367.215, cy=248.375, bf=458.654 * 0.11)
+
+
+def _quat_from_rotvec(r):
+    th = np.linalg.norm(r)
+    if th < 1e-12:
+        return np.array([0, 0, 0, 1.0])
+    a = r / th
+    return np.concatenate([a * np.sin(th / 2), [np.cos(th / 2)]])
+
+
+def _quat_mul(a, b):
+    ax, ay, az, aw = a; bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by + ay * bw + az * bx - ax * bz,
+                     aw * bz + az * bw + ax * by - ay * bx, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def _quat_rot(q, v):
+    u, w = q[:3], q[3]
+    uv = 2 * np.cross(u, v)
+    return v + w * uv + np.cross(u, uv)
+
+
+def _project(pose, X, cam):
+    """pose = (qx,qy,qz,qw,tx,ty,tz) world->camera; returns (u, v, uRight, z)."""
+    Xc = np.array([_quat_rot(pose[:4], x) for x in X]) + pose[4:]
+    z = Xc[:, 2]
+    u = cam["fx"] * Xc[:, 0] / z + cam["cx"]
+    v = cam["fy"] * Xc[:, 1] / z + cam["cy"]
+    return u, v, u - cam["bf"] / z, z
+
+
+def make_pose_problem(n=600, seed=0, outlier_frac=0.1, mono_frac=0.3, rot_deg=2.0, trans=0.05, cam=EUROC_CAM):
+    """One PoseOptimization input: n features, ~all with a MapPoint, stereo/mono mix, gross outliers, perturbed
+    initial pose.  Returns dict of float32 arrays + the true pose."""
+    rng = np.random.default_rng(0x9050 + seed)
+    true = np.concatenate([_quat_from_rotvec(rng.normal(0, 0.1, 3)), rng.normal(0, 0.3, 3)])
+    # points in front of the camera: sample camera-frame points and map them to the world
+    Xc = np.stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(2, 10, n)], 1)
+    qinv = true[:4] * np.array([-1, -1, -1, 1])
+    Xw = np.array([_quat_rot(qinv, x - true[4:]) for x in Xc])
+    u, v, ur, z = _project(true, Xw, cam)
+    octave = rng.integers(0, 8, n)
+    sigma = 1.2 ** octave
+    u = u + rng.normal(0, 1, n) * sigma; v = v + rng.normal(0, 1, n) * sigma; ur = ur + rng.normal(0, 1, n) * sigma
+    out = rng.random(n) < outlier_frac
+    u[out] += rng.choice([-1, 1], out.sum()) * rng.uniform(15, 40, out.sum())
+    v[out] += rng.choice([-1, 1], out.sum()) * rng.uniform(15, 40, out.sum())
+    mono = rng.random(n) < mono_frac
+    ur[mono] = -1
+    has = (rng.random(n) < 0.9).astype(np.uint8)
+    dq = _quat_from_rotvec(rng.normal(0, 1, 3) / np.sqrt(3) * np.deg2rad(rot_deg))
+    init = np.concatenate([_quat_mul(dq, true[:4]), _quat_rot(dq, true[4:]) + rng.normal(0, trans, 3)])
+    return dict(hasMP=has, obs=np.stack([u, v, ur], 1).astype(np.float32), invSigma2=(1.0 / sigma ** 2).astype(np.float32),
+                Xw=Xw.astype(np.float32), pose0=init.astype(np.float32), true=true, outlier_truth=out, cam=cam)
+
+
+def make_ba_problem(n_free=20, n_fixed=6, n_points=3000, seed=0, outlier_frac=0.05, mono_frac=0.15, cam=EUROC_CAM):
+    """LocalBundleAdjustment input shaped like BASELINE config 5: n_free + n_fixed keyframes on an arc looking at
+    a point slab, each point observed by 4-10 keyframes."""
+    rng = np.random.default_rng(0xBA00 + seed)
+    nkf = n_free + n_fixed
+    poses = []
+    for i in range(nkf):
+        ang = (i / max(nkf - 1, 1) - 0.5) * 0.5
+        c = np.array([2.0 * np.sin(ang) * 2, rng.normal(0, 0.05), -2.0 * (1 - np.cos(ang))])   # camera centre
+        q_wc = _quat_from_rotvec(np.array([0, -ang * 0.8, 0]) + rng.normal(0, 0.01, 3))      # camera->world
+        q_cw = q_wc * np.array([-1, -1, -1, 1])
+        poses.append(np.concatenate([q_cw, -_quat_rot(q_cw, c)]))
+    poses = np.array(poses)
+    X = np.stack([rng.uniform(-3, 3, n_points), rng.uniform(-2, 2, n_points), rng.uniform(3, 10, n_points)], 1)
+    eKF, eMP, eObs, eInv = [], [], [], []
+    for j in range(n_points):
+        k = int(rng.integers(4, 11))
+        kfs = rng.choice(nkf, size=min(k, nkf), replace=False)
+        u, v, ur, z = _project_many(poses[kfs], X[j], cam)
+        for a, kf in enumerate(kfs):
+            if z[a] <= 0.5 or not (0 <= u[a] < 752 and 0 <= v[a] < 480):
+                continue
+            octv = int(rng.integers(0, 8)); s = 1.2 ** octv
+            o = np.array([u[a], v[a], ur[a]]) + rng.normal(0, 1, 3) * s
+            if rng.random() < outlier_frac:
+                o[:2] += rng.choice([-1, 1], 2) * rng.uniform(15, 30, 2)
+            if rng.random() < mono_frac:
+                o[2] = -1
+            eKF.append(kf); eMP.append(j); eObs.append(o); eInv.append(1.0 / s ** 2)
+    fixed = np.zeros(nkf, np.uint8); fixed[n_free:] = 1
+    pose0 = poses.copy()
+    for i in range(n_free):
+        dq = _quat_from_rotvec(rng.normal(0, 1, 3) / np.sqrt(3) * np.deg2rad(2.0))
+        pose0[i] = np.concatenate([_quat_mul(dq, poses[i][:4]), _quat_rot(dq, poses[i][4:]) + rng.normal(0, 0.05, 3)])
+    X0 = X + rng.normal(0, 0.05, X.shape)
+    return dict(kfPose=pose0.astype(np.float32), kfFixed=fixed, mpPos=X0.astype(np.float32),
+                eKF=np.array(eKF, np.int32), eMP=np.array(eMP, np.int32), eObs=np.array(eObs, np.float32),
+                eInvSigma2=np.array(eInv, np.float32), true_poses=poses, true_points=X, cam=cam)
+
+
+def _project_many(poses, x, cam):
+    Xc = np.array([_quat_rot(p[:4], x) + p[4:] for p in poses])
+    z = Xc[:, 2]
+    u = cam["fx"] * Xc[:, 0] / z + cam["cx"]
+    v = cam["fy"] * Xc[:, 1] / z + cam["cy"]
+    return u, v, u - cam["bf"] / z, z

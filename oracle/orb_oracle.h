@@ -39,6 +39,11 @@ int orc_search_by_bow(int nKF, const uint8_t* descKF, const float* angleKF, cons
                       int* matchF);
 void orc_bow_transform(const uint8_t* feat, int n, const uint8_t* nodeDesc, const int* firstChild, int k, int L,
                        int levelsup, int* wordId, int* nodeId);
+int orc_pose_optimization(int n, const uint8_t* hasMP, const float* obs, const float* invSigma2, const float* Xw,
+                          float fx, float fy, float cx, float cy, float bf, float* pose, uint8_t* outlier, int* stats);
+int orc_local_ba(int nKF, float* kfPose, const uint8_t* kfFixed, int nMP, float* mpPos, int nE, const int* eKF,
+                 const int* eMP, const float* eObs, const float* eInvSigma2, float fx, float fy, float cx, float cy,
+                 float bf, int lambdaInit100, const int* stopFlag, uint8_t* eraseFlag, int* stats);
 float orc_fast_atan2(float y, float x);
 float orc_cosf(float x);
 float orc_sinf(float x);

@@ -163,3 +163,32 @@ def bow_transform(desc, voc_desc, voc_first, k, Lv, levelsup):
     L.orc_bow_transform(_p(desc), len(desc), _p(np.ascontiguousarray(voc_desc)), _p(np.ascontiguousarray(voc_first)), k, Lv,
                         levelsup, _p(w), _p(nd))
     return w[:len(desc)], nd[:len(desc)]
+
+
+def pose_optimization(p):
+    L = lib()
+    L.orc_pose_optimization.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_float] * 5 + [C.c_void_p] * 3
+    n = len(p["hasMP"])
+    pose = p["pose0"].astype(np.float32).copy()
+    outl = np.zeros(n, np.uint8)
+    stats = np.zeros(2, np.int32)
+    c = p["cam"]
+    a = [np.ascontiguousarray(p[k]) for k in ("hasMP", "obs", "invSigma2", "Xw")]
+    r = L.orc_pose_optimization(n, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), c["fx"], c["fy"], c["cx"], c["cy"], c["bf"],
+                                _p(pose), _p(outl), _p(stats))
+    return r, pose, outl, stats
+
+
+def local_ba(p, lambda100=False, stop=None):
+    L = lib()
+    L.orc_local_ba.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + \
+        [C.c_float] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    kf = p["kfPose"].astype(np.float32).copy(); mp = p["mpPos"].astype(np.float32).copy()
+    nE = len(p["eKF"])
+    erase = np.zeros(nE, np.uint8); stats = np.zeros(2, np.int32)
+    c = p["cam"]
+    a = [np.ascontiguousarray(p[k]) for k in ("kfFixed", "eKF", "eMP", "eObs", "eInvSigma2")]
+    st = None if stop is None else _p(stop)
+    its = L.orc_local_ba(len(kf), _p(kf), _p(a[0]), len(mp), _p(mp), nE, _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]),
+                         c["fx"], c["fy"], c["cx"], c["cy"], c["bf"], 1 if lambda100 else 0, st, _p(erase), _p(stats))
+    return its, kf, mp, erase, stats
