@@ -146,6 +146,70 @@ int morb_search_by_bow_batch(morb_matcher*, int npairs, const int* d_kfImg, cons
                              const uint8_t* d_hasMP, int cap, float nnratio, int checkOri, int* d_matchF,
                              int* d_nmatches, void* stream);
 
+/* The Frame members the projection-guided searches read, as one POD (all frames of a batch share one camera):
+ * mnMinX/Y, mnMaxX/Y, mfGridElementWidthInv/HeightInv, fx, fy, cx, cy, mbf, mb, mfLogScaleFactor, mnScaleLevels,
+ * mvScaleFactors, mvLevelSigma2 (include/Frame.h). */
+typedef struct morb_frame_params {
+  float minX, minY, maxX, maxY, gridInvW, gridInvH;
+  float fx, fy, cx, cy, mbf, mb, logScaleFactor;
+  int32_t nlevels;
+  float scaleFactors[16];
+  float levelSigma2[16];
+} morb_frame_params;
+
+/* bool Frame::isInFrustum(MapPoint*, viewingCosLimit)  Frame.h / Frame.cc:611-678 (+ MapPoint::PredictScale,
+ * MapPoint.cc:536-566) for d_nMP[f] map points of each of nframes frames (arrays [nframes][mpCap]).  Inputs:
+ * d_Rcw [f][9] row-major, d_tcw [f][3], d_Ow [f][3] (Frame::mRcw, mtcw, mOw), world position, normal,
+ * mfMaxDistance, mfMinDistance per point.  Outputs = the MapPoint tracking fields the function fills:
+ * mbTrackInView, mTrackProjX, mTrackProjY, mTrackProjXR, mTrackDepth, mnTrackScaleLevel, mTrackViewCos. */
+int morb_is_in_frustum_batch(morb_matcher*, const morb_frame_params*, int nframes, const float* d_Rcw, const float* d_tcw,
+                             const float* d_Ow, int mpCap, const int* d_nMP, const float* d_Pw, const float* d_normal,
+                             const float* d_maxDist, const float* d_minDist, float viewingCosLimit, uint8_t* d_inView,
+                             float* d_projX, float* d_projY, float* d_projXR, float* d_depth, int* d_level,
+                             float* d_viewCos, void* stream);
+
+/* int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, bFarPoints, thFarPoints)
+ * ORBmatcher.h:49-51, ORBmatcher.cc:42-209.  Frame f uses the features of image d_fImg[f]; d_uRight / d_blocked
+ * are [nframes][cap] (mvuRight or NULL; blocked != 0 <=> mvpMapPoints[i] && Observations() > 0).  Map points
+ * [nframes][mpCap] carry the fields isInFrustum wrote plus isBad, the representative descriptor and
+ * hasObs (Observations() > 0).  d_matchF [nframes][cap] in/out: index of the map point assigned to feature i
+ * (caller initialises to -1 or keeps earlier assignments); d_nmatches[f] = return value. */
+int morb_search_by_projection_mps_batch(morb_matcher*, const morb_frame_params*, int nframes, const int* d_fImg, int cap,
+                                        const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc,
+                                        const float* d_uRight, const uint8_t* d_blocked, int mpCap, const int* d_nMP,
+                                        const uint8_t* d_inView, const uint8_t* d_isBad, const float* d_depth,
+                                        const float* d_projX, const float* d_projY, const float* d_projXR, const int* d_level,
+                                        const float* d_viewCos, const uint8_t* d_mpDesc, const uint8_t* d_mpHasObs, float th,
+                                        int bFarPoints, float thFarPoints, float nnratio, int* d_matchF, int* d_nmatches,
+                                        void* stream);
+
+/* int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)
+ * ORBmatcher.h:55-56, ORBmatcher.cc:1521-1733.  Frame pair f = (image d_curImg[f], image d_lastImg[f]); d_Tcw
+ * [f][7] = CurrentFrame pose (quaternion xyzw + translation); per last-frame feature [nframes][cap]:
+ * lastValid (map point present and not outlier), its world position, representative descriptor, hasObs.
+ * d_bForward / d_bBackward [nframes]: the two flags of :1538-1539 (computed by the caller from the two poses).
+ * d_matchCur [nframes][cap] in/out: index of the last-frame feature whose map point is assigned to current
+ * feature i. */
+int morb_search_by_projection_last_batch(morb_matcher*, const morb_frame_params*, int nframes, const int* d_curImg,
+                                         const int* d_lastImg, int cap, const int* d_count, const morb_keypoint* d_kps,
+                                         const uint8_t* d_desc, const float* d_curURight, const uint8_t* d_curBlocked,
+                                         const float* d_Tcw, const uint8_t* d_lastValid, const float* d_lastXw,
+                                         const uint8_t* d_lastMPdesc, const uint8_t* d_lastMPhasObs, float th,
+                                         const uint8_t* d_bForward, const uint8_t* d_bBackward, int checkOri, int* d_matchCur,
+                                         int* d_nmatches, void* stream);
+
+/* int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, vMatchedPairs, bOnlyStereo, bCoarse)
+ * ORBmatcher.h:84-87, ORBmatcher.cc:821-1042 (pinhole keyframes, no second camera) for npairs keyframe pairs of
+ * a pool of nimg images (arrays [nimg][cap]; d_uRight may be NULL).  R12, t12 (HOST, [npairs][9], [npairs][3]) =
+ * T1w * Tw2; ep (HOST [npairs][2]) = projection of KF1's centre into KF2 (:832-835).  d_match12 [npairs][cap] =
+ * vMatches12 (feature of KF2 matched to feature i of KF1, -1 = none; the pair list is its non-negative entries in
+ * ascending i), d_nmatches = return value. */
+int morb_search_for_triangulation_batch(morb_matcher*, const morb_frame_params*, int npairs, const int* d_img1,
+                                        const int* d_img2, int nimg, int cap, const int* d_count, const morb_keypoint* d_kps,
+                                        const uint8_t* d_desc, const int* d_node, const uint8_t* d_hasMP, const float* d_uRight,
+                                        const float* R12, const float* t12, const float* ep, int bOnlyStereo, int bCoarse,
+                                        int checkOri, int* d_match12, int* d_nmatches, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Optimizer  (include/Optimizer.h:46-139, src/Optimizer.cc; g2o Levenberg-Marquardt semantics)
  * Poses cross the boundary the way the reference hands them to g2o: unit quaternion (x, y, z, w) followed by

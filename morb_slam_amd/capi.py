@@ -15,6 +15,30 @@ assert KP_DTYPE.itemsize == 28
 MORB_OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_EMPTY = 0, -1, -2, -3, -4, -5
 
 
+class FrameParams(C.Structure):
+    """morb_frame_params (include/morb_hip.h)"""
+    _fields_ = [("minX", C.c_float), ("minY", C.c_float), ("maxX", C.c_float), ("maxY", C.c_float),
+                ("gridInvW", C.c_float), ("gridInvH", C.c_float), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("mbf", C.c_float), ("mb", C.c_float), ("logScaleFactor", C.c_float),
+                ("nlevels", C.c_int32), ("scaleFactors", C.c_float * 16), ("levelSigma2", C.c_float * 16)]
+
+
+def make_frame_params(width, height, fx, fy, cx, cy, mbf, mb, scale_factors, level_sigma2, scale_factor=1.2):
+    """Frame constructor bookkeeping for an undistorted camera (Frame.cc:229-241, ComputeImageBounds :859-887)."""
+    import numpy as np
+    p = FrameParams()
+    p.minX, p.minY, p.maxX, p.maxY = 0.0, 0.0, float(width), float(height)
+    p.gridInvW = float(np.float32(64.0) / np.float32(p.maxX - p.minX))
+    p.gridInvH = float(np.float32(48.0) / np.float32(p.maxY - p.minY))
+    p.fx, p.fy, p.cx, p.cy, p.mbf, p.mb = fx, fy, cx, cy, mbf, mb
+    p.logScaleFactor = float(np.log(np.float32(scale_factor)))   # mfLogScaleFactor = log(mfScaleFactor) (float)
+    p.nlevels = len(scale_factors)
+    for i, v in enumerate(scale_factors):
+        p.scaleFactors[i] = float(v)
+        p.levelSigma2[i] = float(level_sigma2[i])
+    return p
+
+
 class MorbError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libmorb_hip error {code}: {msg}")
@@ -66,6 +90,11 @@ def lib():
         L.morb_stereo_match_batch.argtypes = [vp, vp, i, vp, vp, vp, i, f, f, vp, vp, vp]
         L.morb_bow_transform_batch.argtypes = [vp, i, vp, vp, i, vp, vp, i, i, i, vp, vp, vp]
         L.morb_search_by_bow_batch.argtypes = [vp, i, vp, vp, i, vp, vp, vp, vp, vp, i, f, i, vp, vp, vp]
+        PP = C.POINTER(FrameParams)
+        L.morb_is_in_frustum_batch.argtypes = [vp, PP, i, vp, vp, vp, i, vp, vp, vp, vp, vp, f] + [vp] * 8
+        L.morb_search_by_projection_mps_batch.argtypes = [vp, PP, i, vp, i, vp, vp, vp, vp, vp, i] + [vp] * 11 + [f, i, f, f, vp, vp, vp]
+        L.morb_search_by_projection_last_batch.argtypes = [vp, PP, i, vp, vp, i] + [vp] * 10 + [f, vp, vp, i, vp, vp, vp]
+        L.morb_search_for_triangulation_batch.argtypes = [vp, PP, i, vp, vp, i, i] + [vp] * 9 + [i, i, i, vp, vp, vp]
         L.morb_optimizer_create.argtypes = [C.POINTER(vp), i]
         L.morb_optimizer_destroy.argtypes = [vp]
         L.morb_optimizer_destroy.restype = None

@@ -453,6 +453,8 @@ struct morb_matcher {
   float *d_scale = nullptr, *d_invScale = nullptr;
   int* d_idx = nullptr;
   size_t sortElems = 0, binElems = 0, sadElems = 0, idxElems = 0;
+  void* ws[8] = {nullptr};   // generic workspaces for projection.hip
+  size_t wsBytes[8] = {0};
 };
 
 namespace {
@@ -499,8 +501,37 @@ void morb_matcher_destroy(morb_matcher* m) {
   (void)hipStreamSynchronize(m->stream);
   auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   F(m->d_sortA); F(m->d_sortB); F(m->d_bin); F(m->d_sad); F(m->d_scale); F(m->d_invScale); F(m->d_idx);
+  for (auto& w : m->ws) F(w);
   (void)hipStreamDestroy(m->stream);
   delete m;
+}
+
+int morb_matcher_device(const morb_matcher* m) { return m->device; }
+void* morb_matcher_stream(const morb_matcher* m) { return (void*)m->stream; }
+int morb_matcher_workspace(morb_matcher* m, int which, size_t bytes, void** out) {
+  MORB_REQUIRE(m && out && which >= 0 && which < 8, MORB_ERR_INVALID, "bad workspace request");
+  if (m->wsBytes[which] < bytes) {
+    MORB_HIP_CHECK(hipDeviceSynchronize());
+    if (m->ws[which]) (void)hipFree(m->ws[which]);
+    m->ws[which] = nullptr; m->wsBytes[which] = 0;
+    MORB_HIP_CHECK(hipMalloc(&m->ws[which], bytes));
+    m->wsBytes[which] = bytes;
+  }
+  *out = m->ws[which];
+  return MORB_OK;
+}
+int morb_bow_sort_images(morb_matcher* m, int nimg, const int* d_node, const int* d_count, int cap, unsigned long long** d_sorted,
+                         void* stream) {
+  int P = 1;
+  while (P < cap) P <<= 1;
+  MORB_REQUIRE((size_t)P * 8 <= 160 * 1024, MORB_ERR_UNSUPPORTED, "too many features per frame for the LDS sort");
+  hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+  int rc = grow(m->d_sortA, m->sortElems, (size_t)nimg * cap);
+  if (rc != MORB_OK) return rc;
+  MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_sort), hipFuncAttributeMaxDynamicSharedMemorySize, P * 8));
+  hipLaunchKernelGGL(k_bow_sort, dim3(nimg), dim3(256), (size_t)P * 8, st, d_node, d_count, cap, P, m->d_sortA);
+  *d_sorted = m->d_sortA;
+  return MORB_OK;
 }
 
 int morb_hamming_pairs(morb_matcher* m, const uint8_t* d_a, const uint8_t* d_b, int n, int* d_out, void* stream) {

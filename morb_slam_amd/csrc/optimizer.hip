@@ -423,6 +423,10 @@ struct BaDev {
   const float *eObs, *eInfo;            // [nE][3], [nE]
   const int *mpStart, *mpEdges;         // CSR by map point
   const int *kfStart, *kfEdges;         // CSR by keyframe
+  int nPairs;                           // upper-triangular block pairs (i1 <= i2) of the reduced system that occur
+  const int *pairBlock;                 // [nPairs] i1 * nFree + i2
+  const int *pairStart;                 // [nPairs + 1]
+  const int2 *pairEntries;              // (e1, e2): two observations of one map point, col(e1) = i1, col(e2) = i2
   double *pose, *poseBk, *poseEval;     // [nKF][7]
   double *pt, *ptBk, *ptEval;           // [nMP][3]
   double *Hpp;                          // [nFree][36]
@@ -456,7 +460,7 @@ __device__ __forceinline__ void inv3(const double* m, double* o) {
   o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
 }
 
-constexpr int BA_T = 1024, BA_W = BA_T / 64;
+constexpr int BA_T = 512, BA_W = BA_T / 64;
 
 __global__ __launch_bounds__(BA_T) void k_local_ba(const BaDev* __restrict__ probs, int useLds) {
   extern __shared__ double sHs[];  // reduced camera system when it fits
@@ -612,90 +616,105 @@ __global__ __launch_bounds__(BA_T) void k_local_ba(const BaDev* __restrict__ pro
       // push()
       for (int i = tid; i < nKF * 7; i += BA_T) pb.poseBk[i] = pb.pose[i];
       for (int i = tid; i < nMP * 3; i += BA_T) pb.ptBk[i] = pb.pt[i];
-      // ---- BlockSolver::solve (Schur) with lambda on every diagonal ----
-      for (int i = tid; i < P * P; i += BA_T) {
-        const int r = i / P, c = i % P;
-        double v = 0;
-        if (r / 6 == c / 6) { v = pb.Hpp[(size_t)(r / 6) * 36 + (r % 6) * 6 + (c % 6)]; if (r == c) v += lambda; }
-        Hs[i] = v;
-      }
-      for (int i = tid; i < P; i += BA_T) pb.x[i] = pb.b[i];  // bschur accumulates in x[0..P)
-      __syncthreads();
+      // ---- BlockSolver::solve (Schur) with lambda on every diagonal (block_solver.hpp:354-480) ----
+      // (a) per map point: Dinv = (Hll + lambda I)^-1
       for (int m = tid; m < nMP; m += BA_T) {
         double D[9], Di[9];
         for (int k = 0; k < 9; ++k) D[k] = pb.Hll[(size_t)m * 9 + k];
         D[0] += lambda; D[4] += lambda; D[8] += lambda;
         inv3(D, Di);
         for (int k = 0; k < 9; ++k) pb.Dinv[(size_t)m * 9 + k] = Di[k];
-        const double* bl = pb.b + P + 3 * m;
-        double db[3];
-        for (int r = 0; r < 3; ++r) db[r] = Di[r * 3] * bl[0] + Di[r * 3 + 1] * bl[1] + Di[r * 3 + 2] * bl[2];
-        const int k0 = pb.mpStart[m], k1 = pb.mpStart[m + 1];
-        for (int a = k0; a < k1; ++a) {
-          const int e1 = pb.mpEdges[a];
-          const int i1 = pb.kfCol[pb.eKF[e1]];
-          if (i1 < 0) continue;
-          const double* B1 = pb.Hpl + (size_t)e1 * 18;
+      }
+      for (int i = tid; i < P * P; i += BA_T) Hs[i] = 0;
+      __syncthreads();
+      // (b) one wave per block pair (i1 <= i2): Hschur(i1,i2) = [Hpp + lambda I] - sum_l (Hpl_i1 Dinv_l) Hpl_i2^T,
+      //     entries summed in a fixed order (deterministic), mirrored into the lower triangle
+      for (int bp = wv; bp < pb.nPairs; bp += BA_W) {
+        const int i1 = pb.pairBlock[bp] / pb.nFree, i2 = pb.pairBlock[bp] % pb.nFree;
+        double acc[36];
+#pragma unroll
+        for (int k = 0; k < 36; ++k) acc[k] = 0;
+        for (int k = pb.pairStart[bp] + lane; k < pb.pairStart[bp + 1]; k += 64) {
+          const int2 en = pb.pairEntries[k];
+          const double* B1 = pb.Hpl + (size_t)en.x * 18;
+          const double* B2 = pb.Hpl + (size_t)en.y * 18;
+          const double* Di = pb.Dinv + (size_t)pb.eMP[en.x] * 9;
           double BD[18];
+#pragma unroll
           for (int r = 0; r < 6; ++r)
+#pragma unroll
             for (int c = 0; c < 3; ++c) BD[r * 3 + c] = B1[r * 3] * Di[c] + B1[r * 3 + 1] * Di[3 + c] + B1[r * 3 + 2] * Di[6 + c];
-          for (int r = 0; r < 6; ++r) atomicAdd(&pb.x[6 * i1 + r], -(B1[r * 3] * db[0] + B1[r * 3 + 1] * db[1] + B1[r * 3 + 2] * db[2]));
-          for (int bb = k0; bb < k1; ++bb) {
-            const int e2 = pb.mpEdges[bb];
-            const int i2 = pb.kfCol[pb.eKF[e2]];
-            if (i2 < 0) continue;
-            const double* B2 = pb.Hpl + (size_t)e2 * 18;
-            for (int r = 0; r < 6; ++r)
-              for (int c = 0; c < 6; ++c)
-                atomicAdd(&Hs[(size_t)(6 * i1 + r) * P + 6 * i2 + c],
-                          -(BD[r * 3] * B2[c * 3] + BD[r * 3 + 1] * B2[c * 3 + 1] + BD[r * 3 + 2] * B2[c * 3 + 2]));
-          }
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[r * 6 + c] += BD[r * 3] * B2[c * 3] + BD[r * 3 + 1] * B2[c * 3 + 1] + BD[r * 3 + 2] * B2[c * 3 + 2];
+        }
+#pragma unroll
+        for (int k = 0; k < 36; ++k) acc[k] = wave_sum_d(acc[k]);
+        if (lane < 36) {
+          const int r = lane / 6, c = lane % 6;
+          double a = 0;
+#pragma unroll
+          for (int k = 0; k < 36; ++k) if (k == lane) a = acc[k];
+          double v = -a;
+          if (i1 == i2) { v += pb.Hpp[(size_t)i1 * 36 + lane]; if (r == c) v += lambda; }
+          Hs[(size_t)(6 * i1 + r) * P + 6 * i2 + c] = v;
+          if (i1 != i2) Hs[(size_t)(6 * i2 + c) * P + 6 * i1 + r] = v;
         }
       }
+      // (c) bschur = bp - sum Hpl Dinv bl, one wave per free keyframe over its CSR edge list
+      for (int kf = wv; kf < nKF; kf += BA_W) {
+        const int col = pb.kfCol[kf];
+        if (col < 0) continue;
+        double a6[6] = {0, 0, 0, 0, 0, 0};
+        for (int k = pb.kfStart[kf] + lane; k < pb.kfStart[kf + 1]; k += 64) {
+          const int e = pb.kfEdges[k];
+          const int m = pb.eMP[e];
+          const double* Di = pb.Dinv + (size_t)m * 9;
+          const double* bl = pb.b + P + 3 * m;
+          double db[3];
+          for (int r = 0; r < 3; ++r) db[r] = Di[r * 3] * bl[0] + Di[r * 3 + 1] * bl[1] + Di[r * 3 + 2] * bl[2];
+          const double* B1 = pb.Hpl + (size_t)e * 18;
+          for (int r = 0; r < 6; ++r) a6[r] += B1[r * 3] * db[0] + B1[r * 3 + 1] * db[1] + B1[r * 3 + 2] * db[2];
+        }
+        for (int r = 0; r < 6; ++r) a6[r] = wave_sum_d(a6[r]);
+        if (lane == 0) for (int r = 0; r < 6; ++r) pb.x[6 * col + r] = pb.b[6 * col + r] - a6[r];
+      }
       __syncthreads();
-      // ---- reduced system: LDL^T by wave 0 (LinearSolverEigen: fails only on a zero pivot) ----
+      // (d) reduced system: right-looking LDL^T by the whole workgroup (LinearSolverEigen / SimplicialLDLT:
+      //     fails only on a zero pivot), then the two triangular solves by wave 0
       if (tid == 0) sFlag = 1;
       __syncthreads();
-      if (wv == 0) {
-        bool ok = true;
-        for (int j = 0; j < P && ok; ++j) {
-          // d_j = A_jj - sum_k L_jk^2 D_k ; L_ij = (A_ij - sum_k L_ik L_jk D_k) / d_j ; D stored on the diagonal
-          double d = Hs[(size_t)j * P + j];
-          double part = 0;
-          for (int k = lane; k < j; k += 64) { const double l = Hs[(size_t)j * P + k]; part += l * l * Hs[(size_t)k * P + k]; }
-          d -= wave_sum_d(part);
-          if (d == 0 || d != d) { ok = false; break; }
-          for (int i = j + 1 + lane; i < P; i += 64) {
-            double s = Hs[(size_t)i * P + j];
-            for (int k = 0; k < j; ++k) s -= Hs[(size_t)i * P + k] * Hs[(size_t)j * P + k] * Hs[(size_t)k * P + k];
-            Hs[(size_t)i * P + j] = s / d;
-          }
-          if (lane == 0) Hs[(size_t)j * P + j] = d;
+      for (int j = 0; j < P; ++j) {
+        const double d = Hs[(size_t)j * P + j];
+        if (d == 0 || d != d) { if (tid == 0) sFlag = 0; break; }   // uniform: every thread reads the same d
+        __syncthreads();
+        // trailing update with the UNSCALED column: A_ik -= A_ij * A_kj / d  (i >= k > j), then scale column j
+        const int nrem = P - j - 1;
+        for (int t = tid; t < nrem * nrem; t += BA_T) {
+          const int i = j + 1 + t / nrem, k = j + 1 + t % nrem;
+          if (k <= i) Hs[(size_t)i * P + k] -= Hs[(size_t)i * P + j] * Hs[(size_t)k * P + j] / d;
+        }
+        __syncthreads();
+        for (int i = j + 1 + tid; i < P; i += BA_T) Hs[(size_t)i * P + j] /= d;
+      }
+      __syncthreads();
+      if (sFlag != 0 && wv == 0) {
+        for (int j = 0; j < P; ++j) {           // forward: L y = b
+          const double xj = pb.x[j];
+          for (int i = j + 1 + lane; i < P; i += 64) pb.x[i] -= Hs[(size_t)i * P + j] * xj;
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
           __builtin_amdgcn_wave_barrier();
         }
-        if (ok) {
-          // forward, diagonal, backward substitution on x[0..P) (one wave, serial over rows, lanes over columns)
-          for (int i = 0; i < P; ++i) {
-            double part = 0;
-            for (int k = lane; k < i; k += 64) part += Hs[(size_t)i * P + k] * pb.x[k];
-            part = wave_sum_d(part);
-            if (lane == 0) pb.x[i] -= part;
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-          }
-          for (int i = lane; i < P; i += 64) pb.x[i] /= Hs[(size_t)i * P + i];
+        for (int i = lane; i < P; i += 64) pb.x[i] /= Hs[(size_t)i * P + i];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int j = P - 1; j >= 0; --j) {      // backward: L^T x = y
+          const double xj = pb.x[j];
+          for (int i = lane; i < j; i += 64) pb.x[i] -= Hs[(size_t)j * P + i] * xj;
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
           __builtin_amdgcn_wave_barrier();
-          for (int i = P - 1; i >= 0; --i) {
-            double part = 0;
-            for (int k = i + 1 + lane; k < P; k += 64) part += Hs[(size_t)k * P + i] * pb.x[k];
-            part = wave_sum_d(part);
-            if (lane == 0) pb.x[i] -= part;
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-          }
-        } else if (lane == 0) sFlag = 0;
+        }
       }
       __syncthreads();
       const bool ok2 = sFlag != 0;
@@ -875,6 +894,36 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
     std::vector<int> a(mpStart.begin(), mpStart.end() - 1), b(kfStart.begin(), kfStart.end() - 1);
     for (int e = 0; e < nE; ++e) { mpEdges[a[eMP[e]]++] = e; kfEdges[b[eKF[e]]++] = e; }
   }
+  // block pairs of the reduced camera system and, per pair, the (observation, observation) entries that feed it
+  std::vector<int> pairBlock, pairStart;
+  std::vector<int2> pairEntries;
+  {
+    const int nb = std::max(nFree, 1) * std::max(nFree, 1);
+    std::vector<int> cnt(nb + 1, 0);
+    auto forPairs = [&](auto&& fn) {
+      for (int m = 0; m < nMP; ++m)
+        for (int a = mpStart[m]; a < mpStart[m + 1]; ++a) {
+          const int ea = mpEdges[a], ca = kfCol[eKF[ea]];
+          if (ca < 0) continue;
+          for (int b2 = mpStart[m]; b2 < mpStart[m + 1]; ++b2) {
+            const int eb = mpEdges[b2], cb = kfCol[eKF[eb]];
+            if (cb < 0 || cb < ca) continue;
+            fn(ca * nFree + cb, ea, eb);
+          }
+        }
+    };
+    forPairs([&](int key, int, int) { cnt[key + 1]++; });
+    std::vector<int> slot(nb, -1);
+    int total = 0;
+    for (int k = 0; k < nb; ++k) {
+      if (cnt[k + 1] > 0) { slot[k] = (int)pairBlock.size(); pairBlock.push_back(k); pairStart.push_back(total); total += cnt[k + 1]; }
+    }
+    pairStart.push_back(total);
+    pairEntries.resize(std::max(total, 1));
+    std::vector<int> fill(pairStart.begin(), pairStart.end());
+    forPairs([&](int key, int ea, int eb) { pairEntries[fill[slot[key]]++] = make_int2(ea, eb); });
+  }
+  h.nPairs = (int)pairBlock.size();
   bool fail = false;
   auto up = [&](const void* src, size_t bytes) -> void* {
     void* d = nullptr;
@@ -892,6 +941,9 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
   h.mpEdges = (const int*)up(mpEdges.data(), sizeof(int) * nE);
   h.kfStart = (const int*)up(kfStart.data(), sizeof(int) * (nKF + 1));
   h.kfEdges = (const int*)up(kfEdges.data(), sizeof(int) * nE);
+  h.pairBlock = (const int*)up(pairBlock.data(), sizeof(int) * std::max<size_t>(pairBlock.size(), 1));
+  h.pairStart = (const int*)up(pairStart.data(), sizeof(int) * pairStart.size());
+  h.pairEntries = (const int2*)up(pairEntries.data(), sizeof(int2) * pairEntries.size());
   const size_t nx = (size_t)h.P + 3 * (size_t)nMP;
   h.pose = (double*)up(nullptr, sizeof(double) * 7 * nKF);
   h.poseBk = (double*)up(nullptr, sizeof(double) * 7 * nKF);

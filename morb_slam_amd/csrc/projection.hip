@@ -1,0 +1,653 @@
+// Projection-guided matchers and the frustum test for MI355X (gfx950), batched over frames, non-fisheye
+// branches (Frame::Nleft == -1):
+//   F3  Frame::isInFrustum + MapPoint::PredictScale          (reference src/Frame.cc:611-678, MapPoint.cc:536-566)
+//   F4  Frame::PosInGrid / GetFeaturesInArea semantics       (Frame.cc:742-820; 64 x 48 grid, Frame.h:44-45)
+//   M1  ORBmatcher::SearchByProjection(Frame&, MapPoints..)  (src/ORBmatcher.cc:42-209)
+//   M2  ORBmatcher::SearchByProjection(Cur, Last, th, bMono) (:1521-1733)
+//   M4  ORBmatcher::SearchForTriangulation                   (:821-1042)
+// The reference walks a 64 x 48 grid of index vectors and keeps "first best" in the walk order (cell column,
+// cell row, insertion order).  Here no grid is built: a wave tests every feature of the frame against the query
+// window (same cell-range + level + |dx|,|dy| < r predicate, PosInGrid's round() included) and packs
+// (distance, cell, index, octave) into one 64-bit key whose ordering IS the reference's walk order, so best /
+// second best are plain wave64 min-reductions.  The greedy dependency ("skip features that already hold a map
+// point with observations", which includes the ones assigned earlier in the same call) is resolved by a second
+// kernel: one wave per frame replays the queries in reference order over the pre-computed candidate keys.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+using namespace morb;
+
+struct morb_matcher;  // defined in matcher.hip
+extern "C" {
+int morb_matcher_device(const morb_matcher*);
+void* morb_matcher_stream(const morb_matcher*);
+int morb_matcher_workspace(morb_matcher*, int which, size_t bytes, void** out);
+}
+
+namespace {
+
+constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;
+constexpr int GRID_ROWS = 48, GRID_COLS = 64;
+constexpr int CAND_CAP = 128;  // candidate keys kept per query; longer lists are re-derived in the resolve pass
+
+struct Desc { uint32_t w[8]; };
+__device__ __forceinline__ Desc load_desc(const uint8_t* p) {
+  Desc d;
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 a = q[0], b = q[1];
+  d.w[0] = a.x; d.w[1] = a.y; d.w[2] = a.z; d.w[3] = a.w; d.w[4] = b.x; d.w[5] = b.y; d.w[6] = b.z; d.w[7] = b.w;
+  return d;
+}
+__device__ __forceinline__ int hamming(const Desc& a, const Desc& b) {
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += __popc(a.w[i] ^ b.w[i]);
+  return s;
+}
+__device__ __forceinline__ void top2_insert(unsigned long long& k1, unsigned long long& k2, unsigned long long k) {
+  if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;
+}
+__device__ __forceinline__ void wave_top2(unsigned long long& k1, unsigned long long& k2) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o1 = __shfl_xor(k1, off, 64), o2 = __shfl_xor(k2, off, 64);
+    const unsigned long long lo = k1 < o1 ? k1 : o1, hi1 = k1 < o1 ? o1 : k1, lo2 = k1 < o1 ? k2 : o2;
+    k1 = lo;
+    k2 = hi1 < lo2 ? hi1 : lo2;
+  }
+}
+
+struct Query {       // one window search (a map point / a last-frame feature)
+  float x, y, r;     // window centre and half size
+  int minLevel, maxLevel;
+  float xr, erMax;   // stereo gate: |xr - uRight[j]| <= erMax for features with uRight > 0
+  float angle;       // query keypoint angle (rotation histogram, M2)
+  int valid;
+};
+
+// key = dist << 32 | cell << 20 | j << 4 | octave   (cell = posX * 48 + posY: the GetFeaturesInArea walk order)
+__device__ __forceinline__ unsigned long long make_key(const morb_frame_params& P, const Query& q, const Desc& qd,
+                                                       const morb_keypoint& kp, int j, const uint8_t* descRow,
+                                                       const float* uRight, int cx0, int cx1, int cy0, int cy1) {
+  const int posX = (int)roundf((kp.x - P.minX) * P.gridInvW), posY = (int)roundf((kp.y - P.minY) * P.gridInvH);
+  if (posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS) return ~0ull;  // never entered the grid
+  if (posX < cx0 || posX > cx1 || posY < cy0 || posY > cy1) return ~0ull;
+  const bool bCheckLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
+  if (bCheckLevels) {
+    if (kp.octave < q.minLevel) return ~0ull;
+    if (q.maxLevel >= 0 && kp.octave > q.maxLevel) return ~0ull;
+  }
+  const float distx = kp.x - q.x, disty = kp.y - q.y;
+  if (!(fabsf(distx) < q.r && fabsf(disty) < q.r)) return ~0ull;
+  if (uRight) {
+    const float ur = uRight[j];
+    if (ur > 0) {
+      const float er = fabsf(q.xr - ur);
+      if (er > q.erMax) return ~0ull;
+    }
+  }
+  const int d = hamming(qd, load_desc(descRow));
+  return ((unsigned long long)d << 32) | ((unsigned long long)(posX * GRID_ROWS + posY) << 20) |
+         ((unsigned long long)j << 4) | (unsigned long long)(kp.octave & 15);
+}
+__device__ __forceinline__ bool cell_range(const morb_frame_params& P, const Query& q, int& cx0, int& cx1, int& cy0, int& cy1) {
+  cx0 = max(0, (int)floorf((q.x - P.minX - q.r) * P.gridInvW));
+  if (cx0 >= GRID_COLS) return false;
+  cx1 = min(GRID_COLS - 1, (int)ceilf((q.x - P.minX + q.r) * P.gridInvW));
+  if (cx1 < 0) return false;
+  cy0 = max(0, (int)floorf((q.y - P.minY - q.r) * P.gridInvH));
+  if (cy0 >= GRID_ROWS) return false;
+  cy1 = min(GRID_ROWS - 1, (int)ceilf((q.y - P.minY + q.r) * P.gridInvH));
+  if (cy1 < 0) return false;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// F3: isInFrustum, one thread per map point
+__global__ __launch_bounds__(256) void k_frustum(morb_frame_params P, const float* __restrict__ Rcw, const float* __restrict__ tcw,
+                                                 const float* __restrict__ Ow, int mpCap, const int* __restrict__ nMPv,
+                                                 const float* __restrict__ Pw, const float* __restrict__ normal,
+                                                 const float* __restrict__ maxDist, const float* __restrict__ minDist,
+                                                 float viewingCosLimit, const float* __restrict__ ratioThr,
+                                                 uint8_t* __restrict__ inView, float* __restrict__ projX,
+                                                 float* __restrict__ projY, float* __restrict__ projXR,
+                                                 float* __restrict__ depth, int* __restrict__ level, float* __restrict__ viewCosOut) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nMPv[f]) return;
+  const size_t o = (size_t)f * mpCap + i;
+  uint8_t in = 0;
+  float pX = -1, pY = -1, pXR = -1, dep = -1, vc = -1;
+  int lvl = -1;
+  const float* R = Rcw + 9 * f; const float* t = tcw + 3 * f; const float* O = Ow + 3 * f;
+  const float* X = Pw + o * 3;
+  float Pc[3];
+  for (int r = 0; r < 3; ++r) Pc[r] = (R[r * 3] * X[0] + R[r * 3 + 1] * X[1]) + R[r * 3 + 2] * X[2] + t[r];
+  const float Pc_dist = sqrtf(Pc[0] * Pc[0] + Pc[1] * Pc[1] + Pc[2] * Pc[2]);
+  const float invz = 1.0f / Pc[2];
+  do {
+    if (Pc[2] < 0.0f) break;
+    const float u = P.fx * Pc[0] / Pc[2] + P.cx, v = P.fy * Pc[1] / Pc[2] + P.cy;
+    if (u < P.minX || u > P.maxX) break;
+    if (v < P.minY || v > P.maxY) break;
+    pX = u; pY = v;
+    const float maxDistance = 1.2f * maxDist[o], minDistance = 0.8f * minDist[o];
+    const float PO[3] = {X[0] - O[0], X[1] - O[1], X[2] - O[2]};
+    const float dist = sqrtf(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+    if (dist < minDistance || dist > maxDistance) break;
+    const float* Pn = normal + o * 3;
+    const float viewCos = (PO[0] * Pn[0] + PO[1] * Pn[1] + PO[2] * Pn[2]) / dist;
+    if (viewCos < viewingCosLimit) break;
+    // PredictScale: ceil(logf(ratio) / logScaleFactor) clamped to [0, nlevels-1].  ratioThr[n] = the largest float
+    // ratio whose predicted level is <= n, tabulated on the host with the host libm's logf (the reference's logf),
+    // so the device needs no logf of its own and reproduces the reference's rounding exactly.
+    const float ratio = maxDist[o] / dist;
+    int n = 0;
+    while (n < P.nlevels - 1 && ratio > ratioThr[n]) ++n;
+    in = 1; pXR = u - P.mbf * invz; dep = Pc_dist; lvl = n; vc = viewCos;
+  } while (0);
+  inView[o] = in; projX[o] = pX; projY[o] = pY; projXR[o] = pXR; depth[o] = dep; level[o] = lvl; viewCosOut[o] = vc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// query preparation
+__global__ __launch_bounds__(256) void k_prep_mps(morb_frame_params P, int mpCap, const int* __restrict__ nMPv,
+                                                  const uint8_t* __restrict__ inView, const uint8_t* __restrict__ isBad,
+                                                  const float* __restrict__ depth, const float* __restrict__ projX,
+                                                  const float* __restrict__ projY, const float* __restrict__ projXR,
+                                                  const int* __restrict__ level, const float* __restrict__ viewCos, float th,
+                                                  int bFarPoints, float thFarPoints, Query* __restrict__ qs) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= mpCap) return;
+  const size_t o = (size_t)f * mpCap + i;
+  Query q;
+  memset(&q, 0, sizeof q);
+  if (i < nMPv[f] && inView[o] && !(bFarPoints && depth[o] > thFarPoints) && !isBad[o]) {
+    const int lv = level[o];
+    float r = ((double)viewCos[o] > 0.998) ? 2.5f : 4.0f;  // RadiusByViewingCos (:211-216)
+    if ((double)th != 1.0) r *= th;
+    q.valid = 1; q.x = projX[o]; q.y = projY[o]; q.r = r * P.scaleFactors[lv];
+    q.minLevel = lv - 1; q.maxLevel = lv; q.xr = projXR[o]; q.erMax = r * P.scaleFactors[lv];
+  }
+  qs[o] = q;
+}
+
+__device__ __forceinline__ void q_rotate_f(const float* q, const float* v, float* out) {
+  const float ux = q[0], uy = q[1], uz = q[2], w = q[3];
+  float a = uy * v[2] - uz * v[1], b = uz * v[0] - ux * v[2], c = ux * v[1] - uy * v[0];
+  a += a; b += b; c += c;
+  out[0] = v[0] + w * a + (uy * c - uz * b);
+  out[1] = v[1] + w * b + (uz * a - ux * c);
+  out[2] = v[2] + w * c + (ux * b - uy * a);
+}
+
+__global__ __launch_bounds__(256) void k_prep_last(morb_frame_params P, int cap, const int* __restrict__ count,
+                                                   const int* __restrict__ lastImg, const morb_keypoint* __restrict__ kps,
+                                                   const uint8_t* __restrict__ lastValid, const float* __restrict__ lastXw,
+                                                   const float* __restrict__ Tcw, float th, const uint8_t* __restrict__ fwd,
+                                                   const uint8_t* __restrict__ bwd, Query* __restrict__ qs) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cap) return;
+  const size_t o = (size_t)f * cap + i;
+  Query q;
+  memset(&q, 0, sizeof q);
+  const int img = lastImg[f];
+  if (i < count[img] && lastValid[o]) {
+    const float* T = Tcw + 7 * f;
+    float x3Dc[3];
+    q_rotate_f(T, lastXw + o * 3, x3Dc);
+    x3Dc[0] += T[4]; x3Dc[1] += T[5]; x3Dc[2] += T[6];
+    const float invzc = (float)(1.0 / (double)x3Dc[2]);
+    const float u = P.fx * x3Dc[0] / x3Dc[2] + P.cx, v = P.fy * x3Dc[1] / x3Dc[2] + P.cy;
+    if (!(invzc < 0) && !(u < P.minX || u > P.maxX) && !(v < P.minY || v > P.maxY)) {
+      const morb_keypoint kp = kps[(size_t)img * cap + i];
+      const int oct = kp.octave;
+      q.valid = 1; q.x = u; q.y = v; q.r = th * P.scaleFactors[oct];
+      if (fwd[f]) { q.minLevel = oct; q.maxLevel = -1; }
+      else if (bwd[f]) { q.minLevel = 0; q.maxLevel = oct; }
+      else { q.minLevel = oct - 1; q.maxLevel = oct + 1; }
+      q.xr = u - P.mbf * invzc; q.erMax = q.r; q.angle = kp.angle;
+    }
+  }
+  qs[o] = q;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// phase A: candidate keys per query (one wave per query, lanes over the frame's features)
+__global__ __launch_bounds__(256) void k_candidates(morb_frame_params P, int qCap, const Query* __restrict__ qs,
+                                                    const uint8_t* __restrict__ qDesc, const int* __restrict__ fImg, int cap,
+                                                    const int* __restrict__ count, const morb_keypoint* __restrict__ kps,
+                                                    const uint8_t* __restrict__ desc, const float* __restrict__ uRight,
+                                                    unsigned long long* __restrict__ cand, int* __restrict__ candCnt) {
+  const int f = blockIdx.y, lane = threadIdx.x & 63;
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= qCap) return;
+  const size_t qo = (size_t)f * qCap + qi;
+  const Query q = qs[qo];
+  int n = 0;
+  int cx0, cx1, cy0, cy1;
+  if (q.valid && cell_range(P, q, cx0, cx1, cy0, cy1)) {
+    const int img = fImg[f];
+    const int N = count[img];
+    const Desc qd = load_desc(qDesc + qo * 32);
+    const float* ur = uRight ? uRight + (size_t)f * cap : nullptr;
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int j0 = 0; j0 < N; j0 += 64) {
+      const int j = j0 + lane;
+      unsigned long long k = ~0ull;
+      if (j < N) k = make_key(P, q, qd, kps[(size_t)img * cap + j], j, desc + ((size_t)img * cap + j) * 32, ur, cx0, cx1, cy0, cy1);
+      const uint64_t m = __ballot(k != ~0ull);
+      if (k != ~0ull) {
+        const int slot = n + __popcll(m & lt);
+        if (slot < CAND_CAP) cand[qo * CAND_CAP + slot] = k;
+      }
+      n += __popcll(m);
+    }
+  }
+  if (lane == 0) candCnt[qo] = n;
+}
+
+// phase B: replay the queries in reference order, one wave per frame
+template <bool TOP2>
+__global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, const int* __restrict__ nQv,
+                                                const Query* __restrict__ qs, const uint8_t* __restrict__ qDesc,
+                                                const uint8_t* __restrict__ qHasObs, const int* __restrict__ fImg, int cap,
+                                                const int* __restrict__ count, const morb_keypoint* __restrict__ kps,
+                                                const uint8_t* __restrict__ desc, const float* __restrict__ uRight,
+                                                const uint8_t* __restrict__ blockedIn,
+                                                const unsigned long long* __restrict__ cand, const int* __restrict__ candCnt,
+                                                float nnratio, int checkOri, int* __restrict__ match,
+                                                int* __restrict__ nmatches, int* __restrict__ entryJ, int* __restrict__ entryBin) {
+  extern __shared__ uint8_t blocked[];
+  __shared__ int hist[HISTO_LENGTH];
+  const int f = blockIdx.x, lane = threadIdx.x;
+  const int img = fImg[f];
+  const int N = count[img];
+  const int nQ = nQv ? nQv[f] : count[fImg[f]];
+  for (int j = lane; j < N; j += 64) blocked[j] = blockedIn ? blockedIn[(size_t)f * cap + j] : 0;
+  if (lane < HISTO_LENGTH) hist[lane] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  const float* ur = uRight ? uRight + (size_t)f * cap : nullptr;
+  int* mF = match + (size_t)f * cap;
+  int nm = 0, nEntries = 0;
+  const float factor = 1.0f / HISTO_LENGTH;
+  for (int qi = 0; qi < nQ && qi < qCap; ++qi) {
+    const size_t qo = (size_t)f * qCap + qi;
+    const int cnt = candCnt[qo];
+    if (cnt == 0) continue;
+    unsigned long long k1 = ~0ull, k2 = ~0ull;
+    if (cnt <= CAND_CAP) {
+      for (int c = lane; c < cnt; c += 64) {
+        const unsigned long long k = cand[qo * CAND_CAP + c];
+        if (!blocked[(k >> 4) & 0xFFFF]) top2_insert(k1, k2, k);
+      }
+    } else {  // dense window: derive the keys again from the features
+      const Query q = qs[qo];
+      int cx0, cx1, cy0, cy1;
+      cell_range(P, q, cx0, cx1, cy0, cy1);
+      const Desc qd = load_desc(qDesc + qo * 32);
+      for (int j = lane; j < N; j += 64) {
+        if (blocked[j]) continue;
+        const unsigned long long k = make_key(P, q, qd, kps[(size_t)img * cap + j], j, desc + ((size_t)img * cap + j) * 32, ur, cx0, cx1, cy0, cy1);
+        if (k != ~0ull) top2_insert(k1, k2, k);
+      }
+    }
+    wave_top2(k1, k2);
+    if (k1 == ~0ull) continue;
+    const int bestDist = (int)(k1 >> 32), bestIdx = (int)((k1 >> 4) & 0xFFFF);
+    bool accept;
+    if (TOP2) {  // ORBmatcher.cc:118-137
+      const int bestLevel = (int)(k1 & 15);
+      const int bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 32), bestLevel2 = k2 == ~0ull ? -1 : (int)(k2 & 15);
+      accept = bestDist <= TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2);
+    } else {
+      accept = bestDist <= TH_HIGH;  // :1617
+    }
+    if (accept) {
+      if (lane == 0) {
+        mF[bestIdx] = qi;
+        blocked[bestIdx] = qHasObs ? qHasObs[qo] : 1;
+        if (!TOP2 && checkOri) {
+          float rot = qs[qo].angle - kps[(size_t)img * cap + bestIdx].angle;
+          if (rot < 0.0f) rot += 360.0f;
+          int bin = (int)roundf(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          entryJ[(size_t)f * qCap + nEntries] = bestIdx;
+          entryBin[(size_t)f * qCap + nEntries] = bin;
+          hist[bin] += 1;
+        }
+      }
+      ++nm; ++nEntries;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (!TOP2 && checkOri) {  // ComputeThreeMaxima + un-assign (:1708-1730)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      const int s = hist[i];
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+      else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+    int removed = 0;
+    for (int e = lane; e < nEntries; e += 64) {
+      const int b = entryBin[(size_t)f * qCap + e];
+      if (b != ind1 && b != ind2 && b != ind3) { mF[entryJ[(size_t)f * qCap + e]] = -1; ++removed; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) removed += __shfl_xor(removed, off, 64);
+    nm -= removed;
+  }
+  if (lane == 0) nmatches[f] = nm;
+}
+
+__global__ void k_gather_counts(const int* __restrict__ count, const int* __restrict__ img, int n, int* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = count[img[i]];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// M4: SearchForTriangulation.  vbMatched2 is never set in this fork, so every KF1 feature is independent:
+// one wave per KF1 feature, lanes over the KF2 features of the same BoW node (sorted lists from k_bow_sort),
+// minimum of (dist, -position): the reference's "dist <= bestDist replaces" keeps the LAST equal candidate.
+__global__ __launch_bounds__(256) void k_triangulation(const unsigned long long* __restrict__ sorted, int cap,
+                                                       const int* __restrict__ count, const int* __restrict__ img1v,
+                                                       const int* __restrict__ img2v, const morb_keypoint* __restrict__ kps,
+                                                       const uint8_t* __restrict__ desc, const int* __restrict__ node,
+                                                       const uint8_t* __restrict__ hasMP, const float* __restrict__ uRight,
+                                                       morb_frame_params P, const float* __restrict__ F12v,
+                                                       const float* __restrict__ epv, int bOnlyStereo, int bCoarse,
+                                                       int* __restrict__ match12, int* __restrict__ bin12) {
+  const int pair = blockIdx.y, lane = threadIdx.x & 63;
+  const int idx1 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int i1 = img1v[pair], i2 = img2v[pair];
+  if (idx1 >= cap) return;
+  int result = -1, bin = -1;
+  const size_t o1 = (size_t)i1 * cap + idx1;
+  const int nd = idx1 < count[i1] ? node[o1] : -1;
+  const bool bStereo1 = uRight && uRight[o1] >= 0;
+  if (nd >= 0 && !hasMP[o1] && !(bOnlyStereo && !bStereo1)) {
+    const unsigned long long* s2 = sorted + (size_t)i2 * cap;
+    const int n2 = count[i2];
+    int lo = 0, hi = n2;
+    const unsigned long long target = (unsigned long long)(unsigned)nd << 32;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s2[mid] < target) lo = mid + 1; else hi = mid; }
+    const morb_keypoint kp1 = kps[o1];
+    const Desc d1 = load_desc(desc + o1 * 32);
+    const float* F12 = F12v + 9 * pair;
+    const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+    const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+    const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+    const float den = a * a + b * b;
+    unsigned long long best = ~0ull;
+    for (int s0 = lo; s0 < n2; s0 += 64) {
+      const unsigned long long first = s2[s0];
+      if ((unsigned)(first >> 32) != (unsigned)nd) break;  // wave-uniform: s0 is uniform
+      const int s = s0 + lane;
+      if (s < n2) {
+        const unsigned long long k2 = s2[s];
+        if ((unsigned)(k2 >> 32) == (unsigned)nd) {
+          const int idx2 = (int)(k2 & 0xFFFFFFFFu);
+          const size_t o2 = (size_t)i2 * cap + idx2;
+          const bool bStereo2 = uRight && uRight[o2] >= 0;
+          if (!hasMP[o2] && !(bOnlyStereo && !bStereo2)) {
+            const int dist = hamming(d1, load_desc(desc + o2 * 32));
+            if (dist <= TH_LOW) {
+              const morb_keypoint kp2 = kps[o2];
+              bool ok = true;
+              if (!bStereo1 && !bStereo2) {
+                const float distex = epv[2 * pair] - kp2.x, distey = epv[2 * pair + 1] - kp2.y;
+                if (distex * distex + distey * distey < 100 * P.scaleFactors[kp2.octave]) ok = false;
+              }
+              if (ok && !bCoarse) {  // Pinhole::epipolarConstrain (Pinhole.cpp:111-139)
+                const float num = a * kp2.x + b * kp2.y + c;
+                if (den == 0) ok = false;
+                else { const float dsqr = num * num / den; ok = (double)dsqr < 3.84 * (double)P.levelSigma2[kp2.octave]; }
+              }
+              if (ok) {
+                const unsigned long long k = ((unsigned long long)dist << 32) | (unsigned)(0x7FFFFFFF - (s - lo));
+                best = k < best ? k : best;
+              }
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(best, off, 64); best = o < best ? o : best; }
+    if (best != ~0ull) {
+      const int pos = lo + (0x7FFFFFFF - (int)(best & 0xFFFFFFFFu));
+      result = (int)(s2[pos] & 0xFFFFFFFFu);
+      float rot = kp1.angle - kps[(size_t)i2 * cap + result].angle;
+      if (rot < 0.0f) rot += 360.0f;
+      bin = (int)roundf(rot * (1.0f / HISTO_LENGTH));
+      if (bin == HISTO_LENGTH) bin = 0;
+    }
+  }
+  if (lane == 0) { match12[(size_t)pair * cap + idx1] = result; bin12[(size_t)pair * cap + idx1] = bin; }
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+// largest float ratio whose PredictScale level is <= n, using the host libm logf (monotone): bisection on the
+// float bit pattern
+static float ratio_threshold(int n, float logScaleFactor) {
+  auto lvl = [&](float r) { return (int)std::ceil(std::log(r) / logScaleFactor); };
+  uint32_t lo = 0x00800000u, hi = 0x7F7FFFFFu;  // smallest normal .. FLT_MAX
+  auto asf = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+  if (lvl(asf(lo)) > n) return 0.f;
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (lvl(asf(mid)) <= n) lo = mid; else hi = mid;
+  }
+  return asf(lo);
+}
+
+int morb_is_in_frustum_batch(morb_matcher* m, const morb_frame_params* P, int nframes, const float* d_Rcw, const float* d_tcw,
+                             const float* d_Ow, int mpCap, const int* d_nMP, const float* d_Pw, const float* d_normal,
+                             const float* d_maxDist, const float* d_minDist, float viewingCosLimit, uint8_t* d_inView,
+                             float* d_projX, float* d_projY, float* d_projXR, float* d_depth, int* d_level,
+                             float* d_viewCos, void* stream) {
+  MORB_REQUIRE(m && P && d_Rcw && d_tcw && d_Ow && d_nMP && d_Pw && d_normal && d_maxDist && d_minDist && d_inView && d_projX &&
+                   d_projY && d_projXR && d_depth && d_level && d_viewCos, MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(nframes > 0 && mpCap > 0 && P->nlevels >= 1 && P->nlevels <= 16, MORB_ERR_INVALID, "bad sizes");
+  MORB_HIP_CHECK(hipSetDevice(morb_matcher_device(m)));
+  hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
+  float thr[16];
+  for (int n = 0; n < 16; ++n) thr[n] = n < P->nlevels - 1 ? ratio_threshold(n, P->logScaleFactor) : 3.4e38f;
+  void* d_thr = nullptr;
+  int rc = morb_matcher_workspace(m, 4, sizeof thr, &d_thr);
+  if (rc != MORB_OK) return rc;
+  MORB_HIP_CHECK(hipMemcpyAsync(d_thr, thr, sizeof thr, hipMemcpyHostToDevice, st));
+  MORB_HIP_CHECK(hipStreamSynchronize(st));  // thr lives on this stack frame
+  hipLaunchKernelGGL(k_frustum, dim3(div_up(mpCap, 256), nframes), dim3(256), 0, st, *P, d_Rcw, d_tcw, d_Ow, mpCap, d_nMP, d_Pw,
+                     d_normal, d_maxDist, d_minDist, viewingCosLimit, (const float*)d_thr, d_inView, d_projX, d_projY, d_projXR,
+                     d_depth, d_level, d_viewCos);
+  MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}
+
+static int window_search(morb_matcher* m, const morb_frame_params* P, bool top2, int nframes, int qCap, const int* d_nQ,
+                         const Query* d_qs, const uint8_t* d_qDesc, const uint8_t* d_qHasObs, const int* d_fImg, int cap,
+                         const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc, const float* d_uRight,
+                         const uint8_t* d_blocked, float nnratio, int checkOri, int* d_match, int* d_nmatches,
+                         hipStream_t st) {
+  void *cand = nullptr, *cnt = nullptr, *ej = nullptr, *eb = nullptr;
+  int rc = morb_matcher_workspace(m, 0, sizeof(unsigned long long) * (size_t)nframes * qCap * CAND_CAP, &cand);
+  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 1, sizeof(int) * (size_t)nframes * qCap, &cnt);
+  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 2, sizeof(int) * (size_t)nframes * qCap, &ej);
+  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 3, sizeof(int) * (size_t)nframes * qCap, &eb);
+  if (rc != MORB_OK) return rc;
+  hipLaunchKernelGGL(k_candidates, dim3(div_up(qCap, 4), nframes), dim3(256), 0, st, *P, qCap, d_qs, d_qDesc, d_fImg, cap, d_count,
+                     d_kps, d_desc, d_uRight, (unsigned long long*)cand, (int*)cnt);
+  const size_t smem = (size_t)cap;
+  if (top2)
+    hipLaunchKernelGGL(k_resolve<true>, dim3(nframes), dim3(64), smem, st, *P, qCap, d_nQ, d_qs, d_qDesc, d_qHasObs, d_fImg, cap,
+                       d_count, d_kps, d_desc, d_uRight, d_blocked, (const unsigned long long*)cand, (const int*)cnt, nnratio,
+                       checkOri, d_match, d_nmatches, (int*)ej, (int*)eb);
+  else
+    hipLaunchKernelGGL(k_resolve<false>, dim3(nframes), dim3(64), smem, st, *P, qCap, d_nQ, d_qs, d_qDesc, d_qHasObs, d_fImg, cap,
+                       d_count, d_kps, d_desc, d_uRight, d_blocked, (const unsigned long long*)cand, (const int*)cnt, nnratio,
+                       checkOri, d_match, d_nmatches, (int*)ej, (int*)eb);
+  MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}
+
+int morb_search_by_projection_mps_batch(morb_matcher* m, const morb_frame_params* P, int nframes, const int* d_fImg, int cap,
+                                        const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc,
+                                        const float* d_uRight, const uint8_t* d_blocked, int mpCap, const int* d_nMP,
+                                        const uint8_t* d_inView, const uint8_t* d_isBad, const float* d_depth,
+                                        const float* d_projX, const float* d_projY, const float* d_projXR, const int* d_level,
+                                        const float* d_viewCos, const uint8_t* d_mpDesc, const uint8_t* d_mpHasObs, float th,
+                                        int bFarPoints, float thFarPoints, float nnratio, int* d_matchF, int* d_nmatches,
+                                        void* stream) {
+  MORB_REQUIRE(m && P && d_fImg && d_count && d_kps && d_desc && d_nMP && d_inView && d_isBad && d_depth && d_projX && d_projY &&
+                   d_projXR && d_level && d_viewCos && d_mpDesc && d_mpHasObs && d_matchF && d_nmatches, MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(nframes > 0 && cap > 0 && cap <= 65535 && mpCap > 0, MORB_ERR_INVALID, "bad sizes");
+  MORB_HIP_CHECK(hipSetDevice(morb_matcher_device(m)));
+  hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
+  void* qs = nullptr;
+  int rc = morb_matcher_workspace(m, 5, sizeof(Query) * (size_t)nframes * mpCap, &qs);
+  if (rc != MORB_OK) return rc;
+  hipLaunchKernelGGL(k_prep_mps, dim3(div_up(mpCap, 256), nframes), dim3(256), 0, st, *P, mpCap, d_nMP, d_inView, d_isBad, d_depth,
+                     d_projX, d_projY, d_projXR, d_level, d_viewCos, th, bFarPoints, thFarPoints, (Query*)qs);
+  return window_search(m, P, true, nframes, mpCap, d_nMP, (const Query*)qs, d_mpDesc, d_mpHasObs, d_fImg, cap, d_count, d_kps,
+                       d_desc, d_uRight, d_blocked, nnratio, 0, d_matchF, d_nmatches, st);
+}
+
+int morb_search_by_projection_last_batch(morb_matcher* m, const morb_frame_params* P, int nframes, const int* d_curImg,
+                                         const int* d_lastImg, int cap, const int* d_count, const morb_keypoint* d_kps,
+                                         const uint8_t* d_desc, const float* d_curURight, const uint8_t* d_curBlocked,
+                                         const float* d_Tcw, const uint8_t* d_lastValid, const float* d_lastXw,
+                                         const uint8_t* d_lastMPdesc, const uint8_t* d_lastMPhasObs, float th,
+                                         const uint8_t* d_bForward, const uint8_t* d_bBackward, int checkOri, int* d_matchCur,
+                                         int* d_nmatches, void* stream) {
+  MORB_REQUIRE(m && P && d_curImg && d_lastImg && d_count && d_kps && d_desc && d_Tcw && d_lastValid && d_lastXw && d_lastMPdesc &&
+                   d_lastMPhasObs && d_bForward && d_bBackward && d_matchCur && d_nmatches, MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(nframes > 0 && cap > 0 && cap <= 65535, MORB_ERR_INVALID, "bad sizes");
+  MORB_HIP_CHECK(hipSetDevice(morb_matcher_device(m)));
+  hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
+  void* qs = nullptr;
+  int rc = morb_matcher_workspace(m, 5, sizeof(Query) * (size_t)nframes * cap, &qs);
+  if (rc != MORB_OK) return rc;
+  hipLaunchKernelGGL(k_prep_last, dim3(div_up(cap, 256), nframes), dim3(256), 0, st, *P, cap, d_count, d_lastImg, d_kps, d_lastValid,
+                     d_lastXw, d_Tcw, th, d_bForward, d_bBackward, (Query*)qs);
+  // the number of queries of frame f is the feature count of its LAST image (gathered on the device)
+  void* nq = nullptr;
+  rc = morb_matcher_workspace(m, 6, sizeof(int) * (size_t)nframes, &nq);
+  if (rc != MORB_OK) return rc;
+  hipLaunchKernelGGL(k_gather_counts, dim3(div_up(nframes, 256)), dim3(256), 0, st, d_count, d_lastImg, nframes, (int*)nq);
+  return window_search(m, P, false, nframes, cap, (const int*)nq, (const Query*)qs, d_lastMPdesc, d_lastMPhasObs, d_curImg, cap,
+                       d_count, d_kps, d_desc, d_curURight, d_curBlocked, 0.f, checkOri, d_matchCur, d_nmatches, st);
+}
+
+}  // extern "C"
+
+
+extern "C" {
+int morb_bow_sort_images(morb_matcher* m, int nimg, const int* d_node, const int* d_count, int cap, unsigned long long** d_sorted,
+                         void* stream);
+
+// F12 = K1^-T [t12]x R12 K2^-1 in float, products left to right (Pinhole.cpp:118-122)
+static void fundamental_f12(const float* K1, const float* K2, const float* R12, const float* t12, float* F12) {
+  const float k1it[9] = {1.f / K1[0], 0, 0, 0, 1.f / K1[1], 0, -K1[2] / K1[0], -K1[3] / K1[1], 1.f};
+  const float k2i[9] = {1.f / K2[0], 0, -K2[2] / K2[0], 0, 1.f / K2[1], -K2[3] / K2[1], 0, 0, 1.f};
+  const float tx[9] = {0, -t12[2], t12[1], t12[2], 0, -t12[0], -t12[1], t12[0], 0};
+  auto mul = [](const float* A, const float* B, float* C) {
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) C[i * 3 + j] = (A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j]) + A[i * 3 + 2] * B[6 + j];
+  };
+  float m1[9], m2[9];
+  mul(k1it, tx, m1);
+  mul(m1, R12, m2);
+  mul(m2, k2i, F12);
+}
+
+}
+
+namespace {
+__global__ __launch_bounds__(256) void k_rot_filter12(const int* __restrict__ count, const int* __restrict__ img1v, int cap,
+                                                      int checkOri, int* __restrict__ match12, const int* __restrict__ bin12,
+                                                      int* __restrict__ nmatches) {
+  __shared__ int hist[HISTO_LENGTH];
+  __shared__ int keep[3];
+  __shared__ int total;
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int n1 = count[img1v[pair]];
+  int* mm = match12 + (size_t)pair * cap;
+  const int* bb = bin12 + (size_t)pair * cap;
+  if (tid < HISTO_LENGTH) hist[tid] = 0;
+  if (tid == 0) total = 0;
+  __syncthreads();
+  for (int i = tid; i < n1; i += 256)
+    if (mm[i] >= 0) { atomicAdd(&total, 1); if (checkOri) atomicAdd(&hist[bb[i]], 1); }
+  __syncthreads();
+  if (checkOri) {
+    if (tid == 0) {
+      int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+      for (int i = 0; i < HISTO_LENGTH; i++) {
+        const int s = hist[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+      }
+      if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+      else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+      keep[0] = ind1; keep[1] = ind2; keep[2] = ind3;
+    }
+    __syncthreads();
+    for (int i = tid; i < n1; i += 256)
+      if (mm[i] >= 0) { const int b = bb[i]; if (b != keep[0] && b != keep[1] && b != keep[2]) { mm[i] = -1; atomicSub(&total, 1); } }
+    __syncthreads();
+  }
+  if (tid == 0) nmatches[pair] = total;
+}
+}  // namespace
+
+extern "C" int morb_search_for_triangulation_batch(morb_matcher* m, const morb_frame_params* P, int npairs, const int* d_img1,
+                                                   const int* d_img2, int nimg, int cap, const int* d_count,
+                                                   const morb_keypoint* d_kps, const uint8_t* d_desc, const int* d_node,
+                                                   const uint8_t* d_hasMP, const float* d_uRight, const float* R12,
+                                                   const float* t12, const float* ep, int bOnlyStereo, int bCoarse,
+                                                   int checkOri, int* d_match12, int* d_nmatches, void* stream) {
+  MORB_REQUIRE(m && P && d_img1 && d_img2 && d_count && d_kps && d_desc && d_node && d_hasMP && R12 && t12 && ep && d_match12 &&
+                   d_nmatches, MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(npairs > 0 && nimg > 0 && cap > 0, MORB_ERR_INVALID, "bad sizes");
+  MORB_HIP_CHECK(hipSetDevice(morb_matcher_device(m)));
+  hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
+  unsigned long long* sorted = nullptr;
+  int rc = morb_bow_sort_images(m, nimg, d_node, d_count, cap, &sorted, st);
+  if (rc != MORB_OK) return rc;
+  std::vector<float> hf((size_t)npairs * 11);
+  const float K[4] = {P->fx, P->fy, P->cx, P->cy};
+  for (int p = 0; p < npairs; ++p) {
+    fundamental_f12(K, K, R12 + 9 * p, t12 + 3 * p, &hf[(size_t)p * 9]);
+    hf[(size_t)npairs * 9 + 2 * p] = ep[2 * p];
+    hf[(size_t)npairs * 9 + 2 * p + 1] = ep[2 * p + 1];
+  }
+  void *dF = nullptr, *dBin = nullptr;
+  rc = morb_matcher_workspace(m, 4, sizeof(float) * hf.size(), &dF);
+  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 2, sizeof(int) * (size_t)npairs * cap, &dBin);
+  if (rc != MORB_OK) return rc;
+  MORB_HIP_CHECK(hipMemcpyAsync(dF, hf.data(), sizeof(float) * hf.size(), hipMemcpyHostToDevice, st));
+  MORB_HIP_CHECK(hipStreamSynchronize(st));  // hf is a local
+  hipLaunchKernelGGL(k_triangulation, dim3(div_up(cap, 4), npairs), dim3(256), 0, st, sorted, cap, d_count, d_img1, d_img2, d_kps,
+                     d_desc, d_node, d_hasMP, d_uRight, *P, (const float*)dF, (const float*)dF + (size_t)npairs * 9, bOnlyStereo,
+                     bCoarse, d_match12, (int*)dBin);
+  hipLaunchKernelGGL(k_rot_filter12, dim3(npairs), dim3(256), 0, st, d_count, d_img1, cap, checkOri, d_match12, (const int*)dBin, d_nmatches);
+  MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}

@@ -86,3 +86,64 @@ class ORBmatcher:
                                                1 if self.mbCheckOrientation else 0, ptr(out[0]), ptr(out[1]),
                                                self._st(stream)))
         return out
+
+    # ---- projection-guided searches (projection.hip) ------------------------------------------------------
+    def isInFrustum(self, params, Rcw, tcw, Ow, nMP, Pw, normal, maxDist, minDist, viewingCosLimit=0.5, stream=None):
+        """Frame::isInFrustum for [F, mpCap] map points; returns dict of the MapPoint tracking fields (device tensors)."""
+        import torch
+        F, mpCap = Pw.shape[0], Pw.shape[1]
+        dev = Pw.device
+        o = dict(inView=torch.zeros((F, mpCap), dtype=torch.uint8, device=dev),
+                 projX=torch.full((F, mpCap), -1.0, device=dev), projY=torch.full((F, mpCap), -1.0, device=dev),
+                 projXR=torch.full((F, mpCap), -1.0, device=dev), depth=torch.full((F, mpCap), -1.0, device=dev),
+                 level=torch.full((F, mpCap), -1, dtype=torch.int32, device=dev), viewCos=torch.full((F, mpCap), -1.0, device=dev))
+        check(self._L.morb_is_in_frustum_batch(self._h, C.byref(params), F, ptr(Rcw), ptr(tcw), ptr(Ow), mpCap, ptr(nMP), ptr(Pw),
+                                               ptr(normal), ptr(maxDist), ptr(minDist), float(viewingCosLimit), ptr(o["inView"]),
+                                               ptr(o["projX"]), ptr(o["projY"]), ptr(o["projXR"]), ptr(o["depth"]), ptr(o["level"]),
+                                               ptr(o["viewCos"]), self._st(stream)))
+        return o
+
+    def SearchByProjectionMapPoints(self, params, fImg, kps, desc, count, uRight, blocked, nMP, trk, isBad, mpDesc, mpHasObs,
+                                    th=1.0, bFarPoints=False, thFarPoints=50.0, matchF=None, stream=None):
+        """SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints); trk = dict from isInFrustum."""
+        import torch
+        F, cap = fImg.shape[0], kps.shape[1]
+        mpCap = mpDesc.shape[1]
+        if matchF is None:
+            matchF = torch.full((F, cap), -1, dtype=torch.int32, device=kps.device)
+        nm = torch.zeros((F,), dtype=torch.int32, device=kps.device)
+        check(self._L.morb_search_by_projection_mps_batch(
+            self._h, C.byref(params), F, ptr(fImg), cap, ptr(count), ptr(kps), ptr(desc), ptr(uRight), ptr(blocked), mpCap, ptr(nMP),
+            ptr(trk["inView"]), ptr(isBad), ptr(trk["depth"]), ptr(trk["projX"]), ptr(trk["projY"]), ptr(trk["projXR"]),
+            ptr(trk["level"]), ptr(trk["viewCos"]), ptr(mpDesc), ptr(mpHasObs), float(th), 1 if bFarPoints else 0,
+            float(thFarPoints), self.mfNNratio, ptr(matchF), ptr(nm), self._st(stream)))
+        return matchF, nm
+
+    def SearchByProjectionLastFrame(self, params, curImg, lastImg, kps, desc, count, curURight, curBlocked, Tcw, lastValid,
+                                    lastXw, lastMPdesc, lastMPhasObs, th, bForward, bBackward, matchCur=None, stream=None):
+        """SearchByProjection(CurrentFrame, LastFrame, th, bMono)."""
+        import torch
+        F, cap = curImg.shape[0], kps.shape[1]
+        if matchCur is None:
+            matchCur = torch.full((F, cap), -1, dtype=torch.int32, device=kps.device)
+        nm = torch.zeros((F,), dtype=torch.int32, device=kps.device)
+        check(self._L.morb_search_by_projection_last_batch(
+            self._h, C.byref(params), F, ptr(curImg), ptr(lastImg), cap, ptr(count), ptr(kps), ptr(desc), ptr(curURight),
+            ptr(curBlocked), ptr(Tcw), ptr(lastValid), ptr(lastXw), ptr(lastMPdesc), ptr(lastMPhasObs), float(th), ptr(bForward),
+            ptr(bBackward), 1 if self.mbCheckOrientation else 0, ptr(matchCur), ptr(nm), self._st(stream)))
+        return matchCur, nm
+
+    def SearchForTriangulation(self, params, img1, img2, kps, desc, node, count, hasMP, uRight, R12, t12, ep,
+                               bOnlyStereo=False, bCoarse=False, stream=None):
+        """SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse); R12/t12/ep are host numpy arrays."""
+        import torch
+        npairs = img1.shape[0]
+        nimg, cap = kps.shape[0], kps.shape[1]
+        m12 = torch.full((npairs, cap), -1, dtype=torch.int32, device=kps.device)
+        nm = torch.zeros((npairs,), dtype=torch.int32, device=kps.device)
+        R12 = np.ascontiguousarray(R12, np.float32); t12 = np.ascontiguousarray(t12, np.float32); ep = np.ascontiguousarray(ep, np.float32)
+        check(self._L.morb_search_for_triangulation_batch(
+            self._h, C.byref(params), npairs, ptr(img1), ptr(img2), nimg, cap, ptr(count), ptr(kps), ptr(desc), ptr(node),
+            ptr(hasMP), ptr(uRight), ptr(R12), ptr(t12), ptr(ep), 1 if bOnlyStereo else 0, 1 if bCoarse else 0,
+            1 if self.mbCheckOrientation else 0, ptr(m12), ptr(nm), self._st(stream)))
+        return m12, nm

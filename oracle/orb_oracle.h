@@ -8,6 +8,17 @@ extern "C" {
 
 typedef struct { float x, y, size, angle, response; int octave, class_id; } orc_keypoint; /* cv::KeyPoint, 28 B */
 typedef struct orc_extractor orc_extractor;
+/* the Frame fields the projection matchers read (Frame.h), flattened */
+typedef struct {
+  int N;
+  const orc_keypoint* kpsUn;   /* mvKeysUn */
+  const uint8_t* desc;         /* mDescriptors */
+  const float* uRight;         /* mvuRight or NULL */
+  float minX, minY, maxX, maxY, gridInvW, gridInvH;
+  const float* scaleFactors;
+  int nlevels;
+  float fx, fy, cx, cy, mbf, mb, logScaleFactor;
+} orc_frame;
 
 orc_extractor* orc_extractor_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
 void orc_extractor_destroy(orc_extractor*);
@@ -44,6 +55,25 @@ int orc_pose_optimization(int n, const uint8_t* hasMP, const float* obs, const f
 int orc_local_ba(int nKF, float* kfPose, const uint8_t* kfFixed, int nMP, float* mpPos, int nE, const int* eKF,
                  const int* eMP, const float* eObs, const float* eInvSigma2, float fx, float fy, float cx, float cy,
                  float bf, int lambdaInit100, const int* stopFlag, uint8_t* eraseFlag, int* stats);
+void orc_is_in_frustum(const orc_frame* F, const float* Rcw, const float* tcw, const float* Ow, int nMP, const float* Pw,
+                       const float* normal, const float* maxDist, const float* minDist, float viewingCosLimit,
+                       uint8_t* inView, float* projX, float* projY, float* projXR, float* depth, int* level,
+                       float* viewCos);
+int orc_search_by_projection_mps(const orc_frame* F, const uint8_t* fBlocked, int nMP, const uint8_t* inView,
+                                 const uint8_t* isBad, const float* depth, const float* projX, const float* projY,
+                                 const float* projXR, const int* level, const float* viewCos, const uint8_t* mpDesc,
+                                 const uint8_t* mpHasObs, float th, int bFarPoints, float thFarPoints, float nnratio,
+                                 int* matchF);
+int orc_search_by_projection_last(const orc_frame* Cur, const uint8_t* curBlocked, const float* Tcw7, int nLast,
+                                  const orc_keypoint* lastKpsUn, const uint8_t* lastValid, const float* lastXw,
+                                  const uint8_t* lastMPdesc, const uint8_t* lastMPhasObs, float th, int bForward,
+                                  int bBackward, int checkOri, int* matchCur);
+void orc_fundamental_f12(const float* K1, const float* K2, const float* R12, const float* t12, float* F12);
+int orc_search_for_triangulation(int n1, const orc_keypoint* kps1, const uint8_t* desc1, const int* node1,
+                                 const uint8_t* hasMP1, const float* uRight1, const float* sigma2_1, int n2,
+                                 const orc_keypoint* kps2, const uint8_t* desc2, const int* node2, const uint8_t* hasMP2,
+                                 const float* uRight2, const float* sigma2_2, const float* scaleFactors2, const float* F12,
+                                 const float* ep, int bOnlyStereo, int bCoarse, int checkOri, int* matches12);
 float orc_fast_atan2(float y, float x);
 float orc_cosf(float x);
 float orc_sinf(float x);

@@ -1,0 +1,403 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product path.
+//
+// CPU restatement (flattened inputs) of the projection-guided matchers and the frustum test, non-fisheye
+// branches (Frame::Nleft == -1):
+//   Frame::isInFrustum                    /root/reference/src/Frame.cc:611-678, MapPoint::PredictScale MapPoint.cc:536-566
+//   Frame::PosInGrid / GetFeaturesInArea  Frame.cc:809-820, :742-807 (grid 64 x 48, Frame.h:44-45)
+//   ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th, bFarPoints, thFarPoints)   ORBmatcher.cc:42-209
+//   ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono)                 ORBmatcher.cc:1521-1733
+//   ORBmatcher::SearchForTriangulation                                                        ORBmatcher.cc:821-1042
+//   Pinhole::project / epipolarConstrain                                                      Pinhole.cpp:46-52, :111-139
+// Eigen / Sophus float expressions are restated with explicit left-to-right float arithmetic (the oracle is
+// built -ffp-contract=off); vs the real binary they are equal up to float rounding (PARITY UNPINNED there).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "cvprims.h"
+#include "matcher.h"
+#include "orb_oracle.h"
+
+namespace orc {
+
+static const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;
+static const int FRAME_GRID_ROWS = 48, FRAME_GRID_COLS = 64;
+
+void ComputeThreeMaxima(const std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3);
+
+struct Grid {
+  std::vector<size_t> cell[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+};
+
+// Frame::PosInGrid (:809-820)
+static bool PosInGrid(const orc_frame& F, const KeyPoint& kp, int& posX, int& posY) {
+  posX = (int)std::round((kp.x - F.minX) * F.gridInvW);
+  posY = (int)std::round((kp.y - F.minY) * F.gridInvH);
+  if (posX < 0 || posX >= FRAME_GRID_COLS || posY < 0 || posY >= FRAME_GRID_ROWS) return false;
+  return true;
+}
+// Frame::AssignFeaturesToGrid (:501-528)
+static void AssignFeaturesToGrid(const orc_frame& F, Grid& g) {
+  const KeyPoint* k = (const KeyPoint*)F.kpsUn;
+  for (int i = 0; i < F.N; i++) {
+    int x, y;
+    if (PosInGrid(F, k[i], x, y)) g.cell[x][y].push_back(i);
+  }
+}
+// Frame::GetFeaturesInArea (:742-807)
+static std::vector<size_t> GetFeaturesInArea(const orc_frame& F, const Grid& g, float x, float y, float r, int minLevel,
+                                             int maxLevel) {
+  std::vector<size_t> vIndices;
+  const KeyPoint* k = (const KeyPoint*)F.kpsUn;
+  const float factorX = r, factorY = r;
+  const int nMinCellX = std::max(0, (int)std::floor((x - F.minX - factorX) * F.gridInvW));
+  if (nMinCellX >= FRAME_GRID_COLS) return vIndices;
+  const int nMaxCellX = std::min((int)FRAME_GRID_COLS - 1, (int)std::ceil((x - F.minX + factorX) * F.gridInvW));
+  if (nMaxCellX < 0) return vIndices;
+  const int nMinCellY = std::max(0, (int)std::floor((y - F.minY - factorY) * F.gridInvH));
+  if (nMinCellY >= FRAME_GRID_ROWS) return vIndices;
+  const int nMaxCellY = std::min((int)FRAME_GRID_ROWS - 1, (int)std::ceil((y - F.minY + factorY) * F.gridInvH));
+  if (nMaxCellY < 0) return vIndices;
+  const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+  for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+    for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+      const std::vector<size_t>& vCell = g.cell[ix][iy];
+      for (size_t j = 0, jend = vCell.size(); j < jend; j++) {
+        const KeyPoint& kpUn = k[vCell[j]];
+        if (bCheckLevels) {
+          if (kpUn.octave < minLevel) continue;
+          if (maxLevel >= 0)
+            if (kpUn.octave > maxLevel) continue;
+        }
+        const float distx = kpUn.x - x;
+        const float disty = kpUn.y - y;
+        if (std::fabs(distx) < factorX && std::fabs(disty) < factorY) vIndices.push_back(vCell[j]);
+      }
+    }
+  return vIndices;
+}
+
+// Eigen quaternion * vector (float), Sophus::SE3f * Vector3f
+static void rotateF(const float* q, const float* v, float* out) {
+  const float ux = q[0], uy = q[1], uz = q[2], w = q[3];
+  float a = uy * v[2] - uz * v[1], b = uz * v[0] - ux * v[2], c = ux * v[1] - uy * v[0];
+  a += a; b += b; c += c;
+  out[0] = v[0] + w * a + (uy * c - uz * b);
+  out[1] = v[1] + w * b + (uz * a - ux * c);
+  out[2] = v[2] + w * c + (ux * b - uy * a);
+}
+
+// ---- Frame::isInFrustum (:611-678) ----------------------------------------------------------------------------
+void isInFrustum(const orc_frame& F, const float* mRcw, const float* mtcw, const float* mOw, int nMP, const float* Pw,
+                 const float* normal, const float* mfMaxDistance, const float* mfMinDistance, float viewingCosLimit,
+                 uint8_t* mbTrackInView, float* mTrackProjX, float* mTrackProjY, float* mTrackProjXR, float* mTrackDepth,
+                 int* mnTrackScaleLevel, float* mTrackViewCos) {
+  for (int i = 0; i < nMP; ++i) {
+    mbTrackInView[i] = 0;
+    mTrackProjX[i] = -1; mTrackProjY[i] = -1; mTrackProjXR[i] = -1; mTrackDepth[i] = -1; mnTrackScaleLevel[i] = -1;
+    mTrackViewCos[i] = -1;
+    const float* P = Pw + 3 * i;
+    float Pc[3];
+    for (int r = 0; r < 3; ++r) Pc[r] = (mRcw[r * 3] * P[0] + mRcw[r * 3 + 1] * P[1]) + mRcw[r * 3 + 2] * P[2] + mtcw[r];
+    const float Pc_dist = std::sqrt(Pc[0] * Pc[0] + Pc[1] * Pc[1] + Pc[2] * Pc[2]);
+    const float PcZ = Pc[2];
+    const float invz = 1.0f / PcZ;
+    if (PcZ < 0.0f) continue;
+    const float u = F.fx * Pc[0] / Pc[2] + F.cx;  // Pinhole::project(Vector3f)
+    const float v = F.fy * Pc[1] / Pc[2] + F.cy;
+    if (u < F.minX || u > F.maxX) continue;
+    if (v < F.minY || v > F.maxY) continue;
+    mTrackProjX[i] = u;
+    mTrackProjY[i] = v;
+    const float maxDistance = 1.2f * mfMaxDistance[i];  // MapPoint::GetMaxDistanceInvariance
+    const float minDistance = 0.8f * mfMinDistance[i];
+    const float PO[3] = {P[0] - mOw[0], P[1] - mOw[1], P[2] - mOw[2]};
+    const float dist = std::sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+    if (dist < minDistance || dist > maxDistance) continue;
+    const float* Pn = normal + 3 * i;
+    const float viewCos = (PO[0] * Pn[0] + PO[1] * Pn[1] + PO[2] * Pn[2]) / dist;
+    if (viewCos < viewingCosLimit) continue;
+    // MapPoint::PredictScale (MapPoint.cc:552-566): log(float) = logf
+    const float ratio = mfMaxDistance[i] / dist;
+    int nScale = (int)std::ceil(std::log(ratio) / F.logScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= F.nlevels) nScale = F.nlevels - 1;
+    mbTrackInView[i] = 1;
+    mTrackProjXR[i] = u - F.mbf * invz;
+    mTrackDepth[i] = Pc_dist;
+    mnTrackScaleLevel[i] = nScale;
+    mTrackViewCos[i] = viewCos;
+  }
+}
+
+// ---- ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints) (:42-209) ----
+int SearchByProjectionMPs(const orc_frame& F, const uint8_t* fBlocked, int nMP, const uint8_t* mbTrackInView,
+                          const uint8_t* isBad, const float* mTrackDepth, const float* mTrackProjX,
+                          const float* mTrackProjY, const float* mTrackProjXR, const int* mnTrackScaleLevel,
+                          const float* mTrackViewCos, const uint8_t* mpDesc, const uint8_t* mpHasObs, float th,
+                          bool bFarPoints, float thFarPoints, float mfNNratio, int* matchF) {
+  Grid g;
+  AssignFeaturesToGrid(F, g);
+  const KeyPoint* k = (const KeyPoint*)F.kpsUn;
+  std::vector<char> blocked(fBlocked, fBlocked + F.N);
+  int nmatches = 0;
+  const bool bFactor = th != 1.0;
+  for (int iMP = 0; iMP < nMP; iMP++) {
+    if (!mbTrackInView[iMP]) continue;
+    if (bFarPoints && mTrackDepth[iMP] > thFarPoints) continue;
+    if (isBad[iMP]) continue;
+    const int nPredictedLevel = mnTrackScaleLevel[iMP];
+    float r = mTrackViewCos[iMP] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos (:211-216)
+    if (bFactor) r *= th;
+    const std::vector<size_t> vIndices = GetFeaturesInArea(F, g, mTrackProjX[iMP], mTrackProjY[iMP],
+                                                           r * F.scaleFactors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel);
+    if (vIndices.empty()) continue;
+    const uint8_t* MPdescriptor = mpDesc + (size_t)iMP * 32;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (size_t q = 0; q < vIndices.size(); ++q) {
+      const size_t idx = vIndices[q];
+      if (blocked[idx]) continue;  // F.mvpMapPoints[idx] && Observations() > 0
+      if (F.uRight && F.uRight[idx] > 0) {
+        const float er = std::fabs(mTrackProjXR[iMP] - F.uRight[idx]);
+        if (er > r * F.scaleFactors[nPredictedLevel]) continue;
+      }
+      const int dist = DescriptorDistance(MPdescriptor, F.desc + idx * 32);
+      if (dist < bestDist) {
+        bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = k[idx].octave; bestIdx = (int)idx;
+      } else if (dist < bestDist2) {
+        bestLevel2 = k[idx].octave; bestDist2 = dist;
+      }
+    }
+    if (bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+      if (bestLevel != bestLevel2 || bestDist <= mfNNratio * bestDist2) {
+        matchF[bestIdx] = iMP;
+        blocked[bestIdx] = mpHasObs[iMP] ? 1 : 0;
+        nmatches++;
+      }
+    }
+  }
+  return nmatches;
+}
+
+// ---- ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (:1521-1733) ----
+// bForward / bBackward are computed by the caller exactly as :1530-1539 does (two flags per call).
+int SearchByProjectionLast(const orc_frame& Cur, const uint8_t* curBlocked, const float* Tcw7, int nLast,
+                           const KeyPoint* lastKpsUn, const uint8_t* lastValid, const float* lastXw,
+                           const uint8_t* lastMPdesc, const uint8_t* lastMPhasObs, float th, bool bForward, bool bBackward,
+                           bool mbCheckOrientation, int* matchCur) {
+  Grid g;
+  AssignFeaturesToGrid(Cur, g);
+  const KeyPoint* kc = (const KeyPoint*)Cur.kpsUn;
+  std::vector<char> blocked(curBlocked, curBlocked + Cur.N);
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  for (int i = 0; i < nLast; i++) {
+    if (!lastValid[i]) continue;  // pMP && !LastFrame.mvbOutlier[i]
+    float x3Dc[3];
+    rotateF(Tcw7, lastXw + 3 * i, x3Dc);
+    x3Dc[0] += Tcw7[4]; x3Dc[1] += Tcw7[5]; x3Dc[2] += Tcw7[6];
+    const float invzc = (float)(1.0 / x3Dc[2]);
+    if (invzc < 0) continue;
+    const float u = Cur.fx * x3Dc[0] / x3Dc[2] + Cur.cx;
+    const float v = Cur.fy * x3Dc[1] / x3Dc[2] + Cur.cy;
+    if (u < Cur.minX || u > Cur.maxX) continue;
+    if (v < Cur.minY || v > Cur.maxY) continue;
+    const int nLastOctave = lastKpsUn[i].octave;
+    const float radius = th * Cur.scaleFactors[nLastOctave];
+    std::vector<size_t> vIndices2;
+    if (bForward) vIndices2 = GetFeaturesInArea(Cur, g, u, v, radius, nLastOctave, -1);
+    else if (bBackward) vIndices2 = GetFeaturesInArea(Cur, g, u, v, radius, 0, nLastOctave);
+    else vIndices2 = GetFeaturesInArea(Cur, g, u, v, radius, nLastOctave - 1, nLastOctave + 1);
+    if (vIndices2.empty()) continue;
+    const uint8_t* dMP = lastMPdesc + (size_t)i * 32;
+    int bestDist = 256, bestIdx2 = -1;
+    for (size_t q = 0; q < vIndices2.size(); ++q) {
+      const size_t i2 = vIndices2[q];
+      if (blocked[i2]) continue;
+      if (Cur.uRight && Cur.uRight[i2] > 0) {
+        const float ur = u - Cur.mbf * invzc;
+        const float er = std::fabs(ur - Cur.uRight[i2]);
+        if (er > radius) continue;
+      }
+      const int dist = DescriptorDistance(dMP, Cur.desc + i2 * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+    }
+    if (bestDist <= TH_HIGH) {
+      matchCur[bestIdx2] = i;
+      blocked[bestIdx2] = lastMPhasObs[i] ? 1 : 0;
+      nmatches++;
+      if (mbCheckOrientation) {
+        float rot = lastKpsUn[i].angle - kc[bestIdx2].angle;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rotHist[bin].push_back(bestIdx2);
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i != ind1 && i != ind2 && i != ind3) {
+        for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+          matchCur[rotHist[i][j]] = -1;
+          nmatches--;
+        }
+      }
+    }
+  }
+  return nmatches;
+}
+
+// ---- Pinhole::epipolarConstrain (Pinhole.cpp:111-139) with F12 given --------------------------------------
+static bool epipolarConstrain(const float* F12, const KeyPoint& kp1, const KeyPoint& kp2, float unc) {
+  const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+  const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+  const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+  const float num = a * kp2.x + b * kp2.y + c;
+  const float den = a * a + b * b;
+  if (den == 0) return false;
+  const float dsqr = num * num / den;
+  return dsqr < 3.84 * unc;
+}
+
+// F12 = K1^-T * [t12]x * R12 * K2^-1 (Pinhole.cpp:118-122), float, products left to right
+void FundamentalF12(const float* K1 /*fx fy cx cy*/, const float* K2, const float* R12, const float* t12, float* F12) {
+  // K^-1 = [[1/fx, 0, -cx/fx], [0, 1/fy, -cy/fy], [0, 0, 1]];  K^-T is its transpose
+  const float k1it[9] = {1.f / K1[0], 0, 0, 0, 1.f / K1[1], 0, -K1[2] / K1[0], -K1[3] / K1[1], 1.f};
+  const float k2i[9] = {1.f / K2[0], 0, -K2[2] / K2[0], 0, 1.f / K2[1], -K2[3] / K2[1], 0, 0, 1.f};
+  const float tx[9] = {0, -t12[2], t12[1], t12[2], 0, -t12[0], -t12[1], t12[0], 0};
+  auto mul = [](const float* A, const float* B, float* C) {
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) C[i * 3 + j] = (A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j]) + A[i * 3 + 2] * B[6 + j];
+  };
+  float m1[9], m2[9];
+  mul(k1it, tx, m1);
+  mul(m1, R12, m2);
+  mul(m2, k2i, F12);
+}
+
+// ---- ORBmatcher::SearchForTriangulation (:821-1042), pinhole / no second camera ---------------------------
+int SearchForTriangulation(int n1, const KeyPoint* kps1, const uint8_t* desc1, const int* node1, const uint8_t* hasMP1,
+                           const float* uRight1, const float* levelSigma2_1, int n2, const KeyPoint* kps2,
+                           const uint8_t* desc2, const int* node2, const uint8_t* hasMP2, const float* uRight2,
+                           const float* levelSigma2_2, const float* scaleFactors2, const float* F12, const float* ep,
+                           bool bOnlyStereo, bool bCoarse, bool mbCheckOrientation, int* vMatches12) {
+  std::map<int, std::vector<unsigned>> vFeatVec1, vFeatVec2;
+  for (int i = 0; i < n1; ++i) if (node1[i] >= 0) vFeatVec1[node1[i]].push_back(i);
+  for (int i = 0; i < n2; ++i) if (node2[i] >= 0) vFeatVec2[node2[i]].push_back(i);
+  int nmatches = 0;
+  for (int i = 0; i < n1; ++i) vMatches12[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  auto f1it = vFeatVec1.begin(), f1end = vFeatVec1.end();
+  auto f2it = vFeatVec2.begin(), f2end = vFeatVec2.end();
+  while (f1it != f1end && f2it != f2end) {
+    if (f1it->first == f2it->first) {
+      for (size_t i1 = 0, iend1 = f1it->second.size(); i1 < iend1; i1++) {
+        const size_t idx1 = f1it->second[i1];
+        if (hasMP1[idx1]) continue;
+        const bool bStereo1 = uRight1 && uRight1[idx1] >= 0;
+        if (bOnlyStereo) if (!bStereo1) continue;
+        const KeyPoint& kp1 = kps1[idx1];
+        const uint8_t* d1 = desc1 + idx1 * 32;
+        int bestDist = TH_LOW, bestIdx2 = -1;
+        for (size_t i2 = 0, iend2 = f2it->second.size(); i2 < iend2; i2++) {
+          const size_t idx2 = f2it->second[i2];
+          if (hasMP2[idx2]) continue;  // vbMatched2 is never set in this fork
+          const bool bStereo2 = uRight2 && uRight2[idx2] >= 0;
+          if (bOnlyStereo) if (!bStereo2) continue;
+          const int dist = DescriptorDistance(d1, desc2 + idx2 * 32);
+          if (dist > TH_LOW || dist > bestDist) continue;
+          const KeyPoint& kp2 = kps2[idx2];
+          if (!bStereo1 && !bStereo2) {
+            const float distex = ep[0] - kp2.x;
+            const float distey = ep[1] - kp2.y;
+            if (distex * distex + distey * distey < 100 * scaleFactors2[kp2.octave]) continue;
+          }
+          if (bCoarse || epipolarConstrain(F12, kp1, kp2, levelSigma2_2[kp2.octave])) {
+            bestIdx2 = (int)idx2;
+            bestDist = dist;
+          }
+        }
+        if (bestIdx2 >= 0) {
+          const KeyPoint& kp2 = kps2[bestIdx2];
+          vMatches12[idx1] = bestIdx2;
+          nmatches++;
+          if (mbCheckOrientation) {
+            float rot = kp1.angle - kp2.angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)std::round(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            rotHist[bin].push_back((int)idx1);
+          }
+        }
+      }
+      f1it++;
+      f2it++;
+    } else if (f1it->first < f2it->first) {
+      f1it = vFeatVec1.lower_bound(f2it->first);
+    } else {
+      f2it = vFeatVec2.lower_bound(f1it->first);
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+        vMatches12[rotHist[i][j]] = -1;
+        nmatches--;
+      }
+    }
+  }
+  (void)levelSigma2_1;
+  return nmatches;
+}
+
+}  // namespace orc
+
+using namespace orc;
+extern "C" {
+
+void orc_is_in_frustum(const orc_frame* F, const float* Rcw, const float* tcw, const float* Ow, int nMP, const float* Pw,
+                       const float* normal, const float* maxDist, const float* minDist, float viewingCosLimit,
+                       uint8_t* inView, float* projX, float* projY, float* projXR, float* depth, int* level,
+                       float* viewCos) {
+  isInFrustum(*F, Rcw, tcw, Ow, nMP, Pw, normal, maxDist, minDist, viewingCosLimit, inView, projX, projY, projXR, depth, level,
+              viewCos);
+}
+int orc_search_by_projection_mps(const orc_frame* F, const uint8_t* fBlocked, int nMP, const uint8_t* inView,
+                                 const uint8_t* isBad, const float* depth, const float* projX, const float* projY,
+                                 const float* projXR, const int* level, const float* viewCos, const uint8_t* mpDesc,
+                                 const uint8_t* mpHasObs, float th, int bFarPoints, float thFarPoints, float nnratio,
+                                 int* matchF) {
+  return SearchByProjectionMPs(*F, fBlocked, nMP, inView, isBad, depth, projX, projY, projXR, level, viewCos, mpDesc, mpHasObs,
+                               th, bFarPoints != 0, thFarPoints, nnratio, matchF);
+}
+int orc_search_by_projection_last(const orc_frame* Cur, const uint8_t* curBlocked, const float* Tcw7, int nLast,
+                                  const orc_keypoint* lastKpsUn, const uint8_t* lastValid, const float* lastXw,
+                                  const uint8_t* lastMPdesc, const uint8_t* lastMPhasObs, float th, int bForward,
+                                  int bBackward, int checkOri, int* matchCur) {
+  return SearchByProjectionLast(*Cur, curBlocked, Tcw7, nLast, (const KeyPoint*)lastKpsUn, lastValid, lastXw, lastMPdesc,
+                                lastMPhasObs, th, bForward != 0, bBackward != 0, checkOri != 0, matchCur);
+}
+void orc_fundamental_f12(const float* K1, const float* K2, const float* R12, const float* t12, float* F12) {
+  FundamentalF12(K1, K2, R12, t12, F12);
+}
+int orc_search_for_triangulation(int n1, const orc_keypoint* kps1, const uint8_t* desc1, const int* node1,
+                                 const uint8_t* hasMP1, const float* uRight1, const float* sigma2_1, int n2,
+                                 const orc_keypoint* kps2, const uint8_t* desc2, const int* node2, const uint8_t* hasMP2,
+                                 const float* uRight2, const float* sigma2_2, const float* scaleFactors2, const float* F12,
+                                 const float* ep, int bOnlyStereo, int bCoarse, int checkOri, int* matches12) {
+  return SearchForTriangulation(n1, (const KeyPoint*)kps1, desc1, node1, hasMP1, uRight1, sigma2_1, n2, (const KeyPoint*)kps2,
+                                desc2, node2, hasMP2, uRight2, sigma2_2, scaleFactors2, F12, ep, bOnlyStereo != 0,
+                                bCoarse != 0, checkOri != 0, matches12);
+}
+}

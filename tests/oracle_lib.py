@@ -192,3 +192,72 @@ def local_ba(p, lambda100=False, stop=None):
     its = L.orc_local_ba(len(kf), _p(kf), _p(a[0]), len(mp), _p(mp), nE, _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]),
                          c["fx"], c["fy"], c["cx"], c["cy"], c["bf"], 1 if lambda100 else 0, st, _p(erase), _p(stats))
     return its, kf, mp, erase, stats
+
+
+class OrcFrame(C.Structure):
+    _fields_ = [("N", C.c_int), ("kpsUn", C.c_void_p), ("desc", C.c_void_p), ("uRight", C.c_void_p),
+                ("minX", C.c_float), ("minY", C.c_float), ("maxX", C.c_float), ("maxY", C.c_float), ("gridInvW", C.c_float),
+                ("gridInvH", C.c_float), ("scaleFactors", C.c_void_p), ("nlevels", C.c_int), ("fx", C.c_float),
+                ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("mbf", C.c_float), ("mb", C.c_float),
+                ("logScaleFactor", C.c_float)]
+
+
+def make_frame(P, kps, desc, uRight):
+    """OrcFrame from a morb_slam_amd.capi.FrameParams + host arrays (keeps references alive on the struct)."""
+    f = OrcFrame()
+    f._keep = [np.ascontiguousarray(kps), np.ascontiguousarray(desc), None if uRight is None else np.ascontiguousarray(uRight, np.float32),
+               np.array(list(P.scaleFactors)[:P.nlevels], np.float32)]
+    f.N = len(kps); f.kpsUn = _p(f._keep[0]); f.desc = _p(f._keep[1]); f.uRight = None if uRight is None else _p(f._keep[2])
+    for k in ("minX", "minY", "maxX", "maxY", "gridInvW", "gridInvH", "fx", "fy", "cx", "cy", "mbf", "mb", "logScaleFactor", "nlevels"):
+        setattr(f, k, getattr(P, k))
+    f.scaleFactors = _p(f._keep[3])
+    return f
+
+
+def is_in_frustum(F, Rcw, tcw, Ow, Pw, normal, maxDist, minDist, cosLimit=0.5):
+    L = lib(); n = len(Pw)
+    a = [np.ascontiguousarray(x, np.float32) for x in (Rcw, tcw, Ow, Pw, normal, maxDist, minDist)]
+    o = dict(inView=np.zeros(n, np.uint8), projX=np.zeros(n, np.float32), projY=np.zeros(n, np.float32), projXR=np.zeros(n, np.float32),
+             depth=np.zeros(n, np.float32), level=np.zeros(n, np.int32), viewCos=np.zeros(n, np.float32))
+    L.orc_is_in_frustum.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 7
+    L.orc_is_in_frustum(C.byref(F), _p(a[0]), _p(a[1]), _p(a[2]), n, _p(a[3]), _p(a[4]), _p(a[5]), _p(a[6]), cosLimit,
+                        _p(o["inView"]), _p(o["projX"]), _p(o["projY"]), _p(o["projXR"]), _p(o["depth"]), _p(o["level"]), _p(o["viewCos"]))
+    return o
+
+
+def search_by_projection_mps(F, blocked, trk, isBad, mpDesc, mpHasObs, th, bFar, thFar, nnratio, match_init=None):
+    L = lib(); n = len(mpDesc)
+    L.orc_search_by_projection_mps.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 10 + [C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    m = np.full(F.N, -1, np.int32) if match_init is None else match_init.astype(np.int32).copy()
+    a = [np.ascontiguousarray(x) for x in (blocked.astype(np.uint8), trk["inView"], isBad.astype(np.uint8), trk["depth"], trk["projX"],
+                                           trk["projY"], trk["projXR"], trk["level"], trk["viewCos"], mpDesc, mpHasObs.astype(np.uint8))]
+    r = L.orc_search_by_projection_mps(C.byref(F), _p(a[0]), n, _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), _p(a[5]), _p(a[6]), _p(a[7]),
+                                       _p(a[8]), _p(a[9]), _p(a[10]), th, 1 if bFar else 0, thFar, nnratio, _p(m))
+    return r, m
+
+
+def search_by_projection_last(Cur, blocked, Tcw7, lastKps, lastValid, lastXw, lastMPdesc, lastHasObs, th, fwd, bwd, checkOri):
+    L = lib()
+    L.orc_search_by_projection_last.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    m = np.full(Cur.N, -1, np.int32)
+    a = [np.ascontiguousarray(x) for x in (blocked.astype(np.uint8), np.asarray(Tcw7, np.float32), lastKps, lastValid.astype(np.uint8),
+                                           np.asarray(lastXw, np.float32), lastMPdesc, lastHasObs.astype(np.uint8))]
+    r = L.orc_search_by_projection_last(C.byref(Cur), _p(a[0]), _p(a[1]), len(lastKps), _p(a[2]), _p(a[3]), _p(a[4]), _p(a[5]), _p(a[6]),
+                                        th, int(fwd), int(bwd), int(checkOri), _p(m))
+    return r, m
+
+
+def search_for_triangulation(k1, d1, node1, has1, ur1, k2, d2, node2, has2, ur2, sigma2, scaleF, K, R12, t12, ep, onlyStereo, coarse, checkOri):
+    L = lib()
+    F12 = np.zeros(9, np.float32)
+    Kf = np.asarray(K, np.float32)
+    L.orc_fundamental_f12(_p(Kf), _p(Kf), _p(np.ascontiguousarray(R12, np.float32)), _p(np.ascontiguousarray(t12, np.float32)), _p(F12))
+    L.orc_search_for_triangulation.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 9 + [C.c_int] * 3 + [C.c_void_p]
+    m = np.full(len(k1), -1, np.int32)
+    a = [np.ascontiguousarray(x) for x in (k1, d1, node1.astype(np.int32), has1.astype(np.uint8), k2, d2, node2.astype(np.int32), has2.astype(np.uint8),
+                                           np.asarray(sigma2, np.float32), np.asarray(scaleF, np.float32), np.asarray(ep, np.float32))]
+    u1 = None if ur1 is None else np.ascontiguousarray(ur1, np.float32); u2 = None if ur2 is None else np.ascontiguousarray(ur2, np.float32)
+    r = L.orc_search_for_triangulation(len(k1), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), None if u1 is None else _p(u1), _p(a[8]),
+                                       len(k2), _p(a[4]), _p(a[5]), _p(a[6]), _p(a[7]), None if u2 is None else _p(u2), _p(a[8]), _p(a[9]),
+                                       _p(F12), _p(a[10]), int(onlyStereo), int(coarse), int(checkOri), _p(m))
+    return r, m

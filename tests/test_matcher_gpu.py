@@ -127,3 +127,163 @@ def test_bow_transform_and_search_by_bow(batch):
             np.testing.assert_array_equal(match[p, :len(kb)], me)
             tot += ne
         assert tot > 500
+
+
+# ---- projection-guided searches --------------------------------------------------------------------------
+def _scene(batch):
+    """Map points = stereo-triangulated features of frame 0 (identity pose), observed again in frame 2 (a shifted copy)."""
+    import torch
+    from morb_slam_amd import ORBmatcher
+    from morb_slam_amd.capi import make_frame_params
+    ext = batch["ext"]
+    P = make_frame_params(752, 480, 458.654, 457.296, 367.215, 248.375, float(MBF), float(MB), ext.GetScaleFactors(),
+                          ext.GetScaleSigmaSquares())
+    m = ORBmatcher(0.8, True)
+    u, d = m.ComputeStereoMatches(ext, batch["kps"], batch["desc"], batch["cnt"], MBF, MB)
+    torch.cuda.synchronize()
+    return P, u, d
+
+
+def test_is_in_frustum_and_search_by_projection_mappoints(batch):
+    import torch
+    from morb_slam_amd import ORBmatcher
+    P, uR, dep = _scene(batch)
+    k0, d0 = batch["ora"][0][1], batch["ora"][0][2]
+    z = dep[0, :len(k0)].cpu().numpy()
+    valid = z > 0
+    Xw = np.stack([(k0["x"] - P.cx) * z / P.fx, (k0["y"] - P.cy) * z / P.fy, z], 1).astype(np.float32)[valid]
+    mpDesc = d0[valid]
+    n = len(Xw)
+    rng = np.random.default_rng(3)
+    normal = (Xw / np.linalg.norm(Xw, axis=1, keepdims=True) + rng.normal(0, 0.2, Xw.shape)).astype(np.float32)  # mean viewing direction camera -> point
+    dist = np.linalg.norm(Xw, axis=1).astype(np.float32)
+    lvl = k0["octave"][valid]
+    maxD = (dist * 1.2 ** lvl * rng.uniform(0.9, 1.3, n)).astype(np.float32)   # mfMaxDistance ~ dist * scale^level
+    minD = (maxD / 1.2 ** 7).astype(np.float32)
+    # two frames looking at the same points: identity, and a small translation + rotation about y
+    th_ = 0.01
+    R1 = np.array([[np.cos(th_), 0, np.sin(th_)], [0, 1, 0], [-np.sin(th_), 0, np.cos(th_)]], np.float32)
+    Rs = np.stack([np.eye(3, dtype=np.float32), R1]); ts = np.array([[0, 0, 0], [0.02, -0.01, 0.05]], np.float32)
+    Ows = np.stack([-(Rs[i].T @ ts[i]) for i in range(2)]).astype(np.float32)
+    m = ORBmatcher(0.8, True)
+    dev = "cuda"
+    rep = lambda a: torch.from_numpy(np.stack([a, a])).to(dev)
+    trk = m.isInFrustum(P, torch.from_numpy(Rs.reshape(2, 9)).to(dev), torch.from_numpy(ts).to(dev), torch.from_numpy(Ows).to(dev),
+                        torch.tensor([n, n], dtype=torch.int32, device=dev), rep(Xw), rep(normal), rep(maxD), rep(minD), 0.5)
+    torch.cuda.synchronize()
+    isBad = (rng.random(n) < 0.05).astype(np.uint8); hasObs = (rng.random(n) < 0.9).astype(np.uint8)
+    fImg = torch.tensor([4, 4], dtype=torch.int32, device=dev)       # current frame = image 4 (frame 2, left)
+    k4, d4 = batch["ora"][4][1], batch["ora"][4][2]
+    ur4 = uR[2, :len(k4)].cpu().numpy()
+    blocked = (rng.random(len(k4)) < 0.1).astype(np.uint8)
+    cap = batch["kps"].shape[1]
+    pad = lambda a, fill=0: np.concatenate([a, np.full((cap - len(a),) + a.shape[1:], fill, a.dtype)])
+    uRt = torch.from_numpy(np.stack([pad(ur4, -1), pad(ur4, -1)])).to(dev)
+    blk = torch.from_numpy(np.stack([pad(blocked), pad(blocked)])).to(dev)
+    tot = 0
+    for th, bFar, thFar in ((1.0, False, 0.0), (3.0, True, 6.0), (5.0, False, 0.0)):
+        mt, nm = m.SearchByProjectionMapPoints(P, fImg, batch["kps"], batch["desc"], batch["cnt"], uRt, blk,
+                                               torch.tensor([n, n], dtype=torch.int32, device=dev), trk, rep(isBad), rep(mpDesc),
+                                               rep(hasObs), th, bFar, thFar)
+        torch.cuda.synchronize()
+        mt, nm = mt.cpu().numpy(), nm.cpu().numpy()
+        Fo = O.make_frame(P, k4, d4, ur4)
+        for f in range(2):
+            te = O.is_in_frustum(Fo, Rs[f], ts[f], Ows[f], Xw, normal, maxD, minD, 0.5)
+            for key in te:
+                g = trk[key][f, :n].cpu().numpy()
+                if te[key].dtype == np.float32:
+                    assert g.view(np.uint32).tolist() == te[key].view(np.uint32).tolist(), key
+                else:
+                    np.testing.assert_array_equal(g, te[key], err_msg=key)
+            r, me = O.search_by_projection_mps(Fo, blocked, te, isBad, mpDesc, hasObs, th, bFar, thFar, 0.8)
+            assert nm[f] == r
+            np.testing.assert_array_equal(mt[f, :len(k4)], me)
+            tot += r
+        assert te["inView"].sum() > 0.5 * n
+    assert tot > 600
+
+
+def test_search_by_projection_last_frame(batch):
+    import torch
+    from morb_slam_amd import ORBmatcher
+    P, uR, dep = _scene(batch)
+    dev = "cuda"
+    cap = batch["kps"].shape[1]
+    rng = np.random.default_rng(4)
+    pad = lambda a, fill=0: np.concatenate([a, np.full((cap - len(a),) + a.shape[1:], fill, a.dtype)])
+    # pairs (last image, current image): (0 -> 4), (2 -> 6), (4 -> 0)
+    pairs = [(0, 4), (2, 6), (4, 0)]
+    lastValid, lastXw, lastDesc, lastObs, curUR, curBlk, Tcw = [], [], [], [], [], [], []
+    for li, ci in pairs:
+        kl, dl = batch["ora"][li][1], batch["ora"][li][2]
+        z = dep[li // 2, :len(kl)].cpu().numpy()
+        v = (z > 0) & (rng.random(len(kl)) < 0.9)
+        zz = np.where(z > 0, z, 1.0)
+        X = np.stack([(kl["x"] - P.cx) * zz / P.fx, (kl["y"] - P.cy) * zz / P.fy, zz], 1).astype(np.float32)
+        lastValid.append(pad(v.astype(np.uint8))); lastXw.append(pad(X)); lastDesc.append(pad(dl))
+        lastObs.append(pad((rng.random(len(kl)) < 0.85).astype(np.uint8)))
+        kc = batch["ora"][ci][1]
+        curUR.append(pad(uR[ci // 2, :len(kc)].cpu().numpy(), -1)); curBlk.append(pad((rng.random(len(kc)) < 0.05).astype(np.uint8)))
+        q = np.array([0.0, 0.002, 0.0, 1.0]); q /= np.linalg.norm(q)
+        Tcw.append(np.concatenate([q, [0.01, 0.0, 0.02]]).astype(np.float32))
+    t = lambda a, dt=None: torch.from_numpy(np.stack(a)).to(dev)
+    curImg = torch.tensor([c for _, c in pairs], dtype=torch.int32, device=dev)
+    lastImg = torch.tensor([l for l, _ in pairs], dtype=torch.int32, device=dev)
+    tot = 0
+    for th, fwd, bwd, ori in ((7.0, 0, 0, True), (15.0, 1, 0, True), (7.0, 0, 1, False)):
+        m = ORBmatcher(0.9, ori)
+        fw = torch.full((3,), fwd, dtype=torch.uint8, device=dev); bw = torch.full((3,), bwd, dtype=torch.uint8, device=dev)
+        mc, nm = m.SearchByProjectionLastFrame(P, curImg, lastImg, batch["kps"], batch["desc"], batch["cnt"], t(curUR), t(curBlk), t(Tcw),
+                                               t(lastValid), t(lastXw), t(lastDesc), t(lastObs), th, fw, bw)
+        torch.cuda.synchronize()
+        mc, nm = mc.cpu().numpy(), nm.cpu().numpy()
+        for p, (li, ci) in enumerate(pairs):
+            kl = batch["ora"][li][1]; kc, dc = batch["ora"][ci][1], batch["ora"][ci][2]
+            Fo = O.make_frame(P, kc, dc, curUR[p][:len(kc)])
+            r, me = O.search_by_projection_last(Fo, curBlk[p][:len(kc)], Tcw[p], kl, lastValid[p][:len(kl)], lastXw[p][:len(kl)],
+                                                lastDesc[p][:len(kl)], lastObs[p][:len(kl)], th, fwd, bwd, ori)
+            assert nm[p] == r, (th, p, nm[p], r)
+            np.testing.assert_array_equal(mc[p, :len(kc)], me)
+            tot += r
+    assert tot > 1000
+
+
+def test_search_for_triangulation(batch):
+    import torch
+    from morb_slam_amd import ORBmatcher
+    P, uR, dep = _scene(batch)
+    dev = "cuda"
+    k, Lv, lup = 10, 3, 1
+    vd, vf = make_vocabulary(k, Lv, seed=2)
+    m0 = ORBmatcher(0.6, False)
+    word, node = m0.bow_transform(batch["desc"], batch["cnt"], torch.from_numpy(vd).to(dev), torch.from_numpy(vf).to(dev), k, Lv, lup)
+    torch.cuda.synchronize()
+    nn_ = node.cpu().numpy()
+    cap = batch["kps"].shape[1]
+    nimg = batch["kps"].shape[0]
+    rng = np.random.default_rng(6)
+    has = (rng.random((nimg, cap)) < 0.3).astype(np.uint8)
+    ur = np.full((nimg, cap), -1, np.float32)
+    for i in range(0, nimg, 2):
+        n = len(batch["ora"][i][1]); ur[i, :n] = uR[i // 2, :n].cpu().numpy()
+    pairs = [(0, 4), (4, 0), (2, 6)]
+    R12 = np.stack([np.eye(3, dtype=np.float32)] * 3); t12 = np.array([[0.05, 0.01, 0.0], [-0.05, 0.0, 0.01], [0.0, 0.03, 0.1]], np.float32)
+    ep = np.array([[900.0, 250.0], [-150.0, 240.0], [370.0, 250.0]], np.float32)
+    img1 = torch.tensor([a for a, _ in pairs], dtype=torch.int32, device=dev); img2 = torch.tensor([b for _, b in pairs], dtype=torch.int32, device=dev)
+    tot = 0
+    for onlyStereo, coarse, ori in ((False, False, True), (False, True, False), (True, False, True)):
+        m = ORBmatcher(0.6, ori)
+        m12, nm = m.SearchForTriangulation(P, img1, img2, batch["kps"], batch["desc"], node, batch["cnt"], torch.from_numpy(has).to(dev),
+                                           torch.from_numpy(ur).to(dev), R12, t12, ep, onlyStereo, coarse)
+        torch.cuda.synchronize()
+        m12, nm = m12.cpu().numpy(), nm.cpu().numpy()
+        for p, (a, b) in enumerate(pairs):
+            ka, da = batch["ora"][a][1], batch["ora"][a][2]; kb, db = batch["ora"][b][1], batch["ora"][b][2]
+            r, me = O.search_for_triangulation(ka, da, nn_[a, :len(ka)], has[a, :len(ka)], ur[a, :len(ka)], kb, db, nn_[b, :len(kb)],
+                                               has[b, :len(kb)], ur[b, :len(kb)], list(P.levelSigma2)[:8], list(P.scaleFactors)[:8],
+                                               [P.fx, P.fy, P.cx, P.cy], R12[p], t12[p], ep[p], onlyStereo, coarse, ori)
+            assert nm[p] == r, (p, nm[p], r)
+            np.testing.assert_array_equal(m12[p, :len(ka)], me)
+            tot += r
+    assert tot > 100
