@@ -43,18 +43,19 @@ def algorithmic_bytes(w, h):
     return {"pyramid": w * h + (P - last) + Pp, "fast": P, "blur": 2 * P}
 
 
-def make_batch(nframes, seed):
-    """nframes stereo pairs = 4 seeded sequences of nframes/4 consecutive frames with a 3x2 px/frame global
-    shift, so frame f-1 is a real 'previous frame' of frame f except at the 4 sequence starts."""
+def make_batch(global_ids, total, seed=0):
+    """Stereo frames `global_ids` of a synthetic stream of `total` frames: 4 seeded sequences of total/4 consecutive
+    frames with a 3x2 px/frame global shift, so frame g-1 is a real 'previous frame' of frame g except at the 4
+    sequence starts."""
     from morb_slam_amd.synth import make_stereo_pair, shift_image
     base = [make_stereo_pair(W, H, seed=seed * 16 + i) for i in range(4)]
-    imgs = np.empty((nframes, 2, H, W), np.uint8)
-    per = max(nframes // 4, 1)
-    for f in range(nframes):
-        l, r = base[(f // per) % 4]
-        dx, dy = 3 * (f % per), 2 * (f % per)
-        imgs[f, 0] = shift_image(l, dx, dy)
-        imgs[f, 1] = shift_image(r, dx, dy)
+    imgs = np.empty((len(global_ids), 2, H, W), np.uint8)
+    per = max(total // 4, 1)
+    for k, g in enumerate(global_ids):
+        l, r = base[(g // per) % 4]
+        dx, dy = 3 * (g % per), 2 * (g % per)
+        imgs[k, 0] = shift_image(l, dx, dy)
+        imgs[k, 1] = shift_image(r, dx, dy)
     return imgs
 
 
@@ -65,7 +66,7 @@ def cpu_baseline(target_s=12.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import OracleExtractor
     cores = os.cpu_count() or 1
-    frames = make_batch(4, seed=99)
+    frames = make_batch(range(4), 4, seed=99)
     exts = [(OracleExtractor(NFEAT), OracleExtractor(NFEAT)) for _ in range(cores)]
 
     def work(i):
@@ -81,6 +82,50 @@ def cpu_baseline(target_s=12.0):
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "stereo frames/s", "cores": cores, "kind": "port",
             "sample": f"{done} stereo 752x480 frames, 1200 features, oracle extract x2 (frame-parallel on {cores} threads)"}
+
+
+def optimizer_extras(dev_index):
+    """Secondary BASELINE metrics on rank 0: LocalBA LM iterations/s (config 5: 20 free + 6 fixed KFs, 3000 points)
+    and PoseOptimization frames/s (config 3 stage), device-resident problems, CPU oracle timed beside them."""
+    import torch
+    from morb_slam_amd import BAProblem, Optimizer
+    from morb_slam_amd.synth import make_ba_problem, make_pose_problem
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    opt = Optimizer(device=dev_index)
+    b = make_ba_problem(seed=1)
+    p = BAProblem(opt, b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"], b["eInvSigma2"], b["cam"])
+    p.solve(); _, _, _, st = p.results()
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        p.solve()
+    _, _, _, st = p.results()
+    dt = (time.perf_counter() - t0) / n
+    t0 = time.perf_counter(); its, *_ = O.local_ba(b); dc = time.perf_counter() - t0
+    F = 256
+    probs = [make_pose_problem(600, seed=s % 8) for s in range(F)]
+    dev = torch.device("cuda", dev_index)
+    t = [torch.from_numpy(np.stack([q[k] for q in probs])).to(dev) for k in ("hasMP", "obs", "invSigma2", "Xw")]
+    pose0 = torch.from_numpy(np.stack([q["pose0"] for q in probs])).to(dev)
+    out = None
+    for _ in range(2):
+        out = opt.PoseOptimization(t[0], t[1], t[2], t[3], pose0.clone(), probs[0]["cam"], out=out)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        out = opt.PoseOptimization(t[0], t[1], t[2], t[3], pose0.clone(), probs[0]["cam"], out=out)
+    torch.cuda.synchronize(dev)
+    dtp = (time.perf_counter() - t0) / 5
+    t0 = time.perf_counter()
+    for q in probs[:8]:
+        O.pose_optimization(q)
+    dcp = (time.perf_counter() - t0) / 8
+    return {"local_ba": {"edges": int(len(b["eKF"])), "keyframes_free_fixed": [20, 6], "points": 3000,
+                         "outer_lm_iters": int(st[0]), "lm_trials": int(st[1]), "ms_per_solve": dt * 1e3,
+                         "lm_iters_per_s": float(st[0] / dt), "cpu_oracle_lm_iters_per_s": float(its / dc)},
+            "pose_optimization": {"frames": F, "edges_per_frame": 600, "frames_per_s": F / dtp,
+                                  "cpu_oracle_frames_per_s_1core": 1.0 / dcp}}
 
 
 def main():
@@ -105,10 +150,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from morb_slam_amd import ORBextractor, ORBmatcher
+    from morb_slam_amd import ORBextractor, ORBmatcher, parallel
     from morb_slam_amd.synth import make_vocabulary
     B = args.batch
-    frames = torch.from_numpy(make_batch(B, seed=rank)).to(dev)      # [B, 2, H, W] resident in HBM
+    # global frame g lives on rank g % world, slot g // world (morb_slam_amd/parallel.py)
+    gids = [parallel.global_frame(rank, world, s) for s in range(B)]
+    frames = torch.from_numpy(make_batch(gids, B * world, seed=0)).to(dev)      # [B, 2, H, W] resident in HBM
     images = frames.view(2 * B, H, W)
     ext = ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank)
     stream = torch.cuda.Stream(device=dev)
@@ -118,11 +165,20 @@ def main():
     vd, vf = make_vocabulary(VK, VL, seed=0)                  # synthetic: ORBvoc.txt is a missing blob (SURVEY finding 3)
     vd, vf = torch.from_numpy(vd).to(dev), torch.from_numpy(vf).to(dev)
     cap = ext.max_keypoints
-    # SearchByBoW pairs: left image of frame f (as F) against left image of frame f-1 (as the reference keyframe)
-    kf_img = torch.tensor([2 * ((f - 1) % B) for f in range(B)], dtype=torch.int32, device=dev)
-    f_img = torch.tensor([2 * f for f in range(B)], dtype=torch.int32, device=dev)
+    # SearchByBoW pairs: left image of global frame g (as F) against left image of frame g-1 (as the reference
+    # keyframe).  One GPU: both are local.  N GPUs: g-1 lives on the previous rank -> the left-image features are
+    # all-gathered (RCCL) once per step and the pairs index the gathered pool.
     rng = np.random.default_rng(7)
-    has_mp = torch.from_numpy((rng.random((2 * B, cap)) < 0.8).astype(np.uint8)).to(dev)   # 80 % of KF features hold a MapPoint
+    if world == 1:
+        kf_img = torch.tensor([2 * max(f - 1, 0) for f in range(B)], dtype=torch.int32, device=dev)
+        f_img = torch.tensor([2 * f for f in range(B)], dtype=torch.int32, device=dev)
+        has_mp = torch.from_numpy((rng.random((2 * B, cap)) < 0.8).astype(np.uint8)).to(dev)   # 80 % of KF features hold a MapPoint
+        exch = None
+    else:
+        kfp, frp = parallel.predecessor_pairs(rank, world, B)
+        kf_img, f_img = torch.from_numpy(kfp).to(dev), torch.from_numpy(frp).to(dev)
+        has_mp = torch.from_numpy((rng.random((world * B, cap)) < 0.8).astype(np.uint8)).to(dev)
+        exch = parallel.FeatureExchange()
     out = st_out = bow_out = match_out = None
 
     def step():
@@ -132,7 +188,12 @@ def main():
         kps, desc, cnt, _ = out
         st_out = matcher.ComputeStereoMatches(ext, kps, desc, cnt, mbf, mb, out=st_out, stream=s)   # Frame.cc:217
         bow_out = matcher.bow_transform(desc, cnt, vd, vf, VK, VL, 4, out=bow_out, stream=s)        # Frame::ComputeBoW
-        match_out = matcher.SearchByBoW(kf_img, f_img, kps, desc, bow_out[1], cnt, has_mp, out=match_out, stream=s)
+        if exch is None:
+            match_out = matcher.SearchByBoW(kf_img, f_img, kps, desc, bow_out[1], cnt, has_mp, out=match_out, stream=s)
+        else:
+            with torch.cuda.stream(stream):      # the collective is ordered after the kernels on this stream
+                pk, pd, pc, pn = exch.exchange(kps[0::2], desc[0::2], cnt[0::2], bow_out[1][0::2])   # left images only
+            match_out = matcher.SearchByBoW(kf_img, f_img, pk, pd, pn, pc, has_mp, out=match_out, stream=s)
 
     def sync_all():
         stream.synchronize()
@@ -176,7 +237,8 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "EuRoC-shaped stereo 752x480, 1200 feat: ORBextractor x2 + ComputeStereoMatches + "
                                    "ComputeBoW (synthetic k=10 L=6 vocabulary) + SearchByBoW vs previous frame",
-                       "stereo_frames_per_step_per_gpu": B, "parallelism": f"frames sharded over {world} GPU(s)",
+                       "stereo_frames_per_step_per_gpu": B, "parallelism": f"frames dealt round-robin over {world} GPU(s)" + ("" if world == 1 else
+                                       "; one RCCL all-gather of left-image keypoints/descriptors/BoW ids per step"),
                        "stages_in_step": ["extract_left+right", "stereo_match", "bow_transform", "search_by_bow"],
                        "mean_keypoints_per_image": float(cnt.mean()), "mean_stereo_matches_per_frame": n_stereo,
                        "mean_bow_matches_per_frame": n_bow},
@@ -186,6 +248,8 @@ def main():
                          "algorithmic_bytes_per_launch": ab[dom] * nimg, "avg_launch_ms": stages[dom]},
             "extract_stage_ms_per_step": stages,
         }
+        if world == 1:
+            line["extra_metrics"] = optimizer_extras(local_rank)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -324,3 +324,66 @@ def test_product_path_has_no_cpu_fallback():
                 assert "oracle_lib" not in txt and "liboracle" not in txt, f
                 assert not re.search(r'#include\s*[<"][^>"]*oracle', txt), f
                 assert not re.search(r"^\s*(from|import)\s+\S*oracle", txt, flags=re.M), f
+
+
+# ---- matcher / optimiser oracle sanity (CPU) ---------------------------------------------------------------
+def test_descriptor_distance_and_three_maxima():
+    import oracle_lib as O
+    L = lib()
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, 256, (50, 32), dtype=np.uint8); b = rng.integers(0, 256, (50, 32), dtype=np.uint8)
+    for i in range(50):
+        assert L.orc_descriptor_distance(_p(a[i]), _p(b[i])) == int(np.unpackbits(a[i] ^ b[i]).sum())
+    ind = np.zeros(3, np.int32)
+    cnt = np.zeros(30, np.int32); cnt[[3, 7, 20]] = [50, 40, 4]          # third < 10 % of max -> dropped
+    L.orc_three_maxima(_p(cnt), 30, _p(ind)); assert ind.tolist() == [3, 7, -1]
+    cnt[:] = 0; cnt[[1, 2]] = [10, 10]                                   # ties: strict '>' keeps the first as max
+    L.orc_three_maxima(_p(cnt), 30, _p(ind)); assert ind.tolist() == [1, 2, -1]
+    cnt[:] = 0; cnt[5] = 9
+    L.orc_three_maxima(_p(cnt), 30, _p(ind)); assert ind.tolist() == [5, -1, -1]
+
+
+def test_knn2_against_numpy():
+    import oracle_lib as O
+    rng = np.random.default_rng(3)
+    q = rng.integers(0, 256, (40, 32), dtype=np.uint8); t = rng.integers(0, 256, (70, 32), dtype=np.uint8)
+    t[10] = t[3]                                                         # exact tie -> lower train index first
+    idx, dist = O.knn2(q, t)
+    D = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2)
+    order = np.argsort(D, axis=1, kind="stable")
+    np.testing.assert_array_equal(idx, order[:, :2])
+    np.testing.assert_array_equal(dist, np.take_along_axis(D, order[:, :2], 1))
+
+
+def test_stereo_oracle_on_synthetic_pair():
+    import oracle_lib as O
+    from morb_slam_amd.synth import make_stereo_pair
+    l, r = make_stereo_pair(752, 480, seed=60)
+    ol, orr = OracleExtractor(1200), OracleExtractor(1200)
+    _, kl, dl = ol(l); _, kr, dr = orr(r)
+    mbf, mb = np.float32(458.654 * 0.11), np.float32(0.11)
+    u, d = O.stereo_matches(ol, orr, kl, dl, kr, dr, mbf, mb)
+    ok = u >= 0
+    assert ok.sum() > 300
+    disp = kl["x"][ok] - u[ok]
+    assert (disp >= 0).all() and (disp < mbf / mb).all()
+    np.testing.assert_allclose(d[ok], mbf / np.maximum(disp, 0.01), rtol=1e-5)
+    assert 2 <= np.median(disp) <= 60                                    # the synthetic disparity field is in [2, 60] px
+
+
+def test_pose_and_ba_oracle_converge():
+    import oracle_lib as O
+    from morb_slam_amd.synth import make_ba_problem, make_pose_problem
+    p = make_pose_problem(500, seed=3)
+    r, pose, outl, stats = O.pose_optimization(p)
+    assert np.abs(pose - p["true"]).max() < 0.01 and r > 300
+    flagged = outl[p["hasMP"] > 0].astype(bool); truth = p["outlier_truth"][p["hasMP"] > 0]
+    assert (flagged[truth]).mean() > 0.95                                # gross outliers are caught
+    few = make_pose_problem(30, seed=4); few["hasMP"][:] = 0; few["hasMP"][:2] = 1
+    assert O.pose_optimization(few)[0] == 0                              # < 3 correspondences (Optimizer.cc:951)
+    b = make_ba_problem(seed=5, n_free=6, n_fixed=2, n_points=300)
+    its, kf, mp, erase, st = O.local_ba(b)
+    assert 1 <= its <= 10 and np.abs(kf[:6] - b["true_poses"][:6]).max() < 0.05
+    stop = np.array([1], np.int32)
+    its, kf2, _, _, _ = O.local_ba(b, stop=stop)
+    assert its == 0 and np.array_equal(kf2, b["kfPose"])                 # *pbStopFlag (Optimizer.cc:1355)

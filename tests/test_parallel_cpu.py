@@ -1,0 +1,82 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU frame sharding + feature all-gather (morb_slam_amd/parallel.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from morb_slam_amd import parallel
+
+
+def test_round_robin_index_math():
+    world, S = 4, 3
+    seen = set()
+    for r in range(world):
+        kf, fr = parallel.predecessor_pairs(r, world, S)
+        for s in range(S):
+            g = parallel.global_frame(r, world, s)
+            assert parallel.owner(world, g) == (r, s)
+            assert fr[s] == r * S + s
+            gp = max(g - 1, 0)
+            assert kf[s] == (gp % world) * S + gp // world
+            seen.add(g)
+    assert seen == set(range(world * S))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S, cap = 3, 17
+        g = torch.Generator().manual_seed(100 + rank)
+        kps = torch.randint(0, 256, (S, cap, 28), dtype=torch.uint8, generator=g)
+        desc = torch.randint(0, 256, (S, cap, 32), dtype=torch.uint8, generator=g)
+        cnt = torch.tensor([cap - rank - s for s in range(S)], dtype=torch.int32)
+        node = torch.randint(0, 100, (S, cap), dtype=torch.int32, generator=g)
+        ex = parallel.FeatureExchange()
+        pk, pd, pc, pn = ex.exchange(kps, desc, cnt, node)
+        # rebuild every rank's slab locally and compare
+        ok = True
+        for r in range(world):
+            gg = torch.Generator().manual_seed(100 + r)
+            k2 = torch.randint(0, 256, (S, cap, 28), dtype=torch.uint8, generator=gg)
+            d2 = torch.randint(0, 256, (S, cap, 32), dtype=torch.uint8, generator=gg)
+            c2 = torch.tensor([cap - r - s for s in range(S)], dtype=torch.int32)
+            n2 = torch.randint(0, 100, (S, cap), dtype=torch.int32, generator=gg)
+            ok &= bool((pk[r * S:(r + 1) * S] == k2).all() and (pd[r * S:(r + 1) * S] == d2).all()
+                       and (pc[r * S:(r + 1) * S] == c2).all() and (pn[r * S:(r + 1) * S] == n2).all())
+        kf, fr = parallel.predecessor_pairs(rank, world, S)
+        # the predecessor of local slot s (global g) must be the slab row of global g-1
+        for s in range(S):
+            gidx = parallel.global_frame(rank, world, s)
+            gp = max(gidx - 1, 0)
+            r2, s2 = parallel.owner(world, gp)
+            ok &= int(pc[kf[s]]) == cap - r2 - s2 and int(pc[fr[s]]) == cap - rank - s
+        # weak-scaling timing reduction used by bench.py: MAX over ranks
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ok &= float(t) == float(world)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_feature_exchange_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
