@@ -1,0 +1,114 @@
+// Drop-in adapter: ORB_SLAM3::ORBextractor (reference include/ORBextractor.h:44-105) over libmorb_hip.so.
+// Same constructor, same operator(), same accessors, same public mvImagePyramid member semantics, so
+// src/Frame.cc / src/Tracking.cc compile against it unchanged.  With OpenCV headers present the cv:: types are
+// used directly; without them (this build container has no OpenCV) the POD stand-ins below keep the header
+// compilable for the C++ smoke test in tests/native/adapter_smoke.cc.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../morb_hip.h"
+
+#if __has_include(<opencv2/core/core.hpp>)
+#include <opencv2/core/core.hpp>
+#define MORB_HAVE_OPENCV 1
+#else
+#define MORB_HAVE_OPENCV 0
+#endif
+
+namespace ORB_SLAM3 {
+
+#if !MORB_HAVE_OPENCV
+namespace podcv {  // minimal stand-ins with the layouts the ABI uses
+struct KeyPoint { float x, y, size, angle, response; int octave, class_id; };
+struct Mat8u { std::vector<uint8_t> data; int rows = 0, cols = 0, step = 0; bool empty() const { return rows == 0 || cols == 0; } };
+}  // namespace podcv
+#endif
+
+class ORBextractor {
+ public:
+  enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+  ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = 0)
+      : nlevels_(nlevels), scaleFactor_(scaleFactor) {
+    if (morb_extractor_create(&h_, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device) != MORB_OK)
+      throw std::runtime_error(std::string("morb_extractor_create: ") + morb_last_error());
+    mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
+    morb_extractor_tables(h_, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(), nullptr);
+    cap_ = morb_extractor_max_keypoints(h_);
+  }
+  ~ORBextractor() { morb_extractor_destroy(h_); }
+  ORBextractor(const ORBextractor&) = delete;
+  ORBextractor& operator=(const ORBextractor&) = delete;
+
+#if MORB_HAVE_OPENCV
+  // int operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint>&, cv::OutputArray, std::vector<int>&)
+  int operator()(cv::InputArray _image, cv::InputArray /*mask*/, std::vector<cv::KeyPoint>& _keypoints,
+                 cv::OutputArray _descriptors, std::vector<int>& vLappingArea) {
+    if (_image.empty()) return -1;
+    cv::Mat image = _image.getMat();
+    CV_Assert(image.type() == CV_8UC1);
+    static_assert(sizeof(cv::KeyPoint) == sizeof(morb_keypoint), "cv::KeyPoint layout");
+    std::vector<morb_keypoint> k(cap_);
+    std::vector<uint8_t> d((size_t)cap_ * 32);
+    int n = 0;
+    const int mono = morb_extract(h_, image.data, image.cols, image.rows, (int)image.step, vLappingArea[0], vLappingArea[1],
+                                  k.data(), d.data(), cap_, &n);
+    if (mono < 0) { if (mono == MORB_ERR_EMPTY) return -1; throw std::runtime_error(morb_last_error()); }
+    _keypoints.resize(n);
+    if (n) std::memcpy(static_cast<void*>(_keypoints.data()), k.data(), sizeof(morb_keypoint) * n);
+    if (n == 0) _descriptors.release();
+    else { _descriptors.create(n, 32, CV_8U); std::memcpy(_descriptors.getMat().data, d.data(), (size_t)n * 32); }
+    refreshPyramid();
+    return mono;
+  }
+  std::vector<cv::Mat> mvImagePyramid;  // reference: public, read by Frame::ComputeStereoMatches (Frame.cc:895)
+#else
+  int operator()(const podcv::Mat8u& image, std::vector<podcv::KeyPoint>& keypoints, std::vector<uint8_t>& descriptors,
+                 const std::vector<int>& vLappingArea) {
+    if (image.empty()) return -1;
+    static_assert(sizeof(podcv::KeyPoint) == sizeof(morb_keypoint), "KeyPoint layout");
+    keypoints.resize(cap_);
+    descriptors.resize((size_t)cap_ * 32);
+    int n = 0;
+    const int mono = morb_extract(h_, image.data.data(), image.cols, image.rows, image.step, vLappingArea[0], vLappingArea[1],
+                                  reinterpret_cast<morb_keypoint*>(keypoints.data()), descriptors.data(), cap_, &n);
+    if (mono < 0) { if (mono == MORB_ERR_EMPTY) return -1; throw std::runtime_error(morb_last_error()); }
+    keypoints.resize(n);
+    descriptors.resize((size_t)n * 32);
+    return mono;
+  }
+#endif
+
+  int inline GetLevels() { return nlevels_; }
+  float inline GetScaleFactor() { return scaleFactor_; }
+  std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
+  std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
+  std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
+  std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+  morb_extractor* handle() { return h_; }  // for the batched / device-resident entry points
+
+ private:
+#if MORB_HAVE_OPENCV
+  void refreshPyramid() {  // host copies of the levels with their 19-px pad, exposed as ROIs like the reference
+    mvImagePyramid.resize(nlevels_);
+    for (int l = 0; l < nlevels_; ++l) {
+      int w, h, s; const uint8_t* p;
+      morb_extractor_pyramid_level(h_, 0, l, &p, &w, &h, &s);
+      cv::Mat padded(h + 38, w + 38, CV_8UC1);
+      morb_extractor_pyramid_level_host(h_, 0, l, padded.data);
+      mvImagePyramid[l] = padded(cv::Rect(19, 19, w, h));
+    }
+  }
+#endif
+  morb_extractor* h_ = nullptr;
+  int nlevels_, cap_ = 0;
+  float scaleFactor_;
+  std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+};
+
+}  // namespace ORB_SLAM3
