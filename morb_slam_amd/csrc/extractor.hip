@@ -105,38 +105,60 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
 // K5: GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101), OpenCV fixed-point path: 8.8 kernel
 // {18,34,48,56,48,34,18}, row pass exact, column pass rounded (+0.5) to u8.  The level's own 19-px
 // reflect-101 pad is exactly the border the blur needs, so the tile loads straight from the padded pyramid.
-constexpr int BT_W = 64, BT_H = 16;
+// v2: no LDS.  A thread owns a 4-pixel-wide column strip and walks down BT_ROWS rows keeping the last seven
+// row-pass results (4 x u16, packed in two dwords) in registers; every output dword (4 pixels) needs three
+// aligned dword loads of the source row (bytes x-3 .. x+8; the interior starts 19 bytes into the padded row and
+// 19 - 3 = 16, so x % 4 == 0 makes the window 4-byte aligned).  HBM traffic = read P (+halo rows) + write P.
+constexpr int BT_W = 256, BT_ROWS = 16, BT_TY = 4;   // workgroup: 64 x 4 threads -> 256 px x 64 rows per tile
+constexpr int BT_H = BT_ROWS * BT_TY;
+__device__ __forceinline__ void blur_row4(const uint8_t* __restrict__ rowAligned, uint32_t& lo, uint32_t& hi) {
+  // rowAligned points at byte (x - 3) of the padded row: 12 bytes = pixels x-3 .. x+8
+  const uint32_t w0 = reinterpret_cast<const uint32_t*>(rowAligned)[0];
+  const uint32_t w1 = reinterpret_cast<const uint32_t*>(rowAligned)[1];
+  const uint32_t w2 = reinterpret_cast<const uint32_t*>(rowAligned)[2];
+  uint32_t p[12];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { p[k] = (w0 >> (8 * k)) & 0xFF; p[4 + k] = (w1 >> (8 * k)) & 0xFF; p[8 + k] = (w2 >> (8 * k)) & 0xFF; }
+  uint32_t r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    r[k] = 18u * (p[k] + p[k + 6]) + 34u * (p[k + 1] + p[k + 5]) + 48u * (p[k + 2] + p[k + 4]) + 56u * p[k + 3];
+  lo = r[0] | (r[1] << 16);
+  hi = r[2] | (r[3] << 16);
+}
 __global__ __launch_bounds__(256) void k_blur(const LevelGeom* __restrict__ geom, int nlevels,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
-  __shared__ uint8_t tin[BT_H + 6][BT_W + 8];
-  __shared__ uint16_t hrow[BT_H + 6][BT_W];
   int l = 0;
   while (l + 1 < nlevels && (int)blockIdx.x >= geom[l + 1].blurTileBase) ++l;
   const LevelGeom g = geom[l];
   const int t = blockIdx.x - g.blurTileBase;
-  const int x0 = (t % g.blurTilesX) * BT_W, y0 = (t / g.blurTilesX) * BT_H;
+  const int tx = t % g.blurTilesX, ty = t / g.blurTilesX;
   const int img = blockIdx.y;
-  const uint8_t* base = pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)EDGE * g.pstride + EDGE;
-  for (int i = threadIdx.x; i < (BT_H + 6) * (BT_W + 6); i += 256) {
-    const int r = i / (BT_W + 6), c = i % (BT_W + 6);
-    int gy = y0 + r - 3, gx = x0 + c - 3;
-    gy = gy > g.h + EDGE - 1 ? g.h + EDGE - 1 : gy;  // tile overhang: stay inside the allocation
-    gx = gx > g.w + EDGE - 1 ? g.w + EDGE - 1 : gx;
-    tin[r][c] = base[(ptrdiff_t)gy * g.pstride + gx];
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < (BT_H + 6) * BT_W; i += 256) {
-    const int r = i / BT_W, c = i % BT_W;
-    const uint8_t* p = &tin[r][c];
-    hrow[r][c] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
-  }
-  __syncthreads();
-  uint8_t* out = blur + g.blurOff + (size_t)img * g.blurImg;
-  for (int i = threadIdx.x; i < BT_H * BT_W; i += 256) {
-    const int r = i / BT_W, c = i % BT_W;
-    const uint32_t acc = 18u * (hrow[r][c] + hrow[r + 6][c]) + 34u * (hrow[r + 1][c] + hrow[r + 5][c]) +
-                         48u * (hrow[r + 2][c] + hrow[r + 4][c]) + 56u * hrow[r + 3][c];
-    if (x0 + c < g.w && y0 + r < g.h) out[(size_t)(y0 + r) * g.bstride + x0 + c] = (uint8_t)((acc + 32768u) >> 16);
+  const int x = tx * BT_W + (threadIdx.x & 63) * 4;
+  const int y0 = ty * BT_H + (threadIdx.x >> 6) * BT_ROWS;
+  if (x >= g.w || y0 >= g.h) return;
+  // padded-row origin of this strip: row (y + 19 - 3), byte (19 + x - 3) = 16 + x
+  const uint8_t* src = pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)(EDGE + y0 - 3) * g.pstride + (EDGE - 3) + x;
+  uint8_t* dst = blur + g.blurOff + (size_t)img * g.blurImg + (size_t)y0 * g.bstride + x;
+  uint32_t lo[7], hi[7];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) blur_row4(src + (size_t)k * g.pstride, lo[k], hi[k]);
+  const int rows = (g.h - y0) < BT_ROWS ? (g.h - y0) : BT_ROWS;
+  for (int r = 0; r < rows; ++r) {
+    blur_row4(src + (size_t)(r + 6) * g.pstride, lo[6], hi[6]);
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int sh = (k & 1) * 16;
+      const uint32_t* a = (k < 2) ? lo : hi;
+      const uint32_t v0 = (a[0] >> sh) & 0xFFFF, v1 = (a[1] >> sh) & 0xFFFF, v2 = (a[2] >> sh) & 0xFFFF, v3 = (a[3] >> sh) & 0xFFFF;
+      const uint32_t v4 = (a[4] >> sh) & 0xFFFF, v5 = (a[5] >> sh) & 0xFFFF, v6 = (a[6] >> sh) & 0xFFFF;
+      const uint32_t acc = 18u * (v0 + v6) + 34u * (v1 + v5) + 48u * (v2 + v4) + 56u * v3;
+      o |= ((acc + 32768u) >> 16) << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)r * g.bstride) = o;   // columns >= w land in the row's alignment slack
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { lo[k] = lo[k + 1]; hi[k] = hi[k + 1]; }
   }
 }
 
@@ -180,9 +202,12 @@ __global__ __launch_bounds__(256) void k_fast(const LevelGeom* __restrict__ geom
                                               int tileRows, int iniTh, int minTh) {
   extern __shared__ __align__(16) uint8_t smem[];
   uint8_t* tile = smem;                           // [tileRows][tilePitch]
-  uint8_t* sc = smem + tileRows * tilePitch;      // [tileRows][tilePitch] strength, 0 outside the evaluated area
-  __shared__ int waveCnt[4];
-  __shared__ int sTotal;
+  uint8_t* sc = smem + tileRows * tilePitch;      // [tileRows][tilePitch] strength, 0 where it cannot matter
+  uint16_t* queue = reinterpret_cast<uint16_t*>(smem + 2 * tileRows * tilePitch);  // [tileRows * tilePitch] y << 8 | x
+  uint32_t* bmHi = reinterpret_cast<uint32_t*>(smem + 4 * tileRows * tilePitch);  // [tileRows][8] keep bits at iniThFAST
+  uint32_t* bmLo = bmHi + tileRows * 8;                                            // [tileRows][8] keep bits at minThFAST
+  int* rowCnt = reinterpret_cast<int*>(bmLo + tileRows * 8);                       // [tileRows + 1]
+  __shared__ int qn;
 
   int l = 0;
   while (l + 1 < nlevels && (int)blockIdx.x >= geom[l + 1].cellBase) ++l;
@@ -207,72 +232,106 @@ __global__ __launch_bounds__(256) void k_fast(const LevelGeom* __restrict__ geom
     if (tid == 0) candCnt[cellSlot] = 0;
     return;
   }
+  // thread layout: 64 lanes along x, 4 waves along y (no integer division anywhere below)
   const uint8_t* base = pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)(EDGE + iniY) * g.pstride + EDGE + iniX;
-  for (int i = tid; i < th * tw; i += 256) {
-    const int r = i / tw, c = i % tw;
-    tile[r * tilePitch + c] = base[(size_t)r * g.pstride + c];
-    sc[r * tilePitch + c] = 0;
-  }
+  for (int r = wv; r < th; r += 4)
+    for (int c = lane; c < tw; c += 64) {
+      tile[r * tilePitch + c] = base[(size_t)r * g.pstride + c];
+      sc[r * tilePitch + c] = 0;
+    }
+  for (int i = tid; i < th * 8; i += 256) { bmHi[i] = 0; bmLo[i] = 0; }
+  if (tid == 0) qn = 0;
   __syncthreads();
-  const int nEval = ew * eh;
-  for (int i = tid; i < nEval; i += 256) {
-    const int y = i / ew + 3, x = i % ew + 3;
-    int s = fast_strength(tile + y * tilePitch + x, tilePitch);
-    sc[y * tilePitch + x] = (uint8_t)imin(imax(s, 0), 255);
+
+  // Phase 1 — cheap reject.  Every 9-arc of the 16-pixel ring contains at least two of the four compass pixels
+  // (0, 4, 8, 12), so a pixel can only exceed strength tmin if >= 2 compass pixels are darker than v - tmin or
+  // >= 2 are brighter than v + tmin.  Pixels that fail keep strength 0: they are corners at neither threshold
+  // and count as score 0 in their neighbours' NMS, exactly like cv::FAST's score buffer.
+  const int tmin = imin(iniTh, minTh);
+  for (int y = 3 + wv; y < th - 3; y += 4)
+    for (int x0 = 3; x0 < tw - 3; x0 += 64) {
+      const int x = x0 + lane;
+      bool possible = false;
+      if (x < tw - 3) {
+        const uint8_t* p = tile + y * tilePitch + x;
+        const int v = p[0];
+        const int d0 = v - p[3 * tilePitch], d4 = v - p[3], d8 = v - p[-3 * tilePitch], d12 = v - p[-3];
+        const int nd = (d0 > tmin) + (d4 > tmin) + (d8 > tmin) + (d12 > tmin);
+        const int nb = (d0 < -tmin) + (d4 < -tmin) + (d8 < -tmin) + (d12 < -tmin);
+        possible = nd >= 2 || nb >= 2;
+      }
+      const uint64_t m = __ballot(possible);
+      if (m) {
+        int qbase = 0;
+        if (lane == 0) qbase = atomicAdd(&qn, __popcll(m));
+        qbase = __shfl(qbase, 0, 64);
+        if (possible) queue[qbase + __popcll(m & (lane == 0 ? 0ull : (~0ull >> (64 - lane))))] = (uint16_t)((y << 8) | x);
+      }
+    }
+  __syncthreads();
+  // Phase 2 — exact strength for the survivors only, densely packed over the workgroup
+  const int nq = qn;
+  for (int q = tid; q < nq; q += 256) {
+    const int e = queue[q];
+    const int y = e >> 8, x = e & 255;
+    const int s = fast_strength(tile + y * tilePitch + x, tilePitch);
+    sc[y * tilePitch + x] = (uint8_t)(s > tmin ? imin(s, 255) : 0);
   }
   __syncthreads();
 
-  // NMS at threshold t: corner iff S > t, score = S - 1, neighbours that are not corners score 0; keep iff
-  // score strictly greater than all 8 neighbour scores.
-  auto keepAt = [&](int i, int t) -> bool {
-    const int y = i / ew + 3, x = i % ew + 3;
-    const uint8_t* q = sc + y * tilePitch + x;
-    const int S = q[0];
-    if (S <= t) return false;
-    bool keep = true;
+  // Phase 3 — NMS at both thresholds, only for pixels that have a strength; results go to per-row bitmaps.
+  // corner at t iff S > t, score S - 1, non-corner neighbours score 0; keep iff strictly greater than all 8.
+  for (int q = tid; q < nq; q += 256) {
+    const int e = queue[q];
+    const int y = e >> 8, x = e & 255;
+    const uint8_t* c = sc + y * tilePitch + x;
+    const int S = c[0];
+    if (S == 0) continue;
+    bool kh = S > iniTh, kl = S > minTh;
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
       for (int dx = -1; dx <= 1; ++dx) {
         if (dx == 0 && dy == 0) continue;
-        const int Sn = q[dy * tilePitch + dx];
-        const int ns = Sn > t ? Sn - 1 : 0;
-        keep = keep && (S - 1 > ns);
+        const int Sn = c[dy * tilePitch + dx];
+        kh = kh && (S - 1 > (Sn > iniTh ? Sn - 1 : 0));
+        kl = kl && (S - 1 > (Sn > minTh ? Sn - 1 : 0));
       }
-    return keep;
-  };
-
-  int thr = iniTh;
-  for (int pass = 0; pass < 2; ++pass) {
-    int cnt = 0;
-    for (int i = tid; i < nEval; i += 256) cnt += keepAt(i, thr) ? 1 : 0;
-    const int tot = __syncthreads_count(cnt > 0);
-    if (tot > 0 || pass == 1) break;
-    thr = minTh;  // vKeysCell.empty() -> second cv::FAST with minThFAST (:795)
+    if (kh) atomicOr(&bmHi[y * 8 + (x >> 5)], 1u << (x & 31));
+    if (kl) atomicOr(&bmLo[y * 8 + (x >> 5)], 1u << (x & 31));
   }
-
-  // ordered compaction, row-major over the evaluated area
+  __syncthreads();
+  // Phase 4 — vKeysCell.empty() -> second cv::FAST with minThFAST (:795); row prefix sums of the chosen bitmap
+  unsigned anyBits = 0;
+  for (int i = tid; i < th * 8; i += 256) anyBits |= bmHi[i];
+  const int anyHi = __syncthreads_or(anyBits != 0);
+  const uint32_t* bm = anyHi ? bmHi : bmLo;
+  if (tid < th) {
+    int c = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) c += __popc(bm[tid * 8 + w]);
+    rowCnt[tid] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int r = 0; r < th; ++r) { const int c = rowCnt[r]; rowCnt[r] = acc; acc += c; }
+    rowCnt[th] = acc;
+  }
+  __syncthreads();
+  // Phase 5 — ordered output (row-major over the evaluated area): slot = row prefix + set bits to the left
   uint32_t* out = cand + cellSlot * (size_t)cellCap;
-  int running = 0;
-  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  for (int i0 = 0; i0 < nEval; i0 += 256) {
-    const int i = i0 + tid;
-    const bool k = i < nEval && keepAt(i, thr);
-    const uint64_t m = __ballot(k);
-    if (lane == 0) waveCnt[wv] = __popcll(m);
-    __syncthreads();
-    int off = running;
-    for (int q = 0; q < wv; ++q) off += waveCnt[q];
-    if (k) {
-      const int y = i / ew + 3, x = i % ew + 3;
-      const int slot = off + __popcll(m & lt);
-      if (slot < cellCap)
-        out[slot] = morbqt::make_key(x + cj * g.wCell, y + ci * g.hCell, sc[y * tilePitch + x] - 1);
-    }
-    running += waveCnt[0] + waveCnt[1] + waveCnt[2] + waveCnt[3];
-    __syncthreads();
+  for (int q = tid; q < nq; q += 256) {
+    const int e = queue[q];
+    const int y = e >> 8, x = e & 255;
+    const int w = x >> 5;
+    const uint32_t word = bm[y * 8 + w];
+    if (!((word >> (x & 31)) & 1u)) continue;
+    int slot = rowCnt[y] + __popc(word & ((1u << (x & 31)) - 1u));
+    for (int ww = 0; ww < w; ++ww) slot += __popc(bm[y * 8 + ww]);
+    if (slot < cellCap) out[slot] = morbqt::make_key(x + cj * g.wCell, y + ci * g.hCell, sc[y * tilePitch + x] - 1);
   }
-  if (tid == 0) candCnt[cellSlot] = imin(running, cellCap);
+  if (tid == 0) candCnt[cellSlot] = imin(rowCnt[th], cellCap);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -575,6 +634,7 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     e->cellCap = std::max(e->cellCap, ((g.wCell + 1) / 2) * ((g.hCell + 1) / 2));
     e->tilePitch = std::max(e->tilePitch, (int)align_up((size_t)g.wCell + 6, 4));
     e->tileRows = std::max(e->tileRows, g.hCell + 6);
+    MORB_REQUIRE(g.wCell + 6 < 256 && g.hCell + 6 < 256, MORB_ERR_UNSUPPORTED, "FAST cell too large for 8-bit tile coordinates");
     g.quota = e->quota[l];
     g.nIni = (int)std::round(width / height);  // :545
     MORB_REQUIRE(g.nIni >= 1 && g.nIni <= 4, MORB_ERR_UNSUPPORTED, "aspect ratio unsupported (need 0.5 <= w/h < 4.5)");
@@ -825,7 +885,7 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   hipLaunchKernelGGL(k_blur, dim3(e->blurTiles, nimg), dim3(256), 0, st, e->d_geom, L, e->d_pyr, e->d_blur);
   mark(2);
   {
-    const size_t smem = 2ull * e->tileRows * e->tilePitch;
+    const size_t smem = 4ull * e->tileRows * e->tilePitch + (size_t)e->tileRows * 68 + 16;  // tile, strength, u16 queue, 2 bitmaps, row counts
     hipLaunchKernelGGL(k_fast, dim3(e->totalCells, nimg), dim3(256), smem, st, e->d_geom, L, e->d_pyr, e->d_cand,
                        e->d_candCnt, e->totalCells, e->cellCap, e->tilePitch, e->tileRows, e->iniTh, e->minTh);
   }
