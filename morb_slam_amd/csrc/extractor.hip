@@ -57,48 +57,88 @@ __device__ __forceinline__ int reflect101(int p, int len) {
   return p;
 }
 
+constexpr int PY_ROWS = 8;  // rows per thread in the pyramid kernels (block = 64 x 4 threads -> 256 px x 32 rows)
 __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src, int w, int h, int stride,
                                                 size_t pitch, uint8_t* __restrict__ pyr, LevelGeom g) {
-  const int px = (blockIdx.x * 256 + threadIdx.x) * 4;
-  const int py = blockIdx.y;
+  const int px = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  const int py0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * PY_ROWS;
   const int img = blockIdx.z;
   if (px >= g.pstride) return;
-  const uint8_t* s = src + (size_t)img * pitch + (size_t)reflect101(py - EDGE, h) * stride;
-  uint32_t v = 0;
+  int xs[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    int x = px + k - EDGE;
-    if (px + k < w + 2 * EDGE) v |= (uint32_t)s[reflect101(x, w)] << (8 * k);
+  for (int k = 0; k < 4; ++k) xs[k] = reflect101(px + k - EDGE, w);
+  const bool interior = px >= EDGE && px + 3 < w + EDGE;
+  for (int r = 0; r < PY_ROWS; ++r) {
+    const int py = py0 + r;
+    if (py >= h + 2 * EDGE) break;
+    const uint8_t* s = src + (size_t)img * pitch + (size_t)reflect101(py - EDGE, h) * stride;
+    uint32_t v = 0;
+    if (interior) {
+      __builtin_memcpy(&v, s + xs[0], 4);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (px + k < w + 2 * EDGE) v |= (uint32_t)s[xs[k]] << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)py * g.pstride + px) = v;
   }
-  *reinterpret_cast<uint32_t*>(pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)py * g.pstride + px) = v;
 }
 
 // K1b: level l = resize(level l-1, INTER_LINEAR) + copyMakeBorder(BORDER_REFLECT_101|ISOLATED)
 // (ORBextractor.cc:1101-1104).  Every padded pixel is computed directly from level l-1 through tables that
 // already fold the reflection, so one launch writes interior and pad.
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, LevelGeom gs, LevelGeom gd,
                                                 const ResizeTab* __restrict__ xtab,
                                                 const ResizeTab* __restrict__ ytab) {
-  const int px = (blockIdx.x * 256 + threadIdx.x) * 4;
-  const int py = blockIdx.y;
+  const int px = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  const int py0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * PY_ROWS;
   const int img = blockIdx.z;
   if (px >= gd.pstride) return;
-  const ResizeTab ty = ytab[py];
-  const uint8_t* sbase = pyr + gs.pyrOff + (size_t)img * gs.pyrImg + (size_t)EDGE * gs.pstride + EDGE;
-  const uint8_t* r0 = sbase + (size_t)ty.s0 * gs.pstride;
-  const uint8_t* r1 = sbase + (size_t)ty.s1 * gs.pstride;
-  uint32_t v = 0;
+  ResizeTab tx[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (px + k < gd.w + 2 * EDGE) {
-      const ResizeTab tx = xtab[px + k];
-      const int h0 = r0[tx.s0] * tx.c0 + r0[tx.s1] * tx.c1;
-      const int h1 = r1[tx.s0] * tx.c0 + r1[tx.s1] * tx.c1;
-      const int o = ((((int)ty.c0 * (h0 >> 4)) >> 16) + (((int)ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
-      v |= (uint32_t)(o & 0xFF) << (8 * k);
+  for (int k = 0; k < 4; ++k) tx[k] = xtab[(px + k) < gd.w + 2 * EDGE ? (px + k) : gd.w + 2 * EDGE - 1];
+  // interior columns: the four outputs read source columns s0(px) .. s0(px+3)+1, a span of at most 6 bytes ->
+  // two (unaligned) dword loads per source row; pad columns (reflected, non-monotone) gather bytes.
+  const bool interior = px >= EDGE && px + 3 < gd.w + EDGE;
+  const int base = tx[0].s0;
+  const uint8_t* sbase = pyr + gs.pyrOff + (size_t)img * gs.pyrImg + (size_t)EDGE * gs.pstride + EDGE;
+  uint8_t* dbase = pyr + gd.pyrOff + (size_t)img * gd.pyrImg + px;
+  for (int r = 0; r < PY_ROWS; ++r) {
+    const int py = py0 + r;
+    if (py >= gd.h + 2 * EDGE) break;
+    const ResizeTab ty = ytab[py];
+    const uint8_t* r0 = sbase + (size_t)ty.s0 * gs.pstride;
+    const uint8_t* r1 = sbase + (size_t)ty.s1 * gs.pstride;
+    uint32_t v = 0;
+    if (interior) {
+      const unsigned long long a = (unsigned long long)load_u32_unaligned(r0 + base) | ((unsigned long long)load_u32_unaligned(r0 + base + 4) << 32);
+      const unsigned long long b = (unsigned long long)load_u32_unaligned(r1 + base) | ((unsigned long long)load_u32_unaligned(r1 + base + 4) << 32);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int o0 = (tx[k].s0 - base) * 8, o1 = (tx[k].s1 - base) * 8;
+        const int h0 = (int)((a >> o0) & 0xFF) * tx[k].c0 + (int)((a >> o1) & 0xFF) * tx[k].c1;
+        const int h1 = (int)((b >> o0) & 0xFF) * tx[k].c0 + (int)((b >> o1) & 0xFF) * tx[k].c1;
+        const int o = ((((int)ty.c0 * (h0 >> 4)) >> 16) + (((int)ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        v |= (uint32_t)(o & 0xFF) << (8 * k);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (px + k < gd.w + 2 * EDGE) {
+          const int h0 = r0[tx[k].s0] * tx[k].c0 + r0[tx[k].s1] * tx[k].c1;
+          const int h1 = r1[tx[k].s0] * tx[k].c0 + r1[tx[k].s1] * tx[k].c1;
+          const int o = ((((int)ty.c0 * (h0 >> 4)) >> 16) + (((int)ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
+          v |= (uint32_t)(o & 0xFF) << (8 * k);
+        }
+      }
     }
+    *reinterpret_cast<uint32_t*>(dbase + (size_t)py * gd.pstride) = v;
   }
-  *reinterpret_cast<uint32_t*>(pyr + gd.pyrOff + (size_t)img * gd.pyrImg + (size_t)py * gd.pstride + px) = v;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -872,11 +912,11 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   mark(0);
   {
     const LevelGeom& g0 = e->geom[0];
-    dim3 grid(div_up(g0.pstride / 4, 256), g0.h + 2 * EDGE, nimg);
+    dim3 grid(div_up(g0.pstride / 4, 64), div_up(g0.h + 2 * EDGE, 4 * PY_ROWS), nimg);
     hipLaunchKernelGGL(k_level0, grid, dim3(256), 0, st, d_images, width, height, stride, image_pitch, e->d_pyr, g0);
     for (int l = 1; l < L; ++l) {
       const LevelGeom& g = e->geom[l];
-      dim3 gr(div_up(g.pstride / 4, 256), g.h + 2 * EDGE, nimg);
+      dim3 gr(div_up(g.pstride / 4, 64), div_up(g.h + 2 * EDGE, 4 * PY_ROWS), nimg);
       hipLaunchKernelGGL(k_resize, gr, dim3(256), 0, st, e->d_pyr, e->geom[l - 1], g, e->d_tabs + g.xtabOff,
                          e->d_tabs + g.ytabOff);
     }
