@@ -258,6 +258,9 @@ int morb_ba_problem_create(morb_optimizer*, morb_ba_problem** out, int nKF, cons
                            int lambdaInit100);
 void morb_ba_problem_destroy(morb_ba_problem*);
 int morb_ba_set_stop(morb_ba_problem*, int stop);
+/* mode 0 (default): one launch per LM phase over the whole GPU, accept/reject on the host (one 32-byte read-back per
+ * trial); mode 1: the whole LM loop inside ONE persistent workgroup (no host round trips; for many small problems). */
+int morb_ba_set_mode(morb_ba_problem*, int mode);
 int morb_ba_solve(morb_ba_problem*, void* stream);
 int morb_ba_results(morb_ba_problem*, float* kfPose, float* mpPos, uint8_t* eraseFlag, int* stats2);
 

@@ -104,6 +104,7 @@ def lib():
         L.morb_ba_problem_destroy.argtypes = [vp]
         L.morb_ba_problem_destroy.restype = None
         L.morb_ba_set_stop.argtypes = [vp, i]
+        L.morb_ba_set_mode.argtypes = [vp, i]
         L.morb_ba_solve.argtypes = [vp, vp]
         L.morb_ba_results.argtypes = [vp, vp, vp, vp, vp]
         _lib = L

@@ -440,6 +440,13 @@ struct BaDev {
   const int* stop;                      // device-visible abort flag (may be NULL)
   Cam cam;
   double userLambda;
+  // grid mode (one launch per LM phase across the whole chip)
+  int nChunks;                          // keyframe edge lists cut into chunks of <= 64 edges (one wave each)
+  const int *chunkKF, *chunkStart, *chunkEnd;   // [nChunks]
+  const int *kfChunkStart;              // [nKF + 1]
+  double *kfPart;                       // [nChunks][27]
+  double *redPart;                      // [2][redBlocks] block partial sums (chi2, scale)
+  double *scal;                         // [8] device scalars: chi2, scale, ok, maxdiag
 };
 
 __device__ __forceinline__ SE3 load_se3(const double* p) {
@@ -791,6 +798,366 @@ __global__ __launch_bounds__(BA_T) void k_local_ba(const BaDev* __restrict__ pro
   if (tid == 0) { pb.stats[0] = its; pb.stats[1] = trials; }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Grid mode: the same LM, one launch per phase over the whole chip; the accept/reject decision is taken on the
+// host from three doubles read back once per trial (chi2, scale, ok).  Every reduction has a fixed order
+// (block partials summed by one block; chunk partials summed per keyframe), so results are deterministic.
+constexpr int GB = 256;
+
+__global__ __launch_bounds__(GB) void k_g_chi2(const BaDev* __restrict__ pbp, double* __restrict__ part) {
+  __shared__ double red[4];
+  const BaDev pb = *pbp;
+  const int gid = blockIdx.x * GB + threadIdx.x;
+  if (gid < pb.nKF * 7) pb.poseEval[gid] = pb.pose[gid];
+  if (gid < pb.nMP * 3) pb.ptEval[gid] = pb.pt[gid];
+  double s = 0;
+  if (gid < pb.nE) {
+    const SE3 T = load_se3(pb.pose + 7 * pb.eKF[gid]);
+    double xc[3], err[3], w;
+    se3_map(T, pb.pt + 3 * pb.eMP[gid], xc);
+    const float* o = pb.eObs + 3 * gid;
+    const bool st = !(o[2] < 0);
+    const double c = edge_error(pb.cam, st, xc, o, (double)pb.eInfo[gid], err);
+    s = huber(st ? (double)(float)sqrt(7.815) : (double)(float)sqrt(5.991), c, &w);
+  }
+  s = block_sum_d<4>(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(GB) void k_g_reduce(const double* __restrict__ part, int n, double* __restrict__ out) {
+  __shared__ double red[4];
+  double s = 0;
+  for (int i = threadIdx.x; i < n; i += GB) s += part[i];
+  s = block_sum_d<4>(s, red);
+  if (threadIdx.x == 0) *out = s;
+}
+__global__ __launch_bounds__(GB) void k_g_build_mp(const BaDev* __restrict__ pbp) {
+  const BaDev pb = *pbp;
+  const int m = blockIdx.x * GB + threadIdx.x;
+  if (m >= pb.nMP) return;
+  const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
+  double Hl[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
+  const double* X = pb.pt + 3 * m;
+  for (int k = pb.mpStart[m]; k < pb.mpStart[m + 1]; ++k) {
+    const int e = pb.mpEdges[k];
+    const SE3 T = load_se3(pb.pose + 7 * pb.eKF[e]);
+    double xc[3], err[3], w, R[9], Jl[9];
+    se3_map(T, X, xc);
+    const float* o = pb.eObs + 3 * e;
+    const bool st = !(o[2] < 0);
+    const double info = (double)pb.eInfo[e];
+    const double c = edge_error(pb.cam, st, xc, o, info, err);
+    huber(st ? deltaStereo : deltaMono, c, &w);
+    q_to_R(T.q, R);
+    jac_point(pb.cam, st, xc, R, Jl);
+    const int d = st ? 3 : 2;
+    const double wo = w * info;
+    for (int r = 0; r < 3; ++r) {
+      double sacc = 0;
+      for (int i = 0; i < d; ++i) sacc += Jl[i * 3 + r] * (-info * err[i] * w);
+      bl[r] += sacc;
+      for (int cc = 0; cc < 3; ++cc) {
+        double h = 0;
+        for (int i = 0; i < d; ++i) h += Jl[i * 3 + r] * wo * Jl[i * 3 + cc];
+        Hl[r * 3 + cc] += h;
+      }
+    }
+  }
+  for (int k = 0; k < 9; ++k) pb.Hll[(size_t)m * 9 + k] = Hl[k];
+  for (int k = 0; k < 3; ++k) pb.b[pb.P + 3 * m + k] = bl[k];
+}
+__global__ __launch_bounds__(GB) void k_g_build_kf(const BaDev* __restrict__ pbp) {
+  const BaDev pb = *pbp;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= pb.nChunks) return;
+  const int kf = pb.chunkKF[c];
+  const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
+  const SE3 T = load_se3(pb.pose + 7 * kf);
+  double R[9];
+  q_to_R(T.q, R);
+  double acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0;
+  const int k = pb.chunkStart[c] + lane;
+  if (k < pb.chunkEnd[c]) {
+    const int e = pb.kfEdges[k];
+    double xc[3], err[3], w, Jp[18], Jl[9];
+    se3_map(T, pb.pt + 3 * pb.eMP[e], xc);
+    const float* o = pb.eObs + 3 * e;
+    const bool st = !(o[2] < 0);
+    const double info = (double)pb.eInfo[e];
+    const double ch = edge_error(pb.cam, st, xc, o, info, err);
+    huber(st ? deltaStereo : deltaMono, ch, &w);
+    jac_pose(pb.cam, st, false, xc, Jp);
+    jac_point(pb.cam, st, xc, R, Jl);
+    const int d = st ? 3 : 2;
+    const double wo = w * info;
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      double sacc = 0;
+      for (int i = 0; i < d; ++i) sacc += Jp[i * 6 + r] * (-info * err[i] * w);
+      acc[21 + r] = sacc;
+#pragma unroll
+      for (int cc = r; cc < 6; ++cc) {
+        double h = 0;
+        for (int i = 0; i < d; ++i) h += Jp[i * 6 + r] * wo * Jp[i * 6 + cc];
+        acc[q++] = h;
+      }
+      for (int cc = 0; cc < 3; ++cc) {
+        double h = 0;
+        for (int i = 0; i < d; ++i) h += Jp[i * 6 + r] * wo * Jl[i * 3 + cc];
+        pb.Hpl[(size_t)e * 18 + r * 3 + cc] = h;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 27; ++q) acc[q] = wave_sum_d(acc[q]);
+  if (lane < 27) {
+    double v = 0;
+#pragma unroll
+    for (int q = 0; q < 27; ++q) if (q == lane) v = acc[q];
+    pb.kfPart[(size_t)c * 27 + lane] = v;
+  }
+}
+__global__ __launch_bounds__(64) void k_g_kf_reduce(const BaDev* __restrict__ pbp) {
+  const BaDev pb = *pbp;
+  const int kf = blockIdx.x, lane = threadIdx.x;
+  const int col = pb.kfCol[kf];
+  if (col < 0 || lane >= 27) return;
+  double s = 0;
+  for (int c = pb.kfChunkStart[kf]; c < pb.kfChunkStart[kf + 1]; ++c) s += pb.kfPart[(size_t)c * 27 + lane];
+  if (lane < 21) {
+    int r = 0, q = lane;
+    while (q >= 6 - r) { q -= 6 - r; ++r; }
+    const int cc = r + q;
+    pb.Hpp[(size_t)col * 36 + r * 6 + cc] = s;
+    pb.Hpp[(size_t)col * 36 + cc * 6 + r] = s;
+  } else {
+    pb.b[6 * col + (lane - 21)] = s;
+  }
+}
+__global__ __launch_bounds__(GB) void k_g_maxdiag(const BaDev* __restrict__ pbp) {
+  __shared__ double red[4];
+  const BaDev pb = *pbp;
+  double m = 0;
+  for (int i = threadIdx.x; i < pb.nFree * 6; i += GB) m = fmax(m, fabs(pb.Hpp[(size_t)(i / 6) * 36 + (i % 6) * 7]));
+  for (int i = threadIdx.x; i < pb.nMP * 3; i += GB) m = fmax(m, fabs(pb.Hll[(size_t)(i / 3) * 9 + (i % 3) * 4]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) pb.scal[3] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+__global__ __launch_bounds__(GB) void k_g_dinv_push(const BaDev* __restrict__ pbp, double lambda, double* __restrict__ Hs) {
+  const BaDev pb = *pbp;
+  const int gid = blockIdx.x * GB + threadIdx.x;
+  if (gid < pb.nKF * 7) pb.poseBk[gid] = pb.pose[gid];
+  if (gid < pb.nMP * 3) pb.ptBk[gid] = pb.pt[gid];
+  if (gid < pb.P * pb.P) Hs[gid] = 0;
+  if (gid < pb.nMP) {
+    double D[9], Di[9];
+    for (int k = 0; k < 9; ++k) D[k] = pb.Hll[(size_t)gid * 9 + k];
+    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+    inv3(D, Di);
+    for (int k = 0; k < 9; ++k) pb.Dinv[(size_t)gid * 9 + k] = Di[k];
+  }
+}
+__global__ __launch_bounds__(GB) void k_g_schur(const BaDev* __restrict__ pbp, double lambda, double* __restrict__ Hs) {
+  const BaDev pb = *pbp;
+  const int bp = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (bp >= pb.nPairs) return;
+  const int P = pb.P;
+  const int i1 = pb.pairBlock[bp] / pb.nFree, i2 = pb.pairBlock[bp] % pb.nFree;
+  double acc[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = 0;
+  for (int k = pb.pairStart[bp] + lane; k < pb.pairStart[bp + 1]; k += 64) {
+    const int2 en = pb.pairEntries[k];
+    const double* B1 = pb.Hpl + (size_t)en.x * 18;
+    const double* B2 = pb.Hpl + (size_t)en.y * 18;
+    const double* Di = pb.Dinv + (size_t)pb.eMP[en.x] * 9;
+    double BD[18];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) BD[r * 3 + c] = B1[r * 3] * Di[c] + B1[r * 3 + 1] * Di[3 + c] + B1[r * 3 + 2] * Di[6 + c];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[r * 6 + c] += BD[r * 3] * B2[c * 3] + BD[r * 3 + 1] * B2[c * 3 + 1] + BD[r * 3 + 2] * B2[c * 3 + 2];
+  }
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = wave_sum_d(acc[k]);
+  if (lane < 36) {
+    const int r = lane / 6, c = lane % 6;
+    double a = 0;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) if (k == lane) a = acc[k];
+    double v = -a;
+    if (i1 == i2) { v += pb.Hpp[(size_t)i1 * 36 + lane]; if (r == c) v += lambda; }
+    Hs[(size_t)(6 * i1 + r) * P + 6 * i2 + c] = v;
+    if (i1 != i2) Hs[(size_t)(6 * i2 + c) * P + 6 * i1 + r] = v;
+  }
+}
+__global__ __launch_bounds__(64) void k_g_bschur(const BaDev* __restrict__ pbp) {
+  const BaDev pb = *pbp;
+  const int kf = blockIdx.x, lane = threadIdx.x;
+  const int col = pb.kfCol[kf];
+  if (col < 0) return;
+  const int P = pb.P;
+  double a6[6] = {0, 0, 0, 0, 0, 0};
+  for (int k = pb.kfStart[kf] + lane; k < pb.kfStart[kf + 1]; k += 64) {
+    const int e = pb.kfEdges[k];
+    const int m = pb.eMP[e];
+    const double* Di = pb.Dinv + (size_t)m * 9;
+    const double* bl = pb.b + P + 3 * m;
+    double db[3];
+    for (int r = 0; r < 3; ++r) db[r] = Di[r * 3] * bl[0] + Di[r * 3 + 1] * bl[1] + Di[r * 3 + 2] * bl[2];
+    const double* B1 = pb.Hpl + (size_t)e * 18;
+    for (int r = 0; r < 6; ++r) a6[r] += B1[r * 3] * db[0] + B1[r * 3 + 1] * db[1] + B1[r * 3 + 2] * db[2];
+  }
+  for (int r = 0; r < 6; ++r) a6[r] = wave_sum_d(a6[r]);
+  if (lane == 0) for (int r = 0; r < 6; ++r) pb.x[6 * col + r] = pb.b[6 * col + r] - a6[r];
+}
+// reduced camera system: LDL^T + triangular solves by ONE workgroup (the system is <= 132 x 132)
+constexpr int LD_T = 1024;
+// One wave factorises: rows are dealt to lanes (row i -> lane (i - j - 1) % 64), the k-loop of every lane reads the
+// same pivot-column element at the same time (LDS broadcast), rows are padded to P + 1 doubles so that the
+// per-lane row accesses fall on different banks.  Only wave-level barriers are needed (no s_barrier).
+#define LD_WAVE_SYNC()                                        \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");    \
+    __builtin_amdgcn_wave_barrier();                          \
+  } while (0)
+// The body is instantiated twice (LDS / global) so that each copy sees a pointer of known address space: a
+// pointer that may be either forces FLAT loads/stores, which cost several times an LDS access.
+// Right-looking LDL^T by the whole workgroup: per column one barrier after staging the pivot column, one after
+// the trailing update (32 x 32 thread tile, no integer division); triangular solves by wave 0.
+template <typename HsPtr>
+__device__ __forceinline__ bool ldlt_block(HsPtr Hs, int pitch, int P, int tid, double* __restrict__ cv, double* __restrict__ x,
+                                           int* sOk) {
+  const int tx = tid & 31, ty = tid >> 5, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) *sOk = 1;
+  __syncthreads();
+  for (int j = 0; j < P; ++j) {
+    const double d = Hs[(size_t)j * pitch + j];
+    if (d == 0 || d != d) { if (tid == 0) *sOk = 0; break; }   // uniform: every thread reads the same d
+    const double invd = 1.0 / d;
+    for (int i = j + 1 + tid; i < P; i += LD_T) cv[i] = Hs[(size_t)i * pitch + j];
+    __syncthreads();
+    for (int i = j + 1 + ty; i < P; i += 32) {
+      HsPtr row = Hs + (size_t)i * pitch;
+      const double li = cv[i] * invd;
+      for (int k = j + 1 + tx; k <= i; k += 32) row[k] -= li * cv[k];
+      if (tx == 0) row[j] = li;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  const bool ok = *sOk != 0;
+  if (ok && wv == 0) {
+    for (int j = 0; j < P; ++j) {             // L y = b
+      const double xj = x[j];
+      for (int i = j + 1 + lane; i < P; i += 64) x[i] -= Hs[(size_t)i * pitch + j] * xj;
+      LD_WAVE_SYNC();
+    }
+    for (int i = lane; i < P; i += 64) x[i] /= Hs[(size_t)i * pitch + i];
+    LD_WAVE_SYNC();
+    for (int j = P - 1; j >= 0; --j) {        // L^T x = y
+      const double xj = x[j];
+      for (int i = lane; i < j; i += 64) x[i] -= Hs[(size_t)j * pitch + i] * xj;
+      LD_WAVE_SYNC();
+    }
+  }
+  __syncthreads();
+  return ok;
+}
+constexpr int LD_MAXP = 192;
+__global__ __launch_bounds__(LD_T) void k_g_ldlt(const BaDev* __restrict__ pbp, double* __restrict__ HsG, double* __restrict__ wsG,
+                                                 int useLds) {
+  extern __shared__ double sHs[];
+  __shared__ double sx[LD_MAXP];
+  __shared__ double cv[LD_MAXP];
+  __shared__ int sOk;
+  const BaDev pb = *pbp;
+  const int P = pb.P, tid = threadIdx.x;
+  if (useLds) {
+    const int pitch = P + 1;
+    for (int i = tid; i < P * P; i += LD_T) { const int r = i / P, c = i - r * P; sHs[r * pitch + c] = HsG[i]; }
+    for (int i = tid; i < P; i += LD_T) sx[i] = pb.x[i];
+    __syncthreads();
+    const bool ok = ldlt_block(sHs, pitch, P, tid, cv, sx, &sOk);
+    if (ok) for (int i = tid; i < P; i += LD_T) pb.x[i] = sx[i];
+    if (tid == 0) pb.scal[2] = ok ? 1.0 : 0.0;
+  } else {
+    const bool ok = ldlt_block(HsG, P, P, tid, wsG, pb.x, &sOk);   // large reduced systems stay in global memory
+    if (tid == 0) pb.scal[2] = ok ? 1.0 : 0.0;
+  }
+}
+__global__ __launch_bounds__(GB) void k_g_backsub_update(const BaDev* __restrict__ pbp, double lambda, double* __restrict__ part) {
+  __shared__ double red[4];
+  const BaDev pb = *pbp;
+  const int gid = blockIdx.x * GB + threadIdx.x;
+  const int P = pb.P;
+  const bool ok = pb.scal[2] != 0.0;
+  double sc = 0;
+  if (gid < pb.nMP) {
+    const int m = gid;
+    double xl[3] = {0, 0, 0};
+    if (ok) {
+      double cl[3] = {pb.b[P + 3 * m], pb.b[P + 3 * m + 1], pb.b[P + 3 * m + 2]};
+      for (int a = pb.mpStart[m]; a < pb.mpStart[m + 1]; ++a) {
+        const int e = pb.mpEdges[a];
+        const int i1 = pb.kfCol[pb.eKF[e]];
+        if (i1 < 0) continue;
+        const double* B = pb.Hpl + (size_t)e * 18;
+        for (int c = 0; c < 3; ++c)
+          for (int r = 0; r < 6; ++r) cl[c] -= B[r * 3 + c] * pb.x[6 * i1 + r];
+      }
+      const double* Di = pb.Dinv + (size_t)m * 9;
+      for (int r = 0; r < 3; ++r) xl[r] = Di[r * 3] * cl[0] + Di[r * 3 + 1] * cl[1] + Di[r * 3 + 2] * cl[2];
+    }
+    for (int r = 0; r < 3; ++r) {
+      pb.x[P + 3 * m + r] = xl[r];
+      pb.pt[3 * m + r] += xl[r];
+      sc += xl[r] * (lambda * xl[r] + pb.b[P + 3 * m + r]);
+    }
+  }
+  if (gid < pb.nKF) {
+    const int col = pb.kfCol[gid];
+    if (col >= 0) {
+      double u[6];
+      for (int r = 0; r < 6; ++r) { u[r] = ok ? pb.x[6 * col + r] : 0.0; sc += u[r] * (lambda * u[r] + pb.b[6 * col + r]); }
+      store_se3(pb.pose + 7 * gid, se3_mul(se3_exp(u), load_se3(pb.pose + 7 * gid)));
+    }
+  }
+  sc = block_sum_d<4>(sc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = sc;
+}
+__global__ __launch_bounds__(GB) void k_g_pop(const BaDev* __restrict__ pbp) {
+  const BaDev pb = *pbp;
+  const int gid = blockIdx.x * GB + threadIdx.x;
+  if (gid < pb.nKF * 7) pb.pose[gid] = pb.poseBk[gid];
+  if (gid < pb.nMP * 3) pb.pt[gid] = pb.ptBk[gid];
+}
+__global__ __launch_bounds__(GB) void k_g_finish(const BaDev* __restrict__ pbp, int its, int trials) {
+  const BaDev pb = *pbp;
+  const int gid = blockIdx.x * GB + threadIdx.x;
+  if (gid < pb.nE) {
+    const int e = gid;
+    const float* o = pb.eObs + 3 * e;
+    const bool st = !(o[2] < 0);
+    double xc[3], err[3];
+    se3_map(load_se3(pb.poseEval + 7 * pb.eKF[e]), pb.ptEval + 3 * pb.eMP[e], xc);
+    const double c = edge_error(pb.cam, st, xc, o, (double)pb.eInfo[e], err);
+    se3_map(load_se3(pb.pose + 7 * pb.eKF[e]), pb.pt + 3 * pb.eMP[e], xc);
+    pb.erase[e] = (c > (st ? 7.815 : 5.991) || !(xc[2] > 0.0)) ? 1 : 0;
+  }
+  if (gid < pb.nKF && pb.kfCol[gid] >= 0) for (int k = 0; k < 7; ++k) pb.poseIO[7 * gid + k] = (float)pb.pose[7 * gid + k];
+  if (gid < pb.nMP * 3) pb.ptIO[gid] = (float)pb.pt[gid];
+  if (gid == 0) { pb.stats[0] = its; pb.stats[1] = trials; }
+}
+
 __global__ void k_ba_reset(BaDev pb, const float* __restrict__ pose0, const float* __restrict__ pt0) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < pb.nKF) {
@@ -818,6 +1185,10 @@ struct morb_ba_problem {
   int* d_stop = nullptr;
   int useLds = 1;
   size_t ldsBytes = 0;
+  int mode = 0;            // 0 = grid (one launch per LM phase, host-side accept/reject), 1 = one persistent workgroup
+  int stopHost = 0;
+  int redBlocks = 0;
+  double* h_scal = nullptr;  // pinned host mirror of scal[0..3]
 };
 
 extern "C" {
@@ -924,6 +1295,14 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
     forPairs([&](int key, int ea, int eb) { pairEntries[fill[slot[key]]++] = make_int2(ea, eb); });
   }
   h.nPairs = (int)pairBlock.size();
+  std::vector<int> chunkKF, chunkStart, chunkEnd, kfChunkStart(nKF + 1, 0);
+  for (int kf = 0; kf < nKF; ++kf) {
+    kfChunkStart[kf] = (int)chunkKF.size();
+    if (kfCol[kf] >= 0)
+      for (int k = kfStart[kf]; k < kfStart[kf + 1]; k += 64) { chunkKF.push_back(kf); chunkStart.push_back(k); chunkEnd.push_back(std::min(k + 64, kfStart[kf + 1])); }
+  }
+  kfChunkStart[nKF] = (int)chunkKF.size();
+  h.nChunks = (int)chunkKF.size();
   bool fail = false;
   auto up = [&](const void* src, size_t bytes) -> void* {
     void* d = nullptr;
@@ -944,6 +1323,14 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
   h.pairBlock = (const int*)up(pairBlock.data(), sizeof(int) * std::max<size_t>(pairBlock.size(), 1));
   h.pairStart = (const int*)up(pairStart.data(), sizeof(int) * pairStart.size());
   h.pairEntries = (const int2*)up(pairEntries.data(), sizeof(int2) * pairEntries.size());
+  h.chunkKF = (const int*)up(chunkKF.data(), sizeof(int) * std::max<size_t>(chunkKF.size(), 1));
+  h.chunkStart = (const int*)up(chunkStart.data(), sizeof(int) * std::max<size_t>(chunkStart.size(), 1));
+  h.chunkEnd = (const int*)up(chunkEnd.data(), sizeof(int) * std::max<size_t>(chunkEnd.size(), 1));
+  h.kfChunkStart = (const int*)up(kfChunkStart.data(), sizeof(int) * (nKF + 1));
+  h.kfPart = (double*)up(nullptr, sizeof(double) * 27 * std::max<size_t>(chunkKF.size(), 1));
+  p->redBlocks = div_up(std::max(std::max(nE, nMP * 3), std::max(nKF * 7, 1)), GB);
+  h.redPart = (double*)up(nullptr, sizeof(double) * 2 * p->redBlocks);
+  h.scal = (double*)up(nullptr, sizeof(double) * 8);
   const size_t nx = (size_t)h.P + 3 * (size_t)nMP;
   h.pose = (double*)up(nullptr, sizeof(double) * 7 * nKF);
   h.poseBk = (double*)up(nullptr, sizeof(double) * 7 * nKF);
@@ -970,11 +1357,13 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
   p->d_pt0 = (float*)up(mpPos, sizeof(float) * 3 * nMP);
   p->d_desc = (BaDev*)up(&h, sizeof(BaDev));
   if (!fail && hipMemset(p->d_stop, 0, sizeof(int)) != hipSuccess) fail = true;
-  p->ldsBytes = sizeof(double) * (size_t)h.P * h.P;
-  p->useLds = p->ldsBytes <= 136 * 1024 ? 1 : 0;
+  if (!fail && hipHostMalloc(&p->h_scal, sizeof(double) * 8) != hipSuccess) fail = true;
+  p->ldsBytes = sizeof(double) * (size_t)h.P * (h.P + 1);
+  p->useLds = (p->ldsBytes <= 136 * 1024 && h.P <= 192) ? 1 : 0;
   if (!p->useLds) p->ldsBytes = 0;
   if (!fail && p->useLds &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_ba), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024) != hipSuccess)
+      (hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_ba), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024) != hipSuccess ||
+       hipFuncSetAttribute(reinterpret_cast<const void*>(k_g_ldlt), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024) != hipSuccess))
     fail = true;
   if (fail) {
     for (void* d : p->allocs) (void)hipFree(d);
@@ -991,13 +1380,21 @@ void morb_ba_problem_destroy(morb_ba_problem* p) {
   (void)hipSetDevice(p->opt->device);
   (void)hipStreamSynchronize(p->opt->stream);
   for (void* d : p->allocs) (void)hipFree(d);
+  if (p->h_scal) (void)hipHostFree(p->h_scal);
   delete p;
+}
+
+int morb_ba_set_mode(morb_ba_problem* p, int mode) {
+  MORB_REQUIRE(p && (mode == 0 || mode == 1), MORB_ERR_INVALID, "mode must be 0 (grid) or 1 (persistent workgroup)");
+  p->mode = mode;
+  return MORB_OK;
 }
 
 int morb_ba_set_stop(morb_ba_problem* p, int stop) {
   MORB_REQUIRE(p, MORB_ERR_INVALID, "NULL problem");
   MORB_HIP_CHECK(hipSetDevice(p->opt->device));
   MORB_HIP_CHECK(hipMemcpy(p->d_stop, &stop, sizeof(int), hipMemcpyHostToDevice));
+  p->stopHost = stop;
   return MORB_OK;
 }
 
@@ -1007,7 +1404,84 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
   hipStream_t st = stream ? (hipStream_t)stream : p->opt->stream;
   const int n = std::max(p->h.nKF, p->h.nMP * 3);
   hipLaunchKernelGGL(k_ba_reset, dim3(div_up(n, 256)), dim3(256), 0, st, p->h, p->d_pose0, p->d_pt0);
-  hipLaunchKernelGGL(k_local_ba, dim3(1), dim3(BA_T), p->ldsBytes, st, p->d_desc, p->useLds);
+  if (p->mode == 1) {
+    hipLaunchKernelGGL(k_local_ba, dim3(1), dim3(BA_T), p->ldsBytes, st, p->d_desc, p->useLds);
+    MORB_HIP_CHECK(hipGetLastError());
+    return MORB_OK;
+  }
+  // ---- grid mode: LM control flow on the host (optimization_algorithm_levenberg.cpp:61-169), phases on the chip ----
+  const BaDev& h = p->h;
+  const BaDev* d = p->d_desc;
+  const int rb = p->redBlocks;
+  double* part0 = h.redPart;
+  double* part1 = h.redPart + rb;
+  volatile double* hs = p->h_scal;
+  auto readScal = [&]() -> int {
+    MORB_HIP_CHECK(hipMemcpyAsync(p->h_scal, h.scal, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
+    MORB_HIP_CHECK(hipStreamSynchronize(st));
+    return MORB_OK;
+  };
+  auto chi2 = [&]() {
+    hipLaunchKernelGGL(k_g_chi2, dim3(rb), dim3(GB), 0, st, d, part0);
+    hipLaunchKernelGGL(k_g_reduce, dim3(1), dim3(GB), 0, st, (const double*)part0, rb, h.scal + 0);
+  };
+  int its = 0, trials = 0;
+  if (!p->stopHost) {
+    chi2();
+    int rc = readScal();
+    if (rc != MORB_OK) return rc;
+    double currentChi = hs[0], lambda = 0, ni = 2;
+    int nBad = 0;
+    for (int iter = 0; iter < 10 && !p->stopHost; ++iter) {
+      ++its;
+      const double iniChi = currentChi;
+      hipLaunchKernelGGL(k_g_build_mp, dim3(div_up(h.nMP, GB)), dim3(GB), 0, st, d);
+      hipLaunchKernelGGL(k_g_build_kf, dim3(div_up(std::max(h.nChunks, 1), 4)), dim3(GB), 0, st, d);
+      hipLaunchKernelGGL(k_g_kf_reduce, dim3(h.nKF), dim3(64), 0, st, d);
+      if (iter == 0) {
+        if (h.userLambda > 0) lambda = h.userLambda;
+        else {
+          hipLaunchKernelGGL(k_g_maxdiag, dim3(1), dim3(GB), 0, st, d);
+          rc = readScal();
+          if (rc != MORB_OK) return rc;
+          lambda = 1e-5 * hs[3];
+        }
+        ni = 2; nBad = 0;
+      }
+      double rho = 0;
+      int qmax = 0;
+      do {
+        hipLaunchKernelGGL(k_g_dinv_push, dim3(rb > div_up(h.P * h.P, GB) ? rb : div_up(h.P * h.P, GB)), dim3(GB), 0, st, d, lambda, h.HsG);
+        hipLaunchKernelGGL(k_g_schur, dim3(div_up(std::max(h.nPairs, 1), 4)), dim3(GB), 0, st, d, lambda, h.HsG);
+        hipLaunchKernelGGL(k_g_bschur, dim3(h.nKF), dim3(64), 0, st, d);
+        hipLaunchKernelGGL(k_g_ldlt, dim3(1), dim3(LD_T), p->ldsBytes, st, d, h.HsG, h.kfPart /* scratch >= P doubles when nChunks*27 >= P */, p->useLds);
+        hipLaunchKernelGGL(k_g_backsub_update, dim3(rb), dim3(GB), 0, st, d, lambda, part1);
+        hipLaunchKernelGGL(k_g_reduce, dim3(1), dim3(GB), 0, st, (const double*)part1, rb, h.scal + 1);
+        chi2();
+        rc = readScal();
+        if (rc != MORB_OK) return rc;
+        double tempChi = hs[0];
+        if (hs[2] == 0.0) tempChi = 1.7976931348623157e308;
+        rho = (currentChi - tempChi) / (hs[1] + 1e-3);
+        if (rho > 0 && std::isfinite(tempChi)) {
+          double alpha = 1. - std::pow((2 * rho - 1), 3);
+          alpha = std::min(alpha, 2. / 3.);
+          lambda *= std::max(1. / 3., alpha);
+          ni = 2;
+          currentChi = tempChi;
+        } else {
+          lambda *= ni;
+          ni *= 2;
+          hipLaunchKernelGGL(k_g_pop, dim3(rb), dim3(GB), 0, st, d);
+        }
+        ++qmax; ++trials;
+      } while (rho < 0 && qmax < 10 && !p->stopHost);
+      if (qmax == 10 || rho == 0) break;
+      if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+      if (nBad >= 3) break;
+    }
+  }
+  hipLaunchKernelGGL(k_g_finish, dim3(rb), dim3(GB), 0, st, d, its, trials);
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
 }

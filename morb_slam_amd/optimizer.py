@@ -37,9 +37,10 @@ class Optimizer:
                                                    ptr(out[1]), ptr(out[0]), ptr(out[2]), st))
         return out
 
-    def LocalBundleAdjustment(self, kfPose, kfFixed, mpPos, eKF, eMP, eObs, eInvSigma2, cam, inertial=False, stop=False):
+    def LocalBundleAdjustment(self, kfPose, kfFixed, mpPos, eKF, eMP, eObs, eInvSigma2, cam, inertial=False, stop=False, mode=0):
         """One-shot LocalBundleAdjustment on host numpy arrays; returns (kfPose, mpPos, eraseFlag, stats)."""
         p = BAProblem(self, kfPose, kfFixed, mpPos, eKF, eMP, eObs, eInvSigma2, cam, inertial)
+        p.set_mode(mode)
         if stop:
             p.set_stop(True)
         p.solve()
@@ -68,6 +69,10 @@ class BAProblem:
             self._h = None
 
     __del__ = close
+
+    def set_mode(self, mode):
+        """0 = grid (phase kernels over the whole GPU, default), 1 = one persistent workgroup."""
+        check(self._L.morb_ba_set_mode(self._h, int(mode)))
 
     def set_stop(self, on):
         check(self._L.morb_ba_set_stop(self._h, 1 if on else 0))

@@ -62,9 +62,9 @@ def test_local_ba_matches_oracle(kw):
     from morb_slam_amd import Optimizer
     b = make_ba_problem(**kw)
     opt = Optimizer()
-    for inertial in (False, True):
+    for inertial, mode in ((False, 0), (True, 0), (False, 1), (True, 1)):   # grid mode and persistent-workgroup mode
         kf, mp, erase, stats = opt.LocalBundleAdjustment(b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"],
-                                                         b["eInvSigma2"], b["cam"], inertial=inertial)
+                                                         b["eInvSigma2"], b["cam"], inertial=inertial, mode=mode)
         its, kfe, mpe, ee, se = O.local_ba(b, lambda100=inertial)
         assert abs(int(stats[0]) - int(se[0])) <= 1 and abs(int(stats[1]) - int(se[1])) <= 3, (stats, se)
         assert np.abs(kf - kfe).max() <= POSE_TOL
@@ -77,7 +77,8 @@ def test_local_ba_matches_oracle(kw):
 def test_local_ba_stop_flag():
     from morb_slam_amd import Optimizer
     b = make_ba_problem(seed=4, n_free=5, n_fixed=2, n_points=200)
-    kf, mp, erase, stats = Optimizer().LocalBundleAdjustment(b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"],
-                                                             b["eInvSigma2"], b["cam"], stop=True)
-    assert stats.tolist() == [0, 0]                       # *pbStopFlag set: graph is not optimised (:1355)
-    np.testing.assert_array_equal(kf, b["kfPose"])
+    for mode in (0, 1):
+        kf, mp, erase, stats = Optimizer().LocalBundleAdjustment(b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"],
+                                                                 b["eInvSigma2"], b["cam"], stop=True, mode=mode)
+        assert stats.tolist() == [0, 0]                       # *pbStopFlag set: graph is not optimised (:1355)
+        np.testing.assert_array_equal(kf, b["kfPose"])
