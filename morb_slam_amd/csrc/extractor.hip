@@ -274,11 +274,16 @@ __global__ __launch_bounds__(256) void k_fast(const LevelGeom* __restrict__ geom
   }
   // thread layout: 64 lanes along x, 4 waves along y (no integer division anywhere below)
   const uint8_t* base = pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)(EDGE + iniY) * g.pstride + EDGE + iniX;
-  for (int r = wv; r < th; r += 4)
-    for (int c = lane; c < tw; c += 64) {
-      tile[r * tilePitch + c] = base[(size_t)r * g.pstride + c];
-      sc[r * tilePitch + c] = 0;
-    }
+  // flat indices over the window / the evaluated area, split into (row, column) with a multiply-high by
+  // ceil(2^32 / width): every lane of every wave has work (a 64-lane row layout would idle ~40 % of the lanes
+  // on these 36..44-pixel-wide cells)
+  const unsigned twMagic = (unsigned)((0x100000000ull + (unsigned)tw - 1) / (unsigned)tw);
+  const unsigned ewMagic = (unsigned)((0x100000000ull + (unsigned)ew - 1) / (unsigned)ew);
+  for (int i = tid; i < th * tw; i += 256) {
+    const int r = (int)__umulhi((unsigned)i, twMagic), c = i - r * tw;
+    tile[r * tilePitch + c] = base[(size_t)r * g.pstride + c];
+    sc[r * tilePitch + c] = 0;
+  }
   for (int i = tid; i < th * 8; i += 256) { bmHi[i] = 0; bmLo[i] = 0; }
   if (tid == 0) qn = 0;
   __syncthreads();
@@ -288,26 +293,30 @@ __global__ __launch_bounds__(256) void k_fast(const LevelGeom* __restrict__ geom
   // >= 2 are brighter than v + tmin.  Pixels that fail keep strength 0: they are corners at neither threshold
   // and count as score 0 in their neighbours' NMS, exactly like cv::FAST's score buffer.
   const int tmin = imin(iniTh, minTh);
-  for (int y = 3 + wv; y < th - 3; y += 4)
-    for (int x0 = 3; x0 < tw - 3; x0 += 64) {
-      const int x = x0 + lane;
-      bool possible = false;
-      if (x < tw - 3) {
-        const uint8_t* p = tile + y * tilePitch + x;
-        const int v = p[0];
-        const int d0 = v - p[3 * tilePitch], d4 = v - p[3], d8 = v - p[-3 * tilePitch], d12 = v - p[-3];
-        const int nd = (d0 > tmin) + (d4 > tmin) + (d8 > tmin) + (d12 > tmin);
-        const int nb = (d0 < -tmin) + (d4 < -tmin) + (d8 < -tmin) + (d12 < -tmin);
-        possible = nd >= 2 || nb >= 2;
-      }
-      const uint64_t m = __ballot(possible);
-      if (m) {
-        int qbase = 0;
-        if (lane == 0) qbase = atomicAdd(&qn, __popcll(m));
-        qbase = __shfl(qbase, 0, 64);
-        if (possible) queue[qbase + __popcll(m & (lane == 0 ? 0ull : (~0ull >> (64 - lane))))] = (uint16_t)((y << 8) | x);
-      }
+  const int nEval = ew * eh;
+  const uint64_t ltmask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int i0 = 0; i0 < nEval; i0 += 256) {
+    const int i = i0 + tid;
+    bool possible = false;
+    int x = 0, y = 0;
+    if (i < nEval) {
+      const int ry = (int)__umulhi((unsigned)i, ewMagic);
+      y = ry + 3; x = i - ry * ew + 3;
+      const uint8_t* p = tile + y * tilePitch + x;
+      const int v = p[0];
+      const int d0 = v - p[3 * tilePitch], d4 = v - p[3], d8 = v - p[-3 * tilePitch], d12 = v - p[-3];
+      const int nd = (d0 > tmin) + (d4 > tmin) + (d8 > tmin) + (d12 > tmin);
+      const int nb = (d0 < -tmin) + (d4 < -tmin) + (d8 < -tmin) + (d12 < -tmin);
+      possible = nd >= 2 || nb >= 2;
     }
+    const uint64_t m = __ballot(possible);
+    if (m) {
+      int qbase = 0;
+      if (lane == 0) qbase = atomicAdd(&qn, __popcll(m));
+      qbase = __shfl(qbase, 0, 64);
+      if (possible) queue[qbase + __popcll(m & ltmask)] = (uint16_t)((y << 8) | x);
+    }
+  }
   __syncthreads();
   // Phase 2 — exact strength for the survivors only, densely packed over the workgroup
   const int nq = qn;
