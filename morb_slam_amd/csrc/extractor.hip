@@ -581,19 +581,26 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
   const uint32_t key = sel[(size_t)img * selPerImg + g.selBase + (gi - b)];
   const int cx = morbqt::key_x(key) + MINB, cy = morbqt::key_y(key) + MINB;
 
-  // IC_Angle on the un-blurred level: lanes 0..30 take rows v = -15..15
+  // IC_Angle on the un-blurred level: lanes take the columns u = -d..d of each of the 31 rows; the row loop is
+  // fully unrolled so the 31 byte loads of a lane are all in flight together (no dependent-latency chain)
   int m10 = 0, m01 = 0;
-  if (lane < 2 * HALF_PATCH + 1) {
-    const int v = lane - HALF_PATCH;
-    const int d = c_umax[v < 0 ? -v : v];
-    const uint8_t* row = pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)(EDGE + cy + v) * g.pstride + EDGE + cx;
-    int rs = 0;
-    for (int u = -d; u <= d; ++u) {
-      const int val = row[u];
-      m10 += u * val;
-      rs += val;
+  {
+    constexpr int kUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // == c_umax (checked on the host)
+    const uint8_t* ctr = pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)(EDGE + cy) * g.pstride + EDGE + cx;
+    int vals[31];
+#pragma unroll
+    for (int v = -HALF_PATCH; v <= HALF_PATCH; ++v) {
+      const int d = kUmax[v < 0 ? -v : v];
+      const int u = lane - d;
+      vals[v + HALF_PATCH] = (lane <= 2 * d) ? (int)ctr[(ptrdiff_t)v * g.pstride + u] : 0;
     }
-    m01 = v * rs;
+#pragma unroll
+    for (int v = -HALF_PATCH; v <= HALF_PATCH; ++v) {
+      const int d = kUmax[v < 0 ? -v : v];
+      const int u = lane - d;
+      m10 += u * vals[v + HALF_PATCH];
+      m01 += v * vals[v + HALF_PATCH];
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -818,6 +825,11 @@ int morb_extractor_create(morb_extractor** out, int nfeatures, float scaleFactor
       e->umax[v] = v0;
       ++v0;
     }
+  }
+  {
+    static const int kStd[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    for (int i = 0; i < 16; ++i)
+      if (e->umax[i] != kStd[i]) { set_error("umax table mismatch"); delete e; return MORB_ERR_UNSUPPORTED; }
   }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
     set_error("cannot create a stream on device %d", device);

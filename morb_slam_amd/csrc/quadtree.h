@@ -318,15 +318,34 @@ QT_HD void qt_split(Work& w, State& s, int id, int* nToExpand) {
 // Move the live entries to the top of the list array (order preserved) and refresh Node::lit.
 QT_HD void qt_compact(Work& w, State& s) {
   QT_SYNC();
+#if QT_DEVICE
+  // 64 list slots per step, from the top down: a live entry moves up by the number of tombstones above it
+  const int lane = QT_LANE;
+  int wp = w.listCap;
+  for (int top = w.listCap; top > s.head; top -= 64) {
+    const int idx = top - 64 + lane;                    // lane 63 = highest slot of the chunk
+    uint16_t id = 0xFFFF;
+    if (idx >= s.head) id = w.list[idx];
+    const uint64_t m = __ballot(id != 0xFFFF);
+    const int above = __popcll(lane == 63 ? 0ull : (m >> (lane + 1)));
+    QT_SYNC();                                           // every lane has read before any lane writes
+    if (id != 0xFFFF) { const int np = wp - 1 - above; w.list[np] = id; w.nodes[id].lit = (uint16_t)np; }
+    wp -= __popcll(m);
+    QT_SYNC();
+  }
+  s.head = wp;
+#else
   int wp = w.listCap;
   for (int rp = w.listCap - 1; rp >= s.head; --rp) {
     const uint16_t id = w.list[rp];
     if (id != 0xFFFF) {
       --wp;
-      if (QT_LANE0) { w.list[wp] = id; w.nodes[id].lit = (uint16_t)wp; }
+      w.list[wp] = id;
+      w.nodes[id].lit = (uint16_t)wp;
     }
   }
   s.head = wp;
+#endif
   QT_SYNC();
 }
 
@@ -387,12 +406,32 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
     int nToExpand = 0;
     s.nA = 0;
     const int oldHead = s.head;
+#if QT_DEVICE
+    // children are pushed in front of oldHead: not visited.  64 slots are fetched at once; only the nodes that
+    // need a split are visited (in list order) through the ballot mask.
+    for (int pos0 = oldHead; pos0 < w.listCap; pos0 += 64) {
+      const int pos = pos0 + QT_LANE;
+      int id = 0xFFFF;
+      bool todo = false;
+      if (pos < w.listCap) {
+        id = w.list[pos];
+        if (id != 0xFFFF) todo = !w.nodes[id].noMore;
+      }
+      uint64_t m = __ballot(todo);
+      while (m) {
+        const int b = __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        qt_split(w, s, __shfl(id, b, 64), &nToExpand);
+      }
+    }
+#else
     for (int pos = oldHead; pos < w.listCap; ++pos) {  // children are pushed in front of oldHead: not visited
       const uint16_t id = w.list[pos];
       if (id == 0xFFFF) continue;
       if (w.nodes[id].noMore) continue;
       qt_split(w, s, id, &nToExpand);
     }
+#endif
     if (s.size >= N || s.size == prevSize) {
       bFinish = true;
     } else if (s.size + nToExpand * 3 > N) {
@@ -421,14 +460,43 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
   // retain the best point in each node, list order (:716-737)
   QT_SYNC();
   int nOut = 0;
+#if QT_DEVICE
+  // one node per lane (most nodes hold a handful of keys); nodes with many keys are finished by the whole wave
+  for (int pos0 = s.head; pos0 < w.listCap; pos0 += 64) {
+    const int pos = pos0 + QT_LANE;
+    int id = 0xFFFF;
+    if (pos < w.listCap) id = w.list[pos];
+    const bool live = id != 0xFFFF;
+    const uint64_t m = __ballot(live);
+    const int rank = nOut + __popcll(m & (QT_LANE == 0 ? 0ull : (~0ull >> (64 - QT_LANE))));
+    uint32_t begin = 0, count = 0;
+    if (live) { begin = w.nodes[id].begin; count = w.nodes[id].count; }
+    const bool big = live && count > 32;
+    if (live && !big) {
+      uint32_t bk = w.keys[begin];
+      for (uint32_t k = 1; k < count; ++k) { const uint32_t kk = w.keys[begin + k]; if (key_r(kk) > key_r(bk)) bk = kk; }
+      if (rank < outCap) out[rank] = bk;
+    }
+    uint64_t mb = __ballot(big);
+    while (mb) {
+      const int b = __ffsll((unsigned long long)mb) - 1;
+      mb &= mb - 1;
+      const uint32_t bk = qt_best_key(w.keys, __shfl(begin, b, 64), __shfl(count, b, 64));
+      const int r = __shfl(rank, b, 64);
+      if (QT_LANE0 && r < outCap) out[r] = bk;
+    }
+    nOut += __popcll(m);
+  }
+#else
   for (int pos = s.head; pos < w.listCap; ++pos) {
     const uint16_t id = w.list[pos];
     if (id == 0xFFFF) continue;
     const Node nd = w.nodes[id];
     const uint32_t bk = qt_best_key(w.keys, nd.begin, nd.count);
-    if (nOut < outCap && QT_LANE0) out[nOut] = bk;
+    if (nOut < outCap) out[nOut] = bk;
     ++nOut;
   }
+#endif
   QT_SYNC();
   return nOut;
 }
