@@ -289,6 +289,74 @@ QT_HD void qt_push_child(Work& w, State& s, int x0, int y0, int x1, int y1, uint
 }
 
 // DivideNode + the four push_front blocks + erase of the parent (ORBextractor.cc:609-650 / :671-708).
+#if QT_DEVICE
+// Device form: few dependent LDS round trips per split.  The four free ids are fetched while the keys are being
+// partitioned, nodes of <= 64 keys are partitioned in registers in one pass (one load, four ballots, one store),
+// and lanes 0..3 write the four children (node record, list slot, vA entry) in one step.
+QT_HD void qt_split(Work& w, State& s, int id, int* nToExpand) {
+  QT_SYNC();
+  const int lane = QT_LANE;
+  const Node nd = w.nodes[id];
+  int freeReg = 0;
+  if (lane < 4 && s.nFree - 1 - lane >= 0) freeReg = w.freeIds[s.nFree - 1 - lane];
+  const int halfX = (nd.x1 - nd.x0 + 1) >> 1;  // ceil((UR.x-UL.x)/2.f) for non-negative ints
+  const int halfY = (nd.y1 - nd.y0 + 1) >> 1;
+  const int mx = nd.x0 + halfX, my = nd.y0 + halfY;
+  uint32_t cnt[4];
+  if (nd.count <= 64) {
+    int g = -1;
+    uint32_t k = 0;
+    if ((uint32_t)lane < nd.count) { k = w.keys[nd.begin + lane]; g = (key_x(k) < mx ? 0 : 1) + (key_y(k) < my ? 0 : 2); }
+    const uint64_t m0 = __ballot(g == 0), m1 = __ballot(g == 1), m2 = __ballot(g == 2), m3 = __ballot(g == 3);
+    cnt[0] = __popcll(m0); cnt[1] = __popcll(m1); cnt[2] = __popcll(m2); cnt[3] = __popcll(m3);
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t dst = 0;
+    if (g == 0) dst = __popcll(m0 & lt);
+    if (g == 1) dst = cnt[0] + __popcll(m1 & lt);
+    if (g == 2) dst = cnt[0] + cnt[1] + __popcll(m2 & lt);
+    if (g == 3) dst = cnt[0] + cnt[1] + cnt[2] + __popcll(m3 & lt);
+    if (g >= 0) w.keys[nd.begin + dst] = k;   // every lane's key is already in a register
+  } else {
+    qt_partition(w.keys, w.tmp, nd.begin, nd.count,
+                 [mx, my](uint32_t k) -> int { return (key_x(k) < mx ? 0 : 1) + (key_y(k) < my ? 0 : 2); }, cnt);
+  }
+  // group order 0:n1 (x<mx,y<my) 1:n2 (x>=mx,y<my) 2:n3 (x<mx,y>=my) 3:n4; children with keys are pushed to the front
+  // in that order; those with more than one key also enter vSizeAndPointerToNode
+  const int has0 = cnt[0] > 0, has1 = cnt[1] > 0, has2 = cnt[2] > 0, has3 = cnt[3] > 0;
+  const int ex0 = cnt[0] > 1, ex1 = cnt[1] > 1, ex2 = cnt[2] > 1, ex3 = cnt[3] > 1;
+  const int nCh = has0 + has1 + has2 + has3, nEx = ex0 + ex1 + ex2 + ex3;
+  if (lane < 4) {
+    const int c = lane;
+    const uint32_t myCnt = c == 0 ? cnt[0] : c == 1 ? cnt[1] : c == 2 ? cnt[2] : cnt[3];
+    const int r = c == 0 ? 0 : c == 1 ? has0 : c == 2 ? has0 + has1 : has0 + has1 + has2;          // push rank
+    const int re = c == 0 ? 0 : c == 1 ? ex0 : c == 2 ? ex0 + ex1 : ex0 + ex1 + ex2;               // rank in vA
+    const uint32_t b = nd.begin + (c == 0 ? 0u : c == 1 ? cnt[0] : c == 2 ? cnt[0] + cnt[1] : cnt[0] + cnt[1] + cnt[2]);
+    const int cid = __shfl(freeReg, r, 64);
+    if (myCnt > 0) {
+      Node ch;
+      ch.x0 = (int16_t)((c & 1) ? mx : nd.x0); ch.x1 = (int16_t)((c & 1) ? nd.x1 : mx);
+      ch.y0 = (int16_t)((c & 2) ? my : nd.y0); ch.y1 = (int16_t)((c & 2) ? nd.y1 : my);
+      ch.begin = b; ch.count = myCnt; ch.lit = (uint16_t)(s.head - 1 - r); ch.noMore = (myCnt == 1) ? 1 : 0;
+      w.nodes[cid] = ch;
+      w.list[s.head - 1 - r] = (uint16_t)cid;
+      if (myCnt > 1) w.vA[s.nA + re] = ((uint64_t)myCnt << 32) | ((uint64_t)(uint16_t)ch.x0 << 16) | (uint64_t)cid;
+    }
+  } else {
+    (void)__shfl(freeReg, 0, 64);   // keep the shuffle convergent
+  }
+  s.head -= nCh;
+  s.size += nCh - 1;
+  s.nA += nEx;
+  if (nToExpand) *nToExpand += nEx;
+  s.nFree -= nCh;
+  if (QT_LANE0) {
+    w.list[nd.lit] = 0xFFFF;
+    w.freeIds[s.nFree] = (uint16_t)id;   // the parent's id is released last
+  }
+  ++s.nFree;
+  QT_SYNC();
+}
+#else
 QT_HD void qt_split(Work& w, State& s, int id, int* nToExpand) {
   QT_SYNC();
   const Node nd = w.nodes[id];
@@ -314,6 +382,7 @@ QT_HD void qt_split(Work& w, State& s, int id, int* nToExpand) {
   --s.size;
   QT_SYNC();
 }
+#endif
 
 // Move the live entries to the top of the list array (order preserved) and refresh Node::lit.
 QT_HD void qt_compact(Work& w, State& s) {
