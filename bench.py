@@ -230,6 +230,18 @@ def main():
         # dominant streaming kernel of the extractor; "fast" is ONE kernel (k_fast), so its stage time is the
         # kernel's launch duration measured with HIP events on the launch stream
         ach = ab[dom] * nimg / (stages[dom] * 1e-3) / 1e9
+        # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+        # runs of this same command at B = 64; profiles/r01/pmc_traffic_b64.json) — not measurable live
+        traffic = None
+        try:
+            if B == 64:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_b64.json")))
+                names = {"pyramid": ["k_level0", "k_resize"], "blur": ["k_blur"], "fast": ["k_fast"]}[dom]
+                mult = {"k_resize": 7}
+                traffic = sum((pm[k]["FETCH_SIZE_KB_per_launch"] + pm[k]["WRITE_SIZE_KB_per_launch"]) * 1024 * mult.get(k, 1)
+                              for k in names)
+        except Exception:
+            traffic = None
         line = {
             "metric": "stereo frames/sec ORB extract+match (752x480, 1200 feat)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -244,7 +256,7 @@ def main():
                        "mean_bow_matches_per_frame": n_bow},
             "roofline": {"bound": "hbm", "kernel": {"pyramid": "k_level0+k_resize", "blur": "k_blur", "fast": "k_fast"}[dom],
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": traffic,
                          "algorithmic_bytes_per_launch": ab[dom] * nimg, "avg_launch_ms": stages[dom]},
             "extract_stage_ms_per_step": stages,
         }
