@@ -138,6 +138,15 @@ void fast9_16(const Img& img, std::vector<KeyPoint>& kps, int threshold, bool nm
       const uint8_t* p = img.ptr(y) + x;
       // definition used by the detector: >= 9 contiguous ring pixels all < v - t or all > v + t
       const int v = p[0];
+      {  // cv::FAST's high-speed test (same result, keeps the CPU baseline honest): any 9-arc contains ring pixel
+         // 0 or 8, so both must not be "similar"
+        const int q0 = p[kFastOfs[0][0] + kFastOfs[0][1] * img.step], q8 = p[kFastOfs[8][0] + kFastOfs[8][1] * img.step];
+        const bool d = (q0 < v - threshold) || (q8 < v - threshold), b = (q0 > v + threshold) || (q8 > v + threshold);
+        if (!d && !b) continue;
+        const int q4 = p[kFastOfs[4][0] + kFastOfs[4][1] * img.step], q12 = p[kFastOfs[12][0] + kFastOfs[12][1] * img.step];
+        const bool d2 = d && ((q4 < v - threshold) || (q12 < v - threshold)), b2 = b && ((q4 > v + threshold) || (q12 > v + threshold));
+        if (!d2 && !b2) continue;
+      }
       int runD = 0, runB = 0;
       bool is = false;
       for (int k = 0; k < 25 && !is; ++k) {
