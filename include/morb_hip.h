@@ -198,6 +198,27 @@ int morb_search_by_projection_last_batch(morb_matcher*, const morb_frame_params*
                                          const uint8_t* d_bForward, const uint8_t* d_bBackward, int checkOri, int* d_matchCur,
                                          int* d_nmatches, void* stream);
 
+/* int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist)
+ * ORBmatcher.h:60-62, ORBmatcher.cc:1735-1842 (relocalisation refinement).  Pair f = (current image d_curImg[f],
+ * keyframe image d_kfImg[f]); d_Tcw [f][7], d_Ow [f][3] = Tcw.inverse().translation(); per keyframe feature
+ * [nframes][cap]: kfValid (map point present, not bad, not in sAlreadyFound), world position, mfMaxDistance,
+ * mfMinDistance, representative descriptor.  d_curHasMP [nframes][cap] != 0 <=> CurrentFrame.mvpMapPoints[i].
+ * d_matchCur in/out as in the last-frame variant. */
+int morb_search_by_projection_kf_batch(morb_matcher*, const morb_frame_params*, int nframes, const int* d_curImg,
+                                       const int* d_kfImg, int cap, const int* d_count, const morb_keypoint* d_kps,
+                                       const uint8_t* d_desc, const uint8_t* d_curHasMP, const float* d_Tcw, const float* d_Ow,
+                                       const uint8_t* d_kfValid, const float* d_Xw, const float* d_maxDist,
+                                       const float* d_minDist, const uint8_t* d_mpDesc, float th, int ORBdist, int checkOri,
+                                       int* d_matchCur, int* d_nmatches, void* stream);
+
+/* int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, vbPrevMatched, vnMatches12, windowSize)
+ * ORBmatcher.h:80-82, ORBmatcher.cc:603-700 (monocular initialisation).  Pair p = (image d_img1[p], image d_img2[p]);
+ * d_prevMatched [npairs][cap][2] in/out (vbPrevMatched); d_matches12 [npairs][cap] = vnMatches12. */
+int morb_search_for_initialization_batch(morb_matcher*, const morb_frame_params*, int npairs, const int* d_img1,
+                                         const int* d_img2, int cap, const int* d_count, const morb_keypoint* d_kps,
+                                         const uint8_t* d_desc, float* d_prevMatched, int windowSize, float nnratio,
+                                         int checkOri, int* d_matches12, int* d_nmatches, void* stream);
+
 /* int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, vMatchedPairs, bOnlyStereo, bCoarse)
  * ORBmatcher.h:84-87, ORBmatcher.cc:821-1042 (pinhole keyframes, no second camera) for npairs keyframe pairs of
  * a pool of nimg images (arrays [nimg][cap]; d_uRight may be NULL).  R12, t12 (HOST, [npairs][9], [npairs][3]) =

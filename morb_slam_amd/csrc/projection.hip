@@ -251,8 +251,12 @@ __global__ __launch_bounds__(256) void k_candidates(morb_frame_params P, int qCa
   if (lane == 0) candCnt[qo] = n;
 }
 
-// phase B: replay the queries in reference order, one wave per frame
-template <bool TOP2>
+// phase B: replay the queries in reference order, one wave per frame.
+// MODE 0: best only, accept dist <= thAccept (SearchByProjection with the last frame :1617 / with a keyframe :1805)
+// MODE 1: best + second best with the level rule and the ratio test (SearchByProjection with map points :118-137)
+// MODE 2: SearchForInitialization (:603-700): candidates already matched with a smaller-or-equal distance are
+//         skipped, a better match steals the feature from its previous owner
+template <int MODE>
 __global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, const int* __restrict__ nQv,
                                                 const Query* __restrict__ qs, const uint8_t* __restrict__ qDesc,
                                                 const uint8_t* __restrict__ qHasObs, const int* __restrict__ fImg, int cap,
@@ -260,20 +264,28 @@ __global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, c
                                                 const uint8_t* __restrict__ desc, const float* __restrict__ uRight,
                                                 const uint8_t* __restrict__ blockedIn,
                                                 const unsigned long long* __restrict__ cand, const int* __restrict__ candCnt,
-                                                float nnratio, int checkOri, int* __restrict__ match,
-                                                int* __restrict__ nmatches, int* __restrict__ entryJ, int* __restrict__ entryBin) {
-  extern __shared__ uint8_t blocked[];
+                                                float nnratio, int thAccept, int checkOri, int* __restrict__ match,
+                                                int* __restrict__ nmatches, int* __restrict__ entryJ, int* __restrict__ entryBin,
+                                                float* __restrict__ prevMatched) {
+  extern __shared__ __align__(8) uint8_t smemRaw[];
+  uint8_t* blocked = smemRaw;                                   // MODE 0/1: [cap]
+  int* matchedDist = reinterpret_cast<int*>(smemRaw);           // MODE 2:   [cap]
+  int* match21 = reinterpret_cast<int*>(smemRaw) + cap;         // MODE 2:   [cap]
   __shared__ int hist[HISTO_LENGTH];
   const int f = blockIdx.x, lane = threadIdx.x;
   const int img = fImg[f];
   const int N = count[img];
   const int nQ = nQv ? nQv[f] : count[fImg[f]];
-  for (int j = lane; j < N; j += 64) blocked[j] = blockedIn ? blockedIn[(size_t)f * cap + j] : 0;
+  if (MODE == 2) {
+    for (int j = lane; j < N; j += 64) { matchedDist[j] = 0x7fffffff; match21[j] = -1; }
+  } else {
+    for (int j = lane; j < N; j += 64) blocked[j] = blockedIn ? blockedIn[(size_t)f * cap + j] : 0;
+  }
   if (lane < HISTO_LENGTH) hist[lane] = 0;
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   __builtin_amdgcn_wave_barrier();
   const float* ur = uRight ? uRight + (size_t)f * cap : nullptr;
-  int* mF = match + (size_t)f * cap;
+  int* mF = match + (size_t)f * (MODE == 2 ? qCap : cap);
   int nm = 0, nEntries = 0;
   const float factor = 1.0f / HISTO_LENGTH;
   for (int qi = 0; qi < nQ && qi < qCap; ++qi) {
@@ -284,7 +296,9 @@ __global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, c
     if (cnt <= CAND_CAP) {
       for (int c = lane; c < cnt; c += 64) {
         const unsigned long long k = cand[qo * CAND_CAP + c];
-        if (!blocked[(k >> 4) & 0xFFFF]) top2_insert(k1, k2, k);
+        const int j = (int)((k >> 4) & 0xFFFF);
+        const bool skip = MODE == 2 ? (matchedDist[j] <= (int)(k >> 32)) : (blocked[j] != 0);
+        if (!skip) top2_insert(k1, k2, k);
       }
     } else {  // dense window: derive the keys again from the features
       const Query q = qs[qo];
@@ -292,42 +306,57 @@ __global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, c
       cell_range(P, q, cx0, cx1, cy0, cy1);
       const Desc qd = load_desc(qDesc + qo * 32);
       for (int j = lane; j < N; j += 64) {
-        if (blocked[j]) continue;
+        if (MODE != 2 && blocked[j]) continue;
         const unsigned long long k = make_key(P, q, qd, kps[(size_t)img * cap + j], j, desc + ((size_t)img * cap + j) * 32, ur, cx0, cx1, cy0, cy1);
-        if (k != ~0ull) top2_insert(k1, k2, k);
+        if (k == ~0ull) continue;
+        if (MODE == 2 && matchedDist[j] <= (int)(k >> 32)) continue;
+        top2_insert(k1, k2, k);
       }
     }
     wave_top2(k1, k2);
     if (k1 == ~0ull) continue;
     const int bestDist = (int)(k1 >> 32), bestIdx = (int)((k1 >> 4) & 0xFFFF);
     bool accept;
-    if (TOP2) {  // ORBmatcher.cc:118-137
+    if (MODE == 1) {  // ORBmatcher.cc:118-137
       const int bestLevel = (int)(k1 & 15);
       const int bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 32), bestLevel2 = k2 == ~0ull ? -1 : (int)(k2 & 15);
       accept = bestDist <= TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2);
+    } else if (MODE == 2) {  // :646-647
+      const int bestDist2 = k2 == ~0ull ? 0x7fffffff : (int)(k2 >> 32);
+      accept = bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * nnratio;
     } else {
-      accept = bestDist <= TH_HIGH;  // :1617
+      accept = bestDist <= thAccept;
     }
     if (accept) {
+      int stolen = 0;
+      if (MODE == 2) stolen = match21[bestIdx] >= 0 ? 1 : 0;
       if (lane == 0) {
-        mF[bestIdx] = qi;
-        blocked[bestIdx] = qHasObs ? qHasObs[qo] : 1;
-        if (!TOP2 && checkOri) {
+        if (MODE == 2) {
+          if (match21[bestIdx] >= 0) mF[match21[bestIdx]] = -1;
+          mF[qi] = bestIdx;
+          match21[bestIdx] = qi;
+          matchedDist[bestIdx] = bestDist;
+        } else {
+          mF[bestIdx] = qi;
+          blocked[bestIdx] = qHasObs ? qHasObs[qo] : 1;
+        }
+        if (MODE != 1 && checkOri) {
           float rot = qs[qo].angle - kps[(size_t)img * cap + bestIdx].angle;
           if (rot < 0.0f) rot += 360.0f;
           int bin = (int)roundf(rot * factor);
           if (bin == HISTO_LENGTH) bin = 0;
-          entryJ[(size_t)f * qCap + nEntries] = bestIdx;
+          entryJ[(size_t)f * qCap + nEntries] = MODE == 2 ? qi : bestIdx;
           entryBin[(size_t)f * qCap + nEntries] = bin;
           hist[bin] += 1;
         }
       }
-      ++nm; ++nEntries;
+      nm += 1 - stolen;
+      ++nEntries;
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __builtin_amdgcn_wave_barrier();
     }
   }
-  if (!TOP2 && checkOri) {  // ComputeThreeMaxima + un-assign (:1708-1730)
+  if (MODE != 1 && checkOri) {  // ComputeThreeMaxima + un-assign
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
     int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
@@ -340,17 +369,99 @@ __global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, c
     if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
     else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
     int removed = 0;
-    for (int e = lane; e < nEntries; e += 64) {
-      const int b = entryBin[(size_t)f * qCap + e];
-      if (b != ind1 && b != ind2 && b != ind3) { mF[entryJ[(size_t)f * qCap + e]] = -1; ++removed; }
+    if (MODE == 2) {
+      // entries of one query are unique, but a stolen match may already be -1: decrement only live ones (:683-686)
+      for (int e = lane; e < nEntries; e += 64) {
+        const int b = entryBin[(size_t)f * qCap + e];
+        const int i1 = entryJ[(size_t)f * qCap + e];
+        if (b != ind1 && b != ind2 && b != ind3 && mF[i1] >= 0) { mF[i1] = -1; ++removed; }
+      }
+    } else {
+      for (int e = lane; e < nEntries; e += 64) {
+        const int b = entryBin[(size_t)f * qCap + e];
+        if (b != ind1 && b != ind2 && b != ind3) { mF[entryJ[(size_t)f * qCap + e]] = -1; ++removed; }
+      }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) removed += __shfl_xor(removed, off, 64);
     nm -= removed;
   }
+  if (MODE == 2 && prevMatched) {  // :692-695
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int i1 = lane; i1 < nQ && i1 < qCap; i1 += 64) {
+      const int j = mF[i1];
+      if (j >= 0) {
+        const morb_keypoint kp = kps[(size_t)img * cap + j];
+        prevMatched[((size_t)f * qCap + i1) * 2] = kp.x;
+        prevMatched[((size_t)f * qCap + i1) * 2 + 1] = kp.y;
+      }
+    }
+  }
   if (lane == 0) nmatches[f] = nm;
 }
 
+// query preparation for SearchByProjection(CurrentFrame, KeyFrame*, ...) (:1735-1790) and SearchForInitialization
+__global__ __launch_bounds__(256) void k_prep_kf(morb_frame_params P, int cap, const int* __restrict__ count,
+                                                 const int* __restrict__ kfImg, const morb_keypoint* __restrict__ kps,
+                                                 const uint8_t* __restrict__ kfValid, const float* __restrict__ Xw,
+                                                 const float* __restrict__ maxDist, const float* __restrict__ minDist,
+                                                 const float* __restrict__ Tcw, const float* __restrict__ Ow, float th,
+                                                 const float* __restrict__ ratioThr, Query* __restrict__ qs) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cap) return;
+  const size_t o = (size_t)f * cap + i;
+  Query q;
+  memset(&q, 0, sizeof q);
+  const int img = kfImg[f];
+  if (i < count[img] && kfValid[o]) {
+    const float* T = Tcw + 7 * f;
+    const float* X = Xw + o * 3;
+    float x3Dc[3];
+    q_rotate_f(T, X, x3Dc);
+    x3Dc[0] += T[4]; x3Dc[1] += T[5]; x3Dc[2] += T[6];
+    const float u = P.fx * x3Dc[0] / x3Dc[2] + P.cx, v = P.fy * x3Dc[1] / x3Dc[2] + P.cy;
+    const float PO[3] = {X[0] - Ow[3 * f], X[1] - Ow[3 * f + 1], X[2] - Ow[3 * f + 2]};
+    const float dist3D = sqrtf(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+    const float maxDistance = 1.2f * maxDist[o], minDistance = 0.8f * minDist[o];
+    if (!(u < P.minX || u > P.maxX) && !(v < P.minY || v > P.maxY) && !(dist3D < minDistance || dist3D > maxDistance)) {
+      const float ratio = maxDist[o] / dist3D;
+      int n = 0;
+      while (n < P.nlevels - 1 && ratio > ratioThr[n]) ++n;
+      q.valid = 1; q.x = u; q.y = v; q.r = th * P.scaleFactors[n];
+      q.minLevel = n - 1; q.maxLevel = n + 1; q.angle = kps[(size_t)img * cap + i].angle;
+    }
+  }
+  qs[o] = q;
+}
+__global__ __launch_bounds__(256) void k_prep_init(int cap, const int* __restrict__ count, const int* __restrict__ img1v,
+                                                   const morb_keypoint* __restrict__ kps, const float* __restrict__ prevMatched,
+                                                   int windowSize, Query* __restrict__ qs) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cap) return;
+  const size_t o = (size_t)f * cap + i;
+  Query q;
+  memset(&q, 0, sizeof q);
+  const int img = img1v[f];
+  if (i < count[img]) {
+    const morb_keypoint kp = kps[(size_t)img * cap + i];
+    if (!(kp.octave > 0)) {
+      q.valid = 1; q.x = prevMatched[o * 2]; q.y = prevMatched[o * 2 + 1]; q.r = (float)windowSize;
+      q.minLevel = kp.octave; q.maxLevel = kp.octave; q.angle = kp.angle;
+    }
+  }
+  qs[o] = q;
+}
+
+__global__ void k_gather_desc(const uint8_t* __restrict__ desc, const int* __restrict__ img, int cap, uint8_t* __restrict__ out) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;   // one uint4 (16 B) per thread
+  if (i >= cap * 2) return;
+  reinterpret_cast<uint4*>(out)[(size_t)f * cap * 2 + i] = reinterpret_cast<const uint4*>(desc)[(size_t)img[f] * cap * 2 + i];
+}
+__global__ void k_fill_m1(int* p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = -1;
+}
 __global__ void k_gather_counts(const int* __restrict__ count, const int* __restrict__ img, int n, int* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = count[img[i]];
@@ -480,11 +591,11 @@ int morb_is_in_frustum_batch(morb_matcher* m, const morb_frame_params* P, int nf
   return MORB_OK;
 }
 
-static int window_search(morb_matcher* m, const morb_frame_params* P, bool top2, int nframes, int qCap, const int* d_nQ,
+static int window_search(morb_matcher* m, const morb_frame_params* P, int mode, int nframes, int qCap, const int* d_nQ,
                          const Query* d_qs, const uint8_t* d_qDesc, const uint8_t* d_qHasObs, const int* d_fImg, int cap,
                          const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc, const float* d_uRight,
-                         const uint8_t* d_blocked, float nnratio, int checkOri, int* d_match, int* d_nmatches,
-                         hipStream_t st) {
+                         const uint8_t* d_blocked, float nnratio, int thAccept, int checkOri, int* d_match, int* d_nmatches,
+                         float* d_prevMatched, hipStream_t st) {
   void *cand = nullptr, *cnt = nullptr, *ej = nullptr, *eb = nullptr;
   int rc = morb_matcher_workspace(m, 0, sizeof(unsigned long long) * (size_t)nframes * qCap * CAND_CAP, &cand);
   if (rc == MORB_OK) rc = morb_matcher_workspace(m, 1, sizeof(int) * (size_t)nframes * qCap, &cnt);
@@ -493,15 +604,16 @@ static int window_search(morb_matcher* m, const morb_frame_params* P, bool top2,
   if (rc != MORB_OK) return rc;
   hipLaunchKernelGGL(k_candidates, dim3(div_up(qCap, 4), nframes), dim3(256), 0, st, *P, qCap, d_qs, d_qDesc, d_fImg, cap, d_count,
                      d_kps, d_desc, d_uRight, (unsigned long long*)cand, (int*)cnt);
-  const size_t smem = (size_t)cap;
-  if (top2)
-    hipLaunchKernelGGL(k_resolve<true>, dim3(nframes), dim3(64), smem, st, *P, qCap, d_nQ, d_qs, d_qDesc, d_qHasObs, d_fImg, cap,
-                       d_count, d_kps, d_desc, d_uRight, d_blocked, (const unsigned long long*)cand, (const int*)cnt, nnratio,
-                       checkOri, d_match, d_nmatches, (int*)ej, (int*)eb);
-  else
-    hipLaunchKernelGGL(k_resolve<false>, dim3(nframes), dim3(64), smem, st, *P, qCap, d_nQ, d_qs, d_qDesc, d_qHasObs, d_fImg, cap,
-                       d_count, d_kps, d_desc, d_uRight, d_blocked, (const unsigned long long*)cand, (const int*)cnt, nnratio,
-                       checkOri, d_match, d_nmatches, (int*)ej, (int*)eb);
+#define MORB_RESOLVE(MODE, SMEM)                                                                                             \
+  hipLaunchKernelGGL(k_resolve<MODE>, dim3(nframes), dim3(64), (SMEM), st, *P, qCap, d_nQ, d_qs, d_qDesc, d_qHasObs, d_fImg, cap, \
+                     d_count, d_kps, d_desc, d_uRight, d_blocked, (const unsigned long long*)cand, (const int*)cnt, nnratio,   \
+                     thAccept, checkOri, d_match, d_nmatches, (int*)ej, (int*)eb, d_prevMatched)
+  if (mode == 1) MORB_RESOLVE(1, (size_t)cap);
+  else if (mode == 2) {
+    MORB_REQUIRE((size_t)cap * 8 <= 64 * 1024, MORB_ERR_UNSUPPORTED, "too many features for SearchForInitialization's LDS state");
+    MORB_RESOLVE(2, (size_t)cap * 8);
+  } else MORB_RESOLVE(0, (size_t)cap);
+#undef MORB_RESOLVE
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
 }
@@ -524,8 +636,8 @@ int morb_search_by_projection_mps_batch(morb_matcher* m, const morb_frame_params
   if (rc != MORB_OK) return rc;
   hipLaunchKernelGGL(k_prep_mps, dim3(div_up(mpCap, 256), nframes), dim3(256), 0, st, *P, mpCap, d_nMP, d_inView, d_isBad, d_depth,
                      d_projX, d_projY, d_projXR, d_level, d_viewCos, th, bFarPoints, thFarPoints, (Query*)qs);
-  return window_search(m, P, true, nframes, mpCap, d_nMP, (const Query*)qs, d_mpDesc, d_mpHasObs, d_fImg, cap, d_count, d_kps,
-                       d_desc, d_uRight, d_blocked, nnratio, 0, d_matchF, d_nmatches, st);
+  return window_search(m, P, 1, nframes, mpCap, d_nMP, (const Query*)qs, d_mpDesc, d_mpHasObs, d_fImg, cap, d_count, d_kps,
+                       d_desc, d_uRight, d_blocked, nnratio, TH_HIGH, 0, d_matchF, d_nmatches, nullptr, st);
 }
 
 int morb_search_by_projection_last_batch(morb_matcher* m, const morb_frame_params* P, int nframes, const int* d_curImg,
@@ -550,8 +662,59 @@ int morb_search_by_projection_last_batch(morb_matcher* m, const morb_frame_param
   rc = morb_matcher_workspace(m, 6, sizeof(int) * (size_t)nframes, &nq);
   if (rc != MORB_OK) return rc;
   hipLaunchKernelGGL(k_gather_counts, dim3(div_up(nframes, 256)), dim3(256), 0, st, d_count, d_lastImg, nframes, (int*)nq);
-  return window_search(m, P, false, nframes, cap, (const int*)nq, (const Query*)qs, d_lastMPdesc, d_lastMPhasObs, d_curImg, cap,
-                       d_count, d_kps, d_desc, d_curURight, d_curBlocked, 0.f, checkOri, d_matchCur, d_nmatches, st);
+  return window_search(m, P, 0, nframes, cap, (const int*)nq, (const Query*)qs, d_lastMPdesc, d_lastMPhasObs, d_curImg, cap,
+                       d_count, d_kps, d_desc, d_curURight, d_curBlocked, 0.f, TH_HIGH, checkOri, d_matchCur, d_nmatches, nullptr, st);
+}
+
+int morb_search_by_projection_kf_batch(morb_matcher* m, const morb_frame_params* P, int nframes, const int* d_curImg,
+                                       const int* d_kfImg, int cap, const int* d_count, const morb_keypoint* d_kps,
+                                       const uint8_t* d_desc, const uint8_t* d_curHasMP, const float* d_Tcw, const float* d_Ow,
+                                       const uint8_t* d_kfValid, const float* d_Xw, const float* d_maxDist,
+                                       const float* d_minDist, const uint8_t* d_mpDesc, float th, int ORBdist, int checkOri,
+                                       int* d_matchCur, int* d_nmatches, void* stream) {
+  MORB_REQUIRE(m && P && d_curImg && d_kfImg && d_count && d_kps && d_desc && d_Tcw && d_Ow && d_kfValid && d_Xw && d_maxDist &&
+                   d_minDist && d_mpDesc && d_matchCur && d_nmatches, MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(nframes > 0 && cap > 0 && cap <= 65535, MORB_ERR_INVALID, "bad sizes");
+  MORB_HIP_CHECK(hipSetDevice(morb_matcher_device(m)));
+  hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
+  float thr[16];
+  for (int n = 0; n < 16; ++n) thr[n] = n < P->nlevels - 1 ? ratio_threshold(n, P->logScaleFactor) : 3.4e38f;
+  void *d_thr = nullptr, *qs = nullptr, *nq = nullptr;
+  int rc = morb_matcher_workspace(m, 4, sizeof thr, &d_thr);
+  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 5, sizeof(Query) * (size_t)nframes * cap, &qs);
+  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 6, sizeof(int) * (size_t)nframes, &nq);
+  if (rc != MORB_OK) return rc;
+  MORB_HIP_CHECK(hipMemcpyAsync(d_thr, thr, sizeof thr, hipMemcpyHostToDevice, st));
+  MORB_HIP_CHECK(hipStreamSynchronize(st));
+  hipLaunchKernelGGL(k_prep_kf, dim3(div_up(cap, 256), nframes), dim3(256), 0, st, *P, cap, d_count, d_kfImg, d_kps, d_kfValid, d_Xw,
+                     d_maxDist, d_minDist, d_Tcw, d_Ow, th, (const float*)d_thr, (Query*)qs);
+  hipLaunchKernelGGL(k_gather_counts, dim3(div_up(nframes, 256)), dim3(256), 0, st, d_count, d_kfImg, nframes, (int*)nq);
+  return window_search(m, P, 0, nframes, cap, (const int*)nq, (const Query*)qs, d_mpDesc, nullptr, d_curImg, cap, d_count, d_kps,
+                       d_desc, nullptr, d_curHasMP, 0.f, ORBdist, checkOri, d_matchCur, d_nmatches, nullptr, st);
+}
+
+int morb_search_for_initialization_batch(morb_matcher* m, const morb_frame_params* P, int npairs, const int* d_img1,
+                                         const int* d_img2, int cap, const int* d_count, const morb_keypoint* d_kps,
+                                         const uint8_t* d_desc, float* d_prevMatched, int windowSize, float nnratio,
+                                         int checkOri, int* d_matches12, int* d_nmatches, void* stream) {
+  MORB_REQUIRE(m && P && d_img1 && d_img2 && d_count && d_kps && d_desc && d_prevMatched && d_matches12 && d_nmatches,
+               MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(npairs > 0 && cap > 0 && cap <= 65535, MORB_ERR_INVALID, "bad sizes");
+  MORB_HIP_CHECK(hipSetDevice(morb_matcher_device(m)));
+  hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
+  void *qs = nullptr, *nq = nullptr, *qd = nullptr;
+  int rc = morb_matcher_workspace(m, 5, sizeof(Query) * (size_t)npairs * cap, &qs);
+  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 6, sizeof(int) * (size_t)npairs, &nq);
+  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 7, (size_t)npairs * cap * 32, &qd);
+  if (rc != MORB_OK) return rc;
+  hipLaunchKernelGGL(k_prep_init, dim3(div_up(cap, 256), npairs), dim3(256), 0, st, cap, d_count, d_img1, d_kps, d_prevMatched,
+                     windowSize, (Query*)qs);
+  hipLaunchKernelGGL(k_gather_counts, dim3(div_up(npairs, 256)), dim3(256), 0, st, d_count, d_img1, npairs, (int*)nq);
+  // query descriptors = F1's descriptor rows, gathered per pair
+  hipLaunchKernelGGL(k_gather_desc, dim3(div_up(cap * 2, 256), npairs), dim3(256), 0, st, d_desc, d_img1, cap, (uint8_t*)qd);
+  hipLaunchKernelGGL(k_fill_m1, dim3(div_up(npairs * cap, 256)), dim3(256), 0, st, d_matches12, npairs * cap);
+  return window_search(m, P, 2, npairs, cap, (const int*)nq, (const Query*)qs, (const uint8_t*)qd, nullptr, d_img2, cap, d_count,
+                       d_kps, d_desc, nullptr, nullptr, nnratio, TH_LOW, checkOri, d_matches12, d_nmatches, d_prevMatched, st);
 }
 
 }  // extern "C"

@@ -147,3 +147,28 @@ class ORBmatcher:
             ptr(hasMP), ptr(uRight), ptr(R12), ptr(t12), ptr(ep), 1 if bOnlyStereo else 0, 1 if bCoarse else 0,
             1 if self.mbCheckOrientation else 0, ptr(m12), ptr(nm), self._st(stream)))
         return m12, nm
+
+    def SearchByProjectionKeyFrame(self, params, curImg, kfImg, kps, desc, count, curHasMP, Tcw, Ow, kfValid, Xw, maxDist, minDist,
+                                   mpDesc, th, ORBdist, matchCur=None, stream=None):
+        """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (relocalisation)."""
+        import torch
+        F, cap = curImg.shape[0], kps.shape[1]
+        if matchCur is None:
+            matchCur = torch.full((F, cap), -1, dtype=torch.int32, device=kps.device)
+        nm = torch.zeros((F,), dtype=torch.int32, device=kps.device)
+        check(self._L.morb_search_by_projection_kf_batch(
+            self._h, C.byref(params), F, ptr(curImg), ptr(kfImg), cap, ptr(count), ptr(kps), ptr(desc), ptr(curHasMP), ptr(Tcw), ptr(Ow),
+            ptr(kfValid), ptr(Xw), ptr(maxDist), ptr(minDist), ptr(mpDesc), float(th), int(ORBdist),
+            1 if self.mbCheckOrientation else 0, ptr(matchCur), ptr(nm), self._st(stream)))
+        return matchCur, nm
+
+    def SearchForInitialization(self, params, img1, img2, kps, desc, count, prevMatched, windowSize=10, stream=None):
+        """SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize); prevMatched [P, cap, 2] f32 is updated in place."""
+        import torch
+        npairs, cap = img1.shape[0], kps.shape[1]
+        m12 = torch.full((npairs, cap), -1, dtype=torch.int32, device=kps.device)
+        nm = torch.zeros((npairs,), dtype=torch.int32, device=kps.device)
+        check(self._L.morb_search_for_initialization_batch(
+            self._h, C.byref(params), npairs, ptr(img1), ptr(img2), cap, ptr(count), ptr(kps), ptr(desc), ptr(prevMatched),
+            int(windowSize), self.mfNNratio, 1 if self.mbCheckOrientation else 0, ptr(m12), ptr(nm), self._st(stream)))
+        return m12, nm

@@ -254,6 +254,130 @@ int SearchByProjectionLast(const orc_frame& Cur, const uint8_t* curBlocked, cons
   return nmatches;
 }
 
+// ---- ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist) (:1735-1842) ----
+// kfValid[i] != 0 <=> vpMPs[i] && !isBad() && !sAlreadyFound.count(pMP); curHasMP[i2] != 0 <=> CurrentFrame.mvpMapPoints[i2].
+int SearchByProjectionKF(const orc_frame& Cur, const uint8_t* curHasMP, const float* Tcw7, const float* Ow, int nKF,
+                         const KeyPoint* kfKpsUn, const uint8_t* kfValid, const float* Xw, const float* mfMaxDistance,
+                         const float* mfMinDistance, const uint8_t* mpDesc, float th, int ORBdist, bool mbCheckOrientation,
+                         int* matchCur) {
+  Grid g;
+  AssignFeaturesToGrid(Cur, g);
+  const KeyPoint* kc = (const KeyPoint*)Cur.kpsUn;
+  std::vector<char> has(curHasMP, curHasMP + Cur.N);
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  for (int i = 0; i < nKF; i++) {
+    if (!kfValid[i]) continue;
+    const float* x3Dw = Xw + 3 * i;
+    float x3Dc[3];
+    rotateF(Tcw7, x3Dw, x3Dc);
+    x3Dc[0] += Tcw7[4]; x3Dc[1] += Tcw7[5]; x3Dc[2] += Tcw7[6];
+    const float u = Cur.fx * x3Dc[0] / x3Dc[2] + Cur.cx;
+    const float v = Cur.fy * x3Dc[1] / x3Dc[2] + Cur.cy;
+    if (u < Cur.minX || u > Cur.maxX) continue;
+    if (v < Cur.minY || v > Cur.maxY) continue;
+    const float PO[3] = {x3Dw[0] - Ow[0], x3Dw[1] - Ow[1], x3Dw[2] - Ow[2]};
+    const float dist3D = std::sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+    const float maxDistance = 1.2f * mfMaxDistance[i], minDistance = 0.8f * mfMinDistance[i];
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    const float ratio = mfMaxDistance[i] / dist3D;
+    int nPredictedLevel = (int)std::ceil(std::log(ratio) / Cur.logScaleFactor);
+    if (nPredictedLevel < 0) nPredictedLevel = 0;
+    else if (nPredictedLevel >= Cur.nlevels) nPredictedLevel = Cur.nlevels - 1;
+    const float radius = th * Cur.scaleFactors[nPredictedLevel];
+    const std::vector<size_t> vIndices2 = GetFeaturesInArea(Cur, g, u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1);
+    if (vIndices2.empty()) continue;
+    const uint8_t* dMP = mpDesc + (size_t)i * 32;
+    int bestDist = 256, bestIdx2 = -1;
+    for (size_t q = 0; q < vIndices2.size(); ++q) {
+      const size_t i2 = vIndices2[q];
+      if (has[i2]) continue;
+      const int dist = DescriptorDistance(dMP, Cur.desc + i2 * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+    }
+    if (bestDist <= ORBdist) {
+      matchCur[bestIdx2] = i;
+      has[bestIdx2] = 1;
+      nmatches++;
+      if (mbCheckOrientation) {
+        float rot = kfKpsUn[i].angle - kc[bestIdx2].angle;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rotHist[bin].push_back(bestIdx2);
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) { matchCur[rotHist[i][j]] = -1; nmatches--; }
+  }
+  return nmatches;
+}
+
+// ---- ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (:603-700) ----
+int SearchForInitialization(int n1, const KeyPoint* kps1, const uint8_t* desc1, const orc_frame& F2, float* vbPrevMatched,
+                            int windowSize, float mfNNratio, bool mbCheckOrientation, int* vnMatches12) {
+  Grid g;
+  AssignFeaturesToGrid(F2, g);
+  const KeyPoint* k2 = (const KeyPoint*)F2.kpsUn;
+  int nmatches = 0;
+  for (int i = 0; i < n1; ++i) vnMatches12[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  std::vector<int> vMatchedDistance(F2.N, 2147483647), vnMatches21(F2.N, -1);
+  for (int i1 = 0; i1 < n1; i1++) {
+    const KeyPoint kp1 = kps1[i1];
+    const int level1 = kp1.octave;
+    if (level1 > 0) continue;
+    std::vector<size_t> vIndices2 = GetFeaturesInArea(F2, g, vbPrevMatched[2 * i1], vbPrevMatched[2 * i1 + 1], (float)windowSize, level1, level1);
+    if (vIndices2.empty()) continue;
+    const uint8_t* d1 = desc1 + (size_t)i1 * 32;
+    int bestDist = 2147483647, bestDist2 = 2147483647, bestIdx2 = -1;
+    for (size_t q = 0; q < vIndices2.size(); ++q) {
+      const size_t i2 = vIndices2[q];
+      const int dist = DescriptorDistance(d1, F2.desc + i2 * 32);
+      if (vMatchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = (int)i2; }
+      else if (dist < bestDist2) { bestDist2 = dist; }
+    }
+    if (bestDist <= TH_LOW) {
+      if (bestDist < (float)bestDist2 * mfNNratio) {
+        if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+        vnMatches12[i1] = bestIdx2;
+        vnMatches21[bestIdx2] = i1;
+        vMatchedDistance[bestIdx2] = bestDist;
+        nmatches++;
+        if (mbCheckOrientation) {
+          float rot = kps1[i1].angle - k2[bestIdx2].angle;
+          if (rot < 0.0) rot += 360.0f;
+          int bin = (int)std::round(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          rotHist[bin].push_back(i1);
+        }
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+        const int idx1 = rotHist[i][j];
+        if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+      }
+    }
+  }
+  for (int i1 = 0; i1 < n1; i1++)
+    if (vnMatches12[i1] >= 0) { vbPrevMatched[2 * i1] = k2[vnMatches12[i1]].x; vbPrevMatched[2 * i1 + 1] = k2[vnMatches12[i1]].y; }
+  return nmatches;
+}
+
 // ---- Pinhole::epipolarConstrain (Pinhole.cpp:111-139) with F12 given --------------------------------------
 static bool epipolarConstrain(const float* F12, const KeyPoint& kp1, const KeyPoint& kp2, float unc) {
   const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
@@ -387,6 +511,16 @@ int orc_search_by_projection_last(const orc_frame* Cur, const uint8_t* curBlocke
                                   int bBackward, int checkOri, int* matchCur) {
   return SearchByProjectionLast(*Cur, curBlocked, Tcw7, nLast, (const KeyPoint*)lastKpsUn, lastValid, lastXw, lastMPdesc,
                                 lastMPhasObs, th, bForward != 0, bBackward != 0, checkOri != 0, matchCur);
+}
+int orc_search_by_projection_kf(const orc_frame* Cur, const uint8_t* curHasMP, const float* Tcw7, const float* Ow, int nKF,
+                                const orc_keypoint* kfKpsUn, const uint8_t* kfValid, const float* Xw, const float* maxDist,
+                                const float* minDist, const uint8_t* mpDesc, float th, int ORBdist, int checkOri, int* matchCur) {
+  return SearchByProjectionKF(*Cur, curHasMP, Tcw7, Ow, nKF, (const KeyPoint*)kfKpsUn, kfValid, Xw, maxDist, minDist, mpDesc, th,
+                              ORBdist, checkOri != 0, matchCur);
+}
+int orc_search_for_initialization(int n1, const orc_keypoint* kps1, const uint8_t* desc1, const orc_frame* F2, float* prevMatched,
+                                  int windowSize, float nnratio, int checkOri, int* matches12) {
+  return SearchForInitialization(n1, (const KeyPoint*)kps1, desc1, *F2, prevMatched, windowSize, nnratio, checkOri != 0, matches12);
 }
 void orc_fundamental_f12(const float* K1, const float* K2, const float* R12, const float* t12, float* F12) {
   FundamentalF12(K1, K2, R12, t12, F12);

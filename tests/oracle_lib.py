@@ -261,3 +261,25 @@ def search_for_triangulation(k1, d1, node1, has1, ur1, k2, d2, node2, has2, ur2,
                                        len(k2), _p(a[4]), _p(a[5]), _p(a[6]), _p(a[7]), None if u2 is None else _p(u2), _p(a[8]), _p(a[9]),
                                        _p(F12), _p(a[10]), int(onlyStereo), int(coarse), int(checkOri), _p(m))
     return r, m
+
+
+def search_by_projection_kf(Cur, curHasMP, Tcw7, Ow, kfKps, kfValid, Xw, maxD, minD, mpDesc, th, ORBdist, checkOri):
+    L = lib()
+    L.orc_search_by_projection_kf.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_int, C.c_int, C.c_void_p]
+    m = np.full(Cur.N, -1, np.int32)
+    a = [np.ascontiguousarray(x) for x in (curHasMP.astype(np.uint8), np.asarray(Tcw7, np.float32), np.asarray(Ow, np.float32), kfKps,
+                                           kfValid.astype(np.uint8), np.asarray(Xw, np.float32), np.asarray(maxD, np.float32),
+                                           np.asarray(minD, np.float32), mpDesc)]
+    r = L.orc_search_by_projection_kf(C.byref(Cur), _p(a[0]), _p(a[1]), _p(a[2]), len(kfKps), _p(a[3]), _p(a[4]), _p(a[5]), _p(a[6]),
+                                      _p(a[7]), _p(a[8]), th, int(ORBdist), int(checkOri), _p(m))
+    return r, m
+
+
+def search_for_initialization(k1, d1, F2, prev, windowSize, nnratio, checkOri):
+    L = lib()
+    L.orc_search_for_initialization.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    m = np.full(len(k1), -1, np.int32)
+    pv = np.ascontiguousarray(prev, np.float32).copy()
+    k1 = np.ascontiguousarray(k1); d1 = np.ascontiguousarray(d1)
+    r = L.orc_search_for_initialization(len(k1), _p(k1), _p(d1), C.byref(F2), _p(pv), int(windowSize), nnratio, int(checkOri), _p(m))
+    return r, m, pv

@@ -287,3 +287,80 @@ def test_search_for_triangulation(batch):
             np.testing.assert_array_equal(m12[p, :len(ka)], me)
             tot += r
     assert tot > 100
+
+
+def test_search_for_initialization(batch):
+    import torch
+    from morb_slam_amd import ORBmatcher
+    P, uR, dep = _scene(batch)
+    dev = "cuda"
+    cap = batch["kps"].shape[1]
+    pairs = [(0, 4), (2, 6), (4, 0)]
+    img1 = torch.tensor([a for a, _ in pairs], dtype=torch.int32, device=dev); img2 = torch.tensor([b for _, b in pairs], dtype=torch.int32, device=dev)
+    prev0 = np.zeros((3, cap, 2), np.float32)
+    for p, (a, b) in enumerate(pairs):
+        ka = batch["ora"][a][1]
+        prev0[p, :len(ka), 0] = ka["x"]; prev0[p, :len(ka), 1] = ka["y"]        # Tracking.cc: mvbPrevMatched = F1 keypoints
+    tot = 0
+    for win, ratio, ori in ((100, 0.9, True), (20, 0.7, False)):
+        m = ORBmatcher(ratio, ori)
+        prev = torch.from_numpy(prev0.copy()).to(dev)
+        m12, nm = m.SearchForInitialization(P, img1, img2, batch["kps"], batch["desc"], batch["cnt"], prev, win)
+        torch.cuda.synchronize()
+        m12, nm, prevg = m12.cpu().numpy(), nm.cpu().numpy(), prev.cpu().numpy()
+        for p, (a, b) in enumerate(pairs):
+            ka, da = batch["ora"][a][1], batch["ora"][a][2]; kb, db = batch["ora"][b][1], batch["ora"][b][2]
+            F2 = O.make_frame(P, kb, db, None)
+            r, me, pe = O.search_for_initialization(ka, da, F2, prev0[p, :len(ka)], win, ratio, ori)
+            assert nm[p] == r, (p, nm[p], r)
+            np.testing.assert_array_equal(m12[p, :len(ka)], me)
+            assert prevg[p, :len(ka)].tobytes() == pe.tobytes()
+            tot += r
+    assert tot > 300
+
+
+def test_search_by_projection_keyframe(batch):
+    import torch
+    from morb_slam_amd import ORBmatcher
+    P, uR, dep = _scene(batch)
+    dev = "cuda"
+    cap = batch["kps"].shape[1]
+    rng = np.random.default_rng(9)
+    pad = lambda a, fill=0: np.concatenate([a, np.full((cap - len(a),) + a.shape[1:], fill, a.dtype)])
+    pairs = [(0, 4), (2, 6)]       # (keyframe image, current image)
+    val, Xs, dsc, mx, mn, has, Tcw, Ow = [], [], [], [], [], [], [], []
+    for ki, ci in pairs:
+        kk, dk = batch["ora"][ki][1], batch["ora"][ki][2]
+        z = dep[ki // 2, :len(kk)].cpu().numpy()
+        v = (z > 0) & (rng.random(len(kk)) < 0.9)
+        zz = np.where(z > 0, z, 1.0)
+        X = np.stack([(kk["x"] - P.cx) * zz / P.fx, (kk["y"] - P.cy) * zz / P.fy, zz], 1).astype(np.float32)
+        d3 = np.linalg.norm(X, axis=1).astype(np.float32)
+        maxD = (d3 * 1.2 ** kk["octave"] * rng.uniform(0.9, 1.2, len(kk))).astype(np.float32)
+        val.append(pad(v.astype(np.uint8))); Xs.append(pad(X)); dsc.append(pad(dk)); mx.append(pad(maxD, 1)); mn.append(pad((maxD / 1.2 ** 7).astype(np.float32), 1))
+        kc = batch["ora"][ci][1]
+        has.append(pad((rng.random(len(kc)) < 0.2).astype(np.uint8)))
+        q = np.array([0.001, -0.002, 0.0, 1.0]); q /= np.linalg.norm(q)
+        t = np.array([0.01, 0.0, -0.02])
+        Tcw.append(np.concatenate([q, t]).astype(np.float32))
+        # Ow = -R^T t (float32, like Tcw.inverse().translation())
+        qc = q * np.array([-1, -1, -1, 1])
+        u = qc[:3]; uv = 2 * np.cross(u, -t); Ow.append((-t + qc[3] * uv + np.cross(u, uv)).astype(np.float32))
+    t_ = lambda a: torch.from_numpy(np.stack(a)).to(dev)
+    curImg = torch.tensor([c for _, c in pairs], dtype=torch.int32, device=dev); kfImg = torch.tensor([k for k, _ in pairs], dtype=torch.int32, device=dev)
+    tot = 0
+    for th, orb, ori in ((10.0, 100, True), (3.0, 64, False)):
+        m = ORBmatcher(0.9, ori)
+        mc, nm = m.SearchByProjectionKeyFrame(P, curImg, kfImg, batch["kps"], batch["desc"], batch["cnt"], t_(has), t_(Tcw), t_(Ow),
+                                              t_(val), t_(Xs), t_(mx), t_(mn), t_(dsc), th, orb)
+        torch.cuda.synchronize()
+        mc, nm = mc.cpu().numpy(), nm.cpu().numpy()
+        for p, (ki, ci) in enumerate(pairs):
+            kk = batch["ora"][ki][1]; kc, dc = batch["ora"][ci][1], batch["ora"][ci][2]
+            Fo = O.make_frame(P, kc, dc, None)
+            r, me = O.search_by_projection_kf(Fo, has[p][:len(kc)], Tcw[p], Ow[p], kk, val[p][:len(kk)], Xs[p][:len(kk)], mx[p][:len(kk)],
+                                              mn[p][:len(kk)], dsc[p][:len(kk)], th, orb, ori)
+            assert nm[p] == r, (p, nm[p], r)
+            np.testing.assert_array_equal(mc[p, :len(kc)], me)
+            tot += r
+    assert tot > 300
