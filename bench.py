@@ -145,8 +145,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # MORB_DIST_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks (ranks then
+        # share devices); the driver's multi-GPU runs use the default: nccl = RCCL over xGMI, one rank per GPU
+        backend = os.environ.get("MORB_DIST_BACKEND", "nccl")
+        ndev = max(torch.cuda.device_count(), 1)
+        local_rank = local_rank % ndev
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 

@@ -60,7 +60,7 @@ class FeatureExchange:
             out = torch.empty(shape, dtype=x.dtype, device=x.device)
             self._out[name] = out
         x = x.contiguous()
-        if x.device.type == "cpu":
+        if x.device.type == "cpu" or self.dist.get_backend(self.group) != "nccl":
             # gloo has no all_gather_into_tensor for every dtype: gather a list and copy
             parts = [torch.empty_like(x) for _ in range(self.world)]
             self.dist.all_gather(parts, x, group=self.group)
