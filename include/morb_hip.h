@@ -124,6 +124,17 @@ int morb_stereo_match_batch(morb_matcher*, const morb_extractor*, int nframes, c
                             const uint8_t* d_desc, const int* d_count, int cap, float mbf, float mb, float* d_uRight,
                             float* d_depth, void* stream);
 
+/* void Frame::ComputeStereoFishEyeMatches()  Frame.cc:1222-1274 for nframes fisheye stereo frames (left = image 2f,
+ * right = image 2f+1 of one extract batch): brute-force 2-NN over the lapping-area features (from index
+ * d_mono[image] = the monoIndex ORBextractor::operator() returned), ratio 0.7, KannalaBrandt8::TriangulateMatches.
+ * camL8 / camR8 (HOST) = fx fy cx cy k0..k3; Rlr9 / tlr3 (HOST) = Frame::mRlr / mtlr; levelSigma2 = mvLevelSigma2.
+ * Outputs [nframes][cap]: mvLeftToRightMatch, mvRightToLeftMatch, mvDepth, mvStereo3Dpoints ([..][3]); d_nMatches[f]. */
+int morb_stereo_fisheye_match_batch(morb_matcher*, int nframes, const morb_keypoint* d_kps, const uint8_t* d_desc,
+                                    const int* d_count, const int* d_mono, int cap, const float* camL8, const float* camR8,
+                                    const float* Rlr9, const float* tlr3, const float* levelSigma2, int nlevels,
+                                    int* d_leftToRight, int* d_rightToLeft, float* d_depth, float* d_p3D, int* d_nMatches,
+                                    void* stream);
+
 /* DBoW2 TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup)
  * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1218-1259) for every feature of nimg images: the vocabulary is
  * a k-ary tree in arrays (node 0 = root; children of n = firstChild[n] .. firstChild[n]+k-1; firstChild < 0 =
@@ -235,8 +246,8 @@ int morb_search_for_triangulation_batch(morb_matcher*, const morb_frame_params*,
  * Optimizer  (include/Optimizer.h:46-139, src/Optimizer.cc; g2o Levenberg-Marquardt semantics)
  * Poses cross the boundary the way the reference hands them to g2o: unit quaternion (x, y, z, w) followed by
  * the translation, 7 floats (Sophus::SE3f::unit_quaternion() / translation(), Optimizer.cc:781-783, :1046-1048).
- * Pinhole mono (uRight < 0) and rectified-stereo (uRight >= 0) observations are supported; the KannalaBrandt8
- * "ToBody" edges are not yet (MORB_ERR_UNSUPPORTED is never silently substituted).
+ * Pinhole mono (uRight < 0) and rectified-stereo (uRight >= 0) observations; PoseOptimization also for the
+ * KannalaBrandt8 fisheye rig ("ToBody" edges); LocalBundleAdjustment with fisheye edges is not provided yet.
  * ---------------------------------------------------------------------------------------------------- */
 typedef struct morb_optimizer morb_optimizer;
 int morb_optimizer_create(morb_optimizer** out, int device);
@@ -253,6 +264,15 @@ int morb_pose_optimization_batch(morb_optimizer*, int nframes, int cap, const in
                                  const float* d_obs, const float* d_invSigma2, const float* d_Xw, float fx, float fy,
                                  float cx, float cy, float bf, float* d_pose, uint8_t* d_outlier, int* d_nInliers,
                                  int* d_stats, void* stream);
+
+/* PoseOptimization for a fisheye stereo rig (pFrame->mpCamera2 != NULL: Optimizer.cc:880-946): features
+ * [0, d_nLeft[f]) are left-camera observations (EdgeSE3ProjectXYZOnlyPose on the left KannalaBrandt8 camera), the rest
+ * right-camera ones (EdgeSE3ProjectXYZOnlyPoseToBody with mTrl).  d_obs[i] = (x, y, unused).  camL8 / camR8 (HOST) =
+ * fx fy cx cy k0 k1 k2 k3; Trl7 (HOST) = Frame::GetRelativePoseTrl() as quaternion xyzw + translation. */
+int morb_pose_optimization_fisheye_batch(morb_optimizer*, int nframes, int cap, const int* d_count, const int* d_nLeft,
+                                         const uint8_t* d_hasMP, const float* d_obs, const float* d_invSigma2,
+                                         const float* d_Xw, const float* camL8, const float* camR8, const float* Trl7,
+                                         float* d_pose, uint8_t* d_outlier, int* d_nInliers, int* d_stats, void* stream);
 
 /* static void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF,
  * int& num_OptKF, int& num_MPs, int& num_edges)  Optimizer.h:67-69, Optimizer.cc:1053-1441, on the graph the

@@ -88,6 +88,7 @@ def lib():
         L.morb_hamming_pairs.argtypes = [vp, vp, vp, i, vp, vp]
         L.morb_hamming_knn2_batch.argtypes = [vp, i, vp, vp, i, vp, vp, vp, i, vp, vp, vp, vp]
         L.morb_stereo_match_batch.argtypes = [vp, vp, i, vp, vp, vp, i, f, f, vp, vp, vp]
+        L.morb_stereo_fisheye_match_batch.argtypes = [vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp]
         L.morb_bow_transform_batch.argtypes = [vp, i, vp, vp, i, vp, vp, i, i, i, vp, vp, vp]
         L.morb_search_by_bow_batch.argtypes = [vp, i, vp, vp, i, vp, vp, vp, vp, vp, i, f, i, vp, vp, vp]
         PP = C.POINTER(FrameParams)
@@ -101,6 +102,7 @@ def lib():
         L.morb_optimizer_destroy.argtypes = [vp]
         L.morb_optimizer_destroy.restype = None
         L.morb_pose_optimization_batch.argtypes = [vp, i, i, vp, vp, vp, vp, vp, f, f, f, f, f, vp, vp, vp, vp, vp]
+        L.morb_pose_optimization_fisheye_batch.argtypes = [vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.morb_local_bundle_adjustment.argtypes = [vp, i, vp, vp, i, vp, i, vp, vp, vp, vp, f, f, f, f, f, i, vp, vp, vp]
         L.morb_ba_problem_create.argtypes = [vp, C.POINTER(vp), i, vp, vp, i, vp, i, vp, vp, vp, vp, f, f, f, f, f, i]
         L.morb_ba_problem_destroy.argtypes = [vp]

@@ -245,14 +245,87 @@ __device__ __forceinline__ bool ldlt6(const double* Hin, const double* rhs, doub
   return true;
 }
 
+// ---- KannalaBrandt8 (fisheye) camera in the optimisers (KannalaBrandt8.cpp:48-66, :149-184) ------------------
+struct Rig {            // fisheye stereo rig: left / right KB8 cameras and mTrl (left-camera frame -> right-camera frame)
+  float kbL[8], kbR[8];
+  SE3 Trl;
+};
+__device__ __forceinline__ void kb8_project_d(const float* c, const double* v, double* uv) {
+  const double x2_plus_y2 = v[0] * v[0] + v[1] * v[1];
+  const double theta = (double)atan2f(sqrtf((float)x2_plus_y2), (float)v[2]);   // the reference's float leak
+  const double psi = (double)atan2f((float)v[1], (float)v[0]);
+  const double theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2,
+               theta9 = theta7 * theta2;
+  const double r = theta + c[4] * theta3 + c[5] * theta5 + c[6] * theta7 + c[7] * theta9;
+  uv[0] = c[0] * r * cos(psi) + c[2];
+  uv[1] = c[1] * r * sin(psi) + c[3];
+}
+__device__ __forceinline__ void kb8_project_jac(const float* c, const double* v, double* J) {
+  const double x2 = v[0] * v[0], y2 = v[1] * v[1], z2 = v[2] * v[2];
+  const double r2 = x2 + y2, r = sqrt(r2), r3 = r2 * r;
+  const double theta = atan2(r, v[2]);
+  const double theta2 = theta * theta, theta3 = theta2 * theta, theta4 = theta2 * theta2, theta5 = theta4 * theta;
+  const double theta6 = theta2 * theta4, theta7 = theta6 * theta, theta8 = theta4 * theta4, theta9 = theta8 * theta;
+  const double f = theta + theta3 * c[4] + theta5 * c[5] + theta7 * c[6] + theta9 * c[7];
+  const double fd = 1 + 3 * c[4] * theta2 + 5 * c[5] * theta4 + 7 * c[6] * theta6 + 9 * c[7] * theta8;
+  J[0] = c[0] * (fd * v[2] * x2 / (r2 * (r2 + z2)) + f * y2 / r3);
+  J[3] = c[1] * (fd * v[2] * v[1] * v[0] / (r2 * (r2 + z2)) - f * v[1] * v[0] / r3);
+  J[1] = c[0] * (fd * v[2] * v[1] * v[0] / (r2 * (r2 + z2)) - f * v[1] * v[0] / r3);
+  J[4] = c[1] * (fd * v[2] * y2 / (r2 * (r2 + z2)) + f * x2 / r3);
+  J[2] = -c[0] * fd * v[0] / (r2 + z2);
+  J[5] = -c[1] * fd * v[1] / (r2 + z2);
+}
+// unary edge of PoseOptimization: residual (returns chi2, sets st = "3-D stereo residual") ...
+template <bool FISH>
+__device__ __forceinline__ double pose_edge_error(const Cam& cam, const Rig& rig, const SE3& P, const SE3& Pr, bool right,
+                                                  const double* X, const float* o, double info, double* err, bool& st,
+                                                  double* xc) {
+  se3_map(P, X, xc);
+  if (!FISH) {
+    st = !(o[2] < 0);
+    return edge_error(cam, st, xc, o, info, err);
+  }
+  st = false;
+  double uv[2];
+  if (!right) kb8_project_d(rig.kbL, xc, uv);                       // EdgeSE3ProjectXYZOnlyPose, pCamera = left KB8
+  else { double xr[3]; se3_map(Pr, X, xr); kb8_project_d(rig.kbR, xr, uv); }   // ...ToBody: (mTrl * T).map(Xw)
+  err[0] = (double)o[0] - uv[0]; err[1] = (double)o[1] - uv[1]; err[2] = 0;
+  return err[0] * (info * err[0]) + err[1] * (info * err[1]);
+}
+// ... and its 2x6 / 3x6 Jacobian w.r.t. the pose
+template <bool FISH>
+__device__ __forceinline__ void pose_edge_jac(const Cam& cam, const Rig& rig, bool right, bool st, const double* xc, double* Jp) {
+  if (!FISH) { jac_pose(cam, st, true, xc, Jp); return; }
+  const double x = xc[0], y = xc[1], z = xc[2];
+  double pj[6], pjM[6];
+  if (!right) {
+    kb8_project_jac(rig.kbL, xc, pj);
+    for (int k = 0; k < 6; ++k) pjM[k] = pj[k];
+  } else {  // -projectJac(X_r) * R_rl * SE3deriv(X_l), X_r = mTrl.map(T.map(Xw))  (OptimizableTypes.cpp:88-104)
+    double xr[3], M[9];
+    se3_map(rig.Trl, xc, xr);
+    kb8_project_jac(rig.kbR, xr, pj);
+    q_to_R(rig.Trl.q, M);
+    for (int r = 0; r < 2; ++r)
+      for (int c = 0; c < 3; ++c) pjM[r * 3 + c] = pj[r * 3] * M[c] + pj[r * 3 + 1] * M[3 + c] + pj[r * 3 + 2] * M[6 + c];
+  }
+  for (int r = 0; r < 2; ++r) {
+    const double a = pjM[r * 3], b = pjM[r * 3 + 1], c = pjM[r * 3 + 2];
+    Jp[r * 6 + 0] = -(b * -z + c * y); Jp[r * 6 + 1] = -(a * z + c * -x); Jp[r * 6 + 2] = -(a * -y + b * x);
+    Jp[r * 6 + 3] = -a; Jp[r * 6 + 4] = -b; Jp[r * 6 + 5] = -c;
+  }
+  for (int k = 12; k < 18; ++k) Jp[k] = 0;
+}
+
 // =====================================================================================================
 // PoseOptimization: one workgroup per frame
 // =====================================================================================================
+template <bool FISH>
 __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict__ count, const uint8_t* __restrict__ hasMP,
                                                   const float* __restrict__ obs, const float* __restrict__ invSigma2,
-                                                  const float* __restrict__ Xw, Cam cam, float* __restrict__ poseIO,
-                                                  uint8_t* __restrict__ outlier, int* __restrict__ nInliers,
-                                                  int* __restrict__ stats) {
+                                                  const float* __restrict__ Xw, Cam cam, Rig rig, const int* __restrict__ nLeft,
+                                                  float* __restrict__ poseIO, uint8_t* __restrict__ outlier,
+                                                  int* __restrict__ nInliers, int* __restrict__ stats) {
   __shared__ double red[4];
   __shared__ double sH[4][28];
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -274,17 +347,18 @@ __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict
   bool robust = true;
   int nBadEdges = 0, outerIts = 0, trials = 0;
 
+  const int nL = FISH ? nLeft[f] : n;   // features >= nL are right-camera observations (fisheye rig)
   // robustified chi2 of the active edges at pose P
   auto chi2Active = [&](const SE3& P) -> double {
+    const SE3 Pr = FISH ? se3_mul(rig.Trl, P) : P;
     double s = 0;
     for (int i = tid; i < n; i += 256) {
       if (!hasMP[base + i] || outlier[base + i]) continue;
       const float* o = obs + (base + i) * 3;
       const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
       double xc[3], err[3], w;
-      se3_map(P, X, xc);
-      const bool st = !(o[2] < 0);
-      double c = edge_error(cam, st, xc, o, (double)invSigma2[base + i], err);
+      bool st;
+      double c = pose_edge_error<FISH>(cam, rig, P, Pr, FISH && i >= nL, X, o, (double)invSigma2[base + i], err, st, xc);
       if (robust) c = huber(st ? deltaStereo : deltaMono, c, &w);
       s += c;
     }
@@ -299,6 +373,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict
     for (int iter = 0; iter < 10; ++iter) {
       ++outerIts;
       // computeActiveErrors + activeRobustChi2 + buildSystem in one pass
+      const SE3 Tr = FISH ? se3_mul(rig.Trl, T) : T;
       double acc[28];
 #pragma unroll
       for (int k = 0; k < 28; ++k) acc[k] = 0;
@@ -307,13 +382,13 @@ __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict
         const float* o = obs + (base + i) * 3;
         const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
         double xc[3], err[3], Jp[18], w = 1.0;
-        se3_map(T, X, xc);
-        const bool st = !(o[2] < 0);
+        bool st;
         const double info = (double)invSigma2[base + i];
-        double c = edge_error(cam, st, xc, o, info, err);
+        const bool right = FISH && i >= nL;
+        double c = pose_edge_error<FISH>(cam, rig, T, Tr, right, X, o, info, err, st, xc);
         if (robust) c = huber(st ? deltaStereo : deltaMono, c, &w);
         acc[27] += c;
-        jac_pose(cam, st, true, xc, Jp);
+        pose_edge_jac<FISH>(cam, rig, right, st, xc, Jp);
         const int d = st ? 3 : 2;
         const double wo = w * info;
         int q = 0;
@@ -389,14 +464,16 @@ __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict
     // rejected trial when the LM loop ended on a failure), current outliers are re-evaluated at the final pose
     int bad = 0;
     __syncthreads();
+    const SE3 TrFin = FISH ? se3_mul(rig.Trl, T) : T, TrEval = FISH ? se3_mul(rig.Trl, Teval) : Teval;
     for (int i = tid; i < n; i += 256) {
       if (!hasMP[base + i]) continue;
       const float* o = obs + (base + i) * 3;
       const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
       double xc[3], err[3];
-      se3_map(outlier[base + i] ? T : Teval, X, xc);
-      const bool st = !(o[2] < 0);
-      const float chi2 = (float)edge_error(cam, st, xc, o, (double)invSigma2[base + i], err);
+      bool st;
+      const SE3& Pc = outlier[base + i] ? T : Teval;
+      const float chi2 = (float)pose_edge_error<FISH>(cam, rig, Pc, outlier[base + i] ? TrFin : TrEval, FISH && i >= nL, X, o,
+                                                      (double)invSigma2[base + i], err, st, xc);
       const bool isOut = chi2 > (st ? 7.815f : 5.991f);
       outlier[base + i] = isOut ? 1 : 0;
       bad += isOut ? 1 : 0;
@@ -1228,8 +1305,36 @@ int morb_pose_optimization_batch(morb_optimizer* o, int nframes, int cap, const 
   MORB_HIP_CHECK(hipSetDevice(o->device));
   hipStream_t st = stream ? (hipStream_t)stream : o->stream;
   Cam cam{fx, fy, cx, cy, bf};
-  hipLaunchKernelGGL(k_pose_opt, dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam,
-                     d_pose, d_outlier, d_nInliers, d_stats);
+  Rig rig;
+  memset(&rig, 0, sizeof rig);
+  hipLaunchKernelGGL(k_pose_opt<false>, dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
+                     (const int*)nullptr, d_pose, d_outlier, d_nInliers, d_stats);
+  MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}
+
+int morb_pose_optimization_fisheye_batch(morb_optimizer* o, int nframes, int cap, const int* d_count, const int* d_nLeft,
+                                         const uint8_t* d_hasMP, const float* d_obs, const float* d_invSigma2,
+                                         const float* d_Xw, const float* camL8, const float* camR8, const float* Trl7,
+                                         float* d_pose, uint8_t* d_outlier, int* d_nInliers, int* d_stats, void* stream) {
+  MORB_REQUIRE(o && d_count && d_nLeft && d_hasMP && d_obs && d_invSigma2 && d_Xw && camL8 && camR8 && Trl7 && d_pose && d_outlier &&
+                   d_nInliers, MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(nframes > 0 && cap > 0, MORB_ERR_INVALID, "bad sizes");
+  MORB_HIP_CHECK(hipSetDevice(o->device));
+  hipStream_t st = stream ? (hipStream_t)stream : o->stream;
+  Cam cam{0, 0, 0, 0, 0};
+  Rig rig;
+  memcpy(rig.kbL, camL8, 32);
+  memcpy(rig.kbR, camR8, 32);
+  {  // g2o::SE3Quat(Trl.unit_quaternion().cast<double>(), Trl.translation().cast<double>()) incl. normalisation
+    double q[4] = {Trl7[0], Trl7[1], Trl7[2], Trl7[3]};
+    if (q[3] < 0) for (double& c : q) c = -c;
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; ++i) rig.Trl.q[i] = q[i] / n;
+    for (int i = 0; i < 3; ++i) rig.Trl.t[i] = Trl7[4 + i];
+  }
+  hipLaunchKernelGGL(k_pose_opt<true>, dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
+                     d_nLeft, d_pose, d_outlier, d_nInliers, d_stats);
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
 }

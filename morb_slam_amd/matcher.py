@@ -172,3 +172,19 @@ class ORBmatcher:
             self._h, C.byref(params), npairs, ptr(img1), ptr(img2), cap, ptr(count), ptr(kps), ptr(desc), ptr(prevMatched),
             int(windowSize), self.mfNNratio, 1 if self.mbCheckOrientation else 0, ptr(m12), ptr(nm), self._st(stream)))
         return m12, nm
+
+    def ComputeStereoFishEyeMatches(self, kps, desc, count, mono, camL, camR, Rlr, tlr, levelSigma2, stream=None):
+        """Frame::ComputeStereoFishEyeMatches (left = image 2f, right = image 2f+1).  camL/camR: 8 floats (fx fy cx cy k0..k3);
+        Rlr (3x3), tlr (3): right-to-left rotation / translation.  Returns dict of device tensors."""
+        import torch
+        nimg, cap = kps.shape[0], kps.shape[1]
+        nf = nimg // 2
+        dev = kps.device
+        o = dict(leftToRight=torch.empty((nf, cap), dtype=torch.int32, device=dev), rightToLeft=torch.empty((nf, cap), dtype=torch.int32, device=dev),
+                 depth=torch.empty((nf, cap), dtype=torch.float32, device=dev), p3D=torch.empty((nf, cap, 3), dtype=torch.float32, device=dev),
+                 nMatches=torch.empty((nf,), dtype=torch.int32, device=dev))
+        a = [np.ascontiguousarray(x, np.float32) for x in (camL, camR, Rlr, tlr, levelSigma2)]
+        check(self._L.morb_stereo_fisheye_match_batch(self._h, nf, ptr(kps), ptr(desc), ptr(count), ptr(mono), cap, ptr(a[0]), ptr(a[1]),
+                                                      ptr(a[2]), ptr(a[3]), ptr(a[4]), len(a[4]), ptr(o["leftToRight"]), ptr(o["rightToLeft"]),
+                                                      ptr(o["depth"]), ptr(o["p3D"]), ptr(o["nMatches"]), self._st(stream)))
+        return o

@@ -37,6 +37,22 @@ class Optimizer:
                                                    ptr(out[1]), ptr(out[0]), ptr(out[2]), st))
         return out
 
+    def PoseOptimizationFisheye(self, hasMP, obs, invSigma2, Xw, pose, nLeft, count, camL, camR, Trl, out=None, stream=None):
+        """PoseOptimization for a fisheye rig: features [0, nLeft[f]) left camera, the rest right camera ("ToBody").
+        camL/camR: 8 floats; Trl: 7 floats (quaternion xyzw + translation, left-camera -> right-camera frame)."""
+        import torch
+        F, cap = hasMP.shape
+        if out is None:
+            out = (torch.empty((F,), dtype=torch.int32, device=hasMP.device),
+                   torch.zeros((F, cap), dtype=torch.uint8, device=hasMP.device),
+                   torch.empty((F, 2), dtype=torch.int32, device=hasMP.device))
+        a = [np.ascontiguousarray(x, np.float32) for x in (camL, camR, Trl)]
+        st = None if stream is None else C.c_void_p(stream)
+        check(self._L.morb_pose_optimization_fisheye_batch(self._h, F, cap, ptr(count), ptr(nLeft), ptr(hasMP), ptr(obs), ptr(invSigma2),
+                                                           ptr(Xw), ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(pose), ptr(out[1]), ptr(out[0]),
+                                                           ptr(out[2]), st))
+        return out
+
     def LocalBundleAdjustment(self, kfPose, kfFixed, mpPos, eKF, eMP, eObs, eInvSigma2, cam, inertial=False, stop=False, mode=0):
         """One-shot LocalBundleAdjustment on host numpy arrays; returns (kfPose, mpPos, eraseFlag, stats)."""
         p = BAProblem(self, kfPose, kfFixed, mpPos, eKF, eMP, eObs, eInvSigma2, cam, inertial)

@@ -197,3 +197,86 @@ def _project_many(poses, x, cam):
     u = cam["fx"] * Xc[:, 0] / z + cam["cx"]
     v = cam["fy"] * Xc[:, 1] / z + cam["cy"]
     return u, v, u - cam["bf"] / z, z
+
+
+# ---- fisheye rig (TUM-VI, Examples/Stereo/TUM-VI.yaml) -------------------------------------------------------
+TUMVI_CAM_L = np.array([190.97847715128717, 190.9733070521226, 254.93170605935475, 256.8974428996504,
+                        0.0034823894022493434, 0.0007150348452162257, -0.0020532361418706202, 0.00020293673591811182], np.float32)
+TUMVI_CAM_R = np.array([190.44236969414825, 190.4344384721956, 252.59949716835982, 254.91723064636983,
+                        0.0034003170790442797, 0.001766278153469831, -0.00266312569781606, 0.0003299517423931039], np.float32)
+TUMVI_T_C1_C2 = np.array([[0.999999445773493, 0.000791687752817, 0.000694034010224, 0.101063427414194],
+                          [-0.000823363992158, 0.998899461915674, 0.046895490788700, 0.001946204678584],
+                          [-0.000656143613644, -0.046896036240590, 0.998899560146304, 0.001015350132563],
+                          [0, 0, 0, 1.0]])   # Stereo.T_c1_c2 = Tlr (right-camera coordinates -> left-camera coordinates)
+
+
+def kb8_project(cam, X):
+    """KannalaBrandt8::project in float64 numpy (reference formula) for an [n, 3] array."""
+    x, y, z = X[:, 0], X[:, 1], X[:, 2]
+    th = np.arctan2(np.sqrt(x * x + y * y), z); psi = np.arctan2(y, x)
+    r = th + cam[4] * th ** 3 + cam[5] * th ** 5 + cam[6] * th ** 7 + cam[7] * th ** 9
+    return np.stack([cam[0] * r * np.cos(psi) + cam[2], cam[1] * r * np.sin(psi) + cam[3]], 1)
+
+
+def _quat_from_R(R):
+    w = np.sqrt(max(0.0, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    return np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
+
+
+def make_fisheye_features(n_pairs=600, n_mono=80, n_distract=150, seed=0):
+    """Synthetic fisheye stereo feature sets (no images): n_pairs 3-D points seen by both KB8 cameras with matching
+    descriptors (a few bits flipped), mono-area features in front of the arrays, unmatched distractors behind."""
+    rng = np.random.default_rng(0xF15E + seed)
+    Tlr = TUMVI_T_C1_C2
+    Trl = np.linalg.inv(Tlr)
+    X = np.stack([rng.uniform(-4, 4, n_pairs), rng.uniform(-3, 3, n_pairs), rng.uniform(0.8, 8, n_pairs)], 1)
+    uvL = kb8_project(TUMVI_CAM_L, X) + rng.normal(0, 0.2, (n_pairs, 2))
+    Xr = X @ Trl[:3, :3].T + Trl[:3, 3]
+    uvR = kb8_project(TUMVI_CAM_R, Xr) + rng.normal(0, 0.2, (n_pairs, 2))
+    ok = (uvL > 20).all(1) & (uvL < 492).all(1) & (uvR > 20).all(1) & (uvR < 492).all(1) & (Xr[:, 2] > 0.3)
+    uvL, uvR = uvL[ok], uvR[ok]
+    m = len(uvL)
+    base = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    flip = np.packbits(rng.random((m, 256)) < 0.03, axis=1)
+    dt = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+    def side(uv, desc, nm, nd):
+        n = nm + len(uv) + nd
+        k = np.zeros(n, dt); d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        k["x"] = rng.uniform(20, 492, n); k["y"] = rng.uniform(20, 492, n)
+        k["octave"] = rng.integers(0, 8, n); k["size"] = 31; k["angle"] = rng.uniform(0, 360, n); k["class_id"] = -1
+        perm = rng.permutation(len(uv))
+        k["x"][nm:nm + len(uv)] = uv[perm, 0]; k["y"][nm:nm + len(uv)] = uv[perm, 1]
+        d[nm:nm + len(uv)] = desc[perm]
+        return k, d, nm
+
+    kL, dL, monoL = side(uvL, base, n_mono, n_distract)
+    kR, dR, monoR = side(uvR, base ^ flip, n_mono // 2, n_distract)
+    return dict(kL=kL, dL=dL, monoL=monoL, kR=kR, dR=dR, monoR=monoR, Rlr=Tlr[:3, :3].astype(np.float32),
+                tlr=Tlr[:3, 3].astype(np.float32), camL=TUMVI_CAM_L, camR=TUMVI_CAM_R)
+
+
+def make_pose_problem_fisheye(n_left=400, n_right=300, seed=0, outlier_frac=0.1, rot_deg=2.0, trans=0.05):
+    """PoseOptimization input for the fisheye rig: left-camera and right-camera observations of map points."""
+    rng = np.random.default_rng(0xF0E5 + seed)
+    Trl_m = np.linalg.inv(TUMVI_T_C1_C2)
+    true = np.concatenate([_quat_from_rotvec(rng.normal(0, 0.1, 3)), rng.normal(0, 0.3, 3)])
+    n = n_left + n_right
+    Xc = np.stack([rng.uniform(-4, 4, n), rng.uniform(-3, 3, n), rng.uniform(1, 8, n)], 1)
+    qinv = true[:4] * np.array([-1, -1, -1, 1])
+    Xw = np.array([_quat_rot(qinv, x - true[4:]) for x in Xc])
+    uv = np.zeros((n, 2))
+    uv[:n_left] = kb8_project(TUMVI_CAM_L, Xc[:n_left])
+    Xr = Xc[n_left:] @ Trl_m[:3, :3].T + Trl_m[:3, 3]
+    uv[n_left:] = kb8_project(TUMVI_CAM_R, Xr)
+    octave = rng.integers(0, 8, n); sigma = 1.2 ** octave
+    uv += rng.normal(0, 0.5, (n, 2)) * sigma[:, None]
+    out = rng.random(n) < outlier_frac
+    uv[out] += rng.choice([-1, 1], (out.sum(), 2)) * rng.uniform(15, 40, (out.sum(), 2))
+    dq = _quat_from_rotvec(rng.normal(0, 1, 3) / np.sqrt(3) * np.deg2rad(rot_deg))
+    init = np.concatenate([_quat_mul(dq, true[:4]), _quat_rot(dq, true[4:]) + rng.normal(0, trans, 3)])
+    obs = np.concatenate([uv, np.zeros((n, 1))], 1).astype(np.float32)
+    Trl7 = np.concatenate([_quat_from_R(Trl_m[:3, :3]), Trl_m[:3, 3]]).astype(np.float32)
+    return dict(hasMP=(rng.random(n) < 0.92).astype(np.uint8), obs=obs, invSigma2=(1 / sigma ** 2).astype(np.float32),
+                Xw=Xw.astype(np.float32), pose0=init.astype(np.float32), true=true, Nleft=n_left, camL=TUMVI_CAM_L, camR=TUMVI_CAM_R,
+                Trl=Trl7)

@@ -21,6 +21,7 @@
 #include <limits>
 #include <vector>
 
+#include "matcher.h"
 #include "orb_oracle.h"
 
 namespace orc {
@@ -128,7 +129,7 @@ static SE3Quat fromFloatPose(const float p[7]) {  // g2o::SE3Quat(Tcw.unit_quate
   return s;
 }
 
-enum { KIND_MONO = 0, KIND_STEREO = 1 };
+enum { KIND_MONO = 0, KIND_STEREO = 1, KIND_KB8_LEFT = 2, KIND_KB8_RIGHT = 3 };  // 2/3: fisheye rig (left camera / right camera 'ToBody')
 
 struct Edge {
   int kind, pose, point;
@@ -149,6 +150,8 @@ struct Graph {
   std::vector<char> pointFixed;             // unary edges = binary edges to a fixed point
   std::vector<Edge> edges;
   Camera cam;
+  orc::kb8::Cam kbL, kbR;   // fisheye rig cameras (KIND_KB8_*)
+  SE3Quat Trl;              // mTrl: left-camera frame -> right-camera frame
   bool unaryForm = false;  // use the "...OnlyPose" Jacobian formulas (types_six_dof_expmap.cpp:375-403)
   // solver state
   std::vector<int> poseCol, pointCol, active;
@@ -163,7 +166,10 @@ struct Graph {
   int dim(const Edge& e) const { return e.kind == KIND_STEREO ? 3 : 2; }
 
   void project(const Edge& e, const double xc[3], double out[3]) const {
-    if (e.kind == KIND_MONO) {  // Pinhole::project(Vector3d), Pinhole.cpp:38-44 (float parameters in double math)
+    if (e.kind == KIND_KB8_LEFT || e.kind == KIND_KB8_RIGHT) {  // KannalaBrandt8::project(Vector3d)
+      orc::kb8::projectD(e.kind == KIND_KB8_LEFT ? kbL : kbR, xc, out);
+      out[2] = 0;
+    } else if (e.kind == KIND_MONO) {  // Pinhole::project(Vector3d), Pinhole.cpp:38-44 (float parameters in double math)
       out[0] = (double)cam.fx * xc[0] / xc[2] + (double)cam.cx;
       out[1] = (double)cam.fy * xc[1] / xc[2] + (double)cam.cy;
       out[2] = 0;
@@ -176,7 +182,8 @@ struct Graph {
   }
   void computeError(Edge& e) const {
     double xc[3], pr[3];
-    mapPoint(poses[e.pose], &points[3 * e.point], xc);
+    if (e.kind == KIND_KB8_RIGHT) mapPoint(mul(Trl, poses[e.pose]), &points[3 * e.point], xc);  // (mTrl * T).map(Xw)
+    else mapPoint(poses[e.pose], &points[3 * e.point], xc);
     project(e, xc, pr);
     for (int i = 0; i < dim(e); ++i) e.err[i] = e.obs[i] - pr[i];
   }
@@ -214,7 +221,27 @@ struct Graph {
     const double x = xc[0], y = xc[1], z = xc[2];
     double R[9];
     toRotationMatrix(T.q, R);
-    if (e.kind == KIND_MONO) {
+    if (e.kind == KIND_KB8_LEFT || e.kind == KIND_KB8_RIGHT) {
+      // OptimizableTypes.cpp:49-62 (left) / :88-104 (right: -projectJac(X_r) * R_rl * SE3deriv(X_l))
+      const double D[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+      double pj[6], M[9];
+      if (e.kind == KIND_KB8_LEFT) {
+        orc::kb8::projectJac(kbL, xc, pj);
+        for (int i = 0; i < 9; ++i) M[i] = (i % 4 == 0) ? 1.0 : 0.0;
+      } else {
+        double xr[3];
+        mapPoint(Trl, xc, xr);
+        orc::kb8::projectJac(kbR, xr, pj);
+        toRotationMatrix(Trl.q, M);
+      }
+      double pjM[6];
+      for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 3; ++c) pjM[r * 3 + c] = pj[r * 3] * M[c] + pj[r * 3 + 1] * M[3 + c] + pj[r * 3 + 2] * M[6 + c];
+      for (int r = 0; r < 2; ++r) {
+        for (int c = 0; c < 6; ++c) Jp[r * 6 + c] = -(pjM[r * 3] * D[c] + pjM[r * 3 + 1] * D[6 + c] + pjM[r * 3 + 2] * D[12 + c]);
+        for (int c = 0; c < 3; ++c) Jl[r * 3 + c] = -(pjM[r * 3] * R[c] + pjM[r * 3 + 1] * R[3 + c] + pjM[r * 3 + 2] * R[6 + c]);
+      }
+    } else if (e.kind == KIND_MONO) {
       // -projectJac * SE3deriv and -projectJac * R  (OptimizableTypes.cpp:49-62, :134-156; Pinhole.cpp:73-83)
       const double fx = cam.fx, fy = cam.fy;
       const double pj[6] = {fx / z, 0.0, -fx * x / (z * z), 0.0, fy / z, -fy * y / (z * z)};
@@ -532,6 +559,66 @@ int orc_pose_optimization(int n, const uint8_t* hasMP, const float* obs, const f
       const float chi2 = (float)g.chi2(e);
       const float th = e.kind == KIND_MONO ? chi2Mono[it] : chi2Stereo[it];
       if (chi2 > th) { outlier[idx] = 1; e.level = 1; nBad++; }
+      else { outlier[idx] = 0; e.level = 0; }
+      if (it == 2) e.delta = 0;
+    }
+    if (g.edges.size() < 10) break;
+  }
+  if (stats) stats[1] = g.levenbergIterations;
+  for (int i = 0; i < 4; ++i) pose[i] = (float)g.poses[0].q[i];
+  for (int i = 0; i < 3; ++i) pose[4 + i] = (float)g.poses[0].t[i];
+  return nInitialCorrespondences - nBad;
+}
+
+// Optimizer::PoseOptimization for a fisheye rig (pFrame->mpCamera2 != NULL, Optimizer.cc:880-946): feature i < Nleft is a
+// left-camera observation (EdgeSE3ProjectXYZOnlyPose, KB8 left), i >= Nleft a right-camera one
+// (EdgeSE3ProjectXYZOnlyPoseToBody, KB8 right, mTrl).  obs = (x, y) per feature.
+int orc_pose_optimization_fisheye(int n, int Nleft, const uint8_t* hasMP, const float* obs, const float* invSigma2,
+                                  const float* Xw, const float* camL8, const float* camR8, const float* Trl7, float* pose,
+                                  uint8_t* outlier, int* stats) {
+  Graph g;
+  g.cam = Camera{0, 0, 0, 0, 0};
+  memcpy(g.kbL.p, camL8, 32); memcpy(g.kbR.p, camR8, 32);
+  g.Trl = fromFloatPose(Trl7);
+  g.unaryForm = true;
+  g.poses.push_back(fromFloatPose(pose));
+  g.poseFixed.push_back(0);
+  const float deltaMono = (float)std::sqrt(5.991);
+  std::vector<int> featOfEdge;
+  int nInitialCorrespondences = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!hasMP[i]) continue;
+    nInitialCorrespondences++;
+    outlier[i] = 0;
+    Edge e;
+    memset(&e, 0, sizeof e);
+    e.kind = i < Nleft ? KIND_KB8_LEFT : KIND_KB8_RIGHT;
+    e.pose = 0;
+    e.point = (int)g.points.size() / 3;
+    e.obs[0] = (double)obs[2 * i]; e.obs[1] = (double)obs[2 * i + 1];
+    for (int k = 0; k < 3; ++k) g.points.push_back((double)Xw[3 * i + k]);
+    g.pointFixed.push_back(1);
+    e.info = (double)invSigma2[i];
+    e.delta = (double)deltaMono;
+    g.edges.push_back(e);
+    featOfEdge.push_back(i);
+  }
+  if (stats) stats[0] = stats[1] = 0;
+  if (nInitialCorrespondences < 3) return 0;
+  const SE3Quat initial = g.poses[0];
+  int nBad = 0;
+  for (size_t it = 0; it < 4; it++) {
+    g.poses[0] = initial;
+    g.initializeOptimization(0);
+    const int its = g.optimize(10);
+    if (stats) stats[0] += its;
+    nBad = 0;
+    for (size_t k = 0; k < g.edges.size(); ++k) {
+      Edge& e = g.edges[k];
+      const int idx = featOfEdge[k];
+      if (outlier[idx]) g.computeError(e);
+      const float chi2 = (float)g.chi2(e);
+      if (chi2 > 5.991f) { outlier[idx] = 1; e.level = 1; nBad++; }
       else { outlier[idx] = 0; e.level = 0; }
       if (it == 2) e.delta = 0;
     }

@@ -79,6 +79,17 @@ int orc_search_for_triangulation(int n1, const orc_keypoint* kps1, const uint8_t
                                  const orc_keypoint* kps2, const uint8_t* desc2, const int* node2, const uint8_t* hasMP2,
                                  const float* uRight2, const float* sigma2_2, const float* scaleFactors2, const float* F12,
                                  const float* ep, int bOnlyStereo, int bCoarse, int checkOri, int* matches12);
+void orc_kb8_project_f(const float* cam8, const float* v3, float* uv);
+void orc_kb8_project_d(const float* cam8, const double* v3, double* uv);
+void orc_kb8_unproject(const float* cam8, float x, float y, float* ray);
+void orc_kb8_project_jac(const float* cam8, const double* v3, double* J6);
+int orc_stereo_fisheye_matches(int Nleft, int monoLeft, const orc_keypoint* kpsL, const uint8_t* descL, int Nright,
+                               int monoRight, const orc_keypoint* kpsR, const uint8_t* descR, const float* camL8,
+                               const float* camR8, const float* Rlr, const float* tlr, const float* levelSigma2,
+                               int* leftToRight, int* rightToLeft, float* depth, float* p3D);
+int orc_pose_optimization_fisheye(int n, int Nleft, const uint8_t* hasMP, const float* obs, const float* invSigma2,
+                                  const float* Xw, const float* camL8, const float* camR8, const float* Trl7, float* pose,
+                                  uint8_t* outlier, int* stats);
 float orc_fast_atan2(float y, float x);
 float orc_cosf(float x);
 float orc_sinf(float x);

@@ -283,3 +283,27 @@ def search_for_initialization(k1, d1, F2, prev, windowSize, nnratio, checkOri):
     k1 = np.ascontiguousarray(k1); d1 = np.ascontiguousarray(d1)
     r = L.orc_search_for_initialization(len(k1), _p(k1), _p(d1), C.byref(F2), _p(pv), int(windowSize), nnratio, int(checkOri), _p(m))
     return r, m, pv
+
+
+def stereo_fisheye_matches(fe, sigma2):
+    L = lib()
+    L.orc_stereo_fisheye_matches.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 11
+    nl, nr = len(fe["kL"]), len(fe["kR"])
+    l2r = np.zeros(nl, np.int32); r2l = np.zeros(nr, np.int32); dep = np.zeros(nl, np.float32); p3 = np.zeros((nl, 3), np.float32)
+    a = [np.ascontiguousarray(x) for x in (fe["kL"], fe["dL"], fe["kR"], fe["dR"], fe["camL"], fe["camR"], fe["Rlr"], fe["tlr"],
+                                           np.asarray(sigma2, np.float32))]
+    n = L.orc_stereo_fisheye_matches(nl, fe["monoL"], _p(a[0]), _p(a[1]), nr, fe["monoR"], _p(a[2]), _p(a[3]), _p(a[4]), _p(a[5]),
+                                     _p(a[6]), _p(a[7]), _p(a[8]), _p(l2r), _p(r2l), _p(dep), _p(p3))
+    return n, l2r, r2l, dep, p3
+
+
+def pose_optimization_fisheye(p):
+    L = lib()
+    L.orc_pose_optimization_fisheye.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 10
+    n = len(p["hasMP"])
+    pose = p["pose0"].astype(np.float32).copy(); outl = np.zeros(n, np.uint8); stats = np.zeros(2, np.int32)
+    obs2 = np.ascontiguousarray(p["obs"][:, :2], np.float32)
+    a = [np.ascontiguousarray(p[k]) for k in ("hasMP", "invSigma2", "Xw", "camL", "camR", "Trl")]
+    r = L.orc_pose_optimization_fisheye(n, p["Nleft"], _p(a[0]), _p(obs2), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), _p(a[5]), _p(pose),
+                                        _p(outl), _p(stats))
+    return r, pose, outl, stats
