@@ -61,18 +61,30 @@ def make_batch(global_ids, total, seed=0):
 
 def cpu_baseline(target_s=12.0):
     """The CPU oracle ("port": an OpenCV-free restatement, not the OpenCV-backed binary) timed on this host's
-    cores, frame-parallel, on a bounded sample of the same workload."""
+    cores, frame-parallel, on a bounded sample of the SAME per-frame workload as the GPU step: ORBextractor x2 +
+    ComputeStereoMatches + ComputeBoW + SearchByBoW against the previous frame."""
     from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle_lib import OracleExtractor
+    import oracle_lib as O
+    from morb_slam_amd.synth import make_vocabulary
     cores = os.cpu_count() or 1
     frames = make_batch(range(4), 4, seed=99)
-    exts = [(OracleExtractor(NFEAT), OracleExtractor(NFEAT)) for _ in range(cores)]
+    vd, vf = make_vocabulary(10, 6, seed=0)
+    mbf, mb = np.float32(458.654 * 0.11), np.float32(0.11)
+    exts = [(O.OracleExtractor(NFEAT), O.OracleExtractor(NFEAT)) for _ in range(cores)]
+    prev = [None] * cores
+    rng = np.random.default_rng(7)
 
     def work(i):
         l, r = exts[i]
         f = frames[i % len(frames)]
-        l(f[0]); r(f[1])     # the reference runs the two eyes on two threads (Frame.cc:194-197); here a core does both
+        _, kl, dl = l(f[0]); _, kr, dr = r(f[1])     # the reference runs the two eyes on two threads (Frame.cc:194-197); here one core does both
+        O.stereo_matches(l, r, kl, dl, kr, dr, mbf, mb)
+        _, node = O.bow_transform(dl, vd, vf, 10, 6, 4)
+        if prev[i] is not None:
+            pk, pd, pn, has = prev[i]
+            O.search_by_bow(pd, pk["angle"], has, pn, dl, kl["angle"], node, 0.7, True)
+        prev[i] = (kl, dl, node, (rng.random(len(kl)) < 0.8))
         return 1
 
     done, t0 = 0, time.perf_counter()
@@ -81,7 +93,8 @@ def cpu_baseline(target_s=12.0):
             done += sum(ex.map(work, range(cores)))
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "stereo frames/s", "cores": cores, "kind": "port",
-            "sample": f"{done} stereo 752x480 frames, 1200 features, oracle extract x2 (frame-parallel on {cores} threads)"}
+            "sample": f"{done} stereo 752x480 frames, 1200 features: oracle extract x2 + stereo match + BoW descent + "
+                      f"SearchByBoW (frame-parallel on {cores} threads)"}
 
 
 def optimizer_extras(dev_index):

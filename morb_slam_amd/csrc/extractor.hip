@@ -277,8 +277,9 @@ __global__ __launch_bounds__(256) void k_fast(const LevelGeom* __restrict__ geom
   // flat indices over the window / the evaluated area, split into (row, column) with a multiply-high by
   // ceil(2^32 / width): every lane of every wave has work (a 64-lane row layout would idle ~40 % of the lanes
   // on these 36..44-pixel-wide cells)
-  const unsigned twMagic = (unsigned)((0x100000000ull + (unsigned)tw - 1) / (unsigned)tw);
-  const unsigned ewMagic = (unsigned)((0x100000000ull + (unsigned)ew - 1) / (unsigned)ew);
+  // ceil(2^32 / w) with one 32-bit division (w >= 1 here; exact for every index < 2^16)
+  const unsigned twMagic = 0xFFFFFFFFu / (unsigned)tw + 1u;
+  const unsigned ewMagic = 0xFFFFFFFFu / (unsigned)ew + 1u;
   for (int i = tid; i < th * tw; i += 256) {
     const int r = (int)__umulhi((unsigned)i, twMagic), c = i - r * tw;
     tile[r * tilePitch + c] = base[(size_t)r * g.pstride + c];
