@@ -118,3 +118,24 @@ def test_batch_matches_single():
         kg = kps[i, :cnt[i]].reshape(-1).view(KP_DTYPE)
         assert kg.tobytes() == ko.tobytes()
         np.testing.assert_array_equal(desc[i, :cnt[i]], do)
+
+
+def test_two_extractors_on_two_threads():
+    # Frame::Frame runs the left and right extractor on two std::threads (Frame.cc:194-197): two handles, concurrent calls
+    import threading
+    left, right = make_stereo_pair(752, 480, seed=77)
+    from morb_slam_amd import ORBextractor
+    from oracle_lib import OracleExtractor
+    gl, gr = ORBextractor(1200, 1.2, 8, 20, 7), ORBextractor(1200, 1.2, 8, 20, 7)
+    res = {}
+
+    def run(name, g, img):
+        for _ in range(5):
+            res[name] = g(img, None, (0, 0))
+
+    th = [threading.Thread(target=run, args=("l", gl, left)), threading.Thread(target=run, args=("r", gr, right))]
+    [t.start() for t in th]; [t.join() for t in th]
+    for name, img in (("l", left), ("r", right)):
+        mo, ko, do = OracleExtractor(1200)(img)
+        mg, kg, dg = res[name]
+        assert mg == mo and kg.tobytes() == ko.tobytes() and np.array_equal(dg, do)
