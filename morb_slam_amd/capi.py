@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "libmorb_hip.so")
+# MORB_HIP_LIB selects another build of the same HIP library (the phase-timing build of tools/fast_phases.py); never a CPU path
+LIB_PATH = os.environ.get("MORB_HIP_LIB") or os.path.join(_DIR, "libmorb_hip.so")
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])

@@ -236,10 +236,34 @@ __device__ __forceinline__ int fast_strength(const uint8_t* __restrict__ p, int 
   return imax(A, -B);
 }
 
-__global__ __launch_bounds__(256) void k_fast(const LevelGeom* __restrict__ geom, int nlevels,
+#ifdef MORB_FAST_TIMING
+__device__ unsigned long long g_fastPhase[8];
+#define PHASE_MARK(k) do { __syncthreads(); if (threadIdx.x == 0 && ((blockIdx.x * 7 + blockIdx.y) & 63) == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_fastPhase[k], now_ - t0_); t0_ = now_; } } while (0)
+extern "C" int morb_fast_timing(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[8] = {0}; MORB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fastPhase), z, sizeof(z))); return 0; }
+  MORB_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fastPhase), 8 * sizeof(unsigned long long)));
+  return 0;
+}
+#else
+#define PHASE_MARK(k)
+#endif
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {   // v_pk_min_u16
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {   // v_pk_max_u16
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+
+constexpr int FAST_LD = 6;    // dwords per thread for the window: 256 * 6 * 4 bytes covers the largest one (checked in configure())
+
+// PMC (profiles/r01): the kernel is VALU-issue bound (~90 % of SIMD cycles issue VALU), not memory bound, so the
+// design rule is instruction count: no integer divisions (host-side magics in FastGeom / kernel arguments), SWAR
+// for the reject test, exact strength only for survivors.
+__global__ __launch_bounds__(256) void k_fast(const morb::FastGeom fg, int nlevels,
                                               const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
                                               int* __restrict__ candCnt, int totalCells, int cellCap, int tilePitch,
-                                              int tileRows, int iniTh, int minTh) {
+                                              int tileRows, unsigned gMagic, int iniTh, int minTh) {
   extern __shared__ __align__(16) uint8_t smem[];
   uint8_t* tile = smem;                           // [tileRows][tilePitch]
   uint8_t* sc = smem + tileRows * tilePitch;      // [tileRows][tilePitch] strength, 0 where it cannot matter
@@ -249,139 +273,197 @@ __global__ __launch_bounds__(256) void k_fast(const LevelGeom* __restrict__ geom
   int* rowCnt = reinterpret_cast<int*>(bmLo + tileRows * 8);                       // [tileRows + 1]
   __shared__ int qn;
 
-  int l = 0;
-  while (l + 1 < nlevels && (int)blockIdx.x >= geom[l + 1].cellBase) ++l;
-  const LevelGeom g = geom[l];
-  const int cell = blockIdx.x - g.cellBase;
-  const int ci = cell / g.nCols, cj = cell % g.nCols;
+#ifdef MORB_FAST_TIMING
+  unsigned long long t0_ = wall_clock64();
+#endif
   const int img = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int tmin = imin(iniTh, minTh);
+  const uint64_t ltmask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const int G = tilePitch >> 2;                         // dwords per window row in LDS; gMagic = ceil(2^32 / G)
   const size_t cellSlot = (size_t)img * totalCells + blockIdx.x;
 
-  const int iniX = MINB + cj * g.wCell, iniY = MINB + ci * g.hCell;
-  int maxX = iniX + g.wCell + 6, maxY = iniY + g.hCell + 6;
-  if (iniY >= g.maxBorderY - 3 || iniX >= g.maxBorderX - 6) {  // :770, :775
-    if (tid == 0) candCnt[cellSlot] = 0;
-    return;
-  }
-  maxX = imin(maxX, g.maxBorderX);
-  maxY = imin(maxY, g.maxBorderY);
-  const int tw = maxX - iniX, th = maxY - iniY;
+  // the cell's level and geometry: scalar loads from the kernarg segment, no dependent global-memory round trip
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < kMaxLevels; ++k) l += (k < nlevels && (int)blockIdx.x >= fg.cellBase[k]) ? 1 : 0;   // cellBase is increasing
+  struct { int ci, cj, wCell, hCell; } c;
+  const int cell = blockIdx.x - fg.cellBase[l];
+  c.ci = (int)__umulhi((unsigned)cell, fg.nColsMagic[l]); c.cj = cell - c.ci * fg.nCols[l];
+  c.wCell = fg.wCell[l]; c.hCell = fg.hCell[l];
+  const int pstride = fg.pstride[l], mbx = fg.maxBorderX[l], mby = fg.maxBorderY[l];
+  const int iniX = MINB + c.cj * c.wCell, iniY = MINB + c.ci * c.hCell;
+  const int tw = imin(iniX + c.wCell + 6, mbx) - iniX, th = imin(iniY + c.hCell + 6, mby) - iniY;
   const int ew = tw - 6, eh = th - 6;  // evaluated area: x in [3, tw-3), y in [3, th-3)
-  if (ew <= 0 || eh <= 0) {
+  if (iniY >= mby - 3 || iniX >= mbx - 6 || ew <= 0 || eh <= 0) {  // :770, :775
     if (tid == 0) candCnt[cellSlot] = 0;
     return;
   }
-  // thread layout: 64 lanes along x, 4 waves along y (no integer division anywhere below)
-  const uint8_t* base = pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)(EDGE + iniY) * g.pstride + EDGE + iniX;
-  // flat indices over the window / the evaluated area, split into (row, column) with a multiply-high by
-  // ceil(2^32 / width): every lane of every wave has work (a 64-lane row layout would idle ~40 % of the lanes
-  // on these 36..44-pixel-wide cells)
-  // ceil(2^32 / w) with one 32-bit division (w >= 1 here; exact for every index < 2^16)
-  const unsigned twMagic = 0xFFFFFFFFu / (unsigned)tw + 1u;
-  const unsigned ewMagic = 0xFFFFFFFFu / (unsigned)ew + 1u;
-  for (int i = tid; i < th * tw; i += 256) {
-    const int r = (int)__umulhi((unsigned)i, twMagic), c = i - r * tw;
-    tile[r * tilePitch + c] = base[(size_t)r * g.pstride + c];
-    sc[r * tilePitch + c] = 0;
-  }
-  for (int i = tid; i < th * 8; i += 256) { bmHi[i] = 0; bmLo[i] = 0; }
-  if (tid == 0) qn = 0;
-  __syncthreads();
-
-  // Phase 1 — cheap reject.  Every 9-arc of the 16-pixel ring contains at least two of the four compass pixels
-  // (0, 4, 8, 12), so a pixel can only exceed strength tmin if >= 2 compass pixels are darker than v - tmin or
-  // >= 2 are brighter than v + tmin.  Pixels that fail keep strength 0: they are corners at neither threshold
-  // and count as score 0 in their neighbours' NMS, exactly like cv::FAST's score buffer.
-  const int tmin = imin(iniTh, minTh);
-  const int nEval = ew * eh;
-  const uint64_t ltmask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  for (int i0 = 0; i0 < nEval; i0 += 256) {
-    const int i = i0 + tid;
-    bool possible = false;
-    int x = 0, y = 0;
-    if (i < nEval) {
-      const int ry = (int)__umulhi((unsigned)i, ewMagic);
-      y = ry + 3; x = i - ry * ew + 3;
-      const uint8_t* p = tile + y * tilePitch + x;
-      const int v = p[0];
-      const int d0 = v - p[3 * tilePitch], d4 = v - p[3], d8 = v - p[-3 * tilePitch], d12 = v - p[-3];
-      const int nd = (d0 > tmin) + (d4 > tmin) + (d8 > tmin) + (d12 > tmin);
-      const int nb = (d0 < -tmin) + (d4 < -tmin) + (d8 < -tmin) + (d12 < -tmin);
-      possible = nd >= 2 || nb >= 2;
-    }
-    const uint64_t m = __ballot(possible);
-    if (m) {
-      int qbase = 0;
-      if (lane == 0) qbase = atomicAdd(&qn, __popcll(m));
-      qbase = __shfl(qbase, 0, 64);
-      if (possible) queue[qbase + __popcll(m & ltmask)] = (uint16_t)((y << 8) | x);
-    }
-  }
-  __syncthreads();
-  // Phase 2 — exact strength for the survivors only, densely packed over the workgroup
-  const int nq = qn;
-  for (int q = tid; q < nq; q += 256) {
-    const int e = queue[q];
-    const int y = e >> 8, x = e & 255;
-    const int s = fast_strength(tile + y * tilePitch + x, tilePitch);
-    sc[y * tilePitch + x] = (uint8_t)(s > tmin ? imin(s, 255) : 0);
-  }
-  __syncthreads();
-
-  // Phase 3 — NMS at both thresholds, only for pixels that have a strength; results go to per-row bitmaps.
-  // corner at t iff S > t, score S - 1, non-corner neighbours score 0; keep iff strictly greater than all 8.
-  for (int q = tid; q < nq; q += 256) {
-    const int e = queue[q];
-    const int y = e >> 8, x = e & 255;
-    const uint8_t* c = sc + y * tilePitch + x;
-    const int S = c[0];
-    if (S == 0) continue;
-    bool kh = S > iniTh, kl = S > minTh;
+  const uint8_t* base = pyr + fg.pyrOff[l] + (size_t)img * fg.pyrImg[l] + (size_t)(EDGE + iniY) * pstride + EDGE + iniX;
+  {
+    // Window -> LDS as (unaligned) dwords, th rows of the full LDS pitch: every load of a thread is issued before its
+    // first LDS store and there are no per-lane branches (an index past the window re-reads its last dword), so the
+    // block pays one global-load latency.  Columns >= tw are never evaluated; they lie in the padded pyramid row or
+    // the next one (the slab has 256 bytes of slack behind it).
+    const int nD = th * G;
+    uint32_t v[FAST_LD]; int off[FAST_LD];
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
+    for (int k = 0; k < FAST_LD; ++k) {
+      const int i = imin(tid + k * 256, nD - 1);
+      const int r = (int)__umulhi((unsigned)i, gMagic), c4 = (i - r * G) << 2;
+      off[k] = r * tilePitch + c4;
+      v[k] = *reinterpret_cast<const uint32_t*>(base + (size_t)r * pstride + c4);
+    }
 #pragma unroll
-      for (int dx = -1; dx <= 1; ++dx) {
-        if (dx == 0 && dy == 0) continue;
-        const int Sn = c[dy * tilePitch + dx];
-        kh = kh && (S - 1 > (Sn > iniTh ? Sn - 1 : 0));
-        kl = kl && (S - 1 > (Sn > minTh ? Sn - 1 : 0));
+    for (int k = 0; k < FAST_LD; ++k) {
+      *reinterpret_cast<uint32_t*>(tile + off[k]) = v[k];
+      *reinterpret_cast<uint32_t*>(sc + off[k]) = 0u;
+    }
+    for (int i = tid; i < th * 8; i += 256) { bmHi[i] = 0; bmLo[i] = 0; }
+    if (tid == 0) qn = 0;
+  }
+  __syncthreads();
+  PHASE_MARK(0);
+  {
+    // Phase 1 — cheap reject.  Every 9-arc of the 16-pixel ring contains at least two of the four compass pixels
+    // (0, 4, 8, 12), so a pixel can only exceed strength tmin if >= 2 compass pixels are darker than v - tmin or
+    // >= 2 are brighter than v + tmin, i.e. the second smallest compass value < v - tmin or the second largest
+    // > v + tmin.  Pixels that fail keep strength 0: they are corners at neither threshold and count as score 0 in
+    // their neighbours' NMS, exactly like cv::FAST's score buffer.
+    // Four pixels per lane: the window row is read as aligned dwords (centre, the dwords left and right of it, the
+    // rows 3 above / below), bytes are split into even / odd 16-bit lanes, the second smallest / largest come from a
+    // packed-u16 min/max network, and bit 15 of (0x8000 + a - b - 1) says "a > b" for two pixels at once.
+    const int nGroups = eh * G;
+    const unsigned K = 0x80008000u, LO = 0x00FF00FFu;
+    const unsigned T1 = (unsigned)(tmin + 1) * 0x00010001u;
+    for (int i0 = 0; i0 < nGroups; i0 += 256) {
+      const int i = i0 + tid;
+      unsigned re = 0, ro = 0;   // bit 15 / 31: pixel may exceed tmin (even bytes, odd bytes)
+      int x4 = 0, y = 0;
+      if (i < nGroups) {
+        const int ry = (int)__umulhi((unsigned)i, gMagic);
+        y = ry + 3; const int gi = i - ry * G; x4 = gi << 2;
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(tile + y * tilePitch);
+        const uint32_t C = row[gi];
+        const uint32_t Lw = gi > 0 ? row[gi - 1] : 0u, Rw = gi + 1 < G ? row[gi + 1] : 0u;
+        const uint32_t U = reinterpret_cast<const uint32_t*>(tile + (y - 3) * tilePitch)[gi];   // ring pixel 8 (0,-3)
+        const uint32_t D = reinterpret_cast<const uint32_t*>(tile + (y + 3) * tilePitch)[gi];   // ring pixel 0 (0,+3)
+        const uint32_t L = __builtin_amdgcn_alignbyte(C, Lw, 1);                                 // ring pixel 12 (-3,0)
+        const uint32_t R = __builtin_amdgcn_alignbyte(Rw, C, 3);                                 // ring pixel 4 (+3,0)
+        unsigned res[2];
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+          const unsigned Ve = (par ? (C >> 8) : C) & LO;
+          const unsigned a = (par ? (U >> 8) : U) & LO, b = (par ? (D >> 8) : D) & LO;
+          const unsigned cc = (par ? (L >> 8) : L) & LO, d = (par ? (R >> 8) : R) & LO;
+          const unsigned lo1 = pk_min(a, b), hi1 = pk_max(a, b), lo2 = pk_min(cc, d), hi2 = pk_max(cc, d);
+          const unsigned mlo = pk_max(lo1, lo2), mhi = pk_min(hi1, hi2);
+          const unsigned s2 = pk_min(mlo, mhi);      // second smallest of the four
+          const unsigned l2 = pk_max(mlo, mhi);      // second largest
+          const unsigned dark = ((Ve | K) - T1) - s2;        // bit 15: v - s2 >= tmin + 1
+          const unsigned bright = (l2 | K) - (Ve + T1);      // bit 15: l2 - v >= tmin + 1
+          res[par] = (dark | bright) & K;
+        }
+        re = res[0]; ro = res[1];
+        // only pixels of the evaluated area count (byte k of the dword is pixel x4 + k: even-lo, odd-lo, even-hi, odd-hi)
+        const int lim = tw - 3;   // first x outside
+        if (x4 + 0 < 3 || x4 + 0 >= lim) re &= 0xFFFF0000u;
+        if (x4 + 1 < 3 || x4 + 1 >= lim) ro &= 0xFFFF0000u;
+        if (x4 + 2 < 3 || x4 + 2 >= lim) re &= 0x0000FFFFu;
+        if (x4 + 3 >= lim) ro &= 0x0000FFFFu;
       }
-    if (kh) atomicOr(&bmHi[y * 8 + (x >> 5)], 1u << (x & 31));
-    if (kl) atomicOr(&bmLo[y * 8 + (x >> 5)], 1u << (x & 31));
+      const uint64_t m0 = __ballot(re & 0x8000u), m1 = __ballot(ro & 0x8000u), m2 = __ballot(re >> 31), m3 = __ballot(ro >> 31);
+      const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
+      const int total = c0 + c1 + c2 + c3;
+      if (total) {
+        int qbase = 0;
+        if (lane == 0) qbase = atomicAdd(&qn, total);
+        qbase = __shfl(qbase, 0, 64);
+        const uint16_t e = (uint16_t)((y << 8) | x4);
+        if (re & 0x8000u) queue[qbase + __popcll(m0 & ltmask)] = e;
+        if (ro & 0x8000u) queue[qbase + c0 + __popcll(m1 & ltmask)] = (uint16_t)(e + 1);
+        if (re >> 31) queue[qbase + c0 + c1 + __popcll(m2 & ltmask)] = (uint16_t)(e + 2);
+        if (ro >> 31) queue[qbase + c0 + c1 + c2 + __popcll(m3 & ltmask)] = (uint16_t)(e + 3);
+      }
+    }
   }
-  __syncthreads();
-  // Phase 4 — vKeysCell.empty() -> second cv::FAST with minThFAST (:795); row prefix sums of the chosen bitmap
-  unsigned anyBits = 0;
-  for (int i = tid; i < th * 8; i += 256) anyBits |= bmHi[i];
-  const int anyHi = __syncthreads_or(anyBits != 0);
-  const uint32_t* bm = anyHi ? bmHi : bmLo;
-  if (tid < th) {
-    int c = 0;
+  {
+    __syncthreads();
+    PHASE_MARK(1);
+    // Phase 2 — exact strength for the survivors only, densely packed over the workgroup
+    const int nq = qn;
+    for (int q = tid; q < nq; q += 256) {
+      const int e = queue[q];
+      const int y = e >> 8, x = e & 255;
+      const int s = fast_strength(tile + y * tilePitch + x, tilePitch);
+      sc[y * tilePitch + x] = (uint8_t)(s > tmin ? imin(s, 255) : 0);
+    }
+    __syncthreads();
+    PHASE_MARK(2);
+
+    // Phase 3 — NMS at both thresholds, only for pixels that have a strength; results go to per-row bitmaps.
+    // corner at t iff S > t, score S - 1, non-corner neighbours score 0; keep iff strictly greater than all 8.
+    for (int q = tid; q < nq; q += 256) {
+      const int e = queue[q];
+      const int y = e >> 8, x = e & 255;
+      const uint8_t* c = sc + y * tilePitch + x;
+      const int S = c[0];
+      if (S == 0) continue;
+      bool kh = S > iniTh, kl = S > minTh;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) c += __popc(bm[tid * 8 + w]);
-    rowCnt[tid] = c;
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          if (dx == 0 && dy == 0) continue;
+          const int Sn = c[dy * tilePitch + dx];
+          kh = kh && (S - 1 > (Sn > iniTh ? Sn - 1 : 0));
+          kl = kl && (S - 1 > (Sn > minTh ? Sn - 1 : 0));
+        }
+      if (kh) atomicOr(&bmHi[y * 8 + (x >> 5)], 1u << (x & 31));
+      if (kl) atomicOr(&bmLo[y * 8 + (x >> 5)], 1u << (x & 31));
+    }
+    __syncthreads();
+    PHASE_MARK(3);
+    // Phase 4 — vKeysCell.empty() -> second cv::FAST with minThFAST (:795); row prefix sums of the chosen bitmap
+    unsigned anyBits = 0;
+    for (int i = tid; i < th * 8; i += 256) anyBits |= bmHi[i];
+    const int anyHi = __syncthreads_or(anyBits != 0);
+    const uint32_t* bm = anyHi ? bmHi : bmLo;
+    if (tid < th) {
+      int c = 0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) c += __popc(bm[tid * 8 + w]);
+      rowCnt[tid] = c;
+    }
+    __syncthreads();
+    if (tid < 64) {   // exclusive scan of the row counts by one wave, ceil(th / 64) consecutive rows per lane
+      const int per = (th + 63) >> 6, r0 = tid * per, r1 = imin(r0 + per, th);
+      int c = 0;
+      for (int r = r0; r < r1; ++r) c += rowCnt[r];
+      int inc = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+      int acc = inc - c;
+      for (int r = r0; r < r1; ++r) { const int cr = rowCnt[r]; rowCnt[r] = acc; acc += cr; }
+      if (r0 < th && r1 == th) rowCnt[th] = acc;
+    }
+    __syncthreads();
+    PHASE_MARK(4);
+    // Phase 5 — ordered output (row-major over the evaluated area): slot = row prefix + set bits to the left
+    uint32_t* out = cand + cellSlot * (size_t)cellCap;
+    for (int q = tid; q < nq; q += 256) {
+      const int e = queue[q];
+      const int y = e >> 8, x = e & 255;
+      const int w = x >> 5;
+      const uint32_t word = bm[y * 8 + w];
+      if (!((word >> (x & 31)) & 1u)) continue;
+      int slot = rowCnt[y] + __popc(word & ((1u << (x & 31)) - 1u));
+      for (int ww = 0; ww < w; ++ww) slot += __popc(bm[y * 8 + ww]);
+      if (slot < cellCap) out[slot] = morbqt::make_key(x + c.cj * c.wCell, y + c.ci * c.hCell, sc[y * tilePitch + x] - 1);
+    }
+    if (tid == 0) candCnt[cellSlot] = imin(rowCnt[th], cellCap);
+    PHASE_MARK(5);
   }
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int r = 0; r < th; ++r) { const int c = rowCnt[r]; rowCnt[r] = acc; acc += c; }
-    rowCnt[th] = acc;
-  }
-  __syncthreads();
-  // Phase 5 — ordered output (row-major over the evaluated area): slot = row prefix + set bits to the left
-  uint32_t* out = cand + cellSlot * (size_t)cellCap;
-  for (int q = tid; q < nq; q += 256) {
-    const int e = queue[q];
-    const int y = e >> 8, x = e & 255;
-    const int w = x >> 5;
-    const uint32_t word = bm[y * 8 + w];
-    if (!((word >> (x & 31)) & 1u)) continue;
-    int slot = rowCnt[y] + __popc(word & ((1u << (x & 31)) - 1u));
-    for (int ww = 0; ww < w; ++ww) slot += __popc(bm[y * 8 + ww]);
-    if (slot < cellCap) out[slot] = morbqt::make_key(x + cj * g.wCell, y + ci * g.hCell, sc[y * tilePitch + x] - 1);
-  }
-  if (tid == 0) candCnt[cellSlot] = imin(rowCnt[th], cellCap);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -749,6 +831,8 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     g.ytabOff = (int)tabs.size(); build(g.h, gs.h, false, tabs);
   }
   e->totalCells = cellBase;
+  MORB_REQUIRE(e->tileRows * (e->tilePitch / 4) <= 256 * FAST_LD, MORB_ERR_UNSUPPORTED,
+               "FAST cell window larger than the register tile of k_fast");
   e->selPerImg = selBase;
   e->blurTiles = blurTileBase;
   e->pyrBytes = pyrOff; e->blurBytes = blurOff; e->qtElems = qtOff;
@@ -759,6 +843,13 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
 
   MORB_HIP_CHECK(hipMalloc(&e->d_geom, sizeof(LevelGeom) * kMaxLevels));
   MORB_HIP_CHECK(hipMemcpy(e->d_geom, e->geom, sizeof(LevelGeom) * kMaxLevels, hipMemcpyHostToDevice));
+  for (int l = 0; l < kMaxLevels; ++l) {
+    const LevelGeom& g = e->geom[l < L ? l : L - 1];
+    e->fastGeom.cellBase[l] = l < L ? g.cellBase : 0x7fffffff;
+    e->fastGeom.nCols[l] = g.nCols; e->fastGeom.nColsMagic[l] = 0xFFFFFFFFu / (unsigned)g.nCols + 1u; e->fastGeom.wCell[l] = g.wCell; e->fastGeom.hCell[l] = g.hCell;
+    e->fastGeom.pstride[l] = g.pstride; e->fastGeom.maxBorderX[l] = g.maxBorderX; e->fastGeom.maxBorderY[l] = g.maxBorderY;
+    e->fastGeom.pyrOff[l] = g.pyrOff; e->fastGeom.pyrImg[l] = g.pyrImg;
+  }
   MORB_HIP_CHECK(hipMalloc(&e->d_tabs, sizeof(ResizeTab) * std::max<size_t>(tabs.size(), 1)));
   if (!tabs.empty()) MORB_HIP_CHECK(hipMemcpy(e->d_tabs, tabs.data(), sizeof(ResizeTab) * tabs.size(), hipMemcpyHostToDevice));
   MORB_HIP_CHECK(hipMalloc(&e->d_pyr, e->pyrBytes + 256));
@@ -948,8 +1039,9 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   mark(2);
   {
     const size_t smem = 4ull * e->tileRows * e->tilePitch + (size_t)e->tileRows * 68 + 16;  // tile, strength, u16 queue, 2 bitmaps, row counts
-    hipLaunchKernelGGL(k_fast, dim3(e->totalCells, nimg), dim3(256), smem, st, e->d_geom, L, e->d_pyr, e->d_cand,
-                       e->d_candCnt, e->totalCells, e->cellCap, e->tilePitch, e->tileRows, e->iniTh, e->minTh);
+    hipLaunchKernelGGL(k_fast, dim3(e->totalCells, nimg), dim3(256), smem, st, e->fastGeom, L, e->d_pyr, e->d_cand,
+                       e->d_candCnt, e->totalCells, e->cellCap, e->tilePitch, e->tileRows,
+                       0xFFFFFFFFu / (unsigned)(e->tilePitch / 4) + 1u, e->iniTh, e->minTh);
   }
   mark(3);
   hipLaunchKernelGGL(k_distribute, dim3(L, nimg), dim3(64), e->distSmem, st, e->d_geom, e->d_cand, e->d_candCnt,

@@ -33,6 +33,15 @@ struct LevelGeom {
   float kpSize;                         // (float)(int)(PATCH_SIZE * mvScaleFactor[l])  (:831)
 };
 
+// What k_fast needs of every level, passed by value: the kernarg segment is read with scalar loads, so looking a
+// cell's level up costs no dependent global-memory round trip.
+struct FastGeom {
+  int cellBase[kMaxLevels], nCols[kMaxLevels], wCell[kMaxLevels], hCell[kMaxLevels];
+  unsigned nColsMagic[kMaxLevels];      // ceil(2^32 / nCols): cell / nCols == umulhi(cell, magic) for every cell < 2^16
+  int pstride[kMaxLevels], maxBorderX[kMaxLevels], maxBorderY[kMaxLevels];
+  unsigned long long pyrOff[kMaxLevels], pyrImg[kMaxLevels];
+};
+
 struct ResizeTab {  // one entry per padded destination column / row
   short s0, s1, c0, c1;  // source index (clipped), source index + 1 (clipped), fixed-point weights (2048 = 1)
 };
@@ -40,6 +49,7 @@ struct ResizeTab {  // one entry per padded destination column / row
 }  // namespace morb
 
 struct morb_extractor {
+  morb::FastGeom fastGeom = {};
   int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0, device = 0;
   float scaleFactor = 1.2f;
   std::vector<float> scale, invScale, sigma2, invSigma2;

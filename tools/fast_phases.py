@@ -1,0 +1,36 @@
+"""Per-phase wall-clock split of k_fast (developer tool, GPU only).
+
+Builds a -DMORB_FAST_TIMING variant of the HIP library next to the product one, runs the C2 extract batch through it and
+prints the share of block-time each phase of the kernel takes (100 MHz wall clock ticks summed over all workgroups).
+Usage: python tools/fast_phases.py [B]
+"""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+csrc = os.path.join(ROOT, "morb_slam_amd", "csrc")
+out = os.path.join(ROOT, "gpurun_out", "libmorb_hip_timing.so")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+srcs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".hip")]
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+                       "-DMORB_FAST_TIMING", "-I", os.path.join(ROOT, "include"), "-o", out] + srcs)
+os.environ["MORB_HIP_LIB"] = out
+import torch
+from morb_slam_amd import capi, synth
+from morb_slam_amd.extractor import ORBextractor
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+ims = [synth.make_stereo_pair(752, 480, seed=i) for i in range(4)]
+import numpy as np
+batch = np.stack([ims[i % 4][k] for i in range(B) for k in (0, 1)])
+ex = ORBextractor(1200, 1.2, 8, 20, 7)
+dev = torch.from_numpy(batch).cuda()
+lib = capi.lib()
+lib.morb_fast_timing.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+ex.extract_batch(dev); torch.cuda.synchronize()
+lib.morb_fast_timing(None, 1)
+for _ in range(5): ex.extract_batch(dev)
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 8)()
+lib.morb_fast_timing(buf, 0)
+names = ["load", "p1_reject", "p2_strength", "p3_nms", "p4_rows", "p5_output"]
+tot = sum(buf[:6])
+for n, v in zip(names, buf[:6]): print(f"{n:12s} {v:12d} ticks  {100.0 * v / max(tot, 1):5.1f} %")
