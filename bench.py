@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="stereo frames per step per GPU")
+    ap.add_argument("--chunks", type=int, default=1,
+                    help="the batch is cut into this many frame chunks, each with its own extractor/matcher handle and HIP "
+                         "stream, so the latency-bound quadtree of one chunk runs under the VALU-bound FAST of another")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -178,9 +181,14 @@ def main():
     gids = [parallel.global_frame(rank, world, s) for s in range(B)]
     frames = torch.from_numpy(make_batch(gids, B * world, seed=0)).to(dev)      # [B, 2, H, W] resident in HBM
     images = frames.view(2 * B, H, W)
-    ext = ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank)
+    C = max(1, min(args.chunks, B))
+    bounds = [(c * B // C, (c + 1) * B // C) for c in range(C)]          # frame ranges of the chunks
+    exts = [ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank) for _ in range(C)]
+    ext = exts[0]
     stream = torch.cuda.Stream(device=dev)
+    cstreams = [stream] if C == 1 else [torch.cuda.Stream(device=dev) for _ in range(C)]
     matcher = ORBmatcher(0.7, True, device=local_rank)        # TrackReferenceKeyFrame: ORBmatcher(0.7, true), Tracking.cc:2541
+    cmatchers = [matcher] if C == 1 else [ORBmatcher(0.7, True, device=local_rank) for _ in range(C)]   # one workspace set per stream
     mbf, mb = 458.654 * 0.11, 0.11                            # EuRoC fx * baseline, baseline (Examples/Stereo/EuRoC.yaml)
     VK, VL = 10, 6                                            # DBoW2 ORBvoc shape: k=10, L=6, levelsup=4
     vd, vf = make_vocabulary(VK, VL, seed=0)                  # synthetic: ORBvoc.txt is a missing blob (SURVEY finding 3)
@@ -200,15 +208,30 @@ def main():
         kf_img, f_img = torch.from_numpy(kfp).to(dev), torch.from_numpy(frp).to(dev)
         has_mp = torch.from_numpy((rng.random((world * B, cap)) < 0.8).astype(np.uint8)).to(dev)
         exch = parallel.FeatureExchange()
-    out = st_out = bow_out = match_out = None
+    match_out = None
+    out = (torch.empty((2 * B, cap, 28), dtype=torch.uint8, device=dev), torch.empty((2 * B, cap, 32), dtype=torch.uint8, device=dev),
+           torch.empty((2 * B,), dtype=torch.int32, device=dev), torch.empty((2 * B,), dtype=torch.int32, device=dev))
+    st_out = (torch.empty((B, cap), dtype=torch.float32, device=dev), torch.empty((B, cap), dtype=torch.float32, device=dev))
+    bow_out = (torch.empty((2 * B, cap), dtype=torch.int32, device=dev), torch.empty((2 * B, cap), dtype=torch.int32, device=dev))
 
     def step():
-        nonlocal out, st_out, bow_out, match_out
+        nonlocal match_out
         s = stream.cuda_stream
-        out = ext.extract_batch(images, out=out, stream=s)                                   # Frame::ExtractORB x2
         kps, desc, cnt, _ = out
-        st_out = matcher.ComputeStereoMatches(ext, kps, desc, cnt, mbf, mb, out=st_out, stream=s)   # Frame.cc:217
-        bow_out = matcher.bow_transform(desc, cnt, vd, vf, VK, VL, 4, out=bow_out, stream=s)        # Frame::ComputeBoW
+        for c, (f0, f1) in enumerate(bounds):     # per chunk: extract -> stereo -> BoW on the chunk's own stream
+            cs = cstreams[c]
+            if C > 1:
+                cs.wait_stream(stream)            # fork: ordered after whatever the step stream did before
+            i0, i1 = 2 * f0, 2 * f1
+            co = tuple(t[i0:i1] for t in out)
+            exts[c].extract_batch(images[i0:i1], out=co, stream=cs.cuda_stream)                 # Frame::ExtractORB x2
+            cmatchers[c].ComputeStereoMatches(exts[c], co[0], co[1], co[2], mbf, mb,
+                                              out=(st_out[0][f0:f1], st_out[1][f0:f1]), stream=cs.cuda_stream)   # Frame.cc:217
+            cmatchers[c].bow_transform(co[1], co[2], vd, vf, VK, VL, 4,
+                                       out=(bow_out[0][i0:i1], bow_out[1][i0:i1]), stream=cs.cuda_stream)       # Frame::ComputeBoW
+        if C > 1:
+            for cs in cstreams:
+                stream.wait_stream(cs)            # join: SearchByBoW pairs frames across chunk borders
         if exch is None:
             match_out = matcher.SearchByBoW(kf_img, f_img, kps, desc, bow_out[1], cnt, has_mp, out=match_out, stream=s)
         else:
@@ -217,6 +240,8 @@ def main():
             match_out = matcher.SearchByBoW(kf_img, f_img, pk, pd, pn, pc, has_mp, out=match_out, stream=s)
 
     def sync_all():
+        for cs in cstreams:
+            cs.synchronize()
         stream.synchronize()
         torch.cuda.synchronize(dev)
         if dist is not None:
@@ -224,7 +249,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ext.set_profiling(True)   # stage-boundary HIP events on the launch stream; no host sync inside the timed region
+    for e in exts:
+        e.set_profiling(True)   # stage-boundary HIP events on the launch stream; no host sync inside the timed region
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -237,8 +263,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         dist.barrier()
-    stages = ext.stage_ms()
-    ext.set_profiling(False)
+    # per-stage ms per step, summed over the chunks' launches (chunks overlap in time, so the sum can exceed wall time)
+    per_chunk = [e.stage_ms() for e in exts]
+    stages = {k: sum(pc[k] for pc in per_chunk) for k in per_chunk[0]}
+    for e in exts:
+        e.set_profiling(False)
     cnt = out[2].cpu().numpy()
     n_stereo = float((st_out[0] >= 0).sum().item()) / B
     n_bow = float(match_out[1].float().mean().item())
@@ -250,17 +279,17 @@ def main():
         dom = max(("pyramid", "blur", "fast"), key=lambda k: stages[k])
         # dominant streaming kernel of the extractor; "fast" is ONE kernel (k_fast), so its stage time is the
         # kernel's launch duration measured with HIP events on the launch stream
-        ach = ab[dom] * nimg / (stages[dom] * 1e-3) / 1e9
+        ach = ab[dom] * nimg / (stages[dom] * 1e-3) / 1e9    # = bytes of one chunk launch / its mean duration
         # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # runs of this same command at B = 64; profiles/r01/pmc_traffic_b64.json) — not measurable live
         traffic = None
         try:
-            if B == 64:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_b64.json")))
-                names = {"pyramid": ["k_level0", "k_resize"], "blur": ["k_blur"], "fast": ["k_fast"]}[dom]
-                mult = {"k_resize": 7}
-                traffic = sum((pm[k]["FETCH_SIZE_KB_per_launch"] + pm[k]["WRITE_SIZE_KB_per_launch"]) * 1024 * mult.get(k, 1)
-                              for k in names)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_b64.json")))
+            names = {"pyramid": ["k_level0", "k_resize"], "blur": ["k_blur"], "fast": ["k_fast"]}[dom]
+            mult = {"k_resize": 7}
+            # the PMC passes ran launches of pm["images_per_launch"] images; traffic scales with the image count
+            traffic = sum((pm[k]["FETCH_SIZE_KB_per_launch"] + pm[k]["WRITE_SIZE_KB_per_launch"]) * 1024 * mult.get(k, 1)
+                          for k in names) * (nimg / C) / pm.get("images_per_launch", 128)
         except Exception:
             traffic = None
         line = {
@@ -270,7 +299,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "EuRoC-shaped stereo 752x480, 1200 feat: ORBextractor x2 + ComputeStereoMatches + "
                                    "ComputeBoW (synthetic k=10 L=6 vocabulary) + SearchByBoW vs previous frame",
-                       "stereo_frames_per_step_per_gpu": B, "parallelism": f"frames dealt round-robin over {world} GPU(s)" + ("" if world == 1 else
+                       "stereo_frames_per_step_per_gpu": B, "chunks_per_step": C, "parallelism": f"frames dealt round-robin over {world} GPU(s)" + ("" if world == 1 else
                                        "; one RCCL all-gather of left-image keypoints/descriptors/BoW ids per step"),
                        "stages_in_step": ["extract_left+right", "stereo_match", "bow_transform", "search_by_bow"],
                        "mean_keypoints_per_image": float(cnt.mean()), "mean_stereo_matches_per_frame": n_stereo,
@@ -278,7 +307,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": {"pyramid": "k_level0+k_resize", "blur": "k_blur", "fast": "k_fast"}[dom],
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "algorithmic_bytes_per_launch": ab[dom] * nimg, "avg_launch_ms": stages[dom]},
+                         "algorithmic_bytes_per_launch": ab[dom] * nimg // C, "avg_launch_ms": stages[dom] / C},
             "extract_stage_ms_per_step": stages,
         }
         if world == 1:

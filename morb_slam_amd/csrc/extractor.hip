@@ -64,22 +64,25 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src,
   const int py0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * PY_ROWS;
   const int img = blockIdx.z;
   if (px >= g.pstride) return;
+  // four consecutive (reflected) source columns span at most 4 bytes: one unaligned dword load at the smallest one
+  // (kept inside the source row) serves interior and pad lanes alike, so edge waves do not run two code paths
   int xs[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) xs[k] = reflect101(px + k - EDGE, w);
-  const bool interior = px >= EDGE && px + 3 < w + EDGE;
+  int base = min(min(xs[0], xs[1]), min(xs[2], xs[3]));
+  base = min(base, w - 4);
+  int sh[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sh[k] = (xs[k] - base) * 8;
   for (int r = 0; r < PY_ROWS; ++r) {
     const int py = py0 + r;
     if (py >= h + 2 * EDGE) break;
     const uint8_t* s = src + (size_t)img * pitch + (size_t)reflect101(py - EDGE, h) * stride;
+    uint32_t word;
+    __builtin_memcpy(&word, s + base, 4);
     uint32_t v = 0;
-    if (interior) {
-      __builtin_memcpy(&v, s + xs[0], 4);
-    } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (px + k < w + 2 * EDGE) v |= (uint32_t)s[xs[k]] << (8 * k);
-    }
+    for (int k = 0; k < 4; ++k) v |= ((word >> sh[k]) & 0xFFu) << (8 * k);
     *reinterpret_cast<uint32_t*>(pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)py * g.pstride + px) = v;
   }
 }
@@ -102,10 +105,19 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
   ResizeTab tx[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) tx[k] = xtab[(px + k) < gd.w + 2 * EDGE ? (px + k) : gd.w + 2 * EDGE - 1];
-  // interior columns: the four outputs read source columns s0(px) .. s0(px+3)+1, a span of at most 6 bytes ->
-  // two (unaligned) dword loads per source row; pad columns (reflected, non-monotone) gather bytes.
-  const bool interior = px >= EDGE && px + 3 < gd.w + EDGE;
-  const int base = tx[0].s0;
+  // The four outputs read source columns within a span of a few bytes — s0(px) .. s0(px+3)+1 in the interior, the
+  // mirrored equivalent in the reflected pad — so two (unaligned) dword loads per source row starting at the
+  // smallest column feed all four; one code path for interior and pad keeps the edge waves from running both.
+  int base = tx[0].s0, top = tx[0].s1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    base = min(base, min((int)tx[k].s0, (int)tx[k].s1));
+    top = max(top, max((int)tx[k].s0, (int)tx[k].s1));
+  }
+  const bool packed = top - base < 8;   // always true for scale factors <= 2 (the gather below is the general fallback)
+  int o0[4], o1[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { o0[k] = (tx[k].s0 - base) * 8; o1[k] = (tx[k].s1 - base) * 8; }
   const uint8_t* sbase = pyr + gs.pyrOff + (size_t)img * gs.pyrImg + (size_t)EDGE * gs.pstride + EDGE;
   uint8_t* dbase = pyr + gd.pyrOff + (size_t)img * gd.pyrImg + px;
   for (int r = 0; r < PY_ROWS; ++r) {
@@ -115,28 +127,26 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
     const uint8_t* r0 = sbase + (size_t)ty.s0 * gs.pstride;
     const uint8_t* r1 = sbase + (size_t)ty.s1 * gs.pstride;
     uint32_t v = 0;
-    if (interior) {
+    if (packed) {
       const unsigned long long a = (unsigned long long)load_u32_unaligned(r0 + base) | ((unsigned long long)load_u32_unaligned(r0 + base + 4) << 32);
       const unsigned long long b = (unsigned long long)load_u32_unaligned(r1 + base) | ((unsigned long long)load_u32_unaligned(r1 + base + 4) << 32);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int o0 = (tx[k].s0 - base) * 8, o1 = (tx[k].s1 - base) * 8;
-        const int h0 = (int)((a >> o0) & 0xFF) * tx[k].c0 + (int)((a >> o1) & 0xFF) * tx[k].c1;
-        const int h1 = (int)((b >> o0) & 0xFF) * tx[k].c0 + (int)((b >> o1) & 0xFF) * tx[k].c1;
+        const int h0 = (int)((a >> o0[k]) & 0xFF) * tx[k].c0 + (int)((a >> o1[k]) & 0xFF) * tx[k].c1;
+        const int h1 = (int)((b >> o0[k]) & 0xFF) * tx[k].c0 + (int)((b >> o1[k]) & 0xFF) * tx[k].c1;
         const int o = ((((int)ty.c0 * (h0 >> 4)) >> 16) + (((int)ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
         v |= (uint32_t)(o & 0xFF) << (8 * k);
       }
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (px + k < gd.w + 2 * EDGE) {
-          const int h0 = r0[tx[k].s0] * tx[k].c0 + r0[tx[k].s1] * tx[k].c1;
-          const int h1 = r1[tx[k].s0] * tx[k].c0 + r1[tx[k].s1] * tx[k].c1;
-          const int o = ((((int)ty.c0 * (h0 >> 4)) >> 16) + (((int)ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
-          v |= (uint32_t)(o & 0xFF) << (8 * k);
-        }
+        const int h0 = r0[tx[k].s0] * tx[k].c0 + r0[tx[k].s1] * tx[k].c1;
+        const int h1 = r1[tx[k].s0] * tx[k].c0 + r1[tx[k].s1] * tx[k].c1;
+        const int o = ((((int)ty.c0 * (h0 >> 4)) >> 16) + (((int)ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        v |= (uint32_t)(o & 0xFF) << (8 * k);
       }
     }
+    // columns >= w + 2 * EDGE repeat the last table entry and land in the row's alignment slack
     *reinterpret_cast<uint32_t*>(dbase + (size_t)py * gd.pstride) = v;
   }
 }
@@ -237,11 +247,10 @@ __device__ __forceinline__ int fast_strength(const uint8_t* __restrict__ p, int 
 }
 
 #ifdef MORB_FAST_TIMING
-__device__ unsigned long long g_fastPhase[8];
 #define PHASE_MARK(k) do { __syncthreads(); if (threadIdx.x == 0 && ((blockIdx.x * 7 + blockIdx.y) & 63) == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_fastPhase[k], now_ - t0_); t0_ = now_; } } while (0)
 extern "C" int morb_fast_timing(unsigned long long* out, int reset) {
-  if (reset) { unsigned long long z[8] = {0}; MORB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fastPhase), z, sizeof(z))); return 0; }
-  MORB_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fastPhase), 8 * sizeof(unsigned long long)));
+  if (reset) { unsigned long long z[16] = {0}; MORB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fastPhase), z, sizeof(z))); return 0; }
+  MORB_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fastPhase), 16 * sizeof(unsigned long long)));
   return 0;
 }
 #else
@@ -487,6 +496,12 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
   uint16_t* freeIds = reinterpret_cast<uint16_t*>(sp); sp += (size_t)maxNodeCap * 2;
   uint16_t* list = reinterpret_cast<uint16_t*>(sp);
 
+#ifdef MORB_FAST_TIMING
+  unsigned long long d0_ = wall_clock64();
+#define DMARK(k) do { if (lvl == 0 && lane == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_fastPhase[k], now_ - d0_); d0_ = now_; } } while (0)
+#else
+#define DMARK(k)
+#endif
   const int ncell = g.nRows * g.nCols;
   const int* counts = candCnt + (size_t)img * totalCells + g.cellBase;
   int running = 0;
@@ -505,6 +520,7 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
   const int T = running;
   if (lane == 0) cellOff[ncell] = T;
   QT_SYNC();
+  DMARK(8);
 
   uint32_t* keys;
   uint32_t* tmp;
@@ -525,6 +541,7 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
     keys[t] = cbase[(size_t)lo * cellCap + (t - cellOff[lo])];
   }
   QT_SYNC();
+  DMARK(9);
 
   morbqt::Work w;
   w.keys = keys; w.tmp = tmp; w.nodes = nodes; w.freeIds = freeIds; w.list = list; w.vA = vA; w.vB = vB;
@@ -532,6 +549,10 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
   uint32_t* out = sel + (size_t)img * selPerImg + g.selBase;
   const int n = morbqt::qt_distribute(w, (uint32_t)T, g.maxBorderX - MINB, g.maxBorderY - MINB, g.quota, out, g.selCap);
   if (lane == 0) selCnt[img * nlevels + lvl] = n < g.selCap ? n : g.selCap;
+  DMARK(10);
+#ifdef MORB_FAST_TIMING
+  if (lvl == 0 && lane == 0) { atomicAdd(&g_fastPhase[11], (unsigned long long)T); atomicAdd(&g_fastPhase[12], (unsigned long long)n); }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -26,6 +26,16 @@
 #define QT_HD inline
 #endif
 
+#if defined(MORB_FAST_TIMING) && defined(__HIPCC__)
+__device__ unsigned long long g_fastPhase[16];   // phase clocks of tools/fast_phases.py (timing build only)
+#endif
+#if defined(MORB_FAST_TIMING) && QT_DEVICE
+#define QT_T0() unsigned long long q0_ = wall_clock64()
+#define QT_MARK(k) do { if (QT_LANE0 && blockIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_fastPhase[k], now_ - q0_); q0_ = now_; } } while (0)
+#else
+#define QT_T0()
+#define QT_MARK(k)
+#endif
 namespace morbqt {
 
 // key = x | y << 12 | response << 24, x/y relative to (minBorderX, minBorderY); position in the key array =
@@ -208,13 +218,16 @@ QT_HD void qt_insertion_sort(uint64_t* v, int first, int last) {
   }
 }
 
-// Serial; call from ONE lane (or the host).
-QT_HD void qt_std_sort(uint64_t* v, int n) {
+// std::__introsort_loop(first, last, 2 * lg(n)): leaves every element within a <= 16-element partition of its
+// sorted position.  Serial; call from ONE lane (or the host).
+// st: 3 * 64 ints of stack storage (LDS on the device: a local array would live in scratch memory, i.e. a
+// global-memory round trip per push / pop).
+QT_HD void qt_introsort_loop(uint64_t* v, int n, int* st) {
   if (n <= 0) return;
+  int* stF = st; int* stL = st + 64; int* stD = st + 128;
   int lg = 0;
   for (int t = n; t > 1; t >>= 1) ++lg;  // std::__lg(n)
   // __introsort_loop with an explicit stack of (first, last, depth) for the recursive right halves
-  int stF[64], stL[64], stD[64];
   int sp = 0;
   stF[0] = 0; stL[0] = n; stD[0] = lg * 2; sp = 1;
   while (sp > 0) {
@@ -251,6 +264,13 @@ QT_HD void qt_std_sort(uint64_t* v, int n) {
       last = cut;
     }
   }
+}
+
+// Serial; call from ONE lane (or the host).
+QT_HD void qt_std_sort(uint64_t* v, int n) {
+  if (n <= 0) return;
+  int st[3 * 64];
+  qt_introsort_loop(v, n, st);
   // __final_insertion_sort
   if (n > 16) {
     qt_insertion_sort(v, 0, 16);
@@ -258,6 +278,32 @@ QT_HD void qt_std_sort(uint64_t* v, int n) {
   } else
     qt_insertion_sort(v, 0, n);
 }
+
+#if QT_DEVICE
+// Whole wave, convergent: v[0..n) in LDS ends up exactly as std::sort(v, v + n, compareNodes) leaves it.
+// std::__final_insertion_sort is a STABLE insertion sort (both __insertion_sort and __unguarded_linear_insert stop
+// at the first element that is not greater), so after the serial introsort loop the result is the stable sort of
+// the array by key: every lane ranks its entries (keys smaller + equal keys to the left) instead of one lane
+// walking LDS element by element (that walk was ~25 % of k_distribute).
+__device__ inline void qt_std_sort_wave(uint64_t* v, uint64_t* tmp, int n) {
+  __shared__ int st[3 * 64];
+  if (QT_LANE0) qt_introsort_loop(v, n, st);
+  QT_SYNC();
+  for (int i = QT_LANE; i < n; i += 64) {
+    const uint64_t e = v[i];
+    const uint64_t k = e >> 16;
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const uint64_t kj = v[j] >> 16;
+      rank += (kj < k || (kj == k && j < i)) ? 1 : 0;
+    }
+    tmp[rank] = e;
+  }
+  QT_SYNC();
+  for (int i = QT_LANE; i < n; i += 64) v[i] = tmp[i];
+  QT_SYNC();
+}
+#endif
 
 // ---- the distribution -----------------------------------------------------------------------------
 
@@ -469,8 +515,10 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
   }
 
   bool bFinish = false;
+  QT_T0();
   while (!bFinish) {
     qt_compact(w, s);
+    QT_MARK(13);
     const int prevSize = s.size;
     int nToExpand = 0;
     s.nA = 0;
@@ -501,6 +549,7 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
       qt_split(w, s, id, &nToExpand);
     }
 #endif
+    QT_MARK(14);
     if (s.size >= N || s.size == prevSize) {
       bFinish = true;
     } else if (s.size + nToExpand * 3 > N) {
@@ -512,8 +561,13 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
         for (int i = QT_LANE; i < nPrev; i += (QT_DEVICE ? 64 : 1)) w.vB[i] = w.vA[i];
         QT_SYNC();
         s.nA = 0;
-        if (QT_LANE0) qt_std_sort(w.vB, nPrev);
-        QT_SYNC();
+        QT_MARK(14);
+#if QT_DEVICE
+        qt_std_sort_wave(w.vB, w.vA, nPrev);   // vA was just cleared: free as scratch until the splits below refill it
+#else
+        qt_std_sort(w.vB, nPrev);
+#endif
+        QT_MARK(15);
         // compaction keeps ids stable (vB holds ids), only Node::lit moves
         qt_compact(w, s);
         for (int j = nPrev - 1; j >= 0; --j) {
@@ -528,6 +582,7 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
 
   // retain the best point in each node, list order (:716-737)
   QT_SYNC();
+  QT_MARK(14);
   int nOut = 0;
 #if QT_DEVICE
   // one node per lane (most nodes hold a handful of keys); nodes with many keys are finished by the whole wave
