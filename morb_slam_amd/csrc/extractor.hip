@@ -43,7 +43,7 @@ using namespace morb;
 
 namespace {
 
-__constant__ int c_pattern[256 * 4] = {
+__constant__ __align__(16) int c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
 __constant__ int c_umax[16];
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
 // in list order; x in [lap0, lap1] (after pt *= scale) fills from the back, the rest from the front.
 __global__ __launch_bounds__(256) void k_layout(const LevelGeom* __restrict__ geom, int nlevels,
                                                 const uint32_t* __restrict__ sel, const int* __restrict__ selCnt,
-                                                int selPerImg, const int* __restrict__ lap, int* __restrict__ slots,
+                                                int selPerImg, const int* __restrict__ lap, int2* __restrict__ kref,
                                                 int* __restrict__ nkp, int* __restrict__ mono, int cap) {
   __shared__ int wm[4], ws[4];
   const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -575,10 +575,11 @@ __global__ __launch_bounds__(256) void k_layout(const LevelGeom* __restrict__ ge
     const int gi = g0 + tid;
     const bool valid = gi < total;
     bool isLap = false;
+    int l = 0;
+    uint32_t key = 0;
     if (valid) {
-      int l = 0;
       while (gi >= base[l + 1]) ++l;
-      const uint32_t key = sel[(size_t)img * selPerImg + geom[l].selBase + (gi - base[l])];
+      key = sel[(size_t)img * selPerImg + geom[l].selBase + (gi - base[l])];
       float x = (float)(morbqt::key_x(key) + MINB);
       if (l != 0) x = x * geom[l].scale;
       isLap = (x >= lap0) && (x <= lap1);
@@ -590,12 +591,14 @@ __global__ __launch_bounds__(256) void k_layout(const LevelGeom* __restrict__ ge
     for (int q = 0; q < wv; ++q) { offS += ws[q]; offM += wm[q]; }
     if (valid) {
       const int slot = isLap ? (total - 1 - (offS + __popcll(mS & lt))) : (offM + __popcll(mM & lt));
-      slots[(size_t)img * selPerImg + gi] = slot < cap ? slot : -1;
+      // everything k_describe needs about keypoint gi in ONE record: output slot | level << 24 (or -1), packed key
+      kref[(size_t)img * selPerImg + gi] = make_int2(slot < cap ? (slot | (l << 24)) : -1, (int)key);
     }
     stereoRun += ws[0] + ws[1] + ws[2] + ws[3];
     monoRun += wm[0] + wm[1] + wm[2] + wm[3];
     __syncthreads();
   }
+  for (int gi = total + tid; gi < selPerImg; gi += 256) kref[(size_t)img * selPerImg + gi] = make_int2(-1, 0);
   if (tid == 0) { nkp[img] = total < cap ? total : cap; mono[img] = monoRun; }
 }
 
@@ -661,49 +664,55 @@ __device__ __forceinline__ void sincosf_glibc(float y, float* sn, float* cs) {
   *sn = (float)sc_poly(x * s, x * x, p, n);
 }
 
-__global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ geom, int nlevels,
-                                                  const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
-                                                  const uint32_t* __restrict__ sel, const int* __restrict__ selCnt,
-                                                  int selPerImg, const int* __restrict__ slots,
-                                                  morb_keypoint* __restrict__ kps, uint8_t* __restrict__ desc, int cap) {
+// The wave's lifetime is a chain of dependent global-memory round trips, so the chain is kept short: one record
+// per keypoint from k_layout (slot, level, key), level geometry from the kernarg segment, and the (keypoint-
+// independent) rBRIEF pattern rows of the lane requested before anything else.
+__global__ __launch_bounds__(256) void k_describe(const morb::DescGeom dg, const uint8_t* __restrict__ pyr,
+                                                  const uint8_t* __restrict__ blur, const int2* __restrict__ kref,
+                                                  int selPerImg, morb_keypoint* __restrict__ kps,
+                                                  uint8_t* __restrict__ desc, int cap) {
   const int img = blockIdx.y, lane = threadIdx.x & 63;
   const int gi = blockIdx.x * 4 + (threadIdx.x >> 6);
-  int l = 0, b = 0;
-  {
-    int acc = 0;
-    bool found = false;
-    for (int q = 0; q < nlevels; ++q) {
-      const int n = selCnt[img * nlevels + q];
-      if (!found && gi < acc + n) { l = q; b = acc; found = true; }
-      acc += n;
-    }
-    if (!found) return;
-  }
-  const LevelGeom g = geom[l];
-  const int slot = slots[(size_t)img * selPerImg + gi];
-  if (slot < 0) return;
-  const uint32_t key = sel[(size_t)img * selPerImg + g.selBase + (gi - b)];
+  if (gi >= selPerImg) return;
+  int4 pat[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) pat[q] = reinterpret_cast<const int4*>(c_pattern)[lane * 4 + q];
+  const int2 ref = kref[(size_t)img * selPerImg + gi];
+  if (ref.x < 0) return;
+  const int l = ref.x >> 24, slot = ref.x & 0xFFFFFF;
+  const uint32_t key = (uint32_t)ref.y;
+  struct { int pstride, bstride; float scale, kpSize; } g;
+  g.pstride = dg.pstride[l]; g.bstride = dg.bstride[l]; g.scale = dg.scale[l]; g.kpSize = dg.kpSize[l];
+  const size_t pyrBase = dg.pyrOff[l] + (size_t)img * dg.pyrImg[l], blurBase = dg.blurOff[l] + (size_t)img * dg.blurImg[l];
   const int cx = morbqt::key_x(key) + MINB, cy = morbqt::key_y(key) + MINB;
 
-  // IC_Angle on the un-blurred level: lanes take the columns u = -d..d of each of the 31 rows; the row loop is
-  // fully unrolled so the 31 byte loads of a lane are all in flight together (no dependent-latency chain)
+  // IC_Angle on the un-blurred level.  The texture path handles a byte load of a wave no faster than a dword load
+  // (the kernel was bound by the number of vector-memory instructions, not by bytes or ALU), so the 31 x 31 patch
+  // is read as 31 rows x 8 unaligned dwords = 248 dword loads, four per lane, instead of 31 byte loads per lane.
   int m10 = 0, m01 = 0;
   {
-    constexpr int kUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // == c_umax (checked on the host)
-    const uint8_t* ctr = pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)(EDGE + cy) * g.pstride + EDGE + cx;
-    int vals[31];
+    const uint8_t* ctr = pyr + pyrBase + (size_t)(EDGE + cy) * g.pstride + EDGE + cx;
+    uint32_t wv[4];
 #pragma unroll
-    for (int v = -HALF_PATCH; v <= HALF_PATCH; ++v) {
-      const int d = kUmax[v < 0 ? -v : v];
-      const int u = lane - d;
-      vals[v + HALF_PATCH] = (lane <= 2 * d) ? (int)ctr[(ptrdiff_t)v * g.pstride + u] : 0;
+    for (int j = 0; j < 4; ++j) {
+      const int t = lane + 64 * j;              // row = t / 8, dword = t % 8
+      const int tt = t < 248 ? t : 247;
+      wv[j] = load_u32_unaligned(ctr + (ptrdiff_t)((tt >> 3) - HALF_PATCH) * g.pstride + ((tt & 7) * 4 - HALF_PATCH));
     }
 #pragma unroll
-    for (int v = -HALF_PATCH; v <= HALF_PATCH; ++v) {
-      const int d = kUmax[v < 0 ? -v : v];
-      const int u = lane - d;
-      m10 += u * vals[v + HALF_PATCH];
-      m01 += v * vals[v + HALF_PATCH];
+    for (int j = 0; j < 4; ++j) {
+      const int t = lane + 64 * j;
+      const int v = (t >> 3) - HALF_PATCH, u0 = (t & 7) * 4 - HALF_PATCH;
+      const int av = v < 0 ? -v : v;
+      const int d = (int)((0x3689ABCDDEEEFFFFull >> (4 * av)) & 15);   // umax[|v|] (== c_umax, checked on the host)
+      int sum = 0, usum = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int u = u0 + k;
+        const int val = (t < 248 && u >= -d && u <= d) ? (int)((wv[j] >> (8 * k)) & 0xFF) : 0;
+        sum += val; usum += u * val;
+      }
+      m10 += usum; m01 += v * sum;
     }
   }
 #pragma unroll
@@ -717,12 +726,11 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   float a, bsin;
   sincosf_glibc(angle * factorPI, &bsin, &a);
-  const uint8_t* center = blur + g.blurOff + (size_t)img * g.blurImg + (size_t)cy * g.bstride + cx;
+  const uint8_t* center = blur + blurBase + (size_t)cy * g.bstride + cx;
   uint32_t nib = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int* pt = &c_pattern[(lane * 4 + q) * 4];
-    const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+    const float x0 = (float)pat[q].x, y0 = (float)pat[q].y, x1 = (float)pat[q].z, y1 = (float)pat[q].w;
     const int r0 = __float2int_rn(x0 * bsin + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bsin);
     const int r1 = __float2int_rn(x1 * bsin + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bsin);
     const int t0 = center[(ptrdiff_t)r0 * g.bstride + c0], t1 = center[(ptrdiff_t)r1 * g.bstride + c1];
@@ -752,7 +760,7 @@ static int cvRoundF(float v) { return (int)lrintf(v); }
 void free_buffers(morb_extractor* e) {
   auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   F(e->d_geom); F(e->d_tabs); F(e->d_pyr); F(e->d_blur); F(e->d_cand); F(e->d_qt); F(e->d_sel);
-  F(e->d_candCnt); F(e->d_selCnt); F(e->d_slots); F(e->d_lap);
+  F(e->d_candCnt); F(e->d_selCnt); F(e->d_kref); F(e->d_lap);
   e->W = e->H = e->nimgCap = 0;
   e->lapLast.clear();
 }
@@ -870,6 +878,9 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     e->fastGeom.nCols[l] = g.nCols; e->fastGeom.nColsMagic[l] = 0xFFFFFFFFu / (unsigned)g.nCols + 1u; e->fastGeom.wCell[l] = g.wCell; e->fastGeom.hCell[l] = g.hCell;
     e->fastGeom.pstride[l] = g.pstride; e->fastGeom.maxBorderX[l] = g.maxBorderX; e->fastGeom.maxBorderY[l] = g.maxBorderY;
     e->fastGeom.pyrOff[l] = g.pyrOff; e->fastGeom.pyrImg[l] = g.pyrImg;
+    e->descGeom.pyrOff[l] = g.pyrOff; e->descGeom.pyrImg[l] = g.pyrImg; e->descGeom.blurOff[l] = g.blurOff;
+    e->descGeom.blurImg[l] = g.blurImg; e->descGeom.pstride[l] = g.pstride; e->descGeom.bstride[l] = g.bstride;
+    e->descGeom.scale[l] = g.scale; e->descGeom.kpSize[l] = g.kpSize;
   }
   MORB_HIP_CHECK(hipMalloc(&e->d_tabs, sizeof(ResizeTab) * std::max<size_t>(tabs.size(), 1)));
   if (!tabs.empty()) MORB_HIP_CHECK(hipMemcpy(e->d_tabs, tabs.data(), sizeof(ResizeTab) * tabs.size(), hipMemcpyHostToDevice));
@@ -880,7 +891,7 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
   MORB_HIP_CHECK(hipMalloc(&e->d_qt, sizeof(uint32_t) * std::max<size_t>(e->qtElems, 1)));
   MORB_HIP_CHECK(hipMalloc(&e->d_sel, sizeof(uint32_t) * (size_t)nimg * e->selPerImg));
   MORB_HIP_CHECK(hipMalloc(&e->d_selCnt, sizeof(int) * (size_t)nimg * L));
-  MORB_HIP_CHECK(hipMalloc(&e->d_slots, sizeof(int) * (size_t)nimg * e->selPerImg));
+  MORB_HIP_CHECK(hipMalloc(&e->d_kref, sizeof(int2) * (size_t)nimg * e->selPerImg));
   MORB_HIP_CHECK(hipMalloc(&e->d_lap, sizeof(int) * (size_t)nimg * 2));
   MORB_HIP_CHECK(hipMemset(e->d_selCnt, 0, sizeof(int) * (size_t)nimg * L));
   MORB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), e->umax, sizeof(int) * 16));
@@ -1070,10 +1081,10 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
                      e->maxCells);
   mark(4);
   hipLaunchKernelGGL(k_layout, dim3(nimg), dim3(256), 0, st, e->d_geom, L, e->d_sel, e->d_selCnt, e->selPerImg,
-                     e->d_lap, e->d_slots, d_count, d_mono, cap);
+                     e->d_lap, e->d_kref, d_count, d_mono, cap);
   mark(5);
-  hipLaunchKernelGGL(k_describe, dim3(div_up(e->selPerImg, 4), nimg), dim3(256), 0, st, e->d_geom, L, e->d_pyr,
-                     e->d_blur, e->d_sel, e->d_selCnt, e->selPerImg, e->d_slots, d_kps, d_desc, cap);
+  hipLaunchKernelGGL(k_describe, dim3(div_up(e->selPerImg, 4), nimg), dim3(256), 0, st, e->descGeom, e->d_pyr,
+                     e->d_blur, e->d_kref, e->selPerImg, d_kps, d_desc, cap);
   mark(6);
   MORB_HIP_CHECK(hipGetLastError());
   if (e->profiling) ++e->profCalls;

@@ -42,6 +42,13 @@ struct FastGeom {
   unsigned long long pyrOff[kMaxLevels], pyrImg[kMaxLevels];
 };
 
+// What k_describe needs of every level, by value (see FastGeom).
+struct DescGeom {
+  unsigned long long pyrOff[kMaxLevels], pyrImg[kMaxLevels], blurOff[kMaxLevels], blurImg[kMaxLevels];
+  int pstride[kMaxLevels], bstride[kMaxLevels];
+  float scale[kMaxLevels], kpSize[kMaxLevels];
+};
+
 struct ResizeTab {  // one entry per padded destination column / row
   short s0, s1, c0, c1;  // source index (clipped), source index + 1 (clipped), fixed-point weights (2048 = 1)
 };
@@ -50,6 +57,8 @@ struct ResizeTab {  // one entry per padded destination column / row
 
 struct morb_extractor {
   morb::FastGeom fastGeom = {};
+  morb::DescGeom descGeom = {};
+  int2* d_kref = nullptr;   // per selected keypoint: output slot | level << 24 (or -1), packed key (k_layout -> k_describe)
   int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0, device = 0;
   float scaleFactor = 1.2f;
   std::vector<float> scale, invScale, sigma2, invSigma2;
@@ -67,7 +76,7 @@ struct morb_extractor {
   morb::ResizeTab* d_tabs = nullptr;
   uint8_t *d_pyr = nullptr, *d_blur = nullptr;
   uint32_t *d_cand = nullptr, *d_qt = nullptr, *d_sel = nullptr;
-  int *d_candCnt = nullptr, *d_selCnt = nullptr, *d_slots = nullptr, *d_lap = nullptr;
+  int *d_candCnt = nullptr, *d_selCnt = nullptr,  *d_lap = nullptr;
   // staging for the single-image host API
   uint8_t* d_img = nullptr; size_t imgBytes = 0;
   morb_keypoint* d_kps1 = nullptr; uint8_t* d_desc1 = nullptr; int *d_cnt1 = nullptr, *d_mono1 = nullptr;

@@ -133,102 +133,219 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, con
 // Hamming match (lexicographic (dist, iR) minimum = the reference's first-best over vRowIndices[row]), then the
 // 11x11 SAD search over 11 shifts on the un-blurred pyramid level, parabola refinement, disparity -> depth.
 // Kernel B: one workgroup per frame: median of the accepted SAD distances, 1.5*1.4*median cut.
-__global__ __launch_bounds__(256) void k_stereo_match(const LevelGeom* __restrict__ geom, const uint8_t* __restrict__ pyr,
+// One workgroup = SM_LK left keypoints of one frame (4 waves x SM_LK/4 keypoints in turn).  PMC showed the first
+// version (one wave per left keypoint, every wave re-reading all right keypoints from global memory) bound by the
+// number of vector-memory instructions, so: the right keypoints' row band / x / octave go to LDS once per workgroup,
+// the row-band test runs on LDS, the survivors are compacted to a candidate list before any descriptor is loaded,
+// and the two SAD patches are fetched as unaligned dwords into LDS instead of 24 byte loads per lane.
+constexpr int SM_LK = 16;
+constexpr int SM_BAND = 16;   // rows per band of the per-workgroup row index (the reference's vRowIndices, coarsened)
+constexpr int SM_MAXB = 256;  // bands that fit (images up to 4096 rows); SM_LIST * cap list entries, else the full scan
+// Per-level facts the stereo kernel needs, by value in the kernarg segment (scalar loads, no dependent round trip
+// and no per-call host-to-device table copies).
+struct StereoGeom {
+  unsigned long long pyrOff[16], pyrImg[16];
+  int pstride[16], w[16];
+  float scale[16], invScale[16];
+  int nRows;
+};
+struct RightKp { uint32_t band; float x; };   // band = (minr + 4096) | (maxr + 4096) << 14 | octave << 28  (vRowIndices band, Frame.cc:736-747)
+constexpr int SM_LIST = 4;
+constexpr int SM_CAND = 256;                  // per-wave candidate list; flushed (descriptors compared) whenever it could overflow
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+
+__global__ __launch_bounds__(256) void k_stereo_match(const StereoGeom sg, const uint8_t* __restrict__ pyr,
                                                       const morb_keypoint* __restrict__ kps,
                                                       const uint8_t* __restrict__ desc, const int* __restrict__ count,
-                                                      int cap, const float* __restrict__ scaleF,
-                                                      const float* __restrict__ invScaleF, float mbf, float mb,
+                                                      int cap, float mbf, float mb,
                                                       float* __restrict__ uRight, float* __restrict__ depth,
                                                       int* __restrict__ sadDist) {
-  const int f = blockIdx.y, lane = threadIdx.x & 63;
-  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+  extern __shared__ __align__(16) uint8_t smem[];
+  RightKp* tab = reinterpret_cast<RightKp*>(smem);                       // [cap]
+  int* bandStart = reinterpret_cast<int*>(tab + cap);                    // [SM_MAXB + 1]
+  int* bandFill = bandStart + SM_MAXB + 1;                               // [SM_MAXB]
+  uint16_t* list = reinterpret_cast<uint16_t*>(bandFill + SM_MAXB);      // [SM_LIST * cap] right keypoints per band
+  uint16_t* candAll = list + SM_LIST * (size_t)cap;                      // [4][SM_CAND]
+  uint8_t* patchAll = reinterpret_cast<uint8_t*>(candAll + 4 * SM_CAND);        // [4][11 * 12 + 11 * 24]
+  __shared__ int listTotal;
+  const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int imgL = 2 * f, imgR = 2 * f + 1;
-  if (iL >= cap) return;
-  const size_t o = (size_t)f * cap + iL;
-  float outU = -1.0f, outD = -1.0f;
-  int outS = -1;
   const int NL = count[imgL], NR = count[imgR];
-  if (iL < NL) {
-    const morb_keypoint kpL = kps[(size_t)imgL * cap + iL];
-    const int levelL = kpL.octave;
-    const float vL = kpL.y, uL = kpL.x;
-    const int nRows = geom[0].h;
-    const int row = (int)vL;
-    const float maxD = mbf / mb;
-    const float minU = uL - maxD, maxU = uL - 0.f;
-    const Desc dL = load_desc(desc + ((size_t)imgL * cap + iL) * 32);
-    unsigned long long best = ~0ull;
-    if (row >= 0 && row < nRows && !(maxU < 0)) {
-      for (int j0 = 0; j0 < NR; j0 += 64) {
-        const int iR = j0 + lane;
-        if (iR < NR) {
-          const morb_keypoint kpR = kps[(size_t)imgR * cap + iR];
-          const float r = 2.0f * scaleF[kpR.octave];
-          int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
-          const bool ok = row >= minr && row <= maxr && !(kpR.octave < levelL - 1 || kpR.octave > levelL + 1) &&
-                          kpR.x >= minU && kpR.x <= maxU;
-          if (ok) {
-            const int d = hamming(dL, load_desc(desc + ((size_t)imgR * cap + iR) * 32));
-            if (d < TH_HIGH) {
-              const unsigned long long k = ((unsigned long long)d << 32) | (unsigned)iR;
-              best = k < best ? k : best;
-            }
-          }
-        }
-      }
+  const int iL0 = blockIdx.x * SM_LK;
+  if (iL0 >= cap) return;
+  const int nRows = sg.nRows;
+  const int nBands = (nRows + SM_BAND - 1) / SM_BAND;
+  const bool banded = nBands <= SM_MAXB;
+  if (iL0 < NL) {
+    for (int i = tid; i < SM_MAXB + 1; i += 256) { bandStart[i] = 0; if (i < SM_MAXB) bandFill[i] = 0; }
+    __syncthreads();
+    for (int iR = tid; iR < NR; iR += 256) {
+      const morb_keypoint kpR = kps[(size_t)imgR * cap + iR];
+      const float r = 2.0f * sg.scale[kpR.octave & 15];
+      const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
+      // clamped to +-4095 rows: far beyond any image row, so the band test below is unchanged
+      const int lo = min(max(minr, -4095), 4095) + 4096, hi = min(max(maxr, -4095), 4095) + 4096;
+      RightKp t;
+      t.band = (uint32_t)lo | ((uint32_t)hi << 14) | ((uint32_t)kpR.octave << 28); t.x = kpR.x;
+      tab[iR] = t;
+      if (banded && maxr >= 0 && minr < nRows)
+        for (int bnd = max(minr, 0) / SM_BAND; bnd <= min(maxr, nRows - 1) / SM_BAND; ++bnd) atomicAdd(&bandStart[bnd + 1], 1);
     }
-    best = wave_min_u64(best);
-    const int bestDist = best == ~0ull ? TH_HIGH : (int)(best >> 32);
-    if (bestDist < (TH_HIGH + TH_LOW) / 2) {
-      const int bestIdxR = (int)(best & 0xFFFFFFFFu);
-      const float uR0 = kps[(size_t)imgR * cap + bestIdxR].x;
-      const float sf = invScaleF[levelL];
-      const float scaleduL = roundf(kpL.x * sf), scaledvL = roundf(kpL.y * sf), scaleduR0 = roundf(uR0 * sf);
-      const LevelGeom g = geom[levelL];
-      const float iniu = scaleduR0 + 5 - 5, endu = scaleduR0 + 5 + 5 + 1;
-      if (!(iniu < 0 || endu >= (float)g.w)) {
-        const uint8_t* L0 = pyr + g.pyrOff + (size_t)imgL * g.pyrImg + (size_t)(EDGE_ + (int)scaledvL) * g.pstride + EDGE_ + (int)scaleduL;
-        const uint8_t* R0 = pyr + g.pyrOff + (size_t)imgR * g.pyrImg + (size_t)(EDGE_ + (int)scaledvL) * g.pstride + EDGE_ + (int)scaleduR0;
-        // lanes cover the 121 patch pixels (two per lane)
-        const int p0 = lane, p1 = lane + 64;
-        const int dy0 = p0 / 11 - 5, dx0 = p0 % 11 - 5, dy1 = p1 / 11 - 5, dx1 = p1 % 11 - 5;
-        const int a0 = L0[dy0 * g.pstride + dx0];
-        const int a1 = p1 < 121 ? L0[dy1 * g.pstride + dx1] : 0;
-        float vDists[11];
-        int bestS = 0x7fffffff, bestinc = 0;
+    __syncthreads();
+    if (tid < 64) {   // inclusive scan of the band counts -> bandStart[b] = first list slot of band b
+      int c[4], sum = 0;
 #pragma unroll
-        for (int inc = -5; inc <= 5; ++inc) {
-          int s = abs(a0 - (int)R0[dy0 * g.pstride + dx0 + inc]);
-          if (p1 < 121) s += abs(a1 - (int)R0[dy1 * g.pstride + dx1 + inc]);
-          s = wave_sum(s);
-          const float dist = (float)s;
-          if (dist < (float)bestS) { bestS = (int)dist; bestinc = inc; }
-          vDists[inc + 5] = dist;
-        }
-        if (!(bestinc == -5 || bestinc == 5)) {
-          float dist1 = 0, dist2 = 0, dist3 = 0;
+      for (int k = 0; k < 4; ++k) { c[k] = bandStart[1 + tid * 4 + k]; sum += c[k]; }
+      int inc = sum;
 #pragma unroll
-          for (int q = 1; q < 10; ++q)
-            if (q == bestinc + 5) { dist1 = vDists[q - 1]; dist2 = vDists[q]; dist3 = vDists[q + 1]; }
-          const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
-          if (!(deltaR < -1 || deltaR > 1)) {
-            float bestuR = scaleF[levelL] * ((float)scaleduR0 + (float)bestinc + deltaR);
-            float disparity = uL - bestuR;
-            if (disparity >= 0.f && disparity < maxD) {
-              if (disparity <= 0) {
-                disparity = 0.01f;
-                bestuR = (float)((double)uL - 0.01);
-              }
-              outD = mbf / disparity;
-              outU = bestuR;
-              outS = bestS;
-            }
-          }
-        }
+      for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+      int acc = inc - sum;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { acc += c[k]; bandStart[1 + tid * 4 + k] = acc; }
+      if (tid == 63) listTotal = acc;
+    }
+    __syncthreads();
+    if (banded && listTotal <= SM_LIST * cap) {
+      for (int iR = tid; iR < NR; iR += 256) {
+        const RightKp t = tab[iR];
+        const int minr = (int)(t.band & 0x3FFF) - 4096, maxr = (int)((t.band >> 14) & 0x3FFF) - 4096;
+        if (maxr >= 0 && minr < nRows)
+          for (int bnd = max(minr, 0) / SM_BAND; bnd <= min(maxr, nRows - 1) / SM_BAND; ++bnd)
+            list[bandStart[bnd] + atomicAdd(&bandFill[bnd], 1)] = (uint16_t)iR;   // order inside a band is irrelevant: best = min (dist, index)
       }
     }
   }
-  if (lane == 0) { uRight[o] = outU; depth[o] = outD; sadDist[o] = outS; }
+  __syncthreads();
+  const bool useBands = banded && listTotal <= SM_LIST * cap;
+  uint16_t* cand = candAll + wv * SM_CAND;
+  uint8_t* Lp = patchAll + wv * (11 * 12 + 11 * 24);   // [11][12]: columns -5 .. 6 of the left patch rows
+  uint8_t* Rp = Lp + 11 * 12;                          // [11][24]: columns -10 .. 13 of the right strip rows
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const float maxD = mbf / mb;
+  // the wave's SM_LK / 4 left keypoints, one per lane, fetched in one round trip and broadcast below
+  float myX = 0.f, myY = 0.f;
+  int myOct = 0;
+  if (lane < SM_LK / 4) {
+    const int iL = iL0 + lane * 4 + wv;
+    if (iL < NL) { const morb_keypoint k = kps[(size_t)imgL * cap + iL]; myX = k.x; myY = k.y; myOct = k.octave; }
+  }
+  for (int q = 0; q < SM_LK / 4; ++q) {
+    const int iL = iL0 + q * 4 + wv;
+    if (iL >= cap) break;
+    const size_t o = (size_t)f * cap + iL;
+    float outU = -1.0f, outD = -1.0f;
+    int outS = -1;
+    if (iL < NL) {
+      const int levelL = __shfl(myOct, q, 64);
+      const float vL = __shfl(myY, q, 64), uL = __shfl(myX, q, 64);
+      const int row = (int)vL;
+      const float minU = uL - maxD, maxU = uL - 0.f;
+      unsigned long long best = ~0ull;
+      if (row >= 0 && row < nRows && !(maxU < 0)) {
+        const Desc dL = load_desc(desc + ((size_t)imgL * cap + iL) * 32);
+        int n = 0;
+        const int e0 = useBands ? bandStart[row / SM_BAND] : 0, e1 = useBands ? bandStart[row / SM_BAND + 1] : NR;
+        for (int j0 = e0; j0 < e1; j0 += 64) {
+          const int ei = j0 + lane;
+          bool ok = false;
+          int iR = 0;
+          if (ei < e1) {
+            iR = useBands ? (int)list[ei] : ei;
+            const RightKp t = tab[iR];
+            const int minr = (int)(t.band & 0x3FFF) - 4096, maxr = (int)((t.band >> 14) & 0x3FFF) - 4096, oct = (int)(t.band >> 28);
+            ok = row >= minr && row <= maxr && !(oct < levelL - 1 || oct > levelL + 1) && t.x >= minU && t.x <= maxU;
+          }
+          const uint64_t m = __ballot(ok);
+          if (ok) cand[n + __popcll(m & lt)] = (uint16_t)iR;
+          n += __popcll(m);
+          if (n > SM_CAND - 64 || j0 + 64 >= e1) {   // flush: compare the descriptors of the collected candidates
+            WAVE_SYNC();
+            for (int c0 = 0; c0 < n; c0 += 64) {
+              const int c = c0 + lane;
+              if (c < n) {
+                const int jR = cand[c];
+                const int d = hamming(dL, load_desc(desc + ((size_t)imgR * cap + jR) * 32));
+                if (d < TH_HIGH) {
+                  const unsigned long long k = ((unsigned long long)d << 32) | (unsigned)jR;
+                  best = k < best ? k : best;
+                }
+              }
+            }
+            WAVE_SYNC();
+            n = 0;
+          }
+        }
+      }
+      best = wave_min_u64(best);
+      const int bestDist = best == ~0ull ? TH_HIGH : (int)(best >> 32);
+      if (bestDist < (TH_HIGH + TH_LOW) / 2) {
+        const int bestIdxR = (int)(best & 0xFFFFFFFFu);
+        const float uR0 = tab[bestIdxR].x;
+        const float sf = sg.invScale[levelL & 15];
+        const float scaleduL = roundf(uL * sf), scaledvL = roundf(vL * sf), scaleduR0 = roundf(uR0 * sf);
+        struct { unsigned long long pyrOff, pyrImg; int pstride, w; } g;
+        g.pyrOff = sg.pyrOff[levelL & 15]; g.pyrImg = sg.pyrImg[levelL & 15]; g.pstride = sg.pstride[levelL & 15]; g.w = sg.w[levelL & 15];
+        const float iniu = scaleduR0 + 5 - 5, endu = scaleduR0 + 5 + 5 + 1;
+        if (!(iniu < 0 || endu >= (float)g.w)) {
+          const uint8_t* L0 = pyr + g.pyrOff + (size_t)imgL * g.pyrImg + (size_t)(EDGE_ + (int)scaledvL) * g.pstride + EDGE_ + (int)scaleduL;
+          const uint8_t* R0 = pyr + g.pyrOff + (size_t)imgR * g.pyrImg + (size_t)(EDGE_ + (int)scaledvL) * g.pstride + EDGE_ + (int)scaleduR0;
+          // 11 x 3 dwords of the left patch + 11 x 6 dwords of the right strip = 99 dword loads, two per lane (the
+          // bytes past the 11 / 21 used columns lie inside the level's 19-pixel pad)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int t = lane + 64 * j;
+            if (t < 33) {
+              const int r = t / 3, c4 = (t - r * 3) * 4;
+              *reinterpret_cast<uint32_t*>(Lp + r * 12 + c4) = load_u32_unaligned(L0 + (ptrdiff_t)(r - 5) * g.pstride + c4 - 5);
+            } else if (t < 99) {
+              const int t2 = t - 33, r = t2 / 6, c4 = (t2 - r * 6) * 4;
+              *reinterpret_cast<uint32_t*>(Rp + r * 24 + c4) = load_u32_unaligned(R0 + (ptrdiff_t)(r - 5) * g.pstride + c4 - 10);
+            }
+          }
+          WAVE_SYNC();
+          // lanes cover the 121 patch pixels (two per lane)
+          const int p0 = lane, p1 = lane + 64;
+          const int dy0 = p0 / 11, dx0 = p0 % 11, dy1 = p1 / 11, dx1 = p1 % 11;   // 0-based here
+          const int a0 = Lp[dy0 * 12 + dx0];
+          const int a1 = p1 < 121 ? Lp[dy1 * 12 + dx1] : 0;
+          float vDists[11];
+          int bestS = 0x7fffffff, bestinc = 0;
+#pragma unroll
+          for (int inc = -5; inc <= 5; ++inc) {
+            int s = abs(a0 - (int)Rp[dy0 * 24 + dx0 + 5 + inc]);
+            if (p1 < 121) s += abs(a1 - (int)Rp[dy1 * 24 + dx1 + 5 + inc]);
+            s = wave_sum(s);
+            const float dist = (float)s;
+            if (dist < (float)bestS) { bestS = (int)dist; bestinc = inc; }
+            vDists[inc + 5] = dist;
+          }
+          WAVE_SYNC();   // the patches are rewritten for the next keypoint
+          if (!(bestinc == -5 || bestinc == 5)) {
+            float dist1 = 0, dist2 = 0, dist3 = 0;
+#pragma unroll
+            for (int qq = 1; qq < 10; ++qq)
+              if (qq == bestinc + 5) { dist1 = vDists[qq - 1]; dist2 = vDists[qq]; dist3 = vDists[qq + 1]; }
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (!(deltaR < -1 || deltaR > 1)) {
+              float bestuR = sg.scale[levelL & 15] * ((float)scaleduR0 + (float)bestinc + deltaR);
+              float disparity = uL - bestuR;
+              if (disparity >= 0.f && disparity < maxD) {
+                if (disparity <= 0) {
+                  disparity = 0.01f;
+                  bestuR = (float)((double)uL - 0.01);
+                }
+                outD = mbf / disparity;
+                outU = bestuR;
+                outS = bestS;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (lane == 0) { uRight[o] = outU; depth[o] = outD; sadDist[o] = outS; }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_stereo_median(const int* __restrict__ count, int cap, float* __restrict__ uRight,
@@ -568,10 +685,19 @@ int morb_stereo_match_batch(morb_matcher* m, const morb_extractor* e, int nframe
   hipStream_t st = stream ? (hipStream_t)stream : m->stream;
   int rc = grow(m->d_sad, m->sadElems, (size_t)nframes * cap);
   if (rc != MORB_OK) return rc;
-  MORB_HIP_CHECK(hipMemcpyAsync(m->d_scale, e->scale.data(), sizeof(float) * e->nlevels, hipMemcpyHostToDevice, st));
-  MORB_HIP_CHECK(hipMemcpyAsync(m->d_invScale, e->invScale.data(), sizeof(float) * e->nlevels, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_stereo_match, dim3(div_up(cap, 4), nframes), dim3(256), 0, st, e->d_geom, e->d_pyr, d_kps, d_desc,
-                     d_count, cap, m->d_scale, m->d_invScale, mbf, mb, d_uRight, d_depth, m->d_sad);
+  StereoGeom sg = {};
+  for (int l = 0; l < 16; ++l) {
+    const LevelGeom& g = e->geom[l < e->nlevels ? l : e->nlevels - 1];
+    sg.pyrOff[l] = g.pyrOff; sg.pyrImg[l] = g.pyrImg; sg.pstride[l] = g.pstride; sg.w[l] = g.w;
+    sg.scale[l] = e->scale[l < e->nlevels ? l : e->nlevels - 1]; sg.invScale[l] = e->invScale[l < e->nlevels ? l : e->nlevels - 1];
+  }
+  sg.nRows = e->geom[0].h;
+  const size_t stereoSmem = (size_t)cap * (sizeof(RightKp) + SM_LIST * sizeof(uint16_t)) + (2 * SM_MAXB + 1) * sizeof(int) +
+                            4 * SM_CAND * sizeof(uint16_t) + 4 * (11 * 12 + 11 * 24);
+  MORB_REQUIRE(stereoSmem <= 160 * 1024 && cap < 65536 && e->nlevels <= 16, MORB_ERR_UNSUPPORTED, "too many keypoints per image for the LDS-resident right-keypoint table");
+  MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stereo_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stereoSmem));
+  hipLaunchKernelGGL(k_stereo_match, dim3(div_up(cap, SM_LK), nframes), dim3(256), stereoSmem, st, sg, e->d_pyr, d_kps, d_desc,
+                     d_count, cap, mbf, mb, d_uRight, d_depth, m->d_sad);
   hipLaunchKernelGGL(k_stereo_median, dim3(nframes), dim3(256), 0, st, d_count, cap, d_uRight, d_depth, m->d_sad);
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
