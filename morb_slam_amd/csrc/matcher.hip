@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "common.h"
+#include "wave.h"
 #include "extractor_internal.h"
 
 using namespace morb;
@@ -40,19 +41,9 @@ __device__ __forceinline__ int hamming(const Desc& a, const Desc& b) {
   for (int i = 0; i < 8; ++i) s += __popc(a.w[i] ^ b.w[i]);
   return s;
 }
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const unsigned long long o = __shfl_xor(v, off, 64);
-    v = o < v ? o : v;
-  }
-  return v;
-}
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+// full-wave reductions on the DPP path (wave.h); every call site below is convergent over all 64 lanes
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) { return morbwave::min_u64(v); }
+__device__ __forceinline__ int wave_sum(int v) { return morbwave::sum_i32(v); }
 // merge two sorted pairs (a1<=a2), (b1<=b2) of u64 keys -> the two smallest
 __device__ __forceinline__ void top2_merge(unsigned long long& a1, unsigned long long& a2, unsigned long long b1,
                                            unsigned long long b2) {
@@ -444,6 +435,23 @@ __global__ __launch_bounds__(256) void k_bow_sort(const int* __restrict__ node, 
   for (int i = tid; i < cap; i += 256) sorted[(size_t)img * cap + i] = i < P ? skeys[i] : ~0ull;
 }
 
+// SearchByBoW core (ORBmatcher.cc:222-404).  Features of one vocabulary node only compete with each other, so a
+// node is an independent unit; inside a node the keyframe features are visited in order and each takes the best
+// still-unmatched frame feature (greedy), which one wave replays sequentially.
+// v2: BM_NB workgroups per pair stage the two sorted (node, index) arrays in LDS once; a wave then owns a stretch of
+// keyframe positions.  For a node with <= 64 features on either side everything it needs — descriptors, angles,
+// MapPoint flags — is fetched in ONE round trip into registers (frame feature s in lane s, keyframe feature q in
+// lane q) and the greedy loop runs on registers with readlane broadcasts; v1 paid ~5 dependent global round trips
+// per keyframe feature plus a 10-step binary search in global memory per node (0.10 VALU utilisation).
+#ifdef MORB_FAST_TIMING
+__device__ unsigned long long g_bowTrace[16384 * 4];   // per-wave clocks (start, staged, compacted, end) for tools/bow_phases.py
+#define BOW_MARK(k) do { if (lane == 0 && bw_ < 16384) g_bowTrace[bw_ * 4 + (k)] = wall_clock64(); } while (0)
+#else
+#define BOW_MARK(k)
+#endif
+constexpr int BM_NB = 25;
+constexpr int BM_FJ = 4;    // frame features of a node held in registers: up to BM_FJ per lane   // x 4 waves: one node per wave for vocabularies with ~100 nodes at the matching level
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) { return morbwave::min_u32(v); }
 __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __restrict__ sortedKF,
                                                    const unsigned long long* __restrict__ sortedF,
                                                    const int* __restrict__ nKFv, const int* __restrict__ nFv, int cap,
@@ -452,62 +460,196 @@ __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __r
                                                    const uint8_t* __restrict__ descF, const morb_keypoint* __restrict__ kpsF,
                                                    const int* __restrict__ kfImg, const int* __restrict__ fImg,
                                                    float nnratio, int* __restrict__ matchF, int* __restrict__ binF) {
-  const int pair = blockIdx.y, lane = threadIdx.x & 63;
-  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  extern __shared__ __align__(16) unsigned long long bowLds[];
+#ifdef MORB_FAST_TIMING
+  const int bw_ = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if ((threadIdx.x & 63) == 0 && bw_ < 16384) g_bowTrace[bw_ * 4] = wall_clock64();
+#endif
+  unsigned long long* sk = bowLds;         // [cap] keyframe: node << 32 | feature index, ascending, ~0 = no word
+  unsigned long long* sf = bowLds + cap;   // [cap] frame
+  const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int ik = kfImg[pair], jf = fImg[pair];
   const int nKF = nKFv[ik], nF = nFv[jf];
-  if (p >= nKF) return;
-  const unsigned long long* sk = sortedKF + (size_t)ik * cap;
-  const unsigned long long* sf = sortedF + (size_t)jf * cap;
-  const unsigned long long kp = sk[p];
-  if (kp == ~0ull) return;
-  const unsigned node = (unsigned)(kp >> 32);
-  if (p > 0 && (unsigned)(sk[p - 1] >> 32) == node) return;  // not the first feature of its node
-  // frame segment of this node: lower_bound(node << 32)
-  int lo = 0, hi = nF;
-  const unsigned long long target = (unsigned long long)node << 32;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (sf[mid] < target) lo = mid + 1; else hi = mid;
+  {
+    // stage both tables with all of a thread's loads in flight at once (one global round trip, not one per element)
+    const unsigned long long* gk = sortedKF + (size_t)ik * cap;
+    const unsigned long long* gf = sortedF + (size_t)jf * cap;
+    for (int i0 = 0; i0 < cap; i0 += 256 * 4) {
+      unsigned long long a[4], b[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * 256 + tid;
+        a[k] = i < nKF ? gk[i] : ~0ull;
+        b[k] = i < nF ? gf[i] : ~0ull;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * 256 + tid;
+        if (i < nKF) sk[i] = a[k];
+        if (i < nF) sf[i] = b[k];
+      }
+    }
   }
-  const int fBeg = lo;
-  int fEnd = fBeg;
-  while (fEnd < nF && (unsigned)(sf[fEnd] >> 32) == node) ++fEnd;  // small segments (tens of features)
-  if (fEnd == fBeg) return;
+  __syncthreads();
+  BOW_MARK(1);
+  // node starts of the keyframe, compacted in position order; wave g of the pair takes nodes g, g + G, ...
+  // (node sizes are very uneven — 1 .. 60 features — and a node is a sequential loop, so nodes, not position
+  // ranges, are the unit that is dealt out)
+  uint16_t* starts = reinterpret_cast<uint16_t*>(sf + cap);   // [cap]
+  __shared__ int wcnt[4];
+  const uint64_t ltm = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  int nStarts = 0;
+  for (int i0 = 0; i0 < nKF; i0 += 256) {
+    const int i = i0 + tid;
+    bool st = false;
+    if (i < nKF) {
+      const unsigned long long k = sk[i];
+      st = k != ~0ull && (i == 0 || (unsigned)(sk[i - 1] >> 32) != (unsigned)(k >> 32));
+    }
+    const uint64_t m = __ballot(st);
+    if (lane == 0) wcnt[wv] = __popcll(m);
+    __syncthreads();
+    int off = nStarts;
+    for (int w = 0; w < wv; ++w) off += wcnt[w];
+    if (st) starts[off + __popcll(m & ltm)] = (uint16_t)i;
+    nStarts += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+  const int G = gridDim.x * 4, g = blockIdx.x * 4 + wv;
+  BOW_MARK(2);
   int* mF = matchF + (size_t)pair * cap;
   int* bF = binF + (size_t)pair * cap;
   const float factor = 1.0f / HISTO_LENGTH;
-  for (int q = p; q < nKF; ++q) {
-    const unsigned long long kq = sk[q];
-    if (kq == ~0ull || (unsigned)(kq >> 32) != node) break;
-    const int realIdxKF = (int)(kq & 0xFFFFFFFFu);
-    if (!hasMP[(size_t)ik * cap + realIdxKF]) continue;
-    const Desc dKF = load_desc(descKF + ((size_t)ik * cap + realIdxKF) * 32);
-    unsigned long long k1 = ~0ull, k2 = ~0ull;
-    for (int s0 = fBeg; s0 < fEnd; s0 += 64) {
-      const int s = s0 + lane;
-      if (s < fEnd) {
-        const int realIdxF = (int)(sf[s] & 0xFFFFFFFFu);
-        if (mF[realIdxF] < 0) {
-          const int d = hamming(dKF, load_desc(descF + ((size_t)jf * cap + realIdxF) * 32));
-          top2_insert(k1, k2, ((unsigned long long)d << 32) | (unsigned)realIdxF);
+  for (int o = g; o < nStarts; o += G) {
+    const int p = starts[o];
+    const unsigned node = (unsigned)(sk[p] >> 32);
+    // frame segment of this node: lower_bound(node << 32) in LDS
+    int lo = 0, hi = nF;
+    const unsigned long long target = (unsigned long long)node << 32;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (sf[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    const int fBeg = lo;
+    // frame segment length, up to BM_FJ * 64 positions (lane l looks at positions l, l + 64, ...)
+    int nFs = 0;
+    bool more = false;
+#pragma unroll
+    for (int j = 0; j < BM_FJ; ++j) {
+      const int s = fBeg + j * 64 + lane;
+      const uint64_t mm = __ballot(s < nF && (unsigned)(sf[s] >> 32) == node);
+      nFs += __popcll(mm);
+      more = mm == ~0ull;     // after the last round: the segment may continue past BM_FJ * 64
+      if (mm != ~0ull) break;
+    }
+    if (nFs == 0) continue;
+    if (!more) {
+      // ---- register path: frame feature s of the node lives in slot s / 64 of lane s % 64; the keyframe features are
+      // taken 64 at a time (feature q of the chunk in lane q) and visited in order
+      const int nJ = (nFs + 63) >> 6;
+      int idxF[BM_FJ], myMatch[BM_FJ], myBin[BM_FJ];
+      Desc dF[BM_FJ];
+      float angF[BM_FJ];
+#pragma unroll
+      for (int j = 0; j < BM_FJ; ++j) {
+        idxF[j] = 0; myMatch[j] = -1; myBin[j] = 0; angF[j] = 0.f; dF[j] = Desc{};
+        if (j < nJ && j * 64 + lane < nFs) {
+          idxF[j] = (int)(sf[fBeg + j * 64 + lane] & 0xFFFFFFFFu);
+          dF[j] = load_desc(descF + ((size_t)jf * cap + idxF[j]) * 32);
+          angF[j] = kpsF[(size_t)jf * cap + idxF[j]].angle;
         }
       }
+      for (int q0 = p; q0 < nKF; q0 += 64) {
+        const uint64_t mK = __ballot(q0 + lane < nKF && (unsigned)(sk[q0 + lane] >> 32) == node);
+        const int nKs = mK == ~0ull ? 64 : (int)__builtin_ctzll(~mK);   // the segment is contiguous
+        if (nKs == 0) break;
+        int idxK = 0, has = 0;
+        Desc dK = {};
+        float angK = 0.f;
+        if (lane < nKs) {
+          idxK = (int)(sk[q0 + lane] & 0xFFFFFFFFu);
+          has = hasMP[(size_t)ik * cap + idxK];
+          dK = load_desc(descKF + ((size_t)ik * cap + idxK) * 32);
+          angK = kpsKF[(size_t)ik * cap + idxK].angle;
+        }
+        for (int q = 0; q < nKs; ++q) {
+          if (!__builtin_amdgcn_readlane(has, q)) continue;
+          Desc dk;
+#pragma unroll
+          for (int w = 0; w < 8; ++w) dk.w[w] = (uint32_t)__builtin_amdgcn_readlane((int)dK.w[w], q);
+          unsigned a1 = ~0u, a2 = ~0u;   // this lane's two best keys: dist << 16 | frame feature index (< cap < 65536)
+#pragma unroll
+          for (int j = 0; j < BM_FJ; ++j)
+            if (j < nJ && j * 64 + lane < nFs && myMatch[j] < 0) {
+              const unsigned key = ((unsigned)hamming(dk, dF[j]) << 16) | (unsigned)idxF[j];
+              if (key < a1) { a2 = a1; a1 = key; } else if (key < a2) a2 = key;
+            }
+          const unsigned k1 = wave_min_u32(a1);
+          const unsigned k2 = wave_min_u32(a1 == k1 ? a2 : a1);
+          const int bestDist1 = k1 == ~0u ? 256 : (int)(k1 >> 16);
+          const int bestDist2 = k2 == ~0u ? 256 : (int)(k2 >> 16);
+          if (bestDist1 <= TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {
+            const int realIdxKF = __builtin_amdgcn_readlane(idxK, q);
+            const float aK = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angK), q));
+            if (a1 == k1) {   // exactly one lane: keys differ in the index bits
+              const int bestIdxF = (int)(k1 & 0xFFFFu);
+#pragma unroll
+              for (int j = 0; j < BM_FJ; ++j)
+                if (j < nJ && idxF[j] == bestIdxF && j * 64 + lane < nFs) {
+                  float rot = aK - angF[j];
+                  if (rot < 0.0f) rot += 360.0f;
+                  int bin = (int)roundf(rot * factor);
+                  if (bin == HISTO_LENGTH) bin = 0;
+                  myMatch[j] = realIdxKF; myBin[j] = bin;
+                }
+            }
+          }
+        }
+        if (nKs < 64) break;
+      }
+#pragma unroll
+      for (int j = 0; j < BM_FJ; ++j)
+        if (j < nJ && j * 64 + lane < nFs && myMatch[j] >= 0) { mF[idxF[j]] = myMatch[j]; bF[idxF[j]] = myBin[j]; }
+      continue;
     }
-    wave_top2(k1, k2);
-    const int bestDist1 = k1 == ~0ull ? 256 : (int)(k1 >> 32);
-    const int bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 32);
-    if (bestDist1 <= TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {
-      const int bestIdxF = (int)(k1 & 0xFFFFFFFFu);
-      float rot = kpsKF[(size_t)ik * cap + realIdxKF].angle - kpsF[(size_t)jf * cap + bestIdxF].angle;
-      if (rot < 0.0f) rot += 360.0f;
-      int bin = (int)roundf(rot * factor);
-      if (bin == HISTO_LENGTH) bin = 0;
-      if (lane == 0) { mF[bestIdxF] = realIdxKF; bF[bestIdxF] = bin; }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      __builtin_amdgcn_wave_barrier();
+    // ---- general path (a node with more than BM_FJ * 64 frame features): v1 logic on the LDS tables
+    int fEnd = fBeg;
+    while (fEnd < nF && (unsigned)(sf[fEnd] >> 32) == node) ++fEnd;
+    for (int q = p; q < nKF; ++q) {
+      const unsigned long long kq = sk[q];
+      if (kq == ~0ull || (unsigned)(kq >> 32) != node) break;
+      const int realIdxKF = (int)(kq & 0xFFFFFFFFu);
+      if (!hasMP[(size_t)ik * cap + realIdxKF]) continue;
+      const Desc dKF = load_desc(descKF + ((size_t)ik * cap + realIdxKF) * 32);
+      unsigned long long k1 = ~0ull, k2 = ~0ull;
+      for (int s0 = fBeg; s0 < fEnd; s0 += 64) {
+        const int s = s0 + lane;
+        if (s < fEnd) {
+          const int realIdxF = (int)(sf[s] & 0xFFFFFFFFu);
+          if (mF[realIdxF] < 0) {
+            const int d = hamming(dKF, load_desc(descF + ((size_t)jf * cap + realIdxF) * 32));
+            top2_insert(k1, k2, ((unsigned long long)d << 32) | (unsigned)realIdxF);
+          }
+        }
+      }
+      wave_top2(k1, k2);
+      const int bestDist1 = k1 == ~0ull ? 256 : (int)(k1 >> 32);
+      const int bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 32);
+      if (bestDist1 <= TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {
+        const int bestIdxF = (int)(k1 & 0xFFFFFFFFu);
+        float rot = kpsKF[(size_t)ik * cap + realIdxKF].angle - kpsF[(size_t)jf * cap + bestIdxF].angle;
+        if (rot < 0.0f) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        if (lane == 0) { mF[bestIdxF] = realIdxKF; bF[bestIdxF] = bin; }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
+#ifdef MORB_FAST_TIMING
+  BOW_MARK(3);
+#endif
 }
 
 __device__ void three_maxima(const int* cnt, int L, int& ind1, int& ind2, int& ind3) {  // ORBmatcher.cc:1844-1876
@@ -736,11 +878,21 @@ int morb_search_by_bow_batch(morb_matcher* m, int npairs, const int* d_kfImg, co
   hipLaunchKernelGGL(k_bow_sort, dim3(nimg), dim3(256), (size_t)P * 8, st, d_node, d_count, cap, P, m->d_sortA);
   const size_t nm = (size_t)npairs * cap;
   hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, d_matchF, nm, -1);
-  hipLaunchKernelGGL(k_bow_match, dim3(div_up(cap, 4), npairs), dim3(256), 0, st, m->d_sortA, m->d_sortA, d_count, d_count,
+  MORB_REQUIRE(cap < 65536 && (size_t)cap * 18 <= 160 * 1024, MORB_ERR_UNSUPPORTED, "too many features per frame for the LDS-resident node tables");
+  MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)cap * 18)));
+  hipLaunchKernelGGL(k_bow_match, dim3(BM_NB, npairs), dim3(256), (size_t)cap * 18, st, m->d_sortA, m->d_sortA, d_count, d_count,
                      cap, d_desc, d_hasMP, d_kps, d_desc, d_kps, d_kfImg, d_fImg, nnratio, d_matchF, m->d_bin);
   hipLaunchKernelGGL(k_rot_filter, dim3(npairs), dim3(256), 0, st, d_count, d_fImg, cap, checkOri, d_matchF, m->d_bin, d_nmatches);
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
 }
+
+#ifdef MORB_FAST_TIMING
+int morb_bow_timing(unsigned long long* out, int reset) {
+  (void)reset;
+  MORB_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bowTrace), sizeof(unsigned long long) * 16384 * 4));
+  return 0;
+}
+#endif
 
 }  // extern "C"

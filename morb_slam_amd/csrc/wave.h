@@ -1,0 +1,43 @@
+// Wave64 reductions on the DPP data path (gfx9 row_shr / row_bcast), result broadcast to all lanes.
+// __shfl_xor butterflies compile to ds_bpermute (an LDS-crossbar round trip per step, six dependent steps); in the
+// greedy / sequential kernels of this library (one wave replaying an order-dependent loop) a reduction sits on the
+// critical path of every iteration, so it is done with six DPP VALU ops + one readlane instead.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace morbwave {
+
+// dpp_ctrl: row_shr:n = 0x110 + n, row_bcast:15 = 0x142 (row_mask 0xa), row_bcast:31 = 0x143 (row_mask 0xc)
+#define MORB_DPP_SCAN(v, ident, OP)                                                              \
+  do {                                                                                           \
+    v = OP(v, (decltype(v))__builtin_amdgcn_update_dpp((int)(ident), (int)(v), 0x111, 0xf, 0xf, false)); \
+    v = OP(v, (decltype(v))__builtin_amdgcn_update_dpp((int)(ident), (int)(v), 0x112, 0xf, 0xf, false)); \
+    v = OP(v, (decltype(v))__builtin_amdgcn_update_dpp((int)(ident), (int)(v), 0x114, 0xf, 0xf, false)); \
+    v = OP(v, (decltype(v))__builtin_amdgcn_update_dpp((int)(ident), (int)(v), 0x118, 0xf, 0xf, false)); \
+    v = OP(v, (decltype(v))__builtin_amdgcn_update_dpp((int)(ident), (int)(v), 0x142, 0xa, 0xf, false)); \
+    v = OP(v, (decltype(v))__builtin_amdgcn_update_dpp((int)(ident), (int)(v), 0x143, 0xc, 0xf, false)); \
+  } while (0)
+
+__device__ __forceinline__ uint32_t op_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ int op_add(int a, int b) { return a + b; }
+
+// min over the 64 lanes (all lanes must be active)
+__device__ __forceinline__ uint32_t min_u32(uint32_t v) {
+  MORB_DPP_SCAN(v, 0xFFFFFFFFu, op_umin);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// sum over the 64 lanes (all lanes must be active)
+__device__ __forceinline__ int sum_i32(int v) {
+  MORB_DPP_SCAN(v, 0, op_add);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// min of a 64-bit key: high words first, then the low words of the lanes that hold the winning high word
+__device__ __forceinline__ unsigned long long min_u64(unsigned long long v) {
+  const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+  const uint32_t mh = min_u32(hi);
+  const uint32_t ml = min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+  return ((unsigned long long)mh << 32) | ml;
+}
+
+}  // namespace morbwave

@@ -93,14 +93,17 @@ def test_knn2_ratio(batch):
     assert (idx[0, :nqn[0], 0] == 0).all() and (idx[0, :nqn[0], 1] == -1).all() and (idx[2, :nqn[2]] == -1).all()
 
 
-def test_bow_transform_and_search_by_bow(batch):
+# vocabulary shapes: ~12 features per node (one register slot per lane), ~75 per node (two slots per lane, keyframe
+# features in two chunks), ~400 per node (the general path of k_bow_match)
+@pytest.mark.parametrize("k,Lv,lup,settings", [(10, 3, 1, ((0.7, True), (0.9, False), (0.6, True))),
+                                               (4, 3, 1, ((0.7, True),)), (3, 2, 1, ((0.8, True),))])
+def test_bow_transform_and_search_by_bow(batch, k, Lv, lup, settings):
     import torch
     from morb_slam_amd import ORBmatcher
-    k, Lv, lup = 10, 3, 1
     vd, vf = make_vocabulary(k, Lv, seed=2)
     dvd, dvf = torch.from_numpy(vd).cuda(), torch.from_numpy(vf).cuda()
     desc, cnt, kps = batch["desc"], batch["cnt"], batch["kps"]
-    for ratio, ori in ((0.7, True), (0.9, False), (0.6, True)):
+    for ratio, ori in settings:
         m = ORBmatcher(ratio, ori)
         word, node = m.bow_transform(desc, cnt, dvd, dvf, k, Lv, lup)
         torch.cuda.synchronize()
@@ -126,7 +129,7 @@ def test_bow_transform_and_search_by_bow(batch):
             assert nm[p] == ne
             np.testing.assert_array_equal(match[p, :len(kb)], me)
             tot += ne
-        assert tot > 500
+        assert tot > 300
 
 
 # ---- projection-guided searches --------------------------------------------------------------------------
