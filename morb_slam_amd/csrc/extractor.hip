@@ -264,22 +264,24 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {   // v_pk_m
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
 
-constexpr int FAST_LD = 6;    // dwords per thread for the window: 256 * 6 * 4 bytes covers the largest one (checked in configure())
+constexpr int FAST_LD = 6;    // window dwords a thread keeps in flight per round of the tile load
+constexpr int FAST_NT = 128;  // threads per cell: per-wave fixed costs (setup, row prefix, partly filled survivor rounds) x 2 instead of x 4; 64 leaves too few waves per SIMD
 
 // PMC (profiles/r01): the kernel is VALU-issue bound (~90 % of SIMD cycles issue VALU), not memory bound, so the
 // design rule is instruction count: no integer divisions (host-side magics in FastGeom / kernel arguments), SWAR
 // for the reject test, exact strength only for survivors.
-__global__ __launch_bounds__(256) void k_fast(const morb::FastGeom fg, int nlevels,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_fast(const morb::FastGeom fg, int nlevels,
                                               const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
                                               int* __restrict__ candCnt, int totalCells, int cellCap, int tilePitch,
-                                              int tileRows, unsigned gMagic, int iniTh, int minTh) {
+                                              int tileRows, int bmWords, unsigned gMagic, int iniTh, int minTh) {
   extern __shared__ __align__(16) uint8_t smem[];
   uint8_t* tile = smem;                           // [tileRows][tilePitch]
   uint8_t* sc = smem + tileRows * tilePitch;      // [tileRows][tilePitch] strength, 0 where it cannot matter
   uint16_t* queue = reinterpret_cast<uint16_t*>(smem + 2 * tileRows * tilePitch);  // [tileRows * tilePitch] y << 8 | x
-  uint32_t* bmHi = reinterpret_cast<uint32_t*>(smem + 4 * tileRows * tilePitch);  // [tileRows][8] keep bits at iniThFAST
-  uint32_t* bmLo = bmHi + tileRows * 8;                                            // [tileRows][8] keep bits at minThFAST
-  int* rowCnt = reinterpret_cast<int*>(bmLo + tileRows * 8);                       // [tileRows + 1]
+  uint32_t* bmHi = reinterpret_cast<uint32_t*>(smem + 4 * tileRows * tilePitch);  // [tileRows][bmWords] keep bits at iniThFAST
+  uint32_t* bmLo = bmHi + tileRows * bmWords;                                      // [tileRows][bmWords] keep bits at minThFAST
+  int* rowCnt = reinterpret_cast<int*>(bmLo + tileRows * bmWords);                       // [tileRows + 1]
   __shared__ int qn;
 
 #ifdef MORB_FAST_TIMING
@@ -315,20 +317,22 @@ __global__ __launch_bounds__(256) void k_fast(const morb::FastGeom fg, int nleve
     // block pays one global-load latency.  Columns >= tw are never evaluated; they lie in the padded pyramid row or
     // the next one (the slab has 256 bytes of slack behind it).
     const int nD = th * G;
-    uint32_t v[FAST_LD]; int off[FAST_LD];
+    for (int base0 = 0; base0 < nD; base0 += NT * FAST_LD) {
+      uint32_t v[FAST_LD]; int off[FAST_LD];
 #pragma unroll
-    for (int k = 0; k < FAST_LD; ++k) {
-      const int i = imin(tid + k * 256, nD - 1);
-      const int r = (int)__umulhi((unsigned)i, gMagic), c4 = (i - r * G) << 2;
-      off[k] = r * tilePitch + c4;
-      v[k] = *reinterpret_cast<const uint32_t*>(base + (size_t)r * pstride + c4);
-    }
+      for (int k = 0; k < FAST_LD; ++k) {
+        const int i = imin(base0 + tid + k * NT, nD - 1);
+        const int r = (int)__umulhi((unsigned)i, gMagic), c4 = (i - r * G) << 2;
+        off[k] = r * tilePitch + c4;
+        v[k] = *reinterpret_cast<const uint32_t*>(base + (size_t)r * pstride + c4);
+      }
 #pragma unroll
-    for (int k = 0; k < FAST_LD; ++k) {
-      *reinterpret_cast<uint32_t*>(tile + off[k]) = v[k];
-      *reinterpret_cast<uint32_t*>(sc + off[k]) = 0u;
+      for (int k = 0; k < FAST_LD; ++k) {
+        *reinterpret_cast<uint32_t*>(tile + off[k]) = v[k];
+        *reinterpret_cast<uint32_t*>(sc + off[k]) = 0u;
+      }
     }
-    for (int i = tid; i < th * 8; i += 256) { bmHi[i] = 0; bmLo[i] = 0; }
+    for (int i = tid; i < th * bmWords; i += NT) { bmHi[i] = 0; bmLo[i] = 0; }
     if (tid == 0) qn = 0;
   }
   __syncthreads();
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(256) void k_fast(const morb::FastGeom fg, int nleve
     const int nGroups = eh * G;
     const unsigned K = 0x80008000u, LO = 0x00FF00FFu;
     const unsigned T1 = (unsigned)(tmin + 1) * 0x00010001u;
-    for (int i0 = 0; i0 < nGroups; i0 += 256) {
+    for (int i0 = 0; i0 < nGroups; i0 += NT) {
       const int i = i0 + tid;
       unsigned re = 0, ro = 0;   // bit 15 / 31: pixel may exceed tmin (even bytes, odd bytes)
       int x4 = 0, y = 0;
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(256) void k_fast(const morb::FastGeom fg, int nleve
     PHASE_MARK(1);
     // Phase 2 — exact strength for the survivors only, densely packed over the workgroup
     const int nq = qn;
-    for (int q = tid; q < nq; q += 256) {
+    for (int q = tid; q < nq; q += NT) {
       const int e = queue[q];
       const int y = e >> 8, x = e & 255;
       const int s = fast_strength(tile + y * tilePitch + x, tilePitch);
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(256) void k_fast(const morb::FastGeom fg, int nleve
 
     // Phase 3 — NMS at both thresholds, only for pixels that have a strength; results go to per-row bitmaps.
     // corner at t iff S > t, score S - 1, non-corner neighbours score 0; keep iff strictly greater than all 8.
-    for (int q = tid; q < nq; q += 256) {
+    for (int q = tid; q < nq; q += NT) {
       const int e = queue[q];
       const int y = e >> 8, x = e & 255;
       const uint8_t* c = sc + y * tilePitch + x;
@@ -428,21 +432,20 @@ __global__ __launch_bounds__(256) void k_fast(const morb::FastGeom fg, int nleve
           kh = kh && (S - 1 > (Sn > iniTh ? Sn - 1 : 0));
           kl = kl && (S - 1 > (Sn > minTh ? Sn - 1 : 0));
         }
-      if (kh) atomicOr(&bmHi[y * 8 + (x >> 5)], 1u << (x & 31));
-      if (kl) atomicOr(&bmLo[y * 8 + (x >> 5)], 1u << (x & 31));
+      if (kh) atomicOr(&bmHi[y * bmWords + (x >> 5)], 1u << (x & 31));
+      if (kl) atomicOr(&bmLo[y * bmWords + (x >> 5)], 1u << (x & 31));
     }
     __syncthreads();
     PHASE_MARK(3);
     // Phase 4 — vKeysCell.empty() -> second cv::FAST with minThFAST (:795); row prefix sums of the chosen bitmap
     unsigned anyBits = 0;
-    for (int i = tid; i < th * 8; i += 256) anyBits |= bmHi[i];
+    for (int i = tid; i < th * bmWords; i += NT) anyBits |= bmHi[i];
     const int anyHi = __syncthreads_or(anyBits != 0);
     const uint32_t* bm = anyHi ? bmHi : bmLo;
-    if (tid < th) {
+    for (int r = tid; r < th; r += NT) {
       int c = 0;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) c += __popc(bm[tid * 8 + w]);
-      rowCnt[tid] = c;
+      for (int w = 0; w < bmWords; ++w) c += __popc(bm[r * bmWords + w]);
+      rowCnt[r] = c;
     }
     __syncthreads();
     if (tid < 64) {   // exclusive scan of the row counts by one wave, ceil(th / 64) consecutive rows per lane
@@ -460,14 +463,14 @@ __global__ __launch_bounds__(256) void k_fast(const morb::FastGeom fg, int nleve
     PHASE_MARK(4);
     // Phase 5 — ordered output (row-major over the evaluated area): slot = row prefix + set bits to the left
     uint32_t* out = cand + cellSlot * (size_t)cellCap;
-    for (int q = tid; q < nq; q += 256) {
+    for (int q = tid; q < nq; q += NT) {
       const int e = queue[q];
       const int y = e >> 8, x = e & 255;
       const int w = x >> 5;
-      const uint32_t word = bm[y * 8 + w];
+      const uint32_t word = bm[y * bmWords + w];
       if (!((word >> (x & 31)) & 1u)) continue;
       int slot = rowCnt[y] + __popc(word & ((1u << (x & 31)) - 1u));
-      for (int ww = 0; ww < w; ++ww) slot += __popc(bm[y * 8 + ww]);
+      for (int ww = 0; ww < w; ++ww) slot += __popc(bm[y * bmWords + ww]);
       if (slot < cellCap) out[slot] = morbqt::make_key(x + c.cj * c.wCell, y + c.ci * c.hCell, sc[y * tilePitch + x] - 1);
     }
     if (tid == 0) candCnt[cellSlot] = imin(rowCnt[th], cellCap);
@@ -860,8 +863,7 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     g.ytabOff = (int)tabs.size(); build(g.h, gs.h, false, tabs);
   }
   e->totalCells = cellBase;
-  MORB_REQUIRE(e->tileRows * (e->tilePitch / 4) <= 256 * FAST_LD, MORB_ERR_UNSUPPORTED,
-               "FAST cell window larger than the register tile of k_fast");
+
   e->selPerImg = selBase;
   e->blurTiles = blurTileBase;
   e->pyrBytes = pyrOff; e->blurBytes = blurOff; e->qtElems = qtOff;
@@ -1070,9 +1072,10 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   hipLaunchKernelGGL(k_blur, dim3(e->blurTiles, nimg), dim3(256), 0, st, e->d_geom, L, e->d_pyr, e->d_blur);
   mark(2);
   {
-    const size_t smem = 4ull * e->tileRows * e->tilePitch + (size_t)e->tileRows * 68 + 16;  // tile, strength, u16 queue, 2 bitmaps, row counts
-    hipLaunchKernelGGL(k_fast, dim3(e->totalCells, nimg), dim3(256), smem, st, e->fastGeom, L, e->d_pyr, e->d_cand,
-                       e->d_candCnt, e->totalCells, e->cellCap, e->tilePitch, e->tileRows,
+    const int bmWords = (e->tilePitch + 31) / 32;
+    const size_t smem = 4ull * e->tileRows * e->tilePitch + (size_t)e->tileRows * (8 * bmWords + 4) + 16;  // tile, strength, u16 queue, 2 bitmaps, row counts
+    hipLaunchKernelGGL(k_fast<FAST_NT>, dim3(e->totalCells, nimg), dim3(FAST_NT), smem, st, e->fastGeom, L, e->d_pyr, e->d_cand,
+                       e->d_candCnt, e->totalCells, e->cellCap, e->tilePitch, e->tileRows, bmWords,
                        0xFFFFFFFFu / (unsigned)(e->tilePitch / 4) + 1u, e->iniTh, e->minTh);
   }
   mark(3);
