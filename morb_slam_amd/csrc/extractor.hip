@@ -486,17 +486,21 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
                                                    int* __restrict__ selCnt, int selPerImg, int nlevels,
                                                    int maxNodeCap, int maxCells) {
   extern __shared__ __align__(16) uint8_t smem[];
-  const int lvl = blockIdx.x, img = blockIdx.y, lane = threadIdx.x;
+  const int lvl = blockIdx.y, img = blockIdx.x, lane = threadIdx.x;
+  __builtin_amdgcn_s_setprio(3);   // a long dependent chain: win instruction arbitration against the blur waves sharing the SIMD
   const LevelGeom g = geom[lvl];
   // LDS carve-up (sizes from the largest level)
   uint8_t* sp = smem;
   uint64_t* vA = reinterpret_cast<uint64_t*>(sp); sp += (size_t)maxNodeCap * 8;
   uint64_t* vB = reinterpret_cast<uint64_t*>(sp); sp += (size_t)maxNodeCap * 8;
+  uint64_t* bcnt = vB;   // the batch split's child counts: vB is only live between the sort and the order[] it feeds
   morbqt::Node* nodes = reinterpret_cast<morbqt::Node*>(sp); sp += (size_t)maxNodeCap * sizeof(morbqt::Node);
   uint32_t* ldsKeys = reinterpret_cast<uint32_t*>(sp); sp += (size_t)kLdsKeys * 4;
   uint32_t* ldsTmp = reinterpret_cast<uint32_t*>(sp); sp += (size_t)kLdsKeys * 4;
   int* cellOff = reinterpret_cast<int*>(sp); sp += (size_t)(maxCells + 1) * 4;
+  uint32_t* brank = reinterpret_cast<uint32_t*>(sp); sp += (size_t)maxNodeCap * 4;
   uint16_t* freeIds = reinterpret_cast<uint16_t*>(sp); sp += (size_t)maxNodeCap * 2;
+  uint16_t* order = reinterpret_cast<uint16_t*>(sp); sp += (size_t)maxNodeCap * 2;
   uint16_t* list = reinterpret_cast<uint16_t*>(sp);
 
 #ifdef MORB_FAST_TIMING
@@ -548,6 +552,7 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
 
   morbqt::Work w;
   w.keys = keys; w.tmp = tmp; w.nodes = nodes; w.freeIds = freeIds; w.list = list; w.vA = vA; w.vB = vB;
+  w.order = order; w.bcnt = bcnt; w.brank = brank;
   w.nodeCap = g.nodeCap; w.listCap = g.listCap;
   uint32_t* out = sel + (size_t)img * selPerImg + g.selBase;
   const int n = morbqt::qt_distribute(w, (uint32_t)T, g.maxBorderX - MINB, g.maxBorderY - MINB, g.quota, out, g.selCap);
@@ -868,7 +873,7 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
   e->blurTiles = blurTileBase;
   e->pyrBytes = pyrOff; e->blurBytes = blurOff; e->qtElems = qtOff;
   e->outCap = selBase;
-  e->distSmem = (size_t)e->maxNodeCap * (8 + 8 + sizeof(morbqt::Node) + 2) + (size_t)kLdsKeys * 8 +
+  e->distSmem = (size_t)e->maxNodeCap * (8 + 8 + sizeof(morbqt::Node) + 4 + 2 + 2) + (size_t)kLdsKeys * 8 +
                 (size_t)(e->maxCells + 1) * 4 + (size_t)e->maxListCap * 2 + 64;
   MORB_REQUIRE(e->distSmem <= 160 * 1024, MORB_ERR_UNSUPPORTED, "nfeatures too large for the LDS-resident quadtree");
 
@@ -957,11 +962,15 @@ int morb_extractor_create(morb_extractor** out, int nfeatures, float scaleFactor
     for (int i = 0; i < 16; ++i)
       if (e->umax[i] != kStd[i]) { set_error("umax table mismatch"); delete e; return MORB_ERR_UNSUPPORTED; }
   }
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&e->sideStream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->evJoin, hipEventDisableTiming) != hipSuccess) {
     set_error("cannot create a stream on device %d", device);
     delete e;
     return MORB_ERR_HIP;
   }
+  { const char* v = getenv("MORB_EXTRACT_SERIAL"); e->overlapBlur = !(v && v[0] == '1'); }
   *out = e;
   return MORB_OK;
 }
@@ -974,6 +983,9 @@ void morb_extractor_destroy(morb_extractor* e) {
   free_staging(e);
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   e->ev.clear();
+  if (e->evFork) (void)hipEventDestroy(e->evFork);
+  if (e->evJoin) (void)hipEventDestroy(e->evJoin);
+  if (e->sideStream) (void)hipStreamDestroy(e->sideStream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -1003,7 +1015,7 @@ int morb_extractor_set_profiling(morb_extractor* e, int enable) {
   e->profiling = enable != 0;
   e->profCalls = 0;
   if (e->profiling && e->ev.empty()) {
-    e->ev.resize((size_t)morb_extractor::kProfRing * 7, nullptr);
+    e->ev.resize((size_t)morb_extractor::kProfRing * 8, nullptr);
     for (auto& ev : e->ev) MORB_HIP_CHECK(hipEventCreate(&ev));
   }
   return MORB_OK;
@@ -1013,16 +1025,17 @@ int morb_extractor_stage_ms(morb_extractor* e, float* ms7) {
   const int n = e->profCalls < morb_extractor::kProfRing ? e->profCalls : morb_extractor::kProfRing;
   for (int i = 0; i < 7; ++i) e->stageMs[i] = 0.f;
   for (int c = 0; c < n; ++c) {
-    hipEvent_t* ev = &e->ev[(size_t)c * 7];
-    MORB_HIP_CHECK(hipEventSynchronize(ev[6]));
-    for (int i = 0; i < 6; ++i) {
+    // events: 0 start, 1 pyramid done, 2 FAST done, 3 quadtree done, 4 layout done, 5 describe done (launch stream);
+    // 6 / 7 around the blur on the side stream.  Stages: pyramid, blur, fast, distribute, layout, describe, total.
+    hipEvent_t* ev = &e->ev[(size_t)c * 8];
+    MORB_HIP_CHECK(hipEventSynchronize(ev[5]));
+    MORB_HIP_CHECK(hipEventSynchronize(ev[7]));
+    const int from[7] = {0, 6, 1, 2, 3, 4, 0}, to[7] = {1, 7, 2, 3, 4, 5, 5};
+    for (int i = 0; i < 7; ++i) {
       float ms = 0.f;
-      MORB_HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+      MORB_HIP_CHECK(hipEventElapsedTime(&ms, ev[from[i]], ev[to[i]]));
       e->stageMs[i] += ms / n;
     }
-    float ms = 0.f;
-    MORB_HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[6]));
-    e->stageMs[6] += ms / n;
   }
   for (int i = 0; i < 7; ++i) ms7[i] = e->stageMs[i];
   e->profCalls = 0;
@@ -1054,7 +1067,7 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
     }
   }
 
-  hipEvent_t* evs = e->profiling ? &e->ev[(size_t)(e->profCalls % morb_extractor::kProfRing) * 7] : nullptr;
+  hipEvent_t* evs = e->profiling ? &e->ev[(size_t)(e->profCalls % morb_extractor::kProfRing) * 8] : nullptr;
   auto mark = [&](int i) { if (evs) (void)hipEventRecord(evs[i], st); };
   mark(0);
   {
@@ -1069,8 +1082,6 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
     }
   }
   mark(1);
-  hipLaunchKernelGGL(k_blur, dim3(e->blurTiles, nimg), dim3(256), 0, st, e->d_geom, L, e->d_pyr, e->d_blur);
-  mark(2);
   {
     const int bmWords = (e->tilePitch + 31) / 32;
     const size_t smem = 4ull * e->tileRows * e->tilePitch + (size_t)e->tileRows * (8 * bmWords + 4) + 16;  // tile, strength, u16 queue, 2 bitmaps, row counts
@@ -1078,17 +1089,30 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
                        e->d_candCnt, e->totalCells, e->cellCap, e->tilePitch, e->tileRows, bmWords,
                        0xFFFFFFFFu / (unsigned)(e->tilePitch / 4) + 1u, e->iniTh, e->minTh);
   }
-  mark(3);
-  hipLaunchKernelGGL(k_distribute, dim3(L, nimg), dim3(64), e->distSmem, st, e->d_geom, e->d_cand, e->d_candCnt,
+  mark(2);
+  // The blur only feeds the descriptors and is VALU-bound; the quadtree is one latency-bound wave per (level, image)
+  // that leaves the vector ALUs ~90 % idle.  Fork: the blur runs on the handle's side stream underneath the quadtree
+  // and the layout, and the launch stream joins it again before k_describe.
+  MORB_HIP_CHECK(hipEventRecord(e->evFork, st));
+  // the quadtree is enqueued first so that its 1024 long-running waves get their slots before the blur fills the chip;
+  // level 0 (the longest wave) first: grid x = image, y = level
+  hipLaunchKernelGGL(k_distribute, dim3(nimg, L), dim3(64), e->distSmem, st, e->d_geom, e->d_cand, e->d_candCnt,
                      e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L, e->maxNodeCap,
                      e->maxCells);
-  mark(4);
+  hipStream_t sideStream = e->overlapBlur ? e->sideStream : st;   // MORB_EXTRACT_SERIAL=1: everything on the launch stream
+  MORB_HIP_CHECK(hipStreamWaitEvent(sideStream, e->evFork, 0));
+  if (evs) (void)hipEventRecord(evs[6], sideStream);
+  hipLaunchKernelGGL(k_blur, dim3(e->blurTiles, nimg), dim3(256), 0, sideStream, e->d_geom, L, e->d_pyr, e->d_blur);
+  if (evs) (void)hipEventRecord(evs[7], sideStream);
+  MORB_HIP_CHECK(hipEventRecord(e->evJoin, sideStream));
+  mark(3);
   hipLaunchKernelGGL(k_layout, dim3(nimg), dim3(256), 0, st, e->d_geom, L, e->d_sel, e->d_selCnt, e->selPerImg,
                      e->d_lap, e->d_kref, d_count, d_mono, cap);
-  mark(5);
+  mark(4);
+  MORB_HIP_CHECK(hipStreamWaitEvent(st, e->evJoin, 0));
   hipLaunchKernelGGL(k_describe, dim3(div_up(e->selPerImg, 4), nimg), dim3(256), 0, st, e->descGeom, e->d_pyr,
                      e->d_blur, e->d_kref, e->selPerImg, d_kps, d_desc, cap);
-  mark(6);
+  mark(5);
   MORB_HIP_CHECK(hipGetLastError());
   if (e->profiling) ++e->profCalls;
   return MORB_OK;

@@ -72,6 +72,9 @@ struct morb_extractor {
   size_t pyrBytes = 0, blurBytes = 0, qtElems = 0, distSmem = 0;
 
   hipStream_t stream = nullptr;
+  hipStream_t sideStream = nullptr;          // the blur runs here, underneath the quadtree (fork after FAST, join before describe)
+  hipEvent_t evFork = nullptr, evJoin = nullptr;
+  bool overlapBlur = true;
   morb::LevelGeom* d_geom = nullptr;
   morb::ResizeTab* d_tabs = nullptr;
   uint8_t *d_pyr = nullptr, *d_blur = nullptr;
@@ -85,7 +88,7 @@ struct morb_extractor {
   // timed region never synchronises with the host
   bool profiling = false;
   static constexpr int kProfRing = 64;
-  std::vector<hipEvent_t> ev;  // [kProfRing][7]
+  std::vector<hipEvent_t> ev;  // [kProfRing][8]
   int profCalls = 0;
   float stageMs[7] = {0};
 };

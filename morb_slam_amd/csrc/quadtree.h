@@ -31,7 +31,7 @@ __device__ unsigned long long g_fastPhase[16];   // phase clocks of tools/fast_p
 #endif
 #if defined(MORB_FAST_TIMING) && QT_DEVICE
 #define QT_T0() unsigned long long q0_ = wall_clock64()
-#define QT_MARK(k) do { if (QT_LANE0 && blockIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_fastPhase[k], now_ - q0_); q0_ = now_; } } while (0)
+#define QT_MARK(k) do { if (QT_LANE0 && blockIdx.y == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_fastPhase[k], now_ - q0_); q0_ = now_; } } while (0)
 #else
 #define QT_T0()
 #define QT_MARK(k)
@@ -60,11 +60,20 @@ struct Work {
   uint16_t* list;     // [listCap] node id or 0xFFFF (erased)
   uint64_t* vA;       // [nodeCap] vSizeAndPointerToNode: count << 32 | x0 << 16 | id
   uint64_t* vB;       // [nodeCap] vPrevSizeAndPointerToNode
+  // batch split (device): the nodes one sweep divides, in processing order, with their child key counts and ranks
+  uint16_t* order;    // [nodeCap] node ids
+  uint64_t* bcnt;     // [nodeCap] keys per child, 4 x 16 bit (n1 | n2 << 16 | n3 << 32 | n4 << 48)
+  uint32_t* brank;    // [nodeCap] children pushed before this node | children with > 1 key before it << 16
   int nodeCap, listCap;
 };
 
-QT_HD int qt_node_cap(int N, int nIni) { int a = N + 3, b = 4 * nIni; return (a > b ? a : b) + 8; }
-QT_HD int qt_list_cap(int nodeCap) { return 5 * nodeCap; }
+// Live nodes never exceed N + 3 (a full sweep only runs when it cannot overshoot N, the "largest first" phase stops at
+// N); the device splits a whole sweep at once and takes the children's ids before the parents' ids are released, so
+// it needs up to one id per parent on top of that.
+QT_HD int qt_node_cap(int N, int nIni) { int a = N + 3, b = 4 * nIni; return 2 * (a > b ? a : b) + 16; }
+// Between two compactions the list holds the live nodes at the last compaction (<= N + 3) plus every child pushed since
+// (<= N + 3 live afterwards + one tombstone per parent <= N + 3): 3 (N + 3) < 2 nodeCap.
+QT_HD int qt_list_cap(int nodeCap) { return 2 * nodeCap; }
 
 #if QT_DEVICE
 #define QT_LANE ((int)(threadIdx.x & 63))
@@ -430,6 +439,147 @@ QT_HD void qt_split(Work& w, State& s, int id, int* nToExpand) {
 }
 #endif
 
+#if QT_DEVICE
+// ---- one sweep at a time --------------------------------------------------------------------------------------
+// The splits of one sweep are independent: a node's children only depend on its own keys, and where they go in the
+// list / in vSizeAndPointerToNode only depends on how many children the nodes BEFORE it (in processing order)
+// produce.  So: (1) count the keys per child for every node of the sweep, one node per lane (nodes with more than
+// QT_SMALL keys by the whole wave), (2) prefix-sum children and expandable children in processing order — and, for the
+// "largest first" phase, find the node whose split makes size >= N (the reference breaks right after it) —
+// (3) partition the keys and write the children.  v1 did ~190 dependent splits per level-0 image (94 us).
+constexpr uint32_t QT_SMALL = 64;
+__device__ __forceinline__ int qt_class(uint32_t k, int mx, int my) { return (key_x(k) < mx ? 0 : 1) + (key_y(k) < my ? 0 : 2); }
+__device__ __forceinline__ int qt_scan_incl(int v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d, 64); if (QT_LANE >= d) v += o; }
+  return v;
+}
+__device__ __forceinline__ void qt_write_children(Work& w, const Node& nd, int mx, int my, uint64_t cnt64, uint32_t rk, int oldHead,
+                                                  int nA0, int nFree0, int c) {
+  // child c (0..3) of nd: rank among the node's non-empty children = number of non-empty children before it
+  int r = 0, re = 0;
+  uint32_t b = nd.begin;
+  for (int q = 0; q < c; ++q) { const uint32_t cq = (uint32_t)(cnt64 >> (16 * q)) & 0xFFFFu; r += cq > 0; re += cq > 1; b += cq; }
+  const uint32_t myCnt = (uint32_t)(cnt64 >> (16 * c)) & 0xFFFFu;
+  if (myCnt == 0) return;
+  const int gr = (int)(rk & 0xFFFFu) + r, ge = (int)(rk >> 16) + re;
+  const int cid = w.freeIds[nFree0 - 1 - gr];
+  Node ch;
+  ch.x0 = (int16_t)((c & 1) ? mx : nd.x0); ch.x1 = (int16_t)((c & 1) ? nd.x1 : mx);
+  ch.y0 = (int16_t)((c & 2) ? my : nd.y0); ch.y1 = (int16_t)((c & 2) ? nd.y1 : my);
+  ch.begin = b; ch.count = myCnt; ch.lit = (uint16_t)(oldHead - 1 - gr); ch.noMore = (myCnt == 1) ? 1 : 0;
+  w.nodes[cid] = ch;
+  w.list[oldHead - 1 - gr] = (uint16_t)cid;
+  if (myCnt > 1) w.vA[nA0 + ge] = ((uint64_t)myCnt << 32) | ((uint64_t)(uint16_t)ch.x0 << 16) | (uint64_t)cid;
+}
+
+// Splits w.order[0..m) in that order; cutoffN >= 0: stop after the split that makes s.size >= cutoffN.
+__device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int* nToExpand) {
+  const int lane = QT_LANE;
+  QT_SYNC();
+  // (1) keys per child
+  for (int e0 = 0; e0 < m; e0 += 64) {
+    const int e = e0 + lane;
+    const bool valid = e < m;
+    Node nd = {};
+    if (valid) nd = w.nodes[w.order[e]];
+    const bool small = valid && nd.count <= QT_SMALL;
+    if (small) {
+      const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+      uint64_t c = 0;
+      for (uint32_t k = 0; k < nd.count; ++k) c += 1ull << (16 * qt_class(w.keys[nd.begin + k], mx, my));
+      w.bcnt[e] = c;
+    }
+    uint64_t big = __ballot(valid && !small);
+    while (big) {
+      const int bl = __ffsll((unsigned long long)big) - 1;
+      big &= big - 1;
+      const Node nb = w.nodes[w.order[e0 + bl]];
+      const int mx = nb.x0 + ((nb.x1 - nb.x0 + 1) >> 1), my = nb.y0 + ((nb.y1 - nb.y0 + 1) >> 1);
+      uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+      for (uint32_t i = 0; i < nb.count; i += 64) {
+        int g = -1;
+        if (i + lane < nb.count) g = qt_class(w.keys[nb.begin + i + lane], mx, my);
+        c0 += __popcll(__ballot(g == 0)); c1 += __popcll(__ballot(g == 1));
+        c2 += __popcll(__ballot(g == 2)); c3 += __popcll(__ballot(g == 3));
+      }
+      if (lane == 0) w.bcnt[e0 + bl] = (uint64_t)c0 | ((uint64_t)c1 << 16) | ((uint64_t)c2 << 32) | ((uint64_t)c3 << 48);
+    }
+  }
+  QT_SYNC();
+  // (2) ranks in processing order, and where to stop
+  int runCh = 0, runEx = 0, runSize = s.size, mProc = m;
+  for (int e0 = 0; e0 < m; e0 += 64) {
+    const int e = e0 + lane;
+    const uint64_t c = e < m ? w.bcnt[e] : 0ull;
+    int nCh = 0, nEx = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const uint32_t cq = (uint32_t)(c >> (16 * q)) & 0xFFFFu; nCh += cq > 0; nEx += cq > 1; }
+    const int incCh = qt_scan_incl(nCh), incEx = qt_scan_incl(nEx), incSz = qt_scan_incl(e < m ? nCh - 1 : 0);
+    int last = (m - e0 < 64 ? m - e0 : 64) - 1;
+    bool cut = false;
+    if (cutoffN >= 0) {
+      const uint64_t reach = __ballot(e < m && runSize + incSz >= cutoffN);
+      if (reach) { last = __ffsll((unsigned long long)reach) - 1; mProc = e0 + last + 1; cut = true; }
+    }
+    if (e < m) w.brank[e] = (uint32_t)(runCh + incCh - nCh) | ((uint32_t)(runEx + incEx - nEx) << 16);
+    runCh += __shfl(incCh, last, 64); runEx += __shfl(incEx, last, 64); runSize += __shfl(incSz, last, 64);
+    if (cut) break;
+  }
+  QT_SYNC();
+  // (3) partition the keys, write the children, erase the parents
+  const int oldHead = s.head, nA0 = s.nA, nFree0 = s.nFree;
+  for (int e0 = 0; e0 < mProc; e0 += 64) {
+    const int e = e0 + lane;
+    const bool valid = e < mProc;
+    Node nd = {};
+    uint64_t c = 0;
+    uint32_t rk = 0;
+    if (valid) { nd = w.nodes[w.order[e]]; c = w.bcnt[e]; rk = w.brank[e]; }
+    const bool small = valid && nd.count <= QT_SMALL;
+    const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+    if (small) {
+      // stable 4-way partition through tmp: group bases packed like the counts
+      const uint32_t c0 = (uint32_t)c & 0xFFFFu, c1 = (uint32_t)(c >> 16) & 0xFFFFu, c2 = (uint32_t)(c >> 32) & 0xFFFFu;
+      uint64_t bs = ((uint64_t)c0 << 16) | ((uint64_t)(c0 + c1) << 32) | ((uint64_t)(c0 + c1 + c2) << 48);
+      for (uint32_t k = 0; k < nd.count; ++k) {
+        const uint32_t key = w.keys[nd.begin + k];
+        const int g = qt_class(key, mx, my);
+        w.tmp[nd.begin + ((uint32_t)(bs >> (16 * g)) & 0xFFFFu)] = key;
+        bs += 1ull << (16 * g);
+      }
+      for (uint32_t k = 0; k < nd.count; ++k) w.keys[nd.begin + k] = w.tmp[nd.begin + k];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) qt_write_children(w, nd, mx, my, c, rk, oldHead, nA0, nFree0, q);
+      w.list[nd.lit] = 0xFFFF;
+    }
+    uint64_t big = __ballot(valid && !small);
+    while (big) {
+      const int bl = __ffsll((unsigned long long)big) - 1;
+      big &= big - 1;
+      const Node nb = w.nodes[w.order[e0 + bl]];
+      const int bmx = nb.x0 + ((nb.x1 - nb.x0 + 1) >> 1), bmy = nb.y0 + ((nb.y1 - nb.y0 + 1) >> 1);
+      uint32_t cnt[4];
+      qt_partition(w.keys, w.tmp, nb.begin, nb.count, [bmx, bmy](uint32_t k) -> int { return qt_class(k, bmx, bmy); }, cnt);
+      const uint64_t bc = w.bcnt[e0 + bl];
+      const uint32_t brk = w.brank[e0 + bl];
+      if (lane < 4) qt_write_children(w, nb, bmx, bmy, bc, brk, oldHead, nA0, nFree0, lane);
+      if (lane == 0) w.list[nb.lit] = 0xFFFF;
+    }
+  }
+  QT_SYNC();
+  // (4) bookkeeping; the parents' ids go back on the free stack after every child id has been taken
+  s.head = oldHead - runCh;
+  s.size += runCh - mProc;
+  s.nA = nA0 + runEx;
+  if (nToExpand) *nToExpand += runEx;
+  s.nFree = nFree0 - runCh;
+  for (int e = lane; e < mProc; e += 64) w.freeIds[s.nFree + e] = w.order[e];
+  s.nFree += mProc;
+  QT_SYNC();
+}
+#endif
+
 // Move the live entries to the top of the list array (order preserved) and refresh Node::lit.
 QT_HD void qt_compact(Work& w, State& s) {
   QT_SYNC();
@@ -524,22 +674,24 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
     s.nA = 0;
     const int oldHead = s.head;
 #if QT_DEVICE
-    // children are pushed in front of oldHead: not visited.  64 slots are fetched at once; only the nodes that
-    // need a split are visited (in list order) through the ballot mask.
-    for (int pos0 = oldHead; pos0 < w.listCap; pos0 += 64) {
-      const int pos = pos0 + QT_LANE;
-      int id = 0xFFFF;
-      bool todo = false;
-      if (pos < w.listCap) {
-        id = w.list[pos];
-        if (id != 0xFFFF) todo = !w.nodes[id].noMore;
+    // the sweep visits the list from oldHead on (children are pushed in front of it: not visited) and divides every
+    // node that is not bNoMore, with no early exit (:589-655): collect them in list order, then split them at once
+    {
+      int m = 0;
+      const uint64_t lt = QT_LANE == 0 ? 0ull : (~0ull >> (64 - QT_LANE));
+      for (int pos0 = oldHead; pos0 < w.listCap; pos0 += 64) {
+        const int pos = pos0 + QT_LANE;
+        int id = 0xFFFF;
+        bool todo = false;
+        if (pos < w.listCap) {
+          id = w.list[pos];
+          if (id != 0xFFFF) todo = !w.nodes[id].noMore;
+        }
+        const uint64_t mk = __ballot(todo);
+        if (todo) w.order[m + __popcll(mk & lt)] = (uint16_t)id;
+        m += __popcll(mk);
       }
-      uint64_t m = __ballot(todo);
-      while (m) {
-        const int b = __ffsll((unsigned long long)m) - 1;
-        m &= m - 1;
-        qt_split(w, s, __shfl(id, b, 64), &nToExpand);
-      }
+      qt_split_batch(w, s, m, -1, &nToExpand);
     }
 #else
     for (int pos = oldHead; pos < w.listCap; ++pos) {  // children are pushed in front of oldHead: not visited
@@ -570,11 +722,16 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
         QT_MARK(15);
         // compaction keeps ids stable (vB holds ids), only Node::lit moves
         qt_compact(w, s);
+#if QT_DEVICE
+        for (int j = QT_LANE; j < nPrev; j += 64) w.order[j] = (uint16_t)(w.vB[nPrev - 1 - j] & 0xFFFF);   // largest first
+        qt_split_batch(w, s, nPrev, N, nullptr);
+#else
         for (int j = nPrev - 1; j >= 0; --j) {
           const int id = (int)(w.vB[j] & 0xFFFF);
           qt_split(w, s, id, nullptr);
           if (s.size >= N) break;
         }
+#endif
         if (s.size >= N || s.size == prevSize2) bFinish = true;
       }
     }

@@ -17,7 +17,7 @@ int qt_host_distribute(const uint32_t* keys_in, int n, int width, int height, in
   std::vector<Node> nodes(nodeCap);
   std::vector<uint16_t> freeIds(nodeCap), list(listCap);
   std::vector<uint64_t> vA(nodeCap), vB(nodeCap);
-  Work w{keys.data(), tmp.data(), nodes.data(), freeIds.data(), list.data(), vA.data(), vB.data(), nodeCap, listCap};
+  Work w{keys.data(), tmp.data(), nodes.data(), freeIds.data(), list.data(), vA.data(), vB.data(), nullptr, nullptr, nullptr, nodeCap, listCap};
   return qt_distribute(w, (uint32_t)n, width, height, N, out, outCap);
 }
 
