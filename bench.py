@@ -214,34 +214,46 @@ def main():
     st_out = (torch.empty((B, cap), dtype=torch.float32, device=dev), torch.empty((B, cap), dtype=torch.float32, device=dev))
     bow_out = (torch.empty((2 * B, cap), dtype=torch.int32, device=dev), torch.empty((2 * B, cap), dtype=torch.int32, device=dev))
 
+    # Stereo matching and the BoW chain (ComputeBoW -> SearchByBoW) both only need the extractor's output and are
+    # latency-bound in different ways, so they run side by side: stereo on the extract stream, BoW on its own stream
+    # with its own matcher handle (one workspace set per stream); the step stream joins both at the end.
+    bstream = torch.cuda.Stream(device=dev)
+    bmatcher = ORBmatcher(0.7, True, device=local_rank)
+    ext_done = [torch.cuda.Event() for _ in range(C)]
+
     def step():
         nonlocal match_out
-        s = stream.cuda_stream
         kps, desc, cnt, _ = out
-        for c, (f0, f1) in enumerate(bounds):     # per chunk: extract -> stereo -> BoW on the chunk's own stream
+        bs = bstream.cuda_stream
+        bstream.wait_stream(stream)               # fork: ordered after whatever the step stream did before
+        for c, (f0, f1) in enumerate(bounds):     # per chunk: extract -> stereo on the chunk's stream, BoW descent on the BoW stream
             cs = cstreams[c]
             if C > 1:
-                cs.wait_stream(stream)            # fork: ordered after whatever the step stream did before
+                cs.wait_stream(stream)
             i0, i1 = 2 * f0, 2 * f1
             co = tuple(t[i0:i1] for t in out)
             exts[c].extract_batch(images[i0:i1], out=co, stream=cs.cuda_stream)                 # Frame::ExtractORB x2
+            ext_done[c].record(cs)
             cmatchers[c].ComputeStereoMatches(exts[c], co[0], co[1], co[2], mbf, mb,
                                               out=(st_out[0][f0:f1], st_out[1][f0:f1]), stream=cs.cuda_stream)   # Frame.cc:217
-            cmatchers[c].bow_transform(co[1], co[2], vd, vf, VK, VL, 4,
-                                       out=(bow_out[0][i0:i1], bow_out[1][i0:i1]), stream=cs.cuda_stream)       # Frame::ComputeBoW
-        if C > 1:
-            for cs in cstreams:
-                stream.wait_stream(cs)            # join: SearchByBoW pairs frames across chunk borders
+            bstream.wait_event(ext_done[c])
+            bmatcher.bow_transform(co[1], co[2], vd, vf, VK, VL, 4,
+                                   out=(bow_out[0][i0:i1], bow_out[1][i0:i1]), stream=bs)       # Frame::ComputeBoW
         if exch is None:
-            match_out = matcher.SearchByBoW(kf_img, f_img, kps, desc, bow_out[1], cnt, has_mp, out=match_out, stream=s)
+            match_out = bmatcher.SearchByBoW(kf_img, f_img, kps, desc, bow_out[1], cnt, has_mp, out=match_out, stream=bs)
         else:
-            with torch.cuda.stream(stream):      # the collective is ordered after the kernels on this stream
+            with torch.cuda.stream(bstream):      # the collective is ordered after the kernels on this stream
                 pk, pd, pc, pn = exch.exchange(kps[0::2], desc[0::2], cnt[0::2], bow_out[1][0::2])   # left images only
-            match_out = matcher.SearchByBoW(kf_img, f_img, pk, pd, pn, pc, has_mp, out=match_out, stream=s)
+            match_out = bmatcher.SearchByBoW(kf_img, f_img, pk, pd, pn, pc, has_mp, out=match_out, stream=bs)
+        for cs in cstreams:                       # join
+            if cs is not stream:
+                stream.wait_stream(cs)
+        stream.wait_stream(bstream)
 
     def sync_all():
         for cs in cstreams:
             cs.synchronize()
+        bstream.synchronize()
         stream.synchronize()
         torch.cuda.synchronize(dev)
         if dist is not None:
