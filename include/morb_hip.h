@@ -194,6 +194,37 @@ int morb_search_by_projection_mps_batch(morb_matcher*, const morb_frame_params*,
                                         int bFarPoints, float thFarPoints, float nnratio, int* d_matchF, int* d_nmatches,
                                         void* stream);
 
+/* Fisheye (KannalaBrandt8) rig, Frame::isInFrustum with Nleft != -1 (Frame.cc:665-677) = Frame::isInFrustumChecks
+ * (Frame.cc:1276-1346) once per camera.  One call = one camera: the caller passes mR, mt, twc exactly as :1283-1293
+ * builds them (left: mRcw, mtcw, mOw; right: Rrl * mRcw, Rrl * mtcw + trl, mRwc * mTlr.translation() + mOw; row-major
+ * 3x3 / 3 floats per frame) and that camera's parameters cam8 = fx fy cx cy k0 k1 k2 k3 (host pointer).  Outputs as
+ * morb_is_in_frustum_batch minus mTrackProjXR: left call -> mbTrackInView, mTrackProjX/Y, mTrackDepth,
+ * mnTrackScaleLevel, mTrackViewCos; right call -> mbTrackInViewR, mTrackProjXR/YR, mTrackDepthR, mnTrackScaleLevelR,
+ * mTrackViewCosR.  Fields of a rejected point are -1 (the reference leaves them stale). */
+int morb_is_in_frustum_kb8_batch(morb_matcher* m, const morb_frame_params* P, const float* cam8, int nframes, const float* d_R,
+                                 const float* d_t, const float* d_twc, int mpCap, const int* d_nMP, const float* d_Pw,
+                                 const float* d_normal, const float* d_maxDist, const float* d_minDist, float viewingCosLimit,
+                                 uint8_t* d_inView, float* d_projX, float* d_projY, float* d_depth, int* d_level,
+                                 float* d_viewCos, void* stream);
+
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints) on a fisheye rig: the
+ * F.Nleft != -1 branches of ORBmatcher.cc:42-209.  Image fImg[f] of the pool holds the Nleft left features followed
+ * by the right ones (mvKeys | mvKeysRight, mDescriptors = vconcat, Frame.cc:211-214): count = N, d_nLeft[f] = Nleft.
+ * d_l2r / d_r2l [nframes][cap] = mvLeftToRightMatch / mvRightToLeftMatch (local indices, -1 = none).  Left-camera
+ * fields (*L) and right-camera fields (*R) come from the two morb_is_in_frustum_kb8_batch calls.  matchF[f][j] =
+ * map point index claimed by feature j (left and right halves of the same table), -1 otherwise; nmatches as the
+ * reference counts them (a stereo partner counts as a second match). */
+int morb_search_by_projection_mps_fisheye_batch(morb_matcher* m, const morb_frame_params* P, int nframes, const int* d_fImg,
+                                                int cap, const int* d_count, const int* d_nLeft, const morb_keypoint* d_kps,
+                                                const uint8_t* d_desc, const int* d_l2r, const int* d_r2l,
+                                                const uint8_t* d_blocked, int mpCap, const int* d_nMP,
+                                                const uint8_t* d_inViewL, const uint8_t* d_inViewR, const uint8_t* d_isBad,
+                                                const float* d_depthL, const float* d_projXL, const float* d_projYL,
+                                                const int* d_levelL, const float* d_viewCosL, const float* d_projXR,
+                                                const float* d_projYR, const int* d_levelR, const float* d_viewCosR,
+                                                const uint8_t* d_mpDesc, const uint8_t* d_mpHasObs, float th, int bFarPoints,
+                                                float thFarPoints, float nnratio, int* d_matchF, int* d_nmatches, void* stream);
+
 /* int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)
  * ORBmatcher.h:55-56, ORBmatcher.cc:1521-1733.  Frame pair f = (image d_curImg[f], image d_lastImg[f]); d_Tcw
  * [f][7] = CurrentFrame pose (quaternion xyzw + translation); per last-frame feature [nframes][cap]:

@@ -68,6 +68,7 @@ struct Query {       // one window search (a map point / a last-frame feature)
   float xr, erMax;   // stereo gate: |xr - uRight[j]| <= erMax for features with uRight > 0
   float angle;       // query keypoint angle (rotation histogram, M2)
   int valid;
+  int jLo, jHi;      // feature index range searched; jHi == 0 means "all features" (fisheye rig: left | right halves)
 };
 
 // key = dist << 32 | cell << 20 | j << 4 | octave   (cell = posX * 48 + posY: the GetFeaturesInArea walk order)
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(256) void k_frustum(morb_frame_params P, const floa
                                                  const float* __restrict__ Pw, const float* __restrict__ normal,
                                                  const float* __restrict__ maxDist, const float* __restrict__ minDist,
                                                  float viewingCosLimit, const float* __restrict__ ratioThr,
+                                                 const float* __restrict__ kb8,   // NULL: pinhole of P; else fx fy cx cy k0..k3
                                                  uint8_t* __restrict__ inView, float* __restrict__ projX,
                                                  float* __restrict__ projY, float* __restrict__ projXR,
                                                  float* __restrict__ depth, int* __restrict__ level, float* __restrict__ viewCosOut) {
@@ -131,10 +133,22 @@ __global__ __launch_bounds__(256) void k_frustum(morb_frame_params P, const floa
   const float invz = 1.0f / Pc[2];
   do {
     if (Pc[2] < 0.0f) break;
-    const float u = P.fx * Pc[0] / Pc[2] + P.cx, v = P.fy * Pc[1] / Pc[2] + P.cy;
+    float u, v;
+    if (kb8) {   // KannalaBrandt8::project(Vector3f) (KannalaBrandt8.cpp:49-67): isInFrustumChecks, Frame.cc:1304-1309
+      const float x2_plus_y2 = Pc[0] * Pc[0] + Pc[1] * Pc[1];
+      const float theta = atan2f(sqrtf(x2_plus_y2), Pc[2]);
+      const float psi = atan2f(Pc[1], Pc[0]);
+      const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2,
+                  theta9 = theta7 * theta2;
+      const float r = theta + kb8[4] * theta3 + kb8[5] * theta5 + kb8[6] * theta7 + kb8[7] * theta9;
+      u = kb8[0] * r * cosf(psi) + kb8[2];
+      v = kb8[1] * r * sinf(psi) + kb8[3];
+    } else {
+      u = P.fx * Pc[0] / Pc[2] + P.cx; v = P.fy * Pc[1] / Pc[2] + P.cy;
+    }
     if (u < P.minX || u > P.maxX) break;
     if (v < P.minY || v > P.maxY) break;
-    pX = u; pY = v;
+    if (!kb8) { pX = u; pY = v; }   // the pinhole path stores the projection before the remaining checks (Frame.cc:633-634)
     const float maxDistance = 1.2f * maxDist[o], minDistance = 0.8f * minDist[o];
     const float PO[3] = {X[0] - O[0], X[1] - O[1], X[2] - O[2]};
     const float dist = sqrtf(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(256) void k_frustum(morb_frame_params P, const floa
     const float ratio = maxDist[o] / dist;
     int n = 0;
     while (n < P.nlevels - 1 && ratio > ratioThr[n]) ++n;
-    in = 1; pXR = u - P.mbf * invz; dep = Pc_dist; lvl = n; vc = viewCos;
+    in = 1; pX = u; pY = v; pXR = kb8 ? -1.0f : u - P.mbf * invz; dep = Pc_dist; lvl = n; vc = viewCos;
   } while (0);
   inView[o] = in; projX[o] = pX; projY[o] = pY; projXR[o] = pXR; depth[o] = dep; level[o] = lvl; viewCosOut[o] = vc;
 }
@@ -174,6 +188,44 @@ __global__ __launch_bounds__(256) void k_prep_mps(morb_frame_params P, int mpCap
     q.minLevel = lv - 1; q.maxLevel = lv; q.xr = projXR[o]; q.erMax = r * P.scaleFactors[lv];
   }
   qs[o] = q;
+}
+
+// Fisheye rig: two queries per map point — 2i: left camera (features [0, Nleft), radius x th), 2i + 1: right camera
+// (features [Nleft, N), no th factor, only if mnTrackScaleLevelR != -1); ORBmatcher.cc:50-66 / :140-151.
+__global__ __launch_bounds__(256) void k_prep_mps_fisheye(morb_frame_params P, int mpCap, const int* __restrict__ nMPv,
+                                                          const int* __restrict__ fImg, const int* __restrict__ count,
+                                                          const int* __restrict__ nLeftv, const uint8_t* __restrict__ inViewL,
+                                                          const uint8_t* __restrict__ inViewR, const uint8_t* __restrict__ isBad,
+                                                          const float* __restrict__ depthL, const float* __restrict__ projXL,
+                                                          const float* __restrict__ projYL, const int* __restrict__ levelL,
+                                                          const float* __restrict__ viewCosL, const float* __restrict__ projXR,
+                                                          const float* __restrict__ projYR, const int* __restrict__ levelR,
+                                                          const float* __restrict__ viewCosR, float th, int bFarPoints,
+                                                          float thFarPoints, Query* __restrict__ qs) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= mpCap) return;
+  const size_t o = (size_t)f * mpCap + i;
+  Query ql, qr;
+  memset(&ql, 0, sizeof ql);
+  memset(&qr, 0, sizeof qr);
+  const int nLeft = nLeftv[f], N = count[fImg[f]];
+  if (i < nMPv[f] && (inViewL[o] || inViewR[o]) && !(bFarPoints && depthL[o] > thFarPoints) && !isBad[o]) {
+    if (inViewL[o] && nLeft > 0) {
+      const int lv = levelL[o];
+      float r = ((double)viewCosL[o] > 0.998) ? 2.5f : 4.0f;
+      if ((double)th != 1.0) r *= th;
+      ql.valid = 1; ql.x = projXL[o]; ql.y = projYL[o]; ql.r = r * P.scaleFactors[lv];
+      ql.minLevel = lv - 1; ql.maxLevel = lv; ql.jLo = 0; ql.jHi = nLeft;
+    }
+    if (inViewR[o] && levelR[o] != -1 && N > nLeft) {
+      const int lv = levelR[o];
+      const float r = ((double)viewCosR[o] > 0.998) ? 2.5f : 4.0f;
+      qr.valid = 1; qr.x = projXR[o]; qr.y = projYR[o]; qr.r = r * P.scaleFactors[lv];
+      qr.minLevel = lv - 1; qr.maxLevel = lv; qr.jLo = nLeft; qr.jHi = N;
+    }
+  }
+  qs[2 * o] = ql;
+  qs[2 * o + 1] = qr;
 }
 
 __device__ __forceinline__ void q_rotate_f(const float* q, const float* v, float* out) {
@@ -222,7 +274,8 @@ __global__ __launch_bounds__(256) void k_candidates(morb_frame_params P, int qCa
                                                     const uint8_t* __restrict__ qDesc, const int* __restrict__ fImg, int cap,
                                                     const int* __restrict__ count, const morb_keypoint* __restrict__ kps,
                                                     const uint8_t* __restrict__ desc, const float* __restrict__ uRight,
-                                                    unsigned long long* __restrict__ cand, int* __restrict__ candCnt) {
+                                                    unsigned long long* __restrict__ cand, int* __restrict__ candCnt,
+                                                    int qShift) {   // query descriptor row = query index >> qShift (fisheye: 2 queries per map point)
   const int f = blockIdx.y, lane = threadIdx.x & 63;
   const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (qi >= qCap) return;
@@ -233,13 +286,14 @@ __global__ __launch_bounds__(256) void k_candidates(morb_frame_params P, int qCa
   if (q.valid && cell_range(P, q, cx0, cx1, cy0, cy1)) {
     const int img = fImg[f];
     const int N = count[img];
-    const Desc qd = load_desc(qDesc + qo * 32);
+    const Desc qd = load_desc(qDesc + (qo >> qShift) * 32);
     const float* ur = uRight ? uRight + (size_t)f * cap : nullptr;
     const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    for (int j0 = 0; j0 < N; j0 += 64) {
+    const int jLo = q.jHi > 0 ? q.jLo : 0, jHi = q.jHi > 0 ? min(q.jHi, N) : N;
+    for (int j0 = jLo; j0 < jHi; j0 += 64) {
       const int j = j0 + lane;
       unsigned long long k = ~0ull;
-      if (j < N) k = make_key(P, q, qd, kps[(size_t)img * cap + j], j, desc + ((size_t)img * cap + j) * 32, ur, cx0, cx1, cy0, cy1);
+      if (j < jHi) k = make_key(P, q, qd, kps[(size_t)img * cap + j], j, desc + ((size_t)img * cap + j) * 32, ur, cx0, cx1, cy0, cy1);
       const uint64_t m = __ballot(k != ~0ull);
       if (k != ~0ull) {
         const int slot = n + __popcll(m & lt);
@@ -256,6 +310,9 @@ __global__ __launch_bounds__(256) void k_candidates(morb_frame_params P, int qCa
 // MODE 1: best + second best with the level rule and the ratio test (SearchByProjection with map points :118-137)
 // MODE 2: SearchForInitialization (:603-700): candidates already matched with a smaller-or-equal distance are
 //         skipped, a better match steals the feature from its previous owner
+// MODE 3: MODE 1 on a fisheye rig (F.Nleft != -1, :42-209): queries 2i / 2i + 1 are map point i in the left / right
+//         camera; a match also claims the stereo partner (mvLeftToRightMatch / mvRightToLeftMatch), and a left match
+//         rejected by the ratio test skips the right pass of that map point (the `continue` at :122)
 template <int MODE>
 __global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, const int* __restrict__ nQv,
                                                 const Query* __restrict__ qs, const uint8_t* __restrict__ qDesc,
@@ -266,7 +323,9 @@ __global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, c
                                                 const unsigned long long* __restrict__ cand, const int* __restrict__ candCnt,
                                                 float nnratio, int thAccept, int checkOri, int* __restrict__ match,
                                                 int* __restrict__ nmatches, int* __restrict__ entryJ, int* __restrict__ entryBin,
-                                                float* __restrict__ prevMatched) {
+                                                float* __restrict__ prevMatched, const int* __restrict__ l2r,
+                                                const int* __restrict__ r2l, const int* __restrict__ nLeftv) {
+  constexpr int QS = MODE == 3 ? 1 : 0;   // query index -> descriptor / hasObs row
   extern __shared__ __align__(8) uint8_t smemRaw[];
   uint8_t* blocked = smemRaw;                                   // MODE 0/1: [cap]
   int* matchedDist = reinterpret_cast<int*>(smemRaw);           // MODE 2:   [cap]
@@ -288,8 +347,12 @@ __global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, c
   int* mF = match + (size_t)f * (MODE == 2 ? qCap : cap);
   int nm = 0, nEntries = 0;
   const float factor = 1.0f / HISTO_LENGTH;
-  for (int qi = 0; qi < nQ && qi < qCap; ++qi) {
+  const int nLeft = MODE == 3 ? nLeftv[f] : 0;
+  int skipRightOf = -1;
+  const int nQtot = MODE == 3 ? 2 * nQ : nQ;
+  for (int qi = 0; qi < nQtot && qi < qCap; ++qi) {
     const size_t qo = (size_t)f * qCap + qi;
+    if (MODE == 3 && (qi & 1) && (qi >> 1) == skipRightOf) continue;
     const int cnt = candCnt[qo];
     if (cnt == 0) continue;
     unsigned long long k1 = ~0ull, k2 = ~0ull;
@@ -304,8 +367,9 @@ __global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, c
       const Query q = qs[qo];
       int cx0, cx1, cy0, cy1;
       cell_range(P, q, cx0, cx1, cy0, cy1);
-      const Desc qd = load_desc(qDesc + qo * 32);
-      for (int j = lane; j < N; j += 64) {
+      const Desc qd = load_desc(qDesc + (qo >> QS) * 32);
+      const int jLo = q.jHi > 0 ? q.jLo : 0, jHi = q.jHi > 0 ? min(q.jHi, N) : N;
+      for (int j = jLo + lane; j < jHi; j += 64) {
         if (MODE != 2 && blocked[j]) continue;
         const unsigned long long k = make_key(P, q, qd, kps[(size_t)img * cap + j], j, desc + ((size_t)img * cap + j) * 32, ur, cx0, cx1, cy0, cy1);
         if (k == ~0ull) continue;
@@ -317,10 +381,11 @@ __global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, c
     if (k1 == ~0ull) continue;
     const int bestDist = (int)(k1 >> 32), bestIdx = (int)((k1 >> 4) & 0xFFFF);
     bool accept;
-    if (MODE == 1) {  // ORBmatcher.cc:118-137
+    if (MODE == 1 || MODE == 3) {  // ORBmatcher.cc:118-137 / :182-186
       const int bestLevel = (int)(k1 & 15);
       const int bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 32), bestLevel2 = k2 == ~0ull ? -1 : (int)(k2 & 15);
       accept = bestDist <= TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2);
+      if (MODE == 3 && !(qi & 1) && bestDist <= TH_HIGH && !accept) skipRightOf = qi >> 1;
     } else if (MODE == 2) {  // :646-647
       const int bestDist2 = k2 == ~0ull ? 0x7fffffff : (int)(k2 >> 32);
       accept = bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * nnratio;
@@ -336,6 +401,15 @@ __global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, c
           mF[qi] = bestIdx;
           match21[bestIdx] = qi;
           matchedDist[bestIdx] = bestDist;
+        } else if (MODE == 3) {
+          const int mp = qi >> 1;
+          const uint8_t ho = qHasObs ? qHasObs[qo >> 1] : 1;
+          mF[bestIdx] = mp; blocked[bestIdx] = ho;
+          const int partner = (qi & 1) ? r2l[(size_t)f * cap + (bestIdx - nLeft)] : l2r[(size_t)f * cap + bestIdx];
+          if (partner != -1) {
+            const int pj = (qi & 1) ? partner : partner + nLeft;
+            mF[pj] = mp; blocked[pj] = ho;
+          }
         } else {
           mF[bestIdx] = qi;
           blocked[bestIdx] = qHasObs ? qHasObs[qo] : 1;
@@ -351,6 +425,10 @@ __global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, c
         }
       }
       nm += 1 - stolen;
+      if (MODE == 3) {   // the stereo partner counts as a match of its own (:127-131, :189-193)
+        const int partner = (qi & 1) ? r2l[(size_t)f * cap + (bestIdx - nLeft)] : l2r[(size_t)f * cap + bestIdx];
+        if (partner != -1) ++nm;
+      }
       ++nEntries;
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __builtin_amdgcn_wave_barrier();
@@ -567,35 +645,60 @@ static float ratio_threshold(int n, float logScaleFactor) {
   return asf(lo);
 }
 
-int morb_is_in_frustum_batch(morb_matcher* m, const morb_frame_params* P, int nframes, const float* d_Rcw, const float* d_tcw,
-                             const float* d_Ow, int mpCap, const int* d_nMP, const float* d_Pw, const float* d_normal,
-                             const float* d_maxDist, const float* d_minDist, float viewingCosLimit, uint8_t* d_inView,
-                             float* d_projX, float* d_projY, float* d_projXR, float* d_depth, int* d_level,
-                             float* d_viewCos, void* stream) {
+static int frustum_impl(morb_matcher* m, const morb_frame_params* P, const float* cam8, int nframes, const float* d_Rcw,
+                        const float* d_tcw, const float* d_Ow, int mpCap, const int* d_nMP, const float* d_Pw,
+                        const float* d_normal, const float* d_maxDist, const float* d_minDist, float viewingCosLimit,
+                        uint8_t* d_inView, float* d_projX, float* d_projY, float* d_projXR, float* d_depth, int* d_level,
+                        float* d_viewCos, void* stream) {
   MORB_REQUIRE(m && P && d_Rcw && d_tcw && d_Ow && d_nMP && d_Pw && d_normal && d_maxDist && d_minDist && d_inView && d_projX &&
                    d_projY && d_projXR && d_depth && d_level && d_viewCos, MORB_ERR_INVALID, "NULL argument");
   MORB_REQUIRE(nframes > 0 && mpCap > 0 && P->nlevels >= 1 && P->nlevels <= 16, MORB_ERR_INVALID, "bad sizes");
   MORB_HIP_CHECK(hipSetDevice(morb_matcher_device(m)));
   hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
-  float thr[16];
+  float thr[24];   // 16 level thresholds + the 8 camera parameters of the KB8 variant
   for (int n = 0; n < 16; ++n) thr[n] = n < P->nlevels - 1 ? ratio_threshold(n, P->logScaleFactor) : 3.4e38f;
+  for (int n = 0; n < 8; ++n) thr[16 + n] = cam8 ? cam8[n] : 0.f;
   void* d_thr = nullptr;
   int rc = morb_matcher_workspace(m, 4, sizeof thr, &d_thr);
   if (rc != MORB_OK) return rc;
+  const float* d_kb8 = cam8 ? (const float*)d_thr + 16 : nullptr;
   MORB_HIP_CHECK(hipMemcpyAsync(d_thr, thr, sizeof thr, hipMemcpyHostToDevice, st));
   MORB_HIP_CHECK(hipStreamSynchronize(st));  // thr lives on this stack frame
   hipLaunchKernelGGL(k_frustum, dim3(div_up(mpCap, 256), nframes), dim3(256), 0, st, *P, d_Rcw, d_tcw, d_Ow, mpCap, d_nMP, d_Pw,
-                     d_normal, d_maxDist, d_minDist, viewingCosLimit, (const float*)d_thr, d_inView, d_projX, d_projY, d_projXR,
-                     d_depth, d_level, d_viewCos);
+                     d_normal, d_maxDist, d_minDist, viewingCosLimit, (const float*)d_thr, (const float*)d_kb8, d_inView, d_projX,
+                     d_projY, d_projXR, d_depth, d_level, d_viewCos);
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
+}
+
+int morb_is_in_frustum_batch(morb_matcher* m, const morb_frame_params* P, int nframes, const float* d_Rcw, const float* d_tcw,
+                             const float* d_Ow, int mpCap, const int* d_nMP, const float* d_Pw, const float* d_normal,
+                             const float* d_maxDist, const float* d_minDist, float viewingCosLimit, uint8_t* d_inView,
+                             float* d_projX, float* d_projY, float* d_projXR, float* d_depth, int* d_level,
+                             float* d_viewCos, void* stream) {
+  return frustum_impl(m, P, nullptr, nframes, d_Rcw, d_tcw, d_Ow, mpCap, d_nMP, d_Pw, d_normal, d_maxDist, d_minDist,
+                      viewingCosLimit, d_inView, d_projX, d_projY, d_projXR, d_depth, d_level, d_viewCos, stream);
+}
+
+int morb_is_in_frustum_kb8_batch(morb_matcher* m, const morb_frame_params* P, const float* cam8, int nframes, const float* d_R,
+                                 const float* d_t, const float* d_twc, int mpCap, const int* d_nMP, const float* d_Pw,
+                                 const float* d_normal, const float* d_maxDist, const float* d_minDist, float viewingCosLimit,
+                                 uint8_t* d_inView, float* d_projX, float* d_projY, float* d_depth, int* d_level,
+                                 float* d_viewCos, void* stream) {
+  MORB_REQUIRE(cam8, MORB_ERR_INVALID, "NULL camera");
+  void* xr = nullptr;   // the pinhole-only mTrackProjXR slot of the shared kernel
+  int rc = morb_matcher_workspace(m, 7, sizeof(float) * (size_t)nframes * mpCap, &xr);
+  if (rc != MORB_OK) return rc;
+  return frustum_impl(m, P, cam8, nframes, d_R, d_t, d_twc, mpCap, d_nMP, d_Pw, d_normal, d_maxDist, d_minDist, viewingCosLimit,
+                      d_inView, d_projX, d_projY, (float*)xr, d_depth, d_level, d_viewCos, stream);
 }
 
 static int window_search(morb_matcher* m, const morb_frame_params* P, int mode, int nframes, int qCap, const int* d_nQ,
                          const Query* d_qs, const uint8_t* d_qDesc, const uint8_t* d_qHasObs, const int* d_fImg, int cap,
                          const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc, const float* d_uRight,
                          const uint8_t* d_blocked, float nnratio, int thAccept, int checkOri, int* d_match, int* d_nmatches,
-                         float* d_prevMatched, hipStream_t st) {
+                         float* d_prevMatched, hipStream_t st, const int* d_l2r = nullptr, const int* d_r2l = nullptr,
+                         const int* d_nLeft = nullptr) {
   void *cand = nullptr, *cnt = nullptr, *ej = nullptr, *eb = nullptr;
   int rc = morb_matcher_workspace(m, 0, sizeof(unsigned long long) * (size_t)nframes * qCap * CAND_CAP, &cand);
   if (rc == MORB_OK) rc = morb_matcher_workspace(m, 1, sizeof(int) * (size_t)nframes * qCap, &cnt);
@@ -603,12 +706,13 @@ static int window_search(morb_matcher* m, const morb_frame_params* P, int mode, 
   if (rc == MORB_OK) rc = morb_matcher_workspace(m, 3, sizeof(int) * (size_t)nframes * qCap, &eb);
   if (rc != MORB_OK) return rc;
   hipLaunchKernelGGL(k_candidates, dim3(div_up(qCap, 4), nframes), dim3(256), 0, st, *P, qCap, d_qs, d_qDesc, d_fImg, cap, d_count,
-                     d_kps, d_desc, d_uRight, (unsigned long long*)cand, (int*)cnt);
+                     d_kps, d_desc, d_uRight, (unsigned long long*)cand, (int*)cnt, mode == 3 ? 1 : 0);
 #define MORB_RESOLVE(MODE, SMEM)                                                                                             \
   hipLaunchKernelGGL(k_resolve<MODE>, dim3(nframes), dim3(64), (SMEM), st, *P, qCap, d_nQ, d_qs, d_qDesc, d_qHasObs, d_fImg, cap, \
                      d_count, d_kps, d_desc, d_uRight, d_blocked, (const unsigned long long*)cand, (const int*)cnt, nnratio,   \
-                     thAccept, checkOri, d_match, d_nmatches, (int*)ej, (int*)eb, d_prevMatched)
+                     thAccept, checkOri, d_match, d_nmatches, (int*)ej, (int*)eb, d_prevMatched, d_l2r, d_r2l, d_nLeft)
   if (mode == 1) MORB_RESOLVE(1, (size_t)cap);
+  else if (mode == 3) MORB_RESOLVE(3, (size_t)cap);
   else if (mode == 2) {
     MORB_REQUIRE((size_t)cap * 8 <= 64 * 1024, MORB_ERR_UNSUPPORTED, "too many features for SearchForInitialization's LDS state");
     MORB_RESOLVE(2, (size_t)cap * 8);
@@ -638,6 +742,33 @@ int morb_search_by_projection_mps_batch(morb_matcher* m, const morb_frame_params
                      d_projX, d_projY, d_projXR, d_level, d_viewCos, th, bFarPoints, thFarPoints, (Query*)qs);
   return window_search(m, P, 1, nframes, mpCap, d_nMP, (const Query*)qs, d_mpDesc, d_mpHasObs, d_fImg, cap, d_count, d_kps,
                        d_desc, d_uRight, d_blocked, nnratio, TH_HIGH, 0, d_matchF, d_nmatches, nullptr, st);
+}
+
+int morb_search_by_projection_mps_fisheye_batch(morb_matcher* m, const morb_frame_params* P, int nframes, const int* d_fImg,
+                                                int cap, const int* d_count, const int* d_nLeft, const morb_keypoint* d_kps,
+                                                const uint8_t* d_desc, const int* d_l2r, const int* d_r2l,
+                                                const uint8_t* d_blocked, int mpCap, const int* d_nMP,
+                                                const uint8_t* d_inViewL, const uint8_t* d_inViewR, const uint8_t* d_isBad,
+                                                const float* d_depthL, const float* d_projXL, const float* d_projYL,
+                                                const int* d_levelL, const float* d_viewCosL, const float* d_projXR,
+                                                const float* d_projYR, const int* d_levelR, const float* d_viewCosR,
+                                                const uint8_t* d_mpDesc, const uint8_t* d_mpHasObs, float th, int bFarPoints,
+                                                float thFarPoints, float nnratio, int* d_matchF, int* d_nmatches, void* stream) {
+  MORB_REQUIRE(m && P && d_fImg && d_count && d_nLeft && d_kps && d_desc && d_l2r && d_r2l && d_nMP && d_inViewL && d_inViewR &&
+                   d_isBad && d_depthL && d_projXL && d_projYL && d_levelL && d_viewCosL && d_projXR && d_projYR && d_levelR &&
+                   d_viewCosR && d_mpDesc && d_mpHasObs && d_matchF && d_nmatches, MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(nframes > 0 && cap > 0 && cap <= 65535 && mpCap > 0, MORB_ERR_INVALID, "bad sizes");
+  MORB_HIP_CHECK(hipSetDevice(morb_matcher_device(m)));
+  hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
+  void* qs = nullptr;
+  int rc = morb_matcher_workspace(m, 5, sizeof(Query) * (size_t)nframes * mpCap * 2, &qs);
+  if (rc != MORB_OK) return rc;
+  hipLaunchKernelGGL(k_prep_mps_fisheye, dim3(div_up(mpCap, 256), nframes), dim3(256), 0, st, *P, mpCap, d_nMP, d_fImg, d_count,
+                     d_nLeft, d_inViewL, d_inViewR, d_isBad, d_depthL, d_projXL, d_projYL, d_levelL, d_viewCosL, d_projXR, d_projYR,
+                     d_levelR, d_viewCosR, th, bFarPoints, thFarPoints, (Query*)qs);
+  // 2 queries per map point; the resolve pass (mode 3) walks them as (left, right) pairs in map-point order
+  return window_search(m, P, 3, nframes, 2 * mpCap, d_nMP, (const Query*)qs, d_mpDesc, d_mpHasObs, d_fImg, cap, d_count, d_kps,
+                       d_desc, nullptr, d_blocked, nnratio, TH_HIGH, 0, d_matchF, d_nmatches, nullptr, st, d_l2r, d_r2l, d_nLeft);
 }
 
 int morb_search_by_projection_last_batch(morb_matcher* m, const morb_frame_params* P, int nframes, const int* d_curImg,

@@ -119,6 +119,40 @@ class ORBmatcher:
             float(thFarPoints), self.mfNNratio, ptr(matchF), ptr(nm), self._st(stream)))
         return matchF, nm
 
+    def isInFrustumChecks(self, params, cam8, R, t, twc, nMP, Pw, normal, maxDist, minDist, viewingCosLimit=0.5, stream=None):
+        """Frame::isInFrustumChecks for one camera of a KannalaBrandt8 rig (cam8 = fx fy cx cy k0..k3; R, t, twc as
+        Frame.cc:1283-1293 builds them).  Returns the tracking fields of that camera (device tensors)."""
+        import torch
+        F, mpCap = Pw.shape[0], Pw.shape[1]
+        dev = Pw.device
+        o = dict(inView=torch.zeros((F, mpCap), dtype=torch.uint8, device=dev),
+                 projX=torch.full((F, mpCap), -1.0, device=dev), projY=torch.full((F, mpCap), -1.0, device=dev),
+                 depth=torch.full((F, mpCap), -1.0, device=dev),
+                 level=torch.full((F, mpCap), -1, dtype=torch.int32, device=dev), viewCos=torch.full((F, mpCap), -1.0, device=dev))
+        cam = np.ascontiguousarray(cam8, np.float32)
+        check(self._L.morb_is_in_frustum_kb8_batch(self._h, C.byref(params), ptr(cam), F, ptr(R), ptr(t), ptr(twc), mpCap, ptr(nMP),
+                                                   ptr(Pw), ptr(normal), ptr(maxDist), ptr(minDist), float(viewingCosLimit),
+                                                   ptr(o["inView"]), ptr(o["projX"]), ptr(o["projY"]), ptr(o["depth"]),
+                                                   ptr(o["level"]), ptr(o["viewCos"]), self._st(stream)))
+        return o
+
+    def SearchByProjectionMapPointsFisheye(self, params, fImg, kps, desc, count, nLeft, l2r, r2l, blocked, nMP, trkL, trkR, isBad,
+                                           mpDesc, mpHasObs, th=1.0, bFarPoints=False, thFarPoints=50.0, matchF=None, stream=None):
+        """SearchByProjection(F, vpMapPoints, ...) with F.Nleft != -1; trkL / trkR = dicts from isInFrustumChecks."""
+        import torch
+        F, cap = fImg.shape[0], kps.shape[1]
+        mpCap = mpDesc.shape[1]
+        if matchF is None:
+            matchF = torch.full((F, cap), -1, dtype=torch.int32, device=kps.device)
+        nm = torch.zeros((F,), dtype=torch.int32, device=kps.device)
+        check(self._L.morb_search_by_projection_mps_fisheye_batch(
+            self._h, C.byref(params), F, ptr(fImg), cap, ptr(count), ptr(nLeft), ptr(kps), ptr(desc), ptr(l2r), ptr(r2l), ptr(blocked),
+            mpCap, ptr(nMP), ptr(trkL["inView"]), ptr(trkR["inView"]), ptr(isBad), ptr(trkL["depth"]), ptr(trkL["projX"]),
+            ptr(trkL["projY"]), ptr(trkL["level"]), ptr(trkL["viewCos"]), ptr(trkR["projX"]), ptr(trkR["projY"]), ptr(trkR["level"]),
+            ptr(trkR["viewCos"]), ptr(mpDesc), ptr(mpHasObs), float(th), 1 if bFarPoints else 0, float(thFarPoints),
+            self.mfNNratio, ptr(matchF), ptr(nm), self._st(stream)))
+        return matchF, nm
+
     def SearchByProjectionLastFrame(self, params, curImg, lastImg, kps, desc, count, curURight, curBlocked, Tcw, lastValid,
                                     lastXw, lastMPdesc, lastMPhasObs, th, bForward, bBackward, matchCur=None, stream=None):
         """SearchByProjection(CurrentFrame, LastFrame, th, bMono)."""

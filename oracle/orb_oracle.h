@@ -64,6 +64,17 @@ int orc_search_by_projection_mps(const orc_frame* F, const uint8_t* fBlocked, in
                                  const float* projXR, const int* level, const float* viewCos, const uint8_t* mpDesc,
                                  const uint8_t* mpHasObs, float th, int bFarPoints, float thFarPoints, float nnratio,
                                  int* matchF);
+/* Frame::isInFrustumChecks for one camera of a KB8 rig; SearchByProjection(F, MapPoints) with F.Nleft != -1 */
+void orc_is_in_frustum_kb8(const orc_frame* F, const float* cam8, const float* mR, const float* mt, const float* twc, int nMP,
+                           const float* Pw, const float* normal, const float* maxDist, const float* minDist,
+                           float viewingCosLimit, uint8_t* inView, float* projX, float* projY, float* depth, int* level,
+                           float* viewCos);
+int orc_search_by_projection_mps_fisheye(const orc_frame* F, int Nleft, const int* l2r, const int* r2l, const uint8_t* fBlocked,
+                                         int nMP, const uint8_t* inViewL, const uint8_t* inViewR, const uint8_t* isBad,
+                                         const float* depthL, const float* projXL, const float* projYL, const int* levelL,
+                                         const float* viewCosL, const float* projXR, const float* projYR, const int* levelR,
+                                         const float* viewCosR, const uint8_t* mpDesc, const uint8_t* mpHasObs, float th,
+                                         int bFarPoints, float thFarPoints, float nnratio, int* matchF);
 int orc_search_by_projection_last(const orc_frame* Cur, const uint8_t* curBlocked, const float* Tcw7, int nLast,
                                   const orc_keypoint* lastKpsUn, const uint8_t* lastValid, const float* lastXw,
                                   const uint8_t* lastMPdesc, const uint8_t* lastMPhasObs, float th, int bForward,

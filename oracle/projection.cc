@@ -182,6 +182,131 @@ int SearchByProjectionMPs(const orc_frame& F, const uint8_t* fBlocked, int nMP, 
   return nmatches;
 }
 
+// ---- Frame::isInFrustumChecks (Frame.cc:1276-1346), one camera of a KannalaBrandt8 rig -------------------------
+// The caller passes mR, mt, twc exactly as :1283-1293 builds them (left: mRcw, mtcw, mOw; right: Rrl * mRcw,
+// Rrl * mtcw + trl, mRwc * mTlr.translation() + mOw) and the camera's parameters (fx fy cx cy k0..k3).  Fields of a
+// point that fails a check are reported as -1 (the reference leaves them stale; Frame::isInFrustum :668-671 resets the
+// two flags and the two levels to false / -1 before the checks).
+extern "C" void orc_kb8_project_f(const float* cam8, const float* v3, float* uv);
+void isInFrustumChecks(const orc_frame& F, const float* cam8, const float* mR, const float* mt, const float* twc, int nMP,
+                       const float* Pw, const float* normal, const float* mfMaxDistance, const float* mfMinDistance,
+                       float viewingCosLimit, uint8_t* inView, float* projX, float* projY, float* depth, int* level,
+                       float* viewCosOut) {
+  for (int i = 0; i < nMP; ++i) {
+    inView[i] = 0; projX[i] = -1; projY[i] = -1; depth[i] = -1; level[i] = -1; viewCosOut[i] = -1;
+    const float* P = Pw + 3 * i;
+    float Pc[3];
+    for (int r = 0; r < 3; ++r) Pc[r] = (mR[r * 3] * P[0] + mR[r * 3 + 1] * P[1]) + mR[r * 3 + 2] * P[2] + mt[r];
+    const float Pc_dist = std::sqrt(Pc[0] * Pc[0] + Pc[1] * Pc[1] + Pc[2] * Pc[2]);
+    if (Pc[2] < 0.0f) continue;
+    float uv[2];
+    orc_kb8_project_f(cam8, Pc, uv);
+    if (uv[0] < F.minX || uv[0] > F.maxX) continue;
+    if (uv[1] < F.minY || uv[1] > F.maxY) continue;
+    const float maxDistance = 1.2f * mfMaxDistance[i];
+    const float minDistance = 0.8f * mfMinDistance[i];
+    const float PO[3] = {P[0] - twc[0], P[1] - twc[1], P[2] - twc[2]};
+    const float dist = std::sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+    if (dist < minDistance || dist > maxDistance) continue;
+    const float* Pn = normal + 3 * i;
+    const float viewCos = (PO[0] * Pn[0] + PO[1] * Pn[1] + PO[2] * Pn[2]) / dist;
+    if (viewCos < viewingCosLimit) continue;
+    const float ratio = mfMaxDistance[i] / dist;
+    int nScale = (int)std::ceil(std::log(ratio) / F.logScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= F.nlevels) nScale = F.nlevels - 1;
+    inView[i] = 1; projX[i] = uv[0]; projY[i] = uv[1]; depth[i] = Pc_dist; level[i] = nScale; viewCosOut[i] = viewCos;
+  }
+}
+
+// ---- SearchByProjection(Frame&, MapPoints) on a fisheye rig: the F.Nleft != -1 branches of :42-209 -------------------
+// F holds the Nleft left features followed by the right ones (mvKeys | mvKeysRight, mDescriptors = vconcat, Frame.cc:211).
+// l2r / r2l = mvLeftToRightMatch / mvRightToLeftMatch.
+int SearchByProjectionMPsFisheye(const orc_frame& F, int Nleft, const int* l2r, const int* r2l, const uint8_t* fBlocked, int nMP,
+                                 const uint8_t* inViewL, const uint8_t* inViewR, const uint8_t* isBad, const float* depthL,
+                                 const float* projXL, const float* projYL, const int* levelL, const float* viewCosL,
+                                 const float* projXR, const float* projYR, const int* levelR, const float* viewCosR,
+                                 const uint8_t* mpDesc, const uint8_t* mpHasObs, float th, bool bFarPoints, float thFarPoints,
+                                 float mfNNratio, int* matchF) {
+  orc_frame FL = F, FR = F;
+  FL.N = Nleft;
+  FR.N = F.N - Nleft; FR.kpsUn = F.kpsUn + Nleft; FR.desc = F.desc + (size_t)Nleft * 32;
+  Grid gl, gr;                                  // mGrid, mGridRight (Frame.cc:501-528)
+  AssignFeaturesToGrid(FL, gl);
+  AssignFeaturesToGrid(FR, gr);
+  const KeyPoint* k = (const KeyPoint*)F.kpsUn;
+  std::vector<char> blocked(fBlocked, fBlocked + F.N);
+  int nmatches = 0;
+  const bool bFactor = th != 1.0;
+  for (int iMP = 0; iMP < nMP; iMP++) {
+    if (!inViewL[iMP] && !inViewR[iMP]) continue;
+    if (bFarPoints && depthL[iMP] > thFarPoints) continue;
+    if (isBad[iMP]) continue;
+    const uint8_t* MPdescriptor = mpDesc + (size_t)iMP * 32;
+    if (inViewL[iMP]) {
+      const int nPredictedLevel = levelL[iMP];
+      float r = viewCosL[iMP] > 0.998 ? 2.5f : 4.0f;
+      if (bFactor) r *= th;
+      const std::vector<size_t> vIndices = GetFeaturesInArea(FL, gl, projXL[iMP], projYL[iMP], r * F.scaleFactors[nPredictedLevel],
+                                                             nPredictedLevel - 1, nPredictedLevel);
+      if (!vIndices.empty()) {
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (size_t q = 0; q < vIndices.size(); ++q) {
+          const size_t idx = vIndices[q];
+          if (blocked[idx]) continue;
+          const int dist = DescriptorDistance(MPdescriptor, F.desc + idx * 32);
+          if (dist < bestDist) {
+            bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = k[idx].octave; bestIdx = (int)idx;
+          } else if (dist < bestDist2) {
+            bestLevel2 = k[idx].octave; bestDist2 = dist;
+          }
+        }
+        if (bestDist <= TH_HIGH) {
+          if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;   // skips the right pass too
+          if (bestLevel != bestLevel2 || bestDist <= mfNNratio * bestDist2) {
+            matchF[bestIdx] = iMP; blocked[bestIdx] = mpHasObs[iMP] ? 1 : 0;
+            if (l2r[bestIdx] != -1) {
+              matchF[l2r[bestIdx] + Nleft] = iMP; blocked[l2r[bestIdx] + Nleft] = mpHasObs[iMP] ? 1 : 0;
+              nmatches++;
+            }
+            nmatches++;
+          }
+        }
+      }
+    }
+    if (inViewR[iMP]) {
+      const int nPredictedLevel = levelR[iMP];
+      if (nPredictedLevel != -1) {
+        const float r = viewCosR[iMP] > 0.998 ? 2.5f : 4.0f;   // no th factor in the right pass (:145)
+        const std::vector<size_t> vIndices = GetFeaturesInArea(FR, gr, projXR[iMP], projYR[iMP], r * F.scaleFactors[nPredictedLevel],
+                                                               nPredictedLevel - 1, nPredictedLevel);
+        if (vIndices.empty()) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (size_t q = 0; q < vIndices.size(); ++q) {
+          const size_t idx = vIndices[q];
+          if (blocked[idx + Nleft]) continue;
+          const int dist = DescriptorDistance(MPdescriptor, F.desc + (idx + Nleft) * 32);
+          if (dist < bestDist) {
+            bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = k[idx + Nleft].octave; bestIdx = (int)idx;
+          } else if (dist < bestDist2) {
+            bestLevel2 = k[idx + Nleft].octave; bestDist2 = dist;
+          }
+        }
+        if (bestDist <= TH_HIGH) {
+          if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+          if (r2l[bestIdx] != -1) {
+            matchF[r2l[bestIdx]] = iMP; blocked[r2l[bestIdx]] = mpHasObs[iMP] ? 1 : 0;
+            nmatches++;
+          }
+          matchF[bestIdx + Nleft] = iMP; blocked[bestIdx + Nleft] = mpHasObs[iMP] ? 1 : 0;
+          nmatches++;
+        }
+      }
+    }
+  }
+  return nmatches;
+}
+
 // ---- ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (:1521-1733) ----
 // bForward / bBackward are computed by the caller exactly as :1530-1539 does (two flags per call).
 int SearchByProjectionLast(const orc_frame& Cur, const uint8_t* curBlocked, const float* Tcw7, int nLast,
@@ -504,6 +629,23 @@ int orc_search_by_projection_mps(const orc_frame* F, const uint8_t* fBlocked, in
                                  int* matchF) {
   return SearchByProjectionMPs(*F, fBlocked, nMP, inView, isBad, depth, projX, projY, projXR, level, viewCos, mpDesc, mpHasObs,
                                th, bFarPoints != 0, thFarPoints, nnratio, matchF);
+}
+void orc_is_in_frustum_kb8(const orc_frame* F, const float* cam8, const float* mR, const float* mt, const float* twc, int nMP,
+                           const float* Pw, const float* normal, const float* maxDist, const float* minDist,
+                           float viewingCosLimit, uint8_t* inView, float* projX, float* projY, float* depth, int* level,
+                           float* viewCos) {
+  isInFrustumChecks(*F, cam8, mR, mt, twc, nMP, Pw, normal, maxDist, minDist, viewingCosLimit, inView, projX, projY, depth, level,
+                    viewCos);
+}
+int orc_search_by_projection_mps_fisheye(const orc_frame* F, int Nleft, const int* l2r, const int* r2l, const uint8_t* fBlocked,
+                                         int nMP, const uint8_t* inViewL, const uint8_t* inViewR, const uint8_t* isBad,
+                                         const float* depthL, const float* projXL, const float* projYL, const int* levelL,
+                                         const float* viewCosL, const float* projXR, const float* projYR, const int* levelR,
+                                         const float* viewCosR, const uint8_t* mpDesc, const uint8_t* mpHasObs, float th,
+                                         int bFarPoints, float thFarPoints, float nnratio, int* matchF) {
+  return SearchByProjectionMPsFisheye(*F, Nleft, l2r, r2l, fBlocked, nMP, inViewL, inViewR, isBad, depthL, projXL, projYL, levelL,
+                                      viewCosL, projXR, projYR, levelR, viewCosR, mpDesc, mpHasObs, th, bFarPoints != 0,
+                                      thFarPoints, nnratio, matchF);
 }
 int orc_search_by_projection_last(const orc_frame* Cur, const uint8_t* curBlocked, const float* Tcw7, int nLast,
                                   const orc_keypoint* lastKpsUn, const uint8_t* lastValid, const float* lastXw,

@@ -236,6 +236,31 @@ def search_by_projection_mps(F, blocked, trk, isBad, mpDesc, mpHasObs, th, bFar,
     return r, m
 
 
+def is_in_frustum_kb8(F, cam8, R, t, twc, Pw, normal, maxDist, minDist, cosLimit=0.5):
+    L = lib(); n = len(Pw)
+    a = [np.ascontiguousarray(x, np.float32) for x in (cam8, R, t, twc, Pw, normal, maxDist, minDist)]
+    o = dict(inView=np.zeros(n, np.uint8), projX=np.zeros(n, np.float32), projY=np.zeros(n, np.float32),
+             depth=np.zeros(n, np.float32), level=np.zeros(n, np.int32), viewCos=np.zeros(n, np.float32))
+    L.orc_is_in_frustum_kb8.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 6
+    L.orc_is_in_frustum_kb8(C.byref(F), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), n, _p(a[4]), _p(a[5]), _p(a[6]), _p(a[7]), cosLimit,
+                            _p(o["inView"]), _p(o["projX"]), _p(o["projY"]), _p(o["depth"]), _p(o["level"]), _p(o["viewCos"]))
+    return o
+
+
+def search_by_projection_mps_fisheye(F, Nleft, l2r, r2l, blocked, trkL, trkR, isBad, mpDesc, mpHasObs, th, bFar, thFar, nnratio):
+    L = lib(); n = len(mpDesc)
+    L.orc_search_by_projection_mps_fisheye.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + \
+        [C.c_void_p] * 14 + [C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    m = np.full(F.N, -1, np.int32)
+    a = [np.ascontiguousarray(x) for x in (np.asarray(l2r, np.int32), np.asarray(r2l, np.int32), blocked.astype(np.uint8),
+                                           trkL["inView"], trkR["inView"], isBad.astype(np.uint8), trkL["depth"], trkL["projX"],
+                                           trkL["projY"], trkL["level"], trkL["viewCos"], trkR["projX"], trkR["projY"], trkR["level"],
+                                           trkR["viewCos"], mpDesc, mpHasObs.astype(np.uint8))]
+    r = L.orc_search_by_projection_mps_fisheye(C.byref(F), int(Nleft), _p(a[0]), _p(a[1]), _p(a[2]), n, *[_p(x) for x in a[3:]],
+                                               th, 1 if bFar else 0, thFar, nnratio, _p(m))
+    return r, m
+
+
 def search_by_projection_last(Cur, blocked, Tcw7, lastKps, lastValid, lastXw, lastMPdesc, lastHasObs, th, fwd, bwd, checkOri):
     L = lib()
     L.orc_search_by_projection_last.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p]

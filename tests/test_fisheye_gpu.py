@@ -64,3 +64,145 @@ def test_pose_optimization_fisheye():
         assert abs(int(nin[f]) - r) <= 1                                   # a chi2 sitting on the 5.991 gate may flip with libm ulps
         assert (outl[f, :n].cpu().numpy() != oe).sum() <= 1
         assert np.abs(pg[f] - p["true"]).max() < 0.03
+
+
+def _fisheye_params():
+    from morb_slam_amd.capi import make_frame_params
+    from morb_slam_amd.synth import TUMVI_CAM_L
+    sf = (1.2 ** np.arange(8)).astype(np.float32)
+    return make_frame_params(512, 512, float(TUMVI_CAM_L[0]), float(TUMVI_CAM_L[1]), float(TUMVI_CAM_L[2]), float(TUMVI_CAM_L[3]),
+                             19.0, 0.1, sf, sf * sf), sf
+
+
+def test_is_in_frustum_checks_kb8():
+    """Frame::isInFrustumChecks, both cameras of the TUM-VI rig.  uv goes through atan2f / cosf / sinf (device libm vs
+    glibc): projections to 2e-3 px, everything else exact; flags may differ only for points on a decision boundary."""
+    import torch
+    from morb_slam_amd import ORBmatcher
+    from morb_slam_amd.synth import TUMVI_CAM_L, TUMVI_CAM_R, TUMVI_T_C1_C2
+    P, _ = _fisheye_params()
+    rng = np.random.default_rng(11)
+    Fn, M = 3, 900
+    Tlr = TUMVI_T_C1_C2.astype(np.float32)
+    Trl = np.linalg.inv(TUMVI_T_C1_C2).astype(np.float32)
+    m = ORBmatcher()
+    tot = 0
+    for side, cam in (("L", TUMVI_CAM_L), ("R", TUMVI_CAM_R)):
+        R = np.zeros((Fn, 9), np.float32); t = np.zeros((Fn, 3), np.float32); O3 = np.zeros((Fn, 3), np.float32)
+        Pw = np.zeros((Fn, M, 3), np.float32); nrm = np.zeros((Fn, M, 3), np.float32)
+        maxD = np.zeros((Fn, M), np.float32); minD = np.zeros((Fn, M), np.float32)
+        for f in range(Fn):
+            a = rng.normal(0, 0.05, 3)
+            th = np.linalg.norm(a); k = a / th
+            K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+            Rcw = (np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K).astype(np.float32)
+            tcw = rng.normal(0, 0.2, 3).astype(np.float32)
+            Rwc = Rcw.T.copy(); Ow = (-Rwc @ tcw).astype(np.float32)
+            if side == "R":   # Frame.cc:1283-1288
+                mR = (Trl[:3, :3] @ Rcw).astype(np.float32); mt = (Trl[:3, :3] @ tcw + Trl[:3, 3]).astype(np.float32)
+                twc = (Rwc @ Tlr[:3, 3] + Ow).astype(np.float32)
+            else:
+                mR, mt, twc = Rcw, tcw, Ow
+            R[f] = mR.reshape(-1); t[f] = mt; O3[f] = twc
+            Xc = np.stack([rng.uniform(-6, 6, M), rng.uniform(-5, 5, M), rng.uniform(-1, 9, M)], 1)
+            X = (Xc - tcw) @ Rcw            # world points: Rwc (Xc - tcw)
+            Pw[f] = X.astype(np.float32)
+            d = np.linalg.norm(X - Ow, axis=1)
+            v = (X - Ow) / d[:, None] + rng.normal(0, 0.5, (M, 3))
+            nrm[f] = (v / np.linalg.norm(v, axis=1)[:, None]).astype(np.float32)
+            maxD[f] = (d * rng.uniform(0.6, 3.0, M)).astype(np.float32); minD[f] = (maxD[f] / 4.0).astype(np.float32)
+        nMP = np.full(Fn, M, np.int32)
+        g = m.isInFrustumChecks(P, cam, *[torch.from_numpy(x).cuda() for x in (R, t, O3, nMP, Pw, nrm, maxD, minD)], 0.5)
+        torch.cuda.synchronize()
+        g = {k: v.cpu().numpy() for k, v in g.items()}
+        kps0 = np.zeros(1, O.KP_DTYPE)
+        for f in range(Fn):
+            Fo = O.make_frame(P, kps0, np.zeros((1, 32), np.uint8), None)
+            e = O.is_in_frustum_kb8(Fo, cam, R[f], t[f], O3[f], Pw[f], nrm[f], maxD[f], minD[f], 0.5)
+            same = g["inView"][f] == e["inView"]
+            assert (~same).sum() <= 2                       # boundary cases only
+            both = (g["inView"][f] == 1) & (e["inView"] == 1)
+            np.testing.assert_allclose(g["projX"][f][both], e["projX"][both], atol=2e-3)
+            np.testing.assert_allclose(g["projY"][f][both], e["projY"][both], atol=2e-3)
+            np.testing.assert_array_equal(g["depth"][f][both], e["depth"][both])
+            np.testing.assert_array_equal(g["viewCos"][f][both], e["viewCos"][both])
+            np.testing.assert_array_equal(g["level"][f][both], e["level"][both])
+            rej = (g["inView"][f] == 0) & same
+            assert (g["level"][f][rej] == -1).all() and (g["projX"][f][rej] == -1).all()
+            tot += int(both.sum())
+    assert tot > 600
+
+
+def test_search_by_projection_mappoints_fisheye():
+    """SearchByProjection(F, MapPoints) with F.Nleft != -1: left pass, right pass, stereo-partner claims, the ratio-test
+    `continue` that skips the right pass.  The tracking fields are inputs (same for oracle and GPU): exact tables."""
+    import torch
+    from morb_slam_amd import KP_DTYPE, ORBmatcher
+    P, sf = _fisheye_params()
+    sigma2 = (sf * sf).astype(np.float32)
+    sets = [make_fisheye_features(seed=20 + s, n_pairs=450 + 80 * s) for s in range(3)]
+    Fn = len(sets)
+    cap = max(len(f["kL"]) + len(f["kR"]) for f in sets) + 5
+    M = 700
+    rng = np.random.default_rng(77)
+    kps = np.zeros((Fn, cap), KP_DTYPE); desc = np.zeros((Fn, cap, 32), np.uint8)
+    cnt = np.zeros(Fn, np.int32); nLeft = np.zeros(Fn, np.int32)
+    l2r = np.full((Fn, cap), -1, np.int32); r2l = np.full((Fn, cap), -1, np.int32)
+    blocked = (rng.random((Fn, cap)) < 0.05).astype(np.uint8)
+    keys = ("inView", "projX", "projY", "depth", "level", "viewCos")
+    dt = dict(inView=np.uint8, projX=np.float32, projY=np.float32, depth=np.float32, level=np.int32, viewCos=np.float32)
+    tL = {k: np.zeros((Fn, M), dt[k]) for k in keys}; tR = {k: np.zeros((Fn, M), dt[k]) for k in keys}
+    tL["level"][:] = -1; tR["level"][:] = -1
+    isBad = (rng.random((Fn, M)) < 0.03).astype(np.uint8); hasObs = (rng.random((Fn, M)) < 0.7).astype(np.uint8)
+    mpDesc = rng.integers(0, 256, (Fn, M, 32), dtype=np.uint8)
+    for f, fe in enumerate(sets):
+        nl, nr = len(fe["kL"]), len(fe["kR"])
+        kps[f, :nl] = fe["kL"]; kps[f, nl:nl + nr] = fe["kR"]; desc[f, :nl] = fe["dL"]; desc[f, nl:nl + nr] = fe["dR"]
+        cnt[f] = nl + nr; nLeft[f] = nl
+        _, a, b, _, _ = O.stereo_fisheye_matches(fe, sigma2)
+        l2r[f, :nl] = a; r2l[f, :nr] = b
+
+        def aim(t, i, kp, d):   # point map point i at feature kp of one camera
+            t["inView"][f, i] = 1
+            t["projX"][f, i] = kp["x"] + rng.uniform(-1.5, 1.5); t["projY"][f, i] = kp["y"] + rng.uniform(-1.5, 1.5)
+            t["level"][f, i] = min(7, int(kp["octave"]) + int(rng.integers(0, 2)))
+            t["viewCos"][f, i] = rng.choice([0.9995, 0.9, 0.6]); t["depth"][f, i] = rng.uniform(1, 60)
+            flips = rng.choice([3, 10, 25, 70])
+            dd = d.copy()
+            bits = rng.choice(256, flips, replace=False)
+            for bt in bits: dd[bt >> 3] ^= np.uint8(1 << (bt & 7))
+            mpDesc[f, i] = dd
+        for i in range(M):
+            u = rng.random()
+            if u < 0.4:
+                j = rng.integers(0, nl); aim(tL, i, fe["kL"][j], fe["dL"][j])
+            elif u < 0.7:
+                j = rng.integers(0, nr); aim(tR, i, fe["kR"][j], fe["dR"][j])
+            elif u < 0.9:
+                j = rng.integers(0, nl); aim(tL, i, fe["kL"][j], fe["dL"][j])
+                jr = a[j] if a[j] >= 0 else rng.integers(0, nr)
+                keep = mpDesc[f, i].copy(); aim(tR, i, fe["kR"][jr], fe["dR"][jr]); mpDesc[f, i] = keep
+            else:   # in view of the right camera only, nothing nearby in most cases
+                tR["inView"][f, i] = 1; tR["projX"][f, i] = rng.uniform(0, 512); tR["projY"][f, i] = rng.uniform(0, 512)
+                tR["level"][f, i] = rng.integers(-1, 8); tR["viewCos"][f, i] = 0.8; tL["depth"][f, i] = rng.uniform(1, 60)
+    m = ORBmatcher(0.8, True)
+    fImg = np.arange(Fn, dtype=np.int32); nMP = np.full(Fn, M, np.int32)
+    cu = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    dk = cu(kps.view(np.uint8).reshape(Fn, cap, 28))
+    gL = {k: cu(v) for k, v in tL.items()}; gR = {k: cu(v) for k, v in tR.items()}
+    for th, far in ((1.0, False), (3.0, True)):
+        mt, nm = m.SearchByProjectionMapPointsFisheye(P, cu(fImg), dk, cu(desc), cu(cnt), cu(nLeft), cu(l2r), cu(r2l), cu(blocked), cu(nMP),
+                                                      gL, gR, cu(isBad), cu(mpDesc), cu(hasObs), th, far, 40.0)
+        torch.cuda.synchronize()
+        mt, nm = mt.cpu().numpy(), nm.cpu().numpy()
+        tot = 0
+        for f in range(Fn):
+            N = int(cnt[f])
+            Fo = O.make_frame(P, kps[f, :N], desc[f, :N], None)
+            ne, me = O.search_by_projection_mps_fisheye(Fo, int(nLeft[f]), l2r[f], r2l[f], blocked[f, :N],
+                                                        {k: v[f] for k, v in tL.items()}, {k: v[f] for k, v in tR.items()},
+                                                        isBad[f], mpDesc[f], hasObs[f], th, far, 40.0, 0.8)
+            assert int(nm[f]) == ne
+            np.testing.assert_array_equal(mt[f, :N], me)
+            tot += ne
+        assert tot > 600
