@@ -157,6 +157,15 @@ int morb_search_by_bow_batch(morb_matcher*, int npairs, const int* d_kfImg, cons
                              const uint8_t* d_hasMP, int cap, float nnratio, int checkOri, int* d_matchF,
                              int* d_nmatches, void* stream);
 
+/* The same with a fisheye frame F (F.Nleft != -1, ORBmatcher.cc:262-299 and :333-365): image fImg[p] holds the
+ * Nleft = d_nLeft[p] left features followed by the right ones; left and right candidates of a node are ranked
+ * separately, the right winner is taken whenever the LEFT best distance passes TH_LOW (the reference's nesting and
+ * its `|| true`).  d_nLeft[p] = -1 marks a pinhole frame. */
+int morb_search_by_bow_fisheye_batch(morb_matcher* m, int npairs, const int* d_kfImg, const int* d_fImg, const int* d_nLeft,
+                                     int nimg, const morb_keypoint* d_kps, const uint8_t* d_desc, const int* d_node,
+                                     const int* d_count, const uint8_t* d_hasMP, int cap, float nnratio, int checkOri,
+                                     int* d_matchF, int* d_nmatches, void* stream);
+
 /* The Frame members the projection-guided searches read, as one POD (all frames of a batch share one camera):
  * mnMinX/Y, mnMaxX/Y, mfGridElementWidthInv/HeightInv, fx, fy, cx, cy, mbf, mb, mfLogScaleFactor, mnScaleLevels,
  * mvScaleFactors, mvLevelSigma2 (include/Frame.h). */

@@ -40,6 +40,18 @@ def make_frame_params(width, height, fx, fy, cx, cy, mbf, mb, scale_factors, lev
     return p
 
 
+def stream_arg(stream):
+    """ABI `void* stream` argument.  None = the handle's own (non-blocking) HIP stream: inputs that torch is still
+    producing on ITS current stream (e.g. the DMA of a fresh `.cuda()` upload) would race with it, so the torch
+    stream is drained first.  Pass a raw stream handle (`torch.cuda.Stream.cuda_stream`) to stay asynchronous."""
+    if stream is None:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
+        return None
+    return C.c_void_p(stream)
+
+
 class MorbError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libmorb_hip error {code}: {msg}")
@@ -92,6 +104,7 @@ def lib():
         L.morb_stereo_fisheye_match_batch.argtypes = [vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp]
         L.morb_bow_transform_batch.argtypes = [vp, i, vp, vp, i, vp, vp, i, i, i, vp, vp, vp]
         L.morb_search_by_bow_batch.argtypes = [vp, i, vp, vp, i, vp, vp, vp, vp, vp, i, f, i, vp, vp, vp]
+        L.morb_search_by_bow_fisheye_batch.argtypes = [vp, i, vp, vp, vp, i, vp, vp, vp, vp, vp, i, f, i, vp, vp, vp]
         PP = C.POINTER(FrameParams)
         L.morb_is_in_frustum_batch.argtypes = [vp, PP, i, vp, vp, vp, i, vp, vp, vp, vp, vp, f] + [vp] * 8
         L.morb_search_by_projection_mps_batch.argtypes = [vp, PP, i, vp, i, vp, vp, vp, vp, vp, i] + [vp] * 11 + [f, i, f, f, vp, vp, vp]

@@ -459,7 +459,8 @@ __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __r
                                                    const morb_keypoint* __restrict__ kpsKF,
                                                    const uint8_t* __restrict__ descF, const morb_keypoint* __restrict__ kpsF,
                                                    const int* __restrict__ kfImg, const int* __restrict__ fImg,
-                                                   float nnratio, int* __restrict__ matchF, int* __restrict__ binF) {
+                                                   float nnratio, int* __restrict__ matchF, int* __restrict__ binF,
+                                                   const int* __restrict__ nLeftv) {   // F.Nleft per pair or NULL (pinhole)
   extern __shared__ __align__(16) unsigned long long bowLds[];
 #ifdef MORB_FAST_TIMING
   const int bw_ = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -470,6 +471,9 @@ __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __r
   const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int ik = kfImg[pair], jf = fImg[pair];
   const int nKF = nKFv[ik], nF = nFv[jf];
+  // fisheye frame (ORBmatcher.cc:262-299, :333-365): features >= nLeft are the right camera's and are ranked separately
+  const bool fish = nLeftv != nullptr && nLeftv[pair] >= 0;
+  const int nLeft = fish ? nLeftv[pair] : 0x7fffffff;
   {
     // stage both tables with all of a thread's loads in flight at once (one global round trip, not one per element)
     const unsigned long long* gk = sortedKF + (size_t)ik * cap;
@@ -578,31 +582,37 @@ __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __r
 #pragma unroll
           for (int w = 0; w < 8; ++w) dk.w[w] = (uint32_t)__builtin_amdgcn_readlane((int)dK.w[w], q);
           unsigned a1 = ~0u, a2 = ~0u;   // this lane's two best keys: dist << 16 | frame feature index (< cap < 65536)
+          unsigned b1 = ~0u;             // fisheye: this lane's best right-camera key (the second best is unused: `|| true`, :336)
 #pragma unroll
           for (int j = 0; j < BM_FJ; ++j)
             if (j < nJ && j * 64 + lane < nFs && myMatch[j] < 0) {
               const unsigned key = ((unsigned)hamming(dk, dF[j]) << 16) | (unsigned)idxF[j];
-              if (key < a1) { a2 = a1; a1 = key; } else if (key < a2) a2 = key;
+              if (idxF[j] < nLeft) { if (key < a1) { a2 = a1; a1 = key; } else if (key < a2) a2 = key; }
+              else if (key < b1) b1 = key;
             }
           const unsigned k1 = wave_min_u32(a1);
           const unsigned k2 = wave_min_u32(a1 == k1 ? a2 : a1);
+          const unsigned r1 = fish ? wave_min_u32(b1) : ~0u;
           const int bestDist1 = k1 == ~0u ? 256 : (int)(k1 >> 16);
           const int bestDist2 = k2 == ~0u ? 256 : (int)(k2 >> 16);
-          if (bestDist1 <= TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {
+          const int bestDist1R = r1 == ~0u ? 256 : (int)(r1 >> 16);
+          if (bestDist1 <= TH_LOW) {
             const int realIdxKF = __builtin_amdgcn_readlane(idxK, q);
             const float aK = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angK), q));
-            if (a1 == k1) {   // exactly one lane: keys differ in the index bits
-              const int bestIdxF = (int)(k1 & 0xFFFFu);
+            const bool takeL = (float)bestDist1 < nnratio * (float)bestDist2;
+            const bool takeR = bestDist1R <= TH_LOW;   // nested in the LEFT test, no ratio test of its own (:333-337)
+            // exactly one lane owns each winning key: keys differ in the index bits
+            const int wantIdx = (takeL && a1 == k1) ? (int)(k1 & 0xFFFFu) : -1;
+            const int wantIdxR = (takeR && b1 == r1 && r1 != ~0u) ? (int)(r1 & 0xFFFFu) : -1;
 #pragma unroll
-              for (int j = 0; j < BM_FJ; ++j)
-                if (j < nJ && idxF[j] == bestIdxF && j * 64 + lane < nFs) {
-                  float rot = aK - angF[j];
-                  if (rot < 0.0f) rot += 360.0f;
-                  int bin = (int)roundf(rot * factor);
-                  if (bin == HISTO_LENGTH) bin = 0;
-                  myMatch[j] = realIdxKF; myBin[j] = bin;
-                }
-            }
+            for (int j = 0; j < BM_FJ; ++j)
+              if (j < nJ && j * 64 + lane < nFs && myMatch[j] < 0 && (idxF[j] == wantIdx || idxF[j] == wantIdxR)) {
+                float rot = aK - angF[j];
+                if (rot < 0.0f) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                myMatch[j] = realIdxKF; myBin[j] = bin;
+              }
           }
         }
         if (nKs < 64) break;
@@ -621,27 +631,44 @@ __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __r
       const int realIdxKF = (int)(kq & 0xFFFFFFFFu);
       if (!hasMP[(size_t)ik * cap + realIdxKF]) continue;
       const Desc dKF = load_desc(descKF + ((size_t)ik * cap + realIdxKF) * 32);
-      unsigned long long k1 = ~0ull, k2 = ~0ull;
+      unsigned long long k1 = ~0ull, k2 = ~0ull, r1 = ~0ull, r2 = ~0ull;
       for (int s0 = fBeg; s0 < fEnd; s0 += 64) {
         const int s = s0 + lane;
         if (s < fEnd) {
           const int realIdxF = (int)(sf[s] & 0xFFFFFFFFu);
           if (mF[realIdxF] < 0) {
             const int d = hamming(dKF, load_desc(descF + ((size_t)jf * cap + realIdxF) * 32));
-            top2_insert(k1, k2, ((unsigned long long)d << 32) | (unsigned)realIdxF);
+            if (realIdxF < nLeft) top2_insert(k1, k2, ((unsigned long long)d << 32) | (unsigned)realIdxF);
+            else top2_insert(r1, r2, ((unsigned long long)d << 32) | (unsigned)realIdxF);
           }
         }
       }
       wave_top2(k1, k2);
+      if (fish) wave_top2(r1, r2);
       const int bestDist1 = k1 == ~0ull ? 256 : (int)(k1 >> 32);
       const int bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 32);
-      if (bestDist1 <= TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {
-        const int bestIdxF = (int)(k1 & 0xFFFFFFFFu);
-        float rot = kpsKF[(size_t)ik * cap + realIdxKF].angle - kpsF[(size_t)jf * cap + bestIdxF].angle;
-        if (rot < 0.0f) rot += 360.0f;
-        int bin = (int)roundf(rot * factor);
-        if (bin == HISTO_LENGTH) bin = 0;
-        if (lane == 0) { mF[bestIdxF] = realIdxKF; bF[bestIdxF] = bin; }
+      const int bestDist1R = r1 == ~0ull ? 256 : (int)(r1 >> 32);
+      if (bestDist1 <= TH_LOW) {
+        const float aK = kpsKF[(size_t)ik * cap + realIdxKF].angle;
+        const bool takeL = (float)bestDist1 < nnratio * (float)bestDist2, takeR = bestDist1R <= TH_LOW;
+        if (lane == 0) {
+          if (takeL) {
+            const int bestIdxF = (int)(k1 & 0xFFFFFFFFu);
+            float rot = aK - kpsF[(size_t)jf * cap + bestIdxF].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            mF[bestIdxF] = realIdxKF; bF[bestIdxF] = bin;
+          }
+          if (takeR) {
+            const int bestIdxFR = (int)(r1 & 0xFFFFFFFFu);
+            float rot = aK - kpsF[(size_t)jf * cap + bestIdxFR].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            mF[bestIdxFR] = realIdxKF; bF[bestIdxFR] = bin;
+          }
+        }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
       }
@@ -858,10 +885,10 @@ int morb_bow_transform_batch(morb_matcher* m, int nimg, const uint8_t* d_desc, c
   return MORB_OK;
 }
 
-int morb_search_by_bow_batch(morb_matcher* m, int npairs, const int* d_kfImg, const int* d_fImg, int nimg,
-                             const morb_keypoint* d_kps, const uint8_t* d_desc, const int* d_node, const int* d_count,
-                             const uint8_t* d_hasMP, int cap, float nnratio, int checkOri, int* d_matchF,
-                             int* d_nmatches, void* stream) {
+static int search_by_bow_impl(morb_matcher* m, int npairs, const int* d_kfImg, const int* d_fImg, int nimg,
+                              const morb_keypoint* d_kps, const uint8_t* d_desc, const int* d_node, const int* d_count,
+                              const uint8_t* d_hasMP, int cap, float nnratio, int checkOri, int* d_matchF,
+                              int* d_nmatches, const int* d_nLeft, void* stream) {
   MORB_REQUIRE(m && d_kfImg && d_fImg && d_kps && d_desc && d_node && d_count && d_hasMP && d_matchF && d_nmatches,
                MORB_ERR_INVALID, "NULL argument");
   MORB_REQUIRE(npairs > 0 && nimg > 0 && cap > 0, MORB_ERR_INVALID, "bad sizes");
@@ -881,10 +908,27 @@ int morb_search_by_bow_batch(morb_matcher* m, int npairs, const int* d_kfImg, co
   MORB_REQUIRE(cap < 65536 && (size_t)cap * 18 <= 160 * 1024, MORB_ERR_UNSUPPORTED, "too many features per frame for the LDS-resident node tables");
   MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)cap * 18)));
   hipLaunchKernelGGL(k_bow_match, dim3(BM_NB, npairs), dim3(256), (size_t)cap * 18, st, m->d_sortA, m->d_sortA, d_count, d_count,
-                     cap, d_desc, d_hasMP, d_kps, d_desc, d_kps, d_kfImg, d_fImg, nnratio, d_matchF, m->d_bin);
+                     cap, d_desc, d_hasMP, d_kps, d_desc, d_kps, d_kfImg, d_fImg, nnratio, d_matchF, m->d_bin, d_nLeft);
   hipLaunchKernelGGL(k_rot_filter, dim3(npairs), dim3(256), 0, st, d_count, d_fImg, cap, checkOri, d_matchF, m->d_bin, d_nmatches);
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
+}
+
+int morb_search_by_bow_batch(morb_matcher* m, int npairs, const int* d_kfImg, const int* d_fImg, int nimg,
+                             const morb_keypoint* d_kps, const uint8_t* d_desc, const int* d_node, const int* d_count,
+                             const uint8_t* d_hasMP, int cap, float nnratio, int checkOri, int* d_matchF,
+                             int* d_nmatches, void* stream) {
+  return search_by_bow_impl(m, npairs, d_kfImg, d_fImg, nimg, d_kps, d_desc, d_node, d_count, d_hasMP, cap, nnratio, checkOri,
+                            d_matchF, d_nmatches, nullptr, stream);
+}
+
+int morb_search_by_bow_fisheye_batch(morb_matcher* m, int npairs, const int* d_kfImg, const int* d_fImg, const int* d_nLeft,
+                                     int nimg, const morb_keypoint* d_kps, const uint8_t* d_desc, const int* d_node,
+                                     const int* d_count, const uint8_t* d_hasMP, int cap, float nnratio, int checkOri,
+                                     int* d_matchF, int* d_nmatches, void* stream) {
+  MORB_REQUIRE(d_nLeft, MORB_ERR_INVALID, "NULL argument");
+  return search_by_bow_impl(m, npairs, d_kfImg, d_fImg, nimg, d_kps, d_desc, d_node, d_count, d_hasMP, cap, nnratio, checkOri,
+                            d_matchF, d_nmatches, d_nLeft, stream);
 }
 
 #ifdef MORB_FAST_TIMING

@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import KP_DTYPE, check, lib, ptr
+from .capi import KP_DTYPE, check, lib, ptr, stream_arg
 
 
 class ORBextractor:
@@ -70,7 +70,7 @@ class ORBextractor:
                    torch.empty((nimg,), dtype=torch.int32, device=dev))
         kps, desc, cnt, mono = out
         lap_arr = None if lap is None else np.ascontiguousarray(lap, np.int32).reshape(nimg, 2)
-        st = None if stream is None else C.c_void_p(stream)
+        st = stream_arg(stream)
         check(self._L.morb_extract_batch(self._h, ptr(d_images), nimg, w, h, d_images.stride(1), d_images.stride(0),
                                          ptr(lap_arr), ptr(kps), ptr(desc), cap, ptr(cnt), ptr(mono), st))
         return out

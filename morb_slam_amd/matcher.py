@@ -5,7 +5,7 @@ import ctypes as C
 
 import numpy as np
 
-from .capi import check, lib, ptr
+from .capi import check, lib, ptr, stream_arg
 
 TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30   # ORBmatcher.cc:35-37
 
@@ -28,7 +28,7 @@ class ORBmatcher:
 
     @staticmethod
     def _st(stream):
-        return None if stream is None else C.c_void_p(stream)
+        return stream_arg(stream)
 
     def DescriptorDistance(self, a, b, stream=None):
         """static DescriptorDistance on n pairs: a, b = uint8 device tensors [n, 32] -> int32 [n]."""
@@ -72,15 +72,22 @@ class ORBmatcher:
                                                k, L, levelsup, ptr(out[0]), ptr(out[1]), self._st(stream)))
         return out
 
-    def SearchByBoW(self, kf_img, f_img, kps, desc, node, count, has_mp, out=None, stream=None):
+    def SearchByBoW(self, kf_img, f_img, kps, desc, node, count, has_mp, out=None, stream=None, nLeft=None):
         """SearchByBoW(pKF, F, vpMapPointMatches) for pairs (kf_img[p], f_img[p]) of images of one pool.
-        Returns (matchF int32 [npairs, cap] = keyframe feature index per frame feature or -1, nmatches int32 [npairs])."""
+        Returns (matchF int32 [npairs, cap] = keyframe feature index per frame feature or -1, nmatches int32 [npairs]).
+        nLeft: int32 [npairs] F.Nleft per pair for fisheye frames (left features first, then right), None = pinhole."""
         import torch
         npairs = kf_img.shape[0]
         nimg, cap = kps.shape[0], kps.shape[1]
         if out is None:
             out = (torch.empty((npairs, cap), dtype=torch.int32, device=kps.device),
                    torch.empty((npairs,), dtype=torch.int32, device=kps.device))
+        if nLeft is not None:
+            check(self._L.morb_search_by_bow_fisheye_batch(self._h, npairs, ptr(kf_img), ptr(f_img), ptr(nLeft), nimg, ptr(kps),
+                                                           ptr(desc), ptr(node), ptr(count), ptr(has_mp), cap, self.mfNNratio,
+                                                           1 if self.mbCheckOrientation else 0, ptr(out[0]), ptr(out[1]),
+                                                           self._st(stream)))
+            return out
         check(self._L.morb_search_by_bow_batch(self._h, npairs, ptr(kf_img), ptr(f_img), nimg, ptr(kps), ptr(desc),
                                                ptr(node), ptr(count), ptr(has_mp), cap, self.mfNNratio,
                                                1 if self.mbCheckOrientation else 0, ptr(out[0]), ptr(out[1]),

@@ -4,7 +4,7 @@ import ctypes as C
 
 import numpy as np
 
-from .capi import check, lib, ptr
+from .capi import check, lib, ptr, stream_arg
 
 
 class Optimizer:
@@ -31,7 +31,7 @@ class Optimizer:
             out = (torch.empty((F,), dtype=torch.int32, device=hasMP.device),
                    torch.zeros((F, cap), dtype=torch.uint8, device=hasMP.device),
                    torch.empty((F, 2), dtype=torch.int32, device=hasMP.device))
-        st = None if stream is None else C.c_void_p(stream)
+        st = stream_arg(stream)
         check(self._L.morb_pose_optimization_batch(self._h, F, cap, ptr(count), ptr(hasMP), ptr(obs), ptr(invSigma2), ptr(Xw),
                                                    cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["bf"], ptr(pose),
                                                    ptr(out[1]), ptr(out[0]), ptr(out[2]), st))
@@ -47,7 +47,7 @@ class Optimizer:
                    torch.zeros((F, cap), dtype=torch.uint8, device=hasMP.device),
                    torch.empty((F, 2), dtype=torch.int32, device=hasMP.device))
         a = [np.ascontiguousarray(x, np.float32) for x in (camL, camR, Trl)]
-        st = None if stream is None else C.c_void_p(stream)
+        st = stream_arg(stream)
         check(self._L.morb_pose_optimization_fisheye_batch(self._h, F, cap, ptr(count), ptr(nLeft), ptr(hasMP), ptr(obs), ptr(invSigma2),
                                                            ptr(Xw), ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(pose), ptr(out[1]), ptr(out[0]),
                                                            ptr(out[2]), st))
@@ -94,7 +94,7 @@ class BAProblem:
         check(self._L.morb_ba_set_stop(self._h, 1 if on else 0))
 
     def solve(self, stream=None):
-        check(self._L.morb_ba_solve(self._h, None if stream is None else C.c_void_p(stream)))
+        check(self._L.morb_ba_solve(self._h, stream_arg(stream)))
 
     def results(self):
         kf = self._init[0].copy(); mp = self._init[1].copy()

@@ -178,9 +178,12 @@ void knnMatch2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* idx /*[n
 // (F.Nleft == -1).  FeatureVectors are given as one node id per feature (the DBoW2 contract: map nodeId ->
 // ascending feature indices; a negative node id = feature absent from the FeatureVector).  kfHasMP[i] != 0 <=>
 // vpMapPointsKF[i] != NULL && !isBad().  matchF[j] = KF feature index matched to frame feature j, or -1.
+// FNleft = F.Nleft (-1: pinhole frame; otherwise features [0, FNleft) are the left camera's, the rest the right
+// camera's, and the second set of best / second-best variables of :262-299 and the nested right assignment of
+// :333-365 apply — including its `|| true` and its dependence on the LEFT best distance).
 int SearchByBoW(int nKF, const uint8_t* descKF, const float* angleKF, const uint8_t* kfHasMP, const int* nodeKF,
                 int nF, const uint8_t* descF, const float* angleF, const int* nodeF, float mfNNratio,
-                bool mbCheckOrientation, int* matchF) {
+                bool mbCheckOrientation, int* matchF, int FNleft = -1) {
   std::map<int, std::vector<unsigned>> vFeatVecKF, FFeatVec;
   for (int i = 0; i < nKF; ++i) if (nodeKF[i] >= 0) vFeatVecKF[nodeKF[i]].push_back(i);
   for (int i = 0; i < nF; ++i) if (nodeF[i] >= 0) FFeatVec[nodeF[i]].push_back(i);
@@ -199,12 +202,20 @@ int SearchByBoW(int nKF, const uint8_t* descKF, const float* angleKF, const uint
         if (!kfHasMP[realIdxKF]) continue;
         const uint8_t* dKF = descKF + (size_t)realIdxKF * 32;
         int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        int bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
         for (size_t iF = 0; iF < vIndicesF.size(); iF++) {
           const unsigned realIdxF = vIndicesF[iF];
           if (matchF[realIdxF] >= 0) continue;
           const int dist = DescriptorDistance(dKF, descF + (size_t)realIdxF * 32);
-          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
-          else if (dist < bestDist2) { bestDist2 = dist; }
+          if (FNleft == -1) {
+            if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+            else if (dist < bestDist2) { bestDist2 = dist; }
+          } else {
+            if ((int)realIdxF < FNleft && dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+            else if ((int)realIdxF < FNleft && dist < bestDist2) { bestDist2 = dist; }
+            if ((int)realIdxF >= FNleft && dist < bestDist1R) { bestDist2R = bestDist1R; bestDist1R = dist; bestIdxFR = realIdxF; }
+            else if ((int)realIdxF >= FNleft && dist < bestDist2R) { bestDist2R = dist; }
+          }
         }
         if (bestDist1 <= TH_LOW) {
           if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
@@ -217,6 +228,19 @@ int SearchByBoW(int nKF, const uint8_t* descKF, const float* angleKF, const uint
               rotHist[bin].push_back(bestIdxF);
             }
             nmatches++;
+          }
+          if (bestDist1R <= TH_LOW) {
+            if (static_cast<float>(bestDist1R) < mfNNratio * static_cast<float>(bestDist2R) || true) {
+              matchF[bestIdxFR] = (int)realIdxKF;
+              if (mbCheckOrientation) {
+                float rot = angleKF[realIdxKF] - angleF[bestIdxFR];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdxFR);
+              }
+              nmatches++;
+            }
           }
         }
       }
@@ -290,6 +314,12 @@ int orc_search_by_bow(int nKF, const uint8_t* descKF, const float* angleKF, cons
                       int nF, const uint8_t* descF, const float* angleF, const int* nodeF, float nnratio, int checkOri,
                       int* matchF) {
   return SearchByBoW(nKF, descKF, angleKF, kfHasMP, nodeKF, nF, descF, angleF, nodeF, nnratio, checkOri != 0, matchF);
+}
+
+int orc_search_by_bow_fisheye(int nKF, const uint8_t* descKF, const float* angleKF, const uint8_t* kfHasMP, const int* nodeKF,
+                              int nF, int FNleft, const uint8_t* descF, const float* angleF, const int* nodeF, float nnratio,
+                              int checkOri, int* matchF) {
+  return SearchByBoW(nKF, descKF, angleKF, kfHasMP, nodeKF, nF, descF, angleF, nodeF, nnratio, checkOri != 0, matchF, FNleft);
 }
 
 void orc_bow_transform(const uint8_t* feat, int n, const uint8_t* nodeDesc, const int* firstChild, int k, int L,

@@ -48,6 +48,10 @@ void orc_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* idx, int*
 int orc_search_by_bow(int nKF, const uint8_t* descKF, const float* angleKF, const uint8_t* kfHasMP, const int* nodeKF,
                       int nF, const uint8_t* descF, const float* angleF, const int* nodeF, float nnratio, int checkOri,
                       int* matchF);
+/* SearchByBoW(pKF, F, ...) with F.Nleft = FNleft != -1 (ORBmatcher.cc:262-299, :333-365) */
+int orc_search_by_bow_fisheye(int nKF, const uint8_t* descKF, const float* angleKF, const uint8_t* kfHasMP, const int* nodeKF,
+                              int nF, int FNleft, const uint8_t* descF, const float* angleF, const int* nodeF, float nnratio,
+                              int checkOri, int* matchF);
 void orc_bow_transform(const uint8_t* feat, int n, const uint8_t* nodeDesc, const int* firstChild, int k, int L,
                        int levelsup, int* wordId, int* nodeId);
 int orc_pose_optimization(int n, const uint8_t* hasMP, const float* obs, const float* invSigma2, const float* Xw,

@@ -156,6 +156,17 @@ def search_by_bow(descKF, angleKF, hasMP, nodeKF, descF, angleF, nodeF, nnratio,
     return n, m[:len(descF)]
 
 
+def search_by_bow_fisheye(descKF, angleKF, hasMP, nodeKF, descF, angleF, nodeF, FNleft, nnratio, checkOri):
+    L = lib()
+    a = [np.ascontiguousarray(x) for x in (descKF, angleKF.astype(np.float32), hasMP.astype(np.uint8), nodeKF.astype(np.int32),
+                                           descF, angleF.astype(np.float32), nodeF.astype(np.int32))]
+    m = np.zeros(max(len(descF), 1), np.int32)
+    L.orc_search_by_bow_fisheye.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_float, C.c_int, C.c_void_p]
+    n = L.orc_search_by_bow_fisheye(len(descKF), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), len(descF), int(FNleft), _p(a[4]), _p(a[5]),
+                                    _p(a[6]), nnratio, 1 if checkOri else 0, _p(m))
+    return n, m[:len(descF)]
+
+
 def bow_transform(desc, voc_desc, voc_first, k, Lv, levelsup):
     L = lib()
     desc = np.ascontiguousarray(desc)

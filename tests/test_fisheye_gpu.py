@@ -206,3 +206,49 @@ def test_search_by_projection_mappoints_fisheye():
             np.testing.assert_array_equal(mt[f, :N], me)
             tot += ne
         assert tot > 600
+
+
+@pytest.mark.parametrize("k,Lv", [(10, 3), (3, 2)])   # ~10 features per node (register path) / ~400 (general path)
+def test_search_by_bow_fisheye(k, Lv):
+    """SearchByBoW(pKF, F, ...) with a fisheye frame: left / right candidates ranked separately, right winner taken
+    whenever the left best distance passes TH_LOW (ORBmatcher.cc:262-299, :333-365)."""
+    import torch
+    from morb_slam_amd import KP_DTYPE, ORBmatcher
+    from morb_slam_amd.synth import make_vocabulary
+    sets = [make_fisheye_features(seed=40 + s, n_pairs=420 + 60 * s) for s in range(3)]
+    nimg = len(sets)
+    cap = max(len(f["kL"]) + len(f["kR"]) for f in sets) + 3
+    kps = np.zeros((nimg, cap), KP_DTYPE); desc = np.zeros((nimg, cap, 32), np.uint8)
+    cnt = np.zeros(nimg, np.int32); nl = np.zeros(nimg, np.int32)
+    rng = np.random.default_rng(5)
+    for f, fe in enumerate(sets):
+        a, b = len(fe["kL"]), len(fe["kR"])
+        kps[f, :a] = fe["kL"]; kps[f, a:a + b] = fe["kR"]; desc[f, :a] = fe["dL"]; desc[f, a:a + b] = fe["dR"]
+        cnt[f] = a + b; nl[f] = a
+    # make image 1 and 2 noisy copies of image 0's descriptors so that many keyframe features find close left AND right partners
+    for f in (1, 2):
+        n0 = min(cnt[0], cnt[f])
+        noise = np.packbits(rng.random((n0, 256)) < 0.04, axis=1)
+        desc[f, :n0] = desc[0, :n0] ^ noise
+        half = min(nl[0], cnt[f] - nl[f])
+        desc[f, nl[f]:nl[f] + half] = desc[0, :half] ^ np.packbits(rng.random((half, 256)) < 0.05, axis=1)
+    vd, vf = make_vocabulary(k, Lv, seed=3)
+    has = (rng.random((nimg, cap)) < 0.8).astype(np.uint8)
+    cu = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    dk, dd, dc = cu(kps.view(np.uint8).reshape(nimg, cap, 28)), cu(desc), cu(cnt)
+    kf = np.array([0, 0, 1, 2], np.int32); fr = np.array([1, 2, 2, 0], np.int32)
+    for ratio, ori in ((0.7, True), (0.9, False)):
+        m = ORBmatcher(ratio, ori)
+        _, node = m.bow_transform(dd, dc, cu(vd), cu(vf), k, Lv, 1)
+        match, nm = m.SearchByBoW(cu(kf), cu(fr), dk, dd, node, dc, cu(has), nLeft=cu(nl[fr]))
+        torch.cuda.synchronize()
+        nn_, match, nm = node.cpu().numpy(), match.cpu().numpy(), nm.cpu().numpy()
+        tot = right = 0
+        for p, (a, b) in enumerate(zip(kf, fr)):
+            na, nb = cnt[a], cnt[b]
+            ne, me = O.search_by_bow_fisheye(desc[a, :na], kps[a, :na]["angle"], has[a, :na], nn_[a, :na], desc[b, :nb], kps[b, :nb]["angle"],
+                                             nn_[b, :nb], int(nl[b]), ratio, ori)
+            assert nm[p] == ne
+            np.testing.assert_array_equal(match[p, :nb], me)
+            tot += ne; right += int((me[nl[b]:] >= 0).sum())
+        assert tot > 300 and right > 50
