@@ -249,6 +249,20 @@ int morb_search_by_projection_last_batch(morb_matcher*, const morb_frame_params*
                                          const uint8_t* d_bForward, const uint8_t* d_bBackward, int checkOri, int* d_matchCur,
                                          int* d_nmatches, void* stream);
 
+/* The same with a fisheye current frame (CurrentFrame.Nleft != -1): left pass + right pass of ORBmatcher.cc:1521-1733.
+ * Image curImg[f] holds the d_nLeftCur[f] left features followed by the right ones; cam8 = the LEFT camera's KB8
+ * parameters (the reference projects both passes with mpCamera), Trl7 = GetRelativePoseTrl() as quaternion xyzw +
+ * translation (host pointers).  Projections go through the device's atan2f / cosf / sinf (ulp-level differences from
+ * the host libm can move a candidate that sits exactly on a window edge). */
+int morb_search_by_projection_last_fisheye_batch(morb_matcher* m, const morb_frame_params* P, const float* cam8, const float* Trl7,
+                                                 int nframes, const int* d_curImg, const int* d_lastImg, const int* d_nLeftCur,
+                                                 int cap, const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc,
+                                                 const uint8_t* d_curBlocked, const float* d_Tcw, const uint8_t* d_lastValid,
+                                                 const float* d_lastXw, const uint8_t* d_lastMPdesc,
+                                                 const uint8_t* d_lastMPhasObs, float th, const uint8_t* d_bForward,
+                                                 const uint8_t* d_bBackward, int checkOri, int* d_matchCur, int* d_nmatches,
+                                                 void* stream);
+
 /* int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist)
  * ORBmatcher.h:60-62, ORBmatcher.cc:1735-1842 (relocalisation refinement).  Pair f = (current image d_curImg[f],
  * keyframe image d_kfImg[f]); d_Tcw [f][7], d_Ow [f][3] = Tcw.inverse().translation(); per keyframe feature

@@ -268,6 +268,64 @@ __global__ __launch_bounds__(256) void k_prep_last(morb_frame_params P, int cap,
   qs[o] = q;
 }
 
+// Fisheye current frame (CurrentFrame.Nleft != -1, ORBmatcher.cc:1521-1733): query 2i = left pass, 2i + 1 = right pass
+// of last-frame feature i.  Both project with the LEFT camera model (mpCamera; the right pass after
+// GetRelativePoseTrl() — the reference's quirk); the right pass has no bounds / depth test of its own.
+__device__ __forceinline__ void kb8_project_dev(const float* c, const float* v3, float& u, float& v) {   // KannalaBrandt8.cpp:49-67
+  const float x2_plus_y2 = v3[0] * v3[0] + v3[1] * v3[1];
+  const float theta = atan2f(sqrtf(x2_plus_y2), v3[2]);
+  const float psi = atan2f(v3[1], v3[0]);
+  const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2,
+              theta9 = theta7 * theta2;
+  const float r = theta + c[4] * theta3 + c[5] * theta5 + c[6] * theta7 + c[7] * theta9;
+  u = c[0] * r * cosf(psi) + c[2];
+  v = c[1] * r * sinf(psi) + c[3];
+}
+__global__ __launch_bounds__(256) void k_prep_last_fisheye(morb_frame_params P, int cap, const int* __restrict__ count,
+                                                           const int* __restrict__ lastImg, const int* __restrict__ curImg,
+                                                           const int* __restrict__ nLeftCur, const morb_keypoint* __restrict__ kps,
+                                                           const uint8_t* __restrict__ lastValid, const float* __restrict__ lastXw,
+                                                           const float* __restrict__ Tcw, const float* __restrict__ camTrl,   // [8 + 7]
+                                                           float th, const uint8_t* __restrict__ fwd,
+                                                           const uint8_t* __restrict__ bwd, Query* __restrict__ qs) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cap) return;
+  const size_t o = (size_t)f * cap + i;
+  Query ql, qr;
+  memset(&ql, 0, sizeof ql);
+  memset(&qr, 0, sizeof qr);
+  const int img = lastImg[f];
+  if (i < count[img] && lastValid[o]) {
+    const float* T = Tcw + 7 * f;
+    float x3Dc[3];
+    q_rotate_f(T, lastXw + o * 3, x3Dc);
+    x3Dc[0] += T[4]; x3Dc[1] += T[5]; x3Dc[2] += T[6];
+    const float invzc = (float)(1.0 / (double)x3Dc[2]);
+    float u, v;
+    kb8_project_dev(camTrl, x3Dc, u, v);
+    if (!(invzc < 0) && !(u < P.minX || u > P.maxX) && !(v < P.minY || v > P.maxY)) {
+      const morb_keypoint kp = kps[(size_t)img * cap + i];
+      const int oct = kp.octave;
+      const int nLeft = nLeftCur[f], N = count[curImg[f]];
+      ql.valid = 1; ql.x = u; ql.y = v; ql.r = th * P.scaleFactors[oct];
+      if (fwd[f]) { ql.minLevel = oct; ql.maxLevel = -1; }
+      else if (bwd[f]) { ql.minLevel = 0; ql.maxLevel = oct; }
+      else { ql.minLevel = oct - 1; ql.maxLevel = oct + 1; }
+      ql.angle = kp.angle; ql.jLo = 0; ql.jHi = nLeft;
+      if (nLeft <= 0) ql.valid = 0;
+      qr = ql;
+      const float* Trl = camTrl + 8;
+      float x3Dr[3];
+      q_rotate_f(Trl, x3Dc, x3Dr);
+      x3Dr[0] += Trl[4]; x3Dr[1] += Trl[5]; x3Dr[2] += Trl[6];
+      kb8_project_dev(camTrl, x3Dr, qr.x, qr.y);
+      qr.jLo = nLeft; qr.jHi = N; qr.valid = (ql.valid && N > nLeft) ? 1 : 0;
+    }
+  }
+  qs[2 * o] = ql;
+  qs[2 * o + 1] = qr;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // phase A: candidate keys per query (one wave per query, lanes over the frame's features)
 __global__ __launch_bounds__(256) void k_candidates(morb_frame_params P, int qCap, const Query* __restrict__ qs,
@@ -313,6 +371,8 @@ __global__ __launch_bounds__(256) void k_candidates(morb_frame_params P, int qCa
 // MODE 3: MODE 1 on a fisheye rig (F.Nleft != -1, :42-209): queries 2i / 2i + 1 are map point i in the left / right
 //         camera; a match also claims the stereo partner (mvLeftToRightMatch / mvRightToLeftMatch), and a left match
 //         rejected by the ratio test skips the right pass of that map point (the `continue` at :122)
+// MODE 4: MODE 0 on a fisheye current frame (:1521-1733): queries 2i / 2i + 1 = left / right pass of last-frame feature
+//         i; an empty left window skips the right pass (the `continue` at :1583)
 template <int MODE>
 __global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, const int* __restrict__ nQv,
                                                 const Query* __restrict__ qs, const uint8_t* __restrict__ qDesc,
@@ -325,7 +385,7 @@ __global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, c
                                                 int* __restrict__ nmatches, int* __restrict__ entryJ, int* __restrict__ entryBin,
                                                 float* __restrict__ prevMatched, const int* __restrict__ l2r,
                                                 const int* __restrict__ r2l, const int* __restrict__ nLeftv) {
-  constexpr int QS = MODE == 3 ? 1 : 0;   // query index -> descriptor / hasObs row
+  constexpr int QS = (MODE == 3 || MODE == 4) ? 1 : 0;   // query index -> descriptor / hasObs row
   extern __shared__ __align__(8) uint8_t smemRaw[];
   uint8_t* blocked = smemRaw;                                   // MODE 0/1: [cap]
   int* matchedDist = reinterpret_cast<int*>(smemRaw);           // MODE 2:   [cap]
@@ -349,10 +409,11 @@ __global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, c
   const float factor = 1.0f / HISTO_LENGTH;
   const int nLeft = MODE == 3 ? nLeftv[f] : 0;
   int skipRightOf = -1;
-  const int nQtot = MODE == 3 ? 2 * nQ : nQ;
+  const int nQtot = QS ? 2 * nQ : nQ;
   for (int qi = 0; qi < nQtot && qi < qCap; ++qi) {
     const size_t qo = (size_t)f * qCap + qi;
     if (MODE == 3 && (qi & 1) && (qi >> 1) == skipRightOf) continue;
+    if (MODE == 4 && (qi & 1) && candCnt[qo - 1] == 0) continue;   // the left pass hit `if (vIndices2.empty()) continue;`
     const int cnt = candCnt[qo];
     if (cnt == 0) continue;
     unsigned long long k1 = ~0ull, k2 = ~0ull;
@@ -410,11 +471,14 @@ __global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, c
             const int pj = (qi & 1) ? partner : partner + nLeft;
             mF[pj] = mp; blocked[pj] = ho;
           }
+        } else if (MODE == 4) {
+          mF[bestIdx] = qi >> 1;
+          blocked[bestIdx] = qHasObs ? qHasObs[qo >> 1] : 1;
         } else {
           mF[bestIdx] = qi;
           blocked[bestIdx] = qHasObs ? qHasObs[qo] : 1;
         }
-        if (MODE != 1 && checkOri) {
+        if (MODE != 1 && MODE != 3 && checkOri) {
           float rot = qs[qo].angle - kps[(size_t)img * cap + bestIdx].angle;
           if (rot < 0.0f) rot += 360.0f;
           int bin = (int)roundf(rot * factor);
@@ -434,7 +498,7 @@ __global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, c
       __builtin_amdgcn_wave_barrier();
     }
   }
-  if (MODE != 1 && checkOri) {  // ComputeThreeMaxima + un-assign
+  if (MODE != 1 && MODE != 3 && checkOri) {  // ComputeThreeMaxima + un-assign
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
     int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
@@ -706,13 +770,14 @@ static int window_search(morb_matcher* m, const morb_frame_params* P, int mode, 
   if (rc == MORB_OK) rc = morb_matcher_workspace(m, 3, sizeof(int) * (size_t)nframes * qCap, &eb);
   if (rc != MORB_OK) return rc;
   hipLaunchKernelGGL(k_candidates, dim3(div_up(qCap, 4), nframes), dim3(256), 0, st, *P, qCap, d_qs, d_qDesc, d_fImg, cap, d_count,
-                     d_kps, d_desc, d_uRight, (unsigned long long*)cand, (int*)cnt, mode == 3 ? 1 : 0);
+                     d_kps, d_desc, d_uRight, (unsigned long long*)cand, (int*)cnt, (mode == 3 || mode == 4) ? 1 : 0);
 #define MORB_RESOLVE(MODE, SMEM)                                                                                             \
   hipLaunchKernelGGL(k_resolve<MODE>, dim3(nframes), dim3(64), (SMEM), st, *P, qCap, d_nQ, d_qs, d_qDesc, d_qHasObs, d_fImg, cap, \
                      d_count, d_kps, d_desc, d_uRight, d_blocked, (const unsigned long long*)cand, (const int*)cnt, nnratio,   \
                      thAccept, checkOri, d_match, d_nmatches, (int*)ej, (int*)eb, d_prevMatched, d_l2r, d_r2l, d_nLeft)
   if (mode == 1) MORB_RESOLVE(1, (size_t)cap);
   else if (mode == 3) MORB_RESOLVE(3, (size_t)cap);
+  else if (mode == 4) MORB_RESOLVE(4, (size_t)cap);
   else if (mode == 2) {
     MORB_REQUIRE((size_t)cap * 8 <= 64 * 1024, MORB_ERR_UNSUPPORTED, "too many features for SearchForInitialization's LDS state");
     MORB_RESOLVE(2, (size_t)cap * 8);
@@ -795,6 +860,41 @@ int morb_search_by_projection_last_batch(morb_matcher* m, const morb_frame_param
   hipLaunchKernelGGL(k_gather_counts, dim3(div_up(nframes, 256)), dim3(256), 0, st, d_count, d_lastImg, nframes, (int*)nq);
   return window_search(m, P, 0, nframes, cap, (const int*)nq, (const Query*)qs, d_lastMPdesc, d_lastMPhasObs, d_curImg, cap,
                        d_count, d_kps, d_desc, d_curURight, d_curBlocked, 0.f, TH_HIGH, checkOri, d_matchCur, d_nmatches, nullptr, st);
+}
+
+int morb_search_by_projection_last_fisheye_batch(morb_matcher* m, const morb_frame_params* P, const float* cam8, const float* Trl7,
+                                                 int nframes, const int* d_curImg, const int* d_lastImg, const int* d_nLeftCur,
+                                                 int cap, const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc,
+                                                 const uint8_t* d_curBlocked, const float* d_Tcw, const uint8_t* d_lastValid,
+                                                 const float* d_lastXw, const uint8_t* d_lastMPdesc,
+                                                 const uint8_t* d_lastMPhasObs, float th, const uint8_t* d_bForward,
+                                                 const uint8_t* d_bBackward, int checkOri, int* d_matchCur, int* d_nmatches,
+                                                 void* stream) {
+  MORB_REQUIRE(m && P && cam8 && Trl7 && d_curImg && d_lastImg && d_nLeftCur && d_count && d_kps && d_desc && d_Tcw && d_lastValid &&
+                   d_lastXw && d_lastMPdesc && d_lastMPhasObs && d_bForward && d_bBackward && d_matchCur && d_nmatches,
+               MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(nframes > 0 && cap > 0 && cap <= 65535, MORB_ERR_INVALID, "bad sizes");
+  MORB_HIP_CHECK(hipSetDevice(morb_matcher_device(m)));
+  hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
+  float ct[15];
+  for (int i = 0; i < 8; ++i) ct[i] = cam8[i];
+  for (int i = 0; i < 7; ++i) ct[8 + i] = Trl7[i];
+  void* d_ct = nullptr;
+  int rc = morb_matcher_workspace(m, 4, sizeof ct, &d_ct);
+  if (rc != MORB_OK) return rc;
+  MORB_HIP_CHECK(hipMemcpyAsync(d_ct, ct, sizeof ct, hipMemcpyHostToDevice, st));
+  MORB_HIP_CHECK(hipStreamSynchronize(st));  // ct lives on this stack frame
+  void* qs = nullptr;
+  rc = morb_matcher_workspace(m, 5, sizeof(Query) * (size_t)nframes * cap * 2, &qs);
+  if (rc != MORB_OK) return rc;
+  hipLaunchKernelGGL(k_prep_last_fisheye, dim3(div_up(cap, 256), nframes), dim3(256), 0, st, *P, cap, d_count, d_lastImg, d_curImg,
+                     d_nLeftCur, d_kps, d_lastValid, d_lastXw, d_Tcw, (const float*)d_ct, th, d_bForward, d_bBackward, (Query*)qs);
+  void* nq = nullptr;
+  rc = morb_matcher_workspace(m, 6, sizeof(int) * (size_t)nframes, &nq);
+  if (rc != MORB_OK) return rc;
+  hipLaunchKernelGGL(k_gather_counts, dim3(div_up(nframes, 256)), dim3(256), 0, st, d_count, d_lastImg, nframes, (int*)nq);
+  return window_search(m, P, 4, nframes, 2 * cap, (const int*)nq, (const Query*)qs, d_lastMPdesc, d_lastMPhasObs, d_curImg, cap,
+                       d_count, d_kps, d_desc, nullptr, d_curBlocked, 0.f, TH_HIGH, checkOri, d_matchCur, d_nmatches, nullptr, st);
 }
 
 int morb_search_by_projection_kf_batch(morb_matcher* m, const morb_frame_params* P, int nframes, const int* d_curImg,

@@ -174,6 +174,20 @@ class ORBmatcher:
             ptr(bBackward), 1 if self.mbCheckOrientation else 0, ptr(matchCur), ptr(nm), self._st(stream)))
         return matchCur, nm
 
+    def SearchByProjectionLastFrameFisheye(self, params, cam8, Trl7, curImg, lastImg, nLeftCur, kps, desc, count, curBlocked, Tcw,
+                                           lastValid, lastXw, lastMPdesc, lastMPhasObs, th, bForward, bBackward, stream=None):
+        """SearchByProjection(CurrentFrame, LastFrame, th, bMono) with CurrentFrame.Nleft != -1 (left + right pass)."""
+        import torch
+        F, cap = curImg.shape[0], kps.shape[1]
+        matchCur = torch.full((F, cap), -1, dtype=torch.int32, device=kps.device)
+        nm = torch.zeros((F,), dtype=torch.int32, device=kps.device)
+        cam = np.ascontiguousarray(cam8, np.float32); trl = np.ascontiguousarray(Trl7, np.float32)
+        check(self._L.morb_search_by_projection_last_fisheye_batch(
+            self._h, C.byref(params), ptr(cam), ptr(trl), F, ptr(curImg), ptr(lastImg), ptr(nLeftCur), cap, ptr(count), ptr(kps),
+            ptr(desc), ptr(curBlocked), ptr(Tcw), ptr(lastValid), ptr(lastXw), ptr(lastMPdesc), ptr(lastMPhasObs), float(th),
+            ptr(bForward), ptr(bBackward), 1 if self.mbCheckOrientation else 0, ptr(matchCur), ptr(nm), self._st(stream)))
+        return matchCur, nm
+
     def SearchForTriangulation(self, params, img1, img2, kps, desc, node, count, hasMP, uRight, R12, t12, ep,
                                bOnlyStereo=False, bCoarse=False, stream=None):
         """SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse); R12/t12/ep are host numpy arrays."""

@@ -83,6 +83,11 @@ int orc_search_by_projection_last(const orc_frame* Cur, const uint8_t* curBlocke
                                   const orc_keypoint* lastKpsUn, const uint8_t* lastValid, const float* lastXw,
                                   const uint8_t* lastMPdesc, const uint8_t* lastMPhasObs, float th, int bForward,
                                   int bBackward, int checkOri, int* matchCur);
+int orc_search_by_projection_last_fisheye(const orc_frame* Cur, int NleftCur, const float* cam8, const float* Trl7,
+                                          const uint8_t* curBlocked, const float* Tcw7, int nLast, const orc_keypoint* lastKps,
+                                          const uint8_t* lastValid, const float* lastXw, const uint8_t* lastMPdesc,
+                                          const uint8_t* lastMPhasObs, float th, int bForward, int bBackward, int checkOri,
+                                          int* matchCur);
 int orc_search_by_projection_kf(const orc_frame* Cur, const uint8_t* curHasMP, const float* Tcw7, const float* Ow, int nKF,
                                 const orc_keypoint* kfKpsUn, const uint8_t* kfValid, const float* Xw, const float* maxDist,
                                 const float* minDist, const uint8_t* mpDesc, float th, int ORBdist, int checkOri, int* matchCur);

@@ -379,6 +379,93 @@ int SearchByProjectionLast(const orc_frame& Cur, const uint8_t* curBlocked, cons
   return nmatches;
 }
 
+// ---- SearchByProjection(CurrentFrame, LastFrame, th, bMono) with CurrentFrame.Nleft != -1 (:1521-1733) --------------
+// Cur holds the left features followed by the right ones.  Quirks kept: the right pass projects with mpCamera (the
+// LEFT camera's model) after GetRelativePoseTrl(), has no bounds / depth test, and is skipped together with the left
+// pass by every `continue` of the left pass (behind the camera, out of bounds, empty left window).
+int SearchByProjectionLastFisheye(const orc_frame& Cur, int NleftCur, const float* cam8, const float* Trl7,
+                                  const uint8_t* curBlocked, const float* Tcw7, int nLast, const KeyPoint* lastKps,
+                                  const uint8_t* lastValid, const float* lastXw, const uint8_t* lastMPdesc,
+                                  const uint8_t* lastMPhasObs, float th, bool bForward, bool bBackward,
+                                  bool mbCheckOrientation, int* matchCur) {
+  orc_frame FL = Cur, FR = Cur;
+  FL.N = NleftCur;
+  FR.N = Cur.N - NleftCur; FR.kpsUn = Cur.kpsUn + NleftCur; FR.desc = Cur.desc + (size_t)NleftCur * 32;
+  Grid gl, gr;
+  AssignFeaturesToGrid(FL, gl);
+  AssignFeaturesToGrid(FR, gr);
+  const KeyPoint* kc = (const KeyPoint*)Cur.kpsUn;
+  std::vector<char> blocked(curBlocked, curBlocked + Cur.N);
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  for (int i = 0; i < nLast; i++) {
+    if (!lastValid[i]) continue;
+    float x3Dc[3];
+    rotateF(Tcw7, lastXw + 3 * i, x3Dc);
+    x3Dc[0] += Tcw7[4]; x3Dc[1] += Tcw7[5]; x3Dc[2] += Tcw7[6];
+    const float invzc = (float)(1.0 / x3Dc[2]);
+    if (invzc < 0) continue;
+    float uv[2];
+    orc_kb8_project_f(cam8, x3Dc, uv);
+    if (uv[0] < Cur.minX || uv[0] > Cur.maxX) continue;
+    if (uv[1] < Cur.minY || uv[1] > Cur.maxY) continue;
+    const int nLastOctave = lastKps[i].octave;
+    const float radius = th * Cur.scaleFactors[nLastOctave];
+    const uint8_t* dMP = lastMPdesc + (size_t)i * 32;
+    for (int pass = 0; pass < 2; ++pass) {
+      const orc_frame& Fs = pass ? FR : FL;
+      const Grid& g = pass ? gr : gl;
+      const int base = pass ? NleftCur : 0;
+      float u = uv[0], v = uv[1];
+      if (pass) {
+        float x3Dr[3], uvr[2];
+        rotateF(Trl7, x3Dc, x3Dr);
+        x3Dr[0] += Trl7[4]; x3Dr[1] += Trl7[5]; x3Dr[2] += Trl7[6];
+        orc_kb8_project_f(cam8, x3Dr, uvr);
+        u = uvr[0]; v = uvr[1];
+      }
+      std::vector<size_t> vIndices2;
+      if (bForward) vIndices2 = GetFeaturesInArea(Fs, g, u, v, radius, nLastOctave, -1);
+      else if (bBackward) vIndices2 = GetFeaturesInArea(Fs, g, u, v, radius, 0, nLastOctave);
+      else vIndices2 = GetFeaturesInArea(Fs, g, u, v, radius, nLastOctave - 1, nLastOctave + 1);
+      if (!pass && vIndices2.empty()) break;   // :1583: `continue` of the outer loop, the right pass is skipped too
+      int bestDist = 256, bestIdx2 = -1;
+      for (size_t q = 0; q < vIndices2.size(); ++q) {
+        const size_t i2 = vIndices2[q];
+        if (blocked[i2 + base]) continue;
+        const int dist = DescriptorDistance(dMP, Cur.desc + (i2 + base) * 32);
+        if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+      }
+      if (bestDist <= TH_HIGH) {
+        matchCur[bestIdx2 + base] = i;
+        blocked[bestIdx2 + base] = lastMPhasObs[i] ? 1 : 0;
+        nmatches++;
+        if (mbCheckOrientation) {
+          float rot = lastKps[i].angle - kc[bestIdx2 + base].angle;
+          if (rot < 0.0) rot += 360.0f;
+          int bin = (int)std::round(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          rotHist[bin].push_back(bestIdx2 + base);
+        }
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i != ind1 && i != ind2 && i != ind3) {
+        for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+          matchCur[rotHist[i][j]] = -1;
+          nmatches--;
+        }
+      }
+    }
+  }
+  return nmatches;
+}
+
 // ---- ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist) (:1735-1842) ----
 // kfValid[i] != 0 <=> vpMPs[i] && !isBad() && !sAlreadyFound.count(pMP); curHasMP[i2] != 0 <=> CurrentFrame.mvpMapPoints[i2].
 int SearchByProjectionKF(const orc_frame& Cur, const uint8_t* curHasMP, const float* Tcw7, const float* Ow, int nKF,
@@ -653,6 +740,14 @@ int orc_search_by_projection_last(const orc_frame* Cur, const uint8_t* curBlocke
                                   int bBackward, int checkOri, int* matchCur) {
   return SearchByProjectionLast(*Cur, curBlocked, Tcw7, nLast, (const KeyPoint*)lastKpsUn, lastValid, lastXw, lastMPdesc,
                                 lastMPhasObs, th, bForward != 0, bBackward != 0, checkOri != 0, matchCur);
+}
+int orc_search_by_projection_last_fisheye(const orc_frame* Cur, int NleftCur, const float* cam8, const float* Trl7,
+                                          const uint8_t* curBlocked, const float* Tcw7, int nLast, const orc_keypoint* lastKps,
+                                          const uint8_t* lastValid, const float* lastXw, const uint8_t* lastMPdesc,
+                                          const uint8_t* lastMPhasObs, float th, int bForward, int bBackward, int checkOri,
+                                          int* matchCur) {
+  return SearchByProjectionLastFisheye(*Cur, NleftCur, cam8, Trl7, curBlocked, Tcw7, nLast, (const KeyPoint*)lastKps, lastValid,
+                                       lastXw, lastMPdesc, lastMPhasObs, th, bForward != 0, bBackward != 0, checkOri != 0, matchCur);
 }
 int orc_search_by_projection_kf(const orc_frame* Cur, const uint8_t* curHasMP, const float* Tcw7, const float* Ow, int nKF,
                                 const orc_keypoint* kfKpsUn, const uint8_t* kfValid, const float* Xw, const float* maxDist,

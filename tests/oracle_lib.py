@@ -283,6 +283,20 @@ def search_by_projection_last(Cur, blocked, Tcw7, lastKps, lastValid, lastXw, la
     return r, m
 
 
+def search_by_projection_last_fisheye(Cur, NleftCur, cam8, Trl7, blocked, Tcw7, lastKps, lastValid, lastXw, lastMPdesc, lastHasObs, th,
+                                      fwd, bwd, checkOri):
+    L = lib()
+    L.orc_search_by_projection_last_fisheye.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 5 + \
+        [C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    m = np.full(Cur.N, -1, np.int32)
+    a = [np.ascontiguousarray(x) for x in (np.asarray(cam8, np.float32), np.asarray(Trl7, np.float32), blocked.astype(np.uint8),
+                                           np.asarray(Tcw7, np.float32), lastKps, lastValid.astype(np.uint8),
+                                           np.asarray(lastXw, np.float32), lastMPdesc, lastHasObs.astype(np.uint8))]
+    r = L.orc_search_by_projection_last_fisheye(C.byref(Cur), int(NleftCur), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), len(lastKps),
+                                                _p(a[4]), _p(a[5]), _p(a[6]), _p(a[7]), _p(a[8]), th, int(fwd), int(bwd), int(checkOri), _p(m))
+    return r, m
+
+
 def search_for_triangulation(k1, d1, node1, has1, ur1, k2, d2, node2, has2, ur2, sigma2, scaleF, K, R12, t12, ep, onlyStereo, coarse, checkOri):
     L = lib()
     F12 = np.zeros(9, np.float32)

@@ -252,3 +252,76 @@ def test_search_by_bow_fisheye(k, Lv):
             np.testing.assert_array_equal(match[p, :nb], me)
             tot += ne; right += int((me[nl[b]:] >= 0).sum())
         assert tot > 300 and right > 50
+
+
+def test_search_by_projection_last_frame_fisheye():
+    """SearchByProjection(CurrentFrame, LastFrame, th, bMono) with CurrentFrame.Nleft != -1: left pass, right pass through
+    GetRelativePoseTrl() with the LEFT camera model, the empty-left-window `continue`, rotation histogram over both."""
+    import torch
+    from morb_slam_amd import KP_DTYPE, ORBmatcher
+    from morb_slam_amd.synth import TUMVI_CAM_L, TUMVI_T_C1_C2, kb8_project, _quat_from_rotvec, _quat_rot, _quat_from_R
+    P, sf = _fisheye_params()
+    Trl_m = np.linalg.inv(TUMVI_T_C1_C2)
+    Trl7 = np.concatenate([_quat_from_R(Trl_m[:3, :3]), Trl_m[:3, 3]]).astype(np.float32)
+    Fn, M = 3, 520
+    rng = np.random.default_rng(123)
+    frames = []
+    for f in range(Fn):
+        Xw = np.stack([rng.uniform(-3, 3, M), rng.uniform(-2.5, 2.5, M), rng.uniform(1, 8, M)], 1)
+        Tcw = np.concatenate([_quat_from_rotvec(rng.normal(0, 0.02, 3)), rng.normal(0, 0.05, 3)]).astype(np.float32)
+        Xc = np.array([_quat_rot(Tcw[:4].astype(np.float64), x) + Tcw[4:] for x in Xw])
+        Xr = Xc @ Trl_m[:3, :3].T + Trl_m[:3, 3]
+        uvL, uvR = kb8_project(TUMVI_CAM_L, Xc), kb8_project(TUMVI_CAM_L, Xr)
+        octv = rng.integers(0, 8, M); ang = rng.uniform(0, 360, M)
+        mpd = rng.integers(0, 256, (M, 32), dtype=np.uint8)
+
+        def side(uv, frac, nd):
+            ok = (uv > 8).all(1) & (uv < 504).all(1) & (rng.random(M) < frac)
+            idx = np.nonzero(ok)[0]
+            n = len(idx) + nd
+            k = np.zeros(n, KP_DTYPE); d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            k["x"] = rng.uniform(5, 507, n); k["y"] = rng.uniform(5, 507, n); k["octave"] = rng.integers(0, 8, n)
+            k["angle"] = rng.uniform(0, 360, n); k["size"] = 31; k["class_id"] = -1
+            sel = rng.permutation(n)[:len(idx)]
+            k["x"][sel] = uv[idx, 0] + rng.normal(0, 1.0, len(idx)); k["y"][sel] = uv[idx, 1] + rng.normal(0, 1.0, len(idx))
+            k["octave"][sel] = np.clip(octv[idx] + rng.integers(-1, 2, len(idx)), 0, 7)
+            k["angle"][sel] = (ang[idx] + rng.choice([0.0, 0.0, 0.0, 90.0], len(idx)) + rng.normal(0, 3, len(idx))) % 360
+            d[sel] = mpd[idx] ^ np.packbits(rng.random((len(idx), 256)) < 0.06, axis=1)
+            return k, d
+        kL, dL = side(uvL, 0.8, 150); kR, dR = side(uvR, 0.6, 120)
+        last = np.zeros(M, KP_DTYPE); last["octave"] = octv; last["angle"] = ang
+        frames.append(dict(kL=kL, dL=dL, kR=kR, dR=dR, last=last, Xw=Xw.astype(np.float32), Tcw=Tcw, mpd=mpd,
+                           valid=(rng.random(M) < 0.9).astype(np.uint8), hasObs=(rng.random(M) < 0.7).astype(np.uint8)))
+    cap = max(max(len(fr["kL"]) + len(fr["kR"]), M) for fr in frames) + 2
+    nimg = 2 * Fn
+    kps = np.zeros((nimg, cap), KP_DTYPE); desc = np.zeros((nimg, cap, 32), np.uint8); cnt = np.zeros(nimg, np.int32)
+    nl = np.zeros(Fn, np.int32); Tcw = np.zeros((Fn, 7), np.float32)
+    valid = np.zeros((Fn, cap), np.uint8); Xw = np.zeros((Fn, cap, 3), np.float32); mpd = np.zeros((Fn, cap, 32), np.uint8)
+    hasObs = np.zeros((Fn, cap), np.uint8)
+    blocked = (rng.random((Fn, cap)) < 0.04).astype(np.uint8)
+    for f, fr in enumerate(frames):
+        a, b = len(fr["kL"]), len(fr["kR"])
+        kps[2 * f, :a] = fr["kL"]; kps[2 * f, a:a + b] = fr["kR"]; desc[2 * f, :a] = fr["dL"]; desc[2 * f, a:a + b] = fr["dR"]
+        cnt[2 * f] = a + b; nl[f] = a
+        kps[2 * f + 1, :M] = fr["last"]; cnt[2 * f + 1] = M
+        Tcw[f] = fr["Tcw"]; valid[f, :M] = fr["valid"]; Xw[f, :M] = fr["Xw"]; mpd[f, :M] = fr["mpd"]; hasObs[f, :M] = fr["hasObs"]
+    cu = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    dk = cu(kps.view(np.uint8).reshape(nimg, cap, 28))
+    cur = np.arange(0, nimg, 2, dtype=np.int32); lst = cur + 1
+    m = ORBmatcher(0.9, True)
+    for th, fwd, bwd in ((7.0, 0, 0), (15.0, 1, 0), (7.0, 0, 1)):
+        fw = np.full(Fn, fwd, np.uint8); bw = np.full(Fn, bwd, np.uint8)
+        mt, nm = m.SearchByProjectionLastFrameFisheye(P, TUMVI_CAM_L, Trl7, cu(cur), cu(lst), cu(nl), dk, cu(desc), cu(cnt), cu(blocked),
+                                                      cu(Tcw), cu(valid), cu(Xw), cu(mpd), cu(hasObs), th, cu(fw), cu(bw))
+        torch.cuda.synchronize()
+        mt, nm = mt.cpu().numpy(), nm.cpu().numpy()
+        tot = right = 0
+        for f in range(Fn):
+            N = int(cnt[2 * f])
+            Fo = O.make_frame(P, kps[2 * f, :N], desc[2 * f, :N], None)
+            ne, me = O.search_by_projection_last_fisheye(Fo, int(nl[f]), TUMVI_CAM_L, Trl7, blocked[f, :N], Tcw[f], kps[2 * f + 1, :M],
+                                                         valid[f, :M], Xw[f, :M], mpd[f, :M], hasObs[f, :M], th, fwd, bwd, True)
+            assert int(nm[f]) == ne
+            np.testing.assert_array_equal(mt[f, :N], me)
+            tot += ne; right += int((me[nl[f]:] >= 0).sum())
+        assert tot > 500 and right > 150
