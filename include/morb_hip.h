@@ -351,6 +351,20 @@ int morb_ba_problem_create(morb_optimizer*, morb_ba_problem** out, int nKF, cons
                            int nMP, const float* mpPos, int nE, const int* eKF, const int* eMP, const float* eObs,
                            const float* eInvSigma2, float fx, float fy, float cx, float cy, float bf,
                            int lambdaInit100);
+
+/* The same for a KannalaBrandt8 stereo rig (pKFi->mpCamera2 != NULL, Optimizer.cc:1244-1351): every observation is an
+ * EdgeSE3ProjectXYZ with the left camera (eRight[e] == 0; mvuRight < 0 on such rigs, so there are no stereo edges) or
+ * an EdgeSE3ProjectXYZToBody with the right camera behind mTrl (eRight[e] != 0, observation = mvKeysRight[rightIndex
+ * - NLeft].pt).  eObs2 = [nE][2]; camL8 / camR8 = fx fy cx cy k0..k3; Trl7 = GetRelativePoseTrl() as quaternion xyzw +
+ * translation.  Erase rule: chi2 > 5.991 || !isDepthPositive() for both kinds (:1366-1390). */
+int morb_ba_problem_create_fisheye(morb_optimizer* o, morb_ba_problem** out, int nKF, const float* kfPose, const uint8_t* kfFixed,
+                                   int nMP, const float* mpPos, int nE, const int* eKF, const int* eMP, const float* eObs2,
+                                   const uint8_t* eRight, const float* eInvSigma2, const float* camL8, const float* camR8,
+                                   const float* Trl7, int lambdaInit100);
+int morb_local_bundle_adjustment_fisheye(morb_optimizer* o, int nKF, float* kfPose, const uint8_t* kfFixed, int nMP, float* mpPos,
+                                         int nE, const int* eKF, const int* eMP, const float* eObs2, const uint8_t* eRight,
+                                         const float* eInvSigma2, const float* camL8, const float* camR8, const float* Trl7,
+                                         int lambdaInit100, const int* stopFlag, uint8_t* eraseFlag, int* stats2);
 void morb_ba_problem_destroy(morb_ba_problem*);
 int morb_ba_set_stop(morb_ba_problem*, int stop);
 /* mode 0 (default): one launch per LM phase over the whole GPU, accept/reject on the host (one 32-byte read-back per

@@ -317,6 +317,57 @@ __device__ __forceinline__ void pose_edge_jac(const Cam& cam, const Rig& rig, bo
   for (int k = 12; k < 18; ++k) Jp[k] = 0;
 }
 
+// ---- binary edges of LocalBundleAdjustment, pinhole or fisheye rig ---------------------------------------------
+// obs[2] >= 0: EdgeStereoSE3ProjectXYZ; -1: EdgeSE3ProjectXYZ with the pinhole camera; -2: EdgeSE3ProjectXYZ with the
+// left KB8 camera; -3: EdgeSE3ProjectXYZToBody (right KB8 camera behind mTrl).  (Optimizer.cc:1244-1351)
+__device__ __forceinline__ bool edge_is_kb8(const Rig* rig, const float* o) { return rig != nullptr && o[2] < -1.5f; }
+__device__ __forceinline__ double ba_edge_error(const Cam& cam, const Rig* rig, bool st, const double* xc, const float* o,
+                                                double info, double* err) {
+  if (!edge_is_kb8(rig, o)) return edge_error(cam, st, xc, o, info, err);
+  double uv[2];
+  if (o[2] > -2.5f) kb8_project_d(rig->kbL, xc, uv);
+  else { double xr[3]; se3_map(rig->Trl, xc, xr); kb8_project_d(rig->kbR, xr, uv); }   // (mTrl * T).map(Xw) = mTrl.map(T.map(Xw))
+  err[0] = (double)o[0] - uv[0]; err[1] = (double)o[1] - uv[1]; err[2] = 0;
+  return err[0] * (info * err[0]) + err[1] * (info * err[1]);
+}
+// Jp (d x 6) and / or Jl (d x 3); R = rotation of the keyframe pose.  OptimizableTypes.cpp:134-156 / :185-208
+__device__ __forceinline__ void ba_edge_jac(const Cam& cam, const Rig* rig, bool st, const double* xc, const float* o,
+                                            const double* R, double* Jp, double* Jl) {
+  if (!edge_is_kb8(rig, o)) {
+    if (Jp) jac_pose(cam, st, false, xc, Jp);
+    if (Jl) jac_point(cam, st, xc, R, Jl);
+    return;
+  }
+  const double x = xc[0], y = xc[1], z = xc[2];
+  double pj[6], pjM[6];
+  if (o[2] > -2.5f) {
+    kb8_project_jac(rig->kbL, xc, pj);
+    for (int k = 0; k < 6; ++k) pjM[k] = pj[k];
+  } else {
+    double xr[3], M[9];
+    se3_map(rig->Trl, xc, xr);
+    kb8_project_jac(rig->kbR, xr, pj);
+    q_to_R(rig->Trl.q, M);
+    for (int r = 0; r < 2; ++r)
+      for (int c = 0; c < 3; ++c) pjM[r * 3 + c] = pj[r * 3] * M[c] + pj[r * 3 + 1] * M[3 + c] + pj[r * 3 + 2] * M[6 + c];
+  }
+  for (int r = 0; r < 2; ++r) {
+    const double a = pjM[r * 3], b = pjM[r * 3 + 1], c = pjM[r * 3 + 2];
+    if (Jp) {
+      Jp[r * 6 + 0] = -(b * -z + c * y); Jp[r * 6 + 1] = -(a * z + c * -x); Jp[r * 6 + 2] = -(a * -y + b * x);
+      Jp[r * 6 + 3] = -a; Jp[r * 6 + 4] = -b; Jp[r * 6 + 5] = -c;
+    }
+    if (Jl) for (int k = 0; k < 3; ++k) Jl[r * 3 + k] = -(a * R[k] + b * R[3 + k] + c * R[6 + k]);
+  }
+  if (Jp) for (int k = 12; k < 18; ++k) Jp[k] = 0;
+  if (Jl) for (int k = 6; k < 9; ++k) Jl[k] = 0;
+}
+// isDepthPositive (OptimizableTypes.h:117-123 / :152-158)
+__device__ __forceinline__ bool ba_depth_positive(const Rig* rig, const float* o, const double* xc) {
+  if (edge_is_kb8(rig, o) && !(o[2] > -2.5f)) { double xr[3]; se3_map(rig->Trl, xc, xr); return xr[2] > 0.0; }
+  return xc[2] > 0.0;
+}
+
 // =====================================================================================================
 // PoseOptimization: one workgroup per frame
 // =====================================================================================================
@@ -516,6 +567,7 @@ struct BaDev {
   int* stats;                           // [2]
   const int* stop;                      // device-visible abort flag (may be NULL)
   Cam cam;
+  const struct Rig* rig;                // fisheye rig (KB8 cameras + mTrl) or NULL; its edges carry obs[2] = -2 (left camera) / -3 (right, "ToBody")
   double userLambda;
   // grid mode (one launch per LM phase across the whole chip)
   int nChunks;                          // keyframe edge lists cut into chunks of <= 64 edges (one wave each)
@@ -575,7 +627,7 @@ __global__ __launch_bounds__(BA_T) void k_local_ba(const BaDev* __restrict__ pro
       se3_map(T, pb.pt + 3 * pb.eMP[e], xc);
       const float* o = pb.eObs + 3 * e;
       const bool st = !(o[2] < 0);
-      const double c = edge_error(cam, st, xc, o, (double)pb.eInfo[e], err);
+      const double c = ba_edge_error(cam, pb.rig, st, xc, o, (double)pb.eInfo[e], err);
       s += huber(st ? deltaStereo : deltaMono, c, &w);
     }
     return block_sum_d<BA_W>(s, red);
@@ -605,10 +657,10 @@ __global__ __launch_bounds__(BA_T) void k_local_ba(const BaDev* __restrict__ pro
         const float* o = pb.eObs + 3 * e;
         const bool st = !(o[2] < 0);
         const double info = (double)pb.eInfo[e];
-        const double c = edge_error(cam, st, xc, o, info, err);
+        const double c = ba_edge_error(cam, pb.rig, st, xc, o, info, err);
         huber(st ? deltaStereo : deltaMono, c, &w);
         q_to_R(T.q, R);
-        jac_point(cam, st, xc, R, Jl);
+        ba_edge_jac(cam, pb.rig, st, xc, o, R, nullptr, Jl);
         const int d = st ? 3 : 2;
         const double wo = w * info;
         for (int r = 0; r < 3; ++r) {
@@ -642,10 +694,9 @@ __global__ __launch_bounds__(BA_T) void k_local_ba(const BaDev* __restrict__ pro
         const float* o = pb.eObs + 3 * e;
         const bool st = !(o[2] < 0);
         const double info = (double)pb.eInfo[e];
-        const double c = edge_error(cam, st, xc, o, info, err);
+        const double c = ba_edge_error(cam, pb.rig, st, xc, o, info, err);
         huber(st ? deltaStereo : deltaMono, c, &w);
-        jac_pose(cam, st, false, xc, Jp);
-        jac_point(cam, st, xc, R, Jl);
+        ba_edge_jac(cam, pb.rig, st, xc, o, R, Jp, Jl);
         const int d = st ? 3 : 2;
         const double wo = w * info;
         int q = 0;
@@ -865,9 +916,9 @@ __global__ __launch_bounds__(BA_T) void k_local_ba(const BaDev* __restrict__ pro
     const bool st = !(o[2] < 0);
     double xc[3], err[3];
     se3_map(load_se3(pb.poseEval + 7 * pb.eKF[e]), pb.ptEval + 3 * pb.eMP[e], xc);
-    const double c = edge_error(cam, st, xc, o, (double)pb.eInfo[e], err);
+    const double c = ba_edge_error(cam, pb.rig, st, xc, o, (double)pb.eInfo[e], err);
     se3_map(load_se3(pb.pose + 7 * pb.eKF[e]), pb.pt + 3 * pb.eMP[e], xc);
-    pb.erase[e] = (c > (st ? 7.815 : 5.991) || !(xc[2] > 0.0)) ? 1 : 0;
+    pb.erase[e] = (c > (st ? 7.815 : 5.991) || !ba_depth_positive(pb.rig, o, xc)) ? 1 : 0;
   }
   for (int kf = tid; kf < nKF; kf += BA_T)
     if (pb.kfCol[kf] >= 0) for (int k = 0; k < 7; ++k) pb.poseIO[7 * kf + k] = (float)pb.pose[7 * kf + k];
@@ -894,7 +945,7 @@ __global__ __launch_bounds__(GB) void k_g_chi2(const BaDev* __restrict__ pbp, do
     se3_map(T, pb.pt + 3 * pb.eMP[gid], xc);
     const float* o = pb.eObs + 3 * gid;
     const bool st = !(o[2] < 0);
-    const double c = edge_error(pb.cam, st, xc, o, (double)pb.eInfo[gid], err);
+    const double c = ba_edge_error(pb.cam, pb.rig, st, xc, o, (double)pb.eInfo[gid], err);
     s = huber(st ? (double)(float)sqrt(7.815) : (double)(float)sqrt(5.991), c, &w);
   }
   s = block_sum_d<4>(s, red);
@@ -922,10 +973,10 @@ __global__ __launch_bounds__(GB) void k_g_build_mp(const BaDev* __restrict__ pbp
     const float* o = pb.eObs + 3 * e;
     const bool st = !(o[2] < 0);
     const double info = (double)pb.eInfo[e];
-    const double c = edge_error(pb.cam, st, xc, o, info, err);
+    const double c = ba_edge_error(pb.cam, pb.rig, st, xc, o, info, err);
     huber(st ? deltaStereo : deltaMono, c, &w);
     q_to_R(T.q, R);
-    jac_point(pb.cam, st, xc, R, Jl);
+    ba_edge_jac(pb.cam, pb.rig, st, xc, o, R, nullptr, Jl);
     const int d = st ? 3 : 2;
     const double wo = w * info;
     for (int r = 0; r < 3; ++r) {
@@ -962,10 +1013,9 @@ __global__ __launch_bounds__(GB) void k_g_build_kf(const BaDev* __restrict__ pbp
     const float* o = pb.eObs + 3 * e;
     const bool st = !(o[2] < 0);
     const double info = (double)pb.eInfo[e];
-    const double ch = edge_error(pb.cam, st, xc, o, info, err);
+    const double ch = ba_edge_error(pb.cam, pb.rig, st, xc, o, info, err);
     huber(st ? deltaStereo : deltaMono, ch, &w);
-    jac_pose(pb.cam, st, false, xc, Jp);
-    jac_point(pb.cam, st, xc, R, Jl);
+    ba_edge_jac(pb.cam, pb.rig, st, xc, o, R, Jp, Jl);
     const int d = st ? 3 : 2;
     const double wo = w * info;
     int q = 0;
@@ -1226,9 +1276,9 @@ __global__ __launch_bounds__(GB) void k_g_finish(const BaDev* __restrict__ pbp, 
     const bool st = !(o[2] < 0);
     double xc[3], err[3];
     se3_map(load_se3(pb.poseEval + 7 * pb.eKF[e]), pb.ptEval + 3 * pb.eMP[e], xc);
-    const double c = edge_error(pb.cam, st, xc, o, (double)pb.eInfo[e], err);
+    const double c = ba_edge_error(pb.cam, pb.rig, st, xc, o, (double)pb.eInfo[e], err);
     se3_map(load_se3(pb.pose + 7 * pb.eKF[e]), pb.pt + 3 * pb.eMP[e], xc);
-    pb.erase[e] = (c > (st ? 7.815 : 5.991) || !(xc[2] > 0.0)) ? 1 : 0;
+    pb.erase[e] = (c > (st ? 7.815 : 5.991) || !ba_depth_positive(pb.rig, o, xc)) ? 1 : 0;
   }
   if (gid < pb.nKF && pb.kfCol[gid] >= 0) for (int k = 0; k < 7; ++k) pb.poseIO[7 * gid + k] = (float)pb.pose[7 * gid + k];
   if (gid < pb.nMP * 3) pb.ptIO[gid] = (float)pb.pt[gid];
@@ -1457,6 +1507,7 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
   p->d_stop = (int*)up(nullptr, sizeof(int));
   h.stop = p->d_stop;
   h.cam = Cam{fx, fy, cx, cy, bf};
+  h.rig = nullptr;
   h.userLambda = lambdaInit100 ? 100.0 : 0.0;
   p->d_pose0 = (float*)up(kfPose, sizeof(float) * 7 * nKF);
   p->d_pt0 = (float*)up(mpPos, sizeof(float) * 3 * nMP);
@@ -1488,6 +1539,50 @@ void morb_ba_problem_destroy(morb_ba_problem* p) {
   if (p->h_scal) (void)hipHostFree(p->h_scal);
   delete p;
 }
+
+int morb_ba_problem_create_fisheye(morb_optimizer* o, morb_ba_problem** out, int nKF, const float* kfPose, const uint8_t* kfFixed,
+                                   int nMP, const float* mpPos, int nE, const int* eKF, const int* eMP, const float* eObs2,
+                                   const uint8_t* eRight, const float* eInvSigma2, const float* camL8, const float* camR8,
+                                   const float* Trl7, int lambdaInit100) {
+  MORB_REQUIRE(out && eObs2 && eRight && camL8 && camR8 && Trl7, MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(nE > 0, MORB_ERR_INVALID, "empty problem");
+  // the edge kind travels in the third observation slot: -2 = EdgeSE3ProjectXYZ with the left KB8 camera,
+  // -3 = EdgeSE3ProjectXYZToBody (right KB8 camera behind mTrl)
+  std::vector<float> obs3((size_t)nE * 3);
+  for (int e = 0; e < nE; ++e) { obs3[3 * e] = eObs2[2 * e]; obs3[3 * e + 1] = eObs2[2 * e + 1]; obs3[3 * e + 2] = eRight[e] ? -3.0f : -2.0f; }
+  int rc = morb_ba_problem_create(o, out, nKF, kfPose, kfFixed, nMP, mpPos, nE, eKF, eMP, obs3.data(), eInvSigma2, 0.f, 0.f, 0.f, 0.f,
+                                  0.f, lambdaInit100);
+  if (rc != MORB_OK) return rc;
+  morb_ba_problem* p = *out;
+  Rig rig;
+  memcpy(rig.kbL, camL8, 32);
+  memcpy(rig.kbR, camR8, 32);
+  {  // g2o::SE3Quat(Trl.unit_quaternion().cast<double>(), Trl.translation().cast<double>()) incl. normalisation
+    double q[4] = {Trl7[0], Trl7[1], Trl7[2], Trl7[3]};
+    if (q[3] < 0) for (double& c : q) c = -c;
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; ++i) rig.Trl.q[i] = q[i] / n;
+    for (int i = 0; i < 3; ++i) rig.Trl.t[i] = Trl7[4 + i];
+  }
+  void* d_rig = nullptr;
+  if (hipMalloc(&d_rig, sizeof(Rig)) != hipSuccess || hipMemcpy(d_rig, &rig, sizeof(Rig), hipMemcpyHostToDevice) != hipSuccess) {
+    if (d_rig) (void)hipFree(d_rig);
+    morb_ba_problem_destroy(p);
+    *out = nullptr;
+    set_error("cannot upload the fisheye rig");
+    return MORB_ERR_HIP;
+  }
+  p->allocs.push_back(d_rig);
+  p->h.rig = (const Rig*)d_rig;
+  if (hipMemcpy(p->d_desc, &p->h, sizeof(BaDev), hipMemcpyHostToDevice) != hipSuccess) {
+    morb_ba_problem_destroy(p);
+    *out = nullptr;
+    set_error("cannot upload the problem descriptor");
+    return MORB_ERR_HIP;
+  }
+  return MORB_OK;
+}
+
 
 int morb_ba_set_mode(morb_ba_problem* p, int mode) {
   MORB_REQUIRE(p && (mode == 0 || mode == 1), MORB_ERR_INVALID, "mode must be 0 (grid) or 1 (persistent workgroup)");
@@ -1611,6 +1706,21 @@ int morb_local_bundle_adjustment(morb_optimizer* o, int nKF, float* kfPose, cons
   morb_ba_problem* p = nullptr;
   int rc = morb_ba_problem_create(o, &p, nKF, kfPose, kfFixed, nMP, mpPos, nE, eKF, eMP, eObs, eInvSigma2, fx, fy, cx, cy, bf,
                                   lambdaInit100);
+  if (rc != MORB_OK) return rc;
+  rc = morb_ba_solve(p, nullptr);
+  if (rc == MORB_OK) rc = morb_ba_results(p, kfPose, mpPos, eraseFlag, stats2);
+  morb_ba_problem_destroy(p);
+  return rc;
+}
+
+int morb_local_bundle_adjustment_fisheye(morb_optimizer* o, int nKF, float* kfPose, const uint8_t* kfFixed, int nMP, float* mpPos,
+                                         int nE, const int* eKF, const int* eMP, const float* eObs2, const uint8_t* eRight,
+                                         const float* eInvSigma2, const float* camL8, const float* camR8, const float* Trl7,
+                                         int lambdaInit100, const int* stopFlag, uint8_t* eraseFlag, int* stats2) {
+  if (stopFlag && *stopFlag) { if (stats2) stats2[0] = stats2[1] = 0; return MORB_OK; }  // :1355-1356
+  morb_ba_problem* p = nullptr;
+  int rc = morb_ba_problem_create_fisheye(o, &p, nKF, kfPose, kfFixed, nMP, mpPos, nE, eKF, eMP, eObs2, eRight, eInvSigma2, camL8,
+                                          camR8, Trl7, lambdaInit100);
   if (rc != MORB_OK) return rc;
   rc = morb_ba_solve(p, nullptr);
   if (rc == MORB_OK) rc = morb_ba_results(p, kfPose, mpPos, eraseFlag, stats2);

@@ -53,9 +53,10 @@ class Optimizer:
                                                            ptr(out[2]), st))
         return out
 
-    def LocalBundleAdjustment(self, kfPose, kfFixed, mpPos, eKF, eMP, eObs, eInvSigma2, cam, inertial=False, stop=False, mode=0):
+    def LocalBundleAdjustment(self, kfPose, kfFixed, mpPos, eKF, eMP, eObs, eInvSigma2, cam, inertial=False, stop=False, mode=0,
+                              rig=None):
         """One-shot LocalBundleAdjustment on host numpy arrays; returns (kfPose, mpPos, eraseFlag, stats)."""
-        p = BAProblem(self, kfPose, kfFixed, mpPos, eKF, eMP, eObs, eInvSigma2, cam, inertial)
+        p = BAProblem(self, kfPose, kfFixed, mpPos, eKF, eMP, eObs, eInvSigma2, cam, inertial, rig=rig)
         p.set_mode(mode)
         if stop:
             p.set_stop(True)
@@ -64,9 +65,11 @@ class Optimizer:
 
 
 class BAProblem:
-    """A LocalBundleAdjustment graph resident in HBM (create once, solve repeatedly)."""
+    """A LocalBundleAdjustment graph resident in HBM (create once, solve repeatedly).
+    rig = dict(eRight uint8 [nE], camL, camR (8 floats each), Trl (7 floats)) selects the KannalaBrandt8 stereo rig
+    (eObs is then [nE, 2]; cam is ignored)."""
 
-    def __init__(self, opt, kfPose, kfFixed, mpPos, eKF, eMP, eObs, eInvSigma2, cam, inertial=False):
+    def __init__(self, opt, kfPose, kfFixed, mpPos, eKF, eMP, eObs, eInvSigma2, cam, inertial=False, rig=None):
         self._L = lib()
         self._opt = opt
         self._h = C.c_void_p()
@@ -75,6 +78,14 @@ class BAProblem:
              np.ascontiguousarray(eObs, np.float32), np.ascontiguousarray(eInvSigma2, np.float32)]
         self.nKF, self.nMP, self.nE = len(a[0]), len(a[2]), len(a[3])
         self._init = (a[0], a[2])
+        if rig is not None:
+            r = [np.ascontiguousarray(rig["eRight"], np.uint8), np.ascontiguousarray(rig["camL"], np.float32),
+                 np.ascontiguousarray(rig["camR"], np.float32), np.ascontiguousarray(rig["Trl"], np.float32)]
+            assert a[5].shape == (self.nE, 2)
+            check(self._L.morb_ba_problem_create_fisheye(opt._h, C.byref(self._h), self.nKF, ptr(a[0]), ptr(a[1]), self.nMP, ptr(a[2]),
+                                                         self.nE, ptr(a[3]), ptr(a[4]), ptr(a[5]), ptr(r[0]), ptr(a[6]), ptr(r[1]),
+                                                         ptr(r[2]), ptr(r[3]), 1 if inertial else 0))
+            return
         check(self._L.morb_ba_problem_create(opt._h, C.byref(self._h), self.nKF, ptr(a[0]), ptr(a[1]), self.nMP, ptr(a[2]),
                                              self.nE, ptr(a[3]), ptr(a[4]), ptr(a[5]), ptr(a[6]), cam["fx"], cam["fy"],
                                              cam["cx"], cam["cy"], cam["bf"], 1 if inertial else 0))

@@ -280,3 +280,49 @@ def make_pose_problem_fisheye(n_left=400, n_right=300, seed=0, outlier_frac=0.1,
     return dict(hasMP=(rng.random(n) < 0.92).astype(np.uint8), obs=obs, invSigma2=(1 / sigma ** 2).astype(np.float32),
                 Xw=Xw.astype(np.float32), pose0=init.astype(np.float32), true=true, Nleft=n_left, camL=TUMVI_CAM_L, camR=TUMVI_CAM_R,
                 Trl=Trl7)
+
+
+def make_ba_problem_fisheye(n_free=10, n_fixed=4, n_points=1500, seed=0, outlier_frac=0.05, right_frac=0.45):
+    """LocalBundleAdjustment input on the TUM-VI KannalaBrandt8 rig: left-camera observations (EdgeSE3ProjectXYZ) and
+    right-camera observations behind Trl (EdgeSE3ProjectXYZToBody)."""
+    rng = np.random.default_rng(0xFBA0 + seed)
+    Trl_m = np.linalg.inv(TUMVI_T_C1_C2)
+    nkf = n_free + n_fixed
+    poses = []
+    for i in range(nkf):
+        ang = (i / max(nkf - 1, 1) - 0.5) * 0.5
+        c = np.array([2.0 * np.sin(ang) * 2, rng.normal(0, 0.05), -2.0 * (1 - np.cos(ang))])
+        q_wc = _quat_from_rotvec(np.array([0, -ang * 0.8, 0]) + rng.normal(0, 0.01, 3))
+        q_cw = q_wc * np.array([-1, -1, -1, 1])
+        poses.append(np.concatenate([q_cw, -_quat_rot(q_cw, c)]))
+    poses = np.array(poses)
+    X = np.stack([rng.uniform(-3, 3, n_points), rng.uniform(-2, 2, n_points), rng.uniform(2, 8, n_points)], 1)
+    eKF, eMP, eObs, eInv, eRight = [], [], [], [], []
+    for j in range(n_points):
+        kfs = rng.choice(nkf, size=min(int(rng.integers(4, 9)), nkf), replace=False)
+        for kf in kfs:
+            Xc = _quat_rot(poses[kf][:4], X[j]) + poses[kf][4:]
+            for right in (0, 1):
+                if right and rng.random() > right_frac:
+                    continue
+                Xs = Trl_m[:3, :3] @ Xc + Trl_m[:3, 3] if right else Xc
+                if Xs[2] <= 0.4:
+                    continue
+                uv = kb8_project(TUMVI_CAM_R if right else TUMVI_CAM_L, Xs[None])[0]
+                if not (5 < uv[0] < 507 and 5 < uv[1] < 507):
+                    continue
+                octv = int(rng.integers(0, 8)); sg = 1.2 ** octv
+                o = uv + rng.normal(0, 0.7, 2) * sg
+                if rng.random() < outlier_frac:
+                    o += rng.choice([-1, 1], 2) * rng.uniform(15, 30, 2)
+                eKF.append(kf); eMP.append(j); eObs.append(o); eInv.append(1.0 / sg ** 2); eRight.append(right)
+    fixed = np.zeros(nkf, np.uint8); fixed[n_free:] = 1
+    pose0 = poses.copy()
+    for i in range(n_free):
+        dq = _quat_from_rotvec(rng.normal(0, 1, 3) / np.sqrt(3) * np.deg2rad(1.5))
+        pose0[i] = np.concatenate([_quat_mul(dq, poses[i][:4]), _quat_rot(dq, poses[i][4:]) + rng.normal(0, 0.03, 3)])
+    X0 = X + rng.normal(0, 0.04, X.shape)
+    Trl7 = np.concatenate([_quat_from_R(Trl_m[:3, :3]), Trl_m[:3, 3]]).astype(np.float32)
+    return dict(kfPose=pose0.astype(np.float32), kfFixed=fixed, mpPos=X0.astype(np.float32), eKF=np.array(eKF, np.int32),
+                eMP=np.array(eMP, np.int32), eObs=np.array(eObs, np.float32), eInvSigma2=np.array(eInv, np.float32),
+                eRight=np.array(eRight, np.uint8), camL=TUMVI_CAM_L, camR=TUMVI_CAM_R, Trl=Trl7, true_poses=poses, true_points=X)

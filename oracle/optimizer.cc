@@ -678,4 +678,50 @@ int orc_local_ba(int nKF, float* kfPose, const uint8_t* kfFixed, int nMP, float*
   for (int i = 0; i < nMP; ++i) for (int k = 0; k < 3; ++k) mpPos[3 * i + k] = (float)g.points[3 * i + k];
   return its;
 }
+
+// LocalBundleAdjustment on a KannalaBrandt8 rig (pKFi->mpCamera2, Optimizer.cc:1244-1351): every observation is an
+// EdgeSE3ProjectXYZ with the left camera (eRight == 0) or an EdgeSE3ProjectXYZToBody with the right camera (eRight != 0).
+int orc_local_ba_fisheye(int nKF, float* kfPose, const uint8_t* kfFixed, int nMP, float* mpPos, int nE, const int* eKF,
+                         const int* eMP, const float* eObs2, const uint8_t* eRight, const float* eInvSigma2, const float* camL8,
+                         const float* camR8, const float* Trl7, int lambdaInit100, const int* stopFlag, uint8_t* eraseFlag,
+                         int* stats) {
+  Graph g;
+  g.cam = Camera{0, 0, 0, 0, 0};
+  memcpy(g.kbL.p, camL8, 32); memcpy(g.kbR.p, camR8, 32);
+  g.Trl = fromFloatPose(Trl7);
+  for (int i = 0; i < nKF; ++i) { g.poses.push_back(fromFloatPose(kfPose + 7 * i)); g.poseFixed.push_back(kfFixed[i] ? 1 : 0); }
+  for (int i = 0; i < nMP; ++i) { for (int k = 0; k < 3; ++k) g.points.push_back((double)mpPos[3 * i + k]); g.pointFixed.push_back(0); }
+  const float thHuberMono = (float)std::sqrt(5.991);
+  for (int k = 0; k < nE; ++k) {
+    Edge e;
+    memset(&e, 0, sizeof e);
+    e.kind = eRight[k] ? KIND_KB8_RIGHT : KIND_KB8_LEFT;
+    e.pose = eKF[k]; e.point = eMP[k];
+    e.obs[0] = (double)eObs2[2 * k]; e.obs[1] = (double)eObs2[2 * k + 1];
+    e.info = (double)eInvSigma2[k];
+    e.delta = (double)thHuberMono;
+    g.edges.push_back(e);
+  }
+  if (lambdaInit100) g.userLambdaInit = 100.0;
+  g.forceStop = stopFlag;
+  if (stats) stats[0] = stats[1] = 0;
+  if (stopFlag && *stopFlag) return 0;
+  g.initializeOptimization(0);
+  const int its = g.optimize(10);
+  if (stats) { stats[0] = its; stats[1] = g.levenbergIterations; }
+  for (int k = 0; k < nE; ++k) {
+    const Edge& e = g.edges[k];
+    double xc[3];
+    if (e.kind == KIND_KB8_RIGHT) mapPoint(mul(g.Trl, g.poses[e.pose]), &g.points[3 * e.point], xc);   // OptimizableTypes.h:152-158
+    else mapPoint(g.poses[e.pose], &g.points[3 * e.point], xc);
+    eraseFlag[k] = (g.chi2(e) > 5.991 || !(xc[2] > 0.0)) ? 1 : 0;   // :1366-1390
+  }
+  for (int i = 0; i < nKF; ++i) {
+    if (kfFixed[i]) continue;
+    for (int k = 0; k < 4; ++k) kfPose[7 * i + k] = (float)g.poses[i].q[k];
+    for (int k = 0; k < 3; ++k) kfPose[7 * i + 4 + k] = (float)g.poses[i].t[k];
+  }
+  for (int i = 0; i < nMP; ++i) for (int k = 0; k < 3; ++k) mpPos[3 * i + k] = (float)g.points[3 * i + k];
+  return its;
+}
 }

@@ -110,6 +110,10 @@ int orc_stereo_fisheye_matches(int Nleft, int monoLeft, const orc_keypoint* kpsL
 int orc_pose_optimization_fisheye(int n, int Nleft, const uint8_t* hasMP, const float* obs, const float* invSigma2,
                                   const float* Xw, const float* camL8, const float* camR8, const float* Trl7, float* pose,
                                   uint8_t* outlier, int* stats);
+int orc_local_ba_fisheye(int nKF, float* kfPose, const uint8_t* kfFixed, int nMP, float* mpPos, int nE, const int* eKF,
+                         const int* eMP, const float* eObs2, const uint8_t* eRight, const float* eInvSigma2, const float* camL8,
+                         const float* camR8, const float* Trl7, int lambdaInit100, const int* stopFlag, uint8_t* eraseFlag,
+                         int* stats);
 float orc_fast_atan2(float y, float x);
 float orc_cosf(float x);
 float orc_sinf(float x);

@@ -205,6 +205,19 @@ def local_ba(p, lambda100=False, stop=None):
     return its, kf, mp, erase, stats
 
 
+def local_ba_fisheye(p, lambda100=False):
+    L = lib()
+    L.orc_local_ba_fisheye.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + \
+        [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    kf = p["kfPose"].astype(np.float32).copy(); mp = p["mpPos"].astype(np.float32).copy()
+    nE = len(p["eKF"])
+    erase = np.zeros(nE, np.uint8); stats = np.zeros(2, np.int32)
+    a = [np.ascontiguousarray(p[k]) for k in ("kfFixed", "eKF", "eMP", "eObs", "eRight", "eInvSigma2", "camL", "camR", "Trl")]
+    its = L.orc_local_ba_fisheye(len(kf), _p(kf), _p(a[0]), len(mp), _p(mp), nE, _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), _p(a[5]),
+                                 _p(a[6]), _p(a[7]), _p(a[8]), 1 if lambda100 else 0, None, _p(erase), _p(stats))
+    return its, kf, mp, erase, stats
+
+
 class OrcFrame(C.Structure):
     _fields_ = [("N", C.c_int), ("kpsUn", C.c_void_p), ("desc", C.c_void_p), ("uRight", C.c_void_p),
                 ("minX", C.c_float), ("minY", C.c_float), ("maxX", C.c_float), ("maxY", C.c_float), ("gridInvW", C.c_float),
