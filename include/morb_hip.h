@@ -296,6 +296,19 @@ int morb_search_for_triangulation_batch(morb_matcher*, const morb_frame_params*,
                                         const float* R12, const float* t12, const float* ep, int bOnlyStereo, int bCoarse,
                                         int checkOri, int* d_match12, int* d_nmatches, void* stream);
 
+/* SearchForTriangulation between two keyframes of a KannalaBrandt8 rig (pKF->mpCamera2 != NULL, ORBmatcher.cc:845-852,
+ * :884, :925, :934-975): each image holds its left features (d_nLeft1[p] / d_nLeft2[p] of them) followed by the right
+ * ones; T4 = [npairs][4][12] host floats: Tll, Tlr, Trl, Trr (T1w * Tw2, T1w * Twr2, Tr1w * Tw2, Tr1w * Twr2), each
+ * as rotation matrix (row-major) then translation.  bStereo is false on such rigs (bOnlyStereo rejects everything),
+ * there is no epipole-distance gate, and the constraint is KannalaBrandt8::epipolarConstrain (TriangulateMatches >
+ * 1e-4) with the cameras / relative pose of the two features' sides.  P->levelSigma2 = mvLevelSigma2. */
+int morb_search_for_triangulation_fisheye_batch(morb_matcher* m, const morb_frame_params* P, int npairs, const int* d_img1,
+                                                const int* d_img2, const int* d_nLeft1, const int* d_nLeft2, int nimg, int cap,
+                                                const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc,
+                                                const int* d_node, const uint8_t* d_hasMP, const float* camL8, const float* camR8,
+                                                const float* T4, int bOnlyStereo, int bCoarse, int checkOri, int* d_match12,
+                                                int* d_nmatches, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Optimizer  (include/Optimizer.h:46-139, src/Optimizer.cc; g2o Levenberg-Marquardt semantics)
  * Poses cross the boundary the way the reference hands them to g2o: unit quaternion (x, y, z, w) followed by

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.h"
+#include "kb8.h"
 
 using namespace morb;
 
@@ -620,7 +621,10 @@ __global__ __launch_bounds__(256) void k_triangulation(const unsigned long long*
                                                        const uint8_t* __restrict__ hasMP, const float* __restrict__ uRight,
                                                        morb_frame_params P, const float* __restrict__ F12v,
                                                        const float* __restrict__ epv, int bOnlyStereo, int bCoarse,
-                                                       int* __restrict__ match12, int* __restrict__ bin12) {
+                                                       int* __restrict__ match12, int* __restrict__ bin12,
+                                                       // KannalaBrandt8 rig (NULL = pinhole): [camL8 | camR8 | per pair Tll Tlr Trl Trr as R, t]
+                                                       const float* __restrict__ rig, const int* __restrict__ nLeft1v,
+                                                       const int* __restrict__ nLeft2v) {
   const int pair = blockIdx.y, lane = threadIdx.x & 63;
   const int idx1 = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int i1 = img1v[pair], i2 = img2v[pair];
@@ -628,7 +632,8 @@ __global__ __launch_bounds__(256) void k_triangulation(const unsigned long long*
   int result = -1, bin = -1;
   const size_t o1 = (size_t)i1 * cap + idx1;
   const int nd = idx1 < count[i1] ? node[o1] : -1;
-  const bool bStereo1 = uRight && uRight[o1] >= 0;
+  const bool fish = rig != nullptr;
+  const bool bStereo1 = !fish && uRight && uRight[o1] >= 0;   // (!pKF1->mpCamera2 && mvuRight >= 0), :884
   if (nd >= 0 && !hasMP[o1] && !(bOnlyStereo && !bStereo1)) {
     const unsigned long long* s2 = sorted + (size_t)i2 * cap;
     const int n2 = count[i2];
@@ -652,17 +657,29 @@ __global__ __launch_bounds__(256) void k_triangulation(const unsigned long long*
         if ((unsigned)(k2 >> 32) == (unsigned)nd) {
           const int idx2 = (int)(k2 & 0xFFFFFFFFu);
           const size_t o2 = (size_t)i2 * cap + idx2;
-          const bool bStereo2 = uRight && uRight[o2] >= 0;
+          const bool bStereo2 = !fish && uRight && uRight[o2] >= 0;
           if (!hasMP[o2] && !(bOnlyStereo && !bStereo2)) {
             const int dist = hamming(d1, load_desc(desc + o2 * 32));
             if (dist <= TH_LOW) {
               const morb_keypoint kp2 = kps[o2];
               bool ok = true;
-              if (!bStereo1 && !bStereo2) {
+              if (fish) {
+                // camera pair and relative pose follow the sides of the two features (:934-966); the constraint is
+                // KannalaBrandt8::epipolarConstrain = TriangulateMatches(...) > 0.0001 (KannalaBrandt8.cpp:307-321)
+                if (!bCoarse) {
+                  const bool bRight1 = !(idx1 < nLeft1v[pair]), bRight2 = !(idx2 < nLeft2v[pair]);
+                  const float* T = rig + 16 + (size_t)pair * 48 + 12 * ((bRight1 ? 2 : 0) + (bRight2 ? 1 : 0));
+                  morbkb8::KB8 c1, c2;
+                  for (int q = 0; q < 8; ++q) { c1.p[q] = rig[(bRight1 ? 8 : 0) + q]; c2.p[q] = rig[(bRight2 ? 8 : 0) + q]; }
+                  float p3D[3];
+                  ok = morbkb8::triangulate_matches(c1, c2, T, T + 9, kp1.x, kp1.y, kp2.x, kp2.y, P.levelSigma2[kp1.octave],
+                                                    P.levelSigma2[kp2.octave], p3D) > 0.0001f;
+                }
+              } else if (!bStereo1 && !bStereo2) {
                 const float distex = epv[2 * pair] - kp2.x, distey = epv[2 * pair + 1] - kp2.y;
                 if (distex * distex + distey * distey < 100 * P.scaleFactors[kp2.octave]) ok = false;
               }
-              if (ok && !bCoarse) {  // Pinhole::epipolarConstrain (Pinhole.cpp:111-139)
+              if (ok && !bCoarse && !fish) {  // Pinhole::epipolarConstrain (Pinhole.cpp:111-139)
                 const float num = a * kp2.x + b * kp2.y + c;
                 if (den == 0) ok = false;
                 else { const float dsqr = num * num / den; ok = (double)dsqr < 3.84 * (double)P.levelSigma2[kp2.octave]; }
@@ -1040,7 +1057,38 @@ extern "C" int morb_search_for_triangulation_batch(morb_matcher* m, const morb_f
   MORB_HIP_CHECK(hipStreamSynchronize(st));  // hf is a local
   hipLaunchKernelGGL(k_triangulation, dim3(div_up(cap, 4), npairs), dim3(256), 0, st, sorted, cap, d_count, d_img1, d_img2, d_kps,
                      d_desc, d_node, d_hasMP, d_uRight, *P, (const float*)dF, (const float*)dF + (size_t)npairs * 9, bOnlyStereo,
-                     bCoarse, d_match12, (int*)dBin);
+                     bCoarse, d_match12, (int*)dBin, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL(k_rot_filter12, dim3(npairs), dim3(256), 0, st, d_count, d_img1, cap, checkOri, d_match12, (const int*)dBin, d_nmatches);
+  MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}
+
+extern "C" int morb_search_for_triangulation_fisheye_batch(morb_matcher* m, const morb_frame_params* P, int npairs, const int* d_img1,
+                                                           const int* d_img2, const int* d_nLeft1, const int* d_nLeft2, int nimg,
+                                                           int cap, const int* d_count, const morb_keypoint* d_kps,
+                                                           const uint8_t* d_desc, const int* d_node, const uint8_t* d_hasMP,
+                                                           const float* camL8, const float* camR8, const float* T4, int bOnlyStereo,
+                                                           int bCoarse, int checkOri, int* d_match12, int* d_nmatches, void* stream) {
+  MORB_REQUIRE(m && P && d_img1 && d_img2 && d_nLeft1 && d_nLeft2 && d_count && d_kps && d_desc && d_node && d_hasMP && camL8 && camR8 &&
+                   T4 && d_match12 && d_nmatches, MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(npairs > 0 && nimg > 0 && cap > 0, MORB_ERR_INVALID, "bad sizes");
+  MORB_HIP_CHECK(hipSetDevice(morb_matcher_device(m)));
+  hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
+  unsigned long long* sorted = nullptr;
+  int rc = morb_bow_sort_images(m, nimg, d_node, d_count, cap, &sorted, st);
+  if (rc != MORB_OK) return rc;
+  std::vector<float> hf(16 + (size_t)npairs * 48);
+  for (int i = 0; i < 8; ++i) { hf[i] = camL8[i]; hf[8 + i] = camR8[i]; }
+  for (size_t i = 0; i < (size_t)npairs * 48; ++i) hf[16 + i] = T4[i];
+  void *dF = nullptr, *dBin = nullptr;
+  rc = morb_matcher_workspace(m, 4, sizeof(float) * hf.size(), &dF);
+  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 2, sizeof(int) * (size_t)npairs * cap, &dBin);
+  if (rc != MORB_OK) return rc;
+  MORB_HIP_CHECK(hipMemcpyAsync(dF, hf.data(), sizeof(float) * hf.size(), hipMemcpyHostToDevice, st));
+  MORB_HIP_CHECK(hipStreamSynchronize(st));  // hf is a local
+  hipLaunchKernelGGL(k_triangulation, dim3(div_up(cap, 4), npairs), dim3(256), 0, st, sorted, cap, d_count, d_img1, d_img2, d_kps,
+                     d_desc, d_node, d_hasMP, (const float*)nullptr, *P, (const float*)dF, (const float*)dF, bOnlyStereo, bCoarse,
+                     d_match12, (int*)dBin, (const float*)dF, d_nLeft1, d_nLeft2);
   hipLaunchKernelGGL(k_rot_filter12, dim3(npairs), dim3(256), 0, st, d_count, d_img1, cap, checkOri, d_match12, (const int*)dBin, d_nmatches);
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;

@@ -188,6 +188,21 @@ class ORBmatcher:
             ptr(bForward), ptr(bBackward), 1 if self.mbCheckOrientation else 0, ptr(matchCur), ptr(nm), self._st(stream)))
         return matchCur, nm
 
+    def SearchForTriangulationFisheye(self, params, img1, img2, nLeft1, nLeft2, kps, desc, node, count, hasMP, camL8, camR8, T4,
+                                      bOnlyStereo=False, bCoarse=False, stream=None):
+        """SearchForTriangulation between keyframes of a KB8 rig; T4 = host [npairs, 4, 12] (Tll, Tlr, Trl, Trr as R | t)."""
+        import torch
+        npairs = img1.shape[0]
+        nimg, cap = kps.shape[0], kps.shape[1]
+        m12 = torch.full((npairs, cap), -1, dtype=torch.int32, device=kps.device)
+        nm = torch.zeros((npairs,), dtype=torch.int32, device=kps.device)
+        a = [np.ascontiguousarray(x, np.float32) for x in (camL8, camR8, T4)]
+        check(self._L.morb_search_for_triangulation_fisheye_batch(
+            self._h, C.byref(params), npairs, ptr(img1), ptr(img2), ptr(nLeft1), ptr(nLeft2), nimg, cap, ptr(count), ptr(kps), ptr(desc),
+            ptr(node), ptr(hasMP), ptr(a[0]), ptr(a[1]), ptr(a[2]), 1 if bOnlyStereo else 0, 1 if bCoarse else 0,
+            1 if self.mbCheckOrientation else 0, ptr(m12), ptr(nm), self._st(stream)))
+        return m12, nm
+
     def SearchForTriangulation(self, params, img1, img2, kps, desc, node, count, hasMP, uRight, R12, t12, ep,
                                bOnlyStereo=False, bCoarse=False, stream=None):
         """SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse); R12/t12/ep are host numpy arrays."""

@@ -178,6 +178,11 @@ static float TriangulateMatches(const Cam& c1, const Cam& c2, float x1, float y1
 using namespace orc;
 extern "C" {
 
+float orc_kb8_triangulate_matches(const float* cam1_8, const float* cam2_8, float x1, float y1, float x2, float y2, const float* R12,
+                                  const float* t12, float sigmaLevel, float unc, float* p3D) {
+  kb8::Cam a, b; memcpy(a.p, cam1_8, 32); memcpy(b.p, cam2_8, 32);
+  return kb8::TriangulateMatches(a, b, x1, y1, x2, y2, R12, t12, sigmaLevel, unc, p3D);
+}
 void orc_kb8_project_f(const float* cam8, const float* v3, float* uv) { kb8::Cam c; memcpy(c.p, cam8, 32); kb8::projectF(c, v3, uv); }
 void orc_kb8_project_d(const float* cam8, const double* v3, double* uv) { kb8::Cam c; memcpy(c.p, cam8, 32); kb8::projectD(c, v3, uv); }
 void orc_kb8_unproject(const float* cam8, float x, float y, float* ray) { kb8::Cam c; memcpy(c.p, cam8, 32); kb8::unproject(c, x, y, ray); }

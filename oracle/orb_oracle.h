@@ -99,6 +99,13 @@ int orc_search_for_triangulation(int n1, const orc_keypoint* kps1, const uint8_t
                                  const orc_keypoint* kps2, const uint8_t* desc2, const int* node2, const uint8_t* hasMP2,
                                  const float* uRight2, const float* sigma2_2, const float* scaleFactors2, const float* F12,
                                  const float* ep, int bOnlyStereo, int bCoarse, int checkOri, int* matches12);
+int orc_search_for_triangulation_fisheye(int n1, int NLeft1, const orc_keypoint* kps1, const uint8_t* desc1, const int* node1,
+                                         const uint8_t* hasMP1, int n2, int NLeft2, const orc_keypoint* kps2, const uint8_t* desc2,
+                                         const int* node2, const uint8_t* hasMP2, const float* levelSigma2, const float* camL8,
+                                         const float* camR8, const float* T4, int bOnlyStereo, int bCoarse, int checkOri,
+                                         int* matches12);
+float orc_kb8_triangulate_matches(const float* cam1_8, const float* cam2_8, float x1, float y1, float x2, float y2, const float* R12,
+                                  const float* t12, float sigmaLevel, float unc, float* p3D);
 void orc_kb8_project_f(const float* cam8, const float* v3, float* uv);
 void orc_kb8_project_d(const float* cam8, const double* v3, double* uv);
 void orc_kb8_unproject(const float* cam8, float x, float y, float* ray);

@@ -697,6 +697,87 @@ int SearchForTriangulation(int n1, const KeyPoint* kps1, const uint8_t* desc1, c
   return nmatches;
 }
 
+// ---- SearchForTriangulation between two keyframes of a KannalaBrandt8 rig (pKF->mpCamera2 != NULL, :821-1042) --------
+// Features of each keyframe: left camera's first (NLeft), then the right camera's.  T4 = Tll, Tlr, Trl, Trr (:845-852),
+// each as R (row-major 3x3) then t.  bStereo1 / bStereo2 are false on such rigs (so bOnlyStereo rejects everything),
+// the epipole-distance gate is skipped (:925), the camera pair and (R12, t12) follow the sides of the two features
+// (:934-966) and the constraint is KannalaBrandt8::epipolarConstrain = TriangulateMatches(...) > 0.0001 (:307-321).
+extern "C" float orc_kb8_triangulate_matches(const float* cam1_8, const float* cam2_8, float x1, float y1, float x2, float y2,
+                                             const float* R12, const float* t12, float sigmaLevel, float unc, float* p3D);
+int SearchForTriangulationFisheye(int n1, int NLeft1, const KeyPoint* kps1, const uint8_t* desc1, const int* node1,
+                                  const uint8_t* hasMP1, int n2, int NLeft2, const KeyPoint* kps2, const uint8_t* desc2,
+                                  const int* node2, const uint8_t* hasMP2, const float* levelSigma2, const float* camL8,
+                                  const float* camR8, const float* T4, bool bOnlyStereo, bool bCoarse, bool mbCheckOrientation,
+                                  int* vMatches12) {
+  std::map<int, std::vector<unsigned>> vFeatVec1, vFeatVec2;
+  for (int i = 0; i < n1; ++i) if (node1[i] >= 0) vFeatVec1[node1[i]].push_back(i);
+  for (int i = 0; i < n2; ++i) if (node2[i] >= 0) vFeatVec2[node2[i]].push_back(i);
+  int nmatches = 0;
+  for (int i = 0; i < n1; ++i) vMatches12[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  auto f1it = vFeatVec1.begin(), f1end = vFeatVec1.end();
+  auto f2it = vFeatVec2.begin(), f2end = vFeatVec2.end();
+  while (f1it != f1end && f2it != f2end) {
+    if (f1it->first == f2it->first) {
+      for (size_t i1 = 0, iend1 = f1it->second.size(); i1 < iend1; i1++) {
+        const size_t idx1 = f1it->second[i1];
+        if (hasMP1[idx1]) continue;
+        if (bOnlyStereo) continue;                 // bStereo1 == false
+        const KeyPoint& kp1 = kps1[idx1];
+        const bool bRight1 = !((int)idx1 < NLeft1);
+        const uint8_t* d1 = desc1 + idx1 * 32;
+        int bestDist = TH_LOW, bestIdx2 = -1;
+        for (size_t i2 = 0, iend2 = f2it->second.size(); i2 < iend2; i2++) {
+          const size_t idx2 = f2it->second[i2];
+          if (hasMP2[idx2]) continue;
+          const int dist = DescriptorDistance(d1, desc2 + idx2 * 32);
+          if (dist > TH_LOW || dist > bestDist) continue;
+          const KeyPoint& kp2 = kps2[idx2];
+          const bool bRight2 = !((int)idx2 < NLeft2);
+          const float* T = T4 + 12 * ((bRight1 ? 2 : 0) + (bRight2 ? 1 : 0));   // ll, lr, rl, rr
+          float p3D[3];
+          if (bCoarse || orc_kb8_triangulate_matches(bRight1 ? camR8 : camL8, bRight2 ? camR8 : camL8, kp1.x, kp1.y, kp2.x, kp2.y, T,
+                                                     T + 9, levelSigma2[kp1.octave], levelSigma2[kp2.octave], p3D) > 0.0001f) {
+            bestIdx2 = (int)idx2;
+            bestDist = dist;
+          }
+        }
+        if (bestIdx2 >= 0) {
+          const KeyPoint& kp2 = kps2[bestIdx2];
+          vMatches12[idx1] = bestIdx2;
+          nmatches++;
+          if (mbCheckOrientation) {
+            float rot = kp1.angle - kp2.angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)std::round(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            rotHist[bin].push_back((int)idx1);
+          }
+        }
+      }
+      f1it++;
+      f2it++;
+    } else if (f1it->first < f2it->first) {
+      f1it = vFeatVec1.lower_bound(f2it->first);
+    } else {
+      f2it = vFeatVec2.lower_bound(f1it->first);
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+        vMatches12[rotHist[i][j]] = -1;
+        nmatches--;
+      }
+    }
+  }
+  return nmatches;
+}
+
 }  // namespace orc
 
 using namespace orc;
@@ -758,6 +839,15 @@ int orc_search_by_projection_kf(const orc_frame* Cur, const uint8_t* curHasMP, c
 int orc_search_for_initialization(int n1, const orc_keypoint* kps1, const uint8_t* desc1, const orc_frame* F2, float* prevMatched,
                                   int windowSize, float nnratio, int checkOri, int* matches12) {
   return SearchForInitialization(n1, (const KeyPoint*)kps1, desc1, *F2, prevMatched, windowSize, nnratio, checkOri != 0, matches12);
+}
+int orc_search_for_triangulation_fisheye(int n1, int NLeft1, const orc_keypoint* kps1, const uint8_t* desc1, const int* node1,
+                                         const uint8_t* hasMP1, int n2, int NLeft2, const orc_keypoint* kps2, const uint8_t* desc2,
+                                         const int* node2, const uint8_t* hasMP2, const float* levelSigma2, const float* camL8,
+                                         const float* camR8, const float* T4, int bOnlyStereo, int bCoarse, int checkOri,
+                                         int* matches12) {
+  return SearchForTriangulationFisheye(n1, NLeft1, (const KeyPoint*)kps1, desc1, node1, hasMP1, n2, NLeft2, (const KeyPoint*)kps2,
+                                       desc2, node2, hasMP2, levelSigma2, camL8, camR8, T4, bOnlyStereo != 0, bCoarse != 0,
+                                       checkOri != 0, matches12);
 }
 void orc_fundamental_f12(const float* K1, const float* K2, const float* R12, const float* t12, float* F12) {
   FundamentalF12(K1, K2, R12, t12, F12);

@@ -310,6 +310,20 @@ def search_by_projection_last_fisheye(Cur, NleftCur, cam8, Trl7, blocked, Tcw7, 
     return r, m
 
 
+def search_for_triangulation_fisheye(k1, nl1, d1, node1, has1, k2, nl2, d2, node2, has2, sigma2, camL8, camR8, T4, onlyStereo, coarse, checkOri):
+    L = lib()
+    L.orc_search_for_triangulation_fisheye.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 8 + \
+        [C.c_int] * 3 + [C.c_void_p]
+    m = np.full(len(k1), -1, np.int32)
+    a = [np.ascontiguousarray(x) for x in (k1, d1, node1.astype(np.int32), has1.astype(np.uint8), k2, d2, node2.astype(np.int32),
+                                           has2.astype(np.uint8), np.asarray(sigma2, np.float32), np.asarray(camL8, np.float32),
+                                           np.asarray(camR8, np.float32), np.asarray(T4, np.float32))]
+    n = L.orc_search_for_triangulation_fisheye(len(k1), int(nl1), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), len(k2), int(nl2), _p(a[4]),
+                                               _p(a[5]), _p(a[6]), _p(a[7]), _p(a[8]), _p(a[9]), _p(a[10]), _p(a[11]),
+                                               int(onlyStereo), int(coarse), int(checkOri), _p(m))
+    return n, m
+
+
 def search_for_triangulation(k1, d1, node1, has1, ur1, k2, d2, node2, has2, ur2, sigma2, scaleF, K, R12, t12, ep, onlyStereo, coarse, checkOri):
     L = lib()
     F12 = np.zeros(9, np.float32)
