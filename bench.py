@@ -141,6 +141,76 @@ def optimizer_extras(dev_index):
                                   "cpu_oracle_frames_per_s_1core": 1.0 / dcp}}
 
 
+def config_extras(dev_index):
+    """Throughput of the other BASELINE configs on rank 0 (short runs; parity for these shapes is in tests/):
+    C3 = TUM-VI-shaped fisheye stereo 512x512, 1500 features, lapping areas: extract x2 + ComputeStereoFishEyeMatches
+    (all-pairs Hamming knn2 + KB8 triangulation) + PoseOptimization on the rig; C4 = 1920x1080 stereo, 4000 features."""
+    import torch
+    from morb_slam_amd import ORBextractor, ORBmatcher, Optimizer
+    from morb_slam_amd.synth import (TUMVI_CAM_L, TUMVI_CAM_R, TUMVI_T_C1_C2, make_pose_problem_fisheye, make_stereo_pair)
+    dev = torch.device("cuda", dev_index)
+    out = {}
+    st = torch.cuda.Stream(device=dev)
+
+    def timed(fn, n):
+        fn(); st.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        st.synchronize()
+        return (time.perf_counter() - t0) / n
+    # ---- C3
+    B3 = 32
+    base = [make_stereo_pair(512, 512, seed=100 + i) for i in range(4)]
+    imgs = torch.from_numpy(np.stack([base[i % 4][k] for i in range(B3) for k in (0, 1)])).to(dev)
+    ext = ORBextractor(1500, 1.2, 8, 20, 7, device=dev_index)
+    mt = ORBmatcher(0.7, True, device=dev_index)
+    lap = np.tile(np.array([[0, 511], [0, 511]], np.int32), (B3, 1))     # TUM-VI.yaml: the lapping areas span the images
+    sigma2 = ext.GetScaleSigmaSquares()
+    Rlr = TUMVI_T_C1_C2[:3, :3].astype(np.float32); tlr = TUMVI_T_C1_C2[:3, 3].astype(np.float32)
+    probs = [make_pose_problem_fisheye(seed=s % 4) for s in range(B3)]
+    capP = max(len(q["hasMP"]) for q in probs)
+    t = {k: torch.from_numpy(np.stack([np.pad(q[k], [(0, capP - len(q[k]))] + [(0, 0)] * (q[k].ndim - 1)) for q in probs])).to(dev)
+         for k in ("hasMP", "obs", "invSigma2", "Xw")}
+    pose0 = torch.from_numpy(np.stack([q["pose0"] for q in probs])).to(dev)
+    nl = torch.tensor([q["Nleft"] for q in probs], dtype=torch.int32, device=dev)
+    cn = torch.tensor([len(q["hasMP"]) for q in probs], dtype=torch.int32, device=dev)
+    opt = Optimizer(device=dev_index)
+    eo = None
+
+    def c3():
+        nonlocal eo
+        eo = ext.extract_batch(imgs, lap=lap, out=eo, stream=st.cuda_stream)
+        mt.ComputeStereoFishEyeMatches(eo[0], eo[1], eo[2], eo[3], TUMVI_CAM_L, TUMVI_CAM_R, Rlr, tlr, sigma2, stream=st.cuda_stream)
+        opt.PoseOptimizationFisheye(t["hasMP"], t["obs"], t["invSigma2"], t["Xw"], pose0.clone(), nl, cn, TUMVI_CAM_L, TUMVI_CAM_R,
+                                    probs[0]["Trl"], stream=st.cuda_stream)
+    with torch.cuda.stream(st):
+        dt3 = timed(c3, 5)
+    out["c3_fisheye_512x512_1500feat"] = {"stereo_frames_per_step": B3, "frames_per_s": B3 / dt3, "ms_per_step": dt3 * 1e3,
+                                          "stages": ["extract_left+right(lapping areas)", "ComputeStereoFishEyeMatches",
+                                                     "PoseOptimization(700 edges, KB8 rig)"],
+                                          "mean_keypoints_per_image": float(eo[2].float().mean().item())}
+    ext.close()
+    # ---- C4
+    B4 = 8
+    base = [make_stereo_pair(1920, 1080, seed=200 + i) for i in range(2)]
+    imgs4 = torch.from_numpy(np.stack([base[i % 2][k] for i in range(B4) for k in (0, 1)])).to(dev)
+    ext4 = ORBextractor(4000, 1.2, 8, 20, 7, device=dev_index)
+    mbf, mb = 458.654 * 0.11, 0.11
+    e4 = s4 = None
+
+    def c4():
+        nonlocal e4, s4
+        e4 = ext4.extract_batch(imgs4, out=e4, stream=st.cuda_stream)
+        s4 = mt.ComputeStereoMatches(ext4, e4[0], e4[1], e4[2], mbf, mb, out=s4, stream=st.cuda_stream)
+    dt4 = timed(c4, 5)
+    out["c4_1920x1080_4000feat"] = {"stereo_frames_per_step": B4, "frames_per_s": B4 / dt4, "ms_per_step": dt4 * 1e3,
+                                    "stages": ["extract_left+right", "ComputeStereoMatches"],
+                                    "mean_keypoints_per_image": float(e4[2].float().mean().item())}
+    ext4.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,6 +394,7 @@ def main():
         }
         if world == 1:
             line["extra_metrics"] = optimizer_extras(local_rank)
+            line["extra_metrics"].update(config_extras(local_rank))
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
