@@ -1160,29 +1160,91 @@ constexpr int LD_T = 1024;
 // pointer that may be either forces FLAT loads/stores, which cost several times an LDS access.
 // Right-looking LDL^T by the whole workgroup: per column one barrier after staging the pivot column, one after
 // the trailing update (32 x 32 thread tile, no integer division); triangular solves by wave 0.
+// Blocked right-looking LDL^T (block width LB): per block step (1) one thread factors the LB x LB diagonal block in
+// registers, (2) one thread per row below it solves that row's LB entries (keeping u = l * d for step 3), (3) all
+// threads apply the rank-LB update to the trailing lower triangle.  3 workgroup barriers per LB columns instead of
+// 2 per column (the column-by-column version spent ~120 us of its 137 us at P = 120 in barriers).
+constexpr int LB = 8;
 template <typename HsPtr>
-__device__ __forceinline__ bool ldlt_block(HsPtr Hs, int pitch, int P, int tid, double* __restrict__ cv, double* __restrict__ x,
-                                           int* sOk) {
+__device__ __forceinline__ bool ldlt_block(HsPtr Hs, int pitch, int P, int tid, double* __restrict__ up /*[P][LB]*/,
+                                           double* __restrict__ x, int* sOk) {
   const int tx = tid & 31, ty = tid >> 5, lane = tid & 63, wv = tid >> 6;
   if (tid == 0) *sOk = 1;
   __syncthreads();
-  for (int j = 0; j < P; ++j) {
-    const double d = Hs[(size_t)j * pitch + j];
-    if (d == 0 || d != d) { if (tid == 0) *sOk = 0; break; }   // uniform: every thread reads the same d
-    const double invd = 1.0 / d;
-    for (int i = j + 1 + tid; i < P; i += LD_T) cv[i] = Hs[(size_t)i * pitch + j];
+  for (int j0 = 0; j0 < P; j0 += LB) {
+    const int nb = P - j0 < LB ? P - j0 : LB;
+    if (tid == 0) {   // (1) diagonal block
+      double a[LB][LB];
+#pragma unroll
+      for (int i = 0; i < LB; ++i)
+#pragma unroll
+        for (int c = 0; c <= i; ++c) a[i][c] = (i < nb) ? (double)Hs[(size_t)(j0 + i) * pitch + j0 + c] : (i == c ? 1.0 : 0.0);
+      bool good = true;
+#pragma unroll
+      for (int c = 0; c < LB; ++c) {
+        double d = a[c][c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) d -= a[c][k] * a[c][k] * a[k][k];
+        a[c][c] = d;
+        if (c < nb && (d == 0 || d != d)) good = false;
+        const double invd = 1.0 / d;
+#pragma unroll
+        for (int i = c + 1; i < LB; ++i) {
+          double v = a[i][c];
+#pragma unroll
+          for (int k = 0; k < c; ++k) v -= a[i][k] * a[k][k] * a[c][k];
+          a[i][c] = v * invd;
+        }
+      }
+      if (!good) *sOk = 0;
+#pragma unroll
+      for (int i = 0; i < LB; ++i)
+#pragma unroll
+        for (int c = 0; c <= i; ++c) if (i < nb) Hs[(size_t)(j0 + i) * pitch + j0 + c] = a[i][c];
+    }
     __syncthreads();
-    for (int i = j + 1 + ty; i < P; i += 32) {
+    if (*sOk == 0) break;   // uniform
+    const int r0 = j0 + nb, m = P - r0;   // rows below the block
+    if (tid < m) {   // (2) panel: one row per thread
+      const int i = r0 + tid;
+      double u[LB], l[LB];
+#pragma unroll
+      for (int c = 0; c < LB; ++c) {
+        if (c < nb) {
+          double v = Hs[(size_t)i * pitch + j0 + c];
+#pragma unroll
+          for (int k = 0; k < c; ++k) v -= u[k] * (double)Hs[(size_t)(j0 + c) * pitch + j0 + k];
+          u[c] = v;
+          l[c] = v / (double)Hs[(size_t)(j0 + c) * pitch + j0 + c];
+        } else { u[c] = 0; l[c] = 0; }
+      }
+#pragma unroll
+      for (int c = 0; c < LB; ++c) { up[(size_t)tid * LB + c] = u[c]; if (c < nb) Hs[(size_t)i * pitch + j0 + c] = l[c]; }
+    }
+    __syncthreads();
+    // (3) trailing update: Hs[i][k] -= sum_c u[i][c] * l[k][c], r0 <= k <= i < P
+    for (int ii = ty; ii < m; ii += 32) {
+      const int i = r0 + ii;
+      double ui[LB];
+#pragma unroll
+      for (int c = 0; c < LB; ++c) ui[c] = up[(size_t)ii * LB + c];
       HsPtr row = Hs + (size_t)i * pitch;
-      const double li = cv[i] * invd;
-      for (int k = j + 1 + tx; k <= i; k += 32) row[k] -= li * cv[k];
-      if (tx == 0) row[j] = li;
+      for (int kk = tx; kk <= ii; kk += 32) {
+        const int k = r0 + kk;
+        HsPtr lk = Hs + (size_t)k * pitch + j0;
+        double acc = 0;
+#pragma unroll
+        for (int c = 0; c < LB; ++c) acc += ui[c] * (double)lk[c];
+        row[k] -= acc;
+      }
     }
     __syncthreads();
   }
   __syncthreads();
   const bool ok = *sOk != 0;
   if (ok && wv == 0) {
+    // column-at-a-time substitutions by one wave (a blocked variant with the LB x LB triangles solved by one lane was
+    // measured slower: 123 vs 98 us per call at P = 120)
     for (int j = 0; j < P; ++j) {             // L y = b
       const double xj = x[j];
       for (int i = j + 1 + lane; i < P; i += 64) x[i] -= Hs[(size_t)i * pitch + j] * xj;
@@ -1204,7 +1266,7 @@ __global__ __launch_bounds__(LD_T) void k_g_ldlt(const BaDev* __restrict__ pbp, 
                                                  int useLds) {
   extern __shared__ double sHs[];
   __shared__ double sx[LD_MAXP];
-  __shared__ double cv[LD_MAXP];
+  __shared__ double upanel[LD_MAXP * LB];
   __shared__ int sOk;
   const BaDev pb = *pbp;
   const int P = pb.P, tid = threadIdx.x;
@@ -1213,7 +1275,7 @@ __global__ __launch_bounds__(LD_T) void k_g_ldlt(const BaDev* __restrict__ pbp, 
     for (int i = tid; i < P * P; i += LD_T) { const int r = i / P, c = i - r * P; sHs[r * pitch + c] = HsG[i]; }
     for (int i = tid; i < P; i += LD_T) sx[i] = pb.x[i];
     __syncthreads();
-    const bool ok = ldlt_block(sHs, pitch, P, tid, cv, sx, &sOk);
+    const bool ok = ldlt_block(sHs, pitch, P, tid, upanel, sx, &sOk);
     if (ok) for (int i = tid; i < P; i += LD_T) pb.x[i] = sx[i];
     if (tid == 0) pb.scal[2] = ok ? 1.0 : 0.0;
   } else {
@@ -1316,6 +1378,7 @@ struct morb_ba_problem {
   int stopHost = 0;
   int redBlocks = 0;
   double* h_scal = nullptr;  // pinned host mirror of scal[0..3]
+  double* d_ldws = nullptr;  // [P][LB] panel scratch of the LDL^T when the reduced system does not fit LDS
 };
 
 extern "C" {
@@ -1483,6 +1546,7 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
   h.chunkEnd = (const int*)up(chunkEnd.data(), sizeof(int) * std::max<size_t>(chunkEnd.size(), 1));
   h.kfChunkStart = (const int*)up(kfChunkStart.data(), sizeof(int) * (nKF + 1));
   h.kfPart = (double*)up(nullptr, sizeof(double) * 27 * std::max<size_t>(chunkKF.size(), 1));
+  p->d_ldws = (double*)up(nullptr, sizeof(double) * LB * std::max<size_t>((size_t)h.P, 1));
   p->redBlocks = div_up(std::max(std::max(nE, nMP * 3), std::max(nKF * 7, 1)), GB);
   h.redPart = (double*)up(nullptr, sizeof(double) * 2 * p->redBlocks);
   h.scal = (double*)up(nullptr, sizeof(double) * 8);
@@ -1654,7 +1718,7 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
         hipLaunchKernelGGL(k_g_dinv_push, dim3(rb > div_up(h.P * h.P, GB) ? rb : div_up(h.P * h.P, GB)), dim3(GB), 0, st, d, lambda, h.HsG);
         hipLaunchKernelGGL(k_g_schur, dim3(div_up(std::max(h.nPairs, 1), 4)), dim3(GB), 0, st, d, lambda, h.HsG);
         hipLaunchKernelGGL(k_g_bschur, dim3(h.nKF), dim3(64), 0, st, d);
-        hipLaunchKernelGGL(k_g_ldlt, dim3(1), dim3(LD_T), p->ldsBytes, st, d, h.HsG, h.kfPart /* scratch >= P doubles when nChunks*27 >= P */, p->useLds);
+        hipLaunchKernelGGL(k_g_ldlt, dim3(1), dim3(LD_T), p->ldsBytes, st, d, h.HsG, p->d_ldws, p->useLds);
         hipLaunchKernelGGL(k_g_backsub_update, dim3(rb), dim3(GB), 0, st, d, lambda, part1);
         hipLaunchKernelGGL(k_g_reduce, dim3(1), dim3(GB), 0, st, (const double*)part1, rb, h.scal + 1);
         chi2();
