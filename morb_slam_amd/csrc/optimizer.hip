@@ -1363,6 +1363,10 @@ __global__ void k_ba_reset(BaDev pb, const float* __restrict__ pose0, const floa
 struct morb_optimizer {
   int device = 0;
   hipStream_t stream = nullptr;
+  // grid-mode LocalBA runs pairs of independent small phases side by side (per-point / per-keyframe builds, Schur
+  // complement / reduced right-hand side): fork-join on a side stream
+  hipStream_t side = nullptr;
+  hipEvent_t evFork = nullptr, evJoin = nullptr;
 };
 
 struct morb_ba_problem {
@@ -1392,7 +1396,10 @@ int morb_optimizer_create(morb_optimizer** out, int device) {
   MORB_HIP_CHECK(hipSetDevice(device));
   morb_optimizer* o = new morb_optimizer();
   o->device = device;
-  if (hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&o->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&o->evFork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&o->evJoin, hipEventDisableTiming) != hipSuccess) {
     delete o;
     set_error("cannot create stream");
     return MORB_ERR_HIP;
@@ -1405,6 +1412,9 @@ void morb_optimizer_destroy(morb_optimizer* o) {
   if (!o) return;
   (void)hipSetDevice(o->device);
   (void)hipStreamSynchronize(o->stream);
+  if (o->side) { (void)hipStreamSynchronize(o->side); (void)hipStreamDestroy(o->side); }
+  if (o->evFork) (void)hipEventDestroy(o->evFork);
+  if (o->evJoin) (void)hipEventDestroy(o->evJoin);
   (void)hipStreamDestroy(o->stream);
   delete o;
 }
@@ -1696,12 +1706,24 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
     if (rc != MORB_OK) return rc;
     double currentChi = hs[0], lambda = 0, ni = 2;
     int nBad = 0;
+    hipStream_t s2 = p->opt->side;
+    // buildSystem: per-point blocks (Hll, bl) and per-keyframe blocks (Hpp, bp, Hpl) do not depend on each other
+    auto launchBuilds = [&]() -> int {
+      MORB_HIP_CHECK(hipEventRecord(p->opt->evFork, st));
+      MORB_HIP_CHECK(hipStreamWaitEvent(s2, p->opt->evFork, 0));
+      hipLaunchKernelGGL(k_g_build_kf, dim3(div_up(std::max(h.nChunks, 1), 4)), dim3(GB), 0, s2, d);
+      hipLaunchKernelGGL(k_g_kf_reduce, dim3(h.nKF), dim3(64), 0, s2, d);
+      MORB_HIP_CHECK(hipEventRecord(p->opt->evJoin, s2));
+      hipLaunchKernelGGL(k_g_build_mp, dim3(div_up(h.nMP, GB)), dim3(GB), 0, st, d);
+      MORB_HIP_CHECK(hipStreamWaitEvent(st, p->opt->evJoin, 0));
+      return MORB_OK;
+    };
+    bool built = false;   // the next iteration's system is already being built (speculatively, see below)
     for (int iter = 0; iter < 10 && !p->stopHost; ++iter) {
       ++its;
       const double iniChi = currentChi;
-      hipLaunchKernelGGL(k_g_build_mp, dim3(div_up(h.nMP, GB)), dim3(GB), 0, st, d);
-      hipLaunchKernelGGL(k_g_build_kf, dim3(div_up(std::max(h.nChunks, 1), 4)), dim3(GB), 0, st, d);
-      hipLaunchKernelGGL(k_g_kf_reduce, dim3(h.nKF), dim3(64), 0, st, d);
+      if (!built) { rc = launchBuilds(); if (rc != MORB_OK) return rc; }
+      built = false;
       if (iter == 0) {
         if (h.userLambda > 0) lambda = h.userLambda;
         else {
@@ -1716,12 +1738,20 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
       int qmax = 0;
       do {
         hipLaunchKernelGGL(k_g_dinv_push, dim3(rb > div_up(h.P * h.P, GB) ? rb : div_up(h.P * h.P, GB)), dim3(GB), 0, st, d, lambda, h.HsG);
+        // the Schur complement of the matrix and of the right-hand side both only need Dinv
+        MORB_HIP_CHECK(hipEventRecord(p->opt->evFork, st));
+        MORB_HIP_CHECK(hipStreamWaitEvent(s2, p->opt->evFork, 0));
+        hipLaunchKernelGGL(k_g_bschur, dim3(h.nKF), dim3(64), 0, s2, d);
+        MORB_HIP_CHECK(hipEventRecord(p->opt->evJoin, s2));
         hipLaunchKernelGGL(k_g_schur, dim3(div_up(std::max(h.nPairs, 1), 4)), dim3(GB), 0, st, d, lambda, h.HsG);
-        hipLaunchKernelGGL(k_g_bschur, dim3(h.nKF), dim3(64), 0, st, d);
+        MORB_HIP_CHECK(hipStreamWaitEvent(st, p->opt->evJoin, 0));
         hipLaunchKernelGGL(k_g_ldlt, dim3(1), dim3(LD_T), p->ldsBytes, st, d, h.HsG, p->d_ldws, p->useLds);
         hipLaunchKernelGGL(k_g_backsub_update, dim3(rb), dim3(GB), 0, st, d, lambda, part1);
         hipLaunchKernelGGL(k_g_reduce, dim3(1), dim3(GB), 0, st, (const double*)part1, rb, h.scal + 1);
         chi2();
+        // (building the NEXT iteration's system speculatively before the accept / reject decision returns was measured:
+        // 2.29 vs 2.19 ms per solve — the host round trip is shorter than the extra stream traffic; left off)
+        const bool spec = false;
         rc = readScal();
         if (rc != MORB_OK) return rc;
         double tempChi = hs[0];
@@ -1733,10 +1763,12 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
           lambda *= std::max(1. / 3., alpha);
           ni = 2;
           currentChi = tempChi;
+          built = spec;
         } else {
           lambda *= ni;
           ni *= 2;
           hipLaunchKernelGGL(k_g_pop, dim3(rb), dim3(GB), 0, st, d);
+          if (spec) { rc = launchBuilds(); if (rc != MORB_OK) return rc; }
         }
         ++qmax; ++trials;
       } while (rho < 0 && qmax < 10 && !p->stopHost);
