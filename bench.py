@@ -221,6 +221,7 @@ def main():
                     help="the batch is cut into this many frame chunks, each with its own extractor/matcher handle and HIP "
                          "stream, so the latency-bound quadtree of one chunk runs under the VALU-bound FAST of another")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline workload only (used for the committed profiles)")
     args = ap.parse_args()
 
     import torch
@@ -392,7 +393,7 @@ def main():
                          "algorithmic_bytes_per_launch": ab[dom] * nimg // C, "avg_launch_ms": stages[dom] / C},
             "extract_stage_ms_per_step": stages,
         }
-        if world == 1:
+        if world == 1 and not args.no_extras:
             line["extra_metrics"] = optimizer_extras(local_rank)
             line["extra_metrics"].update(config_extras(local_rank))
         if not args.no_cpu_baseline:

@@ -7,10 +7,10 @@ R=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$R
 rm -rf "$O" && mkdir -p "$O"
-rocprofv3 --kernel-trace --stats -d "$O/stats" -o s --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$O/bench_under_rocprof.json" 2>/dev/null
+rocprofv3 --kernel-trace --stats -d "$O/stats" -o s --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > "$O/bench_under_rocprof.json" 2>/dev/null
 for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM"; do
   n=$(echo "$p" | cut -c1-12 | tr " " _)
-  timeout 300 rocprofv3 --pmc $p --kernel-trace -d "$O/pmc/$n" -o q --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $p --kernel-trace -d "$O/pmc/$n" -o q --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
 done
 python3 tools/pmc_table.py "$O/pmc" > "$O/pmc_issue_table.txt"
 python3 tools/pmc_traffic.py "$O/pmc" 128 > "$O/pmc_traffic_b64.json"
