@@ -157,6 +157,15 @@ int morb_search_by_bow_batch(morb_matcher*, int npairs, const int* d_kfImg, cons
                              const uint8_t* d_hasMP, int cap, float nnratio, int checkOri, int* d_matchF,
                              int* d_nmatches, void* stream);
 
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (ORBmatcher.cc:702-819; loop
+ * closing / merging): both sides are keyframes of the pool; hasMP[img][i] != 0 <=> GetMapPointMatches()[i] && !isBad();
+ * d_nValid[img] = mvKeysUn.size() (features at or beyond it are skipped on fisheye keyframes, :734 / :751; NULL = all).
+ * match12[p][idx1] = index of the matched pKF2 feature or -1 (vpMatches12[idx1] = vpMapPoints2[match12]). */
+int morb_search_by_bow_kfkf_batch(morb_matcher* m, int npairs, const int* d_kf1Img, const int* d_kf2Img, const int* d_nValid, int nimg,
+                                  const morb_keypoint* d_kps, const uint8_t* d_desc, const int* d_node, const int* d_count,
+                                  const uint8_t* d_hasMP, int cap, float nnratio, int checkOri, int* d_match12, int* d_nmatches,
+                                  void* stream);
+
 /* The same with a fisheye frame F (F.Nleft != -1, ORBmatcher.cc:262-299 and :333-365): image fImg[p] holds the
  * Nleft = d_nLeft[p] left features followed by the right ones; left and right candidates of a node are ranked
  * separately, the right winner is taken whenever the LEFT best distance passes TH_LOW (the reference's nesting and

@@ -104,6 +104,7 @@ def lib():
         L.morb_stereo_fisheye_match_batch.argtypes = [vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp]
         L.morb_bow_transform_batch.argtypes = [vp, i, vp, vp, i, vp, vp, i, i, i, vp, vp, vp]
         L.morb_search_by_bow_batch.argtypes = [vp, i, vp, vp, i, vp, vp, vp, vp, vp, i, f, i, vp, vp, vp]
+        L.morb_search_by_bow_kfkf_batch.argtypes = [vp, i, vp, vp, vp, i, vp, vp, vp, vp, vp, i, f, i, vp, vp, vp]
         L.morb_search_by_bow_fisheye_batch.argtypes = [vp, i, vp, vp, vp, i, vp, vp, vp, vp, vp, i, f, i, vp, vp, vp]
         PP = C.POINTER(FrameParams)
         L.morb_is_in_frustum_batch.argtypes = [vp, PP, i, vp, vp, vp, i, vp, vp, vp, vp, vp, f] + [vp] * 8

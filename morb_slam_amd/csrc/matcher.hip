@@ -460,7 +460,12 @@ __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __r
                                                    const uint8_t* __restrict__ descF, const morb_keypoint* __restrict__ kpsF,
                                                    const int* __restrict__ kfImg, const int* __restrict__ fImg,
                                                    float nnratio, int* __restrict__ matchF, int* __restrict__ binF,
-                                                   const int* __restrict__ nLeftv) {   // F.Nleft per pair or NULL (pinhole)
+                                                   const int* __restrict__ nLeftv,     // F.Nleft per pair or NULL (pinhole)
+                                                   // SearchByBoW(pKF1, pKF2) (:702-819) when hasMP2 != NULL: the "frame" side is
+                                                   // keyframe 2, only its features with a MapPoint compete, the threshold is strict,
+                                                   // the table is indexed by keyframe-1 feature (match12[idx1] = idx2)
+                                                   const uint8_t* __restrict__ hasMP2, const int* __restrict__ nValidv,
+                                                   int* __restrict__ matched2) {
   extern __shared__ __align__(16) unsigned long long bowLds[];
 #ifdef MORB_FAST_TIMING
   const int bw_ = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -474,6 +479,9 @@ __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __r
   // fisheye frame (ORBmatcher.cc:262-299, :333-365): features >= nLeft are the right camera's and are ranked separately
   const bool fish = nLeftv != nullptr && nLeftv[pair] >= 0;
   const int nLeft = fish ? nLeftv[pair] : 0x7fffffff;
+  const bool kfkf = hasMP2 != nullptr;
+  const int nValid1 = (kfkf && nValidv) ? nValidv[ik] : 0x7fffffff, nValid2 = (kfkf && nValidv) ? nValidv[jf] : 0x7fffffff;
+  const int thLow = kfkf ? TH_LOW - 1 : TH_LOW;    // bestDist1 < TH_LOW (:768) vs <= TH_LOW (:307)
   {
     // stage both tables with all of a thread's loads in flight at once (one global round trip, not one per element)
     const unsigned long long* gk = sortedKF + (size_t)ik * cap;
@@ -561,6 +569,7 @@ __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __r
           idxF[j] = (int)(sf[fBeg + j * 64 + lane] & 0xFFFFFFFFu);
           dF[j] = load_desc(descF + ((size_t)jf * cap + idxF[j]) * 32);
           angF[j] = kpsF[(size_t)jf * cap + idxF[j]].angle;
+          if (kfkf && (!hasMP2[(size_t)jf * cap + idxF[j]] || idxF[j] >= nValid2)) myMatch[j] = -2;   // never a candidate
         }
       }
       for (int q0 = p; q0 < nKF; q0 += 64) {
@@ -572,7 +581,7 @@ __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __r
         float angK = 0.f;
         if (lane < nKs) {
           idxK = (int)(sk[q0 + lane] & 0xFFFFFFFFu);
-          has = hasMP[(size_t)ik * cap + idxK];
+          has = hasMP[(size_t)ik * cap + idxK] && idxK < nValid1;
           dK = load_desc(descKF + ((size_t)ik * cap + idxK) * 32);
           angK = kpsKF[(size_t)ik * cap + idxK].angle;
         }
@@ -585,7 +594,7 @@ __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __r
           unsigned b1 = ~0u;             // fisheye: this lane's best right-camera key (the second best is unused: `|| true`, :336)
 #pragma unroll
           for (int j = 0; j < BM_FJ; ++j)
-            if (j < nJ && j * 64 + lane < nFs && myMatch[j] < 0) {
+            if (j < nJ && j * 64 + lane < nFs && myMatch[j] == -1) {
               const unsigned key = ((unsigned)hamming(dk, dF[j]) << 16) | (unsigned)idxF[j];
               if (idxF[j] < nLeft) { if (key < a1) { a2 = a1; a1 = key; } else if (key < a2) a2 = key; }
               else if (key < b1) b1 = key;
@@ -596,7 +605,7 @@ __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __r
           const int bestDist1 = k1 == ~0u ? 256 : (int)(k1 >> 16);
           const int bestDist2 = k2 == ~0u ? 256 : (int)(k2 >> 16);
           const int bestDist1R = r1 == ~0u ? 256 : (int)(r1 >> 16);
-          if (bestDist1 <= TH_LOW) {
+          if (bestDist1 <= thLow) {
             const int realIdxKF = __builtin_amdgcn_readlane(idxK, q);
             const float aK = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angK), q));
             const bool takeL = (float)bestDist1 < nnratio * (float)bestDist2;
@@ -606,7 +615,7 @@ __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __r
             const int wantIdxR = (takeR && b1 == r1 && r1 != ~0u) ? (int)(r1 & 0xFFFFu) : -1;
 #pragma unroll
             for (int j = 0; j < BM_FJ; ++j)
-              if (j < nJ && j * 64 + lane < nFs && myMatch[j] < 0 && (idxF[j] == wantIdx || idxF[j] == wantIdxR)) {
+              if (j < nJ && j * 64 + lane < nFs && myMatch[j] == -1 && (idxF[j] == wantIdx || idxF[j] == wantIdxR)) {
                 float rot = aK - angF[j];
                 if (rot < 0.0f) rot += 360.0f;
                 int bin = (int)roundf(rot * factor);
@@ -619,7 +628,10 @@ __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __r
       }
 #pragma unroll
       for (int j = 0; j < BM_FJ; ++j)
-        if (j < nJ && j * 64 + lane < nFs && myMatch[j] >= 0) { mF[idxF[j]] = myMatch[j]; bF[idxF[j]] = myBin[j]; }
+        if (j < nJ && j * 64 + lane < nFs && myMatch[j] >= 0) {
+          if (kfkf) { mF[myMatch[j]] = idxF[j]; bF[myMatch[j]] = myBin[j]; }     // indexed by the keyframe-1 feature
+          else { mF[idxF[j]] = myMatch[j]; bF[idxF[j]] = myBin[j]; }
+        }
       continue;
     }
     // ---- general path (a node with more than BM_FJ * 64 frame features): v1 logic on the LDS tables
@@ -629,14 +641,16 @@ __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __r
       const unsigned long long kq = sk[q];
       if (kq == ~0ull || (unsigned)(kq >> 32) != node) break;
       const int realIdxKF = (int)(kq & 0xFFFFFFFFu);
-      if (!hasMP[(size_t)ik * cap + realIdxKF]) continue;
+      if (!hasMP[(size_t)ik * cap + realIdxKF] || realIdxKF >= nValid1) continue;
       const Desc dKF = load_desc(descKF + ((size_t)ik * cap + realIdxKF) * 32);
       unsigned long long k1 = ~0ull, k2 = ~0ull, r1 = ~0ull, r2 = ~0ull;
       for (int s0 = fBeg; s0 < fEnd; s0 += 64) {
         const int s = s0 + lane;
         if (s < fEnd) {
           const int realIdxF = (int)(sf[s] & 0xFFFFFFFFu);
-          if (mF[realIdxF] < 0) {
+          const bool cand = kfkf ? (hasMP2[(size_t)jf * cap + realIdxF] && realIdxF < nValid2 && !matched2[(size_t)pair * cap + realIdxF])
+                                 : (mF[realIdxF] < 0);
+          if (cand) {
             const int d = hamming(dKF, load_desc(descF + ((size_t)jf * cap + realIdxF) * 32));
             if (realIdxF < nLeft) top2_insert(k1, k2, ((unsigned long long)d << 32) | (unsigned)realIdxF);
             else top2_insert(r1, r2, ((unsigned long long)d << 32) | (unsigned)realIdxF);
@@ -648,7 +662,7 @@ __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __r
       const int bestDist1 = k1 == ~0ull ? 256 : (int)(k1 >> 32);
       const int bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 32);
       const int bestDist1R = r1 == ~0ull ? 256 : (int)(r1 >> 32);
-      if (bestDist1 <= TH_LOW) {
+      if (bestDist1 <= thLow) {
         const float aK = kpsKF[(size_t)ik * cap + realIdxKF].angle;
         const bool takeL = (float)bestDist1 < nnratio * (float)bestDist2, takeR = bestDist1R <= TH_LOW;
         if (lane == 0) {
@@ -658,7 +672,8 @@ __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __r
             if (rot < 0.0f) rot += 360.0f;
             int bin = (int)roundf(rot * factor);
             if (bin == HISTO_LENGTH) bin = 0;
-            mF[bestIdxF] = realIdxKF; bF[bestIdxF] = bin;
+            if (kfkf) { mF[realIdxKF] = bestIdxF; bF[realIdxKF] = bin; matched2[(size_t)pair * cap + bestIdxF] = 1; }
+            else { mF[bestIdxF] = realIdxKF; bF[bestIdxF] = bin; }
           }
           if (takeR) {
             const int bestIdxFR = (int)(r1 & 0xFFFFFFFFu);
@@ -888,7 +903,8 @@ int morb_bow_transform_batch(morb_matcher* m, int nimg, const uint8_t* d_desc, c
 static int search_by_bow_impl(morb_matcher* m, int npairs, const int* d_kfImg, const int* d_fImg, int nimg,
                               const morb_keypoint* d_kps, const uint8_t* d_desc, const int* d_node, const int* d_count,
                               const uint8_t* d_hasMP, int cap, float nnratio, int checkOri, int* d_matchF,
-                              int* d_nmatches, const int* d_nLeft, void* stream) {
+                              int* d_nmatches, const int* d_nLeft, void* stream, const uint8_t* d_hasMP2 = nullptr,
+                              const int* d_nValid = nullptr) {
   MORB_REQUIRE(m && d_kfImg && d_fImg && d_kps && d_desc && d_node && d_count && d_hasMP && d_matchF && d_nmatches,
                MORB_ERR_INVALID, "NULL argument");
   MORB_REQUIRE(npairs > 0 && nimg > 0 && cap > 0, MORB_ERR_INVALID, "bad sizes");
@@ -905,11 +921,22 @@ static int search_by_bow_impl(morb_matcher* m, int npairs, const int* d_kfImg, c
   hipLaunchKernelGGL(k_bow_sort, dim3(nimg), dim3(256), (size_t)P * 8, st, d_node, d_count, cap, P, m->d_sortA);
   const size_t nm = (size_t)npairs * cap;
   hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, d_matchF, nm, -1);
+  int* matched2 = nullptr;
+  if (d_hasMP2) {   // vbMatched2 of the general path (nodes with very many features)
+    void* w = nullptr;
+    rc = morb_matcher_workspace(m, 7, sizeof(int) * nm, &w);
+    if (rc != MORB_OK) return rc;
+    matched2 = (int*)w;
+    hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, matched2, nm, 0);
+  }
   MORB_REQUIRE(cap < 65536 && (size_t)cap * 18 <= 160 * 1024, MORB_ERR_UNSUPPORTED, "too many features per frame for the LDS-resident node tables");
   MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)cap * 18)));
   hipLaunchKernelGGL(k_bow_match, dim3(BM_NB, npairs), dim3(256), (size_t)cap * 18, st, m->d_sortA, m->d_sortA, d_count, d_count,
-                     cap, d_desc, d_hasMP, d_kps, d_desc, d_kps, d_kfImg, d_fImg, nnratio, d_matchF, m->d_bin, d_nLeft);
-  hipLaunchKernelGGL(k_rot_filter, dim3(npairs), dim3(256), 0, st, d_count, d_fImg, cap, checkOri, d_matchF, m->d_bin, d_nmatches);
+                     cap, d_desc, d_hasMP, d_kps, d_desc, d_kps, d_kfImg, d_fImg, nnratio, d_matchF, m->d_bin, d_nLeft, d_hasMP2,
+                     d_nValid, matched2);
+  // the table is indexed by frame feature (M3) or by keyframe-1 feature (SearchByBoW(KF, KF))
+  hipLaunchKernelGGL(k_rot_filter, dim3(npairs), dim3(256), 0, st, d_count, d_hasMP2 ? d_kfImg : d_fImg, cap, checkOri, d_matchF,
+                     m->d_bin, d_nmatches);
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
 }
@@ -920,6 +947,14 @@ int morb_search_by_bow_batch(morb_matcher* m, int npairs, const int* d_kfImg, co
                              int* d_nmatches, void* stream) {
   return search_by_bow_impl(m, npairs, d_kfImg, d_fImg, nimg, d_kps, d_desc, d_node, d_count, d_hasMP, cap, nnratio, checkOri,
                             d_matchF, d_nmatches, nullptr, stream);
+}
+
+int morb_search_by_bow_kfkf_batch(morb_matcher* m, int npairs, const int* d_kf1Img, const int* d_kf2Img, const int* d_nValid, int nimg,
+                                  const morb_keypoint* d_kps, const uint8_t* d_desc, const int* d_node, const int* d_count,
+                                  const uint8_t* d_hasMP, int cap, float nnratio, int checkOri, int* d_match12, int* d_nmatches,
+                                  void* stream) {
+  return search_by_bow_impl(m, npairs, d_kf1Img, d_kf2Img, nimg, d_kps, d_desc, d_node, d_count, d_hasMP, cap, nnratio, checkOri,
+                            d_match12, d_nmatches, nullptr, stream, d_hasMP, d_nValid);
 }
 
 int morb_search_by_bow_fisheye_batch(morb_matcher* m, int npairs, const int* d_kfImg, const int* d_fImg, const int* d_nLeft,

@@ -94,6 +94,17 @@ class ORBmatcher:
                                                self._st(stream)))
         return out
 
+    def SearchByBoWKeyFrames(self, kf1_img, kf2_img, kps, desc, node, count, has_mp, nValid=None, stream=None):
+        """SearchByBoW(pKF1, pKF2, vpMatches12): match12 int32 [npairs, cap] (index of the pKF2 feature per pKF1 feature)."""
+        import torch
+        npairs = kf1_img.shape[0]
+        nimg, cap = kps.shape[0], kps.shape[1]
+        out = (torch.empty((npairs, cap), dtype=torch.int32, device=kps.device), torch.empty((npairs,), dtype=torch.int32, device=kps.device))
+        check(self._L.morb_search_by_bow_kfkf_batch(self._h, npairs, ptr(kf1_img), ptr(kf2_img), ptr(nValid), nimg, ptr(kps), ptr(desc),
+                                                    ptr(node), ptr(count), ptr(has_mp), cap, self.mfNNratio,
+                                                    1 if self.mbCheckOrientation else 0, ptr(out[0]), ptr(out[1]), self._st(stream)))
+        return out
+
     # ---- projection-guided searches (projection.hip) ------------------------------------------------------
     def isInFrustum(self, params, Rcw, tcw, Ow, nMP, Pw, normal, maxDist, minDist, viewingCosLimit=0.5, stream=None):
         """Frame::isInFrustum for [F, mpCap] map points; returns dict of the MapPoint tracking fields (device tensors)."""

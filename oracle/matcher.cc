@@ -266,6 +266,75 @@ int SearchByBoW(int nKF, const uint8_t* descKF, const float* angleKF, const uint
   return nmatches;
 }
 
+// ---- ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (:702-819) ------------
+// hasMP[i] != 0 <=> vpMapPoints[i] && !isBad().  nValid = mvKeysUn.size() (features at or beyond it are skipped on
+// fisheye keyframes, :734, :751).  matches12[idx1] = idx2 of the matched pKF2 feature, or -1.
+int SearchByBoWKFKF(int n1, int nValid1, const uint8_t* desc1, const float* angle1, const uint8_t* hasMP1, const int* node1, int n2,
+                    int nValid2, const uint8_t* desc2, const float* angle2, const uint8_t* hasMP2, const int* node2,
+                    float mfNNratio, bool mbCheckOrientation, int* matches12) {
+  std::map<int, std::vector<unsigned>> vFeatVec1, vFeatVec2;
+  for (int i = 0; i < n1; ++i) if (node1[i] >= 0) vFeatVec1[node1[i]].push_back(i);
+  for (int i = 0; i < n2; ++i) if (node2[i] >= 0) vFeatVec2[node2[i]].push_back(i);
+  for (int i = 0; i < n1; ++i) matches12[i] = -1;
+  std::vector<char> vbMatched2(n2, 0);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  int nmatches = 0;
+  auto f1it = vFeatVec1.begin(), f1end = vFeatVec1.end();
+  auto f2it = vFeatVec2.begin(), f2end = vFeatVec2.end();
+  while (f1it != f1end && f2it != f2end) {
+    if (f1it->first == f2it->first) {
+      for (size_t i1 = 0, iend1 = f1it->second.size(); i1 < iend1; i1++) {
+        const size_t idx1 = f1it->second[i1];
+        if ((int)idx1 >= nValid1) continue;
+        if (!hasMP1[idx1]) continue;
+        const uint8_t* d1 = desc1 + idx1 * 32;
+        int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+        for (size_t i2 = 0, iend2 = f2it->second.size(); i2 < iend2; i2++) {
+          const size_t idx2 = f2it->second[i2];
+          if ((int)idx2 >= nValid2) continue;
+          if (vbMatched2[idx2] || !hasMP2[idx2]) continue;
+          const int dist = DescriptorDistance(d1, desc2 + idx2 * 32);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = (int)idx2; }
+          else if (dist < bestDist2) { bestDist2 = dist; }
+        }
+        if (bestDist1 < TH_LOW) {
+          if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+            matches12[idx1] = bestIdx2;
+            vbMatched2[bestIdx2] = 1;
+            if (mbCheckOrientation) {
+              float rot = angle1[idx1] - angle2[bestIdx2];
+              if (rot < 0.0) rot += 360.0f;
+              int bin = (int)std::round(rot * factor);
+              if (bin == HISTO_LENGTH) bin = 0;
+              rotHist[bin].push_back((int)idx1);
+            }
+            nmatches++;
+          }
+        }
+      }
+      f1it++;
+      f2it++;
+    } else if (f1it->first < f2it->first) {
+      f1it = vFeatVec1.lower_bound(f2it->first);
+    } else {
+      f2it = vFeatVec2.lower_bound(f1it->first);
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+        matches12[rotHist[i][j]] = -1;
+        nmatches--;
+      }
+    }
+  }
+  return nmatches;
+}
+
 // DBoW2 TemplatedVocabulary::transform(feature, word id, weight, nid, levelsup)
 // (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1218-1259): greedy descent, at each level the child with the
 // smallest Hamming distance (first minimum), nid = the ancestor at level (L - levelsup).  The tree is given as
@@ -314,6 +383,13 @@ int orc_search_by_bow(int nKF, const uint8_t* descKF, const float* angleKF, cons
                       int nF, const uint8_t* descF, const float* angleF, const int* nodeF, float nnratio, int checkOri,
                       int* matchF) {
   return SearchByBoW(nKF, descKF, angleKF, kfHasMP, nodeKF, nF, descF, angleF, nodeF, nnratio, checkOri != 0, matchF);
+}
+
+int orc_search_by_bow_kfkf(int n1, int nValid1, const uint8_t* desc1, const float* angle1, const uint8_t* hasMP1, const int* node1,
+                           int n2, int nValid2, const uint8_t* desc2, const float* angle2, const uint8_t* hasMP2, const int* node2,
+                           float nnratio, int checkOri, int* matches12) {
+  return SearchByBoWKFKF(n1, nValid1, desc1, angle1, hasMP1, node1, n2, nValid2, desc2, angle2, hasMP2, node2, nnratio, checkOri != 0,
+                         matches12);
 }
 
 int orc_search_by_bow_fisheye(int nKF, const uint8_t* descKF, const float* angleKF, const uint8_t* kfHasMP, const int* nodeKF,

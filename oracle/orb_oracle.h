@@ -48,6 +48,10 @@ void orc_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* idx, int*
 int orc_search_by_bow(int nKF, const uint8_t* descKF, const float* angleKF, const uint8_t* kfHasMP, const int* nodeKF,
                       int nF, const uint8_t* descF, const float* angleF, const int* nodeF, float nnratio, int checkOri,
                       int* matchF);
+/* SearchByBoW(pKF1, pKF2, vpMatches12) (ORBmatcher.cc:702-819) */
+int orc_search_by_bow_kfkf(int n1, int nValid1, const uint8_t* desc1, const float* angle1, const uint8_t* hasMP1, const int* node1,
+                           int n2, int nValid2, const uint8_t* desc2, const float* angle2, const uint8_t* hasMP2, const int* node2,
+                           float nnratio, int checkOri, int* matches12);
 /* SearchByBoW(pKF, F, ...) with F.Nleft = FNleft != -1 (ORBmatcher.cc:262-299, :333-365) */
 int orc_search_by_bow_fisheye(int nKF, const uint8_t* descKF, const float* angleKF, const uint8_t* kfHasMP, const int* nodeKF,
                               int nF, int FNleft, const uint8_t* descF, const float* angleF, const int* nodeF, float nnratio,

@@ -156,6 +156,17 @@ def search_by_bow(descKF, angleKF, hasMP, nodeKF, descF, angleF, nodeF, nnratio,
     return n, m[:len(descF)]
 
 
+def search_by_bow_kfkf(d1, a1, has1, node1, nv1, d2, a2, has2, node2, nv2, nnratio, checkOri):
+    L = lib()
+    L.orc_search_by_bow_kfkf.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p]
+    a = [np.ascontiguousarray(x) for x in (d1, a1.astype(np.float32), has1.astype(np.uint8), node1.astype(np.int32),
+                                           d2, a2.astype(np.float32), has2.astype(np.uint8), node2.astype(np.int32))]
+    m = np.zeros(max(len(d1), 1), np.int32)
+    n = L.orc_search_by_bow_kfkf(len(d1), int(nv1), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), len(d2), int(nv2), _p(a[4]), _p(a[5]), _p(a[6]),
+                                 _p(a[7]), nnratio, 1 if checkOri else 0, _p(m))
+    return n, m[:len(d1)]
+
+
 def search_by_bow_fisheye(descKF, angleKF, hasMP, nodeKF, descF, angleF, nodeF, FNleft, nnratio, checkOri):
     L = lib()
     a = [np.ascontiguousarray(x) for x in (descKF, angleKF.astype(np.float32), hasMP.astype(np.uint8), nodeKF.astype(np.int32),

@@ -132,6 +132,40 @@ def test_bow_transform_and_search_by_bow(batch, k, Lv, lup, settings):
         assert tot > 300
 
 
+@pytest.mark.parametrize("k,Lv,lup", [(10, 3, 1), (4, 3, 1), (3, 2, 1)])
+def test_search_by_bow_keyframes(batch, k, Lv, lup):
+    """SearchByBoW(pKF1, pKF2, vpMatches12) (:702-819): only features with a MapPoint on both sides, strict TH_LOW,
+    vbMatched2, table indexed by the pKF1 feature; mvKeysUn.size() limit of fisheye keyframes."""
+    import torch
+    from morb_slam_amd import ORBmatcher
+    vd, vf = make_vocabulary(k, Lv, seed=4)
+    desc, cnt, kps = batch["desc"], batch["cnt"], batch["kps"]
+    nimg, cap = desc.shape[0], desc.shape[1]
+    rng = np.random.default_rng(9)
+    has = (rng.random((nimg, cap)) < 0.7).astype(np.uint8)
+    cn = cnt.cpu().numpy()
+    nvalid = cn.copy(); nvalid[0] = cn[0] * 2 // 3; nvalid[4] = cn[4] // 2          # two "fisheye" keyframes
+    kf1 = torch.tensor([0, 2, 4, 1, 0], dtype=torch.int32, device="cuda")
+    kf2 = torch.tensor([4, 6, 0, 5, 0], dtype=torch.int32, device="cuda")
+    for ratio, ori in ((0.8, True), (0.6, False)):
+        m = ORBmatcher(ratio, ori)
+        _, node = m.bow_transform(desc, cnt, torch.from_numpy(vd).cuda(), torch.from_numpy(vf).cuda(), k, Lv, lup)
+        m12, nm = m.SearchByBoWKeyFrames(kf1, kf2, kps, desc, node, cnt, torch.from_numpy(has).cuda(),
+                                         nValid=torch.from_numpy(nvalid.astype(np.int32)).cuda())
+        torch.cuda.synchronize()
+        nn_, m12, nm = node.cpu().numpy(), m12.cpu().numpy(), nm.cpu().numpy()
+        tot = 0
+        for p, (a, b) in enumerate(zip(kf1.cpu().tolist(), kf2.cpu().tolist())):
+            ka, da = batch["ora"][a][1], batch["ora"][a][2]
+            kb, db = batch["ora"][b][1], batch["ora"][b][2]
+            ne, me = O.search_by_bow_kfkf(da, ka["angle"], has[a, :len(ka)], nn_[a, :len(ka)], nvalid[a], db, kb["angle"], has[b, :len(kb)],
+                                          nn_[b, :len(kb)], nvalid[b], ratio, ori)
+            assert nm[p] == ne
+            np.testing.assert_array_equal(m12[p, :len(ka)], me)
+            tot += ne
+        assert tot > 150
+
+
 # ---- projection-guided searches --------------------------------------------------------------------------
 def _scene(batch):
     """Map points = stereo-triangulated features of frame 0 (identity pose), observed again in frame 2 (a shifted copy)."""
