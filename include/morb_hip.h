@@ -318,6 +318,51 @@ int morb_search_for_triangulation_fisheye_batch(morb_matcher* m, const morb_fram
                                                 const float* T4, int bOnlyStereo, int bCoarse, int checkOri, int* d_match12,
                                                 int* d_nmatches, void* stream);
 
+/* ---- M7: loop-closing / local-mapping searches ---------------------------------------------------------
+ * Common inputs: problem f searches keyframe image d_kfImg[f] of the pool; map points are [nprob][mpCap] arrays;
+ * d_valid[f][i] != 0 <=> the point passes the reference's state checks at the top of its loop (non-null, !isBad(),
+ * !IsInKeyFrame(pKF) / !spAlreadyFound.count(pMP)); d_maxDist / d_minDist = mfMaxDistance / mfMinDistance (the 1.2 /
+ * 0.8 factors of Get{Max,Min}DistanceInvariance are applied inside); poses are quaternion xyzw + translation.
+ *
+ * ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th, bRight) (ORBmatcher.cc:1044-1213) and
+ * Fuse(KeyFrame*, Sim3f& Scw, vpPoints, th, vpReplacePoint) (:1215-1321; sim3Form != 0: no reprojection gate, the caller
+ * passes Tcw = SE3(Scw.rotationMatrix(), Scw.translation() / Scw.scale()) and Ow = Tcw.inverse().translation()).
+ * Output: d_bestIdx[f][i] = feature chosen for map point i (bestDist <= TH_LOW) or -1, d_bestDist likewise (may be NULL).
+ * The map-graph bookkeeping that follows a hit (Replace / AddObservation / AddMapPoint, :1196-1208, :1303-1310) depends on
+ * live map state and stays with the caller, which replays the reference loop over these per-point results.
+ * bRight on a fisheye rig: pass the right camera's pose / centre, cam8 = mpCamera2's KB8 parameters (host pointer, NULL =
+ * the pinhole of P), d_jLo / d_jHi = [NLeft, N) per problem (NULL = all features) and d_uRight = NULL. */
+int morb_fuse_batch(morb_matcher* m, const morb_frame_params* P, int nprob, const int* d_kfImg, int cap, const int* d_count,
+                    const morb_keypoint* d_kps, const uint8_t* d_desc, const float* d_uRight, const float* d_Tcw, const float* d_Ow,
+                    const float* cam8, const int* d_jLo, const int* d_jHi, int mpCap, const int* d_nMP, const uint8_t* d_valid,
+                    const float* d_Pw, const float* d_normal, const float* d_maxDist, const float* d_minDist,
+                    const uint8_t* d_mpDesc, float th, int sim3Form, int* d_bestIdx, int* d_bestDist, void* stream);
+
+/* ORBmatcher::SearchByProjection(KeyFrame*, Sim3f& Scw, vpPoints, vpMatched, th, ratioHamming) (:397-494) and its twin
+ * with vpPointsKFs / vpMatchedKF (:496-601, manualProjection != 0: u = fx * (X * (1 / Z)) + cx instead of
+ * mpCamera->project).  Tcw / Ow from Scw as above.  d_matched[f][idx] != 0 <=> vpMatched[idx] on entry.  Map points are
+ * visited in order; a match blocks its feature.  d_matchF[f][idx] = index of the map point newly assigned to feature idx
+ * or -1 (the caller writes vpMatched / vpMatchedKF from it); d_nmatches as returned by the reference. */
+int morb_search_by_projection_sim3_batch(morb_matcher* m, const morb_frame_params* P, int nprob, const int* d_kfImg, int cap,
+                                         const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc, const float* d_Tcw,
+                                         const float* d_Ow, int mpCap, const int* d_nMP, const uint8_t* d_valid, const float* d_Pw,
+                                         const float* d_normal, const float* d_maxDist, const float* d_minDist,
+                                         const uint8_t* d_mpDesc, const uint8_t* d_matched, int th, float ratioHamming,
+                                         int manualProjection, int* d_matchF, int* d_nmatches, void* stream);
+
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (:1323-1519).  Per pair: T1w / T2w = GetPose(); S12 and S21 =
+ * S12.inverse() as 8 floats each (RxSO3 quaternion xyzw whose squared norm is the scale, then translation).  d_valid1[p][i1]
+ * != 0 <=> vpMapPoints1[i1] && !vbAlreadyMatched1[i1] && !isBad() (likewise 2); per-feature map-point arrays are [npairs][cap].
+ * Outputs: d_vnMatch1 / d_vnMatch2 (the two one-way tables), d_match12[p][i1] = idx2 for mutually consistent pairs else -1,
+ * d_nFound. */
+int morb_search_by_sim3_batch(morb_matcher* m, const morb_frame_params* P, int npairs, const int* d_kf1Img, const int* d_kf2Img, int cap,
+                              const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc, const float* d_T1w,
+                              const float* d_T2w, const float* d_S12, const float* d_S21, const uint8_t* d_valid1, const float* d_Pw1,
+                              const float* d_maxDist1, const float* d_minDist1, const uint8_t* d_mpDesc1, const uint8_t* d_valid2,
+                              const float* d_Pw2, const float* d_maxDist2, const float* d_minDist2, const uint8_t* d_mpDesc2,
+                              float th, int* d_vnMatch1, int* d_vnMatch2, int* d_match12, int* d_nFound, void* stream);
+
+
 /* ------------------------------------------------------------------------------------------------------
  * Optimizer  (include/Optimizer.h:46-139, src/Optimizer.cc; g2o Levenberg-Marquardt semantics)
  * Poses cross the boundary the way the reference hands them to g2o: unit quaternion (x, y, z, w) followed by

@@ -117,6 +117,9 @@ def lib():
         L.morb_search_for_initialization_batch.argtypes = [vp, PP, i, vp, vp, i, vp, vp, vp, vp, i, f, i, vp, vp, vp]
         L.morb_search_for_triangulation_batch.argtypes = [vp, PP, i, vp, vp, i, i] + [vp] * 9 + [i, i, i, vp, vp, vp]
         L.morb_search_for_triangulation_fisheye_batch.argtypes = [vp, PP, i, vp, vp, vp, vp, i, i] + [vp] * 8 + [i, i, i, vp, vp, vp]
+        L.morb_fuse_batch.argtypes = [vp, PP, i, vp, i] + [vp] * 9 + [i] + [vp] * 7 + [f, i, vp, vp, vp]
+        L.morb_search_by_projection_sim3_batch.argtypes = [vp, PP, i, vp, i] + [vp] * 5 + [i] + [vp] * 8 + [i, f, i, vp, vp, vp]
+        L.morb_search_by_sim3_batch.argtypes = [vp, PP, i, vp, vp, i] + [vp] * 17 + [f, vp, vp, vp, vp, vp]
         L.morb_optimizer_create.argtypes = [C.POINTER(vp), i]
         L.morb_optimizer_destroy.argtypes = [vp]
         L.morb_optimizer_destroy.restype = None

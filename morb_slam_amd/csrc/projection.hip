@@ -70,6 +70,7 @@ struct Query {       // one window search (a map point / a last-frame feature)
   float angle;       // query keypoint angle (rotation histogram, M2)
   int valid;
   int jLo, jHi;      // feature index range searched; jHi == 0 means "all features" (fisheye rig: left | right halves)
+  int gate;          // 1: Fuse's reprojection gate (ORBmatcher.cc:1160-1181) on (x, y, xr) against the candidate keypoint
 };
 
 // key = dist << 32 | cell << 20 | j << 4 | octave   (cell = posX * 48 + posY: the GetFeaturesInArea walk order)
@@ -91,6 +92,18 @@ __device__ __forceinline__ unsigned long long make_key(const morb_frame_params& 
     if (ur > 0) {
       const float er = fabsf(q.xr - ur);
       if (er > q.erMax) return ~0ull;
+    }
+  }
+  if (q.gate == 1) {   // mvInvLevelSigma2[l] = 1.0f / mvLevelSigma2[l] (ORBextractor.cc:421)
+    const float invS = 1.0f / P.levelSigma2[kp.octave & 15];
+    const float ex = q.x - kp.x, ey = q.y - kp.y;
+    if (uRight && uRight[j] >= 0) {
+      const float er = q.xr - uRight[j];
+      const float e2 = ex * ex + ey * ey + er * er;
+      if ((double)(e2 * invS) > 7.8) return ~0ull;
+    } else {
+      const float e2 = ex * ex + ey * ey;
+      if ((double)(e2 * invS) > 5.99) return ~0ull;
     }
   }
   const int d = hamming(qd, load_desc(descRow));
@@ -325,6 +338,130 @@ __global__ __launch_bounds__(256) void k_prep_last_fisheye(morb_frame_params P, 
   }
   qs[2 * o] = ql;
   qs[2 * o + 1] = qr;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// M7: queries of the keyframe-projection searches — Fuse x2 (ORBmatcher.cc:1044-1321), SearchByProjection(KF, Sim3) x2
+// (:397-601), one direction of SearchBySim3 (:1354-1499).  One thread per map point.
+//   projMode 0: pCamera->project(p3Dc) = fx * X / Z + cx            (Fuse, SearchByProjection v1; KB8 when cam8 != NULL)
+//            1: invz = 1 / Z (float), u = fx * (X * invz) + cx       (SearchByProjection with vpPointsKFs, :531-536)
+//            2: invz = (float)(1.0 / Z), same form                    (SearchBySim3, :1373-1378)
+//   sim (8 floats per problem, RxSO3 quaternion + translation, or NULL): applied after T; then dist3D = |p| in the
+//   target camera and there is no viewing-angle test (SearchBySim3); otherwise dist3D = |Pw - Ow| and PO . Pn >= dist / 2.
+__device__ __forceinline__ void sim3_map_f(const float* S, const float* p, float* out) {   // Sophus rxso3.hpp:265-273
+  const float qx = S[0], qy = S[1], qz = S[2], qw = S[3];
+  const float scale = ((qx * qx + qy * qy) + qz * qz) + qw * qw;
+  float a = qy * p[2] - qz * p[1], b = qz * p[0] - qx * p[2], c = qx * p[1] - qy * p[0];
+  a += a; b += b; c += c;
+  out[0] = scale * p[0] + (qw * a + (qy * c - qz * b)) + S[4];
+  out[1] = scale * p[1] + (qw * b + (qz * a - qx * c)) + S[5];
+  out[2] = scale * p[2] + (qw * c + (qx * b - qy * a)) + S[6];
+}
+__global__ __launch_bounds__(256) void k_prep_kfproj(morb_frame_params P, int mpCap, const int* __restrict__ nMPv,
+                                                     const uint8_t* __restrict__ valid, const float* __restrict__ Pw,
+                                                     const float* __restrict__ normal, const float* __restrict__ maxDist,
+                                                     const float* __restrict__ minDist, const float* __restrict__ T,
+                                                     const float* __restrict__ sim, const float* __restrict__ Ow,
+                                                     const float* __restrict__ ratioThr, const float* __restrict__ kb8,
+                                                     const int* __restrict__ jLo, const int* __restrict__ jHi, float th,
+                                                     int projMode, int gate, Query* __restrict__ qs) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= mpCap) return;
+  const size_t o = (size_t)f * mpCap + i;
+  Query q;
+  memset(&q, 0, sizeof q);
+  do {
+    if (i >= nMPv[f] || !valid[o]) break;
+    const float* X = Pw + o * 3;
+    float p[3];
+    q_rotate_f(T + 7 * f, X, p);
+    p[0] += T[7 * f + 4]; p[1] += T[7 * f + 5]; p[2] += T[7 * f + 6];
+    if (sim) { float p2[3]; sim3_map_f(sim + 8 * f, p, p2); p[0] = p2[0]; p[1] = p2[1]; p[2] = p2[2]; }
+    if (p[2] < 0.0f) break;
+    float u, v;
+    if (kb8) kb8_project_dev(kb8, p, u, v);
+    else if (projMode == 0) { u = P.fx * p[0] / p[2] + P.cx; v = P.fy * p[1] / p[2] + P.cy; }
+    else {
+      const float invz = projMode == 1 ? 1 / p[2] : (float)(1.0 / (double)p[2]);
+      const float x = p[0] * invz, y = p[1] * invz;
+      u = P.fx * x + P.cx; v = P.fy * y + P.cy;
+    }
+    if (!(u >= P.minX && u < P.maxX && v >= P.minY && v < P.maxY)) break;          // KeyFrame::IsInImage
+    const float maxDistance = 1.2f * maxDist[o], minDistance = 0.8f * minDist[o];
+    float dist3D;
+    if (sim) dist3D = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    else {
+      const float* O = Ow + 3 * f;
+      const float PO[3] = {X[0] - O[0], X[1] - O[1], X[2] - O[2]};
+      dist3D = sqrtf(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+      if (dist3D < minDistance || dist3D > maxDistance) break;
+      const float* Pn = normal + o * 3;
+      if ((double)(PO[0] * Pn[0] + PO[1] * Pn[1] + PO[2] * Pn[2]) < 0.5 * (double)dist3D) break;
+    }
+    if (dist3D < minDistance || dist3D > maxDistance) break;
+    const float ratio = maxDist[o] / dist3D;       // MapPoint::PredictScale through the host-built threshold table
+    int lvl = 0;
+    while (lvl < P.nlevels - 1 && ratio > ratioThr[lvl]) ++lvl;
+    q.valid = 1; q.x = u; q.y = v; q.r = th * P.scaleFactors[lvl];
+    q.minLevel = lvl - 1; q.maxLevel = lvl;
+    q.xr = u - P.mbf * (1 / p[2]); q.erMax = 3.4e38f;   // ur of Fuse's gate; the M1 / M2 stereo-window gate never fires
+    q.gate = gate;
+    if (jHi) { q.jLo = jLo[f]; q.jHi = jHi[f]; }
+  } while (0);
+  qs[o] = q;
+}
+
+// Best candidate of every query, queries independent of each other (no "already taken" state): one wave per query.
+__global__ __launch_bounds__(256) void k_best_per_query(morb_frame_params P, int qCap, const Query* __restrict__ qs,
+                                                        const uint8_t* __restrict__ qDesc, const int* __restrict__ fImg, int cap,
+                                                        const int* __restrict__ count, const morb_keypoint* __restrict__ kps,
+                                                        const uint8_t* __restrict__ desc, const float* __restrict__ uRight,
+                                                        const unsigned long long* __restrict__ cand,
+                                                        const int* __restrict__ candCnt, int thAccept, int* __restrict__ bestIdx,
+                                                        int* __restrict__ bestDist) {
+  const int f = blockIdx.y, lane = threadIdx.x & 63;
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= qCap) return;
+  const size_t qo = (size_t)f * qCap + qi;
+  const int cnt = candCnt[qo];
+  unsigned long long best = ~0ull;
+  if (cnt > 0 && cnt <= CAND_CAP) {
+    for (int c = lane; c < cnt; c += 64) { const unsigned long long k = cand[qo * CAND_CAP + c]; best = k < best ? k : best; }
+  } else if (cnt > CAND_CAP) {   // dense window: derive the keys again from the features
+    const Query q = qs[qo];
+    int cx0, cx1, cy0, cy1;
+    cell_range(P, q, cx0, cx1, cy0, cy1);
+    const int img = fImg[f], N = count[img];
+    const Desc qd = load_desc(qDesc + qo * 32);
+    const float* ur = uRight ? uRight + (size_t)f * cap : nullptr;
+    const int jLo = q.jHi > 0 ? q.jLo : 0, jHi = q.jHi > 0 ? min(q.jHi, N) : N;
+    for (int j = jLo + lane; j < jHi; j += 64) {
+      const unsigned long long k = make_key(P, q, qd, kps[(size_t)img * cap + j], j, desc + ((size_t)img * cap + j) * 32, ur, cx0, cx1, cy0, cy1);
+      best = k < best ? k : best;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(best, off, 64); best = o < best ? o : best; }
+  if (lane == 0) {
+    const bool ok = best != ~0ull && (int)(best >> 32) <= thAccept;
+    bestIdx[qo] = ok ? (int)((best >> 4) & 0xFFFF) : -1;
+    if (bestDist) bestDist[qo] = ok ? (int)(best >> 32) : -1;
+  }
+}
+
+// SearchBySim3's agreement check (:1501-1516): match12[i1] = idx2 iff vnMatch1[i1] == idx2 and vnMatch2[idx2] == i1
+__global__ __launch_bounds__(256) void k_sim3_agree(int cap, const int* __restrict__ vn1, const int* __restrict__ vn2,
+                                                    int* __restrict__ match12, int* __restrict__ nFound) {
+  const int f = blockIdx.y, i1 = blockIdx.x * 256 + threadIdx.x;
+  int hit = 0;
+  if (i1 < cap) {
+    const int idx2 = vn1[(size_t)f * cap + i1];
+    int r = -1;
+    if (idx2 >= 0 && vn2[(size_t)f * cap + idx2] == i1) { r = idx2; hit = 1; }
+    match12[(size_t)f * cap + i1] = r;
+  }
+  const int n = __syncthreads_count(hit);
+  if (threadIdx.x == 0 && n) atomicAdd(&nFound[f], n);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1027,6 +1164,139 @@ __global__ __launch_bounds__(256) void k_rot_filter12(const int* __restrict__ co
   if (tid == 0) nmatches[pair] = total;
 }
 }  // namespace
+
+// ---- M7 host side ---------------------------------------------------------------------------------------------------
+static int upload_ratio_thresholds(morb_matcher* m, const morb_frame_params* P, const float* cam8, hipStream_t st, const float** d_thr,
+                                   const float** d_kb8) {
+  float thr[24];
+  for (int n = 0; n < 16; ++n) thr[n] = n < P->nlevels - 1 ? ratio_threshold(n, P->logScaleFactor) : 3.4e38f;
+  for (int n = 0; n < 8; ++n) thr[16 + n] = cam8 ? cam8[n] : 0.f;
+  void* d = nullptr;
+  int rc = morb_matcher_workspace(m, 4, sizeof thr, &d);
+  if (rc != MORB_OK) return rc;
+  MORB_HIP_CHECK(hipMemcpyAsync(d, thr, sizeof thr, hipMemcpyHostToDevice, st));
+  MORB_HIP_CHECK(hipStreamSynchronize(st));  // thr lives on this stack frame
+  *d_thr = (const float*)d;
+  *d_kb8 = cam8 ? (const float*)d + 16 : nullptr;
+  return MORB_OK;
+}
+
+// queries -> candidate keys (workspaces 0 / 1 / 5)
+static int kfproj_candidates(morb_matcher* m, const morb_frame_params* P, int nprob, const int* d_kfImg, int cap, const int* d_count,
+                             const morb_keypoint* d_kps, const uint8_t* d_desc, const float* d_uRight, int mpCap, const int* d_nMP,
+                             const uint8_t* d_valid, const float* d_Pw, const float* d_normal, const float* d_maxDist,
+                             const float* d_minDist, const uint8_t* d_mpDesc, const float* d_T, const float* d_sim, const float* d_Ow,
+                             const float* cam8, const int* d_jLo, const int* d_jHi, float th, int projMode, int gate, hipStream_t st,
+                             const Query** qsOut, const unsigned long long** candOut, const int** cntOut) {
+  const float *d_thr = nullptr, *d_kb8 = nullptr;
+  int rc = upload_ratio_thresholds(m, P, cam8, st, &d_thr, &d_kb8);
+  if (rc != MORB_OK) return rc;
+  void *qs = nullptr, *cand = nullptr, *cnt = nullptr;
+  rc = morb_matcher_workspace(m, 5, sizeof(Query) * (size_t)nprob * mpCap, &qs);
+  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 0, sizeof(unsigned long long) * (size_t)nprob * mpCap * CAND_CAP, &cand);
+  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 1, sizeof(int) * (size_t)nprob * mpCap, &cnt);
+  if (rc != MORB_OK) return rc;
+  hipLaunchKernelGGL(k_prep_kfproj, dim3(div_up(mpCap, 256), nprob), dim3(256), 0, st, *P, mpCap, d_nMP, d_valid, d_Pw, d_normal,
+                     d_maxDist, d_minDist, d_T, d_sim, d_Ow, d_thr, d_kb8, d_jLo, d_jHi, th, projMode, gate, (Query*)qs);
+  hipLaunchKernelGGL(k_candidates, dim3(div_up(mpCap, 4), nprob), dim3(256), 0, st, *P, mpCap, (const Query*)qs, d_mpDesc, d_kfImg, cap,
+                     d_count, d_kps, d_desc, d_uRight, (unsigned long long*)cand, (int*)cnt, 0);
+  *qsOut = (const Query*)qs; *candOut = (const unsigned long long*)cand; *cntOut = (const int*)cnt;
+  return MORB_OK;
+}
+
+extern "C" int morb_fuse_batch(morb_matcher* m, const morb_frame_params* P, int nprob, const int* d_kfImg, int cap, const int* d_count,
+                               const morb_keypoint* d_kps, const uint8_t* d_desc, const float* d_uRight, const float* d_Tcw,
+                               const float* d_Ow, const float* cam8, const int* d_jLo, const int* d_jHi, int mpCap, const int* d_nMP,
+                               const uint8_t* d_valid, const float* d_Pw, const float* d_normal, const float* d_maxDist,
+                               const float* d_minDist, const uint8_t* d_mpDesc, float th, int sim3Form, int* d_bestIdx,
+                               int* d_bestDist, void* stream) {
+  MORB_REQUIRE(m && P && d_kfImg && d_count && d_kps && d_desc && d_Tcw && d_Ow && d_nMP && d_valid && d_Pw && d_normal && d_maxDist &&
+                   d_minDist && d_mpDesc && d_bestIdx, MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(nprob > 0 && cap > 0 && cap <= 65535 && mpCap > 0 && P->nlevels >= 1 && P->nlevels <= 16, MORB_ERR_INVALID, "bad sizes");
+  MORB_REQUIRE((d_jLo == nullptr) == (d_jHi == nullptr), MORB_ERR_INVALID, "feature range needs both ends");
+  MORB_HIP_CHECK(hipSetDevice(morb_matcher_device(m)));
+  hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
+  const Query* qs; const unsigned long long* cand; const int* cnt;
+  int rc = kfproj_candidates(m, P, nprob, d_kfImg, cap, d_count, d_kps, d_desc, d_uRight, mpCap, d_nMP, d_valid, d_Pw, d_normal,
+                             d_maxDist, d_minDist, d_mpDesc, d_Tcw, nullptr, d_Ow, cam8, d_jLo, d_jHi, th, 0, sim3Form ? 0 : 1, st, &qs,
+                             &cand, &cnt);
+  if (rc != MORB_OK) return rc;
+  hipLaunchKernelGGL(k_best_per_query, dim3(div_up(mpCap, 4), nprob), dim3(256), 0, st, *P, mpCap, qs, d_mpDesc, d_kfImg, cap, d_count,
+                     d_kps, d_desc, d_uRight, cand, cnt, TH_LOW, d_bestIdx, d_bestDist);
+  MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}
+
+extern "C" int morb_search_by_projection_sim3_batch(morb_matcher* m, const morb_frame_params* P, int nprob, const int* d_kfImg, int cap,
+                                                    const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc,
+                                                    const float* d_Tcw, const float* d_Ow, int mpCap, const int* d_nMP,
+                                                    const uint8_t* d_valid, const float* d_Pw, const float* d_normal,
+                                                    const float* d_maxDist, const float* d_minDist, const uint8_t* d_mpDesc,
+                                                    const uint8_t* d_matched, int th, float ratioHamming, int manualProjection,
+                                                    int* d_matchF, int* d_nmatches, void* stream) {
+  MORB_REQUIRE(m && P && d_kfImg && d_count && d_kps && d_desc && d_Tcw && d_Ow && d_nMP && d_valid && d_Pw && d_normal && d_maxDist &&
+                   d_minDist && d_mpDesc && d_matched && d_matchF && d_nmatches, MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(nprob > 0 && cap > 0 && cap <= 65535 && mpCap > 0 && P->nlevels >= 1 && P->nlevels <= 16, MORB_ERR_INVALID, "bad sizes");
+  MORB_HIP_CHECK(hipSetDevice(morb_matcher_device(m)));
+  hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
+  const Query* qs; const unsigned long long* cand; const int* cnt;
+  int rc = kfproj_candidates(m, P, nprob, d_kfImg, cap, d_count, d_kps, d_desc, nullptr, mpCap, d_nMP, d_valid, d_Pw, d_normal, d_maxDist,
+                             d_minDist, d_mpDesc, d_Tcw, nullptr, d_Ow, nullptr, nullptr, nullptr, (float)th, manualProjection ? 1 : 0, 0,
+                             st, &qs, &cand, &cnt);
+  if (rc != MORB_OK) return rc;
+  void *ej = nullptr, *eb = nullptr;
+  rc = morb_matcher_workspace(m, 2, sizeof(int) * (size_t)nprob * mpCap, &ej);
+  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 3, sizeof(int) * (size_t)nprob * mpCap, &eb);
+  if (rc != MORB_OK) return rc;
+  // bestDist <= TH_LOW * ratioHamming (int vs float product, :486 / :593) == bestDist <= floor(TH_LOW * ratioHamming)
+  const int thAccept = (int)floorf((float)TH_LOW * ratioHamming);
+  MORB_HIP_CHECK(hipMemsetAsync(d_matchF, 0xFF, sizeof(int) * (size_t)nprob * cap, st));   // -1 everywhere
+  // the sequential pass: features already holding a match are skipped and a new match blocks its feature (:466, :487)
+  hipLaunchKernelGGL(k_resolve<0>, dim3(nprob), dim3(64), (size_t)cap, st, *P, mpCap, d_nMP, qs, d_mpDesc, (const uint8_t*)nullptr,
+                     d_kfImg, cap, d_count, d_kps, d_desc, (const float*)nullptr, d_matched, cand, cnt, 0.f, thAccept, 0, d_matchF,
+                     d_nmatches, (int*)ej, (int*)eb, (float*)nullptr, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr);
+  MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}
+
+extern "C" int morb_search_by_sim3_batch(morb_matcher* m, const morb_frame_params* P, int npairs, const int* d_kf1Img,
+                                         const int* d_kf2Img, int cap, const int* d_count, const morb_keypoint* d_kps,
+                                         const uint8_t* d_desc, const float* d_T1w, const float* d_T2w, const float* d_S12,
+                                         const float* d_S21, const uint8_t* d_valid1, const float* d_Pw1, const float* d_maxDist1,
+                                         const float* d_minDist1, const uint8_t* d_mpDesc1, const uint8_t* d_valid2,
+                                         const float* d_Pw2, const float* d_maxDist2, const float* d_minDist2,
+                                         const uint8_t* d_mpDesc2, float th, int* d_vnMatch1, int* d_vnMatch2, int* d_match12,
+                                         int* d_nFound, void* stream) {
+  MORB_REQUIRE(m && P && d_kf1Img && d_kf2Img && d_count && d_kps && d_desc && d_T1w && d_T2w && d_S12 && d_S21 && d_valid1 && d_Pw1 &&
+                   d_maxDist1 && d_minDist1 && d_mpDesc1 && d_valid2 && d_Pw2 && d_maxDist2 && d_minDist2 && d_mpDesc2 && d_vnMatch1 &&
+                   d_vnMatch2 && d_match12 && d_nFound, MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(npairs > 0 && cap > 0 && cap <= 65535 && P->nlevels >= 1 && P->nlevels <= 16, MORB_ERR_INVALID, "bad sizes");
+  MORB_HIP_CHECK(hipSetDevice(morb_matcher_device(m)));
+  hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
+  void* nq = nullptr;
+  int rc = morb_matcher_workspace(m, 6, sizeof(int) * (size_t)npairs * 2, &nq);
+  if (rc != MORB_OK) return rc;
+  int* n1 = (int*)nq; int* n2 = n1 + npairs;
+  hipLaunchKernelGGL(k_gather_counts, dim3(div_up(npairs, 256)), dim3(256), 0, st, d_count, d_kf1Img, npairs, n1);
+  hipLaunchKernelGGL(k_gather_counts, dim3(div_up(npairs, 256)), dim3(256), 0, st, d_count, d_kf2Img, npairs, n2);
+  const Query* qs; const unsigned long long* cand; const int* cnt;
+  // map points of keyframe 1 -> camera 1 -> camera 2 (S21) -> keyframe 2's features (:1354-1425)
+  rc = kfproj_candidates(m, P, npairs, d_kf2Img, cap, d_count, d_kps, d_desc, nullptr, cap, n1, d_valid1, d_Pw1, nullptr, d_maxDist1,
+                         d_minDist1, d_mpDesc1, d_T1w, d_S21, nullptr, nullptr, nullptr, nullptr, th, 2, 0, st, &qs, &cand, &cnt);
+  if (rc != MORB_OK) return rc;
+  hipLaunchKernelGGL(k_best_per_query, dim3(div_up(cap, 4), npairs), dim3(256), 0, st, *P, cap, qs, d_mpDesc1, d_kf2Img, cap, d_count,
+                     d_kps, d_desc, (const float*)nullptr, cand, cnt, TH_HIGH, d_vnMatch1, (int*)nullptr);
+  // and the other way round (:1428-1499)
+  rc = kfproj_candidates(m, P, npairs, d_kf1Img, cap, d_count, d_kps, d_desc, nullptr, cap, n2, d_valid2, d_Pw2, nullptr, d_maxDist2,
+                         d_minDist2, d_mpDesc2, d_T2w, d_S12, nullptr, nullptr, nullptr, nullptr, th, 2, 0, st, &qs, &cand, &cnt);
+  if (rc != MORB_OK) return rc;
+  hipLaunchKernelGGL(k_best_per_query, dim3(div_up(cap, 4), npairs), dim3(256), 0, st, *P, cap, qs, d_mpDesc2, d_kf1Img, cap, d_count,
+                     d_kps, d_desc, (const float*)nullptr, cand, cnt, TH_HIGH, d_vnMatch2, (int*)nullptr);
+  MORB_HIP_CHECK(hipMemsetAsync(d_nFound, 0, sizeof(int) * npairs, st));
+  hipLaunchKernelGGL(k_sim3_agree, dim3(div_up(cap, 256), npairs), dim3(256), 0, st, cap, d_vnMatch1, d_vnMatch2, d_match12, d_nFound);
+  MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}
 
 extern "C" int morb_search_for_triangulation_batch(morb_matcher* m, const morb_frame_params* P, int npairs, const int* d_img1,
                                                    const int* d_img2, int nimg, int cap, const int* d_count,

@@ -105,6 +105,46 @@ class ORBmatcher:
                                                     1 if self.mbCheckOrientation else 0, ptr(out[0]), ptr(out[1]), self._st(stream)))
         return out
 
+    # ---- M7: loop-closing / local-mapping searches ---------------------------------------------------------
+    def Fuse(self, params, kfImg, kps, desc, count, uRight, Tcw, Ow, nMP, valid, Pw, normal, maxDist, minDist, mpDesc, th=3.0,
+             sim3Form=False, cam8=None, jLo=None, jHi=None, stream=None):
+        """The search of ORBmatcher::Fuse (both overloads): (bestIdx, bestDist) int32 [nprob, mpCap]."""
+        import torch
+        F, cap, mpCap = kfImg.shape[0], kps.shape[1], mpDesc.shape[1]
+        bi = torch.empty((F, mpCap), dtype=torch.int32, device=kps.device); bd = torch.empty_like(bi)
+        cam = None if cam8 is None else np.ascontiguousarray(cam8, np.float32)
+        check(self._L.morb_fuse_batch(self._h, C.byref(params), F, ptr(kfImg), cap, ptr(count), ptr(kps), ptr(desc), ptr(uRight), ptr(Tcw),
+                                      ptr(Ow), ptr(cam), ptr(jLo), ptr(jHi), mpCap, ptr(nMP), ptr(valid), ptr(Pw), ptr(normal),
+                                      ptr(maxDist), ptr(minDist), ptr(mpDesc), float(th), 1 if sim3Form else 0, ptr(bi), ptr(bd),
+                                      self._st(stream)))
+        return bi, bd
+
+    def SearchByProjectionSim3(self, params, kfImg, kps, desc, count, Tcw, Ow, nMP, valid, Pw, normal, maxDist, minDist, mpDesc, matched,
+                               th, ratioHamming=1.0, manualProjection=False, stream=None):
+        """SearchByProjection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming) (and the vpPointsKFs twin)."""
+        import torch
+        F, cap, mpCap = kfImg.shape[0], kps.shape[1], mpDesc.shape[1]
+        mf = torch.empty((F, cap), dtype=torch.int32, device=kps.device); nm = torch.zeros((F,), dtype=torch.int32, device=kps.device)
+        check(self._L.morb_search_by_projection_sim3_batch(self._h, C.byref(params), F, ptr(kfImg), cap, ptr(count), ptr(kps), ptr(desc),
+                                                           ptr(Tcw), ptr(Ow), mpCap, ptr(nMP), ptr(valid), ptr(Pw), ptr(normal),
+                                                           ptr(maxDist), ptr(minDist), ptr(mpDesc), ptr(matched), int(th),
+                                                           float(ratioHamming), 1 if manualProjection else 0, ptr(mf), ptr(nm),
+                                                           self._st(stream)))
+        return mf, nm
+
+    def SearchBySim3(self, params, kf1, kf2, kps, desc, count, T1w, T2w, S12, S21, valid1, Pw1, maxD1, minD1, mpDesc1, valid2, Pw2, maxD2,
+                     minD2, mpDesc2, th, stream=None):
+        """SearchBySim3(pKF1, pKF2, vpMatches12, S12, th): (vnMatch1, vnMatch2, match12, nFound)."""
+        import torch
+        F, cap = kf1.shape[0], kps.shape[1]
+        v1 = torch.empty((F, cap), dtype=torch.int32, device=kps.device); v2 = torch.empty_like(v1); m12 = torch.empty_like(v1)
+        nf = torch.zeros((F,), dtype=torch.int32, device=kps.device)
+        check(self._L.morb_search_by_sim3_batch(self._h, C.byref(params), F, ptr(kf1), ptr(kf2), cap, ptr(count), ptr(kps), ptr(desc),
+                                                ptr(T1w), ptr(T2w), ptr(S12), ptr(S21), ptr(valid1), ptr(Pw1), ptr(maxD1), ptr(minD1),
+                                                ptr(mpDesc1), ptr(valid2), ptr(Pw2), ptr(maxD2), ptr(minD2), ptr(mpDesc2), float(th),
+                                                ptr(v1), ptr(v2), ptr(m12), ptr(nf), self._st(stream)))
+        return v1, v2, m12, nf
+
     # ---- projection-guided searches (projection.hip) ------------------------------------------------------
     def isInFrustum(self, params, Rcw, tcw, Ow, nMP, Pw, normal, maxDist, minDist, viewingCosLimit=0.5, stream=None):
         """Frame::isInFrustum for [F, mpCap] map points; returns dict of the MapPoint tracking fields (device tensors)."""

@@ -110,6 +110,16 @@ int orc_search_for_triangulation_fisheye(int n1, int NLeft1, const orc_keypoint*
                                          int* matches12);
 float orc_kb8_triangulate_matches(const float* cam1_8, const float* cam2_8, float x1, float y1, float x2, float y2, const float* R12,
                                   const float* t12, float sigmaLevel, float unc, float* p3D);
+/* M7 (N2): Fuse x2, SearchByProjection(KF, Sim3) x2, one direction of SearchBySim3 (ORBmatcher.cc:397-601, :1044-1519) */
+void orc_fuse_search(const orc_frame* KF, const float* invLevelSigma2, const float* Tcw7, const float* Ow, int nMP, const uint8_t* valid,
+                     const float* Pw, const float* normal, const float* maxDist, const float* minDist, const uint8_t* mpDesc, float th,
+                     int sim3Form, int* bestIdx, int* bestDist);
+int orc_search_by_projection_sim3(const orc_frame* KF, const float* Tcw7, const float* Ow, int nMP, const uint8_t* valid,
+                                  const float* Pw, const float* normal, const float* maxDist, const float* minDist,
+                                  const uint8_t* mpDesc, const uint8_t* matchedIn, int th, float ratioHamming, int manualProjection,
+                                  int* matchF);
+void orc_search_by_sim3_dir(const orc_frame* B, const float* TAw7, const float* SBA8, int nA, const uint8_t* valid, const float* Pw,
+                            const float* maxDist, const float* minDist, const uint8_t* mpDesc, float th, int* vnMatch);
 void orc_kb8_project_f(const float* cam8, const float* v3, float* uv);
 void orc_kb8_project_d(const float* cam8, const double* v3, double* uv);
 void orc_kb8_unproject(const float* cam8, float x, float y, float* ray);

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "cvprims.h"
+#include <climits>
 #include "matcher.h"
 #include "orb_oracle.h"
 
@@ -778,6 +779,188 @@ int SearchForTriangulationFisheye(int n1, int NLeft1, const KeyPoint* kps1, cons
   return nmatches;
 }
 
+// =====================================================================================================================
+// M7 ("next" row N2): the loop-closing / local-mapping variants of project -> window -> best Hamming.
+// What is restated here is each method's search; the map-graph bookkeeping that follows a hit (Replace / AddObservation
+// / AddMapPoint, ORBmatcher.cc:1196-1208, :1303-1310) stays with the caller and is replayed from the per-point results.
+// =====================================================================================================================
+// KeyFrame::GetFeaturesInArea (KeyFrame.cc:729-774): the Frame version without the level filter.
+static std::vector<size_t> KFGetFeaturesInArea(const orc_frame& F, const Grid& g, float x, float y, float r) {
+  return GetFeaturesInArea(F, g, x, y, r, -1, -1);   // bCheckLevels = (minLevel > 0) || (maxLevel >= 0) = false
+}
+static bool KFIsInImage(const orc_frame& F, float x, float y) { return x >= F.minX && x < F.maxX && y >= F.minY && y < F.maxY; }
+static int PredictScaleKF(const orc_frame& F, float mfMaxDistance, float dist) {   // MapPoint.cc:536-550
+  const float ratio = mfMaxDistance / dist;
+  int nScale = (int)std::ceil(std::log(ratio) / F.logScaleFactor);
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= F.nlevels) nScale = F.nlevels - 1;
+  return nScale;
+}
+
+// ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th, bRight) (:1044-1213) with bRight == false on a pinhole
+// keyframe, and Fuse(KeyFrame*, Sim3f& Scw, vpPoints, th, vpReplacePoint) (:1215-1321) with sim3Form (no chi2 gate;
+// the caller passes Tcw = SE3(Scw.rotationMatrix(), Scw.translation() / Scw.scale()) and Ow = Tcw.inverse().translation()).
+// valid[i] = the point passes the reference's state checks (non-null, !isBad(), !IsInKeyFrame / !spAlreadyFound).
+// bestIdx[i] = feature chosen for map point i (bestDist <= TH_LOW) or -1.
+void FuseSearch(const orc_frame& KF, const float* invLevelSigma2, const float* Tcw7, const float* Ow, int nMP,
+                const uint8_t* valid, const float* Pw, const float* normal, const float* mfMaxDistance,
+                const float* mfMinDistance, const uint8_t* mpDesc, float th, bool sim3Form, int* bestIdxOut, int* bestDistOut) {
+  Grid g;
+  AssignFeaturesToGrid(KF, g);
+  const KeyPoint* k = (const KeyPoint*)KF.kpsUn;
+  for (int i = 0; i < nMP; i++) {
+    bestIdxOut[i] = -1; bestDistOut[i] = -1;
+    if (!valid[i]) continue;
+    const float* p3Dw = Pw + 3 * i;
+    float p3Dc[3];
+    rotateF(Tcw7, p3Dw, p3Dc);
+    p3Dc[0] += Tcw7[4]; p3Dc[1] += Tcw7[5]; p3Dc[2] += Tcw7[6];
+    if (p3Dc[2] < 0.0f) continue;
+    const float invz = 1 / p3Dc[2];
+    const float u = KF.fx * p3Dc[0] / p3Dc[2] + KF.cx, v = KF.fy * p3Dc[1] / p3Dc[2] + KF.cy;   // pCamera->project
+    if (!KFIsInImage(KF, u, v)) continue;
+    const float ur = u - KF.mbf * invz;
+    const float maxDistance = 1.2f * mfMaxDistance[i], minDistance = 0.8f * mfMinDistance[i];
+    const float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
+    const float dist3D = std::sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    const float* Pn = normal + 3 * i;
+    if ((PO[0] * Pn[0] + PO[1] * Pn[1] + PO[2] * Pn[2]) < 0.5 * dist3D) continue;
+    const int nPredictedLevel = PredictScaleKF(KF, mfMaxDistance[i], dist3D);
+    const float radius = th * KF.scaleFactors[nPredictedLevel];
+    const std::vector<size_t> vIndices = KFGetFeaturesInArea(KF, g, u, v, radius);
+    if (vIndices.empty()) continue;
+    const uint8_t* dMP = mpDesc + (size_t)i * 32;
+    int bestDist = sim3Form ? INT_MAX : 256, bestIdx = -1;
+    for (size_t q = 0; q < vIndices.size(); ++q) {
+      const size_t idx = vIndices[q];
+      const KeyPoint& kp = k[idx];
+      const int kpLevel = kp.octave;
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      if (!sim3Form) {
+        if (KF.uRight && KF.uRight[idx] >= 0) {
+          const float ex = u - kp.x, ey = v - kp.y, er = ur - KF.uRight[idx];
+          const float e2 = ex * ex + ey * ey + er * er;
+          if (e2 * invLevelSigma2[kpLevel] > 7.8) continue;
+        } else {
+          const float ex = u - kp.x, ey = v - kp.y;
+          const float e2 = ex * ex + ey * ey;
+          if (e2 * invLevelSigma2[kpLevel] > 5.99) continue;
+        }
+      }
+      const int dist = DescriptorDistance(dMP, KF.desc + idx * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+    }
+    if (bestDist <= TH_LOW) { bestIdxOut[i] = bestIdx; bestDistOut[i] = bestDist; }
+  }
+}
+
+// ORBmatcher::SearchByProjection(KeyFrame*, Sim3f& Scw, vpPoints, vpMatched, th, ratioHamming) (:397-494) and its twin
+// with vpPointsKFs / vpMatchedKF (:496-601; manualProjection: u = fx * (X * invz) + cx instead of mpCamera->project).
+// matched[idx] != 0 <=> vpMatched[idx] on entry; matchF[idx] = index of the map point newly assigned to feature idx.
+int SearchByProjectionSim3(const orc_frame& KF, const float* Tcw7, const float* Ow, int nMP, const uint8_t* valid,
+                           const float* Pw, const float* normal, const float* mfMaxDistance, const float* mfMinDistance,
+                           const uint8_t* mpDesc, const uint8_t* matchedIn, int th, float ratioHamming, bool manualProjection,
+                           int* matchF) {
+  Grid g;
+  AssignFeaturesToGrid(KF, g);
+  const KeyPoint* k = (const KeyPoint*)KF.kpsUn;
+  std::vector<char> vpMatched(matchedIn, matchedIn + KF.N);
+  for (int i = 0; i < KF.N; ++i) matchF[i] = -1;
+  int nmatches = 0;
+  for (int iMP = 0; iMP < nMP; iMP++) {
+    if (!valid[iMP]) continue;
+    const float* p3Dw = Pw + 3 * iMP;
+    float p3Dc[3];
+    rotateF(Tcw7, p3Dw, p3Dc);
+    p3Dc[0] += Tcw7[4]; p3Dc[1] += Tcw7[5]; p3Dc[2] += Tcw7[6];
+    if (p3Dc[2] < 0.0) continue;
+    float u, v;
+    if (manualProjection) {
+      const float invz = 1 / p3Dc[2];
+      const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+      u = KF.fx * x + KF.cx; v = KF.fy * y + KF.cy;
+    } else {
+      u = KF.fx * p3Dc[0] / p3Dc[2] + KF.cx; v = KF.fy * p3Dc[1] / p3Dc[2] + KF.cy;
+    }
+    if (!KFIsInImage(KF, u, v)) continue;
+    const float maxDistance = 1.2f * mfMaxDistance[iMP], minDistance = 0.8f * mfMinDistance[iMP];
+    const float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
+    const float dist = std::sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+    if (dist < minDistance || dist > maxDistance) continue;
+    const float* Pn = normal + 3 * iMP;
+    if ((PO[0] * Pn[0] + PO[1] * Pn[1] + PO[2] * Pn[2]) < 0.5 * dist) continue;
+    const int nPredictedLevel = PredictScaleKF(KF, mfMaxDistance[iMP], dist);
+    const float radius = th * KF.scaleFactors[nPredictedLevel];
+    const std::vector<size_t> vIndices = KFGetFeaturesInArea(KF, g, u, v, radius);
+    if (vIndices.empty()) continue;
+    const uint8_t* dMP = mpDesc + (size_t)iMP * 32;
+    int bestDist = 256, bestIdx = -1;
+    for (size_t q = 0; q < vIndices.size(); ++q) {
+      const size_t idx = vIndices[q];
+      if (vpMatched[idx]) continue;
+      const int kpLevel = k[idx].octave;
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      const int dist2 = DescriptorDistance(dMP, KF.desc + idx * 32);
+      if (dist2 < bestDist) { bestDist = dist2; bestIdx = (int)idx; }
+    }
+    if (bestDist <= TH_LOW * ratioHamming) {
+      vpMatched[bestIdx] = 1;
+      matchF[bestIdx] = iMP;
+      nmatches++;
+    }
+  }
+  return nmatches;
+}
+
+// One direction of ORBmatcher::SearchBySim3 (:1354-1425 / :1428-1499): map points of keyframe A (valid = has a MapPoint,
+// !isBad(), !vbAlreadyMatched) -> camera A (TAw) -> camera B through the similarity S_BA -> window in keyframe B.
+// Sim3 = RxSO3 quaternion (x y z w, squared norm = scale) + translation; Sophus rxso3.hpp:265-273.
+static void sim3Map(const float* S8, const float* p, float* out) {
+  const float qx = S8[0], qy = S8[1], qz = S8[2], qw = S8[3];
+  const float scale = ((qx * qx + qy * qy) + qz * qz) + qw * qw;
+  float a = qy * p[2] - qz * p[1], b = qz * p[0] - qx * p[2], c = qx * p[1] - qy * p[0];
+  a += a; b += b; c += c;
+  out[0] = scale * p[0] + (qw * a + (qy * c - qz * b)) + S8[4];
+  out[1] = scale * p[1] + (qw * b + (qz * a - qx * c)) + S8[5];
+  out[2] = scale * p[2] + (qw * c + (qx * b - qy * a)) + S8[6];
+}
+void SearchBySim3Dir(const orc_frame& B, const float* TAw7, const float* SBA8, int nA, const uint8_t* valid, const float* Pw,
+                     const float* mfMaxDistance, const float* mfMinDistance, const uint8_t* mpDesc, float th, int* vnMatch) {
+  Grid g;
+  AssignFeaturesToGrid(B, g);
+  const KeyPoint* k = (const KeyPoint*)B.kpsUn;
+  for (int i = 0; i < nA; i++) {
+    vnMatch[i] = -1;
+    if (!valid[i]) continue;
+    float pA[3], pB[3];
+    rotateF(TAw7, Pw + 3 * i, pA);
+    pA[0] += TAw7[4]; pA[1] += TAw7[5]; pA[2] += TAw7[6];
+    sim3Map(SBA8, pA, pB);
+    if (pB[2] < 0.0) continue;
+    const float invz = (float)(1.0 / pB[2]);
+    const float x = pB[0] * invz, y = pB[1] * invz;
+    const float u = B.fx * x + B.cx, v = B.fy * y + B.cy;
+    if (!KFIsInImage(B, u, v)) continue;
+    const float maxDistance = 1.2f * mfMaxDistance[i], minDistance = 0.8f * mfMinDistance[i];
+    const float dist3D = std::sqrt(pB[0] * pB[0] + pB[1] * pB[1] + pB[2] * pB[2]);
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    const int nPredictedLevel = PredictScaleKF(B, mfMaxDistance[i], dist3D);
+    const float radius = th * B.scaleFactors[nPredictedLevel];
+    const std::vector<size_t> vIndices = KFGetFeaturesInArea(B, g, u, v, radius);
+    if (vIndices.empty()) continue;
+    const uint8_t* dMP = mpDesc + (size_t)i * 32;
+    int bestDist = INT_MAX, bestIdx = -1;
+    for (size_t q = 0; q < vIndices.size(); ++q) {
+      const size_t idx = vIndices[q];
+      if (k[idx].octave < nPredictedLevel - 1 || k[idx].octave > nPredictedLevel) continue;
+      const int dist = DescriptorDistance(dMP, B.desc + idx * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+    }
+    if (bestDist <= TH_HIGH) vnMatch[i] = bestIdx;
+  }
+}
+
 }  // namespace orc
 
 using namespace orc;
@@ -848,6 +1031,22 @@ int orc_search_for_triangulation_fisheye(int n1, int NLeft1, const orc_keypoint*
   return SearchForTriangulationFisheye(n1, NLeft1, (const KeyPoint*)kps1, desc1, node1, hasMP1, n2, NLeft2, (const KeyPoint*)kps2,
                                        desc2, node2, hasMP2, levelSigma2, camL8, camR8, T4, bOnlyStereo != 0, bCoarse != 0,
                                        checkOri != 0, matches12);
+}
+void orc_fuse_search(const orc_frame* KF, const float* invLevelSigma2, const float* Tcw7, const float* Ow, int nMP, const uint8_t* valid,
+                     const float* Pw, const float* normal, const float* maxDist, const float* minDist, const uint8_t* mpDesc, float th,
+                     int sim3Form, int* bestIdx, int* bestDist) {
+  FuseSearch(*KF, invLevelSigma2, Tcw7, Ow, nMP, valid, Pw, normal, maxDist, minDist, mpDesc, th, sim3Form != 0, bestIdx, bestDist);
+}
+int orc_search_by_projection_sim3(const orc_frame* KF, const float* Tcw7, const float* Ow, int nMP, const uint8_t* valid,
+                                  const float* Pw, const float* normal, const float* maxDist, const float* minDist,
+                                  const uint8_t* mpDesc, const uint8_t* matchedIn, int th, float ratioHamming, int manualProjection,
+                                  int* matchF) {
+  return SearchByProjectionSim3(*KF, Tcw7, Ow, nMP, valid, Pw, normal, maxDist, minDist, mpDesc, matchedIn, th, ratioHamming,
+                                manualProjection != 0, matchF);
+}
+void orc_search_by_sim3_dir(const orc_frame* B, const float* TAw7, const float* SBA8, int nA, const uint8_t* valid, const float* Pw,
+                            const float* maxDist, const float* minDist, const uint8_t* mpDesc, float th, int* vnMatch) {
+  SearchBySim3Dir(*B, TAw7, SBA8, nA, valid, Pw, maxDist, minDist, mpDesc, th, vnMatch);
 }
 void orc_fundamental_f12(const float* K1, const float* K2, const float* R12, const float* t12, float* F12) {
   FundamentalF12(K1, K2, R12, t12, F12);

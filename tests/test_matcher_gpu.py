@@ -401,3 +401,127 @@ def test_search_by_projection_keyframe(batch):
             np.testing.assert_array_equal(mc[p, :len(kc)], me)
             tot += r
     assert tot > 300
+
+
+# ---- M7: loop-closing / local-mapping searches -----------------------------------------------------------------
+def _quat_from_R(R):
+    from morb_slam_amd.synth import _quat_from_R as q
+    return q(R)
+
+
+def _lc_scene(batch):
+    """Keyframe A = image 0 (world = its camera frame), keyframe B = image 4 (a 4 x 2 px shifted copy) with a nearby pose;
+    map points = stereo back-projections of each keyframe's own features."""
+    from morb_slam_amd.synth import _quat_from_rotvec, _quat_rot
+    P, uR, dep = _scene(batch)
+    rng = np.random.default_rng(21)
+    out = {}
+    q2 = _quat_from_rotvec(np.array([0.002, -0.004, 0.001])); t2 = np.array([-0.03, -0.015, 0.01])
+    T = {0: np.array([0, 0, 0, 1, 0, 0, 0], np.float64), 4: np.concatenate([q2, t2])}
+    for img, fr in ((0, 0), (4, 2)):
+        k, d = batch["ora"][img][1], batch["ora"][img][2]
+        z = dep[fr, :len(k)].cpu().numpy()
+        Xc = np.stack([(k["x"] - P.cx) * np.abs(z) / P.fx, (k["y"] - P.cy) * np.abs(z) / P.fy, np.abs(z)], 1)
+        qinv = T[img][:4] * np.array([-1, -1, -1, 1])
+        Xw = np.array([_quat_rot(qinv, x - T[img][4:]) for x in Xc])
+        dist = np.linalg.norm(Xc, axis=1)
+        maxD = dist * 1.2 ** k["octave"] * rng.uniform(0.9, 1.3, len(k)); minD = maxD / 1.2 ** 7
+        Ow = -_quat_rot(qinv, T[img][4:])
+        nrm = (Xw - Ow) / np.linalg.norm(Xw - Ow, axis=1, keepdims=True) + rng.normal(0, 0.2, Xw.shape)
+        out[img] = dict(k=k, d=d, valid=z > 0, Xw=Xw.astype(np.float32), maxD=maxD.astype(np.float32), minD=minD.astype(np.float32),
+                        normal=nrm.astype(np.float32), T=T[img].astype(np.float32), Ow=Ow.astype(np.float32),
+                        uR=uR[fr, :len(k)].cpu().numpy())
+    return P, out
+
+
+def test_fuse_and_search_by_projection_sim3(batch):
+    """Fuse x2 and SearchByProjection(KF, Sim3) x2: map points of keyframe A searched in keyframe B."""
+    import torch
+    from morb_slam_amd import ORBmatcher
+    from morb_slam_amd.synth import _quat_from_rotvec, _quat_rot
+    P, sc = _lc_scene(batch)
+    A = sc[0]
+    # the searched keyframe: image 0 again, seen from a pose a few millimetres / a fraction of a milliradian away, so that the
+    # projections land within a pixel or two of the features (Fuse's reprojection gate is 5.99 sigma^2)
+    qp = _quat_from_rotvec(np.array([0.0004, -0.0006, 0.0003])); tp = np.array([0.002, -0.001, 0.003])
+    B = dict(A, T=np.concatenate([qp, tp]).astype(np.float32), Ow=(-_quat_rot(qp * np.array([-1, -1, -1, 1]), tp)).astype(np.float32))
+    rng = np.random.default_rng(8)
+    n = len(A["Xw"]); nB = len(B["k"])
+    cap = batch["kps"].shape[1]
+    valid = (A["valid"] & (rng.random(n) < 0.9)).astype(np.uint8)
+    invS = (1.0 / np.array(list(P.levelSigma2)[:P.nlevels], np.float32)).astype(np.float32)
+    cu = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    one = lambda x: cu(x[None])
+    padf = lambda a, fill: np.concatenate([a, np.full((cap - len(a),) + a.shape[1:], fill, a.dtype)])
+    m = ORBmatcher(0.8, True)
+    kf = torch.tensor([0], dtype=torch.int32, device="cuda"); nmp = torch.tensor([n], dtype=torch.int32, device="cuda")
+    Fo = O.make_frame(P, B["k"], B["d"], B["uR"])
+    args = (one(valid), one(A["Xw"]), one(A["normal"]), one(A["maxD"]), one(A["minD"]), one(A["d"]))
+    tot = 0
+    for th, sim3 in ((3.0, False), (6.0, True), (10.0, False)):
+        bi, bd = m.Fuse(P, kf, batch["kps"], batch["desc"], batch["cnt"], one(padf(B["uR"], -1.0)), one(B["T"]), one(B["Ow"]), nmp, *args,
+                        th=th, sim3Form=sim3)
+        torch.cuda.synchronize()
+        ei, ed = O.fuse_search(Fo, invS, B["T"], B["Ow"], valid, A["Xw"], A["normal"], A["maxD"], A["minD"], A["d"], th, sim3)
+        np.testing.assert_array_equal(bi[0, :n].cpu().numpy(), ei)
+        np.testing.assert_array_equal(bd[0, :n].cpu().numpy(), ed)
+        tot += int((ei >= 0).sum())
+    assert tot > 400
+    matched = (rng.random(nB) < 0.1).astype(np.uint8)
+    tot = 0
+    for th, ratio, manual in ((8, 1.0, False), (8, 0.8, True), (4, 1.2, False)):
+        mf, nm = m.SearchByProjectionSim3(P, kf, batch["kps"], batch["desc"], batch["cnt"], one(B["T"]), one(B["Ow"]), nmp, *args,
+                                          one(padf(matched, 0)), th, ratio, manual)
+        torch.cuda.synchronize()
+        r, me = O.search_by_projection_sim3(Fo, B["T"], B["Ow"], valid, A["Xw"], A["normal"], A["maxD"], A["minD"], A["d"], matched, th,
+                                            ratio, manual)
+        g = mf[0, :nB].cpu().numpy()
+        assert int(nm[0]) == r
+        np.testing.assert_array_equal(g, me)
+        tot += r
+    assert tot > 300
+
+
+def test_search_by_sim3(batch):
+    """SearchBySim3: both one-way searches through S21 / S12 and the agreement check."""
+    import torch
+    from morb_slam_amd import ORBmatcher
+    from morb_slam_amd.synth import _quat_rot
+    P, sc = _lc_scene(batch)
+    A, B = sc[0], sc[4]
+    rng = np.random.default_rng(13)
+    cap = batch["kps"].shape[1]
+    # S12 maps camera-2 coordinates to camera-1 coordinates: p1 = s * R12 p2 + t12 with the true relative pose and s = 1.01
+    def Rof(q):
+        return np.array([_quat_rot(q.astype(np.float64), e) for e in np.eye(3)]).T
+    R1, t1 = Rof(A["T"][:4]), A["T"][4:].astype(np.float64); R2, t2 = Rof(B["T"][:4]), B["T"][4:].astype(np.float64)
+    R12 = R1 @ R2.T; t12 = t1 - R12 @ t2
+    s = 1.01
+    def sim8(R, t, sc_):
+        q = _quat_from_R(R) * np.sqrt(sc_)
+        return np.concatenate([q, t]).astype(np.float32)
+    S12 = sim8(R12, t12, s)
+    R21 = R12.T; S21 = sim8(R21, -(R21 @ t12) / s, 1.0 / s)
+    cu = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    def padded(d, key, fill=0):
+        a = d[key]
+        return np.concatenate([a, np.full((cap - len(a),) + a.shape[1:], fill, a.dtype)])[None]
+    v1 = (A["valid"] & (rng.random(len(A["k"])) < 0.85)).astype(np.uint8); v2 = (B["valid"] & (rng.random(len(B["k"])) < 0.85)).astype(np.uint8)
+    A2 = dict(A, valid=v1); B2 = dict(B, valid=v2)
+    m = ORBmatcher(0.8, True)
+    kf1 = torch.tensor([0], dtype=torch.int32, device="cuda"); kf2 = torch.tensor([4], dtype=torch.int32, device="cuda")
+    for th in (7.5, 3.0):
+        o = m.SearchBySim3(P, kf1, kf2, batch["kps"], batch["desc"], batch["cnt"], cu(A["T"][None]), cu(B["T"][None]), cu(S12[None]),
+                           cu(S21[None]), cu(padded(A2, "valid")), cu(padded(A, "Xw")), cu(padded(A, "maxD")), cu(padded(A, "minD")),
+                           cu(padded(A, "d")), cu(padded(B2, "valid")), cu(padded(B, "Xw")), cu(padded(B, "maxD")), cu(padded(B, "minD")),
+                           cu(padded(B, "d")), th)
+        torch.cuda.synchronize()
+        g1, g2, g12, nf = [x.cpu().numpy() for x in o]
+        FB = O.make_frame(P, B["k"], B["d"], None); FA = O.make_frame(P, A["k"], A["d"], None)
+        e1 = O.search_by_sim3_dir(FB, A["T"], S21, v1, A["Xw"], A["maxD"], A["minD"], A["d"], th)
+        e2 = O.search_by_sim3_dir(FA, B["T"], S12, v2, B["Xw"], B["maxD"], B["minD"], B["d"], th)
+        np.testing.assert_array_equal(g1[0, :len(e1)], e1)
+        np.testing.assert_array_equal(g2[0, :len(e2)], e2)
+        e12 = np.array([i2 if (i2 >= 0 and e2[i2] == i1) else -1 for i1, i2 in enumerate(e1)])
+        np.testing.assert_array_equal(g12[0, :len(e1)], e12)
+        assert int(nf[0]) == int((e12 >= 0).sum()) and int(nf[0]) > (50 if th > 5 else 3)
