@@ -145,6 +145,23 @@ int morb_bow_transform_batch(morb_matcher*, int nimg, const uint8_t* d_desc, con
                              const uint8_t* d_nodeDesc, const int* d_firstChild, int k, int L, int levelsup,
                              int* d_wordId, int* d_nodeId, void* stream);
 
+/* The same descent on a trained vocabulary whose nodes may have fewer than k children (ORBvoc.txt: 1 082 073 nodes, not the
+ * 1 111 111 of a complete 10-ary tree): children of node n are [d_firstChild[n], d_firstChild[n] + d_childCount[n]). */
+int morb_bow_transform_tree_batch(morb_matcher* m, int nimg, const uint8_t* d_desc, const int* d_count, int cap,
+                                  const uint8_t* d_nodeDesc, const int* d_firstChild, const int* d_childCount, int L, int levelsup,
+                                  int* d_wordId, int* d_nodeId, void* stream);
+
+/* DBoW2 text vocabulary (TemplatedVocabulary::loadFromTextFile, Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1420;
+ * SURVEY 8f N3): header "k L scoring weighting", then one node per line "parent isLeaf d0 .. d31 weight"; node ids in file
+ * order from 1 (0 = root), word ids = order of the leaves.  Host-side loader; morb_vocabulary_arrays copies the flattened
+ * tree (caller-allocated arrays of nNodes entries; any may be NULL) for upload to the device.  wordId[leaf node] maps the
+ * transform's leaf node id to DBoW2's WordId. */
+typedef struct morb_vocabulary morb_vocabulary;
+int morb_vocabulary_load_text(const char* path, morb_vocabulary** out);
+void morb_vocabulary_destroy(morb_vocabulary* v);
+int morb_vocabulary_info(const morb_vocabulary* v, int* k, int* L, int* nNodes, int* nWords);
+int morb_vocabulary_arrays(const morb_vocabulary* v, uint8_t* nodeDesc, int* firstChild, int* childCount, int* wordId, float* weight);
+
 /* int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)
  * ORBmatcher.h:68, ORBmatcher.cc:218-395 (non-fisheye branch) for npairs (keyframe, frame) pairs drawn from a
  * pool of nimg images: pair p matches image d_kfImg[p] (as pKF) against image d_fImg[p] (as F).
@@ -156,6 +173,14 @@ int morb_search_by_bow_batch(morb_matcher*, int npairs, const int* d_kfImg, cons
                              const morb_keypoint* d_kps, const uint8_t* d_desc, const int* d_node, const int* d_count,
                              const uint8_t* d_hasMP, int cap, float nnratio, int checkOri, int* d_matchF,
                              int* d_nmatches, void* stream);
+
+/* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:367-435) for nMP map points at once: the observed
+ * descriptors of point m (the rows the reference pushes into vDescriptors, in observation order) are rows
+ * [d_start[m], d_start[m + 1]) of d_desc.  d_bestIdx[m] = index (within the point's rows) of the descriptor with the least
+ * median Hamming distance to the others (first minimum), -1 for a point without descriptors; the caller clones that row
+ * into mDescriptor.  At most 65535 descriptors per point. */
+int morb_distinctive_descriptors_batch(morb_matcher* m, int nMP, const int* d_start, const uint8_t* d_desc, int* d_bestIdx,
+                                       void* stream);
 
 /* ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (ORBmatcher.cc:702-819; loop
  * closing / merging): both sides are keyframes of the pool; hasMP[img][i] != 0 <=> GetMapPointMatches()[i] && !isBad();

@@ -104,6 +104,13 @@ def lib():
         L.morb_stereo_fisheye_match_batch.argtypes = [vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp]
         L.morb_bow_transform_batch.argtypes = [vp, i, vp, vp, i, vp, vp, i, i, i, vp, vp, vp]
         L.morb_search_by_bow_batch.argtypes = [vp, i, vp, vp, i, vp, vp, vp, vp, vp, i, f, i, vp, vp, vp]
+        L.morb_bow_transform_tree_batch.argtypes = [vp, i, vp, vp, i, vp, vp, vp, i, i, vp, vp, vp]
+        L.morb_vocabulary_load_text.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.morb_vocabulary_destroy.argtypes = [vp]
+        L.morb_vocabulary_destroy.restype = None
+        L.morb_vocabulary_info.argtypes = [vp] + [C.POINTER(C.c_int)] * 4
+        L.morb_vocabulary_arrays.argtypes = [vp] * 6
+        L.morb_distinctive_descriptors_batch.argtypes = [vp, i, vp, vp, vp, vp]
         L.morb_search_by_bow_kfkf_batch.argtypes = [vp, i, vp, vp, vp, i, vp, vp, vp, vp, vp, i, f, i, vp, vp, vp]
         L.morb_search_by_bow_fisheye_batch.argtypes = [vp, i, vp, vp, vp, i, vp, vp, vp, vp, vp, i, f, i, vp, vp, vp]
         PP = C.POINTER(FrameParams)

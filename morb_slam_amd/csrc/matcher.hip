@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "common.h"
@@ -378,7 +379,8 @@ __global__ __launch_bounds__(256) void k_stereo_median(const int* __restrict__ c
 __global__ __launch_bounds__(256) void k_bow_transform(const uint8_t* __restrict__ feat, const int* __restrict__ count,
                                                        int cap, const uint8_t* __restrict__ nodeDesc,
                                                        const int* __restrict__ firstChild, int k, int L, int levelsup,
-                                                       int* __restrict__ wordId, int* __restrict__ nodeId) {
+                                                       int* __restrict__ wordId, int* __restrict__ nodeId,
+                                                       const int* __restrict__ childCount) {   // per node, or NULL: k everywhere
   const int img = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
   if (i >= cap) return;
   const size_t o = (size_t)img * cap + i;
@@ -390,7 +392,8 @@ __global__ __launch_bounds__(256) void k_bow_transform(const uint8_t* __restrict
     ++level;
     const int c0 = firstChild[final_id];
     int best = c0, bestd = hamming(d, load_desc(nodeDesc + (size_t)c0 * 32));
-    for (int c = c0 + 1; c < c0 + k; ++c) {
+    const int nc = childCount ? childCount[final_id] : k;   // trained vocabularies have nodes with fewer than k children
+    for (int c = c0 + 1; c < c0 + nc; ++c) {
       const int dd = hamming(d, load_desc(nodeDesc + (size_t)c * 32));
       if (dd < bestd) { bestd = dd; best = c; }
     }
@@ -694,6 +697,39 @@ __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __r
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------
+// N4: MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:367-435): one wave per map point, one observed descriptor
+// per lane (64 at a time).  The median of a row is found without storing the N x N matrix: the smallest v with
+// #(distances <= v) > floor(0.5 (N - 1)) by bisection over v in [0, 256], recomputing the row's distances per step
+// (the descriptors of the point are read through uniform addresses).  Best = first row with the smallest median.
+__global__ __launch_bounds__(64) void k_distinctive(const int* __restrict__ start, const uint8_t* __restrict__ desc,
+                                                    int* __restrict__ bestIdx) {
+  const int mp = blockIdx.x, lane = threadIdx.x;
+  const int s0 = start[mp], N = start[mp + 1] - s0;
+  if (N <= 0) { if (lane == 0) bestIdx[mp] = -1; return; }
+  const uint8_t* D = desc + (size_t)s0 * 32;
+  const int k = (N - 1) >> 1;                       // (size_t)(0.5 * (N - 1))
+  unsigned best = ~0u;
+  for (int i0 = 0; i0 < N; i0 += 64) {
+    const int i = i0 + lane;
+    unsigned key = ~0u;
+    if (i < N) {
+      const Desc di = load_desc(D + (size_t)i * 32);
+      int lo = 0, hi = 256;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        int c = 0;
+        for (int j = 0; j < N; ++j) c += hamming(di, load_desc(D + (size_t)j * 32)) <= mid ? 1 : 0;
+        if (c > k) hi = mid; else lo = mid + 1;
+      }
+      key = ((unsigned)lo << 16) | (unsigned)i;     // N < 65536
+    }
+    best = key < best ? key : best;
+  }
+  best = wave_min_u32(best);
+  if (lane == 0) bestIdx[mp] = (int)(best & 0xFFFFu);
+}
+
 __device__ void three_maxima(const int* cnt, int L, int& ind1, int& ind2, int& ind3) {  // ORBmatcher.cc:1844-1876
   int max1 = 0, max2 = 0, max3 = 0;
   ind1 = ind2 = ind3 = -1;
@@ -895,8 +931,100 @@ int morb_bow_transform_batch(morb_matcher* m, int nimg, const uint8_t* d_desc, c
   MORB_HIP_CHECK(hipSetDevice(m->device));
   hipStream_t st = stream ? (hipStream_t)stream : m->stream;
   hipLaunchKernelGGL(k_bow_transform, dim3(div_up(cap, 256), nimg), dim3(256), 0, st, d_desc, d_count, cap, d_nodeDesc,
-                     d_firstChild, k, L, levelsup, d_wordId, d_nodeId);
+                     d_firstChild, k, L, levelsup, d_wordId, d_nodeId, (const int*)nullptr);
   MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}
+
+int morb_bow_transform_tree_batch(morb_matcher* m, int nimg, const uint8_t* d_desc, const int* d_count, int cap,
+                                  const uint8_t* d_nodeDesc, const int* d_firstChild, const int* d_childCount, int L, int levelsup,
+                                  int* d_wordId, int* d_nodeId, void* stream) {
+  MORB_REQUIRE(m && d_desc && d_count && d_nodeDesc && d_firstChild && d_childCount && d_wordId && d_nodeId, MORB_ERR_INVALID,
+               "NULL argument");
+  MORB_REQUIRE(nimg > 0 && cap > 0 && L > 0, MORB_ERR_INVALID, "bad sizes");
+  MORB_HIP_CHECK(hipSetDevice(m->device));
+  hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+  hipLaunchKernelGGL(k_bow_transform, dim3(div_up(cap, 256), nimg), dim3(256), 0, st, d_desc, d_count, cap, d_nodeDesc,
+                     d_firstChild, 0, L, levelsup, d_wordId, d_nodeId, d_childCount);
+  MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}
+
+// ---- DBoW2 text vocabulary (TemplatedVocabulary::loadFromTextFile, TemplatedVocabulary.h:1338-1420) ------------------
+struct morb_vocabulary {
+  int k = 0, L = 0, scoring = 0, weighting = 0;
+  std::vector<uint8_t> desc;       // [nNodes][32]
+  std::vector<int> firstChild;     // [nNodes] first child id or -1 (leaf)
+  std::vector<int> childCount;     // [nNodes]
+  std::vector<int> parent;         // [nNodes]
+  std::vector<int> wordId;         // [nNodes] word id of a leaf (order of appearance, :1403-1408) or -1
+  std::vector<float> weight;       // [nNodes]
+};
+
+int morb_vocabulary_load_text(const char* path, morb_vocabulary** out) {
+  MORB_REQUIRE(path && out, MORB_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  FILE* f = fopen(path, "r");
+  MORB_REQUIRE(f, MORB_ERR_INVALID, "cannot open the vocabulary file");
+  std::unique_ptr<morb_vocabulary> v(new morb_vocabulary());
+  int n1 = 0, n2 = 0;
+  if (fscanf(f, "%d %d %d %d", &v->k, &v->L, &n1, &n2) != 4 || v->k < 0 || v->k > 20 || v->L < 1 || v->L > 10 || n1 < 0 || n1 > 5 ||
+      n2 < 0 || n2 > 3) {   // :1356-1360
+    fclose(f);
+    set_error("Vocabulary loading failure: This is not a correct text file!");
+    return MORB_ERR_INVALID;
+  }
+  v->scoring = n1; v->weighting = n2;
+  // node 0 = root
+  v->desc.assign(32, 0); v->firstChild.assign(1, -1); v->childCount.assign(1, 0); v->parent.assign(1, -1); v->wordId.assign(1, -1);
+  v->weight.assign(1, 0.f);
+  int nWords = 0;
+  for (;;) {
+    int pid = 0, isLeaf = 0;
+    if (fscanf(f, "%d %d", &pid, &isLeaf) != 2) break;
+    const int nid = (int)v->parent.size();
+    int d[32];
+    bool ok = pid >= 0 && pid < nid;
+    for (int i = 0; i < 32 && ok; ++i) ok = fscanf(f, "%d", &d[i]) == 1;
+    double w = 0;
+    if (ok) ok = fscanf(f, "%lf", &w) == 1;
+    if (!ok) { fclose(f); set_error("malformed vocabulary node %d", nid); return MORB_ERR_INVALID; }
+    v->parent.push_back(pid);
+    for (int i = 0; i < 32; ++i) v->desc.push_back((uint8_t)d[i]);
+    v->weight.push_back((float)w);
+    v->firstChild.push_back(-1); v->childCount.push_back(0);
+    v->wordId.push_back(isLeaf > 0 ? nWords++ : -1);
+    // the descent kernels address children as [firstChild, firstChild + childCount): DBoW2 creates the children of a node
+    // together (HKmeansStep), so they are contiguous in every vocabulary it writes; anything else is refused
+    if (v->childCount[pid] == 0) v->firstChild[pid] = nid;
+    else if (v->firstChild[pid] + v->childCount[pid] != nid) {
+      fclose(f);
+      set_error("children of vocabulary node %d are not contiguous", pid);
+      return MORB_ERR_UNSUPPORTED;
+    }
+    v->childCount[pid]++;
+  }
+  fclose(f);
+  *out = v.release();
+  return MORB_OK;
+}
+void morb_vocabulary_destroy(morb_vocabulary* v) { delete v; }
+int morb_vocabulary_info(const morb_vocabulary* v, int* k, int* L, int* nNodes, int* nWords) {
+  MORB_REQUIRE(v, MORB_ERR_INVALID, "NULL vocabulary");
+  if (k) *k = v->k;
+  if (L) *L = v->L;
+  if (nNodes) *nNodes = (int)v->parent.size();
+  if (nWords) { int n = 0; for (int w : v->wordId) n += w >= 0; *nWords = n; }
+  return MORB_OK;
+}
+int morb_vocabulary_arrays(const morb_vocabulary* v, uint8_t* nodeDesc, int* firstChild, int* childCount, int* wordId, float* weight) {
+  MORB_REQUIRE(v, MORB_ERR_INVALID, "NULL vocabulary");
+  const size_t n = v->parent.size();
+  if (nodeDesc) memcpy(nodeDesc, v->desc.data(), n * 32);
+  if (firstChild) memcpy(firstChild, v->firstChild.data(), n * sizeof(int));
+  if (childCount) memcpy(childCount, v->childCount.data(), n * sizeof(int));
+  if (wordId) memcpy(wordId, v->wordId.data(), n * sizeof(int));
+  if (weight) memcpy(weight, v->weight.data(), n * sizeof(float));
   return MORB_OK;
 }
 
@@ -947,6 +1075,16 @@ int morb_search_by_bow_batch(morb_matcher* m, int npairs, const int* d_kfImg, co
                              int* d_nmatches, void* stream) {
   return search_by_bow_impl(m, npairs, d_kfImg, d_fImg, nimg, d_kps, d_desc, d_node, d_count, d_hasMP, cap, nnratio, checkOri,
                             d_matchF, d_nmatches, nullptr, stream);
+}
+
+int morb_distinctive_descriptors_batch(morb_matcher* m, int nMP, const int* d_start, const uint8_t* d_desc, int* d_bestIdx,
+                                       void* stream) {
+  MORB_REQUIRE(m && d_start && d_desc && d_bestIdx && nMP >= 0, MORB_ERR_INVALID, "bad argument");
+  MORB_HIP_CHECK(hipSetDevice(m->device));
+  hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+  if (nMP) hipLaunchKernelGGL(k_distinctive, dim3(nMP), dim3(64), 0, st, d_start, d_desc, d_bestIdx);
+  MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
 }
 
 int morb_search_by_bow_kfkf_batch(morb_matcher* m, int npairs, const int* d_kf1Img, const int* d_kf2Img, const int* d_nValid, int nimg,

@@ -72,6 +72,15 @@ class ORBmatcher:
                                                k, L, levelsup, ptr(out[0]), ptr(out[1]), self._st(stream)))
         return out
 
+    def bow_transform_tree(self, desc, count, voc_desc, voc_first, voc_nchild, L, levelsup=4, stream=None):
+        """DBoW2 transform on a trained (possibly incomplete) tree: children of n = [first[n], first[n] + nchild[n])."""
+        import torch
+        nimg, cap = desc.shape[0], desc.shape[1]
+        out = (torch.empty((nimg, cap), dtype=torch.int32, device=desc.device), torch.empty((nimg, cap), dtype=torch.int32, device=desc.device))
+        check(self._L.morb_bow_transform_tree_batch(self._h, nimg, ptr(desc), ptr(count), cap, ptr(voc_desc), ptr(voc_first), ptr(voc_nchild),
+                                                    L, levelsup, ptr(out[0]), ptr(out[1]), self._st(stream)))
+        return out
+
     def SearchByBoW(self, kf_img, f_img, kps, desc, node, count, has_mp, out=None, stream=None, nLeft=None):
         """SearchByBoW(pKF, F, vpMapPointMatches) for pairs (kf_img[p], f_img[p]) of images of one pool.
         Returns (matchF int32 [npairs, cap] = keyframe feature index per frame feature or -1, nmatches int32 [npairs]).
@@ -103,6 +112,15 @@ class ORBmatcher:
         check(self._L.morb_search_by_bow_kfkf_batch(self._h, npairs, ptr(kf1_img), ptr(kf2_img), ptr(nValid), nimg, ptr(kps), ptr(desc),
                                                     ptr(node), ptr(count), ptr(has_mp), cap, self.mfNNratio,
                                                     1 if self.mbCheckOrientation else 0, ptr(out[0]), ptr(out[1]), self._st(stream)))
+        return out
+
+    def ComputeDistinctiveDescriptors(self, start, desc, stream=None):
+        """MapPoint::ComputeDistinctiveDescriptors for many map points: start int32 [nMP + 1] (CSR), desc uint8 [total, 32];
+        returns int32 [nMP] = row (within each point) of its most representative descriptor."""
+        import torch
+        nMP = start.shape[0] - 1
+        out = torch.empty((nMP,), dtype=torch.int32, device=desc.device)
+        check(self._L.morb_distinctive_descriptors_batch(self._h, nMP, ptr(start), ptr(desc), ptr(out), self._st(stream)))
         return out
 
     # ---- M7: loop-closing / local-mapping searches ---------------------------------------------------------

@@ -335,13 +335,36 @@ int SearchByBoWKFKF(int n1, int nValid1, const uint8_t* desc1, const float* angl
   return nmatches;
 }
 
+// ---- MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:367-435), the search: index of the observed descriptor with
+// the least median Hamming distance to the others (first minimum).  vDescriptors = N rows of 32 bytes in observation order.
+int DistinctiveDescriptor(const uint8_t* vDescriptors, int N) {
+  if (N <= 0) return -1;
+  std::vector<std::vector<int>> Distances(N, std::vector<int>(N, 0));
+  for (int i = 0; i < N; i++) {
+    Distances[i][i] = 0;
+    for (int j = i + 1; j < N; j++) {
+      const int distij = DescriptorDistance(vDescriptors + (size_t)i * 32, vDescriptors + (size_t)j * 32);
+      Distances[i][j] = distij;
+      Distances[j][i] = distij;
+    }
+  }
+  int BestMedian = INT_MAX, BestIdx = 0;
+  for (int i = 0; i < N; i++) {
+    std::vector<int> vDists(Distances[i].begin(), Distances[i].end());
+    std::sort(vDists.begin(), vDists.end());
+    const int median = vDists[(size_t)(0.5 * (N - 1))];
+    if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+  }
+  return BestIdx;
+}
+
 // DBoW2 TemplatedVocabulary::transform(feature, word id, weight, nid, levelsup)
 // (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1218-1259): greedy descent, at each level the child with the
 // smallest Hamming distance (first minimum), nid = the ancestor at level (L - levelsup).  The tree is given as
 // a complete k-ary array: node 0 = root, children of node n are firstChild[n] .. firstChild[n]+k-1
 // (firstChild < 0 for leaves), one 32-byte descriptor per node.
 void BowTransform(const uint8_t* feat, int n, const uint8_t* nodeDesc, const int* firstChild, int k, int L, int levelsup,
-                  int* wordId, int* nodeId) {
+                  int* wordId, int* nodeId, const int* childCount = nullptr) {
   const int nid_level = L - levelsup;
   for (int f = 0; f < n; ++f) {
     int final_id = 0, current_level = 0, nid = 0;
@@ -351,7 +374,8 @@ void BowTransform(const uint8_t* feat, int n, const uint8_t* nodeDesc, const int
       const int c0 = firstChild[final_id];
       int best_d = DescriptorDistance(feat + (size_t)f * 32, nodeDesc + (size_t)c0 * 32);
       int best = c0;
-      for (int c = c0 + 1; c < c0 + k; ++c) {
+      const int nc = childCount ? childCount[final_id] : k;
+      for (int c = c0 + 1; c < c0 + nc; ++c) {
         int d = DescriptorDistance(feat + (size_t)f * 32, nodeDesc + (size_t)c * 32);
         if (d < best_d) { best_d = d; best = c; }
       }
@@ -385,6 +409,10 @@ int orc_search_by_bow(int nKF, const uint8_t* descKF, const float* angleKF, cons
   return SearchByBoW(nKF, descKF, angleKF, kfHasMP, nodeKF, nF, descF, angleF, nodeF, nnratio, checkOri != 0, matchF);
 }
 
+void orc_distinctive_descriptors(int nMP, const int* start, const uint8_t* desc, int* bestIdx) {
+  for (int m = 0; m < nMP; ++m) bestIdx[m] = DistinctiveDescriptor(desc + (size_t)start[m] * 32, start[m + 1] - start[m]);
+}
+
 int orc_search_by_bow_kfkf(int n1, int nValid1, const uint8_t* desc1, const float* angle1, const uint8_t* hasMP1, const int* node1,
                            int n2, int nValid2, const uint8_t* desc2, const float* angle2, const uint8_t* hasMP2, const int* node2,
                            float nnratio, int checkOri, int* matches12) {
@@ -398,6 +426,10 @@ int orc_search_by_bow_fisheye(int nKF, const uint8_t* descKF, const float* angle
   return SearchByBoW(nKF, descKF, angleKF, kfHasMP, nodeKF, nF, descF, angleF, nodeF, nnratio, checkOri != 0, matchF, FNleft);
 }
 
+void orc_bow_transform_tree(const uint8_t* feat, int n, const uint8_t* nodeDesc, const int* firstChild, const int* childCount, int L,
+                            int levelsup, int* wordId, int* nodeId) {
+  BowTransform(feat, n, nodeDesc, firstChild, 0, L, levelsup, wordId, nodeId, childCount);
+}
 void orc_bow_transform(const uint8_t* feat, int n, const uint8_t* nodeDesc, const int* firstChild, int k, int L,
                        int levelsup, int* wordId, int* nodeId) {
   BowTransform(feat, n, nodeDesc, firstChild, k, L, levelsup, wordId, nodeId);

@@ -48,6 +48,8 @@ void orc_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* idx, int*
 int orc_search_by_bow(int nKF, const uint8_t* descKF, const float* angleKF, const uint8_t* kfHasMP, const int* nodeKF,
                       int nF, const uint8_t* descF, const float* angleF, const int* nodeF, float nnratio, int checkOri,
                       int* matchF);
+/* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:367-435) for nMP map points: descriptors of point m = rows [start[m], start[m+1]) */
+void orc_distinctive_descriptors(int nMP, const int* start, const uint8_t* desc, int* bestIdx);
 /* SearchByBoW(pKF1, pKF2, vpMatches12) (ORBmatcher.cc:702-819) */
 int orc_search_by_bow_kfkf(int n1, int nValid1, const uint8_t* desc1, const float* angle1, const uint8_t* hasMP1, const int* node1,
                            int n2, int nValid2, const uint8_t* desc2, const float* angle2, const uint8_t* hasMP2, const int* node2,
@@ -56,6 +58,8 @@ int orc_search_by_bow_kfkf(int n1, int nValid1, const uint8_t* desc1, const floa
 int orc_search_by_bow_fisheye(int nKF, const uint8_t* descKF, const float* angleKF, const uint8_t* kfHasMP, const int* nodeKF,
                               int nF, int FNleft, const uint8_t* descF, const float* angleF, const int* nodeF, float nnratio,
                               int checkOri, int* matchF);
+void orc_bow_transform_tree(const uint8_t* feat, int n, const uint8_t* nodeDesc, const int* firstChild, const int* childCount, int L,
+                            int levelsup, int* wordId, int* nodeId);
 void orc_bow_transform(const uint8_t* feat, int n, const uint8_t* nodeDesc, const int* firstChild, int k, int L,
                        int levelsup, int* wordId, int* nodeId);
 int orc_pose_optimization(int n, const uint8_t* hasMP, const float* obs, const float* invSigma2, const float* Xw,

@@ -156,6 +156,24 @@ def search_by_bow(descKF, angleKF, hasMP, nodeKF, descF, angleF, nodeF, nnratio,
     return n, m[:len(descF)]
 
 
+def bow_transform_tree(feat, nodeDesc, firstChild, childCount, L, levelsup):
+    L_ = lib()
+    L_.orc_bow_transform_tree.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    a = [np.ascontiguousarray(feat), np.ascontiguousarray(nodeDesc), np.ascontiguousarray(firstChild, np.int32), np.ascontiguousarray(childCount, np.int32)]
+    w = np.zeros(len(feat), np.int32); nid = np.zeros(len(feat), np.int32)
+    L_.orc_bow_transform_tree(_p(a[0]), len(feat), _p(a[1]), _p(a[2]), _p(a[3]), L, levelsup, _p(w), _p(nid))
+    return w, nid
+
+
+def distinctive_descriptors(start, desc):
+    L = lib()
+    L.orc_distinctive_descriptors.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    a = [np.ascontiguousarray(start, np.int32), np.ascontiguousarray(desc)]
+    out = np.zeros(len(start) - 1, np.int32)
+    L.orc_distinctive_descriptors(len(start) - 1, _p(a[0]), _p(a[1]), _p(out))
+    return out
+
+
 def search_by_bow_kfkf(d1, a1, has1, node1, nv1, d2, a2, has2, node2, nv2, nnratio, checkOri):
     L = lib()
     L.orc_search_by_bow_kfkf.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p]

@@ -525,3 +525,43 @@ def test_search_by_sim3(batch):
         e12 = np.array([i2 if (i2 >= 0 and e2[i2] == i1) else -1 for i1, i2 in enumerate(e1)])
         np.testing.assert_array_equal(g12[0, :len(e1)], e12)
         assert int(nf[0]) == int((e12 >= 0).sum()) and int(nf[0]) > (50 if th > 5 else 3)
+
+
+def test_compute_distinctive_descriptors():
+    """MapPoint::ComputeDistinctiveDescriptors: least-median row, first minimum, N from 0 to a few hundred."""
+    import torch
+    from morb_slam_amd import ORBmatcher
+    rng = np.random.default_rng(99)
+    sizes = [0, 1, 2, 3, 5, 8, 17, 40, 64, 65, 130, 300] + list(rng.integers(1, 30, 400))
+    start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    desc = np.zeros((start[-1], 32), np.uint8)
+    for m, n in enumerate(sizes):
+        if n == 0: continue
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        rows = np.tile(base, (n, 1)) ^ np.packbits(rng.random((n, 256)) < rng.uniform(0.02, 0.2), axis=1)
+        if m % 5 == 0 and n > 2: rows[1] = rows[0]                 # ties between rows
+        desc[start[m]:start[m + 1]] = rows
+    g = ORBmatcher().ComputeDistinctiveDescriptors(torch.from_numpy(start).cuda(), torch.from_numpy(desc).cuda())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(g.cpu().numpy(), O.distinctive_descriptors(start, desc))
+
+
+def test_bow_transform_on_loaded_vocabulary(batch, tmp_path):
+    """ComputeBoW on a trained-style tree (nodes with fewer than k children, early leaves) loaded from the DBoW2 text format."""
+    import torch
+    from morb_slam_amd import ORBmatcher
+    from morb_slam_amd.vocabulary import Vocabulary
+    from test_oracle_cpu import _irregular_vocabulary
+    path, *_ = _irregular_vocabulary(tmp_path, seed=11, k=6, L=4)
+    v = Vocabulary.load_text(path)
+    desc, cnt = batch["desc"], batch["cnt"]
+    cu = lambda x: torch.from_numpy(x).cuda()
+    for lup in (1, 2, 4):
+        w, nid = ORBmatcher().bow_transform_tree(desc, cnt, cu(v.nodeDesc), cu(v.firstChild), cu(v.childCount), v.L, lup)
+        torch.cuda.synchronize()
+        w, nid, cn = w.cpu().numpy(), nid.cpu().numpy(), cnt.cpu().numpy()
+        for i in range(desc.shape[0]):
+            we, ne = O.bow_transform_tree(batch["ora"][i][2], v.nodeDesc, v.firstChild, v.childCount, v.L, lup)
+            np.testing.assert_array_equal(w[i, :cn[i]], we)
+            np.testing.assert_array_equal(nid[i, :cn[i]], ne)
+        assert len(np.unique(w[0, :cn[0]])) > 20

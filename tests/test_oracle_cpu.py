@@ -9,6 +9,7 @@ import re
 import numpy as np
 import pytest
 
+import oracle_lib as O
 from oracle_lib import KP_DTYPE, OracleExtractor, _p, lib
 from morb_slam_amd.synth import make_image
 
@@ -387,3 +388,55 @@ def test_pose_and_ba_oracle_converge():
     stop = np.array([1], np.int32)
     its, kf2, _, _, _ = O.local_ba(b, stop=stop)
     assert its == 0 and np.array_equal(kf2, b["kfPose"])                 # *pbStopFlag (Optimizer.cc:1355)
+
+
+def _irregular_vocabulary(tmp_path, seed=0, k=4, L=3):
+    """A DBoW2-style tree written in ORBvoc.txt format: nodes created depth-first, the children of a node together
+    (HKmeansStep), some nodes with fewer than k children, leaves above the last level."""
+    from morb_slam_amd.vocabulary import save_text
+    rng = np.random.default_rng(seed)
+    parent, leaf, desc, weight = [], [], [], []
+
+    def grow(pid, level):
+        nc = int(rng.integers(2, k + 1))
+        ids = []
+        for _ in range(nc):
+            parent.append(pid); leaf.append(0); desc.append(rng.integers(0, 256, 32)); weight.append(rng.random())
+            ids.append(len(parent))          # node id (1-based position)
+        for nid in ids:
+            if level + 1 < L and rng.random() < 0.85:
+                grow(nid, level + 1)
+            else:
+                leaf[nid - 1] = 1
+    grow(0, 0)
+    path = tmp_path / "voc.txt"
+    save_text(path, k, L, parent, leaf, np.array(desc), weight)
+    return path, np.array(parent), np.array(leaf), np.array(desc, np.uint8), np.array(weight, np.float32)
+
+
+def test_vocabulary_text_loader(tmp_path):
+    """morb_vocabulary_load_text (host-side, no GPU): DBoW2 text format -> flattened tree; malformed files are refused."""
+    from morb_slam_amd.vocabulary import Vocabulary
+    from morb_slam_amd.capi import MorbError
+    path, parent, leaf, desc, weight = _irregular_vocabulary(tmp_path, seed=3)
+    v = Vocabulary.load_text(path)
+    n = len(parent) + 1
+    assert (v.k, v.L, v.nNodes) == (4, 3, n)
+    np.testing.assert_array_equal(v.nodeDesc[1:], desc)
+    np.testing.assert_allclose(v.weight[1:], weight, rtol=1e-5)
+    for node in range(n):
+        kids = [i + 1 for i in range(len(parent)) if parent[i] == node]
+        assert v.childCount[node] == len(kids)
+        assert v.firstChild[node] == (kids[0] if kids else -1)
+        assert kids == list(range(kids[0], kids[0] + len(kids))) if kids else True
+    words = [i + 1 for i in range(len(parent)) if leaf[i]]
+    np.testing.assert_array_equal(v.wordId[words], np.arange(len(words)))       # word ids = order of the leaves
+    assert (v.wordId[[i for i in range(n) if i not in words]] == -1).all()
+    # the oracle descends the loaded tree the same way the file describes it
+    feats = np.random.default_rng(1).integers(0, 256, (200, 32), dtype=np.uint8)
+    w, nid = O.bow_transform_tree(feats, v.nodeDesc, v.firstChild, v.childCount, v.L, 1)
+    assert (v.childCount[w] == 0).all() and (v.wordId[w] >= 0).all()
+    bad = tmp_path / "bad.txt"
+    bad.write_text("40 3 0 0\n")
+    with pytest.raises(MorbError):
+        Vocabulary.load_text(bad)
