@@ -396,7 +396,7 @@ def main():
         if world == 1 and not args.no_extras:
             line["extra_metrics"] = optimizer_extras(local_rank)
             line["extra_metrics"].update(config_extras(local_rank))
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:      # reported on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     if dist is not None:

@@ -1,0 +1,31 @@
+"""Latency of ONE stereo frame through the hot path (developer tool): device-resident batch of 2 images, and the
+host-pointer form morb_extract (includes the PCIe copies)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from morb_slam_amd import ORBextractor, ORBmatcher
+from morb_slam_amd.synth import make_stereo_pair
+l, r = make_stereo_pair(752, 480, seed=1)
+imgs = torch.from_numpy(np.stack([l, r])).cuda()
+ext = ORBextractor(1200, 1.2, 8, 20, 7); m = ORBmatcher(0.7, True)
+st = torch.cuda.Stream()
+out = None
+def one():
+    global out
+    out = ext.extract_batch(imgs, out=out, stream=st.cuda_stream)
+    m.ComputeStereoMatches(ext, out[0], out[1], out[2], 50.4, 0.11, stream=st.cuda_stream)
+for _ in range(5): one()
+st.synchronize()
+ext.set_profiling(True)
+t0 = time.perf_counter()
+N = 50
+for _ in range(N):
+    one(); st.synchronize()
+dt = (time.perf_counter() - t0) / N
+print(f"device-resident stereo frame: extract x2 + stereo match = {dt * 1e3:.3f} ms  stages {ext.stage_ms()}")
+ext.set_profiling(False)
+t0 = time.perf_counter()
+for _ in range(20):
+    ext(l)
+dth = (time.perf_counter() - t0) / 20
+print(f"host-pointer morb_extract (one 752x480 image, copies included): {dth * 1e3:.3f} ms")
