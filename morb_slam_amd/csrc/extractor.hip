@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "common.h"
+#include "wave.h"
 #include "extractor_internal.h"
 #include "quadtree.h"
 
@@ -675,38 +676,63 @@ __device__ __forceinline__ void sincosf_glibc(float y, float* sn, float* cs) {
 // The wave's lifetime is a chain of dependent global-memory round trips, so the chain is kept short: one record
 // per keypoint from k_layout (slot, level, key), level geometry from the kernarg segment, and the (keypoint-
 // independent) rBRIEF pattern rows of the lane requested before anything else.
+constexpr int DESC_KPW = 4;   // keypoints per wave in k_describe
+// One wave describes DESC_KPW keypoints *in lock step*: the kernel is bound by dependent global-memory round trips per
+// keypoint (record -> patch -> angle -> pattern gathers), so each stage is issued for all DESC_KPW keypoints before the
+// next stage waits on it — three round trips per wave instead of three per keypoint.  Slots without a keypoint repeat
+// the wave's first valid one (no divergent control flow around the loads) and skip the stores.
 __global__ __launch_bounds__(256) void k_describe(const morb::DescGeom dg, const uint8_t* __restrict__ pyr,
                                                   const uint8_t* __restrict__ blur, const int2* __restrict__ kref,
                                                   int selPerImg, morb_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int cap) {
   const int img = blockIdx.y, lane = threadIdx.x & 63;
-  const int gi = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (gi >= selPerImg) return;
+  const int gi0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DESC_KPW;
+  if (gi0 >= selPerImg) return;
   int4 pat[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) pat[q] = reinterpret_cast<const int4*>(c_pattern)[lane * 4 + q];
-  const int2 ref = kref[(size_t)img * selPerImg + gi];
-  if (ref.x < 0) return;
-  const int l = ref.x >> 24, slot = ref.x & 0xFFFFFF;
-  const uint32_t key = (uint32_t)ref.y;
-  struct { int pstride, bstride; float scale, kpSize; } g;
-  g.pstride = dg.pstride[l]; g.bstride = dg.bstride[l]; g.scale = dg.scale[l]; g.kpSize = dg.kpSize[l];
-  const size_t pyrBase = dg.pyrOff[l] + (size_t)img * dg.pyrImg[l], blurBase = dg.blurOff[l] + (size_t)img * dg.blurImg[l];
-  const int cx = morbqt::key_x(key) + MINB, cy = morbqt::key_y(key) + MINB;
+  int2 ref[DESC_KPW];
+#pragma unroll
+  for (int kk = 0; kk < DESC_KPW; ++kk) ref[kk] = kref[(size_t)img * selPerImg + min(gi0 + kk, selPerImg - 1)];
+  bool ok[DESC_KPW];
+  int first = -1;
+#pragma unroll
+  for (int kk = 0; kk < DESC_KPW; ++kk) {
+    ok[kk] = gi0 + kk < selPerImg && ref[kk].x >= 0;
+    if (ok[kk] && first < 0) first = kk;
+  }
+  if (first < 0) return;   // wave-uniform
+#pragma unroll
+  for (int kk = 0; kk < DESC_KPW; ++kk) if (!ok[kk]) ref[kk] = ref[first];
 
-  // IC_Angle on the un-blurred level.  The texture path handles a byte load of a wave no faster than a dword load
-  // (the kernel was bound by the number of vector-memory instructions, not by bytes or ALU), so the 31 x 31 patch
-  // is read as 31 rows x 8 unaligned dwords = 248 dword loads, four per lane, instead of 31 byte loads per lane.
-  int m10 = 0, m01 = 0;
-  {
-    const uint8_t* ctr = pyr + pyrBase + (size_t)(EDGE + cy) * g.pstride + EDGE + cx;
-    uint32_t wv[4];
+  int lvl[DESC_KPW], cx[DESC_KPW], cy[DESC_KPW], pstride[DESC_KPW], bstride[DESC_KPW];
+  const uint8_t* ctr[DESC_KPW];
+  const uint8_t* center[DESC_KPW];
+#pragma unroll
+  for (int kk = 0; kk < DESC_KPW; ++kk) {
+    const int l = ref[kk].x >> 24;
+    const uint32_t key = (uint32_t)ref[kk].y;
+    lvl[kk] = l; pstride[kk] = dg.pstride[l]; bstride[kk] = dg.bstride[l];
+    cx[kk] = morbqt::key_x(key) + MINB; cy[kk] = morbqt::key_y(key) + MINB;
+    ctr[kk] = pyr + dg.pyrOff[l] + (size_t)img * dg.pyrImg[l] + (size_t)(EDGE + cy[kk]) * pstride[kk] + EDGE + cx[kk];
+    center[kk] = blur + dg.blurOff[l] + (size_t)img * dg.blurImg[l] + (size_t)cy[kk] * bstride[kk] + cx[kk];
+  }
+  // IC_Angle on the un-blurred level.  The texture path handles a byte load of a wave no faster than a dword load, so the
+  // 31 x 31 patch is read as 31 rows x 8 unaligned dwords = 248 dword loads, four per lane.
+  uint32_t wv[DESC_KPW][4];
+#pragma unroll
+  for (int kk = 0; kk < DESC_KPW; ++kk)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int t = lane + 64 * j;              // row = t / 8, dword = t % 8
       const int tt = t < 248 ? t : 247;
-      wv[j] = load_u32_unaligned(ctr + (ptrdiff_t)((tt >> 3) - HALF_PATCH) * g.pstride + ((tt & 7) * 4 - HALF_PATCH));
+      wv[kk][j] = load_u32_unaligned(ctr[kk] + (ptrdiff_t)((tt >> 3) - HALF_PATCH) * pstride[kk] + ((tt & 7) * 4 - HALF_PATCH));
     }
+  float angle[DESC_KPW];
+  int t0v[DESC_KPW][4], t1v[DESC_KPW][4];
+#pragma unroll
+  for (int kk = 0; kk < DESC_KPW; ++kk) {
+    int m10 = 0, m01 = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int t = lane + 64 * j;
@@ -717,42 +743,53 @@ __global__ __launch_bounds__(256) void k_describe(const morb::DescGeom dg, const
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int u = u0 + k;
-        const int val = (t < 248 && u >= -d && u <= d) ? (int)((wv[j] >> (8 * k)) & 0xFF) : 0;
+        const int val = (t < 248 && u >= -d && u <= d) ? (int)((wv[kk][j] >> (8 * k)) & 0xFF) : 0;
         sum += val; usum += u * val;
       }
       m10 += usum; m01 += v * sum;
     }
+    m10 = morbwave::sum_i32(m10);   // DPP reductions (wave.h): all 64 lanes are active here
+    m01 = morbwave::sum_i32(m01);
+    // (computing the DESC_KPW angles / sincos in DESC_KPW lanes at once was measured slower: it puts every keypoint's
+    // gathers behind one serial f64 chain; here keypoint kk's gathers are in flight while kk + 1's angle is computed)
+    angle[kk] = fast_atan2_deg((float)m01, (float)m10);
+    // rBRIEF on the blurred level: lane k evaluates tests 4k..4k+3
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float a, bsin;
+    sincosf_glibc(angle[kk] * factorPI, &bsin, &a);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float x0 = (float)pat[q].x, y0 = (float)pat[q].y, x1 = (float)pat[q].z, y1 = (float)pat[q].w;
+      const int r0 = __float2int_rn(x0 * bsin + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bsin);
+      const int r1 = __float2int_rn(x1 * bsin + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bsin);
+      t0v[kk][q] = center[kk][(ptrdiff_t)r0 * bstride[kk] + c0];
+      t1v[kk][q] = center[kk][(ptrdiff_t)r1 * bstride[kk] + c1];
+    }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    m10 += __shfl_xor(m10, off, 64);
-    m01 += __shfl_xor(m01, off, 64);
-  }
-  const float angle = fast_atan2_deg((float)m01, (float)m10);
-
-  // rBRIEF on the blurred level: lane k evaluates tests 4k..4k+3
-  const float factorPI = (float)(3.14159265358979323846 / 180.f);
-  float a, bsin;
-  sincosf_glibc(angle * factorPI, &bsin, &a);
-  const uint8_t* center = blur + blurBase + (size_t)cy * g.bstride + cx;
-  uint32_t nib = 0;
+  for (int kk = 0; kk < DESC_KPW; ++kk) {
+    uint32_t nib = 0;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float x0 = (float)pat[q].x, y0 = (float)pat[q].y, x1 = (float)pat[q].z, y1 = (float)pat[q].w;
-    const int r0 = __float2int_rn(x0 * bsin + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bsin);
-    const int r1 = __float2int_rn(x1 * bsin + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bsin);
-    const int t0 = center[(ptrdiff_t)r0 * g.bstride + c0], t1 = center[(ptrdiff_t)r1 * g.bstride + c1];
-    nib |= (uint32_t)(t0 < t1) << q;
-  }
-  const uint32_t hi = __shfl_down(nib, 1, 64);
-  if ((lane & 1) == 0) desc[((size_t)img * cap + slot) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
-  if (lane == 0) {
-    morb_keypoint kp;
-    float x = (float)cx, y = (float)cy;
-    if (l != 0) { x = x * g.scale; y = y * g.scale; }
-    kp.x = x; kp.y = y; kp.size = g.kpSize; kp.angle = angle; kp.response = (float)morbqt::key_r(key);
-    kp.octave = l; kp.class_id = -1;
-    kps[(size_t)img * cap + slot] = kp;
+    for (int q = 0; q < 4; ++q) nib |= (uint32_t)(t0v[kk][q] < t1v[kk][q]) << q;
+    const uint32_t hi = __shfl_down(nib, 1, 64);
+    if (!ok[kk]) continue;   // wave-uniform
+    const int slot = ref[kk].x & 0xFFFFFF, l = lvl[kk];
+    if ((lane & 1) == 0) desc[((size_t)img * cap + slot) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+    if (lane < 7) {   // the 28-byte cv::KeyPoint record, one dword per lane: a single vector store
+      float x = (float)cx[kk], y = (float)cy[kk];
+      if (l != 0) { x = x * dg.scale[l]; y = y * dg.scale[l]; }
+      uint32_t w;
+      switch (lane) {
+        case 0: w = __float_as_uint(x); break;
+        case 1: w = __float_as_uint(y); break;
+        case 2: w = __float_as_uint(dg.kpSize[l]); break;
+        case 3: w = __float_as_uint(angle[kk]); break;
+        case 4: w = __float_as_uint((float)morbqt::key_r((uint32_t)ref[kk].y)); break;
+        case 5: w = (uint32_t)l; break;
+        default: w = 0xFFFFFFFFu; break;   // class_id = -1
+      }
+      reinterpret_cast<uint32_t*>(kps + (size_t)img * cap + slot)[lane] = w;
+    }
   }
 }
 
@@ -1110,7 +1147,7 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
                      e->d_lap, e->d_kref, d_count, d_mono, cap);
   mark(4);
   MORB_HIP_CHECK(hipStreamWaitEvent(st, e->evJoin, 0));
-  hipLaunchKernelGGL(k_describe, dim3(div_up(e->selPerImg, 4), nimg), dim3(256), 0, st, e->descGeom, e->d_pyr,
+  hipLaunchKernelGGL(k_describe, dim3(div_up(e->selPerImg, 4 * DESC_KPW), nimg), dim3(256), 0, st, e->descGeom, e->d_pyr,
                      e->d_blur, e->d_kref, e->selPerImg, d_kps, d_desc, cap);
   mark(5);
   MORB_HIP_CHECK(hipGetLastError());
