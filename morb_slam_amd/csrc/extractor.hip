@@ -462,17 +462,22 @@ __global__ __launch_bounds__(NT) void k_fast(const morb::FastGeom fg, int nlevel
     }
     __syncthreads();
     PHASE_MARK(4);
-    // Phase 5 — ordered output (row-major over the evaluated area): slot = row prefix + set bits to the left
+    // Phase 5 — ordered output (row-major over the evaluated area).  Only a handful of the survivors are corners after
+    // NMS, so the walk is over the bitmap words (one per lane), not over the survivor queue: slot = row prefix + set
+    // bits in the row's earlier words + position inside the word.
     uint32_t* out = cand + cellSlot * (size_t)cellCap;
-    for (int q = tid; q < nq; q += NT) {
-      const int e = queue[q];
-      const int y = e >> 8, x = e & 255;
-      const int w = x >> 5;
-      const uint32_t word = bm[y * bmWords + w];
-      if (!((word >> (x & 31)) & 1u)) continue;
-      int slot = rowCnt[y] + __popc(word & ((1u << (x & 31)) - 1u));
-      for (int ww = 0; ww < w; ++ww) slot += __popc(bm[y * bmWords + ww]);
-      if (slot < cellCap) out[slot] = morbqt::make_key(x + c.cj * c.wCell, y + c.ci * c.hCell, sc[y * tilePitch + x] - 1);
+    for (int y = tid; y < th; y += NT) {      // one row per lane (no division by the runtime word count)
+      int slot = rowCnt[y];
+      for (int w = 0; w < bmWords; ++w) {
+        uint32_t word = bm[y * bmWords + w];
+        while (word) {
+          const int b = __ffs(word) - 1;
+          word &= word - 1;
+          const int x = w * 32 + b;
+          if (slot < cellCap) out[slot] = morbqt::make_key(x + c.cj * c.wCell, y + c.ci * c.hCell, sc[y * tilePitch + x] - 1);
+          ++slot;
+        }
+      }
     }
     if (tid == 0) candCnt[cellSlot] = imin(rowCnt[th], cellCap);
     PHASE_MARK(5);
