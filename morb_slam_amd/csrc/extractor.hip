@@ -347,7 +347,10 @@ __global__ __launch_bounds__(NT) void k_fast(const morb::FastGeom fg, int nlevel
     // Four pixels per lane: the window row is read as aligned dwords (centre, the dwords left and right of it, the
     // rows 3 above / below), bytes are split into even / odd 16-bit lanes, the second smallest / largest come from a
     // packed-u16 min/max network, and bit 15 of (0x8000 + a - b - 1) says "a > b" for two pixels at once.
-    const int nGroups = eh * G;
+    // only the dword groups that contain an evaluated pixel (x in [3, tw - 3)) are visited: Gu <= G of them per row
+    const int Gu = ((tw - 4) >> 2) + 1;
+    const unsigned guMagic = 0xFFFFFFFFu / (unsigned)Gu + 1u;
+    const int nGroups = eh * Gu;
     const unsigned K = 0x80008000u, LO = 0x00FF00FFu;
     const unsigned T1 = (unsigned)(tmin + 1) * 0x00010001u;
     for (int i0 = 0; i0 < nGroups; i0 += NT) {
@@ -355,8 +358,8 @@ __global__ __launch_bounds__(NT) void k_fast(const morb::FastGeom fg, int nlevel
       unsigned re = 0, ro = 0;   // bit 15 / 31: pixel may exceed tmin (even bytes, odd bytes)
       int x4 = 0, y = 0;
       if (i < nGroups) {
-        const int ry = (int)__umulhi((unsigned)i, gMagic);
-        y = ry + 3; const int gi = i - ry * G; x4 = gi << 2;
+        const int ry = (int)__umulhi((unsigned)i, guMagic);
+        y = ry + 3; const int gi = i - ry * Gu; x4 = gi << 2;
         const uint32_t* row = reinterpret_cast<const uint32_t*>(tile + y * tilePitch);
         const uint32_t C = row[gi];
         const uint32_t Lw = gi > 0 ? row[gi - 1] : 0u, Rw = gi + 1 < G ? row[gi + 1] : 0u;
