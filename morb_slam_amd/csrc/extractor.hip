@@ -116,9 +116,10 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
     top = max(top, max((int)tx[k].s0, (int)tx[k].s1));
   }
   const bool packed = top - base < 8;   // always true for scale factors <= 2 (the gather below is the general fallback)
-  int o0[4], o1[4];
+  // byte selectors for v_perm_b32: output k's left / right source byte inside the 8 loaded bytes
+  uint32_t selL = 0, selR = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { o0[k] = (tx[k].s0 - base) * 8; o1[k] = (tx[k].s1 - base) * 8; }
+  for (int k = 0; k < 4; ++k) { selL |= (uint32_t)(tx[k].s0 - base) << (8 * k); selR |= (uint32_t)(tx[k].s1 - base) << (8 * k); }
   const uint8_t* sbase = pyr + gs.pyrOff + (size_t)img * gs.pyrImg + (size_t)EDGE * gs.pstride + EDGE;
   uint8_t* dbase = pyr + gd.pyrOff + (size_t)img * gd.pyrImg + px;
   for (int r = 0; r < PY_ROWS; ++r) {
@@ -129,12 +130,15 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
     const uint8_t* r1 = sbase + (size_t)ty.s1 * gs.pstride;
     uint32_t v = 0;
     if (packed) {
-      const unsigned long long a = (unsigned long long)load_u32_unaligned(r0 + base) | ((unsigned long long)load_u32_unaligned(r0 + base + 4) << 32);
-      const unsigned long long b = (unsigned long long)load_u32_unaligned(r1 + base) | ((unsigned long long)load_u32_unaligned(r1 + base + 4) << 32);
+      // one v_perm_b32 gathers the four outputs' left (right) samples of a source row
+      const uint32_t a0 = load_u32_unaligned(r0 + base), a1 = load_u32_unaligned(r0 + base + 4);
+      const uint32_t b0 = load_u32_unaligned(r1 + base), b1 = load_u32_unaligned(r1 + base + 4);
+      const uint32_t aL = __builtin_amdgcn_perm(a1, a0, selL), aR = __builtin_amdgcn_perm(a1, a0, selR);
+      const uint32_t bL = __builtin_amdgcn_perm(b1, b0, selL), bR = __builtin_amdgcn_perm(b1, b0, selR);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int h0 = (int)((a >> o0[k]) & 0xFF) * tx[k].c0 + (int)((a >> o1[k]) & 0xFF) * tx[k].c1;
-        const int h1 = (int)((b >> o0[k]) & 0xFF) * tx[k].c0 + (int)((b >> o1[k]) & 0xFF) * tx[k].c1;
+        const int h0 = (int)((aL >> (8 * k)) & 0xFF) * tx[k].c0 + (int)((aR >> (8 * k)) & 0xFF) * tx[k].c1;
+        const int h1 = (int)((bL >> (8 * k)) & 0xFF) * tx[k].c0 + (int)((bR >> (8 * k)) & 0xFF) * tx[k].c1;
         const int o = ((((int)ty.c0 * (h0 >> 4)) >> 16) + (((int)ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
         v |= (uint32_t)(o & 0xFF) << (8 * k);
       }
