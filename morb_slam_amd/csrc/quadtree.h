@@ -294,9 +294,94 @@ QT_HD void qt_std_sort(uint64_t* v, int n) {
 // at the first element that is not greater), so after the serial introsort loop the result is the stable sort of
 // the array by key: every lane ranks its entries (keys smaller + equal keys to the left) instead of one lane
 // walking LDS element by element (that walk was ~25 % of k_distribute).
-__device__ inline void qt_std_sort_wave(uint64_t* v, uint64_t* tmp, int n) {
+// std::__unguarded_partition_pivot(first, last) by the whole wave; returns the cut.  The serial loop swaps the k-th
+// entry from the left that is not less than the pivot (list L, ascending positions) with the k-th entry from the right
+// that is not greater (list R, descending positions, closed by the pivot slot `first` itself) for as long as the left
+// position is below the right one -- so the lanes build both lists with ballots, perform all those swaps at once, and the
+// cut is the position where the serial scan stops: min(L[K], R[K-1]) with K the number of swaps.
+// posL / posR: scratch for n and n + 1 positions.
+__device__ inline int qt_partition_pivot_wave(uint64_t* v, int first, int last, uint16_t* posL, uint16_t* posR) {
+  const int lane = QT_LANE;
+  {  // __move_median_to_first(first, first + 1, mid, last - 1)
+    const int a = first + 1, b = first + (last - first) / 2, c = last - 1;
+    const uint64_t va = v[a], vb = v[b], vc = v[c];
+    int m;
+    if (qt_less(va, vb)) m = qt_less(vb, vc) ? b : (qt_less(va, vc) ? c : a);
+    else m = qt_less(va, vc) ? a : (qt_less(vb, vc) ? c : b);
+    QT_SYNC();
+    if (lane == 0) qt_swap(v, first, m);
+    QT_SYNC();
+  }
+  const uint64_t pivot = v[first];
+  const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  int nL = 0, nR = 0;
+  for (int p0 = first + 1; p0 < last; p0 += 64) {
+    const int p = p0 + lane;
+    const bool in = p < last;
+    const uint64_t e = in ? v[p] : 0;
+    nL += __popcll(__ballot(in && !qt_less(e, pivot)));
+    nR += __popcll(__ballot(in && !qt_less(pivot, e)));
+  }
+  int bl = 0, br = 0;   // entries of L / R at lower positions
+  for (int p0 = first + 1; p0 < last; p0 += 64) {
+    const int p = p0 + lane;
+    const bool in = p < last;
+    const uint64_t e = in ? v[p] : 0;
+    const bool ge = in && !qt_less(e, pivot), le = in && !qt_less(pivot, e);
+    const uint64_t mg = __ballot(ge), ml = __ballot(le);
+    if (ge) posL[bl + __popcll(mg & below)] = (uint16_t)p;
+    if (le) posR[nR - 1 - (br + __popcll(ml & below))] = (uint16_t)p;
+    bl += __popcll(mg); br += __popcll(ml);
+  }
+  if (lane == 0) posR[nR] = (uint16_t)first;
+  QT_SYNC();
+  const int nPair = nL < nR + 1 ? nL : nR + 1;
+  int K = 0;
+  for (int k0 = 0; k0 < nPair; k0 += 64) {
+    const int k = k0 + lane;
+    bool act = false;
+    int pl = 0, pr = 0;
+    if (k < nPair) { pl = posL[k]; pr = posR[k]; act = pl < pr; }
+    if (act) qt_swap(v, pl, pr);
+    const uint64_t ma = __ballot(act);
+    K += __popcll(ma);
+    if (ma != ~0ull) break;   // the swapping pairs are a prefix of the pairing
+  }
+  int cut = last;
+  if (K < nL) cut = posL[K];
+  if (K > 0) { const int r = posR[K - 1]; cut = r < cut ? r : cut; }
+  QT_SYNC();
+  return cut;
+}
+
+__device__ inline void qt_std_sort_wave(uint64_t* v, uint64_t* tmp, int n, uint16_t* posL, uint16_t* posR) {
   __shared__ int st[3 * 64];
-  if (QT_LANE0) qt_introsort_loop(v, n, st);
+  if (n > 16) {  // std::__introsort_loop with the recursion on an explicit (wave-uniform) stack, see qt_introsort_loop
+    int* stF = st; int* stL = st + 64; int* stD = st + 128;
+    int lg = 0;
+    for (int t = n; t > 1; t >>= 1) ++lg;
+    int sp = 1;
+    if (QT_LANE0) { stF[0] = 0; stL[0] = n; stD[0] = lg * 2; }
+    QT_SYNC();
+    while (sp > 0) {
+      --sp;
+      int first = stF[sp], last = stL[sp], depth = stD[sp];
+      while (last - first > 16) {
+        if (depth == 0) {
+          QT_SYNC();
+          if (QT_LANE0) qt_heapsort(v, first, last);
+          QT_SYNC();
+          break;
+        }
+        --depth;
+        const int cut = qt_partition_pivot_wave(v, first, last, posL, posR);
+        if (QT_LANE0) { stF[sp] = cut; stL[sp] = last; stD[sp] = depth; }
+        ++sp;
+        last = cut;
+      }
+      QT_SYNC();
+    }
+  }
   QT_SYNC();
   for (int i = QT_LANE; i < n; i += 64) {
     const uint64_t e = v[i];
@@ -715,7 +800,7 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
         s.nA = 0;
         QT_MARK(14);
 #if QT_DEVICE
-        qt_std_sort_wave(w.vB, w.vA, nPrev);   // vA was just cleared: free as scratch until the splits below refill it
+        qt_std_sort_wave(w.vB, w.vA, nPrev, w.order, (uint16_t*)w.brank);   // vA was just cleared: free as scratch until the splits below refill it
 #else
         qt_std_sort(w.vB, nPrev);
 #endif
