@@ -166,21 +166,25 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
 // 19 - 3 = 16, so x % 4 == 0 makes the window 4-byte aligned).  HBM traffic = read P (+halo rows) + write P.
 constexpr int BT_W = 256, BT_ROWS = 16, BT_TY = 4;   // workgroup: 64 x 4 threads -> 256 px x 64 rows per tile
 constexpr int BT_H = BT_ROWS * BT_TY;
-__device__ __forceinline__ void blur_row4(const uint8_t* __restrict__ rowAligned, uint32_t& lo, uint32_t& hi) {
+typedef unsigned short blur_u16x2 __attribute__((ext_vector_type(2)));
+// Horizontal 7-tap of four neighbouring pixels: v_dot4_u32_u8 against the packed kernel weights (18 34 48 56 | 48 34 18 0),
+// the byte windows cut out of the three loaded dwords with v_alignbyte.  Results are exact integers <= 255 * 256.
+__device__ __forceinline__ void blur_h4(const uint8_t* __restrict__ rowAligned, uint32_t h[4]) {
   // rowAligned points at byte (x - 3) of the padded row: 12 bytes = pixels x-3 .. x+8
   const uint32_t w0 = reinterpret_cast<const uint32_t*>(rowAligned)[0];
   const uint32_t w1 = reinterpret_cast<const uint32_t*>(rowAligned)[1];
   const uint32_t w2 = reinterpret_cast<const uint32_t*>(rowAligned)[2];
-  uint32_t p[12];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { p[k] = (w0 >> (8 * k)) & 0xFF; p[4 + k] = (w1 >> (8 * k)) & 0xFF; p[8 + k] = (w2 >> (8 * k)) & 0xFF; }
-  uint32_t r[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    r[k] = 18u * (p[k] + p[k + 6]) + 34u * (p[k + 1] + p[k + 5]) + 48u * (p[k + 2] + p[k + 4]) + 56u * p[k + 3];
-  lo = r[0] | (r[1] << 16);
-  hi = r[2] | (r[3] << 16);
+  constexpr uint32_t WA = 18u | (34u << 8) | (48u << 16) | (56u << 24), WB = 48u | (34u << 8) | (18u << 16);
+  h[0] = __builtin_amdgcn_udot4(w0, WA, __builtin_amdgcn_udot4(w1, WB, 0u, false), false);
+  h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), WA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), WB, 0u, false), false);
+  h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), WA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), WB, 0u, false), false);
+  h[3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), WA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), WB, 0u, false), false);
 }
+__device__ __forceinline__ uint32_t blur_dot2(uint32_t pair, uint32_t w, uint32_t acc) {   // v_dot2_u32_u16
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(blur_u16x2, pair), __builtin_bit_cast(blur_u16x2, w), acc, false);
+}
+// PMC: VALU-issue bound, so the design rule is instruction count.  Vertical pass: consecutive rows' horizontal sums are
+// kept as 16-bit pairs (row r | row r+1 << 16), so the 7 taps are three v_dot2_u32_u16 and one multiply-add.
 __global__ __launch_bounds__(256) void k_blur(const LevelGeom* __restrict__ geom, int nlevels,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
   int l = 0;
@@ -195,25 +199,38 @@ __global__ __launch_bounds__(256) void k_blur(const LevelGeom* __restrict__ geom
   // padded-row origin of this strip: row (y + 19 - 3), byte (19 + x - 3) = 16 + x
   const uint8_t* src = pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)(EDGE + y0 - 3) * g.pstride + (EDGE - 3) + x;
   uint8_t* dst = blur + g.blurOff + (size_t)img * g.blurImg + (size_t)y0 * g.bstride + x;
-  uint32_t lo[7], hi[7];
+  uint32_t P[5][4], hl[4];   // P[j] = rows (y + j, y + j + 1) of the horizontal sums, hl = row y + 5
+  {
+    uint32_t h[6][4];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) blur_row4(src + (size_t)k * g.pstride, lo[k], hi[k]);
+    for (int k = 0; k < 6; ++k) blur_h4(src + (size_t)k * g.pstride, h[k]);
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) P[j][k] = h[j][k] | (h[j + 1][k] << 16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hl[k] = h[5][k];
+  }
   const int rows = (g.h - y0) < BT_ROWS ? (g.h - y0) : BT_ROWS;
-  for (int r = 0; r < rows; ++r) {
-    blur_row4(src + (size_t)(r + 6) * g.pstride, lo[6], hi[6]);
-    uint32_t o = 0;
+  constexpr uint32_t W01 = 18u | (34u << 16), W23 = 48u | (56u << 16), W45 = 48u | (34u << 16);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int sh = (k & 1) * 16;
-      const uint32_t* a = (k < 2) ? lo : hi;
-      const uint32_t v0 = (a[0] >> sh) & 0xFFFF, v1 = (a[1] >> sh) & 0xFFFF, v2 = (a[2] >> sh) & 0xFFFF, v3 = (a[3] >> sh) & 0xFFFF;
-      const uint32_t v4 = (a[4] >> sh) & 0xFFFF, v5 = (a[5] >> sh) & 0xFFFF, v6 = (a[6] >> sh) & 0xFFFF;
-      const uint32_t acc = 18u * (v0 + v6) + 34u * (v1 + v5) + 48u * (v2 + v4) + 56u * v3;
-      o |= ((acc + 32768u) >> 16) << (8 * k);
-    }
+  for (int r = 0; r < BT_ROWS; ++r) {
+    if (r < rows) {   // (fully unrolled: the row window rotates by renaming)
+    uint32_t hn[4], acc[4];
+    blur_h4(src + (size_t)(r + 6) * g.pstride, hn);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      acc[k] = blur_dot2(P[0][k], W01, blur_dot2(P[2][k], W23, blur_dot2(P[4][k], W45, 18u * hn[k] + 32768u)));
+    // acc < 2^24: the rounded output is byte 2 of each accumulator
+    const uint32_t o = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u) | __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
     *reinterpret_cast<uint32_t*>(dst + (size_t)r * g.bstride) = o;   // columns >= w land in the row's alignment slack
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { lo[k] = lo[k + 1]; hi[k] = hi[k + 1]; }
+    for (int k = 0; k < 4; ++k) {
+      P[0][k] = P[1][k]; P[1][k] = P[2][k]; P[2][k] = P[3][k]; P[3][k] = P[4][k];
+      P[4][k] = hl[k] | (hn[k] << 16);
+      hl[k] = hn[k];
+    }
+    }
   }
 }
 
@@ -715,7 +732,12 @@ __global__ __launch_bounds__(256) void k_describe(const morb::DescGeom dg, const
   }
   if (first < 0) return;   // wave-uniform
 #pragma unroll
-  for (int kk = 0; kk < DESC_KPW; ++kk) if (!ok[kk]) ref[kk] = ref[first];
+  for (int kk = 0; kk < DESC_KPW; ++kk) {
+    if (!ok[kk]) ref[kk] = ref[first];
+    // wave-uniform by construction: in SGPRs the per-keypoint geometry and base addresses are scalar arithmetic
+    ref[kk].x = __builtin_amdgcn_readfirstlane(ref[kk].x);
+    ref[kk].y = __builtin_amdgcn_readfirstlane(ref[kk].y);
+  }
 
   int lvl[DESC_KPW], cx[DESC_KPW], cy[DESC_KPW], pstride[DESC_KPW], bstride[DESC_KPW];
   const uint8_t* ctr[DESC_KPW];
@@ -726,8 +748,10 @@ __global__ __launch_bounds__(256) void k_describe(const morb::DescGeom dg, const
     const uint32_t key = (uint32_t)ref[kk].y;
     lvl[kk] = l; pstride[kk] = dg.pstride[l]; bstride[kk] = dg.bstride[l];
     cx[kk] = morbqt::key_x(key) + MINB; cy[kk] = morbqt::key_y(key) + MINB;
-    ctr[kk] = pyr + dg.pyrOff[l] + (size_t)img * dg.pyrImg[l] + (size_t)(EDGE + cy[kk]) * pstride[kk] + EDGE + cx[kk];
-    center[kk] = blur + dg.blurOff[l] + (size_t)img * dg.blurImg[l] + (size_t)cy[kk] * bstride[kk] + cx[kk];
+    // top-left corners of the 31 x 31 moment patch and of the (2 * EDGE + 1)^2 window the rotated pattern stays inside:
+    // the lanes add unsigned 32-bit offsets (scalar base + vector offset addressing)
+    ctr[kk] = pyr + dg.pyrOff[l] + (size_t)img * dg.pyrImg[l] + (size_t)(EDGE + cy[kk] - HALF_PATCH) * pstride[kk] + EDGE + cx[kk] - HALF_PATCH;
+    center[kk] = blur + dg.blurOff[l] + (size_t)img * dg.blurImg[l] + (ptrdiff_t)(cy[kk] - EDGE) * bstride[kk] + cx[kk] - EDGE;
   }
   // IC_Angle on the un-blurred level.  The texture path handles a byte load of a wave no faster than a dword load, so the
   // 31 x 31 patch is read as 31 rows x 8 unaligned dwords = 248 dword loads, four per lane.
@@ -738,28 +762,43 @@ __global__ __launch_bounds__(256) void k_describe(const morb::DescGeom dg, const
     for (int j = 0; j < 4; ++j) {
       const int t = lane + 64 * j;              // row = t / 8, dword = t % 8
       const int tt = t < 248 ? t : 247;
-      wv[kk][j] = load_u32_unaligned(ctr[kk] + (ptrdiff_t)((tt >> 3) - HALF_PATCH) * pstride[kk] + ((tt & 7) * 4 - HALF_PATCH));
+      wv[kk][j] = load_u32_unaligned(ctr[kk] + (uint32_t)((tt >> 3) * pstride[kk] + (tt & 7) * 4));
     }
+  // The circular mask and the column weights of a lane's four dwords do not depend on the keypoint: byte masks and the
+  // biased weights (u + 15, so that v_dot4_u32_u8 applies) are built once, and per keypoint a dword costs one AND, two
+  // dot products and a multiply-add: m10 = sum (u + 15) I - 15 sum I, m01 = sum v (row sum of I).
+  uint32_t pmask[4], pw[4];
+  int pv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = lane + 64 * j;
+    const int v = (t >> 3) - HALF_PATCH, u0 = (t & 7) * 4 - HALF_PATCH;
+    const int av = v < 0 ? -v : v;
+    const int d = (int)((0x3689ABCDDEEEFFFFull >> (4 * av)) & 15);   // umax[|v|] (== c_umax, checked on the host)
+    uint32_t m = 0, w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int u = u0 + k;
+      if (t < 248 && u >= -d && u <= d) m |= 0xFFu << (8 * k);
+      w |= (uint32_t)(u + HALF_PATCH) << (8 * k);
+    }
+    pmask[j] = m; pw[j] = w; pv[j] = v;
+  }
   float angle[DESC_KPW];
   int t0v[DESC_KPW][4], t1v[DESC_KPW][4];
 #pragma unroll
   for (int kk = 0; kk < DESC_KPW; ++kk) {
-    int m10 = 0, m01 = 0;
+    uint32_t usumB = 0, sumAll = 0;
+    int m01 = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int t = lane + 64 * j;
-      const int v = (t >> 3) - HALF_PATCH, u0 = (t & 7) * 4 - HALF_PATCH;
-      const int av = v < 0 ? -v : v;
-      const int d = (int)((0x3689ABCDDEEEFFFFull >> (4 * av)) & 15);   // umax[|v|] (== c_umax, checked on the host)
-      int sum = 0, usum = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int u = u0 + k;
-        const int val = (t < 248 && u >= -d && u <= d) ? (int)((wv[kk][j] >> (8 * k)) & 0xFF) : 0;
-        sum += val; usum += u * val;
-      }
-      m10 += usum; m01 += v * sum;
+      const uint32_t px = wv[kk][j] & pmask[j];
+      const uint32_t sum = __builtin_amdgcn_udot4(px, 0x01010101u, 0u, false);
+      usumB = __builtin_amdgcn_udot4(px, pw[j], usumB, false);
+      sumAll += sum;
+      m01 += pv[j] * (int)sum;
     }
+    int m10 = (int)usumB - HALF_PATCH * (int)sumAll;
     m10 = morbwave::sum_i32(m10);   // DPP reductions (wave.h): all 64 lanes are active here
     m01 = morbwave::sum_i32(m01);
     // (computing the DESC_KPW angles / sincos in DESC_KPW lanes at once was measured slower: it puts every keypoint's
@@ -774,8 +813,8 @@ __global__ __launch_bounds__(256) void k_describe(const morb::DescGeom dg, const
       const float x0 = (float)pat[q].x, y0 = (float)pat[q].y, x1 = (float)pat[q].z, y1 = (float)pat[q].w;
       const int r0 = __float2int_rn(x0 * bsin + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bsin);
       const int r1 = __float2int_rn(x1 * bsin + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bsin);
-      t0v[kk][q] = center[kk][(ptrdiff_t)r0 * bstride[kk] + c0];
-      t1v[kk][q] = center[kk][(ptrdiff_t)r1 * bstride[kk] + c1];
+      t0v[kk][q] = center[kk][(uint32_t)((r0 + EDGE) * bstride[kk] + c0 + EDGE)];
+      t1v[kk][q] = center[kk][(uint32_t)((r1 + EDGE) * bstride[kk] + c1 + EDGE)];
     }
   }
 #pragma unroll
