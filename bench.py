@@ -217,9 +217,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="stereo frames per step per GPU")
-    ap.add_argument("--chunks", type=int, default=1,
-                    help="the batch is cut into this many frame chunks, each with its own extractor/matcher handle and HIP "
-                         "stream, so the latency-bound quadtree of one chunk runs under the VALU-bound FAST of another")
+    ap.add_argument("--sets", type=int, default=2, help="buffer sets = steps in flight (>= 2)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="join all streams at the end of every step instead of running step i's matchers underneath step "
+                         "i + 1's extraction (one buffer set instead of two)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline workload only (used for the committed profiles)")
     args = ap.parse_args()
@@ -252,14 +253,19 @@ def main():
     gids = [parallel.global_frame(rank, world, s) for s in range(B)]
     frames = torch.from_numpy(make_batch(gids, B * world, seed=0)).to(dev)      # [B, 2, H, W] resident in HBM
     images = frames.view(2 * B, H, W)
-    C = max(1, min(args.chunks, B))
-    bounds = [(c * B // C, (c + 1) * B // C) for c in range(C)]          # frame ranges of the chunks
-    exts = [ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank) for _ in range(C)]
+    # Two buffer sets (extractor handle with its pyramids, feature tables, matcher outputs): consecutive steps alternate
+    # between them, so the matchers of step i -- latency-bound kernels -- run on their own streams underneath the
+    # VALU-bound extraction of step i + 1.  Set s is reused by step i + 2 only after its readers of step i finished
+    # (events).  --no-pipeline joins all streams at the end of every step instead.
+    NSET = 1 if args.no_pipeline else max(2, args.sets)
+    exts = [ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank) for _ in range(NSET)]
     ext = exts[0]
-    stream = torch.cuda.Stream(device=dev)
-    cstreams = [stream] if C == 1 else [torch.cuda.Stream(device=dev) for _ in range(C)]
+    stream = torch.cuda.Stream(device=dev)                    # extraction
+    mstream = torch.cuda.Stream(device=dev) if NSET >= 2 else stream   # stereo matching
+    estreams = [torch.cuda.Stream(device=dev) for _ in range(NSET)] if NSET >= 2 and not os.environ.get('MORB_BENCH_ONE_ESTREAM') else [stream] * NSET
+    bstream = torch.cuda.Stream(device=dev)                   # ComputeBoW -> (feature exchange) -> SearchByBoW
     matcher = ORBmatcher(0.7, True, device=local_rank)        # TrackReferenceKeyFrame: ORBmatcher(0.7, true), Tracking.cc:2541
-    cmatchers = [matcher] if C == 1 else [ORBmatcher(0.7, True, device=local_rank) for _ in range(C)]   # one workspace set per stream
+    bmatcher = ORBmatcher(0.7, True, device=local_rank)       # one workspace set per stream
     mbf, mb = 458.654 * 0.11, 0.11                            # EuRoC fx * baseline, baseline (Examples/Stereo/EuRoC.yaml)
     VK, VL = 10, 6                                            # DBoW2 ORBvoc shape: k=10, L=6, levelsup=4
     vd, vf = make_vocabulary(VK, VL, seed=0)                  # synthetic: ORBvoc.txt is a missing blob (SURVEY finding 3)
@@ -279,51 +285,52 @@ def main():
         kf_img, f_img = torch.from_numpy(kfp).to(dev), torch.from_numpy(frp).to(dev)
         has_mp = torch.from_numpy((rng.random((world * B, cap)) < 0.8).astype(np.uint8)).to(dev)
         exch = parallel.FeatureExchange()
-    match_out = None
-    out = (torch.empty((2 * B, cap, 28), dtype=torch.uint8, device=dev), torch.empty((2 * B, cap, 32), dtype=torch.uint8, device=dev),
-           torch.empty((2 * B,), dtype=torch.int32, device=dev), torch.empty((2 * B,), dtype=torch.int32, device=dev))
-    st_out = (torch.empty((B, cap), dtype=torch.float32, device=dev), torch.empty((B, cap), dtype=torch.float32, device=dev))
-    bow_out = (torch.empty((2 * B, cap), dtype=torch.int32, device=dev), torch.empty((2 * B, cap), dtype=torch.int32, device=dev))
 
-    # Stereo matching and the BoW chain (ComputeBoW -> SearchByBoW) both only need the extractor's output and are
-    # latency-bound in different ways, so they run side by side: stereo on the extract stream, BoW on its own stream
-    # with its own matcher handle (one workspace set per stream); the step stream joins both at the end.
-    bstream = torch.cuda.Stream(device=dev)
-    bmatcher = ORBmatcher(0.7, True, device=local_rank)
-    ext_done = [torch.cuda.Event() for _ in range(C)]
+    class BufferSet:
+        def __init__(self):
+            self.out = (torch.empty((2 * B, cap, 28), dtype=torch.uint8, device=dev), torch.empty((2 * B, cap, 32), dtype=torch.uint8, device=dev),
+                        torch.empty((2 * B,), dtype=torch.int32, device=dev), torch.empty((2 * B,), dtype=torch.int32, device=dev))
+            self.st_out = (torch.empty((B, cap), dtype=torch.float32, device=dev), torch.empty((B, cap), dtype=torch.float32, device=dev))
+            self.bow_out = (torch.empty((2 * B, cap), dtype=torch.int32, device=dev), torch.empty((2 * B, cap), dtype=torch.int32, device=dev))
+            self.match_out = None
+            self.ext_done, self.stereo_done, self.bow_done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+            self.used = False
+    sets = [BufferSet() for _ in range(NSET)]
+    nstep = 0
 
     def step():
-        nonlocal match_out
-        kps, desc, cnt, _ = out
+        nonlocal nstep
+        S = sets[nstep % NSET]
+        e = exts[nstep % NSET]
+        stream = estreams[nstep % NSET]
+        nstep += 1
+        kps, desc, cnt, _ = S.out
+        if S.used:                                # the set's previous readers (two steps ago) must be done before it is overwritten
+            stream.wait_event(S.stereo_done)
+            stream.wait_event(S.bow_done)
+        S.used = True
+        e.extract_batch(images, out=S.out, stream=stream.cuda_stream)                                  # Frame::ExtractORB x2
+        S.ext_done.record(stream)
+        mstream.wait_event(S.ext_done)
+        matcher.ComputeStereoMatches(e, kps, desc, cnt, mbf, mb, out=S.st_out, stream=mstream.cuda_stream)   # Frame.cc:217
+        S.stereo_done.record(mstream)
         bs = bstream.cuda_stream
-        bstream.wait_stream(stream)               # fork: ordered after whatever the step stream did before
-        for c, (f0, f1) in enumerate(bounds):     # per chunk: extract -> stereo on the chunk's stream, BoW descent on the BoW stream
-            cs = cstreams[c]
-            if C > 1:
-                cs.wait_stream(stream)
-            i0, i1 = 2 * f0, 2 * f1
-            co = tuple(t[i0:i1] for t in out)
-            exts[c].extract_batch(images[i0:i1], out=co, stream=cs.cuda_stream)                 # Frame::ExtractORB x2
-            ext_done[c].record(cs)
-            cmatchers[c].ComputeStereoMatches(exts[c], co[0], co[1], co[2], mbf, mb,
-                                              out=(st_out[0][f0:f1], st_out[1][f0:f1]), stream=cs.cuda_stream)   # Frame.cc:217
-            bstream.wait_event(ext_done[c])
-            bmatcher.bow_transform(co[1], co[2], vd, vf, VK, VL, 4,
-                                   out=(bow_out[0][i0:i1], bow_out[1][i0:i1]), stream=bs)       # Frame::ComputeBoW
+        bstream.wait_event(S.ext_done)
+        bmatcher.bow_transform(desc, cnt, vd, vf, VK, VL, 4, out=S.bow_out, stream=bs)                 # Frame::ComputeBoW
         if exch is None:
-            match_out = bmatcher.SearchByBoW(kf_img, f_img, kps, desc, bow_out[1], cnt, has_mp, out=match_out, stream=bs)
+            S.match_out = bmatcher.SearchByBoW(kf_img, f_img, kps, desc, S.bow_out[1], cnt, has_mp, out=S.match_out, stream=bs)
         else:
             with torch.cuda.stream(bstream):      # the collective is ordered after the kernels on this stream
-                pk, pd, pc, pn = exch.exchange(kps[0::2], desc[0::2], cnt[0::2], bow_out[1][0::2])   # left images only
-            match_out = bmatcher.SearchByBoW(kf_img, f_img, pk, pd, pn, pc, has_mp, out=match_out, stream=bs)
-        for cs in cstreams:                       # join
-            if cs is not stream:
-                stream.wait_stream(cs)
-        stream.wait_stream(bstream)
+                pk, pd, pc, pn = exch.exchange(kps[0::2], desc[0::2], cnt[0::2], S.bow_out[1][0::2])   # left images only
+            S.match_out = bmatcher.SearchByBoW(kf_img, f_img, pk, pd, pn, pc, has_mp, out=S.match_out, stream=bs)
+        S.bow_done.record(bstream)
+        if NSET == 1:                             # un-pipelined: the step ends when all streams are done
+            stream.wait_stream(bstream)
 
     def sync_all():
-        for cs in cstreams:
-            cs.synchronize()
+        for es in estreams:
+            es.synchronize()
+        mstream.synchronize()
         bstream.synchronize()
         stream.synchronize()
         torch.cuda.synchronize(dev)
@@ -338,6 +345,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    for es in estreams:
+        es.synchronize()
+    mstream.synchronize()
+    bstream.synchronize()
     stream.synchronize()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
@@ -346,14 +357,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         dist.barrier()
-    # per-stage ms per step, summed over the chunks' launches (chunks overlap in time, so the sum can exceed wall time)
-    per_chunk = [e.stage_ms() for e in exts]
-    stages = {k: sum(pc[k] for pc in per_chunk) for k in per_chunk[0]}
+    # per-stage ms per extract call (= per step), averaged over the handles of the buffer sets
+    per_set = [e.stage_ms() for e in exts]
+    stages = {k: sum(ps[k] for ps in per_set) / len(per_set) for k in per_set[0]}
     for e in exts:
         e.set_profiling(False)
-    cnt = out[2].cpu().numpy()
-    n_stereo = float((st_out[0] >= 0).sum().item()) / B
-    n_bow = float(match_out[1].float().mean().item())
+    cnt = sets[0].out[2].cpu().numpy()
+    n_stereo = float((sets[0].st_out[0] >= 0).sum().item()) / B
+    n_bow = float(sets[0].match_out[1].float().mean().item())
 
     if rank == 0:
         fps = B * world * args.steps / dt
@@ -362,7 +373,7 @@ def main():
         dom = max(("pyramid", "blur", "fast"), key=lambda k: stages[k])
         # dominant streaming kernel of the extractor; "fast" is ONE kernel (k_fast), so its stage time is the
         # kernel's launch duration measured with HIP events on the launch stream
-        ach = ab[dom] * nimg / (stages[dom] * 1e-3) / 1e9    # = bytes of one chunk launch / its mean duration
+        ach = ab[dom] * nimg / (stages[dom] * 1e-3) / 1e9    # = bytes of one launch / its mean duration
         # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # runs of this same command at B = 64; profiles/r01/pmc_traffic_b64.json) — not measurable live
         traffic = None
@@ -372,7 +383,7 @@ def main():
             mult = {"k_resize": 7}
             # the PMC passes ran launches of pm["images_per_launch"] images; traffic scales with the image count
             traffic = sum((pm[k]["FETCH_SIZE_KB_per_launch"] + pm[k]["WRITE_SIZE_KB_per_launch"]) * 1024 * mult.get(k, 1)
-                          for k in names) * (nimg / C) / pm.get("images_per_launch", 128)
+                          for k in names) * nimg / pm.get("images_per_launch", 128)
         except Exception:
             traffic = None
         line = {
@@ -382,7 +393,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "EuRoC-shaped stereo 752x480, 1200 feat: ORBextractor x2 + ComputeStereoMatches + "
                                    "ComputeBoW (synthetic k=10 L=6 vocabulary) + SearchByBoW vs previous frame",
-                       "stereo_frames_per_step_per_gpu": B, "chunks_per_step": C, "parallelism": f"frames dealt round-robin over {world} GPU(s)" + ("" if world == 1 else
+                       "stereo_frames_per_step_per_gpu": B, "steps_in_flight": NSET, "parallelism": f"frames dealt round-robin over {world} GPU(s)" + ("" if world == 1 else
                                        "; one RCCL all-gather of left-image keypoints/descriptors/BoW ids per step"),
                        "stages_in_step": ["extract_left+right", "stereo_match", "bow_transform", "search_by_bow"],
                        "mean_keypoints_per_image": float(cnt.mean()), "mean_stereo_matches_per_frame": n_stereo,
@@ -390,7 +401,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": {"pyramid": "k_level0+k_resize", "blur": "k_blur", "fast": "k_fast"}[dom],
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "algorithmic_bytes_per_launch": ab[dom] * nimg // C, "avg_launch_ms": stages[dom] / C},
+                         "algorithmic_bytes_per_launch": ab[dom] * nimg, "avg_launch_ms": stages[dom]},
             "extract_stage_ms_per_step": stages,
         }
         if world == 1 and not args.no_extras:
