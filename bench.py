@@ -360,6 +360,13 @@ def main():
     # per-stage ms per extract call (= per step), averaged over the handles of the buffer sets
     per_set = [e.stage_ms() for e in exts]
     stages = {k: sum(ps[k] for ps in per_set) / len(per_set) for k in per_set[0]}
+    # reference point outside the timed region: the same extraction with nothing else on the chip (the pipelined steps
+    # above share the CUs between two extractions and the matchers, which stretches every kernel's launch duration)
+    iso_n = 5
+    for _ in range(iso_n):
+        exts[0].extract_batch(images, out=sets[0].out, stream=estreams[0].cuda_stream)
+        estreams[0].synchronize()
+    iso = exts[0].stage_ms()
     for e in exts:
         e.set_profiling(False)
     cnt = sets[0].out[2].cpu().numpy()
@@ -401,7 +408,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": {"pyramid": "k_level0+k_resize", "blur": "k_blur", "fast": "k_fast"}[dom],
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "algorithmic_bytes_per_launch": ab[dom] * nimg, "avg_launch_ms": stages[dom]},
+                         "algorithmic_bytes_per_launch": ab[dom] * nimg, "avg_launch_ms": stages[dom],
+                         # not part of the timed region: the kernel alone on the chip (steps not overlapped)
+                         "isolated_avg_launch_ms": iso[dom], "isolated_frac": ab[dom] * nimg / (iso[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "extract_stage_ms_per_step": stages,
         }
         if world == 1 and not args.no_extras:
