@@ -420,6 +420,43 @@ int morb_pose_optimization_fisheye_batch(morb_optimizer*, int nframes, int cap, 
                                          const float* d_Xw, const float* camL8, const float* camR8, const float* Trl7,
                                          float* d_pose, uint8_t* d_outlier, int* d_nInliers, int* d_stats, void* stream);
 
+/* ---- visual-inertial tracking (first slice) ----
+ * IMU::Preintegrated as plain data (include/ImuTypes.h:154-263): 3 x 3 blocks row-major, C = the 15 x 15 covariance
+ * row-major, b = the bias the measurements were integrated with in IMU::Bias order (bax bay baz bwx bwy bwz),
+ * nga / ngaWalk = the diagonals of IMU::Calib::Cov / CovWalk (gyro x3, acc x3; ImuTypes.cc:375-388). */
+typedef struct {
+  float dT;
+  float dR[9], dV[3], dP[3];
+  float JRg[9], JVg[9], JVa[9], JPg[9], JPa[9];
+  float C[225];
+  float b[6];
+  float nga[6], ngaWalk[6];
+  float avgA[3], avgW[3];
+} morb_imu_preintegrated;
+
+/* IMU::Preintegrated::Initialize + IntegrateNewMeasurement over each measurement sequence (ImuTypes.cc:152-170, :191-247;
+ * what Tracking::PreintegrateIMU feeds it, Tracking.cc:1705-1790) for nseq sequences at once.  DEVICE pointers:
+ * sequence s owns the measurements [d_start[s], d_start[s+1]) of d_acc / d_gyro ([.][3]) and d_dt; d_bias [nseq][6].
+ * ngaDiag6 / walkDiag6 are HOST pointers. */
+int morb_imu_preintegrate_batch(morb_optimizer*, int nseq, const int* d_start, const float* d_acc, const float* d_gyro,
+                                const float* d_dt, const float* d_bias, const float* ngaDiag6, const float* walkDiag6,
+                                morb_imu_preintegrated* d_out, void* stream);
+
+/* static int Optimizer::PoseInertialOptimizationLastKeyFrame(Frame* pFrame, bool bRecInit)  Optimizer.h:127-128,
+ * Optimizer.cc:4391-4757, for nframes frames at once (DEVICE pointers, frame f at offset f*cap; same per-feature arrays
+ * as morb_pose_optimization_batch plus d_close[i] != 0 <=> mvpMapPoints[i]->mTrackDepth < 10).  States are Rwb (9,
+ * row-major), twb, velocity, gyro bias, acc bias = 21 floats: d_kfState = pFrame->mpLastKeyFrame (fixed vertices),
+ * d_state in/out = the frame (GetImuRotation / GetImuPosition / GetVelocity / mImuBias -> SetImuPoseVelocity, mImuBias).
+ * Tbc12 (HOST) = mImuCalib.mTbc rotation (9) + translation (3); d_pre[f] = pFrame->mpImuPreintegrated.
+ * d_nInliers[f] = the return value; d_prior (optional) [nframes][246] doubles = pFrame->mpcpi (ConstraintPoseImu): the
+ * 21 state values in FP64 followed by the 15 x 15 H, row-major.  Pinhole camera 0 only (no second fisheye camera yet). */
+int morb_pose_inertial_optimization_last_keyframe_batch(morb_optimizer*, int nframes, int cap, const int* d_count,
+                                                        const uint8_t* d_hasMP, const float* d_obs, const float* d_invSigma2,
+                                                        const float* d_Xw, const uint8_t* d_close, float fx, float fy, float cx,
+                                                        float cy, float bf, const float* Tbc12, const float* d_kfState,
+                                                        const morb_imu_preintegrated* d_pre, int bRecInit, float* d_state,
+                                                        uint8_t* d_outlier, int* d_nInliers, double* d_prior, void* stream);
+
 /* static void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF,
  * int& num_OptKF, int& num_MPs, int& num_edges)  Optimizer.h:67-69, Optimizer.cc:1053-1441, on the graph the
  * reference assembles at :1058-1351, flattened (HOST pointers): nKF keyframes (local ones first or in any

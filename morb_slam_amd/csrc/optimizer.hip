@@ -1408,6 +1408,9 @@ int morb_optimizer_create(morb_optimizer** out, int device) {
   return MORB_OK;
 }
 
+int morb_optimizer_device(const morb_optimizer* o) { return o ? o->device : 0; }
+void* morb_optimizer_stream(const morb_optimizer* o) { return o ? (void*)o->stream : nullptr; }
+
 void morb_optimizer_destroy(morb_optimizer* o) {
   if (!o) return;
   (void)hipSetDevice(o->device);

@@ -7,6 +7,13 @@ import numpy as np
 from .capi import check, lib, ptr, stream_arg
 
 
+# morb_imu_preintegrated as a float32 record: field -> (offset, length)
+PREINT_FIELDS = {"dT": (0, 1), "dR": (1, 9), "dV": (10, 3), "dP": (13, 3), "JRg": (16, 9), "JVg": (25, 9), "JVa": (34, 9),
+                 "JPg": (43, 9), "JPa": (52, 9), "C": (61, 225), "b": (286, 6), "nga": (292, 6), "ngaWalk": (298, 6),
+                 "avgA": (304, 3), "avgW": (307, 3)}
+PREINT_FLOATS = 310
+
+
 class Optimizer:
     def __init__(self, device=0):
         self._L = lib()
@@ -51,6 +58,43 @@ class Optimizer:
         check(self._L.morb_pose_optimization_fisheye_batch(self._h, F, cap, ptr(count), ptr(nLeft), ptr(hasMP), ptr(obs), ptr(invSigma2),
                                                            ptr(Xw), ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(pose), ptr(out[1]), ptr(out[0]),
                                                            ptr(out[2]), st))
+        return out
+
+    # ---- visual-inertial tracking (first slice) -------------------------------------------------
+    def PreintegrateIMU(self, start, acc, gyro, dt, bias, nga, walk, out=None, stream=None):
+        """IMU::Preintegrated::Initialize + IntegrateNewMeasurement for many measurement sequences at once.
+        Device tensors: start i32 [S+1] (sequence s owns measurements start[s]:start[s+1]), acc / gyro f32 [M, 3],
+        dt f32 [M], bias f32 [S, 6] (bax bay baz bwx bwy bwz).  nga / walk: 6 floats each (diagonals of Calib::Cov /
+        CovWalk).  Returns f32 [S, PREINT_FLOATS] (morb_imu_preintegrated records, see PREINT_FIELDS)."""
+        import torch
+        S = start.shape[0] - 1
+        if out is None:
+            out = torch.empty((S, PREINT_FLOATS), dtype=torch.float32, device=acc.device)
+        a = [np.ascontiguousarray(x, np.float32) for x in (nga, walk)]
+        st = stream_arg(stream)
+        check(self._L.morb_imu_preintegrate_batch(self._h, S, ptr(start), ptr(acc), ptr(gyro), ptr(dt), ptr(bias), ptr(a[0]), ptr(a[1]),
+                                                  ptr(out), st))
+        return out
+
+    def PoseInertialOptimizationLastKeyFrame(self, hasMP, obs, invSigma2, Xw, close, cam, Tbc, kfState, pre, state, bRecInit=False,
+                                             count=None, want_prior=True, out=None, stream=None):
+        """Batched Optimizer::PoseInertialOptimizationLastKeyFrame.  Device tensors as PoseOptimization plus close u8
+        [F, cap] (mTrackDepth < 10), kfState f32 [F, 21] (fixed), pre f32 [F, PREINT_FLOATS], state f32 [F, 21] in/out
+        (Rwb row-major, twb, velocity, gyro bias, acc bias).  Tbc: 12 floats (rotation row-major + translation).
+        Returns (nInliers i32 [F], outlier u8 [F, cap], prior f64 [F, 246] or None)."""
+        import torch
+        F, cap = hasMP.shape
+        if out is None:
+            out = (torch.empty((F,), dtype=torch.int32, device=hasMP.device),
+                   torch.zeros((F, cap), dtype=torch.uint8, device=hasMP.device),
+                   torch.empty((F, 246), dtype=torch.float64, device=hasMP.device) if want_prior else None)
+        t = np.ascontiguousarray(Tbc, np.float32)
+        assert t.size == 12 and pre.shape[1] == PREINT_FLOATS and state.shape[1] == 21 and kfState.shape[1] == 21
+        st = stream_arg(stream)
+        check(self._L.morb_pose_inertial_optimization_last_keyframe_batch(
+            self._h, F, cap, ptr(count), ptr(hasMP), ptr(obs), ptr(invSigma2), ptr(Xw), ptr(close), cam["fx"], cam["fy"], cam["cx"],
+            cam["cy"], cam["bf"], ptr(t), ptr(kfState), ptr(pre), int(bool(bRecInit)), ptr(state), ptr(out[1]), ptr(out[0]),
+            ptr(out[2]), st))
         return out
 
     def LocalBundleAdjustment(self, kfPose, kfFixed, mpPos, eKF, eMP, eObs, eInvSigma2, cam, inertial=False, stop=False, mode=0,

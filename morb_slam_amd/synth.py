@@ -326,3 +326,74 @@ def make_ba_problem_fisheye(n_free=10, n_fixed=4, n_points=1500, seed=0, outlier
     return dict(kfPose=pose0.astype(np.float32), kfFixed=fixed, mpPos=X0.astype(np.float32), eKF=np.array(eKF, np.int32),
                 eMP=np.array(eMP, np.int32), eObs=np.array(eObs, np.float32), eInvSigma2=np.array(eInv, np.float32),
                 eRight=np.array(eRight, np.uint8), camL=TUMVI_CAM_L, camR=TUMVI_CAM_R, Trl=Trl7, true_poses=poses, true_points=X)
+
+
+# ---- visual-inertial tracking (PoseInertialOptimizationLastKeyFrame) ------------------------------------------------------
+def _rot_from_rotvec(r):
+    th = np.linalg.norm(r)
+    K = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
+    if th < 1e-9:
+        return np.eye(3) + K
+    return np.eye(3) + K * np.sin(th) / th + K @ K * (1 - np.cos(th)) / th ** 2
+
+
+# EuRoC-like IMU: body -> camera-0 extrinsics, noise densities at 200 Hz (Examples/Stereo-Inertial/EuRoC.yaml)
+EUROC_TBC = np.array([[0.0148655429818, -0.999880929698, 0.00414029679422, -0.0216401454975],
+                      [0.999557249008, 0.0149672133247, 0.025715529948, -0.064676986768],
+                      [-0.0257744366974, 0.00375618835797, 0.999660727178, 0.00981073058949],
+                      [0, 0, 0, 1]])
+IMU_FREQ = 200.0
+IMU_NOISE = dict(ng=1.7e-4, na=2.0e-3, ngw=1.9393e-05, naw=3.0e-3)
+
+
+def imu_calib_diagonals(freq=IMU_FREQ, noise=IMU_NOISE):
+    """Diagonals of IMU::Calib::Cov / CovWalk the way Tracking builds them (Tracking.cc ParseIMUParamFile:
+    Calib(Tbc, Ng * sqrt(freq), Na * sqrt(freq), Ngw / sqrt(freq), Naw / sqrt(freq)); ImuTypes.cc:375-388)."""
+    sf = np.sqrt(freq)
+    ng, na, ngw, naw = noise["ng"] * sf, noise["na"] * sf, noise["ngw"] / sf, noise["naw"] / sf
+    return (np.array([ng * ng] * 3 + [na * na] * 3, np.float32), np.array([ngw * ngw] * 3 + [naw * naw] * 3, np.float32))
+
+
+def make_inertial_problem(n=500, seed=0, n_imu=20, outlier_frac=0.1, mono_frac=0.3, rot_deg=1.0, trans=0.03, cam=EUROC_CAM):
+    """One PoseInertialOptimizationLastKeyFrame input: the last keyframe's state, n_imu IMU samples of a smooth motion
+    (constant body angular rate, constant world acceleration) between keyframe and frame, map points seen from the
+    frame's true pose, and a perturbed initial frame state.  States: Rwb (9), twb, v, bg, ba."""
+    rng = np.random.default_rng(0x1A70 + seed)
+    g = np.array([0, 0, -9.81])
+    R1 = _rot_from_rotvec(rng.normal(0, 0.3, 3)); p1 = rng.normal(0, 0.5, 3); v1 = rng.normal(0, 0.8, 3)
+    bg = rng.normal(0, 0.01, 3); ba = rng.normal(0, 0.05, 3)
+    w_b = rng.normal(0, 0.4, 3); a_w = rng.normal(0, 1.0, 3)
+    dt = 1.0 / IMU_FREQ
+    acc, gyro, dts = [], [], []
+    for i in range(n_imu):
+        tm = (i + 0.5) * dt
+        Rm = R1 @ _rot_from_rotvec(w_b * tm)
+        acc.append(Rm.T @ (a_w - g) + ba + rng.normal(0, 0.02, 3))
+        gyro.append(w_b + bg + rng.normal(0, 0.002, 3))
+        dts.append(dt)
+    T = n_imu * dt
+    R2 = R1 @ _rot_from_rotvec(w_b * T); v2 = v1 + a_w * T; p2 = p1 + v1 * T + 0.5 * a_w * T * T
+    Tbc = EUROC_TBC
+    Rcb = Tbc[:3, :3].T; tcb = -Rcb @ Tbc[:3, 3]
+    Rcw = Rcb @ R2.T; tcw = Rcb @ (-R2.T @ p2) + tcb
+    Xc = np.stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(1.5, 25, n)], 1)
+    Xw = (Xc - tcw) @ Rcw          # Rcw^T (Xc - tcw)
+    z = Xc[:, 2]
+    u = cam["fx"] * Xc[:, 0] / z + cam["cx"]; v = cam["fy"] * Xc[:, 1] / z + cam["cy"]; ur = u - cam["bf"] / z
+    octave = rng.integers(0, 8, n); sigma = 1.2 ** octave
+    u = u + rng.normal(0, 1, n) * sigma; v = v + rng.normal(0, 1, n) * sigma; ur = ur + rng.normal(0, 1, n) * sigma
+    out = rng.random(n) < outlier_frac
+    u[out] += rng.choice([-1, 1], out.sum()) * rng.uniform(15, 40, out.sum())
+    v[out] += rng.choice([-1, 1], out.sum()) * rng.uniform(15, 40, out.sum())
+    mono = rng.random(n) < mono_frac
+    ur[mono] = -1
+    has = (rng.random(n) < 0.9).astype(np.uint8)
+    R0 = R2 @ _rot_from_rotvec(rng.normal(0, 1, 3) / np.sqrt(3) * np.deg2rad(rot_deg))
+    state0 = np.concatenate([R0.ravel(), p2 + rng.normal(0, trans, 3), v2 + rng.normal(0, 0.05, 3), bg, ba]).astype(np.float32)
+    kf = np.concatenate([R1.ravel(), p1, v1, bg, ba]).astype(np.float32)
+    return dict(hasMP=has, obs=np.stack([u, v, ur], 1).astype(np.float32), invSigma2=(1.0 / sigma ** 2).astype(np.float32),
+                Xw=Xw.astype(np.float32), close=(z < 10).astype(np.uint8), state0=state0, kfState=kf,
+                acc=np.array(acc, np.float32), gyro=np.array(gyro, np.float32), dt=np.array(dts, np.float32),
+                bias=np.concatenate([ba, bg]).astype(np.float32),      # IMU::Bias order: acc then gyro
+                Tbc12=np.concatenate([Tbc[:3, :3].ravel(), Tbc[:3, 3]]).astype(np.float32), cam=cam,
+                true=np.concatenate([R2.ravel(), p2, v2, bg, ba]), outlier_truth=out)

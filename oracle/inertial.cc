@@ -1,0 +1,654 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product path.
+//
+// CPU restatement of the first slice of SURVEY §8(f) row N1 (visual-inertial tracking):
+//   IMU::Preintegrated::IntegrateNewMeasurement / GetDelta{Rotation,Velocity,Position}   src/ImuTypes.cc:84-107, :191-247, :289-312
+//   Optimizer::PoseInertialOptimizationLastKeyFrame                                      src/Optimizer.cc:4391-4757
+//   ImuCamPose (Project / ProjectStereo / isDepthPositive / Update)                      src/G2oTypes.cc:74-216
+//   EdgeMonoOnlyPose / EdgeStereoOnlyPose                                                include/G2oTypes.h:390-423, :466-493, src/G2oTypes.cc:361-442
+//   EdgeInertial (information, error, Jacobians, GetHessian2)                            src/G2oTypes.cc:472-585, include/G2oTypes.h:531-537
+//   EdgeGyroRW / EdgeAccRW                                                               include/G2oTypes.h:635-704
+//   ExpSO3 / LogSO3 / InverseRightJacobianSO3                                            src/G2oTypes.cc:779-829
+//   g2o Gauss-Newton (computeActiveErrors, buildSystem, dense LDLT solve, update)        Thirdparty/g2o/g2o/core/optimization_algorithm_gauss_newton.cpp:51-96,
+//                                                                                        core/sparse_optimizer.cpp:354-420, solvers/linear_solver_dense.h:65-113
+//   Pinhole::project / projectJac (double overloads, float parameters)                   src/CameraModels/Pinhole.cpp:38-44, :76-86
+// PARITY UNPINNED: the reference's tests hold no vectors for these functions and the reference does not build here (Eigen,
+// Sophus, g2o's Eigen dependency are absent).  Eigen / Sophus pieces are restated from their published formulas:
+//   * NormalizeRotation = U V^T of a JacobiSVD: restated as the polar factor (Newton iteration in FP64).  In ExpSO3 (FP64) the
+//     argument is already orthonormal to rounding, so the projection is omitted there; ImuCamPose::Update calls
+//     NormalizeRotation(Rwb) and DISCARDS the result (src/G2oTypes.cc:204-207), i.e. it does not normalise: restated as such.
+//   * Sophus::SO3f::exp(v).matrix() is restated with Rodrigues' formula in float.
+//   * Eigen::LDLT (pivoted) of the 15 x 15 system: restated as an LDL^T with diagonal pivoting and the same isPositive() test.
+//   * EdgeInertial's information: inverse of C(0:9,0:9) in FP64, symmetrised, eigenvalues below 1e-12 clamped to zero
+//     (cyclic Jacobi eigen-decomposition instead of Eigen::SelfAdjointEigenSolver).
+// Pinhole cameras only (mono and rectified-stereo observations of camera 0); the KannalaBrandt8 second camera is not restated.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "orb_oracle.h"
+
+namespace orc {
+namespace imu {
+
+// ---- float 3x3 helpers (row-major) ------------------------------------------------------------------------------------
+static void mul33f(const float* A, const float* B, float* C) {
+  float T[9];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) T[r * 3 + c] = A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c] + A[r * 3 + 2] * B[6 + c];
+  memcpy(C, T, sizeof T);
+}
+static void mul3vf(const float* A, const float* v, float* o) {
+  float t[3];
+  for (int r = 0; r < 3; ++r) t[r] = A[r * 3] * v[0] + A[r * 3 + 1] * v[1] + A[r * 3 + 2] * v[2];
+  memcpy(o, t, sizeof t);
+}
+static void hatf(const float* v, float* W) {
+  W[0] = 0; W[1] = -v[2]; W[2] = v[1]; W[3] = v[2]; W[4] = 0; W[5] = -v[0]; W[6] = -v[1]; W[7] = v[0]; W[8] = 0;
+}
+static void transpose33f(const float* A, float* T) {
+  float t[9];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) t[r * 3 + c] = A[c * 3 + r];
+  memcpy(T, t, sizeof t);
+}
+// polar factor of a near-rotation (= U V^T of its SVD), FP64 Newton iteration X <- (X + X^-T) / 2
+static void polar33(const double* A, double* Q) {
+  double X[9];
+  memcpy(X, A, sizeof X);
+  for (int it = 0; it < 6; ++it) {
+    const double c00 = X[4] * X[8] - X[5] * X[7], c01 = X[5] * X[6] - X[3] * X[8], c02 = X[3] * X[7] - X[4] * X[6];
+    const double det = X[0] * c00 + X[1] * c01 + X[2] * c02;
+    const double inv = 1.0 / det;
+    // inverse transpose = cofactor matrix / det
+    const double C[9] = {c00, c01, c02,
+                         X[2] * X[7] - X[1] * X[8], X[0] * X[8] - X[2] * X[6], X[1] * X[6] - X[0] * X[7],
+                         X[1] * X[5] - X[2] * X[4], X[2] * X[3] - X[0] * X[5], X[0] * X[4] - X[1] * X[3]};
+    for (int k = 0; k < 9; ++k) X[k] = 0.5 * (X[k] + C[k] * inv);
+  }
+  memcpy(Q, X, sizeof X);
+}
+static void normalizeRotationF(float* R) {  // ImuTypes.cc:35-39
+  double A[9], Q[9];
+  for (int k = 0; k < 9; ++k) A[k] = R[k];
+  polar33(A, Q);
+  for (int k = 0; k < 9; ++k) R[k] = (float)Q[k];
+}
+
+// IntegratedRotation (ImuTypes.cc:84-107)
+static void integratedRotation(const float* w, const float* b, float dt, float* deltaR, float* rightJ) {
+  const float eps = 1e-4f;  // ImuTypes.cc:33
+  const float x = (w[0] - b[3]) * dt, y = (w[1] - b[4]) * dt, z = (w[2] - b[5]) * dt;
+  const float d2 = x * x + y * y + z * z, d = std::sqrt(d2);
+  const float v[3] = {x, y, z};
+  float W[9], WW[9];
+  hatf(v, W);
+  mul33f(W, W, WW);
+  const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (d < eps) {
+    for (int k = 0; k < 9; ++k) { deltaR[k] = I[k] + W[k]; rightJ[k] = I[k]; }
+  } else {
+    const float s = std::sin(d), c = std::cos(d);
+    for (int k = 0; k < 9; ++k) {
+      deltaR[k] = I[k] + W[k] * s / d + WW[k] * (1.0f - c) / d2;
+      rightJ[k] = I[k] - W[k] * (1.0f - c) / d2 + WW[k] * (d - s) / (d2 * d);
+    }
+  }
+}
+
+static void initialize(orc_imu_preintegrated* P, const float* bias, const float* ngaDiag, const float* walkDiag) {  // :152-170
+  memset(P, 0, sizeof *P);
+  P->dR[0] = P->dR[4] = P->dR[8] = 1.f;
+  memcpy(P->b, bias, sizeof(float) * 6);
+  memcpy(P->nga, ngaDiag, sizeof(float) * 6);
+  memcpy(P->ngaWalk, walkDiag, sizeof(float) * 6);
+}
+
+// Preintegrated::IntegrateNewMeasurement (ImuTypes.cc:191-247); bias layout b = (bax, bay, baz, bwx, bwy, bwz)
+static void integrate(orc_imu_preintegrated* P, const float* a, const float* w, float dt) {
+  float A[81], B[54];
+  memset(A, 0, sizeof A); memset(B, 0, sizeof B);
+  for (int k = 0; k < 9; ++k) A[k * 9 + k] = 1.f;
+  const float acc[3] = {a[0] - P->b[0], a[1] - P->b[1], a[2] - P->b[2]};
+  const float accW[3] = {w[0] - P->b[3], w[1] - P->b[4], w[2] - P->b[5]};
+  float Racc[3];
+  mul3vf(P->dR, acc, Racc);
+  for (int k = 0; k < 3; ++k) {
+    P->avgA[k] = (P->dT * P->avgA[k] + Racc[k] * dt) / (P->dT + dt);
+    P->avgW[k] = (P->dT * P->avgW[k] + accW[k] * dt) / (P->dT + dt);
+  }
+  for (int k = 0; k < 3; ++k) {
+    P->dP[k] = P->dP[k] + P->dV[k] * dt + 0.5f * Racc[k] * dt * dt;
+    P->dV[k] = P->dV[k] + Racc[k] * dt;
+  }
+  float Wacc[9], RW[9];
+  hatf(acc, Wacc);
+  mul33f(P->dR, Wacc, RW);   // dR * Wacc
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      A[(3 + r) * 9 + c] = -RW[r * 3 + c] * dt;
+      A[(6 + r) * 9 + c] = -0.5f * RW[r * 3 + c] * dt * dt;
+      B[(3 + r) * 6 + 3 + c] = P->dR[r * 3 + c] * dt;
+      B[(6 + r) * 6 + 3 + c] = 0.5f * P->dR[r * 3 + c] * dt * dt;
+    }
+  for (int k = 0; k < 3; ++k) A[(6 + k) * 9 + 3 + k] = dt;
+  // bias-correction Jacobians of position and velocity
+  float RWJ[9];
+  mul33f(RW, P->JRg, RWJ);   // dR * Wacc * JRg
+  for (int k = 0; k < 9; ++k) {
+    P->JPa[k] = P->JPa[k] + P->JVa[k] * dt - 0.5f * P->dR[k] * dt * dt;
+    P->JPg[k] = P->JPg[k] + P->JVg[k] * dt - 0.5f * RWJ[k] * dt * dt;
+    P->JVa[k] = P->JVa[k] - P->dR[k] * dt;
+    P->JVg[k] = P->JVg[k] - RWJ[k] * dt;
+  }
+  float dRi[9], rJ[9], dRiT[9];
+  integratedRotation(w, P->b, dt, dRi, rJ);
+  mul33f(P->dR, dRi, P->dR);
+  normalizeRotationF(P->dR);
+  transpose33f(dRi, dRiT);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) { A[r * 9 + c] = dRiT[r * 3 + c]; B[r * 6 + c] = rJ[r * 3 + c] * dt; }
+  // C(0:9,0:9) = A C A^T + B Nga B^T ;  C(9:15,9:15) += NgaWalk   (C is 15 x 15 row-major)
+  float AC[81], N[81];
+  for (int r = 0; r < 9; ++r)
+    for (int c = 0; c < 9; ++c) {
+      float s = 0;
+      for (int k = 0; k < 9; ++k) s += A[r * 9 + k] * P->C[k * 15 + c];
+      AC[r * 9 + c] = s;
+    }
+  for (int r = 0; r < 9; ++r)
+    for (int c = 0; c < 9; ++c) {
+      float s = 0;
+      for (int k = 0; k < 9; ++k) s += AC[r * 9 + k] * A[c * 9 + k];
+      float t = 0;
+      for (int k = 0; k < 6; ++k) t += B[r * 6 + k] * P->nga[k] * B[c * 6 + k];
+      N[r * 9 + c] = s + t;
+    }
+  for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) P->C[r * 15 + c] = N[r * 9 + c];
+  for (int k = 0; k < 6; ++k) P->C[(9 + k) * 15 + 9 + k] += P->ngaWalk[k];
+  // JRg = dRi^T JRg - rightJ dt
+  float t9[9];
+  mul33f(dRiT, P->JRg, t9);
+  for (int k = 0; k < 9; ++k) P->JRg[k] = t9[k] - rJ[k] * dt;
+  P->dT += dt;
+}
+
+// ---- FP64 pieces ----------------------------------------------------------------------------------------------------------
+static void mul33(const double* A, const double* B, double* C) {
+  double T[9];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) T[r * 3 + c] = A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c] + A[r * 3 + 2] * B[6 + c];
+  memcpy(C, T, sizeof T);
+}
+static void mul3v(const double* A, const double* v, double* o) {
+  double t[3];
+  for (int r = 0; r < 3; ++r) t[r] = A[r * 3] * v[0] + A[r * 3 + 1] * v[1] + A[r * 3 + 2] * v[2];
+  memcpy(o, t, sizeof t);
+}
+static void mulT3v(const double* A, const double* v, double* o) {   // A^T v
+  double t[3];
+  for (int r = 0; r < 3; ++r) t[r] = A[r] * v[0] + A[3 + r] * v[1] + A[6 + r] * v[2];
+  memcpy(o, t, sizeof t);
+}
+static void transpose33(const double* A, double* T) {
+  double t[9];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) t[r * 3 + c] = A[c * 3 + r];
+  memcpy(T, t, sizeof t);
+}
+static void expSO3(const double* w, double* R) {  // G2oTypes.cc:783-796 (projection omitted, see header)
+  const double x = w[0], y = w[1], z = w[2];
+  const double d2 = x * x + y * y + z * z, d = std::sqrt(d2);
+  const double W[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+  double WW[9];
+  mul33(W, W, WW);
+  const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (d < 1e-5) for (int k = 0; k < 9; ++k) R[k] = I[k] + W[k] + 0.5 * WW[k];
+  else {
+    const double s = std::sin(d), c = std::cos(d);
+    for (int k = 0; k < 9; ++k) R[k] = I[k] + W[k] * s / d + WW[k] * (1.0 - c) / d2;
+  }
+}
+static void logSO3(const double* R, double* w) {  // G2oTypes.cc:798-811
+  const double tr = R[0] + R[4] + R[8];
+  w[0] = (R[7] - R[5]) / 2; w[1] = (R[2] - R[6]) / 2; w[2] = (R[3] - R[1]) / 2;
+  const double costheta = (tr - 1.0) * 0.5f;
+  if (costheta > 1 || costheta < -1) return;
+  const double theta = std::acos(costheta), s = std::sin(theta);
+  if (std::fabs(s) < 1e-5) return;
+  for (int k = 0; k < 3; ++k) w[k] = theta * w[k] / s;
+}
+static void invRightJacobianSO3(const double* v, double* J) {  // G2oTypes.cc:817-829
+  const double x = v[0], y = v[1], z = v[2];
+  const double d2 = x * x + y * y + z * z, d = std::sqrt(d2);
+  const double W[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+  const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (d < 1e-5) { memcpy(J, I, sizeof I); return; }
+  double WW[9];
+  mul33(W, W, WW);
+  const double k2 = 1.0 / d2 - (1.0 + std::cos(d)) / (2.0 * d * std::sin(d));
+  for (int k = 0; k < 9; ++k) J[k] = I[k] + W[k] / 2 + WW[k] * k2;
+}
+
+// general n x n inverse, Gauss-Jordan with partial pivoting (Eigen: PartialPivLU based inverse)
+static bool invertN(const double* A, int n, double* Ainv) {
+  std::vector<double> M((size_t)n * 2 * n, 0.0);
+  for (int r = 0; r < n; ++r) { for (int c = 0; c < n; ++c) M[(size_t)r * 2 * n + c] = A[r * n + c]; M[(size_t)r * 2 * n + n + r] = 1.0; }
+  for (int c = 0; c < n; ++c) {
+    int p = c;
+    for (int r = c + 1; r < n; ++r) if (std::fabs(M[(size_t)r * 2 * n + c]) > std::fabs(M[(size_t)p * 2 * n + c])) p = r;
+    if (M[(size_t)p * 2 * n + c] == 0.0) return false;
+    if (p != c) for (int k = 0; k < 2 * n; ++k) std::swap(M[(size_t)p * 2 * n + k], M[(size_t)c * 2 * n + k]);
+    const double inv = 1.0 / M[(size_t)c * 2 * n + c];
+    for (int k = 0; k < 2 * n; ++k) M[(size_t)c * 2 * n + k] *= inv;
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      const double f = M[(size_t)r * 2 * n + c];
+      if (f != 0.0) for (int k = 0; k < 2 * n; ++k) M[(size_t)r * 2 * n + k] -= f * M[(size_t)c * 2 * n + k];
+    }
+  }
+  for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) Ainv[r * n + c] = M[(size_t)r * 2 * n + n + c];
+  return true;
+}
+// symmetric eigen-decomposition, cyclic Jacobi: A = V diag(e) V^T
+static void jacobiEig(const double* A, int n, double* e, double* V) {
+  std::vector<double> a(A, A + (size_t)n * n);
+  for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) V[r * n + c] = r == c ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0, diag = 0;
+    for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) (r == c ? diag : off) += a[r * n + c] * a[r * n + c];
+    if (off <= 1e-30 * diag) break;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        if (a[p * n + q] == 0.0) continue;
+        const double theta = (a[q * n + q] - a[p * n + p]) / (2.0 * a[p * n + q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; ++k) {
+          const double akp = a[k * n + p], akq = a[k * n + q];
+          a[k * n + p] = c * akp - s * akq; a[k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double apk = a[p * n + k], aqk = a[q * n + k];
+          a[p * n + k] = c * apk - s * aqk; a[q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double vkp = V[k * n + p], vkq = V[k * n + q];
+          V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  for (int k = 0; k < n; ++k) e[k] = a[k * n + k];
+}
+// EdgeInertial's information (G2oTypes.cc:484-491)
+static void inertialInformation(const float* C15, double* Info) {
+  double C9[81], Inv[81];
+  for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) C9[r * 9 + c] = (double)C15[r * 15 + c];
+  if (!invertN(C9, 9, Inv)) { memset(Info, 0, sizeof(double) * 81); return; }
+  double S[81];
+  for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) S[r * 9 + c] = (Inv[r * 9 + c] + Inv[c * 9 + r]) / 2;
+  double e[9], V[81];
+  jacobiEig(S, 9, e, V);
+  for (int k = 0; k < 9; ++k) if (e[k] < 1e-12) e[k] = 0;
+  for (int r = 0; r < 9; ++r)
+    for (int c = 0; c < 9; ++c) {
+      double s = 0;
+      for (int k = 0; k < 9; ++k) s += V[r * 9 + k] * e[k] * V[c * 9 + k];
+      Info[r * 9 + c] = s;
+    }
+}
+
+// Eigen::LDLT with diagonal pivoting; solves H x = b when the factorisation is positive (linear_solver_dense.h:104-112)
+static bool ldltSolve(const double* Hin, const double* b, int n, double* x) {
+  std::vector<double> A(Hin, Hin + (size_t)n * n);
+  std::vector<int> perm(n);
+  for (int k = 0; k < n; ++k) perm[k] = k;
+  bool positive = true;
+  for (int k = 0; k < n; ++k) {
+    int p = k;
+    for (int r = k + 1; r < n; ++r) if (std::fabs(A[r * n + r]) > std::fabs(A[p * n + p])) p = r;
+    if (p != k) {
+      for (int c = 0; c < n; ++c) std::swap(A[k * n + c], A[p * n + c]);
+      for (int r = 0; r < n; ++r) std::swap(A[r * n + k], A[r * n + p]);
+      std::swap(perm[k], perm[p]);
+    }
+    const double d = A[k * n + k];
+    if (!(d > 0)) positive = false;
+    if (d == 0) continue;
+    for (int r = k + 1; r < n; ++r) {
+      const double l = A[r * n + k] / d;
+      for (int c = k + 1; c <= r; ++c) { A[r * n + c] -= l * A[c * n + k]; A[c * n + r] = A[r * n + c]; }
+      A[r * n + k] = l;
+    }
+  }
+  if (!positive) return false;
+  std::vector<double> y(n);
+  for (int k = 0; k < n; ++k) y[k] = b[perm[k]];
+  for (int r = 0; r < n; ++r) for (int c = 0; c < r; ++c) y[r] -= A[r * n + c] * y[c];
+  for (int k = 0; k < n; ++k) y[k] /= A[k * n + k];
+  for (int r = n - 1; r >= 0; --r) for (int c = r + 1; c < n; ++c) y[r] -= A[c * n + r] * y[c];
+  for (int k = 0; k < n; ++k) x[perm[k]] = y[k];
+  return true;
+}
+
+struct CamPose {  // ImuCamPose with one pinhole camera
+  double Rwb[9], twb[3];
+  double Rcw[9], tcw[3];
+  double Rcb[9], tcb[3], Rbc[9], tbc[3];
+  double bf;
+  float fx, fy, cx, cy;
+  void refreshCamera() {   // G2oTypes.cc:209-215
+    double Rbw[9], tbw[3];
+    transpose33(Rwb, Rbw);
+    mul3v(Rbw, twb, tbw);
+    for (double& c : tbw) c = -c;
+    mul33(Rcb, Rbw, Rcw);
+    mul3v(Rcb, tbw, tcw);
+    for (int k = 0; k < 3; ++k) tcw[k] += tcb[k];
+  }
+  void update(const double* pu) {   // ImuCamPose::Update (G2oTypes.cc:192-216)
+    double t[3], dR[9];
+    mul3v(Rwb, pu + 3, t);
+    for (int k = 0; k < 3; ++k) twb[k] += t[k];
+    expSO3(pu, dR);
+    mul33(Rwb, dR, Rwb);
+    refreshCamera();
+  }
+  void camPoint(const double* Xw, double* Xc) const { mul3v(Rcw, Xw, Xc); for (int k = 0; k < 3; ++k) Xc[k] += tcw[k]; }
+  void project(const double* Xc, double* uv) const {   // Pinhole.cpp:38-44
+    uv[0] = fx * Xc[0] / Xc[2] + cx;
+    uv[1] = fy * Xc[1] / Xc[2] + cy;
+  }
+  void projectJac(const double* Xc, double* J) const {   // Pinhole.cpp:76-86
+    J[0] = fx / Xc[2]; J[1] = 0; J[2] = -fx * Xc[0] / (Xc[2] * Xc[2]);
+    J[3] = 0; J[4] = fy / Xc[2]; J[5] = -fy * Xc[1] / (Xc[2] * Xc[2]);
+  }
+};
+
+struct VisEdge {
+  int idx; bool stereo; double obs[3]; double Xw[3]; double info; bool close;
+  int level = 0; bool robust = true;
+  double err[3] = {0, 0, 0};
+  double chi2() const { const int d = stereo ? 3 : 2; double s = 0; for (int k = 0; k < d; ++k) s += err[k] * info * err[k]; return s; }
+  void computeError(const CamPose& P) {   // G2oTypes.h:401-405 / :477-481, G2oTypes.cc:171-186
+    double Xc[3], uv[2];
+    P.camPoint(Xw, Xc);
+    P.project(Xc, uv);
+    err[0] = obs[0] - uv[0]; err[1] = obs[1] - uv[1];
+    if (stereo) { const double invZ = 1 / Xc[2]; err[2] = obs[2] - (uv[0] - P.bf * invZ); }
+  }
+  bool depthPositive(const CamPose& P) const { return (P.Rcw[6] * Xw[0] + P.Rcw[7] * Xw[1] + P.Rcw[8] * Xw[2] + P.tcw[2]) > 0.0; }
+  void jacobian(const CamPose& P, double* J /* d x 6 */) const {   // G2oTypes.cc:361-382 / :417-442
+    double Xc[3], Xb[3];
+    P.camPoint(Xw, Xc);
+    mul3v(P.Rbc, Xc, Xb);
+    for (int k = 0; k < 3; ++k) Xb[k] += P.tbc[k];
+    double pj[9];
+    P.projectJac(Xc, pj);
+    int d = 2;
+    if (stereo) {
+      d = 3;
+      const double inv_z2 = 1.0 / (Xc[2] * Xc[2]);
+      pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + P.bf * inv_z2;
+    }
+    const double x = Xb[0], y = Xb[1], z = Xb[2];
+    const double S[18] = {0.0, z, -y, 1.0, 0.0, 0.0, -z, 0.0, x, 0.0, 1.0, 0.0, y, -x, 0.0, 0.0, 0.0, 1.0};
+    double PR[9];
+    for (int r = 0; r < d; ++r)
+      for (int c = 0; c < 3; ++c) PR[r * 3 + c] = pj[r * 3] * P.Rcb[c] + pj[r * 3 + 1] * P.Rcb[3 + c] + pj[r * 3 + 2] * P.Rcb[6 + c];
+    for (int r = 0; r < d; ++r)
+      for (int c = 0; c < 6; ++c) J[r * 6 + c] = PR[r * 3] * S[c] + PR[r * 3 + 1] * S[6 + c] + PR[r * 3 + 2] * S[12 + c];
+  }
+};
+
+static void huber(double delta, double e2, double* rho) {   // robust_kernel_impl.cpp:65-91
+  const double dsqr = delta * delta;
+  if (e2 <= dsqr) { rho[0] = e2; rho[1] = 1.; rho[2] = 0.; }
+  else {
+    const double sqrte = std::sqrt(e2);
+    rho[0] = 2 * sqrte * delta - dsqr;
+    rho[1] = delta / sqrte;
+    rho[2] = -0.5 * rho[1] / e2;
+  }
+}
+
+}  // namespace imu
+}  // namespace orc
+
+using namespace orc::imu;
+
+extern "C" void orc_imu_preintegrate(const float* bias6, const float* ngaDiag6, const float* walkDiag6, int n, const float* acc,
+                                     const float* gyro, const float* dt, orc_imu_preintegrated* out) {
+  initialize(out, bias6, ngaDiag6, walkDiag6);
+  for (int i = 0; i < n; ++i) integrate(out, acc + 3 * i, gyro + 3 * i, dt[i]);
+}
+
+// GetDeltaRotation / GetDeltaVelocity / GetDeltaPosition at bias b1 (ImuTypes.cc:289-312), FP32 like the reference
+extern "C" void orc_imu_delta(const orc_imu_preintegrated* P, const float* b1, float* dR, float* dV, float* dP) {
+  const float dbg[3] = {b1[3] - P->b[3], b1[4] - P->b[4], b1[5] - P->b[5]};
+  const float dba[3] = {b1[0] - P->b[0], b1[1] - P->b[1], b1[2] - P->b[2]};
+  float w[3];
+  mul3vf(P->JRg, dbg, w);
+  // Sophus::SO3f::exp(w).matrix(): Rodrigues
+  const float t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], t = std::sqrt(t2);
+  float W[9], WW[9], E[9];
+  hatf(w, W);
+  mul33f(W, W, WW);
+  const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (t < 1e-5f) for (int k = 0; k < 9; ++k) E[k] = I[k] + W[k] + 0.5f * WW[k];
+  else { const float s = std::sin(t), c = std::cos(t); for (int k = 0; k < 9; ++k) E[k] = I[k] + W[k] * s / t + WW[k] * (1.0f - c) / t2; }
+  mul33f(P->dR, E, dR);
+  normalizeRotationF(dR);
+  float g1[3], a1[3];
+  mul3vf(P->JVg, dbg, g1); mul3vf(P->JVa, dba, a1);
+  for (int k = 0; k < 3; ++k) dV[k] = P->dV[k] + g1[k] + a1[k];
+  mul3vf(P->JPg, dbg, g1); mul3vf(P->JPa, dba, a1);
+  for (int k = 0; k < 3; ++k) dP[k] = P->dP[k] + g1[k] + a1[k];
+}
+
+// Optimizer::PoseInertialOptimizationLastKeyFrame (Optimizer.cc:4391-4757) for one frame.
+// state / kfState = Rwb (9, row-major), twb, velocity, gyro bias, acc bias (21 floats); Tbc12 = Rbc (9) + tbc (3).
+// prior246 (optional) = ConstraintPoseImu: Rwb, twb, v, bg, ba (21 doubles) + H (15 x 15 row-major).
+extern "C" int orc_pose_inertial_optimization_last_keyframe(int n, const uint8_t* hasMP, const float* obs, const float* invSigma2,
+                                                            const float* Xw, const uint8_t* closeFlag, float fx, float fy, float cx,
+                                                            float cy, float bf, const float* Tbc12, const float* kfState21,
+                                                            const orc_imu_preintegrated* pre, int bRecInit, float* state21,
+                                                            uint8_t* outlier, double* prior246) {
+  CamPose VP;
+  for (int k = 0; k < 9; ++k) VP.Rwb[k] = state21[k];
+  for (int k = 0; k < 3; ++k) VP.twb[k] = state21[9 + k];
+  double v[3], bg[3], ba[3];
+  for (int k = 0; k < 3; ++k) { v[k] = state21[12 + k]; bg[k] = state21[15 + k]; ba[k] = state21[18 + k]; }
+  for (int k = 0; k < 9; ++k) VP.Rbc[k] = Tbc12[k];
+  for (int k = 0; k < 3; ++k) VP.tbc[k] = Tbc12[9 + k];
+  transpose33(VP.Rbc, VP.Rcb);                      // mTcb = mTbc.inverse()
+  mul3v(VP.Rcb, VP.tbc, VP.tcb);
+  for (double& c : VP.tcb) c = -c;
+  VP.bf = bf; VP.fx = fx; VP.fy = fy; VP.cx = cx; VP.cy = cy;
+  VP.refreshCamera();
+
+  const double thHuberMono = (double)(float)std::sqrt(5.991), thHuberStereo = (double)(float)std::sqrt(7.815);
+  std::vector<VisEdge> mono, stereo;
+  for (int i = 0; i < n; ++i) {
+    if (!hasMP[i]) continue;
+    VisEdge e;
+    e.idx = i; e.stereo = !(obs[3 * i + 2] < 0);
+    e.obs[0] = obs[3 * i]; e.obs[1] = obs[3 * i + 1]; e.obs[2] = obs[3 * i + 2];
+    for (int k = 0; k < 3; ++k) e.Xw[k] = Xw[3 * i + k];
+    const float unc2 = 1.0f;                        // Pinhole::uncertainty2
+    const float is2 = invSigma2[i] / unc2;
+    e.info = is2; e.close = closeFlag[i] != 0;
+    outlier[i] = 0;
+    (e.stereo ? stereo : mono).push_back(e);
+  }
+  const int nInitial = (int)(mono.size() + stereo.size());
+
+  // fixed keyframe vertices and the inertial edge's constants
+  double Rwb1[9], twb1[3], v1[3], bg1[3], ba1[3];
+  for (int k = 0; k < 9; ++k) Rwb1[k] = kfState21[k];
+  for (int k = 0; k < 3; ++k) { twb1[k] = kfState21[9 + k]; v1[k] = kfState21[12 + k]; bg1[k] = kfState21[15 + k]; ba1[k] = kfState21[18 + k]; }
+  const float b1f[6] = {(float)ba1[0], (float)ba1[1], (float)ba1[2], (float)bg1[0], (float)bg1[1], (float)bg1[2]};   // IMU::Bias(float...)
+  float dRf[9], dVf[3], dPf[3];
+  orc_imu_delta(pre, b1f, dRf, dVf, dPf);
+  double dR[9], dV[3], dP[3];
+  for (int k = 0; k < 9; ++k) dR[k] = dRf[k];
+  for (int k = 0; k < 3; ++k) { dV[k] = dVf[k]; dP[k] = dPf[k]; }
+  const double dt = pre->dT;
+  const double g[3] = {0, 0, -(double)9.81f};
+  double InfoI[81], InfoG[9], InfoA[9];
+  inertialInformation(pre->C, InfoI);
+  {
+    double Cg[9], Ca[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { Cg[r * 3 + c] = pre->C[(9 + r) * 15 + 9 + c]; Ca[r * 3 + c] = pre->C[(12 + r) * 15 + 12 + c]; }
+    invertN(Cg, 3, InfoG); invertN(Ca, 3, InfoA);
+  }
+  double Rbw1[9];
+  transpose33(Rwb1, Rbw1);
+
+  // inertial edge: error (9) and the Jacobians w.r.t. pose 2 (9 x 6) and velocity 2 (9 x 3)   G2oTypes.cc:494-585
+  auto inertial = [&](double* err, double* J4, double* J5) {
+    double dRt[9], M[9], eR[9], er[3];
+    transpose33(dR, dRt);
+    mul33(dRt, Rbw1, M);
+    mul33(M, VP.Rwb, eR);
+    logSO3(eR, er);
+    double t[3], ev[3], ep[3];
+    for (int k = 0; k < 3; ++k) t[k] = v[k] - v1[k] - g[k] * dt;
+    mul3v(Rbw1, t, ev);
+    for (int k = 0; k < 3; ++k) ev[k] -= dV[k];
+    for (int k = 0; k < 3; ++k) t[k] = VP.twb[k] - twb1[k] - v1[k] * dt - g[k] * dt * dt / 2;
+    mul3v(Rbw1, t, ep);
+    for (int k = 0; k < 3; ++k) ep[k] -= dP[k];
+    for (int k = 0; k < 3; ++k) { err[k] = er[k]; err[3 + k] = ev[k]; err[6 + k] = ep[k]; }
+    if (J4) {
+      double invJr[9], RR[9];
+      invRightJacobianSO3(er, invJr);
+      mul33(Rbw1, VP.Rwb, RR);
+      memset(J4, 0, sizeof(double) * 54); memset(J5, 0, sizeof(double) * 27);
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) { J4[r * 6 + c] = invJr[r * 3 + c]; J4[(6 + r) * 6 + 3 + c] = RR[r * 3 + c]; J5[(3 + r) * 3 + c] = Rbw1[r * 3 + c]; }
+    }
+  };
+
+  const float chi2Mono[4] = {12, 7.5, 5.991, 5.991};
+  const float chi2Stereo[4] = {15.6, 9.8, 7.815, 7.815};
+  int nBad = 0, nInliers = 0;
+  double xPrev[15];
+  memset(xPrev, 0, sizeof xPrev);
+  for (int it = 0; it < 4; ++it) {
+    // optimizer.initializeOptimization(0); optimizer.optimize(10): Gauss-Newton over the level-0 edges
+    bool ok = true;
+    for (int iter = 0; iter < 10 && ok; ++iter) {
+      double H[225], b[15];
+      memset(H, 0, sizeof H); memset(b, 0, sizeof b);
+      auto visual = [&](std::vector<VisEdge>& E, double delta) {
+        for (VisEdge& e : E) {
+          if (e.level != 0) continue;
+          e.computeError(VP);
+          const int d = e.stereo ? 3 : 2;
+          double J[18];
+          e.jacobian(VP, J);
+          double w = 1.0;
+          if (e.robust) { double rho[3]; huber(delta, e.chi2(), rho); w = rho[1]; }
+          for (int r = 0; r < 6; ++r) {
+            double bb = 0;
+            for (int k = 0; k < d; ++k) bb += J[k * 6 + r] * (e.info * e.err[k]);
+            b[r] -= w * bb;
+            for (int c = 0; c < 6; ++c) {
+              double h = 0;
+              for (int k = 0; k < d; ++k) h += J[k * 6 + r] * (w * e.info) * J[k * 6 + c];
+              H[r * 15 + c] += h;
+            }
+          }
+        }
+      };
+      visual(mono, thHuberMono);
+      visual(stereo, thHuberStereo);
+      {  // EdgeInertial on (pose 2, velocity 2): columns 0..5 and 6..8
+        double err[9], J4[54], J5[27], J[81];
+        inertial(err, J4, J5);
+        for (int r = 0; r < 9; ++r) { for (int c = 0; c < 6; ++c) J[r * 9 + c] = J4[r * 6 + c]; for (int c = 0; c < 3; ++c) J[r * 9 + 6 + c] = J5[r * 3 + c]; }
+        double OJ[81], Oe[9];
+        for (int r = 0; r < 9; ++r) {
+          for (int c = 0; c < 9; ++c) { double s = 0; for (int k = 0; k < 9; ++k) s += InfoI[r * 9 + k] * J[k * 9 + c]; OJ[r * 9 + c] = s; }
+          double s = 0; for (int k = 0; k < 9; ++k) s += InfoI[r * 9 + k] * err[k]; Oe[r] = s;
+        }
+        for (int r = 0; r < 9; ++r) {
+          double s = 0; for (int k = 0; k < 9; ++k) s += J[k * 9 + r] * Oe[k];
+          b[r] -= s;
+          for (int c = 0; c < 9; ++c) { double h = 0; for (int k = 0; k < 9; ++k) h += J[k * 9 + r] * OJ[k * 9 + c]; H[r * 15 + c] += h; }
+        }
+      }
+      for (int r = 0; r < 3; ++r) {  // EdgeGyroRW / EdgeAccRW: error = bias2 - bias1, Jacobian w.r.t. bias2 = I
+        double sg = 0, sa = 0;
+        for (int k = 0; k < 3; ++k) { sg += InfoG[r * 3 + k] * (bg[k] - bg1[k]); sa += InfoA[r * 3 + k] * (ba[k] - ba1[k]); }
+        b[9 + r] -= sg; b[12 + r] -= sa;
+        for (int c = 0; c < 3; ++c) { H[(9 + r) * 15 + 9 + c] += InfoG[r * 3 + c]; H[(12 + r) * 15 + 12 + c] += InfoA[r * 3 + c]; }
+      }
+      double x[15];
+      memcpy(x, xPrev, sizeof x);   // a failed solve leaves the previous solution in the solver's x (block_solver.hpp)
+      ok = ldltSolve(H, b, 15, x);
+      memcpy(xPrev, x, sizeof x);
+      VP.update(x);
+      for (int k = 0; k < 3; ++k) { v[k] += x[6 + k]; bg[k] += x[9 + k]; ba[k] += x[12 + k]; }
+    }
+
+    nBad = 0; nInliers = 0;
+    const float chi2close = 1.5 * chi2Mono[it];
+    for (VisEdge& e : mono) {
+      if (outlier[e.idx]) e.computeError(VP);
+      const float chi2 = (float)e.chi2();
+      const bool bClose = e.close;
+      if ((chi2 > chi2Mono[it] && !bClose) || (bClose && chi2 > chi2close) || !e.depthPositive(VP)) { outlier[e.idx] = 1; e.level = 1; ++nBad; }
+      else { outlier[e.idx] = 0; e.level = 0; ++nInliers; }
+      if (it == 2) e.robust = false;
+    }
+    for (VisEdge& e : stereo) {
+      if (outlier[e.idx]) e.computeError(VP);
+      const float chi2 = (float)e.chi2();
+      if (chi2 > chi2Stereo[it]) { outlier[e.idx] = 1; e.level = 1; ++nBad; }
+      else { outlier[e.idx] = 0; e.level = 0; ++nInliers; }
+      if (it == 2) e.robust = false;
+    }
+    if (nInitial + 3 < 10) break;   // optimizer.edges().size() < 10
+  }
+
+  if (nInliers < 30 && !bRecInit) {   // :4683-4707
+    nBad = 0;
+    for (VisEdge& e : mono) { e.computeError(VP); if ((float)e.chi2() < 18.f) outlier[e.idx] = 0; else ++nBad; }
+    for (VisEdge& e : stereo) { e.computeError(VP); if ((float)e.chi2() < 24.f) outlier[e.idx] = 0; else ++nBad; }
+  }
+
+  // SetImuPoseVelocity + bias (:4709-4715): floats
+  for (int k = 0; k < 9; ++k) state21[k] = (float)VP.Rwb[k];
+  for (int k = 0; k < 3; ++k) { state21[9 + k] = (float)VP.twb[k]; state21[12 + k] = (float)v[k]; state21[15 + k] = (float)bg[k]; state21[18 + k] = (float)ba[k]; }
+
+  if (prior246) {   // ConstraintPoseImu (:4717-4754)
+    double Hm[225];
+    memset(Hm, 0, sizeof Hm);
+    {
+      double err[9], J4[54], J5[27], J[81];
+      inertial(err, J4, J5);
+      for (int r = 0; r < 9; ++r) { for (int c = 0; c < 6; ++c) J[r * 9 + c] = J4[r * 6 + c]; for (int c = 0; c < 3; ++c) J[r * 9 + 6 + c] = J5[r * 3 + c]; }
+      for (int r = 0; r < 9; ++r)
+        for (int c = 0; c < 9; ++c) {
+          double h = 0;
+          for (int k = 0; k < 9; ++k) for (int l = 0; l < 9; ++l) h += J[k * 9 + r] * InfoI[k * 9 + l] * J[l * 9 + c];
+          Hm[r * 15 + c] += h;
+        }
+    }
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { Hm[(9 + r) * 15 + 9 + c] += InfoG[r * 3 + c]; Hm[(12 + r) * 15 + 12 + c] += InfoA[r * 3 + c]; }
+    auto add = [&](std::vector<VisEdge>& E) {
+      for (VisEdge& e : E) {
+        if (outlier[e.idx]) continue;
+        const int d = e.stereo ? 3 : 2;
+        double J[18];
+        e.jacobian(VP, J);
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { double h = 0; for (int k = 0; k < d; ++k) h += J[k * 6 + r] * e.info * J[k * 6 + c]; Hm[r * 15 + c] += h; }
+      }
+    };
+    add(mono); add(stereo);
+    for (int k = 0; k < 9; ++k) prior246[k] = VP.Rwb[k];
+    for (int k = 0; k < 3; ++k) { prior246[9 + k] = VP.twb[k]; prior246[12 + k] = v[k]; prior246[15 + k] = bg[k]; prior246[18 + k] = ba[k]; }
+    memcpy(prior246 + 21, Hm, sizeof Hm);
+  }
+  return nInitial - nBad;
+}

@@ -139,6 +139,24 @@ int orc_local_ba_fisheye(int nKF, float* kfPose, const uint8_t* kfFixed, int nMP
                          const int* eMP, const float* eObs2, const uint8_t* eRight, const float* eInvSigma2, const float* camL8,
                          const float* camR8, const float* Trl7, int lambdaInit100, const int* stopFlag, uint8_t* eraseFlag,
                          int* stats);
+/* ---- N1 slice: IMU preintegration + PoseInertialOptimizationLastKeyFrame (oracle/inertial.cc) ---- */
+typedef struct {
+  float dT;
+  float dR[9], dV[3], dP[3];                 /* row-major 3x3 */
+  float JRg[9], JVg[9], JVa[9], JPg[9], JPa[9];
+  float C[225];                              /* 15 x 15 row-major */
+  float b[6];                                /* bax bay baz bwx bwy bwz (IMU::Bias order) */
+  float nga[6], ngaWalk[6];                  /* diagonals of Calib::Cov / CovWalk: gyro x3, acc x3 */
+  float avgA[3], avgW[3];
+} orc_imu_preintegrated;
+void orc_imu_preintegrate(const float* bias6, const float* ngaDiag6, const float* walkDiag6, int n, const float* acc,
+                          const float* gyro, const float* dt, orc_imu_preintegrated* out);
+void orc_imu_delta(const orc_imu_preintegrated* P, const float* b1, float* dR, float* dV, float* dP);
+int orc_pose_inertial_optimization_last_keyframe(int n, const uint8_t* hasMP, const float* obs, const float* invSigma2,
+                                                 const float* Xw, const uint8_t* closeFlag, float fx, float fy, float cx,
+                                                 float cy, float bf, const float* Tbc12, const float* kfState21,
+                                                 const orc_imu_preintegrated* pre, int bRecInit, float* state21,
+                                                 uint8_t* outlier, double* prior246);
 float orc_fast_atan2(float y, float x);
 float orc_cosf(float x);
 float orc_sinf(float x);

@@ -447,3 +447,33 @@ def pose_optimization_fisheye(p):
     r = L.orc_pose_optimization_fisheye(n, p["Nleft"], _p(a[0]), _p(obs2), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), _p(a[5]), _p(pose),
                                         _p(outl), _p(stats))
     return r, pose, outl, stats
+
+
+# ---- N1 slice: IMU preintegration + PoseInertialOptimizationLastKeyFrame (oracle/inertial.cc) ----
+PREINT_FLOATS = 310   # orc_imu_preintegrated is all floats: same record layout as morb_imu_preintegrated
+
+
+def imu_preintegrate(bias6, nga6, walk6, acc, gyro, dt):
+    L = lib()
+    L.orc_imu_preintegrate.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4
+    L.orc_imu_preintegrate.restype = None
+    out = np.zeros(PREINT_FLOATS, np.float32)
+    a = [np.ascontiguousarray(x, np.float32) for x in (bias6, nga6, walk6, acc, gyro, dt)]
+    L.orc_imu_preintegrate(_p(a[0]), _p(a[1]), _p(a[2]), len(a[5]), _p(a[3]), _p(a[4]), _p(a[5]), _p(out))
+    return out
+
+
+def pose_inertial_optimization_last_keyframe(p, pre, bRecInit=False):
+    L = lib()
+    f = C.c_float
+    L.orc_pose_inertial_optimization_last_keyframe.argtypes = [C.c_int] + [C.c_void_p] * 5 + [f] * 5 + [C.c_void_p] * 3 + [C.c_int] + \
+        [C.c_void_p] * 3
+    n = len(p["hasMP"])
+    state = p["state0"].astype(np.float32).copy(); outl = np.zeros(n, np.uint8); prior = np.zeros(246, np.float64)
+    a = [np.ascontiguousarray(p[k]) for k in ("hasMP", "obs", "invSigma2", "Xw", "close", "Tbc12", "kfState")]
+    pre = np.ascontiguousarray(pre, np.float32)
+    cam = p["cam"]
+    r = L.orc_pose_inertial_optimization_last_keyframe(n, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), cam["fx"], cam["fy"],
+                                                       cam["cx"], cam["cy"], cam["bf"], _p(a[5]), _p(a[6]), _p(pre),
+                                                       int(bool(bRecInit)), _p(state), _p(outl), _p(prior))
+    return r, state, outl, prior

@@ -440,3 +440,30 @@ def test_vocabulary_text_loader(tmp_path):
     bad.write_text("40 3 0 0\n")
     with pytest.raises(MorbError):
         Vocabulary.load_text(bad)
+
+
+def test_inertial_oracle_recovers_generating_motion():
+    """N1 slice (parity unpinned): the restated preintegration + PoseInertialOptimizationLastKeyFrame pull a perturbed
+    frame state back to the motion the IMU samples were generated from, and flag the planted gross outliers."""
+    import oracle_lib as orc
+    from morb_slam_amd.synth import imu_calib_diagonals, make_inertial_problem
+    nga, walk = imu_calib_diagonals()
+    p = make_inertial_problem(400, seed=3, n_imu=20)
+    pre = orc.imu_preintegrate(p["bias"], nga, walk, p["acc"], p["gyro"], p["dt"])
+    assert abs(pre[0] - 0.1) < 1e-6                                  # dT
+    R = pre[1:10].reshape(3, 3)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-6)
+    C = pre[61:286].reshape(15, 15)
+    assert np.allclose(C, C.T, atol=1e-9) and np.all(np.diag(C) > 0)
+    # zero-length sequence = Initialize(): identity rotation, zero covariance
+    z = orc.imu_preintegrate(p["bias"], nga, walk, np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros(0, np.float32))
+    assert np.allclose(z[1:10].reshape(3, 3), np.eye(3)) and z[0] == 0 and not z[61:286].any()
+    r, st, outl, prior = orc.pose_inertial_optimization_last_keyframe(p, pre)
+    Rt = p["true"][:9].reshape(3, 3)
+    ang = np.degrees(np.arccos(np.clip((np.trace(st[:9].reshape(3, 3).T @ Rt) - 1) / 2, -1, 1)))
+    assert ang < 0.1 and np.abs(st[9:12] - p["true"][9:12]).max() < 0.01
+    planted = p["outlier_truth"] & (p["hasMP"] > 0)
+    assert (outl[planted] == 1).mean() > 0.9
+    assert r == int(p["hasMP"].sum()) - int(outl.sum())
+    H = prior[21:].reshape(15, 15)
+    assert np.allclose(H, H.T, rtol=1e-9, atol=1e-9 * np.abs(H).max()) and np.all(np.linalg.eigvalsh(H) > 0)
