@@ -449,13 +449,26 @@ int morb_imu_preintegrate_batch(morb_optimizer*, int nseq, const int* d_start, c
  * d_state in/out = the frame (GetImuRotation / GetImuPosition / GetVelocity / mImuBias -> SetImuPoseVelocity, mImuBias).
  * Tbc12 (HOST) = mImuCalib.mTbc rotation (9) + translation (3); d_pre[f] = pFrame->mpImuPreintegrated.
  * d_nInliers[f] = the return value; d_prior (optional) [nframes][246] doubles = pFrame->mpcpi (ConstraintPoseImu): the
- * 21 state values in FP64 followed by the 15 x 15 H, row-major.  Pinhole camera 0 only (no second fisheye camera yet). */
+ * 21 state values in FP64 followed by the 15 x 15 H (after the constructor's eigenvalue clamp), row-major.  Pinhole camera 0 only (no second fisheye camera yet). */
 int morb_pose_inertial_optimization_last_keyframe_batch(morb_optimizer*, int nframes, int cap, const int* d_count,
                                                         const uint8_t* d_hasMP, const float* d_obs, const float* d_invSigma2,
                                                         const float* d_Xw, const uint8_t* d_close, float fx, float fy, float cx,
                                                         float cy, float bf, const float* Tbc12, const float* d_kfState,
                                                         const morb_imu_preintegrated* d_pre, int bRecInit, float* d_state,
                                                         uint8_t* d_outlier, int* d_nInliers, double* d_prior, void* stream);
+
+/* static int Optimizer::PoseInertialOptimizationLastFrame(Frame* pFrame, bool bRecInit)  Optimizer.h:125-126,
+ * Optimizer.cc:4761-5161: the frame and the previous frame (d_prevState, free) are optimised together, tied by
+ * EdgeInertial(d_preFrame = pFrame->mpImuPreintegratedFrame), the bias random walks (information from d_preKF =
+ * pFrame->mpImuPreintegrated) and EdgePriorPoseImu(d_prevPrior = pFp->mpcpi, [nframes][246] doubles as produced by either
+ * function).  d_prior (optional) = the frame's new mpcpi after Optimizer::Marginalize(H, 0, 14).  Other arguments as above. */
+int morb_pose_inertial_optimization_last_frame_batch(morb_optimizer*, int nframes, int cap, const int* d_count,
+                                                     const uint8_t* d_hasMP, const float* d_obs, const float* d_invSigma2,
+                                                     const float* d_Xw, const uint8_t* d_close, float fx, float fy, float cx, float cy,
+                                                     float bf, const float* Tbc12, const float* d_prevState,
+                                                     const morb_imu_preintegrated* d_preFrame, const morb_imu_preintegrated* d_preKF,
+                                                     const double* d_prevPrior, int bRecInit, float* d_state, uint8_t* d_outlier,
+                                                     int* d_nInliers, double* d_prior, void* stream);
 
 /* static void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF,
  * int& num_OptKF, int& num_MPs, int& num_edges)  Optimizer.h:67-69, Optimizer.cc:1053-1441, on the graph the

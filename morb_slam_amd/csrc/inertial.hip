@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "wave.h"
 
 using namespace morb;
 
@@ -50,7 +51,7 @@ __device__ void normalize_rotation_f(float* R) {
   double X[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) X[k] = R[k];
-  for (int it = 0; it < 6; ++it) {
+  for (int it = 0; it < 3; ++it) {   // quadratic convergence from a float-rounded rotation: 1e-7 -> 1e-14 -> below FP64 rounding
     const double c00 = X[4] * X[8] - X[5] * X[7], c01 = X[5] * X[6] - X[3] * X[8], c02 = X[3] * X[7] - X[4] * X[6];
     const double inv = 1.0 / (X[0] * c00 + X[1] * c01 + X[2] * c02);
     const double C[9] = {c00, c01, c02,
@@ -230,20 +231,35 @@ __device__ void inv_right_jacobian_so3(const double* v, double* J) {   // G2oTyp
   for (int k = 0; k < 9; ++k) J[k] = ((k & 3) == 0 ? 1.0 : 0.0) + W[k] / 2 + WW[k] * k2;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+__device__ __forceinline__ double wave_sum(double v) { return morbwave::sum_f64(v); }   // DPP, no LDS-crossbar round trips
+
+__device__ void right_jacobian_so3(const double* v, double* J) {   // G2oTypes.cc:835-848
+  const double x = v[0], y = v[1], z = v[2];
+  const double d2 = x * x + y * y + z * z, d = sqrt(d2);
+  const double W[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+  if (d < 1e-5) { for (int k = 0; k < 9; ++k) J[k] = (k & 3) == 0 ? 1.0 : 0.0; return; }
+  double WW[9];
+  mul33(W, W, WW);
+  for (int k = 0; k < 9; ++k) J[k] = ((k & 3) == 0 ? 1.0 : 0.0) - W[k] * (1.0 - cos(d)) / d2 + WW[k] * (d - sin(d)) / (d2 * d);
 }
 
-// Shared per-frame constants prepared by thread 0
-struct InertialConst {
-  double dR[9], dV[3], dP[3], dt;
-  double Rbw1[9], twb1[3], v1[3], bg1[3], ba1[3];
+// ---- per-frame workspace in LDS ------------------------------------------------------------------------------------------------
+// The visual edges are spread over the 256 threads; the few dense edges (inertial 9 x 24, prior 15 x 15) are written into LDS by
+// one thread and multiplied out by all of them; the dense solve runs in wave 0 on the LDS matrix.
+struct InertialWork {
+  double H[30 * 30], b[30], x[32];
+  double J[9 * 24], OJ[9 * 24], e[9], Oe[9];          // inertial edge (columns in edge order P1 V1 G1 A1 P2 V2)
+  double Jp[15 * 15], OJp[15 * 15], ep[15], Oep[15];  // prior edge (last-frame variant); scratch for the one-off 9 x 9 / 15 x 15 work
   double InfoI[81], InfoG[9], InfoA[9];
+  double pH[225];                                     // prior information
+  double red[4][28];
+  double delta[18];                                   // dR dV dP dbg of the inertial edge while state 1 is fixed
+  double wPrior;
+  int cnt[4][2];
+  int flag;
 };
 
-// n x n inverse in place (Gauss-Jordan, partial pivoting); M is n x 2n scratch
+// n x n inverse (Gauss-Jordan, partial pivoting); M is n x 2n scratch.  One thread.
 __device__ bool invert_n(const double* A, int n, double* Ainv, double* M) {
   for (int r = 0; r < n; ++r) for (int c = 0; c < 2 * n; ++c) M[r * 2 * n + c] = c < n ? A[r * n + c] : (c - n == r ? 1.0 : 0.0);
   for (int c = 0; c < n; ++c) {
@@ -262,46 +278,93 @@ __device__ bool invert_n(const double* A, int n, double* Ainv, double* M) {
   for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) Ainv[r * n + c] = M[r * 2 * n + n + c];
   return true;
 }
-// EdgeInertial's information (G2oTypes.cc:484-491): inverse, symmetrise, clamp eigenvalues below 1e-12 to zero.  The eigen
-// rebuild only changes the matrix when such an eigenvalue exists: S - 1e-12 I positive definite (LDL^T test) <=> none does,
-// and the cyclic-Jacobi rebuild runs otherwise.  S (9 x 9) in/out; scratch >= 171 doubles.
-__device__ void clamp_information(double* S, double* scratch) {
-  double* A = scratch;          // 81
-  double* V = scratch + 81;     // 81
+// S (n x n, symmetric) <- V max(e, clamp) V^T with eigenvalues below `thr` set to zero (EdgeInertial's information,
+// G2oTypes.cc:484-491; ConstraintPoseImu, G2oTypes.h:715-720).  The rebuild only changes S when such an eigenvalue exists:
+// S - thr I positive definite (LDL^T test) <=> none does; the cyclic-Jacobi rebuild runs otherwise.  One thread; A, V: n x n scratch.
+__device__ void clamp_eigenvalues(double* S, int n, double thr, double* A, double* V) {
   bool pd = true;
-  for (int k = 0; k < 81; ++k) A[k] = S[k];
-  for (int k = 0; k < 9; ++k) A[k * 9 + k] -= 1e-12;
-  for (int j = 0; j < 9 && pd; ++j) {
-    const double d = A[j * 9 + j];
+  for (int k = 0; k < n * n; ++k) A[k] = S[k];
+  for (int k = 0; k < n; ++k) A[k * n + k] -= thr;
+  for (int j = 0; j < n && pd; ++j) {
+    const double d = A[j * n + j];
     if (!(d > 0)) { pd = false; break; }
-    for (int r = j + 1; r < 9; ++r) {
-      const double l = A[r * 9 + j] / d;
-      for (int c = j + 1; c <= r; ++c) A[r * 9 + c] -= l * A[c * 9 + j];
+    for (int r = n - 1; r > j; --r) {       // descending rows: A[c][j] for c < r is still the un-scaled column entry
+      const double l = A[r * n + j] / d;
+      for (int c = j + 1; c <= r; ++c) A[r * n + c] -= l * A[c * n + j];
     }
   }
   if (pd) return;
-  for (int k = 0; k < 81; ++k) { A[k] = S[k]; V[k] = (k % 10 == 0) ? 1.0 : 0.0; }
+  for (int k = 0; k < n * n; ++k) { A[k] = S[k]; V[k] = 0.0; }
+  for (int k = 0; k < n; ++k) V[k * n + k] = 1.0;
   for (int sweep = 0; sweep < 60; ++sweep) {
     double off = 0, diag = 0;
-    for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) { const double t = A[r * 9 + c] * A[r * 9 + c]; if (r == c) diag += t; else off += t; }
+    for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) { const double t = A[r * n + c] * A[r * n + c]; if (r == c) diag += t; else off += t; }
     if (off <= 1e-30 * diag) break;
-    for (int p = 0; p < 9; ++p)
-      for (int q = p + 1; q < 9; ++q) {
-        if (A[p * 9 + q] == 0.0) continue;
-        const double theta = (A[q * 9 + q] - A[p * 9 + p]) / (2.0 * A[p * 9 + q]);
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        if (A[p * n + q] == 0.0) continue;
+        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * A[p * n + q]);
         const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
         const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 9; ++k) { const double a = A[k * 9 + p], b = A[k * 9 + q]; A[k * 9 + p] = c * a - s * b; A[k * 9 + q] = s * a + c * b; }
-        for (int k = 0; k < 9; ++k) { const double a = A[p * 9 + k], b = A[q * 9 + k]; A[p * 9 + k] = c * a - s * b; A[q * 9 + k] = s * a + c * b; }
-        for (int k = 0; k < 9; ++k) { const double a = V[k * 9 + p], b = V[k * 9 + q]; V[k * 9 + p] = c * a - s * b; V[k * 9 + q] = s * a + c * b; }
+        for (int k = 0; k < n; ++k) { const double a = A[k * n + p], bq = A[k * n + q]; A[k * n + p] = c * a - s * bq; A[k * n + q] = s * a + c * bq; }
+        for (int k = 0; k < n; ++k) { const double a = A[p * n + k], bq = A[q * n + k]; A[p * n + k] = c * a - s * bq; A[q * n + k] = s * a + c * bq; }
+        for (int k = 0; k < n; ++k) { const double a = V[k * n + p], bq = V[k * n + q]; V[k * n + p] = c * a - s * bq; V[k * n + q] = s * a + c * bq; }
       }
   }
-  for (int r = 0; r < 9; ++r)
-    for (int c = 0; c < 9; ++c) {
+  for (int r = 0; r < n; ++r)
+    for (int c = 0; c < n; ++c) {
       double s = 0;
-      for (int k = 0; k < 9; ++k) { const double e = A[k * 9 + k] < 1e-12 ? 0.0 : A[k * 9 + k]; s += V[r * 9 + k] * e * V[c * 9 + k]; }
-      S[r * 9 + c] = s;
+      for (int k = 0; k < n; ++k) { const double e = A[k * n + k] < thr ? 0.0 : A[k * n + k]; s += V[r * n + k] * e * V[c * n + k]; }
+      S[r * n + c] = s;
     }
+}
+
+#define WAVE_SYNC()                                        \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); \
+    __builtin_amdgcn_wave_barrier();                       \
+  } while (0)
+
+// LinearSolverDense (linear_solver_dense.h:104-112): LDL^T solve, solution only when every pivot is positive.  ONE wave; lane r
+// keeps row r of the matrix in registers, column entries of other rows arrive through v_readlane (the loops are fully
+// unrolled, so every register index and every source lane is a compile-time constant): no LDS round trip and no barrier in
+// the factorisation or the forward substitution.  The backward substitution needs L transposed: the rows go to LDS once.
+template <int N>
+__device__ bool wave_ldlt_solve(const double* H, int ld, const double* rhs, double* x, double* Lscr, int lane) {
+  const int row = lane < N ? lane : N - 1;   // lanes >= N replicate the last row; their results are not used
+  double a[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c) a[c] = H[row * ld + c];
+  double y = rhs[row], diag = 1.0;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double d = morbwave::readlane_f64(a[j], j);
+    ok = ok && (d > 0);
+    if (row == j) diag = d;
+    const double l = a[j] / d;
+#pragma unroll
+    for (int c = j + 1; c < N; ++c) a[c] -= l * morbwave::readlane_f64(a[j], c);   // A[r][c] -= A[r][j] A[c][j] / d
+    a[j] = l;
+  }
+  if (!ok) return false;   // wave-uniform
+#pragma unroll
+  for (int j = 0; j < N - 1; ++j) {   // L y = b
+    const double yj = morbwave::readlane_f64(y, j);
+    if (row > j) y -= a[j] * yj;
+  }
+  y /= diag;
+#pragma unroll
+  for (int c = 0; c < N; ++c) Lscr[row * N + c] = a[c];
+  WAVE_SYNC();
+#pragma unroll
+  for (int j = N - 1; j > 0; --j) {   // L^T x = y
+    const double xj = morbwave::readlane_f64(y, j);
+    if (row < j) y -= Lscr[j * N + row] * xj;
+  }
+  if (lane < N) x[lane] = y;
+  WAVE_SYNC();
+  return true;
 }
 
 struct CamGeom { double Rcb[9], tcb[3], Rbc[9], tbc[3], bf; float fx, fy, cx, cy; };
@@ -310,6 +373,7 @@ struct VIState {
   double Rwb[9], twb[3], v[3], bg[3], ba[3];
   double Rcw[9], tcw[3];
 };
+__device__ void load_state(const CamGeom& g, const float* s0, VIState& S);
 __device__ void refresh_camera(const CamGeom& g, VIState& S) {   // G2oTypes.cc:209-215
   double Rbw[9], tbw[3];
   transpose33(S.Rwb, Rbw);
@@ -318,6 +382,11 @@ __device__ void refresh_camera(const CamGeom& g, VIState& S) {   // G2oTypes.cc:
   mul33(g.Rcb, Rbw, S.Rcw);
   mul3v(g.Rcb, tbw, S.tcw);
   for (int k = 0; k < 3; ++k) S.tcw[k] += g.tcb[k];
+}
+__device__ void load_state(const CamGeom& g, const float* s0, VIState& S) {
+  for (int k = 0; k < 9; ++k) S.Rwb[k] = s0[k];
+  for (int k = 0; k < 3; ++k) { S.twb[k] = s0[9 + k]; S.v[k] = s0[12 + k]; S.bg[k] = s0[15 + k]; S.ba[k] = s0[18 + k]; }
+  refresh_camera(g, S);
 }
 __device__ void apply_update(const CamGeom& g, VIState& S, const double* x) {   // ImuCamPose::Update + the additive vertices
   double t[3], dR[9];
@@ -362,205 +431,329 @@ __device__ __forceinline__ void vis_jacobian(const CamGeom& g, const double* Xc,
 __device__ __forceinline__ double huber_w(double delta, double e2) {   // rho'(e2), robust_kernel_impl.cpp:65-91
   return e2 <= delta * delta ? 1.0 : delta / sqrt(e2);
 }
-// inertial edge at state S: error and the Jacobian blocks w.r.t. (pose 2, velocity 2) as one 9 x 9 matrix J   G2oTypes.cc:494-585
-__device__ void inertial_edge(const InertialConst& K, const VIState& S, double* err, double* J) {
-  double dRt[9], M[9], eR[9], er[3];
-  transpose33(K.dR, dRt);
-  mul33(dRt, K.Rbw1, M);
-  mul33(M, S.Rwb, eR);
+__device__ __forceinline__ void put33(double* J, int ld, int r0, int c0, const double* B, double sgn) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) J[(r0 + r) * ld + c0 + c] = sgn * B[r * 3 + c];
+}
+// GetDeltaRotation / GetDeltaVelocity / GetDeltaPosition at the bias (bg1, ba1) (ImuTypes.cc:289-312): FP32 like the reference
+__device__ void imu_delta(const morb_imu_preintegrated& P, const double* bg1, const double* ba1, double* dR, double* dV, double* dP,
+                          double* dbg3) {
+  const float b1[6] = {(float)ba1[0], (float)ba1[1], (float)ba1[2], (float)bg1[0], (float)bg1[1], (float)bg1[2]};
+  const float dbg[3] = {b1[3] - P.b[3], b1[4] - P.b[4], b1[5] - P.b[5]};
+  const float dba[3] = {b1[0] - P.b[0], b1[1] - P.b[1], b1[2] - P.b[2]};
+  float w[3], W[9], WW[9], E[9], dRf[9];
+  mul3vf(P.JRg, dbg, w);
+  const float t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], t = sqrtf(t2);
+  hatf(w, W);
+  mul33f(W, W, WW);
+  if (t < 1e-5f) for (int k = 0; k < 9; ++k) E[k] = ((k & 3) == 0 ? 1.f : 0.f) + W[k] + 0.5f * WW[k];
+  else { const float sn = sinf(t), cs = cosf(t); for (int k = 0; k < 9; ++k) E[k] = ((k & 3) == 0 ? 1.f : 0.f) + W[k] * sn / t + WW[k] * (1.0f - cs) / t2; }
+  mul33f(P.dR, E, dRf);
+  normalize_rotation_f(dRf);
+  for (int k = 0; k < 9; ++k) dR[k] = dRf[k];
+  float g1[3], a1[3];
+  mul3vf(P.JVg, dbg, g1); mul3vf(P.JVa, dba, a1);
+  for (int k = 0; k < 3; ++k) dV[k] = (double)(P.dV[k] + g1[k] + a1[k]);
+  mul3vf(P.JPg, dbg, g1); mul3vf(P.JPa, dba, a1);
+  for (int k = 0; k < 3; ++k) dP[k] = (double)(P.dP[k] + g1[k] + a1[k]);
+  for (int k = 0; k < 3; ++k) dbg3[k] = dbg[k];
+}
+// EdgeInertial between state 1 (S1) and state 2 (S2): error and, when J != nullptr, the 9 x 24 Jacobian (edge column order
+// P1 V1 G1 A1 P2 V2) written to LDS.  G2oTypes.cc:494-585.  One thread.
+// delta != nullptr: dR dV dP dbg precomputed (state 1 fixed).  full == false: only the (P2, V2) column blocks are written.
+// J must have been zeroed once: the same entries are rewritten at every call.
+__device__ void inertial_edge(const morb_imu_preintegrated& P, const VIState& S1, const VIState& S2, const double* delta, bool full,
+                              double* err, double* J) {
+  double dR[9], dV[3], dP[3], dbg[3];
+  if (delta) {
+    for (int k = 0; k < 9; ++k) dR[k] = delta[k];
+    for (int k = 0; k < 3; ++k) { dV[k] = delta[9 + k]; dP[k] = delta[12 + k]; dbg[k] = delta[15 + k]; }
+  } else imu_delta(P, S1.bg, S1.ba, dR, dV, dP, dbg);
+  const double dt = P.dT;
+  double Rbw1[9], dRt[9], M[9], eR[9], er[3];
+  transpose33(S1.Rwb, Rbw1);
+  transpose33(dR, dRt);
+  mul33(dRt, Rbw1, M);
+  mul33(M, S2.Rwb, eR);
   log_so3(eR, er);
   const double g[3] = {0, 0, -(double)9.81f};
-  double t[3], ev[3], ep[3];
-  for (int k = 0; k < 3; ++k) t[k] = S.v[k] - K.v1[k] - g[k] * K.dt;
-  mul3v(K.Rbw1, t, ev);
-  for (int k = 0; k < 3; ++k) t[k] = S.twb[k] - K.twb1[k] - K.v1[k] * K.dt - g[k] * K.dt * K.dt / 2;
-  mul3v(K.Rbw1, t, ep);
-  for (int k = 0; k < 3; ++k) { err[k] = er[k]; err[3 + k] = ev[k] - K.dV[k]; err[6 + k] = ep[k] - K.dP[k]; }
-  if (J) {
-    double invJr[9], RR[9];
-    inv_right_jacobian_so3(er, invJr);
-    mul33(K.Rbw1, S.Rwb, RR);
-    for (int k = 0; k < 81; ++k) J[k] = 0;
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) { J[r * 9 + c] = invJr[r * 3 + c]; J[(6 + r) * 9 + 3 + c] = RR[r * 3 + c]; J[(3 + r) * 9 + 6 + c] = K.Rbw1[r * 3 + c]; }
+  double t[3], a1[3], a2[3];
+  for (int k = 0; k < 3; ++k) t[k] = S2.v[k] - S1.v[k] - g[k] * dt;
+  mul3v(Rbw1, t, a1);
+  for (int k = 0; k < 3; ++k) t[k] = S2.twb[k] - S1.twb[k] - S1.v[k] * dt - g[k] * dt * dt / 2;
+  mul3v(Rbw1, t, a2);
+  for (int k = 0; k < 3; ++k) { err[k] = er[k]; err[3 + k] = a1[k] - dV[k]; err[6 + k] = a2[k] - dP[k]; }
+  if (!J) return;
+  double invJr[9], T[9], T2[9], W[9];
+  inv_right_jacobian_so3(er, invJr);
+  // pose 2, velocity 2
+  put33(J, 24, 0, 15, invJr, 1.0);
+  mul33(Rbw1, S2.Rwb, T);
+  put33(J, 24, 6, 18, T, 1.0);
+  put33(J, 24, 3, 21, Rbw1, 1.0);
+  if (!full) return;
+  // pose 1
+  transpose33(S2.Rwb, T2);
+  mul33(invJr, T2, T); mul33(T, S1.Rwb, T2);
+  put33(J, 24, 0, 0, T2, -1.0);
+  W[0] = 0; W[1] = -a1[2]; W[2] = a1[1]; W[3] = a1[2]; W[4] = 0; W[5] = -a1[0]; W[6] = -a1[1]; W[7] = a1[0]; W[8] = 0;
+  put33(J, 24, 3, 0, W, 1.0);
+  {
+    double a3[3];
+    for (int k = 0; k < 3; ++k) t[k] = S2.twb[k] - S1.twb[k] - S1.v[k] * dt - 0.5 * g[k] * dt * dt;
+    mul3v(Rbw1, t, a3);
+    W[0] = 0; W[1] = -a3[2]; W[2] = a3[1]; W[3] = a3[2]; W[4] = 0; W[5] = -a3[0]; W[6] = -a3[1]; W[7] = a3[0]; W[8] = 0;
+    put33(J, 24, 6, 0, W, 1.0);
   }
+  for (int k = 0; k < 3; ++k) J[(6 + k) * 24 + 3 + k] = -1.0;
+  // velocity 1
+  put33(J, 24, 3, 6, Rbw1, -1.0);
+  for (int k = 0; k < 9; ++k) T[k] = Rbw1[k] * dt;
+  put33(J, 24, 6, 6, T, -1.0);
+  // gyro bias 1
+  {
+    double JRg[9], w3[3], rj[9], eRt[9];
+    for (int k = 0; k < 9; ++k) JRg[k] = P.JRg[k];
+    mul3v(JRg, dbg, w3);
+    right_jacobian_so3(w3, rj);
+    transpose33(eR, eRt);
+    mul33(invJr, eRt, T); mul33(T, rj, T2); mul33(T2, JRg, T);
+    put33(J, 24, 0, 9, T, -1.0);
+    for (int k = 0; k < 9; ++k) T[k] = P.JVg[k];
+    put33(J, 24, 3, 9, T, -1.0);
+    for (int k = 0; k < 9; ++k) T[k] = P.JPg[k];
+    put33(J, 24, 6, 9, T, -1.0);
+  }
+  // acc bias 1
+  for (int k = 0; k < 9; ++k) T[k] = P.JVa[k];
+  put33(J, 24, 3, 12, T, -1.0);
+  for (int k = 0; k < 9; ++k) T[k] = P.JPa[k];
+  put33(J, 24, 6, 12, T, -1.0);
 }
-// H += J^T Info J (9 x 9 into the 15 x 15), b -= J^T Info e
-__device__ void add_inertial(const InertialConst& K, const double* err, const double* J, double* H, double* b) {
-  for (int r = 0; r < 9; ++r) {
-    double JtO[9];   // row r of J^T Info
-    for (int c = 0; c < 9; ++c) { double s = 0; for (int k = 0; k < 9; ++k) s += J[k * 9 + r] * K.InfoI[k * 9 + c]; JtO[c] = s; }
-    if (b) { double s = 0; for (int k = 0; k < 9; ++k) s += JtO[k] * err[k]; b[r] -= s; }
-    for (int c = 0; c < 9; ++c) { double s = 0; for (int k = 0; k < 9; ++k) s += JtO[k] * J[k * 9 + c]; H[r * 15 + c] += s; }
-  }
-}
-// LinearSolverDense: LDL^T, solution only when positive (linear_solver_dense.h:104-112)
-__device__ bool ldlt15(double* A /* 15 x 15, destroyed */, const double* rhs, double* x) {
-  for (int j = 0; j < 15; ++j) {
-    const double d = A[j * 15 + j];
-    if (!(d > 0)) return false;
-    for (int r = j + 1; r < 15; ++r) {
-      const double l = A[r * 15 + j] / d;
-      for (int c = j + 1; c <= r; ++c) A[r * 15 + c] -= l * A[c * 15 + j];
-      A[r * 15 + j] = l;
-    }
-  }
-  double y[15];
-  for (int r = 0; r < 15; ++r) { double s = rhs[r]; for (int c = 0; c < r; ++c) s -= A[r * 15 + c] * y[c]; y[r] = s; }
-  for (int k = 0; k < 15; ++k) y[k] /= A[k * 15 + k];
-  for (int r = 14; r >= 0; --r) { double s = y[r]; for (int c = r + 1; c < 15; ++c) s -= A[c * 15 + r] * y[c]; y[r] = s; }
-  for (int k = 0; k < 15; ++k) x[k] = y[k];
-  return true;
+// EdgePriorPoseImu (G2oTypes.cc:739-766): error (15) and the 15 x 15 Jacobian in LDS.  prior = Rwb twb v bg ba (21 doubles).
+__device__ void prior_edge(const double* prior, const VIState& S1, double* err, double* J) {
+  double pRt[9], E[9], er[3], d[3], et[3];
+  transpose33(prior, pRt);
+  mul33(pRt, S1.Rwb, E);
+  log_so3(E, er);
+  for (int k = 0; k < 3; ++k) d[k] = S1.twb[k] - prior[9 + k];
+  mul3v(pRt, d, et);
+  for (int k = 0; k < 3; ++k) { err[k] = er[k]; err[3 + k] = et[k]; err[6 + k] = S1.v[k] - prior[12 + k]; err[9 + k] = S1.bg[k] - prior[15 + k]; err[12 + k] = S1.ba[k] - prior[18 + k]; }
+  if (!J) return;   // J zeroed once by the caller
+  double invJr[9];
+  inv_right_jacobian_so3(er, invJr);
+  put33(J, 15, 0, 0, invJr, 1.0);
+  put33(J, 15, 3, 3, E, 1.0);
+  for (int k = 6; k < 15; ++k) J[k * 15 + k] = 1.0;
 }
 
+// system column of an inertial-edge column: frame = [P 0..5, V 6..8, G 9..11, A 12..14], previous frame / keyframe = 15 + the same
+__device__ __forceinline__ int edge_col(int a) { return a < 15 ? 15 + a : a - 15; }
+
+// LASTFRAME = false: PoseInertialOptimizationLastKeyFrame (state 1 = the keyframe, fixed: 15 unknowns)
+// LASTFRAME = true : PoseInertialOptimizationLastFrame   (state 1 = the previous frame, free, with its prior: 30 unknowns)
+#ifdef MORB_INERTIAL_TIMING
+__device__ unsigned long long g_inertialPhase[16];
+#define IMARK(k) do { __syncthreads(); if (tid == 0 && blockIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_inertialPhase[k], now_ - t0_); t0_ = now_; } } while (0)
+#else
+#define IMARK(k)
+#endif
+template <bool LASTFRAME>
 __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __restrict__ count, const uint8_t* __restrict__ hasMP,
                                                        const float* __restrict__ obs, const float* __restrict__ invSigma2,
                                                        const float* __restrict__ Xw, const uint8_t* __restrict__ closeFlag,
-                                                       CamGeom g, const float* __restrict__ kfState,
-                                                       const morb_imu_preintegrated* __restrict__ pre, int bRecInit,
+                                                       CamGeom g, const float* __restrict__ state1,
+                                                       const morb_imu_preintegrated* __restrict__ pre,
+                                                       const morb_imu_preintegrated* __restrict__ preKF,
+                                                       const double* __restrict__ prevPrior, int bRecInit,
                                                        float* __restrict__ stateIO, uint8_t* __restrict__ outlier,
                                                        int* __restrict__ nInliersOut, double* __restrict__ prior) {
-  __shared__ InertialConst K;
-  __shared__ double sScratch[9 * 18 + 81];
-  __shared__ double sRed[4][28];
-  __shared__ double sX[16];
-  __shared__ int sCnt[4][2];
+  __shared__ InertialWork Wk;
+  constexpr int NV = LASTFRAME ? 30 : 15;
+  // threads on the visual edges; wave 3 evaluates the inertial edge and (last-frame variant) wave 2 the prior edge meanwhile
+  constexpr int NVIS = LASTFRAME ? 128 : 192, NVW = NVIS / 64;
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = count ? count[f] : cap;
   const size_t base = (size_t)f * cap;
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
+  const morb_imu_preintegrated& P = pre[f];
+  const double* pr = LASTFRAME ? prevPrior + (size_t)246 * f : nullptr;
 
   int nInit = 0;
   for (int i = tid; i < n; i += 256) if (hasMP[base + i]) { ++nInit; outlier[base + i] = 0; }
-  {
-    nInit = (int)wave_sum((double)nInit);
-    if (lane == 0) sCnt[wv][0] = nInit;
-    __syncthreads();
-    nInit = sCnt[0][0] + sCnt[1][0] + sCnt[2][0] + sCnt[3][0];
-    __syncthreads();
-  }
-
-  if (tid == 0) {   // the inertial edge's constants (GetDelta*, ImuTypes.cc:289-312; information, G2oTypes.cc:484-491)
-    const morb_imu_preintegrated& P = pre[f];
-    const float* ks = kfState + 21 * f;
-    double Rwb1[9];
-    for (int k = 0; k < 9; ++k) Rwb1[k] = ks[k];
-    transpose33(Rwb1, K.Rbw1);
-    for (int k = 0; k < 3; ++k) { K.twb1[k] = ks[9 + k]; K.v1[k] = ks[12 + k]; K.bg1[k] = ks[15 + k]; K.ba1[k] = ks[18 + k]; }
-    const float dbg[3] = {ks[15] - P.b[3], ks[16] - P.b[4], ks[17] - P.b[5]};
-    const float dba[3] = {ks[18] - P.b[0], ks[19] - P.b[1], ks[20] - P.b[2]};
-    float w[3], W[9], WW[9], E[9], dRf[9];
-    mul3vf(P.JRg, dbg, w);
-    const float t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], t = sqrtf(t2);
-    hatf(w, W);
-    mul33f(W, W, WW);
-    if (t < 1e-5f) for (int k = 0; k < 9; ++k) E[k] = ((k & 3) == 0 ? 1.f : 0.f) + W[k] + 0.5f * WW[k];
-    else { const float sn = sinf(t), cs = cosf(t); for (int k = 0; k < 9; ++k) E[k] = ((k & 3) == 0 ? 1.f : 0.f) + W[k] * sn / t + WW[k] * (1.0f - cs) / t2; }
-    mul33f(P.dR, E, dRf);
-    normalize_rotation_f(dRf);
-    for (int k = 0; k < 9; ++k) K.dR[k] = dRf[k];
-    float g1[3], a1[3];
-    mul3vf(P.JVg, dbg, g1); mul3vf(P.JVa, dba, a1);
-    for (int k = 0; k < 3; ++k) K.dV[k] = (double)(P.dV[k] + g1[k] + a1[k]);
-    mul3vf(P.JPg, dbg, g1); mul3vf(P.JPa, dba, a1);
-    for (int k = 0; k < 3; ++k) K.dP[k] = (double)(P.dP[k] + g1[k] + a1[k]);
-    K.dt = P.dT;
-    double C9[81];
-    for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) C9[r * 9 + c] = (double)P.C[r * 15 + c];
-    if (invert_n(C9, 9, K.InfoI, sScratch)) {
-      for (int r = 0; r < 9; ++r) for (int c = r + 1; c < 9; ++c) { const double s = (K.InfoI[r * 9 + c] + K.InfoI[c * 9 + r]) / 2; K.InfoI[r * 9 + c] = s; K.InfoI[c * 9 + r] = s; }
-      clamp_information(K.InfoI, sScratch);
-    } else for (int k = 0; k < 81; ++k) K.InfoI[k] = 0;
-    double Cg[9], Ca[9];
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { Cg[r * 3 + c] = P.C[(9 + r) * 15 + 9 + c]; Ca[r * 3 + c] = P.C[(12 + r) * 15 + 12 + c]; }
-    if (!invert_n(Cg, 3, K.InfoG, sScratch)) for (int k = 0; k < 9; ++k) K.InfoG[k] = 0;
-    if (!invert_n(Ca, 3, K.InfoA, sScratch)) for (int k = 0; k < 9; ++k) K.InfoA[k] = 0;
-  }
+  nInit = (int)wave_sum((double)nInit);
+  if (lane == 0) Wk.cnt[wv][0] = nInit;
+  __syncthreads();
+  nInit = Wk.cnt[0][0] + Wk.cnt[1][0] + Wk.cnt[2][0] + Wk.cnt[3][0];
   __syncthreads();
 
-  VIState S, Sprev;
-  {
-    const float* s0 = stateIO + 21 * f;
-    for (int k = 0; k < 9; ++k) S.Rwb[k] = s0[k];
-    for (int k = 0; k < 3; ++k) { S.twb[k] = s0[9 + k]; S.v[k] = s0[12 + k]; S.bg[k] = s0[15 + k]; S.ba[k] = s0[18 + k]; }
-    refresh_camera(g, S);
-    Sprev = S;
+  if (tid == 0) {   // informations: EdgeInertial (G2oTypes.cc:484-491), EdgeGyroRW / EdgeAccRW (Optimizer.cc:4580-4594)
+    double* C9 = Wk.J;        // scratch: 81 + 162 + 162 doubles fit in J | OJ | Jp | OJp
+    for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) C9[r * 9 + c] = (double)P.C[r * 15 + c];
+    if (invert_n(C9, 9, Wk.InfoI, Wk.Jp)) {
+      for (int r = 0; r < 9; ++r) for (int c = r + 1; c < 9; ++c) { const double s = (Wk.InfoI[r * 9 + c] + Wk.InfoI[c * 9 + r]) / 2; Wk.InfoI[r * 9 + c] = s; Wk.InfoI[c * 9 + r] = s; }
+      clamp_eigenvalues(Wk.InfoI, 9, 1e-12, Wk.Jp, Wk.OJp);
+    } else for (int k = 0; k < 81; ++k) Wk.InfoI[k] = 0;
+    const morb_imu_preintegrated& PK = LASTFRAME ? preKF[f] : P;
+    double Cg[9], Ca[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { Cg[r * 3 + c] = PK.C[(9 + r) * 15 + 9 + c]; Ca[r * 3 + c] = PK.C[(12 + r) * 15 + 12 + c]; }
+    if (!invert_n(Cg, 3, Wk.InfoG, Wk.Jp)) for (int k = 0; k < 9; ++k) Wk.InfoG[k] = 0;
+    if (!invert_n(Ca, 3, Wk.InfoA, Wk.Jp)) for (int k = 0; k < 9; ++k) Wk.InfoA[k] = 0;
   }
+  if (LASTFRAME) for (int k = tid; k < 225; k += 256) Wk.pH[k] = pr[21 + k];
+  __syncthreads();
+
+#ifdef MORB_INERTIAL_TIMING
+  unsigned long long t0_ = wall_clock64();
+#endif
+  IMARK(0);
+  VIState S, Sprev, S1;
+  load_state(g, stateIO + 21 * f, S);
+  load_state(g, state1 + 21 * f, S1);
+  Sprev = S;
+  __syncthreads();   // the setup above used J / Jp as scratch
+  for (int k = tid; k < 216; k += 256) Wk.J[k] = 0;
+  for (int k = tid; k < 225; k += 256) Wk.Jp[k] = 0;
+  if (!LASTFRAME && tid == 0) imu_delta(P, S1.bg, S1.ba, Wk.delta, Wk.delta + 9, Wk.delta + 12, Wk.delta + 15);
+  __syncthreads();
+  const double* delta = LASTFRAME ? nullptr : Wk.delta;
+  auto redsum = [&](int q) { double s = 0; for (int w = 0; w < NVW; ++w) s += Wk.red[w][q]; return s; };
   bool robust = true;
   int nBad = 0, nInl = 0;
-  double xPrev[15];
-  for (int k = 0; k < 15; ++k) xPrev[k] = 0;
-  const float chi2Mono[4] = {12.f, 7.5f, 5.991f, 5.991f}, chi2Stereo[4] = {15.6f, 9.8f, 7.815f, 7.815f};
+  for (int k = tid; k < 32; k += 256) Wk.x[k] = 0;
+  const float chi2MonoKF[4] = {12.f, 7.5f, 5.991f, 5.991f}, chi2MonoF[4] = {5.991f, 5.991f, 5.991f, 5.991f};
+  const float chi2Stereo[4] = {15.6f, 9.8f, 7.815f, 7.815f};
 
   for (int it = 0; it < 4; ++it) {
     bool ok = true;
     for (int iter = 0; iter < 10 && ok; ++iter) {
+      IMARK(1);
       Sprev = S;   // the state the active edges' errors belong to
-      double acc[27];
+      // ---- visual edges -> 6 x 6 block and right-hand side of the frame's pose
+      if (tid < NVIS) {
+        double acc[27];
 #pragma unroll
-      for (int k = 0; k < 27; ++k) acc[k] = 0;
-      for (int i = tid; i < n; i += 256) {
-        if (!hasMP[base + i] || outlier[base + i]) continue;
-        const float* o = obs + (base + i) * 3;
-        const bool st = !(o[2] < 0);
-        const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
-        const double info = (double)invSigma2[base + i];
-        double err[3], Xc[3], J[18];
-        const double c = vis_error(g, S, X, o, st, info, err, Xc);
-        const double w = robust ? huber_w(st ? deltaStereo : deltaMono, c) : 1.0;
-        vis_jacobian(g, Xc, st, J);
-        const int d = st ? 3 : 2;
-        int q = 0;
+        for (int k = 0; k < 27; ++k) acc[k] = 0;
+        for (int i = tid; i < n; i += NVIS) {
+          if (!hasMP[base + i] || outlier[base + i]) continue;
+          const float* o = obs + (base + i) * 3;
+          const bool st = !(o[2] < 0);
+          const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
+          const double info = (double)invSigma2[base + i];
+          double err[3], Xc[3], J[18];
+          const double c = vis_error(g, S, X, o, st, info, err, Xc);
+          const double w = robust ? huber_w(st ? deltaStereo : deltaMono, c) : 1.0;
+          vis_jacobian(g, Xc, st, J);   // a mono edge has a zero third row and err[2] = 0: one fully unrolled 3-row form (registers only)
+          int q = 0;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          double bb = 0;
-          for (int k = 0; k < d; ++k) bb += J[k * 6 + r] * (info * err[k]);
-          acc[21 + r] -= w * bb;
+          for (int r = 0; r < 6; ++r) {
+            double bb = 0;
 #pragma unroll
-          for (int cc = r; cc < 6; ++cc) {
-            double h = 0;
-            for (int k = 0; k < d; ++k) h += J[k * 6 + r] * (w * info) * J[k * 6 + cc];
-            acc[q++] += h;
+            for (int k = 0; k < 3; ++k) bb += J[k * 6 + r] * (info * err[k]);
+            acc[21 + r] -= w * bb;
+#pragma unroll
+            for (int cc = r; cc < 6; ++cc) {
+              double h = 0;
+#pragma unroll
+              for (int k = 0; k < 3; ++k) h += J[k * 6 + r] * (w * info) * J[k * 6 + cc];
+              acc[q++] += h;
+            }
           }
         }
-      }
 #pragma unroll
-      for (int k = 0; k < 27; ++k) acc[k] = wave_sum(acc[k]);
+        for (int k = 0; k < 27; ++k) acc[k] = wave_sum(acc[k]);
+        if (lane == 0) for (int k = 0; k < 27; ++k) Wk.red[wv][k] = acc[k];
+      } else if (tid == 192) {
+        inertial_edge(P, S1, S, delta, LASTFRAME, Wk.e, Wk.J);   // error + Jacobian to LDS
+      } else if (LASTFRAME && tid == 128) {
+        prior_edge(pr, S1, Wk.ep, Wk.Jp);
+      }
+      IMARK(2);
       __syncthreads();
-      if (lane == 0) for (int k = 0; k < 27; ++k) sRed[wv][k] = acc[k];
-      __syncthreads();
-      if (tid == 0) {
-        double H[225], b[15];
-        for (int k = 0; k < 225; ++k) H[k] = 0;
-        for (int k = 0; k < 15; ++k) b[k] = 0;
-        int q = 0;
-        for (int r = 0; r < 6; ++r) for (int cc = r; cc < 6; ++cc) { const double t = sRed[0][q] + sRed[1][q] + sRed[2][q] + sRed[3][q]; H[r * 15 + cc] = t; H[cc * 15 + r] = t; ++q; }
-        for (int r = 0; r < 6; ++r) b[r] = sRed[0][21 + r] + sRed[1][21 + r] + sRed[2][21 + r] + sRed[3][21 + r];
-        double err[9];
-        double* J = sScratch;   // 81
-        inertial_edge(K, S, err, J);
-        add_inertial(K, err, J, H, b);
-        for (int r = 0; r < 3; ++r) {   // EdgeGyroRW / EdgeAccRW (G2oTypes.h:645-654)
-          double sg = 0, sa = 0;
-          for (int k = 0; k < 3; ++k) { sg += K.InfoG[r * 3 + k] * (S.bg[k] - K.bg1[k]); sa += K.InfoA[r * 3 + k] * (S.ba[k] - K.ba1[k]); }
-          b[9 + r] -= sg; b[12 + r] -= sa;
-          for (int c = 0; c < 3; ++c) { H[(9 + r) * 15 + 9 + c] += K.InfoG[r * 3 + c]; H[(12 + r) * 15 + 12 + c] += K.InfoA[r * 3 + c]; }
+      IMARK(3);
+      // ---- Omega J, Omega e
+      for (int k = tid; k < 9 * 24 + 9; k += 256) {
+        if (k < 216) { const int r = k / 24, c = k - r * 24; double s = 0; for (int l = 0; l < 9; ++l) s += Wk.InfoI[r * 9 + l] * Wk.J[l * 24 + c]; Wk.OJ[k] = s; }
+        else { const int r = k - 216; double s = 0; for (int l = 0; l < 9; ++l) s += Wk.InfoI[r * 9 + l] * Wk.e[l]; Wk.Oe[r] = s; }
+      }
+      if (LASTFRAME) {
+        for (int k = tid; k < 225 + 15; k += 256) {
+          if (k < 225) { const int r = k / 15, c = k - r * 15; double s = 0; for (int l = 0; l < 15; ++l) s += Wk.pH[r * 15 + l] * Wk.Jp[l * 15 + c]; Wk.OJp[k] = s; }
+          else { const int r = k - 225; double s = 0; for (int l = 0; l < 15; ++l) s += Wk.pH[r * 15 + l] * Wk.ep[l]; Wk.Oep[r] = s; }
         }
-        double x[15];
-        for (int k = 0; k < 15; ++k) x[k] = xPrev[k];   // a failed solve leaves the solver's previous x in place
-        const bool good = ldlt15(H, b, x);
-        for (int k = 0; k < 15; ++k) sX[k] = x[k];
-        sX[15] = good ? 1.0 : 0.0;
       }
       __syncthreads();
-      double x[15];
-      for (int k = 0; k < 15; ++k) { x[k] = sX[k]; xPrev[k] = x[k]; }
-      ok = sX[15] != 0.0;
+      if (LASTFRAME && tid == 0) {   // Huber weight of the prior edge (delta 5, Optimizer.cc:4981-4984)
+        double chi2 = 0;
+        for (int k = 0; k < 15; ++k) chi2 += Wk.ep[k] * Wk.Oep[k];
+        Wk.wPrior = huber_w(5.0, chi2);
+      }
+      if (LASTFRAME) __syncthreads();
+      IMARK(4);
+      // ---- H and b: every entry by one thread
+      for (int k = tid; k < NV * NV + NV; k += 256) {
+        if (k < NV * NV) {
+          const int r = k / NV, c = k - r * NV;
+          double h = 0;
+          if (r < 6 && c < 6) {   // visual block (upper triangle was accumulated)
+            const int a = r < c ? r : c, bq = r < c ? c : r;
+            const int q = a * 6 - a * (a - 1) / 2 + (bq - a);
+            h = redsum(q);
+          }
+          // inertial edge: system index -> edge column
+          const int ea = r < 15 ? (r < 9 ? 15 + r : -1) : r - 15, ec = c < 15 ? (c < 9 ? 15 + c : -1) : c - 15;
+          if (ea >= 0 && ec >= 0) { double s = 0; for (int l = 0; l < 9; ++l) s += Wk.J[l * 24 + ea] * Wk.OJ[l * 24 + ec]; h += s; }
+          // random walks: e = bias2 - bias1 (G2oTypes.h:645-654)
+          const int rb = r % 15, cb = c % 15;
+          if (rb >= 9 && cb >= 9 && (rb < 12) == (cb < 12)) {
+            const double* I3 = rb < 12 ? Wk.InfoG : Wk.InfoA;
+            const double v = I3[(rb - (rb < 12 ? 9 : 12)) * 3 + (cb - (cb < 12 ? 9 : 12))];
+            h += ((r < 15) == (c < 15)) ? v : -v;
+          }
+          if (LASTFRAME && r >= 15 && c >= 15) { double s = 0; for (int l = 0; l < 15; ++l) s += Wk.Jp[l * 15 + (r - 15)] * Wk.OJp[l * 15 + (c - 15)]; h += Wk.wPrior * s; }
+          Wk.H[r * 30 + c] = h;
+        } else {
+          const int r = k - NV * NV;
+          double s = 0;
+          if (r < 6) s = redsum(21 + r);
+          const int ea = r < 15 ? (r < 9 ? 15 + r : -1) : r - 15;
+          if (ea >= 0) { double t = 0; for (int l = 0; l < 9; ++l) t += Wk.J[l * 24 + ea] * Wk.Oe[l]; s -= t; }
+          const int rb = r % 15;
+          if (rb >= 9) {
+            const double* I3 = rb < 12 ? Wk.InfoG : Wk.InfoA;
+            const double* b2 = rb < 12 ? S.bg : S.ba; const double* b1 = rb < 12 ? S1.bg : S1.ba;
+            const int q = rb - (rb < 12 ? 9 : 12);
+            double t = 0;
+            for (int l = 0; l < 3; ++l) t += I3[q * 3 + l] * (b2[l] - b1[l]);
+            s += r < 15 ? -t : t;   // J2 = I, J1 = -I
+          }
+          if (LASTFRAME && r >= 15) { double t = 0; for (int l = 0; l < 15; ++l) t += Wk.Jp[l * 15 + (r - 15)] * Wk.Oep[l]; s -= Wk.wPrior * t; }
+          Wk.b[r] = s;
+        }
+      }
+      __syncthreads();
+      IMARK(5);
+      if (wv == 0) {
+        const bool good = wave_ldlt_solve<NV>(Wk.H, 30, Wk.b, Wk.x, Wk.H, lane);   // a failed solve leaves the previous x in place; L overwrites H
+        if (lane == 0) Wk.flag = good ? 1 : 0;
+      }
+      __syncthreads();
+      IMARK(6);
+      double x[NV];
+      for (int k = 0; k < NV; ++k) x[k] = Wk.x[k];
+      ok = Wk.flag != 0;
       apply_update(g, S, x);
+      if (LASTFRAME) apply_update(g, S1, x + 15);
+      __syncthreads();
+      IMARK(7);
     }
-    // ---- classification (Optimizer.cc:4619-4676)
+    IMARK(1);
+    // ---- classification (Optimizer.cc:4619-4676 / :5000-5057)
     int bad = 0, inl = 0;
-    const float chi2close = 1.5f * chi2Mono[it];
+    const float cm = LASTFRAME ? chi2MonoF[it] : chi2MonoKF[it];
+    const float chi2close = 1.5f * cm;
     for (int i = tid; i < n; i += 256) {
       if (!hasMP[base + i]) continue;
       const float* o = obs + (base + i) * 3;
@@ -573,20 +766,21 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
       else {
         const bool bClose = closeFlag[base + i] != 0;
         const bool depthPos = (S.Rcw[6] * X[0] + S.Rcw[7] * X[1] + S.Rcw[8] * X[2] + S.tcw[2]) > 0.0;
-        isOut = (chi2 > chi2Mono[it] && !bClose) || (bClose && chi2 > chi2close) || !depthPos;
+        isOut = (chi2 > cm && !bClose) || (bClose && chi2 > chi2close) || !depthPos;
       }
       outlier[base + i] = isOut ? 1 : 0;
       bad += isOut ? 1 : 0; inl += isOut ? 0 : 1;
     }
     bad = (int)wave_sum((double)bad); inl = (int)wave_sum((double)inl);
     __syncthreads();
-    if (lane == 0) { sCnt[wv][0] = bad; sCnt[wv][1] = inl; }
+    if (lane == 0) { Wk.cnt[wv][0] = bad; Wk.cnt[wv][1] = inl; }
     __syncthreads();
-    nBad = sCnt[0][0] + sCnt[1][0] + sCnt[2][0] + sCnt[3][0];
-    nInl = sCnt[0][1] + sCnt[1][1] + sCnt[2][1] + sCnt[3][1];
+    nBad = Wk.cnt[0][0] + Wk.cnt[1][0] + Wk.cnt[2][0] + Wk.cnt[3][0];
+    nInl = Wk.cnt[0][1] + Wk.cnt[1][1] + Wk.cnt[2][1] + Wk.cnt[3][1];
     __syncthreads();
+    IMARK(8);
     if (it == 2) robust = false;
-    if (nInit + 3 < 10) break;   // optimizer.edges().size() < 10
+    if (nInit + (LASTFRAME ? 4 : 3) < 10) break;   // optimizer.edges().size() < 10
   }
 
   if (nInl < 30 && !bRecInit) {   // :4683-4707
@@ -602,9 +796,9 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
     }
     bad = (int)wave_sum((double)bad);
     __syncthreads();
-    if (lane == 0) sCnt[wv][0] = bad;
+    if (lane == 0) Wk.cnt[wv][0] = bad;
     __syncthreads();
-    nBad = sCnt[0][0] + sCnt[1][0] + sCnt[2][0] + sCnt[3][0];
+    nBad = Wk.cnt[0][0] + Wk.cnt[1][0] + Wk.cnt[2][0] + Wk.cnt[3][0];
     __syncthreads();
   }
 
@@ -614,55 +808,176 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
     for (int k = 0; k < 3; ++k) { s0[9 + k] = (float)S.twb[k]; s0[12 + k] = (float)S.v[k]; s0[15 + k] = (float)S.bg[k]; s0[18 + k] = (float)S.ba[k]; }
     nInliersOut[f] = nInit - nBad;
   }
-  if (prior) {   // ConstraintPoseImu (:4717-4754): H from the un-robustified Jacobians at the final state, inliers only
-    double acc[21];
+  IMARK(9);
+  if (!prior) return;
+  // ---- ConstraintPoseImu for the next frame (:4717-4754 / :5094-5150): un-robustified Hessians at the final state, inliers only.
+  // Reference order of the 30 x 30 H: [state 1 (0..14) | frame (15..29)] = the inertial edge's own column order for its first 24.
+  double acc[21];
 #pragma unroll
-    for (int k = 0; k < 21; ++k) acc[k] = 0;
-    for (int i = tid; i < n; i += 256) {
-      if (!hasMP[base + i] || outlier[base + i]) continue;
-      const float* o = obs + (base + i) * 3;
-      const bool st = !(o[2] < 0);
-      const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
-      const double info = (double)invSigma2[base + i];
-      double err[3], Xc[3], J[18];
-      vis_error(g, S, X, o, st, info, err, Xc);
-      vis_jacobian(g, Xc, st, J);
-      const int d = st ? 3 : 2;
-      int q = 0;
+  for (int k = 0; k < 21; ++k) acc[k] = 0;
+  for (int i = tid; i < n; i += 256) {
+    if (!hasMP[base + i] || outlier[base + i]) continue;
+    const float* o = obs + (base + i) * 3;
+    const bool st = !(o[2] < 0);
+    const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
+    const double info = (double)invSigma2[base + i];
+    double err[3], Xc[3], J[18];
+    vis_error(g, S, X, o, st, info, err, Xc);
+    vis_jacobian(g, Xc, st, J);
+    int q = 0;
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
+    for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int cc = r; cc < 6; ++cc) {
-          double h = 0;
-          for (int k = 0; k < d; ++k) h += J[k * 6 + r] * info * J[k * 6 + cc];
-          acc[q++] += h;
-        }
+      for (int cc = r; cc < 6; ++cc) {
+        double h = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) h += J[k * 6 + r] * info * J[k * 6 + cc];   // mono: third row is zero
+        acc[q++] += h;
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < 21; ++k) acc[k] = wave_sum(acc[k]);
+  __syncthreads();
+  if (lane == 0) for (int k = 0; k < 21; ++k) Wk.red[wv][k] = acc[k];
+  if (tid == 64) inertial_edge(P, S1, S, delta, LASTFRAME, Wk.e, Wk.J);
+  if (LASTFRAME && tid == 128) prior_edge(pr, S1, Wk.ep, Wk.Jp);
+  __syncthreads();
+  for (int k = tid; k < 216; k += 256) { const int r = k / 24, c = k - r * 24; double s = 0; for (int l = 0; l < 9; ++l) s += Wk.InfoI[r * 9 + l] * Wk.J[l * 24 + c]; Wk.OJ[k] = s; }
+  if (LASTFRAME) for (int k = tid; k < 225; k += 256) { const int r = k / 15, c = k - r * 15; double s = 0; for (int l = 0; l < 15; ++l) s += Wk.pH[r * 15 + l] * Wk.Jp[l * 15 + c]; Wk.OJp[k] = s; }
+  __syncthreads();
+  for (int k = tid; k < 900; k += 256) {   // H30 in the reference order
+    const int r = k / 30, c = k - r * 30;
+    double h = 0;
+    if (r < 24 && c < 24) { double s = 0; for (int l = 0; l < 9; ++l) s += Wk.J[l * 24 + r] * Wk.OJ[l * 24 + c]; h += s; }
+    const int rb = r % 15, cb = c % 15;
+    if (rb >= 9 && cb >= 9 && (rb < 12) == (cb < 12)) {
+      const double* I3 = rb < 12 ? Wk.InfoG : Wk.InfoA;
+      const double v = I3[(rb - (rb < 12 ? 9 : 12)) * 3 + (cb - (cb < 12 ? 9 : 12))];
+      if (LASTFRAME) h += ((r < 15) == (c < 15)) ? v : -v;          // GetHessian(): both vertices
+      else if (r >= 15 && c >= 15) h += v;                           // GetHessian2(): the frame's bias only
     }
-#pragma unroll
-    for (int k = 0; k < 21; ++k) acc[k] = wave_sum(acc[k]);
+    if (LASTFRAME && r < 15 && c < 15) { double s = 0; for (int l = 0; l < 15; ++l) s += Wk.Jp[l * 15 + r] * Wk.OJp[l * 15 + c]; h += s; }
+    if (r >= 15 && c >= 15 && r < 21 && c < 21) {
+      const int a = (r < c ? r : c) - 15, bq = (r < c ? c : r) - 15;
+      const int q = a * 6 - a * (a - 1) / 2 + (bq - a);
+      h += Wk.red[0][q] + Wk.red[1][q] + Wk.red[2][q] + Wk.red[3][q];
+    }
+    Wk.H[k] = h;
+  }
+  __syncthreads();
+  double* Hout = prior + (size_t)246 * f + 21;
+  if (!LASTFRAME) {
+    // GetHessian2 of the inertial edge = its (P2, V2) columns: rows / cols 15..23 of H30; the result is the trailing 15 x 15
+    for (int k = tid; k < 225; k += 256) { const int r = k / 15, c = k - r * 15; Wk.Jp[k] = Wk.H[(15 + r) * 30 + 15 + c]; }
     __syncthreads();
-    if (lane == 0) for (int k = 0; k < 21; ++k) sRed[wv][k] = acc[k];
+  } else {
+    // Optimizer::Marginalize(H, 0, 14) (Optimizer.cc:2898-2977): Hcc - Hcp pinv(Hpp) Hpc, singular values <= 1e-6 dropped.
+    // All singular values above the threshold (Hpp - 1e-6 I positive definite) <=> the pseudo-inverse is the inverse: LDL^T
+    // solves; otherwise the eigen-decomposition path below.
+    // Hpp -> Jp (factor), Hpc -> OJp (15 right-hand sides, solved in place column by column)
+    for (int k = tid; k < 225; k += 256) { const int r = k / 15, c = k - r * 15; Wk.Jp[k] = 0.5 * (Wk.H[r * 30 + c] + Wk.H[c * 30 + r]); Wk.OJp[k] = Wk.H[r * 30 + 15 + c]; }
     __syncthreads();
     if (tid == 0) {
-      double* out = prior + (size_t)246 * f;
-      for (int k = 0; k < 9; ++k) out[k] = S.Rwb[k];
-      for (int k = 0; k < 3; ++k) { out[9 + k] = S.twb[k]; out[12 + k] = S.v[k]; out[15 + k] = S.bg[k]; out[18 + k] = S.ba[k]; }
-      double* H = out + 21;
-      for (int k = 0; k < 225; ++k) H[k] = 0;
-      double err[9];
-      double* J = sScratch;
-      inertial_edge(K, S, err, J);
-      add_inertial(K, err, J, H, nullptr);
-      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { H[(9 + r) * 15 + 9 + c] += K.InfoG[r * 3 + c]; H[(12 + r) * 15 + 12 + c] += K.InfoA[r * 3 + c]; }
-      int q = 0;
-      for (int r = 0; r < 6; ++r)
-        for (int cc = r; cc < 6; ++cc) {
-          const double t = sRed[0][q] + sRed[1][q] + sRed[2][q] + sRed[3][q];
-          H[r * 15 + cc] += t;
-          if (cc != r) H[cc * 15 + r] += t;
-          ++q;
-        }
+      // test on a copy (J | OJ hold 432 doubles)
+      double* T = Wk.J;
+      for (int k = 0; k < 225; ++k) T[k] = Wk.Jp[k];
+      for (int k = 0; k < 15; ++k) T[k * 15 + k] -= 1e-6;
+      bool pd = true;
+      for (int j = 0; j < 15 && pd; ++j) {
+        const double d = T[j * 15 + j];
+        if (!(d > 0)) { pd = false; break; }
+        for (int r = 14; r > j; --r) { const double l = T[r * 15 + j] / d; for (int c = j + 1; c <= r; ++c) T[r * 15 + c] -= l * T[c * 15 + j]; }
+      }
+      Wk.flag = pd ? 1 : 0;
     }
+    __syncthreads();
+    if (Wk.flag) {
+      // X = Hpp^-1 Hpc: factor once (wave 0), then 15 substitutions
+      if (wv == 0) {
+        for (int j = 0; j < 15; ++j) {
+          WAVE_SYNC();
+          const double d = Wk.Jp[j * 15 + j];
+          const int m = 14 - j, pairs = m * (m + 1) / 2;
+          for (int p = lane; p < pairs; p += 64) {
+            int rr = (int)((sqrtf(8.f * (float)p + 1.f) - 1.f) * 0.5f);
+            while ((rr + 1) * (rr + 2) / 2 <= p) ++rr;
+            while (rr * (rr + 1) / 2 > p) --rr;
+            const int cc = p - rr * (rr + 1) / 2;
+            const int r = j + 1 + rr, c = j + 1 + cc;
+            Wk.Jp[r * 15 + c] -= Wk.Jp[r * 15 + j] * Wk.Jp[c * 15 + j] / d;
+          }
+          WAVE_SYNC();
+          for (int r = j + 1 + lane; r < 15; r += 64) Wk.Jp[r * 15 + j] /= d;
+        }
+        WAVE_SYNC();
+      }
+      __syncthreads();
+      if (tid < 15) {   // one right-hand side (column tid of Hpc) per thread
+        double y[15];
+        for (int r = 0; r < 15; ++r) { double s = Wk.OJp[r * 15 + tid]; for (int c = 0; c < r; ++c) s -= Wk.Jp[r * 15 + c] * y[c]; y[r] = s; }
+        for (int r = 0; r < 15; ++r) y[r] /= Wk.Jp[r * 15 + r];
+        for (int r = 14; r >= 0; --r) { double s = y[r]; for (int c = r + 1; c < 15; ++c) s -= Wk.Jp[c * 15 + r] * y[c]; y[r] = s; }
+        for (int r = 0; r < 15; ++r) Wk.OJp[r * 15 + tid] = y[r];
+      }
+      __syncthreads();
+    } else {
+      if (tid == 0) {   // pinv by the eigen-decomposition (rare): V diag(1/e, |e| > 1e-6) V^T
+        double* A = Wk.J;          // 225 (J | OJ = 432 doubles)
+        double* V = Wk.J + 225;    // needs 225: spills into OJ's tail + e/Oe ... keep within J|OJ: 432 < 450 -> use b/x region too
+        // 450 doubles needed: J (216) + OJ (216) + e (9) + Oe (9) are contiguous in InertialWork
+        for (int k = 0; k < 225; ++k) { A[k] = Wk.Jp[k]; V[k] = 0.0; }
+        for (int k = 0; k < 15; ++k) V[k * 15 + k] = 1.0;
+        for (int sweep = 0; sweep < 60; ++sweep) {
+          double off = 0, diag = 0;
+          for (int r = 0; r < 15; ++r) for (int c = 0; c < 15; ++c) { const double t = A[r * 15 + c] * A[r * 15 + c]; if (r == c) diag += t; else off += t; }
+          if (off <= 1e-30 * diag) break;
+          for (int p = 0; p < 15; ++p)
+            for (int q = p + 1; q < 15; ++q) {
+              if (A[p * 15 + q] == 0.0) continue;
+              const double theta = (A[q * 15 + q] - A[p * 15 + p]) / (2.0 * A[p * 15 + q]);
+              const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+              const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+              for (int k = 0; k < 15; ++k) { const double a = A[k * 15 + p], bq = A[k * 15 + q]; A[k * 15 + p] = c * a - s * bq; A[k * 15 + q] = s * a + c * bq; }
+              for (int k = 0; k < 15; ++k) { const double a = A[p * 15 + k], bq = A[q * 15 + k]; A[p * 15 + k] = c * a - s * bq; A[q * 15 + k] = s * a + c * bq; }
+              for (int k = 0; k < 15; ++k) { const double a = V[k * 15 + p], bq = V[k * 15 + q]; V[k * 15 + p] = c * a - s * bq; V[k * 15 + q] = s * a + c * bq; }
+            }
+        }
+        // Jp <- pinv
+        for (int r = 0; r < 15; ++r)
+          for (int c = 0; c < 15; ++c) {
+            double s = 0;
+            for (int k = 0; k < 15; ++k) { const double e = A[k * 15 + k]; if (fabs(e) > 1e-6) s += V[r * 15 + k] * (1.0 / e) * V[c * 15 + k]; }
+            Wk.Jp[r * 15 + c] = s;
+          }
+        // OJp <- pinv * Hpc
+        for (int c = 0; c < 15; ++c) {
+          double y[15];
+          for (int r = 0; r < 15; ++r) { double s = 0; for (int k = 0; k < 15; ++k) s += Wk.Jp[r * 15 + k] * Wk.OJp[k * 15 + c]; y[r] = s; }
+          for (int r = 0; r < 15; ++r) Wk.OJp[r * 15 + c] = y[r];
+        }
+      }
+      __syncthreads();
+    }
+    // Hcc - Hcp X  -> Jp
+    double hv = 0;
+    if (tid < 225) {
+      const int r = tid / 15, c = tid - r * 15;
+      double s = 0;
+      for (int k = 0; k < 15; ++k) s += Wk.H[(15 + r) * 30 + k] * Wk.OJp[k * 15 + c];
+      hv = Wk.H[(15 + r) * 30 + 15 + c] - s;
+    }
+    __syncthreads();
+    if (tid < 225) Wk.Jp[tid] = hv;
+    __syncthreads();
+  }
+  if (tid == 0) clamp_eigenvalues(Wk.Jp, 15, 1e-12, Wk.J, Wk.OJp);   // ConstraintPoseImu's constructor; J | OJ | e | Oe = 450 doubles
+  __syncthreads();
+  IMARK(10);
+  for (int k = tid; k < 225; k += 256) Hout[k] = Wk.Jp[k];
+  if (tid == 0) {
+    double* out = prior + (size_t)246 * f;
+    for (int k = 0; k < 9; ++k) out[k] = S.Rwb[k];
+    for (int k = 0; k < 3; ++k) { out[9 + k] = S.twb[k]; out[12 + k] = S.v[k]; out[15 + k] = S.bg[k]; out[18 + k] = S.ba[k]; }
   }
 }
 
@@ -686,14 +1001,15 @@ int morb_imu_preintegrate_batch(morb_optimizer* o, int nseq, const int* d_start,
   return MORB_OK;
 }
 
-int morb_pose_inertial_optimization_last_keyframe_batch(morb_optimizer* o, int nframes, int cap, const int* d_count,
-                                                        const uint8_t* d_hasMP, const float* d_obs, const float* d_invSigma2,
-                                                        const float* d_Xw, const uint8_t* d_close, float fx, float fy, float cx,
-                                                        float cy, float bf, const float* Tbc12, const float* d_kfState,
-                                                        const morb_imu_preintegrated* d_pre, int bRecInit, float* d_state,
-                                                        uint8_t* d_outlier, int* d_nInliers, double* d_prior, void* stream) {
-  MORB_REQUIRE(o && d_hasMP && d_obs && d_invSigma2 && d_Xw && d_close && Tbc12 && d_kfState && d_pre && d_state && d_outlier && d_nInliers,
+static int launch_pose_inertial(bool lastFrame, morb_optimizer* o, int nframes, int cap, const int* d_count, const uint8_t* d_hasMP,
+                                const float* d_obs, const float* d_invSigma2, const float* d_Xw, const uint8_t* d_close, float fx,
+                                float fy, float cx, float cy, float bf, const float* Tbc12, const float* d_state1,
+                                const morb_imu_preintegrated* d_pre, const morb_imu_preintegrated* d_preKF,
+                                const double* d_prevPrior, int bRecInit, float* d_state, uint8_t* d_outlier, int* d_nInliers,
+                                double* d_prior, void* stream) {
+  MORB_REQUIRE(o && d_hasMP && d_obs && d_invSigma2 && d_Xw && d_close && Tbc12 && d_state1 && d_pre && d_state && d_outlier && d_nInliers,
                MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(!lastFrame || (d_preKF && d_prevPrior), MORB_ERR_INVALID, "NULL argument");
   MORB_REQUIRE(nframes > 0 && cap > 0, MORB_ERR_INVALID, "bad sizes");
   MORB_HIP_CHECK(hipSetDevice(morb_optimizer_device(o)));
   hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_optimizer_stream(o);
@@ -703,10 +1019,43 @@ int morb_pose_inertial_optimization_last_keyframe_batch(morb_optimizer* o, int n
   for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) g.Rcb[r * 3 + c] = g.Rbc[c * 3 + r];   // mTcb = mTbc.inverse()
   for (int r = 0; r < 3; ++r) g.tcb[r] = -(g.Rcb[r * 3] * g.tbc[0] + g.Rcb[r * 3 + 1] * g.tbc[1] + g.Rcb[r * 3 + 2] * g.tbc[2]);
   g.bf = bf; g.fx = fx; g.fy = fy; g.cx = cx; g.cy = cy;
-  hipLaunchKernelGGL(k_pose_inertial, dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, d_close, g,
-                     d_kfState, d_pre, bRecInit, d_state, d_outlier, d_nInliers, d_prior);
+  if (lastFrame)
+    hipLaunchKernelGGL(k_pose_inertial<true>, dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, d_close,
+                       g, d_state1, d_pre, d_preKF, d_prevPrior, bRecInit, d_state, d_outlier, d_nInliers, d_prior);
+  else
+    hipLaunchKernelGGL(k_pose_inertial<false>, dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, d_close,
+                       g, d_state1, d_pre, d_preKF, d_prevPrior, bRecInit, d_state, d_outlier, d_nInliers, d_prior);
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
 }
+
+int morb_pose_inertial_optimization_last_keyframe_batch(morb_optimizer* o, int nframes, int cap, const int* d_count,
+                                                        const uint8_t* d_hasMP, const float* d_obs, const float* d_invSigma2,
+                                                        const float* d_Xw, const uint8_t* d_close, float fx, float fy, float cx,
+                                                        float cy, float bf, const float* Tbc12, const float* d_kfState,
+                                                        const morb_imu_preintegrated* d_pre, int bRecInit, float* d_state,
+                                                        uint8_t* d_outlier, int* d_nInliers, double* d_prior, void* stream) {
+  return launch_pose_inertial(false, o, nframes, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, d_close, fx, fy, cx, cy, bf, Tbc12,
+                              d_kfState, d_pre, nullptr, nullptr, bRecInit, d_state, d_outlier, d_nInliers, d_prior, stream);
+}
+
+int morb_pose_inertial_optimization_last_frame_batch(morb_optimizer* o, int nframes, int cap, const int* d_count,
+                                                     const uint8_t* d_hasMP, const float* d_obs, const float* d_invSigma2,
+                                                     const float* d_Xw, const uint8_t* d_close, float fx, float fy, float cx, float cy,
+                                                     float bf, const float* Tbc12, const float* d_prevState,
+                                                     const morb_imu_preintegrated* d_preFrame, const morb_imu_preintegrated* d_preKF,
+                                                     const double* d_prevPrior, int bRecInit, float* d_state, uint8_t* d_outlier,
+                                                     int* d_nInliers, double* d_prior, void* stream) {
+  return launch_pose_inertial(true, o, nframes, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, d_close, fx, fy, cx, cy, bf, Tbc12,
+                              d_prevState, d_preFrame, d_preKF, d_prevPrior, bRecInit, d_state, d_outlier, d_nInliers, d_prior, stream);
+}
+
+#ifdef MORB_INERTIAL_TIMING
+int morb_inertial_timing(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[16] = {0}; MORB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_inertialPhase), z, sizeof(z))); return 0; }
+  MORB_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_inertialPhase), 16 * sizeof(unsigned long long)));
+  return 0;
+}
+#endif
 
 }  // extern "C"

@@ -40,4 +40,33 @@ __device__ __forceinline__ unsigned long long min_u64(unsigned long long v) {
   return ((unsigned long long)mh << 32) | ml;
 }
 
+// sum of a double over the 64 lanes (all lanes must be active): the two halves travel through DPP separately
+__device__ __forceinline__ double sum_f64(double v) {
+#define MORB_DPP_ADD_F64(ctrl, rowmask)                                                                             \
+  do {                                                                                                              \
+    const unsigned long long u_ = (unsigned long long)__double_as_longlong(v);                                      \
+    const int lo_ = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u_, ctrl, rowmask, 0xf, false);                   \
+    const int hi_ = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u_ >> 32), ctrl, rowmask, 0xf, false);           \
+    v += __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi_ << 32) | (uint32_t)lo_));             \
+  } while (0)
+  MORB_DPP_ADD_F64(0x111, 0xf);
+  MORB_DPP_ADD_F64(0x112, 0xf);
+  MORB_DPP_ADD_F64(0x114, 0xf);
+  MORB_DPP_ADD_F64(0x118, 0xf);
+  MORB_DPP_ADD_F64(0x142, 0xa);
+  MORB_DPP_ADD_F64(0x143, 0xc);
+#undef MORB_DPP_ADD_F64
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, 63);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), 63);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// broadcast of lane `src`'s double (src wave-uniform; a compile-time constant compiles to two v_readlane_b32)
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, src);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), src);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 }  // namespace morbwave

@@ -97,6 +97,27 @@ class Optimizer:
             ptr(out[2]), st))
         return out
 
+    def PoseInertialOptimizationLastFrame(self, hasMP, obs, invSigma2, Xw, close, cam, Tbc, prevState, preFrame, preKF, prevPrior, state,
+                                          bRecInit=False, count=None, want_prior=True, out=None, stream=None):
+        """Batched Optimizer::PoseInertialOptimizationLastFrame: as PoseInertialOptimizationLastKeyFrame, but the previous
+        frame's state (prevState f32 [F, 21]) is free and carries the prior prevPrior f64 [F, 246] (a previous call's third
+        result); preFrame = preintegration since the previous frame, preKF = since the last keyframe."""
+        import torch
+        F, cap = hasMP.shape
+        if out is None:
+            out = (torch.empty((F,), dtype=torch.int32, device=hasMP.device),
+                   torch.zeros((F, cap), dtype=torch.uint8, device=hasMP.device),
+                   torch.empty((F, 246), dtype=torch.float64, device=hasMP.device) if want_prior else None)
+        t = np.ascontiguousarray(Tbc, np.float32)
+        assert t.size == 12 and preFrame.shape[1] == PREINT_FLOATS and preKF.shape[1] == PREINT_FLOATS
+        assert state.shape[1] == 21 and prevState.shape[1] == 21 and prevPrior.shape[1] == 246 and prevPrior.dtype == torch.float64
+        st = stream_arg(stream)
+        check(self._L.morb_pose_inertial_optimization_last_frame_batch(
+            self._h, F, cap, ptr(count), ptr(hasMP), ptr(obs), ptr(invSigma2), ptr(Xw), ptr(close), cam["fx"], cam["fy"], cam["cx"],
+            cam["cy"], cam["bf"], ptr(t), ptr(prevState), ptr(preFrame), ptr(preKF), ptr(prevPrior), int(bool(bRecInit)), ptr(state),
+            ptr(out[1]), ptr(out[0]), ptr(out[2]), st))
+        return out
+
     def LocalBundleAdjustment(self, kfPose, kfFixed, mpPos, eKF, eMP, eObs, eInvSigma2, cam, inertial=False, stop=False, mode=0,
                               rig=None):
         """One-shot LocalBundleAdjustment on host numpy arrays; returns (kfPose, mpPos, eraseFlag, stats)."""

@@ -354,7 +354,20 @@ def imu_calib_diagonals(freq=IMU_FREQ, noise=IMU_NOISE):
     return (np.array([ng * ng] * 3 + [na * na] * 3, np.float32), np.array([ngw * ngw] * 3 + [naw * naw] * 3, np.float32))
 
 
-def make_inertial_problem(n=500, seed=0, n_imu=20, outlier_frac=0.1, mono_frac=0.3, rot_deg=1.0, trans=0.03, cam=EUROC_CAM):
+def make_inertial_sequence(n=500, seed=0, n_imu=20, **kw):
+    """Keyframe -> frame A -> frame B: (pA, pB).  pA is a PoseInertialOptimizationLastKeyFrame input; pB a
+    PoseInertialOptimizationLastFrame input whose IMU samples continue the same motion: accF / gyroF / dtF since frame A
+    (mpImuPreintegratedFrame) and acc / gyro / dt since the keyframe (mpImuPreintegrated).  The previous-frame state and
+    prior of pB are frame A's optimisation results (not part of the dict)."""
+    pA = make_inertial_problem(n, seed, n_imu, **kw)
+    pB = make_inertial_problem(n, seed, 2 * n_imu, _obs_seed=1, **kw)
+    assert np.array_equal(pA["acc"], pB["acc"][:n_imu])      # same motion and noise stream
+    pB["accF"], pB["gyroF"], pB["dtF"] = pB["acc"][n_imu:], pB["gyro"][n_imu:], pB["dt"][n_imu:]
+    return pA, pB
+
+
+def make_inertial_problem(n=500, seed=0, n_imu=20, outlier_frac=0.1, mono_frac=0.3, rot_deg=1.0, trans=0.03, cam=EUROC_CAM,
+                          _obs_seed=0):
     """One PoseInertialOptimizationLastKeyFrame input: the last keyframe's state, n_imu IMU samples of a smooth motion
     (constant body angular rate, constant world acceleration) between keyframe and frame, map points seen from the
     frame's true pose, and a perturbed initial frame state.  States: Rwb (9), twb, v, bg, ba."""
@@ -372,6 +385,7 @@ def make_inertial_problem(n=500, seed=0, n_imu=20, outlier_frac=0.1, mono_frac=0
         gyro.append(w_b + bg + rng.normal(0, 0.002, 3))
         dts.append(dt)
     T = n_imu * dt
+    rng = np.random.default_rng([0x1A71 + seed, _obs_seed, n_imu])   # map points / observations / initial guess
     R2 = R1 @ _rot_from_rotvec(w_b * T); v2 = v1 + a_w * T; p2 = p1 + v1 * T + 0.5 * a_w * T * T
     Tbc = EUROC_TBC
     Rcb = Tbc[:3, :3].T; tcb = -Rcb @ Tbc[:3, 3]

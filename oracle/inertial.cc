@@ -228,6 +228,20 @@ static void invRightJacobianSO3(const double* v, double* J) {  // G2oTypes.cc:81
   for (int k = 0; k < 9; ++k) J[k] = I[k] + W[k] / 2 + WW[k] * k2;
 }
 
+static void rightJacobianSO3(const double* v, double* J) {  // G2oTypes.cc:835-848
+  const double x = v[0], y = v[1], z = v[2];
+  const double d2 = x * x + y * y + z * z, d = std::sqrt(d2);
+  const double W[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+  const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (d < 1e-5) { memcpy(J, I, sizeof I); return; }
+  double WW[9];
+  mul33(W, W, WW);
+  for (int k = 0; k < 9; ++k) J[k] = I[k] - W[k] * (1.0 - std::cos(d)) / d2 + WW[k] * (d - std::sin(d)) / (d2 * d);
+}
+static void hat(const double* v, double* W) {
+  W[0] = 0; W[1] = -v[2]; W[2] = v[1]; W[3] = v[2]; W[4] = 0; W[5] = -v[0]; W[6] = -v[1]; W[7] = v[0]; W[8] = 0;
+}
+
 // general n x n inverse, Gauss-Jordan with partial pivoting (Eigen: PartialPivLU based inverse)
 static bool invertN(const double* A, int n, double* Ainv) {
   std::vector<double> M((size_t)n * 2 * n, 0.0);
@@ -296,6 +310,37 @@ static void inertialInformation(const float* C15, double* Info) {
     }
 }
 
+// ConstraintPoseImu's constructor (G2oTypes.h:711-721): eigenvalues of H below 1e-12 are set to zero
+static void clampConstraintH(double* H15) {
+  double e[15], V[225], S[225];
+  jacobiEig(H15, 15, e, V);
+  for (int k = 0; k < 15; ++k) if (e[k] < 1e-12) e[k] = 0;
+  for (int r = 0; r < 15; ++r)
+    for (int c = 0; c < 15; ++c) { double t = 0; for (int k = 0; k < 15; ++k) t += V[r * 15 + k] * e[k] * V[c * 15 + k]; S[r * 15 + c] = t; }
+  memcpy(H15, S, sizeof S);
+}
+// Optimizer::Marginalize(H, 0, 14) of a 30 x 30 H (Optimizer.cc:2898-2977), returning the trailing 15 x 15 block:
+// Hcc - Hcp pinv(Hpp) Hpc with the pseudo-inverse from the SVD (singular values <= 1e-6 dropped).  Hpp is symmetric, so its
+// SVD is its eigen-decomposition with singular values |e| (restated with the cyclic Jacobi solver).
+static void marginalizeFirst15(const double* H30, double* out15) {
+  double Hpp[225], e[15], V[225], P[225];
+  for (int r = 0; r < 15; ++r) for (int c = 0; c < 15; ++c) Hpp[r * 15 + c] = H30[r * 30 + c];
+  for (int r = 0; r < 15; ++r) for (int c = r + 1; c < 15; ++c) { const double m = 0.5 * (Hpp[r * 15 + c] + Hpp[c * 15 + r]); Hpp[r * 15 + c] = m; Hpp[c * 15 + r] = m; }
+  jacobiEig(Hpp, 15, e, V);
+  for (int r = 0; r < 15; ++r)
+    for (int c = 0; c < 15; ++c) {
+      double t = 0;
+      for (int k = 0; k < 15; ++k) if (std::fabs(e[k]) > 1e-6) t += V[r * 15 + k] * (1.0 / e[k]) * V[c * 15 + k];
+      P[r * 15 + c] = t;
+    }
+  for (int r = 0; r < 15; ++r)
+    for (int c = 0; c < 15; ++c) {
+      double t = 0;
+      for (int k = 0; k < 15; ++k) for (int l = 0; l < 15; ++l) t += H30[(15 + r) * 30 + k] * P[k * 15 + l] * H30[l * 30 + 15 + c];
+      out15[r * 15 + c] = H30[(15 + r) * 30 + 15 + c] - t;
+    }
+}
+
 // Eigen::LDLT with diagonal pivoting; solves H x = b when the factorisation is positive (linear_solver_dense.h:104-112)
 static bool ldltSolve(const double* Hin, const double* b, int n, double* x) {
   std::vector<double> A(Hin, Hin + (size_t)n * n);
@@ -313,9 +358,11 @@ static bool ldltSolve(const double* Hin, const double* b, int n, double* x) {
     const double d = A[k * n + k];
     if (!(d > 0)) positive = false;
     if (d == 0) continue;
+    std::vector<double> col(n);
+    for (int r = k + 1; r < n; ++r) col[r] = A[r * n + k];
     for (int r = k + 1; r < n; ++r) {
-      const double l = A[r * n + k] / d;
-      for (int c = k + 1; c <= r; ++c) { A[r * n + c] -= l * A[c * n + k]; A[c * n + r] = A[r * n + c]; }
+      const double l = col[r] / d;
+      for (int c = k + 1; c <= r; ++c) { A[r * n + c] -= l * col[c]; A[c * n + r] = A[r * n + c]; }
       A[r * n + k] = l;
     }
   }
@@ -646,6 +693,298 @@ extern "C" int orc_pose_inertial_optimization_last_keyframe(int n, const uint8_t
       }
     };
     add(mono); add(stereo);
+    for (int k = 0; k < 9; ++k) prior246[k] = VP.Rwb[k];
+    for (int k = 0; k < 3; ++k) { prior246[9 + k] = VP.twb[k]; prior246[12 + k] = v[k]; prior246[15 + k] = bg[k]; prior246[18 + k] = ba[k]; }
+    clampConstraintH(Hm);
+    memcpy(prior246 + 21, Hm, sizeof Hm);
+  }
+  return nInitial - nBad;
+}
+
+// Optimizer::PoseInertialOptimizationLastFrame (Optimizer.cc:4761-5161) for one frame: the frame's 15 states and the previous
+// frame's 15 states are free, tied by EdgeInertial(mpImuPreintegratedFrame), the two random-walk edges (information from
+// mpImuPreintegrated, i.e. since the last keyframe) and EdgePriorPoseImu(pFp->mpcpi) with a Huber kernel (delta 5).
+// prevPrior246 = pFp->mpcpi (21 state doubles + 15 x 15 H); prior246 (out) = the frame's new mpcpi after Marginalize(H, 0, 14).
+extern "C" int orc_pose_inertial_optimization_last_frame(int n, const uint8_t* hasMP, const float* obs, const float* invSigma2,
+                                                         const float* Xw, const uint8_t* closeFlag, float fx, float fy, float cx,
+                                                         float cy, float bf, const float* Tbc12, const float* prevState21,
+                                                         const orc_imu_preintegrated* preFrame, const orc_imu_preintegrated* preKF,
+                                                         const double* prevPrior246, int bRecInit, float* state21,
+                                                         uint8_t* outlier, double* prior246) {
+  CamPose VP, VPk;
+  auto load = [&](CamPose& P, const float* s, double* v, double* bg, double* ba) {
+    for (int k = 0; k < 9; ++k) P.Rwb[k] = s[k];
+    for (int k = 0; k < 3; ++k) { P.twb[k] = s[9 + k]; v[k] = s[12 + k]; bg[k] = s[15 + k]; ba[k] = s[18 + k]; }
+    for (int k = 0; k < 9; ++k) P.Rbc[k] = Tbc12[k];
+    for (int k = 0; k < 3; ++k) P.tbc[k] = Tbc12[9 + k];
+    transpose33(P.Rbc, P.Rcb);
+    mul3v(P.Rcb, P.tbc, P.tcb);
+    for (double& c : P.tcb) c = -c;
+    P.bf = bf; P.fx = fx; P.fy = fy; P.cx = cx; P.cy = cy;
+    P.refreshCamera();
+  };
+  double v[3], bg[3], ba[3], vk[3], bgk[3], bak[3];
+  load(VP, state21, v, bg, ba);
+  load(VPk, prevState21, vk, bgk, bak);
+
+  const double thHuberMono = (double)(float)std::sqrt(5.991), thHuberStereo = (double)(float)std::sqrt(7.815);
+  std::vector<VisEdge> mono, stereo;
+  for (int i = 0; i < n; ++i) {
+    if (!hasMP[i]) continue;
+    VisEdge e;
+    e.idx = i; e.stereo = !(obs[3 * i + 2] < 0);
+    e.obs[0] = obs[3 * i]; e.obs[1] = obs[3 * i + 1]; e.obs[2] = obs[3 * i + 2];
+    for (int k = 0; k < 3; ++k) e.Xw[k] = Xw[3 * i + k];
+    const float is2 = invSigma2[i] / 1.0f;
+    e.info = is2; e.close = closeFlag[i] != 0;
+    outlier[i] = 0;
+    (e.stereo ? stereo : mono).push_back(e);
+  }
+  const int nInitial = (int)(mono.size() + stereo.size());
+
+  double JRg[9], JVg[9], JPg[9], JVa[9], JPa[9];
+  for (int k = 0; k < 9; ++k) { JRg[k] = preFrame->JRg[k]; JVg[k] = preFrame->JVg[k]; JPg[k] = preFrame->JPg[k]; JVa[k] = preFrame->JVa[k]; JPa[k] = preFrame->JPa[k]; }
+  const double dt = preFrame->dT;
+  const double g[3] = {0, 0, -(double)9.81f};
+  double InfoI[81], InfoG[9], InfoA[9];
+  inertialInformation(preFrame->C, InfoI);
+  {
+    double Cg[9], Ca[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { Cg[r * 3 + c] = preKF->C[(9 + r) * 15 + 9 + c]; Ca[r * 3 + c] = preKF->C[(12 + r) * 15 + 12 + c]; }
+    invertN(Cg, 3, InfoG); invertN(Ca, 3, InfoA);
+  }
+  // prior (EdgePriorPoseImu, G2oTypes.cc:729-766)
+  double pR[9], pt[3], pv[3], pbg[3], pba[3], pH[225];
+  for (int k = 0; k < 9; ++k) pR[k] = prevPrior246[k];
+  for (int k = 0; k < 3; ++k) { pt[k] = prevPrior246[9 + k]; pv[k] = prevPrior246[12 + k]; pbg[k] = prevPrior246[15 + k]; pba[k] = prevPrior246[18 + k]; }
+  memcpy(pH, prevPrior246 + 21, sizeof pH);
+
+  // inertial edge between (VPk, vk, bgk, bak) and (VP, v): error (9) and the 9 x 24 Jacobian in edge order [P1 V1 G1 A1 P2 V2]
+  auto inertial = [&](double* err, double* J) {
+    const float b1f[6] = {(float)bak[0], (float)bak[1], (float)bak[2], (float)bgk[0], (float)bgk[1], (float)bgk[2]};
+    float dRf[9], dVf[3], dPf[3];
+    orc_imu_delta(preFrame, b1f, dRf, dVf, dPf);
+    double dR[9], dV[3], dP[3];
+    for (int k = 0; k < 9; ++k) dR[k] = dRf[k];
+    for (int k = 0; k < 3; ++k) { dV[k] = dVf[k]; dP[k] = dPf[k]; }
+    double Rbw1[9], dRt[9], M[9], eR[9], er[3];
+    transpose33(VPk.Rwb, Rbw1);
+    transpose33(dR, dRt);
+    mul33(dRt, Rbw1, M);
+    mul33(M, VP.Rwb, eR);
+    logSO3(eR, er);
+    double t1[3], t2[3], a1[3], a2[3];
+    for (int k = 0; k < 3; ++k) t1[k] = v[k] - vk[k] - g[k] * dt;
+    mul3v(Rbw1, t1, a1);
+    for (int k = 0; k < 3; ++k) t2[k] = VP.twb[k] - VPk.twb[k] - vk[k] * dt - g[k] * dt * dt / 2;
+    mul3v(Rbw1, t2, a2);
+    for (int k = 0; k < 3; ++k) { err[k] = er[k]; err[3 + k] = a1[k] - dV[k]; err[6 + k] = a2[k] - dP[k]; }
+    if (!J) return;
+    memset(J, 0, sizeof(double) * 9 * 24);
+    double invJr[9], Rwb2t[9], T[9], T2[9];
+    invRightJacobianSO3(er, invJr);
+    auto put = [&](int r0, int c0, const double* B, double sgn) { for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) J[(r0 + r) * 24 + c0 + c] = sgn * B[r * 3 + c]; };
+    // pose 1 (cols 0..5)
+    transpose33(VP.Rwb, Rwb2t);
+    mul33(invJr, Rwb2t, T); mul33(T, VPk.Rwb, T2);
+    put(0, 0, T2, -1.0);
+    {
+      // hat(Rbw1 * (v2 - v1 - g dt)); the position row uses 0.5 * g * dt * dt (G2oTypes.cc:549-552)
+      double W[9];
+      hat(a1, W); put(3, 0, W, 1.0);
+      double t3[3], a3[3];
+      for (int k = 0; k < 3; ++k) t3[k] = VP.twb[k] - VPk.twb[k] - vk[k] * dt - 0.5 * g[k] * dt * dt;
+      mul3v(Rbw1, t3, a3);
+      hat(a3, W); put(6, 0, W, 1.0);
+    }
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    put(6, 3, I3, -1.0);
+    // velocity 1 (cols 6..8)
+    put(3, 6, Rbw1, -1.0);
+    { double B[9]; for (int k = 0; k < 9; ++k) B[k] = Rbw1[k] * dt; put(6, 6, B, -1.0); }
+    // gyro bias 1 (cols 9..11): -invJr * eR^T * RightJacobianSO3(JRg * dbg) * JRg, -JVg, -JPg
+    {
+      const float dbgf[3] = {b1f[3] - preFrame->b[3], b1f[4] - preFrame->b[4], b1f[5] - preFrame->b[5]};   // GetDeltaBias (float)
+      const double dbg[3] = {dbgf[0], dbgf[1], dbgf[2]};
+      double w3[3], rj[9], eRt[9];
+      mul3v(JRg, dbg, w3);
+      rightJacobianSO3(w3, rj);
+      transpose33(eR, eRt);
+      mul33(invJr, eRt, T); mul33(T, rj, T2); mul33(T2, JRg, T);
+      put(0, 9, T, -1.0);
+      put(3, 9, JVg, -1.0); put(6, 9, JPg, -1.0);
+    }
+    // acc bias 1 (cols 12..14)
+    put(3, 12, JVa, -1.0); put(6, 12, JPa, -1.0);
+    // pose 2 (cols 15..20)
+    put(0, 15, invJr, 1.0);
+    mul33(Rbw1, VP.Rwb, T); put(6, 18, T, 1.0);
+    // velocity 2 (cols 21..23)
+    put(3, 21, Rbw1, 1.0);
+  };
+  auto priorEdge = [&](double* err, double* J /* 15 x 15 */) {
+    double pRt[9], E[9], er[3], d[3], et[3];
+    transpose33(pR, pRt);
+    mul33(pRt, VPk.Rwb, E);
+    logSO3(E, er);
+    for (int k = 0; k < 3; ++k) d[k] = VPk.twb[k] - pt[k];
+    mul3v(pRt, d, et);
+    for (int k = 0; k < 3; ++k) { err[k] = er[k]; err[3 + k] = et[k]; err[6 + k] = vk[k] - pv[k]; err[9 + k] = bgk[k] - pbg[k]; err[12 + k] = bak[k] - pba[k]; }
+    if (!J) return;
+    memset(J, 0, sizeof(double) * 225);
+    double invJr[9];
+    invRightJacobianSO3(er, invJr);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { J[r * 15 + c] = invJr[r * 3 + c]; J[(3 + r) * 15 + 3 + c] = E[r * 3 + c]; }
+    for (int k = 6; k < 15; ++k) J[k * 15 + k] = 1.0;
+  };
+  // system order (vertex ids): frame [P 0..5, V 6..8, G 9..11, A 12..14], previous frame 15 + the same
+  const int edgeCol[24] = {15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 0, 1, 2, 3, 4, 5, 6, 7, 8};
+
+  const float chi2Mono[4] = {5.991, 5.991, 5.991, 5.991};
+  const float chi2Stereo[4] = {15.6f, 9.8f, 7.815f, 7.815f};
+  int nBad = 0, nInliers = 0;
+  double xPrev[30];
+  memset(xPrev, 0, sizeof xPrev);
+  for (int it = 0; it < 4; ++it) {
+    bool ok = true;
+    for (int iter = 0; iter < 10 && ok; ++iter) {
+      double H[900], b[30];
+      memset(H, 0, sizeof H); memset(b, 0, sizeof b);
+      auto visual = [&](std::vector<VisEdge>& E, double delta) {
+        for (VisEdge& e : E) {
+          if (e.level != 0) continue;
+          e.computeError(VP);
+          const int d = e.stereo ? 3 : 2;
+          double J[18];
+          e.jacobian(VP, J);
+          double w = 1.0;
+          if (e.robust) { double rho[3]; huber(delta, e.chi2(), rho); w = rho[1]; }
+          for (int r = 0; r < 6; ++r) {
+            double bb = 0;
+            for (int k = 0; k < d; ++k) bb += J[k * 6 + r] * (e.info * e.err[k]);
+            b[r] -= w * bb;
+            for (int c = 0; c < 6; ++c) { double h = 0; for (int k = 0; k < d; ++k) h += J[k * 6 + r] * (w * e.info) * J[k * 6 + c]; H[r * 30 + c] += h; }
+          }
+        }
+      };
+      visual(mono, thHuberMono);
+      visual(stereo, thHuberStereo);
+      {
+        double err[9], J[216];
+        inertial(err, J);
+        for (int a = 0; a < 24; ++a) {
+          double JtO[9];
+          for (int c = 0; c < 9; ++c) { double s = 0; for (int k = 0; k < 9; ++k) s += J[k * 24 + a] * InfoI[k * 9 + c]; JtO[c] = s; }
+          double s = 0; for (int k = 0; k < 9; ++k) s += JtO[k] * err[k];
+          b[edgeCol[a]] -= s;
+          for (int c = 0; c < 24; ++c) { double h = 0; for (int k = 0; k < 9; ++k) h += JtO[k] * J[k * 24 + c]; H[edgeCol[a] * 30 + edgeCol[c]] += h; }
+        }
+      }
+      for (int r = 0; r < 3; ++r) {   // EdgeGyroRW(VGk, VG) / EdgeAccRW(VAk, VA): e = x2 - x1, J1 = -I, J2 = I
+        double sg = 0, sa = 0;
+        for (int k = 0; k < 3; ++k) { sg += InfoG[r * 3 + k] * (bg[k] - bgk[k]); sa += InfoA[r * 3 + k] * (ba[k] - bak[k]); }
+        b[9 + r] -= sg; b[24 + r] += sg; b[12 + r] -= sa; b[27 + r] += sa;
+        for (int c = 0; c < 3; ++c) {
+          const double ig = InfoG[r * 3 + c], ia = InfoA[r * 3 + c];
+          H[(9 + r) * 30 + 9 + c] += ig; H[(24 + r) * 30 + 24 + c] += ig; H[(9 + r) * 30 + 24 + c] -= ig; H[(24 + r) * 30 + 9 + c] -= ig;
+          H[(12 + r) * 30 + 12 + c] += ia; H[(27 + r) * 30 + 27 + c] += ia; H[(12 + r) * 30 + 27 + c] -= ia; H[(27 + r) * 30 + 12 + c] -= ia;
+        }
+      }
+      {  // EdgePriorPoseImu with Huber(5) on the previous frame's block (system rows 15..29)
+        double err[15], J[225], Oe[15];
+        priorEdge(err, J);
+        double chi2 = 0;
+        for (int r = 0; r < 15; ++r) { double s = 0; for (int k = 0; k < 15; ++k) s += pH[r * 15 + k] * err[k]; Oe[r] = s; chi2 += err[r] * s; }
+        double rho[3];
+        huber(5.0, chi2, rho);
+        for (int a = 0; a < 15; ++a) {
+          double s = 0; for (int k = 0; k < 15; ++k) s += J[k * 15 + a] * Oe[k];
+          b[15 + a] -= rho[1] * s;
+          for (int c = 0; c < 15; ++c) {
+            double h = 0;
+            for (int k = 0; k < 15; ++k) for (int l = 0; l < 15; ++l) h += J[k * 15 + a] * (rho[1] * pH[k * 15 + l]) * J[l * 15 + c];
+            H[(15 + a) * 30 + 15 + c] += h;
+          }
+        }
+      }
+      double x[30];
+      memcpy(x, xPrev, sizeof x);
+      ok = ldltSolve(H, b, 30, x);
+      memcpy(xPrev, x, sizeof x);
+      VP.update(x);
+      for (int k = 0; k < 3; ++k) { v[k] += x[6 + k]; bg[k] += x[9 + k]; ba[k] += x[12 + k]; }
+      VPk.update(x + 15);
+      for (int k = 0; k < 3; ++k) { vk[k] += x[21 + k]; bgk[k] += x[24 + k]; bak[k] += x[27 + k]; }
+    }
+    nBad = 0; nInliers = 0;
+    const float chi2close = 1.5 * chi2Mono[it];
+    for (VisEdge& e : mono) {
+      if (outlier[e.idx]) e.computeError(VP);
+      const float chi2 = (float)e.chi2();
+      const bool bClose = e.close;
+      if ((chi2 > chi2Mono[it] && !bClose) || (bClose && chi2 > chi2close) || !e.depthPositive(VP)) { outlier[e.idx] = 1; e.level = 1; ++nBad; }
+      else { outlier[e.idx] = 0; e.level = 0; ++nInliers; }
+      if (it == 2) e.robust = false;
+    }
+    for (VisEdge& e : stereo) {
+      if (outlier[e.idx]) e.computeError(VP);
+      const float chi2 = (float)e.chi2();
+      if (chi2 > chi2Stereo[it]) { outlier[e.idx] = 1; e.level = 1; ++nBad; }
+      else { outlier[e.idx] = 0; e.level = 0; ++nInliers; }
+      if (it == 2) e.robust = false;
+    }
+    if (nInitial + 4 < 10) break;   // optimizer.edges().size() < 10
+  }
+  if (nInliers < 30 && !bRecInit) {
+    nBad = 0;
+    for (VisEdge& e : mono) { e.computeError(VP); if ((float)e.chi2() < 18.f) outlier[e.idx] = 0; else ++nBad; }
+    for (VisEdge& e : stereo) { e.computeError(VP); if ((float)e.chi2() < 24.f) outlier[e.idx] = 0; else ++nBad; }
+  }
+  for (int k = 0; k < 9; ++k) state21[k] = (float)VP.Rwb[k];
+  for (int k = 0; k < 3; ++k) { state21[9 + k] = (float)VP.twb[k]; state21[12 + k] = (float)v[k]; state21[15 + k] = (float)bg[k]; state21[18 + k] = (float)ba[k]; }
+
+  if (prior246) {   // :5094-5150, H in the reference's order [previous frame 0..14 | frame 15..29]
+    double H[900];
+    memset(H, 0, sizeof H);
+    {
+      double err[9], J[216];
+      inertial(err, J);   // edge order = the first 24 rows / columns of H
+      for (int a = 0; a < 24; ++a)
+        for (int c = 0; c < 24; ++c) {
+          double h = 0;
+          for (int k = 0; k < 9; ++k) for (int l = 0; l < 9; ++l) h += J[k * 24 + a] * InfoI[k * 9 + l] * J[l * 24 + c];
+          H[a * 30 + c] += h;
+        }
+    }
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        const double ig = InfoG[r * 3 + c], ia = InfoA[r * 3 + c];
+        H[(9 + r) * 30 + 9 + c] += ig; H[(9 + r) * 30 + 24 + c] -= ig; H[(24 + r) * 30 + 9 + c] -= ig; H[(24 + r) * 30 + 24 + c] += ig;
+        H[(12 + r) * 30 + 12 + c] += ia; H[(12 + r) * 30 + 27 + c] -= ia; H[(27 + r) * 30 + 12 + c] -= ia; H[(27 + r) * 30 + 27 + c] += ia;
+      }
+    {
+      double err[15], J[225];
+      priorEdge(err, J);
+      for (int a = 0; a < 15; ++a)
+        for (int c = 0; c < 15; ++c) {
+          double h = 0;
+          for (int k = 0; k < 15; ++k) for (int l = 0; l < 15; ++l) h += J[k * 15 + a] * pH[k * 15 + l] * J[l * 15 + c];
+          H[a * 30 + c] += h;
+        }
+    }
+    auto add = [&](std::vector<VisEdge>& E) {
+      for (VisEdge& e : E) {
+        if (outlier[e.idx]) continue;
+        const int d = e.stereo ? 3 : 2;
+        double J[18];
+        e.jacobian(VP, J);
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { double h = 0; for (int k = 0; k < d; ++k) h += J[k * 6 + r] * e.info * J[k * 6 + c]; H[(15 + r) * 30 + 15 + c] += h; }
+      }
+    };
+    add(mono); add(stereo);
+    double Hm[225];
+    marginalizeFirst15(H, Hm);
+    clampConstraintH(Hm);
     for (int k = 0; k < 9; ++k) prior246[k] = VP.Rwb[k];
     for (int k = 0; k < 3; ++k) { prior246[9 + k] = VP.twb[k]; prior246[12 + k] = v[k]; prior246[15 + k] = bg[k]; prior246[18 + k] = ba[k]; }
     memcpy(prior246 + 21, Hm, sizeof Hm);

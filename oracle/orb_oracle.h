@@ -157,6 +157,12 @@ int orc_pose_inertial_optimization_last_keyframe(int n, const uint8_t* hasMP, co
                                                  float cy, float bf, const float* Tbc12, const float* kfState21,
                                                  const orc_imu_preintegrated* pre, int bRecInit, float* state21,
                                                  uint8_t* outlier, double* prior246);
+int orc_pose_inertial_optimization_last_frame(int n, const uint8_t* hasMP, const float* obs, const float* invSigma2,
+                                              const float* Xw, const uint8_t* closeFlag, float fx, float fy, float cx, float cy,
+                                              float bf, const float* Tbc12, const float* prevState21,
+                                              const orc_imu_preintegrated* preFrame, const orc_imu_preintegrated* preKF,
+                                              const double* prevPrior246, int bRecInit, float* state21, uint8_t* outlier,
+                                              double* prior246);
 float orc_fast_atan2(float y, float x);
 float orc_cosf(float x);
 float orc_sinf(float x);

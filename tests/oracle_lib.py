@@ -477,3 +477,20 @@ def pose_inertial_optimization_last_keyframe(p, pre, bRecInit=False):
                                                        cam["cx"], cam["cy"], cam["bf"], _p(a[5]), _p(a[6]), _p(pre),
                                                        int(bool(bRecInit)), _p(state), _p(outl), _p(prior))
     return r, state, outl, prior
+
+
+def pose_inertial_optimization_last_frame(p, prevState, preFrame, preKF, prevPrior, bRecInit=False):
+    L = lib()
+    f = C.c_float
+    L.orc_pose_inertial_optimization_last_frame.argtypes = [C.c_int] + [C.c_void_p] * 5 + [f] * 5 + [C.c_void_p] * 5 + [C.c_int] + \
+        [C.c_void_p] * 3
+    n = len(p["hasMP"])
+    state = p["state0"].astype(np.float32).copy(); outl = np.zeros(n, np.uint8); prior = np.zeros(246, np.float64)
+    a = [np.ascontiguousarray(p[k]) for k in ("hasMP", "obs", "invSigma2", "Xw", "close", "Tbc12")]
+    b = [np.ascontiguousarray(prevState, np.float32), np.ascontiguousarray(preFrame, np.float32),
+         np.ascontiguousarray(preKF, np.float32), np.ascontiguousarray(prevPrior, np.float64)]
+    cam = p["cam"]
+    r = L.orc_pose_inertial_optimization_last_frame(n, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), cam["fx"], cam["fy"], cam["cx"],
+                                                    cam["cy"], cam["bf"], _p(a[5]), _p(b[0]), _p(b[1]), _p(b[2]), _p(b[3]),
+                                                    int(bool(bRecInit)), _p(state), _p(outl), _p(prior))
+    return r, state, outl, prior
