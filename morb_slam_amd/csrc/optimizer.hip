@@ -440,18 +440,19 @@ __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict
         if (robust) c = huber(st ? deltaStereo : deltaMono, c, &w);
         acc[27] += c;
         pose_edge_jac<FISH>(cam, rig, right, st, xc, Jp);
-        const int d = st ? 3 : 2;
         const double wo = w * info;
         int q = 0;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
           double bb = 0;
-          for (int k = 0; k < d; ++k) bb += Jp[k * 6 + r] * (info * err[k]);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) bb += Jp[k * 6 + r] * (info * err[k]);   // mono: row 2 and err[2] are zero; a runtime bound would push Jp into scratch memory
           acc[21 + r] -= w * bb;  // b -= rho' * J^T * Omega * e  (base_unary_edge.hpp:61)
 #pragma unroll
           for (int cc = r; cc < 6; ++cc) {
             double h = 0;
-            for (int k = 0; k < d; ++k) h += Jp[k * 6 + r] * wo * Jp[k * 6 + cc];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) h += Jp[k * 6 + r] * wo * Jp[k * 6 + cc];
             acc[q++] += h;
           }
         }
@@ -661,15 +662,14 @@ __global__ __launch_bounds__(BA_T) void k_local_ba(const BaDev* __restrict__ pro
         huber(st ? deltaStereo : deltaMono, c, &w);
         q_to_R(T.q, R);
         ba_edge_jac(cam, pb.rig, st, xc, o, R, nullptr, Jl);
-        const int d = st ? 3 : 2;
         const double wo = w * info;
         for (int r = 0; r < 3; ++r) {
           double s = 0;
-          for (int i = 0; i < d; ++i) s += Jl[i * 3 + r] * (-info * err[i] * w);
+          _Pragma("unroll") for (int i = 0; i < 3; ++i) s += Jl[i * 3 + r] * (-info * err[i] * w);
           bl[r] += s;
           for (int cc = 0; cc < 3; ++cc) {
             double h = 0;
-            for (int i = 0; i < d; ++i) h += Jl[i * 3 + r] * wo * Jl[i * 3 + cc];
+            _Pragma("unroll") for (int i = 0; i < 3; ++i) h += Jl[i * 3 + r] * wo * Jl[i * 3 + cc];
             Hl[r * 3 + cc] += h;
           }
         }
@@ -697,23 +697,22 @@ __global__ __launch_bounds__(BA_T) void k_local_ba(const BaDev* __restrict__ pro
         const double c = ba_edge_error(cam, pb.rig, st, xc, o, info, err);
         huber(st ? deltaStereo : deltaMono, c, &w);
         ba_edge_jac(cam, pb.rig, st, xc, o, R, Jp, Jl);
-        const int d = st ? 3 : 2;
         const double wo = w * info;
         int q = 0;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
           double s = 0;
-          for (int i = 0; i < d; ++i) s += Jp[i * 6 + r] * (-info * err[i] * w);
+          _Pragma("unroll") for (int i = 0; i < 3; ++i) s += Jp[i * 6 + r] * (-info * err[i] * w);
           acc[21 + r] += s;
 #pragma unroll
           for (int cc = r; cc < 6; ++cc) {
             double h = 0;
-            for (int i = 0; i < d; ++i) h += Jp[i * 6 + r] * wo * Jp[i * 6 + cc];
+            _Pragma("unroll") for (int i = 0; i < 3; ++i) h += Jp[i * 6 + r] * wo * Jp[i * 6 + cc];
             acc[q++] += h;
           }
           for (int cc = 0; cc < 3; ++cc) {
             double h = 0;
-            for (int i = 0; i < d; ++i) h += Jp[i * 6 + r] * wo * Jl[i * 3 + cc];
+            _Pragma("unroll") for (int i = 0; i < 3; ++i) h += Jp[i * 6 + r] * wo * Jl[i * 3 + cc];
             pb.Hpl[(size_t)e * 18 + r * 3 + cc] = h;
           }
         }
@@ -977,15 +976,14 @@ __global__ __launch_bounds__(GB) void k_g_build_mp(const BaDev* __restrict__ pbp
     huber(st ? deltaStereo : deltaMono, c, &w);
     q_to_R(T.q, R);
     ba_edge_jac(pb.cam, pb.rig, st, xc, o, R, nullptr, Jl);
-    const int d = st ? 3 : 2;
-    const double wo = w * info;
+    const double wo = w * info;   // (mono edges: third Jacobian row and err[2] are zero, so the 3-row form is exact)
     for (int r = 0; r < 3; ++r) {
       double sacc = 0;
-      for (int i = 0; i < d; ++i) sacc += Jl[i * 3 + r] * (-info * err[i] * w);
+      _Pragma("unroll") for (int i = 0; i < 3; ++i) sacc += Jl[i * 3 + r] * (-info * err[i] * w);
       bl[r] += sacc;
       for (int cc = 0; cc < 3; ++cc) {
         double h = 0;
-        for (int i = 0; i < d; ++i) h += Jl[i * 3 + r] * wo * Jl[i * 3 + cc];
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) h += Jl[i * 3 + r] * wo * Jl[i * 3 + cc];
         Hl[r * 3 + cc] += h;
       }
     }
@@ -1016,23 +1014,22 @@ __global__ __launch_bounds__(GB) void k_g_build_kf(const BaDev* __restrict__ pbp
     const double ch = ba_edge_error(pb.cam, pb.rig, st, xc, o, info, err);
     huber(st ? deltaStereo : deltaMono, ch, &w);
     ba_edge_jac(pb.cam, pb.rig, st, xc, o, R, Jp, Jl);
-    const int d = st ? 3 : 2;
-    const double wo = w * info;
+    const double wo = w * info;   // (mono edges: third Jacobian row and err[2] are zero, so the 3-row form is exact)
     int q = 0;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       double sacc = 0;
-      for (int i = 0; i < d; ++i) sacc += Jp[i * 6 + r] * (-info * err[i] * w);
+      _Pragma("unroll") for (int i = 0; i < 3; ++i) sacc += Jp[i * 6 + r] * (-info * err[i] * w);
       acc[21 + r] = sacc;
 #pragma unroll
       for (int cc = r; cc < 6; ++cc) {
         double h = 0;
-        for (int i = 0; i < d; ++i) h += Jp[i * 6 + r] * wo * Jp[i * 6 + cc];
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) h += Jp[i * 6 + r] * wo * Jp[i * 6 + cc];
         acc[q++] = h;
       }
       for (int cc = 0; cc < 3; ++cc) {
         double h = 0;
-        for (int i = 0; i < d; ++i) h += Jp[i * 6 + r] * wo * Jl[i * 3 + cc];
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) h += Jp[i * 6 + r] * wo * Jl[i * 3 + cc];
         pb.Hpl[(size_t)e * 18 + r * 3 + cc] = h;
       }
     }
