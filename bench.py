@@ -134,7 +134,53 @@ def optimizer_extras(dev_index):
     for q in probs[:8]:
         O.pose_optimization(q)
     dcp = (time.perf_counter() - t0) / 8
-    return {"local_ba": {"edges": int(len(b["eKF"])), "keyframes_free_fixed": [20, 6], "points": 3000,
+    # visual-inertial tracking (SURVEY 8(f) N1 slice): keyframe -> frame A (LastKeyFrame) -> frame B (LastFrame), IMU at 200 Hz
+    from morb_slam_amd.synth import imu_calib_diagonals, make_inertial_sequence
+    FI = 256
+    seq = [make_inertial_sequence(600, seed=s % 8, n_imu=20) for s in range(FI)]
+    nga, walk = imu_calib_diagonals()
+    stk = lambda which, k: torch.from_numpy(np.stack([q[which][k] for q in seq])).to(dev)
+    cat = lambda which, k: torch.from_numpy(np.concatenate([q[which][k] for q in seq])).to(dev)
+    def starts(which, k):
+        return torch.from_numpy(np.cumsum([0] + [len(q[which][k]) for q in seq]).astype(np.int32)).to(dev)
+    A = [stk(0, k) for k in ("hasMP", "obs", "invSigma2", "Xw", "close", "kfState", "state0", "bias")]
+    B = [stk(1, k) for k in ("hasMP", "obs", "invSigma2", "Xw", "close", "state0")]
+    imuA = (starts(0, "dt"), cat(0, "acc"), cat(0, "gyro"), cat(0, "dt"))
+    imuF = (starts(1, "dtF"), cat(1, "accF"), cat(1, "gyroF"), cat(1, "dtF"))
+    imuK = (starts(1, "dt"), cat(1, "acc"), cat(1, "gyro"), cat(1, "dt"))
+    camI, Tbc = seq[0][0]["cam"], seq[0][0]["Tbc12"]
+    preA = preF = preK = outA = outB = None
+    stA, stB = A[6].clone(), B[5].clone()
+    def inertial_step():
+        nonlocal preA, preF, preK, outA, outB
+        preA = opt.PreintegrateIMU(*imuA, A[7], nga, walk, out=preA)
+        preF = opt.PreintegrateIMU(*imuF, A[7], nga, walk, out=preF)
+        preK = opt.PreintegrateIMU(*imuK, A[7], nga, walk, out=preK)
+        stA.copy_(A[6]); stB.copy_(B[5])
+        torch.cuda.synchronize(dev)   # the copies run on torch's stream, the kernels on the handle's
+        outA = opt.PoseInertialOptimizationLastKeyFrame(A[0], A[1], A[2], A[3], A[4], camI, Tbc, A[5], preA, stA, out=outA)
+        outB = opt.PoseInertialOptimizationLastFrame(B[0], B[1], B[2], B[3], B[4], camI, Tbc, stA, preF, preK, outA[2], stB, out=outB)
+    for _ in range(2):
+        inertial_step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        inertial_step()
+    torch.cuda.synchronize(dev)
+    dti = (time.perf_counter() - t0) / 5
+    t0 = time.perf_counter()
+    for pA, pB in seq[:4]:
+        oa = O.imu_preintegrate(pA["bias"], nga, walk, pA["acc"], pA["gyro"], pA["dt"])
+        rA = O.pose_inertial_optimization_last_keyframe(pA, oa)
+        of = O.imu_preintegrate(pB["bias"], nga, walk, pB["accF"], pB["gyroF"], pB["dtF"])
+        ok = O.imu_preintegrate(pB["bias"], nga, walk, pB["acc"], pB["gyro"], pB["dt"])
+        O.pose_inertial_optimization_last_frame(pB, rA[1], of, ok, rA[3])
+    dci = (time.perf_counter() - t0) / 4
+    inertial = {"frame_pairs": FI, "edges_per_frame": 600, "imu_samples_per_interval": 20,
+                "stages": ["PreintegrateIMU x3", "PoseInertialOptimizationLastKeyFrame", "PoseInertialOptimizationLastFrame"],
+                "ms_per_batch": dti * 1e3, "frame_pairs_per_s": FI / dti, "cpu_oracle_frame_pairs_per_s_1core": 1.0 / dci}
+    return {"pose_inertial_tracking": inertial,
+            "local_ba": {"edges": int(len(b["eKF"])), "keyframes_free_fixed": [20, 6], "points": 3000,
                          "outer_lm_iters": int(st[0]), "lm_trials": int(st[1]), "ms_per_solve": dt * 1e3,
                          "lm_iters_per_s": float(st[0] / dt), "cpu_oracle_lm_iters_per_s": float(its / dc)},
             "pose_optimization": {"frames": F, "edges_per_frame": 600, "frames_per_s": F / dtp,
