@@ -470,6 +470,24 @@ int morb_pose_inertial_optimization_last_frame_batch(morb_optimizer*, int nframe
                                                      const double* d_prevPrior, int bRecInit, float* d_state, uint8_t* d_outlier,
                                                      int* d_nInliers, double* d_prior, void* stream);
 
+/* static void Optimizer::LocalInertialBA(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int&, int&, int&, int&, bool bLarge,
+ * bool bRecInit)  Optimizer.h:71-74, Optimizer.cc:2324-2897, on the graph the reference assembles at :2337-2768, flattened
+ * (HOST pointers).  nKF keyframes with states of 21 floats (Rwb row-major, twb, velocity, gyro bias, acc bias);
+ * kfKind[k]: 0 = temporal optimizable keyframe (vpOptimizableKFs), 1 = the fixed keyframe before the window (its IMU
+ * state enters the last inertial link), 2 = fixed keyframe that only observes points (lFixedKeyFrames).  nMP points
+ * (mpClose[j] != 0 <=> mTrackDepth < 10), nE observations (eObs = x, y, uRight; uRight < 0 = EdgeMono, else EdgeStereo).
+ * nI inertial links: iKF1 = mPrevKF, iKF2 = the keyframe owning iPre[i] (mpImuPreintegrated); iRobust[i] != 0 and
+ * iInfoScale[i] = 1e-2 on the link to the fixed keyframe (and iRobust on all links when bRecInit) as at :2553-2563; each
+ * link also carries EdgeGyroRW / EdgeAccRW.  bLarge selects 4 iterations / lambda 1e-2 instead of 10 / 1.
+ * Outputs: kfState21 (optimizable keyframes) and mpPos in place, eraseFlag[e] = 1 where the reference erases the
+ * observation (:2773-2826), stats3 = {outer LM iterations, LM trials, ok} with ok = 0 for "FAIL LOCAL-INERTIAL BA"
+ * (nothing written back).  Pinhole camera 0 only. */
+int morb_local_inertial_ba(morb_optimizer*, int nKF, float* kfState21, const uint8_t* kfKind, int nMP, float* mpPos,
+                           const uint8_t* mpClose, int nE, const int* eKF, const int* eMP, const float* eObs, const float* eInvSigma2,
+                           int nI, const int* iKF1, const int* iKF2, const morb_imu_preintegrated* iPre, const uint8_t* iRobust,
+                           const float* iInfoScale, float fx, float fy, float cx, float cy, float bf, const float* Tbc12, int bLarge,
+                           uint8_t* eraseFlag, int* stats3);
+
 /* static void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF,
  * int& num_OptKF, int& num_MPs, int& num_edges)  Optimizer.h:67-69, Optimizer.cc:1053-1441, on the graph the
  * reference assembles at :1058-1351, flattened (HOST pointers): nKF keyframes (local ones first or in any

@@ -12,7 +12,11 @@
 // the state is needed: all threads apply the same update).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <limits>
+#include <vector>
 
 #include "common.h"
 #include "wave.h"
@@ -981,6 +985,457 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
   }
 }
 
+
+// =====================================================================================================================================
+// LocalInertialBA (reference src/Optimizer.cc:2324-2897): the temporal window of keyframes with 15-dof states, the points they see
+// behind a Schur complement, the chain of inertial / random-walk edges.  g2o Levenberg-Marquardt semantics
+// (optimization_algorithm_levenberg.cpp:61-194, block_solver.hpp) with the accept / reject decision on the host from one small
+// read-back per trial, like the grid mode of LocalBundleAdjustment.  One launch per phase over the whole chip:
+//   k_iba_errors   computeActiveErrors + activeRobustChi2 (one thread per visual edge / per inertial link)
+//   k_iba_points   per point: Hll, bl                      k_iba_kf   per 64-edge chunk of a keyframe: Hpp, bp (wave sums), Hpl
+//   k_iba_links    inertial + random-walk edges into the dense 15 N x 15 N system
+//   k_iba_schur    per point: (Hll + lambda I)^-1, Schur complement into the pose blocks and right-hand side
+//   k_iba_solve    one workgroup: dense LDL^T          k_iba_update   back-substitution of the points, oplus of all vertices
+// =====================================================================================================================================
+struct IbaDev {
+  int nKF, nMP, nE, nI, P, nChunks;
+  const int *eKF, *eMP;
+  const float *eObs, *eInfo;
+  const int *ptStart, *ptEdges;                 // CSR by point
+  const int *kfEdges, *chunkKF, *chunkStart, *chunkEnd;   // edges of free keyframes in chunks of <= 64
+  const int* col;                               // [nKF] index of an optimizable keyframe or -1
+  const int *iKF1, *iKF2;
+  const morb_imu_preintegrated* iPre;
+  const uint8_t* iRobust;
+  const uint8_t* mpClose;
+  double* S;                                    // [nKF][33]: Rwb twb v bg ba | Rcw tcw
+  double* pts;                                  // [nMP][3]
+  double *vErr, *iErr, *gErr, *aErr;            // errors of the last computeActiveErrors
+  double *InfoI, *InfoG, *InfoA;
+  double *H, *b, *Hll, *Hpl, *Hs, *bs, *x;      // b, x: P + 3 nMP
+  double* scal;                                 // [0] robust chi2, [1] scale, [2] solve ok
+  CamGeom g;
+};
+__device__ __forceinline__ void iba_load(const double* s, VIState& V) {
+  for (int k = 0; k < 9; ++k) { V.Rwb[k] = s[k]; V.Rcw[k] = s[21 + k]; }
+  for (int k = 0; k < 3; ++k) { V.twb[k] = s[9 + k]; V.v[k] = s[12 + k]; V.bg[k] = s[15 + k]; V.ba[k] = s[18 + k]; V.tcw[k] = s[30 + k]; }
+}
+__device__ __forceinline__ void iba_store(const VIState& V, double* s) {
+  for (int k = 0; k < 9; ++k) { s[k] = V.Rwb[k]; s[21 + k] = V.Rcw[k]; }
+  for (int k = 0; k < 3; ++k) { s[9 + k] = V.twb[k]; s[12 + k] = V.v[k]; s[15 + k] = V.bg[k]; s[18 + k] = V.ba[k]; s[30 + k] = V.tcw[k]; }
+}
+__device__ __forceinline__ double huber_rho(double delta, double e2) {   // rho(e2)
+  return e2 <= delta * delta ? e2 : 2 * sqrt(e2) * delta - delta * delta;
+}
+__device__ __forceinline__ double block_add(double v, double* target) {   // sum over the block -> one atomic
+  __shared__ double red[16];
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if (lane == 0) red[wv] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { double s = 0; for (int w = 0; w < nw; ++w) s += red[w]; unsafeAtomicAdd(target, s); }
+  __syncthreads();
+  return 0;
+}
+__device__ __forceinline__ double iba_vis_chi2(const IbaDev& D, int e) {
+  const double info = (double)D.eInfo[e];
+  const double* er = D.vErr + 3 * (size_t)e;
+  return er[0] * info * er[0] + er[1] * info * er[1] + er[2] * info * er[2];   // mono: er[2] = 0
+}
+__device__ __forceinline__ double iba_quad(const double* e, const double* Om, int n) {
+  double s = 0;
+  for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) s += e[r] * Om[r * n + c] * e[c];
+  return s;
+}
+
+__global__ void k_iba_setup_kf(IbaDev D, const float* __restrict__ kfState) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= D.nKF) return;
+  VIState V;
+  load_state(D.g, kfState + 21 * k, V);
+  iba_store(V, D.S + 33 * (size_t)k);
+}
+__global__ void k_iba_setup_links(IbaDev D, const float* __restrict__ infoScale, double* __restrict__ scratch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= D.nI) return;
+  const morb_imu_preintegrated& P = D.iPre[i];
+  double* sc = scratch + (size_t)i * 420;   // 81 (C9) + 162 (M) + 162 (V) + slack
+  double* C9 = sc; double* M = sc + 81; double* V = sc + 243;
+  double* Info = D.InfoI + (size_t)i * 81;
+  for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) C9[r * 9 + c] = (double)P.C[r * 15 + c];
+  if (invert_n(C9, 9, Info, M)) {
+    for (int r = 0; r < 9; ++r) for (int c = r + 1; c < 9; ++c) { const double s = (Info[r * 9 + c] + Info[c * 9 + r]) / 2; Info[r * 9 + c] = s; Info[c * 9 + r] = s; }
+    clamp_eigenvalues(Info, 9, 1e-12, M, V);
+  } else for (int k = 0; k < 81; ++k) Info[k] = 0;
+  for (int k = 0; k < 81; ++k) Info[k] *= (double)infoScale[i];
+  double Cg[9], Ca[9];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { Cg[r * 3 + c] = P.C[(9 + r) * 15 + 9 + c]; Ca[r * 3 + c] = P.C[(12 + r) * 15 + 12 + c]; }
+  if (!invert_n(Cg, 3, D.InfoG + (size_t)i * 9, M)) for (int k = 0; k < 9; ++k) D.InfoG[(size_t)i * 9 + k] = 0;
+  if (!invert_n(Ca, 3, D.InfoA + (size_t)i * 9, M)) for (int k = 0; k < 9; ++k) D.InfoA[(size_t)i * 9 + k] = 0;
+}
+
+// computeActiveErrors + activeRobustChi2 -> scal[0]
+__global__ __launch_bounds__(256) void k_iba_errors(IbaDev D) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815), deltaI = sqrt(16.92);
+  double c = 0;
+  if (t < D.nE) {
+    VIState V;
+    iba_load(D.S + 33 * (size_t)D.eKF[t], V);
+    const float* o = D.eObs + 3 * (size_t)t;
+    const bool st = !(o[2] < 0);
+    const double* Xp = D.pts + 3 * (size_t)D.eMP[t];
+    const double X[3] = {Xp[0], Xp[1], Xp[2]};
+    double err[3], Xc[3];
+    const double chi = vis_error(D.g, V, X, o, st, (double)D.eInfo[t], err, Xc);
+    for (int k = 0; k < 3; ++k) D.vErr[3 * (size_t)t + k] = err[k];
+    c = huber_rho(st ? deltaStereo : deltaMono, chi);
+  } else if (t - D.nE < D.nI) {
+    const int i = t - D.nE;
+    VIState V1, V2;
+    iba_load(D.S + 33 * (size_t)D.iKF1[i], V1);
+    iba_load(D.S + 33 * (size_t)D.iKF2[i], V2);
+    double err[9];
+    inertial_edge(D.iPre[i], V1, V2, nullptr, true, err, nullptr);
+    double ge[3], ae[3];
+    for (int k = 0; k < 9; ++k) D.iErr[9 * (size_t)i + k] = err[k];
+    for (int k = 0; k < 3; ++k) { ge[k] = V2.bg[k] - V1.bg[k]; ae[k] = V2.ba[k] - V1.ba[k]; D.gErr[3 * i + k] = ge[k]; D.aErr[3 * i + k] = ae[k]; }
+    const double ci = iba_quad(err, D.InfoI + (size_t)i * 81, 9);
+    c = (D.iRobust[i] ? huber_rho(deltaI, ci) : ci) + iba_quad(ge, D.InfoG + (size_t)i * 9, 3) + iba_quad(ae, D.InfoA + (size_t)i * 9, 3);
+  }
+  block_add(c, D.scal + 0);
+}
+
+// point side of buildSystem: Hll, bl (one thread per point over its edges, no atomics)
+__global__ __launch_bounds__(256) void k_iba_points(IbaDev D) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= D.nMP) return;
+  const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
+  double Hl[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
+  const double X[3] = {D.pts[3 * (size_t)l], D.pts[3 * (size_t)l + 1], D.pts[3 * (size_t)l + 2]};
+  for (int k = D.ptStart[l]; k < D.ptStart[l + 1]; ++k) {
+    const int e = D.ptEdges[k];
+    const double* s = D.S + 33 * (size_t)D.eKF[e];
+    const float* o = D.eObs + 3 * (size_t)e;
+    const bool st = !(o[2] < 0);
+    const double info = (double)D.eInfo[e];
+    const double w = huber_w(st ? deltaStereo : deltaMono, iba_vis_chi2(D, e));
+    double Xc[3];
+    for (int r = 0; r < 3; ++r) Xc[r] = s[21 + r * 3] * X[0] + s[22 + r * 3] * X[1] + s[23 + r * 3] * X[2] + s[30 + r];
+    // -proj_jac * Rcw (G2oTypes.cc:334-415)
+    double pj[9];
+    pj[0] = D.g.fx / Xc[2]; pj[1] = 0; pj[2] = -D.g.fx * Xc[0] / (Xc[2] * Xc[2]);
+    pj[3] = 0; pj[4] = D.g.fy / Xc[2]; pj[5] = -D.g.fy * Xc[1] / (Xc[2] * Xc[2]);
+    pj[6] = pj[7] = pj[8] = 0;
+    if (st) { pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + D.g.bf * (1.0 / (Xc[2] * Xc[2])); }
+    double Jl[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Jl[r * 3 + c] = -(pj[r * 3] * s[21 + c] + pj[r * 3 + 1] * s[24 + c] + pj[r * 3 + 2] * s[27 + c]);
+    const double* er = D.vErr + 3 * (size_t)e;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      double sm = 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) sm += Jl[i * 3 + r] * info * er[i];
+      bl[r] -= w * sm;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        double h = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) h += Jl[i * 3 + r] * (w * info) * Jl[i * 3 + c];
+        Hl[r * 3 + c] += h;
+      }
+    }
+  }
+  for (int k = 0; k < 9; ++k) D.Hll[(size_t)l * 9 + k] = Hl[k];
+  for (int k = 0; k < 3; ++k) D.b[D.P + 3 * (size_t)l + k] = bl[k];
+}
+// keyframe side: one wave per chunk of <= 64 edges of one optimizable keyframe
+__global__ __launch_bounds__(256) void k_iba_kf(IbaDev D) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= D.nChunks) return;
+  const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
+  const int kf = D.chunkKF[c];
+  VIState V;
+  iba_load(D.S + 33 * (size_t)kf, V);
+  double acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0;
+  const int k = D.chunkStart[c] + lane;
+  if (k < D.chunkEnd[c]) {
+    const int e = D.kfEdges[k];
+    const float* o = D.eObs + 3 * (size_t)e;
+    const bool st = !(o[2] < 0);
+    const double info = (double)D.eInfo[e];
+    const double w = huber_w(st ? deltaStereo : deltaMono, iba_vis_chi2(D, e));
+    const double* Xp = D.pts + 3 * (size_t)D.eMP[e];
+    const double X[3] = {Xp[0], Xp[1], Xp[2]};
+    double Xc[3], Jp[18], Jl[9];
+    mul3v(V.Rcw, X, Xc);
+    for (int r = 0; r < 3; ++r) Xc[r] += V.tcw[r];
+    vis_jacobian(D.g, Xc, st, Jp);
+    double pj[9];
+    pj[0] = D.g.fx / Xc[2]; pj[1] = 0; pj[2] = -D.g.fx * Xc[0] / (Xc[2] * Xc[2]);
+    pj[3] = 0; pj[4] = D.g.fy / Xc[2]; pj[5] = -D.g.fy * Xc[1] / (Xc[2] * Xc[2]);
+    pj[6] = pj[7] = pj[8] = 0;
+    if (st) { pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + D.g.bf * (1.0 / (Xc[2] * Xc[2])); }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) Jl[r * 3 + cc] = -(pj[r * 3] * V.Rcw[cc] + pj[r * 3 + 1] * V.Rcw[3 + cc] + pj[r * 3 + 2] * V.Rcw[6 + cc]);
+    const double* er = D.vErr + 3 * (size_t)e;
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      double sm = 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) sm += Jp[i * 6 + r] * info * er[i];
+      acc[21 + r] = -w * sm;
+#pragma unroll
+      for (int cc = r; cc < 6; ++cc) {
+        double h = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) h += Jp[i * 6 + r] * (w * info) * Jp[i * 6 + cc];
+        acc[q++] = h;
+      }
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        double h = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) h += Jp[i * 6 + r] * (w * info) * Jl[i * 3 + cc];
+        D.Hpl[(size_t)e * 18 + r * 3 + cc] = h;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 27; ++q) acc[q] = wave_sum(acc[q]);
+  if (lane == 0) {
+    const int o = 15 * D.col[kf];
+    int q = 0;
+    for (int r = 0; r < 6; ++r)
+      for (int cc = r; cc < 6; ++cc) {
+        unsafeAtomicAdd(&D.H[(size_t)(o + r) * D.P + o + cc], acc[q]);
+        if (cc != r) unsafeAtomicAdd(&D.H[(size_t)(o + cc) * D.P + o + r], acc[q]);
+        ++q;
+      }
+    for (int r = 0; r < 6; ++r) unsafeAtomicAdd(&D.b[o + r], acc[21 + r]);
+  }
+}
+// inertial + random-walk edges: one thread per link, Jacobian scratch in global memory
+__global__ void k_iba_links(IbaDev D, double* __restrict__ scratch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= D.nI) return;
+  const int k1 = D.iKF1[i], k2 = D.iKF2[i];
+  VIState V1, V2;
+  iba_load(D.S + 33 * (size_t)k1, V1);
+  iba_load(D.S + 33 * (size_t)k2, V2);
+  double* J = scratch + (size_t)i * 420;   // 216
+  double* JtO = J + 216;                   // 9
+  for (int k = 0; k < 216; ++k) J[k] = 0;
+  double errNow[9];
+  inertial_edge(D.iPre[i], V1, V2, nullptr, true, errNow, J);
+  const double* er = D.iErr + 9 * (size_t)i;   // = errNow (buildSystem follows computeActiveErrors at the same state)
+  const double* Om = D.InfoI + (size_t)i * 81;
+  double w = 1.0;
+  if (D.iRobust[i]) w = huber_w(sqrt(16.92), iba_quad(er, Om, 9));
+  const int c1 = D.col[k1], c2 = D.col[k2];
+  for (int a = 0; a < 24; ++a) {
+    const int ca = a < 15 ? (c1 >= 0 ? 15 * c1 + a : -1) : (c2 >= 0 ? 15 * c2 + (a - 15) : -1);
+    if (ca < 0) continue;
+    for (int c = 0; c < 9; ++c) { double s = 0; for (int k = 0; k < 9; ++k) s += J[k * 24 + a] * Om[k * 9 + c]; JtO[c] = s; }
+    double s = 0;
+    for (int k = 0; k < 9; ++k) s += JtO[k] * er[k];
+    unsafeAtomicAdd(&D.b[ca], -w * s);
+    for (int b2 = 0; b2 < 24; ++b2) {
+      const int cb = b2 < 15 ? (c1 >= 0 ? 15 * c1 + b2 : -1) : (c2 >= 0 ? 15 * c2 + (b2 - 15) : -1);
+      if (cb < 0) continue;
+      double h = 0;
+      for (int k = 0; k < 9; ++k) h += JtO[k] * J[k * 24 + b2];
+      unsafeAtomicAdd(&D.H[(size_t)ca * D.P + cb], w * h);
+    }
+  }
+  for (int t = 0; t < 2; ++t) {   // EdgeGyroRW / EdgeAccRW: e = bias2 - bias1
+    const double* I3 = (t == 0 ? D.InfoG : D.InfoA) + (size_t)i * 9;
+    const double* e3 = (t == 0 ? D.gErr : D.aErr) + 3 * (size_t)i;
+    const int o1 = c1 >= 0 ? 15 * c1 + 9 + 3 * t : -1, o2 = c2 >= 0 ? 15 * c2 + 9 + 3 * t : -1;
+    for (int r = 0; r < 3; ++r) {
+      double s = 0;
+      for (int k = 0; k < 3; ++k) s += I3[r * 3 + k] * e3[k];
+      if (o2 >= 0) unsafeAtomicAdd(&D.b[o2 + r], -s);
+      if (o1 >= 0) unsafeAtomicAdd(&D.b[o1 + r], s);
+      for (int c = 0; c < 3; ++c) {
+        const double v = I3[r * 3 + c];
+        if (o2 >= 0) unsafeAtomicAdd(&D.H[(size_t)(o2 + r) * D.P + o2 + c], v);
+        if (o1 >= 0) unsafeAtomicAdd(&D.H[(size_t)(o1 + r) * D.P + o1 + c], v);
+        if (o1 >= 0 && o2 >= 0) { unsafeAtomicAdd(&D.H[(size_t)(o1 + r) * D.P + o2 + c], -v); unsafeAtomicAdd(&D.H[(size_t)(o2 + r) * D.P + o1 + c], -v); }
+      }
+    }
+  }
+}
+__device__ __forceinline__ bool inv3(const double* D3, double* I) {
+  const double a = D3[0], b = D3[1], c = D3[2], d = D3[3], e = D3[4], f = D3[5], g = D3[6], h = D3[7], i = D3[8];
+  const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  const double det = a * A + b * B + c * C;
+  if (det == 0.0) { for (int k = 0; k < 9; ++k) I[k] = 0; return false; }
+  const double inv = 1.0 / det;
+  I[0] = A * inv; I[1] = -(b * i - c * h) * inv; I[2] = (b * f - c * e) * inv;
+  I[3] = B * inv; I[4] = (a * i - c * g) * inv; I[5] = -(a * f - c * d) * inv;
+  I[6] = C * inv; I[7] = -(a * h - b * g) * inv; I[8] = (a * e - b * d) * inv;
+  return true;
+}
+// Hs = H + lambda I, bs = b[0:P]
+__global__ __launch_bounds__(256) void k_iba_hs_init(IbaDev D, double lambda) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int n = D.P * D.P;
+  if (t < n) { const int r = t / D.P, c = t - r * D.P; D.Hs[t] = D.H[t] + (r == c ? lambda : 0.0); }
+  else if (t - n < D.P) D.bs[t - n] = D.b[t - n];
+}
+// Schur complement of the points (block_solver.hpp): one thread per point
+__global__ __launch_bounds__(256) void k_iba_schur(IbaDev D, double lambda) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= D.nMP) return;
+  double Dm[9], Di[9];
+  for (int k = 0; k < 9; ++k) Dm[k] = D.Hll[(size_t)l * 9 + k];
+  Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
+  inv3(Dm, Di);
+  const double* bl = D.b + D.P + 3 * (size_t)l;
+  double db[3];
+  for (int r = 0; r < 3; ++r) db[r] = Di[r * 3] * bl[0] + Di[r * 3 + 1] * bl[1] + Di[r * 3 + 2] * bl[2];
+  const int s0 = D.ptStart[l], s1 = D.ptStart[l + 1];
+  for (int k1 = s0; k1 < s1; ++k1) {
+    const int e1 = D.ptEdges[k1];
+    const int c1 = D.col[D.eKF[e1]];
+    if (c1 < 0) continue;
+    const double* B1 = D.Hpl + (size_t)e1 * 18;
+    double BD[18];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) BD[r * 3 + c] = B1[r * 3] * Di[c] + B1[r * 3 + 1] * Di[3 + c] + B1[r * 3 + 2] * Di[6 + c];
+    for (int r = 0; r < 6; ++r) unsafeAtomicAdd(&D.bs[15 * c1 + r], -(B1[r * 3] * db[0] + B1[r * 3 + 1] * db[1] + B1[r * 3 + 2] * db[2]));
+    for (int k2 = s0; k2 < s1; ++k2) {
+      const int e2 = D.ptEdges[k2];
+      const int c2 = D.col[D.eKF[e2]];
+      if (c2 < 0) continue;
+      const double* B2 = D.Hpl + (size_t)e2 * 18;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+          unsafeAtomicAdd(&D.Hs[(size_t)(15 * c1 + r) * D.P + 15 * c2 + c], -(BD[r * 3] * B2[c * 3] + BD[r * 3 + 1] * B2[c * 3 + 1] + BD[r * 3 + 2] * B2[c * 3 + 2]));
+    }
+  }
+}
+// dense LDL^T of Hs (lower triangle) + solve -> x[0:P], scal[2] = positive.  ONE workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void k_iba_solve(IbaDev D) {
+  const int n = D.P, tid = threadIdx.x;
+  double* A = D.Hs;
+  __shared__ int sOk;
+  if (tid == 0) sOk = 1;
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {
+    const double d = A[(size_t)j * n + j];
+    if (!(d > 0)) { if (tid == 0) sOk = 0; break; }   // uniform: every thread reads the same d
+    const int m = n - 1 - j;
+    // trailing update: (r, c), j < c <= r, uses the un-scaled column j
+    for (int p = tid; p < m * m; p += 1024) {
+      const int rr = p / m, cc = p - rr * m;
+      if (cc > rr) continue;
+      const int r = j + 1 + rr, c = j + 1 + cc;
+      A[(size_t)r * n + c] -= A[(size_t)r * n + j] * A[(size_t)c * n + j] / d;
+    }
+    __syncthreads();
+    for (int r = j + 1 + tid; r < n; r += 1024) A[(size_t)r * n + j] /= d;
+    __syncthreads();
+  }
+  __syncthreads();
+  if (!sOk) { if (tid == 0) D.scal[2] = 0.0; return; }
+  double* y = D.x;
+  for (int r = tid; r < n; r += 1024) y[r] = D.bs[r];
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {
+    const double yj = y[j];
+    __syncthreads();
+    for (int r = j + 1 + tid; r < n; r += 1024) y[r] -= A[(size_t)r * n + j] * yj;
+    __syncthreads();
+  }
+  for (int r = tid; r < n; r += 1024) y[r] /= A[(size_t)r * n + r];
+  __syncthreads();
+  for (int j = n - 1; j >= 0; --j) {
+    const double xj = y[j];
+    __syncthreads();
+    for (int r = tid; r < j; r += 1024) y[r] -= A[(size_t)j * n + r] * xj;
+    __syncthreads();
+  }
+  if (tid == 0) D.scal[2] = 1.0;
+}
+// back-substitution of the points + oplus of every vertex + the LM scale  sum x (lambda x + b) -> scal[1]
+__global__ __launch_bounds__(256) void k_iba_update(IbaDev D, double lambda) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  double sc = 0;
+  if (t < D.nMP) {
+    const int l = t;
+    double Dm[9], Di[9];
+    for (int k = 0; k < 9; ++k) Dm[k] = D.Hll[(size_t)l * 9 + k];
+    Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
+    inv3(Dm, Di);
+    const double* bl = D.b + D.P + 3 * (size_t)l;
+    double cl[3] = {bl[0], bl[1], bl[2]};
+    for (int k = D.ptStart[l]; k < D.ptStart[l + 1]; ++k) {
+      const int e = D.ptEdges[k];
+      const int c1 = D.col[D.eKF[e]];
+      if (c1 < 0) continue;
+      const double* B = D.Hpl + (size_t)e * 18;
+      const double* xp = D.x + 15 * c1;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) cl[c] -= B[r * 3 + c] * xp[r];
+    }
+    for (int r = 0; r < 3; ++r) {
+      const double xl = Di[r * 3] * cl[0] + Di[r * 3 + 1] * cl[1] + Di[r * 3 + 2] * cl[2];
+      D.x[D.P + 3 * (size_t)l + r] = xl;
+      D.pts[3 * (size_t)l + r] += xl;
+      sc += xl * (lambda * xl + bl[r]);
+    }
+  } else if (t - D.nMP < D.nKF) {
+    const int k = t - D.nMP;
+    const int c = D.col[k];
+    if (c >= 0) {
+      VIState V;
+      iba_load(D.S + 33 * (size_t)k, V);
+      double dx[15];
+      for (int q = 0; q < 15; ++q) { dx[q] = D.x[15 * c + q]; sc += dx[q] * (lambda * dx[q] + D.b[15 * c + q]); }
+      apply_update(D.g, V, dx);
+      iba_store(V, D.S + 33 * (size_t)k);
+    }
+  }
+  block_add(sc, D.scal + 1);
+}
+// erase flags (:2773-2801) from the errors of the last computeActiveErrors, and the float outputs
+__global__ __launch_bounds__(256) void k_iba_finish(IbaDev D, uint8_t* __restrict__ erase, float* __restrict__ kfOut, float* __restrict__ mpOut) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < D.nE) {
+    const float* o = D.eObs + 3 * (size_t)t;
+    const bool st = !(o[2] < 0);
+    const double c = iba_vis_chi2(D, t);
+    bool er;
+    if (st) er = c > (double)7.815f;
+    else {
+      const bool bClose = D.mpClose[D.eMP[t]] != 0;
+      const double* s = D.S + 33 * (size_t)D.eKF[t];
+      const double* X = D.pts + 3 * (size_t)D.eMP[t];
+      const bool depthPos = (s[27] * X[0] + s[28] * X[1] + s[29] * X[2] + s[32]) > 0.0;
+      er = (c > (double)5.991f && !bClose) || (c > (double)(1.5f * 5.991f) && bClose) || !depthPos;
+    }
+    erase[t] = er ? 1 : 0;
+  }
+  if (t < D.nKF && D.col[t] >= 0) for (int k = 0; k < 21; ++k) kfOut[21 * (size_t)t + k] = (float)D.S[33 * (size_t)t + k];
+  if (t < 3 * D.nMP) mpOut[t] = (float)D.pts[t];
+}
+
 }  // namespace
 
 extern "C" {
@@ -1048,6 +1503,177 @@ int morb_pose_inertial_optimization_last_frame_batch(morb_optimizer* o, int nfra
                                                      int* d_nInliers, double* d_prior, void* stream) {
   return launch_pose_inertial(true, o, nframes, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, d_close, fx, fy, cx, cy, bf, Tbc12,
                               d_prevState, d_preFrame, d_preKF, d_prevPrior, bRecInit, d_state, d_outlier, d_nInliers, d_prior, stream);
+}
+
+// static void Optimizer::LocalInertialBA(KeyFrame*, bool* pbStopFlag, Map*, int&, int&, int&, int&, bool bLarge, bool bRecInit)
+// on the flattened graph (see include/morb_hip.h).  HOST pointers.
+int morb_local_inertial_ba(morb_optimizer* o, int nKF, float* kfState21, const uint8_t* kfKind, int nMP, float* mpPos,
+                           const uint8_t* mpClose, int nE, const int* eKF, const int* eMP, const float* eObs, const float* eInvSigma2,
+                           int nI, const int* iKF1, const int* iKF2, const morb_imu_preintegrated* iPre, const uint8_t* iRobust,
+                           const float* iInfoScale, float fx, float fy, float cx, float cy, float bf, const float* Tbc12, int bLarge,
+                           uint8_t* eraseFlag, int* stats3) {
+  MORB_REQUIRE(o && kfState21 && kfKind && mpPos && mpClose && eKF && eMP && eObs && eInvSigma2 && iKF1 && iKF2 && iPre && iRobust &&
+                   iInfoScale && Tbc12 && eraseFlag, MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(nKF > 0 && nMP > 0 && nE > 0 && nI >= 0, MORB_ERR_INVALID, "bad sizes");
+  MORB_HIP_CHECK(hipSetDevice(morb_optimizer_device(o)));
+  hipStream_t st = (hipStream_t)morb_optimizer_stream(o);
+  // ---- host-side graph layout
+  std::vector<int> col(nKF, -1);
+  int nOpt = 0;
+  for (int k = 0; k < nKF; ++k) if (kfKind[k] == 0) col[k] = nOpt++;
+  MORB_REQUIRE(nOpt > 0, MORB_ERR_INVALID, "no optimizable keyframe");
+  const int P = 15 * nOpt;
+  for (int e = 0; e < nE; ++e) MORB_REQUIRE(eKF[e] >= 0 && eKF[e] < nKF && eMP[e] >= 0 && eMP[e] < nMP, MORB_ERR_INVALID, "edge index out of range");
+  for (int i = 0; i < nI; ++i) MORB_REQUIRE(iKF1[i] >= 0 && iKF1[i] < nKF && iKF2[i] >= 0 && iKF2[i] < nKF, MORB_ERR_INVALID, "link index out of range");
+  std::vector<int> ptStart(nMP + 1, 0), ptEdges(nE);
+  for (int e = 0; e < nE; ++e) ++ptStart[eMP[e] + 1];
+  for (int l = 0; l < nMP; ++l) ptStart[l + 1] += ptStart[l];
+  { std::vector<int> fill(ptStart.begin(), ptStart.end() - 1); for (int e = 0; e < nE; ++e) ptEdges[fill[eMP[e]]++] = e; }
+  std::vector<std::vector<int>> byKF(nKF);
+  for (int e = 0; e < nE; ++e) if (col[eKF[e]] >= 0) byKF[eKF[e]].push_back(e);
+  std::vector<int> kfEdges, chunkKF, chunkStart, chunkEnd;
+  for (int k = 0; k < nKF; ++k)
+    for (size_t s0 = 0; s0 < byKF[k].size(); s0 += 64) {
+      chunkKF.push_back(k); chunkStart.push_back((int)kfEdges.size() + 0);
+      const size_t s1 = std::min(byKF[k].size(), s0 + 64);
+      for (size_t q = s0; q < s1; ++q) kfEdges.push_back(byKF[k][q]);
+      chunkEnd.push_back((int)kfEdges.size());
+    }
+  const int nChunks = (int)chunkKF.size();
+
+  // ---- device memory (one allocation)
+  std::vector<void*> allocs;
+  auto dalloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr; allocs.push_back(p); return p; };
+  auto cleanup = [&]() { for (void* p : allocs) (void)hipFree(p); };
+  auto up = [&](const void* h, size_t bytes) -> void* { void* d = dalloc(bytes); if (d && bytes) (void)hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st); return d; };
+  IbaDev D;
+  memset(&D, 0, sizeof D);
+  D.nKF = nKF; D.nMP = nMP; D.nE = nE; D.nI = nI; D.P = P; D.nChunks = nChunks;
+  D.eKF = (const int*)up(eKF, sizeof(int) * nE); D.eMP = (const int*)up(eMP, sizeof(int) * nE);
+  D.eObs = (const float*)up(eObs, sizeof(float) * 3 * nE); D.eInfo = (const float*)up(eInvSigma2, sizeof(float) * nE);
+  D.ptStart = (const int*)up(ptStart.data(), sizeof(int) * (nMP + 1)); D.ptEdges = (const int*)up(ptEdges.data(), sizeof(int) * nE);
+  D.kfEdges = (const int*)up(kfEdges.data(), sizeof(int) * kfEdges.size());
+  D.chunkKF = (const int*)up(chunkKF.data(), sizeof(int) * nChunks); D.chunkStart = (const int*)up(chunkStart.data(), sizeof(int) * nChunks);
+  D.chunkEnd = (const int*)up(chunkEnd.data(), sizeof(int) * nChunks);
+  D.col = (const int*)up(col.data(), sizeof(int) * nKF);
+  D.iKF1 = (const int*)up(iKF1, sizeof(int) * nI); D.iKF2 = (const int*)up(iKF2, sizeof(int) * nI);
+  D.iPre = (const morb_imu_preintegrated*)up(iPre, sizeof(morb_imu_preintegrated) * nI);
+  D.iRobust = (const uint8_t*)up(iRobust, nI); D.mpClose = (const uint8_t*)up(mpClose, nMP);
+  float* d_scale = (float*)up(iInfoScale, sizeof(float) * nI);
+  float* d_kfIn = (float*)up(kfState21, sizeof(float) * 21 * nKF);
+  float* d_mpIn = (float*)up(mpPos, sizeof(float) * 3 * nMP);
+  const size_t nS = (size_t)33 * nKF, nPts = (size_t)3 * nMP, nX = (size_t)P + 3 * nMP;
+  D.S = (double*)dalloc(sizeof(double) * nS); double* Sbk = (double*)dalloc(sizeof(double) * nS);
+  D.pts = (double*)dalloc(sizeof(double) * nPts); double* ptsBk = (double*)dalloc(sizeof(double) * nPts);
+  D.vErr = (double*)dalloc(sizeof(double) * 3 * nE); D.iErr = (double*)dalloc(sizeof(double) * 9 * std::max(nI, 1));
+  D.gErr = (double*)dalloc(sizeof(double) * 3 * std::max(nI, 1)); D.aErr = (double*)dalloc(sizeof(double) * 3 * std::max(nI, 1));
+  D.InfoI = (double*)dalloc(sizeof(double) * 81 * std::max(nI, 1)); D.InfoG = (double*)dalloc(sizeof(double) * 9 * std::max(nI, 1));
+  D.InfoA = (double*)dalloc(sizeof(double) * 9 * std::max(nI, 1));
+  D.H = (double*)dalloc(sizeof(double) * (size_t)P * P); D.Hs = (double*)dalloc(sizeof(double) * (size_t)P * P);
+  D.b = (double*)dalloc(sizeof(double) * nX); D.bs = (double*)dalloc(sizeof(double) * P); D.x = (double*)dalloc(sizeof(double) * nX);
+  D.Hll = (double*)dalloc(sizeof(double) * 9 * nMP); D.Hpl = (double*)dalloc(sizeof(double) * 18 * nE);
+  D.scal = (double*)dalloc(sizeof(double) * 4);
+  double* scratch = (double*)dalloc(sizeof(double) * 420 * std::max(nI, 1));
+  uint8_t* d_erase = (uint8_t*)dalloc(nE);
+  for (void* p : allocs) if (!p) { cleanup(); set_error("hipMalloc failed in morb_local_inertial_ba"); return MORB_ERR_HIP; }
+  (void)hipMemsetAsync(D.x, 0, sizeof(double) * nX, st);   // the solver's x before the first solve
+  for (int k = 0; k < 9; ++k) D.g.Rbc[k] = Tbc12[k];
+  for (int k = 0; k < 3; ++k) D.g.tbc[k] = Tbc12[9 + k];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) D.g.Rcb[r * 3 + c] = D.g.Rbc[c * 3 + r];
+  for (int r = 0; r < 3; ++r) D.g.tcb[r] = -(D.g.Rcb[r * 3] * D.g.tbc[0] + D.g.Rcb[r * 3 + 1] * D.g.tbc[1] + D.g.Rcb[r * 3 + 2] * D.g.tbc[2]);
+  D.g.bf = bf; D.g.fx = fx; D.g.fy = fy; D.g.cx = cx; D.g.cy = cy;
+
+  auto fail = [&](const char* what) { cleanup(); set_error("%s", what); return MORB_ERR_HIP; };
+  double h[4];
+  auto errors = [&](double* chi) -> bool {   // computeActiveErrors + activeRobustChi2
+    if (hipMemsetAsync(D.scal, 0, sizeof(double) * 4, st) != hipSuccess) return false;
+    hipLaunchKernelGGL(k_iba_errors, dim3(div_up(nE + nI, 256)), dim3(256), 0, st, D);
+    if (hipMemcpyAsync(h, D.scal, sizeof(double) * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+    if (hipStreamSynchronize(st) != hipSuccess) return false;
+    *chi = h[0];
+    return true;
+  };
+  hipLaunchKernelGGL(k_iba_setup_kf, dim3(div_up(nKF, 64)), dim3(64), 0, st, D, d_kfIn);
+  if (nI) hipLaunchKernelGGL(k_iba_setup_links, dim3(div_up(nI, 64)), dim3(64), 0, st, D, d_scale, scratch);
+  {  // points to FP64
+    std::vector<double> pd(nPts);
+    for (size_t k = 0; k < nPts; ++k) pd[k] = (double)mpPos[k];
+    if (hipMemcpyAsync(D.pts, pd.data(), sizeof(double) * nPts, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      return fail("upload failed in morb_local_inertial_ba");
+  }
+  double chi = 0;
+  if (!errors(&chi)) return fail("k_iba_errors failed");
+  const float err0 = (float)chi;
+  double lambda = bLarge ? 1e-2 : 1e0, ni = 2;
+  int nBadIts = 0, trials = 0, outer = 0;
+  const int optIt = bLarge ? 4 : 10;
+  double currentChi = chi;   // errors of the current state are valid here
+  for (int it = 0; it < optIt; ++it) {
+    ++outer;
+    if (it > 0 && !errors(&currentChi)) return fail("k_iba_errors failed");   // computeActiveErrors at the top of solve()
+    const double iniChi = currentChi;
+    // buildSystem
+    (void)hipMemsetAsync(D.H, 0, sizeof(double) * (size_t)P * P, st);
+    (void)hipMemsetAsync(D.b, 0, sizeof(double) * P, st);
+    (void)hipMemsetAsync(D.Hpl, 0, sizeof(double) * 18 * nE, st);
+    hipLaunchKernelGGL(k_iba_points, dim3(div_up(nMP, 256)), dim3(256), 0, st, D);
+    if (nChunks) hipLaunchKernelGGL(k_iba_kf, dim3(div_up(nChunks, 4)), dim3(256), 0, st, D);
+    if (nI) hipLaunchKernelGGL(k_iba_links, dim3(div_up(nI, 64)), dim3(64), 0, st, D, scratch);
+    if (it == 0) { ni = 2; nBadIts = 0; }
+    double rho = 0;
+    int qmax = 0;
+    do {
+      (void)hipMemcpyAsync(Sbk, D.S, sizeof(double) * nS, hipMemcpyDeviceToDevice, st);
+      (void)hipMemcpyAsync(ptsBk, D.pts, sizeof(double) * nPts, hipMemcpyDeviceToDevice, st);
+      hipLaunchKernelGGL(k_iba_hs_init, dim3(div_up(P * P + P, 256)), dim3(256), 0, st, D, lambda);
+      hipLaunchKernelGGL(k_iba_schur, dim3(div_up(nMP, 256)), dim3(256), 0, st, D, lambda);
+      hipLaunchKernelGGL(k_iba_solve, dim3(1), dim3(1024), 0, st, D);
+      // a failed solve leaves x as it was (zero at the first trial): g2o still applies the update
+      (void)hipMemsetAsync(D.scal, 0, sizeof(double) * 2, st);
+      hipLaunchKernelGGL(k_iba_update, dim3(div_up(nMP + nKF, 256)), dim3(256), 0, st, D, lambda);
+      (void)hipMemcpyAsync(h + 1, D.scal + 1, sizeof(double) * 2, hipMemcpyDeviceToHost, st);
+      hipLaunchKernelGGL(k_iba_errors, dim3(div_up(nE + nI, 256)), dim3(256), 0, st, D);
+      (void)hipMemcpyAsync(h, D.scal, sizeof(double), hipMemcpyDeviceToHost, st);
+      if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail("LocalInertialBA trial failed");
+      double tempChi = h[0];
+      const bool ok2 = h[2] != 0.0;
+      if (!ok2) tempChi = std::numeric_limits<double>::max();
+      rho = currentChi - tempChi;
+      const double scale = h[1] + 1e-3;
+      rho /= scale;
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow((2 * rho - 1), 3);
+        alpha = std::min(alpha, 2. / 3.);
+        lambda *= std::max(1. / 3., alpha);
+        ni = 2;
+        currentChi = tempChi;
+      } else {
+        lambda *= ni;
+        ni *= 2;
+        (void)hipMemcpyAsync(D.S, Sbk, sizeof(double) * nS, hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(D.pts, ptsBk, sizeof(double) * nPts, hipMemcpyDeviceToDevice, st);
+      }
+      ++qmax; ++trials;
+    } while (rho < 0 && qmax < 10);
+    if (qmax == 10 || rho == 0) break;
+    if ((iniChi - currentChi) * 1e3 < iniChi) nBadIts++; else nBadIts = 0;
+    if (nBadIts >= 3) break;
+  }
+  // activeRobustChi2 of the last computed errors = h[0] of the last trial (or the initial one)
+  const float errEnd = (float)(trials ? h[0] : chi);
+  int okFlag = 1;
+  if ((2 * err0 < errEnd || std::isnan(err0) || std::isnan(errEnd)) && !bLarge) okFlag = 0;   // "FAIL LOCAL-INERTIAL BA" (:2808-2813)
+  memset(eraseFlag, 0, nE);
+  if (okFlag) {
+    hipLaunchKernelGGL(k_iba_finish, dim3(div_up(std::max(nE, std::max(nKF, 3 * nMP)), 256)), dim3(256), 0, st, D, d_erase, d_kfIn, d_mpIn);
+    (void)hipMemcpyAsync(eraseFlag, d_erase, nE, hipMemcpyDeviceToHost, st);
+    (void)hipMemcpyAsync(kfState21, d_kfIn, sizeof(float) * 21 * nKF, hipMemcpyDeviceToHost, st);
+    (void)hipMemcpyAsync(mpPos, d_mpIn, sizeof(float) * 3 * nMP, hipMemcpyDeviceToHost, st);
+    if (hipStreamSynchronize(st) != hipSuccess) return fail("LocalInertialBA read-back failed");
+  }
+  if (stats3) { stats3[0] = outer; stats3[1] = trials; stats3[2] = okFlag; }
+  cleanup();
+  return MORB_OK;
 }
 
 #ifdef MORB_INERTIAL_TIMING

@@ -118,6 +118,25 @@ class Optimizer:
             ptr(out[1]), ptr(out[0]), ptr(out[2]), st))
         return out
 
+    def LocalInertialBA(self, kfState, kfKind, mpPos, mpClose, eKF, eMP, eObs, eInvSigma2, iKF1, iKF2, iPre, iRobust, iInfoScale, cam, Tbc,
+                        bLarge=False):
+        """Optimizer::LocalInertialBA on host numpy arrays (see morb_local_inertial_ba).  iPre: float32 [nI, PREINT_FLOATS].
+        Returns (kfState, mpPos, eraseFlag, stats) with stats = (outer LM iterations, LM trials, ok)."""
+        a = [np.ascontiguousarray(kfState, np.float32).copy(), np.ascontiguousarray(kfKind, np.uint8),
+             np.ascontiguousarray(mpPos, np.float32).copy(), np.ascontiguousarray(mpClose, np.uint8),
+             np.ascontiguousarray(eKF, np.int32), np.ascontiguousarray(eMP, np.int32), np.ascontiguousarray(eObs, np.float32),
+             np.ascontiguousarray(eInvSigma2, np.float32), np.ascontiguousarray(iKF1, np.int32), np.ascontiguousarray(iKF2, np.int32),
+             np.ascontiguousarray(iPre, np.float32), np.ascontiguousarray(iRobust, np.uint8), np.ascontiguousarray(iInfoScale, np.float32),
+             np.ascontiguousarray(Tbc, np.float32)]
+        nI = len(a[8])
+        assert a[10].shape == (nI, PREINT_FLOATS) and a[0].shape[1] == 21 and a[6].shape[1] == 3
+        erase = np.zeros(len(a[4]), np.uint8); stats = np.zeros(3, np.int32)
+        check(self._L.morb_local_inertial_ba(self._h, len(a[0]), ptr(a[0]), ptr(a[1]), len(a[2]), ptr(a[2]), ptr(a[3]), len(a[4]), ptr(a[4]),
+                                             ptr(a[5]), ptr(a[6]), ptr(a[7]), nI, ptr(a[8]), ptr(a[9]), ptr(a[10]), ptr(a[11]), ptr(a[12]),
+                                             cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["bf"], ptr(a[13]), int(bool(bLarge)),
+                                             ptr(erase), ptr(stats)))
+        return a[0], a[2], erase, stats
+
     def LocalBundleAdjustment(self, kfPose, kfFixed, mpPos, eKF, eMP, eObs, eInvSigma2, cam, inertial=False, stop=False, mode=0,
                               rig=None):
         """One-shot LocalBundleAdjustment on host numpy arrays; returns (kfPose, mpPos, eraseFlag, stats)."""

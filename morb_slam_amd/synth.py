@@ -411,3 +411,79 @@ def make_inertial_problem(n=500, seed=0, n_imu=20, outlier_frac=0.1, mono_frac=0
                 bias=np.concatenate([ba, bg]).astype(np.float32),      # IMU::Bias order: acc then gyro
                 Tbc12=np.concatenate([Tbc[:3, :3].ravel(), Tbc[:3, 3]]).astype(np.float32), cam=cam,
                 true=np.concatenate([R2.ravel(), p2, v2, bg, ba]), outlier_truth=out)
+
+
+def make_inertial_ba_problem(n_opt=10, n_fixed_vis=6, n_points=1500, n_imu=40, seed=0, outlier_frac=0.03, mono_frac=0.25,
+                             cam=EUROC_CAM):
+    """LocalInertialBA input: a temporal chain keyframe 0 (fixed, with IMU state) -> n_opt optimizable keyframes, plus
+    n_fixed_vis fixed keyframes that only observe points.  Each link carries n_imu IMU samples of a smooth motion
+    (per-link constant body rate and world acceleration).  States: Rwb (9), twb, v, bg, ba; kfKind 0 / 1 / 2 as in
+    morb_local_inertial_ba."""
+    rng = np.random.default_rng(0x1BA0 + seed)
+    g = np.array([0, 0, -9.81])
+    dt = 1.0 / IMU_FREQ
+    bg = rng.normal(0, 0.01, 3); ba = rng.normal(0, 0.05, 3)
+    Tbc = EUROC_TBC
+    Rcb = Tbc[:3, :3].T; tcb = -Rcb @ Tbc[:3, 3]
+    # the camera looks along +z of the camera frame: start with the body oriented so that the camera faces world +x
+    R = _rot_from_rotvec(rng.normal(0, 0.1, 3)); p = rng.normal(0, 0.2, 3); v = np.array([0.6, 0.1, 0.0]) + rng.normal(0, 0.1, 3)
+    states = [(R, p, v)]
+    acc, gyro, dts, start = [], [], [], [0]
+    for k in range(n_opt):
+        w_b = rng.normal(0, 0.15, 3); a_w = rng.normal(0, 0.5, 3)
+        for i in range(n_imu):
+            tm = (i + 0.5) * dt
+            Rm = R @ _rot_from_rotvec(w_b * tm)
+            acc.append(Rm.T @ (a_w - g) + ba + rng.normal(0, 0.02, 3))
+            gyro.append(w_b + bg + rng.normal(0, 0.002, 3))
+            dts.append(dt)
+        T = n_imu * dt
+        R, p, v = R @ _rot_from_rotvec(w_b * T), p + v * T + 0.5 * a_w * T * T, v + a_w * T
+        states.append((R, p, v))
+        start.append(len(dts))
+    # visual-only fixed keyframes: near the start of the chain, slightly displaced
+    for k in range(n_fixed_vis):
+        R0, p0, _ = states[rng.integers(0, 3)]
+        states.append((R0 @ _rot_from_rotvec(rng.normal(0, 0.05, 3)), p0 + rng.normal(0, 0.15, 3), np.zeros(3)))
+    nKF = len(states)
+    kind = np.array([1] + [0] * n_opt + [2] * n_fixed_vis, np.uint8)
+    cams = [(Rcb @ Rk.T, Rcb @ (-Rk.T @ pk) + tcb) for Rk, pk, _ in states]
+    # points in front of the middle keyframe's camera
+    Rm, tm_ = cams[n_opt // 2]
+    Xc = np.stack([rng.uniform(-4, 4, n_points), rng.uniform(-2.5, 2.5, n_points), rng.uniform(2, 20, n_points)], 1)
+    X = (Xc - tm_) @ Rm
+    eKF, eMP, eObs, eInv = [], [], [], []
+    depth_ref = np.full(n_points, 1e9)
+    for j in range(n_points):
+        ks = rng.choice(nKF, size=min(int(rng.integers(3, 9)), nKF), replace=False)
+        for k in ks:
+            Rcw, tcw = cams[k]
+            xc = Rcw @ X[j] + tcw
+            if xc[2] < 0.5:
+                continue
+            u = cam["fx"] * xc[0] / xc[2] + cam["cx"]; vv = cam["fy"] * xc[1] / xc[2] + cam["cy"]
+            if not (0 <= u < 752 and 0 <= vv < 480):
+                continue
+            octv = int(rng.integers(0, 8)); s = 1.2 ** octv
+            o = np.array([u, vv, u - cam["bf"] / xc[2]]) + rng.normal(0, 1, 3) * s
+            if rng.random() < outlier_frac:
+                o[:2] += rng.choice([-1, 1], 2) * rng.uniform(15, 30, 2)
+            if rng.random() < mono_frac:
+                o[2] = -1
+            eKF.append(k); eMP.append(j); eObs.append(o); eInv.append(1.0 / (s * s))
+            depth_ref[j] = min(depth_ref[j], xc[2])
+    true = np.stack([np.concatenate([Rk.ravel(), pk, vk, bg, ba]) for Rk, pk, vk in states])
+    init = true.copy()
+    for k in range(nKF):
+        if kind[k] == 0:
+            Rk = states[k][0] @ _rot_from_rotvec(rng.normal(0, 1, 3) / np.sqrt(3) * np.deg2rad(0.5))
+            init[k, :9] = Rk.ravel(); init[k, 9:12] += rng.normal(0, 0.02, 3); init[k, 12:15] += rng.normal(0, 0.03, 3)
+            init[k, 15:18] += rng.normal(0, 0.001, 3); init[k, 18:21] += rng.normal(0, 0.005, 3)
+    iKF1 = np.arange(0, n_opt, dtype=np.int32); iKF2 = np.arange(1, n_opt + 1, dtype=np.int32)
+    return dict(kfState=init.astype(np.float32), kfKind=kind, mpPos=(X + rng.normal(0, 0.03, X.shape)).astype(np.float32),
+                mpClose=(depth_ref < 10).astype(np.uint8), eKF=np.array(eKF, np.int32), eMP=np.array(eMP, np.int32),
+                eObs=np.array(eObs, np.float32), eInvSigma2=np.array(eInv, np.float32), iKF1=iKF1, iKF2=iKF2,
+                iRobust=(iKF1 == 0).astype(np.uint8), iInfoScale=np.where(iKF1 == 0, 1e-2, 1.0).astype(np.float32),
+                imuStart=np.array(start, np.int32), acc=np.array(acc, np.float32), gyro=np.array(gyro, np.float32),
+                dt=np.array(dts, np.float32), bias=np.concatenate([ba, bg]).astype(np.float32),
+                Tbc12=np.concatenate([Tbc[:3, :3].ravel(), Tbc[:3, 3]]).astype(np.float32), cam=cam, true=true, truePts=X)

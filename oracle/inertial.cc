@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <limits>
 #include <vector>
 
 #include "orb_oracle.h"
@@ -990,4 +991,361 @@ extern "C" int orc_pose_inertial_optimization_last_frame(int n, const uint8_t* h
     memcpy(prior246 + 21, Hm, sizeof Hm);
   }
   return nInitial - nBad;
+}
+
+// =========================================================================================================================
+// Optimizer::LocalInertialBA (Optimizer.cc:2324-2897) on the flattened graph the reference assembles at :2337-2768:
+//   kfKind[k]: 0 = temporal optimizable keyframe (pose, velocity, gyro bias, acc bias free), 1 = the fixed keyframe before the
+//   window (its IMU state enters the last inertial edge), 2 = fixed keyframe that only observes points.
+//   nI inertial links (iKF1 = mPrevKF, iKF2 = the keyframe whose mpImuPreintegrated is iPre[i]); iRobust[i] = Huber
+//   sqrt(16.92) (i == N - 1 || bRecInit, :2553-2563), iInfoScale[i] = 1e-2 on the link to the fixed keyframe else 1.
+//   EdgeGyroRW / EdgeAccRW accompany every link (:2566-2583).  Points are marginalised (Schur), EdgeMono / EdgeStereo
+//   (G2oTypes.h:352-463, G2oTypes.cc:334-415) with Huber; g2o Levenberg-Marquardt with a user lambda (1 or 1e-2), opt_it = 10
+//   (4 when bLarge) iterations (optimization_algorithm_levenberg.cpp:61-194, block_solver.hpp Schur path).
+// Returns 1, or 0 for "FAIL LOCAL-INERTIAL BA" (:2808-2813: nothing is written back).  eraseFlag[e] = observation erased.
+// =========================================================================================================================
+namespace orc {
+namespace imu {
+namespace {
+
+struct IbaKF { CamPose P; double v[3], bg[3], ba[3]; int col; };
+struct IbaState { std::vector<IbaKF> kf; std::vector<double> pts; };
+
+static void inertialFull(const orc_imu_preintegrated* pre, const IbaKF& K1, const IbaKF& K2, double* err, double* J) {
+  const float b1f[6] = {(float)K1.ba[0], (float)K1.ba[1], (float)K1.ba[2], (float)K1.bg[0], (float)K1.bg[1], (float)K1.bg[2]};
+  float dRf[9], dVf[3], dPf[3];
+  orc_imu_delta(pre, b1f, dRf, dVf, dPf);
+  double dR[9], dV[3], dP[3], JRg[9], JVg[9], JPg[9], JVa[9], JPa[9];
+  for (int k = 0; k < 9; ++k) { dR[k] = dRf[k]; JRg[k] = pre->JRg[k]; JVg[k] = pre->JVg[k]; JPg[k] = pre->JPg[k]; JVa[k] = pre->JVa[k]; JPa[k] = pre->JPa[k]; }
+  for (int k = 0; k < 3; ++k) { dV[k] = dVf[k]; dP[k] = dPf[k]; }
+  const double dt = pre->dT;
+  const double g[3] = {0, 0, -(double)9.81f};
+  double Rbw1[9], dRt[9], M[9], eR[9], er[3];
+  transpose33(K1.P.Rwb, Rbw1);
+  transpose33(dR, dRt);
+  mul33(dRt, Rbw1, M);
+  mul33(M, K2.P.Rwb, eR);
+  logSO3(eR, er);
+  double t1[3], t2[3], a1[3], a2[3];
+  for (int k = 0; k < 3; ++k) t1[k] = K2.v[k] - K1.v[k] - g[k] * dt;
+  mul3v(Rbw1, t1, a1);
+  for (int k = 0; k < 3; ++k) t2[k] = K2.P.twb[k] - K1.P.twb[k] - K1.v[k] * dt - g[k] * dt * dt / 2;
+  mul3v(Rbw1, t2, a2);
+  for (int k = 0; k < 3; ++k) { err[k] = er[k]; err[3 + k] = a1[k] - dV[k]; err[6 + k] = a2[k] - dP[k]; }
+  if (!J) return;
+  memset(J, 0, sizeof(double) * 9 * 24);
+  double invJr[9], Rwb2t[9], T[9], T2[9], W[9];
+  invRightJacobianSO3(er, invJr);
+  auto put = [&](int r0, int c0, const double* B, double sgn) { for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) J[(r0 + r) * 24 + c0 + c] = sgn * B[r * 3 + c]; };
+  transpose33(K2.P.Rwb, Rwb2t);
+  mul33(invJr, Rwb2t, T); mul33(T, K1.P.Rwb, T2);
+  put(0, 0, T2, -1.0);
+  hat(a1, W); put(3, 0, W, 1.0);
+  {
+    double t3[3], a3[3];
+    for (int k = 0; k < 3; ++k) t3[k] = K2.P.twb[k] - K1.P.twb[k] - K1.v[k] * dt - 0.5 * g[k] * dt * dt;
+    mul3v(Rbw1, t3, a3);
+    hat(a3, W); put(6, 0, W, 1.0);
+  }
+  const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  put(6, 3, I3, -1.0);
+  put(3, 6, Rbw1, -1.0);
+  { double B[9]; for (int k = 0; k < 9; ++k) B[k] = Rbw1[k] * dt; put(6, 6, B, -1.0); }
+  {
+    const float dbgf[3] = {b1f[3] - pre->b[3], b1f[4] - pre->b[4], b1f[5] - pre->b[5]};
+    const double dbg[3] = {dbgf[0], dbgf[1], dbgf[2]};
+    double w3[3], rj[9], eRt[9];
+    mul3v(JRg, dbg, w3);
+    rightJacobianSO3(w3, rj);
+    transpose33(eR, eRt);
+    mul33(invJr, eRt, T); mul33(T, rj, T2); mul33(T2, JRg, T);
+    put(0, 9, T, -1.0);
+    put(3, 9, JVg, -1.0); put(6, 9, JPg, -1.0);
+  }
+  put(3, 12, JVa, -1.0); put(6, 12, JPa, -1.0);
+  put(0, 15, invJr, 1.0);
+  mul33(Rbw1, K2.P.Rwb, T); put(6, 18, T, 1.0);
+  put(3, 21, Rbw1, 1.0);
+}
+
+}  // namespace
+}  // namespace imu
+}  // namespace orc
+
+extern "C" int orc_local_inertial_ba(int nKF, float* kfState21, const uint8_t* kfKind, int nMP, float* mpPos, const uint8_t* mpClose,
+                                     int nE, const int* eKF, const int* eMP, const float* eObs, const float* eInvSigma2, int nI,
+                                     const int* iKF1, const int* iKF2, const orc_imu_preintegrated* iPre, const uint8_t* iRobust,
+                                     const float* iInfoScale, float fx, float fy, float cx, float cy, float bf, const float* Tbc12,
+                                     int bLarge, uint8_t* eraseFlag, int* stats2) {
+  using namespace orc::imu;
+  IbaState S;
+  S.kf.resize(nKF);
+  int nOpt = 0;
+  for (int k = 0; k < nKF; ++k) {
+    IbaKF& K = S.kf[k];
+    const float* s = kfState21 + 21 * k;
+    for (int i = 0; i < 9; ++i) K.P.Rwb[i] = s[i];
+    for (int i = 0; i < 3; ++i) { K.P.twb[i] = s[9 + i]; K.v[i] = s[12 + i]; K.bg[i] = s[15 + i]; K.ba[i] = s[18 + i]; }
+    for (int i = 0; i < 9; ++i) K.P.Rbc[i] = Tbc12[i];
+    for (int i = 0; i < 3; ++i) K.P.tbc[i] = Tbc12[9 + i];
+    transpose33(K.P.Rbc, K.P.Rcb);
+    mul3v(K.P.Rcb, K.P.tbc, K.P.tcb);
+    for (double& c : K.P.tcb) c = -c;
+    K.P.bf = bf; K.P.fx = fx; K.P.fy = fy; K.P.cx = cx; K.P.cy = cy;
+    K.P.refreshCamera();
+    K.col = kfKind[k] == 0 ? nOpt++ : -1;
+  }
+  S.pts.resize((size_t)3 * nMP);
+  for (int k = 0; k < 3 * nMP; ++k) S.pts[k] = mpPos[k];
+  const int P = 15 * nOpt;
+  const double thMono = (double)(float)std::sqrt(5.991), thStereo = (double)(float)std::sqrt(7.815), thInertial = std::sqrt(16.92);
+
+  // informations
+  std::vector<double> InfoI((size_t)nI * 81), InfoG((size_t)nI * 9), InfoA((size_t)nI * 9);
+  for (int i = 0; i < nI; ++i) {
+    inertialInformation(iPre[i].C, &InfoI[(size_t)i * 81]);
+    for (int k = 0; k < 81; ++k) InfoI[(size_t)i * 81 + k] *= (double)iInfoScale[i];
+    double Cg[9], Ca[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { Cg[r * 3 + c] = iPre[i].C[(9 + r) * 15 + 9 + c]; Ca[r * 3 + c] = iPre[i].C[(12 + r) * 15 + 12 + c]; }
+    invertN(Cg, 3, &InfoG[(size_t)i * 9]); invertN(Ca, 3, &InfoA[(size_t)i * 9]);
+  }
+
+  // error storage (the values of the last computeActiveErrors)
+  std::vector<double> vErr((size_t)nE * 3), iErr((size_t)nI * 9), gErr((size_t)nI * 3), aErr((size_t)nI * 3);
+  auto visChi2 = [&](int e) { const bool st = !(eObs[3 * e + 2] < 0); const double info = eInvSigma2[e]; double s = 0; for (int k = 0; k < (st ? 3 : 2); ++k) s += vErr[3 * e + k] * info * vErr[3 * e + k]; return s; };
+  auto inertialChi2 = [&](int i) { double s = 0; for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) s += iErr[9 * i + r] * InfoI[(size_t)i * 81 + r * 9 + c] * iErr[9 * i + c]; return s; };
+  auto rwChi2 = [&](const std::vector<double>& E, const std::vector<double>& I3, int i) { double s = 0; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) s += E[3 * i + r] * I3[(size_t)i * 9 + r * 3 + c] * E[3 * i + c]; return s; };
+  auto computeActiveErrors = [&]() {
+    for (int e = 0; e < nE; ++e) {
+      VisEdge ve;
+      ve.stereo = !(eObs[3 * e + 2] < 0);
+      for (int k = 0; k < 3; ++k) { ve.obs[k] = eObs[3 * e + k]; ve.Xw[k] = S.pts[3 * eMP[e] + k]; }
+      ve.err[2] = 0;
+      ve.computeError(S.kf[eKF[e]].P);
+      for (int k = 0; k < 3; ++k) vErr[3 * e + k] = ve.stereo || k < 2 ? ve.err[k] : 0.0;
+    }
+    for (int i = 0; i < nI; ++i) {
+      inertialFull(&iPre[i], S.kf[iKF1[i]], S.kf[iKF2[i]], &iErr[9 * i], nullptr);
+      for (int k = 0; k < 3; ++k) { gErr[3 * i + k] = S.kf[iKF2[i]].bg[k] - S.kf[iKF1[i]].bg[k]; aErr[3 * i + k] = S.kf[iKF2[i]].ba[k] - S.kf[iKF1[i]].ba[k]; }
+    }
+  };
+  auto activeRobustChi2 = [&]() {
+    double s = 0;
+    for (int e = 0; e < nE; ++e) { double rho[3]; huber(!(eObs[3 * e + 2] < 0) ? thStereo : thMono, visChi2(e), rho); s += rho[0]; }
+    for (int i = 0; i < nI; ++i) {
+      const double c = inertialChi2(i);
+      if (iRobust[i]) { double rho[3]; huber(thInertial, c, rho); s += rho[0]; } else s += c;
+      s += rwChi2(gErr, InfoG, i) + rwChi2(aErr, InfoA, i);
+    }
+    return s;
+  };
+
+  // system
+  std::vector<double> H((size_t)P * P), b((size_t)P + 3 * nMP), Hll((size_t)nMP * 9), Hpl((size_t)nE * 18), x((size_t)P + 3 * nMP);
+  std::vector<std::vector<int>> byPoint(nMP);
+  for (int e = 0; e < nE; ++e) byPoint[eMP[e]].push_back(e);
+  auto buildSystem = [&]() {
+    std::fill(H.begin(), H.end(), 0.0); std::fill(b.begin(), b.end(), 0.0); std::fill(Hll.begin(), Hll.end(), 0.0); std::fill(Hpl.begin(), Hpl.end(), 0.0);
+    for (int e = 0; e < nE; ++e) {
+      const IbaKF& K = S.kf[eKF[e]];
+      VisEdge ve;
+      ve.stereo = !(eObs[3 * e + 2] < 0);
+      for (int k = 0; k < 3; ++k) ve.Xw[k] = S.pts[3 * eMP[e] + k];
+      const int d = ve.stereo ? 3 : 2;
+      const double info = eInvSigma2[e];
+      double rho[3];
+      huber(ve.stereo ? thStereo : thMono, visChi2(e), rho);
+      const double w = rho[1];
+      double Jp[18], Jl[9];
+      ve.jacobian(K.P, Jp);
+      {  // EdgeMono / EdgeStereo::linearizeOplus: _jacobianOplusXi = -proj_jac * Rcw (G2oTypes.cc:334-415)
+        double Xc[3], pj[9];
+        K.P.camPoint(ve.Xw, Xc);
+        K.P.projectJac(Xc, pj);
+        if (ve.stereo) { pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + K.P.bf * (1.0 / (Xc[2] * Xc[2])); }
+        for (int r = 0; r < d; ++r) for (int c = 0; c < 3; ++c) Jl[r * 3 + c] = -(pj[r * 3] * K.P.Rcw[c] + pj[r * 3 + 1] * K.P.Rcw[3 + c] + pj[r * 3 + 2] * K.P.Rcw[6 + c]);
+      }
+      const double* er = &vErr[3 * e];
+      const int l = eMP[e];
+      for (int r = 0; r < 3; ++r) {
+        double s = 0; for (int k = 0; k < d; ++k) s += Jl[k * 3 + r] * info * er[k];
+        b[P + 3 * l + r] -= w * s;
+        for (int c = 0; c < 3; ++c) { double h = 0; for (int k = 0; k < d; ++k) h += Jl[k * 3 + r] * (w * info) * Jl[k * 3 + c]; Hll[(size_t)l * 9 + r * 3 + c] += h; }
+      }
+      if (K.col < 0) continue;
+      const int o = 15 * K.col;
+      for (int r = 0; r < 6; ++r) {
+        double s = 0; for (int k = 0; k < d; ++k) s += Jp[k * 6 + r] * info * er[k];
+        b[o + r] -= w * s;
+        for (int c = 0; c < 6; ++c) { double h = 0; for (int k = 0; k < d; ++k) h += Jp[k * 6 + r] * (w * info) * Jp[k * 6 + c]; H[(size_t)(o + r) * P + o + c] += h; }
+        for (int c = 0; c < 3; ++c) { double h = 0; for (int k = 0; k < d; ++k) h += Jp[k * 6 + r] * (w * info) * Jl[k * 3 + c]; Hpl[(size_t)e * 18 + r * 3 + c] = h; }
+      }
+    }
+    for (int i = 0; i < nI; ++i) {
+      const IbaKF &K1 = S.kf[iKF1[i]], &K2 = S.kf[iKF2[i]];
+      double err[9], J[216];
+      inertialFull(&iPre[i], K1, K2, err, J);
+      double w = 1.0;
+      if (iRobust[i]) { double rho[3]; huber(thInertial, inertialChi2(i), rho); w = rho[1]; }
+      // edge column -> system column (-1: fixed vertex): P1 V1 G1 A1 of K1, P2 V2 of K2
+      int colOf[24];
+      for (int a = 0; a < 15; ++a) colOf[a] = K1.col >= 0 ? 15 * K1.col + a : -1;
+      for (int a = 0; a < 9; ++a) colOf[15 + a] = K2.col >= 0 ? 15 * K2.col + a : -1;
+      const double* Om = &InfoI[(size_t)i * 81];
+      const double* er = &iErr[9 * i];
+      for (int a = 0; a < 24; ++a) {
+        if (colOf[a] < 0) continue;
+        double JtO[9];
+        for (int c = 0; c < 9; ++c) { double s = 0; for (int k = 0; k < 9; ++k) s += J[k * 24 + a] * Om[k * 9 + c]; JtO[c] = s; }
+        double s = 0; for (int k = 0; k < 9; ++k) s += JtO[k] * er[k];
+        b[colOf[a]] -= w * s;
+        for (int c = 0; c < 24; ++c) {
+          if (colOf[c] < 0) continue;
+          double h = 0; for (int k = 0; k < 9; ++k) h += JtO[k] * J[k * 24 + c];
+          H[(size_t)colOf[a] * P + colOf[c]] += w * h;
+        }
+      }
+      // random walks: e = bias2 - bias1
+      const int c1g = K1.col >= 0 ? 15 * K1.col + 9 : -1, c2g = K2.col >= 0 ? 15 * K2.col + 9 : -1;
+      for (int t = 0; t < 2; ++t) {
+        const double* I3 = t == 0 ? &InfoG[(size_t)i * 9] : &InfoA[(size_t)i * 9];
+        const double* er3 = t == 0 ? &gErr[3 * i] : &aErr[3 * i];
+        const int o1 = c1g < 0 ? -1 : c1g + 3 * t, o2 = c2g < 0 ? -1 : c2g + 3 * t;
+        for (int r = 0; r < 3; ++r) {
+          double s = 0; for (int k = 0; k < 3; ++k) s += I3[r * 3 + k] * er3[k];
+          if (o2 >= 0) b[o2 + r] -= s;
+          if (o1 >= 0) b[o1 + r] += s;
+          for (int c = 0; c < 3; ++c) {
+            const double v = I3[r * 3 + c];
+            if (o2 >= 0) H[(size_t)(o2 + r) * P + o2 + c] += v;
+            if (o1 >= 0) H[(size_t)(o1 + r) * P + o1 + c] += v;
+            if (o1 >= 0 && o2 >= 0) { H[(size_t)(o1 + r) * P + o2 + c] -= v; H[(size_t)(o2 + r) * P + o1 + c] -= v; }
+          }
+        }
+      }
+    }
+  };
+  auto solveSystem = [&](double lam) -> bool {   // block_solver.hpp: Schur complement on the points, dense solve, back-substitution
+    std::vector<double> Hs = H, bs(b.begin(), b.begin() + P), Dinv((size_t)nMP * 9);
+    for (int i = 0; i < P; ++i) Hs[(size_t)i * P + i] += lam;
+    for (int l = 0; l < nMP; ++l) {
+      double D[9];
+      memcpy(D, &Hll[(size_t)l * 9], sizeof D);
+      D[0] += lam; D[4] += lam; D[8] += lam;
+      if (!invertN(D, 3, &Dinv[(size_t)l * 9])) memset(&Dinv[(size_t)l * 9], 0, sizeof D);
+    }
+    for (int l = 0; l < nMP; ++l) {
+      const double* Di = &Dinv[(size_t)l * 9];
+      double db[3];
+      for (int r = 0; r < 3; ++r) db[r] = Di[r * 3] * b[P + 3 * l] + Di[r * 3 + 1] * b[P + 3 * l + 1] + Di[r * 3 + 2] * b[P + 3 * l + 2];
+      for (int e1 : byPoint[l]) {
+        const int c1 = S.kf[eKF[e1]].col;
+        if (c1 < 0) continue;
+        const double* B1 = &Hpl[(size_t)e1 * 18];
+        double BD[18];
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) BD[r * 3 + c] = B1[r * 3] * Di[c] + B1[r * 3 + 1] * Di[3 + c] + B1[r * 3 + 2] * Di[6 + c];
+        for (int r = 0; r < 6; ++r) bs[15 * c1 + r] -= B1[r * 3] * db[0] + B1[r * 3 + 1] * db[1] + B1[r * 3 + 2] * db[2];
+        for (int e2 : byPoint[l]) {
+          const int c2 = S.kf[eKF[e2]].col;
+          if (c2 < 0) continue;
+          const double* B2 = &Hpl[(size_t)e2 * 18];
+          for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c)
+              Hs[(size_t)(15 * c1 + r) * P + 15 * c2 + c] -= BD[r * 3] * B2[c * 3] + BD[r * 3 + 1] * B2[c * 3 + 1] + BD[r * 3 + 2] * B2[c * 3 + 2];
+        }
+      }
+    }
+    if (!ldltSolve(Hs.data(), bs.data(), P, x.data())) return false;
+    for (int l = 0; l < nMP; ++l) {
+      double cl[3] = {b[P + 3 * l], b[P + 3 * l + 1], b[P + 3 * l + 2]};
+      for (int e : byPoint[l]) {
+        const int c1 = S.kf[eKF[e]].col;
+        if (c1 < 0) continue;
+        const double* B = &Hpl[(size_t)e * 18];
+        for (int c = 0; c < 3; ++c) for (int r = 0; r < 6; ++r) cl[c] -= B[r * 3 + c] * x[15 * c1 + r];
+      }
+      const double* Di = &Dinv[(size_t)l * 9];
+      for (int r = 0; r < 3; ++r) x[P + 3 * l + r] = Di[r * 3] * cl[0] + Di[r * 3 + 1] * cl[1] + Di[r * 3 + 2] * cl[2];
+    }
+    return true;
+  };
+  auto update = [&]() {
+    for (IbaKF& K : S.kf) {
+      if (K.col < 0) continue;
+      const double* dx = &x[15 * K.col];
+      K.P.update(dx);
+      for (int k = 0; k < 3; ++k) { K.v[k] += dx[6 + k]; K.bg[k] += dx[9 + k]; K.ba[k] += dx[12 + k]; }
+    }
+    for (int k = 0; k < 3 * nMP; ++k) S.pts[k] += x[P + k];
+  };
+
+  computeActiveErrors();
+  const float err0 = (float)activeRobustChi2();
+  // optimizer.optimize(opt_it): Levenberg-Marquardt with the user lambda
+  double lambda = bLarge ? 1e-2 : 1e0, ni = 2;
+  int nBadIts = 0, trials = 0, outer = 0;
+  const int optIt = bLarge ? 4 : 10;
+  for (int it = 0; it < optIt; ++it) {
+    ++outer;
+    computeActiveErrors();
+    double currentChi = activeRobustChi2(), tempChi = currentChi;
+    const double iniChi = currentChi;
+    buildSystem();
+    if (it == 0) { ni = 2; nBadIts = 0; }
+    double rho = 0;
+    int qmax = 0;
+    do {
+      const IbaState backup = S;
+      const bool ok2 = solveSystem(lambda);
+      update();
+      computeActiveErrors();
+      tempChi = activeRobustChi2();
+      if (!ok2) tempChi = std::numeric_limits<double>::max();
+      rho = currentChi - tempChi;
+      double scale = 0;
+      for (size_t j = 0; j < x.size(); ++j) scale += x[j] * (lambda * x[j] + b[j]);
+      scale += 1e-3;
+      rho /= scale;
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow((2 * rho - 1), 3);
+        alpha = std::min(alpha, 2. / 3.);
+        lambda *= std::max(1. / 3., alpha);
+        ni = 2;
+        currentChi = tempChi;
+      } else {
+        lambda *= ni;
+        ni *= 2;
+        S = backup;
+      }
+      ++qmax; ++trials;
+    } while (rho < 0 && qmax < 10);
+    if (qmax == 10 || rho == 0) break;
+    if ((iniChi - currentChi) * 1e3 < iniChi) nBadIts++; else nBadIts = 0;
+    if (nBadIts >= 3) break;
+  }
+  if (stats2) { stats2[0] = outer; stats2[1] = trials; }
+  const float errEnd = (float)activeRobustChi2();
+  memset(eraseFlag, 0, nE);
+  if ((2 * err0 < errEnd || std::isnan(err0) || std::isnan(errEnd)) && !bLarge) return 0;   // "FAIL LOCAL-INERTIAL BA"
+  for (int e = 0; e < nE; ++e) {   // :2773-2801 with the errors of the last computeActiveErrors
+    const bool st = !(eObs[3 * e + 2] < 0);
+    const double c = visChi2(e);
+    if (st) { if (c > 7.815f) eraseFlag[e] = 1; }
+    else {
+      const bool bClose = mpClose[eMP[e]] != 0;
+      const IbaKF& K = S.kf[eKF[e]];
+      const double* X = &S.pts[3 * eMP[e]];
+      const bool depthPos = (K.P.Rcw[6] * X[0] + K.P.Rcw[7] * X[1] + K.P.Rcw[8] * X[2] + K.P.tcw[2]) > 0.0;
+      if ((c > 5.991f && !bClose) || (c > 1.5f * 5.991f && bClose) || !depthPos) eraseFlag[e] = 1;
+    }
+  }
+  for (int k = 0; k < nKF; ++k) {
+    if (S.kf[k].col < 0) continue;
+    float* s = kfState21 + 21 * k;
+    const IbaKF& K = S.kf[k];
+    for (int i = 0; i < 9; ++i) s[i] = (float)K.P.Rwb[i];
+    for (int i = 0; i < 3; ++i) { s[9 + i] = (float)K.P.twb[i]; s[12 + i] = (float)K.v[i]; s[15 + i] = (float)K.bg[i]; s[18 + i] = (float)K.ba[i]; }
+  }
+  for (int k = 0; k < 3 * nMP; ++k) mpPos[k] = (float)S.pts[k];
+  return 1;
 }

@@ -163,6 +163,11 @@ int orc_pose_inertial_optimization_last_frame(int n, const uint8_t* hasMP, const
                                               const orc_imu_preintegrated* preFrame, const orc_imu_preintegrated* preKF,
                                               const double* prevPrior246, int bRecInit, float* state21, uint8_t* outlier,
                                               double* prior246);
+int orc_local_inertial_ba(int nKF, float* kfState21, const uint8_t* kfKind, int nMP, float* mpPos, const uint8_t* mpClose, int nE,
+                          const int* eKF, const int* eMP, const float* eObs, const float* eInvSigma2, int nI, const int* iKF1,
+                          const int* iKF2, const orc_imu_preintegrated* iPre, const uint8_t* iRobust, const float* iInfoScale,
+                          float fx, float fy, float cx, float cy, float bf, const float* Tbc12, int bLarge, uint8_t* eraseFlag,
+                          int* stats2);
 float orc_fast_atan2(float y, float x);
 float orc_cosf(float x);
 float orc_sinf(float x);

@@ -494,3 +494,21 @@ def pose_inertial_optimization_last_frame(p, prevState, preFrame, preKF, prevPri
                                                     cam["cy"], cam["bf"], _p(a[5]), _p(b[0]), _p(b[1]), _p(b[2]), _p(b[3]),
                                                     int(bool(bRecInit)), _p(state), _p(outl), _p(prior))
     return r, state, outl, prior
+
+
+def local_inertial_ba(p, pre, bLarge=False):
+    """pre: [nI, PREINT_FLOATS] preintegration records of the links."""
+    L = lib()
+    f = C.c_float
+    vp = C.c_void_p
+    L.orc_local_inertial_ba.argtypes = [C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp] + [f] * 5 + \
+        [vp, C.c_int, vp, vp]
+    kf = p["kfState"].astype(np.float32).copy(); mp = p["mpPos"].astype(np.float32).copy()
+    nE = len(p["eKF"]); erase = np.zeros(nE, np.uint8); stats = np.zeros(2, np.int32)
+    a = [np.ascontiguousarray(p[k]) for k in ("kfKind", "mpClose", "eKF", "eMP", "eObs", "eInvSigma2", "iKF1", "iKF2", "iRobust", "iInfoScale", "Tbc12")]
+    pre = np.ascontiguousarray(pre, np.float32)
+    cam = p["cam"]
+    r = L.orc_local_inertial_ba(len(kf), _p(kf), _p(a[0]), len(mp), _p(mp), _p(a[1]), nE, _p(a[2]), _p(a[3]), _p(a[4]), _p(a[5]),
+                                len(a[6]), _p(a[6]), _p(a[7]), _p(pre), _p(a[8]), _p(a[9]), cam["fx"], cam["fy"], cam["cx"], cam["cy"],
+                                cam["bf"], _p(a[10]), int(bool(bLarge)), _p(erase), _p(stats))
+    return r, kf, mp, erase, stats

@@ -170,3 +170,33 @@ def test_pose_inertial_chain_on_device(opt):
         assert abs(int(nin[i].item()) - rB[0]) <= 2
         H = priorB[i][21:].reshape(15, 15).cpu().numpy()
         assert np.all(np.linalg.eigvalsh((H + H.T) / 2) > 0)
+
+
+@pytest.mark.parametrize("large,n_opt,seeds", [(False, 10, range(3)), (True, 25, range(2)), (False, 4, range(2))])
+def test_local_inertial_ba(opt, large, n_opt, seeds):
+    import time
+    from morb_slam_amd.synth import make_inertial_ba_problem
+    nga, walk = imu_calib_diagonals()
+    for s in seeds:
+        p = make_inertial_ba_problem(n_opt=n_opt, seed=s, n_points=1500 if n_opt > 4 else 400)
+        pre = np.stack([orc.imu_preintegrate(p["bias"], nga, walk, p["acc"][a:b], p["gyro"][a:b], p["dt"][a:b])
+                        for a, b in zip(p["imuStart"][:-1], p["imuStart"][1:])])
+        r, kf_o, mp_o, er_o, st_o = orc.local_inertial_ba(p, pre, bLarge=large)
+        kf, mp, er, st = opt.LocalInertialBA(p["kfState"], p["kfKind"], p["mpPos"], p["mpClose"], p["eKF"], p["eMP"], p["eObs"], p["eInvSigma2"],
+                                             p["iKF1"], p["iKF2"], pre, p["iRobust"], p["iInfoScale"], p["cam"], p["Tbc12"], bLarge=large)
+        assert int(st[2]) == r == 1
+        assert (int(st[0]), int(st[1])) == (int(st_o[0]), int(st_o[1])), (st, st_o)      # same LM path
+        optk = p["kfKind"] == 0
+        assert np.allclose(kf[optk], kf_o[optk], rtol=0, atol=1e-4), np.abs(kf[optk] - kf_o[optk]).max()
+        assert np.array_equal(kf[~optk], p["kfState"][~optk])                            # fixed keyframes untouched
+        # points: FP64 on both sides, different summation orders (atomics); ill-conditioned far points are compared relative
+        # to their distance
+        d = np.abs(mp - mp_o).max(1) / np.maximum(1.0, np.linalg.norm(mp_o, axis=1))
+        assert np.quantile(d, 0.99) < 1e-4 and d.max() < 1e-2, (np.quantile(d, 0.99), d.max())
+        assert (er != er_o).sum() <= max(2, len(er) // 2000), int((er != er_o).sum())
+        # sanity: the window moved towards the generating trajectory
+        def ang(a, b):
+            return np.degrees(np.arccos(np.clip((np.trace(a.reshape(3, 3).T @ b.reshape(3, 3)) - 1) / 2, -1, 1)))
+        a0 = max(ang(p["kfState"][k, :9], p["true"][k, :9]) for k in np.where(optk)[0])
+        a1 = max(ang(kf[k, :9], p["true"][k, :9]) for k in np.where(optk)[0])
+        assert a1 < 0.2 * a0 + 0.05
