@@ -27,6 +27,7 @@ struct morb_optimizer;
 extern "C" {
 int morb_optimizer_device(const morb_optimizer*);
 void* morb_optimizer_stream(const morb_optimizer*);
+int morb_optimizer_workspace(morb_optimizer*, size_t bytes, void** out);
 }
 
 namespace {
@@ -1223,54 +1224,64 @@ __global__ __launch_bounds__(256) void k_iba_kf(IbaDev D) {
     for (int r = 0; r < 6; ++r) unsafeAtomicAdd(&D.b[o + r], acc[21 + r]);
   }
 }
-// inertial + random-walk edges: one thread per link, Jacobian scratch in global memory
-__global__ void k_iba_links(IbaDev D, double* __restrict__ scratch) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= D.nI) return;
+// inertial + random-walk edges: one 64-thread workgroup per link; thread 0 evaluates the edge (error, 9 x 24 Jacobian) into LDS, all
+// threads multiply out J^T Omega J
+__global__ __launch_bounds__(64) void k_iba_links(IbaDev D) {
+  __shared__ double J[216], OJ[216], Oe[9];
+  __shared__ double sw;
+  const int i = blockIdx.x, tid = threadIdx.x;
   const int k1 = D.iKF1[i], k2 = D.iKF2[i];
-  VIState V1, V2;
-  iba_load(D.S + 33 * (size_t)k1, V1);
-  iba_load(D.S + 33 * (size_t)k2, V2);
-  double* J = scratch + (size_t)i * 420;   // 216
-  double* JtO = J + 216;                   // 9
-  for (int k = 0; k < 216; ++k) J[k] = 0;
-  double errNow[9];
-  inertial_edge(D.iPre[i], V1, V2, nullptr, true, errNow, J);
-  const double* er = D.iErr + 9 * (size_t)i;   // = errNow (buildSystem follows computeActiveErrors at the same state)
+  for (int k = tid; k < 216; k += 64) J[k] = 0;
+  __syncthreads();
+  const double* er = D.iErr + 9 * (size_t)i;   // errors of computeActiveErrors (same state)
   const double* Om = D.InfoI + (size_t)i * 81;
-  double w = 1.0;
-  if (D.iRobust[i]) w = huber_w(sqrt(16.92), iba_quad(er, Om, 9));
+  if (tid == 0) {
+    VIState V1, V2;
+    iba_load(D.S + 33 * (size_t)k1, V1);
+    iba_load(D.S + 33 * (size_t)k2, V2);
+    double errNow[9];
+    inertial_edge(D.iPre[i], V1, V2, nullptr, true, errNow, J);
+    sw = D.iRobust[i] ? huber_w(sqrt(16.92), iba_quad(er, Om, 9)) : 1.0;
+  }
+  __syncthreads();
+  for (int k = tid; k < 216 + 9; k += 64) {
+    if (k < 216) { const int r = k / 24, c = k - r * 24; double sm = 0; for (int l = 0; l < 9; ++l) sm += Om[r * 9 + l] * J[l * 24 + c]; OJ[k] = sm; }
+    else { const int r = k - 216; double sm = 0; for (int l = 0; l < 9; ++l) sm += Om[r * 9 + l] * er[l]; Oe[r] = sm; }
+  }
+  __syncthreads();
+  const double w = sw;
   const int c1 = D.col[k1], c2 = D.col[k2];
-  for (int a = 0; a < 24; ++a) {
+  for (int idx = tid; idx < 24 * 24 + 24; idx += 64) {
+    const int a = idx < 576 ? idx / 24 : idx - 576;
     const int ca = a < 15 ? (c1 >= 0 ? 15 * c1 + a : -1) : (c2 >= 0 ? 15 * c2 + (a - 15) : -1);
     if (ca < 0) continue;
-    for (int c = 0; c < 9; ++c) { double s = 0; for (int k = 0; k < 9; ++k) s += J[k * 24 + a] * Om[k * 9 + c]; JtO[c] = s; }
-    double s = 0;
-    for (int k = 0; k < 9; ++k) s += JtO[k] * er[k];
-    unsafeAtomicAdd(&D.b[ca], -w * s);
-    for (int b2 = 0; b2 < 24; ++b2) {
+    if (idx < 576) {
+      const int b2 = idx - a * 24;
       const int cb = b2 < 15 ? (c1 >= 0 ? 15 * c1 + b2 : -1) : (c2 >= 0 ? 15 * c2 + (b2 - 15) : -1);
       if (cb < 0) continue;
       double h = 0;
-      for (int k = 0; k < 9; ++k) h += JtO[k] * J[k * 24 + b2];
-      unsafeAtomicAdd(&D.H[(size_t)ca * D.P + cb], w * h);
+      for (int k = 0; k < 9; ++k) h += J[k * 24 + a] * OJ[k * 24 + b2];
+      if (h != 0.0) unsafeAtomicAdd(&D.H[(size_t)ca * D.P + cb], w * h);
+    } else {
+      double sm = 0;
+      for (int k = 0; k < 9; ++k) sm += J[k * 24 + a] * Oe[k];
+      unsafeAtomicAdd(&D.b[ca], -w * sm);
     }
   }
-  for (int t = 0; t < 2; ++t) {   // EdgeGyroRW / EdgeAccRW: e = bias2 - bias1
+  if (tid < 18) {   // EdgeGyroRW / EdgeAccRW: e = bias2 - bias1; thread = (type, row r, column c)
+    const int t = tid / 9, r = (tid % 9) / 3, c = tid % 3;
     const double* I3 = (t == 0 ? D.InfoG : D.InfoA) + (size_t)i * 9;
     const double* e3 = (t == 0 ? D.gErr : D.aErr) + 3 * (size_t)i;
     const int o1 = c1 >= 0 ? 15 * c1 + 9 + 3 * t : -1, o2 = c2 >= 0 ? 15 * c2 + 9 + 3 * t : -1;
-    for (int r = 0; r < 3; ++r) {
-      double s = 0;
-      for (int k = 0; k < 3; ++k) s += I3[r * 3 + k] * e3[k];
-      if (o2 >= 0) unsafeAtomicAdd(&D.b[o2 + r], -s);
-      if (o1 >= 0) unsafeAtomicAdd(&D.b[o1 + r], s);
-      for (int c = 0; c < 3; ++c) {
-        const double v = I3[r * 3 + c];
-        if (o2 >= 0) unsafeAtomicAdd(&D.H[(size_t)(o2 + r) * D.P + o2 + c], v);
-        if (o1 >= 0) unsafeAtomicAdd(&D.H[(size_t)(o1 + r) * D.P + o1 + c], v);
-        if (o1 >= 0 && o2 >= 0) { unsafeAtomicAdd(&D.H[(size_t)(o1 + r) * D.P + o2 + c], -v); unsafeAtomicAdd(&D.H[(size_t)(o2 + r) * D.P + o1 + c], -v); }
-      }
+    const double v = I3[r * 3 + c];
+    if (o2 >= 0) unsafeAtomicAdd(&D.H[(size_t)(o2 + r) * D.P + o2 + c], v);
+    if (o1 >= 0) unsafeAtomicAdd(&D.H[(size_t)(o1 + r) * D.P + o1 + c], v);
+    if (o1 >= 0 && o2 >= 0) { unsafeAtomicAdd(&D.H[(size_t)(o1 + r) * D.P + o2 + c], -v); unsafeAtomicAdd(&D.H[(size_t)(o2 + r) * D.P + o1 + c], -v); }
+    if (c == 0) {
+      double sm = 0;
+      for (int k = 0; k < 3; ++k) sm += I3[r * 3 + k] * e3[k];
+      if (o2 >= 0) unsafeAtomicAdd(&D.b[o2 + r], -sm);
+      if (o1 >= 0) unsafeAtomicAdd(&D.b[o1 + r], sm);
     }
   }
 }
@@ -1292,83 +1303,101 @@ __global__ __launch_bounds__(256) void k_iba_hs_init(IbaDev D, double lambda) {
   if (t < n) { const int r = t / D.P, c = t - r * D.P; D.Hs[t] = D.H[t] + (r == c ? lambda : 0.0); }
   else if (t - n < D.P) D.bs[t - n] = D.b[t - n];
 }
-// Schur complement of the points (block_solver.hpp): one thread per point
+// Schur complement of the points (block_solver.hpp): one thread per point.  The pose blocks of the reduced system receive ~k^2 6 x 6
+// updates per point on a few thousand addresses: with LDSACC the workgroup accumulates them in LDS ((6 N)^2 doubles, LDS atomics)
+// and flushes once; without (large windows) they go to global memory directly.
+template <bool LDSACC>
 __global__ __launch_bounds__(256) void k_iba_schur(IbaDev D, double lambda) {
+  extern __shared__ double sS[];   // LDSACC: M * M + M, M = 6 * (P / 15)
+  const int M = 6 * (D.P / 15);
+  if (LDSACC) { for (int k = threadIdx.x; k < M * M + M; k += 256) sS[k] = 0; __syncthreads(); }
   const int l = blockIdx.x * 256 + threadIdx.x;
-  if (l >= D.nMP) return;
-  double Dm[9], Di[9];
-  for (int k = 0; k < 9; ++k) Dm[k] = D.Hll[(size_t)l * 9 + k];
-  Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
-  inv3(Dm, Di);
-  const double* bl = D.b + D.P + 3 * (size_t)l;
-  double db[3];
-  for (int r = 0; r < 3; ++r) db[r] = Di[r * 3] * bl[0] + Di[r * 3 + 1] * bl[1] + Di[r * 3 + 2] * bl[2];
-  const int s0 = D.ptStart[l], s1 = D.ptStart[l + 1];
-  for (int k1 = s0; k1 < s1; ++k1) {
-    const int e1 = D.ptEdges[k1];
-    const int c1 = D.col[D.eKF[e1]];
-    if (c1 < 0) continue;
-    const double* B1 = D.Hpl + (size_t)e1 * 18;
-    double BD[18];
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) BD[r * 3 + c] = B1[r * 3] * Di[c] + B1[r * 3 + 1] * Di[3 + c] + B1[r * 3 + 2] * Di[6 + c];
-    for (int r = 0; r < 6; ++r) unsafeAtomicAdd(&D.bs[15 * c1 + r], -(B1[r * 3] * db[0] + B1[r * 3 + 1] * db[1] + B1[r * 3 + 2] * db[2]));
-    for (int k2 = s0; k2 < s1; ++k2) {
-      const int e2 = D.ptEdges[k2];
-      const int c2 = D.col[D.eKF[e2]];
-      if (c2 < 0) continue;
-      const double* B2 = D.Hpl + (size_t)e2 * 18;
+  if (l < D.nMP) {
+    double Dm[9], Di[9];
+    for (int k = 0; k < 9; ++k) Dm[k] = D.Hll[(size_t)l * 9 + k];
+    Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
+    inv3(Dm, Di);
+    const double* bl = D.b + D.P + 3 * (size_t)l;
+    double db[3];
+    for (int r = 0; r < 3; ++r) db[r] = Di[r * 3] * bl[0] + Di[r * 3 + 1] * bl[1] + Di[r * 3 + 2] * bl[2];
+    const int s0 = D.ptStart[l], s1 = D.ptStart[l + 1];
+    for (int k1 = s0; k1 < s1; ++k1) {
+      const int e1 = D.ptEdges[k1];
+      const int c1 = D.col[D.eKF[e1]];
+      if (c1 < 0) continue;
+      const double* B1 = D.Hpl + (size_t)e1 * 18;
+      double BD[18];
 #pragma unroll
       for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int c = 0; c < 6; ++c)
-          unsafeAtomicAdd(&D.Hs[(size_t)(15 * c1 + r) * D.P + 15 * c2 + c], -(BD[r * 3] * B2[c * 3] + BD[r * 3 + 1] * B2[c * 3 + 1] + BD[r * 3 + 2] * B2[c * 3 + 2]));
+        for (int c = 0; c < 3; ++c) BD[r * 3 + c] = B1[r * 3] * Di[c] + B1[r * 3 + 1] * Di[3 + c] + B1[r * 3 + 2] * Di[6 + c];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const double v = -(B1[r * 3] * db[0] + B1[r * 3 + 1] * db[1] + B1[r * 3 + 2] * db[2]);
+        if (LDSACC) unsafeAtomicAdd(&sS[M * M + 6 * c1 + r], v); else unsafeAtomicAdd(&D.bs[15 * c1 + r], v);
+      }
+      for (int k2 = s0; k2 < s1; ++k2) {
+        const int e2 = D.ptEdges[k2];
+        const int c2 = D.col[D.eKF[e2]];
+        if (c2 < 0) continue;
+        const double* B2 = D.Hpl + (size_t)e2 * 18;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+            const double v = -(BD[r * 3] * B2[c * 3] + BD[r * 3 + 1] * B2[c * 3 + 1] + BD[r * 3 + 2] * B2[c * 3 + 2]);
+            if (LDSACC) unsafeAtomicAdd(&sS[(6 * c1 + r) * M + 6 * c2 + c], v);
+            else unsafeAtomicAdd(&D.Hs[(size_t)(15 * c1 + r) * D.P + 15 * c2 + c], v);
+          }
+      }
+    }
+  }
+  if (LDSACC) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < M * M + M; k += 256) {
+      const double v = sS[k];
+      if (v == 0.0) continue;
+      if (k < M * M) { const int R = k / M, C = k - R * M; unsafeAtomicAdd(&D.Hs[(size_t)(15 * (R / 6) + R % 6) * D.P + 15 * (C / 6) + C % 6], v); }
+      else { const int R = k - M * M; unsafeAtomicAdd(&D.bs[15 * (R / 6) + R % 6], v); }
     }
   }
 }
-// dense LDL^T of Hs (lower triangle) + solve -> x[0:P], scal[2] = positive.  ONE workgroup of 1024 threads.
+// dense LDL^T of Hs (lower triangle) + solve -> x[0:P], scal[2] = positive.  ONE workgroup of 1024 threads (16 waves): the pivot
+// column is staged in LDS, a wave owns a row of the trailing update (coalesced), two barriers per column.
 __global__ __launch_bounds__(1024) void k_iba_solve(IbaDev D) {
-  const int n = D.P, tid = threadIdx.x;
+  extern __shared__ double sm[];   // colj[n] | y[n]
+  const int n = D.P, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double* colj = sm; double* y = sm + n;
   double* A = D.Hs;
-  __shared__ int sOk;
-  if (tid == 0) sOk = 1;
-  __syncthreads();
+  bool ok = true;
   for (int j = 0; j < n; ++j) {
-    const double d = A[(size_t)j * n + j];
-    if (!(d > 0)) { if (tid == 0) sOk = 0; break; }   // uniform: every thread reads the same d
-    const int m = n - 1 - j;
-    // trailing update: (r, c), j < c <= r, uses the un-scaled column j
-    for (int p = tid; p < m * m; p += 1024) {
-      const int rr = p / m, cc = p - rr * m;
-      if (cc > rr) continue;
-      const int r = j + 1 + rr, c = j + 1 + cc;
-      A[(size_t)r * n + c] -= A[(size_t)r * n + j] * A[(size_t)c * n + j] / d;
+    for (int r = j + tid; r < n; r += 1024) colj[r] = A[(size_t)r * n + j];
+    __syncthreads();
+    const double d = colj[j];
+    if (!(d > 0)) { ok = false; break; }   // uniform
+    for (int r = j + 1 + wv; r < n; r += 16) {
+      const double lr = colj[r] / d;
+      for (int c = j + 1 + lane; c <= r; c += 64) A[(size_t)r * n + c] -= lr * colj[c];
+      if (lane == 0) A[(size_t)r * n + j] = lr;
     }
     __syncthreads();
-    for (int r = j + 1 + tid; r < n; r += 1024) A[(size_t)r * n + j] /= d;
-    __syncthreads();
   }
-  __syncthreads();
-  if (!sOk) { if (tid == 0) D.scal[2] = 0.0; return; }
-  double* y = D.x;
+  if (!ok) { if (tid == 0) D.scal[2] = 0.0; return; }
   for (int r = tid; r < n; r += 1024) y[r] = D.bs[r];
   __syncthreads();
-  for (int j = 0; j < n; ++j) {
+  for (int j = 0; j < n; ++j) {   // L y = b
     const double yj = y[j];
-    __syncthreads();
     for (int r = j + 1 + tid; r < n; r += 1024) y[r] -= A[(size_t)r * n + j] * yj;
     __syncthreads();
   }
   for (int r = tid; r < n; r += 1024) y[r] /= A[(size_t)r * n + r];
   __syncthreads();
-  for (int j = n - 1; j >= 0; --j) {
+  for (int j = n - 1; j >= 0; --j) {   // L^T x = y
     const double xj = y[j];
-    __syncthreads();
     for (int r = tid; r < j; r += 1024) y[r] -= A[(size_t)j * n + r] * xj;
     __syncthreads();
   }
+  for (int r = tid; r < n; r += 1024) D.x[r] = y[r];
   if (tid == 0) D.scal[2] = 1.0;
 }
 // back-substitution of the points + oplus of every vertex + the LM scale  sum x (lambda x + b) -> scal[1]
@@ -1541,10 +1570,32 @@ int morb_local_inertial_ba(morb_optimizer* o, int nKF, float* kfState21, const u
     }
   const int nChunks = (int)chunkKF.size();
 
-  // ---- device memory (one allocation)
-  std::vector<void*> allocs;
-  auto dalloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr; allocs.push_back(p); return p; };
-  auto cleanup = [&]() { for (void* p : allocs) (void)hipFree(p); };
+  // ---- device memory: one arena carved from the handle's grow-only workspace
+  const size_t nS = (size_t)33 * nKF, nPts = (size_t)3 * nMP, nX = (size_t)P + 3 * nMP;
+  const int nI1 = std::max(nI, 1);
+  size_t arenaBytes = 0;
+  auto reserve = [&](size_t bytes) { arenaBytes += (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255; };
+  for (size_t b : {sizeof(int) * (size_t)nE, sizeof(int) * (size_t)nE, sizeof(float) * 3 * (size_t)nE, sizeof(float) * (size_t)nE,
+                   sizeof(int) * (size_t)(nMP + 1), sizeof(int) * (size_t)nE, sizeof(int) * kfEdges.size(), sizeof(int) * (size_t)nChunks,
+                   sizeof(int) * (size_t)nChunks, sizeof(int) * (size_t)nChunks, sizeof(int) * (size_t)nKF, sizeof(int) * (size_t)nI,
+                   sizeof(int) * (size_t)nI, sizeof(morb_imu_preintegrated) * (size_t)nI, (size_t)nI, (size_t)nMP, sizeof(float) * (size_t)nI,
+                   sizeof(float) * 21 * (size_t)nKF, sizeof(float) * 3 * (size_t)nMP,
+                   sizeof(double) * nS, sizeof(double) * nS, sizeof(double) * nPts, sizeof(double) * nPts, sizeof(double) * 3 * (size_t)nE,
+                   sizeof(double) * 9 * (size_t)nI1, sizeof(double) * 3 * (size_t)nI1, sizeof(double) * 3 * (size_t)nI1,
+                   sizeof(double) * 81 * (size_t)nI1, sizeof(double) * 9 * (size_t)nI1, sizeof(double) * 9 * (size_t)nI1,
+                   sizeof(double) * (size_t)P * P, sizeof(double) * (size_t)P * P, sizeof(double) * nX, sizeof(double) * (size_t)P,
+                   sizeof(double) * nX, sizeof(double) * 9 * (size_t)nMP, sizeof(double) * 18 * (size_t)nE, sizeof(double) * 4,
+                   sizeof(double) * 420 * (size_t)nI1, (size_t)nE})
+    reserve(b);
+  void* arena = nullptr;
+  { const int rc = morb_optimizer_workspace(o, arenaBytes, &arena); if (rc != MORB_OK) return rc; }
+  size_t arenaOff = 0;
+  auto dalloc = [&](size_t bytes) -> void* {
+    void* p = (char*)arena + arenaOff;
+    arenaOff += (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
+    return arenaOff <= arenaBytes ? p : nullptr;
+  };
+  auto cleanup = [&]() {};
   auto up = [&](const void* h, size_t bytes) -> void* { void* d = dalloc(bytes); if (d && bytes) (void)hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st); return d; };
   IbaDev D;
   memset(&D, 0, sizeof D);
@@ -1562,7 +1613,6 @@ int morb_local_inertial_ba(morb_optimizer* o, int nKF, float* kfState21, const u
   float* d_scale = (float*)up(iInfoScale, sizeof(float) * nI);
   float* d_kfIn = (float*)up(kfState21, sizeof(float) * 21 * nKF);
   float* d_mpIn = (float*)up(mpPos, sizeof(float) * 3 * nMP);
-  const size_t nS = (size_t)33 * nKF, nPts = (size_t)3 * nMP, nX = (size_t)P + 3 * nMP;
   D.S = (double*)dalloc(sizeof(double) * nS); double* Sbk = (double*)dalloc(sizeof(double) * nS);
   D.pts = (double*)dalloc(sizeof(double) * nPts); double* ptsBk = (double*)dalloc(sizeof(double) * nPts);
   D.vErr = (double*)dalloc(sizeof(double) * 3 * nE); D.iErr = (double*)dalloc(sizeof(double) * 9 * std::max(nI, 1));
@@ -1575,7 +1625,7 @@ int morb_local_inertial_ba(morb_optimizer* o, int nKF, float* kfState21, const u
   D.scal = (double*)dalloc(sizeof(double) * 4);
   double* scratch = (double*)dalloc(sizeof(double) * 420 * std::max(nI, 1));
   uint8_t* d_erase = (uint8_t*)dalloc(nE);
-  for (void* p : allocs) if (!p) { cleanup(); set_error("hipMalloc failed in morb_local_inertial_ba"); return MORB_ERR_HIP; }
+  MORB_REQUIRE(d_erase != nullptr && arenaOff <= arenaBytes, MORB_ERR_HIP, "workspace carve-up overflow in morb_local_inertial_ba");
   (void)hipMemsetAsync(D.x, 0, sizeof(double) * nX, st);   // the solver's x before the first solve
   for (int k = 0; k < 9; ++k) D.g.Rbc[k] = Tbc12[k];
   for (int k = 0; k < 3; ++k) D.g.tbc[k] = Tbc12[9 + k];
@@ -1601,6 +1651,9 @@ int morb_local_inertial_ba(morb_optimizer* o, int nKF, float* kfState21, const u
     if (hipMemcpyAsync(D.pts, pd.data(), sizeof(double) * nPts, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
       return fail("upload failed in morb_local_inertial_ba");
   }
+  const int Mpose = 6 * nOpt;
+  const size_t schurLds = sizeof(double) * ((size_t)Mpose * Mpose + Mpose);
+  const bool ldsSchur = schurLds <= 60 * 1024;   // larger windows accumulate in global memory
   double chi = 0;
   if (!errors(&chi)) return fail("k_iba_errors failed");
   const float err0 = (float)chi;
@@ -1618,7 +1671,7 @@ int morb_local_inertial_ba(morb_optimizer* o, int nKF, float* kfState21, const u
     (void)hipMemsetAsync(D.Hpl, 0, sizeof(double) * 18 * nE, st);
     hipLaunchKernelGGL(k_iba_points, dim3(div_up(nMP, 256)), dim3(256), 0, st, D);
     if (nChunks) hipLaunchKernelGGL(k_iba_kf, dim3(div_up(nChunks, 4)), dim3(256), 0, st, D);
-    if (nI) hipLaunchKernelGGL(k_iba_links, dim3(div_up(nI, 64)), dim3(64), 0, st, D, scratch);
+    if (nI) hipLaunchKernelGGL(k_iba_links, dim3(nI), dim3(64), 0, st, D);
     if (it == 0) { ni = 2; nBadIts = 0; }
     double rho = 0;
     int qmax = 0;
@@ -1626,8 +1679,9 @@ int morb_local_inertial_ba(morb_optimizer* o, int nKF, float* kfState21, const u
       (void)hipMemcpyAsync(Sbk, D.S, sizeof(double) * nS, hipMemcpyDeviceToDevice, st);
       (void)hipMemcpyAsync(ptsBk, D.pts, sizeof(double) * nPts, hipMemcpyDeviceToDevice, st);
       hipLaunchKernelGGL(k_iba_hs_init, dim3(div_up(P * P + P, 256)), dim3(256), 0, st, D, lambda);
-      hipLaunchKernelGGL(k_iba_schur, dim3(div_up(nMP, 256)), dim3(256), 0, st, D, lambda);
-      hipLaunchKernelGGL(k_iba_solve, dim3(1), dim3(1024), 0, st, D);
+      if (ldsSchur) hipLaunchKernelGGL(k_iba_schur<true>, dim3(div_up(nMP, 256)), dim3(256), schurLds, st, D, lambda);
+      else hipLaunchKernelGGL(k_iba_schur<false>, dim3(div_up(nMP, 256)), dim3(256), 0, st, D, lambda);
+      hipLaunchKernelGGL(k_iba_solve, dim3(1), dim3(1024), sizeof(double) * 2 * P, st, D);
       // a failed solve leaves x as it was (zero at the first trial): g2o still applies the update
       (void)hipMemsetAsync(D.scal, 0, sizeof(double) * 2, st);
       hipLaunchKernelGGL(k_iba_update, dim3(div_up(nMP + nKF, 256)), dim3(256), 0, st, D, lambda);

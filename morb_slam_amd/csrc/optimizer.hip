@@ -1364,6 +1364,8 @@ struct morb_optimizer {
   // complement / reduced right-hand side): fork-join on a side stream
   hipStream_t side = nullptr;
   hipEvent_t evFork = nullptr, evJoin = nullptr;
+  void* work = nullptr;        // grow-only device workspace of the one-shot entry points (morb_local_inertial_ba)
+  size_t workBytes = 0;
 };
 
 struct morb_ba_problem {
@@ -1407,6 +1409,18 @@ int morb_optimizer_create(morb_optimizer** out, int device) {
 
 int morb_optimizer_device(const morb_optimizer* o) { return o ? o->device : 0; }
 void* morb_optimizer_stream(const morb_optimizer* o) { return o ? (void*)o->stream : nullptr; }
+int morb_optimizer_workspace(morb_optimizer* o, size_t bytes, void** out) {
+  MORB_REQUIRE(o && out, MORB_ERR_INVALID, "NULL argument");
+  if (bytes > o->workBytes) {
+    MORB_HIP_CHECK(hipStreamSynchronize(o->stream));
+    if (o->work) MORB_HIP_CHECK(hipFree(o->work));
+    o->work = nullptr; o->workBytes = 0;
+    MORB_HIP_CHECK(hipMalloc(&o->work, bytes + bytes / 4));
+    o->workBytes = bytes + bytes / 4;
+  }
+  *out = o->work;
+  return MORB_OK;
+}
 
 void morb_optimizer_destroy(morb_optimizer* o) {
   if (!o) return;
@@ -1415,6 +1429,7 @@ void morb_optimizer_destroy(morb_optimizer* o) {
   if (o->side) { (void)hipStreamSynchronize(o->side); (void)hipStreamDestroy(o->side); }
   if (o->evFork) (void)hipEventDestroy(o->evFork);
   if (o->evJoin) (void)hipEventDestroy(o->evJoin);
+  if (o->work) (void)hipFree(o->work);
   (void)hipStreamDestroy(o->stream);
   delete o;
 }
