@@ -179,7 +179,23 @@ def optimizer_extras(dev_index):
     inertial = {"frame_pairs": FI, "edges_per_frame": 600, "imu_samples_per_interval": 20,
                 "stages": ["PreintegrateIMU x3", "PoseInertialOptimizationLastKeyFrame", "PoseInertialOptimizationLastFrame"],
                 "ms_per_batch": dti * 1e3, "frame_pairs_per_s": FI / dti, "cpu_oracle_frame_pairs_per_s_1core": 1.0 / dci}
-    return {"pose_inertial_tracking": inertial,
+    # LocalInertialBA: 10-keyframe window + 6 fixed keyframes, 3000 points (one-shot call incl. graph upload)
+    from morb_slam_amd.synth import make_inertial_ba_problem
+    pi = make_inertial_ba_problem(n_opt=10, seed=1, n_points=3000)
+    prei = np.stack([O.imu_preintegrate(pi["bias"], nga, walk, pi["acc"][a:b_], pi["gyro"][a:b_], pi["dt"][a:b_])
+                     for a, b_ in zip(pi["imuStart"][:-1], pi["imuStart"][1:])])
+    iargs = (pi["kfState"], pi["kfKind"], pi["mpPos"], pi["mpClose"], pi["eKF"], pi["eMP"], pi["eObs"], pi["eInvSigma2"], pi["iKF1"],
+             pi["iKF2"], prei, pi["iRobust"], pi["iInfoScale"], pi["cam"], pi["Tbc12"])
+    opt.LocalInertialBA(*iargs)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        _, _, _, sti = opt.LocalInertialBA(*iargs)
+    dtl = (time.perf_counter() - t0) / 5
+    t0 = time.perf_counter(); ro = O.local_inertial_ba(pi, prei); dcl = time.perf_counter() - t0
+    inertial_ba = {"keyframes_opt_fixed": [10, 7], "points": 3000, "edges": int(len(pi["eKF"])), "inertial_links": 10,
+                   "outer_lm_iters": int(sti[0]), "lm_trials": int(sti[1]), "ms_per_solve": dtl * 1e3,
+                   "lm_iters_per_s": float(sti[0] / dtl), "cpu_oracle_lm_iters_per_s": float(ro[4][0] / dcl)}
+    return {"pose_inertial_tracking": inertial, "local_inertial_ba": inertial_ba,
             "local_ba": {"edges": int(len(b["eKF"])), "keyframes_free_fixed": [20, 6], "points": 3000,
                          "outer_lm_iters": int(st[0]), "lm_trials": int(st[1]), "ms_per_solve": dt * 1e3,
                          "lm_iters_per_s": float(st[0] / dt), "cpu_oracle_lm_iters_per_s": float(its / dc)},

@@ -467,3 +467,26 @@ def test_inertial_oracle_recovers_generating_motion():
     assert r == int(p["hasMP"].sum()) - int(outl.sum())
     H = prior[21:].reshape(15, 15)
     assert np.allclose(H, H.T, rtol=1e-9, atol=1e-9 * np.abs(H).max()) and np.all(np.linalg.eigvalsh(H) > 0)
+
+
+def test_local_inertial_ba_oracle_converges():
+    """N1 (parity unpinned): the restated LocalInertialBA pulls a perturbed window back onto the generating trajectory,
+    keeps fixed keyframes fixed and erases the planted gross outliers."""
+    import oracle_lib as orc
+    from morb_slam_amd.synth import imu_calib_diagonals, make_inertial_ba_problem
+    nga, walk = imu_calib_diagonals()
+    p = make_inertial_ba_problem(n_opt=6, n_points=500, seed=2)
+    pre = np.stack([orc.imu_preintegrate(p["bias"], nga, walk, p["acc"][a:b], p["gyro"][a:b], p["dt"][a:b])
+                    for a, b in zip(p["imuStart"][:-1], p["imuStart"][1:])])
+    r, kf, mp, erase, stats = orc.local_inertial_ba(p, pre)
+    assert r == 1 and 1 <= stats[0] <= 10 and stats[1] >= stats[0]
+    optk = p["kfKind"] == 0
+    assert np.array_equal(kf[~optk], p["kfState"][~optk])
+
+    def ang(a, b):
+        return np.degrees(np.arccos(np.clip((np.trace(a.reshape(3, 3).T @ b.reshape(3, 3)) - 1) / 2, -1, 1)))
+    a0 = max(ang(p["kfState"][k, :9], p["true"][k, :9]) for k in np.where(optk)[0])
+    a1 = max(ang(kf[k, :9], p["true"][k, :9]) for k in np.where(optk)[0])
+    assert a1 < 0.15 * a0
+    assert np.abs(kf[optk, 9:12] - p["true"][optk, 9:12]).max() < 0.2 * np.abs(p["kfState"][optk, 9:12] - p["true"][optk, 9:12]).max()
+    assert 0.01 < erase.mean() < 0.15
