@@ -449,7 +449,7 @@ int morb_imu_preintegrate_batch(morb_optimizer*, int nseq, const int* d_start, c
  * d_state in/out = the frame (GetImuRotation / GetImuPosition / GetVelocity / mImuBias -> SetImuPoseVelocity, mImuBias).
  * Tbc12 (HOST) = mImuCalib.mTbc rotation (9) + translation (3); d_pre[f] = pFrame->mpImuPreintegrated.
  * d_nInliers[f] = the return value; d_prior (optional) [nframes][246] doubles = pFrame->mpcpi (ConstraintPoseImu): the
- * 21 state values in FP64 followed by the 15 x 15 H (after the constructor's eigenvalue clamp), row-major.  Pinhole camera 0 only (no second fisheye camera yet). */
+ * 21 state values in FP64 followed by the 15 x 15 H (after the constructor's eigenvalue clamp), row-major.  One pinhole camera; the _fisheye forms below take a KannalaBrandt8 rig. */
 int morb_pose_inertial_optimization_last_keyframe_batch(morb_optimizer*, int nframes, int cap, const int* d_count,
                                                         const uint8_t* d_hasMP, const float* d_obs, const float* d_invSigma2,
                                                         const float* d_Xw, const uint8_t* d_close, float fx, float fy, float cx,
@@ -481,12 +481,36 @@ int morb_pose_inertial_optimization_last_frame_batch(morb_optimizer*, int nframe
  * link also carries EdgeGyroRW / EdgeAccRW.  bLarge selects 4 iterations / lambda 1e-2 instead of 10 / 1.
  * Outputs: kfState21 (optimizable keyframes) and mpPos in place, eraseFlag[e] = 1 where the reference erases the
  * observation (:2773-2826), stats3 = {outer LM iterations, LM trials, ok} with ok = 0 for "FAIL LOCAL-INERTIAL BA"
- * (nothing written back).  Pinhole camera 0 only. */
+ * (nothing written back).  One pinhole camera; morb_local_inertial_ba_fisheye for a KB8 rig. */
 int morb_local_inertial_ba(morb_optimizer*, int nKF, float* kfState21, const uint8_t* kfKind, int nMP, float* mpPos,
                            const uint8_t* mpClose, int nE, const int* eKF, const int* eMP, const float* eObs, const float* eInvSigma2,
                            int nI, const int* iKF1, const int* iKF2, const morb_imu_preintegrated* iPre, const uint8_t* iRobust,
                            const float* iInfoScale, float fx, float fy, float cx, float cy, float bf, const float* Tbc12, int bLarge,
                            uint8_t* eraseFlag, int* stats3);
+
+/* The three inertial optimisers on a fisheye rig (pFrame->mpCamera2 / pKFi->mpCamera2: Optimizer.cc:4453-4528, :2722-2754;
+ * ImuCamPose with two cameras, G2oTypes.cc:96-113).  rig28 (HOST) = left KannalaBrandt8 parameters (8), right ones (8), the
+ * rotation (9, row-major) and translation (3) of Frame::GetRelativePoseTrl().  Every observation is monocular: features
+ * [0, d_nLeft[f]) / edges with eRight[e] == 0 on the left camera (EdgeMonoOnlyPose(Xw, 0) / EdgeMono(0), mvKeys), the rest on
+ * the right camera (cam_idx 1, mvKeysRight); d_obs / eObs = (x, y, unused).  Other arguments as the pinhole forms. */
+int morb_pose_inertial_optimization_last_keyframe_fisheye_batch(morb_optimizer*, int nframes, int cap, const int* d_count, const int* d_nLeft,
+                                                                const uint8_t* d_hasMP, const float* d_obs, const float* d_invSigma2,
+                                                                const float* d_Xw, const uint8_t* d_close, const float* rig28,
+                                                                const float* Tbc12, const float* d_kfState,
+                                                                const morb_imu_preintegrated* d_pre, int bRecInit, float* d_state,
+                                                                uint8_t* d_outlier, int* d_nInliers, double* d_prior, void* stream);
+int morb_pose_inertial_optimization_last_frame_fisheye_batch(morb_optimizer*, int nframes, int cap, const int* d_count, const int* d_nLeft,
+                                                             const uint8_t* d_hasMP, const float* d_obs, const float* d_invSigma2,
+                                                             const float* d_Xw, const uint8_t* d_close, const float* rig28, const float* Tbc12,
+                                                             const float* d_prevState, const morb_imu_preintegrated* d_preFrame,
+                                                             const morb_imu_preintegrated* d_preKF, const double* d_prevPrior, int bRecInit,
+                                                             float* d_state, uint8_t* d_outlier, int* d_nInliers, double* d_prior,
+                                                             void* stream);
+int morb_local_inertial_ba_fisheye(morb_optimizer*, int nKF, float* kfState21, const uint8_t* kfKind, int nMP, float* mpPos,
+                                   const uint8_t* mpClose, int nE, const int* eKF, const int* eMP, const float* eObs, const uint8_t* eRight,
+                                   const float* eInvSigma2, int nI, const int* iKF1, const int* iKF2, const morb_imu_preintegrated* iPre,
+                                   const uint8_t* iRobust, const float* iInfoScale, const float* rig28, const float* Tbc12, int bLarge,
+                                   uint8_t* eraseFlag, int* stats3);
 
 /* static void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF,
  * int& num_OptKF, int& num_MPs, int& num_edges)  Optimizer.h:67-69, Optimizer.cc:1053-1441, on the graph the

@@ -137,6 +137,11 @@ def lib():
         L.morb_pose_inertial_optimization_last_frame_batch.argtypes = [vp, i, i, vp, vp, vp, vp, vp, vp, f, f, f, f, f, vp, vp, vp, vp, vp,
                                                                        i, vp, vp, vp, vp, vp]
         L.morb_local_inertial_ba.argtypes = [vp, i, vp, vp, i, vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, f, f, f, f, f, vp, i, vp, vp]
+        L.morb_pose_inertial_optimization_last_keyframe_fisheye_batch.argtypes = [vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i,
+                                                                                  vp, vp, vp, vp, vp]
+        L.morb_pose_inertial_optimization_last_frame_fisheye_batch.argtypes = [vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i,
+                                                                               vp, vp, vp, vp, vp]
+        L.morb_local_inertial_ba_fisheye.argtypes = [vp, i, vp, vp, i, vp, vp, i, vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, i, vp, vp]
         L.morb_pose_optimization_fisheye_batch.argtypes = [vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.morb_ba_problem_create_fisheye.argtypes = [vp, C.POINTER(vp), i, vp, vp, i, vp, i, vp, vp, vp, vp, vp, vp, vp, vp, i]
         L.morb_local_bundle_adjustment.argtypes = [vp, i, vp, vp, i, vp, i, vp, vp, vp, vp, f, f, f, f, f, i, vp, vp, vp]

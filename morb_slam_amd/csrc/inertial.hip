@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.h"
+#include "kb8.h"
 #include "wave.h"
 
 using namespace morb;
@@ -372,11 +373,20 @@ __device__ bool wave_ldlt_solve(const double* H, int ld, const double* rhs, doub
   return true;
 }
 
-struct CamGeom { double Rcb[9], tcb[3], Rbc[9], tbc[3], bf; float fx, fy, cx, cy; };
+// camera 0 = the pinhole camera, or on a fisheye rig (rig != 0) the left KannalaBrandt8 camera with camera 1 = the right one
+// (ImuCamPose, G2oTypes.cc:74-118: Rcb[1] = Rrl Rcb[0], tcb[1] = Rrl tcb[0] + trl)
+struct CamGeom {
+  double Rcb[9], tcb[3], Rbc[9], tbc[3], bf;
+  float fx, fy, cx, cy;
+  int rig;
+  float kb[2][8];
+  double Rcb1[9], tcb1[3], Rbc1[9], tbc1[3];
+};
 
 struct VIState {
   double Rwb[9], twb[3], v[3], bg[3], ba[3];
   double Rcw[9], tcw[3];
+  double Rcw1[9], tcw1[3];   // right camera of a rig
 };
 __device__ void load_state(const CamGeom& g, const float* s0, VIState& S);
 __device__ void refresh_camera(const CamGeom& g, VIState& S) {   // G2oTypes.cc:209-215
@@ -387,6 +397,11 @@ __device__ void refresh_camera(const CamGeom& g, VIState& S) {   // G2oTypes.cc:
   mul33(g.Rcb, Rbw, S.Rcw);
   mul3v(g.Rcb, tbw, S.tcw);
   for (int k = 0; k < 3; ++k) S.tcw[k] += g.tcb[k];
+  if (g.rig) {
+    mul33(g.Rcb1, Rbw, S.Rcw1);
+    mul3v(g.Rcb1, tbw, S.tcw1);
+    for (int k = 0; k < 3; ++k) S.tcw1[k] += g.tcb1[k];
+  }
 }
 __device__ void load_state(const CamGeom& g, const float* s0, VIState& S) {
   for (int k = 0; k < 9; ++k) S.Rwb[k] = s0[k];
@@ -404,22 +419,30 @@ __device__ void apply_update(const CamGeom& g, VIState& S, const double* x) {   
 }
 // visual edge: error (obs - projection) and chi2; st = stereo
 __device__ __forceinline__ double vis_error(const CamGeom& g, const VIState& S, const double* X, const float* o, bool st, double info,
-                                            double* err, double* Xc) {
-  mul3v(S.Rcw, X, Xc);
-  for (int k = 0; k < 3; ++k) Xc[k] += S.tcw[k];
-  const double u = g.fx * Xc[0] / Xc[2] + g.cx, v = g.fy * Xc[1] / Xc[2] + g.cy;   // Pinhole.cpp:38-44
+                                            double* err, double* Xc, int cam = 0) {
+  mul3v(cam ? S.Rcw1 : S.Rcw, X, Xc);
+  for (int k = 0; k < 3; ++k) Xc[k] += (cam ? S.tcw1 : S.tcw)[k];
+  double u, v;
+  if (g.rig) { double uv[2]; morbkb8::kb8_project_d(g.kb[cam], Xc, uv); u = uv[0]; v = uv[1]; }   // KannalaBrandt8::project(Vector3d)
+  else { u = g.fx * Xc[0] / Xc[2] + g.cx; v = g.fy * Xc[1] / Xc[2] + g.cy; }                       // Pinhole.cpp:38-44
   err[0] = (double)o[0] - u; err[1] = (double)o[1] - v; err[2] = 0;
   double c = err[0] * info * err[0] + err[1] * info * err[1];
   if (st) { const double invZ = 1 / Xc[2]; err[2] = (double)o[2] - (u - g.bf * invZ); c += err[2] * info * err[2]; }
   return c;
 }
-__device__ __forceinline__ void vis_jacobian(const CamGeom& g, const double* Xc, bool st, double* J /*[3][6]*/) {   // G2oTypes.cc:361-442
-  double Xb[3];
-  mul3v(g.Rbc, Xc, Xb);
-  for (int k = 0; k < 3; ++k) Xb[k] += g.tbc[k];
-  double pj[9];
+// projectJac of the edge's camera (2 x 3 in pj[0..5]); pinhole: Pinhole.cpp:76-86
+__device__ __forceinline__ void cam_project_jac(const CamGeom& g, const double* Xc, int cam, double* pj) {
+  if (g.rig) { morbkb8::kb8_project_jac(g.kb[cam], Xc, pj); return; }
   pj[0] = g.fx / Xc[2]; pj[1] = 0; pj[2] = -g.fx * Xc[0] / (Xc[2] * Xc[2]);
   pj[3] = 0; pj[4] = g.fy / Xc[2]; pj[5] = -g.fy * Xc[1] / (Xc[2] * Xc[2]);
+}
+__device__ __forceinline__ void vis_jacobian(const CamGeom& g, const double* Xc, bool st, double* J /*[3][6]*/, int cam = 0) {   // G2oTypes.cc:361-442
+  double Xb[3];
+  mul3v(cam ? g.Rbc1 : g.Rbc, Xc, Xb);
+  for (int k = 0; k < 3; ++k) Xb[k] += (cam ? g.tbc1 : g.tbc)[k];
+  const double* Rcb = cam ? g.Rcb1 : g.Rcb;
+  double pj[9];
+  cam_project_jac(g, Xc, cam, pj);
   pj[6] = pj[7] = pj[8] = 0;
   if (st) { pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + g.bf * (1.0 / (Xc[2] * Xc[2])); }
   const double x = Xb[0], y = Xb[1], z = Xb[2];
@@ -428,7 +451,7 @@ __device__ __forceinline__ void vis_jacobian(const CamGeom& g, const double* Xc,
   for (int r = 0; r < 3; ++r) {
     double PR[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) PR[c] = pj[r * 3] * g.Rcb[c] + pj[r * 3 + 1] * g.Rcb[3 + c] + pj[r * 3 + 2] * g.Rcb[6 + c];
+    for (int c = 0; c < 3; ++c) PR[c] = pj[r * 3] * Rcb[c] + pj[r * 3 + 1] * Rcb[3 + c] + pj[r * 3 + 2] * Rcb[6 + c];
 #pragma unroll
     for (int c = 0; c < 6; ++c) J[r * 6 + c] = PR[0] * Sd[c] + PR[1] * Sd[6 + c] + PR[2] * Sd[12 + c];
   }
@@ -572,8 +595,8 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
                                                        CamGeom g, const float* __restrict__ state1,
                                                        const morb_imu_preintegrated* __restrict__ pre,
                                                        const morb_imu_preintegrated* __restrict__ preKF,
-                                                       const double* __restrict__ prevPrior, int bRecInit,
-                                                       float* __restrict__ stateIO, uint8_t* __restrict__ outlier,
+                                                       const double* __restrict__ prevPrior, const int* __restrict__ nLeft,
+                                                       int bRecInit, float* __restrict__ stateIO, uint8_t* __restrict__ outlier,
                                                        int* __restrict__ nInliersOut, double* __restrict__ prior) {
   __shared__ InertialWork Wk;
   constexpr int NV = LASTFRAME ? 30 : 15;
@@ -585,6 +608,7 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   const morb_imu_preintegrated& P = pre[f];
   const double* pr = LASTFRAME ? prevPrior + (size_t)246 * f : nullptr;
+  const int nL = g.rig ? nLeft[f] : n;   // fisheye rig: features >= nL are right-camera observations; every edge is monocular
 
   int nInit = 0;
   for (int i = tid; i < n; i += 256) if (hasMP[base + i]) { ++nInit; outlier[base + i] = 0; }
@@ -644,13 +668,14 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
         for (int i = tid; i < n; i += NVIS) {
           if (!hasMP[base + i] || outlier[base + i]) continue;
           const float* o = obs + (base + i) * 3;
-          const bool st = !(o[2] < 0);
+          const bool st = !g.rig && !(o[2] < 0);
+          const int cam = i >= nL ? 1 : 0;
           const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
           const double info = (double)invSigma2[base + i];
           double err[3], Xc[3], J[18];
-          const double c = vis_error(g, S, X, o, st, info, err, Xc);
+          const double c = vis_error(g, S, X, o, st, info, err, Xc, cam);
           const double w = robust ? huber_w(st ? deltaStereo : deltaMono, c) : 1.0;
-          vis_jacobian(g, Xc, st, J);   // a mono edge has a zero third row and err[2] = 0: one fully unrolled 3-row form (registers only)
+          vis_jacobian(g, Xc, st, J, cam);   // a mono edge has a zero third row and err[2] = 0: one fully unrolled 3-row form (registers only)
           int q = 0;
 #pragma unroll
           for (int r = 0; r < 6; ++r) {
@@ -762,15 +787,17 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
     for (int i = tid; i < n; i += 256) {
       if (!hasMP[base + i]) continue;
       const float* o = obs + (base + i) * 3;
-      const bool st = !(o[2] < 0);
+      const bool st = !g.rig && !(o[2] < 0);
+      const int cam = i >= nL ? 1 : 0;
       const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
       double err[3], Xc[3];
-      const float chi2 = (float)vis_error(g, outlier[base + i] ? S : Sprev, X, o, st, (double)invSigma2[base + i], err, Xc);
+      const float chi2 = (float)vis_error(g, outlier[base + i] ? S : Sprev, X, o, st, (double)invSigma2[base + i], err, Xc, cam);
       bool isOut;
       if (st) isOut = chi2 > chi2Stereo[it];
       else {
         const bool bClose = closeFlag[base + i] != 0;
-        const bool depthPos = (S.Rcw[6] * X[0] + S.Rcw[7] * X[1] + S.Rcw[8] * X[2] + S.tcw[2]) > 0.0;
+        const double* Rc = cam ? S.Rcw1 : S.Rcw;
+        const bool depthPos = (Rc[6] * X[0] + Rc[7] * X[1] + Rc[8] * X[2] + (cam ? S.tcw1 : S.tcw)[2]) > 0.0;
         isOut = (chi2 > cm && !bClose) || (bClose && chi2 > chi2close) || !depthPos;
       }
       outlier[base + i] = isOut ? 1 : 0;
@@ -793,10 +820,10 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
     for (int i = tid; i < n; i += 256) {
       if (!hasMP[base + i]) continue;
       const float* o = obs + (base + i) * 3;
-      const bool st = !(o[2] < 0);
+      const bool st = !g.rig && !(o[2] < 0);
       const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
       double err[3], Xc[3];
-      const float chi2 = (float)vis_error(g, S, X, o, st, (double)invSigma2[base + i], err, Xc);
+      const float chi2 = (float)vis_error(g, S, X, o, st, (double)invSigma2[base + i], err, Xc, i >= nL ? 1 : 0);
       if (chi2 < (st ? 24.f : 18.f)) outlier[base + i] = 0; else ++bad;
     }
     bad = (int)wave_sum((double)bad);
@@ -823,12 +850,13 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
   for (int i = tid; i < n; i += 256) {
     if (!hasMP[base + i] || outlier[base + i]) continue;
     const float* o = obs + (base + i) * 3;
-    const bool st = !(o[2] < 0);
+    const bool st = !g.rig && !(o[2] < 0);
+    const int cam = i >= nL ? 1 : 0;
     const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
     const double info = (double)invSigma2[base + i];
     double err[3], Xc[3], J[18];
-    vis_error(g, S, X, o, st, info, err, Xc);
-    vis_jacobian(g, Xc, st, J);
+    vis_error(g, S, X, o, st, info, err, Xc, cam);
+    vis_jacobian(g, Xc, st, J, cam);
     int q = 0;
 #pragma unroll
     for (int r = 0; r < 6; ++r)
@@ -1009,6 +1037,7 @@ struct IbaDev {
   const morb_imu_preintegrated* iPre;
   const uint8_t* iRobust;
   const uint8_t* mpClose;
+  const uint8_t* eRight;                        // fisheye rig: edge on the right camera (NULL: pinhole)
   double* S;                                    // [nKF][33]: Rwb twb v bg ba | Rcw tcw
   double* pts;                                  // [nMP][3]
   double *vErr, *iErr, *gErr, *aErr;            // errors of the last computeActiveErrors
@@ -1017,9 +1046,10 @@ struct IbaDev {
   double* scal;                                 // [0] robust chi2, [1] scale, [2] solve ok
   CamGeom g;
 };
-__device__ __forceinline__ void iba_load(const double* s, VIState& V) {
+__device__ __forceinline__ void iba_load(const CamGeom& g, const double* s, VIState& V) {
   for (int k = 0; k < 9; ++k) { V.Rwb[k] = s[k]; V.Rcw[k] = s[21 + k]; }
   for (int k = 0; k < 3; ++k) { V.twb[k] = s[9 + k]; V.v[k] = s[12 + k]; V.bg[k] = s[15 + k]; V.ba[k] = s[18 + k]; V.tcw[k] = s[30 + k]; }
+  if (g.rig) refresh_camera(g, V);   // the right camera's pose is derived, not stored
 }
 __device__ __forceinline__ void iba_store(const VIState& V, double* s) {
   for (int k = 0; k < 9; ++k) { s[k] = V.Rwb[k]; s[21 + k] = V.Rcw[k]; }
@@ -1082,20 +1112,20 @@ __global__ __launch_bounds__(256) void k_iba_errors(IbaDev D) {
   double c = 0;
   if (t < D.nE) {
     VIState V;
-    iba_load(D.S + 33 * (size_t)D.eKF[t], V);
+    iba_load(D.g, D.S + 33 * (size_t)D.eKF[t], V);
     const float* o = D.eObs + 3 * (size_t)t;
-    const bool st = !(o[2] < 0);
+    const bool st = !D.g.rig && !(o[2] < 0);
     const double* Xp = D.pts + 3 * (size_t)D.eMP[t];
     const double X[3] = {Xp[0], Xp[1], Xp[2]};
     double err[3], Xc[3];
-    const double chi = vis_error(D.g, V, X, o, st, (double)D.eInfo[t], err, Xc);
+    const double chi = vis_error(D.g, V, X, o, st, (double)D.eInfo[t], err, Xc, D.eRight && D.eRight[t] ? 1 : 0);
     for (int k = 0; k < 3; ++k) D.vErr[3 * (size_t)t + k] = err[k];
     c = huber_rho(st ? deltaStereo : deltaMono, chi);
   } else if (t - D.nE < D.nI) {
     const int i = t - D.nE;
     VIState V1, V2;
-    iba_load(D.S + 33 * (size_t)D.iKF1[i], V1);
-    iba_load(D.S + 33 * (size_t)D.iKF2[i], V2);
+    iba_load(D.g, D.S + 33 * (size_t)D.iKF1[i], V1);
+    iba_load(D.g, D.S + 33 * (size_t)D.iKF2[i], V2);
     double err[9];
     inertial_edge(D.iPre[i], V1, V2, nullptr, true, err, nullptr);
     double ge[3], ae[3];
@@ -1116,24 +1146,27 @@ __global__ __launch_bounds__(256) void k_iba_points(IbaDev D) {
   const double X[3] = {D.pts[3 * (size_t)l], D.pts[3 * (size_t)l + 1], D.pts[3 * (size_t)l + 2]};
   for (int k = D.ptStart[l]; k < D.ptStart[l + 1]; ++k) {
     const int e = D.ptEdges[k];
-    const double* s = D.S + 33 * (size_t)D.eKF[e];
+    VIState V;
+    iba_load(D.g, D.S + 33 * (size_t)D.eKF[e], V);
+    const int cam = D.eRight && D.eRight[e] ? 1 : 0;
+    const double* Rc = cam ? V.Rcw1 : V.Rcw;
+    const double* tc = cam ? V.tcw1 : V.tcw;
     const float* o = D.eObs + 3 * (size_t)e;
-    const bool st = !(o[2] < 0);
+    const bool st = !D.g.rig && !(o[2] < 0);
     const double info = (double)D.eInfo[e];
     const double w = huber_w(st ? deltaStereo : deltaMono, iba_vis_chi2(D, e));
     double Xc[3];
-    for (int r = 0; r < 3; ++r) Xc[r] = s[21 + r * 3] * X[0] + s[22 + r * 3] * X[1] + s[23 + r * 3] * X[2] + s[30 + r];
+    for (int r = 0; r < 3; ++r) Xc[r] = Rc[r * 3] * X[0] + Rc[r * 3 + 1] * X[1] + Rc[r * 3 + 2] * X[2] + tc[r];
     // -proj_jac * Rcw (G2oTypes.cc:334-415)
     double pj[9];
-    pj[0] = D.g.fx / Xc[2]; pj[1] = 0; pj[2] = -D.g.fx * Xc[0] / (Xc[2] * Xc[2]);
-    pj[3] = 0; pj[4] = D.g.fy / Xc[2]; pj[5] = -D.g.fy * Xc[1] / (Xc[2] * Xc[2]);
+    cam_project_jac(D.g, Xc, cam, pj);
     pj[6] = pj[7] = pj[8] = 0;
     if (st) { pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + D.g.bf * (1.0 / (Xc[2] * Xc[2])); }
     double Jl[9];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) Jl[r * 3 + c] = -(pj[r * 3] * s[21 + c] + pj[r * 3 + 1] * s[24 + c] + pj[r * 3 + 2] * s[27 + c]);
+      for (int c = 0; c < 3; ++c) Jl[r * 3 + c] = -(pj[r * 3] * Rc[c] + pj[r * 3 + 1] * Rc[3 + c] + pj[r * 3 + 2] * Rc[6 + c]);
     const double* er = D.vErr + 3 * (size_t)e;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -1160,7 +1193,7 @@ __global__ __launch_bounds__(256) void k_iba_kf(IbaDev D) {
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   const int kf = D.chunkKF[c];
   VIState V;
-  iba_load(D.S + 33 * (size_t)kf, V);
+  iba_load(D.g, D.S + 33 * (size_t)kf, V);
   double acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0;
@@ -1168,24 +1201,25 @@ __global__ __launch_bounds__(256) void k_iba_kf(IbaDev D) {
   if (k < D.chunkEnd[c]) {
     const int e = D.kfEdges[k];
     const float* o = D.eObs + 3 * (size_t)e;
-    const bool st = !(o[2] < 0);
+    const bool st = !D.g.rig && !(o[2] < 0);
+    const int cam = D.eRight && D.eRight[e] ? 1 : 0;
+    const double* Rc = cam ? V.Rcw1 : V.Rcw;
     const double info = (double)D.eInfo[e];
     const double w = huber_w(st ? deltaStereo : deltaMono, iba_vis_chi2(D, e));
     const double* Xp = D.pts + 3 * (size_t)D.eMP[e];
     const double X[3] = {Xp[0], Xp[1], Xp[2]};
     double Xc[3], Jp[18], Jl[9];
-    mul3v(V.Rcw, X, Xc);
-    for (int r = 0; r < 3; ++r) Xc[r] += V.tcw[r];
-    vis_jacobian(D.g, Xc, st, Jp);
+    mul3v(Rc, X, Xc);
+    for (int r = 0; r < 3; ++r) Xc[r] += (cam ? V.tcw1 : V.tcw)[r];
+    vis_jacobian(D.g, Xc, st, Jp, cam);
     double pj[9];
-    pj[0] = D.g.fx / Xc[2]; pj[1] = 0; pj[2] = -D.g.fx * Xc[0] / (Xc[2] * Xc[2]);
-    pj[3] = 0; pj[4] = D.g.fy / Xc[2]; pj[5] = -D.g.fy * Xc[1] / (Xc[2] * Xc[2]);
+    cam_project_jac(D.g, Xc, cam, pj);
     pj[6] = pj[7] = pj[8] = 0;
     if (st) { pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + D.g.bf * (1.0 / (Xc[2] * Xc[2])); }
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc) Jl[r * 3 + cc] = -(pj[r * 3] * V.Rcw[cc] + pj[r * 3 + 1] * V.Rcw[3 + cc] + pj[r * 3 + 2] * V.Rcw[6 + cc]);
+      for (int cc = 0; cc < 3; ++cc) Jl[r * 3 + cc] = -(pj[r * 3] * Rc[cc] + pj[r * 3 + 1] * Rc[3 + cc] + pj[r * 3 + 2] * Rc[6 + cc]);
     const double* er = D.vErr + 3 * (size_t)e;
     int q = 0;
 #pragma unroll
@@ -1237,8 +1271,8 @@ __global__ __launch_bounds__(64) void k_iba_links(IbaDev D) {
   const double* Om = D.InfoI + (size_t)i * 81;
   if (tid == 0) {
     VIState V1, V2;
-    iba_load(D.S + 33 * (size_t)k1, V1);
-    iba_load(D.S + 33 * (size_t)k2, V2);
+    iba_load(D.g, D.S + 33 * (size_t)k1, V1);
+    iba_load(D.g, D.S + 33 * (size_t)k2, V2);
     double errNow[9];
     inertial_edge(D.iPre[i], V1, V2, nullptr, true, errNow, J);
     sw = D.iRobust[i] ? huber_w(sqrt(16.92), iba_quad(er, Om, 9)) : 1.0;
@@ -1441,7 +1475,7 @@ __global__ __launch_bounds__(256) void k_iba_update(IbaDev D, double lambda) {
     const int c = D.col[k];
     if (c >= 0) {
       VIState V;
-      iba_load(D.S + 33 * (size_t)k, V);
+      iba_load(D.g, D.S + 33 * (size_t)k, V);
       double dx[15];
       for (int q = 0; q < 15; ++q) { dx[q] = D.x[15 * c + q]; sc += dx[q] * (lambda * dx[q] + D.b[15 * c + q]); }
       apply_update(D.g, V, dx);
@@ -1455,15 +1489,18 @@ __global__ __launch_bounds__(256) void k_iba_finish(IbaDev D, uint8_t* __restric
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t < D.nE) {
     const float* o = D.eObs + 3 * (size_t)t;
-    const bool st = !(o[2] < 0);
+    const bool st = !D.g.rig && !(o[2] < 0);
     const double c = iba_vis_chi2(D, t);
     bool er;
     if (st) er = c > (double)7.815f;
     else {
       const bool bClose = D.mpClose[D.eMP[t]] != 0;
-      const double* s = D.S + 33 * (size_t)D.eKF[t];
+      VIState V;
+      iba_load(D.g, D.S + 33 * (size_t)D.eKF[t], V);
+      const int cam = D.eRight && D.eRight[t] ? 1 : 0;
+      const double* Rc = cam ? V.Rcw1 : V.Rcw;
       const double* X = D.pts + 3 * (size_t)D.eMP[t];
-      const bool depthPos = (s[27] * X[0] + s[28] * X[1] + s[29] * X[2] + s[32]) > 0.0;
+      const bool depthPos = (Rc[6] * X[0] + Rc[7] * X[1] + Rc[8] * X[2] + (cam ? V.tcw1 : V.tcw)[2]) > 0.0;
       er = (c > (double)5.991f && !bClose) || (c > (double)(1.5f * 5.991f) && bClose) || !depthPos;
     }
     erase[t] = er ? 1 : 0;
@@ -1492,30 +1529,50 @@ int morb_imu_preintegrate_batch(morb_optimizer* o, int nseq, const int* d_start,
   return MORB_OK;
 }
 
-static int launch_pose_inertial(bool lastFrame, morb_optimizer* o, int nframes, int cap, const int* d_count, const uint8_t* d_hasMP,
-                                const float* d_obs, const float* d_invSigma2, const float* d_Xw, const uint8_t* d_close, float fx,
-                                float fy, float cx, float cy, float bf, const float* Tbc12, const float* d_state1,
-                                const morb_imu_preintegrated* d_pre, const morb_imu_preintegrated* d_preKF,
-                                const double* d_prevPrior, int bRecInit, float* d_state, uint8_t* d_outlier, int* d_nInliers,
-                                double* d_prior, void* stream) {
-  MORB_REQUIRE(o && d_hasMP && d_obs && d_invSigma2 && d_Xw && d_close && Tbc12 && d_state1 && d_pre && d_state && d_outlier && d_nInliers,
-               MORB_ERR_INVALID, "NULL argument");
-  MORB_REQUIRE(!lastFrame || (d_preKF && d_prevPrior), MORB_ERR_INVALID, "NULL argument");
-  MORB_REQUIRE(nframes > 0 && cap > 0, MORB_ERR_INVALID, "bad sizes");
-  MORB_HIP_CHECK(hipSetDevice(morb_optimizer_device(o)));
-  hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_optimizer_stream(o);
-  CamGeom g;
+// ImuCamPose's constant part: Tcb = Tbc^-1 and, on a fisheye rig, the right camera behind Trl (G2oTypes.cc:96-113).
+// rig28 = left KB8 (8), right KB8 (8), Trl rotation (9, row-major) + translation (3), or NULL for one pinhole camera.
+static void make_geom(const float* Tbc12, float fx, float fy, float cx, float cy, float bf, const float* rig28, CamGeom& g) {
+  memset(&g, 0, sizeof g);
   for (int k = 0; k < 9; ++k) g.Rbc[k] = Tbc12[k];
   for (int k = 0; k < 3; ++k) g.tbc[k] = Tbc12[9 + k];
   for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) g.Rcb[r * 3 + c] = g.Rbc[c * 3 + r];   // mTcb = mTbc.inverse()
   for (int r = 0; r < 3; ++r) g.tcb[r] = -(g.Rcb[r * 3] * g.tbc[0] + g.Rcb[r * 3 + 1] * g.tbc[1] + g.Rcb[r * 3 + 2] * g.tbc[2]);
   g.bf = bf; g.fx = fx; g.fy = fy; g.cx = cx; g.cy = cy;
+  if (!rig28) return;
+  g.rig = 1;
+  memcpy(g.kb[0], rig28, 32); memcpy(g.kb[1], rig28 + 8, 32);
+  double Rrl[9], trl[3];
+  for (int k = 0; k < 9; ++k) Rrl[k] = rig28[16 + k];
+  for (int k = 0; k < 3; ++k) trl[k] = rig28[25 + k];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) g.Rcb1[r * 3 + c] = Rrl[r * 3] * g.Rcb[c] + Rrl[r * 3 + 1] * g.Rcb[3 + c] + Rrl[r * 3 + 2] * g.Rcb[6 + c];
+    g.tcb1[r] = Rrl[r * 3] * g.tcb[0] + Rrl[r * 3 + 1] * g.tcb[1] + Rrl[r * 3 + 2] * g.tcb[2] + trl[r];
+  }
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) g.Rbc1[r * 3 + c] = g.Rcb1[c * 3 + r];
+  for (int r = 0; r < 3; ++r) g.tbc1[r] = -(g.Rbc1[r * 3] * g.tcb1[0] + g.Rbc1[r * 3 + 1] * g.tcb1[1] + g.Rbc1[r * 3 + 2] * g.tcb1[2]);
+}
+
+static int launch_pose_inertial(bool lastFrame, morb_optimizer* o, int nframes, int cap, const int* d_count, const uint8_t* d_hasMP,
+                                const float* d_obs, const float* d_invSigma2, const float* d_Xw, const uint8_t* d_close, float fx,
+                                float fy, float cx, float cy, float bf, const float* Tbc12, const float* d_state1,
+                                const morb_imu_preintegrated* d_pre, const morb_imu_preintegrated* d_preKF,
+                                const double* d_prevPrior, int bRecInit, float* d_state, uint8_t* d_outlier, int* d_nInliers,
+                                double* d_prior, void* stream, const int* d_nLeft = nullptr, const float* rig28 = nullptr) {
+  MORB_REQUIRE(o && d_hasMP && d_obs && d_invSigma2 && d_Xw && d_close && Tbc12 && d_state1 && d_pre && d_state && d_outlier && d_nInliers,
+               MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(!lastFrame || (d_preKF && d_prevPrior), MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(!rig28 || d_nLeft, MORB_ERR_INVALID, "a fisheye rig needs d_nLeft");
+  MORB_REQUIRE(nframes > 0 && cap > 0, MORB_ERR_INVALID, "bad sizes");
+  MORB_HIP_CHECK(hipSetDevice(morb_optimizer_device(o)));
+  hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_optimizer_stream(o);
+  CamGeom g;
+  make_geom(Tbc12, fx, fy, cx, cy, bf, rig28, g);
   if (lastFrame)
     hipLaunchKernelGGL(k_pose_inertial<true>, dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, d_close,
-                       g, d_state1, d_pre, d_preKF, d_prevPrior, bRecInit, d_state, d_outlier, d_nInliers, d_prior);
+                       g, d_state1, d_pre, d_preKF, d_prevPrior, d_nLeft, bRecInit, d_state, d_outlier, d_nInliers, d_prior);
   else
     hipLaunchKernelGGL(k_pose_inertial<false>, dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, d_close,
-                       g, d_state1, d_pre, d_preKF, d_prevPrior, bRecInit, d_state, d_outlier, d_nInliers, d_prior);
+                       g, d_state1, d_pre, d_preKF, d_prevPrior, d_nLeft, bRecInit, d_state, d_outlier, d_nInliers, d_prior);
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
 }
@@ -1541,13 +1598,37 @@ int morb_pose_inertial_optimization_last_frame_batch(morb_optimizer* o, int nfra
                               d_prevState, d_preFrame, d_preKF, d_prevPrior, bRecInit, d_state, d_outlier, d_nInliers, d_prior, stream);
 }
 
+int morb_pose_inertial_optimization_last_keyframe_fisheye_batch(morb_optimizer* o, int nframes, int cap, const int* d_count, const int* d_nLeft,
+                                                                const uint8_t* d_hasMP, const float* d_obs, const float* d_invSigma2,
+                                                                const float* d_Xw, const uint8_t* d_close, const float* rig28,
+                                                                const float* Tbc12, const float* d_kfState,
+                                                                const morb_imu_preintegrated* d_pre, int bRecInit, float* d_state,
+                                                                uint8_t* d_outlier, int* d_nInliers, double* d_prior, void* stream) {
+  MORB_REQUIRE(rig28 && d_nLeft, MORB_ERR_INVALID, "NULL argument");
+  return launch_pose_inertial(false, o, nframes, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, d_close, 0, 0, 0, 0, 0, Tbc12, d_kfState, d_pre,
+                              nullptr, nullptr, bRecInit, d_state, d_outlier, d_nInliers, d_prior, stream, d_nLeft, rig28);
+}
+
+int morb_pose_inertial_optimization_last_frame_fisheye_batch(morb_optimizer* o, int nframes, int cap, const int* d_count, const int* d_nLeft,
+                                                             const uint8_t* d_hasMP, const float* d_obs, const float* d_invSigma2,
+                                                             const float* d_Xw, const uint8_t* d_close, const float* rig28, const float* Tbc12,
+                                                             const float* d_prevState, const morb_imu_preintegrated* d_preFrame,
+                                                             const morb_imu_preintegrated* d_preKF, const double* d_prevPrior, int bRecInit,
+                                                             float* d_state, uint8_t* d_outlier, int* d_nInliers, double* d_prior,
+                                                             void* stream) {
+  MORB_REQUIRE(rig28 && d_nLeft, MORB_ERR_INVALID, "NULL argument");
+  return launch_pose_inertial(true, o, nframes, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, d_close, 0, 0, 0, 0, 0, Tbc12, d_prevState,
+                              d_preFrame, d_preKF, d_prevPrior, bRecInit, d_state, d_outlier, d_nInliers, d_prior, stream, d_nLeft, rig28);
+}
+
 // static void Optimizer::LocalInertialBA(KeyFrame*, bool* pbStopFlag, Map*, int&, int&, int&, int&, bool bLarge, bool bRecInit)
-// on the flattened graph (see include/morb_hip.h).  HOST pointers.
-int morb_local_inertial_ba(morb_optimizer* o, int nKF, float* kfState21, const uint8_t* kfKind, int nMP, float* mpPos,
+// on the flattened graph (see include/morb_hip.h).  HOST pointers.  eRight / rig28 != NULL: fisheye rig.
+static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, const uint8_t* kfKind, int nMP, float* mpPos,
                            const uint8_t* mpClose, int nE, const int* eKF, const int* eMP, const float* eObs, const float* eInvSigma2,
                            int nI, const int* iKF1, const int* iKF2, const morb_imu_preintegrated* iPre, const uint8_t* iRobust,
                            const float* iInfoScale, float fx, float fy, float cx, float cy, float bf, const float* Tbc12, int bLarge,
-                           uint8_t* eraseFlag, int* stats3) {
+                           uint8_t* eraseFlag, int* stats3, const uint8_t* eRight, const float* rig28) {
+  MORB_REQUIRE((eRight == nullptr) == (rig28 == nullptr), MORB_ERR_INVALID, "eRight and rig28 go together");
   MORB_REQUIRE(o && kfState21 && kfKind && mpPos && mpClose && eKF && eMP && eObs && eInvSigma2 && iKF1 && iKF2 && iPre && iRobust &&
                    iInfoScale && Tbc12 && eraseFlag, MORB_ERR_INVALID, "NULL argument");
   MORB_REQUIRE(nKF > 0 && nMP > 0 && nE > 0 && nI >= 0, MORB_ERR_INVALID, "bad sizes");
@@ -1592,7 +1673,7 @@ int morb_local_inertial_ba(morb_optimizer* o, int nKF, float* kfState21, const u
                    sizeof(double) * 81 * (size_t)nI1, sizeof(double) * 9 * (size_t)nI1, sizeof(double) * 9 * (size_t)nI1,
                    sizeof(double) * (size_t)P * P, sizeof(double) * (size_t)P * P, sizeof(double) * nX, sizeof(double) * (size_t)P,
                    sizeof(double) * nX, sizeof(double) * 9 * (size_t)nMP, sizeof(double) * 18 * (size_t)nE, sizeof(double) * 4,
-                   sizeof(double) * 420 * (size_t)nI1, (size_t)nE})
+                   sizeof(double) * 420 * (size_t)nI1, (size_t)nE, (size_t)nE})
     reserve(b);
   void* arena = nullptr;
   { const int rc = morb_optimizer_workspace(o, arenaBytes, &arena); if (rc != MORB_OK) return rc; }
@@ -1634,11 +1715,8 @@ int morb_local_inertial_ba(morb_optimizer* o, int nKF, float* kfState21, const u
   uint8_t* d_erase = (uint8_t*)dalloc(nE);
   MORB_REQUIRE(d_erase != nullptr && arenaOff <= arenaBytes, MORB_ERR_HIP, "workspace carve-up overflow in morb_local_inertial_ba");
   (void)hipMemsetAsync(D.x, 0, sizeof(double) * nX, st);   // the solver's x before the first solve
-  for (int k = 0; k < 9; ++k) D.g.Rbc[k] = Tbc12[k];
-  for (int k = 0; k < 3; ++k) D.g.tbc[k] = Tbc12[9 + k];
-  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) D.g.Rcb[r * 3 + c] = D.g.Rbc[c * 3 + r];
-  for (int r = 0; r < 3; ++r) D.g.tcb[r] = -(D.g.Rcb[r * 3] * D.g.tbc[0] + D.g.Rcb[r * 3 + 1] * D.g.tbc[1] + D.g.Rcb[r * 3 + 2] * D.g.tbc[2]);
-  D.g.bf = bf; D.g.fx = fx; D.g.fy = fy; D.g.cx = cx; D.g.cy = cy;
+  make_geom(Tbc12, fx, fy, cx, cy, bf, rig28, D.g);
+  D.eRight = eRight ? (const uint8_t*)up(eRight, nE) : nullptr;
 
   auto fail = [&](const char* what) { cleanup(); set_error("%s", what); return MORB_ERR_HIP; };
   double h[4];
@@ -1740,6 +1818,24 @@ int morb_local_inertial_ba(morb_optimizer* o, int nKF, float* kfState21, const u
   if (stats3) { stats3[0] = outer; stats3[1] = trials; stats3[2] = okFlag; }
   cleanup();
   return MORB_OK;
+}
+
+int morb_local_inertial_ba(morb_optimizer* o, int nKF, float* kfState21, const uint8_t* kfKind, int nMP, float* mpPos,
+                           const uint8_t* mpClose, int nE, const int* eKF, const int* eMP, const float* eObs, const float* eInvSigma2,
+                           int nI, const int* iKF1, const int* iKF2, const morb_imu_preintegrated* iPre, const uint8_t* iRobust,
+                           const float* iInfoScale, float fx, float fy, float cx, float cy, float bf, const float* Tbc12, int bLarge,
+                           uint8_t* eraseFlag, int* stats3) {
+  return local_inertial_ba_impl(o, nKF, kfState21, kfKind, nMP, mpPos, mpClose, nE, eKF, eMP, eObs, eInvSigma2, nI, iKF1, iKF2, iPre, iRobust,
+                                iInfoScale, fx, fy, cx, cy, bf, Tbc12, bLarge, eraseFlag, stats3, nullptr, nullptr);
+}
+int morb_local_inertial_ba_fisheye(morb_optimizer* o, int nKF, float* kfState21, const uint8_t* kfKind, int nMP, float* mpPos,
+                                   const uint8_t* mpClose, int nE, const int* eKF, const int* eMP, const float* eObs, const uint8_t* eRight,
+                                   const float* eInvSigma2, int nI, const int* iKF1, const int* iKF2, const morb_imu_preintegrated* iPre,
+                                   const uint8_t* iRobust, const float* iInfoScale, const float* rig28, const float* Tbc12, int bLarge,
+                                   uint8_t* eraseFlag, int* stats3) {
+  MORB_REQUIRE(eRight && rig28, MORB_ERR_INVALID, "NULL argument");
+  return local_inertial_ba_impl(o, nKF, kfState21, kfKind, nMP, mpPos, mpClose, nE, eKF, eMP, eObs, eInvSigma2, nI, iKF1, iKF2, iPre, iRobust,
+                                iInfoScale, 0, 0, 0, 0, 0, Tbc12, bLarge, eraseFlag, stats3, eRight, rig28);
 }
 
 #ifdef MORB_INERTIAL_TIMING

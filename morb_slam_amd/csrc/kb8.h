@@ -108,4 +108,32 @@ __device__ inline float triangulate_matches(const KB8& c1, const KB8& c2, const 
   return z1;
 }
 
+// FP64 forms used by the optimisers: KannalaBrandt8::project(Vector3d) (KannalaBrandt8.cpp:74-92, with its float atan2f leak) and
+// projectJac (:164-199).  c = fx fy cx cy k0 k1 k2 k3.
+__device__ __forceinline__ void kb8_project_d(const float* c, const double* v, double* uv) {
+  const double x2_plus_y2 = v[0] * v[0] + v[1] * v[1];
+  const double theta = (double)atan2f(sqrtf((float)x2_plus_y2), (float)v[2]);   // the reference's float leak
+  const double psi = (double)atan2f((float)v[1], (float)v[0]);
+  const double theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2,
+               theta9 = theta7 * theta2;
+  const double r = theta + c[4] * theta3 + c[5] * theta5 + c[6] * theta7 + c[7] * theta9;
+  uv[0] = c[0] * r * cos(psi) + c[2];
+  uv[1] = c[1] * r * sin(psi) + c[3];
+}
+__device__ __forceinline__ void kb8_project_jac(const float* c, const double* v, double* J) {
+  const double x2 = v[0] * v[0], y2 = v[1] * v[1], z2 = v[2] * v[2];
+  const double r2 = x2 + y2, r = sqrt(r2), r3 = r2 * r;
+  const double theta = atan2(r, v[2]);
+  const double theta2 = theta * theta, theta3 = theta2 * theta, theta4 = theta2 * theta2, theta5 = theta4 * theta;
+  const double theta6 = theta2 * theta4, theta7 = theta6 * theta, theta8 = theta4 * theta4, theta9 = theta8 * theta;
+  const double f = theta + theta3 * c[4] + theta5 * c[5] + theta7 * c[6] + theta9 * c[7];
+  const double fd = 1 + 3 * c[4] * theta2 + 5 * c[5] * theta4 + 7 * c[6] * theta6 + 9 * c[7] * theta8;
+  J[0] = c[0] * (fd * v[2] * x2 / (r2 * (r2 + z2)) + f * y2 / r3);
+  J[3] = c[1] * (fd * v[2] * v[1] * v[0] / (r2 * (r2 + z2)) - f * v[1] * v[0] / r3);
+  J[1] = c[0] * (fd * v[2] * v[1] * v[0] / (r2 * (r2 + z2)) - f * v[1] * v[0] / r3);
+  J[4] = c[1] * (fd * v[2] * y2 / (r2 * (r2 + z2)) + f * x2 / r3);
+  J[2] = -c[0] * fd * v[0] / (r2 + z2);
+  J[5] = -c[1] * fd * v[1] / (r2 + z2);
+}
+
 }  // namespace morbkb8

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "common.h"
+#include "kb8.h"
 
 using namespace morb;
 
@@ -250,31 +251,8 @@ struct Rig {            // fisheye stereo rig: left / right KB8 cameras and mTrl
   float kbL[8], kbR[8];
   SE3 Trl;
 };
-__device__ __forceinline__ void kb8_project_d(const float* c, const double* v, double* uv) {
-  const double x2_plus_y2 = v[0] * v[0] + v[1] * v[1];
-  const double theta = (double)atan2f(sqrtf((float)x2_plus_y2), (float)v[2]);   // the reference's float leak
-  const double psi = (double)atan2f((float)v[1], (float)v[0]);
-  const double theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2,
-               theta9 = theta7 * theta2;
-  const double r = theta + c[4] * theta3 + c[5] * theta5 + c[6] * theta7 + c[7] * theta9;
-  uv[0] = c[0] * r * cos(psi) + c[2];
-  uv[1] = c[1] * r * sin(psi) + c[3];
-}
-__device__ __forceinline__ void kb8_project_jac(const float* c, const double* v, double* J) {
-  const double x2 = v[0] * v[0], y2 = v[1] * v[1], z2 = v[2] * v[2];
-  const double r2 = x2 + y2, r = sqrt(r2), r3 = r2 * r;
-  const double theta = atan2(r, v[2]);
-  const double theta2 = theta * theta, theta3 = theta2 * theta, theta4 = theta2 * theta2, theta5 = theta4 * theta;
-  const double theta6 = theta2 * theta4, theta7 = theta6 * theta, theta8 = theta4 * theta4, theta9 = theta8 * theta;
-  const double f = theta + theta3 * c[4] + theta5 * c[5] + theta7 * c[6] + theta9 * c[7];
-  const double fd = 1 + 3 * c[4] * theta2 + 5 * c[5] * theta4 + 7 * c[6] * theta6 + 9 * c[7] * theta8;
-  J[0] = c[0] * (fd * v[2] * x2 / (r2 * (r2 + z2)) + f * y2 / r3);
-  J[3] = c[1] * (fd * v[2] * v[1] * v[0] / (r2 * (r2 + z2)) - f * v[1] * v[0] / r3);
-  J[1] = c[0] * (fd * v[2] * v[1] * v[0] / (r2 * (r2 + z2)) - f * v[1] * v[0] / r3);
-  J[4] = c[1] * (fd * v[2] * y2 / (r2 * (r2 + z2)) + f * x2 / r3);
-  J[2] = -c[0] * fd * v[0] / (r2 + z2);
-  J[5] = -c[1] * fd * v[1] / (r2 + z2);
-}
+using morbkb8::kb8_project_d;
+using morbkb8::kb8_project_jac;
 // unary edge of PoseOptimization: residual (returns chi2, sets st = "3-D stereo residual") ...
 template <bool FISH>
 __device__ __forceinline__ double pose_edge_error(const Cam& cam, const Rig& rig, const SE3& P, const SE3& Pr, bool right,

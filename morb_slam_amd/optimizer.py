@@ -77,7 +77,7 @@ class Optimizer:
         return out
 
     def PoseInertialOptimizationLastKeyFrame(self, hasMP, obs, invSigma2, Xw, close, cam, Tbc, kfState, pre, state, bRecInit=False,
-                                             count=None, want_prior=True, out=None, stream=None):
+                                             count=None, want_prior=True, out=None, stream=None, rig=None, nLeft=None):
         """Batched Optimizer::PoseInertialOptimizationLastKeyFrame.  Device tensors as PoseOptimization plus close u8
         [F, cap] (mTrackDepth < 10), kfState f32 [F, 21] (fixed), pre f32 [F, PREINT_FLOATS], state f32 [F, 21] in/out
         (Rwb row-major, twb, velocity, gyro bias, acc bias).  Tbc: 12 floats (rotation row-major + translation).
@@ -91,6 +91,13 @@ class Optimizer:
         t = np.ascontiguousarray(Tbc, np.float32)
         assert t.size == 12 and pre.shape[1] == PREINT_FLOATS and state.shape[1] == 21 and kfState.shape[1] == 21
         st = stream_arg(stream)
+        if rig is not None:   # fisheye rig: rig = 28 floats (see morb_hip.h), nLeft i32 [F] on the device; cam is ignored
+            r28 = np.ascontiguousarray(rig, np.float32)
+            assert r28.size == 28 and nLeft is not None
+            check(self._L.morb_pose_inertial_optimization_last_keyframe_fisheye_batch(
+                self._h, F, cap, ptr(count), ptr(nLeft), ptr(hasMP), ptr(obs), ptr(invSigma2), ptr(Xw), ptr(close), ptr(r28), ptr(t),
+                ptr(kfState), ptr(pre), int(bool(bRecInit)), ptr(state), ptr(out[1]), ptr(out[0]), ptr(out[2]), st))
+            return out
         check(self._L.morb_pose_inertial_optimization_last_keyframe_batch(
             self._h, F, cap, ptr(count), ptr(hasMP), ptr(obs), ptr(invSigma2), ptr(Xw), ptr(close), cam["fx"], cam["fy"], cam["cx"],
             cam["cy"], cam["bf"], ptr(t), ptr(kfState), ptr(pre), int(bool(bRecInit)), ptr(state), ptr(out[1]), ptr(out[0]),
@@ -98,7 +105,7 @@ class Optimizer:
         return out
 
     def PoseInertialOptimizationLastFrame(self, hasMP, obs, invSigma2, Xw, close, cam, Tbc, prevState, preFrame, preKF, prevPrior, state,
-                                          bRecInit=False, count=None, want_prior=True, out=None, stream=None):
+                                          bRecInit=False, count=None, want_prior=True, out=None, stream=None, rig=None, nLeft=None):
         """Batched Optimizer::PoseInertialOptimizationLastFrame: as PoseInertialOptimizationLastKeyFrame, but the previous
         frame's state (prevState f32 [F, 21]) is free and carries the prior prevPrior f64 [F, 246] (a previous call's third
         result); preFrame = preintegration since the previous frame, preKF = since the last keyframe."""
@@ -112,6 +119,14 @@ class Optimizer:
         assert t.size == 12 and preFrame.shape[1] == PREINT_FLOATS and preKF.shape[1] == PREINT_FLOATS
         assert state.shape[1] == 21 and prevState.shape[1] == 21 and prevPrior.shape[1] == 246 and prevPrior.dtype == torch.float64
         st = stream_arg(stream)
+        if rig is not None:
+            r28 = np.ascontiguousarray(rig, np.float32)
+            assert r28.size == 28 and nLeft is not None
+            check(self._L.morb_pose_inertial_optimization_last_frame_fisheye_batch(
+                self._h, F, cap, ptr(count), ptr(nLeft), ptr(hasMP), ptr(obs), ptr(invSigma2), ptr(Xw), ptr(close), ptr(r28), ptr(t),
+                ptr(prevState), ptr(preFrame), ptr(preKF), ptr(prevPrior), int(bool(bRecInit)), ptr(state), ptr(out[1]), ptr(out[0]),
+                ptr(out[2]), st))
+            return out
         check(self._L.morb_pose_inertial_optimization_last_frame_batch(
             self._h, F, cap, ptr(count), ptr(hasMP), ptr(obs), ptr(invSigma2), ptr(Xw), ptr(close), cam["fx"], cam["fy"], cam["cx"],
             cam["cy"], cam["bf"], ptr(t), ptr(prevState), ptr(preFrame), ptr(preKF), ptr(prevPrior), int(bool(bRecInit)), ptr(state),
@@ -119,7 +134,7 @@ class Optimizer:
         return out
 
     def LocalInertialBA(self, kfState, kfKind, mpPos, mpClose, eKF, eMP, eObs, eInvSigma2, iKF1, iKF2, iPre, iRobust, iInfoScale, cam, Tbc,
-                        bLarge=False):
+                        bLarge=False, rig=None, eRight=None):
         """Optimizer::LocalInertialBA on host numpy arrays (see morb_local_inertial_ba).  iPre: float32 [nI, PREINT_FLOATS].
         Returns (kfState, mpPos, eraseFlag, stats) with stats = (outer LM iterations, LM trials, ok)."""
         a = [np.ascontiguousarray(kfState, np.float32).copy(), np.ascontiguousarray(kfKind, np.uint8),
@@ -131,6 +146,14 @@ class Optimizer:
         nI = len(a[8])
         assert a[10].shape == (nI, PREINT_FLOATS) and a[0].shape[1] == 21 and a[6].shape[1] == 3
         erase = np.zeros(len(a[4]), np.uint8); stats = np.zeros(3, np.int32)
+        if rig is not None:   # fisheye rig: rig = 28 floats, eRight uint8 [nE]; cam is ignored
+            r28 = np.ascontiguousarray(rig, np.float32); er = np.ascontiguousarray(eRight, np.uint8)
+            assert r28.size == 28 and len(er) == len(a[4])
+            check(self._L.morb_local_inertial_ba_fisheye(self._h, len(a[0]), ptr(a[0]), ptr(a[1]), len(a[2]), ptr(a[2]), ptr(a[3]), len(a[4]),
+                                                         ptr(a[4]), ptr(a[5]), ptr(a[6]), ptr(er), ptr(a[7]), nI, ptr(a[8]), ptr(a[9]),
+                                                         ptr(a[10]), ptr(a[11]), ptr(a[12]), ptr(r28), ptr(a[13]), int(bool(bLarge)),
+                                                         ptr(erase), ptr(stats)))
+            return a[0], a[2], erase, stats
         check(self._L.morb_local_inertial_ba(self._h, len(a[0]), ptr(a[0]), ptr(a[1]), len(a[2]), ptr(a[2]), ptr(a[3]), len(a[4]), ptr(a[4]),
                                              ptr(a[5]), ptr(a[6]), ptr(a[7]), nI, ptr(a[8]), ptr(a[9]), ptr(a[10]), ptr(a[11]), ptr(a[12]),
                                              cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["bf"], ptr(a[13]), int(bool(bLarge)),

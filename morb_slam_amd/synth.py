@@ -366,8 +366,15 @@ def make_inertial_sequence(n=500, seed=0, n_imu=20, **kw):
     return pA, pB
 
 
+def tumvi_rig28():
+    """Fisheye rig as the inertial entry points take it: left KB8 (8), right KB8 (8), Trl rotation (9, row-major) +
+    translation (3)."""
+    Trl = np.linalg.inv(TUMVI_T_C1_C2)
+    return np.concatenate([TUMVI_CAM_L, TUMVI_CAM_R, Trl[:3, :3].ravel(), Trl[:3, 3]]).astype(np.float32)
+
+
 def make_inertial_problem(n=500, seed=0, n_imu=20, outlier_frac=0.1, mono_frac=0.3, rot_deg=1.0, trans=0.03, cam=EUROC_CAM,
-                          _obs_seed=0):
+                          _obs_seed=0, rig=False):
     """One PoseInertialOptimizationLastKeyFrame input: the last keyframe's state, n_imu IMU samples of a smooth motion
     (constant body angular rate, constant world acceleration) between keyframe and frame, map points seen from the
     frame's true pose, and a perturbed initial frame state.  States: Rwb (9), twb, v, bg, ba."""
@@ -393,13 +400,23 @@ def make_inertial_problem(n=500, seed=0, n_imu=20, outlier_frac=0.1, mono_frac=0
     Xc = np.stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(1.5, 25, n)], 1)
     Xw = (Xc - tcw) @ Rcw          # Rcw^T (Xc - tcw)
     z = Xc[:, 2]
-    u = cam["fx"] * Xc[:, 0] / z + cam["cx"]; v = cam["fy"] * Xc[:, 1] / z + cam["cy"]; ur = u - cam["bf"] / z
     octave = rng.integers(0, 8, n); sigma = 1.2 ** octave
+    n_left = n
+    if rig:   # fisheye rig: features [0, n_left) seen by the left KB8 camera, the rest by the right one; all monocular
+        n_left = int(0.55 * n)
+        Trl = np.linalg.inv(TUMVI_T_C1_C2)
+        uv = np.zeros((n, 2))
+        uv[:n_left] = kb8_project(TUMVI_CAM_L, Xc[:n_left])
+        uv[n_left:] = kb8_project(TUMVI_CAM_R, Xc[n_left:] @ Trl[:3, :3].T + Trl[:3, 3])
+        u, v, ur = uv[:, 0], uv[:, 1], np.full(n, -1.0)
+        sigma = sigma * 0.5
+    else:
+        u = cam["fx"] * Xc[:, 0] / z + cam["cx"]; v = cam["fy"] * Xc[:, 1] / z + cam["cy"]; ur = u - cam["bf"] / z
     u = u + rng.normal(0, 1, n) * sigma; v = v + rng.normal(0, 1, n) * sigma; ur = ur + rng.normal(0, 1, n) * sigma
     out = rng.random(n) < outlier_frac
     u[out] += rng.choice([-1, 1], out.sum()) * rng.uniform(15, 40, out.sum())
     v[out] += rng.choice([-1, 1], out.sum()) * rng.uniform(15, 40, out.sum())
-    mono = rng.random(n) < mono_frac
+    mono = (rng.random(n) < mono_frac) | rig
     ur[mono] = -1
     has = (rng.random(n) < 0.9).astype(np.uint8)
     R0 = R2 @ _rot_from_rotvec(rng.normal(0, 1, 3) / np.sqrt(3) * np.deg2rad(rot_deg))
@@ -410,11 +427,12 @@ def make_inertial_problem(n=500, seed=0, n_imu=20, outlier_frac=0.1, mono_frac=0
                 acc=np.array(acc, np.float32), gyro=np.array(gyro, np.float32), dt=np.array(dts, np.float32),
                 bias=np.concatenate([ba, bg]).astype(np.float32),      # IMU::Bias order: acc then gyro
                 Tbc12=np.concatenate([Tbc[:3, :3].ravel(), Tbc[:3, 3]]).astype(np.float32), cam=cam,
-                true=np.concatenate([R2.ravel(), p2, v2, bg, ba]), outlier_truth=out)
+                true=np.concatenate([R2.ravel(), p2, v2, bg, ba]), outlier_truth=out, Nleft=n_left,
+                rig28=tumvi_rig28() if rig else None)
 
 
 def make_inertial_ba_problem(n_opt=10, n_fixed_vis=6, n_points=1500, n_imu=40, seed=0, outlier_frac=0.03, mono_frac=0.25,
-                             cam=EUROC_CAM):
+                             cam=EUROC_CAM, rig=False):
     """LocalInertialBA input: a temporal chain keyframe 0 (fixed, with IMU state) -> n_opt optimizable keyframes, plus
     n_fixed_vis fixed keyframes that only observe points.  Each link carries n_imu IMU samples of a smooth motion
     (per-link constant body rate and world acceleration).  States: Rwb (9), twb, v, bg, ba; kfKind 0 / 1 / 2 as in
@@ -452,7 +470,8 @@ def make_inertial_ba_problem(n_opt=10, n_fixed_vis=6, n_points=1500, n_imu=40, s
     Rm, tm_ = cams[n_opt // 2]
     Xc = np.stack([rng.uniform(-4, 4, n_points), rng.uniform(-2.5, 2.5, n_points), rng.uniform(2, 20, n_points)], 1)
     X = (Xc - tm_) @ Rm
-    eKF, eMP, eObs, eInv = [], [], [], []
+    eKF, eMP, eObs, eInv, eRight = [], [], [], [], []
+    Trl = np.linalg.inv(TUMVI_T_C1_C2)
     depth_ref = np.full(n_points, 1e9)
     for j in range(n_points):
         ks = rng.choice(nKF, size=min(int(rng.integers(3, 9)), nKF), replace=False)
@@ -461,16 +480,28 @@ def make_inertial_ba_problem(n_opt=10, n_fixed_vis=6, n_points=1500, n_imu=40, s
             xc = Rcw @ X[j] + tcw
             if xc[2] < 0.5:
                 continue
-            u = cam["fx"] * xc[0] / xc[2] + cam["cx"]; vv = cam["fy"] * xc[1] / xc[2] + cam["cy"]
-            if not (0 <= u < 752 and 0 <= vv < 480):
-                continue
             octv = int(rng.integers(0, 8)); s = 1.2 ** octv
-            o = np.array([u, vv, u - cam["bf"] / xc[2]]) + rng.normal(0, 1, 3) * s
+            right = 0
+            if rig:   # one monocular observation on the left or on the right KB8 camera
+                right = int(rng.random() < 0.45)
+                xr = Trl[:3, :3] @ xc + Trl[:3, 3] if right else xc
+                if xr[2] < 0.5:
+                    continue
+                u, vv = kb8_project(TUMVI_CAM_R if right else TUMVI_CAM_L, xr[None])[0]
+                if not (0 <= u < 512 and 0 <= vv < 512):
+                    continue
+                s *= 0.5
+                o = np.array([u, vv, -1.0]) + np.array([rng.normal(0, 1) * s, rng.normal(0, 1) * s, 0.0])
+            else:
+                u = cam["fx"] * xc[0] / xc[2] + cam["cx"]; vv = cam["fy"] * xc[1] / xc[2] + cam["cy"]
+                if not (0 <= u < 752 and 0 <= vv < 480):
+                    continue
+                o = np.array([u, vv, u - cam["bf"] / xc[2]]) + rng.normal(0, 1, 3) * s
             if rng.random() < outlier_frac:
                 o[:2] += rng.choice([-1, 1], 2) * rng.uniform(15, 30, 2)
-            if rng.random() < mono_frac:
+            if not rig and rng.random() < mono_frac:
                 o[2] = -1
-            eKF.append(k); eMP.append(j); eObs.append(o); eInv.append(1.0 / (s * s))
+            eKF.append(k); eMP.append(j); eObs.append(o); eInv.append(1.0 / (s * s)); eRight.append(right)
             depth_ref[j] = min(depth_ref[j], xc[2])
     true = np.stack([np.concatenate([Rk.ravel(), pk, vk, bg, ba]) for Rk, pk, vk in states])
     init = true.copy()
@@ -486,4 +517,5 @@ def make_inertial_ba_problem(n_opt=10, n_fixed_vis=6, n_points=1500, n_imu=40, s
                 iRobust=(iKF1 == 0).astype(np.uint8), iInfoScale=np.where(iKF1 == 0, 1e-2, 1.0).astype(np.float32),
                 imuStart=np.array(start, np.int32), acc=np.array(acc, np.float32), gyro=np.array(gyro, np.float32),
                 dt=np.array(dts, np.float32), bias=np.concatenate([ba, bg]).astype(np.float32),
-                Tbc12=np.concatenate([Tbc[:3, :3].ravel(), Tbc[:3, 3]]).astype(np.float32), cam=cam, true=true, truePts=X)
+                Tbc12=np.concatenate([Tbc[:3, :3].ravel(), Tbc[:3, 3]]).astype(np.float32), cam=cam, true=true, truePts=X,
+                eRight=np.array(eRight, np.uint8), rig28=tumvi_rig28() if rig else None)

@@ -27,6 +27,7 @@
 #include <limits>
 #include <vector>
 
+#include "matcher.h"
 #include "orb_oracle.h"
 
 namespace orc {
@@ -377,12 +378,34 @@ static bool ldltSolve(const double* Hin, const double* b, int n, double* x) {
   return true;
 }
 
-struct CamPose {  // ImuCamPose with one pinhole camera
+struct CamPose {  // ImuCamPose: one pinhole camera, or the two KannalaBrandt8 cameras of a fisheye rig (G2oTypes.cc:74-118)
   double Rwb[9], twb[3];
   double Rcw[9], tcw[3];
   double Rcb[9], tcb[3], Rbc[9], tbc[3];
   double bf;
   float fx, fy, cx, cy;
+  bool rig = false;           // pCamera2 != NULL: camera 0 / 1 = left / right KB8
+  orc::kb8::Cam kb[2];
+  double Rcw1[9], tcw1[3], Rcb1[9], tcb1[3], Rbc1[9], tbc1[3];
+  // rig28 = left KB8 (8), right KB8 (8), Trl rotation (9, row-major) + translation (3)   (G2oTypes.cc:104-113)
+  void setRig(const float* rig28) {
+    rig = true;
+    memcpy(kb[0].p, rig28, 32); memcpy(kb[1].p, rig28 + 8, 32);
+    double Rrl[9], trl[3];
+    for (int k = 0; k < 9; ++k) Rrl[k] = rig28[16 + k];
+    for (int k = 0; k < 3; ++k) trl[k] = rig28[25 + k];
+    mul33(Rrl, Rcb, Rcb1);
+    mul3v(Rrl, tcb, tcb1);
+    for (int k = 0; k < 3; ++k) tcb1[k] += trl[k];
+    transpose33(Rcb1, Rbc1);
+    mul3v(Rbc1, tcb1, tbc1);
+    for (double& c : tbc1) c = -c;
+  }
+  const double* R_cw(int cam) const { return cam ? Rcw1 : Rcw; }
+  const double* t_cw(int cam) const { return cam ? tcw1 : tcw; }
+  const double* R_cb(int cam) const { return cam ? Rcb1 : Rcb; }
+  const double* R_bc(int cam) const { return cam ? Rbc1 : Rbc; }
+  const double* t_bc(int cam) const { return cam ? tbc1 : tbc; }
   void refreshCamera() {   // G2oTypes.cc:209-215
     double Rbw[9], tbw[3];
     transpose33(Rwb, Rbw);
@@ -391,6 +414,11 @@ struct CamPose {  // ImuCamPose with one pinhole camera
     mul33(Rcb, Rbw, Rcw);
     mul3v(Rcb, tbw, tcw);
     for (int k = 0; k < 3; ++k) tcw[k] += tcb[k];
+    if (rig) {
+      mul33(Rcb1, Rbw, Rcw1);
+      mul3v(Rcb1, tbw, tcw1);
+      for (int k = 0; k < 3; ++k) tcw1[k] += tcb1[k];
+    }
   }
   void update(const double* pu) {   // ImuCamPose::Update (G2oTypes.cc:192-216)
     double t[3], dR[9];
@@ -400,37 +428,40 @@ struct CamPose {  // ImuCamPose with one pinhole camera
     mul33(Rwb, dR, Rwb);
     refreshCamera();
   }
-  void camPoint(const double* Xw, double* Xc) const { mul3v(Rcw, Xw, Xc); for (int k = 0; k < 3; ++k) Xc[k] += tcw[k]; }
-  void project(const double* Xc, double* uv) const {   // Pinhole.cpp:38-44
-    uv[0] = fx * Xc[0] / Xc[2] + cx;
+  void camPoint(const double* Xw, double* Xc, int cam = 0) const { mul3v(R_cw(cam), Xw, Xc); for (int k = 0; k < 3; ++k) Xc[k] += t_cw(cam)[k]; }
+  void project(const double* Xc, double* uv, int cam = 0) const {
+    if (rig) { orc::kb8::projectD(kb[cam], Xc, uv); return; }   // KannalaBrandt8::project(Vector3d)
+    uv[0] = fx * Xc[0] / Xc[2] + cx;                            // Pinhole.cpp:38-44
     uv[1] = fy * Xc[1] / Xc[2] + cy;
   }
-  void projectJac(const double* Xc, double* J) const {   // Pinhole.cpp:76-86
-    J[0] = fx / Xc[2]; J[1] = 0; J[2] = -fx * Xc[0] / (Xc[2] * Xc[2]);
+  void projectJac(const double* Xc, double* J, int cam = 0) const {
+    if (rig) { orc::kb8::projectJac(kb[cam], Xc, J); return; }  // KannalaBrandt8::projectJac
+    J[0] = fx / Xc[2]; J[1] = 0; J[2] = -fx * Xc[0] / (Xc[2] * Xc[2]);   // Pinhole.cpp:76-86
     J[3] = 0; J[4] = fy / Xc[2]; J[5] = -fy * Xc[1] / (Xc[2] * Xc[2]);
   }
 };
 
 struct VisEdge {
   int idx; bool stereo; double obs[3]; double Xw[3]; double info; bool close;
+  int cam = 0;   // EdgeMonoOnlyPose(Xw, cam_idx) / EdgeMono(cam_idx)
   int level = 0; bool robust = true;
   double err[3] = {0, 0, 0};
   double chi2() const { const int d = stereo ? 3 : 2; double s = 0; for (int k = 0; k < d; ++k) s += err[k] * info * err[k]; return s; }
   void computeError(const CamPose& P) {   // G2oTypes.h:401-405 / :477-481, G2oTypes.cc:171-186
     double Xc[3], uv[2];
-    P.camPoint(Xw, Xc);
-    P.project(Xc, uv);
+    P.camPoint(Xw, Xc, cam);
+    P.project(Xc, uv, cam);
     err[0] = obs[0] - uv[0]; err[1] = obs[1] - uv[1];
     if (stereo) { const double invZ = 1 / Xc[2]; err[2] = obs[2] - (uv[0] - P.bf * invZ); }
   }
-  bool depthPositive(const CamPose& P) const { return (P.Rcw[6] * Xw[0] + P.Rcw[7] * Xw[1] + P.Rcw[8] * Xw[2] + P.tcw[2]) > 0.0; }
+  bool depthPositive(const CamPose& P) const { const double* R = P.R_cw(cam); return (R[6] * Xw[0] + R[7] * Xw[1] + R[8] * Xw[2] + P.t_cw(cam)[2]) > 0.0; }
   void jacobian(const CamPose& P, double* J /* d x 6 */) const {   // G2oTypes.cc:361-382 / :417-442
     double Xc[3], Xb[3];
-    P.camPoint(Xw, Xc);
-    mul3v(P.Rbc, Xc, Xb);
-    for (int k = 0; k < 3; ++k) Xb[k] += P.tbc[k];
+    P.camPoint(Xw, Xc, cam);
+    mul3v(P.R_bc(cam), Xc, Xb);
+    for (int k = 0; k < 3; ++k) Xb[k] += P.t_bc(cam)[k];
     double pj[9];
-    P.projectJac(Xc, pj);
+    P.projectJac(Xc, pj, cam);
     int d = 2;
     if (stereo) {
       d = 3;
@@ -441,7 +472,7 @@ struct VisEdge {
     const double S[18] = {0.0, z, -y, 1.0, 0.0, 0.0, -z, 0.0, x, 0.0, 1.0, 0.0, y, -x, 0.0, 0.0, 0.0, 1.0};
     double PR[9];
     for (int r = 0; r < d; ++r)
-      for (int c = 0; c < 3; ++c) PR[r * 3 + c] = pj[r * 3] * P.Rcb[c] + pj[r * 3 + 1] * P.Rcb[3 + c] + pj[r * 3 + 2] * P.Rcb[6 + c];
+      for (int c = 0; c < 3; ++c) PR[r * 3 + c] = pj[r * 3] * P.R_cb(cam)[c] + pj[r * 3 + 1] * P.R_cb(cam)[3 + c] + pj[r * 3 + 2] * P.R_cb(cam)[6 + c];
     for (int r = 0; r < d; ++r)
       for (int c = 0; c < 6; ++c) J[r * 6 + c] = PR[r * 3] * S[c] + PR[r * 3 + 1] * S[6 + c] + PR[r * 3 + 2] * S[12 + c];
   }
@@ -495,11 +526,12 @@ extern "C" void orc_imu_delta(const orc_imu_preintegrated* P, const float* b1, f
 // Optimizer::PoseInertialOptimizationLastKeyFrame (Optimizer.cc:4391-4757) for one frame.
 // state / kfState = Rwb (9, row-major), twb, velocity, gyro bias, acc bias (21 floats); Tbc12 = Rbc (9) + tbc (3).
 // prior246 (optional) = ConstraintPoseImu: Rwb, twb, v, bg, ba (21 doubles) + H (15 x 15 row-major).
-extern "C" int orc_pose_inertial_optimization_last_keyframe(int n, const uint8_t* hasMP, const float* obs, const float* invSigma2,
-                                                            const float* Xw, const uint8_t* closeFlag, float fx, float fy, float cx,
-                                                            float cy, float bf, const float* Tbc12, const float* kfState21,
-                                                            const orc_imu_preintegrated* pre, int bRecInit, float* state21,
-                                                            uint8_t* outlier, double* prior246) {
+// Nleft / rig28: fisheye rig (pFrame->Nleft != -1): features [0, Nleft) are left-camera, the rest right-camera monocular edges
+// (Optimizer.cc:4453-4528); rig28 = nullptr: one pinhole camera.
+static int poseInertialLastKeyFrame(int n, const uint8_t* hasMP, const float* obs, const float* invSigma2, const float* Xw,
+                                    const uint8_t* closeFlag, float fx, float fy, float cx, float cy, float bf, const float* Tbc12,
+                                    const float* kfState21, const orc_imu_preintegrated* pre, int bRecInit, float* state21,
+                                    uint8_t* outlier, double* prior246, int Nleft, const float* rig28) {
   CamPose VP;
   for (int k = 0; k < 9; ++k) VP.Rwb[k] = state21[k];
   for (int k = 0; k < 3; ++k) VP.twb[k] = state21[9 + k];
@@ -511,6 +543,7 @@ extern "C" int orc_pose_inertial_optimization_last_keyframe(int n, const uint8_t
   mul3v(VP.Rcb, VP.tbc, VP.tcb);
   for (double& c : VP.tcb) c = -c;
   VP.bf = bf; VP.fx = fx; VP.fy = fy; VP.cx = cx; VP.cy = cy;
+  if (rig28) VP.setRig(rig28);
   VP.refreshCamera();
 
   const double thHuberMono = (double)(float)std::sqrt(5.991), thHuberStereo = (double)(float)std::sqrt(7.815);
@@ -518,10 +551,11 @@ extern "C" int orc_pose_inertial_optimization_last_keyframe(int n, const uint8_t
   for (int i = 0; i < n; ++i) {
     if (!hasMP[i]) continue;
     VisEdge e;
-    e.idx = i; e.stereo = !(obs[3 * i + 2] < 0);
+    e.idx = i; e.stereo = !rig28 && !(obs[3 * i + 2] < 0);
+    e.cam = rig28 && i >= Nleft ? 1 : 0;
     e.obs[0] = obs[3 * i]; e.obs[1] = obs[3 * i + 1]; e.obs[2] = obs[3 * i + 2];
     for (int k = 0; k < 3; ++k) e.Xw[k] = Xw[3 * i + k];
-    const float unc2 = 1.0f;                        // Pinhole::uncertainty2
+    const float unc2 = 1.0f;                        // Pinhole / KannalaBrandt8::uncertainty2
     const float is2 = invSigma2[i] / unc2;
     e.info = is2; e.close = closeFlag[i] != 0;
     outlier[i] = 0;
@@ -702,16 +736,32 @@ extern "C" int orc_pose_inertial_optimization_last_keyframe(int n, const uint8_t
   return nInitial - nBad;
 }
 
+extern "C" int orc_pose_inertial_optimization_last_keyframe(int n, const uint8_t* hasMP, const float* obs, const float* invSigma2,
+                                                            const float* Xw, const uint8_t* closeFlag, float fx, float fy, float cx,
+                                                            float cy, float bf, const float* Tbc12, const float* kfState21,
+                                                            const orc_imu_preintegrated* pre, int bRecInit, float* state21,
+                                                            uint8_t* outlier, double* prior246) {
+  return poseInertialLastKeyFrame(n, hasMP, obs, invSigma2, Xw, closeFlag, fx, fy, cx, cy, bf, Tbc12, kfState21, pre, bRecInit, state21,
+                                  outlier, prior246, -1, nullptr);
+}
+extern "C" int orc_pose_inertial_optimization_last_keyframe_fisheye(int n, int Nleft, const uint8_t* hasMP, const float* obs,
+                                                                    const float* invSigma2, const float* Xw, const uint8_t* closeFlag,
+                                                                    const float* rig28, const float* Tbc12, const float* kfState21,
+                                                                    const orc_imu_preintegrated* pre, int bRecInit, float* state21,
+                                                                    uint8_t* outlier, double* prior246) {
+  return poseInertialLastKeyFrame(n, hasMP, obs, invSigma2, Xw, closeFlag, 0, 0, 0, 0, 0, Tbc12, kfState21, pre, bRecInit, state21,
+                                  outlier, prior246, Nleft, rig28);
+}
+
 // Optimizer::PoseInertialOptimizationLastFrame (Optimizer.cc:4761-5161) for one frame: the frame's 15 states and the previous
 // frame's 15 states are free, tied by EdgeInertial(mpImuPreintegratedFrame), the two random-walk edges (information from
 // mpImuPreintegrated, i.e. since the last keyframe) and EdgePriorPoseImu(pFp->mpcpi) with a Huber kernel (delta 5).
 // prevPrior246 = pFp->mpcpi (21 state doubles + 15 x 15 H); prior246 (out) = the frame's new mpcpi after Marginalize(H, 0, 14).
-extern "C" int orc_pose_inertial_optimization_last_frame(int n, const uint8_t* hasMP, const float* obs, const float* invSigma2,
-                                                         const float* Xw, const uint8_t* closeFlag, float fx, float fy, float cx,
-                                                         float cy, float bf, const float* Tbc12, const float* prevState21,
-                                                         const orc_imu_preintegrated* preFrame, const orc_imu_preintegrated* preKF,
-                                                         const double* prevPrior246, int bRecInit, float* state21,
-                                                         uint8_t* outlier, double* prior246) {
+static int poseInertialLastFrame(int n, const uint8_t* hasMP, const float* obs, const float* invSigma2, const float* Xw,
+                                 const uint8_t* closeFlag, float fx, float fy, float cx, float cy, float bf, const float* Tbc12,
+                                 const float* prevState21, const orc_imu_preintegrated* preFrame, const orc_imu_preintegrated* preKF,
+                                 const double* prevPrior246, int bRecInit, float* state21, uint8_t* outlier, double* prior246, int Nleft,
+                                 const float* rig28) {
   CamPose VP, VPk;
   auto load = [&](CamPose& P, const float* s, double* v, double* bg, double* ba) {
     for (int k = 0; k < 9; ++k) P.Rwb[k] = s[k];
@@ -722,6 +772,7 @@ extern "C" int orc_pose_inertial_optimization_last_frame(int n, const uint8_t* h
     mul3v(P.Rcb, P.tbc, P.tcb);
     for (double& c : P.tcb) c = -c;
     P.bf = bf; P.fx = fx; P.fy = fy; P.cx = cx; P.cy = cy;
+    if (rig28) P.setRig(rig28);
     P.refreshCamera();
   };
   double v[3], bg[3], ba[3], vk[3], bgk[3], bak[3];
@@ -733,7 +784,8 @@ extern "C" int orc_pose_inertial_optimization_last_frame(int n, const uint8_t* h
   for (int i = 0; i < n; ++i) {
     if (!hasMP[i]) continue;
     VisEdge e;
-    e.idx = i; e.stereo = !(obs[3 * i + 2] < 0);
+    e.idx = i; e.stereo = !rig28 && !(obs[3 * i + 2] < 0);
+    e.cam = rig28 && i >= Nleft ? 1 : 0;
     e.obs[0] = obs[3 * i]; e.obs[1] = obs[3 * i + 1]; e.obs[2] = obs[3 * i + 2];
     for (int k = 0; k < 3; ++k) e.Xw[k] = Xw[3 * i + k];
     const float is2 = invSigma2[i] / 1.0f;
@@ -993,6 +1045,25 @@ extern "C" int orc_pose_inertial_optimization_last_frame(int n, const uint8_t* h
   return nInitial - nBad;
 }
 
+extern "C" int orc_pose_inertial_optimization_last_frame(int n, const uint8_t* hasMP, const float* obs, const float* invSigma2,
+                                                         const float* Xw, const uint8_t* closeFlag, float fx, float fy, float cx,
+                                                         float cy, float bf, const float* Tbc12, const float* prevState21,
+                                                         const orc_imu_preintegrated* preFrame, const orc_imu_preintegrated* preKF,
+                                                         const double* prevPrior246, int bRecInit, float* state21,
+                                                         uint8_t* outlier, double* prior246) {
+  return poseInertialLastFrame(n, hasMP, obs, invSigma2, Xw, closeFlag, fx, fy, cx, cy, bf, Tbc12, prevState21, preFrame, preKF,
+                               prevPrior246, bRecInit, state21, outlier, prior246, -1, nullptr);
+}
+extern "C" int orc_pose_inertial_optimization_last_frame_fisheye(int n, int Nleft, const uint8_t* hasMP, const float* obs,
+                                                                 const float* invSigma2, const float* Xw, const uint8_t* closeFlag,
+                                                                 const float* rig28, const float* Tbc12, const float* prevState21,
+                                                                 const orc_imu_preintegrated* preFrame, const orc_imu_preintegrated* preKF,
+                                                                 const double* prevPrior246, int bRecInit, float* state21,
+                                                                 uint8_t* outlier, double* prior246) {
+  return poseInertialLastFrame(n, hasMP, obs, invSigma2, Xw, closeFlag, 0, 0, 0, 0, 0, Tbc12, prevState21, preFrame, preKF, prevPrior246,
+                               bRecInit, state21, outlier, prior246, Nleft, rig28);
+}
+
 // =========================================================================================================================
 // Optimizer::LocalInertialBA (Optimizer.cc:2324-2897) on the flattened graph the reference assembles at :2337-2768:
 //   kfKind[k]: 0 = temporal optimizable keyframe (pose, velocity, gyro bias, acc bias free), 1 = the fixed keyframe before the
@@ -1072,12 +1143,15 @@ static void inertialFull(const orc_imu_preintegrated* pre, const IbaKF& K1, cons
 }  // namespace imu
 }  // namespace orc
 
-extern "C" int orc_local_inertial_ba(int nKF, float* kfState21, const uint8_t* kfKind, int nMP, float* mpPos, const uint8_t* mpClose,
-                                     int nE, const int* eKF, const int* eMP, const float* eObs, const float* eInvSigma2, int nI,
-                                     const int* iKF1, const int* iKF2, const orc_imu_preintegrated* iPre, const uint8_t* iRobust,
-                                     const float* iInfoScale, float fx, float fy, float cx, float cy, float bf, const float* Tbc12,
-                                     int bLarge, uint8_t* eraseFlag, int* stats2) {
+// eRight / rig28: fisheye rig (pKFi->mpCamera2): eRight[e] != 0 = EdgeMono(1) on the right camera (:2722-2754), all edges monocular
+static int localInertialBA(int nKF, float* kfState21, const uint8_t* kfKind, int nMP, float* mpPos, const uint8_t* mpClose, int nE,
+                           const int* eKF, const int* eMP, const float* eObs, const float* eInvSigma2, int nI, const int* iKF1,
+                           const int* iKF2, const orc_imu_preintegrated* iPre, const uint8_t* iRobust, const float* iInfoScale, float fx,
+                           float fy, float cx, float cy, float bf, const float* Tbc12, int bLarge, uint8_t* eraseFlag, int* stats2,
+                           const uint8_t* eRight, const float* rig28) {
   using namespace orc::imu;
+  auto isStereo = [&](int e) { return !rig28 && !(eObs[3 * e + 2] < 0); };
+  auto camOf = [&](int e) { return rig28 && eRight[e] ? 1 : 0; };
   IbaState S;
   S.kf.resize(nKF);
   int nOpt = 0;
@@ -1092,6 +1166,7 @@ extern "C" int orc_local_inertial_ba(int nKF, float* kfState21, const uint8_t* k
     mul3v(K.P.Rcb, K.P.tbc, K.P.tcb);
     for (double& c : K.P.tcb) c = -c;
     K.P.bf = bf; K.P.fx = fx; K.P.fy = fy; K.P.cx = cx; K.P.cy = cy;
+    if (rig28) K.P.setRig(rig28);
     K.P.refreshCamera();
     K.col = kfKind[k] == 0 ? nOpt++ : -1;
   }
@@ -1112,13 +1187,13 @@ extern "C" int orc_local_inertial_ba(int nKF, float* kfState21, const uint8_t* k
 
   // error storage (the values of the last computeActiveErrors)
   std::vector<double> vErr((size_t)nE * 3), iErr((size_t)nI * 9), gErr((size_t)nI * 3), aErr((size_t)nI * 3);
-  auto visChi2 = [&](int e) { const bool st = !(eObs[3 * e + 2] < 0); const double info = eInvSigma2[e]; double s = 0; for (int k = 0; k < (st ? 3 : 2); ++k) s += vErr[3 * e + k] * info * vErr[3 * e + k]; return s; };
+  auto visChi2 = [&](int e) { const bool st = isStereo(e); const double info = eInvSigma2[e]; double s = 0; for (int k = 0; k < (st ? 3 : 2); ++k) s += vErr[3 * e + k] * info * vErr[3 * e + k]; return s; };
   auto inertialChi2 = [&](int i) { double s = 0; for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) s += iErr[9 * i + r] * InfoI[(size_t)i * 81 + r * 9 + c] * iErr[9 * i + c]; return s; };
   auto rwChi2 = [&](const std::vector<double>& E, const std::vector<double>& I3, int i) { double s = 0; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) s += E[3 * i + r] * I3[(size_t)i * 9 + r * 3 + c] * E[3 * i + c]; return s; };
   auto computeActiveErrors = [&]() {
     for (int e = 0; e < nE; ++e) {
       VisEdge ve;
-      ve.stereo = !(eObs[3 * e + 2] < 0);
+      ve.stereo = isStereo(e); ve.cam = camOf(e);
       for (int k = 0; k < 3; ++k) { ve.obs[k] = eObs[3 * e + k]; ve.Xw[k] = S.pts[3 * eMP[e] + k]; }
       ve.err[2] = 0;
       ve.computeError(S.kf[eKF[e]].P);
@@ -1131,7 +1206,7 @@ extern "C" int orc_local_inertial_ba(int nKF, float* kfState21, const uint8_t* k
   };
   auto activeRobustChi2 = [&]() {
     double s = 0;
-    for (int e = 0; e < nE; ++e) { double rho[3]; huber(!(eObs[3 * e + 2] < 0) ? thStereo : thMono, visChi2(e), rho); s += rho[0]; }
+    for (int e = 0; e < nE; ++e) { double rho[3]; huber(isStereo(e) ? thStereo : thMono, visChi2(e), rho); s += rho[0]; }
     for (int i = 0; i < nI; ++i) {
       const double c = inertialChi2(i);
       if (iRobust[i]) { double rho[3]; huber(thInertial, c, rho); s += rho[0]; } else s += c;
@@ -1149,7 +1224,7 @@ extern "C" int orc_local_inertial_ba(int nKF, float* kfState21, const uint8_t* k
     for (int e = 0; e < nE; ++e) {
       const IbaKF& K = S.kf[eKF[e]];
       VisEdge ve;
-      ve.stereo = !(eObs[3 * e + 2] < 0);
+      ve.stereo = isStereo(e); ve.cam = camOf(e);
       for (int k = 0; k < 3; ++k) ve.Xw[k] = S.pts[3 * eMP[e] + k];
       const int d = ve.stereo ? 3 : 2;
       const double info = eInvSigma2[e];
@@ -1160,10 +1235,11 @@ extern "C" int orc_local_inertial_ba(int nKF, float* kfState21, const uint8_t* k
       ve.jacobian(K.P, Jp);
       {  // EdgeMono / EdgeStereo::linearizeOplus: _jacobianOplusXi = -proj_jac * Rcw (G2oTypes.cc:334-415)
         double Xc[3], pj[9];
-        K.P.camPoint(ve.Xw, Xc);
-        K.P.projectJac(Xc, pj);
+        K.P.camPoint(ve.Xw, Xc, ve.cam);
+        K.P.projectJac(Xc, pj, ve.cam);
         if (ve.stereo) { pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + K.P.bf * (1.0 / (Xc[2] * Xc[2])); }
-        for (int r = 0; r < d; ++r) for (int c = 0; c < 3; ++c) Jl[r * 3 + c] = -(pj[r * 3] * K.P.Rcw[c] + pj[r * 3 + 1] * K.P.Rcw[3 + c] + pj[r * 3 + 2] * K.P.Rcw[6 + c]);
+        const double* Rc = K.P.R_cw(ve.cam);
+        for (int r = 0; r < d; ++r) for (int c = 0; c < 3; ++c) Jl[r * 3 + c] = -(pj[r * 3] * Rc[c] + pj[r * 3 + 1] * Rc[3 + c] + pj[r * 3 + 2] * Rc[6 + c]);
       }
       const double* er = &vErr[3 * e];
       const int l = eMP[e];
@@ -1328,14 +1404,15 @@ extern "C" int orc_local_inertial_ba(int nKF, float* kfState21, const uint8_t* k
   memset(eraseFlag, 0, nE);
   if ((2 * err0 < errEnd || std::isnan(err0) || std::isnan(errEnd)) && !bLarge) return 0;   // "FAIL LOCAL-INERTIAL BA"
   for (int e = 0; e < nE; ++e) {   // :2773-2801 with the errors of the last computeActiveErrors
-    const bool st = !(eObs[3 * e + 2] < 0);
+    const bool st = isStereo(e);
     const double c = visChi2(e);
     if (st) { if (c > 7.815f) eraseFlag[e] = 1; }
     else {
       const bool bClose = mpClose[eMP[e]] != 0;
       const IbaKF& K = S.kf[eKF[e]];
       const double* X = &S.pts[3 * eMP[e]];
-      const bool depthPos = (K.P.Rcw[6] * X[0] + K.P.Rcw[7] * X[1] + K.P.Rcw[8] * X[2] + K.P.tcw[2]) > 0.0;
+      const double* Rc = K.P.R_cw(camOf(e));
+      const bool depthPos = (Rc[6] * X[0] + Rc[7] * X[1] + Rc[8] * X[2] + K.P.t_cw(camOf(e))[2]) > 0.0;
       if ((c > 5.991f && !bClose) || (c > 1.5f * 5.991f && bClose) || !depthPos) eraseFlag[e] = 1;
     }
   }
@@ -1348,4 +1425,21 @@ extern "C" int orc_local_inertial_ba(int nKF, float* kfState21, const uint8_t* k
   }
   for (int k = 0; k < 3 * nMP; ++k) mpPos[k] = (float)S.pts[k];
   return 1;
+}
+
+extern "C" int orc_local_inertial_ba(int nKF, float* kfState21, const uint8_t* kfKind, int nMP, float* mpPos, const uint8_t* mpClose,
+                                     int nE, const int* eKF, const int* eMP, const float* eObs, const float* eInvSigma2, int nI,
+                                     const int* iKF1, const int* iKF2, const orc_imu_preintegrated* iPre, const uint8_t* iRobust,
+                                     const float* iInfoScale, float fx, float fy, float cx, float cy, float bf, const float* Tbc12,
+                                     int bLarge, uint8_t* eraseFlag, int* stats2) {
+  return localInertialBA(nKF, kfState21, kfKind, nMP, mpPos, mpClose, nE, eKF, eMP, eObs, eInvSigma2, nI, iKF1, iKF2, iPre, iRobust,
+                         iInfoScale, fx, fy, cx, cy, bf, Tbc12, bLarge, eraseFlag, stats2, nullptr, nullptr);
+}
+extern "C" int orc_local_inertial_ba_fisheye(int nKF, float* kfState21, const uint8_t* kfKind, int nMP, float* mpPos,
+                                             const uint8_t* mpClose, int nE, const int* eKF, const int* eMP, const float* eObs,
+                                             const uint8_t* eRight, const float* eInvSigma2, int nI, const int* iKF1, const int* iKF2,
+                                             const orc_imu_preintegrated* iPre, const uint8_t* iRobust, const float* iInfoScale,
+                                             const float* rig28, const float* Tbc12, int bLarge, uint8_t* eraseFlag, int* stats2) {
+  return localInertialBA(nKF, kfState21, kfKind, nMP, mpPos, mpClose, nE, eKF, eMP, eObs, eInvSigma2, nI, iKF1, iKF2, iPre, iRobust,
+                         iInfoScale, 0, 0, 0, 0, 0, Tbc12, bLarge, eraseFlag, stats2, eRight, rig28);
 }

@@ -168,6 +168,23 @@ int orc_local_inertial_ba(int nKF, float* kfState21, const uint8_t* kfKind, int 
                           const int* iKF2, const orc_imu_preintegrated* iPre, const uint8_t* iRobust, const float* iInfoScale,
                           float fx, float fy, float cx, float cy, float bf, const float* Tbc12, int bLarge, uint8_t* eraseFlag,
                           int* stats2);
+/* fisheye-rig forms: rig28 = left KB8 (8), right KB8 (8), Trl rotation (9, row-major) + translation (3); features / edges are
+ * monocular on the left (index < Nleft, eRight == 0) or the right camera */
+int orc_pose_inertial_optimization_last_keyframe_fisheye(int n, int Nleft, const uint8_t* hasMP, const float* obs,
+                                                         const float* invSigma2, const float* Xw, const uint8_t* closeFlag,
+                                                         const float* rig28, const float* Tbc12, const float* kfState21,
+                                                         const orc_imu_preintegrated* pre, int bRecInit, float* state21,
+                                                         uint8_t* outlier, double* prior246);
+int orc_pose_inertial_optimization_last_frame_fisheye(int n, int Nleft, const uint8_t* hasMP, const float* obs, const float* invSigma2,
+                                                      const float* Xw, const uint8_t* closeFlag, const float* rig28, const float* Tbc12,
+                                                      const float* prevState21, const orc_imu_preintegrated* preFrame,
+                                                      const orc_imu_preintegrated* preKF, const double* prevPrior246, int bRecInit,
+                                                      float* state21, uint8_t* outlier, double* prior246);
+int orc_local_inertial_ba_fisheye(int nKF, float* kfState21, const uint8_t* kfKind, int nMP, float* mpPos, const uint8_t* mpClose,
+                                  int nE, const int* eKF, const int* eMP, const float* eObs, const uint8_t* eRight,
+                                  const float* eInvSigma2, int nI, const int* iKF1, const int* iKF2, const orc_imu_preintegrated* iPre,
+                                  const uint8_t* iRobust, const float* iInfoScale, const float* rig28, const float* Tbc12, int bLarge,
+                                  uint8_t* eraseFlag, int* stats2);
 float orc_fast_atan2(float y, float x);
 float orc_cosf(float x);
 float orc_sinf(float x);

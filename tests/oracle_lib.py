@@ -473,6 +473,13 @@ def pose_inertial_optimization_last_keyframe(p, pre, bRecInit=False):
     a = [np.ascontiguousarray(p[k]) for k in ("hasMP", "obs", "invSigma2", "Xw", "close", "Tbc12", "kfState")]
     pre = np.ascontiguousarray(pre, np.float32)
     cam = p["cam"]
+    if p.get("rig28") is not None:
+        L.orc_pose_inertial_optimization_last_keyframe_fisheye.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.c_int] + [C.c_void_p] * 3
+        rig = np.ascontiguousarray(p["rig28"], np.float32)
+        r = L.orc_pose_inertial_optimization_last_keyframe_fisheye(n, int(p["Nleft"]), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]),
+                                                                   _p(rig), _p(a[5]), _p(a[6]), _p(pre), int(bool(bRecInit)), _p(state),
+                                                                   _p(outl), _p(prior))
+        return r, state, outl, prior
     r = L.orc_pose_inertial_optimization_last_keyframe(n, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), cam["fx"], cam["fy"],
                                                        cam["cx"], cam["cy"], cam["bf"], _p(a[5]), _p(a[6]), _p(pre),
                                                        int(bool(bRecInit)), _p(state), _p(outl), _p(prior))
@@ -490,6 +497,13 @@ def pose_inertial_optimization_last_frame(p, prevState, preFrame, preKF, prevPri
     b = [np.ascontiguousarray(prevState, np.float32), np.ascontiguousarray(preFrame, np.float32),
          np.ascontiguousarray(preKF, np.float32), np.ascontiguousarray(prevPrior, np.float64)]
     cam = p["cam"]
+    if p.get("rig28") is not None:
+        L.orc_pose_inertial_optimization_last_frame_fisheye.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 11 + [C.c_int] + [C.c_void_p] * 3
+        rig = np.ascontiguousarray(p["rig28"], np.float32)
+        r = L.orc_pose_inertial_optimization_last_frame_fisheye(n, int(p["Nleft"]), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), _p(rig),
+                                                                _p(a[5]), _p(b[0]), _p(b[1]), _p(b[2]), _p(b[3]), int(bool(bRecInit)),
+                                                                _p(state), _p(outl), _p(prior))
+        return r, state, outl, prior
     r = L.orc_pose_inertial_optimization_last_frame(n, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), cam["fx"], cam["fy"], cam["cx"],
                                                     cam["cy"], cam["bf"], _p(a[5]), _p(b[0]), _p(b[1]), _p(b[2]), _p(b[3]),
                                                     int(bool(bRecInit)), _p(state), _p(outl), _p(prior))
@@ -508,6 +522,14 @@ def local_inertial_ba(p, pre, bLarge=False):
     a = [np.ascontiguousarray(p[k]) for k in ("kfKind", "mpClose", "eKF", "eMP", "eObs", "eInvSigma2", "iKF1", "iKF2", "iRobust", "iInfoScale", "Tbc12")]
     pre = np.ascontiguousarray(pre, np.float32)
     cam = p["cam"]
+    if p.get("rig28") is not None:
+        L.orc_local_inertial_ba_fisheye.argtypes = [C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp,
+                                                    vp, vp, C.c_int, vp, vp]
+        rig = np.ascontiguousarray(p["rig28"], np.float32); er = np.ascontiguousarray(p["eRight"], np.uint8)
+        r = L.orc_local_inertial_ba_fisheye(len(kf), _p(kf), _p(a[0]), len(mp), _p(mp), _p(a[1]), nE, _p(a[2]), _p(a[3]), _p(a[4]), _p(er),
+                                            _p(a[5]), len(a[6]), _p(a[6]), _p(a[7]), _p(pre), _p(a[8]), _p(a[9]), _p(rig), _p(a[10]),
+                                            int(bool(bLarge)), _p(erase), _p(stats))
+        return r, kf, mp, erase, stats
     r = L.orc_local_inertial_ba(len(kf), _p(kf), _p(a[0]), len(mp), _p(mp), _p(a[1]), nE, _p(a[2]), _p(a[3]), _p(a[4]), _p(a[5]),
                                 len(a[6]), _p(a[6]), _p(a[7]), _p(pre), _p(a[8]), _p(a[9]), cam["fx"], cam["fy"], cam["cx"], cam["cy"],
                                 cam["bf"], _p(a[10]), int(bool(bLarge)), _p(erase), _p(stats))

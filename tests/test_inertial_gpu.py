@@ -200,3 +200,62 @@ def test_local_inertial_ba(opt, large, n_opt, seeds):
         a0 = max(ang(p["kfState"][k, :9], p["true"][k, :9]) for k in np.where(optk)[0])
         a1 = max(ang(kf[k, :9], p["true"][k, :9]) for k in np.where(optk)[0])
         assert a1 < 0.2 * a0 + 0.05
+
+
+def test_pose_inertial_optimization_fisheye_rig(opt):
+    """Both tracking optimisers on the KannalaBrandt8 rig (left / right monocular edges, ImuCamPose with two cameras)."""
+    from morb_slam_amd.synth import make_inertial_sequence
+    dev = torch.device("cuda", 0)
+    seq = [make_inertial_sequence(500, seed=s, n_imu=20, rig=True) for s in range(4)]
+    nga, walk = imu_calib_diagonals()
+    pre = lambda p, a, g, d: orc.imu_preintegrate(p["bias"], nga, walk, p[a], p[g], p[d])
+    preA = np.stack([pre(pA, "acc", "gyro", "dt") for pA, _ in seq])
+    resA = [orc.pose_inertial_optimization_last_keyframe(pA, preA[i]) for i, (pA, _) in enumerate(seq)]
+    rig = seq[0][0]["rig28"]
+    nLeft = torch.tensor([pA["Nleft"] for pA, _ in seq], dtype=torch.int32, device=dev)
+    sa = lambda k: torch.from_numpy(np.stack([pA[k] for pA, _ in seq])).to(dev)
+    insA = [sa(k) for k in ("hasMP", "obs", "invSigma2", "Xw", "close", "kfState")] + [torch.from_numpy(preA).to(dev)]
+    stateA = sa("state0").clone()
+    ninA, outA, priorA = opt.PoseInertialOptimizationLastKeyFrame(insA[0], insA[1], insA[2], insA[3], insA[4], None, seq[0][0]["Tbc12"],
+                                                                  insA[5], insA[6], stateA, rig=rig, nLeft=nLeft)
+    torch.cuda.synchronize()
+    for i, r in enumerate(resA):
+        assert np.allclose(stateA[i].cpu().numpy(), r[1], atol=1e-4), np.abs(stateA[i].cpu().numpy() - r[1]).max()
+        assert int((outA[i].cpu().numpy() != r[2]).sum()) <= 1 and abs(int(ninA[i]) - r[0]) <= 1
+        H, Ho = priorA[i][21:].reshape(15, 15).cpu().numpy(), r[3][21:].reshape(15, 15)
+        if int((outA[i].cpu().numpy() != r[2]).sum()) == 0:
+            assert np.allclose(H, Ho, rtol=1e-4, atol=1e-6 * np.abs(Ho).max())
+    # frame B with the oracle's frame-A results on both sides
+    preF = np.stack([pre(pB, "accF", "gyroF", "dtF") for _, pB in seq]); preK = np.stack([pre(pB, "acc", "gyro", "dt") for _, pB in seq])
+    prevState = np.stack([r[1] for r in resA]); prevPrior = np.stack([r[3] for r in resA])
+    sb = lambda k: torch.from_numpy(np.stack([pB[k] for _, pB in seq])).to(dev)
+    insB = [sb(k) for k in ("hasMP", "obs", "invSigma2", "Xw", "close")] + [torch.from_numpy(x).to(dev) for x in (prevState, preF, preK, prevPrior)]
+    stateB = sb("state0").clone()
+    ninB, outB, priorB = opt.PoseInertialOptimizationLastFrame(insB[0], insB[1], insB[2], insB[3], insB[4], None, seq[0][0]["Tbc12"], insB[5],
+                                                               insB[6], insB[7], insB[8], stateB, rig=rig, nLeft=nLeft)
+    torch.cuda.synchronize()
+    for i, (_, pB) in enumerate(seq):
+        r = orc.pose_inertial_optimization_last_frame(pB, prevState[i], preF[i], preK[i], prevPrior[i])
+        assert np.allclose(stateB[i].cpu().numpy(), r[1], atol=1e-4), np.abs(stateB[i].cpu().numpy() - r[1]).max()
+        assert int((outB[i].cpu().numpy() != r[2]).sum()) <= 1 and abs(int(ninB[i]) - r[0]) <= 1
+        assert int(outB[i].sum()) > 0.5 * int((pB["outlier_truth"] & (pB["hasMP"] > 0)).sum())   # planted outliers found on both cameras
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_local_inertial_ba_fisheye_rig(opt, seed):
+    from morb_slam_amd.synth import make_inertial_ba_problem
+    nga, walk = imu_calib_diagonals()
+    p = make_inertial_ba_problem(n_opt=8, seed=seed, n_points=1200, rig=True)
+    pre = np.stack([orc.imu_preintegrate(p["bias"], nga, walk, p["acc"][a:b], p["gyro"][a:b], p["dt"][a:b])
+                    for a, b in zip(p["imuStart"][:-1], p["imuStart"][1:])])
+    r, kf_o, mp_o, er_o, st_o = orc.local_inertial_ba(p, pre)
+    kf, mp, er, st = opt.LocalInertialBA(p["kfState"], p["kfKind"], p["mpPos"], p["mpClose"], p["eKF"], p["eMP"], p["eObs"], p["eInvSigma2"],
+                                         p["iKF1"], p["iKF2"], pre, p["iRobust"], p["iInfoScale"], None, p["Tbc12"], rig=p["rig28"],
+                                         eRight=p["eRight"])
+    assert int(st[2]) == r == 1 and (int(st[0]), int(st[1])) == (int(st_o[0]), int(st_o[1])), (st, st_o)
+    optk = p["kfKind"] == 0
+    assert np.allclose(kf[optk], kf_o[optk], rtol=0, atol=1e-4), np.abs(kf[optk] - kf_o[optk]).max()
+    d = np.abs(mp - mp_o).max(1) / np.maximum(1.0, np.linalg.norm(mp_o, axis=1))
+    assert np.quantile(d, 0.99) < 1e-4 and d.max() < 1e-2, (np.quantile(d, 0.99), d.max())
+    assert (er != er_o).sum() <= max(2, len(er) // 2000)
+    assert er[p["eRight"] > 0].sum() > 0 and er[p["eRight"] == 0].sum() > 0
