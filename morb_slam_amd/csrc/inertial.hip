@@ -388,8 +388,8 @@ struct VIState {
   double Rcw[9], tcw[3];
   double Rcw1[9], tcw1[3];   // right camera of a rig
 };
-__device__ void load_state(const CamGeom& g, const float* s0, VIState& S);
-__device__ void refresh_camera(const CamGeom& g, VIState& S) {   // G2oTypes.cc:209-215
+template <bool RIG>
+__device__ __forceinline__ void refresh_camera_t(const CamGeom& g, VIState& S) {   // G2oTypes.cc:209-215
   double Rbw[9], tbw[3];
   transpose33(S.Rwb, Rbw);
   mul3v(Rbw, S.twb, tbw);
@@ -397,52 +397,69 @@ __device__ void refresh_camera(const CamGeom& g, VIState& S) {   // G2oTypes.cc:
   mul33(g.Rcb, Rbw, S.Rcw);
   mul3v(g.Rcb, tbw, S.tcw);
   for (int k = 0; k < 3; ++k) S.tcw[k] += g.tcb[k];
-  if (g.rig) {
+  if (RIG) {
     mul33(g.Rcb1, Rbw, S.Rcw1);
     mul3v(g.Rcb1, tbw, S.tcw1);
     for (int k = 0; k < 3; ++k) S.tcw1[k] += g.tcb1[k];
   }
 }
-__device__ void load_state(const CamGeom& g, const float* s0, VIState& S) {
+// RIG as a template parameter keeps the right camera's pose out of the registers of the pinhole instantiations
+__device__ __forceinline__ void refresh_camera(const CamGeom& g, VIState& S) { if (g.rig) refresh_camera_t<true>(g, S); else refresh_camera_t<false>(g, S); }
+template <bool RIG>
+__device__ __forceinline__ void load_state_t(const CamGeom& g, const float* s0, VIState& S) {
   for (int k = 0; k < 9; ++k) S.Rwb[k] = s0[k];
   for (int k = 0; k < 3; ++k) { S.twb[k] = s0[9 + k]; S.v[k] = s0[12 + k]; S.bg[k] = s0[15 + k]; S.ba[k] = s0[18 + k]; }
-  refresh_camera(g, S);
+  refresh_camera_t<RIG>(g, S);
 }
-__device__ void apply_update(const CamGeom& g, VIState& S, const double* x) {   // ImuCamPose::Update + the additive vertices
+__device__ __forceinline__ void load_state(const CamGeom& g, const float* s0, VIState& S) { if (g.rig) load_state_t<true>(g, s0, S); else load_state_t<false>(g, s0, S); }
+template <bool RIG>
+__device__ __forceinline__ void apply_update_t(const CamGeom& g, VIState& S, const double* x) {   // ImuCamPose::Update + the additive vertices
   double t[3], dR[9];
   mul3v(S.Rwb, x + 3, t);
   for (int k = 0; k < 3; ++k) S.twb[k] += t[k];
   exp_so3(x, dR);
   mul33(S.Rwb, dR, S.Rwb);
-  refresh_camera(g, S);
+  refresh_camera_t<RIG>(g, S);
   for (int k = 0; k < 3; ++k) { S.v[k] += x[6 + k]; S.bg[k] += x[9 + k]; S.ba[k] += x[12 + k]; }
 }
+__device__ __forceinline__ void apply_update(const CamGeom& g, VIState& S, const double* x) { if (g.rig) apply_update_t<true>(g, S, x); else apply_update_t<false>(g, S, x); }
 // visual edge: error (obs - projection) and chi2; st = stereo
-__device__ __forceinline__ double vis_error(const CamGeom& g, const VIState& S, const double* X, const float* o, bool st, double info,
-                                            double* err, double* Xc, int cam = 0) {
-  mul3v(cam ? S.Rcw1 : S.Rcw, X, Xc);
-  for (int k = 0; k < 3; ++k) Xc[k] += (cam ? S.tcw1 : S.tcw)[k];
+template <bool RIG>
+__device__ __forceinline__ double vis_error_t(const CamGeom& g, const VIState& S, const double* X, const float* o, bool st, double info,
+                                              double* err, double* Xc, int cam) {
+  if (RIG && cam) { mul3v(S.Rcw1, X, Xc); for (int k = 0; k < 3; ++k) Xc[k] += S.tcw1[k]; }
+  else { mul3v(S.Rcw, X, Xc); for (int k = 0; k < 3; ++k) Xc[k] += S.tcw[k]; }
   double u, v;
-  if (g.rig) { double uv[2]; morbkb8::kb8_project_d(g.kb[cam], Xc, uv); u = uv[0]; v = uv[1]; }   // KannalaBrandt8::project(Vector3d)
+  if (RIG) { double uv[2]; morbkb8::kb8_project_d(g.kb[cam], Xc, uv); u = uv[0]; v = uv[1]; }   // KannalaBrandt8::project(Vector3d)
   else { u = g.fx * Xc[0] / Xc[2] + g.cx; v = g.fy * Xc[1] / Xc[2] + g.cy; }                       // Pinhole.cpp:38-44
   err[0] = (double)o[0] - u; err[1] = (double)o[1] - v; err[2] = 0;
   double c = err[0] * info * err[0] + err[1] * info * err[1];
   if (st) { const double invZ = 1 / Xc[2]; err[2] = (double)o[2] - (u - g.bf * invZ); c += err[2] * info * err[2]; }
   return c;
 }
+__device__ __forceinline__ double vis_error(const CamGeom& g, const VIState& S, const double* X, const float* o, bool st, double info,
+                                            double* err, double* Xc, int cam = 0) {
+  return g.rig ? vis_error_t<true>(g, S, X, o, st, info, err, Xc, cam) : vis_error_t<false>(g, S, X, o, st, info, err, Xc, 0);
+}
 // projectJac of the edge's camera (2 x 3 in pj[0..5]); pinhole: Pinhole.cpp:76-86
-__device__ __forceinline__ void cam_project_jac(const CamGeom& g, const double* Xc, int cam, double* pj) {
-  if (g.rig) { morbkb8::kb8_project_jac(g.kb[cam], Xc, pj); return; }
+template <bool RIG>
+__device__ __forceinline__ void cam_project_jac_t(const CamGeom& g, const double* Xc, int cam, double* pj) {
+  if (RIG) { morbkb8::kb8_project_jac(g.kb[cam], Xc, pj); return; }
   pj[0] = g.fx / Xc[2]; pj[1] = 0; pj[2] = -g.fx * Xc[0] / (Xc[2] * Xc[2]);
   pj[3] = 0; pj[4] = g.fy / Xc[2]; pj[5] = -g.fy * Xc[1] / (Xc[2] * Xc[2]);
 }
-__device__ __forceinline__ void vis_jacobian(const CamGeom& g, const double* Xc, bool st, double* J /*[3][6]*/, int cam = 0) {   // G2oTypes.cc:361-442
+__device__ __forceinline__ void cam_project_jac(const CamGeom& g, const double* Xc, int cam, double* pj) {
+  if (g.rig) cam_project_jac_t<true>(g, Xc, cam, pj); else cam_project_jac_t<false>(g, Xc, 0, pj);
+}
+template <bool RIG>
+__device__ __forceinline__ void vis_jacobian_t(const CamGeom& g, const double* Xc, bool st, double* J /*[3][6]*/, int cam) {   // G2oTypes.cc:361-442
   double Xb[3];
-  mul3v(cam ? g.Rbc1 : g.Rbc, Xc, Xb);
-  for (int k = 0; k < 3; ++k) Xb[k] += (cam ? g.tbc1 : g.tbc)[k];
-  const double* Rcb = cam ? g.Rcb1 : g.Rcb;
+  const bool c1 = RIG && cam;
+  mul3v(c1 ? g.Rbc1 : g.Rbc, Xc, Xb);
+  for (int k = 0; k < 3; ++k) Xb[k] += (c1 ? g.tbc1 : g.tbc)[k];
+  const double* Rcb = c1 ? g.Rcb1 : g.Rcb;
   double pj[9];
-  cam_project_jac(g, Xc, cam, pj);
+  cam_project_jac_t<RIG>(g, Xc, cam, pj);
   pj[6] = pj[7] = pj[8] = 0;
   if (st) { pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + g.bf * (1.0 / (Xc[2] * Xc[2])); }
   const double x = Xb[0], y = Xb[1], z = Xb[2];
@@ -455,6 +472,9 @@ __device__ __forceinline__ void vis_jacobian(const CamGeom& g, const double* Xc,
 #pragma unroll
     for (int c = 0; c < 6; ++c) J[r * 6 + c] = PR[0] * Sd[c] + PR[1] * Sd[6 + c] + PR[2] * Sd[12 + c];
   }
+}
+__device__ __forceinline__ void vis_jacobian(const CamGeom& g, const double* Xc, bool st, double* J, int cam = 0) {
+  if (g.rig) vis_jacobian_t<true>(g, Xc, st, J, cam); else vis_jacobian_t<false>(g, Xc, st, J, 0);
 }
 __device__ __forceinline__ double huber_w(double delta, double e2) {   // rho'(e2), robust_kernel_impl.cpp:65-91
   return e2 <= delta * delta ? 1.0 : delta / sqrt(e2);
@@ -588,7 +608,7 @@ __device__ unsigned long long g_inertialPhase[16];
 #else
 #define IMARK(k)
 #endif
-template <bool LASTFRAME>
+template <bool LASTFRAME, bool RIG>
 __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __restrict__ count, const uint8_t* __restrict__ hasMP,
                                                        const float* __restrict__ obs, const float* __restrict__ invSigma2,
                                                        const float* __restrict__ Xw, const uint8_t* __restrict__ closeFlag,
@@ -599,6 +619,7 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
                                                        int bRecInit, float* __restrict__ stateIO, uint8_t* __restrict__ outlier,
                                                        int* __restrict__ nInliersOut, double* __restrict__ prior) {
   __shared__ InertialWork Wk;
+  __shared__ VIState sS1;   // state 1 (keyframe / previous frame): only the dense-edge threads read it, one thread updates it
   constexpr int NV = LASTFRAME ? 30 : 15;
   // threads on the visual edges; wave 3 evaluates the inertial edge and (last-frame variant) wave 2 the prior edge meanwhile
   constexpr int NVIS = LASTFRAME ? 128 : 192, NVW = NVIS / 64;
@@ -608,7 +629,7 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   const morb_imu_preintegrated& P = pre[f];
   const double* pr = LASTFRAME ? prevPrior + (size_t)246 * f : nullptr;
-  const int nL = g.rig ? nLeft[f] : n;   // fisheye rig: features >= nL are right-camera observations; every edge is monocular
+  const int nL = RIG ? nLeft[f] : n;   // fisheye rig: features >= nL are right-camera observations; every edge is monocular
 
   int nInit = 0;
   for (int i = tid; i < n; i += 256) if (hasMP[base + i]) { ++nInit; outlier[base + i] = 0; }
@@ -638,11 +659,16 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
   unsigned long long t0_ = wall_clock64();
 #endif
   IMARK(0);
-  VIState S, Sprev, S1;
-  load_state(g, stateIO + 21 * f, S);
-  load_state(g, state1 + 21 * f, S1);
-  Sprev = S;
-  __syncthreads();   // the setup above used J / Jp as scratch
+  VIState S, Sprev;   // Sprev: only its camera poses are ever assigned / read
+  load_state_t<RIG>(g, stateIO + 21 * f, S);
+  if (tid == 0) load_state_t<RIG>(g, state1 + 21 * f, sS1);
+  const VIState& S1 = sS1;
+  auto keep_cameras = [&]() {
+    for (int k = 0; k < 9; ++k) { Sprev.Rcw[k] = S.Rcw[k]; if (RIG) Sprev.Rcw1[k] = S.Rcw1[k]; }
+    for (int k = 0; k < 3; ++k) { Sprev.tcw[k] = S.tcw[k]; if (RIG) Sprev.tcw1[k] = S.tcw1[k]; }
+  };
+  keep_cameras();
+  __syncthreads();   // the setup above used J / Jp as scratch; sS1 is visible
   for (int k = tid; k < 216; k += 256) Wk.J[k] = 0;
   for (int k = tid; k < 225; k += 256) Wk.Jp[k] = 0;
   if (!LASTFRAME && tid == 0) imu_delta(P, S1.bg, S1.ba, Wk.delta, Wk.delta + 9, Wk.delta + 12, Wk.delta + 15);
@@ -659,7 +685,7 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
     bool ok = true;
     for (int iter = 0; iter < 10 && ok; ++iter) {
       IMARK(1);
-      Sprev = S;   // the state the active edges' errors belong to
+      keep_cameras();   // the state the active edges' errors belong to
       // ---- visual edges -> 6 x 6 block and right-hand side of the frame's pose
       if (tid < NVIS) {
         double acc[27];
@@ -668,14 +694,14 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
         for (int i = tid; i < n; i += NVIS) {
           if (!hasMP[base + i] || outlier[base + i]) continue;
           const float* o = obs + (base + i) * 3;
-          const bool st = !g.rig && !(o[2] < 0);
+          const bool st = !RIG && !(o[2] < 0);
           const int cam = i >= nL ? 1 : 0;
           const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
           const double info = (double)invSigma2[base + i];
           double err[3], Xc[3], J[18];
-          const double c = vis_error(g, S, X, o, st, info, err, Xc, cam);
+          const double c = vis_error_t<RIG>(g, S, X, o, st, info, err, Xc, cam);
           const double w = robust ? huber_w(st ? deltaStereo : deltaMono, c) : 1.0;
-          vis_jacobian(g, Xc, st, J, cam);   // a mono edge has a zero third row and err[2] = 0: one fully unrolled 3-row form (registers only)
+          vis_jacobian_t<RIG>(g, Xc, st, J, cam);   // a mono edge has a zero third row and err[2] = 0: one fully unrolled 3-row form (registers only)
           int q = 0;
 #pragma unroll
           for (int r = 0; r < 6; ++r) {
@@ -774,8 +800,8 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
       double x[NV];
       for (int k = 0; k < NV; ++k) x[k] = Wk.x[k];
       ok = Wk.flag != 0;
-      apply_update(g, S, x);
-      if (LASTFRAME) apply_update(g, S1, x + 15);
+      apply_update_t<RIG>(g, S, x);
+      if (LASTFRAME && tid == 0) apply_update_t<RIG>(g, sS1, x + 15);
       __syncthreads();
       IMARK(7);
     }
@@ -787,11 +813,11 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
     for (int i = tid; i < n; i += 256) {
       if (!hasMP[base + i]) continue;
       const float* o = obs + (base + i) * 3;
-      const bool st = !g.rig && !(o[2] < 0);
+      const bool st = !RIG && !(o[2] < 0);
       const int cam = i >= nL ? 1 : 0;
       const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
       double err[3], Xc[3];
-      const float chi2 = (float)vis_error(g, outlier[base + i] ? S : Sprev, X, o, st, (double)invSigma2[base + i], err, Xc, cam);
+      const float chi2 = (float)vis_error_t<RIG>(g, outlier[base + i] ? S : Sprev, X, o, st, (double)invSigma2[base + i], err, Xc, cam);
       bool isOut;
       if (st) isOut = chi2 > chi2Stereo[it];
       else {
@@ -820,10 +846,10 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
     for (int i = tid; i < n; i += 256) {
       if (!hasMP[base + i]) continue;
       const float* o = obs + (base + i) * 3;
-      const bool st = !g.rig && !(o[2] < 0);
+      const bool st = !RIG && !(o[2] < 0);
       const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
       double err[3], Xc[3];
-      const float chi2 = (float)vis_error(g, S, X, o, st, (double)invSigma2[base + i], err, Xc, i >= nL ? 1 : 0);
+      const float chi2 = (float)vis_error_t<RIG>(g, S, X, o, st, (double)invSigma2[base + i], err, Xc, i >= nL ? 1 : 0);
       if (chi2 < (st ? 24.f : 18.f)) outlier[base + i] = 0; else ++bad;
     }
     bad = (int)wave_sum((double)bad);
@@ -850,13 +876,13 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
   for (int i = tid; i < n; i += 256) {
     if (!hasMP[base + i] || outlier[base + i]) continue;
     const float* o = obs + (base + i) * 3;
-    const bool st = !g.rig && !(o[2] < 0);
+    const bool st = !RIG && !(o[2] < 0);
     const int cam = i >= nL ? 1 : 0;
     const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
     const double info = (double)invSigma2[base + i];
     double err[3], Xc[3], J[18];
-    vis_error(g, S, X, o, st, info, err, Xc, cam);
-    vis_jacobian(g, Xc, st, J, cam);
+    vis_error_t<RIG>(g, S, X, o, st, info, err, Xc, cam);
+    vis_jacobian_t<RIG>(g, Xc, st, J, cam);
     int q = 0;
 #pragma unroll
     for (int r = 0; r < 6; ++r)
@@ -1567,12 +1593,12 @@ static int launch_pose_inertial(bool lastFrame, morb_optimizer* o, int nframes, 
   hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_optimizer_stream(o);
   CamGeom g;
   make_geom(Tbc12, fx, fy, cx, cy, bf, rig28, g);
-  if (lastFrame)
-    hipLaunchKernelGGL(k_pose_inertial<true>, dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, d_close,
-                       g, d_state1, d_pre, d_preKF, d_prevPrior, d_nLeft, bRecInit, d_state, d_outlier, d_nInliers, d_prior);
-  else
-    hipLaunchKernelGGL(k_pose_inertial<false>, dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, d_close,
-                       g, d_state1, d_pre, d_preKF, d_prevPrior, d_nLeft, bRecInit, d_state, d_outlier, d_nInliers, d_prior);
+#define MORB_LAUNCH_PI(LF, RG)                                                                                                       \
+  hipLaunchKernelGGL((k_pose_inertial<LF, RG>), dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, d_close, \
+                     g, d_state1, d_pre, d_preKF, d_prevPrior, d_nLeft, bRecInit, d_state, d_outlier, d_nInliers, d_prior)
+  if (lastFrame) { if (rig28) MORB_LAUNCH_PI(true, true); else MORB_LAUNCH_PI(true, false); }
+  else { if (rig28) MORB_LAUNCH_PI(false, true); else MORB_LAUNCH_PI(false, false); }
+#undef MORB_LAUNCH_PI
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
 }
