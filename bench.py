@@ -278,8 +278,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128,
-                    help="stereo frames per step per GPU (64 -> 62.8 k, 128 -> 65.7 k, 192 -> 67.9 k frames/s on one MI355X)")
+    ap.add_argument("--batch", type=int, default=256,
+                    help="stereo frames per step per GPU (64 -> 62.8 k, 128 -> 65.0 k, 192 -> 67.1 k, 256 -> 69.0 k frames/s on one MI355X)")
     ap.add_argument("--sets", type=int, default=2, help="buffer sets = steps in flight (>= 2)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="join all streams at the end of every step instead of running step i's matchers underneath step "

@@ -15,7 +15,7 @@ for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INST
 done
 python3 tools/pmc_table.py "$O/pmc" > "$O/pmc_issue_table.txt"
 python3 tools/pmc_traffic.py "$O/pmc" 128 > "$O/pmc_traffic_b64.json"
-cp "$O/stats/s_kernel_stats.csv" "$O/extract_match_b128_kernel_stats.csv"
+cp "$O/stats/s_kernel_stats.csv" "$O/extract_match_b256_kernel_stats.csv"
 # the optimisers (secondary metrics): kernel stats of the tracking / mapping micro-benchmarks
 rocprofv3 --kernel-trace --stats -d "$O/opt" -o s --output-format csv -- python3 tools/bench_opt_all.py > "$O/optimisers_bench.txt" 2>/dev/null
 cp "$O/opt/s_kernel_stats.csv" "$O/optimisers_kernel_stats.csv"
