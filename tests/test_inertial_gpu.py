@@ -259,3 +259,41 @@ def test_local_inertial_ba_fisheye_rig(opt, seed):
     assert np.quantile(d, 0.99) < 1e-4 and d.max() < 1e-2, (np.quantile(d, 0.99), d.max())
     assert (er != er_o).sum() <= max(2, len(er) // 2000)
     assert er[p["eRight"] > 0].sum() > 0 and er[p["eRight"] == 0].sum() > 0
+
+
+def test_pose_inertial_edge_cases(opt):
+    """Few correspondences (optimizer.edges().size() < 10 stops after the first round), bRecInit (no recovery of weak
+    outliers), and a count array shorter than the capacity."""
+    from morb_slam_amd.synth import make_inertial_sequence
+    dev = torch.device("cuda", 0)
+    nga, walk = imu_calib_diagonals()
+    cases = [(5, False), (12, True), (25, True), (200, True)]
+    for n, rec in cases:
+        pA, pB = make_inertial_sequence(n, seed=7, n_imu=12)
+        cap = n + 9                                   # padded rows carry garbage that must be ignored through count
+        def pad(a, fill):
+            out = np.full((cap,) + a.shape[1:], fill, a.dtype); out[:n] = a; return out
+        preA = orc.imu_preintegrate(pA["bias"], nga, walk, pA["acc"], pA["gyro"], pA["dt"])
+        rA = orc.pose_inertial_optimization_last_keyframe(pA, preA, bRecInit=rec)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a[None])).to(dev)
+        ins = [t(pad(pA["hasMP"], 1)), t(pad(pA["obs"], 7.0)), t(pad(pA["invSigma2"], 1.0)), t(pad(pA["Xw"], 3.0)), t(pad(pA["close"], 0)),
+               t(pA["kfState"]), t(preA), torch.tensor([n], dtype=torch.int32, device=dev)]
+        state = t(pA["state0"]).clone()
+        nin, outl, prior = opt.PoseInertialOptimizationLastKeyFrame(ins[0], ins[1], ins[2], ins[3], ins[4], pA["cam"], pA["Tbc12"], ins[5],
+                                                                    ins[6], state, bRecInit=rec, count=ins[7])
+        torch.cuda.synchronize()
+        assert np.allclose(state[0].cpu().numpy(), rA[1], atol=1e-4), (n, rec, np.abs(state[0].cpu().numpy() - rA[1]).max())
+        assert int((outl[0, :n].cpu().numpy() != rA[2]).sum()) <= 1 and abs(int(nin[0]) - rA[0]) <= 1, (n, rec)
+        assert not outl[0, n:].any()                  # rows beyond count untouched
+        # frame B with the same padding
+        preF = orc.imu_preintegrate(pB["bias"], nga, walk, pB["accF"], pB["gyroF"], pB["dtF"])
+        preK = orc.imu_preintegrate(pB["bias"], nga, walk, pB["acc"], pB["gyro"], pB["dt"])
+        rB = orc.pose_inertial_optimization_last_frame(pB, rA[1], preF, preK, rA[3], bRecInit=rec)
+        insB = [t(pad(pB["hasMP"], 1)), t(pad(pB["obs"], 7.0)), t(pad(pB["invSigma2"], 1.0)), t(pad(pB["Xw"], 3.0)), t(pad(pB["close"], 0)),
+                t(rA[1]), t(preF), t(preK), t(rA[3])]
+        stateB = t(pB["state0"]).clone()
+        ninB, outB, _ = opt.PoseInertialOptimizationLastFrame(insB[0], insB[1], insB[2], insB[3], insB[4], pB["cam"], pB["Tbc12"], insB[5],
+                                                              insB[6], insB[7], insB[8], stateB, bRecInit=rec, count=ins[7], want_prior=False)
+        torch.cuda.synchronize()
+        assert np.allclose(stateB[0].cpu().numpy(), rB[1], atol=1e-4), (n, rec, np.abs(stateB[0].cpu().numpy() - rB[1]).max())
+        assert int((outB[0, :n].cpu().numpy() != rB[2]).sum()) <= 1 and abs(int(ninB[0]) - rB[0]) <= 1, (n, rec)
