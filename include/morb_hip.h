@@ -388,6 +388,20 @@ int morb_search_by_sim3_batch(morb_matcher* m, const morb_frame_params* P, int n
                               float th, int* d_vnMatch1, int* d_vnMatch2, int* d_match12, int* d_nFound, void* stream);
 
 
+/* ---- Frame-side helpers of the non-rectified / RGB-D input paths ----
+ * void Frame::UndistortKeyPoints()  Frame.h, Frame.cc:829-857: cv::undistortPoints(mvKeys, K, mDistCoef, I, mK) for nimg images
+ * (DEVICE pointers, image i at offset i*cap; d_count NULL = cap).  dist5 (HOST) = k1 k2 p1 p2 k3 (mDistCoef, k3 = 0 when it has
+ * four entries); dist5[0] == 0 copies the records (:830-833).  Only pt.x / pt.y differ between d_kps and d_kpsUn. */
+int morb_undistort_keypoints_batch(morb_matcher*, int nimg, int cap, const int* d_count, const morb_keypoint* d_kps, float fx,
+                                   float fy, float cx, float cy, const float* dist5, morb_keypoint* d_kpsUn, void* stream);
+/* void Frame::ComputeStereoFromRGBD(const cv::Mat& imDepth)  Frame.cc:1049-1067: d_depth = CV_32F depth images (already scaled
+ * by mDepthMapFactor), row / image pitches in floats; outputs mvuRight / mvDepth ([nimg][cap], -1 where the depth is <= 0). */
+int morb_stereo_from_rgbd_batch(morb_matcher*, int nimg, int cap, const int* d_count, const morb_keypoint* d_kps,
+                                const morb_keypoint* d_kpsUn, const float* d_depth, int width, int height, size_t rowPitchFloats,
+                                size_t imagePitchFloats, float bf, float* d_uRight, float* d_depthOut, void* stream);
+/* void Frame::ComputeImageBounds(const cv::Mat& imLeft)  Frame.cc:859-887 (host): bounds4 = mnMinX, mnMaxX, mnMinY, mnMaxY. */
+int morb_image_bounds(int width, int height, float fx, float fy, float cx, float cy, const float* dist5, float* bounds4);
+
 /* ------------------------------------------------------------------------------------------------------
  * Optimizer  (include/Optimizer.h:46-139, src/Optimizer.cc; g2o Levenberg-Marquardt semantics)
  * Poses cross the boundary the way the reference hands them to g2o: unit quaternion (x, y, z, w) followed by

@@ -114,6 +114,40 @@ class ORBmatcher:
                                                     1 if self.mbCheckOrientation else 0, ptr(out[0]), ptr(out[1]), self._st(stream)))
         return out
 
+    # ---- Frame-side helpers of the non-rectified / RGB-D input paths ----------------------------
+    def UndistortKeyPoints(self, kps, count, cam, dist, out=None, stream=None):
+        """Frame::UndistortKeyPoints for a batch: kps u8 [F, cap, 28] (cv::KeyPoint records), count i32 [F] or None, dist =
+        (k1, k2, p1, p2[, k3]) as in mDistCoef.  Returns the mvKeysUn records [F, cap, 28]."""
+        import torch
+        F, cap = kps.shape[0], kps.shape[1]
+        if out is None:
+            out = torch.zeros_like(kps)
+        d5 = np.zeros(5, np.float32); d5[:len(dist)] = np.asarray(dist, np.float32)
+        st = stream_arg(stream)
+        check(self._L.morb_undistort_keypoints_batch(self._h, F, cap, ptr(count), ptr(kps), cam["fx"], cam["fy"], cam["cx"], cam["cy"], ptr(d5),
+                                                     ptr(out), st))
+        return out
+
+    def ComputeStereoFromRGBD(self, kps, kpsUn, count, depth, bf, out=None, stream=None):
+        """Frame::ComputeStereoFromRGBD: depth f32 [F, H, W] (contiguous).  Returns (mvuRight, mvDepth) f32 [F, cap]."""
+        import torch
+        F, cap = kps.shape[0], kps.shape[1]
+        H, W = depth.shape[1], depth.shape[2]
+        if out is None:
+            out = (torch.empty((F, cap), dtype=torch.float32, device=kps.device), torch.empty((F, cap), dtype=torch.float32, device=kps.device))
+        st = stream_arg(stream)
+        check(self._L.morb_stereo_from_rgbd_batch(self._h, F, cap, ptr(count), ptr(kps), ptr(kpsUn), ptr(depth), W, H, W, H * W, float(bf),
+                                                  ptr(out[0]), ptr(out[1]), st))
+        return out
+
+    @staticmethod
+    def ComputeImageBounds(width, height, cam, dist):
+        """Frame::ComputeImageBounds -> (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+        d5 = np.zeros(5, np.float32); d5[:len(dist)] = np.asarray(dist, np.float32)
+        b = np.zeros(4, np.float32)
+        check(lib().morb_image_bounds(width, height, cam["fx"], cam["fy"], cam["cx"], cam["cy"], ptr(d5), ptr(b)))
+        return tuple(float(x) for x in b)
+
     def ComputeDistinctiveDescriptors(self, start, desc, stream=None):
         """MapPoint::ComputeDistinctiveDescriptors for many map points: start int32 [nMP + 1] (CSR), desc uint8 [total, 32];
         returns int32 [nMP] = row (within each point) of its most representative descriptor."""

@@ -258,3 +258,44 @@ float sinf_glibc(float y) {
 }
 
 }  // namespace orc
+
+// ---- cv::undistortPoints(src, K, distCoeffs, R = I, P) — OpenCV 4.x calib3d cvUndistortPointsInternal, the 6-argument overload's
+// TermCriteria(MAX_ITER, 5, 0.01): FP64, five fixed-point iterations, k = (k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4) with everything
+// past k3 zero for the reference's 4- or 5-entry mDistCoef.  Used by Frame::UndistortKeyPoints / ComputeImageBounds
+// (reference src/Frame.cc:829-887).  PARITY UNPINNED (OpenCV is not vendored).
+extern "C" void orc_undistort_points(int n, const float* xy, float fx, float fy, float cx, float cy, const float* dist5,
+                                     float pfx, float pfy, float pcx, float pcy, float* out) {
+  double k[12] = {0};
+  k[0] = dist5[0]; k[1] = dist5[1]; k[2] = dist5[2]; k[3] = dist5[3]; k[4] = dist5[4];
+  const double dfx = fx, dfy = fy, dcx = cx, dcy = cy, ifx = 1. / dfx, ify = 1. / dfy;
+  for (int i = 0; i < n; ++i) {
+    const double u = xy[2 * i], v = xy[2 * i + 1];
+    double x = (u - dcx) * ifx, y = (v - dcy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; ++j) {
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+      if (icdist < 0) { x = (u - dcx) * ifx; y = (v - dcy) * ify; break; }
+      const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+      const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    const double RR[9] = {(double)pfx, 0, (double)pcx, 0, (double)pfy, (double)pcy, 0, 0, 1};
+    const double xx = RR[0] * x + RR[1] * y + RR[2], yy = RR[3] * x + RR[4] * y + RR[5], ww = 1. / (RR[6] * x + RR[7] * y + RR[8]);
+    out[2 * i] = (float)(xx * ww);
+    out[2 * i + 1] = (float)(yy * ww);
+  }
+}
+
+// Frame::ComputeStereoFromRGBD (reference src/Frame.cc:1049-1067); kp / kpUn = (x, y) pairs
+extern "C" void orc_stereo_from_rgbd(int n, const float* kp, const float* kpUn, const float* depth, int W, int H, float bf,
+                                     float* uRight, float* depthOut) {
+  for (int i = 0; i < n; ++i) {
+    uRight[i] = -1; depthOut[i] = -1;
+    const int v = (int)kp[2 * i + 1], u = (int)kp[2 * i];   // imDepth.at<float>(float v, float u)
+    if (u < 0 || u >= W || v < 0 || v >= H) continue;        // (out-of-image reads are undefined in the reference)
+    const float d = depth[(size_t)v * W + u];
+    if (d > 0) { depthOut[i] = d; uRight[i] = kpUn[2 * i] - bf / d; }
+  }
+}

@@ -185,6 +185,10 @@ int orc_local_inertial_ba_fisheye(int nKF, float* kfState21, const uint8_t* kfKi
                                   const float* eInvSigma2, int nI, const int* iKF1, const int* iKF2, const orc_imu_preintegrated* iPre,
                                   const uint8_t* iRobust, const float* iInfoScale, const float* rig28, const float* Tbc12, int bLarge,
                                   uint8_t* eraseFlag, int* stats2);
+void orc_undistort_points(int n, const float* xy, float fx, float fy, float cx, float cy, const float* dist5, float pfx, float pfy,
+                          float pcx, float pcy, float* out);
+void orc_stereo_from_rgbd(int n, const float* kp, const float* kpUn, const float* depth, int W, int H, float bf, float* uRight,
+                          float* depthOut);
 float orc_fast_atan2(float y, float x);
 float orc_cosf(float x);
 float orc_sinf(float x);

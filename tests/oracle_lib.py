@@ -534,3 +534,25 @@ def local_inertial_ba(p, pre, bLarge=False):
                                 len(a[6]), _p(a[6]), _p(a[7]), _p(pre), _p(a[8]), _p(a[9]), cam["fx"], cam["fy"], cam["cx"], cam["cy"],
                                 cam["bf"], _p(a[10]), int(bool(bLarge)), _p(erase), _p(stats))
     return r, kf, mp, erase, stats
+
+
+def undistort_points(xy, cam, dist, pcam=None):
+    L = lib()
+    f = C.c_float
+    L.orc_undistort_points.argtypes = [C.c_int, C.c_void_p] + [f] * 4 + [C.c_void_p] + [f] * 4 + [C.c_void_p]
+    L.orc_undistort_points.restype = None
+    xy = np.ascontiguousarray(xy, np.float32); out = np.zeros_like(xy)
+    d5 = np.zeros(5, np.float32); d5[:len(dist)] = np.asarray(dist, np.float32)
+    pc = pcam or cam
+    L.orc_undistort_points(len(xy), _p(xy), cam["fx"], cam["fy"], cam["cx"], cam["cy"], _p(d5), pc["fx"], pc["fy"], pc["cx"], pc["cy"], _p(out))
+    return out
+
+
+def stereo_from_rgbd(kp_xy, kpun_xy, depth, bf):
+    L = lib()
+    L.orc_stereo_from_rgbd.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_stereo_from_rgbd.restype = None
+    a = [np.ascontiguousarray(x, np.float32) for x in (kp_xy, kpun_xy, depth)]
+    n = len(a[0]); ur = np.zeros(n, np.float32); d = np.zeros(n, np.float32)
+    L.orc_stereo_from_rgbd(n, _p(a[0]), _p(a[1]), _p(a[2]), depth.shape[1], depth.shape[0], bf, _p(ur), _p(d))
+    return ur, d
