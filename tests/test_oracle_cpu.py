@@ -490,3 +490,25 @@ def test_local_inertial_ba_oracle_converges():
     assert a1 < 0.15 * a0
     assert np.abs(kf[optk, 9:12] - p["true"][optk, 9:12]).max() < 0.2 * np.abs(p["kfState"][optk, 9:12] - p["true"][optk, 9:12]).max()
     assert 0.01 < erase.mean() < 0.15
+
+
+def test_undistort_points_oracle_inverts_the_forward_model():
+    """cv::undistortPoints as restated in oracle/cvprims.cc (parity unpinned): five iterations invert the Brown-Conrady model to a
+    small fraction of a pixel away from the image corners, and zero distortion with P = K is the identity up to float rounding."""
+    import oracle_lib as orc
+    cam = dict(fx=517.306408, fy=516.469215, cx=318.643040, cy=255.313989)
+    dist = (0.262383, -0.953104, -0.005358, 0.002628, 1.163314)
+    rng = np.random.default_rng(3)
+    xy = np.stack([rng.uniform(120, 520, 500), rng.uniform(90, 400, 500)], 1).astype(np.float32)
+    un = orc.undistort_points(xy, cam, dist).astype(np.float64)
+    xn, yn = (un[:, 0] - cam["cx"]) / cam["fx"], (un[:, 1] - cam["cy"]) / cam["fy"]
+    k1, k2, p1, p2, k3 = dist
+    r2 = xn * xn + yn * yn
+    rad = 1 + k1 * r2 + k2 * r2 * r2 + k3 * r2 ** 3
+    xd = xn * rad + 2 * p1 * xn * yn + p2 * (r2 + 2 * xn * xn); yd = yn * rad + p1 * (r2 + 2 * yn * yn) + 2 * p2 * xn * yn
+    err = np.hypot(xd * cam["fx"] + cam["cx"] - xy[:, 0], yd * cam["fy"] + cam["cy"] - xy[:, 1])
+    assert err.max() < 0.05
+    assert np.abs(orc.undistort_points(xy, cam, (0, 0, 0, 0, 0)) - xy).max() < 1e-4
+    ur, d = orc.stereo_from_rgbd(np.array([[10.7, 20.9], [3.2, 1.1]], np.float32), np.array([[10.0, 20.0], [3.0, 1.0]], np.float32),
+                                 np.arange(30 * 40, dtype=np.float32).reshape(30, 40) * 0.01, 40.0)
+    assert np.allclose(d, [0.01 * (20 * 40 + 10), 0.01 * (1 * 40 + 3)]) and np.allclose(ur, [10.0 - 40.0 / d[0], 3.0 - 40.0 / d[1]])
