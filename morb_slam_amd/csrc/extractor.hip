@@ -311,7 +311,6 @@ __global__ __launch_bounds__(NT) void k_fast(const morb::FastGeom fg, int nlevel
 #endif
   const int img = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int tmin = imin(iniTh, minTh);
   const uint64_t ltmask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const int G = tilePitch >> 2;                         // dwords per window row in LDS; gMagic = ceil(2^32 / G)
   const size_t cellSlot = (size_t)img * totalCells + blockIdx.x;
@@ -354,16 +353,21 @@ __global__ __launch_bounds__(NT) void k_fast(const morb::FastGeom fg, int nlevel
         *reinterpret_cast<uint32_t*>(sc + off[k]) = 0u;
       }
     }
-    for (int i = tid; i < th * bmWords; i += NT) { bmHi[i] = 0; bmLo[i] = 0; }
-    if (tid == 0) qn = 0;
+    for (int i = tid; i < th * bmWords; i += NT) bmHi[i] = 0;
   }
-  __syncthreads();
   PHASE_MARK(0);
+  // cv::FAST(iniThFAST) first; only a cell that yields no keypoint is evaluated again with minThFAST (:791-796).  Most cells stop
+  // after the first pass, whose cheap reject passes about half as many pixels as a reject at the lower threshold would.
+  int nq = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+  const int T = pass ? minTh : iniTh;
+  if (tid == 0) qn = 0;
+  __syncthreads();
   {
     // Phase 1 — cheap reject.  Every 9-arc of the 16-pixel ring contains at least two of the four compass pixels
-    // (0, 4, 8, 12), so a pixel can only exceed strength tmin if >= 2 compass pixels are darker than v - tmin or
-    // >= 2 are brighter than v + tmin, i.e. the second smallest compass value < v - tmin or the second largest
-    // > v + tmin.  Pixels that fail keep strength 0: they are corners at neither threshold and count as score 0 in
+    // (0, 4, 8, 12), so a pixel can only exceed strength T if >= 2 compass pixels are darker than v - T or
+    // >= 2 are brighter than v + T, i.e. the second smallest compass value < v - T or the second largest
+    // > v + T.  Pixels that fail keep strength 0: they are no corners at this threshold and count as score 0 in
     // their neighbours' NMS, exactly like cv::FAST's score buffer.
     // Four pixels per lane: the window row is read as aligned dwords (centre, the dwords left and right of it, the
     // rows 3 above / below), bytes are split into even / odd 16-bit lanes, the second smallest / largest come from a
@@ -373,10 +377,10 @@ __global__ __launch_bounds__(NT) void k_fast(const morb::FastGeom fg, int nlevel
     const unsigned guMagic = 0xFFFFFFFFu / (unsigned)Gu + 1u;
     const int nGroups = eh * Gu;
     const unsigned K = 0x80008000u, LO = 0x00FF00FFu;
-    const unsigned T1 = (unsigned)(tmin + 1) * 0x00010001u;
+    const unsigned T1 = (unsigned)(T + 1) * 0x00010001u;
     for (int i0 = 0; i0 < nGroups; i0 += NT) {
       const int i = i0 + tid;
-      unsigned re = 0, ro = 0;   // bit 15 / 31: pixel may exceed tmin (even bytes, odd bytes)
+      unsigned re = 0, ro = 0;   // bit 15 / 31: pixel may exceed T (even bytes, odd bytes)
       int x4 = 0, y = 0;
       if (i < nGroups) {
         const int ry = (int)__umulhi((unsigned)i, guMagic);
@@ -398,8 +402,8 @@ __global__ __launch_bounds__(NT) void k_fast(const morb::FastGeom fg, int nlevel
           const unsigned mlo = pk_max(lo1, lo2), mhi = pk_min(hi1, hi2);
           const unsigned s2 = pk_min(mlo, mhi);      // second smallest of the four
           const unsigned l2 = pk_max(mlo, mhi);      // second largest
-          const unsigned dark = ((Ve | K) - T1) - s2;        // bit 15: v - s2 >= tmin + 1
-          const unsigned bright = (l2 | K) - (Ve + T1);      // bit 15: l2 - v >= tmin + 1
+          const unsigned dark = ((Ve | K) - T1) - s2;        // bit 15: v - s2 >= T + 1
+          const unsigned bright = (l2 | K) - (Ve + T1);      // bit 15: l2 - v >= T + 1
           res[par] = (dark | bright) & K;
         }
         re = res[0]; ro = res[1];
@@ -429,44 +433,49 @@ __global__ __launch_bounds__(NT) void k_fast(const morb::FastGeom fg, int nlevel
     __syncthreads();
     PHASE_MARK(1);
     // Phase 2 — exact strength for the survivors only, densely packed over the workgroup
-    const int nq = qn;
+    nq = qn;
     for (int q = tid; q < nq; q += NT) {
       const int e = queue[q];
       const int y = e >> 8, x = e & 255;
       const int s = fast_strength(tile + y * tilePitch + x, tilePitch);
-      sc[y * tilePitch + x] = (uint8_t)(s > tmin ? imin(s, 255) : 0);
+      sc[y * tilePitch + x] = (uint8_t)(s > T ? imin(s, 255) : 0);
     }
     __syncthreads();
     PHASE_MARK(2);
 
-    // Phase 3 — NMS at both thresholds, only for pixels that have a strength; results go to per-row bitmaps.
-    // corner at t iff S > t, score S - 1, non-corner neighbours score 0; keep iff strictly greater than all 8.
+    // Phase 3 — NMS, only for pixels that have a strength; results go to the per-row bitmap.  The strength map holds S for the
+    // corners of this pass (S > T) and 0 elsewhere: corner score S - 1, non-corner neighbours score 0; keep iff strictly
+    // greater than all 8.
     for (int q = tid; q < nq; q += NT) {
       const int e = queue[q];
       const int y = e >> 8, x = e & 255;
       const uint8_t* c = sc + y * tilePitch + x;
       const int S = c[0];
       if (S == 0) continue;
-      bool kh = S > iniTh, kl = S > minTh;
+      bool keep = true;
 #pragma unroll
       for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
           if (dx == 0 && dy == 0) continue;
           const int Sn = c[dy * tilePitch + dx];
-          kh = kh && (S - 1 > (Sn > iniTh ? Sn - 1 : 0));
-          kl = kl && (S - 1 > (Sn > minTh ? Sn - 1 : 0));
+          keep = keep && (S - 1 > (Sn ? Sn - 1 : 0));
         }
-      if (kh) atomicOr(&bmHi[y * bmWords + (x >> 5)], 1u << (x & 31));
-      if (kl) atomicOr(&bmLo[y * bmWords + (x >> 5)], 1u << (x & 31));
+      if (keep) atomicOr(&bmHi[y * bmWords + (x >> 5)], 1u << (x & 31));
     }
     __syncthreads();
     PHASE_MARK(3);
-    // Phase 4 — vKeysCell.empty() -> second cv::FAST with minThFAST (:795); row prefix sums of the chosen bitmap
+    // vKeysCell.empty() -> second cv::FAST with minThFAST (:795)
     unsigned anyBits = 0;
     for (int i = tid; i < th * bmWords; i += NT) anyBits |= bmHi[i];
-    const int anyHi = __syncthreads_or(anyBits != 0);
-    const uint32_t* bm = anyHi ? bmHi : bmLo;
+    const int any = __syncthreads_or(anyBits != 0);
+    if (any || pass == 1) break;   // uniform
+    for (int q = tid; q < nq; q += NT) { const int e = queue[q]; sc[(e >> 8) * tilePitch + (e & 255)] = 0; }   // strengths of the first pass
+  }
+  }   // pass
+  {
+    // Phase 4 — row prefix sums of the bitmap
+    const uint32_t* bm = bmHi;
     for (int r = tid; r < th; r += NT) {
       int c = 0;
       for (int w = 0; w < bmWords; ++w) c += __popc(bm[r * bmWords + w]);
