@@ -31,6 +31,12 @@ void* morb_optimizer_stream(const morb_optimizer*);
 int morb_optimizer_workspace(morb_optimizer*, size_t bytes, void** out);
 }
 
+#define WAVE_SYNC_F()                                      \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); \
+    __builtin_amdgcn_wave_barrier();                       \
+  } while (0)
+
 namespace {
 
 // ---- FP32 3x3 helpers (the reference preintegrates in float) ---------------------------------------------------------------
@@ -70,111 +76,122 @@ __device__ void normalize_rotation_f(float* R) {
   for (int k = 0; k < 9; ++k) R[k] = (float)X[k];
 }
 
+// One wave per measurement sequence (the recursion over the samples is sequential, sequences are independent).  Lane 0 carries the
+// 3 x 3 state (rotation, velocity, position, bias Jacobians) and writes the sample's A (9 x 9) and B (9 x 6) to LDS; the 64 lanes
+// then share the two dense 9 x 9 covariance products, each entry summed in the reference's order.
 __global__ __launch_bounds__(64) void k_imu_preintegrate(int nseq, const int* __restrict__ start, const float* __restrict__ acc,
                                                          const float* __restrict__ gyro, const float* __restrict__ dts,
                                                          const float* __restrict__ bias, morb_imu_preintegrated calib,
                                                          morb_imu_preintegrated* __restrict__ out) {
-  const int s = blockIdx.x * 64 + threadIdx.x;
+  __shared__ float sA[81], sB[54], sC[81], sAC[81];
+  const int s = blockIdx.x, lane = threadIdx.x;
   if (s >= nseq) return;
-  morb_imu_preintegrated P;
-  memset(&P, 0, sizeof P);
-  P.dR[0] = P.dR[4] = P.dR[8] = 1.f;
-  for (int k = 0; k < 6; ++k) { P.b[k] = bias[6 * s + k]; P.nga[k] = calib.nga[k]; P.ngaWalk[k] = calib.ngaWalk[k]; }
-  float C9[81];   // the 9 x 9 block that the recursion touches; the bias-walk block is diagonal
-  for (int k = 0; k < 81; ++k) C9[k] = 0.f;
-  float walk[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = start[s]; i < start[s + 1]; ++i) {
+  float dR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, dV[3] = {0, 0, 0}, dP[3] = {0, 0, 0};
+  float JRg[9], JVg[9], JVa[9], JPg[9], JPa[9], avgA[3] = {0, 0, 0}, avgW[3] = {0, 0, 0}, b[6], dT = 0.f, walk[6] = {0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < 9; ++k) { JRg[k] = 0; JVg[k] = 0; JVa[k] = 0; JPg[k] = 0; JPa[k] = 0; }
+  for (int k = 0; k < 6; ++k) b[k] = bias[6 * s + k];
+  for (int k = lane; k < 81; k += 64) sC[k] = 0.f;
+  const int i0 = start[s], i1 = start[s + 1];
+  for (int i = i0; i < i1; ++i) {
     const float dt = dts[i];
-    const float a[3] = {acc[3 * i] - P.b[0], acc[3 * i + 1] - P.b[1], acc[3 * i + 2] - P.b[2]};
-    const float wv[3] = {gyro[3 * i] - P.b[3], gyro[3 * i + 1] - P.b[4], gyro[3 * i + 2] - P.b[5]};
-    float Racc[3];
-    mul3vf(P.dR, a, Racc);
-    for (int k = 0; k < 3; ++k) {
-      P.avgA[k] = (P.dT * P.avgA[k] + Racc[k] * dt) / (P.dT + dt);
-      P.avgW[k] = (P.dT * P.avgW[k] + wv[k] * dt) / (P.dT + dt);
-    }
-    for (int k = 0; k < 3; ++k) {
-      P.dP[k] = P.dP[k] + P.dV[k] * dt + 0.5f * Racc[k] * dt * dt;
-      P.dV[k] = P.dV[k] + Racc[k] * dt;
-    }
-    float Wacc[9], RW[9], RWJ[9];
-    hatf(a, Wacc);
-    mul33f(P.dR, Wacc, RW);
-    mul33f(RW, P.JRg, RWJ);
-    // A = [dRi^T 0 0; -dR dt Wacc, I, 0; -dR dt^2/2 Wacc, I dt, I],  B = [rightJ dt, 0; 0, dR dt; 0, dR dt^2/2]
-    float A10[9], A20[9], B11[9], B21[9];
-    for (int k = 0; k < 9; ++k) {
-      A10[k] = -RW[k] * dt; A20[k] = -0.5f * RW[k] * dt * dt;
-      B11[k] = P.dR[k] * dt; B21[k] = 0.5f * P.dR[k] * dt * dt;
-    }
-    for (int k = 0; k < 9; ++k) {
-      P.JPa[k] = P.JPa[k] + P.JVa[k] * dt - 0.5f * P.dR[k] * dt * dt;
-      P.JPg[k] = P.JPg[k] + P.JVg[k] * dt - 0.5f * RWJ[k] * dt * dt;
-      P.JVa[k] = P.JVa[k] - P.dR[k] * dt;
-      P.JVg[k] = P.JVg[k] - RWJ[k] * dt;
-    }
-    // IntegratedRotation (ImuTypes.cc:84-107)
-    float dRi[9], rJ[9];
-    {
-      const float x = wv[0] * dt, y = wv[1] * dt, z = wv[2] * dt;
-      const float d2 = x * x + y * y + z * z, d = sqrtf(d2);
-      const float v[3] = {x, y, z};
-      float W[9], WW[9];
-      hatf(v, W);
-      mul33f(W, W, WW);
-      if (d < 1e-4f) {
-        for (int k = 0; k < 9; ++k) { dRi[k] = ((k & 3) == 0 ? 1.f : 0.f) + W[k]; rJ[k] = (k & 3) == 0 ? 1.f : 0.f; }
-      } else {
-        const float sn = sinf(d), cs = cosf(d);
-        for (int k = 0; k < 9; ++k) {
-          const float I = (k & 3) == 0 ? 1.f : 0.f;
-          dRi[k] = I + W[k] * sn / d + WW[k] * (1.0f - cs) / d2;
-          rJ[k] = I - W[k] * (1.0f - cs) / d2 + WW[k] * (d - sn) / (d2 * d);
+    if (lane == 0) {
+      const float a[3] = {acc[3 * i] - b[0], acc[3 * i + 1] - b[1], acc[3 * i + 2] - b[2]};
+      const float wv[3] = {gyro[3 * i] - b[3], gyro[3 * i + 1] - b[4], gyro[3 * i + 2] - b[5]};
+      float Racc[3];
+      mul3vf(dR, a, Racc);
+      for (int k = 0; k < 3; ++k) {
+        avgA[k] = (dT * avgA[k] + Racc[k] * dt) / (dT + dt);
+        avgW[k] = (dT * avgW[k] + wv[k] * dt) / (dT + dt);
+      }
+      for (int k = 0; k < 3; ++k) {
+        dP[k] = dP[k] + dV[k] * dt + 0.5f * Racc[k] * dt * dt;
+        dV[k] = dV[k] + Racc[k] * dt;
+      }
+      float Wacc[9], RW[9], RWJ[9];
+      hatf(a, Wacc);
+      mul33f(dR, Wacc, RW);
+      mul33f(RW, JRg, RWJ);
+      // A = [dRi^T 0 0; -dR dt Wacc, I, 0; -dR dt^2/2 Wacc, I dt, I],  B = [rightJ dt, 0; 0, dR dt; 0, dR dt^2/2]
+      for (int k = 0; k < 81; ++k) sA[k] = 0.f;
+      for (int k = 0; k < 54; ++k) sB[k] = 0.f;
+      for (int k = 0; k < 9; ++k) sA[k * 9 + k] = 1.f;
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          sA[(3 + r) * 9 + c] = -RW[r * 3 + c] * dt; sA[(6 + r) * 9 + c] = -0.5f * RW[r * 3 + c] * dt * dt;
+          sB[(3 + r) * 6 + 3 + c] = dR[r * 3 + c] * dt; sB[(6 + r) * 6 + 3 + c] = 0.5f * dR[r * 3 + c] * dt * dt;
+        }
+      for (int k = 0; k < 3; ++k) sA[(6 + k) * 9 + 3 + k] = dt;
+      for (int k = 0; k < 9; ++k) {
+        JPa[k] = JPa[k] + JVa[k] * dt - 0.5f * dR[k] * dt * dt;
+        JPg[k] = JPg[k] + JVg[k] * dt - 0.5f * RWJ[k] * dt * dt;
+        JVa[k] = JVa[k] - dR[k] * dt;
+        JVg[k] = JVg[k] - RWJ[k] * dt;
+      }
+      // IntegratedRotation (ImuTypes.cc:84-107)
+      float dRi[9], rJ[9];
+      {
+        const float x = wv[0] * dt, y = wv[1] * dt, z = wv[2] * dt;
+        const float d2 = x * x + y * y + z * z, d = sqrtf(d2);
+        const float v[3] = {x, y, z};
+        float W[9], WW[9];
+        hatf(v, W);
+        mul33f(W, W, WW);
+        if (d < 1e-4f) {
+          for (int k = 0; k < 9; ++k) { dRi[k] = ((k & 3) == 0 ? 1.f : 0.f) + W[k]; rJ[k] = (k & 3) == 0 ? 1.f : 0.f; }
+        } else {
+          const float sn = sinf(d), cs = cosf(d);
+          for (int k = 0; k < 9; ++k) {
+            const float I = (k & 3) == 0 ? 1.f : 0.f;
+            dRi[k] = I + W[k] * sn / d + WW[k] * (1.0f - cs) / d2;
+            rJ[k] = I - W[k] * (1.0f - cs) / d2 + WW[k] * (d - sn) / (d2 * d);
+          }
         }
       }
+      mul33f(dR, dRi, dR);
+      normalize_rotation_f(dR);
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) { sA[r * 9 + c] = dRi[c * 3 + r]; sB[r * 6 + c] = rJ[r * 3 + c] * dt; }
+      float dRiT[9], t9[9];
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) dRiT[r * 3 + c] = dRi[c * 3 + r];
+      mul33f(dRiT, JRg, t9);
+      for (int k = 0; k < 9; ++k) JRg[k] = t9[k] - rJ[k] * dt;
+      dT += dt;
+      for (int k = 0; k < 6; ++k) walk[k] += calib.ngaWalk[k];
     }
-    mul33f(P.dR, dRi, P.dR);
-    normalize_rotation_f(P.dR);
-    // dense 9 x 9 products like the reference (A and B as full matrices, zeros included, same summation order)
-    float A[81], B[54];
-    for (int k = 0; k < 81; ++k) A[k] = 0.f;
-    for (int k = 0; k < 54; ++k) B[k] = 0.f;
-    for (int k = 0; k < 9; ++k) A[k * 9 + k] = 1.f;
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) {
-        A[r * 9 + c] = dRi[c * 3 + r];
-        A[(3 + r) * 9 + c] = A10[r * 3 + c]; A[(6 + r) * 9 + c] = A20[r * 3 + c];
-        B[r * 6 + c] = rJ[r * 3 + c] * dt;
-        B[(3 + r) * 6 + 3 + c] = B11[r * 3 + c]; B[(6 + r) * 6 + 3 + c] = B21[r * 3 + c];
-      }
-    for (int k = 0; k < 3; ++k) A[(6 + k) * 9 + 3 + k] = dt;
-    float AC[81];
-    for (int r = 0; r < 9; ++r)
-      for (int c = 0; c < 9; ++c) {
-        float sum = 0;
-        for (int k = 0; k < 9; ++k) sum += A[r * 9 + k] * C9[k * 9 + c];
-        AC[r * 9 + c] = sum;
-      }
-    float N[81];
-    for (int r = 0; r < 9; ++r)
-      for (int c = 0; c < 9; ++c) {
-        float sum = 0;
-        for (int k = 0; k < 9; ++k) sum += AC[r * 9 + k] * A[c * 9 + k];
-        float t = 0;
-        for (int k = 0; k < 6; ++k) t += B[r * 6 + k] * P.nga[k] * B[c * 6 + k];
-        N[r * 9 + c] = sum + t;
-      }
-    for (int k = 0; k < 81; ++k) C9[k] = N[k];
-    for (int k = 0; k < 6; ++k) walk[k] += P.ngaWalk[k];
-    float dRiT[9], t9[9];
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) dRiT[r * 3 + c] = dRi[c * 3 + r];
-    mul33f(dRiT, P.JRg, t9);
-    for (int k = 0; k < 9; ++k) P.JRg[k] = t9[k] - rJ[k] * dt;
-    P.dT += dt;
+    WAVE_SYNC_F();
+    // C(0:9,0:9) = A C A^T + B Nga B^T, dense like the reference (zeros included, k ascending)
+    for (int idx = lane; idx < 81; idx += 64) {
+      const int r = idx / 9, c = idx - r * 9;
+      float sum = 0;
+      for (int k = 0; k < 9; ++k) sum += sA[r * 9 + k] * sC[k * 9 + c];
+      sAC[idx] = sum;
+    }
+    WAVE_SYNC_F();
+    float nv[2] = {0.f, 0.f};
+    for (int q = 0, idx = lane; idx < 81; idx += 64, ++q) {
+      const int r = idx / 9, c = idx - r * 9;
+      float sum = 0;
+      for (int k = 0; k < 9; ++k) sum += sAC[r * 9 + k] * sA[c * 9 + k];
+      float t = 0;
+      for (int k = 0; k < 6; ++k) t += sB[r * 6 + k] * calib.nga[k] * sB[c * 6 + k];
+      nv[q] = sum + t;
+    }
+    WAVE_SYNC_F();
+    for (int q = 0, idx = lane; idx < 81; idx += 64, ++q) sC[idx] = nv[q];
+    WAVE_SYNC_F();
   }
-  for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) P.C[r * 15 + c] = C9[r * 9 + c];
-  for (int k = 0; k < 6; ++k) P.C[(9 + k) * 15 + 9 + k] = walk[k];
-  out[s] = P;
+  morb_imu_preintegrated* o = out + s;
+  for (int k = lane; k < 225; k += 64) {
+    const int r = k / 15, c = k - r * 15;
+    o->C[k] = (r < 9 && c < 9) ? sC[r * 9 + c] : 0.f;
+  }
+  WAVE_SYNC_F();
+  if (lane == 0) {
+    o->dT = dT;
+    for (int k = 0; k < 9; ++k) { o->dR[k] = dR[k]; o->JRg[k] = JRg[k]; o->JVg[k] = JVg[k]; o->JVa[k] = JVa[k]; o->JPg[k] = JPg[k]; o->JPa[k] = JPa[k]; }
+    for (int k = 0; k < 3; ++k) { o->dV[k] = dV[k]; o->dP[k] = dP[k]; o->avgA[k] = avgA[k]; o->avgW[k] = avgW[k]; }
+    for (int k = 0; k < 6; ++k) { o->b[k] = b[k]; o->nga[k] = calib.nga[k]; o->ngaWalk[k] = calib.ngaWalk[k]; o->C[(9 + k) * 15 + 9 + k] = walk[k]; }
+  }
 }
 
 // ---- FP64 pieces ------------------------------------------------------------------------------------------------------------
@@ -1550,7 +1567,7 @@ int morb_imu_preintegrate_batch(morb_optimizer* o, int nseq, const int* d_start,
   memset(&calib, 0, sizeof calib);
   memcpy(calib.nga, ngaDiag6, sizeof(float) * 6);
   memcpy(calib.ngaWalk, walkDiag6, sizeof(float) * 6);
-  hipLaunchKernelGGL(k_imu_preintegrate, dim3(div_up(nseq, 64)), dim3(64), 0, st, nseq, d_start, d_acc, d_gyro, d_dt, d_bias, calib, d_out);
+  hipLaunchKernelGGL(k_imu_preintegrate, dim3(nseq), dim3(64), 0, st, nseq, d_start, d_acc, d_gyro, d_dt, d_bias, calib, d_out);
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
 }
