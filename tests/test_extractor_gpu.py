@@ -92,6 +92,15 @@ def test_other_sizes_and_params():
     _compare(make_image(1280, 720, seed=23), 2000, iniThFAST=15, minThFAST=5)
 
 
+def test_threshold_orderings():
+    # the reference runs cv::FAST(iniThFAST) and, for an empty cell, cv::FAST(minThFAST), whatever their order: equal and
+    # swapped thresholds exercise the second pass after a first pass that left strengths behind
+    img = make_image(640, 480, seed=41)
+    _compare(img, 800, iniThFAST=12, minThFAST=12)
+    _compare(img, 800, iniThFAST=7, minThFAST=20)
+    _compare(img, 800, iniThFAST=60, minThFAST=3)     # most cells fall through to the second pass
+
+
 def test_1080p_4000():
     _compare(make_image(1920, 1080, seed=31), 4000)
 
