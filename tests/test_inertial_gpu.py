@@ -297,3 +297,49 @@ def test_pose_inertial_edge_cases(opt):
         torch.cuda.synchronize()
         assert np.allclose(stateB[0].cpu().numpy(), rB[1], atol=1e-4), (n, rec, np.abs(stateB[0].cpu().numpy() - rB[1]).max())
         assert int((outB[0, :n].cpu().numpy() != rB[2]).sum()) <= 1 and abs(int(ninB[0]) - rB[0]) <= 1, (n, rec)
+
+
+def test_local_inertial_ba_variants(opt):
+    """bRecInit (Huber on every inertial link), no fixed visual keyframes, points seen only by fixed keyframes, a single
+    optimizable keyframe."""
+    from morb_slam_amd.synth import make_inertial_ba_problem
+    nga, walk = imu_calib_diagonals()
+
+    def run(p, **kw):
+        pre = np.stack([orc.imu_preintegrate(p["bias"], nga, walk, p["acc"][a:b], p["gyro"][a:b], p["dt"][a:b])
+                        for a, b in zip(p["imuStart"][:-1], p["imuStart"][1:])])
+        r, kf_o, mp_o, er_o, st_o = orc.local_inertial_ba(p, pre, **kw)
+        kf, mp, er, st = opt.LocalInertialBA(p["kfState"], p["kfKind"], p["mpPos"], p["mpClose"], p["eKF"], p["eMP"], p["eObs"], p["eInvSigma2"],
+                                             p["iKF1"], p["iKF2"], pre, p["iRobust"], p["iInfoScale"], p["cam"], p["Tbc12"], **kw)
+        assert int(st[2]) == r
+        assert abs(int(st[0]) - int(st_o[0])) <= 1 and abs(int(st[1]) - int(st_o[1])) <= 3, (st, st_o)
+        optk = p["kfKind"] == 0
+        assert np.allclose(kf[optk], kf_o[optk], rtol=0, atol=1e-4), np.abs(kf[optk] - kf_o[optk]).max()
+        d = np.abs(mp - mp_o).max(1) / np.maximum(1.0, np.linalg.norm(mp_o, axis=1))
+        assert np.quantile(d, 0.99) < 1e-4, np.quantile(d, 0.99)
+        assert (er != er_o).sum() <= max(2, len(er) // 1000)
+        return kf, mp, er
+
+    p = make_inertial_ba_problem(n_opt=6, seed=11, n_points=600)
+    p["iRobust"] = np.ones_like(p["iRobust"])                       # bRecInit: every link carries the Huber kernel (:2553)
+    run(p)
+    p = make_inertial_ba_problem(n_opt=5, n_fixed_vis=0, seed=12, n_points=500)
+    run(p)
+    p = make_inertial_ba_problem(n_opt=6, n_fixed_vis=4, seed=13, n_points=600)
+    fixed = np.where(p["kfKind"] != 0)[0]                            # 40 extra points observed by fixed keyframes only
+    rng = np.random.default_rng(1)
+    n0 = len(p["mpPos"])
+    seen = [j for j in range(n0) if (p["eMP"] == j).any()][:40]
+    extra = p["mpPos"][seen] + 0.01
+    p["mpPos"] = np.concatenate([p["mpPos"], extra]); p["mpClose"] = np.concatenate([p["mpClose"], p["mpClose"][seen]])
+    src = [np.where(p["eMP"] == j)[0] for j in seen]
+    eK, eM, eO, eI = [p["eKF"]], [p["eMP"]], [p["eObs"]], [p["eInvSigma2"]]
+    for j in range(40):
+        for t in range(2):
+            e = src[j][t % len(src[j])]
+            eK.append(np.array([fixed[(j + t) % len(fixed)]], np.int32)); eM.append(np.array([n0 + j], np.int32))
+            eO.append(p["eObs"][e:e + 1] + rng.normal(0, 0.5, (1, 3)).astype(np.float32) * (p["eObs"][e:e + 1] >= 0)); eI.append(p["eInvSigma2"][e:e + 1])
+    p["eKF"], p["eMP"], p["eObs"], p["eInvSigma2"] = np.concatenate(eK), np.concatenate(eM), np.concatenate(eO), np.concatenate(eI)
+    kf, mp, er = run(p)
+    p = make_inertial_ba_problem(n_opt=1, n_fixed_vis=3, seed=14, n_points=300)
+    run(p)
