@@ -1484,6 +1484,82 @@ __global__ __launch_bounds__(1024) void k_iba_solve(IbaDev D) {
   for (int r = tid; r < n; r += 1024) D.x[r] = y[r];
   if (tid == 0) D.scal[2] = 1.0;
 }
+// The same solve for systems whose triangle does not fit LDS (large windows: n = 375): blocked right-looking LDL^T with a
+// 16-column panel.  The panel (rows j0 .. n-1, row pitch 17 doubles: no LDS bank conflicts when lanes read different rows) is
+// factorised inside LDS column by column, written back once, and the trailing matrix in global memory is updated once per
+// panel (16-term dot products from the LDS panel) instead of once per column.
+constexpr int IBA_NB = 16, IBA_NBP = 17;
+__global__ __launch_bounds__(1024) void k_iba_solve_blocked(IbaDev D) {
+  extern __shared__ double sm[];   // panel[n * NBP] | colc[NB] | dk[NB] | y[n]
+  const int n = D.P, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double* pnl = sm; double* colc = sm + (size_t)n * IBA_NBP; double* dk = colc + IBA_NB; double* y = dk + IBA_NB;
+  double* A = D.Hs;
+  __shared__ int sOk;
+  if (tid == 0) sOk = 1;
+  __syncthreads();
+  for (int j0 = 0; j0 < n; j0 += IBA_NB) {
+    const int nb = n - j0 < IBA_NB ? n - j0 : IBA_NB, m = n - j0;   // panel rows
+    for (int idx = tid; idx < m * IBA_NB; idx += 1024) {
+      const int r = idx / IBA_NB, c = idx - r * IBA_NB;
+      pnl[r * IBA_NBP + c] = (c < nb && c <= r) ? A[(size_t)(j0 + r) * n + j0 + c] : 0.0;
+    }
+    __syncthreads();
+    for (int c = 0; c < nb; ++c) {
+      if (tid < nb) colc[tid] = pnl[tid * IBA_NBP + c];   // column c of the panel's top block, un-scaled
+      __syncthreads();
+      const double d = colc[c];
+      if (!(d > 0)) { if (tid == 0) sOk = 0; break; }   // uniform
+      for (int r = c + 1 + tid; r < m; r += 1024) {
+        double* row = pnl + r * IBA_NBP;
+        const double l = row[c] / d;
+        const int lim = r < nb ? r : nb - 1;
+#pragma unroll 4
+        for (int cc = c + 1; cc <= lim; ++cc) row[cc] -= l * colc[cc];
+        row[c] = l;
+      }
+      if (tid == 0) dk[c] = d;
+      __syncthreads();
+    }
+    __syncthreads();
+    if (sOk == 0) break;   // uniform
+    for (int idx = tid; idx < m * IBA_NB; idx += 1024) {   // write the factorised panel back (L below the diagonal, D on it)
+      const int r = idx / IBA_NB, c = idx - r * IBA_NB;
+      if (c < nb && c <= r) A[(size_t)(j0 + r) * n + j0 + c] = (c == r) ? dk[c] : pnl[r * IBA_NBP + c];
+    }
+    // trailing update: A[r][cc] -= sum_k L[r][k] d_k L[cc][k], rows / columns >= j0 + nb
+    for (int r = nb + wv; r < m; r += 16) {
+      double lr[IBA_NB];
+#pragma unroll
+      for (int k = 0; k < IBA_NB; ++k) lr[k] = k < nb ? pnl[r * IBA_NBP + k] * dk[k] : 0.0;
+      for (int cc = nb + lane; cc <= r; cc += 64) {
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < IBA_NB; ++k) acc += lr[k] * pnl[cc * IBA_NBP + k];
+        A[(size_t)(j0 + r) * n + j0 + cc] -= acc;
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (sOk == 0) { if (tid == 0) D.scal[2] = 0.0; return; }
+  for (int r = tid; r < n; r += 1024) y[r] = D.bs[r];
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {   // L y = b
+    const double yj = y[j];
+    for (int r = j + 1 + tid; r < n; r += 1024) y[r] -= A[(size_t)r * n + j] * yj;
+    __syncthreads();
+  }
+  for (int r = tid; r < n; r += 1024) y[r] /= A[(size_t)r * n + r];
+  __syncthreads();
+  for (int j = n - 1; j >= 0; --j) {   // L^T x = y
+    const double xj = y[j];
+    for (int r = tid; r < j; r += 1024) y[r] -= A[(size_t)j * n + r] * xj;
+    __syncthreads();
+  }
+  for (int r = tid; r < n; r += 1024) D.x[r] = y[r];
+  if (tid == 0) D.scal[2] = 1.0;
+}
+
 // back-substitution of the points + oplus of every vertex + the LM scale  sum x (lambda x + b) -> scal[1]
 __global__ __launch_bounds__(256) void k_iba_update(IbaDev D, double lambda) {
   const int t = blockIdx.x * 256 + threadIdx.x;
@@ -1784,6 +1860,12 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
   const bool ldsSchur = schurLds <= 60 * 1024;   // larger windows accumulate in global memory
   const size_t solveLds = sizeof(double) * (2 * (size_t)P + (size_t)P * (P + 1) / 2);
   const bool ldsSolve = solveLds <= 150 * 1024;
+  const size_t blockedLds = sizeof(double) * ((size_t)P * IBA_NBP + 2 * IBA_NB + (size_t)P);
+  if (!ldsSolve) {
+    MORB_REQUIRE(blockedLds <= 150 * 1024, MORB_ERR_CAPACITY, "window too large for the dense solver");
+    if (blockedLds > 48 * 1024)
+      MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_iba_solve_blocked), hipFuncAttributeMaxDynamicSharedMemorySize, (int)blockedLds));
+  }
   if (ldsSolve && solveLds > 48 * 1024)
     MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_iba_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
   double chi = 0;
@@ -1814,7 +1896,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
       if (ldsSchur) hipLaunchKernelGGL(k_iba_schur<true>, dim3(div_up(nMP, 256)), dim3(256), schurLds, st, D, lambda);
       else hipLaunchKernelGGL(k_iba_schur<false>, dim3(div_up(nMP, 256)), dim3(256), 0, st, D, lambda);
       if (ldsSolve) hipLaunchKernelGGL(k_iba_solve<true>, dim3(1), dim3(1024), solveLds, st, D);
-      else hipLaunchKernelGGL(k_iba_solve<false>, dim3(1), dim3(1024), sizeof(double) * 2 * P, st, D);
+      else hipLaunchKernelGGL(k_iba_solve_blocked, dim3(1), dim3(1024), blockedLds, st, D);
       // a failed solve leaves x as it was (zero at the first trial): g2o still applies the update
       (void)hipMemsetAsync(D.scal, 0, sizeof(double) * 2, st);
       hipLaunchKernelGGL(k_iba_update, dim3(div_up(nMP + nKF, 256)), dim3(256), 0, st, D, lambda);
