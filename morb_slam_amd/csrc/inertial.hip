@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -1439,53 +1440,9 @@ __global__ __launch_bounds__(256) void k_iba_schur(IbaDev D, double lambda) {
     }
   }
 }
-// dense LDL^T of Hs (lower triangle) + solve -> x[0:P], scal[2] = positive.  ONE workgroup of 1024 threads (16 waves): the pivot
-// column is staged in LDS, a wave owns a row of the trailing update, two barriers per column.  INLDS: the packed lower triangle
-// itself lives in LDS (n <= 190: up to 12 keyframes), otherwise the factorisation works on global memory.
-template <bool INLDS>
-__global__ __launch_bounds__(1024) void k_iba_solve(IbaDev D) {
-  extern __shared__ double sm[];   // colj[n] | y[n] | (INLDS) packed lower triangle n (n + 1) / 2
-  const int n = D.P, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  double* colj = sm; double* y = sm + n; double* T = sm + 2 * n;
-  double* G = D.Hs;
-  auto A = [&](int r, int c) -> double& { return INLDS ? T[(size_t)r * (r + 1) / 2 + c] : G[(size_t)r * n + c]; };
-  if (INLDS) {
-    for (int r = wv; r < n; r += 16) for (int c = lane; c <= r; c += 64) T[(size_t)r * (r + 1) / 2 + c] = G[(size_t)r * n + c];
-    __syncthreads();
-  }
-  bool ok = true;
-  for (int j = 0; j < n; ++j) {
-    for (int r = j + tid; r < n; r += 1024) colj[r] = A(r, j);
-    __syncthreads();
-    const double d = colj[j];
-    if (!(d > 0)) { ok = false; break; }   // uniform
-    for (int r = j + 1 + wv; r < n; r += 16) {
-      const double lr = colj[r] / d;
-      for (int c = j + 1 + lane; c <= r; c += 64) A(r, c) -= lr * colj[c];
-      if (lane == 0) A(r, j) = lr;
-    }
-    __syncthreads();
-  }
-  if (!ok) { if (tid == 0) D.scal[2] = 0.0; return; }
-  for (int r = tid; r < n; r += 1024) y[r] = D.bs[r];
-  __syncthreads();
-  for (int j = 0; j < n; ++j) {   // L y = b
-    const double yj = y[j];
-    for (int r = j + 1 + tid; r < n; r += 1024) y[r] -= A(r, j) * yj;
-    __syncthreads();
-  }
-  for (int r = tid; r < n; r += 1024) y[r] /= A(r, r);
-  __syncthreads();
-  for (int j = n - 1; j >= 0; --j) {   // L^T x = y
-    const double xj = y[j];
-    for (int r = tid; r < j; r += 1024) y[r] -= A(j, r) * xj;
-    __syncthreads();
-  }
-  for (int r = tid; r < n; r += 1024) D.x[r] = y[r];
-  if (tid == 0) D.scal[2] = 1.0;
-}
-// The same solve for systems whose triangle does not fit LDS (large windows: n = 375): blocked right-looking LDL^T with a
-// 16-column panel.  The panel (rows j0 .. n-1, row pitch 17 doubles: no LDS bank conflicts when lanes read different rows) is
+// dense LDL^T of Hs (lower triangle) + solve -> x[0:P], scal[2] = positive.  ONE workgroup of 1024 threads: blocked right-looking
+// LDL^T with a 16-column panel (a column-at-a-time form with the whole triangle in LDS was measured slower: 0.32 vs 0.26 ms at
+// n = 150, and does not fit beyond n = 190).  The panel (rows j0 .. n-1, row pitch 17 doubles: no LDS bank conflicts when lanes read different rows) is
 // factorised inside LDS column by column, written back once, and the trailing matrix in global memory is updated once per
 // panel (16-term dot products from the LDS panel) instead of once per column.
 constexpr int IBA_NB = 16, IBA_NBP = 17;
@@ -1858,16 +1815,10 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
   const int Mpose = 6 * nOpt;
   const size_t schurLds = sizeof(double) * ((size_t)Mpose * Mpose + Mpose);
   const bool ldsSchur = schurLds <= 60 * 1024;   // larger windows accumulate in global memory
-  const size_t solveLds = sizeof(double) * (2 * (size_t)P + (size_t)P * (P + 1) / 2);
-  const bool ldsSolve = solveLds <= 150 * 1024;
   const size_t blockedLds = sizeof(double) * ((size_t)P * IBA_NBP + 2 * IBA_NB + (size_t)P);
-  if (!ldsSolve) {
-    MORB_REQUIRE(blockedLds <= 150 * 1024, MORB_ERR_CAPACITY, "window too large for the dense solver");
-    if (blockedLds > 48 * 1024)
-      MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_iba_solve_blocked), hipFuncAttributeMaxDynamicSharedMemorySize, (int)blockedLds));
-  }
-  if (ldsSolve && solveLds > 48 * 1024)
-    MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_iba_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
+  MORB_REQUIRE(blockedLds <= 150 * 1024, MORB_ERR_CAPACITY, "window too large for the dense solver");
+  if (blockedLds > 48 * 1024)
+    MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_iba_solve_blocked), hipFuncAttributeMaxDynamicSharedMemorySize, (int)blockedLds));
   double chi = 0;
   if (!errors(&chi)) return fail("k_iba_errors failed");
   const float err0 = (float)chi;
@@ -1895,8 +1846,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
       hipLaunchKernelGGL(k_iba_hs_init, dim3(div_up(P * P + P, 256)), dim3(256), 0, st, D, lambda);
       if (ldsSchur) hipLaunchKernelGGL(k_iba_schur<true>, dim3(div_up(nMP, 256)), dim3(256), schurLds, st, D, lambda);
       else hipLaunchKernelGGL(k_iba_schur<false>, dim3(div_up(nMP, 256)), dim3(256), 0, st, D, lambda);
-      if (ldsSolve) hipLaunchKernelGGL(k_iba_solve<true>, dim3(1), dim3(1024), solveLds, st, D);
-      else hipLaunchKernelGGL(k_iba_solve_blocked, dim3(1), dim3(1024), blockedLds, st, D);
+      hipLaunchKernelGGL(k_iba_solve_blocked, dim3(1), dim3(1024), blockedLds, st, D);
       // a failed solve leaves x as it was (zero at the first trial): g2o still applies the update
       (void)hipMemsetAsync(D.scal, 0, sizeof(double) * 2, st);
       hipLaunchKernelGGL(k_iba_update, dim3(div_up(nMP + nKF, 256)), dim3(256), 0, st, D, lambda);
