@@ -512,3 +512,28 @@ def test_undistort_points_oracle_inverts_the_forward_model():
     ur, d = orc.stereo_from_rgbd(np.array([[10.7, 20.9], [3.2, 1.1]], np.float32), np.array([[10.0, 20.0], [3.0, 1.0]], np.float32),
                                  np.arange(30 * 40, dtype=np.float32).reshape(30, 40) * 0.01, 40.0)
     assert np.allclose(d, [0.01 * (20 * 40 + 10), 0.01 * (1 * 40 + 3)]) and np.allclose(ur, [10.0 - 40.0 / d[0], 3.0 - 40.0 / d[1]])
+
+
+def test_golden_inertial_fixture():
+    """Regression pin of the inertial oracle (oracle_* fixture, generated by tests/golden/make_golden.py)."""
+    import oracle_lib as orc
+    from morb_slam_amd.synth import imu_calib_diagonals, make_inertial_ba_problem, make_inertial_sequence
+    g = np.load(os.path.join(GOLD, "oracle_inertial.npz"))
+    nga, walk = imu_calib_diagonals()
+    pA, pB = make_inertial_sequence(200, seed=5, n_imu=15)
+    preA = orc.imu_preintegrate(pA["bias"], nga, walk, pA["acc"], pA["gyro"], pA["dt"])
+    assert np.allclose(preA, g["preA"], rtol=1e-6, atol=1e-9)
+    rA = orc.pose_inertial_optimization_last_keyframe(pA, preA)
+    assert rA[0] == int(g["nA"]) and np.array_equal(rA[2], g["outlierA"]) and np.allclose(rA[1], g["stateA"], atol=1e-6)
+    assert np.allclose(rA[3], g["priorA"], rtol=1e-6, atol=1e-6 * np.abs(g["priorA"]).max())
+    preF = orc.imu_preintegrate(pB["bias"], nga, walk, pB["accF"], pB["gyroF"], pB["dtF"])
+    preK = orc.imu_preintegrate(pB["bias"], nga, walk, pB["acc"], pB["gyro"], pB["dt"])
+    rB = orc.pose_inertial_optimization_last_frame(pB, rA[1], preF, preK, rA[3])
+    assert rB[0] == int(g["nB"]) and np.array_equal(rB[2], g["outlierB"]) and np.allclose(rB[1], g["stateB"], atol=1e-6)
+    assert np.allclose(rB[3], g["priorB"], rtol=1e-6, atol=1e-6 * np.abs(g["priorB"]).max())
+    pw = make_inertial_ba_problem(n_opt=4, n_fixed_vis=2, n_points=150, n_imu=20, seed=5)
+    prew = np.stack([orc.imu_preintegrate(pw["bias"], nga, walk, pw["acc"][a:b], pw["gyro"][a:b], pw["dt"][a:b])
+                     for a, b in zip(pw["imuStart"][:-1], pw["imuStart"][1:])])
+    rw = orc.local_inertial_ba(pw, prew)
+    assert rw[0] == int(g["ba_ok"]) and np.array_equal(rw[4], g["ba_stats"]) and np.array_equal(rw[3], g["ba_erase"])
+    assert np.allclose(rw[1], g["ba_kf"], atol=1e-6) and np.allclose(rw[2], g["ba_mp"], atol=1e-5)
