@@ -1130,23 +1130,24 @@ __global__ void k_iba_setup_kf(IbaDev D, const float* __restrict__ kfState) {
   load_state(D.g, kfState + 21 * k, V);
   iba_store(V, D.S + 33 * (size_t)k);
 }
-__global__ void k_iba_setup_links(IbaDev D, const float* __restrict__ infoScale, double* __restrict__ scratch) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= D.nI) return;
-  const morb_imu_preintegrated& P = D.iPre[i];
-  double* sc = scratch + (size_t)i * 420;   // 81 (C9) + 162 (M) + 162 (V) + slack
-  double* C9 = sc; double* M = sc + 81; double* V = sc + 243;
-  double* Info = D.InfoI + (size_t)i * 81;
-  for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) C9[r * 9 + c] = (double)P.C[r * 15 + c];
-  if (invert_n(C9, 9, Info, M)) {
-    for (int r = 0; r < 9; ++r) for (int c = r + 1; c < 9; ++c) { const double s = (Info[r * 9 + c] + Info[c * 9 + r]) / 2; Info[r * 9 + c] = s; Info[c * 9 + r] = s; }
-    clamp_eigenvalues(Info, 9, 1e-12, M, V);
-  } else for (int k = 0; k < 81; ++k) Info[k] = 0;
-  for (int k = 0; k < 81; ++k) Info[k] *= (double)infoScale[i];
-  double Cg[9], Ca[9];
-  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { Cg[r * 3 + c] = P.C[(9 + r) * 15 + 9 + c]; Ca[r * 3 + c] = P.C[(12 + r) * 15 + 12 + c]; }
-  if (!invert_n(Cg, 3, D.InfoG + (size_t)i * 9, M)) for (int k = 0; k < 9; ++k) D.InfoG[(size_t)i * 9 + k] = 0;
-  if (!invert_n(Ca, 3, D.InfoA + (size_t)i * 9, M)) for (int k = 0; k < 9; ++k) D.InfoA[(size_t)i * 9 + k] = 0;
+// informations of the inertial links: one workgroup per link, the 9 x 9 work arrays in LDS (one thread computes)
+__global__ __launch_bounds__(64) void k_iba_setup_links(IbaDev D, const float* __restrict__ infoScale) {
+  __shared__ double C9[81], M[162], V[162], Inf[81];
+  const int i = blockIdx.x;
+  if (threadIdx.x == 0) {
+    const morb_imu_preintegrated& P = D.iPre[i];
+    for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) C9[r * 9 + c] = (double)P.C[r * 15 + c];
+    if (invert_n(C9, 9, Inf, M)) {
+      for (int r = 0; r < 9; ++r) for (int c = r + 1; c < 9; ++c) { const double s = (Inf[r * 9 + c] + Inf[c * 9 + r]) / 2; Inf[r * 9 + c] = s; Inf[c * 9 + r] = s; }
+      clamp_eigenvalues(Inf, 9, 1e-12, M, V);
+    } else for (int k = 0; k < 81; ++k) Inf[k] = 0;
+    double Cg[9], Ca[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { Cg[r * 3 + c] = P.C[(9 + r) * 15 + 9 + c]; Ca[r * 3 + c] = P.C[(12 + r) * 15 + 12 + c]; }
+    if (!invert_n(Cg, 3, D.InfoG + (size_t)i * 9, M)) for (int k = 0; k < 9; ++k) D.InfoG[(size_t)i * 9 + k] = 0;
+    if (!invert_n(Ca, 3, D.InfoA + (size_t)i * 9, M)) for (int k = 0; k < 9; ++k) D.InfoA[(size_t)i * 9 + k] = 0;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 81; k += 64) D.InfoI[(size_t)i * 81 + k] = Inf[k] * (double)infoScale[i];
 }
 
 // computeActiveErrors + activeRobustChi2 -> scal[0]
@@ -1749,7 +1750,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
                    sizeof(double) * 81 * (size_t)nI1, sizeof(double) * 9 * (size_t)nI1, sizeof(double) * 9 * (size_t)nI1,
                    sizeof(double) * (size_t)P * P, sizeof(double) * (size_t)P * P, sizeof(double) * nX, sizeof(double) * (size_t)P,
                    sizeof(double) * nX, sizeof(double) * 9 * (size_t)nMP, sizeof(double) * 18 * (size_t)nE, sizeof(double) * 4,
-                   sizeof(double) * 420 * (size_t)nI1, (size_t)nE, (size_t)nE})
+                   (size_t)nE, (size_t)nE})
     reserve(b);
   void* arena = nullptr;
   { const int rc = morb_optimizer_workspace(o, arenaBytes, &arena); if (rc != MORB_OK) return rc; }
@@ -1787,7 +1788,6 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
   D.b = (double*)dalloc(sizeof(double) * nX); D.bs = (double*)dalloc(sizeof(double) * P); D.x = (double*)dalloc(sizeof(double) * nX);
   D.Hll = (double*)dalloc(sizeof(double) * 9 * nMP); D.Hpl = (double*)dalloc(sizeof(double) * 18 * nE);
   D.scal = (double*)dalloc(sizeof(double) * 4);
-  double* scratch = (double*)dalloc(sizeof(double) * 420 * std::max(nI, 1));
   uint8_t* d_erase = (uint8_t*)dalloc(nE);
   MORB_REQUIRE(d_erase != nullptr && arenaOff <= arenaBytes, MORB_ERR_HIP, "workspace carve-up overflow in morb_local_inertial_ba");
   (void)hipMemsetAsync(D.x, 0, sizeof(double) * nX, st);   // the solver's x before the first solve
@@ -1805,7 +1805,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
     return true;
   };
   hipLaunchKernelGGL(k_iba_setup_kf, dim3(div_up(nKF, 64)), dim3(64), 0, st, D, d_kfIn);
-  if (nI) hipLaunchKernelGGL(k_iba_setup_links, dim3(div_up(nI, 64)), dim3(64), 0, st, D, d_scale, scratch);
+  if (nI) hipLaunchKernelGGL(k_iba_setup_links, dim3(nI), dim3(64), 0, st, D, d_scale);
   {  // points to FP64
     std::vector<double> pd(nPts);
     for (size_t k = 0; k < nPts; ++k) pd[k] = (double)mpPos[k];
