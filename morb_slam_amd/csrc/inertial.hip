@@ -1442,76 +1442,150 @@ __global__ __launch_bounds__(256) void k_iba_schur(IbaDev D, double lambda) {
   }
 }
 // dense LDL^T of Hs (lower triangle) + solve -> x[0:P], scal[2] = positive.  ONE workgroup of 1024 threads: blocked right-looking
-// LDL^T with a 16-column panel (a column-at-a-time form with the whole triangle in LDS was measured slower: 0.32 vs 0.26 ms at
-// n = 150, and does not fit beyond n = 190).  The panel (rows j0 .. n-1, row pitch 17 doubles: no LDS bank conflicts when lanes read different rows) is
+// LDL^T with 16-column panels (a column-at-a-time form with the whole triangle in LDS was measured slower, 0.32 ms at n = 150, and
+// does not fit beyond n = 190): the 16 x 16 diagonal block is factorised by one wave in registers, every row below it is
+// substituted by one thread (16 values in registers), then one trailing update of the matrix per panel: 3 barriers per panel.  The panel (rows j0 .. n-1, row pitch 17 doubles: no LDS bank conflicts when lanes read different rows) is
 // factorised inside LDS column by column, written back once, and the trailing matrix in global memory is updated once per
 // panel (16-term dot products from the LDS panel) instead of once per column.
 constexpr int IBA_NB = 16, IBA_NBP = 17;
+// LDL^T of a 16 x 16 block held in LDS (pitch 17; rows / columns >= nb are identity padding) by ONE wave: lane r keeps row r in
+// registers, other rows' entries arrive through v_readlane (see wave_ldlt_solve).  Leaves L below the diagonal and D on it.
+__device__ bool wave_ldl_factor16(double* blk, int lane) {
+  const int row = lane < IBA_NB ? lane : IBA_NB - 1;
+  double a[IBA_NB];
+#pragma unroll
+  for (int c = 0; c < IBA_NB; ++c) a[c] = blk[row * IBA_NBP + c];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < IBA_NB; ++j) {
+    const double d = morbwave::readlane_f64(a[j], j);
+    ok = ok && (d > 0);
+    const double l = a[j] / d;
+#pragma unroll
+    for (int c = j + 1; c < IBA_NB; ++c) a[c] -= l * morbwave::readlane_f64(a[j], c);
+    if (row > j) a[j] = l;
+  }
+  if (lane < IBA_NB) {
+#pragma unroll
+    for (int c = 0; c < IBA_NB; ++c) if (c <= row) blk[row * IBA_NBP + c] = a[c];
+  }
+  return ok;
+}
 __global__ __launch_bounds__(1024) void k_iba_solve_blocked(IbaDev D) {
-  extern __shared__ double sm[];   // panel[n * NBP] | colc[NB] | dk[NB] | y[n]
+  extern __shared__ double sm[];   // pnlL[n * NBP] | pnlU[n * NBP] | dblk[NB * NBP] | y[n]
   const int n = D.P, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  double* pnl = sm; double* colc = sm + (size_t)n * IBA_NBP; double* dk = colc + IBA_NB; double* y = dk + IBA_NB;
+  double* pnlL = sm; double* pnlU = sm + (size_t)n * IBA_NBP; double* dblk = pnlU + (size_t)n * IBA_NBP; double* y = dblk + IBA_NB * IBA_NBP;
   double* A = D.Hs;
   __shared__ int sOk;
   if (tid == 0) sOk = 1;
   __syncthreads();
   for (int j0 = 0; j0 < n; j0 += IBA_NB) {
-    const int nb = n - j0 < IBA_NB ? n - j0 : IBA_NB, m = n - j0;   // panel rows
-    for (int idx = tid; idx < m * IBA_NB; idx += 1024) {
-      const int r = idx / IBA_NB, c = idx - r * IBA_NB;
-      pnl[r * IBA_NBP + c] = (c < nb && c <= r) ? A[(size_t)(j0 + r) * n + j0 + c] : 0.0;
+    const int nb = n - j0 < IBA_NB ? n - j0 : IBA_NB, m = n - j0 - nb;   // m rows below the diagonal block
+    // (1) diagonal block -> LDS (identity padding), factorised by wave 0
+    if (tid < IBA_NB * IBA_NB) {
+      const int r = tid / IBA_NB, c = tid - r * IBA_NB;
+      dblk[r * IBA_NBP + c] = (r < nb && c < nb) ? (c <= r ? A[(size_t)(j0 + r) * n + j0 + c] : A[(size_t)(j0 + c) * n + j0 + r]) : (r == c ? 1.0 : 0.0);
     }
     __syncthreads();
-    for (int c = 0; c < nb; ++c) {
-      if (tid < nb) colc[tid] = pnl[tid * IBA_NBP + c];   // column c of the panel's top block, un-scaled
-      __syncthreads();
-      const double d = colc[c];
-      if (!(d > 0)) { if (tid == 0) sOk = 0; break; }   // uniform
-      for (int r = c + 1 + tid; r < m; r += 1024) {
-        double* row = pnl + r * IBA_NBP;
-        const double l = row[c] / d;
-        const int lim = r < nb ? r : nb - 1;
-#pragma unroll 4
-        for (int cc = c + 1; cc <= lim; ++cc) row[cc] -= l * colc[cc];
-        row[c] = l;
-      }
-      if (tid == 0) dk[c] = d;
-      __syncthreads();
-    }
+    if (wv == 0) { const bool ok = wave_ldl_factor16(dblk, lane); if (lane == 0 && !ok) sOk = 0; }
     __syncthreads();
     if (sOk == 0) break;   // uniform
-    for (int idx = tid; idx < m * IBA_NB; idx += 1024) {   // write the factorised panel back (L below the diagonal, D on it)
-      const int r = idx / IBA_NB, c = idx - r * IBA_NB;
-      if (c < nb && c <= r) A[(size_t)(j0 + r) * n + j0 + c] = (c == r) ? dk[c] : pnl[r * IBA_NBP + c];
+    if (tid < IBA_NB * IBA_NB) {   // write L / D of the block back
+      const int r = tid / IBA_NB, c = tid - r * IBA_NB;
+      if (r < nb && c <= r) A[(size_t)(j0 + r) * n + j0 + c] = dblk[r * IBA_NBP + c];
     }
-    // trailing update: A[r][cc] -= sum_k L[r][k] d_k L[cc][k], rows / columns >= j0 + nb
-    for (int r = nb + wv; r < m; r += 16) {
-      double lr[IBA_NB];
+    // (2) panel rows below the block, one per thread: u = a - sum_k u_k L[c][k], l = u / d
+    for (int rr = tid; rr < m; rr += 1024) {
+      const size_t g = (size_t)(j0 + nb + rr) * n + j0;
+      double u[IBA_NB];
 #pragma unroll
-      for (int k = 0; k < IBA_NB; ++k) lr[k] = k < nb ? pnl[r * IBA_NBP + k] * dk[k] : 0.0;
-      for (int cc = nb + lane; cc <= r; cc += 64) {
+      for (int c = 0; c < IBA_NB; ++c) {
+        double v = c < nb ? A[g + c] : 0.0;
+#pragma unroll
+        for (int k = 0; k < c; ++k) v -= u[k] * dblk[c * IBA_NBP + k];
+        u[c] = v;
+      }
+#pragma unroll
+      for (int c = 0; c < IBA_NB; ++c) {
+        const double l = u[c] / dblk[c * IBA_NBP + c];
+        pnlU[rr * IBA_NBP + c] = u[c];
+        pnlL[rr * IBA_NBP + c] = l;
+        if (c < nb) A[g + c] = l;
+      }
+    }
+    __syncthreads();
+    // (3) trailing update: A[r][cc] -= sum_k u[r][k] l[cc][k]
+    for (int rr = wv; rr < m; rr += 16) {
+      double ur[IBA_NB];
+#pragma unroll
+      for (int k = 0; k < IBA_NB; ++k) ur[k] = pnlU[rr * IBA_NBP + k];
+      double* arow = A + (size_t)(j0 + nb + rr) * n + j0 + nb;
+      for (int cc = lane; cc <= rr; cc += 64) {
         double acc = 0;
 #pragma unroll
-        for (int k = 0; k < IBA_NB; ++k) acc += lr[k] * pnl[cc * IBA_NBP + k];
-        A[(size_t)(j0 + r) * n + j0 + cc] -= acc;
+        for (int k = 0; k < IBA_NB; ++k) acc += ur[k] * pnlL[cc * IBA_NBP + k];
+        arow[cc] -= acc;
       }
     }
     __syncthreads();
   }
   __syncthreads();
   if (sOk == 0) { if (tid == 0) D.scal[2] = 0.0; return; }
+  // blocked substitutions: per 16-column panel the 16 x 16 triangular block is solved by wave 0 in registers (v_readlane), the
+  // rest of the panel is one 16-term dot product per row
   for (int r = tid; r < n; r += 1024) y[r] = D.bs[r];
   __syncthreads();
-  for (int j = 0; j < n; ++j) {   // L y = b
-    const double yj = y[j];
-    for (int r = j + 1 + tid; r < n; r += 1024) y[r] -= A[(size_t)r * n + j] * yj;
+  for (int j0 = 0; j0 < n; j0 += IBA_NB) {   // L y = b
+    const int nb = n - j0 < IBA_NB ? n - j0 : IBA_NB;
+    if (tid < IBA_NB * IBA_NB) {
+      const int r = tid / IBA_NB, c = tid - r * IBA_NB;
+      dblk[r * IBA_NBP + c] = (r < nb && c < r) ? A[(size_t)(j0 + r) * n + j0 + c] : 0.0;
+    }
+    __syncthreads();
+    if (wv == 0) {
+      const int row = lane < IBA_NB ? lane : IBA_NB - 1;
+      double yr = row < nb ? y[j0 + row] : 0.0;
+#pragma unroll
+      for (int c = 0; c < IBA_NB - 1; ++c) {
+        const double yc = morbwave::readlane_f64(yr, c);
+        if (row > c) yr -= dblk[row * IBA_NBP + c] * yc;
+      }
+      if (lane < nb) y[j0 + lane] = yr;
+    }
+    __syncthreads();
+    for (int r = j0 + nb + tid; r < n; r += 1024) {
+      const double* lr = A + (size_t)r * n + j0;
+      double acc = 0;
+      for (int k = 0; k < nb; ++k) acc += lr[k] * y[j0 + k];
+      y[r] -= acc;
+    }
     __syncthreads();
   }
   for (int r = tid; r < n; r += 1024) y[r] /= A[(size_t)r * n + r];
   __syncthreads();
-  for (int j = n - 1; j >= 0; --j) {   // L^T x = y
-    const double xj = y[j];
-    for (int r = tid; r < j; r += 1024) y[r] -= A[(size_t)j * n + r] * xj;
+  for (int j0 = ((n - 1) / IBA_NB) * IBA_NB; j0 >= 0; j0 -= IBA_NB) {   // L^T x = y
+    const int nb = n - j0 < IBA_NB ? n - j0 : IBA_NB;
+    if (tid < IBA_NB * IBA_NB) {
+      const int r = tid / IBA_NB, c = tid - r * IBA_NB;
+      dblk[r * IBA_NBP + c] = (r < nb && c < r) ? A[(size_t)(j0 + r) * n + j0 + c] : 0.0;
+    }
+    __syncthreads();
+    if (wv == 0) {
+      const int row = lane < IBA_NB ? lane : IBA_NB - 1;
+      double xr = row < nb ? y[j0 + row] : 0.0;
+#pragma unroll
+      for (int c = IBA_NB - 1; c > 0; --c) {
+        const double xc = morbwave::readlane_f64(xr, c);
+        if (row < c) xr -= dblk[c * IBA_NBP + row] * xc;   // L^T[row][c] = L[c][row]
+      }
+      if (lane < nb) y[j0 + lane] = xr;
+    }
+    __syncthreads();
+    for (int r = tid; r < j0; r += 1024) {
+      double acc = 0;
+      for (int k = 0; k < nb; ++k) acc += A[(size_t)(j0 + k) * n + r] * y[j0 + k];
+      y[r] -= acc;
+    }
     __syncthreads();
   }
   for (int r = tid; r < n; r += 1024) D.x[r] = y[r];
@@ -1815,7 +1889,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
   const int Mpose = 6 * nOpt;
   const size_t schurLds = sizeof(double) * ((size_t)Mpose * Mpose + Mpose);
   const bool ldsSchur = schurLds <= 60 * 1024;   // larger windows accumulate in global memory
-  const size_t blockedLds = sizeof(double) * ((size_t)P * IBA_NBP + 2 * IBA_NB + (size_t)P);
+  const size_t blockedLds = sizeof(double) * (2 * (size_t)P * IBA_NBP + IBA_NB * IBA_NBP + (size_t)P);
   MORB_REQUIRE(blockedLds <= 150 * 1024, MORB_ERR_CAPACITY, "window too large for the dense solver");
   if (blockedLds > 48 * 1024)
     MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_iba_solve_blocked), hipFuncAttributeMaxDynamicSharedMemorySize, (int)blockedLds));
