@@ -161,6 +161,18 @@ int morb_vocabulary_load_text(const char* path, morb_vocabulary** out);
 void morb_vocabulary_destroy(morb_vocabulary* v);
 int morb_vocabulary_info(const morb_vocabulary* v, int* k, int* L, int* nNodes, int* nWords);
 int morb_vocabulary_arrays(const morb_vocabulary* v, uint8_t* nodeDesc, int* firstChild, int* childCount, int* wordId, float* weight);
+/* the node weights as DBoW2 holds them (WordValue = double) and the header's scoring / weighting types (BowVector.h:39-56:
+ * weighting 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY; scoring 0 L1_NORM .. 5 DOT_PRODUCT); any pointer may be NULL */
+int morb_vocabulary_weights(const morb_vocabulary* v, double* weight, int* scoring, int* weighting);
+
+/* The BowVector half of TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup)
+ * (TemplatedVocabulary.h:1127-1190, BowVector.cpp:34-84), for nimg images: d_leaf = the leaf NODE ids of the descent
+ * (morb_bow_transform*'s d_wordId output), d_nodeWordId = node -> WordId (NULL: the node id itself), d_nodeWeight = node weights
+ * (double).  Words with weight 0 are "stopped".  Outputs: the map's entries in ascending word order, d_bowWord / d_bowValue
+ * [nimg][cap] and d_bowCount[nimg]. */
+int morb_bow_vector_batch(morb_matcher*, int nimg, const int* d_leaf, const int* d_count, int cap, const int* d_nodeWordId,
+                          const double* d_nodeWeight, int weighting, int scoring, int* d_bowWord, double* d_bowValue, int* d_bowCount,
+                          void* stream);
 
 /* int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)
  * ORBmatcher.h:68, ORBmatcher.cc:218-395 (non-fisheye branch) for npairs (keyframe, frame) pairs drawn from a

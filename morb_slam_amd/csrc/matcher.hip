@@ -958,7 +958,7 @@ struct morb_vocabulary {
   std::vector<int> childCount;     // [nNodes]
   std::vector<int> parent;         // [nNodes]
   std::vector<int> wordId;         // [nNodes] word id of a leaf (order of appearance, :1403-1408) or -1
-  std::vector<float> weight;       // [nNodes]
+  std::vector<double> weight;      // [nNodes] WordValue is double in DBoW2
 };
 
 int morb_vocabulary_load_text(const char* path, morb_vocabulary** out) {
@@ -977,7 +977,7 @@ int morb_vocabulary_load_text(const char* path, morb_vocabulary** out) {
   v->scoring = n1; v->weighting = n2;
   // node 0 = root
   v->desc.assign(32, 0); v->firstChild.assign(1, -1); v->childCount.assign(1, 0); v->parent.assign(1, -1); v->wordId.assign(1, -1);
-  v->weight.assign(1, 0.f);
+  v->weight.assign(1, 0.0);
   int nWords = 0;
   for (;;) {
     int pid = 0, isLeaf = 0;
@@ -991,7 +991,7 @@ int morb_vocabulary_load_text(const char* path, morb_vocabulary** out) {
     if (!ok) { fclose(f); set_error("malformed vocabulary node %d", nid); return MORB_ERR_INVALID; }
     v->parent.push_back(pid);
     for (int i = 0; i < 32; ++i) v->desc.push_back((uint8_t)d[i]);
-    v->weight.push_back((float)w);
+    v->weight.push_back((double)w);
     v->firstChild.push_back(-1); v->childCount.push_back(0);
     v->wordId.push_back(isLeaf > 0 ? nWords++ : -1);
     // the descent kernels address children as [firstChild, firstChild + childCount): DBoW2 creates the children of a node
@@ -1024,7 +1024,15 @@ int morb_vocabulary_arrays(const morb_vocabulary* v, uint8_t* nodeDesc, int* fir
   if (firstChild) memcpy(firstChild, v->firstChild.data(), n * sizeof(int));
   if (childCount) memcpy(childCount, v->childCount.data(), n * sizeof(int));
   if (wordId) memcpy(wordId, v->wordId.data(), n * sizeof(int));
-  if (weight) memcpy(weight, v->weight.data(), n * sizeof(float));
+  if (weight) for (size_t i = 0; i < n; ++i) weight[i] = (float)v->weight[i];
+  return MORB_OK;
+}
+
+int morb_vocabulary_weights(const morb_vocabulary* v, double* weight, int* scoring, int* weighting) {
+  MORB_REQUIRE(v, MORB_ERR_INVALID, "NULL vocabulary");
+  if (weight) memcpy(weight, v->weight.data(), v->weight.size() * sizeof(double));
+  if (scoring) *scoring = v->scoring;
+  if (weighting) *weighting = v->weighting;
   return MORB_OK;
 }
 

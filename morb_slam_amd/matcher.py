@@ -72,6 +72,20 @@ class ORBmatcher:
                                                k, L, levelsup, ptr(out[0]), ptr(out[1]), self._st(stream)))
         return out
 
+    def bow_vector(self, leaf, count, node_weight, node_word=None, weighting=0, scoring=0, out=None, stream=None):
+        """The BowVector of TemplatedVocabulary::transform for a batch: leaf i32 [nimg, cap] (bow_transform's first output),
+        node_weight f64 [nNodes] (device), node_word i32 [nNodes] or None.  weighting / scoring: DBoW2 enum values (TF_IDF = 0,
+        L1_NORM = 0: ORBvoc).  Returns (word i32 [nimg, cap], value f64 [nimg, cap], count i32 [nimg]), words ascending."""
+        import torch
+        nimg, cap = leaf.shape
+        if out is None:
+            out = (torch.empty((nimg, cap), dtype=torch.int32, device=leaf.device), torch.empty((nimg, cap), dtype=torch.float64, device=leaf.device),
+                   torch.empty((nimg,), dtype=torch.int32, device=leaf.device))
+        assert node_weight.dtype == torch.float64
+        check(self._L.morb_bow_vector_batch(self._h, nimg, ptr(leaf), ptr(count), cap, ptr(node_word), ptr(node_weight), int(weighting),
+                                            int(scoring), ptr(out[0]), ptr(out[1]), ptr(out[2]), self._st(stream)))
+        return out
+
     def bow_transform_tree(self, desc, count, voc_desc, voc_first, voc_nchild, L, levelsup=4, stream=None):
         """DBoW2 transform on a trained (possibly incomplete) tree: children of n = [first[n], first[n] + nchild[n])."""
         import torch

@@ -28,9 +28,13 @@ class Vocabulary:
             a = (np.zeros((n.value, 32), np.uint8), np.zeros(n.value, np.int32), np.zeros(n.value, np.int32), np.zeros(n.value, np.int32),
                  np.zeros(n.value, np.float32))
             check(Lb.morb_vocabulary_arrays(h, *[ptr(x) for x in a]))
+            w64 = np.zeros(n.value, np.float64); sc, wt = C.c_int(), C.c_int()
+            check(Lb.morb_vocabulary_weights(h, ptr(w64), C.byref(sc), C.byref(wt)))
         finally:
             Lb.morb_vocabulary_destroy(h)
-        return Vocabulary(k.value, L.value, *a)
+        v = Vocabulary(k.value, L.value, *a)
+        v.weight64, v.scoring, v.weighting = w64, sc.value, wt.value   # WordValue is double in DBoW2
+        return v
 
 
 def save_text(path, k, L, parent, is_leaf, desc, weight, scoring=0, weighting=0):

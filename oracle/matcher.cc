@@ -435,3 +435,40 @@ void orc_bow_transform(const uint8_t* feat, int n, const uint8_t* nodeDesc, cons
   BowTransform(feat, n, nodeDesc, firstChild, k, L, levelsup, wordId, nodeId);
 }
 }
+
+// TemplatedVocabulary::transform(features, BowVector& v, FeatureVector& fv, levelsup): the BowVector
+// (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1190, BowVector.cpp:34-84, ScoringObject.h:60-92).  leaf[i] = leaf node of
+// feature i (from orc_bow_transform*), nodeWordId (optional) maps it to the WordId, nodeWeight = WordValue (double).
+// weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY; scoring: 0 L1_NORM, 1 L2_NORM, 2 CHI_SQUARE, 3 KL, 4 BHATTACHARYYA, 5 DOT_PRODUCT.
+#include <map>
+extern "C" int orc_bow_vector(int n, const int* leaf, const int* nodeWordId, const double* nodeWeight, int weighting, int scoring,
+                              int* outWord, double* outValue) {
+  std::map<unsigned, double> v;
+  const bool must = scoring != 5;            // __SCORING_CLASS(DotProductScoring, false, L1)
+  const bool l2 = scoring == 1;              // __SCORING_CLASS(L2Scoring, true, L2); every other object normalises with L1
+  for (int i = 0; i < n; ++i) {
+    if (leaf[i] < 0) continue;
+    const double w = nodeWeight[leaf[i]];
+    if (!(w > 0)) continue;                  // "not stopped"
+    const unsigned id = (unsigned)(nodeWordId ? nodeWordId[leaf[i]] : leaf[i]);
+    auto it = v.lower_bound(id);
+    if (weighting == 0 || weighting == 1) {  // addWeight
+      if (it != v.end() && !(id < it->first)) it->second += w; else v.insert(it, {id, w});
+    } else {                                 // addIfNotExist
+      if (it == v.end() || id < it->first) v.insert(it, {id, w});
+    }
+  }
+  if ((weighting == 0 || weighting == 1) && !v.empty() && !must) {
+    const double nd = (double)v.size();
+    for (auto& kv : v) kv.second /= nd;
+  }
+  if (must) {                                // BowVector::normalize
+    double norm = 0.0;
+    if (!l2) { for (auto& kv : v) norm += std::fabs(kv.second); }
+    else { for (auto& kv : v) norm += kv.second * kv.second; norm = std::sqrt(norm); }
+    if (norm > 0.0) for (auto& kv : v) kv.second /= norm;
+  }
+  int k = 0;
+  for (auto& kv : v) { outWord[k] = (int)kv.first; outValue[k] = kv.second; ++k; }
+  return k;
+}

@@ -189,6 +189,8 @@ void orc_undistort_points(int n, const float* xy, float fx, float fy, float cx, 
                           float pcx, float pcy, float* out);
 void orc_stereo_from_rgbd(int n, const float* kp, const float* kpUn, const float* depth, int W, int H, float bf, float* uRight,
                           float* depthOut);
+int orc_bow_vector(int n, const int* leaf, const int* nodeWordId, const double* nodeWeight, int weighting, int scoring, int* outWord,
+                   double* outValue);
 float orc_fast_atan2(float y, float x);
 float orc_cosf(float x);
 float orc_sinf(float x);

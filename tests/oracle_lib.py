@@ -556,3 +556,13 @@ def stereo_from_rgbd(kp_xy, kpun_xy, depth, bf):
     n = len(a[0]); ur = np.zeros(n, np.float32); d = np.zeros(n, np.float32)
     L.orc_stereo_from_rgbd(n, _p(a[0]), _p(a[1]), _p(a[2]), depth.shape[1], depth.shape[0], bf, _p(ur), _p(d))
     return ur, d
+
+
+def bow_vector(leaf, node_weight, node_word=None, weighting=0, scoring=0):
+    L = lib()
+    L.orc_bow_vector.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    leaf = np.ascontiguousarray(leaf, np.int32); w = np.ascontiguousarray(node_weight, np.float64)
+    nw = None if node_word is None else np.ascontiguousarray(node_word, np.int32)
+    ow = np.zeros(len(leaf), np.int32); ov = np.zeros(len(leaf), np.float64)
+    k = L.orc_bow_vector(len(leaf), _p(leaf), None if nw is None else _p(nw), _p(w), weighting, scoring, _p(ow), _p(ov))
+    return ow[:k], ov[:k]

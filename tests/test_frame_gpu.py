@@ -86,3 +86,29 @@ def test_stereo_from_rgbd_and_image_bounds(matcher):
     c = orc.undistort_points(np.array([[0, 0], [W, 0], [0, H], [W, H]], np.float32), TUM_CAM, TUM_DIST)
     assert b == (float(min(c[0, 0], c[2, 0])), float(max(c[1, 0], c[3, 0])), float(min(c[0, 1], c[1, 1])), float(max(c[2, 1], c[3, 1])))
     assert ORBmatcher.ComputeImageBounds(W, H, TUM_CAM, (0.0, 0, 0, 0)) == (0.0, float(W), 0.0, float(H))
+
+
+@pytest.mark.parametrize("weighting,scoring", [(0, 0), (1, 1), (0, 5), (1, 5), (2, 0), (3, 5), (0, 3)])
+def test_bow_vector(matcher, weighting, scoring):
+    """BowVector of TemplatedVocabulary::transform: bit-exact doubles, map order, stopped words, every weighting / norm branch."""
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(17 + weighting * 7 + scoring)
+    n_nodes, cap = 5000, 1500
+    weight = rng.uniform(0.5, 9.0, n_nodes); weight[rng.random(n_nodes) < 0.1] = 0.0          # stopped words
+    word = rng.permutation(n_nodes).astype(np.int32)                                           # node -> WordId (any injective map)
+    counts = np.array([1500, 0, 1, 777], np.int32)
+    leaf = np.full((4, cap), -1, np.int32)
+    for f, n in enumerate(counts):
+        leaf[f, :n] = rng.integers(0, 400 if f == 0 else n_nodes, n)                           # image 0: many repeated words
+    leaf[3, 5] = -1                                                                            # a feature outside the vocabulary
+    for use_word in (True, False):
+        w, v, c = matcher.bow_vector(torch.from_numpy(leaf).to(dev), torch.from_numpy(counts).to(dev), torch.from_numpy(weight).to(dev),
+                                     torch.from_numpy(word).to(dev) if use_word else None, weighting, scoring)
+        torch.cuda.synchronize()
+        w, v, c = w.cpu().numpy(), v.cpu().numpy(), c.cpu().numpy()
+        for f, n in enumerate(counts):
+            ow, ov = orc.bow_vector(leaf[f, :n], weight, word if use_word else None, weighting, scoring)
+            assert int(c[f]) == len(ow)
+            assert np.array_equal(w[f, :c[f]], ow) and np.array_equal(v[f, :c[f]], ov)         # bit-exact doubles
+            if len(ov) and scoring == 0:
+                assert abs(np.abs(ov).sum() - 1.0) < 1e-12

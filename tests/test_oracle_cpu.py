@@ -436,6 +436,18 @@ def test_vocabulary_text_loader(tmp_path):
     feats = np.random.default_rng(1).integers(0, 256, (200, 32), dtype=np.uint8)
     w, nid = O.bow_transform_tree(feats, v.nodeDesc, v.firstChild, v.childCount, v.L, 1)
     assert (v.childCount[w] == 0).all() and (v.wordId[w] >= 0).all()
+    # weights as DBoW2 holds them (double) and the header's scoring / weighting types; the BowVector of the descended features:
+    # distinct words ascending, TF-IDF weights accumulated per occurrence, L1-normalised (ORBvoc: weighting 0, scoring 0)
+    np.testing.assert_allclose(v.weight64[1:], weight, rtol=1e-5)
+    assert (v.scoring, v.weighting) == (0, 0)
+    bw, bv = O.bow_vector(w, v.weight64, v.wordId, v.weighting, v.scoring)
+    ref = {}
+    for lf in w:
+        if v.weight64[lf] > 0:
+            ref[int(v.wordId[lf])] = ref.get(int(v.wordId[lf]), 0.0) + v.weight64[lf]
+    keys = sorted(ref)
+    assert list(bw) == keys and abs(bv.sum() - 1.0) < 1e-12
+    np.testing.assert_allclose(bv, np.array([ref[k] for k in keys]) / sum(ref.values()), rtol=1e-12)
     bad = tmp_path / "bad.txt"
     bad.write_text("40 3 0 0\n")
     with pytest.raises(MorbError):
