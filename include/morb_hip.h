@@ -419,7 +419,7 @@ int morb_image_bounds(int width, int height, float fx, float fy, float cx, float
  * Poses cross the boundary the way the reference hands them to g2o: unit quaternion (x, y, z, w) followed by
  * the translation, 7 floats (Sophus::SE3f::unit_quaternion() / translation(), Optimizer.cc:781-783, :1046-1048).
  * Pinhole mono (uRight < 0) and rectified-stereo (uRight >= 0) observations; PoseOptimization also for the
- * KannalaBrandt8 fisheye rig ("ToBody" edges); LocalBundleAdjustment with fisheye edges is not provided yet.
+ * KannalaBrandt8 fisheye rig ("ToBody" edges), and so has LocalBundleAdjustment (morb_local_bundle_adjustment_fisheye).
  * ---------------------------------------------------------------------------------------------------- */
 typedef struct morb_optimizer morb_optimizer;
 int morb_optimizer_create(morb_optimizer** out, int device);
@@ -446,7 +446,7 @@ int morb_pose_optimization_fisheye_batch(morb_optimizer*, int nframes, int cap, 
                                          const float* d_Xw, const float* camL8, const float* camR8, const float* Trl7,
                                          float* d_pose, uint8_t* d_outlier, int* d_nInliers, int* d_stats, void* stream);
 
-/* ---- visual-inertial tracking (first slice) ----
+/* ---- visual-inertial tracking and mapping ----
  * IMU::Preintegrated as plain data (include/ImuTypes.h:154-263): 3 x 3 blocks row-major, C = the 15 x 15 covariance
  * row-major, b = the bias the measurements were integrated with in IMU::Bias order (bax bay baz bwx bwy bwz),
  * nga / ngaWalk = the diagonals of IMU::Calib::Cov / CovWalk (gyro x3, acc x3; ImuTypes.cc:375-388). */

@@ -1,5 +1,6 @@
 """Optimizer — host-side mirror of the reference's static Optimizer functions on the hot path
-(include/Optimizer.h:46-139): PoseOptimization and LocalBundleAdjustment, over the device-resident LM kernels."""
+(include/Optimizer.h:46-139): PoseOptimization, LocalBundleAdjustment and the inertial functions of SURVEY 8(f) N1
+(IMU preintegration, PoseInertialOptimizationLastKeyFrame / LastFrame, LocalInertialBA), over the device-resident kernels."""
 import ctypes as C
 
 import numpy as np
@@ -60,7 +61,7 @@ class Optimizer:
                                                            ptr(out[2]), st))
         return out
 
-    # ---- visual-inertial tracking (first slice) -------------------------------------------------
+    # ---- visual-inertial tracking and mapping ---------------------------------------------------
     def PreintegrateIMU(self, start, acc, gyro, dt, bias, nga, walk, out=None, stream=None):
         """IMU::Preintegrated::Initialize + IntegrateNewMeasurement for many measurement sequences at once.
         Device tensors: start i32 [S+1] (sequence s owns measurements start[s]:start[s+1]), acc / gyro f32 [M, 3],
