@@ -1059,7 +1059,7 @@ int morb_extractor_create(morb_extractor** out, int nfeatures, float scaleFactor
     for (int i = 0; i < 16; ++i)
       if (e->umax[i] != kStd[i]) { set_error("umax table mismatch"); delete e; return MORB_ERR_UNSUPPORTED; }
   }
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamDefault) != hipSuccess ||
       hipStreamCreateWithFlags(&e->sideStream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&e->evJoin, hipEventDisableTiming) != hipSuccess) {

@@ -818,7 +818,9 @@ int morb_matcher_create(morb_matcher** out, int device) {
   MORB_HIP_CHECK(hipSetDevice(device));
   morb_matcher* m = new morb_matcher();
   m->device = device;
-  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+  // the handle's own stream (used when the caller passes stream = NULL) is a BLOCKING stream: it is implicitly ordered with the
+  // legacy default stream, so callers that prepare inputs / consume outputs there (torch's default stream) need no events
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamDefault) != hipSuccess) {
     delete m;
     set_error("cannot create stream");
     return MORB_ERR_HIP;

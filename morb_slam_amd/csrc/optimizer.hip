@@ -1373,7 +1373,7 @@ int morb_optimizer_create(morb_optimizer** out, int device) {
   MORB_HIP_CHECK(hipSetDevice(device));
   morb_optimizer* o = new morb_optimizer();
   o->device = device;
-  if (hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking) != hipSuccess ||
+  if (hipStreamCreateWithFlags(&o->stream, hipStreamDefault) != hipSuccess ||
       hipStreamCreateWithFlags(&o->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&o->evFork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&o->evJoin, hipEventDisableTiming) != hipSuccess) {
