@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.h"
+#include "wave.h"
 #include "kb8.h"
 
 using namespace morb;
@@ -53,14 +54,14 @@ __device__ __forceinline__ int hamming(const Desc& a, const Desc& b) {
 __device__ __forceinline__ void top2_insert(unsigned long long& k1, unsigned long long& k2, unsigned long long k) {
   if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;
 }
+// the two smallest of the lanes' (k1 <= k2) pairs, in every lane.  Keys carry the candidate index, so they are unique (apart
+// from the ~0 sentinel): the runner-up is the smallest of "k2 of the lane that owns the winner, k1 of every other lane".  Two
+// DPP reductions (wave.h) instead of a 6-step butterfly of four ds_bpermute each: this sits on the critical path of the
+// sequential resolve loops.  All 64 lanes must be active.
 __device__ __forceinline__ void wave_top2(unsigned long long& k1, unsigned long long& k2) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const unsigned long long o1 = __shfl_xor(k1, off, 64), o2 = __shfl_xor(k2, off, 64);
-    const unsigned long long lo = k1 < o1 ? k1 : o1, hi1 = k1 < o1 ? o1 : k1, lo2 = k1 < o1 ? k2 : o2;
-    k1 = lo;
-    k2 = hi1 < lo2 ? hi1 : lo2;
-  }
+  const unsigned long long g1 = morbwave::min_u64(k1);
+  const unsigned long long g2 = morbwave::min_u64(k1 == g1 ? k2 : k1);
+  k1 = g1; k2 = g2;
 }
 
 struct Query {       // one window search (a map point / a last-frame feature)
@@ -440,8 +441,7 @@ __global__ __launch_bounds__(256) void k_best_per_query(morb_frame_params P, int
       best = k < best ? k : best;
     }
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(best, off, 64); best = o < best ? o : best; }
+  best = morbwave::min_u64(best);   // DPP reduction, all lanes active
   if (lane == 0) {
     const bool ok = best != ~0ull && (int)(best >> 32) <= thAccept;
     bestIdx[qo] = ok ? (int)((best >> 4) & 0xFFFF) : -1;
@@ -830,8 +830,7 @@ __global__ __launch_bounds__(256) void k_triangulation(const unsigned long long*
         }
       }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(best, off, 64); best = o < best ? o : best; }
+    best = morbwave::min_u64(best);   // DPP reduction, all lanes active
     if (best != ~0ull) {
       const int pos = lo + (0x7FFFFFFF - (int)(best & 0xFFFFFFFFu));
       result = (int)(s2[pos] & 0xFFFFFFFFu);
