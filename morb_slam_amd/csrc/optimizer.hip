@@ -26,6 +26,7 @@
 
 #include "common.h"
 #include "kb8.h"
+#include "wave.h"
 
 using namespace morb;
 
@@ -206,11 +207,7 @@ __device__ __forceinline__ void jac_point(const Cam& cam, bool stereo, const dou
 }
 
 // ---- block reductions (fixed order -> deterministic) --------------------------------------------------------
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+__device__ __forceinline__ double wave_sum_d(double v) { return morbwave::sum_f64(v); }   // DPP (wave.h), all lanes active
 template <int NW>
 __device__ __forceinline__ double block_sum_d(double v, double* red /*[NW]*/) {
   v = wave_sum_d(v);
