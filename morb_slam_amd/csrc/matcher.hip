@@ -58,12 +58,12 @@ __device__ __forceinline__ void top2_insert(unsigned long long& k1, unsigned lon
   if (k < k1) { k2 = k1; k1 = k; }
   else if (k < k2) k2 = k;
 }
+// the two smallest of the lanes' (k1 <= k2) pairs, in every lane; keys carry the candidate index (unique apart from the ~0
+// sentinel), so the runner-up is the smallest of "k2 of the winner's lane, k1 of the others".  DPP (wave.h); all lanes active.
 __device__ __forceinline__ void wave_top2(unsigned long long& k1, unsigned long long& k2) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const unsigned long long o1 = __shfl_xor(k1, off, 64), o2 = __shfl_xor(k2, off, 64);
-    top2_merge(k1, k2, o1, o2);
-  }
+  const unsigned long long g1 = morbwave::min_u64(k1);
+  const unsigned long long g2 = morbwave::min_u64(k1 == g1 ? k2 : k1);
+  k1 = g1; k2 = g2;
 }
 
 // ---------------------------------------------------------------------------------------------------

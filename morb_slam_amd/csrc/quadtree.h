@@ -147,10 +147,7 @@ QT_HD uint32_t qt_best_key(const uint32_t* keys, uint32_t begin, uint32_t count)
     uint64_t v = ((uint64_t)key_r(keys[begin + i]) << 32) | (uint64_t)(0xFFFFFFFFu - i);
     best = v > best ? v : best;
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    uint64_t o = __shfl_xor(best, off, 64);
-    best = o > best ? o : best;
-  }
+  best = ~morbwave::min_u64(~best);   // wave maximum on DPP (all lanes active)
   uint32_t pos = 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFu);
   return keys[begin + pos];
 #else
