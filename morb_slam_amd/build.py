@@ -22,18 +22,36 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_hip(force=False, verbose=False):
+def build_hip(force=False, verbose=False, extra_flags=(), out=OUT):
+    """One hipcc -c per translation unit (in parallel, objects under csrc/_obj/), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + \
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + \
         glob.glob(os.path.join(ROOT, "include", "*.h"))
-    if not force and not _stale(OUT, deps):
-        return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", OUT] + srcs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return OUT
+    objdir = os.path.join(CSRC, "_obj" + ("_" + "".join(c for c in "".join(extra_flags) if c.isalnum()) if extra_flags else ""))
+    os.makedirs(objdir, exist_ok=True)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [hipcc] + flags + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            return obj, True
+        return obj, False
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as ex:
+        res = list(ex.map(compile_one, srcs))
+    objs = [o for o, _ in res]
+    if any(c for _, c in res) or not os.path.exists(out) or _stale(out, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return out
 
 
 def build_oracle():

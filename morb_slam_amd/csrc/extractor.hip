@@ -236,37 +236,29 @@ __global__ __launch_bounds__(256) void k_blur(const LevelGeom* __restrict__ geom
 
 // ---------------------------------------------------------------------------------------------------
 // K2: per-cell FAST-9/16 + cornerScore + 3x3 NMS with the iniThFAST -> minThFAST fallback
-// (ORBextractor.cc:763-820 calling cv::FAST twice).  One workgroup per 35-px cell; the cell window
-// (wCell+6 x hCell+6) sits in LDS; survivors are written in row-major order (ordered ballot compaction) so
-// that concatenating cells in row-major cell order reproduces vToDistributeKeys.
+// (ORBextractor.cc:763-820 calling cv::FAST once or twice per 35-px cell).
+//
+// One 256-thread workgroup per SEGMENT = up to three horizontally adjacent cells of one cell row.  The cells' evaluated
+// areas tile the segment without overlap (cell j evaluates x in [iniX_j + 3, iniX_j + wCell + 3)), so the strength of every
+// pixel is computed once; what makes cv::FAST's result per-cell is only (a) the threshold a cell ends up with and (b) that
+// its non-maximum suppression sees nothing outside its own evaluated area — both are applied per cell below.  Versus one
+// workgroup per cell (round 1) this shares the 6-px horizontal apron, loads the window with 16-byte accesses and amortises
+// the per-workgroup set-up, the barriers and the partly filled rounds over three cells.
+//
+// Phases (PMC, profiles/r01: the kernel is bound by VALU issue, so the design rule is instructions per pixel):
+//   load     window (<= 128 px wide, hCell + 6 rows) -> LDS with unaligned 16-byte global loads; pitch 128, so a pixel's LDS
+//            offset is y << 7 | x and fits 14 bits of a 16-bit queue entry.
+//   reject   4 px per lane, packed-u16 SWAR: every 9-arc of the ring contains >= 2 of the compass pixels (0, 4, 8, 12), so a
+//            pixel can exceed strength T only if the second smallest compass value < v - T (dark) or the second largest
+//            > v + T (bright).  Survivors are queued densely (ballot compaction) with their possible polarities.
+//   strength exact max-min over the 16 arcs (v_min3 / v_max3 trees) for the queued pixels only and only for the polarity
+//            the compass test left possible: a 9-arc darker than v and a 9-arc brighter than v cannot both exist on a
+//            16-pixel ring, so cornerScore = that polarity's value (both are evaluated for the ~0.02 % with both flags).
+//   nms      bits of the corner bitmap; a neighbour outside the pixel's own cell counts as score 0.
+//   count / prefix / output per (row, cell): ordered row-major inside each cell, which is cv::FAST's order.
+// A cell without a keypoint after the iniThFAST pass is evaluated again with minThFAST (:795), alone.
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
-
-// max(A, C): A = max over the 16 circular 9-arcs of min(v - p_k), C likewise for (p_k - v).  A pixel is a
-// FAST-9 corner at threshold t iff this exceeds t, and cv's cornerScore<16> equals it minus 1.
-__device__ __forceinline__ int fast_strength(const uint8_t* __restrict__ p, int pitch) {
-  const int v = p[0];
-  int d[16];
-  d[0] = v - p[3 * pitch];       d[1] = v - p[3 * pitch + 1];   d[2] = v - p[2 * pitch + 2];
-  d[3] = v - p[pitch + 3];       d[4] = v - p[3];               d[5] = v - p[-pitch + 3];
-  d[6] = v - p[-2 * pitch + 2];  d[7] = v - p[-3 * pitch + 1];  d[8] = v - p[-3 * pitch];
-  d[9] = v - p[-3 * pitch - 1];  d[10] = v - p[-2 * pitch - 2]; d[11] = v - p[-pitch - 3];
-  d[12] = v - p[-3];             d[13] = v - p[pitch - 3];      d[14] = v - p[2 * pitch - 2];
-  d[15] = v - p[3 * pitch - 1];
-  int mn3[16], mx3[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    mn3[k] = imin(imin(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-    mx3[k] = imax(imax(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-  }
-  int A = -256, B = 256;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    A = imax(A, imin(imin(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]));
-    B = imin(B, imax(imax(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]));
-  }
-  return imax(A, -B);
-}
 
 #ifdef MORB_FAST_TIMING
 #define PHASE_MARK(k) do { __syncthreads(); if (threadIdx.x == 0 && ((blockIdx.x * 7 + blockIdx.y) & 63) == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_fastPhase[k], now_ - t0_); t0_ = now_; } } while (0)
@@ -285,234 +277,382 @@ __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {   // v_pk_m
 __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {   // v_pk_max_u16
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {   // v_pk_sub_u16 clamp
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {   // v_pk_add_u16
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));
+}
 
-constexpr int FAST_LD = 6;    // window dwords a thread keeps in flight per round of the tile load
-constexpr int FAST_NT = 128;  // threads per cell: per-wave fixed costs (setup, row prefix, partly filled survivor rounds) x 2 instead of x 4; 64 leaves too few waves per SIMD
+#ifndef MORB_FS_NT
+#define MORB_FS_NT 256
+#endif
+constexpr int FS_NT = MORB_FS_NT;          // threads per segment
+constexpr int FS_P = 128;           // LDS pitch of the window (bytes)
+constexpr int FS_BW = FS_P / 32;    // bitmap words per window row
+constexpr int FS_CQ = 512;          // corner list of a job (typically ~60 corners per segment)
+constexpr int FS_QCAP = 2048;       // survivor queue (typically ~400 per segment); a multiple of FS_P
+constexpr int FS_KCAP = 64;         // keypoint list of a cell (typically ~6)
 
-// PMC (profiles/r01): the kernel is VALU-issue bound (~90 % of SIMD cycles issue VALU), not memory bound, so the
-// design rule is instruction count: no integer divisions (host-side magics in FastGeom / kernel arguments), SWAR
-// for the reject test, exact strength only for survivors.
-template <int NT>
-__global__ __launch_bounds__(NT) void k_fast(const morb::FastGeom fg, int nlevels,
-                                              const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
-                                              int* __restrict__ candCnt, int totalCells, int cellCap, int tilePitch,
-                                              int tileRows, int bmWords, unsigned gMagic, int iniTh, int minTh) {
+// i / d == (i * ceil(2^20 / d)) >> 20 for i < 2^15, d < 40 (both factors fit v_mul_u32_u24)
+struct Magic20 { unsigned m[40]; constexpr Magic20() : m() { for (int d = 1; d < 40; ++d) m[d] = 0xFFFFFu / (unsigned)d + 1u; } };
+__constant__ Magic20 c_magic20 = Magic20();
+
+// max over the 16 circular 9-arcs of the arc's minimum
+__device__ __forceinline__ int arc9_maxmin(const int (&d)[16]) {
+  int mn3[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) mn3[k] = imin(imin(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+  int A = -256;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) A = imax(A, imin(imin(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]));
+  return A;
+}
+// bits [lo, hi) of a 32-bit word (empty if hi <= lo; lo, hi may lie outside [0, 32])
+__device__ __forceinline__ uint32_t range_mask(int lo, int hi) {
+  lo = imax(lo, 0); hi = imin(hi, 32);
+  if (hi <= lo) return 0u;
+  return (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+}
+
+__global__ __launch_bounds__(FS_NT) void k_fast(const morb::FastGeom fg, const morb::FastSeg* __restrict__ segTab,
+                                                 const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
+                                                 int* __restrict__ candCnt, int totalCells, int cellCap, int rows,
+                                                 int iniTh, int minTh, int stopPhase) {
   extern __shared__ __align__(16) uint8_t smem[];
-  uint8_t* tile = smem;                           // [tileRows][tilePitch]
-  uint8_t* sc = smem + tileRows * tilePitch;      // [tileRows][tilePitch] strength, 0 where it cannot matter
-  uint16_t* queue = reinterpret_cast<uint16_t*>(smem + 2 * tileRows * tilePitch);  // [tileRows * tilePitch] y << 8 | x
-  uint32_t* bmHi = reinterpret_cast<uint32_t*>(smem + 4 * tileRows * tilePitch);  // [tileRows][bmWords] keep bits at iniThFAST
-  uint32_t* bmLo = bmHi + tileRows * bmWords;                                      // [tileRows][bmWords] keep bits at minThFAST
-  int* rowCnt = reinterpret_cast<int*>(bmLo + tileRows * bmWords);                       // [tileRows + 1]
+  uint8_t* tile = smem;                                                   // [rows][FS_P] pixels (+16 bytes: the last block's right neighbour)
+  uint8_t* sc = smem + rows * FS_P + 16;                                  // [rows][FS_P] strength S of corners (S > the cell's threshold), else 0
+  uint32_t* cornerBm = reinterpret_cast<uint32_t*>(sc + rows * FS_P);     // [rows][FS_BW] pixels with a strength
+  uint32_t* keepBm = cornerBm + rows * FS_BW;                             // [rows][FS_BW] keypoints (after NMS)
+  uint16_t* queue = reinterpret_cast<uint16_t*>(keepBm + rows * FS_BW);   // [FS_QCAP] bright << 15 | dark << 14 | y << 7 | x
   __shared__ int qn;
+  __shared__ int cellTot[4];
+  // fast paths for the usual case of few corners: a compact corner list per job and the keypoints of every cell as short lists;
+  // when either overflows (slow != 0) the bitmaps, which are always kept, drive the NMS / the output instead
+  __shared__ int cn, slow, dup, qover, keptN[4];
+  __shared__ uint16_t cornerQ[FS_CQ];
+  __shared__ uint16_t kept[4][FS_KCAP];
 
 #ifdef MORB_FAST_TIMING
   unsigned long long t0_ = wall_clock64();
 #endif
-  const int img = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const uint64_t ltmask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  const int G = tilePitch >> 2;                         // dwords per window row in LDS; gMagic = ceil(2^32 / G)
-  const size_t cellSlot = (size_t)img * totalCells + blockIdx.x;
-
-  // the cell's level and geometry: scalar loads from the kernarg segment, no dependent global-memory round trip
-  int l = 0;
-#pragma unroll
-  for (int k = 1; k < kMaxLevels; ++k) l += (k < nlevels && (int)blockIdx.x >= fg.cellBase[k]) ? 1 : 0;   // cellBase is increasing
-  struct { int ci, cj, wCell, hCell; } c;
-  const int cell = blockIdx.x - fg.cellBase[l];
-  c.ci = (int)__umulhi((unsigned)cell, fg.nColsMagic[l]); c.cj = cell - c.ci * fg.nCols[l];
-  c.wCell = fg.wCell[l]; c.hCell = fg.hCell[l];
-  const int pstride = fg.pstride[l], mbx = fg.maxBorderX[l], mby = fg.maxBorderY[l];
-  const int iniX = MINB + c.cj * c.wCell, iniY = MINB + c.ci * c.hCell;
-  const int tw = imin(iniX + c.wCell + 6, mbx) - iniX, th = imin(iniY + c.hCell + 6, mby) - iniY;
-  const int ew = tw - 6, eh = th - 6;  // evaluated area: x in [3, tw-3), y in [3, th-3)
-  if (iniY >= mby - 3 || iniX >= mbx - 6 || ew <= 0 || eh <= 0) {  // :770, :775
-    if (tid == 0) candCnt[cellSlot] = 0;
+  const int img = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  // the segment's geometry: one scalar load of its host-built descriptor, the level's constants from the kernarg segment
+  const morb::FastSeg sd = segTab[blockIdx.x];
+  const int l = sd.geo & 0xFF, nc = (sd.geo >> 8) & 0xFF, tw = (sd.geo >> 16) & 0xFF, th = (int)((unsigned)sd.geo >> 24);
+  const int wCell = fg.wCell[l], pstride = fg.pstride[l];
+  const unsigned wMagic = fg.wCellMagic[l];
+  const size_t cellSlot0 = (size_t)img * totalCells + sd.cell0;
+  if (tw <= 6 || th <= 6) {   // :770, :775: skipped cells, or windows cv::FAST finds nothing in
+    if (tid < nc) candCnt[cellSlot0 + tid] = 0;
     return;
   }
-  const uint8_t* base = pyr + fg.pyrOff[l] + (size_t)img * fg.pyrImg[l] + (size_t)(EDGE + iniY) * pstride + EDGE + iniX;
   {
-    // Window -> LDS as (unaligned) dwords, th rows of the full LDS pitch: every load of a thread is issued before its
-    // first LDS store and there are no per-lane branches (an index past the window re-reads its last dword), so the
-    // block pays one global-load latency.  Columns >= tw are never evaluated; they lie in the padded pyramid row or
-    // the next one (the slab has 256 bytes of slack behind it).
-    const int nD = th * G;
-    for (int base0 = 0; base0 < nD; base0 += NT * FAST_LD) {
-      uint32_t v[FAST_LD]; int off[FAST_LD];
+    // Window -> LDS, 16 bytes per access (global: unaligned; LDS: aligned).  Columns >= tw are never evaluated; they lie in
+    // the padded pyramid row or the next one (the slab has 256 bytes of slack behind it).
+    const uint8_t* base = pyr + fg.pyrOff[l] + (size_t)img * fg.pyrImg[l] + sd.winOff;
+    const int n16 = rows * (FS_P / 16);
+    for (int i0 = 0; i0 < n16; i0 += 2 * FS_NT) {
+      uint4 v[2]; int off[2];
 #pragma unroll
-      for (int k = 0; k < FAST_LD; ++k) {
-        const int i = imin(base0 + tid + k * NT, nD - 1);
-        const int r = (int)__umulhi((unsigned)i, gMagic), c4 = (i - r * G) << 2;
-        off[k] = r * tilePitch + c4;
-        v[k] = *reinterpret_cast<const uint32_t*>(base + (size_t)r * pstride + c4);
+      for (int k = 0; k < 2; ++k) {
+        const int i = i0 + tid + k * FS_NT;
+        const int rr = i >> 3, c16 = (i & 7) << 4;
+        off[k] = i < n16 ? rr * FS_P + c16 : -1;
+        v[k] = make_uint4(0, 0, 0, 0);
+        if (i < n16 && rr < th && stopPhase != 10) __builtin_memcpy(&v[k], base + (unsigned)(__umul24(rr, pstride) + c16), 16);
       }
 #pragma unroll
-      for (int k = 0; k < FAST_LD; ++k) {
-        *reinterpret_cast<uint32_t*>(tile + off[k]) = v[k];
-        *reinterpret_cast<uint32_t*>(sc + off[k]) = 0u;
-      }
-    }
-    for (int i = tid; i < th * bmWords; i += NT) bmHi[i] = 0;
-  }
-  PHASE_MARK(0);
-  // cv::FAST(iniThFAST) first; only a cell that yields no keypoint is evaluated again with minThFAST (:791-796).  Most cells stop
-  // after the first pass, whose cheap reject passes about half as many pixels as a reject at the lower threshold would.
-  int nq = 0;
-  for (int pass = 0; pass < 2; ++pass) {
-  const int T = pass ? minTh : iniTh;
-  if (tid == 0) qn = 0;
-  __syncthreads();
-  {
-    // Phase 1 — cheap reject.  Every 9-arc of the 16-pixel ring contains at least two of the four compass pixels
-    // (0, 4, 8, 12), so a pixel can only exceed strength T if >= 2 compass pixels are darker than v - T or
-    // >= 2 are brighter than v + T, i.e. the second smallest compass value < v - T or the second largest
-    // > v + T.  Pixels that fail keep strength 0: they are no corners at this threshold and count as score 0 in
-    // their neighbours' NMS, exactly like cv::FAST's score buffer.
-    // Four pixels per lane: the window row is read as aligned dwords (centre, the dwords left and right of it, the
-    // rows 3 above / below), bytes are split into even / odd 16-bit lanes, the second smallest / largest come from a
-    // packed-u16 min/max network, and bit 15 of (0x8000 + a - b - 1) says "a > b" for two pixels at once.
-    // only the dword groups that contain an evaluated pixel (x in [3, tw - 3)) are visited: Gu <= G of them per row
-    const int Gu = ((tw - 4) >> 2) + 1;
-    const unsigned guMagic = 0xFFFFFFFFu / (unsigned)Gu + 1u;
-    const int nGroups = eh * Gu;
-    const unsigned K = 0x80008000u, LO = 0x00FF00FFu;
-    const unsigned T1 = (unsigned)(T + 1) * 0x00010001u;
-    for (int i0 = 0; i0 < nGroups; i0 += NT) {
-      const int i = i0 + tid;
-      unsigned re = 0, ro = 0;   // bit 15 / 31: pixel may exceed T (even bytes, odd bytes)
-      int x4 = 0, y = 0;
-      if (i < nGroups) {
-        const int ry = (int)__umulhi((unsigned)i, guMagic);
-        y = ry + 3; const int gi = i - ry * Gu; x4 = gi << 2;
-        const uint32_t* row = reinterpret_cast<const uint32_t*>(tile + y * tilePitch);
-        const uint32_t C = row[gi];
-        const uint32_t Lw = gi > 0 ? row[gi - 1] : 0u, Rw = gi + 1 < G ? row[gi + 1] : 0u;
-        const uint32_t U = reinterpret_cast<const uint32_t*>(tile + (y - 3) * tilePitch)[gi];   // ring pixel 8 (0,-3)
-        const uint32_t D = reinterpret_cast<const uint32_t*>(tile + (y + 3) * tilePitch)[gi];   // ring pixel 0 (0,+3)
-        const uint32_t L = __builtin_amdgcn_alignbyte(C, Lw, 1);                                 // ring pixel 12 (-3,0)
-        const uint32_t R = __builtin_amdgcn_alignbyte(Rw, C, 3);                                 // ring pixel 4 (+3,0)
-        unsigned res[2];
-#pragma unroll
-        for (int par = 0; par < 2; ++par) {
-          const unsigned Ve = (par ? (C >> 8) : C) & LO;
-          const unsigned a = (par ? (U >> 8) : U) & LO, b = (par ? (D >> 8) : D) & LO;
-          const unsigned cc = (par ? (L >> 8) : L) & LO, d = (par ? (R >> 8) : R) & LO;
-          const unsigned lo1 = pk_min(a, b), hi1 = pk_max(a, b), lo2 = pk_min(cc, d), hi2 = pk_max(cc, d);
-          const unsigned mlo = pk_max(lo1, lo2), mhi = pk_min(hi1, hi2);
-          const unsigned s2 = pk_min(mlo, mhi);      // second smallest of the four
-          const unsigned l2 = pk_max(mlo, mhi);      // second largest
-          const unsigned dark = ((Ve | K) - T1) - s2;        // bit 15: v - s2 >= T + 1
-          const unsigned bright = (l2 | K) - (Ve + T1);      // bit 15: l2 - v >= T + 1
-          res[par] = (dark | bright) & K;
+      for (int k = 0; k < 2; ++k)
+        if (off[k] >= 0) {
+          *reinterpret_cast<uint4*>(tile + off[k]) = v[k];
+          *reinterpret_cast<uint4*>(sc + off[k]) = make_uint4(0, 0, 0, 0);
         }
-        re = res[0]; ro = res[1];
-        // only pixels of the evaluated area count (byte k of the dword is pixel x4 + k: even-lo, odd-lo, even-hi, odd-hi)
-        const int lim = tw - 3;   // first x outside
-        if (x4 + 0 < 3 || x4 + 0 >= lim) re &= 0xFFFF0000u;
-        if (x4 + 1 < 3 || x4 + 1 >= lim) ro &= 0xFFFF0000u;
-        if (x4 + 2 < 3 || x4 + 2 >= lim) re &= 0x0000FFFFu;
-        if (x4 + 3 >= lim) ro &= 0x0000FFFFu;
+    }
+    for (int i = tid; i < rows * (2 * FS_BW); i += FS_NT) cornerBm[i] = 0;   // cornerBm and keepBm are contiguous
+    if (tid < 4) { *reinterpret_cast<uint32_t*>(tile + rows * FS_P + 4 * tid) = 0; cellTot[tid] = 0; keptN[tid] = 0; }
+    if (tid == 0) { qn = 0; cn = 0; slow = 0; dup = 0; qover = 0; }
+  }
+  __syncthreads();
+  PHASE_MARK(0);
+  if (stopPhase >= 0 && tid < nc) candCnt[cellSlot0 + tid] = 0;   // developer hook (tools/fast_cost.py prices the phases with early exits); -1 in the product
+  if (stopPhase == 0) return;
+
+  // keypoints of row y inside cell j (the cell's evaluated columns)
+  auto row_cell_count = [&](int y, int j) -> int {
+    const int a = 3 + j * wCell, b = imin(a + wCell, tw - 3);
+    int cnt = 0;
+#pragma unroll
+    for (int w = 0; w < FS_BW; ++w) cnt += __popc(keepBm[y * FS_BW + w] & range_mask(a - 32 * w, b - 32 * w));
+    return cnt;
+  };
+  // per-cell totals -> cellTot: wave j counts cell j, one row per lane
+  auto count_cells = [&]() {
+    const int j = tid >> 6;
+    if (j < nc) {
+      int tot = 0;
+      for (int y0 = 0; y0 < th; y0 += 64) tot += y0 + lane < th ? row_cell_count(y0 + lane, j) : 0;
+      tot = morbwave::sum_i32(tot);
+      if (lane == 0) cellTot[j] = tot;
+    }
+    __syncthreads();
+  };
+
+  for (int job = 0; job <= nc; ++job) {
+    // job 0: cv::FAST(iniThFAST) on every cell of the segment; job j >= 1: cell j - 1 again with minThFAST if it is empty (:795)
+    int xa = 3, xb = tw - 3, T = iniTh;
+    if (job > 0) {
+      const int j = job - 1;
+      if (cellTot[j] != 0) continue;   // uniform: written before the last barrier
+      xa = 3 + j * wCell; xb = imin(xa + wCell, tw - 3); T = minTh;
+      if (xb <= xa) continue;
+      // the second cv::FAST call starts from nothing: forget the first pass's strengths in this cell (they exist when its
+      // corners tied each other out in the NMS, and matter when minThFAST > iniThFAST)
+      for (int wi = tid; wi < th * FS_BW; wi += FS_NT) {
+        const uint32_t mask = range_mask(xa - ((wi & 3) << 5), xb - ((wi & 3) << 5));
+        uint32_t bits = cornerBm[wi] & mask;
+        if (bits) {
+          cornerBm[wi] &= ~mask;
+          while (bits) { const int b = __ffs(bits) - 1; bits &= bits - 1; sc[((wi >> 2) << 7) | (((wi & 3) << 5) + b)] = 0; }
+        }
       }
-      const uint64_t m0 = __ballot(re & 0x8000u), m1 = __ballot(ro & 0x8000u), m2 = __ballot(re >> 31), m3 = __ballot(ro >> 31);
-      const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
-      const int total = c0 + c1 + c2 + c3;
-      if (total) {
-        int qbase = 0;
-        if (lane == 0) qbase = atomicAdd(&qn, total);
-        qbase = __shfl(qbase, 0, 64);
-        const uint16_t e = (uint16_t)((y << 8) | x4);
-        if (re & 0x8000u) queue[qbase + __popcll(m0 & ltmask)] = e;
-        if (ro & 0x8000u) queue[qbase + c0 + __popcll(m1 & ltmask)] = (uint16_t)(e + 1);
-        if (re >> 31) queue[qbase + c0 + c1 + __popcll(m2 & ltmask)] = (uint16_t)(e + 2);
-        if (ro >> 31) queue[qbase + c0 + c1 + c2 + __popcll(m3 & ltmask)] = (uint16_t)(e + 3);
+      __syncthreads();
+    }
+    // All evaluated rows at once; if the survivor queue (FS_QCAP entries) cannot hold them — far more survivors than any natural
+    // image produces — the job starts over in chunks of FS_QCAP / 128 rows, which always fit.
+    int chunkRows = th - 6;
+    for (int ya = 3; ya < th - 3; ya += chunkRows) {
+    const int yb = imin(ya + chunkRows, th - 3);
+    {
+      // reject: one lane = 16 consecutive pixels of a window row (four dwords C0..C3 plus the dword on either side), read with
+      // three 16-byte and two 4-byte LDS loads.  Bytes are split into even / odd 16-bit lanes once per dword; the left / right
+      // compass pixels (x - 3, x + 3) of a dword's even pixels are the odd lanes of its neighbours and vice versa, so they cost one
+      // v_alignbit each.  The second smallest / largest of the four compass values come from a packed-u16 min / max network, and
+      // the margin tests (v - s2 > T, l2 - v > T) are packed adds whose carries land on a different bit per (dword, parity,
+      // polarity): 32 flag bits per lane.  Compaction: per-lane popcount, one DPP scan per wave, one LDS atomic per wave, then
+      // every lane emits its own entries.  Blocks that straddle xa / xb also flag pixels outside [xa, xb): those are dropped
+      // when their strength would be stored.
+      const int nItems = (yb - ya) * 8;
+      const unsigned LO = 0x00FF00FFu;
+      unsigned KF[8], MF[8];   // per (dword & 1, parity, polarity): the add constant and the flag bit (8 + index) in both halves
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { KF[j] = ((1u << (8 + j)) - 1u - (unsigned)T) * 0x00010001u; MF[j] = (1u << (8 + j)) * 0x00010001u; }
+      for (int i0 = 0; i0 < nItems; i0 += FS_NT) {
+        if (i0 + __builtin_amdgcn_readfirstlane(tid & ~63) >= nItems) break;   // wave-uniform: no item left for this wave
+        const int i = i0 + tid;
+        const int y = (i >> 3) + ya, xb0 = (i & 7) << 4;
+        unsigned W = 0;   // bit f: f[0] polarity (0 dark, 1 bright), pixel offset in the block = f[3] f[2] f[4] f[1]
+        if (i < nItems && xb0 < xb && xb0 + 16 > xa) {
+          const uint8_t* rowp = tile + ((y << 7) | xb0);
+          const uint4 C = *reinterpret_cast<const uint4*>(rowp);
+          const uint4 U = *reinterpret_cast<const uint4*>(rowp - 3 * FS_P);   // ring pixel 8 (0,-3)
+          const uint4 D = *reinterpret_cast<const uint4*>(rowp + 3 * FS_P);   // ring pixel 0 (0,+3)
+          const uint32_t Lw = *reinterpret_cast<const uint32_t*>(rowp - 4), Rw = *reinterpret_cast<const uint32_t*>(rowp + 16);
+          const uint32_t Cw[6] = {Lw, C.x, C.y, C.z, C.w, Rw}, Uw[4] = {U.x, U.y, U.z, U.w}, Dw[4] = {D.x, D.y, D.z, D.w};
+          unsigned E[6], O[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { E[k] = Cw[k] & LO; O[k] = (Cw[k] >> 8) & LO; }
+          unsigned acc[2] = {0u, 0u};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+              const unsigned Ve = par ? O[k + 1] : E[k + 1];
+              const unsigned a = (par ? (Uw[k] >> 8) : Uw[k]) & LO, b = (par ? (Dw[k] >> 8) : Dw[k]) & LO;
+              // ring pixels 12 (-3,0) and 4 (+3,0)
+              const unsigned cc = par ? __builtin_amdgcn_alignbit(E[k + 1], E[k], 16) : O[k];
+              const unsigned d = par ? E[k + 2] : __builtin_amdgcn_alignbit(O[k + 2], O[k + 1], 16);
+              const unsigned lo1 = pk_min(a, b), hi1 = pk_max(a, b), lo2 = pk_min(cc, d), hi2 = pk_max(cc, d);
+              const unsigned mlo = pk_max(lo1, lo2), mhi = pk_min(hi1, hi2);
+              const unsigned s2 = pk_min(mlo, mhi);      // second smallest of the four
+              const unsigned l2 = pk_max(mlo, mhi);      // second largest
+              const int j = (k & 1) * 4 + par * 2;
+              acc[k >> 1] |= pk_add(pk_sub_sat(Ve, s2), KF[j]) & MF[j];           // v - s2 > T
+              acc[k >> 1] |= pk_add(pk_sub_sat(l2, Ve), KF[j + 1]) & MF[j + 1];   // l2 - v > T
+            }
+          }
+          W = ((acc[0] >> 8) & 0x00FF00FFu) | (acc[1] & 0xFF00FF00u);
+        }
+        unsigned anyW = (W | (W >> 1)) & 0x55555555u;
+        const int cnt = __popc(anyW);
+        int incl = cnt;
+        MORB_DPP_SCAN(incl, 0, morbwave::op_add);   // inclusive prefix over the wave (all lanes active)
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total) {   // wave-uniform
+          int qbase = 0;
+          if (lane == 63) qbase = atomicAdd(&qn, total);
+          qbase = __builtin_amdgcn_readlane(qbase, 63);
+          if (qbase + total > FS_QCAP) { if (lane == 0) qover = 1; continue; }   // wave-uniform
+          int slot = qbase + incl - cnt;
+          const unsigned pos0 = (unsigned)((y << 7) | xb0);
+          while (anyW) {
+            const unsigned f = (unsigned)__ffs(anyW) - 1u;
+            anyW &= anyW - 1u;
+            const unsigned o = ((f >> 1) & 1u) | ((f >> 3) & 2u) | (f & 12u);
+            queue[slot++] = (uint16_t)((((W >> f) & 3u) << 14) | (pos0 + o));
+          }
+        }
       }
     }
-  }
-  {
     __syncthreads();
     PHASE_MARK(1);
-    // Phase 2 — exact strength for the survivors only, densely packed over the workgroup
-    nq = qn;
-    for (int q = tid; q < nq; q += NT) {
-      const int e = queue[q];
-      const int y = e >> 8, x = e & 255;
-      const int s = fast_strength(tile + y * tilePitch + x, tilePitch);
-      sc[y * tilePitch + x] = (uint8_t)(s > T ? imin(s, 255) : 0);
+    if (stopPhase == 1) return;
+    if (qover) {   // uniform (written before the barrier): start the job over, row chunk by row chunk
+      __syncthreads();
+      if (tid == 0) { qover = 0; qn = 0; dup = 1; }   // (strengths found so far are found again: the corner list would hold them twice)
+      __syncthreads();
+      chunkRows = FS_QCAP / FS_P;
+      ya = 3 - chunkRows;
+      continue;
+    }
+    {
+      // strength of the queued pixels, densely packed over the workgroup
+      const int n = qn;
+      for (int q = tid; q < n; q += FS_NT) {
+        const unsigned e = queue[q];
+        const int off = (int)(e & 0x3FFFu), x = off & (FS_P - 1);
+        // every ring offset relative to the ring's top-left corner is non-negative: one address, immediates only
+        constexpr int O = 3 * FS_P + 3;
+        int cornerOff = imax(off - O, 0);   // (negative only for a flagged pixel left of the evaluated area, whose result is dropped)
+        asm volatile("" : "+v"(cornerOff));   // (opaque: otherwise the address is re-based on the centre and 7 offsets need their own add)
+        const uint8_t* p = tile + cornerOff;
+        const int v = p[O];
+        int rr[16];
+        rr[0] = p[O + 3 * FS_P];   rr[1] = p[O + 3 * FS_P + 1];  rr[2] = p[O + 2 * FS_P + 2];  rr[3] = p[O + FS_P + 3];
+        rr[4] = p[O + 3];          rr[5] = p[O - FS_P + 3];      rr[6] = p[O - 2 * FS_P + 2];  rr[7] = p[O - 3 * FS_P + 1];
+        rr[8] = p[O - 3 * FS_P];   rr[9] = p[O - 3 * FS_P - 1];  rr[10] = p[O - 2 * FS_P - 2]; rr[11] = p[O - FS_P - 3];
+        rr[12] = p[O - 3];         rr[13] = p[O + FS_P - 3];     rr[14] = p[O + 2 * FS_P - 2]; rr[15] = p[O + 3 * FS_P - 1];
+        // d = v - p for the dark polarity (= ~p + v + 1), p - v for the bright one: (p ^ m) + c, one v_xad_u32 per ring pixel
+        const int xm = (e & 0x4000u) ? -1 : 0, xc = (e & 0x4000u) ? v + 1 : -v;
+        int d[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d[k] = (rr[k] ^ xm) + xc;
+        int S = arc9_maxmin(d);
+        const bool both = (e >> 14) == 3u;
+        if (__ballot(both)) {   // rare: the compass test left both polarities possible
+#pragma unroll
+          for (int k = 0; k < 16; ++k) d[k] = rr[k] - v;
+          const int S2 = arc9_maxmin(d);
+          if (both) S = imax(S, S2);
+        }
+        const bool isCorner = S > T && x >= xa && x < xb;
+        if (isCorner) {
+          sc[off] = (uint8_t)imin(S, 255);
+          atomicOr(&cornerBm[off >> 5], 1u << (x & 31));
+        }
+        const uint64_t cm = __ballot(isCorner);
+        if (cm) {   // wave-uniform; lane 0 holds the wave's smallest q, so it is active whenever the wave is
+          int cbase = 0;
+          if (lane == 0) cbase = atomicAdd(&cn, __popcll(cm));
+          cbase = __builtin_amdgcn_readfirstlane(cbase);
+          const int idx = cbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+          if (isCorner && idx < FS_CQ) cornerQ[idx] = (uint16_t)off;
+        }
+      }
     }
     __syncthreads();
+    if (tid == 0) qn = 0;
+    if (chunkRows != th - 6) __syncthreads();   // (uniform) the next chunk's reservations start from 0
+    }   // row chunks
+    const int ncn = cn;
+    const bool useList = ncn <= FS_CQ && !dup;   // (both written before the last barrier)
     PHASE_MARK(2);
-
-    // Phase 3 — NMS, only for pixels that have a strength; results go to the per-row bitmap.  The strength map holds S for the
-    // corners of this pass (S > T) and 0 elsewhere: corner score S - 1, non-corner neighbours score 0; keep iff strictly
-    // greater than all 8.
-    for (int q = tid; q < nq; q += NT) {
-      const int e = queue[q];
-      const int y = e >> 8, x = e & 255;
-      const uint8_t* c = sc + y * tilePitch + x;
+    if (stopPhase == 2) return;
+    // NMS.  The strength map holds S for corners (S > T) and 0 elsewhere: corner score S - 1, everything else 0; keep iff
+    // strictly greater than all 8 neighbours' scores, where a neighbour outside the pixel's own cell (or outside the
+    // evaluated rows, where the map stays 0) counts as 0.
+    auto nms_keep = [&](int x, int y, int* cellOut) -> bool {
+      const uint8_t* c = sc + ((y << 7) | x);
       const int S = c[0];
-      if (S == 0) continue;
-      bool keep = true;
-#pragma unroll
-      for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-          if (dx == 0 && dy == 0) continue;
-          const int Sn = c[dy * tilePitch + dx];
-          keep = keep && (S - 1 > (Sn ? Sn - 1 : 0));
+      const int cj = (int)(((unsigned)(x - 3) * wMagic) >> 16), cxa = 3 + cj * wCell;
+      *cellOut = cj;
+      int m = imax(c[-FS_P], c[FS_P]);
+      if (x != cxa) m = imax(m, imax(imax(c[-FS_P - 1], c[-1]), c[FS_P - 1]));
+      if (x != cxa + wCell - 1) m = imax(m, imax(imax(c[-FS_P + 1], c[1]), c[FS_P + 1]));
+      return S > imax(m, 1);
+    };
+    if (useList) {   // one corner per lane
+      for (int q = tid; q < ncn; q += FS_NT) {
+        const int off = cornerQ[q], x = off & (FS_P - 1), y = off >> 7;
+        int cj;
+        if (nms_keep(x, y, &cj)) {
+          atomicOr(&keepBm[off >> 5], 1u << (x & 31));
+          const int idx = atomicAdd(&keptN[cj], 1);
+          if (idx < FS_KCAP) kept[cj][idx] = (uint16_t)off; else slow = 1;
         }
-      if (keep) atomicOr(&bmHi[y * bmWords + (x >> 5)], 1u << (x & 31));
+      }
+    } else {   // corner list overflowed: one 32-pixel word of the corner bitmap per lane
+      if (tid == 0) slow = 1;
+      for (int wi = tid; wi < th * FS_BW; wi += FS_NT) {
+        const int y = wi >> 2, x0 = (wi & 3) << 5;
+        uint32_t bits = cornerBm[wi] & range_mask(xa - x0, xb - x0);
+        uint32_t keep = 0;
+        while (bits) {
+          const int b = __ffs(bits) - 1;
+          bits &= bits - 1;
+          int cj;
+          if (nms_keep(x0 + b, y, &cj)) keep |= 1u << b;
+        }
+        if (keep) keepBm[wi] |= keep;
+      }
     }
     __syncthreads();
     PHASE_MARK(3);
-    // vKeysCell.empty() -> second cv::FAST with minThFAST (:795)
-    unsigned anyBits = 0;
-    for (int i = tid; i < th * bmWords; i += NT) anyBits |= bmHi[i];
-    const int any = __syncthreads_or(anyBits != 0);
-    if (any || pass == 1) break;   // uniform
-    for (int q = tid; q < nq; q += NT) { const int e = queue[q]; sc[(e >> 8) * tilePitch + (e & 255)] = 0; }   // strengths of the first pass
+    if (stopPhase == 3) return;
+    // keypoints per cell so far (decides which cells run again): the lists' lengths, or a count over the bitmap
+    if (tid == 0) { cn = 0; dup = 0; }
+    if (slow) {
+      count_cells();
+    } else {
+      if (tid < 4) cellTot[tid] = keptN[tid];
+      __syncthreads();
+    }
+    if (stopPhase == 4) return;
   }
-  }   // pass
+  PHASE_MARK(4);
+  if (stopPhase == 5) return;
   {
-    // Phase 4 — row prefix sums of the bitmap
-    const uint32_t* bm = bmHi;
-    for (int r = tid; r < th; r += NT) {
-      int c = 0;
-      for (int w = 0; w < bmWords; ++w) c += __popc(bm[r * bmWords + w]);
-      rowCnt[r] = c;
-    }
-    __syncthreads();
-    if (tid < 64) {   // exclusive scan of the row counts by one wave, ceil(th / 64) consecutive rows per lane
-      const int per = (th + 63) >> 6, r0 = tid * per, r1 = imin(r0 + per, th);
-      int c = 0;
-      for (int r = r0; r < r1; ++r) c += rowCnt[r];
-      int inc = c;
+    // ordered output, row-major inside each cell: wave j writes cell j, one row per lane — the lane's slot is the exclusive
+    // prefix (one DPP scan) of the rows' keypoint counts
+    const int j = tid >> 6;
+    const int keyX0 = sd.key0 & 0xFFFF, keyY0 = sd.key0 >> 16;
+    if (j < nc && !slow) {
+      // the cell's keypoints are a short unordered list: a keypoint's slot is the number of keypoints before it in row-major
+      // order, counted against the list broadcast lane by lane
+      const int n = __builtin_amdgcn_readfirstlane(keptN[j]);   // <= FS_KCAP = 64
+      const int mine = lane < n ? kept[j][lane] : 0xFFFF;
+      int rank = 0;
+      for (int k = 0; k < n; ++k) rank += __builtin_amdgcn_readlane(mine, k) < mine ? 1 : 0;
+      if (lane < n && rank < cellCap)
+        cand[(cellSlot0 + j) * (size_t)cellCap + rank] = morbqt::make_key((mine & (FS_P - 1)) + keyX0, (mine >> 7) + keyY0, sc[mine] - 1);
+      if (lane == 0) candCnt[cellSlot0 + j] = imin(n, cellCap);
+    } else if (j < nc) {
+      const int a = 3 + j * wCell, b = imin(a + wCell, tw - 3);
+      uint32_t* out = cand + (cellSlot0 + j) * (size_t)cellCap;
+      int running = 0;
+      for (int y0 = 0; y0 < th; y0 += 64) {
+        const int y = y0 + lane;
+        const int c = y < th ? row_cell_count(y, j) : 0;
+        int inc = c;
+        MORB_DPP_SCAN(inc, 0, morbwave::op_add);
+        int slot = running + inc - c;
+        running += __builtin_amdgcn_readlane(inc, 63);
+        if (c) {
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
-      int acc = inc - c;
-      for (int r = r0; r < r1; ++r) { const int cr = rowCnt[r]; rowCnt[r] = acc; acc += cr; }
-      if (r0 < th && r1 == th) rowCnt[th] = acc;
-    }
-    __syncthreads();
-    PHASE_MARK(4);
-    // Phase 5 — ordered output (row-major over the evaluated area).  Only a handful of the survivors are corners after
-    // NMS, so the walk is over the bitmap words (one per lane), not over the survivor queue: slot = row prefix + set
-    // bits in the row's earlier words + position inside the word.
-    uint32_t* out = cand + cellSlot * (size_t)cellCap;
-    for (int y = tid; y < th; y += NT) {      // one row per lane (no division by the runtime word count)
-      int slot = rowCnt[y];
-      for (int w = 0; w < bmWords; ++w) {
-        uint32_t word = bm[y * bmWords + w];
-        while (word) {
-          const int b = __ffs(word) - 1;
-          word &= word - 1;
-          const int x = w * 32 + b;
-          if (slot < cellCap) out[slot] = morbqt::make_key(x + c.cj * c.wCell, y + c.ci * c.hCell, sc[y * tilePitch + x] - 1);
-          ++slot;
+          for (int w = 0; w < FS_BW; ++w) {
+            uint32_t word = keepBm[y * FS_BW + w] & range_mask(a - 32 * w, b - 32 * w);
+            while (word) {
+              const int bb = __ffs(word) - 1;
+              word &= word - 1;
+              const int x = w * 32 + bb;
+              if (slot < cellCap) out[slot] = morbqt::make_key(x + keyX0, y + keyY0, sc[(y << 7) | x] - 1);
+              ++slot;
+            }
+          }
         }
       }
+      if (lane == 0) candCnt[cellSlot0 + j] = imin(running, cellCap);
     }
-    if (tid == 0) candCnt[cellSlot] = imin(rowCnt[th], cellCap);
     PHASE_MARK(5);
   }
 }
@@ -864,7 +1004,7 @@ static int cvRoundF(float v) { return (int)lrintf(v); }
 
 void free_buffers(morb_extractor* e) {
   auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-  F(e->d_geom); F(e->d_tabs); F(e->d_pyr); F(e->d_blur); F(e->d_cand); F(e->d_qt); F(e->d_sel);
+  F(e->d_geom); F(e->d_tabs); F(e->d_segTab); F(e->d_pyr); F(e->d_blur); F(e->d_cand); F(e->d_qt); F(e->d_sel);
   F(e->d_candCnt); F(e->d_selCnt); F(e->d_kref); F(e->d_lap);
   e->W = e->H = e->nimgCap = 0;
   e->lapLast.clear();
@@ -885,7 +1025,8 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
   std::vector<ResizeTab> tabs;
   size_t pyrOff = 0, blurOff = 0, qtOff = 0;
   int cellBase = 0, selBase = 0, blurTileBase = 0;
-  e->cellCap = 0; e->tilePitch = 0; e->tileRows = 0; e->maxCells = 0; e->maxNodeCap = 0; e->maxListCap = 0;
+  e->cellCap = 0; e->maxCells = 0; e->maxNodeCap = 0; e->maxListCap = 0;
+  std::vector<FastSeg> segs;
   for (int l = 0; l < L; ++l) {
     LevelGeom& g = e->geom[l];
     memset(&g, 0, sizeof g);
@@ -905,9 +1046,27 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     g.cellBase = cellBase; cellBase += g.nCols * g.nRows;
     e->maxCells = std::max(e->maxCells, g.nCols * g.nRows);
     e->cellCap = std::max(e->cellCap, ((g.wCell + 1) / 2) * ((g.hCell + 1) / 2));
-    e->tilePitch = std::max(e->tilePitch, (int)align_up((size_t)g.wCell + 6, 4));
-    e->tileRows = std::max(e->tileRows, g.hCell + 6);
-    MORB_REQUIRE(g.wCell + 6 < 256 && g.hCell + 6 < 256, MORB_ERR_UNSUPPORTED, "FAST cell too large for 8-bit tile coordinates");
+    // k_fast segments: as many whole cells as fit a 128-px window (wCell + 6 <= 128 always: wCell < 70), spread evenly
+    MORB_REQUIRE(g.wCell + 6 <= FS_P && g.hCell + 6 < 128, MORB_ERR_UNSUPPORTED, "FAST cell too large for the 128-px segment window");
+    {
+      int cps = std::max(1, std::min(FS_NT / 64, (FS_P - 6) / g.wCell));   // (one wave per cell in the output phase)
+      const int nSeg = div_up(g.nCols, cps);
+      cps = div_up(g.nCols, nSeg);
+      e->fastGeom.wCellMagic[l] = 0xFFFFu / (unsigned)g.wCell + 1u;
+      for (int ci = 0; ci < g.nRows; ++ci)
+        for (int sj = 0; sj < nSeg; ++sj) {
+          const int c0 = sj * cps, nc = std::min(c0 + cps, g.nCols) - c0;
+          const int X0 = MINB + c0 * g.wCell, iniY = MINB + ci * g.hCell;
+          int tw = std::min(X0 + nc * g.wCell + 6, g.maxBorderX) - X0, th = std::min(iniY + g.hCell + 6, g.maxBorderY) - iniY;
+          if (iniY >= g.maxBorderY - 3 || tw <= 6 || th <= 6) tw = th = 0;   // ORBextractor.cc:770, :775
+          FastSeg sd;
+          sd.winOff = (unsigned)((size_t)(EDGE + iniY) * g.pstride + EDGE + X0);
+          sd.cell0 = g.cellBase + ci * g.nCols + c0;
+          sd.geo = l | (nc << 8) | (tw << 16) | (int)((unsigned)th << 24);
+          sd.key0 = (c0 * g.wCell) | ((ci * g.hCell) << 16);
+          segs.push_back(sd);
+        }
+    }
     g.quota = e->quota[l];
     g.nIni = (int)std::round(width / height);  // :545
     MORB_REQUIRE(g.nIni >= 1 && g.nIni <= 4, MORB_ERR_UNSUPPORTED, "aspect ratio unsupported (need 0.5 <= w/h < 4.5)");
@@ -965,6 +1124,22 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     g.ytabOff = (int)tabs.size(); build(g.h, gs.h, false, tabs);
   }
   e->totalCells = cellBase;
+  {
+    // Two launches of k_fast: the LDS window is sized by the tallest cell, and the few large cells of the small top levels would
+    // cost every workgroup of the big levels its occupancy.  Group 0 = segments of levels whose cells are at most two rows taller
+    // than level 0's, group 1 = the rest (possibly empty).
+    const int rowsA = e->geom[0].hCell + 6 + 2;
+    std::vector<FastSeg> a, b;
+    int ra = 0, rb = 0;
+    for (const FastSeg& sd : segs) {
+      const int rows = e->geom[sd.geo & 0xFF].hCell + 6;
+      if (rows <= rowsA) { a.push_back(sd); ra = std::max(ra, rows); } else { b.push_back(sd); rb = std::max(rb, rows); }
+    }
+    e->fastSegs[0] = (int)a.size(); e->fastSegs[1] = (int)b.size();
+    e->fastRows[0] = ra; e->fastRows[1] = rb;
+    segs = a;
+    segs.insert(segs.end(), b.begin(), b.end());
+  }
 
   e->selPerImg = selBase;
   e->blurTiles = blurTileBase;
@@ -979,13 +1154,15 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
   for (int l = 0; l < kMaxLevels; ++l) {
     const LevelGeom& g = e->geom[l < L ? l : L - 1];
     e->fastGeom.cellBase[l] = l < L ? g.cellBase : 0x7fffffff;
-    e->fastGeom.nCols[l] = g.nCols; e->fastGeom.nColsMagic[l] = 0xFFFFFFFFu / (unsigned)g.nCols + 1u; e->fastGeom.wCell[l] = g.wCell; e->fastGeom.hCell[l] = g.hCell;
+    e->fastGeom.nCols[l] = g.nCols; e->fastGeom.wCell[l] = g.wCell; e->fastGeom.hCell[l] = g.hCell;
     e->fastGeom.pstride[l] = g.pstride; e->fastGeom.maxBorderX[l] = g.maxBorderX; e->fastGeom.maxBorderY[l] = g.maxBorderY;
     e->fastGeom.pyrOff[l] = g.pyrOff; e->fastGeom.pyrImg[l] = g.pyrImg;
     e->descGeom.pyrOff[l] = g.pyrOff; e->descGeom.pyrImg[l] = g.pyrImg; e->descGeom.blurOff[l] = g.blurOff;
     e->descGeom.blurImg[l] = g.blurImg; e->descGeom.pstride[l] = g.pstride; e->descGeom.bstride[l] = g.bstride;
     e->descGeom.scale[l] = g.scale; e->descGeom.kpSize[l] = g.kpSize;
   }
+  MORB_HIP_CHECK(hipMalloc(&e->d_segTab, sizeof(FastSeg) * segs.size()));
+  MORB_HIP_CHECK(hipMemcpy(e->d_segTab, segs.data(), sizeof(FastSeg) * segs.size(), hipMemcpyHostToDevice));
   MORB_HIP_CHECK(hipMalloc(&e->d_tabs, sizeof(ResizeTab) * std::max<size_t>(tabs.size(), 1)));
   if (!tabs.empty()) MORB_HIP_CHECK(hipMemcpy(e->d_tabs, tabs.data(), sizeof(ResizeTab) * tabs.size(), hipMemcpyHostToDevice));
   MORB_HIP_CHECK(hipMalloc(&e->d_pyr, e->pyrBytes + 256));
@@ -1001,6 +1178,9 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
   MORB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), e->umax, sizeof(int) * 16));
   MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_distribute),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->distSmem));
+  for (int k = 0; k < 2; ++k)   // window, strengths, 2 bitmaps, queue
+    e->fastSmem[k] = 2ull * e->fastRows[k] * FS_P + 16 + (size_t)e->fastRows[k] * (2 * FS_BW) * 4 + 2ull * FS_QCAP;
+  MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   e->W = W; e->H = H; e->nimgCap = nimg;
   return MORB_OK;
 }
@@ -1068,6 +1248,7 @@ int morb_extractor_create(morb_extractor** out, int nfeatures, float scaleFactor
     return MORB_ERR_HIP;
   }
   { const char* v = getenv("MORB_EXTRACT_SERIAL"); e->overlapBlur = !(v && v[0] == '1'); }
+  { const char* v = getenv("MORB_FAST_STOP"); e->fastStop = v ? atoi(v) : -1; }   // developer hook, see k_fast
   *out = e;
   return MORB_OK;
 }
@@ -1180,11 +1361,10 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   }
   mark(1);
   {
-    const int bmWords = (e->tilePitch + 31) / 32;
-    const size_t smem = 4ull * e->tileRows * e->tilePitch + (size_t)e->tileRows * (8 * bmWords + 4) + 16;  // tile, strength, u16 queue, 2 bitmaps, row counts
-    hipLaunchKernelGGL(k_fast<FAST_NT>, dim3(e->totalCells, nimg), dim3(FAST_NT), smem, st, e->fastGeom, L, e->d_pyr, e->d_cand,
-                       e->d_candCnt, e->totalCells, e->cellCap, e->tilePitch, e->tileRows, bmWords,
-                       0xFFFFFFFFu / (unsigned)(e->tilePitch / 4) + 1u, e->iniTh, e->minTh);
+    for (int k = 0, s0 = 0; k < 2; s0 += e->fastSegs[k], ++k)
+      if (e->fastSegs[k])
+        hipLaunchKernelGGL(k_fast, dim3(e->fastSegs[k], nimg), dim3(FS_NT), e->fastSmem[k], st, e->fastGeom, e->d_segTab + s0, e->d_pyr,
+                           e->d_cand, e->d_candCnt, e->totalCells, e->cellCap, e->fastRows[k], e->iniTh, e->minTh, e->fastStop);
   }
   mark(2);
   // The blur only feeds the descriptors and is VALU-bound; the quadtree is one latency-bound wave per (level, image)

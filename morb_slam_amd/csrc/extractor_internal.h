@@ -37,9 +37,18 @@ struct LevelGeom {
 // cell's level up costs no dependent global-memory round trip.
 struct FastGeom {
   int cellBase[kMaxLevels], nCols[kMaxLevels], wCell[kMaxLevels], hCell[kMaxLevels];
-  unsigned nColsMagic[kMaxLevels];      // ceil(2^32 / nCols): cell / nCols == umulhi(cell, magic) for every cell < 2^16
   int pstride[kMaxLevels], maxBorderX[kMaxLevels], maxBorderY[kMaxLevels];
   unsigned long long pyrOff[kMaxLevels], pyrImg[kMaxLevels];
+  unsigned wCellMagic[kMaxLevels];      // ceil(2^16 / wCell): x / wCell == (x * magic) >> 16 for every x < 128
+};
+
+// k_fast works on segments: a run of horizontally adjacent cells of one cell row whose window is <= 128 px wide.  One
+// descriptor per segment of an image (all levels), built on the host, read with one scalar load.
+struct FastSeg {
+  unsigned winOff;   // byte offset of the window's top-left pixel inside the level's (padded) image
+  int cell0;         // flat index of the segment's first cell within the image (cellBase + ci * nCols + c0)
+  int geo;           // level | cells << 8 | window width << 16 | window height << 24 (width 0: nothing to evaluate)
+  int key0;          // added to window coordinates to form candidate keys: c0 * wCell | (ci * hCell) << 16
 };
 
 // What k_describe needs of every level, by value (see FastGeom).
@@ -67,16 +76,19 @@ struct morb_extractor {
 
   int W = 0, H = 0, nimgCap = 0, nimgLast = 0;
   morb::LevelGeom geom[morb::kMaxLevels];
-  int totalCells = 0, cellCap = 0, tilePitch = 0, tileRows = 0, maxCells = 0, maxNodeCap = 0, maxListCap = 0;
+  int totalCells = 0, cellCap = 0, maxCells = 0, maxNodeCap = 0, maxListCap = 0;
+  int fastSegs[2] = {0, 0}, fastRows[2] = {0, 0};   // k_fast launch groups (segments, LDS window rows)
   int selPerImg = 0, blurTiles = 0, outCap = 0;
-  size_t pyrBytes = 0, blurBytes = 0, qtElems = 0, distSmem = 0;
+  size_t pyrBytes = 0, blurBytes = 0, qtElems = 0, distSmem = 0, fastSmem[2] = {0, 0};
 
   hipStream_t stream = nullptr;
   hipStream_t sideStream = nullptr;          // the blur runs here, underneath the quadtree (fork after FAST, join before describe)
   hipEvent_t evFork = nullptr, evJoin = nullptr;
   bool overlapBlur = true;
+  int fastStop = -1;                         // developer hook (MORB_FAST_STOP): k_fast returns after that phase
   morb::LevelGeom* d_geom = nullptr;
   morb::ResizeTab* d_tabs = nullptr;
+  morb::FastSeg* d_segTab = nullptr;
   uint8_t *d_pyr = nullptr, *d_blur = nullptr;
   uint32_t *d_cand = nullptr, *d_qt = nullptr, *d_sel = nullptr;
   int *d_candCnt = nullptr, *d_selCnt = nullptr,  *d_lap = nullptr;
