@@ -63,7 +63,8 @@ int morb_extract(morb_extractor*, const uint8_t* image, int width, int height, i
 /* Batched, device-resident form of operator(): nimg images of identical size, image i at
  * d_images + i*image_pitch.  lap = host array [nimg][2] of lapping areas, or NULL for {0,0} (the rectified
  * stereo call, Frame.cc:194-197).  Outputs are device arrays: d_kps [nimg][cap], d_desc [nimg][cap][32],
- * d_count [nimg], d_mono [nimg] (monoIndex).  Asynchronous on `stream`. */
+ * d_count [nimg], d_mono [nimg] (monoIndex); cap >= morb_extractor_max_keypoints() (else MORB_ERR_CAPACITY: the lapping-area
+ * keypoints fill every image's range from the back).  Asynchronous on `stream`. */
 int morb_extract_batch(morb_extractor*, const uint8_t* d_images, int nimg, int width, int height, int stride,
                        size_t image_pitch, const int* lap, morb_keypoint* d_kps, uint8_t* d_desc, int cap,
                        int* d_count, int* d_mono, void* stream);
@@ -543,19 +544,21 @@ int morb_local_inertial_ba_fisheye(morb_optimizer*, int nKF, float* kfState21, c
  * reference assembles at :1058-1351, flattened (HOST pointers): nKF keyframes (local ones first or in any
  * order; kfFixed[i] != 0 for lFixedCameras and the map's initial keyframe), nMP local map points, nE
  * observations (eKF, eMP indices; eObs = (x, y, uRight); eInvSigma2).  lambdaInit100 != 0 <=>
- * pMap->IsInertial() (:1137).  stopFlag = *pbStopFlag at entry (the graph is not optimised when set, :1355).
+ * pMap->IsInertial() (:1137).  stopFlag = pbStopFlag itself (a bool is one byte; NULL = none): read at entry (the graph is
+ * not optimised when set, :1355) and polled at every LM iteration and trial like optimizer.setForceStopFlag does (:1142).
  * Outputs: optimised kfPose (free keyframes) and mpPos in place, eraseFlag[e] = 1 where the reference erases the
  * observation (:1366-1401), stats2 = {outer LM iterations, LM trials}. */
 int morb_local_bundle_adjustment(morb_optimizer*, int nKF, float* kfPose, const uint8_t* kfFixed, int nMP, float* mpPos,
                                  int nE, const int* eKF, const int* eMP, const float* eObs, const float* eInvSigma2,
                                  float fx, float fy, float cx, float cy, float bf, int lambdaInit100,
-                                 const int* stopFlag, uint8_t* eraseFlag, int* stats2);
+                                 const unsigned char* stopFlag, uint8_t* eraseFlag, int* stats2);
 
 /* The same in three steps, so that a problem can stay resident in HBM and be solved repeatedly (benchmarks) or
  * aborted from another thread: create (upload + CSR build), solve (device only, asynchronous on `stream`,
  * restarts from the uploaded initial values), results (synchronises, downloads).  morb_ba_set_stop mirrors
- * LocalMapping::InterruptBA -> mbAbortBA (LocalMapping.cc:884): the kernel polls the flag at the top of every
- * outer iteration and every LM trial like g2o does (sparse_optimizer.cpp:376, optimization_algorithm_levenberg.cpp:149). */
+ * LocalMapping::InterruptBA -> mbAbortBA (LocalMapping.cc:884): the flag lives in pinned host memory mapped into the
+ * device, so setting it makes no HIP call, may come from any thread while a solve runs, and is seen at the top of the
+ * next outer iteration / LM trial like in g2o (sparse_optimizer.cpp:376, optimization_algorithm_levenberg.cpp:149). */
 typedef struct morb_ba_problem morb_ba_problem;
 int morb_ba_problem_create(morb_optimizer*, morb_ba_problem** out, int nKF, const float* kfPose, const uint8_t* kfFixed,
                            int nMP, const float* mpPos, int nE, const int* eKF, const int* eMP, const float* eObs,
@@ -574,7 +577,7 @@ int morb_ba_problem_create_fisheye(morb_optimizer* o, morb_ba_problem** out, int
 int morb_local_bundle_adjustment_fisheye(morb_optimizer* o, int nKF, float* kfPose, const uint8_t* kfFixed, int nMP, float* mpPos,
                                          int nE, const int* eKF, const int* eMP, const float* eObs2, const uint8_t* eRight,
                                          const float* eInvSigma2, const float* camL8, const float* camR8, const float* Trl7,
-                                         int lambdaInit100, const int* stopFlag, uint8_t* eraseFlag, int* stats2);
+                                         int lambdaInit100, const unsigned char* stopFlag, uint8_t* eraseFlag, int* stats2);
 void morb_ba_problem_destroy(morb_ba_problem*);
 int morb_ba_set_stop(morb_ba_problem*, int stop);
 /* mode 0 (default): one launch per LM phase over the whole GPU, accept/reject on the host (one 32-byte read-back per

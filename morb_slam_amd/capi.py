@@ -41,9 +41,10 @@ def make_frame_params(width, height, fx, fy, cx, cy, mbf, mb, scale_factors, lev
 
 
 def stream_arg(stream):
-    """ABI `void* stream` argument.  None = the handle's own (non-blocking) HIP stream: inputs that torch is still
-    producing on ITS current stream (e.g. the DMA of a fresh `.cuda()` upload) would race with it, so the torch
-    stream is drained first.  Pass a raw stream handle (`torch.cuda.Stream.cuda_stream`) to stay asynchronous."""
+    """ABI `void* stream` argument.  None = the handle's own HIP stream.  That stream is a blocking stream, i.e. ordered
+    with the legacy default stream, but torch may be producing the inputs on a non-default current stream (e.g. the DMA
+    of a fresh `.cuda()` upload inside a `torch.cuda.stream(...)` block), so the torch stream is drained first.  Pass a
+    raw stream handle (`torch.cuda.Stream.cuda_stream`) to stay asynchronous."""
     if stream is None:
         import torch
         if torch.cuda.is_available():

@@ -1327,7 +1327,8 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   MORB_REQUIRE(nimg > 0, MORB_ERR_INVALID, "nimg must be positive");
   if (width <= 0 || height <= 0) { set_error("empty image"); return MORB_ERR_EMPTY; }
   MORB_REQUIRE(stride >= width && image_pitch >= (size_t)stride * height, MORB_ERR_INVALID, "bad stride/pitch");
-  MORB_REQUIRE(cap > 0, MORB_ERR_CAPACITY, "cap must be positive");
+  // k_layout places the lapping-area keypoints from the back of [0, count): a smaller cap would cut the wrong end
+  MORB_REQUIRE(cap >= morb_extractor_max_keypoints(e), MORB_ERR_CAPACITY, "cap must be at least morb_extractor_max_keypoints()");
   MORB_HIP_CHECK(hipSetDevice(e->device));
   int rc = configure(e, width, height, nimg);
   if (rc != MORB_OK) return rc;
@@ -1431,9 +1432,10 @@ int morb_extract(morb_extractor* e, const uint8_t* image, int width, int height,
   MORB_HIP_CHECK(hipStreamSynchronize(e->stream));
   *n = cnt;
   MORB_REQUIRE(cnt <= cap, MORB_ERR_CAPACITY, "keypoint buffer too small");
-  if (cnt) {
-    MORB_HIP_CHECK(hipMemcpy(kps, e->d_kps1, sizeof(morb_keypoint) * cnt, hipMemcpyDeviceToHost));
-    MORB_HIP_CHECK(hipMemcpy(desc, e->d_desc1, 32 * (size_t)cnt, hipMemcpyDeviceToHost));
+  if (cnt) {   // on the handle's own stream: a copy on the null stream would wait for every other handle's blocking stream too
+    MORB_HIP_CHECK(hipMemcpyAsync(kps, e->d_kps1, sizeof(morb_keypoint) * cnt, hipMemcpyDeviceToHost, e->stream));
+    MORB_HIP_CHECK(hipMemcpyAsync(desc, e->d_desc1, 32 * (size_t)cnt, hipMemcpyDeviceToHost, e->stream));
+    MORB_HIP_CHECK(hipStreamSynchronize(e->stream));
   }
   return mono;
 }

@@ -588,7 +588,7 @@ __global__ __launch_bounds__(BA_T) void k_local_ba(const BaDev* __restrict__ pro
   auto terminate = [&]() -> bool {
     if (!pb.stop) return false;
     __syncthreads();
-    if (tid == 0) sFlag = *((volatile const int*)pb.stop);
+    if (tid == 0) sFlag = __hip_atomic_load(pb.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-written, pinned
     __syncthreads();
     return sFlag != 0;
   };
@@ -1349,11 +1349,11 @@ struct morb_ba_problem {
   BaDev* d_desc = nullptr;
   std::vector<void*> allocs;
   float *d_pose0 = nullptr, *d_pt0 = nullptr;
-  int* d_stop = nullptr;
+  int* h_stop = nullptr;   // abort flag in pinned, device-mapped host memory: morb_ba_set_stop writes it without any HIP call, kernels poll it
+  const volatile unsigned char* userStop = nullptr;   // the caller's *pbStopFlag (one-shot entry points), polled by the host LM loop
   int useLds = 1;
   size_t ldsBytes = 0;
   int mode = 0;            // 0 = grid (one launch per LM phase, host-side accept/reject), 1 = one persistent workgroup
-  int stopHost = 0;
   int redBlocks = 0;
   double* h_scal = nullptr;  // pinned host mirror of scal[0..3]
   double* d_ldws = nullptr;  // [P][LB] panel scratch of the LDL^T when the reduced system does not fit LDS
@@ -1568,15 +1568,14 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
   h.ptIO = (float*)up(nullptr, sizeof(float) * 3 * nMP);
   h.erase = (uint8_t*)up(nullptr, nE);
   h.stats = (int*)up(nullptr, sizeof(int) * 2);
-  p->d_stop = (int*)up(nullptr, sizeof(int));
-  h.stop = p->d_stop;
+  if (hipHostMalloc(&p->h_stop, sizeof(int), hipHostMallocMapped) != hipSuccess) { p->h_stop = nullptr; fail = true; }
+  else { *p->h_stop = 0; int* dv = nullptr; if (hipHostGetDevicePointer((void**)&dv, p->h_stop, 0) != hipSuccess) fail = true; h.stop = dv; }
   h.cam = Cam{fx, fy, cx, cy, bf};
   h.rig = nullptr;
   h.userLambda = lambdaInit100 ? 100.0 : 0.0;
   p->d_pose0 = (float*)up(kfPose, sizeof(float) * 7 * nKF);
   p->d_pt0 = (float*)up(mpPos, sizeof(float) * 3 * nMP);
   p->d_desc = (BaDev*)up(&h, sizeof(BaDev));
-  if (!fail && hipMemset(p->d_stop, 0, sizeof(int)) != hipSuccess) fail = true;
   if (!fail && hipHostMalloc(&p->h_scal, sizeof(double) * 8) != hipSuccess) fail = true;
   p->ldsBytes = sizeof(double) * (size_t)h.P * (h.P + 1);
   p->useLds = (p->ldsBytes <= 136 * 1024 && h.P <= 192) ? 1 : 0;
@@ -1587,6 +1586,7 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
     fail = true;
   if (fail) {
     for (void* d : p->allocs) (void)hipFree(d);
+    if (p->h_stop) (void)hipHostFree(p->h_stop);
     delete p;
     set_error("device allocation/copy failed while creating the BA problem");
     return MORB_ERR_HIP;
@@ -1601,6 +1601,7 @@ void morb_ba_problem_destroy(morb_ba_problem* p) {
   (void)hipStreamSynchronize(p->opt->stream);
   for (void* d : p->allocs) (void)hipFree(d);
   if (p->h_scal) (void)hipHostFree(p->h_scal);
+  if (p->h_stop) (void)hipHostFree(p->h_stop);
   delete p;
 }
 
@@ -1656,9 +1657,9 @@ int morb_ba_set_mode(morb_ba_problem* p, int mode) {
 
 int morb_ba_set_stop(morb_ba_problem* p, int stop) {
   MORB_REQUIRE(p, MORB_ERR_INVALID, "NULL problem");
-  MORB_HIP_CHECK(hipSetDevice(p->opt->device));
-  MORB_HIP_CHECK(hipMemcpy(p->d_stop, &stop, sizeof(int), hipMemcpyHostToDevice));
-  p->stopHost = stop;
+  // No HIP call: the flag lives in pinned host memory that the device maps, so it lands while a solve is running on any
+  // stream (a copy on the null stream would wait for the very kernels it is meant to stop) and from any thread.
+  __atomic_store_n(p->h_stop, stop ? 1 : 0, __ATOMIC_RELEASE);
   return MORB_OK;
 }
 
@@ -1690,7 +1691,8 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
     hipLaunchKernelGGL(k_g_reduce, dim3(1), dim3(GB), 0, st, (const double*)part0, rb, h.scal + 0);
   };
   int its = 0, trials = 0;
-  if (!p->stopHost) {
+  auto stopped = [&]() -> bool { return __atomic_load_n(p->h_stop, __ATOMIC_ACQUIRE) != 0 || (p->userStop && *p->userStop); };
+  if (!stopped()) {
     chi2();
     int rc = readScal();
     if (rc != MORB_OK) return rc;
@@ -1709,7 +1711,7 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
       return MORB_OK;
     };
     bool built = false;   // the next iteration's system is already being built (speculatively, see below)
-    for (int iter = 0; iter < 10 && !p->stopHost; ++iter) {
+    for (int iter = 0; iter < 10 && !stopped(); ++iter) {
       ++its;
       const double iniChi = currentChi;
       if (!built) { rc = launchBuilds(); if (rc != MORB_OK) return rc; }
@@ -1761,7 +1763,7 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
           if (spec) { rc = launchBuilds(); if (rc != MORB_OK) return rc; }
         }
         ++qmax; ++trials;
-      } while (rho < 0 && qmax < 10 && !p->stopHost);
+      } while (rho < 0 && qmax < 10 && !stopped());
       if (qmax == 10 || rho == 0) break;
       if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
       if (nBad >= 3) break;
@@ -1775,24 +1777,28 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
 int morb_ba_results(morb_ba_problem* p, float* kfPose, float* mpPos, uint8_t* eraseFlag, int* stats2) {
   MORB_REQUIRE(p, MORB_ERR_INVALID, "NULL problem");
   MORB_HIP_CHECK(hipSetDevice(p->opt->device));
-  MORB_HIP_CHECK(hipStreamSynchronize(p->opt->stream));
+  // the solve may have run on a caller's stream: wait for the device once, then copy on the handle's own stream (a copy on
+  // the null stream would also wait for, and hold up, every other handle's blocking stream)
   MORB_HIP_CHECK(hipDeviceSynchronize());
-  if (kfPose) MORB_HIP_CHECK(hipMemcpy(kfPose, p->h.poseIO, sizeof(float) * 7 * p->h.nKF, hipMemcpyDeviceToHost));
-  if (mpPos) MORB_HIP_CHECK(hipMemcpy(mpPos, p->h.ptIO, sizeof(float) * 3 * p->h.nMP, hipMemcpyDeviceToHost));
-  if (eraseFlag) MORB_HIP_CHECK(hipMemcpy(eraseFlag, p->h.erase, p->h.nE, hipMemcpyDeviceToHost));
-  if (stats2) MORB_HIP_CHECK(hipMemcpy(stats2, p->h.stats, sizeof(int) * 2, hipMemcpyDeviceToHost));
+  hipStream_t st = p->opt->stream;
+  if (kfPose) MORB_HIP_CHECK(hipMemcpyAsync(kfPose, p->h.poseIO, sizeof(float) * 7 * p->h.nKF, hipMemcpyDeviceToHost, st));
+  if (mpPos) MORB_HIP_CHECK(hipMemcpyAsync(mpPos, p->h.ptIO, sizeof(float) * 3 * p->h.nMP, hipMemcpyDeviceToHost, st));
+  if (eraseFlag) MORB_HIP_CHECK(hipMemcpyAsync(eraseFlag, p->h.erase, p->h.nE, hipMemcpyDeviceToHost, st));
+  if (stats2) MORB_HIP_CHECK(hipMemcpyAsync(stats2, p->h.stats, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+  MORB_HIP_CHECK(hipStreamSynchronize(st));
   return MORB_OK;
 }
 
 int morb_local_bundle_adjustment(morb_optimizer* o, int nKF, float* kfPose, const uint8_t* kfFixed, int nMP, float* mpPos,
                                  int nE, const int* eKF, const int* eMP, const float* eObs, const float* eInvSigma2,
                                  float fx, float fy, float cx, float cy, float bf, int lambdaInit100,
-                                 const int* stopFlag, uint8_t* eraseFlag, int* stats2) {
-  if (stopFlag && *stopFlag) { if (stats2) stats2[0] = stats2[1] = 0; return MORB_OK; }  // :1355-1356
+                                 const unsigned char* stopFlag, uint8_t* eraseFlag, int* stats2) {
+  if (stopFlag && *(const volatile unsigned char*)stopFlag) { if (stats2) stats2[0] = stats2[1] = 0; return MORB_OK; }  // :1355-1356
   morb_ba_problem* p = nullptr;
   int rc = morb_ba_problem_create(o, &p, nKF, kfPose, kfFixed, nMP, mpPos, nE, eKF, eMP, eObs, eInvSigma2, fx, fy, cx, cy, bf,
                                   lambdaInit100);
   if (rc != MORB_OK) return rc;
+  p->userStop = stopFlag;   // optimizer.setForceStopFlag(pbStopFlag) (:1142): the LM loop polls the caller's flag at every iteration and trial
   rc = morb_ba_solve(p, nullptr);
   if (rc == MORB_OK) rc = morb_ba_results(p, kfPose, mpPos, eraseFlag, stats2);
   morb_ba_problem_destroy(p);
@@ -1802,12 +1808,13 @@ int morb_local_bundle_adjustment(morb_optimizer* o, int nKF, float* kfPose, cons
 int morb_local_bundle_adjustment_fisheye(morb_optimizer* o, int nKF, float* kfPose, const uint8_t* kfFixed, int nMP, float* mpPos,
                                          int nE, const int* eKF, const int* eMP, const float* eObs2, const uint8_t* eRight,
                                          const float* eInvSigma2, const float* camL8, const float* camR8, const float* Trl7,
-                                         int lambdaInit100, const int* stopFlag, uint8_t* eraseFlag, int* stats2) {
-  if (stopFlag && *stopFlag) { if (stats2) stats2[0] = stats2[1] = 0; return MORB_OK; }  // :1355-1356
+                                         int lambdaInit100, const unsigned char* stopFlag, uint8_t* eraseFlag, int* stats2) {
+  if (stopFlag && *(const volatile unsigned char*)stopFlag) { if (stats2) stats2[0] = stats2[1] = 0; return MORB_OK; }  // :1355-1356
   morb_ba_problem* p = nullptr;
   int rc = morb_ba_problem_create_fisheye(o, &p, nKF, kfPose, kfFixed, nMP, mpPos, nE, eKF, eMP, eObs2, eRight, eInvSigma2, camL8,
                                           camR8, Trl7, lambdaInit100);
   if (rc != MORB_OK) return rc;
+  p->userStop = stopFlag;   // optimizer.setForceStopFlag(pbStopFlag) (:1142): the LM loop polls the caller's flag at every iteration and trial
   rc = morb_ba_solve(p, nullptr);
   if (rc == MORB_OK) rc = morb_ba_results(p, kfPose, mpPos, eraseFlag, stats2);
   morb_ba_problem_destroy(p);

@@ -172,6 +172,24 @@ class Optimizer:
         return p.results()
 
 
+def local_bundle_adjustment_oneshot(opt, kfPose, kfFixed, mpPos, eKF, eMP, eObs, eInvSigma2, cam, inertial=False, stop_flag=None):
+    """The one-shot ABI entry (`morb_local_bundle_adjustment`), as the reference binding calls it: `stop_flag` is a one-byte
+    numpy array standing for `bool* pbStopFlag` (another thread may set it while the call runs)."""
+    L = lib()
+    a = [np.ascontiguousarray(kfPose, np.float32).copy(), np.ascontiguousarray(kfFixed, np.uint8),
+         np.ascontiguousarray(mpPos, np.float32).copy(), np.ascontiguousarray(eKF, np.int32), np.ascontiguousarray(eMP, np.int32),
+         np.ascontiguousarray(eObs, np.float32), np.ascontiguousarray(eInvSigma2, np.float32)]
+    erase = np.zeros(len(a[3]), np.uint8); stats = np.zeros(2, np.int32)
+    L.morb_local_bundle_adjustment.restype = C.c_int
+    L.morb_local_bundle_adjustment.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+                                               C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    check(L.morb_local_bundle_adjustment(opt._h, len(a[0]), ptr(a[0]), ptr(a[1]), len(a[2]), ptr(a[2]), len(a[3]), ptr(a[3]), ptr(a[4]),
+                                         ptr(a[5]), ptr(a[6]), cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["bf"],
+                                         1 if inertial else 0, ptr(stop_flag) if stop_flag is not None else None, ptr(erase), ptr(stats)))
+    return a[0], a[2], erase, stats
+
+
 class BAProblem:
     """A LocalBundleAdjustment graph resident in HBM (create once, solve repeatedly).
     rig = dict(eRight uint8 [nE], camL, camR (8 floats each), Trl (7 floats)) selects the KannalaBrandt8 stereo rig

@@ -148,3 +148,18 @@ def test_two_extractors_on_two_threads():
         mo, ko, do = OracleExtractor(1200)(img)
         mg, kg, dg = res[name]
         assert mg == mo and kg.tobytes() == ko.tobytes() and np.array_equal(dg, do)
+
+
+def test_batch_capacity_is_checked():
+    # k_layout fills the lapping-area keypoints from the back of [0, count): a caller's cap below the extractor's maximum
+    # must be refused, not silently produce a cut block
+    import torch
+    from morb_slam_amd import ORBextractor
+    from morb_slam_amd.capi import MorbError, lib, ptr
+    g = ORBextractor(500, 1.2, 8, 20, 7)
+    img = torch.from_numpy(make_image(640, 480, seed=2)[None]).cuda()
+    cap = g.max_keypoints - 1
+    kps = torch.empty((1, cap, 28), dtype=torch.uint8, device="cuda"); desc = torch.empty((1, cap, 32), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda"); mono = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rc = lib().morb_extract_batch(g._h, ptr(img), 1, 640, 480, 640, 640 * 480, None, ptr(kps), ptr(desc), cap, ptr(cnt), ptr(mono), None)
+    assert rc == -3, rc   # MORB_ERR_CAPACITY

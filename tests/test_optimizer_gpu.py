@@ -82,3 +82,53 @@ def test_local_ba_stop_flag():
                                                                  b["eInvSigma2"], b["cam"], stop=True, mode=mode)
         assert stats.tolist() == [0, 0]                       # *pbStopFlag set: graph is not optimised (:1355)
         np.testing.assert_array_equal(kf, b["kfPose"])
+
+
+def test_local_ba_abort_from_another_thread_while_solving():
+    # LocalMapping::InterruptBA arrives on the tracking thread while LocalBundleAdjustment runs (LocalMapping.cc:884,
+    # Optimizer.cc:1142): the persistent-workgroup solve (25 ms for the C5 graph) must stop early, on the handle's own stream
+    import threading, time
+    from morb_slam_amd import Optimizer
+    from morb_slam_amd.optimizer import BAProblem
+    b = make_ba_problem(seed=3, n_free=20, n_fixed=6, n_points=3000, mono_frac=0.5)
+    opt = Optimizer()
+    p = BAProblem(opt, b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"], b["eInvSigma2"], b["cam"])
+    p.set_mode(1)
+    p.solve(); full = p.results()[3].copy()        # undisturbed: the full schedule
+    assert full[0] >= 3
+    p.set_stop(False)
+    t = threading.Thread(target=lambda: (time.sleep(0.003), p.set_stop(True)))
+    t0 = time.perf_counter()
+    p.solve(); t.start()
+    kf, mp, erase, stats = p.results()
+    dt = time.perf_counter() - t0
+    t.join()
+    assert stats[0] < full[0], (stats, full)       # fewer outer iterations than the undisturbed solve
+    assert np.isfinite(kf).all() and np.isfinite(mp).all()
+    p.set_stop(False)
+    p.solve()
+    assert p.results()[3].tolist() == full.tolist()  # the flag is a level, not sticky state
+
+
+def test_local_ba_oneshot_polls_the_callers_flag():
+    # the reference binding passes pbStopFlag itself (a one-byte bool): set at entry -> nothing optimised; set by another
+    # thread during the grid-mode solve -> the host LM loop stops at the next iteration / trial
+    import threading, time
+    from morb_slam_amd import Optimizer
+    from morb_slam_amd.optimizer import local_bundle_adjustment_oneshot
+    b = make_ba_problem(seed=3, n_free=20, n_fixed=6, n_points=3000, mono_frac=0.5)
+    opt = Optimizer()
+    args = (b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"], b["eInvSigma2"], b["cam"])
+    flag = np.zeros(4, np.uint8); flag[1:] = 255                 # neighbours of the bool must not be read as part of it
+    full = local_bundle_adjustment_oneshot(opt, *args, stop_flag=flag[:1])[3]
+    assert full[0] >= 3
+    flag[0] = 1
+    kf, mp, erase, stats = local_bundle_adjustment_oneshot(opt, *args, stop_flag=flag[:1])
+    assert stats.tolist() == [0, 0]
+    np.testing.assert_array_equal(kf, b["kfPose"])
+    flag[0] = 0
+    t = threading.Thread(target=lambda: (time.sleep(0.0015), flag.__setitem__(0, 1)))
+    t.start()
+    stats = local_bundle_adjustment_oneshot(opt, *args, stop_flag=flag[:1])[3]
+    t.join()
+    assert stats[1] <= full[1]
