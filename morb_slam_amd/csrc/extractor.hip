@@ -100,12 +100,17 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
                                                 const ResizeTab* __restrict__ xtab,
                                                 const ResizeTab* __restrict__ ytab) {
   const int px = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-  const int py0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * PY_ROWS;
+  // the wave's eight rows are wave-uniform: their table entries are scalar loads, fetched before any pixel
+  const int py0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * PY_ROWS;
   const int img = blockIdx.z;
-  if (px >= gd.pstride) return;
+  const int H = gd.h + 2 * EDGE;
+  if (px >= gd.pstride || py0 >= H) return;
   ResizeTab tx[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) tx[k] = xtab[(px + k) < gd.w + 2 * EDGE ? (px + k) : gd.w + 2 * EDGE - 1];
+  ResizeTab ty[PY_ROWS];
+#pragma unroll
+  for (int r = 0; r < PY_ROWS; ++r) ty[r] = ytab[py0 + r < H ? py0 + r : H - 1];
   // The four outputs read source columns within a span of a few bytes — s0(px) .. s0(px+3)+1 in the interior, the
   // mirrored equivalent in the reflected pad — so two (unaligned) dword loads per source row starting at the
   // smallest column feed all four; one code path for interior and pad keeps the edge waves from running both.
@@ -122,37 +127,49 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
   for (int k = 0; k < 4; ++k) { selL |= (uint32_t)(tx[k].s0 - base) << (8 * k); selR |= (uint32_t)(tx[k].s1 - base) << (8 * k); }
   const uint8_t* sbase = pyr + gs.pyrOff + (size_t)img * gs.pyrImg + (size_t)EDGE * gs.pstride + EDGE;
   uint8_t* dbase = pyr + gd.pyrOff + (size_t)img * gd.pyrImg + px;
-  for (int r = 0; r < PY_ROWS; ++r) {
-    const int py = py0 + r;
-    if (py >= gd.h + 2 * EDGE) break;
-    const ResizeTab ty = ytab[py];
-    const uint8_t* r0 = sbase + (size_t)ty.s0 * gs.pstride;
-    const uint8_t* r1 = sbase + (size_t)ty.s1 * gs.pstride;
-    uint32_t v = 0;
-    if (packed) {
+  if (__builtin_expect(__ballot(!packed) == 0, 1)) {
+    // every source dword of the wave's eight rows is requested before the first one is used: one memory round trip per
+    // wave instead of one per row (PMC r01: the kernel waited 66 % of its wave-cycles)
+    uint32_t a0[PY_ROWS], a1[PY_ROWS], b0[PY_ROWS], b1[PY_ROWS];
+#pragma unroll
+    for (int r = 0; r < PY_ROWS; ++r) {
+      const uint8_t* r0 = sbase + (unsigned)(__umul24(ty[r].s0, gs.pstride) + base);
+      const uint8_t* r1 = sbase + (unsigned)(__umul24(ty[r].s1, gs.pstride) + base);
+      a0[r] = load_u32_unaligned(r0); a1[r] = load_u32_unaligned(r0 + 4);
+      b0[r] = load_u32_unaligned(r1); b1[r] = load_u32_unaligned(r1 + 4);
+    }
+#pragma unroll
+    for (int r = 0; r < PY_ROWS; ++r) {
+      if (py0 + r >= H) break;   // wave-uniform
       // one v_perm_b32 gathers the four outputs' left (right) samples of a source row
-      const uint32_t a0 = load_u32_unaligned(r0 + base), a1 = load_u32_unaligned(r0 + base + 4);
-      const uint32_t b0 = load_u32_unaligned(r1 + base), b1 = load_u32_unaligned(r1 + base + 4);
-      const uint32_t aL = __builtin_amdgcn_perm(a1, a0, selL), aR = __builtin_amdgcn_perm(a1, a0, selR);
-      const uint32_t bL = __builtin_amdgcn_perm(b1, b0, selL), bR = __builtin_amdgcn_perm(b1, b0, selR);
+      const uint32_t aL = __builtin_amdgcn_perm(a1[r], a0[r], selL), aR = __builtin_amdgcn_perm(a1[r], a0[r], selR);
+      const uint32_t bL = __builtin_amdgcn_perm(b1[r], b0[r], selL), bR = __builtin_amdgcn_perm(b1[r], b0[r], selR);
+      uint32_t v = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int h0 = (int)((aL >> (8 * k)) & 0xFF) * tx[k].c0 + (int)((aR >> (8 * k)) & 0xFF) * tx[k].c1;
         const int h1 = (int)((bL >> (8 * k)) & 0xFF) * tx[k].c0 + (int)((bR >> (8 * k)) & 0xFF) * tx[k].c1;
-        const int o = ((((int)ty.c0 * (h0 >> 4)) >> 16) + (((int)ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        const int o = ((((int)ty[r].c0 * (h0 >> 4)) >> 16) + (((int)ty[r].c1 * (h1 >> 4)) >> 16) + 2) >> 2;
         v |= (uint32_t)(o & 0xFF) << (8 * k);
       }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int h0 = r0[tx[k].s0] * tx[k].c0 + r0[tx[k].s1] * tx[k].c1;
-        const int h1 = r1[tx[k].s0] * tx[k].c0 + r1[tx[k].s1] * tx[k].c1;
-        const int o = ((((int)ty.c0 * (h0 >> 4)) >> 16) + (((int)ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        v |= (uint32_t)(o & 0xFF) << (8 * k);
-      }
+      // columns >= w + 2 * EDGE repeat the last table entry and land in the row's alignment slack
+      *reinterpret_cast<uint32_t*>(dbase + (size_t)(py0 + r) * gd.pstride) = v;
     }
-    // columns >= w + 2 * EDGE repeat the last table entry and land in the row's alignment slack
-    *reinterpret_cast<uint32_t*>(dbase + (size_t)py * gd.pstride) = v;
+    return;
+  }
+  for (int r = 0; r < PY_ROWS; ++r) {
+    if (py0 + r >= H) break;
+    const uint8_t* r0 = sbase + (size_t)ty[r].s0 * gs.pstride;
+    const uint8_t* r1 = sbase + (size_t)ty[r].s1 * gs.pstride;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int h0 = r0[tx[k].s0] * tx[k].c0 + r0[tx[k].s1] * tx[k].c1;
+      const int h1 = r1[tx[k].s0] * tx[k].c0 + r1[tx[k].s1] * tx[k].c1;
+      const int o = ((((int)ty[r].c0 * (h0 >> 4)) >> 16) + (((int)ty[r].c1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      v |= (uint32_t)(o & 0xFF) << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(dbase + (size_t)(py0 + r) * gd.pstride) = v;
   }
 }
 
@@ -911,7 +928,7 @@ __global__ __launch_bounds__(256) void k_describe(const morb::DescGeom dg, const
     for (int j = 0; j < 4; ++j) {
       const int t = lane + 64 * j;              // row = t / 8, dword = t % 8
       const int tt = t < 248 ? t : 247;
-      wv[kk][j] = load_u32_unaligned(ctr[kk] + (uint32_t)((tt >> 3) * pstride[kk] + (tt & 7) * 4));
+      wv[kk][j] = load_u32_unaligned(ctr[kk] + (uint32_t)(__umul24(tt >> 3, pstride[kk]) + (tt & 7) * 4));
     }
   // The circular mask and the column weights of a lane's four dwords do not depend on the keypoint: byte masks and the
   // biased weights (u + 15, so that v_dot4_u32_u8 applies) are built once, and per keypoint a dword costs one AND, two
@@ -1362,10 +1379,21 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   }
   mark(1);
   {
+    // the second group (few, large cells) runs beside the first on the side stream
+    const bool two = e->fastSegs[1] > 0 && e->overlapBlur;
+    if (two) {
+      MORB_HIP_CHECK(hipEventRecord(e->evFork, st));
+      MORB_HIP_CHECK(hipStreamWaitEvent(e->sideStream, e->evFork, 0));
+    }
     for (int k = 0, s0 = 0; k < 2; s0 += e->fastSegs[k], ++k)
       if (e->fastSegs[k])
-        hipLaunchKernelGGL(k_fast, dim3(e->fastSegs[k], nimg), dim3(FS_NT), e->fastSmem[k], st, e->fastGeom, e->d_segTab + s0, e->d_pyr,
-                           e->d_cand, e->d_candCnt, e->totalCells, e->cellCap, e->fastRows[k], e->iniTh, e->minTh, e->fastStop);
+        hipLaunchKernelGGL(k_fast, dim3(e->fastSegs[k], nimg), dim3(FS_NT), e->fastSmem[k], (k == 1 && two) ? e->sideStream : st, e->fastGeom,
+                           e->d_segTab + s0, e->d_pyr, e->d_cand, e->d_candCnt, e->totalCells, e->cellCap, e->fastRows[k], e->iniTh,
+                           e->minTh, e->fastStop);
+    if (two) {
+      MORB_HIP_CHECK(hipEventRecord(e->evJoin, e->sideStream));
+      MORB_HIP_CHECK(hipStreamWaitEvent(st, e->evJoin, 0));
+    }
   }
   mark(2);
   // The blur only feeds the descriptors and is VALU-bound; the quadtree is one latency-bound wave per (level, image)
