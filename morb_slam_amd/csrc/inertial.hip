@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "kb8.h"
+#include "schur_mfma.h"
 #include "wave.h"
 
 using namespace morb;
@@ -1088,6 +1089,12 @@ struct IbaDev {
   double *InfoI, *InfoG, *InfoA;
   double *H, *b, *Hll, *Hpl, *Hs, *bs, *x;      // b, x: P + 3 nMP
   double* scal;                                 // [0] robust chi2, [1] scale, [2] solve ok
+  // Schur complement on the FP64 matrix cores (schur_mfma.h): dense K-major operands (columns 6 c + r of the pose parts, plus
+  // the right-hand-side column 6 nOpt), partial products, block directory
+  double *sW, *sWD, *sPart;
+  const int2* sBlocks;
+  const int* sBlkIndex;
+  int sMp, sNb, sNblk, sNsplit;
   CamGeom g;
 };
 __device__ __forceinline__ void iba_load(const CamGeom& g, const double* s, VIState& V) {
@@ -1381,6 +1388,67 @@ __global__ __launch_bounds__(256) void k_iba_hs_init(IbaDev D, double lambda) {
   const int n = D.P * D.P;
   if (t < n) { const int r = t / D.P, c = t - r * D.P; D.Hs[t] = D.H[t] + (r == c ? lambda : 0.0); }
   else if (t - n < D.P) D.bs[t - n] = D.b[t - n];
+}
+// MFMA operands of the Schur complement (schur_mfma.h).  W: Hpl of every observation of an optimizable keyframe and b_l in the extra
+// column (once per outer iteration, after buildSystem); WD = Hpl (Hll + lambda I)^-1 (every trial).
+// Hpl of (keyframe column c1, point m) as the MFMA operands need it: on a fisheye rig a keyframe may observe a point with both
+// cameras, i.e. through two edges — the first of them (lowest edge index) carries the sum, the others nothing.
+__device__ __forceinline__ bool iba_pair_block(const IbaDev& D, int e, int c1, int m, double* __restrict__ B) {
+  for (int q = 0; q < 18; ++q) B[q] = D.Hpl[(size_t)e * 18 + q];
+  for (int k = D.ptStart[m]; k < D.ptStart[m + 1]; ++k) {
+    const int e2 = D.ptEdges[k];
+    if (e2 == e || D.col[D.eKF[e2]] != c1) continue;
+    if (e2 < e) return false;
+    for (int q = 0; q < 18; ++q) B[q] += D.Hpl[(size_t)e2 * 18 + q];
+  }
+  return true;
+}
+__global__ __launch_bounds__(256) void k_iba_pack_w(IbaDev D) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int M = 6 * (D.P / 15);
+  if (t < D.nE) {
+    const int c1 = D.col[D.eKF[t]];
+    const int m = D.eMP[t];
+    double B1[18];
+    if (c1 >= 0 && iba_pair_block(D, t, c1, m, B1)) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) D.sW[(size_t)(3 * m + c) * D.sMp + 6 * c1 + r] = B1[r * 3 + c];
+    }
+  }
+  if (t < 3 * D.nMP) D.sW[(size_t)t * D.sMp + M] = D.b[D.P + t];
+}
+__global__ __launch_bounds__(256) void k_iba_pack_wd(IbaDev D, double lambda) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= D.nE) return;
+  const int c1 = D.col[D.eKF[t]];
+  if (c1 < 0) return;
+  const int m = D.eMP[t];
+  double B1[18];
+  if (!iba_pair_block(D, t, c1, m, B1)) return;
+  double Dm[9], Di[9];
+  for (int k = 0; k < 9; ++k) Dm[k] = D.Hll[(size_t)m * 9 + k];
+  Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
+  inv3(Dm, Di);
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      D.sWD[(size_t)(3 * m + c) * D.sMp + 6 * c1 + r] = B1[r * 3] * Di[c] + B1[r * 3 + 1] * Di[3 + c] + B1[r * 3 + 2] * Di[6 + c];
+}
+// Hs(pose rows / columns) -= C, bs(pose rows) -= C[:, M], from the partial products (four lanes per element, fixed order)
+__global__ __launch_bounds__(256) void k_iba_schur_finish(IbaDev D) {
+  const int t = blockIdx.x * 256 + threadIdx.x, gid = t >> 2, q = t & 3;
+  const int M = 6 * (D.P / 15);
+  const bool mat = gid < M * M, rhs = !mat && gid < M * M + M;
+  int r = 0, c = M;
+  if (mat) { r = gid / M; c = gid - r * M; } else if (rhs) r = gid - M * M;
+  const int i = r < c ? r : c, j = r < c ? c : r;
+  const double cs = morbschur::schur_sum4(D.sPart, D.sBlkIndex, D.sNb, D.sNblk, D.sNsplit, (mat || rhs) ? i : 0, (mat || rhs) ? j : 0, q);
+  if (q != 0) return;
+  if (mat) D.Hs[(size_t)(15 * (r / 6) + r % 6) * D.P + 15 * (c / 6) + c % 6] -= cs;
+  else if (rhs) D.bs[15 * (r / 6) + r % 6] -= cs;
 }
 // Schur complement of the points (block_solver.hpp): one thread per point.  The pose blocks of the reduced system receive ~k^2 6 x 6
 // updates per point on a few thousand addresses: with LDSACC the workgroup accumulates them in LDS ((6 N)^2 doubles, LDS atomics)
@@ -1812,6 +1880,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
   // ---- device memory: one arena carved from the handle's grow-only workspace
   const size_t nS = (size_t)33 * nKF, nPts = (size_t)3 * nMP, nX = (size_t)P + 3 * nMP;
   const int nI1 = std::max(nI, 1);
+  const morbschur::Plan splan = morbschur::make_plan(6 * nOpt + 1, 3 * nMP);
   size_t arenaBytes = 0;
   auto reserve = [&](size_t bytes) { arenaBytes += (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255; };
   for (size_t b : {sizeof(int) * (size_t)nE, sizeof(int) * (size_t)nE, sizeof(float) * 3 * (size_t)nE, sizeof(float) * (size_t)nE,
@@ -1824,7 +1893,8 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
                    sizeof(double) * 81 * (size_t)nI1, sizeof(double) * 9 * (size_t)nI1, sizeof(double) * 9 * (size_t)nI1,
                    sizeof(double) * (size_t)P * P, sizeof(double) * (size_t)P * P, sizeof(double) * nX, sizeof(double) * (size_t)P,
                    sizeof(double) * nX, sizeof(double) * 9 * (size_t)nMP, sizeof(double) * 18 * (size_t)nE, sizeof(double) * 4,
-                   (size_t)nE, (size_t)nE})
+                   (size_t)nE, (size_t)nE, sizeof(double) * splan.wElems(), sizeof(double) * splan.wElems(), sizeof(double) * splan.partElems(),
+                   sizeof(int2) * (size_t)splan.nblk, sizeof(int) * (size_t)splan.nb * splan.nb})
     reserve(b);
   void* arena = nullptr;
   { const int rc = morb_optimizer_workspace(o, arenaBytes, &arena); if (rc != MORB_OK) return rc; }
@@ -1867,6 +1937,19 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
   (void)hipMemsetAsync(D.x, 0, sizeof(double) * nX, st);   // the solver's x before the first solve
   make_geom(Tbc12, fx, fy, cx, cy, bf, rig28, D.g);
   D.eRight = eRight ? (const uint8_t*)up(eRight, nE) : nullptr;
+  {
+    std::vector<int2> blocks; std::vector<int> blkIndex((size_t)splan.nb * splan.nb, 0);
+    for (int bi = 0; bi < splan.nb; ++bi) for (int bj = bi; bj < splan.nb; ++bj) { blkIndex[(size_t)bi * splan.nb + bj] = (int)blocks.size(); blocks.push_back(make_int2(bi, bj)); }
+    D.sW = (double*)dalloc(sizeof(double) * splan.wElems()); D.sWD = (double*)dalloc(sizeof(double) * splan.wElems());
+    D.sPart = (double*)dalloc(sizeof(double) * splan.partElems());
+    D.sBlocks = (const int2*)up(blocks.data(), sizeof(int2) * blocks.size()); D.sBlkIndex = (const int*)up(blkIndex.data(), sizeof(int) * blkIndex.size());
+    MORB_REQUIRE(D.sBlkIndex != nullptr && arenaOff <= arenaBytes, MORB_ERR_HIP, "workspace carve-up overflow in morb_local_inertial_ba");
+    if (hipStreamSynchronize(st) != hipSuccess) return MORB_ERR_HIP;   // (blocks / blkIndex are host temporaries)
+    D.sMp = splan.Mp; D.sNb = splan.nb; D.sNblk = splan.nblk; D.sNsplit = splan.nsplit;
+    // the operands' zero pattern is this graph's: the workspace is reused from call to call
+    (void)hipMemsetAsync(D.sW, 0, sizeof(double) * splan.wElems(), st);
+    (void)hipMemsetAsync(D.sWD, 0, sizeof(double) * splan.wElems(), st);
+  }
 
   auto fail = [&](const char* what) { cleanup(); set_error("%s", what); return MORB_ERR_HIP; };
   double h[4];
@@ -1887,6 +1970,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
       return fail("upload failed in morb_local_inertial_ba");
   }
   const int Mpose = 6 * nOpt;
+  static const bool valuSchur = [] { const char* v = getenv("MORB_SCHUR_VALU"); return v && v[0] == '1'; }();
   const size_t schurLds = sizeof(double) * ((size_t)Mpose * Mpose + Mpose);
   const bool ldsSchur = schurLds <= 60 * 1024;   // larger windows accumulate in global memory
   const size_t blockedLds = sizeof(double) * (2 * (size_t)P * IBA_NBP + IBA_NB * IBA_NBP + (size_t)P);
@@ -1911,6 +1995,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
     hipLaunchKernelGGL(k_iba_points, dim3(div_up(nMP, 256)), dim3(256), 0, st, D);
     if (nChunks) hipLaunchKernelGGL(k_iba_kf, dim3(div_up(nChunks, 4)), dim3(256), 0, st, D);
     if (nI) hipLaunchKernelGGL(k_iba_links, dim3(nI), dim3(64), 0, st, D);
+    if (!valuSchur) hipLaunchKernelGGL(k_iba_pack_w, dim3(div_up(std::max(nE, 3 * nMP), 256)), dim3(256), 0, st, D);
     if (it == 0) { ni = 2; nBadIts = 0; }
     double rho = 0;
     int qmax = 0;
@@ -1918,7 +2003,13 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
       (void)hipMemcpyAsync(Sbk, D.S, sizeof(double) * nS, hipMemcpyDeviceToDevice, st);
       (void)hipMemcpyAsync(ptsBk, D.pts, sizeof(double) * nPts, hipMemcpyDeviceToDevice, st);
       hipLaunchKernelGGL(k_iba_hs_init, dim3(div_up(P * P + P, 256)), dim3(256), 0, st, D, lambda);
-      if (ldsSchur) hipLaunchKernelGGL(k_iba_schur<true>, dim3(div_up(nMP, 256)), dim3(256), schurLds, st, D, lambda);
+      if (!valuSchur) {
+        // Schur complement of the points on the FP64 matrix cores: one dense product for matrix and right-hand side
+        hipLaunchKernelGGL(k_iba_pack_wd, dim3(div_up(nE, 256)), dim3(256), 0, st, D, lambda);
+        hipLaunchKernelGGL(morbschur::k_schur_mfma, dim3(splan.nblk, splan.nsplit), dim3(64), 0, st, (const double*)D.sWD, (const double*)D.sW,
+                           splan.Mp, splan.ksteps, splan.stepsPerSplit, D.sBlocks, D.sPart);
+        hipLaunchKernelGGL(k_iba_schur_finish, dim3(div_up(4 * (Mpose * Mpose + Mpose), 256)), dim3(256), 0, st, D);
+      } else if (ldsSchur) hipLaunchKernelGGL(k_iba_schur<true>, dim3(div_up(nMP, 256)), dim3(256), schurLds, st, D, lambda);   // (measurement only, MORB_SCHUR_VALU=1: round 1's form with FP64 atomics)
       else hipLaunchKernelGGL(k_iba_schur<false>, dim3(div_up(nMP, 256)), dim3(256), 0, st, D, lambda);
       hipLaunchKernelGGL(k_iba_solve_blocked, dim3(1), dim3(1024), blockedLds, st, D);
       // a failed solve leaves x as it was (zero at the first trial): g2o still applies the update

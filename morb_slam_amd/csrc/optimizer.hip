@@ -26,6 +26,7 @@
 
 #include "common.h"
 #include "kb8.h"
+#include "schur_mfma.h"
 #include "wave.h"
 
 using namespace morb;
@@ -552,6 +553,11 @@ struct BaDev {
   double *kfPart;                       // [nChunks][27]
   double *redPart;                      // [2][redBlocks] block partial sums (chi2, scale)
   double *scal;                         // [8] device scalars: chi2, scale, ok, maxdiag
+  // Schur complement on the FP64 matrix cores (schur_mfma.h): dense K-major operands, partial products, block directory
+  double *sW, *sWD, *sPart;
+  const int2* sBlocks;
+  const int* sBlkIndex;
+  int sMp, sNb, sNblk, sNsplit;
 };
 
 __device__ __forceinline__ SE3 load_se3(const double* p) {
@@ -1047,18 +1053,84 @@ __global__ __launch_bounds__(GB) void k_g_maxdiag(const BaDev* __restrict__ pbp)
   __syncthreads();
   if (threadIdx.x == 0) pb.scal[3] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
-__global__ __launch_bounds__(GB) void k_g_dinv_push(const BaDev* __restrict__ pbp, double lambda, double* __restrict__ Hs) {
+// Hpl of (keyframe column i, landmark m) as the MFMA operands need it: a fisheye rig may observe a landmark with both cameras
+// of one keyframe, i.e. through two edges — the first of them (lowest edge index) carries the sum, the others nothing.
+__device__ __forceinline__ bool pair_block(const BaDev& pb, int e, int i, int m, double* __restrict__ B) {
+  for (int q = 0; q < 18; ++q) B[q] = pb.Hpl[(size_t)e * 18 + q];
+  for (int k = pb.mpStart[m]; k < pb.mpStart[m + 1]; ++k) {
+    const int e2 = pb.mpEdges[k];
+    if (e2 == e || pb.kfCol[pb.eKF[e2]] != i) continue;
+    if (e2 < e) return false;
+    for (int q = 0; q < 18; ++q) B[q] += pb.Hpl[(size_t)e2 * 18 + q];
+  }
+  return true;
+}
+__global__ __launch_bounds__(GB) void k_g_dinv_push(const BaDev* __restrict__ pbp, double lambda, double* __restrict__ Hs, int valuSchur) {
   const BaDev pb = *pbp;
   const int gid = blockIdx.x * GB + threadIdx.x;
   if (gid < pb.nKF * 7) pb.poseBk[gid] = pb.pose[gid];
   if (gid < pb.nMP * 3) pb.ptBk[gid] = pb.pt[gid];
-  if (gid < pb.P * pb.P) Hs[gid] = 0;
+  if (valuSchur && gid < pb.P * pb.P) Hs[gid] = 0;
   if (gid < pb.nMP) {
     double D[9], Di[9];
     for (int k = 0; k < 9; ++k) D[k] = pb.Hll[(size_t)gid * 9 + k];
     D[0] += lambda; D[4] += lambda; D[8] += lambda;
     inv3(D, Di);
     for (int k = 0; k < 9; ++k) pb.Dinv[(size_t)gid * 9 + k] = Di[k];
+  }
+  if (!valuSchur && gid < pb.nE) {
+    // the MFMA operand WD = Hpl (Hll + lambda I)^-1 of this observation (rows 3 m + c, columns 6 i + r); the inverse is
+    // recomputed per observation so that the pack needs no second launch behind the per-point loop above
+    const int i = pb.kfCol[pb.eKF[gid]];
+    const int m = pb.eMP[gid];
+    double B1[18];
+    if (i >= 0 && pair_block(pb, gid, i, m, B1)) {
+      double D[9], Di[9];
+      for (int k = 0; k < 9; ++k) D[k] = pb.Hll[(size_t)m * 9 + k];
+      D[0] += lambda; D[4] += lambda; D[8] += lambda;
+      inv3(D, Di);
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          pb.sWD[(size_t)(3 * m + c) * pb.sMp + 6 * i + r] = B1[r * 3] * Di[c] + B1[r * 3 + 1] * Di[3 + c] + B1[r * 3 + 2] * Di[6 + c];
+    }
+  }
+}
+// the MFMA operand W (once per outer iteration, after the builds): Hpl of every observation, and b_l in the extra column P
+__global__ __launch_bounds__(GB) void k_g_pack_w(const BaDev* __restrict__ pbp) {
+  const BaDev pb = *pbp;
+  const int gid = blockIdx.x * GB + threadIdx.x;
+  if (gid < pb.nE) {
+    const int i = pb.kfCol[pb.eKF[gid]];
+    const int m = pb.eMP[gid];
+    double B1[18];
+    if (i >= 0 && pair_block(pb, gid, i, m, B1)) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pb.sW[(size_t)(3 * m + c) * pb.sMp + 6 * i + r] = B1[r * 3 + c];
+    }
+  }
+  if (gid < pb.nMP * 3) pb.sW[(size_t)gid * pb.sMp + pb.P] = pb.b[pb.P + gid];
+}
+// reduced system from the partial products: Hs = Hpp + lambda I - C (C symmetric: the upper blocks serve both triangles),
+// x[0:P] = b_p - C[:, P]
+__global__ __launch_bounds__(GB) void k_g_schur_finish(const BaDev* __restrict__ pbp, double lambda, double* __restrict__ Hs) {
+  const BaDev pb = *pbp;
+  const int t = blockIdx.x * GB + threadIdx.x, gid = t >> 2, q = t & 3, P = pb.P;   // four lanes per element (schur_sum4)
+  const bool mat = gid < P * P, rhs = !mat && gid < P * P + P;
+  int r = 0, c = P;
+  if (mat) { r = gid / P; c = gid - r * P; } else if (rhs) r = gid - P * P;
+  const int i = r < c ? r : c, j = r < c ? c : r;
+  const double cs = morbschur::schur_sum4(pb.sPart, pb.sBlkIndex, pb.sNb, pb.sNblk, pb.sNsplit, (mat || rhs) ? i : 0, (mat || rhs) ? j : 0, q);
+  if (q != 0) return;
+  if (mat) {
+    double v = -cs;
+    if (r / 6 == c / 6) { v += pb.Hpp[(size_t)(r / 6) * 36 + (r % 6) * 6 + (c % 6)]; if (r == c) v += lambda; }
+    Hs[gid] = v;
+  } else if (rhs) {
+    pb.x[r] = pb.b[r] - cs;
   }
 }
 __global__ __launch_bounds__(GB) void k_g_schur(const BaDev* __restrict__ pbp, double lambda, double* __restrict__ Hs) {
@@ -1355,6 +1427,7 @@ struct morb_ba_problem {
   size_t ldsBytes = 0;
   int mode = 0;            // 0 = grid (one launch per LM phase, host-side accept/reject), 1 = one persistent workgroup
   int redBlocks = 0;
+  morbschur::Plan schur;
   double* h_scal = nullptr;  // pinned host mirror of scal[0..3]
   double* d_ldws = nullptr;  // [P][LB] panel scratch of the LDL^T when the reduced system does not fit LDS
 };
@@ -1550,6 +1623,19 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
   p->redBlocks = div_up(std::max(std::max(nE, nMP * 3), std::max(nKF * 7, 1)), GB);
   h.redPart = (double*)up(nullptr, sizeof(double) * 2 * p->redBlocks);
   h.scal = (double*)up(nullptr, sizeof(double) * 8);
+  {
+    const morbschur::Plan sp = morbschur::make_plan(h.P + 1, 3 * nMP);
+    p->schur = sp;
+    std::vector<int2> blocks; std::vector<int> blkIndex((size_t)sp.nb * sp.nb, 0);
+    for (int bi = 0; bi < sp.nb; ++bi) for (int bj = bi; bj < sp.nb; ++bj) { blkIndex[(size_t)bi * sp.nb + bj] = (int)blocks.size(); blocks.push_back(make_int2(bi, bj)); }
+    h.sW = (double*)up(nullptr, sizeof(double) * sp.wElems());
+    h.sWD = (double*)up(nullptr, sizeof(double) * sp.wElems());
+    if (!fail && (hipMemset(h.sW, 0, sizeof(double) * sp.wElems()) != hipSuccess || hipMemset(h.sWD, 0, sizeof(double) * sp.wElems()) != hipSuccess)) fail = true;
+    h.sPart = (double*)up(nullptr, sizeof(double) * sp.partElems());
+    h.sBlocks = (const int2*)up(blocks.data(), sizeof(int2) * blocks.size());
+    h.sBlkIndex = (const int*)up(blkIndex.data(), sizeof(int) * blkIndex.size());
+    h.sMp = sp.Mp; h.sNb = sp.nb; h.sNblk = sp.nblk; h.sNsplit = sp.nsplit;
+  }
   const size_t nx = (size_t)h.P + 3 * (size_t)nMP;
   h.pose = (double*)up(nullptr, sizeof(double) * 7 * nKF);
   h.poseBk = (double*)up(nullptr, sizeof(double) * 7 * nKF);
@@ -1690,6 +1776,7 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
     hipLaunchKernelGGL(k_g_chi2, dim3(rb), dim3(GB), 0, st, d, part0);
     hipLaunchKernelGGL(k_g_reduce, dim3(1), dim3(GB), 0, st, (const double*)part0, rb, h.scal + 0);
   };
+  static const bool valuSchur = [] { const char* v = getenv("MORB_SCHUR_VALU"); return v && v[0] == '1'; }();
   int its = 0, trials = 0;
   auto stopped = [&]() -> bool { return __atomic_load_n(p->h_stop, __ATOMIC_ACQUIRE) != 0 || (p->userStop && *p->userStop); };
   if (!stopped()) {
@@ -1708,6 +1795,7 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
       MORB_HIP_CHECK(hipEventRecord(p->opt->evJoin, s2));
       hipLaunchKernelGGL(k_g_build_mp, dim3(div_up(h.nMP, GB)), dim3(GB), 0, st, d);
       MORB_HIP_CHECK(hipStreamWaitEvent(st, p->opt->evJoin, 0));
+      hipLaunchKernelGGL(k_g_pack_w, dim3(rb), dim3(GB), 0, st, d);
       return MORB_OK;
     };
     bool built = false;   // the next iteration's system is already being built (speculatively, see below)
@@ -1729,14 +1817,21 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
       double rho = 0;
       int qmax = 0;
       do {
-        hipLaunchKernelGGL(k_g_dinv_push, dim3(rb > div_up(h.P * h.P, GB) ? rb : div_up(h.P * h.P, GB)), dim3(GB), 0, st, d, lambda, h.HsG);
-        // the Schur complement of the matrix and of the right-hand side both only need Dinv
-        MORB_HIP_CHECK(hipEventRecord(p->opt->evFork, st));
-        MORB_HIP_CHECK(hipStreamWaitEvent(s2, p->opt->evFork, 0));
-        hipLaunchKernelGGL(k_g_bschur, dim3(h.nKF), dim3(64), 0, s2, d);
-        MORB_HIP_CHECK(hipEventRecord(p->opt->evJoin, s2));
-        hipLaunchKernelGGL(k_g_schur, dim3(div_up(std::max(h.nPairs, 1), 4)), dim3(GB), 0, st, d, lambda, h.HsG);
-        MORB_HIP_CHECK(hipStreamWaitEvent(st, p->opt->evJoin, 0));
+        hipLaunchKernelGGL(k_g_dinv_push, dim3(rb > div_up(h.P * h.P, GB) ? rb : div_up(h.P * h.P, GB)), dim3(GB), 0, st, d, lambda, h.HsG, valuSchur ? 1 : 0);
+        if (!valuSchur) {
+          // Schur complement of the landmarks (matrix and right-hand side in one product) on the FP64 matrix cores
+          hipLaunchKernelGGL(morbschur::k_schur_mfma, dim3(p->schur.nblk, p->schur.nsplit), dim3(64), 0, st, (const double*)h.sWD,
+                             (const double*)h.sW, p->schur.Mp, p->schur.ksteps, p->schur.stepsPerSplit, h.sBlocks, h.sPart);
+          hipLaunchKernelGGL(k_g_schur_finish, dim3(div_up(4 * (h.P * h.P + h.P), GB)), dim3(GB), 0, st, d, lambda, h.HsG);
+        } else {
+          // (measurement only, MORB_SCHUR_VALU=1: round 1's per-block-pair VALU form, kept so that profiles/ can show both)
+          MORB_HIP_CHECK(hipEventRecord(p->opt->evFork, st));
+          MORB_HIP_CHECK(hipStreamWaitEvent(s2, p->opt->evFork, 0));
+          hipLaunchKernelGGL(k_g_bschur, dim3(h.nKF), dim3(64), 0, s2, d);
+          MORB_HIP_CHECK(hipEventRecord(p->opt->evJoin, s2));
+          hipLaunchKernelGGL(k_g_schur, dim3(div_up(std::max(h.nPairs, 1), 4)), dim3(GB), 0, st, d, lambda, h.HsG);
+          MORB_HIP_CHECK(hipStreamWaitEvent(st, p->opt->evJoin, 0));
+        }
         hipLaunchKernelGGL(k_g_ldlt, dim3(1), dim3(LD_T), p->ldsBytes, st, d, h.HsG, p->d_ldws, p->useLds);
         hipLaunchKernelGGL(k_g_backsub_update, dim3(rb), dim3(GB), 0, st, d, lambda, part1);
         hipLaunchKernelGGL(k_g_reduce, dim3(1), dim3(GB), 0, st, (const double*)part1, rb, h.scal + 1);

@@ -343,8 +343,8 @@ def test_local_ba_fisheye_matches_oracle(kw):
         its, kfe, mpe, ee, se = O.local_ba_fisheye(b, lambda100=inertial)
         assert abs(int(stats[0]) - int(se[0])) <= 1 and abs(int(stats[1]) - int(se[1])) <= 3, (stats, se)
         assert np.abs(kf - kfe).max() <= 1e-4
-        assert np.abs(mp - mpe).max() <= 1e-3 * max(1.0, np.abs(mpe).max())
-        assert (erase != ee).mean() < 1e-3
+        assert np.abs(mp - mpe).max() <= 1e-4 * max(1.0, np.abs(mpe).max())
+        assert (erase != ee).mean() < 1e-3   # (KB8 projection: device vs host libm, see kb8.h)
         nf = int((b["kfFixed"] == 0).sum())
         assert np.abs(kf[:nf] - b["true_poses"][:nf]).max() < 0.05
         assert 0.01 < ee.mean() < 0.3

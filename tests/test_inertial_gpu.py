@@ -189,11 +189,15 @@ def test_local_inertial_ba(opt, large, n_opt, seeds):
         optk = p["kfKind"] == 0
         assert np.allclose(kf[optk], kf_o[optk], rtol=0, atol=1e-4), np.abs(kf[optk] - kf_o[optk]).max()
         assert np.array_equal(kf[~optk], p["kfState"][~optk])                            # fixed keyframes untouched
-        # points: FP64 on both sides, different summation orders (atomics); ill-conditioned far points are compared relative
-        # to their distance
+        # points: FP64 on both sides, different (but fixed: no atomics) summation orders; far points are compared relative to
+        # their distance
         d = np.abs(mp - mp_o).max(1) / np.maximum(1.0, np.linalg.norm(mp_o, axis=1))
-        assert np.quantile(d, 0.99) < 1e-4 and d.max() < 1e-2, (np.quantile(d, 0.99), d.max())
-        assert (er != er_o).sum() <= max(2, len(er) // 2000), int((er != er_o).sum())
+        assert d.max() < 1e-4, (np.quantile(d, 0.99), d.max())
+        np.testing.assert_array_equal(er, er_o)
+        # the Schur complement is summed in a fixed order on the matrix cores: a second run is bit-identical
+        kf2, mp2, er2, st2 = opt.LocalInertialBA(p["kfState"], p["kfKind"], p["mpPos"], p["mpClose"], p["eKF"], p["eMP"], p["eObs"], p["eInvSigma2"],
+                                                 p["iKF1"], p["iKF2"], pre, p["iRobust"], p["iInfoScale"], p["cam"], p["Tbc12"], bLarge=large)
+        assert kf2.tobytes() == kf.tobytes() and mp2.tobytes() == mp.tobytes() and er2.tobytes() == er.tobytes()
         # sanity: the window moved towards the generating trajectory
         def ang(a, b):
             return np.degrees(np.arccos(np.clip((np.trace(a.reshape(3, 3).T @ b.reshape(3, 3)) - 1) / 2, -1, 1)))
@@ -256,8 +260,8 @@ def test_local_inertial_ba_fisheye_rig(opt, seed):
     optk = p["kfKind"] == 0
     assert np.allclose(kf[optk], kf_o[optk], rtol=0, atol=1e-4), np.abs(kf[optk] - kf_o[optk]).max()
     d = np.abs(mp - mp_o).max(1) / np.maximum(1.0, np.linalg.norm(mp_o, axis=1))
-    assert np.quantile(d, 0.99) < 1e-4 and d.max() < 1e-2, (np.quantile(d, 0.99), d.max())
-    assert (er != er_o).sum() <= max(2, len(er) // 2000)
+    assert d.max() < 1e-4, (np.quantile(d, 0.99), d.max())
+    np.testing.assert_array_equal(er, er_o)
     assert er[p["eRight"] > 0].sum() > 0 and er[p["eRight"] == 0].sum() > 0
 
 
