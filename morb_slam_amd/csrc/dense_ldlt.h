@@ -1,0 +1,215 @@
+// Dense symmetric solve H x = b by LDL^T for the reduced camera systems (n <= ~160: LocalBundleAdjustment's 6 nFree, LocalInertialBA's
+// 15 nOpt), ONE workgroup with the whole lower triangle resident in LDS.
+//
+// Round 1 factorised in global memory (LocalInertialBA: ~230 us at n = 150) or with a one-thread diagonal block and
+// column-at-a-time substitutions (LocalBA: 98 us at n = 120); with a single workgroup nothing hides a global round trip.  Here:
+//   * the lower triangle is packed in LDS (row r at r (r + 1) / 2), the right-hand side is carried as an extra ROW n of the matrix:
+//     the panel step then performs the forward substitution and the division by D on the way (row n ends up holding D^-1 L^-1 b),
+//     so only the back substitution L^T x = w remains;
+//   * right-looking, 16-column panels.  Diagonal block: one wave, row r in lane r, the pivot row reaches the other lanes through
+//     v_mov_b32_dpp row_newbcast (no SGPR round trip).  Rows below it: SIXTEEN lanes per row, one per column — the 16 dependent
+//     stages of a row are one DPP broadcast + one FMA each, the lane's row of L sits in registers (a thread-per-row version with
+//     the 120 LDS operands hoisted by the compiler spilled to scratch and took 7x longer).  Trailing triangle: rank-16 update on
+//     the FP64 matrix cores, one wave per 16 x 16 tile.  3 barriers per panel; the back substitution takes 2 more per panel.
+// Rounding differs from Eigen's / the oracle's column order only in the order of the updates (all FP64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "wave.h"
+
+namespace morbdense {
+namespace {
+
+constexpr int NB = 16, NBP = 17, LT = 512;   // 512 threads: two waves per SIMD
+typedef double ld_d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int tri(int r, int c) { return ((r * (r + 1)) >> 1) + c; }   // c <= r
+
+// lane SRC (0..15, compile-time) of every 16-lane row -> all lanes of the row: two v_mov_b32_dpp row_newbcast (gfx90a+)
+template <int SRC>
+__device__ __forceinline__ double row_bcast_f64(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x150 + SRC, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x150 + SRC, 0xf, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+// stage J of the in-register LDL^T of a 16 x 16 block (row r in lane r of each 16-lane row)
+template <int J>
+struct DiagStage {
+  template <bool PIVOT_POSITIVE>
+  static __device__ __forceinline__ void run(double (&a)[16], int row, bool& ok, double& rd) {
+    const double d = row_bcast_f64<J>(a[J]);
+    ok = ok && (PIVOT_POSITIVE ? (d > 0) : !(d == 0 || d != d));
+    const double inv = 1.0 / d;
+    if (row == J) rd = inv;
+    const double l = a[J] * inv;
+    bc<J + 1>(a, l);
+    if (row > J) a[J] = l;
+    if constexpr (J + 1 < 16) DiagStage<J + 1>::template run<PIVOT_POSITIVE>(a, row, ok, rd);
+  }
+  template <int C>
+  static __device__ __forceinline__ void bc(double (&a)[16], double l) {
+    if constexpr (C < 16) { a[C] -= l * row_bcast_f64<J>(a[C]); bc<C + 1>(a, l); }
+  }
+};
+// stages of a row below the block, one column per lane: v_c -= u_K L[c][K] with u_K = the (final) value of lane K
+template <int K>
+struct PanelStage {
+  static __device__ __forceinline__ void run(double& v, const double (&lrow)[16]) {
+    v -= row_bcast_f64<K>(v) * lrow[K];   // lrow[K] = 0 for K >= c: lanes at or left of the pivot column keep their value
+    if constexpr (K + 1 < 16) PanelStage<K + 1>::run(v, lrow);
+  }
+};
+
+// back substitution inside a block, row per lane: x_row -= L[C][row] x_C for C = 15 .. 1 (x_C final when its turn comes)
+template <int C>
+struct BackStage {
+  static __device__ __forceinline__ void run(double& xr, const double (&lcol)[16]) {
+    xr -= lcol[C] * row_bcast_f64<C>(xr);
+    if constexpr (C > 1) BackStage<C - 1>::run(xr, lcol);
+  }
+};
+
+// LDS doubles the solver needs for an n x n system (panel copies padded to whole 16-row tiles)
+__host__ __device__ inline size_t lds_doubles(int n) {
+  const size_t prow = (size_t)((n + 1 + NB - 1) / NB * NB);
+  return (size_t)(n + 1) * (n + 2) / 2 + 2 * prow * NBP + NB * NBP + NB + n;
+}
+
+// PIVOT_POSITIVE: a pivot must be > 0 (LocalInertialBA's rule); otherwise it must be non-zero and not NaN (LocalBA's).
+// Hs: symmetric n x n, row-major, pitch n (only the lower triangle is read); b, x: n.  Returns false if a pivot failed (x untouched).
+template <bool PIVOT_POSITIVE>
+__device__ bool ldlt_solve(const double* __restrict__ Hs, const double* b, double* x /* may alias b */, int n, double* sm, int* sOk,
+                           unsigned long long* dbg = nullptr /* developer hook: phase clocks */) {
+#define LD_MARK(k) do { if (dbg && threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); dbg[k] += now_ - t0_; t0_ = now_; } } while (0)
+  unsigned long long t0_ = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int prow = (n + 1 + NB - 1) / NB * NB;
+  double* L = sm;                                        // packed lower triangle of the (n + 1) x (n + 1) augmented matrix
+  double* pnlU = L + (size_t)(n + 1) * (n + 2) / 2;      // [prow][NBP]: u = l d of the rows below the current diagonal block
+  double* pnlL = pnlU + (size_t)prow * NBP;              // [prow][NBP]: l of the same rows
+  double* dblk = pnlL + (size_t)prow * NBP;              // [NB][NBP]: the factorised diagonal block: strictly lower part L, rest 0
+  double* rdiag = dblk + NB * NBP;                       // [NB]: 1 / D
+  double* xs = rdiag + NB;                               // [n]
+  for (int r = wv; r < n; r += LT / 64)   // one wave per row: coalesced reads of the row's lower part
+    for (int c = lane; c <= r; c += 64) L[tri(r, c)] = Hs[(size_t)r * n + c];
+  for (int c = tid; c <= n; c += LT) L[tri(n, c)] = c < n ? b[c] : 0.0;
+  for (int i = tid; i < 2 * prow * NBP; i += LT) pnlU[i] = 0.0;   // (rows beyond m feed MFMA lanes whose results are dropped: keep them finite)
+  if (tid == 0) *sOk = 1;
+  __syncthreads();
+  LD_MARK(0);
+  for (int j0 = 0; j0 < n; j0 += NB) {
+    const int nb = n - j0 < NB ? n - j0 : NB, m = n + 1 - j0 - nb;   // m rows below the block (the last one is the right-hand side)
+    // (1) the diagonal block: wave 0, row r in lane r (identity padding beyond nb)
+    if (wv == 0) {
+      // the symmetric block -> dblk (four passes of 64 lanes, branch-free), then row r -> lane r (same wave: LDS keeps the order)
+#pragma unroll
+      for (int q = 0; q < NB * NB / 64; ++q) {
+        const int idx = lane + 64 * q, r = idx >> 4, c = idx & 15;
+        const bool in = r < nb && c < nb;
+        const int hi = r > c ? r : c, lo = r > c ? c : r;
+        const double v = L[in ? tri(j0 + hi, j0 + lo) : 0];
+        dblk[r * NBP + c] = in ? v : (r == c ? 1.0 : 0.0);
+      }
+      const int row = lane & 15;   // (lanes 16..63 repeat the block in their own DPP rows; only lanes 0..15 store)
+      double a[NB];
+#pragma unroll
+      for (int c = 0; c < NB; ++c) a[c] = dblk[row * NBP + c];
+      bool ok = true;
+      double rd = 1.0;
+      DiagStage<0>::template run<PIVOT_POSITIVE>(a, row, ok, rd);
+      ok = __ballot(!ok && lane < NB) == 0;
+      if (lane < NB) {
+        rdiag[row] = rd;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+          dblk[row * NBP + c] = c < row ? a[c] : 0.0;
+          if (c <= row && row < nb) L[tri(j0 + row, j0 + c)] = a[c];
+        }
+      }
+      if (lane == 0 && !ok) *sOk = 0;
+    }
+    __syncthreads();
+    LD_MARK(1);
+    if (*sOk == 0) break;   // uniform
+    // (2) rows below the block: u = a - sum_k u_k L[c][k], l = u / d — sixteen lanes per row, one per column
+    {
+      const int c = tid & 15;
+      double lrow[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) lrow[k] = dblk[c * NBP + k];   // strictly lower part of row c, zero from the diagonal on
+      const double rdc = rdiag[c];
+      for (int rr = tid >> 4; rr < m; rr += LT / 16) {
+        const int R = j0 + nb + rr;
+        const double t = L[tri(R, j0 + (c < nb ? c : 0))];
+        double v = c < nb ? t : 0.0;
+        PanelStage<0>::run(v, lrow);
+        const double l = v * rdc;
+        pnlU[rr * NBP + c] = v;
+        pnlL[rr * NBP + c] = l;
+        if (c < nb) L[tri(R, j0 + c)] = l;
+      }
+    }
+    __syncthreads();
+    LD_MARK(2);
+    // (3) trailing update A[r][c] -= sum_k u[r][k] l[c][k] on the FP64 matrix cores: one wave per 16 x 16 tile of the lower
+    // triangle (4 v_mfma_f64_16x16x4_f64; A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k, D[i][j] in lane j + 16 (i % 4),
+    // register i / 4 — tools/micro/mfma_f64_layout.hip)
+    {
+      const int mt = (m + NB - 1) / NB, ntile = mt * (mt + 1) / 2;
+      const int li = lane & 15, lk = lane >> 4;
+      for (int t = wv; t < ntile; t += LT / 64) {
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;   // tile (ti, tj), tj <= ti
+        const int tj = t - ti * (ti + 1) / 2;
+        ld_d4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int s4 = 0; s4 < NB / 4; ++s4)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pnlU[(ti * NB + li) * NBP + 4 * s4 + lk], pnlL[(tj * NB + li) * NBP + 4 * s4 + lk], acc, 0, 0, 0);
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) {
+          const int rr = ti * NB + 4 * v4 + lk, cc = tj * NB + li;
+          if (rr < m && cc <= rr && j0 + nb + cc < n) L[tri(j0 + nb + rr, j0 + nb + cc)] -= acc[v4];
+        }
+      }
+    }
+    __syncthreads();
+    LD_MARK(3);
+  }
+  __syncthreads();
+  if (*sOk == 0) return false;
+  // back substitution L^T x = w, w = row n of the factorised matrix
+  for (int r = tid; r < n; r += LT) xs[r] = L[tri(n, r)];
+  __syncthreads();
+  for (int j0 = ((n - 1) / NB) * NB; j0 >= 0; j0 -= NB) {
+    const int nb = n - j0 < NB ? n - j0 : NB;
+    if (wv == 0) {   // the block's unit upper triangle, lane = row
+      const int row = lane & 15;
+      double lcol[NB];
+#pragma unroll
+      for (int c = 1; c < NB; ++c) {   // L^T[row][c] = L[c][row]
+        const bool in = row < c && c < nb;
+        const double t = L[in ? tri(j0 + c, j0 + row) : 0];
+        lcol[c] = in ? t : 0.0;
+      }
+      lcol[0] = 0.0;
+      double xr = row < nb ? xs[j0 + row] : 0.0;
+      BackStage<NB - 1>::run(xr, lcol);
+      if (lane < nb) xs[j0 + lane] = xr;
+    }
+    __syncthreads();
+    for (int r = tid; r < j0; r += LT) {
+      double acc = 0;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) if (k < nb) acc += L[tri(j0 + k, r)] * xs[j0 + k];
+      xs[r] -= acc;
+    }
+    __syncthreads();
+  }
+  for (int r = tid; r < n; r += LT) x[r] = xs[r];
+  LD_MARK(4);
+#undef LD_MARK
+  return true;
+}
+
+}  // namespace
+}  // namespace morbdense

@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "kb8.h"
+#include "dense_ldlt.h"
 #include "schur_mfma.h"
 #include "wave.h"
 
@@ -1539,6 +1540,13 @@ __device__ bool wave_ldl_factor16(double* blk, int lane) {
   }
   return ok;
 }
+// dense LDL^T + solve with the lower triangle resident in LDS (dense_ldlt.h): windows up to 15 N = 165
+__global__ __launch_bounds__(morbdense::LT) void k_iba_solve_lds(IbaDev D) {
+  extern __shared__ double sLd[];
+  __shared__ int sOk;
+  const bool ok = morbdense::ldlt_solve<true>(D.Hs, D.bs, D.x, D.P, sLd, &sOk);
+  if (threadIdx.x == 0) D.scal[2] = ok ? 1.0 : 0.0;
+}
 __global__ __launch_bounds__(1024) void k_iba_solve_blocked(IbaDev D) {
   extern __shared__ double sm[];   // pnlL[n * NBP] | pnlU[n * NBP] | dblk[NB * NBP] | y[n]
   const int n = D.P, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1977,6 +1985,9 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
   MORB_REQUIRE(blockedLds <= 150 * 1024, MORB_ERR_CAPACITY, "window too large for the dense solver");
   if (blockedLds > 48 * 1024)
     MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_iba_solve_blocked), hipFuncAttributeMaxDynamicSharedMemorySize, (int)blockedLds));
+  size_t denseLds = sizeof(double) * morbdense::lds_doubles(P);
+  if (denseLds > 156 * 1024 || getenv("MORB_LDLT_R1")) denseLds = 0;   // larger windows (bLarge) keep the global-memory solver; MORB_LDLT_R1: measurement only
+  if (denseLds) MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_iba_solve_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
   double chi = 0;
   if (!errors(&chi)) return fail("k_iba_errors failed");
   const float err0 = (float)chi;
@@ -2011,7 +2022,8 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
         hipLaunchKernelGGL(k_iba_schur_finish, dim3(div_up(4 * (Mpose * Mpose + Mpose), 256)), dim3(256), 0, st, D);
       } else if (ldsSchur) hipLaunchKernelGGL(k_iba_schur<true>, dim3(div_up(nMP, 256)), dim3(256), schurLds, st, D, lambda);   // (measurement only, MORB_SCHUR_VALU=1: round 1's form with FP64 atomics)
       else hipLaunchKernelGGL(k_iba_schur<false>, dim3(div_up(nMP, 256)), dim3(256), 0, st, D, lambda);
-      hipLaunchKernelGGL(k_iba_solve_blocked, dim3(1), dim3(1024), blockedLds, st, D);
+      if (denseLds) hipLaunchKernelGGL(k_iba_solve_lds, dim3(1), dim3(morbdense::LT), denseLds, st, D);
+      else hipLaunchKernelGGL(k_iba_solve_blocked, dim3(1), dim3(1024), blockedLds, st, D);
       // a failed solve leaves x as it was (zero at the first trial): g2o still applies the update
       (void)hipMemsetAsync(D.scal, 0, sizeof(double) * 2, st);
       hipLaunchKernelGGL(k_iba_update, dim3(div_up(nMP + nKF, 256)), dim3(256), 0, st, D, lambda);

@@ -26,6 +26,7 @@
 
 #include "common.h"
 #include "kb8.h"
+#include "dense_ldlt.h"
 #include "schur_mfma.h"
 #include "wave.h"
 
@@ -1327,6 +1328,14 @@ __global__ __launch_bounds__(LD_T) void k_g_ldlt(const BaDev* __restrict__ pbp, 
     if (tid == 0) pb.scal[2] = ok ? 1.0 : 0.0;
   }
 }
+// the reduced camera system with its lower triangle resident in LDS (dense_ldlt.h); x = Hs^-1 x in place
+__global__ __launch_bounds__(morbdense::LT) void k_g_ldlt_lds(const BaDev* __restrict__ pbp, const double* __restrict__ HsG) {
+  extern __shared__ double sLd[];
+  __shared__ int sOk;
+  const BaDev pb = *pbp;
+  const bool ok = morbdense::ldlt_solve<false>(HsG, pb.x, pb.x, pb.P, sLd, &sOk);
+  if (threadIdx.x == 0) pb.scal[2] = ok ? 1.0 : 0.0;
+}
 __global__ __launch_bounds__(GB) void k_g_backsub_update(const BaDev* __restrict__ pbp, double lambda, double* __restrict__ part) {
   __shared__ double red[4];
   const BaDev pb = *pbp;
@@ -1425,6 +1434,7 @@ struct morb_ba_problem {
   const volatile unsigned char* userStop = nullptr;   // the caller's *pbStopFlag (one-shot entry points), polled by the host LM loop
   int useLds = 1;
   size_t ldsBytes = 0;
+  size_t denseLds = 0;     // LDS bytes of the triangle-resident solver (0: the system is too large for it)
   int mode = 0;            // 0 = grid (one launch per LM phase, host-side accept/reject), 1 = one persistent workgroup
   int redBlocks = 0;
   morbschur::Plan schur;
@@ -1666,6 +1676,9 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
   p->ldsBytes = sizeof(double) * (size_t)h.P * (h.P + 1);
   p->useLds = (p->ldsBytes <= 136 * 1024 && h.P <= 192) ? 1 : 0;
   if (!p->useLds) p->ldsBytes = 0;
+  p->denseLds = sizeof(double) * morbdense::lds_doubles(h.P);
+  if (p->denseLds > 156 * 1024 || h.P < 1 || getenv("MORB_LDLT_R1")) p->denseLds = 0;   // (MORB_LDLT_R1: measurement only, round 1's solver)
+  if (!fail && p->denseLds && hipFuncSetAttribute(reinterpret_cast<const void*>(k_g_ldlt_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) fail = true;
   if (!fail && p->useLds &&
       (hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_ba), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024) != hipSuccess ||
        hipFuncSetAttribute(reinterpret_cast<const void*>(k_g_ldlt), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024) != hipSuccess))
@@ -1832,7 +1845,8 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
           hipLaunchKernelGGL(k_g_schur, dim3(div_up(std::max(h.nPairs, 1), 4)), dim3(GB), 0, st, d, lambda, h.HsG);
           MORB_HIP_CHECK(hipStreamWaitEvent(st, p->opt->evJoin, 0));
         }
-        hipLaunchKernelGGL(k_g_ldlt, dim3(1), dim3(LD_T), p->ldsBytes, st, d, h.HsG, p->d_ldws, p->useLds);
+        if (p->denseLds) hipLaunchKernelGGL(k_g_ldlt_lds, dim3(1), dim3(morbdense::LT), p->denseLds, st, d, (const double*)h.HsG);
+        else hipLaunchKernelGGL(k_g_ldlt, dim3(1), dim3(LD_T), p->ldsBytes, st, d, h.HsG, p->d_ldws, p->useLds);
         hipLaunchKernelGGL(k_g_backsub_update, dim3(rb), dim3(GB), 0, st, d, lambda, part1);
         hipLaunchKernelGGL(k_g_reduce, dim3(1), dim3(GB), 0, st, (const double*)part1, rb, h.scal + 1);
         chi2();
