@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "common.h"
+#include "libm_f32.h"
 #include "wave.h"
 #include "extractor_internal.h"
 #include "quadtree.h"
@@ -829,44 +830,8 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fast
   return a;
 }
 
-// glibc 2.35 sincosf restated (same sequence as oracle/cvprims.cc; bit-equal to libm cosf/sinf on [0, 7])
-struct SinCosTab { double sign[4]; double hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3; };
-__device__ __forceinline__ double sc_poly(double x, double x2, const SinCosTab& p, int n) {
-  if ((n & 1) == 0) {
-    const double x3 = x * x2, s1 = p.s2 + x2 * p.s3, x7 = x3 * x2, s = x + x3 * p.s1;
-    return s + x7 * s1;
-  }
-  const double x4 = x2 * x2, c2 = p.c3 + x2 * p.c4, c1 = p.c0 + x2 * p.c1, x6 = x4 * x2, c = c1 + x4 * p.c2;
-  return c + x6 * c2;
-}
-__device__ __forceinline__ void sincosf_glibc(float y, float* sn, float* cs) {
-  const SinCosTab t0 = {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, 0x1p0,
-                        -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5, -0x1.6c087e89a359dp-10,
-                        0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7,
-                        -0x1.994eb3774cf24p-13};
-  const SinCosTab t1 = {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, -0x1p0,
-                        0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5, 0x1.6c087e89a359dp-10,
-                        -0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7,
-                        -0x1.994eb3774cf24p-13};
-  const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ff;
-  const uint32_t topPio4 = (__float_as_uint(0x1.921FB6p-1f) >> 20) & 0x7ff;
-  const uint32_t topTiny = (__float_as_uint(0x1p-12f) >> 20) & 0x7ff;
-  double x = (double)y;
-  if (top < topPio4) {
-    const double x2 = x * x;
-    if (top < topTiny) { *cs = 1.0f; *sn = y; return; }
-    *cs = (float)sc_poly(x, x2, t0, 1);
-    *sn = (float)sc_poly(x, x2, t0, 0);
-    return;
-  }
-  const double r = x * t0.hpi_inv;
-  const int n = ((int32_t)r + 0x800000) >> 24;
-  x = x - n * t0.hpi;
-  const double s = t0.sign[n & 3];
-  const SinCosTab& p = (n & 2) ? t1 : t0;
-  *cs = (float)sc_poly(x * s, x * x, p, n ^ 1);
-  *sn = (float)sc_poly(x * s, x * x, p, n);
-}
+// cos / sin of the keypoint angle: glibc 2.35's sincosf restated (libm_f32.h), bit-equal to the CPU libm the reference runs on
+using morbm::sincosf_glibc;
 
 // The wave's lifetime is a chain of dependent global-memory round trips, so the chain is kept short: one record
 // per keypoint from k_layout (slot, level, key), level geometry from the kernarg segment, and the (keypoint-

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "common.h"
+#include "libm_f32.h"
 #include "kb8.h"
 #include "dense_ldlt.h"
 #include "schur_mfma.h"
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(64) void k_imu_preintegrate(int nseq, const int* __
         if (d < 1e-4f) {
           for (int k = 0; k < 9; ++k) { dRi[k] = ((k & 3) == 0 ? 1.f : 0.f) + W[k]; rJ[k] = (k & 3) == 0 ? 1.f : 0.f; }
         } else {
-          const float sn = sinf(d), cs = cosf(d);
+          const float sn = morbm::sinf_glibc(d), cs = morbm::cosf_glibc(d);
           for (int k = 0; k < 9; ++k) {
             const float I = (k & 3) == 0 ? 1.f : 0.f;
             dRi[k] = I + W[k] * sn / d + WW[k] * (1.0f - cs) / d2;
@@ -517,7 +518,7 @@ __device__ void imu_delta(const morb_imu_preintegrated& P, const double* bg1, co
   hatf(w, W);
   mul33f(W, W, WW);
   if (t < 1e-5f) for (int k = 0; k < 9; ++k) E[k] = ((k & 3) == 0 ? 1.f : 0.f) + W[k] + 0.5f * WW[k];
-  else { const float sn = sinf(t), cs = cosf(t); for (int k = 0; k < 9; ++k) E[k] = ((k & 3) == 0 ? 1.f : 0.f) + W[k] * sn / t + WW[k] * (1.0f - cs) / t2; }
+  else { const float sn = morbm::sinf_glibc(t), cs = morbm::cosf_glibc(t); for (int k = 0; k < 9; ++k) E[k] = ((k & 3) == 0 ? 1.f : 0.f) + W[k] * sn / t + WW[k] * (1.0f - cs) / t2; }
   mul33f(P.dR, E, dRf);
   normalize_rotation_f(dRf);
   for (int k = 0; k < 9; ++k) dR[k] = dRf[k];

@@ -5,19 +5,21 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "libm_f32.h"   // glibc's atan2f / tanf / cosf / sinf, bit for bit: the reference runs on the CPU's libm
+
 namespace morbkb8 {
 
 struct KB8 { float p[8]; };
 
 __device__ __forceinline__ void kb8_project_f(const KB8& c, const float* v, float* uv) {
   const float x2_plus_y2 = v[0] * v[0] + v[1] * v[1];
-  const float theta = atan2f(sqrtf(x2_plus_y2), v[2]);
-  const float psi = atan2f(v[1], v[0]);
+  const float theta = morbm::atan2f_glibc(sqrtf(x2_plus_y2), v[2]);
+  const float psi = morbm::atan2f_glibc(v[1], v[0]);
   const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2,
               theta9 = theta7 * theta2;
   const float r = theta + c.p[4] * theta3 + c.p[5] * theta5 + c.p[6] * theta7 + c.p[7] * theta9;
-  uv[0] = c.p[0] * r * cosf(psi) + c.p[2];
-  uv[1] = c.p[1] * r * sinf(psi) + c.p[3];
+  uv[0] = c.p[0] * r * morbm::cosf_glibc(psi) + c.p[2];
+  uv[1] = c.p[1] * r * morbm::sinf_glibc(psi) + c.p[3];
 }
 __device__ __forceinline__ void kb8_unproject(const KB8& c, float px, float py, float* ray) {
   const float pwx = (px - c.p[2]) / c.p[0], pwy = (py - c.p[3]) / c.p[1];
@@ -33,7 +35,7 @@ __device__ __forceinline__ void kb8_unproject(const KB8& c, float px, float py, 
       theta = theta - fix;
       if (fabsf(fix) < 1e-6f) break;
     }
-    scale = tanf(theta) / theta_d;
+    scale = morbm::tanf_glibc(theta) / theta_d;
   }
   ray[0] = pwx * scale; ray[1] = pwy * scale; ray[2] = 1.f;
 }
@@ -112,8 +114,8 @@ __device__ inline float triangulate_matches(const KB8& c1, const KB8& c2, const 
 // projectJac (:164-199).  c = fx fy cx cy k0 k1 k2 k3.
 __device__ __forceinline__ void kb8_project_d(const float* c, const double* v, double* uv) {
   const double x2_plus_y2 = v[0] * v[0] + v[1] * v[1];
-  const double theta = (double)atan2f(sqrtf((float)x2_plus_y2), (float)v[2]);   // the reference's float leak
-  const double psi = (double)atan2f((float)v[1], (float)v[0]);
+  const double theta = (double)morbm::atan2f_glibc(sqrtf((float)x2_plus_y2), (float)v[2]);   // the reference's float leak
+  const double psi = (double)morbm::atan2f_glibc((float)v[1], (float)v[0]);
   const double theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2,
                theta9 = theta7 * theta2;
   const double r = theta + c[4] * theta3 + c[5] * theta5 + c[6] * theta7 + c[7] * theta9;

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.h"
+#include "libm_f32.h"
 #include "wave.h"
 #include "kb8.h"
 
@@ -151,13 +152,13 @@ __global__ __launch_bounds__(256) void k_frustum(morb_frame_params P, const floa
     float u, v;
     if (kb8) {   // KannalaBrandt8::project(Vector3f) (KannalaBrandt8.cpp:49-67): isInFrustumChecks, Frame.cc:1304-1309
       const float x2_plus_y2 = Pc[0] * Pc[0] + Pc[1] * Pc[1];
-      const float theta = atan2f(sqrtf(x2_plus_y2), Pc[2]);
-      const float psi = atan2f(Pc[1], Pc[0]);
+      const float theta = morbm::atan2f_glibc(sqrtf(x2_plus_y2), Pc[2]);
+      const float psi = morbm::atan2f_glibc(Pc[1], Pc[0]);
       const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2,
                   theta9 = theta7 * theta2;
       const float r = theta + kb8[4] * theta3 + kb8[5] * theta5 + kb8[6] * theta7 + kb8[7] * theta9;
-      u = kb8[0] * r * cosf(psi) + kb8[2];
-      v = kb8[1] * r * sinf(psi) + kb8[3];
+      u = kb8[0] * r * morbm::cosf_glibc(psi) + kb8[2];
+      v = kb8[1] * r * morbm::sinf_glibc(psi) + kb8[3];
     } else {
       u = P.fx * Pc[0] / Pc[2] + P.cx; v = P.fy * Pc[1] / Pc[2] + P.cy;
     }
@@ -288,13 +289,13 @@ __global__ __launch_bounds__(256) void k_prep_last(morb_frame_params P, int cap,
 // GetRelativePoseTrl() — the reference's quirk); the right pass has no bounds / depth test of its own.
 __device__ __forceinline__ void kb8_project_dev(const float* c, const float* v3, float& u, float& v) {   // KannalaBrandt8.cpp:49-67
   const float x2_plus_y2 = v3[0] * v3[0] + v3[1] * v3[1];
-  const float theta = atan2f(sqrtf(x2_plus_y2), v3[2]);
-  const float psi = atan2f(v3[1], v3[0]);
+  const float theta = morbm::atan2f_glibc(sqrtf(x2_plus_y2), v3[2]);
+  const float psi = morbm::atan2f_glibc(v3[1], v3[0]);
   const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2,
               theta9 = theta7 * theta2;
   const float r = theta + c[4] * theta3 + c[5] * theta5 + c[6] * theta7 + c[7] * theta9;
-  u = c[0] * r * cosf(psi) + c[2];
-  v = c[1] * r * sinf(psi) + c[3];
+  u = c[0] * r * morbm::cosf_glibc(psi) + c[2];
+  v = c[1] * r * morbm::sinf_glibc(psi) + c[3];
 }
 __global__ __launch_bounds__(256) void k_prep_last_fisheye(morb_frame_params P, int cap, const int* __restrict__ count,
                                                            const int* __restrict__ lastImg, const int* __restrict__ curImg,

@@ -549,3 +549,14 @@ def test_golden_inertial_fixture():
     rw = orc.local_inertial_ba(pw, prew)
     assert rw[0] == int(g["ba_ok"]) and np.array_equal(rw[4], g["ba_stats"]) and np.array_equal(rw[3], g["ba_erase"])
     assert np.allclose(rw[1], g["ba_kf"], atol=1e-6) and np.allclose(rw[2], g["ba_mp"], atol=1e-5)
+
+
+def test_libm_restatement_matches_this_libm(tmp_path):
+    """csrc/libm_f32.h (glibc 2.35's atanf / atan2f / tanf / sinf / cosf restated for the device) against this machine's libm:
+    the quick mode of tools/check_libm_f32.cc samples every 257th float and a few million atan2f pairs (the full run — every float —
+    takes ~4 CPU-minutes and is what the header's claim rests on)."""
+    import subprocess
+    exe = tmp_path / "check_libm"
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-pthread", "-o", str(exe), os.path.join(ROOT, "tools", "check_libm_f32.cc")])
+    out = subprocess.run([str(exe), "quick"], capture_output=True, text=True)
+    assert out.returncode == 0 and "atanf 0, tanf 0, sinf 0, cosf 0, atan2f 0" in out.stdout, out.stdout[-500:]
