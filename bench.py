@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json metric: stereo frames/s, ORB extract+match, 752x480, 1200 features (configs[1]).
+"""bench.py — BASELINE.json metric: stereo frames/s, ORB extract+match.
 
-One "step" = one pass of the hot path over one batch of B synthetic stereo frames that are already resident
-in HBM.  N > 1: one process per GPU (torch.distributed / RCCL), frames sharded per rank, no data-path
-collective for this workload (each stereo frame is an independent unit) -> weak scaling; the timed region is
-bracketed by barrier + synchronize and the MAX over ranks is reported.  Rank 0 prints ONE JSON line.
+Workloads: c2 (default) = BASELINE configs[1], EuRoC-shaped stereo 752x480 / 1200 features (the configuration the metric is
+quoted on; the metric string's "1000 feat" is configs[0]'s mono plumbing case); c4 = configs[3], 1920x1080 / 4000 features.
+One "step" = one pass of the hot path over one batch of B synthetic stereo frames per GPU that are already resident in HBM:
+ORBextractor x2, ComputeStereoMatches, ComputeBoW, SearchByBoW against the previous frame.  N > 1: one process per GPU
+(torch.distributed, RCCL), frames dealt round-robin; the previous frame lives on the previous rank, so every step ships the
+left-image features one rank up the ring (point-to-point over xGMI, morb_slam_amd/parallel.py) -> weak scaling.  The timed
+region is bracketed by barrier + synchronize and the MAX over ranks is reported.  Rank 0 prints ONE JSON line.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4] [--batch B] [--no-cpu-baseline] [--no-extras]
 """
 import argparse
 import json
@@ -19,6 +22,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+WORKLOADS = {"c2": (752, 480, 1200, 256), "c4": (1920, 1080, 4000, 8)}   # width, height, features, default stereo frames per step per GPU
 W, H, NFEAT = 752, 480, 1200
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -61,8 +65,10 @@ def make_batch(global_ids, total, seed=0):
 
 def cpu_baseline(target_s=12.0):
     """The CPU oracle ("port": an OpenCV-free restatement, not the OpenCV-backed binary) timed on this host's
-    cores, frame-parallel, on a bounded sample of the SAME per-frame workload as the GPU step: ORBextractor x2 +
-    ComputeStereoMatches + ComputeBoW + SearchByBoW against the previous frame."""
+    cores on a bounded sample of the SAME per-frame workload as the GPU step: ORBextractor x2 +
+    ComputeStereoMatches + ComputeBoW + SearchByBoW against the previous frame.  `value` = frame-parallel on every
+    hardware thread; beside it the reference's own shapes: one thread, and two threads with the left / right extraction
+    side by side (Frame.cc:194-197)."""
     from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
@@ -74,11 +80,16 @@ def cpu_baseline(target_s=12.0):
     exts = [(O.OracleExtractor(NFEAT), O.OracleExtractor(NFEAT)) for _ in range(cores)]
     prev = [None] * cores
     rng = np.random.default_rng(7)
+    pair = ThreadPoolExecutor(2)
 
-    def work(i):
+    def work(i, two_threads=False):
         l, r = exts[i]
         f = frames[i % len(frames)]
-        _, kl, dl = l(f[0]); _, kr, dr = r(f[1])     # the reference runs the two eyes on two threads (Frame.cc:194-197); here one core does both
+        if two_threads:      # the reference's threadLeft / threadRight
+            fl, fr = pair.submit(l, f[0]), pair.submit(r, f[1])
+            (_, kl, dl), (_, kr, dr) = fl.result(), fr.result()
+        else:
+            _, kl, dl = l(f[0]); _, kr, dr = r(f[1])
         O.stereo_matches(l, r, kl, dl, kr, dr, mbf, mb)
         _, node = O.bow_transform(dl, vd, vf, 10, 6, 4)
         if prev[i] is not None:
@@ -87,14 +98,22 @@ def cpu_baseline(target_s=12.0):
         prev[i] = (kl, dl, node, (rng.random(len(kl)) < 0.8))
         return 1
 
+    def serial(two, budget):
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget:
+            n += work(0, two)
+        return n / (time.perf_counter() - t0)
+    fps1 = serial(False, target_s / 6)
+    fps2 = serial(True, target_s / 6)
     done, t0 = 0, time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
-        while time.perf_counter() - t0 < target_s:
+        while time.perf_counter() - t0 < target_s * 2 / 3:
             done += sum(ex.map(work, range(cores)))
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "stereo frames/s", "cores": cores, "kind": "port",
-            "sample": f"{done} stereo 752x480 frames, 1200 features: oracle extract x2 + stereo match + BoW descent + "
-                      f"SearchByBoW (frame-parallel on {cores} threads)"}
+            "one_thread": {"value": fps1, "cores": 1}, "two_threads_left_right": {"value": fps2, "cores": 2},
+            "sample": f"{done} stereo {W}x{H} frames, {NFEAT} features: oracle extract x2 + stereo match + BoW descent + "
+                      f"SearchByBoW (frame-parallel on {cores} threads); the 1- and 2-thread figures on ~{target_s / 6:.0f} s each"}
 
 
 def optimizer_extras(dev_index):
@@ -116,6 +135,7 @@ def optimizer_extras(dev_index):
     _, _, _, st = p.results()
     dt = (time.perf_counter() - t0) / n
     t0 = time.perf_counter(); its, *_ = O.local_ba(b); dc = time.perf_counter() - t0
+    sms, sflops, suseful = p.schur_profile(50)     # the Schur product alone, HIP events on the handle's stream
     F = 256
     probs = [make_pose_problem(600, seed=s % 8) for s in range(F)]
     dev = torch.device("cuda", dev_index)
@@ -184,8 +204,12 @@ def optimizer_extras(dev_index):
     # LocalInertialBA: 10-keyframe window + 6 fixed keyframes, 3000 points (one-shot call incl. graph upload)
     from morb_slam_amd.synth import make_inertial_ba_problem
     pi = make_inertial_ba_problem(n_opt=10, seed=1, n_points=3000)
-    prei = np.stack([O.imu_preintegrate(pi["bias"], nga, walk, pi["acc"][a:b_], pi["gyro"][a:b_], pi["dt"][a:b_])
-                     for a, b_ in zip(pi["imuStart"][:-1], pi["imuStart"][1:])])
+    nlink = len(pi["imuStart"]) - 1
+    prei = opt.PreintegrateIMU(torch.from_numpy(np.asarray(pi["imuStart"], np.int32)).to(dev), torch.from_numpy(pi["acc"]).to(dev),
+                               torch.from_numpy(pi["gyro"]).to(dev), torch.from_numpy(pi["dt"]).to(dev),
+                               torch.from_numpy(np.tile(pi["bias"], (nlink, 1)).astype(np.float32)).to(dev), nga, walk)
+    torch.cuda.synchronize(dev)
+    prei = prei.cpu().numpy()      # k_imu_preintegrate's records (bit-identical to the oracle's, tests/test_inertial_gpu.py)
     iargs = (pi["kfState"], pi["kfKind"], pi["mpPos"], pi["mpClose"], pi["eKF"], pi["eMP"], pi["eObs"], pi["eInvSigma2"], pi["iKF1"],
              pi["iKF2"], prei, pi["iRobust"], pi["iInfoScale"], pi["cam"], pi["Tbc12"])
     opt.LocalInertialBA(*iargs)
@@ -200,7 +224,13 @@ def optimizer_extras(dev_index):
     return {"pose_inertial_tracking": inertial, "local_inertial_ba": inertial_ba,
             "local_ba": {"edges": int(len(b["eKF"])), "keyframes_free_fixed": [20, 6], "points": 3000,
                          "outer_lm_iters": int(st[0]), "lm_trials": int(st[1]), "ms_per_solve": dt * 1e3,
-                         "lm_iters_per_s": float(st[0] / dt), "cpu_oracle_lm_iters_per_s": float(its / dc)},
+                         "lm_iters_per_s": float(st[0] / dt), "cpu_oracle_lm_iters_per_s": float(its / dc),
+                         # the MFMA kernel of the solve (north_star: Schur reduction on the matrix cores); peak = dense FP64 MFMA,
+                         # 256 CUs x 128 flop/clk x 2.4 GHz (tools/alu_issue.hip: v_mfma_f64_16x16x4_f64 issues every 64 cycles per SIMD)
+                         "roofline": {"bound": "mfma", "kernel": "k_schur_mfma", "achieved": sflops / (sms * 1e-3) / 1e12, "peak": 78.6,
+                                      "unit": "TFLOP/s", "frac": sflops / (sms * 1e-3) / 1e12 / 78.6, "avg_launch_ms": sms,
+                                      "flops_per_launch": sflops, "sparse_form_flops": suseful,
+                                      "note": "dense product over all landmarks (zero blocks included); ~11 us launch, latency-bound"}},
             "pose_optimization": {"frames": F, "edges_per_frame": 600, "frames_per_s": F / dtp,
                                   "cpu_oracle_frames_per_s_1core": 1.0 / dcp}}
 
@@ -276,12 +306,16 @@ def config_extras(dev_index):
 
 
 def main():
+    global W, H, NFEAT
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256,
-                    help="stereo frames per step per GPU (64 -> 62.8 k, 128 -> 65.0 k, 192 -> 67.1 k, 256 -> 69.0 k frames/s on one MI355X)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
+                    help="c2 = BASELINE configs[1] (752x480 / 1200 feat, the configuration the metric is quoted on); c4 = configs[3] (1920x1080 / 4000 feat)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="stereo frames per step per GPU (default 256 for c2: 64 -> 62.8 k, 128 -> 65.0 k, 192 -> 67.1 k, 256 -> 69.0 k frames/s "
+                         "on one MI355X in round 1; 8 for c4)")
     ap.add_argument("--sets", type=int, default=2, help="buffer sets = steps in flight (>= 2)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="join all streams at the end of every step instead of running step i's matchers underneath step "
@@ -289,6 +323,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline workload only (used for the committed profiles)")
     args = ap.parse_args()
+    W, H, NFEAT, defB = WORKLOADS[args.workload]
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -313,10 +348,11 @@ def main():
 
     from morb_slam_amd import ORBextractor, ORBmatcher, parallel
     from morb_slam_amd.synth import make_vocabulary
-    B = args.batch
+    B = args.batch or defB
     # global frame g lives on rank g % world, slot g // world (morb_slam_amd/parallel.py)
     gids = [parallel.global_frame(rank, world, s) for s in range(B)]
-    frames = torch.from_numpy(make_batch(gids, B * world, seed=0)).to(dev)      # [B, 2, H, W] resident in HBM
+    host_frames = torch.from_numpy(make_batch(gids, B * world, seed=0))
+    frames = host_frames.to(dev)                                                # [B, 2, H, W] resident in HBM
     images = frames.view(2 * B, H, W)
     # Two buffer sets (extractor handle with its pyramids, feature tables, matcher outputs): consecutive steps alternate
     # between them, so the matchers of step i -- latency-bound kernels -- run on their own streams underneath the
@@ -340,8 +376,8 @@ def main():
     vd, vf = torch.from_numpy(vd).to(dev), torch.from_numpy(vf).to(dev)
     cap = ext.max_keypoints
     # SearchByBoW pairs: left image of global frame g (as F) against left image of frame g-1 (as the reference
-    # keyframe).  One GPU: both are local.  N GPUs: g-1 lives on the previous rank -> the left-image features are
-    # all-gathered (RCCL) once per step and the pairs index the gathered pool.
+    # keyframe).  One GPU: both are local.  N GPUs: g-1 lives on the previous rank -> the left-image features travel one
+    # rank up the ring (RCCL send / recv) once per step and the pairs index the pool [own slab; received slab].
     rng = np.random.default_rng(7)
     if world == 1:
         kf_img = torch.tensor([2 * max(f - 1, 0) for f in range(B)], dtype=torch.int32, device=dev)
@@ -349,10 +385,10 @@ def main():
         has_mp = torch.from_numpy((rng.random((2 * B, cap)) < 0.8).astype(np.uint8)).to(dev)   # 80 % of KF features hold a MapPoint
         exch = None
     else:
-        kfp, frp = parallel.predecessor_pairs(rank, world, B)
+        kfp, frp = parallel.neighbour_pairs(rank, world, B)
         kf_img, f_img = torch.from_numpy(kfp).to(dev), torch.from_numpy(frp).to(dev)
-        has_mp = torch.from_numpy((rng.random((world * B, cap)) < 0.8).astype(np.uint8)).to(dev)
-        exch = parallel.FeatureExchange()
+        has_mp = torch.from_numpy((rng.random((2 * B, cap)) < 0.8).astype(np.uint8)).to(dev)
+        exch = parallel.NeighbourExchange()
 
     class BufferSet:
         def __init__(self):
@@ -366,7 +402,7 @@ def main():
     sets = [BufferSet() for _ in range(NSET)]
     nstep = 0
 
-    def step():
+    def step(src=None, src_ready=None):
         nonlocal nstep
         S = sets[nstep % NSET]
         e = exts[nstep % NSET]
@@ -377,7 +413,9 @@ def main():
             stream.wait_event(S.stereo_done)
             stream.wait_event(S.bow_done)
         S.used = True
-        e.extract_batch(images, out=S.out, stream=stream.cuda_stream)                                  # Frame::ExtractORB x2
+        if src_ready is not None:
+            stream.wait_event(src_ready)          # (H2D-inclusive variant: the upload of this step's images)
+        e.extract_batch(images if src is None else src, out=S.out, stream=stream.cuda_stream)         # Frame::ExtractORB x2
         S.ext_done.record(stream)
         mstream.wait_event(S.ext_done)
         matcher.ComputeStereoMatches(e, kps, desc, cnt, mbf, mb, out=S.st_out, stream=mstream.cuda_stream)   # Frame.cc:217
@@ -388,20 +426,23 @@ def main():
         if exch is None:
             S.match_out = bmatcher.SearchByBoW(kf_img, f_img, kps, desc, S.bow_out[1], cnt, has_mp, out=S.match_out, stream=bs)
         else:
-            with torch.cuda.stream(bstream):      # the collective is ordered after the kernels on this stream
+            with torch.cuda.stream(bstream):      # the transfer is ordered after the kernels on this stream
                 pk, pd, pc, pn = exch.exchange(kps[0::2], desc[0::2], cnt[0::2], S.bow_out[1][0::2])   # left images only
             S.match_out = bmatcher.SearchByBoW(kf_img, f_img, pk, pd, pn, pc, has_mp, out=S.match_out, stream=bs)
         S.bow_done.record(bstream)
         if NSET == 1:                             # un-pipelined: the step ends when all streams are done
             stream.wait_stream(bstream)
 
-    def sync_all():
+    def sync_streams():
         for es in estreams:
             es.synchronize()
         mstream.synchronize()
         bstream.synchronize()
         stream.synchronize()
         torch.cuda.synchronize(dev)
+
+    def sync_all():
+        sync_streams()
         if dist is not None:
             dist.barrier()
 
@@ -413,12 +454,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    for es in estreams:
-        es.synchronize()
-    mstream.synchronize()
-    bstream.synchronize()
-    stream.synchronize()
-    torch.cuda.synchronize(dev)
+    sync_streams()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -441,51 +477,142 @@ def main():
     n_stereo = float((sets[0].st_out[0] >= 0).sum().item()) / B
     n_bow = float(sets[0].match_out[1].float().mean().item())
 
+    h2d = lat = None
+    if world == 1 and not args.no_extras:
+        # ---- the same steps with the images arriving over PCIe: pinned host frames, uploaded on a copy stream into one of two
+        # device buffers while the previous step computes (never `value`: the contract's number is HBM-resident)
+        pinned = host_frames.view(2 * B, H, W).pin_memory()
+        dbuf = [torch.empty_like(images) for _ in range(2)]
+        cstream = torch.cuda.Stream(device=dev)
+        up_done = [torch.cuda.Event() for _ in range(2)]
+        consumed = [torch.cuda.Event() for _ in range(2)]
+        ksteps = max(4, args.steps // 2)
+
+        def h2d_step(i):
+            b = i % 2
+            if i >= 2:
+                cstream.wait_event(consumed[b])
+            with torch.cuda.stream(cstream):
+                dbuf[b].copy_(pinned, non_blocking=True)
+            up_done[b].record(cstream)
+            es = estreams[nstep % NSET]
+            step(src=dbuf[b], src_ready=up_done[b])
+            consumed[b].record(es)
+        for i in range(2):
+            h2d_step(i)
+        sync_streams(); cstream.synchronize()
+        t1 = time.perf_counter()
+        for i in range(ksteps):
+            h2d_step(i)
+        sync_streams(); cstream.synchronize()
+        dth = (time.perf_counter() - t1) / ksteps
+        h2d = {"value": B / dth, "unit": "frames/s", "ms_per_step": dth * 1e3, "steps": ksteps,
+               "pcie_GBps": 2 * B * W * H / dth / 1e9,
+               "note": "pinned host images uploaded on a copy stream, double-buffered, overlapped with the previous step's compute"}
+        # ---- one stereo frame at a time, host image in -> host arrays out (the reference's call pattern, Frame.cc:190-226):
+        # upload 2 images, ORBextractor x2, ComputeStereoMatches, download keypoints / descriptors / counts / uRight / depth
+        one = ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank)
+        lst = torch.cuda.Stream(device=dev)
+        pin1 = host_frames[0].pin_memory()                                     # [2, H, W]
+        d1 = torch.empty((2, H, W), dtype=torch.uint8, device=dev)
+        o1 = so1 = None
+        hk = torch.empty((2, cap, 28), dtype=torch.uint8).pin_memory(); hd = torch.empty((2, cap, 32), dtype=torch.uint8).pin_memory()
+        hc = torch.empty((2,), dtype=torch.int32).pin_memory(); hu = torch.empty((1, cap), dtype=torch.float32).pin_memory()
+        hz = torch.empty((1, cap), dtype=torch.float32).pin_memory()
+
+        def one_frame():
+            nonlocal o1, so1
+            with torch.cuda.stream(lst):
+                d1.copy_(pin1, non_blocking=True)
+                o1 = one.extract_batch(d1, out=o1, stream=lst.cuda_stream)
+                so1 = matcher.ComputeStereoMatches(one, o1[0], o1[1], o1[2], mbf, mb, out=so1, stream=lst.cuda_stream)
+                hk.copy_(o1[0], non_blocking=True); hd.copy_(o1[1], non_blocking=True); hc.copy_(o1[2], non_blocking=True)
+                hu.copy_(so1[0], non_blocking=True); hz.copy_(so1[1], non_blocking=True)
+            lst.synchronize()
+        for _ in range(5):
+            one_frame()
+        t1 = time.perf_counter()
+        for _ in range(30):
+            one_frame()
+        lat_dev = (time.perf_counter() - t1) / 30
+        # and through the host-pointer ABI entry (morb_extract == ORBextractor::operator()) on two threads like Frame.cc:194-197
+        from concurrent.futures import ThreadPoolExecutor
+        eL, eR = ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank), ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank)
+        imL, imR = host_frames[0, 0].numpy(), host_frames[0, 1].numpy()
+        with ThreadPoolExecutor(2) as tp:
+            for _ in range(3):
+                a, b_ = tp.submit(eL, imL), tp.submit(eR, imR); a.result(); b_.result()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                a, b_ = tp.submit(eL, imL), tp.submit(eR, imR); a.result(); b_.result()
+            lat_host = (time.perf_counter() - t1) / 20
+        lat = {"latency_b1_ms": lat_dev * 1e3, "stages": ["H2D 2 images", "extract_left+right", "ComputeStereoMatches", "D2H keypoints/descriptors/uRight/depth"],
+               "extract_host_api_two_threads_ms": lat_host * 1e3,
+               "note": "one stereo frame per call, host image in -> host arrays out"}
+        one.close(); eL.close(); eR.close()
+
     if rank == 0:
         fps = B * world * args.steps / dt
         ab = algorithmic_bytes(W, H)
         nimg = 2 * B
-        # the dominant single streaming kernel by its launch time alone on the chip ("pyramid" is eight launches of two kernels,
-        # none of which comes close; in the pipelined region its stage time is also stretched by the co-running matchers)
-        dom = max(("blur", "fast"), key=lambda k: iso[k])
-        # dominant streaming kernel of the extractor; "fast" is ONE kernel (k_fast), so its stage time is the
-        # kernel's launch duration measured with HIP events on the launch stream
-        ach = ab[dom] * nimg / (stages[dom] * 1e-3) / 1e9    # = bytes of one launch / its mean duration
-        # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-        # runs of this same command at B = 64; profiles/r01/pmc_traffic_b64.json) — not measurable live
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_b64.json")))
-            names = {"pyramid": ["k_level0", "k_resize"], "blur": ["k_blur"], "fast": ["k_fast"]}[dom]
-            mult = {"k_resize": 7}
-            # the PMC passes ran launches of pm["images_per_launch"] images; traffic scales with the image count
-            traffic = sum((pm[k]["FETCH_SIZE_KB_per_launch"] + pm[k]["WRITE_SIZE_KB_per_launch"]) * 1024 * mult.get(k, 1)
-                          for k in names) * nimg / pm.get("images_per_launch", 128)
-        except Exception:
-            traffic = None
+        kern = {"pyramid": "k_level0+k_resize", "blur": "k_blur", "fast": "k_fast"}
+        # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this same
+        # command at B = 64; profiles/<round>/pmc_traffic_b64.json) — not measurable live
+        pm = None
+        for rnd in ("r02", "r01"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic_b64.json")))
+                break
+            except Exception:
+                pm = None
+
+        def traffic_of(stage):
+            if pm is None or args.workload != "c2":
+                return None
+            try:
+                names = {"pyramid": ["k_level0", "k_resize"], "blur": ["k_blur"], "fast": ["k_fast"]}[stage]
+                mult = {"k_resize": 7, "k_fast": pm.get("k_fast_launches", 1)}
+                return sum((pm[k]["FETCH_SIZE_KB_per_launch"] + pm[k]["WRITE_SIZE_KB_per_launch"]) * 1024 * mult.get(k, 1)
+                           for k in names) * nimg / pm.get("images_per_launch", 128)
+            except Exception:
+                return None
+
+        def roof(stage):
+            ach = ab[stage] * nimg / (stages[stage] * 1e-3) / 1e9    # algorithmic bytes of the stage's launches / their in-region time
+            return {"bound": "hbm", "kernel": kern[stage], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": traffic_of(stage), "algorithmic_bytes_per_launch": ab[stage] * nimg, "avg_launch_ms": stages[stage],
+                    # not part of the timed region: the stage alone on the chip (steps not overlapped)
+                    "isolated_avg_launch_ms": iso[stage], "isolated_frac": ab[stage] * nimg / (iso[stage] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # the dominant streaming stage of the extractor = the longest of the three by its time INSIDE the timed region (HIP
+        # events on the launch stream; "pyramid" is the eight dependent launches of k_level0 / k_resize, "fast" the two k_fast
+        # launch groups, which run side by side)
+        dom = max(("pyramid", "blur", "fast"), key=lambda k: stages[k])
+        wl = {"c2": f"BASELINE configs[1]: EuRoC-shaped stereo {W}x{H}, {NFEAT} feat", "c4": f"BASELINE configs[3]: synthetic stereo {W}x{H}, {NFEAT} feat"}[args.workload]
         line = {
-            "metric": "stereo frames/sec ORB extract+match (752x480, 1200 feat)",
+            "metric": f"stereo frames/sec ORB extract+match ({W}x{H}, {NFEAT} feat = BASELINE configs[{1 if args.workload == 'c2' else 3}])",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "EuRoC-shaped stereo 752x480, 1200 feat: ORBextractor x2 + ComputeStereoMatches + "
-                                   "ComputeBoW (synthetic k=10 L=6 vocabulary) + SearchByBoW vs previous frame",
+            "config": {"workload": wl + ": ORBextractor x2 + ComputeStereoMatches + ComputeBoW (synthetic k=10 L=6 vocabulary) + "
+                                   "SearchByBoW vs previous frame",
                        "stereo_frames_per_step_per_gpu": B, "steps_in_flight": NSET, "parallelism": f"frames dealt round-robin over {world} GPU(s)" + ("" if world == 1 else
-                                       "; one RCCL all-gather of left-image keypoints/descriptors/BoW ids per step"),
-                       "stages_in_step": ["extract_left+right", "stereo_match", "bow_transform", "search_by_bow"],
+                                       "; per step one RCCL send/recv of the left-image keypoints/descriptors/BoW ids to the next rank (ring)"),
+                       "stages_in_step": ["extract_left+right", "stereo_match", "bow_transform"] + (["feature_exchange"] if world > 1 else []) + ["search_by_bow"],
                        "mean_keypoints_per_image": float(cnt.mean()), "mean_stereo_matches_per_frame": n_stereo,
                        "mean_bow_matches_per_frame": n_bow},
-            "roofline": {"bound": "hbm", "kernel": {"pyramid": "k_level0+k_resize", "blur": "k_blur", "fast": "k_fast"}[dom],
-                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         "algorithmic_bytes_per_launch": ab[dom] * nimg, "avg_launch_ms": stages[dom],
-                         # not part of the timed region: the kernel alone on the chip (steps not overlapped)
-                         "isolated_avg_launch_ms": iso[dom], "isolated_frac": ab[dom] * nimg / (iso[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "roofline": roof(dom),
+            "stage_roofline": {k: {kk: vv for kk, vv in roof(k).items() if kk in ("kernel", "achieved", "frac", "avg_launch_ms", "isolated_avg_launch_ms", "isolated_frac", "traffic")}
+                               for k in ("pyramid", "blur", "fast")},
             "extract_stage_ms_per_step": stages,
         }
+        if h2d is not None:
+            line["h2d_inclusive"] = h2d
+        if lat is not None:
+            line["latency_b1"] = lat
         if world == 1 and not args.no_extras:
             line["extra_metrics"] = optimizer_extras(local_rank)
-            line["extra_metrics"].update(config_extras(local_rank))
+            if args.workload == "c2":
+                line["extra_metrics"].update(config_extras(local_rank))
         if world == 1 and not args.no_cpu_baseline:      # reported on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

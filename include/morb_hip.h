@@ -585,6 +585,9 @@ int morb_ba_set_stop(morb_ba_problem*, int stop);
 int morb_ba_set_mode(morb_ba_problem*, int mode);
 int morb_ba_solve(morb_ba_problem*, void* stream);
 int morb_ba_results(morb_ba_problem*, float* kfPose, float* mpPos, uint8_t* eraseFlag, int* stats2);
+/* Measurement hook (bench.py's LocalBA roofline entry; not a reference method): times the FP64-MFMA Schur product of block_solver.hpp:
+ * 354-480 on the operands the last morb_ba_solve left behind.  flops = MFMA flops issued per launch, usefulFlops = the sparse form's. */
+int morb_ba_schur_profile(morb_ba_problem*, int iters, float* msPerLaunch, double* flops, double* usefulFlops);
 
 #ifdef __cplusplus
 }

@@ -1438,6 +1438,7 @@ struct morb_ba_problem {
   int mode = 0;            // 0 = grid (one launch per LM phase, host-side accept/reject), 1 = one persistent workgroup
   int redBlocks = 0;
   morbschur::Plan schur;
+  size_t nPairEntries = 0;   // (e1, e2) observation pairs of the sparse block-pair Schur form (flop accounting only)
   double* h_scal = nullptr;  // pinned host mirror of scal[0..3]
   double* d_ldws = nullptr;  // [P][LB] panel scratch of the LDL^T when the reduced system does not fit LDS
 };
@@ -1624,6 +1625,7 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
   h.pairBlock = (const int*)up(pairBlock.data(), sizeof(int) * std::max<size_t>(pairBlock.size(), 1));
   h.pairStart = (const int*)up(pairStart.data(), sizeof(int) * pairStart.size());
   h.pairEntries = (const int2*)up(pairEntries.data(), sizeof(int2) * pairEntries.size());
+  p->nPairEntries = pairEntries.size();
   h.chunkKF = (const int*)up(chunkKF.data(), sizeof(int) * std::max<size_t>(chunkKF.size(), 1));
   h.chunkStart = (const int*)up(chunkStart.data(), sizeof(int) * std::max<size_t>(chunkStart.size(), 1));
   h.chunkEnd = (const int*)up(chunkEnd.data(), sizeof(int) * std::max<size_t>(chunkEnd.size(), 1));
@@ -1880,6 +1882,31 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
   }
   hipLaunchKernelGGL(k_g_finish, dim3(rb), dim3(GB), 0, st, d, its, trials);
   MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}
+
+// Measurement hook for bench.py's LocalBA roofline entry: the Schur product (k_schur_mfma on the operands of the last solve) launched
+// `iters` times between two HIP events on the handle's stream.  flops = the MFMA flops one launch issues (upper 32 x 32 blocks of
+// WD^T W over all landmark rows), usefulFlops = the flops of g2o's sparse block-pair form of the same complement.
+int morb_ba_schur_profile(morb_ba_problem* p, int iters, float* msPerLaunch, double* flops, double* usefulFlops) {
+  MORB_REQUIRE(p && iters > 0 && msPerLaunch && flops && usefulFlops, MORB_ERR_INVALID, "bad argument");
+  MORB_HIP_CHECK(hipSetDevice(p->opt->device));
+  hipStream_t st = p->opt->stream;
+  hipEvent_t e0, e1;
+  MORB_HIP_CHECK(hipEventCreate(&e0)); MORB_HIP_CHECK(hipEventCreate(&e1));
+  const morbschur::Plan& sp = p->schur;
+  auto launch = [&]() { hipLaunchKernelGGL(morbschur::k_schur_mfma, dim3(sp.nblk, sp.nsplit), dim3(64), 0, st, (const double*)p->h.sWD, (const double*)p->h.sW, sp.Mp, sp.ksteps, sp.stepsPerSplit, p->h.sBlocks, p->h.sPart); };
+  launch();
+  MORB_HIP_CHECK(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) launch();
+  MORB_HIP_CHECK(hipEventRecord(e1, st));
+  MORB_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  MORB_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  *msPerLaunch = ms / iters;
+  *flops = 2.0 * sp.nblk * morbschur::SB * morbschur::SB * (double)sp.nsplit * sp.stepsPerSplit * 4;
+  *usefulFlops = 2.0 * 6 * 3 * (3 + 6) * (double)p->nPairEntries;   // per (e1, e2) entry: B1 D^-1 (6x3x3) and (B1 D^-1) B2^T (6x3x6)
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return MORB_OK;
 }
 

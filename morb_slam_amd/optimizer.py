@@ -227,6 +227,13 @@ class BAProblem:
         """0 = grid (phase kernels over the whole GPU, default), 1 = one persistent workgroup."""
         check(self._L.morb_ba_set_mode(self._h, int(mode)))
 
+    def schur_profile(self, iters=50):
+        """(ms per launch, MFMA flops issued per launch, flops of the sparse block-pair form) of the Schur product."""
+        ms = C.c_float(); fl = C.c_double(); uf = C.c_double()
+        self._L.morb_ba_schur_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        check(self._L.morb_ba_schur_profile(self._h, int(iters), C.byref(ms), C.byref(fl), C.byref(uf)))
+        return ms.value, fl.value, uf.value
+
     def set_stop(self, on):
         check(self._L.morb_ba_set_stop(self._h, 1 if on else 0))
 

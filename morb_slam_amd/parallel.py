@@ -3,9 +3,12 @@
 stereo frames is dealt round-robin: global frame g lives on rank g % world, local slot g // world.  Extraction
 and the intra-frame stereo match are rank-local; matching a frame against its predecessor (SearchByBoW /
 SearchByProjection with the last frame) needs the predecessor's keypoints + descriptors, which live on the
-previous rank -> ONE all-gather of fixed-capacity slabs per batch (keypoints 28 B + descriptors 32 B + BoW node
-ids 4 B per feature, plus the counts).  xGMI is point-to-point and the slabs are a few MB, so a single
-all_gather_into_tensor per array (4 collectives per batch) is used instead of many small messages.
+PREVIOUS rank only (frame g - 1 of rank r's slot s is rank r - 1's slot s; for rank 0 it is the last rank's slot
+s - 1).  So the exchange is a ring shift, not an all-gather: every rank sends its fixed-capacity slabs (keypoints
+28 B + descriptors 32 B + BoW node ids 4 B per feature, plus the counts) to rank + 1 and receives rank - 1's —
+one point-to-point transfer per xGMI link and step, 1 / world of the bytes an all-gather would move
+(`NeighbourExchange`).  `FeatureExchange` (the all-gather of round 1) is kept for callers that need every rank's
+features (e.g. loop-closure candidates).
 
 The reference has no counterpart (it is single-process, CPU-only); this layer is new."""
 import numpy as np
@@ -75,3 +78,82 @@ class FeatureExchange:
         out = (self._gather("kps", kps), self._gather("desc", desc), self._gather("count", count),
                None if node is None else self._gather("node", node))
         return out
+
+
+def neighbour_pairs(rank, world, slots_per_rank):
+    """Pairs for NeighbourExchange's pool = [own slab (rows 0 .. S-1); previous rank's slab (rows S .. 2S-1)]:
+    (pool row of the predecessor g - 1 acting as keyframe, pool row of the frame itself).  The very first global frame
+    has no predecessor and is paired with itself."""
+    S = slots_per_rank
+    kf, fr = [], []
+    for s in range(S):
+        g = global_frame(rank, world, s)
+        if g == 0:
+            kf.append(s)
+        elif world == 1:
+            kf.append(s - 1)
+        elif rank > 0:
+            kf.append(S + s)           # rank - 1, same slot
+        else:
+            kf.append(S + s - 1)       # last rank, previous slot
+        fr.append(s)
+    return np.array(kf, np.int32), np.array(fr, np.int32)
+
+
+class NeighbourExchange:
+    """Ring shift of the per-frame feature slabs: send to rank + 1, receive from rank - 1.  `exchange` returns the pool
+    [own; received] per array (2 S rows).  nccl (RCCL): batched isend / irecv on the current stream, device to device over
+    xGMI.  gloo (tests, or ranks sharing a GPU): staged through host memory."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._pool = {}
+
+    def _shift(self, named):
+        import torch
+        pools = []
+        for name, x in named:
+            S = x.shape[0]
+            shape = (2 * S,) + tuple(x.shape[1:])
+            pool = self._pool.get(name)
+            if pool is None or pool.shape != shape or pool.dtype != x.dtype or pool.device != x.device:
+                pool = torch.empty(shape, dtype=x.dtype, device=x.device)
+                self._pool[name] = pool
+            pool[:S].copy_(x)
+            pools.append(pool)
+        if self.world == 1:
+            for pool in pools:
+                S = pool.shape[0] // 2
+                pool[S:].copy_(pool[:S])
+            return pools
+        nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
+        nccl = self.dist.get_backend(self.group) == "nccl"
+        if nccl:
+            ops = []
+            for pool in pools:
+                S = pool.shape[0] // 2
+                ops.append(self.dist.P2POp(self.dist.isend, pool[:S], nxt, self.group))
+                ops.append(self.dist.P2POp(self.dist.irecv, pool[S:], prv, self.group))
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+        else:
+            for pool in pools:
+                S = pool.shape[0] // 2
+                src = pool[:S].cpu()
+                dst = torch.empty_like(src)
+                reqs = [self.dist.isend(src, nxt, group=self.group), self.dist.irecv(dst, prv, group=self.group)]
+                for r in reqs:
+                    r.wait()
+                pool[S:].copy_(dst)
+        return pools
+
+    def exchange(self, kps, desc, count, node=None):
+        """kps [S, cap, 28] u8, desc [S, cap, 32] u8, count [S] i32, node [S, cap] i32 -> pools of 2 S rows: own slab, then
+        the previous rank's."""
+        named = [("kps", kps), ("desc", desc), ("count", count)] + ([] if node is None else [("node", node)])
+        out = self._shift(named)
+        return (out[0], out[1], out[2], out[3] if node is not None else None)

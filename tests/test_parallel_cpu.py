@@ -80,3 +80,58 @@ def test_feature_exchange_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_neighbour_pairs_index_math():
+    # pool = [own slab; previous rank's slab]: the predecessor of (rank r, slot s) is (r - 1, s), or (last rank, s - 1) for r = 0
+    for world, S in ((1, 4), (2, 3), (4, 3), (8, 2)):
+        for r in range(world):
+            kf, fr = parallel.neighbour_pairs(r, world, S)
+            assert fr.tolist() == list(range(S))
+            for s in range(S):
+                g = parallel.global_frame(r, world, s)
+                if g == 0:
+                    assert kf[s] == s
+                    continue
+                pr, ps = parallel.owner(world, g - 1)
+                if world == 1:
+                    assert kf[s] == ps
+                else:
+                    assert pr == (r - 1) % world and kf[s] == S + ps
+
+
+def _ring_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S, cap = 3, 17
+        def slab(r):
+            g = torch.Generator().manual_seed(100 + r)
+            return (torch.randint(0, 256, (S, cap, 28), dtype=torch.uint8, generator=g), torch.randint(0, 256, (S, cap, 32), dtype=torch.uint8, generator=g),
+                    torch.tensor([cap - r - s for s in range(S)], dtype=torch.int32), torch.randint(0, 100, (S, cap), dtype=torch.int32, generator=g))
+        ex = parallel.NeighbourExchange()
+        ok = True
+        for _ in range(2):     # pools are reused from call to call
+            pools = ex.exchange(*slab(rank))
+            own, prev = slab(rank), slab((rank - 1) % world)
+            for pool, a, b in zip(pools, own, prev):
+                ok &= bool((pool[:S] == a).all() and (pool[S:] == b).all())
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_neighbour_exchange_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ring_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r for r, _ in res) == [0, 1] and all(ok for _, ok in res)
