@@ -62,10 +62,13 @@ class ORBextractor {
     if (n) std::memcpy(static_cast<void*>(_keypoints.data()), k.data(), sizeof(morb_keypoint) * n);
     if (n == 0) _descriptors.release();
     else { _descriptors.create(n, 32, CV_8U); std::memcpy(_descriptors.getMat().data, d.data(), (size_t)n * 32); }
-    refreshPyramid();
     return mono;
   }
-  std::vector<cv::Mat> mvImagePyramid;  // reference: public, read by Frame::ComputeStereoMatches (Frame.cc:895)
+  // reference: public member read by Frame::ComputeStereoMatches (Frame.cc:895).  The stereo matcher of this library reads the
+  // pyramids where they are (morb_stereo_match_batch takes the extractor handles), so operator() no longer downloads eight padded
+  // levels per call; a caller that still wants host copies asks for them.
+  std::vector<cv::Mat> mvImagePyramid;
+  void DownloadImagePyramid() { refreshPyramid(); }
 #else
   int operator()(const podcv::Mat8u& image, std::vector<podcv::KeyPoint>& keypoints, std::vector<uint8_t>& descriptors,
                  const std::vector<int>& vLappingArea) {

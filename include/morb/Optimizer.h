@@ -1,0 +1,87 @@
+// Drop-in adapter: ORB_SLAM3::Optimizer (reference include/Optimizer.h:46-139) over libmorb_hip.so — the two static methods of the
+// hot path, PoseOptimization and LocalBundleAdjustment.  As in ORBmatcher.h the arguments are plain views of what the reference
+// methods read from Frame / KeyFrame / MapPoint / Map and write back to them; INTEGRATION.md shows the glue inside the reference tree.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../morb_hip.h"
+#include "device_buffer.h"
+
+namespace ORB_SLAM3 {
+
+// What Optimizer::PoseOptimization(Frame* pFrame) reads and writes (Optimizer.cc:762-1051): per feature i "mvpMapPoints[i] != NULL",
+// (mvKeysUn[i].pt.x, .pt.y, mvuRight[i]), mvInvLevelSigma2[octave], the map point's world position; the camera; in / out the pose
+// (Sophus::SE3f as unit quaternion xyzw + translation, :781-783) and mvbOutlier.
+struct PoseOptimizationView {
+  int N = 0;
+  const uint8_t* hasMapPoint = nullptr;   // [N]
+  const float* obs = nullptr;             // [N][3]
+  const float* invSigma2 = nullptr;       // [N]
+  const float* worldPos = nullptr;        // [N][3]
+  float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0;
+  float pose[7] = {0, 0, 0, 1, 0, 0, 0};  // in / out
+  std::vector<uint8_t> mvbOutlier;        // in / out [N] (empty on input = all false)
+};
+// The graph Optimizer::LocalBundleAdjustment assembles (Optimizer.cc:1058-1351), flattened.
+struct LocalBAView {
+  int nKF = 0, nMP = 0, nE = 0;
+  float* kfPose = nullptr;          // [nKF][7] in / out
+  const uint8_t* kfFixed = nullptr; // [nKF]
+  float* mpPos = nullptr;           // [nMP][3] in / out
+  const int* eKF = nullptr;         // [nE]
+  const int* eMP = nullptr;         // [nE]
+  const float* eObs = nullptr;      // [nE][3] (x, y, uRight or < 0)
+  const float* eInvSigma2 = nullptr;
+  float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0;
+  bool inertialMap = false;         // pMap->IsInertial() (:1137)
+  std::vector<uint8_t> eraseFlag;   // out [nE]: observations the reference erases (:1366-1401)
+  int outerIterations = 0, lmTrials = 0;
+};
+
+class Optimizer {
+ public:
+  // static int PoseOptimization(Frame* pFrame)  Optimizer.h:86 -> number of inliers
+  static int PoseOptimization(PoseOptimizationView& f, int device = 0) {
+    using morb_adapter::DeviceBuffer;
+    if (f.N <= 0) return 0;
+    const int N = f.N;
+    DeviceBuffer<uint8_t> has(f.hasMapPoint, N), outl(N);
+    // mvbOutlier is only written for features that hold a map point (Optimizer.cc:817, :860): the others keep what they had
+    if ((int)f.mvbOutlier.size() == N) outl.upload(f.mvbOutlier.data(), N); else outl.fill_bytes(0);
+    DeviceBuffer<float> obs(f.obs, (size_t)N * 3), inv(f.invSigma2, N), Xw(f.worldPos, (size_t)N * 3), pose(f.pose, 7);
+    DeviceBuffer<int> nin(1), cnt(&N, 1);
+    check(morb_pose_optimization_batch(optimizer(device), 1, N, cnt.get(), has.get(), obs.get(), inv.get(), Xw.get(), f.fx, f.fy, f.cx, f.cy, f.mbf,
+                                       pose.get(), outl.get(), nin.get(), nullptr, nullptr));
+    morb_adapter::hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    pose.download(f.pose, 7);
+    f.mvbOutlier = outl.to_host();
+    return nin.to_host()[0];
+  }
+
+  // static void LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int&, int&, int&, int&)  Optimizer.h:67-69.  pbStopFlag is
+  // the reference's own bool (LocalMapping::mbAbortBA): it is polled at every LM iteration and trial.
+  static void LocalBundleAdjustment(LocalBAView& g, bool* pbStopFlag, int device = 0) {
+    static_assert(sizeof(bool) == 1, "pbStopFlag is read as one byte");
+    g.eraseFlag.assign(g.nE, 0);
+    int stats[2] = {0, 0};
+    check(morb_local_bundle_adjustment(optimizer(device), g.nKF, g.kfPose, g.kfFixed, g.nMP, g.mpPos, g.nE, g.eKF, g.eMP, g.eObs, g.eInvSigma2, g.fx,
+                                       g.fy, g.cx, g.cy, g.mbf, g.inertialMap ? 1 : 0, reinterpret_cast<const unsigned char*>(pbStopFlag),
+                                       g.eraseFlag.data(), stats));
+    g.outerIterations = stats[0]; g.lmTrials = stats[1];
+  }
+
+  static morb_optimizer* optimizer(int device = 0) {   // one handle per process and device, like the reference's stateless static class
+    static morb_optimizer* h[16] = {nullptr};
+    if (device < 0 || device >= 16) throw std::runtime_error("bad device");
+    if (!h[device] && morb_optimizer_create(&h[device], device) != MORB_OK) throw std::runtime_error(std::string("morb_optimizer_create: ") + morb_last_error());
+    return h[device];
+  }
+
+ private:
+  static void check(int rc) { if (rc < 0) throw std::runtime_error(morb_last_error()); }
+};
+
+}  // namespace ORB_SLAM3

@@ -439,3 +439,73 @@ def test_search_for_triangulation_fisheye():
                                                                   TUMVI_CAM_L, TUMVI_CAM_R, T4, bOnlyStereo=True)
     torch.cuda.synchronize()
     assert int(nm.sum()) == 0 and int((m12 >= 0).sum()) == 0
+
+
+def test_c3_chain_on_extracted_features():
+    """BASELINE config 3 as bench.py runs it, on EXTRACTED features: 512x512 / 1500-feature extraction with lapping areas ->
+    ComputeStereoFishEyeMatches -> PoseOptimization on the TUM-VI rig, every stage against the oracle on the same inputs."""
+    import torch
+    from morb_slam_amd import KP_DTYPE, ORBextractor, ORBmatcher, Optimizer
+    from morb_slam_amd.synth import TUMVI_CAM_L, TUMVI_CAM_R, TUMVI_T_C1_C2, make_stereo_pair
+    left, right = make_stereo_pair(512, 512, seed=104, dmin=1.0, dmax=12.0)
+    lap = np.array([[0, 511], [0, 511]], np.int32)
+    ext = ORBextractor(1500, 1.2, 8, 20, 7)
+    kps, desc, cnt, mono = ext.extract_batch(torch.from_numpy(np.stack([left, right])).cuda(), lap=lap)
+    sigma2 = np.asarray(ext.GetScaleSigmaSquares(), np.float32)
+    Rlr = TUMVI_T_C1_C2[:3, :3].astype(np.float32); tlr = TUMVI_T_C1_C2[:3, 3].astype(np.float32)
+    m = ORBmatcher()
+    o = m.ComputeStereoFishEyeMatches(kps, desc, cnt, mono, TUMVI_CAM_L, TUMVI_CAM_R, Rlr, tlr, sigma2)
+    torch.cuda.synchronize()
+    # the oracle's extraction of the same images: byte-identical features, so both matchers see the same input
+    oL, oR = O.OracleExtractor(1500), O.OracleExtractor(1500)
+    mL, kL, dL = oL(left, (0, 511)); mR, kR, dR = oR(right, (0, 511))
+    c = cnt.cpu().numpy()
+    assert kps[0, :c[0]].cpu().numpy().reshape(-1).view(KP_DTYPE).tobytes() == kL.tobytes() and int(mono[0]) == mL
+    assert kps[1, :c[1]].cpu().numpy().reshape(-1).view(KP_DTYPE).tobytes() == kR.tobytes() and int(mono[1]) == mR
+    fe = dict(kL=kL, dL=dL, monoL=mL, kR=kR, dR=dR, monoR=mR, Rlr=Rlr, tlr=tlr, camL=TUMVI_CAM_L, camR=TUMVI_CAM_R)
+    n, l2r, r2l, dep, p3 = O.stereo_fisheye_matches(fe, sigma2)
+    nl, nr = len(kL), len(kR)
+    assert int(o["nMatches"][0]) == n
+    np.testing.assert_array_equal(o["leftToRight"][0, :nl].cpu().numpy(), l2r)
+    np.testing.assert_array_equal(o["rightToLeft"][0, :nr].cpu().numpy(), r2l)
+    np.testing.assert_allclose(o["depth"][0, :nl].cpu().numpy(), dep, rtol=1e-4, atol=1e-5)
+    # PoseOptimization on the rig from these very features: map points = points in front of the extracted left / right keypoints (a
+    # KB8 ray through the keypoint at a random depth), seen from a slightly wrong initial pose
+    rng = np.random.default_rng(9)
+    Trl_m = np.linalg.inv(TUMVI_T_C1_C2)
+
+    def rays(cam, k):   # unproject by bisection on theta (test-side helper; the product's unproject is KannalaBrandt8::unproject)
+        x = (k["x"] - cam[2]) / cam[0]; y = (k["y"] - cam[3]) / cam[1]
+        rd = np.sqrt(x * x + y * y)
+        lo, hi = np.zeros_like(rd), np.full_like(rd, np.pi / 2)
+        for _ in range(50):
+            th = (lo + hi) / 2
+            f = th * (1 + cam[4] * th ** 2 + cam[5] * th ** 4 + cam[6] * th ** 6 + cam[7] * th ** 8)
+            lo = np.where(f < rd, th, lo); hi = np.where(f < rd, hi, th)
+        th = (lo + hi) / 2
+        s = np.where(rd > 1e-8, np.tan(th) / np.maximum(rd, 1e-8), 1.0)
+        return np.stack([x * s, y * s, np.ones_like(x)], 1)
+    selL = rng.choice(nl, 400, replace=False); selR = rng.choice(nr, 300, replace=False)
+    XL = rays(TUMVI_CAM_L, kL[selL]) * rng.uniform(1, 8, (400, 1))                                      # left-camera frame
+    XRr = rays(TUMVI_CAM_R, kR[selR]) * rng.uniform(1, 8, (300, 1))                                      # right-camera frame
+    XR = (XRr - Trl_m[:3, 3]) @ Trl_m[:3, :3]                                                            # -> left-camera frame (= world: true pose is identity)
+    Xw = np.concatenate([XL, XR]).astype(np.float32)
+    obs = np.concatenate([np.stack([kL[selL]["x"], kL[selL]["y"], np.full(400, -1.0)], 1), np.stack([kR[selR]["x"], kR[selR]["y"], np.full(300, -1.0)], 1)]).astype(np.float32)
+    obs[rng.random(700) < 0.1, :2] += rng.uniform(15, 40, 2)                                            # gross outliers
+    octv = np.concatenate([kL[selL]["octave"], kR[selR]["octave"]])
+    q = np.array([0.004, -0.006, 0.003, 1.0]); q /= np.linalg.norm(q)
+    from scipy.spatial.transform import Rotation
+    Trl_q = np.concatenate([Rotation.from_matrix(Trl_m[:3, :3]).as_quat(), Trl_m[:3, 3]]).astype(np.float32)
+    p = dict(hasMP=(rng.random(700) < 0.95).astype(np.uint8), obs=obs, invSigma2=(1.0 / sigma2[octv]).astype(np.float32), Xw=Xw,
+             pose0=np.concatenate([q, [0.02, -0.015, 0.03]]).astype(np.float32), Nleft=400, camL=np.asarray(TUMVI_CAM_L, np.float32),
+             camR=np.asarray(TUMVI_CAM_R, np.float32), Trl=Trl_q)
+    dev = "cuda"
+    t = [torch.from_numpy(p[k][None].copy()).to(dev) for k in ("hasMP", "obs", "invSigma2", "Xw", "pose0")]
+    nin, outl, stats = Optimizer().PoseOptimizationFisheye(t[0], t[1], t[2], t[3], t[4], torch.tensor([400], dtype=torch.int32, device=dev),
+                                                           torch.tensor([700], dtype=torch.int32, device=dev), p["camL"], p["camR"], p["Trl"])
+    torch.cuda.synchronize()
+    r, pe, oe, se = O.pose_optimization_fisheye(p)
+    assert int(nin[0]) == r and r > 400
+    assert np.abs(t[4][0].cpu().numpy() - pe).max() <= 1e-4
+    np.testing.assert_array_equal(outl[0, :700].cpu().numpy(), oe)
+    assert np.abs(pe[4:]).max() < 0.02 and np.abs(pe[:3]).max() < 0.01                                  # converged back to the identity

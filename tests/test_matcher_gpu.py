@@ -565,3 +565,27 @@ def test_bow_transform_on_loaded_vocabulary(batch, tmp_path):
             np.testing.assert_array_equal(w[i, :cn[i]], we)
             np.testing.assert_array_equal(nid[i, :cn[i]], ne)
         assert len(np.unique(w[0, :cn[0]])) > 20
+
+
+def test_stereo_matches_1080p_4000_bit_exact():
+    """ComputeStereoMatches at the size bench.py's C4 workload runs it (1920x1080, 4000 features: LDS tables scale with the
+    keypoint capacity), extraction included: mvuRight / mvDepth bit patterns equal the oracle's."""
+    import torch
+    from morb_slam_amd import KP_DTYPE, ORBextractor, ORBmatcher
+    left, right = make_stereo_pair(1920, 1080, seed=71)
+    ext = ORBextractor(4000, 1.2, 8, 20, 7)
+    kps, desc, cnt, _ = ext.extract_batch(torch.from_numpy(np.stack([left, right])).cuda())
+    u, d = ORBmatcher().ComputeStereoMatches(ext, kps, desc, cnt, MBF, MB)
+    torch.cuda.synchronize()
+    ol, orr = O.OracleExtractor(4000), O.OracleExtractor(4000)
+    _, kl, dl = ol(left)
+    _, kr, dr = orr(right)
+    c = cnt.cpu().numpy()
+    assert kps[0, :c[0]].cpu().numpy().reshape(-1).view(KP_DTYPE).tobytes() == kl.tobytes()
+    assert kps[1, :c[1]].cpu().numpy().reshape(-1).view(KP_DTYPE).tobytes() == kr.tobytes()
+    ue, de = O.stereo_matches(ol, orr, kl, dl, kr, dr, MBF, MB)
+    n = len(kl)
+    assert n > 3900
+    assert u[0, :n].cpu().numpy().view(np.uint32).tolist() == ue.view(np.uint32).tolist()
+    assert d[0, :n].cpu().numpy().view(np.uint32).tolist() == de.view(np.uint32).tolist()
+    assert int((ue >= 0).sum()) > 1500
