@@ -22,7 +22,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = os.path.join(ORACLE_DIR, "liboracle.so")
+    path = os.environ.get("MORB_ORACLE_LIB") or os.path.join(ORACLE_DIR, "liboracle.so")   # (the sanitizer test points this at its own build)
     try:
         _lib = C.CDLL(path)
     except OSError:

@@ -226,7 +226,7 @@ def test_extract_invariants():
 @pytest.fixture(scope="module")
 def qt():
     from morb_slam_amd import build
-    return C.CDLL(build.build_test_native())
+    return C.CDLL(os.environ.get("MORB_QT_HOST_LIB") or build.build_test_native())   # (the sanitizer test points this at its own build)
 
 
 def _killer(n):
@@ -560,3 +560,46 @@ def test_libm_restatement_matches_this_libm(tmp_path):
     subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-pthread", "-o", str(exe), os.path.join(ROOT, "tools", "check_libm_f32.cc")])
     out = subprocess.run([str(exe), "quick"], capture_output=True, text=True)
     assert out.returncode == 0 and "atanf 0, tanf 0, sinf 0, cosf 0, atan2f 0" in out.stdout, out.stdout[-500:]
+
+
+def test_oracle_and_quadtree_under_sanitizers(tmp_path):
+    """SURVEY 5 (race / memory-error detection, CPU side only: GPU sanitizers are not available on this pool): the oracle and the
+    host instantiation of the device quadtree are rebuilt with -fsanitize=address,undefined and the fixture / quadtree / small
+    optimiser tests are run against those builds in a child interpreter; any report aborts the child."""
+    import glob
+    import subprocess
+    import sys
+    if os.environ.get("MORB_ORACLE_LIB"):
+        pytest.skip("already inside the sanitizer run")
+    oracle_dir = os.path.join(ROOT, "oracle")
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g1", "-O1", "-march=x86-64-v3", "-ffp-contract=off",
+           "-fPIC", "-std=c++17"]
+    objs, procs = [], []
+    for src in sorted(glob.glob(os.path.join(oracle_dir, "*.cc"))):
+        obj = str(tmp_path / (os.path.basename(src) + ".o"))
+        objs.append(obj)
+        procs.append(subprocess.Popen(["g++"] + san + ["-c", "-o", obj, src]))
+    qt_so = str(tmp_path / "libqt_host_san.so")
+    procs.append(subprocess.Popen(["g++"] + san + ["-shared", "-o", qt_so, os.path.join(ROOT, "tests", "native", "qt_host.cc")]))
+    assert all(p.wait() == 0 for p in procs)
+    or_so = str(tmp_path / "liboracle_san.so")
+    subprocess.check_call(["g++"] + san + ["-shared", "-o", or_so] + objs + ["-lpthread"])
+    rt = lambda name: subprocess.check_output(["gcc", "-print-file-name=" + name], text=True).strip()
+    env = dict(os.environ, MORB_ORACLE_LIB=or_so, MORB_QT_HOST_LIB=qt_so, LD_PRELOAD=rt("libasan.so") + ":" + rt("libubsan.so"),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    sel = "golden_small or golden_inertial or quadtree_matches_oracle or introsort or pose_and_ba_oracle or knn2 or stereo_oracle or three_maxima"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", sel, "-p", "no:cacheprovider"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-3000:]
+
+
+def test_orb_pattern_table_matches_the_reference():
+    """csrc/orb_pattern.inc is the reference's bit_pattern_31_ (a constant table): re-extract it when the reference is present (build
+    container only) and compare."""
+    import subprocess
+    import sys
+    if not os.path.exists("/root/reference/src/ORBextractor.cc"):
+        pytest.skip("the reference is not present on this machine")
+    fresh = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "extract_pattern.py"), "/root/reference"], text=True)
+    assert fresh == open(os.path.join(ROOT, "morb_slam_amd", "csrc", "orb_pattern.inc")).read()
