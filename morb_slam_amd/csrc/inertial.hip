@@ -111,25 +111,30 @@ __global__ __launch_bounds__(64) void k_imu_preintegrate(int nseq, const int* __
         dP[k] = dP[k] + dV[k] * dt + 0.5f * Racc[k] * dt * dt;
         dV[k] = dV[k] + Racc[k] * dt;
       }
-      float Wacc[9], RW[9], RWJ[9];
+      // scalar factors where the C++ expressions apply them (:217-226): -dR * dt * Wacc = ((-dR) * dt) * Wacc,
+      // 0.5f * dR * dt * dt * Wacc * JRg = ((((0.5f * dR) * dt) * dt) * Wacc) * JRg
+      float Wacc[9], Rdt[9], Rhdt2[9], RdtW[9], Rhdt2W[9], RdtWJ[9], Rhdt2WJ[9];
       hatf(a, Wacc);
-      mul33f(dR, Wacc, RW);
-      mul33f(RW, JRg, RWJ);
+      for (int k = 0; k < 9; ++k) { Rdt[k] = dR[k] * dt; Rhdt2[k] = 0.5f * dR[k] * dt * dt; }
+      mul33f(Rdt, Wacc, RdtW);
+      mul33f(Rhdt2, Wacc, Rhdt2W);
+      mul33f(RdtW, JRg, RdtWJ);
+      mul33f(Rhdt2W, JRg, Rhdt2WJ);
       // A = [dRi^T 0 0; -dR dt Wacc, I, 0; -dR dt^2/2 Wacc, I dt, I],  B = [rightJ dt, 0; 0, dR dt; 0, dR dt^2/2]
       for (int k = 0; k < 81; ++k) sA[k] = 0.f;
       for (int k = 0; k < 54; ++k) sB[k] = 0.f;
       for (int k = 0; k < 9; ++k) sA[k * 9 + k] = 1.f;
       for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) {
-          sA[(3 + r) * 9 + c] = -RW[r * 3 + c] * dt; sA[(6 + r) * 9 + c] = -0.5f * RW[r * 3 + c] * dt * dt;
-          sB[(3 + r) * 6 + 3 + c] = dR[r * 3 + c] * dt; sB[(6 + r) * 6 + 3 + c] = 0.5f * dR[r * 3 + c] * dt * dt;
+          sA[(3 + r) * 9 + c] = -RdtW[r * 3 + c]; sA[(6 + r) * 9 + c] = -Rhdt2W[r * 3 + c];
+          sB[(3 + r) * 6 + 3 + c] = Rdt[r * 3 + c]; sB[(6 + r) * 6 + 3 + c] = Rhdt2[r * 3 + c];
         }
       for (int k = 0; k < 3; ++k) sA[(6 + k) * 9 + 3 + k] = dt;
       for (int k = 0; k < 9; ++k) {
-        JPa[k] = JPa[k] + JVa[k] * dt - 0.5f * dR[k] * dt * dt;
-        JPg[k] = JPg[k] + JVg[k] * dt - 0.5f * RWJ[k] * dt * dt;
-        JVa[k] = JVa[k] - dR[k] * dt;
-        JVg[k] = JVg[k] - RWJ[k] * dt;
+        JPa[k] = JPa[k] + JVa[k] * dt - Rhdt2[k];
+        JPg[k] = JPg[k] + JVg[k] * dt - Rhdt2WJ[k];
+        JVa[k] = JVa[k] - Rdt[k];
+        JVg[k] = JVg[k] - RdtWJ[k];
       }
       // IntegratedRotation (ImuTypes.cc:84-107)
       float dRi[9], rJ[9];

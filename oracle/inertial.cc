@@ -122,25 +122,30 @@ static void integrate(orc_imu_preintegrated* P, const float* a, const float* w, 
     P->dP[k] = P->dP[k] + P->dV[k] * dt + 0.5f * Racc[k] * dt * dt;
     P->dV[k] = P->dV[k] + Racc[k] * dt;
   }
-  float Wacc[9], RW[9];
+  // Scalar factors are applied where the C++ expressions apply them (operator precedence, left to right):
+  // -dR * dt * Wacc = ((-dR) * dt) * Wacc, 0.5f * dR * dt * dt * Wacc * JRg = ((((0.5f * dR) * dt) * dt) * Wacc) * JRg  (:217-226)
+  float Wacc[9], Rdt[9], Rhdt2[9], RdtW[9], Rhdt2W[9];
   hatf(acc, Wacc);
-  mul33f(P->dR, Wacc, RW);   // dR * Wacc
+  for (int k = 0; k < 9; ++k) { Rdt[k] = P->dR[k] * dt; Rhdt2[k] = 0.5f * P->dR[k] * dt * dt; }
+  mul33f(Rdt, Wacc, RdtW);       // dR * dt * Wacc
+  mul33f(Rhdt2, Wacc, Rhdt2W);   // 0.5f * dR * dt * dt * Wacc
   for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 3; ++c) {
-      A[(3 + r) * 9 + c] = -RW[r * 3 + c] * dt;
-      A[(6 + r) * 9 + c] = -0.5f * RW[r * 3 + c] * dt * dt;
-      B[(3 + r) * 6 + 3 + c] = P->dR[r * 3 + c] * dt;
-      B[(6 + r) * 6 + 3 + c] = 0.5f * P->dR[r * 3 + c] * dt * dt;
+      A[(3 + r) * 9 + c] = -RdtW[r * 3 + c];      // (negation commutes with every rounding)
+      A[(6 + r) * 9 + c] = -Rhdt2W[r * 3 + c];
+      B[(3 + r) * 6 + 3 + c] = Rdt[r * 3 + c];
+      B[(6 + r) * 6 + 3 + c] = Rhdt2[r * 3 + c];
     }
   for (int k = 0; k < 3; ++k) A[(6 + k) * 9 + 3 + k] = dt;
   // bias-correction Jacobians of position and velocity
-  float RWJ[9];
-  mul33f(RW, P->JRg, RWJ);   // dR * Wacc * JRg
+  float RdtWJ[9], Rhdt2WJ[9];
+  mul33f(RdtW, P->JRg, RdtWJ);
+  mul33f(Rhdt2W, P->JRg, Rhdt2WJ);
   for (int k = 0; k < 9; ++k) {
-    P->JPa[k] = P->JPa[k] + P->JVa[k] * dt - 0.5f * P->dR[k] * dt * dt;
-    P->JPg[k] = P->JPg[k] + P->JVg[k] * dt - 0.5f * RWJ[k] * dt * dt;
-    P->JVa[k] = P->JVa[k] - P->dR[k] * dt;
-    P->JVg[k] = P->JVg[k] - RWJ[k] * dt;
+    P->JPa[k] = P->JPa[k] + P->JVa[k] * dt - Rhdt2[k];
+    P->JPg[k] = P->JPg[k] + P->JVg[k] * dt - Rhdt2WJ[k];
+    P->JVa[k] = P->JVa[k] - Rdt[k];
+    P->JVg[k] = P->JVg[k] - RdtWJ[k];
   }
   float dRi[9], rJ[9], dRiT[9];
   integratedRotation(w, P->b, dt, dRi, rJ);
