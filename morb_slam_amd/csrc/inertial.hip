@@ -2024,7 +2024,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
         // Schur complement of the points on the FP64 matrix cores: one dense product for matrix and right-hand side
         hipLaunchKernelGGL(k_iba_pack_wd, dim3(div_up(nE, 256)), dim3(256), 0, st, D, lambda);
         hipLaunchKernelGGL(morbschur::k_schur_mfma, dim3(splan.nblk, splan.nsplit), dim3(64), 0, st, (const double*)D.sWD, (const double*)D.sW,
-                           splan.Mp, splan.ksteps, splan.stepsPerSplit, D.sBlocks, D.sPart);
+                           splan.Mp, splan.ksteps, splan.stepsPerSplit, D.sBlocks, D.sPart, (const int*)nullptr);
         hipLaunchKernelGGL(k_iba_schur_finish, dim3(div_up(4 * (Mpose * Mpose + Mpose), 256)), dim3(256), 0, st, D);
       } else if (ldsSchur) hipLaunchKernelGGL(k_iba_schur<true>, dim3(div_up(nMP, 256)), dim3(256), schurLds, st, D, lambda);   // (measurement only, MORB_SCHUR_VALU=1: round 1's form with FP64 atomics)
       else hipLaunchKernelGGL(k_iba_schur<false>, dim3(div_up(nMP, 256)), dim3(256), 0, st, D, lambda);

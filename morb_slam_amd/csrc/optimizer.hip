@@ -3,20 +3,19 @@
 // OptimizationAlgorithmLevenberg (Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:61-194) over
 // BlockSolver_6_3 (core/block_solver.hpp:354-590) with the reference's edges (src/OptimizableTypes.cpp,
 // g2o/types/types_six_dof_expmap.cpp), restated as batched kernels:
-//   * the whole LM loop (outer iterations, <= 10 trials each, accept/reject, lambda schedule, the ORB-SLAM stop
-//     rule, the 4 robust/outlier rounds of PoseOptimization) runs inside ONE launch per batch — no host round
-//     trips; control flow is workgroup-uniform, decisions are taken redundantly by every thread from values
-//     reduced through LDS.
-//   * PoseOptimization: one 256-thread workgroup per frame; residual + Jacobian + J^T W J evaluated per edge
-//     and tree-reduced (27 doubles) in a fixed order -> deterministic; the 6x6 system is solved in registers.
-//   * LocalBundleAdjustment: one 1024-thread workgroup per problem; Hpp blocks reduced per keyframe by a wave
-//     over a CSR edge list, Hll per map point by a thread, Schur complement accumulated into an LDS-resident
-//     reduced camera system (<= 132 x 132 doubles = 136 KiB of the 160 KiB LDS) with ds_add_f64, dense LDL^T
-//     by one wave, back-substitution per map point.
+//   * PoseOptimization: one 256-thread workgroup per frame, the whole LM schedule (4 robust / outlier rounds) inside ONE
+//     launch per batch; residual + Jacobian + J^T W J per edge, reduced in a fixed order (27 doubles, DPP wave sums)
+//     -> deterministic; the 6x6 system is solved in registers.
+//   * LocalBundleAdjustment, grid mode (default): one launch per LM phase over the whole chip.  Hpp blocks per keyframe by a
+//     wave per 64-edge chunk, Hll per map point by a thread; the Schur complement of the landmarks is ONE dense FP64 product
+//     WD^T W on the matrix cores (schur_mfma.h: v_mfma_f64_16x16x4_f64, split-K with fixed-order partial sums); the reduced
+//     camera system is factorised in LDS (dense_ldlt.h); back-substitution per map point.  The LM control flow
+//     (optimization_algorithm_levenberg.cpp:61-169: rho, lambda schedule, <= 10 trials, the ORB-SLAM stop rule) runs ON THE
+//     DEVICE in a one-workgroup decision kernel; every phase kernel reads the LM state and returns at once when the solve
+//     is finished or the phase is not due, so the host only keeps the queue one trial ahead and watches a mapped flag.
+//   * LocalBundleAdjustment, persistent mode: one 1024-thread workgroup runs the whole loop (many small problems side by side).
 // All arithmetic is FP64 like g2o; the reference's float leaks (float camera parameters, `const float invz` in
-// the stereo projection, float Huber deltas, float chi2 tests) are reproduced.  FP64 MFMA
-// (v_mfma_f64_16x16x4_f64) was considered for the Schur reduction; the reduced system is 120 x 120 with ~25 %
-// block density per landmark, far below the size where a dense MFMA formulation pays — see DESIGN.md.
+// the stereo projection, float Huber deltas, float chi2 tests) are reproduced.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -554,6 +553,11 @@ struct BaDev {
   double *kfPart;                       // [nChunks][27]
   double *redPart;                      // [2][redBlocks] block partial sums (chi2, scale)
   double *scal;                         // [8] device scalars: chi2, scale, ok, maxdiag
+  // device-side LM control (k_g_lm_*): the state of optimization_algorithm_levenberg.cpp's loop, and its mirror in mapped host memory
+  double *lmd;                          // [4] LMD_*: currentChi, lambda, ni, iniChi
+  int *lmi;                             // [16] LM_*
+  int *lmHost;                          // [4] mapped host memory: decided trials, done, outer iterations, trials
+  int *kfTicket;                        // [nKF] chunks of the keyframe that have delivered their partial blocks (k_g_build)
   // Schur complement on the FP64 matrix cores (schur_mfma.h): dense K-major operands, partial products, block directory
   double *sW, *sWD, *sPart;
   const int2* sBlocks;
@@ -913,9 +917,79 @@ __global__ __launch_bounds__(BA_T) void k_local_ba(const BaDev* __restrict__ pro
 // (block partials summed by one block; chunk partials summed per keyframe), so results are deterministic.
 constexpr int GB = 256;
 
-__global__ __launch_bounds__(GB) void k_g_chi2(const BaDev* __restrict__ pbp, double* __restrict__ part) {
+// LM state (grid mode, device-side control).  A phase kernel launched with gated = 1 returns at once when the solve has finished
+// (launches are queued one trial ahead of the decisions) or, for the build kernels, when this trial re-solves the same system
+// with a larger lambda (the previous trial was rejected).
+enum { LM_ITER, LM_QMAX, LM_NBAD, LM_ITS, LM_TRIALS, LM_DONE, LM_NEEDBUILD, LM_REJECTED, LM_TICKET };
+enum { LMD_CHI, LMD_LAMBDA, LMD_NI, LMD_INICHI };
+__device__ __forceinline__ bool lm_skip(const BaDev& pb, int gated) { return gated && pb.lmi[LM_DONE] != 0; }
+__device__ __forceinline__ bool lm_skip_build(const BaDev& pb, int gated) { return gated && (pb.lmi[LM_DONE] != 0 || pb.lmi[LM_NEEDBUILD] == 0); }
+__device__ __forceinline__ bool lm_stop_requested(const BaDev& pb) {   // morb_ba_set_stop's flag and the caller's *pbStopFlag as the host loop forwards it
+  return pb.stop && (__hip_atomic_load(pb.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 ||
+                     __hip_atomic_load(pb.stop + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0);
+}
+
+// after the first chi2 (sum s): currentChi, and the state at the top of the first iteration.  One thread.
+__device__ void lm_init(const BaDev& pb, double s) {
+  const bool stop = lm_stop_requested(pb);
+  pb.scal[0] = s;
+  pb.lmd[LMD_CHI] = s; pb.lmd[LMD_LAMBDA] = 0; pb.lmd[LMD_NI] = 2; pb.lmd[LMD_INICHI] = s;
+  pb.lmi[LM_ITER] = 0; pb.lmi[LM_QMAX] = 0; pb.lmi[LM_NBAD] = 0; pb.lmi[LM_ITS] = stop ? 0 : 1; pb.lmi[LM_TRIALS] = 0;
+  pb.lmi[LM_DONE] = stop ? 1 : 0; pb.lmi[LM_NEEDBUILD] = 1; pb.lmi[LM_REJECTED] = 0;
+  __hip_atomic_store(pb.lmHost + 2, stop ? 0 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(pb.lmHost + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(pb.lmHost + 1, stop ? 1 : 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// after a trial's chi2 (s0) and linear-model gain (s1): rho, accept / reject, the lambda schedule, and whether another trial /
+// iteration follows (optimization_algorithm_levenberg.cpp:99-169 with ORB-SLAM's stop rule).  One thread.
+__device__ void lm_decide(const BaDev& pb, double s0, double s1) {
+  pb.scal[0] = s0; pb.scal[1] = s1;
+  double currentChi = pb.lmd[LMD_CHI], lambda = pb.lmd[LMD_LAMBDA], ni = pb.lmd[LMD_NI];
+  const double iniChi = pb.lmd[LMD_INICHI];
+  int iter = pb.lmi[LM_ITER], qmax = pb.lmi[LM_QMAX], nBad = pb.lmi[LM_NBAD], its = pb.lmi[LM_ITS];
+  double tempChi = s0;
+  if (pb.scal[2] == 0.0) tempChi = 1.7976931348623157e308;   // the linear solve failed
+  const double rho = (currentChi - tempChi) / (s1 + 1e-3);
+  const bool accept = rho > 0 && isfinite(tempChi);
+  if (accept) {
+    double alpha = 1. - pow((2 * rho - 1), 3);
+    alpha = fmin(alpha, 2. / 3.);
+    lambda *= fmax(1. / 3., alpha);
+    ni = 2;
+    currentChi = tempChi;
+  } else {
+    lambda *= ni;
+    ni *= 2;
+  }
+  ++qmax;
+  const int trials = pb.lmi[LM_TRIALS] + 1;
+  const bool stop = lm_stop_requested(pb);
+  int done = 0, needBuild = 0;
+  if (!(rho < 0 && qmax < 10 && !stop)) {   // the trial loop ends (:139)
+    bool fin = (qmax == 10 || rho == 0);
+    if (!fin) { if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0; fin = nBad >= 3; }   // the stop rule of ORB-SLAM's g2o (:146-151)
+    if (!fin) { ++iter; fin = iter >= 10 || stop; }
+    if (fin) done = 1;
+    else { ++its; qmax = 0; needBuild = 1; pb.lmd[LMD_INICHI] = currentChi; }
+  }
+  pb.lmd[LMD_CHI] = currentChi; pb.lmd[LMD_LAMBDA] = lambda; pb.lmd[LMD_NI] = ni;
+  pb.lmi[LM_ITER] = iter; pb.lmi[LM_QMAX] = qmax; pb.lmi[LM_NBAD] = nBad; pb.lmi[LM_ITS] = its; pb.lmi[LM_TRIALS] = trials;
+  pb.lmi[LM_DONE] = done; pb.lmi[LM_NEEDBUILD] = needBuild; pb.lmi[LM_REJECTED] = accept ? 0 : 1;
+  __hip_atomic_store(pb.lmHost + 2, its, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(pb.lmHost + 3, trials, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(pb.lmHost + 1, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(pb.lmHost + 0, trials, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // decided trials: the host queues trial k + 2 when it sees k
+}
+__device__ __forceinline__ double load_l2(const double* p) {   // another workgroup of this launch wrote it: read at agent scope
+  return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// mode 0: block partial sums only (host-side LM control).  mode 1 / 2 (device-side control): the last workgroup to finish adds the
+// partials up in k_g_reduce's order and takes the LM decision of this trial (1) or sets up the first iteration (2).
+__global__ __launch_bounds__(GB) void k_g_chi2(const BaDev* __restrict__ pbp, double* __restrict__ part, const double* __restrict__ part1, int mode) {
   __shared__ double red[4];
+  __shared__ int isLast;
   const BaDev pb = *pbp;
+  if (lm_skip(pb, mode == 1)) return;
   const int gid = blockIdx.x * GB + threadIdx.x;
   if (gid < pb.nKF * 7) pb.poseEval[gid] = pb.pose[gid];
   if (gid < pb.nMP * 3) pb.ptEval[gid] = pb.pt[gid];
@@ -931,6 +1005,22 @@ __global__ __launch_bounds__(GB) void k_g_chi2(const BaDev* __restrict__ pbp, do
   }
   s = block_sum_d<4>(s, red);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
+  if (mode == 0) return;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    isLast = atomicAdd(&pb.lmi[LM_TICKET], 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!isLast) return;
+  __threadfence();
+  const int n = gridDim.x;
+  double s0 = 0, s1 = 0;
+  for (int i = threadIdx.x; i < n; i += GB) { s0 += load_l2(part + i); if (mode == 1) s1 += load_l2(part1 + i); }
+  s0 = block_sum_d<4>(s0, red);
+  s1 = block_sum_d<4>(s1, red);
+  if (threadIdx.x != 0) return;
+  pb.lmi[LM_TICKET] = 0;
+  if (mode == 1) lm_decide(pb, s0, s1); else lm_init(pb, s0);
 }
 __global__ __launch_bounds__(GB) void k_g_reduce(const double* __restrict__ part, int n, double* __restrict__ out) {
   __shared__ double red[4];
@@ -939,10 +1029,7 @@ __global__ __launch_bounds__(GB) void k_g_reduce(const double* __restrict__ part
   s = block_sum_d<4>(s, red);
   if (threadIdx.x == 0) *out = s;
 }
-__global__ __launch_bounds__(GB) void k_g_build_mp(const BaDev* __restrict__ pbp) {
-  const BaDev pb = *pbp;
-  const int m = blockIdx.x * GB + threadIdx.x;
-  if (m >= pb.nMP) return;
+__device__ __forceinline__ void build_mp_point(const BaDev& pb, int m) {
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   double Hl[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
   const double* X = pb.pt + 3 * m;
@@ -973,10 +1060,14 @@ __global__ __launch_bounds__(GB) void k_g_build_mp(const BaDev* __restrict__ pbp
   for (int k = 0; k < 9; ++k) pb.Hll[(size_t)m * 9 + k] = Hl[k];
   for (int k = 0; k < 3; ++k) pb.b[pb.P + 3 * m + k] = bl[k];
 }
-__global__ __launch_bounds__(GB) void k_g_build_kf(const BaDev* __restrict__ pbp) {
+__global__ __launch_bounds__(GB) void k_g_build_mp(const BaDev* __restrict__ pbp, int gated) {
   const BaDev pb = *pbp;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (c >= pb.nChunks) return;
+  if (lm_skip_build(pb, gated)) return;
+  const int m = blockIdx.x * GB + threadIdx.x;
+  if (m >= pb.nMP) return;
+  build_mp_point(pb, m);
+}
+__device__ __forceinline__ void build_kf_chunk(const BaDev& pb, int c, int lane) {
   const int kf = pb.chunkKF[c];
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   const SE3 T = load_se3(pb.pose + 7 * kf);
@@ -1025,8 +1116,16 @@ __global__ __launch_bounds__(GB) void k_g_build_kf(const BaDev* __restrict__ pbp
     pb.kfPart[(size_t)c * 27 + lane] = v;
   }
 }
-__global__ __launch_bounds__(64) void k_g_kf_reduce(const BaDev* __restrict__ pbp) {
+__global__ __launch_bounds__(GB) void k_g_build_kf(const BaDev* __restrict__ pbp, int gated) {
   const BaDev pb = *pbp;
+  if (lm_skip_build(pb, gated)) return;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= pb.nChunks) return;
+  build_kf_chunk(pb, c, lane);
+}
+__global__ __launch_bounds__(64) void k_g_kf_reduce(const BaDev* __restrict__ pbp, int gated) {
+  const BaDev pb = *pbp;
+  if (lm_skip_build(pb, gated)) return;
   const int kf = blockIdx.x, lane = threadIdx.x;
   const int col = pb.kfCol[kf];
   if (col < 0 || lane >= 27) return;
@@ -1038,6 +1137,44 @@ __global__ __launch_bounds__(64) void k_g_kf_reduce(const BaDev* __restrict__ pb
     const int cc = r + q;
     pb.Hpp[(size_t)col * 36 + r * 6 + cc] = s;
     pb.Hpp[(size_t)col * 36 + cc * 6 + r] = s;
+  } else {
+    pb.b[6 * col + (lane - 21)] = s;
+  }
+}
+// buildSystem in ONE launch (device-side LM control): workgroups [0, kfBlocks) take the keyframe chunks, the rest the map points;
+// the last chunk of a keyframe to deliver its partial blocks adds them up in chunk order (k_g_kf_reduce's sum, whoever runs it).
+// Two launches on two streams cost more in cross-stream events (~25 us per trial) than running side by side saved.
+__global__ __launch_bounds__(GB) void k_g_build(const BaDev* __restrict__ pbp, int kfBlocks) {
+  const BaDev pb = *pbp;
+  if (lm_skip_build(pb, 1)) return;
+  if ((int)blockIdx.x >= kfBlocks) {
+    const int m = (blockIdx.x - kfBlocks) * GB + threadIdx.x;
+    if (m < pb.nMP) build_mp_point(pb, m);
+    return;
+  }
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= pb.nChunks) return;
+  build_kf_chunk(pb, c, lane);
+  const int kf = pb.chunkKF[c];
+  int last = 0;
+  if (lane == 0) {
+    __threadfence();
+    const int nc = pb.kfChunkStart[kf + 1] - pb.kfChunkStart[kf];
+    last = atomicAdd(&pb.kfTicket[kf], 1) == nc - 1;
+    if (last) pb.kfTicket[kf] = 0;
+  }
+  if (!__builtin_amdgcn_readfirstlane(last)) return;
+  __threadfence();
+  const int col = pb.kfCol[kf];
+  if (lane >= 27) return;
+  double s = 0;
+  for (int cc = pb.kfChunkStart[kf]; cc < pb.kfChunkStart[kf + 1]; ++cc) s += load_l2(pb.kfPart + (size_t)cc * 27 + lane);
+  if (lane < 21) {
+    int r = 0, q = lane;
+    while (q >= 6 - r) { q -= 6 - r; ++r; }
+    const int c2 = r + q;
+    pb.Hpp[(size_t)col * 36 + r * 6 + c2] = s;
+    pb.Hpp[(size_t)col * 36 + c2 * 6 + r] = s;
   } else {
     pb.b[6 * col + (lane - 21)] = s;
   }
@@ -1066,11 +1203,21 @@ __device__ __forceinline__ bool pair_block(const BaDev& pb, int e, int i, int m,
   }
   return true;
 }
-__global__ __launch_bounds__(GB) void k_g_dinv_push(const BaDev* __restrict__ pbp, double lambda, double* __restrict__ Hs, int valuSchur) {
+// Start of a trial.  gated (device-side LM control): lambda comes from the LM state; a rejected previous trial is undone here
+// (pose / point backup restored instead of taken), and after an accepted one the operand W is packed too (k_g_pack_w's work).
+__global__ __launch_bounds__(GB) void k_g_dinv_push(const BaDev* __restrict__ pbp, double lambda, double* __restrict__ Hs, int valuSchur, int gated) {
   const BaDev pb = *pbp;
+  if (lm_skip(pb, gated)) return;
+  bool restore = false, packW = false;
+  if (gated) { lambda = pb.lmd[LMD_LAMBDA]; restore = pb.lmi[LM_REJECTED] != 0; packW = pb.lmi[LM_NEEDBUILD] != 0; }
   const int gid = blockIdx.x * GB + threadIdx.x;
-  if (gid < pb.nKF * 7) pb.poseBk[gid] = pb.pose[gid];
-  if (gid < pb.nMP * 3) pb.ptBk[gid] = pb.pt[gid];
+  if (restore) {
+    if (gid < pb.nKF * 7) pb.pose[gid] = pb.poseBk[gid];
+    if (gid < pb.nMP * 3) pb.pt[gid] = pb.ptBk[gid];
+  } else {
+    if (gid < pb.nKF * 7) pb.poseBk[gid] = pb.pose[gid];
+    if (gid < pb.nMP * 3) pb.ptBk[gid] = pb.pt[gid];
+  }
   if (valuSchur && gid < pb.P * pb.P) Hs[gid] = 0;
   if (gid < pb.nMP) {
     double D[9], Di[9];
@@ -1093,14 +1240,18 @@ __global__ __launch_bounds__(GB) void k_g_dinv_push(const BaDev* __restrict__ pb
 #pragma unroll
       for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < 3; ++c) {
           pb.sWD[(size_t)(3 * m + c) * pb.sMp + 6 * i + r] = B1[r * 3] * Di[c] + B1[r * 3 + 1] * Di[3 + c] + B1[r * 3 + 2] * Di[6 + c];
+          if (packW) pb.sW[(size_t)(3 * m + c) * pb.sMp + 6 * i + r] = B1[r * 3 + c];
+        }
     }
   }
+  if (packW && gid < pb.nMP * 3) pb.sW[(size_t)gid * pb.sMp + pb.P] = pb.b[pb.P + gid];
 }
 // the MFMA operand W (once per outer iteration, after the builds): Hpl of every observation, and b_l in the extra column P
-__global__ __launch_bounds__(GB) void k_g_pack_w(const BaDev* __restrict__ pbp) {
+__global__ __launch_bounds__(GB) void k_g_pack_w(const BaDev* __restrict__ pbp, int gated) {
   const BaDev pb = *pbp;
+  if (lm_skip_build(pb, gated)) return;
   const int gid = blockIdx.x * GB + threadIdx.x;
   if (gid < pb.nE) {
     const int i = pb.kfCol[pb.eKF[gid]];
@@ -1117,8 +1268,10 @@ __global__ __launch_bounds__(GB) void k_g_pack_w(const BaDev* __restrict__ pbp) 
 }
 // reduced system from the partial products: Hs = Hpp + lambda I - C (C symmetric: the upper blocks serve both triangles),
 // x[0:P] = b_p - C[:, P]
-__global__ __launch_bounds__(GB) void k_g_schur_finish(const BaDev* __restrict__ pbp, double lambda, double* __restrict__ Hs) {
+__global__ __launch_bounds__(GB) void k_g_schur_finish(const BaDev* __restrict__ pbp, double lambda, double* __restrict__ Hs, int gated) {
   const BaDev pb = *pbp;
+  if (lm_skip(pb, gated)) return;
+  if (gated) lambda = pb.lmd[LMD_LAMBDA];
   const int t = blockIdx.x * GB + threadIdx.x, gid = t >> 2, q = t & 3, P = pb.P;   // four lanes per element (schur_sum4)
   const bool mat = gid < P * P, rhs = !mat && gid < P * P + P;
   int r = 0, c = P;
@@ -1308,12 +1461,13 @@ __device__ __forceinline__ bool ldlt_block(HsPtr Hs, int pitch, int P, int tid, 
 }
 constexpr int LD_MAXP = 192;
 __global__ __launch_bounds__(LD_T) void k_g_ldlt(const BaDev* __restrict__ pbp, double* __restrict__ HsG, double* __restrict__ wsG,
-                                                 int useLds) {
+                                                 int useLds, int gated) {
   extern __shared__ double sHs[];
   __shared__ double sx[LD_MAXP];
   __shared__ double upanel[LD_MAXP * LB];
   __shared__ int sOk;
   const BaDev pb = *pbp;
+  if (lm_skip(pb, gated)) return;
   const int P = pb.P, tid = threadIdx.x;
   if (useLds) {
     const int pitch = P + 1;
@@ -1329,16 +1483,19 @@ __global__ __launch_bounds__(LD_T) void k_g_ldlt(const BaDev* __restrict__ pbp, 
   }
 }
 // the reduced camera system with its lower triangle resident in LDS (dense_ldlt.h); x = Hs^-1 x in place
-__global__ __launch_bounds__(morbdense::LT) void k_g_ldlt_lds(const BaDev* __restrict__ pbp, const double* __restrict__ HsG) {
+__global__ __launch_bounds__(morbdense::LT) void k_g_ldlt_lds(const BaDev* __restrict__ pbp, const double* __restrict__ HsG, int gated) {
   extern __shared__ double sLd[];
   __shared__ int sOk;
   const BaDev pb = *pbp;
+  if (lm_skip(pb, gated)) return;
   const bool ok = morbdense::ldlt_solve<false>(HsG, pb.x, pb.x, pb.P, sLd, &sOk);
   if (threadIdx.x == 0) pb.scal[2] = ok ? 1.0 : 0.0;
 }
-__global__ __launch_bounds__(GB) void k_g_backsub_update(const BaDev* __restrict__ pbp, double lambda, double* __restrict__ part) {
+__global__ __launch_bounds__(GB) void k_g_backsub_update(const BaDev* __restrict__ pbp, double lambda, double* __restrict__ part, int gated) {
   __shared__ double red[4];
   const BaDev pb = *pbp;
+  if (lm_skip(pb, gated)) return;
+  if (gated) lambda = pb.lmd[LMD_LAMBDA];
   const int gid = blockIdx.x * GB + threadIdx.x;
   const int P = pb.P;
   const bool ok = pb.scal[2] != 0.0;
@@ -1376,14 +1533,20 @@ __global__ __launch_bounds__(GB) void k_g_backsub_update(const BaDev* __restrict
   sc = block_sum_d<4>(sc, red);
   if (threadIdx.x == 0) part[blockIdx.x] = sc;
 }
-__global__ __launch_bounds__(GB) void k_g_pop(const BaDev* __restrict__ pbp) {
+__global__ __launch_bounds__(GB) void k_g_pop(const BaDev* __restrict__ pbp, int gated) {
   const BaDev pb = *pbp;
+  if (gated && pb.lmi[LM_REJECTED] == 0) return;   // (idempotent: a launch queued behind the last decision restores the same backup again)
   const int gid = blockIdx.x * GB + threadIdx.x;
   if (gid < pb.nKF * 7) pb.pose[gid] = pb.poseBk[gid];
   if (gid < pb.nMP * 3) pb.pt[gid] = pb.ptBk[gid];
 }
 __global__ __launch_bounds__(GB) void k_g_finish(const BaDev* __restrict__ pbp, int its, int trials) {
   const BaDev pb = *pbp;
+  const double *pose = pb.pose, *pt = pb.pt;
+  if (its < 0) {   // device-side LM control keeps the counters; a rejected last trial is undone by reading its backup
+    its = pb.lmi[LM_ITS]; trials = pb.lmi[LM_TRIALS];
+    if (pb.lmi[LM_REJECTED]) { pose = pb.poseBk; pt = pb.ptBk; }
+  }
   const int gid = blockIdx.x * GB + threadIdx.x;
   if (gid < pb.nE) {
     const int e = gid;
@@ -1392,12 +1555,29 @@ __global__ __launch_bounds__(GB) void k_g_finish(const BaDev* __restrict__ pbp, 
     double xc[3], err[3];
     se3_map(load_se3(pb.poseEval + 7 * pb.eKF[e]), pb.ptEval + 3 * pb.eMP[e], xc);
     const double c = ba_edge_error(pb.cam, pb.rig, st, xc, o, (double)pb.eInfo[e], err);
-    se3_map(load_se3(pb.pose + 7 * pb.eKF[e]), pb.pt + 3 * pb.eMP[e], xc);
+    se3_map(load_se3(pose + 7 * pb.eKF[e]), pt + 3 * pb.eMP[e], xc);
     pb.erase[e] = (c > (st ? 7.815 : 5.991) || !ba_depth_positive(pb.rig, o, xc)) ? 1 : 0;
   }
-  if (gid < pb.nKF && pb.kfCol[gid] >= 0) for (int k = 0; k < 7; ++k) pb.poseIO[7 * gid + k] = (float)pb.pose[7 * gid + k];
-  if (gid < pb.nMP * 3) pb.ptIO[gid] = (float)pb.pt[gid];
+  if (gid < pb.nKF && pb.kfCol[gid] >= 0) for (int k = 0; k < 7; ++k) pb.poseIO[7 * gid + k] = (float)pose[7 * gid + k];
+  if (gid < pb.nMP * 3) pb.ptIO[gid] = (float)pt[gid];
   if (gid == 0) { pb.stats[0] = its; pb.stats[1] = trials; }
+}
+
+// ---- device-side LM control (optimization_algorithm_levenberg.cpp:61-169 as morb_ba_solve's host loop used to run it) ----
+// first iteration, after the first build: lambda = userLambda or tau * max diagonal (computeLambdaInit, :186-194)
+__global__ __launch_bounds__(GB) void k_g_lm_lambda0(const BaDev* __restrict__ pbp) {
+  __shared__ double red[4];
+  const BaDev pb = *pbp;
+  if (pb.lmi[LM_DONE]) return;
+  if (pb.userLambda > 0) { if (threadIdx.x == 0) pb.lmd[LMD_LAMBDA] = pb.userLambda; return; }
+  double m = 0;
+  for (int i = threadIdx.x; i < pb.nFree * 6; i += GB) m = fmax(m, fabs(pb.Hpp[(size_t)(i / 6) * 36 + (i % 6) * 7]));
+  for (int i = threadIdx.x; i < pb.nMP * 3; i += GB) m = fmax(m, fabs(pb.Hll[(size_t)(i / 3) * 9 + (i % 3) * 4]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) { m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3])); pb.scal[3] = m; pb.lmd[LMD_LAMBDA] = 1e-5 * m; }
 }
 
 __global__ void k_ba_reset(BaDev pb, const float* __restrict__ pose0, const float* __restrict__ pt0) {
@@ -1430,7 +1610,7 @@ struct morb_ba_problem {
   BaDev* d_desc = nullptr;
   std::vector<void*> allocs;
   float *d_pose0 = nullptr, *d_pt0 = nullptr;
-  int* h_stop = nullptr;   // abort flag in pinned, device-mapped host memory: morb_ba_set_stop writes it without any HIP call, kernels poll it
+  int* h_stop = nullptr;   // [16] pinned, device-mapped host words: [0] abort flag (morb_ba_set_stop writes it without any HIP call, kernels poll it), [1] forwarded *pbStopFlag, [4..7] LM state mirror
   const volatile unsigned char* userStop = nullptr;   // the caller's *pbStopFlag (one-shot entry points), polled by the host LM loop
   int useLds = 1;
   size_t ldsBytes = 0;
@@ -1666,8 +1846,18 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
   h.ptIO = (float*)up(nullptr, sizeof(float) * 3 * nMP);
   h.erase = (uint8_t*)up(nullptr, nE);
   h.stats = (int*)up(nullptr, sizeof(int) * 2);
-  if (hipHostMalloc(&p->h_stop, sizeof(int), hipHostMallocMapped) != hipSuccess) { p->h_stop = nullptr; fail = true; }
-  else { *p->h_stop = 0; int* dv = nullptr; if (hipHostGetDevicePointer((void**)&dv, p->h_stop, 0) != hipSuccess) fail = true; h.stop = dv; }
+  h.lmd = (double*)up(nullptr, sizeof(double) * 4);
+  h.kfTicket = (int*)up(nullptr, sizeof(int) * std::max(nKF, 1));
+  if (!fail && hipMemset(h.kfTicket, 0, sizeof(int) * std::max(nKF, 1)) != hipSuccess) fail = true;
+  h.lmi = (int*)up(nullptr, sizeof(int) * 16);
+  // mapped host words: [0] morb_ba_set_stop, [1] the caller's *pbStopFlag as the host loop forwards it, [4..7] the LM state mirror
+  if (hipHostMalloc(&p->h_stop, sizeof(int) * 16, hipHostMallocMapped) != hipSuccess) { p->h_stop = nullptr; fail = true; }
+  else {
+    memset(p->h_stop, 0, sizeof(int) * 16);
+    int* dv = nullptr;
+    if (hipHostGetDevicePointer((void**)&dv, p->h_stop, 0) != hipSuccess) fail = true;
+    h.stop = dv; h.lmHost = dv + 4;
+  }
   h.cam = Cam{fx, fy, cx, cy, bf};
   h.rig = nullptr;
   h.userLambda = lambdaInit100 ? 100.0 : 0.0;
@@ -1775,12 +1965,51 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
     MORB_HIP_CHECK(hipGetLastError());
     return MORB_OK;
   }
-  // ---- grid mode: LM control flow on the host (optimization_algorithm_levenberg.cpp:61-169), phases on the chip ----
   const BaDev& h = p->h;
   const BaDev* d = p->d_desc;
   const int rb = p->redBlocks;
   double* part0 = h.redPart;
   double* part1 = h.redPart + rb;
+  static const bool valuSchur = [] { const char* v = getenv("MORB_SCHUR_VALU"); return v && v[0] == '1'; }();
+  static const bool hostLm = [] { const char* v = getenv("MORB_LM_HOST"); return v && v[0] == '1'; }();
+  if (!hostLm && !valuSchur) {
+    // ---- grid mode, LM control flow on the device: the host queues trial after trial, one trial ahead of the decisions, and
+    // stops when the mapped `done` word says so; kernels queued behind the last decision return at once ----
+    const int kfBlocks = div_up(std::max(h.nChunks, 1), 4);
+    volatile int* hostw = p->h_stop;
+    auto forwardStop = [&]() { if (p->userStop && *p->userStop) __atomic_store_n(p->h_stop + 1, 1, __ATOMIC_RELEASE); };
+    __atomic_store_n(p->h_stop + 1, 0, __ATOMIC_RELAXED);
+    for (int k = 4; k < 8; ++k) __atomic_store_n(p->h_stop + k, 0, __ATOMIC_RELAXED);
+    forwardStop();
+    MORB_HIP_CHECK(hipMemsetAsync(h.lmi + LM_TICKET, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_g_chi2, dim3(rb), dim3(GB), 0, st, d, part0, (const double*)part1, 2);
+    constexpr int kAhead = 1;   // trials queued beyond the last decided one
+    for (int slot = 0; slot < 100; ++slot) {
+      // buildSystem (runs only when the previous trial was accepted): keyframe chunks and map points in one launch
+      hipLaunchKernelGGL(k_g_build, dim3(kfBlocks + div_up(h.nMP, GB)), dim3(GB), 0, st, d, kfBlocks);
+      if (slot == 0) hipLaunchKernelGGL(k_g_lm_lambda0, dim3(1), dim3(GB), 0, st, d);
+      hipLaunchKernelGGL(k_g_dinv_push, dim3(rb > div_up(h.P * h.P, GB) ? rb : div_up(h.P * h.P, GB)), dim3(GB), 0, st, d, 0.0, h.HsG, 0, 1);
+      hipLaunchKernelGGL(morbschur::k_schur_mfma, dim3(p->schur.nblk, p->schur.nsplit), dim3(64), 0, st, (const double*)h.sWD,
+                         (const double*)h.sW, p->schur.Mp, p->schur.ksteps, p->schur.stepsPerSplit, h.sBlocks, h.sPart, (const int*)(h.lmi + LM_DONE));
+      hipLaunchKernelGGL(k_g_schur_finish, dim3(div_up(4 * (h.P * h.P + h.P), GB)), dim3(GB), 0, st, d, 0.0, h.HsG, 1);
+      if (p->denseLds) hipLaunchKernelGGL(k_g_ldlt_lds, dim3(1), dim3(morbdense::LT), p->denseLds, st, d, (const double*)h.HsG, 1);
+      else hipLaunchKernelGGL(k_g_ldlt, dim3(1), dim3(LD_T), p->ldsBytes, st, d, h.HsG, p->d_ldws, p->useLds, 1);
+      hipLaunchKernelGGL(k_g_backsub_update, dim3(rb), dim3(GB), 0, st, d, 0.0, part1, 1);
+      hipLaunchKernelGGL(k_g_chi2, dim3(rb), dim3(GB), 0, st, d, part0, (const double*)part1, 1);
+      MORB_HIP_CHECK(hipGetLastError());
+      // wait until all but the last kAhead queued trials are decided (or the solve is done): a spin on mapped host memory
+      unsigned spins = 0;
+      while (!__atomic_load_n(hostw + 5, __ATOMIC_ACQUIRE) && __atomic_load_n(hostw + 4, __ATOMIC_ACQUIRE) < slot + 1 - kAhead) {
+        forwardStop();
+        if ((++spins & 0xFFFFu) == 0 && hipStreamQuery(st) == hipSuccess) break;   // (everything queued has run: the words are final)
+      }
+      if (__atomic_load_n(hostw + 5, __ATOMIC_ACQUIRE)) break;
+    }
+    hipLaunchKernelGGL(k_g_finish, dim3(rb), dim3(GB), 0, st, d, -1, -1);
+    MORB_HIP_CHECK(hipGetLastError());
+    return MORB_OK;
+  }
+  // ---- grid mode, LM control flow on the host (measurement only: MORB_LM_HOST=1 or MORB_SCHUR_VALU=1; round 2's first form) ----
   volatile double* hs = p->h_scal;
   auto readScal = [&]() -> int {
     MORB_HIP_CHECK(hipMemcpyAsync(p->h_scal, h.scal, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
@@ -1788,10 +2017,9 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
     return MORB_OK;
   };
   auto chi2 = [&]() {
-    hipLaunchKernelGGL(k_g_chi2, dim3(rb), dim3(GB), 0, st, d, part0);
+    hipLaunchKernelGGL(k_g_chi2, dim3(rb), dim3(GB), 0, st, d, part0, (const double*)part1, 0);
     hipLaunchKernelGGL(k_g_reduce, dim3(1), dim3(GB), 0, st, (const double*)part0, rb, h.scal + 0);
   };
-  static const bool valuSchur = [] { const char* v = getenv("MORB_SCHUR_VALU"); return v && v[0] == '1'; }();
   int its = 0, trials = 0;
   auto stopped = [&]() -> bool { return __atomic_load_n(p->h_stop, __ATOMIC_ACQUIRE) != 0 || (p->userStop && *p->userStop); };
   if (!stopped()) {
@@ -1805,12 +2033,12 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
     auto launchBuilds = [&]() -> int {
       MORB_HIP_CHECK(hipEventRecord(p->opt->evFork, st));
       MORB_HIP_CHECK(hipStreamWaitEvent(s2, p->opt->evFork, 0));
-      hipLaunchKernelGGL(k_g_build_kf, dim3(div_up(std::max(h.nChunks, 1), 4)), dim3(GB), 0, s2, d);
-      hipLaunchKernelGGL(k_g_kf_reduce, dim3(h.nKF), dim3(64), 0, s2, d);
+      hipLaunchKernelGGL(k_g_build_kf, dim3(div_up(std::max(h.nChunks, 1), 4)), dim3(GB), 0, s2, d, 0);
+      hipLaunchKernelGGL(k_g_kf_reduce, dim3(h.nKF), dim3(64), 0, s2, d, 0);
       MORB_HIP_CHECK(hipEventRecord(p->opt->evJoin, s2));
-      hipLaunchKernelGGL(k_g_build_mp, dim3(div_up(h.nMP, GB)), dim3(GB), 0, st, d);
+      hipLaunchKernelGGL(k_g_build_mp, dim3(div_up(h.nMP, GB)), dim3(GB), 0, st, d, 0);
       MORB_HIP_CHECK(hipStreamWaitEvent(st, p->opt->evJoin, 0));
-      hipLaunchKernelGGL(k_g_pack_w, dim3(rb), dim3(GB), 0, st, d);
+      hipLaunchKernelGGL(k_g_pack_w, dim3(rb), dim3(GB), 0, st, d, 0);
       return MORB_OK;
     };
     bool built = false;   // the next iteration's system is already being built (speculatively, see below)
@@ -1832,12 +2060,12 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
       double rho = 0;
       int qmax = 0;
       do {
-        hipLaunchKernelGGL(k_g_dinv_push, dim3(rb > div_up(h.P * h.P, GB) ? rb : div_up(h.P * h.P, GB)), dim3(GB), 0, st, d, lambda, h.HsG, valuSchur ? 1 : 0);
+        hipLaunchKernelGGL(k_g_dinv_push, dim3(rb > div_up(h.P * h.P, GB) ? rb : div_up(h.P * h.P, GB)), dim3(GB), 0, st, d, lambda, h.HsG, valuSchur ? 1 : 0, 0);
         if (!valuSchur) {
           // Schur complement of the landmarks (matrix and right-hand side in one product) on the FP64 matrix cores
           hipLaunchKernelGGL(morbschur::k_schur_mfma, dim3(p->schur.nblk, p->schur.nsplit), dim3(64), 0, st, (const double*)h.sWD,
-                             (const double*)h.sW, p->schur.Mp, p->schur.ksteps, p->schur.stepsPerSplit, h.sBlocks, h.sPart);
-          hipLaunchKernelGGL(k_g_schur_finish, dim3(div_up(4 * (h.P * h.P + h.P), GB)), dim3(GB), 0, st, d, lambda, h.HsG);
+                             (const double*)h.sW, p->schur.Mp, p->schur.ksteps, p->schur.stepsPerSplit, h.sBlocks, h.sPart, (const int*)nullptr);
+          hipLaunchKernelGGL(k_g_schur_finish, dim3(div_up(4 * (h.P * h.P + h.P), GB)), dim3(GB), 0, st, d, lambda, h.HsG, 0);
         } else {
           // (measurement only, MORB_SCHUR_VALU=1: round 1's per-block-pair VALU form, kept so that profiles/ can show both)
           MORB_HIP_CHECK(hipEventRecord(p->opt->evFork, st));
@@ -1847,9 +2075,9 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
           hipLaunchKernelGGL(k_g_schur, dim3(div_up(std::max(h.nPairs, 1), 4)), dim3(GB), 0, st, d, lambda, h.HsG);
           MORB_HIP_CHECK(hipStreamWaitEvent(st, p->opt->evJoin, 0));
         }
-        if (p->denseLds) hipLaunchKernelGGL(k_g_ldlt_lds, dim3(1), dim3(morbdense::LT), p->denseLds, st, d, (const double*)h.HsG);
-        else hipLaunchKernelGGL(k_g_ldlt, dim3(1), dim3(LD_T), p->ldsBytes, st, d, h.HsG, p->d_ldws, p->useLds);
-        hipLaunchKernelGGL(k_g_backsub_update, dim3(rb), dim3(GB), 0, st, d, lambda, part1);
+        if (p->denseLds) hipLaunchKernelGGL(k_g_ldlt_lds, dim3(1), dim3(morbdense::LT), p->denseLds, st, d, (const double*)h.HsG, 0);
+        else hipLaunchKernelGGL(k_g_ldlt, dim3(1), dim3(LD_T), p->ldsBytes, st, d, h.HsG, p->d_ldws, p->useLds, 0);
+        hipLaunchKernelGGL(k_g_backsub_update, dim3(rb), dim3(GB), 0, st, d, lambda, part1, 0);
         hipLaunchKernelGGL(k_g_reduce, dim3(1), dim3(GB), 0, st, (const double*)part1, rb, h.scal + 1);
         chi2();
         // (building the NEXT iteration's system speculatively before the accept / reject decision returns was measured:
@@ -1870,7 +2098,7 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
         } else {
           lambda *= ni;
           ni *= 2;
-          hipLaunchKernelGGL(k_g_pop, dim3(rb), dim3(GB), 0, st, d);
+          hipLaunchKernelGGL(k_g_pop, dim3(rb), dim3(GB), 0, st, d, 0);
           if (spec) { rc = launchBuilds(); if (rc != MORB_OK) return rc; }
         }
         ++qmax; ++trials;
@@ -1895,7 +2123,7 @@ int morb_ba_schur_profile(morb_ba_problem* p, int iters, float* msPerLaunch, dou
   hipEvent_t e0, e1;
   MORB_HIP_CHECK(hipEventCreate(&e0)); MORB_HIP_CHECK(hipEventCreate(&e1));
   const morbschur::Plan& sp = p->schur;
-  auto launch = [&]() { hipLaunchKernelGGL(morbschur::k_schur_mfma, dim3(sp.nblk, sp.nsplit), dim3(64), 0, st, (const double*)p->h.sWD, (const double*)p->h.sW, sp.Mp, sp.ksteps, sp.stepsPerSplit, p->h.sBlocks, p->h.sPart); };
+  auto launch = [&]() { hipLaunchKernelGGL(morbschur::k_schur_mfma, dim3(sp.nblk, sp.nsplit), dim3(64), 0, st, (const double*)p->h.sWD, (const double*)p->h.sW, sp.Mp, sp.ksteps, sp.stepsPerSplit, p->h.sBlocks, p->h.sPart, (const int*)nullptr); };
   launch();
   MORB_HIP_CHECK(hipEventRecord(e0, st));
   for (int i = 0; i < iters; ++i) launch();

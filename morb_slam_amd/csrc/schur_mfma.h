@@ -27,7 +27,9 @@ constexpr int SU = 8;    // k-steps per software-pipeline group
 // Partial products: part[(split * nblk + blk) * 1024 + i * 32 + j] = sum over the split's k range of WD[k][32 bi + i] W[k][32 bj + j],
 // for the upper-triangular blocks (bi <= bj) listed in `blocks`.  Grid (nblk, nsplit), 64 threads.
 __global__ __launch_bounds__(64) void k_schur_mfma(const double* __restrict__ WD, const double* __restrict__ W, int Mp, int ksteps,
-                                                   int stepsPerSplit, const int2* __restrict__ blocks, double* __restrict__ part) {
+                                                   int stepsPerSplit, const int2* __restrict__ blocks, double* __restrict__ part,
+                                                   const int* __restrict__ skip) {
+  if (skip && *skip) return;   // (device-side LM control: the solve has finished, this launch was queued ahead)
   const int lane = threadIdx.x, r = lane & 15, kq = lane >> 4;
   const int2 blk = blocks[blockIdx.x];
   const int ks0 = blockIdx.y * stepsPerSplit, ks1 = ks0 + stepsPerSplit;   // (rows beyond the last landmark are zero)
