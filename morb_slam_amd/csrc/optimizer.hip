@@ -558,6 +558,7 @@ struct BaDev {
   int *lmi;                             // [16] LM_*
   int *lmHost;                          // [4] mapped host memory: decided trials, done, outer iterations, trials
   int *kfTicket;                        // [nKF] chunks of the keyframe that have delivered their partial blocks (k_g_build)
+  int dupPairs;                         // some (keyframe, landmark) pair carries two edges (fisheye rig: both cameras)
   // Schur complement on the FP64 matrix cores (schur_mfma.h): dense K-major operands, partial products, block directory
   double *sW, *sWD, *sPart;
   const int2* sBlocks;
@@ -1029,7 +1030,7 @@ __global__ __launch_bounds__(GB) void k_g_reduce(const double* __restrict__ part
   s = block_sum_d<4>(s, red);
   if (threadIdx.x == 0) *out = s;
 }
-__device__ __forceinline__ void build_mp_point(const BaDev& pb, int m) {
+__device__ __forceinline__ double build_mp_point(const BaDev& pb, int m) {   // -> max |diag Hll| of the point
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   double Hl[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
   const double* X = pb.pt + 3 * m;
@@ -1059,6 +1060,7 @@ __device__ __forceinline__ void build_mp_point(const BaDev& pb, int m) {
   }
   for (int k = 0; k < 9; ++k) pb.Hll[(size_t)m * 9 + k] = Hl[k];
   for (int k = 0; k < 3; ++k) pb.b[pb.P + 3 * m + k] = bl[k];
+  return fmax(fmax(fabs(Hl[0]), fabs(Hl[4])), fabs(Hl[8]));
 }
 __global__ __launch_bounds__(GB) void k_g_build_mp(const BaDev* __restrict__ pbp, int gated) {
   const BaDev pb = *pbp;
@@ -1147,9 +1149,18 @@ __global__ __launch_bounds__(64) void k_g_kf_reduce(const BaDev* __restrict__ pb
 __global__ __launch_bounds__(GB) void k_g_build(const BaDev* __restrict__ pbp, int kfBlocks) {
   const BaDev pb = *pbp;
   if (lm_skip_build(pb, 1)) return;
+  // first iteration: the largest diagonal entry of the system for computeLambdaInit (:186-194) — a max is order-independent, so an
+  // atomic on the bit pattern of the non-negative double keeps the result deterministic
+  const bool first = pb.lmi[LM_TRIALS] == 0;
+  unsigned long long* maxDiag = reinterpret_cast<unsigned long long*>(pb.scal + 3);
   if ((int)blockIdx.x >= kfBlocks) {
     const int m = (blockIdx.x - kfBlocks) * GB + threadIdx.x;
-    if (m < pb.nMP) build_mp_point(pb, m);
+    double dm = m < pb.nMP ? build_mp_point(pb, m) : 0.0;
+    if (first) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) dm = fmax(dm, __shfl_xor(dm, off, 64));
+      if ((threadIdx.x & 63) == 0) atomicMax(maxDiag, __builtin_bit_cast(unsigned long long, dm));
+    }
     return;
   }
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1175,6 +1186,7 @@ __global__ __launch_bounds__(GB) void k_g_build(const BaDev* __restrict__ pbp, i
     const int c2 = r + q;
     pb.Hpp[(size_t)col * 36 + r * 6 + c2] = s;
     pb.Hpp[(size_t)col * 36 + c2 * 6 + r] = s;
+    if (first && r == c2) atomicMax(maxDiag, __builtin_bit_cast(unsigned long long, fabs(s)));
   } else {
     pb.b[6 * col + (lane - 21)] = s;
   }
@@ -1195,6 +1207,7 @@ __global__ __launch_bounds__(GB) void k_g_maxdiag(const BaDev* __restrict__ pbp)
 // of one keyframe, i.e. through two edges — the first of them (lowest edge index) carries the sum, the others nothing.
 __device__ __forceinline__ bool pair_block(const BaDev& pb, int e, int i, int m, double* __restrict__ B) {
   for (int q = 0; q < 18; ++q) B[q] = pb.Hpl[(size_t)e * 18 + q];
+  if (!pb.dupPairs) return true;
   for (int k = pb.mpStart[m]; k < pb.mpStart[m + 1]; ++k) {
     const int e2 = pb.mpEdges[k];
     if (e2 == e || pb.kfCol[pb.eKF[e2]] != i) continue;
@@ -1209,8 +1222,14 @@ __global__ __launch_bounds__(GB) void k_g_dinv_push(const BaDev* __restrict__ pb
   const BaDev pb = *pbp;
   if (lm_skip(pb, gated)) return;
   bool restore = false, packW = false;
-  if (gated) { lambda = pb.lmd[LMD_LAMBDA]; restore = pb.lmi[LM_REJECTED] != 0; packW = pb.lmi[LM_NEEDBUILD] != 0; }
   const int gid = blockIdx.x * GB + threadIdx.x;
+  if (gated) {
+    lambda = pb.lmd[LMD_LAMBDA]; restore = pb.lmi[LM_REJECTED] != 0; packW = pb.lmi[LM_NEEDBUILD] != 0;
+    if (pb.lmi[LM_TRIALS] == 0) {   // first trial: computeLambdaInit (:186-194) from the build's max diagonal; later kernels read it from the state
+      lambda = pb.userLambda > 0 ? pb.userLambda : 1e-5 * pb.scal[3];
+      if (gid == 0) pb.lmd[LMD_LAMBDA] = lambda;
+    }
+  }
   if (restore) {
     if (gid < pb.nKF * 7) pb.pose[gid] = pb.poseBk[gid];
     if (gid < pb.nMP * 3) pb.pt[gid] = pb.ptBk[gid];
@@ -1564,22 +1583,6 @@ __global__ __launch_bounds__(GB) void k_g_finish(const BaDev* __restrict__ pbp, 
 }
 
 // ---- device-side LM control (optimization_algorithm_levenberg.cpp:61-169 as morb_ba_solve's host loop used to run it) ----
-// first iteration, after the first build: lambda = userLambda or tau * max diagonal (computeLambdaInit, :186-194)
-__global__ __launch_bounds__(GB) void k_g_lm_lambda0(const BaDev* __restrict__ pbp) {
-  __shared__ double red[4];
-  const BaDev pb = *pbp;
-  if (pb.lmi[LM_DONE]) return;
-  if (pb.userLambda > 0) { if (threadIdx.x == 0) pb.lmd[LMD_LAMBDA] = pb.userLambda; return; }
-  double m = 0;
-  for (int i = threadIdx.x; i < pb.nFree * 6; i += GB) m = fmax(m, fabs(pb.Hpp[(size_t)(i / 6) * 36 + (i % 6) * 7]));
-  for (int i = threadIdx.x; i < pb.nMP * 3; i += GB) m = fmax(m, fabs(pb.Hll[(size_t)(i / 3) * 9 + (i % 3) * 4]));
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) { m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3])); pb.scal[3] = m; pb.lmd[LMD_LAMBDA] = 1e-5 * m; }
-}
-
 __global__ void k_ba_reset(BaDev pb, const float* __restrict__ pose0, const float* __restrict__ pt0) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < pb.nKF) {
@@ -1588,6 +1591,7 @@ __global__ void k_ba_reset(BaDev pb, const float* __restrict__ pose0, const floa
     for (int k = 0; k < 7; ++k) pb.poseIO[7 * i + k] = pose0[7 * i + k];
   }
   if (i < pb.nMP * 3) pb.pt[i] = (double)pt0[i];
+  if (i == 0) { pb.lmi[LM_TICKET] = 0; pb.scal[3] = 0; }
 }
 
 }  // namespace
@@ -1747,6 +1751,11 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
     std::vector<int> a(mpStart.begin(), mpStart.end() - 1), b(kfStart.begin(), kfStart.end() - 1);
     for (int e = 0; e < nE; ++e) { mpEdges[a[eMP[e]]++] = e; kfEdges[b[eKF[e]]++] = e; }
   }
+  h.dupPairs = 0;
+  for (int m = 0; m < nMP && !h.dupPairs; ++m)
+    for (int a = mpStart[m]; a < mpStart[m + 1] && !h.dupPairs; ++a)
+      for (int b2 = a + 1; b2 < mpStart[m + 1]; ++b2)
+        if (eKF[mpEdges[a]] == eKF[mpEdges[b2]]) { h.dupPairs = 1; break; }
   // block pairs of the reduced camera system and, per pair, the (observation, observation) entries that feed it
   std::vector<int> pairBlock, pairStart;
   std::vector<int2> pairEntries;
@@ -1981,13 +1990,11 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
     __atomic_store_n(p->h_stop + 1, 0, __ATOMIC_RELAXED);
     for (int k = 4; k < 8; ++k) __atomic_store_n(p->h_stop + k, 0, __ATOMIC_RELAXED);
     forwardStop();
-    MORB_HIP_CHECK(hipMemsetAsync(h.lmi + LM_TICKET, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_g_chi2, dim3(rb), dim3(GB), 0, st, d, part0, (const double*)part1, 2);
     constexpr int kAhead = 1;   // trials queued beyond the last decided one
     for (int slot = 0; slot < 100; ++slot) {
       // buildSystem (runs only when the previous trial was accepted): keyframe chunks and map points in one launch
       hipLaunchKernelGGL(k_g_build, dim3(kfBlocks + div_up(h.nMP, GB)), dim3(GB), 0, st, d, kfBlocks);
-      if (slot == 0) hipLaunchKernelGGL(k_g_lm_lambda0, dim3(1), dim3(GB), 0, st, d);
       hipLaunchKernelGGL(k_g_dinv_push, dim3(rb > div_up(h.P * h.P, GB) ? rb : div_up(h.P * h.P, GB)), dim3(GB), 0, st, d, 0.0, h.HsG, 0, 1);
       hipLaunchKernelGGL(morbschur::k_schur_mfma, dim3(p->schur.nblk, p->schur.nsplit), dim3(64), 0, st, (const double*)h.sWD,
                          (const double*)h.sW, p->schur.Mp, p->schur.ksteps, p->schur.stepsPerSplit, h.sBlocks, h.sPart, (const int*)(h.lmi + LM_DONE));
