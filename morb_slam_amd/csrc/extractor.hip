@@ -59,12 +59,32 @@ __device__ __forceinline__ int reflect101(int p, int len) {
   return p;
 }
 
-constexpr int PY_ROWS = 8;  // rows per thread in the pyramid kernels (block = 64 x 4 threads -> 256 px x 32 rows)
+#ifndef MORB_PY_ROWS
+#define MORB_PY_ROWS 8
+#endif
+constexpr int PY_ROWS = MORB_PY_ROWS;  // rows per thread in the pyramid kernels (block = 64 x 4 threads -> 256 px x 32 rows)
+// Workgroup -> tile mapping of the pyramid kernels.  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with
+// its own L2); with the plain (x, y, image) order the tiles of one image are spread over all of them and the source rows that
+// vertically adjacent tiles share are fetched once per XCD.  Remapped, XCD k works through images k, k + 8, ... tile by tile.
+struct PyTile { int bx, by, img; };
+__device__ __forceinline__ PyTile py_tile() {
+  if ((gridDim.z & 7) == 0) {   // (measured at 512 images: pyramid 557 -> 540 us; neutral at 128)
+    const unsigned n = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), tiles = gridDim.x * gridDim.y;
+    const unsigned xcd = n & 7u, slot = n >> 3, g = slot / tiles, t = slot - g * tiles;
+    PyTile r; r.img = (int)(xcd + 8u * g); r.by = (int)(t / gridDim.x); r.bx = (int)(t - (unsigned)r.by * gridDim.x);
+    // (the divisions run on the vector ALU; the results are wave-uniform and belong in SGPRs)
+    r.img = __builtin_amdgcn_readfirstlane(r.img); r.by = __builtin_amdgcn_readfirstlane(r.by); r.bx = __builtin_amdgcn_readfirstlane(r.bx);
+    return r;
+  }
+  PyTile r; r.bx = blockIdx.x; r.by = blockIdx.y; r.img = blockIdx.z;
+  return r;
+}
 __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src, int w, int h, int stride,
                                                 size_t pitch, uint8_t* __restrict__ pyr, LevelGeom g) {
-  const int px = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-  const int py0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * PY_ROWS;
-  const int img = blockIdx.z;
+  const PyTile pt = py_tile();
+  const int px = (pt.bx * 64 + (threadIdx.x & 63)) * 4;
+  const int py0 = (pt.by * 4 + (threadIdx.x >> 6)) * PY_ROWS;
+  const int img = pt.img;
   if (px >= g.pstride) return;
   // four consecutive (reflected) source columns span at most 4 bytes: one unaligned dword load at the smallest one
   // (kept inside the source row) serves interior and pad lanes alike, so edge waves do not run two code paths
@@ -100,18 +120,25 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, LevelGeom gs, LevelGeom gd,
                                                 const ResizeTab* __restrict__ xtab,
                                                 const ResizeTab* __restrict__ ytab) {
-  const int px = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  const PyTile pt = py_tile();
+  const int px = (pt.bx * 64 + (threadIdx.x & 63)) * 4;
   // the wave's eight rows are wave-uniform: their table entries are scalar loads, fetched before any pixel
-  const int py0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * PY_ROWS;
-  const int img = blockIdx.z;
+  const int py0 = (pt.by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * PY_ROWS;
+  const int img = pt.img;
   const int H = gd.h + 2 * EDGE;
   if (px >= gd.pstride || py0 >= H) return;
+  // The tables carry PY_ROWS repeats of their last entry, so groups are read unclamped: the four column entries are 32 contiguous
+  // bytes per lane; the eight row entries are wave-uniform and 8-byte aligned (alignas on ResizeTab: a scalar load
+  // needs dword alignment), i.e. ONE s_load_dwordx16 instead of a second vector-memory round trip in front of the pixel loads.
   ResizeTab tx[4];
+  {
+    const int pxc = px < gd.w + 2 * EDGE ? px : gd.w + 2 * EDGE - 1;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) tx[k] = xtab[(px + k) < gd.w + 2 * EDGE ? (px + k) : gd.w + 2 * EDGE - 1];
+    for (int k = 0; k < 4; ++k) tx[k] = xtab[pxc + k];
+  }
   ResizeTab ty[PY_ROWS];
 #pragma unroll
-  for (int r = 0; r < PY_ROWS; ++r) ty[r] = ytab[py0 + r < H ? py0 + r : H - 1];
+  for (int r = 0; r < PY_ROWS; ++r) ty[r] = ytab[py0 + r];
   // The four outputs read source columns within a span of a few bytes — s0(px) .. s0(px+3)+1 in the interior, the
   // mirrored equivalent in the reflected pad — so two (unaligned) dword loads per source row starting at the
   // smallest column feed all four; one code path for interior and pad keeps the edge waves from running both.
@@ -136,8 +163,9 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
     for (int r = 0; r < PY_ROWS; ++r) {
       const uint8_t* r0 = sbase + (unsigned)(__umul24(ty[r].s0, gs.pstride) + base);
       const uint8_t* r1 = sbase + (unsigned)(__umul24(ty[r].s1, gs.pstride) + base);
-      a0[r] = load_u32_unaligned(r0); a1[r] = load_u32_unaligned(r0 + 4);
-      b0[r] = load_u32_unaligned(r1); b1[r] = load_u32_unaligned(r1 + 4);
+      uint2 va, vb;   // 8 unaligned bytes per source row: one vector-memory instruction each
+      __builtin_memcpy(&va, r0, 8); __builtin_memcpy(&vb, r1, 8);
+      a0[r] = va.x; a1[r] = va.y; b0[r] = vb.x; b1[r] = vb.y;
     }
 #pragma unroll
     for (int r = 0; r < PY_ROWS; ++r) {
@@ -1095,8 +1123,8 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
         t.c1 = (short)std::min(std::max(cvRoundF(f * ONE), -32768), 32767);
         interior[d] = t;
       }
-      for (int p = 0; p < dn + 2 * EDGE; ++p) {
-        int q = p - EDGE;
+      for (int p = 0; p < dn + 2 * EDGE + PY_ROWS; ++p) {   // (PY_ROWS repeats of the last entry: k_resize reads whole groups unclamped)
+        int q = std::min(p, dn + 2 * EDGE - 1) - EDGE;
         if (q < 0) q = -q;
         if (q >= dn) q = 2 * (dn - 1) - q;
         out.push_back(interior[q]);

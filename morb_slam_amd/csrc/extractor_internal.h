@@ -58,7 +58,7 @@ struct DescGeom {
   float scale[kMaxLevels], kpSize[kMaxLevels];
 };
 
-struct ResizeTab {  // one entry per padded destination column / row
+struct alignas(8) ResizeTab {  // one entry per padded destination column / row (8-byte aligned: scalar loads need dword alignment)
   short s0, s1, c0, c1;  // source index (clipped), source index + 1 (clipped), fixed-point weights (2048 = 1)
 };
 
