@@ -79,12 +79,10 @@ __device__ __forceinline__ PyTile py_tile() {
   PyTile r; r.bx = blockIdx.x; r.by = blockIdx.y; r.img = blockIdx.z;
   return r;
 }
-__global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src, int w, int h, int stride,
-                                                size_t pitch, uint8_t* __restrict__ pyr, LevelGeom g) {
-  const PyTile pt = py_tile();
-  const int px = (pt.bx * 64 + (threadIdx.x & 63)) * 4;
-  const int py0 = (pt.by * 4 + (threadIdx.x >> 6)) * PY_ROWS;
-  const int img = pt.img;
+__device__ __forceinline__ void level0_block(const uint8_t* __restrict__ src, int w, int h, int stride, size_t pitch,
+                                             uint8_t* __restrict__ pyr, const LevelGeom& g, int bx, int by, int img) {
+  const int px = (bx * 64 + (threadIdx.x & 63)) * 4;
+  const int py0 = (by * 4 + (threadIdx.x >> 6)) * PY_ROWS;
   if (px >= g.pstride) return;
   // four consecutive (reflected) source columns span at most 4 bytes: one unaligned dword load at the smallest one
   // (kept inside the source row) serves interior and pad lanes alike, so edge waves do not run two code paths
@@ -108,6 +106,11 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src,
     *reinterpret_cast<uint32_t*>(pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)py * g.pstride + px) = v;
   }
 }
+__global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src, int w, int h, int stride,
+                                                size_t pitch, uint8_t* __restrict__ pyr, LevelGeom g) {
+  const PyTile pt = py_tile();
+  level0_block(src, w, h, stride, pitch, pyr, g, pt.bx, pt.by, pt.img);
+}
 
 // K1b: level l = resize(level l-1, INTER_LINEAR) + copyMakeBorder(BORDER_REFLECT_101|ISOLATED)
 // (ORBextractor.cc:1101-1104).  Every padded pixel is computed directly from level l-1 through tables that
@@ -117,10 +120,10 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
   __builtin_memcpy(&v, p, 4);
   return v;
 }
-__global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, LevelGeom gs, LevelGeom gd,
-                                                const ResizeTab* __restrict__ xtab,
-                                                const ResizeTab* __restrict__ ytab) {
-  const PyTile pt = py_tile();
+// sbase / sstride: the source level's interior origin and row pitch (level l - 1 inside the pyramid, or — level 1 in the fused
+// kernel below — the caller's image, of which level 0's interior is a copy)
+__device__ __forceinline__ void resize_tile(const uint8_t* __restrict__ sbase, int sstride, uint8_t* __restrict__ pyr, const LevelGeom& gd,
+                                            const ResizeTab* __restrict__ xtab, const ResizeTab* __restrict__ ytab, const PyTile pt) {
   const int px = (pt.bx * 64 + (threadIdx.x & 63)) * 4;
   // the wave's eight rows are wave-uniform: their table entries are scalar loads, fetched before any pixel
   const int py0 = (pt.by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * PY_ROWS;
@@ -153,7 +156,6 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
   uint32_t selL = 0, selR = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) { selL |= (uint32_t)(tx[k].s0 - base) << (8 * k); selR |= (uint32_t)(tx[k].s1 - base) << (8 * k); }
-  const uint8_t* sbase = pyr + gs.pyrOff + (size_t)img * gs.pyrImg + (size_t)EDGE * gs.pstride + EDGE;
   uint8_t* dbase = pyr + gd.pyrOff + (size_t)img * gd.pyrImg + px;
   if (__builtin_expect(__ballot(!packed) == 0, 1)) {
     // every source dword of the wave's eight rows is requested before the first one is used: one memory round trip per
@@ -161,8 +163,8 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
     uint32_t a0[PY_ROWS], a1[PY_ROWS], b0[PY_ROWS], b1[PY_ROWS];
 #pragma unroll
     for (int r = 0; r < PY_ROWS; ++r) {
-      const uint8_t* r0 = sbase + (unsigned)(__umul24(ty[r].s0, gs.pstride) + base);
-      const uint8_t* r1 = sbase + (unsigned)(__umul24(ty[r].s1, gs.pstride) + base);
+      const uint8_t* r0 = sbase + (unsigned)(__umul24(ty[r].s0, sstride) + base);
+      const uint8_t* r1 = sbase + (unsigned)(__umul24(ty[r].s1, sstride) + base);
       uint2 va, vb;   // 8 unaligned bytes per source row: one vector-memory instruction each
       __builtin_memcpy(&va, r0, 8); __builtin_memcpy(&vb, r1, 8);
       a0[r] = va.x; a1[r] = va.y; b0[r] = vb.x; b1[r] = vb.y;
@@ -188,8 +190,8 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
   }
   for (int r = 0; r < PY_ROWS; ++r) {
     if (py0 + r >= H) break;
-    const uint8_t* r0 = sbase + (size_t)ty[r].s0 * gs.pstride;
-    const uint8_t* r1 = sbase + (size_t)ty[r].s1 * gs.pstride;
+    const uint8_t* r0 = sbase + (size_t)ty[r].s0 * sstride;
+    const uint8_t* r1 = sbase + (size_t)ty[r].s1 * sstride;
     uint32_t v = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -199,6 +201,28 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
       v |= (uint32_t)(o & 0xFF) << (8 * k);
     }
     *reinterpret_cast<uint32_t*>(dbase + (size_t)(py0 + r) * gd.pstride) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, LevelGeom gs, LevelGeom gd,
+                                                const ResizeTab* __restrict__ xtab,
+                                                const ResizeTab* __restrict__ ytab) {
+  const PyTile pt = py_tile();
+  resize_tile(pyr + gs.pyrOff + (size_t)pt.img * gs.pyrImg + (size_t)EDGE * gs.pstride + EDGE, gs.pstride, pyr, gd, xtab, ytab, pt);
+}
+// Levels 0 and 1 in one launch: level 1 is resized straight from the caller's image (level 0's interior is a copy of it, so the
+// bytes are the same) while the same workgroups also write level 0's padded copy, block t and t + tiles1 of k_level0's grid.
+// With the XCD-aware tile order all workgroups of an image run on one XCD at about the same time, so the image is fetched from
+// HBM once and level 0 is never read back by the pyramid stage.
+__global__ __launch_bounds__(256) void k_level01(const uint8_t* __restrict__ src, int w, int h, int stride, size_t pitch,
+                                                 uint8_t* __restrict__ pyr, LevelGeom g0, LevelGeom g1,
+                                                 const ResizeTab* __restrict__ xtab, const ResizeTab* __restrict__ ytab, int bx0n, int by0n) {
+  const PyTile pt = py_tile();
+  resize_tile(src + (size_t)pt.img * pitch, stride, pyr, g1, xtab, ytab, pt);
+  const int tiles1 = gridDim.x * gridDim.y, tiles0 = bx0n * by0n;
+  for (int t = pt.by * gridDim.x + pt.bx; t < tiles0; t += tiles1) {
+    const int by = t / bx0n;
+    level0_block(src, w, h, stride, pitch, pyr, g0, t - by * bx0n, by, pt.img);
   }
 }
 
@@ -1362,8 +1386,18 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   {
     const LevelGeom& g0 = e->geom[0];
     dim3 grid(div_up(g0.pstride / 4, 64), div_up(g0.h + 2 * EDGE, 4 * PY_ROWS), nimg);
-    hipLaunchKernelGGL(k_level0, grid, dim3(256), 0, st, d_images, width, height, stride, image_pitch, e->d_pyr, g0);
-    for (int l = 1; l < L; ++l) {
+    static const bool unfused = [] { const char* v = getenv("MORB_PYR_UNFUSED"); return v && v[0] == '1'; }();   // (measurement only)
+    int l0 = 1;
+    if (L >= 2 && !unfused) {
+      const LevelGeom& g1 = e->geom[1];
+      dim3 gr(div_up(g1.pstride / 4, 64), div_up(g1.h + 2 * EDGE, 4 * PY_ROWS), nimg);
+      hipLaunchKernelGGL(k_level01, gr, dim3(256), 0, st, d_images, width, height, stride, image_pitch, e->d_pyr, g0, g1,
+                         e->d_tabs + g1.xtabOff, e->d_tabs + g1.ytabOff, (int)grid.x, (int)grid.y);
+      l0 = 2;
+    } else {
+      hipLaunchKernelGGL(k_level0, grid, dim3(256), 0, st, d_images, width, height, stride, image_pitch, e->d_pyr, g0);
+    }
+    for (int l = l0; l < L; ++l) {
       const LevelGeom& g = e->geom[l];
       dim3 gr(div_up(g.pstride / 4, 64), div_up(g.h + 2 * EDGE, 4 * PY_ROWS), nimg);
       hipLaunchKernelGGL(k_resize, gr, dim3(256), 0, st, e->d_pyr, e->geom[l - 1], g, e->d_tabs + g.xtabOff,
