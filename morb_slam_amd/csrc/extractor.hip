@@ -234,27 +234,32 @@ __global__ __launch_bounds__(256) void k_level01(const uint8_t* __restrict__ src
 // row-pass results (4 x u16, packed in two dwords) in registers; every output dword (4 pixels) needs three
 // aligned dword loads of the source row (bytes x-3 .. x+8; the interior starts 19 bytes into the padded row and
 // 19 - 3 = 16, so x % 4 == 0 makes the window 4-byte aligned).  HBM traffic = read P (+halo rows) + write P.
-constexpr int BT_W = 256, BT_ROWS = 16, BT_TY = 4;   // workgroup: 64 x 4 threads -> 256 px x 64 rows per tile
+constexpr int BT_W = 256, BT_ROWS = 16, BT_TY = 8;   // workgroup: 32 lanes x 8 px wide, 8 half-waves x 16 rows tall -> 256 px x 128 rows per tile
 constexpr int BT_H = BT_ROWS * BT_TY;
 typedef unsigned short blur_u16x2 __attribute__((ext_vector_type(2)));
-// Horizontal 7-tap of four neighbouring pixels: v_dot4_u32_u8 against the packed kernel weights (18 34 48 56 | 48 34 18 0),
-// the byte windows cut out of the three loaded dwords with v_alignbyte.  Results are exact integers <= 255 * 256.
-__device__ __forceinline__ void blur_h4(const uint8_t* __restrict__ rowAligned, uint32_t h[4]) {
-  // rowAligned points at byte (x - 3) of the padded row: 12 bytes = pixels x-3 .. x+8
-  const uint32_t w0 = reinterpret_cast<const uint32_t*>(rowAligned)[0];
-  const uint32_t w1 = reinterpret_cast<const uint32_t*>(rowAligned)[1];
-  const uint32_t w2 = reinterpret_cast<const uint32_t*>(rowAligned)[2];
+// Horizontal 7-tap of eight neighbouring pixels: v_dot4_u32_u8 against the packed kernel weights (18 34 48 56 | 48 34 18 0),
+// the byte windows cut out of the four loaded dwords with v_alignbyte.  Results are exact integers <= 255 * 256.
+__device__ __forceinline__ void blur_h8(const uint8_t* __restrict__ row, uint32_t h[8]) {
+  // row points at byte (x - 3) of the padded row (8-byte aligned): 16 bytes = pixels x-3 .. x+12, ONE vector-memory instruction
+  uint4 w;
+  __builtin_memcpy(&w, __builtin_assume_aligned(row, 8), 16);
   constexpr uint32_t WA = 18u | (34u << 8) | (48u << 16) | (56u << 24), WB = 48u | (34u << 8) | (18u << 16);
-  h[0] = __builtin_amdgcn_udot4(w0, WA, __builtin_amdgcn_udot4(w1, WB, 0u, false), false);
-  h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), WA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), WB, 0u, false), false);
-  h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), WA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), WB, 0u, false), false);
-  h[3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), WA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), WB, 0u, false), false);
+  const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const uint32_t w0 = ws[g], w1 = ws[g + 1], w2 = ws[g + 2];
+    h[4 * g + 0] = __builtin_amdgcn_udot4(w0, WA, __builtin_amdgcn_udot4(w1, WB, 0u, false), false);
+    h[4 * g + 1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), WA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), WB, 0u, false), false);
+    h[4 * g + 2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), WA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), WB, 0u, false), false);
+    h[4 * g + 3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), WA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), WB, 0u, false), false);
+  }
 }
 __device__ __forceinline__ uint32_t blur_dot2(uint32_t pair, uint32_t w, uint32_t acc) {   // v_dot2_u32_u16
   return __builtin_amdgcn_udot2(__builtin_bit_cast(blur_u16x2, pair), __builtin_bit_cast(blur_u16x2, w), acc, false);
 }
-// PMC: VALU-issue bound, so the design rule is instruction count.  Vertical pass: consecutive rows' horizontal sums are
-// kept as 16-bit pairs (row r | row r+1 << 16), so the 7 taps are three v_dot2_u32_u16 and one multiply-add.
+// Vertical pass: consecutive rows' horizontal sums are kept as 16-bit pairs (row r | row r+1 << 16), so the 7 taps are three
+// v_dot2_u32_u16 and one multiply-add.  Round 2: 8 pixels per thread — one 16-byte load and one 8-byte store per row instead of
+// 3 + 1 dword accesses per 4 pixels (the texture path is priced per instruction).
 __global__ __launch_bounds__(256) void k_blur(const LevelGeom* __restrict__ geom, int nlevels,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
   int l = 0;
@@ -263,39 +268,41 @@ __global__ __launch_bounds__(256) void k_blur(const LevelGeom* __restrict__ geom
   const int t = blockIdx.x - g.blurTileBase;
   const int tx = t % g.blurTilesX, ty = t / g.blurTilesX;
   const int img = blockIdx.y;
-  const int x = tx * BT_W + (threadIdx.x & 63) * 4;
-  const int y0 = ty * BT_H + (threadIdx.x >> 6) * BT_ROWS;
+  const int x = tx * BT_W + (threadIdx.x & 31) * 8;
+  const int y0 = ty * BT_H + (threadIdx.x >> 5) * BT_ROWS;
   if (x >= g.w || y0 >= g.h) return;
   // padded-row origin of this strip: row (y + 19 - 3), byte (19 + x - 3) = 16 + x
   const uint8_t* src = pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)(EDGE + y0 - 3) * g.pstride + (EDGE - 3) + x;
   uint8_t* dst = blur + g.blurOff + (size_t)img * g.blurImg + (size_t)y0 * g.bstride + x;
-  uint32_t P[5][4], hl[4];   // P[j] = rows (y + j, y + j + 1) of the horizontal sums, hl = row y + 5
+  uint32_t P[5][8], hl[8];   // P[j] = rows (y + j, y + j + 1) of the horizontal sums, hl = row y + 5
   {
-    uint32_t h[6][4];
+    uint32_t h[6][8];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) blur_h4(src + (size_t)k * g.pstride, h[k]);
+    for (int k = 0; k < 6; ++k) blur_h8(src + (size_t)k * g.pstride, h[k]);
 #pragma unroll
     for (int j = 0; j < 5; ++j)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) P[j][k] = h[j][k] | (h[j + 1][k] << 16);
+      for (int k = 0; k < 8; ++k) P[j][k] = h[j][k] | (h[j + 1][k] << 16);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) hl[k] = h[5][k];
+    for (int k = 0; k < 8; ++k) hl[k] = h[5][k];
   }
   const int rows = (g.h - y0) < BT_ROWS ? (g.h - y0) : BT_ROWS;
   constexpr uint32_t W01 = 18u | (34u << 16), W23 = 48u | (56u << 16), W45 = 48u | (34u << 16);
 #pragma unroll
   for (int r = 0; r < BT_ROWS; ++r) {
     if (r < rows) {   // (fully unrolled: the row window rotates by renaming)
-    uint32_t hn[4], acc[4];
-    blur_h4(src + (size_t)(r + 6) * g.pstride, hn);
+    uint32_t hn[8], acc[8];
+    blur_h8(src + (size_t)(r + 6) * g.pstride, hn);
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 8; ++k)
       acc[k] = blur_dot2(P[0][k], W01, blur_dot2(P[2][k], W23, blur_dot2(P[4][k], W45, 18u * hn[k] + 32768u)));
     // acc < 2^24: the rounded output is byte 2 of each accumulator
-    const uint32_t o = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u) | __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
-    *reinterpret_cast<uint32_t*>(dst + (size_t)r * g.bstride) = o;   // columns >= w land in the row's alignment slack
+    uint2 o;
+    o.x = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u) | __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
+    o.y = __builtin_amdgcn_perm(acc[5], acc[4], 0x0c0c0602u) | __builtin_amdgcn_perm(acc[7], acc[6], 0x06020c0cu);
+    *reinterpret_cast<uint2*>(dst + (size_t)r * g.bstride) = o;   // columns >= w land in the row's alignment slack
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 8; ++k) {
       P[0][k] = P[1][k]; P[1][k] = P[2][k]; P[2][k] = P[3][k]; P[3][k] = P[4][k];
       P[4][k] = hl[k] | (hn[k] << 16);
       hl[k] = hn[k];
@@ -388,7 +395,7 @@ __device__ __forceinline__ uint32_t range_mask(int lo, int hi) {
 __global__ __launch_bounds__(FS_NT) void k_fast(const morb::FastGeom fg, const morb::FastSeg* __restrict__ segTab,
                                                  const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
                                                  int* __restrict__ candCnt, int totalCells, int cellCap, int rows,
-                                                 int iniTh, int minTh, int stopPhase) {
+                                                 int iniTh, int minTh, int stopPhase, int segMajor) {
   extern __shared__ __align__(16) uint8_t smem[];
   uint8_t* tile = smem;                                                   // [rows][FS_P] pixels (+16 bytes: the last block's right neighbour)
   uint8_t* sc = smem + rows * FS_P + 16;                                  // [rows][FS_P] strength S of corners (S > the cell's threshold), else 0
@@ -406,9 +413,9 @@ __global__ __launch_bounds__(FS_NT) void k_fast(const morb::FastGeom fg, const m
 #ifdef MORB_FAST_TIMING
   unsigned long long t0_ = wall_clock64();
 #endif
-  const int img = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int img = segMajor ? blockIdx.x : blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   // the segment's geometry: one scalar load of its host-built descriptor, the level's constants from the kernarg segment
-  const morb::FastSeg sd = segTab[blockIdx.x];
+  const morb::FastSeg sd = segTab[segMajor ? blockIdx.y : blockIdx.x];
   const int l = sd.geo & 0xFF, nc = (sd.geo >> 8) & 0xFF, tw = (sd.geo >> 16) & 0xFF, th = (int)((unsigned)sd.geo >> 24);
   const int wCell = fg.wCell[l], pstride = fg.pstride[l];
   const unsigned wMagic = fg.wCellMagic[l];
@@ -896,8 +903,8 @@ constexpr int DESC_KPW = 4;   // keypoints per wave in k_describe
 __global__ __launch_bounds__(256) void k_describe(const morb::DescGeom dg, const uint8_t* __restrict__ pyr,
                                                   const uint8_t* __restrict__ blur, const int2* __restrict__ kref,
                                                   int selPerImg, morb_keypoint* __restrict__ kps,
-                                                  uint8_t* __restrict__ desc, int cap) {
-  const int img = blockIdx.y, lane = threadIdx.x & 63;
+                                                  uint8_t* __restrict__ desc, int cap, int imgRev) {
+  const int img = imgRev ? gridDim.y - 1 - blockIdx.y : blockIdx.y, lane = threadIdx.x & 63;
   const int gi0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DESC_KPW;
   if (gi0 >= selPerImg) return;
   int4 pat[4];
@@ -1169,6 +1176,7 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
       const int rows = e->geom[sd.geo & 0xFF].hCell + 6;
       if (rows <= rowsA) { a.push_back(sd); ra = std::max(ra, rows); } else { b.push_back(sd); rb = std::max(rb, rows); }
     }
+    { const char* v = getenv("MORB_FAST_ORDER"); if (!v || atoi(v) == 2) { std::reverse(a.begin(), a.end()); std::reverse(b.begin(), b.end()); } }
     e->fastSegs[0] = (int)a.size(); e->fastSegs[1] = (int)b.size();
     e->fastRows[0] = ra; e->fastRows[1] = rb;
     segs = a;
@@ -1412,11 +1420,14 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
       MORB_HIP_CHECK(hipEventRecord(e->evFork, st));
       MORB_HIP_CHECK(hipStreamWaitEvent(e->sideStream, e->evFork, 0));
     }
+    // Dispatch order: segment-major (x = image), segments from the top level down — the reverse of the order in which the pyramid stage
+    // wrote the levels, so the most recently written (still cached) levels are read first.  Measured at 512 images: 997 -> 969 us.
+    static const int segMajor = [] { const char* v = getenv("MORB_FAST_ORDER"); return v ? atoi(v) : 2; }();   // (0 / 1: measurement only)
     for (int k = 0, s0 = 0; k < 2; s0 += e->fastSegs[k], ++k)
       if (e->fastSegs[k])
-        hipLaunchKernelGGL(k_fast, dim3(e->fastSegs[k], nimg), dim3(FS_NT), e->fastSmem[k], (k == 1 && two) ? e->sideStream : st, e->fastGeom,
-                           e->d_segTab + s0, e->d_pyr, e->d_cand, e->d_candCnt, e->totalCells, e->cellCap, e->fastRows[k], e->iniTh,
-                           e->minTh, e->fastStop);
+        hipLaunchKernelGGL(k_fast, segMajor ? dim3(nimg, e->fastSegs[k]) : dim3(e->fastSegs[k], nimg), dim3(FS_NT), e->fastSmem[k],
+                           (k == 1 && two) ? e->sideStream : st, e->fastGeom, e->d_segTab + s0, e->d_pyr, e->d_cand, e->d_candCnt, e->totalCells,
+                           e->cellCap, e->fastRows[k], e->iniTh, e->minTh, e->fastStop, segMajor ? 1 : 0);
     if (two) {
       MORB_HIP_CHECK(hipEventRecord(e->evJoin, e->sideStream));
       MORB_HIP_CHECK(hipStreamWaitEvent(st, e->evJoin, 0));
@@ -1443,8 +1454,9 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
                      e->d_lap, e->d_kref, d_count, d_mono, cap);
   mark(4);
   MORB_HIP_CHECK(hipStreamWaitEvent(st, e->evJoin, 0));
+  static const int descRev = [] { const char* v = getenv("MORB_DESC_REV"); return v ? atoi(v) : 1; }();   // images in reverse order: the blur wrote the last ones most recently (581 -> 565 us at 512 images)
   hipLaunchKernelGGL(k_describe, dim3(div_up(e->selPerImg, 4 * DESC_KPW), nimg), dim3(256), 0, st, e->descGeom, e->d_pyr,
-                     e->d_blur, e->d_kref, e->selPerImg, d_kps, d_desc, cap);
+                     e->d_blur, e->d_kref, e->selPerImg, d_kps, d_desc, cap, descRev);
   mark(5);
   MORB_HIP_CHECK(hipGetLastError());
   if (e->profiling) ++e->profCalls;
