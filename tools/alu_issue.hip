@@ -17,18 +17,23 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 enum Op { PK_MIN_U16, AND_B32, SUB_U32, DOT4_U8, MIN3_I32, MAD_I24, PERM_B32, ALIGNBYTE, LSHL_OR, FMA_F32, ADD_F64, FMA_F64, MUL_F64,
-          MFMA_F64_16, MFMA_F64_4, SAD_U8, PK_SUB_U16, BFE_U32, CNDMASK, CMP_BALLOT, DPP_ADD, MIN_I32, ADD3_U32, CNDMASK_E64, LSHRREV, NOPS };
+          MFMA_F64_16, MFMA_F64_4, SAD_U8, PK_SUB_U16, BFE_U32, CNDMASK, CMP_BALLOT, DPP_ADD, MIN_I32, ADD3_U32, CNDMASK_E64, LSHRREV, S_ADD, MIX_V_S, MIX_PK_S, MIX_V_2S, NOPS };
 static const char* kNames[NOPS] = {"v_pk_min_u16", "v_and_b32", "v_sub_u32", "v_dot4_u32_u8", "v_min3_i32", "v_mad_i32_i24",
                                    "v_perm_b32", "v_alignbyte_b32", "v_lshl_or_b32", "v_fma_f32", "v_add_f64", "v_fma_f64", "v_mul_f64",
                                    "v_mfma_f64_16x16x4_f64", "v_mfma_f64_4x4x4_4b_f64", "v_sad_u8", "v_pk_sub_u16", "v_bfe_u32", "v_cndmask_b32",
                                    "v_cmp_lt_u32 (sgpr pair dst)", "v_add_u32_dpp row_shr:1", "v_min_i32 (VOP2)", "v_add3_u32 (VOP3)",
-                                   "v_cndmask_b32 (VOP3, sgpr pair)", "v_lshrrev_b32 (VOP2)"};
+                                   "v_cndmask_b32 (VOP3, sgpr pair)", "v_lshrrev_b32 (VOP2)", "s_add_u32 (scalar ALU)",
+                                   "8 x (v_and_b32 + s_add_u32), per instruction", "8 x (v_pk_min_u16 + s_add_u32), per instruction",
+                                   "8 v_and + 4 v_pk_min + 4 s_add, per instruction"};
 
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
 template <int OP>
 __global__ __launch_bounds__(1024) void k_issue(int iters, unsigned long long* out, unsigned* sink, unsigned seed) {
   unsigned a[8], b = seed * 2654435761u + threadIdx.x, c = seed ^ 0x01020304u;
+  unsigned sa[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sa[k] = seed + k;
   double fa[8], fb = 1.0 + 1e-9 * threadIdx.x, fc = 1e-12;
   d4 acc[8];
 #pragma unroll
@@ -140,6 +145,32 @@ __global__ __launch_bounds__(1024) void k_issue(int iters, unsigned long long* o
 #define X(k) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(a[k]));
         REP8(X)
 #undef X
+      } else if constexpr (OP == S_ADD) {
+#define X(k) asm volatile("s_add_u32 %0, %0, %1" : "+s"(sa[k]) : "s"(seed) : "scc");
+        REP8(X)
+#undef X
+      } else if constexpr (OP == MIX_V_S) {
+        if (rep == 0) {
+#define X(k) asm volatile("v_and_b32 %0, %0, %2\n\ts_add_u32 %1, %1, %3" : "+v"(a[k]), "+s"(sa[k]) : "v"(b), "s"(seed) : "scc");
+        REP8(X)
+#undef X
+        }
+      } else if constexpr (OP == MIX_PK_S) {
+        if (rep == 0) {
+#define X(k) asm volatile("v_pk_min_u16 %0, %0, %2\n\ts_add_u32 %1, %1, %3" : "+v"(a[k]), "+s"(sa[k]) : "v"(b), "s"(seed) : "scc");
+        REP8(X)
+#undef X
+        }
+      } else if constexpr (OP == MIX_V_2S) {   // the k_fast mix: 0.38 scalar instructions per vector one
+        if (rep == 0) {
+#define X(k) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+        REP8(X)
+#undef X
+        } else {
+#define X(k) asm volatile("v_pk_min_u16 %0, %0, %2\n\ts_add_u32 %1, %1, %3" : "+v"(a[k]), "+s"(sa[k]) : "v"(b), "s"(seed) : "scc");
+        X(0) X(1) X(2) X(3)
+#undef X
+        }
       } else if constexpr (OP == DPP_ADD) {
 #define X(k) asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[k]));
         REP8(X)
@@ -152,7 +183,7 @@ __global__ __launch_bounds__(1024) void k_issue(int iters, unsigned long long* o
   unsigned s = 0;
   double fs = 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { s ^= a[k]; fs += fa[k] + acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3]; }
+  for (int k = 0; k < 8; ++k) { s ^= a[k] ^ sa[k]; fs += fa[k] + acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3]; }
   if (iters < 0) sink[threadIdx.x & 15] = s + (unsigned)(long long)fs;   // never true at run time: keeps the chains alive
   if ((threadIdx.x & 63) == 0) {
     const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -213,6 +244,7 @@ int main() {
   ROW(AND_B32) ROW(SUB_U32) ROW(MIN_I32) ROW(LSHRREV) ROW(CNDMASK) ROW(CNDMASK_E64) ROW(FMA_F32)
   ROW(PK_MIN_U16) ROW(PK_SUB_U16) ROW(DOT4_U8) ROW(MIN3_I32) ROW(ADD3_U32) ROW(MAD_I24) ROW(PERM_B32) ROW(ALIGNBYTE) ROW(LSHL_OR)
   ROW(SAD_U8) ROW(BFE_U32) ROW(CMP_BALLOT) ROW(DPP_ADD)
+  ROW(S_ADD) ROW(MIX_V_S) ROW(MIX_PK_S) ROW(MIX_V_2S)
   ROW(ADD_F64) ROW(FMA_F64) ROW(MUL_F64) ROW(MFMA_F64_16) ROW(MFMA_F64_4)
   return 0;
 }
