@@ -396,9 +396,11 @@ def main():
                         torch.empty((2 * B,), dtype=torch.int32, device=dev), torch.empty((2 * B,), dtype=torch.int32, device=dev))
             self.st_out = (torch.empty((B, cap), dtype=torch.float32, device=dev), torch.empty((B, cap), dtype=torch.float32, device=dev))
             self.bow_out = (torch.empty((2 * B, cap), dtype=torch.int32, device=dev), torch.empty((2 * B, cap), dtype=torch.int32, device=dev))
+            self.cnt_left = torch.empty((2 * B,), dtype=torch.int32, device=dev)
             self.match_out = None
             self.ext_done, self.stereo_done, self.bow_done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
             self.used = False
+    left_mask = torch.zeros((2 * B,), dtype=torch.int32, device=dev); left_mask[0::2] = 1
     sets = [BufferSet() for _ in range(NSET)]
     nstep = 0
 
@@ -422,9 +424,13 @@ def main():
         S.stereo_done.record(mstream)
         bs = bstream.cuda_stream
         bstream.wait_event(S.ext_done)
-        bmatcher.bow_transform(desc, cnt, vd, vf, VK, VL, 4, out=S.bow_out, stream=bs)                 # Frame::ComputeBoW
+        # Frame::ComputeBoW converts mDescriptors = the LEFT image's descriptors (Frame.cc:822-827): the right images take no part in BoW
+        # matching, so their feature count is zeroed for the BoW kernels (which then skip them)
+        with torch.cuda.stream(bstream):
+            torch.mul(cnt, left_mask, out=S.cnt_left)
+        bmatcher.bow_transform(desc, S.cnt_left, vd, vf, VK, VL, 4, out=S.bow_out, stream=bs)                 # Frame::ComputeBoW
         if exch is None:
-            S.match_out = bmatcher.SearchByBoW(kf_img, f_img, kps, desc, S.bow_out[1], cnt, has_mp, out=S.match_out, stream=bs)
+            S.match_out = bmatcher.SearchByBoW(kf_img, f_img, kps, desc, S.bow_out[1], S.cnt_left, has_mp, out=S.match_out, stream=bs)
         else:
             with torch.cuda.stream(bstream):      # the transfer is ordered after the kernels on this stream
                 pk, pd, pc, pn = exch.exchange(kps[0::2], desc[0::2], cnt[0::2], S.bow_out[1][0::2])   # left images only

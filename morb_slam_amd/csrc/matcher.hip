@@ -414,6 +414,10 @@ __global__ __launch_bounds__(256) void k_bow_sort(const int* __restrict__ node, 
   extern __shared__ unsigned long long skeys[];
   const int img = blockIdx.x, tid = threadIdx.x;
   const int n = count[img];
+  if (n == 0) {   // (an image that takes no part in BoW matching — the right images of a stereo batch — costs one store pass)
+    for (int i = tid; i < cap; i += 256) sorted[(size_t)img * cap + i] = ~0ull;
+    return;
+  }
   for (int i = tid; i < P; i += 256) {
     unsigned long long k = ~0ull;
     if (i < n) {
