@@ -1552,6 +1552,50 @@ __global__ __launch_bounds__(GB) void k_g_backsub_update(const BaDev* __restrict
   sc = block_sum_d<4>(sc, red);
   if (threadIdx.x == 0) part[blockIdx.x] = sc;
 }
+// The same step with the landmark part read from the MFMA operand W (dense rows [3 nMP][Mp], column P = b_l): 16 lanes per point,
+// lane q takes columns q, q + 16, ... of the point's three rows (coalesced 128-byte reads, all in flight at once) and the row sums are
+// DPP reductions in a fixed order — round 2's first form walked the point's edges one dependent load chain after the other (21 us).
+__global__ __launch_bounds__(GB) void k_g_backsub_update_w(const BaDev* __restrict__ pbp, double* __restrict__ part) {
+  __shared__ double red[4];
+  const BaDev pb = *pbp;
+  if (lm_skip(pb, 1)) return;
+  const double lambda = pb.lmd[LMD_LAMBDA];
+  const int gid = blockIdx.x * GB + threadIdx.x, m = gid >> 4, q = gid & 15;
+  const int P = pb.P;
+  const bool ok = pb.scal[2] != 0.0;
+  double sc = 0;
+  {
+    const bool live = m < pb.nMP;
+    const size_t row = (size_t)3 * (live ? m : 0) * pb.sMp;
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int j = q; j < P; j += 16) {
+      const double xj = pb.x[j];
+      a0 += pb.sW[row + j] * xj; a1 += pb.sW[row + pb.sMp + j] * xj; a2 += pb.sW[row + 2 * (size_t)pb.sMp + j] * xj;
+    }
+    a0 = morbwave::row_sum_f64(a0); a1 = morbwave::row_sum_f64(a1); a2 = morbwave::row_sum_f64(a2);
+    if (live && q < 3) {
+      double xl = 0;
+      if (ok) {
+        const double cl[3] = {pb.sW[row + P] - a0, pb.sW[row + pb.sMp + P] - a1, pb.sW[row + 2 * (size_t)pb.sMp + P] - a2};
+        const double* Di = pb.Dinv + (size_t)m * 9;
+        xl = Di[q * 3] * cl[0] + Di[q * 3 + 1] * cl[1] + Di[q * 3 + 2] * cl[2];
+      }
+      pb.x[P + 3 * m + q] = xl;
+      pb.pt[3 * m + q] += xl;
+      sc += xl * (lambda * xl + pb.b[P + 3 * m + q]);
+    }
+  }
+  if (gid < pb.nKF) {
+    const int col = pb.kfCol[gid];
+    if (col >= 0) {
+      double u[6];
+      for (int r = 0; r < 6; ++r) { u[r] = ok ? pb.x[6 * col + r] : 0.0; sc += u[r] * (lambda * u[r] + pb.b[6 * col + r]); }
+      store_se3(pb.pose + 7 * gid, se3_mul(se3_exp(u), load_se3(pb.pose + 7 * gid)));
+    }
+  }
+  sc = block_sum_d<4>(sc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = sc;
+}
 __global__ __launch_bounds__(GB) void k_g_pop(const BaDev* __restrict__ pbp, int gated) {
   const BaDev pb = *pbp;
   if (gated && pb.lmi[LM_REJECTED] == 0) return;   // (idempotent: a launch queued behind the last decision restores the same backup again)
@@ -1821,7 +1865,7 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
   h.kfChunkStart = (const int*)up(kfChunkStart.data(), sizeof(int) * (nKF + 1));
   h.kfPart = (double*)up(nullptr, sizeof(double) * 27 * std::max<size_t>(chunkKF.size(), 1));
   p->d_ldws = (double*)up(nullptr, sizeof(double) * LB * std::max<size_t>((size_t)h.P, 1));
-  p->redBlocks = div_up(std::max(std::max(nE, nMP * 3), std::max(nKF * 7, 1)), GB);
+  p->redBlocks = div_up(std::max(std::max(nE, nMP * 16), std::max(nKF * 7, 1)), GB);   // (16 lanes per point in k_g_backsub_update_w)
   h.redPart = (double*)up(nullptr, sizeof(double) * 2 * p->redBlocks);
   h.scal = (double*)up(nullptr, sizeof(double) * 8);
   {
@@ -2001,7 +2045,7 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
       hipLaunchKernelGGL(k_g_schur_finish, dim3(div_up(4 * (h.P * h.P + h.P), GB)), dim3(GB), 0, st, d, 0.0, h.HsG, 1);
       if (p->denseLds) hipLaunchKernelGGL(k_g_ldlt_lds, dim3(1), dim3(morbdense::LT), p->denseLds, st, d, (const double*)h.HsG, 1);
       else hipLaunchKernelGGL(k_g_ldlt, dim3(1), dim3(LD_T), p->ldsBytes, st, d, h.HsG, p->d_ldws, p->useLds, 1);
-      hipLaunchKernelGGL(k_g_backsub_update, dim3(rb), dim3(GB), 0, st, d, 0.0, part1, 1);
+      hipLaunchKernelGGL(k_g_backsub_update_w, dim3(rb), dim3(GB), 0, st, d, part1);
       hipLaunchKernelGGL(k_g_chi2, dim3(rb), dim3(GB), 0, st, d, part0, (const double*)part1, 1);
       MORB_HIP_CHECK(hipGetLastError());
       // wait until all but the last kAhead queued trials are decided (or the solve is done): a spin on mapped host memory

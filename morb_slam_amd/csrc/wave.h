@@ -61,6 +61,25 @@ __device__ __forceinline__ double sum_f64(double v) {
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), 63);
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+// sum of a double over each 16-lane row (all lanes active), broadcast to the row's lanes: four row_shr steps put the total in the
+// row's lane 15, row_newbcast:15 (gfx90a+) hands it to the other lanes.  Fixed order, no LDS.
+__device__ __forceinline__ double row_sum_f64(double v) {
+#define MORB_DPP_ROW_F64(ctrl, OPASSIGN)                                                                            \
+  do {                                                                                                              \
+    const unsigned long long u_ = (unsigned long long)__double_as_longlong(v);                                      \
+    const int lo_ = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u_, ctrl, 0xf, 0xf, false);                       \
+    const int hi_ = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u_ >> 32), ctrl, 0xf, 0xf, false);               \
+    const double o_ = __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi_ << 32) | (uint32_t)lo_)); \
+    OPASSIGN;                                                                                                       \
+  } while (0)
+  MORB_DPP_ROW_F64(0x111, v += o_);
+  MORB_DPP_ROW_F64(0x112, v += o_);
+  MORB_DPP_ROW_F64(0x114, v += o_);
+  MORB_DPP_ROW_F64(0x118, v += o_);
+  MORB_DPP_ROW_F64(0x15F, v = o_);
+#undef MORB_DPP_ROW_F64
+  return v;
+}
 // broadcast of lane `src`'s double (src wave-uniform; a compile-time constant compiles to two v_readlane_b32)
 __device__ __forceinline__ double readlane_f64(double v, int src) {
   const unsigned long long u = (unsigned long long)__double_as_longlong(v);
