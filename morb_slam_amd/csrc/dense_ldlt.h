@@ -39,7 +39,11 @@ struct DiagStage {
   static __device__ __forceinline__ void run(double (&a)[16], int row, bool& ok, double& rd) {
     const double d = row_bcast_f64<J>(a[J]);
     ok = ok && (PIVOT_POSITIVE ? (d > 0) : !(d == 0 || d != d));
-    const double inv = 1.0 / d;
+    // 1 / d: v_rcp_f64 + two Newton steps (5 dependent instructions; the IEEE division sequence is 12, and this chain is what one wave
+    // alone on its SIMD — ~6 cycles per instruction — spends the diagonal block on).  <= 1 ulp from the rounded quotient.
+    double inv = __builtin_amdgcn_rcp(d);
+    inv = __builtin_fma(__builtin_fma(-d, inv, 1.0), inv, inv);
+    inv = __builtin_fma(__builtin_fma(-d, inv, 1.0), inv, inv);
     if (row == J) rd = inv;
     const double l = a[J] * inv;
     bc<J + 1>(a, l);
