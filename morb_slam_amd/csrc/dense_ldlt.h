@@ -101,10 +101,12 @@ __device__ bool ldlt_solve(const double* __restrict__ Hs, const double* b, doubl
   if (tid == 0) *sOk = 1;
   __syncthreads();
   LD_MARK(0);
-  for (int j0 = 0; j0 < n; j0 += NB) {
-    const int nb = n - j0 < NB ? n - j0 : NB, m = n + 1 - j0 - nb;   // m rows below the block (the last one is the right-hand side)
-    // (1) the diagonal block: wave 0, row r in lane r (identity padding beyond nb)
-    if (wv == 0) {
+  // The diagonal block at j0: wave 0 only, row r in lane r (identity padding beyond nb).  It is the critical path of the whole
+  // factorisation (one wave issues an instruction every ~6 cycles), so from the second block on it runs UNDER the previous panel's
+  // trailing update: wave 0 updates the tile that is the next diagonal block first, factorises it, and only the other seven waves
+  // work through the remaining tiles (look-ahead).
+  auto factor_diag = [&](int j0) {
+    const int nb = n - j0 < NB ? n - j0 : NB;
       // the symmetric block -> dblk (four passes of 64 lanes, branch-free), then row r -> lane r (same wave: LDS keeps the order)
 #pragma unroll
       for (int q = 0; q < NB * NB / 64; ++q) {
@@ -131,9 +133,12 @@ __device__ bool ldlt_solve(const double* __restrict__ Hs, const double* b, doubl
         }
       }
       if (lane == 0 && !ok) *sOk = 0;
-    }
-    __syncthreads();
-    LD_MARK(1);
+  };
+  if (wv == 0) factor_diag(0);
+  __syncthreads();
+  LD_MARK(1);
+  for (int j0 = 0; j0 < n; j0 += NB) {
+    const int nb = n - j0 < NB ? n - j0 : NB, m = n + 1 - j0 - nb;   // m rows below the block (the last one is the right-hand side)
     if (*sOk == 0) break;   // uniform
     // (2) rows below the block: u = a - sum_k u_k L[c][k], l = u / d — sixteen lanes per row, one per column
     {
@@ -161,7 +166,8 @@ __device__ bool ldlt_solve(const double* __restrict__ Hs, const double* b, doubl
     {
       const int mt = (m + NB - 1) / NB, ntile = mt * (mt + 1) / 2;
       const int li = lane & 15, lk = lane >> 4;
-      for (int t = wv; t < ntile; t += LT / 64) {
+      const bool ahead = j0 + nb < n;   // another diagonal block follows: wave 0 = tile 0 + that block, waves 1.. = the other tiles
+      for (int t = ahead ? (wv == 0 ? 0 : wv) : wv; t < ntile; t += ahead ? (wv == 0 ? ntile : LT / 64 - 1) : LT / 64) {
         int ti = 0;
         while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;   // tile (ti, tj), tj <= ti
         const int tj = t - ti * (ti + 1) / 2;
@@ -176,6 +182,7 @@ __device__ bool ldlt_solve(const double* __restrict__ Hs, const double* b, doubl
         }
       }
     }
+    if (wv == 0 && j0 + nb < n) factor_diag(j0 + nb);
     __syncthreads();
     LD_MARK(3);
   }
