@@ -1414,8 +1414,11 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   }
   mark(1);
   {
-    // the second group (few, large cells) runs beside the first on the side stream
-    const bool two = e->fastSegs[1] > 0 && e->overlapBlur;
+    // Both groups follow each other in the launch stream.  Side by side on two streams they finish no earlier when the extractor is
+    // alone on the chip (1.009 vs 1.014 ms per 512 images) and inside the pipelined bench the fork / join through a second hardware
+    // queue stretched the stage from 1.44 to 1.65 ms for the same frame rate; MORB_FAST_TWO_STREAMS=1 restores that form for A/B runs.
+    static const bool fastTwoStreams = [] { const char* v = getenv("MORB_FAST_TWO_STREAMS"); return v && v[0] == '1'; }();
+    const bool two = e->fastSegs[1] > 0 && e->overlapBlur && fastTwoStreams;
     if (two) {
       MORB_HIP_CHECK(hipEventRecord(e->evFork, st));
       MORB_HIP_CHECK(hipStreamWaitEvent(e->sideStream, e->evFork, 0));
