@@ -92,6 +92,36 @@ def test_other_sizes_and_params():
     _compare(make_image(1280, 720, seed=23), 2000, iniThFAST=15, minThFAST=5)
 
 
+def test_pyramid_launch_paths():
+    # the pyramid stage has several shapes: one level (plain copy kernel), two (levels 0 + 1 from one launch only), other scale
+    # factors (row / column tables with other strides; 2.0 leaves the 8-byte source window of four outputs), widths whose padded
+    # pitch ends in a 64-, 128- or 192-px partial block column
+    _compare(make_image(640, 480, seed=51), 300, nlevels=1)
+    _compare(make_image(640, 480, seed=52), 400, nlevels=2)
+    _compare(make_image(752, 480, seed=53), 600, scaleFactor=1.5, nlevels=4)
+    _compare(make_image(800, 600, seed=54), 600, scaleFactor=2.0, nlevels=3)
+    _compare(make_image(601, 377, seed=55), 500, scaleFactor=1.1, nlevels=6)
+    for w in (474, 538, 602, 666):   # padded pitch = 512 + 64, 128, 192, 256
+        _compare(make_image(w, 240, seed=56 + w), 300, nlevels=3)
+
+
+def test_batches_of_8_and_16_follow_the_xcd_tile_order():
+    # with a multiple of 8 images the pyramid workgroups are dealt to the XCDs image by image (py_tile); other counts use the plain order
+    import torch
+    from morb_slam_amd import KP_DTYPE
+    for nimg in (8, 16, 5):
+        g, o = _extractors(700)
+        imgs = np.stack([make_image(752, 480, seed=60 + i) for i in range(nimg)])
+        kps, desc, cnt, mono = g.extract_batch(torch.from_numpy(imgs).cuda())
+        torch.cuda.synchronize()
+        cnt = cnt.cpu().numpy(); kps = kps.cpu().numpy(); desc = desc.cpu().numpy()
+        for i in range(nimg):
+            mo, ko, do = o(imgs[i])
+            assert cnt[i] == len(ko)
+            assert kps[i, :cnt[i]].reshape(-1).view(KP_DTYPE).tobytes() == ko.tobytes()
+            np.testing.assert_array_equal(desc[i, :cnt[i]], do)
+
+
 def test_threshold_orderings():
     # the reference runs cv::FAST(iniThFAST) and, for an empty cell, cv::FAST(minThFAST), whatever their order: equal and
     # swapped thresholds exercise the second pass after a first pass that left strengths behind
