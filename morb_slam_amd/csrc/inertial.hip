@@ -1553,7 +1553,8 @@ __global__ __launch_bounds__(morbdense::LT) void k_iba_solve_lds(IbaDev D) {
   const bool ok = morbdense::ldlt_solve<true>(D.Hs, D.bs, D.x, D.P, sLd, &sOk);
   if (threadIdx.x == 0) D.scal[2] = ok ? 1.0 : 0.0;
 }
-__global__ __launch_bounds__(1024) void k_iba_solve_blocked(IbaDev D) {
+constexpr int IBA_SB_T = 1024;
+__global__ __launch_bounds__(IBA_SB_T) void k_iba_solve_blocked(IbaDev D) {
   extern __shared__ double sm[];   // pnlL[n * NBP] | pnlU[n * NBP] | dblk[NB * NBP] | y[n]
   const int n = D.P, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   double* pnlL = sm; double* pnlU = sm + (size_t)n * IBA_NBP; double* dblk = pnlU + (size_t)n * IBA_NBP; double* y = dblk + IBA_NB * IBA_NBP;
@@ -1576,37 +1577,50 @@ __global__ __launch_bounds__(1024) void k_iba_solve_blocked(IbaDev D) {
       const int r = tid / IBA_NB, c = tid - r * IBA_NB;
       if (r < nb && c <= r) A[(size_t)(j0 + r) * n + j0 + c] = dblk[r * IBA_NBP + c];
     }
-    // (2) panel rows below the block, one per thread: u = a - sum_k u_k L[c][k], l = u / d
-    for (int rr = tid; rr < m; rr += 1024) {
-      const size_t g = (size_t)(j0 + nb + rr) * n + j0;
-      double u[IBA_NB];
+    // (2) panel rows below the block: u = a - sum_k u_k L[c][k], l = u / d — sixteen lanes per row, one per column, the 16 dependent
+    // stages are one DPP row broadcast + one FMA each (dense_ldlt.h's PanelStage).  The thread-per-row form, fully unrolled, had the
+    // compiler hoist its 120 LDS operands into registers and spill 748 bytes per lane.
+    {
+      const int c = tid & 15;
+      double lrow[IBA_NB];
 #pragma unroll
-      for (int c = 0; c < IBA_NB; ++c) {
-        double v = c < nb ? A[g + c] : 0.0;
-#pragma unroll
-        for (int k = 0; k < c; ++k) v -= u[k] * dblk[c * IBA_NBP + k];
-        u[c] = v;
-      }
-#pragma unroll
-      for (int c = 0; c < IBA_NB; ++c) {
-        const double l = u[c] / dblk[c * IBA_NBP + c];
-        pnlU[rr * IBA_NBP + c] = u[c];
+      for (int k = 0; k < IBA_NB; ++k) { const double t = dblk[c * IBA_NBP + k]; lrow[k] = k < c ? t : 0.0; }
+      const double dc = dblk[c * IBA_NBP + c];
+      for (int rr = tid >> 4; rr < m; rr += IBA_SB_T / 16) {
+        const size_t g = (size_t)(j0 + nb + rr) * n + j0;
+        const double t = A[g + (c < nb ? c : 0)];
+        double v = c < nb ? t : 0.0;
+        morbdense::PanelStage<0>::run(v, lrow);
+        const double l = v / dc;
+        pnlU[rr * IBA_NBP + c] = v;
         pnlL[rr * IBA_NBP + c] = l;
         if (c < nb) A[g + c] = l;
       }
     }
     __syncthreads();
     // (3) trailing update: A[r][cc] -= sum_k u[r][k] l[cc][k]
-    for (int rr = wv; rr < m; rr += 16) {
+    // (a wave per row; the row's elements are all requested before the first is used — one global round trip per row instead of
+    // one per 64 columns: with a single workgroup nothing else hides that latency)
+    for (int rr = wv; rr < m; rr += IBA_SB_T / 64) {
       double ur[IBA_NB];
 #pragma unroll
       for (int k = 0; k < IBA_NB; ++k) ur[k] = pnlU[rr * IBA_NBP + k];
       double* arow = A + (size_t)(j0 + nb + rr) * n + j0 + nb;
-      for (int cc = lane; cc <= rr; cc += 64) {
-        double acc = 0;
+      constexpr int CH = 8;   // 64 CH columns per pass (n <= 512 in one)
+      for (int c0 = 0; c0 <= rr; c0 += 64 * CH) {
+        double av[CH];
 #pragma unroll
-        for (int k = 0; k < IBA_NB; ++k) acc += ur[k] * pnlL[cc * IBA_NBP + k];
-        arow[cc] -= acc;
+        for (int i = 0; i < CH; ++i) { const int cc = c0 + lane + 64 * i; av[i] = cc <= rr ? arow[cc] : 0.0; }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int cc = c0 + lane + 64 * i;
+          if (c0 + 64 * i > rr) break;   // wave-uniform
+          double acc = 0;
+          const double* pl = pnlL + (cc <= rr ? cc : 0) * IBA_NBP;
+#pragma unroll
+          for (int k = 0; k < IBA_NB; ++k) acc += ur[k] * pl[k];
+          if (cc <= rr) arow[cc] = av[i] - acc;
+        }
       }
     }
     __syncthreads();
@@ -1615,7 +1629,7 @@ __global__ __launch_bounds__(1024) void k_iba_solve_blocked(IbaDev D) {
   if (sOk == 0) { if (tid == 0) D.scal[2] = 0.0; return; }
   // blocked substitutions: per 16-column panel the 16 x 16 triangular block is solved by wave 0 in registers (v_readlane), the
   // rest of the panel is one 16-term dot product per row
-  for (int r = tid; r < n; r += 1024) y[r] = D.bs[r];
+  for (int r = tid; r < n; r += IBA_SB_T) y[r] = D.bs[r];
   __syncthreads();
   for (int j0 = 0; j0 < n; j0 += IBA_NB) {   // L y = b
     const int nb = n - j0 < IBA_NB ? n - j0 : IBA_NB;
@@ -1635,7 +1649,7 @@ __global__ __launch_bounds__(1024) void k_iba_solve_blocked(IbaDev D) {
       if (lane < nb) y[j0 + lane] = yr;
     }
     __syncthreads();
-    for (int r = j0 + nb + tid; r < n; r += 1024) {
+    for (int r = j0 + nb + tid; r < n; r += IBA_SB_T) {
       const double* lr = A + (size_t)r * n + j0;
       double acc = 0;
       for (int k = 0; k < nb; ++k) acc += lr[k] * y[j0 + k];
@@ -1643,7 +1657,7 @@ __global__ __launch_bounds__(1024) void k_iba_solve_blocked(IbaDev D) {
     }
     __syncthreads();
   }
-  for (int r = tid; r < n; r += 1024) y[r] /= A[(size_t)r * n + r];
+  for (int r = tid; r < n; r += IBA_SB_T) y[r] /= A[(size_t)r * n + r];
   __syncthreads();
   for (int j0 = ((n - 1) / IBA_NB) * IBA_NB; j0 >= 0; j0 -= IBA_NB) {   // L^T x = y
     const int nb = n - j0 < IBA_NB ? n - j0 : IBA_NB;
@@ -1663,14 +1677,14 @@ __global__ __launch_bounds__(1024) void k_iba_solve_blocked(IbaDev D) {
       if (lane < nb) y[j0 + lane] = xr;
     }
     __syncthreads();
-    for (int r = tid; r < j0; r += 1024) {
+    for (int r = tid; r < j0; r += IBA_SB_T) {
       double acc = 0;
       for (int k = 0; k < nb; ++k) acc += A[(size_t)(j0 + k) * n + r] * y[j0 + k];
       y[r] -= acc;
     }
     __syncthreads();
   }
-  for (int r = tid; r < n; r += 1024) D.x[r] = y[r];
+  for (int r = tid; r < n; r += IBA_SB_T) D.x[r] = y[r];
   if (tid == 0) D.scal[2] = 1.0;
 }
 
@@ -2029,7 +2043,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
       } else if (ldsSchur) hipLaunchKernelGGL(k_iba_schur<true>, dim3(div_up(nMP, 256)), dim3(256), schurLds, st, D, lambda);   // (measurement only, MORB_SCHUR_VALU=1: round 1's form with FP64 atomics)
       else hipLaunchKernelGGL(k_iba_schur<false>, dim3(div_up(nMP, 256)), dim3(256), 0, st, D, lambda);
       if (denseLds) hipLaunchKernelGGL(k_iba_solve_lds, dim3(1), dim3(morbdense::LT), denseLds, st, D);
-      else hipLaunchKernelGGL(k_iba_solve_blocked, dim3(1), dim3(1024), blockedLds, st, D);
+      else hipLaunchKernelGGL(k_iba_solve_blocked, dim3(1), dim3(IBA_SB_T), blockedLds, st, D);
       // a failed solve leaves x as it was (zero at the first trial): g2o still applies the update
       (void)hipMemsetAsync(D.scal, 0, sizeof(double) * 2, st);
       hipLaunchKernelGGL(k_iba_update, dim3(div_up(nMP + nKF, 256)), dim3(256), 0, st, D, lambda);
