@@ -795,13 +795,21 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
     tmp = keys + g.qtImg / 2;
   }
   const uint32_t* cbase = cand + ((size_t)img * totalCells + g.cellBase) * (size_t)cellCap;
-  for (int t = lane; t < T; t += 64) {
-    int lo = 0, hi = ncell;  // largest c with cellOff[c] <= t
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (cellOff[mid] <= t) lo = mid; else hi = mid;
+  // gather the cells' candidate lists into one array, cell-major: a lane per cell copies its list, four loads in flight per lane
+  // (a lane per candidate had to binary-search its cell first: 8 dependent LDS reads in front of every global load, 34 of level 0's 152 us)
+  for (int c0 = 0; c0 < ncell; c0 += 64) {
+    const int c = c0 + lane;
+    const int off = c < ncell ? cellOff[c] : 0;
+    const int n = c < ncell ? cellOff[c + 1] - off : 0;
+    const int nmax = (int)~morbwave::min_u32(~(uint32_t)n);   // wave maximum
+    const uint32_t* src = cbase + (size_t)(c < ncell ? c : 0) * cellCap;
+    for (int i0 = 0; i0 < nmax; i0 += 4) {
+      uint32_t v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = i0 + k < n ? src[i0 + k] : 0u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (i0 + k < n) keys[off + i0 + k] = v[k];
     }
-    keys[t] = cbase[(size_t)lo * cellCap + (t - cellOff[lo])];
   }
   QT_SYNC();
   DMARK(9);
