@@ -317,6 +317,7 @@ def main():
                     help="stereo frames per step per GPU (default 256 for c2: 64 -> 62.8 k, 128 -> 65.0 k, 192 -> 67.1 k, 256 -> 69.0 k frames/s "
                          "on one MI355X in round 1; 8 for c4)")
     ap.add_argument("--sets", type=int, default=2, help="buffer sets = steps in flight (>= 2)")
+    ap.add_argument("--extract-streams", type=int, default=1, help="1: one extraction stream for all buffer sets (default); 2: one per set")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="join all streams at the end of every step instead of running step i's matchers underneath step "
                          "i + 1's extraction (one buffer set instead of two)")
@@ -363,7 +364,11 @@ def main():
     ext = exts[0]
     stream = torch.cuda.Stream(device=dev)                    # extraction
     mstream = torch.cuda.Stream(device=dev) if NSET >= 2 else stream   # stereo matching
-    estreams = [torch.cuda.Stream(device=dev) for _ in range(NSET)] if NSET >= 2 and not os.environ.get('MORB_BENCH_ONE_ESTREAM') else [stream] * NSET
+    # --extract-streams 1 (default): the sets' extractions follow each other on ONE stream and only the matchers of the previous step run
+    # beside them; 2: one extraction stream per set, so two extractions also overlap each other (measured: +1.8 % frames/s, but every
+    # extraction kernel then shares the chip with another one and its in-region launch time is ~1.5 x its time alone — see DESIGN.md §4).
+    # (HIP stream priorities were tried both ways: 58 - 76 k frames/s, worse than either.)
+    estreams = [torch.cuda.Stream(device=dev) for _ in range(NSET)] if NSET >= 2 and args.extract_streams >= 2 else [stream] * NSET
     # pipelined: ONE matcher stream (stereo, then the BoW chain): HIP multiplexes streams onto 4 hardware queues and streams that
     # alias serialise; with extraction A / B, their blur side streams and one matcher stream only one pair aliases (+3.5 %
     # over two matcher streams).  Un-pipelined: the BoW chain runs beside the stereo matcher on its own stream.
@@ -601,7 +606,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl + ": ORBextractor x2 + ComputeStereoMatches + ComputeBoW (synthetic k=10 L=6 vocabulary) + "
                                    "SearchByBoW vs previous frame",
-                       "stereo_frames_per_step_per_gpu": B, "steps_in_flight": NSET, "parallelism": f"frames dealt round-robin over {world} GPU(s)" + ("" if world == 1 else
+                       "stereo_frames_per_step_per_gpu": B, "steps_in_flight": NSET, "extract_streams": len(set(id(x) for x in estreams)), "parallelism": f"frames dealt round-robin over {world} GPU(s)" + ("" if world == 1 else
                                        "; per step one RCCL send/recv of the left-image keypoints/descriptors/BoW ids to the next rank (ring)"),
                        "stages_in_step": ["extract_left+right", "stereo_match", "bow_transform"] + (["feature_exchange"] if world > 1 else []) + ["search_by_bow"],
                        "mean_keypoints_per_image": float(cnt.mean()), "mean_stereo_matches_per_frame": n_stereo,
