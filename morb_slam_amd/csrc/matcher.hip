@@ -130,7 +130,10 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, con
 // number of vector-memory instructions, so: the right keypoints' row band / x / octave go to LDS once per workgroup,
 // the row-band test runs on LDS, the survivors are compacted to a candidate list before any descriptor is loaded,
 // and the two SAD patches are fetched as unaligned dwords into LDS instead of 24 byte loads per lane.
-constexpr int SM_LK = 16;
+#ifndef MORB_SM_LK
+#define MORB_SM_LK 32   // (16: 429 us, 32: 391 us, 64: 405 us per 256 frames)
+#endif
+constexpr int SM_LK = MORB_SM_LK;
 constexpr int SM_BAND = 16;   // rows per band of the per-workgroup row index (the reference's vRowIndices, coarsened)
 constexpr int SM_MAXB = 256;  // bands that fit (images up to 4096 rows); SM_LIST * cap list entries, else the full scan
 // Per-level facts the stereo kernel needs, by value in the kernarg segment (scalar loads, no dependent round trip
