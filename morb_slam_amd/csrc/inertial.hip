@@ -1555,9 +1555,10 @@ __global__ __launch_bounds__(morbdense::LT) void k_iba_solve_lds(IbaDev D) {
 }
 constexpr int IBA_SB_T = 1024;
 __global__ __launch_bounds__(IBA_SB_T) void k_iba_solve_blocked(IbaDev D) {
-  extern __shared__ double sm[];   // pnlL[n * NBP] | pnlU[n * NBP] | dblk[NB * NBP] | y[n]
+  extern __shared__ double sm[];   // pnlL[(n + 16) * NBP] | pnlU[(n + 16) * NBP] | dblk[NB * NBP] | y[n]
   const int n = D.P, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  double* pnlL = sm; double* pnlU = sm + (size_t)n * IBA_NBP; double* dblk = pnlU + (size_t)n * IBA_NBP; double* y = dblk + IBA_NB * IBA_NBP;
+  const int np = n + IBA_NB;   // (the panel copies are read in whole 16-row tiles by the matrix-core trailing update)
+  double* pnlL = sm; double* pnlU = sm + (size_t)np * IBA_NBP; double* dblk = pnlU + (size_t)np * IBA_NBP; double* y = dblk + IBA_NB * IBA_NBP;
   double* A = D.Hs;
   __shared__ int sOk;
   if (tid == 0) sOk = 1;
@@ -1596,30 +1597,49 @@ __global__ __launch_bounds__(IBA_SB_T) void k_iba_solve_blocked(IbaDev D) {
         pnlL[rr * IBA_NBP + c] = l;
         if (c < nb) A[g + c] = l;
       }
+      // rows m .. next multiple of 16 of the panel copies feed matrix-core lanes whose results are dropped: keep them zero
+      for (int i = m * IBA_NBP + tid; i < ((m + IBA_NB - 1) / IBA_NB * IBA_NB) * IBA_NBP; i += IBA_SB_T) { pnlU[i] = 0.0; pnlL[i] = 0.0; }
     }
     __syncthreads();
-    // (3) trailing update: A[r][cc] -= sum_k u[r][k] l[cc][k]
-    // (a wave per row; the row's elements are all requested before the first is used — one global round trip per row instead of
-    // one per 64 columns: with a single workgroup nothing else hides that latency)
-    for (int rr = wv; rr < m; rr += IBA_SB_T / 64) {
-      double ur[IBA_NB];
+    // (3) trailing update A[r][cc] -= sum_k u[r][k] l[cc][k] on the FP64 matrix cores: one wave per 16 x 16 tile of the lower triangle
+    // (4 v_mfma_f64_16x16x4_f64, layout as in dense_ldlt.h), TWO tiles per pass so that eight global loads per lane are in flight —
+    // the matrix lives in global memory (L2) and with a single workgroup nothing else hides that round trip.  (A wave per row with the
+    // row requested 64 columns at a time took 1.0 ms per solve at n = 375; whole rows at once 0.74.)
+    {
+      typedef double iba_d4 __attribute__((ext_vector_type(4)));
+      const int mt = (m + IBA_NB - 1) / IBA_NB, ntile = mt * (mt + 1) / 2;
+      const int li = lane & 15, lk = lane >> 4;
+      double* Abase = A + (size_t)(j0 + nb) * n + j0 + nb;
+      constexpr int NW = IBA_SB_T / 64;
+      for (int t0 = wv; t0 < ntile; t0 += 2 * NW) {
+        int ti[2], tj[2];
+        bool live[2];
+        double c[2][4];
 #pragma unroll
-      for (int k = 0; k < IBA_NB; ++k) ur[k] = pnlU[rr * IBA_NBP + k];
-      double* arow = A + (size_t)(j0 + nb + rr) * n + j0 + nb;
-      constexpr int CH = 8;   // 64 CH columns per pass (n <= 512 in one)
-      for (int c0 = 0; c0 <= rr; c0 += 64 * CH) {
-        double av[CH];
+        for (int u = 0; u < 2; ++u) {
+          const int t = t0 + u * NW;
+          live[u] = t < ntile;
+          int a = 0;
+          while ((a + 1) * (a + 2) / 2 <= (live[u] ? t : 0)) ++a;
+          ti[u] = a; tj[u] = (live[u] ? t : 0) - a * (a + 1) / 2;
 #pragma unroll
-        for (int i = 0; i < CH; ++i) { const int cc = c0 + lane + 64 * i; av[i] = cc <= rr ? arow[cc] : 0.0; }
+          for (int v4 = 0; v4 < 4; ++v4) {
+            const int rr = ti[u] * IBA_NB + 4 * v4 + lk, cc = tj[u] * IBA_NB + li;
+            c[u][v4] = (live[u] && rr < m && cc <= rr) ? Abase[(size_t)rr * n + cc] : 0.0;
+          }
+        }
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-          const int cc = c0 + lane + 64 * i;
-          if (c0 + 64 * i > rr) break;   // wave-uniform
-          double acc = 0;
-          const double* pl = pnlL + (cc <= rr ? cc : 0) * IBA_NBP;
+        for (int u = 0; u < 2; ++u) {
+          if (!live[u]) continue;   // wave-uniform
+          iba_d4 acc = {0, 0, 0, 0};
 #pragma unroll
-          for (int k = 0; k < IBA_NB; ++k) acc += ur[k] * pl[k];
-          if (cc <= rr) arow[cc] = av[i] - acc;
+          for (int s4 = 0; s4 < IBA_NB / 4; ++s4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pnlU[(ti[u] * IBA_NB + li) * IBA_NBP + 4 * s4 + lk], pnlL[(tj[u] * IBA_NB + li) * IBA_NBP + 4 * s4 + lk], acc, 0, 0, 0);
+#pragma unroll
+          for (int v4 = 0; v4 < 4; ++v4) {
+            const int rr = ti[u] * IBA_NB + 4 * v4 + lk, cc = tj[u] * IBA_NB + li;
+            if (rr < m && cc <= rr) Abase[(size_t)rr * n + cc] = c[u][v4] - acc[v4];
+          }
         }
       }
     }
@@ -2001,7 +2021,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
   static const bool valuSchur = [] { const char* v = getenv("MORB_SCHUR_VALU"); return v && v[0] == '1'; }();
   const size_t schurLds = sizeof(double) * ((size_t)Mpose * Mpose + Mpose);
   const bool ldsSchur = schurLds <= 60 * 1024;   // larger windows accumulate in global memory
-  const size_t blockedLds = sizeof(double) * (2 * (size_t)P * IBA_NBP + IBA_NB * IBA_NBP + (size_t)P);
+  const size_t blockedLds = sizeof(double) * (2 * (size_t)(P + IBA_NB) * IBA_NBP + IBA_NB * IBA_NBP + (size_t)P);
   MORB_REQUIRE(blockedLds <= 150 * 1024, MORB_ERR_CAPACITY, "window too large for the dense solver");
   if (blockedLds > 48 * 1024)
     MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_iba_solve_blocked), hipFuncAttributeMaxDynamicSharedMemorySize, (int)blockedLds));
