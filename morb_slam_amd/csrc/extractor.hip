@@ -740,7 +740,7 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
                                                    const int* __restrict__ candCnt, int totalCells, int cellCap,
                                                    uint32_t* __restrict__ qtScratch, uint32_t* __restrict__ sel,
                                                    int* __restrict__ selCnt, int selPerImg, int nlevels,
-                                                   int maxNodeCap, int maxCells) {
+                                                   int maxNodeCap, int maxCells, int keyCap) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int lvl = blockIdx.y, img = blockIdx.x, lane = threadIdx.x;
   __builtin_amdgcn_s_setprio(3);   // a long dependent chain: win instruction arbitration against the blur waves sharing the SIMD
@@ -751,8 +751,8 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
   uint64_t* vB = reinterpret_cast<uint64_t*>(sp); sp += (size_t)maxNodeCap * 8;
   uint64_t* bcnt = vB;   // the batch split's child counts: vB is only live between the sort and the order[] it feeds
   morbqt::Node* nodes = reinterpret_cast<morbqt::Node*>(sp); sp += (size_t)maxNodeCap * sizeof(morbqt::Node);
-  uint32_t* ldsKeys = reinterpret_cast<uint32_t*>(sp); sp += (size_t)kLdsKeys * 4;
-  uint32_t* ldsTmp = reinterpret_cast<uint32_t*>(sp); sp += (size_t)kLdsKeys * 4;
+  uint32_t* ldsKeys = reinterpret_cast<uint32_t*>(sp); sp += (size_t)keyCap * 4;
+  uint32_t* ldsTmp = reinterpret_cast<uint32_t*>(sp); sp += (size_t)keyCap * 4;
   int* cellOff = reinterpret_cast<int*>(sp); sp += (size_t)(maxCells + 1) * 4;
   uint32_t* brank = reinterpret_cast<uint32_t*>(sp); sp += (size_t)maxNodeCap * 4;
   uint16_t* freeIds = reinterpret_cast<uint16_t*>(sp); sp += (size_t)maxNodeCap * 2;
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
 
   uint32_t* keys;
   uint32_t* tmp;
-  if (T <= kLdsKeys) {
+  if (T <= keyCap) {
     keys = ldsKeys;
     tmp = ldsTmp;
   } else {
@@ -1195,9 +1195,18 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
   e->blurTiles = blurTileBase;
   e->pyrBytes = pyrOff; e->blurBytes = blurOff; e->qtElems = qtOff;
   e->outCap = selBase;
-  e->distSmem = (size_t)e->maxNodeCap * (8 + 8 + sizeof(morbqt::Node) + 4 + 2 + 2) + (size_t)kLdsKeys * 8 +
-                (size_t)(e->maxCells + 1) * 4 + (size_t)e->maxListCap * 2 + 64;
-  MORB_REQUIRE(e->distSmem <= 160 * 1024, MORB_ERR_UNSUPPORTED, "nfeatures too large for the LDS-resident quadtree");
+  // Candidate keys of a level live in LDS (two arrays) when they fit, else in the global scratch (much slower: every partition pass goes
+  // through the L2).  The capacity scales with level 0's area — twice the ~1 candidate per 233 px the benchmark images give, i.e. the
+  // kLdsKeys = 3072 of a 752 x 480 image — and is cut to what the LDS leaves beside the node arrays (1920 x 1080 / 4000 features: ~8 k keys).
+  {
+    const size_t fixed = (size_t)e->maxNodeCap * (8 + 8 + sizeof(morbqt::Node) + 4 + 2 + 2) + (size_t)(e->maxCells + 1) * 4 + (size_t)e->maxListCap * 2 + 64;
+    constexpr size_t kLdsBudget = 156 * 1024;   // (the full 160 KB is refused as a dynamic allocation)
+    MORB_REQUIRE(fixed + 1024 * 8 <= kLdsBudget, MORB_ERR_UNSUPPORTED, "nfeatures too large for the LDS-resident quadtree");
+    const long long want = std::max<long long>(kLdsKeys, (long long)e->geom[0].w * e->geom[0].h * 2 / 233);
+    const long long fit = (long long)((kLdsBudget - fixed) / 8);
+    e->distKeyCap = (int)std::min(want, fit) / 64 * 64;
+    e->distSmem = fixed + (size_t)e->distKeyCap * 8;
+  }
 
   MORB_HIP_CHECK(hipMalloc(&e->d_geom, sizeof(LevelGeom) * kMaxLevels));
   MORB_HIP_CHECK(hipMemcpy(e->d_geom, e->geom, sizeof(LevelGeom) * kMaxLevels, hipMemcpyHostToDevice));
@@ -1453,7 +1462,7 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   // level 0 (the longest wave) first: grid x = image, y = level
   hipLaunchKernelGGL(k_distribute, dim3(nimg, L), dim3(64), e->distSmem, st, e->d_geom, e->d_cand, e->d_candCnt,
                      e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L, e->maxNodeCap,
-                     e->maxCells);
+                     e->maxCells, e->distKeyCap);
   hipStream_t sideStream = e->overlapBlur ? e->sideStream : st;   // MORB_EXTRACT_SERIAL=1: everything on the launch stream
   MORB_HIP_CHECK(hipStreamWaitEvent(sideStream, e->evFork, 0));
   if (evs) (void)hipEventRecord(evs[6], sideStream);

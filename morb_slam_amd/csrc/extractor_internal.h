@@ -14,7 +14,7 @@ constexpr int EDGE = 19;        // EDGE_THRESHOLD  ORBextractor.cc:73
 constexpr int HALF_PATCH = 15;  // HALF_PATCH_SIZE :72
 constexpr int PATCH = 31;       // PATCH_SIZE :71
 constexpr int MINB = 16;        // minBorderX/Y = EDGE_THRESHOLD - 3 (:746-747)
-constexpr int kLdsKeys = 3072;  // distribute: key arrays live in LDS up to this many candidates per level
+constexpr int kLdsKeys = 3072;  // distribute: the LDS key arrays hold at least this many candidates per level (more for larger images, see configure())
 
 struct LevelGeom {
   int w, h;
@@ -80,6 +80,7 @@ struct morb_extractor {
   int fastSegs[2] = {0, 0}, fastRows[2] = {0, 0};   // k_fast launch groups (segments, LDS window rows)
   int selPerImg = 0, blurTiles = 0, outCap = 0;
   size_t pyrBytes = 0, blurBytes = 0, qtElems = 0, distSmem = 0, fastSmem[2] = {0, 0};
+  int distKeyCap = 0;                        // candidate keys of a level that fit the quadtree's LDS arrays
 
   hipStream_t stream = nullptr;
   hipStream_t sideStream = nullptr;          // the blur runs here, underneath the quadtree (fork after FAST, join before describe)

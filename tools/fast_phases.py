@@ -18,10 +18,11 @@ import torch
 from morb_slam_amd import capi, synth
 from morb_slam_amd.extractor import ORBextractor
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-ims = [synth.make_stereo_pair(752, 480, seed=i) for i in range(4)]
+W, H, NF = int(os.environ.get('MORB_W', 752)), int(os.environ.get('MORB_H', 480)), int(os.environ.get('MORB_NF', 1200))
+ims = [synth.make_stereo_pair(W, H, seed=i) for i in range(4)]
 import numpy as np
 batch = np.stack([ims[i % 4][k] for i in range(B) for k in (0, 1)])
-ex = ORBextractor(1200, 1.2, 8, 20, 7)
+ex = ORBextractor(NF, 1.2, 8, 20, 7)
 dev = torch.from_numpy(batch).cuda()
 lib = capi.lib()
 lib.morb_fast_timing.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
