@@ -33,6 +33,7 @@ extern "C" {
 int morb_optimizer_device(const morb_optimizer*);
 void* morb_optimizer_stream(const morb_optimizer*);
 int morb_optimizer_workspace(morb_optimizer*, size_t bytes, void** out);
+int morb_optimizer_lm_words(morb_optimizer*, int** host, int** dev);   // 16 pinned, device-mapped ints (LM state mirror)
 }
 
 #define WAVE_SYNC_F()                                      \
@@ -1102,8 +1103,18 @@ struct IbaDev {
   const int2* sBlocks;
   const int* sBlkIndex;
   int sMp, sNb, sNblk, sNsplit;
+  // device-side LM control (see optimizer.hip, grid-mode LocalBA): the loop state, its mirror in mapped host memory, the backups
+  double* lmd;                                  // IBA_LMD_*: currentChi, lambda, ni, iniChi, chi2 of the last evaluated trial
+  int* lmi;                                     // IBA_LM_*
+  int* lmHost;                                  // [0] decided trials, [1] done
+  double *Sbk, *ptsBk;                          // state / points before the trial
+  int nS, nPts, optIt;
   CamGeom g;
 };
+enum { IBA_LM_ITER, IBA_LM_QMAX, IBA_LM_NBAD, IBA_LM_ITS, IBA_LM_TRIALS, IBA_LM_DONE, IBA_LM_NEEDBUILD, IBA_LM_REJECTED, IBA_LM_TICKET };
+enum { IBA_LMD_CHI, IBA_LMD_LAMBDA, IBA_LMD_NI, IBA_LMD_INICHI, IBA_LMD_LASTCHI };
+__device__ __forceinline__ bool iba_done(const IbaDev& D) { return D.lmi[IBA_LM_DONE] != 0; }
+__device__ __forceinline__ bool iba_no_build(const IbaDev& D) { return D.lmi[IBA_LM_DONE] != 0 || D.lmi[IBA_LM_NEEDBUILD] == 0; }
 __device__ __forceinline__ void iba_load(const CamGeom& g, const double* s, VIState& V) {
   for (int k = 0; k < 9; ++k) { V.Rwb[k] = s[k]; V.Rcw[k] = s[21 + k]; }
   for (int k = 0; k < 3; ++k) { V.twb[k] = s[9 + k]; V.v[k] = s[12 + k]; V.bg[k] = s[15 + k]; V.ba[k] = s[18 + k]; V.tcw[k] = s[30 + k]; }
@@ -1165,7 +1176,11 @@ __global__ __launch_bounds__(64) void k_iba_setup_links(IbaDev D, const float* _
 }
 
 // computeActiveErrors + activeRobustChi2 -> scal[0]
-__global__ __launch_bounds__(256) void k_iba_errors(IbaDev D) {
+__device__ void iba_lm_decide(const IbaDev& D);
+// mode 0: computeActiveErrors + activeRobustChi2 (the chi2 accumulates into scal[0]).  mode 1 (a trial under device-side LM control):
+// returns at once when the solve has finished; the last workgroup to finish takes the trial's accept / reject decision.
+__global__ __launch_bounds__(256) void k_iba_errors(IbaDev D, int mode) {
+  if (mode == 1 && iba_done(D)) return;
   const int t = blockIdx.x * 256 + threadIdx.x;
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815), deltaI = sqrt(16.92);
   double c = 0;
@@ -1194,10 +1209,97 @@ __global__ __launch_bounds__(256) void k_iba_errors(IbaDev D) {
     c = (D.iRobust[i] ? huber_rho(deltaI, ci) : ci) + iba_quad(ge, D.InfoG + (size_t)i * 9, 3) + iba_quad(ae, D.InfoA + (size_t)i * 9, 3);
   }
   block_add(c, D.scal + 0);
+  if (mode != 1) return;
+  __shared__ int isLast;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    isLast = atomicAdd(&D.lmi[IBA_LM_TICKET], 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!isLast || threadIdx.x != 0) return;
+  __threadfence();
+  D.lmi[IBA_LM_TICKET] = 0;
+  iba_lm_decide(D);
+}
+// optimization_algorithm_levenberg.cpp:99-169 with ORB-SLAM's stop rule, as local_inertial_ba_impl's host loop ran it: rho from
+// the trial's chi2 (scal[0]), the linear-model gain (scal[1]) and the solver's flag (scal[2]); the accumulators are cleared for the
+// next trial.  One thread.
+__device__ void iba_lm_decide(const IbaDev& D) {
+  const double s0 = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<unsigned long long*>(D.scal + 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  const double s1 = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<unsigned long long*>(D.scal + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  const bool ok2 = D.scal[2] != 0.0;
+  D.scal[0] = 0.0; D.scal[1] = 0.0;
+  double currentChi = D.lmd[IBA_LMD_CHI], lambda = D.lmd[IBA_LMD_LAMBDA], ni = D.lmd[IBA_LMD_NI];
+  const double iniChi = D.lmd[IBA_LMD_INICHI];
+  int iter = D.lmi[IBA_LM_ITER], qmax = D.lmi[IBA_LM_QMAX], nBad = D.lmi[IBA_LM_NBAD], its = D.lmi[IBA_LM_ITS];
+  double tempChi = s0;
+  if (!ok2) tempChi = 1.7976931348623157e308;
+  const double rho = (currentChi - tempChi) / (s1 + 1e-3);
+  const bool accept = rho > 0 && isfinite(tempChi);
+  if (accept) {
+    double alpha = 1. - pow((2 * rho - 1), 3);
+    alpha = fmin(alpha, 2. / 3.);
+    lambda *= fmax(1. / 3., alpha);
+    ni = 2;
+    currentChi = tempChi;
+  } else {
+    lambda *= ni;
+    ni *= 2;
+  }
+  ++qmax;
+  const int trials = D.lmi[IBA_LM_TRIALS] + 1;
+  int done = 0, needBuild = 0;
+  if (!(rho < 0 && qmax < 10)) {   // the trial loop ends
+    // (a NaN rho — NaN errors — leaves the loop with the trial rejected: the host loop went on from the restored state; here the
+    // solve ends, the stored errors belong to the rejected state)
+    bool fin = (qmax == 10 || rho == 0 || !(rho == rho));
+    if (!fin) { if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0; fin = nBad >= 3; }
+    if (!fin) { ++iter; fin = iter >= D.optIt; }
+    if (fin) done = 1;
+    else { ++its; qmax = 0; needBuild = 1; D.lmd[IBA_LMD_INICHI] = currentChi; }
+  }
+  D.lmd[IBA_LMD_CHI] = currentChi; D.lmd[IBA_LMD_LAMBDA] = lambda; D.lmd[IBA_LMD_NI] = ni; D.lmd[IBA_LMD_LASTCHI] = s0;
+  D.lmi[IBA_LM_ITER] = iter; D.lmi[IBA_LM_QMAX] = qmax; D.lmi[IBA_LM_NBAD] = nBad; D.lmi[IBA_LM_ITS] = its; D.lmi[IBA_LM_TRIALS] = trials;
+  D.lmi[IBA_LM_DONE] = done; D.lmi[IBA_LM_NEEDBUILD] = needBuild; D.lmi[IBA_LM_REJECTED] = accept ? 0 : 1;
+  __hip_atomic_store(D.lmHost + 1, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(D.lmHost + 0, trials, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// start of a trial slot: take the backup of states and points (or, after a rejected trial, restore it) and — when the system is rebuilt —
+// clear the accumulators of buildSystem
+__global__ __launch_bounds__(256) void k_iba_begin(IbaDev D) {
+  if (iba_done(D)) return;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const bool restore = D.lmi[IBA_LM_REJECTED] != 0;
+  if (restore) {
+    if (t < D.nS) D.S[t] = D.Sbk[t];
+    if (t < D.nPts) D.pts[t] = D.ptsBk[t];
+  } else {
+    if (t < D.nS) D.Sbk[t] = D.S[t];
+    if (t < D.nPts) D.ptsBk[t] = D.pts[t];
+  }
+  if (D.lmi[IBA_LM_NEEDBUILD]) {
+    if (t < D.P * D.P) D.H[t] = 0.0;
+    if (t < D.P) D.b[t] = 0.0;
+    if (t < 18 * D.nE) D.Hpl[t] = 0.0;
+  }
+}
+// after the last slot: a rejected last trial is undone
+__global__ __launch_bounds__(256) void k_iba_end(IbaDev D) {
+  if (!D.lmi[IBA_LM_REJECTED]) return;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < D.nS) D.S[t] = D.Sbk[t];
+  if (t < D.nPts) D.pts[t] = D.ptsBk[t];
+}
+__global__ void k_iba_lm_init(IbaDev D, double chi, double lambda0) {
+  D.lmd[IBA_LMD_CHI] = chi; D.lmd[IBA_LMD_LAMBDA] = lambda0; D.lmd[IBA_LMD_NI] = 2; D.lmd[IBA_LMD_INICHI] = chi; D.lmd[IBA_LMD_LASTCHI] = chi;
+  for (int k = 0; k < 16; ++k) D.lmi[k] = 0;
+  D.lmi[IBA_LM_ITS] = 1; D.lmi[IBA_LM_NEEDBUILD] = 1;
+  D.scal[0] = 0.0; D.scal[1] = 0.0;
 }
 
 // point side of buildSystem: Hll, bl (one thread per point over its edges, no atomics)
 __global__ __launch_bounds__(256) void k_iba_points(IbaDev D) {
+  if (iba_no_build(D)) return;
   const int l = blockIdx.x * 256 + threadIdx.x;
   if (l >= D.nMP) return;
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
@@ -1247,6 +1349,7 @@ __global__ __launch_bounds__(256) void k_iba_points(IbaDev D) {
 }
 // keyframe side: one wave per chunk of <= 64 edges of one optimizable keyframe
 __global__ __launch_bounds__(256) void k_iba_kf(IbaDev D) {
+  if (iba_no_build(D)) return;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= D.nChunks) return;
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
@@ -1322,6 +1425,7 @@ __global__ __launch_bounds__(256) void k_iba_kf(IbaDev D) {
 __global__ __launch_bounds__(64) void k_iba_links(IbaDev D) {
   __shared__ double J[216], OJ[216], Oe[9];
   __shared__ double sw;
+  if (iba_no_build(D)) return;
   const int i = blockIdx.x, tid = threadIdx.x;
   const int k1 = D.iKF1[i], k2 = D.iKF2[i];
   for (int k = tid; k < 216; k += 64) J[k] = 0;
@@ -1390,7 +1494,9 @@ __device__ __forceinline__ bool inv3(const double* D3, double* I) {
   return true;
 }
 // Hs = H + lambda I, bs = b[0:P]
-__global__ __launch_bounds__(256) void k_iba_hs_init(IbaDev D, double lambda) {
+__global__ __launch_bounds__(256) void k_iba_hs_init(IbaDev D) {
+  if (iba_done(D)) return;
+  const double lambda = D.lmd[IBA_LMD_LAMBDA];
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int n = D.P * D.P;
   if (t < n) { const int r = t / D.P, c = t - r * D.P; D.Hs[t] = D.H[t] + (r == c ? lambda : 0.0); }
@@ -1411,6 +1517,7 @@ __device__ __forceinline__ bool iba_pair_block(const IbaDev& D, int e, int c1, i
   return true;
 }
 __global__ __launch_bounds__(256) void k_iba_pack_w(IbaDev D) {
+  if (iba_no_build(D)) return;
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int M = 6 * (D.P / 15);
   if (t < D.nE) {
@@ -1426,7 +1533,9 @@ __global__ __launch_bounds__(256) void k_iba_pack_w(IbaDev D) {
   }
   if (t < 3 * D.nMP) D.sW[(size_t)t * D.sMp + M] = D.b[D.P + t];
 }
-__global__ __launch_bounds__(256) void k_iba_pack_wd(IbaDev D, double lambda) {
+__global__ __launch_bounds__(256) void k_iba_pack_wd(IbaDev D) {
+  if (iba_done(D)) return;
+  const double lambda = D.lmd[IBA_LMD_LAMBDA];
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= D.nE) return;
   const int c1 = D.col[D.eKF[t]];
@@ -1446,6 +1555,7 @@ __global__ __launch_bounds__(256) void k_iba_pack_wd(IbaDev D, double lambda) {
 }
 // Hs(pose rows / columns) -= C, bs(pose rows) -= C[:, M], from the partial products (four lanes per element, fixed order)
 __global__ __launch_bounds__(256) void k_iba_schur_finish(IbaDev D) {
+  if (iba_done(D)) return;
   const int t = blockIdx.x * 256 + threadIdx.x, gid = t >> 2, q = t & 3;
   const int M = 6 * (D.P / 15);
   const bool mat = gid < M * M, rhs = !mat && gid < M * M + M;
@@ -1461,8 +1571,10 @@ __global__ __launch_bounds__(256) void k_iba_schur_finish(IbaDev D) {
 // updates per point on a few thousand addresses: with LDSACC the workgroup accumulates them in LDS ((6 N)^2 doubles, LDS atomics)
 // and flushes once; without (large windows) they go to global memory directly.
 template <bool LDSACC>
-__global__ __launch_bounds__(256) void k_iba_schur(IbaDev D, double lambda) {
+__global__ __launch_bounds__(256) void k_iba_schur(IbaDev D) {
   extern __shared__ double sS[];   // LDSACC: M * M + M, M = 6 * (P / 15)
+  if (iba_done(D)) return;
+  const double lambda = D.lmd[IBA_LMD_LAMBDA];
   const int M = 6 * (D.P / 15);
   if (LDSACC) { for (int k = threadIdx.x; k < M * M + M; k += 256) sS[k] = 0; __syncthreads(); }
   const int l = blockIdx.x * 256 + threadIdx.x;
@@ -1550,12 +1662,14 @@ __device__ bool wave_ldl_factor16(double* blk, int lane) {
 __global__ __launch_bounds__(morbdense::LT) void k_iba_solve_lds(IbaDev D) {
   extern __shared__ double sLd[];
   __shared__ int sOk;
+  if (iba_done(D)) return;
   const bool ok = morbdense::ldlt_solve<true>(D.Hs, D.bs, D.x, D.P, sLd, &sOk);
   if (threadIdx.x == 0) D.scal[2] = ok ? 1.0 : 0.0;
 }
 constexpr int IBA_SB_T = 1024;
 __global__ __launch_bounds__(IBA_SB_T) void k_iba_solve_blocked(IbaDev D) {
   extern __shared__ double sm[];   // pnlL[(n + 16) * NBP] | pnlU[(n + 16) * NBP] | dblk[NB * NBP] | y[n]
+  if (iba_done(D)) return;
   const int n = D.P, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int np = n + IBA_NB;   // (the panel copies are read in whole 16-row tiles by the matrix-core trailing update)
   double* pnlL = sm; double* pnlU = sm + (size_t)np * IBA_NBP; double* dblk = pnlU + (size_t)np * IBA_NBP; double* y = dblk + IBA_NB * IBA_NBP;
@@ -1709,7 +1823,9 @@ __global__ __launch_bounds__(IBA_SB_T) void k_iba_solve_blocked(IbaDev D) {
 }
 
 // back-substitution of the points + oplus of every vertex + the LM scale  sum x (lambda x + b) -> scal[1]
-__global__ __launch_bounds__(256) void k_iba_update(IbaDev D, double lambda) {
+__global__ __launch_bounds__(256) void k_iba_update(IbaDev D) {
+  if (iba_done(D)) return;
+  const double lambda = D.lmd[IBA_LMD_LAMBDA];
   const int t = blockIdx.x * 256 + threadIdx.x;
   double sc = 0;
   if (t < D.nMP) {
@@ -1942,7 +2058,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
                    sizeof(double) * (size_t)P * P, sizeof(double) * (size_t)P * P, sizeof(double) * nX, sizeof(double) * (size_t)P,
                    sizeof(double) * nX, sizeof(double) * 9 * (size_t)nMP, sizeof(double) * 18 * (size_t)nE, sizeof(double) * 4,
                    (size_t)nE, (size_t)nE, sizeof(double) * splan.wElems(), sizeof(double) * splan.wElems(), sizeof(double) * splan.partElems(),
-                   sizeof(int2) * (size_t)splan.nblk, sizeof(int) * (size_t)splan.nb * splan.nb})
+                   sizeof(int2) * (size_t)splan.nblk, sizeof(int) * (size_t)splan.nb * splan.nb, sizeof(double) * 8, sizeof(int) * 16})
     reserve(b);
   void* arena = nullptr;
   { const int rc = morb_optimizer_workspace(o, arenaBytes, &arena); if (rc != MORB_OK) return rc; }
@@ -1970,8 +2086,10 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
   float* d_scale = (float*)up(iInfoScale, sizeof(float) * nI);
   float* d_kfIn = (float*)up(kfState21, sizeof(float) * 21 * nKF);
   float* d_mpIn = (float*)up(mpPos, sizeof(float) * 3 * nMP);
-  D.S = (double*)dalloc(sizeof(double) * nS); double* Sbk = (double*)dalloc(sizeof(double) * nS);
-  D.pts = (double*)dalloc(sizeof(double) * nPts); double* ptsBk = (double*)dalloc(sizeof(double) * nPts);
+  D.S = (double*)dalloc(sizeof(double) * nS); D.Sbk = (double*)dalloc(sizeof(double) * nS);
+  D.pts = (double*)dalloc(sizeof(double) * nPts); D.ptsBk = (double*)dalloc(sizeof(double) * nPts);
+  D.nS = (int)nS; D.nPts = (int)nPts;
+  D.lmd = (double*)dalloc(sizeof(double) * 8); D.lmi = (int*)dalloc(sizeof(int) * 16);
   D.vErr = (double*)dalloc(sizeof(double) * 3 * nE); D.iErr = (double*)dalloc(sizeof(double) * 9 * std::max(nI, 1));
   D.gErr = (double*)dalloc(sizeof(double) * 3 * std::max(nI, 1)); D.aErr = (double*)dalloc(sizeof(double) * 3 * std::max(nI, 1));
   D.InfoI = (double*)dalloc(sizeof(double) * 81 * std::max(nI, 1)); D.InfoG = (double*)dalloc(sizeof(double) * 9 * std::max(nI, 1));
@@ -2003,7 +2121,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
   double h[4];
   auto errors = [&](double* chi) -> bool {   // computeActiveErrors + activeRobustChi2
     if (hipMemsetAsync(D.scal, 0, sizeof(double) * 4, st) != hipSuccess) return false;
-    hipLaunchKernelGGL(k_iba_errors, dim3(div_up(nE + nI, 256)), dim3(256), 0, st, D);
+    hipLaunchKernelGGL(k_iba_errors, dim3(div_up(nE + nI, 256)), dim3(256), 0, st, D, 0);
     if (hipMemcpyAsync(h, D.scal, sizeof(double) * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
     if (hipStreamSynchronize(st) != hipSuccess) return false;
     *chi = h[0];
@@ -2031,69 +2149,56 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
   double chi = 0;
   if (!errors(&chi)) return fail("k_iba_errors failed");
   const float err0 = (float)chi;
-  double lambda = bLarge ? 1e-2 : 1e0, ni = 2;
-  int nBadIts = 0, trials = 0, outer = 0;
-  const int optIt = bLarge ? 4 : 10;
-  double currentChi = chi;   // errors of the current state are valid here
-  for (int it = 0; it < optIt; ++it) {
-    ++outer;
-    if (it > 0 && !errors(&currentChi)) return fail("k_iba_errors failed");   // computeActiveErrors at the top of solve()
-    const double iniChi = currentChi;
-    // buildSystem
-    (void)hipMemsetAsync(D.H, 0, sizeof(double) * (size_t)P * P, st);
-    (void)hipMemsetAsync(D.b, 0, sizeof(double) * P, st);
-    (void)hipMemsetAsync(D.Hpl, 0, sizeof(double) * 18 * nE, st);
-    hipLaunchKernelGGL(k_iba_points, dim3(div_up(nMP, 256)), dim3(256), 0, st, D);
-    if (nChunks) hipLaunchKernelGGL(k_iba_kf, dim3(div_up(nChunks, 4)), dim3(256), 0, st, D);
-    if (nI) hipLaunchKernelGGL(k_iba_links, dim3(nI), dim3(64), 0, st, D);
-    if (!valuSchur) hipLaunchKernelGGL(k_iba_pack_w, dim3(div_up(std::max(nE, 3 * nMP), 256)), dim3(256), 0, st, D);
-    if (it == 0) { ni = 2; nBadIts = 0; }
-    double rho = 0;
-    int qmax = 0;
-    do {
-      (void)hipMemcpyAsync(Sbk, D.S, sizeof(double) * nS, hipMemcpyDeviceToDevice, st);
-      (void)hipMemcpyAsync(ptsBk, D.pts, sizeof(double) * nPts, hipMemcpyDeviceToDevice, st);
-      hipLaunchKernelGGL(k_iba_hs_init, dim3(div_up(P * P + P, 256)), dim3(256), 0, st, D, lambda);
+  // ---- Levenberg-Marquardt with the control flow on the device (as grid-mode LocalBA, optimizer.hip): one slot = one trial; the host queues
+  // slots one ahead of the decisions and stops when the mapped `done` word appears; kernels queued behind the last decision return at once
+  int trials = 0, outer = 0;
+  {
+    int* hostw = nullptr;
+    int* hostwDev = nullptr;
+    MORB_REQUIRE(morb_optimizer_lm_words(o, &hostw, &hostwDev) == MORB_OK, MORB_ERR_HIP, "cannot map the LM state words");
+    D.lmHost = hostwDev;
+    D.optIt = bLarge ? 4 : 10;
+    __atomic_store_n(hostw + 0, 0, __ATOMIC_RELAXED); __atomic_store_n(hostw + 1, 0, __ATOMIC_RELEASE);
+    hipLaunchKernelGGL(k_iba_lm_init, dim3(1), dim3(1), 0, st, D, chi, bLarge ? 1e-2 : 1e0);
+    const int beginGrid = div_up((int)std::max<size_t>(std::max<size_t>(nS, nPts), std::max<size_t>((size_t)P * P, (size_t)18 * nE)), 256);
+    for (int slot = 0; slot < 120; ++slot) {
+      hipLaunchKernelGGL(k_iba_begin, dim3(beginGrid), dim3(256), 0, st, D);
+      // buildSystem (runs only when the previous trial was accepted)
+      hipLaunchKernelGGL(k_iba_points, dim3(div_up(nMP, 256)), dim3(256), 0, st, D);
+      if (nChunks) hipLaunchKernelGGL(k_iba_kf, dim3(div_up(nChunks, 4)), dim3(256), 0, st, D);
+      if (nI) hipLaunchKernelGGL(k_iba_links, dim3(nI), dim3(64), 0, st, D);
+      if (!valuSchur) hipLaunchKernelGGL(k_iba_pack_w, dim3(div_up(std::max(nE, 3 * nMP), 256)), dim3(256), 0, st, D);
+      // the trial
+      hipLaunchKernelGGL(k_iba_hs_init, dim3(div_up(P * P + P, 256)), dim3(256), 0, st, D);
       if (!valuSchur) {
         // Schur complement of the points on the FP64 matrix cores: one dense product for matrix and right-hand side
-        hipLaunchKernelGGL(k_iba_pack_wd, dim3(div_up(nE, 256)), dim3(256), 0, st, D, lambda);
+        hipLaunchKernelGGL(k_iba_pack_wd, dim3(div_up(nE, 256)), dim3(256), 0, st, D);
         hipLaunchKernelGGL(morbschur::k_schur_mfma, dim3(splan.nblk, splan.nsplit), dim3(64), 0, st, (const double*)D.sWD, (const double*)D.sW,
-                           splan.Mp, splan.ksteps, splan.stepsPerSplit, D.sBlocks, D.sPart, (const int*)nullptr);
+                           splan.Mp, splan.ksteps, splan.stepsPerSplit, D.sBlocks, D.sPart, (const int*)(D.lmi + IBA_LM_DONE));
         hipLaunchKernelGGL(k_iba_schur_finish, dim3(div_up(4 * (Mpose * Mpose + Mpose), 256)), dim3(256), 0, st, D);
-      } else if (ldsSchur) hipLaunchKernelGGL(k_iba_schur<true>, dim3(div_up(nMP, 256)), dim3(256), schurLds, st, D, lambda);   // (measurement only, MORB_SCHUR_VALU=1: round 1's form with FP64 atomics)
-      else hipLaunchKernelGGL(k_iba_schur<false>, dim3(div_up(nMP, 256)), dim3(256), 0, st, D, lambda);
+      } else if (ldsSchur) hipLaunchKernelGGL(k_iba_schur<true>, dim3(div_up(nMP, 256)), dim3(256), schurLds, st, D);   // (measurement only, MORB_SCHUR_VALU=1: round 1's form with FP64 atomics)
+      else hipLaunchKernelGGL(k_iba_schur<false>, dim3(div_up(nMP, 256)), dim3(256), 0, st, D);
       if (denseLds) hipLaunchKernelGGL(k_iba_solve_lds, dim3(1), dim3(morbdense::LT), denseLds, st, D);
       else hipLaunchKernelGGL(k_iba_solve_blocked, dim3(1), dim3(IBA_SB_T), blockedLds, st, D);
       // a failed solve leaves x as it was (zero at the first trial): g2o still applies the update
-      (void)hipMemsetAsync(D.scal, 0, sizeof(double) * 2, st);
-      hipLaunchKernelGGL(k_iba_update, dim3(div_up(nMP + nKF, 256)), dim3(256), 0, st, D, lambda);
-      (void)hipMemcpyAsync(h + 1, D.scal + 1, sizeof(double) * 2, hipMemcpyDeviceToHost, st);
-      hipLaunchKernelGGL(k_iba_errors, dim3(div_up(nE + nI, 256)), dim3(256), 0, st, D);
-      (void)hipMemcpyAsync(h, D.scal, sizeof(double), hipMemcpyDeviceToHost, st);
-      if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail("LocalInertialBA trial failed");
-      double tempChi = h[0];
-      const bool ok2 = h[2] != 0.0;
-      if (!ok2) tempChi = std::numeric_limits<double>::max();
-      rho = currentChi - tempChi;
-      const double scale = h[1] + 1e-3;
-      rho /= scale;
-      if (rho > 0 && std::isfinite(tempChi)) {
-        double alpha = 1. - std::pow((2 * rho - 1), 3);
-        alpha = std::min(alpha, 2. / 3.);
-        lambda *= std::max(1. / 3., alpha);
-        ni = 2;
-        currentChi = tempChi;
-      } else {
-        lambda *= ni;
-        ni *= 2;
-        (void)hipMemcpyAsync(D.S, Sbk, sizeof(double) * nS, hipMemcpyDeviceToDevice, st);
-        (void)hipMemcpyAsync(D.pts, ptsBk, sizeof(double) * nPts, hipMemcpyDeviceToDevice, st);
+      hipLaunchKernelGGL(k_iba_update, dim3(div_up(nMP + nKF, 256)), dim3(256), 0, st, D);
+      hipLaunchKernelGGL(k_iba_errors, dim3(div_up(nE + nI, 256)), dim3(256), 0, st, D, 1);
+      if (hipGetLastError() != hipSuccess) return fail("LocalInertialBA trial failed");
+      unsigned spins = 0;
+      while (!__atomic_load_n(hostw + 1, __ATOMIC_ACQUIRE) && __atomic_load_n(hostw + 0, __ATOMIC_ACQUIRE) < slot) {   // one slot ahead
+        if ((++spins & 0xFFFFu) == 0 && hipStreamQuery(st) == hipSuccess) break;   // (everything queued has run: the words are final)
       }
-      ++qmax; ++trials;
-    } while (rho < 0 && qmax < 10);
-    if (qmax == 10 || rho == 0) break;
-    if ((iniChi - currentChi) * 1e3 < iniChi) nBadIts++; else nBadIts = 0;
-    if (nBadIts >= 3) break;
+      if (__atomic_load_n(hostw + 1, __ATOMIC_ACQUIRE)) break;
+    }
+    hipLaunchKernelGGL(k_iba_end, dim3(div_up((int)std::max<size_t>(nS, nPts), 256)), dim3(256), 0, st, D);
+    // the loop's counters and the chi2 of the last evaluated trial (h[0] below)
+    int hi[16];
+    double hd[8];
+    if (hipMemcpyAsync(hi, D.lmi, sizeof hi, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(hd, D.lmd, sizeof hd, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
+      return fail("LocalInertialBA failed");
+    outer = hi[IBA_LM_ITS]; trials = hi[IBA_LM_TRIALS];
+    h[0] = hd[IBA_LMD_LASTCHI];
   }
   // activeRobustChi2 of the last computed errors = h[0] of the last trial (or the initial one)
   const float errEnd = (float)(trials ? h[0] : chi);

@@ -1650,6 +1650,8 @@ struct morb_optimizer {
   hipEvent_t evFork = nullptr, evJoin = nullptr;
   void* work = nullptr;        // grow-only device workspace of the one-shot entry points (morb_local_inertial_ba)
   size_t workBytes = 0;
+  int* lmWords = nullptr;      // 16 pinned, device-mapped ints: LM state mirror of morb_local_inertial_ba (device-side LM control)
+  int* lmWordsDev = nullptr;
 };
 
 struct morb_ba_problem {
@@ -1709,6 +1711,17 @@ int morb_optimizer_workspace(morb_optimizer* o, size_t bytes, void** out) {
   return MORB_OK;
 }
 
+int morb_optimizer_lm_words(morb_optimizer* o, int** host, int** dev) {
+  MORB_REQUIRE(o && host && dev, MORB_ERR_INVALID, "NULL argument");
+  if (!o->lmWords) {
+    MORB_HIP_CHECK(hipHostMalloc(&o->lmWords, sizeof(int) * 16, hipHostMallocMapped));
+    memset(o->lmWords, 0, sizeof(int) * 16);
+    MORB_HIP_CHECK(hipHostGetDevicePointer((void**)&o->lmWordsDev, o->lmWords, 0));
+  }
+  *host = o->lmWords; *dev = o->lmWordsDev;
+  return MORB_OK;
+}
+
 void morb_optimizer_destroy(morb_optimizer* o) {
   if (!o) return;
   (void)hipSetDevice(o->device);
@@ -1717,6 +1730,7 @@ void morb_optimizer_destroy(morb_optimizer* o) {
   if (o->evFork) (void)hipEventDestroy(o->evFork);
   if (o->evJoin) (void)hipEventDestroy(o->evJoin);
   if (o->work) (void)hipFree(o->work);
+  if (o->lmWords) (void)hipHostFree(o->lmWords);
   (void)hipStreamDestroy(o->stream);
   delete o;
 }
