@@ -1264,25 +1264,6 @@ __device__ void iba_lm_decide(const IbaDev& D) {
   __hip_atomic_store(D.lmHost + 1, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(D.lmHost + 0, trials, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// start of a trial slot: take the backup of states and points (or, after a rejected trial, restore it) and — when the system is rebuilt —
-// clear the accumulators of buildSystem
-__global__ __launch_bounds__(256) void k_iba_begin(IbaDev D) {
-  if (iba_done(D)) return;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  const bool restore = D.lmi[IBA_LM_REJECTED] != 0;
-  if (restore) {
-    if (t < D.nS) D.S[t] = D.Sbk[t];
-    if (t < D.nPts) D.pts[t] = D.ptsBk[t];
-  } else {
-    if (t < D.nS) D.Sbk[t] = D.S[t];
-    if (t < D.nPts) D.ptsBk[t] = D.pts[t];
-  }
-  if (D.lmi[IBA_LM_NEEDBUILD]) {
-    if (t < D.P * D.P) D.H[t] = 0.0;
-    if (t < D.P) D.b[t] = 0.0;
-    if (t < 18 * D.nE) D.Hpl[t] = 0.0;
-  }
-}
 // after the last slot: a rejected last trial is undone
 __global__ __launch_bounds__(256) void k_iba_end(IbaDev D) {
   if (!D.lmi[IBA_LM_REJECTED]) return;
@@ -1298,8 +1279,26 @@ __global__ void k_iba_lm_init(IbaDev D, double chi, double lambda0) {
 }
 
 // point side of buildSystem: Hll, bl (one thread per point over its edges, no atomics)
+// (the launch starts with k_iba_begin's work — backup / restore, clearing the accumulators — on as many threads as that needs)
+__device__ __forceinline__ void iba_begin_part(const IbaDev& D, int t) {
+  const bool restore = D.lmi[IBA_LM_REJECTED] != 0;
+  if (restore) {
+    if (t < D.nS) D.S[t] = D.Sbk[t];
+    if (t < D.nPts) D.pts[t] = D.ptsBk[t];
+  } else {
+    if (t < D.nS) D.Sbk[t] = D.S[t];
+    if (t < D.nPts) D.ptsBk[t] = D.pts[t];
+  }
+  if (D.lmi[IBA_LM_NEEDBUILD]) {
+    if (t < D.P * D.P) D.H[t] = 0.0;
+    if (t < D.P) D.b[t] = 0.0;
+    if (t < 18 * D.nE) D.Hpl[t] = 0.0;
+  }
+}
 __global__ __launch_bounds__(256) void k_iba_points(IbaDev D) {
-  if (iba_no_build(D)) return;
+  if (iba_done(D)) return;
+  iba_begin_part(D, blockIdx.x * 256 + threadIdx.x);
+  if (D.lmi[IBA_LM_NEEDBUILD] == 0) return;   // (a rebuild follows an accepted trial: nothing was restored, the points read below are current)
   const int l = blockIdx.x * 256 + threadIdx.x;
   if (l >= D.nMP) return;
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
@@ -1533,10 +1532,16 @@ __global__ __launch_bounds__(256) void k_iba_pack_w(IbaDev D) {
   }
   if (t < 3 * D.nMP) D.sW[(size_t)t * D.sMp + M] = D.b[D.P + t];
 }
+// (the launch also does k_iba_hs_init's work — Hs = H + lambda I, bs = b — on its first P * P + P threads: one launch fewer per trial)
 __global__ __launch_bounds__(256) void k_iba_pack_wd(IbaDev D) {
   if (iba_done(D)) return;
   const double lambda = D.lmd[IBA_LMD_LAMBDA];
   const int t = blockIdx.x * 256 + threadIdx.x;
+  {
+    const int n = D.P * D.P;
+    if (t < n) { const int r = t / D.P, c = t - r * D.P; D.Hs[t] = D.H[t] + (r == c ? lambda : 0.0); }
+    else if (t - n < D.P) D.bs[t - n] = D.b[t - n];
+  }
   if (t >= D.nE) return;
   const int c1 = D.col[D.eKF[t]];
   if (c1 < 0) return;
@@ -2160,19 +2165,18 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
     D.optIt = bLarge ? 4 : 10;
     __atomic_store_n(hostw + 0, 0, __ATOMIC_RELAXED); __atomic_store_n(hostw + 1, 0, __ATOMIC_RELEASE);
     hipLaunchKernelGGL(k_iba_lm_init, dim3(1), dim3(1), 0, st, D, chi, bLarge ? 1e-2 : 1e0);
-    const int beginGrid = div_up((int)std::max<size_t>(std::max<size_t>(nS, nPts), std::max<size_t>((size_t)P * P, (size_t)18 * nE)), 256);
+    const int beginGrid = div_up((int)std::max<size_t>(std::max<size_t>(std::max<size_t>(nS, nPts), (size_t)nMP), std::max<size_t>((size_t)P * P, (size_t)18 * nE)), 256);
     for (int slot = 0; slot < 120; ++slot) {
-      hipLaunchKernelGGL(k_iba_begin, dim3(beginGrid), dim3(256), 0, st, D);
-      // buildSystem (runs only when the previous trial was accepted)
-      hipLaunchKernelGGL(k_iba_points, dim3(div_up(nMP, 256)), dim3(256), 0, st, D);
+      // backup / restore, then buildSystem (which runs only when the previous trial was accepted)
+      hipLaunchKernelGGL(k_iba_points, dim3(beginGrid), dim3(256), 0, st, D);
       if (nChunks) hipLaunchKernelGGL(k_iba_kf, dim3(div_up(nChunks, 4)), dim3(256), 0, st, D);
       if (nI) hipLaunchKernelGGL(k_iba_links, dim3(nI), dim3(64), 0, st, D);
       if (!valuSchur) hipLaunchKernelGGL(k_iba_pack_w, dim3(div_up(std::max(nE, 3 * nMP), 256)), dim3(256), 0, st, D);
       // the trial
-      hipLaunchKernelGGL(k_iba_hs_init, dim3(div_up(P * P + P, 256)), dim3(256), 0, st, D);
+      if (valuSchur) hipLaunchKernelGGL(k_iba_hs_init, dim3(div_up(P * P + P, 256)), dim3(256), 0, st, D);
       if (!valuSchur) {
         // Schur complement of the points on the FP64 matrix cores: one dense product for matrix and right-hand side
-        hipLaunchKernelGGL(k_iba_pack_wd, dim3(div_up(nE, 256)), dim3(256), 0, st, D);
+        hipLaunchKernelGGL(k_iba_pack_wd, dim3(div_up(std::max(nE, P * P + P), 256)), dim3(256), 0, st, D);
         hipLaunchKernelGGL(morbschur::k_schur_mfma, dim3(splan.nblk, splan.nsplit), dim3(64), 0, st, (const double*)D.sWD, (const double*)D.sW,
                            splan.Mp, splan.ksteps, splan.stepsPerSplit, D.sBlocks, D.sPart, (const int*)(D.lmi + IBA_LM_DONE));
         hipLaunchKernelGGL(k_iba_schur_finish, dim3(div_up(4 * (Mpose * Mpose + Mpose), 256)), dim3(256), 0, st, D);
