@@ -6,7 +6,8 @@ for r in csv.DictReader(open(sys.argv[1])):
     m = re.search(r"\bk_\w+", r["Kernel_Name"])
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), m.group(0) if m else r["Kernel_Name"][:24]))
 rows.sort()
-idx = [i for i, r in enumerate(rows) if r[2] == "k_ba_reset"]
+marker = sys.argv[2] if len(sys.argv) > 2 else "k_ba_reset"
+idx = [i for i, r in enumerate(rows) if r[2] == marker]
 a = idx[-2] if len(idx) > 1 else idx[-1]
 b = idx[-1] if len(idx) > 1 else len(rows)
 sel = rows[a:b]
