@@ -753,7 +753,10 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
   morbqt::Node* nodes = reinterpret_cast<morbqt::Node*>(sp); sp += (size_t)maxNodeCap * sizeof(morbqt::Node);
   uint32_t* ldsKeys = reinterpret_cast<uint32_t*>(sp); sp += (size_t)keyCap * 4;
   uint32_t* ldsTmp = reinterpret_cast<uint32_t*>(sp); sp += (size_t)keyCap * 4;
-  int* cellOff = reinterpret_cast<int*>(sp); sp += (size_t)(maxCells + 1) * 4;
+  // the cell offsets are dead once the candidates are gathered and the split ranks are first written inside qt_distribute: one region
+  // serves both when the offsets fit it (the host sizes the allocation the same way)
+  const bool aliasCells = maxCells + 1 <= maxNodeCap;
+  int* cellOff = reinterpret_cast<int*>(sp); if (!aliasCells) sp += (size_t)(maxCells + 1) * 4;
   uint32_t* brank = reinterpret_cast<uint32_t*>(sp); sp += (size_t)maxNodeCap * 4;
   uint16_t* freeIds = reinterpret_cast<uint16_t*>(sp); sp += (size_t)maxNodeCap * 2;
   uint16_t* order = reinterpret_cast<uint16_t*>(sp); sp += (size_t)maxNodeCap * 2;
@@ -1199,8 +1202,9 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
   // through the L2).  The capacity scales with level 0's area — twice the ~1 candidate per 233 px the benchmark images give, i.e. the
   // kLdsKeys = 3072 of a 752 x 480 image — and is cut to what the LDS leaves beside the node arrays (1920 x 1080 / 4000 features: ~8 k keys).
   {
-    const size_t fixed = (size_t)e->maxNodeCap * (8 + 8 + sizeof(morbqt::Node) + 4 + 2 + 2) + (size_t)(e->maxCells + 1) * 4 + (size_t)e->maxListCap * 2 + 64;
-    constexpr size_t kLdsBudget = 156 * 1024;   // (the full 160 KB is refused as a dynamic allocation)
+    const size_t fixed = (size_t)e->maxNodeCap * (8 + 8 + sizeof(morbqt::Node) + 4 + 2 + 2) + (e->maxCells + 1 <= e->maxNodeCap ? 0 : (size_t)(e->maxCells + 1) * 4) +
+                         (size_t)e->maxListCap * 2 + 64;
+    constexpr size_t kLdsBudget = 158 * 1024;   // (160 KB minus the kernel's static LDS)
     MORB_REQUIRE(fixed + 1024 * 8 <= kLdsBudget, MORB_ERR_UNSUPPORTED, "nfeatures too large for the LDS-resident quadtree");
     const long long want = std::max<long long>(kLdsKeys, (long long)e->geom[0].w * e->geom[0].h * 2 / 233);
     const long long fit = (long long)((kLdsBudget - fixed) / 8);
