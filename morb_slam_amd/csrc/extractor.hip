@@ -340,8 +340,8 @@ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 #ifdef MORB_FAST_TIMING
 #define PHASE_MARK(k) do { __syncthreads(); if (threadIdx.x == 0 && ((blockIdx.x * 7 + blockIdx.y) & 63) == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_fastPhase[k], now_ - t0_); t0_ = now_; } } while (0)
 extern "C" int morb_fast_timing(unsigned long long* out, int reset) {
-  if (reset) { unsigned long long z[16] = {0}; MORB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fastPhase), z, sizeof(z))); return 0; }
-  MORB_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fastPhase), 16 * sizeof(unsigned long long)));
+  if (reset) { unsigned long long z[32] = {0}; MORB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fastPhase), z, sizeof(z))); return 0; }
+  MORB_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fastPhase), 32 * sizeof(unsigned long long)));
   return 0;
 }
 #else

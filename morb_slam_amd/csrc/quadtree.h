@@ -27,7 +27,7 @@
 #endif
 
 #if defined(MORB_FAST_TIMING) && defined(__HIPCC__)
-__device__ unsigned long long g_fastPhase[16];   // phase clocks of tools/fast_phases.py (timing build only)
+__device__ unsigned long long g_fastPhase[32];   // phase clocks of tools/fast_phases.py (timing build only)
 #endif
 #if defined(MORB_FAST_TIMING) && QT_DEVICE
 #define QT_T0() unsigned long long q0_ = wall_clock64()
@@ -564,6 +564,7 @@ __device__ __forceinline__ void qt_write_children(Work& w, const Node& nd, int m
 __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int* nToExpand) {
   const int lane = QT_LANE;
   QT_SYNC();
+  QT_T0();
   // (1) keys per child
   for (int e0 = 0; e0 < m; e0 += 64) {
     const int e = e0 + lane;
@@ -594,6 +595,7 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
     }
   }
   QT_SYNC();
+  QT_MARK(16);
   // (2) ranks in processing order, and where to stop
   int runCh = 0, runEx = 0, runSize = s.size, mProc = m;
   for (int e0 = 0; e0 < m; e0 += 64) {
@@ -614,6 +616,7 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
     if (cut) break;
   }
   QT_SYNC();
+  QT_MARK(17);
   // (3) partition the keys, write the children, erase the parents
   const int oldHead = s.head, nA0 = s.nA, nFree0 = s.nFree;
   for (int e0 = 0; e0 < mProc; e0 += 64) {
@@ -655,6 +658,7 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
     }
   }
   QT_SYNC();
+  QT_MARK(18);
   // (4) bookkeeping; the parents' ids go back on the free stack after every child id has been taken
   s.head = oldHead - runCh;
   s.size += runCh - mProc;
@@ -664,6 +668,7 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
   for (int e = lane; e < mProc; e += 64) w.freeIds[s.nFree + e] = w.order[e];
   s.nFree += mProc;
   QT_SYNC();
+  QT_MARK(19);
 }
 #endif
 

@@ -30,11 +30,11 @@ ex.extract_batch(dev); torch.cuda.synchronize()
 lib.morb_fast_timing(None, 1)
 for _ in range(5): ex.extract_batch(dev)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 32)()
 lib.morb_fast_timing(buf, 0)
 names = ["load", "p1_reject", "p2_strength", "p3_nms", "p4_rows", "p5_output"]
 tot = sum(buf[:6])
 for n, v in zip(names, buf[:6]): print(f"{n:12s} {v:12d} ticks  {100.0 * v / max(tot, 1):5.1f} %")
 print("k_distribute level 0 (ticks of 10 ns per wave, mean over images):")
 nw = 5 * 2 * B
-for n, v in zip(["cell prefix", "gather", "quadtree", "candidates T", "selected n", "qt compact", "qt splits", "qt std::sort"], buf[8:16]): print(f"  {n:14s} {v / nw:10.1f}")
+for n, v in zip(["cell prefix", "gather", "quadtree", "candidates T", "selected n", "qt compact", "qt splits", "qt std::sort", "split: child counts", "split: ranks", "split: partition + children", "split: bookkeeping"], list(buf[8:16]) + list(buf[16:20])): print(f"  {n:28s} {v / nw:10.1f}")
