@@ -509,7 +509,11 @@ __global__ __launch_bounds__(FS_NT) void k_fast(const morb::FastGeom fg, const m
       // polarity): 32 flag bits per lane.  Compaction: per-lane popcount, one DPP scan per wave, one LDS atomic per wave, then
       // every lane emits its own entries.  Blocks that straddle xa / xb also flag pixels outside [xa, xb): those are dropped
       // when their strength would be stored.
-      const int nItems = (yb - ya) * 8;
+      // items per row = the 16-px blocks that hold evaluated pixels [xa, xb) — 7 of the window's 8 for a typical three-cell segment, 3
+      // for the single-cell second pass — so that a row's dead blocks do not take lane slots of a round
+      const int ix0 = xa >> 4, nIt = ((xb + 15) >> 4) - ix0;
+      const unsigned itMagic = c_magic20.m[nIt];
+      const int nItems = (yb - ya) * nIt;
       const unsigned LO = 0x00FF00FFu;
       unsigned KF[8], MF[8];   // per (dword & 1, parity, polarity): the add constant and the flag bit (8 + index) in both halves
 #pragma unroll
@@ -517,7 +521,8 @@ __global__ __launch_bounds__(FS_NT) void k_fast(const morb::FastGeom fg, const m
       for (int i0 = 0; i0 < nItems; i0 += FS_NT) {
         if (i0 + __builtin_amdgcn_readfirstlane(tid & ~63) >= nItems) break;   // wave-uniform: no item left for this wave
         const int i = i0 + tid;
-        const int y = (i >> 3) + ya, xb0 = (i & 7) << 4;
+        const int iy = (int)(((unsigned)i * itMagic) >> 20);
+        const int y = iy + ya, xb0 = (i - __mul24(iy, nIt) + ix0) << 4;
         unsigned W = 0;   // bit f: f[0] polarity (0 dark, 1 bright), pixel offset in the block = f[3] f[2] f[4] f[1]
         if (i < nItems && xb0 < xb && xb0 + 16 > xa) {
           const uint8_t* rowp = tile + ((y << 7) | xb0);
