@@ -125,15 +125,14 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, con
 // Hamming match (lexicographic (dist, iR) minimum = the reference's first-best over vRowIndices[row]), then the
 // 11x11 SAD search over 11 shifts on the un-blurred pyramid level, parabola refinement, disparity -> depth.
 // Kernel B: one workgroup per frame: median of the accepted SAD distances, 1.5*1.4*median cut.
-// One workgroup = SM_LK left keypoints of one frame (4 waves x SM_LK/4 keypoints in turn).  PMC showed the first
+// One workgroup = SM_LK left keypoints of one frame (4 waves x SM_LK/4 keypoints in turn; SM_LK by batch size, sm_lk_for()).  PMC showed the first
 // version (one wave per left keypoint, every wave re-reading all right keypoints from global memory) bound by the
 // number of vector-memory instructions, so: the right keypoints' row band / x / octave go to LDS once per workgroup,
 // the row-band test runs on LDS, the survivors are compacted to a candidate list before any descriptor is loaded,
 // and the two SAD patches are fetched as unaligned dwords into LDS instead of 24 byte loads per lane.
-#ifndef MORB_SM_LK
-#define MORB_SM_LK 32   // (16: 429 us, 32: 391 us, 64: 405 us per 256 frames)
-#endif
-constexpr int SM_LK = MORB_SM_LK;
+// left keypoints per workgroup: 32 for large batches (256 frames: 16: 429 us, 32: 391 us, 64: 405 us), fewer for a handful of frames, where
+// a wave's keypoints — one dependent chain each — are the latency of the call (one frame: 4 per workgroup, i.e. one per wave)
+__host__ __device__ inline int sm_lk_for(int nframes) { return nframes <= 2 ? 4 : nframes <= 8 ? 8 : nframes <= 32 ? 16 : 32; }
 constexpr int SM_BAND = 16;   // rows per band of the per-workgroup row index (the reference's vRowIndices, coarsened)
 constexpr int SM_MAXB = 256;  // bands that fit (images up to 4096 rows); SM_LIST * cap list entries, else the full scan
 // Per-level facts the stereo kernel needs, by value in the kernarg segment (scalar loads, no dependent round trip
@@ -155,7 +154,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const StereoGeom sg, const
                                                       const uint8_t* __restrict__ desc, const int* __restrict__ count,
                                                       int cap, float mbf, float mb,
                                                       float* __restrict__ uRight, float* __restrict__ depth,
-                                                      int* __restrict__ sadDist) {
+                                                      int* __restrict__ sadDist, int SM_LK) {
   extern __shared__ __align__(16) uint8_t smem[];
   RightKp* tab = reinterpret_cast<RightKp*>(smem);                       // [cap]
   int* bandStart = reinterpret_cast<int*>(tab + cap);                    // [SM_MAXB + 1]
@@ -925,8 +924,9 @@ int morb_stereo_match_batch(morb_matcher* m, const morb_extractor* e, int nframe
                             4 * SM_CAND * sizeof(uint16_t) + 4 * (11 * 12 + 11 * 24);
   MORB_REQUIRE(stereoSmem <= 160 * 1024 && cap < 65536 && e->nlevels <= 16, MORB_ERR_UNSUPPORTED, "too many keypoints per image for the LDS-resident right-keypoint table");
   MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stereo_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stereoSmem));
-  hipLaunchKernelGGL(k_stereo_match, dim3(div_up(cap, SM_LK), nframes), dim3(256), stereoSmem, st, sg, e->d_pyr, d_kps, d_desc,
-                     d_count, cap, mbf, mb, d_uRight, d_depth, m->d_sad);
+  const int lk = sm_lk_for(nframes);
+  hipLaunchKernelGGL(k_stereo_match, dim3(div_up(cap, lk), nframes), dim3(256), stereoSmem, st, sg, e->d_pyr, d_kps, d_desc,
+                     d_count, cap, mbf, mb, d_uRight, d_depth, m->d_sad, lk);
   hipLaunchKernelGGL(k_stereo_median, dim3(nframes), dim3(256), 0, st, d_count, cap, d_uRight, d_depth, m->d_sad);
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
