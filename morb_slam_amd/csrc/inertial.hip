@@ -33,7 +33,8 @@ extern "C" {
 int morb_optimizer_device(const morb_optimizer*);
 void* morb_optimizer_stream(const morb_optimizer*);
 int morb_optimizer_workspace(morb_optimizer*, size_t bytes, void** out);
-int morb_optimizer_lm_words(morb_optimizer*, int** host, int** dev);   // 16 pinned, device-mapped ints (LM state mirror)
+int morb_optimizer_lm_words(morb_optimizer*, int** host, int** dev);
+int morb_optimizer_staging(morb_optimizer*, size_t bytes, void** host);   // grow-only pinned host buffer   // 16 pinned, device-mapped ints (LM state mirror)
 }
 
 #define WAVE_SYNC_F()                                      \
@@ -1155,6 +1156,10 @@ __global__ void k_iba_setup_kf(IbaDev D, const float* __restrict__ kfState) {
   load_state(D.g, kfState + 21 * k, V);
   iba_store(V, D.S + 33 * (size_t)k);
 }
+__global__ void k_iba_setup_pts(IbaDev D, const float* __restrict__ mpPos) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < D.nPts) D.pts[k] = (double)mpPos[k];
+}
 // informations of the inertial links: one workgroup per link, the 9 x 9 work arrays in LDS (one thread computes)
 __global__ __launch_bounds__(64) void k_iba_setup_links(IbaDev D, const float* __restrict__ infoScale) {
   __shared__ double C9[81], M[162], V[162], Inf[81];
@@ -2074,7 +2079,33 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
     return arenaOff <= arenaBytes ? p : nullptr;
   };
   auto cleanup = [&]() {};
-  auto up = [&](const void* h, size_t bytes) -> void* { void* d = dalloc(bytes); if (d && bytes) (void)hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st); return d; };
+  // host -> device: every array goes into a pinned mirror of the arena's upload prefix first and crosses PCIe in ONE copy (twenty
+  // pageable hipMemcpyAsync calls, each staged and synchronised by the runtime, were ~0.25 ms of a 1.8 ms call)
+  void* stage = nullptr;
+  size_t stageCap = 0;
+  {
+    size_t upBytes = 0;
+    for (size_t b : {sizeof(int) * (size_t)nE, sizeof(int) * (size_t)nE, sizeof(float) * 3 * (size_t)nE, sizeof(float) * (size_t)nE,
+                     sizeof(int) * (size_t)(nMP + 1), sizeof(int) * (size_t)nE, sizeof(int) * kfEdges.size(), sizeof(int) * (size_t)nChunks,
+                     sizeof(int) * (size_t)nChunks, sizeof(int) * (size_t)nChunks, sizeof(int) * (size_t)nKF, sizeof(int) * (size_t)nI,
+                     sizeof(int) * (size_t)nI, sizeof(morb_imu_preintegrated) * (size_t)nI, (size_t)nI, (size_t)nMP, sizeof(float) * (size_t)nI,
+                     sizeof(float) * 21 * (size_t)nKF, sizeof(float) * 3 * (size_t)nMP, (size_t)nE, sizeof(int2) * (size_t)splan.nblk,
+                     sizeof(int) * (size_t)splan.nb * splan.nb})
+      upBytes += (std::max<size_t>(b, 16) + 255) & ~(size_t)255;
+    const int rc = morb_optimizer_staging(o, upBytes, &stage);
+    if (rc != MORB_OK) return rc;
+    stageCap = upBytes;
+  }
+  size_t upHi = 0;
+  auto up = [&](const void* h, size_t bytes) -> void* {
+    const size_t off = arenaOff;
+    void* d = dalloc(bytes);
+    if (d && bytes) {
+      if (off + bytes > stageCap) return nullptr;   // (cannot happen: the uploads are the arena's first allocations, sized above)
+      memcpy((char*)stage + off, h, bytes); upHi = off + bytes;
+    }
+    return d;
+  };
   IbaDev D;
   memset(&D, 0, sizeof D);
   D.nKF = nKF; D.nMP = nMP; D.nE = nE; D.nI = nI; D.P = P; D.nChunks = nChunks;
@@ -2091,6 +2122,14 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
   float* d_scale = (float*)up(iInfoScale, sizeof(float) * nI);
   float* d_kfIn = (float*)up(kfState21, sizeof(float) * 21 * nKF);
   float* d_mpIn = (float*)up(mpPos, sizeof(float) * 3 * nMP);
+  D.eRight = eRight ? (const uint8_t*)up(eRight, nE) : nullptr;
+  {
+    std::vector<int2> blocks; std::vector<int> blkIndex((size_t)splan.nb * splan.nb, 0);
+    for (int bi = 0; bi < splan.nb; ++bi) for (int bj = bi; bj < splan.nb; ++bj) { blkIndex[(size_t)bi * splan.nb + bj] = (int)blocks.size(); blocks.push_back(make_int2(bi, bj)); }
+    D.sBlocks = (const int2*)up(blocks.data(), sizeof(int2) * blocks.size()); D.sBlkIndex = (const int*)up(blkIndex.data(), sizeof(int) * blkIndex.size());
+  }
+  MORB_REQUIRE(D.sBlkIndex != nullptr && arenaOff <= arenaBytes, MORB_ERR_HIP, "workspace carve-up overflow in morb_local_inertial_ba");
+  if (hipMemcpyAsync(arena, stage, upHi, hipMemcpyHostToDevice, st) != hipSuccess) return MORB_ERR_HIP;   // the one upload
   D.S = (double*)dalloc(sizeof(double) * nS); D.Sbk = (double*)dalloc(sizeof(double) * nS);
   D.pts = (double*)dalloc(sizeof(double) * nPts); D.ptsBk = (double*)dalloc(sizeof(double) * nPts);
   D.nS = (int)nS; D.nPts = (int)nPts;
@@ -2107,15 +2146,10 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
   MORB_REQUIRE(d_erase != nullptr && arenaOff <= arenaBytes, MORB_ERR_HIP, "workspace carve-up overflow in morb_local_inertial_ba");
   (void)hipMemsetAsync(D.x, 0, sizeof(double) * nX, st);   // the solver's x before the first solve
   make_geom(Tbc12, fx, fy, cx, cy, bf, rig28, D.g);
-  D.eRight = eRight ? (const uint8_t*)up(eRight, nE) : nullptr;
   {
-    std::vector<int2> blocks; std::vector<int> blkIndex((size_t)splan.nb * splan.nb, 0);
-    for (int bi = 0; bi < splan.nb; ++bi) for (int bj = bi; bj < splan.nb; ++bj) { blkIndex[(size_t)bi * splan.nb + bj] = (int)blocks.size(); blocks.push_back(make_int2(bi, bj)); }
     D.sW = (double*)dalloc(sizeof(double) * splan.wElems()); D.sWD = (double*)dalloc(sizeof(double) * splan.wElems());
     D.sPart = (double*)dalloc(sizeof(double) * splan.partElems());
-    D.sBlocks = (const int2*)up(blocks.data(), sizeof(int2) * blocks.size()); D.sBlkIndex = (const int*)up(blkIndex.data(), sizeof(int) * blkIndex.size());
-    MORB_REQUIRE(D.sBlkIndex != nullptr && arenaOff <= arenaBytes, MORB_ERR_HIP, "workspace carve-up overflow in morb_local_inertial_ba");
-    if (hipStreamSynchronize(st) != hipSuccess) return MORB_ERR_HIP;   // (blocks / blkIndex are host temporaries)
+    MORB_REQUIRE(D.sPart != nullptr && arenaOff <= arenaBytes, MORB_ERR_HIP, "workspace carve-up overflow in morb_local_inertial_ba");
     D.sMp = splan.Mp; D.sNb = splan.nb; D.sNblk = splan.nblk; D.sNsplit = splan.nsplit;
     // the operands' zero pattern is this graph's: the workspace is reused from call to call
     (void)hipMemsetAsync(D.sW, 0, sizeof(double) * splan.wElems(), st);
@@ -2134,12 +2168,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
   };
   hipLaunchKernelGGL(k_iba_setup_kf, dim3(div_up(nKF, 64)), dim3(64), 0, st, D, d_kfIn);
   if (nI) hipLaunchKernelGGL(k_iba_setup_links, dim3(nI), dim3(64), 0, st, D, d_scale);
-  {  // points to FP64
-    std::vector<double> pd(nPts);
-    for (size_t k = 0; k < nPts; ++k) pd[k] = (double)mpPos[k];
-    if (hipMemcpyAsync(D.pts, pd.data(), sizeof(double) * nPts, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-      return fail("upload failed in morb_local_inertial_ba");
-  }
+  hipLaunchKernelGGL(k_iba_setup_pts, dim3(div_up((int)nPts, 256)), dim3(256), 0, st, D, (const float*)d_mpIn);   // points to FP64
   const int Mpose = 6 * nOpt;
   static const bool valuSchur = [] { const char* v = getenv("MORB_SCHUR_VALU"); return v && v[0] == '1'; }();
   const size_t schurLds = sizeof(double) * ((size_t)Mpose * Mpose + Mpose);

@@ -1652,6 +1652,8 @@ struct morb_optimizer {
   size_t workBytes = 0;
   int* lmWords = nullptr;      // 16 pinned, device-mapped ints: LM state mirror of morb_local_inertial_ba (device-side LM control)
   int* lmWordsDev = nullptr;
+  void* stage = nullptr;       // grow-only pinned host buffer: the one-shot entry points gather their inputs here for a single upload
+  size_t stageBytes = 0;
 };
 
 struct morb_ba_problem {
@@ -1722,6 +1724,19 @@ int morb_optimizer_lm_words(morb_optimizer* o, int** host, int** dev) {
   return MORB_OK;
 }
 
+int morb_optimizer_staging(morb_optimizer* o, size_t bytes, void** host) {
+  MORB_REQUIRE(o && host, MORB_ERR_INVALID, "NULL argument");
+  if (bytes > o->stageBytes) {
+    MORB_HIP_CHECK(hipStreamSynchronize(o->stream));
+    if (o->stage) MORB_HIP_CHECK(hipHostFree(o->stage));
+    o->stage = nullptr; o->stageBytes = 0;
+    MORB_HIP_CHECK(hipHostMalloc(&o->stage, bytes + bytes / 4));
+    o->stageBytes = bytes + bytes / 4;
+  }
+  *host = o->stage;
+  return MORB_OK;
+}
+
 void morb_optimizer_destroy(morb_optimizer* o) {
   if (!o) return;
   (void)hipSetDevice(o->device);
@@ -1731,6 +1746,7 @@ void morb_optimizer_destroy(morb_optimizer* o) {
   if (o->evJoin) (void)hipEventDestroy(o->evJoin);
   if (o->work) (void)hipFree(o->work);
   if (o->lmWords) (void)hipHostFree(o->lmWords);
+  if (o->stage) (void)hipHostFree(o->stage);
   (void)hipStreamDestroy(o->stream);
   delete o;
 }
