@@ -1654,6 +1654,8 @@ struct morb_optimizer {
   int* lmWordsDev = nullptr;
   void* stage = nullptr;       // grow-only pinned host buffer: the one-shot entry points gather their inputs here for a single upload
   size_t stageBytes = 0;
+  bool arenaCreate = false;    // morb_ba_problem_create carves the problem from `work` / `stage` (the one-shot entry points set this around the call)
+  double* scalPinned = nullptr;   // pinned scalars of an arena-mode problem
 };
 
 struct morb_ba_problem {
@@ -1673,6 +1675,7 @@ struct morb_ba_problem {
   size_t nPairEntries = 0;   // (e1, e2) observation pairs of the sparse block-pair Schur form (flop accounting only)
   double* h_scal = nullptr;  // pinned host mirror of scal[0..3]
   double* d_ldws = nullptr;  // [P][LB] panel scratch of the LDL^T when the reduced system does not fit LDS
+  bool arena = false;        // device memory and pinned words belong to the optimizer handle (one-shot entry points): nothing to free
 };
 
 extern "C" {
@@ -1747,6 +1750,7 @@ void morb_optimizer_destroy(morb_optimizer* o) {
   if (o->work) (void)hipFree(o->work);
   if (o->lmWords) (void)hipHostFree(o->lmWords);
   if (o->stage) (void)hipHostFree(o->stage);
+  if (o->scalPinned) (void)hipHostFree(o->scalPinned);
   (void)hipStreamDestroy(o->stream);
   delete o;
 }
@@ -1830,10 +1834,22 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
     for (int a = mpStart[m]; a < mpStart[m + 1] && !h.dupPairs; ++a)
       for (int b2 = a + 1; b2 < mpStart[m + 1]; ++b2)
         if (eKF[mpEdges[a]] == eKF[mpEdges[b2]]) { h.dupPairs = 1; break; }
-  // block pairs of the reduced camera system and, per pair, the (observation, observation) entries that feed it
+  // block pairs of the reduced camera system and, per pair, the (observation, observation) entries that feed it: operands of the
+  // persistent-workgroup mode and of round 1's VALU Schur form (MORB_SCHUR_VALU=1).  The one-shot entry points always solve in grid
+  // mode on the matrix cores, which only needs the number of entries (flop accounting): they skip the lists (0.3 ms of host work, 0.6 MB).
   std::vector<int> pairBlock, pairStart;
   std::vector<int2> pairEntries;
-  {
+  static const bool valuSchurEnv = [] { const char* v = getenv("MORB_SCHUR_VALU"); return v && v[0] == '1'; }();
+  const bool wantPairs = valuSchurEnv || !o->arenaCreate;
+  size_t nPairEntriesCount = 0;
+  if (!wantPairs) {
+    for (int m = 0; m < nMP; ++m) {
+      size_t nf = 0;
+      for (int a = mpStart[m]; a < mpStart[m + 1]; ++a) nf += kfCol[eKF[mpEdges[a]]] >= 0 ? 1 : 0;
+      nPairEntriesCount += nf * (nf + 1) / 2;   // (pairs with column(e1) <= column(e2), as the lists would hold them; approximate for duplicate columns)
+    }
+    pairBlock.push_back(0); pairStart.assign(2, 0); pairEntries.assign(1, make_int2(0, 0));
+  } else {
     const int nb = std::max(nFree, 1) * std::max(nFree, 1);
     std::vector<int> cnt(nb + 1, 0);
     auto forPairs = [&](auto&& fn) {
@@ -1859,7 +1875,7 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
     std::vector<int> fill(pairStart.begin(), pairStart.end());
     forPairs([&](int key, int ea, int eb) { pairEntries[fill[slot[key]]++] = make_int2(ea, eb); });
   }
-  h.nPairs = (int)pairBlock.size();
+  h.nPairs = wantPairs ? (int)pairBlock.size() : 0;
   std::vector<int> chunkKF, chunkStart, chunkEnd, kfChunkStart(nKF + 1, 0);
   for (int kf = 0; kf < nKF; ++kf) {
     kfChunkStart[kf] = (int)chunkKF.size();
@@ -1869,13 +1885,33 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
   kfChunkStart[nKF] = (int)chunkKF.size();
   h.nChunks = (int)chunkKF.size();
   bool fail = false;
+  // Memory: a persistent problem (three-step API) owns one hipMalloc per array.  The one-shot entry points (arena mode) carve
+  // everything from the optimizer's grow-only workspace — uploads first, mirrored in a pinned host buffer and sent in ONE copy,
+  // device-only arrays behind them — because ~45 hipMalloc / hipFree pairs and ~25 synchronous copies were 3.5 ms of a 4.7 ms call.
+  const bool arena = o->arenaCreate;
+  p->arena = arena;
+  bool dry = false;
+  size_t upOff = 0, devOff = 0, upCap = 0, devCap = 0;
+  char *aBase = nullptr, *stage = nullptr;
   auto up = [&](const void* src, size_t bytes) -> void* {
+    if (arena) {
+      const size_t sz = (std::max<size_t>(bytes, 8) + 255) & ~(size_t)255;
+      size_t& off = src ? upOff : devOff;
+      const size_t at = off;
+      off += sz;
+      if (dry) return nullptr;
+      if (off > (src ? upCap : devCap)) { fail = true; return nullptr; }
+      if (src) { memcpy(stage + at, src, bytes); return aBase + at; }
+      return aBase + upCap + at;
+    }
     void* d = nullptr;
     if (hipMalloc(&d, std::max<size_t>(bytes, 8)) != hipSuccess) { fail = true; return nullptr; }
     p->allocs.push_back(d);
     if (src && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) fail = true;
     return d;
   };
+  hipStream_t cst = o->stream;
+  auto carve = [&]() {
   h.kfCol = (const int*)up(kfCol.data(), sizeof(int) * nKF);
   h.eKF = (const int*)up(eKF, sizeof(int) * nE);
   h.eMP = (const int*)up(eMP, sizeof(int) * nE);
@@ -1888,7 +1924,7 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
   h.pairBlock = (const int*)up(pairBlock.data(), sizeof(int) * std::max<size_t>(pairBlock.size(), 1));
   h.pairStart = (const int*)up(pairStart.data(), sizeof(int) * pairStart.size());
   h.pairEntries = (const int2*)up(pairEntries.data(), sizeof(int2) * pairEntries.size());
-  p->nPairEntries = pairEntries.size();
+  p->nPairEntries = wantPairs ? pairEntries.size() : nPairEntriesCount;
   h.chunkKF = (const int*)up(chunkKF.data(), sizeof(int) * std::max<size_t>(chunkKF.size(), 1));
   h.chunkStart = (const int*)up(chunkStart.data(), sizeof(int) * std::max<size_t>(chunkStart.size(), 1));
   h.chunkEnd = (const int*)up(chunkEnd.data(), sizeof(int) * std::max<size_t>(chunkEnd.size(), 1));
@@ -1905,7 +1941,8 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
     for (int bi = 0; bi < sp.nb; ++bi) for (int bj = bi; bj < sp.nb; ++bj) { blkIndex[(size_t)bi * sp.nb + bj] = (int)blocks.size(); blocks.push_back(make_int2(bi, bj)); }
     h.sW = (double*)up(nullptr, sizeof(double) * sp.wElems());
     h.sWD = (double*)up(nullptr, sizeof(double) * sp.wElems());
-    if (!fail && (hipMemset(h.sW, 0, sizeof(double) * sp.wElems()) != hipSuccess || hipMemset(h.sWD, 0, sizeof(double) * sp.wElems()) != hipSuccess)) fail = true;
+    if (!dry && !fail && (arena ? (hipMemsetAsync(h.sW, 0, sizeof(double) * sp.wElems(), cst) != hipSuccess || hipMemsetAsync(h.sWD, 0, sizeof(double) * sp.wElems(), cst) != hipSuccess)
+                              : (hipMemset(h.sW, 0, sizeof(double) * sp.wElems()) != hipSuccess || hipMemset(h.sWD, 0, sizeof(double) * sp.wElems()) != hipSuccess))) fail = true;
     h.sPart = (double*)up(nullptr, sizeof(double) * sp.partElems());
     h.sBlocks = (const int2*)up(blocks.data(), sizeof(int2) * blocks.size());
     h.sBlkIndex = (const int*)up(blkIndex.data(), sizeof(int) * blkIndex.size());
@@ -1931,15 +1968,21 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
   h.stats = (int*)up(nullptr, sizeof(int) * 2);
   h.lmd = (double*)up(nullptr, sizeof(double) * 4);
   h.kfTicket = (int*)up(nullptr, sizeof(int) * std::max(nKF, 1));
-  if (!fail && hipMemset(h.kfTicket, 0, sizeof(int) * std::max(nKF, 1)) != hipSuccess) fail = true;
+  if (!dry && !fail && (arena ? hipMemsetAsync(h.kfTicket, 0, sizeof(int) * std::max(nKF, 1), cst) : hipMemset(h.kfTicket, 0, sizeof(int) * std::max(nKF, 1))) != hipSuccess) fail = true;
   h.lmi = (int*)up(nullptr, sizeof(int) * 16);
   // mapped host words: [0] morb_ba_set_stop, [1] the caller's *pbStopFlag as the host loop forwards it, [4..7] the LM state mirror
-  if (hipHostMalloc(&p->h_stop, sizeof(int) * 16, hipHostMallocMapped) != hipSuccess) { p->h_stop = nullptr; fail = true; }
-  else {
-    memset(p->h_stop, 0, sizeof(int) * 16);
-    int* dv = nullptr;
-    if (hipHostGetDevicePointer((void**)&dv, p->h_stop, 0) != hipSuccess) fail = true;
-    h.stop = dv; h.lmHost = dv + 4;
+  if (!dry) {
+    if (arena) {
+      int* dv = nullptr;
+      if (morb_optimizer_lm_words(o, &p->h_stop, &dv) != MORB_OK) { p->h_stop = nullptr; fail = true; }
+      else { memset(p->h_stop, 0, sizeof(int) * 16); h.stop = dv; h.lmHost = dv + 4; }
+    } else if (hipHostMalloc(&p->h_stop, sizeof(int) * 16, hipHostMallocMapped) != hipSuccess) { p->h_stop = nullptr; fail = true; }
+    else {
+      memset(p->h_stop, 0, sizeof(int) * 16);
+      int* dv = nullptr;
+      if (hipHostGetDevicePointer((void**)&dv, p->h_stop, 0) != hipSuccess) fail = true;
+      h.stop = dv; h.lmHost = dv + 4;
+    }
   }
   h.cam = Cam{fx, fy, cx, cy, bf};
   h.rig = nullptr;
@@ -1947,7 +1990,25 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
   p->d_pose0 = (float*)up(kfPose, sizeof(float) * 7 * nKF);
   p->d_pt0 = (float*)up(mpPos, sizeof(float) * 3 * nMP);
   p->d_desc = (BaDev*)up(&h, sizeof(BaDev));
-  if (!fail && hipHostMalloc(&p->h_scal, sizeof(double) * 8) != hipSuccess) fail = true;
+  };   // carve
+  if (arena) {
+    dry = true; carve(); dry = false;   // sizes
+    upCap = upOff; devCap = devOff; upOff = devOff = 0;
+    void *w = nullptr, *sg = nullptr;
+    if (morb_optimizer_workspace(o, upCap + devCap, &w) != MORB_OK || morb_optimizer_staging(o, upCap, &sg) != MORB_OK) fail = true;
+    aBase = (char*)w; stage = (char*)sg;
+    if (!fail) {
+      carve();
+      if (!fail && hipMemcpyAsync(aBase, stage, upCap, hipMemcpyHostToDevice, cst) != hipSuccess) fail = true;   // the one upload
+    }
+    if (!fail) {
+      if (!o->scalPinned && hipHostMalloc(&o->scalPinned, sizeof(double) * 8) != hipSuccess) fail = true;
+      p->h_scal = o->scalPinned;
+    }
+  } else {
+    carve();
+    if (!fail && hipHostMalloc(&p->h_scal, sizeof(double) * 8) != hipSuccess) fail = true;
+  }
   p->ldsBytes = sizeof(double) * (size_t)h.P * (h.P + 1);
   p->useLds = (p->ldsBytes <= 136 * 1024 && h.P <= 192) ? 1 : 0;
   if (!p->useLds) p->ldsBytes = 0;
@@ -1960,7 +2021,7 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
     fail = true;
   if (fail) {
     for (void* d : p->allocs) (void)hipFree(d);
-    if (p->h_stop) (void)hipHostFree(p->h_stop);
+    if (p->h_stop && !p->arena) (void)hipHostFree(p->h_stop);
     delete p;
     set_error("device allocation/copy failed while creating the BA problem");
     return MORB_ERR_HIP;
@@ -1974,8 +2035,10 @@ void morb_ba_problem_destroy(morb_ba_problem* p) {
   (void)hipSetDevice(p->opt->device);
   (void)hipStreamSynchronize(p->opt->stream);
   for (void* d : p->allocs) (void)hipFree(d);
-  if (p->h_scal) (void)hipHostFree(p->h_scal);
-  if (p->h_stop) (void)hipHostFree(p->h_stop);
+  if (!p->arena) {
+    if (p->h_scal) (void)hipHostFree(p->h_scal);
+    if (p->h_stop) (void)hipHostFree(p->h_stop);
+  }
   delete p;
 }
 
@@ -2240,8 +2303,11 @@ int morb_local_bundle_adjustment(morb_optimizer* o, int nKF, float* kfPose, cons
                                  const unsigned char* stopFlag, uint8_t* eraseFlag, int* stats2) {
   if (stopFlag && *(const volatile unsigned char*)stopFlag) { if (stats2) stats2[0] = stats2[1] = 0; return MORB_OK; }  // :1355-1356
   morb_ba_problem* p = nullptr;
+  MORB_REQUIRE(o, MORB_ERR_INVALID, "NULL optimizer");
+  o->arenaCreate = true;   // the problem lives in the handle's workspace for the duration of this call
   int rc = morb_ba_problem_create(o, &p, nKF, kfPose, kfFixed, nMP, mpPos, nE, eKF, eMP, eObs, eInvSigma2, fx, fy, cx, cy, bf,
                                   lambdaInit100);
+  o->arenaCreate = false;
   if (rc != MORB_OK) return rc;
   p->userStop = stopFlag;   // optimizer.setForceStopFlag(pbStopFlag) (:1142): the LM loop polls the caller's flag at every iteration and trial
   rc = morb_ba_solve(p, nullptr);
@@ -2256,8 +2322,11 @@ int morb_local_bundle_adjustment_fisheye(morb_optimizer* o, int nKF, float* kfPo
                                          int lambdaInit100, const unsigned char* stopFlag, uint8_t* eraseFlag, int* stats2) {
   if (stopFlag && *(const volatile unsigned char*)stopFlag) { if (stats2) stats2[0] = stats2[1] = 0; return MORB_OK; }  // :1355-1356
   morb_ba_problem* p = nullptr;
+  MORB_REQUIRE(o, MORB_ERR_INVALID, "NULL optimizer");
+  o->arenaCreate = true;
   int rc = morb_ba_problem_create_fisheye(o, &p, nKF, kfPose, kfFixed, nMP, mpPos, nE, eKF, eMP, eObs2, eRight, eInvSigma2, camL8,
                                           camR8, Trl7, lambdaInit100);
+  o->arenaCreate = false;
   if (rc != MORB_OK) return rc;
   p->userStop = stopFlag;   // optimizer.setForceStopFlag(pbStopFlag) (:1142): the LM loop polls the caller's flag at every iteration and trial
   rc = morb_ba_solve(p, nullptr);
