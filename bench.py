@@ -135,6 +135,14 @@ def optimizer_extras(dev_index):
     _, _, _, st = p.results()
     dt = (time.perf_counter() - t0) / n
     t0 = time.perf_counter(); its, *_ = O.local_ba(b); dc = time.perf_counter() - t0
+    # the one-shot ABI call of the reference binding (host graph in -> host poses / points / erase flags out, problem built per call)
+    from morb_slam_amd.optimizer import local_bundle_adjustment_oneshot
+    oargs = (opt, b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"], b["eInvSigma2"], b["cam"])
+    local_bundle_adjustment_oneshot(*oargs)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        local_bundle_adjustment_oneshot(*oargs)
+    d1 = (time.perf_counter() - t0) / 5
     sms, sflops, suseful = p.schur_profile(50)     # the Schur product alone, HIP events on the handle's stream
     F = 256
     probs = [make_pose_problem(600, seed=s % 8) for s in range(F)]
@@ -223,7 +231,7 @@ def optimizer_extras(dev_index):
                    "lm_iters_per_s": float(sti[0] / dtl), "cpu_oracle_lm_iters_per_s": float(ro[4][0] / dcl)}
     return {"pose_inertial_tracking": inertial, "local_inertial_ba": inertial_ba,
             "local_ba": {"edges": int(len(b["eKF"])), "keyframes_free_fixed": [20, 6], "points": 3000,
-                         "outer_lm_iters": int(st[0]), "lm_trials": int(st[1]), "ms_per_solve": dt * 1e3,
+                         "outer_lm_iters": int(st[0]), "lm_trials": int(st[1]), "ms_per_solve": dt * 1e3, "one_shot_call_ms": d1 * 1e3,
                          "lm_iters_per_s": float(st[0] / dt), "cpu_oracle_lm_iters_per_s": float(its / dc),
                          # the MFMA kernel of the solve (north_star: Schur reduction on the matrix cores); peak = dense FP64 MFMA,
                          # 256 CUs x 128 flop/clk x 2.4 GHz (tools/alu_issue.hip: v_mfma_f64_16x16x4_f64 issues every 64 cycles per SIMD)
