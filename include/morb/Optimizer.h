@@ -48,11 +48,16 @@ class Optimizer {
     using morb_adapter::DeviceBuffer;
     if (f.N <= 0) return 0;
     const int N = f.N;
-    DeviceBuffer<uint8_t> has(f.hasMapPoint, N), outl(N);
+    // per-thread staging buffers that only grow: Tracking calls this once per frame, and eight hipMalloc / hipFree pairs per call
+    // cost more than the optimisation itself
+    static thread_local DeviceBuffer<uint8_t> has, outl;
+    static thread_local DeviceBuffer<float> obs, inv, Xw, pose;
+    static thread_local DeviceBuffer<int> nin, cnt;
+    has.assign(f.hasMapPoint, N); outl.resize(N);
     // mvbOutlier is only written for features that hold a map point (Optimizer.cc:817, :860): the others keep what they had
     if ((int)f.mvbOutlier.size() == N) outl.upload(f.mvbOutlier.data(), N); else outl.fill_bytes(0);
-    DeviceBuffer<float> obs(f.obs, (size_t)N * 3), inv(f.invSigma2, N), Xw(f.worldPos, (size_t)N * 3), pose(f.pose, 7);
-    DeviceBuffer<int> nin(1), cnt(&N, 1);
+    obs.assign(f.obs, (size_t)N * 3); inv.assign(f.invSigma2, N); Xw.assign(f.worldPos, (size_t)N * 3); pose.assign(f.pose, 7);
+    nin.resize(1); cnt.assign(&N, 1);
     check(morb_pose_optimization_batch(optimizer(device), 1, N, cnt.get(), has.get(), obs.get(), inv.get(), Xw.get(), f.fx, f.fy, f.cx, f.cy, f.mbf,
                                        pose.get(), outl.get(), nin.get(), nullptr, nullptr));
     morb_adapter::hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");

@@ -34,6 +34,7 @@ class DeviceBuffer {
     hip_check(hipMalloc(reinterpret_cast<void**>(&p_), (n ? n : 1) * sizeof(T)), "hipMalloc");
     cap_ = n_ = n;
   }
+  void assign(const T* host, size_t n) { resize(n); upload(host, n); }   // grow-only: a static / member buffer re-used from call to call
   void upload(const T* host, size_t n) { if (n) hip_check(hipMemcpy(p_, host, n * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D"); }
   void fill_bytes(int byte) { if (n_) hip_check(hipMemset(p_, byte, n_ * sizeof(T)), "hipMemset"); }
   void download(T* host, size_t n) const { if (n) hip_check(hipMemcpy(host, p_, n * sizeof(T), hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
