@@ -80,17 +80,23 @@ class ORBmatcher {
     using morb_adapter::DeviceBuffer;
     const int N = F.N, M = mps.n;
     if (N <= 0 || M <= 0) { matchF.assign(N > 0 ? N : 0, -1); return 0; }
-    DeviceBuffer<morb_keypoint> kps(F.mvKeysUn, N);
-    DeviceBuffer<uint8_t> desc(F.mDescriptors, (size_t)N * 32);
-    DeviceBuffer<float> uR; DeviceBuffer<uint8_t> blocked;
-    if (F.mvuRight) { uR.resize(N); uR.upload(F.mvuRight, N); }
-    if (F.hasTrackedMapPoint) { blocked.resize(N); blocked.upload(F.hasTrackedMapPoint, N); } else { blocked.resize(N); blocked.fill_bytes(0); }
+    // per-thread staging buffers that only grow (Tracking calls this every frame: ~25 hipMalloc / hipFree pairs per call otherwise)
+    static thread_local DeviceBuffer<morb_keypoint> kps;
+    static thread_local DeviceBuffer<uint8_t> desc, blocked, inView, isBad, hasObs, mpDesc;
+    static thread_local DeviceBuffer<float> uR, R, t, Ow, Pw, nrm, maxD, minD, projX, projY, projXR, depth, viewCos;
+    static thread_local DeviceBuffer<int> fImg, count, nMP, nmatch, level, match;
+    kps.assign(F.mvKeysUn, N);
+    desc.assign(F.mDescriptors, (size_t)N * 32);
+    if (F.mvuRight) uR.assign(F.mvuRight, N);
+    blocked.resize(N);
+    if (F.hasTrackedMapPoint) blocked.upload(F.hasTrackedMapPoint, N); else blocked.fill_bytes(0);
     const int one = 0, cnt = N, nmp = M;
-    DeviceBuffer<int> fImg(&one, 1), count(&cnt, 1), nMP(&nmp, 1), nmatch(1);
-    DeviceBuffer<float> R(F.mRcw, 9), t(F.mtcw, 3), Ow(F.mOw, 3), Pw(mps.worldPos, (size_t)M * 3), nrm(mps.normal, (size_t)M * 3),
-        maxD(mps.maxDistance, M), minD(mps.minDistance, M), projX(M), projY(M), projXR(M), depth(M), viewCos(M);
-    DeviceBuffer<uint8_t> inView(M), isBad(mps.isBad, M), hasObs(mps.hasObservations, M), mpDesc(mps.descriptor, (size_t)M * 32);
-    DeviceBuffer<int> level(M), match(N);
+    fImg.assign(&one, 1); count.assign(&cnt, 1); nMP.assign(&nmp, 1); nmatch.resize(1);
+    R.assign(F.mRcw, 9); t.assign(F.mtcw, 3); Ow.assign(F.mOw, 3); Pw.assign(mps.worldPos, (size_t)M * 3); nrm.assign(mps.normal, (size_t)M * 3);
+    maxD.assign(mps.maxDistance, M); minD.assign(mps.minDistance, M);
+    projX.resize(M); projY.resize(M); projXR.resize(M); depth.resize(M); viewCos.resize(M);
+    inView.resize(M); isBad.assign(mps.isBad, M); hasObs.assign(mps.hasObservations, M); mpDesc.assign(mps.descriptor, (size_t)M * 32);
+    level.resize(M); match.resize(N);
     if ((int)matchF.size() == N) match.upload(matchF.data(), N); else match.fill_bytes(0xFF);   // -1
     check(morb_is_in_frustum_batch(h_, &F.params, 1, R.get(), t.get(), Ow.get(), M, nMP.get(), Pw.get(), nrm.get(), maxD.get(), minD.get(),
                                    viewingCosLimit, inView.get(), projX.get(), projY.get(), projXR.get(), depth.get(), level.get(),
