@@ -1070,6 +1070,7 @@ void free_staging(morb_extractor* e) {
   auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   F(e->d_img); F(e->d_kps1); F(e->d_desc1); F(e->d_cnt1); F(e->d_mono1);
   e->imgBytes = 0;
+  if (e->h_io1) { (void)hipHostFree(e->h_io1); e->h_io1 = nullptr; e->ioBytes1 = 0; }
 }
 
 // Build geometry + tables for (W, H) and allocate for nimg images.
@@ -1517,22 +1518,36 @@ int morb_extract(morb_extractor* e, const uint8_t* image, int width, int height,
   }
   int rc = configure(e, width, height, 1);
   if (rc != MORB_OK) return rc;
-  MORB_HIP_CHECK(hipMemcpyAsync(e->d_img, image, bytes, hipMemcpyHostToDevice, e->stream));
+  // Host <-> device through ONE pinned buffer: the image is copied into it and uploaded asynchronously, the results (count, monoIndex,
+  // all keypoint / descriptor slots) come back in four asynchronous copies and one synchronisation; pageable copies straight from / to the
+  // caller's buffers are staged and synchronised by the runtime one by one.
+  const size_t outBytes = 16 + (sizeof(morb_keypoint) + 32) * (size_t)maxk, need = std::max(bytes, outBytes);
+  if (e->ioBytes1 < need) {
+    MORB_HIP_CHECK(hipStreamSynchronize(e->stream));
+    if (e->h_io1) (void)hipHostFree(e->h_io1);
+    e->h_io1 = nullptr; e->ioBytes1 = 0;
+    MORB_HIP_CHECK(hipHostMalloc(&e->h_io1, need));
+    e->ioBytes1 = need;
+  }
+  memcpy(e->h_io1, image, bytes);
+  MORB_HIP_CHECK(hipMemcpyAsync(e->d_img, e->h_io1, bytes, hipMemcpyHostToDevice, e->stream));
   int lap[2] = {lap0, lap1};
   rc = morb_extract_batch(e, e->d_img, 1, width, height, stride, bytes, lap, e->d_kps1, e->d_desc1, maxk, e->d_cnt1,
                           e->d_mono1, e->stream);
   if (rc != MORB_OK) return rc;
-  int cnt = 0, mono = 0;
-  MORB_HIP_CHECK(hipMemcpyAsync(&cnt, e->d_cnt1, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  MORB_HIP_CHECK(hipMemcpyAsync(&mono, e->d_mono1, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  int* hcnt = reinterpret_cast<int*>(e->h_io1);
+  morb_keypoint* hkps = reinterpret_cast<morb_keypoint*>(e->h_io1 + 16);
+  uint8_t* hdesc = e->h_io1 + 16 + sizeof(morb_keypoint) * (size_t)maxk;
+  // (the upload is ordered before these copies on the same stream, so the buffer can be reused for the way back)
+  MORB_HIP_CHECK(hipMemcpyAsync(hcnt, e->d_cnt1, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  MORB_HIP_CHECK(hipMemcpyAsync(hcnt + 1, e->d_mono1, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  MORB_HIP_CHECK(hipMemcpyAsync(hkps, e->d_kps1, sizeof(morb_keypoint) * (size_t)maxk, hipMemcpyDeviceToHost, e->stream));
+  MORB_HIP_CHECK(hipMemcpyAsync(hdesc, e->d_desc1, 32 * (size_t)maxk, hipMemcpyDeviceToHost, e->stream));
   MORB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  const int cnt = hcnt[0], mono = hcnt[1];
   *n = cnt;
   MORB_REQUIRE(cnt <= cap, MORB_ERR_CAPACITY, "keypoint buffer too small");
-  if (cnt) {   // on the handle's own stream: a copy on the null stream would wait for every other handle's blocking stream too
-    MORB_HIP_CHECK(hipMemcpyAsync(kps, e->d_kps1, sizeof(morb_keypoint) * cnt, hipMemcpyDeviceToHost, e->stream));
-    MORB_HIP_CHECK(hipMemcpyAsync(desc, e->d_desc1, 32 * (size_t)cnt, hipMemcpyDeviceToHost, e->stream));
-    MORB_HIP_CHECK(hipStreamSynchronize(e->stream));
-  }
+  if (cnt) { memcpy(kps, hkps, sizeof(morb_keypoint) * (size_t)cnt); memcpy(desc, hdesc, 32 * (size_t)cnt); }
   return mono;
 }
 

@@ -96,6 +96,7 @@ struct morb_extractor {
   // staging for the single-image host API
   uint8_t* d_img = nullptr; size_t imgBytes = 0;
   morb_keypoint* d_kps1 = nullptr; uint8_t* d_desc1 = nullptr; int *d_cnt1 = nullptr, *d_mono1 = nullptr;
+  uint8_t* h_io1 = nullptr; size_t ioBytes1 = 0;   // pinned host staging of morb_extract: the image on the way in, [cnt, mono | keypoints | descriptors] on the way out
   std::vector<int> lapLast;  // host mirror of d_lap
   // profiling: a ring of event sets, one per morb_extract_batch call, read back (and averaged) on demand so the
   // timed region never synchronises with the host
