@@ -190,6 +190,24 @@ def local_bundle_adjustment_oneshot(opt, kfPose, kfFixed, mpPos, eKF, eMP, eObs,
     return a[0], a[2], erase, stats
 
 
+def local_bundle_adjustment_fisheye_oneshot(opt, kfPose, kfFixed, mpPos, eKF, eMP, eObs2, eRight, eInvSigma2, camL, camR, Trl, inertial=False,
+                                            stop_flag=None):
+    """The one-shot ABI entry on the KannalaBrandt8 rig (`morb_local_bundle_adjustment_fisheye`)."""
+    L = lib()
+    a = [np.ascontiguousarray(kfPose, np.float32).copy(), np.ascontiguousarray(kfFixed, np.uint8),
+         np.ascontiguousarray(mpPos, np.float32).copy(), np.ascontiguousarray(eKF, np.int32), np.ascontiguousarray(eMP, np.int32),
+         np.ascontiguousarray(eObs2, np.float32), np.ascontiguousarray(eRight, np.uint8), np.ascontiguousarray(eInvSigma2, np.float32),
+         np.ascontiguousarray(camL, np.float32), np.ascontiguousarray(camR, np.float32), np.ascontiguousarray(Trl, np.float32)]
+    erase = np.zeros(len(a[3]), np.uint8); stats = np.zeros(2, np.int32)
+    L.morb_local_bundle_adjustment_fisheye.restype = C.c_int
+    L.morb_local_bundle_adjustment_fisheye.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + \
+        [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    check(L.morb_local_bundle_adjustment_fisheye(opt._h, len(a[0]), ptr(a[0]), ptr(a[1]), len(a[2]), ptr(a[2]), len(a[3]), ptr(a[3]), ptr(a[4]),
+                                                 ptr(a[5]), ptr(a[6]), ptr(a[7]), ptr(a[8]), ptr(a[9]), ptr(a[10]), 1 if inertial else 0,
+                                                 ptr(stop_flag) if stop_flag is not None else None, ptr(erase), ptr(stats)))
+    return a[0], a[2], erase, stats
+
+
 class BAProblem:
     """A LocalBundleAdjustment graph resident in HBM (create once, solve repeatedly).
     rig = dict(eRight uint8 [nE], camL, camR (8 floats each), Trl (7 floats)) selects the KannalaBrandt8 stereo rig

@@ -132,3 +132,17 @@ def test_local_ba_oneshot_polls_the_callers_flag():
     stats = local_bundle_adjustment_oneshot(opt, *args, stop_flag=flag[:1])[3]
     t.join()
     assert stats[1] <= full[1]
+
+
+def test_local_ba_oneshot_equals_the_three_step_form():
+    # the one-shot entry carves its problem from the handle's workspace and uploads it in one copy; the persistent form owns one
+    # allocation per array: same kernels, same numbers — bit for bit — and the workspace is reused by the next call
+    from morb_slam_amd import Optimizer
+    from morb_slam_amd.optimizer import local_bundle_adjustment_oneshot
+    opt = Optimizer()
+    for kw in (dict(seed=1), dict(seed=2, n_free=8, n_fixed=3, n_points=500), dict(seed=1)):
+        b = make_ba_problem(**kw)
+        ref = opt.LocalBundleAdjustment(b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"], b["eInvSigma2"], b["cam"])
+        one = local_bundle_adjustment_oneshot(opt, b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"], b["eInvSigma2"], b["cam"])
+        for x, y in zip(ref, one):
+            np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
