@@ -15,8 +15,10 @@
 // describe (IC_Angle + rBRIEF + final keypoint records).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -741,30 +743,41 @@ __global__ __launch_bounds__(FS_NT) void k_fast(const morb::FastGeom fg, const m
 
 // ---------------------------------------------------------------------------------------------------
 // K3: DistributeOctTree, one wave per (level, image).  See quadtree.h.
-__global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ cand,
+// A wave's LDS need (node arrays by the level's quota, key arrays by its area) falls by ~25 % per level, and a launch has ONE LDS size:
+// sized for level 0, three one-wave workgroups fill a CU's LDS and every small level holds as much as level 0.  So the levels of an image
+// are packed (host: first fit, decreasing) into a few workgroups of up to QT_MAX_WAVES waves whose needs add up to what level 0 takes
+// (752 x 480 / 1200: {0} {1, 5} {2, 3} {4, 6, 7}); the waves of a workgroup never synchronise with each other.
+__global__ __launch_bounds__(64 * QT_MAX_WAVES) void k_distribute(const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ cand,
                                                    const int* __restrict__ candCnt, int totalCells, int cellCap,
                                                    uint32_t* __restrict__ qtScratch, uint32_t* __restrict__ sel,
-                                                   int* __restrict__ selCnt, int selPerImg, int nlevels,
-                                                   int maxNodeCap, int maxCells, int keyCap) {
+                                                   int* __restrict__ selCnt, int selPerImg, int nlevels) {
   extern __shared__ __align__(16) uint8_t smem[];
-  const int lvl = blockIdx.y, img = blockIdx.x, lane = threadIdx.x;
+  const int img = blockIdx.x, lane = threadIdx.x & 63;
+  int lvl = -1;
+  {
+    const int grp = blockIdx.y, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int l = 0; l < nlevels; ++l) if (geom[l].distGroup == grp && geom[l].distWave == wv) lvl = l;
+  }
+  if (lvl < 0) return;   // (wave-uniform: this workgroup packs fewer levels than the launch has waves)
   __builtin_amdgcn_s_setprio(3);   // a long dependent chain: win instruction arbitration against the blur waves sharing the SIMD
   const LevelGeom g = geom[lvl];
-  // LDS carve-up (sizes from the largest level)
-  uint8_t* sp = smem;
-  uint64_t* vA = reinterpret_cast<uint64_t*>(sp); sp += (size_t)maxNodeCap * 8;
-  uint64_t* vB = reinterpret_cast<uint64_t*>(sp); sp += (size_t)maxNodeCap * 8;
+  const int nodeCap = g.nodeCap, keyCap = g.distKeyCap;
+  const int ncell = g.nRows * g.nCols;
+  // the level's LDS region (the host sizes it with the same arithmetic: dist_lds_bytes)
+  uint8_t* sp = smem + g.distLdsOff;
+  uint64_t* vA = reinterpret_cast<uint64_t*>(sp); sp += (size_t)nodeCap * 8;
+  uint64_t* vB = reinterpret_cast<uint64_t*>(sp); sp += (size_t)nodeCap * 8;
   uint64_t* bcnt = vB;   // the batch split's child counts: vB is only live between the sort and the order[] it feeds
-  morbqt::Node* nodes = reinterpret_cast<morbqt::Node*>(sp); sp += (size_t)maxNodeCap * sizeof(morbqt::Node);
+  morbqt::Node* nodes = reinterpret_cast<morbqt::Node*>(sp); sp += (size_t)nodeCap * sizeof(morbqt::Node);
   uint32_t* ldsKeys = reinterpret_cast<uint32_t*>(sp); sp += (size_t)keyCap * 4;
   uint32_t* ldsTmp = reinterpret_cast<uint32_t*>(sp); sp += (size_t)keyCap * 4;
   // the cell offsets are dead once the candidates are gathered and the split ranks are first written inside qt_distribute: one region
   // serves both when the offsets fit it (the host sizes the allocation the same way)
-  const bool aliasCells = maxCells + 1 <= maxNodeCap;
-  int* cellOff = reinterpret_cast<int*>(sp); if (!aliasCells) sp += (size_t)(maxCells + 1) * 4;
-  uint32_t* brank = reinterpret_cast<uint32_t*>(sp); sp += (size_t)maxNodeCap * 4;
-  uint16_t* freeIds = reinterpret_cast<uint16_t*>(sp); sp += (size_t)maxNodeCap * 2;
-  uint16_t* order = reinterpret_cast<uint16_t*>(sp); sp += (size_t)maxNodeCap * 2;
+  const bool aliasCells = ncell + 1 <= nodeCap;
+  int* cellOff = reinterpret_cast<int*>(sp); if (!aliasCells) sp += (size_t)(ncell + 1) * 4;
+  uint32_t* brank = reinterpret_cast<uint32_t*>(sp); sp += (size_t)nodeCap * 4;
+  uint16_t* freeIds = reinterpret_cast<uint16_t*>(sp); sp += (size_t)nodeCap * 2;
+  uint16_t* order = reinterpret_cast<uint16_t*>(sp); sp += (size_t)nodeCap * 2;
   uint16_t* list = reinterpret_cast<uint16_t*>(sp);
 
 #ifdef MORB_FAST_TIMING
@@ -773,7 +786,6 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
 #else
 #define DMARK(k)
 #endif
-  const int ncell = g.nRows * g.nCols;
   const int* counts = candCnt + (size_t)img * totalCells + g.cellBase;
   int running = 0;
   for (int c0 = 0; c0 < ncell; c0 += 64) {
@@ -1205,17 +1217,63 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
   e->pyrBytes = pyrOff; e->blurBytes = blurOff; e->qtElems = qtOff;
   e->outCap = selBase;
   // Candidate keys of a level live in LDS (two arrays) when they fit, else in the global scratch (much slower: every partition pass goes
-  // through the L2).  The capacity scales with level 0's area — twice the ~1 candidate per 233 px the benchmark images give, i.e. the
-  // kLdsKeys = 3072 of a 752 x 480 image — and is cut to what the LDS leaves beside the node arrays (1920 x 1080 / 4000 features: ~8 k keys).
+  // through the L2).  Level 0's capacity scales with its area — twice the ~1 candidate per 233 px the benchmark images give, i.e. the
+  // kLdsKeys = 3072 of a 752 x 480 image — and is cut to what the LDS leaves beside the node arrays (1920 x 1080 / 4000 features: ~8 k keys);
+  // the other levels' capacities follow their width (below).
   {
-    const size_t fixed = (size_t)e->maxNodeCap * (8 + 8 + sizeof(morbqt::Node) + 4 + 2 + 2) + (e->maxCells + 1 <= e->maxNodeCap ? 0 : (size_t)(e->maxCells + 1) * 4) +
-                         (size_t)e->maxListCap * 2 + 64;
-    constexpr size_t kLdsBudget = 158 * 1024;   // (160 KB minus the kernel's static LDS)
-    MORB_REQUIRE(fixed + 1024 * 8 <= kLdsBudget, MORB_ERR_UNSUPPORTED, "nfeatures too large for the LDS-resident quadtree");
-    const long long want = std::max<long long>(kLdsKeys, (long long)e->geom[0].w * e->geom[0].h * 2 / 233);
-    const long long fit = (long long)((kLdsBudget - fixed) / 8);
+    constexpr size_t kLdsBudget = 156 * 1024;   // largest dynamic allocation of one workgroup (160 KB minus the kernel's static LDS, with room to spare)
+    constexpr size_t kLdsCu = 160 * 1024, kLdsStatic = 3584;   // k workgroups share a CU when each takes <= 160 KB / k, static part included
+    auto lds_bytes = [&](const LevelGeom& g, int keyCap) -> size_t {   // == the carve-up in k_distribute
+      const int ncell = g.nCols * g.nRows;
+      const size_t b = (size_t)g.nodeCap * (8 + 8 + sizeof(morbqt::Node) + 4 + 2 + 2) + (ncell + 1 <= g.nodeCap ? 0 : (size_t)(ncell + 1) * 4) +
+                       (size_t)g.listCap * 2 + (size_t)keyCap * 8;
+      return (b + 63) / 64 * 64;
+    };
+    const size_t fixed0 = lds_bytes(e->geom[0], 0);
+    MORB_REQUIRE(fixed0 + 1024 * 8 <= kLdsBudget, MORB_ERR_UNSUPPORTED, "nfeatures too large for the LDS-resident quadtree");
+    const double area0 = (double)e->geom[0].w * e->geom[0].h;
+    const long long want = std::max<long long>(kLdsKeys, (long long)(area0 * 2 / 233));
+    const long long fit = (long long)((kLdsBudget - fixed0) / 8);
     e->distKeyCap = (int)std::min(want, fit) / 64 * 64;
-    e->distSmem = fixed + (size_t)e->distKeyCap * 8;
+    size_t need[kMaxLevels];
+    size_t needMax = 0;
+    for (int l = 0; l < L; ++l) {
+      LevelGeom& g = e->geom[l];
+      // candidates per level fall like the level's width, not its area (measured on the benchmark images: 1400, 1255, 1018, 839, 767, 652,
+      // 570, 440 at 752 x 480 — FAST answers to the same structures at every scale)
+      const long long k = (long long)std::ceil(e->distKeyCap * ((double)g.w / e->geom[0].w));
+      g.distKeyCap = (int)std::min<long long>(e->distKeyCap, std::max<long long>(256, (k + 63) / 64 * 64));
+      need[l] = lds_bytes(g, g.distKeyCap);
+      needMax = std::max(needMax, need[l]);
+    }
+    // First fit, decreasing need, into bins of 1 / k of a CU's LDS.  Measured at 752 x 480 / 1200 features, 512 images (us alone | under the
+    // blur | end-to-end frames/s): one level per workgroup 470 | 495 | 85.3 k; k = 3: 498 | 521 | 84.2 k; k = 2: 398 | 424 | 85.9 k;
+    // k = 1 (two workgroups of four waves per image, one per CU): 433 | 465 | 86.1 k — the default.  MORB_DIST_PACK = 0 / k for A/B.
+    int order[kMaxLevels];
+    for (int l = 0; l < L; ++l) order[l] = l;
+    std::stable_sort(order, order + L, [&](int a, int b) { return need[a] > need[b]; });
+    const int packEnv = getenv("MORB_DIST_PACK") ? atoi(getenv("MORB_DIST_PACK")) : 1;
+    int kMax = 1;
+    while (std::min(kLdsBudget, kLdsCu / (kMax + 1) - kLdsStatic) >= needMax) ++kMax;
+    const int bestK = std::max(1, std::min(packEnv, kMax));
+    const size_t binCap = std::min(kLdsBudget, kLdsCu / bestK - kLdsStatic);
+    size_t binFill[kMaxLevels] = {0};
+    int binWaves[kMaxLevels] = {0};
+    int nb = 0;
+    for (int i = 0; i < L; ++i) {
+      const int l = order[i];
+      int b = 0;
+      while (b < nb && !(packEnv > 0 && binWaves[b] < QT_MAX_WAVES && binFill[b] + need[l] <= binCap)) ++b;
+      if (b == nb) ++nb;
+      e->geom[l].distGroup = b; e->geom[l].distWave = binWaves[b]++; e->geom[l].distLdsOff = (int)binFill[b];
+      binFill[b] += need[l];
+    }
+    if (getenv("MORB_DIST_DEBUG"))
+      for (int l = 0; l < L; ++l)
+        fprintf(stderr, "k_distribute level %d: group %d wave %d lds %zu B at %d, %d keys (k = %d of %d)\n", l, e->geom[l].distGroup, e->geom[l].distWave,
+                need[l], e->geom[l].distLdsOff, e->geom[l].distKeyCap, bestK, kMax);
+    e->distGroups = nb; e->distWaves = 1; e->distSmem = 0;
+    for (int b = 0; b < nb; ++b) { e->distWaves = std::max(e->distWaves, binWaves[b]); e->distSmem = std::max(e->distSmem, binFill[b]); }
   }
 
   MORB_HIP_CHECK(hipMalloc(&e->d_geom, sizeof(LevelGeom) * kMaxLevels));
@@ -1468,11 +1526,10 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   // that leaves the vector ALUs ~90 % idle.  Fork: the blur runs on the handle's side stream underneath the quadtree
   // and the layout, and the launch stream joins it again before k_describe.
   MORB_HIP_CHECK(hipEventRecord(e->evFork, st));
-  // the quadtree is enqueued first so that its 1024 long-running waves get their slots before the blur fills the chip;
-  // level 0 (the longest wave) first: grid x = image, y = level
-  hipLaunchKernelGGL(k_distribute, dim3(nimg, L), dim3(64), e->distSmem, st, e->d_geom, e->d_cand, e->d_candCnt,
-                     e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L, e->maxNodeCap,
-                     e->maxCells, e->distKeyCap);
+  // the quadtree is enqueued first so that its long-running waves get their slots before the blur fills the chip;
+  // the workgroups with level 0 (the longest wave) first: grid x = image, y = group of levels
+  hipLaunchKernelGGL(k_distribute, dim3(nimg, e->distGroups), dim3(64 * e->distWaves), e->distSmem, st, e->d_geom, e->d_cand, e->d_candCnt,
+                     e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L);
   hipStream_t sideStream = e->overlapBlur ? e->sideStream : st;   // MORB_EXTRACT_SERIAL=1: everything on the launch stream
   MORB_HIP_CHECK(hipStreamWaitEvent(sideStream, e->evFork, 0));
   if (evs) (void)hipEventRecord(evs[6], sideStream);

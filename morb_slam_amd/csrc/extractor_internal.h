@@ -31,6 +31,9 @@ struct LevelGeom {
   int xtabOff, ytabOff;                 // offsets (entries) into the resize tables
   float scale;                          // mvScaleFactor[l]
   float kpSize;                         // (float)(int)(PATCH_SIZE * mvScaleFactor[l])  (:831)
+  // k_distribute packs several levels of an image into one workgroup, a wave per level: the workgroup (group) and wave of this
+  // level, the byte offset of its LDS region inside the workgroup's allocation, and the candidate keys its LDS arrays hold
+  int distGroup, distWave, distLdsOff, distKeyCap;
 };
 
 // What k_fast needs of every level, passed by value: the kernarg segment is read with scalar loads, so looking a
@@ -80,7 +83,8 @@ struct morb_extractor {
   int fastSegs[2] = {0, 0}, fastRows[2] = {0, 0};   // k_fast launch groups (segments, LDS window rows)
   int selPerImg = 0, blurTiles = 0, outCap = 0;
   size_t pyrBytes = 0, blurBytes = 0, qtElems = 0, distSmem = 0, fastSmem[2] = {0, 0};
-  int distKeyCap = 0;                        // candidate keys of a level that fit the quadtree's LDS arrays
+  int distKeyCap = 0;                        // candidate keys of level 0 that fit the quadtree's LDS arrays (smaller levels: scaled by area)
+  int distGroups = 0, distWaves = 1;         // k_distribute grid: workgroups per image, waves per workgroup
 
   hipStream_t stream = nullptr;
   hipStream_t sideStream = nullptr;          // the blur runs here, underneath the quadtree (fork after FAST, join before describe)

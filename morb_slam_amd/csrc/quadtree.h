@@ -75,12 +75,13 @@ QT_HD int qt_node_cap(int N, int nIni) { int a = N + 3, b = 4 * nIni; return 2 *
 // (<= N + 3 live afterwards + one tombstone per parent <= N + 3): 3 (N + 3) < 2 nodeCap.
 QT_HD int qt_list_cap(int nodeCap) { return 2 * nodeCap; }
 
+#define QT_MAX_WAVES 4   // waves (= levels) of one k_distribute workgroup; nothing below synchronises across waves
 #if QT_DEVICE
 #define QT_LANE ((int)(threadIdx.x & 63))
 #define QT_LANE0 (QT_LANE == 0)
 #define QT_SYNC()                                          \
   do {                                                     \
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); \
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
     __builtin_amdgcn_wave_barrier();                       \
   } while (0)
 #else
@@ -352,7 +353,8 @@ __device__ inline int qt_partition_pivot_wave(uint64_t* v, int first, int last, 
 }
 
 __device__ inline void qt_std_sort_wave(uint64_t* v, uint64_t* tmp, int n, uint16_t* posL, uint16_t* posR) {
-  __shared__ int st[3 * 64];
+  __shared__ int stAll[QT_MAX_WAVES * 3 * 64];   // (one explicit stack per wave of the workgroup)
+  int* st = stAll + (threadIdx.x >> 6) * (3 * 64);
   if (n > 16) {  // std::__introsort_loop with the recursion on an explicit (wave-uniform) stack, see qt_introsort_loop
     int* stF = st; int* stL = st + 64; int* stD = st + 128;
     int lg = 0;
