@@ -121,17 +121,20 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, con
 }
 
 // ---------------------------------------------------------------------------------------------------
-// F1: ComputeStereoMatches.  Kernel A: one wave per left keypoint: row-band/octave/disparity-gated best
-// Hamming match (lexicographic (dist, iR) minimum = the reference's first-best over vRowIndices[row]), then the
-// 11x11 SAD search over 11 shifts on the un-blurred pyramid level, parabola refinement, disparity -> depth.
-// Kernel B: one workgroup per frame: median of the accepted SAD distances, 1.5*1.4*median cut.
-// One workgroup = SM_LK left keypoints of one frame (4 waves x SM_LK/4 keypoints in turn; SM_LK by batch size, sm_lk_for()).  PMC showed the first
-// version (one wave per left keypoint, every wave re-reading all right keypoints from global memory) bound by the
-// number of vector-memory instructions, so: the right keypoints' row band / x / octave go to LDS once per workgroup,
-// the row-band test runs on LDS, the survivors are compacted to a candidate list before any descriptor is loaded,
-// and the two SAD patches are fetched as unaligned dwords into LDS instead of 24 byte loads per lane.
-// left keypoints per workgroup: 32 for large batches (256 frames: 16: 429 us, 32: 391 us, 64: 405 us), fewer for a handful of frames, where
-// a wave's keypoints — one dependent chain each — are the latency of the call (one frame: 4 per workgroup, i.e. one per wave)
+// F1: ComputeStereoMatches (Frame.cc:889-1047), three kernels.
+//   k_stereo_prep   one workgroup per frame: the right keypoints' row band / octave / x table and the per-16-row-band index (the
+//                   reference's vRowIndices, coarsened), written once per frame.
+//   k_stereo_match  one workgroup = SM_LK left keypoints of a frame (4 waves x SM_LK / 4 keypoints; SM_LK by batch size, sm_lk_for()):
+//                   copies the frame's record into LDS, then per wave (A) the band scans -> (keypoint, candidate) pairs, (B) Hamming
+//                   distances of the pairs, best = lexicographic (dist, iR) minimum = the reference's first-best over vRowIndices[row],
+//                   (C) the 11 x 11 SAD search over 11 shifts on the un-blurred pyramid level, parabola refinement, disparity -> depth.
+//   k_stereo_median one workgroup per frame: median of the accepted SAD distances, 1.5 * 1.4 * median cut.
+// History of the middle kernel, 256 frames of 752 x 480 / 1200 features: one wave per left keypoint re-reading all right keypoints from
+// global memory (round 1, bound by the number of vector-memory instructions) -> table in LDS per workgroup, candidates compacted before
+// any descriptor load, patches as unaligned dwords: 391 us -> the stages run for all of a wave's keypoints together: 360 -> SAD rows by
+// v_sad_u8 + 16-lane DPP sums: 314 -> table built once per frame: 271 -> per-keypoint scalar math in lane q: 224 us.
+// Left keypoints per workgroup at 256 frames: 8: 357 us, 16: 251, 32: 221; fewer for a handful of frames, where a wave's keypoints are
+// the latency of the call (one frame: 4 per workgroup, i.e. one per wave).
 __host__ __device__ inline int sm_lk_for(int nframes) { return nframes <= 2 ? 4 : nframes <= 8 ? 8 : nframes <= 32 ? 16 : 32; }
 constexpr int SM_BAND = 16;   // rows per band of the per-workgroup row index (the reference's vRowIndices, coarsened)
 constexpr int SM_MAXB = 256;  // bands that fit (images up to 4096 rows); SM_LIST * cap list entries, else the full scan
@@ -145,24 +148,102 @@ struct StereoGeom {
 };
 struct RightKp { uint32_t band; float x; };   // band = (minr + 4096) | (maxr + 4096) << 14 | octave << 28  (vRowIndices band, Frame.cc:736-747)
 constexpr int SM_LIST = 4;
-constexpr int SM_CAND = 256;                  // per-wave candidate list; flushed (descriptors compared) whenever it could overflow
+constexpr int SM_KQ = 8;                      // left keypoints of one wave (SM_LK / 4 <= SM_KQ)
+constexpr int SM_PCAP = 512;                  // per-wave list of (left keypoint, right candidate) pairs; flushed (descriptors compared) before it could overflow
+constexpr int SM_PATCH = 11 * 12 + 11 * 24;   // bytes of one keypoint's two SAD patches
+static_assert(4 * SM_PATCH <= SM_PCAP * 4, "four keypoints' patches reuse the pair list");
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
+// The right image's keypoints as the left keypoints' searches need them (one record per frame, built once by k_stereo_prep and copied
+// into LDS by every workgroup of k_stereo_match; before, each of a frame's 38 workgroups rebuilt it from the 28-byte keypoint structs):
+// the table [cap] of (row band, octave, x), the first list slot of every 16-row band, the list's length, the per-band lists.
+struct StereoRec { int band, list, bytes; };   // byte offsets inside a record (16-byte aligned) and its size
+__host__ __device__ inline StereoRec stereo_rec(int cap) {
+  StereoRec r;
+  r.band = (cap * (int)sizeof(RightKp) + 15) & ~15;
+  r.list = r.band + (((SM_MAXB + 2) * 4 + 15) & ~15);
+  r.bytes = r.list + ((SM_LIST * cap * 2 + 15) & ~15);
+  return r;
+}
+__global__ __launch_bounds__(256) void k_stereo_prep(const StereoGeom sg, const morb_keypoint* __restrict__ kps, const int* __restrict__ count,
+                                                     int cap, uint8_t* __restrict__ rec) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const StereoRec ro = stereo_rec(cap);
+  RightKp* tab = reinterpret_cast<RightKp*>(smem);
+  int* bandStart = reinterpret_cast<int*>(smem + ro.band);
+  uint16_t* list = reinterpret_cast<uint16_t*>(smem + ro.list);
+  int* bandFill = reinterpret_cast<int*>(smem + ro.bytes);   // [SM_MAXB]
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int imgR = 2 * f + 1, NR = count[imgR];
+  const int nRows = sg.nRows;
+  const int nBands = (nRows + SM_BAND - 1) / SM_BAND;
+  const bool banded = nBands <= SM_MAXB;
+  for (int i = tid; i < SM_MAXB + 2; i += 256) { bandStart[i] = 0; if (i < SM_MAXB) bandFill[i] = 0; }
+  __syncthreads();
+  for (int iR = tid; iR < NR; iR += 256) {
+    const morb_keypoint kpR = kps[(size_t)imgR * cap + iR];
+    const float r = 2.0f * sg.scale[kpR.octave & 15];
+    const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);   // the rows the keypoint is registered in (Frame.cc:904-912)
+    // clamped to +-4095 rows: far beyond any image row, so the band test is unchanged
+    const int lo = min(max(minr, -4095), 4095) + 4096, hi = min(max(maxr, -4095), 4095) + 4096;
+    RightKp t;
+    t.band = (uint32_t)lo | ((uint32_t)hi << 14) | ((uint32_t)kpR.octave << 28); t.x = kpR.x;
+    tab[iR] = t;
+    if (banded && maxr >= 0 && minr < nRows)
+      for (int bnd = max(minr, 0) / SM_BAND; bnd <= min(maxr, nRows - 1) / SM_BAND; ++bnd) atomicAdd(&bandStart[bnd + 1], 1);
+  }
+  __syncthreads();
+  if (tid < 64) {   // inclusive scan of the band counts -> bandStart[b] = first list slot of band b
+    int c[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { c[k] = bandStart[1 + tid * 4 + k]; sum += c[k]; }
+    int inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    int acc = inc - sum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { acc += c[k]; bandStart[1 + tid * 4 + k] = acc; }
+    if (tid == 63) bandStart[SM_MAXB + 1] = acc;   // the list's length
+  }
+  __syncthreads();
+  const int listTotal = bandStart[SM_MAXB + 1];
+  if (banded && listTotal <= SM_LIST * cap) {
+    for (int iR = tid; iR < NR; iR += 256) {
+      const RightKp t = tab[iR];
+      const int minr = (int)(t.band & 0x3FFF) - 4096, maxr = (int)((t.band >> 14) & 0x3FFF) - 4096;
+      if (maxr >= 0 && minr < nRows)
+        for (int bnd = max(minr, 0) / SM_BAND; bnd <= min(maxr, nRows - 1) / SM_BAND; ++bnd)
+          list[bandStart[bnd] + atomicAdd(&bandFill[bnd], 1)] = (uint16_t)iR;   // order inside a band is irrelevant: best = min (dist, index)
+    }
+  }
+  __syncthreads();
+  const uint4* src = reinterpret_cast<const uint4*>(smem);
+  uint4* dst = reinterpret_cast<uint4*>(rec + (size_t)f * ro.bytes);
+  for (int i = tid; i < (ro.bytes >> 4); i += 256) dst[i] = src[i];
+}
+
+// A wave's keypoints used to be one dependent chain each (band scan -> candidate descriptors -> best -> patches -> SAD: three global
+// round trips per keypoint, eight keypoints in turn); the kernel was bound by exactly that latency.  Now the wave takes its keypoints
+// through each stage together: (A) the band scans of all of them (LDS only) append (keypoint, candidate) pairs to one list; (B) the
+// list is compared 64 pairs per round — full lanes instead of ~10 candidates of one keypoint — with a segmented minimum per keypoint
+// (pairs of a keypoint are contiguous); (C) the patches of four keypoints are requested at once, then summed.  Three round trips per
+// wave instead of three per keypoint.
 __global__ __launch_bounds__(256) void k_stereo_match(const StereoGeom sg, const uint8_t* __restrict__ pyr,
                                                       const morb_keypoint* __restrict__ kps,
                                                       const uint8_t* __restrict__ desc, const int* __restrict__ count,
                                                       int cap, float mbf, float mb,
                                                       float* __restrict__ uRight, float* __restrict__ depth,
-                                                      int* __restrict__ sadDist, int SM_LK) {
+                                                      int* __restrict__ sadDist, int SM_LK, const uint8_t* __restrict__ rec) {
   extern __shared__ __align__(16) uint8_t smem[];
-  RightKp* tab = reinterpret_cast<RightKp*>(smem);                       // [cap]
-  int* bandStart = reinterpret_cast<int*>(tab + cap);                    // [SM_MAXB + 1]
-  int* bandFill = bandStart + SM_MAXB + 1;                               // [SM_MAXB]
-  uint16_t* list = reinterpret_cast<uint16_t*>(bandFill + SM_MAXB);      // [SM_LIST * cap] right keypoints per band
-  uint16_t* candAll = list + SM_LIST * (size_t)cap;                      // [4][SM_CAND]
-  uint8_t* patchAll = reinterpret_cast<uint8_t*>(candAll + 4 * SM_CAND);        // [4][11 * 12 + 11 * 24]
-  __shared__ int listTotal;
+  uint4* dLAll = reinterpret_cast<uint4*>(smem);                                               // [4][SM_KQ][2] left descriptors
+  unsigned long long* bestAll = reinterpret_cast<unsigned long long*>(dLAll + 4 * SM_KQ * 2);  // [4][SM_KQ] best (distance << 32 | right index)
+  uint32_t* pairsAll = reinterpret_cast<uint32_t*>(bestAll + 4 * SM_KQ);                       // [4][SM_PCAP]; later four keypoints' SAD patches
+  uint8_t* recL = reinterpret_cast<uint8_t*>(pairsAll + 4 * SM_PCAP);    // the frame's right-keypoint record, as k_stereo_prep laid it out
+  const StereoRec ro = stereo_rec(cap);
+  const RightKp* tab = reinterpret_cast<const RightKp*>(recL);           // [cap]
+  const int* bandStart = reinterpret_cast<const int*>(recL + ro.band);   // [SM_MAXB + 1], then the list's length
+  const uint16_t* list = reinterpret_cast<const uint16_t*>(recL + ro.list);   // [SM_LIST * cap] right keypoints per band
   const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int imgL = 2 * f, imgR = 2 * f + 1;
   const int NL = count[imgL], NR = count[imgR];
@@ -171,174 +252,257 @@ __global__ __launch_bounds__(256) void k_stereo_match(const StereoGeom sg, const
   const int nRows = sg.nRows;
   const int nBands = (nRows + SM_BAND - 1) / SM_BAND;
   const bool banded = nBands <= SM_MAXB;
+  const uint8_t* recG = rec + (size_t)f * ro.bytes;
+  const int listTotal = reinterpret_cast<const int*>(recG + ro.band)[SM_MAXB + 1];   // (wave-uniform: a scalar load)
+  const bool useBands = banded && listTotal <= SM_LIST * cap;
   if (iL0 < NL) {
-    for (int i = tid; i < SM_MAXB + 1; i += 256) { bandStart[i] = 0; if (i < SM_MAXB) bandFill[i] = 0; }
-    __syncthreads();
-    for (int iR = tid; iR < NR; iR += 256) {
-      const morb_keypoint kpR = kps[(size_t)imgR * cap + iR];
-      const float r = 2.0f * sg.scale[kpR.octave & 15];
-      const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
-      // clamped to +-4095 rows: far beyond any image row, so the band test below is unchanged
-      const int lo = min(max(minr, -4095), 4095) + 4096, hi = min(max(maxr, -4095), 4095) + 4096;
-      RightKp t;
-      t.band = (uint32_t)lo | ((uint32_t)hi << 14) | ((uint32_t)kpR.octave << 28); t.x = kpR.x;
-      tab[iR] = t;
-      if (banded && maxr >= 0 && minr < nRows)
-        for (int bnd = max(minr, 0) / SM_BAND; bnd <= min(maxr, nRows - 1) / SM_BAND; ++bnd) atomicAdd(&bandStart[bnd + 1], 1);
-    }
-    __syncthreads();
-    if (tid < 64) {   // inclusive scan of the band counts -> bandStart[b] = first list slot of band b
-      int c[4], sum = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { c[k] = bandStart[1 + tid * 4 + k]; sum += c[k]; }
-      int inc = sum;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
-      int acc = inc - sum;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { acc += c[k]; bandStart[1 + tid * 4 + k] = acc; }
-      if (tid == 63) listTotal = acc;
-    }
-    __syncthreads();
-    if (banded && listTotal <= SM_LIST * cap) {
-      for (int iR = tid; iR < NR; iR += 256) {
-        const RightKp t = tab[iR];
-        const int minr = (int)(t.band & 0x3FFF) - 4096, maxr = (int)((t.band >> 14) & 0x3FFF) - 4096;
-        if (maxr >= 0 && minr < nRows)
-          for (int bnd = max(minr, 0) / SM_BAND; bnd <= min(maxr, nRows - 1) / SM_BAND; ++bnd)
-            list[bandStart[bnd] + atomicAdd(&bandFill[bnd], 1)] = (uint16_t)iR;   // order inside a band is irrelevant: best = min (dist, index)
-      }
-    }
+    // the record -> LDS: table, band starts, band lists; 16 bytes per access, all requests in flight together
+    const uint4* src = reinterpret_cast<const uint4*>(recG);
+    uint4* dst = reinterpret_cast<uint4*>(recL);
+    const int nTab = (NR * (int)sizeof(RightKp) + 15) >> 4, nBand = ((SM_MAXB + 2) * 4 + 15) >> 4, nList = useBands ? (listTotal * 2 + 15) >> 4 : 0;
+    for (int i = tid; i < nTab; i += 256) dst[i] = src[i];
+    for (int i = tid; i < nBand; i += 256) dst[(ro.band >> 4) + i] = src[(ro.band >> 4) + i];
+    for (int i = tid; i < nList; i += 256) dst[(ro.list >> 4) + i] = src[(ro.list >> 4) + i];
   }
   __syncthreads();
-  const bool useBands = banded && listTotal <= SM_LIST * cap;
-  uint16_t* cand = candAll + wv * SM_CAND;
-  uint8_t* Lp = patchAll + wv * (11 * 12 + 11 * 24);   // [11][12]: columns -5 .. 6 of the left patch rows
-  uint8_t* Rp = Lp + 11 * 12;                          // [11][24]: columns -10 .. 13 of the right strip rows
+#if defined(MORB_STEREO_STOP) && MORB_STEREO_STOP == 1
+  return;
+#endif
+  const int KQ = SM_LK / 4;
+  uint32_t* pairs = pairsAll + wv * SM_PCAP;
+  uint4* dLs = dLAll + wv * (SM_KQ * 2);
+  unsigned long long* bestL = bestAll + wv * SM_KQ;
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const float maxD = mbf / mb;
-  // the wave's SM_LK / 4 left keypoints, one per lane, fetched in one round trip and broadcast below
+  // the wave's left keypoints (one per lane) and their descriptors (16 bytes per lane), one round trip
   float myX = 0.f, myY = 0.f;
   int myOct = 0;
-  if (lane < SM_LK / 4) {
+  if (lane < KQ) {
     const int iL = iL0 + lane * 4 + wv;
     if (iL < NL) { const morb_keypoint k = kps[(size_t)imgL * cap + iL]; myX = k.x; myY = k.y; myOct = k.octave; }
   }
-  for (int q = 0; q < SM_LK / 4; ++q) {
-    const int iL = iL0 + q * 4 + wv;
-    if (iL >= cap) break;
-    const size_t o = (size_t)f * cap + iL;
-    float outU = -1.0f, outD = -1.0f;
-    int outS = -1;
-    if (iL < NL) {
-      const int levelL = __shfl(myOct, q, 64);
-      const float vL = __shfl(myY, q, 64), uL = __shfl(myX, q, 64);
+  if (lane < 2 * KQ) {
+    const int iL = iL0 + (lane >> 1) * 4 + wv;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (iL < NL) v = reinterpret_cast<const uint4*>(desc + ((size_t)imgL * cap + iL) * 32)[lane & 1];
+    dLs[lane] = v;
+  }
+  if (lane < SM_KQ) bestL[lane] = ~0ull;
+  WAVE_SYNC();
+
+  // (B) compare the n collected pairs; entries of one keypoint are contiguous and the keypoints ascend along the list
+  auto flush = [&](int n) {
+    WAVE_SYNC();
+    for (int c0 = 0; c0 < n; c0 += 64) {
+      const int c = c0 + lane;
+      const bool act = c < n;
+      const uint32_t pr = pairs[act ? c : n - 1];
+      const int q = (int)(pr >> 16), jR = (int)(pr & 0xFFFFu);
+      unsigned long long key = ~0ull;
+      if (act) {
+        Desc dL;
+        const uint4 a = dLs[2 * q], b = dLs[2 * q + 1];
+        dL.w[0] = a.x; dL.w[1] = a.y; dL.w[2] = a.z; dL.w[3] = a.w; dL.w[4] = b.x; dL.w[5] = b.y; dL.w[6] = b.z; dL.w[7] = b.w;
+        const int d = hamming(dL, load_desc(desc + ((size_t)imgR * cap + jR) * 32));
+        if (d < TH_HIGH) key = ((unsigned long long)d << 32) | (unsigned)jR;
+      }
+      const int qlo = __builtin_amdgcn_readfirstlane(q), qhi = __builtin_amdgcn_readlane(q, 63);   // (inactive lanes repeat the last entry)
+      for (int qq = qlo; qq <= qhi; ++qq) {
+        const unsigned long long m = wave_min_u64(q == qq ? key : ~0ull);
+        if (lane == 0 && m < bestL[qq]) bestL[qq] = m;
+      }
+    }
+    WAVE_SYNC();
+  };
+  // (A) band scans: the reference's vRowIndices[row] candidates that pass the octave and disparity gates (Frame.cc:933-952)
+  {
+    int n = 0;
+    for (int q = 0; q < KQ; ++q) {
+      const int iL = iL0 + q * 4 + wv;
+      if (iL >= NL) break;
+      const int levelL = __builtin_amdgcn_readlane(myOct, q);
+      const float vL = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myY), q));
+      const float uL = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myX), q));
       const int row = (int)vL;
       const float minU = uL - maxD, maxU = uL - 0.f;
-      unsigned long long best = ~0ull;
-      if (row >= 0 && row < nRows && !(maxU < 0)) {
-        const Desc dL = load_desc(desc + ((size_t)imgL * cap + iL) * 32);
-        int n = 0;
-        const int e0 = useBands ? bandStart[row / SM_BAND] : 0, e1 = useBands ? bandStart[row / SM_BAND + 1] : NR;
-        for (int j0 = e0; j0 < e1; j0 += 64) {
-          const int ei = j0 + lane;
-          bool ok = false;
-          int iR = 0;
-          if (ei < e1) {
-            iR = useBands ? (int)list[ei] : ei;
-            const RightKp t = tab[iR];
-            const int minr = (int)(t.band & 0x3FFF) - 4096, maxr = (int)((t.band >> 14) & 0x3FFF) - 4096, oct = (int)(t.band >> 28);
-            ok = row >= minr && row <= maxr && !(oct < levelL - 1 || oct > levelL + 1) && t.x >= minU && t.x <= maxU;
-          }
-          const uint64_t m = __ballot(ok);
-          if (ok) cand[n + __popcll(m & lt)] = (uint16_t)iR;
-          n += __popcll(m);
-          if (n > SM_CAND - 64 || j0 + 64 >= e1) {   // flush: compare the descriptors of the collected candidates
-            WAVE_SYNC();
-            for (int c0 = 0; c0 < n; c0 += 64) {
-              const int c = c0 + lane;
-              if (c < n) {
-                const int jR = cand[c];
-                const int d = hamming(dL, load_desc(desc + ((size_t)imgR * cap + jR) * 32));
-                if (d < TH_HIGH) {
-                  const unsigned long long k = ((unsigned long long)d << 32) | (unsigned)jR;
-                  best = k < best ? k : best;
-                }
-              }
-            }
-            WAVE_SYNC();
-            n = 0;
-          }
+      if (!(row >= 0 && row < nRows && !(maxU < 0))) continue;
+      const int e0 = useBands ? bandStart[row / SM_BAND] : 0, e1 = useBands ? bandStart[row / SM_BAND + 1] : NR;
+      for (int j0 = e0; j0 < e1; j0 += 64) {
+        const int ei = j0 + lane;
+        bool ok = false;
+        int iR = 0;
+        if (ei < e1) {
+          iR = useBands ? (int)list[ei] : ei;
+          const RightKp t = tab[iR];
+          const int minr = (int)(t.band & 0x3FFF) - 4096, maxr = (int)((t.band >> 14) & 0x3FFF) - 4096, oct = (int)(t.band >> 28);
+          ok = row >= minr && row <= maxr && !(oct < levelL - 1 || oct > levelL + 1) && t.x >= minU && t.x <= maxU;
         }
+        const uint64_t m = __ballot(ok);
+        if (ok) pairs[n + __popcll(m & lt)] = ((uint32_t)q << 16) | (uint32_t)iR;
+        n += __popcll(m);
+        if (n > SM_PCAP - 64) { flush(n); n = 0; }
       }
-      best = wave_min_u64(best);
+    }
+    if (n) flush(n);
+  }
+#if defined(MORB_STEREO_STOP) && MORB_STEREO_STOP == 2
+  return;
+#endif
+  // (C) sub-pixel refinement by SAD over 11 shifts on the un-blurred level (Frame.cc:963-1031).  Everything about a keypoint that is one
+  // number per keypoint — scaled coordinates, patch addresses, and afterwards the parabola and the depth — is computed by lane q for
+  // keypoint q (gfx950 has no scalar float unit: as wave-uniform code it cost 64 lanes' worth of issue per keypoint); the wave only
+  // fetches and sums the patches together, four keypoints' loads in flight.
+  bool cDo = false;
+  float cUL = 0.f, cUR0 = 0.f;
+  int cLvl = 0, cPs = 0;
+  unsigned long long cOffL = 0, cOffR = 0;
+  if (lane < KQ) {
+    const int iL = iL0 + lane * 4 + wv;
+    if (iL < NL) {
+      const unsigned long long best = bestL[lane];
       const int bestDist = best == ~0ull ? TH_HIGH : (int)(best >> 32);
       if (bestDist < (TH_HIGH + TH_LOW) / 2) {
         const int bestIdxR = (int)(best & 0xFFFFFFFFu);
+        const int levelL = myOct;
+        const float vL = myY, uL = myX;
         const float uR0 = tab[bestIdxR].x;
         const float sf = sg.invScale[levelL & 15];
         const float scaleduL = roundf(uL * sf), scaledvL = roundf(vL * sf), scaleduR0 = roundf(uR0 * sf);
-        struct { unsigned long long pyrOff, pyrImg; int pstride, w; } g;
-        g.pyrOff = sg.pyrOff[levelL & 15]; g.pyrImg = sg.pyrImg[levelL & 15]; g.pstride = sg.pstride[levelL & 15]; g.w = sg.w[levelL & 15];
+        const unsigned long long pyrOff = sg.pyrOff[levelL & 15], pyrImg = sg.pyrImg[levelL & 15];
+        const int pstride = sg.pstride[levelL & 15], w = sg.w[levelL & 15];
         const float iniu = scaleduR0 + 5 - 5, endu = scaleduR0 + 5 + 5 + 1;
-        if (!(iniu < 0 || endu >= (float)g.w)) {
-          const uint8_t* L0 = pyr + g.pyrOff + (size_t)imgL * g.pyrImg + (size_t)(EDGE_ + (int)scaledvL) * g.pstride + EDGE_ + (int)scaleduL;
-          const uint8_t* R0 = pyr + g.pyrOff + (size_t)imgR * g.pyrImg + (size_t)(EDGE_ + (int)scaledvL) * g.pstride + EDGE_ + (int)scaleduR0;
-          // 11 x 3 dwords of the left patch + 11 x 6 dwords of the right strip = 99 dword loads, two per lane (the
-          // bytes past the 11 / 21 used columns lie inside the level's 19-pixel pad)
+        if (!(iniu < 0 || endu >= (float)w)) {
+          cDo = true; cUL = uL; cUR0 = scaleduR0; cLvl = levelL; cPs = pstride;
+          cOffL = pyrOff + (size_t)imgL * pyrImg + (size_t)(EDGE_ + (int)scaledvL) * pstride + EDGE_ + (int)scaleduL;
+          cOffR = pyrOff + (size_t)imgR * pyrImg + (size_t)(EDGE_ + (int)scaledvL) * pstride + EDGE_ + (int)scaleduR0;
+        }
+      }
+    }
+  }
+  // a lane's two patch dwords: 11 x 3 dwords of the left patch + 11 x 6 dwords of the right strip = 99 dword loads (the bytes past the
+  // 11 / 21 used columns lie inside the level's 19-pixel pad); which dword a lane takes does not depend on the keypoint
+  int pRow[2], pCol[2], pLds[2];
+  bool pLeft[2], pAct[2];
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int t = lane + 64 * j;
-            if (t < 33) {
-              const int r = t / 3, c4 = (t - r * 3) * 4;
-              *reinterpret_cast<uint32_t*>(Lp + r * 12 + c4) = load_u32_unaligned(L0 + (ptrdiff_t)(r - 5) * g.pstride + c4 - 5);
-            } else if (t < 99) {
-              const int t2 = t - 33, r = t2 / 6, c4 = (t2 - r * 6) * 4;
-              *reinterpret_cast<uint32_t*>(Rp + r * 24 + c4) = load_u32_unaligned(R0 + (ptrdiff_t)(r - 5) * g.pstride + c4 - 10);
-            }
+  for (int j = 0; j < 2; ++j) {
+    const int t = lane + 64 * j;
+    pAct[j] = t < 99; pLeft[j] = t < 33;
+    if (t < 33) {
+      const int r = t / 3, c4 = (t - r * 3) * 4;
+      pRow[j] = r - 5; pCol[j] = c4 - 5; pLds[j] = r * 12 + c4;
+    } else {
+      const int t2 = min(t, 98) - 33, r = t2 / 6, c4 = (t2 - r * 6) * 4;
+      pRow[j] = r - 5; pCol[j] = c4 - 10; pLds[j] = 11 * 12 + r * 24 + c4;
+    }
+  }
+  const uint64_t doMask = __ballot(cDo);
+  const uint32_t cOffLlo = (uint32_t)cOffL, cOffLhi = (uint32_t)(cOffL >> 32), cOffRlo = (uint32_t)cOffR, cOffRhi = (uint32_t)(cOffR >> 32);
+  uint8_t* patch = reinterpret_cast<uint8_t*>(pairs);
+  int rS = -1, rInc = 0;        // lane q: keypoint q's best SAD and its shift
+  float rD1 = 0.f, rD3 = 0.f;   // and the distances on either side of it
+  const int dy = min(lane & 15, 10);
+  for (int q0 = 0; q0 < KQ; q0 += 4) {
+    if (((doMask >> q0) & 15ull) == 0) continue;   // wave-uniform
+    uint32_t pv[4][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int q = q0 + k;
+      pv[k][0] = pv[k][1] = 0;
+      if ((doMask >> q) & 1ull) {   // wave-uniform
+        const unsigned long long oL = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)cOffLhi, q) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)cOffLlo, q);
+        const unsigned long long oR = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)cOffRhi, q) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)cOffRlo, q);
+        const int ps = __builtin_amdgcn_readlane(cPs, q);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (pAct[j]) pv[k][j] = load_u32_unaligned(pyr + (pLeft[j] ? oL : oR) + (ptrdiff_t)pRow[j] * ps + pCol[j]);
+      }
+    }
+    WAVE_SYNC();   // (the pair list / the previous four keypoints' patches are dead)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!((doMask >> (q0 + k)) & 1ull)) continue;   // wave-uniform
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (pAct[j]) *reinterpret_cast<uint32_t*>(patch + k * SM_PATCH + pLds[j]) = pv[k][j];
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int q = q0 + k;
+      if (!((doMask >> q) & 1ull)) continue;   // wave-uniform
+      const uint8_t* Lp = patch + k * SM_PATCH;   // [11][12]: columns -5 .. 6 of the left patch rows
+      const uint8_t* Rp = Lp + 11 * 12;           // [11][24]: columns -10 .. 13 of the right strip rows
+      // cv::norm(IL, IR, NORM_L1) for the 11 shifts (Frame.cc:987-1003): a lane sums one patch row of one shift — three v_sad_u8 on the
+      // row's 11 bytes, the right row's window cut out with v_alignbyte — and a 16-lane row of the wave adds up the 11 rows of a shift
+      // by DPP: four shifts per round, three rounds (before: two pixels per lane and a 64-lane reduction per shift, 11 in a chain)
+      const uint32_t l0 = *reinterpret_cast<const uint32_t*>(Lp + dy * 12), l1 = *reinterpret_cast<const uint32_t*>(Lp + dy * 12 + 4),
+                     l2 = *reinterpret_cast<const uint32_t*>(Lp + dy * 12 + 8) & 0x00FFFFFFu;
+      int svr[3];
+      // the reference walks the shifts in order and keeps the first smallest distance (`dist < bestDist` on floats that are exact integers
+      // <= 121 * 255): the minimum of (sum << 4 | shift index).  The sums are wave-uniform (v_readlane), so this runs on the scalar unit.
+      uint32_t bestKey = 0xFFFFFFFFu;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int sh = min(r * 4 + (lane >> 4), 10);   // shift index = inc + 5: the window starts at column sh of the 21-column strip
+        const uint8_t* rp = Rp + dy * 24 + (sh & ~3);
+        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(rp), w1 = *reinterpret_cast<const uint32_t*>(rp + 4),
+                       w2 = *reinterpret_cast<const uint32_t*>(rp + 8), w3 = *reinterpret_cast<const uint32_t*>(rp + 12);
+        const uint32_t bsh = (uint32_t)(sh & 3);
+        const uint32_t r0 = __builtin_amdgcn_alignbyte(w1, w0, bsh), r1 = __builtin_amdgcn_alignbyte(w2, w1, bsh),
+                       r2 = __builtin_amdgcn_alignbyte(w3, w2, bsh) & 0x00FFFFFFu;
+        int sv = (int)__builtin_amdgcn_sad_u8(l2, r2, __builtin_amdgcn_sad_u8(l1, r1, __builtin_amdgcn_sad_u8(l0, r0, 0u)));
+        if ((lane & 15) > 10) sv = 0;
+        sv += __builtin_amdgcn_update_dpp(0, sv, 0x111, 0xf, 0xf, true);   // row_shr:1, 2, 4, 8: lane 15 of a row ends with the row's total
+        sv += __builtin_amdgcn_update_dpp(0, sv, 0x112, 0xf, 0xf, true);
+        sv += __builtin_amdgcn_update_dpp(0, sv, 0x114, 0xf, 0xf, true);
+        sv += __builtin_amdgcn_update_dpp(0, sv, 0x118, 0xf, 0xf, true);
+        svr[r] = sv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (r * 4 + j < 11) {
+            const uint32_t key = ((uint32_t)__builtin_amdgcn_readlane(sv, 16 * j + 15) << 4) | (uint32_t)(r * 4 + j);
+            bestKey = key < bestKey ? key : bestKey;
           }
-          WAVE_SYNC();
-          // lanes cover the 121 patch pixels (two per lane)
-          const int p0 = lane, p1 = lane + 64;
-          const int dy0 = p0 / 11, dx0 = p0 % 11, dy1 = p1 / 11, dx1 = p1 % 11;   // 0-based here
-          const int a0 = Lp[dy0 * 12 + dx0];
-          const int a1 = p1 < 121 ? Lp[dy1 * 12 + dx1] : 0;
-          float vDists[11];
-          int bestS = 0x7fffffff, bestinc = 0;
-#pragma unroll
-          for (int inc = -5; inc <= 5; ++inc) {
-            int s = abs(a0 - (int)Rp[dy0 * 24 + dx0 + 5 + inc]);
-            if (p1 < 121) s += abs(a1 - (int)Rp[dy1 * 24 + dx1 + 5 + inc]);
-            s = wave_sum(s);
-            const float dist = (float)s;
-            if (dist < (float)bestS) { bestS = (int)dist; bestinc = inc; }
-            vDists[inc + 5] = dist;
-          }
-          WAVE_SYNC();   // the patches are rewritten for the next keypoint
-          if (!(bestinc == -5 || bestinc == 5)) {
-            float dist1 = 0, dist2 = 0, dist3 = 0;
-#pragma unroll
-            for (int qq = 1; qq < 10; ++qq)
-              if (qq == bestinc + 5) { dist1 = vDists[qq - 1]; dist2 = vDists[qq]; dist3 = vDists[qq + 1]; }
-            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
-            if (!(deltaR < -1 || deltaR > 1)) {
-              float bestuR = sg.scale[levelL & 15] * ((float)scaleduR0 + (float)bestinc + deltaR);
-              float disparity = uL - bestuR;
-              if (disparity >= 0.f && disparity < maxD) {
-                if (disparity <= 0) {
-                  disparity = 0.01f;
-                  bestuR = (float)((double)uL - 0.01);
-                }
-                outD = mbf / disparity;
-                outU = bestuR;
-                outS = bestS;
+      }
+      const int bestS = (int)(bestKey >> 4), bi = (int)(bestKey & 15u);
+      // vDists[best - 1] and [best + 1]: shift index i sits in round i >> 2, lane 16 * (i & 3) + 15
+      auto sum_at = [&](int i) -> int {
+        i = min(max(i, 0), 10);
+        const int v = (i >> 2) == 0 ? svr[0] : (i >> 2) == 1 ? svr[1] : svr[2];
+        return __builtin_amdgcn_readlane(v, 16 * (i & 3) + 15);
+      };
+      const int s1 = sum_at(bi - 1), s3 = sum_at(bi + 1);
+      if (lane == q) { rS = bestS; rInc = bi - 5; rD1 = (float)s1; rD3 = (float)s3; }
+    }
+  }
+  if (lane < KQ) {
+    const int iL = iL0 + lane * 4 + wv;
+    if (iL < cap) {
+      float outU = -1.0f, outD = -1.0f;
+      int outS = -1;
+      if (cDo) {
+        const int bestinc = rInc, bestS = rS;
+        if (!(bestinc == -5 || bestinc == 5)) {
+          const float dist1 = rD1, dist2 = (float)bestS, dist3 = rD3;
+          const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+          if (!(deltaR < -1 || deltaR > 1)) {
+            float bestuR = sg.scale[cLvl & 15] * ((float)cUR0 + (float)bestinc + deltaR);
+            float disparity = cUL - bestuR;
+            if (disparity >= 0.f && disparity < maxD) {
+              if (disparity <= 0) {
+                disparity = 0.01f;
+                bestuR = (float)((double)cUL - 0.01);
               }
+              outD = mbf / disparity;
+              outU = bestuR;
+              outS = bestS;
             }
           }
         }
       }
+      const size_t o = (size_t)f * cap + iL;
+      uRight[o] = outU; depth[o] = outD; sadDist[o] = outS;
     }
-    if (lane == 0) { uRight[o] = outU; depth[o] = outD; sadDist[o] = outS; }
   }
 }
 
@@ -793,9 +957,10 @@ struct morb_matcher {
   unsigned long long *d_sortA = nullptr, *d_sortB = nullptr;
   int* d_bin = nullptr;
   int* d_sad = nullptr;
+  uint8_t* d_stereoRec = nullptr;   // k_stereo_prep's per-frame records
   float *d_scale = nullptr, *d_invScale = nullptr;
   int* d_idx = nullptr;
-  size_t sortElems = 0, binElems = 0, sadElems = 0, idxElems = 0;
+  size_t sortElems = 0, binElems = 0, sadElems = 0, idxElems = 0, stereoRecBytes = 0;
   void* ws[8] = {nullptr};   // generic workspaces for projection.hip
   size_t wsBytes[8] = {0};
 };
@@ -845,7 +1010,7 @@ void morb_matcher_destroy(morb_matcher* m) {
   (void)hipSetDevice(m->device);
   (void)hipStreamSynchronize(m->stream);
   auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-  F(m->d_sortA); F(m->d_sortB); F(m->d_bin); F(m->d_sad); F(m->d_scale); F(m->d_invScale); F(m->d_idx);
+  F(m->d_sortA); F(m->d_sortB); F(m->d_bin); F(m->d_sad); F(m->d_stereoRec); F(m->d_scale); F(m->d_invScale); F(m->d_idx);
   for (auto& w : m->ws) F(w);
   (void)hipStreamDestroy(m->stream);
   delete m;
@@ -920,13 +1085,18 @@ int morb_stereo_match_batch(morb_matcher* m, const morb_extractor* e, int nframe
     sg.scale[l] = e->scale[l < e->nlevels ? l : e->nlevels - 1]; sg.invScale[l] = e->invScale[l < e->nlevels ? l : e->nlevels - 1];
   }
   sg.nRows = e->geom[0].h;
-  const size_t stereoSmem = (size_t)cap * (sizeof(RightKp) + SM_LIST * sizeof(uint16_t)) + (2 * SM_MAXB + 1) * sizeof(int) +
-                            4 * SM_CAND * sizeof(uint16_t) + 4 * (11 * 12 + 11 * 24);
-  MORB_REQUIRE(stereoSmem <= 160 * 1024 && cap < 65536 && e->nlevels <= 16, MORB_ERR_UNSUPPORTED, "too many keypoints per image for the LDS-resident right-keypoint table");
+  const StereoRec ro = stereo_rec(cap);
+  rc = grow(m->d_stereoRec, m->stereoRecBytes, (size_t)nframes * ro.bytes);
+  if (rc != MORB_OK) return rc;
+  const size_t prepSmem = (size_t)ro.bytes + SM_MAXB * sizeof(int);
+  const size_t stereoSmem = (size_t)ro.bytes + 4 * SM_KQ * (32 + 8) + 4 * SM_PCAP * sizeof(uint32_t);
+  MORB_REQUIRE(prepSmem <= 160 * 1024 && stereoSmem <= 160 * 1024 && cap < 65536 && e->nlevels <= 16, MORB_ERR_UNSUPPORTED, "too many keypoints per image for the LDS-resident right-keypoint table");
+  MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stereo_prep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prepSmem));
   MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stereo_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stereoSmem));
   const int lk = sm_lk_for(nframes);
+  hipLaunchKernelGGL(k_stereo_prep, dim3(nframes), dim3(256), prepSmem, st, sg, d_kps, d_count, cap, m->d_stereoRec);
   hipLaunchKernelGGL(k_stereo_match, dim3(div_up(cap, lk), nframes), dim3(256), stereoSmem, st, sg, e->d_pyr, d_kps, d_desc,
-                     d_count, cap, mbf, mb, d_uRight, d_depth, m->d_sad, lk);
+                     d_count, cap, mbf, mb, d_uRight, d_depth, m->d_sad, lk, m->d_stereoRec);
   hipLaunchKernelGGL(k_stereo_median, dim3(nframes), dim3(256), 0, st, d_count, cap, d_uRight, d_depth, m->d_sad);
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
