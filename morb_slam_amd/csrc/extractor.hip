@@ -923,7 +923,12 @@ using morbm::sincosf_glibc;
 // The wave's lifetime is a chain of dependent global-memory round trips, so the chain is kept short: one record
 // per keypoint from k_layout (slot, level, key), level geometry from the kernarg segment, and the (keypoint-
 // independent) rBRIEF pattern rows of the lane requested before anything else.
+#ifndef MORB_DESC_STAGED
+#define MORB_DESC_STAGED 1
+#endif
 constexpr int DESC_KPW = 4;   // keypoints per wave in k_describe
+constexpr int DESC_R = 18;    // the rotated rBRIEF pattern stays within +-18 px of the keypoint (|(+-13, +-13)| = 18.4, then cvRound)
+constexpr int DESC_WIN = 2 * DESC_R + 1, DESC_WP = 48;   // window rows / LDS pitch (three 16-byte segments)
 // One wave describes DESC_KPW keypoints *in lock step*: the kernel is bound by dependent global-memory round trips per
 // keypoint (record -> patch -> angle -> pattern gathers), so each stage is issued for all DESC_KPW keypoints before the
 // next stage waits on it — three round trips per wave instead of three per keypoint.  Slots without a keypoint repeat
@@ -932,6 +937,9 @@ __global__ __launch_bounds__(256) void k_describe(const morb::DescGeom dg, const
                                                   const uint8_t* __restrict__ blur, const int2* __restrict__ kref,
                                                   int selPerImg, morb_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int cap, int imgRev) {
+#if MORB_DESC_STAGED
+  __shared__ __align__(16) uint8_t s_win[4 * DESC_KPW * DESC_WIN * DESC_WP];
+#endif
   const int img = imgRev ? gridDim.y - 1 - blockIdx.y : blockIdx.y, lane = threadIdx.x & 63;
   const int gi0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DESC_KPW;
   if (gi0 >= selPerImg) return;
@@ -942,16 +950,17 @@ __global__ __launch_bounds__(256) void k_describe(const morb::DescGeom dg, const
 #pragma unroll
   for (int kk = 0; kk < DESC_KPW; ++kk) ref[kk] = kref[(size_t)img * selPerImg + min(gi0 + kk, selPerImg - 1)];
   bool ok[DESC_KPW];
-  int first = -1;
+  bool any = false;
+  int2 firstRef = ref[DESC_KPW - 1];   // the first valid record, by selects: `ref[first]` with a run-time index put the array into LDS / scratch
 #pragma unroll
-  for (int kk = 0; kk < DESC_KPW; ++kk) {
+  for (int kk = DESC_KPW - 1; kk >= 0; --kk) {
     ok[kk] = gi0 + kk < selPerImg && ref[kk].x >= 0;
-    if (ok[kk] && first < 0) first = kk;
+    if (ok[kk]) { firstRef = ref[kk]; any = true; }
   }
-  if (first < 0) return;   // wave-uniform
+  if (!any) return;   // wave-uniform
 #pragma unroll
   for (int kk = 0; kk < DESC_KPW; ++kk) {
-    if (!ok[kk]) ref[kk] = ref[first];
+    if (!ok[kk]) ref[kk] = firstRef;
     // wave-uniform by construction: in SGPRs the per-keypoint geometry and base addresses are scalar arithmetic
     ref[kk].x = __builtin_amdgcn_readfirstlane(ref[kk].x);
     ref[kk].y = __builtin_amdgcn_readfirstlane(ref[kk].y);
@@ -969,7 +978,7 @@ __global__ __launch_bounds__(256) void k_describe(const morb::DescGeom dg, const
     // top-left corners of the 31 x 31 moment patch and of the (2 * EDGE + 1)^2 window the rotated pattern stays inside:
     // the lanes add unsigned 32-bit offsets (scalar base + vector offset addressing)
     ctr[kk] = pyr + dg.pyrOff[l] + (size_t)img * dg.pyrImg[l] + (size_t)(EDGE + cy[kk] - HALF_PATCH) * pstride[kk] + EDGE + cx[kk] - HALF_PATCH;
-    center[kk] = blur + dg.blurOff[l] + (size_t)img * dg.blurImg[l] + (ptrdiff_t)(cy[kk] - EDGE) * bstride[kk] + cx[kk] - EDGE;
+    center[kk] = blur + dg.blurOff[l] + (size_t)img * dg.blurImg[l] + (ptrdiff_t)(cy[kk] - DESC_R) * bstride[kk] + cx[kk] - DESC_R;
   }
   // IC_Angle on the un-blurred level.  The texture path handles a byte load of a wave no faster than a dword load, so the
   // 31 x 31 patch is read as 31 rows x 8 unaligned dwords = 248 dword loads, four per lane.
@@ -982,6 +991,22 @@ __global__ __launch_bounds__(256) void k_describe(const morb::DescGeom dg, const
       const int tt = t < 248 ? t : 247;
       wv[kk][j] = load_u32_unaligned(ctr[kk] + (uint32_t)(__umul24(tt >> 3, pstride[kk]) + (tt & 7) * 4));
     }
+  // The blurred window the rotated pattern can reach — 37 x 37 around the keypoint, |coordinate| <= 18 = round(13 * sqrt 2) — does not
+  // depend on the angle: it is requested in the same round trip as the patch, 37 rows x three 16-byte loads (the 11 bytes past the window
+  // stay inside the row's slack or the next row), and goes to LDS, where the 512 byte gathers of the tests cost a fraction of what they
+  // cost the vector cache: PMC showed the kernel at 1.13 cache-line accesses per cycle per CU (TCP_TOTAL_CACHE_ACCESSES: 692 per keypoint,
+  // 512 of them the byte gathers), i.e. bound by the L1's one tag lookup per clock; the window's row loads are ~60 accesses.
+#if MORB_DESC_STAGED
+  uint4 ww[DESC_KPW][2];
+#pragma unroll
+  for (int kk = 0; kk < DESC_KPW; ++kk)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int t = min(lane + 64 * j, DESC_WIN * 3 - 1);   // row = t / 3, 16-byte segment = t % 3
+      const int row = (int)(((unsigned)t * 21846u) >> 16), seg = t - row * 3;
+      __builtin_memcpy(&ww[kk][j], center[kk] + (uint32_t)(__umul24(row, bstride[kk]) + seg * 16), 16);
+    }
+#endif
   // The circular mask and the column weights of a lane's four dwords do not depend on the keypoint: byte masks and the
   // biased weights (u + 15, so that v_dot4_u32_u8 applies) are built once, and per keypoint a dword costs one AND, two
   // dot products and a multiply-add: m10 = sum (u + 15) I - 15 sum I, m01 = sum v (row sum of I).
@@ -1004,6 +1029,19 @@ __global__ __launch_bounds__(256) void k_describe(const morb::DescGeom dg, const
   }
   float angle[DESC_KPW];
   int t0v[DESC_KPW][4], t1v[DESC_KPW][4];
+  int m10k[DESC_KPW], m01k[DESC_KPW];
+#if MORB_DESC_STAGED
+  uint8_t* win = s_win + (threadIdx.x >> 6) * (DESC_KPW * DESC_WIN * DESC_WP);   // this wave's windows: [DESC_KPW][37 rows][48 bytes]
+#pragma unroll
+  for (int kk = 0; kk < DESC_KPW; ++kk)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int t = lane + 64 * j;
+      if (t < DESC_WIN * 3) *reinterpret_cast<uint4*>(win + kk * (DESC_WIN * DESC_WP) + t * 16) = ww[kk][j];   // row * 48 + seg * 16 == t * 16
+    }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#endif
 #pragma unroll
   for (int kk = 0; kk < DESC_KPW; ++kk) {
     uint32_t usumB = 0, sumAll = 0;
@@ -1017,22 +1055,39 @@ __global__ __launch_bounds__(256) void k_describe(const morb::DescGeom dg, const
       m01 += pv[j] * (int)sum;
     }
     int m10 = (int)usumB - HALF_PATCH * (int)sumAll;
-    m10 = morbwave::sum_i32(m10);   // DPP reductions (wave.h): all 64 lanes are active here
-    m01 = morbwave::sum_i32(m01);
-    // (computing the DESC_KPW angles / sincos in DESC_KPW lanes at once was measured slower: it puts every keypoint's
-    // gathers behind one serial f64 chain; here keypoint kk's gathers are in flight while kk + 1's angle is computed)
-    angle[kk] = fast_atan2_deg((float)m01, (float)m10);
-    // rBRIEF on the blurred level: lane k evaluates tests 4k..4k+3
+    m10k[kk] = morbwave::sum_i32(m10);   // DPP reductions (wave.h): all 64 lanes are active here
+    m01k[kk] = morbwave::sum_i32(m01);
+  }
+  // fastAtan2 and sincosf are one number per keypoint: lane kk computes keypoint kk's (as wave-uniform code the four of them cost four
+  // serial passes of ~70 instructions, the FP64 polynomial of glibc's sincosf included, on all 64 lanes), and every keypoint's gathers
+  // can be issued as soon as that one pass is through
+  float angL, aL, bL;
+  {
+    int m10 = m10k[DESC_KPW - 1], m01 = m01k[DESC_KPW - 1];
+#pragma unroll
+    for (int kk = DESC_KPW - 2; kk >= 0; --kk) { m10 = lane == kk ? m10k[kk] : m10; m01 = lane == kk ? m01k[kk] : m01; }
+    angL = fast_atan2_deg((float)m01, (float)m10);
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    float a, bsin;
-    sincosf_glibc(angle[kk] * factorPI, &bsin, &a);
+    sincosf_glibc(angL * factorPI, &bL, &aL);
+  }
+#pragma unroll
+  for (int kk = 0; kk < DESC_KPW; ++kk) {
+    angle[kk] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, angL), kk));
+    // rBRIEF on the blurred level: lane k evaluates tests 4k..4k+3
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, aL), kk));
+    const float bsin = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bL), kk));
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float x0 = (float)pat[q].x, y0 = (float)pat[q].y, x1 = (float)pat[q].z, y1 = (float)pat[q].w;
       const int r0 = __float2int_rn(x0 * bsin + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bsin);
       const int r1 = __float2int_rn(x1 * bsin + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bsin);
-      t0v[kk][q] = center[kk][(uint32_t)((r0 + EDGE) * bstride[kk] + c0 + EDGE)];
-      t1v[kk][q] = center[kk][(uint32_t)((r1 + EDGE) * bstride[kk] + c1 + EDGE)];
+#if MORB_DESC_STAGED
+      t0v[kk][q] = win[kk * (DESC_WIN * DESC_WP) + (r0 + DESC_R) * DESC_WP + c0 + DESC_R];
+      t1v[kk][q] = win[kk * (DESC_WIN * DESC_WP) + (r1 + DESC_R) * DESC_WP + c1 + DESC_R];
+#else
+      t0v[kk][q] = center[kk][(uint32_t)((r0 + DESC_R) * bstride[kk] + c0 + DESC_R)];
+      t1v[kk][q] = center[kk][(uint32_t)((r1 + DESC_R) * bstride[kk] + c1 + DESC_R)];
+#endif
     }
   }
 #pragma unroll

@@ -158,23 +158,24 @@ MORB_LIBM_FN float tanf_glibc(float x) {
 }
 
 // sinf / cosf (sincosf.h: __sincosf_table, sinf_poly, reduce_fast); valid for |y| < 120
-struct SinCosTab { double sign[4]; double hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3; };
+// glibc keeps two tables (__sincosf_table[0 / 1]) that differ only in the sign of the cosine coefficients, and a sign[4] array indexed by
+// the quadrant.  Both are restated as arithmetic: a per-thread array with a dynamic index ends up in LDS or scratch on the GPU (k_describe
+// carried 8 KB of LDS and 23 LDS instructions per wave for it).  Negating every coefficient of the cosine polynomial negates its value
+// exactly (IEEE rounding is symmetric), so "table 1" is "table 0, cosine negated"; sign[q] = {1, -1, -1, 1}[q] = -1 iff (q + 1) & 2.
+struct SinCosTab { double hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3; };
 MORB_LIBM_FN double sc_poly(double x, double x2, const SinCosTab& p, int n) {
   if ((n & 1) == 0) {
     const double x3 = x * x2, s1 = p.s2 + x2 * p.s3, x7 = x3 * x2, s = x + x3 * p.s1;
     return s + x7 * s1;
   }
   const double x4 = x2 * x2, c2 = p.c3 + x2 * p.c4, c1 = p.c0 + x2 * p.c1, x6 = x4 * x2, c = c1 + x4 * p.c2;
-  return c + x6 * c2;
+  const double v = c + x6 * c2;
+  return (n & 2) ? -v : v;   // (__sincosf_table[1]: the same polynomial with every coefficient negated)
 }
 MORB_LIBM_FN void sincosf_glibc(float y, float* sn, float* cs) {
-  const SinCosTab t0 = {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, 0x1p0,
+  const SinCosTab t0 = {0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, 0x1p0,
                         -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5, -0x1.6c087e89a359dp-10,
                         0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7,
-                        -0x1.994eb3774cf24p-13};
-  const SinCosTab t1 = {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, -0x1p0,
-                        0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5, 0x1.6c087e89a359dp-10,
-                        -0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7,
                         -0x1.994eb3774cf24p-13};
   const uint32_t top = (f2u(y) >> 20) & 0x7ff;
   const uint32_t topPio4 = (f2u(0x1.921FB6p-1f) >> 20) & 0x7ff;
@@ -190,10 +191,12 @@ MORB_LIBM_FN void sincosf_glibc(float y, float* sn, float* cs) {
   const double r = x * t0.hpi_inv;
   const int n = ((int32_t)r + 0x800000) >> 24;
   x = x - n * t0.hpi;
-  const double s = t0.sign[n & 3];
-  const SinCosTab& p = (n & 2) ? t1 : t0;
-  *cs = (float)sc_poly(x * s, x * x, p, n ^ 1);
-  *sn = (float)sc_poly(x * s, x * x, p, n);
+  const double s = ((n + 1) & 2) ? -1.0 : 1.0;
+  // glibc: p = &__sincosf_table[(n >> 1) & 1]; cos = poly(x * s, x2, p, n ^ 1), sin = poly(x * s, x2, p, n) — the table index is bit 1 of n,
+  // which sc_poly applies to the cosine-type branch
+  const int tb = n & 2;
+  *cs = (float)sc_poly(x * s, x * x, t0, ((n ^ 1) & 1) | tb);
+  *sn = (float)sc_poly(x * s, x * x, t0, (n & 1) | tb);
 }
 MORB_LIBM_FN float sinf_glibc(float y) { float s, c; sincosf_glibc(y, &s, &c); return s; }
 MORB_LIBM_FN float cosf_glibc(float y) { float s, c; sincosf_glibc(y, &s, &c); return c; }

@@ -437,10 +437,10 @@ __global__ __launch_bounds__(256) void k_stereo_match(const StereoGeom sg, const
       // by DPP: four shifts per round, three rounds (before: two pixels per lane and a 64-lane reduction per shift, 11 in a chain)
       const uint32_t l0 = *reinterpret_cast<const uint32_t*>(Lp + dy * 12), l1 = *reinterpret_cast<const uint32_t*>(Lp + dy * 12 + 4),
                      l2 = *reinterpret_cast<const uint32_t*>(Lp + dy * 12 + 8) & 0x00FFFFFFu;
-      int svr[3];
       // the reference walks the shifts in order and keeps the first smallest distance (`dist < bestDist` on floats that are exact integers
       // <= 121 * 255): the minimum of (sum << 4 | shift index).  The sums are wave-uniform (v_readlane), so this runs on the scalar unit.
       uint32_t bestKey = 0xFFFFFFFFu;
+      int sums[12];   // (constant indices only: a run-time index would put the array into scratch)
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const int sh = min(r * 4 + (lane >> 4), 10);   // shift index = inc + 5: the window starts at column sh of the 21-column strip
@@ -456,22 +456,20 @@ __global__ __launch_bounds__(256) void k_stereo_match(const StereoGeom sg, const
         sv += __builtin_amdgcn_update_dpp(0, sv, 0x112, 0xf, 0xf, true);
         sv += __builtin_amdgcn_update_dpp(0, sv, 0x114, 0xf, 0xf, true);
         sv += __builtin_amdgcn_update_dpp(0, sv, 0x118, 0xf, 0xf, true);
-        svr[r] = sv;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+          sums[r * 4 + j] = __builtin_amdgcn_readlane(sv, 16 * j + 15);
           if (r * 4 + j < 11) {
-            const uint32_t key = ((uint32_t)__builtin_amdgcn_readlane(sv, 16 * j + 15) << 4) | (uint32_t)(r * 4 + j);
+            const uint32_t key = ((uint32_t)sums[r * 4 + j] << 4) | (uint32_t)(r * 4 + j);
             bestKey = key < bestKey ? key : bestKey;
           }
+        }
       }
       const int bestS = (int)(bestKey >> 4), bi = (int)(bestKey & 15u);
-      // vDists[best - 1] and [best + 1]: shift index i sits in round i >> 2, lane 16 * (i & 3) + 15
-      auto sum_at = [&](int i) -> int {
-        i = min(max(i, 0), 10);
-        const int v = (i >> 2) == 0 ? svr[0] : (i >> 2) == 1 ? svr[1] : svr[2];
-        return __builtin_amdgcn_readlane(v, 16 * (i & 3) + 15);
-      };
-      const int s1 = sum_at(bi - 1), s3 = sum_at(bi + 1);
+      // vDists[best - 1] and [best + 1] (only used when 1 <= best <= 9), by compares against the constant indices
+      int s1 = 0, s3 = 0;
+#pragma unroll
+      for (int i = 0; i < 11; ++i) { s1 = (i == bi - 1) ? sums[i] : s1; s3 = (i == bi + 1) ? sums[i] : s3; }
       if (lane == q) { rS = bestS; rInc = bi - 5; rD1 = (float)s1; rD3 = (float)s3; }
     }
   }
