@@ -318,25 +318,25 @@ __device__ __forceinline__ void ba_edge_jac(const Cam& cam, const Rig* rig, bool
   double pj[6], pjM[6];
   if (o[2] > -2.5f) {
     kb8_project_jac(rig->kbL, xc, pj);
-    for (int k = 0; k < 6; ++k) pjM[k] = pj[k];
+    _Pragma("unroll") for (int k = 0; k < 6; ++k) pjM[k] = pj[k];
   } else {
     double xr[3], M[9];
     se3_map(rig->Trl, xc, xr);
     kb8_project_jac(rig->kbR, xr, pj);
     q_to_R(rig->Trl.q, M);
-    for (int r = 0; r < 2; ++r)
-      for (int c = 0; c < 3; ++c) pjM[r * 3 + c] = pj[r * 3] * M[c] + pj[r * 3 + 1] * M[3 + c] + pj[r * 3 + 2] * M[6 + c];
+    _Pragma("unroll") for (int r = 0; r < 2; ++r)
+      _Pragma("unroll") for (int c = 0; c < 3; ++c) pjM[r * 3 + c] = pj[r * 3] * M[c] + pj[r * 3 + 1] * M[3 + c] + pj[r * 3 + 2] * M[6 + c];
   }
-  for (int r = 0; r < 2; ++r) {
+  _Pragma("unroll") for (int r = 0; r < 2; ++r) {
     const double a = pjM[r * 3], b = pjM[r * 3 + 1], c = pjM[r * 3 + 2];
     if (Jp) {
       Jp[r * 6 + 0] = -(b * -z + c * y); Jp[r * 6 + 1] = -(a * z + c * -x); Jp[r * 6 + 2] = -(a * -y + b * x);
       Jp[r * 6 + 3] = -a; Jp[r * 6 + 4] = -b; Jp[r * 6 + 5] = -c;
     }
-    if (Jl) for (int k = 0; k < 3; ++k) Jl[r * 3 + k] = -(a * R[k] + b * R[3 + k] + c * R[6 + k]);
+    if (Jl) _Pragma("unroll") for (int k = 0; k < 3; ++k) Jl[r * 3 + k] = -(a * R[k] + b * R[3 + k] + c * R[6 + k]);
   }
-  if (Jp) for (int k = 12; k < 18; ++k) Jp[k] = 0;
-  if (Jl) for (int k = 6; k < 9; ++k) Jl[k] = 0;
+  if (Jp) _Pragma("unroll") for (int k = 12; k < 18; ++k) Jp[k] = 0;
+  if (Jl) _Pragma("unroll") for (int k = 6; k < 9; ++k) Jl[k] = 0;
 }
 // isDepthPositive (OptimizableTypes.h:117-123 / :152-158)
 __device__ __forceinline__ bool ba_depth_positive(const Rig* rig, const float* o, const double* xc) {
@@ -1047,10 +1047,12 @@ __device__ __forceinline__ double build_mp_point(const BaDev& pb, int m) {   // 
     q_to_R(T.q, R);
     ba_edge_jac(pb.cam, pb.rig, st, xc, o, R, nullptr, Jl);
     const double wo = w * info;   // (mono edges: third Jacobian row and err[2] are zero, so the 3-row form is exact)
+#pragma unroll
     for (int r = 0; r < 3; ++r) {
       double sacc = 0;
       _Pragma("unroll") for (int i = 0; i < 3; ++i) sacc += Jl[i * 3 + r] * (-info * err[i] * w);
       bl[r] += sacc;
+#pragma unroll
       for (int cc = 0; cc < 3; ++cc) {
         double h = 0;
         _Pragma("unroll") for (int i = 0; i < 3; ++i) h += Jl[i * 3 + r] * wo * Jl[i * 3 + cc];
@@ -1058,7 +1060,9 @@ __device__ __forceinline__ double build_mp_point(const BaDev& pb, int m) {   // 
       }
     }
   }
+#pragma unroll
   for (int k = 0; k < 9; ++k) pb.Hll[(size_t)m * 9 + k] = Hl[k];
+#pragma unroll
   for (int k = 0; k < 3; ++k) pb.b[pb.P + 3 * m + k] = bl[k];
   return fmax(fmax(fabs(Hl[0]), fabs(Hl[4])), fabs(Hl[8]));
 }
@@ -1102,6 +1106,7 @@ __device__ __forceinline__ void build_kf_chunk(const BaDev& pb, int c, int lane)
         _Pragma("unroll") for (int i = 0; i < 3; ++i) h += Jp[i * 6 + r] * wo * Jp[i * 6 + cc];
         acc[q++] = h;
       }
+#pragma unroll
       for (int cc = 0; cc < 3; ++cc) {
         double h = 0;
         _Pragma("unroll") for (int i = 0; i < 3; ++i) h += Jp[i * 6 + r] * wo * Jl[i * 3 + cc];
