@@ -124,8 +124,10 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
 }
 // sbase / sstride: the source level's interior origin and row pitch (level l - 1 inside the pyramid, or — level 1 in the fused
 // kernel below — the caller's image, of which level 0's interior is a copy)
+// srcW: the source row's valid bytes when the source is the caller's image — its last row ends where the buffer ends, so the 8-byte
+// window must not start beyond srcW - 8 (inside the pyramid the bytes behind a row are the pad / the next row: INT_MAX there)
 __device__ __forceinline__ void resize_tile(const uint8_t* __restrict__ sbase, int sstride, uint8_t* __restrict__ pyr, const LevelGeom& gd,
-                                            const ResizeTab* __restrict__ xtab, const ResizeTab* __restrict__ ytab, const PyTile pt) {
+                                            const ResizeTab* __restrict__ xtab, const ResizeTab* __restrict__ ytab, const PyTile pt, int srcW) {
   const int px = (pt.bx * 64 + (threadIdx.x & 63)) * 4;
   // the wave's eight rows are wave-uniform: their table entries are scalar loads, fetched before any pixel
   const int py0 = (pt.by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * PY_ROWS;
@@ -154,6 +156,7 @@ __device__ __forceinline__ void resize_tile(const uint8_t* __restrict__ sbase, i
     top = max(top, max((int)tx[k].s0, (int)tx[k].s1));
   }
   const bool packed = top - base < 8;   // always true for scale factors <= 2 (the gather below is the general fallback)
+  base = min(base, srcW - 8);           // (top <= srcW - 1: the selectors stay below 8)
   // byte selectors for v_perm_b32: output k's left / right source byte inside the 8 loaded bytes
   uint32_t selL = 0, selR = 0;
 #pragma unroll
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
                                                 const ResizeTab* __restrict__ xtab,
                                                 const ResizeTab* __restrict__ ytab) {
   const PyTile pt = py_tile();
-  resize_tile(pyr + gs.pyrOff + (size_t)pt.img * gs.pyrImg + (size_t)EDGE * gs.pstride + EDGE, gs.pstride, pyr, gd, xtab, ytab, pt);
+  resize_tile(pyr + gs.pyrOff + (size_t)pt.img * gs.pyrImg + (size_t)EDGE * gs.pstride + EDGE, gs.pstride, pyr, gd, xtab, ytab, pt, 0x7fffffff);
 }
 // Levels 0 and 1 in one launch: level 1 is resized straight from the caller's image (level 0's interior is a copy of it, so the
 // bytes are the same) while the same workgroups also write level 0's padded copy, block t and t + tiles1 of k_level0's grid.
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void k_level01(const uint8_t* __restrict__ src
                                                  uint8_t* __restrict__ pyr, LevelGeom g0, LevelGeom g1,
                                                  const ResizeTab* __restrict__ xtab, const ResizeTab* __restrict__ ytab, int bx0n, int by0n) {
   const PyTile pt = py_tile();
-  resize_tile(src + (size_t)pt.img * pitch, stride, pyr, g1, xtab, ytab, pt);
+  resize_tile(src + (size_t)pt.img * pitch, stride, pyr, g1, xtab, ytab, pt, w);
   const int tiles1 = gridDim.x * gridDim.y, tiles0 = bx0n * by0n;
   for (int t = pt.by * gridDim.x + pt.bx; t < tiles0; t += tiles1) {
     const int by = t / bx0n;

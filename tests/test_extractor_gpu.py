@@ -193,3 +193,16 @@ def test_batch_capacity_is_checked():
     cnt = torch.zeros(1, dtype=torch.int32, device="cuda"); mono = torch.zeros(1, dtype=torch.int32, device="cuda")
     rc = lib().morb_extract_batch(g._h, ptr(img), 1, 640, 480, 640, 640 * 480, None, ptr(kps), ptr(desc), cap, ptr(cnt), ptr(mono), None)
     assert rc == -3, rc   # MORB_ERR_CAPACITY
+
+
+def test_input_ending_on_a_page_boundary():
+    # 64 images of 512 x 512 = exactly 16 MiB: the device buffer ends where its last page ends.  The fused level-0 / level-1 kernel
+    # read 8-byte windows of the caller's image and the last row's window ran up to 6 bytes past the end of the buffer — silent for
+    # most sizes, a memory fault for this one (found with the C3 shape at 32 stereo frames).  Run in a child process: a fault kills it.
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "native", "extract_once.py"), "512", "512", "1500", "32", "1"],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
