@@ -67,6 +67,18 @@ __device__ __forceinline__ void q_to_R(const double* q, double* R) {
   R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
   R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
 }
+// Eigen's matrix -> quaternion (Quaternion.h, QuaternionBase::operator=(MatrixBase)); the largest-diagonal branch indexes the matrix with
+// i, j = (i + 1) % 3, k = (j + 1) % 3 — as run-time indices they put the matrix into scratch memory in every pose update (a store and nine
+// dependent loads on the critical path of each LM trial), so the three cases are spelled out with constant indices.
+template <int I, int J, int K>
+__device__ __forceinline__ void R_to_q_case(const double* m, double* q) {
+  double t = sqrt(m[I * 3 + I] - m[J * 3 + J] - m[K * 3 + K] + 1.0);
+  q[I] = 0.5 * t;
+  t = 0.5 / t;
+  q[3] = (m[K * 3 + J] - m[J * 3 + K]) * t;
+  q[J] = (m[J * 3 + I] + m[I * 3 + J]) * t;
+  q[K] = (m[K * 3 + I] + m[I * 3 + K]) * t;
+}
 __device__ __forceinline__ void R_to_q(const double* m, double* q) {
   double t = m[0] + m[4] + m[8];
   if (t > 0) {
@@ -75,18 +87,11 @@ __device__ __forceinline__ void R_to_q(const double* m, double* q) {
     t = 0.5 / t;
     q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
   } else {
-    int i = 0;
-    if (m[4] > m[0]) i = 1;
-    if (m[8] > m[i * 3 + i]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    t = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
-    double qq[4];
-    qq[i] = 0.5 * t;
-    t = 0.5 / t;
-    qq[3] = (m[k * 3 + j] - m[j * 3 + k]) * t;
-    qq[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
-    qq[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
-    q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2]; q[3] = qq[3];
+    const bool one = m[4] > m[0];
+    const bool two = m[8] > (one ? m[4] : m[0]);
+    if (two) R_to_q_case<2, 0, 1>(m, q);
+    else if (one) R_to_q_case<1, 2, 0>(m, q);
+    else R_to_q_case<0, 1, 2>(m, q);
   }
 }
 __device__ __forceinline__ SE3 se3_mul(const SE3& a, const SE3& b) {
@@ -223,23 +228,43 @@ __device__ __forceinline__ double block_sum_d(double v, double* red /*[NW]*/) {
 
 // LDL^T solve of an n x n SPD system held in registers/local arrays (n = 6)
 __device__ __forceinline__ bool ldlt6(const double* Hin, const double* rhs, double* x) {
+  // (every loop fully unrolled: an index that is not a compile-time constant puts the arrays into scratch memory, and the solve sits on
+  // the critical path of every LM iteration)
   double A[36], D[6];
+#pragma unroll
   for (int i = 0; i < 36; ++i) A[i] = Hin[i];
+  bool ok = true;
+#pragma unroll
   for (int j = 0; j < 6; ++j) {
     double d = A[j * 6 + j];
+#pragma unroll
     for (int k = 0; k < j; ++k) d -= A[j * 6 + k] * A[j * 6 + k] * D[k];
-    if (!(d > 0)) return false;  // LinearSolverDense: _cholesky.isPositive()
+    ok = ok && (d > 0);   // LinearSolverDense: _cholesky.isPositive() (the factorisation runs on; the caller discards x)
     D[j] = d;
+#pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       double s = A[i * 6 + j];
+#pragma unroll
       for (int k = 0; k < j; ++k) s -= A[i * 6 + k] * A[j * 6 + k] * D[k];
       A[i * 6 + j] = s / d;
     }
   }
+  if (!ok) return false;
   double y[6];
-  for (int i = 0; i < 6; ++i) { y[i] = rhs[i]; for (int k = 0; k < i; ++k) y[i] -= A[i * 6 + k] * y[k]; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    y[i] = rhs[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) y[i] -= A[i * 6 + k] * y[k];
+  }
+#pragma unroll
   for (int i = 0; i < 6; ++i) y[i] /= D[i];
-  for (int i = 5; i >= 0; --i) for (int k = i + 1; k < 6; ++k) y[i] -= A[k * 6 + i] * y[k];
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) y[i] -= A[k * 6 + i] * y[k];
+  }
+#pragma unroll
   for (int i = 0; i < 6; ++i) x[i] = y[i];
   return true;
 }
