@@ -39,30 +39,49 @@ __device__ __forceinline__ void kb8_unproject(const KB8& c, float px, float py, 
   }
   ray[0] = pwx * scale; ray[1] = pwy * scale; ray[2] = 1.f;
 }
+// (the (p, q) loops and every k loop are unrolled: with run-time indices M and V live in scratch memory and each of the 180 rotations is
+// ~50 dependent memory accesses; with constant indices they are 32 FP64 registers)
 __device__ inline void null_vector4(const float* A, double* out) {
   double M[16], V[16];
+#pragma unroll
   for (int i = 0; i < 4; ++i)
+#pragma unroll
     for (int j = 0; j < 4; ++j) {
       double s = 0;
+#pragma unroll
       for (int k = 0; k < 4; ++k) s += (double)A[k * 4 + i] * (double)A[k * 4 + j];
       M[i * 4 + j] = s;
       V[i * 4 + j] = i == j ? 1.0 : 0.0;
     }
-  for (int sweep = 0; sweep < 30; ++sweep)
+  for (int sweep = 0; sweep < 30; ++sweep) {
+#pragma unroll
     for (int p = 0; p < 3; ++p)
+#pragma unroll
       for (int q = p + 1; q < 4; ++q) {
         const double apq = M[p * 4 + q];
         if (apq == 0.0) continue;
         const double tau = (M[q * 4 + q] - M[p * 4 + p]) / (2.0 * apq);
         const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
         const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
+#pragma unroll
         for (int k = 0; k < 4; ++k) { const double a = M[k * 4 + p], b = M[k * 4 + q]; M[k * 4 + p] = cs * a - sn * b; M[k * 4 + q] = sn * a + cs * b; }
+#pragma unroll
         for (int k = 0; k < 4; ++k) { const double a = M[p * 4 + k], b = M[q * 4 + k]; M[p * 4 + k] = cs * a - sn * b; M[q * 4 + k] = sn * a + cs * b; }
+#pragma unroll
         for (int k = 0; k < 4; ++k) { const double a = V[k * 4 + p], b = V[k * 4 + q]; V[k * 4 + p] = cs * a - sn * b; V[k * 4 + q] = sn * a + cs * b; }
       }
-  int best = 0;
-  for (int i = 1; i < 4; ++i) if (M[i * 4 + i] < M[best * 4 + best]) best = i;
-  for (int k = 0; k < 4; ++k) out[k] = V[k * 4 + best];
+  }
+  // the eigenvector of the smallest eigenvalue (first of equal ones), selected without a run-time column index
+  double bestVal = M[0];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out[k] = V[k * 4];
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (M[i * 4 + i] < bestVal) {
+      bestVal = M[i * 4 + i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out[k] = V[k * 4 + i];
+    }
 }
 // KannalaBrandt8::TriangulateMatches (KannalaBrandt8.cpp:323-395): this = c1, pCamera2 = c2; returns the depth in c1 (> 0) or a
 // negative reject code
