@@ -1,0 +1,49 @@
+"""The hot kernels must not use scratch (private) memory: a per-thread array that is indexed with a run-time value cannot live in
+registers, the compiler moves it to scratch memory (or LDS), and every access becomes a memory operation on the kernel's critical
+path.  Round 2 found five such arrays (glibc's sincosf sign table, `ref[first]` in k_describe, Eigen's matrix -> quaternion indices, the
+Jacobi rotations of the KB8 triangulation, the shift selection of the stereo SAD).  This test reads the kernel descriptors out of the
+built library (no GPU needed) and pins `private_segment_fixed_size == 0` for them."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+HOT = ["k_level01", "k_resize", "k_level0", "k_blur", "k_fast", "k_distribute", "k_layout", "k_describe",
+       "k_stereo_prep", "k_stereo_match", "k_stereo_median", "k_bow_transform", "k_bow_sort", "k_rot_filter",
+       "k_pose_opt", "k_g_chi2", "k_g_dinv_push", "k_g_backsub_update_w", "k_g_finish", "k_schur_mfma",
+       "k_fe_triangulate", "k_triangulation", "k_frustum"]
+
+
+def _kernel_metadata(lib, tmp):
+    fat = os.path.join(tmp, "fat.bin")
+    subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib])
+    blob = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(re.escape(b"__CLANG_OFFLOAD_BUNDLE__"), blob)]
+    meta = {}
+    for i, st in enumerate(starts):
+        en = starts[i + 1] if i + 1 < len(starts) else len(blob)
+        bun, co = os.path.join(tmp, f"bundle{i}.bin"), os.path.join(tmp, f"code{i}.o")
+        open(bun, "wb").write(blob[st:en])
+        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + bun, "--output=" + co])
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
+        for m in re.finditer(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+)", notes, re.S):
+            meta[m.group(1)] = int(m.group(2))
+    return meta
+
+
+def test_hot_kernels_use_no_scratch_memory(tmp_path):
+    lib = os.path.join(ROOT, "morb_slam_amd", "libmorb_hip.so")
+    if not (os.path.exists(lib) and all(shutil.which(os.path.join(LLVM, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf"))):
+        pytest.skip("library or LLVM tools not available")
+    meta = _kernel_metadata(lib, str(tmp_path))
+    assert len(meta) > 50, "kernel descriptors not found"
+    for short in HOT:
+        hits = {k: v for k, v in meta.items() if re.search(r"\d+" + short + r"(I|E)", k)}
+        assert hits, f"kernel {short} not found in the code objects"
+        for name, scratch in hits.items():
+            assert scratch == 0, f"{name} uses {scratch} bytes of scratch memory per thread"
