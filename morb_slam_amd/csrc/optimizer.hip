@@ -332,9 +332,12 @@ __device__ __forceinline__ double ba_edge_error(const Cam& cam, const Rig* rig, 
   return err[0] * (info * err[0]) + err[1] * (info * err[1]);
 }
 // Jp (d x 6) and / or Jl (d x 3); R = rotation of the keyframe pose.  OptimizableTypes.cpp:134-156 / :185-208
+// RIG = false: the problem has no fisheye rig.  The KannalaBrandt8 branch (its float libm, the right camera's extrinsics) otherwise costs
+// the pinhole build kernel 100 VGPRs (220 instead of 119) and puts the pose Jacobian into scratch memory — for a branch it never takes.
+template <bool RIG = true>
 __device__ __forceinline__ void ba_edge_jac(const Cam& cam, const Rig* rig, bool st, const double* xc, const float* o,
                                             const double* R, double* Jp, double* Jl) {
-  if (!edge_is_kb8(rig, o)) {
+  if (!RIG || !edge_is_kb8(rig, o)) {
     if (Jp) jac_pose(cam, st, false, xc, Jp);
     if (Jl) jac_point(cam, st, xc, R, Jl);
     return;
@@ -1055,6 +1058,7 @@ __global__ __launch_bounds__(GB) void k_g_reduce(const double* __restrict__ part
   s = block_sum_d<4>(s, red);
   if (threadIdx.x == 0) *out = s;
 }
+template <bool RIG>
 __device__ __forceinline__ double build_mp_point(const BaDev& pb, int m) {   // -> max |diag Hll| of the point
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   double Hl[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
@@ -1070,7 +1074,7 @@ __device__ __forceinline__ double build_mp_point(const BaDev& pb, int m) {   // 
     const double c = ba_edge_error(pb.cam, pb.rig, st, xc, o, info, err);
     huber(st ? deltaStereo : deltaMono, c, &w);
     q_to_R(T.q, R);
-    ba_edge_jac(pb.cam, pb.rig, st, xc, o, R, nullptr, Jl);
+    ba_edge_jac<RIG>(pb.cam, pb.rig, st, xc, o, R, nullptr, Jl);
     const double wo = w * info;   // (mono edges: third Jacobian row and err[2] are zero, so the 3-row form is exact)
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -1091,13 +1095,15 @@ __device__ __forceinline__ double build_mp_point(const BaDev& pb, int m) {   // 
   for (int k = 0; k < 3; ++k) pb.b[pb.P + 3 * m + k] = bl[k];
   return fmax(fmax(fabs(Hl[0]), fabs(Hl[4])), fabs(Hl[8]));
 }
+template <bool RIG>
 __global__ __launch_bounds__(GB) void k_g_build_mp(const BaDev* __restrict__ pbp, int gated) {
   const BaDev pb = *pbp;
   if (lm_skip_build(pb, gated)) return;
   const int m = blockIdx.x * GB + threadIdx.x;
   if (m >= pb.nMP) return;
-  build_mp_point(pb, m);
+  build_mp_point<RIG>(pb, m);
 }
+template <bool RIG>
 __device__ __forceinline__ void build_kf_chunk(const BaDev& pb, int c, int lane) {
   const int kf = pb.chunkKF[c];
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
@@ -1117,7 +1123,7 @@ __device__ __forceinline__ void build_kf_chunk(const BaDev& pb, int c, int lane)
     const double info = (double)pb.eInfo[e];
     const double ch = ba_edge_error(pb.cam, pb.rig, st, xc, o, info, err);
     huber(st ? deltaStereo : deltaMono, ch, &w);
-    ba_edge_jac(pb.cam, pb.rig, st, xc, o, R, Jp, Jl);
+    ba_edge_jac<RIG>(pb.cam, pb.rig, st, xc, o, R, Jp, Jl);
     const double wo = w * info;   // (mono edges: third Jacobian row and err[2] are zero, so the 3-row form is exact)
     int q = 0;
 #pragma unroll
@@ -1148,12 +1154,13 @@ __device__ __forceinline__ void build_kf_chunk(const BaDev& pb, int c, int lane)
     pb.kfPart[(size_t)c * 27 + lane] = v;
   }
 }
+template <bool RIG>
 __global__ __launch_bounds__(GB) void k_g_build_kf(const BaDev* __restrict__ pbp, int gated) {
   const BaDev pb = *pbp;
   if (lm_skip_build(pb, gated)) return;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= pb.nChunks) return;
-  build_kf_chunk(pb, c, lane);
+  build_kf_chunk<RIG>(pb, c, lane);
 }
 __global__ __launch_bounds__(64) void k_g_kf_reduce(const BaDev* __restrict__ pbp, int gated) {
   const BaDev pb = *pbp;
@@ -1176,6 +1183,7 @@ __global__ __launch_bounds__(64) void k_g_kf_reduce(const BaDev* __restrict__ pb
 // buildSystem in ONE launch (device-side LM control): workgroups [0, kfBlocks) take the keyframe chunks, the rest the map points;
 // the last chunk of a keyframe to deliver its partial blocks adds them up in chunk order (k_g_kf_reduce's sum, whoever runs it).
 // Two launches on two streams cost more in cross-stream events (~25 us per trial) than running side by side saved.
+template <bool RIG>
 __global__ __launch_bounds__(GB) void k_g_build(const BaDev* __restrict__ pbp, int kfBlocks) {
   const BaDev pb = *pbp;
   if (lm_skip_build(pb, 1)) return;
@@ -1185,7 +1193,7 @@ __global__ __launch_bounds__(GB) void k_g_build(const BaDev* __restrict__ pbp, i
   unsigned long long* maxDiag = reinterpret_cast<unsigned long long*>(pb.scal + 3);
   if ((int)blockIdx.x >= kfBlocks) {
     const int m = (blockIdx.x - kfBlocks) * GB + threadIdx.x;
-    double dm = m < pb.nMP ? build_mp_point(pb, m) : 0.0;
+    double dm = m < pb.nMP ? build_mp_point<RIG>(pb, m) : 0.0;
     if (first) {
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) dm = fmax(dm, __shfl_xor(dm, off, 64));
@@ -1195,7 +1203,7 @@ __global__ __launch_bounds__(GB) void k_g_build(const BaDev* __restrict__ pbp, i
   }
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= pb.nChunks) return;
-  build_kf_chunk(pb, c, lane);
+  build_kf_chunk<RIG>(pb, c, lane);
   const int kf = pb.chunkKF[c];
   int last = 0;
   if (lane == 0) {
@@ -2161,7 +2169,8 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
     constexpr int kAhead = 1;   // trials queued beyond the last decided one
     for (int slot = 0; slot < 100; ++slot) {
       // buildSystem (runs only when the previous trial was accepted): keyframe chunks and map points in one launch
-      hipLaunchKernelGGL(k_g_build, dim3(kfBlocks + div_up(h.nMP, GB)), dim3(GB), 0, st, d, kfBlocks);
+      if (h.rig) hipLaunchKernelGGL(k_g_build<true>, dim3(kfBlocks + div_up(h.nMP, GB)), dim3(GB), 0, st, d, kfBlocks);
+      else hipLaunchKernelGGL(k_g_build<false>, dim3(kfBlocks + div_up(h.nMP, GB)), dim3(GB), 0, st, d, kfBlocks);
       hipLaunchKernelGGL(k_g_dinv_push, dim3(rb > div_up(h.P * h.P, GB) ? rb : div_up(h.P * h.P, GB)), dim3(GB), 0, st, d, 0.0, h.HsG, 0, 1);
       hipLaunchKernelGGL(morbschur::k_schur_mfma, dim3(p->schur.nblk, p->schur.nsplit), dim3(64), 0, st, (const double*)h.sWD,
                          (const double*)h.sW, p->schur.Mp, p->schur.ksteps, p->schur.stepsPerSplit, h.sBlocks, h.sPart, (const int*)(h.lmi + LM_DONE));
@@ -2207,10 +2216,12 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
     auto launchBuilds = [&]() -> int {
       MORB_HIP_CHECK(hipEventRecord(p->opt->evFork, st));
       MORB_HIP_CHECK(hipStreamWaitEvent(s2, p->opt->evFork, 0));
-      hipLaunchKernelGGL(k_g_build_kf, dim3(div_up(std::max(h.nChunks, 1), 4)), dim3(GB), 0, s2, d, 0);
+      if (h.rig) hipLaunchKernelGGL(k_g_build_kf<true>, dim3(div_up(std::max(h.nChunks, 1), 4)), dim3(GB), 0, s2, d, 0);
+      else hipLaunchKernelGGL(k_g_build_kf<false>, dim3(div_up(std::max(h.nChunks, 1), 4)), dim3(GB), 0, s2, d, 0);
       hipLaunchKernelGGL(k_g_kf_reduce, dim3(h.nKF), dim3(64), 0, s2, d, 0);
       MORB_HIP_CHECK(hipEventRecord(p->opt->evJoin, s2));
-      hipLaunchKernelGGL(k_g_build_mp, dim3(div_up(h.nMP, GB)), dim3(GB), 0, st, d, 0);
+      if (h.rig) hipLaunchKernelGGL(k_g_build_mp<true>, dim3(div_up(h.nMP, GB)), dim3(GB), 0, st, d, 0);
+      else hipLaunchKernelGGL(k_g_build_mp<false>, dim3(div_up(h.nMP, GB)), dim3(GB), 0, st, d, 0);
       MORB_HIP_CHECK(hipStreamWaitEvent(st, p->opt->evJoin, 0));
       hipLaunchKernelGGL(k_g_pack_w, dim3(rb), dim3(GB), 0, st, d, 0);
       return MORB_OK;
