@@ -67,6 +67,30 @@ def test_stereo_matches_bit_exact(batch):
     assert nmatched > 4 * 300   # the synthetic pairs really produce stereo matches
 
 
+@pytest.mark.parametrize("nframes", [1, 9, 40])
+def test_stereo_matches_every_workgroup_shape(batch, nframes):
+    # k_stereo_match sizes its workgroups by the batch (4 / 8 / 16 / 32 left keypoints = 1 / 2 / 4 / 8 per wave, sm_lk_for()): the fixture's
+    # 4 frames run the 8-keypoint shape; 1, 9 and 40 frames (the fixture's frames, repeated) run the others.  Every copy of a frame must give
+    # that frame's oracle result.
+    import torch
+    from morb_slam_amd import ORBextractor, ORBmatcher
+    imgs = np.stack([batch["imgs"][2 * (f % 4) + k] for f in range(nframes) for k in (0, 1)])
+    ext = ORBextractor(1200, 1.2, 8, 20, 7)
+    kps, desc, cnt, _ = ext.extract_batch(torch.from_numpy(imgs).cuda())
+    u, d = ORBmatcher().ComputeStereoMatches(ext, kps, desc, cnt, MBF, MB)
+    torch.cuda.synchronize()
+    u, d = u.cpu().numpy(), d.cpu().numpy()
+    exp = {}
+    for f in range(nframes):
+        b = f % 4
+        if b not in exp:
+            (ol, kl, dl), (orr, kr, dr) = batch["ora"][2 * b], batch["ora"][2 * b + 1]
+            exp[b] = O.stereo_matches(ol, orr, kl, dl, kr, dr, MBF, MB) + (len(kl),)
+        ue, de, n = exp[b]
+        assert u[f, :n].view(np.uint32).tolist() == ue.view(np.uint32).tolist(), f"frame {f}"
+        assert d[f, :n].view(np.uint32).tolist() == de.view(np.uint32).tolist(), f"frame {f}"
+
+
 def test_knn2_ratio(batch):
     import torch
     from morb_slam_amd import ORBmatcher
