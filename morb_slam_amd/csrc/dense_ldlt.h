@@ -24,13 +24,11 @@ constexpr int NB = 16, NBP = 17, LT = 512;   // 512 threads: two waves per SIMD
 typedef double ld_d4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int tri(int r, int c) { return ((r * (r + 1)) >> 1) + c; }   // c <= r
 
-// lane SRC (0..15, compile-time) of every 16-lane row -> all lanes of the row: two v_mov_b32_dpp row_newbcast (gfx90a+)
+// lane SRC (0..15, compile-time) of every 16-lane row -> all lanes of the row: ONE v_mov_b64_dpp row_newbcast (the only DPP control gfx90a+
+// offers on 64-bit operands; as two v_mov_b32_dpp halves every broadcast was two of the ~6-cycle issue slots a lone wave gets)
 template <int SRC>
 __device__ __forceinline__ double row_bcast_f64(double v) {
-  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x150 + SRC, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x150 + SRC, 0xf, 0xf, false);
-  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+  return __longlong_as_double(__builtin_amdgcn_update_dpp((long long)0, __double_as_longlong(v), 0x150 + SRC, 0xf, 0xf, false));
 }
 // stage J of the in-register LDL^T of a 16 x 16 block (row r in lane r of each 16-lane row)
 template <int J>

@@ -76,9 +76,9 @@ __device__ __forceinline__ double row_sum_f64(double v) {
   MORB_DPP_ROW_F64(0x112, v += o_);
   MORB_DPP_ROW_F64(0x114, v += o_);
   MORB_DPP_ROW_F64(0x118, v += o_);
-  MORB_DPP_ROW_F64(0x15F, v = o_);
 #undef MORB_DPP_ROW_F64
-  return v;
+  // (row_newbcast is the one DPP control with a 64-bit form: v_mov_b64_dpp)
+  return __longlong_as_double(__builtin_amdgcn_update_dpp((long long)0, __double_as_longlong(v), 0x15F, 0xf, 0xf, false));
 }
 // broadcast of lane `src`'s double (src wave-uniform; a compile-time constant compiles to two v_readlane_b32)
 __device__ __forceinline__ double readlane_f64(double v, int src) {
