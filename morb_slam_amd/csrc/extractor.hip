@@ -523,13 +523,40 @@ __global__ __launch_bounds__(FS_NT) void k_fast(const morb::FastGeom fg, const m
       unsigned KF[8], MF[8];   // per (dword & 1, parity, polarity): the add constant and the flag bit (8 + index) in both halves
 #pragma unroll
       for (int j = 0; j < 8; ++j) { KF[j] = ((1u << (8 + j)) - 1u - (unsigned)T) * 0x00010001u; MF[j] = (1u << (8 + j)) * 0x00010001u; }
-      for (int i0 = 0; i0 < nItems; i0 += FS_NT) {
-        if (i0 + __builtin_amdgcn_readfirstlane(tid & ~63) >= nItems) break;   // wave-uniform: no item left for this wave
+      // compaction of a wave's flag words: per-lane popcount, one DPP scan per wave, one LDS atomic per wave, every lane emits its own entries
+      auto emit = [&](unsigned W, int y, int xb0) {
+        unsigned anyW = (W | (W >> 1)) & 0x55555555u;
+        const int cnt = __popc(anyW);
+        int incl = cnt;
+        MORB_DPP_SCAN(incl, 0, morbwave::op_add);   // inclusive prefix over the wave (all lanes active)
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (!total) return;   // wave-uniform
+        int qbase = 0;
+        if (lane == 63) qbase = atomicAdd(&qn, total);
+        qbase = __builtin_amdgcn_readlane(qbase, 63);
+        if (qbase + total > FS_QCAP) { if (lane == 0) qover = 1; return; }   // wave-uniform
+        int slot = qbase + incl - cnt;
+        const unsigned pos0 = (unsigned)((y << 7) | xb0);
+        while (anyW) {
+          const unsigned f = (unsigned)__ffs(anyW) - 1u;
+          anyW &= anyW - 1u;
+          const unsigned o = ((f >> 1) & 1u) | ((f >> 3) & 2u) | (f & 12u);
+          queue[slot++] = (uint16_t)((((W >> f) & 3u) << 14) | (pos0 + o));
+        }
+      };
+      // A typical three-cell segment is 259 - 266 items: one full round of the 256 lanes and 3 - 10 items more, for which wave 0 used to run
+      // a whole second round (a fifth of the phase's wave-rounds for 2 % of its pixels).  The remainder is now spread over four lanes per
+      // item — a lane takes ONE of the block's four dwords — so the tail round costs a third of a full one.
+      const int rem = nItems % FS_NT;
+      const bool lightTail = nItems > FS_NT && rem != 0 && rem * 4 <= FS_NT;
+      const int nMain = lightTail ? nItems - rem : nItems;
+      for (int i0 = 0; i0 < nMain; i0 += FS_NT) {
+        if (i0 + __builtin_amdgcn_readfirstlane(tid & ~63) >= nMain) break;   // wave-uniform: no item left for this wave
         const int i = i0 + tid;
         const int iy = (int)(((unsigned)i * itMagic) >> 20);
         const int y = iy + ya, xb0 = (i - __mul24(iy, nIt) + ix0) << 4;
         unsigned W = 0;   // bit f: f[0] polarity (0 dark, 1 bright), pixel offset in the block = f[3] f[2] f[4] f[1]
-        if (i < nItems && xb0 < xb && xb0 + 16 > xa) {
+        if (i < nMain && xb0 < xb && xb0 + 16 > xa) {
           const uint8_t* rowp = tile + ((y << 7) | xb0);
           const uint4 C = *reinterpret_cast<const uint4*>(rowp);
           const uint4 U = *reinterpret_cast<const uint4*>(rowp - 3 * FS_P);   // ring pixel 8 (0,-3)
@@ -560,25 +587,38 @@ __global__ __launch_bounds__(FS_NT) void k_fast(const morb::FastGeom fg, const m
           }
           W = ((acc[0] >> 8) & 0x00FF00FFu) | (acc[1] & 0xFF00FF00u);
         }
-        unsigned anyW = (W | (W >> 1)) & 0x55555555u;
-        const int cnt = __popc(anyW);
-        int incl = cnt;
-        MORB_DPP_SCAN(incl, 0, morbwave::op_add);   // inclusive prefix over the wave (all lanes active)
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        if (total) {   // wave-uniform
-          int qbase = 0;
-          if (lane == 63) qbase = atomicAdd(&qn, total);
-          qbase = __builtin_amdgcn_readlane(qbase, 63);
-          if (qbase + total > FS_QCAP) { if (lane == 0) qover = 1; continue; }   // wave-uniform
-          int slot = qbase + incl - cnt;
-          const unsigned pos0 = (unsigned)((y << 7) | xb0);
-          while (anyW) {
-            const unsigned f = (unsigned)__ffs(anyW) - 1u;
-            anyW &= anyW - 1u;
-            const unsigned o = ((f >> 1) & 1u) | ((f >> 3) & 2u) | (f & 12u);
-            queue[slot++] = (uint16_t)((((W >> f) & 3u) << 14) | (pos0 + o));
+        emit(W, y, xb0);
+      }
+      if (lightTail && __builtin_amdgcn_readfirstlane(tid & ~63) < rem * 4) {   // wave-uniform
+        const int i = nMain + (tid >> 2), k = tid & 3;
+        const int iy = (int)(((unsigned)i * itMagic) >> 20);
+        const int y = iy + ya, xb0 = (i - __mul24(iy, nIt) + ix0) << 4;
+        unsigned W = 0;
+        if (i < nItems && xb0 < xb && xb0 + 16 > xa) {
+          const uint8_t* rowp = tile + ((y << 7) | xb0) + 4 * k;   // the lane's dword of the block
+          const uint32_t cwL = *reinterpret_cast<const uint32_t*>(rowp - 4), cw = *reinterpret_cast<const uint32_t*>(rowp),
+                         cwR = *reinterpret_cast<const uint32_t*>(rowp + 4);
+          const uint32_t uw = *reinterpret_cast<const uint32_t*>(rowp - 3 * FS_P), dw = *reinterpret_cast<const uint32_t*>(rowp + 3 * FS_P);
+          const unsigned E0 = cwL & LO, E1 = cw & LO, E2 = cwR & LO, O0 = (cwL >> 8) & LO, O1 = (cw >> 8) & LO, O2 = (cwR >> 8) & LO;
+          const unsigned jb = (unsigned)(k & 1) * 4u;   // flag bits 8 + jb .. 8 + jb + 3: (parity, polarity) of this dword
+          unsigned acc = 0u;
+#pragma unroll
+          for (int par = 0; par < 2; ++par) {
+            const unsigned Ve = par ? O1 : E1;
+            const unsigned a = (par ? (uw >> 8) : uw) & LO, b = (par ? (dw >> 8) : dw) & LO;
+            const unsigned cc = par ? __builtin_amdgcn_alignbit(E1, E0, 16) : O0;
+            const unsigned d = par ? E2 : __builtin_amdgcn_alignbit(O2, O1, 16);
+            const unsigned lo1 = pk_min(a, b), hi1 = pk_max(a, b), lo2 = pk_min(cc, d), hi2 = pk_max(cc, d);
+            const unsigned mlo = pk_max(lo1, lo2), mhi = pk_min(hi1, hi2);
+            const unsigned s2 = pk_min(mlo, mhi), l2 = pk_max(mlo, mhi);
+            const unsigned m0 = (0x0100u << (jb + par * 2)) * 0x00010001u, m1 = m0 << 1;   // MF[j], MF[j + 1]
+            const unsigned k0 = m0 - (1u + (unsigned)T) * 0x00010001u, k1 = m1 - (1u + (unsigned)T) * 0x00010001u;   // KF[j], KF[j + 1]
+            acc |= pk_add(pk_sub_sat(Ve, s2), k0) & m0;
+            acc |= pk_add(pk_sub_sat(l2, Ve), k1) & m1;
           }
+          W = (k >> 1) ? (acc & 0xFF00FF00u) : ((acc >> 8) & 0x00FF00FFu);
         }
+        emit(W, y, xb0);
       }
     }
     __syncthreads();
