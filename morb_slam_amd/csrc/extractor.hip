@@ -785,6 +785,9 @@ __global__ __launch_bounds__(FS_NT) void k_fast(const morb::FastGeom fg, const m
 }
 
 // ---------------------------------------------------------------------------------------------------
+#ifndef QT_GATHER
+#define QT_GATHER 16   // candidate loads in flight per lane while the cells' lists are gathered (4: 457 us, 8: 444, 16: 438 per 512 images under the blur)
+#endif
 // K3: DistributeOctTree, one wave per (level, image).  See quadtree.h.
 // A wave's LDS need (node arrays by the level's quota, key arrays by its area) falls by ~25 % per level, and a launch has ONE LDS size:
 // sized for level 0, three one-wave workgroups fill a CU's LDS and every small level holds as much as level 0.  So the levels of an image
@@ -858,7 +861,7 @@ __global__ __launch_bounds__(64 * QT_MAX_WAVES) void k_distribute(const LevelGeo
     tmp = keys + g.qtImg / 2;
   }
   const uint32_t* cbase = cand + ((size_t)img * totalCells + g.cellBase) * (size_t)cellCap;
-  // gather the cells' candidate lists into one array, cell-major: a lane per cell copies its list, four loads in flight per lane
+  // gather the cells' candidate lists into one array, cell-major: a lane per cell copies its list, QT_GATHER loads in flight per lane
   // (a lane per candidate had to binary-search its cell first: 8 dependent LDS reads in front of every global load, 34 of level 0's 152 us)
   for (int c0 = 0; c0 < ncell; c0 += 64) {
     const int c = c0 + lane;
@@ -866,12 +869,12 @@ __global__ __launch_bounds__(64 * QT_MAX_WAVES) void k_distribute(const LevelGeo
     const int n = c < ncell ? cellOff[c + 1] - off : 0;
     const int nmax = (int)~morbwave::min_u32(~(uint32_t)n);   // wave maximum
     const uint32_t* src = cbase + (size_t)(c < ncell ? c : 0) * cellCap;
-    for (int i0 = 0; i0 < nmax; i0 += 4) {
-      uint32_t v[4];
+    for (int i0 = 0; i0 < nmax; i0 += QT_GATHER) {
+      uint32_t v[QT_GATHER];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = i0 + k < n ? src[i0 + k] : 0u;
+      for (int k = 0; k < QT_GATHER; ++k) v[k] = i0 + k < n ? src[i0 + k] : 0u;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) if (i0 + k < n) keys[off + i0 + k] = v[k];
+      for (int k = 0; k < QT_GATHER; ++k) if (i0 + k < n) keys[off + i0 + k] = v[k];
     }
   }
   QT_SYNC();
