@@ -838,54 +838,52 @@ __global__ __launch_bounds__(64 * QT_MAX_WAVES) void k_distribute(const LevelGeo
     const int c = c0 + lane;
     const int n = c < ncell ? counts[c] : 0;
     int incl = n;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int o = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += o;
-    }
+    MORB_DPP_SCAN(incl, 0, morbwave::op_add);   // inclusive prefix over the wave
     if (c < ncell) cellOff[c] = running + incl - n;
-    running += __shfl(incl, 63, 64);
+    running += __builtin_amdgcn_readlane(incl, 63);
   }
   const int T = running;
   if (lane == 0) cellOff[ncell] = T;
   QT_SYNC();
   DMARK(8);
 
-  uint32_t* keys;
-  uint32_t* tmp;
-  if (T <= keyCap) {
-    keys = ldsKeys;
-    tmp = ldsTmp;
-  } else {
-    keys = qtScratch + g.qtOff + (size_t)img * g.qtImg;
-    tmp = keys + g.qtImg / 2;
-  }
   const uint32_t* cbase = cand + ((size_t)img * totalCells + g.cellBase) * (size_t)cellCap;
-  // gather the cells' candidate lists into one array, cell-major: a lane per cell copies its list, QT_GATHER loads in flight per lane
-  // (a lane per candidate had to binary-search its cell first: 8 dependent LDS reads in front of every global load, 34 of level 0's 152 us)
-  for (int c0 = 0; c0 < ncell; c0 += 64) {
-    const int c = c0 + lane;
-    const int off = c < ncell ? cellOff[c] : 0;
-    const int n = c < ncell ? cellOff[c + 1] - off : 0;
-    const int nmax = (int)~morbwave::min_u32(~(uint32_t)n);   // wave maximum
-    const uint32_t* src = cbase + (size_t)(c < ncell ? c : 0) * cellCap;
-    for (int i0 = 0; i0 < nmax; i0 += QT_GATHER) {
-      uint32_t v[QT_GATHER];
-#pragma unroll
-      for (int k = 0; k < QT_GATHER; ++k) v[k] = i0 + k < n ? src[i0 + k] : 0u;
-#pragma unroll
-      for (int k = 0; k < QT_GATHER; ++k) if (i0 + k < n) keys[off + i0 + k] = v[k];
-    }
-  }
-  QT_SYNC();
-  DMARK(9);
-
-  morbqt::Work w;
-  w.keys = keys; w.tmp = tmp; w.nodes = nodes; w.freeIds = freeIds; w.list = list; w.vA = vA; w.vB = vB;
-  w.order = order; w.bcnt = bcnt; w.brank = brank;
-  w.nodeCap = g.nodeCap; w.listCap = g.listCap;
   uint32_t* out = sel + (size_t)img * selPerImg + g.selBase;
-  const int n = morbqt::qt_distribute(w, (uint32_t)T, g.maxBorderX - MINB, g.maxBorderY - MINB, g.quota, out, g.selCap);
+  int n = 0;
+  // The key arrays are LDS (the usual case) or the global scratch.  The two cases are two inlined copies of the whole distribution: with ONE
+  // copy and a run-time choice of the pointers every access to the keys was a FLAT instruction (PMC: 828 vector-memory instructions per wave,
+  // nearly all of them LDS traffic taking the slow way), with two the compiler proves the address space of each.
+  auto run = [&](uint32_t* keys, uint32_t* tmp) {
+    // gather the cells' candidate lists into one array, cell-major: a lane per cell copies its list, QT_GATHER loads in flight per lane
+    // (a lane per candidate had to binary-search its cell first: 8 dependent LDS reads in front of every global load, 34 of level 0's 152 us)
+    for (int c0 = 0; c0 < ncell; c0 += 64) {
+      const int c = c0 + lane;
+      const int off = c < ncell ? cellOff[c] : 0;
+      const int nc = c < ncell ? cellOff[c + 1] - off : 0;
+      const int nmax = (int)~morbwave::min_u32(~(uint32_t)nc);   // wave maximum
+      const uint32_t* src = cbase + (size_t)(c < ncell ? c : 0) * cellCap;
+      for (int i0 = 0; i0 < nmax; i0 += QT_GATHER) {
+        uint32_t v[QT_GATHER];
+#pragma unroll
+        for (int k = 0; k < QT_GATHER; ++k) v[k] = i0 + k < nc ? src[i0 + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < QT_GATHER; ++k) if (i0 + k < nc) keys[off + i0 + k] = v[k];
+      }
+    }
+    QT_SYNC();
+    DMARK(9);
+    morbqt::Work w;
+    w.keys = keys; w.tmp = tmp; w.nodes = nodes; w.freeIds = freeIds; w.list = list; w.vA = vA; w.vB = vB;
+    w.order = order; w.bcnt = bcnt; w.brank = brank;
+    w.nodeCap = g.nodeCap; w.listCap = g.listCap;
+    n = morbqt::qt_distribute(w, (uint32_t)T, g.maxBorderX - MINB, g.maxBorderY - MINB, g.quota, out, g.selCap);
+  };
+  if (T <= keyCap) {
+    run(ldsKeys, ldsTmp);
+  } else {
+    uint32_t* gk = qtScratch + g.qtOff + (size_t)img * g.qtImg;
+    run(gk, gk + g.qtImg / 2);
+  }
   if (lane == 0) selCnt[img * nlevels + lvl] = n < g.selCap ? n : g.selCap;
   DMARK(10);
 #ifdef MORB_FAST_TIMING
@@ -1629,6 +1627,7 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   MORB_HIP_CHECK(hipEventRecord(e->evFork, st));
   // the quadtree is enqueued first so that its long-running waves get their slots before the blur fills the chip;
   // the workgroups with level 0 (the longest wave) first: grid x = image, y = group of levels
+  // (which of the two is enqueued first makes no difference: measured both ways)
   hipLaunchKernelGGL(k_distribute, dim3(nimg, e->distGroups), dim3(64 * e->distWaves), e->distSmem, st, e->d_geom, e->d_cand, e->d_candCnt,
                      e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L);
   hipStream_t sideStream = e->overlapBlur ? e->sideStream : st;   // MORB_EXTRACT_SERIAL=1: everything on the launch stream

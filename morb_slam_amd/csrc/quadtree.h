@@ -538,9 +538,8 @@ QT_HD void qt_split(Work& w, State& s, int id, int* nToExpand) {
 // (3) partition the keys and write the children.  v1 did ~190 dependent splits per level-0 image (94 us).
 constexpr uint32_t QT_SMALL = 64;
 __device__ __forceinline__ int qt_class(uint32_t k, int mx, int my) { return (key_x(k) < mx ? 0 : 1) + (key_y(k) < my ? 0 : 2); }
-__device__ __forceinline__ int qt_scan_incl(int v) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d, 64); if (QT_LANE >= d) v += o; }
+__device__ __forceinline__ int qt_scan_incl(int v) {   // inclusive prefix sum over the wave (all lanes active): DPP, no LDS-crossbar round trips
+  MORB_DPP_SCAN(v, 0, morbwave::op_add);
   return v;
 }
 __device__ __forceinline__ void qt_write_children(Work& w, const Node& nd, int mx, int my, uint64_t cnt64, uint32_t rk, int oldHead,
@@ -614,7 +613,7 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
       if (reach) { last = __ffsll((unsigned long long)reach) - 1; mProc = e0 + last + 1; cut = true; }
     }
     if (e < m) w.brank[e] = (uint32_t)(runCh + incCh - nCh) | ((uint32_t)(runEx + incEx - nEx) << 16);
-    runCh += __shfl(incCh, last, 64); runEx += __shfl(incEx, last, 64); runSize += __shfl(incSz, last, 64);
+    runCh += __builtin_amdgcn_readlane(incCh, last); runEx += __builtin_amdgcn_readlane(incEx, last); runSize += __builtin_amdgcn_readlane(incSz, last);   // (last is wave-uniform)
     if (cut) break;
   }
   QT_SYNC();
@@ -856,8 +855,8 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
     while (mb) {
       const int b = __ffsll((unsigned long long)mb) - 1;
       mb &= mb - 1;
-      const uint32_t bk = qt_best_key(w.keys, __shfl(begin, b, 64), __shfl(count, b, 64));
-      const int r = __shfl(rank, b, 64);
+      const uint32_t bk = qt_best_key(w.keys, (uint32_t)__builtin_amdgcn_readlane((int)begin, b), (uint32_t)__builtin_amdgcn_readlane((int)count, b));
+      const int r = __builtin_amdgcn_readlane(rank, b);
       if (QT_LANE0 && r < outCap) out[r] = bk;
     }
     nOut += __popcll(m);
