@@ -805,7 +805,10 @@ __global__ __launch_bounds__(64 * QT_MAX_WAVES) void k_distribute(const LevelGeo
     for (int l = 0; l < nlevels; ++l) if (geom[l].distGroup == grp && geom[l].distWave == wv) lvl = l;
   }
   if (lvl < 0) return;   // (wave-uniform: this workgroup packs fewer levels than the launch has waves)
-  __builtin_amdgcn_s_setprio(3);   // a long dependent chain: win instruction arbitration against the blur waves sharing the SIMD
+#ifndef QT_PRIO
+#define QT_PRIO 3
+#endif
+  __builtin_amdgcn_s_setprio(QT_PRIO);   // a long dependent chain: win instruction arbitration against the blur waves sharing the SIMD (measured 0 / 1 / 3: within 0.6 % of each other)
   const LevelGeom g = geom[lvl];
   const int nodeCap = g.nodeCap, keyCap = g.distKeyCap;
   const int ncell = g.nRows * g.nCols;
