@@ -313,6 +313,58 @@ def config_extras(dev_index):
     return out
 
 
+def launch_ranks(n):
+    """`bench.py --gpus N` run directly (no torchrun): start N rank processes of this same script — fresh interpreters with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, one per GPU — relay rank 0's stdout (the ONE JSON line),
+    let the other ranks' output through to stderr, and return non-zero if any rank fails (the survivors are terminated)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
+    rc, out0 = 0, b""
+    pending = set(range(n))
+    try:
+        while pending:
+            for r in sorted(pending):
+                p = procs[r]
+                if r == 0:
+                    try:
+                        o, _ = p.communicate(timeout=0.2)
+                        out0 += o or b""
+                    except subprocess.TimeoutExpired:
+                        continue
+                else:
+                    try:
+                        p.wait(timeout=0.2)
+                    except subprocess.TimeoutExpired:
+                        continue
+                pending.discard(r)
+                if p.returncode != 0:
+                    rc = rc or (p.returncode if p.returncode > 0 else 1)
+                    print(f"bench.py: rank {r} exited with {p.returncode}", file=sys.stderr)
+            if rc and pending:          # a rank died: the others would wait in the rendezvous / collective for ever
+                time.sleep(2.0)
+                for r in pending:
+                    if procs[r].poll() is None:
+                        procs[r].terminate()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     global W, H, NFEAT
     ap = argparse.ArgumentParser()
@@ -331,13 +383,32 @@ def main():
                          "i + 1's extraction (one buffer set instead of two)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline workload only (used for the committed profiles)")
+    ap.add_argument("--launch-probe", action="store_true",
+                    help="ranks only rendezvous (gloo, CPU), count each other and exit: checks the --gpus N launcher without a GPU")
     args = ap.parse_args()
     W, H, NFEAT, defB = WORKLOADS[args.workload]
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: THIS process becomes the launcher.  It has not touched the GPU
+        # (nothing above imports torch.cuda or the HIP library), starts N fresh rank processes and never exec()s.
+        sys.exit(launch_ranks(args.gpus))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.launch_probe:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([1.0, float(rank)], dtype=torch.float64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_probe": True, "n_gpus": world, "ranks_counted": int(t[0]), "rank_sum": int(t[1]),
+                              "gpus_flag": args.gpus}))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -135,3 +135,48 @@ def test_neighbour_exchange_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(r for r, _ in res) == [0, 1] and all(ok for _, ok in res)
+
+
+def _run_bench(args, env_extra=None, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=timeout)
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    return p.returncode, [json.loads(l) for l in lines], p.stderr.decode()
+
+
+def test_bench_gpus_flag_spawns_ranks():
+    """`python bench.py --gpus 3` (no torchrun, WORLD_SIZE unset — the driver's command shape) must start 3 rank processes that
+    find each other; --launch-probe stops them after the rendezvous, before anything needs a GPU."""
+    rc, lines, err = _run_bench(["--gpus", "3", "--launch-probe"])
+    assert rc == 0, err
+    assert len(lines) == 1                        # ONE JSON line, from rank 0, relayed by the launcher
+    assert lines[0]["n_gpus"] == 3 and lines[0]["ranks_counted"] == 3 and lines[0]["rank_sum"] == 0 + 1 + 2
+
+
+def test_bench_under_external_launcher_does_not_respawn():
+    """Under torchrun (WORLD_SIZE set by the launcher) bench.py is a rank, not a launcher."""
+    port = _free_port()
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-probe"],
+                              env=dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                                       MASTER_PORT=str(port)), stdout=subprocess.PIPE) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    assert '"n_gpus": 2' in outs[0] and "{" not in outs[1]
+
+
+@pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="needs a box WITHOUT a GPU: the ranks must fail")
+def test_bench_launcher_propagates_rank_failure():
+    """Without a GPU every rank dies in torch.cuda.set_device: the launcher must return non-zero and print no JSON line."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-extras", "--no-cpu-baseline"],
+                                env_extra={"MORB_DIST_BACKEND": "gloo"})
+    assert rc != 0 and not lines
+    assert "rank" in err

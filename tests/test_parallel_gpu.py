@@ -42,3 +42,27 @@ def test_two_ranks_match_one_rank(tmp_path):
             seen.add(int(g))
     assert seen == set(range(total))
     assert sum(v[1] for v in by_g.values()) > 100          # the frames really match their predecessors
+
+
+@pytest.mark.parametrize("workload", ["c2", "c4"])
+def test_bench_gpus2_launches_two_ranks(workload):
+    """`python bench.py --gpus 2` (the driver's command shape, WORLD_SIZE unset) spawns two ranks; they share GPU 0 here, so
+    the exchange goes through gloo.  The world > 1 branch of bench.py — ring exchange, cross-frame SearchByBoW on the
+    [own; received] pool, MAX-over-ranks timing — must run and produce matches, for BASELINE configs[1] and configs[3]."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MORB_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", workload, "--batch", "4",
+                        "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0
+    lines = [json.loads(l) for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2
+    assert "feature_exchange" in line["config"]["stages_in_step"]
+    assert line["config"]["mean_bow_matches_per_frame"] > 0
+    assert line["config"]["mean_stereo_matches_per_frame"] > 0
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0
+    want = (752, 1200) if workload == "c2" else (1920, 4000)
+    assert f"{want[0]}x" in line["metric"] and f"{want[1]} feat" in line["metric"]
