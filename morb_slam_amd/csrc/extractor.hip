@@ -784,6 +784,8 @@ __global__ __launch_bounds__(FS_NT) void k_fast(const morb::FastGeom fg, const m
   }
 }
 
+#include "fast_wave.h"
+
 // ---------------------------------------------------------------------------------------------------
 #ifndef QT_GATHER
 #define QT_GATHER 16   // candidate loads in flight per lane while the cells' lists are gathered (4: 457 us, 8: 444, 16: 438 per 512 images under the blur)
@@ -1221,7 +1223,7 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     // k_fast segments: as many whole cells as fit a 128-px window (wCell + 6 <= 128 always: wCell < 70), spread evenly
     MORB_REQUIRE(g.wCell + 6 <= FS_P && g.hCell + 6 < 128, MORB_ERR_UNSUPPORTED, "FAST cell too large for the 128-px segment window");
     {
-      int cps = std::max(1, std::min(FS_NT / 64, (FS_P - 6) / g.wCell));   // (one wave per cell in the output phase)
+      int cps = std::max(1, std::min(e->fastWave ? MORB_FASTW_CPS : FS_NT / 64, (FS_P - 6) / g.wCell));   // (k_fast: one wave per cell in the output phase)
       const int nSeg = div_up(g.nCols, cps);
       cps = div_up(g.nCols, nSeg);
       e->fastGeom.wCellMagic[l] = 0xFFFFu / (unsigned)g.wCell + 1u;
@@ -1407,9 +1409,27 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
   MORB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), e->umax, sizeof(int) * 16));
   MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_distribute),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->distSmem));
-  for (int k = 0; k < 2; ++k)   // window, strengths, 2 bitmaps, queue
-    e->fastSmem[k] = 2ull * e->fastRows[k] * FS_P + 16 + (size_t)e->fastRows[k] * (2 * FS_BW) * 4 + 2ull * FS_QCAP;
-  MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  if (e->fastWave) {
+    // k_fastw: the LDS pitch of a wave's window = the widest segment window, rounded up to whole 16-px blocks
+    int twMax = 0;
+    for (const FastSeg& sd : segs) twMax = std::max(twMax, (sd.geo >> 16) & 0xFF);
+    e->fastP = twMax <= 48 ? 48 : (twMax <= 64 ? 64 : (twMax <= 80 ? 80 : (twMax <= 96 ? 96 : 128)));
+    for (int k = 0; k < 2; ++k) {
+      const int r = e->fastRows[k];
+      const int region = e->fastP == 48 ? fw_region_bytes<48>(r) : e->fastP == 64 ? fw_region_bytes<64>(r) : e->fastP == 80 ? fw_region_bytes<80>(r)
+                       : e->fastP == 96 ? fw_region_bytes<96>(r) : fw_region_bytes<128>(r);
+      e->fastSmem[k] = (size_t)FW_WAVES * region;
+      MORB_REQUIRE(e->fastSmem[k] <= 160 * 1024 - 1024, MORB_ERR_UNSUPPORTED, "FAST cells too tall for the LDS windows");
+    }
+    const void* fn = e->fastP == 48 ? reinterpret_cast<const void*>(k_fastw<48>) : e->fastP == 64 ? reinterpret_cast<const void*>(k_fastw<64>)
+                   : e->fastP == 80 ? reinterpret_cast<const void*>(k_fastw<80>) : e->fastP == 96 ? reinterpret_cast<const void*>(k_fastw<96>)
+                   : reinterpret_cast<const void*>(k_fastw<128>);
+    MORB_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+  } else {
+    for (int k = 0; k < 2; ++k)   // window, strengths, 2 bitmaps, queue
+      e->fastSmem[k] = 2ull * e->fastRows[k] * FS_P + 16 + (size_t)e->fastRows[k] * (2 * FS_BW) * 4 + 2ull * FS_QCAP;
+    MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  }
   e->W = W; e->H = H; e->nimgCap = nimg;
   return MORB_OK;
 }
@@ -1613,7 +1633,21 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
     // Dispatch order: segment-major (x = image), segments from the top level down — the reverse of the order in which the pyramid stage
     // wrote the levels, so the most recently written (still cached) levels are read first.  Measured at 512 images: 997 -> 969 us.
     static const int segMajor = [] { const char* v = getenv("MORB_FAST_ORDER"); return v ? atoi(v) : 2; }();   // (0 / 1: measurement only)
-    for (int k = 0, s0 = 0; k < 2; s0 += e->fastSegs[k], ++k)
+    for (int k = 0, s0 = 0; k < 2 && e->fastWave; s0 += e->fastSegs[k], ++k)
+      if (e->fastSegs[k]) {
+        const dim3 gr(nimg, div_up(e->fastSegs[k], FW_WAVES)), bl(64 * FW_WAVES);
+#define MORB_FW_LAUNCH(PP) hipLaunchKernelGGL(k_fastw<PP>, gr, bl, e->fastSmem[k], st, e->fastGeom, e->d_segTab + s0, e->fastSegs[k], e->d_pyr, e->d_cand, \
+                                              e->d_candCnt, e->totalCells, e->cellCap, e->fastRows[k], e->iniTh, e->minTh)
+        switch (e->fastP) {
+          case 48: MORB_FW_LAUNCH(48); break;
+          case 64: MORB_FW_LAUNCH(64); break;
+          case 80: MORB_FW_LAUNCH(80); break;
+          case 96: MORB_FW_LAUNCH(96); break;
+          default: MORB_FW_LAUNCH(128); break;
+        }
+#undef MORB_FW_LAUNCH
+      }
+    for (int k = 0, s0 = 0; k < 2 && !e->fastWave; s0 += e->fastSegs[k], ++k)
       if (e->fastSegs[k])
         hipLaunchKernelGGL(k_fast, segMajor ? dim3(nimg, e->fastSegs[k]) : dim3(e->fastSegs[k], nimg), dim3(FS_NT), e->fastSmem[k],
                            (k == 1 && two) ? e->sideStream : st, e->fastGeom, e->d_segTab + s0, e->d_pyr, e->d_cand, e->d_candCnt, e->totalCells,

@@ -8,6 +8,12 @@
 
 #include "morb_hip.h"
 
+#ifndef MORB_FASTW
+#define MORB_FASTW 1        // 1: k_fastw (fast_wave.h); 0: round 2's k_fast (kept for A/B timing builds)
+#endif
+#ifndef MORB_FASTW_CPS
+#define MORB_FASTW_CPS 1    // k_fastw: cells per segment (1 - 3)
+#endif
 namespace morb {
 constexpr int kMaxLevels = 16;
 constexpr int EDGE = 19;        // EDGE_THRESHOLD  ORBextractor.cc:73
@@ -81,6 +87,8 @@ struct morb_extractor {
   morb::LevelGeom geom[morb::kMaxLevels];
   int totalCells = 0, cellCap = 0, maxCells = 0, maxNodeCap = 0, maxListCap = 0;
   int fastSegs[2] = {0, 0}, fastRows[2] = {0, 0};   // k_fast launch groups (segments, LDS window rows)
+  bool fastWave = MORB_FASTW != 0;                  // k_fastw (one wave per segment) instead of round 2's workgroup-per-segment k_fast
+  int fastP = 128;                                  // k_fastw: LDS pitch of the segment windows
   int selPerImg = 0, blurTiles = 0, outCap = 0;
   size_t pyrBytes = 0, blurBytes = 0, qtElems = 0, distSmem = 0, fastSmem[2] = {0, 0};
   int distKeyCap = 0;                        // candidate keys of level 0 that fit the quadtree's LDS arrays (smaller levels: scaled by area)

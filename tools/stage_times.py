@@ -1,5 +1,5 @@
 """Per-stage time of the C2 extraction, isolated (one extractor alone on the chip; developer tool, GPU only).
-Usage: python tools/stage_times.py [B]"""
+Usage: python tools/stage_times.py [B] [calls]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,7 +13,7 @@ ex = ORBextractor(1200, 1.2, 8, 20, 7)
 dev = torch.from_numpy(batch).cuda()
 ex.extract_batch(dev); torch.cuda.synchronize()
 ex.set_profiling(True)
-for _ in range(20): ex.extract_batch(dev)
+for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20): ex.extract_batch(dev)
 torch.cuda.synchronize()
 ms = ex.stage_ms()
 print(" ".join(f"{k} {v * 1e3:.1f}us" for k, v in ms.items()), f"(per {2 * B} images)")
