@@ -1223,7 +1223,7 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     // k_fast segments: as many whole cells as fit a 128-px window (wCell + 6 <= 128 always: wCell < 70), spread evenly
     MORB_REQUIRE(g.wCell + 6 <= FS_P && g.hCell + 6 < 128, MORB_ERR_UNSUPPORTED, "FAST cell too large for the 128-px segment window");
     {
-      int cps = std::max(1, std::min(e->fastWave ? MORB_FASTW_CPS : FS_NT / 64, (FS_P - 6) / g.wCell));   // (k_fast: one wave per cell in the output phase)
+      int cps = e->fastWave ? 1 : std::max(1, std::min(FS_NT / 64, (FS_P - 6) / g.wCell));   // (k_fastw: a wave per cell; k_fast: a wave per cell in the output phase)
       const int nSeg = div_up(g.nCols, cps);
       cps = div_up(g.nCols, nSeg);
       e->fastGeom.wCellMagic[l] = 0xFFFFu / (unsigned)g.wCell + 1u;
@@ -1413,18 +1413,15 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     // k_fastw: the LDS pitch of a wave's window = the widest segment window, rounded up to whole 16-px blocks
     int twMax = 0;
     for (const FastSeg& sd : segs) twMax = std::max(twMax, (sd.geo >> 16) & 0xFF);
-    e->fastP = twMax <= 48 ? 48 : (twMax <= 64 ? 64 : (twMax <= 80 ? 80 : (twMax <= 96 ? 96 : 128)));
+    e->fastP = twMax <= 48 ? 48 : (twMax <= 64 ? 64 : 80);   // (wCell < 70: a cell's window is at most 75 px wide)
     for (int k = 0; k < 2; ++k) {
       const int r = e->fastRows[k];
-      const int region = e->fastP == 48 ? fw_region_bytes<48>(r) : e->fastP == 64 ? fw_region_bytes<64>(r) : e->fastP == 80 ? fw_region_bytes<80>(r)
-                       : e->fastP == 96 ? fw_region_bytes<96>(r) : fw_region_bytes<128>(r);
+      const int region = e->fastP == 48 ? fw_region_bytes<48>(r) : e->fastP == 64 ? fw_region_bytes<64>(r) : fw_region_bytes<80>(r);
       e->fastSmem[k] = (size_t)FW_WAVES * region;
-      MORB_REQUIRE(e->fastSmem[k] <= 160 * 1024 - 1024, MORB_ERR_UNSUPPORTED, "FAST cells too tall for the LDS windows");
     }
     const void* fn = e->fastP == 48 ? reinterpret_cast<const void*>(k_fastw<48>) : e->fastP == 64 ? reinterpret_cast<const void*>(k_fastw<64>)
-                   : e->fastP == 80 ? reinterpret_cast<const void*>(k_fastw<80>) : e->fastP == 96 ? reinterpret_cast<const void*>(k_fastw<96>)
-                   : reinterpret_cast<const void*>(k_fastw<128>);
-    MORB_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+                   : reinterpret_cast<const void*>(k_fastw<80>);
+    MORB_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   } else {
     for (int k = 0; k < 2; ++k)   // window, strengths, 2 bitmaps, queue
       e->fastSmem[k] = 2ull * e->fastRows[k] * FS_P + 16 + (size_t)e->fastRows[k] * (2 * FS_BW) * 4 + 2ull * FS_QCAP;
@@ -1641,9 +1638,7 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
         switch (e->fastP) {
           case 48: MORB_FW_LAUNCH(48); break;
           case 64: MORB_FW_LAUNCH(64); break;
-          case 80: MORB_FW_LAUNCH(80); break;
-          case 96: MORB_FW_LAUNCH(96); break;
-          default: MORB_FW_LAUNCH(128); break;
+          default: MORB_FW_LAUNCH(80); break;
         }
 #undef MORB_FW_LAUNCH
       }

@@ -11,9 +11,6 @@
 #ifndef MORB_FASTW
 #define MORB_FASTW 1        // 1: k_fastw (fast_wave.h); 0: round 2's k_fast (kept for A/B timing builds)
 #endif
-#ifndef MORB_FASTW_CPS
-#define MORB_FASTW_CPS 1    // k_fastw: cells per segment (1 - 3)
-#endif
 namespace morb {
 constexpr int kMaxLevels = 16;
 constexpr int EDGE = 19;        // EDGE_THRESHOLD  ORBextractor.cc:73

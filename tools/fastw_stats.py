@@ -25,6 +25,6 @@ ex.extract_batch(dev); torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 16)()
 lib.morb_fw_stats(buf, 0)
 names = ["waves", "jobs", "reject rounds", "emit loop trips", "survivors", "strength rounds", "corners", "nms rounds", "keypoints",
-         "output rank trips", "both-polarity rounds", "fallback jobs", "half-round splits", "dense nms"]
+         "output rank trips", "-", "minThFAST passes", "partial queue takes", "strip-mode passes"]
 w = max(buf[0], 1)
 for n, v in zip(names, buf): print(f"{n:22s} {v:12d}   {v / w:8.3f} per wave")
