@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64 * FW_WAVES, 8) void k_fastw(const morb::FastGeom
   const int seg = blockIdx.y * FW_WAVES + wv, img = blockIdx.x;
   if (seg >= nSeg) return;
   uint8_t* tile = smem + wv * fw_region_bytes<P>(rows);                     // [rows][P] pixels, later the corners' strengths (+16 bytes: the last block's right neighbour)
-  uint16_t* queue = reinterpret_cast<uint16_t*>(tile + rows * P + 16);      // bright << 14 | y << 7 | x
+  uint16_t* queue = reinterpret_cast<uint16_t*>(tile + rows * P + 16);      // y << 8 | 16-px block << 5 | flag index
   uint16_t* cornerPos = queue + FW_QCAP;                                    // y << 7 | x
   uint8_t* cornerS = reinterpret_cast<uint8_t*>(cornerPos + FW_CQ);         // S (<= 255)
   uint32_t* kept = reinterpret_cast<uint32_t*>(cornerS + FW_CQ);            // S << 16 | y << 7 | x
@@ -240,13 +240,12 @@ __global__ __launch_bounds__(64 * FW_WAVES, 8) void k_fastw(const morb::FastGeom
             { const unsigned mx = ~morbwave::min_u32(~(unsigned)cnt); FW_STAT(3, mx); FW_STAT(4, total); }
 #endif
             int slot = qn + incl - cnt;
-            const unsigned pos0 = (unsigned)((y << 7) | xb0);
+            const unsigned rec0 = (unsigned)((y << 8) | (bi << 5));   // the flag index is decoded by the strength round: once per 64 entries, not per entry
             unsigned t = take;
             while (t) {
               const unsigned f = (unsigned)__ffs(t) - 1u;
               t &= t - 1u;
-              const unsigned o = ((f >> 1) & 1u) | ((f >> 3) & 2u) | (f & 12u);
-              queue[slot++] = (uint16_t)(((f & 1u) << 14) | (pos0 + o));
+              queue[slot++] = (uint16_t)(rec0 | f);
             }
             qn += total;
             FW_SYNC();
@@ -259,12 +258,13 @@ __global__ __launch_bounds__(64 * FW_WAVES, 8) void k_fastw(const morb::FastGeom
             const int nq = imin(qn, 64), q0 = qn - nq;
             qn = q0;
             const bool act = lane < nq;
-            const unsigned e = act ? queue[q0 + lane] : (unsigned)((3 << 7) | 3);
-            const int x = (int)(e & 127u), yy = (int)((e >> 7) & 127u);
+            const unsigned e = act ? queue[q0 + lane] : (unsigned)((3 << 8) | 18);   // (inactive lanes: pixel (3, 3))
+            // entry = y << 8 | block << 5 | f; f[0] = polarity, pixel offset in the block = f[3] f[2] f[4] f[1]
+            const int x = (int)(((e >> 1) & 0x70u) | ((e >> 1) & 1u) | ((e >> 3) & 2u) | (e & 12u)), yy = (int)(e >> 8);
             int rr[16];
             const int v = ring(__mul24(yy, P) + x, rr);
             // d = v - p for the dark polarity (= ~p + v + 1), p - v for the bright one: (p ^ m) + c, one v_xad_u32 per ring pixel
-            const bool bright = (e & 0x4000u) != 0u;
+            const bool bright = (e & 1u) != 0u;
             const int xm = bright ? 0 : -1, xc = bright ? -v : v + 1;
             int d[16];
 #pragma unroll
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * FW_WAVES, 8) void k_fastw(const morb::FastGeom
             const uint64_t cm = __ballot(isCorner);
             if (cm) {   // wave-uniform
               const int idx = cn + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
-              if (isCorner && idx < FW_CQ) { cornerPos[idx] = (uint16_t)(e & 0x3FFFu); cornerS[idx] = (uint8_t)imin(S, 255); }
+              if (isCorner && idx < FW_CQ) { cornerPos[idx] = (uint16_t)((yy << 7) | x); cornerS[idx] = (uint8_t)imin(S, 255); }
               cn += __popcll(cm);
             }
           }

@@ -86,6 +86,20 @@ def test_noise_image_many_candidates():
     _compare(img, 1200)
 
 
+def test_dense_corners_strip_mode():
+    # k_fastw keeps a cell's corners in a 512-entry list and its keypoints in a 64-entry list; white noise at thresholds this low
+    # makes about half of the pixels corners and every ~9th a keypoint, so every cell takes the row-by-row strip mode (whole pass
+    # redone with a rolling strength buffer), through both triggers: corner-list overflow (T = 1) and keypoint-list overflow (T = 6)
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, (240, 320), dtype=np.uint8)
+    _compare(img, 2000, nlevels=3, iniThFAST=1, minThFAST=1)
+    _compare(img, 2000, nlevels=3, iniThFAST=6, minThFAST=2)
+    # and a window whose every reject round overflows the survivor queue (both polarities flagged): alternating extremes
+    chk = ((np.indices((240, 320)).sum(0) & 1) * 255).astype(np.uint8)
+    chk[::7, ::5] = 128
+    _compare(chk, 1000, nlevels=2, iniThFAST=20, minThFAST=7)
+
+
 def test_other_sizes_and_params():
     _compare(make_image(640, 480, seed=21), 500, scaleFactor=1.2, nlevels=8)
     _compare(make_image(333, 217, seed=22), 300, nlevels=4)

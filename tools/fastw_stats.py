@@ -15,7 +15,10 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 W, H, NF = int(os.environ.get('MORB_W', 752)), int(os.environ.get('MORB_H', 480)), int(os.environ.get('MORB_NF', 1200))
 ims = [synth.make_stereo_pair(W, H, seed=i) for i in range(4)]
 batch = np.stack([ims[i % 4][k] for i in range(B) for k in (0, 1)])
-ex = ORBextractor(NF, 1.2, 8, 20, 7)
+TH = (int(os.environ.get('MORB_INI', 20)), int(os.environ.get('MORB_MIN', 7)))
+if os.environ.get('MORB_NOISE'):      # white noise instead of the benchmark images (with MORB_INI=1 MORB_MIN=1: every cell in strip mode)
+    batch = np.random.default_rng(12).integers(0, 256, batch.shape, dtype=np.uint8)
+ex = ORBextractor(NF, 1.2, 8, TH[0], TH[1])
 dev = torch.from_numpy(batch).cuda()
 lib = capi.lib()
 lib.morb_fw_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
