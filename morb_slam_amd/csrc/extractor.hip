@@ -318,40 +318,10 @@ __global__ __launch_bounds__(256) void k_blur(const LevelGeom* __restrict__ geom
 
 // ---------------------------------------------------------------------------------------------------
 // K2: per-cell FAST-9/16 + cornerScore + 3x3 NMS with the iniThFAST -> minThFAST fallback
-// (ORBextractor.cc:763-820 calling cv::FAST once or twice per 35-px cell).
-//
-// One 256-thread workgroup per SEGMENT = up to three horizontally adjacent cells of one cell row.  The cells' evaluated
-// areas tile the segment without overlap (cell j evaluates x in [iniX_j + 3, iniX_j + wCell + 3)), so the strength of every
-// pixel is computed once; what makes cv::FAST's result per-cell is only (a) the threshold a cell ends up with and (b) that
-// its non-maximum suppression sees nothing outside its own evaluated area — both are applied per cell below.  Versus one
-// workgroup per cell (round 1) this shares the 6-px horizontal apron, loads the window with 16-byte accesses and amortises
-// the per-workgroup set-up, the barriers and the partly filled rounds over three cells.
-//
-// Phases (PMC, profiles/r01: the kernel is bound by VALU issue, so the design rule is instructions per pixel):
-//   load     window (<= 128 px wide, hCell + 6 rows) -> LDS with unaligned 16-byte global loads; pitch 128, so a pixel's LDS
-//            offset is y << 7 | x and fits 14 bits of a 16-bit queue entry.
-//   reject   4 px per lane, packed-u16 SWAR: every 9-arc of the ring contains >= 2 of the compass pixels (0, 4, 8, 12), so a
-//            pixel can exceed strength T only if the second smallest compass value < v - T (dark) or the second largest
-//            > v + T (bright).  Survivors are queued densely (ballot compaction) with their possible polarities.
-//   strength exact max-min over the 16 arcs (v_min3 / v_max3 trees) for the queued pixels only and only for the polarity
-//            the compass test left possible: a 9-arc darker than v and a 9-arc brighter than v cannot both exist on a
-//            16-pixel ring, so cornerScore = that polarity's value (both are evaluated for the ~0.02 % with both flags).
-//   nms      bits of the corner bitmap; a neighbour outside the pixel's own cell counts as score 0.
-//   count / prefix / output per (row, cell): ordered row-major inside each cell, which is cv::FAST's order.
-// A cell without a keypoint after the iniThFAST pass is evaluated again with minThFAST (:795), alone.
+// (ORBextractor.cc:763-820 calling cv::FAST once or twice per 35-px cell): k_fastw, fast_wave.h.
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
-#ifdef MORB_FAST_TIMING
-#define PHASE_MARK(k) do { __syncthreads(); if (threadIdx.x == 0 && ((blockIdx.x * 7 + blockIdx.y) & 63) == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_fastPhase[k], now_ - t0_); t0_ = now_; } } while (0)
-extern "C" int morb_fast_timing(unsigned long long* out, int reset) {
-  if (reset) { unsigned long long z[32] = {0}; MORB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fastPhase), z, sizeof(z))); return 0; }
-  MORB_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fastPhase), 32 * sizeof(unsigned long long)));
-  return 0;
-}
-#else
-#define PHASE_MARK(k)
-#endif
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {   // v_pk_min_u16
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
@@ -365,16 +335,6 @@ __device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {   // v_
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {   // v_pk_add_u16
   return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));
 }
-
-#ifndef MORB_FS_NT
-#define MORB_FS_NT 256
-#endif
-constexpr int FS_NT = MORB_FS_NT;          // threads per segment
-constexpr int FS_P = 128;           // LDS pitch of the window (bytes)
-constexpr int FS_BW = FS_P / 32;    // bitmap words per window row
-constexpr int FS_CQ = 512;          // corner list of a job (typically ~60 corners per segment)
-constexpr int FS_QCAP = 2048;       // survivor queue (typically ~400 per segment); a multiple of FS_P
-constexpr int FS_KCAP = 64;         // keypoint list of a cell (typically ~6)
 
 // i / d == (i * ceil(2^20 / d)) >> 20 for i < 2^15, d < 40 (both factors fit v_mul_u32_u24)
 struct Magic20 { unsigned m[40]; constexpr Magic20() : m() { for (int d = 1; d < 40; ++d) m[d] = 0xFFFFFu / (unsigned)d + 1u; } };
@@ -390,400 +350,14 @@ __device__ __forceinline__ int arc9_maxmin(const int (&d)[16]) {
   for (int k = 0; k < 16; ++k) A = imax(A, imin(imin(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]));
   return A;
 }
-// bits [lo, hi) of a 32-bit word (empty if hi <= lo; lo, hi may lie outside [0, 32])
-__device__ __forceinline__ uint32_t range_mask(int lo, int hi) {
-  lo = imax(lo, 0); hi = imin(hi, 32);
-  if (hi <= lo) return 0u;
-  return (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
-}
-
-__global__ __launch_bounds__(FS_NT) void k_fast(const morb::FastGeom fg, const morb::FastSeg* __restrict__ segTab,
-                                                 const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
-                                                 int* __restrict__ candCnt, int totalCells, int cellCap, int rows,
-                                                 int iniTh, int minTh, int stopPhase, int segMajor) {
-  extern __shared__ __align__(16) uint8_t smem[];
-  uint8_t* tile = smem;                                                   // [rows][FS_P] pixels (+16 bytes: the last block's right neighbour)
-  uint8_t* sc = smem + rows * FS_P + 16;                                  // [rows][FS_P] strength S of corners (S > the cell's threshold), else 0
-  uint32_t* cornerBm = reinterpret_cast<uint32_t*>(sc + rows * FS_P);     // [rows][FS_BW] pixels with a strength
-  uint32_t* keepBm = cornerBm + rows * FS_BW;                             // [rows][FS_BW] keypoints (after NMS)
-  uint16_t* queue = reinterpret_cast<uint16_t*>(keepBm + rows * FS_BW);   // [FS_QCAP] bright << 15 | dark << 14 | y << 7 | x
-  __shared__ int qn;
-  __shared__ int cellTot[4];
-  // fast paths for the usual case of few corners: a compact corner list per job and the keypoints of every cell as short lists;
-  // when either overflows (slow != 0) the bitmaps, which are always kept, drive the NMS / the output instead
-  __shared__ int cn, slow, dup, qover, keptN[4];
-  __shared__ uint16_t cornerQ[FS_CQ];
-  __shared__ uint16_t kept[4][FS_KCAP];
 
 #ifdef MORB_FAST_TIMING
-  unsigned long long t0_ = wall_clock64();
-#endif
-  const int img = segMajor ? blockIdx.x : blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-  // the segment's geometry: one scalar load of its host-built descriptor, the level's constants from the kernarg segment
-  const morb::FastSeg sd = segTab[segMajor ? blockIdx.y : blockIdx.x];
-  const int l = sd.geo & 0xFF, nc = (sd.geo >> 8) & 0xFF, tw = (sd.geo >> 16) & 0xFF, th = (int)((unsigned)sd.geo >> 24);
-  const int wCell = fg.wCell[l], pstride = fg.pstride[l];
-  const unsigned wMagic = fg.wCellMagic[l];
-  const size_t cellSlot0 = (size_t)img * totalCells + sd.cell0;
-  if (tw <= 6 || th <= 6) {   // :770, :775: skipped cells, or windows cv::FAST finds nothing in
-    if (tid < nc) candCnt[cellSlot0 + tid] = 0;
-    return;
-  }
-  {
-    // Window -> LDS, 16 bytes per access (global: unaligned; LDS: aligned).  Columns >= tw are never evaluated; they lie in
-    // the padded pyramid row or the next one (the slab has 256 bytes of slack behind it).
-    const uint8_t* base = pyr + fg.pyrOff[l] + (size_t)img * fg.pyrImg[l] + sd.winOff;
-    const int n16 = rows * (FS_P / 16);
-    for (int i0 = 0; i0 < n16; i0 += 2 * FS_NT) {
-      uint4 v[2]; int off[2];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int i = i0 + tid + k * FS_NT;
-        const int rr = i >> 3, c16 = (i & 7) << 4;
-        off[k] = i < n16 ? rr * FS_P + c16 : -1;
-        v[k] = make_uint4(0, 0, 0, 0);
-        if (i < n16 && rr < th && stopPhase != 10) __builtin_memcpy(&v[k], base + (unsigned)(__umul24(rr, pstride) + c16), 16);
-      }
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-        if (off[k] >= 0) {
-          *reinterpret_cast<uint4*>(tile + off[k]) = v[k];
-          *reinterpret_cast<uint4*>(sc + off[k]) = make_uint4(0, 0, 0, 0);
-        }
-    }
-    for (int i = tid; i < rows * (2 * FS_BW); i += FS_NT) cornerBm[i] = 0;   // cornerBm and keepBm are contiguous
-    if (tid < 4) { *reinterpret_cast<uint32_t*>(tile + rows * FS_P + 4 * tid) = 0; cellTot[tid] = 0; keptN[tid] = 0; }
-    if (tid == 0) { qn = 0; cn = 0; slow = 0; dup = 0; qover = 0; }
-  }
-  __syncthreads();
-  PHASE_MARK(0);
-  if (stopPhase >= 0 && tid < nc) candCnt[cellSlot0 + tid] = 0;   // developer hook (tools/fast_cost.py prices the phases with early exits); -1 in the product
-  if (stopPhase == 0) return;
-
-  // keypoints of row y inside cell j (the cell's evaluated columns)
-  auto row_cell_count = [&](int y, int j) -> int {
-    const int a = 3 + j * wCell, b = imin(a + wCell, tw - 3);
-    int cnt = 0;
-#pragma unroll
-    for (int w = 0; w < FS_BW; ++w) cnt += __popc(keepBm[y * FS_BW + w] & range_mask(a - 32 * w, b - 32 * w));
-    return cnt;
-  };
-  // per-cell totals -> cellTot: wave j counts cell j, one row per lane
-  auto count_cells = [&]() {
-    const int j = tid >> 6;
-    if (j < nc) {
-      int tot = 0;
-      for (int y0 = 0; y0 < th; y0 += 64) tot += y0 + lane < th ? row_cell_count(y0 + lane, j) : 0;
-      tot = morbwave::sum_i32(tot);
-      if (lane == 0) cellTot[j] = tot;
-    }
-    __syncthreads();
-  };
-
-  for (int job = 0; job <= nc; ++job) {
-    // job 0: cv::FAST(iniThFAST) on every cell of the segment; job j >= 1: cell j - 1 again with minThFAST if it is empty (:795)
-    int xa = 3, xb = tw - 3, T = iniTh;
-    if (job > 0) {
-      const int j = job - 1;
-      if (cellTot[j] != 0) continue;   // uniform: written before the last barrier
-      xa = 3 + j * wCell; xb = imin(xa + wCell, tw - 3); T = minTh;
-      if (xb <= xa) continue;
-      // the second cv::FAST call starts from nothing: forget the first pass's strengths in this cell (they exist when its
-      // corners tied each other out in the NMS, and matter when minThFAST > iniThFAST)
-      for (int wi = tid; wi < th * FS_BW; wi += FS_NT) {
-        const uint32_t mask = range_mask(xa - ((wi & 3) << 5), xb - ((wi & 3) << 5));
-        uint32_t bits = cornerBm[wi] & mask;
-        if (bits) {
-          cornerBm[wi] &= ~mask;
-          while (bits) { const int b = __ffs(bits) - 1; bits &= bits - 1; sc[((wi >> 2) << 7) | (((wi & 3) << 5) + b)] = 0; }
-        }
-      }
-      __syncthreads();
-    }
-    // All evaluated rows at once; if the survivor queue (FS_QCAP entries) cannot hold them — far more survivors than any natural
-    // image produces — the job starts over in chunks of FS_QCAP / 128 rows, which always fit.
-    int chunkRows = th - 6;
-    for (int ya = 3; ya < th - 3; ya += chunkRows) {
-    const int yb = imin(ya + chunkRows, th - 3);
-    {
-      // reject: one lane = 16 consecutive pixels of a window row (four dwords C0..C3 plus the dword on either side), read with
-      // three 16-byte and two 4-byte LDS loads.  Bytes are split into even / odd 16-bit lanes once per dword; the left / right
-      // compass pixels (x - 3, x + 3) of a dword's even pixels are the odd lanes of its neighbours and vice versa, so they cost one
-      // v_alignbit each.  The second smallest / largest of the four compass values come from a packed-u16 min / max network, and
-      // the margin tests (v - s2 > T, l2 - v > T) are packed adds whose carries land on a different bit per (dword, parity,
-      // polarity): 32 flag bits per lane.  Compaction: per-lane popcount, one DPP scan per wave, one LDS atomic per wave, then
-      // every lane emits its own entries.  Blocks that straddle xa / xb also flag pixels outside [xa, xb): those are dropped
-      // when their strength would be stored.
-      // items per row = the 16-px blocks that hold evaluated pixels [xa, xb) — 7 of the window's 8 for a typical three-cell segment, 3
-      // for the single-cell second pass — so that a row's dead blocks do not take lane slots of a round
-      const int ix0 = xa >> 4, nIt = ((xb + 15) >> 4) - ix0;
-      const unsigned itMagic = c_magic20.m[nIt];
-      const int nItems = (yb - ya) * nIt;
-      const unsigned LO = 0x00FF00FFu;
-      unsigned KF[8], MF[8];   // per (dword & 1, parity, polarity): the add constant and the flag bit (8 + index) in both halves
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { KF[j] = ((1u << (8 + j)) - 1u - (unsigned)T) * 0x00010001u; MF[j] = (1u << (8 + j)) * 0x00010001u; }
-      // compaction of a wave's flag words: per-lane popcount, one DPP scan per wave, one LDS atomic per wave, every lane emits its own entries
-      auto emit = [&](unsigned W, int y, int xb0) {
-        unsigned anyW = (W | (W >> 1)) & 0x55555555u;
-        const int cnt = __popc(anyW);
-        int incl = cnt;
-        MORB_DPP_SCAN(incl, 0, morbwave::op_add);   // inclusive prefix over the wave (all lanes active)
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        if (!total) return;   // wave-uniform
-        int qbase = 0;
-        if (lane == 63) qbase = atomicAdd(&qn, total);
-        qbase = __builtin_amdgcn_readlane(qbase, 63);
-        if (qbase + total > FS_QCAP) { if (lane == 0) qover = 1; return; }   // wave-uniform
-        int slot = qbase + incl - cnt;
-        const unsigned pos0 = (unsigned)((y << 7) | xb0);
-        while (anyW) {
-          const unsigned f = (unsigned)__ffs(anyW) - 1u;
-          anyW &= anyW - 1u;
-          const unsigned o = ((f >> 1) & 1u) | ((f >> 3) & 2u) | (f & 12u);
-          queue[slot++] = (uint16_t)((((W >> f) & 3u) << 14) | (pos0 + o));
-        }
-      };
-      // A typical three-cell segment is 259 - 266 items: one full round of the 256 lanes and 3 - 10 items more, for which wave 0 used to run
-      // a whole second round (a fifth of the phase's wave-rounds for 2 % of its pixels).  The remainder is now spread over four lanes per
-      // item — a lane takes ONE of the block's four dwords — so the tail round costs a third of a full one.
-      const int rem = nItems % FS_NT;
-      const bool lightTail = nItems > FS_NT && rem != 0 && rem * 4 <= FS_NT;
-      const int nMain = lightTail ? nItems - rem : nItems;
-      for (int i0 = 0; i0 < nMain; i0 += FS_NT) {
-        if (i0 + __builtin_amdgcn_readfirstlane(tid & ~63) >= nMain) break;   // wave-uniform: no item left for this wave
-        const int i = i0 + tid;
-        const int iy = (int)(((unsigned)i * itMagic) >> 20);
-        const int y = iy + ya, xb0 = (i - __mul24(iy, nIt) + ix0) << 4;
-        unsigned W = 0;   // bit f: f[0] polarity (0 dark, 1 bright), pixel offset in the block = f[3] f[2] f[4] f[1]
-        if (i < nMain && xb0 < xb && xb0 + 16 > xa) {
-          const uint8_t* rowp = tile + ((y << 7) | xb0);
-          const uint4 C = *reinterpret_cast<const uint4*>(rowp);
-          const uint4 U = *reinterpret_cast<const uint4*>(rowp - 3 * FS_P);   // ring pixel 8 (0,-3)
-          const uint4 D = *reinterpret_cast<const uint4*>(rowp + 3 * FS_P);   // ring pixel 0 (0,+3)
-          const uint32_t Lw = *reinterpret_cast<const uint32_t*>(rowp - 4), Rw = *reinterpret_cast<const uint32_t*>(rowp + 16);
-          const uint32_t Cw[6] = {Lw, C.x, C.y, C.z, C.w, Rw}, Uw[4] = {U.x, U.y, U.z, U.w}, Dw[4] = {D.x, D.y, D.z, D.w};
-          unsigned E[6], O[6];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) { E[k] = Cw[k] & LO; O[k] = (Cw[k] >> 8) & LO; }
-          unsigned acc[2] = {0u, 0u};
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-#pragma unroll
-            for (int par = 0; par < 2; ++par) {
-              const unsigned Ve = par ? O[k + 1] : E[k + 1];
-              const unsigned a = (par ? (Uw[k] >> 8) : Uw[k]) & LO, b = (par ? (Dw[k] >> 8) : Dw[k]) & LO;
-              // ring pixels 12 (-3,0) and 4 (+3,0)
-              const unsigned cc = par ? __builtin_amdgcn_alignbit(E[k + 1], E[k], 16) : O[k];
-              const unsigned d = par ? E[k + 2] : __builtin_amdgcn_alignbit(O[k + 2], O[k + 1], 16);
-              const unsigned lo1 = pk_min(a, b), hi1 = pk_max(a, b), lo2 = pk_min(cc, d), hi2 = pk_max(cc, d);
-              const unsigned mlo = pk_max(lo1, lo2), mhi = pk_min(hi1, hi2);
-              const unsigned s2 = pk_min(mlo, mhi);      // second smallest of the four
-              const unsigned l2 = pk_max(mlo, mhi);      // second largest
-              const int j = (k & 1) * 4 + par * 2;
-              acc[k >> 1] |= pk_add(pk_sub_sat(Ve, s2), KF[j]) & MF[j];           // v - s2 > T
-              acc[k >> 1] |= pk_add(pk_sub_sat(l2, Ve), KF[j + 1]) & MF[j + 1];   // l2 - v > T
-            }
-          }
-          W = ((acc[0] >> 8) & 0x00FF00FFu) | (acc[1] & 0xFF00FF00u);
-        }
-        emit(W, y, xb0);
-      }
-      if (lightTail && __builtin_amdgcn_readfirstlane(tid & ~63) < rem * 4) {   // wave-uniform
-        const int i = nMain + (tid >> 2), k = tid & 3;
-        const int iy = (int)(((unsigned)i * itMagic) >> 20);
-        const int y = iy + ya, xb0 = (i - __mul24(iy, nIt) + ix0) << 4;
-        unsigned W = 0;
-        if (i < nItems && xb0 < xb && xb0 + 16 > xa) {
-          const uint8_t* rowp = tile + ((y << 7) | xb0) + 4 * k;   // the lane's dword of the block
-          const uint32_t cwL = *reinterpret_cast<const uint32_t*>(rowp - 4), cw = *reinterpret_cast<const uint32_t*>(rowp),
-                         cwR = *reinterpret_cast<const uint32_t*>(rowp + 4);
-          const uint32_t uw = *reinterpret_cast<const uint32_t*>(rowp - 3 * FS_P), dw = *reinterpret_cast<const uint32_t*>(rowp + 3 * FS_P);
-          const unsigned E0 = cwL & LO, E1 = cw & LO, E2 = cwR & LO, O0 = (cwL >> 8) & LO, O1 = (cw >> 8) & LO, O2 = (cwR >> 8) & LO;
-          const unsigned jb = (unsigned)(k & 1) * 4u;   // flag bits 8 + jb .. 8 + jb + 3: (parity, polarity) of this dword
-          unsigned acc = 0u;
-#pragma unroll
-          for (int par = 0; par < 2; ++par) {
-            const unsigned Ve = par ? O1 : E1;
-            const unsigned a = (par ? (uw >> 8) : uw) & LO, b = (par ? (dw >> 8) : dw) & LO;
-            const unsigned cc = par ? __builtin_amdgcn_alignbit(E1, E0, 16) : O0;
-            const unsigned d = par ? E2 : __builtin_amdgcn_alignbit(O2, O1, 16);
-            const unsigned lo1 = pk_min(a, b), hi1 = pk_max(a, b), lo2 = pk_min(cc, d), hi2 = pk_max(cc, d);
-            const unsigned mlo = pk_max(lo1, lo2), mhi = pk_min(hi1, hi2);
-            const unsigned s2 = pk_min(mlo, mhi), l2 = pk_max(mlo, mhi);
-            const unsigned m0 = (0x0100u << (jb + par * 2)) * 0x00010001u, m1 = m0 << 1;   // MF[j], MF[j + 1]
-            const unsigned k0 = m0 - (1u + (unsigned)T) * 0x00010001u, k1 = m1 - (1u + (unsigned)T) * 0x00010001u;   // KF[j], KF[j + 1]
-            acc |= pk_add(pk_sub_sat(Ve, s2), k0) & m0;
-            acc |= pk_add(pk_sub_sat(l2, Ve), k1) & m1;
-          }
-          W = (k >> 1) ? (acc & 0xFF00FF00u) : ((acc >> 8) & 0x00FF00FFu);
-        }
-        emit(W, y, xb0);
-      }
-    }
-    __syncthreads();
-    PHASE_MARK(1);
-    if (stopPhase == 1) return;
-    if (qover) {   // uniform (written before the barrier): start the job over, row chunk by row chunk
-      __syncthreads();
-      if (tid == 0) { qover = 0; qn = 0; dup = 1; }   // (strengths found so far are found again: the corner list would hold them twice)
-      __syncthreads();
-      chunkRows = FS_QCAP / FS_P;
-      ya = 3 - chunkRows;
-      continue;
-    }
-    {
-      // strength of the queued pixels, densely packed over the workgroup
-      const int n = qn;
-      for (int q = tid; q < n; q += FS_NT) {
-        const unsigned e = queue[q];
-        const int off = (int)(e & 0x3FFFu), x = off & (FS_P - 1);
-        // every ring offset relative to the ring's top-left corner is non-negative: one address, immediates only
-        constexpr int O = 3 * FS_P + 3;
-        int cornerOff = imax(off - O, 0);   // (negative only for a flagged pixel left of the evaluated area, whose result is dropped)
-        asm volatile("" : "+v"(cornerOff));   // (opaque: otherwise the address is re-based on the centre and 7 offsets need their own add)
-        const uint8_t* p = tile + cornerOff;
-        const int v = p[O];
-        int rr[16];
-        rr[0] = p[O + 3 * FS_P];   rr[1] = p[O + 3 * FS_P + 1];  rr[2] = p[O + 2 * FS_P + 2];  rr[3] = p[O + FS_P + 3];
-        rr[4] = p[O + 3];          rr[5] = p[O - FS_P + 3];      rr[6] = p[O - 2 * FS_P + 2];  rr[7] = p[O - 3 * FS_P + 1];
-        rr[8] = p[O - 3 * FS_P];   rr[9] = p[O - 3 * FS_P - 1];  rr[10] = p[O - 2 * FS_P - 2]; rr[11] = p[O - FS_P - 3];
-        rr[12] = p[O - 3];         rr[13] = p[O + FS_P - 3];     rr[14] = p[O + 2 * FS_P - 2]; rr[15] = p[O + 3 * FS_P - 1];
-        // d = v - p for the dark polarity (= ~p + v + 1), p - v for the bright one: (p ^ m) + c, one v_xad_u32 per ring pixel
-        const int xm = (e & 0x4000u) ? -1 : 0, xc = (e & 0x4000u) ? v + 1 : -v;
-        int d[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) d[k] = (rr[k] ^ xm) + xc;
-        int S = arc9_maxmin(d);
-        const bool both = (e >> 14) == 3u;
-        if (__ballot(both)) {   // rare: the compass test left both polarities possible
-#pragma unroll
-          for (int k = 0; k < 16; ++k) d[k] = rr[k] - v;
-          const int S2 = arc9_maxmin(d);
-          if (both) S = imax(S, S2);
-        }
-        const bool isCorner = S > T && x >= xa && x < xb;
-        if (isCorner) {
-          sc[off] = (uint8_t)imin(S, 255);
-          atomicOr(&cornerBm[off >> 5], 1u << (x & 31));
-        }
-        const uint64_t cm = __ballot(isCorner);
-        if (cm) {   // wave-uniform; lane 0 holds the wave's smallest q, so it is active whenever the wave is
-          int cbase = 0;
-          if (lane == 0) cbase = atomicAdd(&cn, __popcll(cm));
-          cbase = __builtin_amdgcn_readfirstlane(cbase);
-          const int idx = cbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
-          if (isCorner && idx < FS_CQ) cornerQ[idx] = (uint16_t)off;
-        }
-      }
-    }
-    __syncthreads();
-    if (tid == 0) qn = 0;
-    if (chunkRows != th - 6) __syncthreads();   // (uniform) the next chunk's reservations start from 0
-    }   // row chunks
-    const int ncn = cn;
-    const bool useList = ncn <= FS_CQ && !dup;   // (both written before the last barrier)
-    PHASE_MARK(2);
-    if (stopPhase == 2) return;
-    // NMS.  The strength map holds S for corners (S > T) and 0 elsewhere: corner score S - 1, everything else 0; keep iff
-    // strictly greater than all 8 neighbours' scores, where a neighbour outside the pixel's own cell (or outside the
-    // evaluated rows, where the map stays 0) counts as 0.
-    auto nms_keep = [&](int x, int y, int* cellOut) -> bool {
-      const uint8_t* c = sc + ((y << 7) | x);
-      const int S = c[0];
-      const int cj = (int)(((unsigned)(x - 3) * wMagic) >> 16), cxa = 3 + cj * wCell;
-      *cellOut = cj;
-      int m = imax(c[-FS_P], c[FS_P]);
-      if (x != cxa) m = imax(m, imax(imax(c[-FS_P - 1], c[-1]), c[FS_P - 1]));
-      if (x != cxa + wCell - 1) m = imax(m, imax(imax(c[-FS_P + 1], c[1]), c[FS_P + 1]));
-      return S > imax(m, 1);
-    };
-    if (useList) {   // one corner per lane
-      for (int q = tid; q < ncn; q += FS_NT) {
-        const int off = cornerQ[q], x = off & (FS_P - 1), y = off >> 7;
-        int cj;
-        if (nms_keep(x, y, &cj)) {
-          atomicOr(&keepBm[off >> 5], 1u << (x & 31));
-          const int idx = atomicAdd(&keptN[cj], 1);
-          if (idx < FS_KCAP) kept[cj][idx] = (uint16_t)off; else slow = 1;
-        }
-      }
-    } else {   // corner list overflowed: one 32-pixel word of the corner bitmap per lane
-      if (tid == 0) slow = 1;
-      for (int wi = tid; wi < th * FS_BW; wi += FS_NT) {
-        const int y = wi >> 2, x0 = (wi & 3) << 5;
-        uint32_t bits = cornerBm[wi] & range_mask(xa - x0, xb - x0);
-        uint32_t keep = 0;
-        while (bits) {
-          const int b = __ffs(bits) - 1;
-          bits &= bits - 1;
-          int cj;
-          if (nms_keep(x0 + b, y, &cj)) keep |= 1u << b;
-        }
-        if (keep) keepBm[wi] |= keep;
-      }
-    }
-    __syncthreads();
-    PHASE_MARK(3);
-    if (stopPhase == 3) return;
-    // keypoints per cell so far (decides which cells run again): the lists' lengths, or a count over the bitmap
-    if (tid == 0) { cn = 0; dup = 0; }
-    if (slow) {
-      count_cells();
-    } else {
-      if (tid < 4) cellTot[tid] = keptN[tid];
-      __syncthreads();
-    }
-    if (stopPhase == 4) return;
-  }
-  PHASE_MARK(4);
-  if (stopPhase == 5) return;
-  {
-    // ordered output, row-major inside each cell: wave j writes cell j, one row per lane — the lane's slot is the exclusive
-    // prefix (one DPP scan) of the rows' keypoint counts
-    const int j = tid >> 6;
-    const int keyX0 = sd.key0 & 0xFFFF, keyY0 = sd.key0 >> 16;
-    if (j < nc && !slow) {
-      // the cell's keypoints are a short unordered list: a keypoint's slot is the number of keypoints before it in row-major
-      // order, counted against the list broadcast lane by lane
-      const int n = __builtin_amdgcn_readfirstlane(keptN[j]);   // <= FS_KCAP = 64
-      const int mine = lane < n ? kept[j][lane] : 0xFFFF;
-      int rank = 0;
-      for (int k = 0; k < n; ++k) rank += __builtin_amdgcn_readlane(mine, k) < mine ? 1 : 0;
-      if (lane < n && rank < cellCap)
-        cand[(cellSlot0 + j) * (size_t)cellCap + rank] = morbqt::make_key((mine & (FS_P - 1)) + keyX0, (mine >> 7) + keyY0, sc[mine] - 1);
-      if (lane == 0) candCnt[cellSlot0 + j] = imin(n, cellCap);
-    } else if (j < nc) {
-      const int a = 3 + j * wCell, b = imin(a + wCell, tw - 3);
-      uint32_t* out = cand + (cellSlot0 + j) * (size_t)cellCap;
-      int running = 0;
-      for (int y0 = 0; y0 < th; y0 += 64) {
-        const int y = y0 + lane;
-        const int c = y < th ? row_cell_count(y, j) : 0;
-        int inc = c;
-        MORB_DPP_SCAN(inc, 0, morbwave::op_add);
-        int slot = running + inc - c;
-        running += __builtin_amdgcn_readlane(inc, 63);
-        if (c) {
-#pragma unroll
-          for (int w = 0; w < FS_BW; ++w) {
-            uint32_t word = keepBm[y * FS_BW + w] & range_mask(a - 32 * w, b - 32 * w);
-            while (word) {
-              const int bb = __ffs(word) - 1;
-              word &= word - 1;
-              const int x = w * 32 + bb;
-              if (slot < cellCap) out[slot] = morbqt::make_key(x + keyX0, y + keyY0, sc[(y << 7) | x] - 1);
-              ++slot;
-            }
-          }
-        }
-      }
-      if (lane == 0) candCnt[cellSlot0 + j] = imin(running, cellCap);
-    }
-    PHASE_MARK(5);
-  }
+extern "C" int morb_fast_timing(unsigned long long* out, int reset) {   // phase clocks of k_distribute (tools/fast_phases.py)
+  if (reset) { unsigned long long z[32] = {0}; MORB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fastPhase), z, sizeof(z))); return 0; }
+  MORB_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fastPhase), 32 * sizeof(unsigned long long)));
+  return 0;
 }
-
+#endif
 #include "fast_wave.h"
 
 // ---------------------------------------------------------------------------------------------------
@@ -1220,27 +794,20 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     g.cellBase = cellBase; cellBase += g.nCols * g.nRows;
     e->maxCells = std::max(e->maxCells, g.nCols * g.nRows);
     e->cellCap = std::max(e->cellCap, ((g.wCell + 1) / 2) * ((g.hCell + 1) / 2));
-    // k_fast segments: as many whole cells as fit a 128-px window (wCell + 6 <= 128 always: wCell < 70), spread evenly
-    MORB_REQUIRE(g.wCell + 6 <= FS_P && g.hCell + 6 < 128, MORB_ERR_UNSUPPORTED, "FAST cell too large for the 128-px segment window");
-    {
-      int cps = e->fastWave ? 1 : std::max(1, std::min(FS_NT / 64, (FS_P - 6) / g.wCell));   // (k_fastw: a wave per cell; k_fast: a wave per cell in the output phase)
-      const int nSeg = div_up(g.nCols, cps);
-      cps = div_up(g.nCols, nSeg);
-      e->fastGeom.wCellMagic[l] = 0xFFFFu / (unsigned)g.wCell + 1u;
-      for (int ci = 0; ci < g.nRows; ++ci)
-        for (int sj = 0; sj < nSeg; ++sj) {
-          const int c0 = sj * cps, nc = std::min(c0 + cps, g.nCols) - c0;
-          const int X0 = MINB + c0 * g.wCell, iniY = MINB + ci * g.hCell;
-          int tw = std::min(X0 + nc * g.wCell + 6, g.maxBorderX) - X0, th = std::min(iniY + g.hCell + 6, g.maxBorderY) - iniY;
-          if (iniY >= g.maxBorderY - 3 || tw <= 6 || th <= 6) tw = th = 0;   // ORBextractor.cc:770, :775
-          FastSeg sd;
-          sd.winOff = (unsigned)((size_t)(EDGE + iniY) * g.pstride + EDGE + X0);
-          sd.cell0 = g.cellBase + ci * g.nCols + c0;
-          sd.geo = l | (nc << 8) | (tw << 16) | (int)((unsigned)th << 24);
-          sd.key0 = (c0 * g.wCell) | ((ci * g.hCell) << 16);
-          segs.push_back(sd);
-        }
-    }
+    // k_fastw works cell by cell: one descriptor per cell (a "segment" of one cell)
+    MORB_REQUIRE(g.wCell + 6 <= 80 && g.hCell + 6 < 128, MORB_ERR_UNSUPPORTED, "FAST cell too large for the LDS window");
+    for (int ci = 0; ci < g.nRows; ++ci)
+      for (int c0 = 0; c0 < g.nCols; ++c0) {
+        const int X0 = MINB + c0 * g.wCell, iniY = MINB + ci * g.hCell;
+        int tw = std::min(X0 + g.wCell + 6, g.maxBorderX) - X0, th = std::min(iniY + g.hCell + 6, g.maxBorderY) - iniY;
+        if (iniY >= g.maxBorderY - 3 || tw <= 6 || th <= 6) tw = th = 0;   // ORBextractor.cc:770, :775
+        FastSeg sd;
+        sd.winOff = (unsigned)((size_t)(EDGE + iniY) * g.pstride + EDGE + X0);
+        sd.cell0 = g.cellBase + ci * g.nCols + c0;
+        sd.geo = l | (1 << 8) | (tw << 16) | (int)((unsigned)th << 24);
+        sd.key0 = (c0 * g.wCell) | ((ci * g.hCell) << 16);
+        segs.push_back(sd);
+      }
     g.quota = e->quota[l];
     g.nIni = (int)std::round(width / height);  // :545
     MORB_REQUIRE(g.nIni >= 1 && g.nIni <= 4, MORB_ERR_UNSUPPORTED, "aspect ratio unsupported (need 0.5 <= w/h < 4.5)");
@@ -1299,7 +866,7 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
   }
   e->totalCells = cellBase;
   {
-    // Two launches of k_fast: the LDS window is sized by the tallest cell, and the few large cells of the small top levels would
+    // Two launches of k_fastw: the LDS window is sized by the tallest cell, and the few large cells of the small top levels would
     // cost every workgroup of the big levels its occupancy.  Group 0 = segments of levels whose cells are at most two rows taller
     // than level 0's, group 1 = the rest (possibly empty).
     const int rowsA = e->geom[0].hCell + 6 + 2;
@@ -1309,7 +876,9 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
       const int rows = e->geom[sd.geo & 0xFF].hCell + 6;
       if (rows <= rowsA) { a.push_back(sd); ra = std::max(ra, rows); } else { b.push_back(sd); rb = std::max(rb, rows); }
     }
-    { const char* v = getenv("MORB_FAST_ORDER"); if (!v || atoi(v) == 2) { std::reverse(a.begin(), a.end()); std::reverse(b.begin(), b.end()); } }
+    // cells are dispatched from the top level down — the reverse of the order in which the pyramid stage wrote the levels, so the most
+    // recently written (still cached) levels are read first (measured on round 2's kernel at 512 images: 997 -> 969 us)
+    std::reverse(a.begin(), a.end()); std::reverse(b.begin(), b.end());
     e->fastSegs[0] = (int)a.size(); e->fastSegs[1] = (int)b.size();
     e->fastRows[0] = ra; e->fastRows[1] = rb;
     segs = a;
@@ -1352,11 +921,11 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     }
     // First fit, decreasing need, into bins of 1 / k of a CU's LDS.  Measured at 752 x 480 / 1200 features, 512 images (us alone | under the
     // blur | end-to-end frames/s): one level per workgroup 470 | 495 | 85.3 k; k = 3: 498 | 521 | 84.2 k; k = 2: 398 | 424 | 85.9 k;
-    // k = 1 (two workgroups of four waves per image, one per CU): 433 | 465 | 86.1 k — the default.  MORB_DIST_PACK = 0 / k for A/B.
+    // k = 1 (two workgroups of four waves per image, one per CU): 433 | 465 | 86.1 k — what is built.
     int order[kMaxLevels];
     for (int l = 0; l < L; ++l) order[l] = l;
     std::stable_sort(order, order + L, [&](int a, int b) { return need[a] > need[b]; });
-    const int packEnv = getenv("MORB_DIST_PACK") ? atoi(getenv("MORB_DIST_PACK")) : 1;
+    constexpr int packEnv = 1;   // workgroups per CU the bins are sized for (measured in round 2: 0 = one level per workgroup, 2, 3: no better end to end)
     int kMax = 1;
     while (std::min(kLdsBudget, kLdsCu / (kMax + 1) - kLdsStatic) >= needMax) ++kMax;
     const int bestK = std::max(1, std::min(packEnv, kMax));
@@ -1372,10 +941,6 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
       e->geom[l].distGroup = b; e->geom[l].distWave = binWaves[b]++; e->geom[l].distLdsOff = (int)binFill[b];
       binFill[b] += need[l];
     }
-    if (getenv("MORB_DIST_DEBUG"))
-      for (int l = 0; l < L; ++l)
-        fprintf(stderr, "k_distribute level %d: group %d wave %d lds %zu B at %d, %d keys (k = %d of %d)\n", l, e->geom[l].distGroup, e->geom[l].distWave,
-                need[l], e->geom[l].distLdsOff, e->geom[l].distKeyCap, bestK, kMax);
     e->distGroups = nb; e->distWaves = 1; e->distSmem = 0;
     for (int b = 0; b < nb; ++b) { e->distWaves = std::max(e->distWaves, binWaves[b]); e->distSmem = std::max(e->distSmem, binFill[b]); }
   }
@@ -1409,7 +974,7 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
   MORB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), e->umax, sizeof(int) * 16));
   MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_distribute),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->distSmem));
-  if (e->fastWave) {
+  {
     // k_fastw: the LDS pitch of a wave's window = the widest segment window, rounded up to whole 16-px blocks
     int twMax = 0;
     for (const FastSeg& sd : segs) twMax = std::max(twMax, (sd.geo >> 16) & 0xFF);
@@ -1422,10 +987,6 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     const void* fn = e->fastP == 48 ? reinterpret_cast<const void*>(k_fastw<48>) : e->fastP == 64 ? reinterpret_cast<const void*>(k_fastw<64>)
                    : reinterpret_cast<const void*>(k_fastw<80>);
     MORB_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  } else {
-    for (int k = 0; k < 2; ++k)   // window, strengths, 2 bitmaps, queue
-      e->fastSmem[k] = 2ull * e->fastRows[k] * FS_P + 16 + (size_t)e->fastRows[k] * (2 * FS_BW) * 4 + 2ull * FS_QCAP;
-    MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   }
   e->W = W; e->H = H; e->nimgCap = nimg;
   return MORB_OK;
@@ -1493,8 +1054,6 @@ int morb_extractor_create(morb_extractor** out, int nfeatures, float scaleFactor
     delete e;
     return MORB_ERR_HIP;
   }
-  { const char* v = getenv("MORB_EXTRACT_SERIAL"); e->overlapBlur = !(v && v[0] == '1'); }
-  { const char* v = getenv("MORB_FAST_STOP"); e->fastStop = v ? atoi(v) : -1; }   // developer hook, see k_fast
   *out = e;
   return MORB_OK;
 }
@@ -1598,9 +1157,8 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   {
     const LevelGeom& g0 = e->geom[0];
     dim3 grid(div_up(g0.pstride / 4, 64), div_up(g0.h + 2 * EDGE, 4 * PY_ROWS), nimg);
-    static const bool unfused = [] { const char* v = getenv("MORB_PYR_UNFUSED"); return v && v[0] == '1'; }();   // (measurement only)
     int l0 = 1;
-    if (L >= 2 && !unfused) {
+    if (L >= 2) {
       const LevelGeom& g1 = e->geom[1];
       dim3 gr(div_up(g1.pstride / 4, 64), div_up(g1.h + 2 * EDGE, 4 * PY_ROWS), nimg);
       hipLaunchKernelGGL(k_level01, gr, dim3(256), 0, st, d_images, width, height, stride, image_pitch, e->d_pyr, g0, g1,
@@ -1617,41 +1175,21 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
     }
   }
   mark(1);
-  {
-    // Both groups follow each other in the launch stream.  Side by side on two streams they finish no earlier when the extractor is
-    // alone on the chip (1.009 vs 1.014 ms per 512 images) and inside the pipelined bench the fork / join through a second hardware
-    // queue stretched the stage from 1.44 to 1.65 ms for the same frame rate; MORB_FAST_TWO_STREAMS=1 restores that form for A/B runs.
-    static const bool fastTwoStreams = [] { const char* v = getenv("MORB_FAST_TWO_STREAMS"); return v && v[0] == '1'; }();
-    const bool two = e->fastSegs[1] > 0 && e->overlapBlur && fastTwoStreams;
-    if (two) {
-      MORB_HIP_CHECK(hipEventRecord(e->evFork, st));
-      MORB_HIP_CHECK(hipStreamWaitEvent(e->sideStream, e->evFork, 0));
-    }
-    // Dispatch order: segment-major (x = image), segments from the top level down — the reverse of the order in which the pyramid stage
-    // wrote the levels, so the most recently written (still cached) levels are read first.  Measured at 512 images: 997 -> 969 us.
-    static const int segMajor = [] { const char* v = getenv("MORB_FAST_ORDER"); return v ? atoi(v) : 2; }();   // (0 / 1: measurement only)
-    for (int k = 0, s0 = 0; k < 2 && e->fastWave; s0 += e->fastSegs[k], ++k)
-      if (e->fastSegs[k]) {
-        const dim3 gr(nimg, div_up(e->fastSegs[k], FW_WAVES)), bl(64 * FW_WAVES);
+  // FAST: the two launch groups (cells of the big levels; the taller cells of the small top levels) follow each other in the launch
+  // stream.  Grid x = image: hardware deals consecutive workgroups round-robin over the 8 XCDs, so with a multiple of 8 images all
+  // cells of an image meet in one XCD's L2.
+  for (int k = 0, s0 = 0; k < 2; s0 += e->fastSegs[k], ++k)
+    if (e->fastSegs[k]) {
+      const dim3 gr(nimg, div_up(e->fastSegs[k], FW_WAVES)), bl(64 * FW_WAVES);
 #define MORB_FW_LAUNCH(PP) hipLaunchKernelGGL(k_fastw<PP>, gr, bl, e->fastSmem[k], st, e->fastGeom, e->d_segTab + s0, e->fastSegs[k], e->d_pyr, e->d_cand, \
                                               e->d_candCnt, e->totalCells, e->cellCap, e->fastRows[k], e->iniTh, e->minTh)
-        switch (e->fastP) {
-          case 48: MORB_FW_LAUNCH(48); break;
-          case 64: MORB_FW_LAUNCH(64); break;
-          default: MORB_FW_LAUNCH(80); break;
-        }
-#undef MORB_FW_LAUNCH
+      switch (e->fastP) {
+        case 48: MORB_FW_LAUNCH(48); break;
+        case 64: MORB_FW_LAUNCH(64); break;
+        default: MORB_FW_LAUNCH(80); break;
       }
-    for (int k = 0, s0 = 0; k < 2 && !e->fastWave; s0 += e->fastSegs[k], ++k)
-      if (e->fastSegs[k])
-        hipLaunchKernelGGL(k_fast, segMajor ? dim3(nimg, e->fastSegs[k]) : dim3(e->fastSegs[k], nimg), dim3(FS_NT), e->fastSmem[k],
-                           (k == 1 && two) ? e->sideStream : st, e->fastGeom, e->d_segTab + s0, e->d_pyr, e->d_cand, e->d_candCnt, e->totalCells,
-                           e->cellCap, e->fastRows[k], e->iniTh, e->minTh, e->fastStop, segMajor ? 1 : 0);
-    if (two) {
-      MORB_HIP_CHECK(hipEventRecord(e->evJoin, e->sideStream));
-      MORB_HIP_CHECK(hipStreamWaitEvent(st, e->evJoin, 0));
+#undef MORB_FW_LAUNCH
     }
-  }
   mark(2);
   // The blur only feeds the descriptors and is VALU-bound; the quadtree is one latency-bound wave per (level, image)
   // that leaves the vector ALUs ~90 % idle.  Fork: the blur runs on the handle's side stream underneath the quadtree
@@ -1662,7 +1200,7 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   // (which of the two is enqueued first makes no difference: measured both ways)
   hipLaunchKernelGGL(k_distribute, dim3(nimg, e->distGroups), dim3(64 * e->distWaves), e->distSmem, st, e->d_geom, e->d_cand, e->d_candCnt,
                      e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L);
-  hipStream_t sideStream = e->overlapBlur ? e->sideStream : st;   // MORB_EXTRACT_SERIAL=1: everything on the launch stream
+  hipStream_t sideStream = e->sideStream;
   MORB_HIP_CHECK(hipStreamWaitEvent(sideStream, e->evFork, 0));
   if (evs) (void)hipEventRecord(evs[6], sideStream);
   hipLaunchKernelGGL(k_blur, dim3(e->blurTiles, nimg), dim3(256), 0, sideStream, e->d_geom, L, e->d_pyr, e->d_blur);
@@ -1673,7 +1211,7 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
                      e->d_lap, e->d_kref, d_count, d_mono, cap);
   mark(4);
   MORB_HIP_CHECK(hipStreamWaitEvent(st, e->evJoin, 0));
-  static const int descRev = [] { const char* v = getenv("MORB_DESC_REV"); return v ? atoi(v) : 1; }();   // images in reverse order: the blur wrote the last ones most recently (581 -> 565 us at 512 images)
+  constexpr int descRev = 1;   // images in reverse order: the blur wrote the last ones most recently (581 -> 565 us at 512 images)
   hipLaunchKernelGGL(k_describe, dim3(div_up(e->selPerImg, 4 * DESC_KPW), nimg), dim3(256), 0, st, e->descGeom, e->d_pyr,
                      e->d_blur, e->d_kref, e->selPerImg, d_kps, d_desc, cap, descRev);
   mark(5);

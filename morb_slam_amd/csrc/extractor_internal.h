@@ -8,9 +8,6 @@
 
 #include "morb_hip.h"
 
-#ifndef MORB_FASTW
-#define MORB_FASTW 1        // 1: k_fastw (fast_wave.h); 0: round 2's k_fast (kept for A/B timing builds)
-#endif
 namespace morb {
 constexpr int kMaxLevels = 16;
 constexpr int EDGE = 19;        // EDGE_THRESHOLD  ORBextractor.cc:73
@@ -39,7 +36,7 @@ struct LevelGeom {
   int distGroup, distWave, distLdsOff, distKeyCap;
 };
 
-// What k_fast needs of every level, passed by value: the kernarg segment is read with scalar loads, so looking a
+// What k_fastw needs of every level, passed by value: the kernarg segment is read with scalar loads, so looking a
 // cell's level up costs no dependent global-memory round trip.
 struct FastGeom {
   int cellBase[kMaxLevels], nCols[kMaxLevels], wCell[kMaxLevels], hCell[kMaxLevels];
@@ -48,8 +45,8 @@ struct FastGeom {
   unsigned wCellMagic[kMaxLevels];      // ceil(2^16 / wCell): x / wCell == (x * magic) >> 16 for every x < 128
 };
 
-// k_fast works on segments: a run of horizontally adjacent cells of one cell row whose window is <= 128 px wide.  One
-// descriptor per segment of an image (all levels), built on the host, read with one scalar load.
+// k_fastw works cell by cell.  One descriptor per FAST cell of an image (all levels), built on the host, read with one scalar load
+// (the "segment" of round 2's kernel, which ran up to three cells per workgroup; the cell count field stays at 1).
 struct FastSeg {
   unsigned winOff;   // byte offset of the window's top-left pixel inside the level's (padded) image
   int cell0;         // flat index of the segment's first cell within the image (cellBase + ci * nCols + c0)
@@ -83,8 +80,7 @@ struct morb_extractor {
   int W = 0, H = 0, nimgCap = 0, nimgLast = 0;
   morb::LevelGeom geom[morb::kMaxLevels];
   int totalCells = 0, cellCap = 0, maxCells = 0, maxNodeCap = 0, maxListCap = 0;
-  int fastSegs[2] = {0, 0}, fastRows[2] = {0, 0};   // k_fast launch groups (segments, LDS window rows)
-  bool fastWave = MORB_FASTW != 0;                  // k_fastw (one wave per segment) instead of round 2's workgroup-per-segment k_fast
+  int fastSegs[2] = {0, 0}, fastRows[2] = {0, 0};   // k_fastw launch groups (cells, LDS window rows)
   int fastP = 128;                                  // k_fastw: LDS pitch of the segment windows
   int selPerImg = 0, blurTiles = 0, outCap = 0;
   size_t pyrBytes = 0, blurBytes = 0, qtElems = 0, distSmem = 0, fastSmem[2] = {0, 0};
@@ -94,8 +90,6 @@ struct morb_extractor {
   hipStream_t stream = nullptr;
   hipStream_t sideStream = nullptr;          // the blur runs here, underneath the quadtree (fork after FAST, join before describe)
   hipEvent_t evFork = nullptr, evJoin = nullptr;
-  bool overlapBlur = true;
-  int fastStop = -1;                         // developer hook (MORB_FAST_STOP): k_fast returns after that phase
   morb::LevelGeom* d_geom = nullptr;
   morb::ResizeTab* d_tabs = nullptr;
   morb::FastSeg* d_segTab = nullptr;

@@ -1,14 +1,15 @@
-"""Per-phase wall-clock split of k_fast (developer tool, GPU only).
+"""Per-phase wall-clock split of k_distribute's level-0 wave (developer tool, GPU only; k_fastw's dynamic phase counts:
+tools/fastw_stats.py).
 
 Builds a -DMORB_FAST_TIMING variant of the HIP library next to the product one, runs the C2 extract batch through it and
-prints the share of block-time each phase of the kernel takes (100 MHz wall clock ticks summed over all workgroups).
+prints the 10-ns ticks each phase of the quadtree takes (mean over images).
 Usage: python tools/fast_phases.py [B]
 """
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "morb_slam_amd", "csrc")
-out = os.path.join(ROOT, "gpurun_out", "libmorb_hip_timing.so")
+out = os.path.join(ROOT, "morb_slam_amd", "libmorb_hip_timing.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 srcs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".hip")]
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
@@ -32,9 +33,6 @@ for _ in range(5): ex.extract_batch(dev)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 32)()
 lib.morb_fast_timing(buf, 0)
-names = ["load", "p1_reject", "p2_strength", "p3_nms", "p4_rows", "p5_output"]
-tot = sum(buf[:6])
-for n, v in zip(names, buf[:6]): print(f"{n:12s} {v:12d} ticks  {100.0 * v / max(tot, 1):5.1f} %")
 print("k_distribute level 0 (ticks of 10 ns per wave, mean over images):")
 nw = 5 * 2 * B
 for n, v in zip(["cell prefix", "gather", "quadtree", "candidates T", "selected n", "qt compact", "qt splits", "qt std::sort", "split: child counts", "split: ranks", "split: partition + children", "split: bookkeeping"], list(buf[8:16]) + list(buf[16:20])): print(f"  {n:28s} {v / nw:10.1f}")

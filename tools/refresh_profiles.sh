@@ -22,7 +22,7 @@ cp "$O/opt/s_kernel_stats.csv" "$O/optimisers_kernel_stats.csv"
 rm -rf "$O/opt"
 # this round's extra evidence: VALU issue microbenchmark, MFMA Schur counters and A/B timings, phase costs of k_fast
 hipcc --offload-arch=gfx950 -O3 -o /tmp/alu_issue tools/alu_issue.hip 2>/dev/null && /tmp/alu_issue > "$O/alu_issue.txt" 2>&1
-python3 tools/fast_cost.py 64 > "$O/k_fast_phase_cost_b64.txt" 2>/dev/null
+python3 tools/fastw_stats.py 64 > "$O/k_fastw_phase_counts_b64.txt" 2>/dev/null
 python3 tools/stage_times.py 64 > "$O/extract_stage_times_isolated.txt" 2>/dev/null; python3 tools/stage_times.py 256 >> "$O/extract_stage_times_isolated.txt" 2>/dev/null
 hipcc --offload-arch=gfx950 -O3 -o /tmp/ldp tools/micro/ldlt_phases.hip 2>/dev/null && { /tmp/ldp 120; /tmp/ldp 150; } > "$O/dense_ldlt_phases.txt" 2>&1
 rm -rf "$O/stats" "$O"/pmc/*/q_kernel_trace.csv "$O"/pmc/*/q_agent_info.csv
