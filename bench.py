@@ -662,11 +662,13 @@ def main():
         fps = B * world * args.steps / dt
         ab = algorithmic_bytes(W, H)
         nimg = 2 * B
-        kern = {"pyramid": "k_level0+k_resize", "blur": "k_blur", "fast": "k_fast"}
-        # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this same
-        # command at B = 64; profiles/<round>/pmc_traffic_b64.json) — not measurable live
+        kern = {"pyramid": "k_level01+k_resize", "blur": "k_blur", "fast": "k_fastw"}
+        # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of the extraction
+        # at 128 images per launch; profiles/<round>/pmc_traffic_b64.json) — not measurable live.  Corrected as the calibration kernel
+        # prescribes (profiles/r03/fetch_calib.txt: FETCH_SIZE reads 0.500 x the bytes of coalesced 4 / 8 / 16-byte reads, WRITE_SIZE 1.0 x):
+        # traffic = 2 x FETCH_SIZE + WRITE_SIZE
         pm = None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03",):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic_b64.json")))
                 break
@@ -677,10 +679,9 @@ def main():
             if pm is None or args.workload != "c2":
                 return None
             try:
-                names = {"pyramid": ["k_level0", "k_resize"], "blur": ["k_blur"], "fast": ["k_fast"]}[stage]
-                mult = {"k_resize": 7, "k_fast": pm.get("k_fast_launches", 1)}
-                return sum((pm[k]["FETCH_SIZE_KB_per_launch"] + pm[k]["WRITE_SIZE_KB_per_launch"]) * 1024 * mult.get(k, 1)
-                           for k in names) * nimg / pm.get("images_per_launch", 128)
+                # launches per extraction: levels 0 + 1 from one launch, six resizes; two k_fastw launch groups (the per-launch mean is over both)
+                names = {"pyramid": [("k_level01", 1), ("k_resize", 6)], "blur": [("k_blur", 1)], "fast": [("k_fastw", 2)]}[stage]
+                return sum(pm[k]["traffic_KB_per_launch"] * 1024 * m for k, m in names) * nimg / pm.get("images_per_launch", 128)
             except Exception:
                 return None
 
@@ -691,8 +692,8 @@ def main():
                     # not part of the timed region: the stage alone on the chip (steps not overlapped)
                     "isolated_avg_launch_ms": iso[stage], "isolated_frac": ab[stage] * nimg / (iso[stage] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         # the dominant streaming stage of the extractor = the longest of the three by its time INSIDE the timed region (HIP
-        # events on the launch stream; "pyramid" is the eight dependent launches of k_level0 / k_resize, "fast" the two k_fast
-        # launch groups, which run side by side)
+        # events on the launch stream; "pyramid" is the dependent launches of k_level01 / k_resize, "fast" the two k_fastw
+        # launch groups, which follow each other)
         dom = max(("pyramid", "blur", "fast"), key=lambda k: stages[k])
         wl = {"c2": f"BASELINE configs[1]: EuRoC-shaped stereo {W}x{H}, {NFEAT} feat", "c4": f"BASELINE configs[3]: synthetic stereo {W}x{H}, {NFEAT} feat"}[args.workload]
         line = {

@@ -3,6 +3,7 @@
 // methods read from Frame / KeyFrame / MapPoint / Map and write back to them; INTEGRATION.md shows the glue inside the reference tree.
 #pragma once
 #include <cstdint>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -48,22 +49,25 @@ class Optimizer {
     using morb_adapter::DeviceBuffer;
     if (f.N <= 0) return 0;
     const int N = f.N;
-    // per-thread staging buffers that only grow: Tracking calls this once per frame, and eight hipMalloc / hipFree pairs per call
-    // cost more than the optimisation itself
-    static thread_local DeviceBuffer<uint8_t> has, outl;
-    static thread_local DeviceBuffer<float> obs, inv, Xw, pose;
-    static thread_local DeviceBuffer<int> nin, cnt;
-    has.assign(f.hasMapPoint, N); outl.resize(N);
+    Slot& o = slot(device, kTracking);
+    std::lock_guard<std::mutex> lock(o.mu);   // one caller per handle at a time (Tracking's handle is not LocalMapping's: see slot())
+    morb_adapter::hip_check(hipSetDevice(device), "hipSetDevice");
+    // per-thread, per-device staging buffers that only grow: Tracking calls this once per frame, and eight hipMalloc / hipFree pairs
+    // per call cost more than the optimisation itself
+    struct Staging { DeviceBuffer<uint8_t> has, outl; DeviceBuffer<float> obs, inv, Xw, pose; DeviceBuffer<int> nin, cnt; };
+    static thread_local Staging per_device[kMaxDevices];
+    Staging& s = per_device[device];
+    s.has.assign(f.hasMapPoint, N); s.outl.resize(N);
     // mvbOutlier is only written for features that hold a map point (Optimizer.cc:817, :860): the others keep what they had
-    if ((int)f.mvbOutlier.size() == N) outl.upload(f.mvbOutlier.data(), N); else outl.fill_bytes(0);
-    obs.assign(f.obs, (size_t)N * 3); inv.assign(f.invSigma2, N); Xw.assign(f.worldPos, (size_t)N * 3); pose.assign(f.pose, 7);
-    nin.resize(1); cnt.assign(&N, 1);
-    check(morb_pose_optimization_batch(optimizer(device), 1, N, cnt.get(), has.get(), obs.get(), inv.get(), Xw.get(), f.fx, f.fy, f.cx, f.cy, f.mbf,
-                                       pose.get(), outl.get(), nin.get(), nullptr, nullptr));
+    if ((int)f.mvbOutlier.size() == N) s.outl.upload(f.mvbOutlier.data(), N); else s.outl.fill_bytes(0);
+    s.obs.assign(f.obs, (size_t)N * 3); s.inv.assign(f.invSigma2, N); s.Xw.assign(f.worldPos, (size_t)N * 3); s.pose.assign(f.pose, 7);
+    s.nin.resize(1); s.cnt.assign(&N, 1);
+    check(morb_pose_optimization_batch(o.h, 1, N, s.cnt.get(), s.has.get(), s.obs.get(), s.inv.get(), s.Xw.get(), f.fx, f.fy, f.cx, f.cy, f.mbf,
+                                       s.pose.get(), s.outl.get(), s.nin.get(), nullptr, nullptr));
     morb_adapter::hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
-    pose.download(f.pose, 7);
-    f.mvbOutlier = outl.to_host();
-    return nin.to_host()[0];
+    s.pose.download(f.pose, 7);
+    f.mvbOutlier = s.outl.to_host();
+    return s.nin.to_host()[0];
   }
 
   // static void LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int&, int&, int&, int&)  Optimizer.h:67-69.  pbStopFlag is
@@ -72,20 +76,35 @@ class Optimizer {
     static_assert(sizeof(bool) == 1, "pbStopFlag is read as one byte");
     g.eraseFlag.assign(g.nE, 0);
     int stats[2] = {0, 0};
-    check(morb_local_bundle_adjustment(optimizer(device), g.nKF, g.kfPose, g.kfFixed, g.nMP, g.mpPos, g.nE, g.eKF, g.eMP, g.eObs, g.eInvSigma2, g.fx,
+    Slot& o = slot(device, kMapping);
+    std::lock_guard<std::mutex> lock(o.mu);   // the one-shot entry point works in the handle's grow-only workspace
+    morb_adapter::hip_check(hipSetDevice(device), "hipSetDevice");
+    check(morb_local_bundle_adjustment(o.h, g.nKF, g.kfPose, g.kfFixed, g.nMP, g.mpPos, g.nE, g.eKF, g.eMP, g.eObs, g.eInvSigma2, g.fx,
                                        g.fy, g.cx, g.cy, g.mbf, g.inertialMap ? 1 : 0, reinterpret_cast<const unsigned char*>(pbStopFlag),
                                        g.eraseFlag.data(), stats));
     g.outerIterations = stats[0]; g.lmTrials = stats[1];
   }
 
-  static morb_optimizer* optimizer(int device = 0) {   // one handle per process and device, like the reference's stateless static class
-    static morb_optimizer* h[16] = {nullptr};
-    if (device < 0 || device >= 16) throw std::runtime_error("bad device");
-    if (!h[device] && morb_optimizer_create(&h[device], device) != MORB_OK) throw std::runtime_error(std::string("morb_optimizer_create: ") + morb_last_error());
-    return h[device];
-  }
+  // The reference's Optimizer is a stateless static class entered concurrently from Tracking (PoseOptimization, every frame) and from
+  // LocalMapping (LocalBundleAdjustment, hundreds of milliseconds of LM trials): each role has its own handle — own stream, own
+  // workspace — per device, created once (std::call_once), so a tracked frame never queues behind local-mapping trials; a mutex per
+  // handle serialises callers of the same role.
+  enum Role { kTracking = 0, kMapping = 1 };
+  static morb_optimizer* optimizer(int device = 0, Role role = kTracking) { return slot(device, role).h; }
 
  private:
+  static constexpr int kMaxDevices = 16;
+  struct Slot { std::once_flag once; std::mutex mu; morb_optimizer* h = nullptr; };
+  static Slot& slot(int device, Role role) {
+    if (device < 0 || device >= kMaxDevices) throw std::runtime_error("bad device");
+    static Slot slots[kMaxDevices][2];
+    Slot& o = slots[device][role];
+    std::call_once(o.once, [&] {
+      if (morb_optimizer_create(&o.h, device) != MORB_OK) { o.h = nullptr; throw std::runtime_error(std::string("morb_optimizer_create: ") + morb_last_error()); }
+    });
+    if (!o.h) throw std::runtime_error("morb_optimizer_create failed earlier");
+    return o;
+  }
   static void check(int rc) { if (rc < 0) throw std::runtime_error(morb_last_error()); }
 };
 

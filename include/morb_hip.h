@@ -389,7 +389,7 @@ int morb_search_by_projection_sim3_batch(morb_matcher* m, const morb_frame_param
                                          int manualProjection, int* d_matchF, int* d_nmatches, void* stream);
 
 /* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (:1323-1519).  Per pair: T1w / T2w = GetPose(); S12 and S21 =
- * S12.inverse() as 8 floats each (RxSO3 quaternion xyzw whose squared norm is the scale, then translation).  d_valid1[p][i1]
+ * S12.inverse() as 7 floats each (RxSO3 quaternion xyzw whose squared norm is the scale, then the translation).  d_valid1[p][i1]
  * != 0 <=> vpMapPoints1[i1] && !vbAlreadyMatched1[i1] && !isBad() (likewise 2); per-feature map-point arrays are [npairs][cap].
  * Outputs: d_vnMatch1 / d_vnMatch2 (the two one-way tables), d_match12[p][i1] = idx2 for mutually consistent pairs else -1,
  * d_nFound. */

@@ -40,6 +40,14 @@ int main(int argc, char** argv) {
     const int mono = ext(img, k, d, {dims[4], dims[5]});
     const int head[2] = {mono, (int)k.size()};
     dump("ext_head", head, 2); dump("ext_kps", k.data(), k.size()); dump("ext_desc", d.data(), d.size());
+    // mvImagePyramid (read by Frame::ComputeStereoMatches, Frame.cc:895): nothing is downloaded by operator() itself, the first access fetches
+    const int lazy0 = ext.mvImagePyramid.downloaded() ? 1 : 0;
+    const auto& lvl2 = ext.mvImagePyramid[2];
+    const int pyr[5] = {lazy0, ext.mvImagePyramid.downloaded() ? 1 : 0, (int)ext.mvImagePyramid.size(), lvl2.cols, lvl2.rows};
+    dump("ext_pyr_head", pyr, 5); dump("ext_pyr_l2", lvl2.data.data(), lvl2.data.size());
+    const int mono2 = ext(img, k, d, {dims[4], dims[5]});   // a second extraction invalidates the host copies
+    const int again[2] = {mono2 == mono ? 1 : 0, ext.mvImagePyramid.downloaded() ? 1 : 0};
+    dump("ext_pyr_again", again, 2);
   }
   // ---- ORBmatcher::SearchByProjection(Frame, MapPoints)
   {

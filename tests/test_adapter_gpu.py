@@ -86,6 +86,13 @@ def test_cpp_adapters_match_oracle(tmp_path):
     assert head.tolist() == [mono_o, len(ko)]
     assert get("ext_kps", np.uint8).tobytes() == ko.tobytes()
     assert get("ext_desc", np.uint8).tobytes() == do.tobytes()
+    # lazy mvImagePyramid: not downloaded by operator(), fetched on first access, invalidated by the next extraction
+    oe2 = O.OracleExtractor(nfeat, 1.2, nlev, 20, 7); oe2(img, lap)
+    l2 = oe2.level_image(2)[19:-19, 19:-19]      # (the POD build exposes the interior of each level; with OpenCV: ROIs into the padded copies)
+    ph = get("ext_pyr_head", np.int32)
+    assert ph.tolist() == [0, 1, nlev, l2.shape[1], l2.shape[0]]
+    np.testing.assert_array_equal(get("ext_pyr_l2", np.uint8).reshape(l2.shape), l2)
+    assert get("ext_pyr_again", np.int32).tolist() == [1, 0]
     # ---- ORBmatcher::SearchByProjection(F, MPs) (+ isInFrustum)
     Fo = O.make_frame(P, k0, d0, ur0)
     te = O.is_in_frustum(Fo, R, t, Ow, Xw, normal, maxD, minD, 0.5)

@@ -13,6 +13,10 @@ MBF, MB = np.float32(458.654 * 0.11), np.float32(0.11)   # EuRoC: bf = fx * base
 
 @pytest.fixture(scope="module")
 def batch():
+    return make_batch()
+
+
+def make_batch():
     """4 stereo frames extracted on the GPU (bit-exact with the oracle per test_extractor_gpu) + oracle twins."""
     import torch
     from morb_slam_amd import KP_DTYPE, ORBextractor

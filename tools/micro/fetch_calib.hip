@@ -21,7 +21,7 @@ template <> __device__ __forceinline__ unsigned fold(uint4 v) { return v.x ^ v.y
 template <typename T> __global__ __launch_bounds__(256) void k_calib_read(const T* __restrict__ src, size_t n, unsigned* __restrict__ sink) {
   unsigned acc = 0;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc ^= fold(src[i]);
-  if (acc == 0x12345678u) sink[blockIdx.x] = acc;   // (never true for the test pattern: keeps the loads alive without a store stream)
+  if (acc == 0x5Au) sink[blockIdx.x] = acc;   // (never true for the test pattern, but not provably so: keeps the loads alive without a store stream)
 }
 // write-only
 template <typename T> __global__ __launch_bounds__(256) void k_calib_write(T* __restrict__ dst, size_t n) {
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_calib_read_unaligned16(const uint8_t* _
     __builtin_memcpy(&v, src + i * 16 + 1, 16);
     acc ^= fold(v);
   }
-  if (acc == 0x12345678u) sink[blockIdx.x] = acc;
+  if (acc == 0x5Au) sink[blockIdx.x] = acc;
 }
 // rows of 48 bytes out of a pitch of 832 (a k_fastw cell window on a 752-px level): 3 x 16-byte loads per row, rows 832 bytes apart
 __global__ __launch_bounds__(256) void k_calib_read_window48(const uint8_t* __restrict__ src, size_t rows, unsigned* __restrict__ sink) {
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_calib_read_window48(const uint8_t* __re
     __builtin_memcpy(&v, src + r * 832 + 35 + c * 16, 16);
     acc ^= fold(v);
   }
-  if (acc == 0x12345678u) sink[blockIdx.x] = acc;
+  if (acc == 0x5Au) sink[blockIdx.x] = acc;
 }
 
 int main(int argc, char** argv) {
