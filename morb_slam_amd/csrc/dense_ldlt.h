@@ -220,5 +220,194 @@ __device__ bool ldlt_solve(const double* __restrict__ Hs, const double* b, doubl
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same factorisation for systems whose packed triangle does not fit LDS (n > ~176: LocalBundleAdjustment beyond 29 free keyframes —
+// the reference takes every covisible keyframe, Optimizer.cc:1058-1070 — and LocalInertialBA beyond 11): the matrix stays in global
+// memory (L2), only the current 16-column panel lives in LDS.  ONE workgroup of 1024 threads, blocked right-looking LDL^T:
+// the 16 x 16 diagonal block is factorised by one wave in registers, every row below it by sixteen lanes (PanelStage), then one
+// trailing update of the matrix per panel on the FP64 matrix cores, TWO tiles per wave in flight so that eight global loads per lane
+// hide the L2 round trip (a wave per row with the row requested 64 columns at a time took 1.0 ms per solve at n = 375; whole rows
+// at once 0.74; this form 0.5).  3 barriers per panel.  Substitutions are blocked the same way.
+constexpr int GT = 1024;   // threads of the global-memory solver
+// LDS doubles: dblk[NB * NBP] | y[n]; and the panel copies pnlL | pnlU, (n + NB) * NBP doubles each, in LDS when they fit or in global scratch
+__host__ __device__ inline size_t global_lds_doubles(int n) { return (size_t)NB * NBP + (size_t)n; }
+__host__ __device__ inline size_t global_panel_doubles(int n) { return 2 * (size_t)(n + NB) * NBP; }
+
+// LDL^T of a 16 x 16 block held in LDS (pitch 17; rows / columns >= nb are identity padding) by ONE wave: lane r keeps row r in
+// registers, other rows' entries arrive through v_readlane.  Leaves L below the diagonal and D on it.
+template <bool PIVOT_POSITIVE>
+__device__ inline bool wave_ldl_factor16(double* blk, int lane) {
+  const int row = lane < NB ? lane : NB - 1;
+  double a[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) a[c] = blk[row * NBP + c];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const double d = morbwave::readlane_f64(a[j], j);
+    ok = ok && (PIVOT_POSITIVE ? (d > 0) : !(d == 0 || d != d));
+    const double l = a[j] / d;
+#pragma unroll
+    for (int c = j + 1; c < NB; ++c) a[c] -= l * morbwave::readlane_f64(a[j], c);
+    if (row > j) a[j] = l;
+  }
+  if (lane < NB) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c) if (c <= row) blk[row * NBP + c] = a[c];
+  }
+  return ok;
+}
+
+// A: symmetric n x n, row-major, pitch n; its lower triangle is overwritten by L (unit, strictly lower) and D (diagonal).
+// b, x: n (x may alias b).  pnl: global_panel_doubles(n) doubles (LDS or global), sm: global_lds_doubles(n) doubles of LDS.
+// Returns false if a pivot failed (x untouched).  All GT threads must call.
+template <bool PIVOT_POSITIVE>
+__device__ bool ldlt_solve_global(double* __restrict__ A, const double* b, double* x, int n, double* pnl, double* sm, int* sOk) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int np = n + NB;   // (the panel copies are read in whole 16-row tiles by the matrix-core trailing update)
+  double* pnlL = pnl; double* pnlU = pnl + (size_t)np * NBP; double* dblk = sm; double* y = sm + NB * NBP;
+  if (tid == 0) *sOk = 1;
+  __syncthreads();
+  for (int j0 = 0; j0 < n; j0 += NB) {
+    const int nb = n - j0 < NB ? n - j0 : NB, m = n - j0 - nb;   // m rows below the diagonal block
+    // (1) diagonal block -> LDS (identity padding), factorised by wave 0
+    if (tid < NB * NB) {
+      const int r = tid / NB, c = tid - r * NB;
+      dblk[r * NBP + c] = (r < nb && c < nb) ? (c <= r ? A[(size_t)(j0 + r) * n + j0 + c] : A[(size_t)(j0 + c) * n + j0 + r]) : (r == c ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (wv == 0) { const bool ok = wave_ldl_factor16<PIVOT_POSITIVE>(dblk, lane); if (lane == 0 && !ok) *sOk = 0; }
+    __syncthreads();
+    if (*sOk == 0) break;   // uniform
+    if (tid < NB * NB) {   // write L / D of the block back
+      const int r = tid / NB, c = tid - r * NB;
+      if (r < nb && c <= r) A[(size_t)(j0 + r) * n + j0 + c] = dblk[r * NBP + c];
+    }
+    // (2) panel rows below the block: u = a - sum_k u_k L[c][k], l = u / d — sixteen lanes per row, one per column, the 16 dependent
+    // stages are one DPP row broadcast + one FMA each.  (The thread-per-row form, fully unrolled, had the compiler hoist its 120 LDS
+    // operands into registers and spill 748 bytes per lane.)
+    {
+      const int c = tid & 15;
+      double lrow[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) { const double t = dblk[c * NBP + k]; lrow[k] = k < c ? t : 0.0; }
+      const double dc = dblk[c * NBP + c];
+      for (int rr = tid >> 4; rr < m; rr += GT / 16) {
+        const size_t g = (size_t)(j0 + nb + rr) * n + j0;
+        const double t = A[g + (c < nb ? c : 0)];
+        double v = c < nb ? t : 0.0;
+        PanelStage<0>::run(v, lrow);
+        const double l = v / dc;
+        pnlU[rr * NBP + c] = v;
+        pnlL[rr * NBP + c] = l;
+        if (c < nb) A[g + c] = l;
+      }
+      // rows m .. next multiple of 16 of the panel copies feed matrix-core lanes whose results are dropped: keep them zero
+      for (int i = m * NBP + tid; i < ((m + NB - 1) / NB * NB) * NBP; i += GT) { pnlU[i] = 0.0; pnlL[i] = 0.0; }
+    }
+    __syncthreads();
+    // (3) trailing update A[r][cc] -= sum_k u[r][k] l[cc][k] on the FP64 matrix cores: one wave per 16 x 16 tile of the lower triangle
+    {
+      const int mt = (m + NB - 1) / NB, ntile = mt * (mt + 1) / 2;
+      const int li = lane & 15, lk = lane >> 4;
+      double* Abase = A + (size_t)(j0 + nb) * n + j0 + nb;
+      constexpr int NW = GT / 64;
+      for (int t0 = wv; t0 < ntile; t0 += 2 * NW) {
+        int ti[2], tj[2];
+        bool live[2];
+        double c[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int t = t0 + u * NW;
+          live[u] = t < ntile;
+          int a = 0;
+          while ((a + 1) * (a + 2) / 2 <= (live[u] ? t : 0)) ++a;
+          ti[u] = a; tj[u] = (live[u] ? t : 0) - a * (a + 1) / 2;
+#pragma unroll
+          for (int v4 = 0; v4 < 4; ++v4) {
+            const int rr = ti[u] * NB + 4 * v4 + lk, cc = tj[u] * NB + li;
+            c[u][v4] = (live[u] && rr < m && cc <= rr) ? Abase[(size_t)rr * n + cc] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (!live[u]) continue;   // wave-uniform
+          ld_d4 acc = {0, 0, 0, 0};
+#pragma unroll
+          for (int s4 = 0; s4 < NB / 4; ++s4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pnlU[(ti[u] * NB + li) * NBP + 4 * s4 + lk], pnlL[(tj[u] * NB + li) * NBP + 4 * s4 + lk], acc, 0, 0, 0);
+#pragma unroll
+          for (int v4 = 0; v4 < 4; ++v4) {
+            const int rr = ti[u] * NB + 4 * v4 + lk, cc = tj[u] * NB + li;
+            if (rr < m && cc <= rr) Abase[(size_t)rr * n + cc] = c[u][v4] - acc[v4];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (*sOk == 0) return false;
+  // blocked substitutions: per 16-column panel the 16 x 16 triangular block is solved by wave 0 in registers (v_readlane), the
+  // rest of the panel is one 16-term dot product per row
+  for (int r = tid; r < n; r += GT) y[r] = b[r];
+  __syncthreads();
+  for (int j0 = 0; j0 < n; j0 += NB) {   // L y = b
+    const int nb = n - j0 < NB ? n - j0 : NB;
+    if (tid < NB * NB) {
+      const int r = tid / NB, c = tid - r * NB;
+      dblk[r * NBP + c] = (r < nb && c < r) ? A[(size_t)(j0 + r) * n + j0 + c] : 0.0;
+    }
+    __syncthreads();
+    if (wv == 0) {
+      const int row = lane < NB ? lane : NB - 1;
+      double yr = row < nb ? y[j0 + row] : 0.0;
+#pragma unroll
+      for (int c = 0; c < NB - 1; ++c) {
+        const double yc = morbwave::readlane_f64(yr, c);
+        if (row > c) yr -= dblk[row * NBP + c] * yc;
+      }
+      if (lane < nb) y[j0 + lane] = yr;
+    }
+    __syncthreads();
+    for (int r = j0 + nb + tid; r < n; r += GT) {
+      const double* lr = A + (size_t)r * n + j0;
+      double acc = 0;
+      for (int k = 0; k < nb; ++k) acc += lr[k] * y[j0 + k];
+      y[r] -= acc;
+    }
+    __syncthreads();
+  }
+  for (int r = tid; r < n; r += GT) y[r] /= A[(size_t)r * n + r];
+  __syncthreads();
+  for (int j0 = ((n - 1) / NB) * NB; j0 >= 0; j0 -= NB) {   // L^T x = y
+    const int nb = n - j0 < NB ? n - j0 : NB;
+    if (tid < NB * NB) {
+      const int r = tid / NB, c = tid - r * NB;
+      dblk[r * NBP + c] = (r < nb && c < r) ? A[(size_t)(j0 + r) * n + j0 + c] : 0.0;
+    }
+    __syncthreads();
+    if (wv == 0) {
+      const int row = lane < NB ? lane : NB - 1;
+      double xr = row < nb ? y[j0 + row] : 0.0;
+#pragma unroll
+      for (int c = NB - 1; c > 0; --c) {
+        const double xc = morbwave::readlane_f64(xr, c);
+        if (row < c) xr -= dblk[c * NBP + row] * xc;   // L^T[row][c] = L[c][row]
+      }
+      if (lane < nb) y[j0 + lane] = xr;
+    }
+    __syncthreads();
+    for (int r = tid; r < j0; r += GT) {
+      double acc = 0;
+      for (int k = 0; k < nb; ++k) acc += A[(size_t)(j0 + k) * n + r] * y[j0 + k];
+      y[r] -= acc;
+    }
+    __syncthreads();
+  }
+  for (int r = tid; r < n; r += GT) x[r] = y[r];
+  return true;
+}
+
 }  // namespace
 }  // namespace morbdense

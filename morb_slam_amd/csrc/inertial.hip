@@ -626,7 +626,6 @@ __device__ void prior_edge(const double* prior, const VIState& S1, double* err, 
 }
 
 // system column of an inertial-edge column: frame = [P 0..5, V 6..8, G 9..11, A 12..14], previous frame / keyframe = 15 + the same
-__device__ __forceinline__ int edge_col(int a) { return a < 15 ? 15 + a : a - 15; }
 
 // LASTFRAME = false: PoseInertialOptimizationLastKeyFrame (state 1 = the keyframe, fixed: 15 unknowns)
 // LASTFRAME = true : PoseInertialOptimizationLastFrame   (state 1 = the previous frame, free, with its prior: 30 unknowns)
@@ -1077,7 +1076,7 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
 //   k_iba_errors   computeActiveErrors + activeRobustChi2 (one thread per visual edge / per inertial link)
 //   k_iba_points   per point: Hll, bl                      k_iba_kf   per 64-edge chunk of a keyframe: Hpp, bp (wave sums), Hpl
 //   k_iba_links    inertial + random-walk edges into the dense 15 N x 15 N system
-//   k_iba_schur    per point: (Hll + lambda I)^-1, Schur complement into the pose blocks and right-hand side
+//   k_iba_pack_w / k_iba_pack_wd + k_schur_mfma + k_iba_schur_finish   Schur complement of the points on the FP64 matrix cores
 //   k_iba_solve    one workgroup: dense LDL^T          k_iba_update   back-substitution of the points, oplus of all vertices
 // =====================================================================================================================================
 struct IbaDev {
@@ -1109,6 +1108,7 @@ struct IbaDev {
   int* lmi;                                     // IBA_LM_*
   int* lmHost;                                  // [0] decided trials, [1] done
   double *Sbk, *ptsBk;                          // state / points before the trial
+  double* pnlG;                                 // panel copies of the global-memory LDL^T when they do not fit LDS
   int nS, nPts, optIt;
   CamGeom g;
 };
@@ -1497,15 +1497,6 @@ __device__ __forceinline__ bool inv3(const double* D3, double* I) {
   I[6] = C * inv; I[7] = -(a * h - b * g) * inv; I[8] = (a * e - b * d) * inv;
   return true;
 }
-// Hs = H + lambda I, bs = b[0:P]
-__global__ __launch_bounds__(256) void k_iba_hs_init(IbaDev D) {
-  if (iba_done(D)) return;
-  const double lambda = D.lmd[IBA_LMD_LAMBDA];
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  const int n = D.P * D.P;
-  if (t < n) { const int r = t / D.P, c = t - r * D.P; D.Hs[t] = D.H[t] + (r == c ? lambda : 0.0); }
-  else if (t - n < D.P) D.bs[t - n] = D.b[t - n];
-}
 // MFMA operands of the Schur complement (schur_mfma.h).  W: Hpl of every observation of an optimizable keyframe and b_l in the extra
 // column (once per outer iteration, after buildSystem); WD = Hpl (Hll + lambda I)^-1 (every trial).
 // Hpl of (keyframe column c1, point m) as the MFMA operands need it: on a fisheye rig a keyframe may observe a point with both
@@ -1537,7 +1528,7 @@ __global__ __launch_bounds__(256) void k_iba_pack_w(IbaDev D) {
   }
   if (t < 3 * D.nMP) D.sW[(size_t)t * D.sMp + M] = D.b[D.P + t];
 }
-// (the launch also does k_iba_hs_init's work — Hs = H + lambda I, bs = b — on its first P * P + P threads: one launch fewer per trial)
+// (the launch also sets Hs = H + lambda I, bs = b on its first P * P + P threads: one launch fewer per trial)
 __global__ __launch_bounds__(256) void k_iba_pack_wd(IbaDev D) {
   if (iba_done(D)) return;
   const double lambda = D.lmd[IBA_LMD_LAMBDA];
@@ -1577,97 +1568,6 @@ __global__ __launch_bounds__(256) void k_iba_schur_finish(IbaDev D) {
   if (mat) D.Hs[(size_t)(15 * (r / 6) + r % 6) * D.P + 15 * (c / 6) + c % 6] -= cs;
   else if (rhs) D.bs[15 * (r / 6) + r % 6] -= cs;
 }
-// Schur complement of the points (block_solver.hpp): one thread per point.  The pose blocks of the reduced system receive ~k^2 6 x 6
-// updates per point on a few thousand addresses: with LDSACC the workgroup accumulates them in LDS ((6 N)^2 doubles, LDS atomics)
-// and flushes once; without (large windows) they go to global memory directly.
-template <bool LDSACC>
-__global__ __launch_bounds__(256) void k_iba_schur(IbaDev D) {
-  extern __shared__ double sS[];   // LDSACC: M * M + M, M = 6 * (P / 15)
-  if (iba_done(D)) return;
-  const double lambda = D.lmd[IBA_LMD_LAMBDA];
-  const int M = 6 * (D.P / 15);
-  if (LDSACC) { for (int k = threadIdx.x; k < M * M + M; k += 256) sS[k] = 0; __syncthreads(); }
-  const int l = blockIdx.x * 256 + threadIdx.x;
-  if (l < D.nMP) {
-    double Dm[9], Di[9];
-    for (int k = 0; k < 9; ++k) Dm[k] = D.Hll[(size_t)l * 9 + k];
-    Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
-    inv3(Dm, Di);
-    const double* bl = D.b + D.P + 3 * (size_t)l;
-    double db[3];
-    for (int r = 0; r < 3; ++r) db[r] = Di[r * 3] * bl[0] + Di[r * 3 + 1] * bl[1] + Di[r * 3 + 2] * bl[2];
-    const int s0 = D.ptStart[l], s1 = D.ptStart[l + 1];
-    for (int k1 = s0; k1 < s1; ++k1) {
-      const int e1 = D.ptEdges[k1];
-      const int c1 = D.col[D.eKF[e1]];
-      if (c1 < 0) continue;
-      const double* B1 = D.Hpl + (size_t)e1 * 18;
-      double BD[18];
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) BD[r * 3 + c] = B1[r * 3] * Di[c] + B1[r * 3 + 1] * Di[3 + c] + B1[r * 3 + 2] * Di[6 + c];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        const double v = -(B1[r * 3] * db[0] + B1[r * 3 + 1] * db[1] + B1[r * 3 + 2] * db[2]);
-        if (LDSACC) unsafeAtomicAdd(&sS[M * M + 6 * c1 + r], v); else unsafeAtomicAdd(&D.bs[15 * c1 + r], v);
-      }
-      for (int k2 = s0; k2 < s1; ++k2) {
-        const int e2 = D.ptEdges[k2];
-        const int c2 = D.col[D.eKF[e2]];
-        if (c2 < 0) continue;
-        const double* B2 = D.Hpl + (size_t)e2 * 18;
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-          for (int c = 0; c < 6; ++c) {
-            const double v = -(BD[r * 3] * B2[c * 3] + BD[r * 3 + 1] * B2[c * 3 + 1] + BD[r * 3 + 2] * B2[c * 3 + 2]);
-            if (LDSACC) unsafeAtomicAdd(&sS[(6 * c1 + r) * M + 6 * c2 + c], v);
-            else unsafeAtomicAdd(&D.Hs[(size_t)(15 * c1 + r) * D.P + 15 * c2 + c], v);
-          }
-      }
-    }
-  }
-  if (LDSACC) {
-    __syncthreads();
-    for (int k = threadIdx.x; k < M * M + M; k += 256) {
-      const double v = sS[k];
-      if (v == 0.0) continue;
-      if (k < M * M) { const int R = k / M, C = k - R * M; unsafeAtomicAdd(&D.Hs[(size_t)(15 * (R / 6) + R % 6) * D.P + 15 * (C / 6) + C % 6], v); }
-      else { const int R = k - M * M; unsafeAtomicAdd(&D.bs[15 * (R / 6) + R % 6], v); }
-    }
-  }
-}
-// dense LDL^T of Hs (lower triangle) + solve -> x[0:P], scal[2] = positive.  ONE workgroup of 1024 threads: blocked right-looking
-// LDL^T with 16-column panels (a column-at-a-time form with the whole triangle in LDS was measured slower, 0.32 ms at n = 150, and
-// does not fit beyond n = 190): the 16 x 16 diagonal block is factorised by one wave in registers, every row below it is
-// substituted by one thread (16 values in registers), then one trailing update of the matrix per panel: 3 barriers per panel.  The panel (rows j0 .. n-1, row pitch 17 doubles: no LDS bank conflicts when lanes read different rows) is
-// factorised inside LDS column by column, written back once, and the trailing matrix in global memory is updated once per
-// panel (16-term dot products from the LDS panel) instead of once per column.
-constexpr int IBA_NB = 16, IBA_NBP = 17;
-// LDL^T of a 16 x 16 block held in LDS (pitch 17; rows / columns >= nb are identity padding) by ONE wave: lane r keeps row r in
-// registers, other rows' entries arrive through v_readlane (see wave_ldlt_solve).  Leaves L below the diagonal and D on it.
-__device__ bool wave_ldl_factor16(double* blk, int lane) {
-  const int row = lane < IBA_NB ? lane : IBA_NB - 1;
-  double a[IBA_NB];
-#pragma unroll
-  for (int c = 0; c < IBA_NB; ++c) a[c] = blk[row * IBA_NBP + c];
-  bool ok = true;
-#pragma unroll
-  for (int j = 0; j < IBA_NB; ++j) {
-    const double d = morbwave::readlane_f64(a[j], j);
-    ok = ok && (d > 0);
-    const double l = a[j] / d;
-#pragma unroll
-    for (int c = j + 1; c < IBA_NB; ++c) a[c] -= l * morbwave::readlane_f64(a[j], c);
-    if (row > j) a[j] = l;
-  }
-  if (lane < IBA_NB) {
-#pragma unroll
-    for (int c = 0; c < IBA_NB; ++c) if (c <= row) blk[row * IBA_NBP + c] = a[c];
-  }
-  return ok;
-}
 // dense LDL^T + solve with the lower triangle resident in LDS (dense_ldlt.h): windows up to 15 N = 165
 __global__ __launch_bounds__(morbdense::LT) void k_iba_solve_lds(IbaDev D) {
   extern __shared__ double sLd[];
@@ -1676,160 +1576,15 @@ __global__ __launch_bounds__(morbdense::LT) void k_iba_solve_lds(IbaDev D) {
   const bool ok = morbdense::ldlt_solve<true>(D.Hs, D.bs, D.x, D.P, sLd, &sOk);
   if (threadIdx.x == 0) D.scal[2] = ok ? 1.0 : 0.0;
 }
-constexpr int IBA_SB_T = 1024;
-__global__ __launch_bounds__(IBA_SB_T) void k_iba_solve_blocked(IbaDev D) {
-  extern __shared__ double sm[];   // pnlL[(n + 16) * NBP] | pnlU[(n + 16) * NBP] | dblk[NB * NBP] | y[n]
-  if (iba_done(D)) return;
-  const int n = D.P, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int np = n + IBA_NB;   // (the panel copies are read in whole 16-row tiles by the matrix-core trailing update)
-  double* pnlL = sm; double* pnlU = sm + (size_t)np * IBA_NBP; double* dblk = pnlU + (size_t)np * IBA_NBP; double* y = dblk + IBA_NB * IBA_NBP;
-  double* A = D.Hs;
+// larger windows (bLarge, or more than 11 optimizable keyframes): the matrix stays in global memory, one 16-column panel at a time in LDS
+// (dense_ldlt.h: ldlt_solve_global; the panel copies move to a global scratch when even they do not fit LDS, P > ~530)
+__global__ __launch_bounds__(morbdense::GT) void k_iba_solve_blocked(IbaDev D, int panelInLds) {
+  extern __shared__ double sm[];   // dblk[NB * NBP] | y[n] | (pnlL | pnlU when they fit)
   __shared__ int sOk;
-  if (tid == 0) sOk = 1;
-  __syncthreads();
-  for (int j0 = 0; j0 < n; j0 += IBA_NB) {
-    const int nb = n - j0 < IBA_NB ? n - j0 : IBA_NB, m = n - j0 - nb;   // m rows below the diagonal block
-    // (1) diagonal block -> LDS (identity padding), factorised by wave 0
-    if (tid < IBA_NB * IBA_NB) {
-      const int r = tid / IBA_NB, c = tid - r * IBA_NB;
-      dblk[r * IBA_NBP + c] = (r < nb && c < nb) ? (c <= r ? A[(size_t)(j0 + r) * n + j0 + c] : A[(size_t)(j0 + c) * n + j0 + r]) : (r == c ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    if (wv == 0) { const bool ok = wave_ldl_factor16(dblk, lane); if (lane == 0 && !ok) sOk = 0; }
-    __syncthreads();
-    if (sOk == 0) break;   // uniform
-    if (tid < IBA_NB * IBA_NB) {   // write L / D of the block back
-      const int r = tid / IBA_NB, c = tid - r * IBA_NB;
-      if (r < nb && c <= r) A[(size_t)(j0 + r) * n + j0 + c] = dblk[r * IBA_NBP + c];
-    }
-    // (2) panel rows below the block: u = a - sum_k u_k L[c][k], l = u / d — sixteen lanes per row, one per column, the 16 dependent
-    // stages are one DPP row broadcast + one FMA each (dense_ldlt.h's PanelStage).  The thread-per-row form, fully unrolled, had the
-    // compiler hoist its 120 LDS operands into registers and spill 748 bytes per lane.
-    {
-      const int c = tid & 15;
-      double lrow[IBA_NB];
-#pragma unroll
-      for (int k = 0; k < IBA_NB; ++k) { const double t = dblk[c * IBA_NBP + k]; lrow[k] = k < c ? t : 0.0; }
-      const double dc = dblk[c * IBA_NBP + c];
-      for (int rr = tid >> 4; rr < m; rr += IBA_SB_T / 16) {
-        const size_t g = (size_t)(j0 + nb + rr) * n + j0;
-        const double t = A[g + (c < nb ? c : 0)];
-        double v = c < nb ? t : 0.0;
-        morbdense::PanelStage<0>::run(v, lrow);
-        const double l = v / dc;
-        pnlU[rr * IBA_NBP + c] = v;
-        pnlL[rr * IBA_NBP + c] = l;
-        if (c < nb) A[g + c] = l;
-      }
-      // rows m .. next multiple of 16 of the panel copies feed matrix-core lanes whose results are dropped: keep them zero
-      for (int i = m * IBA_NBP + tid; i < ((m + IBA_NB - 1) / IBA_NB * IBA_NB) * IBA_NBP; i += IBA_SB_T) { pnlU[i] = 0.0; pnlL[i] = 0.0; }
-    }
-    __syncthreads();
-    // (3) trailing update A[r][cc] -= sum_k u[r][k] l[cc][k] on the FP64 matrix cores: one wave per 16 x 16 tile of the lower triangle
-    // (4 v_mfma_f64_16x16x4_f64, layout as in dense_ldlt.h), TWO tiles per pass so that eight global loads per lane are in flight —
-    // the matrix lives in global memory (L2) and with a single workgroup nothing else hides that round trip.  (A wave per row with the
-    // row requested 64 columns at a time took 1.0 ms per solve at n = 375; whole rows at once 0.74.)
-    {
-      typedef double iba_d4 __attribute__((ext_vector_type(4)));
-      const int mt = (m + IBA_NB - 1) / IBA_NB, ntile = mt * (mt + 1) / 2;
-      const int li = lane & 15, lk = lane >> 4;
-      double* Abase = A + (size_t)(j0 + nb) * n + j0 + nb;
-      constexpr int NW = IBA_SB_T / 64;
-      for (int t0 = wv; t0 < ntile; t0 += 2 * NW) {
-        int ti[2], tj[2];
-        bool live[2];
-        double c[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int t = t0 + u * NW;
-          live[u] = t < ntile;
-          int a = 0;
-          while ((a + 1) * (a + 2) / 2 <= (live[u] ? t : 0)) ++a;
-          ti[u] = a; tj[u] = (live[u] ? t : 0) - a * (a + 1) / 2;
-#pragma unroll
-          for (int v4 = 0; v4 < 4; ++v4) {
-            const int rr = ti[u] * IBA_NB + 4 * v4 + lk, cc = tj[u] * IBA_NB + li;
-            c[u][v4] = (live[u] && rr < m && cc <= rr) ? Abase[(size_t)rr * n + cc] : 0.0;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          if (!live[u]) continue;   // wave-uniform
-          iba_d4 acc = {0, 0, 0, 0};
-#pragma unroll
-          for (int s4 = 0; s4 < IBA_NB / 4; ++s4)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pnlU[(ti[u] * IBA_NB + li) * IBA_NBP + 4 * s4 + lk], pnlL[(tj[u] * IBA_NB + li) * IBA_NBP + 4 * s4 + lk], acc, 0, 0, 0);
-#pragma unroll
-          for (int v4 = 0; v4 < 4; ++v4) {
-            const int rr = ti[u] * IBA_NB + 4 * v4 + lk, cc = tj[u] * IBA_NB + li;
-            if (rr < m && cc <= rr) Abase[(size_t)rr * n + cc] = c[u][v4] - acc[v4];
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  __syncthreads();
-  if (sOk == 0) { if (tid == 0) D.scal[2] = 0.0; return; }
-  // blocked substitutions: per 16-column panel the 16 x 16 triangular block is solved by wave 0 in registers (v_readlane), the
-  // rest of the panel is one 16-term dot product per row
-  for (int r = tid; r < n; r += IBA_SB_T) y[r] = D.bs[r];
-  __syncthreads();
-  for (int j0 = 0; j0 < n; j0 += IBA_NB) {   // L y = b
-    const int nb = n - j0 < IBA_NB ? n - j0 : IBA_NB;
-    if (tid < IBA_NB * IBA_NB) {
-      const int r = tid / IBA_NB, c = tid - r * IBA_NB;
-      dblk[r * IBA_NBP + c] = (r < nb && c < r) ? A[(size_t)(j0 + r) * n + j0 + c] : 0.0;
-    }
-    __syncthreads();
-    if (wv == 0) {
-      const int row = lane < IBA_NB ? lane : IBA_NB - 1;
-      double yr = row < nb ? y[j0 + row] : 0.0;
-#pragma unroll
-      for (int c = 0; c < IBA_NB - 1; ++c) {
-        const double yc = morbwave::readlane_f64(yr, c);
-        if (row > c) yr -= dblk[row * IBA_NBP + c] * yc;
-      }
-      if (lane < nb) y[j0 + lane] = yr;
-    }
-    __syncthreads();
-    for (int r = j0 + nb + tid; r < n; r += IBA_SB_T) {
-      const double* lr = A + (size_t)r * n + j0;
-      double acc = 0;
-      for (int k = 0; k < nb; ++k) acc += lr[k] * y[j0 + k];
-      y[r] -= acc;
-    }
-    __syncthreads();
-  }
-  for (int r = tid; r < n; r += IBA_SB_T) y[r] /= A[(size_t)r * n + r];
-  __syncthreads();
-  for (int j0 = ((n - 1) / IBA_NB) * IBA_NB; j0 >= 0; j0 -= IBA_NB) {   // L^T x = y
-    const int nb = n - j0 < IBA_NB ? n - j0 : IBA_NB;
-    if (tid < IBA_NB * IBA_NB) {
-      const int r = tid / IBA_NB, c = tid - r * IBA_NB;
-      dblk[r * IBA_NBP + c] = (r < nb && c < r) ? A[(size_t)(j0 + r) * n + j0 + c] : 0.0;
-    }
-    __syncthreads();
-    if (wv == 0) {
-      const int row = lane < IBA_NB ? lane : IBA_NB - 1;
-      double xr = row < nb ? y[j0 + row] : 0.0;
-#pragma unroll
-      for (int c = IBA_NB - 1; c > 0; --c) {
-        const double xc = morbwave::readlane_f64(xr, c);
-        if (row < c) xr -= dblk[c * IBA_NBP + row] * xc;   // L^T[row][c] = L[c][row]
-      }
-      if (lane < nb) y[j0 + lane] = xr;
-    }
-    __syncthreads();
-    for (int r = tid; r < j0; r += IBA_SB_T) {
-      double acc = 0;
-      for (int k = 0; k < nb; ++k) acc += A[(size_t)(j0 + k) * n + r] * y[j0 + k];
-      y[r] -= acc;
-    }
-    __syncthreads();
-  }
-  for (int r = tid; r < n; r += IBA_SB_T) D.x[r] = y[r];
-  if (tid == 0) D.scal[2] = 1.0;
+  if (iba_done(D)) return;
+  double* pnl = panelInLds ? sm + morbdense::global_lds_doubles(D.P) : D.pnlG;
+  const bool ok = morbdense::ldlt_solve_global<true>(D.Hs, D.bs, D.x, D.P, pnl, sm, &sOk);
+  if (threadIdx.x == 0) D.scal[2] = ok ? 1.0 : 0.0;
 }
 
 // back-substitution of the points + oplus of every vertex + the LM scale  sum x (lambda x + b) -> scal[1]
@@ -2067,7 +1822,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
                    sizeof(double) * 81 * (size_t)nI1, sizeof(double) * 9 * (size_t)nI1, sizeof(double) * 9 * (size_t)nI1,
                    sizeof(double) * (size_t)P * P, sizeof(double) * (size_t)P * P, sizeof(double) * nX, sizeof(double) * (size_t)P,
                    sizeof(double) * nX, sizeof(double) * 9 * (size_t)nMP, sizeof(double) * 18 * (size_t)nE, sizeof(double) * 4,
-                   (size_t)nE, (size_t)nE, sizeof(double) * splan.wElems(), sizeof(double) * splan.wElems(), sizeof(double) * splan.partElems(),
+                   (size_t)nE, (size_t)nE, sizeof(double) * splan.wElems(), sizeof(double) * splan.wElems(), sizeof(double) * splan.partElems(), sizeof(double) * morbdense::global_panel_doubles(P),
                    sizeof(int2) * (size_t)splan.nblk, sizeof(int) * (size_t)splan.nb * splan.nb, sizeof(double) * 8, sizeof(int) * 16})
     reserve(b);
   void* arena = nullptr;
@@ -2142,6 +1897,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
   D.b = (double*)dalloc(sizeof(double) * nX); D.bs = (double*)dalloc(sizeof(double) * P); D.x = (double*)dalloc(sizeof(double) * nX);
   D.Hll = (double*)dalloc(sizeof(double) * 9 * nMP); D.Hpl = (double*)dalloc(sizeof(double) * 18 * nE);
   D.scal = (double*)dalloc(sizeof(double) * 4);
+  D.pnlG = (double*)dalloc(sizeof(double) * morbdense::global_panel_doubles(P));
   uint8_t* d_erase = (uint8_t*)dalloc(nE);
   MORB_REQUIRE(d_erase != nullptr && arenaOff <= arenaBytes, MORB_ERR_HIP, "workspace carve-up overflow in morb_local_inertial_ba");
   (void)hipMemsetAsync(D.x, 0, sizeof(double) * nX, st);   // the solver's x before the first solve
@@ -2170,15 +1926,14 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
   if (nI) hipLaunchKernelGGL(k_iba_setup_links, dim3(nI), dim3(64), 0, st, D, d_scale);
   hipLaunchKernelGGL(k_iba_setup_pts, dim3(div_up((int)nPts, 256)), dim3(256), 0, st, D, (const float*)d_mpIn);   // points to FP64
   const int Mpose = 6 * nOpt;
-  static const bool valuSchur = [] { const char* v = getenv("MORB_SCHUR_VALU"); return v && v[0] == '1'; }();
-  const size_t schurLds = sizeof(double) * ((size_t)Mpose * Mpose + Mpose);
-  const bool ldsSchur = schurLds <= 60 * 1024;   // larger windows accumulate in global memory
-  const size_t blockedLds = sizeof(double) * (2 * (size_t)(P + IBA_NB) * IBA_NBP + IBA_NB * IBA_NBP + (size_t)P);
+  size_t blockedLds = sizeof(double) * (morbdense::global_lds_doubles(P) + morbdense::global_panel_doubles(P));
+  const int panelInLds = blockedLds <= 150 * 1024 ? 1 : 0;
+  if (!panelInLds) blockedLds = sizeof(double) * morbdense::global_lds_doubles(P);
   MORB_REQUIRE(blockedLds <= 150 * 1024, MORB_ERR_CAPACITY, "window too large for the dense solver");
   if (blockedLds > 48 * 1024)
     MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_iba_solve_blocked), hipFuncAttributeMaxDynamicSharedMemorySize, (int)blockedLds));
   size_t denseLds = sizeof(double) * morbdense::lds_doubles(P);
-  if (denseLds > 156 * 1024 || getenv("MORB_LDLT_R1")) denseLds = 0;   // larger windows (bLarge) keep the global-memory solver; MORB_LDLT_R1: measurement only
+  if (denseLds > 156 * 1024) denseLds = 0;   // larger windows (bLarge) use the global-memory solver
   if (denseLds) MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_iba_solve_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
   double chi = 0;
   if (!errors(&chi)) return fail("k_iba_errors failed");
@@ -2200,26 +1955,26 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
       hipLaunchKernelGGL(k_iba_points, dim3(beginGrid), dim3(256), 0, st, D);
       if (nChunks) hipLaunchKernelGGL(k_iba_kf, dim3(div_up(nChunks, 4)), dim3(256), 0, st, D);
       if (nI) hipLaunchKernelGGL(k_iba_links, dim3(nI), dim3(64), 0, st, D);
-      if (!valuSchur) hipLaunchKernelGGL(k_iba_pack_w, dim3(div_up(std::max(nE, 3 * nMP), 256)), dim3(256), 0, st, D);
-      // the trial
-      if (valuSchur) hipLaunchKernelGGL(k_iba_hs_init, dim3(div_up(P * P + P, 256)), dim3(256), 0, st, D);
-      if (!valuSchur) {
-        // Schur complement of the points on the FP64 matrix cores: one dense product for matrix and right-hand side
-        hipLaunchKernelGGL(k_iba_pack_wd, dim3(div_up(std::max(nE, P * P + P), 256)), dim3(256), 0, st, D);
-        hipLaunchKernelGGL(morbschur::k_schur_mfma, dim3(splan.nblk, splan.nsplit), dim3(64), 0, st, (const double*)D.sWD, (const double*)D.sW,
-                           splan.Mp, splan.ksteps, splan.stepsPerSplit, D.sBlocks, D.sPart, (const int*)(D.lmi + IBA_LM_DONE));
-        hipLaunchKernelGGL(k_iba_schur_finish, dim3(div_up(4 * (Mpose * Mpose + Mpose), 256)), dim3(256), 0, st, D);
-      } else if (ldsSchur) hipLaunchKernelGGL(k_iba_schur<true>, dim3(div_up(nMP, 256)), dim3(256), schurLds, st, D);   // (measurement only, MORB_SCHUR_VALU=1: round 1's form with FP64 atomics)
-      else hipLaunchKernelGGL(k_iba_schur<false>, dim3(div_up(nMP, 256)), dim3(256), 0, st, D);
+      hipLaunchKernelGGL(k_iba_pack_w, dim3(div_up(std::max(nE, 3 * nMP), 256)), dim3(256), 0, st, D);
+      // the trial: Schur complement of the points on the FP64 matrix cores, one dense product for matrix and right-hand side
+      hipLaunchKernelGGL(k_iba_pack_wd, dim3(div_up(std::max(nE, P * P + P), 256)), dim3(256), 0, st, D);
+      hipLaunchKernelGGL(morbschur::k_schur_mfma, dim3(splan.nblk, splan.nsplit), dim3(64), 0, st, (const double*)D.sWD, (const double*)D.sW,
+                         splan.Mp, splan.ksteps, splan.stepsPerSplit, D.sBlocks, D.sPart, (const int*)(D.lmi + IBA_LM_DONE));
+      hipLaunchKernelGGL(k_iba_schur_finish, dim3(div_up(4 * (Mpose * Mpose + Mpose), 256)), dim3(256), 0, st, D);
       if (denseLds) hipLaunchKernelGGL(k_iba_solve_lds, dim3(1), dim3(morbdense::LT), denseLds, st, D);
-      else hipLaunchKernelGGL(k_iba_solve_blocked, dim3(1), dim3(IBA_SB_T), blockedLds, st, D);
+      else hipLaunchKernelGGL(k_iba_solve_blocked, dim3(1), dim3(morbdense::GT), blockedLds, st, D, panelInLds);
       // a failed solve leaves x as it was (zero at the first trial): g2o still applies the update
       hipLaunchKernelGGL(k_iba_update, dim3(div_up(nMP + nKF, 256)), dim3(256), 0, st, D);
       hipLaunchKernelGGL(k_iba_errors, dim3(div_up(nE + nI, 256)), dim3(256), 0, st, D, 1);
       if (hipGetLastError() != hipSuccess) return fail("LocalInertialBA trial failed");
       unsigned spins = 0;
       while (!__atomic_load_n(hostw + 1, __ATOMIC_ACQUIRE) && __atomic_load_n(hostw + 0, __ATOMIC_ACQUIRE) < slot) {   // one slot ahead
-        if ((++spins & 0xFFFFu) == 0 && hipStreamQuery(st) == hipSuccess) break;   // (everything queued has run: the words are final)
+        if ((++spins & 0x3FFu) == 0) {
+          const hipError_t q = hipStreamQuery(st);
+          if (q == hipSuccess) break;   // (everything queued has run: the words are final)
+          if (q != hipErrorNotReady) return fail("LocalInertialBA: device error while waiting for the LM decision");
+        }
+        __builtin_ia32_pause();
       }
       if (__atomic_load_n(hostw + 1, __ATOMIC_ACQUIRE)) break;
     }

@@ -1051,13 +1051,6 @@ __global__ __launch_bounds__(GB) void k_g_chi2(const BaDev* __restrict__ pbp, do
   pb.lmi[LM_TICKET] = 0;
   if (mode == 1) lm_decide(pb, s0, s1); else lm_init(pb, s0);
 }
-__global__ __launch_bounds__(GB) void k_g_reduce(const double* __restrict__ part, int n, double* __restrict__ out) {
-  __shared__ double red[4];
-  double s = 0;
-  for (int i = threadIdx.x; i < n; i += GB) s += part[i];
-  s = block_sum_d<4>(s, red);
-  if (threadIdx.x == 0) *out = s;
-}
 template <bool RIG>
 __device__ __forceinline__ double build_mp_point(const BaDev& pb, int m) {   // -> max |diag Hll| of the point
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
@@ -1094,14 +1087,6 @@ __device__ __forceinline__ double build_mp_point(const BaDev& pb, int m) {   // 
 #pragma unroll
   for (int k = 0; k < 3; ++k) pb.b[pb.P + 3 * m + k] = bl[k];
   return fmax(fmax(fabs(Hl[0]), fabs(Hl[4])), fabs(Hl[8]));
-}
-template <bool RIG>
-__global__ __launch_bounds__(GB) void k_g_build_mp(const BaDev* __restrict__ pbp, int gated) {
-  const BaDev pb = *pbp;
-  if (lm_skip_build(pb, gated)) return;
-  const int m = blockIdx.x * GB + threadIdx.x;
-  if (m >= pb.nMP) return;
-  build_mp_point<RIG>(pb, m);
 }
 template <bool RIG>
 __device__ __forceinline__ void build_kf_chunk(const BaDev& pb, int c, int lane) {
@@ -1154,32 +1139,6 @@ __device__ __forceinline__ void build_kf_chunk(const BaDev& pb, int c, int lane)
     pb.kfPart[(size_t)c * 27 + lane] = v;
   }
 }
-template <bool RIG>
-__global__ __launch_bounds__(GB) void k_g_build_kf(const BaDev* __restrict__ pbp, int gated) {
-  const BaDev pb = *pbp;
-  if (lm_skip_build(pb, gated)) return;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (c >= pb.nChunks) return;
-  build_kf_chunk<RIG>(pb, c, lane);
-}
-__global__ __launch_bounds__(64) void k_g_kf_reduce(const BaDev* __restrict__ pbp, int gated) {
-  const BaDev pb = *pbp;
-  if (lm_skip_build(pb, gated)) return;
-  const int kf = blockIdx.x, lane = threadIdx.x;
-  const int col = pb.kfCol[kf];
-  if (col < 0 || lane >= 27) return;
-  double s = 0;
-  for (int c = pb.kfChunkStart[kf]; c < pb.kfChunkStart[kf + 1]; ++c) s += pb.kfPart[(size_t)c * 27 + lane];
-  if (lane < 21) {
-    int r = 0, q = lane;
-    while (q >= 6 - r) { q -= 6 - r; ++r; }
-    const int cc = r + q;
-    pb.Hpp[(size_t)col * 36 + r * 6 + cc] = s;
-    pb.Hpp[(size_t)col * 36 + cc * 6 + r] = s;
-  } else {
-    pb.b[6 * col + (lane - 21)] = s;
-  }
-}
 // buildSystem in ONE launch (device-side LM control): workgroups [0, kfBlocks) take the keyframe chunks, the rest the map points;
 // the last chunk of a keyframe to deliver its partial blocks adds them up in chunk order (k_g_kf_reduce's sum, whoever runs it).
 // Two launches on two streams cost more in cross-stream events (~25 us per trial) than running side by side saved.
@@ -1228,18 +1187,6 @@ __global__ __launch_bounds__(GB) void k_g_build(const BaDev* __restrict__ pbp, i
   } else {
     pb.b[6 * col + (lane - 21)] = s;
   }
-}
-__global__ __launch_bounds__(GB) void k_g_maxdiag(const BaDev* __restrict__ pbp) {
-  __shared__ double red[4];
-  const BaDev pb = *pbp;
-  double m = 0;
-  for (int i = threadIdx.x; i < pb.nFree * 6; i += GB) m = fmax(m, fabs(pb.Hpp[(size_t)(i / 6) * 36 + (i % 6) * 7]));
-  for (int i = threadIdx.x; i < pb.nMP * 3; i += GB) m = fmax(m, fabs(pb.Hll[(size_t)(i / 3) * 9 + (i % 3) * 4]));
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) pb.scal[3] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 // Hpl of (keyframe column i, landmark m) as the MFMA operands need it: a fisheye rig may observe a landmark with both cameras
 // of one keyframe, i.e. through two edges — the first of them (lowest edge index) carries the sum, the others nothing.
@@ -1305,24 +1252,6 @@ __global__ __launch_bounds__(GB) void k_g_dinv_push(const BaDev* __restrict__ pb
   }
   if (packW && gid < pb.nMP * 3) pb.sW[(size_t)gid * pb.sMp + pb.P] = pb.b[pb.P + gid];
 }
-// the MFMA operand W (once per outer iteration, after the builds): Hpl of every observation, and b_l in the extra column P
-__global__ __launch_bounds__(GB) void k_g_pack_w(const BaDev* __restrict__ pbp, int gated) {
-  const BaDev pb = *pbp;
-  if (lm_skip_build(pb, gated)) return;
-  const int gid = blockIdx.x * GB + threadIdx.x;
-  if (gid < pb.nE) {
-    const int i = pb.kfCol[pb.eKF[gid]];
-    const int m = pb.eMP[gid];
-    double B1[18];
-    if (i >= 0 && pair_block(pb, gid, i, m, B1)) {
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) pb.sW[(size_t)(3 * m + c) * pb.sMp + 6 * i + r] = B1[r * 3 + c];
-    }
-  }
-  if (gid < pb.nMP * 3) pb.sW[(size_t)gid * pb.sMp + pb.P] = pb.b[pb.P + gid];
-}
 // reduced system from the partial products: Hs = Hpp + lambda I - C (C symmetric: the upper blocks serve both triangles),
 // x[0:P] = b_p - C[:, P]
 __global__ __launch_bounds__(GB) void k_g_schur_finish(const BaDev* __restrict__ pbp, double lambda, double* __restrict__ Hs, int gated) {
@@ -1344,200 +1273,18 @@ __global__ __launch_bounds__(GB) void k_g_schur_finish(const BaDev* __restrict__
     pb.x[r] = pb.b[r] - cs;
   }
 }
-__global__ __launch_bounds__(GB) void k_g_schur(const BaDev* __restrict__ pbp, double lambda, double* __restrict__ Hs) {
-  const BaDev pb = *pbp;
-  const int bp = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (bp >= pb.nPairs) return;
-  const int P = pb.P;
-  const int i1 = pb.pairBlock[bp] / pb.nFree, i2 = pb.pairBlock[bp] % pb.nFree;
-  double acc[36];
-#pragma unroll
-  for (int k = 0; k < 36; ++k) acc[k] = 0;
-  for (int k = pb.pairStart[bp] + lane; k < pb.pairStart[bp + 1]; k += 64) {
-    const int2 en = pb.pairEntries[k];
-    const double* B1 = pb.Hpl + (size_t)en.x * 18;
-    const double* B2 = pb.Hpl + (size_t)en.y * 18;
-    const double* Di = pb.Dinv + (size_t)pb.eMP[en.x] * 9;
-    double BD[18];
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) BD[r * 3 + c] = B1[r * 3] * Di[c] + B1[r * 3 + 1] * Di[3 + c] + B1[r * 3 + 2] * Di[6 + c];
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int c = 0; c < 6; ++c) acc[r * 6 + c] += BD[r * 3] * B2[c * 3] + BD[r * 3 + 1] * B2[c * 3 + 1] + BD[r * 3 + 2] * B2[c * 3 + 2];
-  }
-#pragma unroll
-  for (int k = 0; k < 36; ++k) acc[k] = wave_sum_d(acc[k]);
-  if (lane < 36) {
-    const int r = lane / 6, c = lane % 6;
-    double a = 0;
-#pragma unroll
-    for (int k = 0; k < 36; ++k) if (k == lane) a = acc[k];
-    double v = -a;
-    if (i1 == i2) { v += pb.Hpp[(size_t)i1 * 36 + lane]; if (r == c) v += lambda; }
-    Hs[(size_t)(6 * i1 + r) * P + 6 * i2 + c] = v;
-    if (i1 != i2) Hs[(size_t)(6 * i2 + c) * P + 6 * i1 + r] = v;
-  }
-}
-__global__ __launch_bounds__(64) void k_g_bschur(const BaDev* __restrict__ pbp) {
-  const BaDev pb = *pbp;
-  const int kf = blockIdx.x, lane = threadIdx.x;
-  const int col = pb.kfCol[kf];
-  if (col < 0) return;
-  const int P = pb.P;
-  double a6[6] = {0, 0, 0, 0, 0, 0};
-  for (int k = pb.kfStart[kf] + lane; k < pb.kfStart[kf + 1]; k += 64) {
-    const int e = pb.kfEdges[k];
-    const int m = pb.eMP[e];
-    const double* Di = pb.Dinv + (size_t)m * 9;
-    const double* bl = pb.b + P + 3 * m;
-    double db[3];
-    for (int r = 0; r < 3; ++r) db[r] = Di[r * 3] * bl[0] + Di[r * 3 + 1] * bl[1] + Di[r * 3 + 2] * bl[2];
-    const double* B1 = pb.Hpl + (size_t)e * 18;
-    for (int r = 0; r < 6; ++r) a6[r] += B1[r * 3] * db[0] + B1[r * 3 + 1] * db[1] + B1[r * 3 + 2] * db[2];
-  }
-  for (int r = 0; r < 6; ++r) a6[r] = wave_sum_d(a6[r]);
-  if (lane == 0) for (int r = 0; r < 6; ++r) pb.x[6 * col + r] = pb.b[6 * col + r] - a6[r];
-}
-// reduced camera system: LDL^T + triangular solves by ONE workgroup (the system is <= 132 x 132)
-constexpr int LD_T = 1024;
-// One wave factorises: rows are dealt to lanes (row i -> lane (i - j - 1) % 64), the k-loop of every lane reads the
-// same pivot-column element at the same time (LDS broadcast), rows are padded to P + 1 doubles so that the
-// per-lane row accesses fall on different banks.  Only wave-level barriers are needed (no s_barrier).
-#define LD_WAVE_SYNC()                                        \
-  do {                                                        \
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");    \
-    __builtin_amdgcn_wave_barrier();                          \
-  } while (0)
-// The body is instantiated twice (LDS / global) so that each copy sees a pointer of known address space: a
-// pointer that may be either forces FLAT loads/stores, which cost several times an LDS access.
-// Right-looking LDL^T by the whole workgroup: per column one barrier after staging the pivot column, one after
-// the trailing update (32 x 32 thread tile, no integer division); triangular solves by wave 0.
-// Blocked right-looking LDL^T (block width LB): per block step (1) one thread factors the LB x LB diagonal block in
-// registers, (2) one thread per row below it solves that row's LB entries (keeping u = l * d for step 3), (3) all
-// threads apply the rank-LB update to the trailing lower triangle.  3 workgroup barriers per LB columns instead of
-// 2 per column (the column-by-column version spent ~120 us of its 137 us at P = 120 in barriers).
-constexpr int LB = 8;
-template <typename HsPtr>
-__device__ __forceinline__ bool ldlt_block(HsPtr Hs, int pitch, int P, int tid, double* __restrict__ up /*[P][LB]*/,
-                                           double* __restrict__ x, int* sOk) {
-  const int tx = tid & 31, ty = tid >> 5, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) *sOk = 1;
-  __syncthreads();
-  for (int j0 = 0; j0 < P; j0 += LB) {
-    const int nb = P - j0 < LB ? P - j0 : LB;
-    if (tid == 0) {   // (1) diagonal block
-      double a[LB][LB];
-#pragma unroll
-      for (int i = 0; i < LB; ++i)
-#pragma unroll
-        for (int c = 0; c <= i; ++c) a[i][c] = (i < nb) ? (double)Hs[(size_t)(j0 + i) * pitch + j0 + c] : (i == c ? 1.0 : 0.0);
-      bool good = true;
-#pragma unroll
-      for (int c = 0; c < LB; ++c) {
-        double d = a[c][c];
-#pragma unroll
-        for (int k = 0; k < c; ++k) d -= a[c][k] * a[c][k] * a[k][k];
-        a[c][c] = d;
-        if (c < nb && (d == 0 || d != d)) good = false;
-        const double invd = 1.0 / d;
-#pragma unroll
-        for (int i = c + 1; i < LB; ++i) {
-          double v = a[i][c];
-#pragma unroll
-          for (int k = 0; k < c; ++k) v -= a[i][k] * a[k][k] * a[c][k];
-          a[i][c] = v * invd;
-        }
-      }
-      if (!good) *sOk = 0;
-#pragma unroll
-      for (int i = 0; i < LB; ++i)
-#pragma unroll
-        for (int c = 0; c <= i; ++c) if (i < nb) Hs[(size_t)(j0 + i) * pitch + j0 + c] = a[i][c];
-    }
-    __syncthreads();
-    if (*sOk == 0) break;   // uniform
-    const int r0 = j0 + nb, m = P - r0;   // rows below the block
-    if (tid < m) {   // (2) panel: one row per thread
-      const int i = r0 + tid;
-      double u[LB], l[LB];
-#pragma unroll
-      for (int c = 0; c < LB; ++c) {
-        if (c < nb) {
-          double v = Hs[(size_t)i * pitch + j0 + c];
-#pragma unroll
-          for (int k = 0; k < c; ++k) v -= u[k] * (double)Hs[(size_t)(j0 + c) * pitch + j0 + k];
-          u[c] = v;
-          l[c] = v / (double)Hs[(size_t)(j0 + c) * pitch + j0 + c];
-        } else { u[c] = 0; l[c] = 0; }
-      }
-#pragma unroll
-      for (int c = 0; c < LB; ++c) { up[(size_t)tid * LB + c] = u[c]; if (c < nb) Hs[(size_t)i * pitch + j0 + c] = l[c]; }
-    }
-    __syncthreads();
-    // (3) trailing update: Hs[i][k] -= sum_c u[i][c] * l[k][c], r0 <= k <= i < P
-    for (int ii = ty; ii < m; ii += 32) {
-      const int i = r0 + ii;
-      double ui[LB];
-#pragma unroll
-      for (int c = 0; c < LB; ++c) ui[c] = up[(size_t)ii * LB + c];
-      HsPtr row = Hs + (size_t)i * pitch;
-      for (int kk = tx; kk <= ii; kk += 32) {
-        const int k = r0 + kk;
-        HsPtr lk = Hs + (size_t)k * pitch + j0;
-        double acc = 0;
-#pragma unroll
-        for (int c = 0; c < LB; ++c) acc += ui[c] * (double)lk[c];
-        row[k] -= acc;
-      }
-    }
-    __syncthreads();
-  }
-  __syncthreads();
-  const bool ok = *sOk != 0;
-  if (ok && wv == 0) {
-    // column-at-a-time substitutions by one wave (a blocked variant with the LB x LB triangles solved by one lane was
-    // measured slower: 123 vs 98 us per call at P = 120)
-    for (int j = 0; j < P; ++j) {             // L y = b
-      const double xj = x[j];
-      for (int i = j + 1 + lane; i < P; i += 64) x[i] -= Hs[(size_t)i * pitch + j] * xj;
-      LD_WAVE_SYNC();
-    }
-    for (int i = lane; i < P; i += 64) x[i] /= Hs[(size_t)i * pitch + i];
-    LD_WAVE_SYNC();
-    for (int j = P - 1; j >= 0; --j) {        // L^T x = y
-      const double xj = x[j];
-      for (int i = lane; i < j; i += 64) x[i] -= Hs[(size_t)j * pitch + i] * xj;
-      LD_WAVE_SYNC();
-    }
-  }
-  __syncthreads();
-  return ok;
-}
-constexpr int LD_MAXP = 192;
-__global__ __launch_bounds__(LD_T) void k_g_ldlt(const BaDev* __restrict__ pbp, double* __restrict__ HsG, double* __restrict__ wsG,
-                                                 int useLds, int gated) {
-  extern __shared__ double sHs[];
-  __shared__ double sx[LD_MAXP];
-  __shared__ double upanel[LD_MAXP * LB];
+// the reduced camera system beyond ~176 unknowns (30 free keyframes and more: the reference takes every covisible keyframe,
+// Optimizer.cc:1058-1070): the matrix stays in global memory, one 16-column panel at a time in LDS (dense_ldlt.h: ldlt_solve_global);
+// HsG is overwritten by the factors (k_g_schur_finish rebuilds it for every trial); x = Hs^-1 x in place
+__global__ __launch_bounds__(morbdense::GT) void k_g_ldlt_global(const BaDev* __restrict__ pbp, double* __restrict__ HsG, double* __restrict__ pnlG,
+                                                                 int panelInLds, int gated) {
+  extern __shared__ double sLd[];   // dblk | y | (the panel copies when they fit)
   __shared__ int sOk;
   const BaDev pb = *pbp;
   if (lm_skip(pb, gated)) return;
-  const int P = pb.P, tid = threadIdx.x;
-  if (useLds) {
-    const int pitch = P + 1;
-    for (int i = tid; i < P * P; i += LD_T) { const int r = i / P, c = i - r * P; sHs[r * pitch + c] = HsG[i]; }
-    for (int i = tid; i < P; i += LD_T) sx[i] = pb.x[i];
-    __syncthreads();
-    const bool ok = ldlt_block(sHs, pitch, P, tid, upanel, sx, &sOk);
-    if (ok) for (int i = tid; i < P; i += LD_T) pb.x[i] = sx[i];
-    if (tid == 0) pb.scal[2] = ok ? 1.0 : 0.0;
-  } else {
-    const bool ok = ldlt_block(HsG, P, P, tid, wsG, pb.x, &sOk);   // large reduced systems stay in global memory
-    if (tid == 0) pb.scal[2] = ok ? 1.0 : 0.0;
-  }
+  double* pnl = panelInLds ? sLd + morbdense::global_lds_doubles(pb.P) : pnlG;
+  const bool ok = morbdense::ldlt_solve_global<false>(HsG, pb.x, pb.x, pb.P, pnl, sLd, &sOk);
+  if (threadIdx.x == 0) pb.scal[2] = ok ? 1.0 : 0.0;
 }
 // the reduced camera system with its lower triangle resident in LDS (dense_ldlt.h); x = Hs^-1 x in place
 __global__ __launch_bounds__(morbdense::LT) void k_g_ldlt_lds(const BaDev* __restrict__ pbp, const double* __restrict__ HsG, int gated) {
@@ -1547,48 +1294,6 @@ __global__ __launch_bounds__(morbdense::LT) void k_g_ldlt_lds(const BaDev* __res
   if (lm_skip(pb, gated)) return;
   const bool ok = morbdense::ldlt_solve<false>(HsG, pb.x, pb.x, pb.P, sLd, &sOk);
   if (threadIdx.x == 0) pb.scal[2] = ok ? 1.0 : 0.0;
-}
-__global__ __launch_bounds__(GB) void k_g_backsub_update(const BaDev* __restrict__ pbp, double lambda, double* __restrict__ part, int gated) {
-  __shared__ double red[4];
-  const BaDev pb = *pbp;
-  if (lm_skip(pb, gated)) return;
-  if (gated) lambda = pb.lmd[LMD_LAMBDA];
-  const int gid = blockIdx.x * GB + threadIdx.x;
-  const int P = pb.P;
-  const bool ok = pb.scal[2] != 0.0;
-  double sc = 0;
-  if (gid < pb.nMP) {
-    const int m = gid;
-    double xl[3] = {0, 0, 0};
-    if (ok) {
-      double cl[3] = {pb.b[P + 3 * m], pb.b[P + 3 * m + 1], pb.b[P + 3 * m + 2]};
-      for (int a = pb.mpStart[m]; a < pb.mpStart[m + 1]; ++a) {
-        const int e = pb.mpEdges[a];
-        const int i1 = pb.kfCol[pb.eKF[e]];
-        if (i1 < 0) continue;
-        const double* B = pb.Hpl + (size_t)e * 18;
-        for (int c = 0; c < 3; ++c)
-          for (int r = 0; r < 6; ++r) cl[c] -= B[r * 3 + c] * pb.x[6 * i1 + r];
-      }
-      const double* Di = pb.Dinv + (size_t)m * 9;
-      for (int r = 0; r < 3; ++r) xl[r] = Di[r * 3] * cl[0] + Di[r * 3 + 1] * cl[1] + Di[r * 3 + 2] * cl[2];
-    }
-    for (int r = 0; r < 3; ++r) {
-      pb.x[P + 3 * m + r] = xl[r];
-      pb.pt[3 * m + r] += xl[r];
-      sc += xl[r] * (lambda * xl[r] + pb.b[P + 3 * m + r]);
-    }
-  }
-  if (gid < pb.nKF) {
-    const int col = pb.kfCol[gid];
-    if (col >= 0) {
-      double u[6];
-      for (int r = 0; r < 6; ++r) { u[r] = ok ? pb.x[6 * col + r] : 0.0; sc += u[r] * (lambda * u[r] + pb.b[6 * col + r]); }
-      store_se3(pb.pose + 7 * gid, se3_mul(se3_exp(u), load_se3(pb.pose + 7 * gid)));
-    }
-  }
-  sc = block_sum_d<4>(sc, red);
-  if (threadIdx.x == 0) part[blockIdx.x] = sc;
 }
 // The same step with the landmark part read from the MFMA operand W (dense rows [3 nMP][Mp], column P = b_l): 16 lanes per point,
 // lane q takes columns q, q + 16, ... of the point's three rows (coalesced 128-byte reads, all in flight at once) and the row sums are
@@ -1633,13 +1338,6 @@ __global__ __launch_bounds__(GB) void k_g_backsub_update_w(const BaDev* __restri
   }
   sc = block_sum_d<4>(sc, red);
   if (threadIdx.x == 0) part[blockIdx.x] = sc;
-}
-__global__ __launch_bounds__(GB) void k_g_pop(const BaDev* __restrict__ pbp, int gated) {
-  const BaDev pb = *pbp;
-  if (gated && pb.lmi[LM_REJECTED] == 0) return;   // (idempotent: a launch queued behind the last decision restores the same backup again)
-  const int gid = blockIdx.x * GB + threadIdx.x;
-  if (gid < pb.nKF * 7) pb.pose[gid] = pb.poseBk[gid];
-  if (gid < pb.nMP * 3) pb.pt[gid] = pb.ptBk[gid];
 }
 __global__ __launch_bounds__(GB) void k_g_finish(const BaDev* __restrict__ pbp, int its, int trials) {
   const BaDev pb = *pbp;
@@ -1712,7 +1410,9 @@ struct morb_ba_problem {
   morbschur::Plan schur;
   size_t nPairEntries = 0;   // (e1, e2) observation pairs of the sparse block-pair Schur form (flop accounting only)
   double* h_scal = nullptr;  // pinned host mirror of scal[0..3]
-  double* d_ldws = nullptr;  // [P][LB] panel scratch of the LDL^T when the reduced system does not fit LDS
+  double* d_ldws = nullptr;  // panel copies of the global-memory LDL^T when they do not fit LDS (dense_ldlt.h: global_panel_doubles)
+  size_t globalLds = 0;      // dynamic LDS of k_g_ldlt_global
+  int panelInLds = 1;
   bool arena = false;        // device memory and pinned words belong to the optimizer handle (one-shot entry points): nothing to free
 };
 
@@ -1873,12 +1573,11 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
       for (int b2 = a + 1; b2 < mpStart[m + 1]; ++b2)
         if (eKF[mpEdges[a]] == eKF[mpEdges[b2]]) { h.dupPairs = 1; break; }
   // block pairs of the reduced camera system and, per pair, the (observation, observation) entries that feed it: operands of the
-  // persistent-workgroup mode and of round 1's VALU Schur form (MORB_SCHUR_VALU=1).  The one-shot entry points always solve in grid
+  // persistent-workgroup mode.  The one-shot entry points always solve in grid
   // mode on the matrix cores, which only needs the number of entries (flop accounting): they skip the lists (0.3 ms of host work, 0.6 MB).
   std::vector<int> pairBlock, pairStart;
   std::vector<int2> pairEntries;
-  static const bool valuSchurEnv = [] { const char* v = getenv("MORB_SCHUR_VALU"); return v && v[0] == '1'; }();
-  const bool wantPairs = valuSchurEnv || !o->arenaCreate;
+  const bool wantPairs = !o->arenaCreate;
   size_t nPairEntriesCount = 0;
   if (!wantPairs) {
     for (int m = 0; m < nMP; ++m) {
@@ -1968,7 +1667,7 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
   h.chunkEnd = (const int*)up(chunkEnd.data(), sizeof(int) * std::max<size_t>(chunkEnd.size(), 1));
   h.kfChunkStart = (const int*)up(kfChunkStart.data(), sizeof(int) * (nKF + 1));
   h.kfPart = (double*)up(nullptr, sizeof(double) * 27 * std::max<size_t>(chunkKF.size(), 1));
-  p->d_ldws = (double*)up(nullptr, sizeof(double) * LB * std::max<size_t>((size_t)h.P, 1));
+  p->d_ldws = (double*)up(nullptr, sizeof(double) * morbdense::global_panel_doubles(std::max(h.P, 1)));
   p->redBlocks = div_up(std::max(std::max(nE, nMP * 16), std::max(nKF * 7, 1)), GB);   // (16 lanes per point in k_g_backsub_update_w)
   h.redPart = (double*)up(nullptr, sizeof(double) * 2 * p->redBlocks);
   h.scal = (double*)up(nullptr, sizeof(double) * 8);
@@ -2051,11 +1750,14 @@ int morb_ba_problem_create(morb_optimizer* o, morb_ba_problem** out, int nKF, co
   p->useLds = (p->ldsBytes <= 136 * 1024 && h.P <= 192) ? 1 : 0;
   if (!p->useLds) p->ldsBytes = 0;
   p->denseLds = sizeof(double) * morbdense::lds_doubles(h.P);
-  if (p->denseLds > 156 * 1024 || h.P < 1 || getenv("MORB_LDLT_R1")) p->denseLds = 0;   // (MORB_LDLT_R1: measurement only, round 1's solver)
+  if (p->denseLds > 156 * 1024 || h.P < 1) p->denseLds = 0;   // larger systems: the global-memory solver
   if (!fail && p->denseLds && hipFuncSetAttribute(reinterpret_cast<const void*>(k_g_ldlt_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) fail = true;
-  if (!fail && p->useLds &&
-      (hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_ba), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024) != hipSuccess ||
-       hipFuncSetAttribute(reinterpret_cast<const void*>(k_g_ldlt), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024) != hipSuccess))
+  p->globalLds = sizeof(double) * (morbdense::global_lds_doubles(std::max(h.P, 1)) + morbdense::global_panel_doubles(std::max(h.P, 1)));
+  p->panelInLds = p->globalLds <= 150 * 1024 ? 1 : 0;
+  if (!p->panelInLds) p->globalLds = sizeof(double) * morbdense::global_lds_doubles(std::max(h.P, 1));
+  if (!fail && !p->denseLds && (p->globalLds > 150 * 1024 ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_g_ldlt_global), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)) fail = true;
+  if (!fail && p->useLds && hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_ba), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024) != hipSuccess)
     fail = true;
   if (fail) {
     for (void* d : p->allocs) (void)hipFree(d);
@@ -2154,9 +1856,7 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
   const int rb = p->redBlocks;
   double* part0 = h.redPart;
   double* part1 = h.redPart + rb;
-  static const bool valuSchur = [] { const char* v = getenv("MORB_SCHUR_VALU"); return v && v[0] == '1'; }();
-  static const bool hostLm = [] { const char* v = getenv("MORB_LM_HOST"); return v && v[0] == '1'; }();
-  if (!hostLm && !valuSchur) {
+  {
     // ---- grid mode, LM control flow on the device: the host queues trial after trial, one trial ahead of the decisions, and
     // stops when the mapped `done` word says so; kernels queued behind the last decision return at once ----
     const int kfBlocks = div_up(std::max(h.nChunks, 1), 4);
@@ -2176,7 +1876,7 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
                          (const double*)h.sW, p->schur.Mp, p->schur.ksteps, p->schur.stepsPerSplit, h.sBlocks, h.sPart, (const int*)(h.lmi + LM_DONE));
       hipLaunchKernelGGL(k_g_schur_finish, dim3(div_up(4 * (h.P * h.P + h.P), GB)), dim3(GB), 0, st, d, 0.0, h.HsG, 1);
       if (p->denseLds) hipLaunchKernelGGL(k_g_ldlt_lds, dim3(1), dim3(morbdense::LT), p->denseLds, st, d, (const double*)h.HsG, 1);
-      else hipLaunchKernelGGL(k_g_ldlt, dim3(1), dim3(LD_T), p->ldsBytes, st, d, h.HsG, p->d_ldws, p->useLds, 1);
+      else hipLaunchKernelGGL(k_g_ldlt_global, dim3(1), dim3(morbdense::GT), p->globalLds, st, d, h.HsG, p->d_ldws, p->panelInLds, 1);
       hipLaunchKernelGGL(k_g_backsub_update_w, dim3(rb), dim3(GB), 0, st, d, part1);
       hipLaunchKernelGGL(k_g_chi2, dim3(rb), dim3(GB), 0, st, d, part0, (const double*)part1, 1);
       MORB_HIP_CHECK(hipGetLastError());
@@ -2184,123 +1884,27 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
       unsigned spins = 0;
       while (!__atomic_load_n(hostw + 5, __ATOMIC_ACQUIRE) && __atomic_load_n(hostw + 4, __ATOMIC_ACQUIRE) < slot + 1 - kAhead) {
         forwardStop();
-        if ((++spins & 0xFFFFu) == 0 && hipStreamQuery(st) == hipSuccess) break;   // (everything queued has run: the words are final)
+        if ((++spins & 0x3FFu) == 0) {
+          const hipError_t q = hipStreamQuery(st);
+          if (q == hipSuccess) break;   // (everything queued has run: the words are final)
+          if (q != hipErrorNotReady) {  // a kernel fault: the words will never change
+            set_error("LocalBundleAdjustment: %s while waiting for the LM decision", hipGetErrorString(q));
+            return MORB_ERR_HIP;
+          }
+        }
+        __builtin_ia32_pause();
       }
       if (__atomic_load_n(hostw + 5, __ATOMIC_ACQUIRE)) break;
     }
     hipLaunchKernelGGL(k_g_finish, dim3(rb), dim3(GB), 0, st, d, -1, -1);
     MORB_HIP_CHECK(hipGetLastError());
+    // slot limit reached without a `done`: decisions of this solve may still be on their way — let them land before the next solve resets
+    // the mirror words (the usual exit has seen `done`, after which no kernel writes them)
+    if (!__atomic_load_n(hostw + 5, __ATOMIC_ACQUIRE)) MORB_HIP_CHECK(hipStreamSynchronize(st));
     return MORB_OK;
   }
-  // ---- grid mode, LM control flow on the host (measurement only: MORB_LM_HOST=1 or MORB_SCHUR_VALU=1; round 2's first form) ----
-  volatile double* hs = p->h_scal;
-  auto readScal = [&]() -> int {
-    MORB_HIP_CHECK(hipMemcpyAsync(p->h_scal, h.scal, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
-    MORB_HIP_CHECK(hipStreamSynchronize(st));
-    return MORB_OK;
-  };
-  auto chi2 = [&]() {
-    hipLaunchKernelGGL(k_g_chi2, dim3(rb), dim3(GB), 0, st, d, part0, (const double*)part1, 0);
-    hipLaunchKernelGGL(k_g_reduce, dim3(1), dim3(GB), 0, st, (const double*)part0, rb, h.scal + 0);
-  };
-  int its = 0, trials = 0;
-  auto stopped = [&]() -> bool { return __atomic_load_n(p->h_stop, __ATOMIC_ACQUIRE) != 0 || (p->userStop && *p->userStop); };
-  if (!stopped()) {
-    chi2();
-    int rc = readScal();
-    if (rc != MORB_OK) return rc;
-    double currentChi = hs[0], lambda = 0, ni = 2;
-    int nBad = 0;
-    hipStream_t s2 = p->opt->side;
-    // buildSystem: per-point blocks (Hll, bl) and per-keyframe blocks (Hpp, bp, Hpl) do not depend on each other
-    auto launchBuilds = [&]() -> int {
-      MORB_HIP_CHECK(hipEventRecord(p->opt->evFork, st));
-      MORB_HIP_CHECK(hipStreamWaitEvent(s2, p->opt->evFork, 0));
-      if (h.rig) hipLaunchKernelGGL(k_g_build_kf<true>, dim3(div_up(std::max(h.nChunks, 1), 4)), dim3(GB), 0, s2, d, 0);
-      else hipLaunchKernelGGL(k_g_build_kf<false>, dim3(div_up(std::max(h.nChunks, 1), 4)), dim3(GB), 0, s2, d, 0);
-      hipLaunchKernelGGL(k_g_kf_reduce, dim3(h.nKF), dim3(64), 0, s2, d, 0);
-      MORB_HIP_CHECK(hipEventRecord(p->opt->evJoin, s2));
-      if (h.rig) hipLaunchKernelGGL(k_g_build_mp<true>, dim3(div_up(h.nMP, GB)), dim3(GB), 0, st, d, 0);
-      else hipLaunchKernelGGL(k_g_build_mp<false>, dim3(div_up(h.nMP, GB)), dim3(GB), 0, st, d, 0);
-      MORB_HIP_CHECK(hipStreamWaitEvent(st, p->opt->evJoin, 0));
-      hipLaunchKernelGGL(k_g_pack_w, dim3(rb), dim3(GB), 0, st, d, 0);
-      return MORB_OK;
-    };
-    bool built = false;   // the next iteration's system is already being built (speculatively, see below)
-    for (int iter = 0; iter < 10 && !stopped(); ++iter) {
-      ++its;
-      const double iniChi = currentChi;
-      if (!built) { rc = launchBuilds(); if (rc != MORB_OK) return rc; }
-      built = false;
-      if (iter == 0) {
-        if (h.userLambda > 0) lambda = h.userLambda;
-        else {
-          hipLaunchKernelGGL(k_g_maxdiag, dim3(1), dim3(GB), 0, st, d);
-          rc = readScal();
-          if (rc != MORB_OK) return rc;
-          lambda = 1e-5 * hs[3];
-        }
-        ni = 2; nBad = 0;
-      }
-      double rho = 0;
-      int qmax = 0;
-      do {
-        hipLaunchKernelGGL(k_g_dinv_push, dim3(rb > div_up(h.P * h.P, GB) ? rb : div_up(h.P * h.P, GB)), dim3(GB), 0, st, d, lambda, h.HsG, valuSchur ? 1 : 0, 0);
-        if (!valuSchur) {
-          // Schur complement of the landmarks (matrix and right-hand side in one product) on the FP64 matrix cores
-          hipLaunchKernelGGL(morbschur::k_schur_mfma, dim3(p->schur.nblk, p->schur.nsplit), dim3(64), 0, st, (const double*)h.sWD,
-                             (const double*)h.sW, p->schur.Mp, p->schur.ksteps, p->schur.stepsPerSplit, h.sBlocks, h.sPart, (const int*)nullptr);
-          hipLaunchKernelGGL(k_g_schur_finish, dim3(div_up(4 * (h.P * h.P + h.P), GB)), dim3(GB), 0, st, d, lambda, h.HsG, 0);
-        } else {
-          // (measurement only, MORB_SCHUR_VALU=1: round 1's per-block-pair VALU form, kept so that profiles/ can show both)
-          MORB_HIP_CHECK(hipEventRecord(p->opt->evFork, st));
-          MORB_HIP_CHECK(hipStreamWaitEvent(s2, p->opt->evFork, 0));
-          hipLaunchKernelGGL(k_g_bschur, dim3(h.nKF), dim3(64), 0, s2, d);
-          MORB_HIP_CHECK(hipEventRecord(p->opt->evJoin, s2));
-          hipLaunchKernelGGL(k_g_schur, dim3(div_up(std::max(h.nPairs, 1), 4)), dim3(GB), 0, st, d, lambda, h.HsG);
-          MORB_HIP_CHECK(hipStreamWaitEvent(st, p->opt->evJoin, 0));
-        }
-        if (p->denseLds) hipLaunchKernelGGL(k_g_ldlt_lds, dim3(1), dim3(morbdense::LT), p->denseLds, st, d, (const double*)h.HsG, 0);
-        else hipLaunchKernelGGL(k_g_ldlt, dim3(1), dim3(LD_T), p->ldsBytes, st, d, h.HsG, p->d_ldws, p->useLds, 0);
-        hipLaunchKernelGGL(k_g_backsub_update, dim3(rb), dim3(GB), 0, st, d, lambda, part1, 0);
-        hipLaunchKernelGGL(k_g_reduce, dim3(1), dim3(GB), 0, st, (const double*)part1, rb, h.scal + 1);
-        chi2();
-        // (building the NEXT iteration's system speculatively before the accept / reject decision returns was measured:
-        // 2.29 vs 2.19 ms per solve — the host round trip is shorter than the extra stream traffic; left off)
-        const bool spec = false;
-        rc = readScal();
-        if (rc != MORB_OK) return rc;
-        double tempChi = hs[0];
-        if (hs[2] == 0.0) tempChi = 1.7976931348623157e308;
-        rho = (currentChi - tempChi) / (hs[1] + 1e-3);
-        if (rho > 0 && std::isfinite(tempChi)) {
-          double alpha = 1. - std::pow((2 * rho - 1), 3);
-          alpha = std::min(alpha, 2. / 3.);
-          lambda *= std::max(1. / 3., alpha);
-          ni = 2;
-          currentChi = tempChi;
-          built = spec;
-        } else {
-          lambda *= ni;
-          ni *= 2;
-          hipLaunchKernelGGL(k_g_pop, dim3(rb), dim3(GB), 0, st, d, 0);
-          if (spec) { rc = launchBuilds(); if (rc != MORB_OK) return rc; }
-        }
-        ++qmax; ++trials;
-      } while (rho < 0 && qmax < 10 && !stopped());
-      if (qmax == 10 || rho == 0) break;
-      if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
-      if (nBad >= 3) break;
-    }
-  }
-  hipLaunchKernelGGL(k_g_finish, dim3(rb), dim3(GB), 0, st, d, its, trials);
-  MORB_HIP_CHECK(hipGetLastError());
-  return MORB_OK;
 }
 
-// Measurement hook for bench.py's LocalBA roofline entry: the Schur product (k_schur_mfma on the operands of the last solve) launched
-// `iters` times between two HIP events on the handle's stream.  flops = the MFMA flops one launch issues (upper 32 x 32 blocks of
-// WD^T W over all landmark rows), usefulFlops = the flops of g2o's sparse block-pair form of the same complement.
 int morb_ba_schur_profile(morb_ba_problem* p, int iters, float* msPerLaunch, double* flops, double* usefulFlops) {
   MORB_REQUIRE(p && iters > 0 && msPerLaunch && flops && usefulFlops, MORB_ERR_INVALID, "bad argument");
   MORB_HIP_CHECK(hipSetDevice(p->opt->device));
