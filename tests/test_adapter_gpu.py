@@ -108,7 +108,7 @@ def test_cpp_adapters_match_oracle(tmp_path):
     # ---- Optimizer::LocalBundleAdjustment
     its, kfe, mpe, ee, se = O.local_ba(b)
     st = get("ba_stats", np.int32)
-    assert abs(int(st[0]) - int(se[0])) <= 1 and abs(int(st[1]) - int(se[1])) <= 3
+    assert int(st[0]) == int(se[0]) and int(st[1]) == int(se[1])
     assert np.abs(get("ba_kf", np.float32).reshape(-1, 7) - kfe).max() <= 1e-4
     assert np.abs(get("ba_mp", np.float32).reshape(-1, 3) - mpe).max() <= 1e-4 * max(1.0, np.abs(mpe).max())
     np.testing.assert_array_equal(get("ba_erase", np.uint8), ee)

@@ -328,7 +328,8 @@ def test_search_by_projection_last_frame_fisheye():
         assert tot > 500 and right > 150
 
 
-@pytest.mark.parametrize("kw", [dict(seed=1), dict(seed=2, n_free=6, n_fixed=2, n_points=500, right_frac=0.7)])
+@pytest.mark.parametrize("kw", [dict(seed=1), dict(seed=2, n_free=6, n_fixed=2, n_points=500, right_frac=0.7),
+                                dict(seed=3, n_free=45, n_fixed=5, n_points=2500)])   # (45 free keyframes: the global-memory LDL^T)
 def test_local_ba_fisheye_matches_oracle(kw):
     """LocalBundleAdjustment on the KB8 rig: EdgeSE3ProjectXYZ (left camera) + EdgeSE3ProjectXYZToBody (right camera
     behind mTrl), both solver modes.  Same tolerances as the pinhole test: poses 1e-4, points 1e-3 relative."""
@@ -338,11 +339,11 @@ def test_local_ba_fisheye_matches_oracle(kw):
     assert 0.2 < b["eRight"].mean() < 0.8
     rig = dict(eRight=b["eRight"], camL=b["camL"], camR=b["camR"], Trl=b["Trl"])
     opt = Optimizer()
-    for inertial, mode in ((False, 0), (True, 0), (False, 1)):
+    for inertial, mode in ((False, 0), (True, 0), (False, 1)) if kw.get("n_free", 10) <= 20 else ((False, 0),):
         kf, mp, erase, stats = opt.LocalBundleAdjustment(b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"],
                                                          b["eInvSigma2"], None, inertial=inertial, mode=mode, rig=rig)
         its, kfe, mpe, ee, se = O.local_ba_fisheye(b, lambda100=inertial)
-        assert abs(int(stats[0]) - int(se[0])) <= 1 and abs(int(stats[1]) - int(se[1])) <= 3, (stats, se)
+        assert int(stats[0]) == int(se[0]) and int(stats[1]) == int(se[1]), (stats, se)
         assert np.abs(kf - kfe).max() <= 1e-4
         assert np.abs(mp - mpe).max() <= 1e-4 * max(1.0, np.abs(mpe).max())
         np.testing.assert_array_equal(erase, ee)   # (the KB8 projection's libm calls are the same restated code on both sides, libm_f32.h)

@@ -66,8 +66,8 @@ def test_pose_inertial_optimization_last_keyframe(opt, n, n_imu, seeds):
         # FP64 Gauss-Newton on both sides; tolerance 1e-4 on the state (north_star's FP bar)
         assert np.allclose(state[i], s_o, rtol=0, atol=1e-4), (i, np.abs(state[i] - s_o).max())
         diff = int((outl[i] != out_o).sum())
-        assert diff <= 1, (i, diff)            # a chi2 within rounding of its threshold may flip
-        assert abs(int(nin[i]) - r) <= 1
+        assert diff == 0, (i, diff)
+        assert int(nin[i]) == r
         assert np.allclose(prior[i][:21], prior_o[:21], atol=1e-6)
         if diff == 0:
             H, Ho = prior[i][21:].reshape(15, 15), prior_o[21:].reshape(15, 15)
@@ -95,8 +95,8 @@ def test_pose_inertial_uses_gpu_preintegration_end_to_end(opt):
     for i, p in enumerate(probs):
         pre_o = orc.imu_preintegrate(p["bias"], nga, walk, p["acc"], p["gyro"], p["dt"])
         r, s_o, out_o, _ = orc.pose_inertial_optimization_last_keyframe(p, pre_o)
-        assert np.allclose(state[i].cpu().numpy(), s_o, atol=2e-4)
-        assert abs(int(nin[i].item()) - r) <= 2
+        assert np.allclose(state[i].cpu().numpy(), s_o, atol=1e-4), np.abs(state[i].cpu().numpy() - s_o).max()
+        assert int(nin[i].item()) == r
 
 
 @pytest.mark.parametrize("n,n_imu,seeds", [(500, 20, range(5)), (60, 10, range(3)), (25, 10, range(3))])
@@ -125,8 +125,8 @@ def test_pose_inertial_optimization_last_frame(opt, n, n_imu, seeds):
         r, s_o, out_o, prior_o = orc.pose_inertial_optimization_last_frame(pB, prevState[i], preF[i], preK[i], prevPrior[i])
         assert np.allclose(state[i], s_o, rtol=0, atol=1e-4), (i, np.abs(state[i] - s_o).max())
         diff = int((outl[i] != out_o).sum())
-        assert diff <= 1, (i, diff)
-        assert abs(int(nin[i]) - r) <= 1
+        assert diff == 0, (i, diff)
+        assert int(nin[i]) == r
         assert np.allclose(prior[i][:21], prior_o[:21], atol=1e-6)
         if diff == 0:
             H, Ho = prior[i][21:].reshape(15, 15), prior_o[21:].reshape(15, 15)
@@ -166,13 +166,15 @@ def test_pose_inertial_chain_on_device(opt):
         o = lambda p, a, g, d: orc.imu_preintegrate(p["bias"], nga, walk, p[a], p[g], p[d])
         rA = orc.pose_inertial_optimization_last_keyframe(pA, o(pA, "acc", "gyro", "dt"))
         rB = orc.pose_inertial_optimization_last_frame(pB, rA[1], o(pB, "accF", "gyroF", "dtF"), o(pB, "acc", "gyro", "dt"), rA[3])
-        assert np.allclose(stateB[i].cpu().numpy(), rB[1], atol=2e-4), np.abs(stateB[i].cpu().numpy() - rB[1]).max()
-        assert abs(int(nin[i].item()) - rB[0]) <= 2
+        assert np.allclose(stateB[i].cpu().numpy(), rB[1], atol=1e-4), np.abs(stateB[i].cpu().numpy() - rB[1]).max()
+        assert int(nin[i].item()) == rB[0]
         H = priorB[i][21:].reshape(15, 15).cpu().numpy()
         assert np.all(np.linalg.eigvalsh((H + H.T) / 2) > 0)
 
 
-@pytest.mark.parametrize("large,n_opt,seeds", [(False, 10, range(3)), (True, 25, range(2)), (False, 4, range(2))])
+# (30 / 45 / 60 optimizable keyframes: 450 / 675 / 900 unknowns — the global-memory LDL^T, from 45 on with its panel copies in global scratch)
+@pytest.mark.parametrize("large,n_opt,seeds", [(False, 10, range(3)), (True, 25, range(2)), (False, 4, range(2)), (True, 30, [7]), (True, 45, [8]),
+                                               (True, 60, [9])])
 def test_local_inertial_ba(opt, large, n_opt, seeds):
     import time
     from morb_slam_amd.synth import make_inertial_ba_problem
@@ -225,7 +227,7 @@ def test_pose_inertial_optimization_fisheye_rig(opt):
     torch.cuda.synchronize()
     for i, r in enumerate(resA):
         assert np.allclose(stateA[i].cpu().numpy(), r[1], atol=1e-4), np.abs(stateA[i].cpu().numpy() - r[1]).max()
-        assert int((outA[i].cpu().numpy() != r[2]).sum()) <= 1 and abs(int(ninA[i]) - r[0]) <= 1
+        assert int((outA[i].cpu().numpy() != r[2]).sum()) == 0 and int(ninA[i]) == r[0]
         H, Ho = priorA[i][21:].reshape(15, 15).cpu().numpy(), r[3][21:].reshape(15, 15)
         if int((outA[i].cpu().numpy() != r[2]).sum()) == 0:
             assert np.allclose(H, Ho, rtol=1e-4, atol=1e-6 * np.abs(Ho).max())
@@ -241,7 +243,7 @@ def test_pose_inertial_optimization_fisheye_rig(opt):
     for i, (_, pB) in enumerate(seq):
         r = orc.pose_inertial_optimization_last_frame(pB, prevState[i], preF[i], preK[i], prevPrior[i])
         assert np.allclose(stateB[i].cpu().numpy(), r[1], atol=1e-4), np.abs(stateB[i].cpu().numpy() - r[1]).max()
-        assert int((outB[i].cpu().numpy() != r[2]).sum()) <= 1 and abs(int(ninB[i]) - r[0]) <= 1
+        assert int((outB[i].cpu().numpy() != r[2]).sum()) == 0 and int(ninB[i]) == r[0]
         assert int(outB[i].sum()) > 0.5 * int((pB["outlier_truth"] & (pB["hasMP"] > 0)).sum())   # planted outliers found on both cameras
 
 
@@ -287,7 +289,7 @@ def test_pose_inertial_edge_cases(opt):
                                                                     ins[6], state, bRecInit=rec, count=ins[7])
         torch.cuda.synchronize()
         assert np.allclose(state[0].cpu().numpy(), rA[1], atol=1e-4), (n, rec, np.abs(state[0].cpu().numpy() - rA[1]).max())
-        assert int((outl[0, :n].cpu().numpy() != rA[2]).sum()) <= 1 and abs(int(nin[0]) - rA[0]) <= 1, (n, rec)
+        assert int((outl[0, :n].cpu().numpy() != rA[2]).sum()) == 0 and int(nin[0]) == rA[0], (n, rec)
         assert not outl[0, n:].any()                  # rows beyond count untouched
         # frame B with the same padding
         preF = orc.imu_preintegrate(pB["bias"], nga, walk, pB["accF"], pB["gyroF"], pB["dtF"])
@@ -300,7 +302,7 @@ def test_pose_inertial_edge_cases(opt):
                                                               insB[6], insB[7], insB[8], stateB, bRecInit=rec, count=ins[7], want_prior=False)
         torch.cuda.synchronize()
         assert np.allclose(stateB[0].cpu().numpy(), rB[1], atol=1e-4), (n, rec, np.abs(stateB[0].cpu().numpy() - rB[1]).max())
-        assert int((outB[0, :n].cpu().numpy() != rB[2]).sum()) <= 1 and abs(int(ninB[0]) - rB[0]) <= 1, (n, rec)
+        assert int((outB[0, :n].cpu().numpy() != rB[2]).sum()) == 0 and int(ninB[0]) == rB[0], (n, rec)
 
 
 def test_local_inertial_ba_variants(opt):
@@ -316,12 +318,12 @@ def test_local_inertial_ba_variants(opt):
         kf, mp, er, st = opt.LocalInertialBA(p["kfState"], p["kfKind"], p["mpPos"], p["mpClose"], p["eKF"], p["eMP"], p["eObs"], p["eInvSigma2"],
                                              p["iKF1"], p["iKF2"], pre, p["iRobust"], p["iInfoScale"], p["cam"], p["Tbc12"], **kw)
         assert int(st[2]) == r
-        assert abs(int(st[0]) - int(st_o[0])) <= 1 and abs(int(st[1]) - int(st_o[1])) <= 3, (st, st_o)
+        assert int(st[0]) == int(st_o[0]) and int(st[1]) == int(st_o[1]), (st, st_o)
         optk = p["kfKind"] == 0
         assert np.allclose(kf[optk], kf_o[optk], rtol=0, atol=1e-4), np.abs(kf[optk] - kf_o[optk]).max()
         d = np.abs(mp - mp_o).max(1) / np.maximum(1.0, np.linalg.norm(mp_o, axis=1))
-        assert np.quantile(d, 0.99) < 1e-4, np.quantile(d, 0.99)
-        assert (er != er_o).sum() <= max(2, len(er) // 1000)
+        assert d.max() < 1e-4, (np.quantile(d, 0.99), d.max())
+        np.testing.assert_array_equal(er, er_o)
         return kf, mp, er
 
     p = make_inertial_ba_problem(n_opt=6, seed=11, n_points=600)

@@ -39,9 +39,9 @@ def test_pose_optimization_matches_oracle():
         assert np.abs(pose[f] - pe).max() <= POSE_TOL, (f, pose[f], pe)
         assert nin[f] == r
         np.testing.assert_array_equal(outl[f, :n], oe)
-        # same LM trajectory: near convergence rho = dChi2/scale is ~0 and its sign can flip with summation
-        # order (SURVEY "hard parts" 6), so allow a couple of extra/missing trials
-        assert abs(int(stats[f][0]) - int(se[0])) <= 1 and abs(int(stats[f][1]) - int(se[1])) <= 3, (stats[f], se)
+        # same LM trajectory: the outer iterations are identical; near convergence rho = dChi2 / scale is ~0 and its sign can flip with
+        # the summation order (SURVEY "hard parts" 6), which costs or saves a trial there (observed: 50 vs 49 trials in one of nine problems)
+        assert int(stats[f][0]) == int(se[0]) and abs(int(stats[f][1]) - int(se[1])) <= 2, (stats[f], se)
         assert np.abs(pose[f] - p["true"]).max() < 0.02   # and it actually converged to the truth
 
 
@@ -53,7 +53,7 @@ def test_pose_optimization_degenerate():
     nin, outl, stats, pose = _run_pose_batch([few, eight])
     assert nin[0] == 0 and np.array_equal(pose[0], few["pose0"])
     r, pe, oe, se = O.pose_optimization(eight)
-    assert nin[1] == r and np.abs(pose[1] - pe).max() <= POSE_TOL and abs(int(stats[1][1]) - int(se[1])) <= 3
+    assert nin[1] == r and np.abs(pose[1] - pe).max() <= POSE_TOL and abs(int(stats[1][1]) - int(se[1])) <= 2
 
 
 @pytest.mark.parametrize("kw", [dict(seed=1), dict(seed=2, n_free=8, n_fixed=3, n_points=500),
@@ -66,12 +66,31 @@ def test_local_ba_matches_oracle(kw):
         kf, mp, erase, stats = opt.LocalBundleAdjustment(b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"],
                                                          b["eInvSigma2"], b["cam"], inertial=inertial, mode=mode)
         its, kfe, mpe, ee, se = O.local_ba(b, lambda100=inertial)
-        assert abs(int(stats[0]) - int(se[0])) <= 1 and abs(int(stats[1]) - int(se[1])) <= 3, (stats, se)
+        assert int(stats[0]) == int(se[0]) and int(stats[1]) == int(se[1]), (stats, se)
         assert np.abs(kf - kfe).max() <= POSE_TOL
         assert np.abs(mp - mpe).max() <= 1e-4 * max(1.0, np.abs(mpe).max())
         np.testing.assert_array_equal(erase, ee)
         nf = int((b["kfFixed"] == 0).sum())
         assert np.abs(kf[:nf] - b["true_poses"][:nf]).max() < 0.05
+
+
+@pytest.mark.parametrize("n_free", [30, 45, 60])
+def test_local_ba_large_windows(n_free):
+    """The reference takes EVERY covisible keyframe (Optimizer.cc:1058-1070, no cap): beyond 29 free keyframes the reduced camera system
+    (6 n > 176 unknowns) no longer fits the LDS-resident LDL^T and is factorised in global memory, one 16-column panel in LDS at a time
+    (dense_ldlt.h: ldlt_solve_global) — same LM path, poses / points within 1e-4, identical erase flags."""
+    from morb_slam_amd import Optimizer
+    b = make_ba_problem(seed=5, n_free=n_free, n_fixed=6, n_points=3000)
+    opt = Optimizer()
+    for inertial in (False, True):
+        kf, mp, erase, stats = opt.LocalBundleAdjustment(b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"], b["eInvSigma2"],
+                                                         b["cam"], inertial=inertial, mode=0)
+        its, kfe, mpe, ee, se = O.local_ba(b, lambda100=inertial)
+        assert int(stats[0]) == int(se[0]) and int(stats[1]) == int(se[1]), (stats, se)
+        assert np.abs(kf - kfe).max() <= POSE_TOL
+        assert np.abs(mp - mpe).max() <= 1e-4 * max(1.0, np.abs(mpe).max())
+        np.testing.assert_array_equal(erase, ee)
+        assert np.abs(kf[:n_free] - b["true_poses"][:n_free]).max() < 0.05
 
 
 def test_local_ba_stop_flag():
