@@ -47,6 +47,8 @@ using namespace morb;
 
 namespace {
 
+constexpr int kTeamMaxImages = 16;   // k_distribute: calls with at most this many images use the team packing of the big levels
+
 __constant__ __align__(16) int c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
@@ -375,12 +377,17 @@ __global__ __launch_bounds__(64 * QT_MAX_WAVES) void k_distribute(const LevelGeo
                                                    int* __restrict__ selCnt, int selPerImg, int nlevels) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int img = blockIdx.x, lane = threadIdx.x & 63;
+  __shared__ int teamSh[16];
   int lvl = -1;
+  const int wvIdx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   {
-    const int grp = blockIdx.y, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int l = 0; l < nlevels; ++l) if (geom[l].distGroup == grp && geom[l].distWave == wv) lvl = l;
+    const int grp = blockIdx.y;
+    // a workgroup holds up to QT_MAX_WAVES levels, a wave each — or ONE level worked by all its waves as a team (quadtree.h)
+    for (int l = 0; l < nlevels; ++l) if (geom[l].distGroup == grp && (geom[l].distTeam || geom[l].distWave == wvIdx)) lvl = l;
   }
   if (lvl < 0) return;   // (wave-uniform: this workgroup packs fewer levels than the launch has waves)
+  morbqt::Team tm;
+  tm.nw = geom[lvl].distTeam ? (int)(blockDim.x >> 6) : 1; tm.tw = geom[lvl].distTeam ? wvIdx : 0; tm.sh = teamSh;
 #ifndef QT_PRIO
 #define QT_PRIO 3
 #endif
@@ -407,23 +414,25 @@ __global__ __launch_bounds__(64 * QT_MAX_WAVES) void k_distribute(const LevelGeo
 
 #ifdef MORB_FAST_TIMING
   unsigned long long d0_ = wall_clock64();
-#define DMARK(k) do { if (lvl == 0 && lane == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_fastPhase[k], now_ - d0_); d0_ = now_; } } while (0)
+#define DMARK(k) do { if (lvl == 0 && lane == 0 && tm.tw == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_fastPhase[k], now_ - d0_); d0_ = now_; } } while (0)
 #else
 #define DMARK(k)
 #endif
   const int* counts = candCnt + (size_t)img * totalCells + g.cellBase;
   int running = 0;
-  for (int c0 = 0; c0 < ncell; c0 += 64) {
-    const int c = c0 + lane;
-    const int n = c < ncell ? counts[c] : 0;
-    int incl = n;
-    MORB_DPP_SCAN(incl, 0, morbwave::op_add);   // inclusive prefix over the wave
-    if (c < ncell) cellOff[c] = running + incl - n;
-    running += __builtin_amdgcn_readlane(incl, 63);
+  if (tm.tw == 0) {
+    for (int c0 = 0; c0 < ncell; c0 += 64) {
+      const int c = c0 + lane;
+      const int n = c < ncell ? counts[c] : 0;
+      int incl = n;
+      MORB_DPP_SCAN(incl, 0, morbwave::op_add);   // inclusive prefix over the wave
+      if (c < ncell) cellOff[c] = running + incl - n;
+      running += __builtin_amdgcn_readlane(incl, 63);
+    }
+    if (lane == 0) { cellOff[ncell] = running; teamSh[11] = running; }
   }
-  const int T = running;
-  if (lane == 0) cellOff[ncell] = T;
-  QT_SYNC();
+  QT_TEAM_SYNC(tm);
+  const int T = tm.nw > 1 ? teamSh[11] : running;
   DMARK(8);
 
   const uint32_t* cbase = cand + ((size_t)img * totalCells + g.cellBase) * (size_t)cellCap;
@@ -435,7 +444,7 @@ __global__ __launch_bounds__(64 * QT_MAX_WAVES) void k_distribute(const LevelGeo
   auto run = [&](uint32_t* keys, uint32_t* tmp) {
     // gather the cells' candidate lists into one array, cell-major: a lane per cell copies its list, QT_GATHER loads in flight per lane
     // (a lane per candidate had to binary-search its cell first: 8 dependent LDS reads in front of every global load, 34 of level 0's 152 us)
-    for (int c0 = 0; c0 < ncell; c0 += 64) {
+    for (int c0 = tm.tw * 64; c0 < ncell; c0 += tm.nw * 64) {
       const int c = c0 + lane;
       const int off = c < ncell ? cellOff[c] : 0;
       const int nc = c < ncell ? cellOff[c + 1] - off : 0;
@@ -449,13 +458,13 @@ __global__ __launch_bounds__(64 * QT_MAX_WAVES) void k_distribute(const LevelGeo
         for (int k = 0; k < QT_GATHER; ++k) if (i0 + k < nc) keys[off + i0 + k] = v[k];
       }
     }
-    QT_SYNC();
+    QT_TEAM_SYNC(tm);
     DMARK(9);
     morbqt::Work w;
     w.keys = keys; w.tmp = tmp; w.nodes = nodes; w.freeIds = freeIds; w.list = list; w.vA = vA; w.vB = vB;
     w.order = order; w.bcnt = bcnt; w.brank = brank;
     w.nodeCap = g.nodeCap; w.listCap = g.listCap;
-    n = morbqt::qt_distribute(w, (uint32_t)T, g.maxBorderX - MINB, g.maxBorderY - MINB, g.quota, out, g.selCap);
+    n = morbqt::qt_distribute(w, (uint32_t)T, g.maxBorderX - MINB, g.maxBorderY - MINB, g.quota, out, g.selCap, tm);
   };
   if (T <= keyCap) {
     run(ldsKeys, ldsTmp);
@@ -463,10 +472,10 @@ __global__ __launch_bounds__(64 * QT_MAX_WAVES) void k_distribute(const LevelGeo
     uint32_t* gk = qtScratch + g.qtOff + (size_t)img * g.qtImg;
     run(gk, gk + g.qtImg / 2);
   }
-  if (lane == 0) selCnt[img * nlevels + lvl] = n < g.selCap ? n : g.selCap;
+  if (lane == 0 && tm.tw == 0) selCnt[img * nlevels + lvl] = n < g.selCap ? n : g.selCap;
   DMARK(10);
 #ifdef MORB_FAST_TIMING
-  if (lvl == 0 && lane == 0) { atomicAdd(&g_fastPhase[11], (unsigned long long)T); atomicAdd(&g_fastPhase[12], (unsigned long long)n); }
+  if (lvl == 0 && lane == 0 && tm.tw == 0) { atomicAdd(&g_fastPhase[11], (unsigned long long)T); atomicAdd(&g_fastPhase[12], (unsigned long long)n); }
 #endif
 }
 
@@ -751,7 +760,7 @@ static int cvRoundF(float v) { return (int)lrintf(v); }
 
 void free_buffers(morb_extractor* e) {
   auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-  F(e->d_geom); F(e->d_tabs); F(e->d_segTab); F(e->d_pyr); F(e->d_blur); F(e->d_cand); F(e->d_qt); F(e->d_sel);
+  F(e->d_geom); F(e->d_geomTeam); F(e->d_tabs); F(e->d_segTab); F(e->d_pyr); F(e->d_blur); F(e->d_cand); F(e->d_qt); F(e->d_sel);
   F(e->d_candCnt); F(e->d_selCnt); F(e->d_kref); F(e->d_lap);
   e->W = e->H = e->nimgCap = 0;
   e->lapLast.clear();
@@ -775,6 +784,8 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
   int cellBase = 0, selBase = 0, blurTileBase = 0;
   e->cellCap = 0; e->maxCells = 0; e->maxNodeCap = 0; e->maxListCap = 0;
   std::vector<FastSeg> segs;
+  LevelGeom teamGeom[kMaxLevels];
+  memset(teamGeom, 0, sizeof teamGeom);
   for (int l = 0; l < L; ++l) {
     LevelGeom& g = e->geom[l];
     memset(&g, 0, sizeof g);
@@ -943,10 +954,37 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     }
     e->distGroups = nb; e->distWaves = 1; e->distSmem = 0;
     for (int b = 0; b < nb; ++b) { e->distWaves = std::max(e->distWaves, binWaves[b]); e->distSmem = std::max(e->distSmem, binFill[b]); }
+    // The packing for calls with few images (one frame at a time: latency, or BASELINE configs[3]'s one 1920 x 1080 frame per GPU): a level
+    // of >= 160 k pixels gets a workgroup of its own whose QT_MAX_WAVES waves work it as a team (quadtree.h), the smaller levels are
+    // packed as above.  A second copy of the geometry carries these assignments.
+    for (int l = 0; l < L; ++l) { teamGeom[l] = e->geom[l]; teamGeom[l].distTeam = 0; }
+    int tb = 0;
+    size_t tFill[kMaxLevels] = {0};
+    int tWaves[kMaxLevels] = {0};
+    e->distSmemTeam = 0;
+    for (int l = 0; l < L; ++l)
+      if ((long long)e->geom[l].w * e->geom[l].h >= 160000) {
+        teamGeom[l].distTeam = 1; teamGeom[l].distGroup = tb; teamGeom[l].distWave = 0; teamGeom[l].distLdsOff = 0;
+        tFill[tb] = need[l]; tWaves[tb] = QT_MAX_WAVES; ++tb;
+      }
+    const int firstPacked = tb;
+    for (int i = 0; i < L; ++i) {
+      const int l = order[i];
+      if (teamGeom[l].distTeam) continue;
+      int b = firstPacked;
+      while (b < tb && !(tWaves[b] < QT_MAX_WAVES && tFill[b] + need[l] <= binCap)) ++b;
+      if (b == tb) ++tb;
+      teamGeom[l].distGroup = b; teamGeom[l].distWave = tWaves[b]++; teamGeom[l].distLdsOff = (int)tFill[b];
+      tFill[b] += need[l];
+    }
+    e->distGroupsTeam = firstPacked > 0 ? tb : 0;   // (no big level: the team launch is not used)
+    for (int b = 0; b < tb; ++b) e->distSmemTeam = std::max(e->distSmemTeam, tFill[b]);
   }
 
   MORB_HIP_CHECK(hipMalloc(&e->d_geom, sizeof(LevelGeom) * kMaxLevels));
   MORB_HIP_CHECK(hipMemcpy(e->d_geom, e->geom, sizeof(LevelGeom) * kMaxLevels, hipMemcpyHostToDevice));
+  MORB_HIP_CHECK(hipMalloc(&e->d_geomTeam, sizeof(LevelGeom) * kMaxLevels));
+  MORB_HIP_CHECK(hipMemcpy(e->d_geomTeam, teamGeom, sizeof(LevelGeom) * kMaxLevels, hipMemcpyHostToDevice));
   for (int l = 0; l < kMaxLevels; ++l) {
     const LevelGeom& g = e->geom[l < L ? l : L - 1];
     e->fastGeom.cellBase[l] = l < L ? g.cellBase : 0x7fffffff;
@@ -973,7 +1011,7 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
   MORB_HIP_CHECK(hipMemset(e->d_selCnt, 0, sizeof(int) * (size_t)nimg * L));
   MORB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), e->umax, sizeof(int) * 16));
   MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_distribute),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->distSmem));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(e->distSmem, e->distSmemTeam)));
   {
     // k_fastw: the LDS pitch of a wave's window = the widest segment window, rounded up to whole 16-px blocks
     int twMax = 0;
@@ -1198,8 +1236,12 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   // the quadtree is enqueued first so that its long-running waves get their slots before the blur fills the chip;
   // the workgroups with level 0 (the longest wave) first: grid x = image, y = group of levels
   // (which of the two is enqueued first makes no difference: measured both ways)
-  hipLaunchKernelGGL(k_distribute, dim3(nimg, e->distGroups), dim3(64 * e->distWaves), e->distSmem, st, e->d_geom, e->d_cand, e->d_candCnt,
-                     e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L);
+  if (nimg <= kTeamMaxImages && e->distGroupsTeam > 0)   // few images: latency matters, the big levels are worked by teams of waves
+    hipLaunchKernelGGL(k_distribute, dim3(nimg, e->distGroupsTeam), dim3(64 * QT_MAX_WAVES), e->distSmemTeam, st, e->d_geomTeam, e->d_cand, e->d_candCnt,
+                       e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L);
+  else
+    hipLaunchKernelGGL(k_distribute, dim3(nimg, e->distGroups), dim3(64 * e->distWaves), e->distSmem, st, e->d_geom, e->d_cand, e->d_candCnt,
+                       e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L);
   hipStream_t sideStream = e->sideStream;
   MORB_HIP_CHECK(hipStreamWaitEvent(sideStream, e->evFork, 0));
   if (evs) (void)hipEventRecord(evs[6], sideStream);

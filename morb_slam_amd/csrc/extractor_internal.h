@@ -34,6 +34,7 @@ struct LevelGeom {
   // k_distribute packs several levels of an image into one workgroup, a wave per level: the workgroup (group) and wave of this
   // level, the byte offset of its LDS region inside the workgroup's allocation, and the candidate keys its LDS arrays hold
   int distGroup, distWave, distLdsOff, distKeyCap;
+  int distTeam;                         // all waves of the workgroup work this level as a team (quadtree.h: Team)
 };
 
 // What k_fastw needs of every level, passed by value: the kernarg segment is read with scalar loads, so looking a
@@ -86,6 +87,9 @@ struct morb_extractor {
   size_t pyrBytes = 0, blurBytes = 0, qtElems = 0, distSmem = 0, fastSmem[2] = {0, 0};
   int distKeyCap = 0;                        // candidate keys of level 0 that fit the quadtree's LDS arrays (smaller levels: scaled by area)
   int distGroups = 0, distWaves = 1;         // k_distribute grid: workgroups per image, waves per workgroup
+  // the same for calls with few images (latency): the big levels are worked by a team of QT_MAX_WAVES waves each
+  int distGroupsTeam = 0; size_t distSmemTeam = 0;
+  morb::LevelGeom* d_geomTeam = nullptr;
 
   hipStream_t stream = nullptr;
   hipStream_t sideStream = nullptr;          // the blur runs here, underneath the quadtree (fork after FAST, join before describe)

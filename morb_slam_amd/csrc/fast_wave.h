@@ -45,7 +45,10 @@ extern "C" int morb_fw_stats(unsigned long long* out, int reset) {
 constexpr int FW_QCAP = 320;   // survivor queue: < 64 left over + 256 of a reject round's flags (a fuller round is queued in several pieces)
 constexpr int FW_CQ = 512;     // corner list of a pass (~50 per cell on the benchmark images); more -> strip mode
 constexpr int FW_KC = 64;      // keypoint list of a cell (~10); more -> strip mode
-constexpr int FW_WAVES = 4;    // cells (waves) per workgroup
+#ifndef MORB_FW_WAVES
+#define MORB_FW_WAVES 4
+#endif
+constexpr int FW_WAVES = MORB_FW_WAVES;    // cells (waves) per workgroup
 template <int P> __host__ __device__ constexpr int fw_region_bytes(int rows) {   // LDS of one wave
   return (rows * P + 16) + FW_QCAP * 2 + FW_CQ * 2 + FW_CQ + FW_KC * 4 + MORB_FW_PADLDS;
 }
@@ -54,7 +57,7 @@ struct FwPixMask { unsigned m[17]; constexpr FwPixMask() : m() { unsigned a = 0;
 __constant__ FwPixMask c_fwPixMask = FwPixMask();
 
 template <int P>
-__global__ __launch_bounds__(64 * FW_WAVES, 8) void k_fastw(const morb::FastGeom fg, const morb::FastSeg* __restrict__ segTab, int nSeg,
+__global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW_WAVES * 8 + 3) / 4) void k_fastw(const morb::FastGeom fg, const morb::FastSeg* __restrict__ segTab, int nSeg,
                                                             const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
                                                             int* __restrict__ candCnt, int totalCells, int cellCap, int rows, int iniTh, int minTh) {
   constexpr int BPR = P / 16;   // 16-px blocks per window row

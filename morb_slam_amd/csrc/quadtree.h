@@ -92,6 +92,21 @@ QT_HD int qt_list_cap(int nodeCap) { return 2 * nodeCap; }
   } while (0)
 #endif
 
+// A level may be worked by a TEAM of QT_MAX_WAVES waves (a whole workgroup; used for the big levels of a few images: one wave per
+// (image, level) leaves a 1920 x 1080 level-0 quadtree at 0.7 ms).  The splits of one sweep are independent of each other, so the
+// team divides a sweep's nodes among its waves — every wave still partitions the nodes it owns with the wave-level code below —
+// and only the order-dependent steps (list compaction, ranks of the children, the std::sort emulation) stay with wave 0.  Between the
+// phases the waves meet at workgroup barriers and exchange the wave-uniform state through a few LDS words.
+struct Team {
+  int nw, tw;   // waves in the team (1: the level has a single wave, no workgroup barrier is ever executed), this wave's index
+  int* sh;      // [16] shared words (LDS)
+};
+#if QT_DEVICE
+#define QT_TEAM_SYNC(t) do { if ((t).nw > 1) __syncthreads(); else QT_SYNC(); } while (0)
+#else
+#define QT_TEAM_SYNC(t) do { } while (0)
+#endif
+
 // ---- wave-cooperative primitives ---------------------------------------------------------------------
 
 // Stable partition of keys[begin, begin+count) into G (<= 4) groups given by cls(key) in group order;
@@ -562,13 +577,15 @@ __device__ __forceinline__ void qt_write_children(Work& w, const Node& nd, int m
 }
 
 // Splits w.order[0..m) in that order; cutoffN >= 0: stop after the split that makes s.size >= cutoffN.
-__device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int* nToExpand) {
+__device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int* nToExpand, const Team& tm) {
   const int lane = QT_LANE;
-  QT_SYNC();
+  const int estart = tm.tw * 64, estep = tm.nw * 64;
+  // the team's waves take the sweep's nodes interleaved (node e -> wave e % nw): the first sweeps have a handful of huge nodes, one wave each
+  QT_TEAM_SYNC(tm);
   QT_T0();
   // (1) keys per child
-  for (int e0 = 0; e0 < m; e0 += 64) {
-    const int e = e0 + lane;
+  for (int q0 = 0; q0 * tm.nw < m; q0 += 64) {
+    const int e = (q0 + lane) * tm.nw + tm.tw;
     const bool valid = e < m;
     Node nd = {};
     if (valid) nd = w.nodes[w.order[e]];
@@ -583,7 +600,8 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
     while (big) {
       const int bl = __ffsll((unsigned long long)big) - 1;
       big &= big - 1;
-      const Node nb = w.nodes[w.order[e0 + bl]];
+      const int eb = (q0 + bl) * tm.nw + tm.tw;
+      const Node nb = w.nodes[w.order[eb]];
       const int mx = nb.x0 + ((nb.x1 - nb.x0 + 1) >> 1), my = nb.y0 + ((nb.y1 - nb.y0 + 1) >> 1);
       uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
       for (uint32_t i = 0; i < nb.count; i += 64) {
@@ -592,13 +610,14 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
         c0 += __popcll(__ballot(g == 0)); c1 += __popcll(__ballot(g == 1));
         c2 += __popcll(__ballot(g == 2)); c3 += __popcll(__ballot(g == 3));
       }
-      if (lane == 0) w.bcnt[e0 + bl] = (uint64_t)c0 | ((uint64_t)c1 << 16) | ((uint64_t)c2 << 32) | ((uint64_t)c3 << 48);
+      if (lane == 0) w.bcnt[eb] = (uint64_t)c0 | ((uint64_t)c1 << 16) | ((uint64_t)c2 << 32) | ((uint64_t)c3 << 48);
     }
   }
-  QT_SYNC();
+  QT_TEAM_SYNC(tm);
   QT_MARK(16);
-  // (2) ranks in processing order, and where to stop
+  // (2) ranks in processing order, and where to stop (wave 0 of a team; the totals reach the others through tm.sh)
   int runCh = 0, runEx = 0, runSize = s.size, mProc = m;
+  if (tm.tw == 0) {
   for (int e0 = 0; e0 < m; e0 += 64) {
     const int e = e0 + lane;
     const uint64_t c = e < m ? w.bcnt[e] : 0ull;
@@ -616,12 +635,15 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
     runCh += __builtin_amdgcn_readlane(incCh, last); runEx += __builtin_amdgcn_readlane(incEx, last); runSize += __builtin_amdgcn_readlane(incSz, last);   // (last is wave-uniform)
     if (cut) break;
   }
-  QT_SYNC();
+  if (tm.nw > 1 && lane == 0) { tm.sh[0] = runCh; tm.sh[1] = runEx; tm.sh[2] = mProc; }
+  }
+  QT_TEAM_SYNC(tm);
+  if (tm.nw > 1) { runCh = tm.sh[0]; runEx = tm.sh[1]; mProc = tm.sh[2]; }
   QT_MARK(17);
   // (3) partition the keys, write the children, erase the parents
   const int oldHead = s.head, nA0 = s.nA, nFree0 = s.nFree;
-  for (int e0 = 0; e0 < mProc; e0 += 64) {
-    const int e = e0 + lane;
+  for (int q0 = 0; q0 * tm.nw < mProc; q0 += 64) {
+    const int e = (q0 + lane) * tm.nw + tm.tw;
     const bool valid = e < mProc;
     Node nd = {};
     uint64_t c = 0;
@@ -648,27 +670,28 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
     while (big) {
       const int bl = __ffsll((unsigned long long)big) - 1;
       big &= big - 1;
-      const Node nb = w.nodes[w.order[e0 + bl]];
+      const int eb = (q0 + bl) * tm.nw + tm.tw;
+      const Node nb = w.nodes[w.order[eb]];
       const int bmx = nb.x0 + ((nb.x1 - nb.x0 + 1) >> 1), bmy = nb.y0 + ((nb.y1 - nb.y0 + 1) >> 1);
       uint32_t cnt[4];
       qt_partition(w.keys, w.tmp, nb.begin, nb.count, [bmx, bmy](uint32_t k) -> int { return qt_class(k, bmx, bmy); }, cnt);
-      const uint64_t bc = w.bcnt[e0 + bl];
-      const uint32_t brk = w.brank[e0 + bl];
+      const uint64_t bc = w.bcnt[eb];
+      const uint32_t brk = w.brank[eb];
       if (lane < 4) qt_write_children(w, nb, bmx, bmy, bc, brk, oldHead, nA0, nFree0, lane);
       if (lane == 0) w.list[nb.lit] = 0xFFFF;
     }
   }
-  QT_SYNC();
+  QT_TEAM_SYNC(tm);
   QT_MARK(18);
-  // (4) bookkeeping; the parents' ids go back on the free stack after every child id has been taken
+  // (4) bookkeeping (every wave of a team computes the same state); the parents' ids go back on the free stack after every child id has been taken
   s.head = oldHead - runCh;
   s.size += runCh - mProc;
   s.nA = nA0 + runEx;
   if (nToExpand) *nToExpand += runEx;
   s.nFree = nFree0 - runCh;
-  for (int e = lane; e < mProc; e += 64) w.freeIds[s.nFree + e] = w.order[e];
+  for (int e = estart + lane; e < mProc; e += estep) w.freeIds[s.nFree + e] = w.order[e];
   s.nFree += mProc;
-  QT_SYNC();
+  QT_TEAM_SYNC(tm);
   QT_MARK(19);
 }
 #endif
@@ -708,29 +731,38 @@ QT_HD void qt_compact(Work& w, State& s) {
 }
 
 // keys[0..nkeys) hold vToDistributeKeys in order.  Writes the selected keys (reference output order) to
-// out[] and returns their number.  width = maxX-minX, height = maxY-minY.
-QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, uint32_t* out, int outCap) {
+// out[] and returns their number.  width = maxX-minX, height = maxY-minY.  tm: the team of waves working this level (device; see Team).
+QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, uint32_t* out, int outCap, const Team& tm = Team{1, 0, nullptr}) {
   // nIni = round((float)width / height); hX = (float)width / nIni   (:545-547)
   const float ratio = (float)width / (float)height;
   const int nIni = (int)roundf(ratio);
   if (nIni <= 0 || nIni > 4 || nkeys == 0) return 0;
   const float hX = (float)width / (float)nIni;
+  const bool w0 = tm.tw == 0;   // the wave that performs the order-dependent steps and every single-lane store
 
   State s;
   s.head = w.listCap;
   s.size = 0;
   s.nA = 0;
   s.nFree = w.nodeCap;
-  for (int i = QT_LANE; i < w.nodeCap; i += (QT_DEVICE ? 64 : 1)) w.freeIds[i] = (uint16_t)(w.nodeCap - 1 - i);
-  QT_SYNC();
+  for (int i = (QT_DEVICE ? tm.tw * 64 + QT_LANE : 0); i < w.nodeCap; i += (QT_DEVICE ? 64 * tm.nw : 1)) w.freeIds[i] = (uint16_t)(w.nodeCap - 1 - i);
+  QT_TEAM_SYNC(tm);
 
   // initial nodes, pushed BACK in order i = 0..nIni-1 (:555-567); keys go to node (int)(x / hX) (:570-573);
   // empty initial nodes are erased (:577-585).  nIni <= 4 (aspect ratio < 4.5:1) is enforced by the caller.
   {
     uint32_t cnt[4] = {0, 0, 0, 0};
     const int last = nIni - 1;
-    qt_partition(w.keys, w.tmp, 0, nkeys,
-                 [hX, last](uint32_t k) -> int { int g = (int)((float)key_x(k) / hX); return g > last ? last : g; }, cnt);
+    if (w0) {
+      qt_partition(w.keys, w.tmp, 0, nkeys,
+                   [hX, last](uint32_t k) -> int { int g = (int)((float)key_x(k) / hX); return g > last ? last : g; }, cnt);
+#if QT_DEVICE
+      if (tm.nw > 1 && QT_LANE0) for (int i = 0; i < 4; ++i) tm.sh[4 + i] = (int)cnt[i];
+#endif
+    }
+#if QT_DEVICE
+    if (tm.nw > 1) { __syncthreads(); for (int i = 0; i < 4; ++i) cnt[i] = (uint32_t)tm.sh[4 + i]; }
+#endif
     int live = 0;
     for (int i = 0; i < nIni; ++i) live += cnt[i] > 0 ? 1 : 0;
     s.head = w.listCap - live;
@@ -740,7 +772,7 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
     for (int i = 0; i < nIni; ++i) {
       if (cnt[i] > 0) {
         const int id = qt_alloc(w, s);
-        if (QT_LANE0) {
+        if (QT_LANE0 && w0) {
           Node nd;
           nd.x0 = (int16_t)(int)(hX * (float)i);
           nd.x1 = (int16_t)(int)(hX * (float)(i + 1));
@@ -754,25 +786,21 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
       }
       begin += cnt[i];
     }
-    QT_SYNC();
+    QT_TEAM_SYNC(tm);
   }
 
   bool bFinish = false;
   QT_T0();
   while (!bFinish) {
-    qt_compact(w, s);
-    QT_MARK(13);
-    const int prevSize = s.size;
-    int nToExpand = 0;
-    s.nA = 0;
-    const int oldHead = s.head;
 #if QT_DEVICE
-    // the sweep visits the list from oldHead on (children are pushed in front of it: not visited) and divides every
-    // node that is not bNoMore, with no early exit (:589-655): collect them in list order, then split them at once
-    {
-      int m = 0;
+    // the sweep visits the list from the (compacted) head on — children are pushed in front of it: not visited — and divides every
+    // node that is not bNoMore, with no early exit (:589-655): collect them in list order (wave 0), then split them at once (the team)
+    int m = 0;
+    if (w0) {
+      qt_compact(w, s);
+      QT_MARK(13);
       const uint64_t lt = QT_LANE == 0 ? 0ull : (~0ull >> (64 - QT_LANE));
-      for (int pos0 = oldHead; pos0 < w.listCap; pos0 += 64) {
+      for (int pos0 = s.head; pos0 < w.listCap; pos0 += 64) {
         const int pos = pos0 + QT_LANE;
         int id = 0xFFFF;
         bool todo = false;
@@ -784,9 +812,19 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
         if (todo) w.order[m + __popcll(mk & lt)] = (uint16_t)id;
         m += __popcll(mk);
       }
-      qt_split_batch(w, s, m, -1, &nToExpand);
+      if (tm.nw > 1 && QT_LANE0) { tm.sh[8] = s.head; tm.sh[9] = m; }
     }
+    if (tm.nw > 1) { __syncthreads(); s.head = tm.sh[8]; m = tm.sh[9]; }
+    const int prevSize = s.size;
+    int nToExpand = 0;
+    s.nA = 0;
+    qt_split_batch(w, s, m, -1, &nToExpand, tm);
 #else
+    qt_compact(w, s);
+    const int prevSize = s.size;
+    int nToExpand = 0;
+    s.nA = 0;
+    const int oldHead = s.head;
     for (int pos = oldHead; pos < w.listCap; ++pos) {  // children are pushed in front of oldHead: not visited
       const uint16_t id = w.list[pos];
       if (id == 0xFFFF) continue;
@@ -802,23 +840,26 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
         const int prevSize2 = s.size;
         // vPrev = vSize; vSize.clear(); sort(vPrev)
         const int nPrev = s.nA;
-        QT_SYNC();
-        for (int i = QT_LANE; i < nPrev; i += (QT_DEVICE ? 64 : 1)) w.vB[i] = w.vA[i];
-        QT_SYNC();
         s.nA = 0;
-        QT_MARK(14);
 #if QT_DEVICE
-        qt_std_sort_wave(w.vB, w.vA, nPrev, w.order, (uint16_t*)w.brank);   // vA was just cleared: free as scratch until the splits below refill it
+        if (w0) {
+          QT_SYNC();
+          for (int i = QT_LANE; i < nPrev; i += 64) w.vB[i] = w.vA[i];
+          QT_SYNC();
+          QT_MARK(14);
+          qt_std_sort_wave(w.vB, w.vA, nPrev, w.order, (uint16_t*)w.brank);   // vA was just cleared: free as scratch until the splits below refill it
+          QT_MARK(15);
+          // compaction keeps ids stable (vB holds ids), only Node::lit moves
+          qt_compact(w, s);
+          for (int j = QT_LANE; j < nPrev; j += 64) w.order[j] = (uint16_t)(w.vB[nPrev - 1 - j] & 0xFFFF);   // largest first
+          if (tm.nw > 1 && QT_LANE0) tm.sh[8] = s.head;
+        }
+        if (tm.nw > 1) { __syncthreads(); s.head = tm.sh[8]; }
+        qt_split_batch(w, s, nPrev, N, nullptr, tm);
 #else
+        for (int i = 0; i < nPrev; ++i) w.vB[i] = w.vA[i];
         qt_std_sort(w.vB, nPrev);
-#endif
-        QT_MARK(15);
-        // compaction keeps ids stable (vB holds ids), only Node::lit moves
         qt_compact(w, s);
-#if QT_DEVICE
-        for (int j = QT_LANE; j < nPrev; j += 64) w.order[j] = (uint16_t)(w.vB[nPrev - 1 - j] & 0xFFFF);   // largest first
-        qt_split_batch(w, s, nPrev, N, nullptr);
-#else
         for (int j = nPrev - 1; j >= 0; --j) {
           const int id = (int)(w.vB[j] & 0xFFFF);
           qt_split(w, s, id, nullptr);
@@ -831,20 +872,31 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
   }
 
   // retain the best point in each node, list order (:716-737)
-  QT_SYNC();
+  QT_TEAM_SYNC(tm);
   QT_MARK(14);
   int nOut = 0;
 #if QT_DEVICE
-  // one node per lane (most nodes hold a handful of keys); nodes with many keys are finished by the whole wave
-  for (int pos0 = s.head; pos0 < w.listCap; pos0 += 64) {
-    const int pos = pos0 + QT_LANE;
-    int id = 0xFFFF;
-    if (pos < w.listCap) id = w.list[pos];
-    const bool live = id != 0xFFFF;
-    const uint64_t m = __ballot(live);
-    const int rank = nOut + __popcll(m & (QT_LANE == 0 ? 0ull : (~0ull >> (64 - QT_LANE))));
+  // wave 0 lists the live nodes in list order; then one node per lane over the whole team (most nodes hold a handful of keys),
+  // nodes with many keys are finished by the whole wave that owns them
+  if (w0) {
+    const uint64_t lt = QT_LANE == 0 ? 0ull : (~0ull >> (64 - QT_LANE));
+    for (int pos0 = s.head; pos0 < w.listCap; pos0 += 64) {
+      const int pos = pos0 + QT_LANE;
+      int id = 0xFFFF;
+      if (pos < w.listCap) id = w.list[pos];
+      const uint64_t mlive = __ballot(id != 0xFFFF);
+      if (id != 0xFFFF) w.order[nOut + __popcll(mlive & lt)] = (uint16_t)id;
+      nOut += __popcll(mlive);
+    }
+    if (tm.nw > 1 && QT_LANE0) tm.sh[10] = nOut;
+  }
+  QT_TEAM_SYNC(tm);
+  if (tm.nw > 1) nOut = tm.sh[10];
+  for (int q0 = 0; q0 * tm.nw < nOut; q0 += 64) {
+    const int rank = (q0 + QT_LANE) * tm.nw + tm.tw;
+    const bool live = rank < nOut;
     uint32_t begin = 0, count = 0;
-    if (live) { begin = w.nodes[id].begin; count = w.nodes[id].count; }
+    if (live) { const int id = w.order[rank]; begin = w.nodes[id].begin; count = w.nodes[id].count; }
     const bool big = live && count > 32;
     if (live && !big) {
       uint32_t bk = w.keys[begin];
@@ -856,10 +908,9 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
       const int b = __ffsll((unsigned long long)mb) - 1;
       mb &= mb - 1;
       const uint32_t bk = qt_best_key(w.keys, (uint32_t)__builtin_amdgcn_readlane((int)begin, b), (uint32_t)__builtin_amdgcn_readlane((int)count, b));
-      const int r = __builtin_amdgcn_readlane(rank, b);
+      const int r = (q0 + b) * tm.nw + tm.tw;
       if (QT_LANE0 && r < outCap) out[r] = bk;
     }
-    nOut += __popcll(m);
   }
 #else
   for (int pos = s.head; pos < w.listCap; ++pos) {
@@ -871,7 +922,7 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
     ++nOut;
   }
 #endif
-  QT_SYNC();
+  QT_TEAM_SYNC(tm);
   return nOut;
 }
 

@@ -220,3 +220,23 @@ def test_input_ending_on_a_page_boundary():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "native", "extract_once.py"), "512", "512", "1500", "32", "1"],
                        cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_quadtree_team_and_single_wave_packings_agree():
+    # k_distribute has two packings of an image's levels into workgroups: calls with <= 16 images give every level of >= 160 k pixels a
+    # team of four waves (latency), larger batches keep one wave per (image, level).  Every other test here runs the first; this one
+    # runs both on the same images and requires the same bytes — and the oracle's.
+    import torch
+    from morb_slam_amd import KP_DTYPE
+    g, o = _extractors(1200)
+    imgs = np.stack([make_image(752, 480, seed=80 + (i % 3)) for i in range(20)])
+    exp = [o(imgs[i]) for i in range(3)]
+    for n in (20, 3):   # 20 images: single-wave packing; 3: teams
+        kps, desc, cnt, mono = g.extract_batch(torch.from_numpy(imgs[:n]).cuda())
+        torch.cuda.synchronize()
+        cnt = cnt.cpu().numpy(); kps = kps.cpu().numpy(); desc = desc.cpu().numpy()
+        for i in range(n):
+            mo, ko, do = exp[i % 3]
+            assert cnt[i] == len(ko), (n, i)
+            assert kps[i, :cnt[i]].reshape(-1).view(KP_DTYPE).tobytes() == ko.tobytes(), (n, i)
+            np.testing.assert_array_equal(desc[i, :cnt[i]], do)
