@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64 * QT_MAX_WAVES) void k_distribute(const LevelGeo
                                                    int* __restrict__ selCnt, int selPerImg, int nlevels) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int img = blockIdx.x, lane = threadIdx.x & 63;
-  __shared__ int teamSh[16];
+  __shared__ int teamSh[32];
   int lvl = -1;
   const int wvIdx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   {

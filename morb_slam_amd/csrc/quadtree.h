@@ -31,7 +31,7 @@ __device__ unsigned long long g_fastPhase[32];   // phase clocks of tools/fast_p
 #endif
 #if defined(MORB_FAST_TIMING) && QT_DEVICE
 #define QT_T0() unsigned long long q0_ = wall_clock64()
-#define QT_MARK(k) do { if (QT_LANE0 && blockIdx.y == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_fastPhase[k], now_ - q0_); q0_ = now_; } } while (0)
+#define QT_MARK(k) do { if (threadIdx.x == 0 && blockIdx.y == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_fastPhase[k], now_ - q0_); q0_ = now_; } } while (0)
 #else
 #define QT_T0()
 #define QT_MARK(k)
@@ -99,7 +99,7 @@ QT_HD int qt_list_cap(int nodeCap) { return 2 * nodeCap; }
 // phases the waves meet at workgroup barriers and exchange the wave-uniform state through a few LDS words.
 struct Team {
   int nw, tw;   // waves in the team (1: the level has a single wave, no workgroup barrier is ever executed), this wave's index
-  int* sh;      // [16] shared words (LDS)
+  int* sh;      // [32] shared words (LDS): 0-11 state exchanged between phases, 16-31 per-wave slice counts of the team partition
 };
 #if QT_DEVICE
 #define QT_TEAM_SYNC(t) do { if ((t).nw > 1) __syncthreads(); else QT_SYNC(); } while (0)
@@ -111,20 +111,24 @@ struct Team {
 
 // Stable partition of keys[begin, begin+count) into G (<= 4) groups given by cls(key) in group order;
 // returns the group sizes in cnt[].  All lanes call this convergently.
+// (device) knownCnt: cnt[] already holds the group sizes (the batch split counted them in its first phase): the counting pass is skipped.
 template <typename Cls>
-QT_HD void qt_partition(uint32_t* keys, uint32_t* tmp, uint32_t begin, uint32_t count, Cls cls, uint32_t cnt[4]) {
+QT_HD void qt_partition(uint32_t* keys, uint32_t* tmp, uint32_t begin, uint32_t count, Cls cls, uint32_t cnt[4], bool knownCnt = false) {
 #if QT_DEVICE
   const int lane = QT_LANE;
-  uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-  for (uint32_t i = 0; i < count; i += 64) {
-    int g = -1;
-    if (i + lane < count) g = cls(keys[begin + i + lane]);
-    c0 += __popcll(__ballot(g == 0));
-    c1 += __popcll(__ballot(g == 1));
-    c2 += __popcll(__ballot(g == 2));
-    c3 += __popcll(__ballot(g == 3));
+  uint32_t c0 = cnt[0], c1 = cnt[1], c2 = cnt[2], c3 = cnt[3];
+  if (!knownCnt) {
+    c0 = c1 = c2 = c3 = 0;
+    for (uint32_t i = 0; i < count; i += 64) {
+      int g = -1;
+      if (i + lane < count) g = cls(keys[begin + i + lane]);
+      c0 += __popcll(__ballot(g == 0));
+      c1 += __popcll(__ballot(g == 1));
+      c2 += __popcll(__ballot(g == 2));
+      c3 += __popcll(__ballot(g == 3));
+    }
+    cnt[0] = c0; cnt[1] = c1; cnt[2] = c2; cnt[3] = c3;
   }
-  cnt[0] = c0; cnt[1] = c1; cnt[2] = c2; cnt[3] = c3;
   uint32_t b0 = 0, b1 = c0, b2 = c0 + c1, b3 = c0 + c1 + c2;
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (uint32_t i = 0; i < count; i += 64) {
@@ -152,6 +156,63 @@ QT_HD void qt_partition(uint32_t* keys, uint32_t* tmp, uint32_t begin, uint32_t 
   for (int g = 0; g < 4; ++g) cnt[g] = c[g];
 #endif
 }
+
+#if QT_DEVICE
+constexpr uint32_t QT_HUGE = 2048;   // nodes with more keys are partitioned by the whole team together (the first sweeps of a large level)
+// Group sizes of keys[begin, begin + count) by the whole team (all waves call this convergently): wave tw counts the tw-th slice;
+// tm.sh[16 + 4 w + g] = keys of group g in wave w's slice, cnt[] = the totals.  Ends with the slice counts still valid in tm.sh.
+template <typename Cls>
+__device__ inline void qt_count_team(const uint32_t* keys, uint32_t begin, uint32_t count, Cls cls, uint32_t cnt[4], const Team& tm, uint32_t* lo_, uint32_t* hi_) {
+  const int lane = QT_LANE;
+  const uint32_t per = ((count + tm.nw * 64 - 1) / (tm.nw * 64)) * 64;
+  const uint32_t lo = per * tm.tw < count ? per * tm.tw : count, hi = lo + per < count ? lo + per : count;
+  uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  for (uint32_t i = lo; i < hi; i += 64) {
+    int g = -1;
+    if (i + lane < hi) g = cls(keys[begin + i + lane]);
+    c0 += __popcll(__ballot(g == 0)); c1 += __popcll(__ballot(g == 1));
+    c2 += __popcll(__ballot(g == 2)); c3 += __popcll(__ballot(g == 3));
+  }
+  if (lane == 0) { int* o = tm.sh + 16 + 4 * tm.tw; o[0] = (int)c0; o[1] = (int)c1; o[2] = (int)c2; o[3] = (int)c3; }
+  __syncthreads();
+  for (int g = 0; g < 4; ++g) { uint32_t t = 0; for (int wv = 0; wv < tm.nw; ++wv) t += (uint32_t)tm.sh[16 + 4 * wv + g]; cnt[g] = t; }
+  *lo_ = lo; *hi_ = hi;
+}
+// Stable partition by the whole team; same result as qt_partition.
+template <typename Cls>
+__device__ inline void qt_partition_team(uint32_t* keys, uint32_t* tmp, uint32_t begin, uint32_t count, Cls cls, uint32_t cnt[4], const Team& tm) {
+  const int lane = QT_LANE;
+  uint32_t lo, hi;
+  qt_count_team(keys, begin, count, cls, cnt, tm, &lo, &hi);
+  // this wave's first slot in every group = the groups before it + the earlier slices' keys of the group
+  uint32_t b[4];
+  uint32_t gb = 0;
+  for (int g = 0; g < 4; ++g) {
+    uint32_t before = 0;
+    for (int wv = 0; wv < tm.tw; ++wv) before += (uint32_t)tm.sh[16 + 4 * wv + g];
+    b[g] = gb + before;
+    gb += cnt[g];
+  }
+  uint32_t b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (uint32_t i = lo; i < hi; i += 64) {
+    int g = -1;
+    uint32_t k = 0;
+    if (i + lane < hi) { k = keys[begin + i + lane]; g = cls(k); }
+    const uint64_t m0 = __ballot(g == 0), m1 = __ballot(g == 1), m2 = __ballot(g == 2), m3 = __ballot(g == 3);
+    uint32_t dst = 0;
+    if (g == 0) dst = b0 + __popcll(m0 & lt);
+    if (g == 1) dst = b1 + __popcll(m1 & lt);
+    if (g == 2) dst = b2 + __popcll(m2 & lt);
+    if (g == 3) dst = b3 + __popcll(m3 & lt);
+    if (g >= 0) tmp[begin + dst] = k;
+    b0 += __popcll(m0); b1 += __popcll(m1); b2 += __popcll(m2); b3 += __popcll(m3);
+  }
+  __syncthreads();
+  for (uint32_t i = lo + lane; i < hi; i += 64) keys[begin + i] = tmp[begin + i];
+  __syncthreads();
+}
+#endif
 
 // First key with the maximum response in keys[begin, begin+count)  (ORBextractor.cc:719-735).
 QT_HD uint32_t qt_best_key(const uint32_t* keys, uint32_t begin, uint32_t count) {
@@ -583,12 +644,30 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
   // the team's waves take the sweep's nodes interleaved (node e -> wave e % nw): the first sweeps have a handful of huge nodes, one wave each
   QT_TEAM_SYNC(tm);
   QT_T0();
-  // (1) keys per child
+  // (1) keys per child.  A team first counts the huge nodes together, slice by slice (every wave walks the sweep's nodes: the choice is uniform)
+  const bool teamHuge = tm.nw > 1;
+  if (teamHuge) {
+    for (int e0 = 0; e0 < m; e0 += 64) {
+      uint32_t cntN = 0;
+      if (e0 + lane < m) cntN = w.nodes[w.order[e0 + lane]].count;
+      uint64_t hm = __ballot(cntN > QT_HUGE);
+      while (hm) {
+        const int bl = __ffsll((unsigned long long)hm) - 1;
+        hm &= hm - 1;
+        const Node nb = w.nodes[w.order[e0 + bl]];
+        const int mx = nb.x0 + ((nb.x1 - nb.x0 + 1) >> 1), my = nb.y0 + ((nb.y1 - nb.y0 + 1) >> 1);
+        uint32_t cnt[4], lo, hi;
+        qt_count_team(w.keys, nb.begin, nb.count, [mx, my](uint32_t k) -> int { return qt_class(k, mx, my); }, cnt, tm, &lo, &hi);
+        if (tm.tw == 0 && lane == 0) w.bcnt[e0 + bl] = (uint64_t)cnt[0] | ((uint64_t)cnt[1] << 16) | ((uint64_t)cnt[2] << 32) | ((uint64_t)cnt[3] << 48);
+        __syncthreads();   // (the slice counts in tm.sh are rewritten by the next huge node)
+      }
+    }
+  }
   for (int q0 = 0; q0 * tm.nw < m; q0 += 64) {
     const int e = (q0 + lane) * tm.nw + tm.tw;
-    const bool valid = e < m;
     Node nd = {};
-    if (valid) nd = w.nodes[w.order[e]];
+    if (e < m) nd = w.nodes[w.order[e]];
+    const bool valid = e < m && !(teamHuge && nd.count > QT_HUGE);
     const bool small = valid && nd.count <= QT_SMALL;
     if (small) {
       const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
@@ -642,13 +721,35 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
   QT_MARK(17);
   // (3) partition the keys, write the children, erase the parents
   const int oldHead = s.head, nA0 = s.nA, nFree0 = s.nFree;
+  if (teamHuge) {   // the huge nodes: partitioned by the whole team
+    for (int e0 = 0; e0 < mProc; e0 += 64) {
+      uint32_t cntN = 0;
+      if (e0 + lane < mProc) cntN = w.nodes[w.order[e0 + lane]].count;
+      uint64_t hm = __ballot(cntN > QT_HUGE);
+      while (hm) {
+        const int bl = __ffsll((unsigned long long)hm) - 1;
+        hm &= hm - 1;
+        const Node nb = w.nodes[w.order[e0 + bl]];
+        const int bmx = nb.x0 + ((nb.x1 - nb.x0 + 1) >> 1), bmy = nb.y0 + ((nb.y1 - nb.y0 + 1) >> 1);
+        uint32_t cnt[4];
+        qt_partition_team(w.keys, w.tmp, nb.begin, nb.count, [bmx, bmy](uint32_t k) -> int { return qt_class(k, bmx, bmy); }, cnt, tm);
+        if (tm.tw == 0) {
+          const uint64_t bc = w.bcnt[e0 + bl];
+          const uint32_t brk = w.brank[e0 + bl];
+          if (lane < 4) qt_write_children(w, nb, bmx, bmy, bc, brk, oldHead, nA0, nFree0, lane);
+          if (lane == 0) w.list[nb.lit] = 0xFFFF;
+        }
+      }
+    }
+  }
   for (int q0 = 0; q0 * tm.nw < mProc; q0 += 64) {
     const int e = (q0 + lane) * tm.nw + tm.tw;
-    const bool valid = e < mProc;
     Node nd = {};
     uint64_t c = 0;
     uint32_t rk = 0;
-    if (valid) { nd = w.nodes[w.order[e]]; c = w.bcnt[e]; rk = w.brank[e]; }
+    if (e < mProc) nd = w.nodes[w.order[e]];
+    const bool valid = e < mProc && !(teamHuge && nd.count > QT_HUGE);
+    if (valid) { c = w.bcnt[e]; rk = w.brank[e]; }
     const bool small = valid && nd.count <= QT_SMALL;
     const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
     if (small) {
@@ -673,10 +774,10 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
       const int eb = (q0 + bl) * tm.nw + tm.tw;
       const Node nb = w.nodes[w.order[eb]];
       const int bmx = nb.x0 + ((nb.x1 - nb.x0 + 1) >> 1), bmy = nb.y0 + ((nb.y1 - nb.y0 + 1) >> 1);
-      uint32_t cnt[4];
-      qt_partition(w.keys, w.tmp, nb.begin, nb.count, [bmx, bmy](uint32_t k) -> int { return qt_class(k, bmx, bmy); }, cnt);
       const uint64_t bc = w.bcnt[eb];
       const uint32_t brk = w.brank[eb];
+      uint32_t cnt[4] = {(uint32_t)bc & 0xFFFFu, (uint32_t)(bc >> 16) & 0xFFFFu, (uint32_t)(bc >> 32) & 0xFFFFu, (uint32_t)(bc >> 48) & 0xFFFFu};
+      qt_partition(w.keys, w.tmp, nb.begin, nb.count, [bmx, bmy](uint32_t k) -> int { return qt_class(k, bmx, bmy); }, cnt, true);
       if (lane < 4) qt_write_children(w, nb, bmx, bmy, bc, brk, oldHead, nA0, nFree0, lane);
       if (lane == 0) w.list[nb.lit] = 0xFFFF;
     }
@@ -753,15 +854,12 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
   {
     uint32_t cnt[4] = {0, 0, 0, 0};
     const int last = nIni - 1;
-    if (w0) {
-      qt_partition(w.keys, w.tmp, 0, nkeys,
-                   [hX, last](uint32_t k) -> int { int g = (int)((float)key_x(k) / hX); return g > last ? last : g; }, cnt);
+    auto rootOf = [hX, last](uint32_t k) -> int { int g = (int)((float)key_x(k) / hX); return g > last ? last : g; };
 #if QT_DEVICE
-      if (tm.nw > 1 && QT_LANE0) for (int i = 0; i < 4; ++i) tm.sh[4 + i] = (int)cnt[i];
-#endif
-    }
-#if QT_DEVICE
-    if (tm.nw > 1) { __syncthreads(); for (int i = 0; i < 4; ++i) cnt[i] = (uint32_t)tm.sh[4 + i]; }
+    if (tm.nw > 1) qt_partition_team(w.keys, w.tmp, 0, nkeys, rootOf, cnt, tm);
+    else qt_partition(w.keys, w.tmp, 0, nkeys, rootOf, cnt);
+#else
+    qt_partition(w.keys, w.tmp, 0, nkeys, rootOf, cnt);
 #endif
     int live = 0;
     for (int i = 0; i < nIni; ++i) live += cnt[i] > 0 ? 1 : 0;
