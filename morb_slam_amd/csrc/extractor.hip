@@ -572,8 +572,19 @@ __global__ __launch_bounds__(256) void k_describe(const morb::DescGeom dg, const
 #if MORB_DESC_STAGED
   __shared__ __align__(16) uint8_t s_win[4 * DESC_KPW * DESC_WIN * DESC_WP];
 #endif
-  const int img = imgRev ? gridDim.y - 1 - blockIdx.y : blockIdx.y, lane = threadIdx.x & 63;
-  const int gi0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DESC_KPW;
+  // Workgroup -> (image, keypoint chunk).  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own L2: with the
+  // plain (chunk, image) order the chunks of one image — whose patches cover the image's whole pyramid and blur between them — are spread
+  // over all eight L2s and every XCD fetches (nearly) every line (PMC r02: 2.2 x the gather bytes fetched, 4.4 x with the FETCH_SIZE
+  // correction).  Remapped (image counts that are multiples of 8), XCD k works through images k, k + 8, ... chunk by chunk.
+  int imgIdx = blockIdx.y, chunk = blockIdx.x;
+  if ((gridDim.y & 7) == 0) {
+    const unsigned n = blockIdx.x + gridDim.x * blockIdx.y;
+    const unsigned xcd = n & 7u, slot = n >> 3, grp = slot / gridDim.x;
+    chunk = (int)(slot - grp * gridDim.x); imgIdx = (int)(xcd + 8u * grp);
+    chunk = __builtin_amdgcn_readfirstlane(chunk); imgIdx = __builtin_amdgcn_readfirstlane(imgIdx);
+  }
+  const int img = imgRev ? gridDim.y - 1 - imgIdx : imgIdx, lane = threadIdx.x & 63;
+  const int gi0 = (chunk * 4 + (threadIdx.x >> 6)) * DESC_KPW;
   if (gi0 >= selPerImg) return;
   int4 pat[4];
 #pragma unroll
