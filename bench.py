@@ -415,7 +415,9 @@ def launch_ranks(n):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    sys.stdout.write(out0.decode(errors="replace"))
+    # rank 0's stdout: the JSON line goes to stdout, anything else a library printed there (gloo's "[Gloo] Rank 0 is connected ...") to stderr
+    for ln in out0.decode(errors="replace").splitlines():
+        print(ln, file=sys.stdout if ln.startswith("{") else sys.stderr)
     sys.stdout.flush()
     return rc
 

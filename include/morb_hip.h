@@ -580,9 +580,13 @@ int morb_local_bundle_adjustment_fisheye(morb_optimizer* o, int nKF, float* kfPo
                                          int lambdaInit100, const unsigned char* stopFlag, uint8_t* eraseFlag, int* stats2);
 void morb_ba_problem_destroy(morb_ba_problem*);
 int morb_ba_set_stop(morb_ba_problem*, int stop);
-/* mode 0 (default): one launch per LM phase over the whole GPU, accept/reject on the host (one 32-byte read-back per
- * trial); mode 1: the whole LM loop inside ONE persistent workgroup (no host round trips; for many small problems). */
+/* mode 0 (default): one launch per LM phase over the whole GPU, accept / reject decided on the device; mode 1: the whole LM loop
+ * inside ONE persistent workgroup (for many small problems). */
 int morb_ba_set_mode(morb_ba_problem*, int mode);
+/* Mode 0 BLOCKS the calling host thread until the last LM decision: it queues trial after trial on `stream`, one trial ahead of the
+ * decisions, and watches two words in mapped host memory (forwarding the caller's stop flag meanwhile); MORB_ERR_HIP if the stream
+ * reports a fault while it waits.  The kernels queued behind the last decision are empty; results are read with morb_ba_results
+ * (which synchronises).  Mode 1 only enqueues one launch. */
 int morb_ba_solve(morb_ba_problem*, void* stream);
 int morb_ba_results(morb_ba_problem*, float* kfPose, float* mpPos, uint8_t* eraseFlag, int* stats2);
 /* Measurement hook (bench.py's LocalBA roofline entry; not a reference method): times the FP64-MFMA Schur product of block_solver.hpp:

@@ -1,11 +1,13 @@
 #!/bin/bash
-# MFMA utilisation of the Schur kernels (profiles/r02/mfma_schur.txt; run through gpurun): separate --pmc passes, kernel trace only.
+# MFMA utilisation of the Schur kernels, one program (= one problem shape) per call (profiles/<round>/mfma_schur.txt; run through gpurun):
+# separate --pmc passes, kernel trace only.   Usage: bash tools/mfma_util.sh <outdir under gpurun_out> [program, default tools/bench_opt.py]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/${1:-mfmautil}
+PROG=${2:-tools/bench_opt.py}
 rm -rf "$O" && mkdir -p "$O"
 for p in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVES" "GRBM_GUI_ACTIVE"; do
   n=$(echo "$p" | cut -c1-12 | tr " " _)
-  timeout 300 rocprofv3 --pmc $p --kernel-trace -d "$O/$n" -o q --output-format csv -- python3 tools/bench_opt_all.py > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $p --kernel-trace -d "$O/$n" -o q --output-format csv -- python3 $PROG > /dev/null 2>&1
 done
 python3 - "$O" <<'PY'
 import csv, glob, collections, re, sys

@@ -3,7 +3,7 @@
 # command plus separate --pmc passes (HBM traffic: FETCH_SIZE / WRITE_SIZE; issue mix: SQ_*), as the MI355X guide
 # prescribes (counters never combined with sys/runtime traces).  Usage: bash tools/refresh_profiles.sh r01
 set -u
-R=${1:-r02}
+R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$R
 rm -rf "$O" && mkdir -p "$O"
@@ -16,14 +16,27 @@ done
 python3 tools/pmc_table.py "$O/pmc" > "$O/pmc_issue_table.txt"
 python3 tools/pmc_traffic.py "$O/pmc" 128 > "$O/pmc_traffic_b64.json"
 cp "$O/stats/s_kernel_stats.csv" "$O/extract_match_b256_kernel_stats.csv"
+# FETCH_SIZE / WRITE_SIZE calibration on known byte counts
+bash tools/fetch_calib.sh calib_$R > /dev/null 2>&1; cp gpurun_out/calib_$R/fetch_calib.txt gpurun_out/calib_$R/fetch_calib.json "$O/" 2>/dev/null
 # the optimisers (secondary metrics): kernel stats of the tracking / mapping micro-benchmarks
 rocprofv3 --kernel-trace --stats -d "$O/opt" -o s --output-format csv -- python3 tools/bench_opt_all.py > "$O/optimisers_bench.txt" 2>/dev/null
 cp "$O/opt/s_kernel_stats.csv" "$O/optimisers_kernel_stats.csv"
 rm -rf "$O/opt"
-# this round's extra evidence: VALU issue microbenchmark, MFMA Schur counters and A/B timings, phase costs of k_fast
-hipcc --offload-arch=gfx950 -O3 -o /tmp/alu_issue tools/alu_issue.hip 2>/dev/null && /tmp/alu_issue > "$O/alu_issue.txt" 2>&1
+# MFMA Schur counters, one problem shape per table: LocalBA (C5: 20 + 6 keyframes, 3000 points), then LocalInertialBA
+{ echo "== LocalBundleAdjustment (tools/bench_opt.py)"; bash tools/mfma_util.sh mfma_lba_$R tools/bench_opt.py; echo "== LocalInertialBA (tools/bench_iba.py)"; bash tools/mfma_util.sh mfma_iba_$R tools/bench_iba.py; } > "$O/mfma_schur.txt" 2>/dev/null
+bash tools/opt_prof.sh optprof_$R > "$O/localba_kernel_stats.txt" 2>/dev/null
+python3 tools/lba_sizes.py > "$O/localba_window_sizes.txt" 2>/dev/null
+# this round's extra evidence: phase counts of k_fastw, stage times alone on the chip, quadtree phases (1 and 256 frames), single-frame latency
 python3 tools/fastw_stats.py 64 > "$O/k_fastw_phase_counts_b64.txt" 2>/dev/null
 python3 tools/stage_times.py 64 > "$O/extract_stage_times_isolated.txt" 2>/dev/null; python3 tools/stage_times.py 256 >> "$O/extract_stage_times_isolated.txt" 2>/dev/null
-hipcc --offload-arch=gfx950 -O3 -o /tmp/ldp tools/micro/ldlt_phases.hip 2>/dev/null && { /tmp/ldp 120; /tmp/ldp 150; } > "$O/dense_ldlt_phases.txt" 2>&1
-rm -rf "$O/stats" "$O"/pmc/*/q_kernel_trace.csv "$O"/pmc/*/q_agent_info.csv
+{ echo "== 752 x 480, 1 stereo frame (team packing)"; python3 tools/fast_phases.py 1 | tail -13; echo "== 1920 x 1080 / 4000, 4 stereo frames (team packing)"; MORB_W=1920 MORB_H=1080 MORB_NF=4000 python3 tools/fast_phases.py 4 | tail -13; } > "$O/k_distribute_phases.txt" 2>/dev/null
+python3 tools/latency_b1.py > "$O/latency_b1.txt" 2>/dev/null
+# the other headline shapes: BASELINE configs[3] on one GPU, and the --gpus 2 launcher path (two ranks sharing this GPU, gloo)
+python3 bench.py --workload c4 --no-extras --no-cpu-baseline > "$O/bench_c4.json" 2>/dev/null
+MORB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --batch 64 --steps 10 --no-extras --no-cpu-baseline > "$O/bench_gpus2_gloo_one_gpu.json" 2>/dev/null
+MORB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --workload c4 --steps 10 --no-extras --no-cpu-baseline > "$O/bench_c4_gpus2_gloo_one_gpu.json" 2>/dev/null
+python3 bench.py > "$O/bench_default.json" 2>/dev/null
+python3 tools/time_stats.py "$O" 50 10 > /dev/null 2>&1
+python3 -m pytest tests -m gpu -q 2>&1 | tail -3 > "$O/pytest_gpu.txt"
+rm -rf "$O/stats" "$O"/pmc/*/q_kernel_trace.csv "$O"/pmc/*/q_agent_info.csv "$O/pmc"
 ls -la "$O"
