@@ -244,11 +244,17 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
 #endif
             int slot = qn + incl - cnt;
             const unsigned rec0 = (unsigned)((y << 8) | (bi << 5));   // the flag index is decoded by the strength round: once per 64 entries, not per entry
+            // (two flags per trip: the loop runs for as long as ANY lane has flags left, and the fullest lane has several times the average)
             unsigned t = take;
             while (t) {
               const unsigned f = (unsigned)__ffs(t) - 1u;
               t &= t - 1u;
-              queue[slot++] = (uint16_t)(rec0 | f);
+              queue[slot] = (uint16_t)(rec0 | f);
+              const bool two = t != 0u;
+              const unsigned g = (unsigned)__ffs(t) - 1u;
+              t &= t - 1u;
+              if (two) queue[slot + 1] = (uint16_t)(rec0 | (g & 31u));
+              slot += two ? 2 : 1;
             }
             qn += total;
             FW_SYNC();
