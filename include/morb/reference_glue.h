@@ -10,7 +10,9 @@
 //   morb_glue::LocalBundleAdjustment(mpCurrentKeyFrame, &mbAbortBA, mpCurrentKeyFrame->GetMap(), a, b, c, d);      // LocalMapping.cc:181
 //
 // Compiled only inside the reference tree (it needs Frame.h, KeyFrame.h, MapPoint.h, Map.h and with them OpenCV / Eigen / Sophus /
-// DBoW2).  THIS FILE HAS NEVER BEEN COMPILED: the build container has none of those headers.  It is written against the member
+// DBoW2).  THIS FILE HAS NEVER BEEN COMPILED AGAINST THE REFERENCE: the build container has none of those headers.  What is checked
+// here (tests/test_oracle_cpu.py::test_reference_glue_parses) is that it parses and type-checks against mock declarations of the
+// members it touches (tests/native/mock_ref: names and types read off the reference headers, no behaviour).  It is written against the member
 // names of /root/reference/include/{Frame,KeyFrame,MapPoint,Map}.h and follows, statement for statement, the gathering and
 // write-back code of the methods it replaces (cited per function); the views it fills are the ones tests/native/adapters_check.cc
 // drives.  Pinhole cameras only: on a KannalaBrandt8 rig (Nleft != -1 / mpCamera2) call the *_fisheye entry points of morb_hip.h with

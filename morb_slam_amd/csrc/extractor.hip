@@ -565,12 +565,16 @@ constexpr int DESC_WIN = 2 * DESC_R + 1, DESC_WP = 48;   // window rows / LDS pi
 // keypoint (record -> patch -> angle -> pattern gathers), so each stage is issued for all DESC_KPW keypoints before the
 // next stage waits on it — three round trips per wave instead of three per keypoint.  Slots without a keypoint repeat
 // the wave's first valid one (no divergent control flow around the loads) and skip the stores.
-__global__ __launch_bounds__(256) void k_describe(const morb::DescGeom dg, const uint8_t* __restrict__ pyr,
+#ifndef MORB_DESC_WAVES
+#define MORB_DESC_WAVES 4
+#endif
+constexpr int DESC_WAVES = MORB_DESC_WAVES;   // waves (of DESC_KPW keypoints each) per workgroup
+__global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGeom dg, const uint8_t* __restrict__ pyr,
                                                   const uint8_t* __restrict__ blur, const int2* __restrict__ kref,
                                                   int selPerImg, morb_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int cap, int imgRev) {
 #if MORB_DESC_STAGED
-  __shared__ __align__(16) uint8_t s_win[4 * DESC_KPW * DESC_WIN * DESC_WP];
+  __shared__ __align__(16) uint8_t s_win[DESC_WAVES * DESC_KPW * DESC_WIN * DESC_WP];
 #endif
   // Workgroup -> (image, keypoint chunk).  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own L2: with the
   // plain (chunk, image) order the chunks of one image — whose patches cover the image's whole pyramid and blur between them — are spread
@@ -584,7 +588,7 @@ __global__ __launch_bounds__(256) void k_describe(const morb::DescGeom dg, const
     chunk = __builtin_amdgcn_readfirstlane(chunk); imgIdx = __builtin_amdgcn_readfirstlane(imgIdx);
   }
   const int img = imgRev ? gridDim.y - 1 - imgIdx : imgIdx, lane = threadIdx.x & 63;
-  const int gi0 = (chunk * 4 + (threadIdx.x >> 6)) * DESC_KPW;
+  const int gi0 = (chunk * DESC_WAVES + (threadIdx.x >> 6)) * DESC_KPW;
   if (gi0 >= selPerImg) return;
   int4 pat[4];
 #pragma unroll
@@ -1265,7 +1269,7 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   mark(4);
   MORB_HIP_CHECK(hipStreamWaitEvent(st, e->evJoin, 0));
   constexpr int descRev = 1;   // images in reverse order: the blur wrote the last ones most recently (581 -> 565 us at 512 images)
-  hipLaunchKernelGGL(k_describe, dim3(div_up(e->selPerImg, 4 * DESC_KPW), nimg), dim3(256), 0, st, e->descGeom, e->d_pyr,
+  hipLaunchKernelGGL(k_describe, dim3(div_up(e->selPerImg, DESC_WAVES * DESC_KPW), nimg), dim3(64 * DESC_WAVES), 0, st, e->descGeom, e->d_pyr,
                      e->d_blur, e->d_kref, e->selPerImg, d_kps, d_desc, cap, descRev);
   mark(5);
   MORB_HIP_CHECK(hipGetLastError());

@@ -5,6 +5,7 @@ import hashlib
 import math
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -603,3 +604,14 @@ def test_orb_pattern_table_matches_the_reference():
         pytest.skip("the reference is not present on this machine")
     fresh = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "extract_pattern.py"), "/root/reference"], text=True)
     assert fresh == open(os.path.join(ROOT, "morb_slam_amd", "csrc", "orb_pattern.inc")).read()
+
+
+def test_reference_glue_parses():
+    """include/morb/reference_glue.h (the Frame& / KeyFrame* forms of the matcher and optimiser calls) can only be built for real
+    inside the reference tree; here it is parsed and type-checked against mock declarations of the reference members it touches
+    (tests/native/mock_ref — names and types only), so a typo or a wrong view field fails on CPU."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(root, "tests", "native", "mock_ref"), "-I" + os.path.join(root, "include", "morb"),
+                        "-I" + os.path.join(root, "include"), "-I/opt/rocm/include", os.path.join(root, "tests", "native", "glue_syntax_check.cc")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]

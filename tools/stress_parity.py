@@ -16,10 +16,13 @@ bad = 0
 for case in range(N):
     W, H = SHAPES[case % len(SHAPES)]
     nf = int(rng.choice([500, 1000, 1200, 1500, 2000]))
-    nfr = int(rng.choice([1, 2, 3, 5]))
-    pairs = [make_stereo_pair(W, H, seed=1000 + 10 * case + k) for k in range(nfr)]
+    nfr = int(rng.choice([1, 2, 3, 5, 9]))     # (9 frames = 18 images: beyond 16 the quadtree keeps one wave per level; up to 16 the big levels get teams)
+    ini, mn = [(20, 7), (12, 5), (30, 10), (7, 20)][int(rng.integers(0, 4))]
+    pairs = [make_stereo_pair(W, H, seed=1000 + 10 * case + (k % 3)) for k in range(nfr)]
     imgs = np.stack([im for p in pairs for im in p])
-    ext = ORBextractor(nf, 1.2, 8, 20, 7)
+    if case % 5 == 4:                           # every fifth case: heavy pixel noise on top (many more FAST survivors and corners per cell)
+        imgs = np.clip(imgs.astype(np.int16) + rng.integers(-25, 26, imgs.shape), 0, 255).astype(np.uint8)
+    ext = ORBextractor(nf, 1.2, 8, ini, mn)
     kps, desc, cnt, mono = ext.extract_batch(torch.from_numpy(imgs).cuda())
     u, d = ORBmatcher().ComputeStereoMatches(ext, kps, desc, cnt, np.float32(458.654 * 0.11), np.float32(0.11))
     torch.cuda.synchronize()
@@ -27,7 +30,7 @@ for case in range(N):
     ora = []
     ok = True
     for i, im in enumerate(imgs):
-        o = O.OracleExtractor(nf)
+        o = O.OracleExtractor(nf, 1.2, 8, ini, mn)
         _, k, de = o(im)
         ora.append((o, k, de))
         if c[i] != len(k) or kn[i, :c[i]].reshape(-1).view(KP_DTYPE).tobytes() != k.tobytes() or dn[i, :c[i]].tobytes() != de.tobytes():
