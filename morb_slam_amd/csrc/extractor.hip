@@ -66,7 +66,9 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 #ifndef MORB_PY_ROWS
 #define MORB_PY_ROWS 8
 #endif
-constexpr int PY_ROWS = MORB_PY_ROWS;  // rows per thread in the pyramid kernels (block = 64 x 4 threads -> 256 px x 32 rows)
+constexpr int PY_ROWS = MORB_PY_ROWS;  // rows per thread in k_resize_gather (block = 64 x 4 threads -> 256 px x 32 rows)
+constexpr int PR = 8;    // rows per item of k_resize
+constexpr int P0R = 4;   // rows per item of the level-0 copy
 // Workgroup -> tile mapping of the pyramid kernels.  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with
 // its own L2); with the plain (x, y, image) order the tiles of one image are spread over all of them and the source rows that
 // vertically adjacent tiles share are fetched once per XCD.  Remapped, XCD k works through images k, k + 8, ... tile by tile.
@@ -83,39 +85,6 @@ __device__ __forceinline__ PyTile py_tile() {
   PyTile r; r.bx = blockIdx.x; r.by = blockIdx.y; r.img = blockIdx.z;
   return r;
 }
-__device__ __forceinline__ void level0_block(const uint8_t* __restrict__ src, int w, int h, int stride, size_t pitch,
-                                             uint8_t* __restrict__ pyr, const LevelGeom& g, int bx, int by, int img) {
-  const int px = (bx * 64 + (threadIdx.x & 63)) * 4;
-  const int py0 = (by * 4 + (threadIdx.x >> 6)) * PY_ROWS;
-  if (px >= g.pstride) return;
-  // four consecutive (reflected) source columns span at most 4 bytes: one unaligned dword load at the smallest one
-  // (kept inside the source row) serves interior and pad lanes alike, so edge waves do not run two code paths
-  int xs[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) xs[k] = reflect101(px + k - EDGE, w);
-  int base = min(min(xs[0], xs[1]), min(xs[2], xs[3]));
-  base = min(base, w - 4);
-  int sh[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) sh[k] = (xs[k] - base) * 8;
-  for (int r = 0; r < PY_ROWS; ++r) {
-    const int py = py0 + r;
-    if (py >= h + 2 * EDGE) break;
-    const uint8_t* s = src + (size_t)img * pitch + (size_t)reflect101(py - EDGE, h) * stride;
-    uint32_t word;
-    __builtin_memcpy(&word, s + base, 4);
-    uint32_t v = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v |= ((word >> sh[k]) & 0xFFu) << (8 * k);
-    *reinterpret_cast<uint32_t*>(pyr + g.pyrOff + (size_t)img * g.pyrImg + (size_t)py * g.pstride + px) = v;
-  }
-}
-__global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src, int w, int h, int stride,
-                                                size_t pitch, uint8_t* __restrict__ pyr, LevelGeom g) {
-  const PyTile pt = py_tile();
-  level0_block(src, w, h, stride, pitch, pyr, g, pt.bx, pt.by, pt.img);
-}
-
 // K1b: level l = resize(level l-1, INTER_LINEAR) + copyMakeBorder(BORDER_REFLECT_101|ISOLATED)
 // (ORBextractor.cc:1101-1104).  Every padded pixel is computed directly from level l-1 through tables that
 // already fold the reflection, so one launch writes interior and pad.
@@ -124,113 +93,159 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
   __builtin_memcpy(&v, p, 4);
   return v;
 }
-// sbase / sstride: the source level's interior origin and row pitch (level l - 1 inside the pyramid, or — level 1 in the fused
-// kernel below — the caller's image, of which level 0's interior is a copy)
-// srcW: the source row's valid bytes when the source is the caller's image — its last row ends where the buffer ends, so the 8-byte
-// window must not start beyond srcW - 8 (inside the pyramid the bytes behind a row are the pad / the next row: INT_MAX there)
-__device__ __forceinline__ void resize_tile(const uint8_t* __restrict__ sbase, int sstride, uint8_t* __restrict__ pyr, const LevelGeom& gd,
-                                            const ResizeTab* __restrict__ xtab, const ResizeTab* __restrict__ ytab, const PyTile pt, int srcW) {
+// General form (any scale factor): four byte gathers per output pixel.  Used only when a level's four-pixel chunks do not fit the
+// 8-byte source windows of k_resize (scale factors above ~1.75).
+__global__ __launch_bounds__(256) void k_resize_gather(uint8_t* __restrict__ pyr, LevelGeom gs, LevelGeom gd,
+                                                       const ResizeTab* __restrict__ xtab, const ResizeTab* __restrict__ ytab) {
+  const PyTile pt = py_tile();
+  const uint8_t* sbase = pyr + gs.pyrOff + (size_t)pt.img * gs.pyrImg + (size_t)EDGE * gs.pstride + EDGE;
   const int px = (pt.bx * 64 + (threadIdx.x & 63)) * 4;
-  // the wave's eight rows are wave-uniform: their table entries are scalar loads, fetched before any pixel
-  const int py0 = (pt.by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * PY_ROWS;
-  const int img = pt.img;
+  const int py0 = (pt.by * 4 + (threadIdx.x >> 6)) * PY_ROWS;
   const int H = gd.h + 2 * EDGE;
   if (px >= gd.pstride || py0 >= H) return;
-  // The tables carry PY_ROWS repeats of their last entry, so groups are read unclamped: the four column entries are 32 contiguous
-  // bytes per lane; the eight row entries are wave-uniform and 8-byte aligned (alignas on ResizeTab: a scalar load
-  // needs dword alignment), i.e. ONE s_load_dwordx16 instead of a second vector-memory round trip in front of the pixel loads.
   ResizeTab tx[4];
-  {
-    const int pxc = px < gd.w + 2 * EDGE ? px : gd.w + 2 * EDGE - 1;
+  const int pxc = px < gd.w + 2 * EDGE ? px : gd.w + 2 * EDGE - 1;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) tx[k] = xtab[pxc + k];
-  }
-  ResizeTab ty[PY_ROWS];
-#pragma unroll
-  for (int r = 0; r < PY_ROWS; ++r) ty[r] = ytab[py0 + r];
-  // The four outputs read source columns within a span of a few bytes — s0(px) .. s0(px+3)+1 in the interior, the
-  // mirrored equivalent in the reflected pad — so two (unaligned) dword loads per source row starting at the
-  // smallest column feed all four; one code path for interior and pad keeps the edge waves from running both.
-  int base = tx[0].s0, top = tx[0].s1;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    base = min(base, min((int)tx[k].s0, (int)tx[k].s1));
-    top = max(top, max((int)tx[k].s0, (int)tx[k].s1));
-  }
-  const bool packed = top - base < 8;   // always true for scale factors <= 2 (the gather below is the general fallback)
-  base = min(base, srcW - 8);           // (top <= srcW - 1: the selectors stay below 8)
-  // byte selectors for v_perm_b32: output k's left / right source byte inside the 8 loaded bytes
-  uint32_t selL = 0, selR = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { selL |= (uint32_t)(tx[k].s0 - base) << (8 * k); selR |= (uint32_t)(tx[k].s1 - base) << (8 * k); }
-  uint8_t* dbase = pyr + gd.pyrOff + (size_t)img * gd.pyrImg + px;
-  if (__builtin_expect(__ballot(!packed) == 0, 1)) {
-    // every source dword of the wave's eight rows is requested before the first one is used: one memory round trip per
-    // wave instead of one per row (PMC r01: the kernel waited 66 % of its wave-cycles)
-    uint32_t a0[PY_ROWS], a1[PY_ROWS], b0[PY_ROWS], b1[PY_ROWS];
-#pragma unroll
-    for (int r = 0; r < PY_ROWS; ++r) {
-      const uint8_t* r0 = sbase + (unsigned)(__umul24(ty[r].s0, sstride) + base);
-      const uint8_t* r1 = sbase + (unsigned)(__umul24(ty[r].s1, sstride) + base);
-      uint2 va, vb;   // 8 unaligned bytes per source row: one vector-memory instruction each
-      __builtin_memcpy(&va, r0, 8); __builtin_memcpy(&vb, r1, 8);
-      a0[r] = va.x; a1[r] = va.y; b0[r] = vb.x; b1[r] = vb.y;
-    }
-#pragma unroll
-    for (int r = 0; r < PY_ROWS; ++r) {
-      if (py0 + r >= H) break;   // wave-uniform
-      // one v_perm_b32 gathers the four outputs' left (right) samples of a source row
-      const uint32_t aL = __builtin_amdgcn_perm(a1[r], a0[r], selL), aR = __builtin_amdgcn_perm(a1[r], a0[r], selR);
-      const uint32_t bL = __builtin_amdgcn_perm(b1[r], b0[r], selL), bR = __builtin_amdgcn_perm(b1[r], b0[r], selR);
-      uint32_t v = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int h0 = (int)((aL >> (8 * k)) & 0xFF) * tx[k].c0 + (int)((aR >> (8 * k)) & 0xFF) * tx[k].c1;
-        const int h1 = (int)((bL >> (8 * k)) & 0xFF) * tx[k].c0 + (int)((bR >> (8 * k)) & 0xFF) * tx[k].c1;
-        const int o = ((((int)ty[r].c0 * (h0 >> 4)) >> 16) + (((int)ty[r].c1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        v |= (uint32_t)(o & 0xFF) << (8 * k);
-      }
-      // columns >= w + 2 * EDGE repeat the last table entry and land in the row's alignment slack
-      *reinterpret_cast<uint32_t*>(dbase + (size_t)(py0 + r) * gd.pstride) = v;
-    }
-    return;
-  }
+  for (int k = 0; k < 4; ++k) tx[k] = xtab[pxc + k];
+  uint8_t* dbase = pyr + gd.pyrOff + (size_t)pt.img * gd.pyrImg + px;
   for (int r = 0; r < PY_ROWS; ++r) {
     if (py0 + r >= H) break;
-    const uint8_t* r0 = sbase + (size_t)ty[r].s0 * sstride;
-    const uint8_t* r1 = sbase + (size_t)ty[r].s1 * sstride;
+    const ResizeTab ty = ytab[py0 + r];
+    const uint8_t* r0 = sbase + (size_t)ty.s0 * gs.pstride;
+    const uint8_t* r1 = sbase + (size_t)ty.s1 * gs.pstride;
     uint32_t v = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int h0 = r0[tx[k].s0] * tx[k].c0 + r0[tx[k].s1] * tx[k].c1;
       const int h1 = r1[tx[k].s0] * tx[k].c0 + r1[tx[k].s1] * tx[k].c1;
-      const int o = ((((int)ty[r].c0 * (h0 >> 4)) >> 16) + (((int)ty[r].c1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      const int o = ((((int)ty.c0 * (h0 >> 4)) >> 16) + (((int)ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
       v |= (uint32_t)(o & 0xFF) << (8 * k);
     }
     *reinterpret_cast<uint32_t*>(dbase + (size_t)(py0 + r) * gd.pstride) = v;
   }
 }
 
-__global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, LevelGeom gs, LevelGeom gd,
-                                                const ResizeTab* __restrict__ xtab,
-                                                const ResizeTab* __restrict__ ytab) {
-  const PyTile pt = py_tile();
-  resize_tile(pyr + gs.pyrOff + (size_t)pt.img * gs.pyrImg + (size_t)EDGE * gs.pstride + EDGE, gs.pstride, pyr, gd, xtab, ytab, pt, 0x7fffffff);
+// The resize proper.  Round 3 found the stage bound by VALU issue and by idle lanes, not by memory (27 lane-cycles per pixel against
+// 16.6 VALU instructions per pixel; a 256-px-wide wave tile leaves 15 - 45 % of the lanes of levels 2 - 6 outside the image).
+//  * work item = one destination dword (4 px) x PR rows; the items of a level are numbered linearly (row group major) and dealt to
+//    lanes 256 per workgroup, so every lane of every wave but the level's last works;
+//  * per column chunk the host precomputes (PyrCol) the 8-byte source window's offset, a v_perm_b32 selector per pixel that drops the
+//    pixel's left and right source bytes into the two halves of a dword, and the coefficient pair in the same layout: the horizontal
+//    pass of a pixel is v_perm_b32 + v_dot2_u32_u16;
+//  * the vertical term (c * (h >> 4)) >> 16 is v_mul_hi_u32_u24(c << 12, h & ~15): the row table (PyrRow) carries c << 12;
+//  * rows are no longer wave-uniform (a wave's items can span two or three row groups), so the workgroup stages its slice of the row
+//    table in LDS and every lane reads its eight entries from there (ds_read_b128, off the vector-memory path);
+//  * (c0 + c1 + 2) >> 2 and the byte packing run two pixels per instruction (v_pk_lshrrev_b16, one v_perm_b32 per dword).
+// Arithmetic identical to cv::resize's fixed-point path (the oracle's resize_linear_u8): 11-bit coefficients, horizontal sums >> 4,
+// vertical products >> 16, + 2 >> 2.
+struct ResizeArgs {
+  const PyrCol* col; const PyrRow* row;
+  int nC, nItems, H, dpstride;
+  uint32_t magicC;
+  unsigned long long dOff, dImg;
+};
+typedef unsigned short pyr_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t mul_hi_u24(uint32_t a, uint32_t b) {   // v_mul_hi_u32_u24 (the masks tell the compiler so; they cost nothing)
+  return (uint32_t)(((unsigned long long)(a & 0xFFFFFFu) * (b & 0xFFFFFFu)) >> 32);
 }
-// Levels 0 and 1 in one launch: level 1 is resized straight from the caller's image (level 0's interior is a copy of it, so the
-// bytes are the same) while the same workgroups also write level 0's padded copy, block t and t + tiles1 of k_level0's grid.
-// With the XCD-aware tile order all workgroups of an image run on one XCD at about the same time, so the image is fetched from
-// HBM once and level 0 is never read back by the pyramid stage.
-__global__ __launch_bounds__(256) void k_level01(const uint8_t* __restrict__ src, int w, int h, int stride, size_t pitch,
-                                                 uint8_t* __restrict__ pyr, LevelGeom g0, LevelGeom g1,
-                                                 const ResizeTab* __restrict__ xtab, const ResizeTab* __restrict__ ytab, int bx0n, int by0n) {
-  const PyTile pt = py_tile();
-  resize_tile(src + (size_t)pt.img * pitch, stride, pyr, g1, xtab, ytab, pt, w);
-  const int tiles1 = gridDim.x * gridDim.y, tiles0 = bx0n * by0n;
-  for (int t = pt.by * gridDim.x + pt.bx; t < tiles0; t += tiles1) {
-    const int by = t / bx0n;
-    level0_block(src, w, h, stride, pitch, pyr, g0, t - by * bx0n, by, pt.img);
+__device__ __forceinline__ void resize_items(const uint8_t* __restrict__ sbase, int sstride, uint8_t* __restrict__ dimg,
+                                             const ResizeArgs& a, int tile, PyrRow* __restrict__ sRow) {
+  const int id0 = tile * 256;
+  if (id0 >= a.nItems) return;   // (whole workgroup)
+  const int gLo = (int)__umulhi((uint32_t)id0, a.magicC), gHi = (int)__umulhi((uint32_t)min(id0 + 255, a.nItems - 1), a.magicC);
+  for (int t = threadIdx.x; t < (gHi - gLo + 1) * PR; t += 256) sRow[t] = a.row[gLo * PR + t];
+  __syncthreads();
+  const int id = id0 + (int)threadIdx.x;
+  if (id >= a.nItems) return;
+  const int g = (int)__umulhi((uint32_t)id, a.magicC), c = id - g * a.nC;
+  const PyrCol pc = a.col[c];
+  const PyrRow* rr = sRow + (g - gLo) * PR;
+  // every source dword of the item's rows is requested before the first one is used (no branch inside the row loops: a per-row exit
+  // makes the compiler sink each row's loads behind it, one dependent round trip per row)
+  // The memory pipe charges a wave's load 16 cycles per dword unless every lane's address is dword aligned, then 16 cycles flat up to
+  // 16 bytes per lane (tools/micro/ta_rate.hip: an 8-byte load at a byte-granular address costs 32, an aligned 12-byte one 16): the
+  // 8-byte window is fetched as the three aligned dwords around it and cut out with two v_alignbyte_b32.
+  uint32_t A0[PR], A1[PR], A2[PR], B0[PR], B1[PR], B2[PR];
+#pragma unroll
+  for (int r = 0; r < PR; ++r) {
+    const int2 sr = *reinterpret_cast<const int2*>(&rr[r].s0);
+    struct W3 { uint32_t x, y, z; } wa, wb;
+    __builtin_memcpy(&wa, __builtin_assume_aligned(sbase + (uint32_t)(__umul24(sr.x, sstride) + pc.base), 4), 12);
+    __builtin_memcpy(&wb, __builtin_assume_aligned(sbase + (uint32_t)(__umul24(sr.y, sstride) + pc.base), 4), 12);
+    A0[r] = wa.x; A1[r] = wa.y; A2[r] = wa.z; B0[r] = wb.x; B1[r] = wb.y; B2[r] = wb.z;
   }
+  const int row0 = g * PR;
+#pragma unroll
+  for (int r = 0; r < PR; ++r) {
+    const uint2 cy = *reinterpret_cast<const uint2*>(&rr[r].c0s);
+    const uint32_t ax = __builtin_amdgcn_alignbyte(A1[r], A0[r], pc.sh), ay = __builtin_amdgcn_alignbyte(A2[r], A1[r], pc.sh);
+    const uint32_t bx = __builtin_amdgcn_alignbyte(B1[r], B0[r], pc.sh), by = __builtin_amdgcn_alignbyte(B2[r], B1[r], pc.sh);
+    uint32_t sum[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t pa = __builtin_amdgcn_perm(ay, ax, pc.sel[k]), pb = __builtin_amdgcn_perm(by, bx, pc.sel[k]);
+      const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(pyr_u16x2, pa), __builtin_bit_cast(pyr_u16x2, pc.coef[k]), 0u, false);
+      const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(pyr_u16x2, pb), __builtin_bit_cast(pyr_u16x2, pc.coef[k]), 0u, false);
+      sum[k] = mul_hi_u24(cy.x, h0 & 0xFFFFF0u) + mul_hi_u24(cy.y, h1 & 0xFFFFF0u) + 2u;
+    }
+    pyr_u16x2 lo = __builtin_bit_cast(pyr_u16x2, sum[0] | (sum[1] << 16)), hi = __builtin_bit_cast(pyr_u16x2, sum[2] | (sum[3] << 16));
+    lo >>= 2; hi >>= 2;
+    const uint32_t v = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
+    // rows past the bottom of the last group: the row table repeats its last entry, the store rewrites the last row with the same bytes
+#if MORB_EXP == 4
+    if (v == 0x12345678u)
+#endif
+    *reinterpret_cast<uint32_t*>(dimg + (uint32_t)(__umul24(min(row0 + r, a.H - 1), a.dpstride) + c * 4)) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsigned long long sOff, unsigned long long sImg, int sstride, ResizeArgs a) {
+  extern __shared__ __align__(16) uint8_t pyr_smem[];
+  const PyTile pt = py_tile();
+  resize_items(pyr + sOff + (size_t)pt.img * sImg, sstride, pyr + a.dOff + (size_t)pt.img * a.dImg, a, pt.bx, reinterpret_cast<PyrRow*>(pyr_smem));
+}
+
+// Level 0 = copyMakeBorder(image, 19, BORDER_REFLECT_101), as items of two kinds: "interior" = one aligned 16-byte destination chunk
+// whose sixteen source pixels are consecutive (one unaligned 16-byte load — the caller's image has whatever alignment it has —, one 16-byte store) x P0R rows, and "edge" = one destination
+// dword of the reflected pad (or of the ragged ends of the interior) x P0R rows, a dword load + v_perm_b32 with a host-made selector.
+struct Level0Args {
+  const PyrEdge* edge;
+  int nInt, j0, nEdge, nIntItems, nItems, H, h, dpstride;
+  uint32_t magicInt, magicEdge;
+  unsigned long long dOff, dImg;
+};
+__device__ __forceinline__ void level0_items(const uint8_t* __restrict__ src, int stride, uint8_t* __restrict__ dimg, const Level0Args& a, int tile, int nTiles) {
+  for (int id = tile * 256 + (int)threadIdx.x; id < a.nItems; id += nTiles * 256) {
+    if (id < a.nIntItems) {
+      const int g = (int)__umulhi((uint32_t)id, a.magicInt), j = id - g * a.nInt + a.j0;
+      uint4 v[P0R];
+#pragma unroll
+      for (int r = 0; r < P0R; ++r) {
+        const int py = min(g * P0R + r, a.H - 1);
+        __builtin_memcpy(&v[r], src + (uint32_t)(__umul24(reflect101(py - EDGE, a.h), stride) + 16 * j - EDGE), 16);
+      }
+#pragma unroll
+      for (int r = 0; r < P0R; ++r)
+        *reinterpret_cast<uint4*>(dimg + (uint32_t)(__umul24(min(g * P0R + r, a.H - 1), a.dpstride) + 16 * j)) = v[r];
+    } else {
+      const int e = id - a.nIntItems;
+      const int g = (int)__umulhi((uint32_t)e, a.magicEdge);
+      const PyrEdge pe = a.edge[e - g * a.nEdge];
+      uint32_t w[P0R];
+#pragma unroll
+      for (int r = 0; r < P0R; ++r) {
+        const int py = min(g * P0R + r, a.H - 1);
+        __builtin_memcpy(&w[r], src + (uint32_t)(__umul24(reflect101(py - EDGE, a.h), stride) + pe.base), 4);
+      }
+#pragma unroll
+      for (int r = 0; r < P0R; ++r)
+        *reinterpret_cast<uint32_t*>(dimg + (uint32_t)(__umul24(min(g * P0R + r, a.H - 1), a.dpstride) + pe.dword * 4)) = __builtin_amdgcn_perm(0u, w[r], pe.sel);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src, int stride, size_t pitch, uint8_t* __restrict__ pyr, Level0Args a0) {
+  const PyTile pt = py_tile();
+  level0_items(src + (size_t)pt.img * pitch, stride, pyr + a0.dOff + (size_t)pt.img * a0.dImg, a0, pt.bx, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -616,6 +631,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGe
   int lvl[DESC_KPW], cx[DESC_KPW], cy[DESC_KPW], pstride[DESC_KPW], bstride[DESC_KPW];
   const uint8_t* ctr[DESC_KPW];
   const uint8_t* center[DESC_KPW];
+  int wsh[DESC_KPW] = {};
 #pragma unroll
   for (int kk = 0; kk < DESC_KPW; ++kk) {
     const int l = ref[kk].x >> 24;
@@ -626,6 +642,13 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGe
     // the lanes add unsigned 32-bit offsets (scalar base + vector offset addressing)
     ctr[kk] = pyr + dg.pyrOff[l] + (size_t)img * dg.pyrImg[l] + (size_t)(EDGE + cy[kk] - HALF_PATCH) * pstride[kk] + EDGE + cx[kk] - HALF_PATCH;
     center[kk] = blur + dg.blurOff[l] + (size_t)img * dg.blurImg[l] + (ptrdiff_t)(cy[kk] - DESC_R) * bstride[kk] + cx[kk] - DESC_R;
+#if MORB_DESC_STAGED
+    // the window is fetched from the dword boundary below its left edge (blurred rows are 64-byte aligned, a keypoint sits at x >= 19):
+    // a wave's 16-byte load costs the memory pipe 64 cycles at a byte-granular address and 16 at a dword-aligned one
+    // (tools/micro/ta_rate.hip); the 37 columns + the shift still fit the 48-byte rows, the gathers add the shift
+    wsh[kk] = (cx[kk] - DESC_R) & 3;
+    center[kk] -= wsh[kk];
+#endif
   }
   // IC_Angle on the un-blurred level.  The texture path handles a byte load of a wave no faster than a dword load, so the
   // 31 x 31 patch is read as 31 rows x 8 unaligned dwords = 248 dword loads, four per lane.
@@ -651,7 +674,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGe
     for (int j = 0; j < 2; ++j) {
       const int t = min(lane + 64 * j, DESC_WIN * 3 - 1);   // row = t / 3, 16-byte segment = t % 3
       const int row = (int)(((unsigned)t * 21846u) >> 16), seg = t - row * 3;
-      __builtin_memcpy(&ww[kk][j], center[kk] + (uint32_t)(__umul24(row, bstride[kk]) + seg * 16), 16);
+      __builtin_memcpy(&ww[kk][j], __builtin_assume_aligned(center[kk] + (uint32_t)(__umul24(row, bstride[kk]) + seg * 16), 4), 16);
     }
 #endif
   // The circular mask and the column weights of a lane's four dwords do not depend on the keypoint: byte masks and the
@@ -729,10 +752,10 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGe
       const int r0 = __float2int_rn(x0 * bsin + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bsin);
       const int r1 = __float2int_rn(x1 * bsin + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bsin);
 #if MORB_DESC_STAGED
-      t0v[kk][q] = win[kk * (DESC_WIN * DESC_WP) + (r0 + DESC_R) * DESC_WP + c0 + DESC_R];
-      t1v[kk][q] = win[kk * (DESC_WIN * DESC_WP) + (r1 + DESC_R) * DESC_WP + c1 + DESC_R];
+      t0v[kk][q] = win[kk * (DESC_WIN * DESC_WP) + (r0 + DESC_R) * DESC_WP + c0 + DESC_R + wsh[kk]];
+      t1v[kk][q] = win[kk * (DESC_WIN * DESC_WP) + (r1 + DESC_R) * DESC_WP + c1 + DESC_R + wsh[kk]];
 #else
-      t0v[kk][q] = center[kk][(uint32_t)((r0 + DESC_R) * bstride[kk] + c0 + DESC_R)];
+      t0v[kk][q] = center[kk][(uint32_t)((r0 + DESC_R) * bstride[kk] + c0 + DESC_R)];   // (unstaged build: center is the window's own corner)
       t1v[kk][q] = center[kk][(uint32_t)((r1 + DESC_R) * bstride[kk] + c1 + DESC_R)];
 #endif
     }
@@ -775,7 +798,7 @@ static int cvRoundF(float v) { return (int)lrintf(v); }
 
 void free_buffers(morb_extractor* e) {
   auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-  F(e->d_geom); F(e->d_geomTeam); F(e->d_tabs); F(e->d_segTab); F(e->d_pyr); F(e->d_blur); F(e->d_cand); F(e->d_qt); F(e->d_sel);
+  F(e->d_geom); F(e->d_geomTeam); F(e->d_tabs); F(e->d_pcol); F(e->d_prow); F(e->d_pedge); F(e->d_segTab); F(e->d_pyr); F(e->d_blur); F(e->d_cand); F(e->d_qt); F(e->d_sel);
   F(e->d_candCnt); F(e->d_selCnt); F(e->d_kref); F(e->d_lap);
   e->W = e->H = e->nimgCap = 0;
   e->lapLast.clear();
@@ -795,6 +818,8 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
   free_buffers(e);
   const int L = e->nlevels;
   std::vector<ResizeTab> tabs;
+  std::vector<PyrCol> pcols; std::vector<PyrRow> prows; std::vector<PyrEdge> pedges;
+  bool pyrPacked = true;
   size_t pyrOff = 0, blurOff = 0, qtOff = 0;
   int cellBase = 0, selBase = 0, blurTileBase = 0;
   e->cellCap = 0; e->maxCells = 0; e->maxNodeCap = 0; e->maxListCap = 0;
@@ -889,7 +914,65 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     };
     g.xtabOff = (int)tabs.size(); build(g.w, gs.w, true, tabs);
     g.ytabOff = (int)tabs.size(); build(g.h, gs.h, false, tabs);
+    // k_resize's item tables: one PyrCol per destination dword, one PyrRow per destination row (padded to whole groups of PR)
+    PyrLevel& pl = e->pyrLv[l];
+    pl.nC = div_up(g.w + 2 * EDGE, 4); pl.nG = div_up(g.h + 2 * EDGE, PR); pl.nItems = pl.nC * pl.nG;
+    pl.magicC = (uint32_t)((1ull << 32) / (unsigned)pl.nC + 1);
+    MORB_REQUIRE((unsigned long long)pl.nItems * (unsigned)pl.nC < (1ull << 32), MORB_ERR_UNSUPPORTED, "pyramid level too large for the item index arithmetic");
+    pl.ldsRows = (255 / pl.nC + 2) * PR;
+    pl.colOff = (int)pcols.size(); pl.rowOff = (int)prows.size();
+    const ResizeTab* xt = tabs.data() + g.xtabOff; const ResizeTab* yt = tabs.data() + g.ytabOff;
+    for (int c = 0; c < pl.nC; ++c) {
+      ResizeTab t4[4];
+      for (int k = 0; k < 4; ++k) t4[k] = xt[std::min(4 * c + k, g.w + 2 * EDGE - 1)];
+      int base = t4[0].s0, top = t4[0].s0;
+      for (int k = 0; k < 4; ++k) { base = std::min(base, (int)std::min(t4[k].s0, t4[k].s1)); top = std::max(top, (int)std::max(t4[k].s0, t4[k].s1)); }
+      if (top - base >= 8) pyrPacked = false;
+      // the window as three aligned dwords of the source's padded row (the interior starts EDGE bytes into it; rows are 64-byte aligned)
+      PyrCol pc; pc.base = (EDGE + base) & ~3; pc.sh = (EDGE + base) & 3; pc.pad_[0] = pc.pad_[1] = 0;
+      for (int k = 0; k < 4; ++k) {
+        pc.sel[k] = (uint32_t)((t4[k].s0 - base) & 7) | 0x0C00u | (uint32_t)((t4[k].s1 - base) & 7) << 16 | 0x0C000000u;
+        pc.coef[k] = (uint32_t)(uint16_t)t4[k].c0 | (uint32_t)(uint16_t)t4[k].c1 << 16;
+        if (t4[k].c0 < 0 || t4[k].c1 < 0) pyrPacked = false;
+      }
+      pcols.push_back(pc);
+    }
+    for (int r = 0; r < pl.nG * PR; ++r) {
+      const ResizeTab t = yt[std::min(r, g.h + 2 * EDGE - 1)];
+      PyrRow pr; pr.s0 = t.s0; pr.s1 = t.s1; pr.c0s = (uint32_t)t.c0 << 12; pr.c1s = (uint32_t)t.c1 << 12;
+      if (t.c0 < 0 || t.c1 < 0) pyrPacked = false;
+      prows.push_back(pr);
+    }
   }
+  {
+    // level 0 = the image plus its reflected pad: interior 16-byte chunks and edge dwords (k_level0)
+    const LevelGeom& g0 = e->geom[0];
+    PyrLevel0& p0 = e->pyrL0;
+    const int nC0 = div_up(g0.w + 2 * EDGE, 4);               // destination dwords per row
+    p0.j0 = div_up(EDGE, 16);                                  // first 16-byte chunk that lies wholly inside the image
+    p0.nInt = std::max(0, (EDGE + g0.w) / 16 - p0.j0);
+    p0.nG = div_up(g0.h + 2 * EDGE, P0R);
+    for (int d = 0; d < nC0; ++d) {
+      if (d >= 4 * p0.j0 && d < 4 * (p0.j0 + p0.nInt)) continue;
+      int xs[4], base = 1 << 30;
+      for (int k = 0; k < 4; ++k) {
+        int q = 4 * d + k - EDGE;
+        if (q < 0) q = -q;
+        if (q >= g0.w) q = 2 * (g0.w - 1) - q;
+        xs[k] = q; base = std::min(base, q);
+      }
+      base = std::min(base, g0.w - 4);
+      PyrEdge pe; pe.dword = d; pe.base = base; pe.sel = 0; pe.pad_ = 0;
+      for (int k = 0; k < 4; ++k) pe.sel |= (uint32_t)(xs[k] - base) << (8 * k);
+      pedges.push_back(pe);
+    }
+    p0.nEdge = (int)pedges.size();
+    p0.nIntItems = p0.nInt * p0.nG; p0.nItems = p0.nIntItems + p0.nEdge * p0.nG;
+    p0.magicInt = (uint32_t)((1ull << 32) / (unsigned)std::max(p0.nInt, 1) + 1);
+    p0.magicEdge = (uint32_t)((1ull << 32) / (unsigned)std::max(p0.nEdge, 1) + 1);
+    MORB_REQUIRE((unsigned long long)p0.nItems * (unsigned)std::max(p0.nInt, p0.nEdge) < (1ull << 32), MORB_ERR_UNSUPPORTED, "image too large for the item index arithmetic");
+  }
+  e->pyrPacked = pyrPacked;
   e->totalCells = cellBase;
   {
     // Two launches of k_fastw: the LDS window is sized by the tallest cell, and the few large cells of the small top levels would
@@ -1014,7 +1097,14 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
   MORB_HIP_CHECK(hipMemcpy(e->d_segTab, segs.data(), sizeof(FastSeg) * segs.size(), hipMemcpyHostToDevice));
   MORB_HIP_CHECK(hipMalloc(&e->d_tabs, sizeof(ResizeTab) * std::max<size_t>(tabs.size(), 1)));
   if (!tabs.empty()) MORB_HIP_CHECK(hipMemcpy(e->d_tabs, tabs.data(), sizeof(ResizeTab) * tabs.size(), hipMemcpyHostToDevice));
+  MORB_HIP_CHECK(hipMalloc(&e->d_pcol, sizeof(PyrCol) * std::max<size_t>(pcols.size(), 1)));
+  if (!pcols.empty()) MORB_HIP_CHECK(hipMemcpy(e->d_pcol, pcols.data(), sizeof(PyrCol) * pcols.size(), hipMemcpyHostToDevice));
+  MORB_HIP_CHECK(hipMalloc(&e->d_prow, sizeof(PyrRow) * std::max<size_t>(prows.size(), 1)));
+  if (!prows.empty()) MORB_HIP_CHECK(hipMemcpy(e->d_prow, prows.data(), sizeof(PyrRow) * prows.size(), hipMemcpyHostToDevice));
+  MORB_HIP_CHECK(hipMalloc(&e->d_pedge, sizeof(PyrEdge) * std::max<size_t>(pedges.size(), 1)));
+  if (!pedges.empty()) MORB_HIP_CHECK(hipMemcpy(e->d_pedge, pedges.data(), sizeof(PyrEdge) * pedges.size(), hipMemcpyHostToDevice));
   MORB_HIP_CHECK(hipMalloc(&e->d_pyr, e->pyrBytes + 256));
+  MORB_HIP_CHECK(hipMemset(e->d_pyr, 0, e->pyrBytes + 256));   // (the alignment slack behind each row is never written; other kernels' wide loads may touch it)
   MORB_HIP_CHECK(hipMalloc(&e->d_blur, e->blurBytes + 256));
   MORB_HIP_CHECK(hipMalloc(&e->d_cand, sizeof(uint32_t) * (size_t)nimg * e->totalCells * e->cellCap));
   MORB_HIP_CHECK(hipMalloc(&e->d_candCnt, sizeof(int) * (size_t)nimg * e->totalCells));
@@ -1209,22 +1299,36 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   mark(0);
   {
     const LevelGeom& g0 = e->geom[0];
-    dim3 grid(div_up(g0.pstride / 4, 64), div_up(g0.h + 2 * EDGE, 4 * PY_ROWS), nimg);
-    int l0 = 1;
-    if (L >= 2) {
-      const LevelGeom& g1 = e->geom[1];
-      dim3 gr(div_up(g1.pstride / 4, 64), div_up(g1.h + 2 * EDGE, 4 * PY_ROWS), nimg);
-      hipLaunchKernelGGL(k_level01, gr, dim3(256), 0, st, d_images, width, height, stride, image_pitch, e->d_pyr, g0, g1,
-                         e->d_tabs + g1.xtabOff, e->d_tabs + g1.ytabOff, (int)grid.x, (int)grid.y);
-      l0 = 2;
-    } else {
-      hipLaunchKernelGGL(k_level0, grid, dim3(256), 0, st, d_images, width, height, stride, image_pitch, e->d_pyr, g0);
-    }
-    for (int l = l0; l < L; ++l) {
+    const PyrLevel0& p0 = e->pyrL0;
+    Level0Args a0;
+    a0.edge = e->d_pedge; a0.nInt = p0.nInt; a0.j0 = p0.j0; a0.nEdge = p0.nEdge; a0.nIntItems = p0.nIntItems; a0.nItems = p0.nItems;
+    a0.H = g0.h + 2 * EDGE; a0.h = g0.h; a0.dpstride = g0.pstride; a0.magicInt = p0.magicInt; a0.magicEdge = p0.magicEdge; a0.dOff = g0.pyrOff; a0.dImg = g0.pyrImg;
+    auto resize_args = [&](int l) {
       const LevelGeom& g = e->geom[l];
-      dim3 gr(div_up(g.pstride / 4, 64), div_up(g.h + 2 * EDGE, 4 * PY_ROWS), nimg);
-      hipLaunchKernelGGL(k_resize, gr, dim3(256), 0, st, e->d_pyr, e->geom[l - 1], g, e->d_tabs + g.xtabOff,
-                         e->d_tabs + g.ytabOff);
+      const PyrLevel& pl = e->pyrLv[l];
+      ResizeArgs a;
+      a.col = e->d_pcol + pl.colOff; a.row = e->d_prow + pl.rowOff; a.nC = pl.nC; a.nItems = pl.nItems; a.H = g.h + 2 * EDGE; a.dpstride = g.pstride;
+      a.magicC = pl.magicC; a.dOff = g.pyrOff; a.dImg = g.pyrImg;
+      return a;
+    };
+    if (e->pyrPacked) {
+      // level 0 first, in its own launch: level 1 reads it back from the pyramid (dword-aligned rows with slack behind them — the wide
+      // aligned window loads of k_resize cannot be pointed at a caller-owned buffer; the fused level-0 + level-1 kernel of round 2 did
+      // that with byte-granular 8-byte loads at twice the memory-pipe cost)
+      hipLaunchKernelGGL(k_level0, dim3(div_up(p0.nItems, 256), 1, nimg), dim3(256), 0, st, d_images, stride, image_pitch, e->d_pyr, a0);
+      for (int l = 1; l < L; ++l) {
+        const LevelGeom& gs = e->geom[l - 1];
+        const PyrLevel& pl = e->pyrLv[l];
+        hipLaunchKernelGGL(k_resize, dim3(div_up(pl.nItems, 256), 1, nimg), dim3(256), sizeof(PyrRow) * pl.ldsRows, st, e->d_pyr,
+                           gs.pyrOff + (unsigned long long)EDGE * gs.pstride, gs.pyrImg, gs.pstride, resize_args(l));
+      }
+    } else {
+      hipLaunchKernelGGL(k_level0, dim3(div_up(p0.nItems, 256), 1, nimg), dim3(256), 0, st, d_images, stride, image_pitch, e->d_pyr, a0);
+      for (int l = 1; l < L; ++l) {
+        const LevelGeom& g = e->geom[l];
+        dim3 gr(div_up(g.pstride / 4, 64), div_up(g.h + 2 * EDGE, 4 * PY_ROWS), nimg);
+        hipLaunchKernelGGL(k_resize_gather, gr, dim3(256), 0, st, e->d_pyr, e->geom[l - 1], g, e->d_tabs + g.xtabOff, e->d_tabs + g.ytabOff);
+      }
     }
   }
   mark(1);

@@ -66,6 +66,19 @@ struct alignas(8) ResizeTab {  // one entry per padded destination column / row 
   short s0, s1, c0, c1;  // source index (clipped), source index + 1 (clipped), fixed-point weights (2048 = 1)
 };
 
+// k_resize / k_level01 work on linearly numbered items (extractor.hip): per destination dword of a level (PyrCol), per destination
+// row (PyrRow), per pad dword of level 0 (PyrEdge)
+struct alignas(16) PyrCol {   // 48 bytes: three 16-byte loads
+  int base;            // the chunk's 8-byte source window starts at byte base + sh of the source's padded row; base is a multiple of 4
+  uint32_t sel[4];     // v_perm_b32 selector of pixel k: left source byte -> byte 0, right source byte -> byte 2, bytes 1 and 3 zero
+  uint32_t coef[4];    // c0 | c1 << 16 (2048 = 1)
+  int sh, pad_[2];
+};
+struct alignas(16) PyrRow { int s0, s1; uint32_t c0s, c1s; };   // source rows (clipped), vertical weights << 12
+struct alignas(16) PyrEdge { int dword, base; uint32_t sel; int pad_; };   // destination dword, source byte offset of its 4-byte window, byte selector
+struct PyrLevel { int nC, nG, nItems, colOff, rowOff, ldsRows; uint32_t magicC; };
+struct PyrLevel0 { int nInt, j0, nEdge, nG, nIntItems, nItems; uint32_t magicInt, magicEdge; };
+
 }  // namespace morb
 
 struct morb_extractor {
@@ -96,6 +109,9 @@ struct morb_extractor {
   hipEvent_t evFork = nullptr, evJoin = nullptr;
   morb::LevelGeom* d_geom = nullptr;
   morb::ResizeTab* d_tabs = nullptr;
+  morb::PyrCol* d_pcol = nullptr; morb::PyrRow* d_prow = nullptr; morb::PyrEdge* d_pedge = nullptr;
+  morb::PyrLevel pyrLv[morb::kMaxLevels] = {}; morb::PyrLevel0 pyrL0 = {};
+  bool pyrPacked = true;   // every level's four-pixel chunks fit k_resize's 8-byte source windows (scale factors up to ~1.75)
   morb::FastSeg* d_segTab = nullptr;
   uint8_t *d_pyr = nullptr, *d_blur = nullptr;
   uint32_t *d_cand = nullptr, *d_qt = nullptr, *d_sel = nullptr;
