@@ -719,7 +719,7 @@ def main():
         fps = B * world * args.steps / dt
         ab = algorithmic_bytes(W, H)
         nimg = 2 * B
-        kern = {"pyramid": "k_level01+k_resize", "blur": "k_blur", "fast": "k_fastw"}
+        kern = {"pyramid": "k_level0+k_resize", "blur": "k_blur", "fast": "k_fastw"}
         # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of the extraction
         # at 128 images per launch; profiles/<round>/pmc_traffic_b64.json) — not measurable live.  Corrected as the calibration kernel
         # prescribes (profiles/r03/fetch_calib.txt: FETCH_SIZE reads 0.500 x the bytes of coalesced 4 / 8 / 16-byte reads, WRITE_SIZE 1.0 x):
@@ -736,8 +736,8 @@ def main():
             if pm is None or args.workload != "c2":
                 return None
             try:
-                # launches per extraction: levels 0 + 1 from one launch, six resizes; two k_fastw launch groups (the per-launch mean is over both)
-                names = {"pyramid": [("k_level01", 1), ("k_resize", 6)], "blur": [("k_blur", 1)], "fast": [("k_fastw", 2)]}[stage]
+                # launches per extraction: level 0, seven resizes; two k_fastw launch groups (the per-launch mean is over both)
+                names = {"pyramid": [("k_level0", 1), ("k_resize", 7)], "blur": [("k_blur", 1)], "fast": [("k_fastw", 2)]}[stage]
                 return sum(pm[k]["traffic_KB_per_launch"] * 1024 * m for k, m in names) * nimg / pm.get("images_per_launch", 128)
             except Exception:
                 return None
@@ -749,7 +749,7 @@ def main():
                     # not part of the timed region: the stage alone on the chip (steps not overlapped)
                     "isolated_avg_launch_ms": iso[stage], "isolated_frac": ab[stage] * nimg / (iso[stage] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         # the dominant streaming stage of the extractor = the longest of the three by its time INSIDE the timed region (HIP
-        # events on the launch stream; "pyramid" is the dependent launches of k_level01 / k_resize, "fast" the two k_fastw
+        # events on the launch stream; "pyramid" is the dependent launches of k_level0 / k_resize, "fast" the two k_fastw
         # launch groups, which follow each other)
         dom = max(("pyramid", "blur", "fast"), key=lambda k: stages[k])
         wl = {"c2": f"BASELINE configs[1]: EuRoC-shaped stereo {W}x{H}, {NFEAT} feat", "c4": f"BASELINE configs[3]: synthetic stereo {W}x{H}, {NFEAT} feat"}[args.workload]

@@ -47,7 +47,10 @@ using namespace morb;
 
 namespace {
 
-constexpr int kTeamMaxImages = 16;   // k_distribute: calls with at most this many images use the team packing of the big levels
+#ifndef MORB_TEAM_MAX_IMAGES
+#define MORB_TEAM_MAX_IMAGES 16
+#endif
+constexpr int kTeamMaxImages = MORB_TEAM_MAX_IMAGES;   // k_distribute: calls with at most this many images use the team packing of the big levels
 
 __constant__ __align__(16) int c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
@@ -310,19 +313,23 @@ __global__ __launch_bounds__(256) void k_blur(const LevelGeom* __restrict__ geom
   }
   const int rows = (g.h - y0) < BT_ROWS ? (g.h - y0) : BT_ROWS;
   constexpr uint32_t W01 = 18u | (34u << 16), W23 = 48u | (56u << 16), W45 = 48u | (34u << 16);
+  // Rows past the bottom of the level (the last strip of a tile column) are computed like the others — from the last padded row, so no
+  // load leaves the level — and only their store is skipped: with the whole row body under `if (r < rows)` (per-lane: the two halves of a
+  // wave work different strips) the compiler merged the rotating row window through 688 v_mov per wave, a third of the kernel's VALU work.
+  const int lastRow = g.h + 2 * EDGE - 1 - (EDGE + y0 - 3);   // last padded row, relative to src
 #pragma unroll
   for (int r = 0; r < BT_ROWS; ++r) {
-    if (r < rows) {   // (fully unrolled: the row window rotates by renaming)
+    {   // (fully unrolled: the row window rotates by renaming)
     uint32_t hn[8], acc[8];
-    blur_h8(src + (size_t)(r + 6) * g.pstride, hn);
+    blur_h8(src + (uint32_t)__umul24(min(r + 6, lastRow), g.pstride), hn);
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      acc[k] = blur_dot2(P[0][k], W01, blur_dot2(P[2][k], W23, blur_dot2(P[4][k], W45, 18u * hn[k] + 32768u)));
+      acc[k] = blur_dot2(P[0][k], W01, blur_dot2(P[2][k], W23, blur_dot2(P[4][k], W45, __umul24(18u, hn[k]) + 32768u)));   // (hn < 2^16: v_mad_u32_u24, full rate)
     // acc < 2^24: the rounded output is byte 2 of each accumulator
     uint2 o;
     o.x = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u) | __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
     o.y = __builtin_amdgcn_perm(acc[5], acc[4], 0x0c0c0602u) | __builtin_amdgcn_perm(acc[7], acc[6], 0x06020c0cu);
-    *reinterpret_cast<uint2*>(dst + (size_t)r * g.bstride) = o;   // columns >= w land in the row's alignment slack
+    if (r < rows) *reinterpret_cast<uint2*>(dst + (size_t)r * g.bstride) = o;   // columns >= w land in the row's alignment slack
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       P[0][k] = P[1][k]; P[1][k] = P[2][k]; P[2][k] = P[3][k]; P[3][k] = P[4][k];

@@ -1085,6 +1085,8 @@ struct IbaDev {
   const float *eObs, *eInfo;
   const int *ptStart, *ptEdges;                 // CSR by point
   const int *kfEdges, *chunkKF, *chunkStart, *chunkEnd;   // edges of free keyframes in chunks of <= 64
+  double* kfPart; int* kfTicket;                          // per-chunk partial sums of k_iba_kf (27 each), arrival counter per keyframe
+  const int* linkOrder;                                   // inertial links sorted by colour: links of one colour share no keyframe
   const int* col;                               // [nKF] index of an optimizable keyframe or -1
   const int *iKF1, *iKF2;
   const morb_imu_preintegrated* iPre;
@@ -1096,7 +1098,8 @@ struct IbaDev {
   double *vErr, *iErr, *gErr, *aErr;            // errors of the last computeActiveErrors
   double *InfoI, *InfoG, *InfoA;
   double *H, *b, *Hll, *Hpl, *Hs, *bs, *x;      // b, x: P + 3 nMP
-  double* scal;                                 // [0] robust chi2, [1] scale, [2] solve ok
+  double* scal;                                 // [0] robust chi2 of the last k_iba_errors, [2] solve ok
+  double *partChi, *partScale; int nbUpdate;    // per-block partial sums of k_iba_errors / k_iba_update (added up in block order)
   // Schur complement on the FP64 matrix cores (schur_mfma.h): dense K-major operands (columns 6 c + r of the pose parts, plus
   // the right-hand-side column 6 nOpt), partial products, block directory
   double *sW, *sWD, *sPart;
@@ -1128,15 +1131,24 @@ __device__ __forceinline__ void iba_store(const VIState& V, double* s) {
 __device__ __forceinline__ double huber_rho(double delta, double e2) {   // rho(e2)
   return e2 <= delta * delta ? e2 : 2 * sqrt(e2) * delta - delta * delta;
 }
-__device__ __forceinline__ double block_add(double v, double* target) {   // sum over the block -> one atomic
+// Sum over the block, in a fixed order (DPP tree per wave, then the waves in turn): thread 0 holds it.  The blocks' sums are stored one per
+// block and added up in block order by whoever consumes them — a floating-point atomicAdd per block would make the chi2, through rho and
+// lambda every later iterate, depend on the order in which the blocks happen to finish (seen as last-bit differences between two runs).
+__device__ __forceinline__ double block_sum(double v) {
   __shared__ double red[16];
   v = wave_sum(v);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   if (lane == 0) red[wv] = v;
   __syncthreads();
-  if (threadIdx.x == 0) { double s = 0; for (int w = 0; w < nw; ++w) s += red[w]; unsafeAtomicAdd(target, s); }
+  double s = 0;
+  if (threadIdx.x == 0) for (int w = 0; w < nw; ++w) s += red[w];
   __syncthreads();
-  return 0;
+  return s;
+}
+__device__ __forceinline__ double ordered_sum(const double* part, int n) {   // one thread; the partials were written by other workgroups
+  double s = 0;
+  for (int k = 0; k < n; ++k) s += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(part + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  return s;
 }
 __device__ __forceinline__ double iba_vis_chi2(const IbaDev& D, int e) {
   const double info = (double)D.eInfo[e];
@@ -1180,9 +1192,9 @@ __global__ __launch_bounds__(64) void k_iba_setup_links(IbaDev D, const float* _
   for (int k = threadIdx.x; k < 81; k += 64) D.InfoI[(size_t)i * 81 + k] = Inf[k] * (double)infoScale[i];
 }
 
-// computeActiveErrors + activeRobustChi2 -> scal[0]
-__device__ void iba_lm_decide(const IbaDev& D);
-// mode 0: computeActiveErrors + activeRobustChi2 (the chi2 accumulates into scal[0]).  mode 1 (a trial under device-side LM control):
+// computeActiveErrors + activeRobustChi2 -> scal[0] (the last workgroup to finish adds the blocks' partial sums up in block order)
+__device__ void iba_lm_decide(const IbaDev& D, double trialChi2);
+// mode 0: computeActiveErrors + activeRobustChi2.  mode 1 (a trial under device-side LM control):
 // returns at once when the solve has finished; the last workgroup to finish takes the trial's accept / reject decision.
 __global__ __launch_bounds__(256) void k_iba_errors(IbaDev D, int mode) {
   if (mode == 1 && iba_done(D)) return;
@@ -1213,10 +1225,10 @@ __global__ __launch_bounds__(256) void k_iba_errors(IbaDev D, int mode) {
     const double ci = iba_quad(err, D.InfoI + (size_t)i * 81, 9);
     c = (D.iRobust[i] ? huber_rho(deltaI, ci) : ci) + iba_quad(ge, D.InfoG + (size_t)i * 9, 3) + iba_quad(ae, D.InfoA + (size_t)i * 9, 3);
   }
-  block_add(c, D.scal + 0);
-  if (mode != 1) return;
+  const double bs = block_sum(c);
   __shared__ int isLast;
   if (threadIdx.x == 0) {
+    D.partChi[blockIdx.x] = bs;
     __threadfence();
     isLast = atomicAdd(&D.lmi[IBA_LM_TICKET], 1) == (int)gridDim.x - 1;
   }
@@ -1224,16 +1236,16 @@ __global__ __launch_bounds__(256) void k_iba_errors(IbaDev D, int mode) {
   if (!isLast || threadIdx.x != 0) return;
   __threadfence();
   D.lmi[IBA_LM_TICKET] = 0;
-  iba_lm_decide(D);
+  const double chi2 = ordered_sum(D.partChi, (int)gridDim.x);
+  D.scal[0] = chi2;
+  if (mode == 1) iba_lm_decide(D, chi2);
 }
 // optimization_algorithm_levenberg.cpp:99-169 with ORB-SLAM's stop rule, as local_inertial_ba_impl's host loop ran it: rho from
-// the trial's chi2 (scal[0]), the linear-model gain (scal[1]) and the solver's flag (scal[2]); the accumulators are cleared for the
-// next trial.  One thread.
-__device__ void iba_lm_decide(const IbaDev& D) {
-  const double s0 = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<unsigned long long*>(D.scal + 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  const double s1 = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<unsigned long long*>(D.scal + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+// the trial's chi2, the linear-model gain (the sum of k_iba_update's per-block partials) and the solver's flag (scal[2]).  One thread.
+__device__ void iba_lm_decide(const IbaDev& D, double trialChi2) {
+  const double s0 = trialChi2;
+  const double s1 = ordered_sum(D.partScale, D.nbUpdate);   // k_iba_update's blocks, in block order
   const bool ok2 = D.scal[2] != 0.0;
-  D.scal[0] = 0.0; D.scal[1] = 0.0;
   double currentChi = D.lmd[IBA_LMD_CHI], lambda = D.lmd[IBA_LMD_LAMBDA], ni = D.lmd[IBA_LMD_NI];
   const double iniChi = D.lmd[IBA_LMD_INICHI];
   int iter = D.lmi[IBA_LM_ITER], qmax = D.lmi[IBA_LM_QMAX], nBad = D.lmi[IBA_LM_NBAD], its = D.lmi[IBA_LM_ITS];
@@ -1412,25 +1424,47 @@ __global__ __launch_bounds__(256) void k_iba_kf(IbaDev D) {
   }
 #pragma unroll
   for (int q = 0; q < 27; ++q) acc[q] = wave_sum(acc[q]);
+  // A keyframe's chunks are added up in chunk order by whichever of them finishes last (floating-point atomics would add them in
+  // arrival order: the Hessian, and with it every iterate, would differ in the last bits from run to run).  Nothing else has touched the
+  // keyframe's pose block yet — the links are launched afterwards — so the sum is stored with plain read-modify-writes.
+  int first = c, end = c + 1, last = 0;
   if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 27; ++q) D.kfPart[(size_t)c * 27 + q] = acc[q];
+    while (first > 0 && D.chunkKF[first - 1] == kf) --first;
+    while (end < D.nChunks && D.chunkKF[end] == kf) ++end;
+    __threadfence();
+    last = atomicAdd(&D.kfTicket[kf], 1) == end - first - 1;
+  }
+  last = __builtin_amdgcn_readfirstlane(last);
+  if (!last) return;
+  first = __builtin_amdgcn_readfirstlane(first); end = __builtin_amdgcn_readfirstlane(end);
+  __threadfence();
+  if (lane == 0) D.kfTicket[kf] = 0;
+  if (lane < 27) {
+    double sum = 0;
+    for (int j = first; j < end; ++j)
+      sum += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(D.kfPart + (size_t)j * 27 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     const int o = 15 * D.col[kf];
-    int q = 0;
-    for (int r = 0; r < 6; ++r)
-      for (int cc = r; cc < 6; ++cc) {
-        unsafeAtomicAdd(&D.H[(size_t)(o + r) * D.P + o + cc], acc[q]);
-        if (cc != r) unsafeAtomicAdd(&D.H[(size_t)(o + cc) * D.P + o + r], acc[q]);
-        ++q;
-      }
-    for (int r = 0; r < 6; ++r) unsafeAtomicAdd(&D.b[o + r], acc[21 + r]);
+    if (lane >= 21) D.b[o + lane - 21] += sum;
+    else {
+      int r = 0, q0 = 0;
+      while (lane >= q0 + 6 - r) { q0 += 6 - r; ++r; }
+      const int cc = r + lane - q0;
+      D.H[(size_t)(o + r) * D.P + o + cc] += sum;
+      if (cc != r) D.H[(size_t)(o + cc) * D.P + o + r] += sum;
+    }
   }
 }
 // inertial + random-walk edges: one 64-thread workgroup per link; thread 0 evaluates the edge (error, 9 x 24 Jacobian) into LDS, all
 // threads multiply out J^T Omega J
-__global__ __launch_bounds__(64) void k_iba_links(IbaDev D) {
+// One launch per colour: the links of a launch share no keyframe (a chain of consecutive keyframes has two colours), so every entry of H
+// receives its contributions — the keyframe's visual block, then its links colour by colour — in the same order in every run.
+__global__ __launch_bounds__(64) void k_iba_links(IbaDev D, int base) {
   __shared__ double J[216], OJ[216], Oe[9];
   __shared__ double sw;
   if (iba_no_build(D)) return;
-  const int i = blockIdx.x, tid = threadIdx.x;
+  const int i = D.linkOrder[base + blockIdx.x], tid = threadIdx.x;
   const int k1 = D.iKF1[i], k2 = D.iKF2[i];
   for (int k = tid; k < 216; k += 64) J[k] = 0;
   __syncthreads();
@@ -1469,6 +1503,7 @@ __global__ __launch_bounds__(64) void k_iba_links(IbaDev D) {
       unsafeAtomicAdd(&D.b[ca], -w * sm);
     }
   }
+  __syncthreads();   // (the random-walk terms land on entries of the bias blocks the loop above has added to: after it, not in a race with it)
   if (tid < 18) {   // EdgeGyroRW / EdgeAccRW: e = bias2 - bias1; thread = (type, row r, column c)
     const int t = tid / 9, r = (tid % 9) / 3, c = tid % 3;
     const double* I3 = (t == 0 ? D.InfoG : D.InfoA) + (size_t)i * 9;
@@ -1587,7 +1622,7 @@ __global__ __launch_bounds__(morbdense::GT) void k_iba_solve_blocked(IbaDev D, i
   if (threadIdx.x == 0) D.scal[2] = ok ? 1.0 : 0.0;
 }
 
-// back-substitution of the points + oplus of every vertex + the LM scale  sum x (lambda x + b) -> scal[1]
+// back-substitution of the points + oplus of every vertex + the LM scale  sum x (lambda x + b) -> partScale[block]
 __global__ __launch_bounds__(256) void k_iba_update(IbaDev D) {
   if (iba_done(D)) return;
   const double lambda = D.lmd[IBA_LMD_LAMBDA];
@@ -1630,7 +1665,8 @@ __global__ __launch_bounds__(256) void k_iba_update(IbaDev D) {
       iba_store(V, D.S + 33 * (size_t)k);
     }
   }
-  block_add(sc, D.scal + 1);
+  const double bs = block_sum(sc);
+  if (threadIdx.x == 0) D.partScale[blockIdx.x] = bs;
 }
 // erase flags (:2773-2801) from the errors of the last computeActiveErrors, and the float outputs
 __global__ __launch_bounds__(256) void k_iba_finish(IbaDev D, uint8_t* __restrict__ erase, float* __restrict__ kfOut, float* __restrict__ mpOut) {
@@ -1823,7 +1859,9 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
                    sizeof(double) * (size_t)P * P, sizeof(double) * (size_t)P * P, sizeof(double) * nX, sizeof(double) * (size_t)P,
                    sizeof(double) * nX, sizeof(double) * 9 * (size_t)nMP, sizeof(double) * 18 * (size_t)nE, sizeof(double) * 4,
                    (size_t)nE, (size_t)nE, sizeof(double) * splan.wElems(), sizeof(double) * splan.wElems(), sizeof(double) * splan.partElems(), sizeof(double) * morbdense::global_panel_doubles(P),
-                   sizeof(int2) * (size_t)splan.nblk, sizeof(int) * (size_t)splan.nb * splan.nb, sizeof(double) * 8, sizeof(int) * 16})
+                   sizeof(int2) * (size_t)splan.nblk, sizeof(int) * (size_t)splan.nb * splan.nb, sizeof(double) * 8, sizeof(int) * 16,
+                   sizeof(int) * (size_t)nI, sizeof(double) * 27 * (size_t)nChunks, sizeof(int) * (size_t)nKF,
+                   sizeof(double) * (size_t)div_up(nE + nI, 256), sizeof(double) * (size_t)div_up(nMP + nKF, 256)})
     reserve(b);
   void* arena = nullptr;
   { const int rc = morb_optimizer_workspace(o, arenaBytes, &arena); if (rc != MORB_OK) return rc; }
@@ -1845,7 +1883,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
                      sizeof(int) * (size_t)nChunks, sizeof(int) * (size_t)nChunks, sizeof(int) * (size_t)nKF, sizeof(int) * (size_t)nI,
                      sizeof(int) * (size_t)nI, sizeof(morb_imu_preintegrated) * (size_t)nI, (size_t)nI, (size_t)nMP, sizeof(float) * (size_t)nI,
                      sizeof(float) * 21 * (size_t)nKF, sizeof(float) * 3 * (size_t)nMP, (size_t)nE, sizeof(int2) * (size_t)splan.nblk,
-                     sizeof(int) * (size_t)splan.nb * splan.nb})
+                     sizeof(int) * (size_t)splan.nb * splan.nb, sizeof(int) * (size_t)nI})
       upBytes += (std::max<size_t>(b, 16) + 255) & ~(size_t)255;
     const int rc = morb_optimizer_staging(o, upBytes, &stage);
     if (rc != MORB_OK) return rc;
@@ -1883,12 +1921,35 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
     for (int bi = 0; bi < splan.nb; ++bi) for (int bj = bi; bj < splan.nb; ++bj) { blkIndex[(size_t)bi * splan.nb + bj] = (int)blocks.size(); blocks.push_back(make_int2(bi, bj)); }
     D.sBlocks = (const int2*)up(blocks.data(), sizeof(int2) * blocks.size()); D.sBlkIndex = (const int*)up(blkIndex.data(), sizeof(int) * blkIndex.size());
   }
-  MORB_REQUIRE(D.sBlkIndex != nullptr && arenaOff <= arenaBytes, MORB_ERR_HIP, "workspace carve-up overflow in morb_local_inertial_ba");
+  // colour the inertial links so that links of one colour share no keyframe (greedy; a chain of consecutive keyframes alternates 0 / 1)
+  std::vector<int> linkOrder, colourStart;
+  {
+    std::vector<int> colour(nI, 0);
+    int nColours = 0;
+    for (int i = 0; i < nI; ++i) {
+      int c = 0;
+      for (bool clash = true; clash; ) {
+        clash = false;
+        for (int j = 0; j < i && !clash; ++j)
+          clash = colour[j] == c && (iKF1[j] == iKF1[i] || iKF1[j] == iKF2[i] || iKF2[j] == iKF1[i] || iKF2[j] == iKF2[i]);
+        if (clash) ++c;
+      }
+      colour[i] = c; nColours = std::max(nColours, c + 1);
+    }
+    for (int c = 0; c < nColours; ++c) { colourStart.push_back((int)linkOrder.size()); for (int i = 0; i < nI; ++i) if (colour[i] == c) linkOrder.push_back(i); }
+    colourStart.push_back((int)linkOrder.size());
+  }
+  D.linkOrder = (const int*)up(linkOrder.data(), sizeof(int) * nI);
+  MORB_REQUIRE(D.sBlkIndex != nullptr && D.linkOrder != nullptr && arenaOff <= arenaBytes, MORB_ERR_HIP, "workspace carve-up overflow in morb_local_inertial_ba");
   if (hipMemcpyAsync(arena, stage, upHi, hipMemcpyHostToDevice, st) != hipSuccess) return MORB_ERR_HIP;   // the one upload
+  D.kfPart = (double*)dalloc(sizeof(double) * 27 * (size_t)nChunks); D.kfTicket = (int*)dalloc(sizeof(int) * (size_t)nKF);
+  MORB_REQUIRE(D.kfTicket != nullptr, MORB_ERR_HIP, "workspace carve-up overflow in morb_local_inertial_ba");
+  (void)hipMemsetAsync(D.kfTicket, 0, sizeof(int) * (size_t)nKF, st);   // (the last chunk of a keyframe to arrive resets its counter)
   D.S = (double*)dalloc(sizeof(double) * nS); D.Sbk = (double*)dalloc(sizeof(double) * nS);
   D.pts = (double*)dalloc(sizeof(double) * nPts); D.ptsBk = (double*)dalloc(sizeof(double) * nPts);
   D.nS = (int)nS; D.nPts = (int)nPts;
   D.lmd = (double*)dalloc(sizeof(double) * 8); D.lmi = (int*)dalloc(sizeof(int) * 16);
+  if (D.lmi) (void)hipMemsetAsync(D.lmi, 0, sizeof(int) * 16, st);   // (k_iba_errors' arrival counter is live before k_iba_lm_init)
   D.vErr = (double*)dalloc(sizeof(double) * 3 * nE); D.iErr = (double*)dalloc(sizeof(double) * 9 * std::max(nI, 1));
   D.gErr = (double*)dalloc(sizeof(double) * 3 * std::max(nI, 1)); D.aErr = (double*)dalloc(sizeof(double) * 3 * std::max(nI, 1));
   D.InfoI = (double*)dalloc(sizeof(double) * 81 * std::max(nI, 1)); D.InfoG = (double*)dalloc(sizeof(double) * 9 * std::max(nI, 1));
@@ -1897,6 +1958,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
   D.b = (double*)dalloc(sizeof(double) * nX); D.bs = (double*)dalloc(sizeof(double) * P); D.x = (double*)dalloc(sizeof(double) * nX);
   D.Hll = (double*)dalloc(sizeof(double) * 9 * nMP); D.Hpl = (double*)dalloc(sizeof(double) * 18 * nE);
   D.scal = (double*)dalloc(sizeof(double) * 4);
+  D.partChi = (double*)dalloc(sizeof(double) * div_up(nE + nI, 256)); D.partScale = (double*)dalloc(sizeof(double) * div_up(nMP + nKF, 256)); D.nbUpdate = div_up(nMP + nKF, 256);
   D.pnlG = (double*)dalloc(sizeof(double) * morbdense::global_panel_doubles(P));
   uint8_t* d_erase = (uint8_t*)dalloc(nE);
   MORB_REQUIRE(d_erase != nullptr && arenaOff <= arenaBytes, MORB_ERR_HIP, "workspace carve-up overflow in morb_local_inertial_ba");
@@ -1954,7 +2016,8 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
       // backup / restore, then buildSystem (which runs only when the previous trial was accepted)
       hipLaunchKernelGGL(k_iba_points, dim3(beginGrid), dim3(256), 0, st, D);
       if (nChunks) hipLaunchKernelGGL(k_iba_kf, dim3(div_up(nChunks, 4)), dim3(256), 0, st, D);
-      if (nI) hipLaunchKernelGGL(k_iba_links, dim3(nI), dim3(64), 0, st, D);
+      for (size_t c = 0; c + 1 < colourStart.size(); ++c)
+        hipLaunchKernelGGL(k_iba_links, dim3(colourStart[c + 1] - colourStart[c]), dim3(64), 0, st, D, colourStart[c]);
       hipLaunchKernelGGL(k_iba_pack_w, dim3(div_up(std::max(nE, 3 * nMP), 256)), dim3(256), 0, st, D);
       // the trial: Schur complement of the points on the FP64 matrix cores, one dense product for matrix and right-hand side
       hipLaunchKernelGGL(k_iba_pack_wd, dim3(div_up(std::max(nE, P * P + P), 256)), dim3(256), 0, st, D);

@@ -12,7 +12,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
-HOT = ["k_level01", "k_resize", "k_level0", "k_blur", "k_fastw", "k_distribute", "k_layout", "k_describe",
+HOT = ["k_resize", "k_resize_gather", "k_level0", "k_blur", "k_fastw", "k_distribute", "k_layout", "k_describe",
        "k_stereo_prep", "k_stereo_match", "k_stereo_median", "k_bow_transform", "k_bow_sort", "k_rot_filter",
        "k_pose_opt", "k_g_chi2", "k_g_dinv_push", "k_g_backsub_update_w", "k_g_finish", "k_g_ldlt_lds", "k_g_ldlt_global", "k_iba_solve_blocked", "k_schur_mfma",
        "k_fe_triangulate", "k_triangulation", "k_frustum"]

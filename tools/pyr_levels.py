@@ -9,7 +9,6 @@ rows.sort()
 acc = collections.defaultdict(list); lvl = 0
 for s, e, n, gx, gy, gz in rows:
     if n == "k_level0": lvl = 0; acc[("k_level0", 0, gx, gy, gz)].append((e - s) / 1e3)
-    elif n == "k_level01": lvl = 1; acc[("k_level01", 1, gx, gy, gz)].append((e - s) / 1e3)
     elif n == "k_resize": lvl += 1; acc[("k_resize", lvl, gx, gy, gz)].append((e - s) / 1e3)
 for k, v in sorted(acc.items(), key=lambda kv: kv[0][1]):
     v = v[len(v) // 2:]
