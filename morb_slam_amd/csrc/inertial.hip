@@ -1145,10 +1145,13 @@ __device__ __forceinline__ double block_sum(double v) {
   __syncthreads();
   return s;
 }
-__device__ __forceinline__ double ordered_sum(const double* part, int n) {   // one thread; the partials were written by other workgroups
+// The partial sums of n workgroups added up by one full wave, always in the same order (lane k takes partials k, k + 64, ...; then the DPP
+// tree): every lane returns the total.  The partials were written by other workgroups: agent-scope loads.
+__device__ __forceinline__ double ordered_sum_wave(const double* part, int n) {
   double s = 0;
-  for (int k = 0; k < n; ++k) s += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(part + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  return s;
+  for (int k = threadIdx.x & 63; k < n; k += 64)
+    s += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(part + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  return wave_sum(s);
 }
 __device__ __forceinline__ double iba_vis_chi2(const IbaDev& D, int e) {
   const double info = (double)D.eInfo[e];
@@ -1193,7 +1196,7 @@ __global__ __launch_bounds__(64) void k_iba_setup_links(IbaDev D, const float* _
 }
 
 // computeActiveErrors + activeRobustChi2 -> scal[0] (the last workgroup to finish adds the blocks' partial sums up in block order)
-__device__ void iba_lm_decide(const IbaDev& D, double trialChi2);
+__device__ void iba_lm_decide(const IbaDev& D, double trialChi2, double gain);
 // mode 0: computeActiveErrors + activeRobustChi2.  mode 1 (a trial under device-side LM control):
 // returns at once when the solve has finished; the last workgroup to finish takes the trial's accept / reject decision.
 __global__ __launch_bounds__(256) void k_iba_errors(IbaDev D, int mode) {
@@ -1233,18 +1236,20 @@ __global__ __launch_bounds__(256) void k_iba_errors(IbaDev D, int mode) {
     isLast = atomicAdd(&D.lmi[IBA_LM_TICKET], 1) == (int)gridDim.x - 1;
   }
   __syncthreads();
-  if (!isLast || threadIdx.x != 0) return;
+  if (!isLast || threadIdx.x >= 64) return;   // the last workgroup's first wave adds the partials up
   __threadfence();
+  const double chi2 = ordered_sum_wave(D.partChi, (int)gridDim.x);
+  const double gain = mode == 1 ? ordered_sum_wave(D.partScale, D.nbUpdate) : 0.0;   // k_iba_update's blocks
+  if (threadIdx.x != 0) return;
   D.lmi[IBA_LM_TICKET] = 0;
-  const double chi2 = ordered_sum(D.partChi, (int)gridDim.x);
   D.scal[0] = chi2;
-  if (mode == 1) iba_lm_decide(D, chi2);
+  if (mode == 1) iba_lm_decide(D, chi2, gain);
 }
 // optimization_algorithm_levenberg.cpp:99-169 with ORB-SLAM's stop rule, as local_inertial_ba_impl's host loop ran it: rho from
 // the trial's chi2, the linear-model gain (the sum of k_iba_update's per-block partials) and the solver's flag (scal[2]).  One thread.
-__device__ void iba_lm_decide(const IbaDev& D, double trialChi2) {
+__device__ void iba_lm_decide(const IbaDev& D, double trialChi2, double gain) {
   const double s0 = trialChi2;
-  const double s1 = ordered_sum(D.partScale, D.nbUpdate);   // k_iba_update's blocks, in block order
+  const double s1 = gain;
   const bool ok2 = D.scal[2] != 0.0;
   double currentChi = D.lmd[IBA_LMD_CHI], lambda = D.lmd[IBA_LMD_LAMBDA], ni = D.lmd[IBA_LMD_NI];
   const double iniChi = D.lmd[IBA_LMD_INICHI];
@@ -1443,8 +1448,8 @@ __global__ __launch_bounds__(256) void k_iba_kf(IbaDev D) {
   if (lane == 0) D.kfTicket[kf] = 0;
   if (lane < 27) {
     double sum = 0;
-    for (int j = first; j < end; ++j)
-      sum += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(D.kfPart + (size_t)j * 27 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const double* part = D.kfPart + lane;   // (plain loads: the agent-scope fence above has dropped this CU's stale lines, nobody writes these again)
+    for (int j = first; j < end; ++j) sum += part[(size_t)j * 27];
     const int o = 15 * D.col[kf];
     if (lane >= 21) D.b[o + lane - 21] += sum;
     else {
