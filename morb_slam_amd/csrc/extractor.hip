@@ -70,7 +70,10 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 #define MORB_PY_ROWS 8
 #endif
 constexpr int PY_ROWS = MORB_PY_ROWS;  // rows per thread in k_resize_gather (block = 64 x 4 threads -> 256 px x 32 rows)
-constexpr int PR = 8;    // rows per item of k_resize
+#ifndef MORB_PR
+#define MORB_PR 8
+#endif
+constexpr int PR = MORB_PR;    // rows per item of k_resize
 constexpr int P0R = 4;   // rows per item of the level-0 copy
 // Workgroup -> tile mapping of the pyramid kernels.  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with
 // its own L2); with the plain (x, y, image) order the tiles of one image are spread over all of them and the source rows that
@@ -287,12 +290,21 @@ __device__ __forceinline__ uint32_t blur_dot2(uint32_t pair, uint32_t w, uint32_
 // 3 + 1 dword accesses per 4 pixels (the texture path is priced per instruction).
 __global__ __launch_bounds__(256) void k_blur(const LevelGeom* __restrict__ geom, int nlevels,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
+  // Workgroup -> (image, tile).  Consecutive workgroup ids go round-robin to the 8 XCDs: in the plain (tile, image) order the 256-px-wide
+  // neighbours of a tile row — whose 264-byte row segments start 16 bytes into a 128-byte line and so share a line with each neighbour —
+  // and the tiles above / below (6 halo rows) sit on different L2s, and the stage fetched 1.9 x the pyramid.  Remapped (image counts that
+  // are multiples of 8), XCD k works through images k, k + 8, ... tile by tile.
+  int tileId = blockIdx.x, img = blockIdx.y;
+  if ((gridDim.y & 7) == 0) {
+    const unsigned n = blockIdx.x + gridDim.x * blockIdx.y;
+    const unsigned xcd = n & 7u, slot = n >> 3, grp = slot / gridDim.x;
+    tileId = __builtin_amdgcn_readfirstlane((int)(slot - grp * gridDim.x)); img = __builtin_amdgcn_readfirstlane((int)(xcd + 8u * grp));
+  }
   int l = 0;
-  while (l + 1 < nlevels && (int)blockIdx.x >= geom[l + 1].blurTileBase) ++l;
+  while (l + 1 < nlevels && tileId >= geom[l + 1].blurTileBase) ++l;
   const LevelGeom g = geom[l];
-  const int t = blockIdx.x - g.blurTileBase;
+  const int t = tileId - g.blurTileBase;
   const int tx = t % g.blurTilesX, ty = t / g.blurTilesX;
-  const int img = blockIdx.y;
   const int x = tx * BT_W + (threadIdx.x & 31) * 8;
   const int y0 = ty * BT_H + (threadIdx.x >> 5) * BT_ROWS;
   if (x >= g.w || y0 >= g.h) return;

@@ -14,6 +14,8 @@ template <> __device__ __forceinline__ unsigned fold(uint8_t v) { return v; }
 template <> __device__ __forceinline__ unsigned fold(uint32_t v) { return v; }
 template <> __device__ __forceinline__ unsigned fold(uint2 v) { return v.x ^ v.y; }
 template <> __device__ __forceinline__ unsigned fold(uint4 v) { return v.x ^ v.y ^ v.z ^ v.w; }
+struct u3 { unsigned x, y, z; };
+template <> __device__ __forceinline__ unsigned fold(u3 v) { return v.x ^ v.y ^ v.z; }
 
 // every wave issues ITER x 8 independent loads of T; lane address = wave window + lane * strideBytes10 / 10 + misalign + row * 1024
 template <typename T> __global__ __launch_bounds__(256) void k_load(const uint8_t* __restrict__ buf, int stride10, int misalign, int iters, unsigned* __restrict__ sink) {
@@ -68,6 +70,9 @@ int main() {
   run<uint2>("dwordx2", false, buf, sink, 48, 0);
   run<uint2>("dwordx2", false, buf, sink, 48, 3);
   run<uint2>("dwordx2", false, buf, sink, 40, 0);
+  run<u3>("dwordx3", false, buf, sink, 120, 0);
+  run<u3>("dwordx3", false, buf, sink, 48, 0);
+  run<u3>("dwordx3", false, buf, sink, 40, 0);
   run<uint4>("dwordx4", false, buf, sink, 160, 0);
   run<uint4>("dwordx4", false, buf, sink, 160, 4);
   run<uint4>("dwordx4", false, buf, sink, 160, 3);
