@@ -592,7 +592,10 @@ using morbm::sincosf_glibc;
 #ifndef MORB_DESC_STAGED
 #define MORB_DESC_STAGED 1
 #endif
-constexpr int DESC_KPW = 4;   // keypoints per wave in k_describe
+#ifndef MORB_DESC_KPW
+#define MORB_DESC_KPW 2   // (round 3, with the window in LDS: 2 / 3 / 4 / 8 keypoints per wave = 469 / 473 / 486 / 628 us per 512 images; 1: 519)
+#endif
+constexpr int DESC_KPW = MORB_DESC_KPW;   // keypoints per wave in k_describe
 constexpr int DESC_R = 18;    // the rotated rBRIEF pattern stays within +-18 px of the keypoint (|(+-13, +-13)| = 18.4, then cvRound)
 constexpr int DESC_WIN = 2 * DESC_R + 1, DESC_WP = 48;   // window rows / LDS pitch (three 16-byte segments)
 // One wave describes DESC_KPW keypoints *in lock step*: the kernel is bound by dependent global-memory round trips per
