@@ -744,9 +744,9 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGe
       const uint32_t sum = __builtin_amdgcn_udot4(px, 0x01010101u, 0u, false);
       usumB = __builtin_amdgcn_udot4(px, pw[j], usumB, false);
       sumAll += sum;
-      m01 += pv[j] * (int)sum;
+      m01 += __mul24(pv[j], (int)sum);
     }
-    int m10 = (int)usumB - HALF_PATCH * (int)sumAll;
+    int m10 = (int)usumB - __mul24(HALF_PATCH, (int)sumAll);
     m10k[kk] = morbwave::sum_i32(m10);   // DPP reductions (wave.h): all 64 lanes are active here
     m01k[kk] = morbwave::sum_i32(m01);
   }
@@ -774,8 +774,9 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGe
       const int r0 = __float2int_rn(x0 * bsin + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bsin);
       const int r1 = __float2int_rn(x1 * bsin + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bsin);
 #if MORB_DESC_STAGED
-      t0v[kk][q] = win[kk * (DESC_WIN * DESC_WP) + (r0 + DESC_R) * DESC_WP + c0 + DESC_R + wsh[kk]];
-      t1v[kk][q] = win[kk * (DESC_WIN * DESC_WP) + (r1 + DESC_R) * DESC_WP + c1 + DESC_R + wsh[kk]];
+      // (24-bit multiplies: the plain `* 48` compiled to the quarter-rate v_mad_u64_u32, sixteen of them per pair of keypoints)
+      t0v[kk][q] = win[kk * (DESC_WIN * DESC_WP) + __mul24(r0 + DESC_R, DESC_WP) + c0 + DESC_R + wsh[kk]];
+      t1v[kk][q] = win[kk * (DESC_WIN * DESC_WP) + __mul24(r1 + DESC_R, DESC_WP) + c1 + DESC_R + wsh[kk]];
 #else
       t0v[kk][q] = center[kk][(uint32_t)((r0 + DESC_R) * bstride[kk] + c0 + DESC_R)];   // (unstaged build: center is the window's own corner)
       t1v[kk][q] = center[kk][(uint32_t)((r1 + DESC_R) * bstride[kk] + c1 + DESC_R)];

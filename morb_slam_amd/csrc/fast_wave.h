@@ -61,6 +61,7 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
                                                             const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
                                                             int* __restrict__ candCnt, int totalCells, int cellCap, int rows, int iniTh, int minTh) {
   constexpr int BPR = P / 16;   // 16-px blocks per window row
+  constexpr unsigned BPR_MAGIC = 65536u / BPR + 1u;   // i / BPR == (i * BPR_MAGIC) >> 16 for i < 16384 (24-bit multiply: the compiler's own /3 is two quarter-rate v_mul_hi_u32)
   extern __shared__ __align__(16) uint8_t smem[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -93,8 +94,8 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int i = i0 + lane + k * 64;
-        const int rr = i / BPR, c16 = (i - rr * BPR) << 4;
-        off[k] = i < n16 ? rr * P + c16 : -1;
+        const int rr = (int)(__umul24((unsigned)i, BPR_MAGIC) >> 16), c16 = (i - rr * BPR) << 4;
+        off[k] = i < n16 ? __mul24(rr, P) + c16 : -1;
         v[k] = make_uint4(0, 0, 0, 0);
         if (i < n16) __builtin_memcpy(&v[k], base + (unsigned)(__umul24(rr, pstride) + c16), 16);
       }
@@ -299,7 +300,10 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
     // NMS.  The window becomes the strength map: S at the corners (S > T), 0 elsewhere.  Corner score S - 1, everything else 0; keep iff
     // strictly greater than all 8 neighbours' scores (a neighbour outside the evaluated area stays 0).
     FW_SYNC();
-    for (int i = lane; i < n16; i += 64) *reinterpret_cast<uint4*>(tile + ((i / BPR) * P + ((i % BPR) << 4))) = make_uint4(0, 0, 0, 0);
+    for (int i = lane; i < n16; i += 64) {
+      const int rr = (int)(__umul24((unsigned)i, BPR_MAGIC) >> 16);
+      *reinterpret_cast<uint4*>(tile + (__mul24(rr, P) + ((i - rr * BPR) << 4))) = make_uint4(0, 0, 0, 0);
+    }
     FW_SYNC();
     for (int q = lane; q < cn; q += 64) { const int pos = cornerPos[q]; tile[__mul24(pos >> 7, P) + (pos & 127)] = cornerS[q]; }
     FW_SYNC();
