@@ -50,7 +50,10 @@ namespace {
 #ifndef MORB_TEAM_MAX_IMAGES
 #define MORB_TEAM_MAX_IMAGES 16
 #endif
-constexpr int kTeamMaxImages = MORB_TEAM_MAX_IMAGES;   // k_distribute: calls with at most this many images use the team packing of the big levels
+constexpr int kTeamMaxImages = MORB_TEAM_MAX_IMAGES;
+#ifndef MORB_QT_KEYF
+#define MORB_QT_KEYF 200   // LDS key capacity of level 0, in percent of (pixels / 233); 135 / 160 measured: no change (the big bin still takes a CU alone)
+#endif   // k_distribute: calls with at most this many images use the team packing of the big levels
 
 __constant__ __align__(16) int c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
@@ -264,13 +267,20 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src,
 // 19 - 3 = 16, so x % 4 == 0 makes the window 4-byte aligned).  HBM traffic = read P (+halo rows) + write P.
 constexpr int BT_W = 256, BT_ROWS = 16, BT_TY = 8;   // workgroup: 32 lanes x 8 px wide, 8 half-waves x 16 rows tall -> 256 px x 128 rows per tile
 constexpr int BT_H = BT_ROWS * BT_TY;
+#ifndef MORB_BT_AHEAD
+#define MORB_BT_AHEAD 4   // (1 / 2 / 3 / 4 / 6 rows ahead: 440 / 372 / 363 / 359 / 374 us per 512 images on one box)
+#endif
+constexpr int BT_AHEAD = MORB_BT_AHEAD;   // source rows in flight ahead of the row being filtered
 typedef unsigned short blur_u16x2 __attribute__((ext_vector_type(2)));
 // Horizontal 7-tap of eight neighbouring pixels: v_dot4_u32_u8 against the packed kernel weights (18 34 48 56 | 48 34 18 0),
 // the byte windows cut out of the four loaded dwords with v_alignbyte.  Results are exact integers <= 255 * 256.
-__device__ __forceinline__ void blur_h8(const uint8_t* __restrict__ row, uint32_t h[8]) {
+__device__ __forceinline__ uint4 blur_load16(const uint8_t* __restrict__ row) {
   // row points at byte (x - 3) of the padded row (8-byte aligned): 16 bytes = pixels x-3 .. x+12, ONE vector-memory instruction
   uint4 w;
   __builtin_memcpy(&w, __builtin_assume_aligned(row, 8), 16);
+  return w;
+}
+__device__ __forceinline__ void blur_h8(const uint4 w, uint32_t h[8]) {
   constexpr uint32_t WA = 18u | (34u << 8) | (48u << 16) | (56u << 24), WB = 48u | (34u << 8) | (18u << 16);
   const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
@@ -315,7 +325,7 @@ __global__ __launch_bounds__(256) void k_blur(const LevelGeom* __restrict__ geom
   {
     uint32_t h[6][8];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) blur_h8(src + (size_t)k * g.pstride, h[k]);
+    for (int k = 0; k < 6; ++k) blur_h8(blur_load16(src + (size_t)k * g.pstride), h[k]);
 #pragma unroll
     for (int j = 0; j < 5; ++j)
 #pragma unroll
@@ -329,11 +339,18 @@ __global__ __launch_bounds__(256) void k_blur(const LevelGeom* __restrict__ geom
   // load leaves the level — and only their store is skipped: with the whole row body under `if (r < rows)` (per-lane: the two halves of a
   // wave work different strips) the compiler merged the rotating row window through 688 v_mov per wave, a third of the kernel's VALU work.
   const int lastRow = g.h + 2 * EDGE - 1 - (EDGE + y0 - 3);   // last padded row, relative to src
+  // The source rows are requested BT_AHEAD rows before they are used: with the load at the top of the row that needs it the wave sat
+  // through a full memory round trip per row (load, s_waitcnt vmcnt(0), 75 VALU instructions, store — sixteen times), at five waves per SIMD.
+  uint4 wq[BT_AHEAD];
+#pragma unroll
+  for (int d = 0; d < BT_AHEAD; ++d) wq[d] = blur_load16(src + (uint32_t)__umul24(min(6 + d, lastRow), g.pstride));
 #pragma unroll
   for (int r = 0; r < BT_ROWS; ++r) {
     {   // (fully unrolled: the row window rotates by renaming)
     uint32_t hn[8], acc[8];
-    blur_h8(src + (uint32_t)__umul24(min(r + 6, lastRow), g.pstride), hn);
+    const uint4 wcur = wq[r % BT_AHEAD];
+    if (r + BT_AHEAD < BT_ROWS) wq[r % BT_AHEAD] = blur_load16(src + (uint32_t)__umul24(min(r + 6 + BT_AHEAD, lastRow), g.pstride));
+    blur_h8(wcur, hn);
 #pragma unroll
     for (int k = 0; k < 8; ++k)
       acc[k] = blur_dot2(P[0][k], W01, blur_dot2(P[2][k], W23, blur_dot2(P[4][k], W45, __umul24(18u, hn[k]) + 32768u)));   // (hn < 2^16: v_mad_u32_u24, full rate)
@@ -408,14 +425,14 @@ extern "C" int morb_fast_timing(unsigned long long* out, int reset) {   // phase
 __global__ __launch_bounds__(64 * QT_MAX_WAVES) void k_distribute(const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ cand,
                                                    const int* __restrict__ candCnt, int totalCells, int cellCap,
                                                    uint32_t* __restrict__ qtScratch, uint32_t* __restrict__ sel,
-                                                   int* __restrict__ selCnt, int selPerImg, int nlevels) {
+                                                   int* __restrict__ selCnt, int selPerImg, int nlevels, int groupBase) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int img = blockIdx.x, lane = threadIdx.x & 63;
   __shared__ int teamSh[32];
   int lvl = -1;
   const int wvIdx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   {
-    const int grp = blockIdx.y;
+    const int grp = blockIdx.y + groupBase;
     // a workgroup holds up to QT_MAX_WAVES levels, a wave each — or ONE level worked by all its waves as a team (quadtree.h)
     for (int l = 0; l < nlevels; ++l) if (geom[l].distGroup == grp && (geom[l].distTeam || geom[l].distWave == wvIdx)) lvl = l;
   }
@@ -1037,7 +1054,7 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     const size_t fixed0 = lds_bytes(e->geom[0], 0);
     MORB_REQUIRE(fixed0 + 1024 * 8 <= kLdsBudget, MORB_ERR_UNSUPPORTED, "nfeatures too large for the LDS-resident quadtree");
     const double area0 = (double)e->geom[0].w * e->geom[0].h;
-    const long long want = std::max<long long>(kLdsKeys, (long long)(area0 * 2 / 233));
+    const long long want = std::max<long long>(kLdsKeys, (long long)(area0 * MORB_QT_KEYF / 23300));
     const long long fit = (long long)((kLdsBudget - fixed0) / 8);
     e->distKeyCap = (int)std::min(want, fit) / 64 * 64;
     size_t need[kMaxLevels];
@@ -1057,7 +1074,10 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     int order[kMaxLevels];
     for (int l = 0; l < L; ++l) order[l] = l;
     std::stable_sort(order, order + L, [&](int a, int b) { return need[a] > need[b]; });
-    constexpr int packEnv = 1;   // workgroups per CU the bins are sized for (measured in round 2: 0 = one level per workgroup, 2, 3: no better end to end)
+#ifndef MORB_QT_PACK
+#define MORB_QT_PACK 1
+#endif
+    constexpr int packEnv = MORB_QT_PACK;   // workgroups per CU the bins are sized for (measured in round 2: 0 = one level per workgroup, 2, 3: no better end to end; again at the end of round 3 with the faster blur: 1 / 2 / 3 -> quadtree 427 / 398 / 485 us per 512 images but the blur beside it 364 / 404 / 377 and the join 13 / 23 / 13: the slot stays ~430)
     int kMax = 1;
     while (std::min(kLdsBudget, kLdsCu / (kMax + 1) - kLdsStatic) >= needMax) ++kMax;
     const int bestK = std::max(1, std::min(packEnv, kMax));
@@ -1380,10 +1400,12 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   // (which of the two is enqueued first makes no difference: measured both ways)
   if (nimg <= kTeamMaxImages && e->distGroupsTeam > 0)   // few images: latency matters, the big levels are worked by teams of waves
     hipLaunchKernelGGL(k_distribute, dim3(nimg, e->distGroupsTeam), dim3(64 * QT_MAX_WAVES), e->distSmemTeam, st, e->d_geomTeam, e->d_cand, e->d_candCnt,
-                       e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L);
+                       e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L, 0);
   else
+    // (one launch per bin of levels, each with its own LDS size — all bins of one launch get the largest bin's — measured: the launches
+    // follow each other on the stream, 128 -> 204 us per 128 images, 420 -> 435 per 512)
     hipLaunchKernelGGL(k_distribute, dim3(nimg, e->distGroups), dim3(64 * e->distWaves), e->distSmem, st, e->d_geom, e->d_cand, e->d_candCnt,
-                       e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L);
+                       e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L, 0);
   hipStream_t sideStream = e->sideStream;
   MORB_HIP_CHECK(hipStreamWaitEvent(sideStream, e->evFork, 0));
   if (evs) (void)hipEventRecord(evs[6], sideStream);
