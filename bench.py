@@ -12,6 +12,7 @@ region is bracketed by barrier + synchronize and the MAX over ranks is reported.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4] [--batch B] [--no-cpu-baseline] [--no-extras]
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -435,6 +436,9 @@ def main():
                          "on one MI355X in round 1; 8 for c4)")
     ap.add_argument("--sets", type=int, default=2, help="buffer sets = steps in flight (>= 2)")
     ap.add_argument("--extract-streams", type=int, default=1, help="1: one extraction stream for all buffer sets (default); 2: one per set")
+    ap.add_argument("--matchers", choices=["beside-pyramid", "under-quadtree"], default="beside-pyramid",
+                    help="where a step's matchers run: right after its extraction, i.e. beside the NEXT step's pyramid (default), or held back until the "
+                         "next step's FAST stage is done (morb_extractor_event_after_fast), i.e. underneath its quadtree")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="join all streams at the end of every step instead of running step i's matchers underneath step "
                          "i + 1's extraction (one buffer set instead of two)")
@@ -544,11 +548,19 @@ def main():
     left_mask = torch.zeros((2 * B,), dtype=torch.int32, device=dev); left_mask[0::2] = 1
     sets = [BufferSet() for _ in range(NSET)]
     nstep = 0
+    lag_matchers = args.matchers == "under-quadtree" and NSET >= 2
+    pending = None
+    _hip = ctypes.CDLL("libamdhip64.so") if lag_matchers else None
+
+    def hip_stream_wait_event(stream_ptr, event_ptr):
+        rc = _hip.hipStreamWaitEvent(ctypes.c_void_p(stream_ptr), ctypes.c_void_p(event_ptr), 0)
+        assert rc == 0, f"hipStreamWaitEvent: {rc}"
 
     def step(src=None, src_ready=None):
         nonlocal nstep
         S = sets[nstep % NSET]
         e = exts[nstep % NSET]
+        S.ext = e
         stream = estreams[nstep % NSET]
         nstep += 1
         kps, desc, cnt, _ = S.out
@@ -560,7 +572,25 @@ def main():
             stream.wait_event(src_ready)          # (H2D-inclusive variant: the upload of this step's images)
         e.extract_batch(images if src is None else src, out=S.out, stream=stream.cuda_stream)         # Frame::ExtractORB x2
         S.ext_done.record(stream)
+        if lag_matchers:
+            # this step's matchers are queued when the NEXT extraction has been queued, behind its after-FAST event
+            nonlocal pending
+            if pending is not None:
+                run_matchers(pending, gate=e.event_after_fast())
+            pending = S
+        else:
+            run_matchers(S)
+        if NSET == 1:                             # un-pipelined: the step ends when all streams are done
+            stream.wait_stream(bstream)
+
+    def run_matchers(S, gate=None):
+        kps, desc, cnt, _ = S.out
+        e = S.ext
         mstream.wait_event(S.ext_done)
+        if gate is not None:
+            hip_stream_wait_event(mstream.cuda_stream, gate)
+            if bstream is not mstream:
+                hip_stream_wait_event(bstream.cuda_stream, gate)
         matcher.ComputeStereoMatches(e, kps, desc, cnt, mbf, mb, out=S.st_out, stream=mstream.cuda_stream)   # Frame.cc:217
         S.stereo_done.record(mstream)
         bs = bstream.cuda_stream
@@ -577,10 +607,16 @@ def main():
                 pk, pd, pc, pn = exch.exchange(kps[0::2], desc[0::2], cnt[0::2], S.bow_out[1][0::2])   # left images only
             S.match_out = bmatcher.SearchByBoW(kf_img, f_img, pk, pd, pn, pc, has_mp, out=S.match_out, stream=bs)
         S.bow_done.record(bstream)
-        if NSET == 1:                             # un-pipelined: the step ends when all streams are done
-            stream.wait_stream(bstream)
+
+    def flush_matchers():
+        """(--matchers under-quadtree) the last step's matchers, which no later extraction gates"""
+        nonlocal pending
+        if pending is not None:
+            run_matchers(pending)
+            pending = None
 
     def sync_streams():
+        flush_matchers()   # (every queued step's matchers lie inside the region the caller is closing)
         for es in estreams:
             es.synchronize()
         mstream.synchronize()

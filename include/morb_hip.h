@@ -92,6 +92,11 @@ int morb_extractor_level_keypoints_host(const morb_extractor*, int img, int lvl,
  * Mirrors the reference's REGISTER_TIMES spans (src/Frame.cc:190-206). */
 int morb_extractor_set_profiling(morb_extractor*, int enable);
 int morb_extractor_stage_ms(morb_extractor*, float* ms7);
+/* The event (hipEvent_t) the last morb_extract_batch recorded on its stream after the FAST stage — where the memory-bound half of the
+ * extraction (pyramid, FAST's window loads) ends and the quadtree's mostly idle chip begins.  A caller that pipelines frames can make
+ * another stream wait for it (hipStreamWaitEvent) so that other work — the previous frame's matchers — lands underneath the quadtree
+ * instead of beside the next pyramid.  Owned by the handle; valid until the handle is destroyed. */
+int morb_extractor_event_after_fast(morb_extractor*, void** event);
 
 /* ------------------------------------------------------------------------------------------------------
  * Matchers: ORBmatcher (include/ORBmatcher.h:36-129, src/ORBmatcher.cc) and the per-frame stereo matchers

@@ -1289,6 +1289,11 @@ int morb_extractor_set_profiling(morb_extractor* e, int enable) {
   }
   return MORB_OK;
 }
+int morb_extractor_event_after_fast(morb_extractor* e, void** event) {
+  MORB_REQUIRE(e && event, MORB_ERR_INVALID, "NULL argument");
+  *event = (void*)e->evFork;
+  return MORB_OK;
+}
 int morb_extractor_stage_ms(morb_extractor* e, float* ms7) {
   MORB_REQUIRE(e && ms7, MORB_ERR_INVALID, "NULL argument");
   const int n = e->profCalls < morb_extractor::kProfRing ? e->profCalls : morb_extractor::kProfRing;

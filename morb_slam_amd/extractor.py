@@ -106,6 +106,12 @@ class ORBextractor:
     def level_keypoints(self, lvl, img=0):
         return self._kp_tap(self._L.morb_extractor_level_keypoints_host, lvl, img)
 
+    def event_after_fast(self):
+        """hipEvent_t (as an int) recorded by the last extract_batch after its FAST stage (morb_extractor_event_after_fast)."""
+        ev = C.c_void_p()
+        check(self._L.morb_extractor_event_after_fast(self._h, C.byref(ev)))
+        return ev.value
+
     def set_profiling(self, on=True):
         check(self._L.morb_extractor_set_profiling(self._h, 1 if on else 0))
 

@@ -240,3 +240,20 @@ def test_quadtree_team_and_single_wave_packings_agree():
             assert cnt[i] == len(ko), (n, i)
             assert kps[i, :cnt[i]].reshape(-1).view(KP_DTYPE).tobytes() == ko.tobytes(), (n, i)
             np.testing.assert_array_equal(desc[i, :cnt[i]], do)
+
+
+def test_event_after_fast_is_a_live_hip_event():
+    """morb_extractor_event_after_fast: the event the last extract_batch recorded behind its FAST stage can be waited on by the caller."""
+    import ctypes
+    import torch
+    ext, _ = _extractors(500)
+    img = torch.from_numpy(np.stack([make_image(640, 480, seed=3), make_image(640, 480, seed=4)])).cuda()
+    ext.extract_batch(img)
+    ev = ext.event_after_fast()
+    assert ev
+    hip = ctypes.CDLL("libamdhip64.so")
+    assert hip.hipEventSynchronize(ctypes.c_void_p(ev)) == 0
+    s = torch.cuda.Stream()
+    assert hip.hipStreamWaitEvent(ctypes.c_void_p(s.cuda_stream), ctypes.c_void_p(ev), 0) == 0
+    s.synchronize()
+    torch.cuda.synchronize()
