@@ -54,9 +54,12 @@ __device__ __forceinline__ void top2_merge(unsigned long long& a1, unsigned long
   a1 = lo;
   a2 = hi1 < lo2 ? hi1 : lo2;
 }
+// (as selects on the values: written as `if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;` the compiler stored k through a
+// run-time-selected address of k1 / k2 — a private array in scratch memory, read back and written in k_knn2's inner loop)
 __device__ __forceinline__ void top2_insert(unsigned long long& k1, unsigned long long& k2, unsigned long long k) {
-  if (k < k1) { k2 = k1; k1 = k; }
-  else if (k < k2) k2 = k;
+  const bool lt1 = k < k1, lt2 = k < k2;
+  k2 = lt1 ? k1 : (lt2 ? k : k2);
+  k1 = lt1 ? k : k1;
 }
 // the two smallest of the lanes' (k1 <= k2) pairs, in every lane; keys carry the candidate index (unique apart from the ~0
 // sentinel), so the runner-up is the smallest of "k2 of the winner's lane, k1 of the others".  DPP (wave.h); all lanes active.
@@ -823,8 +826,12 @@ __global__ __launch_bounds__(256) void k_bow_match(const unsigned long long* __r
                                  : (mF[realIdxF] < 0);
           if (cand) {
             const int d = hamming(dKF, load_desc(descF + ((size_t)jf * cap + realIdxF) * 32));
-            if (realIdxF < nLeft) top2_insert(k1, k2, ((unsigned long long)d << 32) | (unsigned)realIdxF);
-            else top2_insert(r1, r2, ((unsigned long long)d << 32) | (unsigned)realIdxF);
+            // (left / right camera ranking by value selects, not by a run-time choice of which pair to update: that is a private array in scratch)
+            const unsigned long long key = ((unsigned long long)d << 32) | (unsigned)realIdxF;
+            const bool left = realIdxF < nLeft;
+            unsigned long long t1 = left ? k1 : r1, t2 = left ? k2 : r2;
+            top2_insert(t1, t2, key);
+            k1 = left ? t1 : k1; k2 = left ? t2 : k2; r1 = left ? r1 : t1; r2 = left ? r2 : t2;
           }
         }
       }

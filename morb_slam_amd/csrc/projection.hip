@@ -52,8 +52,12 @@ __device__ __forceinline__ int hamming(const Desc& a, const Desc& b) {
   for (int i = 0; i < 8; ++i) s += __popc(a.w[i] ^ b.w[i]);
   return s;
 }
+// (selects on the values: as `if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;` the compiler stored k through a run-time-selected
+// address of k1 / k2, i.e. a private array in scratch memory inside the candidate loops)
 __device__ __forceinline__ void top2_insert(unsigned long long& k1, unsigned long long& k2, unsigned long long k) {
-  if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;
+  const bool lt1 = k < k1, lt2 = k < k2;
+  k2 = lt1 ? k1 : (lt2 ? k : k2);
+  k1 = lt1 ? k : k1;
 }
 // the two smallest of the lanes' (k1 <= k2) pairs, in every lane.  Keys carry the candidate index, so they are unique (apart
 // from the ~0 sentinel): the runner-up is the smallest of "k2 of the lane that owns the winner, k1 of every other lane".  Two

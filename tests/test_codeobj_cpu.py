@@ -15,7 +15,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 HOT = ["k_resize", "k_resize_gather", "k_level0", "k_blur", "k_fastw", "k_distribute", "k_layout", "k_describe",
        "k_stereo_prep", "k_stereo_match", "k_stereo_median", "k_bow_transform", "k_bow_sort", "k_rot_filter",
        "k_pose_opt", "k_g_chi2", "k_g_dinv_push", "k_g_backsub_update_w", "k_g_finish", "k_g_ldlt_lds", "k_g_ldlt_global", "k_iba_solve_blocked", "k_schur_mfma",
-       "k_fe_triangulate", "k_triangulation", "k_frustum"]
+       "k_fe_triangulate", "k_triangulation", "k_frustum", "k_bow_match", "k_knn2", "k_resolve", "k_candidates", "k_best_per_query", "k_hamming_pairs"]
 
 
 def _kernel_metadata(lib, tmp):
