@@ -644,6 +644,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGe
   const int img = imgRev ? gridDim.y - 1 - imgIdx : imgIdx, lane = threadIdx.x & 63;
   const int gi0 = (chunk * DESC_WAVES + (threadIdx.x >> 6)) * DESC_KPW;
   if (gi0 >= selPerImg) return;
+  // (the pattern fetched once per workgroup into LDS instead — one 16-byte load per thread, a barrier, four ds_read_b128 per lane later —
+  // measured no faster: 2016 - 2058 against 2002 - 2015 us per 512 images for the whole extraction, three runs each on one box)
   int4 pat[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) pat[q] = reinterpret_cast<const int4*>(c_pattern)[lane * 4 + q];
