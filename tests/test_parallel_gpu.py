@@ -66,3 +66,21 @@ def test_bench_gpus2_launches_two_ranks(workload):
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
     want = (752, 1200) if workload == "c2" else (1920, 4000)
     assert f"{want[0]}x" in line["metric"] and f"{want[1]} feat" in line["metric"]
+
+
+def test_bench_matcher_placements_agree():
+    """bench.py's two schedules — a step's matchers right behind its extraction, or held back behind the NEXT extraction's after-FAST event
+    (morb_extractor_event_after_fast) — process the same frames: same stereo and BoW match counts, every step's matchers inside the region."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    got = {}
+    for m in ("beside-pyramid", "under-quadtree"):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--matchers", m, "--batch", "8", "--steps", "3", "--warmup", "1",
+                            "--no-extras", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, timeout=900)
+        assert p.returncode == 0
+        lines = [json.loads(l) for l in p.stdout.decode().splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        got[m] = lines[0]["config"]
+    for k in ("mean_keypoints_per_image", "mean_stereo_matches_per_frame", "mean_bow_matches_per_frame"):
+        assert got["beside-pyramid"][k] == got["under-quadtree"][k] and got["beside-pyramid"][k] > 0, k
