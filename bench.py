@@ -104,6 +104,12 @@ def cpu_baseline(target_s=12.0):
         while time.perf_counter() - t0 < budget:
             n += work(0, two)
         return n / (time.perf_counter() - t0)
+    # C1 = BASELINE configs[0]: mono 752x480, 1000 features, CPU ORBextractor only (Frame.cc:428 passes the lapping area [0, 1000])
+    c1e = O.OracleExtractor(1000)
+    n1, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < 1.5:
+        c1e(frames[n1 % len(frames)][0], (0, 1000)); n1 += 1
+    c1 = n1 / (time.perf_counter() - t1)
     fps1 = serial(False, target_s / 6)
     fps2 = serial(True, target_s / 6)
     done, t0 = 0, time.perf_counter()
@@ -112,6 +118,8 @@ def cpu_baseline(target_s=12.0):
             done += sum(ex.map(work, range(cores)))
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "stereo frames/s", "cores": cores, "kind": "port",
+            "c1_mono_1000feat_extract_only": {"value": c1, "unit": "mono frames/s", "cores": 1,
+                                              "config": "BASELINE configs[0]: mono 752x480, 1000 features, CPU ORBextractor only"},
             "one_thread": {"value": fps1, "cores": 1}, "two_threads_left_right": {"value": fps2, "cores": 2},
             "sample": f"{done} stereo {W}x{H} frames, {NFEAT} features: oracle extract x2 + stereo match + BoW descent + "
                       f"SearchByBoW (frame-parallel on {cores} threads); the 1- and 2-thread figures on ~{target_s / 6:.0f} s each"}
@@ -439,10 +447,16 @@ def main():
     ap.add_argument("--matchers", choices=["beside-pyramid", "under-quadtree"], default="beside-pyramid",
                     help="where a step's matchers run: right after its extraction, i.e. beside the NEXT step's pyramid (default), or held back until the "
                          "next step's FAST stage is done (morb_extractor_event_after_fast), i.e. underneath its quadtree")
+    ap.add_argument("--exchange", choices=["ring", "allgather"], default="ring",
+                    help="N > 1: how a frame's predecessor features reach its rank: one send / recv to the next rank (ring, 1/N of the bytes) "
+                         "or an all-gather of every rank's slabs (what north_star names)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="join all streams at the end of every step instead of running step i's matchers underneath step "
                          "i + 1's extraction (one buffer set instead of two)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-region oracle self-check of the last timed step")
+    ap.add_argument("--verify-frames", type=int, default=8, help="stereo frames of the last timed step compared with the oracle")
+    ap.add_argument("--sustained-s", type=float, default=2.0, help="seconds of the sustained run (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="headline workload only (used for the committed profiles)")
     ap.add_argument("--launch-probe", action="store_true",
                     help="ranks only rendezvous (gloo, CPU), count each other and exit: checks the --gpus N launcher without a GPU")
@@ -487,142 +501,28 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from morb_slam_amd import ORBextractor, ORBmatcher, parallel
-    from morb_slam_amd.synth import make_vocabulary
+    from morb_slam_amd import ORBextractor, parallel
+    from morb_slam_amd.frontend import StereoFrontEnd
     B = args.batch or defB
     # global frame g lives on rank g % world, slot g // world (morb_slam_amd/parallel.py)
     gids = [parallel.global_frame(rank, world, s) for s in range(B)]
     host_frames = torch.from_numpy(make_batch(gids, B * world, seed=0))
     frames = host_frames.to(dev)                                                # [B, 2, H, W] resident in HBM
     images = frames.view(2 * B, H, W)
-    # Two buffer sets (extractor handle with its pyramids, feature tables, matcher outputs): consecutive steps alternate
-    # between them, so the matchers of step i -- latency-bound kernels -- run on their own streams underneath the
-    # VALU-bound extraction of step i + 1.  Set s is reused by step i + 2 only after its readers of step i finished
-    # (events).  --no-pipeline joins all streams at the end of every step instead.
+    # The step itself is morb_slam_amd/frontend.py (StereoFrontEnd): two buffer sets, step i's matchers on their own stream beside
+    # step i + 1's extraction, k=10 / L=6 / levelsup=4 vocabulary (the ORBvoc shape; synthetic: ORBvoc.txt is a missing blob, SURVEY
+    # finding 3), 80 % of the keyframe features holding a MapPoint.  tests/test_bench_chain_gpu.py builds the SAME object and compares
+    # sampled frames with the oracle.  N GPUs: the previous frame lives on the previous rank -> its left-image features travel one rank
+    # up the ring (--exchange ring, RCCL send / recv) or are all-gathered (--exchange allgather, north_star's wording) once per step.
     NSET = 1 if args.no_pipeline else max(2, args.sets)
-    exts = [ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank) for _ in range(NSET)]
+    exch = None
+    if world > 1:
+        exch = parallel.NeighbourExchange() if args.exchange == "ring" else parallel.FeatureExchange()
+    fe = StereoFrontEnd(images, NFEAT, B, device=local_rank, rank=rank, world=world, nset=NSET, extract_streams=args.extract_streams,
+                        matchers=args.matchers, vocab=(10, 6, 4), exchange=exch)
+    exts, sets, estreams, matcher, cap, mbf, mb = fe.exts, fe.sets, fe.estreams, fe.matcher, fe.cap, fe.mbf, fe.mb
     ext = exts[0]
-    stream = torch.cuda.Stream(device=dev)                    # extraction
-    mstream = torch.cuda.Stream(device=dev) if NSET >= 2 else stream   # stereo matching
-    # --extract-streams 1 (default): the sets' extractions follow each other on ONE stream and only the matchers of the previous step run
-    # beside them; 2: one extraction stream per set, so two extractions also overlap each other (measured: +1.8 % frames/s, but every
-    # extraction kernel then shares the chip with another one and its in-region launch time is ~1.5 x its time alone — see DESIGN.md §4).
-    # (HIP stream priorities were tried both ways: 58 - 76 k frames/s, worse than either.)
-    estreams = [torch.cuda.Stream(device=dev) for _ in range(NSET)] if NSET >= 2 and args.extract_streams >= 2 else [stream] * NSET
-    # pipelined: ONE matcher stream (stereo, then the BoW chain): HIP multiplexes streams onto 4 hardware queues and streams that
-    # alias serialise; with extraction A / B, their blur side streams and one matcher stream only one pair aliases (+3.5 %
-    # over two matcher streams).  Un-pipelined: the BoW chain runs beside the stereo matcher on its own stream.
-    bstream = mstream if NSET >= 2 else torch.cuda.Stream(device=dev)   # ComputeBoW -> (feature exchange) -> SearchByBoW
-    matcher = ORBmatcher(0.7, True, device=local_rank)        # TrackReferenceKeyFrame: ORBmatcher(0.7, true), Tracking.cc:2541
-    bmatcher = ORBmatcher(0.7, True, device=local_rank)       # one workspace set per stream
-    mbf, mb = 458.654 * 0.11, 0.11                            # EuRoC fx * baseline, baseline (Examples/Stereo/EuRoC.yaml)
-    VK, VL = 10, 6                                            # DBoW2 ORBvoc shape: k=10, L=6, levelsup=4
-    vd, vf = make_vocabulary(VK, VL, seed=0)                  # synthetic: ORBvoc.txt is a missing blob (SURVEY finding 3)
-    vd, vf = torch.from_numpy(vd).to(dev), torch.from_numpy(vf).to(dev)
-    cap = ext.max_keypoints
-    # SearchByBoW pairs: left image of global frame g (as F) against left image of frame g-1 (as the reference
-    # keyframe).  One GPU: both are local.  N GPUs: g-1 lives on the previous rank -> the left-image features travel one
-    # rank up the ring (RCCL send / recv) once per step and the pairs index the pool [own slab; received slab].
-    rng = np.random.default_rng(7)
-    if world == 1:
-        kf_img = torch.tensor([2 * max(f - 1, 0) for f in range(B)], dtype=torch.int32, device=dev)
-        f_img = torch.tensor([2 * f for f in range(B)], dtype=torch.int32, device=dev)
-        has_mp = torch.from_numpy((rng.random((2 * B, cap)) < 0.8).astype(np.uint8)).to(dev)   # 80 % of KF features hold a MapPoint
-        exch = None
-    else:
-        kfp, frp = parallel.neighbour_pairs(rank, world, B)
-        kf_img, f_img = torch.from_numpy(kfp).to(dev), torch.from_numpy(frp).to(dev)
-        has_mp = torch.from_numpy((rng.random((2 * B, cap)) < 0.8).astype(np.uint8)).to(dev)
-        exch = parallel.NeighbourExchange()
-
-    class BufferSet:
-        def __init__(self):
-            self.out = (torch.empty((2 * B, cap, 28), dtype=torch.uint8, device=dev), torch.empty((2 * B, cap, 32), dtype=torch.uint8, device=dev),
-                        torch.empty((2 * B,), dtype=torch.int32, device=dev), torch.empty((2 * B,), dtype=torch.int32, device=dev))
-            self.st_out = (torch.empty((B, cap), dtype=torch.float32, device=dev), torch.empty((B, cap), dtype=torch.float32, device=dev))
-            self.bow_out = (torch.empty((2 * B, cap), dtype=torch.int32, device=dev), torch.empty((2 * B, cap), dtype=torch.int32, device=dev))
-            self.cnt_left = torch.empty((2 * B,), dtype=torch.int32, device=dev)
-            self.match_out = None
-            self.ext_done, self.stereo_done, self.bow_done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
-            self.used = False
-    left_mask = torch.zeros((2 * B,), dtype=torch.int32, device=dev); left_mask[0::2] = 1
-    sets = [BufferSet() for _ in range(NSET)]
-    nstep = 0
-    lag_matchers = args.matchers == "under-quadtree" and NSET >= 2
-    pending = None
-    _hip = ctypes.CDLL("libamdhip64.so") if lag_matchers else None
-
-    def hip_stream_wait_event(stream_ptr, event_ptr):
-        rc = _hip.hipStreamWaitEvent(ctypes.c_void_p(stream_ptr), ctypes.c_void_p(event_ptr), 0)
-        assert rc == 0, f"hipStreamWaitEvent: {rc}"
-
-    def step(src=None, src_ready=None):
-        nonlocal nstep
-        S = sets[nstep % NSET]
-        e = exts[nstep % NSET]
-        S.ext = e
-        stream = estreams[nstep % NSET]
-        nstep += 1
-        kps, desc, cnt, _ = S.out
-        if S.used:                                # the set's previous readers (two steps ago) must be done before it is overwritten
-            stream.wait_event(S.stereo_done)
-            stream.wait_event(S.bow_done)
-        S.used = True
-        if src_ready is not None:
-            stream.wait_event(src_ready)          # (H2D-inclusive variant: the upload of this step's images)
-        e.extract_batch(images if src is None else src, out=S.out, stream=stream.cuda_stream)         # Frame::ExtractORB x2
-        S.ext_done.record(stream)
-        if lag_matchers:
-            # this step's matchers are queued when the NEXT extraction has been queued, behind its after-FAST event
-            nonlocal pending
-            if pending is not None:
-                run_matchers(pending, gate=e.event_after_fast())
-            pending = S
-        else:
-            run_matchers(S)
-        if NSET == 1:                             # un-pipelined: the step ends when all streams are done
-            stream.wait_stream(bstream)
-
-    def run_matchers(S, gate=None):
-        kps, desc, cnt, _ = S.out
-        e = S.ext
-        mstream.wait_event(S.ext_done)
-        if gate is not None:
-            hip_stream_wait_event(mstream.cuda_stream, gate)
-            if bstream is not mstream:
-                hip_stream_wait_event(bstream.cuda_stream, gate)
-        matcher.ComputeStereoMatches(e, kps, desc, cnt, mbf, mb, out=S.st_out, stream=mstream.cuda_stream)   # Frame.cc:217
-        S.stereo_done.record(mstream)
-        bs = bstream.cuda_stream
-        bstream.wait_event(S.ext_done)
-        # Frame::ComputeBoW converts mDescriptors = the LEFT image's descriptors (Frame.cc:822-827): the right images take no part in BoW
-        # matching, so their feature count is zeroed for the BoW kernels (which then skip them)
-        with torch.cuda.stream(bstream):
-            torch.mul(cnt, left_mask, out=S.cnt_left)
-        bmatcher.bow_transform(desc, S.cnt_left, vd, vf, VK, VL, 4, out=S.bow_out, stream=bs)                 # Frame::ComputeBoW
-        if exch is None:
-            S.match_out = bmatcher.SearchByBoW(kf_img, f_img, kps, desc, S.bow_out[1], S.cnt_left, has_mp, out=S.match_out, stream=bs)
-        else:
-            with torch.cuda.stream(bstream):      # the transfer is ordered after the kernels on this stream
-                pk, pd, pc, pn = exch.exchange(kps[0::2], desc[0::2], cnt[0::2], S.bow_out[1][0::2])   # left images only
-            S.match_out = bmatcher.SearchByBoW(kf_img, f_img, pk, pd, pn, pc, has_mp, out=S.match_out, stream=bs)
-        S.bow_done.record(bstream)
-
-    def flush_matchers():
-        """(--matchers under-quadtree) the last step's matchers, which no later extraction gates"""
-        nonlocal pending
-        if pending is not None:
-            run_matchers(pending)
-            pending = None
-
-    def sync_streams():
-        flush_matchers()   # (every queued step's matchers lie inside the region the caller is closing)
-        for es in estreams:
-            es.synchronize()
-        mstream.synchronize()
-        bstream.synchronize()
-        stream.synchronize()
-        torch.cuda.synchronize(dev)
+    step, sync_streams = fe.step, fe.sync
 
     def sync_all():
         sync_streams()
@@ -647,6 +547,39 @@ def main():
     # per-stage ms per extract call (= per step), averaged over the handles of the buffer sets
     per_set = [e.stage_ms() for e in exts]
     stages = {k: sum(ps[k] for ps in per_set) / len(per_set) for k in per_set[0]}
+    # ---- post-region self-check (outside the timed region, like cpu_baseline): sampled frames of the LAST timed step against the CPU
+    # oracle, every field of the chain (tests/chain_check.py) — the configuration in the headline is one the oracle has seen
+    verified = None
+    if world == 1 and rank == 0 and not args.no_verify:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import chain_check
+        sample = sorted(set(int(x) for x in np.linspace(0, B - 1, min(B, args.verify_frames))))
+        tv = time.perf_counter()
+        nver = chain_check.verify_frames(fe, fe.last, sample, host_frames.view(2 * B, H, W).numpy())   # raises on the first difference
+        verified = {"verified_frames": nver, "of_step": "last timed step", "frames": sample, "seconds": time.perf_counter() - tv,
+                    "fields": ["keypoints", "descriptors", "mvuRight", "mvDepth", "bow_word", "bow_node", "SearchByBoW table", "nmatches"]}
+    # ---- sustained figure (never `value`): the same step for >= 2 s in 100-step windows; the headline's K steps fit inside one
+    # boost-clock burst, this does not
+    sustained = None
+    if world == 1 and rank == 0 and args.sustained_s > 0:
+        win, wfps, wst, tot = 100, [], [], 0.0
+        while tot < args.sustained_s or len(wfps) < 10:
+            tw = time.perf_counter()
+            for _ in range(win):
+                step()
+            sync_streams()
+            d = time.perf_counter() - tw
+            tot += d
+            wfps.append(B * win / d)
+            ps = [e.stage_ms() for e in exts]      # (each handle's last <= 64 calls of the window)
+            wst.append({k: sum(q[k] for q in ps) / len(ps) for k in ps[0]})
+            if len(wfps) >= 200:
+                break
+        srt = sorted(wfps)
+        sustained = {"value": B * win * len(wfps) / tot, "unit": "frames/s", "seconds": tot, "steps": win * len(wfps), "window_steps": win,
+                     "window_min": srt[0], "window_median": srt[len(srt) // 2], "window_max": srt[-1],
+                     "extract_stage_ms_per_step": {k: {"min": min(w[k] for w in wst), "median": sorted(w[k] for w in wst)[len(wst) // 2],
+                                                       "max": max(w[k] for w in wst)} for k in wst[0]}}
     # reference point outside the timed region: the same extraction with nothing else on the chip (the pipelined steps
     # above share the CUs between two extractions and the matchers, which stretches every kernel's launch duration)
     iso_n = 5
@@ -695,7 +628,7 @@ def main():
             with torch.cuda.stream(cstream):
                 dbuf[b].copy_(pinned, non_blocking=True)
             up_done[b].record(cstream)
-            es = estreams[nstep % NSET]
+            es = estreams[fe.nstep % NSET]
             step(src=dbuf[b], src_ready=up_done[b])
             consumed[b].record(es)
         for i in range(2):
@@ -806,6 +739,10 @@ def main():
                                for k in ("pyramid", "blur", "fast")},
             "extract_stage_ms_per_step": stages,
         }
+        if verified is not None:
+            line.update(verified_frames=verified["verified_frames"], verified=verified)
+        if sustained is not None:
+            line["sustained"] = sustained
         if alt is not None:
             line["two_extraction_streams"] = alt
         if h2d is not None:

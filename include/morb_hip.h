@@ -97,6 +97,9 @@ int morb_extractor_stage_ms(morb_extractor*, float* ms7);
  * another stream wait for it (hipStreamWaitEvent) so that other work — the previous frame's matchers — lands underneath the quadtree
  * instead of beside the next pyramid.  Owned by the handle; valid until the handle is destroyed. */
 int morb_extractor_event_after_fast(morb_extractor*, void** event);
+/* hipStreamWaitEvent(stream, event) through the HIP runtime THIS library is linked against: a host language that holds raw stream /
+ * event handles (ctypes, cgo) must not open a second copy of libamdhip64 to make `stream` wait for the event above. */
+int morb_stream_wait_event(void* stream, void* event);
 
 /* ------------------------------------------------------------------------------------------------------
  * Matchers: ORBmatcher (include/ORBmatcher.h:36-129, src/ORBmatcher.cc) and the per-frame stereo matchers

@@ -1296,6 +1296,11 @@ int morb_extractor_event_after_fast(morb_extractor* e, void** event) {
   *event = (void*)e->evFork;
   return MORB_OK;
 }
+int morb_stream_wait_event(void* stream, void* event) {
+  MORB_REQUIRE(event, MORB_ERR_INVALID, "event is NULL");
+  MORB_HIP_CHECK(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), reinterpret_cast<hipEvent_t>(event), 0));
+  return MORB_OK;
+}
 int morb_extractor_stage_ms(morb_extractor* e, float* ms7) {
   MORB_REQUIRE(e && ms7, MORB_ERR_INVALID, "NULL argument");
   const int n = e->profCalls < morb_extractor::kProfRing ? e->profCalls : morb_extractor::kProfRing;

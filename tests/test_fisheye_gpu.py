@@ -209,8 +209,8 @@ def test_search_by_projection_mappoints_fisheye():
         assert tot > 600
 
 
-@pytest.mark.parametrize("k,Lv", [(10, 3), (3, 2)])   # ~10 features per node (register path) / ~400 (general path)
-def test_search_by_bow_fisheye(k, Lv):
+@pytest.mark.parametrize("k,Lv,lup", [(10, 3, 1), (3, 2, 1), (10, 6, 4)])   # ~10 features per node (register path) / ~400 (general path) / the ORBvoc shape
+def test_search_by_bow_fisheye(k, Lv, lup):
     """SearchByBoW(pKF, F, ...) with a fisheye frame: left / right candidates ranked separately, right winner taken
     whenever the left best distance passes TH_LOW (ORBmatcher.cc:262-299, :333-365)."""
     import torch
@@ -240,7 +240,7 @@ def test_search_by_bow_fisheye(k, Lv):
     kf = np.array([0, 0, 1, 2], np.int32); fr = np.array([1, 2, 2, 0], np.int32)
     for ratio, ori in ((0.7, True), (0.9, False)):
         m = ORBmatcher(ratio, ori)
-        _, node = m.bow_transform(dd, dc, cu(vd), cu(vf), k, Lv, 1)
+        _, node = m.bow_transform(dd, dc, cu(vd), cu(vf), k, Lv, lup)
         match, nm = m.SearchByBoW(cu(kf), cu(fr), dk, dd, node, dc, cu(has), nLeft=cu(nl[fr]))
         torch.cuda.synchronize()
         nn_, match, nm = node.cpu().numpy(), match.cpu().numpy(), nm.cpu().numpy()

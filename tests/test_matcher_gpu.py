@@ -124,7 +124,9 @@ def test_knn2_ratio(batch):
 # vocabulary shapes: ~12 features per node (one register slot per lane), ~75 per node (two slots per lane, keyframe
 # features in two chunks), ~400 per node (the general path of k_bow_match)
 @pytest.mark.parametrize("k,Lv,lup,settings", [(10, 3, 1, ((0.7, True), (0.9, False), (0.6, True))),
-                                               (4, 3, 1, ((0.7, True),)), (3, 2, 1, ((0.8, True),))])
+                                               (4, 3, 1, ((0.7, True),)), (3, 2, 1, ((0.8, True),)),
+                                               # the ORBvoc shape bench.py runs: six levels, node ids four levels above the words
+                                               (10, 6, 4, ((0.7, True), (0.9, False)))])
 def test_bow_transform_and_search_by_bow(batch, k, Lv, lup, settings):
     import torch
     from morb_slam_amd import ORBmatcher
@@ -160,7 +162,7 @@ def test_bow_transform_and_search_by_bow(batch, k, Lv, lup, settings):
         assert tot > 300
 
 
-@pytest.mark.parametrize("k,Lv,lup", [(10, 3, 1), (4, 3, 1), (3, 2, 1)])
+@pytest.mark.parametrize("k,Lv,lup", [(10, 3, 1), (4, 3, 1), (3, 2, 1), (10, 6, 4)])
 def test_search_by_bow_keyframes(batch, k, Lv, lup):
     """SearchByBoW(pKF1, pKF2, vpMatches12) (:702-819): only features with a MapPoint on both sides, strict TH_LOW,
     vbMatched2, table indexed by the pKF1 feature; mvKeysUn.size() limit of fisheye keyframes."""

@@ -1,49 +1,72 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep of PoseOptimization and LocalBundleAdjustment against the CPU oracle (developer tool, GPU box): more seeds and
-problem shapes than the test suite; the same criteria (pose / points within 1e-4, outlier and erase flags identical, LM iterations +-1).
-Usage: python tools/stress_optimizers.py [pose cases] [ba cases]"""
-import os, sys
+"""Randomised parity sweep of PoseOptimization and LocalBundleAdjustment against the CPU oracle (GPU box): more seeds and problem shapes
+than the fixtures of tests/; the tests' criteria (pose / points within 1e-4, outlier and erase flags identical, the same LM iterations).
+A seeded subset runs in `-m gpu` (tests/test_stress_gpu.py); the full sweep: python tools/stress_optimizers.py [pose cases] [ba cases]"""
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np, torch
-import oracle_lib as O
-from morb_slam_amd import Optimizer
-from morb_slam_amd.synth import make_ba_problem, make_pose_problem
-NP = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-NB = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-rng = np.random.default_rng(11)
-opt = Optimizer()
-bad = 0
-probs = []
-for s in range(NP):
-    n = int(rng.choice([60, 150, 300, 600, 1200]))
-    probs.append(make_pose_problem(n, seed=500 + s, outlier_frac=float(rng.choice([0.05, 0.15, 0.3])), mono_frac=float(rng.choice([0.0, 0.15, 0.5, 1.0]))))
-cap = max(len(p["hasMP"]) for p in probs)
-pad = lambda a: np.pad(a, [(0, cap - len(a))] + [(0, 0)] * (a.ndim - 1))
-t = [torch.from_numpy(np.stack([pad(p[k]) for p in probs])).cuda() for k in ("hasMP", "obs", "invSigma2", "Xw")]
-pose = torch.from_numpy(np.stack([p["pose0"] for p in probs])).cuda()
-cnt = torch.tensor([len(p["hasMP"]) for p in probs], dtype=torch.int32, device="cuda")
-out = opt.PoseOptimization(t[0], t[1], t[2], t[3], pose, probs[0]["cam"], count=cnt)
-torch.cuda.synchronize()
-poseg = pose.cpu().numpy(); nin = out[0].cpu().numpy(); outl = out[1].cpu().numpy(); st = out[2].cpu().numpy()
-for f, p in enumerate(probs):
-    r, pe, oe, se = O.pose_optimization(p)
-    n = len(p["hasMP"])
-    ok = np.abs(poseg[f] - pe).max() <= 1e-4 and nin[f] == r and np.array_equal(outl[f, :n], oe) and abs(int(st[f][0]) - int(se[0])) <= 1
-    if not ok:
-        bad += 1
-        print(f"PoseOptimization case {f}: MISMATCH dpose {np.abs(poseg[f] - pe).max():.2e} inliers {nin[f]} / {r} flags {int((outl[f, :n] != oe).sum())} its {st[f]} / {se}")
-print(f"PoseOptimization: {NP} cases checked")
-for s in range(NB):
-    kw = dict(seed=700 + s, n_free=int(rng.choice([5, 8, 12, 20])), n_fixed=int(rng.choice([2, 3, 6])), n_points=int(rng.choice([200, 500, 1500, 3000])),
-              mono_frac=float(rng.choice([0.0, 0.15, 0.5])))
-    b = make_ba_problem(**kw)
-    kf, mp, erase, stats = opt.LocalBundleAdjustment(b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"], b["eInvSigma2"], b["cam"])
-    its, kfe, mpe, ee, se = O.local_ba(b)
-    ok = (abs(int(stats[0]) - int(se[0])) <= 1 and np.abs(kf - kfe).max() <= 1e-4 and np.abs(mp - mpe).max() <= 1e-4 * max(1.0, np.abs(mpe).max())
-          and np.array_equal(erase, ee))
-    if not ok:
-        bad += 1
-        print(f"LocalBA case {kw}: MISMATCH dkf {np.abs(kf - kfe).max():.2e} dmp {np.abs(mp - mpe).max():.2e} flags {int((erase != ee).sum())} its {stats} / {se}")
-print(f"LocalBundleAdjustment: {NB} cases checked; {bad} mismatches in total")
-sys.exit(1 if bad else 0)
+import numpy as np
+
+
+def run_pose(NP, seed=11, log=print):
+    import torch
+    import oracle_lib as O
+    from morb_slam_amd import Optimizer
+    from morb_slam_amd.synth import make_pose_problem
+    rng = np.random.default_rng(seed)
+    opt = Optimizer()
+    bad = 0
+    probs = []
+    for s in range(NP):
+        n = int(rng.choice([60, 150, 300, 600, 1200]))
+        probs.append(make_pose_problem(n, seed=500 + 97 * seed + s, outlier_frac=float(rng.choice([0.05, 0.15, 0.3])),
+                                       mono_frac=float(rng.choice([0.0, 0.15, 0.5, 1.0]))))
+    cap = max(len(p["hasMP"]) for p in probs)
+    pad = lambda a: np.pad(a, [(0, cap - len(a))] + [(0, 0)] * (a.ndim - 1))
+    t = [torch.from_numpy(np.stack([pad(p[k]) for p in probs])).cuda() for k in ("hasMP", "obs", "invSigma2", "Xw")]
+    pose = torch.from_numpy(np.stack([p["pose0"] for p in probs])).cuda()
+    cnt = torch.tensor([len(p["hasMP"]) for p in probs], dtype=torch.int32, device="cuda")
+    out = opt.PoseOptimization(t[0], t[1], t[2], t[3], pose, probs[0]["cam"], count=cnt)
+    torch.cuda.synchronize()
+    poseg = pose.cpu().numpy(); nin = out[0].cpu().numpy(); outl = out[1].cpu().numpy(); st = out[2].cpu().numpy()
+    for f, p in enumerate(probs):
+        r, pe, oe, se = O.pose_optimization(p)
+        n = len(p["hasMP"])
+        ok = np.abs(poseg[f] - pe).max() <= 1e-4 and nin[f] == r and np.array_equal(outl[f, :n], oe) and int(st[f][0]) == int(se[0])
+        if not ok:
+            bad += 1
+            log(f"PoseOptimization case {f}: MISMATCH dpose {np.abs(poseg[f] - pe).max():.2e} inliers {nin[f]} / {r} flags {int((outl[f, :n] != oe).sum())} its {st[f]} / {se}")
+    return NP, bad
+
+
+def run_ba(NB, seed=11, log=print, max_points=3000):
+    import oracle_lib as O
+    from morb_slam_amd import Optimizer
+    from morb_slam_amd.synth import make_ba_problem
+    rng = np.random.default_rng(seed + 1)
+    opt = Optimizer()
+    bad = 0
+    for s in range(NB):
+        kw = dict(seed=700 + 97 * seed + s, n_free=int(rng.choice([5, 8, 12, 20])), n_fixed=int(rng.choice([2, 3, 6])),
+                  n_points=int(rng.choice([p for p in (200, 500, 1500, 3000) if p <= max_points])), mono_frac=float(rng.choice([0.0, 0.15, 0.5])))
+        b = make_ba_problem(**kw)
+        kf, mp, erase, stats = opt.LocalBundleAdjustment(b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"], b["eInvSigma2"], b["cam"])
+        its, kfe, mpe, ee, se = O.local_ba(b)
+        ok = (int(stats[0]) == int(se[0]) and np.abs(kf - kfe).max() <= 1e-4 and np.abs(mp - mpe).max() <= 1e-4 * max(1.0, np.abs(mpe).max())
+              and np.array_equal(erase, ee))
+        if not ok:
+            bad += 1
+            log(f"LocalBA case {kw}: MISMATCH dkf {np.abs(kf - kfe).max():.2e} dmp {np.abs(mp - mpe).max():.2e} flags {int((erase != ee).sum())} its {stats} / {se}")
+    return NB, bad
+
+
+if __name__ == "__main__":
+    NP = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    NB = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    _, b1 = run_pose(NP)
+    print(f"PoseOptimization: {NP} cases checked")
+    _, b2 = run_ba(NB)
+    print(f"LocalBundleAdjustment: {NB} cases checked; {b1 + b2} mismatches in total")
+    sys.exit(1 if b1 + b2 else 0)
