@@ -24,6 +24,27 @@
 // A cell without a keypoint after the iniThFAST pass is evaluated again with minThFAST (:795).
 #pragma once
 
+#ifdef MORB_FAST_CYCLES
+// Per-phase shader cycles of a wave's residency (tools/fastw_cycles.py): s_memtime at the phase boundaries (the wait makes pending LDS
+// traffic part of the phase that issued it): 0 load, 1 reject, 2 emit (compaction into the queue), 3 strength, 4 nms (zero + scatter + 3x3),
+// 5 output, 6 strip mode, 7 lifetime.  Accumulated in registers and written once, when the wave is done, to the wave's own 64 bytes of a
+// caller-provided buffer (atomics — even hashed over 64 slots — perturb the kernel: issued inside the phases they sit in front of the next
+// window load in the vector-memory queue; issued at the end they keep finished waves resident).
+__device__ unsigned long long* g_fwCycBuf;
+extern "C" int morb_fw_cycles_buffer(unsigned long long* d_buf) {   // [images x totalCells][8]
+  MORB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fwCycBuf), &d_buf, sizeof(d_buf)));
+  return 0;
+}
+__device__ __forceinline__ unsigned long long fw_now() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; }
+#define FW_CYC0() unsigned long long tc_ = fw_now(), acc_[7] = {0, 0, 0, 0, 0, 0, 0}; const unsigned long long tc0_ = tc_
+#define FW_CYC(k) do { const unsigned long long now_ = fw_now(); acc_[k] += now_ - tc_; tc_ = now_; } while (0)
+#define FW_CYC_END() do { const unsigned long long now_ = fw_now(); if (lane == 0 && g_fwCycBuf) { unsigned long long* g_ = g_fwCycBuf + cellSlot * 8; \
+    for (int k_ = 0; k_ < 7; ++k_) g_[k_] = acc_[k_]; g_[7] = now_ - tc0_; } } while (0)
+#else
+#define FW_CYC0()
+#define FW_CYC(k)
+#define FW_CYC_END()
+#endif
 #ifdef MORB_FAST_TIMING
 // dynamic phase counts of k_fastw (tools/fastw_stats.py): 0 waves, 1 jobs, 2 reject rounds, 3 emit loop trips, 4 survivors, 5 strength rounds,
 // 6 corners, 7 nms rounds, 8 keypoints, 9 output rank trips, 10 -, 11 minThFAST passes, 12 partial queue takes, 13 strip-mode passes
@@ -165,12 +186,14 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
   int n = 0;              // keypoints of the cell
   bool listed = false;    // ... are in `kept` (not yet written)
   FW_STAT(0, 1);
+  FW_CYC0();
   for (int pass = 0; pass < 2 && n == 0; ++pass) {
     // pass 0: cv::FAST(iniThFAST); pass 1: again with minThFAST if the cell came back empty (:795)
     const int T = pass ? minTh : iniTh;
     listed = false;
     FW_STAT(1, 1); FW_STAT(11, pass);
     load_tile();
+    FW_CYC(0);
     int qn = 0, cn = 0;
     {
       const int nIt = (xb + 15) >> 4;   // the 16-px blocks that hold evaluated pixels
@@ -220,6 +243,7 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
           if (bi == nIt - 1) W &= mLast;
         }
         FW_STAT(2, 1);
+        FW_CYC(1);
         const bool lastRound = i0 + 64 >= nItems;
         // one queue entry per flag: a pixel both of whose polarities are still possible is queued twice — a darker and a brighter 9-arc
         // cannot coexist on a 16-pixel ring, so at most one of the two entries finds a strength > T
@@ -262,6 +286,7 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
           }
           const bool more = __ballot(pend != 0u) != 0ull;   // (only after a partial take)
           const bool flush = lastRound && !more;
+          FW_CYC(2);
           // strength of the queued pixels, 64 at a time (fewer only when the pass's last survivors are flushed)
           while (qn >= 64 || (flush && qn > 0)) {
             FW_STAT(5, 1);
@@ -288,6 +313,7 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
               cn += __popcll(cm);
             }
           }
+          FW_CYC(3);
           if (!more) break;
         }
       }
@@ -295,6 +321,7 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
     FW_STAT(6, cn);
     if (cn > FW_CQ) {   // (wave-uniform) the corner list overflowed
       n = strip_mode(T);
+      FW_CYC(6);
       continue;
     }
     // NMS.  The window becomes the strength map: S at the corners (S > T), 0 elsewhere.  Corner score S - 1, everything else 0; keep iff
@@ -324,9 +351,11 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
       }
     }
     listed = true;
+    FW_CYC(4);
     if (n > FW_KC) {   // (wave-uniform) more keypoints than the list holds
       n = strip_mode(T);
       listed = false;
+      FW_CYC(6);
     }
   }
   FW_STAT(8, n); FW_STAT(9, listed ? n : 0);
@@ -342,4 +371,6 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
       out[rank] = morbqt::make_key((mpos & 127) + keyX0, (mpos >> 7) + keyY0, (int)(mine >> 16) - 1);
   }
   if (lane == 0) candCnt[cellSlot] = imin(n, cellCap);
+  FW_CYC(5);
+  FW_CYC_END();
 }

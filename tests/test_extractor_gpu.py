@@ -251,9 +251,9 @@ def test_event_after_fast_is_a_live_hip_event():
     ext.extract_batch(img)
     ev = ext.event_after_fast()
     assert ev
-    hip = ctypes.CDLL("libamdhip64.so")
-    assert hip.hipEventSynchronize(ctypes.c_void_p(ev)) == 0
+    from morb_slam_amd.capi import lib
     s = torch.cuda.Stream()
-    assert hip.hipStreamWaitEvent(ctypes.c_void_p(s.cuda_stream), ctypes.c_void_p(ev), 0) == 0
+    assert lib().morb_stream_wait_event(s.cuda_stream, ev) == 0     # hipStreamWaitEvent through the library's own HIP runtime
     s.synchronize()
     torch.cuda.synchronize()
+    assert lib().morb_stream_wait_event(s.cuda_stream, None) == -1  # MORB_ERR_INVALID

@@ -4,10 +4,11 @@ keypoints it went through.  Usage: python tools/fastw_stats.py [B] [extra -D fla
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-out = os.path.join(ROOT, "morb_slam_amd", "libmorb_hip_timing.so")
+out = os.path.join(ROOT, "morb_slam_amd", "libmorb_hip_fwstats.so")
 os.environ["MORB_HIP_LIB"] = out     # (read by morb_slam_amd.capi at import)
 from morb_slam_amd import build as b
-b.build_hip(extra_flags=("-DMORB_FAST_TIMING",) + tuple(sys.argv[2:]), out=out)
+import subprocess
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "ab_build.py"), "fwstats", "extractor.hip", "-DMORB_FAST_TIMING"] + sys.argv[2:], stdout=subprocess.DEVNULL)
 import numpy as np, torch
 from morb_slam_amd import capi, synth
 from morb_slam_amd.extractor import ORBextractor
