@@ -8,14 +8,17 @@
 // containers the reference methods fill (vpMapPointMatches[i] = map point of keyframe feature table[i], ...); the bookkeeping on live
 // map state (AddObservation, Replace, ...) stays with the caller, as DESIGN.md states for the whole matcher family.
 // Every method: hipSetDevice(device), uploads into per-thread, per-device staging buffers that only grow, one C-ABI call per
-// reference call, one synchronisation.
+// reference call, synchronised on the handle's own stream (never the device: Tracking's matcher calls do not wait for the LocalBundleAdjustment
+// trials the mapping thread has in flight on its optimizer handle).
 #pragma once
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <initializer_list>
+#include <set>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -102,6 +105,7 @@ class ORBmatcher {
                          float thFarPoints = 50.f, float viewingCosLimit = 0.5f) {
     const int N = F.N, M = mps.n;
     if (N <= 0 || M <= 0) { matchF.assign(N > 0 ? N : 0, -1); return 0; }
+    morb_adapter::StreamScope scope_(morb_matcher_stream(h_));   // uploads, kernels, downloads: the handle's stream, never the null stream
     Staging& s = staging();
     s.kp[0].assign(F.mvKeysUn, N);
     s.u8[0].assign(F.mDescriptors, (size_t)N * 32);
@@ -136,6 +140,7 @@ class ORBmatcher {
   int SearchByProjection(const FrameView& Cur, const FrameView& Last, std::vector<int>& matchCur, float th, bool bMono) {
     const int N = Cur.N, NL = Last.N;
     if (N <= 0 || NL <= 0) { matchCur.assign(N > 0 ? N : 0, -1); return 0; }
+    morb_adapter::StreamScope scope_(morb_matcher_stream(h_));   // uploads, kernels, downloads: the handle's stream, never the null stream
     Staging& s = staging();
     const int cap = load_pool(s, {&Cur, &Last});
     // :1536-1539: tlc = Tlw * twc; forward / backward motion widens the octave range
@@ -168,6 +173,7 @@ class ORBmatcher {
                          float th, int ORBdist) {
     const int N = Cur.N, NK = KF.N;
     if (N <= 0 || NK <= 0) { matchCur.assign(N > 0 ? N : 0, -1); return 0; }
+    morb_adapter::StreamScope scope_(morb_matcher_stream(h_));   // uploads, kernels, downloads: the handle's stream, never the null stream
     Staging& s = staging();
     const int cap = load_pool(s, {&Cur, &KF});
     std::vector<uint8_t> kfValid(NK);
@@ -209,6 +215,7 @@ class ORBmatcher {
   // reference keyframe, relocalisation).  vpMapPointMatches[j] = keyframe feature whose map point is matched to frame feature j, or -1.
   int SearchByBoW(const KeyFrameView& KF, const FrameView& F, std::vector<int>& vpMapPointMatches) {
     if (KF.N <= 0 || F.N <= 0) { vpMapPointMatches.assign(F.N > 0 ? F.N : 0, -1); return 0; }
+    morb_adapter::StreamScope scope_(morb_matcher_stream(h_));   // uploads, kernels, downloads: the handle's stream, never the null stream
     Staging& s = staging();
     const int cap = load_pool(s, {&KF, &F});
     const int kf = 0, fr = 1;
@@ -223,6 +230,7 @@ class ORBmatcher {
   // vpMatches12[i1] = feature of pKF2 whose map point is matched to feature i1 of pKF1, or -1.
   int SearchByBoW(const KeyFrameView& KF1, const KeyFrameView& KF2, std::vector<int>& vpMatches12) {
     if (KF1.N <= 0 || KF2.N <= 0) { vpMatches12.assign(KF1.N > 0 ? KF1.N : 0, -1); return 0; }
+    morb_adapter::StreamScope scope_(morb_matcher_stream(h_));   // uploads, kernels, downloads: the handle's stream, never the null stream
     Staging& s = staging();
     const int cap = load_pool(s, {&KF1, &KF2});
     const int a = 0, b = 1;
@@ -240,6 +248,7 @@ class ORBmatcher {
   int SearchForInitialization(const FrameView& F1, const FrameView& F2, std::vector<float>& vbPrevMatched, std::vector<int>& vnMatches12,
                               int windowSize = 10) {
     if (F1.N <= 0 || F2.N <= 0) { vnMatches12.assign(F1.N > 0 ? F1.N : 0, -1); return 0; }
+    morb_adapter::StreamScope scope_(morb_matcher_stream(h_));   // uploads, kernels, downloads: the handle's stream, never the null stream
     Staging& s = staging();
     const int cap = load_pool(s, {&F1, &F2});
     const int a = 0, b = 1;
@@ -263,6 +272,7 @@ class ORBmatcher {
                              std::vector<std::pair<size_t, size_t>>& vMatchedPairs, bool bOnlyStereo, bool bCoarse = false) {
     vMatchedPairs.clear();
     if (KF1.N <= 0 || KF2.N <= 0) return 0;
+    morb_adapter::StreamScope scope_(morb_matcher_stream(h_));   // uploads, kernels, downloads: the handle's stream, never the null stream
     Staging& s = staging();
     const int cap = load_pool(s, {&KF1, &KF2});
     const int a = 0, b = 1;
@@ -284,6 +294,7 @@ class ORBmatcher {
   int SearchBySim3(const KeyFrameView& KF1, const KeyFrameView& KF2, std::vector<int>& vpMatches12, const float S12[7], const float S21[7], float th) {
     const int N1 = KF1.N, N2 = KF2.N;
     if (N1 <= 0 || N2 <= 0) return 0;
+    morb_adapter::StreamScope scope_(morb_matcher_stream(h_));   // uploads, kernels, downloads: the handle's stream, never the null stream
     Staging& s = staging();
     const int cap = load_pool(s, {&KF1, &KF2});
     if ((int)vpMatches12.size() != N1) vpMatches12.assign(N1, -1);
@@ -326,6 +337,37 @@ class ORBmatcher {
 
   morb_matcher* handle() { return h_; }   // for the batched / device-resident entry points
 
+  // ---- the reference's own signatures (include/ORBmatcher.h:41-114) as member templates: a call site of src/Tracking.cc / src/LocalMapping.cc /
+  // src/LoopClosing.cc compiles unchanged and instantiates them with the reference's Frame / KeyFrame / MapPoint / Sophus types
+  // (definitions: ORBmatcher_reference.h, included below) ----
+  template <class Mat, class = typename std::enable_if<!std::is_pointer<Mat>::value>::type>
+  static int DescriptorDistance(const Mat& a, const Mat& b);
+  template <class FrameT, class MP>
+  int SearchByProjection(FrameT& F, const std::vector<MP*>& vpMapPoints, const float th = 3, const bool bFarPoints = false, const float thFarPoints = 50.0f);
+  template <class FrameT>
+  int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono);
+  template <class FrameT, class KF, class MP>
+  int SearchByProjection(FrameT& CurrentFrame, KF* pKF, const std::set<MP*>& sAlreadyFound, const float th, const int ORBdist);
+  template <class KF, class Sim3, class MP>
+  int SearchByProjection(KF* pKF, Sim3& Scw, const std::vector<MP*>& vpPoints, std::vector<MP*>& vpMatched, int th, float ratioHamming = 1.0);
+  template <class KF, class Sim3, class MP>
+  int SearchByProjection(KF* pKF, Sim3& Scw, const std::vector<MP*>& vpPoints, const std::vector<KF*>& vpPointsKFs, std::vector<MP*>& vpMatched,
+                         std::vector<KF*>& vpMatchedKF, int th, float ratioHamming = 1.0);
+  template <class KF, class FrameT, class MP, class = typename std::enable_if<!std::is_pointer<FrameT>::value>::type>
+  int SearchByBoW(KF* pKF, FrameT& F, std::vector<MP*>& vpMapPointMatches);
+  template <class KF, class MP>
+  int SearchByBoW(KF* pKF1, KF* pKF2, std::vector<MP*>& vpMatches12);
+  template <class FrameT, class Pt, class = typename std::enable_if<!std::is_base_of<FrameView, FrameT>::value>::type>
+  int SearchForInitialization(FrameT& F1, FrameT& F2, std::vector<Pt>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize = 10);
+  template <class KF>
+  int SearchForTriangulation(KF* pKF1, KF* pKF2, std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo, const bool bCoarse = false);
+  template <class KF, class MP, class Sim3>
+  int SearchBySim3(KF* pKF1, KF* pKF2, std::vector<MP*>& vpMatches12, const Sim3& S12, const float th);
+  template <class KF, class MP>
+  int Fuse(KF* pKF, const std::vector<MP*>& vpMapPoints, const float th = 3.0, const bool bRight = false);
+  template <class KF, class Sim3, class MP>
+  int Fuse(KF* pKF, Sim3& Scw, const std::vector<MP*>& vpPoints, float th, std::vector<MP*>& vpReplacePoint);
+
  protected:
   static constexpr int kMaxDevices = 16;
   // grow-only device staging, one set per host thread and device (the reference constructs a matcher per call; the buffers outlive it)
@@ -334,13 +376,18 @@ class ORBmatcher {
     morb_adapter::DeviceBuffer<uint8_t> u8[8];
     morb_adapter::DeviceBuffer<float> f32[13];
     morb_adapter::DeviceBuffer<int> i32[8];
+    morb_adapter::DeviceBuffer<int> rig[2];   // fisheye forms: mvRightToLeftMatch, mnTrackScaleLevelR
   };
+  morb_adapter::DeviceBuffer<int>& rigI32(int k) { return staging().rig[k]; }
+  template <class KF, class Sim3, class MP>
+  int sim3_projection_ref(KF* pKF, Sim3& Scw, const std::vector<MP*>& vpPoints, const std::vector<KF*>* vpPointsKFs, std::vector<MP*>& vpMatched,
+                          std::vector<KF*>* vpMatchedKF, int th, float ratioHamming);
   Staging& staging() {
     morb_adapter::hip_check(hipSetDevice(device_), "hipSetDevice");   // the buffers below and the handle's kernels live on device_
     static thread_local Staging per_device[kMaxDevices];
     return per_device[device_];
   }
-  static void sync() { morb_adapter::hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize"); }
+  static void sync() { morb_adapter::sync_current_stream(); }   // the handle's stream only (a device-wide wait would also wait for LocalMapping's optimizer)
   static void check(int rc) { if (rc < 0) throw std::runtime_error(morb_last_error()); }
   // row r (of capacity cap elements x width) of a pooled device array <- n elements of a host array (NULL = zeros)
   template <typename T>
@@ -388,6 +435,7 @@ class ORBmatcher {
     const int N = KF.N, M = P.n;
     if ((int)vpMatched.size() != N) vpMatched.assign(N > 0 ? N : 0, -1);
     if (N <= 0 || M <= 0) return 0;
+    morb_adapter::StreamScope scope_(morb_matcher_stream(h_));   // uploads, kernels, downloads: the handle's stream, never the null stream
     Staging& s = staging();
     const int cap = load_pool(s, {&KF});
     load_points(s, P);
@@ -409,6 +457,7 @@ class ORBmatcher {
     const int N = KF.N, M = P.n;
     bestIdx.assign(M > 0 ? M : 0, -1); bestDist.assign(M > 0 ? M : 0, 256);
     if (N <= 0 || M <= 0) return 0;
+    morb_adapter::StreamScope scope_(morb_matcher_stream(h_));   // uploads, kernels, downloads: the handle's stream, never the null stream
     Staging& s = staging();
     const int cap = load_pool(s, {&KF});
     load_points(s, P);
@@ -432,3 +481,5 @@ class ORBmatcher {
 };
 
 }  // namespace ORB_SLAM3
+
+#include "ORBmatcher_reference.h"

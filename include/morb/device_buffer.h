@@ -18,6 +18,20 @@ inline void hip_check(hipError_t e, const char* what) {
   if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// The stream the calling thread's copies are queued on: an adapter method sets it to its handle's stream for the duration of the call
+// (StreamScope), so that uploads, kernels and downloads of one reference call share one stream and nothing touches the null stream —
+// a copy there would wait for every blocking stream of the device, i.e. for whatever LocalBundleAdjustment trial the mapping thread
+// has in flight (System.cc:209 runs Tracking and LocalMapping side by side).  NULL (no scope) = the null stream, as before.
+inline hipStream_t& current_stream() { static thread_local hipStream_t s = nullptr; return s; }
+struct StreamScope {
+  hipStream_t saved;
+  explicit StreamScope(void* stream) : saved(current_stream()) { current_stream() = reinterpret_cast<hipStream_t>(stream); }
+  ~StreamScope() { current_stream() = saved; }
+  StreamScope(const StreamScope&) = delete;
+  StreamScope& operator=(const StreamScope&) = delete;
+};
+inline void sync_current_stream() { hip_check(hipStreamSynchronize(current_stream()), "hipStreamSynchronize"); }
+
 template <typename T>
 class DeviceBuffer {
  public:
@@ -35,9 +49,18 @@ class DeviceBuffer {
     cap_ = n_ = n;
   }
   void assign(const T* host, size_t n) { resize(n); upload(host, n); }   // grow-only: a static / member buffer re-used from call to call
-  void upload(const T* host, size_t n) { if (n) hip_check(hipMemcpy(p_, host, n * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D"); }
-  void fill_bytes(int byte) { if (n_) hip_check(hipMemset(p_, byte, n_ * sizeof(T)), "hipMemset"); }
-  void download(T* host, size_t n) const { if (n) hip_check(hipMemcpy(host, p_, n * sizeof(T), hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
+  // `host` may be a temporary of the caller: the copy is complete when upload() returns (hipMemcpy's contract, on the scope's stream)
+  void upload(const T* host, size_t n) {
+    if (!n) return;
+    hip_check(hipMemcpyAsync(p_, host, n * sizeof(T), hipMemcpyHostToDevice, current_stream()), "hipMemcpy H2D");
+    sync_current_stream();
+  }
+  void fill_bytes(int byte) { if (n_) hip_check(hipMemsetAsync(p_, byte, n_ * sizeof(T), current_stream()), "hipMemset"); }
+  void download(T* host, size_t n) const {
+    if (!n) return;
+    hip_check(hipMemcpyAsync(host, p_, n * sizeof(T), hipMemcpyDeviceToHost, current_stream()), "hipMemcpy D2H");
+    sync_current_stream();
+  }
   std::vector<T> to_host() const { std::vector<T> v(n_); download(v.data(), n_); return v; }
   T* get() { return p_; }
   const T* get() const { return p_; }

@@ -111,6 +111,11 @@ int morb_stream_wait_event(void* stream, void* event);
 typedef struct morb_matcher morb_matcher;
 int morb_matcher_create(morb_matcher** out, int device);
 void morb_matcher_destroy(morb_matcher*);
+/* Wait for the work queued on the matcher's OWN stream (calls made with stream = NULL) — not for the device: another handle's work
+ * (a LocalBundleAdjustment trial on the mapping thread's optimizer, System.cc:209) keeps running. */
+int morb_matcher_sync(morb_matcher*);
+/* The matcher's own stream (hipStream_t): a host adapter queues its uploads / downloads there instead of on the null stream. */
+void* morb_matcher_stream(const morb_matcher*);
 
 /* static int ORBmatcher::DescriptorDistance(a, b)  ORBmatcher.h:43, ORBmatcher.cc:1880-1894; n pairs of 32-byte
  * descriptors -> n distances. */
@@ -433,6 +438,9 @@ int morb_image_bounds(int width, int height, float fx, float fy, float cx, float
 typedef struct morb_optimizer morb_optimizer;
 int morb_optimizer_create(morb_optimizer** out, int device);
 void morb_optimizer_destroy(morb_optimizer*);
+/* Wait for the work queued on the optimizer's OWN stream (calls made with stream = NULL), not for the device. */
+int morb_optimizer_sync(morb_optimizer*);
+void* morb_optimizer_stream(const morb_optimizer*);   /* the optimizer's own stream (hipStream_t) */
 
 /* static int Optimizer::PoseOptimization(Frame* pFrame)  Optimizer.h:86, Optimizer.cc:762-1051, for nframes
  * frames at once (DEVICE pointers, frame f at offset f*cap): d_count[f] = Frame::N (NULL = cap),

@@ -101,6 +101,9 @@ def lib():
         L.morb_matcher_create.argtypes = [C.POINTER(vp), i]
         L.morb_matcher_destroy.argtypes = [vp]
         L.morb_matcher_destroy.restype = None
+        L.morb_matcher_sync.argtypes = [vp]
+        L.morb_matcher_stream.argtypes = [vp]
+        L.morb_matcher_stream.restype = vp
         L.morb_hamming_pairs.argtypes = [vp, vp, vp, i, vp, vp]
         L.morb_hamming_knn2_batch.argtypes = [vp, i, vp, vp, i, vp, vp, vp, i, vp, vp, vp, vp]
         L.morb_stereo_match_batch.argtypes = [vp, vp, i, vp, vp, vp, i, f, f, vp, vp, vp]
@@ -138,6 +141,9 @@ def lib():
         L.morb_optimizer_create.argtypes = [C.POINTER(vp), i]
         L.morb_optimizer_destroy.argtypes = [vp]
         L.morb_optimizer_destroy.restype = None
+        L.morb_optimizer_sync.argtypes = [vp]
+        L.morb_optimizer_stream.argtypes = [vp]
+        L.morb_optimizer_stream.restype = vp
         L.morb_pose_optimization_batch.argtypes = [vp, i, i, vp, vp, vp, vp, vp, f, f, f, f, f, vp, vp, vp, vp, vp]
         L.morb_imu_preintegrate_batch.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.morb_pose_inertial_optimization_last_keyframe_batch.argtypes = [vp, i, i, vp, vp, vp, vp, vp, vp, f, f, f, f, f, vp, vp, vp, i,

@@ -1028,6 +1028,13 @@ int morb_matcher_create(morb_matcher** out, int device) {
   return MORB_OK;
 }
 
+int morb_matcher_sync(morb_matcher* m) {
+  MORB_REQUIRE(m, MORB_ERR_INVALID, "NULL matcher");
+  MORB_HIP_CHECK(hipSetDevice(m->device));
+  MORB_HIP_CHECK(hipStreamSynchronize(m->stream));
+  return MORB_OK;
+}
+
 void morb_matcher_destroy(morb_matcher* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);

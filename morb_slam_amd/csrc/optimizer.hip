@@ -1406,6 +1406,7 @@ struct morb_ba_problem {
   size_t ldsBytes = 0;
   size_t denseLds = 0;     // LDS bytes of the triangle-resident solver (0: the system is too large for it)
   int mode = 0;            // 0 = grid (one launch per LM phase, host-side accept/reject), 1 = one persistent workgroup
+  hipStream_t lastStream = nullptr;   // the stream the last morb_ba_solve ran on (morb_ba_results waits for it, not for the device)
   int redBlocks = 0;
   morbschur::Plan schur;
   size_t nPairEntries = 0;   // (e1, e2) observation pairs of the sparse block-pair Schur form (flop accounting only)
@@ -1475,6 +1476,13 @@ int morb_optimizer_staging(morb_optimizer* o, size_t bytes, void** host) {
     o->stageBytes = bytes + bytes / 4;
   }
   *host = o->stage;
+  return MORB_OK;
+}
+
+int morb_optimizer_sync(morb_optimizer* o) {
+  MORB_REQUIRE(o, MORB_ERR_INVALID, "NULL optimizer");
+  MORB_HIP_CHECK(hipSetDevice(o->device));
+  MORB_HIP_CHECK(hipStreamSynchronize(o->stream));
   return MORB_OK;
 }
 
@@ -1844,6 +1852,7 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
   MORB_REQUIRE(p, MORB_ERR_INVALID, "NULL problem");
   MORB_HIP_CHECK(hipSetDevice(p->opt->device));
   hipStream_t st = stream ? (hipStream_t)stream : p->opt->stream;
+  p->lastStream = st;
   const int n = std::max(p->h.nKF, p->h.nMP * 3);
   hipLaunchKernelGGL(k_ba_reset, dim3(div_up(n, 256)), dim3(256), 0, st, p->h, p->d_pose0, p->d_pt0);
   if (p->mode == 1) {
@@ -1930,9 +1939,10 @@ int morb_ba_schur_profile(morb_ba_problem* p, int iters, float* msPerLaunch, dou
 int morb_ba_results(morb_ba_problem* p, float* kfPose, float* mpPos, uint8_t* eraseFlag, int* stats2) {
   MORB_REQUIRE(p, MORB_ERR_INVALID, "NULL problem");
   MORB_HIP_CHECK(hipSetDevice(p->opt->device));
-  // the solve may have run on a caller's stream: wait for the device once, then copy on the handle's own stream (a copy on
-  // the null stream would also wait for, and hold up, every other handle's blocking stream)
-  MORB_HIP_CHECK(hipDeviceSynchronize());
+  // the solve may have run on a caller's stream: wait for THAT stream (not for the device: with the reference's threading a tracked
+  // frame's optimisation on another handle must not wait for this solve, nor this copy for it), then copy on the handle's own stream
+  // (a copy on the null stream would also wait for, and hold up, every other handle's blocking stream)
+  if (p->lastStream && p->lastStream != p->opt->stream) MORB_HIP_CHECK(hipStreamSynchronize(p->lastStream));
   hipStream_t st = p->opt->stream;
   if (kfPose) MORB_HIP_CHECK(hipMemcpyAsync(kfPose, p->h.poseIO, sizeof(float) * 7 * p->h.nKF, hipMemcpyDeviceToHost, st));
   if (mpPos) MORB_HIP_CHECK(hipMemcpyAsync(mpPos, p->h.ptIO, sizeof(float) * 3 * p->h.nMP, hipMemcpyDeviceToHost, st));

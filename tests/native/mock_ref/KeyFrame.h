@@ -1,18 +1,28 @@
 #pragma once
-#include "mock_types.h"
+#include "MapPoint.h"
+#include "Map.h"
 namespace ORB_SLAM3 {
-class MapPoint; class Map;
-struct GeometricCamera { Eigen::Vector2f project(const Eigen::Vector3f&); };
-class KeyFrame {   // mock: the members of include/KeyFrame.h the glue touches
+class KeyFrame {   // mock: the members of include/KeyFrame.h the reference-typed members touch
  public:
-  Sophus::SE3f GetPose(); Sophus::SE3f GetPoseInverse(); Eigen::Vector3f GetCameraCenter(); void SetPose(const Sophus::SE3f&);
-  std::vector<MapPoint*> GetMapPointMatches(); std::vector<KeyFrame*> GetVectorCovisibleKeyFrames(); bool isBad(); Map* GetMap();
-  void EraseMapPointMatch(MapPoint*);
-  const int N = 0; const std::vector<cv::KeyPoint> mvKeysUn; const std::vector<float> mvuRight; const cv::Mat mDescriptors; DBoW2::FeatureVector mFeatVec;
-  const float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0, mb = 0, mfGridElementWidthInv = 0, mfGridElementHeightInv = 0, mfLogScaleFactor = 0;
-  const int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0, mnScaleLevels = 0;
-  const std::vector<float> mvScaleFactors, mvLevelSigma2, mvInvLevelSigma2;
-  long unsigned int mnId, mnBALocalForKF, mnBAFixedForKF;
-  GeometricCamera* mpCamera;
+  Sophus::SE3f GetPose() { return mTcw; } Sophus::SE3f GetPoseInverse() { return mTcw.inverse(); }
+  Eigen::Vector3f GetCameraCenter() { return Eigen::Vector3f(mTcw.Ow[0], mTcw.Ow[1], mTcw.Ow[2]); } void SetPose(const Sophus::SE3f& T) { mTcw = T; }
+  std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; } std::set<MapPoint*> GetMapPoints() { std::set<MapPoint*> s; for (auto* p : mvpMapPoints) if (p && !p->isBad()) s.insert(p); return s; }
+  MapPoint* GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; } void AddMapPoint(MapPoint* p, const size_t& idx) { mvpMapPoints[idx] = p; }
+  void EraseMapPointMatch(MapPoint* p) { for (auto& q : mvpMapPoints) if (q == p) q = nullptr; }
+  std::vector<KeyFrame*> GetVectorCovisibleKeyFrames() { return mvpCov; } bool isBad() { return mbBad; } Map* GetMap() { return mpMap; }
+  Sophus::SE3f GetRelativePoseTrl() { return mTrl; }
+  Eigen::Matrix3f GetImuRotation() { return mRwb; } Eigen::Vector3f GetImuPosition() { return mOwb; } Eigen::Vector3f GetVelocity() { return mVw; }
+  IMU::Bias GetImuBias() { return mImuBias; } void SetVelocity(const Eigen::Vector3f& v) { mVw = v; } void SetNewBias(const IMU::Bias& b) { mImuBias = b; }
+  int N = 0, NLeft = -1, NRight = -1;
+  std::vector<cv::KeyPoint> mvKeys, mvKeysRight, mvKeysUn; std::vector<float> mvuRight; cv::Mat mDescriptors; DBoW2::FeatureVector mFeatVec;
+  float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0, mb = 0, mfGridElementWidthInv = 0, mfGridElementHeightInv = 0, mfLogScaleFactor = 0, mfScaleFactor = 1.2f;
+  int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0, mnScaleLevels = 0;
+  std::vector<float> mvScaleFactors, mvLevelSigma2, mvInvLevelSigma2;
+  long unsigned int mnId = 0, mnBALocalForKF = 0, mnBAFixedForKF = 0;
+  GeometricCamera *mpCamera = nullptr, *mpCamera2 = nullptr;
+  bool bImu = false; KeyFrame* mPrevKF = nullptr; IMU::Preintegrated* mpImuPreintegrated = nullptr; IMU::Calib mImuCalib;
+  // (mock state)
+  Sophus::SE3f mTcw, mTrl; std::vector<MapPoint*> mvpMapPoints; std::vector<KeyFrame*> mvpCov; bool mbBad = false; Map* mpMap = nullptr;
+  Eigen::Matrix3f mRwb; Eigen::Vector3f mOwb, mVw; IMU::Bias mImuBias;
 };
 }  // namespace ORB_SLAM3

@@ -1,0 +1,341 @@
+// Drives the REFERENCE-TYPED members of include/morb/ORBmatcher.h / Optimizer.h (the exact signatures of the reference's
+// include/ORBmatcher.h:41-114 and Optimizer.h:86) with mock Frame / KeyFrame / MapPoint objects (tests/native/mock_ref) filled from the
+// SAME input files matcher_adapters_check.cc / adapters_check.cc read, and dumps what they leave in the objects as index tables
+// (out_ref_*).  tests/test_adapter_matcher_gpu.py / test_adapter_gpu.py require out_ref_* == out_* (the view-taking adapters' results, which they
+// compare with the oracle): the gather and write-back code of ORBmatcher_reference.h / Optimizer_reference.h is thereby checked end to end.
+//   reference_members_check <dir> matcher|tracking
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "Frame.h"      // tests/native/mock_ref
+#include "KeyFrame.h"
+#include "Map.h"
+#include "MapPoint.h"
+#include "ORBmatcher.h"   // include/morb
+#include "Optimizer.h"
+
+using namespace ORB_SLAM3;
+namespace ORB_SLAM3 {
+float Frame::fx, Frame::fy, Frame::cx, Frame::cy, Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY, Frame::mfGridElementWidthInv,
+    Frame::mfGridElementHeightInv;
+std::mutex MapPoint::mGlobalMutex;
+}
+
+static std::string g_dir;
+template <typename T>
+static std::vector<T> load(const std::string& name, bool optional = false) {
+  std::ifstream f(g_dir + "/" + name + ".bin", std::ios::binary | std::ios::ate);
+  if (!f) { if (optional) return {}; std::fprintf(stderr, "missing %s\n", name.c_str()); std::exit(3); }
+  const size_t bytes = (size_t)f.tellg();
+  std::vector<T> v(bytes / sizeof(T));
+  f.seekg(0); f.read(reinterpret_cast<char*>(v.data()), (std::streamsize)bytes);
+  return v;
+}
+template <typename T>
+static void dump(const std::string& name, const T* p, size_t n) {
+  std::ofstream f(g_dir + "/out_ref_" + name + ".bin", std::ios::binary);
+  f.write(reinterpret_cast<const char*>(p), (std::streamsize)(n * sizeof(T)));
+}
+
+static std::vector<std::unique_ptr<MapPoint>> g_points;   // owns every mock map point
+static MapPoint* new_point(const float* pos, const uint8_t* desc, float maxD, float minD, int nObs) {
+  g_points.emplace_back(new MapPoint());
+  MapPoint* p = g_points.back().get();
+  if (pos) p->mWorldPos = Eigen::Vector3f(pos[0], pos[1], pos[2]);
+  p->mDescriptor.data.assign(32, 0);
+  if (desc) p->mDescriptor.data.assign(desc, desc + 32);
+  p->mock_set_distances(maxD, minD);
+  p->nObs = nObs;
+  return p;
+}
+static Sophus::SE3f canned_pose(const std::vector<float>& pose22) {
+  Sophus::SE3f T;
+  if (pose22.size() == 22) {
+    for (int i = 0; i < 9; ++i) T.R[i] = pose22[i];
+    for (int i = 0; i < 3; ++i) { T.t[i] = pose22[9 + i]; T.Ow[i] = pose22[12 + i]; }
+    for (int i = 0; i < 4; ++i) T.q[i] = pose22[15 + i];
+  }
+  return T;
+}
+// the per-feature arrays of a test frame (files written by the Python side)
+struct Arrays {
+  std::vector<morb_keypoint> kps; std::vector<uint8_t> desc, tracked, hasmp, mpdesc, mpobs; std::vector<float> uright, mppos, mpmax, mpmin, pose;
+  std::vector<int> node, nvalid; std::vector<morb_frame_params> prm;
+  explicit Arrays(const std::string& p) {
+    kps = load<morb_keypoint>(p + "_kps"); desc = load<uint8_t>(p + "_desc"); uright = load<float>(p + "_uright", true);
+    tracked = load<uint8_t>(p + "_tracked", true); hasmp = load<uint8_t>(p + "_hasmp", true); mpdesc = load<uint8_t>(p + "_mpdesc", true);
+    mpobs = load<uint8_t>(p + "_mpobs", true); mppos = load<float>(p + "_mppos", true); mpmax = load<float>(p + "_mpmax", true);
+    mpmin = load<float>(p + "_mpmin", true); pose = load<float>(p + "_pose", true); node = load<int>(p + "_node", true);
+    nvalid = load<int>(p + "_nvalid", true); prm = load<morb_frame_params>(p + "_params");
+  }
+  // feature i's map point as the reference would hold it: NULL unless the test marks one; Observations() from tracked / mpobs
+  std::vector<MapPoint*> points() const {
+    const int N = (int)kps.size();
+    std::vector<MapPoint*> v(N, nullptr);
+    for (int i = 0; i < N; ++i) {
+      const bool has = !hasmp.empty() && hasmp[i], trk = !tracked.empty() && tracked[i];
+      if (!has && !trk) continue;
+      const int nObs = trk ? 1 : (mpobs.empty() ? 1 : (int)mpobs[i]);
+      v[i] = new_point(mppos.empty() ? nullptr : &mppos[3 * i], mpdesc.empty() ? nullptr : &mpdesc[(size_t)32 * i], mpmax.empty() ? 1.f : mpmax[i],
+                       mpmin.empty() ? 1.f : mpmin[i], nObs);
+    }
+    return v;
+  }
+  template <class F> void common(F& f) const {
+    const int N = (int)kps.size();
+    f.N = N;
+    f.mvKeysUn.resize(N);
+    for (int i = 0; i < N; ++i) { cv::KeyPoint& k = f.mvKeysUn[i]; k.pt.x = kps[i].x; k.pt.y = kps[i].y; k.size = kps[i].size; k.angle = kps[i].angle; k.response = kps[i].response; k.octave = kps[i].octave; k.class_id = kps[i].class_id; }
+    f.mvKeys = f.mvKeysUn;
+    f.mDescriptors.data = desc; f.mDescriptors.rows = N;
+    f.mvuRight = uright.empty() ? std::vector<float>(N, -1.f) : uright;
+    for (int i = 0; i < (int)node.size(); ++i) if (node[i] >= 0) f.mFeatVec[(unsigned)node[i]].push_back((unsigned)i);
+    const morb_frame_params& P = prm[0];
+    f.mbf = P.mbf; f.mb = P.mb; f.mfLogScaleFactor = P.logScaleFactor; f.mnScaleLevels = P.nlevels;
+    f.mvScaleFactors.assign(P.scaleFactors, P.scaleFactors + P.nlevels); f.mvLevelSigma2.assign(P.levelSigma2, P.levelSigma2 + P.nlevels);
+    f.mvInvLevelSigma2.resize(P.nlevels);
+    for (int l = 0; l < P.nlevels; ++l) f.mvInvLevelSigma2[l] = 1.0f / P.levelSigma2[l];
+  }
+  void fill(Frame& f) const {
+    common(f);
+    const morb_frame_params& P = prm[0];
+    Frame::fx = P.fx; Frame::fy = P.fy; Frame::cx = P.cx; Frame::cy = P.cy; Frame::mnMinX = P.minX; Frame::mnMaxX = P.maxX; Frame::mnMinY = P.minY;
+    Frame::mnMaxY = P.maxY; Frame::mfGridElementWidthInv = P.gridInvW; Frame::mfGridElementHeightInv = P.gridInvH;
+    f.mvpMapPoints = points(); f.mvbOutlier.assign(f.N, false);
+    if (pose.size() == 22) f.SetPose(canned_pose(pose));
+  }
+  void fill(KeyFrame& k) const {
+    common(k);
+    const morb_frame_params& P = prm[0];
+    k.fx = P.fx; k.fy = P.fy; k.cx = P.cx; k.cy = P.cy; k.mnMinX = (int)P.minX; k.mnMaxX = (int)P.maxX; k.mnMinY = (int)P.minY; k.mnMaxY = (int)P.maxY;
+    k.mfGridElementWidthInv = P.gridInvW; k.mfGridElementHeightInv = P.gridInvH;
+    k.mvpMapPoints = points();
+    if (!nvalid.empty() && nvalid[0] < k.N) k.mvKeysUn.resize(nvalid[0]);   // (a fisheye keyframe's shorter mvKeysUn, ORBmatcher.cc:734)
+    k.mTcw = canned_pose(pose);
+  }
+};
+template <class V> static std::vector<int> index_of(const std::vector<MapPoint*>& got, const V& pool) {
+  std::vector<int> out(got.size(), -1);
+  for (size_t i = 0; i < got.size(); ++i)
+    if (got[i]) for (size_t j = 0; j < pool.size(); ++j) if (pool[j] == got[i]) { out[i] = (int)j; break; }
+  return out;
+}
+
+static int run_matcher() {
+  {   // int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono)
+    Arrays ac("last_cur"), al("last_last");
+    Frame cur, last; ac.fill(cur); al.fill(last);
+    const auto cfg = load<float>("last_cfg");
+    ORBmatcher matcher(cfg[0], cfg[1] != 0);
+    const std::vector<MapPoint*> before = cur.mvpMapPoints;
+    const int n = matcher.SearchByProjection(cur, last, cfg[2], cfg[3] != 0);
+    std::vector<int> match = index_of(cur.mvpMapPoints, last.mvpMapPoints);
+    dump("last_n", &n, 1); dump("last_match", match.data(), match.size());
+  }
+  {   // int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist)
+    Arrays ac("kfp_cur"), ak("kfp_kf");
+    Frame cur; KeyFrame kf; ac.fill(cur); ak.fill(kf);
+    const auto cfg = load<float>("kfp_cfg");
+    const auto found = load<uint8_t>("kfp_found");
+    std::set<MapPoint*> sFound;
+    for (int i = 0; i < kf.N; ++i) if (found[i] && kf.mvpMapPoints[i]) sFound.insert(kf.mvpMapPoints[i]);
+    ORBmatcher matcher(cfg[0], cfg[1] != 0);
+    const int n = matcher.SearchByProjection(cur, &kf, sFound, cfg[2], (int)cfg[3]);
+    std::vector<int> match = index_of(cur.mvpMapPoints, kf.mvpMapPoints);
+    dump("kfp_n", &n, 1); dump("kfp_match", match.data(), match.size());
+  }
+  {   // int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches) and SearchByBoW(pKF1, pKF2, vpMatches12)
+    Arrays ak("bow_kf"), af("bow_f");
+    KeyFrame kf; Frame fr; ak.fill(kf); af.fill(fr);
+    const auto cfg = load<float>("bow_cfg");
+    ORBmatcher matcher(cfg[0], cfg[1] != 0);
+    std::vector<MapPoint*> vpMapPointMatches;
+    int n = matcher.SearchByBoW(&kf, fr, vpMapPointMatches);
+    std::vector<int> match = index_of(vpMapPointMatches, kf.mvpMapPoints);
+    dump("bow_n", &n, 1); dump("bow_match", match.data(), match.size());
+    Arrays a1("bowkk_1"), a2("bowkk_2");
+    KeyFrame k1, k2; a1.fill(k1); a2.fill(k2);
+    std::vector<MapPoint*> vpMatches12;
+    n = matcher.SearchByBoW(&k1, &k2, vpMatches12);
+    match = index_of(vpMatches12, k2.mvpMapPoints);
+    dump("bowkk_n", &n, 1); dump("bowkk_match", match.data(), match.size());
+  }
+  {   // int SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize)
+    Arrays a1("ini_1"), a2("ini_2");
+    Frame f1, f2; a1.fill(f1); a2.fill(f2);
+    const auto cfg = load<float>("ini_cfg");
+    const auto prev = load<float>("ini_prev");
+    std::vector<cv::Point2f> vbPrevMatched(prev.size() / 2);
+    for (size_t i = 0; i < vbPrevMatched.size(); ++i) { vbPrevMatched[i].x = prev[2 * i]; vbPrevMatched[i].y = prev[2 * i + 1]; }
+    ORBmatcher matcher(cfg[0], cfg[1] != 0);
+    std::vector<int> vnMatches12;
+    const int n = matcher.SearchForInitialization(f1, f2, vbPrevMatched, vnMatches12, (int)cfg[2]);
+    std::vector<float> flat;
+    for (auto& p : vbPrevMatched) { flat.push_back(p.x); flat.push_back(p.y); }
+    dump("ini_n", &n, 1); dump("ini_match", vnMatches12.data(), vnMatches12.size()); dump("ini_prev", flat.data(), flat.size());
+  }
+  {   // int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, vMatchedPairs, const bool bOnlyStereo, const bool bCoarse)
+    Arrays a1("tri_1"), a2("tri_2");
+    KeyFrame k1, k2; a1.fill(k1); a2.fill(k2);
+    const auto cfg = load<float>("tri_cfg");   // nnratio, checkOri, bOnlyStereo, bCoarse, R12 (9), t12 (3), ep (2)
+    for (int i = 0; i < 9; ++i) k1.mTcw.R[i] = cfg[4 + i];     // canned: T1w = (R12, t12), Tw2 = identity -> T1w * Tw2 = T12
+    for (int i = 0; i < 3; ++i) k1.mTcw.t[i] = cfg[13 + i];
+    GeometricCamera cam; cam.ep.v[0] = cfg[16]; cam.ep.v[1] = cfg[17];
+    k1.mpCamera = k2.mpCamera = &cam;
+    ORBmatcher matcher(cfg[0], cfg[1] != 0);
+    std::vector<std::pair<size_t, size_t>> pairs;
+    const int n = matcher.SearchForTriangulation(&k1, &k2, pairs, cfg[2] != 0, cfg[3] != 0);
+    std::vector<int> flat;
+    for (auto& p : pairs) { flat.push_back((int)p.first); flat.push_back((int)p.second); }
+    dump("tri_n", &n, 1); dump("tri_pairs", flat.data(), flat.size());
+  }
+  {   // Fuse x2 and SearchByProjection(pKF, Scw, ...) x2
+    Arrays ak("lc_kf");
+    const auto pos = load<float>("lc_pts_pos"), nrm = load<float>("lc_pts_normal"), maxd = load<float>("lc_pts_maxd"), mind = load<float>("lc_pts_mind");
+    const auto desc = load<uint8_t>("lc_pts_desc"), valid = load<uint8_t>("lc_pts_valid");
+    const auto cfg = load<float>("lc_cfg");   // nnratio, checkOri, thFuse, thFuseSim3, thProj, ratioProj
+    const auto sim = load<float>("lc_sim3");  // Tcw 7, Ow 3
+    const int M = (int)maxd.size();
+    auto make_points = [&]() {
+      std::vector<MapPoint*> v(M);
+      for (int i = 0; i < M; ++i) {
+        v[i] = new_point(&pos[3 * i], &desc[(size_t)32 * i], maxd[i], mind[i], 1);
+        v[i]->mNormalVector = Eigen::Vector3f(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]);
+        v[i]->mbBad = valid[i] == 0;   // valid = non-NULL && !isBad() && !IsInKeyFrame(pKF)
+      }
+      return v;
+    };
+    Sophus::Sim3f Scw;
+    for (int i = 0; i < 4; ++i) Scw.T.q[i] = sim[i];
+    for (int i = 0; i < 3; ++i) { Scw.T.t[i] = sim[4 + i]; Scw.T.Ow[i] = sim[7 + i]; }
+    ORBmatcher matcher(cfg[0], cfg[1] != 0);
+    auto slots = [&](KeyFrame& kf, const std::vector<MapPoint*>& pts, const char* tag, int n) {   // feature -> the point the call put there
+      std::vector<int> s = index_of(kf.mvpMapPoints, pts);
+      dump(std::string(tag) + "_n", &n, 1); dump(std::string(tag) + "_slots", s.data(), s.size());
+    };
+    {
+      KeyFrame kf; ak.fill(kf);
+      const auto kfpose = load<float>("lc_kf_pose");
+      kf.mTcw = canned_pose(kfpose);
+      std::vector<MapPoint*> pts = make_points();
+      const int n = matcher.Fuse(&kf, pts, cfg[2]);
+      slots(kf, pts, "fuse", n);
+    }
+    {
+      KeyFrame kf; ak.fill(kf);
+      std::vector<MapPoint*> pts = make_points();
+      std::vector<MapPoint*> vpReplacePoint(M, static_cast<MapPoint*>(NULL));
+      const int n = matcher.Fuse(&kf, Scw, pts, cfg[3], vpReplacePoint);
+      slots(kf, pts, "fuse3", n);
+    }
+    const auto matched = load<int>("lc_matched");
+    for (int variant = 0; variant < 2; ++variant) {
+      KeyFrame kf; ak.fill(kf);
+      std::vector<MapPoint*> pts = make_points();
+      MapPoint* taken = new_point(nullptr, nullptr, 1.f, 1.f, 1);   // what already sits in vpMatched on entry
+      std::vector<MapPoint*> vpMatched(kf.N, static_cast<MapPoint*>(NULL));
+      for (int i = 0; i < kf.N; ++i) if (matched[i] >= 0) vpMatched[i] = taken;
+      std::vector<KeyFrame*> vpPointsKFs(M, &kf), vpMatchedKF;
+      const int n = variant == 0 ? matcher.SearchByProjection(&kf, Scw, pts, vpMatched, (int)cfg[4], cfg[5])
+                                 : matcher.SearchByProjection(&kf, Scw, pts, vpPointsKFs, vpMatched, vpMatchedKF, (int)cfg[4], cfg[5]);
+      std::vector<int> idx = index_of(vpMatched, pts);
+      for (int i = 0; i < kf.N; ++i) if (vpMatched[i] == taken) idx[i] = matched[i];
+      const char* tag = variant == 0 ? "sim3p" : "sim3k";
+      dump(std::string(tag) + "_n", &n, 1); dump(std::string(tag) + "_match", idx.data(), idx.size());
+    }
+  }
+  {   // int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const Sophus::Sim3f& S12, const float th)
+    Arrays a1("s3_1"), a2("s3_2");
+    KeyFrame k1, k2; a1.fill(k1); a2.fill(k2);
+    const auto cfg = load<float>("s3_cfg");   // nnratio, checkOri, th, S12 (7), S21 (7)
+    Sophus::Sim3f S12, S21;
+    for (int i = 0; i < 7; ++i) { S12.raw[i] = cfg[3 + i]; S21.raw[i] = cfg[10 + i]; }
+    S12.inv = &S21;
+    ORBmatcher matcher(cfg[0], cfg[1] != 0);
+    std::vector<MapPoint*> vpMatches12(k1.N, static_cast<MapPoint*>(NULL));
+    const int n = matcher.SearchBySim3(&k1, &k2, vpMatches12, S12, cfg[2]);
+    std::vector<int> m12 = index_of(vpMatches12, k2.mvpMapPoints);
+    dump("s3_n", &n, 1); dump("s3_match", m12.data(), m12.size());
+  }
+  std::printf("reference members (matcher) ok\n");
+  return 0;
+}
+
+static int run_tracking() {
+  {   // int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bFarPoints, const float thFarPoints)
+    // after the host's isInFrustum loop (Tracking.cc:3117-3183): here that loop's results come from morb_is_in_frustum_batch
+    using morb_adapter::DeviceBuffer;
+    const auto kps = load<morb_keypoint>("f_kps"); const auto desc = load<uint8_t>("f_desc"); const auto ur = load<float>("f_uright");
+    const auto blocked = load<uint8_t>("f_blocked"); const auto prm = load<morb_frame_params>("f_params"); const auto pose = load<float>("f_pose");
+    const auto Xw = load<float>("mp_xw"); const auto nrm = load<float>("mp_normal"); const auto maxD = load<float>("mp_maxd"); const auto minD = load<float>("mp_mind");
+    const auto mdesc = load<uint8_t>("mp_desc"); const auto bad = load<uint8_t>("mp_bad"); const auto obs = load<uint8_t>("mp_hasobs");
+    const auto cfg = load<float>("sbp_cfg");   // nnratio, th, bFar, thFar
+    const int N = (int)kps.size(), M = (int)maxD.size();
+    ORBmatcher matcher(cfg[0], true);
+    DeviceBuffer<float> dR(pose.data(), 9), dt(pose.data() + 9, 3), dO(pose.data() + 12, 3), dX(Xw), dn(nrm), dmax(maxD), dmin(minD), px(M), py(M), pxr(M), dep(M), vc(M);
+    DeviceBuffer<uint8_t> inv(M); DeviceBuffer<int> lvl(M), nmp(&M, 1);
+    if (morb_is_in_frustum_batch(matcher.handle(), &prm[0], 1, dR.get(), dt.get(), dO.get(), M, nmp.get(), dX.get(), dn.get(), dmax.get(), dmin.get(), 0.5f, inv.get(),
+                                 px.get(), py.get(), pxr.get(), dep.get(), lvl.get(), vc.get(), nullptr) != MORB_OK) return 4;
+    morb_matcher_sync(matcher.handle());
+    const auto hin = inv.to_host(); const auto hpx = px.to_host(), hpy = py.to_host(), hpxr = pxr.to_host(), hdep = dep.to_host(), hvc = vc.to_host(); const auto hl = lvl.to_host();
+    Frame F;
+    F.N = N; F.mvKeysUn.resize(N);
+    for (int i = 0; i < N; ++i) { cv::KeyPoint& k = F.mvKeysUn[i]; k.pt.x = kps[i].x; k.pt.y = kps[i].y; k.size = kps[i].size; k.angle = kps[i].angle; k.response = kps[i].response; k.octave = kps[i].octave; k.class_id = kps[i].class_id; }
+    F.mDescriptors.data = desc; F.mDescriptors.rows = N; F.mvuRight = ur;
+    const morb_frame_params& P = prm[0];
+    Frame::fx = P.fx; Frame::fy = P.fy; Frame::cx = P.cx; Frame::cy = P.cy; Frame::mnMinX = P.minX; Frame::mnMaxX = P.maxX; Frame::mnMinY = P.minY;
+    Frame::mnMaxY = P.maxY; Frame::mfGridElementWidthInv = P.gridInvW; Frame::mfGridElementHeightInv = P.gridInvH;
+    F.mbf = P.mbf; F.mb = P.mb; F.mfLogScaleFactor = P.logScaleFactor; F.mnScaleLevels = P.nlevels;
+    F.mvScaleFactors.assign(P.scaleFactors, P.scaleFactors + P.nlevels); F.mvLevelSigma2.assign(P.levelSigma2, P.levelSigma2 + P.nlevels);
+    F.mvpMapPoints.assign(N, static_cast<MapPoint*>(NULL));
+    for (int i = 0; i < N; ++i) if (blocked[i]) F.mvpMapPoints[i] = new_point(nullptr, nullptr, 1.f, 1.f, 1);
+    std::vector<MapPoint*> vpMapPoints(M);
+    for (int j = 0; j < M; ++j) {
+      MapPoint* p = new_point(&Xw[3 * j], &mdesc[(size_t)32 * j], maxD[j], minD[j], obs[j] ? 1 : 0);
+      p->mbBad = bad[j] != 0;
+      p->mbTrackInView = hin[j] != 0 && !p->mbBad;     // (the host loop skips bad points before isInFrustum, Tracking.cc:3152)
+      p->mTrackProjX = hpx[j]; p->mTrackProjY = hpy[j]; p->mTrackProjXR = hpxr[j]; p->mTrackDepth = hdep[j]; p->mnTrackScaleLevel = hl[j]; p->mTrackViewCos = hvc[j];
+      vpMapPoints[j] = p;
+    }
+    const std::vector<MapPoint*> before = F.mvpMapPoints;
+    const int n = matcher.SearchByProjection(F, vpMapPoints, cfg[1], cfg[2] != 0, cfg[3]);
+    std::vector<int> match = index_of(F.mvpMapPoints, vpMapPoints);
+    dump("sbp_n", &n, 1); dump("sbp_match", match.data(), match.size());
+    cv::Mat a, b; a.data.assign(desc.begin(), desc.begin() + 32); b.data.assign(mdesc.begin(), mdesc.begin() + 32);
+    const int dd = ORBmatcher::DescriptorDistance(a, b);
+    dump("dist", &dd, 1);
+  }
+  {   // int Optimizer::PoseOptimization(Frame* pFrame)
+    const auto has = load<uint8_t>("po_has"); const auto obs = load<float>("po_obs"); const auto inv = load<float>("po_inv"); const auto Xw = load<float>("po_xw");
+    const auto cam = load<float>("po_cam"); const auto pose = load<float>("po_pose");
+    const int N = (int)has.size();
+    Frame F;
+    F.N = N; F.mvKeysUn.resize(N); F.mvuRight.resize(N); F.mvInvLevelSigma2.resize(N); F.mvpMapPoints.assign(N, static_cast<MapPoint*>(NULL)); F.mvbOutlier.assign(N, true);
+    for (int i = 0; i < N; ++i) {
+      F.mvKeysUn[i].pt.x = obs[3 * i]; F.mvKeysUn[i].pt.y = obs[3 * i + 1]; F.mvuRight[i] = obs[3 * i + 2];
+      F.mvKeysUn[i].octave = i; F.mvInvLevelSigma2[i] = inv[i];   // (mock: one "octave" per feature so that any 1 / sigma^2 can be carried)
+      if (has[i]) F.mvpMapPoints[i] = new_point(&Xw[3 * i], nullptr, 1.f, 1.f, 1);
+    }
+    Frame::fx = cam[0]; Frame::fy = cam[1]; Frame::cx = cam[2]; Frame::cy = cam[3]; F.mbf = cam[4];
+    Sophus::SE3f T; for (int i = 0; i < 4; ++i) T.q[i] = pose[i]; for (int i = 0; i < 3; ++i) T.t[i] = pose[4 + i];
+    F.SetPose(T);
+    const int nin = Optimizer::PoseOptimization(&F);
+    const Sophus::SE3f To = F.GetPose();
+    const float po[7] = {To.q[0], To.q[1], To.q[2], To.q[3], To.t[0], To.t[1], To.t[2]};
+    std::vector<uint8_t> outl(N);
+    for (int i = 0; i < N; ++i) outl[i] = (has[i] && F.mvbOutlier[i]) ? 1 : 0;
+    dump("po_nin", &nin, 1); dump("po_pose", po, 7); dump("po_outlier", outl.data(), outl.size());
+  }
+  std::printf("reference members (tracking) ok\n");
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 2;
+  g_dir = argv[1];
+  return std::string(argv[2]) == "matcher" ? run_matcher() : run_tracking();
+}

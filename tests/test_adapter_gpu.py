@@ -14,10 +14,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(tmp_path, src):
+def _build(tmp_path, src, mock_ref=False):
     exe = str(tmp_path / os.path.splitext(src)[0])
     libdir = os.path.join(ROOT, "morb_slam_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-o", exe,
+    # mock_ref: the reference-typed members are driven with the mock Frame / KeyFrame / MapPoint of tests/native/mock_ref, with include/morb
+    # first on the include path as in an integrated reference tree (so that "ORBmatcher.h" is the adapter)
+    inc = ["-I" + os.path.join(ROOT, "tests", "native", "mock_ref"), "-I" + os.path.join(ROOT, "include", "morb")] if mock_ref else []
+    subprocess.check_call(["g++", "-std=c++17", "-O1"] + inc + ["-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-o", exe,
                            os.path.join(ROOT, "tests", "native", src), "-L" + libdir, "-lmorb_hip", "-L/opt/rocm/lib", "-lamdhip64",
                            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     return exe
@@ -102,6 +105,14 @@ def test_cpp_adapters_match_oracle(tmp_path):
     assert int(get("dist", np.int32)[0]) == int(np.unpackbits(d0[0] ^ d0[valid][0]).sum())
     # ---- Optimizer::PoseOptimization
     ro, pe, oe_, se = O.pose_optimization(pp)
+    # ---- the reference-typed members (ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, ...), Optimizer::PoseOptimization(Frame*)),
+    # driven with mock objects filled from the same files: what they leave in the objects must equal what the view-taking adapters returned
+    ref = subprocess.run([_build(tmp_path, "reference_members_check.cc", mock_ref=True), str(d), "tracking"], capture_output=True, text=True, timeout=300)
+    assert ref.returncode == 0 and "reference members (tracking) ok" in ref.stdout, ref.stdout + ref.stderr
+    getr = lambda name, dt: np.fromfile(str(d / ("out_ref_" + name + ".bin")), dtype=dt)
+    for name, dt in (("sbp_n", np.int32), ("sbp_match", np.int32), ("dist", np.int32), ("po_nin", np.int32), ("po_outlier", np.uint8)):
+        np.testing.assert_array_equal(getr(name, dt), get(name, dt), err_msg=name)
+    assert getr("po_pose", np.float32).tobytes() == get("po_pose", np.float32).tobytes()
     assert int(get("po_nin", np.int32)[0]) == ro
     assert np.abs(get("po_pose", np.float32) - pe).max() <= 1e-4
     np.testing.assert_array_equal(get("po_outlier", np.uint8), oe_)

@@ -139,6 +139,25 @@ def test_cpp_matcher_adapter_matches_oracle(batch, tmp_path):
     out = subprocess.run([_build(tmp_path, "matcher_adapters_check.cc"), str(d)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "matcher adapters ok" in out.stdout, out.stdout + out.stderr
 
+    # ---- the reference's own signatures (SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&), ...) driven with mock Frame / KeyFrame / MapPoint
+    # objects filled from the same files (tests/native/reference_members_check.cc): the tables they leave in the objects must equal the
+    # view-taking adapters' (compared with the oracle below)
+    ref = subprocess.run([_build(tmp_path, "reference_members_check.cc", mock_ref=True), str(d), "matcher"], capture_output=True, text=True, timeout=600)
+    assert ref.returncode == 0 and "reference members (matcher) ok" in ref.stdout, ref.stdout + ref.stderr
+    getr = lambda name, dt: np.fromfile(str(d / ("out_ref_" + name + ".bin")), dtype=dt)
+    for name in ("last_n", "last_match", "kfp_n", "kfp_match", "bow_n", "bow_match", "bowkk_n", "bowkk_match", "ini_n", "ini_match", "tri_n", "tri_pairs",
+                 "sim3p_n", "sim3p_match", "sim3k_n", "sim3k_match", "s3_n", "s3_match"):
+        np.testing.assert_array_equal(getr(name, np.int32), get(name, np.int32), err_msg="reference-typed member: " + name)
+    assert getr("ini_prev", np.float32).tobytes() == get("ini_prev", np.float32).tobytes()
+    for tag in ("fuse", "fuse3"):   # Fuse writes into the keyframe: feature f ends up holding the first point whose best feature is f
+        idx = get(tag + "_idx", np.int32)
+        slots = np.full(len(kl), -1, np.int32)
+        for i in range(len(idx) - 1, -1, -1):
+            if idx[i] >= 0:
+                slots[idx[i]] = i
+        np.testing.assert_array_equal(getr(tag + "_slots", np.int32), slots, err_msg=tag)
+        assert int(getr(tag + "_n", np.int32)[0]) == int(get(tag + "_n", np.int32)[0])
+
     # ---- expectations from the oracle
     Fo4 = O.make_frame(P, kc, dc, curUR)
     r, me = O.search_by_projection_last(Fo4, curBlk, Tcw.astype(np.float32), kl, lastValid, X, dl, lastObs, 7.0, 0, 0, True)

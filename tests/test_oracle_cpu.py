@@ -606,12 +606,25 @@ def test_orb_pattern_table_matches_the_reference():
     assert fresh == open(os.path.join(ROOT, "morb_slam_amd", "csrc", "orb_pattern.inc")).read()
 
 
-def test_reference_glue_parses():
-    """include/morb/reference_glue.h (the Frame& / KeyFrame* forms of the matcher and optimiser calls) can only be built for real
-    inside the reference tree; here it is parsed and type-checked against mock declarations of the reference members it touches
-    (tests/native/mock_ref — names and types only), so a typo or a wrong view field fails on CPU."""
+def test_reference_call_sites_compile_unchanged():
+    """The reference-typed members of include/morb/ORBmatcher.h / Optimizer.h (member templates with the reference's own signatures) can only be
+    built for real inside the reference tree.  Here the call expressions of src/Tracking.cc, src/LocalMapping.cc and src/LoopClosing.cc, pasted
+    verbatim into tests/native/call_sites_check.cc, are compiled (to an object, so that every member is instantiated) against mock declarations of
+    the reference classes (tests/native/mock_ref): all 13 ORBmatcher methods and the five Optimizer entry points must be instantiated."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(root, "tests", "native", "mock_ref"), "-I" + os.path.join(root, "include", "morb"),
-                        "-I" + os.path.join(root, "include"), "-I/opt/rocm/include", os.path.join(root, "tests", "native", "glue_syntax_check.cc")],
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-3000:]
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        obj = os.path.join(td, "cs.o")
+        r = subprocess.run(["g++", "-std=c++17", "-Wall", "-c", "-o", obj, "-I" + os.path.join(root, "tests", "native", "mock_ref"),
+                            "-I" + os.path.join(root, "include", "morb"), "-I" + os.path.join(root, "include"), "-I/opt/rocm/include",
+                            os.path.join(root, "tests", "native", "call_sites_check.cc")], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        syms = subprocess.run(["nm", "-C", obj], capture_output=True, text=True, check=True).stdout
+    for want in ("ORBmatcher::SearchByProjection<ORB_SLAM3::Frame, ORB_SLAM3::MapPoint>", "ORBmatcher::SearchByProjection<ORB_SLAM3::Frame>(",
+                 "ORBmatcher::SearchByProjection<ORB_SLAM3::Frame, ORB_SLAM3::KeyFrame, ORB_SLAM3::MapPoint>", "ORBmatcher::sim3_projection_ref<",
+                 "ORBmatcher::SearchByBoW<ORB_SLAM3::KeyFrame, ORB_SLAM3::Frame, ORB_SLAM3::MapPoint", "ORBmatcher::SearchByBoW<ORB_SLAM3::KeyFrame, ORB_SLAM3::MapPoint>",
+                 "ORBmatcher::SearchForInitialization<", "ORBmatcher::SearchForTriangulation<", "ORBmatcher::SearchBySim3<",
+                 "ORBmatcher::Fuse<ORB_SLAM3::KeyFrame, ORB_SLAM3::MapPoint>", "ORBmatcher::Fuse<ORB_SLAM3::KeyFrame, Sophus::Sim3f, ORB_SLAM3::MapPoint>",
+                 "ORBmatcher::DescriptorDistance<cv::Mat", "Optimizer::PoseOptimization<ORB_SLAM3::Frame>", "Optimizer::LocalBundleAdjustment<ORB_SLAM3::KeyFrame",
+                 "Optimizer::PoseInertialOptimizationLastKeyFrame<", "Optimizer::PoseInertialOptimizationLastFrame<", "Optimizer::LocalInertialBA<ORB_SLAM3::KeyFrame"):
+        assert want in syms, want
