@@ -425,7 +425,7 @@ extern "C" int morb_fast_timing(unsigned long long* out, int reset) {   // phase
 __global__ __launch_bounds__(64 * QT_MAX_WAVES) void k_distribute(const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ cand,
                                                    const int* __restrict__ candCnt, int totalCells, int cellCap,
                                                    uint32_t* __restrict__ qtScratch, uint32_t* __restrict__ sel,
-                                                   int* __restrict__ selCnt, int selPerImg, int nlevels, int groupBase) {
+                                                   int* __restrict__ selCnt, int selPerImg, int nlevels, int groupBase, int* __restrict__ status) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int img = blockIdx.x, lane = threadIdx.x & 63;
   __shared__ int teamSh[32];
@@ -483,7 +483,14 @@ __global__ __launch_bounds__(64 * QT_MAX_WAVES) void k_distribute(const LevelGeo
     if (lane == 0) { cellOff[ncell] = running; teamSh[11] = running; }
   }
   QT_TEAM_SYNC(tm);
-  const int T = tm.nw > 1 ? teamSh[11] : running;
+  int T = tm.nw > 1 ? teamSh[11] : running;
+  // the quadtree keeps a node's four child counts in 16 bits each (quadtree.h: Work::bcnt): a level with 65536 or more candidates (white noise
+  // at 1080p; ~40 k at 752 x 480) could overflow them and mis-sort silently.  Such a level is cut to 65535 candidates to stay memory-safe and
+  // the call is marked failed: morb_extract returns MORB_ERR_UNSUPPORTED, morb_extractor_status reports it for the batched form.
+  if (T > 65535) {
+    if (lane == 0 && tm.tw == 0) atomicOr(status, 1);
+    T = 65535;
+  }
   DMARK(8);
 
   const uint32_t* cbase = cand + ((size_t)img * totalCells + g.cellBase) * (size_t)cellCap;
@@ -1242,7 +1249,23 @@ int morb_extractor_create(morb_extractor** out, int nfeatures, float scaleFactor
     delete e;
     return MORB_ERR_HIP;
   }
+  // status word the kernels can flag (pinned, device-mapped: the host reads it after a synchronisation without a copy)
+  if (hipHostMalloc(reinterpret_cast<void**>(&e->h_status), sizeof(int), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_status), e->h_status, 0) != hipSuccess) {
+    set_error("cannot allocate the status word");
+    morb_extractor_destroy(e);
+    return MORB_ERR_HIP;
+  }
+  *e->h_status = 0;
   *out = e;
+  return MORB_OK;
+}
+
+int morb_extractor_status(morb_extractor* e, int* flags) {
+  MORB_REQUIRE(e, MORB_ERR_INVALID, "extractor is NULL");
+  const int f = __atomic_exchange_n(e->h_status, 0, __ATOMIC_ACQ_REL);
+  if (flags) *flags = f;
+  if (f & 1) { set_error("a pyramid level held more than 65535 FAST candidates (noise-like image): unsupported, the keypoints of that call are not valid"); return MORB_ERR_UNSUPPORTED; }
   return MORB_OK;
 }
 
@@ -1258,6 +1281,7 @@ void morb_extractor_destroy(morb_extractor* e) {
   if (e->evJoin) (void)hipEventDestroy(e->evJoin);
   if (e->sideStream) (void)hipStreamDestroy(e->sideStream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
+  if (e->h_status) (void)hipHostFree(e->h_status);
   delete e;
 }
 
@@ -1412,12 +1436,12 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   // (which of the two is enqueued first makes no difference: measured both ways)
   if (nimg <= kTeamMaxImages && e->distGroupsTeam > 0)   // few images: latency matters, the big levels are worked by teams of waves
     hipLaunchKernelGGL(k_distribute, dim3(nimg, e->distGroupsTeam), dim3(64 * QT_MAX_WAVES), e->distSmemTeam, st, e->d_geomTeam, e->d_cand, e->d_candCnt,
-                       e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L, 0);
+                       e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L, 0, e->d_status);
   else
     // (one launch per bin of levels, each with its own LDS size — all bins of one launch get the largest bin's — measured: the launches
     // follow each other on the stream, 128 -> 204 us per 128 images, 420 -> 435 per 512)
     hipLaunchKernelGGL(k_distribute, dim3(nimg, e->distGroups), dim3(64 * e->distWaves), e->distSmem, st, e->d_geom, e->d_cand, e->d_candCnt,
-                       e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L, 0);
+                       e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L, 0, e->d_status);
   hipStream_t sideStream = e->sideStream;
   MORB_HIP_CHECK(hipStreamWaitEvent(sideStream, e->evFork, 0));
   if (evs) (void)hipEventRecord(evs[6], sideStream);
@@ -1489,6 +1513,7 @@ int morb_extract(morb_extractor* e, const uint8_t* image, int width, int height,
   MORB_HIP_CHECK(hipMemcpyAsync(hkps, e->d_kps1, sizeof(morb_keypoint) * (size_t)maxk, hipMemcpyDeviceToHost, e->stream));
   MORB_HIP_CHECK(hipMemcpyAsync(hdesc, e->d_desc1, 32 * (size_t)maxk, hipMemcpyDeviceToHost, e->stream));
   MORB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  if ((rc = morb_extractor_status(e, nullptr)) != MORB_OK) { *n = 0; return rc; }
   const int cnt = hcnt[0], mono = hcnt[1];
   *n = cnt;
   MORB_REQUIRE(cnt <= cap, MORB_ERR_CAPACITY, "keypoint buffer too small");

@@ -116,6 +116,7 @@ struct morb_extractor {
   uint8_t *d_pyr = nullptr, *d_blur = nullptr;
   uint32_t *d_cand = nullptr, *d_qt = nullptr, *d_sel = nullptr;
   int *d_candCnt = nullptr, *d_selCnt = nullptr,  *d_lap = nullptr;
+  int *h_status = nullptr, *d_status = nullptr;   // pinned, device-mapped flags the kernels can raise (bit 0: a level with > 65535 FAST candidates)
   // staging for the single-image host API
   uint8_t* d_img = nullptr; size_t imgBytes = 0;
   morb_keypoint* d_kps1 = nullptr; uint8_t* d_desc1 = nullptr; int *d_cnt1 = nullptr, *d_mono1 = nullptr;

@@ -112,6 +112,10 @@ class ORBextractor:
         check(self._L.morb_extractor_event_after_fast(self._h, C.byref(ev)))
         return ev.value
 
+    def check_status(self):
+        """Raise if an extraction since the last check was flagged on the device (call after synchronising the batch call's stream)."""
+        check(self._L.morb_extractor_status(self._h, None))
+
     def set_profiling(self, on=True):
         check(self._L.morb_extractor_set_profiling(self._h, 1 if on else 0))
 

@@ -257,3 +257,26 @@ def test_event_after_fast_is_a_live_hip_event():
     s.synchronize()
     torch.cuda.synchronize()
     assert lib().morb_stream_wait_event(s.cuda_stream, None) == -1  # MORB_ERR_INVALID
+
+
+def test_more_than_65535_candidates_in_a_level_fail_loudly():
+    """The quadtree keeps child counts in 16 bits: a level with more candidates (white noise at 1080p: ~200 k) cannot be distributed exactly.
+    It must be refused (MORB_ERR_UNSUPPORTED), not mis-sorted in silence; the VGA noise image (~40 k candidates) stays exact
+    (test_noise_image_many_candidates)."""
+    import torch
+    from morb_slam_amd import ORBextractor
+    from morb_slam_amd.capi import MorbError
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (1080, 1920), dtype=np.uint8)
+    g = ORBextractor(4000, 1.2, 8, 20, 7)
+    with pytest.raises(MorbError) as ei:
+        g(img)
+    assert ei.value.code == -4
+    # the batched form: flagged, reported after the caller synchronised its stream, cleared by the query
+    g.extract_batch(torch.from_numpy(img[None]).cuda())
+    torch.cuda.synchronize()
+    with pytest.raises(MorbError):
+        g.check_status()
+    g.check_status()
+    mono, k, d = g(make_image(1920, 1080, seed=31))      # and the handle keeps working
+    assert len(k) > 3000

@@ -9,7 +9,10 @@ for r in csv.DictReader(open(sys.argv[1])):
 rows.sort()
 # frames start at k_level0; take frame 30 of the device-resident loop
 starts = [i for i, r in enumerate(rows) if r[2] == "k_level0"]
-i0, i1 = starts[30], starts[31]
+if len(starts) < 2:
+    sys.exit(f"{sys.argv[1]}: fewer than two k_level0 launches in the trace ({len(starts)}): nothing to measure")
+f = min(30, len(starts) - 2)   # (frame 30 when the trace is long enough, else the last complete one)
+i0, i1 = starts[f], starts[f + 1]
 fr = rows[i0:i1]
 print(f"kernels {len(fr)}, sum of durations {sum(e - s for s, e, _ in fr) / 1e3:.1f} us, span {(fr[-1][1] - fr[0][0]) / 1e3:.1f} us, frame period {(rows[i1][0] - fr[0][0]) / 1e3:.1f} us")
 prev = fr[0][0]
