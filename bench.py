@@ -468,14 +468,18 @@ def main():
         # (nothing above imports torch.cuda or the HIP library), starts N fresh rank processes and never exec()s.
         sys.exit(launch_ranks(args.gpus))
 
+    # what RCCL needs on this pool (dmabuf IPC), for ranks started by ANY launcher — torchrun included — and before torch initialises HIP
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import datetime
     import torch
+    pg_timeout = datetime.timedelta(seconds=float(os.environ.get("MORB_DIST_TIMEOUT_S", "180")))   # a rank that waits longer for a peer fails (non-zero exit)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.launch_probe:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout)
         t = torch.tensor([1.0, float(rank)], dtype=torch.float64)
         dist.all_reduce(t)
         if rank == 0:
@@ -495,9 +499,9 @@ def main():
         local_rank = local_rank % ndev
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=pg_timeout)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -515,9 +519,7 @@ def main():
     # sampled frames with the oracle.  N GPUs: the previous frame lives on the previous rank -> its left-image features travel one rank
     # up the ring (--exchange ring, RCCL send / recv) or are all-gathered (--exchange allgather, north_star's wording) once per step.
     NSET = 1 if args.no_pipeline else max(2, args.sets)
-    exch = None
-    if world > 1:
-        exch = parallel.NeighbourExchange() if args.exchange == "ring" else parallel.FeatureExchange()
+    exch = args.exchange if world > 1 else None
     fe = StereoFrontEnd(images, NFEAT, B, device=local_rank, rank=rank, world=world, nset=NSET, extract_streams=args.extract_streams,
                         matchers=args.matchers, vocab=(10, 6, 4), exchange=exch)
     exts, sets, estreams, matcher, cap, mbf, mb = fe.exts, fe.sets, fe.estreams, fe.matcher, fe.cap, fe.mbf, fe.mb
@@ -730,7 +732,8 @@ def main():
             "config": {"workload": wl + ": ORBextractor x2 + ComputeStereoMatches + ComputeBoW (synthetic k=10 L=6 vocabulary) + "
                                    "SearchByBoW vs previous frame",
                        "stereo_frames_per_step_per_gpu": B, "steps_in_flight": NSET, "extract_streams": len(set(id(x) for x in estreams)), "parallelism": f"frames dealt round-robin over {world} GPU(s)" + ("" if world == 1 else
-                                       "; per step one RCCL send/recv of the left-image keypoints/descriptors/BoW ids to the next rank (ring)"),
+                                       ("; per step one RCCL send/recv of the left-image feature slab (keypoints | descriptors | BoW ids | counts) to the next rank (ring)"
+                                                                                    if args.exchange == "ring" else "; per step an RCCL all-gather of every rank's left-image features")),
                        "stages_in_step": ["extract_left+right", "stereo_match", "bow_transform"] + (["feature_exchange"] if world > 1 else []) + ["search_by_bow"],
                        "mean_keypoints_per_image": float(cnt.mean()), "mean_stereo_matches_per_frame": n_stereo,
                        "mean_bow_matches_per_frame": n_bow},

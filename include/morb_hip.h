@@ -121,6 +121,19 @@ int morb_matcher_sync(morb_matcher*);
 /* The matcher's own stream (hipStream_t): a host adapter queues its uploads / downloads there instead of on the null stream. */
 void* morb_matcher_stream(const morb_matcher*);
 
+/* Feature slabs — the unit one GPU ships to another (no counterpart in the single-process reference; north_star's frame sharding).
+ * A frame matched against its predecessor (SearchByBoW / SearchByProjection(Cur, Last)) needs the predecessor's keypoints, descriptors and
+ * BoW node ids; with frames dealt round-robin over GPUs they live on the previous GPU.  pack gathers S rows of the [nimg][cap] feature arrays
+ * (row d_rows[f], or row f when d_rows is NULL — e.g. the left images 0, 2, 4, ...) into ONE contiguous buffer of morb_feature_slab_bytes(S, cap)
+ * bytes: [S][cap] keypoints | [S][cap][32] descriptors | [S][cap] node ids (-1 when d_node is NULL) | [S] counts.  The caller moves that one
+ * buffer (hipMemcpyPeerAsync over xGMI, or an RCCL send / recv) and unpack scatters it into rows d_rows[f] of the receiver's pool.  All
+ * pointers are DEVICE pointers; asynchronous on `stream`.  INTEGRATION.md section 5 shows the sharding loop of a C++ Tracking. */
+size_t morb_feature_slab_bytes(int S, int cap);
+int morb_feature_slab_pack(morb_matcher*, int S, int cap, const int* d_rows, const morb_keypoint* d_kps, const uint8_t* d_desc, const int* d_node,
+                           const int* d_count, void* d_slab, void* stream);
+int morb_feature_slab_unpack(morb_matcher*, int S, int cap, const void* d_slab, const int* d_rows, morb_keypoint* d_kps, uint8_t* d_desc, int* d_node,
+                             int* d_count, void* stream);
+
 /* static int ORBmatcher::DescriptorDistance(a, b)  ORBmatcher.h:43, ORBmatcher.cc:1880-1894; n pairs of 32-byte
  * descriptors -> n distances. */
 int morb_hamming_pairs(morb_matcher*, const uint8_t* d_a, const uint8_t* d_b, int n, int* d_out, void* stream);

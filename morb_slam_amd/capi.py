@@ -106,6 +106,10 @@ def lib():
         L.morb_matcher_stream.argtypes = [vp]
         L.morb_matcher_stream.restype = vp
         L.morb_hamming_pairs.argtypes = [vp, vp, vp, i, vp, vp]
+        L.morb_feature_slab_bytes.argtypes = [i, i]
+        L.morb_feature_slab_bytes.restype = sz
+        L.morb_feature_slab_pack.argtypes = [vp, i, i, vp, vp, vp, vp, vp, vp, vp]
+        L.morb_feature_slab_unpack.argtypes = [vp, i, i, vp, vp, vp, vp, vp, vp, vp]
         L.morb_hamming_knn2_batch.argtypes = [vp, i, vp, vp, i, vp, vp, vp, i, vp, vp, vp, vp]
         L.morb_stereo_match_batch.argtypes = [vp, vp, i, vp, vp, vp, i, f, f, vp, vp, vp]
         L.morb_stereo_fisheye_match_batch.argtypes = [vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp]

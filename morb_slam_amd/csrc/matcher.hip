@@ -1074,6 +1074,51 @@ int morb_bow_sort_images(morb_matcher* m, int nimg, const int* d_node, const int
   return MORB_OK;
 }
 
+// ---- feature slabs: what one GPU ships to another so that a frame can be matched against its predecessor ----
+// slab of S frames, capacity cap: [S][cap] keypoint records (28 B) | [S][cap][32] descriptors | [S][cap] BoW node ids (int32) | [S] counts (int32)
+size_t morb_feature_slab_bytes(int S, int cap) {
+  if (S <= 0 || cap <= 0) return 0;
+  return (size_t)S * cap * (sizeof(morb_keypoint) + 32 + sizeof(int)) + (size_t)S * sizeof(int);
+}
+namespace {
+// one workgroup per (frame, array): 32-bit words, coalesced; dir 0 = pool rows -> slab, 1 = slab -> pool rows
+__global__ __launch_bounds__(256) void k_slab_copy(int S, int cap, const int* __restrict__ rowIdx, uint32_t* kps, uint32_t* desc, uint32_t* node, int* count,
+                                                   uint32_t* slab, int dir) {
+  const int f = blockIdx.x, which = blockIdx.y;
+  const int row = rowIdx ? rowIdx[f] : f;
+  const size_t wK = (size_t)cap * 7, wD = (size_t)cap * 8, wN = (size_t)cap;
+  uint32_t* sK = slab; uint32_t* sD = sK + (size_t)S * wK; uint32_t* sN = sD + (size_t)S * wD; uint32_t* sC = sN + (size_t)S * wN;
+  uint32_t *a, *b; size_t n;
+  if (which == 0) { a = kps + (size_t)row * wK; b = sK + (size_t)f * wK; n = wK; }
+  else if (which == 1) { a = desc + (size_t)row * wD; b = sD + (size_t)f * wD; n = wD; }
+  else { a = node ? node + (size_t)row * wN : nullptr; b = sN + (size_t)f * wN; n = wN; }
+  if (which == 2 && threadIdx.x == 0) { if (dir == 0) sC[f] = (uint32_t)count[row]; else count[row] = (int)sC[f]; }
+  if (!a) { if (dir == 0) for (size_t i = threadIdx.x; i < n; i += 256) b[i] = 0xFFFFFFFFu; return; }
+  if (dir == 0) for (size_t i = threadIdx.x; i < n; i += 256) b[i] = a[i];
+  else for (size_t i = threadIdx.x; i < n; i += 256) a[i] = b[i];
+}
+}  // namespace
+int morb_feature_slab_pack(morb_matcher* m, int S, int cap, const int* d_rows, const morb_keypoint* d_kps, const uint8_t* d_desc, const int* d_node,
+                           const int* d_count, void* d_slab, void* stream) {
+  MORB_REQUIRE(m && S > 0 && cap > 0 && d_kps && d_desc && d_count && d_slab, MORB_ERR_INVALID, "bad argument");
+  MORB_HIP_CHECK(hipSetDevice(m->device));
+  hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+  hipLaunchKernelGGL(k_slab_copy, dim3(S, 3), dim3(256), 0, st, S, cap, d_rows, (uint32_t*)d_kps, (uint32_t*)d_desc, (uint32_t*)d_node, (int*)d_count,
+                     (uint32_t*)d_slab, 0);
+  MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}
+int morb_feature_slab_unpack(morb_matcher* m, int S, int cap, const void* d_slab, const int* d_rows, morb_keypoint* d_kps, uint8_t* d_desc, int* d_node,
+                             int* d_count, void* stream) {
+  MORB_REQUIRE(m && S > 0 && cap > 0 && d_kps && d_desc && d_count && d_slab, MORB_ERR_INVALID, "bad argument");
+  MORB_HIP_CHECK(hipSetDevice(m->device));
+  hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+  hipLaunchKernelGGL(k_slab_copy, dim3(S, 3), dim3(256), 0, st, S, cap, d_rows, (uint32_t*)d_kps, (uint32_t*)d_desc, (uint32_t*)d_node, d_count,
+                     (uint32_t*)const_cast<void*>(d_slab), 1);
+  MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}
+
 int morb_hamming_pairs(morb_matcher* m, const uint8_t* d_a, const uint8_t* d_b, int n, int* d_out, void* stream) {
   MORB_REQUIRE(m && d_a && d_b && d_out && n >= 0, MORB_ERR_INVALID, "bad argument");
   MORB_HIP_CHECK(hipSetDevice(m->device));

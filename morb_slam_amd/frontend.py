@@ -39,7 +39,8 @@ class StereoFrontEnd:
                  vocab=(10, 6, 4), voc_seed=0, has_mp_seed=7, exchange=None, mbf=458.654 * 0.11, mb=0.11):
         """images: uint8 device tensor [2 B, H, W], image 2 f = left, 2 f + 1 = right of local frame f.
         vocab = (k, L, levelsup) of the synthetic complete k-ary vocabulary (ORBvoc.txt's shape is 10 / 6 / 4; the file is a missing blob).
-        exchange: None (one rank: the predecessor is local), or a parallel.NeighbourExchange / FeatureExchange."""
+        exchange: None (one rank: the predecessor is local), "ring" (each rank ships its left-image features to rank + 1 as one slab,
+        parallel.NeighbourExchange), "allgather" (every rank's slabs pooled, parallel.FeatureExchange — north_star's wording), or an instance."""
         import torch
         from .synth import make_vocabulary
         self.torch = torch
@@ -65,6 +66,10 @@ class StereoFrontEnd:
         self.vd, self.vf = torch.from_numpy(vd).to(dev), torch.from_numpy(vf).to(dev)
         # SearchByBoW pairs: left image of global frame g (as F) against left image of frame g - 1 (as the reference keyframe)
         rng = np.random.default_rng(has_mp_seed)
+        if exchange == "ring":
+            exchange = parallel.NeighbourExchange(matcher=self.bmatcher)
+        elif exchange == "allgather":
+            exchange = parallel.FeatureExchange()
         self.exch = exchange
         if exchange is None:
             kf = np.array([2 * max(f - 1, 0) for f in range(B)], np.int32)
@@ -81,6 +86,7 @@ class StereoFrontEnd:
         self.has_mp = torch.from_numpy(self.has_mp_host).to(dev)
         self.left_mask = torch.zeros((2 * B,), dtype=torch.int32, device=dev)
         self.left_mask[0::2] = 1
+        self.left_rows = torch.arange(0, 2 * B, 2, dtype=torch.int32, device=dev)
         self.sets = [BufferSet(B, cap, dev) for _ in range(NSET)]
         self.nstep = 0
         self.lag_matchers = matchers == "under-quadtree" and NSET >= 2
@@ -146,7 +152,10 @@ class StereoFrontEnd:
             S.pool = (kps, desc, S.cnt_left, S.bow_out[1])
         else:
             with torch.cuda.stream(bstream):      # the transfer is ordered after the kernels on this stream
-                pk, pd, pc, pn = self.exch.exchange(kps[0::2], desc[0::2], cnt[0::2], S.bow_out[1][0::2])   # left images only
+                if getattr(self.exch, "matcher", None) is not None:   # left images only, gathered into ONE slab by morb_feature_slab_pack
+                    pk, pd, pc, pn = self.exch.exchange(kps, desc, cnt, S.bow_out[1], rows=self.left_rows)
+                else:
+                    pk, pd, pc, pn = self.exch.exchange(kps[0::2], desc[0::2], cnt[0::2], S.bow_out[1][0::2])
             S.pool = (pk, pd, pc, pn)
         pk, pd, pc, pn = S.pool
         S.match_out = self.bmatcher.SearchByBoW(self.kf_img, self.f_img, pk, pd, pn, pc, self.has_mp, out=S.match_out, stream=bs)

@@ -48,6 +48,26 @@ class ORBmatcher:
                                               train.shape[1], ptr(toff), ptr(idx), ptr(dist), self._st(stream)))
         return idx, dist
 
+    def slab_bytes(self, S, cap):
+        return int(self._L.morb_feature_slab_bytes(S, cap))
+
+    def pack_slab(self, kps, desc, count, node=None, rows=None, out=None, stream=None):
+        """morb_feature_slab_pack: rows `rows` (int32 device tensor, None = all) of the [nimg, cap] feature arrays -> ONE contiguous uint8 slab."""
+        import torch
+        cap = kps.shape[1]
+        S = int(rows.shape[0]) if rows is not None else kps.shape[0]
+        nb = self.slab_bytes(S, cap)
+        if out is None or out.numel() != nb:
+            out = torch.empty((nb,), dtype=torch.uint8, device=kps.device)
+        check(self._L.morb_feature_slab_pack(self._h, S, cap, ptr(rows), ptr(kps), ptr(desc), ptr(node), ptr(count), ptr(out), self._st(stream)))
+        return out
+
+    def unpack_slab(self, slab, S, kps, desc, count, node=None, rows=None, stream=None):
+        """morb_feature_slab_unpack: the slab's S frames -> rows `rows` (None = 0 .. S-1) of the receiver's [nimg, cap] arrays (in place)."""
+        cap = kps.shape[1]
+        assert slab.numel() == self.slab_bytes(S, cap)
+        check(self._L.morb_feature_slab_unpack(self._h, S, cap, ptr(slab), ptr(rows), ptr(kps), ptr(desc), ptr(node), ptr(count), self._st(stream)))
+
     def ComputeStereoMatches(self, extractor, kps, desc, count, mbf, mb, out=None, stream=None):
         """Frame::ComputeStereoMatches for nframes = nimg/2 frames (left = image 2f, right = 2f+1 of the batch the
         extractor just processed).  Returns (mvuRight, mvDepth) float32 [nframes, cap]."""

@@ -105,13 +105,59 @@ class NeighbourExchange:
     [own; received] per array (2 S rows).  nccl (RCCL): batched isend / irecv on the current stream, device to device over
     xGMI.  gloo (tests, or ranks sharing a GPU): staged through host memory."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, matcher=None):
+        """matcher: an ORBmatcher — the slabs then travel as ONE contiguous buffer per step (morb_feature_slab_pack / _unpack of the C ABI:
+        one transfer per xGMI link instead of four, and the form a C++ caller ships with hipMemcpyPeerAsync); None: one transfer per array."""
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._pool = {}
+        self.matcher = matcher
+        self._slab = {}
+
+    def _send_recv(self, send, recv):
+        """One ring step for one pair of equally sized tensors: send to rank + 1, receive from rank - 1."""
+        nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
+        if self.dist.get_backend(self.group) == "nccl":
+            for w in self.dist.batch_isend_irecv([self.dist.P2POp(self.dist.isend, send, nxt, self.group),
+                                                  self.dist.P2POp(self.dist.irecv, recv, prv, self.group)]):
+                w.wait()
+        else:   # gloo (tests, ranks sharing a GPU): staged through host memory
+            src = send.cpu()
+            dst = src.new_empty(src.shape)
+            reqs = [self.dist.isend(src, nxt, group=self.group), self.dist.irecv(dst, prv, group=self.group)]
+            for r in reqs:
+                r.wait()
+            recv.copy_(dst)
+
+    def _exchange_slab(self, kps, desc, count, node, rows=None):
+        import torch
+        cap = kps.shape[1]
+        if rows is None:
+            kps, desc, count = kps.contiguous(), desc.contiguous(), count.contiguous()
+            node = None if node is None else node.contiguous()
+        S = kps.shape[0] if rows is None else int(rows.shape[0])
+        key = (S, cap, kps.device, node is not None)
+        st = self._slab.get(key)
+        if st is None:
+            nb = self.matcher.slab_bytes(S, cap)
+            mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=kps.device)
+            st = dict(send=mk((nb,), torch.uint8), recv=mk((nb,), torch.uint8), kps=mk((2 * S, cap, 28), torch.uint8), desc=mk((2 * S, cap, 32), torch.uint8),
+                      count=mk((2 * S,), torch.int32), node=mk((2 * S, cap), torch.int32) if node is not None else None,
+                      rows=torch.arange(S, 2 * S, dtype=torch.int32, device=kps.device), own=torch.arange(0, S, dtype=torch.int32, device=kps.device))
+            self._slab[key] = st
+        cs = torch.cuda.current_stream(kps.device).cuda_stream
+        # rows `rows` of the caller's arrays (e.g. the left images 0, 2, 4, ...) -> the send slab; the same slab also fills the pool's own half
+        self.matcher.pack_slab(kps, desc, count, node, rows=rows, out=st["send"], stream=cs)
+        self.matcher.unpack_slab(st["send"], S, st["kps"], st["desc"], st["count"], st["node"], rows=st["own"], stream=cs)
+        if self.world == 1:
+            st["recv"].copy_(st["send"])
+        else:
+            self._send_recv(st["send"], st["recv"])
+        self.matcher.unpack_slab(st["recv"], S, st["kps"], st["desc"], st["count"], st["node"], rows=st["rows"], stream=cs)
+        return st["kps"], st["desc"], st["count"], st["node"]
 
     def _shift(self, named):
         import torch
@@ -151,9 +197,12 @@ class NeighbourExchange:
                 pool[S:].copy_(dst)
         return pools
 
-    def exchange(self, kps, desc, count, node=None):
+    def exchange(self, kps, desc, count, node=None, rows=None):
         """kps [S, cap, 28] u8, desc [S, cap, 32] u8, count [S] i32, node [S, cap] i32 -> pools of 2 S rows: own slab, then
-        the previous rank's."""
+        the previous rank's.  rows (int32 device tensor, slab path only): ship these rows of larger arrays instead of all of them."""
+        if self.matcher is not None and kps.is_cuda:
+            return self._exchange_slab(kps, desc, count, node, rows)
+        assert rows is None, "rows= needs the slab path (NeighbourExchange(matcher=...))"
         named = [("kps", kps), ("desc", desc), ("count", count)] + ([] if node is None else [("node", node)])
         out = self._shift(named)
         return (out[0], out[1], out[2], out[3] if node is not None else None)

@@ -1,6 +1,9 @@
 """Worker of tests/test_parallel_gpu.py: one rank of a `world`-rank run of the frame-sharded front end on a small synthetic stream
-(extract -> ComputeBoW -> ring exchange -> SearchByBoW against the previous frame).  Writes, per LOCAL frame, its global id and
-its SearchByBoW match table to <out>/rank<r>.npz.  Ranks may share one GPU (MORB_DIST_BACKEND=gloo)."""
+(extract -> ComputeBoW -> feature exchange -> SearchByBoW against the previous frame).  Writes, per LOCAL frame, its global id and
+its SearchByBoW match table to <out>/rank<r>.npz.  Ranks may share one GPU (MORB_DIST_BACKEND=gloo).
+    dist_stream_worker.py <out> <total frames> [width height nfeat] [ring|ring4|allgather]
+ring = one slab per step (morb_feature_slab_pack / _unpack), ring4 = one transfer per array, allgather = every rank's slabs pooled."""
+import datetime
 import os
 import sys
 
@@ -8,9 +11,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
-def run(rank, world, total, out_dir, width=640, height=480, nfeat=600):
+def run(rank, world, total, out_dir, width=640, height=480, nfeat=600, exchange="ring"):
     import torch
     from morb_slam_amd import ORBextractor, ORBmatcher, parallel
     from morb_slam_amd.synth import make_stereo_pair, make_vocabulary, shift_image
@@ -33,8 +37,15 @@ def run(rank, world, total, out_dir, width=640, height=480, nfeat=600):
         fr = torch.arange(S, dtype=torch.int32, device=dev)
         has = torch.from_numpy(has_all[gids]).to(dev)
         res = m.SearchByBoW(kf, fr, kps, desc, bow[1], cnt, has)
+    elif exchange == "allgather":
+        ex = parallel.FeatureExchange()
+        pk, pd, pc, pn = ex.exchange(kps, desc, cnt, bow[1])
+        kfp, frp = parallel.predecessor_pairs(rank, world, S)
+        pool_gids = [parallel.global_frame(r, world, s) for r in range(world) for s in range(S)]   # rank-major pool rows
+        has = torch.from_numpy(has_all[pool_gids]).to(dev)
+        res = m.SearchByBoW(torch.from_numpy(kfp).to(dev), torch.from_numpy(frp).to(dev), pk, pd, pn, pc, has)
     else:
-        ex = parallel.NeighbourExchange()
+        ex = parallel.NeighbourExchange(matcher=m if exchange == "ring" else None)
         pk, pd, pc, pn = ex.exchange(kps, desc, cnt, bow[1])
         kfp, frp = parallel.neighbour_pairs(rank, world, S)
         prev_gids = [parallel.global_frame((rank - 1) % world, world, s) for s in range(S)]
@@ -47,13 +58,17 @@ def run(rank, world, total, out_dir, width=640, height=480, nfeat=600):
 
 if __name__ == "__main__":
     out_dir, total = sys.argv[1], int(sys.argv[2])
+    dims = [int(x) for x in sys.argv[3:6]] if len(sys.argv) >= 6 else [640, 480, 600]
+    exchange = sys.argv[6] if len(sys.argv) >= 7 else "ring"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("MORB_DIST_BACKEND", "gloo"), rank=rank, world_size=world)
-    run(rank, world, total, out_dir)
+        # a rank whose peer never arrives fails after the timeout (non-zero exit) instead of hanging
+        dist.init_process_group(os.environ.get("MORB_DIST_BACKEND", "gloo"), rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=float(os.environ.get("MORB_DIST_TIMEOUT_S", "180"))))
+    run(rank, world, total, out_dir, *dims, exchange=exchange)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

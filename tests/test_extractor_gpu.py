@@ -273,7 +273,7 @@ def test_more_than_65535_candidates_in_a_level_fail_loudly():
         g(img)
     assert ei.value.code == -4
     # the batched form: flagged, reported after the caller synchronised its stream, cleared by the query
-    g.extract_batch(torch.from_numpy(img[None]).cuda())
+    g.extract_batch(torch.from_numpy(np.stack([img, img])).cuda())
     torch.cuda.synchronize()
     with pytest.raises(MorbError):
         g.check_status()

@@ -17,14 +17,18 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def test_two_ranks_match_one_rank(tmp_path):
-    total = 6
+# 640 x 480 / 600 features / 6 frames through every transport; and BASELINE configs[3]'s size (1920 x 1080 / 4000 features, 4 frames) through the
+# two the bench offers (--exchange ring | allgather): the exchanged 4000-feature slabs must give the tables of the world-1 run
+@pytest.mark.parametrize("dims,total,exchange", [((640, 480, 600), 6, "ring"), ((640, 480, 600), 6, "ring4"), ((640, 480, 600), 6, "allgather"),
+                                                 ((1920, 1080, 4000), 4, "ring"), ((1920, 1080, 4000), 4, "allgather")])
+def test_two_ranks_match_one_rank(tmp_path, dims, total, exchange):
     one, two = tmp_path / "w1", tmp_path / "w2"
     one.mkdir(); two.mkdir()
+    extra = [str(x) for x in dims] + [exchange]
     env = dict(os.environ, WORLD_SIZE="1", RANK="0")
-    subprocess.check_call([sys.executable, os.path.join(HERE, "dist_stream_worker.py"), str(one), str(total)], env=env)
+    subprocess.check_call([sys.executable, os.path.join(HERE, "dist_stream_worker.py"), str(one), str(total)] + extra, env=env)
     port = str(_free_port())
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_stream_worker.py"), str(two), str(total)],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_stream_worker.py"), str(two), str(total)] + extra,
                               env=dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
                                        MORB_DIST_BACKEND="gloo")) for r in range(2)]
     for p in procs:
@@ -84,3 +88,35 @@ def test_bench_matcher_placements_agree():
         got[m] = lines[0]["config"]
     for k in ("mean_keypoints_per_image", "mean_stereo_matches_per_frame", "mean_bow_matches_per_frame"):
         assert got["beside-pyramid"][k] == got["under-quadtree"][k] and got["beside-pyramid"][k] > 0, k
+
+
+def test_a_rank_without_its_peer_times_out_with_a_non_zero_exit(tmp_path):
+    """Every wait on a peer is bounded: a rank whose partner never shows up exits non-zero after the process-group timeout instead of hanging
+    (a fresh child process; nothing re-execs)."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), MORB_DIST_BACKEND="gloo",
+               MORB_DIST_TIMEOUT_S="8")
+    p = subprocess.run([sys.executable, os.path.join(HERE, "dist_stream_worker.py"), str(tmp_path), "4"], env=env, capture_output=True, timeout=300)
+    assert p.returncode != 0
+
+
+def test_feature_slab_round_trip():
+    """morb_feature_slab_pack -> (one contiguous buffer: what hipMemcpyPeerAsync / an RCCL send moves) -> morb_feature_slab_unpack."""
+    import torch
+    from morb_slam_amd import ORBmatcher
+    m = ORBmatcher()
+    rng = np.random.default_rng(0)
+    nimg, cap, S = 10, 333, 5
+    cu = lambda a: torch.from_numpy(a).cuda()
+    kps = cu(rng.integers(0, 256, (nimg, cap, 28), dtype=np.uint8)); desc = cu(rng.integers(0, 256, (nimg, cap, 32), dtype=np.uint8))
+    node = cu(rng.integers(0, 1000, (nimg, cap), dtype=np.int32)); cnt = cu(rng.integers(0, cap, nimg).astype(np.int32))
+    rows = torch.arange(0, nimg, 2, dtype=torch.int32, device="cuda")
+    slab = m.pack_slab(kps, desc, cnt, node, rows=rows)
+    assert slab.numel() == S * cap * 64 + S * 4 == m.slab_bytes(S, cap)
+    k2, d2, n2, c2 = torch.zeros_like(kps), torch.zeros_like(desc), torch.zeros_like(node), torch.zeros_like(cnt)
+    dst = torch.tensor([9, 1, 4, 0, 7], dtype=torch.int32, device="cuda")
+    m.unpack_slab(slab, S, k2, d2, c2, n2, rows=dst)
+    torch.cuda.synchronize()
+    for f in range(S):
+        a, b = int(rows[f]), int(dst[f])
+        assert torch.equal(k2[b], kps[a]) and torch.equal(d2[b], desc[a]) and torch.equal(n2[b], node[a]) and int(c2[b]) == int(cnt[a])
+    assert int(k2[2].sum()) == 0      # rows that are not destinations stay untouched
