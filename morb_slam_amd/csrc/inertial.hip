@@ -452,13 +452,19 @@ __device__ __forceinline__ void apply_update_t(const CamGeom& g, VIState& S, con
 }
 __device__ __forceinline__ void apply_update(const CamGeom& g, VIState& S, const double* x) { if (g.rig) apply_update_t<true>(g, S, x); else apply_update_t<false>(g, S, x); }
 // visual edge: error (obs - projection) and chi2; st = stereo
+// the edge camera's KannalaBrandt8 parameters picked element by element: `g.kb[cam]` with a per-lane index made the compiler copy the whole
+// CamGeom kernel argument to scratch memory to index it (736 B per thread in the rig kernels)
+__device__ __forceinline__ void kb_of(const CamGeom& g, int cam, float (&p)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = cam ? g.kb[1][i] : g.kb[0][i];
+}
 template <bool RIG>
 __device__ __forceinline__ double vis_error_t(const CamGeom& g, const VIState& S, const double* X, const float* o, bool st, double info,
                                               double* err, double* Xc, int cam) {
   if (RIG && cam) { mul3v(S.Rcw1, X, Xc); for (int k = 0; k < 3; ++k) Xc[k] += S.tcw1[k]; }
   else { mul3v(S.Rcw, X, Xc); for (int k = 0; k < 3; ++k) Xc[k] += S.tcw[k]; }
   double u, v;
-  if (RIG) { double uv[2]; morbkb8::kb8_project_d(g.kb[cam], Xc, uv); u = uv[0]; v = uv[1]; }   // KannalaBrandt8::project(Vector3d)
+  if (RIG) { double uv[2]; float kp[8]; kb_of(g, cam, kp); morbkb8::kb8_project_d(kp, Xc, uv); u = uv[0]; v = uv[1]; }   // KannalaBrandt8::project(Vector3d)
   else { u = g.fx * Xc[0] / Xc[2] + g.cx; v = g.fy * Xc[1] / Xc[2] + g.cy; }                       // Pinhole.cpp:38-44
   err[0] = (double)o[0] - u; err[1] = (double)o[1] - v; err[2] = 0;
   double c = err[0] * info * err[0] + err[1] * info * err[1];
@@ -472,7 +478,7 @@ __device__ __forceinline__ double vis_error(const CamGeom& g, const VIState& S, 
 // projectJac of the edge's camera (2 x 3 in pj[0..5]); pinhole: Pinhole.cpp:76-86
 template <bool RIG>
 __device__ __forceinline__ void cam_project_jac_t(const CamGeom& g, const double* Xc, int cam, double* pj) {
-  if (RIG) { morbkb8::kb8_project_jac(g.kb[cam], Xc, pj); return; }
+  if (RIG) { float kp[8]; kb_of(g, cam, kp); morbkb8::kb8_project_jac(kp, Xc, pj); return; }
   pj[0] = g.fx / Xc[2]; pj[1] = 0; pj[2] = -g.fx * Xc[0] / (Xc[2] * Xc[2]);
   pj[3] = 0; pj[4] = g.fy / Xc[2]; pj[5] = -g.fy * Xc[1] / (Xc[2] * Xc[2]);
 }
@@ -483,9 +489,14 @@ template <bool RIG>
 __device__ __forceinline__ void vis_jacobian_t(const CamGeom& g, const double* Xc, bool st, double* J /*[3][6]*/, int cam) {   // G2oTypes.cc:361-442
   double Xb[3];
   const bool c1 = RIG && cam;
-  mul3v(c1 ? g.Rbc1 : g.Rbc, Xc, Xb);
-  for (int k = 0; k < 3; ++k) Xb[k] += (c1 ? g.tbc1 : g.tbc)[k];
-  const double* Rcb = c1 ? g.Rcb1 : g.Rcb;
+  // (element-wise selects: a pointer chosen between two members of the kernel-argument struct sends the struct to scratch memory)
+  double Rbc[9], tbc[3], Rcb[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { Rbc[k] = c1 ? g.Rbc1[k] : g.Rbc[k]; Rcb[k] = c1 ? g.Rcb1[k] : g.Rcb[k]; }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) tbc[k] = c1 ? g.tbc1[k] : g.tbc[k];
+  mul3v(Rbc, Xc, Xb);
+  for (int k = 0; k < 3; ++k) Xb[k] += tbc[k];
   double pj[9];
   cam_project_jac_t<RIG>(g, Xc, cam, pj);
   pj[6] = pj[7] = pj[8] = 0;
@@ -824,8 +835,7 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
       }
       __syncthreads();
       IMARK(6);
-      double x[NV];
-      for (int k = 0; k < NV; ++k) x[k] = Wk.x[k];
+      const double* x = Wk.x;   // read from LDS where it is used (a register copy of the 30 unknowns pushed the kernel past 512 VGPRs: 740 B of scratch)
       ok = Wk.flag != 0;
       apply_update_t<RIG>(g, S, x);
       if (LASTFRAME && tid == 0) apply_update_t<RIG>(g, sS1, x + 15);
@@ -844,13 +854,21 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
       const int cam = i >= nL ? 1 : 0;
       const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
       double err[3], Xc[3];
-      const float chi2 = (float)vis_error_t<RIG>(g, outlier[base + i] ? S : Sprev, X, o, st, (double)invSigma2[base + i], err, Xc, cam);
+      // an outlier's error is taken at the current state, an active edge's at the state of the last linearisation (Sprev) — picked element by
+      // element: a reference chosen between the two structs at run time puts both (2 x 360 B) into scratch memory
+      VIState Q;
+      const bool cur = outlier[base + i] != 0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { Q.Rcw[k] = cur ? S.Rcw[k] : Sprev.Rcw[k]; if (RIG) Q.Rcw1[k] = cur ? S.Rcw1[k] : Sprev.Rcw1[k]; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { Q.tcw[k] = cur ? S.tcw[k] : Sprev.tcw[k]; if (RIG) Q.tcw1[k] = cur ? S.tcw1[k] : Sprev.tcw1[k]; }
+      const float chi2 = (float)vis_error_t<RIG>(g, Q, X, o, st, (double)invSigma2[base + i], err, Xc, cam);
       bool isOut;
       if (st) isOut = chi2 > chi2Stereo[it];
       else {
         const bool bClose = closeFlag[base + i] != 0;
-        const double* Rc = cam ? S.Rcw1 : S.Rcw;
-        const bool depthPos = (Rc[6] * X[0] + Rc[7] * X[1] + Rc[8] * X[2] + (cam ? S.tcw1 : S.tcw)[2]) > 0.0;
+        const double r6 = cam ? S.Rcw1[6] : S.Rcw[6], r7 = cam ? S.Rcw1[7] : S.Rcw[7], r8 = cam ? S.Rcw1[8] : S.Rcw[8], tz = cam ? S.tcw1[2] : S.tcw[2];
+        const bool depthPos = (r6 * X[0] + r7 * X[1] + r8 * X[2] + tz) > 0.0;
         isOut = (chi2 > cm && !bClose) || (bClose && chi2 > chi2close) || !depthPos;
       }
       outlier[base + i] = isOut ? 1 : 0;
@@ -1386,14 +1404,18 @@ __global__ __launch_bounds__(256) void k_iba_kf(IbaDev D) {
     const float* o = D.eObs + 3 * (size_t)e;
     const bool st = !D.g.rig && !(o[2] < 0);
     const int cam = D.eRight && D.eRight[e] ? 1 : 0;
-    const double* Rc = cam ? V.Rcw1 : V.Rcw;
+    double Rc[9], tc[3];   // (element-wise selects: a pointer chosen between two members of V sends V to scratch memory)
+#pragma unroll
+    for (int r = 0; r < 9; ++r) Rc[r] = cam ? V.Rcw1[r] : V.Rcw[r];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) tc[r] = cam ? V.tcw1[r] : V.tcw[r];
     const double info = (double)D.eInfo[e];
     const double w = huber_w(st ? deltaStereo : deltaMono, iba_vis_chi2(D, e));
     const double* Xp = D.pts + 3 * (size_t)D.eMP[e];
     const double X[3] = {Xp[0], Xp[1], Xp[2]};
     double Xc[3], Jp[18], Jl[9];
     mul3v(Rc, X, Xc);
-    for (int r = 0; r < 3; ++r) Xc[r] += (cam ? V.tcw1 : V.tcw)[r];
+    for (int r = 0; r < 3; ++r) Xc[r] += tc[r];
     vis_jacobian(D.g, Xc, st, Jp, cam);
     double pj[9];
     cam_project_jac(D.g, Xc, cam, pj);
@@ -1687,9 +1709,9 @@ __global__ __launch_bounds__(256) void k_iba_finish(IbaDev D, uint8_t* __restric
       VIState V;
       iba_load(D.g, D.S + 33 * (size_t)D.eKF[t], V);
       const int cam = D.eRight && D.eRight[t] ? 1 : 0;
-      const double* Rc = cam ? V.Rcw1 : V.Rcw;
+      const double r6 = cam ? V.Rcw1[6] : V.Rcw[6], r7 = cam ? V.Rcw1[7] : V.Rcw[7], r8 = cam ? V.Rcw1[8] : V.Rcw[8], tz = cam ? V.tcw1[2] : V.tcw[2];
       const double* X = D.pts + 3 * (size_t)D.eMP[t];
-      const bool depthPos = (Rc[6] * X[0] + Rc[7] * X[1] + Rc[8] * X[2] + (cam ? V.tcw1 : V.tcw)[2]) > 0.0;
+      const bool depthPos = (r6 * X[0] + r7 * X[1] + r8 * X[2] + tz) > 0.0;
       er = (c > (double)5.991f && !bClose) || (c > (double)(1.5f * 5.991f) && bClose) || !depthPos;
     }
     erase[t] = er ? 1 : 0;

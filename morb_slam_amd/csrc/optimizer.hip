@@ -334,10 +334,12 @@ __device__ __forceinline__ double ba_edge_error(const Cam& cam, const Rig* rig, 
 // Jp (d x 6) and / or Jl (d x 3); R = rotation of the keyframe pose.  OptimizableTypes.cpp:134-156 / :185-208
 // RIG = false: the problem has no fisheye rig.  The KannalaBrandt8 branch (its float libm, the right camera's extrinsics) otherwise costs
 // the pinhole build kernel 100 VGPRs (220 instead of 119) and puts the pose Jacobian into scratch memory — for a branch it never takes.
-template <bool RIG = true>
+template <bool RIG>
 __device__ __forceinline__ void ba_edge_jac(const Cam& cam, const Rig* rig, bool st, const double* xc, const float* o,
                                             const double* R, double* Jp, double* Jl) {
-  if (!RIG || !edge_is_kb8(rig, o)) {
+  // RIG = true: EVERY edge of the problem is a KannalaBrandt8 edge (morb_ba_problem_create_fisheye writes obs[2] = -2 / -3 for all of them),
+  // so the choice is made at compile time: with a run-time `edge_is_kb8` both branches wrote Jp and the array went to scratch memory (160 B)
+  if (!RIG) {
     if (Jp) jac_pose(cam, st, false, xc, Jp);
     if (Jl) jac_point(cam, st, xc, R, Jl);
     return;
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(BA_T) void k_local_ba(const BaDev* __restrict__ pro
         const double c = ba_edge_error(cam, pb.rig, st, xc, o, info, err);
         huber(st ? deltaStereo : deltaMono, c, &w);
         q_to_R(T.q, R);
-        ba_edge_jac(cam, pb.rig, st, xc, o, R, nullptr, Jl);
+        if (pb.rig) ba_edge_jac<true>(cam, pb.rig, st, xc, o, R, nullptr, Jl); else ba_edge_jac<false>(cam, pb.rig, st, xc, o, R, nullptr, Jl);   // (persistent mode: one kernel for both cameras)
         const double wo = w * info;
         for (int r = 0; r < 3; ++r) {
           double s = 0;
@@ -711,7 +713,7 @@ __global__ __launch_bounds__(BA_T) void k_local_ba(const BaDev* __restrict__ pro
         const double info = (double)pb.eInfo[e];
         const double c = ba_edge_error(cam, pb.rig, st, xc, o, info, err);
         huber(st ? deltaStereo : deltaMono, c, &w);
-        ba_edge_jac(cam, pb.rig, st, xc, o, R, Jp, Jl);
+        if (pb.rig) ba_edge_jac<true>(cam, pb.rig, st, xc, o, R, Jp, Jl); else ba_edge_jac<false>(cam, pb.rig, st, xc, o, R, Jp, Jl);
         const double wo = w * info;
         int q = 0;
 #pragma unroll

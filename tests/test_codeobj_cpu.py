@@ -15,7 +15,13 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 HOT = ["k_resize", "k_resize_gather", "k_level0", "k_blur", "k_fastw", "k_distribute", "k_layout", "k_describe",
        "k_stereo_prep", "k_stereo_match", "k_stereo_median", "k_bow_transform", "k_bow_sort", "k_rot_filter",
        "k_pose_opt", "k_g_chi2", "k_g_dinv_push", "k_g_backsub_update_w", "k_g_finish", "k_g_ldlt_lds", "k_g_ldlt_global", "k_iba_solve_blocked", "k_schur_mfma",
-       "k_fe_triangulate", "k_triangulation", "k_frustum", "k_bow_match", "k_knn2", "k_resolve", "k_candidates", "k_best_per_query", "k_hamming_pairs"]
+       "k_fe_triangulate", "k_triangulation", "k_frustum", "k_bow_match", "k_knn2", "k_resolve", "k_candidates", "k_best_per_query", "k_hamming_pairs",
+       # round 4: the KB8-rig build kernel (a compile-time camera choice instead of two branches writing one array), the inertial kernels
+       "k_g_build", "k_imu_preintegrate", "k_iba_setup_links", "k_iba_points", "k_iba_links", "k_iba_solve_lds", "k_iba_update", "k_iba_finish"]
+# kernels that still spill, pinned at what they use today so that a regression shows: the 30-unknown
+# PoseInertialOptimizationLastFrame kernel sits at the 512-register limit (168 B; 740 B before round 4, the 15-unknown LastKeyFrame forms are at 0),
+# two LocalInertialBA phase kernels, and the persistent-workgroup LocalBA mode (not the default)
+BOUNDED = {"k_pose_inertial": 168, "k_iba_errors": 68, "k_iba_kf": 84, "k_local_ba": 560}
 
 
 def _kernel_metadata(lib, tmp):
@@ -46,4 +52,13 @@ def test_hot_kernels_use_no_scratch_memory(tmp_path):
         hits = {k: v for k, v in meta.items() if re.search(r"\d+" + short + r"(I|E)", k)}
         assert hits, f"kernel {short} not found in the code objects"
         for name, scratch in hits.items():
+            assert scratch == 0, f"{name} uses {scratch} bytes of scratch memory per thread"
+    for short, bound in BOUNDED.items():
+        hits = {k: v for k, v in meta.items() if re.search(r"\d+" + short + r"(I|E)", k)}
+        assert hits, f"kernel {short} not found in the code objects"
+        for name, scratch in hits.items():
+            assert scratch <= bound, f"{name} uses {scratch} bytes of scratch memory per thread (pinned at {bound})"
+    # PoseInertialOptimizationLastKeyFrame (LASTFRAME = false), pinhole and rig: no scratch at all
+    for name, scratch in meta.items():
+        if "k_pose_inertialILb0E" in name:
             assert scratch == 0, f"{name} uses {scratch} bytes of scratch memory per thread"
