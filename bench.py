@@ -181,6 +181,20 @@ def optimizer_extras(dev_index):
         out = opt.PoseOptimization(t[0], t[1], t[2], t[3], poses[k], probs[0]["cam"], out=out)
     torch.cuda.synchronize(dev)
     dtp = (time.perf_counter() - t0) / 10
+    # the deterministic mode (morb_optimizer_set_exact_order: sums in edge order, g2o's LM path decision for decision)
+    opt.set_exact_order(True)
+    out = opt.PoseOptimization(t[0], t[1], t[2], t[3], pose0.clone(), probs[0]["cam"], out=out)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(10):
+        poses[k].copy_(pose0)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(10):
+        out = opt.PoseOptimization(t[0], t[1], t[2], t[3], poses[k], probs[0]["cam"], out=out)
+    torch.cuda.synchronize(dev)
+    dtpe = (time.perf_counter() - t0) / 10
+    opt.set_exact_order(False)
     t0 = time.perf_counter()
     for q in probs[:8]:
         O.pose_optimization(q)
@@ -264,7 +278,7 @@ def optimizer_extras(dev_index):
                                       "note": "frac counts the dense product over all landmarks (zero blocks included), useful_frac only the "
                                               "block pairs g2o forms; ~11 us launch, latency-bound"},
                          "large_windows": large},
-            "pose_optimization": {"frames": F, "edges_per_frame": 600, "frames_per_s": F / dtp,
+            "pose_optimization": {"frames": F, "edges_per_frame": 600, "frames_per_s": F / dtp, "frames_per_s_exact_order_mode": F / dtpe,
                                   "cpu_oracle_frames_per_s_1core": 1.0 / dcp}}
 
 

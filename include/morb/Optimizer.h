@@ -258,6 +258,7 @@ class Optimizer {
     Slot& o = slots[device][role];
     std::call_once(o.once, [&] {
       if (morb_optimizer_create(&o.h, device) != MORB_OK) { o.h = nullptr; throw std::runtime_error(std::string("morb_optimizer_create: ") + morb_last_error()); }
+      morb_optimizer_set_exact_order(o.h, 1);   // the drop-in follows g2o's LM path decision for decision (edge-order sums); a frame at a time the cost is latency, not throughput
     });
     if (!o.h) throw std::runtime_error("morb_optimizer_create failed earlier");
     return o;

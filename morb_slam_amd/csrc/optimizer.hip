@@ -377,7 +377,15 @@ __device__ __forceinline__ bool ba_depth_positive(const Rig* rig, const float* o
 // =====================================================================================================
 // PoseOptimization: one workgroup per frame
 // =====================================================================================================
-template <bool FISH>
+// ORDERED: every sum over the edges (the 21 + 6 entries of H and b, the robustified chi2) is taken in EDGE ORDER, one addition after the
+// other, like g2o's sequential loop over its id-sorted active edges (sparse_optimizer.cpp:482-487, block_solver.hpp:502-560) and like the oracle:
+// near convergence rho = dChi2 / scale is ~0 and its sign — an LM decision — follows the last bits of those sums.  A strided partial sum per
+// thread + a tree gives other last bits (observed: one trial more or less in one of nine problems).  Edges are taken 256 at a time: every
+// thread writes its edge's 28 contributions to LDS (an inactive edge: exact zeros, which leave a floating-point sum unchanged), lanes 0 .. 27
+// of wave 0 add their entry's 256 values in order.  A chain of dependent FP64 additions per sum: 1.19 ms instead of 0.44 ms per 256 frames of
+// 600 edges (tools/pose_opt_modes.py) — the deterministic MODE of the optimizer (morb_optimizer_set_exact_order), not its default.
+constexpr int PO_PITCH = 29;   // doubles per edge row of the contribution buffer (28 used)
+template <bool FISH, bool ORDERED>
 __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict__ count, const uint8_t* __restrict__ hasMP,
                                                   const float* __restrict__ obs, const float* __restrict__ invSigma2,
                                                   const float* __restrict__ Xw, Cam cam, Rig rig, const int* __restrict__ nLeft,
@@ -385,6 +393,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict
                                                   int* __restrict__ nInliers, int* __restrict__ stats) {
   __shared__ double red[4];
   __shared__ double sH[4][28];
+  __shared__ double sC[ORDERED ? 256 * PO_PITCH : 1];   // [edge of the chunk][entry]
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = count ? count[f] : cap;
   const size_t base = (size_t)f * cap;
@@ -409,6 +418,39 @@ __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict
   auto chi2Active = [&](const SE3& P) -> double {
     const SE3 Pr = FISH ? se3_mul(rig.Trl, P) : P;
     double s = 0;
+    if (ORDERED) {
+      double tot = 0;
+      for (int c0 = 0; c0 < n; c0 += 256) {
+        const int i = c0 + tid;
+        double c = 0;
+        if (i < n && hasMP[base + i] && !outlier[base + i]) {
+          const float* o = obs + (base + i) * 3;
+          const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
+          double xc[3], err[3], w;
+          bool st;
+          c = pose_edge_error<FISH>(cam, rig, P, Pr, FISH && i >= nL, X, o, (double)invSigma2[base + i], err, st, xc);
+          if (robust) c = huber(st ? deltaStereo : deltaMono, c, &w);
+        }
+        sC[tid] = c;
+        __syncthreads();
+        if (tid == 0) {   // (16 LDS reads in flight, then the 16 additions in order: one read per addition made the chain ~100 cycles per edge)
+          const int m = n - c0 < 256 ? n - c0 : 256;
+          for (int e0 = 0; e0 < m; e0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = sC[e0 + k];                     // (rows beyond m hold an earlier chunk's values: not added)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) if (e0 + k < m) tot += v[k];
+          }
+        }
+        __syncthreads();
+      }
+      if (tid == 0) red[0] = tot;
+      __syncthreads();
+      tot = red[0];
+      __syncthreads();
+      return tot;
+    }
     for (int i = tid; i < n; i += 256) {
       if (!hasMP[base + i] || outlier[base + i]) continue;
       const float* o = obs + (base + i) * 3;
@@ -434,6 +476,64 @@ __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict
       double acc[28];
 #pragma unroll
       for (int k = 0; k < 28; ++k) acc[k] = 0;
+      if (ORDERED) {
+        double tot = 0;   // lanes 0 .. 27 of wave 0: entry `lane` (H upper triangle 0 .. 20, b 21 .. 26, chi2 27)
+        for (int c0 = 0; c0 < n; c0 += 256) {
+          const int i = c0 + tid;
+          double con[28];
+#pragma unroll
+          for (int k = 0; k < 28; ++k) con[k] = 0;
+          if (i < n && hasMP[base + i] && !outlier[base + i]) {
+            const float* o = obs + (base + i) * 3;
+            const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
+            double xc[3], err[3], Jp[18], w = 1.0;
+            bool st;
+            const double info = (double)invSigma2[base + i];
+            const bool right = FISH && i >= nL;
+            double c = pose_edge_error<FISH>(cam, rig, T, Tr, right, X, o, info, err, st, xc);
+            if (robust) c = huber(st ? deltaStereo : deltaMono, c, &w);
+            con[27] = c;
+            pose_edge_jac<FISH>(cam, rig, right, st, xc, Jp);
+            // g2o's own expressions (base_unary_edge.hpp:54-66): omega_r = -Omega e (then * rho'), b += J^T omega_r, H += J^T (rho' Omega) J
+            const double wr[3] = {-info * err[0] * w, -info * err[1] * w, -info * err[2] * w};
+            const double wo = w * info;
+            int q = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+              double bb = 0;
+#pragma unroll
+              for (int k = 0; k < 3; ++k) bb += Jp[k * 6 + r] * wr[k];   // (mono: row 2 and err[2] are zero)
+              con[21 + r] = bb;
+#pragma unroll
+              for (int cc = r; cc < 6; ++cc) {
+                double h = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) h += Jp[k * 6 + r] * wo * Jp[k * 6 + cc];
+                con[q++] = h;
+              }
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 28; ++k) sC[tid * PO_PITCH + k] = con[k];
+          __syncthreads();
+          if (tid < 28) {
+            const int m = n - c0 < 256 ? n - c0 : 256;
+            for (int e0 = 0; e0 < m; e0 += 16) {
+              double v[16];
+#pragma unroll
+              for (int k = 0; k < 16; ++k) v[k] = sC[(e0 + k) * PO_PITCH + tid];
+#pragma unroll
+              for (int k = 0; k < 16; ++k) if (e0 + k < m) tot += v[k];
+            }
+          }
+          __syncthreads();
+        }
+        if (tid < 28) sH[0][tid] = tot;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 28; ++k) acc[k] = sH[0][k];
+        __syncthreads();
+      } else
       for (int i = tid; i < n; i += 256) {
         if (!hasMP[base + i] || outlier[base + i]) continue;
         const float* o = obs + (base + i) * 3;
@@ -463,15 +563,17 @@ __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict
           }
         }
       }
+      if (!ORDERED) {
 #pragma unroll
-      for (int k = 0; k < 28; ++k) acc[k] = wave_sum_d(acc[k]);
-      __syncthreads();
-      if (lane == 0) for (int k = 0; k < 28; ++k) sH[wv][k] = acc[k];
-      __syncthreads();
+        for (int k = 0; k < 28; ++k) acc[k] = wave_sum_d(acc[k]);
+        __syncthreads();
+        if (lane == 0) for (int k = 0; k < 28; ++k) sH[wv][k] = acc[k];
+        __syncthreads();
+      }
       double H[36], b[6];
       {
         double tot[28];
-        for (int k = 0; k < 28; ++k) tot[k] = sH[0][k] + sH[1][k] + sH[2][k] + sH[3][k];
+        for (int k = 0; k < 28; ++k) tot[k] = ORDERED ? acc[k] : sH[0][k] + sH[1][k] + sH[2][k] + sH[3][k];
         int q = 0;
         for (int r = 0; r < 6; ++r) for (int cc = r; cc < 6; ++cc) { H[r * 6 + cc] = tot[q]; H[cc * 6 + r] = tot[q]; ++q; }
         for (int r = 0; r < 6; ++r) b[r] = tot[21 + r];
@@ -1394,6 +1496,7 @@ struct morb_optimizer {
   size_t stageBytes = 0;
   bool arenaCreate = false;    // morb_ba_problem_create carves the problem from `work` / `stage` (the one-shot entry points set this around the call)
   double* scalPinned = nullptr;   // pinned scalars of an arena-mode problem
+  int exactOrder = 0;             // PoseOptimization: 1 = edge-order sums (k_pose_opt<.., ORDERED>), the LM path of g2o decision for decision
 };
 
 struct morb_ba_problem {
@@ -1481,6 +1584,12 @@ int morb_optimizer_staging(morb_optimizer* o, size_t bytes, void** host) {
   return MORB_OK;
 }
 
+int morb_optimizer_set_exact_order(morb_optimizer* o, int on) {
+  MORB_REQUIRE(o, MORB_ERR_INVALID, "NULL optimizer");
+  o->exactOrder = on ? 1 : 0;
+  return MORB_OK;
+}
+
 int morb_optimizer_sync(morb_optimizer* o) {
   MORB_REQUIRE(o, MORB_ERR_INVALID, "NULL optimizer");
   MORB_HIP_CHECK(hipSetDevice(o->device));
@@ -1514,8 +1623,11 @@ int morb_pose_optimization_batch(morb_optimizer* o, int nframes, int cap, const 
   Cam cam{fx, fy, cx, cy, bf};
   Rig rig;
   memset(&rig, 0, sizeof rig);
-  hipLaunchKernelGGL(k_pose_opt<false>, dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
+  if (o->exactOrder) hipLaunchKernelGGL((k_pose_opt<false, true>), dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
                      (const int*)nullptr, d_pose, d_outlier, d_nInliers, d_stats);
+  else hipLaunchKernelGGL((k_pose_opt<false, false>), dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
+                     (const int*)nullptr, d_pose, d_outlier, d_nInliers, d_stats);
+
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
 }
@@ -1540,8 +1652,11 @@ int morb_pose_optimization_fisheye_batch(morb_optimizer* o, int nframes, int cap
     for (int i = 0; i < 4; ++i) rig.Trl.q[i] = q[i] / n;
     for (int i = 0; i < 3; ++i) rig.Trl.t[i] = Trl7[4 + i];
   }
-  hipLaunchKernelGGL(k_pose_opt<true>, dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
+  if (o->exactOrder) hipLaunchKernelGGL((k_pose_opt<true, true>), dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
                      d_nLeft, d_pose, d_outlier, d_nInliers, d_stats);
+  else hipLaunchKernelGGL((k_pose_opt<true, false>), dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
+                     d_nLeft, d_pose, d_outlier, d_nInliers, d_stats);
+
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
 }

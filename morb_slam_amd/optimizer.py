@@ -29,6 +29,10 @@ class Optimizer:
 
     __del__ = close
 
+    def set_exact_order(self, on=True):
+        """PoseOptimization sums in edge order (default: g2o's LM path decision for decision) or as a tree (faster); morb_optimizer_set_exact_order."""
+        check(self._L.morb_optimizer_set_exact_order(self._h, 1 if on else 0))
+
     def PoseOptimization(self, hasMP, obs, invSigma2, Xw, pose, cam, count=None, out=None, stream=None):
         """Batched PoseOptimization.  Device tensors: hasMP u8 [F, cap], obs f32 [F, cap, 3] (x, y, uRight),
         invSigma2 f32 [F, cap], Xw f32 [F, cap, 3], pose f32 [F, 7] (in/out), count i32 [F] or None.

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 POSE_TOL = 1e-4
 
 
-def _run_pose_batch(problems):
+def _run_pose_batch(problems, exact=True):
     import torch
     from morb_slam_amd import Optimizer
     cap = max(len(p["hasMP"]) for p in problems)
@@ -23,6 +23,7 @@ def _run_pose_batch(problems):
         has[f, :n] = p["hasMP"]; obs[f, :n] = p["obs"]; inv[f, :n] = p["invSigma2"]; Xw[f, :n] = p["Xw"]; pose[f] = p["pose0"]
     t = [torch.from_numpy(a).cuda() for a in (has, obs, inv, Xw, pose, cnt)]
     opt = Optimizer()
+    opt.set_exact_order(exact)
     nin, outl, stats = opt.PoseOptimization(t[0], t[1], t[2], t[3], t[4], problems[0]["cam"], count=t[5])
     torch.cuda.synchronize()
     return nin.cpu().numpy(), outl.cpu().numpy(), stats.cpu().numpy(), t[4].cpu().numpy()
@@ -39,10 +40,33 @@ def test_pose_optimization_matches_oracle():
         assert np.abs(pose[f] - pe).max() <= POSE_TOL, (f, pose[f], pe)
         assert nin[f] == r
         np.testing.assert_array_equal(outl[f, :n], oe)
-        # same LM trajectory: the outer iterations are identical; near convergence rho = dChi2 / scale is ~0 and its sign can flip with
-        # the summation order (SURVEY "hard parts" 6), which costs or saves a trial there (observed: 50 vs 49 trials in one of nine problems)
-        assert int(stats[f][0]) == int(se[0]) and abs(int(stats[f][1]) - int(se[1])) <= 2, (stats[f], se)
+        # same LM trajectory, decision for decision: outer iterations AND trials.  Near convergence rho = dChi2 / scale is ~0 and its sign
+        # follows the last bits of the sums over the edges (SURVEY "hard parts" 6): the kernel adds them in edge order like g2o / the oracle
+        # (k_pose_opt<.., ORDERED>: the optimizer's deterministic mode, morb_optimizer_set_exact_order(1)); the default tree sums are checked below
+        assert int(stats[f][0]) == int(se[0]) and int(stats[f][1]) == int(se[1]), (stats[f], se)
         assert np.abs(pose[f] - p["true"]).max() < 0.02   # and it actually converged to the truth
+
+
+def test_pose_optimization_tree_sum_mode():
+    """The default (morb_optimizer_set_exact_order(0)): tree sums — same poses, flags and outer iterations; the trial count may differ by the
+    rare flip of a ~0 rho (observed: 50 vs 49 in one of nine problems)."""
+    import torch
+    from morb_slam_amd import Optimizer
+    probs = [make_pose_problem(600, seed=s) for s in range(6)] + [make_pose_problem(1200, seed=10, outlier_frac=0.3)]
+    cap = max(len(p["hasMP"]) for p in probs)
+    pad = lambda a: np.pad(a, [(0, cap - len(a))] + [(0, 0)] * (a.ndim - 1))
+    t = [torch.from_numpy(np.stack([pad(p[k]) for p in probs])).cuda() for k in ("hasMP", "obs", "invSigma2", "Xw")]
+    pose = torch.from_numpy(np.stack([p["pose0"] for p in probs])).cuda()
+    cnt = torch.tensor([len(p["hasMP"]) for p in probs], dtype=torch.int32, device="cuda")
+    opt = Optimizer()
+    opt.set_exact_order(False)
+    nin, outl, stats = opt.PoseOptimization(t[0], t[1], t[2], t[3], pose, probs[0]["cam"], count=cnt)
+    torch.cuda.synchronize()
+    for f, p in enumerate(probs):
+        r, pe, oe, se = O.pose_optimization(p)
+        assert np.abs(pose[f].cpu().numpy() - pe).max() <= POSE_TOL and int(nin[f]) == r
+        np.testing.assert_array_equal(outl[f, :len(oe)].cpu().numpy(), oe)
+        assert int(stats[f][0]) == int(se[0]) and abs(int(stats[f][1]) - int(se[1])) <= 2
 
 
 def test_pose_optimization_degenerate():
@@ -53,7 +77,7 @@ def test_pose_optimization_degenerate():
     nin, outl, stats, pose = _run_pose_batch([few, eight])
     assert nin[0] == 0 and np.array_equal(pose[0], few["pose0"])
     r, pe, oe, se = O.pose_optimization(eight)
-    assert nin[1] == r and np.abs(pose[1] - pe).max() <= POSE_TOL and abs(int(stats[1][1]) - int(se[1])) <= 2
+    assert nin[1] == r and np.abs(pose[1] - pe).max() <= POSE_TOL and int(stats[1][1]) == int(se[1])
 
 
 @pytest.mark.parametrize("kw", [dict(seed=1), dict(seed=2, n_free=8, n_fixed=3, n_points=500),
