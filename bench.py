@@ -152,6 +152,25 @@ def optimizer_extras(dev_index):
     for _ in range(5):
         local_bundle_adjustment_oneshot(*oargs)
     d1 = (time.perf_counter() - t0) / 5
+    # eight replicas of the same problem solved side by side (eight handles = eight streams, eight host threads: morb_ba_solve blocks its caller
+    # until the last LM decision): LocalBundleAdjustment does not shard ("replicas only"), this is what one GPU sustains
+    from concurrent.futures import ThreadPoolExecutor
+    NREP = 8
+    ropts = [Optimizer(device=dev_index) for _ in range(NREP)]
+    rprobs = [BAProblem(o, b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"], b["eInvSigma2"], b["cam"]) for o in ropts]
+    def rsolve(q):
+        for _ in range(5):
+            q.solve()
+        return q.results()[3]
+    with ThreadPoolExecutor(NREP) as tp:
+        list(tp.map(lambda q: q.solve(), rprobs))
+        t0 = time.perf_counter()
+        rst = list(tp.map(rsolve, rprobs))
+        drep = time.perf_counter() - t0
+    replicas = {"replicas": NREP, "solves_per_replica": 5, "lm_iters_per_s_aggregate": float(sum(int(x[0]) for x in rst) * 5 / drep),
+                "ms_per_solve_per_replica": drep / 5 * 1e3}
+    for q in rprobs:
+        q.close()
     sms, sflops, suseful = p.schur_profile(50)     # the Schur product alone, HIP events on the handle's stream
     # the reference takes every covisible keyframe (Optimizer.cc:1058-1070): windows beyond the LDS-resident LDL^T (global-memory solver)
     large = {}
@@ -277,7 +296,7 @@ def optimizer_extras(dev_index):
                                       "useful_achieved": suseful / (sms * 1e-3) / 1e12, "useful_frac": suseful / (sms * 1e-3) / 1e12 / 78.6,
                                       "note": "frac counts the dense product over all landmarks (zero blocks included), useful_frac only the "
                                               "block pairs g2o forms; ~11 us launch, latency-bound"},
-                         "large_windows": large},
+                         "large_windows": large, "concurrent_replicas": replicas},
             "pose_optimization": {"frames": F, "edges_per_frame": 600, "frames_per_s": F / dtp, "frames_per_s_exact_order_mode": F / dtpe,
                                   "cpu_oracle_frames_per_s_1core": 1.0 / dcp}}
 
