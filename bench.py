@@ -729,7 +729,7 @@ def main():
         # prescribes (profiles/r03/fetch_calib.txt: FETCH_SIZE reads 0.500 x the bytes of coalesced 4 / 8 / 16-byte reads, WRITE_SIZE 1.0 x):
         # traffic = 2 x FETCH_SIZE + WRITE_SIZE
         pm = None
-        for rnd in ("r03",):
+        for rnd in ("r04", "r03"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic_b64.json")))
                 break

@@ -3,15 +3,15 @@
 # command plus separate --pmc passes (HBM traffic: FETCH_SIZE / WRITE_SIZE; issue mix: SQ_*), as the MI355X guide
 # prescribes (counters never combined with sys/runtime traces).  Usage: bash tools/refresh_profiles.sh r01
 set -u
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$R
 rm -rf "$O" && mkdir -p "$O"
-rocprofv3 --kernel-trace --stats -d "$O/stats" -o s --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > "$O/bench_under_rocprof.json" 2>/dev/null
+rocprofv3 --kernel-trace --stats -d "$O/stats" -o s --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-verify --sustained-s 0 > "$O/bench_under_rocprof.json" 2>/dev/null
 for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_LDS_IDX_ACTIVE"; do
   n=$(echo "$p" | cut -c1-12 | tr " " _)
   # counter passes at B = 64 (128 images per launch), un-pipelined: kernels are serialised under --pmc anyway
-  timeout 300 rocprofv3 --pmc $p --kernel-trace -d "$O/pmc/$n" -o q --output-format csv -- python3 bench.py --batch 64 --no-pipeline --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $p --kernel-trace -d "$O/pmc/$n" -o q --output-format csv -- python3 bench.py --batch 64 --no-pipeline --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-verify --sustained-s 0 > /dev/null 2>&1
 done
 python3 tools/pmc_table.py "$O/pmc" > "$O/pmc_issue_table.txt"
 python3 tools/pmc_traffic.py "$O/pmc" 128 > "$O/pmc_traffic_b64.json"
@@ -28,13 +28,17 @@ bash tools/opt_prof.sh optprof_$R > "$O/localba_kernel_stats.txt" 2>/dev/null
 python3 tools/lba_sizes.py > "$O/localba_window_sizes.txt" 2>/dev/null
 # this round's extra evidence: phase counts of k_fastw, stage times alone on the chip, quadtree phases (1 and 256 frames), single-frame latency
 python3 tools/fastw_stats.py 64 > "$O/k_fastw_phase_counts_b64.txt" 2>/dev/null
+python3 tools/fastw_cycles.py 256 2>/dev/null | grep -v amdgpu.ids > "$O/k_fastw_phase_cycles.txt"
+python3 tools/fast_threshold_sweep.py > "$O/k_fastw_threshold_sweep.txt" 2>/dev/null
+python3 tools/pose_opt_modes.py > "$O/pose_optimization_modes.txt" 2>/dev/null
 python3 tools/stage_times.py 64 > "$O/extract_stage_times_isolated.txt" 2>/dev/null; python3 tools/stage_times.py 256 >> "$O/extract_stage_times_isolated.txt" 2>/dev/null
 { echo "== 752 x 480, 1 stereo frame (team packing)"; python3 tools/fast_phases.py 1 | tail -13; echo "== 1920 x 1080 / 4000, 4 stereo frames (team packing)"; MORB_W=1920 MORB_H=1080 MORB_NF=4000 python3 tools/fast_phases.py 4 | tail -13; } > "$O/k_distribute_phases.txt" 2>/dev/null
 python3 tools/latency_b1.py > "$O/latency_b1.txt" 2>/dev/null
 # the other headline shapes: BASELINE configs[3] on one GPU, and the --gpus 2 launcher path (two ranks sharing this GPU, gloo)
-python3 bench.py --workload c4 --no-extras --no-cpu-baseline > "$O/bench_c4.json" 2>/dev/null
-MORB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --batch 64 --steps 10 --no-extras --no-cpu-baseline > "$O/bench_gpus2_gloo_one_gpu.json" 2>/dev/null
-MORB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --workload c4 --steps 10 --no-extras --no-cpu-baseline > "$O/bench_c4_gpus2_gloo_one_gpu.json" 2>/dev/null
+python3 bench.py --workload c4 --no-extras --no-cpu-baseline --sustained-s 0 > "$O/bench_c4.json" 2>/dev/null
+MORB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --batch 64 --steps 10 --no-extras --no-cpu-baseline --sustained-s 0 > "$O/bench_gpus2_gloo_one_gpu.json" 2>/dev/null
+MORB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --batch 64 --steps 10 --exchange allgather --no-extras --no-cpu-baseline --sustained-s 0 > "$O/bench_gpus2_allgather_gloo_one_gpu.json" 2>/dev/null
+MORB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --workload c4 --steps 10 --no-extras --no-cpu-baseline --sustained-s 0 > "$O/bench_c4_gpus2_gloo_one_gpu.json" 2>/dev/null
 python3 bench.py > "$O/bench_default.json" 2>/dev/null
 python3 tools/time_stats.py "$O" 50 10 > /dev/null 2>&1
 python3 -m pytest tests -m gpu -q 2>&1 | tail -3 > "$O/pytest_gpu.txt"
