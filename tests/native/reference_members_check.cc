@@ -330,6 +330,46 @@ static int run_tracking() {
     for (int i = 0; i < N; ++i) outl[i] = (has[i] && F.mvbOutlier[i]) ? 1 : 0;
     dump("po_nin", &nin, 1); dump("po_pose", po, 7); dump("po_outlier", outl.data(), outl.size());
   }
+  {   // void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF, int& num_MPs, int& num_edges)
+    // the flattened graph of the test (keyframes, fixed flags, points, edges) rebuilt as mock objects: a keyframe's features are its edges
+    auto kfp = load<float>("ba_kf"); auto mpp = load<float>("ba_mp"); const auto fixed = load<uint8_t>("ba_fixed"); const auto eKF = load<int>("ba_ekf");
+    const auto eMP = load<int>("ba_emp"); const auto eObs = load<float>("ba_eobs"); const auto eInv = load<float>("ba_einv"); const auto cam = load<float>("po_cam");
+    const int nKF = (int)fixed.size(), nMP = (int)mpp.size() / 3, nE = (int)eKF.size();
+    Map map; map.initKF = 1u << 30; map.nKFs = (unsigned long)nKF;
+    std::vector<std::unique_ptr<KeyFrame>> kfs(nKF);
+    std::vector<MapPoint*> mps(nMP);
+    for (int j = 0; j < nMP; ++j) { mps[j] = new_point(&mpp[3 * j], nullptr, 1.f, 1.f, 0); mps[j]->mpMap = &map; mps[j]->mnId = (unsigned long)j; }
+    std::vector<int> featOfEdge(nE, -1);
+    for (int k = 0; k < nKF; ++k) {
+      kfs[k].reset(new KeyFrame());
+      KeyFrame& K = *kfs[k];
+      K.mnId = (unsigned long)k; K.mpMap = &map; K.fx = cam[0]; K.fy = cam[1]; K.cx = cam[2]; K.cy = cam[3]; K.mbf = cam[4];
+      for (int i = 0; i < 4; ++i) K.mTcw.q[i] = kfp[7 * k + i];
+      for (int i = 0; i < 3; ++i) K.mTcw.t[i] = kfp[7 * k + 4 + i];
+      for (int e = 0; e < nE; ++e) {
+        if (eKF[e] != k) continue;
+        const int f = (int)K.mvKeysUn.size();
+        featOfEdge[e] = f;
+        cv::KeyPoint kp; kp.pt.x = eObs[3 * e]; kp.pt.y = eObs[3 * e + 1]; kp.octave = f;   // (one "octave" per feature carries the edge's 1 / sigma^2)
+        K.mvKeysUn.push_back(kp); K.mvuRight.push_back(eObs[3 * e + 2]); K.mvInvLevelSigma2.push_back(eInv[e]);
+        K.mvpMapPoints.push_back(mps[eMP[e]]);
+        mps[eMP[e]]->mObservations[&K] = std::make_tuple(f, -1); mps[eMP[e]]->nObs++;
+      }
+      K.N = (int)K.mvKeysUn.size();
+    }
+    KeyFrame* pKF = nullptr;
+    for (int k = 0; k < nKF; ++k) if (!fixed[k]) { if (!pKF) pKF = kfs[k].get(); else pKF->mvpCov.push_back(kfs[k].get()); }
+    bool stop = false;
+    int num_fixedKF = 0, num_OptKF = 0, num_MPs = 0, num_edges = 0;
+    Optimizer::LocalBundleAdjustment(pKF, &stop, &map, num_fixedKF, num_OptKF, num_MPs, num_edges);
+    std::vector<float> kfo((size_t)nKF * 7), mpo((size_t)nMP * 3);
+    for (int k = 0; k < nKF; ++k) { for (int i = 0; i < 4; ++i) kfo[7 * k + i] = kfs[k]->mTcw.q[i]; for (int i = 0; i < 3; ++i) kfo[7 * k + 4 + i] = kfs[k]->mTcw.t[i]; }
+    for (int j = 0; j < nMP; ++j) for (int i = 0; i < 3; ++i) mpo[3 * j + i] = mps[j]->mWorldPos(i);
+    std::vector<uint8_t> erased(nE);
+    for (int e = 0; e < nE; ++e) erased[e] = kfs[eKF[e]]->mvpMapPoints[featOfEdge[e]] == nullptr ? 1 : 0;   // EraseMapPointMatch + EraseObservation (:1404-1414)
+    const int counts[6] = {num_fixedKF, num_OptKF, num_MPs, num_edges, map.changes, mps[0]->nUpdates};
+    dump("ba_kf", kfo.data(), kfo.size()); dump("ba_mp", mpo.data(), mpo.size()); dump("ba_erase", erased.data(), erased.size()); dump("ba_counts", counts, 6);
+  }
   std::printf("reference members (tracking) ok\n");
   return 0;
 }

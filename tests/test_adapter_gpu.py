@@ -79,6 +79,14 @@ def test_cpp_adapters_match_oracle(tmp_path):
     put("po_has", pp["hasMP"]); put("po_obs", pp["obs"]); put("po_inv", pp["invSigma2"]); put("po_xw", pp["Xw"]); put("po_pose", pp["pose0"])
     put("po_cam", np.array([cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["bf"]], np.float32))
     b = make_ba_problem(seed=2, n_free=8, n_fixed=3, n_points=500)
+    # the reference only takes the points a LOCAL keyframe sees (Optimizer.cc:1079-1098): keep that sub-graph, so that the view-taking adapter, the
+    # oracle and the reference-typed member (which runs that selection itself over mock objects) all solve the same problem
+    fr_ = b["kfFixed"] == 0
+    keepMP = np.zeros(len(b["mpPos"]), bool); keepMP[b["eMP"][fr_[b["eKF"]]]] = True
+    remap = np.cumsum(keepMP) - 1
+    keepE = keepMP[b["eMP"]]
+    b = dict(b, mpPos=b["mpPos"][keepMP], eKF=b["eKF"][keepE], eMP=remap[b["eMP"][keepE]].astype(b["eMP"].dtype), eObs=b["eObs"][keepE],
+             eInvSigma2=b["eInvSigma2"][keepE])
     put("ba_kf", b["kfPose"]); put("ba_mp", b["mpPos"]); put("ba_fixed", b["kfFixed"]); put("ba_ekf", b["eKF"].astype(np.int32)); put("ba_emp", b["eMP"].astype(np.int32))
     put("ba_eobs", b["eObs"]); put("ba_einv", b["eInvSigma2"])
     out = subprocess.run([_build(tmp_path, "adapters_check.cc"), str(d)], capture_output=True, text=True, timeout=300)
@@ -113,6 +121,18 @@ def test_cpp_adapters_match_oracle(tmp_path):
     for name, dt in (("sbp_n", np.int32), ("sbp_match", np.int32), ("dist", np.int32), ("po_nin", np.int32), ("po_outlier", np.uint8)):
         np.testing.assert_array_equal(getr(name, dt), get(name, dt), err_msg=name)
     assert getr("po_pose", np.float32).tobytes() == get("po_pose", np.float32).tobytes()
+    # LocalBundleAdjustment(KeyFrame*, bool*, Map*, int& x 4): the reference's graph selection over mock objects (keyframe order, point order and
+    # edge order of the flattened graph then differ from the test's arrays: the optimum agrees to the test's tolerance, the erased observations exactly)
+    free = b["kfFixed"] == 0
+    localMP = np.zeros(len(b["mpPos"]), bool); localMP[b["eMP"][free[b["eKF"]]]] = True           # points seen by a local keyframe (:1079-1098)
+    fixedSeen = np.zeros(len(free), bool); fixedSeen[b["eKF"][localMP[b["eMP"]]]] = True; fixedSeen &= ~free   # fixed keyframes that see one of them (:1100-1116)
+    assert localMP.all() and fixedSeen.sum() == (~free).sum(), "the synthetic graph is expected to be connected as the reference's selection needs"
+    cnts = getr("ba_counts", np.int32)
+    assert cnts[0] == int((~free).sum()) and cnts[1] == int(free.sum()) and cnts[2] == len(b["mpPos"]) and cnts[3] == len(b["eKF"]) and cnts[4] == 1 and cnts[5] == 1
+    assert np.abs(getr("ba_kf", np.float32) - get("ba_kf", np.float32)).max() <= 1e-4
+    mref = get("ba_mp", np.float32)
+    assert np.abs(getr("ba_mp", np.float32) - mref).max() <= 1e-4 * max(1.0, np.abs(mref).max())
+    np.testing.assert_array_equal(getr("ba_erase", np.uint8), get("ba_erase", np.uint8))
     assert int(get("po_nin", np.int32)[0]) == ro
     assert np.abs(get("po_pose", np.float32) - pe).max() <= 1e-4
     np.testing.assert_array_equal(get("po_outlier", np.uint8), oe_)
