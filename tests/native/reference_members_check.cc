@@ -338,12 +338,13 @@ static int run_tracking() {
     Map map; map.initKF = 1u << 30; map.nKFs = (unsigned long)nKF;
     std::vector<std::unique_ptr<KeyFrame>> kfs(nKF);
     std::vector<MapPoint*> mps(nMP);
-    for (int j = 0; j < nMP; ++j) { mps[j] = new_point(&mpp[3 * j], nullptr, 1.f, 1.f, 0); mps[j]->mpMap = &map; mps[j]->mnId = (unsigned long)j; }
+    for (int j = 0; j < nMP; ++j) { mps[j] = new_point(&mpp[3 * j], nullptr, 1.f, 1.f, 0); mps[j]->mpMap = &map; mps[j]->mnId = (unsigned long)j + 1; }
     std::vector<int> featOfEdge(nE, -1);
     for (int k = 0; k < nKF; ++k) {
       kfs[k].reset(new KeyFrame());
       KeyFrame& K = *kfs[k];
-      K.mnId = (unsigned long)k; K.mpMap = &map; K.fx = cam[0]; K.fy = cam[1]; K.cx = cam[2]; K.cy = cam[3]; K.mbf = cam[4];
+      // (ids from 1: mnBALocalForKF / mnBAFixedForKF start at 0, as in the reference, where keyframe 0 never runs a local BA)
+      K.mnId = (unsigned long)k + 1; K.mpMap = &map; K.fx = cam[0]; K.fy = cam[1]; K.cx = cam[2]; K.cy = cam[3]; K.mbf = cam[4];
       for (int i = 0; i < 4; ++i) K.mTcw.q[i] = kfp[7 * k + i];
       for (int i = 0; i < 3; ++i) K.mTcw.t[i] = kfp[7 * k + 4 + i];
       for (int e = 0; e < nE; ++e) {
