@@ -320,7 +320,7 @@ def config_extras(dev_index):
         st.synchronize()
         return (time.perf_counter() - t0) / n
     # ---- C3
-    B3 = 128   # (PoseOptimization is one workgroup per frame, ~1.2 ms whatever the batch: 32 frames per step gave 15 k frames/s, 128 give 40 k)
+    B3 = 256   # stereo frames per step (PoseOptimization is one workgroup per frame, ~1.2 ms whatever the batch: 32 / 128 / 256 / 512 frames per step -> 15 / 50 / 67 / 68 k frames/s)
     base = [make_stereo_pair(512, 512, seed=100 + i) for i in range(4)]
     imgs = torch.from_numpy(np.stack([base[i % 4][k] for i in range(B3) for k in (0, 1)])).to(dev)
     ext = ORBextractor(1500, 1.2, 8, 20, 7, device=dev_index)
