@@ -23,7 +23,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOADS = {"c2": (752, 480, 1200, 256), "c4": (1920, 1080, 4000, 8)}   # width, height, features, default stereo frames per step per GPU
+# width, height, features, default stereo frames per step per GPU (c2 at 512 frames: ~14 GB of HBM for the two
+# buffer sets).  c2: 256 / 512 / 1024 / 2048 / 4096 frames per step -> 120.9 / 125.9 / 126.3 / 126.9 / 125.6 k frames/s on one MI355X (round 4,
+# profiles/r04/batch_sweep.txt): launch tails amortise up to 512 frames (1024 images per launch), nothing beyond.  c4: BASELINE configs[3] is "8 frames in flight".
+WORKLOADS = {"c2": (752, 480, 1200, 512), "c4": (1920, 1080, 4000, 8)}
 W, H, NFEAT = 752, 480, 1200
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -49,13 +52,15 @@ def algorithmic_bytes(w, h):
 
 
 def make_batch(global_ids, total, seed=0):
-    """Stereo frames `global_ids` of a synthetic stream of `total` frames: 4 seeded sequences of total/4 consecutive
-    frames with a 3x2 px/frame global shift, so frame g-1 is a real 'previous frame' of frame g except at the 4
-    sequence starts."""
+    """Stereo frames `global_ids` of a synthetic stream of `total` frames: seeded sequences (four base scenes, taken in turn) of
+    min(total / 4, 64) consecutive frames with a 3x2 px/frame global shift, so frame g-1 is a real 'previous frame' of frame g except at
+    the sequence starts.  Sequences are capped at 64 frames: shift_image replicates the edge, and beyond ~190 px of shift a 752-px image
+    degenerates into streaks with no corners (a 1024-frame sequence would be mostly featureless frames — a batch sweep without the cap
+    "found" 187 k frames/s at 4096 frames per step)."""
     from morb_slam_amd.synth import make_stereo_pair, shift_image
     base = [make_stereo_pair(W, H, seed=seed * 16 + i) for i in range(4)]
     imgs = np.empty((len(global_ids), 2, H, W), np.uint8)
-    per = max(total // 4, 1)
+    per = min(max(total // 4, 1), 64)
     for k, g in enumerate(global_ids):
         l, r = base[(g // per) % 4]
         dx, dy = 3 * (g % per), 2 * (g % per)
@@ -473,8 +478,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
                     help="c2 = BASELINE configs[1] (752x480 / 1200 feat, the configuration the metric is quoted on); c4 = configs[3] (1920x1080 / 4000 feat)")
     ap.add_argument("--batch", type=int, default=0,
-                    help="stereo frames per step per GPU (default 256 for c2: 64 -> 62.8 k, 128 -> 65.0 k, 192 -> 67.1 k, 256 -> 69.0 k frames/s "
-                         "on one MI355X in round 1; 8 for c4)")
+                    help="stereo frames per step per GPU (default 512 for c2, see WORKLOADS; 8 for c4)")
     ap.add_argument("--sets", type=int, default=2, help="buffer sets = steps in flight (>= 2)")
     ap.add_argument("--extract-streams", type=int, default=1, help="1: one extraction stream for all buffer sets (default); 2: one per set")
     ap.add_argument("--matchers", choices=["beside-pyramid", "under-quadtree"], default="beside-pyramid",
@@ -597,7 +601,9 @@ def main():
     # boost-clock burst, this does not
     sustained = None
     if world == 1 and rank == 0 and args.sustained_s > 0:
-        win, wfps, wst, tot = 100, [], [], 0.0
+        # windows of ~0.2 s (at least 10 steps, at most 100), at least 10 of them and at least --sustained-s seconds in all
+        win = int(min(100, max(10, round(0.2 / max(dt / args.steps, 1e-6)))))
+        wfps, wst, tot = [], [], 0.0
         while tot < args.sustained_s or len(wfps) < 10:
             tw = time.perf_counter()
             for _ in range(win):

@@ -1,5 +1,5 @@
 """The BENCHED chain against the oracle: the exact object bench.py times (morb_slam_amd/frontend.py StereoFrontEnd — two buffer
-sets, pipelined streams, the k=10 / L=6 / levelsup=4 vocabulary, the has_mp mask, >= 128 stereo frames = 256 images per launch) is
+sets, pipelined streams, the k=10 / L=6 / levelsup=4 vocabulary, the has_mp mask, bench.py's default batch of stereo frames per step) is
 run for three steps and sampled frames spread over the batch are compared with the CPU oracle field by field: keypoint records,
 descriptors, mvuRight / mvDepth bit patterns, BoW word + node ids, the SearchByBoW table and count (tests/chain_check.py).
 
@@ -27,8 +27,10 @@ def _front_end(B, **kw):
 
 
 def test_bench_step_matches_oracle():
+    import bench
     import chain_check
-    B = 128
+    B = bench.WORKLOADS["c2"][3]      # the batch bench.py runs by default (512 stereo frames = 1024 images per launch)
+    assert B >= 128
     fe, host = _front_end(B)
     sets = [fe.step() for _ in range(3)]
     fe.sync()
