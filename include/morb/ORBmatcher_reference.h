@@ -5,8 +5,8 @@
 // from the objects (reference_glue.h), calls the view-taking overload / the C ABI, and writes the result back the way the reference's
 // method does (cited per member).  See reference_glue.h for what has and has not been compiled.
 //
-// KannalaBrandt8 rigs (Frame::Nleft != -1 / KeyFrame::NLeft != -1): the four per-frame tracking searches dispatch to the *_fisheye entry
-// points of morb_hip.h — SearchByProjection(F, vpMapPoints), SearchByProjection(Cur, Last), SearchByBoW(pKF, F) — the remaining members
+// KannalaBrandt8 rigs (Frame::Nleft != -1 / KeyFrame::NLeft != -1): the per-frame tracking searches and CreateNewMapPoints' search dispatch to the *_fisheye entry
+// points of morb_hip.h — SearchByProjection(F, vpMapPoints), SearchByProjection(Cur, Last), SearchByBoW(pKF, F), SearchForTriangulation — the remaining members
 // throw std::runtime_error on a rig rather than silently running the pinhole form (their fisheye kernels exist behind the C ABI:
 // morb_search_for_triangulation_fisheye_batch, ...; INTEGRATION.md section 3 shows the call).
 #pragma once
@@ -259,9 +259,33 @@ int ORBmatcher::SearchForInitialization(FrameT& F1, FrameT& F2, std::vector<Pt>&
 // int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, vector<pair<size_t, size_t>>& vMatchedPairs, bOnlyStereo, bCoarse)  ORBmatcher.cc:821-1042
 template <class KF>
 int ORBmatcher::SearchForTriangulation(KF* pKF1, KF* pKF2, std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo, const bool bCoarse) {
-  MORB_NO_RIG(pKF1->NLeft != -1 || pKF2->NLeft != -1, "SearchForTriangulation");
   morb_glue::Store<KeyFrameView> a, b;
   morb_glue::keyframe_view(a, pKF1, morb_glue::kAny); morb_glue::keyframe_view(b, pKF2, morb_glue::kAny);   // :876, :903: GetMapPoint(idx) != NULL, bad or not
+  if (pKF1->mpCamera2 || pKF2->mpCamera2) {
+    // KannalaBrandt8 rig (:845-852, :884, :925, :934-975): left features then right ones in one row, the four relative poses of the sides
+    vMatchedPairs.clear();
+    if (a.v.N <= 0 || b.v.N <= 0) return 0;
+    const auto T1w = pKF1->GetPose();
+    const auto Tw2 = pKF2->GetPoseInverse();
+    const auto Tr1w = pKF1->GetRightPose();
+    const auto Twr2 = pKF2->GetRightPoseInverse();
+    float T4[4][12], camL[8], camR[8];
+    morb_glue::rt12(T1w * Tw2, T4[0]); morb_glue::rt12(T1w * Twr2, T4[1]); morb_glue::rt12(Tr1w * Tw2, T4[2]); morb_glue::rt12(Tr1w * Twr2, T4[3]);
+    morb_glue::cam8(pKF1->mpCamera, camL); morb_glue::cam8(pKF1->mpCamera2, camR);
+    morb_adapter::StreamScope scope_(morb_matcher_stream(h_));
+    Staging& s = staging();
+    const int cap = load_pool(s, {&a.v, &b.v});
+    const int i1 = 0, i2 = 1, nl1 = pKF1->NLeft, nl2 = pKF2->NLeft;
+    s.i32[2].assign(&i1, 1); s.i32[3].assign(&i2, 1); s.i32[4].resize(1); s.i32[4].fill_bytes(0); s.i32[5].resize(cap); s.i32[6].assign(&nl1, 1); s.i32[7].assign(&nl2, 1);
+    check(morb_search_for_triangulation_fisheye_batch(h_, &a.v.params, 1, s.i32[2].get(), s.i32[3].get(), s.i32[6].get(), s.i32[7].get(), 2, cap, s.i32[0].get(),
+                                                      s.kp[0].get(), s.u8[0].get(), s.i32[1].get(), s.u8[1].get(), camL, camR, &T4[0][0], bOnlyStereo ? 1 : 0,
+                                                      bCoarse ? 1 : 0, mbCheckOrientation ? 1 : 0, s.i32[5].get(), s.i32[4].get(), nullptr));
+    sync();
+    const std::vector<int> m12 = s.i32[5].to_host();
+    for (int i = 0; i < a.v.N; ++i)
+      if (m12[i] >= 0) vMatchedPairs.emplace_back((size_t)i, (size_t)m12[i]);   // :1030-1036
+    return s.i32[4].to_host()[0];
+  }
   // :829-838
   const auto T1w = pKF1->GetPose();
   const auto T2w = pKF2->GetPose();

@@ -186,6 +186,13 @@ inline void sim3_raw(const Sim3& S, float out[7]) {
   out[0] = q.x(); out[1] = q.y(); out[2] = q.z(); out[3] = q.w();
   for (int k = 0; k < 3; ++k) out[4 + k] = t(k);
 }
+// rotation matrix (row-major) then translation of an SE3: the 12 floats the *_fisheye entry points take per relative pose
+template <class SE3>
+inline void rt12(const SE3& T, float o[12]) {
+  const auto R = T.rotationMatrix();
+  const auto t = T.translation();
+  for (int r = 0; r < 3; ++r) { o[9 + r] = t(r); for (int c = 0; c < 3; ++c) o[3 * r + c] = R(r, c); }
+}
 // GeometricCamera (Pinhole / KannalaBrandt8): fx fy cx cy [k0 k1 k2 k3] through getParameter(i) (CameraModels/GeometricCamera.h:95)
 template <class Cam>
 inline void cam8(Cam* c, float out[8]) {

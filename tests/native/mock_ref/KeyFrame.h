@@ -10,7 +10,7 @@ class KeyFrame {   // mock: the members of include/KeyFrame.h the reference-type
   MapPoint* GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; } void AddMapPoint(MapPoint* p, const size_t& idx) { mvpMapPoints[idx] = p; }
   void EraseMapPointMatch(MapPoint* p) { for (auto& q : mvpMapPoints) if (q == p) q = nullptr; }
   std::vector<KeyFrame*> GetVectorCovisibleKeyFrames() { return mvpCov; } bool isBad() { return mbBad; } Map* GetMap() { return mpMap; }
-  Sophus::SE3f GetRelativePoseTrl() { return mTrl; }
+  Sophus::SE3f GetRelativePoseTrl() { return mTrl; } Sophus::SE3f GetRightPose() { return mTrw; } Sophus::SE3f GetRightPoseInverse() { return mTwr; }
   Eigen::Matrix3f GetImuRotation() { return mRwb; } Eigen::Vector3f GetImuPosition() { return mOwb; } Eigen::Vector3f GetVelocity() { return mVw; }
   IMU::Bias GetImuBias() { return mImuBias; } void SetVelocity(const Eigen::Vector3f& v) { mVw = v; } void SetNewBias(const IMU::Bias& b) { mImuBias = b; }
   int N = 0, NLeft = -1, NRight = -1;
@@ -22,7 +22,7 @@ class KeyFrame {   // mock: the members of include/KeyFrame.h the reference-type
   GeometricCamera *mpCamera = nullptr, *mpCamera2 = nullptr;
   bool bImu = false; KeyFrame* mPrevKF = nullptr; IMU::Preintegrated* mpImuPreintegrated = nullptr; IMU::Calib mImuCalib;
   // (mock state)
-  Sophus::SE3f mTcw, mTrl; std::vector<MapPoint*> mvpMapPoints; std::vector<KeyFrame*> mvpCov; bool mbBad = false; Map* mpMap = nullptr;
+  Sophus::SE3f mTcw, mTrl, mTrw, mTwr; std::vector<MapPoint*> mvpMapPoints; std::vector<KeyFrame*> mvpCov; bool mbBad = false; Map* mpMap = nullptr;
   Eigen::Matrix3f mRwb; Eigen::Vector3f mOwb, mVw; IMU::Bias mImuBias;
 };
 }  // namespace ORB_SLAM3

@@ -62,8 +62,16 @@ struct SE3f {
   Eigen::Matrix3f rotationMatrix() const { Eigen::Matrix3f M; for (int k = 0; k < 9; ++k) M.m[k] = R[k]; M.canned = this; return M; }
   Eigen::Vector3f translation() const { return Eigen::Vector3f(t[0], t[1], t[2]); }
   Eigen::Quaternionf unit_quaternion() const { return Eigen::Quaternionf(q[3], q[0], q[1], q[2]); }
-  SE3f inverse() const { SE3f o; for (int k = 0; k < 3; ++k) o.t[k] = Ow[k]; return o; }
-  SE3f operator*(const SE3f&) const { return *this; }                        // (canned: T1w * Tw2 with Tw2 = identity)
+  // (the translation of the inverse is carried, not computed: Ow as the test wrote it)
+  SE3f inverse() const { SE3f o; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) o.R[3 * r + c] = R[3 * c + r]; for (int k = 0; k < 3; ++k) { o.t[k] = Ow[k]; o.Ow[k] = t[k]; } return o; }
+  SE3f operator*(const SE3f& b) const {   // R, t composed in float, left to right (q / Ow stay the left factor's)
+    SE3f o = *this;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) o.R[3 * r + c] = R[3 * r] * b.R[c] + R[3 * r + 1] * b.R[3 + c] + R[3 * r + 2] * b.R[6 + c];
+      o.t[r] = R[3 * r] * b.t[0] + R[3 * r + 1] * b.t[1] + R[3 * r + 2] * b.t[2] + t[r];
+    }
+    return o;
+  }
   Eigen::Vector3f operator*(const Eigen::Vector3f& x) const { return x; }
 };
 struct RxSO3f { float q[4] = {0, 0, 0, 1}; Eigen::Quaternionf quaternion() const { return Eigen::Quaternionf(q[3], q[0], q[1], q[2]); } };

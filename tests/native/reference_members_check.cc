@@ -3,7 +3,7 @@
 // SAME input files matcher_adapters_check.cc / adapters_check.cc read, and dumps what they leave in the objects as index tables
 // (out_ref_*).  tests/test_adapter_matcher_gpu.py / test_adapter_gpu.py require out_ref_* == out_* (the view-taking adapters' results, which they
 // compare with the oracle): the gather and write-back code of ORBmatcher_reference.h / Optimizer_reference.h is thereby checked end to end.
-//   reference_members_check <dir> matcher|tracking
+//   reference_members_check <dir> matcher|tracking|rig
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -265,6 +265,40 @@ static int run_matcher() {
   return 0;
 }
 
+// SearchForTriangulation between two keyframes of a KannalaBrandt8 rig (KeyFrame::NLeft != -1, mpCamera2 set): ORBmatcher.cc:821-1040
+static int run_rig() {
+  Arrays a1("rig_1"), a2("rig_2");
+  const auto cfg = load<float>("rig_cfg");   // nnratio, checkOri, bOnlyStereo, bCoarse, NLeft1, NLeft2
+  const auto cams = load<float>("rig_cams");   // left 8, right 8
+  const auto poses = load<float>("rig_poses");   // T1w, Tr1w, Tw2, Twr2: R (9 row-major) + t (3) each
+  GeometricCamera camL, camR;
+  camL.mvParameters.assign(cams.begin(), cams.begin() + 8); camR.mvParameters.assign(cams.begin() + 8, cams.begin() + 16);
+  auto rt = [&](int i) { Sophus::SE3f T; for (int k = 0; k < 9; ++k) T.R[k] = poses[12 * i + k]; for (int k = 0; k < 3; ++k) T.t[k] = poses[12 * i + 9 + k]; return T; };
+  auto split = [&](KeyFrame& k, int nl) {   // mvKeys | mvKeysRight as Frame's fisheye constructor leaves them (Frame.cc:1160-1162)
+    k.NLeft = nl; k.NRight = k.N - nl;
+    k.mvKeysRight.assign(k.mvKeys.begin() + nl, k.mvKeys.end()); k.mvKeys.resize(nl); k.mvKeysUn = k.mvKeys;
+    k.mpCamera = &camL; k.mpCamera2 = &camR;
+  };
+  for (int variant = 0; variant < 2; ++variant) {
+    KeyFrame k1, k2; a1.fill(k1); a2.fill(k2);
+    split(k1, (int)cfg[4]); split(k2, (int)cfg[5]);
+    k1.mTcw = rt(0); k1.mTrw = rt(1);
+    const Sophus::SE3f Tw2 = rt(2);
+    k2.mTcw = Sophus::SE3f(); for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) k2.mTcw.R[3 * r + c] = Tw2.R[3 * c + r];
+    for (int k = 0; k < 3; ++k) k2.mTcw.Ow[k] = Tw2.t[k];   // (GetPoseInverse() of the mock: R transposed, Ow carried)
+    k2.mTwr = rt(3);
+    ORBmatcher matcher(cfg[0], cfg[1] != 0);
+    std::vector<std::pair<size_t, size_t>> pairs;
+    const int n = matcher.SearchForTriangulation(&k1, &k2, pairs, variant == 1, cfg[3] != 0);
+    std::vector<int> flat;
+    for (auto& p : pairs) { flat.push_back((int)p.first); flat.push_back((int)p.second); }
+    const std::string tag = variant == 0 ? "rig" : "rig_stereo";
+    dump(tag + "_n", &n, 1); dump(tag + "_pairs", flat.data(), flat.size());
+  }
+  std::printf("reference members (rig) ok\n");
+  return 0;
+}
+
 static int run_tracking() {
   {   // int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bFarPoints, const float thFarPoints)
     // after the host's isInFrustum loop (Tracking.cc:3117-3183): here that loop's results come from morb_is_in_frustum_batch
@@ -378,5 +412,6 @@ static int run_tracking() {
 int main(int argc, char** argv) {
   if (argc < 3) return 2;
   g_dir = argv[1];
-  return std::string(argv[2]) == "matcher" ? run_matcher() : run_tracking();
+  const std::string mode = argv[2];
+  return mode == "matcher" ? run_matcher() : mode == "rig" ? run_rig() : run_tracking();
 }

@@ -2,6 +2,8 @@
 right-camera "ToBody" edges.  The float transcendentals of the KB8 model (atan2f, tanf, cosf, sinf) are glibc's on both sides — the
 kernels restate them bit for bit (csrc/libm_f32.h, tools/check_libm_f32.cc) — so match tables, frustum flags, projections and outlier
 flags are compared exactly; depths / 3-D points come out of an FP64 Jacobi null vector (different sweep order than Eigen): 1e-4."""
+import subprocess
+
 import numpy as np
 import pytest
 
@@ -352,11 +354,9 @@ def test_local_ba_fisheye_matches_oracle(kw):
         assert 0.01 < ee.mean() < 0.3
 
 
-def test_search_for_triangulation_fisheye():
-    """SearchForTriangulation between two keyframes of the KB8 rig: the four (side, side) camera / relative-pose
-    combinations and KannalaBrandt8::epipolarConstrain (TriangulateMatches > 1e-4)."""
-    import torch
-    from morb_slam_amd import KP_DTYPE, ORBmatcher
+def _tri_scene():
+    """Three keyframes of the TUM-VI KB8 rig looking at one cloud: per keyframe the left | right feature row, counts, NLeft, poses."""
+    from morb_slam_amd import KP_DTYPE
     from morb_slam_amd.synth import (TUMVI_CAM_L, TUMVI_CAM_R, TUMVI_T_C1_C2, kb8_project, make_vocabulary, _quat_from_rotvec,
                                      _quat_rot)
     P, sf = _fisheye_params()
@@ -402,6 +402,17 @@ def test_search_for_triangulation_fisheye():
         a, b = len(kl), len(kr)
         kps[i, :a] = kl; kps[i, a:a + b] = kr; desc[i, :a] = dl; desc[i, a:a + b] = dr; cnt[i] = a + b; nl[i] = a
     has = (rng.random((nimg, cap)) < 0.3).astype(np.uint8)
+    return dict(P=P, sf=sf, poses=poses, Trl=Trl_m, kps=kps, desc=desc, cnt=cnt, nl=nl, has=has, cap=cap, nimg=nimg)
+
+
+def test_search_for_triangulation_fisheye():
+    """SearchForTriangulation between two keyframes of the KB8 rig: the four (side, side) camera / relative-pose
+    combinations and KannalaBrandt8::epipolarConstrain (TriangulateMatches > 1e-4)."""
+    import torch
+    from morb_slam_amd import ORBmatcher
+    from morb_slam_amd.synth import TUMVI_CAM_L, TUMVI_CAM_R, make_vocabulary
+    S = _tri_scene()
+    P, sf, poses, Trl_m, kps, desc, cnt, nl, has, cap, nimg = (S[k] for k in ("P", "sf", "poses", "Trl", "kps", "desc", "cnt", "nl", "has", "cap", "nimg"))
     pairs = [(0, 1), (1, 2), (2, 0)]
     T4 = np.zeros((len(pairs), 4, 12), np.float32)
     for p, (a, b) in enumerate(pairs):
@@ -440,6 +451,67 @@ def test_search_for_triangulation_fisheye():
                                                                   TUMVI_CAM_L, TUMVI_CAM_R, T4, bOnlyStereo=True)
     torch.cuda.synchronize()
     assert int(nm.sum()) == 0 and int((m12 >= 0).sum()) == 0
+
+
+def _mul_f32(A, B):
+    """(R, t) of A * B composed in float32 left to right, as tests/native/mock_ref's SE3f does (no FMA: products rounded, then summed)."""
+    A = np.asarray(A, np.float32); B = np.asarray(B, np.float32)
+    Ra, ta, Rb, tb = A[:9].reshape(3, 3), A[9:], B[:9].reshape(3, 3), B[9:]
+    R = np.zeros((3, 3), np.float32); t = np.zeros(3, np.float32)
+    for r in range(3):
+        for c in range(3):
+            R[r, c] = np.float32(np.float32(Ra[r, 0] * Rb[0, c]) + np.float32(Ra[r, 1] * Rb[1, c])) + np.float32(Ra[r, 2] * Rb[2, c])
+        t[r] = np.float32(np.float32(np.float32(Ra[r, 0] * tb[0]) + np.float32(Ra[r, 1] * tb[1])) + np.float32(Ra[r, 2] * tb[2])) + ta[r]
+    return np.concatenate([R.reshape(-1), t]).astype(np.float32)
+
+
+def test_search_for_triangulation_rig_through_the_reference_member(tmp_path):
+    """ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, ...) of include/morb/ORBmatcher.h with KeyFrame::NLeft != -1 / mpCamera2 set
+    (tests/native/reference_members_check.cc `rig`, mock KeyFrames carrying this scene): the pairs it returns are the oracle's, with the
+    four relative poses built from GetPose / GetPoseInverse / GetRightPose / GetRightPoseInverse as ORBmatcher.cc:836-852 builds them."""
+    import torch
+    from morb_slam_amd import ORBmatcher
+    from morb_slam_amd.synth import TUMVI_CAM_L, TUMVI_CAM_R, make_vocabulary
+    from test_adapter_gpu import _build
+    S = _tri_scene()
+    kps, desc, cnt, nl, has, poses, Trl_m, sf = (S[k] for k in ("kps", "desc", "cnt", "nl", "has", "poses", "Trl", "sf"))
+    a, b = 0, 1
+    na, nb = int(cnt[a]), int(cnt[b])
+    cu = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    k, Lv = 5, 3
+    vd, vf = make_vocabulary(k, Lv, seed=9)
+    _, node = ORBmatcher(0.6, True).bow_transform(cu(desc), cu(cnt), cu(vd), cu(vf), k, Lv, 1)
+    torch.cuda.synchronize()
+    nn_ = node.cpu().numpy()
+    d = tmp_path / "io"
+    d.mkdir()
+    put = lambda name, x: np.ascontiguousarray(x).tofile(str(d / (name + ".bin")))
+    Pb = np.frombuffer(bytes(S["P"]), np.uint8)
+    for tag, i, n in (("rig_1", a, na), ("rig_2", b, nb)):
+        put(tag + "_kps", kps[i, :n]); put(tag + "_desc", desc[i, :n]); put(tag + "_params", Pb); put(tag + "_node", nn_[i, :n].astype(np.int32))
+        put(tag + "_hasmp", has[i, :n])
+    rt = lambda T: np.concatenate([T[:3, :3].reshape(-1), T[:3, 3]]).astype(np.float32)
+    T1w, T2w = poses[a], poses[b]
+    four = [rt(T1w), rt(Trl_m @ T1w), rt(np.linalg.inv(T2w)), rt(np.linalg.inv(Trl_m @ T2w))]   # T1w, Tr1w, Tw2, Twr2
+    put("rig_poses", np.concatenate(four))
+    put("rig_cams", np.concatenate([TUMVI_CAM_L, TUMVI_CAM_R]).astype(np.float32))
+    ori, coarse = True, False
+    put("rig_cfg", np.array([0.6, ori, 0, coarse, nl[a], nl[b]], np.float32))
+    out = subprocess.run([_build(tmp_path, "reference_members_check.cc", mock_ref=True), str(d), "rig"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "reference members (rig) ok" in out.stdout, out.stdout + out.stderr
+    T4 = np.stack([_mul_f32(four[0], four[2]), _mul_f32(four[0], four[3]), _mul_f32(four[1], four[2]), _mul_f32(four[1], four[3])])
+    sigma2 = (sf * sf).astype(np.float32)
+    for tag, only in (("rig", False), ("rig_stereo", True)):
+        ne, me = O.search_for_triangulation_fisheye(kps[a, :na], nl[a], desc[a, :na], nn_[a, :na], has[a, :na], kps[b, :nb], nl[b], desc[b, :nb],
+                                                    nn_[b, :nb], has[b, :nb], sigma2, TUMVI_CAM_L, TUMVI_CAM_R, T4, only, coarse, ori)
+        got = np.fromfile(str(d / ("out_ref_" + tag + "_pairs.bin")), np.int32).reshape(-1, 2)
+        assert int(np.fromfile(str(d / ("out_ref_" + tag + "_n.bin")), np.int32)[0]) == ne
+        exp = np.stack([np.nonzero(me >= 0)[0], me[me >= 0]], 1)
+        np.testing.assert_array_equal(got, exp)
+        if not only:
+            assert ne > 80 and ((exp[:, 0] < nl[a]) != (exp[:, 1] < nl[b])).sum() > 5      # left-right pairs too
+        else:
+            assert ne == 0
 
 
 def test_c3_chain_on_extracted_features():
