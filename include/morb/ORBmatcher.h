@@ -324,10 +324,16 @@ class ORBmatcher {
   // ORBmatcher.cc:1044-1213; LocalMapping::SearchInNeighbors) — the search: bestIdx[i] = feature of pKF chosen for map point i
   // (bestDist <= TH_LOW) or -1.  What follows a hit (Replace / AddObservation / AddMapPoint, :1196-1208) depends on live map state and is
   // replayed by the caller over bestIdx in map-point order; the return value here is the number of hits.
-  int Fuse(const KeyFrameView& KF, const MapPointView& vpMapPoints, std::vector<int>& bestIdx, std::vector<int>& bestDist, float th = 3.0f) {
+  // On a KannalaBrandt8 rig (KeyFrame::NLeft != -1; KF holds mvKeys | mvKeysRight in one row) `side` names the camera searched: its pose and
+  // centre (GetPose / GetCameraCenter, or GetRightPose / GetRightCameraCenter with bRight), its KB8 parameters and its feature range
+  // ([0, NLeft) or [NLeft, N)); the indices returned count from the start of the row (:1050-1054, :1130-1177).
+  struct RigSide { float Tcw[7]; float Ow[3]; float cam8[8]; int jLo, jHi; };
+  int Fuse(const KeyFrameView& KF, const MapPointView& vpMapPoints, std::vector<int>& bestIdx, std::vector<int>& bestDist, float th = 3.0f,
+           const RigSide* side = nullptr) {
     Sim3View T;
-    std::memcpy(T.Tcw, KF.Tcw, sizeof T.Tcw); std::memcpy(T.Ow, KF.mOw, sizeof T.Ow);
-    return fuse(KF, T, vpMapPoints, bestIdx, bestDist, th, 0);
+    if (side) { std::memcpy(T.Tcw, side->Tcw, sizeof T.Tcw); std::memcpy(T.Ow, side->Ow, sizeof T.Ow); }
+    else { std::memcpy(T.Tcw, KF.Tcw, sizeof T.Tcw); std::memcpy(T.Ow, KF.mOw, sizeof T.Ow); }
+    return fuse(KF, T, vpMapPoints, bestIdx, bestDist, th, 0, side);
   }
   // int Fuse(KeyFrame* pKF, Sophus::Sim3f& Scw, const vector<MapPoint*>& vpPoints, float th, vector<MapPoint*>& vpReplacePoint)
   // (ORBmatcher.h:112-114, ORBmatcher.cc:1215-1321; loop closing): vpReplacePoint[i] = pKF->GetMapPoint(bestIdx[i]) where that is non-NULL.
@@ -453,7 +459,8 @@ class ORBmatcher {
     for (int i = 0; i < N; ++i) if (mf[i] >= 0) vpMatched[i] = mf[i];
     return s.i32[4].to_host()[0];
   }
-  int fuse(const KeyFrameView& KF, const Sim3View& T, const MapPointView& P, std::vector<int>& bestIdx, std::vector<int>& bestDist, float th, int sim3Form) {
+  int fuse(const KeyFrameView& KF, const Sim3View& T, const MapPointView& P, std::vector<int>& bestIdx, std::vector<int>& bestDist, float th, int sim3Form,
+           const RigSide* side = nullptr) {
     const int N = KF.N, M = P.n;
     bestIdx.assign(M > 0 ? M : 0, -1); bestDist.assign(M > 0 ? M : 0, 256);
     if (N <= 0 || M <= 0) return 0;
@@ -464,8 +471,10 @@ class ORBmatcher {
     const int kf = 0, nmp = M;
     s.i32[2].assign(&kf, 1); s.i32[3].assign(&nmp, 1); s.i32[5].resize(M); s.i32[6].resize(M);
     s.f32[1].assign(T.Tcw, 7); s.f32[2].assign(T.Ow, 3);
-    check(morb_fuse_batch(h_, &KF.params, 1, s.i32[2].get(), cap, s.i32[0].get(), s.kp[0].get(), s.u8[0].get(), KF.mvuRight ? s.f32[0].get() : nullptr,
-                          s.f32[1].get(), s.f32[2].get(), nullptr, nullptr, nullptr, M, s.i32[3].get(), s.u8[2].get(), s.f32[3].get(), s.f32[4].get(),
+    if (side) { s.i32[4].assign(&side->jLo, 1); s.i32[7].assign(&side->jHi, 1); }
+    check(morb_fuse_batch(h_, &KF.params, 1, s.i32[2].get(), cap, s.i32[0].get(), s.kp[0].get(), s.u8[0].get(), (KF.mvuRight && !side) ? s.f32[0].get() : nullptr,
+                          s.f32[1].get(), s.f32[2].get(), side ? side->cam8 : nullptr, side ? s.i32[4].get() : nullptr, side ? s.i32[7].get() : nullptr, M,
+                          s.i32[3].get(), s.u8[2].get(), s.f32[3].get(), s.f32[4].get(),
                           s.f32[5].get(), s.f32[6].get(), s.u8[3].get(), th, sim3Form, s.i32[5].get(), s.i32[6].get(), nullptr));
     sync();
     bestIdx = s.i32[5].to_host(); bestDist = s.i32[6].to_host();

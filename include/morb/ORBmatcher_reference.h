@@ -6,7 +6,7 @@
 // method does (cited per member).  See reference_glue.h for what has and has not been compiled.
 //
 // KannalaBrandt8 rigs (Frame::Nleft != -1 / KeyFrame::NLeft != -1): the per-frame tracking searches and CreateNewMapPoints' search dispatch to the *_fisheye entry
-// points of morb_hip.h — SearchByProjection(F, vpMapPoints), SearchByProjection(Cur, Last), SearchByBoW(pKF, F), SearchForTriangulation — the remaining members
+// points of morb_hip.h — SearchByProjection(F, vpMapPoints), SearchByProjection(Cur, Last), SearchByBoW(pKF, F), SearchForTriangulation, Fuse(pKF, vpMapPoints, th, bRight) — the remaining members
 // throw std::runtime_error on a rig rather than silently running the pinhole form (their fisheye kernels exist behind the C ABI:
 // morb_search_for_triangulation_fisheye_batch, ...; INTEGRATION.md section 3 shows the call).
 #pragma once
@@ -330,7 +330,6 @@ int ORBmatcher::SearchBySim3(KF* pKF1, KF* pKF2, std::vector<MP*>& vpMatches12, 
 // int Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, th, bRight)  ORBmatcher.cc:1044-1213 (LocalMapping::SearchInNeighbors)
 template <class KF, class MP>
 int ORBmatcher::Fuse(KF* pKF, const std::vector<MP*>& vpMapPoints, const float th, const bool bRight) {
-  MORB_NO_RIG(bRight || pKF->NLeft != -1, "Fuse");
   morb_glue::Store<KeyFrameView> kf;
   morb_glue::keyframe_view(kf, pKF);
   morb_glue::PointStore<MapPointView> ps;
@@ -338,7 +337,18 @@ int ORBmatcher::Fuse(KF* pKF, const std::vector<MP*>& vpMapPoints, const float t
   for (size_t i = 0; i < vpMapPoints.size(); ++i)
     if (vpMapPoints[i] && vpMapPoints[i]->IsInKeyFrame(pKF)) ps.valid[i] = 0;   // :1076-1089
   std::vector<int> bestIdx, bestDist;
-  Fuse(kf.v, ps.v, bestIdx, bestDist, th);
+  if (pKF->NLeft != -1) {   // KannalaBrandt8 rig: the side's pose, centre, camera and features (:1050-1058, :1130-1147, :1177)
+    RigSide side;
+    const auto O = bRight ? pKF->GetRightCameraCenter() : pKF->GetCameraCenter();
+    morb_glue::pose7(bRight ? pKF->GetRightPose() : pKF->GetPose(), side.Tcw);
+    for (int k = 0; k < 3; ++k) side.Ow[k] = O(k);
+    morb_glue::cam8(bRight ? pKF->mpCamera2 : pKF->mpCamera, side.cam8);
+    side.jLo = bRight ? pKF->NLeft : 0; side.jHi = bRight ? pKF->N : pKF->NLeft;
+    Fuse(kf.v, ps.v, bestIdx, bestDist, th, &side);
+  } else {
+    if (bRight) throw std::runtime_error("Fuse: bRight on a keyframe without a right camera (NLeft == -1)");   // (the reference would dereference mpCamera2 == NULL)
+    Fuse(kf.v, ps.v, bestIdx, bestDist, th);
+  }
   int nFused = 0;
   for (size_t i = 0; i < vpMapPoints.size(); ++i) {
     if (bestIdx[i] < 0) continue;

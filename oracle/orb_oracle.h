@@ -118,6 +118,9 @@ float orc_kb8_triangulate_matches(const float* cam1_8, const float* cam2_8, floa
 void orc_fuse_search(const orc_frame* KF, const float* invLevelSigma2, const float* Tcw7, const float* Ow, int nMP, const uint8_t* valid,
                      const float* Pw, const float* normal, const float* maxDist, const float* minDist, const uint8_t* mpDesc, float th,
                      int sim3Form, int* bestIdx, int* bestDist);
+void orc_fuse_search_rig(const orc_frame* KF, int NLeft, int bRight, const float* cam8, const float* invLevelSigma2, const float* Tcw7,
+                         const float* Ow, int nMP, const uint8_t* valid, const float* Pw, const float* normal, const float* maxDist,
+                         const float* minDist, const uint8_t* mpDesc, float th, int* bestIdx, int* bestDist);
 int orc_search_by_projection_sim3(const orc_frame* KF, const float* Tcw7, const float* Ow, int nMP, const uint8_t* valid,
                                   const float* Pw, const float* normal, const float* maxDist, const float* minDist,
                                   const uint8_t* mpDesc, const uint8_t* matchedIn, int th, float ratioHamming, int manualProjection,

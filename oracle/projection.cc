@@ -855,6 +855,59 @@ void FuseSearch(const orc_frame& KF, const float* invLevelSigma2, const float* T
   }
 }
 
+// ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th, bRight) (:1044-1213) on a KannalaBrandt8 rig (KeyFrame::NLeft != -1):
+// KF holds the NLeft left features followed by the right ones (mvKeys | mvKeysRight, one descriptor matrix).  bRight picks the side:
+// Tcw7 / Ow = GetRightPose() / GetRightCameraCenter() and cam8 = mpCamera2 (:1050-1054), else GetPose() / GetCameraCenter() /
+// mpCamera; the window is looked up in that side's grid with that side's keypoints (KeyFrame.cc:758-764, side-local indices),
+// mvuRight[idx] — read with the side-local index (:1154), all -1 on a rig — sends every candidate through the 5.99 gate, and the
+// descriptor row / returned index is idx + NLeft on the right (:1177).
+void FuseSearchRig(const orc_frame& KF, int NLeft, bool bRight, const float* cam8, const float* invLevelSigma2, const float* Tcw7,
+                   const float* Ow, int nMP, const uint8_t* valid, const float* Pw, const float* normal, const float* mfMaxDistance,
+                   const float* mfMinDistance, const uint8_t* mpDesc, float th, int* bestIdxOut, int* bestDistOut) {
+  orc_frame S = KF;   // the side's features as a frame of their own
+  const int base = bRight ? NLeft : 0;
+  S.N = bRight ? KF.N - NLeft : NLeft;
+  S.kpsUn = KF.kpsUn + base; S.desc = KF.desc + (size_t)base * 32; S.uRight = nullptr;
+  Grid g;
+  AssignFeaturesToGrid(S, g);
+  const KeyPoint* k = (const KeyPoint*)S.kpsUn;
+  for (int i = 0; i < nMP; i++) {
+    bestIdxOut[i] = -1; bestDistOut[i] = -1;
+    if (!valid[i]) continue;
+    const float* p3Dw = Pw + 3 * i;
+    float p3Dc[3], uv[2];
+    rotateF(Tcw7, p3Dw, p3Dc);
+    p3Dc[0] += Tcw7[4]; p3Dc[1] += Tcw7[5]; p3Dc[2] += Tcw7[6];
+    if (p3Dc[2] < 0.0f) continue;
+    orc_kb8_project_f(cam8, p3Dc, uv);
+    if (!KFIsInImage(KF, uv[0], uv[1])) continue;
+    const float maxDistance = 1.2f * mfMaxDistance[i], minDistance = 0.8f * mfMinDistance[i];
+    const float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
+    const float dist3D = std::sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    const float* Pn = normal + 3 * i;
+    if ((PO[0] * Pn[0] + PO[1] * Pn[1] + PO[2] * Pn[2]) < 0.5 * dist3D) continue;
+    const int nPredictedLevel = PredictScaleKF(KF, mfMaxDistance[i], dist3D);
+    const float radius = th * KF.scaleFactors[nPredictedLevel];
+    const std::vector<size_t> vIndices = KFGetFeaturesInArea(S, g, uv[0], uv[1], radius);
+    if (vIndices.empty()) continue;
+    const uint8_t* dMP = mpDesc + (size_t)i * 32;
+    int bestDist = 256, bestIdx = -1;
+    for (size_t q = 0; q < vIndices.size(); ++q) {
+      const size_t idx = vIndices[q];
+      const KeyPoint& kp = k[idx];
+      const int kpLevel = kp.octave;
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      const float ex = uv[0] - kp.x, ey = uv[1] - kp.y;
+      const float e2 = ex * ex + ey * ey;
+      if (e2 * invLevelSigma2[kpLevel] > 5.99) continue;
+      const int dist = DescriptorDistance(dMP, S.desc + idx * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx + base; }
+    }
+    if (bestDist <= TH_LOW) { bestIdxOut[i] = bestIdx; bestDistOut[i] = bestDist; }
+  }
+}
+
 // ORBmatcher::SearchByProjection(KeyFrame*, Sim3f& Scw, vpPoints, vpMatched, th, ratioHamming) (:397-494) and its twin
 // with vpPointsKFs / vpMatchedKF (:496-601; manualProjection: u = fx * (X * invz) + cx instead of mpCamera->project).
 // matched[idx] != 0 <=> vpMatched[idx] on entry; matchF[idx] = index of the map point newly assigned to feature idx.
@@ -1036,6 +1089,11 @@ void orc_fuse_search(const orc_frame* KF, const float* invLevelSigma2, const flo
                      const float* Pw, const float* normal, const float* maxDist, const float* minDist, const uint8_t* mpDesc, float th,
                      int sim3Form, int* bestIdx, int* bestDist) {
   FuseSearch(*KF, invLevelSigma2, Tcw7, Ow, nMP, valid, Pw, normal, maxDist, minDist, mpDesc, th, sim3Form != 0, bestIdx, bestDist);
+}
+void orc_fuse_search_rig(const orc_frame* KF, int NLeft, int bRight, const float* cam8, const float* invLevelSigma2, const float* Tcw7,
+                         const float* Ow, int nMP, const uint8_t* valid, const float* Pw, const float* normal, const float* maxDist,
+                         const float* minDist, const uint8_t* mpDesc, float th, int* bestIdx, int* bestDist) {
+  FuseSearchRig(*KF, NLeft, bRight != 0, cam8, invLevelSigma2, Tcw7, Ow, nMP, valid, Pw, normal, maxDist, minDist, mpDesc, th, bestIdx, bestDist);
 }
 int orc_search_by_projection_sim3(const orc_frame* KF, const float* Tcw7, const float* Ow, int nMP, const uint8_t* valid,
                                   const float* Pw, const float* normal, const float* maxDist, const float* minDist,

@@ -11,6 +11,7 @@ class KeyFrame {   // mock: the members of include/KeyFrame.h the reference-type
   void EraseMapPointMatch(MapPoint* p) { for (auto& q : mvpMapPoints) if (q == p) q = nullptr; }
   std::vector<KeyFrame*> GetVectorCovisibleKeyFrames() { return mvpCov; } bool isBad() { return mbBad; } Map* GetMap() { return mpMap; }
   Sophus::SE3f GetRelativePoseTrl() { return mTrl; } Sophus::SE3f GetRightPose() { return mTrw; } Sophus::SE3f GetRightPoseInverse() { return mTwr; }
+  Eigen::Vector3f GetRightCameraCenter() { return Eigen::Vector3f(mTrw.Ow[0], mTrw.Ow[1], mTrw.Ow[2]); }
   Eigen::Matrix3f GetImuRotation() { return mRwb; } Eigen::Vector3f GetImuPosition() { return mOwb; } Eigen::Vector3f GetVelocity() { return mVw; }
   IMU::Bias GetImuBias() { return mImuBias; } void SetVelocity(const Eigen::Vector3f& v) { mVw = v; } void SetNewBias(const IMU::Bias& b) { mImuBias = b; }
   int N = 0, NLeft = -1, NRight = -1;

@@ -295,6 +295,28 @@ static int run_rig() {
     const std::string tag = variant == 0 ? "rig" : "rig_stereo";
     dump(tag + "_n", &n, 1); dump(tag + "_pairs", flat.data(), flat.size());
   }
+  for (int right = 0; right < 2; ++right) {   // int Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, const float th, const bool bRight) on the rig keyframe
+    const std::string t = right ? "rigf_r" : "rigf_l";
+    const auto pos = load<float>(t + "_pos"), nrm = load<float>(t + "_normal"), maxd = load<float>(t + "_maxd"), mind = load<float>(t + "_mind");
+    const auto desc = load<uint8_t>(t + "_desc"), valid = load<uint8_t>(t + "_valid");
+    const auto side = load<float>(t + "_pose");   // Tcw (quaternion xyzw, t), Ow of the camera searched
+    const int M = (int)maxd.size();
+    KeyFrame kf; a2.fill(kf);
+    split(kf, (int)cfg[5]);
+    Sophus::SE3f& T = right ? kf.mTrw : kf.mTcw;
+    for (int i = 0; i < 4; ++i) T.q[i] = side[i];
+    for (int i = 0; i < 3; ++i) { T.t[i] = side[4 + i]; T.Ow[i] = side[7 + i]; }
+    std::vector<MapPoint*> pts(M);
+    for (int i = 0; i < M; ++i) {
+      pts[i] = new_point(&pos[3 * i], &desc[(size_t)32 * i], maxd[i], mind[i], 1);
+      pts[i]->mNormalVector = Eigen::Vector3f(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]);
+      pts[i]->mbBad = valid[i] == 0;
+    }
+    ORBmatcher matcher(cfg[0], cfg[1] != 0);
+    const int n = matcher.Fuse(&kf, pts, 3.0f, right != 0);
+    const std::vector<int> slots = index_of(kf.mvpMapPoints, pts);
+    dump(t + "_n", &n, 1); dump(t + "_slots", slots.data(), slots.size());
+  }
   std::printf("reference members (rig) ok\n");
   return 0;
 }

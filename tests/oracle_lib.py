@@ -351,6 +351,19 @@ def fuse_search(KF, invSigma2, Tcw7, Ow, valid, Pw, normal, maxD, minD, mpDesc, 
     return bi, bd
 
 
+def fuse_search_rig(KF, NLeft, bRight, cam8, invSigma2, Tcw7, Ow, valid, Pw, normal, maxD, minD, mpDesc, th):
+    """Fuse(pKF, vpMapPoints, th, bRight) on a KannalaBrandt8 rig keyframe (left | right features in one row)."""
+    L = lib(); n = len(Pw)
+    L.orc_fuse_search_rig.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_void_p, C.c_void_p]
+    a = [np.ascontiguousarray(x) for x in (np.asarray(cam8, np.float32), np.asarray(invSigma2, np.float32), np.asarray(Tcw7, np.float32),
+                                           np.asarray(Ow, np.float32), valid.astype(np.uint8), np.asarray(Pw, np.float32),
+                                           np.asarray(normal, np.float32), np.asarray(maxD, np.float32), np.asarray(minD, np.float32), mpDesc)]
+    bi = np.zeros(n, np.int32); bd = np.zeros(n, np.int32)
+    L.orc_fuse_search_rig(C.byref(KF), int(NLeft), int(bRight), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), n, _p(a[4]), _p(a[5]), _p(a[6]), _p(a[7]),
+                          _p(a[8]), _p(a[9]), th, _p(bi), _p(bd))
+    return bi, bd
+
+
 def search_by_projection_sim3(KF, Tcw7, Ow, valid, Pw, normal, maxD, minD, mpDesc, matched, th, ratio, manual):
     L = lib(); n = len(Pw)
     L.orc_search_by_projection_sim3.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_float, C.c_int, C.c_void_p]

@@ -372,8 +372,9 @@ def _tri_scene():
     Xw = np.stack([rng.uniform(-3, 3, M), rng.uniform(-2.5, 2.5, M), rng.uniform(1.5, 7, M)], 1)
     base = rng.integers(0, 256, (M, 32), dtype=np.uint8)
     poses = [se3([0, 0, 0], [0, 0, 0]), se3([0.01, -0.03, 0.005], [-0.35, 0.02, 0.05]), se3([-0.02, 0.02, 0.0], [0.3, -0.05, -0.1])]
-    feats = []
+    feats, vis = [], []
     for Tcw in poses:
+        seen = []
         Xl = Xw @ Tcw[:3, :3].T + Tcw[:3, 3]
         Xr = Xl @ Trl_m[:3, :3].T + Trl_m[:3, 3]
         parts = []
@@ -394,7 +395,8 @@ def _tri_scene():
             k["angle"][sel] = (37.0 * idx) % 360 + rng.normal(0, 2, len(idx))
             d[sel] = base[idx] ^ np.packbits(rng.random((len(idx), 256)) < 0.04, axis=1)
             parts.append((k, d))
-        feats.append(parts)
+            seen.append((idx, sel, oc))
+        feats.append(parts); vis.append(seen)
     nimg = len(feats)
     cap = max(len(p[0][0]) + len(p[1][0]) for p in feats) + 4
     kps = np.zeros((nimg, cap), KP_DTYPE); desc = np.zeros((nimg, cap, 32), np.uint8); cnt = np.zeros(nimg, np.int32); nl = np.zeros(nimg, np.int32)
@@ -402,7 +404,7 @@ def _tri_scene():
         a, b = len(kl), len(kr)
         kps[i, :a] = kl; kps[i, a:a + b] = kr; desc[i, :a] = dl; desc[i, a:a + b] = dr; cnt[i] = a + b; nl[i] = a
     has = (rng.random((nimg, cap)) < 0.3).astype(np.uint8)
-    return dict(P=P, sf=sf, poses=poses, Trl=Trl_m, kps=kps, desc=desc, cnt=cnt, nl=nl, has=has, cap=cap, nimg=nimg)
+    return dict(P=P, sf=sf, poses=poses, Trl=Trl_m, kps=kps, desc=desc, cnt=cnt, nl=nl, has=has, cap=cap, nimg=nimg, Xw=Xw, base=base, vis=vis)
 
 
 def test_search_for_triangulation_fisheye():
@@ -453,6 +455,66 @@ def test_search_for_triangulation_fisheye():
     assert int(nm.sum()) == 0 and int((m12 >= 0).sum()) == 0
 
 
+def _fuse_rig_problem(S, b, right, seed):
+    """Map points of the cloud offered to keyframe b's left / right camera: pose, centre, per-point normal / distance range."""
+    from morb_slam_amd.synth import _quat_from_R
+    rng = np.random.default_rng(seed)
+    T = (S["Trl"] @ S["poses"][b]) if right else S["poses"][b]
+    T7 = np.concatenate([_quat_from_R(T[:3, :3]), T[:3, 3]]).astype(np.float32)
+    Ow = (-(T[:3, :3].T @ T[:3, 3])).astype(np.float32)
+    Xw = S["Xw"].astype(np.float32); M = len(Xw)
+    PO = Xw - Ow
+    dist = np.linalg.norm(PO, axis=1)
+    normal = PO / dist[:, None] + rng.normal(0, 0.25, (M, 3))
+    normal[rng.random(M) < 0.05] *= -1                                   # seen from behind: rejected by the 60 degree test
+    lvl = rng.integers(0, 8, M)
+    idx, sel, oc = S["vis"][b][1 if right else 0]
+    lvl[idx] = np.clip(oc + rng.integers(0, 2, len(idx)), 0, 7)          # PredictScale lands on the feature's octave or one above
+    maxD = (dist * 1.2 ** (lvl - rng.uniform(0.05, 0.95, M))).astype(np.float32)   # ceil(log(maxD / dist) / log 1.2) = lvl
+    minD = (maxD / 1.2 ** 7 * 0.8).astype(np.float32)
+    far = rng.random(M) < 0.04
+    minD[far] = (dist[far] * 2).astype(np.float32)                        # outside the scale pyramid
+    mpd = S["base"] ^ np.packbits(rng.random((M, 256)) < 0.03, axis=1)
+    valid = (rng.random(M) < 0.93).astype(np.uint8)
+    return dict(T7=T7, Ow=Ow, Xw=Xw, normal=normal.astype(np.float32), maxD=maxD, minD=minD, mpd=mpd, valid=valid)
+
+
+def test_fuse_on_a_rig_matches_oracle():
+    """Fuse(pKF, vpMapPoints, th, bRight) on a KannalaBrandt8 rig keyframe, both sides (ORBmatcher.cc:1044-1213: the side's pose, camera,
+    grid and keypoints; the returned index counts from the start of the left | right row): morb_fuse_batch with cam8 and a feature range."""
+    import torch
+    from morb_slam_amd import ORBmatcher
+    from morb_slam_amd.synth import TUMVI_CAM_L, TUMVI_CAM_R
+    S = _tri_scene()
+    P, sf, kps, desc, cnt, nl = (S[k] for k in ("P", "sf", "kps", "desc", "cnt", "nl"))
+    invS = (1.0 / (sf * sf)).astype(np.float32)
+    cu = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    m = ORBmatcher(0.6, True)
+    dk, dd, dc = cu(kps.view(np.uint8).reshape(S["nimg"], S["cap"], 28)), cu(desc), cu(cnt)
+    tot = 0
+    for b in (1, 2):
+        N = int(cnt[b])
+        Fo = O.make_frame(P, kps[b, :N], desc[b, :N], None)
+        for right in (False, True):
+            pr = _fuse_rig_problem(S, b, right, 50 + 2 * b + right)
+            M = len(pr["Xw"])
+            lo, hi = (int(nl[b]), N) if right else (0, int(nl[b]))
+            one = lambda a: cu(np.asarray(a)[None])
+            for th in (3.0, 6.0):
+                bi, bd = m.Fuse(P, cu(np.array([b], np.int32)), dk, dd, dc, None, one(pr["T7"]), one(pr["Ow"]), cu(np.array([M], np.int32)),
+                                one(pr["valid"]), one(pr["Xw"]), one(pr["normal"]), one(pr["maxD"]), one(pr["minD"]), one(pr["mpd"]), th=th,
+                                cam8=TUMVI_CAM_R if right else TUMVI_CAM_L, jLo=cu(np.array([lo], np.int32)), jHi=cu(np.array([hi], np.int32)))
+                torch.cuda.synchronize()
+                ei, ed = O.fuse_search_rig(Fo, int(nl[b]), right, TUMVI_CAM_R if right else TUMVI_CAM_L, invS, pr["T7"], pr["Ow"], pr["valid"], pr["Xw"],
+                                           pr["normal"], pr["maxD"], pr["minD"], pr["mpd"], th)
+                np.testing.assert_array_equal(bi[0].cpu().numpy(), ei)
+                np.testing.assert_array_equal(bd[0].cpu().numpy(), ed)
+                hit = ei[ei >= 0]
+                assert len(hit) > 60 and ((hit >= nl[b]) == right).all()      # the side's features only
+                tot += len(hit)
+    assert tot > 800
+
+
 def _mul_f32(A, B):
     """(R, t) of A * B composed in float32 left to right, as tests/native/mock_ref's SE3f does (no FMA: products rounded, then summed)."""
     A = np.asarray(A, np.float32); B = np.asarray(B, np.float32)
@@ -497,6 +559,11 @@ def test_search_for_triangulation_rig_through_the_reference_member(tmp_path):
     put("rig_cams", np.concatenate([TUMVI_CAM_L, TUMVI_CAM_R]).astype(np.float32))
     ori, coarse = True, False
     put("rig_cfg", np.array([0.6, ori, 0, coarse, nl[a], nl[b]], np.float32))
+    fuse = {}
+    for right, t in ((False, "rigf_l"), (True, "rigf_r")):   # Fuse(pKF = keyframe b, cloud points, 3.0, bRight)
+        pr = fuse[right] = _fuse_rig_problem(S, b, right, 90 + right)
+        put(t + "_pos", pr["Xw"]); put(t + "_normal", pr["normal"]); put(t + "_maxd", pr["maxD"]); put(t + "_mind", pr["minD"]); put(t + "_desc", pr["mpd"])
+        put(t + "_valid", pr["valid"]); put(t + "_pose", np.concatenate([pr["T7"], pr["Ow"]]).astype(np.float32))
     out = subprocess.run([_build(tmp_path, "reference_members_check.cc", mock_ref=True), str(d), "rig"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "reference members (rig) ok" in out.stdout, out.stdout + out.stderr
     T4 = np.stack([_mul_f32(four[0], four[2]), _mul_f32(four[0], four[3]), _mul_f32(four[1], four[2]), _mul_f32(four[1], four[3])])
@@ -512,6 +579,18 @@ def test_search_for_triangulation_rig_through_the_reference_member(tmp_path):
             assert ne > 80 and ((exp[:, 0] < nl[a]) != (exp[:, 1] < nl[b])).sum() > 5      # left-right pairs too
         else:
             assert ne == 0
+    Fo = O.make_frame(S["P"], kps[b, :nb], desc[b, :nb], None)
+    invS = (1.0 / (sf * sf)).astype(np.float32)
+    for right, t in ((False, "rigf_l"), (True, "rigf_r")):
+        pr = fuse[right]
+        ei, _ = O.fuse_search_rig(Fo, int(nl[b]), right, TUMVI_CAM_R if right else TUMVI_CAM_L, invS, pr["T7"], pr["Ow"], pr["valid"], pr["Xw"], pr["normal"],
+                                  pr["maxD"], pr["minD"], pr["mpd"], 3.0)
+        slots = np.full(nb, -1, np.int32)    # a free feature ends up holding the first point that chose it; one that had a point keeps it (Replace)
+        for i in range(len(ei) - 1, -1, -1):
+            if ei[i] >= 0 and not has[b, ei[i]]:
+                slots[ei[i]] = i
+        np.testing.assert_array_equal(np.fromfile(str(d / ("out_ref_" + t + "_slots.bin")), np.int32), slots)
+        assert int(np.fromfile(str(d / ("out_ref_" + t + "_n.bin")), np.int32)[0]) == int((ei >= 0).sum()) > 60
 
 
 def test_c3_chain_on_extracted_features():
