@@ -5,10 +5,12 @@
 // from the objects (reference_glue.h), calls the view-taking overload / the C ABI, and writes the result back the way the reference's
 // method does (cited per member).  See reference_glue.h for what has and has not been compiled.
 //
-// KannalaBrandt8 rigs (Frame::Nleft != -1 / KeyFrame::NLeft != -1): the per-frame tracking searches and CreateNewMapPoints' search dispatch to the *_fisheye entry
-// points of morb_hip.h — SearchByProjection(F, vpMapPoints), SearchByProjection(Cur, Last), SearchByBoW(pKF, F), SearchForTriangulation, Fuse(pKF, vpMapPoints, th, bRight) — the remaining members
-// throw std::runtime_error on a rig rather than silently running the pinhole form (their fisheye kernels exist behind the C ABI:
-// morb_search_for_triangulation_fisheye_batch, ...; INTEGRATION.md section 3 shows the call).
+// KannalaBrandt8 rigs (Frame::Nleft != -1 / KeyFrame::NLeft != -1): every member in which the reference has a rig branch dispatches to the rig form
+// behind the C ABI — SearchByProjection(F, vpMapPoints), SearchByProjection(Cur, Last), SearchByBoW(pKF, F), SearchByBoW(pKF1, pKF2) (the
+// mvKeysUn.size() bound, :734), SearchForTriangulation, Fuse(pKF, vpMapPoints, th, bRight).  The members in which the reference has NO rig branch
+// (relocalisation's SearchByProjection(Frame, KeyFrame), SearchForInitialization, and loop closing's SearchBySim3, SearchByProjection(pKF, Scw, ...) x 2,
+// Fuse(pKF, Scw, ...)) would there run the left KannalaBrandt8 camera over mvKeysUn and, in two of them, read mvKeysUn[i] past its NLeft entries
+// (:1807 with i < N): these throw std::runtime_error on a rig instead of running the pinhole projection silently.
 #pragma once
 #include <set>
 
@@ -16,7 +18,7 @@
 
 namespace ORB_SLAM3 {
 
-#define MORB_NO_RIG(cond, what) do { if (cond) throw std::runtime_error(what ": KannalaBrandt8 rig — use the *_fisheye entry point (INTEGRATION.md section 3)"); } while (0)
+#define MORB_NO_RIG(cond, what) do { if (cond) throw std::runtime_error(what ": not built for a KannalaBrandt8 rig (the reference has no rig branch in this member; ORBmatcher_reference.h)"); } while (0)
 
 // static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b)  ORBmatcher.cc:1880-1894
 template <class Mat, class>
@@ -168,6 +170,7 @@ template <class KF, class Sim3, class MP>
 int ORBmatcher::sim3_projection_ref(KF* pKF, Sim3& Scw, const std::vector<MP*>& vpPoints, const std::vector<KF*>* vpPointsKFs, std::vector<MP*>& vpMatched,
                                     std::vector<KF*>* vpMatchedKF, int th, float ratioHamming) {
   using SE3 = typename std::decay<decltype(pKF->GetPose())>::type;
+  MORB_NO_RIG(pKF->NLeft != -1, "SearchByProjection(KeyFrame, Sim3)");
   morb_glue::Store<KeyFrameView> kf;
   morb_glue::keyframe_view(kf, pKF);
   Sim3View sv;
@@ -374,6 +377,7 @@ int ORBmatcher::Fuse(KF* pKF, const std::vector<MP*>& vpMapPoints, const float t
 template <class KF, class Sim3, class MP>
 int ORBmatcher::Fuse(KF* pKF, Sim3& Scw, const std::vector<MP*>& vpPoints, float th, std::vector<MP*>& vpReplacePoint) {
   using SE3 = typename std::decay<decltype(pKF->GetPose())>::type;
+  MORB_NO_RIG(pKF->NLeft != -1, "Fuse(KeyFrame, Sim3)");
   morb_glue::Store<KeyFrameView> kf;
   morb_glue::keyframe_view(kf, pKF);
   Sim3View sv;
