@@ -168,8 +168,12 @@ int Optimizer::PoseInertialOptimizationLastFrame(FrameT* pFrame, bool bRecInit) 
   write_back_inertial(pFrame, v);
   pFrame->mImuBias = Bias(v.state[18], v.state[19], v.state[20], v.state[15], v.state[16], v.state[17]);   // :5078-5080
   pFrame->mpcpi = morb_glue::prior_from_doubles<CPI>(v.prior);                                        // :5150-5152
-  delete pFp->mpcpi;                                                                                  // :5157-5158
-  pFp->mpcpi = NULL;
+  static CPI* oldMpcpi = nullptr;                                                                     // :4759, :5153-5159: the fork's guard against freeing the same
+  if (oldMpcpi != pFp->mpcpi) {                                                                       // address twice ("SAME MPCPI": nothing is deleted, the pointer stays)
+    oldMpcpi = pFp->mpcpi;
+    delete pFp->mpcpi;
+    pFp->mpcpi = NULL;
+  }
   fe.outlier = v.mvbOutlier; fe.write_outliers(pFrame);
   return nin;
 }

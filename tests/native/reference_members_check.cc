@@ -3,7 +3,7 @@
 // SAME input files matcher_adapters_check.cc / adapters_check.cc read, and dumps what they leave in the objects as index tables
 // (out_ref_*).  tests/test_adapter_matcher_gpu.py / test_adapter_gpu.py require out_ref_* == out_* (the view-taking adapters' results, which they
 // compare with the oracle): the gather and write-back code of ORBmatcher_reference.h / Optimizer_reference.h is thereby checked end to end.
-//   reference_members_check <dir> matcher|tracking|rig
+//   reference_members_check <dir> matcher|tracking|rig|inertial
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -321,6 +321,77 @@ static int run_rig() {
   return 0;
 }
 
+// Optimizer::PoseInertialOptimizationLastKeyFrame(Frame*) then PoseInertialOptimizationLastFrame(Frame*) on the next frame (Tracking.cc:3032-3041):
+// keyframe -> frame A (its mpcpi comes out of the first call) -> frame B (mpPrevFrame = A).  Dumps, per frame: the IMU state written back
+// (SetImuPoseVelocity + mImuBias, 21 floats), mvbOutlier, the return value, mpcpi as 246 doubles.
+static void fill_pre(IMU::Preintegrated& P, const float* r) {   // the record of morb_hip.h (310 floats) -> the mock IMU::Preintegrated
+  auto m3 = [&](Eigen::Matrix3f& M) { for (int k = 0; k < 9; ++k) M.m[k] = *r++; };
+  auto v3 = [&](Eigen::Vector3f& V) { for (int k = 0; k < 3; ++k) V.v[k] = *r++; };
+  P.dT = *r++;
+  m3(P.dR); v3(P.dV); v3(P.dP); m3(P.JRg); m3(P.JVg); m3(P.JVa); m3(P.JPg); m3(P.JPa);
+  for (int k = 0; k < 225; ++k) P.C.m[k] = *r++;
+  P.b = IMU::Bias(r[0], r[1], r[2], r[3], r[4], r[5]); r += 6;
+  for (int k = 0; k < 6; ++k) P.Nga.d.v[k] = *r++;
+  for (int k = 0; k < 6; ++k) P.NgaWalk.d.v[k] = *r++;
+  v3(P.avgA); v3(P.avgW);
+}
+template <class F> static void set_state(F& f, const float* s) {   // Rwb (9), twb, velocity; the biases: gyro (3), acc (3)
+  for (int k = 0; k < 9; ++k) f.mRwb.m[k] = s[k];
+  for (int k = 0; k < 3; ++k) { f.mOwb.v[k] = s[9 + k]; f.mVw.v[k] = s[12 + k]; }
+  f.mImuBias = IMU::Bias(s[18], s[19], s[20], s[15], s[16], s[17]);
+}
+static void fill_visual(Frame& F, const std::string& t) {
+  const auto has = load<uint8_t>(t + "_has"), close = load<uint8_t>(t + "_close"); const auto obs = load<float>(t + "_obs"), inv = load<float>(t + "_inv"), Xw = load<float>(t + "_xw");
+  const int N = (int)has.size();
+  F.N = N; F.mvKeysUn.resize(N); F.mvuRight.resize(N); F.mvInvLevelSigma2.resize(N); F.mvpMapPoints.assign(N, static_cast<MapPoint*>(NULL)); F.mvbOutlier.assign(N, true);
+  for (int i = 0; i < N; ++i) {
+    F.mvKeysUn[i].pt.x = obs[3 * i]; F.mvKeysUn[i].pt.y = obs[3 * i + 1]; F.mvuRight[i] = obs[3 * i + 2];
+    F.mvKeysUn[i].octave = i; F.mvInvLevelSigma2[i] = inv[i];   // (mock: one "octave" per feature so that any 1 / sigma^2 can be carried)
+    if (has[i]) { F.mvpMapPoints[i] = new_point(&Xw[3 * i], nullptr, 1.f, 1.f, 1); F.mvpMapPoints[i]->mTrackDepth = close[i] ? 5.f : 20.f; }
+  }
+}
+static void dump_frame(Frame& F, const std::string& t, int nin) {
+  float st[21];
+  for (int k = 0; k < 9; ++k) st[k] = F.mRwb.m[k];
+  for (int k = 0; k < 3; ++k) { st[9 + k] = F.mOwb.v[k]; st[12 + k] = F.mVw.v[k]; }
+  st[15] = F.mImuBias.bwx; st[16] = F.mImuBias.bwy; st[17] = F.mImuBias.bwz; st[18] = F.mImuBias.bax; st[19] = F.mImuBias.bay; st[20] = F.mImuBias.baz;
+  std::vector<uint8_t> outl(F.N);
+  for (int i = 0; i < F.N; ++i) outl[i] = (F.mvpMapPoints[i] && F.mvbOutlier[i]) ? 1 : 0;
+  double pr[246] = {0};
+  if (F.mpcpi) {
+    const ConstraintPoseImu& c = *F.mpcpi;
+    for (int k = 0; k < 9; ++k) pr[k] = c.Rwb.m[k];
+    for (int k = 0; k < 3; ++k) { pr[9 + k] = c.twb.v[k]; pr[12 + k] = c.vwb.v[k]; pr[15 + k] = c.bg.v[k]; pr[18 + k] = c.ba.v[k]; }
+    for (int k = 0; k < 225; ++k) pr[21 + k] = c.H.m[k];
+  }
+  dump(t + "_state", st, 21); dump(t + "_outlier", outl.data(), outl.size()); dump(t + "_n", &nin, 1); dump(t + "_prior", pr, 246);
+}
+static int run_inertial() {
+  const auto cam = load<float>("vi_cam");   // fx fy cx cy bf
+  const auto tbc = load<float>("vi_tbc");   // rotation (9) + translation (3)
+  Frame::fx = cam[0]; Frame::fy = cam[1]; Frame::cx = cam[2]; Frame::cy = cam[3];
+  IMU::Preintegrated preA, preBF, preBK;
+  fill_pre(preA, load<float>("vi_a_pre").data()); fill_pre(preBF, load<float>("vi_b_pref").data()); fill_pre(preBK, load<float>("vi_b_prek").data());
+  KeyFrame kf;
+  { const auto s = load<float>("vi_kf_state"); set_state(kf, s.data()); }
+  auto calib = [&](Frame& F) { F.mbf = cam[4]; for (int k = 0; k < 9; ++k) F.mImuCalib.mTbc.R[k] = tbc[k]; for (int k = 0; k < 3; ++k) F.mImuCalib.mTbc.t[k] = tbc[9 + k]; };
+  Frame A; fill_visual(A, "vi_a"); calib(A);
+  { const auto s = load<float>("vi_a_state0"); set_state(A, s.data()); }
+  A.mpLastKeyFrame = &kf; A.mpImuPreintegrated = &preA;
+  const int nA = Optimizer::PoseInertialOptimizationLastKeyFrame(&A);
+  dump_frame(A, "vi_a", nA);
+  Frame B; fill_visual(B, "vi_b"); calib(B);
+  { const auto s = load<float>("vi_b_state0"); set_state(B, s.data()); }
+  B.mpLastKeyFrame = &kf; B.mpPrevFrame = &A; B.mpImuPreintegratedFrame = &preBF; B.mpImuPreintegrated = &preBK;
+  const int nB = Optimizer::PoseInertialOptimizationLastFrame(&B);
+  dump_frame(B, "vi_b", nB);
+  const int freed = A.mpcpi == nullptr ? 1 : 0;   // :5157-5158: the previous frame's prior is deleted
+  dump("vi_a_freed", &freed, 1);
+  dump_frame(A, "vi_a_after", nA);   // LastFrame does not write the previous frame back (its vertices are only read, :5144-5149)
+  std::printf("reference members (inertial) ok\n");
+  return 0;
+}
+
 static int run_tracking() {
   {   // int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bFarPoints, const float thFarPoints)
     // after the host's isInFrustum loop (Tracking.cc:3117-3183): here that loop's results come from morb_is_in_frustum_batch
@@ -435,5 +506,5 @@ int main(int argc, char** argv) {
   if (argc < 3) return 2;
   g_dir = argv[1];
   const std::string mode = argv[2];
-  return mode == "matcher" ? run_matcher() : mode == "rig" ? run_rig() : run_tracking();
+  return mode == "matcher" ? run_matcher() : mode == "rig" ? run_rig() : mode == "inertial" ? run_inertial() : run_tracking();
 }

@@ -349,3 +349,57 @@ def test_local_inertial_ba_variants(opt):
     kf, mp, er = run(p)
     p = make_inertial_ba_problem(n_opt=1, n_fixed_vis=3, seed=14, n_points=300)
     run(p)
+
+
+def test_reference_typed_pose_inertial_members(opt, tmp_path):
+    """Optimizer::PoseInertialOptimizationLastKeyFrame(Frame*) and ...LastFrame(Frame*) of include/morb/Optimizer.h — the reference's
+    signatures (include/Optimizer.h:125-128) — driven with mock Frame / KeyFrame / IMU::Preintegrated / ConstraintPoseImu objects
+    (tests/native/reference_members_check.cc `inertial`): keyframe -> frame A -> frame B as Tracking.cc:3032-3041 calls them.  What they
+    leave in the frames (SetImuPoseVelocity, mImuBias, mvbOutlier, mpcpi) equals the batched C ABI's result on the same inputs (compared
+    with the oracle by the tests above) bit for bit, and the previous frame's prior is freed (Optimizer.cc:5153-5159)."""
+    import os
+    import subprocess
+    from morb_slam_amd.synth import make_inertial_sequence
+    from test_adapter_gpu import _build
+    dev = torch.device("cuda", 0)
+    pA, pB = make_inertial_sequence(400, seed=5, n_imu=20)
+    nga, walk = imu_calib_diagonals()
+    pre = lambda p, a, g, d: orc.imu_preintegrate(p["bias"], nga, walk, p[a], p[g], p[d])
+    preA, preBF, preBK = pre(pA, "acc", "gyro", "dt"), pre(pB, "accF", "gyroF", "dtF"), pre(pB, "acc", "gyro", "dt")
+    d = tmp_path / "io"
+    d.mkdir()
+    put = lambda name, a: np.ascontiguousarray(a).tofile(str(d / (name + ".bin")))
+    cam = pA["cam"]
+    put("vi_cam", np.array([cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["bf"]], np.float32)); put("vi_tbc", np.asarray(pA["Tbc12"], np.float32))
+    put("vi_kf_state", pA["kfState"]); put("vi_a_pre", preA); put("vi_b_pref", preBF); put("vi_b_prek", preBK)
+    for t, p in (("vi_a", pA), ("vi_b", pB)):
+        put(t + "_has", p["hasMP"]); put(t + "_close", p["close"]); put(t + "_obs", p["obs"]); put(t + "_inv", p["invSigma2"]); put(t + "_xw", p["Xw"])
+        put(t + "_state0", p["state0"])
+    out = subprocess.run([_build(tmp_path, "reference_members_check.cc", mock_ref=True), str(d), "inertial"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "reference members (inertial) ok" in out.stdout, out.stdout + out.stderr
+    get = lambda name, dt: np.fromfile(str(d / ("out_ref_" + name + ".bin")), dtype=dt)
+    one = lambda a: torch.from_numpy(np.ascontiguousarray(a)[None]).to(dev)
+    # frame A through the batched entry point
+    stA = one(pA["state0"]).clone()
+    ninA, outA, priA = opt.PoseInertialOptimizationLastKeyFrame(one(pA["hasMP"]), one(pA["obs"]), one(pA["invSigma2"]), one(pA["Xw"]), one(pA["close"]), cam,
+                                                                pA["Tbc12"], one(pA["kfState"]), one(preA), stA)
+    torch.cuda.synchronize()
+    assert get("vi_a_state", np.float32).tobytes() == stA[0].cpu().numpy().tobytes()
+    np.testing.assert_array_equal(get("vi_a_outlier", np.uint8), outA[0].cpu().numpy() & pA["hasMP"])
+    assert int(get("vi_a_n", np.int32)[0]) == int(ninA[0]) > 200
+    assert get("vi_a_prior", np.float64).tobytes() == priA[0].cpu().numpy().tobytes()
+    # frame B: previous state and prior = what the member left in frame A
+    stB = one(pB["state0"]).clone()
+    ninB, outB, priB = opt.PoseInertialOptimizationLastFrame(one(pB["hasMP"]), one(pB["obs"]), one(pB["invSigma2"]), one(pB["Xw"]), one(pB["close"]), cam, pB["Tbc12"],
+                                                             stA.clone(), one(preBF), one(preBK), priA.clone(), stB)
+    torch.cuda.synchronize()
+    assert get("vi_b_state", np.float32).tobytes() == stB[0].cpu().numpy().tobytes()
+    np.testing.assert_array_equal(get("vi_b_outlier", np.uint8), outB[0].cpu().numpy() & pB["hasMP"])
+    assert int(get("vi_b_n", np.int32)[0]) == int(ninB[0]) > 200
+    assert get("vi_b_prior", np.float64).tobytes() == priB[0].cpu().numpy().tobytes()
+    assert int(get("vi_a_freed", np.int32)[0]) == 1
+    assert get("vi_a_after_state", np.float32).tobytes() == get("vi_a_state", np.float32).tobytes()   # the previous frame is not written back
+    # and the oracle on the same chain (1e-4, as above)
+    rA, sA, _, prA = orc.pose_inertial_optimization_last_keyframe(pA, preA)
+    rB, sB, _, _ = orc.pose_inertial_optimization_last_frame(pB, sA, preBF, preBK, prA)
+    assert np.allclose(get("vi_b_state", np.float32), sB, atol=1e-4) and int(get("vi_b_n", np.int32)[0]) == rB
