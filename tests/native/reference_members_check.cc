@@ -3,7 +3,7 @@
 // SAME input files matcher_adapters_check.cc / adapters_check.cc read, and dumps what they leave in the objects as index tables
 // (out_ref_*).  tests/test_adapter_matcher_gpu.py / test_adapter_gpu.py require out_ref_* == out_* (the view-taking adapters' results, which they
 // compare with the oracle): the gather and write-back code of ORBmatcher_reference.h / Optimizer_reference.h is thereby checked end to end.
-//   reference_members_check <dir> matcher|tracking|rig|inertial
+//   reference_members_check <dir> matcher|tracking|rig|inertial|iba
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -392,6 +392,65 @@ static int run_inertial() {
   return 0;
 }
 
+// void Optimizer::LocalInertialBA(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int&, int&, int&, int&, bool bLarge, bool bRecInit): the flattened graph of
+// the test rebuilt as mock objects — the temporal chain through mPrevKF (keyframe 0 = the fixed one before the window), IMU::Preintegrated per link,
+// a keyframe's features = its edges — so that the member's own selection (Optimizer.cc:2337-2435) finds the same graph in its own order.
+static int run_iba() {
+  const auto st = load<float>("iba_kf_state"); const auto kind = load<uint8_t>("iba_kf_kind"); auto mpp = load<float>("iba_mp_pos"); const auto mpc = load<uint8_t>("iba_mp_close");
+  const auto eKF = load<int>("iba_e_kf"), eMP = load<int>("iba_e_mp"); const auto eObs = load<float>("iba_e_obs"), eInv = load<float>("iba_e_inv");
+  const auto iKF2 = load<int>("iba_i_kf2"); const auto iPre = load<float>("iba_i_pre"); const auto cam = load<float>("iba_cam"), tbc = load<float>("iba_tbc");
+  const auto cfg = load<int>("iba_cfg");   // bLarge, bRecInit
+  const int nKF = (int)kind.size(), nMP = (int)mpc.size(), nE = (int)eKF.size(), nI = (int)iKF2.size();
+  int nOpt = 0; for (int k = 0; k < nKF; ++k) nOpt += kind[k] == 0 ? 1 : 0;
+  Map map; map.initKF = 1u << 30; map.nKFs = (unsigned long)nOpt + 2; map.inertial = true;
+  std::vector<std::unique_ptr<KeyFrame>> kfs(nKF);
+  std::vector<std::unique_ptr<IMU::Preintegrated>> pres(nI);
+  std::vector<MapPoint*> mps(nMP);
+  for (int j = 0; j < nMP; ++j) { mps[j] = new_point(&mpp[3 * j], nullptr, 1.f, 1.f, 0); mps[j]->mpMap = &map; mps[j]->mnId = (unsigned long)j + 1; mps[j]->mTrackDepth = mpc[j] ? 5.f : 20.f; }
+  std::vector<int> featOfEdge(nE, -1);
+  for (int k = 0; k < nKF; ++k) {
+    kfs[k].reset(new KeyFrame());
+    KeyFrame& K = *kfs[k];
+    K.mnId = (unsigned long)k + 1; K.mpMap = &map; K.fx = cam[0]; K.fy = cam[1]; K.cx = cam[2]; K.cy = cam[3]; K.mbf = cam[4];
+    set_state(K, &st[(size_t)21 * k]); K.bImu = kind[k] != 2;
+    for (int i = 0; i < 9; ++i) K.mImuCalib.mTbc.R[i] = tbc[i];
+    for (int i = 0; i < 3; ++i) K.mImuCalib.mTbc.t[i] = tbc[9 + i];
+    for (int e = 0; e < nE; ++e) {
+      if (eKF[e] != k) continue;
+      const int f = (int)K.mvKeysUn.size();
+      featOfEdge[e] = f;
+      cv::KeyPoint kp; kp.pt.x = eObs[3 * e]; kp.pt.y = eObs[3 * e + 1]; kp.octave = f;
+      K.mvKeysUn.push_back(kp); K.mvuRight.push_back(eObs[3 * e + 2]); K.mvInvLevelSigma2.push_back(eInv[e]);
+      K.mvpMapPoints.push_back(mps[eMP[e]]);
+      mps[eMP[e]]->mObservations[&K] = std::make_tuple(f, -1); mps[eMP[e]]->nObs++;
+    }
+    K.N = (int)K.mvKeysUn.size();
+  }
+  for (int i = 0; i < nI; ++i) {   // link i: keyframe iKF2[i] owns the preintegration since iKF2[i] - 1 (the chain is 0 -> 1 -> ... -> nOpt in time)
+    pres[i].reset(new IMU::Preintegrated()); fill_pre(*pres[i], &iPre[(size_t)310 * i]);
+    kfs[iKF2[i]]->mpImuPreintegrated = pres[i].get(); kfs[iKF2[i]]->mPrevKF = kfs[iKF2[i] - 1].get();
+  }
+  bool stop = false;
+  int num_fixedKF = 0, num_OptKF = 0, num_MPs = 0, num_edges = 0;
+  Optimizer::LocalInertialBA(kfs[nOpt].get(), &stop, &map, num_fixedKF, num_OptKF, num_MPs, num_edges, cfg[0] != 0, cfg[1] != 0);
+  std::vector<float> kfo((size_t)nKF * 21), mpo((size_t)nMP * 3);
+  for (int k = 0; k < nKF; ++k) {   // what the member wrote: SetPose(Tcw), SetVelocity, SetNewBias
+    const KeyFrame& K = *kfs[k];
+    float* o = &kfo[(size_t)21 * k];
+    for (int i = 0; i < 9; ++i) o[i] = K.mTcw.R[i];
+    for (int i = 0; i < 3; ++i) { o[9 + i] = K.mTcw.t[i]; o[12 + i] = K.mVw.v[i]; }
+    o[15] = K.mImuBias.bwx; o[16] = K.mImuBias.bwy; o[17] = K.mImuBias.bwz; o[18] = K.mImuBias.bax; o[19] = K.mImuBias.bay; o[20] = K.mImuBias.baz;
+  }
+  for (int j = 0; j < nMP; ++j) for (int i = 0; i < 3; ++i) mpo[3 * j + i] = mps[j]->mWorldPos(i);
+  std::vector<uint8_t> erased(nE);
+  for (int e = 0; e < nE; ++e) erased[e] = kfs[eKF[e]]->mvpMapPoints[featOfEdge[e]] == nullptr ? 1 : 0;
+  int flagsLeft = 0; for (int k = 0; k < nKF; ++k) flagsLeft += (kfs[k]->mnBALocalForKF != 0 || kfs[k]->mnBAFixedForKF != 0) ? 1 : 0;   // :2828-2831, :2845: reset on the way out
+  const int counts[7] = {num_fixedKF, num_OptKF, num_MPs, num_edges, map.changes, mps[0]->nUpdates, flagsLeft};
+  dump("iba_kf", kfo.data(), kfo.size()); dump("iba_mp", mpo.data(), mpo.size()); dump("iba_erase", erased.data(), erased.size()); dump("iba_counts", counts, 7);
+  std::printf("reference members (iba) ok\n");
+  return 0;
+}
+
 static int run_tracking() {
   {   // int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bFarPoints, const float thFarPoints)
     // after the host's isInFrustum loop (Tracking.cc:3117-3183): here that loop's results come from morb_is_in_frustum_batch
@@ -506,5 +565,5 @@ int main(int argc, char** argv) {
   if (argc < 3) return 2;
   g_dir = argv[1];
   const std::string mode = argv[2];
-  return mode == "matcher" ? run_matcher() : mode == "rig" ? run_rig() : mode == "inertial" ? run_inertial() : run_tracking();
+  return mode == "matcher" ? run_matcher() : mode == "rig" ? run_rig() : mode == "inertial" ? run_inertial() : mode == "iba" ? run_iba() : run_tracking();
 }

@@ -403,3 +403,56 @@ def test_reference_typed_pose_inertial_members(opt, tmp_path):
     rA, sA, _, prA = orc.pose_inertial_optimization_last_keyframe(pA, preA)
     rB, sB, _, _ = orc.pose_inertial_optimization_last_frame(pB, sA, preBF, preBK, prA)
     assert np.allclose(get("vi_b_state", np.float32), sB, atol=1e-4) and int(get("vi_b_n", np.int32)[0]) == rB
+
+
+def test_reference_typed_local_inertial_ba_member(opt, tmp_path):
+    """Optimizer::LocalInertialBA(KeyFrame*, bool*, Map*, int& x 4, bLarge, bRecInit) of include/morb/Optimizer.h (the reference's signature,
+    include/Optimizer.h:71-74) over a mock keyframe graph (tests/native/reference_members_check.cc `iba`): the member's own selection
+    (temporal window through mPrevKF, local points, fixed observers, Optimizer.cc:2337-2435) finds the test's graph in its own keyframe / point /
+    edge order; what it writes back (SetPose, SetVelocity, SetNewBias, SetWorldPos, the erased observations) agrees with morb_local_inertial_ba
+    on the test's arrays to the tolerance of the test above, the erased observations exactly."""
+    import subprocess
+    from morb_slam_amd.synth import make_inertial_ba_problem
+    from test_adapter_gpu import _build
+    nga, walk = imu_calib_diagonals()
+    p = make_inertial_ba_problem(n_opt=10, seed=1, n_points=900)
+    pre = np.stack([orc.imu_preintegrate(p["bias"], nga, walk, p["acc"][a:b], p["gyro"][a:b], p["dt"][a:b])
+                    for a, b in zip(p["imuStart"][:-1], p["imuStart"][1:])])
+    # the reference optimises the points seen by a keyframe of the temporal window (:2357-2371): keep those and their observations
+    optk = p["kfKind"] == 0
+    local = np.zeros(len(p["mpPos"]), bool); local[p["eMP"][optk[p["eKF"]]]] = True
+    remap = np.cumsum(local) - 1
+    keep = local[p["eMP"]]
+    q = dict(p, mpPos=p["mpPos"][local], mpClose=p["mpClose"][local], eKF=p["eKF"][keep], eMP=remap[p["eMP"][keep]].astype(np.int32),
+             eObs=p["eObs"][keep], eInvSigma2=p["eInvSigma2"][keep])
+    assert local.sum() > 600 and set(q["eKF"]) == set(range(len(p["kfKind"])))      # every fixed keyframe observes a local point
+    kf, mp, er, st = opt.LocalInertialBA(q["kfState"], q["kfKind"], q["mpPos"], q["mpClose"], q["eKF"], q["eMP"], q["eObs"], q["eInvSigma2"],
+                                         q["iKF1"], q["iKF2"], pre, q["iRobust"], q["iInfoScale"], q["cam"], q["Tbc12"], bLarge=False)
+    assert int(st[2]) == 1
+    d = tmp_path / "io"
+    d.mkdir()
+    put = lambda name, a: np.ascontiguousarray(a).tofile(str(d / (name + ".bin")))
+    cam = q["cam"]
+    put("iba_kf_state", q["kfState"]); put("iba_kf_kind", q["kfKind"]); put("iba_mp_pos", q["mpPos"]); put("iba_mp_close", q["mpClose"])
+    put("iba_e_kf", q["eKF"]); put("iba_e_mp", q["eMP"]); put("iba_e_obs", q["eObs"]); put("iba_e_inv", q["eInvSigma2"]); put("iba_i_kf2", q["iKF2"])
+    put("iba_i_pre", pre.astype(np.float32)); put("iba_cam", np.array([cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["bf"]], np.float32))
+    put("iba_tbc", np.asarray(q["Tbc12"], np.float32)); put("iba_cfg", np.array([0, 0], np.int32))
+    out = subprocess.run([_build(tmp_path, "reference_members_check.cc", mock_ref=True), str(d), "iba"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "reference members (iba) ok" in out.stdout, out.stdout + out.stderr
+    get = lambda name, dt: np.fromfile(str(d / ("out_ref_" + name + ".bin")), dtype=dt)
+    cnt = get("iba_counts", np.int32)
+    nfix = int((~optk).sum())
+    assert cnt.tolist() == [nfix, int(optk.sum()), int(local.sum()), int(keep.sum()), 1, 1, 0]
+    got = get("iba_kf", np.float32).reshape(-1, 21)
+    # Tcw = (Rcb Rwb^T, tcb - Rcb Rwb^T twb) of the optimised IMU states (:2836-2842), velocity, biases
+    Rbc, tbc = np.asarray(q["Tbc12"][:9], np.float64).reshape(3, 3), np.asarray(q["Tbc12"][9:], np.float64)
+    for k in np.nonzero(optk)[0]:
+        Rwb, twb = kf[k, :9].astype(np.float64).reshape(3, 3), kf[k, 9:12].astype(np.float64)
+        Rcw = Rbc.T @ Rwb.T; tcw = -Rbc.T @ tbc - Rcw @ twb
+        assert np.abs(got[k, :9].reshape(3, 3) - Rcw).max() <= 1e-4 and np.abs(got[k, 9:12] - tcw).max() <= 1e-4, k
+        assert np.abs(got[k, 12:] - kf[k, 12:]).max() <= 1e-4, k
+    mref = mp
+    dd = np.abs(get("iba_mp", np.float32).reshape(-1, 3) - mref).max(1) / np.maximum(1.0, np.linalg.norm(mref, axis=1))
+    assert dd.max() < 1e-4, dd.max()
+    np.testing.assert_array_equal(get("iba_erase", np.uint8), er)
+    assert er.sum() > 10
