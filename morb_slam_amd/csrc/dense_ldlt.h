@@ -112,8 +112,15 @@ __device__ bool ldlt_solve(const double* __restrict__ Hs, const double* b, doubl
   double* rdiag = dblk + NB * NBP;                       // [NB]: 1 / D
   double* dump = rdiag + NB;                             // [max(n, 64)]: a spare word per lane for the branch-free masked stores
   {   // one wave per row, coalesced reads of the row's lower part — EIGHT rows requested before the first is stored: a request per
-      // iteration (load, wait, store) made this phase 4.2 of the solver's 51 us at n = 120 (30 dependent L2 round trips per wave)
+      // iteration (load, wait, store) made this phase 4.2 of the solver's 51 us at n = 120 (30 dependent L2 round trips per wave).
+      // The zero fill of the panel copies and the right-hand side row go between the first batch's requests and its stores.
     constexpr int RB = 8, NP = 3;   // rows in flight, 64-column pieces per row (n <= 192)
+    auto fill = [&]() {
+      for (int i = tid; i < 2 * prow * NBP + NB * NBP; i += LT) pnlU[i] = 0.0;   // pnlU | pnlL (rows beyond m feed MFMA lanes whose results are dropped: keep them finite) | dblk
+    };
+    const int cb = tid <= n ? tid : n;   // (n + 1 <= LT)
+    const double bv = b[cb < n ? cb : 0];
+    bool filled = false;
     for (int r0 = wv; r0 < n; r0 += RB * (LT / 64)) {
       double v[RB][NP];
 #pragma unroll
@@ -125,19 +132,22 @@ __device__ bool ldlt_solve(const double* __restrict__ Hs, const double* b, doubl
           if (64 * q <= rc) v[k][q] = Hs[(size_t)rc * n + (c <= rc ? c : rc)];   // (piece-uniform test; clamped column: always a valid address)
         }
       }
+      if (!filled) { fill(); filled = true; }
 #pragma unroll
       for (int k = 0; k < RB; ++k) {
         const int r = r0 + k * (LT / 64);
+        if (r >= n) break;   // wave-uniform
+        double* rowp = L + tri(r, 0) + lane;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-          const int c = lane + 64 * q;
-          if (r < n && c <= r) L[tri(r, c)] = v[k][q];
+          if (64 * q + 63 <= r) rowp[64 * q] = v[k][q];                 // a whole piece: no lane test (wave-uniform branch)
+          else if (64 * q <= r && lane + 64 * q <= r) rowp[64 * q] = v[k][q];
         }
       }
     }
+    if (!filled) fill();
+    if (tid <= n) L[tri(n, tid)] = tid < n ? bv : 0.0;
   }
-  for (int c = tid; c <= n; c += LT) L[tri(n, c)] = c < n ? b[c] : 0.0;
-  for (int i = tid; i < 2 * prow * NBP + NB * NBP; i += LT) pnlU[i] = 0.0;   // pnlU | pnlL (rows beyond m feed MFMA lanes whose results are dropped: keep them finite) | dblk
   if (tid == 0) *sOk = 1;
   __syncthreads();
   LD_MARK(0);
@@ -286,13 +296,15 @@ __device__ bool ldlt_solve(const double* __restrict__ Hs, const double* b, doubl
           for (int qq = 0; qq <= q; ++qq) xr[qq] = __builtin_fma(-lrow[qq], xi, xr[qq]);
         };
         int i0 = top;
+        int rowOff = tri(top, 0);
         for (; i0 - (U - 1) >= base; i0 -= U) {   // eight rows of L requested, then the eight dependent steps
           double lv[U][NV];
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            const double* r = lp + tri(i0 - u, 0);
+            const double* r = lp + rowOff;
 #pragma unroll
             for (int qq = 0; qq <= q; ++qq) lv[u][qq] = r[64 * qq];
+            rowOff -= i0 - u;   // tri(i - 1, 0) = tri(i, 0) - i
           }
           asm volatile("" ::: "memory");   // (keeps the requests ahead of the steps: the compiler otherwise sinks each one to its use)
 #pragma unroll
@@ -300,9 +312,10 @@ __device__ bool ldlt_solve(const double* __restrict__ Hs, const double* b, doubl
         }
         for (; i0 >= base; --i0) {
           double lv[NV];
-          const double* r = lp + tri(i0, 0);
+          const double* r = lp + rowOff;
 #pragma unroll
           for (int qq = 0; qq <= q; ++qq) lv[qq] = r[64 * qq];
+          rowOff -= i0;
           step(i0, lv);
         }
       }
