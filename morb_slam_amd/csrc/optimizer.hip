@@ -1113,6 +1113,15 @@ __device__ void lm_decide(const BaDev& pb, double s0, double s1) {
   __hip_atomic_store(pb.lmHost + 1, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(pb.lmHost + 0, trials, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // decided trials: the host queues trial k + 2 when it sees k
 }
+// In-launch hand-off of partial sums to the workgroup that draws the last ticket (guide, guideline 16): the payload is stored write-through
+// at agent scope (sc1), the storing wave waits for its stores (s_waitcnt vmcnt(0)) and only then draws its ticket with a relaxed agent-scope
+// add; the last arriver reads every handed-off word at agent scope (load_l2).  No __threadfence(): on this chip an agent-scope release is a
+// write-back of the XCD's L2, and one per wave (k_g_build: 324 of them, beside the landmark half's stores) was ~8 of the kernel's 18 us.
+__device__ __forceinline__ void store_l2(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ int draw_ticket(int* counter) { return __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double load_l2(const double* p) {   // another workgroup of this launch wrote it: read at agent scope
   return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
@@ -1137,15 +1146,15 @@ __global__ __launch_bounds__(GB) void k_g_chi2(const BaDev* __restrict__ pbp, do
     s = huber(st ? (double)(float)sqrt(7.815) : (double)(float)sqrt(5.991), c, &w);
   }
   s = block_sum_d<4>(s, red);
-  if (threadIdx.x == 0) part[blockIdx.x] = s;
+  if (threadIdx.x == 0) store_l2(part + blockIdx.x, s);
   if (mode == 0) return;
   if (threadIdx.x == 0) {
-    __threadfence();
-    isLast = atomicAdd(&pb.lmi[LM_TICKET], 1) == (int)gridDim.x - 1;
+    wait_stores();
+    isLast = draw_ticket(&pb.lmi[LM_TICKET]) == (int)gridDim.x - 1;
   }
   __syncthreads();
   if (!isLast) return;
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (every handed-off word is read with load_l2)
   const int n = gridDim.x;
   double s0 = 0, s1 = 0;
   for (int i = threadIdx.x; i < n; i += GB) { s0 += load_l2(part + i); if (mode == 1) s1 += load_l2(part1 + i); }
@@ -1155,37 +1164,67 @@ __global__ __launch_bounds__(GB) void k_g_chi2(const BaDev* __restrict__ pbp, do
   pb.lmi[LM_TICKET] = 0;
   if (mode == 1) lm_decide(pb, s0, s1); else lm_init(pb, s0);
 }
+// The landmark blocks Hll / bl of map point m (block_solver.hpp:354-480 reads them): EIGHT lanes per point, one edge each and chunk by chunk
+// (a point has 5 - 8 observations here; a thread per point walked them one after the other: 20 of k_g_build's 23 us).  Each lane leaves its
+// edge's twelve contributions in the wave's LDS slice and the group's first lane adds them up IN EDGE ORDER — the sums are bit for bit those
+// of the serial walk.  Lanes of one wave only: no workgroup barrier.  -> max |diag Hll| of the point (first lane of the group; 0 elsewhere)
+constexpr int MP_LANES = 8;
 template <bool RIG>
-__device__ __forceinline__ double build_mp_point(const BaDev& pb, int m) {   // -> max |diag Hll| of the point
+__device__ __forceinline__ double build_mp_point(const BaDev& pb, int m, int sub, double* __restrict__ slot /* [MP_LANES][12] of the group */) {
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   double Hl[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
-  const double* X = pb.pt + 3 * m;
-  for (int k = pb.mpStart[m]; k < pb.mpStart[m + 1]; ++k) {
-    const int e = pb.mpEdges[k];
-    const SE3 T = load_se3(pb.pose + 7 * pb.eKF[e]);
-    double xc[3], err[3], w, R[9], Jl[9];
-    se3_map(T, X, xc);
-    const float* o = pb.eObs + 3 * e;
-    const bool st = !(o[2] < 0);
-    const double info = (double)pb.eInfo[e];
-    const double c = ba_edge_error(pb.cam, pb.rig, st, xc, o, info, err);
-    huber(st ? deltaStereo : deltaMono, c, &w);
-    q_to_R(T.q, R);
-    ba_edge_jac<RIG>(pb.cam, pb.rig, st, xc, o, R, nullptr, Jl);
-    const double wo = w * info;   // (mono edges: third Jacobian row and err[2] are zero, so the 3-row form is exact)
+  const bool live = m < pb.nMP;
+  const double* X = pb.pt + 3 * (live ? m : 0);
+  const int k0 = live ? pb.mpStart[m] : 0, k1 = live ? pb.mpStart[m + 1] : 0;
+  for (int kb = k0; kb < k1; kb += MP_LANES) {
+    const int k = kb + sub;
+    double c12[12];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      double sacc = 0;
-      _Pragma("unroll") for (int i = 0; i < 3; ++i) sacc += Jl[i * 3 + r] * (-info * err[i] * w);
-      bl[r] += sacc;
+    for (int q = 0; q < 12; ++q) c12[q] = 0;
+    if (k < k1) {
+      const int e = pb.mpEdges[k];
+      const SE3 T = load_se3(pb.pose + 7 * pb.eKF[e]);
+      double xc[3], err[3], w, R[9], Jl[9];
+      se3_map(T, X, xc);
+      const float* o = pb.eObs + 3 * e;
+      const bool st = !(o[2] < 0);
+      const double info = (double)pb.eInfo[e];
+      const double c = ba_edge_error(pb.cam, pb.rig, st, xc, o, info, err);
+      huber(st ? deltaStereo : deltaMono, c, &w);
+      q_to_R(T.q, R);
+      ba_edge_jac<RIG>(pb.cam, pb.rig, st, xc, o, R, nullptr, Jl);
+      const double wo = w * info;   // (mono edges: third Jacobian row and err[2] are zero, so the 3-row form is exact)
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc) {
-        double h = 0;
-        _Pragma("unroll") for (int i = 0; i < 3; ++i) h += Jl[i * 3 + r] * wo * Jl[i * 3 + cc];
-        Hl[r * 3 + cc] += h;
+      for (int r = 0; r < 3; ++r) {
+        double sacc = 0;
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) sacc += Jl[i * 3 + r] * (-info * err[i] * w);
+        c12[9 + r] = sacc;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          double h = 0;
+          _Pragma("unroll") for (int i = 0; i < 3; ++i) h += Jl[i * 3 + r] * wo * Jl[i * 3 + cc];
+          c12[r * 3 + cc] = h;
+        }
       }
     }
+#pragma unroll
+    for (int q = 0; q < 12; ++q) slot[sub * 12 + q] = c12[q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (sub == 0) {
+      const int cnt = k1 - kb < MP_LANES ? k1 - kb : MP_LANES;
+      for (int j = 0; j < cnt; ++j) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) Hl[q] += slot[j * 12 + q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bl[q] += slot[j * 12 + 9 + q];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // (the slice is rewritten by the next chunk)
   }
+  if (!live || sub != 0) return 0.0;
 #pragma unroll
   for (int k = 0; k < 9; ++k) pb.Hll[(size_t)m * 9 + k] = Hl[k];
 #pragma unroll
@@ -1240,7 +1279,7 @@ __device__ __forceinline__ void build_kf_chunk(const BaDev& pb, int c, int lane)
     double v = 0;
 #pragma unroll
     for (int q = 0; q < 27; ++q) if (q == lane) v = acc[q];
-    pb.kfPart[(size_t)c * 27 + lane] = v;
+    store_l2(pb.kfPart + (size_t)c * 27 + lane, v);
   }
 }
 // buildSystem in ONE launch (device-side LM control): workgroups [0, kfBlocks) take the keyframe chunks, the rest the map points;
@@ -1255,8 +1294,10 @@ __global__ __launch_bounds__(GB) void k_g_build(const BaDev* __restrict__ pbp, i
   const bool first = pb.lmi[LM_TRIALS] == 0;
   unsigned long long* maxDiag = reinterpret_cast<unsigned long long*>(pb.scal + 3);
   if ((int)blockIdx.x >= kfBlocks) {
-    const int m = (blockIdx.x - kfBlocks) * GB + threadIdx.x;
-    double dm = m < pb.nMP ? build_mp_point<RIG>(pb, m) : 0.0;
+    __shared__ double sMp[GB * 12];
+    const int g = threadIdx.x / MP_LANES, sub = threadIdx.x % MP_LANES;
+    const int m = (blockIdx.x - kfBlocks) * (GB / MP_LANES) + g;
+    double dm = build_mp_point<RIG>(pb, m, sub, sMp + (size_t)g * MP_LANES * 12);
     if (first) {
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) dm = fmax(dm, __shfl_xor(dm, off, 64));
@@ -1269,14 +1310,14 @@ __global__ __launch_bounds__(GB) void k_g_build(const BaDev* __restrict__ pbp, i
   build_kf_chunk<RIG>(pb, c, lane);
   const int kf = pb.chunkKF[c];
   int last = 0;
+  wait_stores();   // (the wave's partial sums have left for memory)
   if (lane == 0) {
-    __threadfence();
     const int nc = pb.kfChunkStart[kf + 1] - pb.kfChunkStart[kf];
-    last = atomicAdd(&pb.kfTicket[kf], 1) == nc - 1;
+    last = draw_ticket(&pb.kfTicket[kf]) == nc - 1;
     if (last) pb.kfTicket[kf] = 0;
   }
   if (!__builtin_amdgcn_readfirstlane(last)) return;
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (every handed-off word is read with load_l2)
   const int col = pb.kfCol[kf];
   if (lane >= 27) return;
   double s = 0;
@@ -1995,8 +2036,8 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
     constexpr int kAhead = 1;   // trials queued beyond the last decided one
     for (int slot = 0; slot < 100; ++slot) {
       // buildSystem (runs only when the previous trial was accepted): keyframe chunks and map points in one launch
-      if (h.rig) hipLaunchKernelGGL(k_g_build<true>, dim3(kfBlocks + div_up(h.nMP, GB)), dim3(GB), 0, st, d, kfBlocks);
-      else hipLaunchKernelGGL(k_g_build<false>, dim3(kfBlocks + div_up(h.nMP, GB)), dim3(GB), 0, st, d, kfBlocks);
+      if (h.rig) hipLaunchKernelGGL(k_g_build<true>, dim3(kfBlocks + div_up(h.nMP, GB / MP_LANES)), dim3(GB), 0, st, d, kfBlocks);
+      else hipLaunchKernelGGL(k_g_build<false>, dim3(kfBlocks + div_up(h.nMP, GB / MP_LANES)), dim3(GB), 0, st, d, kfBlocks);
       hipLaunchKernelGGL(k_g_dinv_push, dim3(rb > div_up(h.P * h.P, GB) ? rb : div_up(h.P * h.P, GB)), dim3(GB), 0, st, d, 0.0, h.HsG, 0, 1);
       hipLaunchKernelGGL(morbschur::k_schur_mfma, dim3(p->schur.nblk, p->schur.nsplit), dim3(64), 0, st, (const double*)h.sWD,
                          (const double*)h.sW, p->schur.Mp, p->schur.ksteps, p->schur.stepsPerSplit, h.sBlocks, h.sPart, (const int*)(h.lmi + LM_DONE));
