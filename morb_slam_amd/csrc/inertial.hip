@@ -1248,14 +1248,14 @@ __global__ __launch_bounds__(256) void k_iba_errors(IbaDev D, int mode) {
   }
   const double bs = block_sum(c);
   __shared__ int isLast;
-  if (threadIdx.x == 0) {
-    D.partChi[blockIdx.x] = bs;
-    __threadfence();
-    isLast = atomicAdd(&D.lmi[IBA_LM_TICKET], 1) == (int)gridDim.x - 1;
+  if (threadIdx.x == 0) {   // hand-off without __threadfence() (an L2 write-back per workgroup on this chip): write-through store, wait, relaxed ticket
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(D.partChi + blockIdx.x), __builtin_bit_cast(unsigned long long, bs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    isLast = __hip_atomic_fetch_add(&D.lmi[IBA_LM_TICKET], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
   }
   __syncthreads();
   if (!isLast || threadIdx.x >= 64) return;   // the last workgroup's first wave adds the partials up
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (ordered_sum_wave reads every handed-off word at agent scope)
   const double chi2 = ordered_sum_wave(D.partChi, (int)gridDim.x);
   const double gain = mode == 1 ? ordered_sum_wave(D.partScale, D.nbUpdate) : 0.0;   // k_iba_update's blocks
   if (threadIdx.x != 0) return;
@@ -1455,23 +1455,25 @@ __global__ __launch_bounds__(256) void k_iba_kf(IbaDev D) {
   // arrival order: the Hessian, and with it every iterate, would differ in the last bits from run to run).  Nothing else has touched the
   // keyframe's pose block yet — the links are launched afterwards — so the sum is stored with plain read-modify-writes.
   int first = c, end = c + 1, last = 0;
-  if (lane == 0) {
+  if (lane == 0) {   // (hand-off as in k_iba_errors: write-through stores, wait, relaxed ticket; the last arriver reads at agent scope)
 #pragma unroll
-    for (int q = 0; q < 27; ++q) D.kfPart[(size_t)c * 27 + q] = acc[q];
+    for (int q = 0; q < 27; ++q)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(D.kfPart + (size_t)c * 27 + q), __builtin_bit_cast(unsigned long long, acc[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (first > 0 && D.chunkKF[first - 1] == kf) --first;
     while (end < D.nChunks && D.chunkKF[end] == kf) ++end;
-    __threadfence();
-    last = atomicAdd(&D.kfTicket[kf], 1) == end - first - 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = __hip_atomic_fetch_add(&D.kfTicket[kf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == end - first - 1;
   }
   last = __builtin_amdgcn_readfirstlane(last);
   if (!last) return;
   first = __builtin_amdgcn_readfirstlane(first); end = __builtin_amdgcn_readfirstlane(end);
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (lane == 0) D.kfTicket[kf] = 0;
   if (lane < 27) {
     double sum = 0;
-    const double* part = D.kfPart + lane;   // (plain loads: the agent-scope fence above has dropped this CU's stale lines, nobody writes these again)
-    for (int j = first; j < end; ++j) sum += part[(size_t)j * 27];
+    const double* part = D.kfPart + lane;
+    for (int j = first; j < end; ++j)
+      sum += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(part + (size_t)j * 27), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     const int o = 15 * D.col[kf];
     if (lane >= 21) D.b[o + lane - 21] += sum;
     else {
