@@ -597,14 +597,14 @@ def main():
         nver = chain_check.verify_frames(fe, fe.last, sample, host_frames.view(2 * B, H, W).numpy())   # raises on the first difference
         verified = {"verified_frames": nver, "of_step": "last timed step", "frames": sample, "seconds": time.perf_counter() - tv,
                     "fields": ["keypoints", "descriptors", "mvuRight", "mvDepth", "bow_word", "bow_node", "SearchByBoW table", "nmatches"]}
-    # ---- sustained figure (never `value`): the same step for >= 2 s in 100-step windows; the headline's K steps fit inside one
+    # ---- sustained figure (never `value`): the same step for >= 2 s and >= 1000 steps in windows of <= 100 steps; the headline's K steps fit inside one
     # boost-clock burst, this does not
     sustained = None
     if world == 1 and rank == 0 and args.sustained_s > 0:
-        # windows of ~0.2 s (at least 10 steps, at most 100), at least 10 of them and at least --sustained-s seconds in all
+        # windows of ~0.2 s (at least 10 steps, at most 100), at least 10 of them, at least --sustained-s seconds and at least 1000 steps in all
         win = int(min(100, max(10, round(0.2 / max(dt / args.steps, 1e-6)))))
         wfps, wst, tot = [], [], 0.0
-        while tot < args.sustained_s or len(wfps) < 10:
+        while tot < args.sustained_s or len(wfps) < 10 or win * len(wfps) < 1000:   # >= 2 s AND >= 1000 steps
             tw = time.perf_counter()
             for _ in range(win):
                 step()

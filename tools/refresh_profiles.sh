@@ -15,7 +15,7 @@ for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INST
 done
 python3 tools/pmc_table.py "$O/pmc" > "$O/pmc_issue_table.txt"
 python3 tools/pmc_traffic.py "$O/pmc" 128 > "$O/pmc_traffic_b64.json"
-cp "$O/stats/s_kernel_stats.csv" "$O/extract_match_b256_kernel_stats.csv"
+cp "$O/stats/s_kernel_stats.csv" "$O/extract_match_b512_kernel_stats.csv"
 # FETCH_SIZE / WRITE_SIZE calibration on known byte counts
 bash tools/fetch_calib.sh calib_$R > /dev/null 2>&1; cp gpurun_out/calib_$R/fetch_calib.txt gpurun_out/calib_$R/fetch_calib.json "$O/" 2>/dev/null
 # the optimisers (secondary metrics): kernel stats of the tracking / mapping micro-benchmarks
@@ -26,6 +26,9 @@ rm -rf "$O/opt"
 { echo "== LocalBundleAdjustment (tools/bench_opt.py)"; bash tools/mfma_util.sh mfma_lba_$R tools/bench_opt.py; echo "== LocalInertialBA (tools/bench_iba.py)"; bash tools/mfma_util.sh mfma_iba_$R tools/bench_iba.py; } > "$O/mfma_schur.txt" 2>/dev/null
 bash tools/opt_prof.sh optprof_$R > "$O/localba_kernel_stats.txt" 2>/dev/null
 python3 tools/lba_sizes.py > "$O/localba_window_sizes.txt" 2>/dev/null
+# the dense LDL^T of the reduced camera system alone, with wave 0's phase clocks (n = 120: LocalBA C5, n = 150: LocalInertialBA with ten keyframes)
+{ hipcc --offload-arch=gfx950 -O3 -o /tmp/ldlt_phases tools/micro/ldlt_phases.hip 2>/dev/null && for n in 120 150 60; do /tmp/ldlt_phases $n; /tmp/ldlt_phases $n 1; done; } > "$O/ldlt_phases.txt" 2>/dev/null
+python3 tools/bench_iba.py 2>/dev/null | grep LocalInertialBA > "$O/local_inertial_ba_bench.txt"
 # this round's extra evidence: phase counts of k_fastw, stage times alone on the chip, quadtree phases (1 and 256 frames), single-frame latency
 python3 tools/fastw_stats.py 64 > "$O/k_fastw_phase_counts_b64.txt" 2>/dev/null
 python3 tools/fastw_cycles.py 256 2>/dev/null | grep -v amdgpu.ids > "$O/k_fastw_phase_cycles.txt"
