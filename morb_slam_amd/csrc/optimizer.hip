@@ -382,9 +382,31 @@ __device__ __forceinline__ bool ba_depth_positive(const Rig* rig, const float* o
 // near convergence rho = dChi2 / scale is ~0 and its sign — an LM decision — follows the last bits of those sums.  A strided partial sum per
 // thread + a tree gives other last bits (observed: one trial more or less in one of nine problems).  Edges are taken 256 at a time: every
 // thread writes its edge's 28 contributions to LDS (an inactive edge: exact zeros, which leave a floating-point sum unchanged), lanes 0 .. 27
-// of wave 0 add their entry's 256 values in order.  A chain of dependent FP64 additions per sum: 1.19 ms instead of 0.44 ms per 256 frames of
+// of wave 0 add their entry's 256 values in order.  A chain of dependent FP64 additions per sum: 0.68 ms instead of 0.43 ms per 256 frames of
 // 600 edges (tools/pose_opt_modes.py) — the deterministic MODE of the optimizer (morb_optimizer_set_exact_order), not its default.
 constexpr int PO_PITCH = 29;   // doubles per edge row of the contribution buffer (28 used)
+// tot + p[0] + p[STRIDE] + ... (m terms, m wave-uniform, added strictly in that order): sixteen LDS reads in flight, then their sixteen additions
+// — one read per addition made the chain ~100 cycles per term — and no test inside the full batches (a `if (e + k < m)` per addition, although
+// uniform, cost the lone wave four instruction slots per term instead of one); the reads of the last, partial batch stay inside the 256-row buffer
+template <int STRIDE>
+__device__ __forceinline__ double ordered_add(double tot, const double* __restrict__ p, int m) {
+  int e = 0;
+  for (; e + 16 <= m; e += 16) {
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = p[(e + k) * STRIDE];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += v[k];
+  }
+  if (e < m) {
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = p[(e + k) * STRIDE];   // (rows beyond m hold an earlier chunk's values: not added)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (e + k < m) tot += v[k];
+  }
+  return tot;
+}
 template <bool FISH, bool ORDERED>
 __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict__ count, const uint8_t* __restrict__ hasMP,
                                                   const float* __restrict__ obs, const float* __restrict__ invSigma2,
@@ -433,16 +455,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict
         }
         sC[tid] = c;
         __syncthreads();
-        if (tid == 0) {   // (16 LDS reads in flight, then the 16 additions in order: one read per addition made the chain ~100 cycles per edge)
-          const int m = n - c0 < 256 ? n - c0 : 256;
-          for (int e0 = 0; e0 < m; e0 += 16) {
-            double v[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = sC[e0 + k];                     // (rows beyond m hold an earlier chunk's values: not added)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) if (e0 + k < m) tot += v[k];
-          }
-        }
+        if (tid == 0) tot = ordered_add<1>(tot, sC, n - c0 < 256 ? n - c0 : 256);
         __syncthreads();
       }
       if (tid == 0) red[0] = tot;
@@ -516,16 +529,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict
 #pragma unroll
           for (int k = 0; k < 28; ++k) sC[tid * PO_PITCH + k] = con[k];
           __syncthreads();
-          if (tid < 28) {
-            const int m = n - c0 < 256 ? n - c0 : 256;
-            for (int e0 = 0; e0 < m; e0 += 16) {
-              double v[16];
-#pragma unroll
-              for (int k = 0; k < 16; ++k) v[k] = sC[(e0 + k) * PO_PITCH + tid];
-#pragma unroll
-              for (int k = 0; k < 16; ++k) if (e0 + k < m) tot += v[k];
-            }
-          }
+          if (tid < 28) tot = ordered_add<PO_PITCH>(tot, sC + tid, n - c0 < 256 ? n - c0 : 256);
           __syncthreads();
         }
         if (tid < 28) sH[0][tid] = tot;
