@@ -384,6 +384,9 @@ __device__ __forceinline__ bool ba_depth_positive(const Rig* rig, const float* o
 // thread writes its edge's 28 contributions to LDS (an inactive edge: exact zeros, which leave a floating-point sum unchanged), lanes 0 .. 27
 // of wave 0 add their entry's 256 values in order.  A chain of dependent FP64 additions per sum: 0.68 ms instead of 0.43 ms per 256 frames of
 // 600 edges (tools/pose_opt_modes.py) — the deterministic MODE of the optimizer (morb_optimizer_set_exact_order), not its default.
+#ifndef MORB_PO_NT
+#define MORB_PO_NT 256   // threads per frame of PoseOptimization's default (tree-sum) mode
+#endif
 constexpr int PO_PITCH = 29;   // doubles per edge row of the contribution buffer (28 used)
 // tot + p[0] + p[STRIDE] + ... (m terms, m wave-uniform, added strictly in that order): sixteen LDS reads in flight, then their sixteen additions
 // — one read per addition made the chain ~100 cycles per term — and no test inside the full batches (a `if (e + k < m)` per addition, although
@@ -407,14 +410,16 @@ __device__ __forceinline__ double ordered_add(double tot, const double* __restri
   }
   return tot;
 }
-template <bool FISH, bool ORDERED>
-__global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict__ count, const uint8_t* __restrict__ hasMP,
+template <bool FISH, bool ORDERED, int NT>
+__global__ __launch_bounds__(NT) void k_pose_opt(int cap, const int* __restrict__ count, const uint8_t* __restrict__ hasMP,
                                                   const float* __restrict__ obs, const float* __restrict__ invSigma2,
                                                   const float* __restrict__ Xw, Cam cam, Rig rig, const int* __restrict__ nLeft,
                                                   float* __restrict__ poseIO, uint8_t* __restrict__ outlier,
                                                   int* __restrict__ nInliers, int* __restrict__ stats) {
-  __shared__ double red[4];
-  __shared__ double sH[4][28];
+  constexpr int NW = NT / 64;
+  static_assert(!ORDERED || NT == 256, "the edge-order mode takes its edges 256 at a time");
+  __shared__ double red[NW];
+  __shared__ double sH[NW][28];
   __shared__ double sC[ORDERED ? 256 * PO_PITCH : 1];   // [edge of the chunk][entry]
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = count ? count[f] : cap;
@@ -422,10 +427,10 @@ __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
 
   int nInit = 0;
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += NT) {
     if (hasMP[base + i]) { ++nInit; outlier[base + i] = 0; }
   }
-  nInit = (int)block_sum_d<4>((double)nInit, red);
+  nInit = (int)block_sum_d<NW>((double)nInit, red);
   if (nInit < 3) {  // Optimizer.cc:951
     if (tid == 0) { nInliers[f] = 0; if (stats) { stats[2 * f] = 0; stats[2 * f + 1] = 0; } }
     return;
@@ -464,7 +469,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict
       __syncthreads();
       return tot;
     }
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += NT) {
       if (!hasMP[base + i] || outlier[base + i]) continue;
       const float* o = obs + (base + i) * 3;
       const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
@@ -474,7 +479,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict
       if (robust) c = huber(st ? deltaStereo : deltaMono, c, &w);
       s += c;
     }
-    return block_sum_d<4>(s, red);
+    return block_sum_d<NW>(s, red);
   };
 
   for (int it = 0; it < 4; ++it) {
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict
         for (int k = 0; k < 28; ++k) acc[k] = sH[0][k];
         __syncthreads();
       } else
-      for (int i = tid; i < n; i += 256) {
+      for (int i = tid; i < n; i += NT) {
         if (!hasMP[base + i] || outlier[base + i]) continue;
         const float* o = obs + (base + i) * 3;
         const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
@@ -577,7 +582,10 @@ __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict
       double H[36], b[6];
       {
         double tot[28];
-        for (int k = 0; k < 28; ++k) tot[k] = ORDERED ? acc[k] : sH[0][k] + sH[1][k] + sH[2][k] + sH[3][k];
+        for (int k = 0; k < 28; ++k) {
+          if (ORDERED) tot[k] = acc[k];
+          else { double t = sH[0][k]; for (int w = 1; w < NW; ++w) t += sH[w][k]; tot[k] = t; }   // ((s0 + s1) + s2) + s3 ...: the order of the 4-wave form
+        }
         int q = 0;
         for (int r = 0; r < 6; ++r) for (int cc = r; cc < 6; ++cc) { H[r * 6 + cc] = tot[q]; H[cc * 6 + r] = tot[q]; ++q; }
         for (int r = 0; r < 6; ++r) b[r] = tot[21 + r];
@@ -629,7 +637,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict
     int bad = 0;
     __syncthreads();
     const SE3 TrFin = FISH ? se3_mul(rig.Trl, T) : T, TrEval = FISH ? se3_mul(rig.Trl, Teval) : Teval;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += NT) {
       if (!hasMP[base + i]) continue;
       const float* o = obs + (base + i) * 3;
       const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
@@ -642,7 +650,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(int cap, const int* __restrict
       outlier[base + i] = isOut ? 1 : 0;
       bad += isOut ? 1 : 0;
     }
-    nBadEdges = (int)block_sum_d<4>((double)bad, red);
+    nBadEdges = (int)block_sum_d<NW>((double)bad, red);
     if (it == 2) robust = false;
     if (nInit < 10) break;  // optimizer.edges().size() < 10 (:1039)
   }
@@ -1668,9 +1676,9 @@ int morb_pose_optimization_batch(morb_optimizer* o, int nframes, int cap, const 
   Cam cam{fx, fy, cx, cy, bf};
   Rig rig;
   memset(&rig, 0, sizeof rig);
-  if (o->exactOrder) hipLaunchKernelGGL((k_pose_opt<false, true>), dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
+  if (o->exactOrder) hipLaunchKernelGGL((k_pose_opt<false, true, 256>), dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
                      (const int*)nullptr, d_pose, d_outlier, d_nInliers, d_stats);
-  else hipLaunchKernelGGL((k_pose_opt<false, false>), dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
+  else hipLaunchKernelGGL((k_pose_opt<false, false, MORB_PO_NT>), dim3(nframes), dim3(MORB_PO_NT), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
                      (const int*)nullptr, d_pose, d_outlier, d_nInliers, d_stats);
 
   MORB_HIP_CHECK(hipGetLastError());
@@ -1697,9 +1705,9 @@ int morb_pose_optimization_fisheye_batch(morb_optimizer* o, int nframes, int cap
     for (int i = 0; i < 4; ++i) rig.Trl.q[i] = q[i] / n;
     for (int i = 0; i < 3; ++i) rig.Trl.t[i] = Trl7[4 + i];
   }
-  if (o->exactOrder) hipLaunchKernelGGL((k_pose_opt<true, true>), dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
+  if (o->exactOrder) hipLaunchKernelGGL((k_pose_opt<true, true, 256>), dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
                      d_nLeft, d_pose, d_outlier, d_nInliers, d_stats);
-  else hipLaunchKernelGGL((k_pose_opt<true, false>), dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
+  else hipLaunchKernelGGL((k_pose_opt<true, false, MORB_PO_NT>), dim3(nframes), dim3(MORB_PO_NT), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
                      d_nLeft, d_pose, d_outlier, d_nInliers, d_stats);
 
   MORB_HIP_CHECK(hipGetLastError());
