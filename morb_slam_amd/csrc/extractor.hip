@@ -1439,7 +1439,8 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
                        e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L, 0, e->d_status);
   else
     // (one launch per bin of levels, each with its own LDS size — all bins of one launch get the largest bin's — measured: the launches
-    // follow each other on the stream, 128 -> 204 us per 128 images, 420 -> 435 per 512)
+    // follow each other on the stream, 128 -> 204 us per 128 images, 420 -> 435 per 512; round 4: a launch per LEVEL, single-wave workgroups with
+    // exactly the level's LDS, the eight launches side by side on streams of their own: 399 -> 513 us per 512 images alone, bench 124.5 -> 112.8 k frames/s)
     hipLaunchKernelGGL(k_distribute, dim3(nimg, e->distGroups), dim3(64 * e->distWaves), e->distSmem, st, e->d_geom, e->d_cand, e->d_candCnt,
                        e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L, 0, e->d_status);
   hipStream_t sideStream = e->sideStream;
