@@ -399,7 +399,8 @@ int morb_search_for_triangulation_fisheye_batch(morb_matcher* m, const morb_fram
  * The map-graph bookkeeping that follows a hit (Replace / AddObservation / AddMapPoint, :1196-1208, :1303-1310) depends on
  * live map state and stays with the caller, which replays the reference loop over these per-point results.
  * bRight on a fisheye rig: pass the right camera's pose / centre, cam8 = mpCamera2's KB8 parameters (host pointer, NULL =
- * the pinhole of P), d_jLo / d_jHi = [NLeft, N) per problem (NULL = all features) and d_uRight = NULL. */
+ * the pinhole of P), d_jLo / d_jHi = [NLeft, N) per problem (NULL = all features) and d_uRight = NULL.  The Sim3 form on a rig keyframe (no rig
+ * branch in the reference: pCamera = pKF->mpCamera, left features): cam8 = mpCamera's parameters, d_jLo / d_jHi = [0, NLeft). */
 int morb_fuse_batch(morb_matcher* m, const morb_frame_params* P, int nprob, const int* d_kfImg, int cap, const int* d_count,
                     const morb_keypoint* d_kps, const uint8_t* d_desc, const float* d_uRight, const float* d_Tcw, const float* d_Ow,
                     const float* cam8, const int* d_jLo, const int* d_jHi, int mpCap, const int* d_nMP, const uint8_t* d_valid,
@@ -429,6 +430,27 @@ int morb_search_by_sim3_batch(morb_matcher* m, const morb_frame_params* P, int n
                               const float* d_maxDist1, const float* d_minDist1, const uint8_t* d_mpDesc1, const uint8_t* d_valid2,
                               const float* d_Pw2, const float* d_maxDist2, const float* d_minDist2, const uint8_t* d_mpDesc2,
                               float th, int* d_vnMatch1, int* d_vnMatch2, int* d_match12, int* d_nFound, void* stream);
+
+/* The loop-closing searches on keyframes of a KannalaBrandt8 rig (KeyFrame::NLeft != -1; the feature row holds mvKeys | mvKeysRight).  The reference has no
+ * rig branch in them: pKF->GetFeaturesInArea(u, v, r) defaults to bRight = false and mvKeysUn is the copy of mvKeys, so only the LEFT camera's features
+ * [0, NLeft) are candidates (d_nLeft*[p] = NLeft), while every map point of the keyframe (left and right indices) is projected.
+ * SearchByProjection(pKF, Scw, ...) (:397-494) projects with pKF->mpCamera->project (:433) = the left KB8 camera: cam8 (HOST, fx fy cx cy k0..k3); its twin
+ * with vpPointsKFs (:496-601, manualProjection != 0) and SearchBySim3 (:1323-1519) keep the pinhole formula on pKF->fx, fy, cx, cy (:536-543, :1375-1379),
+ * i.e. P's — cam8 is ignored there.  Everything else as in the two entry points above. */
+int morb_search_by_projection_sim3_rig_batch(morb_matcher* m, const morb_frame_params* P, int nprob, const int* d_kfImg, int cap,
+                                             const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc, const float* d_Tcw,
+                                             const float* d_Ow, int mpCap, const int* d_nMP, const uint8_t* d_valid, const float* d_Pw,
+                                             const float* d_normal, const float* d_maxDist, const float* d_minDist,
+                                             const uint8_t* d_mpDesc, const uint8_t* d_matched, int th, float ratioHamming,
+                                             int manualProjection, const float* cam8, const int* d_nLeft, int* d_matchF, int* d_nmatches,
+                                             void* stream);
+int morb_search_by_sim3_rig_batch(morb_matcher* m, const morb_frame_params* P, int npairs, const int* d_kf1Img, const int* d_kf2Img, int cap,
+                                  const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc, const float* d_T1w,
+                                  const float* d_T2w, const float* d_S12, const float* d_S21, const uint8_t* d_valid1, const float* d_Pw1,
+                                  const float* d_maxDist1, const float* d_minDist1, const uint8_t* d_mpDesc1, const uint8_t* d_valid2,
+                                  const float* d_Pw2, const float* d_maxDist2, const float* d_minDist2, const uint8_t* d_mpDesc2,
+                                  float th, const int* d_nLeft1, const int* d_nLeft2, int* d_vnMatch1, int* d_vnMatch2, int* d_match12,
+                                  int* d_nFound, void* stream);
 
 
 /* ---- Frame-side helpers of the non-rectified / RGB-D input paths ----

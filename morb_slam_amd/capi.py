@@ -138,6 +138,8 @@ def lib():
         L.morb_fuse_batch.argtypes = [vp, PP, i, vp, i] + [vp] * 9 + [i] + [vp] * 7 + [f, i, vp, vp, vp]
         L.morb_search_by_projection_sim3_batch.argtypes = [vp, PP, i, vp, i] + [vp] * 5 + [i] + [vp] * 8 + [i, f, i, vp, vp, vp]
         L.morb_search_by_sim3_batch.argtypes = [vp, PP, i, vp, vp, i] + [vp] * 17 + [f, vp, vp, vp, vp, vp]
+        L.morb_search_by_projection_sim3_rig_batch.argtypes = [vp, PP, i, vp, i] + [vp] * 5 + [i] + [vp] * 8 + [i, f, i, vp, vp, vp, vp, vp]
+        L.morb_search_by_sim3_rig_batch.argtypes = [vp, PP, i, vp, vp, i] + [vp] * 17 + [f, vp, vp, vp, vp, vp, vp, vp]
         L.morb_bow_vector_batch.argtypes = [vp, i, vp, vp, i, vp, vp, i, i, vp, vp, vp, vp]
         L.morb_vocabulary_weights.argtypes = [vp, vp, vp, vp]
         L.morb_undistort_keypoints_batch.argtypes = [vp, i, i, vp, vp, f, f, f, f, vp, vp, vp]

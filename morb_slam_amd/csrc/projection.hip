@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void k_prep_kfproj(morb_frame_params P, int mp
     q.minLevel = lvl - 1; q.maxLevel = lvl;
     q.xr = u - P.mbf * (1 / p[2]); q.erMax = 3.4e38f;   // ur of Fuse's gate; the M1 / M2 stereo-window gate never fires
     q.gate = gate;
-    if (jHi) { q.jLo = jLo[f]; q.jHi = jHi[f]; }
+    if (jHi) { q.jLo = jLo ? jLo[f] : 0; q.jHi = jHi[f]; }
   } while (0);
   qs[o] = q;
 }
@@ -1231,13 +1231,15 @@ extern "C" int morb_fuse_batch(morb_matcher* m, const morb_frame_params* P, int 
   return MORB_OK;
 }
 
-extern "C" int morb_search_by_projection_sim3_batch(morb_matcher* m, const morb_frame_params* P, int nprob, const int* d_kfImg, int cap,
-                                                    const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc,
-                                                    const float* d_Tcw, const float* d_Ow, int mpCap, const int* d_nMP,
-                                                    const uint8_t* d_valid, const float* d_Pw, const float* d_normal,
-                                                    const float* d_maxDist, const float* d_minDist, const uint8_t* d_mpDesc,
-                                                    const uint8_t* d_matched, int th, float ratioHamming, int manualProjection,
-                                                    int* d_matchF, int* d_nmatches, void* stream) {
+// cam8 / d_nLeft: a KannalaBrandt8 rig keyframe — the reference then searches the LEFT camera's features only (GetFeaturesInArea with bRight = false,
+// mvKeysUn = mvKeys) and projects with mpCamera->project (the first form, cam8) or with the pinhole formula on pKF->fx ... (the twin, cam8 == NULL)
+static int search_by_projection_sim3_impl(morb_matcher* m, const morb_frame_params* P, int nprob, const int* d_kfImg, int cap,
+                                          const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc,
+                                          const float* d_Tcw, const float* d_Ow, int mpCap, const int* d_nMP,
+                                          const uint8_t* d_valid, const float* d_Pw, const float* d_normal,
+                                          const float* d_maxDist, const float* d_minDist, const uint8_t* d_mpDesc,
+                                          const uint8_t* d_matched, int th, float ratioHamming, int manualProjection,
+                                          const float* cam8, const int* d_nLeft, int* d_matchF, int* d_nmatches, void* stream) {
   MORB_REQUIRE(m && P && d_kfImg && d_count && d_kps && d_desc && d_Tcw && d_Ow && d_nMP && d_valid && d_Pw && d_normal && d_maxDist &&
                    d_minDist && d_mpDesc && d_matched && d_matchF && d_nmatches, MORB_ERR_INVALID, "NULL argument");
   MORB_REQUIRE(nprob > 0 && cap > 0 && cap <= 65535 && mpCap > 0 && P->nlevels >= 1 && P->nlevels <= 16, MORB_ERR_INVALID, "bad sizes");
@@ -1245,7 +1247,7 @@ extern "C" int morb_search_by_projection_sim3_batch(morb_matcher* m, const morb_
   hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
   const Query* qs; const unsigned long long* cand; const int* cnt;
   int rc = kfproj_candidates(m, P, nprob, d_kfImg, cap, d_count, d_kps, d_desc, nullptr, mpCap, d_nMP, d_valid, d_Pw, d_normal, d_maxDist,
-                             d_minDist, d_mpDesc, d_Tcw, nullptr, d_Ow, nullptr, nullptr, nullptr, (float)th, manualProjection ? 1 : 0, 0,
+                             d_minDist, d_mpDesc, d_Tcw, nullptr, d_Ow, cam8, nullptr, d_nLeft, (float)th, manualProjection ? 1 : 0, 0,
                              st, &qs, &cand, &cnt);
   if (rc != MORB_OK) return rc;
   void *ej = nullptr, *eb = nullptr;
@@ -1263,14 +1265,37 @@ extern "C" int morb_search_by_projection_sim3_batch(morb_matcher* m, const morb_
   return MORB_OK;
 }
 
-extern "C" int morb_search_by_sim3_batch(morb_matcher* m, const morb_frame_params* P, int npairs, const int* d_kf1Img,
-                                         const int* d_kf2Img, int cap, const int* d_count, const morb_keypoint* d_kps,
-                                         const uint8_t* d_desc, const float* d_T1w, const float* d_T2w, const float* d_S12,
-                                         const float* d_S21, const uint8_t* d_valid1, const float* d_Pw1, const float* d_maxDist1,
-                                         const float* d_minDist1, const uint8_t* d_mpDesc1, const uint8_t* d_valid2,
-                                         const float* d_Pw2, const float* d_maxDist2, const float* d_minDist2,
-                                         const uint8_t* d_mpDesc2, float th, int* d_vnMatch1, int* d_vnMatch2, int* d_match12,
-                                         int* d_nFound, void* stream) {
+extern "C" int morb_search_by_projection_sim3_batch(morb_matcher* m, const morb_frame_params* P, int nprob, const int* d_kfImg, int cap,
+                                                    const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc,
+                                                    const float* d_Tcw, const float* d_Ow, int mpCap, const int* d_nMP,
+                                                    const uint8_t* d_valid, const float* d_Pw, const float* d_normal,
+                                                    const float* d_maxDist, const float* d_minDist, const uint8_t* d_mpDesc,
+                                                    const uint8_t* d_matched, int th, float ratioHamming, int manualProjection,
+                                                    int* d_matchF, int* d_nmatches, void* stream) {
+  return search_by_projection_sim3_impl(m, P, nprob, d_kfImg, cap, d_count, d_kps, d_desc, d_Tcw, d_Ow, mpCap, d_nMP, d_valid, d_Pw, d_normal, d_maxDist,
+                                        d_minDist, d_mpDesc, d_matched, th, ratioHamming, manualProjection, nullptr, nullptr, d_matchF, d_nmatches, stream);
+}
+extern "C" int morb_search_by_projection_sim3_rig_batch(morb_matcher* m, const morb_frame_params* P, int nprob, const int* d_kfImg, int cap,
+                                                        const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc,
+                                                        const float* d_Tcw, const float* d_Ow, int mpCap, const int* d_nMP,
+                                                        const uint8_t* d_valid, const float* d_Pw, const float* d_normal,
+                                                        const float* d_maxDist, const float* d_minDist, const uint8_t* d_mpDesc,
+                                                        const uint8_t* d_matched, int th, float ratioHamming, int manualProjection,
+                                                        const float* cam8, const int* d_nLeft, int* d_matchF, int* d_nmatches, void* stream) {
+  MORB_REQUIRE(d_nLeft && (cam8 || manualProjection), MORB_ERR_INVALID, "rig form: NLeft per keyframe, and the left camera's parameters unless the projection is the manual one");
+  return search_by_projection_sim3_impl(m, P, nprob, d_kfImg, cap, d_count, d_kps, d_desc, d_Tcw, d_Ow, mpCap, d_nMP, d_valid, d_Pw, d_normal, d_maxDist,
+                                        d_minDist, d_mpDesc, d_matched, th, ratioHamming, manualProjection, manualProjection ? nullptr : cam8, d_nLeft,
+                                        d_matchF, d_nmatches, stream);
+}
+
+static int search_by_sim3_impl(morb_matcher* m, const morb_frame_params* P, int npairs, const int* d_kf1Img,
+                               const int* d_kf2Img, int cap, const int* d_count, const morb_keypoint* d_kps,
+                               const uint8_t* d_desc, const float* d_T1w, const float* d_T2w, const float* d_S12,
+                               const float* d_S21, const uint8_t* d_valid1, const float* d_Pw1, const float* d_maxDist1,
+                               const float* d_minDist1, const uint8_t* d_mpDesc1, const uint8_t* d_valid2,
+                               const float* d_Pw2, const float* d_maxDist2, const float* d_minDist2,
+                               const uint8_t* d_mpDesc2, float th, const int* d_nLeft1, const int* d_nLeft2, int* d_vnMatch1, int* d_vnMatch2,
+                               int* d_match12, int* d_nFound, void* stream) {
   MORB_REQUIRE(m && P && d_kf1Img && d_kf2Img && d_count && d_kps && d_desc && d_T1w && d_T2w && d_S12 && d_S21 && d_valid1 && d_Pw1 &&
                    d_maxDist1 && d_minDist1 && d_mpDesc1 && d_valid2 && d_Pw2 && d_maxDist2 && d_minDist2 && d_mpDesc2 && d_vnMatch1 &&
                    d_vnMatch2 && d_match12 && d_nFound, MORB_ERR_INVALID, "NULL argument");
@@ -1286,13 +1311,13 @@ extern "C" int morb_search_by_sim3_batch(morb_matcher* m, const morb_frame_param
   const Query* qs; const unsigned long long* cand; const int* cnt;
   // map points of keyframe 1 -> camera 1 -> camera 2 (S21) -> keyframe 2's features (:1354-1425)
   rc = kfproj_candidates(m, P, npairs, d_kf2Img, cap, d_count, d_kps, d_desc, nullptr, cap, n1, d_valid1, d_Pw1, nullptr, d_maxDist1,
-                         d_minDist1, d_mpDesc1, d_T1w, d_S21, nullptr, nullptr, nullptr, nullptr, th, 2, 0, st, &qs, &cand, &cnt);
+                         d_minDist1, d_mpDesc1, d_T1w, d_S21, nullptr, nullptr, nullptr, d_nLeft2, th, 2, 0, st, &qs, &cand, &cnt);
   if (rc != MORB_OK) return rc;
   hipLaunchKernelGGL(k_best_per_query, dim3(div_up(cap, 4), npairs), dim3(256), 0, st, *P, cap, qs, d_mpDesc1, d_kf2Img, cap, d_count,
                      d_kps, d_desc, (const float*)nullptr, cand, cnt, TH_HIGH, d_vnMatch1, (int*)nullptr);
   // and the other way round (:1428-1499)
   rc = kfproj_candidates(m, P, npairs, d_kf1Img, cap, d_count, d_kps, d_desc, nullptr, cap, n2, d_valid2, d_Pw2, nullptr, d_maxDist2,
-                         d_minDist2, d_mpDesc2, d_T2w, d_S12, nullptr, nullptr, nullptr, nullptr, th, 2, 0, st, &qs, &cand, &cnt);
+                         d_minDist2, d_mpDesc2, d_T2w, d_S12, nullptr, nullptr, nullptr, d_nLeft1, th, 2, 0, st, &qs, &cand, &cnt);
   if (rc != MORB_OK) return rc;
   hipLaunchKernelGGL(k_best_per_query, dim3(div_up(cap, 4), npairs), dim3(256), 0, st, *P, cap, qs, d_mpDesc2, d_kf1Img, cap, d_count,
                      d_kps, d_desc, (const float*)nullptr, cand, cnt, TH_HIGH, d_vnMatch2, (int*)nullptr);
@@ -1300,6 +1325,29 @@ extern "C" int morb_search_by_sim3_batch(morb_matcher* m, const morb_frame_param
   hipLaunchKernelGGL(k_sim3_agree, dim3(div_up(cap, 256), npairs), dim3(256), 0, st, cap, d_vnMatch1, d_vnMatch2, d_match12, d_nFound);
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
+}
+extern "C" int morb_search_by_sim3_batch(morb_matcher* m, const morb_frame_params* P, int npairs, const int* d_kf1Img,
+                                         const int* d_kf2Img, int cap, const int* d_count, const morb_keypoint* d_kps,
+                                         const uint8_t* d_desc, const float* d_T1w, const float* d_T2w, const float* d_S12,
+                                         const float* d_S21, const uint8_t* d_valid1, const float* d_Pw1, const float* d_maxDist1,
+                                         const float* d_minDist1, const uint8_t* d_mpDesc1, const uint8_t* d_valid2,
+                                         const float* d_Pw2, const float* d_maxDist2, const float* d_minDist2,
+                                         const uint8_t* d_mpDesc2, float th, int* d_vnMatch1, int* d_vnMatch2, int* d_match12,
+                                         int* d_nFound, void* stream) {
+  return search_by_sim3_impl(m, P, npairs, d_kf1Img, d_kf2Img, cap, d_count, d_kps, d_desc, d_T1w, d_T2w, d_S12, d_S21, d_valid1, d_Pw1, d_maxDist1, d_minDist1,
+                             d_mpDesc1, d_valid2, d_Pw2, d_maxDist2, d_minDist2, d_mpDesc2, th, nullptr, nullptr, d_vnMatch1, d_vnMatch2, d_match12, d_nFound, stream);
+}
+extern "C" int morb_search_by_sim3_rig_batch(morb_matcher* m, const morb_frame_params* P, int npairs, const int* d_kf1Img,
+                                             const int* d_kf2Img, int cap, const int* d_count, const morb_keypoint* d_kps,
+                                             const uint8_t* d_desc, const float* d_T1w, const float* d_T2w, const float* d_S12,
+                                             const float* d_S21, const uint8_t* d_valid1, const float* d_Pw1, const float* d_maxDist1,
+                                             const float* d_minDist1, const uint8_t* d_mpDesc1, const uint8_t* d_valid2,
+                                             const float* d_Pw2, const float* d_maxDist2, const float* d_minDist2,
+                                             const uint8_t* d_mpDesc2, float th, const int* d_nLeft1, const int* d_nLeft2, int* d_vnMatch1,
+                                             int* d_vnMatch2, int* d_match12, int* d_nFound, void* stream) {
+  MORB_REQUIRE(d_nLeft1 && d_nLeft2, MORB_ERR_INVALID, "rig form: NLeft of both keyframes");
+  return search_by_sim3_impl(m, P, npairs, d_kf1Img, d_kf2Img, cap, d_count, d_kps, d_desc, d_T1w, d_T2w, d_S12, d_S21, d_valid1, d_Pw1, d_maxDist1, d_minDist1,
+                             d_mpDesc1, d_valid2, d_Pw2, d_maxDist2, d_minDist2, d_mpDesc2, th, d_nLeft1, d_nLeft2, d_vnMatch1, d_vnMatch2, d_match12, d_nFound, stream);
 }
 
 extern "C" int morb_search_for_triangulation_batch(morb_matcher* m, const morb_frame_params* P, int npairs, const int* d_img1,

@@ -206,11 +206,20 @@ class ORBmatcher:
         return bi, bd
 
     def SearchByProjectionSim3(self, params, kfImg, kps, desc, count, Tcw, Ow, nMP, valid, Pw, normal, maxDist, minDist, mpDesc, matched,
-                               th, ratioHamming=1.0, manualProjection=False, stream=None):
-        """SearchByProjection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming) (and the vpPointsKFs twin)."""
+                               th, ratioHamming=1.0, manualProjection=False, stream=None, cam8=None, nLeft=None):
+        """SearchByProjection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming) (and the vpPointsKFs twin).  nLeft (i32 [F], device): the keyframes are
+        KannalaBrandt8 rig keyframes — left features only, cam8 = the left camera's parameters for the first form."""
         import torch
         F, cap, mpCap = kfImg.shape[0], kps.shape[1], mpDesc.shape[1]
         mf = torch.empty((F, cap), dtype=torch.int32, device=kps.device); nm = torch.zeros((F,), dtype=torch.int32, device=kps.device)
+        if nLeft is not None:
+            cam = None if cam8 is None else np.ascontiguousarray(cam8, np.float32)
+            check(self._L.morb_search_by_projection_sim3_rig_batch(self._h, C.byref(params), F, ptr(kfImg), cap, ptr(count), ptr(kps), ptr(desc),
+                                                                   ptr(Tcw), ptr(Ow), mpCap, ptr(nMP), ptr(valid), ptr(Pw), ptr(normal),
+                                                                   ptr(maxDist), ptr(minDist), ptr(mpDesc), ptr(matched), int(th),
+                                                                   float(ratioHamming), 1 if manualProjection else 0, ptr(cam), ptr(nLeft), ptr(mf),
+                                                                   ptr(nm), self._st(stream)))
+            return mf, nm
         check(self._L.morb_search_by_projection_sim3_batch(self._h, C.byref(params), F, ptr(kfImg), cap, ptr(count), ptr(kps), ptr(desc),
                                                            ptr(Tcw), ptr(Ow), mpCap, ptr(nMP), ptr(valid), ptr(Pw), ptr(normal),
                                                            ptr(maxDist), ptr(minDist), ptr(mpDesc), ptr(matched), int(th),
@@ -219,12 +228,18 @@ class ORBmatcher:
         return mf, nm
 
     def SearchBySim3(self, params, kf1, kf2, kps, desc, count, T1w, T2w, S12, S21, valid1, Pw1, maxD1, minD1, mpDesc1, valid2, Pw2, maxD2,
-                     minD2, mpDesc2, th, stream=None):
-        """SearchBySim3(pKF1, pKF2, vpMatches12, S12, th): (vnMatch1, vnMatch2, match12, nFound)."""
+                     minD2, mpDesc2, th, stream=None, nLeft1=None, nLeft2=None):
+        """SearchBySim3(pKF1, pKF2, vpMatches12, S12, th): (vnMatch1, vnMatch2, match12, nFound).  nLeft1 / nLeft2 (i32 [F], device): rig keyframes."""
         import torch
         F, cap = kf1.shape[0], kps.shape[1]
         v1 = torch.empty((F, cap), dtype=torch.int32, device=kps.device); v2 = torch.empty_like(v1); m12 = torch.empty_like(v1)
         nf = torch.zeros((F,), dtype=torch.int32, device=kps.device)
+        if nLeft1 is not None:
+            check(self._L.morb_search_by_sim3_rig_batch(self._h, C.byref(params), F, ptr(kf1), ptr(kf2), cap, ptr(count), ptr(kps), ptr(desc),
+                                                        ptr(T1w), ptr(T2w), ptr(S12), ptr(S21), ptr(valid1), ptr(Pw1), ptr(maxD1), ptr(minD1),
+                                                        ptr(mpDesc1), ptr(valid2), ptr(Pw2), ptr(maxD2), ptr(minD2), ptr(mpDesc2), float(th),
+                                                        ptr(nLeft1), ptr(nLeft2), ptr(v1), ptr(v2), ptr(m12), ptr(nf), self._st(stream)))
+            return v1, v2, m12, nf
         check(self._L.morb_search_by_sim3_batch(self._h, C.byref(params), F, ptr(kf1), ptr(kf2), cap, ptr(count), ptr(kps), ptr(desc),
                                                 ptr(T1w), ptr(T2w), ptr(S12), ptr(S21), ptr(valid1), ptr(Pw1), ptr(maxD1), ptr(minD1),
                                                 ptr(mpDesc1), ptr(valid2), ptr(Pw2), ptr(maxD2), ptr(minD2), ptr(mpDesc2), float(th),

@@ -121,6 +121,14 @@ void orc_fuse_search(const orc_frame* KF, const float* invLevelSigma2, const flo
 void orc_fuse_search_rig(const orc_frame* KF, int NLeft, int bRight, const float* cam8, const float* invLevelSigma2, const float* Tcw7,
                          const float* Ow, int nMP, const uint8_t* valid, const float* Pw, const float* normal, const float* maxDist,
                          const float* minDist, const uint8_t* mpDesc, float th, int* bestIdx, int* bestDist);
+int orc_search_by_projection_sim3_rig(const orc_frame* KF, int NLeft, const float* cam8, const float* Tcw7, const float* Ow, int nMP, const uint8_t* valid,
+                                      const float* Pw, const float* normal, const float* maxDist, const float* minDist, const uint8_t* mpDesc,
+                                      const uint8_t* matchedIn, int th, float ratioHamming, int manualProjection, int* matchF);
+void orc_search_by_sim3_dir_rig(const orc_frame* B, int NLeftB, const float* TAw7, const float* SBA8, int nA, const uint8_t* valid, const float* Pw,
+                                const float* maxDist, const float* minDist, const uint8_t* mpDesc, float th, int* vnMatch);
+void orc_fuse_search_rig_sim3(const orc_frame* KF, int NLeft, const float* cam8, const float* invLevelSigma2, const float* Tcw7, const float* Ow, int nMP,
+                              const uint8_t* valid, const float* Pw, const float* normal, const float* maxDist, const float* minDist,
+                              const uint8_t* mpDesc, float th, int* bestIdx, int* bestDist);
 int orc_search_by_projection_sim3(const orc_frame* KF, const float* Tcw7, const float* Ow, int nMP, const uint8_t* valid,
                                   const float* Pw, const float* normal, const float* maxDist, const float* minDist,
                                   const uint8_t* mpDesc, const uint8_t* matchedIn, int th, float ratioHamming, int manualProjection,

@@ -861,9 +861,11 @@ void FuseSearch(const orc_frame& KF, const float* invLevelSigma2, const float* T
 // mpCamera; the window is looked up in that side's grid with that side's keypoints (KeyFrame.cc:758-764, side-local indices),
 // mvuRight[idx] — read with the side-local index (:1154), all -1 on a rig — sends every candidate through the 5.99 gate, and the
 // descriptor row / returned index is idx + NLeft on the right (:1177).
+// sim3Form: Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (:1215-1321) on a rig keyframe — no rig branch in the reference: pCamera = pKF->mpCamera, the
+// left features, no reprojection gate, bestDist starts at INT_MAX
 void FuseSearchRig(const orc_frame& KF, int NLeft, bool bRight, const float* cam8, const float* invLevelSigma2, const float* Tcw7,
                    const float* Ow, int nMP, const uint8_t* valid, const float* Pw, const float* normal, const float* mfMaxDistance,
-                   const float* mfMinDistance, const uint8_t* mpDesc, float th, int* bestIdxOut, int* bestDistOut) {
+                   const float* mfMinDistance, const uint8_t* mpDesc, float th, int* bestIdxOut, int* bestDistOut, bool sim3Form = false) {
   orc_frame S = KF;   // the side's features as a frame of their own
   const int base = bRight ? NLeft : 0;
   S.N = bRight ? KF.N - NLeft : NLeft;
@@ -892,7 +894,7 @@ void FuseSearchRig(const orc_frame& KF, int NLeft, bool bRight, const float* cam
     const std::vector<size_t> vIndices = KFGetFeaturesInArea(S, g, uv[0], uv[1], radius);
     if (vIndices.empty()) continue;
     const uint8_t* dMP = mpDesc + (size_t)i * 32;
-    int bestDist = 256, bestIdx = -1;
+    int bestDist = sim3Form ? INT_MAX : 256, bestIdx = -1;
     for (size_t q = 0; q < vIndices.size(); ++q) {
       const size_t idx = vIndices[q];
       const KeyPoint& kp = k[idx];
@@ -900,7 +902,7 @@ void FuseSearchRig(const orc_frame& KF, int NLeft, bool bRight, const float* cam
       if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
       const float ex = uv[0] - kp.x, ey = uv[1] - kp.y;
       const float e2 = ex * ex + ey * ey;
-      if (e2 * invLevelSigma2[kpLevel] > 5.99) continue;
+      if (!sim3Form && e2 * invLevelSigma2[kpLevel] > 5.99) continue;
       const int dist = DescriptorDistance(dMP, S.desc + idx * 32);
       if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx + base; }
     }
@@ -911,12 +913,18 @@ void FuseSearchRig(const orc_frame& KF, int NLeft, bool bRight, const float* cam
 // ORBmatcher::SearchByProjection(KeyFrame*, Sim3f& Scw, vpPoints, vpMatched, th, ratioHamming) (:397-494) and its twin
 // with vpPointsKFs / vpMatchedKF (:496-601; manualProjection: u = fx * (X * invz) + cx instead of mpCamera->project).
 // matched[idx] != 0 <=> vpMatched[idx] on entry; matchF[idx] = index of the map point newly assigned to feature idx.
-int SearchByProjectionSim3(const orc_frame& KF, const float* Tcw7, const float* Ow, int nMP, const uint8_t* valid,
+// NLeft >= 0: a KannalaBrandt8 rig keyframe (KF holds mvKeys | mvKeysRight).  The reference has no rig branch here: GetFeaturesInArea(u, v, r) looks up
+// the LEFT grid (bRight defaults to false, KeyFrame.cc:729-774), mvKeysUn is the copy of mvKeys, and the first form projects with
+// pKF->mpCamera->project (:433) = the left KB8 camera (cam8); the twin keeps its pinhole formula on pKF->fx ... (:536-543).  vpMatched spans all N features.
+int SearchByProjectionSim3(const orc_frame& KFall, const float* Tcw7, const float* Ow, int nMP, const uint8_t* valid,
                            const float* Pw, const float* normal, const float* mfMaxDistance, const float* mfMinDistance,
                            const uint8_t* mpDesc, const uint8_t* matchedIn, int th, float ratioHamming, bool manualProjection,
-                           int* matchF) {
+                           int* matchF, const float* cam8 = nullptr, int NLeft = -1) {
+  orc_frame KF = KFall;
+  if (NLeft >= 0) KF.N = NLeft;
   Grid g;
   AssignFeaturesToGrid(KF, g);
+  KF.N = KFall.N;
   const KeyPoint* k = (const KeyPoint*)KF.kpsUn;
   std::vector<char> vpMatched(matchedIn, matchedIn + KF.N);
   for (int i = 0; i < KF.N; ++i) matchF[i] = -1;
@@ -933,6 +941,10 @@ int SearchByProjectionSim3(const orc_frame& KF, const float* Tcw7, const float* 
       const float invz = 1 / p3Dc[2];
       const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
       u = KF.fx * x + KF.cx; v = KF.fy * y + KF.cy;
+    } else if (cam8) {
+      float uv[2];
+      orc_kb8_project_f(cam8, p3Dc, uv);
+      u = uv[0]; v = uv[1];
     } else {
       u = KF.fx * p3Dc[0] / p3Dc[2] + KF.cx; v = KF.fy * p3Dc[1] / p3Dc[2] + KF.cy;
     }
@@ -978,8 +990,11 @@ static void sim3Map(const float* S8, const float* p, float* out) {
   out[1] = scale * p[1] + (qw * b + (qz * a - qx * c)) + S8[5];
   out[2] = scale * p[2] + (qw * c + (qx * b - qy * a)) + S8[6];
 }
-void SearchBySim3Dir(const orc_frame& B, const float* TAw7, const float* SBA8, int nA, const uint8_t* valid, const float* Pw,
-                     const float* mfMaxDistance, const float* mfMinDistance, const uint8_t* mpDesc, float th, int* vnMatch) {
+// NLeftB >= 0: B is a rig keyframe — its left features only (GetFeaturesInArea with bRight = false); the projection stays the pinhole formula (:1375-1379)
+void SearchBySim3Dir(const orc_frame& Ball, const float* TAw7, const float* SBA8, int nA, const uint8_t* valid, const float* Pw,
+                     const float* mfMaxDistance, const float* mfMinDistance, const uint8_t* mpDesc, float th, int* vnMatch, int NLeftB = -1) {
+  orc_frame B = Ball;
+  if (NLeftB >= 0) B.N = NLeftB;
   Grid g;
   AssignFeaturesToGrid(B, g);
   const KeyPoint* k = (const KeyPoint*)B.kpsUn;
@@ -1094,6 +1109,21 @@ void orc_fuse_search_rig(const orc_frame* KF, int NLeft, int bRight, const float
                          const float* Ow, int nMP, const uint8_t* valid, const float* Pw, const float* normal, const float* maxDist,
                          const float* minDist, const uint8_t* mpDesc, float th, int* bestIdx, int* bestDist) {
   FuseSearchRig(*KF, NLeft, bRight != 0, cam8, invLevelSigma2, Tcw7, Ow, nMP, valid, Pw, normal, maxDist, minDist, mpDesc, th, bestIdx, bestDist);
+}
+int orc_search_by_projection_sim3_rig(const orc_frame* KF, int NLeft, const float* cam8, const float* Tcw7, const float* Ow, int nMP, const uint8_t* valid,
+                                      const float* Pw, const float* normal, const float* maxDist, const float* minDist, const uint8_t* mpDesc,
+                                      const uint8_t* matchedIn, int th, float ratioHamming, int manualProjection, int* matchF) {
+  return SearchByProjectionSim3(*KF, Tcw7, Ow, nMP, valid, Pw, normal, maxDist, minDist, mpDesc, matchedIn, th, ratioHamming, manualProjection != 0, matchF,
+                                manualProjection ? nullptr : cam8, NLeft);
+}
+void orc_search_by_sim3_dir_rig(const orc_frame* B, int NLeftB, const float* TAw7, const float* SBA8, int nA, const uint8_t* valid, const float* Pw,
+                                const float* maxDist, const float* minDist, const uint8_t* mpDesc, float th, int* vnMatch) {
+  SearchBySim3Dir(*B, TAw7, SBA8, nA, valid, Pw, maxDist, minDist, mpDesc, th, vnMatch, NLeftB);
+}
+void orc_fuse_search_rig_sim3(const orc_frame* KF, int NLeft, const float* cam8, const float* invLevelSigma2, const float* Tcw7, const float* Ow, int nMP,
+                              const uint8_t* valid, const float* Pw, const float* normal, const float* maxDist, const float* minDist,
+                              const uint8_t* mpDesc, float th, int* bestIdx, int* bestDist) {
+  FuseSearchRig(*KF, NLeft, false, cam8, invLevelSigma2, Tcw7, Ow, nMP, valid, Pw, normal, maxDist, minDist, mpDesc, th, bestIdx, bestDist, true);
 }
 int orc_search_by_projection_sim3(const orc_frame* KF, const float* Tcw7, const float* Ow, int nMP, const uint8_t* valid,
                                   const float* Pw, const float* normal, const float* maxDist, const float* minDist,

@@ -386,6 +386,42 @@ def search_by_sim3_dir(B, TAw7, SBA8, valid, Pw, maxD, minD, mpDesc, th):
     return v
 
 
+def search_by_projection_sim3_rig(KF, NLeft, cam8, Tcw7, Ow, valid, Pw, normal, maxD, minD, mpDesc, matched, th, ratio, manual):
+    """SearchByProjection(pKF, Scw, ...) (and its twin) on a KannalaBrandt8 rig keyframe: left features, the left KB8 camera (first form only)."""
+    L = lib(); n = len(Pw)
+    L.orc_search_by_projection_sim3_rig.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
+    a = [np.ascontiguousarray(x) for x in (np.asarray(cam8, np.float32), np.asarray(Tcw7, np.float32), np.asarray(Ow, np.float32), valid.astype(np.uint8),
+                                           np.asarray(Pw, np.float32), np.asarray(normal, np.float32), np.asarray(maxD, np.float32),
+                                           np.asarray(minD, np.float32), mpDesc, matched.astype(np.uint8))]
+    m = np.zeros(KF.N, np.int32)
+    r = L.orc_search_by_projection_sim3_rig(C.byref(KF), int(NLeft), _p(a[0]), _p(a[1]), _p(a[2]), n, _p(a[3]), _p(a[4]), _p(a[5]), _p(a[6]), _p(a[7]),
+                                            _p(a[8]), _p(a[9]), int(th), ratio, int(manual), _p(m))
+    return r, m
+
+
+def search_by_sim3_dir_rig(B, NLeftB, TAw7, SBA8, valid, Pw, maxD, minD, mpDesc, th):
+    L = lib(); n = len(Pw)
+    L.orc_search_by_sim3_dir_rig.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_void_p]
+    a = [np.ascontiguousarray(x) for x in (np.asarray(TAw7, np.float32), np.asarray(SBA8, np.float32), valid.astype(np.uint8),
+                                           np.asarray(Pw, np.float32), np.asarray(maxD, np.float32), np.asarray(minD, np.float32), mpDesc)]
+    v = np.zeros(n, np.int32)
+    L.orc_search_by_sim3_dir_rig(C.byref(B), int(NLeftB), _p(a[0]), _p(a[1]), n, _p(a[2]), _p(a[3]), _p(a[4]), _p(a[5]), _p(a[6]), th, _p(v))
+    return v
+
+
+def fuse_search_rig_sim3(KF, NLeft, cam8, invSigma2, Tcw7, Ow, valid, Pw, normal, maxD, minD, mpDesc, th):
+    """Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) on a rig keyframe: the left camera and its features, no reprojection gate."""
+    L = lib(); n = len(Pw)
+    L.orc_fuse_search_rig_sim3.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_void_p, C.c_void_p]
+    a = [np.ascontiguousarray(x) for x in (np.asarray(cam8, np.float32), np.asarray(invSigma2, np.float32), np.asarray(Tcw7, np.float32),
+                                           np.asarray(Ow, np.float32), valid.astype(np.uint8), np.asarray(Pw, np.float32),
+                                           np.asarray(normal, np.float32), np.asarray(maxD, np.float32), np.asarray(minD, np.float32), mpDesc)]
+    bi = np.zeros(n, np.int32); bd = np.zeros(n, np.int32)
+    L.orc_fuse_search_rig_sim3(C.byref(KF), int(NLeft), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), n, _p(a[4]), _p(a[5]), _p(a[6]), _p(a[7]),
+                               _p(a[8]), _p(a[9]), th, _p(bi), _p(bd))
+    return bi, bd
+
+
 def search_for_triangulation_fisheye(k1, nl1, d1, node1, has1, k2, nl2, d2, node2, has2, sigma2, camL8, camR8, T4, onlyStereo, coarse, checkOri):
     L = lib()
     L.orc_search_for_triangulation_fisheye.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 8 + \

@@ -515,6 +515,95 @@ def test_fuse_on_a_rig_matches_oracle():
     assert tot > 800
 
 
+def test_loop_closing_searches_on_a_rig_match_oracle():
+    """The matcher members WITHOUT a rig branch in the reference, on KannalaBrandt8 rig keyframes (what LoopClosing runs on a stereo-fisheye
+    sequence): Fuse(pKF, Scw, ...) and SearchByProjection(pKF, Scw, ...) project with pKF->mpCamera (the left KB8 camera), the latter's twin and
+    SearchBySim3 with the pinhole formula on pKF->fx ..., and all of them look the candidates up among the LEFT features only
+    (GetFeaturesInArea's bRight = false) while every map point of the keyframe is projected: ORBmatcher.cc:397-601, :1215-1519."""
+    import torch
+    from morb_slam_amd import ORBmatcher
+    from morb_slam_amd.synth import TUMVI_CAM_L, _quat_from_R
+    S = _tri_scene()
+    P, sf, kps, desc, cnt, nl, poses = (S[k] for k in ("P", "sf", "kps", "desc", "cnt", "nl", "poses"))
+    invS = (1.0 / (sf * sf)).astype(np.float32)
+    cu = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    m = ORBmatcher(0.8, True)
+    dk, dd, dc = cu(kps.view(np.uint8).reshape(S["nimg"], S["cap"], 28)), cu(desc), cu(cnt)
+    rng = np.random.default_rng(808)
+    b = 1
+    N = int(cnt[b]); NL = int(nl[b])
+    Fo = O.make_frame(P, kps[b, :N], desc[b, :N], None)
+    pr = _fuse_rig_problem(S, b, False, 61)
+    M = len(pr["Xw"])
+    one = lambda a: cu(np.asarray(a)[None])
+    kfb = cu(np.array([b], np.int32)); nmp = cu(np.array([M], np.int32)); dnl = cu(np.array([NL], np.int32))
+    # ---- Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)
+    bi, bd = m.Fuse(P, kfb, dk, dd, dc, None, one(pr["T7"]), one(pr["Ow"]), nmp, one(pr["valid"]), one(pr["Xw"]), one(pr["normal"]), one(pr["maxD"]),
+                    one(pr["minD"]), one(pr["mpd"]), th=6.0, sim3Form=True, cam8=TUMVI_CAM_L, jLo=cu(np.array([0], np.int32)), jHi=dnl)
+    torch.cuda.synchronize()
+    ei, ed = O.fuse_search_rig_sim3(Fo, NL, TUMVI_CAM_L, invS, pr["T7"], pr["Ow"], pr["valid"], pr["Xw"], pr["normal"], pr["maxD"], pr["minD"], pr["mpd"], 6.0)
+    np.testing.assert_array_equal(bi[0].cpu().numpy(), ei); np.testing.assert_array_equal(bd[0].cpu().numpy(), ed)
+    assert (ei >= 0).sum() > 100 and ei.max() < NL
+    # ---- SearchByProjection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming) and its twin
+    matched = (rng.random(N) < 0.1).astype(np.uint8)
+    mpad = np.zeros(S["cap"], np.uint8); mpad[:N] = matched
+    for manual in (False, True):
+        mf, nm = m.SearchByProjectionSim3(P, kfb, dk, dd, dc, one(pr["T7"]), one(pr["Ow"]), nmp, one(pr["valid"]), one(pr["Xw"]), one(pr["normal"]),
+                                          one(pr["maxD"]), one(pr["minD"]), one(pr["mpd"]), one(mpad), 8, 0.9, manual, cam8=TUMVI_CAM_L, nLeft=dnl)
+        torch.cuda.synchronize()
+        r, me = O.search_by_projection_sim3_rig(Fo, NL, TUMVI_CAM_L, pr["T7"], pr["Ow"], pr["valid"], pr["Xw"], pr["normal"], pr["maxD"], pr["minD"], pr["mpd"],
+                                                matched, 8, 0.9, manual)
+        assert int(nm[0]) == r
+        np.testing.assert_array_equal(mf[0, :N].cpu().numpy(), me)
+        assert (np.nonzero(me >= 0)[0] < NL).all()
+        if not manual:
+            assert r > 100
+    # ---- SearchBySim3(pKF1, pKF2, vpMatches12, S12, th): the projection is the pinhole formula on fx, fy, cx, cy even on a rig, so the test's map points
+    # are placed where that formula lands on a left feature of the other keyframe (random depths), owned by left AND right features of their own keyframe
+    a = 0
+    Na, NLa = int(cnt[a]), int(nl[a])
+    Fa = O.make_frame(P, kps[a, :Na], desc[a, :Na], None)
+    T = [poses[a], poses[b]]
+    T7 = [np.concatenate([_quat_from_R(t[:3, :3]), t[:3, 3]]).astype(np.float32) for t in T]
+    s12 = 1.01
+    R12 = T[0][:3, :3] @ T[1][:3, :3].T; t12 = T[0][:3, 3] - R12 @ T[1][:3, 3]
+    sim8 = lambda R, t, sc: np.concatenate([_quat_from_R(R) * np.sqrt(sc), t]).astype(np.float32)
+    S12 = sim8(R12, t12, s12); S21 = sim8(R12.T, -(R12.T @ t12) / s12, 1.0 / s12)
+    fx, fy, cx, cy = (float(TUMVI_CAM_L[i]) for i in range(4))
+
+    def points_for(src, dst, nSrc, nDst, nlDst, Ssd_R, Ssd_t, Ssd_s, Tsrc, pairs_src, pairs_dst):
+        """map points of keyframe `src`'s features pairs_src[q] that the search finds at the left feature pairs_dst[q] of keyframe `dst`"""
+        valid = np.zeros(S["cap"], np.uint8); Pw = np.zeros((S["cap"], 3), np.float32); maxD = np.ones(S["cap"], np.float32); minD = np.ones(S["cap"], np.float32)
+        mpd = rng.integers(0, 256, (S["cap"], 32), dtype=np.uint8)
+        for i, j in zip(pairs_src, pairs_dst):
+            kp = kps[dst, j]
+            z = rng.uniform(1.5, 8.0)
+            pd = np.array([(kp["x"] + rng.normal(0, 0.5) - cx) / fx * z, (kp["y"] + rng.normal(0, 0.5) - cy) / fy * z, z])      # in dst's camera
+            ps = Ssd_s * (Ssd_R @ pd) + Ssd_t                                                                                       # in src's camera
+            Pw[i] = Tsrc[:3, :3].T @ (ps - Tsrc[:3, 3])
+            dist = np.linalg.norm(pd)
+            maxD[i] = dist * 1.2 ** (int(kp["octave"]) + rng.uniform(0.1, 0.9)); minD[i] = maxD[i] / 1.2 ** 8
+            mpd[i] = desc[dst, j] ^ np.packbits(rng.random(256) < 0.03)
+            valid[i] = 1
+        return valid, Pw, maxD, minD, mpd
+    nPair = 150
+    i1 = rng.permutation(NLa)[:nPair]; j2 = rng.permutation(NL)[:nPair]                     # mutual pairs among the left features
+    x1 = NLa + rng.permutation(Na - NLa)[:60]; y2 = np.setdiff1d(np.arange(NL), j2)[:60]   # points owned by RIGHT features of keyframe 1, found in keyframe 2
+    v1, Pw1, mx1, mn1, d1 = points_for(a, b, Na, N, NL, R12, t12, s12, T[0], np.concatenate([i1, x1]), np.concatenate([j2, y2]))
+    v2, Pw2, mx2, mn2, d2 = points_for(b, a, N, Na, NLa, R12.T, -(R12.T @ t12) / s12, 1.0 / s12, T[1], j2, i1)
+    o = m.SearchBySim3(P, cu(np.array([a], np.int32)), kfb, dk, dd, dc, one(T7[0]), one(T7[1]), one(S12), one(S21), one(v1), one(Pw1), one(mx1), one(mn1), one(d1),
+                       one(v2), one(Pw2), one(mx2), one(mn2), one(d2), 7.5, nLeft1=cu(np.array([NLa], np.int32)), nLeft2=dnl)
+    torch.cuda.synchronize()
+    g1, g2, g12, nf = [x.cpu().numpy() for x in o]
+    e1 = O.search_by_sim3_dir_rig(Fo, NL, T7[0], S21, v1[:Na], Pw1[:Na], mx1[:Na], mn1[:Na], d1[:Na], 7.5)
+    e2 = O.search_by_sim3_dir_rig(Fa, NLa, T7[1], S12, v2[:N], Pw2[:N], mx2[:N], mn2[:N], d2[:N], 7.5)
+    np.testing.assert_array_equal(g1[0, :Na], e1); np.testing.assert_array_equal(g2[0, :N], e2)
+    e12 = np.array([i2 if (i2 >= 0 and e2[i2] == k1) else -1 for k1, i2 in enumerate(e1)])
+    np.testing.assert_array_equal(g12[0, :Na], e12)
+    assert int(nf[0]) == int((e12 >= 0).sum()) > 100
+    assert (e1[x1] >= 0).sum() > 40 and e1.max() < NL and e2.max() < NLa      # right-owned points are searched too; candidates are left features only
+
+
 def _mul_f32(A, B):
     """(R, t) of A * B composed in float32 left to right, as tests/native/mock_ref's SE3f does (no FMA: products rounded, then summed)."""
     A = np.asarray(A, np.float32); B = np.asarray(B, np.float32)
