@@ -50,7 +50,12 @@ struct FrameView {
   const uint8_t* mpDescriptor = nullptr;        // [N][32] GetDescriptor()
   const uint8_t* mpHasObservations = nullptr;   // [N] Observations() > 0
 };
-struct KeyFrameView : FrameView {};   // the same members read from a KeyFrame (GetMapPointMatches(), mFeatVec, GetPose(), ...)
+struct KeyFrameView : FrameView {   // the same members read from a KeyFrame (GetMapPointMatches(), mFeatVec, GetPose(), ...)
+  // KannalaBrandt8 rig keyframe (KeyFrame::NLeft != -1): the rows hold mvKeys | mvKeysRight; the loop-closing searches (no rig branch in the reference) then
+  // look among the first NLeft features only and project with mpCamera (rigCam8: fx fy cx cy k0..k3) where the reference calls mpCamera->project
+  int NLeft = -1;
+  float rigCam8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
 // MapPoint members read by isInFrustum / SearchByProjection / Fuse (include/MapPoint.h)
 struct MapPointView {
   int n = 0;
@@ -310,6 +315,14 @@ class ORBmatcher {
     up_row(s.f32[7], KF1.mpMinDistance, N1, cap, 1); up_row(s.u8[3], KF1.mpDescriptor, N1, cap, 32);
     up_row(s.u8[4], v2.data(), N2, cap, 1); up_row(s.f32[8], KF2.mpWorldPos, N2, cap, 3); up_row(s.f32[9], KF2.mpMaxDistance, N2, cap, 1);
     up_row(s.f32[10], KF2.mpMinDistance, N2, cap, 1); up_row(s.u8[5], KF2.mpDescriptor, N2, cap, 32);
+    if (KF1.NLeft >= 0 || KF2.NLeft >= 0) {   // rig keyframes: the candidates are the left features (a keyframe without a right camera: all of them)
+      const int nl1 = KF1.NLeft >= 0 ? KF1.NLeft : N1, nl2 = KF2.NLeft >= 0 ? KF2.NLeft : N2;
+      rigI32(0).assign(&nl1, 1); rigI32(1).assign(&nl2, 1);
+      check(morb_search_by_sim3_rig_batch(h_, &KF1.params, 1, s.i32[2].get(), s.i32[3].get(), cap, s.i32[0].get(), s.kp[0].get(), s.u8[0].get(), s.f32[1].get(),
+                                          s.f32[2].get(), s.f32[3].get(), s.f32[4].get(), s.u8[2].get(), s.f32[5].get(), s.f32[6].get(), s.f32[7].get(),
+                                          s.u8[3].get(), s.u8[4].get(), s.f32[8].get(), s.f32[9].get(), s.f32[10].get(), s.u8[5].get(), th, rigI32(0).get(),
+                                          rigI32(1).get(), s.i32[5].get(), s.i32[6].get(), s.i32[7].get(), s.i32[4].get(), nullptr));
+    } else
     check(morb_search_by_sim3_batch(h_, &KF1.params, 1, s.i32[2].get(), s.i32[3].get(), cap, s.i32[0].get(), s.kp[0].get(), s.u8[0].get(), s.f32[1].get(),
                                     s.f32[2].get(), s.f32[3].get(), s.f32[4].get(), s.u8[2].get(), s.f32[5].get(), s.f32[6].get(), s.f32[7].get(),
                                     s.u8[3].get(), s.u8[4].get(), s.f32[8].get(), s.f32[9].get(), s.f32[10].get(), s.u8[5].get(), th, s.i32[5].get(),
@@ -338,6 +351,12 @@ class ORBmatcher {
   // int Fuse(KeyFrame* pKF, Sophus::Sim3f& Scw, const vector<MapPoint*>& vpPoints, float th, vector<MapPoint*>& vpReplacePoint)
   // (ORBmatcher.h:112-114, ORBmatcher.cc:1215-1321; loop closing): vpReplacePoint[i] = pKF->GetMapPoint(bestIdx[i]) where that is non-NULL.
   int Fuse(const KeyFrameView& KF, const Sim3View& Scw, const MapPointView& vpPoints, float th, std::vector<int>& bestIdx, std::vector<int>& bestDist) {
+    if (KF.NLeft >= 0) {   // rig keyframe (no rig branch in the reference: pCamera = pKF->mpCamera, the left features)
+      RigSide side;
+      std::memcpy(side.Tcw, Scw.Tcw, sizeof side.Tcw); std::memcpy(side.Ow, Scw.Ow, sizeof side.Ow); std::memcpy(side.cam8, KF.rigCam8, sizeof side.cam8);
+      side.jLo = 0; side.jHi = KF.NLeft;
+      return fuse(KF, Scw, vpPoints, bestIdx, bestDist, th, 1, &side);
+    }
     return fuse(KF, Scw, vpPoints, bestIdx, bestDist, th, 1);
   }
 
@@ -450,6 +469,13 @@ class ORBmatcher {
     const int kf = 0, nmp = M;
     s.i32[2].assign(&kf, 1); s.i32[3].assign(&nmp, 1); s.i32[4].resize(1); s.i32[4].fill_bytes(0); s.i32[5].resize(cap);
     s.f32[1].assign(Scw.Tcw, 7); s.f32[2].assign(Scw.Ow, 3); s.u8[4].assign(matched.data(), cap);
+    if (KF.NLeft >= 0) {   // rig keyframe: left features, the left KB8 camera where the reference calls mpCamera->project
+      rigI32(0).assign(&KF.NLeft, 1);
+      check(morb_search_by_projection_sim3_rig_batch(h_, &KF.params, 1, s.i32[2].get(), cap, s.i32[0].get(), s.kp[0].get(), s.u8[0].get(), s.f32[1].get(),
+                                                     s.f32[2].get(), M, s.i32[3].get(), s.u8[2].get(), s.f32[3].get(), s.f32[4].get(), s.f32[5].get(),
+                                                     s.f32[6].get(), s.u8[3].get(), s.u8[4].get(), th, ratioHamming, manual, KF.rigCam8, rigI32(0).get(),
+                                                     s.i32[5].get(), s.i32[4].get(), nullptr));
+    } else
     check(morb_search_by_projection_sim3_batch(h_, &KF.params, 1, s.i32[2].get(), cap, s.i32[0].get(), s.kp[0].get(), s.u8[0].get(), s.f32[1].get(),
                                                s.f32[2].get(), M, s.i32[3].get(), s.u8[2].get(), s.f32[3].get(), s.f32[4].get(), s.f32[5].get(),
                                                s.f32[6].get(), s.u8[3].get(), s.u8[4].get(), th, ratioHamming, manual, s.i32[5].get(), s.i32[4].get(),

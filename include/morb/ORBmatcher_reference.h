@@ -7,10 +7,12 @@
 //
 // KannalaBrandt8 rigs (Frame::Nleft != -1 / KeyFrame::NLeft != -1): every member in which the reference has a rig branch dispatches to the rig form
 // behind the C ABI — SearchByProjection(F, vpMapPoints), SearchByProjection(Cur, Last), SearchByBoW(pKF, F), SearchByBoW(pKF1, pKF2) (the
-// mvKeysUn.size() bound, :734), SearchForTriangulation, Fuse(pKF, vpMapPoints, th, bRight).  The members in which the reference has NO rig branch
-// (relocalisation's SearchByProjection(Frame, KeyFrame), SearchForInitialization, and loop closing's SearchBySim3, SearchByProjection(pKF, Scw, ...) x 2,
-// Fuse(pKF, Scw, ...)) would there run the left KannalaBrandt8 camera over mvKeysUn and, in two of them, read mvKeysUn[i] past its NLeft entries
-// (:1807 with i < N): these throw std::runtime_error on a rig instead of running the pinhole projection silently.
+// mvKeysUn.size() bound, :734), SearchForTriangulation, Fuse(pKF, vpMapPoints, th, bRight).  Loop closing's members have NO rig branch in the reference
+// and run there with the left camera's features (GetFeaturesInArea's bRight = false, mvKeysUn = mvKeys), projecting with mpCamera->project (the left
+// KannalaBrandt8 camera: SearchByProjection(pKF, Scw, ...), Fuse(pKF, Scw, ...)) or with the pinhole formula on pKF->fx ... (that search's twin with
+// vpPointsKFs, SearchBySim3): the keyframe views carry NLeft / the camera and the rig entry points do exactly that.  Two members throw
+// std::runtime_error on a rig instead of running the pinhole form silently: relocalisation's SearchByProjection(Frame, KeyFrame), where the reference
+// reads mvKeysUn[i] past its NLeft entries (:1807 with i < N), and SearchForInitialization (monocular initialisation only).
 #pragma once
 #include <set>
 
@@ -170,7 +172,6 @@ template <class KF, class Sim3, class MP>
 int ORBmatcher::sim3_projection_ref(KF* pKF, Sim3& Scw, const std::vector<MP*>& vpPoints, const std::vector<KF*>* vpPointsKFs, std::vector<MP*>& vpMatched,
                                     std::vector<KF*>* vpMatchedKF, int th, float ratioHamming) {
   using SE3 = typename std::decay<decltype(pKF->GetPose())>::type;
-  MORB_NO_RIG(pKF->NLeft != -1, "SearchByProjection(KeyFrame, Sim3)");
   morb_glue::Store<KeyFrameView> kf;
   morb_glue::keyframe_view(kf, pKF);
   Sim3View sv;
@@ -307,7 +308,6 @@ int ORBmatcher::SearchForTriangulation(KF* pKF1, KF* pKF2, std::vector<std::pair
 // int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12, const Sophus::Sim3f& S12, th)  ORBmatcher.cc:1323-1519
 template <class KF, class MP, class Sim3>
 int ORBmatcher::SearchBySim3(KF* pKF1, KF* pKF2, std::vector<MP*>& vpMatches12, const Sim3& S12, const float th) {
-  MORB_NO_RIG(pKF1->NLeft != -1 || pKF2->NLeft != -1, "SearchBySim3");
   morb_glue::Store<KeyFrameView> a, b;
   morb_glue::keyframe_view(a, pKF1); morb_glue::keyframe_view(b, pKF2);
   const std::vector<MP*> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
@@ -377,7 +377,6 @@ int ORBmatcher::Fuse(KF* pKF, const std::vector<MP*>& vpMapPoints, const float t
 template <class KF, class Sim3, class MP>
 int ORBmatcher::Fuse(KF* pKF, Sim3& Scw, const std::vector<MP*>& vpPoints, float th, std::vector<MP*>& vpReplacePoint) {
   using SE3 = typename std::decay<decltype(pKF->GetPose())>::type;
-  MORB_NO_RIG(pKF->NLeft != -1, "Fuse(KeyFrame, Sim3)");
   morb_glue::Store<KeyFrameView> kf;
   morb_glue::keyframe_view(kf, pKF);
   Sim3View sv;

@@ -135,10 +135,19 @@ inline void frame_view(Store<View>& s, F& f, PointRule rule = kSkipBad) {
   node_table(f.mFeatVec, f.N, s.node); s.v.featNode = s.node.data();
   fill_points(s, f.mvpMapPoints, rule, rule == kLastFrame ? &f.mvbOutlier : nullptr);
 }
+template <class Cam> inline void cam8(Cam* c, float out[8]);
+// KeyFrameView::NLeft / rigCam8 of a KannalaBrandt8 rig keyframe (a FrameView has no such members: nothing to do)
+template <class View, class KF>
+inline auto rig_of(View& v, KF* pKF) -> decltype(v.NLeft, void()) {
+  v.NLeft = pKF->NLeft;
+  if (pKF->NLeft != -1 && pKF->mpCamera) cam8(pKF->mpCamera, v.rigCam8);
+}
+inline void rig_of(...) {}
 template <class View, class KF>
 inline void keyframe_view(Store<View>& s, KF* pKF, PointRule rule = kSkipBad) {
   fill_keys(s, *pKF, pKF->N, pKF->NLeft);
   s.v.nValid = (int)pKF->mvKeysUn.size();
+  rig_of(s.v, pKF);
   fill_params(s.v.params, *pKF, pKF->mfGridElementWidthInv, pKF->mfGridElementHeightInv);
   fill_pose(s.v, pKF->GetPose());
   node_table(pKF->mFeatVec, pKF->N, s.node); s.v.featNode = s.node.data();

@@ -317,6 +317,64 @@ static int run_rig() {
     const std::vector<int> slots = index_of(kf.mvpMapPoints, pts);
     dump(t + "_n", &n, 1); dump(t + "_slots", slots.data(), slots.size());
   }
+  {   // loop closing on the rig keyframe: Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) and SearchByProjection(pKF, Scw, ...) x 2 — no rig branch in the
+      // reference: the left features, mpCamera->project (the twin: the pinhole formula on pKF->fx ...)
+    const auto pos = load<float>("rlc_pos"), nrm = load<float>("rlc_normal"), maxd = load<float>("rlc_maxd"), mind = load<float>("rlc_mind");
+    const auto desc = load<uint8_t>("rlc_desc"), valid = load<uint8_t>("rlc_valid");
+    const auto sim = load<float>("rlc_sim3");   // Tcw 7, Ow 3
+    const auto matched = load<int>("rlc_matched");
+    const int M = (int)maxd.size();
+    auto make_points = [&]() {
+      std::vector<MapPoint*> v(M);
+      for (int i = 0; i < M; ++i) {
+        v[i] = new_point(&pos[3 * i], &desc[(size_t)32 * i], maxd[i], mind[i], 1);
+        v[i]->mNormalVector = Eigen::Vector3f(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]);
+        v[i]->mbBad = valid[i] == 0;
+      }
+      return v;
+    };
+    Sophus::Sim3f Scw;
+    for (int i = 0; i < 4; ++i) Scw.T.q[i] = sim[i];
+    for (int i = 0; i < 3; ++i) { Scw.T.t[i] = sim[4 + i]; Scw.T.Ow[i] = sim[7 + i]; }
+    ORBmatcher matcher(0.8f, true);
+    {
+      KeyFrame kf; a2.fill(kf); split(kf, (int)cfg[5]);
+      for (auto& p : kf.mvpMapPoints) p = nullptr;   // (Fuse skips points the keyframe holds: the search's own selection is what is compared)
+      std::vector<MapPoint*> pts = make_points();
+      std::vector<MapPoint*> vpReplacePoint(M, static_cast<MapPoint*>(NULL));
+      const int n = matcher.Fuse(&kf, Scw, pts, 6.0f, vpReplacePoint);
+      const std::vector<int> slots = index_of(kf.mvpMapPoints, pts);
+      dump("rlc_fuse_n", &n, 1); dump("rlc_fuse_slots", slots.data(), slots.size());
+    }
+    for (int variant = 0; variant < 2; ++variant) {
+      KeyFrame kf; a2.fill(kf); split(kf, (int)cfg[5]);
+      std::vector<MapPoint*> pts = make_points();
+      MapPoint* taken = new_point(nullptr, nullptr, 1.f, 1.f, 1);
+      std::vector<MapPoint*> vpMatched(kf.N, static_cast<MapPoint*>(NULL));
+      for (int i = 0; i < kf.N; ++i) if (matched[i] >= 0) vpMatched[i] = taken;
+      std::vector<KeyFrame*> vpPointsKFs(M, &kf), vpMatchedKF;
+      const int n = variant == 0 ? matcher.SearchByProjection(&kf, Scw, pts, vpMatched, 8, 0.9f)
+                                 : matcher.SearchByProjection(&kf, Scw, pts, vpPointsKFs, vpMatched, vpMatchedKF, 8, 0.9f);
+      std::vector<int> idx = index_of(vpMatched, pts);
+      for (int i = 0; i < kf.N; ++i) if (vpMatched[i] == taken) idx[i] = -2;
+      const std::string tag = variant == 0 ? "rlc_proj" : "rlc_projk";
+      dump(tag + "_n", &n, 1); dump(tag + "_match", idx.data(), idx.size());
+    }
+  }
+  {   // SearchBySim3 between the two rig keyframes
+    Arrays b1("rs3_1"), b2("rs3_2");
+    KeyFrame k1, k2; b1.fill(k1); b2.fill(k2);
+    split(k1, (int)cfg[4]); split(k2, (int)cfg[5]);
+    const auto c3 = load<float>("rs3_cfg");   // th, S12 (7), S21 (7)
+    Sophus::Sim3f S12, S21;
+    for (int i = 0; i < 7; ++i) { S12.raw[i] = c3[1 + i]; S21.raw[i] = c3[8 + i]; }
+    S12.inv = &S21;
+    ORBmatcher matcher(0.8f, true);
+    std::vector<MapPoint*> vpMatches12(k1.N, static_cast<MapPoint*>(NULL));
+    const int n = matcher.SearchBySim3(&k1, &k2, vpMatches12, S12, c3[0]);
+    const std::vector<int> m12 = index_of(vpMatches12, k2.mvpMapPoints);
+    dump("rs3_n", &n, 1); dump("rs3_match", m12.data(), m12.size());
+  }
   std::printf("reference members (rig) ok\n");
   return 0;
 }

@@ -515,6 +515,44 @@ def test_fuse_on_a_rig_matches_oracle():
     assert tot > 800
 
 
+def _rig_sim3_problem(S, a, b, seed):
+    """SearchBySim3 between rig keyframes a and b: the projection is the pinhole formula on fx, fy, cx, cy even on a rig (ORBmatcher.cc:1375-1379), so the
+    map points are placed where that formula lands on a left feature of the other keyframe (random depths), owned by left AND right features of their own."""
+    from morb_slam_amd.synth import TUMVI_CAM_L, _quat_from_R
+    kps, desc, cnt, nl, poses = (S[k] for k in ("kps", "desc", "cnt", "nl", "poses"))
+    rng = np.random.default_rng(seed)
+    Na, NLa, N, NL = int(cnt[a]), int(nl[a]), int(cnt[b]), int(nl[b])
+    T = [poses[a], poses[b]]
+    T7 = [np.concatenate([_quat_from_R(t[:3, :3]), t[:3, 3]]).astype(np.float32) for t in T]
+    s12 = 1.01
+    R12 = T[0][:3, :3] @ T[1][:3, :3].T; t12 = T[0][:3, 3] - R12 @ T[1][:3, 3]
+    sim8 = lambda R, t, sc: np.concatenate([_quat_from_R(R) * np.sqrt(sc), t]).astype(np.float32)
+    S12 = sim8(R12, t12, s12); S21 = sim8(R12.T, -(R12.T @ t12) / s12, 1.0 / s12)
+    fx, fy, cx, cy = (float(TUMVI_CAM_L[i]) for i in range(4))
+
+    def points_for(dst, Ssd_R, Ssd_t, Ssd_s, Tsrc, pairs_src, pairs_dst):
+        """map points of the source keyframe's features pairs_src[q] that the search finds at the left feature pairs_dst[q] of keyframe `dst`"""
+        valid = np.zeros(S["cap"], np.uint8); Pw = np.zeros((S["cap"], 3), np.float32); maxD = np.ones(S["cap"], np.float32); minD = np.ones(S["cap"], np.float32)
+        mpd = rng.integers(0, 256, (S["cap"], 32), dtype=np.uint8)
+        for i, j in zip(pairs_src, pairs_dst):
+            kp = kps[dst, j]
+            z = rng.uniform(1.5, 8.0)
+            pd = np.array([(kp["x"] + rng.normal(0, 0.5) - cx) / fx * z, (kp["y"] + rng.normal(0, 0.5) - cy) / fy * z, z])      # in dst's camera
+            ps = Ssd_s * (Ssd_R @ pd) + Ssd_t                                                                                       # in src's camera
+            Pw[i] = Tsrc[:3, :3].T @ (ps - Tsrc[:3, 3])
+            dist = np.linalg.norm(pd)
+            maxD[i] = dist * 1.2 ** (int(kp["octave"]) + rng.uniform(0.1, 0.9)); minD[i] = maxD[i] / 1.2 ** 8
+            mpd[i] = desc[dst, j] ^ np.packbits(rng.random(256) < 0.03)
+            valid[i] = 1
+        return valid, Pw, maxD, minD, mpd
+    nPair = 150
+    i1 = rng.permutation(NLa)[:nPair]; j2 = rng.permutation(NL)[:nPair]                     # mutual pairs among the left features
+    x1 = NLa + rng.permutation(Na - NLa)[:60]; y2 = np.setdiff1d(np.arange(NL), j2)[:60]   # points owned by RIGHT features of keyframe 1, found in keyframe 2
+    k1 = points_for(b, R12, t12, s12, T[0], np.concatenate([i1, x1]), np.concatenate([j2, y2]))
+    k2 = points_for(a, R12.T, -(R12.T @ t12) / s12, 1.0 / s12, T[1], j2, i1)
+    return dict(T7=T7, S12=S12, S21=S21, k1=k1, k2=k2, x1=x1)
+
+
 def test_loop_closing_searches_on_a_rig_match_oracle():
     """The matcher members WITHOUT a rig branch in the reference, on KannalaBrandt8 rig keyframes (what LoopClosing runs on a stereo-fisheye
     sequence): Fuse(pKF, Scw, ...) and SearchByProjection(pKF, Scw, ...) project with pKF->mpCamera (the left KB8 camera), the latter's twin and
@@ -558,39 +596,12 @@ def test_loop_closing_searches_on_a_rig_match_oracle():
         assert (np.nonzero(me >= 0)[0] < NL).all()
         if not manual:
             assert r > 100
-    # ---- SearchBySim3(pKF1, pKF2, vpMatches12, S12, th): the projection is the pinhole formula on fx, fy, cx, cy even on a rig, so the test's map points
-    # are placed where that formula lands on a left feature of the other keyframe (random depths), owned by left AND right features of their own keyframe
     a = 0
     Na, NLa = int(cnt[a]), int(nl[a])
     Fa = O.make_frame(P, kps[a, :Na], desc[a, :Na], None)
-    T = [poses[a], poses[b]]
-    T7 = [np.concatenate([_quat_from_R(t[:3, :3]), t[:3, 3]]).astype(np.float32) for t in T]
-    s12 = 1.01
-    R12 = T[0][:3, :3] @ T[1][:3, :3].T; t12 = T[0][:3, 3] - R12 @ T[1][:3, 3]
-    sim8 = lambda R, t, sc: np.concatenate([_quat_from_R(R) * np.sqrt(sc), t]).astype(np.float32)
-    S12 = sim8(R12, t12, s12); S21 = sim8(R12.T, -(R12.T @ t12) / s12, 1.0 / s12)
-    fx, fy, cx, cy = (float(TUMVI_CAM_L[i]) for i in range(4))
-
-    def points_for(src, dst, nSrc, nDst, nlDst, Ssd_R, Ssd_t, Ssd_s, Tsrc, pairs_src, pairs_dst):
-        """map points of keyframe `src`'s features pairs_src[q] that the search finds at the left feature pairs_dst[q] of keyframe `dst`"""
-        valid = np.zeros(S["cap"], np.uint8); Pw = np.zeros((S["cap"], 3), np.float32); maxD = np.ones(S["cap"], np.float32); minD = np.ones(S["cap"], np.float32)
-        mpd = rng.integers(0, 256, (S["cap"], 32), dtype=np.uint8)
-        for i, j in zip(pairs_src, pairs_dst):
-            kp = kps[dst, j]
-            z = rng.uniform(1.5, 8.0)
-            pd = np.array([(kp["x"] + rng.normal(0, 0.5) - cx) / fx * z, (kp["y"] + rng.normal(0, 0.5) - cy) / fy * z, z])      # in dst's camera
-            ps = Ssd_s * (Ssd_R @ pd) + Ssd_t                                                                                       # in src's camera
-            Pw[i] = Tsrc[:3, :3].T @ (ps - Tsrc[:3, 3])
-            dist = np.linalg.norm(pd)
-            maxD[i] = dist * 1.2 ** (int(kp["octave"]) + rng.uniform(0.1, 0.9)); minD[i] = maxD[i] / 1.2 ** 8
-            mpd[i] = desc[dst, j] ^ np.packbits(rng.random(256) < 0.03)
-            valid[i] = 1
-        return valid, Pw, maxD, minD, mpd
-    nPair = 150
-    i1 = rng.permutation(NLa)[:nPair]; j2 = rng.permutation(NL)[:nPair]                     # mutual pairs among the left features
-    x1 = NLa + rng.permutation(Na - NLa)[:60]; y2 = np.setdiff1d(np.arange(NL), j2)[:60]   # points owned by RIGHT features of keyframe 1, found in keyframe 2
-    v1, Pw1, mx1, mn1, d1 = points_for(a, b, Na, N, NL, R12, t12, s12, T[0], np.concatenate([i1, x1]), np.concatenate([j2, y2]))
-    v2, Pw2, mx2, mn2, d2 = points_for(b, a, N, Na, NLa, R12.T, -(R12.T @ t12) / s12, 1.0 / s12, T[1], j2, i1)
+    q = _rig_sim3_problem(S, a, b, 809)
+    T7, S12, S21, x1 = q["T7"], q["S12"], q["S21"], q["x1"]
+    (v1, Pw1, mx1, mn1, d1), (v2, Pw2, mx2, mn2, d2) = q["k1"], q["k2"]
     o = m.SearchBySim3(P, cu(np.array([a], np.int32)), kfb, dk, dd, dc, one(T7[0]), one(T7[1]), one(S12), one(S21), one(v1), one(Pw1), one(mx1), one(mn1), one(d1),
                        one(v2), one(Pw2), one(mx2), one(mn2), one(d2), 7.5, nLeft1=cu(np.array([NLa], np.int32)), nLeft2=dnl)
     torch.cuda.synchronize()
@@ -653,6 +664,18 @@ def test_search_for_triangulation_rig_through_the_reference_member(tmp_path):
         pr = fuse[right] = _fuse_rig_problem(S, b, right, 90 + right)
         put(t + "_pos", pr["Xw"]); put(t + "_normal", pr["normal"]); put(t + "_maxd", pr["maxD"]); put(t + "_mind", pr["minD"]); put(t + "_desc", pr["mpd"])
         put(t + "_valid", pr["valid"]); put(t + "_pose", np.concatenate([pr["T7"], pr["Ow"]]).astype(np.float32))
+    # loop closing on keyframe b: Fuse(pKF, Scw, ...) / SearchByProjection(pKF, Scw, ...) x 2 with Scw = the left camera's pose, and SearchBySim3(a, b)
+    lc = _fuse_rig_problem(S, b, False, 95)
+    put("rlc_pos", lc["Xw"]); put("rlc_normal", lc["normal"]); put("rlc_maxd", lc["maxD"]); put("rlc_mind", lc["minD"]); put("rlc_desc", lc["mpd"])
+    put("rlc_valid", lc["valid"]); put("rlc_sim3", np.concatenate([lc["T7"], lc["Ow"]]).astype(np.float32))
+    lc_matched = np.where(np.random.default_rng(96).random(nb) < 0.1, 0, -1).astype(np.int32)
+    put("rlc_matched", lc_matched)
+    q3 = _rig_sim3_problem(S, a, b, 97)
+    from test_adapter_matcher_gpu import _pose22
+    for tag, i, n, (v, Pw, mx, mn, dsc), T7 in (("rs3_1", a, na, q3["k1"], q3["T7"][0]), ("rs3_2", b, nb, q3["k2"], q3["T7"][1])):
+        put(tag + "_kps", kps[i, :n]); put(tag + "_desc", desc[i, :n]); put(tag + "_params", Pb); put(tag + "_hasmp", v[:n]); put(tag + "_mppos", Pw[:n])
+        put(tag + "_mpmax", mx[:n]); put(tag + "_mpmin", mn[:n]); put(tag + "_mpdesc", dsc[:n]); put(tag + "_pose", _pose22(T7))
+    put("rs3_cfg", np.concatenate([[7.5], q3["S12"], q3["S21"]]).astype(np.float32))
     out = subprocess.run([_build(tmp_path, "reference_members_check.cc", mock_ref=True), str(d), "rig"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "reference members (rig) ok" in out.stdout, out.stdout + out.stderr
     T4 = np.stack([_mul_f32(four[0], four[2]), _mul_f32(four[0], four[3]), _mul_f32(four[1], four[2]), _mul_f32(four[1], four[3])])
@@ -680,6 +703,26 @@ def test_search_for_triangulation_rig_through_the_reference_member(tmp_path):
                 slots[ei[i]] = i
         np.testing.assert_array_equal(np.fromfile(str(d / ("out_ref_" + t + "_slots.bin")), np.int32), slots)
         assert int(np.fromfile(str(d / ("out_ref_" + t + "_n.bin")), np.int32)[0]) == int((ei >= 0).sum()) > 60
+    getr = lambda name: np.fromfile(str(d / ("out_ref_" + name + ".bin")), np.int32)
+    ei, _ = O.fuse_search_rig_sim3(Fo, int(nl[b]), TUMVI_CAM_L, invS, lc["T7"], lc["Ow"], lc["valid"], lc["Xw"], lc["normal"], lc["maxD"], lc["minD"], lc["mpd"], 6.0)
+    slots = np.full(nb, -1, np.int32)
+    for i in range(len(ei) - 1, -1, -1):
+        if ei[i] >= 0:
+            slots[ei[i]] = i
+    np.testing.assert_array_equal(getr("rlc_fuse_slots"), slots)
+    assert int(getr("rlc_fuse_n")[0]) == int((ei >= 0).sum()) > 100
+    for tag, manual in (("rlc_proj", False), ("rlc_projk", True)):
+        r, me = O.search_by_projection_sim3_rig(Fo, int(nl[b]), TUMVI_CAM_L, lc["T7"], lc["Ow"], lc["valid"], lc["Xw"], lc["normal"], lc["maxD"], lc["minD"], lc["mpd"],
+                                                (lc_matched >= 0).astype(np.uint8), 8, 0.9, manual)
+        assert int(getr(tag + "_n")[0]) == r and (manual or r > 100)
+        np.testing.assert_array_equal(getr(tag + "_match"), np.where(lc_matched >= 0, -2, me))
+    Fa = O.make_frame(S["P"], kps[a, :na], desc[a, :na], None)
+    (v1, Pw1, mx1, mn1, d1), (v2, Pw2, mx2, mn2, d2) = q3["k1"], q3["k2"]
+    e1 = O.search_by_sim3_dir_rig(Fo, int(nl[b]), q3["T7"][0], q3["S21"], v1[:na], Pw1[:na], mx1[:na], mn1[:na], d1[:na], 7.5)
+    e2 = O.search_by_sim3_dir_rig(Fa, int(nl[a]), q3["T7"][1], q3["S12"], v2[:nb], Pw2[:nb], mx2[:nb], mn2[:nb], d2[:nb], 7.5)
+    e12 = np.array([i2 if (i2 >= 0 and e2[i2] == k1) else -1 for k1, i2 in enumerate(e1)])
+    np.testing.assert_array_equal(getr("rs3_match"), e12)
+    assert int(getr("rs3_n")[0]) == int((e12 >= 0).sum()) > 100
 
 
 def test_c3_chain_on_extracted_features():
