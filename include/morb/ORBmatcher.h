@@ -102,7 +102,8 @@ class ORBmatcher {
     return dist;
   }
 
-  // Tracking::SearchLocalPoints' pair (Tracking.cc:3222-3285): Frame::isInFrustum(pMP, 0.5) for every candidate, then
+  // Tracking::SearchLocalPoints' pair (Tracking.cc:3117-3183): Frame::isInFrustum(pMP, 0.5) for every candidate — that host loop (IncreaseVisible,
+  // mnLastFrameSeen, mmProjectPoints) stays in the integrated tree, see the reference-typed member below — then
   // int SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, bFarPoints, thFarPoints)  (ORBmatcher.h:45-47,
   // ORBmatcher.cc:42-209).  matchF[i] = index of the map point assigned to feature i, or -1 (in/out: earlier assignments are kept
   // if the vector already has N entries).  Returns the reference's return value.
