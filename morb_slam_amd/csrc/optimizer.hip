@@ -214,6 +214,42 @@ __device__ __forceinline__ void jac_point(const Cam& cam, bool stereo, const dou
 
 // ---- block reductions (fixed order -> deterministic) --------------------------------------------------------
 __device__ __forceinline__ double wave_sum_d(double v) { return morbwave::sum_f64(v); }   // DPP (wave.h), all lanes active
+// Wave totals of 28 doubles at once, written to out[0 .. 27] (LDS).  Two butterfly steps on gfx950's v_permlane32_swap / v_permlane16_swap fold the
+// values four to a register — after them row r (16 lanes) of register g holds partial sums of value 4 g + {0, 2, 1, 3}[r]
+// (tools/micro/permlane_swap.hip prints the operand layout) — then a row total is sixteen v_fmac_f64_dpp row_newbcast (dense_ldlt.h) for four values together.
+// ~200 instruction slots instead of ~1200 for 28 six-step DPP reductions: a third of k_pose_opt's iteration, whose waves are alone on their SIMDs.
+// Fixed order (deterministic); not the order of sum_f64 (the tree-sum mode of PoseOptimization is the only caller).
+__device__ __forceinline__ double swap_add_f64(double a, double b, bool rows16) {
+  const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+  unsigned lo0, lo1, hi0, hi1;
+  if (rows16) {
+    auto l = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false); lo0 = l[0]; lo1 = l[1];
+    auto h = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false); hi0 = h[0]; hi1 = h[1];
+  } else {
+    auto l = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false); lo0 = l[0]; lo1 = l[1];
+    auto h = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false); hi0 = h[0]; hi1 = h[1];
+  }
+  return __longlong_as_double((long long)(((unsigned long long)hi0 << 32) | lo0)) + __longlong_as_double((long long)(((unsigned long long)hi1 << 32) | lo1));
+}
+template <int K>
+__device__ __forceinline__ void row_total_step(double& acc, double v, double minusOne) {
+  if constexpr (K < 16) { morbdense::fnma_row_bcast_f64<K, K == 0>(acc, v, minusOne); row_total_step<K + 1>(acc, v, minusOne); }
+}
+__device__ __forceinline__ void wave_sum28_to(const double (&v)[28], double* __restrict__ out, int lane) {
+  double c[14], d[7];
+#pragma unroll
+  for (int p = 0; p < 14; ++p) c[p] = swap_add_f64(v[2 * p], v[2 * p + 1], false);   // lanes 0 .. 31: value 2 p, lanes 32 .. 63: value 2 p + 1
+#pragma unroll
+  for (int g = 0; g < 7; ++g) d[g] = swap_add_f64(c[2 * g], c[2 * g + 1], true);      // rows 0 .. 3: values 4 g, 4 g + 2, 4 g + 1, 4 g + 3
+  const double minusOne = -1.0;
+  const int row = lane >> 4, idx = ((row & 1) << 1) | (row >> 1);
+#pragma unroll
+  for (int g = 0; g < 7; ++g) {
+    double tot = 0.0;
+    row_total_step<0>(tot, d[g], minusOne);   // tot += lane k of the row, k = 0 .. 15, in that order: every lane of the row ends with the row's total
+    if ((lane & 15) == 0) out[4 * g + idx] = tot;
+  }
+}
 template <int NW>
 __device__ __forceinline__ double block_sum_d(double v, double* red /*[NW]*/) {
   v = wave_sum_d(v);
@@ -573,10 +609,8 @@ __global__ __launch_bounds__(NT) void k_pose_opt(int cap, const int* __restrict_
         }
       }
       if (!ORDERED) {
-#pragma unroll
-        for (int k = 0; k < 28; ++k) acc[k] = wave_sum_d(acc[k]);
         __syncthreads();
-        if (lane == 0) for (int k = 0; k < 28; ++k) sH[wv][k] = acc[k];
+        wave_sum28_to(acc, sH[wv], lane);
         __syncthreads();
       }
       double H[36], b[6];
