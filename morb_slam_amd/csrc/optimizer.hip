@@ -609,8 +609,13 @@ __global__ __launch_bounds__(NT) void k_pose_opt(int cap, const int* __restrict_
         }
       }
       if (!ORDERED) {
+        // (the chi2 entry keeps the reduction order of chi2Active's block sum: rho compares the two, and near convergence their difference is of the
+        // size of a summation-order effect)
+        const double chiW = wave_sum_d(acc[27]);
+        acc[27] = 0;
         __syncthreads();
         wave_sum28_to(acc, sH[wv], lane);
+        if (lane == 0) sH[wv][27] = chiW;   // (a later instruction than the zero lane 48 just stored there: LDS keeps a wave's instructions in order)
         __syncthreads();
       }
       double H[36], b[6];
