@@ -2084,7 +2084,7 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
     for (int k = 4; k < 8; ++k) __atomic_store_n(p->h_stop + k, 0, __ATOMIC_RELAXED);
     forwardStop();
     hipLaunchKernelGGL(k_g_chi2, dim3(rb), dim3(GB), 0, st, d, part0, (const double*)part1, 2);
-    constexpr int kAhead = 1;   // trials queued beyond the last decided one
+    constexpr int kAhead = 1;   // trials queued beyond the last decided one (the seven launches of a trial as one hipGraph: 0.89 -> 0.95 ms per solve, profiles/r04/README.md)
     for (int slot = 0; slot < 100; ++slot) {
       // buildSystem (runs only when the previous trial was accepted): keyframe chunks and map points in one launch
       if (h.rig) hipLaunchKernelGGL(k_g_build<true>, dim3(kfBlocks + div_up(h.nMP, GB / MP_LANES)), dim3(GB), 0, st, d, kfBlocks);
