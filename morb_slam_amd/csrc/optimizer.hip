@@ -107,6 +107,32 @@ __device__ __forceinline__ SE3 se3_mul(const SE3& a, const SE3& b) {
   se3_normalize(r);
   return r;
 }
+// x^3 rounded once (up to a double rounding in rare cases): glibc's pow — what g2o's `pow(theta, 3)` and `pow(2 * rho - 1, 3)` call on the CPU — is
+// accurate to ~0.52 ulp, x * x * x carries two roundings.  Error-free products through FMA, then one sum.
+__device__ __forceinline__ double cube_rn(double x) {
+  const double p = x * x, e = __builtin_fma(x, x, -p);      // x^2 = p + e
+  const double q = p * x, f = __builtin_fma(p, x, -q);      // p x = q + f
+  return q + (f + e * x);
+}
+// glibc's sin for |x| < 0.126 (sysdeps/ieee754/dbl-64/s_sin.c: TAYLOR_SIN, 0.501 ulp; |x| < 2^-26: x): the argument range of an LM update's rotation.
+// Larger arguments fall back to the device library's sin (<= 1 ulp from it).
+__device__ __forceinline__ double sin_glibc_small(double x) {
+  const double ax = fabs(x);
+  if (ax < 0x1p-26) return x;
+  if (ax < 0.126) {
+    const double s1 = -0x1.5555555555555p-3, s2 = 0x1.1111111110ECEp-7, s3 = -0x1.A01A019DB08B8p-13, s4 = 0x1.71DE27B9A7ED9p-19, s5 = -0x1.ADDFFC2FCDF59p-26;
+    const double xx = x * x;
+    const double poly = ((((s5 * xx + s4) * xx + s3) * xx + s2) * xx) + s1;
+    const double t = (poly * x - 0.5 * 0.0) * xx + 0.0;   // TAYLOR_SIN(xx, a, da) with da = 0
+    return x + t;
+  }
+  return sin(x);
+}
+#ifdef XP_TRIG
+
+__device__ __forceinline__ double xp_sin(double x) { const double xx = x * x; return x * (1.0 + xx * (-1.0 / 6 + xx * (1.0 / 120 + xx * (-1.0 / 5040 + xx * (1.0 / 362880 + xx * (-1.0 / 39916800)))))); }
+__device__ __forceinline__ double xp_cos(double x) { const double xx = x * x; return 1.0 + xx * (-0.5 + xx * (1.0 / 24 + xx * (-1.0 / 720 + xx * (1.0 / 40320 + xx * (-1.0 / 3628800 + xx * (1.0 / 479001600)))))); }
+#endif
 __device__ __forceinline__ SE3 se3_exp(const double* u) {
   const double wx = u[0], wy = u[1], wz = u[2];
   const double theta = sqrt(wx * wx + wy * wy + wz * wz);
@@ -121,8 +147,13 @@ __device__ __forceinline__ SE3 se3_exp(const double* u) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + Om[i] + Om2[i]; V[i] = R[i]; }
   } else {
-    const double s = sin(theta), c = cos(theta);
+#ifdef XP_TRIG
+    const double s = xp_sin(theta), c = xp_cos(theta);
     const double a = s / theta, b = (1 - c) / (theta * theta), cc = (theta - s) / (theta * theta * theta);
+#else
+    const double s = sin_glibc_small(theta), c = cos(theta);
+    const double a = s / theta, b = (1 - c) / (theta * theta), cc = (theta - s) / cube_rn(theta);
+#endif
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
       R[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * Om[i] + b * Om2[i];
@@ -446,6 +477,11 @@ __device__ __forceinline__ double ordered_add(double tot, const double* __restri
   }
   return tot;
 }
+#ifdef MORB_PO_TRACE
+__device__ double g_poTrace[6 * 520];
+__device__ int g_poTraceN;
+extern "C" int morb_po_trace(double* out, int* n) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_poTrace), sizeof(double) * 6 * 520); (void)hipMemcpyFromSymbol(n, HIP_SYMBOL(g_poTraceN), sizeof(int)); const int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_poTraceN), &z, sizeof z); return 0; }
+#endif
 template <bool FISH, bool ORDERED, int NT>
 __global__ __launch_bounds__(NT) void k_pose_opt(int cap, const int* __restrict__ count, const uint8_t* __restrict__ hasMP,
                                                   const float* __restrict__ obs, const float* __restrict__ invSigma2,
@@ -559,7 +595,7 @@ __global__ __launch_bounds__(NT) void k_pose_opt(int cap, const int* __restrict_
               for (int k = 0; k < 3; ++k) bb += Jp[k * 6 + r] * wr[k];   // (mono: row 2 and err[2] are zero)
               con[21 + r] = bb;
 #pragma unroll
-              for (int cc = r; cc < 6; ++cc) {
+              for (int cc = 0; cc <= r; ++cc) {   // the LOWER triangle, (J_r w Omega) J_c as Eigen forms it: LinearSolverDense's LDLT reads that triangle
                 double h = 0;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) h += Jp[k * 6 + r] * wo * Jp[k * 6 + cc];
@@ -600,7 +636,7 @@ __global__ __launch_bounds__(NT) void k_pose_opt(int cap, const int* __restrict_
           for (int k = 0; k < 3; ++k) bb += Jp[k * 6 + r] * (info * err[k]);   // mono: row 2 and err[2] are zero; a runtime bound would push Jp into scratch memory
           acc[21 + r] -= w * bb;  // b -= rho' * J^T * Omega * e  (base_unary_edge.hpp:61)
 #pragma unroll
-          for (int cc = r; cc < 6; ++cc) {
+          for (int cc = 0; cc <= r; ++cc) {   // the LOWER triangle, (J_r w Omega) J_c as Eigen forms it: LinearSolverDense's LDLT reads that triangle
             double h = 0;
 #pragma unroll
             for (int k = 0; k < 3; ++k) h += Jp[k * 6 + r] * wo * Jp[k * 6 + cc];
@@ -626,10 +662,13 @@ __global__ __launch_bounds__(NT) void k_pose_opt(int cap, const int* __restrict_
           else { double t = sH[0][k]; for (int w = 1; w < NW; ++w) t += sH[w][k]; tot[k] = t; }   // ((s0 + s1) + s2) + s3 ...: the order of the 4-wave form
         }
         int q = 0;
-        for (int r = 0; r < 6; ++r) for (int cc = r; cc < 6; ++cc) { H[r * 6 + cc] = tot[q]; H[cc * 6 + r] = tot[q]; ++q; }
+        for (int r = 0; r < 6; ++r) for (int cc = 0; cc <= r; ++cc) { H[r * 6 + cc] = tot[q]; H[cc * 6 + r] = tot[q]; ++q; }   // (the solve reads the lower triangle)
         for (int r = 0; r < 6; ++r) b[r] = tot[21 + r];
         acc[27] = tot[27];
       }
+#ifdef MORB_PO_TRACE
+      if (f == 0 && tid == 0 && outerIts == 1) { double* t = g_poTrace + 6 * 504; for (int k = 0; k < 36; ++k) t[k] = H[k]; for (int k = 0; k < 6; ++k) t[36 + k] = b[k]; }
+#endif
       double currentChi = acc[27];
       const double iniChi = currentChi;
       if (iter == 0) {  // computeLambdaInit (tau = 1e-5)
@@ -654,8 +693,12 @@ __global__ __launch_bounds__(NT) void k_pose_opt(int cap, const int* __restrict_
         for (int r = 0; r < 6; ++r) scale += x[r] * (lambda * x[r] + b[r]);
         scale += 1e-3;
         rho /= scale;
+#ifdef MORB_PO_TRACE
+        if (f == 0 && tid == 0 && g_poTraceN == 0) { double* t = g_poTrace + 6 * 500; for (int k = 0; k < 6; ++k) t[k] = x[k]; for (int k = 0; k < 4; ++k) t[6 + k] = Teval.q[k]; for (int k = 0; k < 3; ++k) t[10 + k] = Teval.t[k]; }
+        if (f == 0 && tid == 0 && g_poTraceN < 500) { double* t = g_poTrace + 6 * g_poTraceN++; t[0] = currentChi; t[1] = tempChi; t[2] = lambda; t[3] = rho; t[4] = scale; t[5] = ok2; }
+#endif
         if (rho > 0 && isfinite(tempChi)) {
-          double alpha = 1. - pow((2 * rho - 1), 3);
+          double alpha = 1. - cube_rn(2 * rho - 1);
           alpha = fmin(alpha, 2. / 3.);
           lambda *= fmax(1. / 3., alpha);
           ni = 2;
@@ -1059,7 +1102,7 @@ __global__ __launch_bounds__(BA_T) void k_local_ba(const BaDev* __restrict__ pro
       double scale = block_sum_d<BA_W>(part, red) + 1e-3;
       rho /= scale;
       if (rho > 0 && isfinite(tempChi)) {
-        double alpha = 1. - pow((2 * rho - 1), 3);
+        double alpha = 1. - cube_rn(2 * rho - 1);
         alpha = fmin(alpha, 2. / 3.);
         lambda *= fmax(1. / 3., alpha);
         ni = 2;
@@ -1136,7 +1179,7 @@ __device__ void lm_decide(const BaDev& pb, double s0, double s1) {
   const double rho = (currentChi - tempChi) / (s1 + 1e-3);
   const bool accept = rho > 0 && isfinite(tempChi);
   if (accept) {
-    double alpha = 1. - pow((2 * rho - 1), 3);
+    double alpha = 1. - cube_rn(2 * rho - 1);
     alpha = fmin(alpha, 2. / 3.);
     lambda *= fmax(1. / 3., alpha);
     ni = 2;

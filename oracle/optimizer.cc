@@ -24,6 +24,7 @@
 #include "matcher.h"
 #include "orb_oracle.h"
 
+double* g_orcTrace = nullptr; int g_orcTraceCap = 0, g_orcTraceN = 0;   // developer hook: per LM trial {currentChi, tempChi, lambda, rho, scale, ok}
 namespace orc {
 namespace ba {
 
@@ -97,6 +98,17 @@ static void mat3mul(const double A[9], const double B[9], double C[9]) {
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
 }
+#ifdef XP_TRIG
+static inline double xp_sin(double x) { const double xx = x * x; return x * (1.0 + xx * (-1.0 / 6 + xx * (1.0 / 120 + xx * (-1.0 / 5040 + xx * (1.0 / 362880 + xx * (-1.0 / 39916800)))))); }
+static inline double xp_cos(double x) { const double xx = x * x; return 1.0 + xx * (-0.5 + xx * (1.0 / 24 + xx * (-1.0 / 720 + xx * (1.0 / 40320 + xx * (-1.0 / 3628800 + xx * (1.0 / 479001600)))))); }
+#define XSIN xp_sin
+#define XCOS xp_cos
+#define XPOW3(t) ((t) * (t) * (t))
+#else
+#define XSIN std::sin
+#define XCOS std::cos
+#define XPOW3(t) std::pow(t, 3)
+#endif
 static SE3Quat expSE3(const double u[6]) {  // se3quat.h:219-250
   const double omega[3] = {u[0], u[1], u[2]}, upsilon[3] = {u[3], u[4], u[5]};
   const double theta = std::sqrt(omega[0] * omega[0] + omega[1] * omega[1] + omega[2] * omega[2]);
@@ -108,8 +120,8 @@ static SE3Quat expSE3(const double u[6]) {  // se3quat.h:219-250
     for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0 ? 1.0 : 0.0) + Om[i] + Om2[i];
     memcpy(V, R, sizeof R);
   } else {
-    const double a = std::sin(theta) / theta, b = (1 - std::cos(theta)) / (theta * theta);
-    const double c = (theta - std::sin(theta)) / std::pow(theta, 3);
+    const double a = XSIN(theta) / theta, b = (1 - XCOS(theta)) / (theta * theta);
+    const double c = (theta - XSIN(theta)) / XPOW3(theta);
     for (int i = 0; i < 9; ++i) {
       R[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * Om[i] + b * Om2[i];
       V[i] = (i % 4 == 0 ? 1.0 : 0.0) + b * Om[i] + c * Om2[i];
@@ -458,6 +470,7 @@ struct Graph {
     double tempChi = currentChi;
     const double iniChi = currentChi;
     buildSystem();
+    if (g_orcTrace && g_orcTraceN == 0 && g_orcTraceCap >= 512 && nFreePoints == 0) { double* t = g_orcTrace + 6 * 504; for (int k = 0; k < 36; ++k) t[k] = Hpp[k]; for (int k = 0; k < 6; ++k) t[36 + k] = b[k]; }
     if (iteration == 0) { lambda = computeLambdaInit(); ni = 2; nBad = 0; }
     double rho = 0;
     int qmax = 0;
@@ -473,6 +486,8 @@ struct Graph {
       for (size_t j = 0; j < x.size(); ++j) scale += x[j] * (lambda * x[j] + b[j]);
       scale += 1e-3;
       rho /= scale;
+      if (g_orcTrace && g_orcTraceN == 0 && g_orcTraceCap >= 512) { double* t = g_orcTrace + 6 * 500; for (int k = 0; k < 6; ++k) t[k] = x[k]; for (size_t i = 0; i < poses.size(); ++i) if (poseCol[i] >= 0) { for (int k = 0; k < 4; ++k) t[6 + k] = poses[i].q[k]; for (int k = 0; k < 3; ++k) t[10 + k] = poses[i].t[k]; } }
+      if (g_orcTrace && g_orcTraceN < 500) { double* t = g_orcTrace + 6 * g_orcTraceN++; t[0] = currentChi; t[1] = tempChi; t[2] = lambda; t[3] = rho; t[4] = scale; t[5] = ok2; }
       if (rho > 0 && std::isfinite(tempChi)) {
         double alpha = 1. - std::pow((2 * rho - 1), 3);
         alpha = std::min(alpha, 2. / 3.);
@@ -514,6 +529,8 @@ extern "C" {
 // obs[i] = (kpUn.x, kpUn.y, mvuRight[i]) (mvuRight < 0 => monocular edge); pose = unit quaternion (x,y,z,w) +
 // translation as floats, in/out; outlier[i] = mvbOutlier[i].  Returns nInitialCorrespondences - nBad
 // (0 when fewer than 3 correspondences).  stats (optional, 2 ints): outer LM iterations, LM trials.
+void orc_set_trace(double* buf, int cap) { g_orcTrace = buf; g_orcTraceCap = cap; g_orcTraceN = 0; }
+int orc_trace_count() { return g_orcTraceN; }
 int orc_pose_optimization(int n, const uint8_t* hasMP, const float* obs, const float* invSigma2, const float* Xw,
                           float fx, float fy, float cx, float cy, float bf, float* pose, uint8_t* outlier, int* stats) {
   Graph g;

@@ -28,16 +28,24 @@ def run_pose(NP, seed=11, log=print):
     t = [torch.from_numpy(np.stack([pad(p[k]) for p in probs])).cuda() for k in ("hasMP", "obs", "invSigma2", "Xw")]
     pose = torch.from_numpy(np.stack([p["pose0"] for p in probs])).cuda()
     cnt = torch.tensor([len(p["hasMP"]) for p in probs], dtype=torch.int32, device="cuda")
-    out = opt.PoseOptimization(t[0], t[1], t[2], t[3], pose, probs[0]["cam"], count=cnt)
-    torch.cuda.synchronize()
-    poseg = pose.cpu().numpy(); nin = out[0].cpu().numpy(); outl = out[1].cpu().numpy(); st = out[2].cpu().numpy()
-    for f, p in enumerate(probs):
-        r, pe, oe, se = O.pose_optimization(p)
-        n = len(p["hasMP"])
-        ok = np.abs(poseg[f] - pe).max() <= 1e-4 and nin[f] == r and np.array_equal(outl[f, :n], oe) and int(st[f][0]) == int(se[0])
-        if not ok:
-            bad += 1
-            log(f"PoseOptimization case {f}: MISMATCH dpose {np.abs(poseg[f] - pe).max():.2e} inliers {nin[f]} / {r} flags {int((outl[f, :n] != oe).sum())} its {st[f]} / {se}")
+    ora = [O.pose_optimization(p) for p in probs]
+    # the deterministic mode (edge-order sums) is held to the LM path too: iterations AND trials; the default tree-sum mode to the results
+    for exact in (True, False):
+        opt.set_exact_order(exact)
+        ps = pose.clone()
+        out = opt.PoseOptimization(t[0], t[1], t[2], t[3], ps, probs[0]["cam"], count=cnt)
+        torch.cuda.synchronize()
+        poseg = ps.cpu().numpy(); nin = out[0].cpu().numpy(); outl = out[1].cpu().numpy(); st = out[2].cpu().numpy()
+        for f, p in enumerate(probs):
+            r, pe, oe, se = ora[f]
+            n = len(p["hasMP"])
+            ok = np.abs(poseg[f] - pe).max() <= 1e-4 and nin[f] == r and np.array_equal(outl[f, :n], oe)
+            if exact:
+                ok = ok and int(st[f][0]) == int(se[0]) and int(st[f][1]) == int(se[1])
+            if not ok:
+                bad += 1
+                log(f"PoseOptimization case {f} ({'edge-order' if exact else 'tree'} sums): MISMATCH dpose {np.abs(poseg[f] - pe).max():.2e} inliers {nin[f]} / {r} "
+                    f"flags {int((outl[f, :n] != oe).sum())} its {st[f]} / {se}")
     return NP, bad
 
 
