@@ -360,7 +360,8 @@ def _tri_scene():
     from morb_slam_amd.synth import (TUMVI_CAM_L, TUMVI_CAM_R, TUMVI_T_C1_C2, kb8_project, make_vocabulary, _quat_from_rotvec,
                                      _quat_rot)
     P, sf = _fisheye_params()
-    rng = np.random.default_rng(314)
+    import os
+    rng = np.random.default_rng(314 + int(os.environ.get("MORB_TEST_SEED", "0")))   # (tools/stress_matchers.sh: the rig tests again on other scenes)
     Trl_m = np.linalg.inv(TUMVI_T_C1_C2)
 
     def se3(rv, t):

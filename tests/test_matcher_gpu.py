@@ -20,7 +20,9 @@ def make_batch():
     """4 stereo frames extracted on the GPU (bit-exact with the oracle per test_extractor_gpu) + oracle twins."""
     import torch
     from morb_slam_amd import KP_DTYPE, ORBextractor
-    pairs = [make_stereo_pair(752, 480, seed=60 + i) for i in range(2)]
+    import os
+    off = 10 * int(os.environ.get("MORB_TEST_SEED", "0"))   # (tools/stress_matchers.sh: the whole file again on other images)
+    pairs = [make_stereo_pair(752, 480, seed=60 + off + i) for i in range(2)]
     pairs += [tuple(shift_image(im, 4, 2) for im in pairs[0]), tuple(shift_image(im, 7, -3) for im in pairs[1])]
     imgs = np.stack([im for p in pairs for im in p])
     ext = ORBextractor(1200, 1.2, 8, 20, 7)
