@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of PoseOptimization and LocalBundleAdjustment against the CPU oracle (GPU box): more seeds and problem shapes
-than the fixtures of tests/; the tests' criteria (pose / points within 1e-4, outlier and erase flags identical, the same LM iterations).
+than the fixtures of tests/; the tests' criteria (pose / points within 1e-4, outlier and erase flags identical, the same LM iterations and trials —
+PoseOptimization in its deterministic mode; its tree-sum mode is held to the results).
 A seeded subset runs in `-m gpu` (tests/test_stress_gpu.py); the full sweep: python tools/stress_optimizers.py [pose cases] [ba cases]"""
 import os
 import sys
@@ -62,8 +63,8 @@ def run_ba(NB, seed=11, log=print, max_points=3000):
         b = make_ba_problem(**kw)
         kf, mp, erase, stats = opt.LocalBundleAdjustment(b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"], b["eInvSigma2"], b["cam"])
         its, kfe, mpe, ee, se = O.local_ba(b)
-        ok = (int(stats[0]) == int(se[0]) and np.abs(kf - kfe).max() <= 1e-4 and np.abs(mp - mpe).max() <= 1e-4 * max(1.0, np.abs(mpe).max())
-              and np.array_equal(erase, ee))
+        ok = (int(stats[0]) == int(se[0]) and int(stats[1]) == int(se[1]) and np.abs(kf - kfe).max() <= 1e-4
+              and np.abs(mp - mpe).max() <= 1e-4 * max(1.0, np.abs(mpe).max()) and np.array_equal(erase, ee))   # iterations AND trials
         if not ok:
             bad += 1
             log(f"LocalBA case {kw}: MISMATCH dkf {np.abs(kf - kfe).max():.2e} dmp {np.abs(mp - mpe).max():.2e} flags {int((erase != ee).sum())} its {stats} / {se}")
