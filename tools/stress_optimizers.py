@@ -50,6 +50,44 @@ def run_pose(NP, seed=11, log=print):
     return NP, bad
 
 
+def run_pose_rig(NP, seed=11, log=print):
+    """PoseOptimization on the KannalaBrandt8 rig (left-camera edges + right-camera ToBody edges), both modes."""
+    import torch
+    import oracle_lib as O
+    from morb_slam_amd import Optimizer
+    from morb_slam_amd.synth import make_pose_problem_fisheye
+    rng = np.random.default_rng(seed + 2)
+    probs = [make_pose_problem_fisheye(int(rng.choice([60, 200, 400])), int(rng.choice([40, 150, 300])), seed=900 + 31 * seed + s,
+                                       outlier_frac=float(rng.choice([0.05, 0.15, 0.3]))) for s in range(NP)]
+    cap = max(len(p["hasMP"]) for p in probs)
+    F = len(probs)
+    has = np.zeros((F, cap), np.uint8); obs = np.zeros((F, cap, 3), np.float32); inv = np.ones((F, cap), np.float32)
+    Xw = np.zeros((F, cap, 3), np.float32); pose = np.zeros((F, 7), np.float32); cnt = np.zeros(F, np.int32); nl = np.zeros(F, np.int32)
+    for f, p in enumerate(probs):
+        n = len(p["hasMP"]); cnt[f] = n; nl[f] = p["Nleft"]
+        has[f, :n] = p["hasMP"]; obs[f, :n] = p["obs"]; inv[f, :n] = p["invSigma2"]; Xw[f, :n] = p["Xw"]; pose[f] = p["pose0"]
+    ora = [O.pose_optimization_fisheye(p) for p in probs]
+    opt = Optimizer()
+    bad = 0
+    for exact in (True, False):
+        opt.set_exact_order(exact)
+        t = [torch.from_numpy(a.copy()).cuda() for a in (has, obs, inv, Xw, pose, nl, cnt)]
+        nin, outl, st = opt.PoseOptimizationFisheye(t[0], t[1], t[2], t[3], t[4], t[5], t[6], probs[0]["camL"], probs[0]["camR"], probs[0]["Trl"])
+        torch.cuda.synchronize()
+        pg = t[4].cpu().numpy(); nin = nin.cpu().numpy(); outl = outl.cpu().numpy(); st = st.cpu().numpy()
+        for f, p in enumerate(probs):
+            r, pe, oe, se = ora[f]
+            n = len(p["hasMP"])
+            ok = np.abs(pg[f] - pe).max() <= 1e-4 and int(nin[f]) == r and np.array_equal(outl[f, :n], oe)
+            if exact:
+                ok = ok and int(st[f][0]) == int(se[0]) and int(st[f][1]) == int(se[1])
+            if not ok:
+                bad += 1
+                log(f"PoseOptimization (rig) case {f} ({'edge-order' if exact else 'tree'} sums): MISMATCH dpose {np.abs(pg[f] - pe).max():.2e} inliers {nin[f]} / {r} "
+                    f"flags {int((outl[f, :n] != oe).sum())} its {st[f]} / {se}")
+    return NP, bad
+
+
 def run_ba(NB, seed=11, log=print, max_points=3000):
     import oracle_lib as O
     from morb_slam_amd import Optimizer
@@ -75,6 +113,9 @@ if __name__ == "__main__":
     NP = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     NB = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     _, b1 = run_pose(NP)
+    nr, b3 = run_pose_rig(max(NP // 2, 1))
+    print(f"PoseOptimization on the rig: {nr} cases checked, {b3} mismatches", flush=True)
+    b1 += b3
     print(f"PoseOptimization: {NP} cases checked")
     _, b2 = run_ba(NB)
     print(f"LocalBundleAdjustment: {NB} cases checked; {b1 + b2} mismatches in total")
