@@ -23,3 +23,15 @@ def test_optimizer_stress_subset():
     n1, b1 = stress_optimizers.run_pose(24, seed=11, log=log.append)
     n2, b2 = stress_optimizers.run_ba(6, seed=11, log=log.append, max_points=1500)
     assert b1 + b2 == 0, "\n".join(log)
+
+
+def test_other_pyramids_and_rig_pose_stress_subset():
+    """Other pyramids (scale factors 1.1 - 1.5, 3 - 12 levels, 100 - 5000 features: the library may refuse a configuration loudly, never answer it wrongly) and
+    PoseOptimization on the KannalaBrandt8 rig in both modes (the deterministic one: iterations and trials of the oracle)."""
+    import stress_optimizers
+    import stress_parity
+    log = []
+    n, bad = stress_parity.run_pyramids(12, seed=9, log=log.append)
+    assert n >= 8 and bad == 0, "\n".join(l for l in log if "MISMATCH" in l)
+    n3, b3 = stress_optimizers.run_pose_rig(12, seed=11, log=log.append)
+    assert b3 == 0, "\n".join(log)

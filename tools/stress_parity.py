@@ -35,7 +35,7 @@ def levels_for(W, H):
     return n
 
 
-def check_case(imgs, nf, ini, mn, log=None, tag=""):
+def check_case(imgs, nf, ini, mn, log=None, tag="", scale=1.2, nlev=None):
     """One batch (2 f = left, 2 f + 1 = right) through the HIP extractor + ComputeStereoMatches and through the oracle; True when identical,
     None when the extractor refused the batch (morb_extractor_status: more than 65535 FAST candidates on a level)."""
     import torch
@@ -43,14 +43,14 @@ def check_case(imgs, nf, ini, mn, log=None, tag=""):
     from morb_slam_amd import KP_DTYPE, ORBextractor, ORBmatcher
     mbf, mb = np.float32(458.654 * 0.11), np.float32(0.11)
     nfr = len(imgs) // 2
-    nlev = levels_for(imgs.shape[2], imgs.shape[1])
-    ext = ORBextractor(nf, 1.2, nlev, ini, mn)
-    kps, desc, cnt, mono = ext.extract_batch(torch.from_numpy(imgs).cuda())
-    u, d = ORBmatcher().ComputeStereoMatches(ext, kps, desc, cnt, mbf, mb)
-    torch.cuda.synchronize()
+    nlev = nlev or levels_for(imgs.shape[2], imgs.shape[1])
+    ext = ORBextractor(nf, scale, nlev, ini, mn)
     try:
+        kps, desc, cnt, mono = ext.extract_batch(torch.from_numpy(imgs).cuda())
+        u, d = ORBmatcher().ComputeStereoMatches(ext, kps, desc, cnt, mbf, mb)
+        torch.cuda.synchronize()
         ext.check_status()
-    except RuntimeError as e:   # the documented limit (a pyramid level with more than 65535 FAST candidates): refused loudly, not a parity case
+    except RuntimeError as e:   # (MorbError is a RuntimeError: a configuration the library refuses — e.g. a per-level quota beyond the LDS-resident quadtree)   # the documented limit (a pyramid level with more than 65535 FAST candidates): refused loudly, not a parity case
         if log:
             log(f"{tag}: {imgs.shape[2]}x{imgs.shape[1]} nfeat {nf} th {ini}/{mn} frames {nfr}: refused ({str(e)[:60]}...)")
         ext.close()
@@ -58,7 +58,7 @@ def check_case(imgs, nf, ini, mn, log=None, tag=""):
     c = cnt.cpu().numpy(); kn = kps.cpu().numpy(); dn = desc.cpu().numpy(); un = u.cpu().numpy(); dd = d.cpu().numpy()
     ora, ok = [], True
     for i, im in enumerate(imgs):
-        o = O.OracleExtractor(nf, 1.2, nlev, ini, mn)
+        o = O.OracleExtractor(nf, scale, nlev, ini, mn)
         _, k, de = o(im)
         ora.append((o, k, de))
         if c[i] != len(k) or kn[i, :c[i]].reshape(-1).view(KP_DTYPE).tobytes() != k.tobytes() or dn[i, :c[i]].tobytes() != de.tobytes():
@@ -70,7 +70,7 @@ def check_case(imgs, nf, ini, mn, log=None, tag=""):
         if un[f, :n].tobytes() != ue.tobytes() or dd[f, :n].tobytes() != dep.tobytes():
             ok = False
     if log:
-        log(f"{tag}: {imgs.shape[2]}x{imgs.shape[1]} nfeat {nf} levels {nlev} th {ini}/{mn} frames {nfr} keypoints {int(c.sum())}: {'ok' if ok else 'MISMATCH'}")
+        log(f"{tag}: {imgs.shape[2]}x{imgs.shape[1]} nfeat {nf} levels {nlev} scale {scale} th {ini}/{mn} frames {nfr} keypoints {int(c.sum())}: {'ok' if ok else 'MISMATCH'}")
     ext.close()
     return ok
 
@@ -108,7 +108,30 @@ def run(cases, seed=7, log=print, specials=True, odd=ODD_SHAPES, max_pixels=None
     return n, bad
 
 
+def run_pyramids(cases, seed=9, log=print):
+    """other pyramids: scale factors 1.1 - 1.5, 3 - 12 levels, 100 - 5000 features (the reference's yaml files use 1.2 / 8 / 1000 - 2000 throughout)"""
+    from morb_slam_amd.synth import make_stereo_pair
+    rng = np.random.default_rng(seed)
+    bad = n = 0
+    for case in range(cases):
+        W, H = SHAPES[int(rng.integers(0, len(SHAPES)))]
+        scale = float(rng.choice([1.1, 1.2, 1.25, 1.3, 1.44, 1.5]))
+        nlev = int(rng.choice([3, 5, 6, 8, 10, 12]))
+        while nlev > 1 and round(min(W, H) / scale ** (nlev - 1)) < 76:
+            nlev -= 1
+        nf = int(rng.choice([100, 300, 1000, 3000, 5000]))
+        l, r = make_stereo_pair(W, H, seed=5000 + 10 * seed + case)
+        res = check_case(np.stack([l, r]), nf, 20, 7, log, f"pyramid {case}", scale=scale, nlev=nlev)
+        bad += 1 if res is False else 0
+        n += 0 if res is None else 1
+    return n, bad
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "pyramids":
+        n, bad = run_pyramids(int(sys.argv[2]), log=lambda s: print(s, flush=True))
+        print(f"{n - bad} / {n} pyramid cases identical")
+        sys.exit(1 if bad else 0)
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     n, bad = run(N, log=lambda s: print(s, flush=True))
     print(f"{n - bad} / {n} cases identical")
