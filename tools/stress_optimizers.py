@@ -109,6 +109,30 @@ def run_ba(NB, seed=11, log=print, max_points=3000):
     return NB, bad
 
 
+def run_ba_rig(NB, seed=11, log=print):
+    """LocalBundleAdjustment on the KannalaBrandt8 rig (left-camera and ToBody edges), the oracle's LM path and results."""
+    import oracle_lib as O
+    from morb_slam_amd import Optimizer
+    from morb_slam_amd.synth import make_ba_problem_fisheye
+    rng = np.random.default_rng(seed + 3)
+    opt = Optimizer()
+    bad = 0
+    for s in range(NB):
+        kw = dict(seed=1300 + 17 * seed + s, n_free=int(rng.choice([4, 6, 10, 16])), n_fixed=int(rng.choice([2, 4])), n_points=int(rng.choice([300, 800, 1500])),
+                  right_frac=float(rng.choice([0.3, 0.45, 0.7])))
+        b = make_ba_problem_fisheye(**kw)
+        rig = dict(eRight=b["eRight"], camL=b["camL"], camR=b["camR"], Trl=b["Trl"])
+        inertial = bool(s & 1)
+        kf, mp, erase, stats = opt.LocalBundleAdjustment(b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"], b["eInvSigma2"], None, inertial=inertial, mode=0, rig=rig)
+        its, kfe, mpe, ee, se = O.local_ba_fisheye(b, lambda100=inertial)
+        ok = (int(stats[0]) == int(se[0]) and int(stats[1]) == int(se[1]) and np.abs(kf - kfe).max() <= 1e-4
+              and np.abs(mp - mpe).max() <= 1e-4 * max(1.0, np.abs(mpe).max()) and np.array_equal(erase, ee))
+        if not ok:
+            bad += 1
+            log(f"LocalBA (rig) case {kw} inertial {inertial}: MISMATCH dkf {np.abs(kf - kfe).max():.2e} dmp {np.abs(mp - mpe).max():.2e} flags {int((erase != ee).sum())} its {stats} / {se}")
+    return NB, bad
+
+
 if __name__ == "__main__":
     NP = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     NB = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -118,5 +142,8 @@ if __name__ == "__main__":
     b1 += b3
     print(f"PoseOptimization: {NP} cases checked")
     _, b2 = run_ba(NB)
+    nr2, b4 = run_ba_rig(max(NB // 2, 1))
+    print(f"LocalBundleAdjustment on the rig: {nr2} cases checked, {b4} mismatches", flush=True)
+    b2 += b4
     print(f"LocalBundleAdjustment: {NB} cases checked; {b1 + b2} mismatches in total")
     sys.exit(1 if b1 + b2 else 0)
