@@ -11,12 +11,13 @@ import oracle_lib as O
 from morb_slam_amd.synth import make_fisheye_features, make_pose_problem_fisheye
 
 pytestmark = pytest.mark.gpu
+_OFF = 1000 * int(__import__("os").environ.get("MORB_TEST_SEED", "0"))   # tools/stress_matchers.sh: the same tests on other scenes
 
 
 def test_stereo_fisheye_matches():
     import torch
     from morb_slam_amd import KP_DTYPE, ORBmatcher
-    sets = [make_fisheye_features(seed=s, n_pairs=500 + 100 * s) for s in range(3)]
+    sets = [make_fisheye_features(seed=_OFF + s, n_pairs=500 + 100 * s) for s in range(3)]
     cap = max(max(len(f["kL"]), len(f["kR"])) for f in sets) + 7
     nimg = 2 * len(sets)
     kps = np.zeros((nimg, cap), KP_DTYPE); desc = np.zeros((nimg, cap, 32), np.uint8)
@@ -84,7 +85,7 @@ def test_is_in_frustum_checks_kb8():
     from morb_slam_amd import ORBmatcher
     from morb_slam_amd.synth import TUMVI_CAM_L, TUMVI_CAM_R, TUMVI_T_C1_C2
     P, _ = _fisheye_params()
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(_OFF + 11)
     Fn, M = 3, 900
     Tlr = TUMVI_T_C1_C2.astype(np.float32)
     Trl = np.linalg.inv(TUMVI_T_C1_C2).astype(np.float32)
@@ -143,11 +144,11 @@ def test_search_by_projection_mappoints_fisheye():
     from morb_slam_amd import KP_DTYPE, ORBmatcher
     P, sf = _fisheye_params()
     sigma2 = (sf * sf).astype(np.float32)
-    sets = [make_fisheye_features(seed=20 + s, n_pairs=450 + 80 * s) for s in range(3)]
+    sets = [make_fisheye_features(seed=_OFF + 20 + s, n_pairs=450 + 80 * s) for s in range(3)]
     Fn = len(sets)
     cap = max(len(f["kL"]) + len(f["kR"]) for f in sets) + 5
     M = 700
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(_OFF + 77)
     kps = np.zeros((Fn, cap), KP_DTYPE); desc = np.zeros((Fn, cap, 32), np.uint8)
     cnt = np.zeros(Fn, np.int32); nLeft = np.zeros(Fn, np.int32)
     l2r = np.full((Fn, cap), -1, np.int32); r2l = np.full((Fn, cap), -1, np.int32)
@@ -218,12 +219,12 @@ def test_search_by_bow_fisheye(k, Lv, lup):
     import torch
     from morb_slam_amd import KP_DTYPE, ORBmatcher
     from morb_slam_amd.synth import make_vocabulary
-    sets = [make_fisheye_features(seed=40 + s, n_pairs=420 + 60 * s) for s in range(3)]
+    sets = [make_fisheye_features(seed=_OFF + 40 + s, n_pairs=420 + 60 * s) for s in range(3)]
     nimg = len(sets)
     cap = max(len(f["kL"]) + len(f["kR"]) for f in sets) + 3
     kps = np.zeros((nimg, cap), KP_DTYPE); desc = np.zeros((nimg, cap, 32), np.uint8)
     cnt = np.zeros(nimg, np.int32); nl = np.zeros(nimg, np.int32)
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(_OFF + 5)
     for f, fe in enumerate(sets):
         a, b = len(fe["kL"]), len(fe["kR"])
         kps[f, :a] = fe["kL"]; kps[f, a:a + b] = fe["kR"]; desc[f, :a] = fe["dL"]; desc[f, a:a + b] = fe["dR"]
@@ -267,7 +268,7 @@ def test_search_by_projection_last_frame_fisheye():
     Trl_m = np.linalg.inv(TUMVI_T_C1_C2)
     Trl7 = np.concatenate([_quat_from_R(Trl_m[:3, :3]), Trl_m[:3, 3]]).astype(np.float32)
     Fn, M = 3, 520
-    rng = np.random.default_rng(123)
+    rng = np.random.default_rng(_OFF + 123)
     frames = []
     for f in range(Fn):
         Xw = np.stack([rng.uniform(-3, 3, M), rng.uniform(-2.5, 2.5, M), rng.uniform(1, 8, M)], 1)
@@ -568,7 +569,7 @@ def test_loop_closing_searches_on_a_rig_match_oracle():
     cu = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
     m = ORBmatcher(0.8, True)
     dk, dd, dc = cu(kps.view(np.uint8).reshape(S["nimg"], S["cap"], 28)), cu(desc), cu(cnt)
-    rng = np.random.default_rng(808)
+    rng = np.random.default_rng(_OFF + 808)
     b = 1
     N = int(cnt[b]); NL = int(nl[b])
     Fo = O.make_frame(P, kps[b, :N], desc[b, :N], None)
@@ -756,7 +757,7 @@ def test_c3_chain_on_extracted_features():
     np.testing.assert_allclose(o["depth"][0, :nl].cpu().numpy(), dep, rtol=1e-4, atol=1e-5)
     # PoseOptimization on the rig from these very features: map points = points in front of the extracted left / right keypoints (a
     # KB8 ray through the keypoint at a random depth), seen from a slightly wrong initial pose
-    rng = np.random.default_rng(9)
+    rng = np.random.default_rng(_OFF + 9)
     Trl_m = np.linalg.inv(TUMVI_T_C1_C2)
 
     def rays(cam, k):   # unproject by bisection on theta (test-side helper; the product's unproject is KannalaBrandt8::unproject)
