@@ -1335,54 +1335,85 @@ __device__ __forceinline__ void iba_begin_part(const IbaDev& D, int t) {
     if (t < 18 * D.nE) D.Hpl[t] = 0.0;
   }
 }
+constexpr int IBA_PT_LANES = 8;   // lanes per point in k_iba_points
 __global__ __launch_bounds__(256) void k_iba_points(IbaDev D) {
+  __shared__ double sPt[256 * 12];
   if (iba_done(D)) return;
   iba_begin_part(D, blockIdx.x * 256 + threadIdx.x);
   if (D.lmi[IBA_LM_NEEDBUILD] == 0) return;   // (a rebuild follows an accepted trial: nothing was restored, the points read below are current)
-  const int l = blockIdx.x * 256 + threadIdx.x;
-  if (l >= D.nMP) return;
+  // EIGHT lanes per point, one edge each and chunk by chunk; the twelve contributions of an edge go to the wave's LDS slice and the group's first lane
+  // adds them up in edge order: the sums of the one-thread-per-point walk this replaces, bit for bit (as in LocalBundleAdjustment's k_g_build)
+  const int g = threadIdx.x / IBA_PT_LANES, sub = threadIdx.x % IBA_PT_LANES;
+  const int l = blockIdx.x * (256 / IBA_PT_LANES) + g;
+  const bool live = l < D.nMP;
+  double* slot = sPt + (size_t)g * IBA_PT_LANES * 12;
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   double Hl[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
-  const double X[3] = {D.pts[3 * (size_t)l], D.pts[3 * (size_t)l + 1], D.pts[3 * (size_t)l + 2]};
-  for (int k = D.ptStart[l]; k < D.ptStart[l + 1]; ++k) {
-    const int e = D.ptEdges[k];
-    VIState V;
-    iba_load(D.g, D.S + 33 * (size_t)D.eKF[e], V);
-    const int cam = D.eRight && D.eRight[e] ? 1 : 0;
-    const double* Rc = cam ? V.Rcw1 : V.Rcw;
-    const double* tc = cam ? V.tcw1 : V.tcw;
-    const float* o = D.eObs + 3 * (size_t)e;
-    const bool st = !D.g.rig && !(o[2] < 0);
-    const double info = (double)D.eInfo[e];
-    const double w = huber_w(st ? deltaStereo : deltaMono, iba_vis_chi2(D, e));
-    double Xc[3];
-    for (int r = 0; r < 3; ++r) Xc[r] = Rc[r * 3] * X[0] + Rc[r * 3 + 1] * X[1] + Rc[r * 3 + 2] * X[2] + tc[r];
-    // -proj_jac * Rcw (G2oTypes.cc:334-415)
-    double pj[9];
-    cam_project_jac(D.g, Xc, cam, pj);
-    pj[6] = pj[7] = pj[8] = 0;
-    if (st) { pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + D.g.bf * (1.0 / (Xc[2] * Xc[2])); }
-    double Jl[9];
+  const size_t lp = live ? (size_t)l : 0;
+  const double X[3] = {D.pts[3 * lp], D.pts[3 * lp + 1], D.pts[3 * lp + 2]};
+  const int k0 = live ? D.ptStart[l] : 0, k1 = live ? D.ptStart[l + 1] : 0;
+  for (int kb = k0; kb < k1; kb += IBA_PT_LANES) {
+    const int k = kb + sub;
+    double c12[12];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int q = 0; q < 12; ++q) c12[q] = 0;
+    if (k < k1) {
+      const int e = D.ptEdges[k];
+      VIState V;
+      iba_load(D.g, D.S + 33 * (size_t)D.eKF[e], V);
+      const int cam = D.eRight && D.eRight[e] ? 1 : 0;
+      const double* Rc = cam ? V.Rcw1 : V.Rcw;
+      const double* tc = cam ? V.tcw1 : V.tcw;
+      const float* o = D.eObs + 3 * (size_t)e;
+      const bool st = !D.g.rig && !(o[2] < 0);
+      const double info = (double)D.eInfo[e];
+      const double w = huber_w(st ? deltaStereo : deltaMono, iba_vis_chi2(D, e));
+      double Xc[3];
+      for (int r = 0; r < 3; ++r) Xc[r] = Rc[r * 3] * X[0] + Rc[r * 3 + 1] * X[1] + Rc[r * 3 + 2] * X[2] + tc[r];
+      // -proj_jac * Rcw (G2oTypes.cc:334-415)
+      double pj[9];
+      cam_project_jac(D.g, Xc, cam, pj);
+      pj[6] = pj[7] = pj[8] = 0;
+      if (st) { pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + D.g.bf * (1.0 / (Xc[2] * Xc[2])); }
+      double Jl[9];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) Jl[r * 3 + c] = -(pj[r * 3] * Rc[c] + pj[r * 3 + 1] * Rc[3 + c] + pj[r * 3 + 2] * Rc[6 + c]);
-    const double* er = D.vErr + 3 * (size_t)e;
+      for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      double sm = 0;
+        for (int c = 0; c < 3; ++c) Jl[r * 3 + c] = -(pj[r * 3] * Rc[c] + pj[r * 3 + 1] * Rc[3 + c] + pj[r * 3 + 2] * Rc[6 + c]);
+      const double* er = D.vErr + 3 * (size_t)e;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) sm += Jl[i * 3 + r] * info * er[i];
-      bl[r] -= w * sm;
+      for (int r = 0; r < 3; ++r) {
+        double sm = 0;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        double h = 0;
+        for (int i = 0; i < 3; ++i) sm += Jl[i * 3 + r] * info * er[i];
+        c12[9 + r] = w * sm;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) h += Jl[i * 3 + r] * (w * info) * Jl[i * 3 + c];
-        Hl[r * 3 + c] += h;
+        for (int c = 0; c < 3; ++c) {
+          double h = 0;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) h += Jl[i * 3 + r] * (w * info) * Jl[i * 3 + c];
+          c12[r * 3 + c] = h;
+        }
       }
     }
+#pragma unroll
+    for (int q = 0; q < 12; ++q) slot[sub * 12 + q] = c12[q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (sub == 0) {
+      const int cnt = k1 - kb < IBA_PT_LANES ? k1 - kb : IBA_PT_LANES;
+      for (int j = 0; j < cnt; ++j) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) Hl[q] += slot[j * 12 + q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bl[q] -= slot[j * 12 + 9 + q];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // (the slice is rewritten by the next chunk)
   }
+  if (!live || sub != 0) return;
   for (int k = 0; k < 9; ++k) D.Hll[(size_t)l * 9 + k] = Hl[k];
   for (int k = 0; k < 3; ++k) D.b[D.P + 3 * (size_t)l + k] = bl[k];
 }
@@ -2040,7 +2071,7 @@ static int local_inertial_ba_impl(morb_optimizer* o, int nKF, float* kfState21, 
     D.optIt = bLarge ? 4 : 10;
     __atomic_store_n(hostw + 0, 0, __ATOMIC_RELAXED); __atomic_store_n(hostw + 1, 0, __ATOMIC_RELEASE);
     hipLaunchKernelGGL(k_iba_lm_init, dim3(1), dim3(1), 0, st, D, chi, bLarge ? 1e-2 : 1e0);
-    const int beginGrid = div_up((int)std::max<size_t>(std::max<size_t>(std::max<size_t>(nS, nPts), (size_t)nMP), std::max<size_t>((size_t)P * P, (size_t)18 * nE)), 256);
+    const int beginGrid = div_up((int)std::max<size_t>(std::max<size_t>(std::max<size_t>(nS, nPts), (size_t)nMP * 8 /* k_iba_points: eight lanes per point */), std::max<size_t>((size_t)P * P, (size_t)18 * nE)), 256);
     for (int slot = 0; slot < 120; ++slot) {
       // backup / restore, then buildSystem (which runs only when the previous trial was accepted)
       hipLaunchKernelGGL(k_iba_points, dim3(beginGrid), dim3(256), 0, st, D);
