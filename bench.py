@@ -481,6 +481,7 @@ def main():
                     help="stereo frames per step per GPU (default 512 for c2, see WORKLOADS; 8 for c4)")
     ap.add_argument("--sets", type=int, default=2, help="buffer sets = steps in flight (>= 2)")
     ap.add_argument("--extract-streams", type=int, default=1, help="1: one extraction stream for all buffer sets (default); 2: one per set")
+    ap.add_argument("--stagger", action="store_true", help="with --extract-streams 2: step i + 1's extraction starts when step i's FAST stage is done")
     ap.add_argument("--matchers", choices=["beside-pyramid", "under-quadtree"], default="beside-pyramid",
                     help="where a step's matchers run: right after its extraction, i.e. beside the NEXT step's pyramid (default), or held back until the "
                          "next step's FAST stage is done (morb_extractor_event_after_fast), i.e. underneath its quadtree")
@@ -558,7 +559,7 @@ def main():
     NSET = 1 if args.no_pipeline else max(2, args.sets)
     exch = args.exchange if world > 1 else None
     fe = StereoFrontEnd(images, NFEAT, B, device=local_rank, rank=rank, world=world, nset=NSET, extract_streams=args.extract_streams,
-                        matchers=args.matchers, vocab=(10, 6, 4), exchange=exch)
+                        matchers=args.matchers, stagger=args.stagger, vocab=(10, 6, 4), exchange=exch)
     exts, sets, estreams, matcher, cap, mbf, mb = fe.exts, fe.sets, fe.estreams, fe.matcher, fe.cap, fe.mbf, fe.mb
     ext = exts[0]
     step, sync_streams = fe.step, fe.sync
@@ -651,6 +652,19 @@ def main():
         sync_streams()
         dta = (time.perf_counter() - t1) / ksa
         alt = {"extract_streams": NSET, "value": B / dta, "unit": "frames/s", "ms_per_step": dta * 1e3, "steps": ksa}
+        # ... and staggered: step i + 1's extraction gated on step i's after-FAST event (its pyramid beside step i's quadtree)
+        if not fe.stagger:
+            fe.stagger = True
+            for _ in range(2):
+                step()
+            sync_streams()
+            t1 = time.perf_counter()
+            for _ in range(ksa):
+                step()
+            sync_streams()
+            dts = (time.perf_counter() - t1) / ksa
+            alt["staggered"] = {"value": B / dts, "ms_per_step": dts * 1e3, "steps": ksa}
+            fe.stagger = False
         estreams[:] = saved
     if world == 1 and not args.no_extras:
         # ---- the same steps with the images arriving over PCIe: pinned host frames, uploaded on a copy stream into one of two

@@ -36,7 +36,7 @@ class BufferSet:
 
 class StereoFrontEnd:
     def __init__(self, images, nfeatures, B, device=0, rank=0, world=1, nset=2, extract_streams=1, matchers="beside-pyramid",
-                 vocab=(10, 6, 4), voc_seed=0, has_mp_seed=7, exchange=None, mbf=458.654 * 0.11, mb=0.11):
+                 stagger=False, vocab=(10, 6, 4), voc_seed=0, has_mp_seed=7, exchange=None, mbf=458.654 * 0.11, mb=0.11):
         """images: uint8 device tensor [2 B, H, W], image 2 f = left, 2 f + 1 = right of local frame f.
         vocab = (k, L, levelsup) of the synthetic complete k-ary vocabulary (ORBvoc.txt's shape is 10 / 6 / 4; the file is a missing blob).
         exchange: None (one rank: the predecessor is local), "ring" (each rank ships its left-image features to rank + 1 as one slab,
@@ -90,6 +90,9 @@ class StereoFrontEnd:
         self.sets = [BufferSet(B, cap, dev) for _ in range(NSET)]
         self.nstep = 0
         self.lag_matchers = matchers == "under-quadtree" and NSET >= 2
+        # stagger (with one extraction stream per set): step i + 1's extraction starts when step i's FAST stage is done, so its pyramid
+        # — a streaming kernel without LDS — runs beside step i's quadtree, whose few waves per CU hold the LDS and leave the rest idle
+        self.stagger = bool(stagger) and self.estreams[0] is not self.estreams[-1]
         self.pending = None
         self.last = None          # the buffer set of the most recent step
 
@@ -115,6 +118,8 @@ class StereoFrontEnd:
         S.used = True
         if src_ready is not None:
             stream.wait_event(src_ready)          # (H2D-inclusive variant: the upload of this step's images)
+        if self.stagger and self.nstep >= 2:
+            self._wait_raw_event(stream, self.exts[(self.nstep - 2) % self.NSET].event_after_fast())
         e.extract_batch(self.images if src is None else src, out=S.out, stream=stream.cuda_stream)         # Frame::ExtractORB x2
         S.ext_done.record(stream)
         self.last = S

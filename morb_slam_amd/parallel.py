@@ -45,17 +45,19 @@ def predecessor_pairs(rank, world, slots_per_rank):
 class FeatureExchange:
     """All-gather of the per-frame feature slabs.  Tensors may live on any device the process group supports."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, always_collective=False):
+        """always_collective: run the all-gather even with one rank (tests: the RCCL call path on a one-GPU box)."""
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._out = {}
+        self.always_collective = bool(always_collective) and dist.is_initialized()
 
     def _gather(self, name, x):
         import torch
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             return x
         shape = (self.world * x.shape[0],) + tuple(x.shape[1:])
         out = self._out.get(name)

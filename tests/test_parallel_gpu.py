@@ -120,3 +120,12 @@ def test_feature_slab_round_trip():
         a, b = int(rows[f]), int(dst[f])
         assert torch.equal(k2[b], kps[a]) and torch.equal(d2[b], desc[a]) and torch.equal(n2[b], node[a]) and int(c2[b]) == int(cnt[a])
     assert int(k2[2].sum()) == 0      # rows that are not destinations stay untouched
+
+
+def test_rccl_world_of_one():
+    """The "nccl" backend (RCCL) on this box's one GPU: communicator creation, barrier, MAX all-reduce and the feature all-gather the
+    multi-GPU path calls, in a fresh process (tests/rccl_world1_worker.py).  No second GPU, so no xGMI transfer — but librccl runs."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(HERE, "rccl_world1_worker.py"), str(_free_port())], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "rccl world-1 ok" in p.stdout
