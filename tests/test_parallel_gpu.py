@@ -129,3 +129,61 @@ def test_rccl_world_of_one():
     p = subprocess.run([sys.executable, os.path.join(HERE, "rccl_world1_worker.py"), str(_free_port())], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "rccl world-1 ok" in p.stdout
+
+
+def test_cpp_shard_ring_without_torch(tmp_path):
+    """INTEGRATION.md section 5 compiled and run: a C++ caller (g++, libmorb_hip + the HIP runtime, no torch) deals a stream over 1 / 2 / 3
+    "GPUs" (sets of handles and streams on this box's one device), ships one feature slab per GPU with hipMemcpyPeerAsync and matches every frame
+    against its predecessor; the program itself requires identical tables for the three world sizes, and the tables must also equal what the
+    Python mirror computes for the whole stream in one batch (and, on two sampled frames, the CPU oracle's SearchByBoW)."""
+    import torch
+    import oracle_lib as O
+    from morb_slam_amd import ORBextractor, ORBmatcher
+    from morb_slam_amd.synth import make_stereo_pair, make_vocabulary, shift_image
+    root = os.path.dirname(HERE)
+    W, H, NF, F, VK, VL, VUP = 640, 480, 600, 6, 10, 3, 1
+    l, r = make_stereo_pair(W, H, seed=11)
+    imgs = np.stack([np.stack([shift_image(l, 3 * g, 2 * g), shift_image(r, 3 * g, 2 * g)]) for g in range(F)])     # [F][2][H][W]
+    vd, vf = make_vocabulary(VK, VL, seed=2)
+    d = tmp_path / "io"
+    d.mkdir()
+    np.array([W, H, NF, F, VK, VL, VUP], np.int32).tofile(str(d / "dims.bin"))
+    imgs.tofile(str(d / "imgs.bin")); vd.tofile(str(d / "voc_desc.bin")); vf.tofile(str(d / "voc_first.bin"))
+    exe = str(tmp_path / "shard_ring_check")
+    libdir = os.path.join(root, "morb_slam_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(root, "include"), "-I/opt/rocm/include", "-o", exe,
+                           os.path.join(root, "tests", "native", "shard_ring_check.cc"), "-L" + libdir, "-lmorb_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, str(d)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "identical for 1 / 2 / 3 GPUs" in out.stdout
+    # ---- the same stream through the Python mirror, one batch on one rank
+    dev = torch.device("cuda", 0)
+    ext = ORBextractor(NF, 1.2, 8, 20, 7)
+    m = ORBmatcher(0.7, True)
+    kps, desc, cnt, _ = ext.extract_batch(torch.from_numpy(imgs.reshape(2 * F, H, W)).to(dev))
+    cap = kps.shape[1]
+    cl = cnt.clone(); cl[1::2] = 0
+    word, node = m.bow_transform(desc, cl, torch.from_numpy(vd).to(dev), torch.from_numpy(vf).to(dev), VK, VL, VUP)
+    has = np.zeros((2 * F, cap), np.uint8)
+    ii = np.arange(cap)
+    for g in range(F):
+        has[2 * g] = ((g * 131 + ii * 7) % 5) != 0
+    kf = torch.tensor([2 * max(g - 1, 0) for g in range(F)], dtype=torch.int32, device=dev)
+    fr = torch.tensor([2 * g for g in range(F)], dtype=torch.int32, device=dev)
+    mt, nm = m.SearchByBoW(kf, fr, kps, desc, node, cl, torch.from_numpy(has).to(dev))
+    torch.cuda.synchronize()
+    got = np.fromfile(str(d / "out_match.bin"), np.int32).reshape(F, cap)
+    gotn = np.fromfile(str(d / "out_nmatch.bin"), np.int32)
+    np.testing.assert_array_equal(gotn, nm.cpu().numpy())
+    np.testing.assert_array_equal(got, mt.cpu().numpy())
+    assert int(gotn[1:].sum()) > 100
+    # ---- and two of the frames against the CPU oracle (the restated ORBmatcher::SearchByBoW on the restated extraction)
+    K, D, C, ND = kps.cpu().numpy(), desc.cpu().numpy(), cnt.cpu().numpy(), node.cpu().numpy()
+    from morb_slam_amd.capi import KP_DTYPE
+    for g in (1, F - 1):
+        a, b = 2 * (g - 1), 2 * g
+        ka = K[a, :C[a]].view(KP_DTYPE).reshape(-1); kb = K[b, :C[b]].view(KP_DTYPE).reshape(-1)
+        on, om = O.search_by_bow(D[a, :C[a]], ka["angle"], has[a, :C[a]].astype(bool), ND[a, :C[a]], D[b, :C[b]], kb["angle"], ND[b, :C[b]], 0.7, True)
+        assert on == int(gotn[g])
+        np.testing.assert_array_equal(got[g, :C[b]], om)
