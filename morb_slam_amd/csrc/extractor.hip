@@ -895,7 +895,7 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     e->maxCells = std::max(e->maxCells, g.nCols * g.nRows);
     e->cellCap = std::max(e->cellCap, ((g.wCell + 1) / 2) * ((g.hCell + 1) / 2));
     // k_fastw works cell by cell: one descriptor per cell (a "segment" of one cell)
-    MORB_REQUIRE(g.wCell + 6 <= 80 && g.hCell + 6 < 128, MORB_ERR_UNSUPPORTED, "FAST cell too large for the LDS window");
+    MORB_REQUIRE(g.wCell + 7 <= 80 && g.hCell + 6 < 128, MORB_ERR_UNSUPPORTED, "FAST cell too large for the LDS window");
     for (int ci = 0; ci < g.nRows; ++ci)
       for (int c0 = 0; c0 < g.nCols; ++c0) {
         const int X0 = MINB + c0 * g.wCell, iniY = MINB + ci * g.hCell;
@@ -1173,7 +1173,8 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     // k_fastw: the LDS pitch of a wave's window = the widest segment window, rounded up to whole 16-px blocks
     int twMax = 0;
     for (const FastSeg& sd : segs) twMax = std::max(twMax, (sd.geo >> 16) & 0xFF);
-    e->fastP = twMax <= 48 ? 48 : (twMax <= 64 ? 64 : 80);   // (wCell < 70: a cell's window is at most 75 px wide)
+    twMax += FW_SH;   // (the tile holds the window from one column to its left, fast_wave.h)
+    e->fastP = twMax <= 48 ? 48 : (twMax <= 64 ? 64 : 80);   // (wCell <= 73: a cell's window is at most 79 px wide)
     for (int k = 0; k < 2; ++k) {
       const int r = e->fastRows[k];
       const int region = e->fastP == 48 ? fw_region_bytes<48>(r) : e->fastP == 64 ? fw_region_bytes<64>(r) : fw_region_bytes<80>(r);

@@ -10,7 +10,7 @@
 // so a wave's LDS is cut to ~4.6 KB (32 waves per CU): ONE window buffer, which holds the pixels while strengths are computed
 // and the corners' strengths afterwards.
 //   load      window (<= P px wide, hCell + 6 rows) -> LDS, 16 bytes per access (global: unaligned; LDS: aligned)
-//   reject    one lane = 16 consecutive pixels of a window row, packed-u16 SWAR.  Every 9-arc of the 16-pixel ring contains at
+//   reject    one lane = 12 consecutive pixels of a window row (round 4; 16 before), packed-u16 SWAR.  Every 9-arc of the 16-pixel ring contains at
 //             least one pixel of each antipodal pair, so a pixel can reach strength > T only if max(min(p0, p8), min(p4, p12)) <
 //             v - T (dark) or min(max(p0, p8), max(p4, p12)) > v + T (bright) — stronger than round 2's "second smallest of the
 //             four compass pixels" and two packed operations shorter.  Flags outside the evaluated columns are masked, the rest
@@ -63,6 +63,7 @@ extern "C" int morb_fw_stats(unsigned long long* out, int reset) {
 #ifndef MORB_FW_PADLDS
 #define MORB_FW_PADLDS 0   // (occupancy experiments: extra LDS bytes per wave)
 #endif
+constexpr int FW_SH = 1;       // window column c = tile column c + FW_SH
 constexpr int FW_QCAP = 320;   // survivor queue: < 64 left over + 256 of a reject round's flags (a fuller round is queued in several pieces)
 constexpr int FW_CQ = 512;     // corner list of a pass (~50 per cell on the benchmark images); more -> strip mode
 constexpr int FW_KC = 64;      // keypoint list of a cell (~10); more -> strip mode
@@ -103,11 +104,15 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
     if (lane == 0) candCnt[cellSlot] = 0;
     return;
   }
-  const uint8_t* base = pyr + fg.pyrOff[l] + (size_t)img * fg.pyrImg[l] + sd.winOff;
-  const int keyX0 = sd.key0 & 0xFFFF, keyY0 = sd.key0 >> 16;
+  // The tile holds the window from one column to its left (FW_SH = 1): the first evaluated column, window column 3, is tile column 4 — dword
+  // aligned — and the reject's items are 12 pixels (three dwords) starting there: the 35 evaluated columns of a cell are three items (36
+  // px), where 16-px items on the window's own grid spent three items on 48 (round 4: 169 -> 130 vector instructions per item, the item
+  // count unchanged; k_fastw is bound by vector-instruction issue, profiles/r04/README.md).
+  const uint8_t* base = pyr + fg.pyrOff[l] + (size_t)img * fg.pyrImg[l] + sd.winOff - FW_SH;
+  const int keyX0 = (sd.key0 & 0xFFFF) - FW_SH, keyY0 = sd.key0 >> 16;
   uint32_t* out = cand + cellSlot * (size_t)cellCap;
   const int n16 = th * BPR;
-  const int xa = 3, xb = tw - 3;   // evaluated columns; evaluated rows: [3, th - 3)
+  const int xa = 3 + FW_SH, xb = tw - 3 + FW_SH;   // evaluated columns (tile coordinates); evaluated rows: [3, th - 3)
 
   auto load_tile = [&]() {
     for (int i0 = 0; i0 < n16; i0 += 128) {
@@ -196,11 +201,11 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
     FW_CYC(0);
     int qn = 0, cn = 0;
     {
-      const int nIt = (xb + 15) >> 4;   // the 16-px blocks that hold evaluated pixels
+      const int nIt = (xb - xa + 11) / 12;   // 12-px items per evaluated row
       const unsigned itMagic = c_magic20.m[nIt];
       const int nItems = (th - 6) * nIt;
-      // flags of pixels outside [xa, xb) in a row's first / last block are dropped before they are queued
-      const unsigned mFirst = ~c_fwPixMask.m[xa], mLast = c_fwPixMask.m[((xb - 1) & 15) + 1];
+      // flags of pixels at or beyond xb in a row's last item are dropped before they are queued (the first item starts at xa)
+      const unsigned mLast = c_fwPixMask.m[(xb - xa) - 12 * (nIt - 1)];
       const unsigned LO = 0x00FF00FFu;
       unsigned KF[8], MF[8];   // per (dword & 1, parity, polarity): the add constant and the flag bit (8 + index) in both halves
 #pragma unroll
@@ -209,21 +214,20 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
         const int i = i0 + lane;
         const int iy = (int)(((unsigned)i * itMagic) >> 20);
         const int bi = i - __mul24(iy, nIt);
-        const int y = iy + 3, xb0 = bi << 4;
-        unsigned W = 0;   // bit f: f[0] polarity (0 dark, 1 bright), pixel offset in the block = f[3] f[2] f[4] f[1]
+        const int y = iy + 3;
+        unsigned W = 0;   // bit f: f[0] polarity (0 dark, 1 bright), pixel offset in the item = f[3] f[2] f[4] f[1] (0 .. 11)
         if (i < nItems) {
-          const uint8_t* rowp = tile + (__mul24(y, P) + xb0);
-          const uint4 Cc = *reinterpret_cast<const uint4*>(rowp);
-          const uint4 U = *reinterpret_cast<const uint4*>(rowp - 3 * P);   // ring pixel 8 (0,-3)
-          const uint4 D = *reinterpret_cast<const uint4*>(rowp + 3 * P);   // ring pixel 0 (0,+3)
-          const uint32_t Lw = *reinterpret_cast<const uint32_t*>(rowp - 4), Rw = *reinterpret_cast<const uint32_t*>(rowp + 16);
-          const uint32_t Cw[6] = {Lw, Cc.x, Cc.y, Cc.z, Cc.w, Rw}, Uw[4] = {U.x, U.y, U.z, U.w}, Dw[4] = {D.x, D.y, D.z, D.w};
-          unsigned E[6], O[6];
+          const uint32_t* rowp = reinterpret_cast<const uint32_t*>(tile + (__mul24(y, P) + xa + __mul24(bi, 12)));   // dword aligned: xa = 4
+          constexpr int P4 = P / 4;
+          const uint32_t Cw[5] = {rowp[-1], rowp[0], rowp[1], rowp[2], rowp[3]};
+          const uint32_t Uw[3] = {rowp[-3 * P4], rowp[-3 * P4 + 1], rowp[-3 * P4 + 2]};   // ring pixel 8 (0,-3)
+          const uint32_t Dw[3] = {rowp[3 * P4], rowp[3 * P4 + 1], rowp[3 * P4 + 2]};      // ring pixel 0 (0,+3)
+          unsigned E[5], O[5];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) { E[k] = Cw[k] & LO; O[k] = (Cw[k] >> 8) & LO; }
+          for (int k = 0; k < 5; ++k) { E[k] = Cw[k] & LO; O[k] = (Cw[k] >> 8) & LO; }
           unsigned acc[2] = {0u, 0u};
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
+          for (int k = 0; k < 3; ++k) {
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
               const unsigned Ve = par ? O[k + 1] : E[k + 1];
@@ -239,7 +243,6 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
             }
           }
           W = ((acc[0] >> 8) & 0x00FF00FFu) | (acc[1] & 0xFF00FF00u);
-          if (bi == 0) W &= mFirst;
           if (bi == nIt - 1) W &= mLast;
         }
         FW_STAT(2, 1);
@@ -293,9 +296,9 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
             const int nq = imin(qn, 64), q0 = qn - nq;
             qn = q0;
             const bool act = lane < nq;
-            const unsigned e = act ? queue[q0 + lane] : (unsigned)((3 << 8) | 18);   // (inactive lanes: pixel (3, 3))
-            // entry = y << 8 | block << 5 | f; f[0] = polarity, pixel offset in the block = f[3] f[2] f[4] f[1]
-            const int x = (int)(((e >> 1) & 0x70u) | ((e >> 1) & 1u) | ((e >> 3) & 2u) | (e & 12u)), yy = (int)(e >> 8);
+            const unsigned e = act ? queue[q0 + lane] : (unsigned)(3 << 8);   // (inactive lanes: pixel (xa, 3))
+            // entry = y << 8 | item << 5 | f; f[0] = polarity, pixel offset in the 12-px item = f[3] f[2] f[4] f[1]
+            const int x = xa + (int)__umul24((e >> 5) & 7u, 12u) + (int)(((e >> 1) & 1u) | ((e >> 3) & 2u) | (e & 12u)), yy = (int)(e >> 8);
             int rr[16];
             const int v = ring(__mul24(yy, P) + x, rr);
             // d = v - p for the dark polarity (= ~p + v + 1), p - v for the bright one: (p ^ m) + c, one v_xad_u32 per ring pixel
