@@ -393,15 +393,21 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {   // v_pk_a
 struct Magic20 { unsigned m[40]; constexpr Magic20() : m() { for (int d = 1; d < 40; ++d) m[d] = 0xFFFFFu / (unsigned)d + 1u; } };
 __constant__ Magic20 c_magic20 = Magic20();
 
-// max over the 16 circular 9-arcs of the arc's minimum
+// max over the 16 circular 9-arcs of the arc's minimum: 16 + 16 v_min3_i32 and 8 v_max3_i32.  The three-operand instructions are written out:
+// left to itself the compiler shares two-operand minima between neighbouring arcs and ends up with 47 instructions instead of 40 — and every
+// vector instruction of k_fastw is 4 cycles of a SIMD that has nothing else to wait for (profiles/r04/valu_rate_saturated.txt).
+__device__ __forceinline__ int vmin3(int a, int b, int c) { int r; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int vmax3(int a, int b, int c) { int r; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ int arc9_maxmin(const int (&d)[16]) {
-  int mn3[16];
+  int mn3[16], mn9[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) mn3[k] = imin(imin(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-  int A = -256;
+  for (int k = 0; k < 16; ++k) mn3[k] = vmin3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
 #pragma unroll
-  for (int k = 0; k < 16; ++k) A = imax(A, imin(imin(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]));
-  return A;
+  for (int k = 0; k < 16; ++k) mn9[k] = vmin3(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]);
+  // (a tree, not a chain: eight dependent instructions of one wave would each wait out the previous one's latency)
+  const int a0 = vmax3(mn9[0], mn9[1], mn9[2]), a1 = vmax3(mn9[3], mn9[4], mn9[5]), a2 = vmax3(mn9[6], mn9[7], mn9[8]);
+  const int a3 = vmax3(mn9[9], mn9[10], mn9[11]), a4 = vmax3(mn9[12], mn9[13], mn9[14]);
+  return vmax3(vmax3(a0, a1, a2), vmax3(a3, a4, mn9[15]), -256);
 }
 
 #ifdef MORB_FAST_TIMING
