@@ -1181,6 +1181,7 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     for (const FastSeg& sd : segs) twMax = std::max(twMax, (sd.geo >> 16) & 0xFF);
     twMax += FW_SH;   // (the tile holds the window from one column to its left, fast_wave.h)
     e->fastP = twMax <= 48 ? 48 : (twMax <= 64 ? 64 : 80);   // (wCell <= 73: a cell's window is at most 79 px wide)
+    if (e->fastP == 48 && std::max(e->fastRows[0], e->fastRows[1]) > FW_ROWS16) e->fastP = 64;   // (16-bit queue entries address 1024 dwords of tile)
     for (int k = 0; k < 2; ++k) {
       const int r = e->fastRows[k];
       const int region = e->fastP == 48 ? fw_region_bytes<48>(r) : e->fastP == 64 ? fw_region_bytes<64>(r) : fw_region_bytes<80>(r);

@@ -71,8 +71,13 @@ constexpr int FW_KC = 64;      // keypoint list of a cell (~10); more -> strip m
 #define MORB_FW_WAVES 4
 #endif
 constexpr int FW_WAVES = MORB_FW_WAVES;    // cells (waves) per workgroup
+// A queue entry = (tile offset of the item's first pixel) / 4 << 5 | flag index: 16 bits while the tile has fewer than 1024 dwords (P = 48, up to
+// 85 rows — every cell of the usual 35-px grid); the wider tiles of unusual cell sizes take 32-bit entries.
+template <int P> struct FwQueueEntry { typedef uint32_t type; };
+template <> struct FwQueueEntry<48> { typedef uint16_t type; };
+constexpr int FW_ROWS16 = 85;   // rows a P = 48 tile may have (85 * 48 / 4 < 1024)
 template <int P> __host__ __device__ constexpr int fw_region_bytes(int rows) {   // LDS of one wave
-  return (rows * P + 16) + FW_QCAP * 2 + FW_CQ * 2 + FW_CQ + FW_KC * 4 + MORB_FW_PADLDS;
+  return (rows * P + 16) + FW_QCAP * (int)sizeof(typename FwQueueEntry<P>::type) + FW_CQ * 2 + FW_CQ + FW_KC * 4 + MORB_FW_PADLDS;
 }
 // pixels [0, o) of a 16-px block as a mask in the reject's flag layout: pixel o -> bits f, f + 1 (dark, bright), f = o[0] << 1 | o[2] << 2 | o[3] << 3 | o[1] << 4
 struct FwPixMask { unsigned m[17]; constexpr FwPixMask() : m() { unsigned a = 0; for (int o = 0; o < 16; ++o) { m[o] = a; a |= 3u << (((o & 1) << 1) | (o & 4) | (o & 8) | ((o & 2) << 3)); } m[16] = a; } };
@@ -90,8 +95,9 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
   const int seg = blockIdx.y * FW_WAVES + wv, img = blockIdx.x;
   if (seg >= nSeg) return;
   uint8_t* tile = smem + wv * fw_region_bytes<P>(rows);                     // [rows][P] pixels, later the corners' strengths (+16 bytes: the last block's right neighbour)
-  uint16_t* queue = reinterpret_cast<uint16_t*>(tile + rows * P + 16);      // y << 8 | 16-px block << 5 | flag index
-  uint16_t* cornerPos = queue + FW_QCAP;                                    // y << 7 | x
+  typedef typename FwQueueEntry<P>::type QE;
+  QE* queue = reinterpret_cast<QE*>(tile + rows * P + 16);                  // (tile offset of the item) / 4 << 5 | flag index
+  uint16_t* cornerPos = reinterpret_cast<uint16_t*>(queue + FW_QCAP);       // tile offset y * P + x
   uint8_t* cornerS = reinterpret_cast<uint8_t*>(cornerPos + FW_CQ);         // S (<= 255)
   uint32_t* kept = reinterpret_cast<uint32_t*>(cornerS + FW_CQ);            // S << 16 | y << 7 | x
   uint8_t* sbuf = reinterpret_cast<uint8_t*>(cornerPos);                    // strip mode: four rolling rows of strengths
@@ -215,9 +221,10 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
         const int iy = (int)(((unsigned)i * itMagic) >> 20);
         const int bi = i - __mul24(iy, nIt);
         const int y = iy + 3;
+        const int itemOff = __mul24(y, P) + xa + __mul24(bi, 12);   // tile offset of the item's first pixel: dword aligned (xa = 4)
         unsigned W = 0;   // bit f: f[0] polarity (0 dark, 1 bright), pixel offset in the item = f[3] f[2] f[4] f[1] (0 .. 11)
         if (i < nItems) {
-          const uint32_t* rowp = reinterpret_cast<const uint32_t*>(tile + (__mul24(y, P) + xa + __mul24(bi, 12)));   // dword aligned: xa = 4
+          const uint32_t* rowp = reinterpret_cast<const uint32_t*>(tile + itemOff);
           constexpr int P4 = P / 4;
           const uint32_t Cw[5] = {rowp[-1], rowp[0], rowp[1], rowp[2], rowp[3]};
           const uint32_t Uw[3] = {rowp[-3 * P4], rowp[-3 * P4 + 1], rowp[-3 * P4 + 2]};   // ring pixel 8 (0,-3)
@@ -271,17 +278,17 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
             { const unsigned mx = ~morbwave::min_u32(~(unsigned)cnt); FW_STAT(3, mx); FW_STAT(4, total); }
 #endif
             int slot = qn + incl - cnt;
-            const unsigned rec0 = (unsigned)((y << 8) | (bi << 5));   // the flag index is decoded by the strength round: once per 64 entries, not per entry
+            const unsigned rec0 = (unsigned)itemOff << 3;   // (offset / 4) << 5; the flag index is decoded by the strength round: once per 64 entries, not per entry
             // (two flags per trip: the loop runs for as long as ANY lane has flags left, and the fullest lane has several times the average)
             unsigned t = take;
             while (t) {
               const unsigned f = (unsigned)__ffs(t) - 1u;
               t &= t - 1u;
-              queue[slot] = (uint16_t)(rec0 | f);
+              queue[slot] = (QE)(rec0 | f);
               const bool two = t != 0u;
               const unsigned g = (unsigned)__ffs(t) - 1u;
               t &= t - 1u;
-              if (two) queue[slot + 1] = (uint16_t)(rec0 | (g & 31u));
+              if (two) queue[slot + 1] = (QE)(rec0 | (g & 31u));
               slot += two ? 2 : 1;
             }
             qn += total;
@@ -296,11 +303,11 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
             const int nq = imin(qn, 64), q0 = qn - nq;
             qn = q0;
             const bool act = lane < nq;
-            const unsigned e = act ? queue[q0 + lane] : (unsigned)(3 << 8);   // (inactive lanes: pixel (xa, 3))
-            // entry = y << 8 | item << 5 | f; f[0] = polarity, pixel offset in the 12-px item = f[3] f[2] f[4] f[1]
-            const int x = xa + (int)__umul24((e >> 5) & 7u, 12u) + (int)(((e >> 1) & 1u) | ((e >> 3) & 2u) | (e & 12u)), yy = (int)(e >> 8);
+            const unsigned e = act ? (unsigned)queue[q0 + lane] : (unsigned)(3 * P + xa) << 3;   // (inactive lanes: pixel (xa, 3))
+            // entry = (item's tile offset / 4) << 5 | f; f[0] = polarity, pixel offset in the 12-px item = f[3] f[2] f[4] f[1]
+            const int off = (int)(((e >> 3) & ~3u) + (((e >> 1) & 1u) | ((e >> 3) & 2u) | (e & 12u)));
             int rr[16];
-            const int v = ring(__mul24(yy, P) + x, rr);
+            const int v = ring(off, rr);
             // d = v - p for the dark polarity (= ~p + v + 1), p - v for the bright one: (p ^ m) + c, one v_xad_u32 per ring pixel
             const bool bright = (e & 1u) != 0u;
             const int xm = bright ? 0 : -1, xc = bright ? -v : v + 1;
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
             const uint64_t cm = __ballot(isCorner);
             if (cm) {   // wave-uniform
               const int idx = cn + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
-              if (isCorner && idx < FW_CQ) { cornerPos[idx] = (uint16_t)((yy << 7) | x); cornerS[idx] = (uint8_t)imin(S, 255); }
+              if (isCorner && idx < FW_CQ) { cornerPos[idx] = (uint16_t)off; cornerS[idx] = (uint8_t)imin(S, 255); }
               cn += __popcll(cm);
             }
           }
@@ -335,15 +342,15 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
       *reinterpret_cast<uint4*>(tile + (__mul24(rr, P) + ((i - rr * BPR) << 4))) = make_uint4(0, 0, 0, 0);
     }
     FW_SYNC();
-    for (int q = lane; q < cn; q += 64) { const int pos = cornerPos[q]; tile[__mul24(pos >> 7, P) + (pos & 127)] = cornerS[q]; }
+    for (int q = lane; q < cn; q += 64) tile[cornerPos[q]] = cornerS[q];
     FW_SYNC();
     for (int q0 = 0; q0 < cn; q0 += 64) {
       FW_STAT(7, 1);
       const int q = q0 + lane;
       const bool act = q < cn;
-      const int pos = act ? cornerPos[q] : ((3 << 7) | 3);
+      const int pos = act ? cornerPos[q] : 3 * P + 3;
       const int S = act ? cornerS[q] : 0;
-      const uint8_t* c = tile + (__mul24(pos >> 7, P) + (pos & 127));
+      const uint8_t* c = tile + pos;
       const int m = imax(imax(imax(c[-P - 1], c[-P]), imax(c[-P + 1], c[-1])), imax(imax(c[1], c[P - 1]), imax(c[P], c[P + 1])));
       const bool keep = S > imax(m, 1);
       const uint64_t km = __ballot(keep);
@@ -367,11 +374,12 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
     // order, counted against the list broadcast lane by lane
     FW_SYNC();
     const uint32_t mine = lane < n ? kept[lane] : 0xFFFFFFFFu;
-    const int mpos = (int)(mine & 0xFFFFu);
+    const int mpos = (int)(mine & 0xFFFFu);   // tile offset y * P + x: row-major order is offset order
     int rank = 0;
     for (int k = 0; k < n; ++k) rank += (__builtin_amdgcn_readlane(mpos, k) < mpos) ? 1 : 0;
+    const int my = (int)(__umul24((unsigned)mpos >> 4, BPR_MAGIC) >> 16), mx = mpos - __mul24(my, P);
     if (lane < n && rank < cellCap)
-      out[rank] = morbqt::make_key((mpos & 127) + keyX0, (mpos >> 7) + keyY0, (int)(mine >> 16) - 1);
+      out[rank] = morbqt::make_key(mx + keyX0, my + keyY0, (int)(mine >> 16) - 1);
   }
   if (lane == 0) candCnt[cellSlot] = imin(n, cellCap);
   FW_CYC(5);
