@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
       for (int j = 0; j < 8; ++j) { KF[j] = ((1u << (8 + j)) - 1u - (unsigned)T) * 0x00010001u; MF[j] = (1u << (8 + j)) * 0x00010001u; }
       for (int i0 = 0; i0 < nItems; i0 += 64) {
         const int i = i0 + lane;
-        const int iy = (int)(((unsigned)i * itMagic) >> 20);
+        const int iy = (int)(__umul24((unsigned)i, itMagic) >> 20);   // (i < 1024, itMagic <= 2^20: a full-rate 24-bit multiply; the 32-bit one is quarter rate)
         const int bi = i - __mul24(iy, nIt);
         const int y = iy + 3;
         const int itemOff = __mul24(y, P) + xa + __mul24(bi, 12);   // tile offset of the item's first pixel: dword aligned (xa = 4)
@@ -308,13 +308,14 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
             const int off = (int)(((e >> 3) & ~3u) + (((e >> 1) & 1u) | ((e >> 3) & 2u) | (e & 12u)));
             int rr[16];
             const int v = ring(off, rr);
-            // d = v - p for the dark polarity (= ~p + v + 1), p - v for the bright one: (p ^ m) + c, one v_xad_u32 per ring pixel
-            const bool bright = (e & 1u) != 0u;
-            const int xm = bright ? 0 : -1, xc = bright ? -v : v + 1;
+            // strength = max over the arcs of min over the arc of (v - p) for the dark polarity, of (p - v) for the bright one.  With
+            // q = p ^ m (m = 255 for dark, 0 for bright) both are  maxmin(q) - (v ^ m):  sixteen v_xor_b32 in a row (half the cycles of the
+            // v_xad_u32 per ring pixel of the (p ^ mask) + c form: tools/micro/valu_rate.hip) and one tree for both polarities
+            const int m8 = (int)(((e & 1u) - 1u) & 0xFFu);
             int d[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) d[k] = (rr[k] ^ xm) + xc;
-            const int S = arc9_maxmin(d);
+            for (int k = 0; k < 16; ++k) d[k] = rr[k] ^ m8;
+            const int S = arc9_maxmin(d) - (v ^ m8);
             const bool isCorner = act && S > T;
             const uint64_t cm = __ballot(isCorner);
             if (cm) {   // wave-uniform

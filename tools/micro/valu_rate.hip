@@ -10,11 +10,11 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 enum { AND, ADD, SUB, XOR, OR, LSHR, LSHL, MOV, MIN_I32, MAX_U32, MIN3, MAX3, PK_MIN, PK_ADD, PK_SUBSAT, PERM, MAD24, MUL24, XAD, ALIGNBIT, AND_OR, OR3, ADD3, LSHL_ADD, BFE, CNDMASK, DOT4, SAD, FMA32, MUL32F,
-       PKFMA32, ADD_DPP, FFBL, BCNT, CMP_VCC, MIX_MIN3_AND, MIX_PK_AND, SALU_MIX, NOPS };
+       PKFMA32, ADD_DPP, FFBL, BCNT, CMP_VCC, MIX_MIN3_AND, MIX_PK_AND, GRP_XOR_MIN3, GRP_XAD_MIN3, SALU_MIX, NOPS };
 static const char* kName[NOPS] = {"v_and_b32", "v_add_u32", "v_sub_u32", "v_xor_b32", "v_or_b32", "v_lshrrev_b32", "v_lshlrev_b32", "v_mov_b32", "v_min_i32", "v_max_u32", "v_min3_i32", "v_max3_i32",
   "v_pk_min_u16", "v_pk_add_u16", "v_pk_sub_u16 clamp", "v_perm_b32", "v_mad_i32_i24", "v_mul_i32_i24", "v_xad_u32", "v_alignbit_b32", "v_and_or_b32", "v_or3_b32", "v_add3_u32", "v_lshl_add_u32", "v_bfe_u32",
   "v_cndmask_b32 (vcc)", "v_dot4_u32_u8", "v_sad_u8", "v_fma_f32", "v_mul_f32", "v_pk_fma_f32", "v_add_u32_dpp row_shr:1", "v_ffbl_b32", "v_bcnt_u32_b32", "v_cmp_lt_u32 vcc",
-  "4 v_min3_i32 + 4 v_and_b32 (per instr)", "4 v_pk_min_u16 + 4 v_and_b32 (per instr)", "8 v_and_b32 + 4 s_add_u32 (per VALU instr)"};
+  "4 v_min3_i32 + 4 v_and_b32 (per instr)", "4 v_pk_min_u16 + 4 v_and_b32 (per instr)", "16 v_xor_b32 then 16 v_min3_i32 (per instr)", "16 v_xad_u32 then 16 v_min3_i32 (per instr)", "8 v_and_b32 + 4 s_add_u32 (per VALU instr)"};
 template <int OP>
 __global__ __launch_bounds__(256) void k(int iters, unsigned* sink, unsigned seed) {
   unsigned a[8], b = seed * 2654435761u + threadIdx.x, c = seed ^ 0x01020304u;
@@ -182,6 +182,26 @@ __global__ __launch_bounds__(256) void k(int iters, unsigned* sink, unsigned see
         asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(a[2]) : "v"(b)); asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[3]) : "v"(b));
         asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(a[4]) : "v"(b)); asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[5]) : "v"(b));
         asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(a[6]) : "v"(b)); asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[7]) : "v"(b));
+      } else if constexpr (OP == GRP_XOR_MIN3) {
+        if (rep & 1) {
+#define I(k) asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+          X1(I)
+#undef I
+        } else {
+#define I(k) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+          X1(I)
+#undef I
+        }
+      } else if constexpr (OP == GRP_XAD_MIN3) {
+        if (rep & 1) {
+#define I(k) asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+          X1(I)
+#undef I
+        } else {
+#define I(k) asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+          X1(I)
+#undef I
+        }
       } else if constexpr (OP == SALU_MIX) {
         asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[0]) : "v"(b)); asm volatile("s_add_u32 %0, %0, 1" : "+s"(s0));
         asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[1]) : "v"(b)); asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[2]) : "v"(b)); asm volatile("s_add_u32 %0, %0, 1" : "+s"(s1));
