@@ -1424,7 +1424,7 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   // cells of an image meet in one XCD's L2.
   for (int k = 0, s0 = 0; k < 2; s0 += e->fastSegs[k], ++k)
     if (e->fastSegs[k]) {
-      const dim3 gr(nimg, div_up(e->fastSegs[k], FW_WAVES)), bl(64 * FW_WAVES);
+      const dim3 gr(nimg, div_up(div_up(e->fastSegs[k], FW_WAVES), FW_CPW)), bl(64 * FW_WAVES);
 #define MORB_FW_LAUNCH(PP) hipLaunchKernelGGL(k_fastw<PP>, gr, bl, e->fastSmem[k], st, e->fastGeom, e->d_segTab + s0, e->fastSegs[k], e->d_pyr, e->d_cand, \
                                               e->d_candCnt, e->totalCells, e->cellCap, e->fastRows[k], e->iniTh, e->minTh)
       switch (e->fastP) {

@@ -70,7 +70,11 @@ constexpr int FW_KC = 64;      // keypoint list of a cell (~10); more -> strip m
 #ifndef MORB_FW_WAVES
 #define MORB_FW_WAVES 4
 #endif
-constexpr int FW_WAVES = MORB_FW_WAVES;    // cells (waves) per workgroup
+constexpr int FW_WAVES = MORB_FW_WAVES;    // waves per workgroup
+#ifndef MORB_FW_CPW
+#define MORB_FW_CPW 1
+#endif
+constexpr int FW_CPW = MORB_FW_CPW;        // cells a wave works through, one after the other
 // A queue entry = (tile offset of the item's first pixel) / 4 << 5 | flag index: 16 bits while the tile has fewer than 1024 dwords (P = 48, up to
 // 85 rows — every cell of the usual 35-px grid); the wider tiles of unusual cell sizes take 32-bit entries.
 template <int P> struct FwQueueEntry { typedef uint32_t type; };
@@ -92,8 +96,9 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
   extern __shared__ __align__(16) uint8_t smem[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int seg = blockIdx.y * FW_WAVES + wv, img = blockIdx.x;
-  if (seg >= nSeg) return;
+  // a wave works through cells seg0, seg0 + stride, ... (the launch sizes the stride: FW_CPW cells per wave)
+  const int seg0 = blockIdx.y * FW_WAVES + wv, segStride = gridDim.y * FW_WAVES, img = blockIdx.x;
+  if (seg0 >= nSeg) return;
   uint8_t* tile = smem + wv * fw_region_bytes<P>(rows);                     // [rows][P] pixels, later the corners' strengths (+16 bytes: the last block's right neighbour)
   typedef typename FwQueueEntry<P>::type QE;
   QE* queue = reinterpret_cast<QE*>(tile + rows * P + 16);                  // (tile offset of the item) / 4 << 5 | flag index
@@ -102,13 +107,14 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
   uint32_t* kept = reinterpret_cast<uint32_t*>(cornerS + FW_CQ);            // S << 16 | y << 7 | x
   uint8_t* sbuf = reinterpret_cast<uint8_t*>(cornerPos);                    // strip mode: four rolling rows of strengths
 
+  for (int seg = seg0; seg < nSeg; seg += segStride) {
   const morb::FastSeg sd = segTab[seg];   // (one cell per segment: the host builds k_fastw's table that way)
   const int l = sd.geo & 0xFF, tw = (sd.geo >> 16) & 0xFF, th = (int)((unsigned)sd.geo >> 24);
   const int pstride = fg.pstride[l];
   const size_t cellSlot = (size_t)img * totalCells + sd.cell0;
   if (tw <= 6 || th <= 6) {   // :770, :775: skipped cells, or windows cv::FAST finds nothing in
     if (lane == 0) candCnt[cellSlot] = 0;
-    return;
+    continue;
   }
   // The tile holds the window from one column to its left (FW_SH = 1): the first evaluated column, window column 3, is tile column 4 — dword
   // aligned — and the reject's items are 12 pixels (three dwords) starting there: the 35 evaluated columns of a cell are three items (36
@@ -385,4 +391,5 @@ __global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW
   if (lane == 0) candCnt[cellSlot] = imin(n, cellCap);
   FW_CYC(5);
   FW_CYC_END();
+  }
 }
