@@ -51,6 +51,9 @@ namespace {
 #define MORB_TEAM_MAX_IMAGES 16
 #endif
 constexpr int kTeamMaxImages = MORB_TEAM_MAX_IMAGES;
+#ifndef MORB_TEAM_MIN_PIXELS
+#define MORB_TEAM_MIN_PIXELS 160000   // k_distribute: levels of at least this many pixels are worked by a team of waves in the team packing
+#endif
 #ifndef MORB_QT_KEYF
 #define MORB_QT_KEYF 200   // LDS key capacity of level 0, in percent of (pixels / 233); 135 / 160 measured: no change (the big bin still takes a CU alone)
 #endif   // k_distribute: calls with at most this many images use the team packing of the big levels
@@ -1119,7 +1122,7 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     int tWaves[kMaxLevels] = {0};
     e->distSmemTeam = 0;
     for (int l = 0; l < L; ++l)
-      if ((long long)e->geom[l].w * e->geom[l].h >= 160000) {
+      if ((long long)e->geom[l].w * e->geom[l].h >= MORB_TEAM_MIN_PIXELS) {
         teamGeom[l].distTeam = 1; teamGeom[l].distGroup = tb; teamGeom[l].distWave = 0; teamGeom[l].distLdsOff = 0;
         tFill[tb] = need[l]; tWaves[tb] = QT_MAX_WAVES; ++tb;
       }
