@@ -309,10 +309,26 @@ __global__ __launch_bounds__(256) void k_stereo_match(const StereoGeom sg, const
         const int d = hamming(dL, load_desc(desc + ((size_t)imgR * cap + jR) * 32));
         if (d < TH_HIGH) key = ((unsigned long long)d << 32) | (unsigned)jR;
       }
-      const int qlo = __builtin_amdgcn_readfirstlane(q), qhi = __builtin_amdgcn_readlane(q, 63);   // (inactive lanes repeat the last entry)
-      for (int qq = qlo; qq <= qhi; ++qq) {
-        const unsigned long long m = wave_min_u64(q == qq ? key : ~0ull);
-        if (lane == 0 && m < bestL[qq]) bestL[qq] = m;
+      if (cap <= 65536) {
+        // Segmented minimum in ONE scan: the list's keypoints ascend, so with (7 - q) in the top bits the ordinary inclusive prefix
+        // minimum of (7 - q) << 24 | distance << 16 | right index is, in every lane, the minimum over the lanes of ITS OWN keypoint up
+        // to there (an earlier keypoint's entries are larger in the top bits); the last lane of a keypoint's run holds the run's
+        // minimum.  (Before: one 64-bit wave minimum — two DPP scans — per keypoint of the round, ~250 vector instructions a round.)
+        uint32_t ck = ((uint32_t)(7 - q) << 24) | (key == ~0ull ? 0xFFFFFFu : (((uint32_t)(key >> 32) << 16) | (uint32_t)(key & 0xFFFFu)));
+        MORB_DPP_SCAN(ck, 0xFFFFFFFFu, morbwave::op_umin);
+        const int qn = (int)(pairs[c + 1 < n ? c + 1 : n - 1] >> 16);
+        const bool runEnd = act && (c == n - 1 || lane == 63 || qn != q);
+        const uint32_t m24 = ck & 0xFFFFFFu;
+        if (runEnd && m24 != 0xFFFFFFu) {
+          const unsigned long long m = ((unsigned long long)(m24 >> 16) << 32) | (m24 & 0xFFFFu);
+          if (m < bestL[q]) bestL[q] = m;   // (one lane per keypoint: a run that continues in the next round meets its own earlier minimum here)
+        }
+      } else {
+        const int qlo = __builtin_amdgcn_readfirstlane(q), qhi = __builtin_amdgcn_readlane(q, 63);   // (inactive lanes repeat the last entry)
+        for (int qq = qlo; qq <= qhi; ++qq) {
+          const unsigned long long m = wave_min_u64(q == qq ? key : ~0ull);
+          if (lane == 0 && m < bestL[qq]) bestL[qq] = m;
+        }
       }
     }
     WAVE_SYNC();
