@@ -88,7 +88,8 @@ struct FwPixMask { unsigned m[17]; constexpr FwPixMask() : m() { unsigned a = 0;
 __constant__ FwPixMask c_fwPixMask = FwPixMask();
 
 template <int P>
-__global__ __launch_bounds__(64 * FW_WAVES, (FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW_WAVES * 8 + 3) / 4) void k_fastw(const morb::FastGeom fg, const morb::FastSeg* __restrict__ segTab, int nSeg,
+// (the wide tiles of unusual cell sizes hold fewer waves per CU by their LDS anyway: 80 registers there, no spill with the 32-bit queue entries)
+__global__ __launch_bounds__(64 * FW_WAVES, P == 48 ? ((FW_WAVES * 8 + 3) / 4 > 8 ? 8 : (FW_WAVES * 8 + 3) / 4) : 6) void k_fastw(const morb::FastGeom fg, const morb::FastSeg* __restrict__ segTab, int nSeg,
                                                             const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
                                                             int* __restrict__ candCnt, int totalCells, int cellCap, int rows, int iniTh, int minTh) {
   constexpr int BPR = P / 16;   // 16-px blocks per window row
