@@ -268,7 +268,10 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src,
 // row-pass results (4 x u16, packed in two dwords) in registers; every output dword (4 pixels) needs three
 // aligned dword loads of the source row (bytes x-3 .. x+8; the interior starts 19 bytes into the padded row and
 // 19 - 3 = 16, so x % 4 == 0 makes the window 4-byte aligned).  HBM traffic = read P (+halo rows) + write P.
-constexpr int BT_W = 256, BT_ROWS = 16, BT_TY = 8;   // workgroup: 32 lanes x 8 px wide, 8 half-waves x 16 rows tall -> 256 px x 128 rows per tile
+#ifndef MORB_BT_ROWS
+#define MORB_BT_ROWS 24   // rows per strip (round 4, B = 512, blur underneath the quadtree: 16 / 24 / 32 rows -> 131.9 / 132.9 / 132.0 k frames/s: fewer halo rows against emptier tiles)
+#endif
+constexpr int BT_W = 256, BT_ROWS = MORB_BT_ROWS, BT_TY = 8;   // workgroup: 32 lanes x 8 px wide, 8 half-waves x BT_ROWS rows tall -> 256 px x 192 rows per tile
 constexpr int BT_H = BT_ROWS * BT_TY;
 #ifndef MORB_BT_AHEAD
 #define MORB_BT_AHEAD 4   // (1 / 2 / 3 / 4 / 6 rows ahead: 440 / 372 / 363 / 359 / 374 us per 512 images on one box)
