@@ -1096,7 +1096,7 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     for (int l = 0; l < L; ++l) order[l] = l;
     std::stable_sort(order, order + L, [&](int a, int b) { return need[a] > need[b]; });
 #ifndef MORB_QT_PACK
-#define MORB_QT_PACK 2   // (round 4, B = 512: bins of half a CU — three workgroups per 752 x 480 image, two per CU — 131.6 k against 130.0 k frames/s with whole-CU bins, 126.4 k with thirds)
+#define MORB_QT_PACK 2   // (round 4, B = 512: bins of half a CU — levels {0, 4}, {1, 3}, {2, 5, 6}, {7}: four workgroups per 752 x 480 image, two of the big ones per CU — 131.6 k against 130.0 k frames/s with whole-CU bins, 126.4 k with thirds)
 #endif
     constexpr int packEnv = MORB_QT_PACK;   // workgroups per CU the bins are sized for (measured in round 2: 0 = one level per workgroup, 2, 3: no better end to end; again at the end of round 3 with the faster blur: 1 / 2 / 3 -> quadtree 427 / 398 / 485 us per 512 images but the blur beside it 364 / 404 / 377 and the join 13 / 23 / 13: the slot stays ~430)
     int kMax = 1;
