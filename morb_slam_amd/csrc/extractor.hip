@@ -1098,7 +1098,7 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     const size_t fixed0 = lds_bytes(e->geom[0], 0);
     MORB_REQUIRE(fixed0 + 1024 * 8 <= kLdsBudget, MORB_ERR_UNSUPPORTED, "nfeatures too large for the LDS-resident quadtree");
     const double area0 = (double)e->geom[0].w * e->geom[0].h;
-    const long long want = std::max<long long>(kLdsKeys, (long long)(area0 * MORB_QT_KEYF / 23300));
+    const long long want = std::max<long long>((long long)kLdsKeys * MORB_QT_KEYF / 200, (long long)(area0 * MORB_QT_KEYF / 23300));
     const long long fit = (long long)((kLdsBudget - fixed0) / 8);
     e->distKeyCap = (int)std::min(want, fit) / 64 * 64;
     size_t need[kMaxLevels];
