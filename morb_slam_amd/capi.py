@@ -129,6 +129,9 @@ def lib():
         L.morb_search_by_projection_mps_batch.argtypes = [vp, PP, i, vp, i, vp, vp, vp, vp, vp, i] + [vp] * 11 + [f, i, f, f, vp, vp, vp]
         L.morb_is_in_frustum_kb8_batch.argtypes = [vp, PP, vp, i, vp, vp, vp, i, vp, vp, vp, vp, vp, f] + [vp] * 7
         L.morb_search_by_projection_mps_fisheye_batch.argtypes = [vp, PP, i, vp, i, vp, vp, vp, vp, vp, vp, vp, i] + [vp] * 15 + [f, i, f, f, vp, vp, vp]
+        L.morb_frame_set_pose_batch.argtypes = [vp, i, vp, vp, vp, vp, vp]
+        L.morb_pose_edges_batch.argtypes = [vp, PP, i, vp, i, vp, vp, vp, vp, vp, i, i] + [vp] * 7
+        L.morb_track_discard_outliers_batch.argtypes = [vp, i, vp, i, vp, vp, vp, i] + [vp] * 6
         L.morb_search_by_projection_last_batch.argtypes = [vp, PP, i, vp, vp, i] + [vp] * 10 + [f, vp, vp, i, vp, vp, vp]
         L.morb_search_by_projection_last_fisheye_batch.argtypes = [vp, PP, vp, vp, i, vp, vp, vp, i] + [vp] * 9 + [f, vp, vp, i, vp, vp, vp]
         L.morb_search_by_projection_kf_batch.argtypes = [vp, PP, i, vp, vp, i] + [vp] * 11 + [f, i, i, vp, vp, vp]

@@ -1002,6 +1002,11 @@ struct morb_matcher {
   size_t sortElems = 0, binElems = 0, sadElems = 0, idxElems = 0, stereoRecBytes = 0;
   void* ws[8] = {nullptr};   // generic workspaces for projection.hip
   size_t wsBytes[8] = {0};
+  std::vector<void*> retired;   // outgrown workspaces: kernels queued on a caller's stream may still read them, so they are freed with the handle
+  // small constant tables (PredictScale thresholds, camera parameters): device copy + the host bytes it was made from, so that a
+  // call with the same table neither uploads nor waits (projection.hip: morb_matcher_const)
+  struct ConstSlot { void* d = nullptr; std::vector<uint8_t> host; };
+  ConstSlot consts[4];
 };
 
 namespace {
@@ -1058,6 +1063,8 @@ void morb_matcher_destroy(morb_matcher* m) {
   auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   F(m->d_sortA); F(m->d_sortB); F(m->d_bin); F(m->d_sad); F(m->d_stereoRec); F(m->d_scale); F(m->d_invScale); F(m->d_idx);
   for (auto& w : m->ws) F(w);
+  for (auto& w : m->retired) F(w);
+  for (auto& c : m->consts) F(c.d);
   (void)hipStreamDestroy(m->stream);
   delete m;
 }
@@ -1067,13 +1074,41 @@ void* morb_matcher_stream(const morb_matcher* m) { return (void*)m->stream; }
 int morb_matcher_workspace(morb_matcher* m, int which, size_t bytes, void** out) {
   MORB_REQUIRE(m && out && which >= 0 && which < 8, MORB_ERR_INVALID, "bad workspace request");
   if (m->wsBytes[which] < bytes) {
-    MORB_HIP_CHECK(hipDeviceSynchronize());
-    if (m->ws[which]) (void)hipFree(m->ws[which]);
-    m->ws[which] = nullptr; m->wsBytes[which] = 0;
-    MORB_HIP_CHECK(hipMalloc(&m->ws[which], bytes));
-    m->wsBytes[which] = bytes;
+    // no device-wide wait and no hipFree here (hipFree waits for the whole device: the Tracking thread would stall behind a
+    // LocalBundleAdjustment running on another stream): the outgrown buffer is retired and the new one is half as large again
+    // as asked, so the retired bytes stay below twice the final size
+    void* fresh = nullptr;
+    const size_t want = bytes + bytes / 2;
+    if (hipMalloc(&fresh, want) != hipSuccess) {
+      (void)hipGetLastError();
+      MORB_HIP_CHECK(hipMalloc(&fresh, bytes));
+      m->wsBytes[which] = bytes;
+    } else {
+      m->wsBytes[which] = want;
+    }
+    if (m->ws[which]) m->retired.push_back(m->ws[which]);
+    m->ws[which] = fresh;
   }
   *out = m->ws[which];
+  return MORB_OK;
+}
+// Device copy of a small host table that rarely changes (level thresholds, camera parameters).  Same bytes as the last call on
+// this slot: no upload, no wait.  Otherwise the table is uploaded in stream order and the call waits for the copy.
+int morb_matcher_const(morb_matcher* m, int slot, const void* host, size_t bytes, void** d_out, void* stream) {
+  MORB_REQUIRE(m && host && d_out && slot >= 0 && slot < 4 && bytes > 0, MORB_ERR_INVALID, "bad constant-table request");
+  morb_matcher::ConstSlot& c = m->consts[slot];
+  if (c.d && c.host.size() == bytes && memcmp(c.host.data(), host, bytes) == 0) { *d_out = c.d; return MORB_OK; }
+  if (!c.d || c.host.size() != bytes) {   // (a table of the same size is rewritten in place, in stream order)
+    void* fresh = nullptr;
+    MORB_HIP_CHECK(hipMalloc(&fresh, bytes));
+    if (c.d) m->retired.push_back(c.d);
+    c.d = fresh;
+  }
+  c.host.assign((const uint8_t*)host, (const uint8_t*)host + bytes);
+  hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+  MORB_HIP_CHECK(hipMemcpyAsync(c.d, c.host.data(), bytes, hipMemcpyHostToDevice, st));
+  MORB_HIP_CHECK(hipStreamSynchronize(st));
+  *d_out = c.d;
   return MORB_OK;
 }
 int morb_bow_sort_images(morb_matcher* m, int nimg, const int* d_node, const int* d_count, int cap, unsigned long long** d_sorted,

@@ -30,6 +30,7 @@ extern "C" {
 int morb_matcher_device(const morb_matcher*);
 void* morb_matcher_stream(const morb_matcher*);
 int morb_matcher_workspace(morb_matcher*, int which, size_t bytes, void** out);
+int morb_matcher_const(morb_matcher*, int slot, const void* host, size_t bytes, void** d_out, void* stream);
 }
 
 namespace {
@@ -867,6 +868,16 @@ static float ratio_threshold(int n, float logScaleFactor) {
   return asf(lo);
 }
 
+// thresholds of all levels of a pyramid (~500 logf calls): kept per thread for the pyramid last asked about
+static void level_thresholds(const morb_frame_params* P, float* thr16) {
+  thread_local int cn = -1; thread_local float cl = 0.f; thread_local float ct[16];
+  if (cn != P->nlevels || cl != P->logScaleFactor) {
+    for (int n = 0; n < 16; ++n) ct[n] = n < P->nlevels - 1 ? ratio_threshold(n, P->logScaleFactor) : 3.4e38f;
+    cn = P->nlevels; cl = P->logScaleFactor;
+  }
+  memcpy(thr16, ct, sizeof ct);
+}
+
 static int frustum_impl(morb_matcher* m, const morb_frame_params* P, const float* cam8, int nframes, const float* d_Rcw,
                         const float* d_tcw, const float* d_Ow, int mpCap, const int* d_nMP, const float* d_Pw,
                         const float* d_normal, const float* d_maxDist, const float* d_minDist, float viewingCosLimit,
@@ -878,14 +889,12 @@ static int frustum_impl(morb_matcher* m, const morb_frame_params* P, const float
   MORB_HIP_CHECK(hipSetDevice(morb_matcher_device(m)));
   hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
   float thr[24];   // 16 level thresholds + the 8 camera parameters of the KB8 variant
-  for (int n = 0; n < 16; ++n) thr[n] = n < P->nlevels - 1 ? ratio_threshold(n, P->logScaleFactor) : 3.4e38f;
+  level_thresholds(P, thr);
   for (int n = 0; n < 8; ++n) thr[16 + n] = cam8 ? cam8[n] : 0.f;
   void* d_thr = nullptr;
-  int rc = morb_matcher_workspace(m, 4, sizeof thr, &d_thr);
+  int rc = morb_matcher_const(m, cam8 ? 1 : 0, thr, sizeof thr, &d_thr, st);   // uploaded once per camera, not per call
   if (rc != MORB_OK) return rc;
   const float* d_kb8 = cam8 ? (const float*)d_thr + 16 : nullptr;
-  MORB_HIP_CHECK(hipMemcpyAsync(d_thr, thr, sizeof thr, hipMemcpyHostToDevice, st));
-  MORB_HIP_CHECK(hipStreamSynchronize(st));  // thr lives on this stack frame
   hipLaunchKernelGGL(k_frustum, dim3(div_up(mpCap, 256), nframes), dim3(256), 0, st, *P, d_Rcw, d_tcw, d_Ow, mpCap, d_nMP, d_Pw,
                      d_normal, d_maxDist, d_minDist, viewingCosLimit, (const float*)d_thr, (const float*)d_kb8, d_inView, d_projX,
                      d_projY, d_projXR, d_depth, d_level, d_viewCos);
@@ -1038,10 +1047,8 @@ int morb_search_by_projection_last_fisheye_batch(morb_matcher* m, const morb_fra
   for (int i = 0; i < 8; ++i) ct[i] = cam8[i];
   for (int i = 0; i < 7; ++i) ct[8 + i] = Trl7[i];
   void* d_ct = nullptr;
-  int rc = morb_matcher_workspace(m, 4, sizeof ct, &d_ct);
+  int rc = morb_matcher_const(m, 2, ct, sizeof ct, &d_ct, st);
   if (rc != MORB_OK) return rc;
-  MORB_HIP_CHECK(hipMemcpyAsync(d_ct, ct, sizeof ct, hipMemcpyHostToDevice, st));
-  MORB_HIP_CHECK(hipStreamSynchronize(st));  // ct lives on this stack frame
   void* qs = nullptr;
   rc = morb_matcher_workspace(m, 5, sizeof(Query) * (size_t)nframes * cap * 2, &qs);
   if (rc != MORB_OK) return rc;
@@ -1066,15 +1073,13 @@ int morb_search_by_projection_kf_batch(morb_matcher* m, const morb_frame_params*
   MORB_REQUIRE(nframes > 0 && cap > 0 && cap <= 65535, MORB_ERR_INVALID, "bad sizes");
   MORB_HIP_CHECK(hipSetDevice(morb_matcher_device(m)));
   hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
-  float thr[16];
-  for (int n = 0; n < 16; ++n) thr[n] = n < P->nlevels - 1 ? ratio_threshold(n, P->logScaleFactor) : 3.4e38f;
+  float thr[24] = {0};   // (same table as isInFrustum's, so the two share constant slot 0)
+  level_thresholds(P, thr);
   void *d_thr = nullptr, *qs = nullptr, *nq = nullptr;
-  int rc = morb_matcher_workspace(m, 4, sizeof thr, &d_thr);
+  int rc = morb_matcher_const(m, 0, thr, sizeof thr, &d_thr, st);
   if (rc == MORB_OK) rc = morb_matcher_workspace(m, 5, sizeof(Query) * (size_t)nframes * cap, &qs);
   if (rc == MORB_OK) rc = morb_matcher_workspace(m, 6, sizeof(int) * (size_t)nframes, &nq);
   if (rc != MORB_OK) return rc;
-  MORB_HIP_CHECK(hipMemcpyAsync(d_thr, thr, sizeof thr, hipMemcpyHostToDevice, st));
-  MORB_HIP_CHECK(hipStreamSynchronize(st));
   hipLaunchKernelGGL(k_prep_kf, dim3(div_up(cap, 256), nframes), dim3(256), 0, st, *P, cap, d_count, d_kfImg, d_kps, d_kfValid, d_Xw,
                      d_maxDist, d_minDist, d_Tcw, d_Ow, th, (const float*)d_thr, (Query*)qs);
   hipLaunchKernelGGL(k_gather_counts, dim3(div_up(nframes, 256)), dim3(256), 0, st, d_count, d_kfImg, nframes, (int*)nq);
@@ -1173,13 +1178,11 @@ __global__ __launch_bounds__(256) void k_rot_filter12(const int* __restrict__ co
 static int upload_ratio_thresholds(morb_matcher* m, const morb_frame_params* P, const float* cam8, hipStream_t st, const float** d_thr,
                                    const float** d_kb8) {
   float thr[24];
-  for (int n = 0; n < 16; ++n) thr[n] = n < P->nlevels - 1 ? ratio_threshold(n, P->logScaleFactor) : 3.4e38f;
+  level_thresholds(P, thr);
   for (int n = 0; n < 8; ++n) thr[16 + n] = cam8 ? cam8[n] : 0.f;
   void* d = nullptr;
-  int rc = morb_matcher_workspace(m, 4, sizeof thr, &d);
+  int rc = morb_matcher_const(m, cam8 ? 1 : 0, thr, sizeof thr, &d, st);
   if (rc != MORB_OK) return rc;
-  MORB_HIP_CHECK(hipMemcpyAsync(d, thr, sizeof thr, hipMemcpyHostToDevice, st));
-  MORB_HIP_CHECK(hipStreamSynchronize(st));  // thr lives on this stack frame
   *d_thr = (const float*)d;
   *d_kb8 = cam8 ? (const float*)d + 16 : nullptr;
   return MORB_OK;

@@ -193,11 +193,14 @@ class ORBmatcher:
 
     # ---- M7: loop-closing / local-mapping searches ---------------------------------------------------------
     def Fuse(self, params, kfImg, kps, desc, count, uRight, Tcw, Ow, nMP, valid, Pw, normal, maxDist, minDist, mpDesc, th=3.0,
-             sim3Form=False, cam8=None, jLo=None, jHi=None, stream=None):
+             sim3Form=False, cam8=None, jLo=None, jHi=None, out=None, stream=None):
         """The search of ORBmatcher::Fuse (both overloads): (bestIdx, bestDist) int32 [nprob, mpCap]."""
         import torch
         F, cap, mpCap = kfImg.shape[0], kps.shape[1], mpDesc.shape[1]
-        bi = torch.empty((F, mpCap), dtype=torch.int32, device=kps.device); bd = torch.empty_like(bi)
+        if out is not None:
+            bi, bd = out
+        else:
+            bi = torch.empty((F, mpCap), dtype=torch.int32, device=kps.device); bd = torch.empty_like(bi)
         cam = None if cam8 is None else np.ascontiguousarray(cam8, np.float32)
         check(self._L.morb_fuse_batch(self._h, C.byref(params), F, ptr(kfImg), cap, ptr(count), ptr(kps), ptr(desc), ptr(uRight), ptr(Tcw),
                                       ptr(Ow), ptr(cam), ptr(jLo), ptr(jHi), mpCap, ptr(nMP), ptr(valid), ptr(Pw), ptr(normal),
@@ -247,12 +250,13 @@ class ORBmatcher:
         return v1, v2, m12, nf
 
     # ---- projection-guided searches (projection.hip) ------------------------------------------------------
-    def isInFrustum(self, params, Rcw, tcw, Ow, nMP, Pw, normal, maxDist, minDist, viewingCosLimit=0.5, stream=None):
-        """Frame::isInFrustum for [F, mpCap] map points; returns dict of the MapPoint tracking fields (device tensors)."""
+    def isInFrustum(self, params, Rcw, tcw, Ow, nMP, Pw, normal, maxDist, minDist, viewingCosLimit=0.5, out=None, stream=None):
+        """Frame::isInFrustum for [F, mpCap] map points; returns dict of the MapPoint tracking fields (device tensors).
+        out: a dict from an earlier call to write into (every field of every row below nMP is written)."""
         import torch
         F, mpCap = Pw.shape[0], Pw.shape[1]
         dev = Pw.device
-        o = dict(inView=torch.zeros((F, mpCap), dtype=torch.uint8, device=dev),
+        o = out if out is not None else dict(inView=torch.zeros((F, mpCap), dtype=torch.uint8, device=dev),
                  projX=torch.full((F, mpCap), -1.0, device=dev), projY=torch.full((F, mpCap), -1.0, device=dev),
                  projXR=torch.full((F, mpCap), -1.0, device=dev), depth=torch.full((F, mpCap), -1.0, device=dev),
                  level=torch.full((F, mpCap), -1, dtype=torch.int32, device=dev), viewCos=torch.full((F, mpCap), -1.0, device=dev))
@@ -263,14 +267,15 @@ class ORBmatcher:
         return o
 
     def SearchByProjectionMapPoints(self, params, fImg, kps, desc, count, uRight, blocked, nMP, trk, isBad, mpDesc, mpHasObs,
-                                    th=1.0, bFarPoints=False, thFarPoints=50.0, matchF=None, stream=None):
+                                    th=1.0, bFarPoints=False, thFarPoints=50.0, matchF=None, nm=None, stream=None):
         """SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints); trk = dict from isInFrustum."""
         import torch
         F, cap = fImg.shape[0], kps.shape[1]
         mpCap = mpDesc.shape[1]
         if matchF is None:
             matchF = torch.full((F, cap), -1, dtype=torch.int32, device=kps.device)
-        nm = torch.zeros((F,), dtype=torch.int32, device=kps.device)
+        if nm is None:
+            nm = torch.zeros((F,), dtype=torch.int32, device=kps.device)
         check(self._L.morb_search_by_projection_mps_batch(
             self._h, C.byref(params), F, ptr(fImg), cap, ptr(count), ptr(kps), ptr(desc), ptr(uRight), ptr(blocked), mpCap, ptr(nMP),
             ptr(trk["inView"]), ptr(isBad), ptr(trk["depth"]), ptr(trk["projX"]), ptr(trk["projY"]), ptr(trk["projXR"]),
@@ -313,13 +318,14 @@ class ORBmatcher:
         return matchF, nm
 
     def SearchByProjectionLastFrame(self, params, curImg, lastImg, kps, desc, count, curURight, curBlocked, Tcw, lastValid,
-                                    lastXw, lastMPdesc, lastMPhasObs, th, bForward, bBackward, matchCur=None, stream=None):
+                                    lastXw, lastMPdesc, lastMPhasObs, th, bForward, bBackward, matchCur=None, nm=None, stream=None):
         """SearchByProjection(CurrentFrame, LastFrame, th, bMono)."""
         import torch
         F, cap = curImg.shape[0], kps.shape[1]
         if matchCur is None:
             matchCur = torch.full((F, cap), -1, dtype=torch.int32, device=kps.device)
-        nm = torch.zeros((F,), dtype=torch.int32, device=kps.device)
+        if nm is None:
+            nm = torch.zeros((F,), dtype=torch.int32, device=kps.device)
         check(self._L.morb_search_by_projection_last_batch(
             self._h, C.byref(params), F, ptr(curImg), ptr(lastImg), cap, ptr(count), ptr(kps), ptr(desc), ptr(curURight),
             ptr(curBlocked), ptr(Tcw), ptr(lastValid), ptr(lastXw), ptr(lastMPdesc), ptr(lastMPhasObs), float(th), ptr(bForward),
@@ -356,13 +362,16 @@ class ORBmatcher:
         return m12, nm
 
     def SearchForTriangulation(self, params, img1, img2, kps, desc, node, count, hasMP, uRight, R12, t12, ep,
-                               bOnlyStereo=False, bCoarse=False, stream=None):
+                               bOnlyStereo=False, bCoarse=False, out=None, stream=None):
         """SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse); R12/t12/ep are host numpy arrays."""
         import torch
         npairs = img1.shape[0]
         nimg, cap = kps.shape[0], kps.shape[1]
-        m12 = torch.full((npairs, cap), -1, dtype=torch.int32, device=kps.device)
-        nm = torch.zeros((npairs,), dtype=torch.int32, device=kps.device)
+        if out is not None:
+            m12, nm = out
+        else:
+            m12 = torch.full((npairs, cap), -1, dtype=torch.int32, device=kps.device)
+            nm = torch.zeros((npairs,), dtype=torch.int32, device=kps.device)
         R12 = np.ascontiguousarray(R12, np.float32); t12 = np.ascontiguousarray(t12, np.float32); ep = np.ascontiguousarray(ep, np.float32)
         check(self._L.morb_search_for_triangulation_batch(
             self._h, C.byref(params), npairs, ptr(img1), ptr(img2), nimg, cap, ptr(count), ptr(kps), ptr(desc), ptr(node),

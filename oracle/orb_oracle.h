@@ -87,6 +87,12 @@ int orc_search_by_projection_mps_fisheye(const orc_frame* F, int Nleft, const in
                                          const float* viewCosL, const float* projXR, const float* projYR, const int* levelR,
                                          const float* viewCosR, const uint8_t* mpDesc, const uint8_t* mpHasObs, float th,
                                          int bFarPoints, float thFarPoints, float nnratio, int* matchF);
+/* Tracking.cc's host loops between the searches and PoseOptimization (Frame.cc:541-585, Optimizer.cc:803-905, Tracking.cc:2716-2740, :3117-3133) */
+void orc_frame_set_pose(const float* Tcw7, float* Rcw, float* tcw, float* Ow);
+void orc_pose_edges(const orc_frame* F, const float* invLevelSigma2, const int* frameMP, const float* mpXw, uint8_t* hasMP, float* obs,
+                    float* invSigma2, float* Xw);
+int orc_discard_outliers(int N, int* frameMP, uint8_t* outlier, int nMP, const uint8_t* mpHasObs, uint8_t* blocked, uint8_t* mpSeen,
+                         int* nmatchesMap);
 int orc_search_by_projection_last(const orc_frame* Cur, const uint8_t* curBlocked, const float* Tcw7, int nLast,
                                   const orc_keypoint* lastKpsUn, const uint8_t* lastValid, const float* lastXw,
                                   const uint8_t* lastMPdesc, const uint8_t* lastMPhasObs, float th, int bForward,

@@ -1029,10 +1029,71 @@ void SearchBySim3Dir(const orc_frame& Ball, const float* TAw7, const float* SBA8
   }
 }
 
+// ---- Tracking.cc's host loops between the searches and PoseOptimization (checker for csrc/tracking.hip) -----------------------
+// Frame::SetPose -> UpdatePoseMatrices (Frame.cc:541-585): mRcw = Tcw.rotationMatrix() (Eigen::Quaternionf::toRotationMatrix),
+// mtcw, mOw = Tcw.inverse().translation() (Sophus: so3().inverse() * (translation() * -1))
+void FrameSetPose(const float* Tcw7, float* mRcw, float* mtcw, float* mOw) {
+  const float x = Tcw7[0], y = Tcw7[1], z = Tcw7[2], w = Tcw7[3];
+  const float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
+  const float twx = tx * w, twy = ty * w, twz = tz * w;
+  const float txx = tx * x, txy = ty * x, txz = tz * x;
+  const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  mRcw[0] = 1.0f - (tyy + tzz); mRcw[1] = txy - twz; mRcw[2] = txz + twy;
+  mRcw[3] = txy + twz; mRcw[4] = 1.0f - (txx + tzz); mRcw[5] = tyz - twx;
+  mRcw[6] = txz - twy; mRcw[7] = tyz + twx; mRcw[8] = 1.0f - (txx + tyy);
+  for (int i = 0; i < 3; ++i) mtcw[i] = Tcw7[4 + i];
+  const float qc[4] = {-x, -y, -z, w};
+  const float mt[3] = {Tcw7[4] * -1.0f, Tcw7[5] * -1.0f, Tcw7[6] * -1.0f};
+  rotateF(qc, mt, mOw);
+}
+// Optimizer::PoseOptimization's edge fill (Optimizer.cc:803-905) over mvpMapPoints given as rows of a map-point table
+void PoseEdges(const orc_frame& F, const float* invLevelSigma2, const int* frameMP, const float* mpXw, uint8_t* hasMP, float* obs,
+               float* invSigma2, float* Xw) {
+  const KeyPoint* kps = (const KeyPoint*)F.kpsUn;
+  for (int i = 0; i < F.N; ++i) {
+    const int mp = frameMP[i];
+    hasMP[i] = mp >= 0;
+    obs[3 * i] = obs[3 * i + 1] = 0.f; obs[3 * i + 2] = -1.f; invSigma2[i] = 0.f;
+    Xw[3 * i] = Xw[3 * i + 1] = Xw[3 * i + 2] = 0.f;
+    if (mp < 0) continue;
+    obs[3 * i] = kps[i].x; obs[3 * i + 1] = kps[i].y; obs[3 * i + 2] = F.uRight ? F.uRight[i] : -1.f;
+    invSigma2[i] = invLevelSigma2[kps[i].octave];
+    for (int k = 0; k < 3; ++k) Xw[3 * i + k] = mpXw[3 * mp + k];
+  }
+}
+// TrackWithMotionModel's discard loop (Tracking.cc:2716-2740) + SearchLocalPoints' first loop (:3117-3133); returns nmatches
+int DiscardOutliers(int N, int* frameMP, uint8_t* outlier, int nMP, const uint8_t* mpHasObs, uint8_t* blocked, uint8_t* mpSeen,
+                    int* nmatchesMap) {
+  int nmatches = 0, nmap = 0;
+  if (mpSeen) for (int i = 0; i < nMP; ++i) mpSeen[i] = 0;
+  for (int i = 0; i < N; ++i) {
+    if (blocked) blocked[i] = 0;
+    const int mp = frameMP[i];
+    if (mp < 0) continue;
+    if (mpSeen) mpSeen[mp] = 1;                     // pMP->mnLastFrameSeen = mCurrentFrame.mnId (both branches)
+    if (outlier[i]) { frameMP[i] = -1; outlier[i] = 0; }
+    else {
+      ++nmatches;
+      if (mpHasObs[mp]) { ++nmap; if (blocked) blocked[i] = 1; }
+    }
+  }
+  *nmatchesMap = nmap;
+  return nmatches;
+}
+
 }  // namespace orc
 
 using namespace orc;
 extern "C" {
+void orc_frame_set_pose(const float* Tcw7, float* Rcw, float* tcw, float* Ow) { FrameSetPose(Tcw7, Rcw, tcw, Ow); }
+void orc_pose_edges(const orc_frame* F, const float* invLevelSigma2, const int* frameMP, const float* mpXw, uint8_t* hasMP, float* obs,
+                    float* invSigma2, float* Xw) {
+  PoseEdges(*F, invLevelSigma2, frameMP, mpXw, hasMP, obs, invSigma2, Xw);
+}
+int orc_discard_outliers(int N, int* frameMP, uint8_t* outlier, int nMP, const uint8_t* mpHasObs, uint8_t* blocked, uint8_t* mpSeen,
+                         int* nmatchesMap) {
+  return DiscardOutliers(N, frameMP, outlier, nMP, mpHasObs, blocked, mpSeen, nmatchesMap);
+}
 
 void orc_is_in_frustum(const orc_frame* F, const float* Rcw, const float* tcw, const float* Ow, int nMP, const float* Pw,
                        const float* normal, const float* maxDist, const float* minDist, float viewingCosLimit,

@@ -615,3 +615,37 @@ def bow_vector(leaf, node_weight, node_word=None, weighting=0, scoring=0):
     ow = np.zeros(len(leaf), np.int32); ov = np.zeros(len(leaf), np.float64)
     k = L.orc_bow_vector(len(leaf), _p(leaf), None if nw is None else _p(nw), _p(w), weighting, scoring, _p(ow), _p(ov))
     return ow[:k], ov[:k]
+
+
+# ---- Tracking.cc's host loops between the searches and PoseOptimization (checker for csrc/tracking.hip) ----
+def frame_set_pose(Tcw7):
+    L = lib()
+    L.orc_frame_set_pose.argtypes = [C.c_void_p] * 4
+    a = np.ascontiguousarray(Tcw7, np.float32)
+    R, t, Ow = np.zeros(9, np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32)
+    L.orc_frame_set_pose(_p(a), _p(R), _p(t), _p(Ow))
+    return R, t, Ow
+
+
+def pose_edges(F, invLevelSigma2, frameMP, mpXw):
+    L = lib()
+    L.orc_pose_edges.argtypes = [C.c_void_p] * 8
+    n = F.N
+    a = [np.ascontiguousarray(invLevelSigma2, np.float32), np.ascontiguousarray(frameMP, np.int32), np.ascontiguousarray(mpXw, np.float32)]
+    has, obs, is2, Xw = np.zeros(n, np.uint8), np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros((n, 3), np.float32)
+    L.orc_pose_edges(C.byref(F), _p(a[0]), _p(a[1]), _p(a[2]), _p(has), _p(obs), _p(is2), _p(Xw))
+    return has, obs, is2, Xw
+
+
+def discard_outliers(frameMP, outlier, mpHasObs, want_blocked=True, want_seen=True):
+    L = lib()
+    L.orc_discard_outliers.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4
+    L.orc_discard_outliers.restype = C.c_int
+    fm = np.ascontiguousarray(frameMP, np.int32).copy(); ol = np.ascontiguousarray(outlier, np.uint8).copy()
+    ho = np.ascontiguousarray(mpHasObs, np.uint8)
+    blk = np.zeros(len(fm), np.uint8) if want_blocked else None
+    seen = np.zeros(len(ho), np.uint8) if want_seen else None
+    nmap = C.c_int(0)
+    nm = L.orc_discard_outliers(len(fm), _p(fm), _p(ol), len(ho), _p(ho), None if blk is None else _p(blk),
+                                None if seen is None else _p(seen), C.byref(nmap))
+    return nm, nmap.value, fm, blk, seen

@@ -1,0 +1,50 @@
+"""Tracking chain (TrackWithMotionModel + TrackLocalMap) and LocalMapping's keyframe searches: throughput at B frames per step
+and latency one frame at a time.  `python tools/bench_tracking.py [B] [steps]`; under rocprofv3 --kernel-trace --stats for the kernel table."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402
+from morb_slam_amd.tracking import TrackingChain, build_chains  # noqa: E402
+
+
+def main():
+    import torch
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    G = 256
+    imgs = bench.make_batch(range(G), G, seed=0)
+    ch, ks, host = build_chains(imgs, B=B, npairs=20, seq_len=64)
+    out = {"B": B}
+
+    def timed(fn, sync, n):
+        for _ in range(3):
+            fn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        sync()
+        return (time.perf_counter() - t0) / n
+    dt = timed(ch.step, ch.sync, steps)
+    out["tracking_ms_per_step"] = dt * 1e3
+    out["tracking_frames_per_s"] = B / dt
+    out["mean_matches_last"] = float(ch.nmLast.float().mean()); out["mean_matches_local"] = float(ch.nmLocal.float().mean())
+    out["mean_inliers"] = float(ch.nInl.float().mean()); out["mean_local_points"] = float(ch.nMP.float().mean())
+    dk = timed(ks.step, ks.sync, steps)
+    out["keyframe_pairs"] = 20
+    out["keyframe_searches_ms"] = dk * 1e3
+    # b = 1
+    one = {k: v[:1] for k, v in host["scene"].items()}
+    c1 = TrackingChain(ch.P, ch.cam, ch.kps, ch.desc, ch.count, ch.uRight[:1].contiguous(), one)
+    out["tracking_b1_ms"] = timed(c1.step, c1.sync, 50) * 1e3
+    # stage split at b = 1 and at B (events on the chain's stream)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
