@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -687,6 +688,279 @@ __global__ __launch_bounds__(64) void k_resolve(morb_frame_params P, int qCap, c
   if (lane == 0) nmatches[f] = nm;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Round 5: MODE 0 / MODE 1 in ONE launch, one workgroup per frame (replaces k_candidates + k_resolve for the two searches
+// Tracking runs on every frame).  Three ideas:
+//  (1) the frame's 64 x 48 grid (Frame::AssignFeaturesToGrid, Frame.cc:501-528) is built in LDS as a CSR whose rows are sorted
+//      by (cell column, cell row, feature index) — the order GetFeaturesInArea (:742-807) hands features out in — so a query
+//      looks at the handful of features in its cell range instead of at every feature of the frame, and a feature's position p
+//      in that order replaces (cell, index) in the key: key = dist << 20 | p << 4 | octave fits 32 bits;
+//  (2) a thread per query keeps its (short) candidate list, c-major in global memory so that the threads of a wave read
+//      neighbouring words; lists longer than SEARCH_CAP are not stored, their query walks the grid again when asked;
+//  (3) the order dependence of the reference's loop lives only in "skip features that an EARLIER query gave a map point with
+//      observations".  Let blk[p] = 1 + the smallest query index that accepts p and blocks it (0: blocked on entry).  Given blk,
+//      every query's result is independent: best / second best among its candidates with blk[p] > q.  Iterate: results from
+//      blk, blk from results, until nothing changes.  Query q only reads results of queries < q, so by induction the fixed point
+//      is unique and equals the sequential replay; queries below the first one that changed are final and are not recomputed.
+//      Typical frames converge in 3 - 5 passes of a few microseconds (the serial replay took 0.7 ms per frame).
+constexpr int SEARCH_THREADS = 1024, SEARCH_CAP = 32, GRID_CELLS = GRID_ROWS * GRID_COLS;
+
+__device__ __forceinline__ void top2_insert32(uint32_t& k1, uint32_t& k2, uint32_t k) {
+  const bool lt1 = k < k1, lt2 = k < k2;
+  k2 = lt1 ? k1 : (lt2 ? k : k2);
+  k1 = lt1 ? k : k1;
+}
+
+// one candidate of query q: feature j (position p of the grid order); ~0u when a test of the reference's inner loop rejects it
+__device__ __forceinline__ uint32_t search_key(const morb_frame_params& P, const Query& q, const Desc& qd, int p, int j,
+                                               const morb_keypoint* __restrict__ kpRow, const uint8_t* __restrict__ descRow,
+                                               const float* __restrict__ ur) {
+  if (q.jHi > 0 && (j < q.jLo || j >= q.jHi)) return ~0u;
+  const float kx = kpRow[j].x, ky = kpRow[j].y;
+  const int oct = kpRow[j].octave;
+  const bool bCheckLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
+  if (bCheckLevels) {
+    if (oct < q.minLevel) return ~0u;
+    if (q.maxLevel >= 0 && oct > q.maxLevel) return ~0u;
+  }
+  if (!(fabsf(kx - q.x) < q.r && fabsf(ky - q.y) < q.r)) return ~0u;
+  if (ur) {
+    const float u = ur[j];
+    if (u > 0 && fabsf(q.xr - u) > q.erMax) return ~0u;
+  }
+  const int d = hamming(qd, load_desc(descRow + (size_t)j * 32));
+  return ((uint32_t)d << 20) | ((uint32_t)p << 4) | (uint32_t)(oct & 15);
+}
+
+struct SearchLds {   // carved from dynamic LDS
+  uint32_t* start;   // [GRID_CELLS + 1] CSR row starts
+  uint32_t* cur;     // [GRID_CELLS]     counts, then fill cursors
+  uint32_t* blk;     // [capR]           1 + smallest blocking query (0 = blocked on entry, ~0u = free); later: owner
+  uint32_t* res;     // [qCapR]          per query: ~0u none, else p | hasObs << 16 (| bin << 17 at the end)
+  uint16_t* cellOf;  // [capR]           feature -> cell (0xFFFF: outside the grid)
+  uint16_t* tmp;     // [capR]           unsorted CSR
+  uint16_t* featOf;  // [capR]           position -> feature
+  uint16_t* qcnt;    // [qCapR]          candidates of the query (> SEARCH_CAP: walk again)
+  uint8_t* blk0;     // [capR]           blocked on entry; later: "an entry of this feature fell to the rotation filter"
+};
+__host__ __device__ inline size_t search_lds_bytes(int cap, int qCap) {
+  const size_t capR = (size_t)(cap + 3) & ~(size_t)3, qCapR = (size_t)(qCap + 3) & ~(size_t)3;
+  return 4 * ((size_t)GRID_CELLS + 4) + 4 * (size_t)GRID_CELLS + 4 * capR + 4 * qCapR + 2 * capR * 3 + 2 * qCapR + capR;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(SEARCH_THREADS) void k_search(morb_frame_params P, int qCap, const int* __restrict__ nQv,
+                                                          const Query* __restrict__ qs, const uint8_t* __restrict__ qDesc,
+                                                          const uint8_t* __restrict__ qHasObs, const int* __restrict__ fImg, int cap,
+                                                          const int* __restrict__ count, const morb_keypoint* __restrict__ kps,
+                                                          const uint8_t* __restrict__ desc, const float* __restrict__ uRight,
+                                                          const uint8_t* __restrict__ blockedIn, uint32_t* __restrict__ cand,
+                                                          float nnratio, int thAccept, int checkOri, int* __restrict__ match,
+                                                          int* __restrict__ nmatches) {
+  static_assert(MODE == 0 || MODE == 1, "the fisheye / initialisation searches keep the serial replay");
+  extern __shared__ __align__(16) uint8_t smemRaw[];
+  __shared__ int hist[HISTO_LENGTH];
+  __shared__ int keep3[3];
+  __shared__ uint32_t waveTot[SEARCH_THREADS / 64];
+  __shared__ int sLo, sAcc, sRem;
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int img = fImg[f];
+  const int N = min(count[img], cap);
+  const int nQ = min(nQv ? nQv[f] : N, qCap);
+  const size_t capR = (size_t)(cap + 3) & ~(size_t)3, qCapR = (size_t)(qCap + 3) & ~(size_t)3;
+  SearchLds L;
+  {
+    uint8_t* p = smemRaw;
+    L.start = (uint32_t*)p; p += 4 * ((size_t)GRID_CELLS + 4);
+    L.cur = (uint32_t*)p; p += 4 * (size_t)GRID_CELLS;
+    L.blk = (uint32_t*)p; p += 4 * capR;
+    L.res = (uint32_t*)p; p += 4 * qCapR;
+    L.cellOf = (uint16_t*)p; p += 2 * capR;
+    L.tmp = (uint16_t*)p; p += 2 * capR;
+    L.featOf = (uint16_t*)p; p += 2 * capR;
+    L.qcnt = (uint16_t*)p; p += 2 * qCapR;
+    L.blk0 = p;
+  }
+  const morb_keypoint* kpRow = kps + (size_t)img * cap;
+  const uint8_t* descRow = desc + (size_t)img * cap * 32;
+  const float* ur = uRight ? uRight + (size_t)f * cap : nullptr;
+  // ---- (1) the grid
+  for (int c = tid; c < GRID_CELLS; c += SEARCH_THREADS) L.cur[c] = 0;
+  if (tid < HISTO_LENGTH) hist[tid] = 0;
+  if (tid == 0) { sAcc = 0; sRem = 0; }
+  __syncthreads();
+  for (int j = tid; j < N; j += SEARCH_THREADS) {
+    const float kx = kpRow[j].x, ky = kpRow[j].y;
+    const int posX = (int)roundf((kx - P.minX) * P.gridInvW), posY = (int)roundf((ky - P.minY) * P.gridInvH);
+    int c = 0xFFFF;
+    if (!(posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS)) { c = posX * GRID_ROWS + posY; atomicAdd(&L.cur[c], 1u); }
+    L.cellOf[j] = (uint16_t)c;
+  }
+  __syncthreads();
+  {   // exclusive scan of the 3072 cell counts: three cells per thread, wave scan, wave totals
+    const int c0 = tid * 3;
+    uint32_t a = 0, b = 0, c = 0;
+    if (c0 < GRID_CELLS) { a = L.cur[c0]; b = L.cur[c0 + 1]; c = L.cur[c0 + 2]; }
+    const uint32_t mine = a + b + c;
+    uint32_t inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off, 64); if ((tid & 63) >= off) inc += o; }
+    if ((tid & 63) == 63) waveTot[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < (tid >> 6); ++w) base += waveTot[w];
+    const uint32_t ex = base + inc - mine;
+    if (c0 < GRID_CELLS) {
+      L.start[c0] = ex; L.start[c0 + 1] = ex + a; L.start[c0 + 2] = ex + a + b;
+      L.cur[c0] = ex; L.cur[c0 + 1] = ex + a; L.cur[c0 + 2] = ex + a + b;
+      if (c0 + 3 == GRID_CELLS) L.start[GRID_CELLS] = ex + mine;
+    }
+  }
+  __syncthreads();
+  const int M = (int)L.start[GRID_CELLS];   // features inside the grid
+  for (int j = tid; j < N; j += SEARCH_THREADS) {
+    const int c = L.cellOf[j];
+    if (c != 0xFFFF) L.tmp[atomicAdd(&L.cur[c], 1u)] = (uint16_t)j;
+  }
+  __syncthreads();
+  for (int p = tid; p < M; p += SEARCH_THREADS) {   // sort each (short) row by feature index: position = start + #smaller
+    const int j = L.tmp[p], c = L.cellOf[j];
+    const int s = (int)L.start[c], e = (int)L.start[c + 1];
+    int r = s;
+    for (int t = s; t < e; ++t) r += (int)L.tmp[t] < j ? 1 : 0;
+    L.featOf[r] = (uint16_t)j;
+    L.blk0[r] = blockedIn ? (blockedIn[(size_t)f * cap + j] != 0) : 0;
+  }
+  __syncthreads();
+  // ---- (2) candidate lists, a thread per query
+  uint32_t* candF = cand + (size_t)f * SEARCH_CAP * qCap;
+  auto for_each_candidate = [&](const Query& q, const Desc& qd, auto&& fn) {
+    int cx0, cx1, cy0, cy1;
+    if (!cell_range(P, q, cx0, cx1, cy0, cy1)) return;
+    for (int cx = cx0; cx <= cx1; ++cx) {
+      const int p0 = (int)L.start[cx * GRID_ROWS + cy0], p1 = (int)L.start[cx * GRID_ROWS + cy1 + 1];
+      for (int p = p0; p < p1; ++p) {
+        const uint32_t k = search_key(P, q, qd, p, (int)L.featOf[p], kpRow, descRow, ur);
+        if (k != ~0u) fn(k);
+      }
+    }
+  };
+  for (int qi = tid; qi < nQ; qi += SEARCH_THREADS) {
+    const size_t qo = (size_t)f * qCap + qi;
+    const Query q = qs[qo];
+    int n = 0;
+    if (q.valid) {
+      const Desc qd = load_desc(qDesc + qo * 32);
+      for_each_candidate(q, qd, [&](uint32_t k) { if (n < SEARCH_CAP) candF[(size_t)n * qCap + qi] = k; ++n; });
+    }
+    L.qcnt[qi] = (uint16_t)min(n, 0xFFFF);
+    L.res[qi] = ~0u;
+  }
+  // ---- (3) results <-> blk until nothing changes
+  int lo = 0;
+  for (;;) {
+    for (int p = tid; p < M; p += SEARCH_THREADS) L.blk[p] = L.blk0[p] ? 0u : ~0u;
+    if (tid == 0) sLo = 0x7fffffff;
+    __syncthreads();
+    for (int qi = tid; qi < nQ; qi += SEARCH_THREADS) {
+      const uint32_t r = L.res[qi];
+      if (r != ~0u && (r & 0x10000u)) atomicMin(&L.blk[r & 0xFFFFu], (uint32_t)qi + 1u);
+    }
+    __syncthreads();
+    int changed = 0x7fffffff;
+    for (int qi = lo + tid; qi < nQ; qi += SEARCH_THREADS) {
+      const int n = L.qcnt[qi];
+      if (n == 0) continue;
+      uint32_t k1 = ~0u, k2 = ~0u;
+      if (n <= SEARCH_CAP) {
+        for (int c = 0; c < n; ++c) {
+          const uint32_t k = candF[(size_t)c * qCap + qi];
+          if (L.blk[(k >> 4) & 0xFFFFu] > (uint32_t)qi) top2_insert32(k1, k2, k);
+        }
+      } else {
+        const size_t qo = (size_t)f * qCap + qi;
+        const Query q = qs[qo];
+        const Desc qd = load_desc(qDesc + qo * 32);
+        for_each_candidate(q, qd, [&](uint32_t k) { if (L.blk[(k >> 4) & 0xFFFFu] > (uint32_t)qi) top2_insert32(k1, k2, k); });
+      }
+      uint32_t r = ~0u;
+      if (k1 != ~0u) {
+        const int bestDist = (int)(k1 >> 20);
+        bool accept;
+        if (MODE == 1) {   // ORBmatcher.cc:118-137
+          const int bestLevel = (int)(k1 & 15);
+          const int bestDist2 = k2 == ~0u ? 256 : (int)(k2 >> 20), bestLevel2 = k2 == ~0u ? -1 : (int)(k2 & 15);
+          accept = bestDist <= TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2);
+        } else {
+          accept = bestDist <= thAccept;
+        }
+        if (accept) {
+          const uint32_t ho = qHasObs ? (qHasObs[(size_t)f * qCap + qi] != 0) : 1u;
+          r = ((k1 >> 4) & 0xFFFFu) | (ho << 16);
+        }
+      }
+      if (r != L.res[qi]) { L.res[qi] = r; changed = min(changed, qi); }
+    }
+    if (changed != 0x7fffffff) atomicMin(&sLo, changed);
+    __syncthreads();
+    const int first = sLo;
+    if (first == 0x7fffffff) break;
+    lo = first + 1;      // queries up to the first change are final (their inputs are results of queries below them)
+    __syncthreads();     // (sLo is rewritten at the top of the loop)
+  }
+  // ---- outputs: last accepted query per feature, rotation filter (MODE 0), counts
+  for (int p = tid; p < M; p += SEARCH_THREADS) { L.blk[p] = 0u; L.blk0[p] = 0; }
+  __syncthreads();
+  int acc = 0;
+  for (int qi = tid; qi < nQ; qi += SEARCH_THREADS) {
+    uint32_t r = L.res[qi];
+    if (r == ~0u) continue;
+    ++acc;
+    const int p = (int)(r & 0xFFFFu);
+    atomicMax(&L.blk[p], (uint32_t)qi + 1u);
+    if (MODE == 0 && checkOri) {
+      float rot = qs[(size_t)f * qCap + qi].angle - kpRow[L.featOf[p]].angle;
+      if (rot < 0.0f) rot += 360.0f;
+      int bin = (int)roundf(rot * (1.0f / HISTO_LENGTH));
+      if (bin == HISTO_LENGTH) bin = 0;
+      atomicAdd(&hist[bin], 1);
+      L.res[qi] = r | ((uint32_t)bin << 17);
+    }
+  }
+  if (acc) atomicAdd(&sAcc, acc);
+  __syncthreads();
+  if (MODE == 0 && checkOri) {
+    if (tid == 0) {   // ComputeThreeMaxima (:1844-1876)
+      int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+      for (int i = 0; i < HISTO_LENGTH; i++) {
+        const int s = hist[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+      }
+      if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+      else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+      keep3[0] = ind1; keep3[1] = ind2; keep3[2] = ind3;
+    }
+    __syncthreads();
+    int rem = 0;
+    for (int qi = tid; qi < nQ; qi += SEARCH_THREADS) {
+      const uint32_t r = L.res[qi];
+      if (r == ~0u) continue;
+      const int b = (int)((r >> 17) & 31);
+      if (b != keep3[0] && b != keep3[1] && b != keep3[2]) { L.blk0[r & 0xFFFFu] = 1; ++rem; }   // every entry counts (:1722-1728)
+    }
+    if (rem) atomicAdd(&sRem, rem);
+    __syncthreads();
+  }
+  int* mF = match + (size_t)f * cap;
+  for (int p = tid; p < M; p += SEARCH_THREADS) {
+    const uint32_t o = L.blk[p];
+    if (o) mF[L.featOf[p]] = L.blk0[p] ? -1 : (int)o - 1;
+  }
+  if (tid == 0) nmatches[f] = sAcc - sRem;
+}
+
 // query preparation for SearchByProjection(CurrentFrame, KeyFrame*, ...) (:1735-1790) and SearchForInitialization
 __global__ __launch_bounds__(256) void k_prep_kf(morb_frame_params P, int cap, const int* __restrict__ count,
                                                  const int* __restrict__ kfImg, const morb_keypoint* __restrict__ kps,
@@ -931,6 +1205,23 @@ static int window_search(morb_matcher* m, const morb_frame_params* P, int mode, 
                          float* d_prevMatched, hipStream_t st, const int* d_l2r = nullptr, const int* d_r2l = nullptr,
                          const int* d_nLeft = nullptr) {
   void *cand = nullptr, *cnt = nullptr, *ej = nullptr, *eb = nullptr;
+  if ((mode == 0 || mode == 1) && cap <= 65535 && qCap <= 65535 && search_lds_bytes(cap, qCap) <= 150 * 1024 && !getenv("MORB_SERIAL_RESOLVE")) {
+    // one launch, one workgroup per frame: grid in LDS, candidate lists, blocked-feature fixed point (k_search)
+    const size_t lds = search_lds_bytes(cap, qCap);
+    int rc = morb_matcher_workspace(m, 0, sizeof(uint32_t) * (size_t)nframes * qCap * SEARCH_CAP, &cand);
+    if (rc != MORB_OK) return rc;
+    if (mode == 0) {
+      MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_search<0>, dim3(nframes), dim3(SEARCH_THREADS), lds, st, *P, qCap, d_nQ, d_qs, d_qDesc, d_qHasObs, d_fImg, cap,
+                         d_count, d_kps, d_desc, d_uRight, d_blocked, (uint32_t*)cand, nnratio, thAccept, checkOri, d_match, d_nmatches);
+    } else {
+      MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_search<1>, dim3(nframes), dim3(SEARCH_THREADS), lds, st, *P, qCap, d_nQ, d_qs, d_qDesc, d_qHasObs, d_fImg, cap,
+                         d_count, d_kps, d_desc, d_uRight, d_blocked, (uint32_t*)cand, nnratio, thAccept, checkOri, d_match, d_nmatches);
+    }
+    MORB_HIP_CHECK(hipGetLastError());
+    return MORB_OK;
+  }
   int rc = morb_matcher_workspace(m, 0, sizeof(unsigned long long) * (size_t)nframes * qCap * CAND_CAP, &cand);
   if (rc == MORB_OK) rc = morb_matcher_workspace(m, 1, sizeof(int) * (size_t)nframes * qCap, &cnt);
   if (rc == MORB_OK) rc = morb_matcher_workspace(m, 2, sizeof(int) * (size_t)nframes * qCap, &ej);
