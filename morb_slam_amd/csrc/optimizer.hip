@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -477,6 +478,47 @@ __device__ __forceinline__ double ordered_add(double tot, const double* __restri
   }
   return tot;
 }
+// The same sum, software-pipelined: the next eight rows are REQUESTED before the current eight are added (empty asm statements that carry the running sum and clobber memory pin the order: without
+// them the compiler sinks the reads behind the additions again — it had placed every batch's reads directly in front of their use — a full LDS round trip per batch
+// on a wave that is alone on its SIMD, ~23 cycles per term).  Two register sets, so no copies.  ROWS = rows of the buffer (a multiple of 8): reads
+// never leave it; rows >= m are read and not added.
+template <int STRIDE, int ROWS>
+__device__ __forceinline__ double ordered_add_pipe(double tot, const double* __restrict__ p, int m) {
+  static_assert(ROWS % 8 == 0, "whole batches");
+  double v[8], w[8];
+#define MORB_LOAD8(dst, row)                                                   \
+  do {                                                                         \
+    const int r_ = (row) <= ROWS - 8 ? (row) : ROWS - 8;                       \
+    _Pragma("unroll") for (int k = 0; k < 8; ++k) dst[k] = p[(r_ + k) * STRIDE]; \
+    asm volatile("" : "+v"(tot) : : "memory");                                 \
+  } while (0)
+#define MORB_ADD8(src)                                         \
+  do {                                                         \
+    _Pragma("unroll") for (int k = 0; k < 8; ++k) tot += src[k]; \
+    asm volatile("" : "+v"(tot) : : "memory");                 \
+  } while (0)
+  MORB_LOAD8(v, 0);
+  int e = 0;
+  for (; e + 16 <= m; e += 16) {
+    MORB_LOAD8(w, e + 8);
+    MORB_ADD8(v);
+    MORB_LOAD8(v, e + 16);
+    MORB_ADD8(w);
+  }
+  if (e + 8 <= m) {
+    MORB_LOAD8(w, e + 8);
+    MORB_ADD8(v);
+    e += 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (e + k < m) tot += w[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (e + k < m) tot += v[k];
+  }
+#undef MORB_LOAD8
+#undef MORB_ADD8
+  return tot;
+}
 #ifdef MORB_PO_TRACE
 __device__ double g_poTrace[6 * 520];
 __device__ int g_poTraceN;
@@ -742,6 +784,309 @@ __global__ __launch_bounds__(NT) void k_pose_opt(int cap, const int* __restrict_
     nInliers[f] = nInit - nBadEdges;
     if (stats) { stats[2 * f] = outerIts; stats[2 * f + 1] = trials; }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: PoseOptimization rebuilt around what a lone frame's latency is made of (the launch is one frame's latency for 1 .. 256 frames).
+//  * The active edges (map point present, not an outlier of the previous round) are COMPACTED, in feature order, at the start of each of
+//    the four rounds, and every worker thread keeps its <= PO2_EPT edges in registers for the round: no global load inside the LM loop, and
+//    the edge-order sums run over the active edges only (a skipped edge contributed an exact +0.0: same bits) — ~600 of 1200 features.
+//  * ONE pass over the edges per LM trial instead of two.  g2o evaluates the errors twice at every accepted state: once for the trial's
+//    chi2 (optimization_algorithm_levenberg.cpp:118-120) and once more, with the Jacobians, when the next iteration builds H and b
+//    (:77-84).  Here the trial's pass speculatively produces H, b AND chi2 at the trial state; accepted (the common case), the next
+//    iteration takes them as they are — the same expressions on the same inputs, so the same bits — and a rejected trial keeps the H, b of
+//    the state it falls back to, as g2o does.
+//  * In the edge-order mode wave 0 owns the 28 ordered sums and the 6 x 6 solve; waves 1 .. 7 compute the edges.  A stage is 448 edges:
+//    while wave 0 adds stage s, the workers already compute stage s + 1.
+//  * The solve, exp and pose update run on wave 0 only; the other waves pick the new pose up from LDS (they used to repeat all of it).
+constexpr int PO2_NT = 512, PO2_NW = PO2_NT / 64, PO2_EPT = 4, PO2_STAGE = PO2_NT - 64;   // edges per stage (edge-order mode)
+constexpr int PO2_MAX_CAP = PO2_EPT * PO2_STAGE;   // 1792 features: larger frames take k_pose_opt
+
+struct PoEdge { float o[3], X[3], info; int right; };
+
+template <bool FISH>
+__device__ __forceinline__ void po2_contrib(const Cam& cam, const Rig& rig, const SE3& P, const SE3& Pr, const PoEdge& e, bool robust,
+                                            double deltaMono, double deltaStereo, double (&con)[28]) {
+  const double X[3] = {(double)e.X[0], (double)e.X[1], (double)e.X[2]};
+  double xc[3], err[3], Jp[18], w = 1.0;
+  bool st;
+  const double info = (double)e.info;
+  const bool right = FISH && e.right;
+  double c = pose_edge_error<FISH>(cam, rig, P, Pr, right, X, e.o, info, err, st, xc);
+  if (robust) c = huber(st ? deltaStereo : deltaMono, c, &w);
+  con[27] = c;
+  pose_edge_jac<FISH>(cam, rig, right, st, xc, Jp);
+  // g2o's own expressions (base_unary_edge.hpp:54-66): omega_r = -Omega e (then * rho'), b += J^T omega_r, H += J^T (rho' Omega) J
+  const double wr[3] = {-info * err[0] * w, -info * err[1] * w, -info * err[2] * w};
+  const double wo = w * info;
+  int q = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    double bb = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) bb += Jp[k * 6 + r] * wr[k];   // (mono: row 2 and err[2] are zero)
+    con[21 + r] = bb;
+#pragma unroll
+    for (int cc = 0; cc <= r; ++cc) {   // the LOWER triangle, (J_r w Omega) J_c as Eigen forms it: LinearSolverDense's LDLT reads that triangle
+      double h = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) h += Jp[k * 6 + r] * wo * Jp[k * 6 + cc];
+      con[q++] = h;
+    }
+  }
+}
+
+#ifdef MORB_PO_CYCLES   // developer build (tools/ab_build.py): thread 0 of frame 0 adds up where its cycles go
+__device__ unsigned long long g_po2Cyc[8];
+extern "C" int morb_po2_cycles(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_po2Cyc), sizeof(unsigned long long) * 8); const unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_po2Cyc), z, sizeof z); return 0; }
+#define PO2_T0(v) const long long v = clock64()
+#define PO2_ADD(slot, v) do { if (f == 0 && tid == 0) g_po2Cyc[slot] += (unsigned long long)(clock64() - v); } while (0)
+#define PO2_CNT(slot) do { if (f == 0 && tid == 0) g_po2Cyc[slot] += 1; } while (0)
+#else
+#define PO2_T0(v)
+#define PO2_ADD(slot, v)
+#define PO2_CNT(slot)
+#endif
+template <bool FISH, bool ORDERED>
+__global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __restrict__ count, const uint8_t* __restrict__ hasMP,
+                                                      const float* __restrict__ obs, const float* __restrict__ invSigma2,
+                                                      const float* __restrict__ Xw, Cam cam, Rig rig, const int* __restrict__ nLeft,
+                                                      float* __restrict__ poseIO, uint8_t* __restrict__ outlier,
+                                                      int* __restrict__ nInliers, int* __restrict__ stats) {
+  constexpr int NT = PO2_NT, NW = PO2_NW;
+  constexpr int W0 = ORDERED ? 64 : 0;          // first worker thread (edge-order mode: wave 0 adds and solves)
+  constexpr int NWORK = NT - W0;                // edges per stage
+  extern __shared__ __align__(16) uint8_t po2Raw[];
+  double* sC = reinterpret_cast<double*>(po2Raw);                                          // ORDERED: [NWORK][PO_PITCH] contributions of a stage
+  uint16_t* actList = reinterpret_cast<uint16_t*>(po2Raw + (ORDERED ? (size_t)NWORK * PO_PITCH * 8 : 0));   // [cap] active features, in order
+  __shared__ double red[NW];
+  __shared__ double sH[NW][28];
+  __shared__ double sTot[2][28];     // H (lower triangle 0 .. 20), b (21 .. 26), robust chi2 (27) at the state last built / at the trial state
+  __shared__ double sPose[8];        // the trial pose (wave 0 -> everybody) + scale
+  __shared__ double sKeep[3][7];     // uniform poses that would otherwise sit in every thread's registers: T0, Teval, the trial's backup
+  __shared__ int sFlag[2];
+  __shared__ int sWaveCnt[NW];
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n = min(count ? count[f] : cap, cap);
+  const size_t base = (size_t)f * cap;
+  const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
+
+  PO2_T0(tAll);
+  int nInit = 0;
+  for (int i = tid; i < n; i += NT) {
+    if (hasMP[base + i]) { ++nInit; outlier[base + i] = 0; }
+  }
+  nInit = (int)block_sum_d<NW>((double)nInit, red);
+  if (nInit < 3) {  // Optimizer.cc:951
+    if (tid == 0) { nInliers[f] = 0; if (stats) { stats[2 * f] = 0; stats[2 * f + 1] = 0; } }
+    return;
+  }
+  SE3 T = se3_from_float(poseIO + 7 * f);
+  auto put = [&](int slot, const SE3& P) { if (tid == 0) { for (int k = 0; k < 4; ++k) sKeep[slot][k] = P.q[k]; for (int k = 0; k < 3; ++k) sKeep[slot][4 + k] = P.t[k]; } };
+  auto get = [&](int slot) { SE3 P; for (int k = 0; k < 4; ++k) P.q[k] = sKeep[slot][k]; for (int k = 0; k < 3; ++k) P.t[k] = sKeep[slot][4 + k]; return P; };
+  put(0, T); put(1, T);     // T0, Teval (read after later barriers)
+  bool robust = true;
+  int nBadEdges = 0, outerIts = 0, trials = 0;
+  const int nL = FISH ? nLeft[f] : n;   // features >= nL are right-camera observations (fisheye rig)
+  PoEdge ed[PO2_EPT];
+  int nAct = 0;
+
+  // H, b, chi2 of the active edges at pose P -> sTot[buf]
+  auto pass = [&](const SE3& P, int buf) {
+    PO2_T0(tp); PO2_CNT(4);
+    const SE3 Pr = FISH ? se3_mul(rig.Trl, P) : P;
+    if (ORDERED) {
+      double tot = 0;   // lanes 0 .. 27 of wave 0: entry `lane`
+#pragma unroll
+      for (int s = 0; s < PO2_EPT; ++s) {   // (unrolled: ed[s] must stay in registers)
+        if (s * NWORK >= nAct) break;
+        double con[28];
+        const int e = s * NWORK + (tid - W0);
+        const bool mine = tid >= W0 && e < nAct;
+        if (mine) po2_contrib<FISH>(cam, rig, P, Pr, ed[s], robust, deltaMono, deltaStereo, con);   // (beside wave 0's sums of stage s - 1)
+        if (s == 0) PO2_ADD(3, tp);
+        __syncthreads();                       // stage s - 1 has been added
+        if (mine) {
+#pragma unroll
+          for (int k = 0; k < 28; ++k) sC[(tid - W0) * PO_PITCH + k] = con[k];
+        }
+        __syncthreads();
+        if (tid < 28) tot = ordered_add_pipe<PO_PITCH, NWORK>(tot, sC + tid, min(NWORK, nAct - s * NWORK));
+      }
+      if (tid < 28) sTot[buf][tid] = tot;
+      __syncthreads();
+      PO2_ADD(2, tp);
+    } else {
+      double acc[28];
+#pragma unroll
+      for (int k = 0; k < 28; ++k) acc[k] = 0;
+#pragma unroll
+      for (int s = 0; s < PO2_EPT; ++s) {
+        if (s * NWORK + tid < nAct) {
+          double con[28];
+          po2_contrib<FISH>(cam, rig, P, Pr, ed[s], robust, deltaMono, deltaStereo, con);
+#pragma unroll
+          for (int k = 0; k < 28; ++k) acc[k] += con[k];
+        }
+      }
+      __syncthreads();                         // (sH / sTot[buf] of an earlier pass have been read)
+      wave_sum28_to(acc, sH[wv], lane);
+      __syncthreads();
+      if (tid < 28) { double t = sH[0][tid]; for (int w = 1; w < NW; ++w) t += sH[w][tid]; sTot[buf][tid] = t; }
+      __syncthreads();
+      PO2_ADD(2, tp);
+    }
+  };
+
+  for (int it = 0; it < 4; ++it) {
+    // ---- the round's active edges, in feature order; each worker thread takes its edges into registers
+    PO2_T0(tc);
+    __syncthreads();
+    T = get(0);  // vSE3->setEstimate(pFrame->GetPose()) (:962-964)
+    nAct = 0;
+    for (int c0 = 0; c0 < n; c0 += NT) {
+      const int i = c0 + tid;
+      const bool a = i < n && hasMP[base + i] && !outlier[base + i];
+      const unsigned long long m = __ballot(a);
+      if (lane == 0) sWaveCnt[wv] = __popcll(m);
+      __syncthreads();
+      int off = nAct, totc = 0;
+      for (int w = 0; w < NW; ++w) { const int c = sWaveCnt[w]; if (w < wv) off += c; totc += c; }
+      if (a) actList[off + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+      nAct += totc;
+      __syncthreads();
+    }
+#pragma unroll
+    for (int s = 0; s < PO2_EPT; ++s) {
+      const int e = s * NWORK + (tid - W0);
+      if (tid >= W0 && e < nAct) {
+        const int i = actList[e];
+        ed[s].o[0] = obs[(base + i) * 3]; ed[s].o[1] = obs[(base + i) * 3 + 1]; ed[s].o[2] = obs[(base + i) * 3 + 2];
+        ed[s].X[0] = Xw[(base + i) * 3]; ed[s].X[1] = Xw[(base + i) * 3 + 1]; ed[s].X[2] = Xw[(base + i) * 3 + 2];
+        ed[s].info = invSigma2[base + i];
+        ed[s].right = i >= nL;
+      }
+    }
+    PO2_ADD(5, tc);
+    // ---- optimizer.optimize(10) ----
+    int cur = 0;
+    pass(T, cur);
+    double lambda = 0, ni = 2;
+    int nBad = 0;
+    for (int iter = 0; iter < 10; ++iter) {
+      ++outerIts;
+      double currentChi = sTot[cur][27];
+      const double iniChi = currentChi;
+      if (iter == 0) {  // computeLambdaInit (tau = 1e-5)
+        double m = 0;
+        int q = 0;
+        for (int r = 0; r < 6; ++r) { q += r; m = fmax(fabs(sTot[cur][q + r]), m); }   // diagonal entries of the packed lower triangle
+        lambda = 1e-5 * m; ni = 2; nBad = 0;
+      }
+      double rho = 0;
+      int qmax = 0;
+      do {
+        put(2, T);           // backup (read behind the barriers of the trial's pass)
+        PO2_T0(ts);
+        if (wv == 0) {
+          double H[36], b[6], x[6] = {0, 0, 0, 0, 0, 0};
+          int q = 0;
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int cc = 0; cc <= r; ++cc) { const double v = sTot[cur][q++]; H[r * 6 + cc] = v; H[cc * 6 + r] = v; }
+#pragma unroll
+          for (int r = 0; r < 6; ++r) { b[r] = sTot[cur][21 + r]; H[r * 6 + r] += lambda; }
+          const bool ok2 = ldlt6(H, b, x);
+          const SE3 Tn = se3_mul(se3_exp(x), T);
+          double scale = 0;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) scale += x[r] * (lambda * x[r] + b[r]);
+          scale += 1e-3;
+          if (lane == 0) {
+            for (int k = 0; k < 4; ++k) sPose[k] = Tn.q[k];
+            for (int k = 0; k < 3; ++k) sPose[4 + k] = Tn.t[k];
+            sPose[7] = scale;
+            sFlag[0] = ok2 ? 1 : 0;
+          }
+        }
+        __syncthreads();
+        for (int k = 0; k < 4; ++k) T.q[k] = sPose[k];
+        for (int k = 0; k < 3; ++k) T.t[k] = sPose[4 + k];
+        const double scale = sPose[7];
+        const bool ok2 = sFlag[0] != 0;
+        PO2_ADD(1, ts);
+        put(1, T);           // Teval
+        pass(T, cur ^ 1);
+        double tempChi = sTot[cur ^ 1][27];
+        if (!ok2) tempChi = 1.7976931348623157e308;
+        rho = (currentChi - tempChi) / scale;
+        if (rho > 0 && isfinite(tempChi)) {
+          double alpha = 1. - cube_rn(2 * rho - 1);
+          alpha = fmin(alpha, 2. / 3.);
+          lambda *= fmax(1. / 3., alpha);
+          ni = 2;
+          currentChi = tempChi;
+          cur ^= 1;           // H, b at the accepted state are already there
+        } else {
+          lambda *= ni;
+          ni *= 2;
+          T = get(2);         // sTot[cur] still holds H, b of this state
+        }
+        ++qmax; ++trials;
+      } while (rho < 0 && qmax < 10);
+      if (qmax == 10 || rho == 0) break;
+      if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+      if (nBad >= 3) break;
+    }
+    // ---- classify (:966-1037): inlier edges keep the error of the LAST evaluated state (Teval, which is a
+    // rejected trial when the LM loop ended on a failure), current outliers are re-evaluated at the final pose
+    int bad = 0;
+    PO2_T0(tk);
+    __syncthreads();
+    const SE3 Teval = get(1);
+    const SE3 TrFin = FISH ? se3_mul(rig.Trl, T) : T, TrEval = FISH ? se3_mul(rig.Trl, Teval) : Teval;
+    for (int i = tid; i < n; i += NT) {
+      if (!hasMP[base + i]) continue;
+      const float* o = obs + (base + i) * 3;
+      const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
+      double xc[3], err[3];
+      bool st;
+      const SE3& Pc = outlier[base + i] ? T : Teval;
+      const float chi2 = (float)pose_edge_error<FISH>(cam, rig, Pc, outlier[base + i] ? TrFin : TrEval, FISH && i >= nL, X, o,
+                                                      (double)invSigma2[base + i], err, st, xc);
+      const bool isOut = chi2 > (st ? 7.815f : 5.991f);
+      outlier[base + i] = isOut ? 1 : 0;
+      bad += isOut ? 1 : 0;
+    }
+    nBadEdges = (int)block_sum_d<NW>((double)bad, red);
+    PO2_ADD(6, tk);
+    if (it == 2) robust = false;
+    if (nInit < 10) break;  // optimizer.edges().size() < 10 (:1039)
+  }
+  if (tid == 0) {
+    for (int k = 0; k < 4; ++k) poseIO[7 * f + k] = (float)T.q[k];
+    for (int k = 0; k < 3; ++k) poseIO[7 * f + 4 + k] = (float)T.t[k];
+    nInliers[f] = nInit - nBadEdges;
+    if (stats) { stats[2 * f] = outerIts; stats[2 * f + 1] = trials; }
+  }
+  PO2_ADD(0, tAll);
+}
+template <bool FISH>
+static int launch_pose_opt2(bool ordered, int nframes, hipStream_t st, int cap, const int* d_count, const uint8_t* d_hasMP, const float* d_obs,
+                            const float* d_invSigma2, const float* d_Xw, const Cam& cam, const Rig& rig, const int* d_nLeft, float* d_pose,
+                            uint8_t* d_outlier, int* d_nInliers, int* d_stats) {
+  const size_t listBytes = ((size_t)cap * 2 + 15) & ~(size_t)15;
+  if (ordered) {
+    const size_t lds = (size_t)PO2_STAGE * PO_PITCH * 8 + listBytes;
+    MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt2<FISH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_pose_opt2<FISH, true>), dim3(nframes), dim3(PO2_NT), lds, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
+                       d_nLeft, d_pose, d_outlier, d_nInliers, d_stats);
+  } else {
+    hipLaunchKernelGGL((k_pose_opt2<FISH, false>), dim3(nframes), dim3(PO2_NT), listBytes, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
+                       d_nLeft, d_pose, d_outlier, d_nInliers, d_stats);
+  }
+  return MORB_OK;
 }
 
 // =====================================================================================================
@@ -1758,6 +2103,11 @@ int morb_pose_optimization_batch(morb_optimizer* o, int nframes, int cap, const 
   Cam cam{fx, fy, cx, cy, bf};
   Rig rig;
   memset(&rig, 0, sizeof rig);
+  if (cap <= PO2_MAX_CAP && !getenv("MORB_PO_OLD")) {
+    const int rc = launch_pose_opt2<false>(o->exactOrder != 0, nframes, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig, nullptr, d_pose,
+                                           d_outlier, d_nInliers, d_stats);
+    if (rc != MORB_OK) return rc;
+  } else
   if (o->exactOrder) hipLaunchKernelGGL((k_pose_opt<false, true, 256>), dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
                      (const int*)nullptr, d_pose, d_outlier, d_nInliers, d_stats);
   else hipLaunchKernelGGL((k_pose_opt<false, false, MORB_PO_NT>), dim3(nframes), dim3(MORB_PO_NT), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
@@ -1787,6 +2137,11 @@ int morb_pose_optimization_fisheye_batch(morb_optimizer* o, int nframes, int cap
     for (int i = 0; i < 4; ++i) rig.Trl.q[i] = q[i] / n;
     for (int i = 0; i < 3; ++i) rig.Trl.t[i] = Trl7[4 + i];
   }
+  if (cap <= PO2_MAX_CAP && !getenv("MORB_PO_OLD")) {
+    const int rc = launch_pose_opt2<true>(o->exactOrder != 0, nframes, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig, d_nLeft, d_pose,
+                                          d_outlier, d_nInliers, d_stats);
+    if (rc != MORB_OK) return rc;
+  } else
   if (o->exactOrder) hipLaunchKernelGGL((k_pose_opt<true, true, 256>), dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
                      d_nLeft, d_pose, d_outlier, d_nInliers, d_stats);
   else hipLaunchKernelGGL((k_pose_opt<true, false, MORB_PO_NT>), dim3(nframes), dim3(MORB_PO_NT), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
