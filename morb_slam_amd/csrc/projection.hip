@@ -711,25 +711,33 @@ __device__ __forceinline__ void top2_insert32(uint32_t& k1, uint32_t& k2, uint32
   k1 = lt1 ? k : k1;
 }
 
-// one candidate of query q: feature j (position p of the grid order); ~0u when a test of the reference's inner loop rejects it
-__device__ __forceinline__ uint32_t search_key(const morb_frame_params& P, const Query& q, const Desc& qd, int p, int j,
-                                               const morb_keypoint* __restrict__ kpRow, const uint8_t* __restrict__ descRow,
-                                               const float* __restrict__ ur) {
-  if (q.jHi > 0 && (j < q.jLo || j >= q.jHi)) return ~0u;
-  const float kx = kpRow[j].x, ky = kpRow[j].y;
-  const int oct = kpRow[j].octave;
+// one candidate of query q: the feature at position p of the grid order; ~0u when a test of the reference's inner loop rejects it.
+// The frame's features are staged in LDS in GRID ORDER (x, y, octave | uRight | descriptor), so the walk over a cell run reads
+// consecutive LDS rows instead of making a dependent global round trip per candidate (one frame alone: 75 -> ~25 us).
+struct SearchFeat { float x, y; int oct; float ur; };   // 16 B
+// LDSDESC is a compile-time choice: with a run-time one the compiler merges the LDS and the global descriptor pointer into a generic one and
+// every distance becomes two FLAT loads behind an `s_waitcnt vmcnt(0)` — which also waits for the candidate store of the visit before.
+template <bool LDSDESC>
+__device__ __forceinline__ uint32_t search_key(const Query& q, const Desc& qd, int p, const SearchFeat* __restrict__ sf,
+                                               const uint16_t* __restrict__ featOf, const uint32_t* __restrict__ sDesc,
+                                               const uint8_t* __restrict__ descRow, bool useUr) {
+  // (the walk is bound by instruction issue — sixteen waves share the CU — so the tests are one predicate, not a ladder of branches: ~55
+  // instead of ~120 instructions per visit.  The feature-index range of a query (jLo / jHi: fisheye searches only) does not occur here.)
+  const SearchFeat ft = sf[p];
   const bool bCheckLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
-  if (bCheckLevels) {
-    if (oct < q.minLevel) return ~0u;
-    if (q.maxLevel >= 0 && oct > q.maxLevel) return ~0u;
+  bool ok = !bCheckLevels || (ft.oct >= q.minLevel && (q.maxLevel < 0 || ft.oct <= q.maxLevel));
+  ok = ok && (fabsf(ft.x - q.x) < q.r) && (fabsf(ft.y - q.y) < q.r);
+  ok = ok && !(useUr && ft.ur > 0 && fabsf(q.xr - ft.ur) > q.erMax);
+  if (!ok) return ~0u;
+  int d;
+  if (LDSDESC) {
+    const uint4 a = *reinterpret_cast<const uint4*>(sDesc + (size_t)p * 8), b = *reinterpret_cast<const uint4*>(sDesc + (size_t)p * 8 + 4);
+    d = __popc(qd.w[0] ^ a.x) + __popc(qd.w[1] ^ a.y) + __popc(qd.w[2] ^ a.z) + __popc(qd.w[3] ^ a.w) + __popc(qd.w[4] ^ b.x) +
+        __popc(qd.w[5] ^ b.y) + __popc(qd.w[6] ^ b.z) + __popc(qd.w[7] ^ b.w);
+  } else {
+    d = hamming(qd, load_desc(descRow + (size_t)featOf[p] * 32));
   }
-  if (!(fabsf(kx - q.x) < q.r && fabsf(ky - q.y) < q.r)) return ~0u;
-  if (ur) {
-    const float u = ur[j];
-    if (u > 0 && fabsf(q.xr - u) > q.erMax) return ~0u;
-  }
-  const int d = hamming(qd, load_desc(descRow + (size_t)j * 32));
-  return ((uint32_t)d << 20) | ((uint32_t)p << 4) | (uint32_t)(oct & 15);
+  return ((uint32_t)d << 20) | ((uint32_t)p << 4) | (uint32_t)(ft.oct & 15);
 }
 
 struct SearchLds {   // carved from dynamic LDS
@@ -737,18 +745,32 @@ struct SearchLds {   // carved from dynamic LDS
   uint32_t* cur;     // [GRID_CELLS]     counts, then fill cursors
   uint32_t* blk;     // [capR]           1 + smallest blocking query (0 = blocked on entry, ~0u = free); later: owner
   uint32_t* res;     // [qCapR]          per query: ~0u none, else p | hasObs << 16 (| bin << 17 at the end)
+  SearchFeat* feat;  // [capR]           features in grid order
+  uint32_t* sDesc;   // [capR][8]        their descriptors (NULL when they do not fit: read from global memory)
   uint16_t* cellOf;  // [capR]           feature -> cell (0xFFFF: outside the grid)
   uint16_t* tmp;     // [capR]           unsorted CSR
   uint16_t* featOf;  // [capR]           position -> feature
-  uint16_t* qcnt;    // [qCapR]          candidates of the query (> SEARCH_CAP: walk again)
+  uint32_t* qcnt;    // [qCapR]          candidates of the query (> SEARCH_CAP: walk again)
+  uint32_t* qOff;    // [qCapR + 4]      exclusive prefix of the queries' visit counts
+  uint32_t* qRange;  // [qCapR]          cx0 | cx1 << 6 | cy0 << 12 | cy1 << 18 | valid << 31
   uint8_t* blk0;     // [capR]           blocked on entry; later: "an entry of this feature fell to the rotation filter"
 };
-__host__ __device__ inline size_t search_lds_bytes(int cap, int qCap) {
+__host__ __device__ inline size_t search_lds_bytes(int cap, int qCap, bool withDesc) {
   const size_t capR = (size_t)(cap + 3) & ~(size_t)3, qCapR = (size_t)(qCap + 3) & ~(size_t)3;
-  return 4 * ((size_t)GRID_CELLS + 4) + 4 * (size_t)GRID_CELLS + 4 * capR + 4 * qCapR + 2 * capR * 3 + 2 * qCapR + capR;
+  return 4 * ((size_t)GRID_CELLS + 4) + 4 * (size_t)GRID_CELLS + 4 * capR + 4 * qCapR + 16 * capR + (withDesc ? 32 * capR : 0) + 2 * capR * 3 +
+         4 * qCapR + 4 * (qCapR + 4) + 4 * qCapR + capR;
 }
 
-template <int MODE>
+#ifdef MORB_SEARCH_CYCLES   // developer build (tools/ab_build.py): thread 0 of frame 0 adds up where its cycles go
+__device__ unsigned long long g_searchCyc[8];
+extern "C" int morb_search_cycles(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_searchCyc), sizeof(unsigned long long) * 8); const unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_searchCyc), z, sizeof z); return 0; }
+#define SRCH_MARK(slot) do { __syncthreads(); if (f == 0 && tid == 0) { const long long now_ = clock64(); g_searchCyc[slot] += (unsigned long long)(now_ - tMark); tMark = now_; } } while (0)
+#define SRCH_CNT(slot) do { if (f == 0 && tid == 0) g_searchCyc[slot] += 1; } while (0)
+#else
+#define SRCH_MARK(slot)
+#define SRCH_CNT(slot)
+#endif
+template <int MODE, bool LDSDESC>
 __global__ __launch_bounds__(SEARCH_THREADS) void k_search(morb_frame_params P, int qCap, const int* __restrict__ nQv,
                                                           const Query* __restrict__ qs, const uint8_t* __restrict__ qDesc,
                                                           const uint8_t* __restrict__ qHasObs, const int* __restrict__ fImg, int cap,
@@ -757,6 +779,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(morb_frame_params P, 
                                                           const uint8_t* __restrict__ blockedIn, uint32_t* __restrict__ cand,
                                                           float nnratio, int thAccept, int checkOri, int* __restrict__ match,
                                                           int* __restrict__ nmatches) {
+  constexpr int withDesc = LDSDESC ? 1 : 0;
   static_assert(MODE == 0 || MODE == 1, "the fisheye / initialisation searches keep the serial replay");
   extern __shared__ __align__(16) uint8_t smemRaw[];
   __shared__ int hist[HISTO_LENGTH];
@@ -775,15 +798,22 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(morb_frame_params P, 
     L.cur = (uint32_t*)p; p += 4 * (size_t)GRID_CELLS;
     L.blk = (uint32_t*)p; p += 4 * capR;
     L.res = (uint32_t*)p; p += 4 * qCapR;
+    L.feat = (SearchFeat*)p; p += 16 * capR;
+    L.sDesc = withDesc ? (uint32_t*)p : nullptr; p += withDesc ? 32 * capR : 0;
     L.cellOf = (uint16_t*)p; p += 2 * capR;
     L.tmp = (uint16_t*)p; p += 2 * capR;
     L.featOf = (uint16_t*)p; p += 2 * capR;
-    L.qcnt = (uint16_t*)p; p += 2 * qCapR;
+    L.qcnt = (uint32_t*)p; p += 4 * qCapR;
+    L.qOff = (uint32_t*)p; p += 4 * (qCapR + 4);
+    L.qRange = (uint32_t*)p; p += 4 * qCapR;
     L.blk0 = p;
   }
   const morb_keypoint* kpRow = kps + (size_t)img * cap;
   const uint8_t* descRow = desc + (size_t)img * cap * 32;
   const float* ur = uRight ? uRight + (size_t)f * cap : nullptr;
+#ifdef MORB_SEARCH_CYCLES
+  long long tMark = clock64();
+#endif
   // ---- (1) the grid
   for (int c = tid; c < GRID_CELLS; c += SEARCH_THREADS) L.cur[c] = 0;
   if (tid < HISTO_LENGTH) hist[tid] = 0;
@@ -830,35 +860,162 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(morb_frame_params P, 
     for (int t = s; t < e; ++t) r += (int)L.tmp[t] < j ? 1 : 0;
     L.featOf[r] = (uint16_t)j;
     L.blk0[r] = blockedIn ? (blockedIn[(size_t)f * cap + j] != 0) : 0;
+    SearchFeat ft;
+    ft.x = kpRow[j].x; ft.y = kpRow[j].y; ft.oct = kpRow[j].octave; ft.ur = ur ? ur[j] : -1.0f;
+    L.feat[r] = ft;
   }
   __syncthreads();
-  // ---- (2) candidate lists, a thread per query
+  if (LDSDESC) {   // descriptors in grid order: eight lanes per feature, a dword each
+    for (int t = tid; t < M * 8; t += SEARCH_THREADS) {
+      const int p = t >> 3, wd = t & 7;
+      L.sDesc[t] = reinterpret_cast<const uint32_t*>(descRow + (size_t)L.featOf[p] * 32)[wd];
+    }
+    __syncthreads();
+  }
+  SRCH_MARK(0);
+  // ---- (2) candidate lists.  A query visits the features of its cell range — 3 on average, 20+ for a wide window at a coarse level — so with a
+  // thread per query a wave ran as long as its widest window (a quarter of the lanes' slots did work).  Instead: every query's visit count from the
+  // CSR, a prefix sum over the queries, and the VISITS dealt evenly to the threads; a thread walks its share (usually inside one or two queries) and
+  // appends what passes the tests to the query's list (LDS counter, c-major global rows).
   uint32_t* candF = cand + (size_t)f * SEARCH_CAP * qCap;
-  auto for_each_candidate = [&](const Query& q, const Desc& qd, auto&& fn) {
+  auto for_each_candidate = [&](const Query& q, const Desc& qd, auto&& fn) {   // (the whole walk of one query: lists longer than SEARCH_CAP)
     int cx0, cx1, cy0, cy1;
     if (!cell_range(P, q, cx0, cx1, cy0, cy1)) return;
     for (int cx = cx0; cx <= cx1; ++cx) {
       const int p0 = (int)L.start[cx * GRID_ROWS + cy0], p1 = (int)L.start[cx * GRID_ROWS + cy1 + 1];
       for (int p = p0; p < p1; ++p) {
-        const uint32_t k = search_key(P, q, qd, p, (int)L.featOf[p], kpRow, descRow, ur);
+        const uint32_t k = search_key<LDSDESC>(q, qd, p, L.feat, L.featOf, L.sDesc, descRow, ur != nullptr);
         if (k != ~0u) fn(k);
       }
     }
   };
   for (int qi = tid; qi < nQ; qi += SEARCH_THREADS) {
-    const size_t qo = (size_t)f * qCap + qi;
-    const Query q = qs[qo];
-    int n = 0;
-    if (q.valid) {
-      const Desc qd = load_desc(qDesc + qo * 32);
-      for_each_candidate(q, qd, [&](uint32_t k) { if (n < SEARCH_CAP) candF[(size_t)n * qCap + qi] = k; ++n; });
+    const Query q = qs[(size_t)f * qCap + qi];
+    uint32_t rg = 0, w = 0;
+    int cx0, cx1, cy0, cy1;
+    if (q.valid && cell_range(P, q, cx0, cx1, cy0, cy1)) {
+      // GetFeaturesInArea's cell range (floor / ceil of the window's ends) holds about twice the cells a feature with |dx| < r, |dy| < r can lie
+      // in: a feature's cell is round((k - min) * inv), monotone in k, so only cells round((c -+ (r + margin) - min) * inv) can pass the window
+      // test that follows anyway.  The margin (0.01 px + 1e-4 r) is far above the rounding of the float expressions involved.
+      const float mr = q.r * 1.0001f + 0.01f;
+      cx0 = max(cx0, (int)roundf((q.x - mr - P.minX) * P.gridInvW)); cx1 = min(cx1, (int)roundf((q.x + mr - P.minX) * P.gridInvW));
+      cy0 = max(cy0, (int)roundf((q.y - mr - P.minY) * P.gridInvH)); cy1 = min(cy1, (int)roundf((q.y + mr - P.minY) * P.gridInvH));
+      if (cx0 <= cx1 && cy0 <= cy1) {
+        rg = (uint32_t)cx0 | ((uint32_t)cx1 << 6) | ((uint32_t)cy0 << 12) | ((uint32_t)cy1 << 18) | 0x80000000u;
+        for (int cx = cx0; cx <= cx1; ++cx) w += L.start[cx * GRID_ROWS + cy1 + 1] - L.start[cx * GRID_ROWS + cy0];
+      }
     }
-    L.qcnt[qi] = (uint16_t)min(n, 0xFFFF);
+    L.qRange[qi] = rg;
+    L.qOff[qi] = w;
+    L.qcnt[qi] = 0;
     L.res[qi] = ~0u;
   }
-  // ---- (3) results <-> blk until nothing changes
+  __syncthreads();
+  {   // exclusive scan of the visit counts (in place): thread t owns queries [t K, (t + 1) K)
+    const int K = (nQ + SEARCH_THREADS - 1) / SEARCH_THREADS;
+    const int b = min(tid * K, nQ), e = min(b + K, nQ);
+    uint32_t mine = 0;
+    for (int i = b; i < e; ++i) mine += L.qOff[i];
+    uint32_t inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off, 64); if ((tid & 63) >= off) inc += o; }
+    __syncthreads();                       // (waveTot was read by the grid's scan)
+    if ((tid & 63) == 63) waveTot[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t run = inc - mine;
+    for (int w = 0; w < (tid >> 6); ++w) run += waveTot[w];
+    for (int i = b; i < e; ++i) { const uint32_t w = L.qOff[i]; L.qOff[i] = run; run += w; }
+    if (tid == SEARCH_THREADS - 1) L.qOff[nQ] = run;
+  }
+  __syncthreads();
+  {
+    const int W = (int)L.qOff[nQ];
+#ifdef MORB_SEARCH_CYCLES
+#endif
+    const int per = (W + SEARCH_THREADS - 1) / SEARCH_THREADS;
+    int item = min(tid * per, W);
+    const int end = min(item + per, W);
+#ifdef MORB_SEARCH_CYCLES
+    long long tW = clock64(); unsigned long long cBs = 0, cLd = 0, cIn = 0;
+#define WK(acc) do { const long long n_ = clock64(); acc += (unsigned long long)(n_ - tW); tW = n_; } while (0)
+#else
+#define WK(acc)
+#endif
+    if (item < end) {
+      int lo_ = 0, hi_ = nQ;               // the query that holds visit `item`: the last one with qOff <= item
+      while (hi_ - lo_ > 1) { const int mid = (lo_ + hi_) >> 1; if ((int)L.qOff[mid] <= item) lo_ = mid; else hi_ = mid; }
+      int qi = lo_;
+      WK(cBs);
+      while (item < end) {
+        while ((int)L.qOff[qi + 1] <= item) ++qi;            // (queries without visits)
+        const size_t qo = (size_t)f * qCap + qi;
+        const Query q = qs[qo];
+        const Desc qd = load_desc(qDesc + qo * 32);
+        const uint32_t rg = L.qRange[qi];
+        const int cx1 = (int)((rg >> 6) & 63), cy0 = (int)((rg >> 12) & 63), cy1 = (int)((rg >> 18) & 63);
+        int cx = (int)(rg & 63);
+        int local = item - (int)L.qOff[qi];
+        const int qEnd = min(end, (int)L.qOff[qi + 1]);
+        int p0 = (int)L.start[cx * GRID_ROWS + cy0], p1 = (int)L.start[cx * GRID_ROWS + cy1 + 1];
+        while (local >= p1 - p0) { local -= p1 - p0; ++cx; p0 = (int)L.start[cx * GRID_ROWS + cy0]; p1 = (int)L.start[cx * GRID_ROWS + cy1 + 1]; }
+        int p = p0 + local;
+#ifdef MORB_SEARCH_CYCLES
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        WK(cLd);
+        while (item < qEnd) {
+          const uint32_t k = search_key<LDSDESC>(q, qd, p, L.feat, L.featOf, L.sDesc, descRow, ur != nullptr);
+          if (k != ~0u) {
+            const uint32_t slot = atomicAdd(&L.qcnt[qi], 1u);
+            if (slot < (uint32_t)SEARCH_CAP) candF[(size_t)slot * qCap + qi] = k;
+          }
+          ++item; ++p;
+          while (p == p1 && cx < cx1) { ++cx; p = (int)L.start[cx * GRID_ROWS + cy0]; p1 = (int)L.start[cx * GRID_ROWS + cy1 + 1]; }
+        }
+        ++qi;
+        WK(cIn);
+      }
+    }
+#ifdef MORB_SEARCH_CYCLES
+    if (f == 0 && tid == 0) { g_searchCyc[5] += cBs; g_searchCyc[6] += cLd; g_searchCyc[7] += cIn; }
+#endif
+  }
+  __threadfence_block();
+  __syncthreads();
+  SRCH_MARK(1);
+  // ---- (3) results <-> blk until nothing changes.  The owner of a query (thread qi % 1024, slot qi / 1024) keeps the first SEARCH_REG keys of its
+  // list in registers: a pass then touches LDS only (the lists were re-read from L2 in every pass: a dependent round trip per key).
+  constexpr int SEARCH_QPT = 2, SEARCH_REG = 4;
+  uint32_t kreg[SEARCH_QPT][SEARCH_REG];
+  uint32_t ownHo = 0;    // bit s: hasObs of slot s's query
+#pragma unroll
+  for (int sl = 0; sl < SEARCH_QPT; ++sl) {
+    const int qi = tid + sl * SEARCH_THREADS;
+#pragma unroll
+    for (int c = 0; c < SEARCH_REG; ++c) kreg[sl][c] = ~0u;
+    if (qi < nQ) {
+      const int n = (int)min(L.qcnt[qi], (uint32_t)SEARCH_CAP);
+#pragma unroll
+      for (int c = 0; c < SEARCH_REG; ++c) if (c < n) kreg[sl][c] = candF[(size_t)c * qCap + qi];
+      if (qHasObs ? (qHasObs[(size_t)f * qCap + qi] != 0) : true) ownHo |= 1u << sl;
+    }
+  }
+  auto decide = [&](int qi, uint32_t k1, uint32_t k2, bool ho) -> uint32_t {
+    if (k1 == ~0u) return ~0u;
+    const int bestDist = (int)(k1 >> 20);
+    bool accept;
+    if (MODE == 1) {   // ORBmatcher.cc:118-137
+      const int bestLevel = (int)(k1 & 15);
+      const int bestDist2 = k2 == ~0u ? 256 : (int)(k2 >> 20), bestLevel2 = k2 == ~0u ? -1 : (int)(k2 & 15);
+      accept = bestDist <= TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2);
+    } else {
+      accept = bestDist <= thAccept;
+    }
+    return accept ? (((k1 >> 4) & 0xFFFFu) | ((ho ? 1u : 0u) << 16)) : ~0u;
+  };
   int lo = 0;
   for (;;) {
+    SRCH_CNT(4);
     for (int p = tid; p < M; p += SEARCH_THREADS) L.blk[p] = L.blk0[p] ? 0u : ~0u;
     if (tid == 0) sLo = 0x7fffffff;
     __syncthreads();
@@ -868,8 +1025,34 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(morb_frame_params P, 
     }
     __syncthreads();
     int changed = 0x7fffffff;
-    for (int qi = lo + tid; qi < nQ; qi += SEARCH_THREADS) {
-      const int n = L.qcnt[qi];
+#pragma unroll
+    for (int sl = 0; sl < SEARCH_QPT; ++sl) {
+      const int qi = tid + sl * SEARCH_THREADS;
+      if (qi < lo || qi >= nQ) continue;
+      const int n = (int)L.qcnt[qi];
+      if (n == 0) continue;
+      uint32_t k1 = ~0u, k2 = ~0u;
+      if (n <= SEARCH_CAP) {
+#pragma unroll
+        for (int c = 0; c < SEARCH_REG; ++c) {
+          const uint32_t k = kreg[sl][c];
+          if (k != ~0u && L.blk[(k >> 4) & 0xFFFFu] > (uint32_t)qi) top2_insert32(k1, k2, k);
+        }
+        for (int c = SEARCH_REG; c < n; ++c) {
+          const uint32_t k = candF[(size_t)c * qCap + qi];
+          if (L.blk[(k >> 4) & 0xFFFFu] > (uint32_t)qi) top2_insert32(k1, k2, k);
+        }
+      } else {
+        const size_t qo = (size_t)f * qCap + qi;
+        const Query q = qs[qo];
+        const Desc qd = load_desc(qDesc + qo * 32);
+        for_each_candidate(q, qd, [&](uint32_t k) { if (L.blk[(k >> 4) & 0xFFFFu] > (uint32_t)qi) top2_insert32(k1, k2, k); });
+      }
+      const uint32_t r = decide(qi, k1, k2, (ownHo >> sl) & 1u);
+      if (r != L.res[qi]) { L.res[qi] = r; changed = min(changed, qi); }
+    }
+    for (int qi = max(lo, SEARCH_QPT * SEARCH_THREADS) + tid; qi < nQ; qi += SEARCH_THREADS) {   // (more than 2048 queries: no register slot)
+      const int n = (int)L.qcnt[qi];
       if (n == 0) continue;
       uint32_t k1 = ~0u, k2 = ~0u;
       if (n <= SEARCH_CAP) {
@@ -883,22 +1066,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(morb_frame_params P, 
         const Desc qd = load_desc(qDesc + qo * 32);
         for_each_candidate(q, qd, [&](uint32_t k) { if (L.blk[(k >> 4) & 0xFFFFu] > (uint32_t)qi) top2_insert32(k1, k2, k); });
       }
-      uint32_t r = ~0u;
-      if (k1 != ~0u) {
-        const int bestDist = (int)(k1 >> 20);
-        bool accept;
-        if (MODE == 1) {   // ORBmatcher.cc:118-137
-          const int bestLevel = (int)(k1 & 15);
-          const int bestDist2 = k2 == ~0u ? 256 : (int)(k2 >> 20), bestLevel2 = k2 == ~0u ? -1 : (int)(k2 & 15);
-          accept = bestDist <= TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2);
-        } else {
-          accept = bestDist <= thAccept;
-        }
-        if (accept) {
-          const uint32_t ho = qHasObs ? (qHasObs[(size_t)f * qCap + qi] != 0) : 1u;
-          r = ((k1 >> 4) & 0xFFFFu) | (ho << 16);
-        }
-      }
+      const uint32_t r = decide(qi, k1, k2, qHasObs ? (qHasObs[(size_t)f * qCap + qi] != 0) : true);
       if (r != L.res[qi]) { L.res[qi] = r; changed = min(changed, qi); }
     }
     if (changed != 0x7fffffff) atomicMin(&sLo, changed);
@@ -908,6 +1076,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(morb_frame_params P, 
     lo = first + 1;      // queries up to the first change are final (their inputs are results of queries below them)
     __syncthreads();     // (sLo is rewritten at the top of the loop)
   }
+  SRCH_MARK(2);
   // ---- outputs: last accepted query per feature, rotation filter (MODE 0), counts
   for (int p = tid; p < M; p += SEARCH_THREADS) { L.blk[p] = 0u; L.blk0[p] = 0; }
   __syncthreads();
@@ -959,6 +1128,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(morb_frame_params P, 
     if (o) mF[L.featOf[p]] = L.blk0[p] ? -1 : (int)o - 1;
   }
   if (tid == 0) nmatches[f] = sAcc - sRem;
+  SRCH_MARK(3);
 }
 
 // query preparation for SearchByProjection(CurrentFrame, KeyFrame*, ...) (:1735-1790) and SearchForInitialization
@@ -1205,20 +1375,21 @@ static int window_search(morb_matcher* m, const morb_frame_params* P, int mode, 
                          float* d_prevMatched, hipStream_t st, const int* d_l2r = nullptr, const int* d_r2l = nullptr,
                          const int* d_nLeft = nullptr) {
   void *cand = nullptr, *cnt = nullptr, *ej = nullptr, *eb = nullptr;
-  if ((mode == 0 || mode == 1) && cap <= 65535 && qCap <= 65535 && search_lds_bytes(cap, qCap) <= 150 * 1024 && !getenv("MORB_SERIAL_RESOLVE")) {
+  if ((mode == 0 || mode == 1) && cap <= 65535 && qCap <= 65535 && search_lds_bytes(cap, qCap, false) <= 150 * 1024 && !getenv("MORB_SERIAL_RESOLVE")) {
     // one launch, one workgroup per frame: grid in LDS, candidate lists, blocked-feature fixed point (k_search)
-    const size_t lds = search_lds_bytes(cap, qCap);
+    const int withDesc = search_lds_bytes(cap, qCap, true) <= 150 * 1024 ? 1 : 0;
+    const size_t lds = search_lds_bytes(cap, qCap, withDesc != 0);
     int rc = morb_matcher_workspace(m, 0, sizeof(uint32_t) * (size_t)nframes * qCap * SEARCH_CAP, &cand);
     if (rc != MORB_OK) return rc;
-    if (mode == 0) {
-      MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_search<0>, dim3(nframes), dim3(SEARCH_THREADS), lds, st, *P, qCap, d_nQ, d_qs, d_qDesc, d_qHasObs, d_fImg, cap,
-                         d_count, d_kps, d_desc, d_uRight, d_blocked, (uint32_t*)cand, nnratio, thAccept, checkOri, d_match, d_nmatches);
-    } else {
-      MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_search<1>, dim3(nframes), dim3(SEARCH_THREADS), lds, st, *P, qCap, d_nQ, d_qs, d_qDesc, d_qHasObs, d_fImg, cap,
-                         d_count, d_kps, d_desc, d_uRight, d_blocked, (uint32_t*)cand, nnratio, thAccept, checkOri, d_match, d_nmatches);
-    }
+#define MORB_SEARCH(MODE, WD)                                                                                                              \
+  do {                                                                                                                                     \
+    MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<MODE, WD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_search<MODE, WD>), dim3(nframes), dim3(SEARCH_THREADS), lds, st, *P, qCap, d_nQ, d_qs, d_qDesc, d_qHasObs, d_fImg, cap, \
+                       d_count, d_kps, d_desc, d_uRight, d_blocked, (uint32_t*)cand, nnratio, thAccept, checkOri, d_match, d_nmatches);         \
+  } while (0)
+    if (mode == 0) { if (withDesc) MORB_SEARCH(0, true); else MORB_SEARCH(0, false); }
+    else { if (withDesc) MORB_SEARCH(1, true); else MORB_SEARCH(1, false); }
+#undef MORB_SEARCH
     MORB_HIP_CHECK(hipGetLastError());
     return MORB_OK;
   }

@@ -16,6 +16,7 @@ def main():
     import torch
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    only = sys.argv[3] if len(sys.argv) > 3 else ""
     G = 256
     imgs = bench.make_batch(range(G), G, seed=0)
     ch, ks, host = build_chains(imgs, B=B, npairs=20, seq_len=64)
@@ -30,6 +31,19 @@ def main():
             fn()
         sync()
         return (time.perf_counter() - t0) / n
+    if only == "search-cycles":   # developer build -DMORB_SEARCH_CYCLES (tools/ab_build.py)
+        import ctypes as C
+        from morb_slam_amd.capi import lib
+        one = {k: v[:1] for k, v in host["scene"].items()}
+        c1 = TrackingChain(ch.P, ch.cam, ch.kps, ch.desc, ch.count, ch.uRight[:1].contiguous(), one)
+        c1.step(); c1.sync()
+        z = (C.c_ulonglong * 8)(); lib().morb_search_cycles(z)
+        c1.step(); c1.sync(); lib().morb_search_cycles(z)
+        print("two searches of one frame: grid+stage %d walk %d fixed-point %d outputs %d passes %d thread0: binsearch %d query-loads %d inner %d" % tuple(list(z)))
+        return
+    if only == "chain-only":     # (for a kernel trace of one step: tools/trk_trace.py)
+        timed(ch.step, ch.sync, steps)
+        return
     dt = timed(ch.step, ch.sync, steps)
     out["tracking_ms_per_step"] = dt * 1e3
     out["tracking_frames_per_s"] = B / dt
@@ -42,7 +56,14 @@ def main():
     one = {k: v[:1] for k, v in host["scene"].items()}
     c1 = TrackingChain(ch.P, ch.cam, ch.kps, ch.desc, ch.count, ch.uRight[:1].contiguous(), one)
     out["tracking_b1_ms"] = timed(c1.step, c1.sync, 50) * 1e3
-    # stage split at b = 1 and at B (events on the chain's stream)
+    c1.close()
+    # the optimiser's default mode (tree sums: same poses to ~1e-9 and same flags, LM trial counts within +-2 of the oracle's)
+    cht = TrackingChain(ch.P, ch.cam, ch.kps, ch.desc, ch.count, ch.uRight, host["scene"], exact_order=False)
+    dtt = timed(cht.step, cht.sync, steps)
+    out["tracking_tree_sums_ms_per_step"] = dtt * 1e3; out["tracking_tree_sums_frames_per_s"] = B / dtt
+    cht.close()
+    c1t = TrackingChain(ch.P, ch.cam, ch.kps, ch.desc, ch.count, ch.uRight[:1].contiguous(), one, exact_order=False)
+    out["tracking_tree_sums_b1_ms"] = timed(c1t.step, c1t.sync, 50) * 1e3
     print(json.dumps(out))
 
 
