@@ -306,6 +306,101 @@ def optimizer_extras(dev_index):
                                   "cpu_oracle_frames_per_s_1core": 1.0 / dcp}}
 
 
+def tracking_extras(dev_index):
+    """The searches and optimisations Tracking / LocalMapping run once a map exists (north_star's SearchByProjection / SearchForTriangulation
+    kernels), device-resident, on rank 0: TrackWithMotionModel + TrackLocalMap as one chain (morb_slam_amd/tracking.py: SearchByProjection(Cur,
+    Last) -> PoseOptimization -> isInFrustum over 2048 local map points -> SearchByProjection(F, MapPoints) -> PoseOptimization) for 256 frames
+    per step and one frame at a time, SearchForTriangulation + Fuse over 20 keyframe pairs, the CPU oracle timed beside each, and frames of the
+    LAST timed step checked against the oracle stage by stage (tests/tracking_check.py: the checker, never the product)."""
+    import torch
+    from morb_slam_amd.tracking import TrackingChain, build_chains
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    import tracking_check
+    B, G = 256, 256
+    imgs = make_batch(range(G), G, seed=0)
+    ch, ks, host = build_chains(imgs, B=B, npairs=20, seq_len=64, device=dev_index)
+    sc = host["scene"]
+
+    def timed(fn, sync, n, warm=3):
+        for _ in range(warm):
+            fn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        sync()
+        return (time.perf_counter() - t0) / n
+    dt = timed(ch.step, ch.sync, 10)
+    ch.step(snapshot=True); ch.sync()
+    nver = tracking_check.verify_tracking(ch, [0, 37, 101, 255], host["kps"], host["cnt"], host["desc"], host["curUR"], sc)
+    out = {"frames_per_step": B, "local_map_points": int(ch.mpCap), "mode": "PoseOptimization in edge order (the LM path of g2o, as the C++ drop-in runs it)",
+           "stages": ["SearchByProjection(Cur, Last, th 7)", "PoseOptimization", "discard outliers", "isInFrustum", "SearchByProjection(F, MapPoints, th 1)",
+                      "PoseOptimization", "inlier count"],
+           "ms_per_step": dt * 1e3, "frames_per_s": B / dt, "verified_frames": nver,
+           "mean_matches_last_frame": float(ch.nmLast.float().mean()), "mean_matches_local_map": float(ch.nmLocal.float().mean()),
+           "mean_inliers": float(ch.nInl.float().mean())}
+    one = {k: v[:1] for k, v in sc.items()}
+    c1 = TrackingChain(ch.P, ch.cam, ch.kps, ch.desc, ch.count, ch.uRight[:1].contiguous(), one, device=dev_index)
+    out["latency_b1_ms"] = timed(c1.step, c1.sync, 50) * 1e3
+    c1.close()
+    cht = TrackingChain(ch.P, ch.cam, ch.kps, ch.desc, ch.count, ch.uRight, sc, device=dev_index, exact_order=False)
+    dtt = timed(cht.step, cht.sync, 10)
+    cht.close()
+    c1t = TrackingChain(ch.P, ch.cam, ch.kps, ch.desc, ch.count, ch.uRight[:1].contiguous(), one, device=dev_index, exact_order=False)
+    out["tree_sum_mode"] = {"frames_per_s": B / dtt, "ms_per_step": dtt * 1e3, "latency_b1_ms": timed(c1t.step, c1t.sync, 50) * 1e3,
+                            "note": "the optimiser's default sums: same poses to ~1e-9 and same outlier flags, LM trial counts within +-2 of g2o's"}
+    c1t.close()
+    # the CPU oracle on the same frames, one thread (the reference runs Tracking on one thread): the chain stage by stage
+    P = ch.P
+    invS2 = (np.float32(1.0) / np.array(list(P.levelSigma2)[:P.nlevels], np.float32)).astype(np.float32)
+
+    def oracle_frame(f):
+        ci, li = int(sc["curImg"][f]), int(sc["lastImg"][f])
+        nc, nl = int(host["cnt"][ci]), int(host["cnt"][li])
+        F = O.make_frame(P, host["kps"][ci, :nc], host["desc"][ci, :nc], host["curUR"][f, :nc])
+        nMP = int(sc["nMP"][f]); lastMP = sc["lastMP"][f, :nl]; lv = (lastMP >= 0).astype(np.uint8); lm = np.maximum(lastMP, 0)
+        mpXw, mpDesc, mpHasObs = sc["mpXw"][f], sc["mpDesc"][f], sc["mpHasObs"][f]
+        _, me = O.search_by_projection_last(F, np.zeros(nc, np.uint8), sc["pose0"][f], host["kps"][li, :nl], lv, mpXw[lm], mpDesc[lm],
+                                            mpHasObs[lm] * lv, 7.0, 0, 0, True)
+        fm = np.where(me >= 0, lastMP[np.maximum(me, 0)], -1).astype(np.int32)
+        he, oe, se, Xe = O.pose_edges(F, invS2, fm, mpXw)
+        _, pe, ole, _ = O.pose_optimization(dict(hasMP=he, obs=oe, invSigma2=se, Xw=Xe, pose0=sc["pose0"][f], cam=ch.cam))
+        _, _, fm2, blk, seen = O.discard_outliers(fm, ole, mpHasObs)
+        Re, te, Oe = O.frame_set_pose(pe)
+        trk = O.is_in_frustum(F, Re, te, Oe, mpXw[:nMP], sc["mpNormal"][f, :nMP], sc["mpMaxD"][f, :nMP], sc["mpMinD"][f, :nMP], 0.5)
+        _, me2 = O.search_by_projection_mps(F, blk, trk, seen[:nMP], mpDesc[:nMP], mpHasObs[:nMP], 1.0, False, 0.0, 0.8, match_init=fm2)
+        he, oe, se, Xe = O.pose_edges(F, invS2, me2, mpXw)
+        O.pose_optimization(dict(hasMP=he, obs=oe, invSigma2=se, Xw=Xe, pose0=pe, cam=ch.cam))
+    t0 = time.perf_counter(); nf = 0
+    while time.perf_counter() - t0 < 3.0:
+        oracle_frame(nf % B); nf += 1
+    out["cpu_oracle_frames_per_s_1core"] = nf / (time.perf_counter() - t0)
+    # LocalMapping's searches per new keyframe
+    dk = timed(ks.step, ks.sync, 10)
+    nk = tracking_check.verify_keyframe_searches(ks, [0, 7, 19], host["kps"], host["cnt"], host["desc"], host["node"], host["uR_img"], host["kscene"])
+    kout = {"keyframe_pairs": 20, "stages": ["SearchForTriangulation", "Fuse (the search)"], "ms_per_step": dk * 1e3, "pairs_per_s": 20 / dk,
+            "verified_pairs": nk, "mean_triangulation_matches": float(ks.tri[1].float().mean()),
+            "mean_fused_candidates": float((ks.fused[0] >= 0).sum(1).float().mean())}
+    ksc = host["kscene"]
+    sig2 = list(P.levelSigma2)[:P.nlevels]; sf = list(P.scaleFactors)[:P.nlevels]
+    t0 = time.perf_counter(); npr = 0
+    while time.perf_counter() - t0 < 2.0:
+        p = npr % 20
+        a, b = int(ksc["img1"][p]), int(ksc["img2"][p]); na, nb = int(host["cnt"][a]), int(host["cnt"][b])
+        O.search_for_triangulation(host["kps"][a, :na], host["desc"][a, :na], host["node"][a, :na], ksc["hasMP"][a, :na], host["uR_img"][a, :na],
+                                   host["kps"][b, :nb], host["desc"][b, :nb], host["node"][b, :nb], ksc["hasMP"][b, :nb], host["uR_img"][b, :nb],
+                                   sig2, sf, [P.fx, P.fy, P.cx, P.cy], ksc["R12"][p].reshape(3, 3), ksc["t12"][p], ksc["ep"][p], False, False, False)
+        KF = O.make_frame(P, host["kps"][b, :nb], host["desc"][b, :nb], ksc["fuseUR"][p, :nb])
+        n = int(ksc["nMP"][p])
+        O.fuse_search(KF, invS2, ksc["Tcw"][p], ksc["Ow"][p], ksc["valid"][p, :n], ksc["Pw"][p, :n], ksc["normal"][p, :n], ksc["maxD"][p, :n],
+                      ksc["minD"][p, :n], ksc["mpDesc"][p, :n], 3.0, False)
+        npr += 1
+    kout["cpu_oracle_pairs_per_s_1core"] = npr / (time.perf_counter() - t0)
+    ch.close(); ks.close()
+    return {"tracking_chain": out, "keyframe_searches": kout}
+
+
 def config_extras(dev_index):
     """Throughput of the other BASELINE configs on rank 0 (short runs; parity for these shapes is in tests/):
     C3 = TUM-VI-shaped fisheye stereo 512x512, 1500 features, lapping areas: extract x2 + ComputeStereoFishEyeMatches
@@ -809,6 +904,7 @@ def main():
             line["latency_b1"] = lat
         if world == 1 and not args.no_extras:
             line["extra_metrics"] = optimizer_extras(local_rank)
+            line["extra_metrics"].update(tracking_extras(local_rank))
             if args.workload == "c2":
                 line["extra_metrics"].update(config_extras(local_rank))
         if world == 1 and not args.no_cpu_baseline:      # reported on rank 0 at N = 1 only
