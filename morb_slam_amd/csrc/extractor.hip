@@ -519,13 +519,7 @@ __global__ __launch_bounds__(64 * QT_MAX_WAVES) void k_distribute(const LevelGeo
   }
   QT_TEAM_SYNC(tm);
   int T = tm.nw > 1 ? teamSh[11] : running;
-  // the quadtree keeps a node's four child counts in 16 bits each (quadtree.h: Work::bcnt): a level with 65536 or more candidates (white noise
-  // at 1080p; ~40 k at 752 x 480) could overflow them and mis-sort silently.  Such a level is cut to 65535 candidates to stay memory-safe and
-  // the call is marked failed: morb_extract returns MORB_ERR_UNSUPPORTED, morb_extractor_status reports it for the batched form.
-  if (T > 65535) {
-    if (lane == 0 && tm.tw == 0) atomicOr(status, 1);
-    T = 65535;
-  }
+  // (any number of candidates: the child counts of Work::bcnt saturate and the few nodes of more than 65535 keys are counted again, quadtree.h)
   DMARK(8);
 
   const uint32_t* cbase = cand + ((size_t)img * totalCells + g.cellBase) * (size_t)cellCap;
@@ -1302,7 +1296,8 @@ int morb_extractor_status(morb_extractor* e, int* flags) {
   MORB_REQUIRE(e, MORB_ERR_INVALID, "extractor is NULL");
   const int f = __atomic_exchange_n(e->h_status, 0, __ATOMIC_ACQ_REL);
   if (flags) *flags = f;
-  if (f & 1) { set_error("a pyramid level held more than 65535 FAST candidates (noise-like image): unsupported, the keypoints of that call are not valid"); return MORB_ERR_UNSUPPORTED; }
+  // (bit 0 was "a level held more than 65535 FAST candidates" until round 5; the quadtree no longer has that limit and no kernel raises a flag today)
+  if (f) { set_error("an extraction was flagged on the device (flags 0x%x): the keypoints of that call are not valid", f); return MORB_ERR_UNSUPPORTED; }
   return MORB_OK;
 }
 
@@ -1537,6 +1532,7 @@ int morb_extract(morb_extractor* e, const uint8_t* image, int width, int height,
     e->ioBytes1 = need;
   }
   memcpy(e->h_io1, image, bytes);
+  const int stale = __atomic_load_n(e->h_status, __ATOMIC_ACQUIRE);   // flags of earlier, unqueried calls on this handle
   MORB_HIP_CHECK(hipMemcpyAsync(e->d_img, e->h_io1, bytes, hipMemcpyHostToDevice, e->stream));
   int lap[2] = {lap0, lap1};
   rc = morb_extract_batch(e, e->d_img, 1, width, height, stride, bytes, lap, e->d_kps1, e->d_desc1, maxk, e->d_cnt1,
@@ -1551,7 +1547,11 @@ int morb_extract(morb_extractor* e, const uint8_t* image, int width, int height,
   MORB_HIP_CHECK(hipMemcpyAsync(hkps, e->d_kps1, sizeof(morb_keypoint) * (size_t)maxk, hipMemcpyDeviceToHost, e->stream));
   MORB_HIP_CHECK(hipMemcpyAsync(hdesc, e->d_desc1, 32 * (size_t)maxk, hipMemcpyDeviceToHost, e->stream));
   MORB_HIP_CHECK(hipStreamSynchronize(e->stream));
-  if ((rc = morb_extractor_status(e, nullptr)) != MORB_OK) { *n = 0; return rc; }
+  {   // only THIS call's flags decide its result: what an earlier batched call left unqueried stays for morb_extractor_status
+    const int own = __atomic_exchange_n(e->h_status, 0, __ATOMIC_ACQ_REL) & ~stale;
+    if (stale) __atomic_fetch_or(e->h_status, stale, __ATOMIC_ACQ_REL);
+    if (own) { set_error("the extraction was flagged on the device (flags 0x%x)", own); *n = 0; return MORB_ERR_UNSUPPORTED; }
+  }
   const int cnt = hcnt[0], mono = hcnt[1];
   *n = cnt;
   MORB_REQUIRE(cnt <= cap, MORB_ERR_CAPACITY, "keypoint buffer too small");

@@ -62,7 +62,8 @@ struct Work {
   uint64_t* vB;       // [nodeCap] vPrevSizeAndPointerToNode
   // batch split (device): the nodes one sweep divides, in processing order, with their child key counts and ranks
   uint16_t* order;    // [nodeCap] node ids
-  uint64_t* bcnt;     // [nodeCap] keys per child, 4 x 16 bit (n1 | n2 << 16 | n3 << 32 | n4 << 48)
+  uint64_t* bcnt;     // [nodeCap] keys per child, 4 x 16 bit (n1 | n2 << 16 | n3 << 32 | n4 << 48), each SATURATED at 0xFFFF: exact for nodes of
+                      //           <= 65535 keys; the few larger nodes of a noise-like level are counted again when they are partitioned (qt_pack4)
   uint32_t* brank;    // [nodeCap] children pushed before this node | children with > 1 key before it << 16
   int nodeCap, listCap;
 };
@@ -618,13 +619,23 @@ __device__ __forceinline__ int qt_scan_incl(int v) {   // inclusive prefix sum o
   MORB_DPP_SCAN(v, 0, morbwave::op_add);
   return v;
 }
-__device__ __forceinline__ void qt_write_children(Work& w, const Node& nd, int mx, int my, uint64_t cnt64, uint32_t rk, int oldHead,
+// four child counts in 16 bits each, saturated: what the rank pass needs (is a child empty, does it hold more than one key) survives, and a
+// node of <= 65535 keys cannot saturate.  Until round 5 the fields simply overflowed and a level of > 65535 candidates was refused.
+__device__ __forceinline__ uint64_t qt_pack4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+  auto sat = [](uint32_t c) -> uint64_t { return c < 0xFFFFu ? c : 0xFFFFu; };
+  return sat(c0) | (sat(c1) << 16) | (sat(c2) << 32) | (sat(c3) << 48);
+}
+__device__ __forceinline__ void qt_unpack4(uint64_t c, uint32_t cnt[4]) {
+  cnt[0] = (uint32_t)c & 0xFFFFu; cnt[1] = (uint32_t)(c >> 16) & 0xFFFFu; cnt[2] = (uint32_t)(c >> 32) & 0xFFFFu; cnt[3] = (uint32_t)(c >> 48) & 0xFFFFu;
+}
+__device__ __forceinline__ void qt_write_children(Work& w, const Node& nd, int mx, int my, const uint32_t (&cnt)[4], uint32_t rk, int oldHead,
                                                   int nA0, int nFree0, int c) {
-  // child c (0..3) of nd: rank among the node's non-empty children = number of non-empty children before it
+  // child c (0..3) of nd: rank among the node's non-empty children = number of non-empty children before it (cnt: EXACT key counts)
   int r = 0, re = 0;
   uint32_t b = nd.begin;
-  for (int q = 0; q < c; ++q) { const uint32_t cq = (uint32_t)(cnt64 >> (16 * q)) & 0xFFFFu; r += cq > 0; re += cq > 1; b += cq; }
-  const uint32_t myCnt = (uint32_t)(cnt64 >> (16 * c)) & 0xFFFFu;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) if (q < c) { const uint32_t cq = cnt[q]; r += cq > 0; re += cq > 1; b += cq; }
+  const uint32_t myCnt = c == 0 ? cnt[0] : c == 1 ? cnt[1] : c == 2 ? cnt[2] : cnt[3];
   if (myCnt == 0) return;
   const int gr = (int)(rk & 0xFFFFu) + r, ge = (int)(rk >> 16) + re;
   const int cid = w.freeIds[nFree0 - 1 - gr];
@@ -658,7 +669,7 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
         const int mx = nb.x0 + ((nb.x1 - nb.x0 + 1) >> 1), my = nb.y0 + ((nb.y1 - nb.y0 + 1) >> 1);
         uint32_t cnt[4], lo, hi;
         qt_count_team(w.keys, nb.begin, nb.count, [mx, my](uint32_t k) -> int { return qt_class(k, mx, my); }, cnt, tm, &lo, &hi);
-        if (tm.tw == 0 && lane == 0) w.bcnt[e0 + bl] = (uint64_t)cnt[0] | ((uint64_t)cnt[1] << 16) | ((uint64_t)cnt[2] << 32) | ((uint64_t)cnt[3] << 48);
+        if (tm.tw == 0 && lane == 0) w.bcnt[e0 + bl] = qt_pack4(cnt[0], cnt[1], cnt[2], cnt[3]);
         __syncthreads();   // (the slice counts in tm.sh are rewritten by the next huge node)
       }
     }
@@ -689,7 +700,7 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
         c0 += __popcll(__ballot(g == 0)); c1 += __popcll(__ballot(g == 1));
         c2 += __popcll(__ballot(g == 2)); c3 += __popcll(__ballot(g == 3));
       }
-      if (lane == 0) w.bcnt[eb] = (uint64_t)c0 | ((uint64_t)c1 << 16) | ((uint64_t)c2 << 32) | ((uint64_t)c3 << 48);
+      if (lane == 0) w.bcnt[eb] = qt_pack4(c0, c1, c2, c3);
     }
   }
   QT_TEAM_SYNC(tm);
@@ -734,9 +745,8 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
         uint32_t cnt[4];
         qt_partition_team(w.keys, w.tmp, nb.begin, nb.count, [bmx, bmy](uint32_t k) -> int { return qt_class(k, bmx, bmy); }, cnt, tm);
         if (tm.tw == 0) {
-          const uint64_t bc = w.bcnt[e0 + bl];
           const uint32_t brk = w.brank[e0 + bl];
-          if (lane < 4) qt_write_children(w, nb, bmx, bmy, bc, brk, oldHead, nA0, nFree0, lane);
+          if (lane < 4) qt_write_children(w, nb, bmx, bmy, cnt, brk, oldHead, nA0, nFree0, lane);   // (cnt: the team partition's own exact counts)
           if (lane == 0) w.list[nb.lit] = 0xFFFF;
         }
       }
@@ -763,8 +773,10 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
         bs += 1ull << (16 * g);
       }
       for (uint32_t k = 0; k < nd.count; ++k) w.keys[nd.begin + k] = w.tmp[nd.begin + k];
+      uint32_t c4[4];
+      qt_unpack4(c, c4);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) qt_write_children(w, nd, mx, my, c, rk, oldHead, nA0, nFree0, q);
+      for (int q = 0; q < 4; ++q) qt_write_children(w, nd, mx, my, c4, rk, oldHead, nA0, nFree0, q);
       w.list[nd.lit] = 0xFFFF;
     }
     uint64_t big = __ballot(valid && !small);
@@ -776,9 +788,11 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
       const int bmx = nb.x0 + ((nb.x1 - nb.x0 + 1) >> 1), bmy = nb.y0 + ((nb.y1 - nb.y0 + 1) >> 1);
       const uint64_t bc = w.bcnt[eb];
       const uint32_t brk = w.brank[eb];
-      uint32_t cnt[4] = {(uint32_t)bc & 0xFFFFu, (uint32_t)(bc >> 16) & 0xFFFFu, (uint32_t)(bc >> 32) & 0xFFFFu, (uint32_t)(bc >> 48) & 0xFFFFu};
-      qt_partition(w.keys, w.tmp, nb.begin, nb.count, [bmx, bmy](uint32_t k) -> int { return qt_class(k, bmx, bmy); }, cnt, true);
-      if (lane < 4) qt_write_children(w, nb, bmx, bmy, bc, brk, oldHead, nA0, nFree0, lane);
+      uint32_t cnt[4];
+      qt_unpack4(bc, cnt);
+      // (a node of more than 65535 keys — noise-like levels only — may have saturated fields: the partition counts again)
+      qt_partition(w.keys, w.tmp, nb.begin, nb.count, [bmx, bmy](uint32_t k) -> int { return qt_class(k, bmx, bmy); }, cnt, nb.count <= 0xFFFFu);
+      if (lane < 4) qt_write_children(w, nb, bmx, bmy, cnt, brk, oldHead, nA0, nFree0, lane);
       if (lane == 0) w.list[nb.lit] = 0xFFFF;
     }
   }

@@ -181,3 +181,5 @@ class StereoFrontEnd:
         self.bstream.synchronize()
         self.stream.synchronize()
         self.torch.cuda.synchronize(self.dev)
+        for e in self.exts:
+            e.check_status()      # an extraction flagged on the device must not be consumed silently

@@ -259,24 +259,28 @@ def test_event_after_fast_is_a_live_hip_event():
     assert lib().morb_stream_wait_event(s.cuda_stream, None) == -1  # MORB_ERR_INVALID
 
 
-def test_more_than_65535_candidates_in_a_level_fail_loudly():
-    """The quadtree keeps child counts in 16 bits: a level with more candidates (white noise at 1080p: ~200 k) cannot be distributed exactly.
-    It must be refused (MORB_ERR_UNSUPPORTED), not mis-sorted in silence; the VGA noise image (~40 k candidates) stays exact
-    (test_noise_image_many_candidates)."""
+def test_more_than_65535_candidates_in_a_level_match_the_oracle():
+    """DistributeOctTree has no size limit (ORBextractor.cc:540-738).  White noise at 1080p puts ~200 k FAST candidates into level 0: until round 5
+    the quadtree's 16-bit child counts refused such a level (MORB_ERR_UNSUPPORTED); the counts now saturate and nodes of more than 65535 keys are
+    counted again when they are split, so the level is distributed exactly — batched (one wave per level) and one image at a time (team of waves)."""
     import torch
-    from morb_slam_amd import ORBextractor
-    from morb_slam_amd.capi import MorbError
+    from morb_slam_amd import KP_DTYPE, ORBextractor
+    from oracle_lib import OracleExtractor
     rng = np.random.default_rng(5)
     img = rng.integers(0, 256, (1080, 1920), dtype=np.uint8)
     g = ORBextractor(4000, 1.2, 8, 20, 7)
-    with pytest.raises(MorbError) as ei:
-        g(img)
-    assert ei.value.code == -4
-    # the batched form: flagged, reported after the caller synchronised its stream, cleared by the query
-    g.extract_batch(torch.from_numpy(np.stack([img, img])).cuda())
+    o = OracleExtractor(4000, 1.2, 8, 20, 7)
+    mono_o, ko, do = o(img)
+    assert max(len(o.level_candidates(l)) for l in range(8)) > 65535
+    mono, k, d = g(img)                                     # <= 16 images per call: the big levels are worked by a team of four waves
+    assert mono == mono_o and k.tobytes() == ko.tobytes() and np.array_equal(d, do)
+    imgs = np.stack([img] * 17)                             # > 16 images per call: one wave per level
+    kps, desc, cnt, _ = g.extract_batch(torch.from_numpy(imgs).cuda())
     torch.cuda.synchronize()
-    with pytest.raises(MorbError):
-        g.check_status()
     g.check_status()
+    for i in (0, 16):
+        n = int(cnt[i])
+        assert n == len(ko) and kps[i, :n].cpu().numpy().reshape(-1).view(KP_DTYPE).tobytes() == ko.tobytes()
+        assert np.array_equal(desc[i, :n].cpu().numpy(), do)
     mono, k, d = g(make_image(1920, 1080, seed=31))      # and the handle keeps working
     assert len(k) > 3000
