@@ -112,6 +112,12 @@ int Optimizer::PoseOptimization(FrameT* pFrame) {
   morb_glue::pose7(pFrame->GetPose(), f.pose);                     // :781-783
   float rig[28];
   if (pFrame->mpCamera2) { morb_glue::rig28(pFrame, rig); f.nLeft = pFrame->Nleft; f.rig28 = rig; }   // :880-946
+  int nInitialCorrespondences = 0;
+  for (int i = 0; i < fe.N; ++i) nInitialCorrespondences += fe.has[i] ? 1 : 0;
+  if (fe.N <= 0 || nInitialCorrespondences < 3) {                   // :951: the reference returns without touching the pose; the graph fill
+    fe.write_outliers(pFrame);                                      // before it has already cleared mvbOutlier[i] of the features with a map point
+    return 0;
+  }
   const int nin = PoseOptimization(f);
   pFrame->SetPose(morb_glue::make_se3<SE3>(f.pose));               // :1044-1048
   fe.outlier = f.mvbOutlier;
@@ -376,9 +382,9 @@ void Optimizer::LocalInertialBA(KF* pKF, bool* pbStopFlag, MapT* pMap, int& num_
     KF* pKFi = vpOptimizableKFs[i];
     if (!pKFi->mPrevKF) continue;
     if (!(pKFi->bImu && pKFi->mPrevKF->bImu && pKFi->mpImuPreintegrated)) continue;
+    pKFi->mpImuPreintegrated->SetNewBias(pKFi->mPrevKF->GetImuBias());                // :2533 (before the vertices are looked up, as the reference does)
     const auto a = kfIndex.find(pKFi->mPrevKF);
     if (a == kfIndex.end()) continue;                                                 // (:2547-2552: a vertex is missing)
-    pKFi->mpImuPreintegrated->SetNewBias(pKFi->mPrevKF->GetImuBias());                // :2535
     iKF1.push_back(a->second); iKF2.push_back(kfIndex[pKFi]);
     iPre.emplace_back(); morb_glue::fill_pre(iPre.back(), pKFi->mpImuPreintegrated);
     iRobust.push_back((i == N - 1 || bRecInit) ? 1 : 0);                              // :2563-2573

@@ -127,7 +127,10 @@ void* morb_matcher_stream(const morb_matcher*);
  * (row d_rows[f], or row f when d_rows is NULL — e.g. the left images 0, 2, 4, ...) into ONE contiguous buffer of morb_feature_slab_bytes(S, cap)
  * bytes: [S][cap] keypoints | [S][cap][32] descriptors | [S][cap] node ids (-1 when d_node is NULL) | [S] counts.  The caller moves that one
  * buffer (hipMemcpyPeerAsync over xGMI, or an RCCL send / recv) and unpack scatters it into rows d_rows[f] of the receiver's pool.  All
- * pointers are DEVICE pointers; asynchronous on `stream`.  INTEGRATION.md section 5 shows the sharding loop of a C++ Tracking. */
+ * pointers are DEVICE pointers; asynchronous on `stream`.  INTEGRATION.md section 5 shows the sharding loop of a C++ Tracking.
+ * PRECONDITIONS (not checked: the sizes live in device memory): the slab holds morb_feature_slab_bytes(S, cap) bytes; every d_rows[f]
+ * (or f itself when d_rows is NULL) is a row of arrays allocated with the SAME cap as the packer's; the counts inside the slab are
+ * <= cap (pack writes min(count, cap)).  A slab packed with another cap must not be unpacked: the row pitch is part of the format. */
 size_t morb_feature_slab_bytes(int S, int cap);
 int morb_feature_slab_pack(morb_matcher*, int S, int cap, const int* d_rows, const morb_keypoint* d_kps, const uint8_t* d_desc, const int* d_node,
                            const int* d_count, void* d_slab, void* stream);

@@ -10,15 +10,14 @@
 #include <cstring>
 
 #include "common.h"
+#include "internal_abi.h"
 #include "kb8.h"
 
 using namespace morb;
 
 struct morb_matcher;
 extern "C" {
-int morb_matcher_device(const morb_matcher*);
 void* morb_matcher_stream(const morb_matcher*);
-int morb_matcher_workspace(morb_matcher*, int which, size_t bytes, void** out);
 int morb_hamming_knn2_batch(morb_matcher*, int nprob, const uint8_t* d_query, const int* d_nq, int qPitch, const int* d_qOff,
                             const uint8_t* d_train, const int* d_nt, int tPitch, const int* d_tOff, int* d_idx, int* d_dist,
                             void* stream);

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "common.h"
+#include "internal_abi.h"
 #include "libm_f32.h"
 #include "kb8.h"
 #include "dense_ldlt.h"
@@ -30,11 +31,7 @@ using namespace morb;
 
 struct morb_optimizer;
 extern "C" {
-int morb_optimizer_device(const morb_optimizer*);
 void* morb_optimizer_stream(const morb_optimizer*);
-int morb_optimizer_workspace(morb_optimizer*, size_t bytes, void** out);
-int morb_optimizer_lm_words(morb_optimizer*, int** host, int** dev);
-int morb_optimizer_staging(morb_optimizer*, size_t bytes, void** host);   // grow-only pinned host buffer   // 16 pinned, device-mapped ints (LM state mirror)
 }
 
 #define WAVE_SYNC_F()                                      \

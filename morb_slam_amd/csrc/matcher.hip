@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "common.h"
+#include "internal_abi.h"
 #include "wave.h"
 #include "extractor_internal.h"
 
@@ -310,11 +311,12 @@ __global__ __launch_bounds__(256) void k_stereo_match(const StereoGeom sg, const
         if (d < TH_HIGH) key = ((unsigned long long)d << 32) | (unsigned)jR;
       }
       if (cap <= 65536) {
-        // Segmented minimum in ONE scan: the list's keypoints ascend, so with (7 - q) in the top bits the ordinary inclusive prefix
-        // minimum of (7 - q) << 24 | distance << 16 | right index is, in every lane, the minimum over the lanes of ITS OWN keypoint up
+        // Segmented minimum in ONE scan: the list's keypoints ascend, so with (SM_KQ - 1 - q) in the top bits the ordinary inclusive prefix
+        // minimum of (SM_KQ - 1 - q) << 24 | distance << 16 | right index is, in every lane, the minimum over the lanes of ITS OWN keypoint up
         // to there (an earlier keypoint's entries are larger in the top bits); the last lane of a keypoint's run holds the run's
         // minimum.  (Before: one 64-bit wave minimum — two DPP scans — per keypoint of the round, ~250 vector instructions a round.)
-        uint32_t ck = ((uint32_t)(7 - q) << 24) | (key == ~0ull ? 0xFFFFFFu : (((uint32_t)(key >> 32) << 16) | (uint32_t)(key & 0xFFFFu)));
+        static_assert(SM_KQ <= 256 && TH_HIGH <= 256, "the packed key holds (SM_KQ - 1 - q) in 8 bits, a distance < TH_HIGH in 8 bits and the right index in 16");
+        uint32_t ck = ((uint32_t)(SM_KQ - 1 - q) << 24) | (key == ~0ull ? 0xFFFFFFu : (((uint32_t)(key >> 32) << 16) | (uint32_t)(key & 0xFFFFu)));
         MORB_DPP_SCAN(ck, 0xFFFFFFFFu, morbwave::op_umin);
         const int qn = (int)(pairs[c + 1 < n ? c + 1 : n - 1] >> 16);
         const bool runEnd = act && (c == n - 1 || lane == 63 || qn != q);
@@ -1143,7 +1145,7 @@ __global__ __launch_bounds__(256) void k_slab_copy(int S, int cap, const int* __
   if (which == 0) { a = kps + (size_t)row * wK; b = sK + (size_t)f * wK; n = wK; }
   else if (which == 1) { a = desc + (size_t)row * wD; b = sD + (size_t)f * wD; n = wD; }
   else { a = node ? node + (size_t)row * wN : nullptr; b = sN + (size_t)f * wN; n = wN; }
-  if (which == 2 && threadIdx.x == 0) { if (dir == 0) sC[f] = (uint32_t)count[row]; else count[row] = (int)sC[f]; }
+  if (which == 2 && threadIdx.x == 0) { if (dir == 0) sC[f] = (uint32_t)min(max(count[row], 0), cap); else count[row] = (int)min(sC[f], (uint32_t)cap); }   // (a count never exceeds the row pitch)
   if (!a) { if (dir == 0) for (size_t i = threadIdx.x; i < n; i += 256) b[i] = 0xFFFFFFFFu; return; }
   if (dir == 0) for (size_t i = threadIdx.x; i < n; i += 256) b[i] = a[i];
   else for (size_t i = threadIdx.x; i < n; i += 256) a[i] = b[i];

@@ -18,13 +18,18 @@
 // the stereo projection, float Huber deltas, float chi2 tests) are reproduced.
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+#include <time.h>
+
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "common.h"
+#include "internal_abi.h"
 #include "kb8.h"
 #include "dense_ldlt.h"
 #include "schur_mfma.h"
@@ -1991,7 +1996,8 @@ struct morb_ba_problem {
   size_t ldsBytes = 0;
   size_t denseLds = 0;     // LDS bytes of the triangle-resident solver (0: the system is too large for it)
   int mode = 0;            // 0 = grid (one launch per LM phase, host-side accept/reject), 1 = one persistent workgroup
-  hipStream_t lastStream = nullptr;   // the stream the last morb_ba_solve ran on (morb_ba_results waits for it, not for the device)
+  hipEvent_t solved = nullptr;   // recorded behind the last morb_ba_solve on whatever stream it ran on: morb_ba_results waits for the EVENT — not for
+                                 // the device, and not through the caller's stream handle, which the caller may have destroyed since
   int redBlocks = 0;
   morbschur::Plan schur;
   size_t nPairEntries = 0;   // (e1, e2) observation pairs of the sparse block-pair Schur form (flop accounting only)
@@ -2389,6 +2395,7 @@ void morb_ba_problem_destroy(morb_ba_problem* p) {
   if (!p) return;
   (void)hipSetDevice(p->opt->device);
   (void)hipStreamSynchronize(p->opt->stream);
+  if (p->solved) { (void)hipEventSynchronize(p->solved); (void)hipEventDestroy(p->solved); }
   for (void* d : p->allocs) (void)hipFree(d);
   if (!p->arena) {
     if (p->h_scal) (void)hipHostFree(p->h_scal);
@@ -2459,7 +2466,8 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
   MORB_REQUIRE(p, MORB_ERR_INVALID, "NULL problem");
   MORB_HIP_CHECK(hipSetDevice(p->opt->device));
   hipStream_t st = stream ? (hipStream_t)stream : p->opt->stream;
-  p->lastStream = st;
+  if (!p->solved) MORB_HIP_CHECK(hipEventCreateWithFlags(&p->solved, hipEventDisableTiming));
+  struct RecordOnExit { hipEvent_t ev; hipStream_t st; ~RecordOnExit() { (void)hipEventRecord(ev, st); } } recordOnExit{p->solved, st};
   const int n = std::max(p->h.nKF, p->h.nMP * 3);
   hipLaunchKernelGGL(k_ba_reset, dim3(div_up(n, 256)), dim3(256), 0, st, p->h, p->d_pose0, p->d_pt0);
   if (p->mode == 1) {
@@ -2496,8 +2504,12 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
       hipLaunchKernelGGL(k_g_backsub_update_w, dim3(rb), dim3(GB), 0, st, d, part1);
       hipLaunchKernelGGL(k_g_chi2, dim3(rb), dim3(GB), 0, st, d, part0, (const double*)part1, 1);
       MORB_HIP_CHECK(hipGetLastError());
-      // wait until all but the last kAhead queued trials are decided (or the solve is done): a spin on mapped host memory
+      // wait until all but the last kAhead queued trials are decided (or the solve is done) on the mapped host words, backing off in tiers: a
+      // trial takes ~110 us, so the first ~30 us are `pause` spins (the decision of a short trial is picked up at once), then the thread yields
+      // its core between looks (LocalMapping's thread no longer holds a core against Tracking's for the whole solve), and a wait that outlasts
+      // 2 ms — a solve stuck behind other work on the device — sleeps 50 us at a time
       unsigned spins = 0;
+      const auto tWait = std::chrono::steady_clock::now();
       while (!__atomic_load_n(hostw + 5, __ATOMIC_ACQUIRE) && __atomic_load_n(hostw + 4, __ATOMIC_ACQUIRE) < slot + 1 - kAhead) {
         forwardStop();
         if ((++spins & 0x3FFu) == 0) {
@@ -2508,7 +2520,9 @@ int morb_ba_solve(morb_ba_problem* p, void* stream) {
             return MORB_ERR_HIP;
           }
         }
-        __builtin_ia32_pause();
+        if (spins < 2048) __builtin_ia32_pause();
+        else if ((spins & 0xFF) != 0 || std::chrono::steady_clock::now() - tWait < std::chrono::milliseconds(2)) sched_yield();
+        else { struct timespec ts = {0, 50000}; nanosleep(&ts, nullptr); }
       }
       if (__atomic_load_n(hostw + 5, __ATOMIC_ACQUIRE)) break;
     }
@@ -2549,7 +2563,7 @@ int morb_ba_results(morb_ba_problem* p, float* kfPose, float* mpPos, uint8_t* er
   // the solve may have run on a caller's stream: wait for THAT stream (not for the device: with the reference's threading a tracked
   // frame's optimisation on another handle must not wait for this solve, nor this copy for it), then copy on the handle's own stream
   // (a copy on the null stream would also wait for, and hold up, every other handle's blocking stream)
-  if (p->lastStream && p->lastStream != p->opt->stream) MORB_HIP_CHECK(hipStreamSynchronize(p->lastStream));
+  if (p->solved) MORB_HIP_CHECK(hipEventSynchronize(p->solved));
   hipStream_t st = p->opt->stream;
   if (kfPose) MORB_HIP_CHECK(hipMemcpyAsync(kfPose, p->h.poseIO, sizeof(float) * 7 * p->h.nKF, hipMemcpyDeviceToHost, st));
   if (mpPos) MORB_HIP_CHECK(hipMemcpyAsync(mpPos, p->h.ptIO, sizeof(float) * 3 * p->h.nMP, hipMemcpyDeviceToHost, st));

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "common.h"
+#include "internal_abi.h"
 #include "libm_f32.h"
 #include "wave.h"
 #include "kb8.h"
@@ -28,10 +29,7 @@ using namespace morb;
 
 struct morb_matcher;  // defined in matcher.hip
 extern "C" {
-int morb_matcher_device(const morb_matcher*);
 void* morb_matcher_stream(const morb_matcher*);
-int morb_matcher_workspace(morb_matcher*, int which, size_t bytes, void** out);
-int morb_matcher_const(morb_matcher*, int slot, const void* host, size_t bytes, void** d_out, void* stream);
 }
 
 namespace {
@@ -1577,8 +1575,6 @@ int morb_search_for_initialization_batch(morb_matcher* m, const morb_frame_param
 
 
 extern "C" {
-int morb_bow_sort_images(morb_matcher* m, int nimg, const int* d_node, const int* d_count, int cap, unsigned long long** d_sorted,
-                         void* stream);
 
 // F12 = K1^-T [t12]x R12 K2^-1 in float, products left to right (Pinhole.cpp:118-122)
 static void fundamental_f12(const float* K1, const float* K2, const float* R12, const float* t12, float* F12) {

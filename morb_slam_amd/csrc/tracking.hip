@@ -13,12 +13,12 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "internal_abi.h"
 
 using namespace morb;
 
 struct morb_matcher;
 extern "C" {
-int morb_matcher_device(const morb_matcher*);
 void* morb_matcher_stream(const morb_matcher*);
 }
 

@@ -312,6 +312,12 @@ def test_c_abi_exports_every_declared_symbol():
     L = C.CDLL(capi.LIB_PATH)   # loads without a GPU; no compute call is made here
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, f"declared in include/*.h but not exported: {missing}"
+    # ... and nothing else: no developer hooks, no cross-unit helpers in the product library's dynamic symbol table
+    import subprocess
+    exported = {ln.split()[-1] for ln in subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout.splitlines()
+                if ln.split() and ln.split()[-1].startswith("morb_")}
+    extra = sorted(exported - set(names))
+    assert not extra, f"exported by libmorb_hip.so but not declared in include/*.h: {extra}"
 
 
 def test_product_path_has_no_cpu_fallback():
