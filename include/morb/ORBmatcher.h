@@ -175,8 +175,11 @@ class ORBmatcher {
   // int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist)
   // (ORBmatcher.h:56-58, ORBmatcher.cc:1735-1842; relocalisation).  alreadyFound[i] != 0 <=> sAlreadyFound.count(pKF's map point i);
   // Cur.hasMapPoint[i2] = CurrentFrame.mvpMapPoints[i2] != NULL.  matchCur[i2] = keyframe feature whose map point goes to current feature i2.
+  // curCam8 / curNLeft: CurrentFrame is a KannalaBrandt8 rig frame (rows hold left | right features): projection with mpCamera (the left
+  // camera: fx fy cx cy k0..k3), search among the left features only — the reference has no rig branch in this member, this is what its
+  // code does on such a frame (GetFeaturesInArea's bRight defaults to false; morb_search_by_projection_kf_rig_batch).
   int SearchByProjection(const FrameView& Cur, const KeyFrameView& KF, const std::vector<uint8_t>& alreadyFound, std::vector<int>& matchCur,
-                         float th, int ORBdist) {
+                         float th, int ORBdist, const float* curCam8 = nullptr, int curNLeft = -1) {
     const int N = Cur.N, NK = KF.N;
     if (N <= 0 || NK <= 0) { matchCur.assign(N > 0 ? N : 0, -1); return 0; }
     morb_adapter::StreamScope scope_(morb_matcher_stream(h_));   // uploads, kernels, downloads: the handle's stream, never the null stream
@@ -192,6 +195,13 @@ class ORBmatcher {
     up_row(s.f32[3], KF.mpWorldPos, NK, cap, 3); up_row(s.f32[4], KF.mpMaxDistance, NK, cap, 1); up_row(s.f32[5], KF.mpMinDistance, NK, cap, 1);
     up_row(s.u8[4], KF.mpDescriptor, NK, cap, 32);
     init_match(s.i32[5], matchCur, N, cap);
+    if (curCam8 && curNLeft >= 0) {
+      s.i32[6].assign(&curNLeft, 1);
+      check(morb_search_by_projection_kf_rig_batch(h_, &Cur.params, curCam8, 1, s.i32[2].get(), s.i32[3].get(), s.i32[6].get(), cap, s.i32[0].get(),
+                                                   s.kp[0].get(), s.u8[0].get(), s.u8[2].get(), s.f32[1].get(), s.f32[2].get(), s.u8[3].get(),
+                                                   s.f32[3].get(), s.f32[4].get(), s.f32[5].get(), s.u8[4].get(), th, ORBdist,
+                                                   mbCheckOrientation ? 1 : 0, s.i32[5].get(), s.i32[4].get(), nullptr));
+    } else
     check(morb_search_by_projection_kf_batch(h_, &Cur.params, 1, s.i32[2].get(), s.i32[3].get(), cap, s.i32[0].get(), s.kp[0].get(), s.u8[0].get(),
                                              s.u8[2].get(), s.f32[1].get(), s.f32[2].get(), s.u8[3].get(), s.f32[3].get(), s.f32[4].get(), s.f32[5].get(),
                                              s.u8[4].get(), th, ORBdist, mbCheckOrientation ? 1 : 0, s.i32[5].get(), s.i32[4].get(), nullptr));

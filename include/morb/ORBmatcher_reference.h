@@ -20,7 +20,6 @@
 
 namespace ORB_SLAM3 {
 
-#define MORB_NO_RIG(cond, what) do { if (cond) throw std::runtime_error(what ": not built for a KannalaBrandt8 rig (the reference has no rig branch in this member; ORBmatcher_reference.h)"); } while (0)
 
 // static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b)  ORBmatcher.cc:1880-1894
 template <class Mat, class>
@@ -141,7 +140,6 @@ int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame
 // int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist)  ORBmatcher.cc:1735-1842 (relocalisation)
 template <class FrameT, class KF, class MP>
 int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, KF* pKF, const std::set<MP*>& sAlreadyFound, const float th, const int ORBdist) {
-  MORB_NO_RIG(CurrentFrame.Nleft != -1, "SearchByProjection(Frame, KeyFrame)");
   morb_glue::Store<FrameView> cur;
   morb_glue::Store<KeyFrameView> kf;
   morb_glue::frame_view(cur, CurrentFrame, morb_glue::kAny);        // :1790: CurrentFrame.mvpMapPoints[i2] non-NULL blocks the feature
@@ -150,7 +148,13 @@ int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, KF* pKF, const std::set
   std::vector<uint8_t> found(kf.v.N, 0);
   for (int i = 0; i < kf.v.N && i < (int)vpMPs.size(); ++i) found[i] = (vpMPs[i] && sAlreadyFound.count(vpMPs[i])) ? 1 : 0;
   std::vector<int> matchCur(CurrentFrame.N, -1);
-  const int n = SearchByProjection(static_cast<const FrameView&>(cur.v), kf.v, found, matchCur, th, ORBdist);
+  // a KannalaBrandt8 rig frame: the reference (no rig branch here) projects with mpCamera and searches the left grid (include/morb_hip.h:
+  // morb_search_by_projection_kf_rig_batch, which also says what replaces the reference's out-of-bounds mvKeysUn[i] of a right keyframe feature)
+  float camL[8];
+  const bool rig = CurrentFrame.Nleft != -1;
+  if (rig) morb_glue::cam8(CurrentFrame.mpCamera, camL);
+  const int n = SearchByProjection(static_cast<const FrameView&>(cur.v), kf.v, found, matchCur, th, ORBdist, rig ? camL : nullptr,
+                                   rig ? (int)CurrentFrame.Nleft : -1);
   for (int i = 0; i < CurrentFrame.N; ++i)
     if (matchCur[i] >= 0) CurrentFrame.mvpMapPoints[i] = vpMPs[matchCur[i]];   // :1809
   return n;
@@ -248,15 +252,17 @@ int ORBmatcher::SearchByBoW(KF* pKF1, KF* pKF2, std::vector<MP*>& vpMatches12) {
 // int SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f>& vbPrevMatched, vector<int>& vnMatches12, windowSize)  ORBmatcher.cc:603-700
 template <class FrameT, class Pt, class>
 int ORBmatcher::SearchForInitialization(FrameT& F1, FrameT& F2, std::vector<Pt>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize) {
-  MORB_NO_RIG(F1.Nleft != -1 || F2.Nleft != -1, "SearchForInitialization");
+  // (rig frames: the member has no rig branch — it walks F1.mvKeysUn (the left keypoints), F2's left grid and descriptor rows [0, Nleft): the
+  // left-camera search, which is what the views below hold)
+  const int n1 = F1.Nleft != -1 ? (int)F1.Nleft : (int)F1.N, n2 = F2.Nleft != -1 ? (int)F2.Nleft : (int)F2.N;
   morb_glue::Store<FrameView> a, b;
-  morb_glue::fill_keys(a, F1, F1.N, -1); morb_glue::fill_keys(b, F2, F2.N, -1);
+  morb_glue::fill_keys(a, F1, n1, F1.Nleft); morb_glue::fill_keys(b, F2, n2, F2.Nleft);
   morb_glue::fill_params(a.v.params, F1, FrameT::mfGridElementWidthInv, FrameT::mfGridElementHeightInv);
   b.v.params = a.v.params;
-  std::vector<float> prev((size_t)F1.N * 2, 0.f);
-  for (int i = 0; i < F1.N && i < (int)vbPrevMatched.size(); ++i) { prev[2 * i] = vbPrevMatched[i].x; prev[2 * i + 1] = vbPrevMatched[i].y; }
+  std::vector<float> prev((size_t)n1 * 2, 0.f);
+  for (int i = 0; i < n1 && i < (int)vbPrevMatched.size(); ++i) { prev[2 * i] = vbPrevMatched[i].x; prev[2 * i + 1] = vbPrevMatched[i].y; }
   const int n = SearchForInitialization(static_cast<const FrameView&>(a.v), static_cast<const FrameView&>(b.v), prev, vnMatches12, windowSize);
-  for (int i = 0; i < F1.N && i < (int)vbPrevMatched.size(); ++i) { vbPrevMatched[i].x = prev[2 * i]; vbPrevMatched[i].y = prev[2 * i + 1]; }   // :696-698
+  for (int i = 0; i < n1 && i < (int)vbPrevMatched.size(); ++i) { vbPrevMatched[i].x = prev[2 * i]; vbPrevMatched[i].y = prev[2 * i + 1]; }   // :696-698
   return n;
 }
 
@@ -404,5 +410,4 @@ int ORBmatcher::Fuse(KF* pKF, Sim3& Scw, const std::vector<MP*>& vpPoints, float
   return nFused;
 }
 
-#undef MORB_NO_RIG
 }  // namespace ORB_SLAM3

@@ -386,6 +386,20 @@ int morb_search_by_projection_kf_batch(morb_matcher*, const morb_frame_params*, 
                                        const float* d_minDist, const uint8_t* d_mpDesc, float th, int ORBdist, int checkOri,
                                        int* d_matchCur, int* d_nmatches, void* stream);
 
+/* The same member when CurrentFrame is a KannalaBrandt8 rig frame (CurrentFrame.Nleft != -1).  The reference has no rig branch here: it
+ * projects with CurrentFrame.mpCamera (cam8 = the LEFT camera's fx fy cx cy k0..k3, host pointer) and GetFeaturesInArea's bRight
+ * defaults to false, so only the current frame's left features [0, d_nLeftCur[f]) are searched; rows hold left | right features.
+ * Rotation check: the reference reads pKF->mvKeysUn[i] for every keyframe map point i, which is out of bounds for the keyframe's RIGHT
+ * features (mvKeysUn holds the NLeft left keypoints); here feature i's own keypoint is used — mvKeysRight[i - NLeft] for a right
+ * feature — i.e. row entry i of the keyframe image. */
+int morb_search_by_projection_kf_rig_batch(morb_matcher*, const morb_frame_params*, const float* cam8, int nframes, const int* d_curImg,
+                                           const int* d_kfImg, const int* d_nLeftCur, int cap, const int* d_count,
+                                           const morb_keypoint* d_kps, const uint8_t* d_desc, const uint8_t* d_curHasMP, const float* d_Tcw,
+                                           const float* d_Ow, const uint8_t* d_kfValid, const float* d_Xw, const float* d_maxDist,
+                                           const float* d_minDist, const uint8_t* d_mpDesc, float th, int ORBdist, int checkOri,
+                                           int* d_matchCur, int* d_nmatches, void* stream);
+
+
 /* int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, vbPrevMatched, vnMatches12, windowSize)
  * ORBmatcher.h:80-82, ORBmatcher.cc:603-700 (monocular initialisation).  Pair p = (image d_img1[p], image d_img2[p]);
  * d_prevMatched [npairs][cap][2] in/out (vbPrevMatched); d_matches12 [npairs][cap] = vnMatches12. */

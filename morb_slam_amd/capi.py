@@ -135,6 +135,7 @@ def lib():
         L.morb_search_by_projection_last_batch.argtypes = [vp, PP, i, vp, vp, i] + [vp] * 10 + [f, vp, vp, i, vp, vp, vp]
         L.morb_search_by_projection_last_fisheye_batch.argtypes = [vp, PP, vp, vp, i, vp, vp, vp, i] + [vp] * 9 + [f, vp, vp, i, vp, vp, vp]
         L.morb_search_by_projection_kf_batch.argtypes = [vp, PP, i, vp, vp, i] + [vp] * 11 + [f, i, i, vp, vp, vp]
+        L.morb_search_by_projection_kf_rig_batch.argtypes = [vp, PP, vp, i, vp, vp, vp, i] + [vp] * 11 + [f, i, i, vp, vp, vp]
         L.morb_search_for_initialization_batch.argtypes = [vp, PP, i, vp, vp, i, vp, vp, vp, vp, i, f, i, vp, vp, vp]
         L.morb_search_for_triangulation_batch.argtypes = [vp, PP, i, vp, vp, i, i] + [vp] * 9 + [i, i, i, vp, vp, vp]
         L.morb_search_for_triangulation_fisheye_batch.argtypes = [vp, PP, i, vp, vp, vp, vp, i, i] + [vp] * 8 + [i, i, i, vp, vp, vp]

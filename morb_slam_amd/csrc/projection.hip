@@ -1135,7 +1135,10 @@ __global__ __launch_bounds__(256) void k_prep_kf(morb_frame_params P, int cap, c
                                                  const uint8_t* __restrict__ kfValid, const float* __restrict__ Xw,
                                                  const float* __restrict__ maxDist, const float* __restrict__ minDist,
                                                  const float* __restrict__ Tcw, const float* __restrict__ Ow, float th,
-                                                 const float* __restrict__ ratioThr, Query* __restrict__ qs) {
+                                                 const float* __restrict__ ratioThr, Query* __restrict__ qs,
+                                                 // KannalaBrandt8 rig frame (NULL: pinhole): mpCamera's fx fy cx cy k0..k3, and the search looks among the
+                                                 // current frame's LEFT features [0, nLeftCur) only (GetFeaturesInArea's bRight = false)
+                                                 const float* __restrict__ kb8, const int* __restrict__ nLeftCur) {
   const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
   if (i >= cap) return;
   const size_t o = (size_t)f * cap + i;
@@ -1148,7 +1151,9 @@ __global__ __launch_bounds__(256) void k_prep_kf(morb_frame_params P, int cap, c
     float x3Dc[3];
     q_rotate_f(T, X, x3Dc);
     x3Dc[0] += T[4]; x3Dc[1] += T[5]; x3Dc[2] += T[6];
-    const float u = P.fx * x3Dc[0] / x3Dc[2] + P.cx, v = P.fy * x3Dc[1] / x3Dc[2] + P.cy;
+    float u, v;
+    if (kb8) kb8_project_dev(kb8, x3Dc, u, v);
+    else { u = P.fx * x3Dc[0] / x3Dc[2] + P.cx; v = P.fy * x3Dc[1] / x3Dc[2] + P.cy; }
     const float PO[3] = {X[0] - Ow[3 * f], X[1] - Ow[3 * f + 1], X[2] - Ow[3 * f + 2]};
     const float dist3D = sqrtf(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
     const float maxDistance = 1.2f * maxDist[o], minDistance = 0.8f * minDist[o];
@@ -1158,6 +1163,7 @@ __global__ __launch_bounds__(256) void k_prep_kf(morb_frame_params P, int cap, c
       while (n < P.nlevels - 1 && ratio > ratioThr[n]) ++n;
       q.valid = 1; q.x = u; q.y = v; q.r = th * P.scaleFactors[n];
       q.minLevel = n - 1; q.maxLevel = n + 1; q.angle = kps[(size_t)img * cap + i].angle;
+      if (nLeftCur) { q.jLo = 0; q.jHi = nLeftCur[f]; q.valid = q.jHi > 0 ? 1 : 0; }
     }
   }
   qs[o] = q;
@@ -1371,9 +1377,9 @@ static int window_search(morb_matcher* m, const morb_frame_params* P, int mode, 
                          const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc, const float* d_uRight,
                          const uint8_t* d_blocked, float nnratio, int thAccept, int checkOri, int* d_match, int* d_nmatches,
                          float* d_prevMatched, hipStream_t st, const int* d_l2r = nullptr, const int* d_r2l = nullptr,
-                         const int* d_nLeft = nullptr) {
+                         const int* d_nLeft = nullptr, bool ranged = false) {   // ranged: queries carry a feature-index range (jLo / jHi)
   void *cand = nullptr, *cnt = nullptr, *ej = nullptr, *eb = nullptr;
-  if ((mode == 0 || mode == 1) && cap <= 65535 && qCap <= 65535 && search_lds_bytes(cap, qCap, false) <= 150 * 1024 && !getenv("MORB_SERIAL_RESOLVE")) {
+  if ((mode == 0 || mode == 1) && !ranged && cap <= 65535 && qCap <= 65535 && search_lds_bytes(cap, qCap, false) <= 150 * 1024 && !getenv("MORB_SERIAL_RESOLVE")) {
     // one launch, one workgroup per frame: grid in LDS, candidate lists, blocked-feature fixed point (k_search)
     const int withDesc = search_lds_bytes(cap, qCap, true) <= 150 * 1024 ? 1 : 0;
     const size_t lds = search_lds_bytes(cap, qCap, withDesc != 0);
@@ -1522,29 +1528,53 @@ int morb_search_by_projection_last_fisheye_batch(morb_matcher* m, const morb_fra
                        d_count, d_kps, d_desc, nullptr, d_curBlocked, 0.f, TH_HIGH, checkOri, d_matchCur, d_nmatches, nullptr, st);
 }
 
+static int search_by_projection_kf_impl(morb_matcher* m, const morb_frame_params* P, const float* cam8, const int* d_nLeftCur, int nframes,
+                                        const int* d_curImg, const int* d_kfImg, int cap, const int* d_count, const morb_keypoint* d_kps,
+                                        const uint8_t* d_desc, const uint8_t* d_curHasMP, const float* d_Tcw, const float* d_Ow,
+                                        const uint8_t* d_kfValid, const float* d_Xw, const float* d_maxDist,
+                                        const float* d_minDist, const uint8_t* d_mpDesc, float th, int ORBdist, int checkOri,
+                                        int* d_matchCur, int* d_nmatches, void* stream) {
+  MORB_REQUIRE(m && P && d_curImg && d_kfImg && d_count && d_kps && d_desc && d_Tcw && d_Ow && d_kfValid && d_Xw && d_maxDist &&
+                   d_minDist && d_mpDesc && d_matchCur && d_nmatches, MORB_ERR_INVALID, "NULL argument");
+  MORB_REQUIRE(nframes > 0 && cap > 0 && cap <= 65535, MORB_ERR_INVALID, "bad sizes");
+  MORB_HIP_CHECK(hipSetDevice(morb_matcher_device(m)));
+  hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
+  float thr[24] = {0};   // (same table as isInFrustum's, so the two share constant slots 0 / 1)
+  level_thresholds(P, thr);
+  for (int n = 0; n < 8; ++n) thr[16 + n] = cam8 ? cam8[n] : 0.f;
+  void *d_thr = nullptr, *qs = nullptr, *nq = nullptr;
+  int rc = morb_matcher_const(m, cam8 ? 1 : 0, thr, sizeof thr, &d_thr, st);
+  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 5, sizeof(Query) * (size_t)nframes * cap, &qs);
+  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 6, sizeof(int) * (size_t)nframes, &nq);
+  if (rc != MORB_OK) return rc;
+  hipLaunchKernelGGL(k_prep_kf, dim3(div_up(cap, 256), nframes), dim3(256), 0, st, *P, cap, d_count, d_kfImg, d_kps, d_kfValid, d_Xw,
+                     d_maxDist, d_minDist, d_Tcw, d_Ow, th, (const float*)d_thr, (Query*)qs, cam8 ? (const float*)d_thr + 16 : (const float*)nullptr,
+                     d_nLeftCur);
+  hipLaunchKernelGGL(k_gather_counts, dim3(div_up(nframes, 256)), dim3(256), 0, st, d_count, d_kfImg, nframes, (int*)nq);
+  return window_search(m, P, 0, nframes, cap, (const int*)nq, (const Query*)qs, d_mpDesc, nullptr, d_curImg, cap, d_count, d_kps,
+                       d_desc, nullptr, d_curHasMP, 0.f, ORBdist, checkOri, d_matchCur, d_nmatches, nullptr, st, nullptr, nullptr, nullptr,
+                       d_nLeftCur != nullptr);
+}
+
 int morb_search_by_projection_kf_batch(morb_matcher* m, const morb_frame_params* P, int nframes, const int* d_curImg,
                                        const int* d_kfImg, int cap, const int* d_count, const morb_keypoint* d_kps,
                                        const uint8_t* d_desc, const uint8_t* d_curHasMP, const float* d_Tcw, const float* d_Ow,
                                        const uint8_t* d_kfValid, const float* d_Xw, const float* d_maxDist,
                                        const float* d_minDist, const uint8_t* d_mpDesc, float th, int ORBdist, int checkOri,
                                        int* d_matchCur, int* d_nmatches, void* stream) {
-  MORB_REQUIRE(m && P && d_curImg && d_kfImg && d_count && d_kps && d_desc && d_Tcw && d_Ow && d_kfValid && d_Xw && d_maxDist &&
-                   d_minDist && d_mpDesc && d_matchCur && d_nmatches, MORB_ERR_INVALID, "NULL argument");
-  MORB_REQUIRE(nframes > 0 && cap > 0 && cap <= 65535, MORB_ERR_INVALID, "bad sizes");
-  MORB_HIP_CHECK(hipSetDevice(morb_matcher_device(m)));
-  hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
-  float thr[24] = {0};   // (same table as isInFrustum's, so the two share constant slot 0)
-  level_thresholds(P, thr);
-  void *d_thr = nullptr, *qs = nullptr, *nq = nullptr;
-  int rc = morb_matcher_const(m, 0, thr, sizeof thr, &d_thr, st);
-  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 5, sizeof(Query) * (size_t)nframes * cap, &qs);
-  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 6, sizeof(int) * (size_t)nframes, &nq);
-  if (rc != MORB_OK) return rc;
-  hipLaunchKernelGGL(k_prep_kf, dim3(div_up(cap, 256), nframes), dim3(256), 0, st, *P, cap, d_count, d_kfImg, d_kps, d_kfValid, d_Xw,
-                     d_maxDist, d_minDist, d_Tcw, d_Ow, th, (const float*)d_thr, (Query*)qs);
-  hipLaunchKernelGGL(k_gather_counts, dim3(div_up(nframes, 256)), dim3(256), 0, st, d_count, d_kfImg, nframes, (int*)nq);
-  return window_search(m, P, 0, nframes, cap, (const int*)nq, (const Query*)qs, d_mpDesc, nullptr, d_curImg, cap, d_count, d_kps,
-                       d_desc, nullptr, d_curHasMP, 0.f, ORBdist, checkOri, d_matchCur, d_nmatches, nullptr, st);
+  return search_by_projection_kf_impl(m, P, nullptr, nullptr, nframes, d_curImg, d_kfImg, cap, d_count, d_kps, d_desc, d_curHasMP, d_Tcw, d_Ow,
+                                      d_kfValid, d_Xw, d_maxDist, d_minDist, d_mpDesc, th, ORBdist, checkOri, d_matchCur, d_nmatches, stream);
+}
+
+int morb_search_by_projection_kf_rig_batch(morb_matcher* m, const morb_frame_params* P, const float* cam8, int nframes, const int* d_curImg,
+                                           const int* d_kfImg, const int* d_nLeftCur, int cap, const int* d_count,
+                                           const morb_keypoint* d_kps, const uint8_t* d_desc, const uint8_t* d_curHasMP, const float* d_Tcw,
+                                           const float* d_Ow, const uint8_t* d_kfValid, const float* d_Xw, const float* d_maxDist,
+                                           const float* d_minDist, const uint8_t* d_mpDesc, float th, int ORBdist, int checkOri,
+                                           int* d_matchCur, int* d_nmatches, void* stream) {
+  MORB_REQUIRE(cam8 && d_nLeftCur, MORB_ERR_INVALID, "NULL rig argument");
+  return search_by_projection_kf_impl(m, P, cam8, d_nLeftCur, nframes, d_curImg, d_kfImg, cap, d_count, d_kps, d_desc, d_curHasMP, d_Tcw, d_Ow,
+                                      d_kfValid, d_Xw, d_maxDist, d_minDist, d_mpDesc, th, ORBdist, checkOri, d_matchCur, d_nmatches, stream);
 }
 
 int morb_search_for_initialization_batch(morb_matcher* m, const morb_frame_params* P, int npairs, const int* d_img1,

@@ -380,13 +380,21 @@ class ORBmatcher:
         return m12, nm
 
     def SearchByProjectionKeyFrame(self, params, curImg, kfImg, kps, desc, count, curHasMP, Tcw, Ow, kfValid, Xw, maxDist, minDist,
-                                   mpDesc, th, ORBdist, matchCur=None, stream=None):
-        """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (relocalisation)."""
+                                   mpDesc, th, ORBdist, matchCur=None, stream=None, cam8=None, nLeftCur=None):
+        """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (relocalisation).  cam8 + nLeftCur (i32 [F], device): the current
+        frames are KannalaBrandt8 rig frames — left-camera projection, left features only."""
         import torch
         F, cap = curImg.shape[0], kps.shape[1]
         if matchCur is None:
             matchCur = torch.full((F, cap), -1, dtype=torch.int32, device=kps.device)
         nm = torch.zeros((F,), dtype=torch.int32, device=kps.device)
+        if cam8 is not None:
+            cam = np.ascontiguousarray(cam8, np.float32)
+            check(self._L.morb_search_by_projection_kf_rig_batch(
+                self._h, C.byref(params), ptr(cam), F, ptr(curImg), ptr(kfImg), ptr(nLeftCur), cap, ptr(count), ptr(kps), ptr(desc), ptr(curHasMP),
+                ptr(Tcw), ptr(Ow), ptr(kfValid), ptr(Xw), ptr(maxDist), ptr(minDist), ptr(mpDesc), float(th), int(ORBdist),
+                1 if self.mbCheckOrientation else 0, ptr(matchCur), ptr(nm), self._st(stream)))
+            return matchCur, nm
         check(self._L.morb_search_by_projection_kf_batch(
             self._h, C.byref(params), F, ptr(curImg), ptr(kfImg), cap, ptr(count), ptr(kps), ptr(desc), ptr(curHasMP), ptr(Tcw), ptr(Ow),
             ptr(kfValid), ptr(Xw), ptr(maxDist), ptr(minDist), ptr(mpDesc), float(th), int(ORBdist),

@@ -105,6 +105,9 @@ int orc_search_by_projection_last_fisheye(const orc_frame* Cur, int NleftCur, co
 int orc_search_by_projection_kf(const orc_frame* Cur, const uint8_t* curHasMP, const float* Tcw7, const float* Ow, int nKF,
                                 const orc_keypoint* kfKpsUn, const uint8_t* kfValid, const float* Xw, const float* maxDist,
                                 const float* minDist, const uint8_t* mpDesc, float th, int ORBdist, int checkOri, int* matchCur);
+int orc_search_by_projection_kf_rig(const orc_frame* CurLeft, const float* cam8, const uint8_t* curHasMP, const float* Tcw7, const float* Ow, int nKF,
+                                    const orc_keypoint* kfKps, const uint8_t* kfValid, const float* Xw, const float* maxDist,
+                                    const float* minDist, const uint8_t* mpDesc, float th, int ORBdist, int checkOri, int* matchCur);
 int orc_search_for_initialization(int n1, const orc_keypoint* kps1, const uint8_t* desc1, const orc_frame* F2, float* prevMatched,
                                   int windowSize, float nnratio, int checkOri, int* matches12);
 void orc_fundamental_f12(const float* K1, const float* K2, const float* R12, const float* t12, float* F12);

@@ -469,10 +469,12 @@ int SearchByProjectionLastFisheye(const orc_frame& Cur, int NleftCur, const floa
 
 // ---- ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist) (:1735-1842) ----
 // kfValid[i] != 0 <=> vpMPs[i] && !isBad() && !sAlreadyFound.count(pMP); curHasMP[i2] != 0 <=> CurrentFrame.mvpMapPoints[i2].
+// cam8 != NULL: CurrentFrame is a KannalaBrandt8 rig frame — Cur holds its LEFT features only (what mGrid holds and GetFeaturesInArea's
+// default bRight = false searches), the projection is mpCamera's; kfKpsUn[i] for a right keyframe feature: see include/morb_hip.h
 int SearchByProjectionKF(const orc_frame& Cur, const uint8_t* curHasMP, const float* Tcw7, const float* Ow, int nKF,
                          const KeyPoint* kfKpsUn, const uint8_t* kfValid, const float* Xw, const float* mfMaxDistance,
                          const float* mfMinDistance, const uint8_t* mpDesc, float th, int ORBdist, bool mbCheckOrientation,
-                         int* matchCur) {
+                         int* matchCur, const float* cam8 = nullptr) {
   Grid g;
   AssignFeaturesToGrid(Cur, g);
   const KeyPoint* kc = (const KeyPoint*)Cur.kpsUn;
@@ -486,8 +488,9 @@ int SearchByProjectionKF(const orc_frame& Cur, const uint8_t* curHasMP, const fl
     float x3Dc[3];
     rotateF(Tcw7, x3Dw, x3Dc);
     x3Dc[0] += Tcw7[4]; x3Dc[1] += Tcw7[5]; x3Dc[2] += Tcw7[6];
-    const float u = Cur.fx * x3Dc[0] / x3Dc[2] + Cur.cx;
-    const float v = Cur.fy * x3Dc[1] / x3Dc[2] + Cur.cy;
+    float u = Cur.fx * x3Dc[0] / x3Dc[2] + Cur.cx;
+    float v = Cur.fy * x3Dc[1] / x3Dc[2] + Cur.cy;
+    if (cam8) { float uv[2]; orc_kb8_project_f(cam8, x3Dc, uv); u = uv[0]; v = uv[1]; }
     if (u < Cur.minX || u > Cur.maxX) continue;
     if (v < Cur.minY || v > Cur.maxY) continue;
     const float PO[3] = {x3Dw[0] - Ow[0], x3Dw[1] - Ow[1], x3Dw[2] - Ow[2]};
@@ -1147,6 +1150,12 @@ int orc_search_by_projection_kf(const orc_frame* Cur, const uint8_t* curHasMP, c
                                 const float* minDist, const uint8_t* mpDesc, float th, int ORBdist, int checkOri, int* matchCur) {
   return SearchByProjectionKF(*Cur, curHasMP, Tcw7, Ow, nKF, (const KeyPoint*)kfKpsUn, kfValid, Xw, maxDist, minDist, mpDesc, th,
                               ORBdist, checkOri != 0, matchCur);
+}
+int orc_search_by_projection_kf_rig(const orc_frame* CurLeft, const float* cam8, const uint8_t* curHasMP, const float* Tcw7, const float* Ow, int nKF,
+                                    const orc_keypoint* kfKps, const uint8_t* kfValid, const float* Xw, const float* maxDist,
+                                    const float* minDist, const uint8_t* mpDesc, float th, int ORBdist, int checkOri, int* matchCur) {
+  return SearchByProjectionKF(*CurLeft, curHasMP, Tcw7, Ow, nKF, (const KeyPoint*)kfKps, kfValid, Xw, maxDist, minDist, mpDesc, th,
+                              ORBdist, checkOri != 0, matchCur, cam8);
 }
 int orc_search_for_initialization(int n1, const orc_keypoint* kps1, const uint8_t* desc1, const orc_frame* F2, float* prevMatched,
                                   int windowSize, float nnratio, int checkOri, int* matches12) {

@@ -649,3 +649,16 @@ def discard_outliers(frameMP, outlier, mpHasObs, want_blocked=True, want_seen=Tr
     nm = L.orc_discard_outliers(len(fm), _p(fm), _p(ol), len(ho), _p(ho), None if blk is None else _p(blk),
                                 None if seen is None else _p(seen), C.byref(nmap))
     return nm, nmap.value, fm, blk, seen
+
+
+def search_by_projection_kf_rig(CurLeft, cam8, curHasMP, Tcw7, Ow, kfKps, kfValid, Xw, maxD, minD, mpDesc, th, ORBdist, checkOri):
+    """SearchByProjection(CurrentFrame, pKF, ...) with a KannalaBrandt8 rig CurrentFrame: CurLeft = OrcFrame of its LEFT features."""
+    L = lib()
+    L.orc_search_by_projection_kf_rig.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_int, C.c_int, C.c_void_p]
+    m = np.full(CurLeft.N, -1, np.int32)
+    a = [np.ascontiguousarray(x) for x in (np.asarray(cam8, np.float32), curHasMP.astype(np.uint8), np.asarray(Tcw7, np.float32), np.asarray(Ow, np.float32),
+                                           kfKps, kfValid.astype(np.uint8), np.asarray(Xw, np.float32), np.asarray(maxD, np.float32),
+                                           np.asarray(minD, np.float32), mpDesc)]
+    r = L.orc_search_by_projection_kf_rig(C.byref(CurLeft), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), len(kfKps), _p(a[4]), _p(a[5]), _p(a[6]), _p(a[7]),
+                                          _p(a[8]), _p(a[9]), th, int(ORBdist), int(checkOri), _p(m))
+    return r, m

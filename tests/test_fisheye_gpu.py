@@ -809,3 +809,68 @@ def test_local_ba_fisheye_oneshot_equals_the_three_step_form():
                                                   b["eInvSigma2"], b["camL"], b["camR"], b["Trl"])
     for x, y in zip(ref, one):
         np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+
+
+def test_search_by_projection_keyframe_with_a_rig_current_frame():
+    """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (relocalisation, ORBmatcher.cc:1735-1842) when CurrentFrame is a
+    KannalaBrandt8 rig frame: left-camera projection, left features only, a keyframe whose map points sit on left AND right features
+    (rotation check with the feature's own keypoint, include/morb_hip.h)."""
+    import torch
+    from morb_slam_amd import KP_DTYPE, ORBmatcher
+    from morb_slam_amd.synth import TUMVI_CAM_L, kb8_project, _quat_from_rotvec, _quat_rot
+    P, sf = _fisheye_params()
+    rng = np.random.default_rng(_OFF + 777)
+    Fn, M = 2, 600
+    cap = 900
+    nimg = 2 * Fn     # image 2 f = current rig frame (left | right), 2 f + 1 = the keyframe's features (left | right in one row)
+    kps = np.zeros((nimg, cap), KP_DTYPE); desc = rng.integers(0, 256, (nimg, cap, 32), dtype=np.uint8); cnt = np.zeros(nimg, np.int32)
+    nl = np.zeros(Fn, np.int32); Tcw = np.zeros((Fn, 7), np.float32); Ow = np.zeros((Fn, 3), np.float32)
+    valid = np.zeros((Fn, cap), np.uint8); Xw = np.zeros((Fn, cap, 3), np.float32); mpd = np.zeros((Fn, cap, 32), np.uint8)
+    maxD = np.ones((Fn, cap), np.float32); minD = np.ones((Fn, cap), np.float32); has = np.zeros((Fn, cap), np.uint8)
+    for f in range(Fn):
+        X = np.stack([rng.uniform(-3, 3, M), rng.uniform(-2.5, 2.5, M), rng.uniform(1, 8, M)], 1)
+        T = np.concatenate([_quat_from_rotvec(rng.normal(0, 0.02, 3)), rng.normal(0, 0.05, 3)])
+        Xc = np.array([_quat_rot(T[:4], x) + T[4:] for x in X])
+        uv = kb8_project(TUMVI_CAM_L, Xc)
+        octv = rng.integers(0, 8, M); ang = rng.uniform(0, 360, M)
+        ok = (uv > 8).all(1) & (uv < 504).all(1) & (rng.random(M) < 0.8)
+        idx = np.nonzero(ok)[0]
+        nL, nR = len(idx) + 120, 200
+        k = np.zeros(nL + nR, KP_DTYPE)
+        k["x"] = rng.uniform(5, 507, nL + nR); k["y"] = rng.uniform(5, 507, nL + nR); k["octave"] = rng.integers(0, 8, nL + nR)
+        k["angle"] = rng.uniform(0, 360, nL + nR); k["size"] = 31; k["class_id"] = -1
+        sel = rng.permutation(nL)[:len(idx)]            # the observed points land on LEFT features
+        k["x"][sel] = uv[idx, 0] + rng.normal(0, 1.0, len(idx)); k["y"][sel] = uv[idx, 1] + rng.normal(0, 1.0, len(idx))
+        k["octave"][sel] = np.clip(octv[idx] + rng.integers(-1, 2, len(idx)), 0, 7)
+        k["angle"][sel] = (ang[idx] + rng.choice([0.0, 0.0, 0.0, 90.0], len(idx)) + rng.normal(0, 3, len(idx))) % 360
+        pd = rng.integers(0, 256, (M, 32), dtype=np.uint8)
+        desc[2 * f, sel] = pd[idx] ^ np.packbits(rng.random((len(idx), 256)) < 0.06, axis=1)
+        kps[2 * f, :nL + nR] = k; cnt[2 * f] = nL + nR; nl[f] = nL
+        kk = np.zeros(M, KP_DTYPE); kk["octave"] = octv; kk["angle"] = ang; kk["size"] = 31     # keyframe feature i holds map point i
+        kps[2 * f + 1, :M] = kk; cnt[2 * f + 1] = M
+        Tcw[f] = T.astype(np.float32)
+        qc = T[:4] * np.array([-1, -1, -1, 1]); Ow[f] = _quat_rot(qc, -T[4:]).astype(np.float32)
+        valid[f, :M] = (rng.random(M) < 0.9); Xw[f, :M] = X.astype(np.float32); mpd[f, :M] = pd
+        d3 = np.linalg.norm(X - Ow[f], axis=1)
+        maxD[f, :M] = (d3 * 1.2 ** octv * rng.uniform(0.95, 1.15, M)).astype(np.float32); minD[f, :M] = (maxD[f, :M] / 1.2 ** 7)
+        has[f, :nL + nR] = rng.random(nL + nR) < 0.1
+    cu = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    dk = cu(kps.view(np.uint8).reshape(nimg, cap, 28))
+    cur = np.arange(0, nimg, 2, dtype=np.int32); kf = cur + 1
+    tot = 0
+    for th, orb, ori in ((10.0, 100, True), (3.0, 64, False)):
+        m = ORBmatcher(0.9, ori)
+        mc, nm = m.SearchByProjectionKeyFrame(P, cu(cur), cu(kf), dk, cu(desc), cu(cnt), cu(has), cu(Tcw), cu(Ow), cu(valid), cu(Xw), cu(maxD),
+                                              cu(minD), cu(mpd), th, orb, cam8=TUMVI_CAM_L, nLeftCur=cu(nl))
+        torch.cuda.synchronize()
+        mc, nm = mc.cpu().numpy(), nm.cpu().numpy()
+        for f in range(Fn):
+            nL = int(nl[f]); N = int(cnt[2 * f])
+            Fo = O.make_frame(P, kps[2 * f, :nL], desc[2 * f, :nL], None)
+            r, me = O.search_by_projection_kf_rig(Fo, TUMVI_CAM_L, has[f, :nL], Tcw[f], Ow[f], kps[2 * f + 1, :M], valid[f, :M], Xw[f, :M],
+                                                  maxD[f, :M], minD[f, :M], mpd[f, :M], th, orb, ori)
+            assert int(nm[f]) == r, (th, f, int(nm[f]), r)
+            np.testing.assert_array_equal(mc[f, :nL], me)
+            assert (mc[f, nL:N] == -1).all()          # right features are never searched
+            tot += r
+    assert tot > 400
