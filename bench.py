@@ -664,20 +664,36 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    if fe.exch is not None:
+        fe.exch.prime(dev)      # communicator + one dummy exchange BEFORE any step: RCCL builds it lazily, and --warmup 0 is a legal request
     for _ in range(args.warmup):
         step()
     for e in exts:
         e.set_profiling(True)   # stage-boundary HIP events on the launch stream; no host sync inside the timed region
     sync_all()
+    if fe.exch is not None:
+        fe.drain_exchange_ms(); fe.exchange_ms = []       # from here on: HIP events around every step's pack -> transfer -> unpack
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync_streams()
     dt = time.perf_counter() - t0
+    multi = None
     if dist is not None:
+        own = dt
+        xms = fe.drain_exchange_ms() or [0.0]
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # per-rank figures (never `value`): the spread of the ranks' own step times and of their exchange times, so that a multi-GPU run shows
+        # whether xGMI time or compute sets the step
+        v = torch.tensor([own / args.steps * 1e3, -own / args.steps * 1e3, float(np.mean(xms)), -float(np.mean(xms)), float(np.max(xms))],
+                         dtype=torch.float64, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        multi = {"rank_ms_per_step": {"min": -float(v[1]), "max": float(v[0])},
+                 "exchange_ms_per_step": {"min_over_ranks_of_mean": -float(v[3]), "max_over_ranks_of_mean": float(v[2]), "max_single": float(v[4]),
+                                          "what": "HIP events on the exchange stream around slab pack -> transfer -> unpack (runs beside the next step's extraction)"},
+                 "exchange": args.exchange, "backend": dist.get_backend()}
         dist.barrier()
     # per-stage ms per extract call (= per step), averaged over the handles of the buffer sets
     per_set = [e.stage_ms() for e in exts]
@@ -892,6 +908,8 @@ def main():
                                for k in ("pyramid", "blur", "fast")},
             "extract_stage_ms_per_step": stages,
         }
+        if multi is not None:
+            line["multi_gpu"] = multi
         if verified is not None:
             line.update(verified_frames=verified["verified_frames"], verified=verified)
         if sustained is not None:

@@ -30,7 +30,9 @@ class BufferSet:
         self.match_out = None
         self.pool = None          # (kps, desc, count, node) SearchByBoW read: the set's own arrays, or [own; received] slabs
         self.ext_done, self.stereo_done, self.bow_done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        self.exch_t0, self.exch_t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # around pack -> transfer -> unpack
         self.used = False
+        self.exch_timed = False
         self.ext = None
 
 
@@ -96,6 +98,7 @@ class StereoFrontEnd:
         self.stagger = bool(stagger) and self.estreams[0] is not self.estreams[-1]
         self.pending = None
         self.last = None          # the buffer set of the most recent step
+        self.exchange_ms = None   # set to a list by the caller: HIP-event time of every COMPLETED exchange (pack -> transfer -> unpack on bstream)
 
     def close(self):
         for e in self.exts:
@@ -158,10 +161,15 @@ class StereoFrontEnd:
             S.pool = (kps, desc, S.cnt_left, S.bow_out[1])
         else:
             with torch.cuda.stream(bstream):      # the transfer is ordered after the kernels on this stream
+                if self.exchange_ms is not None and S.exch_timed and S.exch_t1.query():   # the set's previous exchange (two steps ago), if it has finished
+                    self.exchange_ms.append(S.exch_t0.elapsed_time(S.exch_t1))
+                S.exch_t0.record(bstream)
                 if getattr(self.exch, "matcher", None) is not None:   # left images only, gathered into ONE slab by morb_feature_slab_pack
                     pk, pd, pc, pn = self.exch.exchange(kps, desc, cnt, S.bow_out[1], rows=self.left_rows)
                 else:
                     pk, pd, pc, pn = self.exch.exchange(kps[0::2], desc[0::2], cnt[0::2], S.bow_out[1][0::2])
+                S.exch_t1.record(bstream)
+                S.exch_timed = True
             S.pool = (pk, pd, pc, pn)
         pk, pd, pc, pn = S.pool
         S.match_out = self.bmatcher.SearchByBoW(self.kf_img, self.f_img, pk, pd, pn, pc, self.has_mp, out=S.match_out, stream=bs)
@@ -172,6 +180,14 @@ class StereoFrontEnd:
         if self.pending is not None:
             self.run_matchers(self.pending)
             self.pending = None
+
+    def drain_exchange_ms(self):
+        """After sync(): the exchanges still held by the buffer sets' events (the last NSET steps)."""
+        if self.exchange_ms is not None:
+            for S in self.sets:
+                if S.exch_timed:
+                    self.exchange_ms.append(S.exch_t0.elapsed_time(S.exch_t1)); S.exch_timed = False
+        return self.exchange_ms
 
     def sync(self):
         self.flush_matchers()   # (every queued step's matchers lie inside the region the caller is closing)

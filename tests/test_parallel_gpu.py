@@ -19,9 +19,12 @@ def _free_port():
 
 # 640 x 480 / 600 features / 6 frames through every transport; and BASELINE configs[3]'s size (1920 x 1080 / 4000 features, 4 frames) through the
 # two the bench offers (--exchange ring | allgather): the exchanged 4000-feature slabs must give the tables of the world-1 run
-@pytest.mark.parametrize("dims,total,exchange", [((640, 480, 600), 6, "ring"), ((640, 480, 600), 6, "ring4"), ((640, 480, 600), 6, "allgather"),
-                                                 ((1920, 1080, 4000), 4, "ring"), ((1920, 1080, 4000), 4, "allgather")])
-def test_two_ranks_match_one_rank(tmp_path, dims, total, exchange):
+# round 5: EIGHT ranks (sharing GPU 0) at configs[3]'s size, two slots per rank: the shape of the driver's 8-GPU run, and the only one in which rank 0's
+# second frame takes its predecessor from the LAST rank's previous slot (the ring's wrap) on device data
+@pytest.mark.parametrize("dims,total,exchange,world", [((640, 480, 600), 6, "ring", 2), ((640, 480, 600), 6, "ring4", 2), ((640, 480, 600), 6, "allgather", 2),
+                                                       ((1920, 1080, 4000), 4, "ring", 2), ((1920, 1080, 4000), 4, "allgather", 2),
+                                                       ((1920, 1080, 4000), 16, "ring", 8), ((1920, 1080, 4000), 16, "allgather", 8)])
+def test_ranks_match_one_rank(tmp_path, dims, total, exchange, world):
     one, two = tmp_path / "w1", tmp_path / "w2"
     one.mkdir(); two.mkdir()
     extra = [str(x) for x in dims] + [exchange]
@@ -29,14 +32,14 @@ def test_two_ranks_match_one_rank(tmp_path, dims, total, exchange):
     subprocess.check_call([sys.executable, os.path.join(HERE, "dist_stream_worker.py"), str(one), str(total)] + extra, env=env)
     port = str(_free_port())
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_stream_worker.py"), str(two), str(total)] + extra,
-                              env=dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
-                                       MORB_DIST_BACKEND="gloo")) for r in range(2)]
+                              env=dict(os.environ, WORLD_SIZE=str(world), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                                       MORB_DIST_BACKEND="gloo")) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=600) == 0
     ref = np.load(one / "rank0.npz")
     by_g = {int(g): (ref["match"][i], int(ref["nmatch"][i]), int(ref["count"][i])) for i, g in enumerate(ref["gids"])}
     seen = set()
-    for r in range(2):
+    for r in range(world):
         d = np.load(two / f"rank{r}.npz")
         for i, g in enumerate(d["gids"]):
             m, n, c = by_g[int(g)]
@@ -70,6 +73,27 @@ def test_bench_gpus2_launches_two_ranks(workload):
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
     want = (752, 1200) if workload == "c2" else (1920, 4000)
     assert f"{want[0]}x" in line["metric"] and f"{want[1]} feat" in line["metric"]
+
+
+def test_bench_gpus8_c4_one_frame_per_rank():
+    """BASELINE configs[3] as stated — eight ranks, ONE 1920 x 1080 / 4000-feature frame per rank and step — through bench.py's own launcher (ranks
+    share GPU 0, gloo), ring and all-gather: the line carries the per-rank step-time spread and the exchange's HIP-event time."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MORB_DIST_BACKEND"] = "gloo"
+    for ex in ("ring", "allgather"):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--workload", "c4", "--batch", "1", "--exchange", ex,
+                            "--steps", "3", "--warmup", "0", "--no-extras", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, timeout=1200)
+        assert p.returncode == 0
+        lines = [json.loads(l) for l in p.stdout.decode().splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        line = lines[0]
+        assert line["n_gpus"] == 8 and line["config"]["stereo_frames_per_step_per_gpu"] == 1
+        mg = line["multi_gpu"]
+        assert mg["exchange"] == ex and mg["rank_ms_per_step"]["min"] > 0 and mg["rank_ms_per_step"]["max"] >= mg["rank_ms_per_step"]["min"]
+        assert mg["exchange_ms_per_step"]["max_over_ranks_of_mean"] > 0
+        assert line["config"]["mean_bow_matches_per_frame"] > 0
 
 
 def test_bench_matcher_placements_agree():
