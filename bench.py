@@ -782,32 +782,40 @@ def main():
         # device buffers while the previous step computes (never `value`: the contract's number is HBM-resident)
         pinned = host_frames.view(2 * B, H, W).pin_memory()
         dbuf = [torch.empty_like(images) for _ in range(2)]
-        cstream = torch.cuda.Stream(device=dev)
+        # two copy streams, half the batch each (chunks of ~185 MB): one stream's copies reach ~35 GB/s on this pool's hosts, two ~45 (tools/h2d_bw.py)
+        cstreams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        cstream = cstreams[0]
+        up_half = [[torch.cuda.Event() for _ in range(2)] for _ in range(2)]
         up_done = [torch.cuda.Event() for _ in range(2)]
         consumed = [torch.cuda.Event() for _ in range(2)]
         ksteps = max(20, args.steps)
+        half = (2 * B) // 2
 
         def h2d_step(i):
             b = i % 2
-            if i >= 2:
-                cstream.wait_event(consumed[b])
-            with torch.cuda.stream(cstream):
-                dbuf[b].copy_(pinned, non_blocking=True)
+            for k, cs in enumerate(cstreams):
+                if i >= 2:
+                    cs.wait_event(consumed[b])
+                lo, hi = (0, half) if k == 0 else (half, 2 * B)
+                with torch.cuda.stream(cs):
+                    dbuf[b][lo:hi].copy_(pinned[lo:hi], non_blocking=True)
+                up_half[b][k].record(cs)
+            cstream.wait_event(up_half[b][1])
             up_done[b].record(cstream)
             es = estreams[fe.nstep % NSET]
             step(src=dbuf[b], src_ready=up_done[b])
             consumed[b].record(es)
         for i in range(2):
             h2d_step(i)
-        sync_streams(); cstream.synchronize()
+        sync_streams(); cstreams[0].synchronize(); cstreams[1].synchronize()
         t1 = time.perf_counter()
         for i in range(ksteps):
             h2d_step(i)
-        sync_streams(); cstream.synchronize()
+        sync_streams(); cstreams[0].synchronize(); cstreams[1].synchronize()
         dth = (time.perf_counter() - t1) / ksteps
         h2d = {"value": B / dth, "unit": "frames/s", "ms_per_step": dth * 1e3, "steps": ksteps,
                "pcie_GBps": 2 * B * W * H / dth / 1e9,
-               "note": "pinned host images uploaded on a copy stream, double-buffered, overlapped with the previous step's compute"}
+               "note": "pinned host images uploaded on two copy streams (half the batch each), double-buffered, overlapped with the previous step's compute"}
         # ---- one stereo frame at a time, host image in -> host arrays out (the reference's call pattern, Frame.cc:190-226):
         # upload 2 images, ORBextractor x2, ComputeStereoMatches, download keypoints / descriptors / counts / uRight / depth
         one = ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank)
@@ -859,13 +867,19 @@ def main():
         # at 128 images per launch; profiles/<round>/pmc_traffic_b64.json) — not measurable live.  Corrected as the calibration kernel
         # prescribes (profiles/r03/fetch_calib.txt: FETCH_SIZE reads 0.500 x the bytes of coalesced 4 / 8 / 16-byte reads, WRITE_SIZE 1.0 x):
         # traffic = 2 x FETCH_SIZE + WRITE_SIZE
-        pm = None
-        for rnd in ("r04", "r03"):
+        pm = pmi = None
+        pm_src = None
+        for rnd, fn in (("r05", "pmc_traffic_b512.json"), ("r04", "pmc_traffic_b64.json"), ("r03", "pmc_traffic_b64.json")):   # newest first; r05: taken AT the bench batch
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic_b64.json")))
+                pm = json.load(open(os.path.join(ROOT, "profiles", rnd, fn)))
+                pm_src = f"profiles/{rnd}/{fn}"
                 break
             except Exception:
                 pm = None
+        try:
+            pmi = json.load(open(os.path.join(ROOT, "profiles", "r05", "pmc_issue_b512.json")))
+        except Exception:
+            pmi = None
 
         def traffic_of(stage):
             if pm is None or args.workload != "c2":
@@ -908,6 +922,24 @@ def main():
                                for k in ("pyramid", "blur", "fast")},
             "extract_stage_ms_per_step": stages,
         }
+        if pm_src is not None:
+            line["roofline"]["traffic_source"] = pm_src + (" (counters at this batch)" if pm.get("images_per_launch") == nimg else
+                                                           f" (counters at {pm.get('images_per_launch')} images per launch, scaled)")
+        line["roofline"]["peak_measured_copy"] = 6290.0      # GB/s, the guide's measured HBM copy rate beside the 8 TB/s specification
+        line["roofline"]["frac_of_measured_copy"] = line["roofline"]["achieved"] / 6290.0
+        if pmi is not None and args.workload == "c2" and "k_fastw" in pmi and pmi.get("images_per_launch") == nimg:
+            # k_fastw is bound by vector-instruction ISSUE, not by HBM (traffic = 1.07 x algorithmic, every instruction removed is
+            # time): its real roof.  Instruction counts from the committed counter pass at this batch (not measurable live), duration measured live.
+            kf = pmi["k_fastw"]
+            per_step = kf["valu_insts_per_launch"] * 2             # two launch groups per extraction
+            simd_cycles = pmi["simds"] * stages["fast"] * 1e-3 * pmi["clock_GHz"] * 1e9
+            line["roofline_issue"] = {"bound": "valu_issue", "kernel": "k_fastw", "valu_wave_instructions_per_step": per_step,
+                                      "cycles_per_instruction": pmi["cycles_per_valu_instruction"],
+                                      "achieved": per_step * pmi["cycles_per_valu_instruction"] / simd_cycles, "peak": 1.0, "unit": "fraction of SIMD issue cycles",
+                                      "valu_lane_slots_per_pixel": per_step * 64 / (ab["fast"] * nimg),
+                                      "valu_per_cell_wave": kf["valu_per_wave"], "salu_per_cell_wave": kf["salu_per_wave"], "lds_per_cell_wave": kf["lds_per_wave"],
+                                      "source": "profiles/r05/pmc_issue_b512.json (SQ_INSTS_VALU per launch, 4.1 cycles per instruction from "
+                                                "profiles/r04/valu_rate_saturated.txt) / live k_fastw time x 1024 SIMDs x 2.4 GHz"}
         if multi is not None:
             line["multi_gpu"] = multi
         if verified is not None:

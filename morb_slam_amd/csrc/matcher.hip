@@ -11,6 +11,8 @@
 // reductions are wave64 shuffles.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -605,6 +607,107 @@ __global__ __launch_bounds__(256) void k_bow_transform(const uint8_t* __restrict
     if (level == nid_level) nid = final_id;
   } while (firstChild[final_id] >= 0);
   if (sub == 0) { wordId[o] = final_id; nodeId[o] = nid; }
+}
+
+// Round 5: the first three levels of the tree from LDS.  Every feature walks all of them and they are small — 10 + 100 + 1000 nodes of a
+// 10-ary vocabulary, 35 KB of descriptors — while each level costs a dependent round trip to L2 (a level's children can only be requested once
+// the level above is decided): half of the six round trips of an ORBvoc-shaped descent.  A workgroup stages them ONCE, by walking the tree
+// itself (firstChild / childCount, so any node numbering — ORBvoc.txt's is depth-first — and nodes with fewer than k children work), then works
+// through many 64-feature chunks (a persistent grid: the staging is paid ~1000 times per launch, not 20 000 times).  Slot of a staged node =
+// its path: level 1: a, level 2: 10 + 10 a + b, level 3: 110 + 100 a + 10 b + c.  Deeper levels come from global memory as before.
+constexpr int BT_K = 10, BT_N1 = BT_K, BT_N2 = BT_K * BT_K, BT_N3 = BT_K * BT_K * BT_K, BT_SLOTS = BT_N1 + BT_N2 + BT_N3;   // 1110
+template <int NLV> struct BtLds {
+  static constexpr int SLOTS = NLV == 3 ? BT_SLOTS : BT_N1 + BT_N2;
+  uint2 desc[SLOTS][4];      // [slot][quarter] 32-byte descriptors
+  int id[SLOTS];             // node id of the slot, -1: no such node
+  int fc[SLOTS];             // its firstChild (-1: a leaf)
+  uint16_t nc[SLOTS];        // its child count (more than BT_K: its children are not staged, the descent continues in global memory)
+};
+// NLV = staged levels: 3 (47 KB of LDS per workgroup: three workgroups per CU) or 2 (5 KB: no limit on the occupancy)
+template <int NLV>
+__global__ __launch_bounds__(256) void k_bow_transform_lds(const uint8_t* __restrict__ feat, const int* __restrict__ count, int cap, int nimg,
+                                                           const uint8_t* __restrict__ nodeDesc, const int* __restrict__ firstChild, int k,
+                                                           int L, int levelsup, int* __restrict__ wordId, int* __restrict__ nodeId,
+                                                           const int* __restrict__ childCount) {
+  extern __shared__ __align__(16) uint8_t btRaw[];
+  BtLds<NLV>& S = *reinterpret_cast<BtLds<NLV>*>(btRaw);
+  const int tid = threadIdx.x;
+  const int fc0 = firstChild[0], nc0 = childCount ? childCount[0] : k;
+  // ---- staging: level by level (a level's ids come from the level above)
+  auto stage = [&](int slot, int parentFc, int parentNc, int j) {
+    int id = -1, fc = -1, nc = 0;
+    if (parentFc >= 0 && j < parentNc) {
+      id = parentFc + j;
+      fc = firstChild[id];
+      nc = fc >= 0 ? (childCount ? childCount[id] : k) : 0;
+      const uint4* src = reinterpret_cast<const uint4*>(nodeDesc + (size_t)id * 32);
+      const uint4 a = src[0], b = src[1];
+      S.desc[slot][0] = make_uint2(a.x, a.y); S.desc[slot][1] = make_uint2(a.z, a.w);
+      S.desc[slot][2] = make_uint2(b.x, b.y); S.desc[slot][3] = make_uint2(b.z, b.w);
+    }
+    S.id[slot] = id; S.fc[slot] = fc; S.nc[slot] = (uint16_t)min(nc, 0xFFFF);
+  };
+  if (tid < BT_N1) stage(tid, nc0 <= BT_K ? fc0 : -1, nc0, tid);
+  __syncthreads();
+  if (tid < BT_N2) { const int a = tid / BT_K; stage(BT_N1 + tid, S.nc[a] <= BT_K ? S.fc[a] : -1, S.nc[a], tid % BT_K); }
+  __syncthreads();
+  if (NLV == 3) for (int t = tid; t < BT_N3; t += 256) { const int ab = t / BT_K; stage(BT_N1 + BT_N2 + t, S.nc[BT_N1 + ab] <= BT_K ? S.fc[BT_N1 + ab] : -1, S.nc[BT_N1 + ab], t % BT_K); }
+  __syncthreads();
+  // ---- the chunks: 64 features (four lanes each) of one image per trip
+  const int sub = tid & 3, nid_level = L - levelsup;
+  const int chunksPerImg = (cap + 63) / 64, nChunks = chunksPerImg * nimg;
+  const uint8_t* nd = nodeDesc + sub * 8;
+  for (int ch = blockIdx.x; ch < nChunks; ch += gridDim.x) {
+    const int img = ch / chunksPerImg, i = (ch - img * chunksPerImg) * 64 + (tid >> 2);
+    if (i >= cap) continue;
+    const size_t o = (size_t)img * cap + i;
+    if (i >= count[img]) { if (sub == 0) { wordId[o] = -1; nodeId[o] = -1; } continue; }
+    const uint2 d = *reinterpret_cast<const uint2*>(feat + o * 32 + sub * 8);
+    int final_id = 0, level = 0, nid = 0;
+    int slotBase = 0, nc = nc0, path = 0;   // children of the current node: slots slotBase .. slotBase + nc - 1
+    bool leaf = fc0 < 0;
+    // levels 1 - 3 from LDS
+#pragma unroll
+    for (int lv = 0; lv < NLV; ++lv) {
+      if (leaf || nc > BT_K) break;   // (a node with more than ten children: not staged)
+      ++level;
+      int best = 0, bestd = 0x7fffffff;
+      for (int j = 0; j < nc; ++j) {
+        const uint2 tc = S.desc[slotBase + j][sub];
+        const int dd = quad_sum(__popc(d.x ^ tc.x) + __popc(d.y ^ tc.y));
+        if (dd < bestd) { bestd = dd; best = j; }
+      }
+      const int slot = slotBase + best;
+      final_id = S.id[slot];
+      if (level == nid_level) nid = final_id;
+      leaf = S.fc[slot] < 0;
+      nc = S.nc[slot];
+      path = path * BT_K + best;
+      slotBase = (lv == 0 ? BT_N1 : BT_N1 + BT_N2) + path * BT_K;
+    }
+    // deeper levels from global memory (the round-3 form)
+    while (!leaf) {
+      ++level;
+      const int c0 = firstChild[final_id];
+      const int ncg = childCount ? childCount[final_id] : k;
+      int best = c0, bestd = 0x7fffffff;
+      constexpr int CH = 5;
+      for (int cb = c0; cb < c0 + ncg; cb += CH) {
+        uint2 tc[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) tc[j] = *reinterpret_cast<const uint2*>(nd + (size_t)min(cb + j, c0 + ncg - 1) * 32);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const int dd = quad_sum(__popc(d.x ^ tc[j].x) + __popc(d.y ^ tc[j].y));
+          if (dd < bestd) { bestd = dd; best = min(cb + j, c0 + ncg - 1); }
+        }
+      }
+      final_id = best;
+      if (level == nid_level) nid = final_id;
+      leaf = firstChild[final_id] < 0;
+    }
+    if (sub == 0) { wordId[o] = final_id; nodeId[o] = nid; }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1230,6 +1333,37 @@ int morb_stereo_match_batch(morb_matcher* m, const morb_extractor* e, int nframe
   return MORB_OK;
 }
 
+namespace {
+// the LDS-staged descent when the tree is at most 10-ary (DBoW2's ORB vocabulary: k = 10) and the batch is large enough to pay for the staging
+int launch_bow_transform(hipStream_t st, int nimg, const uint8_t* d_desc, const int* d_count, int cap, const uint8_t* d_nodeDesc,
+                         const int* d_firstChild, int k, int kmax, int L, int levelsup, int* d_wordId, int* d_nodeId, const int* d_childCount) {
+  const int nChunks = div_up(cap, 64) * nimg;
+  // Measured (profiles/r05/README.md): alone on the chip the global-memory descent takes 0.112 ms per 512 frames, the staged forms 0.108 - 0.141
+  // (three staged levels cost the occupancy 47 KB of LDS per workgroup); inside the bench step all of them land within +-0.3 % of each other —
+  // the descent's six round trips hit L2 and are hidden by the kernel's 20 000 workgroups.  The staged kernels are kept for vocabularies that do
+  // not fit L2's share (MORB_BOW_STAGE = 2 | 3 selects them); the default stays the global-memory descent.
+  const char* sv = getenv("MORB_BOW_STAGE");
+  if (sv && kmax <= BT_K && nChunks >= 64) {
+    const int nlv = atoi(sv);
+    const char* gv = getenv("MORB_BOW_GRID");
+    const int grid = std::min(nChunks, gv ? atoi(gv) : 1024);   // persistent workgroups: the launch runs beside the extractor's kernels
+    if (nlv == 3) {
+      MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_transform_lds<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BtLds<3>)));
+      hipLaunchKernelGGL(k_bow_transform_lds<3>, dim3(grid), dim3(256), sizeof(BtLds<3>), st, d_desc, d_count, cap, nimg, d_nodeDesc, d_firstChild, k, L,
+                         levelsup, d_wordId, d_nodeId, d_childCount);
+    } else {
+      hipLaunchKernelGGL(k_bow_transform_lds<2>, dim3(grid), dim3(256), sizeof(BtLds<2>), st, d_desc, d_count, cap, nimg, d_nodeDesc, d_firstChild, k, L,
+                         levelsup, d_wordId, d_nodeId, d_childCount);
+    }
+  } else {
+    hipLaunchKernelGGL(k_bow_transform, dim3(div_up(4 * cap, 256), nimg), dim3(256), 0, st, d_desc, d_count, cap, d_nodeDesc, d_firstChild, k, L,
+                       levelsup, d_wordId, d_nodeId, d_childCount);
+  }
+  MORB_HIP_CHECK(hipGetLastError());
+  return MORB_OK;
+}
+}  // namespace
+
 int morb_bow_transform_batch(morb_matcher* m, int nimg, const uint8_t* d_desc, const int* d_count, int cap,
                              const uint8_t* d_nodeDesc, const int* d_firstChild, int k, int L, int levelsup,
                              int* d_wordId, int* d_nodeId, void* stream) {
@@ -1237,10 +1371,7 @@ int morb_bow_transform_batch(morb_matcher* m, int nimg, const uint8_t* d_desc, c
   MORB_REQUIRE(nimg > 0 && cap > 0 && k > 0 && L > 0, MORB_ERR_INVALID, "bad sizes");
   MORB_HIP_CHECK(hipSetDevice(m->device));
   hipStream_t st = stream ? (hipStream_t)stream : m->stream;
-  hipLaunchKernelGGL(k_bow_transform, dim3(div_up(4 * cap, 256), nimg), dim3(256), 0, st, d_desc, d_count, cap, d_nodeDesc,
-                     d_firstChild, k, L, levelsup, d_wordId, d_nodeId, (const int*)nullptr);
-  MORB_HIP_CHECK(hipGetLastError());
-  return MORB_OK;
+  return launch_bow_transform(st, nimg, d_desc, d_count, cap, d_nodeDesc, d_firstChild, k, k, L, levelsup, d_wordId, d_nodeId, nullptr);
 }
 
 int morb_bow_transform_tree_batch(morb_matcher* m, int nimg, const uint8_t* d_desc, const int* d_count, int cap,
@@ -1251,10 +1382,7 @@ int morb_bow_transform_tree_batch(morb_matcher* m, int nimg, const uint8_t* d_de
   MORB_REQUIRE(nimg > 0 && cap > 0 && L > 0, MORB_ERR_INVALID, "bad sizes");
   MORB_HIP_CHECK(hipSetDevice(m->device));
   hipStream_t st = stream ? (hipStream_t)stream : m->stream;
-  hipLaunchKernelGGL(k_bow_transform, dim3(div_up(4 * cap, 256), nimg), dim3(256), 0, st, d_desc, d_count, cap, d_nodeDesc,
-                     d_firstChild, 0, L, levelsup, d_wordId, d_nodeId, d_childCount);
-  MORB_HIP_CHECK(hipGetLastError());
-  return MORB_OK;
+  return launch_bow_transform(st, nimg, d_desc, d_count, cap, d_nodeDesc, d_firstChild, 0, BT_K, L, levelsup, d_wordId, d_nodeId, d_childCount);   // (nodes with more than ten children are handled inside)
 }
 
 // ---- DBoW2 text vocabulary (TemplatedVocabulary::loadFromTextFile, TemplatedVocabulary.h:1338-1420) ------------------

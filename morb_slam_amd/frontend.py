@@ -98,6 +98,7 @@ class StereoFrontEnd:
         self.stagger = bool(stagger) and self.estreams[0] is not self.estreams[-1]
         self.pending = None
         self.last = None          # the buffer set of the most recent step
+        self.ablate = ""
         self.exchange_ms = None   # set to a list by the caller: HIP-event time of every COMPLETED exchange (pack -> transfer -> unpack on bstream)
 
     def close(self):
@@ -144,12 +145,22 @@ class StereoFrontEnd:
         e = S.ext
         mstream, bstream = self.mstream, self.bstream
         mstream.wait_event(S.ext_done)
+        ablate = self.ablate            # developer experiments (tools/ablate_matchers.py): "" | "stereo" | "bow" | "all" skipped — never set by bench.py
+        if ablate in ("stereo", "all"):
+            S.stereo_done.record(mstream)
+            if ablate == "all":
+                S.bow_done.record(bstream)
+                return
         if gate is not None:
             self._wait_raw_event(mstream, gate)
             if bstream is not mstream:
                 self._wait_raw_event(bstream, gate)
-        self.matcher.ComputeStereoMatches(e, kps, desc, cnt, self.mbf, self.mb, out=S.st_out, stream=mstream.cuda_stream)   # Frame.cc:217
-        S.stereo_done.record(mstream)
+        if ablate not in ("stereo", "all"):
+            self.matcher.ComputeStereoMatches(e, kps, desc, cnt, self.mbf, self.mb, out=S.st_out, stream=mstream.cuda_stream)   # Frame.cc:217
+            S.stereo_done.record(mstream)
+        if ablate == "bow":
+            S.bow_done.record(bstream)
+            return
         bs = bstream.cuda_stream
         bstream.wait_event(S.ext_done)
         # Frame::ComputeBoW converts mDescriptors = the LEFT image's descriptors (Frame.cc:822-827): the right images take no part in BoW

@@ -3,7 +3,7 @@
 # command plus separate --pmc passes (HBM traffic: FETCH_SIZE / WRITE_SIZE; issue mix: SQ_*), as the MI355X guide
 # prescribes (counters never combined with sys/runtime traces).  Usage: bash tools/refresh_profiles.sh r01
 set -u
-R=${1:-r04}
+R=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$R
 rm -rf "$O" && mkdir -p "$O"
@@ -15,6 +15,16 @@ for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INST
 done
 python3 tools/pmc_table.py "$O/pmc" > "$O/pmc_issue_table.txt"
 python3 tools/pmc_traffic.py "$O/pmc" 128 > "$O/pmc_traffic_b64.json"
+# round 5: the same counters AT THE BENCH BATCH (B = 512 stereo frames = 1024 images per launch), which is what bench.py's line quotes
+# (`roofline.traffic`, `roofline_issue`): traffic and instruction counts per launch, no scaling from a smaller batch
+for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY"; do
+  n=$(echo "$p" | cut -c1-12 | tr " " _)
+  timeout 600 rocprofv3 --pmc $p --kernel-trace -d "$O/pmc512/$n" -o q --output-format csv -- python3 bench.py --batch 512 --no-pipeline --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-verify --sustained-s 0 > /dev/null 2>&1
+done
+python3 tools/pmc_traffic.py "$O/pmc512" 1024 > "$O/pmc_traffic_b512.json"
+python3 tools/pmc_issue.py "$O/pmc512" 1024 > "$O/pmc_issue_b512.json"
+python3 tools/pmc_table.py "$O/pmc512" > "$O/pmc_issue_table_b512.txt"
+rm -rf "$O/pmc512"
 cp "$O/stats/s_kernel_stats.csv" "$O/extract_match_b512_kernel_stats.csv"
 # FETCH_SIZE / WRITE_SIZE calibration on known byte counts
 bash tools/fetch_calib.sh calib_$R > /dev/null 2>&1; cp gpurun_out/calib_$R/fetch_calib.txt gpurun_out/calib_$R/fetch_calib.json "$O/" 2>/dev/null
