@@ -634,3 +634,16 @@ def test_reference_call_sites_compile_unchanged():
                  "ORBmatcher::DescriptorDistance<cv::Mat", "Optimizer::PoseOptimization<ORB_SLAM3::Frame>", "Optimizer::LocalBundleAdjustment<ORB_SLAM3::KeyFrame",
                  "Optimizer::PoseInertialOptimizationLastKeyFrame<", "Optimizer::PoseInertialOptimizationLastFrame<", "Optimizer::LocalInertialBA<ORB_SLAM3::KeyFrame"):
         assert want in syms, want
+
+
+def test_oracle_matches_opencv_vectors():
+    """Replays tests/golden/reference_opencv.npz — vectors a real OpenCV produced (tests/golden/make_opencv_golden.py --write, run where cv2 exists) —
+    through the oracle's restatements of cv::resize / GaussianBlur / FAST / fastAtan2 / knnMatch.  The file cannot be generated in this image
+    (no OpenCV): until someone commits it the oracle stays "parity unpinned" and this test is skipped."""
+    path = os.path.join(ROOT, "tests", "golden", "reference_opencv.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/reference_opencv.npz not generated yet (needs OpenCV: tests/golden/make_opencv_golden.py --write)")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_opencv_golden as g
+    ref = dict(np.load(path, allow_pickle=False))
+    assert g.compare(ref, g.from_oracle(g.cases())) == 0
