@@ -189,3 +189,61 @@ def test_local_ba_oneshot_equals_the_three_step_form():
         one = local_bundle_adjustment_oneshot(opt, b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"], b["eInvSigma2"], b["cam"])
         for x, y in zip(ref, one):
             np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+
+
+def test_a_tracking_search_does_not_wait_for_a_running_local_ba():
+    """The reference runs Tracking and LocalMapping on two threads.  A projection search on a fresh matcher handle — whose first call GROWS its
+    workspaces — must not wait for a LocalBundleAdjustment that is running on another handle: until round 5 the growth went through
+    hipDeviceSynchronize + hipFree, i.e. it waited for the whole device.  The solve here is the persistent-workgroup mode (one kernel of tens of ms),
+    started on one thread; the search runs to completion on another while the solve is still in flight."""
+    import threading
+    import time
+    import torch
+    from morb_slam_amd import BAProblem, Optimizer, ORBmatcher
+    from morb_slam_amd.capi import make_frame_params
+    from morb_slam_amd.synth import make_ba_problem
+    opt = Optimizer()
+    b = make_ba_problem(seed=2)
+    p = BAProblem(opt, b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"], b["eInvSigma2"], b["cam"])
+    p.set_mode(1)
+    p.solve(); p.results()                                   # warm (code objects loaded, buffers there)
+    t0 = time.perf_counter(); p.solve(); p.results(); solve_s = time.perf_counter() - t0
+    assert solve_s > 0.005, "the persistent solve is expected to take milliseconds"
+    rng = np.random.default_rng(1)
+    cap = mp = 512
+    from morb_slam_amd import KP_DTYPE
+    k = np.zeros((1, cap), KP_DTYPE); k["x"] = rng.uniform(20, 700, (1, cap)); k["y"] = rng.uniform(20, 440, (1, cap)); k["octave"] = rng.integers(0, 8, (1, cap))
+    dev = "cuda"
+    kps = torch.from_numpy(k.view(np.uint8).reshape(1, cap, 28)).to(dev)
+    desc = torch.from_numpy(rng.integers(0, 256, (1, cap, 32), dtype=np.uint8)).to(dev)
+    cnt = torch.tensor([cap], dtype=torch.int32, device=dev)
+    sf = [1.2 ** i for i in range(8)]
+    P = make_frame_params(752, 480, 458.654, 457.296, 367.215, 248.375, 50.0, 0.11, sf, [s * s for s in sf])
+    trk = dict(inView=torch.ones((1, mp), dtype=torch.uint8, device=dev), projX=torch.from_numpy(k["x"].astype(np.float32)).to(dev),
+               projY=torch.from_numpy(k["y"].astype(np.float32)).to(dev), projXR=torch.full((1, mp), -1.0, device=dev),
+               depth=torch.full((1, mp), 3.0, device=dev), level=torch.from_numpy(k["octave"].astype(np.int32)).to(dev),
+               viewCos=torch.full((1, mp), 0.9, device=dev))
+    z8 = torch.zeros((1, mp), dtype=torch.uint8, device=dev)
+    fImg = torch.zeros((1,), dtype=torch.int32, device=dev); nMP = torch.tensor([mp], dtype=torch.int32, device=dev)
+    ones8 = torch.ones_like(z8)
+    matchF = torch.full((1, cap), -1, dtype=torch.int32, device=dev); nmOut = torch.zeros((1,), dtype=torch.int32, device=dev)
+    # the search runs on a NON-BLOCKING stream, as a C++ caller's would (the adapters of include/morb/ never touch the null stream): the legacy
+    # default stream — torch's current stream here — is ordered with every blocking stream, the solver's included, so nothing below may use it
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    done = {}
+
+    def solver():
+        t = time.perf_counter(); p.solve(); p.results(); done["solve"] = (t, time.perf_counter())
+    th = threading.Thread(target=solver); th.start()
+    time.sleep(solve_s * 0.15)                               # the solve is in flight
+    t1 = time.perf_counter()
+    m = ORBmatcher(0.8, True)                                # fresh handle: every workspace grows inside the call below
+    mt, nm = m.SearchByProjectionMapPoints(P, fImg, kps, desc, cnt, None, z8, nMP, trk, z8, desc, ones8, 3.0, matchF=matchF, nm=nmOut,
+                                           stream=side.cuda_stream)
+    side.synchronize()
+    t2 = time.perf_counter()
+    th.join()
+    assert int(nm[0]) > 100
+    assert t2 < done["solve"][1], f"the search should have finished while the solve was still running (search {t1:.4f} .. {t2:.4f}, solve {done['solve']})"
+    assert t2 - t1 < 0.6 * solve_s, f"the search took {t2 - t1:.4f} s beside a {solve_s:.4f} s solve: it waited for it"
