@@ -2109,7 +2109,11 @@ int morb_pose_optimization_batch(morb_optimizer* o, int nframes, int cap, const 
   Cam cam{fx, fy, cx, cy, bf};
   Rig rig;
   memset(&rig, 0, sizeof rig);
-  if (cap <= PO2_MAX_CAP && !getenv("MORB_PO_OLD")) {
+  // (tree-sum mode on small frames: k_pose_opt2's 512 threads take ONE edge each, so a frame with 513 .. 640 active edges pays a second, nearly
+  // empty stage per pass — 0.447 against 0.400 ms per launch at 600 features; k_pose_opt's 256 threads with 2 - 3 edges each stay the faster
+  // form there.  Frames of ~1200 features of which half hold a map point — tracking — are where the compaction of k_pose_opt2 pays.)
+  const bool smallTree = !o->exactOrder && cap <= 640;
+  if (cap <= PO2_MAX_CAP && !smallTree && !getenv("MORB_PO_OLD")) {
     const int rc = launch_pose_opt2<false>(o->exactOrder != 0, nframes, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig, nullptr, d_pose,
                                            d_outlier, d_nInliers, d_stats);
     if (rc != MORB_OK) return rc;
