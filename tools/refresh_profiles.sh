@@ -52,6 +52,15 @@ python3 bench.py --workload c4 --no-extras --no-cpu-baseline --sustained-s 0 > "
 MORB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --batch 64 --steps 10 --no-extras --no-cpu-baseline --sustained-s 0 > "$O/bench_gpus2_gloo_one_gpu.json" 2>/dev/null
 MORB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --batch 64 --steps 10 --exchange allgather --no-extras --no-cpu-baseline --sustained-s 0 > "$O/bench_gpus2_allgather_gloo_one_gpu.json" 2>/dev/null
 MORB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --workload c4 --steps 10 --no-extras --no-cpu-baseline --sustained-s 0 > "$O/bench_c4_gpus2_gloo_one_gpu.json" 2>/dev/null
+# round 5: the tracking-side matchers (north_star's SearchByProjection / SearchForTriangulation kernels): kernel stats of the chain + keyframe searches,
+# kernel timelines of one step (one frame, 256 frames); the eight-rank shape of the driver's multi-GPU run on this one GPU (gloo), ring and all-gather
+bash tools/prof_tracking.sh trk_$R 256 > "$O/tracking_profile_log.txt" 2>&1
+cp gpurun_out/trk_$R/tracking_kernel_stats.csv gpurun_out/trk_$R/tracking_b1_timeline.txt gpurun_out/trk_$R/tracking_b256_timeline.txt "$O/" 2>/dev/null
+cp gpurun_out/trk_$R/bench.json "$O/tracking_bench.json" 2>/dev/null
+MORB_DIST_BACKEND=gloo python3 bench.py --gpus 8 --workload c4 --batch 1 --steps 10 --warmup 0 --no-extras --no-cpu-baseline --sustained-s 0 > "$O/bench_c4_gpus8_batch1_ring_gloo_one_gpu.json" 2>/dev/null
+MORB_DIST_BACKEND=gloo python3 bench.py --gpus 8 --workload c4 --batch 1 --steps 10 --warmup 0 --exchange allgather --no-extras --no-cpu-baseline --sustained-s 0 > "$O/bench_c4_gpus8_batch1_allgather_gloo_one_gpu.json" 2>/dev/null
+python3 tools/ablate_matchers.py > "$O/matcher_ablation.txt" 2>/dev/null
+python3 tools/h2d_bw.py > "$O/h2d_copy_bandwidth_by_streams.txt" 2>/dev/null
 python3 bench.py > "$O/bench_default.json" 2>/dev/null
 python3 tools/time_stats.py "$O" 50 10 > /dev/null 2>&1
 python3 -m pytest tests -m gpu -q 2>&1 | tail -3 > "$O/pytest_gpu.txt"
