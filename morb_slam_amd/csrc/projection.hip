@@ -715,10 +715,11 @@ __device__ __forceinline__ void top2_insert32(uint32_t& k1, uint32_t& k2, uint32
 struct SearchFeat { float x, y; int oct; float ur; };   // 16 B
 // LDSDESC is a compile-time choice: with a run-time one the compiler merges the LDS and the global descriptor pointer into a generic one and
 // every distance becomes two FLAT loads behind an `s_waitcnt vmcnt(0)` — which also waits for the candidate store of the visit before.
-template <bool LDSDESC>
+// FULL: the tests only the keyframe searches need — a feature-index range (rig keyframes: left | right halves) and Fuse's reprojection gate
+template <bool LDSDESC, bool FULL = false>
 __device__ __forceinline__ uint32_t search_key(const Query& q, const Desc& qd, int p, const SearchFeat* __restrict__ sf,
                                                const uint16_t* __restrict__ featOf, const uint32_t* __restrict__ sDesc,
-                                               const uint8_t* __restrict__ descRow, bool useUr) {
+                                               const uint8_t* __restrict__ descRow, bool useUr, const float* levelSigma2 = nullptr) {
   // (the walk is bound by instruction issue — sixteen waves share the CU — so the tests are one predicate, not a ladder of branches: ~55
   // instead of ~120 instructions per visit.  The feature-index range of a query (jLo / jHi: fisheye searches only) does not occur here.)
   const SearchFeat ft = sf[p];
@@ -726,6 +727,21 @@ __device__ __forceinline__ uint32_t search_key(const Query& q, const Desc& qd, i
   bool ok = !bCheckLevels || (ft.oct >= q.minLevel && (q.maxLevel < 0 || ft.oct <= q.maxLevel));
   ok = ok && (fabsf(ft.x - q.x) < q.r) && (fabsf(ft.y - q.y) < q.r);
   ok = ok && !(useUr && ft.ur > 0 && fabsf(q.xr - ft.ur) > q.erMax);
+  if (FULL) {
+    if (q.jHi > 0) { const int j = featOf[p]; ok = ok && j >= q.jLo && j < q.jHi; }
+    if (q.gate == 1) {   // ORBmatcher.cc:1160-1181; mvInvLevelSigma2[l] = 1.0f / mvLevelSigma2[l] (ORBextractor.cc:421)
+      const float invS = 1.0f / levelSigma2[ft.oct & 15];
+      const float ex = q.x - ft.x, ey = q.y - ft.y;
+      if (useUr && ft.ur >= 0) {
+        const float er = q.xr - ft.ur;
+        const float e2 = ex * ex + ey * ey + er * er;
+        ok = ok && !((double)(e2 * invS) > 7.8);
+      } else {
+        const float e2 = ex * ex + ey * ey;
+        ok = ok && !((double)(e2 * invS) > 5.99);
+      }
+    }
+  }
   if (!ok) return ~0u;
   int d;
   if (LDSDESC) {
@@ -778,7 +794,10 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(morb_frame_params P, 
                                                           float nnratio, int thAccept, int checkOri, int* __restrict__ match,
                                                           int* __restrict__ nmatches) {
   constexpr int withDesc = LDSDESC ? 1 : 0;
-  static_assert(MODE == 0 || MODE == 1, "the fisheye / initialisation searches keep the serial replay");
+  // MODE 5: every query on its own (Fuse, SearchBySim3: no "already matched" state) — the best key per query by an LDS atomic minimum during the
+  // walk, `match` = bestIdx [frames][qCap], `nmatches` = bestDist [frames][qCap] or NULL; no lists, no fixed point
+  static_assert(MODE == 0 || MODE == 1 || MODE == 5, "the fisheye / initialisation searches keep the serial replay");
+  constexpr bool FULLKEY = MODE == 5;
   extern __shared__ __align__(16) uint8_t smemRaw[];
   __shared__ int hist[HISTO_LENGTH];
   __shared__ int keep3[3];
@@ -882,7 +901,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(morb_frame_params P, 
     for (int cx = cx0; cx <= cx1; ++cx) {
       const int p0 = (int)L.start[cx * GRID_ROWS + cy0], p1 = (int)L.start[cx * GRID_ROWS + cy1 + 1];
       for (int p = p0; p < p1; ++p) {
-        const uint32_t k = search_key<LDSDESC>(q, qd, p, L.feat, L.featOf, L.sDesc, descRow, ur != nullptr);
+        const uint32_t k = search_key<LDSDESC, FULLKEY>(q, qd, p, L.feat, L.featOf, L.sDesc, descRow, ur != nullptr, P.levelSigma2);
         if (k != ~0u) fn(k);
       }
     }
@@ -962,10 +981,13 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(morb_frame_params P, 
 #endif
         WK(cLd);
         while (item < qEnd) {
-          const uint32_t k = search_key<LDSDESC>(q, qd, p, L.feat, L.featOf, L.sDesc, descRow, ur != nullptr);
+          const uint32_t k = search_key<LDSDESC, FULLKEY>(q, qd, p, L.feat, L.featOf, L.sDesc, descRow, ur != nullptr, P.levelSigma2);
           if (k != ~0u) {
-            const uint32_t slot = atomicAdd(&L.qcnt[qi], 1u);
-            if (slot < (uint32_t)SEARCH_CAP) candF[(size_t)slot * qCap + qi] = k;
+            if (MODE == 5) atomicMin(&L.res[qi], k);
+            else {
+              const uint32_t slot = atomicAdd(&L.qcnt[qi], 1u);
+              if (slot < (uint32_t)SEARCH_CAP) candF[(size_t)slot * qCap + qi] = k;
+            }
           }
           ++item; ++p;
           while (p == p1 && cx < cx1) { ++cx; p = (int)L.start[cx * GRID_ROWS + cy0]; p1 = (int)L.start[cx * GRID_ROWS + cy1 + 1]; }
@@ -980,6 +1002,17 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(morb_frame_params P, 
   }
   __threadfence_block();
   __syncthreads();
+  if (MODE == 5) {
+    int* bestIdx = match + (size_t)f * qCap;
+    int* bestDist = nmatches ? nmatches + (size_t)f * qCap : nullptr;
+    for (int qi = tid; qi < qCap; qi += SEARCH_THREADS) {
+      const uint32_t r = qi < nQ ? L.res[qi] : ~0u;
+      const bool ok = r != ~0u && (int)(r >> 20) <= thAccept;
+      bestIdx[qi] = ok ? (int)L.featOf[(r >> 4) & 0xFFFFu] : -1;
+      if (bestDist) bestDist[qi] = ok ? (int)(r >> 20) : -1;
+    }
+    return;
+  }
   SRCH_MARK(1);
   // ---- (3) results <-> blk until nothing changes.  The owner of a query (thread qi % 1024, slot qi / 1024) keeps the first SEARCH_REG keys of its
   // list in registers: a pass then touches LDS only (the lists were re-read from L2 in every pass: a dependent round trip per key).
@@ -1682,20 +1715,53 @@ static int kfproj_candidates(morb_matcher* m, const morb_frame_params* P, int np
                              const uint8_t* d_valid, const float* d_Pw, const float* d_normal, const float* d_maxDist,
                              const float* d_minDist, const uint8_t* d_mpDesc, const float* d_T, const float* d_sim, const float* d_Ow,
                              const float* cam8, const int* d_jLo, const int* d_jHi, float th, int projMode, int gate, hipStream_t st,
-                             const Query** qsOut, const unsigned long long** candOut, const int** cntOut) {
+                             const Query** qsOut, const unsigned long long** candOut, const int** cntOut) {   // candOut == NULL: the queries only
   const float *d_thr = nullptr, *d_kb8 = nullptr;
   int rc = upload_ratio_thresholds(m, P, cam8, st, &d_thr, &d_kb8);
   if (rc != MORB_OK) return rc;
   void *qs = nullptr, *cand = nullptr, *cnt = nullptr;
   rc = morb_matcher_workspace(m, 5, sizeof(Query) * (size_t)nprob * mpCap, &qs);
-  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 0, sizeof(unsigned long long) * (size_t)nprob * mpCap * CAND_CAP, &cand);
-  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 1, sizeof(int) * (size_t)nprob * mpCap, &cnt);
+  if (rc == MORB_OK && candOut) rc = morb_matcher_workspace(m, 0, sizeof(unsigned long long) * (size_t)nprob * mpCap * CAND_CAP, &cand);
+  if (rc == MORB_OK && candOut) rc = morb_matcher_workspace(m, 1, sizeof(int) * (size_t)nprob * mpCap, &cnt);
   if (rc != MORB_OK) return rc;
   hipLaunchKernelGGL(k_prep_kfproj, dim3(div_up(mpCap, 256), nprob), dim3(256), 0, st, *P, mpCap, d_nMP, d_valid, d_Pw, d_normal,
                      d_maxDist, d_minDist, d_T, d_sim, d_Ow, d_thr, d_kb8, d_jLo, d_jHi, th, projMode, gate, (Query*)qs);
+  *qsOut = (const Query*)qs;
+  if (!candOut) return MORB_OK;
   hipLaunchKernelGGL(k_candidates, dim3(div_up(mpCap, 4), nprob), dim3(256), 0, st, *P, mpCap, (const Query*)qs, d_mpDesc, d_kfImg, cap,
                      d_count, d_kps, d_desc, d_uRight, (unsigned long long*)cand, (int*)cnt, 0);
-  *qsOut = (const Query*)qs; *candOut = (const unsigned long long*)cand; *cntOut = (const int*)cnt;
+  *candOut = (const unsigned long long*)cand; *cntOut = (const int*)cnt;
+  return MORB_OK;
+}
+
+// best feature of every (independent) query: one launch of k_search<5> when the frame's tables fit LDS, else k_candidates + k_best_per_query
+static int best_per_query(morb_matcher* m, const morb_frame_params* P, int nprob, int qCap, const int* d_nQ, const Query* qs, const uint8_t* d_qDesc,
+                          const int* d_kfImg, int cap, const int* d_count, const morb_keypoint* d_kps, const uint8_t* d_desc, const float* d_uRight,
+                          int thAccept, int* d_bestIdx, int* d_bestDist, hipStream_t st) {
+  if (cap <= 65535 && qCap <= 65535 && search_lds_bytes(cap, qCap, false) <= 150 * 1024 && !getenv("MORB_SERIAL_RESOLVE")) {
+    const bool withDesc = search_lds_bytes(cap, qCap, true) <= 150 * 1024;
+    const size_t lds = search_lds_bytes(cap, qCap, withDesc);
+    if (withDesc) {
+      MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((k_search<5, true>), dim3(nprob), dim3(SEARCH_THREADS), lds, st, *P, qCap, d_nQ, qs, d_qDesc, (const uint8_t*)nullptr, d_kfImg, cap,
+                         d_count, d_kps, d_desc, d_uRight, (const uint8_t*)nullptr, (uint32_t*)nullptr, 0.f, thAccept, 0, d_bestIdx, d_bestDist);
+    } else {
+      MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((k_search<5, false>), dim3(nprob), dim3(SEARCH_THREADS), lds, st, *P, qCap, d_nQ, qs, d_qDesc, (const uint8_t*)nullptr, d_kfImg, cap,
+                         d_count, d_kps, d_desc, d_uRight, (const uint8_t*)nullptr, (uint32_t*)nullptr, 0.f, thAccept, 0, d_bestIdx, d_bestDist);
+    }
+    MORB_HIP_CHECK(hipGetLastError());
+    return MORB_OK;
+  }
+  void *cand = nullptr, *cnt = nullptr;
+  int rc = morb_matcher_workspace(m, 0, sizeof(unsigned long long) * (size_t)nprob * qCap * CAND_CAP, &cand);
+  if (rc == MORB_OK) rc = morb_matcher_workspace(m, 1, sizeof(int) * (size_t)nprob * qCap, &cnt);
+  if (rc != MORB_OK) return rc;
+  hipLaunchKernelGGL(k_candidates, dim3(div_up(qCap, 4), nprob), dim3(256), 0, st, *P, qCap, qs, d_qDesc, d_kfImg, cap, d_count, d_kps, d_desc, d_uRight,
+                     (unsigned long long*)cand, (int*)cnt, 0);
+  hipLaunchKernelGGL(k_best_per_query, dim3(div_up(qCap, 4), nprob), dim3(256), 0, st, *P, qCap, qs, d_qDesc, d_kfImg, cap, d_count, d_kps, d_desc, d_uRight,
+                     (const unsigned long long*)cand, (const int*)cnt, thAccept, d_bestIdx, d_bestDist);
+  MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
 }
 
@@ -1714,12 +1780,9 @@ extern "C" int morb_fuse_batch(morb_matcher* m, const morb_frame_params* P, int 
   const Query* qs; const unsigned long long* cand; const int* cnt;
   int rc = kfproj_candidates(m, P, nprob, d_kfImg, cap, d_count, d_kps, d_desc, d_uRight, mpCap, d_nMP, d_valid, d_Pw, d_normal,
                              d_maxDist, d_minDist, d_mpDesc, d_Tcw, nullptr, d_Ow, cam8, d_jLo, d_jHi, th, 0, sim3Form ? 0 : 1, st, &qs,
-                             &cand, &cnt);
+                             nullptr, nullptr);
   if (rc != MORB_OK) return rc;
-  hipLaunchKernelGGL(k_best_per_query, dim3(div_up(mpCap, 4), nprob), dim3(256), 0, st, *P, mpCap, qs, d_mpDesc, d_kfImg, cap, d_count,
-                     d_kps, d_desc, d_uRight, cand, cnt, TH_LOW, d_bestIdx, d_bestDist);
-  MORB_HIP_CHECK(hipGetLastError());
-  return MORB_OK;
+  return best_per_query(m, P, nprob, mpCap, d_nMP, qs, d_mpDesc, d_kfImg, cap, d_count, d_kps, d_desc, d_uRight, TH_LOW, d_bestIdx, d_bestDist, st);
 }
 
 // cam8 / d_nLeft: a KannalaBrandt8 rig keyframe — the reference then searches the LEFT camera's features only (GetFeaturesInArea with bRight = false,
@@ -1802,16 +1865,16 @@ static int search_by_sim3_impl(morb_matcher* m, const morb_frame_params* P, int 
   const Query* qs; const unsigned long long* cand; const int* cnt;
   // map points of keyframe 1 -> camera 1 -> camera 2 (S21) -> keyframe 2's features (:1354-1425)
   rc = kfproj_candidates(m, P, npairs, d_kf2Img, cap, d_count, d_kps, d_desc, nullptr, cap, n1, d_valid1, d_Pw1, nullptr, d_maxDist1,
-                         d_minDist1, d_mpDesc1, d_T1w, d_S21, nullptr, nullptr, nullptr, d_nLeft2, th, 2, 0, st, &qs, &cand, &cnt);
+                         d_minDist1, d_mpDesc1, d_T1w, d_S21, nullptr, nullptr, nullptr, d_nLeft2, th, 2, 0, st, &qs, nullptr, nullptr);
   if (rc != MORB_OK) return rc;
-  hipLaunchKernelGGL(k_best_per_query, dim3(div_up(cap, 4), npairs), dim3(256), 0, st, *P, cap, qs, d_mpDesc1, d_kf2Img, cap, d_count,
-                     d_kps, d_desc, (const float*)nullptr, cand, cnt, TH_HIGH, d_vnMatch1, (int*)nullptr);
+  rc = best_per_query(m, P, npairs, cap, n1, qs, d_mpDesc1, d_kf2Img, cap, d_count, d_kps, d_desc, nullptr, TH_HIGH, d_vnMatch1, nullptr, st);
+  if (rc != MORB_OK) return rc;
   // and the other way round (:1428-1499)
   rc = kfproj_candidates(m, P, npairs, d_kf1Img, cap, d_count, d_kps, d_desc, nullptr, cap, n2, d_valid2, d_Pw2, nullptr, d_maxDist2,
-                         d_minDist2, d_mpDesc2, d_T2w, d_S12, nullptr, nullptr, nullptr, d_nLeft1, th, 2, 0, st, &qs, &cand, &cnt);
+                         d_minDist2, d_mpDesc2, d_T2w, d_S12, nullptr, nullptr, nullptr, d_nLeft1, th, 2, 0, st, &qs, nullptr, nullptr);
   if (rc != MORB_OK) return rc;
-  hipLaunchKernelGGL(k_best_per_query, dim3(div_up(cap, 4), npairs), dim3(256), 0, st, *P, cap, qs, d_mpDesc2, d_kf1Img, cap, d_count,
-                     d_kps, d_desc, (const float*)nullptr, cand, cnt, TH_HIGH, d_vnMatch2, (int*)nullptr);
+  rc = best_per_query(m, P, npairs, cap, n2, qs, d_mpDesc2, d_kf1Img, cap, d_count, d_kps, d_desc, nullptr, TH_HIGH, d_vnMatch2, nullptr, st);
+  if (rc != MORB_OK) return rc;
   MORB_HIP_CHECK(hipMemsetAsync(d_nFound, 0, sizeof(int) * npairs, st));
   hipLaunchKernelGGL(k_sim3_agree, dim3(div_up(cap, 256), npairs), dim3(256), 0, st, cap, d_vnMatch1, d_vnMatch2, d_match12, d_nFound);
   MORB_HIP_CHECK(hipGetLastError());

@@ -59,15 +59,31 @@ struct PointFiles {
   }
 };
 
+// MORB_ADAPTER_TIMING=1: every member is called 20 more times and its mean host-to-host latency printed (what a drop-in caller pays per call:
+// the views' uploads, the kernels, the downloads and the synchronisations of the handle's stream)
+#include <chrono>
+#include <cstdlib>
+static bool g_time = false;
+template <class Fn> static void timeit(const char* name, Fn&& fn) {
+  if (!g_time) return;
+  fn();
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < 20; ++i) fn();
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / 20;
+  std::printf("TIMING %-52s %.3f ms per call\n", name, ms);
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
   g_dir = argv[1];
+  g_time = std::getenv("MORB_ADAPTER_TIMING") != nullptr;
   {   // SearchByProjection(CurrentFrame, LastFrame, th, bMono)
     FrameFiles cur("last_cur"), last("last_last");
     const auto cfg = load<float>("last_cfg");   // nnratio, checkOri, th, bMono
     ORBmatcher m(cfg[0], cfg[1] != 0);
     std::vector<int> match;
     const int n = m.SearchByProjection(static_cast<const FrameView&>(cur.v), static_cast<const FrameView&>(last.v), match, cfg[2], cfg[3] != 0);
+    timeit("SearchByProjection(CurrentFrame, LastFrame)", [&] { std::vector<int> mm; m.SearchByProjection(static_cast<const FrameView&>(cur.v), static_cast<const FrameView&>(last.v), mm, cfg[2], cfg[3] != 0); });
     dump("last_n", &n, 1); dump("last_match", match.data(), match.size());
   }
   {   // SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)
@@ -77,6 +93,7 @@ int main(int argc, char** argv) {
     ORBmatcher m(cfg[0], cfg[1] != 0);
     std::vector<int> match;
     const int n = m.SearchByProjection(static_cast<const FrameView&>(cur.v), kf.v, found, match, cfg[2], (int)cfg[3]);
+    timeit("SearchByProjection(CurrentFrame, KeyFrame)", [&] { std::vector<int> mm; m.SearchByProjection(static_cast<const FrameView&>(cur.v), kf.v, found, mm, cfg[2], (int)cfg[3]); });
     dump("kfp_n", &n, 1); dump("kfp_match", match.data(), match.size());
   }
   {   // SearchByBoW(pKF, F) and SearchByBoW(pKF1, pKF2)
@@ -85,6 +102,7 @@ int main(int argc, char** argv) {
     ORBmatcher m(cfg[0], cfg[1] != 0);
     std::vector<int> match;
     int n = m.SearchByBoW(kf.v, static_cast<const FrameView&>(fr.v), match);
+    timeit("SearchByBoW(KeyFrame, Frame)", [&] { std::vector<int> mm; m.SearchByBoW(kf.v, static_cast<const FrameView&>(fr.v), mm); });
     dump("bow_n", &n, 1); dump("bow_match", match.data(), match.size());
     FrameFiles k1("bowkk_1"), k2("bowkk_2");
     n = m.SearchByBoW(k1.v, k2.v, match);
@@ -105,6 +123,7 @@ int main(int argc, char** argv) {
     ORBmatcher m(cfg[0], cfg[1] != 0);
     std::vector<std::pair<size_t, size_t>> pairs;
     const int n = m.SearchForTriangulation(k1.v, k2.v, &cfg[4], &cfg[13], &cfg[16], pairs, cfg[2] != 0, cfg[3] != 0);
+    timeit("SearchForTriangulation(KeyFrame, KeyFrame)", [&] { decltype(pairs) pp; m.SearchForTriangulation(k1.v, k2.v, &cfg[4], &cfg[13], &cfg[16], pp, cfg[2] != 0, cfg[3] != 0); });
     std::vector<int> flat;
     for (auto& p : pairs) { flat.push_back((int)p.first); flat.push_back((int)p.second); }
     dump("tri_n", &n, 1); dump("tri_pairs", flat.data(), flat.size());
@@ -118,6 +137,7 @@ int main(int argc, char** argv) {
     ORBmatcher m(cfg[0], cfg[1] != 0);
     std::vector<int> bi, bd;
     int n = m.Fuse(kf.v, pts.v, bi, bd, cfg[2]);
+    timeit("Fuse(KeyFrame, MapPoints)", [&] { auto b1 = bi; auto b2 = bd; m.Fuse(kf.v, pts.v, b1, b2, cfg[2]); });
     dump("fuse_n", &n, 1); dump("fuse_idx", bi.data(), bi.size()); dump("fuse_dist", bd.data(), bd.size());
     n = m.Fuse(kf.v, S, pts.v, cfg[3], bi, bd);
     dump("fuse3_n", &n, 1); dump("fuse3_idx", bi.data(), bi.size()); dump("fuse3_dist", bd.data(), bd.size());

@@ -137,6 +137,10 @@ def test_cpp_matcher_adapter_matches_oracle(batch, tmp_path):
     put("s3_cfg", np.concatenate([[0.8, 1, 7.5], S12, S21]).astype(np.float32))
 
     out = subprocess.run([_build(tmp_path, "matcher_adapters_check.cc"), str(d)], capture_output=True, text=True, timeout=600)
+    if os.environ.get("MORB_ADAPTER_TIMING"):     # developer run: per-call latency of the C++ members (tools/refresh_profiles.sh keeps the lines)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "adapter_call_latency.txt"), "w") as f:
+            f.write("".join(l + "\n" for l in out.stdout.splitlines() if l.startswith("TIMING")))
     assert out.returncode == 0 and "matcher adapters ok" in out.stdout, out.stdout + out.stderr
 
     # ---- the reference's own signatures (SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&), ...) driven with mock Frame / KeyFrame / MapPoint
