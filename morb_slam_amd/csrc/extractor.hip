@@ -658,6 +658,9 @@ constexpr int DESC_WIN = 2 * DESC_R + 1, DESC_WP = 48;   // window rows / LDS pi
 #ifndef MORB_DESC_WAVES
 #define MORB_DESC_WAVES 4
 #endif
+#ifndef MORB_DESC_ANGLE_WG
+#define MORB_DESC_ANGLE_WG 1   // fastAtan2 + sincosf of the workgroup's keypoints in one pass of wave 0 (0: each wave for its own two)
+#endif
 constexpr int DESC_WAVES = MORB_DESC_WAVES;   // waves (of DESC_KPW keypoints each) per workgroup
 __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGeom dg, const uint8_t* __restrict__ pyr,
                                                   const uint8_t* __restrict__ blur, const int2* __restrict__ kref,
@@ -679,7 +682,15 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGe
   }
   const int img = imgRev ? gridDim.y - 1 - imgIdx : imgIdx, lane = threadIdx.x & 63;
   const int gi0 = (chunk * DESC_WAVES + (threadIdx.x >> 6)) * DESC_KPW;
+#if MORB_DESC_ANGLE_WG
+  // (round 5) the workgroup's waves meet at two barriers (the angles of all its keypoints are computed in ONE pass of wave 0): a wave without
+  // work goes through them and leaves
+  __shared__ int s_mom[DESC_WAVES * DESC_KPW][2];
+  __shared__ float s_trig[DESC_WAVES * DESC_KPW][3];
+  if (gi0 >= selPerImg) { __syncthreads(); __syncthreads(); return; }
+#else
   if (gi0 >= selPerImg) return;
+#endif
   // (the pattern fetched once per workgroup into LDS instead — one 16-byte load per thread, a barrier, four ds_read_b128 per lane later —
   // measured no faster: 2016 - 2058 against 2002 - 2015 us per 512 images for the whole extraction, three runs each on one box)
   int4 pat[4];
@@ -696,7 +707,11 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGe
     ok[kk] = gi0 + kk < selPerImg && ref[kk].x >= 0;
     if (ok[kk]) { firstRef = ref[kk]; any = true; }
   }
+#if MORB_DESC_ANGLE_WG
+  if (!any) { __syncthreads(); __syncthreads(); return; }   // wave-uniform
+#else
   if (!any) return;   // wave-uniform
+#endif
 #pragma unroll
   for (int kk = 0; kk < DESC_KPW; ++kk) {
     if (!ok[kk]) ref[kk] = firstRef;
@@ -808,6 +823,36 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGe
   // fastAtan2 and sincosf are one number per keypoint: lane kk computes keypoint kk's (as wave-uniform code the four of them cost four
   // serial passes of ~70 instructions, the FP64 polynomial of glibc's sincosf included, on all 64 lanes), and every keypoint's gathers
   // can be issued as soon as that one pass is through
+#if MORB_DESC_ANGLE_WG
+  // Round 5: ONE pass for the whole workgroup.  fastAtan2 + glibc's sincosf (~90 instructions, FP64 polynomial included) occupy all 64 lanes of a
+  // wave for the two numbers its two keypoints need; the kernel is bound by vector-instruction issue (634 VALU per wave, 5.3 SIMD cycles each,
+  // profiles/r05/pmc_issue_table_b512.txt), so the four waves' passes become one: moments to LDS, wave 0 computes lane k = keypoint k of the
+  // workgroup, everybody picks its two (cos, sin, angle) up again.  The same instructions on the same inputs: identical bits.
+  {
+    const int w0 = (threadIdx.x >> 6) * DESC_KPW;
+    if (lane < DESC_KPW) {
+      int m10 = m10k[DESC_KPW - 1], m01 = m01k[DESC_KPW - 1];
+#pragma unroll
+      for (int kk = DESC_KPW - 2; kk >= 0; --kk) { m10 = lane == kk ? m10k[kk] : m10; m01 = lane == kk ? m01k[kk] : m01; }
+      s_mom[w0 + lane][0] = m10; s_mom[w0 + lane][1] = m01;
+    }
+    __syncthreads();
+    if (threadIdx.x < DESC_WAVES * DESC_KPW) {
+      const float ang = fast_atan2_deg((float)s_mom[threadIdx.x][1], (float)s_mom[threadIdx.x][0]);
+      const float factorPI = (float)(3.14159265358979323846 / 180.f);
+      float sn, cs;
+      sincosf_glibc(ang * factorPI, &sn, &cs);
+      s_trig[threadIdx.x][0] = ang; s_trig[threadIdx.x][1] = cs; s_trig[threadIdx.x][2] = sn;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int kk = 0; kk < DESC_KPW; ++kk) {
+    const int ws = (threadIdx.x >> 6) * DESC_KPW + kk;
+    angle[kk] = s_trig[ws][0];
+    const float a = s_trig[ws][1];
+    const float bsin = s_trig[ws][2];
+#else
   float angL, aL, bL;
   {
     int m10 = m10k[DESC_KPW - 1], m01 = m01k[DESC_KPW - 1];
@@ -823,6 +868,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGe
     // rBRIEF on the blurred level: lane k evaluates tests 4k..4k+3
     const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, aL), kk));
     const float bsin = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bL), kk));
+#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float x0 = (float)pat[q].x, y0 = (float)pat[q].y, x1 = (float)pat[q].z, y1 = (float)pat[q].w;
