@@ -59,3 +59,57 @@ def test_tracking_chain_one_frame_at_a_time(chains):
         assert np.array_equal(c1.frameMP.cpu().numpy()[0], ref[0][f]) and c1.nInl.cpu().numpy()[0] == ref[2][f]
         assert c1.pose.cpu().numpy()[0].tobytes() == ref[1][f].tobytes()
         c1.close()
+
+
+def test_search_paths_beyond_the_register_lists(chains):
+    """k_search's slower in-kernel paths, against the oracle: (1) windows so wide that a query's list overflows the 32 stored candidates (the
+    query walks the grid again in every pass), (2) more than 2048 queries per frame (no register slot: lists read from L2), both with the
+    blocked-feature dependence in play (hasObs set on most points)."""
+    import torch
+    import oracle_lib as O
+    from morb_slam_amd import ORBmatcher
+    ch, ks, host = chains
+    sc = host["scene"]
+    dev = ch.dev
+    P = ch.P
+    # (1) SearchByProjection(Cur, Last) with th = 45: r = 45 * scale -> windows of 90 .. 320 px
+    m = ORBmatcher(0.9, True)
+    F = 4
+    mt, nm = m.SearchByProjectionLastFrame(P, ch.curImg[:F].contiguous(), ch.lastImg[:F].contiguous(), ch.kps, ch.desc, ch.count, ch.uRight[:F].contiguous(), None,
+                                           ch.pose0[:F].contiguous(), ch.lastValid[:F].contiguous(), ch.lastXw[:F].contiguous(), ch.lastDesc[:F].contiguous(),
+                                           ch.lastHasObs[:F].contiguous(), 45.0, ch.fwd[:F].contiguous(), ch.bwd[:F].contiguous())
+    torch.cuda.synchronize()
+    mt, nm = mt.cpu().numpy(), nm.cpu().numpy()
+    for f in range(F):
+        ci, li = int(sc["curImg"][f]), int(sc["lastImg"][f]); nc, nl = int(host["cnt"][ci]), int(host["cnt"][li])
+        Fo = O.make_frame(P, host["kps"][ci, :nc], host["desc"][ci, :nc], host["curUR"][f, :nc])
+        lastMP = sc["lastMP"][f, :nl]; lv = (lastMP >= 0).astype(np.uint8); lm = np.maximum(lastMP, 0)
+        r, me = O.search_by_projection_last(Fo, np.zeros(nc, np.uint8), sc["pose0"][f], host["kps"][li, :nl], lv, sc["mpXw"][f][lm], sc["mpDesc"][f][lm],
+                                            sc["mpHasObs"][f][lm] * lv, 45.0, 0, 0, True)
+        assert int(nm[f]) == r, (f, int(nm[f]), r)
+        np.testing.assert_array_equal(mt[f, :nc], me)
+    # (2) SearchByProjection(F, MapPoints) over 3000 map points (the frame's table, its first 952 rows once more), th = 3
+    mp = 3000
+    rep = lambda a: torch.cat([a, a[:, :mp - a.shape[1]]], 1).contiguous()
+    f0 = slice(0, 2)
+    Rcw = torch.eye(3, device=dev).reshape(1, 9).repeat(2, 1).contiguous(); z3 = torch.zeros((2, 3), device=dev)
+    Xw, nrm, mx, mn = rep(ch.mpXw[f0]), rep(ch.mpNormal[f0]), rep(ch.mpMaxD[f0]), rep(ch.mpMinD[f0])
+    dsc, ho = rep(ch.mpDesc[f0]), rep(ch.mpHasObs[f0])
+    nMP = torch.full((2,), mp, dtype=torch.int32, device=dev)
+    ml = ORBmatcher(0.8, True)
+    trk = ml.isInFrustum(P, Rcw, z3, z3, nMP, Xw, nrm, mx, mn, 0.5)
+    bad = torch.zeros((2, mp), dtype=torch.uint8, device=dev)
+    blocked = torch.zeros((2, ch.cap), dtype=torch.uint8, device=dev)
+    mt2, nm2 = ml.SearchByProjectionMapPoints(P, ch.curImg[f0].contiguous(), ch.kps, ch.desc, ch.count, ch.uRight[f0].contiguous(), blocked, nMP, trk, bad, dsc, ho, 3.0)
+    torch.cuda.synchronize()
+    mt2, nm2 = mt2.cpu().numpy(), nm2.cpu().numpy()
+    cat = lambda a: np.concatenate([a, a[:mp - len(a)]])
+    for f in range(2):
+        ci = int(sc["curImg"][f]); nc = int(host["cnt"][ci])
+        Fo = O.make_frame(P, host["kps"][ci, :nc], host["desc"][ci, :nc], host["curUR"][f, :nc])
+        te = O.is_in_frustum(Fo, np.eye(3, dtype=np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32), cat(sc["mpXw"][f]), cat(sc["mpNormal"][f]),
+                             cat(sc["mpMaxD"][f]), cat(sc["mpMinD"][f]), 0.5)
+        r, me = O.search_by_projection_mps(Fo, np.zeros(nc, np.uint8), te, np.zeros(mp, np.uint8), cat(sc["mpDesc"][f]), cat(sc["mpHasObs"][f]), 3.0, False, 0.0, 0.8)
+        assert int(nm2[f]) == r, (f, int(nm2[f]), r)
+        np.testing.assert_array_equal(mt2[f, :nc], me)
+    assert int(nm.sum()) > 1000 and int(nm2.sum()) > 500
