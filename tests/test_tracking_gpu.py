@@ -113,3 +113,49 @@ def test_search_paths_beyond_the_register_lists(chains):
         assert int(nm2[f]) == r, (f, int(nm2[f]), r)
         np.testing.assert_array_equal(mt2[f, :nc], me)
     assert int(nm.sum()) > 1000 and int(nm2.sum()) > 500
+
+
+@pytest.mark.parametrize("copies,flip", [(4, 0.03), (8, 0.08)])
+def test_search_fixed_point_under_heavy_contention(chains, copies, flip):
+    """The order dependence of SearchByProjection(F, MapPoints) — a feature matched to a point with observations is skipped by every LATER point —
+    is solved as a fixed point in k_search.  Here every map point exists `copies` times (same position, descriptors a few bits apart), all with
+    observations: the copies compete for the same features, the first takes the best one, the next its runner-up, ... long blocking chains that
+    need many passes.  Tables and counts must equal the oracle's sequential loop."""
+    import torch
+    import oracle_lib as O
+    from morb_slam_amd import ORBmatcher
+    ch, ks, host = chains
+    sc = host["scene"]
+    dev = ch.dev
+    P = ch.P
+    rng = np.random.default_rng(77 + copies)
+    F, base = 3, 2048 // copies
+    mp = base * copies
+    Xw = np.zeros((F, mp, 3), np.float32); nrm = np.zeros((F, mp, 3), np.float32); mx = np.ones((F, mp), np.float32); mn = np.ones((F, mp), np.float32)
+    dsc = np.zeros((F, mp, 32), np.uint8)
+    for f in range(F):
+        for c in range(copies):          # interleaved: copies of a point are `base` queries apart AND neighbours differ -> conflicts across the whole range
+            sl = slice(c * base, (c + 1) * base)
+            Xw[f, sl] = sc["mpXw"][f, :base]; nrm[f, sl] = sc["mpNormal"][f, :base]; mx[f, sl] = sc["mpMaxD"][f, :base]; mn[f, sl] = sc["mpMinD"][f, :base]
+            dsc[f, sl] = sc["mpDesc"][f, :base] ^ np.packbits(rng.random((base, 256)) < flip, axis=1)
+    ho = np.ones((F, mp), np.uint8)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    nMP = torch.full((F,), mp, dtype=torch.int32, device=dev)
+    Rcw = torch.eye(3, device=dev).reshape(1, 9).repeat(F, 1).contiguous(); z3 = torch.zeros((F, 3), device=dev)
+    m = ORBmatcher(0.8, True)
+    trk = m.isInFrustum(P, Rcw, z3, z3, nMP, t(Xw), t(nrm), t(mx), t(mn), 0.5)
+    bad = torch.zeros((F, mp), dtype=torch.uint8, device=dev)
+    blocked = torch.zeros((F, ch.cap), dtype=torch.uint8, device=dev)
+    mt, nm = m.SearchByProjectionMapPoints(P, ch.curImg[:F].contiguous(), ch.kps, ch.desc, ch.count, ch.uRight[:F].contiguous(), blocked, nMP, trk, bad, t(dsc),
+                                           t(ho), 5.0)
+    torch.cuda.synchronize()
+    mt, nm = mt.cpu().numpy(), nm.cpu().numpy()
+    for f in range(F):
+        ci = int(sc["curImg"][f]); nc = int(host["cnt"][ci])
+        Fo = O.make_frame(P, host["kps"][ci, :nc], host["desc"][ci, :nc], host["curUR"][f, :nc])
+        te = O.is_in_frustum(Fo, np.eye(3, dtype=np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32), Xw[f], nrm[f], mx[f], mn[f], 0.5)
+        r, me = O.search_by_projection_mps(Fo, np.zeros(nc, np.uint8), te, np.zeros(mp, np.uint8), dsc[f], ho[f], 5.0, False, 0.0, 0.8)
+        assert int(nm[f]) == r, (f, int(nm[f]), r)
+        np.testing.assert_array_equal(mt[f, :nc], me)
+        later = (me >= base).sum()
+        assert later > 20, "the scene should make later copies win features the first copy's match blocked"
