@@ -8,6 +8,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstddef>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -23,14 +24,52 @@ inline void hip_check(hipError_t e, const char* what) {
 // a copy there would wait for every blocking stream of the device, i.e. for whatever LocalBundleAdjustment trial the mapping thread
 // has in flight (System.cc:209 runs Tracking and LocalMapping side by side).  NULL (no scope) = the null stream, as before.
 inline hipStream_t& current_stream() { static thread_local hipStream_t s = nullptr; return s; }
+inline void sync_current_stream() { hip_check(hipStreamSynchronize(current_stream()), "hipStreamSynchronize"); }
+
+// Pinned staging of the calling thread (round 5).  A reference call hands the adapter ~15 host arrays (keypoints, descriptors, map-point fields, ...);
+// uploaded one by one from pageable memory, each copy was a staged transfer plus a stream synchronisation — 0.25 ms of a 0.33 ms
+// SearchByProjection call.  Inside a StreamScope an upload now copies the array into this arena (so the caller's temporary may die at once) and queues
+// an asynchronous copy from there: no wait until the call's results are downloaded.  The arena is rewound when the outermost scope of the thread
+// opens (after the stream has drained) and grows by doubling; outgrown blocks live until that rewind.  (Never freed at thread exit: the HIP
+// runtime may be gone by then.)
+struct PinnedArena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0;
+  int depth = 0;
+  std::vector<char*> outgrown;
+  void* take(size_t n) {
+    n = (n + 63) & ~(size_t)63;
+    if (off + n > cap) {
+      size_t want = cap ? cap * 2 : (size_t)1 << 20;
+      while (want < n) want *= 2;
+      char* fresh = nullptr;
+      hip_check(hipHostMalloc(reinterpret_cast<void**>(&fresh), want, hipHostMallocDefault), "hipHostMalloc");
+      if (base) outgrown.push_back(base);   // copies queued from it are still in flight
+      base = fresh; cap = want; off = 0;
+    }
+    void* p = base + off;
+    off += n;
+    return p;
+  }
+  void rewind() {
+    for (char* o : outgrown) (void)hipHostFree(o);
+    outgrown.clear();
+    off = 0;
+  }
+};
+inline PinnedArena& arena() { static thread_local PinnedArena* a = new PinnedArena(); return *a; }
+
 struct StreamScope {
   hipStream_t saved;
-  explicit StreamScope(void* stream) : saved(current_stream()) { current_stream() = reinterpret_cast<hipStream_t>(stream); }
-  ~StreamScope() { current_stream() = saved; }
+  explicit StreamScope(void* stream) : saved(current_stream()) {
+    current_stream() = reinterpret_cast<hipStream_t>(stream);
+    PinnedArena& a = arena();
+    if (a.depth++ == 0 && a.off) { sync_current_stream(); a.rewind(); }   // whatever an earlier call queued from the arena has landed
+  }
+  ~StreamScope() { --arena().depth; current_stream() = saved; }
   StreamScope(const StreamScope&) = delete;
   StreamScope& operator=(const StreamScope&) = delete;
 };
-inline void sync_current_stream() { hip_check(hipStreamSynchronize(current_stream()), "hipStreamSynchronize"); }
 
 template <typename T>
 class DeviceBuffer {
@@ -52,6 +91,12 @@ class DeviceBuffer {
   // `host` may be a temporary of the caller: the copy is complete when upload() returns (hipMemcpy's contract, on the scope's stream)
   void upload(const T* host, size_t n) {
     if (!n) return;
+    if (arena().depth > 0) {   // inside an adapter call: through the thread's pinned arena, no wait (see PinnedArena)
+      void* st = arena().take(n * sizeof(T));
+      std::memcpy(st, host, n * sizeof(T));
+      hip_check(hipMemcpyAsync(p_, st, n * sizeof(T), hipMemcpyHostToDevice, current_stream()), "hipMemcpy H2D");
+      return;
+    }
     hip_check(hipMemcpyAsync(p_, host, n * sizeof(T), hipMemcpyHostToDevice, current_stream()), "hipMemcpy H2D");
     sync_current_stream();
   }
