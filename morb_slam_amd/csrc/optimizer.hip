@@ -483,10 +483,12 @@ __device__ __forceinline__ double ordered_add(double tot, const double* __restri
   }
   return tot;
 }
-// The same sum, software-pipelined: the next eight rows are REQUESTED before the current eight are added (empty asm statements that carry the running sum and clobber memory pin the order: without
-// them the compiler sinks the reads behind the additions again — it had placed every batch's reads directly in front of their use — a full LDS round trip per batch
-// on a wave that is alone on its SIMD, ~23 cycles per term).  Two register sets, so no copies.  ROWS = rows of the buffer (a multiple of 8): reads
-// never leave it; rows >= m are read and not added.
+// The same sum, software-pipelined for a wave that is (nearly) alone on its SIMD.  Such a wave issues an instruction every ~6 cycles whatever it is and a
+// dependent v_add_f64 every ~12 (tools/micro/f64_chain.hip -> profiles/r05/f64_chain_cycles_per_term.txt), so a term costs 12 cycles + 6 per other
+// instruction: the next eight rows are REQUESTED before the current eight are added (the compiler had placed every batch's reads directly in front of
+// their use: a full LDS round trip per batch, ~23 cycles per term); empty asm statements that carry the running sum and clobber memory pin that order
+// (17); 32 terms per loop trip (two register sets, no copies).  Interleaving one read per two additions measured 20 in the micro-benchmark: reads do not
+// hide in an addition's shadow.  ROWS = rows of the buffer (a multiple of 8): reads never leave it; rows >= m are read and not added.
 template <int STRIDE, int ROWS>
 __device__ __forceinline__ double ordered_add_pipe(double tot, const double* __restrict__ p, int m) {
   static_assert(ROWS % 8 == 0, "whole batches");
@@ -497,31 +499,39 @@ __device__ __forceinline__ double ordered_add_pipe(double tot, const double* __r
     _Pragma("unroll") for (int k = 0; k < 8; ++k) dst[k] = p[(r_ + k) * STRIDE]; \
     asm volatile("" : "+v"(tot) : : "memory");                                 \
   } while (0)
-#define MORB_ADD8(src)                                         \
-  do {                                                         \
-    _Pragma("unroll") for (int k = 0; k < 8; ++k) tot += src[k]; \
-    asm volatile("" : "+v"(tot) : : "memory");                 \
+// (MORB_PO2_CHAIN_ONE_WAIT: an empty asm that "rewrites" the batch's eight registers makes the compiler wait once per batch instead of in front of every
+// second addition — 13.5 instead of 17 cycles per term in the micro-benchmark, but inside k_pose_opt2, which sits at its 256-register limit, the
+// extra register constraints cost more than the waits: 0.572 against 0.537 ms per launch, tools/po_chain_ab.sh.  Off.)
+#ifdef MORB_PO2_CHAIN_ONE_WAIT
+#define MORB_ADD8_WAIT(src) asm volatile("" : "+v"(src[0]), "+v"(src[1]), "+v"(src[2]), "+v"(src[3]), "+v"(src[4]), "+v"(src[5]), "+v"(src[6]), "+v"(src[7]), "+v"(tot) : : "memory")
+#else
+#define MORB_ADD8_WAIT(src)
+#endif
+#define MORB_ADD8(src)                                                                                                                       \
+  do {                                                                                                                                       \
+    MORB_ADD8_WAIT(src);                                                                                                                     \
+    _Pragma("unroll") for (int k = 0; k < 8; ++k) tot += src[k];                                                                             \
+    asm volatile("" : "+v"(tot) : : "memory");                                                                                               \
   } while (0)
   MORB_LOAD8(v, 0);
   int e = 0;
-  for (; e + 16 <= m; e += 16) {
+  for (; e + 32 <= m; e += 32) {
+    MORB_LOAD8(w, e + 8);  MORB_ADD8(v);
+    MORB_LOAD8(v, e + 16); MORB_ADD8(w);
+    MORB_LOAD8(w, e + 24); MORB_ADD8(v);
+    MORB_LOAD8(v, e + 32); MORB_ADD8(w);
+  }
+  for (; e + 8 <= m; e += 8) {   // (v holds rows e .. e + 7)
     MORB_LOAD8(w, e + 8);
     MORB_ADD8(v);
-    MORB_LOAD8(v, e + 16);
-    MORB_ADD8(w);
-  }
-  if (e + 8 <= m) {
-    MORB_LOAD8(w, e + 8);
-    MORB_ADD8(v);
-    e += 8;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) if (e + k < m) tot += w[k];
-  } else {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) if (e + k < m) tot += v[k];
+    for (int k = 0; k < 8; ++k) v[k] = w[k];
   }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) if (e + k < m) tot += v[k];
 #undef MORB_LOAD8
 #undef MORB_ADD8
+#undef MORB_ADD8_WAIT
   return tot;
 }
 #ifdef MORB_PO_TRACE
@@ -804,8 +814,11 @@ __global__ __launch_bounds__(NT) void k_pose_opt(int cap, const int* __restrict_
 //  * In the edge-order mode wave 0 owns the 28 ordered sums and the 6 x 6 solve; waves 1 .. 7 compute the edges.  A stage is 448 edges:
 //    while wave 0 adds stage s, the workers already compute stage s + 1.
 //  * The solve, exp and pose update run on wave 0 only; the other waves pick the new pose up from LDS (they used to repeat all of it).
-constexpr int PO2_NT = 512, PO2_NW = PO2_NT / 64, PO2_EPT = 4, PO2_STAGE = PO2_NT - 64;   // edges per stage (edge-order mode)
-constexpr int PO2_MAX_CAP = PO2_EPT * PO2_STAGE;   // 1792 features: larger frames take k_pose_opt
+#ifndef MORB_PO2_IDLE4
+#define MORB_PO2_IDLE4 0   // edge-order mode: wave 4 — the wave that shares SIMD 0 with the summing wave — takes no edges (measured below)
+#endif
+constexpr int PO2_NT = 512, PO2_NW = PO2_NT / 64, PO2_EPT = 4, PO2_STAGE = PO2_NT - 64 - (MORB_PO2_IDLE4 ? 64 : 0);   // edges per stage (edge-order mode)
+constexpr int PO2_MAX_CAP = PO2_EPT * PO2_STAGE;   // 1536 features (1792 when wave 4 works too): larger frames take k_pose_opt
 
 struct PoEdge { float o[3], X[3], info; int right; };
 
@@ -860,7 +873,8 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
                                                       int* __restrict__ nInliers, int* __restrict__ stats) {
   constexpr int NT = PO2_NT, NW = PO2_NW;
   constexpr int W0 = ORDERED ? 64 : 0;          // first worker thread (edge-order mode: wave 0 adds and solves)
-  constexpr int NWORK = NT - W0;                // edges per stage
+  constexpr bool IDLE4 = ORDERED && MORB_PO2_IDLE4;   // ... and wave 4, its SIMD's other wave, stays out of the FP64 pipe the sums run on
+  constexpr int NWORK = NT - W0 - (IDLE4 ? 64 : 0);   // edges per stage
   extern __shared__ __align__(16) uint8_t po2Raw[];
   double* sC = reinterpret_cast<double*>(po2Raw);                                          // ORDERED: [NWORK][PO_PITCH] contributions of a stage
   uint16_t* actList = reinterpret_cast<uint16_t*>(po2Raw + (ORDERED ? (size_t)NWORK * PO_PITCH * 8 : 0));   // [cap] active features, in order
@@ -875,6 +889,8 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
   const int n = min(count ? count[f] : cap, cap);
   const size_t base = (size_t)f * cap;
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
+  // this thread's row in a stage (-1: not a worker)
+  const int wrow = !ORDERED ? tid : (wv == 0 || (IDLE4 && wv == 4)) ? -1 : ((IDLE4 && wv > 4) ? tid - 128 : tid - 64);
 
   PO2_T0(tAll);
   int nInit = 0;
@@ -906,17 +922,19 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
       for (int s = 0; s < PO2_EPT; ++s) {   // (unrolled: ed[s] must stay in registers)
         if (s * NWORK >= nAct) break;
         double con[28];
-        const int e = s * NWORK + (tid - W0);
-        const bool mine = tid >= W0 && e < nAct;
+        const int e = s * NWORK + wrow;
+        const bool mine = wrow >= 0 && e < nAct;
         if (mine) po2_contrib<FISH>(cam, rig, P, Pr, ed[s], robust, deltaMono, deltaStereo, con);   // (beside wave 0's sums of stage s - 1)
         if (s == 0) PO2_ADD(3, tp);
         __syncthreads();                       // stage s - 1 has been added
         if (mine) {
 #pragma unroll
-          for (int k = 0; k < 28; ++k) sC[(tid - W0) * PO_PITCH + k] = con[k];
+          for (int k = 0; k < 28; ++k) sC[wrow * PO_PITCH + k] = con[k];
         }
         __syncthreads();
+        PO2_T0(tch);
         if (tid < 28) tot = ordered_add_pipe<PO_PITCH, NWORK>(tot, sC + tid, min(NWORK, nAct - s * NWORK));
+        PO2_ADD(7, tch);
       }
       if (tid < 28) sTot[buf][tid] = tot;
       __syncthreads();
@@ -963,8 +981,8 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
     }
 #pragma unroll
     for (int s = 0; s < PO2_EPT; ++s) {
-      const int e = s * NWORK + (tid - W0);
-      if (tid >= W0 && e < nAct) {
+      const int e = s * NWORK + wrow;
+      if (wrow >= 0 && e < nAct) {
         const int i = actList[e];
         ed[s].o[0] = obs[(base + i) * 3]; ed[s].o[1] = obs[(base + i) * 3 + 1]; ed[s].o[2] = obs[(base + i) * 3 + 2];
         ed[s].X[0] = Xw[(base + i) * 3]; ed[s].X[1] = Xw[(base + i) * 3 + 1]; ed[s].X[2] = Xw[(base + i) * 3 + 2];

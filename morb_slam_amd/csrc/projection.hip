@@ -261,8 +261,9 @@ __global__ __launch_bounds__(256) void k_prep_last(morb_frame_params P, int cap,
                                                    const int* __restrict__ lastImg, const morb_keypoint* __restrict__ kps,
                                                    const uint8_t* __restrict__ lastValid, const float* __restrict__ lastXw,
                                                    const float* __restrict__ Tcw, float th, const uint8_t* __restrict__ fwd,
-                                                   const uint8_t* __restrict__ bwd, Query* __restrict__ qs) {
+                                                   const uint8_t* __restrict__ bwd, Query* __restrict__ qs, int* __restrict__ nqOut) {
   const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (nqOut && i == 0) nqOut[f] = count[lastImg[f]];   // the frame's query count = the LAST image's features (was a launch of its own)
   if (i >= cap) return;
   const size_t o = (size_t)f * cap + i;
   Query q;
@@ -1517,13 +1518,12 @@ int morb_search_by_projection_last_batch(morb_matcher* m, const morb_frame_param
   void* qs = nullptr;
   int rc = morb_matcher_workspace(m, 5, sizeof(Query) * (size_t)nframes * cap, &qs);
   if (rc != MORB_OK) return rc;
-  hipLaunchKernelGGL(k_prep_last, dim3(div_up(cap, 256), nframes), dim3(256), 0, st, *P, cap, d_count, d_lastImg, d_kps, d_lastValid,
-                     d_lastXw, d_Tcw, th, d_bForward, d_bBackward, (Query*)qs);
-  // the number of queries of frame f is the feature count of its LAST image (gathered on the device)
+  // the number of queries of frame f is the feature count of its LAST image (written by the same launch)
   void* nq = nullptr;
   rc = morb_matcher_workspace(m, 6, sizeof(int) * (size_t)nframes, &nq);
   if (rc != MORB_OK) return rc;
-  hipLaunchKernelGGL(k_gather_counts, dim3(div_up(nframes, 256)), dim3(256), 0, st, d_count, d_lastImg, nframes, (int*)nq);
+  hipLaunchKernelGGL(k_prep_last, dim3(div_up(cap, 256), nframes), dim3(256), 0, st, *P, cap, d_count, d_lastImg, d_kps, d_lastValid,
+                     d_lastXw, d_Tcw, th, d_bForward, d_bBackward, (Query*)qs, (int*)nq);
   return window_search(m, P, 0, nframes, cap, (const int*)nq, (const Query*)qs, d_lastMPdesc, d_lastMPhasObs, d_curImg, cap,
                        d_count, d_kps, d_desc, d_curURight, d_curBlocked, 0.f, TH_HIGH, checkOri, d_matchCur, d_nmatches, nullptr, st);
 }

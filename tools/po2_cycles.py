@@ -20,5 +20,5 @@ for mode in (True, False):
     torch.cuda.synchronize()
     L.morb_po2_cycles(z)
     c = list(z); st = out[2].cpu().numpy()[0]
-    names = ["kernel", "solve+bcast", "pass", "pass.compute0", "npass", "compact+load", "classify"]
+    names = ["kernel", "solve+bcast", "pass", "pass.compute0", "npass", "compact+load", "classify", "chain"]
     print("exact" if mode else "tree ", f"its {st[0]} trials {st[1]}", " ".join(f"{a}={b}" for a, b in zip(names, c)), f"per pass {c[2] / max(c[4], 1):.0f} per solve {c[1] / max(st[1], 1):.0f}")
