@@ -534,6 +534,101 @@ __device__ __forceinline__ double ordered_add_pipe(double tot, const double* __r
 #undef MORB_ADD8_WAIT
   return tot;
 }
+// The same sums on the FP64 matrix core.  v_mfma_f64_4x4x4_4b_f64 computes D[b][i][j] = C[b][i][j] + sum_k A[b][i][k] B[b][k][j] for four 4 x 4
+// blocks b; on gfx950 the four products are added one after the other, k = 0 .. 3, each sum rounded to double — with B = 1 that is
+// (((c + a0) + a1) + a2) + a3, bit for bit what four dependent v_add_f64 produce (tools/micro/mfma_chain.hip: 262 144 random accumulations with
+// mixed signs, magnitudes 2^-30 .. 2^30 and near-total cancellation, all equal; k_mfma_order_selftest repeats the check when a handle is created and
+// the VALU chain above stays as the form a device that fails it would run).  One instruction therefore advances 16 independent ordered sums
+// (b, i) by FOUR edges in 4 passes; a dependent MFMA issues after ~25 cycles, two interleaved chains at ~18 each: 28 sums = two accumulators at
+// ~9 cycles per edge where the v_add_f64 chain measured 17 inside this kernel (profiles/r05/README.md).
+// Layout (found with one-hot operands): A lane = 16 k + 4 b + i, B lane = 16 k + 4 b + j, C / D lane = 16 i + 4 b + j.  Lane l of the summing wave
+// reads entry (l & 15) [+ 16 for the second accumulator] of edge row e + (l >> 4); sum c (< 16) comes out in lanes 16 (c & 3) + 4 (c >> 2) + j.
+// The rows [m, m16) have been zeroed by the workers (x + 0.0 is exact and the running sums are never -0.0).  ROWS is a multiple of 16.
+template <int STRIDE, int ROWS>
+__device__ __forceinline__ void ordered_add_mfma(double& d0, double& d1, const double* __restrict__ sC, int lane, int m16) {
+  static_assert(ROWS % 16 == 0, "whole batches");
+  const double* p = sC + (lane >> 4) * STRIDE + (lane & 15);
+  double v[8], w[8];
+  // four rows: the two accumulators take their terms, and the registers of a LATER batch are requested in the instructions' shadow (a dependent
+  // MFMA cannot issue for ~25 cycles; the read issues meanwhile).  Empty asm statements pin that order.
+#define MORB_STEP4(use, t, ld, row)                                                                                 \
+  do {                                                                                                              \
+    d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(use[2 * (t)], 1.0, d0, 0, 0, 0);                                        \
+    d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(use[2 * (t) + 1], 1.0, d1, 0, 0, 0);                                    \
+    ld[2 * (t)] = p[((row) + 4 * (t)) * STRIDE]; ld[2 * (t) + 1] = p[((row) + 4 * (t)) * STRIDE + 16];              \
+    asm volatile("" : "+v"(d0), "+v"(d1) : : "memory");                                                             \
+  } while (0)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { v[2 * t] = p[4 * t * STRIDE]; v[2 * t + 1] = p[4 * t * STRIDE + 16]; }
+  asm volatile("" : "+v"(d0), "+v"(d1) : : "memory");
+  int e = 0;
+  for (; e + 32 <= m16; e += 32) {
+    const int r1 = e + 16, r2 = e + 32 <= ROWS - 16 ? e + 32 : ROWS - 16;   // (reads never leave the buffer)
+    MORB_STEP4(v, 0, w, r1); MORB_STEP4(v, 1, w, r1); MORB_STEP4(v, 2, w, r1); MORB_STEP4(v, 3, w, r1);
+    MORB_STEP4(w, 0, v, r2); MORB_STEP4(w, 1, v, r2); MORB_STEP4(w, 2, v, r2); MORB_STEP4(w, 3, v, r2);
+  }
+  if (e < m16) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(v[2 * t], 1.0, d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(v[2 * t + 1], 1.0, d1, 0, 0, 0);
+    }
+  }
+#undef MORB_STEP4
+}
+// One accumulator (16 sums) per wave: a dependent MFMA every ~25 cycles, the reads of the rows 32 ahead in its shadow.  Two waves on two SIMDs carry the
+// 28 sums at ~6.5 cycles per edge (sC16 = sC + 16 x the wave's index; ROWS is a multiple of 32).
+template <int STRIDE, int ROWS>
+__device__ __forceinline__ void ordered_add_mfma1(double& d, const double* __restrict__ sC16, int lane, int m16) {
+  static_assert(ROWS % 32 == 0, "whole batches");
+  const double* p = sC16 + (lane >> 4) * STRIDE + (lane & 15);
+  double r[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) r[t] = p[4 * t * STRIDE];
+  asm volatile("" : "+v"(d) : : "memory");
+  int e = 0;
+  for (; e + 32 <= m16; e += 32) {
+    const double* q = p + (e + 32 <= ROWS - 32 ? e + 32 : ROWS - 32) * STRIDE;   // (reads never leave the buffer)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      d = __builtin_amdgcn_mfma_f64_4x4x4f64(r[t], 1.0, d, 0, 0, 0);
+      r[t] = q[4 * t * STRIDE];
+      asm volatile("" : "+v"(d) : : "memory");
+    }
+  }
+  if (e < m16) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) d = __builtin_amdgcn_mfma_f64_4x4x4f64(r[t], 1.0, d, 0, 0, 0);
+  }
+}
+// one wave: `rounds` accumulations of four pseudo-random terms per lane group through the matrix core and through dependent v_add_f64; *bad counts
+// the results that differ in any bit
+__global__ __launch_bounds__(64) void k_mfma_order_selftest(int rounds, int* __restrict__ bad) {
+  const int lane = threadIdx.x;
+  unsigned long long x = 0x9E3779B97F4A7C15ull * (unsigned long long)(lane + 1);
+  auto next = [&]() {   // xorshift64* -> a double with a random sign, a full mantissa and an exponent in [-30, 30]
+    x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+    const unsigned long long r = x * 0x2545F4914F6CDD1Dull;
+    const unsigned long long expo = 1023ull - 30ull + (r >> 52) % 61ull;
+    return __longlong_as_double((long long)((r & 0x800FFFFFFFFFFFFFull) | (expo << 52)));
+  };
+  const int c16 = 4 * ((lane >> 2) & 3) + (lane >> 4);   // the sum this lane's C / D register holds
+  const int s16 = lane & 15, dl = 16 * (s16 & 3) + 4 * (s16 >> 2);   // the sum this lane's A register feeds, and a D lane that holds it
+  int nbad = 0;
+  double c = 0.0;
+  for (int r = 0; r < rounds; ++r) {
+    double a = next();
+    const double cs = __shfl(c, dl), a0s = __shfl(a, s16);
+    if ((r & 3) == 1 && (lane >> 4) == 1) a = -(cs + a0s) * (1.0 + 0x1p-40 * (double)(x & 1023));   // the second term nearly cancels the running sum
+    double ref = c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const double ak = __shfl(a, c16 + 16 * k); asm volatile("v_add_f64 %0, %0, %1" : "+v"(ref) : "v"(ak)); }
+    c = __builtin_amdgcn_mfma_f64_4x4x4f64(a, 1.0, c, 0, 0, 0);
+    nbad += __double_as_longlong(c) != __double_as_longlong(ref);
+    if ((r & 15) == 15) c = next();   // a fresh running sum now and then
+  }
+  if (nbad) atomicAdd(bad, nbad);
+}
 #ifdef MORB_PO_TRACE
 __device__ double g_poTrace[6 * 520];
 __device__ int g_poTraceN;
@@ -814,11 +909,20 @@ __global__ __launch_bounds__(NT) void k_pose_opt(int cap, const int* __restrict_
 //  * In the edge-order mode wave 0 owns the 28 ordered sums and the 6 x 6 solve; waves 1 .. 7 compute the edges.  A stage is 448 edges:
 //    while wave 0 adds stage s, the workers already compute stage s + 1.
 //  * The solve, exp and pose update run on wave 0 only; the other waves pick the new pose up from LDS (they used to repeat all of it).
-#ifndef MORB_PO2_IDLE4
-#define MORB_PO2_IDLE4 0   // edge-order mode: wave 4 — the wave that shares SIMD 0 with the summing wave — takes no edges (measured below)
+#ifndef MORB_PO2_EPT
+#define MORB_PO2_EPT 4   // edges a worker thread keeps in registers per round
 #endif
-constexpr int PO2_NT = 512, PO2_NW = PO2_NT / 64, PO2_EPT = 4, PO2_STAGE = PO2_NT - 64 - (MORB_PO2_IDLE4 ? 64 : 0);   // edges per stage (edge-order mode)
-constexpr int PO2_MAX_CAP = PO2_EPT * PO2_STAGE;   // 1536 features (1792 when wave 4 works too): larger frames take k_pose_opt
+#ifndef MORB_PO2_CHAIN_WAVES
+#define MORB_PO2_CHAIN_WAVES 2   // matrix-core chain: waves that carry the 28 ordered sums (1: two accumulators in wave 0; 2: one each in waves 0 and 1)
+#endif
+constexpr int PO2_NT = 512, PO2_NW = PO2_NT / 64, PO2_EPT = MORB_PO2_EPT;
+// edges per stage of the edge-order mode: every wave but the summing one(s) computes edges
+__host__ __device__ constexpr int po2_stage(bool mfma) { return PO2_NT - 64 * (mfma ? MORB_PO2_CHAIN_WAVES : 1); }
+// matrix-core chain: the FIRST stage is computed by all eight waves (the summing waves have nothing to add yet) and holds PO2_NT edges
+__host__ __device__ constexpr int po2_rows(bool mfma) { return mfma ? PO2_NT : po2_stage(false); }   // rows of the contribution buffer
+__host__ __device__ constexpr int po2_max_cap(bool ordered, bool mfma) {   // larger frames take k_pose_opt
+  return !ordered ? PO2_EPT * PO2_NT : mfma ? PO2_NT + (PO2_EPT - 1) * po2_stage(true) : PO2_EPT * po2_stage(false);
+}
 
 struct PoEdge { float o[3], X[3], info; int right; };
 
@@ -860,24 +964,30 @@ extern "C" int morb_po2_cycles(unsigned long long* out) { (void)hipMemcpyFromSym
 #define PO2_T0(v) const long long v = clock64()
 #define PO2_ADD(slot, v) do { if (f == 0 && tid == 0) g_po2Cyc[slot] += (unsigned long long)(clock64() - v); } while (0)
 #define PO2_CNT(slot) do { if (f == 0 && tid == 0) g_po2Cyc[slot] += 1; } while (0)
+#define PO2_ADD_T(slot, v, t) do { if (f == 0 && tid == (t)) g_po2Cyc[slot] += (unsigned long long)(clock64() - v); } while (0)   // (timed by thread t)
 #else
+#define PO2_ADD_T(slot, v, t)
 #define PO2_T0(v)
 #define PO2_ADD(slot, v)
 #define PO2_CNT(slot)
 #endif
-template <bool FISH, bool ORDERED>
+template <bool FISH, bool ORDERED, bool MFMA>
 __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __restrict__ count, const uint8_t* __restrict__ hasMP,
                                                       const float* __restrict__ obs, const float* __restrict__ invSigma2,
                                                       const float* __restrict__ Xw, Cam cam, Rig rig, const int* __restrict__ nLeft,
                                                       float* __restrict__ poseIO, uint8_t* __restrict__ outlier,
                                                       int* __restrict__ nInliers, int* __restrict__ stats) {
   constexpr int NT = PO2_NT, NW = PO2_NW;
-  constexpr int W0 = ORDERED ? 64 : 0;          // first worker thread (edge-order mode: wave 0 adds and solves)
-  constexpr bool IDLE4 = ORDERED && MORB_PO2_IDLE4;   // ... and wave 4, its SIMD's other wave, stays out of the FP64 pipe the sums run on
-  constexpr int NWORK = NT - W0 - (IDLE4 ? 64 : 0);   // edges per stage
+  constexpr int NCW = MFMA ? MORB_PO2_CHAIN_WAVES : 1;   // waves that carry the ordered sums (wave 0 also solves)
+  constexpr int W0 = ORDERED ? 64 * NCW : 0;    // first worker thread
+  constexpr int NWORK = NT - W0;                // edges per stage
+  static_assert(!ORDERED || NWORK == po2_stage(MFMA), "stage size");
   extern __shared__ __align__(16) uint8_t po2Raw[];
-  double* sC = reinterpret_cast<double*>(po2Raw);                                          // ORDERED: [NWORK][PO_PITCH] contributions of a stage
-  uint16_t* actList = reinterpret_cast<uint16_t*>(po2Raw + (ORDERED ? (size_t)NWORK * PO_PITCH * 8 : 0));   // [cap] active features, in order
+  constexpr int ROWS = po2_rows(MFMA);          // rows of the contribution buffer
+  constexpr int S0 = ORDERED && MFMA ? NT : NWORK;   // edges of the first stage (matrix-core chain: every wave computes, the summing ones included)
+  double* sC = reinterpret_cast<double*>(po2Raw);                                          // ORDERED: [ROWS][PO_PITCH] contributions of a stage
+  uint16_t* actList = reinterpret_cast<uint16_t*>(po2Raw + (ORDERED ? (size_t)ROWS * PO_PITCH * 8 + 32 : 0));   // [cap] active features, in order
+
   __shared__ double red[NW];
   __shared__ double sH[NW][28];
   __shared__ double sTot[2][28];     // H (lower triangle 0 .. 20), b (21 .. 26), robust chi2 (27) at the state last built / at the trial state
@@ -890,7 +1000,10 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
   const size_t base = (size_t)f * cap;
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   // this thread's row in a stage (-1: not a worker)
-  const int wrow = !ORDERED ? tid : (wv == 0 || (IDLE4 && wv == 4)) ? -1 : ((IDLE4 && wv > 4) ? tid - 128 : tid - 64);
+  const int wrow = tid >= W0 ? tid - W0 : -1;
+  // the edge thread `tid` computes in stage s (its row of the stage, the stage's first edge)
+  auto stage_row = [&](int s) { return ORDERED && (s > 0 || !MFMA) ? wrow : tid; };
+  auto stage_base = [&](int s) { return s == 0 ? 0 : S0 + (s - 1) * NWORK; };
 
   PO2_T0(tAll);
   int nInit = 0;
@@ -917,26 +1030,43 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
     PO2_T0(tp); PO2_CNT(4);
     const SE3 Pr = FISH ? se3_mul(rig.Trl, P) : P;
     if (ORDERED) {
-      double tot = 0;   // lanes 0 .. 27 of wave 0: entry `lane`
+      double tot = 0, tot1 = 0;   // VALU chain: lanes 0 .. 27 of wave 0 hold entry `lane`; matrix-core chain: two accumulators in D layout
+      const int nAct16 = (nAct + 15) & ~15;
 #pragma unroll
       for (int s = 0; s < PO2_EPT; ++s) {   // (unrolled: ed[s] must stay in registers)
-        if (s * NWORK >= nAct) break;
+        const int e0 = stage_base(s), row = stage_row(s);
+        if (e0 >= nAct) break;
         double con[28];
-        const int e = s * NWORK + wrow;
-        const bool mine = wrow >= 0 && e < nAct;
-        if (mine) po2_contrib<FISH>(cam, rig, P, Pr, ed[s], robust, deltaMono, deltaStereo, con);   // (beside wave 0's sums of stage s - 1)
-        if (s == 0) PO2_ADD(3, tp);
-        __syncthreads();                       // stage s - 1 has been added
+        const int e = e0 + row;
+        const bool mine = row >= 0 && e < nAct;
+        if (mine) po2_contrib<FISH>(cam, rig, P, Pr, ed[s], robust, deltaMono, deltaStereo, con);   // (beside the sums of stage s - 1)
+        if (s == 0) PO2_ADD_T(3, tp, NT - 64);   // (a worker's edge math of the first stage)
+        // stage s - 1 has been added.  (The first stage needs no barrier — the previous pass ended with one — and without it a wave's 28 LDS
+        // writes start as soon as ITS edge is done instead of all 512 threads' 114 KB arriving at the LDS together: 1.5 k -> 0.x k cycles.)
+        if (s > 0) __syncthreads();
         if (mine) {
 #pragma unroll
-          for (int k = 0; k < 28; ++k) sC[wrow * PO_PITCH + k] = con[k];
+          for (int k = 0; k < 28; ++k) sC[row * PO_PITCH + k] = con[k];
+        } else if (MFMA && row >= 0 && e < nAct16) {   // the matrix core takes four rows at a time: the last batch's missing rows add 0.0
+#pragma unroll
+          for (int k = 0; k < 28; ++k) sC[row * PO_PITCH + k] = 0.0;
         }
         __syncthreads();
         PO2_T0(tch);
-        if (tid < 28) tot = ordered_add_pipe<PO_PITCH, NWORK>(tot, sC + tid, min(NWORK, nAct - s * NWORK));
+        const int m = min(s == 0 ? S0 : NWORK, (MFMA ? nAct16 : nAct) - e0);
+        if (MFMA && NCW == 2) { if (wv < 2) ordered_add_mfma1<PO_PITCH, ROWS>(tot, sC + 16 * wv, lane, m); }
+        else if (MFMA) { if (wv == 0) ordered_add_mfma<PO_PITCH, ROWS>(tot, tot1, sC, lane, m); }
+        else if (tid < 28) tot = ordered_add_pipe<PO_PITCH, ROWS>(tot, sC + tid, m);
         PO2_ADD(7, tch);
       }
-      if (tid < 28) sTot[buf][tid] = tot;
+      if (MFMA) {
+        const int c16 = 4 * ((lane >> 2) & 3) + (lane >> 4);
+        if (NCW == 2) { if (wv < 2 && (lane & 3) == 0 && 16 * wv + c16 < 28) sTot[buf][16 * wv + c16] = tot; }
+        else if (wv == 0 && (lane & 3) == 0) {
+          sTot[buf][c16] = tot;
+          if (c16 < 12) sTot[buf][16 + c16] = tot1;
+        }
+      } else if (tid < 28) sTot[buf][tid] = tot;
       __syncthreads();
       PO2_ADD(2, tp);
     } else {
@@ -981,8 +1111,8 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
     }
 #pragma unroll
     for (int s = 0; s < PO2_EPT; ++s) {
-      const int e = s * NWORK + wrow;
-      if (wrow >= 0 && e < nAct) {
+      const int e = stage_base(s) + stage_row(s);
+      if (stage_row(s) >= 0 && e < nAct) {
         const int i = actList[e];
         ed[s].o[0] = obs[(base + i) * 3]; ed[s].o[1] = obs[(base + i) * 3 + 1]; ed[s].o[2] = obs[(base + i) * 3 + 2];
         ed[s].X[0] = Xw[(base + i) * 3]; ed[s].X[1] = Xw[(base + i) * 3 + 1]; ed[s].X[2] = Xw[(base + i) * 3 + 2];
@@ -1096,17 +1226,23 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
   PO2_ADD(0, tAll);
 }
 template <bool FISH>
-static int launch_pose_opt2(bool ordered, int nframes, hipStream_t st, int cap, const int* d_count, const uint8_t* d_hasMP, const float* d_obs,
+static int launch_pose_opt2(bool ordered, bool mfmaChain, int nframes, hipStream_t st, int cap, const int* d_count, const uint8_t* d_hasMP, const float* d_obs,
                             const float* d_invSigma2, const float* d_Xw, const Cam& cam, const Rig& rig, const int* d_nLeft, float* d_pose,
                             uint8_t* d_outlier, int* d_nInliers, int* d_stats) {
   const size_t listBytes = ((size_t)cap * 2 + 15) & ~(size_t)15;
   if (ordered) {
-    const size_t lds = (size_t)PO2_STAGE * PO_PITCH * 8 + listBytes;
-    MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt2<FISH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_pose_opt2<FISH, true>), dim3(nframes), dim3(PO2_NT), lds, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
-                       d_nLeft, d_pose, d_outlier, d_nInliers, d_stats);
+    const size_t lds = (size_t)po2_rows(mfmaChain) * PO_PITCH * 8 + 32 + listBytes;   // (+32: the second accumulator's lanes 12 .. 15 read past the last row)
+    if (mfmaChain) {
+      MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt2<FISH, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((k_pose_opt2<FISH, true, true>), dim3(nframes), dim3(PO2_NT), lds, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
+                         d_nLeft, d_pose, d_outlier, d_nInliers, d_stats);
+    } else {
+      MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt2<FISH, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((k_pose_opt2<FISH, true, false>), dim3(nframes), dim3(PO2_NT), lds, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
+                         d_nLeft, d_pose, d_outlier, d_nInliers, d_stats);
+    }
   } else {
-    hipLaunchKernelGGL((k_pose_opt2<FISH, false>), dim3(nframes), dim3(PO2_NT), listBytes, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
+    hipLaunchKernelGGL((k_pose_opt2<FISH, false, false>), dim3(nframes), dim3(PO2_NT), listBytes, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
                        d_nLeft, d_pose, d_outlier, d_nInliers, d_stats);
   }
   return MORB_OK;
@@ -2000,6 +2136,7 @@ struct morb_optimizer {
   bool arenaCreate = false;    // morb_ba_problem_create carves the problem from `work` / `stage` (the one-shot entry points set this around the call)
   double* scalPinned = nullptr;   // pinned scalars of an arena-mode problem
   int exactOrder = 0;             // PoseOptimization: 1 = edge-order sums (k_pose_opt<.., ORDERED>), the LM path of g2o decision for decision
+  int mfmaChain = 0;              // ... carried by the FP64 matrix core (this device passed k_mfma_order_selftest) instead of dependent v_add_f64
 };
 
 struct morb_ba_problem {
@@ -2044,6 +2181,20 @@ int morb_optimizer_create(morb_optimizer** out, int device) {
     delete o;
     set_error("cannot create stream");
     return MORB_ERR_HIP;
+  }
+  {  // may the matrix core carry the edge-order sums?  (one 64-thread launch per handle; MORB_PO2_CHAIN = valu | mfma overrides)
+    const char* force = getenv("MORB_PO2_CHAIN");
+    if (force && (!strcmp(force, "valu") || !strcmp(force, "mfma"))) o->mfmaChain = force[0] == 'm';
+    else {
+      int* d_bad = nullptr;
+      int bad = -1;
+      if (hipMalloc((void**)&d_bad, sizeof(int)) == hipSuccess && hipMemsetAsync(d_bad, 0, sizeof(int), o->stream) == hipSuccess) {
+        hipLaunchKernelGGL(k_mfma_order_selftest, dim3(1), dim3(64), 0, o->stream, 4096, d_bad);
+        if (hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, o->stream) != hipSuccess || hipStreamSynchronize(o->stream) != hipSuccess) bad = -1;
+      }
+      if (d_bad) (void)hipFree(d_bad);
+      o->mfmaChain = bad == 0;
+    }
   }
   *out = o;
   return MORB_OK;
@@ -2131,8 +2282,8 @@ int morb_pose_optimization_batch(morb_optimizer* o, int nframes, int cap, const 
   // empty stage per pass — 0.447 against 0.400 ms per launch at 600 features; k_pose_opt's 256 threads with 2 - 3 edges each stay the faster
   // form there.  Frames of ~1200 features of which half hold a map point — tracking — are where the compaction of k_pose_opt2 pays.)
   const bool smallTree = !o->exactOrder && cap <= 640;
-  if (cap <= PO2_MAX_CAP && !smallTree && !getenv("MORB_PO_OLD")) {
-    const int rc = launch_pose_opt2<false>(o->exactOrder != 0, nframes, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig, nullptr, d_pose,
+  if (cap <= po2_max_cap(o->exactOrder != 0, o->mfmaChain != 0) && !smallTree && !getenv("MORB_PO_OLD")) {
+    const int rc = launch_pose_opt2<false>(o->exactOrder != 0, o->mfmaChain != 0, nframes, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig, nullptr, d_pose,
                                            d_outlier, d_nInliers, d_stats);
     if (rc != MORB_OK) return rc;
   } else
@@ -2165,8 +2316,8 @@ int morb_pose_optimization_fisheye_batch(morb_optimizer* o, int nframes, int cap
     for (int i = 0; i < 4; ++i) rig.Trl.q[i] = q[i] / n;
     for (int i = 0; i < 3; ++i) rig.Trl.t[i] = Trl7[4 + i];
   }
-  if (cap <= PO2_MAX_CAP && !getenv("MORB_PO_OLD")) {
-    const int rc = launch_pose_opt2<true>(o->exactOrder != 0, nframes, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig, d_nLeft, d_pose,
+  if (cap <= po2_max_cap(o->exactOrder != 0, o->mfmaChain != 0) && !getenv("MORB_PO_OLD")) {
+    const int rc = launch_pose_opt2<true>(o->exactOrder != 0, o->mfmaChain != 0, nframes, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig, d_nLeft, d_pose,
                                           d_outlier, d_nInliers, d_stats);
     if (rc != MORB_OK) return rc;
   } else

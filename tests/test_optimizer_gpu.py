@@ -47,6 +47,44 @@ def test_pose_optimization_matches_oracle():
         assert np.abs(pose[f] - p["true"]).max() < 0.02   # and it actually converged to the truth
 
 
+def test_edge_order_sums_on_the_matrix_core_equal_the_vector_chain(monkeypatch):
+    """The edge-order sums run on v_mfma_f64_4x4x4_4b_f64 (four terms per instruction, added one after the other: optimizer.hip
+    `ordered_add_mfma1`, tools/micro/mfma_chain.hip) when the device passes the self-test of morb_optimizer_create, on dependent v_add_f64
+    otherwise.  Same order, same roundings: every output BIT of the two forms is equal — poses, flags, iteration and trial counts — at
+    edge counts on both sides of the stage boundaries (512 edges in the first stage, 384 in the later ones, batches of 16 rows)."""
+    import torch
+    from morb_slam_amd import Optimizer
+    sizes = [40, 511, 512, 513, 527, 529, 600, 895, 896, 897, 1200, 1279, 1280, 1500, 1664]
+    probs = [make_pose_problem(n, seed=100 + i) for i, n in enumerate(sizes)]
+    for p in probs[:-4]:
+        p["hasMP"][:] = 1          # the first round's edge count IS the size (later rounds drop the outliers: other counts)
+    cap = max(len(p["hasMP"]) for p in probs)
+    pad = lambda a: np.pad(a, [(0, cap - len(a))] + [(0, 0)] * (a.ndim - 1))
+    t = [torch.from_numpy(np.stack([pad(p[k]) for p in probs])).cuda() for k in ("hasMP", "obs", "invSigma2", "Xw")]
+    pose0 = torch.from_numpy(np.stack([p["pose0"] for p in probs])).cuda()
+    cnt = torch.tensor([len(p["hasMP"]) for p in probs], dtype=torch.int32, device="cuda")
+    res = {}
+    for form in ("valu", "mfma", ""):
+        if form:
+            monkeypatch.setenv("MORB_PO2_CHAIN", form)
+        else:
+            monkeypatch.delenv("MORB_PO2_CHAIN")      # the handle decides by its self-test
+        opt = Optimizer()
+        opt.set_exact_order(True)
+        pose = pose0.clone()
+        nin, outl, stats = opt.PoseOptimization(t[0], t[1], t[2], t[3], pose, probs[0]["cam"], count=cnt)
+        torch.cuda.synchronize()
+        res[form] = (nin.cpu().numpy(), outl.cpu().numpy(), stats.cpu().numpy(), pose.cpu().numpy().view(np.uint32))
+    for a, b in zip(res["valu"], res["mfma"]):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(res["mfma"], res[""]):            # MI355X passes the self-test: the default IS the matrix-core form
+        np.testing.assert_array_equal(a, b)
+    for f in (0, 3, 7, 9):                            # and both equal the oracle's LM path
+        r, pe, oe, se = O.pose_optimization(probs[f])
+        assert res["mfma"][0][f] == r and int(res["mfma"][2][f][0]) == int(se[0]) and int(res["mfma"][2][f][1]) == int(se[1])
+        np.testing.assert_array_equal(res["mfma"][1][f, :sizes[f]], oe)
+
+
 def test_pose_optimization_tree_sum_mode():
     """The default (morb_optimizer_set_exact_order(0)): tree sums — same poses, flags and outer iterations; the trial count may differ by the
     rare flip of a ~0 rho (observed: 50 vs 49 in one of nine problems)."""
