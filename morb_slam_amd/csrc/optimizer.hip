@@ -920,6 +920,11 @@ constexpr int PO2_NT = 512, PO2_NW = PO2_NT / 64, PO2_EPT = MORB_PO2_EPT;
 __host__ __device__ constexpr int po2_stage(bool mfma) { return PO2_NT - 64 * (mfma ? MORB_PO2_CHAIN_WAVES : 1); }
 // matrix-core chain: the FIRST stage is computed by all eight waves (the summing waves have nothing to add yet) and holds PO2_NT edges
 __host__ __device__ constexpr int po2_rows(bool mfma) { return mfma ? PO2_NT : po2_stage(false); }   // rows of the contribution buffer
+#ifndef MORB_PO2_SPEC
+#define MORB_PO2_SPEC 1   // matrix-core chain: the last wave computes no edges; beside every trial's pass it solves the trial that FOLLOWS A REJECTION
+#endif
+// ... which leaves seven waves for the first stage and five for the later ones (frames too large for that keep all waves on the edges)
+__host__ __device__ constexpr int po2_spec_cap() { return MORB_PO2_SPEC ? (PO2_NT - 64) + (PO2_EPT - 1) * (po2_stage(true) - 64) : 0; }
 __host__ __device__ constexpr int po2_max_cap(bool ordered, bool mfma) {   // larger frames take k_pose_opt
   return !ordered ? PO2_EPT * PO2_NT : mfma ? PO2_NT + (PO2_EPT - 1) * po2_stage(true) : PO2_EPT * po2_stage(false);
 }
@@ -941,18 +946,27 @@ __device__ __forceinline__ void po2_contrib(const Cam& cam, const Rig& rig, cons
   // g2o's own expressions (base_unary_edge.hpp:54-66): omega_r = -Omega e (then * rho'), b += J^T omega_r, H += J^T (rho' Omega) J
   const double wr[3] = {-info * err[0] * w, -info * err[1] * w, -info * err[2] * w};
   const double wo = w * info;
+  // Entries of Jp that are zero BY CONSTRUCTION are left out of the sums: pinhole (jac_pose, unary): Jp[0][4], Jp[1][3], Jp[2][4] (and a mono
+  // edge's whole third row, which a stereo lane of the same wave needs); KB8: the third row.  Their products are exact zeros, x + 0 = x, and a
+  // sum that starts with its first term instead of 0.0 + term differs at most in the SIGN of a zero — which the edge-order sums (they start at
+  // +0.0 and can never reach -0.0) and the tree sums do not see.  63 -> 45 products for H, 18 -> 15 for b: a sixth of the edge's FP64 instructions.
+  auto nz = [](int k, int r) { return FISH ? k < 2 : !((k == 0 && r == 4) || (k == 1 && r == 3) || (k == 2 && r == 4)); };
   int q = 0;
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
     double bb = 0;
+    bool first = true;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) bb += Jp[k * 6 + r] * wr[k];   // (mono: row 2 and err[2] are zero)
+    for (int k = 0; k < 3; ++k)
+      if (nz(k, r)) { const double t = Jp[k * 6 + r] * wr[k]; bb = first ? t : bb + t; first = false; }
     con[21 + r] = bb;
 #pragma unroll
     for (int cc = 0; cc <= r; ++cc) {   // the LOWER triangle, (J_r w Omega) J_c as Eigen forms it: LinearSolverDense's LDLT reads that triangle
       double h = 0;
+      bool firstH = true;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) h += Jp[k * 6 + r] * wo * Jp[k * 6 + cc];
+      for (int k = 0; k < 3; ++k)
+        if (nz(k, r) && nz(k, cc)) { const double t = Jp[k * 6 + r] * wo * Jp[k * 6 + cc]; h = firstH ? t : h + t; firstH = false; }
       con[q++] = h;
     }
   }
@@ -994,6 +1008,8 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
   __shared__ double sPose[8];        // the trial pose (wave 0 -> everybody) + scale
   __shared__ double sKeep[3][7];     // uniform poses that would otherwise sit in every thread's registers: T0, Teval, the trial's backup
   __shared__ int sFlag[2];
+  __shared__ double sSpec[2][8];     // the speculation wave's trial pose + scale, by trial parity
+  __shared__ int sSpecFlag[2];
   __shared__ int sWaveCnt[NW];
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = min(count ? count[f] : cap, cap);
@@ -1001,9 +1017,15 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   // this thread's row in a stage (-1: not a worker)
   const int wrow = tid >= W0 ? tid - W0 : -1;
+  // Speculation wave (matrix-core chain, frames that leave room for it): a rejected trial is followed by a trial from the SAME state with
+  // lambda * ni — everything that solve needs is known when the rejected trial's pass STARTS.  The last wave computes it beside the pass
+  // (no edges of its own), and the ~5 k cycles of LDL^T + exp + pose update leave the critical path of every trial that follows a rejection
+  // (more than half of them: near convergence g2o's LM rejects its way up in lambda, up to ten trials per iteration).
+  const bool spec = ORDERED && MFMA && MORB_PO2_SPEC && cap <= po2_spec_cap();
+  const int s0 = spec ? S0 - 64 : S0, nwork = spec ? NWORK - 64 : NWORK;   // edges of the first / of a later stage
   // the edge thread `tid` computes in stage s (its row of the stage, the stage's first edge)
-  auto stage_row = [&](int s) { return ORDERED && (s > 0 || !MFMA) ? wrow : tid; };
-  auto stage_base = [&](int s) { return s == 0 ? 0 : S0 + (s - 1) * NWORK; };
+  auto stage_row = [&](int s) { return ORDERED && (s > 0 || !MFMA) ? (wrow < nwork ? wrow : -1) : (tid < s0 ? tid : -1); };
+  auto stage_base = [&](int s) { return s == 0 ? 0 : s0 + (s - 1) * nwork; };
 
   PO2_T0(tAll);
   int nInit = 0;
@@ -1026,9 +1048,57 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
   int nAct = 0;
 
   // H, b, chi2 of the active edges at pose P -> sTot[buf]
-  auto pass = [&](const SE3& P, int buf) {
+  // one LM trial's solve, all lanes of the calling wave alike: (H + lam I) x = b of sTot[src], Tn = exp(x) Tb, scale = x . (lam x + b) + 1e-3; in two
+  // parts, because the speculation wave has a workgroup barrier to attend in between
+  auto solve_a = [&](int src, double lam, double (&x)[6], double (&b)[6]) {
+    double H[36];
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int cc = 0; cc <= r; ++cc) { const double v = sTot[src][q++]; H[r * 6 + cc] = v; H[cc * 6 + r] = v; }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) { b[r] = sTot[src][21 + r]; H[r * 6 + r] += lam; x[r] = 0; }
+    return ldlt6(H, b, x);
+  };
+  auto solve_b = [&](bool ok2, double lam, const double (&x)[6], const double (&b)[6], const SE3& Tb, double* out8, int* outFlag) {
+    const SE3 Tn = se3_mul(se3_exp(x), Tb);
+    double scale = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) scale += x[r] * (lam * x[r] + b[r]);
+    scale += 1e-3;
+    if (lane == 0) {
+      for (int k = 0; k < 4; ++k) out8[k] = Tn.q[k];
+      for (int k = 0; k < 3; ++k) out8[4 + k] = Tn.t[k];
+      out8[7] = scale;
+      *outFlag = ok2 ? 1 : 0;
+    }
+  };
+  auto solve_trial = [&](int src, double lam, const SE3& Tb, double* out8, int* outFlag) {
+    double x[6], b[6];
+    const bool ok2 = solve_a(src, lam, x, b);
+    solve_b(ok2, lam, x, b, Tb, out8, outFlag);
+  };
+  // specLam >= 0: beside the pass, the speculation wave solves the trial that follows if THIS one is rejected (state sTot[buf ^ 1], pose sKeep[2])
+  auto pass = [&](const SE3& P, int buf, double specLam, int specSlot) {
     PO2_T0(tp); PO2_CNT(4);
     const SE3 Pr = FISH ? se3_mul(rig.Trl, P) : P;
+    if (ORDERED && MFMA && spec && wv == NW - 1) {
+      // the speculation wave: the LDL^T beside the first stage's edge math, exp and the pose update beside its sums; it meets the other waves at
+      // every barrier of the pass (s_barrier counts arrivals, whichever instruction a wave arrives at)
+      double x[6], b[6];
+      bool ok2 = false;
+      if (specLam >= 0) ok2 = solve_a(buf ^ 1, specLam, x, b);
+      __syncthreads();                                   // the first stage's contributions are in LDS
+      if (specLam >= 0) solve_b(ok2, specLam, x, b, get(2), sSpec[specSlot], &sSpecFlag[specSlot]);
+      for (int s = 1; s < PO2_EPT; ++s) {
+        if (stage_base(s) >= nAct) break;
+        __syncthreads();
+        __syncthreads();
+      }
+      __syncthreads();
+      return;
+    }
     if (ORDERED) {
       double tot = 0, tot1 = 0;   // VALU chain: lanes 0 .. 27 of wave 0 hold entry `lane`; matrix-core chain: two accumulators in D layout
       const int nAct16 = (nAct + 15) & ~15;
@@ -1053,7 +1123,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
         }
         __syncthreads();
         PO2_T0(tch);
-        const int m = min(s == 0 ? S0 : NWORK, (MFMA ? nAct16 : nAct) - e0);
+        const int m = min(s == 0 ? s0 : nwork, (MFMA ? nAct16 : nAct) - e0);
         if (MFMA && NCW == 2) { if (wv < 2) ordered_add_mfma1<PO_PITCH, ROWS>(tot, sC + 16 * wv, lane, m); }
         else if (MFMA) { if (wv == 0) ordered_add_mfma<PO_PITCH, ROWS>(tot, tot1, sC, lane, m); }
         else if (tid < 28) tot = ordered_add_pipe<PO_PITCH, ROWS>(tot, sC + tid, m);
@@ -1123,7 +1193,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
     PO2_ADD(5, tc);
     // ---- optimizer.optimize(10) ----
     int cur = 0;
-    pass(T, cur);
+    pass(T, cur, -1.0, 0);
     double lambda = 0, ni = 2;
     int nBad = 0;
     for (int iter = 0; iter < 10; ++iter) {
@@ -1139,38 +1209,27 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
       double rho = 0;
       int qmax = 0;
       do {
-        put(2, T);           // backup (read behind the barriers of the trial's pass)
         PO2_T0(ts);
-        if (wv == 0) {
-          double H[36], b[6], x[6] = {0, 0, 0, 0, 0, 0};
-          int q = 0;
-#pragma unroll
-          for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int cc = 0; cc <= r; ++cc) { const double v = sTot[cur][q++]; H[r * 6 + cc] = v; H[cc * 6 + r] = v; }
-#pragma unroll
-          for (int r = 0; r < 6; ++r) { b[r] = sTot[cur][21 + r]; H[r * 6 + r] += lambda; }
-          const bool ok2 = ldlt6(H, b, x);
-          const SE3 Tn = se3_mul(se3_exp(x), T);
-          double scale = 0;
-#pragma unroll
-          for (int r = 0; r < 6; ++r) scale += x[r] * (lambda * x[r] + b[r]);
-          scale += 1e-3;
-          if (lane == 0) {
-            for (int k = 0; k < 4; ++k) sPose[k] = Tn.q[k];
-            for (int k = 0; k < 3; ++k) sPose[4 + k] = Tn.t[k];
-            sPose[7] = scale;
-            sFlag[0] = ok2 ? 1 : 0;
-          }
+        double scale;
+        bool ok2;
+        if (spec && qmax > 0) {   // the trial after a rejection: solved beside the rejected trial's pass (same state, lambda * ni: the same bits)
+          const int sl = (trials - 1) & 1;
+          for (int k = 0; k < 4; ++k) T.q[k] = sSpec[sl][k];
+          for (int k = 0; k < 3; ++k) T.t[k] = sSpec[sl][4 + k];
+          scale = sSpec[sl][7];
+          ok2 = sSpecFlag[sl] != 0;
+        } else {
+          put(2, T);           // backup (read behind the barriers of the trial's pass)
+          if (wv == 0) solve_trial(cur, lambda, T, sPose, &sFlag[0]);
+          __syncthreads();
+          for (int k = 0; k < 4; ++k) T.q[k] = sPose[k];
+          for (int k = 0; k < 3; ++k) T.t[k] = sPose[4 + k];
+          scale = sPose[7];
+          ok2 = sFlag[0] != 0;
         }
-        __syncthreads();
-        for (int k = 0; k < 4; ++k) T.q[k] = sPose[k];
-        for (int k = 0; k < 3; ++k) T.t[k] = sPose[4 + k];
-        const double scale = sPose[7];
-        const bool ok2 = sFlag[0] != 0;
         PO2_ADD(1, ts);
         put(1, T);           // Teval
-        pass(T, cur ^ 1);
+        pass(T, cur ^ 1, qmax < 9 ? lambda * ni : -1.0, trials & 1);
         double tempChi = sTot[cur ^ 1][27];
         if (!ok2) tempChi = 1.7976931348623157e308;
         rho = (currentChi - tempChi) / scale;
