@@ -195,6 +195,7 @@ def optimizer_extras(dev_index):
     t = [torch.from_numpy(np.stack([q[k] for q in probs])).to(dev) for k in ("hasMP", "obs", "invSigma2", "Xw")]
     pose0 = torch.from_numpy(np.stack([q["pose0"] for q in probs])).to(dev)
     out = None
+    opt.set_exact_order(False)   # the tree-sum mode first (the trial count may differ from g2o's by one), then the default
     for _ in range(2):
         out = opt.PoseOptimization(t[0], t[1], t[2], t[3], pose0.clone(), probs[0]["cam"], out=out)
     torch.cuda.synchronize(dev)
@@ -205,7 +206,7 @@ def optimizer_extras(dev_index):
         out = opt.PoseOptimization(t[0], t[1], t[2], t[3], poses[k], probs[0]["cam"], out=out)
     torch.cuda.synchronize(dev)
     dtp = (time.perf_counter() - t0) / 10
-    # the deterministic mode (morb_optimizer_set_exact_order: sums in edge order, g2o's LM path decision for decision)
+    # the default mode (morb_optimizer_set_exact_order(1): sums in edge order on the FP64 matrix core, g2o's LM path decision for decision)
     opt.set_exact_order(True)
     out = opt.PoseOptimization(t[0], t[1], t[2], t[3], pose0.clone(), probs[0]["cam"], out=out)
     torch.cuda.synchronize(dev)
@@ -218,7 +219,6 @@ def optimizer_extras(dev_index):
         out = opt.PoseOptimization(t[0], t[1], t[2], t[3], poses[k], probs[0]["cam"], out=out)
     torch.cuda.synchronize(dev)
     dtpe = (time.perf_counter() - t0) / 10
-    opt.set_exact_order(False)
     t0 = time.perf_counter()
     for q in probs[:8]:
         O.pose_optimization(q)
@@ -302,7 +302,8 @@ def optimizer_extras(dev_index):
                                       "note": "frac counts the dense product over all landmarks (zero blocks included), useful_frac only the "
                                               "block pairs g2o forms; ~11 us launch, latency-bound"},
                          "large_windows": large, "concurrent_replicas": replicas},
-            "pose_optimization": {"frames": F, "edges_per_frame": 600, "frames_per_s": F / dtp, "frames_per_s_exact_order_mode": F / dtpe,
+            "pose_optimization": {"frames": F, "edges_per_frame": 600, "frames_per_s": F / dtpe, "frames_per_s_exact_order_mode": F / dtpe, "frames_per_s_tree_sum_mode": F / dtp,
+                                  "mode": "edge-order sums (the default): g2o's LM path decision for decision",
                                   "cpu_oracle_frames_per_s_1core": 1.0 / dcp}}
 
 
@@ -349,7 +350,7 @@ def tracking_extras(dev_index):
     cht.close()
     c1t = TrackingChain(ch.P, ch.cam, ch.kps, ch.desc, ch.count, ch.uRight[:1].contiguous(), one, device=dev_index, exact_order=False)
     out["tree_sum_mode"] = {"frames_per_s": B / dtt, "ms_per_step": dtt * 1e3, "latency_b1_ms": timed(c1t.step, c1t.sync, 50) * 1e3,
-                            "note": "the optimiser's default sums: same poses to ~1e-9 and same outlier flags, LM trial counts within +-2 of g2o's"}
+                            "note": "morb_optimizer_set_exact_order(0), tree sums: same poses to ~1e-9 and same outlier flags, LM trial counts within +-2 of g2o's"}
     c1t.close()
     # the CPU oracle on the same frames, one thread (the reference runs Tracking on one thread): the chain stage by stage
     P = ch.P

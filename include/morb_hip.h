@@ -527,12 +527,14 @@ void morb_optimizer_destroy(morb_optimizer*);
 /* Wait for the work queued on the optimizer's OWN stream (calls made with stream = NULL), not for the device. */
 int morb_optimizer_sync(morb_optimizer*);
 void* morb_optimizer_stream(const morb_optimizer*);   /* the optimizer's own stream (hipStream_t) */
-/* PoseOptimization's deterministic mode.  off (default): the sums over the edges (H, b, the robustified chi2) are per-thread partial sums and a
- * tree — the reference's poses to ~1e-9, identical outlier flags, inlier counts and outer iterations; near convergence rho = dChi2 / scale is ~0
- * and its sign follows the last bits of those sums, so the number of LM TRIALS can differ by one (observed: 50 vs 49 in one of nine problems).
- * on: the sums are taken in edge order, one addition after the other, as g2o's sequential loop over its id-sorted active edges does
- * (sparse_optimizer.cpp:482-487): iterations AND trials are then g2o's, decision for decision (tests/test_optimizer_gpu.py), at 2.7 x the
- * time of a 256-frame batch (chains of dependent FP64 additions).  The C++ drop-in adapter (include/morb/Optimizer.h) turns it on. */
+/* PoseOptimization's deterministic mode.  on (the default since round 5): the sums over the edges (H, b, the robustified chi2) are taken in
+ * edge order, one addition after the other, as g2o's sequential loop over its id-sorted active edges does (sparse_optimizer.cpp:482-487):
+ * iterations AND trials are then g2o's, decision for decision (tests/test_optimizer_gpu.py).  The ordered sums run on the FP64 matrix core
+ * (v_mfma_f64_4x4x4_4b_f64 adds its four products one after the other, each rounded: four edges per instruction) when the device passes the
+ * self-test of morb_optimizer_create, on dependent v_add_f64 otherwise — the same bits either way.
+ * off: per-thread partial sums and a tree — the reference's poses to ~1e-9, identical outlier flags, inlier counts and outer iterations; near
+ * convergence rho = dChi2 / scale is ~0 and its sign follows the last bits of those sums, so the number of LM TRIALS can differ by one
+ * (observed: 50 vs 49 in one of nine problems).  ~3 % faster per 256-frame batch (round 4: 1.7 x; the edge-order mode has closed the gap). */
 int morb_optimizer_set_exact_order(morb_optimizer*, int on);
 
 /* static int Optimizer::PoseOptimization(Frame* pFrame)  Optimizer.h:86, Optimizer.cc:762-1051, for nframes

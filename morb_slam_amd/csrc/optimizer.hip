@@ -456,7 +456,8 @@ __device__ __forceinline__ bool ba_depth_positive(const Rig* rig, const float* o
 // thread + a tree gives other last bits (observed: one trial more or less in one of nine problems).  Edges are taken 256 at a time: every
 // thread writes its edge's 28 contributions to LDS (an inactive edge: exact zeros, which leave a floating-point sum unchanged), lanes 0 .. 27
 // of wave 0 add their entry's 256 values in order.  A chain of dependent FP64 additions per sum: 0.68 ms instead of 0.43 ms per 256 frames of
-// 600 edges (tools/pose_opt_modes.py) — the deterministic MODE of the optimizer (morb_optimizer_set_exact_order), not its default.
+// 600 edges (tools/pose_opt_modes.py; round 4's figures — round 5's k_pose_opt2 runs the ordered sums on the matrix core: 0.41 against 0.40 ms, and the
+// edge-order mode became the default).
 #ifndef MORB_PO_NT
 #define MORB_PO_NT 256   // threads per frame of PoseOptimization's default (tree-sum) mode
 #endif
@@ -2194,7 +2195,7 @@ struct morb_optimizer {
   size_t stageBytes = 0;
   bool arenaCreate = false;    // morb_ba_problem_create carves the problem from `work` / `stage` (the one-shot entry points set this around the call)
   double* scalPinned = nullptr;   // pinned scalars of an arena-mode problem
-  int exactOrder = 0;             // PoseOptimization: 1 = edge-order sums (k_pose_opt<.., ORDERED>), the LM path of g2o decision for decision
+  int exactOrder = 1;             // PoseOptimization: 1 (default) = edge-order sums, the LM path of g2o decision for decision; 0 = tree sums
   int mfmaChain = 0;              // ... carried by the FP64 matrix core (this device passed k_mfma_order_selftest) instead of dependent v_add_f64
 };
 

@@ -75,8 +75,7 @@ class TrackingChain:
         self.m_last = ORBmatcher(0.9, True, device=device)     # TrackWithMotionModel: ORBmatcher(0.9, true)
         self.m_local = ORBmatcher(0.8, True, device=device)    # SearchLocalPoints: ORBmatcher(0.8)
         self.opt = Optimizer(device=device)
-        if exact_order:
-            self.opt.set_exact_order(True)       # g2o's LM path decision for decision (what the C++ drop-in uses)
+        self.opt.set_exact_order(bool(exact_order))   # True (the handle's default): g2o's LM path decision for decision; False: tree sums
         self.stream = torch.cuda.Stream(device=dev)
         self._L = lib()
 
