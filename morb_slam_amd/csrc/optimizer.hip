@@ -2249,7 +2249,7 @@ int morb_optimizer_create(morb_optimizer** out, int device) {
       int* d_bad = nullptr;
       int bad = -1;
       if (hipMalloc((void**)&d_bad, sizeof(int)) == hipSuccess && hipMemsetAsync(d_bad, 0, sizeof(int), o->stream) == hipSuccess) {
-        hipLaunchKernelGGL(k_mfma_order_selftest, dim3(1), dim3(64), 0, o->stream, 4096, d_bad);
+        hipLaunchKernelGGL(k_mfma_order_selftest, dim3(1), dim3(64), 0, o->stream, 1024, d_bad);
         if (hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, o->stream) != hipSuccess || hipStreamSynchronize(o->stream) != hipSuccess) bad = -1;
       }
       if (d_bad) (void)hipFree(d_bad);
