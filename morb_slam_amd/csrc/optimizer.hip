@@ -932,9 +932,11 @@ __host__ __device__ constexpr int po2_max_cap(bool ordered, bool mfma) {   // la
 
 struct PoEdge { float o[3], X[3], info; int right; };
 
-template <bool FISH>
+// (OUT: double (&)[28] registers, or a pointer to the edge's row of the LDS buffer — the first stage writes every entry as soon as it exists, so the
+// 28 x 8 bytes x 448 edges do not arrive at the LDS together at the end of the stage: the write port moves 128 bytes per cycle)
+template <bool FISH, class OUT>
 __device__ __forceinline__ void po2_contrib(const Cam& cam, const Rig& rig, const SE3& P, const SE3& Pr, const PoEdge& e, bool robust,
-                                            double deltaMono, double deltaStereo, double (&con)[28]) {
+                                            double deltaMono, double deltaStereo, OUT&& con) {
   const double X[3] = {(double)e.X[0], (double)e.X[1], (double)e.X[2]};
   double xc[3], err[3], Jp[18], w = 1.0;
   bool st;
@@ -1110,15 +1112,20 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
         double con[28];
         const int e = e0 + row;
         const bool mine = row >= 0 && e < nAct;
-        if (mine) po2_contrib<FISH>(cam, rig, P, Pr, ed[s], robust, deltaMono, deltaStereo, con);   // (beside the sums of stage s - 1)
-        if (s == 0) PO2_ADD_T(3, tp, NT - 64);   // (a worker's edge math of the first stage)
-        // stage s - 1 has been added.  (The first stage needs no barrier — the previous pass ended with one — and without it a wave's 28 LDS
-        // writes start as soon as ITS edge is done instead of all 512 threads' 114 KB arriving at the LDS together: 1.5 k -> 0.x k cycles.)
-        if (s > 0) __syncthreads();
+        // (The first stage needs no barrier in front of its LDS writes — the previous pass ended with one — and writes from inside the edge math.
+        // KB8 rig: through registers in every stage — writing from inside its longer edge math costs that kernel 400 bytes of scratch memory.)
         if (mine) {
+          if (s == 0 && !FISH) po2_contrib<FISH>(cam, rig, P, Pr, ed[s], robust, deltaMono, deltaStereo, sC + row * PO_PITCH);
+          else po2_contrib<FISH>(cam, rig, P, Pr, ed[s], robust, deltaMono, deltaStereo, con);   // (beside the sums of stage s - 1)
+        }
+        if (s == 0) PO2_ADD_T(3, tp, NT - 64);   // (a worker's edge math of the first stage)
+        // Stage s - 1 has been added.  (Measured and not kept: progress words published by the summing waves, so that a later stage's writers wait for
+        // their own row instead of this barrier — 0.404 -> 0.435 ms per launch: writes that arrive while the sums run delay the sums' LDS reads.)
+        if (s > 0) __syncthreads();
+        if (mine && (s > 0 || FISH)) {
 #pragma unroll
           for (int k = 0; k < 28; ++k) sC[row * PO_PITCH + k] = con[k];
-        } else if (MFMA && row >= 0 && e < nAct16) {   // the matrix core takes four rows at a time: the last batch's missing rows add 0.0
+        } else if (!mine && MFMA && row >= 0 && e < nAct16) {   // the matrix core takes four rows at a time: the last batch's missing rows add 0.0
 #pragma unroll
           for (int k = 0; k < 28; ++k) sC[row * PO_PITCH + k] = 0.0;
         }
