@@ -214,11 +214,18 @@ __global__ __launch_bounds__(64 * FW_WAVES, P == 48 ? ((FW_WAVES * 8 + 3) / 4 > 
     FW_CYC(0);
     int qn = 0, cn = 0;
     {
-      const int nIt = (xb - xa + 11) / 12;   // 12-px items per evaluated row
+      // 12-px items per evaluated row.  A row of 37 - 39 evaluated columns (a quarter of the cells: the grid's cell width is 35 - 39 px) would need a
+      // fourth item for its last 1 - 3 pixels — a third reject round for the cell; there the row's LAST item takes up to 15 pixels instead (the flag
+      // layout has room for 16): a fourth dword per item, two more packed pairs, and the cell stays at two rounds.
+#ifndef MORB_FW_WIDE
+#define MORB_FW_WIDE 1
+#endif
+      const bool wide = MORB_FW_WIDE && xb - xa > 36 && xb - xa <= 39;   // (wave-uniform)
+      const int nIt = wide ? 3 : (xb - xa + 11) / 12;
       const unsigned itMagic = c_magic20.m[nIt];
       const int nItems = (th - 6) * nIt;
       // flags of pixels at or beyond xb in a row's last item are dropped before they are queued (the first item starts at xa)
-      const unsigned mLast = c_fwPixMask.m[(xb - xa) - 12 * (nIt - 1)];
+      const unsigned mLast = c_fwPixMask.m[(xb - xa) - 12 * (nIt - 1)], mItem = c_fwPixMask.m[12];
       const unsigned LO = 0x00FF00FFu;
       unsigned KF[8], MF[8];   // per (dword & 1, parity, polarity): the add constant and the flag bit (8 + index) in both halves
 #pragma unroll
@@ -233,15 +240,17 @@ __global__ __launch_bounds__(64 * FW_WAVES, P == 48 ? ((FW_WAVES * 8 + 3) / 4 > 
         if (i < nItems) {
           const uint32_t* rowp = reinterpret_cast<const uint32_t*>(tile + itemOff);
           constexpr int P4 = P / 4;
-          const uint32_t Cw[5] = {rowp[-1], rowp[0], rowp[1], rowp[2], rowp[3]};
-          const uint32_t Uw[3] = {rowp[-3 * P4], rowp[-3 * P4 + 1], rowp[-3 * P4 + 2]};   // ring pixel 8 (0,-3)
-          const uint32_t Dw[3] = {rowp[3 * P4], rowp[3 * P4 + 1], rowp[3 * P4 + 2]};      // ring pixel 0 (0,+3)
-          unsigned E[5], O[5];
+          uint32_t Cw[6] = {rowp[-1], rowp[0], rowp[1], rowp[2], rowp[3], 0u};
+          uint32_t Uw[4] = {rowp[-3 * P4], rowp[-3 * P4 + 1], rowp[-3 * P4 + 2], 0u};   // ring pixel 8 (0,-3)
+          uint32_t Dw[4] = {rowp[3 * P4], rowp[3 * P4 + 1], rowp[3 * P4 + 2], 0u};      // ring pixel 0 (0,+3)
+          if (wide) { Cw[5] = rowp[4]; Uw[3] = rowp[-3 * P4 + 3]; Dw[3] = rowp[3 * P4 + 3]; }
+          unsigned E[6], O[6];
 #pragma unroll
-          for (int k = 0; k < 5; ++k) { E[k] = Cw[k] & LO; O[k] = (Cw[k] >> 8) & LO; }
+          for (int k = 0; k < 6; ++k) { E[k] = Cw[k] & LO; O[k] = (Cw[k] >> 8) & LO; }
           unsigned acc[2] = {0u, 0u};
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
+          for (int k = 0; k < 4; ++k) {
+            if (k == 3 && !wide) break;
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
               const unsigned Ve = par ? O[k + 1] : E[k + 1];
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(64 * FW_WAVES, P == 48 ? ((FW_WAVES * 8 + 3) / 4 > 
             }
           }
           W = ((acc[0] >> 8) & 0x00FF00FFu) | (acc[1] & 0xFF00FF00u);
-          if (bi == nIt - 1) W &= mLast;
+          W &= bi == nIt - 1 ? mLast : mItem;   // (a wide cell's other items have evaluated the next item's first pixels too)
         }
         FW_STAT(2, 1);
         FW_CYC(1);
