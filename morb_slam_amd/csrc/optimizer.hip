@@ -926,9 +926,9 @@ __host__ __device__ constexpr int po2_rows(bool mfma) { return mfma ? PO2_NT : p
 #endif
 // ... which leaves seven waves for the first stage and five for the later ones (frames too large for that keep all waves on the edges)
 __host__ __device__ constexpr int po2_spec_cap() { return MORB_PO2_SPEC ? (PO2_NT - 64) + (PO2_EPT - 1) * (po2_stage(true) - 64) : 0; }
-__host__ __device__ constexpr int po2_max_cap(bool ordered, bool mfma) {   // larger frames take k_pose_opt
-  return !ordered ? PO2_EPT * PO2_NT : mfma ? PO2_NT + (PO2_EPT - 1) * po2_stage(true) : PO2_EPT * po2_stage(false);
-}
+// frames beyond the registers' stages (PO2_NT + (PO2_EPT - 1) x stage edges) read the further edges again in every pass; the list of active features
+// (two bytes per feature) has to fit in LDS beside the contribution buffer
+constexpr int PO2_MAX_CAP = 8192;
 
 struct PoEdge { float o[3], X[3], info; int right; };
 
@@ -988,7 +988,7 @@ extern "C" int morb_po2_cycles(unsigned long long* out) { (void)hipMemcpyFromSym
 #define PO2_ADD(slot, v)
 #define PO2_CNT(slot)
 #endif
-template <bool FISH, bool ORDERED, bool MFMA>
+template <bool FISH, bool ORDERED, bool MFMA, bool BIG>
 __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __restrict__ count, const uint8_t* __restrict__ hasMP,
                                                       const float* __restrict__ obs, const float* __restrict__ invSigma2,
                                                       const float* __restrict__ Xw, Cam cam, Rig rig, const int* __restrict__ nLeft,
@@ -1051,6 +1051,12 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
   int nAct = 0;
 
   // H, b, chi2 of the active edges at pose P -> sTot[buf]
+  auto load_edge = [&](int i, PoEdge& e) {
+    e.o[0] = obs[(base + i) * 3]; e.o[1] = obs[(base + i) * 3 + 1]; e.o[2] = obs[(base + i) * 3 + 2];
+    e.X[0] = Xw[(base + i) * 3]; e.X[1] = Xw[(base + i) * 3 + 1]; e.X[2] = Xw[(base + i) * 3 + 2];
+    e.info = invSigma2[base + i];
+    e.right = i >= nL;
+  };
   // one LM trial's solve, all lanes of the calling wave alike: (H + lam I) x = b of sTot[src], Tn = exp(x) Tb, scale = x . (lam x + b) + 1e-3; in two
   // parts, because the speculation wave has a workgroup barrier to attend in between
   auto solve_a = [&](int src, double lam, double (&x)[6], double (&b)[6]) {
@@ -1137,6 +1143,31 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
         else if (tid < 28) tot = ordered_add_pipe<PO_PITCH, ROWS>(tot, sC + tid, m);
         PO2_ADD(7, tch);
       }
+      // frames with more active edges than the threads' registers hold (PO2_EPT stages): the further stages read their edge again in every pass
+      if (BIG) for (int s = PO2_EPT; stage_base(s) < nAct; ++s) {
+        const int e0 = stage_base(s), row = stage_row(s);
+        double con[28];
+        const int e = e0 + row;
+        const bool mine = row >= 0 && e < nAct;
+        if (mine) {
+          PoEdge ee;
+          load_edge(actList[e], ee);
+          po2_contrib<FISH>(cam, rig, P, Pr, ee, robust, deltaMono, deltaStereo, con);
+        }
+        __syncthreads();
+        if (mine) {
+#pragma unroll
+          for (int k = 0; k < 28; ++k) sC[row * PO_PITCH + k] = con[k];
+        } else if (MFMA && row >= 0 && e < nAct16) {
+#pragma unroll
+          for (int k = 0; k < 28; ++k) sC[row * PO_PITCH + k] = 0.0;
+        }
+        __syncthreads();
+        const int m = min(nwork, (MFMA ? nAct16 : nAct) - e0);
+        if (MFMA && NCW == 2) { if (wv < 2) ordered_add_mfma1<PO_PITCH, ROWS>(tot, sC + 16 * wv, lane, m); }
+        else if (MFMA) { if (wv == 0) ordered_add_mfma<PO_PITCH, ROWS>(tot, tot1, sC, lane, m); }
+        else if (tid < 28) tot = ordered_add_pipe<PO_PITCH, ROWS>(tot, sC + tid, m);
+      }
       if (MFMA) {
         const int c16 = 4 * ((lane >> 2) & 3) + (lane >> 4);
         if (NCW == 2) { if (wv < 2 && (lane & 3) == 0 && 16 * wv + c16 < 28) sTot[buf][16 * wv + c16] = tot; }
@@ -1159,6 +1190,14 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
 #pragma unroll
           for (int k = 0; k < 28; ++k) acc[k] += con[k];
         }
+      }
+      if (BIG) for (int e = PO2_EPT * NWORK + tid; e < nAct; e += NWORK) {   // (larger frames: the edge is read again in every pass)
+        PoEdge ee;
+        load_edge(actList[e], ee);
+        double con[28];
+        po2_contrib<FISH>(cam, rig, P, Pr, ee, robust, deltaMono, deltaStereo, con);
+#pragma unroll
+        for (int k = 0; k < 28; ++k) acc[k] += con[k];
       }
       __syncthreads();                         // (sH / sTot[buf] of an earlier pass have been read)
       wave_sum28_to(acc, sH[wv], lane);
@@ -1191,11 +1230,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
     for (int s = 0; s < PO2_EPT; ++s) {
       const int e = stage_base(s) + stage_row(s);
       if (stage_row(s) >= 0 && e < nAct) {
-        const int i = actList[e];
-        ed[s].o[0] = obs[(base + i) * 3]; ed[s].o[1] = obs[(base + i) * 3 + 1]; ed[s].o[2] = obs[(base + i) * 3 + 2];
-        ed[s].X[0] = Xw[(base + i) * 3]; ed[s].X[1] = Xw[(base + i) * 3 + 1]; ed[s].X[2] = Xw[(base + i) * 3 + 2];
-        ed[s].info = invSigma2[base + i];
-        ed[s].right = i >= nL;
+        load_edge(actList[e], ed[s]);
       }
     }
     PO2_ADD(5, tc);
@@ -1292,27 +1327,38 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
   }
   PO2_ADD(0, tAll);
 }
+// registers hold the edges of PO2_EPT stages; larger frames run the BIG instantiation (further stages read their edge again in every pass: kept out of
+// the common kernels, where the extra code costs registers — 3 % on the tracking chain)
+__host__ __device__ constexpr int po2_reg_cap(bool ordered, bool mfma) {
+  return !ordered ? PO2_EPT * PO2_NT : mfma ? PO2_NT + (PO2_EPT - 1) * po2_stage(true) : PO2_EPT * po2_stage(false);
+}
+template <bool FISH, bool ORDERED, bool MFMA, bool BIG>
+static int launch_pose_opt2_as(int nframes, hipStream_t st, size_t lds, int cap, const int* d_count, const uint8_t* d_hasMP, const float* d_obs,
+                               const float* d_invSigma2, const float* d_Xw, const Cam& cam, const Rig& rig, const int* d_nLeft, float* d_pose,
+                               uint8_t* d_outlier, int* d_nInliers, int* d_stats) {
+  if (lds > 48 * 1024)
+    MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt2<FISH, ORDERED, MFMA, BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_pose_opt2<FISH, ORDERED, MFMA, BIG>), dim3(nframes), dim3(PO2_NT), lds, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
+                     d_nLeft, d_pose, d_outlier, d_nInliers, d_stats);
+  return MORB_OK;
+}
+// false: this mode / size has no k_pose_opt2 form (the caller launches k_pose_opt)
+static bool pose_opt2_covers(bool ordered, bool mfmaChain, int cap) {
+  return cap <= PO2_MAX_CAP && (cap <= po2_reg_cap(ordered, mfmaChain) || !ordered || mfmaChain);   // (no BIG form of the vector-chain mode)
+}
 template <bool FISH>
 static int launch_pose_opt2(bool ordered, bool mfmaChain, int nframes, hipStream_t st, int cap, const int* d_count, const uint8_t* d_hasMP, const float* d_obs,
                             const float* d_invSigma2, const float* d_Xw, const Cam& cam, const Rig& rig, const int* d_nLeft, float* d_pose,
                             uint8_t* d_outlier, int* d_nInliers, int* d_stats) {
   const size_t listBytes = ((size_t)cap * 2 + 15) & ~(size_t)15;
-  if (ordered) {
-    const size_t lds = (size_t)po2_rows(mfmaChain) * PO_PITCH * 8 + 32 + listBytes;   // (+32: the second accumulator's lanes 12 .. 15 read past the last row)
-    if (mfmaChain) {
-      MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt2<FISH, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((k_pose_opt2<FISH, true, true>), dim3(nframes), dim3(PO2_NT), lds, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
-                         d_nLeft, d_pose, d_outlier, d_nInliers, d_stats);
-    } else {
-      MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt2<FISH, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((k_pose_opt2<FISH, true, false>), dim3(nframes), dim3(PO2_NT), lds, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
-                         d_nLeft, d_pose, d_outlier, d_nInliers, d_stats);
-    }
-  } else {
-    hipLaunchKernelGGL((k_pose_opt2<FISH, false, false>), dim3(nframes), dim3(PO2_NT), listBytes, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig,
-                       d_nLeft, d_pose, d_outlier, d_nInliers, d_stats);
-  }
-  return MORB_OK;
+  const bool big = cap > po2_reg_cap(ordered, mfmaChain);
+  const size_t lds = ordered ? (size_t)po2_rows(mfmaChain) * PO_PITCH * 8 + 32 + listBytes : listBytes;   // (+32: the second accumulator's lanes 12 .. 15 read past the last row)
+#define MORB_PO2_GO(O, M, B) return launch_pose_opt2_as<FISH, O, M, B>(nframes, st, lds, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig, d_nLeft, d_pose, d_outlier, d_nInliers, d_stats)
+  if (ordered && mfmaChain) { if (big) MORB_PO2_GO(true, true, true); else MORB_PO2_GO(true, true, false); }
+  if (ordered) MORB_PO2_GO(true, false, false);
+  if (big) MORB_PO2_GO(false, false, true);
+  MORB_PO2_GO(false, false, false);
+#undef MORB_PO2_GO
 }
 
 // =====================================================================================================
@@ -2349,7 +2395,7 @@ int morb_pose_optimization_batch(morb_optimizer* o, int nframes, int cap, const 
   // empty stage per pass — 0.447 against 0.400 ms per launch at 600 features; k_pose_opt's 256 threads with 2 - 3 edges each stay the faster
   // form there.  Frames of ~1200 features of which half hold a map point — tracking — are where the compaction of k_pose_opt2 pays.)
   const bool smallTree = !o->exactOrder && cap <= 640;
-  if (cap <= po2_max_cap(o->exactOrder != 0, o->mfmaChain != 0) && !smallTree && !getenv("MORB_PO_OLD")) {
+  if (pose_opt2_covers(o->exactOrder != 0, o->mfmaChain != 0, cap) && !smallTree && !getenv("MORB_PO_OLD")) {
     const int rc = launch_pose_opt2<false>(o->exactOrder != 0, o->mfmaChain != 0, nframes, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig, nullptr, d_pose,
                                            d_outlier, d_nInliers, d_stats);
     if (rc != MORB_OK) return rc;
@@ -2383,7 +2429,7 @@ int morb_pose_optimization_fisheye_batch(morb_optimizer* o, int nframes, int cap
     for (int i = 0; i < 4; ++i) rig.Trl.q[i] = q[i] / n;
     for (int i = 0; i < 3; ++i) rig.Trl.t[i] = Trl7[4 + i];
   }
-  if (cap <= po2_max_cap(o->exactOrder != 0, o->mfmaChain != 0) && !getenv("MORB_PO_OLD")) {
+  if (pose_opt2_covers(o->exactOrder != 0, o->mfmaChain != 0, cap) && !getenv("MORB_PO_OLD")) {
     const int rc = launch_pose_opt2<true>(o->exactOrder != 0, o->mfmaChain != 0, nframes, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig, d_nLeft, d_pose,
                                           d_outlier, d_nInliers, d_stats);
     if (rc != MORB_OK) return rc;

@@ -23,8 +23,9 @@ HOT = ["k_resize", "k_resize_gather", "k_level0", "k_blur", "k_fastw", "k_distri
 # kernels that still spill, pinned at what they use today so that a regression shows: the 30-unknown
 # PoseInertialOptimizationLastFrame kernel sits at the 512-register limit (168 B; 740 B before round 4, the 15-unknown LastKeyFrame forms are at 0),
 # two LocalInertialBA phase kernels, and the persistent-workgroup LocalBA mode (not the default)
-# round 5: k_pose_opt2 (512 threads per frame: 256 registers per thread) spills a few of its uniform LM scalars
-BOUNDED = {"k_pose_inertial": 168, "k_iba_errors": 68, "k_iba_kf": 84, "k_local_ba": 560, "k_pose_opt2": 600}
+# round 5: k_pose_opt2 (512 threads per frame: 256 registers per thread) spills a few of its uniform LM scalars and the edges of its later stages
+# (pinhole <= 300 B; the KB8-rig forms 450 - 600 B, their large-frame instantiations — a second inlined edge function — up to 850 B)
+BOUNDED = {"k_pose_inertial": 168, "k_iba_errors": 68, "k_iba_kf": 84, "k_local_ba": 560, "k_pose_opt2": 900}
 
 
 def _kernel_metadata(lib, tmp):
@@ -61,6 +62,9 @@ def test_hot_kernels_use_no_scratch_memory(tmp_path):
         assert hits, f"kernel {short} not found in the code objects"
         for name, scratch in hits.items():
             assert scratch <= bound, f"{name} uses {scratch} bytes of scratch memory per thread (pinned at {bound})"
+    for name, scratch in meta.items():      # the pinhole forms of k_pose_opt2 for frames that fit the registers' stages (the tracking chain's kernels)
+        if "k_pose_opt2ILb0E" in name and name.split("k_pose_opt2ILb0E")[1].startswith(("Lb1ELb1ELb0E", "Lb1ELb0ELb0E", "Lb0ELb0ELb0E")):
+            assert scratch <= 300, f"{name} uses {scratch} bytes of scratch memory per thread (pinned at 300)"
     # PoseInertialOptimizationLastKeyFrame (LASTFRAME = false), pinhole and rig: no scratch at all
     for name, scratch in meta.items():
         if "k_pose_inertialILb0E" in name:

@@ -85,6 +85,25 @@ def test_edge_order_sums_on_the_matrix_core_equal_the_vector_chain(monkeypatch):
         np.testing.assert_array_equal(res["mfma"][1][f, :sizes[f]], oe)
 
 
+@pytest.mark.parametrize("n", [1700, 2100, 4000])
+def test_pose_optimization_of_large_frames(n):
+    """Frames with more active edges than the threads' registers hold (1664 in the edge-order mode, 2048 with tree sums) run the large-frame
+    instantiation of k_pose_opt2: the further stages read their edge again in every pass.  Same LM path as the oracle in the edge-order mode."""
+    probs = [make_pose_problem(n, seed=200 + n + s) for s in range(2)]
+    for p in probs:
+        p["hasMP"][:] = 1
+    nin, outl, stats, pose = _run_pose_batch(probs)
+    nin_t, outl_t, stats_t, pose_t = _run_pose_batch(probs, exact=False)
+    for f, p in enumerate(probs):
+        r, pe, oe, se = O.pose_optimization(p)
+        assert np.abs(pose[f] - pe).max() <= POSE_TOL and np.abs(pose_t[f] - pe).max() <= POSE_TOL
+        assert nin[f] == r and nin_t[f] == r
+        np.testing.assert_array_equal(outl[f, :n], oe)
+        np.testing.assert_array_equal(outl_t[f, :n], oe)
+        assert int(stats[f][0]) == int(se[0]) and int(stats[f][1]) == int(se[1]), (stats[f], se)
+        assert int(stats_t[f][0]) == int(se[0]) and abs(int(stats_t[f][1]) - int(se[1])) <= 2
+
+
 def test_pose_optimization_tree_sum_mode():
     """The default (morb_optimizer_set_exact_order(0)): tree sums — same poses, flags and outer iterations; the trial count may differ by the
     rare flip of a ~0 rho (observed: 50 vs 49 in one of nine problems)."""
