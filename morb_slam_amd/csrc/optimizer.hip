@@ -921,6 +921,9 @@ constexpr int PO2_NT = 512, PO2_NW = PO2_NT / 64, PO2_EPT = MORB_PO2_EPT;
 __host__ __device__ constexpr int po2_stage(bool mfma) { return PO2_NT - 64 * (mfma ? MORB_PO2_CHAIN_WAVES : 1); }
 // matrix-core chain: the FIRST stage is computed by all eight waves (the summing waves have nothing to add yet) and holds PO2_NT edges
 __host__ __device__ constexpr int po2_rows(bool mfma) { return mfma ? PO2_NT : po2_stage(false); }   // rows of the contribution buffer
+#ifndef MORB_PO2_PREVIEW
+#define MORB_PO2_PREVIEW 1   // ... and a trial that follows a rejection is first judged by a tree sum of its chi2 (a rigorous "certainly rejected" test)
+#endif
 #ifndef MORB_PO2_SPEC
 #define MORB_PO2_SPEC 1   // matrix-core chain: the last wave computes no edges; beside every trial's pass it solves the trial that FOLLOWS A REJECTION
 #endif
@@ -1011,8 +1014,9 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
   __shared__ double sPose[8];        // the trial pose (wave 0 -> everybody) + scale
   __shared__ double sKeep[3][7];     // uniform poses that would otherwise sit in every thread's registers: T0, Teval, the trial's backup
   __shared__ int sFlag[2];
-  __shared__ double sSpec[2][8];     // the speculation wave's trial pose + scale, by trial parity
-  __shared__ int sSpecFlag[2];
+  __shared__ double sSpec[9][8];     // the speculation wave's trial poses + scales: slot q - 1 = the iteration's trial q if trials 0 .. q - 1 are rejected
+  __shared__ int sSpecFlag[9];
+  __shared__ double sChiA[2][NW];    // the waves' partial sums of a trial's chi2 preview, by trial parity
   __shared__ int sWaveCnt[NW];
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = min(count ? count[f] : cap, cap);
@@ -1070,26 +1074,30 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
     for (int r = 0; r < 6; ++r) { b[r] = sTot[src][21 + r]; H[r * 6 + r] += lam; x[r] = 0; }
     return ldlt6(H, b, x);
   };
-  auto solve_b = [&](bool ok2, double lam, const double (&x)[6], const double (&b)[6], const SE3& Tb, double* out8, int* outFlag) {
+  // (nOut lanes write: lane l its own result to out8 + 8 l / outFlag + l — the speculation wave solves nine trials at once, one lambda per lane)
+  auto solve_b = [&](bool ok2, double lam, const double (&x)[6], const double (&b)[6], const SE3& Tb, double* out8, int* outFlag, int nOut) {
     const SE3 Tn = se3_mul(se3_exp(x), Tb);
     double scale = 0;
 #pragma unroll
     for (int r = 0; r < 6; ++r) scale += x[r] * (lam * x[r] + b[r]);
     scale += 1e-3;
-    if (lane == 0) {
-      for (int k = 0; k < 4; ++k) out8[k] = Tn.q[k];
-      for (int k = 0; k < 3; ++k) out8[4 + k] = Tn.t[k];
-      out8[7] = scale;
-      *outFlag = ok2 ? 1 : 0;
+    if (lane < nOut) {
+      double* o8 = out8 + 8 * lane;
+      for (int k = 0; k < 4; ++k) o8[k] = Tn.q[k];
+      for (int k = 0; k < 3; ++k) o8[4 + k] = Tn.t[k];
+      o8[7] = scale;
+      outFlag[lane] = ok2 ? 1 : 0;
     }
   };
   auto solve_trial = [&](int src, double lam, const SE3& Tb, double* out8, int* outFlag) {
     double x[6], b[6];
     const bool ok2 = solve_a(src, lam, x, b);
-    solve_b(ok2, lam, x, b, Tb, out8, outFlag);
+    solve_b(ok2, lam, x, b, Tb, out8, outFlag, 1);
   };
-  // specLam >= 0: beside the pass, the speculation wave solves the trial that follows if THIS one is rejected (state sTot[buf ^ 1], pose sKeep[2])
-  auto pass = [&](const SE3& P, int buf, double specLam, int specSlot) {
+  // specLam >= 0 (an iteration's first trial, lambda and ni of that trial): beside the pass, the speculation wave solves the NINE trials that follow
+  // if this one and the ones after it are rejected — lane g the trial with lambda_g (lambda *= ni, ni *= 2, g + 1 times: the bookkeeping's own
+  // operations, so the same bits) from the state sTot[buf ^ 1] and the pose sKeep[2]: one solve, nine lambdas
+  auto pass = [&](const SE3& P, int buf, double specLam, double specNi) {
     PO2_T0(tp); PO2_CNT(4);
     const SE3 Pr = FISH ? se3_mul(rig.Trl, P) : P;
     if (ORDERED && MFMA && spec && wv == NW - 1) {
@@ -1097,9 +1105,11 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
       // every barrier of the pass (s_barrier counts arrivals, whichever instruction a wave arrives at)
       double x[6], b[6];
       bool ok2 = false;
-      if (specLam >= 0) ok2 = solve_a(buf ^ 1, specLam, x, b);
+      double lamG = specLam, niG = specNi;
+      for (int g = 0; g <= min(lane, 8); ++g) { lamG *= niG; niG *= 2; }
+      if (specLam >= 0) ok2 = solve_a(buf ^ 1, lamG, x, b);
       __syncthreads();                                   // the first stage's contributions are in LDS
-      if (specLam >= 0) solve_b(ok2, specLam, x, b, get(2), sSpec[specSlot], &sSpecFlag[specSlot]);
+      if (specLam >= 0) solve_b(ok2, lamG, x, b, get(2), sSpec[0], sSpecFlag, 9);
       for (int s = 1; s < PO2_EPT; ++s) {
         if (stage_base(s) >= nAct) break;
         __syncthreads();
@@ -1236,7 +1246,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
     PO2_ADD(5, tc);
     // ---- optimizer.optimize(10) ----
     int cur = 0;
-    pass(T, cur, -1.0, 0);
+    pass(T, cur, -1.0, 0.0);
     double lambda = 0, ni = 2;
     int nBad = 0;
     for (int iter = 0; iter < 10; ++iter) {
@@ -1256,7 +1266,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
         double scale;
         bool ok2;
         if (spec && qmax > 0) {   // the trial after a rejection: solved beside the rejected trial's pass (same state, lambda * ni: the same bits)
-          const int sl = (trials - 1) & 1;
+          const int sl = qmax - 1;
           for (int k = 0; k < 4; ++k) T.q[k] = sSpec[sl][k];
           for (int k = 0; k < 3; ++k) T.t[k] = sSpec[sl][4 + k];
           scale = sSpec[sl][7];
@@ -1272,10 +1282,47 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
         }
         PO2_ADD(1, ts);
         put(1, T);           // Teval
-        pass(T, cur ^ 1, qmax < 9 ? lambda * ni : -1.0, trials & 1);
-        double tempChi = sTot[cur ^ 1][27];
-        if (!ok2) tempChi = 1.7976931348623157e308;
-        rho = (currentChi - tempChi) / scale;
+        // A trial that follows a rejection is usually rejected too (g2o's LM climbs in lambda near convergence), and a rejected trial leaves nothing
+        // behind but the decision rho <= 0: its H, b and even its chi2 are dropped.  The decision is chi2(trial) > chi2(current state) — sums of
+        // non-negative terms — so a PREVIEW decides most of them rigorously: every thread adds the robustified chi2 of its own edges (errors only: a
+        // third of the edge math), a tree sum over the workgroup, and since two floating-point sums of the same n non-negative terms differ by less
+        // than 2 n 2^-53 of their value (any order, any association), `preview (1 - 8 n 2^-53) > currentChi` implies that the edge-order sum is larger
+        // too: rejected, for certain, without the edge-order sums, the Jacobians or the LDS hand-over (measured on the oracle's traces: 90 % of the
+        // rejections, half of all trials).  Otherwise the trial runs its pass as before.  (Its pose has been waiting since the iteration's first trial.)
+        bool certainlyRejected = false;
+        if (spec && MORB_PO2_PREVIEW && qmax > 0 && ok2 && scale > 0) {
+          const int par = trials & 1;
+          double part = 0;
+          if (wv != NW - 1) {
+            const SE3 Tr = FISH ? se3_mul(rig.Trl, T) : T;
+#pragma unroll
+            for (int s = 0; s < PO2_EPT; ++s) {
+              const int row = stage_row(s), e = stage_base(s) + row;
+              if (row >= 0 && e < nAct) {
+                const double X[3] = {(double)ed[s].X[0], (double)ed[s].X[1], (double)ed[s].X[2]};
+                double xc[3], err[3], w;
+                bool st;
+                double c = pose_edge_error<FISH>(cam, rig, T, Tr, FISH && ed[s].right, X, ed[s].o, (double)ed[s].info, err, st, xc);
+                if (robust) c = huber(st ? deltaStereo : deltaMono, c, &w);
+                part += c;
+              }
+            }
+          }
+          part = wave_sum_d(part);
+          if (lane == 0) sChiA[par][wv] = part;
+          __syncthreads();
+          double tt = 0;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) tt += sChiA[par][w];
+          certainlyRejected = isfinite(tt) && tt * (1.0 - 8.0 * (double)nAct * 0x1p-53) > currentChi;
+        }
+        double tempChi = 1.7976931348623157e308;
+        if (!certainlyRejected) {
+          pass(T, cur ^ 1, qmax == 0 ? lambda : -1.0, ni);
+          tempChi = sTot[cur ^ 1][27];
+          if (!ok2) tempChi = 1.7976931348623157e308;
+        }
+        rho = certainlyRejected ? -1.0 : (currentChi - tempChi) / scale;   // (a certainly rejected trial: only the sign of rho is ever read)
         if (rho > 0 && isfinite(tempChi)) {
           double alpha = 1. - cube_rn(2 * rho - 1);
           alpha = fmin(alpha, 2. / 3.);
