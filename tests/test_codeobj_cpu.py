@@ -64,7 +64,7 @@ def test_hot_kernels_use_no_scratch_memory(tmp_path):
             assert scratch <= bound, f"{name} uses {scratch} bytes of scratch memory per thread (pinned at {bound})"
     for name, scratch in meta.items():      # the pinhole forms of k_pose_opt2 for frames that fit the registers' stages (the tracking chain's kernels)
         if "k_pose_opt2ILb0E" in name and name.split("k_pose_opt2ILb0E")[1].startswith(("Lb1ELb1ELb0E", "Lb1ELb0ELb0E", "Lb0ELb0ELb0E")):
-            assert scratch <= 300, f"{name} uses {scratch} bytes of scratch memory per thread (pinned at 300)"
+            assert scratch <= 340, f"{name} uses {scratch} bytes of scratch memory per thread (pinned at 340)"
     # PoseInertialOptimizationLastKeyFrame (LASTFRAME = false), pinhole and rig: no scratch at all
     for name, scratch in meta.items():
         if "k_pose_inertialILb0E" in name:
