@@ -500,17 +500,8 @@ __device__ __forceinline__ double ordered_add_pipe(double tot, const double* __r
     _Pragma("unroll") for (int k = 0; k < 8; ++k) dst[k] = p[(r_ + k) * STRIDE]; \
     asm volatile("" : "+v"(tot) : : "memory");                                 \
   } while (0)
-// (MORB_PO2_CHAIN_ONE_WAIT: an empty asm that "rewrites" the batch's eight registers makes the compiler wait once per batch instead of in front of every
-// second addition — 13.5 instead of 17 cycles per term in the micro-benchmark, but inside k_pose_opt2, which sits at its 256-register limit, the
-// extra register constraints cost more than the waits: 0.572 against 0.537 ms per launch, tools/po_chain_ab.sh.  Off.)
-#ifdef MORB_PO2_CHAIN_ONE_WAIT
-#define MORB_ADD8_WAIT(src) asm volatile("" : "+v"(src[0]), "+v"(src[1]), "+v"(src[2]), "+v"(src[3]), "+v"(src[4]), "+v"(src[5]), "+v"(src[6]), "+v"(src[7]), "+v"(tot) : : "memory")
-#else
-#define MORB_ADD8_WAIT(src)
-#endif
 #define MORB_ADD8(src)                                                                                                                       \
   do {                                                                                                                                       \
-    MORB_ADD8_WAIT(src);                                                                                                                     \
     _Pragma("unroll") for (int k = 0; k < 8; ++k) tot += src[k];                                                                             \
     asm volatile("" : "+v"(tot) : : "memory");                                                                                               \
   } while (0)
@@ -532,7 +523,6 @@ __device__ __forceinline__ double ordered_add_pipe(double tot, const double* __r
   for (int k = 0; k < 8; ++k) if (e + k < m) tot += v[k];
 #undef MORB_LOAD8
 #undef MORB_ADD8
-#undef MORB_ADD8_WAIT
   return tot;
 }
 // The same sums on the FP64 matrix core.  v_mfma_f64_4x4x4_4b_f64 computes D[b][i][j] = C[b][i][j] + sum_k A[b][i][k] B[b][k][j] for four 4 x 4
@@ -540,45 +530,13 @@ __device__ __forceinline__ double ordered_add_pipe(double tot, const double* __r
 // (((c + a0) + a1) + a2) + a3, bit for bit what four dependent v_add_f64 produce (tools/micro/mfma_chain.hip: 262 144 random accumulations with
 // mixed signs, magnitudes 2^-30 .. 2^30 and near-total cancellation, all equal; k_mfma_order_selftest repeats the check when a handle is created and
 // the VALU chain above stays as the form a device that fails it would run).  One instruction therefore advances 16 independent ordered sums
-// (b, i) by FOUR edges in 4 passes; a dependent MFMA issues after ~25 cycles, two interleaved chains at ~18 each: 28 sums = two accumulators at
-// ~9 cycles per edge where the v_add_f64 chain measured 17 inside this kernel (profiles/r05/README.md).
+// (b, i) by FOUR edges in 4 passes; a dependent MFMA issues after ~25 cycles: ~7 cycles per edge with the 28 sums in two waves (16 + 12) where the
+// v_add_f64 chain measured 14 - 17 inside this kernel (profiles/r05/README.md).
 // Layout (found with one-hot operands): A lane = 16 k + 4 b + i, B lane = 16 k + 4 b + j, C / D lane = 16 i + 4 b + j.  Lane l of the summing wave
-// reads entry (l & 15) [+ 16 for the second accumulator] of edge row e + (l >> 4); sum c (< 16) comes out in lanes 16 (c & 3) + 4 (c >> 2) + j.
+// reads entry (l & 15) [+ 16 in the second wave] of edge row e + (l >> 4); sum c (< 16) comes out in lanes 16 (c & 3) + 4 (c >> 2) + j.
 // The rows [m, m16) have been zeroed by the workers (x + 0.0 is exact and the running sums are never -0.0).  ROWS is a multiple of 16.
-template <int STRIDE, int ROWS>
-__device__ __forceinline__ void ordered_add_mfma(double& d0, double& d1, const double* __restrict__ sC, int lane, int m16) {
-  static_assert(ROWS % 16 == 0, "whole batches");
-  const double* p = sC + (lane >> 4) * STRIDE + (lane & 15);
-  double v[8], w[8];
-  // four rows: the two accumulators take their terms, and the registers of a LATER batch are requested in the instructions' shadow (a dependent
-  // MFMA cannot issue for ~25 cycles; the read issues meanwhile).  Empty asm statements pin that order.
-#define MORB_STEP4(use, t, ld, row)                                                                                 \
-  do {                                                                                                              \
-    d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(use[2 * (t)], 1.0, d0, 0, 0, 0);                                        \
-    d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(use[2 * (t) + 1], 1.0, d1, 0, 0, 0);                                    \
-    ld[2 * (t)] = p[((row) + 4 * (t)) * STRIDE]; ld[2 * (t) + 1] = p[((row) + 4 * (t)) * STRIDE + 16];              \
-    asm volatile("" : "+v"(d0), "+v"(d1) : : "memory");                                                             \
-  } while (0)
-#pragma unroll
-  for (int t = 0; t < 4; ++t) { v[2 * t] = p[4 * t * STRIDE]; v[2 * t + 1] = p[4 * t * STRIDE + 16]; }
-  asm volatile("" : "+v"(d0), "+v"(d1) : : "memory");
-  int e = 0;
-  for (; e + 32 <= m16; e += 32) {
-    const int r1 = e + 16, r2 = e + 32 <= ROWS - 16 ? e + 32 : ROWS - 16;   // (reads never leave the buffer)
-    MORB_STEP4(v, 0, w, r1); MORB_STEP4(v, 1, w, r1); MORB_STEP4(v, 2, w, r1); MORB_STEP4(v, 3, w, r1);
-    MORB_STEP4(w, 0, v, r2); MORB_STEP4(w, 1, v, r2); MORB_STEP4(w, 2, v, r2); MORB_STEP4(w, 3, v, r2);
-  }
-  if (e < m16) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(v[2 * t], 1.0, d0, 0, 0, 0);
-      d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(v[2 * t + 1], 1.0, d1, 0, 0, 0);
-    }
-  }
-#undef MORB_STEP4
-}
 // One accumulator (16 sums) per wave: a dependent MFMA every ~25 cycles, the reads of the rows 32 ahead in its shadow.  Two waves on two SIMDs carry the
-// 28 sums at ~6.5 cycles per edge (sC16 = sC + 16 x the wave's index; ROWS is a multiple of 32).
+// 28 sums at ~7 cycles per edge (sC16 = sC + 16 x the wave's index; ROWS is a multiple of 32).  (Both accumulators interleaved in one wave: 11 cycles per edge.)
 template <int STRIDE, int ROWS>
 __device__ __forceinline__ void ordered_add_mfma1(double& d, const double* __restrict__ sC16, int lane, int m16) {
   static_assert(ROWS % 32 == 0, "whole batches");
@@ -913,12 +871,9 @@ __global__ __launch_bounds__(NT) void k_pose_opt(int cap, const int* __restrict_
 #ifndef MORB_PO2_EPT
 #define MORB_PO2_EPT 4   // edges a worker thread keeps in registers per round
 #endif
-#ifndef MORB_PO2_CHAIN_WAVES
-#define MORB_PO2_CHAIN_WAVES 2   // matrix-core chain: waves that carry the 28 ordered sums (1: two accumulators in wave 0; 2: one each in waves 0 and 1)
-#endif
 constexpr int PO2_NT = 512, PO2_NW = PO2_NT / 64, PO2_EPT = MORB_PO2_EPT;
 // edges per stage of the edge-order mode: every wave but the summing one(s) computes edges
-__host__ __device__ constexpr int po2_stage(bool mfma) { return PO2_NT - 64 * (mfma ? MORB_PO2_CHAIN_WAVES : 1); }
+__host__ __device__ constexpr int po2_stage(bool mfma) { return PO2_NT - 64 * (mfma ? 2 : 1); }   // (matrix-core chain: waves 0 and 1 carry 16 + 12 sums)
 // matrix-core chain: the FIRST stage is computed by all eight waves (the summing waves have nothing to add yet) and holds PO2_NT edges
 __host__ __device__ constexpr int po2_rows(bool mfma) { return mfma ? PO2_NT : po2_stage(false); }   // rows of the contribution buffer
 #ifndef MORB_PO2_PREVIEW
@@ -998,7 +953,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
                                                       float* __restrict__ poseIO, uint8_t* __restrict__ outlier,
                                                       int* __restrict__ nInliers, int* __restrict__ stats) {
   constexpr int NT = PO2_NT, NW = PO2_NW;
-  constexpr int NCW = MFMA ? MORB_PO2_CHAIN_WAVES : 1;   // waves that carry the ordered sums (wave 0 also solves)
+  constexpr int NCW = MFMA ? 2 : 1;             // waves that carry the ordered sums (wave 0 also solves)
   constexpr int W0 = ORDERED ? 64 * NCW : 0;    // first worker thread
   constexpr int NWORK = NT - W0;                // edges per stage
   static_assert(!ORDERED || NWORK == po2_stage(MFMA), "stage size");
@@ -1035,6 +990,10 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
   auto stage_base = [&](int s) { return s == 0 ? 0 : s0 + (s - 1) * nwork; };
 
   PO2_T0(tAll);
+#ifdef MORB_PO_FRAME_CYCLES
+  const long long tFrame0 = clock64();
+  int nCertain = 0;
+#endif
   int nInit = 0;
   for (int i = tid; i < n; i += NT) {
     if (hasMP[base + i]) { ++nInit; outlier[base + i] = 0; }
@@ -1119,7 +1078,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
       return;
     }
     if (ORDERED) {
-      double tot = 0, tot1 = 0;   // VALU chain: lanes 0 .. 27 of wave 0 hold entry `lane`; matrix-core chain: two accumulators in D layout
+      double tot = 0;   // VALU chain: lanes 0 .. 27 of wave 0 hold entry `lane`; matrix-core chain: the accumulator (D layout) of waves 0 and 1
       const int nAct16 = (nAct + 15) & ~15;
 #pragma unroll
       for (int s = 0; s < PO2_EPT; ++s) {   // (unrolled: ed[s] must stay in registers)
@@ -1148,8 +1107,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
         __syncthreads();
         PO2_T0(tch);
         const int m = min(s == 0 ? s0 : nwork, (MFMA ? nAct16 : nAct) - e0);
-        if (MFMA && NCW == 2) { if (wv < 2) ordered_add_mfma1<PO_PITCH, ROWS>(tot, sC + 16 * wv, lane, m); }
-        else if (MFMA) { if (wv == 0) ordered_add_mfma<PO_PITCH, ROWS>(tot, tot1, sC, lane, m); }
+        if (MFMA) { if (wv < 2) ordered_add_mfma1<PO_PITCH, ROWS>(tot, sC + 16 * wv, lane, m); }
         else if (tid < 28) tot = ordered_add_pipe<PO_PITCH, ROWS>(tot, sC + tid, m);
         PO2_ADD(7, tch);
       }
@@ -1174,17 +1132,12 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
         }
         __syncthreads();
         const int m = min(nwork, (MFMA ? nAct16 : nAct) - e0);
-        if (MFMA && NCW == 2) { if (wv < 2) ordered_add_mfma1<PO_PITCH, ROWS>(tot, sC + 16 * wv, lane, m); }
-        else if (MFMA) { if (wv == 0) ordered_add_mfma<PO_PITCH, ROWS>(tot, tot1, sC, lane, m); }
+        if (MFMA) { if (wv < 2) ordered_add_mfma1<PO_PITCH, ROWS>(tot, sC + 16 * wv, lane, m); }
         else if (tid < 28) tot = ordered_add_pipe<PO_PITCH, ROWS>(tot, sC + tid, m);
       }
       if (MFMA) {
         const int c16 = 4 * ((lane >> 2) & 3) + (lane >> 4);
-        if (NCW == 2) { if (wv < 2 && (lane & 3) == 0 && 16 * wv + c16 < 28) sTot[buf][16 * wv + c16] = tot; }
-        else if (wv == 0 && (lane & 3) == 0) {
-          sTot[buf][c16] = tot;
-          if (c16 < 12) sTot[buf][16 + c16] = tot1;
-        }
+        if (wv < 2 && (lane & 3) == 0 && 16 * wv + c16 < 28) sTot[buf][16 * wv + c16] = tot;
       } else if (tid < 28) sTot[buf][tid] = tot;
       __syncthreads();
       PO2_ADD(2, tp);
@@ -1322,6 +1275,9 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
           tempChi = sTot[cur ^ 1][27];
           if (!ok2) tempChi = 1.7976931348623157e308;
         }
+#ifdef MORB_PO_FRAME_CYCLES
+        nCertain += certainlyRejected ? 1 : 0;
+#endif
         rho = certainlyRejected ? -1.0 : (currentChi - tempChi) / scale;   // (a certainly rejected trial: only the sign of rho is ever read)
         if (rho > 0 && isfinite(tempChi)) {
           double alpha = 1. - cube_rn(2 * rho - 1);
@@ -1370,7 +1326,11 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
     for (int k = 0; k < 4; ++k) poseIO[7 * f + k] = (float)T.q[k];
     for (int k = 0; k < 3; ++k) poseIO[7 * f + 4 + k] = (float)T.t[k];
     nInliers[f] = nInit - nBadEdges;
+#ifdef MORB_PO_FRAME_CYCLES   // developer build: the frame's kernel time (kilocycles) and its certain rejections instead of iterations / trials
+    if (stats) { stats[2 * f] = (int)((clock64() - tFrame0) / 1000); stats[2 * f + 1] = trials * 100 + nCertain; }
+#else
     if (stats) { stats[2 * f] = outerIts; stats[2 * f + 1] = trials; }
+#endif
   }
   PO2_ADD(0, tAll);
 }
