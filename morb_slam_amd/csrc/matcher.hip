@@ -715,16 +715,19 @@ __global__ __launch_bounds__(256) void k_bow_transform_lds(const uint8_t* __rest
 // last.  (2) one wave per BoW node present in the keyframe: merge-join against the frame's sorted list,
 // then the keyframe's features of that node IN ORDER (the greedy dependency), lanes over the frame's features
 // of the node with a top-2 lexicographic reduction.  (3) per pair: rotation histogram, three maxima, filter.
-__global__ __launch_bounds__(256) void k_bow_sort(const int* __restrict__ node, const int* __restrict__ count, int cap,
-                                                  int P, unsigned long long* __restrict__ sorted) {
+// Bitonic sort, one thread per compare-exchange (P / 2 threads up to 1024).  A step whose partner distance j is below 64 pairs elements of one 128-key
+// block — the block of ONE wave — so only the steps with j >= 64 need the workgroup barrier (15 of the 66 steps of 2048 keys); the others order
+// their LDS traffic inside the wave.  (256 threads looping over the pairs with a barrier per step: 69 us for the 40 images of the keyframe searches.)
+__global__ __launch_bounds__(1024) void k_bow_sort(const int* __restrict__ node, const int* __restrict__ count, int cap,
+                                                   int P, unsigned long long* __restrict__ sorted) {
   extern __shared__ unsigned long long skeys[];
-  const int img = blockIdx.x, tid = threadIdx.x;
+  const int img = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
   const int n = count[img];
   if (n == 0) {   // (an image that takes no part in BoW matching — the right images of a stereo batch — costs one store pass)
-    for (int i = tid; i < cap; i += 256) sorted[(size_t)img * cap + i] = ~0ull;
+    for (int i = tid; i < cap; i += NT) sorted[(size_t)img * cap + i] = ~0ull;
     return;
   }
-  for (int i = tid; i < P; i += 256) {
+  for (int i = tid; i < P; i += NT) {
     unsigned long long k = ~0ull;
     if (i < n) {
       const int nd = node[(size_t)img * cap + i];
@@ -733,19 +736,21 @@ __global__ __launch_bounds__(256) void k_bow_sort(const int* __restrict__ node, 
     skeys[i] = k;
   }
   __syncthreads();
+  const bool onePass = P / 2 <= NT;   // every pair has its own thread: pairs 64 w .. 64 w + 63 (keys 128 w .. 128 w + 127) belong to wave w
   for (int k = 2; k <= P; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < P; i += 256) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long a = skeys[i], b = skeys[ixj];
-          const bool up = (i & k) == 0;
-          if ((a > b) == up) { skeys[i] = b; skeys[ixj] = a; }
-        }
+      for (int l = tid; l < P / 2; l += NT) {
+        const int i = ((l & ~(j - 1)) << 1) | (l & (j - 1)), ixj = i | j;
+        const unsigned long long a = skeys[i], b = skeys[ixj];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) { skeys[i] = b; skeys[ixj] = a; }
       }
-      __syncthreads();
+      // the next step's partner distance: j / 2 within this merge, k for the first step of the next merge
+      const int jn = j > 1 ? j >> 1 : k;
+      if (onePass && jn < 64 && j < 64) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+      else __syncthreads();
     }
-  for (int i = tid; i < cap; i += 256) sorted[(size_t)img * cap + i] = i < P ? skeys[i] : ~0ull;
+  for (int i = tid; i < cap; i += NT) sorted[(size_t)img * cap + i] = i < P ? skeys[i] : ~0ull;
 }
 
 // SearchByBoW core (ORBmatcher.cc:222-404).  Features of one vocabulary node only compete with each other, so a
@@ -1225,7 +1230,7 @@ int morb_bow_sort_images(morb_matcher* m, int nimg, const int* d_node, const int
   int rc = grow(m->d_sortA, m->sortElems, (size_t)nimg * cap);
   if (rc != MORB_OK) return rc;
   MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_sort), hipFuncAttributeMaxDynamicSharedMemorySize, P * 8));
-  hipLaunchKernelGGL(k_bow_sort, dim3(nimg), dim3(256), (size_t)P * 8, st, d_node, d_count, cap, P, m->d_sortA);
+  hipLaunchKernelGGL(k_bow_sort, dim3(nimg), dim3(P / 2 < 64 ? 64 : P / 2 > 1024 ? 1024 : P / 2), (size_t)P * 8, st, d_node, d_count, cap, P, m->d_sortA);
   *d_sorted = m->d_sortA;
   return MORB_OK;
 }
@@ -1489,7 +1494,7 @@ static int search_by_bow_impl(morb_matcher* m, int npairs, const int* d_kfImg, c
   rc = grow(m->d_bin, m->binElems, (size_t)npairs * cap);
   if (rc != MORB_OK) return rc;
   MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_sort), hipFuncAttributeMaxDynamicSharedMemorySize, P * 8));
-  hipLaunchKernelGGL(k_bow_sort, dim3(nimg), dim3(256), (size_t)P * 8, st, d_node, d_count, cap, P, m->d_sortA);
+  hipLaunchKernelGGL(k_bow_sort, dim3(nimg), dim3(P / 2 < 64 ? 64 : P / 2 > 1024 ? 1024 : P / 2), (size_t)P * 8, st, d_node, d_count, cap, P, m->d_sortA);
   const size_t nm = (size_t)npairs * cap;
   hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, d_matchF, nm, -1);
   int* matched2 = nullptr;
