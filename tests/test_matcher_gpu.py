@@ -123,6 +123,42 @@ def test_knn2_ratio(batch):
     assert (idx[0, :nqn[0], 0] == 0).all() and (idx[0, :nqn[0], 1] == -1).all() and (idx[2, :nqn[2]] == -1).all()
 
 
+@pytest.mark.parametrize("cap2", [96, 640, 1088, 2304, 4500])
+def test_search_by_bow_at_other_frame_capacities(batch, cap2):
+    """The per-frame (node, index) sort behind SearchByBoW is a bitonic network over the next power of two of the frame capacity: one thread per
+    compare-exchange up to 2048 keys (steps inside a wave's 128 keys skip the workgroup barrier), a loop over the pairs beyond.  The same frames
+    cut down / padded to other capacities: 128, 1024, 2048, 4096, 8192 keys."""
+    import torch
+    from morb_slam_amd import ORBmatcher
+    k, Lv, lup = 10, 3, 1
+    vd, vf = make_vocabulary(k, Lv, seed=2)
+    dvd, dvf = torch.from_numpy(vd).cuda(), torch.from_numpy(vf).cuda()
+    nimg, cap = batch["desc"].shape[0], batch["desc"].shape[1]
+    keep = min(cap, cap2)
+    cnt = torch.clamp(batch["cnt"], max=keep).contiguous()
+    desc = torch.zeros((nimg, cap2, 32), dtype=torch.uint8, device="cuda"); desc[:, :keep] = batch["desc"][:, :keep]
+    kps = torch.zeros((nimg, cap2) + tuple(batch["kps"].shape[2:]), dtype=batch["kps"].dtype, device="cuda"); kps[:, :keep] = batch["kps"][:, :keep]
+    m = ORBmatcher(0.7, True)
+    word, node = m.bow_transform(desc, cnt, dvd, dvf, k, Lv, lup)
+    rng = np.random.default_rng(7)
+    has = (rng.random((nimg, cap2)) < 0.8).astype(np.uint8)
+    kf = torch.tensor([0, 2, 4], dtype=torch.int32, device="cuda")
+    fr = torch.tensor([4, 6, 0], dtype=torch.int32, device="cuda")
+    match, nm = m.SearchByBoW(kf, fr, kps, desc, node, cnt, torch.from_numpy(has).cuda())
+    torch.cuda.synchronize()
+    match, nm, nn_, cn = match.cpu().numpy(), nm.cpu().numpy(), node.cpu().numpy(), cnt.cpu().numpy()
+    tot = 0
+    for p, (a, b) in enumerate(zip(kf.cpu().tolist(), fr.cpu().tolist())):
+        na, nb = int(cn[a]), int(cn[b])
+        ka, da = batch["ora"][a][1][:na], batch["ora"][a][2][:na]
+        kb, db = batch["ora"][b][1][:nb], batch["ora"][b][2][:nb]
+        ne, me = O.search_by_bow(da, ka["angle"], has[a, :na], nn_[a, :na], db, kb["angle"], nn_[b, :nb], 0.7, True)
+        assert nm[p] == ne
+        np.testing.assert_array_equal(match[p, :nb], me)
+        tot += ne
+    assert tot > (10 if cap2 < 200 else 200)
+
+
 # vocabulary shapes: ~12 features per node (one register slot per lane), ~75 per node (two slots per lane, keyframe
 # features in two chunks), ~400 per node (the general path of k_bow_match)
 @pytest.mark.parametrize("k,Lv,lup,settings", [(10, 3, 1, ((0.7, True), (0.9, False), (0.6, True))),
