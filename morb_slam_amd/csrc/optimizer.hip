@@ -983,7 +983,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
   // lambda * ni — everything that solve needs is known when the rejected trial's pass STARTS.  The last wave computes it beside the pass
   // (no edges of its own), and the ~5 k cycles of LDL^T + exp + pose update leave the critical path of every trial that follows a rejection
   // (more than half of them: near convergence g2o's LM rejects its way up in lambda, up to ten trials per iteration).
-  const bool spec = ORDERED && MFMA && MORB_PO2_SPEC && cap <= po2_spec_cap();
+  const bool spec = ORDERED && MFMA && MORB_PO2_SPEC && (BIG || cap <= po2_spec_cap());   // (the large-frame form reads the edges of its further stages from memory anyway)
   const int s0 = spec ? S0 - 64 : S0, nwork = spec ? NWORK - 64 : NWORK;   // edges of the first / of a later stage
   // the edge thread `tid` computes in stage s (its row of the stage, the stage's first edge)
   auto stage_row = [&](int s) { return ORDERED && (s > 0 || !MFMA) ? (wrow < nwork ? wrow : -1) : (tid < s0 ? tid : -1); };
@@ -1069,8 +1069,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
       if (specLam >= 0) ok2 = solve_a(buf ^ 1, lamG, x, b);
       __syncthreads();                                   // the first stage's contributions are in LDS
       if (specLam >= 0) solve_b(ok2, lamG, x, b, get(2), sSpec[0], sSpecFlag, 9);
-      for (int s = 1; s < PO2_EPT; ++s) {
-        if (stage_base(s) >= nAct) break;
+      for (int s = 1; stage_base(s) < nAct; ++s) {
         __syncthreads();
         __syncthreads();
       }
@@ -1261,6 +1260,22 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
               }
             }
           }
+          if (BIG && wv != NW - 1) {
+            const SE3 Tr = FISH ? se3_mul(rig.Trl, T) : T;
+            for (int s = PO2_EPT; stage_base(s) < nAct; ++s) {   // (the stages whose edges are not in registers)
+              const int row = stage_row(s), e = stage_base(s) + row;
+              if (row >= 0 && e < nAct) {
+                PoEdge ee;
+                load_edge(actList[e], ee);
+                const double X[3] = {(double)ee.X[0], (double)ee.X[1], (double)ee.X[2]};
+                double xc[3], err[3], w;
+                bool st;
+                double c = pose_edge_error<FISH>(cam, rig, T, Tr, FISH && ee.right, X, ee.o, (double)ee.info, err, st, xc);
+                if (robust) c = huber(st ? deltaStereo : deltaMono, c, &w);
+                part += c;
+              }
+            }
+          }
           part = wave_sum_d(part);
           if (lane == 0) sChiA[par][wv] = part;
           __syncthreads();
@@ -1358,7 +1373,7 @@ static int launch_pose_opt2(bool ordered, bool mfmaChain, int nframes, hipStream
                             const float* d_invSigma2, const float* d_Xw, const Cam& cam, const Rig& rig, const int* d_nLeft, float* d_pose,
                             uint8_t* d_outlier, int* d_nInliers, int* d_stats) {
   const size_t listBytes = ((size_t)cap * 2 + 15) & ~(size_t)15;
-  const bool big = cap > po2_reg_cap(ordered, mfmaChain);
+  const bool big = cap > (ordered && mfmaChain && MORB_PO2_SPEC ? po2_spec_cap() : po2_reg_cap(ordered, mfmaChain));   // (matrix-core chain: frames beyond the speculation wave's stages)
   const size_t lds = ordered ? (size_t)po2_rows(mfmaChain) * PO_PITCH * 8 + 32 + listBytes : listBytes;   // (+32: the second accumulator's lanes 12 .. 15 read past the last row)
 #define MORB_PO2_GO(O, M, B) return launch_pose_opt2_as<FISH, O, M, B>(nframes, st, lds, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig, d_nLeft, d_pose, d_outlier, d_nInliers, d_stats)
   if (ordered && mfmaChain) { if (big) MORB_PO2_GO(true, true, true); else MORB_PO2_GO(true, true, false); }

@@ -1,3 +1,2 @@
-timeout 900 python -m pytest tests/test_matcher_gpu.py tests/test_tracking_gpu.py tests/test_bench_chain_gpu.py tests/test_adapter_matcher_gpu.py tests/test_fisheye_gpu.py -m gpu -x -q 2>&1 | tail -2
-timeout 300 python tools/bench_tracking.py 256 10 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('keyframe_searches_ms', d['keyframe_searches_ms'], 'chain', d['tracking_frames_per_s'])"
-python bench.py --no-extras --no-cpu-baseline --sustained-s 0 --no-verify 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('headline', d['value'], d['ms_per_step'])"
+timeout 900 python -m pytest tests/test_optimizer_gpu.py tests/test_tracking_gpu.py tests/test_fisheye_gpu.py tests/test_stress_gpu.py -m gpu -x -q 2>&1 | tail -2
+for n in 600 1600 2000 4000; do echo "features $n"; python tools/pose_opt_modes.py $n 2>/dev/null | grep "exact"; done
