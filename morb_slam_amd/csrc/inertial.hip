@@ -654,6 +654,10 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
                                                        int bRecInit, float* __restrict__ stateIO, uint8_t* __restrict__ outlier,
                                                        int* __restrict__ nInliersOut, double* __restrict__ prior) {
   __shared__ InertialWork Wk;
+  // the round's ACTIVE visual edges (map point present, not an outlier of the round before), compacted in feature order: (u, v, uR | X | info | camera)
+  // as eight floats per edge.  The ten Gauss-Newton iterations of a round read them from here: each of a thread's three to five edges used to start
+  // with a dependent round trip to global memory for its flags and another for its data (~2 k cycles per edge beside ~2.6 k of arithmetic).
+  extern __shared__ __align__(16) float sEdge[];
   __shared__ VIState sS1;   // state 1 (keyframe / previous frame): only the dense-edge threads read it, one thread updates it
   constexpr int NV = LASTFRAME ? 30 : 15;
   // threads on the visual edges; wave 3 evaluates the inertial edge and (last-frame variant) wave 2 the prior edge meanwhile
@@ -718,6 +722,24 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
 
   for (int it = 0; it < 4; ++it) {
     bool ok = true;
+    int nAct = 0;
+    for (int c0 = 0; c0 < n; c0 += 256) {
+      const int i = c0 + tid;
+      const bool a = i < n && hasMP[base + i] && !outlier[base + i];
+      const unsigned long long m = __ballot(a);
+      if (lane == 0) Wk.cnt[wv][0] = __popcll(m);
+      __syncthreads();
+      int off = nAct, totc = 0;
+      for (int w = 0; w < 4; ++w) { const int c = Wk.cnt[w][0]; if (w < wv) off += c; totc += c; }
+      if (a) {
+        float* r = sEdge + 8 * (size_t)(off + __popcll(m & ((1ull << lane) - 1ull)));
+        r[0] = obs[(base + i) * 3]; r[1] = obs[(base + i) * 3 + 1]; r[2] = obs[(base + i) * 3 + 2];
+        r[3] = Xw[(base + i) * 3]; r[4] = Xw[(base + i) * 3 + 1]; r[5] = Xw[(base + i) * 3 + 2];
+        r[6] = invSigma2[base + i]; r[7] = i >= nL ? 1.0f : 0.0f;
+      }
+      nAct += totc;
+      __syncthreads();
+    }
     for (int iter = 0; iter < 10 && ok; ++iter) {
       IMARK(1);
       keep_cameras();   // the state the active edges' errors belong to
@@ -726,13 +748,12 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
         double acc[27];
 #pragma unroll
         for (int k = 0; k < 27; ++k) acc[k] = 0;
-        for (int i = tid; i < n; i += NVIS) {
-          if (!hasMP[base + i] || outlier[base + i]) continue;
-          const float* o = obs + (base + i) * 3;
+        for (int e = tid; e < nAct; e += NVIS) {
+          const float* o = sEdge + 8 * (size_t)e;
           const bool st = !RIG && !(o[2] < 0);
-          const int cam = i >= nL ? 1 : 0;
-          const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
-          const double info = (double)invSigma2[base + i];
+          const int cam = o[7] != 0.0f ? 1 : 0;
+          const double X[3] = {(double)o[3], (double)o[4], (double)o[5]};
+          const double info = (double)o[6];
           double err[3], Xc[3], J[18];
           const double c = vis_error_t<RIG>(g, S, X, o, st, info, err, Xc, cam);
           const double w = robust ? huber_w(st ? deltaStereo : deltaMono, c) : 1.0;
@@ -1808,9 +1829,14 @@ static int launch_pose_inertial(bool lastFrame, morb_optimizer* o, int nframes, 
   hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_optimizer_stream(o);
   CamGeom g;
   make_geom(Tbc12, fx, fy, cx, cy, bf, rig28, g);
+  const size_t edgeLds = (size_t)cap * 32;   // the active visual edges of a frame, eight floats each
+  MORB_REQUIRE(edgeLds + sizeof(InertialWork) + 1024 <= 160 * 1024, MORB_ERR_UNSUPPORTED, "too many features per frame for the LDS edge list");
 #define MORB_LAUNCH_PI(LF, RG)                                                                                                       \
-  hipLaunchKernelGGL((k_pose_inertial<LF, RG>), dim3(nframes), dim3(256), 0, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, d_close, \
-                     g, d_state1, d_pre, d_preKF, d_prevPrior, d_nLeft, bRecInit, d_state, d_outlier, d_nInliers, d_prior)
+  do {                                                                                                                               \
+    MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_inertial<LF, RG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)edgeLds)); \
+    hipLaunchKernelGGL((k_pose_inertial<LF, RG>), dim3(nframes), dim3(256), edgeLds, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, d_close, \
+                       g, d_state1, d_pre, d_preKF, d_prevPrior, d_nLeft, bRecInit, d_state, d_outlier, d_nInliers, d_prior);          \
+  } while (0)
   if (lastFrame) { if (rig28) MORB_LAUNCH_PI(true, true); else MORB_LAUNCH_PI(true, false); }
   else { if (rig28) MORB_LAUNCH_PI(false, true); else MORB_LAUNCH_PI(false, false); }
 #undef MORB_LAUNCH_PI
