@@ -21,11 +21,11 @@ HOT = ["k_resize", "k_resize_gather", "k_level0", "k_blur", "k_fastw", "k_distri
        "k_search", "k_pose_edges", "k_discard", "k_set_pose",
        "k_g_build", "k_imu_preintegrate", "k_iba_setup_links", "k_iba_points", "k_iba_links", "k_iba_solve_lds", "k_iba_update", "k_iba_finish"]
 # kernels that still spill, pinned at what they use today so that a regression shows: the 30-unknown
-# PoseInertialOptimizationLastFrame kernel sits at the 512-register limit (168 B; 740 B before round 4, the 15-unknown LastKeyFrame forms are at 0),
+# PoseInertialOptimizationLastFrame kernel sits at the 512-register limit (168 B pinhole, 200 B on the rig; 740 B before round 4, the 15-unknown LastKeyFrame forms are at 0),
 # two LocalInertialBA phase kernels, and the persistent-workgroup LocalBA mode (not the default)
 # round 5: k_pose_opt2 (512 threads per frame: 256 registers per thread) spills a few of its uniform LM scalars and the edges of its later stages
 # (pinhole <= 300 B; the KB8-rig forms 450 - 600 B, their large-frame instantiations — a second inlined edge function — up to 850 B)
-BOUNDED = {"k_pose_inertial": 168, "k_iba_errors": 68, "k_iba_kf": 84, "k_local_ba": 560, "k_pose_opt2": 900}
+BOUNDED = {"k_pose_inertial": 200, "k_iba_errors": 68, "k_iba_kf": 84, "k_local_ba": 560, "k_pose_opt2": 900}
 
 
 def _kernel_metadata(lib, tmp):
