@@ -499,14 +499,17 @@ __device__ __forceinline__ void vis_jacobian_t(const CamGeom& g, const double* X
   pj[6] = pj[7] = pj[8] = 0;
   if (st) { pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + g.bf * (1.0 / (Xc[2] * Xc[2])); }
   const double x = Xb[0], y = Xb[1], z = Xb[2];
-  const double Sd[18] = {0.0, z, -y, 1.0, 0.0, 0.0, -z, 0.0, x, 0.0, 1.0, 0.0, y, -x, 0.0, 0.0, 0.0, 1.0};
+  // J = (proj_jac Rcb) [ -[Xb]x | I ]: SE3deriv = {0, z, -y, 1, 0, 0; -z, 0, x, 0, 1, 0; y, -x, 0, 0, 0, 1} written out — its zeros and ones cost 63 of an
+  // edge's ~300 FP64 instructions when multiplied through (x * 0.0 does not fold); the same values (a + 0 = a, a * 1 = a)
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     double PR[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) PR[c] = pj[r * 3] * Rcb[c] + pj[r * 3 + 1] * Rcb[3 + c] + pj[r * 3 + 2] * Rcb[6 + c];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) J[r * 6 + c] = PR[0] * Sd[c] + PR[1] * Sd[6 + c] + PR[2] * Sd[12 + c];
+    J[r * 6 + 0] = PR[1] * -z + PR[2] * y;
+    J[r * 6 + 1] = PR[0] * z + PR[2] * -x;
+    J[r * 6 + 2] = PR[0] * -y + PR[1] * x;
+    J[r * 6 + 3] = PR[0]; J[r * 6 + 4] = PR[1]; J[r * 6 + 5] = PR[2];
   }
 }
 __device__ __forceinline__ void vis_jacobian(const CamGeom& g, const double* Xc, bool st, double* J, int cam = 0) {
