@@ -876,14 +876,12 @@ constexpr int PO2_NT = 512, PO2_NW = PO2_NT / 64, PO2_EPT = MORB_PO2_EPT;
 __host__ __device__ constexpr int po2_stage(bool mfma) { return PO2_NT - 64 * (mfma ? 2 : 1); }   // (matrix-core chain: waves 0 and 1 carry 16 + 12 sums)
 // matrix-core chain: the FIRST stage is computed by all eight waves (the summing waves have nothing to add yet) and holds PO2_NT edges
 __host__ __device__ constexpr int po2_rows(bool mfma) { return mfma ? PO2_NT : po2_stage(false); }   // rows of the contribution buffer
+#ifndef MORB_PO2_SPEC
+#define MORB_PO2_SPEC 1      // matrix-core chain: an iteration's first solve carries the nine trials that can follow it (one lambda per lane)
+#endif
 #ifndef MORB_PO2_PREVIEW
 #define MORB_PO2_PREVIEW 1   // ... and a trial that follows a rejection is first judged by a tree sum of its chi2 (a rigorous "certainly rejected" test)
 #endif
-#ifndef MORB_PO2_SPEC
-#define MORB_PO2_SPEC 1   // matrix-core chain: the last wave computes no edges; beside every trial's pass it solves the trial that FOLLOWS A REJECTION
-#endif
-// ... which leaves seven waves for the first stage and five for the later ones (frames too large for that keep all waves on the edges)
-__host__ __device__ constexpr int po2_spec_cap() { return MORB_PO2_SPEC ? (PO2_NT - 64) + (PO2_EPT - 1) * (po2_stage(true) - 64) : 0; }
 // frames beyond the registers' stages (PO2_NT + (PO2_EPT - 1) x stage edges) read the further edges again in every pass; the list of active features
 // (two bytes per feature) has to fit in LDS beside the contribution buffer
 constexpr int PO2_MAX_CAP = 8192;
@@ -966,11 +964,9 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
   __shared__ double red[NW];
   __shared__ double sH[NW][28];
   __shared__ double sTot[2][28];     // H (lower triangle 0 .. 20), b (21 .. 26), robust chi2 (27) at the state last built / at the trial state
-  __shared__ double sPose[8];        // the trial pose (wave 0 -> everybody) + scale
   __shared__ double sKeep[3][7];     // uniform poses that would otherwise sit in every thread's registers: T0, Teval, the trial's backup
-  __shared__ int sFlag[2];
-  __shared__ double sSpec[9][8];     // the speculation wave's trial poses + scales: slot q - 1 = the iteration's trial q if trials 0 .. q - 1 are rejected
-  __shared__ int sSpecFlag[9];
+  __shared__ double sSpec[10][8];    // trial poses + scales of an iteration: slot q = its trial q (if trials 0 .. q - 1 are rejected)
+  __shared__ int sSpecFlag[10];
   __shared__ double sChiA[2][NW];    // the waves' partial sums of a trial's chi2 preview, by trial parity
   __shared__ int sWaveCnt[NW];
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -979,12 +975,13 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   // this thread's row in a stage (-1: not a worker)
   const int wrow = tid >= W0 ? tid - W0 : -1;
-  // Speculation wave (matrix-core chain, frames that leave room for it): a rejected trial is followed by a trial from the SAME state with
-  // lambda * ni — everything that solve needs is known when the rejected trial's pass STARTS.  The last wave computes it beside the pass
-  // (no edges of its own), and the ~5 k cycles of LDL^T + exp + pose update leave the critical path of every trial that follows a rejection
-  // (more than half of them: near convergence g2o's LM rejects its way up in lambda, up to ten trials per iteration).
-  const bool spec = ORDERED && MFMA && MORB_PO2_SPEC && (BIG || cap <= po2_spec_cap());   // (the large-frame form reads the edges of its further stages from memory anyway)
-  const int s0 = spec ? S0 - 64 : S0, nwork = spec ? NWORK - 64 : NWORK;   // edges of the first / of a later stage
+  // Speculation (matrix-core chain): a rejected trial is followed by a trial from the SAME state with lambda * ni, the next one with that * 2 ni, ... —
+  // everything the solves of an iteration's up to ten trials need is known when its first trial is solved.  Wave 0's solve is uniform code, so its
+  // lanes carry all ten at once: lane g the trial with lambda_g (the bookkeeping's own `lambda *= ni; ni *= 2`, g times: the same bits).  The ~5 k
+  // cycles of LDL^T + exp + pose update are paid once per iteration instead of once per trial (more than half of all trials follow a rejection: near
+  // convergence g2o's LM rejects its way up in lambda, up to ten trials per iteration).
+  const bool spec = ORDERED && MFMA && MORB_PO2_SPEC;
+  const int s0 = S0, nwork = NWORK;   // edges of the first / of a later stage
   // the edge thread `tid` computes in stage s (its row of the stage, the stage's first edge)
   auto stage_row = [&](int s) { return ORDERED && (s > 0 || !MFMA) ? (wrow < nwork ? wrow : -1) : (tid < s0 ? tid : -1); };
   auto stage_base = [&](int s) { return s == 0 ? 0 : s0 + (s - 1) * nwork; };
@@ -1013,17 +1010,18 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
   PoEdge ed[PO2_EPT];
   int nAct = 0;
 
-  // H, b, chi2 of the active edges at pose P -> sTot[buf]
   auto load_edge = [&](int i, PoEdge& e) {
     e.o[0] = obs[(base + i) * 3]; e.o[1] = obs[(base + i) * 3 + 1]; e.o[2] = obs[(base + i) * 3 + 2];
     e.X[0] = Xw[(base + i) * 3]; e.X[1] = Xw[(base + i) * 3 + 1]; e.X[2] = Xw[(base + i) * 3 + 2];
     e.info = invSigma2[base + i];
     e.right = i >= nL;
   };
-  // one LM trial's solve, all lanes of the calling wave alike: (H + lam I) x = b of sTot[src], Tn = exp(x) Tb, scale = x . (lam x + b) + 1e-3; in two
-  // parts, because the speculation wave has a workgroup barrier to attend in between
-  auto solve_a = [&](int src, double lam, double (&x)[6], double (&b)[6]) {
-    double H[36];
+  // The solve of an iteration's trials, by wave 0: (H + lam I) x = b of sTot[src], Tn = exp(x) Tb, scale = x . (lam x + b) + 1e-3.  Lane g < nTrials solves
+  // trial g — lam_g = lam after g rejections — and writes sSpec[g] / sSpecFlag[g]; the other lanes repeat lane nTrials - 1's arithmetic.
+  auto solve_trials = [&](int src, double lam, double niv, const SE3& Tb, int nTrials) {
+    const int g = min(lane, nTrials - 1);
+    for (int j = 0; j < g; ++j) { lam *= niv; niv *= 2; }
+    double H[36], b[6], x[6];
     int q = 0;
 #pragma unroll
     for (int r = 0; r < 6; ++r)
@@ -1031,51 +1029,24 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
       for (int cc = 0; cc <= r; ++cc) { const double v = sTot[src][q++]; H[r * 6 + cc] = v; H[cc * 6 + r] = v; }
 #pragma unroll
     for (int r = 0; r < 6; ++r) { b[r] = sTot[src][21 + r]; H[r * 6 + r] += lam; x[r] = 0; }
-    return ldlt6(H, b, x);
-  };
-  // (nOut lanes write: lane l its own result to out8 + 8 l / outFlag + l — the speculation wave solves nine trials at once, one lambda per lane)
-  auto solve_b = [&](bool ok2, double lam, const double (&x)[6], const double (&b)[6], const SE3& Tb, double* out8, int* outFlag, int nOut) {
+    const bool ok2 = ldlt6(H, b, x);
     const SE3 Tn = se3_mul(se3_exp(x), Tb);
     double scale = 0;
 #pragma unroll
     for (int r = 0; r < 6; ++r) scale += x[r] * (lam * x[r] + b[r]);
     scale += 1e-3;
-    if (lane < nOut) {
-      double* o8 = out8 + 8 * lane;
+    if (lane < nTrials) {
+      double* o8 = sSpec[lane];
       for (int k = 0; k < 4; ++k) o8[k] = Tn.q[k];
       for (int k = 0; k < 3; ++k) o8[4 + k] = Tn.t[k];
       o8[7] = scale;
-      outFlag[lane] = ok2 ? 1 : 0;
+      sSpecFlag[lane] = ok2 ? 1 : 0;
     }
   };
-  auto solve_trial = [&](int src, double lam, const SE3& Tb, double* out8, int* outFlag) {
-    double x[6], b[6];
-    const bool ok2 = solve_a(src, lam, x, b);
-    solve_b(ok2, lam, x, b, Tb, out8, outFlag, 1);
-  };
-  // specLam >= 0 (an iteration's first trial, lambda and ni of that trial): beside the pass, the speculation wave solves the NINE trials that follow
-  // if this one and the ones after it are rejected — lane g the trial with lambda_g (lambda *= ni, ni *= 2, g + 1 times: the bookkeeping's own
-  // operations, so the same bits) from the state sTot[buf ^ 1] and the pose sKeep[2]: one solve, nine lambdas
-  auto pass = [&](const SE3& P, int buf, double specLam, double specNi) {
+  // H, b, chi2 of the active edges at pose P -> sTot[buf]
+  auto pass = [&](const SE3& P, int buf) {
     PO2_T0(tp); PO2_CNT(4);
     const SE3 Pr = FISH ? se3_mul(rig.Trl, P) : P;
-    if (ORDERED && MFMA && spec && wv == NW - 1) {
-      // the speculation wave: the LDL^T beside the first stage's edge math, exp and the pose update beside its sums; it meets the other waves at
-      // every barrier of the pass (s_barrier counts arrivals, whichever instruction a wave arrives at)
-      double x[6], b[6];
-      bool ok2 = false;
-      double lamG = specLam, niG = specNi;
-      for (int g = 0; g <= min(lane, 8); ++g) { lamG *= niG; niG *= 2; }
-      if (specLam >= 0) ok2 = solve_a(buf ^ 1, lamG, x, b);
-      __syncthreads();                                   // the first stage's contributions are in LDS
-      if (specLam >= 0) solve_b(ok2, lamG, x, b, get(2), sSpec[0], sSpecFlag, 9);
-      for (int s = 1; stage_base(s) < nAct; ++s) {
-        __syncthreads();
-        __syncthreads();
-      }
-      __syncthreads();
-      return;
-    }
     if (ORDERED) {
       double tot = 0;   // VALU chain: lanes 0 .. 27 of wave 0 hold entry `lane`; matrix-core chain: the accumulator (D layout) of waves 0 and 1
       const int nAct16 = (nAct + 15) & ~15;
@@ -1198,7 +1169,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
     PO2_ADD(5, tc);
     // ---- optimizer.optimize(10) ----
     int cur = 0;
-    pass(T, cur, -1.0, 0.0);
+    pass(T, cur);
     double lambda = 0, ni = 2;
     int nBad = 0;
     for (int iter = 0; iter < 10; ++iter) {
@@ -1215,23 +1186,17 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
       int qmax = 0;
       do {
         PO2_T0(ts);
-        double scale;
-        bool ok2;
-        if (spec && qmax > 0) {   // the trial after a rejection: solved beside the rejected trial's pass (same state, lambda * ni: the same bits)
-          const int sl = qmax - 1;
-          for (int k = 0; k < 4; ++k) T.q[k] = sSpec[sl][k];
-          for (int k = 0; k < 3; ++k) T.t[k] = sSpec[sl][4 + k];
-          scale = sSpec[sl][7];
-          ok2 = sSpecFlag[sl] != 0;
-        } else {
-          put(2, T);           // backup (read behind the barriers of the trial's pass)
-          if (wv == 0) solve_trial(cur, lambda, T, sPose, &sFlag[0]);
+        // the iteration's first trial (every trial without the speculation): the solve; a trial after a rejection finds its pose in its slot
+        if (qmax == 0 || !spec) {
+          if (qmax == 0) put(2, T);           // backup (thread 0 writes it, its own wave reads it back below: LDS operations of a wave execute in order)
+          if (wv == 0) solve_trials(cur, lambda, ni, get(2), spec ? 10 : 1);   // (the slots' last readers are behind the barriers of the pass before)
           __syncthreads();
-          for (int k = 0; k < 4; ++k) T.q[k] = sPose[k];
-          for (int k = 0; k < 3; ++k) T.t[k] = sPose[4 + k];
-          scale = sPose[7];
-          ok2 = sFlag[0] != 0;
         }
+        const int sl = spec ? qmax : 0;
+        for (int k = 0; k < 4; ++k) T.q[k] = sSpec[sl][k];
+        for (int k = 0; k < 3; ++k) T.t[k] = sSpec[sl][4 + k];
+        const double scale = sSpec[sl][7];
+        const bool ok2 = sSpecFlag[sl] != 0;
         PO2_ADD(1, ts);
         put(1, T);           // Teval
         // A trial that follows a rejection is usually rejected too (g2o's LM climbs in lambda near convergence), and a rejected trial leaves nothing
@@ -1245,7 +1210,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
         if (spec && MORB_PO2_PREVIEW && qmax > 0 && ok2 && scale > 0) {
           const int par = trials & 1;
           double part = 0;
-          if (wv != NW - 1) {
+          {
             const SE3 Tr = FISH ? se3_mul(rig.Trl, T) : T;
 #pragma unroll
             for (int s = 0; s < PO2_EPT; ++s) {
@@ -1260,7 +1225,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
               }
             }
           }
-          if (BIG && wv != NW - 1) {
+          if (BIG) {
             const SE3 Tr = FISH ? se3_mul(rig.Trl, T) : T;
             for (int s = PO2_EPT; stage_base(s) < nAct; ++s) {   // (the stages whose edges are not in registers)
               const int row = stage_row(s), e = stage_base(s) + row;
@@ -1286,7 +1251,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
         }
         double tempChi = 1.7976931348623157e308;
         if (!certainlyRejected) {
-          pass(T, cur ^ 1, qmax == 0 ? lambda : -1.0, ni);
+          pass(T, cur ^ 1);
           tempChi = sTot[cur ^ 1][27];
           if (!ok2) tempChi = 1.7976931348623157e308;
         }
@@ -1373,7 +1338,7 @@ static int launch_pose_opt2(bool ordered, bool mfmaChain, int nframes, hipStream
                             const float* d_invSigma2, const float* d_Xw, const Cam& cam, const Rig& rig, const int* d_nLeft, float* d_pose,
                             uint8_t* d_outlier, int* d_nInliers, int* d_stats) {
   const size_t listBytes = ((size_t)cap * 2 + 15) & ~(size_t)15;
-  const bool big = cap > (ordered && mfmaChain && MORB_PO2_SPEC ? po2_spec_cap() : po2_reg_cap(ordered, mfmaChain));   // (matrix-core chain: frames beyond the speculation wave's stages)
+  const bool big = cap > po2_reg_cap(ordered, mfmaChain);
   const size_t lds = ordered ? (size_t)po2_rows(mfmaChain) * PO_PITCH * 8 + 32 + listBytes : listBytes;   // (+32: the second accumulator's lanes 12 .. 15 read past the last row)
 #define MORB_PO2_GO(O, M, B) return launch_pose_opt2_as<FISH, O, M, B>(nframes, st, lds, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, cam, rig, d_nLeft, d_pose, d_outlier, d_nInliers, d_stats)
   if (ordered && mfmaChain) { if (big) MORB_PO2_GO(true, true, true); else MORB_PO2_GO(true, true, false); }
