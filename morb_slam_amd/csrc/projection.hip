@@ -769,11 +769,12 @@ struct SearchLds {   // carved from dynamic LDS
   uint32_t* qOff;    // [qCapR + 4]      exclusive prefix of the queries' visit counts
   uint32_t* qRange;  // [qCapR]          cx0 | cx1 << 6 | cy0 << 12 | cy1 << 18 | valid << 31
   uint8_t* blk0;     // [capR]           blocked on entry; later: "an entry of this feature fell to the rotation filter"
+  uint32_t* blk2;    // [capR]           the fixed point's second copy of blk (the passes alternate)
 };
 __host__ __device__ inline size_t search_lds_bytes(int cap, int qCap, bool withDesc) {
   const size_t capR = (size_t)(cap + 3) & ~(size_t)3, qCapR = (size_t)(qCap + 3) & ~(size_t)3;
   return 4 * ((size_t)GRID_CELLS + 4) + 4 * (size_t)GRID_CELLS + 4 * capR + 4 * qCapR + 16 * capR + (withDesc ? 32 * capR : 0) + 2 * capR * 3 +
-         4 * qCapR + 4 * (qCapR + 4) + 4 * qCapR + capR;
+         4 * qCapR + 4 * (qCapR + 4) + 4 * qCapR + capR + 4 * capR;
 }
 
 #ifdef MORB_SEARCH_CYCLES   // developer build (tools/ab_build.py): thread 0 of frame 0 adds up where its cycles go
@@ -803,7 +804,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(morb_frame_params P, 
   __shared__ int hist[HISTO_LENGTH];
   __shared__ int keep3[3];
   __shared__ uint32_t waveTot[SEARCH_THREADS / 64];
-  __shared__ int sLo, sAcc, sRem;
+  __shared__ int sLo2[2], sAcc, sRem;
   const int f = blockIdx.x, tid = threadIdx.x;
   const int img = fImg[f];
   const int N = min(count[img], cap);
@@ -824,7 +825,8 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(morb_frame_params P, 
     L.qcnt = (uint32_t*)p; p += 4 * qCapR;
     L.qOff = (uint32_t*)p; p += 4 * (qCapR + 4);
     L.qRange = (uint32_t*)p; p += 4 * qCapR;
-    L.blk0 = p;
+    L.blk0 = p; p += capR;
+    L.blk2 = (uint32_t*)p;
   }
   const morb_keypoint* kpRow = kps + (size_t)img * cap;
   const uint8_t* descRow = desc + (size_t)img * cap * 32;
@@ -1045,15 +1047,19 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(morb_frame_params P, 
     }
     return accept ? (((k1 >> 4) & 0xFFFFu) | ((ho ? 1u : 0u) << 16)) : ~0u;
   };
-  int lo = 0;
+  // Two barriers per pass: blk and the "first changed query" word exist twice and the passes alternate — while a pass recomputes the results from its
+  // copy it also resets the other one for the next pass (four barriers per pass before: reset | scatter | recompute | read the word).
+  int lo = 0, pb = 0;
+  for (int p = tid; p < M; p += SEARCH_THREADS) L.blk[p] = L.blk0[p] ? 0u : ~0u;
+  if (tid == 0) { sLo2[0] = 0x7fffffff; sLo2[1] = 0x7fffffff; }
+  __syncthreads();
   for (;;) {
     SRCH_CNT(4);
-    for (int p = tid; p < M; p += SEARCH_THREADS) L.blk[p] = L.blk0[p] ? 0u : ~0u;
-    if (tid == 0) sLo = 0x7fffffff;
-    __syncthreads();
+    uint32_t* const B = pb ? L.blk2 : L.blk;
+    uint32_t* const Bn = pb ? L.blk : L.blk2;
     for (int qi = tid; qi < nQ; qi += SEARCH_THREADS) {
       const uint32_t r = L.res[qi];
-      if (r != ~0u && (r & 0x10000u)) atomicMin(&L.blk[r & 0xFFFFu], (uint32_t)qi + 1u);
+      if (r != ~0u && (r & 0x10000u)) atomicMin(&B[r & 0xFFFFu], (uint32_t)qi + 1u);
     }
     __syncthreads();
     int changed = 0x7fffffff;
@@ -1068,17 +1074,17 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(morb_frame_params P, 
 #pragma unroll
         for (int c = 0; c < SEARCH_REG; ++c) {
           const uint32_t k = kreg[sl][c];
-          if (k != ~0u && L.blk[(k >> 4) & 0xFFFFu] > (uint32_t)qi) top2_insert32(k1, k2, k);
+          if (k != ~0u && B[(k >> 4) & 0xFFFFu] > (uint32_t)qi) top2_insert32(k1, k2, k);
         }
         for (int c = SEARCH_REG; c < n; ++c) {
           const uint32_t k = candF[(size_t)c * qCap + qi];
-          if (L.blk[(k >> 4) & 0xFFFFu] > (uint32_t)qi) top2_insert32(k1, k2, k);
+          if (B[(k >> 4) & 0xFFFFu] > (uint32_t)qi) top2_insert32(k1, k2, k);
         }
       } else {
         const size_t qo = (size_t)f * qCap + qi;
         const Query q = qs[qo];
         const Desc qd = load_desc(qDesc + qo * 32);
-        for_each_candidate(q, qd, [&](uint32_t k) { if (L.blk[(k >> 4) & 0xFFFFu] > (uint32_t)qi) top2_insert32(k1, k2, k); });
+        for_each_candidate(q, qd, [&](uint32_t k) { if (B[(k >> 4) & 0xFFFFu] > (uint32_t)qi) top2_insert32(k1, k2, k); });
       }
       const uint32_t r = decide(qi, k1, k2, (ownHo >> sl) & 1u);
       if (r != L.res[qi]) { L.res[qi] = r; changed = min(changed, qi); }
@@ -1090,23 +1096,25 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(morb_frame_params P, 
       if (n <= SEARCH_CAP) {
         for (int c = 0; c < n; ++c) {
           const uint32_t k = candF[(size_t)c * qCap + qi];
-          if (L.blk[(k >> 4) & 0xFFFFu] > (uint32_t)qi) top2_insert32(k1, k2, k);
+          if (B[(k >> 4) & 0xFFFFu] > (uint32_t)qi) top2_insert32(k1, k2, k);
         }
       } else {
         const size_t qo = (size_t)f * qCap + qi;
         const Query q = qs[qo];
         const Desc qd = load_desc(qDesc + qo * 32);
-        for_each_candidate(q, qd, [&](uint32_t k) { if (L.blk[(k >> 4) & 0xFFFFu] > (uint32_t)qi) top2_insert32(k1, k2, k); });
+        for_each_candidate(q, qd, [&](uint32_t k) { if (B[(k >> 4) & 0xFFFFu] > (uint32_t)qi) top2_insert32(k1, k2, k); });
       }
       const uint32_t r = decide(qi, k1, k2, qHasObs ? (qHasObs[(size_t)f * qCap + qi] != 0) : true);
       if (r != L.res[qi]) { L.res[qi] = r; changed = min(changed, qi); }
     }
-    if (changed != 0x7fffffff) atomicMin(&sLo, changed);
+    if (changed != 0x7fffffff) atomicMin(&sLo2[pb], changed);
+    for (int p = tid; p < M; p += SEARCH_THREADS) Bn[p] = L.blk0[p] ? 0u : ~0u;   // (the next pass's copy: nobody reads it in this pass)
+    if (tid == 0) sLo2[pb ^ 1] = 0x7fffffff;                                        // (read last behind the barrier before this pass's scatter)
     __syncthreads();
-    const int first = sLo;
+    const int first = sLo2[pb];
     if (first == 0x7fffffff) break;
     lo = first + 1;      // queries up to the first change are final (their inputs are results of queries below them)
-    __syncthreads();     // (sLo is rewritten at the top of the loop)
+    pb ^= 1;
   }
   SRCH_MARK(2);
   // ---- outputs: last accepted query per feature, rotation filter (MODE 0), counts
