@@ -23,7 +23,30 @@ for rep in range(2):
     out = (C.c_ulonglong * 16)()
     L.morb_inertial_timing(out, 0)
 names = ["setup", "loop-top/classify-in", "visual", "dense-edges", "OmegaJ", "H-assembly", "solve", "update", "classify", "final", "prior"]
-tot = sum(out)
-for n, v in zip(names, out):
-    print(f"{n:22s} {v / 100.0:9.1f} us")
-print("total", tot / 100.0, "us")
+def show(title, out):
+    print("==", title)
+    for n, v in zip(names, out):
+        print(f"{n:22s} {v / 100.0:9.1f} us")
+    print("total", sum(out) / 100.0, "us")
+show("PoseInertialOptimizationLastKeyFrame", out)
+if len(sys.argv) > 1 and sys.argv[1] == "lf":   # ... and LastFrame: frame B against frame A (its state and prior from the call above)
+    from morb_slam_amd.synth import make_inertial_sequence
+    pA, pB = make_inertial_sequence(600, seed=0, n_imu=20)
+    tb = lambda p, k: torch.from_numpy(p[k][None]).to(dev)
+    startA = torch.tensor([0, len(pA["dt"])], dtype=torch.int32, device=dev)
+    preA = opt.PreintegrateIMU(startA, tb(pA, "acc")[0], tb(pA, "gyro")[0], tb(pA, "dt")[0], tb(pA, "bias"), nga, walk)
+    stA = tb(pA, "state0").clone()
+    oA = opt.PoseInertialOptimizationLastKeyFrame(tb(pA, "hasMP"), tb(pA, "obs"), tb(pA, "invSigma2"), tb(pA, "Xw"), tb(pA, "close"), pA["cam"], pA["Tbc12"],
+                                                  tb(pA, "kfState"), preA, stA)
+    startF = torch.tensor([0, len(pB["dtF"])], dtype=torch.int32, device=dev); startK = torch.tensor([0, len(pB["dt"])], dtype=torch.int32, device=dev)
+    preF = opt.PreintegrateIMU(startF, tb(pB, "accF")[0], tb(pB, "gyroF")[0], tb(pB, "dtF")[0], tb(pA, "bias"), nga, walk)
+    preK = opt.PreintegrateIMU(startK, tb(pB, "acc")[0], tb(pB, "gyro")[0], tb(pB, "dt")[0], tb(pA, "bias"), nga, walk)
+    for rep in range(2):
+        L.morb_inertial_timing(None, 1)
+        stB = tb(pB, "state0").clone()
+        opt.PoseInertialOptimizationLastFrame(tb(pB, "hasMP"), tb(pB, "obs"), tb(pB, "invSigma2"), tb(pB, "Xw"), tb(pB, "close"), pA["cam"], pA["Tbc12"], stA, preF, preK,
+                                              oA[2], stB)
+        torch.cuda.synchronize()
+        out2 = (C.c_ulonglong * 16)()
+        L.morb_inertial_timing(out2, 0)
+    show("PoseInertialOptimizationLastFrame", out2)
