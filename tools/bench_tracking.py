@@ -41,6 +41,23 @@ def main():
         c1.step(); c1.sync(); lib().morb_search_cycles(z)
         print("two searches of one frame: grid+stage %d walk %d fixed-point %d outputs %d passes %d thread0: binsearch %d query-loads %d inner %d" % tuple(list(z)))
         return
+    if only.startswith("split"):   # the B frames as K sub-batches on K streams (a sub-batch does not wait for another one's slowest frame): python tools/bench_tracking.py 256 10 split4
+        K = int(only[5:] or 2)
+        subs = []
+        for k in range(K):
+            a, b = k * B // K, (k + 1) * B // K
+            sub = {key: v[a:b] for key, v in host["scene"].items()}
+            subs.append(TrackingChain(ch.P, ch.cam, ch.kps, ch.desc, ch.count, ch.uRight[a:b].contiguous(), sub))
+        def step_all():
+            for c in subs:
+                c.step()
+        def sync_all():
+            for c in subs:
+                c.sync()
+        dt1 = timed(ch.step, ch.sync, steps)
+        dtk = timed(step_all, sync_all, steps)
+        print(json.dumps({"B": B, "one_batch_ms": dt1 * 1e3, "one_batch_frames_per_s": B / dt1, "sub_batches": K, "split_ms": dtk * 1e3, "split_frames_per_s": B / dtk}))
+        return
     if only == "chain-only":     # (for a kernel trace of one step: tools/trk_trace.py)
         timed(ch.step, ch.sync, steps)
         return
