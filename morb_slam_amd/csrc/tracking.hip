@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_pose_edges(morb_frame_params P, int cap
 // one workgroup per frame.  Features whose map point PoseOptimization flagged lose it (stereo frames: TrackLocalMap does the same
 // after its optimisation); every map point the frame still holds — or just lost — is marked "seen in this frame", which is what
 // keeps SearchLocalPoints from projecting it again; blocked = the feature holds a map point with observations.
-__global__ __launch_bounds__(256) void k_discard(int cap, const int* __restrict__ fImg, const int* __restrict__ count,
+__global__ __launch_bounds__(1024) void k_discard(int cap, const int* __restrict__ fImg, const int* __restrict__ count,
                                                  int* __restrict__ frameMP, uint8_t* __restrict__ outlier, int mpCap,
                                                  const uint8_t* __restrict__ mpHasObs, uint8_t* __restrict__ blocked,
                                                  uint8_t* __restrict__ mpSeen, int* __restrict__ nmatches,
@@ -94,11 +94,11 @@ __global__ __launch_bounds__(256) void k_discard(int cap, const int* __restrict_
   const int f = blockIdx.x;
   const int N = count[fImg[f]];
   if (mpSeen) {
-    for (int i = threadIdx.x; i < mpCap; i += 256) mpSeen[(size_t)f * mpCap + i] = 0;
+    for (int i = threadIdx.x; i < mpCap; i += blockDim.x) mpSeen[(size_t)f * mpCap + i] = 0;
     __syncthreads();
   }
   int nm = 0, nmap = 0;
-  for (int j = threadIdx.x; j < cap; j += 256) {
+  for (int j = threadIdx.x; j < cap; j += blockDim.x) {
     const size_t o = (size_t)f * cap + j;
     uint8_t blk = 0;
     if (j < N) {
@@ -161,7 +161,8 @@ int morb_track_discard_outliers_batch(morb_matcher* m, int nframes, const int* d
   MORB_REQUIRE(nframes > 0 && cap > 0 && mpCap > 0, MORB_ERR_INVALID, "bad sizes");
   MORB_HIP_CHECK(hipSetDevice(morb_matcher_device(m)));
   hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)morb_matcher_stream(m);
-  hipLaunchKernelGGL(k_discard, dim3(nframes), dim3(256), 0, st, cap, d_fImg, d_count, d_frameMP, d_outlier, mpCap, d_mpHasObs,
+  hipLaunchKernelGGL(k_discard, dim3(nframes), dim3(1024), 0, st,   // (one frame's 2048 map points and ~1200 features in two trips each)
+                     cap, d_fImg, d_count, d_frameMP, d_outlier, mpCap, d_mpHasObs,
                      d_blocked, d_mpSeen, d_nmatches, d_nmatchesMap);
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
