@@ -1171,6 +1171,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
     int cur = 0;
     pass(T, cur);
     double lambda = 0, ni = 2;
+    bool sawReject = false;   // (per round: a round's first iterations accept their first trials; after its first rejection most first trials are rejected too)
     int nBad = 0;
     for (int iter = 0; iter < 10; ++iter) {
       ++outerIts;
@@ -1207,7 +1208,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
         // too: rejected, for certain, without the edge-order sums, the Jacobians or the LDS hand-over (measured on the oracle's traces: 90 % of the
         // rejections, half of all trials).  Otherwise the trial runs its pass as before.  (Its pose has been waiting since the iteration's first trial.)
         bool certainlyRejected = false;
-        if (spec && MORB_PO2_PREVIEW && qmax > 0 && ok2 && scale > 0) {
+        if (spec && MORB_PO2_PREVIEW && (qmax > 0 || sawReject) && ok2 && scale > 0) {   // (an iteration's first trial too once this round has rejected one)
           const int par = trials & 1;
           double part = 0;
           {
@@ -1270,6 +1271,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
           lambda *= ni;
           ni *= 2;
           T = get(2);         // sTot[cur] still holds H, b of this state
+          sawReject = true;
         }
         ++qmax; ++trials;
       } while (rho < 0 && qmax < 10);
