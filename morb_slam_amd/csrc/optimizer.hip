@@ -876,6 +876,9 @@ constexpr int PO2_NT = 512, PO2_NW = PO2_NT / 64, PO2_EPT = MORB_PO2_EPT;
 __host__ __device__ constexpr int po2_stage(bool mfma) { return PO2_NT - 64 * (mfma ? 2 : 1); }   // (matrix-core chain: waves 0 and 1 carry 16 + 12 sums)
 // matrix-core chain: the FIRST stage is computed by all eight waves (the summing waves have nothing to add yet) and holds PO2_NT edges
 __host__ __device__ constexpr int po2_rows(bool mfma) { return mfma ? PO2_NT : po2_stage(false); }   // rows of the contribution buffer
+#ifndef MORB_PO2_FIRST_PREVIEW
+#define MORB_PO2_FIRST_PREVIEW 2   // first trials are previewed after a rejection: 1 in this round, 2 in this call (measured best: 318 k against 312 / 317 k frames/s), 3 always
+#endif
 #ifndef MORB_PO2_SPEC
 #define MORB_PO2_SPEC 1      // matrix-core chain: an iteration's first solve carries the nine trials that can follow it (one lambda per lane)
 #endif
@@ -1009,6 +1012,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
   const int nL = FISH ? nLeft[f] : n;   // features >= nL are right-camera observations (fisheye rig)
   PoEdge ed[PO2_EPT];
   int nAct = 0;
+  bool sawReject = MORB_PO2_FIRST_PREVIEW == 3;
 
   auto load_edge = [&](int i, PoEdge& e) {
     e.o[0] = obs[(base + i) * 3]; e.o[1] = obs[(base + i) * 3 + 1]; e.o[2] = obs[(base + i) * 3 + 2];
@@ -1171,7 +1175,9 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
     int cur = 0;
     pass(T, cur);
     double lambda = 0, ni = 2;
-    bool sawReject = false;   // (per round: a round's first iterations accept their first trials; after its first rejection most first trials are rejected too)
+#if MORB_PO2_FIRST_PREVIEW == 1
+    sawReject = false;   // (per round: a round's first iterations accept their first trials; after its first rejection most first trials are rejected too)
+#endif
     int nBad = 0;
     for (int iter = 0; iter < 10; ++iter) {
       ++outerIts;
