@@ -876,6 +876,9 @@ constexpr int PO2_NT = 512, PO2_NW = PO2_NT / 64, PO2_EPT = MORB_PO2_EPT;
 __host__ __device__ constexpr int po2_stage(bool mfma) { return PO2_NT - 64 * (mfma ? 2 : 1); }   // (matrix-core chain: waves 0 and 1 carry 16 + 12 sums)
 // matrix-core chain: the FIRST stage is computed by all eight waves (the summing waves have nothing to add yet) and holds PO2_NT edges
 __host__ __device__ constexpr int po2_rows(bool mfma) { return mfma ? PO2_NT : po2_stage(false); }   // rows of the contribution buffer
+#ifndef MORB_PO2_SKIP_ROUNDS
+#define MORB_PO2_SKIP_ROUNDS 1   // a round that would repeat the one before it bit for bit is not run
+#endif
 #ifndef MORB_PO2_FIRST_PREVIEW
 #define MORB_PO2_FIRST_PREVIEW 2   // first trials are previewed after a rejection: 1 in this round, 2 in this call (measured best: 318 k against 312 / 317 k frames/s), 3 always
 #endif
@@ -970,6 +973,7 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
   __shared__ double sKeep[3][7];     // uniform poses that would otherwise sit in every thread's registers: T0, Teval, the trial's backup
   __shared__ double sSpec[10][8];    // trial poses + scales of an iteration: slot q = its trial q (if trials 0 .. q - 1 are rejected)
   __shared__ int sSpecFlag[10];
+  __shared__ int sRound[5];
   __shared__ double sChiA[2][NW];    // the waves' partial sums of a trial's chi2 preview, by trial parity
   __shared__ int sWaveCnt[NW];
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1145,7 +1149,19 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
     }
   };
 
+  // A round whose classification changes no flag is followed by an IDENTICAL round (same active edges, same start pose, same robust kernel: rounds 1 - 3 of
+  // the reference's four all use the Huber kernel; the computation is deterministic) that would end in the same pose and the same flags: it is not run,
+  // its iterations and trials are counted.  (Outlier sets usually settle after the first round or two; the fourth round, without the kernel, always runs.)
+  // (the round's bookkeeping lives in LDS: the kernel is at its register limit)
+  if (tid == 0) { sRound[0] = 0; sRound[1] = 0; sRound[2] = 0; sRound[3] = 0; sRound[4] = 0; }
   for (int it = 0; it < 4; ++it) {
+    __syncthreads();
+    if (MORB_PO2_SKIP_ROUNDS && sRound[0] != 0 && it <= 2) {   // [0] the last round changed no flag, [1] / [2] its iterations / trials
+      outerIts += sRound[1]; trials += sRound[2];
+      if (it == 2) robust = false;
+      continue;
+    }
+    if (tid == 0) { sRound[3] = outerIts; sRound[4] = trials; }
     // ---- the round's active edges, in feature order; each worker thread takes its edges into registers
     PO2_T0(tc);
     __syncthreads();
@@ -1298,14 +1314,19 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
       const double X[3] = {(double)Xw[(base + i) * 3], (double)Xw[(base + i) * 3 + 1], (double)Xw[(base + i) * 3 + 2]};
       double xc[3], err[3];
       bool st;
-      const SE3& Pc = outlier[base + i] ? T : Teval;
-      const float chi2 = (float)pose_edge_error<FISH>(cam, rig, Pc, outlier[base + i] ? TrFin : TrEval, FISH && i >= nL, X, o,
+      const bool wasOut = outlier[base + i] != 0;
+      const SE3& Pc = wasOut ? T : Teval;
+      const float chi2 = (float)pose_edge_error<FISH>(cam, rig, Pc, wasOut ? TrFin : TrEval, FISH && i >= nL, X, o,
                                                       (double)invSigma2[base + i], err, st, xc);
       const bool isOut = chi2 > (st ? 7.815f : 5.991f);
       outlier[base + i] = isOut ? 1 : 0;
-      bad += isOut ? 1 : 0;
+      bad += (isOut ? 1 : 0) + (isOut != wasOut ? 65536 : 0);   // (outliers | flags that changed: two counts in one exact sum)
     }
-    nBadEdges = (int)block_sum_d<NW>((double)bad, red);
+    {
+      const int packed = (int)block_sum_d<NW>((double)bad, red);
+      nBadEdges = packed & 0xFFFF;
+      if (tid == 0) { sRound[0] = (packed >> 16) == 0 ? 1 : 0; sRound[1] = outerIts - sRound[3]; sRound[2] = trials - sRound[4]; }
+    }
     PO2_ADD(6, tk);
     if (it == 2) robust = false;
     if (nInit < 10) break;  // optimizer.edges().size() < 10 (:1039)
