@@ -973,7 +973,6 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
   __shared__ double sKeep[3][7];     // uniform poses that would otherwise sit in every thread's registers: T0, Teval, the trial's backup
   __shared__ double sSpec[10][8];    // trial poses + scales of an iteration: slot q = its trial q (if trials 0 .. q - 1 are rejected)
   __shared__ int sSpecFlag[10];
-  __shared__ int sRound[5];
   __shared__ double sChiA[2][NW];    // the waves' partial sums of a trial's chi2 preview, by trial parity
   __shared__ int sWaveCnt[NW];
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1152,16 +1151,9 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
   // A round whose classification changes no flag is followed by an IDENTICAL round (same active edges, same start pose, same robust kernel: rounds 1 - 3 of
   // the reference's four all use the Huber kernel; the computation is deterministic) that would end in the same pose and the same flags: it is not run,
   // its iterations and trials are counted.  (Outlier sets usually settle after the first round or two; the fourth round, without the kernel, always runs.)
-  // (the round's bookkeeping lives in LDS: the kernel is at its register limit)
-  if (tid == 0) { sRound[0] = 0; sRound[1] = 0; sRound[2] = 0; sRound[3] = 0; sRound[4] = 0; }
+  // (decided at the END of a round — the loop counter jumps over the rounds that would repeat it: no second path around the round's body)
   for (int it = 0; it < 4; ++it) {
-    __syncthreads();
-    if (MORB_PO2_SKIP_ROUNDS && sRound[0] != 0 && it <= 2) {   // [0] the last round changed no flag, [1] / [2] its iterations / trials
-      outerIts += sRound[1]; trials += sRound[2];
-      if (it == 2) robust = false;
-      continue;
-    }
-    if (tid == 0) { sRound[3] = outerIts; sRound[4] = trials; }
+    const int its0 = outerIts, trials0 = trials;
     // ---- the round's active edges, in feature order; each worker thread takes its edges into registers
     PO2_T0(tc);
     __syncthreads();
@@ -1325,7 +1317,11 @@ __global__ __launch_bounds__(PO2_NT) void k_pose_opt2(int cap, const int* __rest
     {
       const int packed = (int)block_sum_d<NW>((double)bad, red);
       nBadEdges = packed & 0xFFFF;
-      if (tid == 0) { sRound[0] = (packed >> 16) == 0 ? 1 : 0; sRound[1] = outerIts - sRound[3]; sRound[2] = trials - sRound[4]; }
+      if (MORB_PO2_SKIP_ROUNDS && (packed >> 16) == 0 && it < 2 && nInit >= 10) {   // rounds it + 1 .. 2 would repeat this one (fewer than 10 edges: one round only, :1039)
+        const int k = 2 - it;
+        outerIts += k * (outerIts - its0); trials += k * (trials - trials0);
+        it = 2;
+      }
     }
     PO2_ADD(6, tk);
     if (it == 2) robust = false;
