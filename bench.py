@@ -26,7 +26,9 @@ sys.path.insert(0, ROOT)
 # width, height, features, default stereo frames per step per GPU (c2 at 512 frames: ~14 GB of HBM for the two
 # buffer sets).  c2: 256 / 512 / 1024 / 2048 / 4096 frames per step -> 120.9 / 125.9 / 126.3 / 126.9 / 125.6 k frames/s on one MI355X (round 4,
 # profiles/r04/batch_sweep.txt): launch tails amortise up to 512 frames (1024 images per launch), nothing beyond.  c4: BASELINE configs[3] is "8 frames in flight".
-WORKLOADS = {"c2": (752, 480, 1200, 512), "c4": (1920, 1080, 4000, 8)}
+# "vga" is not a BASELINE configuration: 640 x 480 / 600 features, the shape tests/ use to drive the --gpus N launcher and the exchange with many
+# ranks on ONE time-sliced GPU (functional coverage only; a line produced from it says so in `metric`)
+WORKLOADS = {"c2": (752, 480, 1200, 512), "c4": (1920, 1080, 4000, 8), "vga": (640, 480, 600, 8)}
 W, H, NFEAT = 752, 480, 1200
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -208,6 +210,7 @@ def optimizer_extras(dev_index):
     dtp = (time.perf_counter() - t0) / 10
     # the default mode (morb_optimizer_set_exact_order(1): sums in edge order on the FP64 matrix core, g2o's LM path decision for decision)
     opt.set_exact_order(True)
+    info_timed = opt.info()
     out = opt.PoseOptimization(t[0], t[1], t[2], t[3], pose0.clone(), probs[0]["cam"], out=out)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -303,7 +306,7 @@ def optimizer_extras(dev_index):
     return {"pose_inertial_tracking": inertial, "local_inertial_ba": inertial_ba,
             "local_ba": {"edges": int(len(b["eKF"])), "keyframes_free_fixed": [20, 6], "points": 3000,
                          "outer_lm_iters": int(st[0]), "lm_trials": int(st[1]), "ms_per_solve": dt * 1e3, "one_shot_call_ms": d1 * 1e3,
-                         "lm_iters_per_s": float(st[0] / dt), "cpu_oracle_lm_iters_per_s": float(its / dc),
+                         "lm_iters_per_s": float(st[0] / dt), "cpu_oracle_lm_iters_per_s": float(its / dc), "cpu_oracle_ms_per_solve_1core": dc * 1e3,
                          # the MFMA kernel of the solve (north_star: Schur reduction on the matrix cores); peak = dense FP64 MFMA,
                          # 256 CUs x 128 flop/clk x 2.4 GHz (tools/alu_issue.hip: v_mfma_f64_16x16x4_f64 issues every 64 cycles per SIMD)
                          "roofline": {"bound": "mfma", "kernel": "k_schur_mfma", "achieved": sflops / (sms * 1e-3) / 1e12, "peak": 78.6,
@@ -316,6 +319,9 @@ def optimizer_extras(dev_index):
                          "large_windows": large, "concurrent_replicas": replicas},
             "pose_optimization": {"frames": F, "edges_per_frame": 600, "frames_per_s": F / dtpe, "frames_per_s_exact_order_mode": F / dtpe, "frames_per_s_tree_sum_mode": F / dtp,
                                   "mode": "edge-order sums (the default): g2o's LM path decision for decision",
+                                  # morb_optimizer_info of the handle that was timed: mfma_chain 1 = the edge-order sums ran on v_mfma_f64_4x4x4 (0 = on dependent
+                                  # v_add_f64, same bits, ~1.5 x slower); mfma_selftest 1 = this device passed the create-time order self-test, 0 = REJECTED it
+                                  **info_timed,
                                   "cpu_oracle_frames_per_s_1core": 1.0 / dcp}}
 
 
@@ -352,7 +358,7 @@ def tracking_extras(dev_index):
                       "PoseOptimization", "inlier count"],
            "ms_per_step": dt * 1e3, "frames_per_s": B / dt, "verified_frames": nver,
            "mean_matches_last_frame": float(ch.nmLast.float().mean()), "mean_matches_local_map": float(ch.nmLocal.float().mean()),
-           "mean_inliers": float(ch.nInl.float().mean())}
+           "mean_inliers": float(ch.nInl.float().mean()), **{k: v for k, v in ch.opt.info().items()}}
     one = {k: v[:1] for k, v in sc.items()}
     c1 = TrackingChain(ch.P, ch.cam, ch.kps, ch.desc, ch.count, ch.uRight[:1].contiguous(), one, device=dev_index)
     out["latency_b1_ms"] = timed(c1.step, c1.sync, 50) * 1e3
@@ -534,12 +540,17 @@ def launch_ranks(n):
     port = s.getsockname()[1]
     s.close()
     procs = []
+
+    def die_with_launcher():        # Linux PR_SET_PDEATHSIG: a rank never outlives a launcher that was killed (it would sit on the GPU in a collective)
+        import ctypes
+        import signal
+        ctypes.CDLL("libc.so.6").prctl(1, signal.SIGKILL, 0, 0, 0)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this pool
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True, preexec_fn=die_with_launcher))
     rc, out0 = 0, b""
     pending = set(range(n))
     try:
@@ -584,7 +595,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
-                    help="c2 = BASELINE configs[1] (752x480 / 1200 feat, the configuration the metric is quoted on); c4 = configs[3] (1920x1080 / 4000 feat)")
+                    help="c2 = BASELINE configs[1] (752x480 / 1200 feat, the configuration the metric is quoted on); c4 = configs[3] (1920x1080 / 4000 feat); "
+                         "vga = 640x480 / 600 feat, functional tests of the launcher only")
     ap.add_argument("--batch", type=int, default=0,
                     help="stereo frames per step per GPU (default 512 for c2, see WORKLOADS; 8 for c4)")
     ap.add_argument("--sets", type=int, default=2, help="buffer sets = steps in flight (>= 2)")
@@ -869,6 +881,29 @@ def main():
         lat = {"latency_b1_ms": lat_dev * 1e3, "stages": ["H2D 2 images", "extract_left+right", "ComputeStereoMatches", "D2H keypoints/descriptors/uRight/depth"],
                "extract_host_api_two_threads_ms": lat_host * 1e3,
                "note": "one stereo frame per call, host image in -> host arrays out"}
+        if not args.no_cpu_baseline:
+            # the CPU oracle on the same frame and stages, one thread, and with the reference's two extraction threads (Frame.cc:194-197)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            ol, orr = O.OracleExtractor(NFEAT), O.OracleExtractor(NFEAT)
+
+            def oracle_frame(tp=None):
+                if tp is None:
+                    (_, kl, dl), (_, kr, dr) = ol(imL), orr(imR)
+                else:
+                    a, b_ = tp.submit(ol, imL), tp.submit(orr, imR)
+                    (_, kl, dl), (_, kr, dr) = a.result(), b_.result()
+                O.stereo_matches(ol, orr, kl, dl, kr, dr, np.float32(mbf), np.float32(mb))
+            oracle_frame()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                oracle_frame()
+            lat["cpu_oracle_1thread_ms"] = (time.perf_counter() - t1) / 5 * 1e3
+            with ThreadPoolExecutor(2) as tp:
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    oracle_frame(tp)
+                lat["cpu_oracle_2threads_left_right_ms"] = (time.perf_counter() - t1) / 5 * 1e3
         one.close(); eL.close(); eR.close()
 
     if rank == 0:
@@ -916,9 +951,11 @@ def main():
         # a stage for what the matchers cost it.  `achieved` is still the stage's in-region time (HIP events on the launch stream; "pyramid"
         # is the dependent launches of k_level0 / k_resize, "fast" the two k_fastw launch groups); all three stages are in `stage_roofline`.
         dom = max(("pyramid", "blur", "fast"), key=lambda k: iso[k])
-        wl = {"c2": f"BASELINE configs[1]: EuRoC-shaped stereo {W}x{H}, {NFEAT} feat", "c4": f"BASELINE configs[3]: synthetic stereo {W}x{H}, {NFEAT} feat"}[args.workload]
+        wl = {"c2": f"BASELINE configs[1]: EuRoC-shaped stereo {W}x{H}, {NFEAT} feat", "c4": f"BASELINE configs[3]: synthetic stereo {W}x{H}, {NFEAT} feat",
+              "vga": f"FUNCTIONAL TEST SHAPE (not a BASELINE configuration): synthetic stereo {W}x{H}, {NFEAT} feat"}[args.workload]
+        cfg_tag = {"c2": "= BASELINE configs[1]", "c4": "= BASELINE configs[3]", "vga": "functional test shape, NOT a BASELINE configuration"}[args.workload]
         line = {
-            "metric": f"stereo frames/sec ORB extract+match ({W}x{H}, {NFEAT} feat = BASELINE configs[{1 if args.workload == 'c2' else 3}])",
+            "metric": f"stereo frames/sec ORB extract+match ({W}x{H}, {NFEAT} feat {cfg_tag})",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -946,16 +983,16 @@ def main():
             kf = pmi["k_fastw"]
             per_step = kf["valu_insts_per_launch"] * 2             # two launch groups per extraction
             simd_cycles = pmi["simds"] * stages["fast"] * 1e-3 * pmi["clock_GHz"] * 1e9
+            # measured quantities only (round 5 reported min(1, instructions x a separately measured 4.1 cycles / cycles), a model that overshot its own
+            # ceiling): SIMD cycles available per VALU wave-instruction of the stage, live, and the utilisation that follows from the FASTEST issue
+            # rate this chip has for a wave64 VALU instruction (4 cycles on a 16-lane SIMD) — a lower bound on how busy the issue port is, since the
+            # packed / three-operand / DPP forms the kernel is made of take longer.  `roofline.frac` stays the HBM figure.
             line["roofline_issue"] = {"bound": "valu_issue", "kernel": "k_fastw", "valu_wave_instructions_per_step": per_step,
-                                      "cycles_per_instruction": pmi["cycles_per_valu_instruction"],
-                                      # (the 4.1 cycles are the cost of the packed / three-operand / min-max / DPP instructions the kernel is made of; its few plain
-                                      # and / add / shift instructions cost 2.1 - 2.7, so the product can exceed the cycles by a few per cent: capped at 1)
-                                      "achieved": min(1.0, per_step * pmi["cycles_per_valu_instruction"] / simd_cycles), "peak": 1.0, "unit": "fraction of SIMD issue cycles",
                                       "simd_cycles_per_valu_instruction": simd_cycles / per_step,
+                                      "issue_utilisation": 4.0 / (simd_cycles / per_step), "issue_utilisation_basis": "4.0 SIMD cycles per wave64 VALU instruction (the minimum)",
                                       "valu_lane_slots_per_pixel": per_step * 64 / (ab["fast"] * nimg),
                                       "valu_per_cell_wave": kf["valu_per_wave"], "salu_per_cell_wave": kf["salu_per_wave"], "lds_per_cell_wave": kf["lds_per_wave"],
-                                      "source": "profiles/r05/pmc_issue_b512.json (SQ_INSTS_VALU per launch, 4.1 cycles per instruction from "
-                                                "profiles/r04/valu_rate_saturated.txt) / live k_fastw time x 1024 SIMDs x 2.4 GHz"}
+                                      "source": "profiles/r05/pmc_issue_b512.json (SQ_INSTS_VALU per launch) / live k_fastw time x 1024 SIMDs x 2.4 GHz"}
         if multi is not None:
             line["multi_gpu"] = multi
         if verified is not None:
@@ -975,6 +1012,30 @@ def main():
                 line["extra_metrics"].update(config_extras(local_rank))
         if world == 1 and not args.no_cpu_baseline:      # reported on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline()
+        if world == 1 and lat is not None:
+            # What a drop-in sees: the reference calls this path ONE frame at a time (src/Frame.cc:190-226 extraction + ComputeStereoMatches per frame,
+            # src/Tracking.cc:2655-2710 TrackWithMotionModel / TrackLocalMap per frame, src/LocalMapping.cc:173-181 one LocalBundleAdjustment per new
+            # keyframe), host arrays in -> host arrays out.  Every entry: the GPU call (milliseconds, wall clock around the blocking call) and the CPU
+            # oracle on ONE thread on the same input.  `value` above is batch throughput; these are latencies and are not comparable with it.
+            em = line.get("extra_metrics", {})
+            tc, lb = em.get("tracking_chain", {}), em.get("local_ba", {})
+            cb = line.get("cpu_baseline", {})
+            L = {"call_pattern": "one frame / one keyframe per call, host in -> host out (Frame.cc:190-226, Tracking.cc:2655-2710, LocalMapping.cc:173-181)",
+                 "front_end_one_stereo_frame": {"gpu_ms": lat["latency_b1_ms"], "stages": lat["stages"], "cpu_oracle_1thread_ms": lat.get("cpu_oracle_1thread_ms"),
+                                                "cpu_oracle_2threads_left_right_ms": lat.get("cpu_oracle_2threads_left_right_ms"),
+                                                "gpu_extract_only_host_api_two_threads_ms": lat["extract_host_api_two_threads_ms"]}}
+            if tc:
+                L["tracking_chain_one_frame"] = {"gpu_ms": tc["latency_b1_ms"], "stages": tc["stages"], "mfma_chain": tc.get("mfma_chain"),
+                                                 "cpu_oracle_1thread_ms": 1e3 / tc["cpu_oracle_frames_per_s_1core"]}
+            if lb:
+                L["local_ba_one_shot_call"] = {"gpu_ms": lb["one_shot_call_ms"], "gpu_resident_solve_ms": lb["ms_per_solve"], "keyframes_free_fixed": lb["keyframes_free_fixed"],
+                                               "points": lb["points"], "edges": lb["edges"], "cpu_oracle_1thread_ms": lb["cpu_oracle_ms_per_solve_1core"]}
+            if h2d is not None:
+                L["h2d_inclusive_stream"] = {"gpu_frames_per_s": h2d["value"], "pcie_GBps": h2d["pcie_GBps"], "stereo_frames_per_step": B,
+                                             "cpu_oracle_frames_per_s_1thread": cb.get("one_thread", {}).get("value"),
+                                             "cpu_oracle_frames_per_s_all_threads": cb.get("value"), "cpu_threads": cb.get("cores"),
+                                             "note": "the headline chain with the images arriving over PCIe each step (pinned host memory, copy streams overlapped with compute)"}
+            line["latency"] = L
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -536,6 +536,12 @@ void* morb_optimizer_stream(const morb_optimizer*);   /* the optimizer's own str
  * convergence rho = dChi2 / scale is ~0 and its sign follows the last bits of those sums, so the number of LM TRIALS can differ by one
  * (observed: 50 vs 49 in one of nine problems).  ~3 % faster per 256-frame batch (round 4: 1.7 x; the edge-order mode has closed the gap). */
 int morb_optimizer_set_exact_order(morb_optimizer*, int on);
+/* Which PoseOptimization path this handle runs (any out pointer may be NULL): *exact_order = the mode above; *mfma_chain = 1 when the edge-order sums
+ * are carried by v_mfma_f64_4x4x4 (four edges per instruction), 0 when by dependent v_add_f64 — the order being reproduced is g2o's accumulation over
+ * its active edges (Thirdparty/g2o/g2o/core/base_unary_edge.hpp:43-72 constructQuadraticForm, called edge by edge from
+ * sparse_optimizer.cpp:482-487); *mfma_selftest = what the create-time self-test said on this device: 1 passed, 0 REJECTED the device (the vector chain
+ * runs, same bits, slower), -1 not run (MORB_PO2_CHAIN=valu|mfma forced the choice) or could not run.  bench.py prints all three. */
+int morb_optimizer_info(const morb_optimizer*, int* mfma_chain, int* exact_order, int* mfma_selftest);
 
 /* static int Optimizer::PoseOptimization(Frame* pFrame)  Optimizer.h:86, Optimizer.cc:762-1051, for nframes
  * frames at once (DEVICE pointers, frame f at offset f*cap): d_count[f] = Frame::N (NULL = cap),

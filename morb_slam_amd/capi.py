@@ -154,6 +154,7 @@ def lib():
         L.morb_optimizer_destroy.restype = None
         L.morb_optimizer_sync.argtypes = [vp]
         L.morb_optimizer_set_exact_order.argtypes = [vp, i]
+        L.morb_optimizer_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.morb_optimizer_stream.argtypes = [vp]
         L.morb_optimizer_stream.restype = vp
         L.morb_pose_optimization_batch.argtypes = [vp, i, i, vp, vp, vp, vp, vp, f, f, f, f, f, vp, vp, vp, vp, vp]

@@ -2262,6 +2262,11 @@ struct morb_optimizer {
   double* scalPinned = nullptr;   // pinned scalars of an arena-mode problem
   int exactOrder = 1;             // PoseOptimization: 1 (default) = edge-order sums, the LM path of g2o decision for decision; 0 = tree sums
   int mfmaChain = 0;              // ... carried by the FP64 matrix core (this device passed k_mfma_order_selftest) instead of dependent v_add_f64
+  int mfmaSelftest = -1;          // what k_mfma_order_selftest said on this device: 1 passed, 0 rejected, -1 not run (MORB_PO2_CHAIN forced the choice) or failed to run
+  // outgrown workspaces / staging buffers: a kernel or copy queued earlier (on this handle's stream or a caller's) may still use them, so growth neither
+  // waits for a stream nor frees (hipFree waits for the DEVICE): they are released with the handle.  Each growth asks for half as much again, so the
+  // retired bytes stay below twice the final size.
+  std::vector<void*> retiredDev, retiredHost;
 };
 
 struct morb_ba_problem {
@@ -2319,6 +2324,7 @@ int morb_optimizer_create(morb_optimizer** out, int device) {
       }
       if (d_bad) (void)hipFree(d_bad);
       o->mfmaChain = bad == 0;
+      o->mfmaSelftest = bad < 0 ? -1 : (bad == 0 ? 1 : 0);
     }
   }
   *out = o;
@@ -2330,11 +2336,14 @@ void* morb_optimizer_stream(const morb_optimizer* o) { return o ? (void*)o->stre
 int morb_optimizer_workspace(morb_optimizer* o, size_t bytes, void** out) {
   MORB_REQUIRE(o && out, MORB_ERR_INVALID, "NULL argument");
   if (bytes > o->workBytes) {
-    MORB_HIP_CHECK(hipStreamSynchronize(o->stream));
-    if (o->work) MORB_HIP_CHECK(hipFree(o->work));
-    o->work = nullptr; o->workBytes = 0;
-    MORB_HIP_CHECK(hipMalloc(&o->work, bytes + bytes / 4));
-    o->workBytes = bytes + bytes / 4;
+    // no hipStreamSynchronize, no hipFree on the caller's path (Optimizer.h:46-139 is all-static and entered from three threads: a tracking-thread
+    // call must not wait for the LocalBundleAdjustment another thread has running on this device)
+    void* fresh = nullptr;
+    const size_t want = bytes + bytes / 2;
+    MORB_HIP_CHECK(hipMalloc(&fresh, want));
+    if (o->work) o->retiredDev.push_back(o->work);
+    o->work = fresh;
+    o->workBytes = want;
   }
   *out = o->work;
   return MORB_OK;
@@ -2354,13 +2363,22 @@ int morb_optimizer_lm_words(morb_optimizer* o, int** host, int** dev) {
 int morb_optimizer_staging(morb_optimizer* o, size_t bytes, void** host) {
   MORB_REQUIRE(o && host, MORB_ERR_INVALID, "NULL argument");
   if (bytes > o->stageBytes) {
-    MORB_HIP_CHECK(hipStreamSynchronize(o->stream));
-    if (o->stage) MORB_HIP_CHECK(hipHostFree(o->stage));
-    o->stage = nullptr; o->stageBytes = 0;
-    MORB_HIP_CHECK(hipHostMalloc(&o->stage, bytes + bytes / 4));
-    o->stageBytes = bytes + bytes / 4;
+    void* fresh = nullptr;
+    const size_t want = bytes + bytes / 2;
+    MORB_HIP_CHECK(hipHostMalloc(&fresh, want));
+    if (o->stage) o->retiredHost.push_back(o->stage);     // an upload queued from it may still be in flight
+    o->stage = fresh;
+    o->stageBytes = want;
   }
   *host = o->stage;
+  return MORB_OK;
+}
+
+int morb_optimizer_info(const morb_optimizer* o, int* mfma_chain, int* exact_order, int* mfma_selftest) {
+  MORB_REQUIRE(o, MORB_ERR_INVALID, "NULL optimizer");
+  if (mfma_chain) *mfma_chain = o->mfmaChain;
+  if (exact_order) *exact_order = o->exactOrder;
+  if (mfma_selftest) *mfma_selftest = o->mfmaSelftest;
   return MORB_OK;
 }
 
@@ -2385,8 +2403,10 @@ void morb_optimizer_destroy(morb_optimizer* o) {
   if (o->evFork) (void)hipEventDestroy(o->evFork);
   if (o->evJoin) (void)hipEventDestroy(o->evJoin);
   if (o->work) (void)hipFree(o->work);
+  for (void* w : o->retiredDev) (void)hipFree(w);
   if (o->lmWords) (void)hipHostFree(o->lmWords);
   if (o->stage) (void)hipHostFree(o->stage);
+  for (void* w : o->retiredHost) (void)hipHostFree(w);
   if (o->scalPinned) (void)hipHostFree(o->scalPinned);
   (void)hipStreamDestroy(o->stream);
   delete o;

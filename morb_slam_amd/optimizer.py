@@ -33,6 +33,13 @@ class Optimizer:
         """PoseOptimization sums in edge order (the default: g2o's LM path decision for decision) or as a tree (~3 % faster, the trial count may differ by one); morb_optimizer_set_exact_order."""
         check(self._L.morb_optimizer_set_exact_order(self._h, 1 if on else 0))
 
+    def info(self):
+        """morb_optimizer_info: {"exact_order": 0|1, "mfma_chain": 0|1, "mfma_selftest": 1 passed | 0 device rejected | -1 not run} — which
+        PoseOptimization path this handle runs."""
+        a, b, c = C.c_int(-9), C.c_int(-9), C.c_int(-9)
+        check(self._L.morb_optimizer_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"mfma_chain": a.value, "exact_order": b.value, "mfma_selftest": c.value}
+
     def PoseOptimization(self, hasMP, obs, invSigma2, Xw, pose, cam, count=None, out=None, stream=None):
         """Batched PoseOptimization.  Device tensors: hasMP u8 [F, cap], obs f32 [F, cap, 3] (x, y, uRight),
         invSigma2 f32 [F, cap], Xw f32 [F, cap, 3], pose f32 [F, 7] (in/out), count i32 [F] or None.

@@ -57,12 +57,14 @@ def test_other_schedules_match_oracle(kw):
     fe.close()
 
 
-def test_bench_line_reports_verified_frames_and_sustained():
+@pytest.mark.multiprocess
+def test_bench_line_reports_verified_frames_and_sustained(tmp_path):
     """bench.py's own post-region self-check and the sustained block (short run)."""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "16", "--steps", "3", "--warmup", "1", "--no-extras",
-                        "--no-cpu-baseline", "--verify-frames", "3", "--sustained-s", "0.3"], stdout=subprocess.PIPE, timeout=900)
-    assert p.returncode == 0
-    line = [json.loads(l) for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
+    from procs import describe, spawn
+    p = spawn([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "16", "--steps", "3", "--warmup", "1", "--no-extras",
+               "--no-cpu-baseline", "--verify-frames", "3", "--sustained-s", "0.3"], dict(os.environ), tmp_path / "log", timeout=900)
+    assert p.returncode == 0, describe([p])
+    line = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")][-1]
     assert line["verified_frames"] == 3 and line["verified"]["frames"] == [0, 7, 15]
     s = line["sustained"]
     assert s["steps"] >= 1000 and s["window_min"] <= s["window_median"] <= s["window_max"] and s["value"] > 0

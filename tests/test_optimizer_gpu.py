@@ -51,10 +51,11 @@ def test_edge_order_sums_on_the_matrix_core_equal_the_vector_chain(monkeypatch):
     """The edge-order sums run on v_mfma_f64_4x4x4_4b_f64 (four terms per instruction, added one after the other: optimizer.hip
     `ordered_add_mfma1`, tools/micro/mfma_chain.hip) when the device passes the self-test of morb_optimizer_create, on dependent v_add_f64
     otherwise.  Same order, same roundings: every output BIT of the two forms is equal — poses, flags, iteration and trial counts — at
-    edge counts on both sides of the stage boundaries (512 edges in the first stage, 384 in the later ones, batches of 16 rows)."""
+    edge counts on both sides of the stage boundaries (po2_stage / po2_rows: 512 edges in the first stage, 384 in the later ones, batches of
+    16 rows).  morb_optimizer_info must say which form each handle runs, and on this device the self-test must PASS: a rejected device is a
+    failure here, not a skip (the default would silently be the slower vector chain)."""
     import torch
     from morb_slam_amd import Optimizer
-    # (with the speculation wave: 448 edges in the first stage, 320 in the later ones, frames up to 1408 features; without: 512 / 384)
     sizes = [40, 447, 448, 449, 463, 465, 511, 512, 513, 527, 529, 600, 767, 768, 769, 895, 896, 897, 1087, 1088, 1089, 1200, 1279, 1280, 1407, 1408, 1409, 1500, 1664]
     probs = [make_pose_problem(n, seed=100 + i) for i, n in enumerate(sizes)]
     for p in probs[:-4]:
@@ -72,10 +73,15 @@ def test_edge_order_sums_on_the_matrix_core_equal_the_vector_chain(monkeypatch):
             monkeypatch.delenv("MORB_PO2_CHAIN")      # the handle decides by its self-test
         opt = Optimizer()
         opt.set_exact_order(True)
+        want = {"valu": {"mfma_chain": 0, "exact_order": 1, "mfma_selftest": -1}, "mfma": {"mfma_chain": 1, "exact_order": 1, "mfma_selftest": -1},
+                "": {"mfma_chain": 1, "exact_order": 1, "mfma_selftest": 1}}[form]
+        assert opt.info() == want, (form, opt.info())
         pose = pose0.clone()
         nin, outl, stats = opt.PoseOptimization(t[0], t[1], t[2], t[3], pose, probs[0]["cam"], count=cnt)
         torch.cuda.synchronize()
         res[form] = (nin.cpu().numpy(), outl.cpu().numpy(), stats.cpu().numpy(), pose.cpu().numpy().view(np.uint32))
+        opt.set_exact_order(False)
+        assert opt.info()["exact_order"] == 0
     for a, b in zip(res["valu"], res["mfma"]):
         np.testing.assert_array_equal(a, b)
     for a, b in zip(res["mfma"], res[""]):            # MI355X passes the self-test: the default IS the matrix-core form
