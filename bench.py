@@ -602,9 +602,10 @@ def main():
     ap.add_argument("--sets", type=int, default=2, help="buffer sets = steps in flight (>= 2)")
     ap.add_argument("--extract-streams", type=int, default=1, help="1: one extraction stream for all buffer sets (default); 2: one per set")
     ap.add_argument("--stagger", action="store_true", help="with --extract-streams 2: step i + 1's extraction starts when step i's FAST stage is done")
-    ap.add_argument("--matchers", choices=["beside-pyramid", "under-quadtree"], default="beside-pyramid",
+    ap.add_argument("--matchers", choices=["beside-pyramid", "under-quadtree", "under-fast"], default="beside-pyramid",
                     help="where a step's matchers run: right after its extraction, i.e. beside the NEXT step's pyramid (default), or held back until the "
-                         "next step's FAST stage is done (morb_extractor_event_after_fast), i.e. underneath its quadtree")
+                         "next step's FAST stage is done (morb_extractor_event_after_fast), i.e. underneath its quadtree, or until its pyramid is done "
+                         "(morb_extractor_event_after_pyramid), i.e. underneath its FAST stage")
     ap.add_argument("--exchange", choices=["ring", "allgather"], default="ring",
                     help="N > 1: how a frame's predecessor features reach its rank: one send / recv to the next rank (ring, 1/N of the bytes) "
                          "or an all-gather of every rank's slabs (what north_star names)")
@@ -989,7 +990,8 @@ def main():
             # packed / three-operand / DPP forms the kernel is made of take longer.  `roofline.frac` stays the HBM figure.
             line["roofline_issue"] = {"bound": "valu_issue", "kernel": "k_fastw", "valu_wave_instructions_per_step": per_step,
                                       "simd_cycles_per_valu_instruction": simd_cycles / per_step,
-                                      "issue_utilisation": 4.0 / (simd_cycles / per_step), "issue_utilisation_basis": "4.0 SIMD cycles per wave64 VALU instruction (the minimum)",
+                                      "issue_utilisation": 4.0 / (simd_cycles / per_step), "issue_utilisation_basis": "4.0 SIMD cycles per wave64 VALU instruction (the minimum) at an ASSUMED 2.4 GHz; uncapped — a value a few per cent above 1 "
+                                                                 "is the error of that clock assumption / of the counter pass taken at another time, not a faster chip",
                                       "valu_lane_slots_per_pixel": per_step * 64 / (ab["fast"] * nimg),
                                       "valu_per_cell_wave": kf["valu_per_wave"], "salu_per_cell_wave": kf["salu_per_wave"], "lds_per_cell_wave": kf["lds_per_wave"],
                                       "source": "profiles/r05/pmc_issue_b512.json (SQ_INSTS_VALU per launch) / live k_fastw time x 1024 SIMDs x 2.4 GHz"}

@@ -97,6 +97,10 @@ int morb_extractor_stage_ms(morb_extractor*, float* ms7);
  * another stream wait for it (hipStreamWaitEvent) so that other work — the previous frame's matchers — lands underneath the quadtree
  * instead of beside the next pyramid.  Owned by the handle; valid until the handle is destroyed. */
 int morb_extractor_event_after_fast(morb_extractor*, void** event);
+/* Likewise the event recorded behind the last pyramid launch (ComputePyramid, src/ORBextractor.cc:1088-1112), i.e. where the FAST stage starts:
+ * k_fastw is bound by vector-instruction issue and leaves the memory pipe idle, so a pipelining caller may prefer to put the previous frame's
+ * matchers (BoW descent, SAD rows: memory-pipe work) underneath IT rather than beside the pyramid, which needs the same pipe. */
+int morb_extractor_event_after_pyramid(morb_extractor*, void** event);
 /* Failure flags raised on the device by the extractions since the last query (cleared by the call).  To be read AFTER the stream of a
  * morb_extract_batch call has been synchronised; morb_extract checks it itself.  Bit 0: a pyramid level held more than 65535 FAST
  * candidates (noise-like images; the quadtree counts children in 16 bits) -> returns MORB_ERR_UNSUPPORTED, that call's keypoints are not valid. */

@@ -97,6 +97,7 @@ def lib():
         L.morb_extractor_set_profiling.argtypes = [vp, i]
         L.morb_extractor_stage_ms.argtypes = [vp, vp]
         L.morb_extractor_event_after_fast.argtypes = [vp, C.POINTER(vp)]
+        L.morb_extractor_event_after_pyramid.argtypes = [vp, C.POINTER(vp)]
         L.morb_stream_wait_event.argtypes = [vp, vp]
         L.morb_extractor_status.argtypes = [vp, C.POINTER(i)]
         L.morb_matcher_create.argtypes = [C.POINTER(vp), i]

@@ -1321,6 +1321,7 @@ int morb_extractor_create(morb_extractor** out, int nfeatures, float scaleFactor
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamDefault) != hipSuccess ||
       hipStreamCreateWithFlags(&e->sideStream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->evPyr, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&e->evJoin, hipEventDisableTiming) != hipSuccess) {
     set_error("cannot create a stream on device %d", device);
     delete e;
@@ -1356,6 +1357,7 @@ void morb_extractor_destroy(morb_extractor* e) {
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   e->ev.clear();
   if (e->evFork) (void)hipEventDestroy(e->evFork);
+  if (e->evPyr) (void)hipEventDestroy(e->evPyr);
   if (e->evJoin) (void)hipEventDestroy(e->evJoin);
   if (e->sideStream) (void)hipStreamDestroy(e->sideStream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1396,6 +1398,11 @@ int morb_extractor_set_profiling(morb_extractor* e, int enable) {
 int morb_extractor_event_after_fast(morb_extractor* e, void** event) {
   MORB_REQUIRE(e && event, MORB_ERR_INVALID, "NULL argument");
   *event = (void*)e->evFork;
+  return MORB_OK;
+}
+int morb_extractor_event_after_pyramid(morb_extractor* e, void** event) {
+  MORB_REQUIRE(e && event, MORB_ERR_INVALID, "NULL argument");
+  *event = (void*)e->evPyr;
   return MORB_OK;
 }
 int morb_stream_wait_event(void* stream, void* event) {
@@ -1489,6 +1496,7 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
     }
   }
   mark(1);
+  MORB_HIP_CHECK(hipEventRecord(e->evPyr, st));
   // FAST: the two launch groups (cells of the big levels; the taller cells of the small top levels) follow each other in the launch
   // stream.  Grid x = image: hardware deals consecutive workgroups round-robin over the 8 XCDs, so with a multiple of 8 images all
   // cells of an image meet in one XCD's L2.

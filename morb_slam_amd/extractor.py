@@ -112,6 +112,12 @@ class ORBextractor:
         check(self._L.morb_extractor_event_after_fast(self._h, C.byref(ev)))
         return ev.value
 
+    def event_after_pyramid(self):
+        """hipEvent_t (as an int) recorded by the last extract_batch behind its pyramid launches (morb_extractor_event_after_pyramid)."""
+        ev = C.c_void_p()
+        check(self._L.morb_extractor_event_after_pyramid(self._h, C.byref(ev)))
+        return ev.value
+
     def check_status(self):
         """Raise if an extraction since the last check was flagged on the device (call after synchronising the batch call's stream)."""
         check(self._L.morb_extractor_status(self._h, None))

@@ -92,7 +92,10 @@ class StereoFrontEnd:
         self.left_rows = torch.arange(0, 2 * B, 2, dtype=torch.int32, device=dev)
         self.sets = [BufferSet(B, cap, dev) for _ in range(NSET)]
         self.nstep = 0
-        self.lag_matchers = matchers == "under-quadtree" and NSET >= 2
+        self.lag_matchers = matchers in ("under-quadtree", "under-fast") and NSET >= 2
+        # which event of the NEXT extraction releases a step's matchers: after its FAST stage (they land underneath its quadtree) or after its
+        # pyramid (underneath its FAST stage: issue-bound, memory pipe idle)
+        self.lag_gate = "event_after_pyramid" if matchers == "under-fast" else "event_after_fast"
         # stagger (with one extraction stream per set): step i + 1's extraction starts when step i's FAST stage is done, so its pyramid
         # — a streaming kernel without LDS — runs beside step i's quadtree, whose few waves per CU hold the LDS and leave the rest idle
         self.stagger = bool(stagger) and self.estreams[0] is not self.estreams[-1]
@@ -131,7 +134,7 @@ class StereoFrontEnd:
         if self.lag_matchers:
             # this step's matchers are queued when the NEXT extraction has been queued, behind its after-FAST event
             if self.pending is not None:
-                self.run_matchers(self.pending, gate=e.event_after_fast())
+                self.run_matchers(self.pending, gate=getattr(e, self.lag_gate)())
             self.pending = S
         else:
             self.run_matchers(S)

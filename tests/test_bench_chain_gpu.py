@@ -44,9 +44,9 @@ def test_bench_step_matches_oracle():
     fe.close()
 
 
-@pytest.mark.parametrize("kw", [dict(matchers="under-quadtree"), dict(extract_streams=2), dict(nset=1)])
+@pytest.mark.parametrize("kw", [dict(matchers="under-quadtree"), dict(matchers="under-fast"), dict(extract_streams=2), dict(nset=1)])
 def test_other_schedules_match_oracle(kw):
-    """bench.py's other schedules (--matchers under-quadtree, --extract-streams 2, --no-pipeline) produce the same bytes."""
+    """bench.py's other schedules (--matchers under-quadtree | under-fast, --extract-streams 2, --no-pipeline) produce the same bytes."""
     import chain_check
     B = 32
     fe, host = _front_end(B, **kw)

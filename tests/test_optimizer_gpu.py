@@ -316,3 +316,52 @@ def test_a_tracking_search_does_not_wait_for_a_running_local_ba():
     assert int(nm[0]) > 100
     assert t2 < done["solve"][1], f"the search should have finished while the solve was still running (search {t1:.4f} .. {t2:.4f}, solve {done['solve']})"
     assert t2 - t1 < 0.5 * (NS - 1) * solve_s, f"the search took {t2 - t1:.4f} s beside {NS} solves of {solve_s:.4f} s: it waited for them"
+
+
+def test_optimizer_workspace_growth_does_not_wait_for_another_handles_solve():
+    """Optimizer.h:46-139 is all-static and entered from three threads.  The one-shot entry points carve their problem from the handle's grow-only
+    workspace / pinned staging buffer (morb_optimizer_workspace / _staging); until round 6 OUTGROWING them went through hipStreamSynchronize + hipFree,
+    and hipFree waits for the whole DEVICE — i.e. for a LocalBundleAdjustment another thread has running on another handle.  Now the outgrown buffers
+    are retired and freed with the handle.  Here: eight persistent-mode solves (tens of ms each) are queued on one handle by one thread; meanwhile a
+    second handle runs a small one-shot LocalBundleAdjustment (first growth, from nothing) and then one three times its size (outgrows both buffers):
+    both must return while the other handle's solves are still in flight, with the results of an undisturbed run."""
+    import threading
+    import time
+    import torch
+    from morb_slam_amd import BAProblem, Optimizer
+    from morb_slam_amd.optimizer import local_bundle_adjustment_oneshot
+    from morb_slam_amd.synth import make_ba_problem
+    opt = Optimizer()
+    b = make_ba_problem(seed=2)
+    p = BAProblem(opt, b["kfPose"], b["kfFixed"], b["mpPos"], b["eKF"], b["eMP"], b["eObs"], b["eInvSigma2"], b["cam"])
+    p.set_mode(1)
+    p.solve(); p.results()
+    t0 = time.perf_counter(); p.solve(); p.results(); solve_s = time.perf_counter() - t0
+    assert solve_s > 0.005
+    small = make_ba_problem(seed=3, n_free=6, n_fixed=3, n_points=600)
+    large = make_ba_problem(seed=4, n_free=20, n_fixed=6, n_points=3000)
+    args = lambda q: (q["kfPose"], q["kfFixed"], q["mpPos"], q["eKF"], q["eMP"], q["eObs"], q["eInvSigma2"], q["cam"])
+    quiet = Optimizer()
+    want = [local_bundle_adjustment_oneshot(quiet, *args(q)) for q in (small, large)]     # undisturbed (also loads the code objects)
+    quiet.close()
+    torch.cuda.synchronize()
+    NS, done = 8, {}
+
+    def solver():
+        t = time.perf_counter()
+        for _ in range(NS):
+            p.solve()
+        p.results(); done["solve"] = (t, time.perf_counter())
+    th = threading.Thread(target=solver); th.start()
+    time.sleep(solve_s * 0.5)
+    fresh = Optimizer()
+    t1 = time.perf_counter()
+    got = [local_bundle_adjustment_oneshot(fresh, *args(small)), local_bundle_adjustment_oneshot(fresh, *args(large))]
+    t2 = time.perf_counter()
+    th.join()
+    for g, w in zip(got, want):
+        for a, c in zip(g, w):
+            np.testing.assert_array_equal(a, c)
+    assert t2 < done["solve"][1], f"both one-shot calls should have returned while the other handle's solves ran ({t1:.4f} .. {t2:.4f}, solves {done['solve']})"
+    assert t2 - t1 < 0.5 * (NS - 1) * solve_s, f"the one-shot calls took {t2 - t1:.4f} s beside {NS} solves of {solve_s:.4f} s: they waited for them"
+    fresh.close(); p.close(); opt.close()

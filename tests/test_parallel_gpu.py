@@ -127,9 +127,9 @@ def test_bench_matcher_placements_agree(tmp_path):
     """bench.py's schedules — a step's matchers right behind its extraction, or held back behind the NEXT extraction's after-FAST event
     (morb_extractor_event_after_fast) — process the same frames: same stereo and BoW match counts, every step's matchers inside the region."""
     got = {m: _bench_line(tmp_path, ["--matchers", m, "--batch", "8", "--steps", "3", "--warmup", "1"], gloo=False)["config"]
-           for m in ("beside-pyramid", "under-quadtree")}
+           for m in ("beside-pyramid", "under-quadtree", "under-fast")}
     for k in ("mean_keypoints_per_image", "mean_stereo_matches_per_frame", "mean_bow_matches_per_frame"):
-        assert got["beside-pyramid"][k] == got["under-quadtree"][k] and got["beside-pyramid"][k] > 0, k
+        assert got["beside-pyramid"][k] == got["under-quadtree"][k] == got["under-fast"][k] and got["beside-pyramid"][k] > 0, k
 
 
 @pytest.mark.multiprocess
