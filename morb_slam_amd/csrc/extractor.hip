@@ -457,13 +457,13 @@ extern "C" int morb_fast_timing(unsigned long long* out, int reset) {   // phase
 // sized for level 0, three one-wave workgroups fill a CU's LDS and every small level holds as much as level 0.  So the levels of an image
 // are packed (host: first fit, decreasing) into a few workgroups of up to QT_MAX_WAVES waves whose needs add up to what level 0 takes
 // (752 x 480 / 1200: {0} {1, 5} {2, 3} {4, 6, 7}); the waves of a workgroup never synchronise with each other.
-__global__ __launch_bounds__(64 * QT_MAX_WAVES) void k_distribute(const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ cand,
+__global__ __launch_bounds__(64 * QT_TEAM_WAVES) void k_distribute(const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ cand,
                                                    const int* __restrict__ candCnt, int totalCells, int cellCap,
                                                    uint32_t* __restrict__ qtScratch, uint32_t* __restrict__ sel,
                                                    int* __restrict__ selCnt, int selPerImg, int nlevels, int groupBase, int* __restrict__ status) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int img = blockIdx.x, lane = threadIdx.x & 63;
-  __shared__ int teamSh[32];
+  __shared__ int teamSh[QT_TEAM_SH];
   int lvl = -1;
   const int wvIdx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   {
@@ -505,20 +505,33 @@ __global__ __launch_bounds__(64 * QT_MAX_WAVES) void k_distribute(const LevelGeo
 #define DMARK(k)
 #endif
   const int* counts = candCnt + (size_t)img * totalCells + g.cellBase;
-  int running = 0;
-  if (tm.tw == 0) {
-    for (int c0 = 0; c0 < ncell; c0 += 64) {
+  // first slot of every cell's candidate list: exclusive prefix of the cells' counts, a slice of the cells per wave of the team
+  int T = 0;
+  {
+    const int per = ((ncell + tm.nw * 64 - 1) / (tm.nw * 64)) * 64;
+    const int lo = per * tm.tw < ncell ? per * tm.tw : ncell, hi = lo + per < ncell ? lo + per : ncell;
+    int running = 0;
+    for (int c0 = lo; c0 < hi; c0 += 64) {
       const int c = c0 + lane;
-      const int n = c < ncell ? counts[c] : 0;
+      const int n = c < hi ? counts[c] : 0;
       int incl = n;
       MORB_DPP_SCAN(incl, 0, morbwave::op_add);   // inclusive prefix over the wave
-      if (c < ncell) cellOff[c] = running + incl - n;
+      if (c < hi) cellOff[c] = running + incl - n;
       running += __builtin_amdgcn_readlane(incl, 63);
     }
-    if (lane == 0) { cellOff[ncell] = running; teamSh[11] = running; }
+    if (tm.nw > 1) {
+      if (lane == 0) teamSh[16 + tm.tw] = running;
+      __syncthreads();
+      const int v = lane < tm.nw ? teamSh[16 + lane] : 0;
+      T = morbwave::sum_i32(v);
+      const int before = morbwave::sum_i32(lane < tm.tw ? v : 0);
+      if (before) for (int c = lo + lane; c < hi; c += 64) cellOff[c] += before;
+    } else {
+      T = running;
+    }
+    if (tm.tw == 0 && lane == 0) cellOff[ncell] = T;
   }
   QT_TEAM_SYNC(tm);
-  int T = tm.nw > 1 ? teamSh[11] : running;
   // (any number of candidates: the child counts of Work::bcnt saturate and the few nodes of more than 65535 keys are counted again, quadtree.h)
   DMARK(8);
 
@@ -531,7 +544,42 @@ __global__ __launch_bounds__(64 * QT_MAX_WAVES) void k_distribute(const LevelGeo
   auto run = [&](uint32_t* keys, uint32_t* tmp) {
     // gather the cells' candidate lists into one array, cell-major: a lane per cell copies its list, QT_GATHER loads in flight per lane
     // (a lane per candidate had to binary-search its cell first: 8 dependent LDS reads in front of every global load, 34 of level 0's 152 us)
-    for (int c0 = tm.tw * 64; c0 < ncell; c0 += tm.nw * 64) {
+    int cFrom = tm.tw * 64;
+    if (tm.nw > 1) {
+      // a team (latency): two cells per lane and step, the first QT_GATHER candidates of both requested before any is stored — level 0 of a 1920 x 1080
+      // image has 1705 cells for 1024 lanes, i.e. the whole gather is about one global-memory round trip instead of four
+      for (; cFrom < ncell; cFrom += 2 * tm.nw * 64) {
+        int cc[2], off[2], nc[2];
+        uint32_t v[2][QT_GATHER];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          cc[h] = cFrom + h * tm.nw * 64 + lane;
+          const bool in = cc[h] < ncell;
+          off[h] = in ? cellOff[cc[h]] : 0;
+          nc[h] = in ? cellOff[cc[h] + 1] - off[h] : 0;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {   // 16-byte loads (the host keeps cellCap a multiple of 4): QT_GATHER / 4 requests per cell
+          const uint4* src4 = reinterpret_cast<const uint4*>(cbase + (size_t)(cc[h] < ncell ? cc[h] : 0) * cellCap);
+#pragma unroll
+          for (int k4 = 0; k4 < QT_GATHER / 4; ++k4) {
+            uint4 q = make_uint4(0u, 0u, 0u, 0u);
+            if (4 * k4 < nc[h]) q = src4[k4];
+            v[h][4 * k4] = q.x; v[h][4 * k4 + 1] = q.y; v[h][4 * k4 + 2] = q.z; v[h][4 * k4 + 3] = q.w;
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int k = 0; k < QT_GATHER; ++k) if (k < nc[h]) keys[off[h] + k] = v[h][k];
+          if (nc[h] > QT_GATHER) {   // (rare: a cell with more candidates)
+            const uint32_t* src = cbase + (size_t)cc[h] * cellCap;
+            for (int k = QT_GATHER; k < nc[h]; ++k) keys[off[h] + k] = src[k];
+          }
+        }
+      }
+    }
+    for (int c0 = cFrom; c0 < ncell; c0 += tm.nw * 64) {
       const int c = c0 + lane;
       const int off = c < ncell ? cellOff[c] : 0;
       const int nc = c < ncell ? cellOff[c + 1] - off : 0;
@@ -998,6 +1046,7 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     g.blurTilesX = div_up(g.w, BT_W); g.blurTilesY = div_up(g.h, BT_H);
     g.blurTileBase = blurTileBase; blurTileBase += g.blurTilesX * g.blurTilesY;
   }
+  e->cellCap = (std::max(e->cellCap, QT_GATHER) + 3) / 4 * 4;   // (k_distribute's team gather reads a cell's list as 16-byte words)
   // global key scratch: 2 x (cells x cellCap) per (level, image), used only when a level has > kLdsKeys candidates
   for (int l = 0; l < L; ++l) {
     LevelGeom& g = e->geom[l];
@@ -1127,8 +1176,8 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
   // kLdsKeys = 3072 of a 752 x 480 image — and is cut to what the LDS leaves beside the node arrays (1920 x 1080 / 4000 features: ~8 k keys);
   // the other levels' capacities follow their width (below).
   {
-    constexpr size_t kLdsBudget = 156 * 1024;   // largest dynamic allocation of one workgroup (160 KB minus the kernel's static LDS, with room to spare)
-    constexpr size_t kLdsCu = 160 * 1024, kLdsStatic = 3584;   // k workgroups share a CU when each takes <= 160 KB / k, static part included
+    constexpr size_t kLdsBudget = 155 * 1024;   // largest dynamic allocation of one workgroup (160 KB minus the kernel's static LDS — 4.4 KB since round 6 — with room to spare)
+    constexpr size_t kLdsCu = 160 * 1024, kLdsStatic = 4608;   // k workgroups share a CU when each takes <= 160 KB / k, static part included
     auto lds_bytes = [&](const LevelGeom& g, int keyCap) -> size_t {   // == the carve-up in k_distribute
       const int ncell = g.nCols * g.nRows;
       const size_t b = (size_t)g.nodeCap * (8 + 8 + sizeof(morbqt::Node) + 4 + 2 + 2) + (ncell + 1 <= g.nodeCap ? 0 : (size_t)(ncell + 1) * 4) +
@@ -1180,7 +1229,7 @@ int configure(morb_extractor* e, int W, int H, int nimg) {
     e->distGroups = nb; e->distWaves = 1; e->distSmem = 0;
     for (int b = 0; b < nb; ++b) { e->distWaves = std::max(e->distWaves, binWaves[b]); e->distSmem = std::max(e->distSmem, binFill[b]); }
     // The packing for calls with few images (one frame at a time: latency, or BASELINE configs[3]'s one 1920 x 1080 frame per GPU): a level
-    // of >= 160 k pixels gets a workgroup of its own whose QT_MAX_WAVES waves work it as a team (quadtree.h), the smaller levels are
+    // of >= 160 k pixels gets a workgroup of its own whose QT_TEAM_WAVES waves work it as a team (quadtree.h), the smaller levels are
     // packed as above.  A second copy of the geometry carries these assignments.
     for (int l = 0; l < L; ++l) { teamGeom[l] = e->geom[l]; teamGeom[l].distTeam = 0; }
     int tb = 0;
@@ -1521,7 +1570,7 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   // the workgroups with level 0 (the longest wave) first: grid x = image, y = group of levels
   // (which of the two is enqueued first makes no difference: measured both ways)
   if (nimg <= kTeamMaxImages && e->distGroupsTeam > 0)   // few images: latency matters, the big levels are worked by teams of waves
-    hipLaunchKernelGGL(k_distribute, dim3(nimg, e->distGroupsTeam), dim3(64 * QT_MAX_WAVES), e->distSmemTeam, st, e->d_geomTeam, e->d_cand, e->d_candCnt,
+    hipLaunchKernelGGL(k_distribute, dim3(nimg, e->distGroupsTeam), dim3(64 * QT_TEAM_WAVES), e->distSmemTeam, st, e->d_geomTeam, e->d_cand, e->d_candCnt,
                        e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L, 0, e->d_status);
   else
     // (one launch per bin of levels, each with its own LDS size — all bins of one launch get the largest bin's — measured: the launches

@@ -76,7 +76,11 @@ QT_HD int qt_node_cap(int N, int nIni) { int a = N + 3, b = 4 * nIni; return 2 *
 // (<= N + 3 live afterwards + one tombstone per parent <= N + 3): 3 (N + 3) < 2 nodeCap.
 QT_HD int qt_list_cap(int nodeCap) { return 2 * nodeCap; }
 
-#define QT_MAX_WAVES 4   // waves (= levels) of one k_distribute workgroup; nothing below synchronises across waves
+#define QT_MAX_WAVES 4   // waves (= levels) of one k_distribute workgroup in the packed form; nothing below synchronises across waves
+#ifndef QT_TEAM_WAVES
+#define QT_TEAM_WAVES 16  // waves of a workgroup that works ONE level as a team (calls with few images: latency).  Round 6: 4 -> 16, a 1920 x 1080 level 0
+#endif                    // spends its time in dependent LDS round trips per node, and the nodes of a sweep are independent (profiles/r06/k_distribute_phases.txt)
+#define QT_TEAM_SH (16 + 4 * QT_TEAM_WAVES)   // ints of Team::sh
 #if QT_DEVICE
 #define QT_LANE ((int)(threadIdx.x & 63))
 #define QT_LANE0 (QT_LANE == 0)
@@ -93,14 +97,14 @@ QT_HD int qt_list_cap(int nodeCap) { return 2 * nodeCap; }
   } while (0)
 #endif
 
-// A level may be worked by a TEAM of QT_MAX_WAVES waves (a whole workgroup; used for the big levels of a few images: one wave per
+// A level may be worked by a TEAM of QT_TEAM_WAVES waves (a whole workgroup; used for the big levels of a few images: one wave per
 // (image, level) leaves a 1920 x 1080 level-0 quadtree at 0.7 ms).  The splits of one sweep are independent of each other, so the
 // team divides a sweep's nodes among its waves — every wave still partitions the nodes it owns with the wave-level code below —
 // and only the order-dependent steps (list compaction, ranks of the children, the std::sort emulation) stay with wave 0.  Between the
 // phases the waves meet at workgroup barriers and exchange the wave-uniform state through a few LDS words.
 struct Team {
   int nw, tw;   // waves in the team (1: the level has a single wave, no workgroup barrier is ever executed), this wave's index
-  int* sh;      // [32] shared words (LDS): 0-11 state exchanged between phases, 16-31 per-wave slice counts of the team partition
+  int* sh;      // [QT_TEAM_SH] shared words (LDS): 0-11 state exchanged between phases, 16.. per-wave slice counts of the team partition (4 per wave)
 };
 #if QT_DEVICE
 #define QT_TEAM_SYNC(t) do { if ((t).nw > 1) __syncthreads(); else QT_SYNC(); } while (0)
@@ -429,9 +433,22 @@ __device__ inline int qt_partition_pivot_wave(uint64_t* v, int first, int last, 
   return cut;
 }
 
-__device__ inline void qt_std_sort_wave(uint64_t* v, uint64_t* tmp, int n, uint16_t* posL, uint16_t* posR) {
-  __shared__ int stAll[QT_MAX_WAVES * 3 * 64];   // (one explicit stack per wave of the workgroup)
-  int* st = stAll + (threadIdx.x >> 6) * (3 * 64);
+// Stable rank of v[i] among the 33 entries around it (everything further left precedes it, everything further right follows: see below).  A fixed
+// trip count, so the 33 LDS reads are in flight together instead of one round trip after the other.
+__device__ __forceinline__ int qt_window_rank(const uint64_t* v, int n, int i) {
+  const uint64_t k = v[i] >> 16;
+  int rank = i > 16 ? i - 16 : 0;
+#pragma unroll
+  for (int o = -16; o <= 16; ++o) {
+    const int j = i + o;
+    const bool in = j >= 0 && j < n;
+    const uint64_t kj = v[in ? j : i] >> 16;
+    rank += (in && (kj < k || (kj == k && o < 0))) ? 1 : 0;
+  }
+  return rank;
+}
+// st: 3 * 64 ints of LDS, this wave's explicit stack
+__device__ inline void qt_std_sort_wave(uint64_t* v, uint64_t* tmp, int n, uint16_t* posL, uint16_t* posR, int* st) {
   if (n > 16) {  // std::__introsort_loop with the recursion on an explicit (wave-uniform) stack, see qt_introsort_loop
     int* stF = st; int* stL = st + 64; int* stD = st + 128;
     int lg = 0;
@@ -463,17 +480,7 @@ __device__ inline void qt_std_sort_wave(uint64_t* v, uint64_t* tmp, int n, uint1
   // run <= every element of a later one.  An element therefore ends up inside its own run, i.e. fewer than 16 places from where it
   // is: everything more than 16 places to its left precedes it, everything more than 16 to its right follows it, and its rank
   // only needs the 33-element window around it (the full n x n count cost 180 us of the 307 us a level-0 sort takes at 4000 features).
-  for (int i = QT_LANE; i < n; i += 64) {
-    const uint64_t e = v[i];
-    const uint64_t k = e >> 16;
-    const int lo = i > 16 ? i - 16 : 0, hi = i + 17 < n ? i + 17 : n;
-    int rank = lo;
-    for (int j = lo; j < hi; ++j) {
-      const uint64_t kj = v[j] >> 16;
-      rank += (kj < k || (kj == k && j < i)) ? 1 : 0;
-    }
-    tmp[rank] = e;
-  }
+  for (int i = QT_LANE; i < n; i += 64) tmp[qt_window_rank(v, n, i)] = v[i];
   QT_SYNC();
   for (int i = QT_LANE; i < n; i += 64) v[i] = tmp[i];
   QT_SYNC();
@@ -649,14 +656,23 @@ __device__ __forceinline__ void qt_write_children(Work& w, const Node& nd, int m
 }
 
 // Splits w.order[0..m) in that order; cutoffN >= 0: stop after the split that makes s.size >= cutoffN.
-__device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int* nToExpand, const Team& tm) {
+__device__ inline void qt_split_batch(Work& w, State& s, int mAll, int cutoffN, int* nToExpand, const Team& tm) {
   const int lane = QT_LANE;
+  // "largest first" (cutoffN >= 0) stops after the split that makes size >= N, and a split adds at most three nodes: the first
+  // ceil((N - size) / 3) nodes are needed at least, and — the largest nodes rarely leave a child empty — almost always at most a few more.  Only
+  // those are counted (phase 1 was 7 of the phase's 27 us at 1920 x 1080 with all ~480 candidates counted); should the cut lie beyond, the
+  // batch is counted again in full.
+  int m = mAll;
+  if (cutoffN >= 0) { const int need = (cutoffN - s.size + 2) / 3 + 8; m = need < mAll ? need : mAll; }
   const int estart = tm.tw * 64, estep = tm.nw * 64;
+  int runCh = 0, runEx = 0, runSize = s.size, mProc = m;
+  const bool teamHuge = tm.nw > 1;
+  const uint32_t smallMax = QT_SMALL;   // (a team with 6 here — whole-wave counts for nearly every node — counted 2.6 x slower, partitioned 1.5 x faster: no gain)
+  QT_T0();
+  for (;;) {
   // the team's waves take the sweep's nodes interleaved (node e -> wave e % nw): the first sweeps have a handful of huge nodes, one wave each
   QT_TEAM_SYNC(tm);
-  QT_T0();
   // (1) keys per child.  A team first counts the huge nodes together, slice by slice (every wave walks the sweep's nodes: the choice is uniform)
-  const bool teamHuge = tm.nw > 1;
   if (teamHuge) {
     for (int e0 = 0; e0 < m; e0 += 64) {
       uint32_t cntN = 0;
@@ -679,7 +695,7 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
     Node nd = {};
     if (e < m) nd = w.nodes[w.order[e]];
     const bool valid = e < m && !(teamHuge && nd.count > QT_HUGE);
-    const bool small = valid && nd.count <= QT_SMALL;
+    const bool small = valid && nd.count <= smallMax;
     if (small) {
       const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
       uint64_t c = 0;
@@ -706,7 +722,7 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
   QT_TEAM_SYNC(tm);
   QT_MARK(16);
   // (2) ranks in processing order, and where to stop (wave 0 of a team; the totals reach the others through tm.sh)
-  int runCh = 0, runEx = 0, runSize = s.size, mProc = m;
+  runCh = 0; runEx = 0; runSize = s.size; mProc = m;
   if (tm.tw == 0) {
   for (int e0 = 0; e0 < m; e0 += 64) {
     const int e = e0 + lane;
@@ -730,6 +746,9 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
   QT_TEAM_SYNC(tm);
   if (tm.nw > 1) { runCh = tm.sh[0]; runEx = tm.sh[1]; mProc = tm.sh[2]; }
   QT_MARK(17);
+  if (m < mAll && s.size + runCh - mProc < cutoffN) { m = mAll; continue; }   // the cut lies beyond the nodes counted (the same decision in every wave of a team)
+  break;
+  }
   // (3) partition the keys, write the children, erase the parents
   const int oldHead = s.head, nA0 = s.nA, nFree0 = s.nFree;
   if (teamHuge) {   // the huge nodes: partitioned by the whole team
@@ -760,7 +779,7 @@ __device__ inline void qt_split_batch(Work& w, State& s, int m, int cutoffN, int
     if (e < mProc) nd = w.nodes[w.order[e]];
     const bool valid = e < mProc && !(teamHuge && nd.count > QT_HUGE);
     if (valid) { c = w.bcnt[e]; rk = w.brank[e]; }
-    const bool small = valid && nd.count <= QT_SMALL;
+    const bool small = valid && nd.count <= smallMax;
     const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
     if (small) {
       // stable 4-way partition through tmp: group bases packed like the counts
@@ -845,6 +864,362 @@ QT_HD void qt_compact(Work& w, State& s) {
   QT_SYNC();
 }
 
+#if QT_DEVICE
+// ---- the full sweeps at once ("fast forward", round 6) -----------------------------------------------------------
+// While the reference's loop (:589-655) runs FULL sweeps — every node with more than one key is divided, no early exit — the state it
+// reaches is a pure function of the keys' positions: after d sweeps a key lies in the cell named by its root and d (x, y) halving
+// decisions, the d stable 4-way partitions of its ancestors amount to ONE stable sort of the key array by that cell code, the list
+// is (children of sweep d in reverse generation order) ++ (single-key nodes of sweep d - 1, reverse generation order) ++ ... ++
+// (single-key roots), and whether sweep d is followed by another full sweep, by the "largest first" phase or by the end only depends
+// on how many cells of each depth hold one / several keys.  So instead of one partition pass over all keys per sweep (each with its
+// count / rank / scatter phases and barriers: 4 sweeps = 113 of level 0's 207 us at 1920 x 1080 / 4000 features with 16 waves), the
+// keys are histogrammed once by their depth-Dcap cell, the per-depth cell counts decide how many full sweeps d0 the reference runs,
+// the keys are radix-sorted (stable, LSD, 6 bits per pass) by their depth-d0 cell, and the nodes, the list and
+// vSizeAndPointerToNode are written directly in the order the sweeps would have left them.
+//
+// Generation order.  Sweep d visits the list from its head: the children of sweep d - 1 in REVERSE generation order (push_front),
+// each parent emitting its non-empty children in the order n1..n4.  Two depth-d nodes whose paths first differ at digit j (root = 0)
+// therefore compare by that digit ascending when d - j is even and descending when it is odd (the root digit: by d - 1): generation
+// order = ascending order of the path code with those digits complemented (an XOR with 0b11 per child digit).
+enum { QT_FF_CONTINUE = 0, QT_FF_PHASE = 1, QT_FF_FINISH = 2 };
+constexpr int QT_FF_MAXD = 5;
+
+struct FfGeom { float hX; int last, width, height, nIni; };
+
+// cell code of key k after d halvings: root * 4^d + sum of (bx + 2 by) digits, most significant first (DivideNode's arithmetic, :475-523)
+__device__ __forceinline__ uint32_t qt_ff_code(uint32_t k, const FfGeom& fg, int d) {
+  const int x = key_x(k), y = key_y(k);
+  int g = (int)((float)x / fg.hX);
+  g = g > fg.last ? fg.last : g;
+  int x0 = (int)(fg.hX * (float)g), x1 = (int)(fg.hX * (float)(g + 1)), y0 = 0, y1 = fg.height;
+  uint32_t c = (uint32_t)g;
+  for (int j = 0; j < d; ++j) {
+    const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+    const int bx = x >= mx ? 1 : 0, by = y >= my ? 1 : 0;
+    c = c * 4 + (uint32_t)(bx + 2 * by);
+    x0 = bx ? mx : x0; x1 = bx ? x1 : mx; y0 = by ? my : y0; y1 = by ? y1 : my;
+  }
+  return c;
+}
+// rectangle of the depth-d cell `code`
+__device__ __forceinline__ void qt_ff_rect(uint32_t code, int d, const FfGeom& fg, int& x0, int& y0, int& x1, int& y1) {
+  const int g = (int)(code >> (2 * d));
+  x0 = (int)(fg.hX * (float)g); x1 = (int)(fg.hX * (float)(g + 1)); y0 = 0; y1 = fg.height;
+  for (int j = 1; j <= d; ++j) {
+    const int dg = (int)(code >> (2 * (d - j))) & 3;
+    const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+    if (dg & 1) x0 = mx; else x1 = mx;
+    if (dg & 2) y0 = my; else y1 = my;
+  }
+}
+// generation-order index t -> cell code at depth d (d >= 1)
+__device__ __forceinline__ uint32_t qt_ff_untransform(uint32_t t, int d, int nIni) {
+  const uint32_t pm = (1u << (2 * d)) - 1u;
+  const uint32_t tr = t >> (2 * d);
+  const uint32_t r = ((d - 1) & 1) ? (uint32_t)(nIni - 1) - tr : tr;
+  return (r << (2 * d)) | ((t & pm) ^ (0xCCCCCCCCu & pm));
+}
+
+// lanes (among `valid`) that hold the same `bits`-bit digit as this lane: one ballot per digit bit, every lane keeps the lanes that agree with it
+// on that bit.  (Round 6 also tried one step per DISTINCT value present — readfirstlane, compare, ballot — which is fewer steps on these spatially
+// coherent keys but every step is a VALU -> SALU -> VALU round trip: 1.4 x slower per chunk.)
+__device__ __forceinline__ uint64_t qt_peers(int dg, bool valid, int bits) {
+  uint64_t peers = __ballot(valid);
+  for (int b = 0; b < bits; ++b) {
+    const bool one = (dg >> b) & 1;
+    const uint64_t m = __ballot(valid && one);
+    peers &= m ^ (one ? 0ull : ~0ull);
+  }
+  return peers;
+}
+// number of set bits of m in the lanes below this one
+__device__ __forceinline__ int qt_below(uint64_t m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// One stable LSD radix pass of src[0..n) -> dst by digit (code >> shift) & (2^bits - 1), bits <= 6, by the whole team (contiguous slice per
+// wave, so the order of equal digits is the input order).  cnt: 64 ints per wave of the team (row = wave).
+template <typename Code>
+__device__ inline void qt_radix_pass(const uint32_t* src, uint32_t* dst, uint32_t n, int shift, int bits, Code code, const Team& tm, int* cnt) {
+  const int lane = QT_LANE;
+  const int mask = (1 << bits) - 1;
+  int* mine = cnt + 64 * tm.tw;
+  mine[lane] = 0;
+  const uint32_t per = ((n + tm.nw * 64 - 1) / (tm.nw * 64)) * 64;
+  const uint32_t lo = per * tm.tw < n ? per * tm.tw : n, hi = lo + per < n ? lo + per : n;
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  QT_SYNC();
+  QT_T0();
+#pragma unroll 4
+  for (uint32_t i = lo + lane; i < hi; i += 64) atomicAdd(&mine[(int)(code(src[i]) >> shift) & mask], 1);   // (no return value: fire and forget)
+  QT_TEAM_SYNC(tm);
+  QT_MARK(26);
+  if (tm.tw == 0) {   // first slot of (digit, wave): digit-major, wave-minor
+    int tot = 0;
+    for (int wv = 0; wv < tm.nw; ++wv) { const int c = cnt[64 * wv + lane]; cnt[64 * wv + lane] = tot; tot += c; }
+    const int base = qt_scan_incl(tot) - tot;
+    for (int wv = 0; wv < tm.nw; ++wv) cnt[64 * wv + lane] += base;
+  }
+  QT_TEAM_SYNC(tm);
+  QT_MARK(27);
+  // scatter: the slot of a key = first slot of (digit, this wave) + keys of that digit in the wave's earlier chunks + such keys in lower lanes.  The
+  // running slots make the chunks dependent; their keys and digits do not: loaded four chunks ahead.
+  for (uint32_t i0 = lo; i0 < hi; i0 += 256) {
+    uint32_t k[4];
+    int dg[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + 64 * u + lane; k[u] = i < hi ? src[i] : 0u; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dg[u] = (int)(code(k[u]) >> shift) & mask;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (i0 + 64 * u >= hi) break;   // (wave-uniform)
+      const bool valid = i0 + 64 * u + lane < hi;
+      const uint64_t peers = qt_peers(dg[u], valid, bits);
+      const int below = qt_below(peers);
+      int off = 0;
+      if (valid) { off = mine[dg[u]]; dst[off + below] = k[u]; }
+      QT_SYNC();
+      if (valid && below == 0) mine[dg[u]] = off + __popcll(peers);
+      QT_SYNC();
+    }
+  }
+  QT_TEAM_SYNC(tm);
+  QT_MARK(28);
+}
+
+// Replaces the root set-up and every full sweep the reference would run (up to QT_FF_MAXD, and as far as the cell counts fit `hist`): on
+// return the keys are partitioned, nodes / list / vA / State are what the sweeps leave, and the result says how the loop goes on.
+// hist: histCap ints of scratch (the vB region), aux: 16 + 12 * nw ints (the brank region), radix: 64 ints per wave (static LDS).
+__device__ inline int qt_fast_forward(Work& w, State& s, uint32_t nkeys, const FfGeom& fg, int N, const Team& tm, int* hist, int histCap, int* aux,
+                                      int auxCap, int* radix) {
+  const int lane = QT_LANE, tid = tm.tw * 64 + lane, nth = tm.nw * 64;
+  const int nIni = fg.nIni;
+  // depth of the histogram: no deeper than the sweeps can go (a full sweep needs size <= N afterwards, and cells >= nodes), and what fits
+  // level d's counts start at off(d) = sum over j < d of (nIni 4^j + 1): one slot more than cells (the prefix total of step 5)
+  auto offOf = [nIni](int d) -> int { return nIni * (((1 << (2 * d)) - 1) / 3) + d; };
+  int D = 1;
+  while (D < QT_FF_MAXD && (nIni << (2 * D)) <= 2 * N && offOf(D + 2) <= histCap) ++D;
+  const int total = offOf(D + 1);
+  if (total > histCap || 16 + 12 * tm.nw > auxCap) return -1;   // (tiny quotas only: the caller runs the sweeps)
+  for (int i = tid; i < total; i += nth) hist[i] = 0;
+  for (int i = tid; i < 16 + 12 * tm.nw; i += nth) aux[i] = 0;
+  QT_TEAM_SYNC(tm);
+  QT_T0();
+  // The depth-D code of a key is (x half) | (y half): the halving decisions of the two axes do not depend on each other.  Both halves are
+  // tabulated once per level (x: root digit and the bx bits, y: the by bits, each already at its digit position) in the node array, which is
+  // not written before step 6 — a code is then two LDS reads and an OR instead of a float division and D dependent select chains.
+  const int tabW = fg.width + 1, tabH = fg.height + 1;
+  uint16_t* xs = reinterpret_cast<uint16_t*>(w.nodes);
+  uint16_t* ys = xs + tabW;
+  const bool useTab = (size_t)(tabW + tabH) * 2 <= (size_t)w.nodeCap * sizeof(Node) && 2 * D + 2 <= 16;
+  if (useTab) {
+    for (int i = tid; i < tabW + tabH; i += nth) {
+      if (i < tabW) xs[i] = (uint16_t)(qt_ff_code(make_key(i, 0, 0), fg, D) & (0x5555u | (~0u << (2 * D))));
+      else ys[i - tabW] = (uint16_t)(qt_ff_code(make_key(0, i - tabW, 0), fg, D) & (0xAAAAu & ((1u << (2 * D)) - 1u)));
+    }
+    QT_TEAM_SYNC(tm);
+  }
+  const int Dc = D;
+  auto codeD = [xs, ys, useTab, fg, Dc](uint32_t k) -> uint32_t {
+    return useTab ? (uint32_t)xs[key_x(k)] | (uint32_t)ys[key_y(k)] : qt_ff_code(k, fg, Dc);
+  };
+  {  // (1) keys per depth-D cell (LDS atomics without return: nothing waits for them)
+    int* hD = hist + offOf(D);
+#pragma unroll 4
+    for (uint32_t i = (uint32_t)tid; i < nkeys; i += (uint32_t)nth) atomicAdd(&hD[codeD(w.keys[i])], 1);
+  }
+  QT_TEAM_SYNC(tm);
+  QT_MARK(20);
+  // (2) the coarser depths, and per depth the number of non-empty cells (= list size after that many sweeps) and of cells with more than one key
+  for (int d = D - 1; d >= 0; --d) {
+    const int cells = nIni << (2 * d);
+    const int* hc = hist + offOf(d + 1);
+    int* hp = hist + offOf(d);
+    int n1 = 0, n2 = 0;
+    for (int c = tid; c < cells; c += nth) {
+      const int a0 = hc[4 * c], a1 = hc[4 * c + 1], a2 = hc[4 * c + 2], a3 = hc[4 * c + 3];
+      hp[c] = a0 + a1 + a2 + a3;
+      n1 += (a0 > 0) + (a1 > 0) + (a2 > 0) + (a3 > 0);
+      n2 += (a0 > 1) + (a1 > 1) + (a2 > 1) + (a3 > 1);
+    }
+    n1 = morbwave::sum_i32(n1); n2 = morbwave::sum_i32(n2);
+    if (lane == 0 && (n1 | n2)) { atomicAdd(&aux[2 * (d + 1)], n1); atomicAdd(&aux[2 * (d + 1) + 1], n2); }
+    QT_TEAM_SYNC(tm);
+  }
+  int size0 = 0;
+  for (int r = 0; r < nIni; ++r) size0 += hist[offOf(0) + r] > 0;
+  // (3) how many full sweeps the reference runs, and what follows (:652-667)
+  int d0 = D, outcome = QT_FF_CONTINUE;
+  {
+    int prev = size0;
+    for (int d = 1; d <= D; ++d) {
+      const int sz = aux[2 * d], nEx = aux[2 * d + 1];
+      if (sz >= N || sz == prev) { d0 = d; outcome = QT_FF_FINISH; break; }
+      if (sz + 3 * nEx > N) { d0 = d; outcome = QT_FF_PHASE; break; }
+      prev = sz;
+    }
+  }
+  const int size = aux[2 * d0], nMulti = aux[2 * d0 + 1];
+  QT_TEAM_SYNC(tm);   // (aux is rewritten below)
+  QT_MARK(21);
+  // (4) stable sort of the keys by their depth-d0 cell
+  {
+    int rootBits = 0;
+    while ((1 << rootBits) < nIni) ++rootBits;
+    const int bits = 2 * d0 + rootBits;
+    const int down = 2 * (D - d0);
+    auto code = [codeD, down](uint32_t k) -> uint32_t { return codeD(k) >> down; };
+    uint32_t* a = w.keys;
+    uint32_t* b = w.tmp;
+    for (int sh = 0; sh < bits; sh += 6) {
+      qt_radix_pass(a, b, nkeys, sh, bits - sh < 6 ? bits - sh : 6, code, tm, radix);
+      uint32_t* t = a; a = b; b = t;
+    }
+    if (a != w.keys) {
+      for (uint32_t i = (uint32_t)tid; i < nkeys; i += (uint32_t)nth) w.keys[i] = a[i];
+      QT_TEAM_SYNC(tm);
+    }
+  }
+  QT_MARK(22);
+  // (5) first key of every depth-d0 cell: exclusive prefix of its counts, in place (slot `cells` = total)
+  int* P = hist + offOf(d0);
+  const int cells0 = nIni << (2 * d0);
+  {
+    const int perW = ((cells0 + 1 + tm.nw * 64 - 1) / (tm.nw * 64)) * 64;
+    const int lo = perW * tm.tw < cells0 + 1 ? perW * tm.tw : cells0 + 1, hi = lo + perW < cells0 + 1 ? lo + perW : cells0 + 1;
+    int run = 0;
+    for (int c0 = lo; c0 < hi; c0 += 64) {
+      const int c = c0 + lane;
+      const int v = c < hi && c < cells0 ? P[c] : 0;
+      const int inc = qt_scan_incl(v);
+      if (c < hi) P[c] = run + inc - v;
+      run += __builtin_amdgcn_readlane(inc, 63);
+    }
+    if (lane == 0) aux[tm.tw] = run;
+    QT_TEAM_SYNC(tm);
+    int before = 0;
+    for (int wv = 0; wv < tm.tw; ++wv) before += aux[wv];
+    if (before) for (int c = lo + lane; c < hi; c += 64) P[c] += before;
+    QT_TEAM_SYNC(tm);
+  }
+  QT_MARK(23);
+  // (6) the nodes: per depth the members of the list (depth d0: every non-empty cell under a divided parent; shallower: the single-key cells
+  // under a divided parent), counted per wave slice of the generation order, then written
+  int* segCnt = aux + 16;   // [(d * nw + wave) * 2 + {members, members with > 1 key}]
+  auto member = [&](int d, uint32_t c, int& cntOut) -> bool {
+    const int* h = hist + offOf(d);
+    const int cnt = d == d0 ? h[c + 1] - h[c] : h[c];
+    cntOut = cnt;
+    if (d == d0 ? cnt < 1 : cnt != 1) return false;
+    return d == 0 || hist[offOf(d - 1) + (c >> 2)] > 1;
+  };
+  // (depth d0 - 1's counts are intact: only level d0 was turned into a prefix)
+  for (int pass = 0; pass < 2; ++pass) {
+    int segBase = s.head;   // set below in pass 1
+    for (int d = d0; d >= 0; --d) {
+      const int cells = nIni << (2 * d);
+      const int perW = ((cells + tm.nw * 64 - 1) / (tm.nw * 64)) * 64;
+      const int lo = perW * tm.tw < cells ? perW * tm.tw : cells, hi = lo + perW < cells ? lo + perW : cells;
+      int segTotal = 0, before = 0, beforeM = 0;
+      if (pass == 1) {   // lane = wave of the team (nw <= 64)
+        const int c = lane < tm.nw ? segCnt[(d * tm.nw + lane) * 2] : 0, cm = lane < tm.nw ? segCnt[(d * tm.nw + lane) * 2 + 1] : 0;
+        segTotal = morbwave::sum_i32(c);
+        before = morbwave::sum_i32(lane < tm.tw ? c : 0);
+        beforeM = morbwave::sum_i32(lane < tm.tw ? cm : 0);
+      }
+      int run = 0, runM = 0;
+      for (int t0 = lo; t0 < hi; t0 += 64) {
+        const int t = t0 + lane;
+        const bool in = t < hi;
+        const uint32_t c = !in ? 0u : (d == 0 ? (uint32_t)t : qt_ff_untransform((uint32_t)t, d, nIni));
+        int cnt = 0;
+        const bool mem = in && member(d, c, cnt);
+        const bool multi = mem && cnt > 1;
+        const uint64_t mm = __ballot(mem), mx = __ballot(multi);
+        if (pass == 1 && mem) {
+          const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+          const int rankAsc = before + run + __popcll(mm & lt);
+          const int pos = d == 0 ? segBase + rankAsc : segBase + (segTotal - 1 - rankAsc);
+          const int id = pos - s.head;
+          int x0, y0, x1, y1;
+          qt_ff_rect(c, d, fg, x0, y0, x1, y1);
+          Node nd;
+          nd.x0 = (int16_t)x0; nd.y0 = (int16_t)y0; nd.x1 = (int16_t)x1; nd.y1 = (int16_t)y1;
+          nd.begin = (uint32_t)(d == d0 ? P[c] : P[c << (2 * (d0 - d))]);
+          nd.count = (uint32_t)cnt; nd.lit = (uint16_t)pos; nd.noMore = cnt == 1 ? 1 : 0;
+          w.nodes[id] = nd;
+          w.list[pos] = (uint16_t)id;
+          if (multi) w.vA[beforeM + runM + __popcll(mx & lt)] = ((uint64_t)(uint32_t)cnt << 32) | ((uint64_t)(uint16_t)x0 << 16) | (uint64_t)id;
+        }
+        run += __popcll(mm); runM += __popcll(mx);
+      }
+      if (pass == 0) { if (lane == 0) { segCnt[(d * tm.nw + tm.tw) * 2] = run; segCnt[(d * tm.nw + tm.tw) * 2 + 1] = runM; } }
+      else segBase += segTotal;
+    }
+    if (pass == 0) {
+      s.head = w.listCap - size;
+      QT_TEAM_SYNC(tm);
+    }
+  }
+  s.size = size;
+  s.nA = nMulti;
+  s.nFree = w.nodeCap - size;   // ids 0 .. size - 1 are taken: exactly the top `size` entries of the initial free stack
+  QT_TEAM_SYNC(tm);
+  QT_MARK(24);
+  return outcome;
+}
+
+// std::sort emulation by the whole team: the partitions of disjoint ranges do not depend on each other, so after the first cut the ranges of
+// a recursion level are dealt to the waves (breadth first; two range lists in LDS, this level's and the next one's).  Same result as
+// qt_std_sort_wave.  q: 1024 ints of scratch.  false: n too large for the lists (nothing touched).
+__device__ inline bool qt_std_sort_team(uint64_t* v, uint64_t* tmp, int n, uint16_t* posL, uint16_t* posR, const Team& tm, int* q) {
+  constexpr int QCAP = 168;   // ranges of one recursion level: disjoint, each > 16 entries -> at most n / 17
+  if (n / 17 + 1 > QCAP) return false;
+  const int lane = QT_LANE;
+  int* cnt = q + 6 * QCAP;    // [0], [1]: ranges in list 0 / 1
+  if (n > 16) {
+    int lg = 0;
+    for (int t = n; t > 1; t >>= 1) ++lg;
+    if (tm.tw == 0 && lane == 0) { q[0] = 0; q[1] = n; q[2] = lg * 2; cnt[0] = 1; cnt[1] = 0; }
+    __syncthreads();
+    int cur = 0;
+    while (true) {
+      const int avail = cnt[cur];
+      if (avail == 0) break;
+      const int* qc = q + 3 * QCAP * cur;
+      int* qn = q + 3 * QCAP * (cur ^ 1);
+      for (int r = tm.tw; r < avail; r += tm.nw) {
+        const int first = qc[3 * r], last = qc[3 * r + 1];
+        int depth = qc[3 * r + 2];
+        if (depth == 0) {
+          QT_SYNC();
+          if (lane == 0) qt_heapsort(v, first, last);
+          QT_SYNC();
+          continue;
+        }
+        --depth;
+        const int cut = qt_partition_pivot_wave(v, first, last, posL + first, posR + 2 * first);
+        if (lane == 0) {
+          if (last - cut > 16) { const int k = atomicAdd(&cnt[cur ^ 1], 1); qn[3 * k] = cut; qn[3 * k + 1] = last; qn[3 * k + 2] = depth; }
+          if (cut - first > 16) { const int k = atomicAdd(&cnt[cur ^ 1], 1); qn[3 * k] = first; qn[3 * k + 1] = cut; qn[3 * k + 2] = depth; }
+        }
+      }
+      __syncthreads();
+      if (tm.tw == 0 && lane == 0) cnt[cur] = 0;
+      cur ^= 1;
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  for (int i = tm.tw * 64 + lane; i < n; i += tm.nw * 64) tmp[qt_window_rank(v, n, i)] = v[i];   // the final insertion sort = windowed stable ranks
+  __syncthreads();
+  for (int i = tm.tw * 64 + lane; i < n; i += tm.nw * 64) v[i] = tmp[i];
+  __syncthreads();
+  return true;
+}
+#endif
+
 // keys[0..nkeys) hold vToDistributeKeys in order.  Writes the selected keys (reference output order) to
 // out[] and returns their number.  width = maxX-minX, height = maxY-minY.  tm: the team of waves working this level (device; see Team).
 QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, uint32_t* out, int outCap, const Team& tm = Team{1, 0, nullptr}) {
@@ -863,47 +1238,68 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
   for (int i = (QT_DEVICE ? tm.tw * 64 + QT_LANE : 0); i < w.nodeCap; i += (QT_DEVICE ? 64 * tm.nw : 1)) w.freeIds[i] = (uint16_t)(w.nodeCap - 1 - i);
   QT_TEAM_SYNC(tm);
 
-  // initial nodes, pushed BACK in order i = 0..nIni-1 (:555-567); keys go to node (int)(x / hX) (:570-573);
-  // empty initial nodes are erased (:577-585).  nIni <= 4 (aspect ratio < 4.5:1) is enforced by the caller.
-  {
-    uint32_t cnt[4] = {0, 0, 0, 0};
-    const int last = nIni - 1;
-    auto rootOf = [hX, last](uint32_t k) -> int { int g = (int)((float)key_x(k) / hX); return g > last ? last : g; };
+  bool bFinish = false, enterPhase = false;
 #if QT_DEVICE
-    if (tm.nw > 1) qt_partition_team(w.keys, w.tmp, 0, nkeys, rootOf, cnt, tm);
-    else qt_partition(w.keys, w.tmp, 0, nkeys, rootOf, cnt);
-#else
-    qt_partition(w.keys, w.tmp, 0, nkeys, rootOf, cnt);
+  // scratch shared by the radix passes (64 ints per wave), the team sort's range lists and qt_std_sort_wave's stack (192 ints): a team uses all
+  // of it, the unsynchronised waves of a packed workgroup a quarter each
+  __shared__ int qtShared[64 * QT_TEAM_WAVES];
+  int* const shWave = qtShared + (tm.nw > 1 ? 0 : 256 * (int)(threadIdx.x >> 6));
+  int ff = -1;
+#ifndef QT_FAST_FORWARD
+#define QT_FAST_FORWARD 1
 #endif
-    int live = 0;
-    for (int i = 0; i < nIni; ++i) live += cnt[i] > 0 ? 1 : 0;
-    s.head = w.listCap - live;
-    s.size = live;
-    int p = s.head;
-    uint32_t begin = 0;
-    for (int i = 0; i < nIni; ++i) {
-      if (cnt[i] > 0) {
-        const int id = qt_alloc(w, s);
-        if (QT_LANE0 && w0) {
-          Node nd;
-          nd.x0 = (int16_t)(int)(hX * (float)i);
-          nd.x1 = (int16_t)(int)(hX * (float)(i + 1));
-          nd.y0 = 0;
-          nd.y1 = (int16_t)height;
-          nd.begin = begin; nd.count = cnt[i]; nd.lit = (uint16_t)p; nd.noMore = (cnt[i] == 1) ? 1 : 0;
-          w.nodes[id] = nd;
-          w.list[p] = (uint16_t)id;
+  if (QT_FAST_FORWARD) {
+    FfGeom fg;
+    fg.hX = hX; fg.last = nIni - 1; fg.width = width; fg.height = height; fg.nIni = nIni;
+    ff = qt_fast_forward(w, s, nkeys, fg, N, tm, reinterpret_cast<int*>(w.vB), 2 * w.nodeCap, reinterpret_cast<int*>(w.brank), w.nodeCap, shWave);
+    bFinish = ff == QT_FF_FINISH;
+    enterPhase = ff == QT_FF_PHASE;
+  }
+  if (ff < 0)
+#endif
+  {
+    // initial nodes, pushed BACK in order i = 0..nIni-1 (:555-567); keys go to node (int)(x / hX) (:570-573);
+    // empty initial nodes are erased (:577-585).  nIni <= 4 (aspect ratio < 4.5:1) is enforced by the caller.
+    {
+      uint32_t cnt[4] = {0, 0, 0, 0};
+      const int last = nIni - 1;
+      auto rootOf = [hX, last](uint32_t k) -> int { int g = (int)((float)key_x(k) / hX); return g > last ? last : g; };
+#if QT_DEVICE
+      if (tm.nw > 1) qt_partition_team(w.keys, w.tmp, 0, nkeys, rootOf, cnt, tm);
+      else qt_partition(w.keys, w.tmp, 0, nkeys, rootOf, cnt);
+#else
+      qt_partition(w.keys, w.tmp, 0, nkeys, rootOf, cnt);
+#endif
+      int live = 0;
+      for (int i = 0; i < nIni; ++i) live += cnt[i] > 0 ? 1 : 0;
+      s.head = w.listCap - live;
+      s.size = live;
+      int p = s.head;
+      uint32_t begin = 0;
+      for (int i = 0; i < nIni; ++i) {
+        if (cnt[i] > 0) {
+          const int id = qt_alloc(w, s);
+          if (QT_LANE0 && w0) {
+            Node nd;
+            nd.x0 = (int16_t)(int)(hX * (float)i);
+            nd.x1 = (int16_t)(int)(hX * (float)(i + 1));
+            nd.y0 = 0;
+            nd.y1 = (int16_t)height;
+            nd.begin = begin; nd.count = cnt[i]; nd.lit = (uint16_t)p; nd.noMore = (cnt[i] == 1) ? 1 : 0;
+            w.nodes[id] = nd;
+            w.list[p] = (uint16_t)id;
+          }
+          ++p;
         }
-        ++p;
+        begin += cnt[i];
       }
-      begin += cnt[i];
+      QT_TEAM_SYNC(tm);
     }
-    QT_TEAM_SYNC(tm);
   }
 
-  bool bFinish = false;
   QT_T0();
   while (!bFinish) {
+    if (!enterPhase) {
 #if QT_DEVICE
     // the sweep visits the list from the (compacted) head on — children are pushed in front of it: not visited — and divides every
     // node that is not bNoMore, with no early exit (:589-655): collect them in list order (wave 0), then split them at once (the team)
@@ -945,22 +1341,27 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
     }
 #endif
     QT_MARK(14);
-    if (s.size >= N || s.size == prevSize) {
-      bFinish = true;
-    } else if (s.size + nToExpand * 3 > N) {
+    if (s.size >= N || s.size == prevSize) bFinish = true;
+    else if (s.size + nToExpand * 3 > N) enterPhase = true;
+    }
+    if (enterPhase && !bFinish) {
+      enterPhase = false;
       while (!bFinish) {
         const int prevSize2 = s.size;
         // vPrev = vSize; vSize.clear(); sort(vPrev)
         const int nPrev = s.nA;
         s.nA = 0;
 #if QT_DEVICE
+        QT_TEAM_SYNC(tm);
+        for (int i = tm.tw * 64 + QT_LANE; i < nPrev; i += tm.nw * 64) w.vB[i] = w.vA[i];
+        QT_TEAM_SYNC(tm);
+        QT_MARK(14);
+        // vA was just cleared: free as scratch until the splits below refill it
+        bool sorted = false;
+        if (tm.nw > 1) sorted = qt_std_sort_team(w.vB, w.vA, nPrev, w.order, (uint16_t*)w.brank, tm, qtShared);
+        if (!sorted && w0) qt_std_sort_wave(w.vB, w.vA, nPrev, w.order, (uint16_t*)w.brank, shWave);
+        QT_MARK(15);
         if (w0) {
-          QT_SYNC();
-          for (int i = QT_LANE; i < nPrev; i += 64) w.vB[i] = w.vA[i];
-          QT_SYNC();
-          QT_MARK(14);
-          qt_std_sort_wave(w.vB, w.vA, nPrev, w.order, (uint16_t*)w.brank);   // vA was just cleared: free as scratch until the splits below refill it
-          QT_MARK(15);
           // compaction keeps ids stable (vB holds ids), only Node::lit moves
           qt_compact(w, s);
           for (int j = QT_LANE; j < nPrev; j += 64) w.order[j] = (uint16_t)(w.vB[nPrev - 1 - j] & 0xFFFF);   // largest first
@@ -1035,6 +1436,7 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
   }
 #endif
   QT_TEAM_SYNC(tm);
+  QT_MARK(25);
   return nOut;
 }
 

@@ -9,11 +9,11 @@ import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "morb_slam_amd", "csrc")
-out = os.path.join(ROOT, "morb_slam_amd", "libmorb_hip_timing.so")
+out = os.path.join(ROOT, "morb_slam_amd", "libmorb_hip_timing" + os.environ.get("MORB_TIMING_TAG", "") + ".so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 srcs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".hip")]
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-                       "-DMORB_FAST_TIMING", "-I", os.path.join(ROOT, "include"), "-o", out] + srcs)
+                       "-DMORB_FAST_TIMING"] + os.environ.get("MORB_EXTRA_DEFS", "").split() + ["-I", os.path.join(ROOT, "include"), "-o", out] + srcs)
 os.environ["MORB_HIP_LIB"] = out
 import torch
 from morb_slam_amd import capi, synth
@@ -35,4 +35,4 @@ buf = (ctypes.c_ulonglong * 32)()
 lib.morb_fast_timing(buf, 0)
 print("k_distribute level 0 (ticks of 10 ns per wave, mean over images):")
 nw = 5 * 2 * B
-for n, v in zip(["cell prefix", "gather", "quadtree", "candidates T", "selected n", "qt compact", "qt splits", "qt std::sort", "split: child counts", "split: ranks", "split: partition + children", "split: bookkeeping"], list(buf[8:16]) + list(buf[16:20])): print(f"  {n:28s} {v / nw:10.1f}")
+for n, v in zip(["cell prefix", "gather", "quadtree", "candidates T", "selected n", "qt compact", "qt splits", "qt std::sort", "split: child counts", "split: ranks", "split: partition + children", "split: bookkeeping", "ff: histogram", "ff: levels + decision", "ff: radix sort", "ff: prefix", "ff: nodes", "best key per node", "radix: count", "radix: scan", "radix: scatter"], list(buf[8:16]) + list(buf[16:29])): print(f"  {n:28s} {v / nw:10.1f}")
