@@ -36,6 +36,8 @@ struct PinnedArena {
   char* base = nullptr;
   size_t cap = 0, off = 0;
   int depth = 0;
+  hipStream_t lastStream = nullptr;   // the stream the most recent upload from the arena was queued on (the one to drain before a rewind)
+  bool pending = false;               // an upload has been queued from the arena since the last rewind
   std::vector<char*> outgrown;
   void* take(size_t n) {
     n = (n + 63) & ~(size_t)63;
@@ -64,7 +66,17 @@ struct StreamScope {
   explicit StreamScope(void* stream) : saved(current_stream()) {
     current_stream() = reinterpret_cast<hipStream_t>(stream);
     PinnedArena& a = arena();
-    if (a.depth++ == 0 && a.off) { sync_current_stream(); a.rewind(); }   // whatever an earlier call queued from the arena has landed
+    if (a.depth == 0 && a.off) {
+      // whatever an earlier call queued from the arena must have landed before its bytes are reused — on the stream THAT call used (the tracking thread
+      // alternates between the matcher handle's stream and the optimizer handle's; a call that threw after its uploads left copies in flight there)
+      if (a.pending) {
+        const hipError_t e = hipStreamSynchronize(a.lastStream);
+        if (e != hipSuccess) { current_stream() = saved; hip_check(e, "hipStreamSynchronize"); }   // (depth untouched: the destructor will not run)
+      }
+      a.pending = false;
+      a.rewind();
+    }
+    ++a.depth;   // only once nothing above can throw
   }
   ~StreamScope() { --arena().depth; current_stream() = saved; }
   StreamScope(const StreamScope&) = delete;
@@ -94,6 +106,7 @@ class DeviceBuffer {
     if (arena().depth > 0) {   // inside an adapter call: through the thread's pinned arena, no wait (see PinnedArena)
       void* st = arena().take(n * sizeof(T));
       std::memcpy(st, host, n * sizeof(T));
+      arena().lastStream = current_stream(); arena().pending = true;
       hip_check(hipMemcpyAsync(p_, st, n * sizeof(T), hipMemcpyHostToDevice, current_stream()), "hipMemcpy H2D");
       return;
     }

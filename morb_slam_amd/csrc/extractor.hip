@@ -735,7 +735,24 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGe
   // work goes through them and leaves
   __shared__ int s_mom[DESC_WAVES * DESC_KPW][2];
   __shared__ float s_trig[DESC_WAVES * DESC_KPW][3];
-  if (gi0 >= selPerImg) { __syncthreads(); __syncthreads(); return; }
+  // The trig pass belongs to threads 0 .. DESC_WAVES * DESC_KPW - 1, i.e. to wave 0 — which therefore runs it even when it has no keypoint of its own
+  // (today k_layout writes the valid records first, so wave 0 is never the idle one; the kernel no longer depends on that).
+  auto trig_pass = [&]() {
+    if (threadIdx.x < DESC_WAVES * DESC_KPW) {
+      const float ang = fast_atan2_deg((float)s_mom[threadIdx.x][1], (float)s_mom[threadIdx.x][0]);
+      const float factorPI = (float)(3.14159265358979323846 / 180.f);
+      float sn, cs;
+      sincosf_glibc(ang * factorPI, &sn, &cs);
+      s_trig[threadIdx.x][0] = ang; s_trig[threadIdx.x][1] = cs; s_trig[threadIdx.x][2] = sn;
+    }
+  };
+  auto leave = [&]() {   // a wave without work: through the two barriers (its own s_mom slots are never read by anybody), wave 0 still doing the pass
+    if (lane < DESC_KPW) { s_mom[(threadIdx.x >> 6) * DESC_KPW + lane][0] = 0; s_mom[(threadIdx.x >> 6) * DESC_KPW + lane][1] = 0; }
+    __syncthreads();
+    trig_pass();
+    __syncthreads();
+  };
+  if (gi0 >= selPerImg) { leave(); return; }
 #else
   if (gi0 >= selPerImg) return;
 #endif
@@ -756,7 +773,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGe
     if (ok[kk]) { firstRef = ref[kk]; any = true; }
   }
 #if MORB_DESC_ANGLE_WG
-  if (!any) { __syncthreads(); __syncthreads(); return; }   // wave-uniform
+  if (!any) { leave(); return; }   // wave-uniform
 #else
   if (!any) return;   // wave-uniform
 #endif
@@ -885,13 +902,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGe
       s_mom[w0 + lane][0] = m10; s_mom[w0 + lane][1] = m01;
     }
     __syncthreads();
-    if (threadIdx.x < DESC_WAVES * DESC_KPW) {
-      const float ang = fast_atan2_deg((float)s_mom[threadIdx.x][1], (float)s_mom[threadIdx.x][0]);
-      const float factorPI = (float)(3.14159265358979323846 / 180.f);
-      float sn, cs;
-      sincosf_glibc(ang * factorPI, &sn, &cs);
-      s_trig[threadIdx.x][0] = ang; s_trig[threadIdx.x][1] = cs; s_trig[threadIdx.x][2] = sn;
-    }
+    trig_pass();
     __syncthreads();
   }
 #pragma unroll

@@ -646,7 +646,8 @@ __device__ unsigned long long g_inertialPhase[16];
 #else
 #define IMARK(k)
 #endif
-template <bool LASTFRAME, bool RIG>
+// GEDGE: the edge list lives in global memory (frames whose cap * 32 bytes do not fit the LDS beside the kernel's static data: ~4900 features) instead of LDS
+template <bool LASTFRAME, bool RIG, bool GEDGE>
 __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __restrict__ count, const uint8_t* __restrict__ hasMP,
                                                        const float* __restrict__ obs, const float* __restrict__ invSigma2,
                                                        const float* __restrict__ Xw, const uint8_t* __restrict__ closeFlag,
@@ -655,12 +656,13 @@ __global__ __launch_bounds__(256) void k_pose_inertial(int cap, const int* __res
                                                        const morb_imu_preintegrated* __restrict__ preKF,
                                                        const double* __restrict__ prevPrior, const int* __restrict__ nLeft,
                                                        int bRecInit, float* __restrict__ stateIO, uint8_t* __restrict__ outlier,
-                                                       int* __restrict__ nInliersOut, double* __restrict__ prior) {
+                                                       int* __restrict__ nInliersOut, double* __restrict__ prior, float* __restrict__ gEdge) {
   __shared__ InertialWork Wk;
   // the round's ACTIVE visual edges (map point present, not an outlier of the round before), compacted in feature order: (u, v, uR | X | info | camera)
   // as eight floats per edge.  The ten Gauss-Newton iterations of a round read them from here: each of a thread's three to five edges used to start
   // with a dependent round trip to global memory for its flags and another for its data (~2 k cycles per edge beside ~2.6 k of arithmetic).
-  extern __shared__ __align__(16) float sEdge[];
+  extern __shared__ __align__(16) float sEdgeLds[];
+  float* const sEdge = GEDGE ? gEdge + (size_t)blockIdx.x * cap * 8 : sEdgeLds;   // (a compile-time choice: each instantiation knows its address space)
   __shared__ VIState sS1;   // state 1 (keyframe / previous frame): only the dense-edge threads read it, one thread updates it
   constexpr int NV = LASTFRAME ? 30 : 15;
   // threads on the visual edges; wave 3 evaluates the inertial edge and (last-frame variant) wave 2 the prior edge meanwhile
@@ -1833,15 +1835,21 @@ static int launch_pose_inertial(bool lastFrame, morb_optimizer* o, int nframes, 
   CamGeom g;
   make_geom(Tbc12, fx, fy, cx, cy, bf, rig28, g);
   const size_t edgeLds = (size_t)cap * 32;   // the active visual edges of a frame, eight floats each
-  MORB_REQUIRE(edgeLds + sizeof(InertialWork) + 1024 <= 160 * 1024, MORB_ERR_UNSUPPORTED, "too many features per frame for the LDS edge list");
-#define MORB_LAUNCH_PI(LF, RG)                                                                                                       \
+  // (round 5 refused frames whose list does not fit the LDS; now they take the same kernel with the list in a global spill buffer of the handle)
+  const bool spill = edgeLds + sizeof(InertialWork) + 1024 > 160 * 1024;
+  void* gEdge = nullptr;
+  if (spill) { const int rc = morb_optimizer_spill(o, (size_t)nframes * edgeLds, &gEdge); if (rc != MORB_OK) return rc; }
+#define MORB_LAUNCH_PI2(LF, RG, GE)                                                                                                  \
   do {                                                                                                                               \
-    MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_inertial<LF, RG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)edgeLds)); \
-    hipLaunchKernelGGL((k_pose_inertial<LF, RG>), dim3(nframes), dim3(256), edgeLds, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, d_close, \
-                       g, d_state1, d_pre, d_preKF, d_prevPrior, d_nLeft, bRecInit, d_state, d_outlier, d_nInliers, d_prior);          \
+    const size_t lds_ = GE ? 0 : edgeLds;                                                                                            \
+    MORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_inertial<LF, RG, GE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+    hipLaunchKernelGGL((k_pose_inertial<LF, RG, GE>), dim3(nframes), dim3(256), lds_, st, cap, d_count, d_hasMP, d_obs, d_invSigma2, d_Xw, d_close, \
+                       g, d_state1, d_pre, d_preKF, d_prevPrior, d_nLeft, bRecInit, d_state, d_outlier, d_nInliers, d_prior, (float*)gEdge);  \
   } while (0)
+#define MORB_LAUNCH_PI(LF, RG) do { if (spill) MORB_LAUNCH_PI2(LF, RG, true); else MORB_LAUNCH_PI2(LF, RG, false); } while (0)
   if (lastFrame) { if (rig28) MORB_LAUNCH_PI(true, true); else MORB_LAUNCH_PI(true, false); }
   else { if (rig28) MORB_LAUNCH_PI(false, true); else MORB_LAUNCH_PI(false, false); }
+#undef MORB_LAUNCH_PI2
 #undef MORB_LAUNCH_PI
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;

@@ -17,4 +17,5 @@ MORB_INTERNAL int morb_optimizer_device(const morb_optimizer*);
 MORB_INTERNAL int morb_optimizer_workspace(morb_optimizer*, size_t bytes, void** out);
 MORB_INTERNAL int morb_optimizer_lm_words(morb_optimizer*, int** host, int** dev);   // 16 pinned, device-mapped ints (LM state mirror)
 MORB_INTERNAL int morb_optimizer_staging(morb_optimizer*, size_t bytes, void** host);   // grow-only pinned host buffer
+MORB_INTERNAL int morb_optimizer_spill(morb_optimizer*, size_t bytes, void** out);      // grow-only device buffer of the batch entry points (k_pose_inertial's edge lists beyond the LDS)
 }

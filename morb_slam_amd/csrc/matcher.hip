@@ -1115,7 +1115,10 @@ struct morb_matcher {
   std::vector<void*> retired;   // outgrown workspaces: kernels queued on a caller's stream may still read them, so they are freed with the handle
   // small constant tables (PredictScale thresholds, camera parameters): device copy + the host bytes it was made from, so that a
   // call with the same table neither uploads nor waits (projection.hip: morb_matcher_const)
-  struct ConstSlot { void* d = nullptr; std::vector<uint8_t> host; };
+  // Four most-recently-used copies per slot (a KB8 rig alternates the left and the right camera's table on one slot); a live copy is never
+  // rewritten — a kernel of an earlier call, queued on another caller's stream, may still be reading it.
+  struct ConstCopy { void* d = nullptr; std::vector<uint8_t> host; unsigned long long used = 0; };
+  struct ConstSlot { ConstCopy way[4]; unsigned long long clock = 0; };
   ConstSlot consts[4];
 };
 
@@ -1174,7 +1177,7 @@ void morb_matcher_destroy(morb_matcher* m) {
   F(m->d_sortA); F(m->d_sortB); F(m->d_bin); F(m->d_sad); F(m->d_stereoRec); F(m->d_scale); F(m->d_invScale); F(m->d_idx);
   for (auto& w : m->ws) F(w);
   for (auto& w : m->retired) F(w);
-  for (auto& c : m->consts) F(c.d);
+  for (auto& c : m->consts) for (auto& k : c.way) F(k.d);
   (void)hipStreamDestroy(m->stream);
   delete m;
 }
@@ -1207,18 +1210,23 @@ int morb_matcher_workspace(morb_matcher* m, int which, size_t bytes, void** out)
 int morb_matcher_const(morb_matcher* m, int slot, const void* host, size_t bytes, void** d_out, void* stream) {
   MORB_REQUIRE(m && host && d_out && slot >= 0 && slot < 4 && bytes > 0, MORB_ERR_INVALID, "bad constant-table request");
   morb_matcher::ConstSlot& c = m->consts[slot];
-  if (c.d && c.host.size() == bytes && memcmp(c.host.data(), host, bytes) == 0) { *d_out = c.d; return MORB_OK; }
-  if (!c.d || c.host.size() != bytes) {   // (a table of the same size is rewritten in place, in stream order)
-    void* fresh = nullptr;
-    MORB_HIP_CHECK(hipMalloc(&fresh, bytes));
-    if (c.d) m->retired.push_back(c.d);
-    c.d = fresh;
+  int victim = 0;
+  for (int w = 0; w < 4; ++w) {
+    morb_matcher::ConstCopy& k = c.way[w];
+    if (k.d && k.host.size() == bytes && memcmp(k.host.data(), host, bytes) == 0) { k.used = ++c.clock; *d_out = k.d; return MORB_OK; }
+    if (c.way[w].used < c.way[victim].used) victim = w;   // (an empty way has used == 0)
   }
-  c.host.assign((const uint8_t*)host, (const uint8_t*)host + bytes);
+  morb_matcher::ConstCopy& k = c.way[victim];
+  void* fresh = nullptr;
+  MORB_HIP_CHECK(hipMalloc(&fresh, bytes));
+  if (k.d) m->retired.push_back(k.d);   // freed with the handle: never overwritten while a kernel may read it
+  k.d = fresh;
+  k.host.assign((const uint8_t*)host, (const uint8_t*)host + bytes);
+  k.used = ++c.clock;
   hipStream_t st = stream ? (hipStream_t)stream : m->stream;
-  MORB_HIP_CHECK(hipMemcpyAsync(c.d, c.host.data(), bytes, hipMemcpyHostToDevice, st));
-  MORB_HIP_CHECK(hipStreamSynchronize(st));
-  *d_out = c.d;
+  MORB_HIP_CHECK(hipMemcpyAsync(k.d, k.host.data(), bytes, hipMemcpyHostToDevice, st));
+  MORB_HIP_CHECK(hipStreamSynchronize(st));   // (k.host may be reassigned by the next miss on this way)
+  *d_out = k.d;
   return MORB_OK;
 }
 int morb_bow_sort_images(morb_matcher* m, int nimg, const int* d_node, const int* d_count, int cap, unsigned long long** d_sorted,

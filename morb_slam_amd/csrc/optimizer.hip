@@ -2267,6 +2267,8 @@ struct morb_optimizer {
   // waits for a stream nor frees (hipFree waits for the DEVICE): they are released with the handle.  Each growth asks for half as much again, so the
   // retired bytes stay below twice the final size.
   std::vector<void*> retiredDev, retiredHost;
+  void* spill = nullptr;       // grow-only device buffer of the BATCH entry points (the one-shot ones own `work`): edge lists that do not fit the LDS
+  size_t spillBytes = 0;
 };
 
 struct morb_ba_problem {
@@ -2349,6 +2351,20 @@ int morb_optimizer_workspace(morb_optimizer* o, size_t bytes, void** out) {
   return MORB_OK;
 }
 
+int morb_optimizer_spill(morb_optimizer* o, size_t bytes, void** out) {
+  MORB_REQUIRE(o && out, MORB_ERR_INVALID, "NULL argument");
+  if (bytes > o->spillBytes) {
+    void* fresh = nullptr;
+    const size_t want = bytes + bytes / 2;
+    MORB_HIP_CHECK(hipMalloc(&fresh, want));
+    if (o->spill) o->retiredDev.push_back(o->spill);
+    o->spill = fresh;
+    o->spillBytes = want;
+  }
+  *out = o->spill;
+  return MORB_OK;
+}
+
 int morb_optimizer_lm_words(morb_optimizer* o, int** host, int** dev) {
   MORB_REQUIRE(o && host && dev, MORB_ERR_INVALID, "NULL argument");
   if (!o->lmWords) {
@@ -2403,6 +2419,7 @@ void morb_optimizer_destroy(morb_optimizer* o) {
   if (o->evFork) (void)hipEventDestroy(o->evFork);
   if (o->evJoin) (void)hipEventDestroy(o->evJoin);
   if (o->work) (void)hipFree(o->work);
+  if (o->spill) (void)hipFree(o->spill);
   for (void* w : o->retiredDev) (void)hipFree(w);
   if (o->lmWords) (void)hipHostFree(o->lmWords);
   if (o->stage) (void)hipHostFree(o->stage);

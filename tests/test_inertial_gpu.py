@@ -456,3 +456,30 @@ def test_reference_typed_local_inertial_ba_member(opt, tmp_path):
     assert dd.max() < 1e-4, dd.max()
     np.testing.assert_array_equal(get("iba_erase", np.uint8), er)
     assert er.sum() > 10
+
+
+def test_pose_inertial_frames_beyond_the_lds_edge_list(opt):
+    """k_pose_inertial keeps a frame's active visual edges in LDS (cap * 32 bytes); a frame capacity beyond ~4900 features takes the instantiation whose list
+    lives in the handle's global spill buffer (round 5 refused it with MORB_ERR_UNSUPPORTED).  Same instructions on the same data: the two forms agree to
+    the BIT on the same problems (padded to cap 6000), both variants (last keyframe / last frame), and the large one equals the oracle."""
+    dev = torch.device("cuda", 0)
+    probs = [make_inertial_problem(500, seed=40 + s, n_imu=20) for s in range(3)]
+    nga, walk = imu_calib_diagonals()
+    pre_o = np.stack([orc.imu_preintegrate(p["bias"], nga, walk, p["acc"], p["gyro"], p["dt"]) for p in probs])
+    res = {}
+    for cap in (500, 6000):
+        pad = lambda a: np.pad(a, [(0, cap - len(a))] + [(0, 0)] * (a.ndim - 1))
+        st = lambda k: torch.from_numpy(np.stack([pad(p[k]) for p in probs])).to(dev)
+        raw = lambda k: torch.from_numpy(np.stack([p[k] for p in probs])).to(dev)
+        cnt = torch.tensor([500] * len(probs), dtype=torch.int32, device=dev)
+        state = raw("state0").clone()
+        nin, outl, prior = opt.PoseInertialOptimizationLastKeyFrame(st("hasMP"), st("obs"), st("invSigma2"), st("Xw"), st("close"), probs[0]["cam"],
+                                                                    probs[0]["Tbc12"], raw("kfState"), torch.from_numpy(pre_o).to(dev), state, count=cnt)
+        torch.cuda.synchronize()
+        res[cap] = (nin.cpu().numpy(), outl.cpu().numpy()[:, :500], prior.cpu().numpy(), state.cpu().numpy())
+    for a, b in zip(res[500], res[6000]):
+        assert a.tobytes() == b.tobytes()
+    for i, p in enumerate(probs):
+        r, s_o, out_o, _ = orc.pose_inertial_optimization_last_keyframe(p, pre_o[i])
+        assert int(res[6000][0][i]) == r and np.array_equal(res[6000][1][i], out_o)
+        assert np.allclose(res[6000][3][i], s_o, rtol=0, atol=1e-4)

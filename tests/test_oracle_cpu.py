@@ -642,7 +642,10 @@ def test_oracle_matches_opencv_vectors():
     (no OpenCV): until someone commits it the oracle stays "parity unpinned" and this test is skipped."""
     path = os.path.join(ROOT, "tests", "golden", "reference_opencv.npz")
     if not os.path.exists(path):
-        pytest.skip("tests/golden/reference_opencv.npz not generated yet (needs OpenCV: tests/golden/make_opencv_golden.py --write)")
+        pytest.skip("oracle parity UNPINNED: tests/golden/reference_opencv.npz is absent and this image has no OpenCV.  With cv2 >= 4.4 importable (the "
+                    "reference's floor, CMakeLists.txt:27 find_package(OpenCV 4.4)) run ONE command from the repository root:  "
+                    "python tests/golden/make_opencv_golden.py --write   — it compares oracle/cvprims.cc with cv2 primitive by primitive, exits non-zero on "
+                    "the first difference, and writes the .npz this test then replays without cv2 (commit it)")
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import make_opencv_golden as g
     ref = dict(np.load(path, allow_pickle=False))
