@@ -918,17 +918,21 @@ def main():
         # traffic = 2 x FETCH_SIZE + WRITE_SIZE
         pm = pmi = None
         pm_src = None
-        for rnd, fn in (("r05", "pmc_traffic_b512.json"), ("r04", "pmc_traffic_b64.json"), ("r03", "pmc_traffic_b64.json")):   # newest first; r05: taken AT the bench batch
+        for rnd, fn in (("r06", "pmc_traffic_b512.json"), ("r05", "pmc_traffic_b512.json"), ("r04", "pmc_traffic_b64.json"), ("r03", "pmc_traffic_b64.json")):   # newest first; since r05: taken AT the bench batch
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", rnd, fn)))
                 pm_src = f"profiles/{rnd}/{fn}"
                 break
             except Exception:
                 pm = None
-        try:
-            pmi = json.load(open(os.path.join(ROOT, "profiles", "r05", "pmc_issue_b512.json")))
-        except Exception:
-            pmi = None
+        pmi_src = None
+        for rnd in ("r06", "r05"):
+            try:
+                pmi = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_issue_b512.json")))
+                pmi_src = f"profiles/{rnd}/pmc_issue_b512.json"
+                break
+            except Exception:
+                pmi = None
 
         def traffic_of(stage):
             if pm is None or args.workload != "c2":
@@ -994,7 +998,7 @@ def main():
                                                                  "is the error of that clock assumption / of the counter pass taken at another time, not a faster chip",
                                       "valu_lane_slots_per_pixel": per_step * 64 / (ab["fast"] * nimg),
                                       "valu_per_cell_wave": kf["valu_per_wave"], "salu_per_cell_wave": kf["salu_per_wave"], "lds_per_cell_wave": kf["lds_per_wave"],
-                                      "source": "profiles/r05/pmc_issue_b512.json (SQ_INSTS_VALU per launch) / live k_fastw time x 1024 SIMDs x 2.4 GHz"}
+                                      "source": f"{pmi_src} (SQ_INSTS_VALU per launch) / live k_fastw time x 1024 SIMDs x 2.4 GHz"}
         if multi is not None:
             line["multi_gpu"] = multi
         if verified is not None:

@@ -51,6 +51,10 @@ namespace {
 #define MORB_TEAM_MAX_IMAGES 16
 #endif
 constexpr int kTeamMaxImages = MORB_TEAM_MAX_IMAGES;
+#ifndef MORB_PYR_CHUNK_IMAGES
+#define MORB_PYR_CHUNK_IMAGES (1 << 30)
+#endif
+constexpr int kPyrChunkImages = MORB_PYR_CHUNK_IMAGES;   // images per group of pyramid launches (morb_extract_batch)
 #ifndef MORB_TEAM_MIN_PIXELS
 #define MORB_TEAM_MIN_PIXELS 160000   // k_distribute: levels of at least this many pixels are worked by a team of waves in the team packing
 #endif
@@ -108,8 +112,9 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
 // General form (any scale factor): four byte gathers per output pixel.  Used only when a level's four-pixel chunks do not fit the
 // 8-byte source windows of k_resize (scale factors above ~1.75).
 __global__ __launch_bounds__(256) void k_resize_gather(uint8_t* __restrict__ pyr, LevelGeom gs, LevelGeom gd,
-                                                       const ResizeTab* __restrict__ xtab, const ResizeTab* __restrict__ ytab) {
-  const PyTile pt = py_tile();
+                                                       const ResizeTab* __restrict__ xtab, const ResizeTab* __restrict__ ytab, int img0) {
+  PyTile pt = py_tile();
+  pt.img += img0;   // (the launch covers images img0 .. img0 + gridDim.z - 1)
   const uint8_t* sbase = pyr + gs.pyrOff + (size_t)pt.img * gs.pyrImg + (size_t)EDGE * gs.pstride + EDGE;
   const int px = (pt.bx * 64 + (threadIdx.x & 63)) * 4;
   const int py0 = (pt.by * 4 + (threadIdx.x >> 6)) * PY_ROWS;
@@ -1535,23 +1540,36 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
       a.magicC = pl.magicC; a.dOff = g.pyrOff; a.dImg = g.pyrImg;
       return a;
     };
-    if (e->pyrPacked) {
-      // level 0 first, in its own launch: level 1 reads it back from the pyramid (dword-aligned rows with slack behind them — the wide
-      // aligned window loads of k_resize cannot be pointed at a caller-owned buffer; the fused level-0 + level-1 kernel of round 2 did
-      // that with byte-granular 8-byte loads at twice the memory-pipe cost)
-      hipLaunchKernelGGL(k_level0, dim3(div_up(p0.nItems, 256), 1, nimg), dim3(256), 0, st, d_images, stride, image_pitch, e->d_pyr, a0);
-      for (int l = 1; l < L; ++l) {
-        const LevelGeom& gs = e->geom[l - 1];
-        const PyrLevel& pl = e->pyrLv[l];
-        hipLaunchKernelGGL(k_resize, dim3(div_up(pl.nItems, 256), 1, nimg), dim3(256), sizeof(PyrRow) * pl.ldsRows, st, e->d_pyr,
-                           gs.pyrOff + (unsigned long long)EDGE * gs.pstride, gs.pyrImg, gs.pstride, resize_args(l));
-      }
-    } else {
-      hipLaunchKernelGGL(k_level0, dim3(div_up(p0.nItems, 256), 1, nimg), dim3(256), 0, st, d_images, stride, image_pitch, e->d_pyr, a0);
-      for (int l = 1; l < L; ++l) {
-        const LevelGeom& g = e->geom[l];
-        dim3 gr(div_up(g.pstride / 4, 64), div_up(g.h + 2 * EDGE, 4 * PY_ROWS), nimg);
-        hipLaunchKernelGGL(k_resize_gather, gr, dim3(256), 0, st, e->d_pyr, e->geom[l - 1], g, e->d_tabs + g.xtabOff, e->d_tabs + g.ytabOff);
+    // Round 6: the eight dependent launches run over CHUNKS of images.  Level l reads level l - 1 back: with all 1024 images of a bench step in one
+    // launch the producer's 400 MB have long left the L2 / Infinity Cache (256 MB) when the consumer starts and every level is read from HBM again;
+    // chunk by chunk the previous level of the chunk is still on chip (profiles/r06/pyramid_chunk_sweep.txt).
+    static const int pyrChunkEnv = [] { const char* v = getenv("MORB_PYR_CHUNK"); return v ? atoi(v) : 0; }();
+    const int chunk = pyrChunkEnv > 0 ? pyrChunkEnv : kPyrChunkImages;
+    for (int i0 = 0; i0 < nimg; i0 += chunk) {
+      const int ni = nimg - i0 < chunk ? nimg - i0 : chunk;
+      Level0Args a0c = a0;
+      a0c.dOff += (unsigned long long)i0 * a0.dImg;
+      const uint8_t* src = d_images + (size_t)i0 * image_pitch;
+      if (e->pyrPacked) {
+        // level 0 first, in its own launch: level 1 reads it back from the pyramid (dword-aligned rows with slack behind them — the wide
+        // aligned window loads of k_resize cannot be pointed at a caller-owned buffer; the fused level-0 + level-1 kernel of round 2 did
+        // that with byte-granular 8-byte loads at twice the memory-pipe cost)
+        hipLaunchKernelGGL(k_level0, dim3(div_up(p0.nItems, 256), 1, ni), dim3(256), 0, st, src, stride, image_pitch, e->d_pyr, a0c);
+        for (int l = 1; l < L; ++l) {
+          const LevelGeom& gs = e->geom[l - 1];
+          const PyrLevel& pl = e->pyrLv[l];
+          ResizeArgs ra = resize_args(l);
+          ra.dOff += (unsigned long long)i0 * ra.dImg;
+          hipLaunchKernelGGL(k_resize, dim3(div_up(pl.nItems, 256), 1, ni), dim3(256), sizeof(PyrRow) * pl.ldsRows, st, e->d_pyr,
+                             gs.pyrOff + (unsigned long long)i0 * gs.pyrImg + (unsigned long long)EDGE * gs.pstride, gs.pyrImg, gs.pstride, ra);
+        }
+      } else {
+        hipLaunchKernelGGL(k_level0, dim3(div_up(p0.nItems, 256), 1, ni), dim3(256), 0, st, src, stride, image_pitch, e->d_pyr, a0c);
+        for (int l = 1; l < L; ++l) {
+          const LevelGeom& g = e->geom[l];
+          dim3 gr(div_up(g.pstride / 4, 64), div_up(g.h + 2 * EDGE, 4 * PY_ROWS), ni);
+          hipLaunchKernelGGL(k_resize_gather, gr, dim3(256), 0, st, e->d_pyr, e->geom[l - 1], g, e->d_tabs + g.xtabOff, e->d_tabs + g.ytabOff, i0);
+        }
       }
     }
   }

@@ -3,7 +3,7 @@
 # command plus separate --pmc passes (HBM traffic: FETCH_SIZE / WRITE_SIZE; issue mix: SQ_*), as the MI355X guide
 # prescribes (counters never combined with sys/runtime traces).  Usage: bash tools/refresh_profiles.sh r01
 set -u
-R=${1:-r05}
+R=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$R
 rm -rf "$O" && mkdir -p "$O"
@@ -45,24 +45,43 @@ python3 tools/fastw_cycles.py 256 2>/dev/null | grep -v amdgpu.ids > "$O/k_fastw
 python3 tools/fast_threshold_sweep.py > "$O/k_fastw_threshold_sweep.txt" 2>/dev/null
 python3 tools/pose_opt_modes.py > "$O/pose_optimization_modes.txt" 2>/dev/null
 python3 tools/stage_times.py 64 > "$O/extract_stage_times_isolated.txt" 2>/dev/null; python3 tools/stage_times.py 256 >> "$O/extract_stage_times_isolated.txt" 2>/dev/null
-{ echo "== 752 x 480, 1 stereo frame (team packing)"; python3 tools/fast_phases.py 1 | tail -13; echo "== 1920 x 1080 / 4000, 4 stereo frames (team packing)"; MORB_W=1920 MORB_H=1080 MORB_NF=4000 python3 tools/fast_phases.py 4 | tail -13; } > "$O/k_distribute_phases.txt" 2>/dev/null
-python3 tools/latency_b1.py > "$O/latency_b1.txt" 2>/dev/null
+{ echo "== 1920 x 1080 / 4000, 1 stereo frame (team of 16 waves per big level)"; MORB_W=1920 MORB_H=1080 MORB_NF=4000 python3 tools/fast_phases.py 1 | tail -22;
+  echo "== 1920 x 1080 / 4000, 4 stereo frames (team)"; MORB_W=1920 MORB_H=1080 MORB_NF=4000 python3 tools/fast_phases.py 4 | tail -22;
+  echo "== 752 x 480 / 1200, 1 stereo frame (team)"; python3 tools/fast_phases.py 1 | tail -22;
+  echo "== 752 x 480 / 1200, 256 stereo frames (one wave per level, the bench's packing)"; python3 tools/fast_phases.py 256 | tail -22;
+  echo "== the same four with the sweeps one by one (-DQT_FAST_FORWARD=0: round 5's algorithm on this round's team width)";
+  export MORB_EXTRA_DEFS=-DQT_FAST_FORWARD=0 MORB_TIMING_TAG=_noff;
+  MORB_W=1920 MORB_H=1080 MORB_NF=4000 python3 tools/fast_phases.py 1 | tail -22; MORB_W=1920 MORB_H=1080 MORB_NF=4000 python3 tools/fast_phases.py 4 | tail -22; python3 tools/fast_phases.py 1 | tail -22; python3 tools/fast_phases.py 256 | tail -22;
+  echo "== and with round 5's team of four waves (-DQT_FAST_FORWARD=0 -DQT_TEAM_WAVES=4)";
+  export MORB_EXTRA_DEFS="-DQT_FAST_FORWARD=0 -DQT_TEAM_WAVES=4" MORB_TIMING_TAG=_r05;
+  MORB_W=1920 MORB_H=1080 MORB_NF=4000 python3 tools/fast_phases.py 1 | tail -22; python3 tools/fast_phases.py 1 | tail -22;
+  unset MORB_EXTRA_DEFS MORB_TIMING_TAG; } > "$O/k_distribute_phases.txt" 2>/dev/null
+{ python3 tools/latency_b1.py; MORB_W=1920 MORB_H=1080 MORB_NF=4000 python3 tools/latency_b1.py; } 2>/dev/null | grep -v amdgpu.ids > "$O/latency_b1.txt"
 # the other headline shapes: BASELINE configs[3] on one GPU, and the --gpus 2 launcher path (two ranks sharing this GPU, gloo)
 python3 bench.py --workload c4 --no-extras --no-cpu-baseline --sustained-s 0 > "$O/bench_c4.json" 2>/dev/null
+python3 bench.py --workload c4 --batch 1 --no-cpu-baseline > "$O/bench_c4_batch1.json" 2>/dev/null     # one 1920 x 1080 stereo frame per step: what each rank of the 8-GPU run executes
+# the three placements of a step's matchers, each twice
+for rep in 1 2; do for m in beside-pyramid under-quadtree under-fast; do python3 bench.py --matchers $m --no-extras --no-cpu-baseline --steps 40 --warmup 5 --sustained-s 0 2>/dev/null | python3 -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); s=d['extract_stage_ms_per_step']
+        print('$m', round(d['value']), 'frames/s', round(d['ms_per_step'],3), 'ms |', ' '.join(f'{k} {v:.3f}' for k,v in s.items()))
+"; done; done > "$O/matcher_placement_ab.txt"
+bash tools/r06_pyr_chunk.sh > "$O/pyramid_chunk_sweep.txt" 2>/dev/null
+# does v_mfma_f64_4x4x4 add its four products in order, each rounded?  (the probe the edge-order PoseOptimization rests on; the handle repeats a short form of it at creation)
+{ hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_chain tools/micro/mfma_chain.hip 2>&1 && /tmp/mfma_chain; } > "$O/mfma_chain_probe.txt" 2>&1
 MORB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --batch 64 --steps 10 --no-extras --no-cpu-baseline --sustained-s 0 > "$O/bench_gpus2_gloo_one_gpu.json" 2>/dev/null
 MORB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --batch 64 --steps 10 --exchange allgather --no-extras --no-cpu-baseline --sustained-s 0 > "$O/bench_gpus2_allgather_gloo_one_gpu.json" 2>/dev/null
 MORB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --workload c4 --steps 10 --no-extras --no-cpu-baseline --sustained-s 0 > "$O/bench_c4_gpus2_gloo_one_gpu.json" 2>/dev/null
-# round 5: the tracking-side matchers (north_star's SearchByProjection / SearchForTriangulation kernels): kernel stats of the chain + keyframe searches,
-# kernel timelines of one step (one frame, 256 frames); the eight-rank shape of the driver's multi-GPU run on this one GPU (gloo), ring and all-gather
+# the tracking-side matchers (north_star's SearchByProjection / SearchForTriangulation kernels): kernel stats of the chain + keyframe searches,
+# kernel timelines of one step (one frame, 256 frames).  (No eight-rank one-GPU runs any more: not evidence of anything)
 bash tools/prof_tracking.sh trk_$R 256 > "$O/tracking_profile_log.txt" 2>&1
 cp gpurun_out/trk_$R/tracking_kernel_stats.csv gpurun_out/trk_$R/tracking_b1_timeline.txt gpurun_out/trk_$R/tracking_b256_timeline.txt "$O/" 2>/dev/null
 cp gpurun_out/trk_$R/bench.json "$O/tracking_bench.json" 2>/dev/null
-MORB_DIST_BACKEND=gloo python3 bench.py --gpus 8 --workload c4 --batch 1 --steps 10 --warmup 0 --no-extras --no-cpu-baseline --sustained-s 0 > "$O/bench_c4_gpus8_batch1_ring_gloo_one_gpu.json" 2>/dev/null
-MORB_DIST_BACKEND=gloo python3 bench.py --gpus 8 --workload c4 --batch 1 --steps 10 --warmup 0 --exchange allgather --no-extras --no-cpu-baseline --sustained-s 0 > "$O/bench_c4_gpus8_batch1_allgather_gloo_one_gpu.json" 2>/dev/null
 python3 tools/ablate_matchers.py > "$O/matcher_ablation.txt" 2>/dev/null
 python3 tools/h2d_bw.py > "$O/h2d_copy_bandwidth_by_streams.txt" 2>/dev/null
 python3 bench.py > "$O/bench_default.json" 2>/dev/null
 python3 tools/time_stats.py "$O" 50 10 > /dev/null 2>&1
-python3 -m pytest tests -m gpu -q 2>&1 | tail -3 > "$O/pytest_gpu.txt"
 rm -rf "$O/stats" "$O"/pmc/*/q_kernel_trace.csv "$O"/pmc/*/q_agent_info.csv "$O/pmc"
 ls -la "$O"
