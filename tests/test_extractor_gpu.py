@@ -224,7 +224,7 @@ def test_input_ending_on_a_page_boundary():
 
 def test_quadtree_team_and_single_wave_packings_agree():
     # k_distribute has two packings of an image's levels into workgroups: calls with <= 16 images give every level of >= 160 k pixels a
-    # team of four waves (latency), larger batches keep one wave per (image, level).  Every other test here runs the first; this one
+    # team of QT_TEAM_WAVES = 16 waves (latency), larger batches keep one wave per (image, level).  Every other test here runs the first; this one
     # runs both on the same images and requires the same bytes — and the oracle's.
     import torch
     from morb_slam_amd import KP_DTYPE
@@ -284,3 +284,58 @@ def test_more_than_65535_candidates_in_a_level_match_the_oracle():
         assert np.array_equal(desc[i, :n].cpu().numpy(), do)
     mono, k, d = g(make_image(1920, 1080, seed=31))      # and the handle keeps working
     assert len(k) > 3000
+
+
+def _edge_case_images():
+    """Images that steer DistributeOctTree through every way the full sweeps can end (quadtree.h qt_fast_forward): texture in one corner only (a deep,
+    lop-sided tree: the histogram's depth is used up and ordinary sweeps go on), a handful of isolated corners (the tree stops because nothing is left
+    to divide, far below the quota), flat images (no candidate at all), and the aspect ratios that give 1, 3 and 4 initial nodes."""
+    rng = np.random.default_rng(77)
+    out = {}
+    img = np.full((480, 752), 128, np.uint8)
+    img[20:170, 30:230] = rng.integers(0, 256, (150, 200), dtype=np.uint8)
+    out["texture in one corner"] = img
+    img = np.full((480, 752), 90, np.uint8)
+    for k in range(9):
+        y, x = 60 + 40 * k, 80 + 70 * k
+        img[y:y + 9, x:x + 9] = 230
+    out["nine isolated squares"] = img
+    img = np.full((480, 752), 128, np.uint8)
+    img[200:260, 300:420] = make_image(120, 60, seed=5)
+    out["one small textured patch"] = img
+    out["square image (one initial node)"] = make_image(480, 480, seed=6)
+    out["3 : 1 (three initial nodes)"] = make_image(900, 300, seed=7)
+    out["3.2 : 1 (three initial nodes at the bottom of the pyramid, four at the top: the border is a fixed 16 px)"] = make_image(1280, 400, seed=8)
+    img = make_image(752, 480, seed=9)
+    img[:, 376:] = 128                                    # the right half of the image — one of the two initial nodes — is empty
+    out["empty right half"] = img
+    return out
+
+
+@pytest.mark.parametrize("nfeat", [1200, 60])
+def test_quadtree_every_ending_of_the_full_sweeps(nfeat):
+    """Every image of _edge_case_images, one at a time (the big levels are worked by a team of waves) — selection AND order of every level against the
+    oracle's std::list / std::sort restatement — and then all of them in one batch of 32 (one wave per level), which must give the same bytes."""
+    import torch
+    from morb_slam_amd import ORBextractor
+    cases = _edge_case_images()
+    for name, img in cases.items():
+        n = _compare(img, nfeat)
+        assert n >= 0, name
+    same = [im for im in cases.values() if im.shape == (480, 752)]
+    batch = np.stack([same[i % len(same)] for i in range(32)])
+    ext = ORBextractor(nfeat, 1.2, 8, 20, 7)
+    kps, desc, cnt, _ = ext.extract_batch(torch.from_numpy(batch).cuda())
+    torch.cuda.synchronize()
+    for i in range(len(same)):
+        _, k1, d1 = ext(same[i])
+        c = int(cnt[i])
+        assert c == len(k1)
+        assert kps[i, :c].cpu().numpy().tobytes() == k1.tobytes() and np.array_equal(desc[i, :c].cpu().numpy(), d1)
+
+
+def test_quadtree_tiny_quotas_take_the_sweeps():
+    """nfeatures so small that a level's node arrays cannot hold the fast-forward's scratch (qt_fast_forward returns -1): the sweeps run one by one."""
+    for nfeat in (8, 17):
+        _compare(make_image(640, 480, seed=21), nfeat)
+        _compare(make_image(480, 480, seed=22), nfeat)
