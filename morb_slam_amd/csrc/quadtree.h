@@ -667,7 +667,9 @@ __device__ inline void qt_split_batch(Work& w, State& s, int mAll, int cutoffN, 
   const int estart = tm.tw * 64, estep = tm.nw * 64;
   int runCh = 0, runEx = 0, runSize = s.size, mProc = m;
   const bool teamHuge = tm.nw > 1;
-  const uint32_t smallMax = QT_SMALL;   // (a team with 6 here — whole-wave counts for nearly every node — counted 2.6 x slower, partitioned 1.5 x faster: no gain)
+  // a lane walks a node's keys one LDS round trip after the other: fewest instructions (the packed form: many waves per SIMD), longest chain.  A team
+  // (latency) gives every node of more than a few keys to a whole wave: with only the needed nodes counted (below) 4.9 + 10.4 us against 6.4 + 16.5
+  const uint32_t smallMax = tm.nw > 1 ? 6u : QT_SMALL;
   QT_T0();
   for (;;) {
   // the team's waves take the sweep's nodes interleaved (node e -> wave e % nw): the first sweeps have a handful of huge nodes, one wave each
@@ -874,7 +876,7 @@ QT_HD void qt_compact(Work& w, State& s) {
 // on how many cells of each depth hold one / several keys.  So instead of one partition pass over all keys per sweep (each with its
 // count / rank / scatter phases and barriers: 4 sweeps = 113 of level 0's 207 us at 1920 x 1080 / 4000 features with 16 waves), the
 // keys are histogrammed once by their depth-Dcap cell, the per-depth cell counts decide how many full sweeps d0 the reference runs,
-// the keys are radix-sorted (stable, LSD, 6 bits per pass) by their depth-d0 cell, and the nodes, the list and
+// the keys are radix-sorted (stable, LSD, usually ONE pass with the whole cell code as the digit) by their depth-d0 cell, and the nodes, the list and
 // vSizeAndPointerToNode are written directly in the order the sweeps would have left them.
 //
 // Generation order.  Sweep d visits the list from its head: the children of sweep d - 1 in REVERSE generation order (push_front),
@@ -937,28 +939,46 @@ __device__ __forceinline__ int qt_below(uint64_t m) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// One stable LSD radix pass of src[0..n) -> dst by digit (code >> shift) & (2^bits - 1), bits <= 6, by the whole team (contiguous slice per
-// wave, so the order of equal digits is the input order).  cnt: 64 ints per wave of the team (row = wave).
+// One stable LSD radix pass of src[0..n) -> dst by digit (code >> shift) & (2^bits - 1) by the whole team (contiguous slice per wave, so the order of
+// equal digits is the input order).  Round 6, second form: the digit is as wide as the scratch allows — the whole cell code when it fits, i.e. ONE
+// pass instead of two 6-bit ones (22 -> 13 us of level 0's quadtree at 1920 x 1080 / 4000).  cnt16: [2^bits][nw] 16-bit counters (digit-major), tot:
+// [2^bits] ints; both in the node array, which nothing reads before the nodes are written.  n < 65536 (the caller checks).
 template <typename Code>
-__device__ inline void qt_radix_pass(const uint32_t* src, uint32_t* dst, uint32_t n, int shift, int bits, Code code, const Team& tm, int* cnt) {
-  const int lane = QT_LANE;
-  const int mask = (1 << bits) - 1;
-  int* mine = cnt + 64 * tm.tw;
-  mine[lane] = 0;
+__device__ inline void qt_radix_pass(const uint32_t* src, uint32_t* dst, uint32_t n, int shift, int bits, Code code, const Team& tm, uint16_t* cnt16,
+                                     int* tot) {
+  const int lane = QT_LANE, tid = tm.tw * 64 + lane, nth = tm.nw * 64;
+  const int nd = 1 << bits, mask = nd - 1;
+  uint32_t* cnt32 = reinterpret_cast<uint32_t*>(cnt16);
+  for (int i = tid; i < (nd * tm.nw + 1) / 2; i += nth) cnt32[i] = 0u;
   const uint32_t per = ((n + tm.nw * 64 - 1) / (tm.nw * 64)) * 64;
   const uint32_t lo = per * tm.tw < n ? per * tm.tw : n, hi = lo + per < n ? lo + per : n;
-  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  QT_SYNC();
+  QT_TEAM_SYNC(tm);
   QT_T0();
 #pragma unroll 4
-  for (uint32_t i = lo + lane; i < hi; i += 64) atomicAdd(&mine[(int)(code(src[i]) >> shift) & mask], 1);   // (no return value: fire and forget)
+  for (uint32_t i = lo + lane; i < hi; i += 64) {   // (LDS atomics without return value: fire and forget; two 16-bit counters per word, neither can carry: n < 65536)
+    const int e = ((int)(code(src[i]) >> shift) & mask) * tm.nw + tm.tw;
+    atomicAdd(&cnt32[e >> 1], 1u << (16 * (e & 1)));
+  }
   QT_TEAM_SYNC(tm);
   QT_MARK(26);
-  if (tm.tw == 0) {   // first slot of (digit, wave): digit-major, wave-minor
-    int tot = 0;
-    for (int wv = 0; wv < tm.nw; ++wv) { const int c = cnt[64 * wv + lane]; cnt[64 * wv + lane] = tot; tot += c; }
-    const int base = qt_scan_incl(tot) - tot;
-    for (int wv = 0; wv < tm.nw; ++wv) cnt[64 * wv + lane] += base;
+  // first slot of (digit, wave) = keys of smaller digits + keys of this digit in earlier waves: per digit the waves' counts become an exclusive
+  // prefix (in place) and the digit's total goes to tot[]; then wave 0 turns tot[] into its exclusive prefix
+  for (int d = tid; d < nd; d += nth) {
+    uint16_t* row = cnt16 + d * tm.nw;
+    int run = 0;
+    for (int wv = 0; wv < tm.nw; ++wv) { const int c = row[wv]; row[wv] = (uint16_t)run; run += c; }
+    tot[d] = run;
+  }
+  QT_TEAM_SYNC(tm);
+  if (tm.tw == 0) {
+    int run = 0;
+    for (int d0 = 0; d0 < nd; d0 += 64) {
+      const int d = d0 + lane;
+      const int v = d < nd ? tot[d] : 0;
+      const int inc = qt_scan_incl(v);
+      if (d < nd) tot[d] = run + inc - v;
+      run += __builtin_amdgcn_readlane(inc, 63);
+    }
   }
   QT_TEAM_SYNC(tm);
   QT_MARK(27);
@@ -978,9 +998,10 @@ __device__ inline void qt_radix_pass(const uint32_t* src, uint32_t* dst, uint32_
       const uint64_t peers = qt_peers(dg[u], valid, bits);
       const int below = qt_below(peers);
       int off = 0;
-      if (valid) { off = mine[dg[u]]; dst[off + below] = k[u]; }
+      uint16_t* slot = cnt16 + dg[u] * tm.nw + tm.tw;
+      if (valid) { off = *slot; dst[tot[dg[u]] + off + below] = k[u]; }
       QT_SYNC();
-      if (valid && below == 0) mine[dg[u]] = off + __popcll(peers);
+      if (valid && below == 0) *slot = (uint16_t)(off + __popcll(peers));
       QT_SYNC();
     }
   }
@@ -990,9 +1011,9 @@ __device__ inline void qt_radix_pass(const uint32_t* src, uint32_t* dst, uint32_
 
 // Replaces the root set-up and every full sweep the reference would run (up to QT_FF_MAXD, and as far as the cell counts fit `hist`): on
 // return the keys are partitioned, nodes / list / vA / State are what the sweeps leave, and the result says how the loop goes on.
-// hist: histCap ints of scratch (the vB region), aux: 16 + 12 * nw ints (the brank region), radix: 64 ints per wave (static LDS).
+// hist: histCap ints of scratch (the vB region), aux: 16 + 12 * nw ints (the brank region); the code tables and the radix counters live in the node array.
 __device__ inline int qt_fast_forward(Work& w, State& s, uint32_t nkeys, const FfGeom& fg, int N, const Team& tm, int* hist, int histCap, int* aux,
-                                      int auxCap, int* radix) {
+                                      int auxCap) {
   const int lane = QT_LANE, tid = tm.tw * 64 + lane, nth = tm.nw * 64;
   const int nIni = fg.nIni;
   // depth of the histogram: no deeper than the sweeps can go (a full sweep needs size <= N afterwards, and cells >= nodes), and what fits
@@ -1001,7 +1022,7 @@ __device__ inline int qt_fast_forward(Work& w, State& s, uint32_t nkeys, const F
   int D = 1;
   while (D < QT_FF_MAXD && (nIni << (2 * D)) <= 2 * N && offOf(D + 2) <= histCap) ++D;
   const int total = offOf(D + 1);
-  if (total > histCap || 16 + 12 * tm.nw > auxCap) return -1;   // (tiny quotas only: the caller runs the sweeps)
+  if (total > histCap || 16 + 12 * tm.nw > auxCap || nkeys >= 65536u || (size_t)w.nodeCap * sizeof(Node) < (size_t)4 * (2 * tm.nw + 4) + 16) return -1;   // (tiny quotas, or a level of > 65535 candidates: the caller runs the sweeps)
   for (int i = tid; i < total; i += nth) hist[i] = 0;
   for (int i = tid; i < 16 + 12 * tm.nw; i += nth) aux[i] = 0;
   QT_TEAM_SYNC(tm);
@@ -1012,7 +1033,8 @@ __device__ inline int qt_fast_forward(Work& w, State& s, uint32_t nkeys, const F
   const int tabW = fg.width + 1, tabH = fg.height + 1;
   uint16_t* xs = reinterpret_cast<uint16_t*>(w.nodes);
   uint16_t* ys = xs + tabW;
-  const bool useTab = (size_t)(tabW + tabH) * 2 <= (size_t)w.nodeCap * sizeof(Node) && 2 * D + 2 <= 16;
+  // (beside the tables the radix pass wants room for at least 6-bit digits: 64 * (2 nw + 4) bytes)
+  const bool useTab = (((size_t)(tabW + tabH) * 2 + 15) & ~(size_t)15) + (size_t)64 * (2 * tm.nw + 4) <= (size_t)w.nodeCap * sizeof(Node) && 2 * D + 2 <= 16;
   if (useTab) {
     for (int i = tid; i < tabW + tabH; i += nth) {
       if (i < tabW) xs[i] = (uint16_t)(qt_ff_code(make_key(i, 0, 0), fg, D) & (0x5555u | (~0u << (2 * D))));
@@ -1070,10 +1092,18 @@ __device__ inline int qt_fast_forward(Work& w, State& s, uint32_t nkeys, const F
     const int bits = 2 * d0 + rootBits;
     const int down = 2 * (D - d0);
     auto code = [codeD, down](uint32_t k) -> uint32_t { return codeD(k) >> down; };
+    // scratch of a pass with b-bit digits: 2^b * (2 nw + 4) bytes behind the code tables
+    const size_t tabBytes = useTab ? (((size_t)(tabW + tabH) * 2 + 15) & ~(size_t)15) : 0;
+    const size_t room = (size_t)w.nodeCap * sizeof(Node) - tabBytes;
+    int maxDb = 0;
+    while (maxDb < 12 && ((size_t)2 << maxDb) * (size_t)(2 * tm.nw + 4) <= room) ++maxDb;
+    const int passes = (bits + maxDb - 1) / maxDb, db = (bits + passes - 1) / passes;   // (maxDb >= 1: checked before anything was written)
+    uint16_t* cnt16 = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(w.nodes) + tabBytes);
+    int* tot = reinterpret_cast<int*>(cnt16 + ((size_t)(1 << db) * tm.nw + 1) / 2 * 2);
     uint32_t* a = w.keys;
     uint32_t* b = w.tmp;
-    for (int sh = 0; sh < bits; sh += 6) {
-      qt_radix_pass(a, b, nkeys, sh, bits - sh < 6 ? bits - sh : 6, code, tm, radix);
+    for (int sh = 0; sh < bits; sh += db) {
+      qt_radix_pass(a, b, nkeys, sh, bits - sh < db ? bits - sh : db, code, tm, cnt16, tot);
       uint32_t* t = a; a = b; b = t;
     }
     if (a != w.keys) {
@@ -1240,7 +1270,7 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
 
   bool bFinish = false, enterPhase = false;
 #if QT_DEVICE
-  // scratch shared by the radix passes (64 ints per wave), the team sort's range lists and qt_std_sort_wave's stack (192 ints): a team uses all
+  // scratch shared by the team sort's range lists and qt_std_sort_wave's stack (192 ints): a team uses all
   // of it, the unsynchronised waves of a packed workgroup a quarter each
   __shared__ int qtShared[64 * QT_TEAM_WAVES];
   int* const shWave = qtShared + (tm.nw > 1 ? 0 : 256 * (int)(threadIdx.x >> 6));
@@ -1251,7 +1281,7 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
   if (QT_FAST_FORWARD) {
     FfGeom fg;
     fg.hX = hX; fg.last = nIni - 1; fg.width = width; fg.height = height; fg.nIni = nIni;
-    ff = qt_fast_forward(w, s, nkeys, fg, N, tm, reinterpret_cast<int*>(w.vB), 2 * w.nodeCap, reinterpret_cast<int*>(w.brank), w.nodeCap, shWave);
+    ff = qt_fast_forward(w, s, nkeys, fg, N, tm, reinterpret_cast<int*>(w.vB), 2 * w.nodeCap, reinterpret_cast<int*>(w.brank), w.nodeCap);
     bFinish = ff == QT_FF_FINISH;
     enterPhase = ff == QT_FF_PHASE;
   }
