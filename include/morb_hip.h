@@ -99,7 +99,9 @@ int morb_extractor_stage_ms(morb_extractor*, float* ms7);
 int morb_extractor_event_after_fast(morb_extractor*, void** event);
 /* Likewise the event recorded behind the last pyramid launch (ComputePyramid, src/ORBextractor.cc:1088-1112), i.e. where the FAST stage starts:
  * k_fastw is bound by vector-instruction issue and leaves the memory pipe idle, so a pipelining caller may prefer to put the previous frame's
- * matchers (BoW descent, SAD rows: memory-pipe work) underneath IT rather than beside the pyramid, which needs the same pipe. */
+ * matchers (BoW descent, SAD rows: memory-pipe work) underneath IT rather than beside the pyramid, which needs the same pipe.
+ * The event is recorded by the extractions queued AFTER the first call of this function on the handle (call it once before the first batch):
+ * callers that never ask do not pay for an event between the pyramid and FAST. */
 int morb_extractor_event_after_pyramid(morb_extractor*, void** event);
 /* Failure flags raised on the device by the extractions since the last query (cleared by the call).  To be read AFTER the stream of a
  * morb_extract_batch call has been synchronised; morb_extract checks it itself.  Bit 0: a pyramid level held more than 65535 FAST

@@ -622,11 +622,13 @@ __global__ __launch_bounds__(64 * QT_TEAM_WAVES) void k_distribute(const LevelGe
 // ---------------------------------------------------------------------------------------------------
 // Layout: final slot of every keypoint (operator() tail, ORBextractor.cc:1041-1085): levels in order, keypoints
 // in list order; x in [lap0, lap1] (after pt *= scale) fills from the back, the rest from the front.
-__global__ __launch_bounds__(256) void k_layout(const LevelGeom* __restrict__ geom, int nlevels,
+constexpr int LAYOUT_WAVES = 16;   // (round 6: 4 -> 16 waves: the loop below is one global round trip and two barriers per 64 * waves keypoints; 22 -> 9 us for one 4000-feature image)
+__global__ __launch_bounds__(64 * LAYOUT_WAVES) void k_layout(const LevelGeom* __restrict__ geom, int nlevels,
                                                 const uint32_t* __restrict__ sel, const int* __restrict__ selCnt,
                                                 int selPerImg, const int* __restrict__ lap, int2* __restrict__ kref,
                                                 int* __restrict__ nkp, int* __restrict__ mono, int cap) {
-  __shared__ int wm[4], ws[4];
+  constexpr int NT = 64 * LAYOUT_WAVES;
+  __shared__ int wm[LAYOUT_WAVES], ws[LAYOUT_WAVES];
   const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int base[kMaxLevels + 1];
   int total = 0;
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(256) void k_layout(const LevelGeom* __restrict__ ge
   const float lap0 = (float)lap[img * 2], lap1 = (float)lap[img * 2 + 1];
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   int monoRun = 0, stereoRun = 0;
-  for (int g0 = 0; g0 < total; g0 += 256) {
+  for (int g0 = 0; g0 < total; g0 += NT) {
     const int gi = g0 + tid;
     const bool valid = gi < total;
     bool isLap = false;
@@ -651,18 +653,19 @@ __global__ __launch_bounds__(256) void k_layout(const LevelGeom* __restrict__ ge
     const uint64_t mS = __ballot(valid && isLap), mM = __ballot(valid && !isLap);
     if (lane == 0) { ws[wv] = __popcll(mS); wm[wv] = __popcll(mM); }
     __syncthreads();
-    int offS = stereoRun, offM = monoRun;
-    for (int q = 0; q < wv; ++q) { offS += ws[q]; offM += wm[q]; }
+    int offS = stereoRun, offM = monoRun, totS = 0, totM = 0;
+#pragma unroll
+    for (int q = 0; q < LAYOUT_WAVES; ++q) { const int a = ws[q], b = wm[q]; if (q < wv) { offS += a; offM += b; } totS += a; totM += b; }
     if (valid) {
       const int slot = isLap ? (total - 1 - (offS + __popcll(mS & lt))) : (offM + __popcll(mM & lt));
       // everything k_describe needs about keypoint gi in ONE record: output slot | level << 24 (or -1), packed key
       kref[(size_t)img * selPerImg + gi] = make_int2(slot < cap ? (slot | (l << 24)) : -1, (int)key);
     }
-    stereoRun += ws[0] + ws[1] + ws[2] + ws[3];
-    monoRun += wm[0] + wm[1] + wm[2] + wm[3];
+    stereoRun += totS;
+    monoRun += totM;
     __syncthreads();
   }
-  for (int gi = total + tid; gi < selPerImg; gi += 256) kref[(size_t)img * selPerImg + gi] = make_int2(-1, 0);
+  for (int gi = total + tid; gi < selPerImg; gi += NT) kref[(size_t)img * selPerImg + gi] = make_int2(-1, 0);
   if (tid == 0) { nkp[img] = total < cap ? total : cap; mono[img] = monoRun; }
 }
 
@@ -1467,6 +1470,7 @@ int morb_extractor_event_after_fast(morb_extractor* e, void** event) {
 }
 int morb_extractor_event_after_pyramid(morb_extractor* e, void** event) {
   MORB_REQUIRE(e && event, MORB_ERR_INVALID, "NULL argument");
+  e->wantPyrEvent = true;   // recorded by the extractions queued from now on
   *event = (void*)e->evPyr;
   return MORB_OK;
 }
@@ -1574,7 +1578,7 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
     }
   }
   mark(1);
-  MORB_HIP_CHECK(hipEventRecord(e->evPyr, st));
+  if (e->wantPyrEvent) MORB_HIP_CHECK(hipEventRecord(e->evPyr, st));   // (only for callers that asked for it: an event between two launches costs a one-frame call ~10 us)
   // FAST: the two launch groups (cells of the big levels; the taller cells of the small top levels) follow each other in the launch
   // stream.  Grid x = image: hardware deals consecutive workgroups round-robin over the 8 XCDs, so with a multiple of 8 images all
   // cells of an image meet in one XCD's L2.
@@ -1614,7 +1618,7 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   if (evs) (void)hipEventRecord(evs[7], sideStream);
   MORB_HIP_CHECK(hipEventRecord(e->evJoin, sideStream));
   mark(3);
-  hipLaunchKernelGGL(k_layout, dim3(nimg), dim3(256), 0, st, e->d_geom, L, e->d_sel, e->d_selCnt, e->selPerImg,
+  hipLaunchKernelGGL(k_layout, dim3(nimg), dim3(64 * LAYOUT_WAVES), 0, st, e->d_geom, L, e->d_sel, e->d_selCnt, e->selPerImg,
                      e->d_lap, e->d_kref, d_count, d_mono, cap);
   mark(4);
   MORB_HIP_CHECK(hipStreamWaitEvent(st, e->evJoin, 0));

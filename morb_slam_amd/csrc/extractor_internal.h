@@ -108,6 +108,7 @@ struct morb_extractor {
   hipStream_t sideStream = nullptr;          // the blur runs here, underneath the quadtree (fork after FAST, join before describe)
   hipEvent_t evFork = nullptr, evJoin = nullptr;
   hipEvent_t evPyr = nullptr;      // recorded on the launch stream behind the last pyramid launch (morb_extractor_event_after_pyramid)
+  bool wantPyrEvent = false;       // ... once a caller has asked for it
   morb::LevelGeom* d_geom = nullptr;
   morb::ResizeTab* d_tabs = nullptr;
   morb::PyrCol* d_pcol = nullptr; morb::PyrRow* d_prow = nullptr; morb::PyrEdge* d_pedge = nullptr;

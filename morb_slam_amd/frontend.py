@@ -96,6 +96,9 @@ class StereoFrontEnd:
         # which event of the NEXT extraction releases a step's matchers: after its FAST stage (they land underneath its quadtree) or after its
         # pyramid (underneath its FAST stage: issue-bound, memory pipe idle)
         self.lag_gate = "event_after_pyramid" if matchers == "under-fast" else "event_after_fast"
+        if matchers == "under-fast":
+            for e in self.exts:
+                e.event_after_pyramid()     # (the extractor records this event only once somebody has asked for it)
         # stagger (with one extraction stream per set): step i + 1's extraction starts when step i's FAST stage is done, so its pyramid
         # — a streaming kernel without LDS — runs beside step i's quadtree, whose few waves per CU hold the LDS and leave the rest idle
         self.stagger = bool(stagger) and self.estreams[0] is not self.estreams[-1]
