@@ -622,7 +622,9 @@ __global__ __launch_bounds__(64 * QT_TEAM_WAVES) void k_distribute(const LevelGe
 // ---------------------------------------------------------------------------------------------------
 // Layout: final slot of every keypoint (operator() tail, ORBextractor.cc:1041-1085): levels in order, keypoints
 // in list order; x in [lap0, lap1] (after pt *= scale) fills from the back, the rest from the front.
-constexpr int LAYOUT_WAVES = 16;   // (round 6: 4 -> 16 waves: the loop below is one global round trip and two barriers per 64 * waves keypoints; 22 -> 9 us for one 4000-feature image)
+// LAYOUT_WAVES: the loop below is one global round trip and two barriers per 64 * waves keypoints.  16 waves for a handful of images (22 -> 9 us for one
+// 4000-feature image), 4 in a batch (1024 workgroups of 16 waves: 13 -> 162 us per launch — most of their lanes have no keypoint).
+template <int LAYOUT_WAVES>
 __global__ __launch_bounds__(64 * LAYOUT_WAVES) void k_layout(const LevelGeom* __restrict__ geom, int nlevels,
                                                 const uint32_t* __restrict__ sel, const int* __restrict__ selCnt,
                                                 int selPerImg, const int* __restrict__ lap, int2* __restrict__ kref,
@@ -1618,8 +1620,10 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   if (evs) (void)hipEventRecord(evs[7], sideStream);
   MORB_HIP_CHECK(hipEventRecord(e->evJoin, sideStream));
   mark(3);
-  hipLaunchKernelGGL(k_layout, dim3(nimg), dim3(64 * LAYOUT_WAVES), 0, st, e->d_geom, L, e->d_sel, e->d_selCnt, e->selPerImg,
-                     e->d_lap, e->d_kref, d_count, d_mono, cap);
+  if (nimg <= kTeamMaxImages) hipLaunchKernelGGL(k_layout<16>, dim3(nimg), dim3(64 * 16), 0, st, e->d_geom, L, e->d_sel, e->d_selCnt, e->selPerImg,
+                                                 e->d_lap, e->d_kref, d_count, d_mono, cap);
+  else hipLaunchKernelGGL(k_layout<4>, dim3(nimg), dim3(64 * 4), 0, st, e->d_geom, L, e->d_sel, e->d_selCnt, e->selPerImg,
+                          e->d_lap, e->d_kref, d_count, d_mono, cap);
   mark(4);
   MORB_HIP_CHECK(hipStreamWaitEvent(st, e->evJoin, 0));
   constexpr int descRev = 1;   // images in reverse order: the blur wrote the last ones most recently (581 -> 565 us at 512 images)

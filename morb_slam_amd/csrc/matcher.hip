@@ -531,7 +531,10 @@ __global__ __launch_bounds__(256) void k_stereo_match(const StereoGeom sg, const
 // Round 6: the frame's SAD distances are read ONCE, into registers (SMED_V per thread, 1024 threads: frames of up to 8192 features; larger ones
 // re-read global memory as before).  The 15 bisection steps then cost two barriers each instead of a global-memory round trip per 256 features:
 // 22.9 -> ~6 us for one 4000-feature frame.
-constexpr int SMED_WAVES = 16, SMED_V = 8;
+// SMED_WAVES: 16 for a handful of frames (latency), 4 in a batch — 512 workgroups of 16 waves meeting at 17 barriers each took 474 us where four
+// waves take ~50 (profiles/r06/README.md).
+constexpr int SMED_V = 8;
+template <int SMED_WAVES>
 __global__ __launch_bounds__(64 * SMED_WAVES) void k_stereo_median(const int* __restrict__ count, int cap, float* __restrict__ uRight,
                                                        float* __restrict__ depth, const int* __restrict__ sadDist) {
   constexpr int NT = 64 * SMED_WAVES;
@@ -1373,7 +1376,8 @@ int morb_stereo_match_batch(morb_matcher* m, const morb_extractor* e, int nframe
   hipLaunchKernelGGL(k_stereo_prep, dim3(nframes), dim3(nframes <= 16 ? 1024 : 256), prepSmem, st, sg, d_kps, d_count, cap, m->d_stereoRec);
   hipLaunchKernelGGL(k_stereo_match, dim3(div_up(cap, lk), nframes), dim3(256), stereoSmem, st, sg, e->d_pyr, d_kps, d_desc,
                      d_count, cap, mbf, mb, d_uRight, d_depth, m->d_sad, lk, m->d_stereoRec);
-  hipLaunchKernelGGL(k_stereo_median, dim3(nframes), dim3(64 * SMED_WAVES), 0, st, d_count, cap, d_uRight, d_depth, m->d_sad);
+  if (nframes <= 16) hipLaunchKernelGGL(k_stereo_median<16>, dim3(nframes), dim3(64 * 16), 0, st, d_count, cap, d_uRight, d_depth, m->d_sad);
+  else hipLaunchKernelGGL(k_stereo_median<4>, dim3(nframes), dim3(64 * 4), 0, st, d_count, cap, d_uRight, d_depth, m->d_sad);
   MORB_HIP_CHECK(hipGetLastError());
   return MORB_OK;
 }
