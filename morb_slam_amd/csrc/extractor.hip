@@ -62,10 +62,13 @@ constexpr int kPyrChunkImages = MORB_PYR_CHUNK_IMAGES;   // images per group of 
 #define MORB_QT_KEYF 200   // LDS key capacity of level 0, in percent of (pixels / 233); 135 / 160 measured: no change (the big bin still takes a CU alone)
 #endif   // k_distribute: calls with at most this many images use the team packing of the big levels
 
-__constant__ __align__(16) int c_pattern[256 * 4] = {
+// bit_pattern_31_ (ORBextractor.cc:147-404) as floats: k_describe multiplies the coordinates by cos / sin (the conversion of 16 integers per wave was 16 of its ~575
+// vector instructions, and the kernel — like the whole step — is bound by vector-instruction issue)
+__constant__ __align__(16) float c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
 __constant__ int c_umax[16];
+
 
 // ---------------------------------------------------------------------------------------------------
 // K1a: level 0 = copyMakeBorder(image, BORDER_REFLECT_101)  (ORBextractor.cc:1108)
@@ -768,9 +771,9 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGe
 #endif
   // (the pattern fetched once per workgroup into LDS instead — one 16-byte load per thread, a barrier, four ds_read_b128 per lane later —
   // measured no faster: 2016 - 2058 against 2002 - 2015 us per 512 images for the whole extraction, three runs each on one box)
-  int4 pat[4];
+  float4 pat[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) pat[q] = reinterpret_cast<const int4*>(c_pattern)[lane * 4 + q];
+  for (int q = 0; q < 4; ++q) pat[q] = reinterpret_cast<const float4*>(c_pattern)[lane * 4 + q];
   int2 ref[DESC_KPW];
 #pragma unroll
   for (int kk = 0; kk < DESC_KPW; ++kk) ref[kk] = kref[(size_t)img * selPerImg + min(gi0 + kk, selPerImg - 1)];
@@ -847,6 +850,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGe
   // The circular mask and the column weights of a lane's four dwords do not depend on the keypoint: byte masks and the
   // biased weights (u + 15, so that v_dot4_u32_u8 applies) are built once, and per keypoint a dword costs one AND, two
   // dot products and a multiply-add: m10 = sum (u + 15) I - 15 sum I, m01 = sum v (row sum of I).
+  // (round 6: the same constants from a compile-time table, two 16-byte loads per lane instead of ~75 vector instructions per wave: 478 -> 501 us per 512 images —
+  // the kernel answers to its vector-memory instructions before it answers to its VALU count; the masks as byte RANGES, ~40 instructions fewer: no difference outside the noise)
   uint32_t pmask[4], pw[4];
   int pv[4];
 #pragma unroll
@@ -940,7 +945,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const morb::DescGe
 #endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float x0 = (float)pat[q].x, y0 = (float)pat[q].y, x1 = (float)pat[q].z, y1 = (float)pat[q].w;
+      const float x0 = pat[q].x, y0 = pat[q].y, x1 = pat[q].z, y1 = pat[q].w;
       const int r0 = __float2int_rn(x0 * bsin + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bsin);
       const int r1 = __float2int_rn(x1 * bsin + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bsin);
 #if MORB_DESC_STAGED
