@@ -259,6 +259,24 @@ def test_event_after_fast_is_a_live_hip_event():
     assert lib().morb_stream_wait_event(s.cuda_stream, None) == -1  # MORB_ERR_INVALID
 
 
+def test_event_after_pyramid_is_recorded_once_asked_for():
+    """morb_extractor_event_after_pyramid: recorded behind the last pyramid launch by the extractions queued AFTER the first request (callers that never ask
+    pay for no event between the pyramid and FAST).  A stream that waits for it and then reads the pyramid's top level sees this call's pyramid."""
+    import torch
+    from morb_slam_amd.capi import lib
+    ext, orc = _extractors(500)
+    img = make_image(640, 480, seed=5)
+    ev = ext.event_after_pyramid()           # the request; nothing recorded yet
+    assert ev
+    ext.extract_batch(torch.from_numpy(np.stack([img, img])).cuda())
+    assert ext.event_after_pyramid() == ev   # the handle's event, recorded by that call
+    s = torch.cuda.Stream()
+    assert lib().morb_stream_wait_event(s.cuda_stream, ev) == 0
+    s.synchronize()
+    orc(img)
+    np.testing.assert_array_equal(ext.pyramid_level(7), orc.level_image(7))
+
+
 def test_more_than_65535_candidates_in_a_level_match_the_oracle():
     """DistributeOctTree has no size limit (ORBextractor.cc:540-738).  White noise at 1080p puts ~200 k FAST candidates into level 0: until round 5
     the quadtree's 16-bit child counts refused such a level (MORB_ERR_UNSUPPORTED); the counts now saturate and nodes of more than 65535 keys are
