@@ -1204,7 +1204,8 @@ __device__ inline int qt_fast_forward(Work& w, State& s, uint32_t nkeys, const F
 // a recursion level are dealt to the waves (breadth first; two range lists in LDS, this level's and the next one's).  Same result as
 // qt_std_sort_wave.  q: 1024 ints of scratch.  false: n too large for the lists (nothing touched).
 __device__ inline bool qt_std_sort_team(uint64_t* v, uint64_t* tmp, int n, uint16_t* posL, uint16_t* posR, const Team& tm, int* q) {
-  constexpr int QCAP = 168;   // ranges of one recursion level: disjoint, each > 16 entries -> at most n / 17
+  constexpr int QCAP = 168;
+  static_assert(6 * QCAP + 2 <= 1024, "the range lists must fit qt_distribute's static scratch");   // ranges of one recursion level: disjoint, each > 16 entries -> at most n / 17
   if (n / 17 + 1 > QCAP) return false;
   const int lane = QT_LANE;
   int* cnt = q + 6 * QCAP;    // [0], [1]: ranges in list 0 / 1
@@ -1272,7 +1273,8 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
 #if QT_DEVICE
   // scratch shared by the team sort's range lists and qt_std_sort_wave's stack (192 ints): a team uses all
   // of it, the unsynchronised waves of a packed workgroup a quarter each
-  __shared__ int qtShared[64 * QT_TEAM_WAVES];
+  __shared__ int qtShared[1024];   // (a fixed size: the team sort's lists take 1010 ints and a packed workgroup's four waves 256 each, whatever QT_TEAM_WAVES an A/B build sets —
+                                   // with 64 * QT_TEAM_WAVES a -DQT_TEAM_WAVES=4 build wrote past the array and, once in two runs, never came back)
   int* const shWave = qtShared + (tm.nw > 1 ? 0 : 256 * (int)(threadIdx.x >> 6));
   int ff = -1;
 #ifndef QT_FAST_FORWARD
