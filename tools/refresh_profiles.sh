@@ -9,6 +9,7 @@ O=gpurun_out/prof_$R
 # every step is bounded (a hung A/B build cost round 6 fifty GPU-minutes): T = seconds per step.  MORB_REFRESH_TAIL=1: only the second half (from the
 # one-frame latencies on), into the directory the first half left.
 T="timeout 420"
+mkdir -p "$O"
 if [ -z "${MORB_REFRESH_TAIL:-}" ]; then
 rm -rf "$O" && mkdir -p "$O"
 $T rocprofv3 --kernel-trace --stats -d "$O/stats" -o s --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-verify --sustained-s 0 > "$O/bench_under_rocprof.json" 2>/dev/null
