@@ -66,6 +66,7 @@ struct Work {
                       //           <= 65535 keys; the few larger nodes of a noise-like level are counted again when they are partitioned (qt_pack4)
   uint32_t* brank;    // [nodeCap] children pushed before this node | children with > 1 key before it << 16
   int nodeCap, listCap;
+  bool hostFastForward = false;   // (host build with QT_HOST_FAST_FORWARD only: qt_distribute starts from qt_fast_forward_host's state)
 };
 
 // Live nodes never exceed N + 3 (a full sweep only runs when it cannot overshoot N, the "largest first" phase stops at
@@ -866,6 +867,122 @@ QT_HD void qt_compact(Work& w, State& s) {
   QT_SYNC();
 }
 
+enum { QT_FF_CONTINUE = 0, QT_FF_PHASE = 1, QT_FF_FINISH = 2 };
+constexpr int QT_FF_MAXD = 5;
+
+struct FfGeom { float hX; int last, width, height, nIni; };
+
+// cell code of key k after d halvings: root * 4^d + sum of (bx + 2 by) digits, most significant first (DivideNode's arithmetic, :475-523)
+QT_HD uint32_t qt_ff_code(uint32_t k, const FfGeom& fg, int d) {
+  const int x = key_x(k), y = key_y(k);
+  int g = (int)((float)x / fg.hX);
+  g = g > fg.last ? fg.last : g;
+  int x0 = (int)(fg.hX * (float)g), x1 = (int)(fg.hX * (float)(g + 1)), y0 = 0, y1 = fg.height;
+  uint32_t c = (uint32_t)g;
+  for (int j = 0; j < d; ++j) {
+    const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+    const int bx = x >= mx ? 1 : 0, by = y >= my ? 1 : 0;
+    c = c * 4 + (uint32_t)(bx + 2 * by);
+    x0 = bx ? mx : x0; x1 = bx ? x1 : mx; y0 = by ? my : y0; y1 = by ? y1 : my;
+  }
+  return c;
+}
+// rectangle of the depth-d cell `code`
+QT_HD void qt_ff_rect(uint32_t code, int d, const FfGeom& fg, int& x0, int& y0, int& x1, int& y1) {
+  const int g = (int)(code >> (2 * d));
+  x0 = (int)(fg.hX * (float)g); x1 = (int)(fg.hX * (float)(g + 1)); y0 = 0; y1 = fg.height;
+  for (int j = 1; j <= d; ++j) {
+    const int dg = (int)(code >> (2 * (d - j))) & 3;
+    const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+    if (dg & 1) x0 = mx; else x1 = mx;
+    if (dg & 2) y0 = my; else y1 = my;
+  }
+}
+// generation-order index t -> cell code at depth d (d >= 1)
+QT_HD uint32_t qt_ff_untransform(uint32_t t, int d, int nIni) {
+  const uint32_t pm = (1u << (2 * d)) - 1u;
+  const uint32_t tr = t >> (2 * d);
+  const uint32_t r = ((d - 1) & 1) ? (uint32_t)(nIni - 1) - tr : tr;
+  return (r << (2 * d)) | ((t & pm) ^ (0xCCCCCCCCu & pm));
+}
+
+
+#if defined(QT_HOST_FAST_FORWARD) && !QT_DEVICE
+// The fast forward restated serially for the host (tests/native/qt_host.cc defines QT_HOST_FAST_FORWARD): the SAME construction as the device's
+// qt_fast_forward below — cell codes, per-depth counts, the reference's three conditions, one stable sort by the depth-d0 code, the list as
+// (children of sweep d0 in reverse generation order) ++ (single-key nodes of the shallower sweeps) ++ (single-key roots) — in plain loops, so that
+// the CPU suite can check the construction itself (generation order, what follows the sweeps, node rectangles) against the oracle's std::list
+// restatement on thousands of random inputs.  Returns QT_FF_*.
+inline int qt_fast_forward_host(Work& w, State& s, uint32_t nkeys, const FfGeom& fg, int N) {
+  const int nIni = fg.nIni;
+  int D = 1;
+  while (D < QT_FF_MAXD && (nIni << (2 * D)) <= 2 * N) ++D;
+  std::vector<std::vector<int>> cnt(D + 1);
+  for (int d = 0; d <= D; ++d) cnt[d].assign((size_t)nIni << (2 * d), 0);
+  std::vector<uint32_t> code(nkeys);
+  for (uint32_t i = 0; i < nkeys; ++i) { code[i] = qt_ff_code(w.keys[i], fg, D); ++cnt[D][code[i]]; }
+  for (int d = D - 1; d >= 0; --d)
+    for (size_t c = 0; c < cnt[d].size(); ++c) cnt[d][c] = cnt[d + 1][4 * c] + cnt[d + 1][4 * c + 1] + cnt[d + 1][4 * c + 2] + cnt[d + 1][4 * c + 3];
+  auto nonEmpty = [&](int d) { int n = 0; for (int c : cnt[d]) n += c > 0; return n; };
+  auto multi = [&](int d) { int n = 0; for (int c : cnt[d]) n += c > 1; return n; };
+  int d0 = D, outcome = QT_FF_CONTINUE, prev = nonEmpty(0);
+  for (int d = 1; d <= D; ++d) {
+    const int sz = nonEmpty(d), nEx = multi(d);
+    if (sz >= N || sz == prev) { d0 = d; outcome = QT_FF_FINISH; break; }
+    if (sz + 3 * nEx > N) { d0 = d; outcome = QT_FF_PHASE; break; }
+    prev = sz;
+  }
+  // one stable sort of the keys by their depth-d0 cell
+  {
+    const int down = 2 * (D - d0);
+    std::vector<uint32_t> idx(nkeys);
+    for (uint32_t i = 0; i < nkeys; ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return (code[a] >> down) < (code[b] >> down); });
+    for (uint32_t i = 0; i < nkeys; ++i) w.tmp[i] = w.keys[idx[i]];
+    for (uint32_t i = 0; i < nkeys; ++i) w.keys[i] = w.tmp[i];
+  }
+  std::vector<int> P(cnt[d0].size() + 1, 0);
+  for (size_t c = 0; c < cnt[d0].size(); ++c) P[c + 1] = P[c] + cnt[d0][c];
+  // members of the list, segment by segment from the head
+  struct Member { int d; uint32_t c; };
+  std::vector<Member> order;
+  for (int d = d0; d >= 0; --d) {
+    std::vector<Member> seg;
+    const uint32_t cells = (uint32_t)nIni << (2 * d);
+    for (uint32_t t = 0; t < cells; ++t) {   // ascending generation order
+      const uint32_t c = d == 0 ? t : qt_ff_untransform(t, d, nIni);
+      const int k = cnt[d][c];
+      if (d == d0 ? k < 1 : k != 1) continue;
+      if (d > 0 && cnt[d - 1][c >> 2] <= 1) continue;
+      seg.push_back(Member{d, c});
+    }
+    if (d > 0) std::reverse(seg.begin(), seg.end());   // push_front: the list holds a sweep's children in reverse generation order (roots: push_back)
+    order.insert(order.end(), seg.begin(), seg.end());
+  }
+  const int size = (int)order.size();
+  s.head = w.listCap - size;
+  s.size = size;
+  s.nFree = w.nodeCap - size;
+  for (int i = 0; i < size; ++i) {
+    const Member& m = order[i];
+    int x0, y0, x1, y1;
+    qt_ff_rect(m.c, m.d, fg, x0, y0, x1, y1);
+    Node nd;
+    nd.x0 = (int16_t)x0; nd.y0 = (int16_t)y0; nd.x1 = (int16_t)x1; nd.y1 = (int16_t)y1;
+    nd.begin = (uint32_t)P[(size_t)m.c << (2 * (d0 - m.d))];
+    nd.count = (uint32_t)cnt[m.d][m.c]; nd.lit = (uint16_t)(s.head + i); nd.noMore = nd.count == 1 ? 1 : 0;
+    w.nodes[i] = nd;
+    w.list[s.head + i] = (uint16_t)i;
+  }
+  // vSizeAndPointerToNode: the last sweep's children with more than one key, in generation order = the head segment backwards
+  s.nA = 0;
+  for (int i = size - 1; i >= 0; --i)
+    if (order[i].d == d0 && w.nodes[i].count > 1)
+      w.vA[s.nA++] = ((uint64_t)w.nodes[i].count << 32) | ((uint64_t)(uint16_t)w.nodes[i].x0 << 16) | (uint64_t)i;
+  return outcome;
+}
+#endif
+
 #if QT_DEVICE
 // ---- the full sweeps at once ("fast forward", round 6) -----------------------------------------------------------
 // While the reference's loop (:589-655) runs FULL sweeps — every node with more than one key is divided, no early exit — the state it
@@ -883,45 +1000,6 @@ QT_HD void qt_compact(Work& w, State& s) {
 // each parent emitting its non-empty children in the order n1..n4.  Two depth-d nodes whose paths first differ at digit j (root = 0)
 // therefore compare by that digit ascending when d - j is even and descending when it is odd (the root digit: by d - 1): generation
 // order = ascending order of the path code with those digits complemented (an XOR with 0b11 per child digit).
-enum { QT_FF_CONTINUE = 0, QT_FF_PHASE = 1, QT_FF_FINISH = 2 };
-constexpr int QT_FF_MAXD = 5;
-
-struct FfGeom { float hX; int last, width, height, nIni; };
-
-// cell code of key k after d halvings: root * 4^d + sum of (bx + 2 by) digits, most significant first (DivideNode's arithmetic, :475-523)
-__device__ __forceinline__ uint32_t qt_ff_code(uint32_t k, const FfGeom& fg, int d) {
-  const int x = key_x(k), y = key_y(k);
-  int g = (int)((float)x / fg.hX);
-  g = g > fg.last ? fg.last : g;
-  int x0 = (int)(fg.hX * (float)g), x1 = (int)(fg.hX * (float)(g + 1)), y0 = 0, y1 = fg.height;
-  uint32_t c = (uint32_t)g;
-  for (int j = 0; j < d; ++j) {
-    const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
-    const int bx = x >= mx ? 1 : 0, by = y >= my ? 1 : 0;
-    c = c * 4 + (uint32_t)(bx + 2 * by);
-    x0 = bx ? mx : x0; x1 = bx ? x1 : mx; y0 = by ? my : y0; y1 = by ? y1 : my;
-  }
-  return c;
-}
-// rectangle of the depth-d cell `code`
-__device__ __forceinline__ void qt_ff_rect(uint32_t code, int d, const FfGeom& fg, int& x0, int& y0, int& x1, int& y1) {
-  const int g = (int)(code >> (2 * d));
-  x0 = (int)(fg.hX * (float)g); x1 = (int)(fg.hX * (float)(g + 1)); y0 = 0; y1 = fg.height;
-  for (int j = 1; j <= d; ++j) {
-    const int dg = (int)(code >> (2 * (d - j))) & 3;
-    const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
-    if (dg & 1) x0 = mx; else x1 = mx;
-    if (dg & 2) y0 = my; else y1 = my;
-  }
-}
-// generation-order index t -> cell code at depth d (d >= 1)
-__device__ __forceinline__ uint32_t qt_ff_untransform(uint32_t t, int d, int nIni) {
-  const uint32_t pm = (1u << (2 * d)) - 1u;
-  const uint32_t tr = t >> (2 * d);
-  const uint32_t r = ((d - 1) & 1) ? (uint32_t)(nIni - 1) - tr : tr;
-  return (r << (2 * d)) | ((t & pm) ^ (0xCCCCCCCCu & pm));
-}
-
 // lanes (among `valid`) that hold the same `bits`-bit digit as this lane: one ballot per digit bit, every lane keeps the lanes that agree with it
 // on that bit.  (Round 6 also tried one step per DISTINCT value present — readfirstlane, compare, ballot — which is fewer steps on these spatially
 // coherent keys but every step is a VALU -> SALU -> VALU round trip: 1.4 x slower per chunk.)
@@ -1288,6 +1366,16 @@ QT_HD int qt_distribute(Work& w, uint32_t nkeys, int width, int height, int N, u
     enterPhase = ff == QT_FF_PHASE;
   }
   if (ff < 0)
+#elif defined(QT_HOST_FAST_FORWARD)
+  int ffHost = -1;
+  if (w.hostFastForward) {
+    FfGeom fg;
+    fg.hX = hX; fg.last = nIni - 1; fg.width = width; fg.height = height; fg.nIni = nIni;
+    ffHost = qt_fast_forward_host(w, s, nkeys, fg, N);
+    bFinish = ffHost == QT_FF_FINISH;
+    enterPhase = ffHost == QT_FF_PHASE;
+  }
+  if (ffHost < 0)
 #endif
   {
     // initial nodes, pushed BACK in order i = 0..nIni-1 (:555-567); keys go to node (int)(x / hX) (:570-573);

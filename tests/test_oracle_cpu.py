@@ -270,14 +270,21 @@ def test_quadtree_matches_oracle(qt):
     L = lib()
     rng = np.random.default_rng(0)
     checked = 0
-    for t in range(250):
+    for t in range(600):
         W = int(rng.integers(100, 1900)); H = int(rng.integers(80, 1100))
         if not 1 <= round(W / H) <= 4:
             continue
         n = int(rng.integers(1, 5000)); N = int(rng.integers(1, 900))
+        if t % 7 == 5:
+            n = int(rng.integers(1, 12))                      # a handful of points: the tree stops because nothing is left to divide
+        if t % 7 == 6:
+            N = int(rng.integers(1, 9))                       # tiny quotas: the first sweep already overshoots
         if t % 3 == 0:
             xs = np.clip(rng.normal(W / 2, W / 10, n), 3, W - 4).astype(int)
             ys = np.clip(rng.normal(H / 2, H / 10, n), 3, H - 4).astype(int)
+        elif t % 5 == 1:                                      # everything in one corner: a deep, lop-sided tree
+            xs = np.clip(rng.normal(W / 12, W / 40, n), 3, W - 4).astype(int)
+            ys = np.clip(rng.normal(H / 10, H / 40, n), 3, H - 4).astype(int)
         else:
             xs = rng.integers(3, W - 3, n); ys = rng.integers(3, H - 3, n)
         pos = np.unique(ys * 4096 + xs); rng.shuffle(pos)
@@ -289,13 +296,17 @@ def test_quadtree_matches_oracle(qt):
         m = L.orc_distribute(_p(kin), n, 16, 16 + W, 16, 16 + H, N, _p(kout), len(kout))
         keys = (xs.astype(np.uint32) | (ys.astype(np.uint32) << 12) | (resp.astype(np.uint32) << 24)).astype(np.uint32)
         out = np.zeros(4 * N + 64, np.uint32)
-        m2 = qt.qt_host_distribute(_p(keys), n, W, H, N, _p(out), len(out))
-        assert m == m2
-        np.testing.assert_array_equal(out[:m] & 0xFFF, kout["x"][:m].astype(np.uint32))
-        np.testing.assert_array_equal((out[:m] >> 12) & 0xFFF, kout["y"][:m].astype(np.uint32))
-        np.testing.assert_array_equal(out[:m] >> 24, kout["response"][:m].astype(np.uint32))
+        # the sweeps one by one, and (round 6) the full sweeps built at once — histogram, the reference's three conditions on the per-depth cell counts, one
+        # stable sort, the list written in generation order (quadtree.h qt_fast_forward_host: the serial twin of the device's qt_fast_forward)
+        for fn in (qt.qt_host_distribute, qt.qt_host_distribute_ff):
+            out = np.zeros(4 * N + 64, np.uint32)
+            m2 = fn(_p(keys), n, W, H, N, _p(out), len(out))
+            assert m == m2, (t, fn.__name__ if hasattr(fn, "__name__") else fn, m, m2)
+            np.testing.assert_array_equal(out[:m] & 0xFFF, kout["x"][:m].astype(np.uint32))
+            np.testing.assert_array_equal((out[:m] >> 12) & 0xFFF, kout["y"][:m].astype(np.uint32))
+            np.testing.assert_array_equal(out[:m] >> 24, kout["response"][:m].astype(np.uint32))
         checked += 1
-    assert checked > 150
+    assert checked > 350
 
 
 # ---- C ABI surface -------------------------------------------------------------------------------------
