@@ -223,15 +223,15 @@ def test_input_ending_on_a_page_boundary():
 
 
 def test_quadtree_team_and_single_wave_packings_agree():
-    # k_distribute has two packings of an image's levels into workgroups: calls with <= 16 images give every level of >= 160 k pixels a
+    # k_distribute has two packings of an image's levels into workgroups: calls with <= 64 images give every level of >= 160 k pixels a
     # team of QT_TEAM_WAVES = 16 waves (latency), larger batches keep one wave per (image, level).  Every other test here runs the first; this one
     # runs both on the same images and requires the same bytes — and the oracle's.
     import torch
     from morb_slam_amd import KP_DTYPE
     g, o = _extractors(1200)
-    imgs = np.stack([make_image(752, 480, seed=80 + (i % 3)) for i in range(20)])
+    imgs = np.stack([make_image(752, 480, seed=80 + (i % 3)) for i in range(70)])
     exp = [o(imgs[i]) for i in range(3)]
-    for n in (20, 3):   # 20 images: single-wave packing; 3: teams
+    for n in (70, 20, 3):   # 70 images: single-wave packing; 20 and 3: teams
         kps, desc, cnt, mono = g.extract_batch(torch.from_numpy(imgs[:n]).cuda())
         torch.cuda.synchronize()
         cnt = cnt.cpu().numpy(); kps = kps.cpu().numpy(); desc = desc.cpu().numpy()
@@ -290,13 +290,13 @@ def test_more_than_65535_candidates_in_a_level_match_the_oracle():
     o = OracleExtractor(4000, 1.2, 8, 20, 7)
     mono_o, ko, do = o(img)
     assert max(len(o.level_candidates(l)) for l in range(8)) > 65535
-    mono, k, d = g(img)                                     # <= 16 images per call: the big levels are worked by a team of four waves
+    mono, k, d = g(img)                                     # <= 64 images per call: the big levels are worked by a team of 16 waves
     assert mono == mono_o and k.tobytes() == ko.tobytes() and np.array_equal(d, do)
-    imgs = np.stack([img] * 17)                             # > 16 images per call: one wave per level
+    imgs = np.stack([img] * 65)                             # > 64 images per call: one wave per level
     kps, desc, cnt, _ = g.extract_batch(torch.from_numpy(imgs).cuda())
     torch.cuda.synchronize()
     g.check_status()
-    for i in (0, 16):
+    for i in (0, 64):
         n = int(cnt[i])
         assert n == len(ko) and kps[i, :n].cpu().numpy().reshape(-1).view(KP_DTYPE).tobytes() == ko.tobytes()
         assert np.array_equal(desc[i, :n].cpu().numpy(), do)
@@ -333,7 +333,7 @@ def _edge_case_images():
 @pytest.mark.parametrize("nfeat", [1200, 60])
 def test_quadtree_every_ending_of_the_full_sweeps(nfeat):
     """Every image of _edge_case_images, one at a time (the big levels are worked by a team of waves) — selection AND order of every level against the
-    oracle's std::list / std::sort restatement — and then all of them in one batch of 32 (one wave per level), which must give the same bytes."""
+    oracle's std::list / std::sort restatement — and then all of them in one batch of 72 (one wave per level), which must give the same bytes."""
     import torch
     from morb_slam_amd import ORBextractor
     cases = _edge_case_images()
@@ -341,7 +341,7 @@ def test_quadtree_every_ending_of_the_full_sweeps(nfeat):
         n = _compare(img, nfeat)
         assert n >= 0, name
     same = [im for im in cases.values() if im.shape == (480, 752)]
-    batch = np.stack([same[i % len(same)] for i in range(32)])
+    batch = np.stack([same[i % len(same)] for i in range(72)])
     ext = ORBextractor(nfeat, 1.2, 8, 20, 7)
     kps, desc, cnt, _ = ext.extract_batch(torch.from_numpy(batch).cuda())
     torch.cuda.synchronize()
