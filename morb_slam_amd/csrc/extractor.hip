@@ -1609,8 +1609,13 @@ int morb_extract_batch(morb_extractor* e, const uint8_t* d_images, int nimg, int
   // the quadtree is enqueued first so that its long-running waves get their slots before the blur fills the chip;
   // the workgroups with level 0 (the longest wave) first: grid x = image, y = group of levels
   // (which of the two is enqueued first makes no difference: measured both ways)
+  // (developer switch MORB_TEAM_MID=n: calls of up to n images take the team packing with FOUR waves per team; measured, off — see profiles/r06/README.md)
+  static const int teamMid = [] { const char* v = getenv("MORB_TEAM_MID"); return v ? atoi(v) : 0; }();
   if (nimg <= kTeamMaxImages && e->distGroupsTeam > 0)   // few images: latency matters, the big levels are worked by teams of waves
     hipLaunchKernelGGL(k_distribute, dim3(nimg, e->distGroupsTeam), dim3(64 * QT_TEAM_WAVES), e->distSmemTeam, st, e->d_geomTeam, e->d_cand, e->d_candCnt,
+                       e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L, 0, e->d_status);
+  else if (nimg <= teamMid && e->distGroupsTeam > 0)
+    hipLaunchKernelGGL(k_distribute, dim3(nimg, e->distGroupsTeam), dim3(64 * QT_MAX_WAVES), e->distSmemTeam, st, e->d_geomTeam, e->d_cand, e->d_candCnt,
                        e->totalCells, e->cellCap, e->d_qt, e->d_sel, e->d_selCnt, e->selPerImg, L, 0, e->d_status);
   else
     // (one launch per bin of levels, each with its own LDS size — all bins of one launch get the largest bin's — measured: the launches
