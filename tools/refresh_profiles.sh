@@ -85,6 +85,12 @@ MORB_DIST_BACKEND=gloo $T python3 bench.py --gpus 2 --workload c4 --steps 10 --n
 $T bash tools/prof_tracking.sh trk_$R 256 > "$O/tracking_profile_log.txt" 2>&1
 cp gpurun_out/trk_$R/tracking_kernel_stats.csv gpurun_out/trk_$R/tracking_b1_timeline.txt gpurun_out/trk_$R/tracking_b256_timeline.txt "$O/" 2>/dev/null
 cp gpurun_out/trk_$R/bench.json "$O/tracking_bench.json" 2>/dev/null
+# one stereo frame through the front end, kernel by kernel (durations and the gaps in front of them), at configs[3]'s and configs[1]'s shapes
+for shape in "1920 1080 4000" "752 480 1200"; do set -- $shape
+  MORB_W=$1 MORB_H=$2 MORB_NF=$3 $T rocprofv3 --kernel-trace -d "$O/b1trace_$1" -o t --output-format csv -- python3 tools/latency_b1.py > /dev/null 2>&1
+  { echo "== $1 x $2 / $3 features, one stereo frame (rocprofv3 --kernel-trace of tools/latency_b1.py; the profiler adds ~10 us of gaps at the stage events)"; python3 tools/b1_trace.py $(find "$O/b1trace_$1" -name "t_kernel_trace.csv" | head -1); } >> "$O/frontend_one_frame_timeline.txt" 2>&1
+  rm -rf "$O/b1trace_$1"
+done
 $T python3 tools/ablate_matchers.py > "$O/matcher_ablation.txt" 2>/dev/null
 $T python3 tools/h2d_bw.py > "$O/h2d_copy_bandwidth_by_streams.txt" 2>/dev/null
 $T python3 bench.py > "$O/bench_default.json" 2>/dev/null
