@@ -121,6 +121,7 @@ struct morb_extractor {
   int *h_status = nullptr, *d_status = nullptr;   // pinned, device-mapped flags the kernels can raise (bit 0: a level with > 65535 FAST candidates)
   // staging for the single-image host API
   uint8_t* d_img = nullptr; size_t imgBytes = 0;
+  void* d_out1 = nullptr;   // morb_extract's result block: the four pointers below point into it
   morb_keypoint* d_kps1 = nullptr; uint8_t* d_desc1 = nullptr; int *d_cnt1 = nullptr, *d_mono1 = nullptr;
   uint8_t* h_io1 = nullptr; size_t ioBytes1 = 0;   // pinned host staging of morb_extract: the image on the way in, [cnt, mono | keypoints | descriptors] on the way out
   std::vector<int> lapLast;  // host mirror of d_lap
