@@ -132,3 +132,32 @@ def test_inline_asm_dpp_reads_keep_their_wait_states(tmp_path):
                     wait += 1
                 j -= 1
     assert seen > 100, "the DPP instructions of dense_ldlt.h were not found in the code objects"
+
+
+def test_quadtree_kernel_addresses_lds_and_global_memory_directly(tmp_path):
+    """k_distribute keeps a level's keys either in LDS or in a global scratch array and is built as two inlined copies of the distribution so that every
+    access is a DS or a GLOBAL instruction: with one copy and a run-time choice of the pointer the compiler emitted FLAT instructions for ~800 accesses
+    per wave, i.e. LDS traffic through the vector-memory path (round 2).  Round 6 added ~700 lines to that code (the fast forward's tables, histogram,
+    radix passes, the team sort's lists — all reached through pointers carried in structs and lambdas): the built kernel must still contain no FLAT
+    memory instruction."""
+    lib = os.path.join(ROOT, "morb_slam_amd", "libmorb_hip.so")
+    if not (os.path.exists(lib) and all(shutil.which(os.path.join(LLVM, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump"))):
+        pytest.skip("library or LLVM tools not available")
+    found = False
+    for co in _code_objects(lib, str(tmp_path)):
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+        body, inside = [], False
+        for ln in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:$", ln.strip())
+            if m:
+                inside = "12k_distribute" in m.group(1) and not m.group(1).endswith(".kd")
+                found = found or inside
+                continue
+            if inside:
+                body.append(ln)
+        if body:
+            ops = [ln.split()[0] for ln in body if ln.strip() and not ln.strip().startswith((";", "/"))]
+            flat = [o for o in ops if o.startswith("flat_")]
+            assert not flat, f"k_distribute contains {len(flat)} FLAT memory instructions ({sorted(set(flat))})"
+            assert sum(o.startswith("ds_") for o in ops) > 500 and sum(o.startswith("global_") for o in ops) > 50
+    assert found, "k_distribute not found in the code objects"
