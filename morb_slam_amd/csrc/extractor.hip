@@ -625,7 +625,7 @@ __global__ __launch_bounds__(64 * QT_TEAM_WAVES) void k_distribute(const LevelGe
 // ---------------------------------------------------------------------------------------------------
 // Layout: final slot of every keypoint (operator() tail, ORBextractor.cc:1041-1085): levels in order, keypoints
 // in list order; x in [lap0, lap1] (after pt *= scale) fills from the back, the rest from the front.
-// LAYOUT_WAVES: the loop below is one global round trip and two barriers per 64 * waves keypoints.  16 waves for a handful of images (22 -> 9 us for one
+// LAYOUT_WAVES: the loop below is one global round trip and two barriers per 64 * waves keypoints.  16 waves for a handful of images (22 -> 9.6 us for one
 // 4000-feature image), 4 in a batch (1024 workgroups of 16 waves: 13 -> 162 us per launch — most of their lanes have no keypoint).
 template <int LAYOUT_WAVES>
 __global__ __launch_bounds__(64 * LAYOUT_WAVES) void k_layout(const LevelGeom* __restrict__ geom, int nlevels,

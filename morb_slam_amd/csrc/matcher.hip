@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const StereoGeom sg, const
 
 // Round 6: the frame's SAD distances are read ONCE, into registers (SMED_V per thread, 1024 threads: frames of up to 8192 features; larger ones
 // re-read global memory as before).  The 15 bisection steps then cost two barriers each instead of a global-memory round trip per 256 features:
-// 22.9 -> ~6 us for one 4000-feature frame.
+// 22.9 -> 8.8 us for one 4000-feature frame.
 // SMED_WAVES: 16 for a handful of frames (latency), 4 in a batch — 512 workgroups of 16 waves meeting at 17 barriers each took 474 us where four
 // waves take ~50 (profiles/r06/README.md).
 constexpr int SMED_V = 8;

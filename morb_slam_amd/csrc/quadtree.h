@@ -1019,7 +1019,7 @@ __device__ __forceinline__ int qt_below(uint64_t m) {
 
 // One stable LSD radix pass of src[0..n) -> dst by digit (code >> shift) & (2^bits - 1) by the whole team (contiguous slice per wave, so the order of
 // equal digits is the input order).  Round 6, second form: the digit is as wide as the scratch allows — the whole cell code when it fits, i.e. ONE
-// pass instead of two 6-bit ones (22 -> 13 us of level 0's quadtree at 1920 x 1080 / 4000).  cnt16: [2^bits][nw] 16-bit counters (digit-major), tot:
+// pass instead of two 6-bit ones (22 -> 20 us of level 0's quadtree at 1920 x 1080 / 4000 with 16 waves — nine ballots per chunk instead of six eat most of the saved pass —, 36 -> 22 us per wave in the one-wave-per-level packing).  cnt16: [2^bits][nw] 16-bit counters (digit-major), tot:
 // [2^bits] ints; both in the node array, which nothing reads before the nodes are written.  n < 65536 (the caller checks).
 template <typename Code>
 __device__ inline void qt_radix_pass(const uint32_t* src, uint32_t* dst, uint32_t n, int shift, int bits, Code code, const Team& tm, uint16_t* cnt16,
