@@ -541,10 +541,12 @@ def launch_ranks(n):
     s.close()
     procs = []
 
+    import ctypes
+    import signal
+    libc = ctypes.CDLL("libc.so.6")     # (loaded in the launcher, before any fork)
+
     def die_with_launcher():        # Linux PR_SET_PDEATHSIG: a rank never outlives a launcher that was killed (it would sit on the GPU in a collective)
-        import ctypes
-        import signal
-        ctypes.CDLL("libc.so.6").prctl(1, signal.SIGKILL, 0, 0, 0)
+        libc.prctl(1, signal.SIGKILL, 0, 0, 0)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

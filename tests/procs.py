@@ -8,15 +8,12 @@ import subprocess
 import time
 
 # ------------------------------------------------------------------------------------------------------------------------
-_libc = None
+_libc = ctypes.CDLL("libc.so.6", use_errno=True)   # loaded HERE, in the parent: a forked child of a many-threaded process (pytest with torch) must not dlopen / import anything
 
 
 def _die_with_parent():
     """preexec: SIGKILL this child when the process that started it dies (Linux PR_SET_PDEATHSIG = 1), so an aborted pytest
-    leaves no rank on the GPU."""
-    global _libc
-    if _libc is None:
-        _libc = ctypes.CDLL("libc.so.6", use_errno=True)
+    leaves no rank on the GPU.  Nothing but the one foreign call: no import, no allocation worth the name."""
     _libc.prctl(1, signal.SIGKILL, 0, 0, 0)
 
 
