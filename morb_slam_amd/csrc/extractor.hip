@@ -335,7 +335,10 @@ __device__ __forceinline__ uint32_t blur_dot2(uint32_t pair, uint32_t w, uint32_
 // Vertical pass: consecutive rows' horizontal sums are kept as 16-bit pairs (row r | row r+1 << 16), so the 7 taps are three
 // v_dot2_u32_u16 and one multiply-add.  Round 2: 8 pixels per thread — one 16-byte load and one 8-byte store per row instead of
 // 3 + 1 dword accesses per 4 pixels (the texture path is priced per instruction).
-__global__ __launch_bounds__(256) void k_blur(const LevelGeom* __restrict__ geom, int nlevels,
+#ifndef MORB_BLUR_MIN_WAVES
+#define MORB_BLUR_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(256, MORB_BLUR_MIN_WAVES) void k_blur(const LevelGeom* __restrict__ geom, int nlevels,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
   // Workgroup -> (image, tile).  Consecutive workgroup ids go round-robin to the 8 XCDs: in the plain (tile, image) order the 256-px-wide
   // neighbours of a tile row — whose 264-byte row segments start 16 bytes into a 128-byte line and so share a line with each neighbour —
