@@ -7,9 +7,14 @@ One "step" = one pass of the hot path over one batch of B synthetic stereo frame
 ORBextractor x2, ComputeStereoMatches, ComputeBoW, SearchByBoW against the previous frame.  N > 1: one process per GPU
 (torch.distributed, RCCL), frames dealt round-robin; the previous frame lives on the previous rank, so every step ships the
 left-image features one rank up the ring (point-to-point over xGMI, morb_slam_amd/parallel.py) -> weak scaling.  The timed
-region is bracketed by barrier + synchronize and the MAX over ranks is reported.  Rank 0 prints ONE JSON line.
+region is bracketed by barrier + synchronize and the MAX over ranks is reported.  Rank 0 prints ONE JSON line: the contract's keys, `roofline` (HBM, the
+longest extraction stage alone on the chip) with `roofline_issue` (what really bounds that kernel: vector-instruction issue), `cpu_baseline` (the oracle on the
+host's cores, bounded sample), `latency` (round 6: ONE frame / keyframe per call, host to host — the reference's call pattern — each with the oracle on one thread
+beside it), `h2d_inclusive`, `sustained`, `extra_metrics` (optimisers with the PoseOptimization path that ran, tracking chain, the other BASELINE configs).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4] [--batch B] [--no-cpu-baseline] [--no-extras]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4] [--batch B] [--matchers beside-pyramid|under-quadtree|under-fast]
+                    [--exchange ring|allgather] [--no-cpu-baseline] [--no-extras]
+    (--workload vga: 640x480 / 600 features, for tests that drive the launcher with many ranks on one GPU; not a BASELINE configuration)
 """
 import argparse
 import ctypes
